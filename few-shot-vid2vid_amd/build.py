@@ -1,0 +1,99 @@
+"""Build the C-ABI kernel library (and, for the CPU test-suite only, its SIMT-emulated twin).
+
+    libfsv2v_hip.so   hipcc --offload-arch=gfx950, every csrc/*.hip          <- the product
+    libfsv2v_emu.so   clang++ -DFSV_EMU against tests/emu/hip_emu.h          <- `not gpu` logic tests only
+
+Both are written next to this file (git-ignored, but they travel to the GPU box with the snapshot).
+"""
+import glob
+import hashlib
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+ROOT = os.path.dirname(HERE)
+HIP_LIB = os.path.join(HERE, "libfsv2v_hip.so")
+EMU_LIB = os.path.join(HERE, "libfsv2v_emu.so")
+OBJ_DIR = os.path.join(HERE, "build")
+
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+CLANGXX = os.environ.get("FSV_HOST_CXX", "/opt/rocm/lib/llvm/bin/clang++")
+# -ffp-contract=off: the warp kernel replays ATen's un-normalise sequence op by op,
+# and the parity story for every other kernel is simpler when a*b+c never silently becomes an fma.
+COMMON = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-I", CSRC, "-I", os.path.join(ROOT, "include")]
+
+
+def _sources():
+    return sorted(glob.glob(os.path.join(CSRC, "*.hip")))
+
+
+def _digest(paths, extra=""):
+    h = hashlib.sha1(extra.encode())
+    for p in sorted(paths):
+        with open(p, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()
+
+
+def _headers():
+    return sorted(glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(ROOT, "include", "*.h")))
+
+
+def _run(cmd):
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("command failed: %s\n%s\n%s" % (" ".join(cmd), r.stdout, r.stderr))
+    return r
+
+
+def build_hip(force=False, verbose=False):
+    os.makedirs(OBJ_DIR, exist_ok=True)
+    srcs = _sources()
+    hdr = _headers()
+    objs, jobs = [], []
+    for s in srcs:
+        tag = _digest([s] + hdr, "hip")[:16]
+        o = os.path.join(OBJ_DIR, os.path.basename(s) + "." + tag + ".o")
+        objs.append(o)
+        if force or not os.path.exists(o):
+            jobs.append([HIPCC, "--offload-arch=gfx950"] + COMMON + ["-c", s, "-o", o])
+    if jobs:
+        with ThreadPoolExecutor(max_workers=min(8, len(jobs))) as ex:
+            for r in ex.map(_run, jobs):
+                if verbose and r.stderr:
+                    print(r.stderr)
+    stamp = os.path.join(OBJ_DIR, "hip.link." + _digest(objs)[:16])
+    if force or jobs or not os.path.exists(HIP_LIB) or not os.path.exists(stamp):
+        _run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", HIP_LIB] + objs)
+        open(stamp, "w").close()
+    return HIP_LIB
+
+
+def build_emu(force=False):
+    os.makedirs(OBJ_DIR, exist_ok=True)
+    srcs = _sources()
+    emu_h = os.path.join(ROOT, "tests", "emu", "hip_emu.h")
+    tag = _digest(srcs + _headers() + [emu_h], "emu")[:16]
+    stamp = os.path.join(OBJ_DIR, "emu." + tag)
+    if not force and os.path.exists(EMU_LIB) and os.path.exists(stamp):
+        return EMU_LIB
+    unity = os.path.join(OBJ_DIR, "fsv_emu_unity.cpp")
+    with open(unity, "w") as f:
+        for s in srcs:
+            f.write('#include "%s"\n' % s)
+    _run([CLANGXX, "-x", "c++", "-DFSV_EMU", "-O2", "-std=c++17", "-fPIC", "-ffp-contract=off", "-mfma",
+          "-Wno-unused-value", "-I", CSRC, "-I", os.path.join(ROOT, "include"), "-I", os.path.join(ROOT, "tests", "emu"),
+          "-shared", "-o", EMU_LIB, unity])
+    open(stamp, "w").close()
+    return EMU_LIB
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["hip"]
+    if "hip" in which:
+        print(build_hip(verbose=True))
+    if "emu" in which:
+        print(build_emu())

@@ -1,0 +1,186 @@
+"""Convolution / linear / per-sample "batch_conv" operators on the HIP gather-GEMM kernels.
+
+Mirrors the operator surface the reference reaches through ``F.conv2d`` (models/networks/architecture.py:22-27,
+generator.py:541-572, discriminator.py:67-88), ``nn.Linear`` (generator.py:103-110) and ``batch_conv``
+(models/networks/base_network.py:56-71).  Tensors keep the reference's logical NCHW shape but live in
+channels-last memory (NHWC), which is the layout the kernels in csrc/conv_igemm.hip read and write.
+"""
+import torch
+
+from . import lib
+
+ACT_NONE, ACT_LRELU, ACT_TANH, ACT_SIGMOID = 0, 1, 2, 3
+
+
+def to_nhwc(x):
+    """Return a tensor with the same logical NCHW shape whose memory is dense NHWC."""
+    if x.dim() != 4:
+        raise ValueError("expected a 4-D NCHW tensor")
+    if not x.permute(0, 2, 3, 1).is_contiguous():
+        x = x.contiguous(memory_format=torch.channels_last)
+        if not x.permute(0, 2, 3, 1).is_contiguous():   # degenerate shapes (C==1 or H==W==1)
+            x = x.permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2)
+    return x
+
+
+def empty_nhwc(n, c, h, w, like):
+    return torch.empty((n, h, w, c), dtype=torch.float32, device=like.device).permute(0, 3, 1, 2)
+
+
+def zeros_nhwc(n, c, h, w, like):
+    return torch.zeros((n, h, w, c), dtype=torch.float32, device=like.device).permute(0, 3, 1, 2)
+
+
+def _ceil(a, b):
+    return (a + b - 1) // b * b
+
+
+class Geom:
+    """Static geometry of one convolution (kernel, stride, padding) and its tap tables."""
+
+    _cache = {}
+
+    def __new__(cls, kh, kw, stride, pad):
+        key = (kh, kw, stride, pad)
+        g = cls._cache.get(key)
+        if g is None:
+            g = super().__new__(cls)
+            g._init(kh, kw, stride, pad)
+            cls._cache[key] = g
+        return g
+
+    def _init(self, kh, kw, stride, pad):
+        self.kh, self.kw, self.stride, self.pad = kh, kw, stride, pad
+        self.ntaps = kh * kw
+        self.khs = [i for i in range(kh) for _ in range(kw)]
+        self.kws = [j for _ in range(kh) for j in range(kw)]
+        self.ty = [i - pad for i in self.khs]
+        self.tx = [j - pad for j in self.kws]
+        # data-gradient tap classes: for stride s the input pixel (y, x) with ((y + pad) % s, (x + pad) % s) == (a, b)
+        # only receives taps kh = a (mod s), kw = b (mod s); the source row in dout is (y + pad - kh) / s.
+        self.dgrad_classes = []
+        s = stride
+        for py in range(s):
+            for px in range(s):
+                a, b = (py + pad) % s, (px + pad) % s
+                khs = [i for i in range(kh) if i % s == a]
+                kws = [j for j in range(kw) if j % s == b]
+                taps = [(i, j) for i in khs for j in kws]
+                # output pixel (s*y' + py, s*x' + px) reads dout[y' + (py + pad - kh) / s]
+                ty = [(py + pad - i) // s for (i, j) in taps]
+                tx = [(px + pad - j) // s for (i, j) in taps]
+                self.dgrad_classes.append(dict(py=py, px=px, khs=[t[0] for t in taps], kws=[t[1] for t in taps],
+                                               ty=ty, tx=tx))
+
+    def out_hw(self, h, w):
+        return ((h + 2 * self.pad - self.kh) // self.stride + 1, (w + 2 * self.pad - self.kw) // self.stride + 1)
+
+
+def prep_weight(w, mode, geom, khs=None, kws=None, scale=None, out=None):
+    """OIHW weights (optionally a leading per-sample batch dim) -> K-major GEMM operand.
+
+    mode 0: forward  wt[(tap, ci)][co];  mode 1: dgrad  wt[(tap, co)][ci].  Returns (wt, Kpad, ldw).
+    """
+    batched = w.dim() == 5
+    nb = w.shape[0] if batched else 1
+    cout, cin, kh, kw = w.shape[-4:]
+    khs = geom.khs if khs is None else khs
+    kws = geom.kws if kws is None else kws
+    ntaps = len(khs)
+    rowlen, ncols = (cout, cin) if mode == 1 else (cin, cout)
+    kpad = _ceil(max(ntaps * rowlen, 1), 32)
+    ldw = _ceil(ncols, 32)
+    w = w.contiguous()
+    lib.check_device(w, scale)
+    if out is None:
+        out = torch.empty((nb, kpad, ldw), dtype=torch.float32, device=w.device)
+    if ntaps == 0:
+        out.zero_()
+        return out, kpad, ldw
+    lib.call("fsv_prep_weight", lib.ptr(w), lib.ptr(out), lib.ptr(scale), mode, nb, cout, cin, kh, kw, ntaps,
+             lib.int_array(khs), lib.int_array(kws), kpad, ldw, cout * cin * kh * kw, kpad * ldw, lib.stream_ptr())
+    return out, kpad, ldw
+
+
+def unprep_weight_grad(dwt, w_shape, geom, scale=None):
+    """Inverse of mode-0 prep for gradients: dwt[(tap, ci)][co] -> OIHW (optionally batched)."""
+    batched = len(w_shape) == 5
+    nb = w_shape[0] if batched else 1
+    cout, cin, kh, kw = w_shape[-4:]
+    dw = torch.empty(w_shape, dtype=torch.float32, device=dwt.device)
+    kpad, ldw = dwt.shape[-2], dwt.shape[-1]
+    lib.call("fsv_prep_weight", lib.ptr(dw), lib.ptr(dwt), lib.ptr(scale), 2, nb, cout, cin, kh, kw, geom.ntaps,
+             lib.int_array(geom.khs), lib.int_array(geom.kws), kpad, ldw, cout * cin * kh * kw, kpad * ldw,
+             lib.stream_ptr())
+    return dw
+
+
+def gather_gemm(x, wt, ldw, cout, oh, ow, ty, tx, sy, sx, bias=None, res=None, act=ACT_NONE, scale=1.0,
+                per_sample=False, out=None, place=None, accumulate=False, force_tile=-1, force_split=0):
+    """out[n, oy, ox, :] = act((sum_taps x[n, oy*sy+ty, ox*sx+tx, :] @ wt[tap]) + bias) * scale) + res."""
+    x = to_nhwc(x)
+    n, cin, h, w = x.shape
+    if place is None:
+        out_h, out_w, osy, osx, ooy, oox = oh, ow, 1, 1, 0, 0
+    else:
+        out_h, out_w, osy, osx, ooy, oox = place
+    if out is None:
+        out = empty_nhwc(n, cout, out_h, out_w, x)
+    if res is not None:
+        res = to_nhwc(res)
+    lib.check_device(x, wt, bias, res, out)
+    w_bs = wt.shape[-2] * wt.shape[-1] if per_sample else 0
+    b_bs = cout if (per_sample and bias is not None) else 0
+    lib.call("fsv_conv_gather_fwd", lib.ptr(x), lib.ptr(wt), lib.ptr(bias), lib.ptr(res), lib.ptr(out),
+             n, h, w, cin, oh, ow, cout, len(ty), lib.int_array(ty), lib.int_array(tx), sy, sx,
+             out_h, out_w, osy, osx, ooy, oox, ldw, w_bs, b_bs, 1 if per_sample else 0,
+             act, float(scale), force_tile, force_split, 1 if accumulate else 0, lib.stream_ptr())
+    return out
+
+
+def conv_forward(x, wt_f, ldw, cout, geom, bias=None, res=None, act=ACT_NONE, scale=1.0, per_sample=False,
+                 force_tile=-1, force_split=0):
+    n, cin, h, w = x.shape
+    oh, ow = geom.out_hw(h, w)
+    return gather_gemm(x, wt_f, ldw, cout, oh, ow, geom.ty, geom.tx, geom.stride, geom.stride, bias=bias, res=res,
+                       act=act, scale=scale, per_sample=per_sample, force_tile=force_tile, force_split=force_split)
+
+
+def conv_dgrad(dout, w, geom, in_hw, scale=None, per_sample=False):
+    """Data gradient of a convolution: dx[n, y, x, ci] from dout (NHWC) and OIHW weights."""
+    dout = to_nhwc(dout)
+    n, cout, oh, ow = dout.shape
+    cin = w.shape[-3]
+    h, wd = in_hw
+    s = geom.stride
+    if s == 1:
+        c = geom.dgrad_classes[0]
+        wt, _, ldw = prep_weight(w, 1, geom, c['khs'], c['kws'], scale)
+        return gather_gemm(dout, wt, ldw, cin, h, wd, c['ty'], c['tx'], 1, 1, per_sample=per_sample)
+    dx = zeros_nhwc(n, cin, h, wd, dout)
+    for c in geom.dgrad_classes:
+        sub_h = (h - c['py'] + s - 1) // s
+        sub_w = (wd - c['px'] + s - 1) // s
+        if sub_h <= 0 or sub_w <= 0 or not c['khs']:
+            continue
+        wt, _, ldw = prep_weight(w, 1, geom, c['khs'], c['kws'], scale)
+        gather_gemm(dout, wt, ldw, cin, sub_h, sub_w, c['ty'], c['tx'], 1, 1, per_sample=per_sample, out=dx,
+                    place=(h, wd, s, s, c['py'], c['px']), accumulate=True)
+    return dx
+
+
+def conv_wgrad(x, dout, geom, w_shape, per_sample=False, scale=None, force_split=0):
+    """Weight gradient in OIHW layout (batched when per_sample)."""
+    x = to_nhwc(x)
+    dout = to_nhwc(dout)
+    n, cin, h, w = x.shape
+    _, cout, oh, ow = dout.shape
+    kpad = _ceil(geom.ntaps * cin, 32)
+    ldw = _ceil(cout, 32)
+    nb = n if per_sample else 1
+    dwt = torch.empty((nb, kpad, ldw), dtype=torch.float32, device=x.device)
+    lib.check_device(x, dout)
+    lib.call("fsv_conv_wgrad", lib.ptr(x), lib.ptr(dout), lib.ptr(dwt), n, h, w, cin, oh, ow, cout,
+             geom.ntaps, lib.int_array(geom.ty), lib.int_array(geom.tx), geom.stride, geom.stride,
+             ldw, kpad, kpad * ldw, 1 if per_sample else 0, force_split, lib.stream_ptr())
+    return unprep_weight_grad(dwt, tuple(w_shape), geom, scale)

@@ -1,0 +1,598 @@
+// Implicit-GEMM convolution on the gfx950 matrix cores, exact fp32 (v_mfma_f32_32x32x2_f32).
+//
+// One "gather-GEMM" kernel covers every dense contraction of the few-shot-vid2vid G/D step
+// (SURVEY.md section 8a rows a-1, a-3, a-5..a-9): 3x3 / 4x4 / 1x1 convolutions with stride 1 or 2, their data
+// gradients (flipped taps; stride-2 dgrad is split into 4 output-parity classes), nn.Linear, and the
+// per-sample "batch_conv" of the reference (models/networks/base_network.py:56-71) where every sample has
+// its own generated weight matrix.  A second kernel computes weight gradients (reduction over pixels).
+//
+//   out[z][m][co] = sum_{t < ntaps} sum_{ci < Cin}  in[n, oy*sy + ty[t], ox*sx + tx[t], ci] * wt[z][t*Cin + ci][co]
+//
+// Layout: activations NHWC (channels contiguous) so the K dimension of the GEMM is contiguous in HBM;
+// weights are pre-arranged K-major ([K_pad][ldw]) by fsv_prep_weight (which also applies the spectral-norm
+// 1/sigma).  Tiles are staged through LDS: A is stored transposed ([k][m], row stride BM+1) so that the MFMA
+// A-fragment read (32 consecutive m per half-wave) and the staging writes are both bank-conflict free.
+// The MFMA result is bitwise an fp32 fma chain (guide section 3), which is what lets the parity tests use a
+// 1e-3 relative tolerance against the fp32 CPU oracle with a wide margin.
+#include "fsv_common.h"
+
+#define FSV_BK 32
+
+struct ConvP {
+  const float* in;
+  const float* wt;
+  const float* bias;
+  const float* res;
+  float* out;
+  int N, H, W, Cin;        // input tensor NHWC
+  int OH, OW, Cout;        // iteration grid and number of output channels
+  int K, nchunks, ldw;     // K = ntaps*Cin; nchunks = ceil(K/32); ldw = weight row stride
+  int sy, sx, ntaps;
+  unsigned long long taps_lo, taps_hi;   // (ty+8) | (tx+8)<<4 per tap, 8 taps per word
+  int outH, outW, osy, osx, ooy, oox, dense_out;
+  long long w_bstride, b_bstride;        // per-sample weight / bias strides (0: shared)
+  int per_sample, nsplit;                // blockIdx.z = sample*nsplit + ksplit
+  int act; float scale;
+  int Mz;                                // rows (pixels) per z group
+};
+
+__device__ __forceinline__ void fsv_tap(const ConvP& p, int t, int& ty, int& tx) {
+  unsigned long long code = (t < 8) ? p.taps_lo : p.taps_hi;
+  int sh = (t & 7) * 8;
+  ty = (int)((code >> sh) & 15ull) - 8;
+  tx = (int)((code >> (sh + 4)) & 15ull) - 8;
+}
+
+template <int BM, int BN, int WM, int WN, int V>
+__global__ __launch_bounds__(256) void fsv_conv_igemm_kernel(ConvP p) {
+  constexpr int BK = FSV_BK;
+  constexpr int TM = BM / (WM * 32), TN = BN / (WN * 32);
+  constexpr int LDA = BM + 1;
+  constexpr int KV = BK / V;          // A vectors per pixel row and chunk
+  constexpr int RPP = 256 / KV;       // A rows per pass
+  constexpr int NPA = BM / RPP;       // A passes
+  constexpr int QB = BN / 4;          // B float4 per k row
+  constexpr int RPB = 256 / QB;       // B rows per pass
+  constexpr int NPB = BK / RPB;       // B passes
+  static_assert(WM * WN == 4, "4 waves per workgroup");
+  static_assert(NPA >= 1 && NPB >= 1, "tile too small");
+  __shared__ float As[BK * LDA];
+  __shared__ float Bs[BK * BN];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int zs = blockIdx.z / p.nsplit, zk = blockIdx.z % p.nsplit;
+  const int bm0 = blockIdx.x * BM, bn0 = blockIdx.y * BN;
+  const float* wt = p.wt + (long long)zs * p.w_bstride;
+
+  // ---- per-thread A row bookkeeping ------------------------------------------------------------------
+  const int kq = tid % KV, ar0 = tid / KV;
+  int a_iy0[NPA], a_ix0[NPA];
+  long long a_base[NPA];
+  const int ohw = p.OH * p.OW;
+#pragma unroll
+  for (int i = 0; i < NPA; ++i) {
+    int m = bm0 + ar0 + i * RPP;
+    if (m < p.Mz) {
+      int n, rem;
+      if (p.per_sample) { n = zs; rem = m; } else { n = m / ohw; rem = m - n * ohw; }
+      int oy = rem / p.OW, ox = rem - oy * p.OW;
+      a_iy0[i] = oy * p.sy; a_ix0[i] = ox * p.sx;
+      a_base[i] = (long long)n * p.H * p.W;
+    } else {
+      a_iy0[i] = -(1 << 28); a_ix0[i] = 0; a_base[i] = 0;
+    }
+  }
+  const int bq = tid % QB, br0 = tid / QB;
+  const int bcol = bn0 + bq * 4;
+  const bool bcol_ok = bcol < p.ldw;
+
+  // chunk range of this K split
+  const int cps = (p.nchunks + p.nsplit - 1) / p.nsplit;
+  const int c_begin = zk * cps;
+  const int c_end = (c_begin + cps < p.nchunks) ? (c_begin + cps) : p.nchunks;
+
+  float areg[NPA][V];
+  float4 breg[NPB];
+
+  auto load_chunk = [&](int kc) {
+    const int k = kc * BK + kq * V;
+    const bool kok = k < p.K;
+    int t = kok ? (k / p.Cin) : 0;
+    int ci = k - t * p.Cin;
+    int ty, tx;
+    fsv_tap(p, t, ty, tx);
+#pragma unroll
+    for (int i = 0; i < NPA; ++i) {
+      int iy = a_iy0[i] + ty, ix = a_ix0[i] + tx;
+      bool ok = kok && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+      const float* src = p.in + ((a_base[i] + (long long)iy * p.W + ix) * p.Cin + ci);
+      if constexpr (V == 4) {
+        float4 v = ok ? *reinterpret_cast<const float4*>(src) : make_float4(0.f, 0.f, 0.f, 0.f);
+        areg[i][0] = v.x; areg[i][1] = v.y; areg[i][2] = v.z; areg[i][3] = v.w;
+      } else {
+        areg[i][0] = ok ? *src : 0.f;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < NPB; ++i) {
+      int kr = kc * BK + br0 + i * RPB;
+      breg[i] = bcol_ok ? *reinterpret_cast<const float4*>(wt + (long long)kr * p.ldw + bcol)
+                        : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  };
+  auto store_chunk = [&]() {
+#pragma unroll
+    for (int i = 0; i < NPA; ++i) {
+      int r = ar0 + i * RPP;
+#pragma unroll
+      for (int j = 0; j < V; ++j) As[(kq * V + j) * LDA + r] = areg[i][j];
+    }
+#pragma unroll
+    for (int i = 0; i < NPB; ++i) {
+      int kr = br0 + i * RPB;
+      *reinterpret_cast<float4*>(&Bs[kr * BN + bq * 4]) = breg[i];
+    }
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int lrow = lane & 31, lk = lane >> 5;
+  if (c_begin < c_end) {
+    load_chunk(c_begin);
+    store_chunk();
+    __syncthreads();
+    for (int kc = c_begin; kc < c_end; ++kc) {
+      const bool more = (kc + 1) < c_end;
+      if (more) load_chunk(kc + 1);
+#pragma unroll
+      for (int kk = 0; kk < BK / 2; ++kk) {
+        float a[TM], b[TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) a[i] = As[(kk * 2 + lk) * LDA + wm * (TM * 32) + i * 32 + lrow];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) b[j] = Bs[(kk * 2 + lk) * BN + wn * (TN * 32) + j * 32 + lrow];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+      }
+      __syncthreads();
+      if (more) {
+        store_chunk();
+        __syncthreads();
+      }
+    }
+  }
+
+  // ---- epilogue: D layout col = lane&31 (channel), row = (r&3) + 8*(r>>2) + 4*(lane>>5) (pixel) -----------
+  const float* bias = p.bias ? (p.bias + (long long)zs * p.b_bstride) : nullptr;
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int co = bn0 + wn * (TN * 32) + j * 32 + lrow;
+    if (co >= p.Cout) continue;
+    const float bv = (bias && p.nsplit == 1) ? bias[co] : 0.f;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * lk;
+        const int m = bm0 + wm * (TM * 32) + i * 32 + row;
+        if (m >= p.Mz) continue;
+        long long opix;
+        if (p.dense_out) {
+          opix = (long long)zs * (p.per_sample ? p.Mz : 0) + m;
+        } else {
+          int n, rem;
+          if (p.per_sample) { n = zs; rem = m; } else { n = m / ohw; rem = m - n * ohw; }
+          int oy = rem / p.OW, ox = rem - oy * p.OW;
+          opix = ((long long)n * p.outH + (oy * p.osy + p.ooy)) * p.outW + (ox * p.osx + p.oox);
+        }
+        float* dst = p.out + opix * p.Cout + co;
+        float v = acc[i][j][r];
+        if (p.nsplit > 1) {
+          atomicAdd(dst, v);
+        } else {
+          v = (v + bv) * p.scale;
+          v = fsv_act(v, p.act);
+          if (p.res) v += p.res[opix * p.Cout + co];
+          *dst = v;
+        }
+      }
+    }
+  }
+}
+
+// ---- finishing pass for split-K launches: out = act((out + bias) * scale) + res ---------------------------
+__global__ __launch_bounds__(256) void fsv_bias_act_kernel(float* out, const float* bias, const float* res,
+                                                           long long total, int C, long long pix_per_sample,
+                                                           long long b_bstride, int act, float scale) {
+  long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  const long long stride = (long long)gridDim.x * 256;
+  for (; i < total; i += stride) {
+    int c = (int)(i % C);
+    long long pix = i / C;
+    float v = out[i];
+    if (bias) {
+      long long n = b_bstride ? pix / pix_per_sample : 0;
+      v += bias[n * b_bstride + c];
+    }
+    v = fsv_act(v * scale, act);
+    if (res) v += res[i];
+    out[i] = v;
+  }
+}
+
+// ---- weight gradient: dwt[z][t*Cin+ci][co] (+)= sum_pixels in[n, oy*sy+ty, ox*sx+tx, ci] * dout[n,oy,ox,co] ----
+struct WgradP {
+  const float* in;
+  const float* dout;
+  float* dwt;              // [K_pad][ldw] per z-sample
+  int N, H, W, Cin;
+  int OH, OW, Cout;
+  int K, ldw;
+  int sy, sx, ntaps;
+  unsigned long long taps_lo, taps_hi;
+  long long w_bstride;
+  int per_sample, nsplit;
+  int Mz;                  // pixels per z group
+  int pchunks;             // ceil(Mz/32)
+};
+
+template <int BMK, int BN, int WM, int WN, int V>
+__global__ __launch_bounds__(256) void fsv_conv_wgrad_kernel(WgradP p) {
+  constexpr int BK = FSV_BK;   // pixels per chunk
+  constexpr int TM = BMK / (WM * 32), TN = BN / (WN * 32);
+  constexpr int QA = BMK / V, RPA = 256 / QA, NPA = BK / RPA;
+  constexpr int QB = BN / 4, RPB = 256 / QB, NPB = BK / RPB;
+  static_assert(WM * WN == 4, "4 waves");
+  static_assert(NPA >= 1 && NPB >= 1 && RPA >= 1, "tile");
+  __shared__ float As[BK * BMK];
+  __shared__ float Bs[BK * BN];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int zs = blockIdx.z / p.nsplit, zk = blockIdx.z % p.nsplit;
+  const int bi0 = blockIdx.x * BMK, bn0 = blockIdx.y * BN;
+  float* dwt = p.dwt + (long long)zs * p.w_bstride;
+  const int ohw = p.OH * p.OW;
+
+  // A: column (t,ci) handled by this thread is fixed for the whole reduction
+  const int aq = tid % QA, apr0 = tid / QA;
+  const int kcol = bi0 + aq * V;
+  const bool kok = kcol < p.K;
+  int t = kok ? kcol / p.Cin : 0;
+  const int ci = kcol - t * p.Cin;
+  int ty, tx;
+  {
+    unsigned long long code = (t < 8) ? p.taps_lo : p.taps_hi;
+    int sh = (t & 7) * 8;
+    ty = (int)((code >> sh) & 15ull) - 8;
+    tx = (int)((code >> (sh + 4)) & 15ull) - 8;
+  }
+  const int bq = tid % QB, bpr0 = tid / QB;
+  const int bcol = bn0 + bq * 4;
+
+  const int cps = (p.pchunks + p.nsplit - 1) / p.nsplit;
+  const int c_begin = zk * cps;
+  const int c_end = (c_begin + cps < p.pchunks) ? (c_begin + cps) : p.pchunks;
+
+  float areg[NPA][V];
+  float4 breg[NPB];
+  auto load_chunk = [&](int pc) {
+#pragma unroll
+    for (int i = 0; i < NPA; ++i) {
+      int m = pc * BK + apr0 + i * RPA;
+      bool ok = kok && m < p.Mz;
+      const float* src = p.in;
+      if (ok) {
+        int n, rem;
+        if (p.per_sample) { n = zs; rem = m; } else { n = m / ohw; rem = m - n * ohw; }
+        int oy = rem / p.OW, ox = rem - oy * p.OW;
+        int iy = oy * p.sy + ty, ix = ox * p.sx + tx;
+        ok = (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+        src = p.in + ((((long long)n * p.H + iy) * p.W + ix) * p.Cin + ci);
+      }
+      if constexpr (V == 4) {
+        float4 v = ok ? *reinterpret_cast<const float4*>(src) : make_float4(0.f, 0.f, 0.f, 0.f);
+        areg[i][0] = v.x; areg[i][1] = v.y; areg[i][2] = v.z; areg[i][3] = v.w;
+      } else {
+        areg[i][0] = ok ? *src : 0.f;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < NPB; ++i) {
+      int m = pc * BK + bpr0 + i * RPB;
+      bool ok = m < p.Mz && bcol < p.Cout;   // Cout % 4 == 0 is required by the host wrapper when V4 loads are used
+      long long pix = (long long)zs * (p.per_sample ? p.Mz : 0) + m;
+      const float* src = p.dout + pix * p.Cout + bcol;
+      if ((p.Cout & 3) == 0) {
+        breg[i] = ok ? *reinterpret_cast<const float4*>(src) : make_float4(0.f, 0.f, 0.f, 0.f);
+      } else {
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (m < p.Mz) {
+          if (bcol + 0 < p.Cout) v.x = src[0];
+          if (bcol + 1 < p.Cout) v.y = src[1];
+          if (bcol + 2 < p.Cout) v.z = src[2];
+          if (bcol + 3 < p.Cout) v.w = src[3];
+        }
+        breg[i] = v;
+      }
+    }
+  };
+  auto store_chunk = [&]() {
+#pragma unroll
+    for (int i = 0; i < NPA; ++i) {
+      int pr = apr0 + i * RPA;
+#pragma unroll
+      for (int j = 0; j < V; ++j) As[pr * BMK + aq * V + j] = areg[i][j];
+    }
+#pragma unroll
+    for (int i = 0; i < NPB; ++i) {
+      int pr = bpr0 + i * RPB;
+      *reinterpret_cast<float4*>(&Bs[pr * BN + bq * 4]) = breg[i];
+    }
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int lrow = lane & 31, lk = lane >> 5;
+  if (c_begin < c_end) {
+    load_chunk(c_begin);
+    store_chunk();
+    __syncthreads();
+    for (int pc = c_begin; pc < c_end; ++pc) {
+      const bool more = (pc + 1) < c_end;
+      if (more) load_chunk(pc + 1);
+#pragma unroll
+      for (int kk = 0; kk < BK / 2; ++kk) {
+        float a[TM], b[TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) a[i] = As[(kk * 2 + lk) * BMK + wm * (TM * 32) + i * 32 + lrow];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) b[j] = Bs[(kk * 2 + lk) * BN + wn * (TN * 32) + j * 32 + lrow];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+      }
+      __syncthreads();
+      if (more) {
+        store_chunk();
+        __syncthreads();
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int co = bn0 + wn * (TN * 32) + j * 32 + lrow;
+    if (co >= p.Cout) continue;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * lk;
+        const int k = bi0 + wm * (TM * 32) + i * 32 + row;
+        if (k >= p.K) continue;
+        float* dst = dwt + (long long)k * p.ldw + co;
+        if (p.nsplit > 1) atomicAdd(dst, acc[i][j][r]); else *dst = acc[i][j][r];
+      }
+  }
+}
+
+// ---- weight re-arrangement --------------------------------------------------------------------------------
+// mode 0 (forward):  wt[z][j*Cin + ci][co] = s * w[z][co][ci][kh_j][kw_j]
+// mode 1 (dgrad):    wt[z][j*Cout + co][ci] = s * w[z][co][ci][kh_j][kw_j]
+// mode 2 (inverse of mode 0, for gradients): w[z][co][ci][kh_j][kw_j] = s * wt[z][j*Cin + ci][co]
+// taps: (kh | kw<<4) per tap.  Rows >= K and columns >= ncols of wt are written as zero (modes 0/1).
+__global__ __launch_bounds__(256) void fsv_prep_weight_kernel(const float* w, float* wt, const float* scale_ptr,
+                                                              int mode, int Cout, int Cin, int KH, int KW,
+                                                              int ntaps, unsigned long long taps_lo,
+                                                              unsigned long long taps_hi, int Kpad, int ldw,
+                                                              long long w_bstride, long long wt_bstride) {
+  const int z = blockIdx.z;
+  const float s = scale_ptr ? *scale_ptr : 1.f;
+  const long long total = (long long)Kpad * ldw;
+  const int rowlen = (mode == 1) ? Cout : Cin;      // channels per tap in the K dimension
+  const int ncols = (mode == 1) ? Cin : Cout;
+  const int K = ntaps * rowlen;
+  long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  const long long stride = (long long)gridDim.x * 256;
+  for (; i < total; i += stride) {
+    int r = (int)(i / ldw), c = (int)(i - (long long)r * ldw);
+    bool ok = r < K && c < ncols;
+    int j = ok ? r / rowlen : 0;
+    int a = r - j * rowlen;
+    unsigned long long code = (j < 8) ? taps_lo : taps_hi;
+    int sh = (j & 7) * 8;
+    int kh = (int)((code >> sh) & 15ull), kw = (int)((code >> (sh + 4)) & 15ull);
+    int co = (mode == 1) ? a : c, ci = (mode == 1) ? c : a;
+    long long widx = (((long long)co * Cin + ci) * KH + kh) * KW + kw + (long long)z * w_bstride;
+    if (mode == 2) {
+      if (ok) ((float*)w)[widx] = s * wt[(long long)z * wt_bstride + i];
+    } else {
+      wt[(long long)z * wt_bstride + i] = ok ? s * w[widx] : 0.f;
+    }
+  }
+}
+
+// =============================================== host side ===================================================
+static inline void fsv_pack_taps(const int* ty, const int* tx, int n, unsigned long long& lo, unsigned long long& hi,
+                                 int bias) {
+  lo = 0; hi = 0;
+  for (int t = 0; t < n; ++t) {
+    unsigned long long c = (unsigned long long)((ty[t] + bias) & 15) | ((unsigned long long)((tx[t] + bias) & 15) << 4);
+    if (t < 8) lo |= c << (t * 8); else hi |= c << ((t - 8) * 8);
+  }
+}
+
+template <int V>
+static int fsv_launch_conv(const ConvP& p, int M_tiles_rows, int nz, hipStream_t stream, int tile) {
+  dim3 block(256);
+  switch (tile) {
+    case 0: { dim3 g(fsv_cdiv(M_tiles_rows, 128), fsv_cdiv(p.Cout, 128), nz);
+      FSV_LAUNCH((fsv_conv_igemm_kernel<128, 128, 2, 2, V>), g, block, stream, p); break; }
+    case 1: { dim3 g(fsv_cdiv(M_tiles_rows, 128), fsv_cdiv(p.Cout, 64), nz);
+      FSV_LAUNCH((fsv_conv_igemm_kernel<128, 64, 2, 2, V>), g, block, stream, p); break; }
+    case 2: { dim3 g(fsv_cdiv(M_tiles_rows, 128), fsv_cdiv(p.Cout, 32), nz);
+      FSV_LAUNCH((fsv_conv_igemm_kernel<128, 32, 4, 1, V>), g, block, stream, p); break; }
+    case 3: { dim3 g(fsv_cdiv(M_tiles_rows, 256), fsv_cdiv(p.Cout, 32), nz);
+      FSV_LAUNCH((fsv_conv_igemm_kernel<256, 32, 4, 1, V>), g, block, stream, p); break; }
+    case 4: { dim3 g(fsv_cdiv(M_tiles_rows, 64), fsv_cdiv(p.Cout, 64), nz);
+      FSV_LAUNCH((fsv_conv_igemm_kernel<64, 64, 2, 2, V>), g, block, stream, p); break; }
+    default: return FSV_ERR_BAD_ARG;
+  }
+  return fsv_check_launch();
+}
+
+static inline int fsv_tile_dims(int tile, int& bm, int& bn) {
+  static const int BMs[5] = {128, 128, 128, 256, 64}, BNs[5] = {128, 64, 32, 32, 64};
+  if (tile < 0 || tile > 4) return -1;
+  bm = BMs[tile]; bn = BNs[tile];
+  return 0;
+}
+
+extern "C" {
+
+// Generic gather-GEMM (see header comment and include/fsv2v.h: fsv_conv_gather_fwd).
+int fsv_conv_gather_fwd(const float* in, const float* wt, const float* bias, const float* res, float* out,
+                        int N, int H, int W, int Cin, int OH, int OW, int Cout,
+                        int ntaps, const int* ty, const int* tx, int sy, int sx,
+                        int outH, int outW, int osy, int osx, int ooy, int oox,
+                        int ldw, long long w_bstride, long long b_bstride, int per_sample,
+                        int act, float scale, int force_tile, int force_split, int accumulate, hipStream_t stream) {
+  if (!in || !wt || !out || ntaps < 1 || ntaps > 16 || N < 1 || Cin < 1 || Cout < 1) return FSV_ERR_BAD_ARG;
+  for (int t = 0; t < ntaps; ++t)
+    if (ty[t] < -8 || ty[t] > 7 || tx[t] < -8 || tx[t] > 7) return FSV_ERR_UNSUPPORTED;
+  if ((ldw & 3) != 0 || ldw < Cout) return FSV_ERR_BAD_ARG;
+  ConvP p;
+  p.in = in; p.wt = wt; p.bias = bias; p.res = res; p.out = out;
+  p.N = N; p.H = H; p.W = W; p.Cin = Cin; p.OH = OH; p.OW = OW; p.Cout = Cout;
+  p.K = ntaps * Cin; p.nchunks = fsv_cdiv(p.K, FSV_BK); p.ldw = ldw;
+  p.sy = sy; p.sx = sx; p.ntaps = ntaps;
+  fsv_pack_taps(ty, tx, ntaps, p.taps_lo, p.taps_hi, 8);
+  p.outH = outH; p.outW = outW; p.osy = osy; p.osx = osx; p.ooy = ooy; p.oox = oox;
+  p.dense_out = (osy == 1 && osx == 1 && ooy == 0 && oox == 0 && outH == OH && outW == OW) ? 1 : 0;
+  p.w_bstride = w_bstride; p.b_bstride = b_bstride; p.per_sample = per_sample ? 1 : 0;
+  p.act = act; p.scale = scale;
+  p.Mz = per_sample ? OH * OW : N * OH * OW;
+  const int nsamp = per_sample ? N : 1;
+  // split-K for launches that would leave most of the 256 CUs idle
+  int bm = 128, bn = 128;
+  int tile = force_tile;
+  if (tile < 0) {
+    if (Cout <= 32) tile = (p.Mz >= 256 * 256) ? 3 : 2;
+    else if (Cout <= 64) tile = 1;
+    else tile = ((long long)p.Mz * Cout <= 64 * 64 * 64) ? 4 : 0;
+  }
+  if (fsv_tile_dims(tile, bm, bn)) return FSV_ERR_BAD_ARG;
+  long long blocks = (long long)fsv_cdiv(p.Mz, bm) * fsv_cdiv(Cout, bn) * nsamp;
+  int nsplit = 1;
+  if (force_split > 0) nsplit = force_split;
+  else if (blocks < 256 && p.nchunks >= 8) {
+    nsplit = (int)((512 + blocks - 1) / blocks);
+    if (nsplit > p.nchunks / 4) nsplit = p.nchunks / 4;
+    if (nsplit < 1) nsplit = 1;
+  }
+  if (nsplit > p.nchunks) nsplit = p.nchunks;
+  p.nsplit = nsplit;
+  const long long total = (long long)N * outH * outW * Cout;
+  // accumulate != 0: `out` was zeroed by the caller and partial results are added atomically (used by the
+  // four parity-class launches of a stride-2 data gradient); bias/act/res are not applied in that mode.
+  if (accumulate) {
+    if (bias || res || act != FSV_ACT_NONE || scale != 1.f) return FSV_ERR_BAD_ARG;
+    if (nsplit < 2) { nsplit = (p.nchunks >= 2) ? 2 : 1; p.nsplit = nsplit; }
+  } else if (nsplit > 1) {
+    if (!p.dense_out) return FSV_ERR_UNSUPPORTED;
+    (void)hipMemsetAsync(out, 0, (size_t)total * sizeof(float), stream);
+  }
+  const bool vec4 = (Cin % 4 == 0);
+  int rc = vec4 ? fsv_launch_conv<4>(p, p.Mz, nsamp * nsplit, stream, tile)
+                : fsv_launch_conv<1>(p, p.Mz, nsamp * nsplit, stream, tile);
+  if (rc) return rc;
+  if (!accumulate && nsplit > 1 && (bias || res || act != FSV_ACT_NONE || scale != 1.f)) {
+    int grid = (int)((total + 256 * 8 - 1) / (256 * 8));
+    if (grid > 4096) grid = 4096;
+    if (grid < 1) grid = 1;
+    FSV_LAUNCH(fsv_bias_act_kernel, dim3(grid), dim3(256), stream, out, bias, res, total, Cout,
+               (long long)outH * outW, per_sample ? b_bstride : 0ll, act, scale);
+    rc = fsv_check_launch();
+  }
+  return rc;
+}
+
+int fsv_conv_wgrad(const float* in, const float* dout, float* dwt,
+                   int N, int H, int W, int Cin, int OH, int OW, int Cout,
+                   int ntaps, const int* ty, const int* tx, int sy, int sx,
+                   int ldw, int Kpad, long long w_bstride, int per_sample, int force_split, hipStream_t stream) {
+  if (!in || !dout || !dwt || ntaps < 1 || ntaps > 16) return FSV_ERR_BAD_ARG;
+  for (int t = 0; t < ntaps; ++t)
+    if (ty[t] < -8 || ty[t] > 7 || tx[t] < -8 || tx[t] > 7) return FSV_ERR_UNSUPPORTED;
+  WgradP p;
+  p.in = in; p.dout = dout; p.dwt = dwt;
+  p.N = N; p.H = H; p.W = W; p.Cin = Cin; p.OH = OH; p.OW = OW; p.Cout = Cout;
+  p.K = ntaps * Cin; p.ldw = ldw; p.sy = sy; p.sx = sx; p.ntaps = ntaps;
+  fsv_pack_taps(ty, tx, ntaps, p.taps_lo, p.taps_hi, 8);
+  p.w_bstride = w_bstride; p.per_sample = per_sample ? 1 : 0;
+  p.Mz = per_sample ? OH * OW : N * OH * OW;
+  p.pchunks = fsv_cdiv(p.Mz, FSV_BK);
+  const int nsamp = per_sample ? N : 1;
+  const int bn = (Cout <= 32) ? 32 : (Cout <= 64 ? 64 : 128);
+  const int bmk = (bn == 128) ? 128 : 128;
+  long long blocks = (long long)fsv_cdiv(p.K, bmk) * fsv_cdiv(Cout, bn) * nsamp;
+  int nsplit = 1;
+  if (force_split > 0) nsplit = force_split;
+  else {
+    nsplit = (int)((1024 + blocks - 1) / blocks);
+    int maxs = p.pchunks / 8;       // keep at least 8 pixel chunks (256 pixels) per split
+    if (nsplit > maxs) nsplit = maxs;
+    if (nsplit < 1) nsplit = 1;
+  }
+  if (nsplit > p.pchunks) nsplit = p.pchunks;
+  p.nsplit = nsplit;
+  // the whole padded matrix is (re)written: rows >= K / cols >= Cout stay zero
+  (void)hipMemsetAsync(dwt, 0, (size_t)((per_sample ? (long long)N * w_bstride : (long long)Kpad * ldw)) * sizeof(float), stream);
+  dim3 block(256);
+  const bool vec4 = (Cin % 4 == 0);
+  dim3 g(fsv_cdiv(p.K, 128), fsv_cdiv(Cout, bn), nsamp * nsplit);
+  if (vec4) {
+    if (bn == 128) FSV_LAUNCH((fsv_conv_wgrad_kernel<128, 128, 2, 2, 4>), g, block, stream, p);
+    else if (bn == 64) FSV_LAUNCH((fsv_conv_wgrad_kernel<128, 64, 2, 2, 4>), g, block, stream, p);
+    else FSV_LAUNCH((fsv_conv_wgrad_kernel<128, 32, 4, 1, 4>), g, block, stream, p);
+  } else {
+    if (bn == 128) FSV_LAUNCH((fsv_conv_wgrad_kernel<128, 128, 2, 2, 1>), g, block, stream, p);
+    else if (bn == 64) FSV_LAUNCH((fsv_conv_wgrad_kernel<128, 64, 2, 2, 1>), g, block, stream, p);
+    else FSV_LAUNCH((fsv_conv_wgrad_kernel<128, 32, 4, 1, 1>), g, block, stream, p);
+  }
+  return fsv_check_launch();
+}
+
+int fsv_prep_weight(const float* w, float* wt, const float* scale_ptr, int mode, int nbatch,
+                    int Cout, int Cin, int KH, int KW, int ntaps, const int* kh, const int* kw,
+                    int Kpad, int ldw, long long w_bstride, long long wt_bstride, hipStream_t stream) {
+  if (!w || !wt || ntaps < 1 || ntaps > 16 || mode < 0 || mode > 2) return FSV_ERR_BAD_ARG;
+  unsigned long long lo, hi;
+  fsv_pack_taps(kh, kw, ntaps, lo, hi, 0);
+  long long total = (long long)Kpad * ldw;
+  int grid = (int)((total + 255) / 256);
+  if (grid > 2048) grid = 2048;
+  FSV_LAUNCH(fsv_prep_weight_kernel, dim3(grid, 1, nbatch), dim3(256), stream, w, wt, scale_ptr, mode, Cout, Cin,
+             KH, KW, ntaps, lo, hi, Kpad, ldw, w_bstride, wt_bstride);
+  return fsv_check_launch();
+}
+
+}  // extern "C"

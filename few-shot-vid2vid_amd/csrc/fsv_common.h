@@ -1,0 +1,43 @@
+// Shared device/host helpers for the fsv2v HIP kernels (gfx950 / CDNA4 only).
+//
+// Every kernel in this directory is written for 64-wide wavefronts and the gfx950 MFMA lane layouts
+// (see /opt/skills/guides/cdna_hip_programming.md section 3).  The only other compilation mode is the CPU
+// SIMT emulator used by the `not gpu` tests (tests/emu/hip_emu.h), selected with -DFSV_EMU.
+#pragma once
+#ifdef FSV_EMU
+#include "hip_emu.h"
+#else
+#include <hip/hip_runtime.h>
+#define FSV_LAUNCH(kernel, grid, block, stream, ...) \
+  hipLaunchKernelGGL(kernel, (grid), (block), 0, (stream), __VA_ARGS__)
+#endif
+#include <stdint.h>
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// ---- status codes of the C ABI (include/fsv2v.h) -----------------------------------------------------
+#define FSV_OK 0
+#define FSV_ERR_BAD_ARG (-1)
+#define FSV_ERR_UNSUPPORTED (-2)
+#define FSV_ERR_LAUNCH (-3)
+
+// activation codes used by fused epilogues
+#define FSV_ACT_NONE 0
+#define FSV_ACT_LRELU 1   // leaky_relu(x, 0.2)  (reference models/networks/architecture.py:15-17)
+#define FSV_ACT_TANH 2
+#define FSV_ACT_SIGMOID 3
+
+static inline int fsv_check_launch() {
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? FSV_OK : FSV_ERR_LAUNCH;
+}
+
+__device__ __forceinline__ float fsv_act(float v, int act) {
+  if (act == FSV_ACT_LRELU) return v > 0.f ? v : 0.2f * v;
+  if (act == FSV_ACT_TANH) return tanhf(v);
+  if (act == FSV_ACT_SIGMOID) return 1.f / (1.f + expf(-v));
+  return v;
+}
+
+static inline int fsv_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
