@@ -1,0 +1,146 @@
+// Small HBM-bound helpers of the G/D step: nearest x2 up-sampling (generator.py:124 `self.up`, nn.Upsample in
+// FlowGenerator / LabelEmbedder), activation forward/backward, and the fused Adam update on flat parameter
+// buffers (reference optimiser: models/base_model.py:39-48, torch.optim.Adam with TTUR betas (0, 0.999)).
+#include "fsv_common.h"
+
+static inline int fsv_grid_for(long long units) {
+  long long g = (units + 255) / 256;
+  if (g > 16384) g = 16384;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+
+// y[n, 2h+a, 2w+b, :] = x[n, h, w, :]  -- one work-item per output float4 (or scalar when C % 4 != 0)
+template <int V>
+__global__ __launch_bounds__(256) void fsv_up2x_fwd_kernel(const float* x, float* y, int N, int H, int W, int C) {
+  const int CQ = C / V;
+  const long long total = (long long)N * (2 * H) * (2 * W) * CQ;
+  long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  const long long stride = (long long)gridDim.x * 256;
+  for (; i < total; i += stride) {
+    int cq = (int)(i % CQ);
+    long long pix = i / CQ;
+    int ox = (int)(pix % (2 * W));
+    long long t = pix / (2 * W);
+    int oy = (int)(t % (2 * H));
+    int n = (int)(t / (2 * H));
+    long long src = ((((long long)n * H + (oy >> 1)) * W + (ox >> 1)) * CQ + cq) * V;
+    if (V == 4) *reinterpret_cast<float4*>(y + i * 4) = *reinterpret_cast<const float4*>(x + src);
+    else y[i] = x[src];
+  }
+}
+
+// dx[n, h, w, :] = sum_{a,b} dy[n, 2h+a, 2w+b, :]
+template <int V>
+__global__ __launch_bounds__(256) void fsv_up2x_bwd_kernel(const float* dy, float* dx, int N, int H, int W, int C) {
+  const int CQ = C / V;
+  const long long total = (long long)N * H * W * CQ;
+  long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  const long long stride = (long long)gridDim.x * 256;
+  const long long rowq = (long long)(2 * W) * CQ;
+  for (; i < total; i += stride) {
+    int cq = (int)(i % CQ);
+    long long pix = i / CQ;
+    int w = (int)(pix % W);
+    long long t = pix / W;
+    int h = (int)(t % H);
+    int n = (int)(t / H);
+    long long s00 = ((((long long)n * 2 * H + 2 * h) * (2 * W) + 2 * w) * CQ + cq);
+    if (V == 4) {
+      const float4* d = reinterpret_cast<const float4*>(dy);
+      float4 a = d[s00], b = d[s00 + CQ], c = d[s00 + rowq], e = d[s00 + rowq + CQ];
+      *reinterpret_cast<float4*>(dx + i * 4) = make_float4((a.x + b.x) + (c.x + e.x), (a.y + b.y) + (c.y + e.y),
+                                                           (a.z + b.z) + (c.z + e.z), (a.w + b.w) + (c.w + e.w));
+    } else {
+      dx[i] = (dy[s00] + dy[s00 + CQ]) + (dy[s00 + rowq] + dy[s00 + rowq + CQ]);
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void fsv_act_fwd_kernel(const float* x, float* y, long long total, int act) {
+  long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  const long long stride = (long long)gridDim.x * 256;
+  for (; i < total; i += stride) y[i] = fsv_act(x[i], act);
+}
+
+__global__ __launch_bounds__(256) void fsv_act_bwd_kernel(const float* dy, const float* y, float* dx, long long total,
+                                                          int act, float scale) {
+  long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  const long long stride = (long long)gridDim.x * 256;
+  for (; i < total; i += stride) {
+    float d = dy[i] * scale, v = y[i];
+    if (act == FSV_ACT_LRELU) d = v > 0.f ? d : 0.2f * d;
+    else if (act == FSV_ACT_TANH) d = d * (1.f - v * v);
+    else if (act == FSV_ACT_SIGMOID) d = d * v * (1.f - v);
+    dx[i] = d;
+  }
+}
+
+// ---- Adam ------------------------------------------------------------------------------------------------------
+// state[0] = step count (as float), state[1] = 1 - beta1^t, state[2] = 1 - beta2^t, state[3] = lr (set by the host)
+__global__ void fsv_adam_tick_kernel(float* state, float beta1, float beta2) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    float t = state[0] + 1.f;
+    state[0] = t;
+    state[1] = 1.f - powf(beta1, t);
+    state[2] = 1.f - powf(beta2, t);
+  }
+}
+
+__global__ __launch_bounds__(256) void fsv_adam_kernel(float* param, const float* grad, float* m, float* v,
+                                                       const float* state, long long n, float beta1, float beta2,
+                                                       float eps, float gscale) {
+  const float bc1 = state[1], bc2 = state[2], lr = state[3];
+  const float step_size = lr / bc1;
+  const float rbc2 = 1.f / sqrtf(bc2);
+  long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  const long long stride = (long long)gridDim.x * 256;
+  for (; i < n; i += stride) {
+    float g = grad[i] * gscale;
+    float mi = beta1 * m[i] + (1.f - beta1) * g;
+    float vi = beta2 * v[i] + (1.f - beta2) * g * g;
+    m[i] = mi; v[i] = vi;
+    float denom = sqrtf(vi) * rbc2 + eps;
+    param[i] = param[i] - step_size * (mi / denom);
+  }
+}
+
+extern "C" {
+
+int fsv_upsample2x_fwd(const float* x, float* y, int N, int H, int W, int C, hipStream_t stream) {
+  if (!x || !y || N < 1 || H < 1 || W < 1 || C < 1) return FSV_ERR_BAD_ARG;
+  if (C % 4 == 0) FSV_LAUNCH((fsv_up2x_fwd_kernel<4>), dim3(fsv_grid_for((long long)N * H * W * C)), dim3(256), stream, x, y, N, H, W, C);
+  else FSV_LAUNCH((fsv_up2x_fwd_kernel<1>), dim3(fsv_grid_for((long long)N * H * W * C * 4)), dim3(256), stream, x, y, N, H, W, C);
+  return fsv_check_launch();
+}
+
+int fsv_upsample2x_bwd(const float* dy, float* dx, int N, int H, int W, int C, hipStream_t stream) {
+  if (!dy || !dx || N < 1 || H < 1 || W < 1 || C < 1) return FSV_ERR_BAD_ARG;
+  if (C % 4 == 0) FSV_LAUNCH((fsv_up2x_bwd_kernel<4>), dim3(fsv_grid_for((long long)N * H * W * C / 4)), dim3(256), stream, dy, dx, N, H, W, C);
+  else FSV_LAUNCH((fsv_up2x_bwd_kernel<1>), dim3(fsv_grid_for((long long)N * H * W * C)), dim3(256), stream, dy, dx, N, H, W, C);
+  return fsv_check_launch();
+}
+
+int fsv_act_fwd(const float* x, float* y, long long total, int act, hipStream_t stream) {
+  if (!x || !y || total < 0) return FSV_ERR_BAD_ARG;
+  FSV_LAUNCH(fsv_act_fwd_kernel, dim3(fsv_grid_for(total / 4 + 1)), dim3(256), stream, x, y, total, act);
+  return fsv_check_launch();
+}
+
+// dx = dy * scale * act'(y)   (y is the activation OUTPUT)
+int fsv_act_bwd(const float* dy, const float* y, float* dx, long long total, int act, float scale, hipStream_t stream) {
+  if (!dy || !y || !dx || total < 0) return FSV_ERR_BAD_ARG;
+  FSV_LAUNCH(fsv_act_bwd_kernel, dim3(fsv_grid_for(total / 4 + 1)), dim3(256), stream, dy, y, dx, total, act, scale);
+  return fsv_check_launch();
+}
+
+int fsv_adam_step(float* param, const float* grad, float* m, float* v, float* state, long long n, float beta1,
+                  float beta2, float eps, float gscale, hipStream_t stream) {
+  if (!param || !grad || !m || !v || !state || n < 0) return FSV_ERR_BAD_ARG;
+  FSV_LAUNCH(fsv_adam_tick_kernel, dim3(1), dim3(64), stream, state, beta1, beta2);
+  FSV_LAUNCH(fsv_adam_kernel, dim3(fsv_grid_for(n / 4 + 1)), dim3(256), stream, param, grad, m, v, (const float*)state, n,
+             beta1, beta2, eps, gscale);
+  return fsv_check_launch();
+}
+
+}  // extern "C"

@@ -1,0 +1,290 @@
+// Fused adaptive-SPADE modulation on the matrix cores.
+//
+// Reference semantics (models/networks/normalization.py:37-52, SPADE.forward):
+//     out = BN_nofaffine(x)
+//     for each non-None map k:   gamma_k = conv1x1(m_k; Wg_k) + bg_k ;  beta_k = conv1x1(m_k; Wb_k) + bb_k
+//                                out = out * (1 + gamma_k) + beta_k
+// followed (in SPADEResnetBlock, architecture.py:95-97) by leaky_relu(0.2) for bn_0 / bn_1 (not bn_s).
+// Map 0 of the adaptive layers uses per-sample generated weights (batch_conv, base_network.py:56-71); the
+// extra "spade_combine" maps use fixed weights (mlp_gamma2/3).
+//
+// One launch does all of it: for a tile of BM pixels x BN channels the gamma and beta 1x1 convolutions are
+// two fp32 MFMA GEMMs that share the LDS-staged label-map tile, and the epilogue applies the BatchNorm
+// denormalisation, the (1 + gamma) * . + beta modulation of every map in sequence and the activation before
+// the single write of h.  gamma/beta never touch HBM.  Layout NHWC; grid.z = sample so that per-sample and
+// shared weights can be mixed (a per-map batch stride of 0 means shared).
+#include "fsv_common.h"
+
+#define FSV_SP_BK 32
+#define FSV_SP_MAXMAPS 3
+
+struct SpadeP {
+  const float* x;         // [N][HW][C]
+  const float* mean;      // [C] (or [N][C] when stat_bstride != 0)
+  const float* rstd;
+  float* h;               // [N][HW][C]
+  const float* map[FSV_SP_MAXMAPS];    // [N][HW][Ch_k]
+  const float* wg[FSV_SP_MAXMAPS];     // K-major [Kpad_k][ldw] (+ z * w_bstride_k)
+  const float* wb[FSV_SP_MAXMAPS];
+  const float* bg[FSV_SP_MAXMAPS];     // [C] (+ z * b_bstride_k)
+  const float* bb[FSV_SP_MAXMAPS];
+  int ch[FSV_SP_MAXMAPS];
+  long long w_bstride[FSV_SP_MAXMAPS];
+  long long b_bstride[FSV_SP_MAXMAPS];
+  int nmaps;
+  int N, HW, C, ldw;
+  long long stat_bstride;
+  int act;
+};
+
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(256) void fsv_spade_mod_kernel(SpadeP p) {
+  constexpr int BK = FSV_SP_BK;
+  constexpr int TM = BM / (WM * 32), TN = BN / (WN * 32);
+  constexpr int LDA = BM + 1;
+  constexpr int KV = BK / 4, RPP = 256 / KV, NPA = BM / RPP;
+  constexpr int QB = BN / 4, RPB = 256 / QB, NPB = BK / RPB;
+  static_assert(WM * WN == 4, "4 waves");
+  static_assert(NPA >= 1 && NPB >= 1, "tile");
+  __shared__ float As[BK * LDA];
+  __shared__ float Bg[BK * BN];
+  __shared__ float Bb[BK * BN];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int z = blockIdx.z;
+  const int bm0 = blockIdx.x * BM, bn0 = blockIdx.y * BN;
+  const int lrow = lane & 31, lk = lane >> 5;
+  const int kq = tid % KV, ar0 = tid / KV;
+  const int bq = tid % QB, br0 = tid / QB;
+  const int bcol = bn0 + bq * 4;
+  const bool bcol_ok = bcol < p.ldw;
+
+  // running value of the normalised + modulated activation, in MFMA C/D layout
+  f32x16 outv[TM][TN];
+  const float* mean = p.mean + z * p.stat_bstride;
+  const float* rstd = p.rstd + z * p.stat_bstride;
+  const long long pix0 = (long long)z * p.HW;
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int c = bn0 + wn * (TN * 32) + j * 32 + lrow;
+    const bool cok = c < p.C;
+    const float mu = cok ? mean[c] : 0.f, rs = cok ? rstd[c] : 0.f;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * lk;
+        const int m = bm0 + wm * (TM * 32) + i * 32 + row;
+        float v = 0.f;
+        if (cok && m < p.HW) v = (p.x[(pix0 + m) * p.C + c] - mu) * rs;
+        outv[i][j][r] = v;
+      }
+  }
+
+#pragma unroll
+  for (int k = 0; k < FSV_SP_MAXMAPS; ++k) {
+    if (k >= p.nmaps) break;
+    const float* mp = p.map[k] + pix0 * p.ch[k];
+    const float* wg = p.wg[k] + z * p.w_bstride[k];
+    const float* wb = p.wb[k] + z * p.w_bstride[k];
+    const int Ch = p.ch[k];
+    const int nchunks = (Ch + BK - 1) / BK;
+    f32x16 accg[TM][TN], accb[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { accg[i][j][r] = 0.f; accb[i][j][r] = 0.f; }
+
+    float4 areg[NPA], gbreg[NPB], bbreg[NPB];
+    auto load_chunk = [&](int kc) {
+      const int kk = kc * BK + kq * 4;
+#pragma unroll
+      for (int i = 0; i < NPA; ++i) {
+        int m = bm0 + ar0 + i * RPP;
+        bool ok = kk < Ch && m < p.HW;
+        areg[i] = ok ? *reinterpret_cast<const float4*>(mp + (long long)m * Ch + kk) : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+#pragma unroll
+      for (int i = 0; i < NPB; ++i) {
+        int kr = kc * BK + br0 + i * RPB;
+        gbreg[i] = bcol_ok ? *reinterpret_cast<const float4*>(wg + (long long)kr * p.ldw + bcol) : make_float4(0.f, 0.f, 0.f, 0.f);
+        bbreg[i] = bcol_ok ? *reinterpret_cast<const float4*>(wb + (long long)kr * p.ldw + bcol) : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    };
+    auto store_chunk = [&]() {
+#pragma unroll
+      for (int i = 0; i < NPA; ++i) {
+        int r = ar0 + i * RPP;
+        As[(kq * 4 + 0) * LDA + r] = areg[i].x;
+        As[(kq * 4 + 1) * LDA + r] = areg[i].y;
+        As[(kq * 4 + 2) * LDA + r] = areg[i].z;
+        As[(kq * 4 + 3) * LDA + r] = areg[i].w;
+      }
+#pragma unroll
+      for (int i = 0; i < NPB; ++i) {
+        int kr = br0 + i * RPB;
+        *reinterpret_cast<float4*>(&Bg[kr * BN + bq * 4]) = gbreg[i];
+        *reinterpret_cast<float4*>(&Bb[kr * BN + bq * 4]) = bbreg[i];
+      }
+    };
+    __syncthreads();            // previous map's LDS reads are finished
+    load_chunk(0);
+    store_chunk();
+    __syncthreads();
+    for (int kc = 0; kc < nchunks; ++kc) {
+      const bool more = (kc + 1) < nchunks;
+      if (more) load_chunk(kc + 1);
+#pragma unroll
+      for (int kk = 0; kk < BK / 2; ++kk) {
+        float a[TM], g[TN], b[TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) a[i] = As[(kk * 2 + lk) * LDA + wm * (TM * 32) + i * 32 + lrow];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          g[j] = Bg[(kk * 2 + lk) * BN + wn * (TN * 32) + j * 32 + lrow];
+          b[j] = Bb[(kk * 2 + lk) * BN + wn * (TN * 32) + j * 32 + lrow];
+        }
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j) {
+            accg[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], g[j], accg[i][j], 0, 0, 0);
+            accb[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], accb[i][j], 0, 0, 0);
+          }
+      }
+      __syncthreads();
+      if (more) {
+        store_chunk();
+        __syncthreads();
+      }
+    }
+    // modulation epilogue for this map
+    const float* bg = p.bg[k] + z * p.b_bstride[k];
+    const float* bb = p.bb[k] + z * p.b_bstride[k];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int c = bn0 + wn * (TN * 32) + j * 32 + lrow;
+      const float bgv = (c < p.C) ? bg[c] : 0.f, bbv = (c < p.C) ? bb[c] : 0.f;
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          outv[i][j][r] = outv[i][j][r] * (1.f + (accg[i][j][r] + bgv)) + (accb[i][j][r] + bbv);
+    }
+  }
+
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int c = bn0 + wn * (TN * 32) + j * 32 + lrow;
+    if (c >= p.C) continue;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * lk;
+        const int m = bm0 + wm * (TM * 32) + i * 32 + row;
+        if (m < p.HW) p.h[(pix0 + m) * p.C + c] = fsv_act(outv[i][j][r], p.act);
+      }
+  }
+}
+
+// ---- backward, elementwise part -------------------------------------------------------------------------------
+// gb_k: materialised [P][2C] (gamma | beta) per map (recomputed by the caller with the gather-GEMM kernel).
+// Computes, per element, the chain  o_0 = xhat, o_k = o_{k-1} (1 + g_k) + b_k,  h = act(o_n)  backwards:
+//   d = dh * act'(h);  for k = n..1:  dbeta_k = d; dgamma_k = d * o_{k-1}; d = d * (1 + g_k);   dxhat = d
+struct SpadeBwdP {
+  const float* x; const float* mean; const float* rstd;
+  const float* dh; const float* h;
+  const float* gb[FSV_SP_MAXMAPS];
+  float* dgb[FSV_SP_MAXMAPS];
+  float* dxhat;
+  int nmaps, C, act;
+  long long total;        // N*HW*C
+  long long HWC;          // per-sample elements (for per-sample statistics)
+  long long stat_bstride;
+};
+
+__global__ __launch_bounds__(256) void fsv_spade_bwd_elem_kernel(SpadeBwdP p) {
+  long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  const long long stride = (long long)gridDim.x * 256;
+  for (; i < p.total; i += stride) {
+    const int c = (int)(i % p.C);
+    const long long pix = i / p.C;
+    const long long n = i / p.HWC;
+    const float mu = p.mean[n * p.stat_bstride + c], rs = p.rstd[n * p.stat_bstride + c];
+    float o[FSV_SP_MAXMAPS + 1];
+    float g[FSV_SP_MAXMAPS];
+    o[0] = (p.x[i] - mu) * rs;
+#pragma unroll
+    for (int k = 0; k < FSV_SP_MAXMAPS; ++k) {
+      if (k < p.nmaps) {
+        const float* gbp = p.gb[k] + pix * 2 * p.C;
+        g[k] = gbp[c];
+        o[k + 1] = o[k] * (1.f + g[k]) + gbp[p.C + c];
+      }
+    }
+    float d = p.dh[i];
+    if (p.act == FSV_ACT_LRELU) d = (p.h[i] > 0.f) ? d : 0.2f * d;
+#pragma unroll
+    for (int k = FSV_SP_MAXMAPS - 1; k >= 0; --k) {
+      if (k < p.nmaps) {
+        float* dg = p.dgb[k] + pix * 2 * p.C;
+        dg[p.C + c] = d;
+        dg[c] = d * o[k];
+        d = d * (1.f + g[k]);
+      }
+    }
+    p.dxhat[i] = d;
+  }
+}
+
+extern "C" {
+
+// maps/wg/wb/bg/bb: arrays of nmaps device pointers; ch / w_bstride / b_bstride: per-map ints / strides.
+int fsv_spade_mod_fwd(const float* x, const float* mean, const float* rstd, float* h,
+                      int nmaps, const float* const* maps, const float* const* wg, const float* const* wb,
+                      const float* const* bg, const float* const* bb, const int* ch, const long long* w_bstride,
+                      const long long* b_bstride, int N, int HW, int C, int ldw, long long stat_bstride, int act,
+                      hipStream_t stream) {
+  if (!x || !mean || !rstd || !h || nmaps < 0 || nmaps > FSV_SP_MAXMAPS || C < 1 || (ldw & 3)) return FSV_ERR_BAD_ARG;
+  SpadeP p;
+  p.x = x; p.mean = mean; p.rstd = rstd; p.h = h; p.nmaps = nmaps;
+  for (int k = 0; k < FSV_SP_MAXMAPS; ++k) {
+    bool on = k < nmaps;
+    p.map[k] = on ? maps[k] : nullptr; p.wg[k] = on ? wg[k] : nullptr; p.wb[k] = on ? wb[k] : nullptr;
+    p.bg[k] = on ? bg[k] : nullptr; p.bb[k] = on ? bb[k] : nullptr;
+    p.ch[k] = on ? ch[k] : 0; p.w_bstride[k] = on ? w_bstride[k] : 0; p.b_bstride[k] = on ? b_bstride[k] : 0;
+    if (on && ((ch[k] & 3) || !maps[k] || !wg[k] || !wb[k] || !bg[k] || !bb[k])) return FSV_ERR_UNSUPPORTED;
+  }
+  p.N = N; p.HW = HW; p.C = C; p.ldw = ldw; p.stat_bstride = stat_bstride; p.act = act;
+  if (C <= 32) {
+    dim3 g(fsv_cdiv(HW, 128), fsv_cdiv(C, 32), N);
+    FSV_LAUNCH((fsv_spade_mod_kernel<128, 32, 4, 1>), g, dim3(256), stream, p);
+  } else {
+    dim3 g(fsv_cdiv(HW, 128), fsv_cdiv(C, 64), N);
+    FSV_LAUNCH((fsv_spade_mod_kernel<128, 64, 2, 2>), g, dim3(256), stream, p);
+  }
+  return fsv_check_launch();
+}
+
+int fsv_spade_bwd_elem(const float* x, const float* mean, const float* rstd, const float* dh, const float* h,
+                       int nmaps, const float* const* gb, float* const* dgb, float* dxhat,
+                       int N, int HW, int C, long long stat_bstride, int act, hipStream_t stream) {
+  if (!x || !mean || !rstd || !dh || !dxhat || nmaps < 0 || nmaps > FSV_SP_MAXMAPS) return FSV_ERR_BAD_ARG;
+  if (act == FSV_ACT_LRELU && !h) return FSV_ERR_BAD_ARG;
+  if (act != FSV_ACT_LRELU && act != FSV_ACT_NONE) return FSV_ERR_UNSUPPORTED;
+  SpadeBwdP p;
+  p.x = x; p.mean = mean; p.rstd = rstd; p.dh = dh; p.h = h; p.dxhat = dxhat;
+  for (int k = 0; k < FSV_SP_MAXMAPS; ++k) { p.gb[k] = k < nmaps ? gb[k] : nullptr; p.dgb[k] = k < nmaps ? dgb[k] : nullptr; }
+  p.nmaps = nmaps; p.C = C; p.act = act;
+  p.total = (long long)N * HW * C; p.HWC = (long long)HW * C; p.stat_bstride = stat_bstride;
+  long long g = (p.total + 256 * 4 - 1) / (256 * 4);
+  if (g > 8192) g = 8192;
+  if (g < 1) g = 1;
+  FSV_LAUNCH(fsv_spade_bwd_elem_kernel, dim3((unsigned)g), dim3(256), stream, p);
+  return fsv_check_launch();
+}
+
+}  // extern "C"

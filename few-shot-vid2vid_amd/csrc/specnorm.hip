@@ -1,0 +1,140 @@
+// Spectral normalisation (torch.nn.utils.spectral_norm, one power iteration per training forward) for every
+// conv / linear weight of G and D (reference: models/networks/architecture.py:60,81-84, generator.py:106-109,
+// normalization.py:65).  W is viewed as a [R][Cc] matrix (R = out channels):
+//     v = normalize(W^T u);  u = normalize(W v);  sigma = u . (W v);  W_sn = W / sigma
+// u and v are persistent buffers updated in place (also under no_grad: the reference runs G forward twice per
+// iteration in train() mode).  1/sigma is left on the device and folded into the weight re-arrangement
+// (fsv_prep_weight scale pointer), so W_sn is never materialised for the forward pass.
+// Backward (u, v constant):  dW = (dW_sn - <dW_sn, W_sn> u v^T) / sigma.
+#include "fsv_common.h"
+
+// t[j] += sum_{i in row slab} W[i][j] u[i]      (t zero-initialised)
+__global__ __launch_bounds__(256) void fsv_sn_gemv_t_kernel(const float* W, const float* u, float* t, int R, int Cc, int rows_per_blk) {
+  int j = blockIdx.x * 256 + threadIdx.x;
+  int r0 = blockIdx.y * rows_per_blk;
+  int r1 = (r0 + rows_per_blk < R) ? r0 + rows_per_blk : R;
+  if (j >= Cc) return;
+  float acc = 0.f;
+  for (int i = r0; i < r1; ++i) acc += W[(long long)i * Cc + j] * u[i];
+  atomicAdd(&t[j], acc);
+}
+
+// s[i] = sum_j W[i][j] t[j]      one wave per row
+__global__ __launch_bounds__(256) void fsv_sn_gemv_kernel(const float* W, const float* t, float* s, int R, int Cc) {
+  const int lane = threadIdx.x & 63;
+  int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const bool ok = row < R;
+  const float* w = W + (long long)(ok ? row : 0) * Cc;
+  float acc = 0.f;
+  if (ok) for (int j = lane; j < Cc; j += 64) acc += w[j] * t[j];
+  for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+  if (ok && lane == 0) s[row] = acc;
+}
+
+// single block: norms, u, v, sigma.  out[0] = sigma, out[1] = 1/sigma
+__global__ __launch_bounds__(256) void fsv_sn_finalize_kernel(const float* t, const float* s, float* u, float* v, float* out,
+                                                              int R, int Cc, float eps) {
+  __shared__ float red[256];
+  float a = 0.f;
+  for (int j = threadIdx.x; j < Cc; j += 256) a += t[j] * t[j];
+  red[threadIdx.x] = a;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) { if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o]; __syncthreads(); }
+  const float nt = fmaxf(sqrtf(red[0]), eps);
+  __syncthreads();
+  for (int j = threadIdx.x; j < Cc; j += 256) v[j] = t[j] / nt;
+  // W v = s / nt
+  float b = 0.f;
+  for (int i = threadIdx.x; i < R; i += 256) { float wv = s[i] / nt; b += wv * wv; }
+  red[threadIdx.x] = b;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) { if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o]; __syncthreads(); }
+  const float ns = fmaxf(sqrtf(red[0]), eps);
+  __syncthreads();
+  float c = 0.f;
+  for (int i = threadIdx.x; i < R; i += 256) { float wv = s[i] / nt; float ui = wv / ns; u[i] = ui; c += ui * wv; }
+  red[threadIdx.x] = c;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) { if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o]; __syncthreads(); }
+  if (threadIdx.x == 0) { out[0] = red[0]; out[1] = 1.f / red[0]; }
+}
+
+// eval-mode sigma (no power iteration): sigma = u . (W v)
+__global__ __launch_bounds__(256) void fsv_sn_sigma_kernel(const float* s, const float* u, float* out, int R) {
+  __shared__ float red[256];
+  float c = 0.f;
+  for (int i = threadIdx.x; i < R; i += 256) c += u[i] * s[i];
+  red[threadIdx.x] = c;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) { if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o]; __syncthreads(); }
+  if (threadIdx.x == 0) { out[0] = red[0]; out[1] = 1.f / red[0]; }
+}
+
+// partial dot products <A, B> -> part[block] (double)
+__global__ __launch_bounds__(256) void fsv_dot_partial_kernel(const float* a, const float* b, double* part, long long n) {
+  __shared__ double red[256];
+  long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  const long long stride = (long long)gridDim.x * 256;
+  float acc = 0.f; double dacc = 0.0; int cnt = 0;
+  for (; i < n; i += stride) { acc += a[i] * b[i]; if (++cnt == 64) { dacc += (double)acc; acc = 0.f; cnt = 0; } }
+  red[threadIdx.x] = dacc + (double)acc;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) { if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o]; __syncthreads(); }
+  if (threadIdx.x == 0) part[blockIdx.x] = red[0];
+}
+
+// dW[i][j] = inv_sigma * (dWsn[i][j] - inv_sigma * dot * u[i] * v[j]),  dot = <dWsn, W>
+__global__ __launch_bounds__(256) void fsv_sn_bwd_kernel(const float* dWsn, const double* part, int nparts, const float* u,
+                                                         const float* v, const float* sig, float* dW, int R, int Cc) {
+  __shared__ float sdot;
+  if (threadIdx.x == 0) { double d = 0.0; for (int k = 0; k < nparts; ++k) d += part[k]; sdot = (float)d; }
+  __syncthreads();
+  const float inv = sig[1];
+  const float coef = inv * sdot;
+  const long long total = (long long)R * Cc;
+  long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  const long long stride = (long long)gridDim.x * 256;
+  for (; i < total; i += stride) {
+    int r = (int)(i / Cc), c = (int)(i - (long long)r * Cc);
+    dW[i] = inv * (dWsn[i] - coef * u[r] * v[c]);
+  }
+}
+
+extern "C" {
+
+// scratch: float[R + Cc] device scratch; sig: float[2] -> (sigma, 1/sigma)
+int fsv_sn_power_iter(const float* W, float* u, float* v, float* scratch, float* sig, int R, int Cc, float eps,
+                      int training, hipStream_t stream) {
+  if (!W || !u || !v || !scratch || !sig || R < 1 || Cc < 1) return FSV_ERR_BAD_ARG;
+  float* t = scratch;          // [Cc]
+  float* s = scratch + Cc;     // [R]
+  if (training) {
+    (void)hipMemsetAsync(t, 0, sizeof(float) * (size_t)Cc, stream);
+    int rows_per_blk = 64;
+    dim3 g(fsv_cdiv(Cc, 256), fsv_cdiv(R, rows_per_blk));
+    FSV_LAUNCH(fsv_sn_gemv_t_kernel, g, dim3(256), stream, W, (const float*)u, t, R, Cc, rows_per_blk);
+    FSV_LAUNCH(fsv_sn_gemv_kernel, dim3(fsv_cdiv(R, 4)), dim3(256), stream, W, (const float*)t, s, R, Cc);
+    FSV_LAUNCH(fsv_sn_finalize_kernel, dim3(1), dim3(256), stream, (const float*)t, (const float*)s, u, v, sig, R, Cc, eps);
+  } else {
+    FSV_LAUNCH(fsv_sn_gemv_kernel, dim3(fsv_cdiv(R, 4)), dim3(256), stream, W, (const float*)v, s, R, Cc);
+    FSV_LAUNCH(fsv_sn_sigma_kernel, dim3(1), dim3(256), stream, (const float*)s, (const float*)u, sig, R);
+  }
+  return fsv_check_launch();
+}
+
+// part: double[256] scratch
+int fsv_sn_backward(const float* dWsn, const float* W, const float* u, const float* v, const float* sig, double* part,
+                    float* dW, int R, int Cc, hipStream_t stream) {
+  if (!dWsn || !W || !u || !v || !sig || !part || !dW) return FSV_ERR_BAD_ARG;
+  long long n = (long long)R * Cc;
+  int nparts = (int)((n + 256 * 64 - 1) / (256 * 64));
+  if (nparts > 256) nparts = 256;
+  if (nparts < 1) nparts = 1;
+  FSV_LAUNCH(fsv_dot_partial_kernel, dim3(nparts), dim3(256), stream, dWsn, W, part, n);
+  long long g = (n + 1023) / 1024;
+  if (g > 4096) g = 4096;
+  FSV_LAUNCH(fsv_sn_bwd_kernel, dim3((unsigned)g), dim3(256), stream, dWsn, (const double*)part, nparts, u, v, sig, dW, R, Cc);
+  return fsv_check_launch();
+}
+
+}  // extern "C"

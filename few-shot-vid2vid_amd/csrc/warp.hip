@@ -1,0 +1,172 @@
+// Flow warp ("resample") of the few-shot-vid2vid generator and flow losses.
+//
+// Reference: models/networks/base_network.py:13-37 (get_grid + resample): the pixel-unit flow is turned into
+// a normalised grid  g = linspace(-1, 1, n)[i] + flow / ((n - 1) / 2)  and handed to
+// F.grid_sample(bilinear, padding_mode='border', align_corners=True).  ATen then un-normalises
+// ix = (g + 1) * ((n - 1) / 2), clips to [0, n - 1] and floors.  That round trip is not the identity in fp32
+// (at zero flow 76 of 512 columns land on x - 1), so this kernel replays the very same
+// sequence of fp32 operations - it is compiled with -ffp-contract=off - and therefore selects bit-identical
+// tap indices.  The base grid is taken from the host (torch.linspace, exactly what the reference uploads).
+//
+// HBM-bound: per output pixel 8 B of flow + (C taps, mostly L2 hits) + 4*C B written.  One work-item per
+// output pixel, a wave covers 64 consecutive x so flow reads and output writes are coalesced for planar
+// (NCHW) images; strides are explicit so channels-last images work too.
+#include "fsv_common.h"
+
+struct WarpP {
+  const float* img;
+  const float* flow;
+  const float* lin_x;
+  const float* lin_y;
+  float* out;
+  int* taps;       // optional [B,H,W,2] (x_w, y_n) for the index-parity tests
+  int B, C, H, W;
+  long long isb, isc, isy, isx;
+  long long fsb, fsc, fsy, fsx;
+  long long osb, osc, osy, osx;
+};
+
+struct WarpCoord {
+  int x0, y0;
+  float wx, wy;      // fractional parts (weight of the east / south tap)
+  float mx, my;      // d(ix)/d(flow_x) in {0, 1}: 0 where the coordinate was clipped
+};
+
+__device__ __forceinline__ WarpCoord fsv_warp_coord(float fx, float fy, float linx, float liny, int W, int H) {
+  WarpCoord c;
+  const float hx = (float)(W - 1) / 2.0f, hy = (float)(H - 1) / 2.0f;
+  float gx = linx + fx / hx;                 // IEEE division, as on the CPU path of the reference
+  float gy = liny + fy / hy;
+  float ix = (gx + 1.0f) * hx;               // grid_sampler_unnormalize, align_corners=True
+  float iy = (gy + 1.0f) * hy;
+  const float maxx = (float)(W - 1), maxy = (float)(H - 1);
+  c.mx = (ix > 0.0f && ix < maxx) ? 1.0f : 0.0f;   // clip_coordinates_set_grad: borders count as clipped
+  c.my = (iy > 0.0f && iy < maxy) ? 1.0f : 0.0f;
+  ix = fminf(maxx, fmaxf(ix, 0.0f));
+  iy = fminf(maxy, fmaxf(iy, 0.0f));
+  float xw = floorf(ix), yn = floorf(iy);
+  c.x0 = (int)xw; c.y0 = (int)yn;
+  c.wx = ix - xw; c.wy = iy - yn;
+  return c;
+}
+
+__global__ __launch_bounds__(256) void fsv_warp_fwd_kernel(WarpP p) {
+  const long long total = (long long)p.B * p.H * p.W;
+  long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const int x = (int)(i % p.W);
+  const int y = (int)((i / p.W) % p.H);
+  const int b = (int)(i / ((long long)p.W * p.H));
+  const float* fl = p.flow + b * p.fsb + y * p.fsy + x * p.fsx;
+  WarpCoord c = fsv_warp_coord(fl[0], fl[p.fsc], p.lin_x[x], p.lin_y[y], p.W, p.H);
+  if (p.taps) { p.taps[i * 2] = c.x0; p.taps[i * 2 + 1] = c.y0; }
+  const float w = c.wx, e = 1.0f - c.wx, n = c.wy, s = 1.0f - c.wy;
+  const float wnw = s * e, wne = s * w, wsw = n * e, wse = n * w;
+  const bool xe_ok = (c.x0 + 1) < p.W, ys_ok = (c.y0 + 1) < p.H;
+  const float* base = p.img + b * p.isb + c.y0 * p.isy + c.x0 * p.isx;
+  float* o = p.out + b * p.osb + y * p.osy + x * p.osx;
+  for (int ch = 0; ch < p.C; ++ch) {
+    const float* q = base + ch * p.isc;
+    float vnw = q[0];
+    float vne = xe_ok ? q[p.isx] : 0.0f;
+    float vsw = ys_ok ? q[p.isy] : 0.0f;
+    float vse = (xe_ok && ys_ok) ? q[p.isy + p.isx] : 0.0f;
+    o[ch * p.osc] = vnw * wnw + vne * wne + vsw * wsw + vse * wse;
+  }
+}
+
+struct WarpBwdP {
+  const float* img;
+  const float* flow;
+  const float* lin_x;
+  const float* lin_y;
+  const float* gout;
+  float* gimg;       // zero-initialised by the caller; may be null
+  float* gflow;      // [B,2,H,W] with the flow strides; may be null
+  int B, C, H, W;
+  long long isb, isc, isy, isx;
+  long long fsb, fsc, fsy, fsx;
+  long long osb, osc, osy, osx;      // strides of gout
+  long long gsb, gsc, gsy, gsx;      // strides of gimg
+  long long hsb, hsc, hsy, hsx;      // strides of gflow
+};
+
+__global__ __launch_bounds__(256) void fsv_warp_bwd_kernel(WarpBwdP p) {
+  const long long total = (long long)p.B * p.H * p.W;
+  long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const int x = (int)(i % p.W);
+  const int y = (int)((i / p.W) % p.H);
+  const int b = (int)(i / ((long long)p.W * p.H));
+  const float* fl = p.flow + b * p.fsb + y * p.fsy + x * p.fsx;
+  WarpCoord c = fsv_warp_coord(fl[0], fl[p.fsc], p.lin_x[x], p.lin_y[y], p.W, p.H);
+  const float w = c.wx, e = 1.0f - c.wx, n = c.wy, s = 1.0f - c.wy;
+  const float wnw = s * e, wne = s * w, wsw = n * e, wse = n * w;
+  const bool xe_ok = (c.x0 + 1) < p.W, ys_ok = (c.y0 + 1) < p.H;
+  const float* base = p.img + b * p.isb + c.y0 * p.isy + c.x0 * p.isx;
+  float* gbase = p.gimg ? p.gimg + b * p.gsb + c.y0 * p.gsy + c.x0 * p.gsx : nullptr;
+  const float* go = p.gout + b * p.osb + y * p.osy + x * p.osx;
+  float gx = 0.0f, gy = 0.0f;
+  for (int ch = 0; ch < p.C; ++ch) {
+    const float g = go[ch * p.osc];
+    const float* q = base + ch * p.isc;
+    float vnw = q[0];
+    float vne = xe_ok ? q[p.isx] : 0.0f;
+    float vsw = ys_ok ? q[p.isy] : 0.0f;
+    float vse = (xe_ok && ys_ok) ? q[p.isy + p.isx] : 0.0f;
+    gx += g * ((vne - vnw) * s + (vse - vsw) * n);
+    gy += g * ((vsw - vnw) * e + (vse - vne) * w);
+    if (gbase) {
+      float* gq = gbase + ch * p.gsc;
+      atomicAdd(gq, g * wnw);
+      if (xe_ok) atomicAdd(gq + p.gsx, g * wne);
+      if (ys_ok) atomicAdd(gq + p.gsy, g * wsw);
+      if (xe_ok && ys_ok) atomicAdd(gq + p.gsy + p.gsx, g * wse);
+    }
+  }
+  if (p.gflow) {
+    float* gf = p.gflow + b * p.hsb + y * p.hsy + x * p.hsx;
+    gf[0] = gx * c.mx;          // d ix / d flow_x = ((W-1)/2) / ((W-1)/2) = 1 where not clipped
+    gf[p.hsc] = gy * c.my;
+  }
+}
+
+extern "C" {
+
+// strides are in elements, order (batch, channel, y, x)
+int fsv_warp_fwd(const float* img, const float* flow, const float* lin_x, const float* lin_y, float* out, int* taps,
+                 int B, int C, int H, int W, const long long* img_strides, const long long* flow_strides,
+                 const long long* out_strides, hipStream_t stream) {
+  if (!img || !flow || !lin_x || !lin_y || !out || B < 1 || C < 1 || H < 2 || W < 2) return FSV_ERR_BAD_ARG;
+  WarpP p;
+  p.img = img; p.flow = flow; p.lin_x = lin_x; p.lin_y = lin_y; p.out = out; p.taps = taps;
+  p.B = B; p.C = C; p.H = H; p.W = W;
+  p.isb = img_strides[0]; p.isc = img_strides[1]; p.isy = img_strides[2]; p.isx = img_strides[3];
+  p.fsb = flow_strides[0]; p.fsc = flow_strides[1]; p.fsy = flow_strides[2]; p.fsx = flow_strides[3];
+  p.osb = out_strides[0]; p.osc = out_strides[1]; p.osy = out_strides[2]; p.osx = out_strides[3];
+  long long total = (long long)B * H * W;
+  FSV_LAUNCH(fsv_warp_fwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), stream, p);
+  return fsv_check_launch();
+}
+
+int fsv_warp_bwd(const float* img, const float* flow, const float* lin_x, const float* lin_y, const float* gout,
+                 float* gimg, float* gflow, int B, int C, int H, int W, const long long* img_strides,
+                 const long long* flow_strides, const long long* gout_strides, const long long* gimg_strides,
+                 const long long* gflow_strides, hipStream_t stream) {
+  if (!img || !flow || !lin_x || !lin_y || !gout || B < 1 || C < 1 || H < 2 || W < 2) return FSV_ERR_BAD_ARG;
+  WarpBwdP p;
+  p.img = img; p.flow = flow; p.lin_x = lin_x; p.lin_y = lin_y; p.gout = gout; p.gimg = gimg; p.gflow = gflow;
+  p.B = B; p.C = C; p.H = H; p.W = W;
+  p.isb = img_strides[0]; p.isc = img_strides[1]; p.isy = img_strides[2]; p.isx = img_strides[3];
+  p.fsb = flow_strides[0]; p.fsc = flow_strides[1]; p.fsy = flow_strides[2]; p.fsx = flow_strides[3];
+  p.osb = gout_strides[0]; p.osc = gout_strides[1]; p.osy = gout_strides[2]; p.osx = gout_strides[3];
+  if (gimg) { p.gsb = gimg_strides[0]; p.gsc = gimg_strides[1]; p.gsy = gimg_strides[2]; p.gsx = gimg_strides[3]; }
+  else { p.gsb = p.gsc = p.gsy = p.gsx = 0; }
+  if (gflow) { p.hsb = gflow_strides[0]; p.hsc = gflow_strides[1]; p.hsy = gflow_strides[2]; p.hsx = gflow_strides[3]; }
+  else { p.hsb = p.hsc = p.hsy = p.hsx = 0; }
+  long long total = (long long)B * H * W;
+  FSV_LAUNCH(fsv_warp_bwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), stream, p);
+  return fsv_check_launch();
+}
+
+}  // extern "C"

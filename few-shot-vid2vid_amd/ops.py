@@ -1,0 +1,483 @@
+"""Differentiable operators of the G/D hot path, each a torch.autograd.Function over the HIP C-ABI kernels.
+
+Operator surface mirrored from the reference (file:line under /root/reference):
+  conv2d / linear / batch_conv ........ F.conv2d, nn.Linear, models/networks/base_network.py:56-71
+  spectral norm ........................ torch.nn.utils.spectral_norm at architecture.py:60,81-84; generator.py:106-109
+  norm_act ............................. BatchNorm2d / InstanceNorm2d(+LeakyReLU) normalization.py:33-35,78-82
+  spade_mod ............................ SPADE.forward normalization.py:37-52 (+ actvn architecture.py:15-17)
+  upsample2x ........................... F.interpolate(scale_factor=2) generator.py:124, nn.Upsample
+  resample ............................. models/networks/base_network.py:28-37
+All tensors are fp32, logical NCHW, channels-last memory.  No CPU fallback: lib.check_device refuses host
+tensors unless the emulated test library was requested explicitly.
+"""
+import ctypes
+
+import torch
+
+from . import lib
+from .conv import (ACT_LRELU, ACT_NONE, ACT_SIGMOID, ACT_TANH, Geom, conv_dgrad, conv_forward, conv_wgrad, empty_nhwc,
+                   prep_weight, to_nhwc)
+
+c_p, c_i, c_ll, c_f = ctypes.c_void_p, ctypes.c_int, ctypes.c_longlong, ctypes.c_float
+c_llp = ctypes.POINTER(ctypes.c_longlong)
+c_pp = ctypes.POINTER(ctypes.c_void_p)
+c_ip = ctypes.POINTER(ctypes.c_int)
+
+lib.register_sigs({
+    "fsv_warp_fwd": [c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_llp, c_llp, c_llp, c_p],
+    "fsv_warp_bwd": [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_llp, c_llp, c_llp, c_llp, c_llp, c_p],
+    "fsv_norm_stats": [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_f, c_p, c_p, c_f, c_p],
+    "fsv_norm_apply": [c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p],
+    "fsv_norm_bwd": [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p],
+    "fsv_colsum": [c_p, c_p, c_p, c_i, c_i, c_i, c_p],
+    "fsv_spade_mod_fwd": [c_p, c_p, c_p, c_p, c_i, c_pp, c_pp, c_pp, c_pp, c_pp, c_ip, c_llp, c_llp,
+                          c_i, c_i, c_i, c_i, c_ll, c_i, c_p],
+    "fsv_spade_bwd_elem": [c_p, c_p, c_p, c_p, c_p, c_i, c_pp, c_pp, c_p, c_i, c_i, c_i, c_ll, c_i, c_p],
+    "fsv_upsample2x_fwd": [c_p, c_p, c_i, c_i, c_i, c_i, c_p],
+    "fsv_upsample2x_bwd": [c_p, c_p, c_i, c_i, c_i, c_i, c_p],
+    "fsv_act_fwd": [c_p, c_p, c_ll, c_i, c_p],
+    "fsv_act_bwd": [c_p, c_p, c_p, c_ll, c_i, c_f, c_p],
+    "fsv_adam_step": [c_p, c_p, c_p, c_p, c_p, c_ll, c_f, c_f, c_f, c_f, c_p],
+    "fsv_sn_power_iter": [c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_f, c_i, c_p],
+    "fsv_sn_backward": [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_p],
+})
+
+RED_ROWS = 2048
+
+
+def _ws(g, p, c, like):
+    n = g * ((p + RED_ROWS - 1) // RED_ROWS) * c * 2
+    return torch.empty(max(n, 2), dtype=torch.float64, device=like.device)
+
+
+def _ll(vals):
+    return (ctypes.c_longlong * len(vals))(*[int(v) for v in vals])
+
+
+def _pp(tensors):
+    return (ctypes.c_void_p * max(len(tensors), 1))(*[t.data_ptr() for t in tensors])
+
+
+# ------------------------------------------------------------------------------------------------ activations
+def act_backward(dy, y, act, scale=1.0):
+    if act == ACT_NONE and scale == 1.0:
+        return dy
+    dy = to_nhwc(dy) if dy.dim() == 4 else dy.contiguous()
+    dx = torch.empty_like(y)
+    lib.check_device(dy, y)
+    lib.call("fsv_act_bwd", lib.ptr(dy), lib.ptr(y), lib.ptr(dx), y.numel(), act, float(scale), lib.stream_ptr())
+    return dx
+
+
+class _ActFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, act):
+        x = to_nhwc(x) if x.dim() == 4 else x.contiguous()
+        y = torch.empty_like(x)
+        lib.check_device(x)
+        lib.call("fsv_act_fwd", lib.ptr(x), lib.ptr(y), x.numel(), act, lib.stream_ptr())
+        ctx.act = act
+        ctx.save_for_backward(y)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (y,) = ctx.saved_tensors
+        return act_backward(dy, y, ctx.act), None
+
+
+def activation(x, act=ACT_LRELU):
+    return _ActFn.apply(x, act)
+
+
+# ------------------------------------------------------------------------------------------------ column sums
+def colsum(x2d_nhwc, groups, pixels, channels):
+    """x viewed as [groups][pixels][channels] -> [groups, channels]."""
+    out = torch.empty((groups, channels), dtype=torch.float32, device=x2d_nhwc.device)
+    lib.check_device(x2d_nhwc)
+    ws = _ws(groups, pixels, channels, x2d_nhwc)     # must outlive the call (host allocator frees eagerly)
+    lib.call("fsv_colsum", lib.ptr(x2d_nhwc), lib.ptr(ws), lib.ptr(out), groups, pixels, channels, lib.stream_ptr())
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ spectral norm
+class SpectralState:
+    """sigma bookkeeping for one weight: persistent u / v buffers live in the owning module."""
+
+    @staticmethod
+    def update(weight, u, v, training, eps=1e-12):
+        """One power iteration (training) or sigma = u.(Wv) (eval).  Returns sig = [sigma, 1/sigma] (device)."""
+        rows = weight.shape[0]
+        cols = weight.numel() // rows
+        w = weight.detach()
+        if not w.is_contiguous():
+            w = w.contiguous()
+        scratch = torch.empty(rows + cols, dtype=torch.float32, device=w.device)
+        sig = torch.empty(2, dtype=torch.float32, device=w.device)
+        lib.check_device(w, u, v)
+        lib.call("fsv_sn_power_iter", lib.ptr(w), lib.ptr(u), lib.ptr(v), lib.ptr(scratch), lib.ptr(sig), rows, cols,
+                 float(eps), 1 if training else 0, lib.stream_ptr())
+        return sig
+
+
+def sn_backward(dwsn, weight, u, v, sig):
+    rows = weight.shape[0]
+    cols = weight.numel() // rows
+    dwsn = dwsn.contiguous()
+    w = weight.detach().contiguous()
+    part = torch.empty(256, dtype=torch.float64, device=w.device)
+    dw = torch.empty_like(w)
+    lib.call("fsv_sn_backward", lib.ptr(dwsn), lib.ptr(w), lib.ptr(u), lib.ptr(v), lib.ptr(sig), lib.ptr(part),
+             lib.ptr(dw), rows, cols, lib.stream_ptr())
+    return dw
+
+
+# ------------------------------------------------------------------------------------------------ convolution
+class _ConvFn(torch.autograd.Function):
+    """y = act((conv(x, W * inv_sigma) + bias) * scale) + res.  W: OIHW, or [B]OIHW for per-sample weights."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, res, sig, u, v, geom, act, scale):
+        x = to_nhwc(x)
+        per_sample = weight.dim() == 5
+        cout = weight.shape[-4]
+        inv = sig[1:2] if sig is not None else None
+        wt, _, ldw = prep_weight(weight.detach(), 0, geom, scale=inv)
+        b = bias.detach().contiguous() if bias is not None else None
+        if res is not None and act != ACT_NONE:
+            raise ValueError("residual add is only fused after a linear epilogue")
+        if scale != 1.0 and act != ACT_NONE:
+            raise ValueError("output scale is only fused with a linear epilogue")
+        y = conv_forward(x, wt, ldw, cout, geom, bias=b, res=res.detach() if res is not None else None, act=act,
+                         scale=scale, per_sample=per_sample)
+        ctx.geom, ctx.act, ctx.scale, ctx.per_sample = geom, act, scale, per_sample
+        ctx.has_bias, ctx.has_res, ctx.has_sn = bias is not None, res is not None, sig is not None
+        ctx.x_shape = tuple(x.shape)
+        if ctx.has_sn:
+            ctx.save_for_backward(x, weight, y, sig, u.clone(), v.clone())
+        else:
+            ctx.save_for_backward(x, weight, y)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        if ctx.has_sn:
+            x, weight, y, sig, u, v = ctx.saved_tensors
+        else:
+            x, weight, y = ctx.saved_tensors
+            sig = u = v = None
+        dy = to_nhwc(dy)
+        geom = ctx.geom
+        n, cin, h, w = ctx.x_shape
+        dpre = act_backward(dy, y, ctx.act, ctx.scale) if (ctx.act != ACT_NONE or ctx.scale != 1.0) else dy
+        inv = sig[1:2] if sig is not None else None
+        dx = dw = db = dres = None
+        if ctx.needs_input_grad[0]:
+            dx = conv_dgrad(dpre, weight.detach(), geom, (h, w), scale=inv, per_sample=ctx.per_sample)
+        if ctx.needs_input_grad[1]:
+            dwsn = conv_wgrad(x, dpre, geom, tuple(weight.shape), per_sample=ctx.per_sample)
+            dw = sn_backward(dwsn, weight, u, v, sig).view_as(weight) if ctx.has_sn else dwsn
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            cout = dpre.shape[1]
+            hw = dpre.shape[2] * dpre.shape[3]
+            if ctx.per_sample:
+                db = colsum(dpre, n, hw, cout)
+            else:
+                db = colsum(dpre, 1, n * hw, cout).view(cout)
+        if ctx.has_res and ctx.needs_input_grad[3]:
+            dres = dy
+        return dx, dw, db, dres, None, None, None, None, None, None
+
+
+def conv2d(x, weight, bias=None, stride=1, padding=0, act=ACT_NONE, scale=1.0, res=None, sn=None):
+    """sn: None or (sig, u, v) from SpectralState.update for this call."""
+    kh, kw = weight.shape[-2:]
+    geom = Geom(kh, kw, stride, padding)
+    sig, u, v = sn if sn is not None else (None, None, None)
+    return _ConvFn.apply(x, weight, bias, res, sig, u, v, geom, act, scale)
+
+
+def linear(x2d, weight, bias=None, act=ACT_NONE, sn=None):
+    """y[R, out] = act(x2d[R, in] @ weight[out, in]^T + bias) on the same gather-GEMM kernel (1x1, H=1, W=R)."""
+    r, cin = x2d.shape
+    x4 = x2d.contiguous().view(1, 1, r, cin).permute(0, 3, 1, 2)
+    y4 = conv2d(x4, weight.view(weight.shape[0], cin, 1, 1), bias, act=act, sn=sn)
+    return y4.permute(0, 2, 3, 1).reshape(r, weight.shape[0])
+
+
+def batch_conv(x, weight, bias=None, act=ACT_NONE):
+    """Per-sample 1x1 (or kxk) convolution with generated weights [B, Cout, Cin, k, k] (base_network.py:56-71)."""
+    if weight is None:
+        return x
+    k = weight.shape[-1]
+    geom = Geom(k, k, 1, k // 2)
+    b = bias.contiguous() if bias is not None else None
+    return _ConvFn.apply(x, weight.contiguous(), b, None, None, None, None, geom, act, 1.0)
+
+
+# ------------------------------------------------------------------------------------------------ normalisation
+def norm_stats(x, groups, pixels, channels, eps, run_mean=None, run_var=None, momentum=0.1):
+    mean = torch.empty(groups * channels, dtype=torch.float32, device=x.device)
+    rstd = torch.empty_like(mean)
+    lib.check_device(x, run_mean, run_var)
+    ws = _ws(groups, pixels, channels, x)
+    lib.call("fsv_norm_stats", lib.ptr(x), lib.ptr(ws), lib.ptr(mean), lib.ptr(rstd),
+             groups, pixels, channels, float(eps), lib.ptr(run_mean), lib.ptr(run_var), float(momentum),
+             lib.stream_ptr())
+    return mean, rstd
+
+
+class _NormActFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, run_mean, run_var, instance, eps, momentum, act, training):
+        x = to_nhwc(x)
+        n, c, h, w = x.shape
+        g, p = (n, h * w) if instance else (1, n * h * w)
+        if training or instance or run_mean is None:
+            mean, rstd = norm_stats(x, g, p, c, eps, None if instance else run_mean, None if instance else run_var,
+                                    momentum)
+        else:
+            mean = run_mean.detach().clone()
+            rstd = torch.rsqrt(run_var.detach() + eps)
+        y = torch.empty_like(x)
+        wd = weight.detach().contiguous() if weight is not None else None
+        bd = bias.detach().contiguous() if bias is not None else None
+        lib.call("fsv_norm_apply", lib.ptr(x), lib.ptr(mean), lib.ptr(rstd), lib.ptr(wd), lib.ptr(bd), lib.ptr(y), g, p,
+                 c, act, lib.stream_ptr())
+        ctx.dims = (g, p, c)
+        ctx.act, ctx.affine = act, weight is not None
+        ctx.batch_stats = bool(training or instance or run_mean is None)
+        ctx.save_for_backward(x, y, mean, rstd, wd if wd is not None else mean)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, y, mean, rstd, wd = ctx.saved_tensors
+        g, p, c = ctx.dims
+        dy = to_nhwc(dy)
+        if not ctx.batch_stats:
+            raise NotImplementedError("eval-mode normalisation backward is not on the training hot path")
+        dx = torch.empty_like(x)
+        s1 = torch.empty(g * c, dtype=torch.float32, device=x.device)
+        s2 = torch.empty_like(s1)
+        dw = torch.empty(c, dtype=torch.float32, device=x.device) if ctx.affine else None
+        db = torch.empty_like(dw) if ctx.affine else None
+        ws = _ws(g, p, c, x)
+        lib.call("fsv_norm_bwd", lib.ptr(dy), lib.ptr(y), lib.ptr(x), lib.ptr(mean), lib.ptr(rstd),
+                 lib.ptr(wd) if ctx.affine else None, lib.ptr(ws), lib.ptr(s1), lib.ptr(s2), lib.ptr(dx),
+                 lib.ptr(dw), lib.ptr(db), g, p, c, ctx.act, lib.stream_ptr())
+        return dx, dw, db, None, None, None, None, None, None, None
+
+
+def norm_act(x, weight=None, bias=None, run_mean=None, run_var=None, instance=False, eps=1e-5, momentum=0.1,
+             act=ACT_NONE, training=True):
+    return _NormActFn.apply(x, weight, bias, run_mean, run_var, instance, eps, momentum, act, training)
+
+
+# ------------------------------------------------------------------------------------------------ SPADE
+class _SpadeFn(torch.autograd.Function):
+    """h = act(spade(x; maps, weights)).  Argument list: x, run_mean, run_var, then per map (map, wg, wb, bg, bb).
+
+    wg/wb are OIHW 1x1 weights: [C, Ch, 1, 1] (fixed) or [B, C, Ch, 1, 1] (generated per sample).
+    """
+
+    @staticmethod
+    def forward(ctx, act, training, eps, momentum, x, run_mean, run_var, *rest):
+        x = to_nhwc(x)
+        n, c, h, w = x.shape
+        nmaps = len(rest) // 5
+        maps = [to_nhwc(rest[5 * k]) for k in range(nmaps)]
+        wgs = [rest[5 * k + 1] for k in range(nmaps)]
+        wbs = [rest[5 * k + 2] for k in range(nmaps)]
+        bgs = [rest[5 * k + 3] for k in range(nmaps)]
+        bbs = [rest[5 * k + 4] for k in range(nmaps)]
+        if training or run_mean is None:
+            mean, rstd = norm_stats(x, 1, n * h * w, c, eps, run_mean, run_var, momentum)
+        else:
+            mean = run_mean.detach().clone()
+            rstd = torch.rsqrt(run_var.detach() + eps)
+        g1 = Geom(1, 1, 1, 0)
+        wg_t, wb_t, bg_c, bb_c, chs, wbs_stride, bbs_stride = [], [], [], [], [], [], []
+        ldw = (c + 31) // 32 * 32
+        for k in range(nmaps):
+            if maps[k].shape[2:] != x.shape[2:]:
+                raise ValueError("SPADE maps must already be at the resolution of x")
+            per_sample = wgs[k].dim() == 5
+            tg, kpad, _ = prep_weight(wgs[k].detach(), 0, g1)
+            tb, _, _ = prep_weight(wbs[k].detach(), 0, g1)
+            wg_t.append(tg); wb_t.append(tb)
+            bg_c.append(bgs[k].detach().contiguous()); bb_c.append(bbs[k].detach().contiguous())
+            chs.append(maps[k].shape[1])
+            wbs_stride.append(kpad * ldw if per_sample else 0)
+            bbs_stride.append(c if per_sample else 0)
+        hout = torch.empty_like(x)
+        lib.check_device(x, *maps)
+        lib.call("fsv_spade_mod_fwd", lib.ptr(x), lib.ptr(mean), lib.ptr(rstd), lib.ptr(hout), nmaps, _pp(maps),
+                 _pp(wg_t), _pp(wb_t), _pp(bg_c), _pp(bb_c), lib.int_array(chs + [0]), _ll(wbs_stride + [0]),
+                 _ll(bbs_stride + [0]), n, h * w, c, ldw, 0, act, lib.stream_ptr())
+        ctx.nmaps, ctx.act = nmaps, act
+        ctx.batch_stats = bool(training or run_mean is None)
+        ctx.save_for_backward(x, hout, mean, rstd, *maps, *wgs, *wbs, *bgs, *bbs)
+        return hout
+
+    @staticmethod
+    def backward(ctx, dh):
+        nm = ctx.nmaps
+        saved = ctx.saved_tensors
+        x, hout, mean, rstd = saved[:4]
+        maps = saved[4:4 + nm]
+        wgs = saved[4 + nm:4 + 2 * nm]
+        wbs = saved[4 + 2 * nm:4 + 3 * nm]
+        bgs = saved[4 + 3 * nm:4 + 4 * nm]
+        bbs = saved[4 + 4 * nm:4 + 5 * nm]
+        dh = to_nhwc(dh)
+        n, c, h, w = x.shape
+        g1 = Geom(1, 1, 1, 0)
+        # 1) recompute gamma|beta of every map with the gather-GEMM kernel ([P][2C] each)
+        gbs, wcats = [], []
+        for k in range(nm):
+            per_sample = wgs[k].dim() == 5
+            wcat = torch.cat([wgs[k].detach(), wbs[k].detach()], dim=-4)
+            bcat = torch.cat([bgs[k].detach(), bbs[k].detach()], dim=-1).contiguous()
+            wt, _, ldw = prep_weight(wcat, 0, g1)
+            gbs.append(conv_forward(maps[k], wt, ldw, 2 * c, g1, bias=bcat, per_sample=per_sample))
+            wcats.append(wcat)
+        # 2) elementwise chain backward
+        dgbs = [torch.empty_like(gb) for gb in gbs]
+        dxhat = torch.empty_like(x)
+        lib.call("fsv_spade_bwd_elem", lib.ptr(x), lib.ptr(mean), lib.ptr(rstd), lib.ptr(dh), lib.ptr(hout), nm,
+                 _pp(gbs), _pp(dgbs), lib.ptr(dxhat), n, h * w, c, 0, ctx.act, lib.stream_ptr())
+        # 3) param-free BatchNorm backward
+        dx = None
+        if ctx.needs_input_grad[4]:
+            if ctx.batch_stats:
+                dx = torch.empty_like(x)
+                s1 = torch.empty(c, dtype=torch.float32, device=x.device)
+                s2 = torch.empty_like(s1)
+                ws = _ws(1, n * h * w, c, x)
+                lib.call("fsv_norm_bwd", lib.ptr(dxhat), None, lib.ptr(x), lib.ptr(mean), lib.ptr(rstd), None,
+                         lib.ptr(ws), lib.ptr(s1), lib.ptr(s2), lib.ptr(dx), None, None,
+                         1, n * h * w, c, ACT_NONE, lib.stream_ptr())
+            else:
+                dx = dxhat * rstd.view(1, c, 1, 1)
+        grads = []
+        for k in range(nm):
+            per_sample = wgs[k].dim() == 5
+            base = 7 + 5 * k
+            dm = dwg = dwb = dbg = dbb = None
+            if ctx.needs_input_grad[base]:
+                dm = conv_dgrad(dgbs[k], wcats[k], g1, (h, w), per_sample=per_sample)
+            if ctx.needs_input_grad[base + 1] or ctx.needs_input_grad[base + 2]:
+                dwcat = conv_wgrad(maps[k], dgbs[k], g1, tuple(wcats[k].shape), per_sample=per_sample)
+                dwg, dwb = torch.split(dwcat, c, dim=-4)
+            if ctx.needs_input_grad[base + 3] or ctx.needs_input_grad[base + 4]:
+                if per_sample:
+                    dbcat = colsum(dgbs[k], n, h * w, 2 * c)
+                else:
+                    dbcat = colsum(dgbs[k], 1, n * h * w, 2 * c).view(2 * c)
+                dbg, dbb = torch.split(dbcat, c, dim=-1)
+            grads += [dm, dwg, dwb, dbg, dbb]
+        return (None, None, None, None, dx, None, None, *grads)
+
+
+def spade_mod(x, maps, weights, run_mean=None, run_var=None, act=ACT_LRELU, training=True, eps=1e-5, momentum=0.1):
+    """maps: list of tensors; weights: list of (wg, wb, bg, bb) per map (see _SpadeFn)."""
+    flat = []
+    for m, (wg, wb, bg, bb) in zip(maps, weights):
+        flat += [m, wg, wb, bg, bb]
+    return _SpadeFn.apply(act, training, eps, momentum, x, run_mean, run_var, *flat)
+
+
+# ------------------------------------------------------------------------------------------------ upsample
+class _Up2xFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        x = to_nhwc(x)
+        n, c, h, w = x.shape
+        y = empty_nhwc(n, c, 2 * h, 2 * w, x)
+        lib.check_device(x)
+        lib.call("fsv_upsample2x_fwd", lib.ptr(x), lib.ptr(y), n, h, w, c, lib.stream_ptr())
+        ctx.dims = (n, c, h, w)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        n, c, h, w = ctx.dims
+        dy = to_nhwc(dy)
+        dx = empty_nhwc(n, c, h, w, dy)
+        lib.call("fsv_upsample2x_bwd", lib.ptr(dy), lib.ptr(dx), n, h, w, c, lib.stream_ptr())
+        return dx
+
+
+def upsample2x(x):
+    return _Up2xFn.apply(x)
+
+
+# ------------------------------------------------------------------------------------------------ flow warp
+_lin_cache = {}
+
+
+def _linspace(n, device):
+    key = (n, str(device))
+    t = _lin_cache.get(key)
+    if t is None:
+        # built on the host exactly like the reference's get_grid (base_network.py:13-26), then uploaded
+        t = torch.linspace(-1.0, 1.0, n).to(device)
+        _lin_cache[key] = t
+    return t
+
+
+def warp_taps(image, flow):
+    """Forward warp that also returns the integer tap indices (x_w, y_n) - used by the index-parity tests."""
+    b, c, h, w = image.shape
+    out = torch.empty((b, c, h, w), dtype=torch.float32, device=image.device)
+    taps = torch.empty((b, h, w, 2), dtype=torch.int32, device=image.device)
+    lib.check_device(image, flow)
+    lib.call("fsv_warp_fwd", lib.ptr(image), lib.ptr(flow), lib.ptr(_linspace(w, image.device)),
+             lib.ptr(_linspace(h, image.device)), lib.ptr(out), lib.ptr(taps), b, c, h, w, _ll(image.stride()),
+             _ll(flow.stride()), _ll(out.stride()), lib.stream_ptr())
+    return out, taps
+
+
+class _WarpFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, image, flow):
+        b, c, h, w = image.shape
+        if flow.shape != (b, 2, h, w):
+            raise ValueError("flow must be [B, 2, H, W]")
+        image = image if image.stride(-1) in (1, c) else image.contiguous()
+        out = torch.empty((b, c, h, w), dtype=torch.float32, device=image.device)
+        lib.check_device(image, flow)
+        lib.call("fsv_warp_fwd", lib.ptr(image), lib.ptr(flow), lib.ptr(_linspace(w, image.device)),
+                 lib.ptr(_linspace(h, image.device)), lib.ptr(out), None, b, c, h, w, _ll(image.stride()),
+                 _ll(flow.stride()), _ll(out.stride()), lib.stream_ptr())
+        ctx.save_for_backward(image, flow)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        image, flow = ctx.saved_tensors
+        b, c, h, w = image.shape
+        gout = gout.contiguous()
+        gimg = torch.zeros((b, c, h, w), dtype=torch.float32, device=image.device) if ctx.needs_input_grad[0] else None
+        gflow = torch.empty((b, 2, h, w), dtype=torch.float32, device=image.device) if ctx.needs_input_grad[1] else None
+        z4 = _ll([0, 0, 0, 0])
+        lib.call("fsv_warp_bwd", lib.ptr(image), lib.ptr(flow), lib.ptr(_linspace(w, image.device)),
+                 lib.ptr(_linspace(h, image.device)), lib.ptr(gout), lib.ptr(gimg), lib.ptr(gflow), b, c, h, w,
+                 _ll(image.stride()), _ll(flow.stride()), _ll(gout.stride()),
+                 _ll(gimg.stride()) if gimg is not None else z4, _ll(gflow.stride()) if gflow is not None else z4,
+                 lib.stream_ptr())
+        return gimg, gflow
+
+
+def resample(image, flow):
+    """Drop-in for models.networks.base_network.resample (file:28-37)."""
+    return _WarpFn.apply(image, flow)
+
+
+# ------------------------------------------------------------------------------------------------ Adam
+def adam_step(param, grad, m, v, state, beta1, beta2, eps, gscale=1.0):
+    """Fused Adam on flat buffers; state = [t, 1-b1^t, 1-b2^t, lr] (device, fp32)."""
+    lib.check_device(param, grad, m, v, state)
+    lib.call("fsv_adam_step", lib.ptr(param), lib.ptr(grad), lib.ptr(m), lib.ptr(v), lib.ptr(state), param.numel(),
+             float(beta1), float(beta2), float(eps), float(gscale), lib.stream_ptr())

@@ -141,7 +141,7 @@ inline void wave_collective(F&& eval) {
 inline void run_block(const std::function<void()>& body) {
   State& s = S();
   int nthr = (int)(s.block.x * s.block.y * s.block.z);
-  const size_t STK = 96 * 1024;
+  const size_t STK = 256 * 1024;
   s.fibers.assign(nthr, Fiber());
   s.waves.assign((nthr + 63) / 64, WaveSlot());
   s.live = nthr; s.bar_arrived = 0; s.bar_gen = 0; s.body = body;

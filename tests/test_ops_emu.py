@@ -1,0 +1,64 @@
+"""CPU logic tests: the HIP kernel sources executed by the SIMT emulator, compared with the CPU oracle.
+
+These do not replace the `gpu` parity tests (tests/test_ops_gpu.py) - they make sure indexing, tiling, bounds
+and the maths of every kernel are right before a GPU minute is spent.
+"""
+import pytest
+import torch
+
+import op_checks as oc
+
+DEV = torch.device("cpu")
+
+
+@pytest.mark.parametrize("cfg", [
+    (1, 8, 8, 8, 8, 3, 1, 1, 'lrelu', True),
+    (2, 4, 9, 7, 5, 3, 2, 1, 'none', True),
+    (1, 6, 10, 10, 12, 3, 1, 1, 'tanh', True),       # Cin % 4 != 0 -> scalar gather path
+    (1, 20, 9, 9, 32, 4, 2, 2, 'lrelu', True),        # PatchGAN first layer geometry (k4 s2 p2)
+    (1, 8, 7, 7, 16, 4, 1, 2, 'sigmoid', False),      # PatchGAN last layers (k4 s1 p2)
+    (1, 64, 6, 6, 130, 1, 1, 0, 'lrelu', True),       # 1x1, Cout not a multiple of 32
+])
+def test_conv(emu_lib, cfg):
+    n, cin, h, w, cout, k, s, p, act, bias = cfg
+    oc.check_conv(DEV, n, cin, h, w, cout, k, s, p, act=act, bias=bias)
+
+
+def test_conv_spectral_residual(emu_lib):
+    oc.check_conv_sn_res(DEV)
+
+
+def test_linear(emu_lib):
+    oc.check_linear(DEV)
+
+
+def test_batch_conv(emu_lib):
+    oc.check_batch_conv(DEV)
+
+
+@pytest.mark.parametrize("instance,affine,act", [(False, True, 'lrelu'), (True, True, 'lrelu'), (False, False, 'none')])
+def test_norm(emu_lib, instance, affine, act):
+    oc.check_norm(DEV, instance=instance, affine=affine, act=act)
+
+
+@pytest.mark.parametrize("nmaps,generated,act,c,ch", [(1, True, 'lrelu', 12, 8), (3, True, 'none', 12, 8),
+                                                      (2, False, 'lrelu', 40, 12)])
+def test_spade(emu_lib, nmaps, generated, act, c, ch):
+    oc.check_spade(DEV, nmaps=nmaps, generated=generated, act=act, c=c, ch=ch)
+
+
+def test_upsample(emu_lib):
+    oc.check_upsample(DEV)
+
+
+def test_warp_values_grads_and_taps(emu_lib):
+    oc.check_warp(DEV)
+    oc.check_warp(DEV, zero_flow=True)
+
+
+def test_warp_tap_indices_bit_exact(emu_lib):
+    oc.check_warp_index_image(DEV)
+
+
+def test_adam(emu_lib):
+    oc.check_adam(DEV, n=300)

@@ -1,0 +1,92 @@
+"""Operator parity on a real MI355X: HIP kernels (through the C ABI) vs the CPU oracle on identical inputs."""
+import pytest
+import torch
+
+import op_checks as oc
+
+pytestmark = pytest.mark.gpu
+
+
+def dev():
+    return torch.device("cuda:0")
+
+
+@pytest.mark.parametrize("cfg", [
+    (1, 8, 8, 8, 8, 3, 1, 1, 'lrelu', True),
+    (2, 4, 9, 7, 5, 3, 2, 1, 'none', True),
+    (1, 6, 10, 10, 12, 3, 1, 1, 'tanh', True),
+    (1, 20, 9, 9, 32, 4, 2, 2, 'lrelu', True),
+    (1, 8, 7, 7, 16, 4, 1, 2, 'sigmoid', False),
+    (1, 64, 6, 6, 130, 1, 1, 0, 'lrelu', True),
+    (2, 64, 64, 64, 32, 3, 1, 1, 'lrelu', True),      # up_0 conv_0 shape at reduced resolution
+    (2, 128, 32, 32, 256, 3, 2, 1, 'none', True),     # stride-2 encoder conv
+    (2, 512, 8, 8, 512, 3, 1, 1, 'none', True),       # split-K regime (few tiles, long K)
+    (2, 20, 65, 65, 32, 4, 2, 2, 'lrelu', True),      # PatchGAN odd geometry
+    (1, 15, 40, 24, 32, 3, 1, 1, 'lrelu', True),      # FlowGenerator first conv (15 input channels)
+])
+def test_conv(hip_lib, cfg):
+    n, cin, h, w, cout, k, s, p, act, bias = cfg
+    oc.check_conv(dev(), n, cin, h, w, cout, k, s, p, act=act, bias=bias)
+
+
+def test_conv_spectral_residual(hip_lib):
+    oc.check_conv_sn_res(dev())
+
+
+def test_linear(hip_lib):
+    oc.check_linear(dev())
+    oc.check_linear(dev(), r=2048, cin=256, cout=514)
+
+
+def test_batch_conv(hip_lib):
+    oc.check_batch_conv(dev())
+    oc.check_batch_conv(dev(), b=2, cin=64, cout=32, h=32, w=32)
+
+
+@pytest.mark.parametrize("instance,affine,act", [(False, True, 'lrelu'), (True, True, 'lrelu'), (False, False, 'none')])
+def test_norm(hip_lib, instance, affine, act):
+    oc.check_norm(dev(), instance=instance, affine=affine, act=act)
+    oc.check_norm(dev(), instance=instance, affine=affine, act=act, n=2, c=64, h=65, w=33)
+
+
+@pytest.mark.parametrize("nmaps,generated,act,c,ch", [(1, True, 'lrelu', 12, 8), (3, True, 'none', 12, 8),
+                                                      (2, False, 'lrelu', 40, 12), (3, True, 'lrelu', 64, 32)])
+def test_spade(hip_lib, nmaps, generated, act, c, ch):
+    oc.check_spade(dev(), nmaps=nmaps, generated=generated, act=act, c=c, ch=ch)
+    if c == 64:
+        oc.check_spade(dev(), nmaps=nmaps, generated=generated, act=act, c=c, ch=ch, h=32, w=48)
+
+
+def test_upsample(hip_lib):
+    oc.check_upsample(dev())
+    oc.check_upsample(dev(), n=2, c=64, h=16, w=16)
+
+
+def test_warp_values_grads_and_taps(hip_lib):
+    oc.check_warp(dev())
+    oc.check_warp(dev(), zero_flow=True)
+    oc.check_warp(dev(), b=2, c=3, h=128, w=128, mag=30.0)
+
+
+def test_warp_tap_indices_bit_exact(hip_lib):
+    oc.check_warp_index_image(dev())
+    oc.check_warp_index_image(dev(), h=64, w=1024)
+    oc.check_warp_index_image(dev(), h=35, w=128)
+
+
+def test_warp_full_size_zero_flow_round_trip(hip_lib):
+    """BASELINE size (512x512): the fp32 grid round trip at zero flow must reproduce ATen's taps exactly."""
+    import op_checks
+    ops, _ = op_checks.pkg()
+    h = w = 512
+    flow = torch.zeros(1, 2, h, w)
+    _, taps = ops.warp_taps(torch.zeros(1, 1, h, w, device=dev()), flow.to(dev()))
+    ref = op_checks.O.resample_taps(flow)
+    assert torch.equal(taps.cpu(), ref)
+    # 76 of 512 columns land on x-1 at zero flow
+    xs = torch.arange(w, dtype=torch.int32)
+    assert int((ref[0, 0, :, 0] != xs).sum()) > 0
+
+
+def test_adam(hip_lib):
+    oc.check_adam(dev(), n=100003)
