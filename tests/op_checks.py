@@ -262,7 +262,7 @@ def check_warp_index_image(device, h=32, w=512, seed=8):
     g = torch.Generator().manual_seed(seed)
     flow = (torch.rand(1, 2, h, w, generator=g) - 0.5) * 40.0
     flow[:, :, : h // 4] = 0.0                      # zero-flow rows: the fp32 round trip must be reproduced
-    flow[:, :, h // 4: h // 2] = torch.randint(-5, 6, (1, 2, h // 4, w), generator=g).float()
+    flow[:, :, h // 4: h // 2] = torch.randint(-5, 6, (1, 2, h // 2 - h // 4, w), generator=g).float()
     _, taps = ops.warp_taps(_dev(torch.zeros(1, 1, h, w), device), _dev(flow, device))
     taps = taps.cpu()
     # ATen evidence: gradient of grid_sample w.r.t. the image scatters onto exactly the taps it selected
