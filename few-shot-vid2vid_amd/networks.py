@@ -1,0 +1,580 @@
+"""Generator / discriminator networks of the few-shot-vid2vid hot path on the HIP operators in ops.py.
+
+Same operator surface and - deliberately - the same ``state_dict`` key layout as the reference's
+``models.networks`` (generator.py, architecture.py, normalization.py, discriminator.py), so that reference
+checkpoints load unchanged and these classes can be patched into the reference's train.py loop
+(see INTEGRATION.md).  The bodies are new: every convolution, normalisation, SPADE modulation, up-sampling and
+warp goes through the gfx950 kernels, activations stay channels-last between layers, and element-wise chains
+of the reference are folded into kernel epilogues (bias+LeakyReLU, tanh, sigmoid, flow scale, residual add,
+BN+LeakyReLU, SPADE denorm+modulate+LeakyReLU).
+"""
+import math
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import ops
+from .conv import ACT_LRELU, ACT_NONE, ACT_SIGMOID, ACT_TANH
+
+
+# ------------------------------------------------------------------------------------------------ parameter holders
+class _SpectralMixin:
+    def _init_spectral(self, weight):
+        rows = weight.shape[0]
+        cols = weight.numel() // rows
+        self.weight_orig = nn.Parameter(weight)
+        self.register_buffer('weight_u', F.normalize(torch.randn(rows), dim=0, eps=1e-12))
+        self.register_buffer('weight_v', F.normalize(torch.randn(cols), dim=0, eps=1e-12))
+
+    def _sn(self):
+        sig = ops.SpectralState.update(self.weight_orig, self.weight_u, self.weight_v, self.training)
+        return (sig, self.weight_u, self.weight_v)
+
+
+class Conv2d(nn.Module, _SpectralMixin):
+    """nn.Conv2d (+ optional torch.nn.utils.spectral_norm) with a fused epilogue."""
+
+    def __init__(self, cin, cout, k, stride=1, padding=0, bias=True, spectral=False):
+        super().__init__()
+        self.stride, self.padding, self.spectral = stride, padding, spectral
+        w = torch.empty(cout, cin, k, k)
+        if spectral:
+            nn.init.kaiming_uniform_(w, a=math.sqrt(5))       # what survives the reference's init
+            self._init_spectral(w)
+        else:
+            nn.init.xavier_normal_(w, gain=0.02)              # init_type 'xavier', init_variance 0.02
+            self.weight = nn.Parameter(w)
+        self.bias = nn.Parameter(torch.zeros(cout)) if bias else None
+
+    def forward(self, x, act=ACT_NONE, res=None, scale=1.0):
+        if self.spectral:
+            return ops.conv2d(x, self.weight_orig, self.bias, self.stride, self.padding, act, scale, res, self._sn())
+        return ops.conv2d(x, self.weight, self.bias, self.stride, self.padding, act, scale, res, None)
+
+
+class Linear(nn.Module, _SpectralMixin):
+    def __init__(self, cin, cout, spectral=True):
+        super().__init__()
+        w = torch.empty(cout, cin)
+        nn.init.kaiming_uniform_(w, a=math.sqrt(5))
+        self.spectral = spectral
+        if spectral:
+            self._init_spectral(w)
+        else:
+            self.weight = nn.Parameter(w)
+        self.bias = nn.Parameter(torch.zeros(cout))
+
+    def forward(self, x, act=ACT_NONE):
+        if self.spectral:
+            return ops.linear(x, self.weight_orig, self.bias, act, self._sn())
+        return ops.linear(x, self.weight, self.bias, act, None)
+
+
+class BatchNorm(nn.Module):
+    """Train-mode BatchNorm2d statistics holder (apex SyncBatchNorm in one process)."""
+
+    def __init__(self, c, affine=True):
+        super().__init__()
+        self.affine = affine
+        if affine:
+            self.weight = nn.Parameter(torch.ones(c))
+            self.bias = nn.Parameter(torch.zeros(c))
+        self.register_buffer('running_mean', torch.zeros(c))
+        self.register_buffer('running_var', torch.ones(c))
+        self.register_buffer('num_batches_tracked', torch.tensor(0, dtype=torch.long))
+        # the counter does not enter the maths (momentum is fixed); it is kept on the host and folded into the buffer
+        # when a checkpoint is taken, so that no extra kernel is launched per normalisation call
+        self._pending = 0
+        self.register_state_dict_pre_hook(BatchNorm._flush)
+
+    @staticmethod
+    def _flush(module, prefix, keep_vars):
+        if module._pending:
+            module.num_batches_tracked += module._pending
+            module._pending = 0
+
+    def note_forward(self):
+        if self.training:
+            self._pending += 1
+
+    def forward(self, x, act=ACT_NONE):
+        self.note_forward()
+        return ops.norm_act(x, self.weight if self.affine else None, self.bias if self.affine else None,
+                            self.running_mean, self.running_var, instance=False, eps=1e-5, momentum=0.1, act=act,
+                            training=self.training)
+
+
+class InstanceNorm(nn.Module):
+    """nn.InstanceNorm2d(affine=True, eps=0.1) of the discriminator."""
+
+    def __init__(self, c):
+        super().__init__()
+        self.weight = nn.Parameter(torch.ones(c))
+        self.bias = nn.Parameter(torch.zeros(c))
+
+    def forward(self, x, act=ACT_NONE):
+        return ops.norm_act(x, self.weight, self.bias, None, None, instance=True, eps=0.1, act=act, training=True)
+
+
+class _Slot(nn.Module):
+    """Parameter-free placeholder that keeps nn.Sequential-style numeric keys aligned with the reference."""
+
+    def forward(self, x):
+        return x
+
+
+def _seq(*mods):
+    return nn.ModuleList(list(mods))
+
+
+# ------------------------------------------------------------------------------------------------ building blocks
+class SPADEConv2d(nn.Module):
+    """conv3x3(SN) -> BatchNorm(affine) -> LeakyReLU  (reference architecture.py:57-69 with norm='spectralsyncbatch')."""
+
+    def __init__(self, fin, fout, stride=1):
+        super().__init__()
+        self.conv = Conv2d(fin, fout, 3, stride=stride, padding=1, spectral=True)
+        self.bn = BatchNorm(fout, affine=True)
+
+    def forward(self, x):
+        return self.bn(self.conv(x), act=ACT_LRELU)
+
+
+class SPADE(nn.Module):
+    """Reference normalization.py:18-52 with ks = 1: param-free BatchNorm + sequential (1+gamma)*x+beta per map."""
+
+    def __init__(self, norm_nc, hidden_nc, params_free=False):
+        super().__init__()
+        if not isinstance(hidden_nc, list):
+            hidden_nc = [hidden_nc]
+        self.n_hidden = len(hidden_nc)
+        self.params_free = params_free
+        for i, nh in enumerate(hidden_nc):
+            if not params_free or i != 0:
+                s = str(i + 1) if i > 0 else ''
+                setattr(self, 'mlp_gamma%s' % s, Conv2d(nh, norm_nc, 1))
+                setattr(self, 'mlp_beta%s' % s, Conv2d(nh, norm_nc, 1))
+        self.norm = BatchNorm(norm_nc, affine=False)
+        self.norm_nc = norm_nc
+
+    def forward(self, x, maps, weights=None, act=ACT_NONE):
+        if not isinstance(maps, list):
+            maps = [maps]
+        use_maps, use_w = [], []
+        for i, m in enumerate(maps):
+            if m is None:
+                continue
+            if weights is None or i != 0:
+                s = str(i + 1) if i > 0 else ''
+                g, b = getattr(self, 'mlp_gamma%s' % s), getattr(self, 'mlp_beta%s' % s)
+                use_w.append((g.weight, b.weight, g.bias, b.bias))
+            else:
+                # generated weights of map 0: the reference indexes weights[0][j] / weights[1][j], i.e. the weight
+                # tensors only - the generated biases never reach batch_conv (normalization.py:48-50)
+                wg, wb = weights[0][0], weights[1][0]
+                zb = torch.zeros(wg.shape[0], self.norm_nc, dtype=wg.dtype, device=wg.device)
+                use_w.append((wg, wb, zb, zb))
+            use_maps.append(m)
+        self.norm.note_forward()
+        return ops.spade_mod(x, use_maps, use_w, self.norm.running_mean, self.norm.running_var, act=act,
+                             training=self.training)
+
+
+class SPADEResnetBlock(nn.Module):
+    """Reference architecture.py:71-108 (conv_params_free=False; SPADE or plain-BatchNorm flavour)."""
+
+    def __init__(self, fin, fout, hidden_nc=0, spade=True, norm_params_free=False):
+        super().__init__()
+        fhidden = min(fin, fout)
+        self.learned_shortcut = fin != fout
+        self.spade = spade
+        self.conv_0 = Conv2d(fin, fhidden, 3, padding=1, spectral=True)
+        self.conv_1 = Conv2d(fhidden, fout, 3, padding=1, spectral=True)
+        if self.learned_shortcut:
+            self.conv_s = Conv2d(fin, fout, 1, bias=False, spectral=True)
+        if spade:
+            self.bn_0 = SPADE(fin, hidden_nc, norm_params_free)
+            self.bn_1 = SPADE(fhidden, hidden_nc, norm_params_free)
+            if self.learned_shortcut:
+                self.bn_s = SPADE(fin, hidden_nc, norm_params_free)
+        else:
+            self.bn_0 = BatchNorm(fin)
+            self.bn_1 = BatchNorm(fhidden)
+            if self.learned_shortcut:
+                self.bn_s = BatchNorm(fin)
+
+    def forward(self, x, label=None, norm_weights=None):
+        nw = norm_weights if norm_weights else [None] * 3
+        if self.spade:
+            x_s = self.conv_s(self.bn_s(x, label, nw[2], act=ACT_NONE)) if self.learned_shortcut else x
+            dx = self.conv_0(self.bn_0(x, label, nw[0], act=ACT_LRELU))
+            return self.conv_1(self.bn_1(dx, label, nw[1], act=ACT_LRELU), res=x_s)
+        x_s = self.conv_s(self.bn_s(x)) if self.learned_shortcut else x
+        dx = self.conv_0(self.bn_0(x, act=ACT_LRELU))
+        return self.conv_1(self.bn_1(dx, act=ACT_LRELU), res=x_s)
+
+
+def _channels(nf, n, cap=1024):
+    return [min(cap, nf * (2 ** i)) for i in range(n)]
+
+
+class LabelEmbedder(nn.Module):
+    """Reference generator.py:506-572: encoder(-decoder / U-Net) producing one SPADE map per generator level."""
+
+    def __init__(self, opt, input_nc, netS, params_free_layers=0):
+        super().__init__()
+        nf = opt.ngf
+        self.unet = 'unet' in netS
+        self.decode = 'decoder' in netS or self.unet
+        self.n = n = opt.n_downsample_G
+        self.params_free_layers = params_free_layers if params_free_layers != -1 else n
+        ch = _channels(nf, n + 1)
+        self.conv_first = _seq(Conv2d(input_nc, nf, 3, padding=1), _Slot())
+        for i in range(n):
+            if i >= params_free_layers or 'decoder' in netS:
+                setattr(self, 'down_%d' % i, _seq(Conv2d(ch[i], ch[i + 1], 3, stride=2, padding=1), _Slot()))
+        if self.decode:
+            for i in reversed(range(n)):
+                ch_i = ch[i + 1] * (2 if self.unet and i != n - 1 else 1)
+                if i >= params_free_layers:
+                    setattr(self, 'up_%d' % i, _seq(_Slot(), Conv2d(ch_i, ch[i], 3, padding=1), _Slot()))
+
+    def forward(self, x, weights=None):
+        if x is None:
+            return None
+        n = self.n
+        out = [self.conv_first[0](x, act=ACT_LRELU)]
+        for i in range(n):
+            if i >= self.params_free_layers or self.decode:
+                out.append(getattr(self, 'down_%d' % i)[0](out[-1], act=ACT_LRELU))
+            else:
+                raise NotImplementedError("adaptive strided embedding convs are not used by any shipped config")
+        if not self.decode:
+            return out
+        if not self.unet:
+            out = [out[-1]]
+        for i in reversed(range(n)):
+            cur = out[-1]
+            if self.unet and i != n - 1:
+                cur = torch.cat([cur, out[i + 1]], dim=1)
+            if i >= self.params_free_layers:
+                out.append(getattr(self, 'up_%d' % i)[1](ops.upsample2x(cur), act=ACT_LRELU))
+            else:
+                # a 1x1 convolution commutes with nearest up-sampling: run the generated-weight conv on the
+                # quarter-size tensor, then up-sample (bit-identical, 4x fewer MACs and bytes)
+                w, b = weights[i]
+                out.append(ops.upsample2x(ops.batch_conv(cur, w, b, act=ACT_LRELU)))
+        if self.unet:
+            out = out[n:]
+        return out[::-1]
+
+
+class FlowGenerator(nn.Module):
+    """Reference generator.py:456-504."""
+
+    def __init__(self, opt, n_frames_G):
+        super().__init__()
+        input_nc = (opt.label_nc if opt.label_nc != 0 else opt.input_nc) * n_frames_G + opt.output_nc * (n_frames_G - 1)
+        nf, nd = opt.nff, opt.n_downsample_F
+        self.nd = nd
+        self.flow_multiplier = opt.flow_multiplier
+        ch = _channels(nf, nd + 1)
+
+        def normed(cin, cout, stride=1):
+            return _seq(Conv2d(cin, cout, 3, stride=stride, padding=1, bias=False, spectral=True), BatchNorm(cout))
+        down = [normed(input_nc, nf), _Slot()]
+        for i in range(nd):
+            down += [normed(ch[i], ch[i + 1], 2), _Slot()]
+        self.down_flow = _seq(*down)
+        self.res_flow = _seq(*[SPADEResnetBlock(ch[nd], ch[nd], spade=False) for _ in range(opt.n_blocks_F)])
+        up = []
+        for i in reversed(range(nd)):
+            up += [_Slot(), normed(ch[i + 1], ch[i]), _Slot()]
+        self.up_flow = _seq(*up)
+        self.conv_flow = _seq(Conv2d(nf, 2, 3, padding=1))
+        self.conv_mask = _seq(Conv2d(nf, 1, 3, padding=1), _Slot())
+
+    def forward(self, label, label_prev, img_prev, for_ref=False):
+        x = torch.cat([label, label_prev, img_prev], dim=1)
+        for k in range(0, 2 * (self.nd + 1), 2):
+            conv, bn = self.down_flow[k]
+            x = bn(conv(x), act=ACT_LRELU)
+        for blk in self.res_flow:
+            x = blk(x)
+        for k in range(1, 3 * self.nd, 3):
+            conv, bn = self.up_flow[k]
+            x = bn(conv(ops.upsample2x(x)), act=ACT_LRELU)
+        flow = self.conv_flow[0](x, scale=float(self.flow_multiplier))
+        mask = self.conv_mask[0](x, act=ACT_SIGMOID)
+        return flow, mask
+
+
+class FewShotGenerator(nn.Module):
+    """Reference generator.py:20-454 for n_shot == 1, use_label_ref == 'mul', no KLD, no adaptive_conv."""
+
+    def __init__(self, opt):
+        super().__init__()
+        self.opt = opt
+        if getattr(opt, 'n_shot', 1) != 1 or getattr(opt, 'adaptive_conv', False) or getattr(opt, 'lambda_kld', 0) > 0:
+            raise NotImplementedError("n_shot > 1, adaptive_conv and the KLD branch are outside the hot-path scope")
+        if getattr(opt, 'use_label_ref', 'mul') != 'mul' or getattr(opt, 'res_for_ref', False):
+            raise NotImplementedError("only use_label_ref='mul' with SPADEConv2d encoders is on the hot path")
+        if opt.spade_ks != 1 or opt.embed_ks != 1 or opt.conv_ks != 3:
+            raise NotImplementedError("spade_ks = embed_ks = 1, conv_ks = 3 (the defaults of every shipped script)")
+        self.n_downsample_G = n = opt.n_downsample_G
+        nf = opt.ngf
+        nf_max = min(1024, nf * (2 ** n))
+        self.ch = ch = [min(nf_max, nf * (2 ** i)) for i in range(n + 2)]
+        self.spade_combine = opt.spade_combine
+        self.n_sc_layers = opt.n_sc_layers
+        self.add_raw_output_loss = getattr(opt, 'add_raw_output_loss', False) and opt.spade_combine
+        if self.add_raw_output_loss:
+            raise NotImplementedError("add_raw_output_loss")
+        ch_hidden = []
+        for i in range(n + 1):
+            ch_hidden += [[ch[i]]] if not self.spade_combine or i >= self.n_sc_layers else [[ch[i]] * 3]
+        self.ch_hidden = ch_hidden
+        self.adap_spade = opt.adaptive_spade
+        self.adap_embed = opt.adaptive_spade and not getattr(opt, 'no_adaptive_embed', False)
+        self.n_adaptive_layers = opt.n_adaptive_layers if opt.n_adaptive_layers != -1 else n
+        self.n_fc_layers = opt.n_fc_layers
+        input_nc = opt.label_nc if opt.label_nc != 0 else opt.input_nc
+        self.ref_img_first = SPADEConv2d(opt.output_nc, nf)
+        self.ref_label_first = SPADEConv2d(input_nc, nf)
+        for i in range(n):
+            setattr(self, 'ref_img_down_%d' % i, SPADEConv2d(ch[i], ch[i + 1], stride=2))
+            setattr(self, 'ref_img_up_%d' % i, SPADEConv2d(ch[i + 1], ch[i]))
+            setattr(self, 'ref_label_down_%d' % i, SPADEConv2d(ch[i], ch[i + 1], stride=2))
+            setattr(self, 'ref_label_up_%d' % i, SPADEConv2d(ch[i + 1], ch[i]))
+        if self.adap_spade:
+            for i in range(self.n_adaptive_layers):
+                ch_in, ch_out = ch[i], ch[i + 1]
+                ch_h = ch_hidden[i][0]
+                names = ['fc_spade_0', 'fc_spade_1', 'fc_spade_s']
+                outs = [(ch_h + 1) * 2, (ch_h + 1) * (1 if ch_in != ch_out else 2), (ch_h + 1) * 2]
+                if self.adap_embed:
+                    names.append('fc_spade_e')
+                    outs.append(ch_in + 1)
+                for name, fo in zip(names, outs):
+                    layers = [Linear(ch_out, ch_out), _Slot()]
+                    for _ in range(1, self.n_fc_layers):
+                        layers += [Linear(ch_out, ch_out), _Slot()]
+                    layers += [Linear(ch_out, fo)]
+                    setattr(self, '%s_%d' % (name, i), _seq(*layers))
+        self.label_embedding = LabelEmbedder(opt, input_nc, opt.netS,
+                                             params_free_layers=(self.n_adaptive_layers if self.adap_embed else 0))
+        for i in reversed(range(n + 1)):
+            setattr(self, 'up_%d' % i, SPADEResnetBlock(ch[i + 1], ch[i], hidden_nc=ch_hidden[i], spade=True,
+                                                       norm_params_free=(self.adap_spade and i < self.n_adaptive_layers)))
+        self.conv_img = Conv2d(nf, 3, 3, padding=1)
+        self.warp_prev = False
+        self.warp_ref = opt.warp_ref and not getattr(opt, 'for_face', False)
+        if self.warp_ref:
+            self.flow_network_ref = FlowGenerator(opt, 2)
+            if self.spade_combine:
+                self.img_ref_embedding = LabelEmbedder(opt, opt.output_nc + 1, opt.sc_arch)
+
+    # -- temporal extension (reference generator.py:153-179) -------------------------------------------------------
+    def init_temporal_network(self):
+        opt = self.opt
+        self.warp_prev = True
+        self.sep_prev_flownet = opt.sep_flow_prev or (opt.n_frames_G != 2) or not opt.warp_ref
+        self.sep_prev_embedding = self.spade_combine and (not opt.no_sep_warp_embed or not opt.warp_ref)
+        dev = self.conv_img.weight.device
+        if self.sep_prev_flownet:
+            self.flow_network_temp = FlowGenerator(opt, opt.n_frames_G).to(dev)
+        else:
+            self.flow_network_temp = self.flow_network_ref
+        if self.spade_combine:
+            if self.sep_prev_embedding:
+                self.img_prev_embedding = LabelEmbedder(opt, opt.output_nc + 1, opt.sc_arch).to(dev)
+            else:
+                self.img_prev_embedding = self.img_ref_embedding
+        if self.warp_ref:
+            if self.sep_prev_flownet:
+                self.load_pretrained_net(self.flow_network_ref, self.flow_network_temp)
+            if self.sep_prev_embedding:
+                self.load_pretrained_net(self.img_ref_embedding, self.img_prev_embedding)
+            self.flow_temp_is_initalized = True
+
+    @staticmethod
+    def load_pretrained_net(net_src, net_dst):
+        src, dst = net_src.state_dict(), net_dst.state_dict()
+        for k, v in src.items():
+            if k in dst and dst[k].size() == v.size():
+                dst[k] = v
+        net_dst.load_state_dict(dst)
+
+    # -- weight generation ---------------------------------------------------------------------------------------------
+    def _mlp(self, name, i, rows):
+        layers = getattr(self, '%s_%d' % (name, i))
+        x = rows
+        last = len(layers) - 1
+        for k in range(0, last, 2):
+            x = layers[k](x, act=ACT_LRELU)
+        return layers[last](x)
+
+    @staticmethod
+    def _pair(x, cout, cin):
+        return [x[:, :-cout].reshape(x.shape[0], cout, cin, 1, 1), x[:, -cout:]]
+
+    def get_SPADE_weights(self, feat, i):
+        ch_in, ch_out = self.ch[i], self.ch[i + 1]
+        ch_h = self.ch_hidden[i][0]
+        b = feat.shape[0]
+        rows = feat.reshape(b * feat.shape[1], -1)
+        embedding_weights = None
+        if self.adap_embed:
+            fe = self._mlp('fc_spade_e', i, rows).view(b, -1)
+            embedding_weights = self._pair(fe[:, :-ch_in], ch_in, ch_out)
+
+        def two(name, co):
+            f = self._mlp(name, i, rows).view(b, -1)
+            half = co * ch_h + co
+            return [self._pair(f[:, :half], co, ch_h), self._pair(f[:, half:2 * half], co, ch_h)]
+        return embedding_weights, [two('fc_spade_0', ch_out), two('fc_spade_1', ch_in), two('fc_spade_s', ch_out)]
+
+    def reference_encoding(self, img_ref, label_ref):
+        n = self.n_downsample_G
+        x = self.ref_img_first(img_ref)
+        xl = self.ref_label_first(label_ref)
+        for i in range(n):
+            x = getattr(self, 'ref_img_down_%d' % i)(x)
+            xl = getattr(self, 'ref_label_down_%d' % i)(xl)
+        fi, fl = [x], [xl]
+        for i in reversed(range(n)):
+            fi.append(getattr(self, 'ref_img_up_%d' % i)(fi[-1]))
+            fl.append(getattr(self, 'ref_label_up_%d' % i)(fl[-1]))
+        enc = []
+        for a, l in zip(fi, fl):
+            b, c, h, w = a.shape
+            sm = torch.softmax(l, dim=1)
+            # prod[b, i, j] = sum_p a[b, i, p] * sm[b, j, p]  as a per-sample 1x1 "convolution" on the gather-GEMM
+            # kernel: pixels = image channels i, input channels = positions p, generated weights = softmax rows j
+            a_rows = a.reshape(b, c, 1, h * w).permute(0, 3, 1, 2)              # logical [b, hw, c, 1]
+            wts = sm.reshape(b, c, h * w, 1, 1)
+            prod = ops.batch_conv(a_rows, wts)                                    # logical [b, c(j), c(i), 1]
+            enc.append(prod.permute(0, 2, 1, 3))                                  # [b, c(i), c(j), 1]
+        return x, enc[::-1]
+
+    def weight_generation(self, img_ref, label_ref, label):
+        b, n, c, h, w = img_ref.shape
+        img_ref, label_ref = img_ref.reshape(b * n, -1, h, w), label_ref.reshape(b * n, -1, h, w)
+        x, enc = self.reference_encoding(img_ref, label_ref)
+        embed_w, norm_w = [], []
+        if self.adap_spade:
+            for i in range(self.n_adaptive_layers):
+                e, nw = self.get_SPADE_weights(enc[min(len(enc) - 1, i + 1)], i)
+                embed_w.append(e)
+                norm_w.append(nw)
+        enc_label = self.label_embedding(label, weights=(embed_w if self.adap_embed else None))
+        return x, enc_label, norm_w
+
+    def flow_generation(self, label, label_ref, img_ref, prev):
+        label_prev, img_prev = prev
+        flow, mask, warp, ds = [None, None], [None, None], [None, None], [None, None]
+        if self.warp_ref:
+            flow[0], mask[0] = self.flow_network_ref(label, label_ref, img_ref, for_ref=True)
+            warp[0] = ops.resample(img_ref, flow[0])[:, :3]
+        if self.warp_prev and label_prev is not None:
+            flow[1], mask[1] = self.flow_network_temp(label, label_prev, img_prev)
+            warp[1] = ops.resample(img_prev[:, -3:], flow[1])
+        if self.spade_combine:
+            if self.warp_ref:
+                ds[0] = torch.cat([warp[0], mask[0]], dim=1)
+            if warp[1] is not None:
+                ds[1] = torch.cat([warp[1], mask[1]], dim=1)
+        return flow, mask, warp, ds
+
+    def forward(self, label, label_refs, img_refs, prev=(None, None), t=0, img_coarse=None):
+        if img_coarse is not None:
+            raise NotImplementedError("face refinement generator (refine_face) is outside the hot-path scope")
+        x, enc_label, norm_w = self.weight_generation(img_refs, label_refs, label)
+        label_ref, img_ref = label_refs[:, 0], img_refs[:, 0]
+        flow, mask, warp, ds = self.flow_generation(label, label_ref, img_ref, prev)
+        if self.spade_combine:
+            emb = [self.img_ref_embedding(ds[0]), self.img_prev_embedding(ds[1]) if ds[1] is not None else None]
+            for i in range(self.n_sc_layers):
+                enc_label[i] = [enc_label[i]] + [e[i] if e is not None else None for e in emb]
+        for i in range(self.n_downsample_G, -1, -1):
+            nw = norm_w[i] if (self.adap_spade and i < self.n_adaptive_layers) else None
+            x = getattr(self, 'up_%d' % i)(x, enc_label[i], nw)
+            if i != 0:
+                x = ops.upsample2x(x)
+        img_raw = self.conv_img(ops.activation(x, ACT_LRELU), act=ACT_TANH)
+        if not self.spade_combine:
+            img_final = img_raw
+            if self.warp_ref:
+                img_final = img_raw * mask[0] + warp[0] * (1 - mask[0])
+            elif not self.warp_prev:
+                img_raw = None
+            if warp[1] is not None:
+                img_final = img_final * mask[1] + warp[1] * (1 - mask[1])
+        else:
+            img_final, img_raw = img_raw, None
+        return img_final, flow, mask, img_raw, warp, None, None, None, None
+
+
+# ------------------------------------------------------------------------------------------------ discriminator
+class NLayerDiscriminator(nn.Module):
+    """Reference discriminator.py:61-102 with norm 'spectralinstance': k4 p2 PatchGAN returning every feature."""
+
+    def __init__(self, input_nc, ndf=64, n_layers=3, getIntermFeat=False, stride=2):
+        super().__init__()
+        self.getIntermFeat, self.n_layers = getIntermFeat, n_layers
+        self.model0 = _seq(Conv2d(input_nc, ndf, 4, stride=stride, padding=2), _Slot())
+        nf = ndf
+        for n in range(1, n_layers):
+            nf_prev, nf = nf, min(nf * 2, 512)
+            setattr(self, 'model%d' % n, _seq(_seq(Conv2d(nf_prev, nf, 4, stride=stride, padding=2, bias=False, spectral=True),
+                                                   InstanceNorm(nf)), _Slot()))
+        nf_prev, nf = nf, min(nf * 2, 512)
+        setattr(self, 'model%d' % n_layers, _seq(_seq(Conv2d(nf_prev, nf, 4, stride=1, padding=2, bias=False, spectral=True),
+                                                      InstanceNorm(nf)), _Slot()))
+        setattr(self, 'model%d' % (n_layers + 1), _seq(Conv2d(nf, 1, 4, stride=1, padding=2)))
+
+    def forward(self, x):
+        res = []
+        x = self.model0[0](x, act=ACT_LRELU)
+        res.append(x)
+        for n in range(1, self.n_layers + 1):
+            conv, norm = getattr(self, 'model%d' % n)[0]
+            x = norm(conv(x), act=ACT_LRELU)
+            res.append(x)
+        x = getattr(self, 'model%d' % (self.n_layers + 1))[0](x)
+        res.append(x)
+        return res if self.getIntermFeat else res[-1]
+
+
+class MultiscaleDiscriminator(nn.Module):
+    """Reference discriminator.py:16-58 (subarch 'n_layers')."""
+
+    def __init__(self, opt, input_nc, ndf=64, n_layers=3, num_D=1, getIntermFeat=False, stride=2):
+        super().__init__()
+        self.num_D, self.getIntermFeat = num_D, getIntermFeat
+        for i in range(num_D):
+            setattr(self, 'discriminator_%d' % i, NLayerDiscriminator(input_nc, ndf, n_layers, getIntermFeat, stride))
+
+    def forward(self, x, ref=None):
+        result = []
+        for i in range(self.num_D):
+            out = getattr(self, 'discriminator_%d' % i)(x)
+            result.append(out if self.getIntermFeat else [out])
+            if i + 1 < self.num_D:
+                # TODO(next): HIP avg-pool; num_D = 1 in every BASELINE config so this is off the measured path
+                x = F.avg_pool2d(x, 3, stride=2, padding=1, count_include_pad=False)
+        return result
+
+
+def define_G(opt):
+    """Reference models/networks/__init__.py:29-39."""
+    return FewShotGenerator(opt)
+
+
+def define_D(opt, input_nc, ndf, n_layers_D, norm='spectralinstance', subarch='n_layers', num_D=1, getIntermFeat=False,
+             stride=2, gpu_ids=()):
+    """Reference models/networks/__init__.py:41-55."""
+    if norm != 'spectralinstance' or subarch != 'n_layers':
+        raise NotImplementedError("only the shipped 'spectralinstance' n_layers PatchGAN is on the hot path")
+    return MultiscaleDiscriminator(opt, input_nc, ndf, n_layers_D, num_D, getIntermFeat, stride)

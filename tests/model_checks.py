@@ -1,0 +1,226 @@
+"""Network-level parity checks (product modules on the HIP kernels vs the functional CPU oracle), shared by the
+emulated CPU tests, the GPU tests and __graft_entry__.smoke()."""
+import argparse
+import hashlib
+import os
+import sys
+from importlib import import_module
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, 'tests')):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+from oracle import fsv_oracle as O  # noqa: E402
+from op_checks import assert_close  # noqa: E402
+
+
+def make_opt(**kw):
+    """The reference's option namespace (options/base_options.py:21-132, train_options.py) with its defaults."""
+    d = dict(
+        ngf=32, ndf=32, nff=32, n_downsample_G=5, n_downsample_F=3, n_blocks_F=6, flow_multiplier=20,
+        norm_G='spectralspadesyncbatch', norm_F='spectralsyncbatch', norm_D='spectralinstance',
+        conv_ks=3, embed_ks=1, spade_ks=1, netS='encoderdecoder', sc_arch='unet', use_label_ref='mul',
+        res_for_ref=False, adaptive_conv=False, adaptive_spade=True, no_adaptive_embed=False, n_adaptive_layers=4,
+        n_fc_layers=2, n_frames_G=2, n_frames_per_gpu=1, n_frames_D=2, no_flow_gt=True, spade_combine=False,
+        n_sc_layers=2, add_raw_output_loss=False, sep_flow_prev=False, no_sep_warp_embed=False, n_shot=1,
+        n_downsample_A=2, warp_ref=False, which_model_netD='multiscale', netD_subarch='n_layers', num_D=1,
+        n_layers_D=4, gan_mode='hinge', add_face_D=False, lambda_kld=0.0, lambda_feat=10.0, lambda_temp=0.0,
+        lambda_flow=10.0, lambda_mask=10.0, lambda_vgg=10.0, lambda_face=10.0, no_ganFeat_loss=False,
+        no_vgg_loss=True, no_TTUR=False, lr=0.0004, beta1=0.5, beta2=0.999, isTrain=True, finetune=False,
+        dataset_mode='fewshot_pose', label_nc=0, input_nc=6, output_nc=3, aspect_ratio=1.0, fineSize=64, loadSize=64,
+        pose_type='both', remove_face_labels=False, refine_face=False, basic_point_only=False, batchSize=2,
+        gpu_ids=[0], distributed=False, amp='O0', niter_single=50,
+    )
+    for k, v in kw.items():
+        if k not in d:
+            raise KeyError(k)
+        d[k] = v
+    return argparse.Namespace(**d)
+
+
+def fill_state(module, scale=1.0):
+    """Overwrite every parameter/buffer with values that depend only on its state_dict key (numpy Generator is
+    stable across platforms), so that the product, the oracle and the golden fixtures see identical weights."""
+    sd = module.state_dict()
+    new = {}
+    for k, v in sd.items():
+        seed = int(hashlib.sha1(k.encode()).hexdigest()[:8], 16)
+        rng = np.random.default_rng(seed)
+        if k.endswith('num_batches_tracked'):
+            new[k] = torch.zeros_like(v)
+        elif k.endswith('running_mean'):
+            new[k] = torch.zeros_like(v)
+        elif k.endswith('running_var'):
+            new[k] = torch.ones_like(v)
+        elif k.endswith('weight_u') or k.endswith('weight_v'):
+            a = rng.standard_normal(v.shape).astype(np.float32)
+            new[k] = torch.from_numpy(a / max(np.linalg.norm(a), 1e-12))
+        elif v.dim() == 1 and k.endswith('weight'):
+            new[k] = torch.from_numpy((1.0 + 0.1 * rng.standard_normal(v.shape)).astype(np.float32))
+        elif v.dim() == 1:
+            new[k] = torch.from_numpy((0.05 * rng.standard_normal(v.shape)).astype(np.float32))
+        else:
+            fan_in = int(np.prod(v.shape[1:]))
+            std = scale * (1.5 / np.sqrt(fan_in))
+            if 'conv_flow' in k:
+                std *= 0.05      # keep synthetic flows at a few pixels: the warp is only piecewise smooth
+            new[k] = torch.from_numpy((std * rng.standard_normal(v.shape)).astype(np.float32))
+    module.load_state_dict(new)
+    return new
+
+
+def synth_pose_inputs(b, h, w, seed=1234, n_label=6):
+    """SURVEY.md section 8(d) C3-style synthetic tensors: labels U(-1,1) with a DensePose part-id channel, images U(-1,1)."""
+    g = torch.Generator().manual_seed(seed)
+
+    def label():
+        l = torch.rand(b, 1, n_label, h, w, generator=g) * 2 - 1
+        if n_label >= 3:
+            part = torch.round(torch.rand(b, 1, h, w, generator=g) * 24) / 24 * 2 - 1
+            bg = torch.ones(b, 1, h, w, dtype=torch.bool)
+            bg[:, :, h // 8: h - h // 8, w // 6: w - w // 6] = False
+            part[bg] = -1.0
+            l[:, :, 2] = part
+        return l
+    def image():
+        # band-limited content (bilinearly up-sampled coarse noise) + a little pixel noise, in [-1, 1]
+        coarse = torch.rand(b, 3, max(h // 8, 2), max(w // 8, 2), generator=g) * 2 - 1
+        img = torch.nn.functional.interpolate(coarse, size=(h, w), mode='bilinear', align_corners=True)
+        img = (img + 0.05 * (torch.rand(b, 3, h, w, generator=g) * 2 - 1)).clamp(-1, 1)
+        return img.unsqueeze(1)
+    tgt_label, ref_label = label(), label()
+    tgt_image, ref_image = image(), image()
+    return tgt_label, tgt_image, ref_label, ref_image
+
+
+def _net():
+    import fsv2v_amd  # noqa: F401
+    return import_module('few-shot-vid2vid_amd.networks')
+
+
+def _oracle_generator(sd0, cfg, label, ref_label, ref_image, dtype, loss_weights=None, warp_ref=False):
+    sd = {}
+    for k, v in sd0.items():
+        t = v.clone().to(dtype).detach() if v.is_floating_point() else v.clone()
+        if v.is_floating_point() and ('running' not in k) and not k.endswith(('_u', '_v')):
+            t.requires_grad_(True)
+        sd[k] = t
+    img, flow, mask, raw, warp = O.generator_forward(sd, cfg, label.to(dtype), ref_label.to(dtype), ref_image.to(dtype))
+    if loss_weights is not None:
+        wimg, wf, wm = [t.to(dtype) for t in loss_weights]
+        loss = (img * wimg).sum()
+        if warp_ref:
+            loss = loss + (flow[0] * wf).sum() + (mask[0] * wm).sum() + (warp[0] * wimg).sum()
+        loss.backward()
+    return sd, (img, flow, mask, warp)
+
+
+def _close_vs64(name, got, ref32, ref64, tol, floor=0.0):
+    """|got - ref64| <= tol * scale + 4 * |ref32 - ref64|: the product has to be as close to the exact answer as the
+    fp32 CPU reference itself is (the tiny test networks normalise over a handful of values and are ill-conditioned)."""
+    got = got.detach().double().cpu()
+    r64 = ref64.detach().double()
+    noise = float((ref32.detach().double() - r64).abs().max())
+    scale = max(float(r64.abs().max()), floor, 1e-12)
+    err = float((got - r64).abs().max())
+    assert err <= tol * scale + 4.0 * noise, '%s: max|diff| %.3e > %.1e * %.3e + 4 * %.3e' % (name, err, tol, scale, noise)
+    return err / scale
+
+
+def check_generator(device, opt, b=2, tol=1e-3, grads=True, seed=7):
+    net = _net()
+    torch.manual_seed(0)
+    G = net.define_G(opt)
+    sd0 = fill_state(G)
+    G = G.to(device).train()
+    h, w = int(opt.fineSize / opt.aspect_ratio), opt.fineSize
+    nl = opt.label_nc if opt.label_nc != 0 else opt.input_nc
+    tgt_label, tgt_image, ref_label, ref_image = synth_pose_inputs(b, h, w, seed, nl)
+    label = tgt_label[:, 0]
+    cfg = O.cfg_from_opt(opt)
+    gen = torch.Generator().manual_seed(seed + 1)
+    lw = (torch.randn(b, 3, h, w, generator=gen), torch.randn(b, 2, h, w, generator=gen) * 0.1,
+          torch.randn(b, 1, h, w, generator=gen))
+    sd32, o32 = _oracle_generator(sd0, cfg, label, ref_label, ref_image, torch.float32, lw if grads else None, opt.warp_ref)
+    sd64, o64 = _oracle_generator(sd0, cfg, label, ref_label, ref_image, torch.float64, lw if grads else None, opt.warp_ref)
+    out = G(label.to(device), ref_label.to(device), ref_image.to(device), [None, None])
+    _close_vs64('G img', out[0], o32[0], o64[0], tol)
+    if opt.warp_ref:
+        _close_vs64('G flow', out[1][0], o32[1][0], o64[1][0], tol)
+        _close_vs64('G mask', out[2][0], o32[2][0], o64[2][0], tol)
+        _close_vs64('G warp', out[4][0], o32[3][0], o64[3][0], tol)
+    sd1 = G.state_dict()
+    for k in sd1:
+        if k.endswith(('_u', '_v', 'running_mean', 'running_var')):
+            _close_vs64('state ' + k, sd1[k], sd32[k], sd64[k], tol)
+    if not grads:
+        return 0.0
+    wimg, wf, wm = [t.to(device) for t in lw]
+    loss = (out[0] * wimg).sum()
+    if opt.warp_ref:
+        loss = loss + (out[1][0] * wf).sum() + (out[2][0] * wm).sum() + (out[4][0] * wimg).sum()
+    loss.backward()
+    return compare_grads(G, sd32, sd64, tol * 5)
+
+
+def compare_grads(module, sd32, sd64, tol):
+    """Parameter gradients vs the fp64 oracle, with the fp32 oracle's own rounding noise as allowance (see
+    _close_vs64).  Gradients that are mathematically zero (conv bias in front of a normalisation) are noise on all
+    sides; the floor keeps their scale at 1% of the median gradient magnitude of the network."""
+    mags = [float(sd64[n].grad.abs().max()) for n, _ in module.named_parameters() if sd64[n].grad is not None]
+    floor = 1e-2 * float(np.median(mags)) if mags else 0.0
+    worst = 0.0
+    for name, prm in module.named_parameters():
+        ref = sd64[name].grad
+        if ref is None:
+            assert prm.grad is None or float(prm.grad.abs().max()) == 0.0, name
+            continue
+        assert prm.grad is not None, 'no grad for ' + name
+        worst = max(worst, _close_vs64('grad ' + name, prm.grad, sd32[name].grad, ref, tol, floor))
+    return worst
+
+
+def check_discriminator(device, opt, input_nc=20, b=2, tol=1e-3, seed=11):
+    net = _net()
+    D = net.define_D(opt, input_nc, opt.ndf, opt.n_layers_D, opt.norm_D, 'n_layers', opt.num_D, True)
+    sd0 = fill_state(D)
+    D = D.to(device).train()
+    h, w = int(opt.fineSize / opt.aspect_ratio), opt.fineSize
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(2 * b, input_nc, h, w, generator=g)
+    cfg = O.cfg_from_opt(opt)
+    xd = x.to(device).requires_grad_(True)
+    out = D(xd)
+    wgts = [torch.randn(a.shape, generator=g) for a in out[0]]
+
+    def run(dtype):
+        sd = {k: v.clone().to(dtype).detach().requires_grad_(not k.endswith(('_u', '_v'))) for k, v in sd0.items()}
+        xr = x.clone().to(dtype).detach().requires_grad_(True)
+        ref = O.multiscale_discriminator(sd, cfg, xr)
+        loss = sum((r * wg.to(dtype)).sum() for r, wg in zip(ref[0], wgts))
+        loss.backward()
+        return sd, ref[0], xr.grad
+    sd32, f32, dx32 = run(torch.float32)
+    sd64, f64, dx64 = run(torch.float64)
+    loss = sum((a * wg.to(device)).sum() for a, wg in zip(out[0], wgts))
+    for a, r32, r64 in zip(out[0], f32, f64):
+        _close_vs64('D feat', a, r32, r64, tol)
+    loss.backward()
+    _close_vs64('D dx', xd.grad, dx32, dx64, tol * 5)
+    return compare_grads(D, sd32, sd64, tol * 5)
+
+
+def tiny_opt(**kw):
+    base = dict(ngf=4, ndf=4, nff=4, fineSize=64, loadSize=64)
+    base.update(kw)
+    return make_opt(**base)
+
+
+def smoke(device):
+    """Used by __graft_entry__.smoke(): one tiny forward+backward of G and D on the GPU, checked against the oracle."""
+    check_generator(device, tiny_opt(ngf=8, nff=8, warp_ref=True, spade_combine=True), b=2)
+    check_discriminator(device, tiny_opt(ndf=8), b=1)

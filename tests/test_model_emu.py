@@ -1,0 +1,19 @@
+"""Network-level CPU logic tests: product modules (HIP kernel sources under the SIMT emulator) vs the CPU oracle,
+forward values, post-forward state (spectral-norm vectors, BatchNorm running statistics) and every parameter gradient."""
+import torch
+
+import model_checks as mc
+
+DEV = torch.device("cpu")
+
+
+def test_discriminator_tiny(emu_lib):
+    mc.check_discriminator(DEV, mc.tiny_opt(), b=1)
+
+
+def test_generator_adaptive_spade_tiny(emu_lib):
+    mc.check_generator(DEV, mc.tiny_opt(), b=2)
+
+
+def test_generator_warp_combine_tiny(emu_lib):
+    mc.check_generator(DEV, mc.tiny_opt(warp_ref=True, spade_combine=True), b=2)

@@ -1,0 +1,30 @@
+"""Network-level parity on a real MI355X (configs of BASELINE.json at reduced width/resolution so the CPU oracle
+finishes in seconds; the full-size properties live in test_fullsize_gpu.py)."""
+import pytest
+import torch
+
+import model_checks as mc
+
+pytestmark = pytest.mark.gpu
+
+
+def dev():
+    return torch.device("cuda:0")
+
+
+def test_discriminator(hip_lib):
+    mc.check_discriminator(dev(), mc.tiny_opt(ndf=8, fineSize=128, loadSize=128), b=2)
+
+
+def test_generator_face_like_adaptive_spade(hip_lib):
+    # BASELINE configs[0]/[1] flavour: adaptive_spade only, 1-channel labels
+    mc.check_generator(dev(), mc.tiny_opt(ngf=8, dataset_mode='fewshot_face', input_nc=1, fineSize=128, loadSize=128), b=2)
+
+
+def test_generator_pose_warp_combine(hip_lib):
+    # BASELINE configs[2] flavour: adaptive_spade + warp_ref + spade_combine
+    mc.check_generator(dev(), mc.tiny_opt(ngf=8, nff=8, warp_ref=True, spade_combine=True, fineSize=128, loadSize=128), b=2)
+
+
+def test_generator_pose_warp_blend(hip_lib):
+    mc.check_generator(dev(), mc.tiny_opt(ngf=8, nff=8, warp_ref=True), b=2)
