@@ -1,0 +1,192 @@
+"""Headline benchmark: frames/sec of one G+D forward+backward training step (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+Workload (config.workload): BASELINE.json configs[2] - fewshot_pose 512x512, per-GPU batch 2, --adaptive_spade
+--warp_ref --spade_combine --remove_face_labels --no_flow_gt --no_vgg_loss (SURVEY.md section 8d "C3"), synthetic
+labels/images, random-init weights.  One step = the body of the reference's train.py:58-62: D forward (incl. the
+no-grad G forward), D backward, Adam(D), G forward, D forward, full backward, Adam(G).  fp32 throughout (exact-fp32
+MFMA).  Weak scaling: the per-GPU batch is fixed, gradients are all-reduced over RCCL (flat.py).
+
+Besides the contract fields the JSON line carries
+  roofline     - the dominant kernel (the fp32 MFMA implicit-GEMM convolution) priced against the 157.3 TFLOP/s
+                 fp32 matrix peak: algorithmic FLOPs per launch / average launch duration, measured with HIP events
+                 on the launch stream in an instrumented pass of the same step;
+  cpu_baseline - the CPU oracle (oracle/fsv_oracle.py, a port of the reference's algorithm; kind "port") timed on
+                 the host cores on a bounded sample of the same workload (rank 0, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, 'tests'))
+
+FP32_MFMA_PEAK_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md "Peak FP32 (matrix)"
+
+
+def build_opt(size, batch):
+    import model_checks as mc
+    return mc.make_opt(fineSize=size, loadSize=size, batchSize=batch, warp_ref=True, spade_combine=True,
+                       remove_face_labels=True, no_vgg_loss=True, no_flow_gt=True)
+
+
+def make_data(batch, size, seed, device):
+    import model_checks as mc
+    tl, ti, rl, ri = mc.synth_pose_inputs(batch, size, size, seed)
+    tl, ti, rl, ri = [t.to(device) for t in (tl, ti, rl, ri)]
+    return [tl, ti, [None, None], [None, None], rl, ri, None, None, None]
+
+
+def cpu_baseline(size, threads):
+    """One reference iteration on the CPU oracle (D step + G step incl. both backward passes), B=1."""
+    import model_checks as mc
+    from oracle import fsv_oracle as O
+    from importlib import import_module
+    import fsv2v_amd  # noqa: F401
+    M = import_module('few-shot-vid2vid_amd.model')
+    torch.set_num_threads(threads)
+    opt = build_opt(size, 1)
+    model = M.create_model(opt)           # only used as a source of (random-init) weights with the right shapes
+    sdG = {k: v.detach().clone() for k, v in model.netG.state_dict().items()}
+    sdD = {k: v.detach().clone() for k, v in model.netD.state_dict().items()}
+    del model
+    data = mc.synth_pose_inputs(1, size, size, 99)
+    cfg = O.cfg_from_opt(opt)
+    t0 = time.perf_counter()
+    mc._oracle_iteration(sdG, sdD, cfg, data, torch.float32)
+    dt = time.perf_counter() - t0
+    return dict(value=round(1.0 / dt, 4), unit='frames/s', cores=threads, kind='port',
+                sample='1 iteration (D step + G step, fwd+bwd) at B=1, %dx%d, same flags, oracle/fsv_oracle.py, %.1f s' % (size, size, dt))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=10)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--size', type=int, default=512)
+    ap.add_argument('--batch', type=int, default=2, help='per-GPU batch')
+    ap.add_argument('--no-graph', action='store_true')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-roofline', action='store_true')
+    args = ap.parse_args()
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    device = torch.device('cuda', local_rank)
+    group = None
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group(backend='nccl', rank=rank, world_size=world)
+
+    from importlib import import_module
+    import fsv2v_amd  # noqa: F401
+    M = import_module('few-shot-vid2vid_amd.model')
+    prof = import_module('few-shot-vid2vid_amd.profile')
+
+    opt = build_opt(args.size, args.batch)
+    model = M.create_model(opt).to(device).train()          # identical init on every rank (seed 0), like the reference
+    opt_G, opt_D = model.build_optimizers(world_size=world, process_group=group)
+    data = make_data(args.batch, args.size, 1234 + rank, device)
+
+    def step():
+        d_losses = model(data, mode='discriminator')
+        M.loss_backward(opt, d_losses, opt_D, 1)
+        g_losses, _, _ = model(data, mode='generator')
+        M.loss_backward(opt, g_losses, opt_G, 0)
+
+    use_graph = (world == 1) and not args.no_graph
+    graph = None
+    n_eager_warm = max(1, min(args.warmup, 2)) if use_graph else args.warmup
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(n_eager_warm):
+            step()
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    mode = 'eager'
+    if use_graph:
+        try:
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                step()
+            mode = 'hipgraph'
+        except Exception as e:                      # capture is an optimisation; the step itself is unchanged
+            if rank == 0:
+                print('graph capture failed (%s); timing the eager step' % str(e).split('\n')[0], file=sys.stderr)
+            graph = None
+            torch.cuda.synchronize()
+    run = (graph.replay if graph is not None else step)
+    for _ in range(max(0, args.warmup - n_eager_warm)):
+        run()
+
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        run()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    frames = args.batch * world * args.steps
+    result = {
+        'metric': 'frames/sec G+D fwd+bwd step, 512x512 fewshot_pose',
+        'value': round(frames / elapsed, 4),
+        'unit': 'frames/s',
+        'n_gpus': world,
+        'steps': args.steps,
+        'warmup': args.warmup,
+        'ms_per_step': round(elapsed / args.steps * 1e3, 3),
+        'higher_is_better': True,
+        'scaling': 'weak',
+        'vs_baseline': None,
+        'dtype': 'f32',
+        'data': 'synthetic',
+        'config': {'workload': 'fewshot_pose %dx%d, per-GPU batch %d, adaptive_spade+warp_ref+spade_combine, '
+                               'D step + G step (train.py:58-62), Adam included, no VGG / FlowNet2 / face-D'
+                               % (args.size, args.size, args.batch),
+                   'global_batch': args.batch * world, 'parallelism': 'dp%d' % world, 'launch': mode,
+                   'algorithmic_tflop_per_frame': 1.66},
+    }
+    if rank == 0:
+        result['step_tflops'] = round(1.66 * frames / elapsed, 2)
+        if not args.no_roofline:
+            # instrumented eager pass: HIP events around every launch of the dominant kernel, on its launch stream
+            prof.enable()
+            step()
+            torch.cuda.synchronize()
+            rl = prof.summary()
+            prof.disable()
+            result['roofline'] = rl['dominant']
+            result['kernels'] = rl['by_kernel']
+        if world == 1 and not args.no_cpu_baseline:
+            result['cpu_baseline'] = cpu_baseline(args.size, os.cpu_count() or 1)
+        print(json.dumps(result))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

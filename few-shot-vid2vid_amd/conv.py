@@ -7,7 +7,7 @@ channels-last memory (NHWC), which is the layout the kernels in csrc/conv_igemm.
 """
 import torch
 
-from . import lib
+from . import lib, profile
 
 ACT_NONE, ACT_LRELU, ACT_TANH, ACT_SIGMOID = 0, 1, 2, 3
 
@@ -131,10 +131,18 @@ def gather_gemm(x, wt, ldw, cout, oh, ow, ty, tx, sy, sx, bias=None, res=None, a
     lib.check_device(x, wt, bias, res, out)
     w_bs = wt.shape[-2] * wt.shape[-1] if per_sample else 0
     b_bs = cout if (per_sample and bias is not None) else 0
-    lib.call("fsv_conv_gather_fwd", lib.ptr(x), lib.ptr(wt), lib.ptr(bias), lib.ptr(res), lib.ptr(out),
-             n, h, w, cin, oh, ow, cout, len(ty), lib.int_array(ty), lib.int_array(tx), sy, sx,
-             out_h, out_w, osy, osx, ooy, oox, ldw, w_bs, b_bs, 1 if per_sample else 0,
-             act, float(scale), force_tile, force_split, 1 if accumulate else 0, lib.stream_ptr())
+    args = (lib.ptr(x), lib.ptr(wt), lib.ptr(bias), lib.ptr(res), lib.ptr(out),
+            n, h, w, cin, oh, ow, cout, len(ty), lib.int_array(ty), lib.int_array(tx), sy, sx,
+            out_h, out_w, osy, osx, ooy, oox, ldw, w_bs, b_bs, 1 if per_sample else 0,
+            act, float(scale), force_tile, force_split, 1 if accumulate else 0, lib.stream_ptr())
+    if profile.enabled():
+        mz = oh * ow if per_sample else n * oh * ow
+        label = profile.conv_label(mz, cout, (len(ty) * cin + 31) // 32, n if per_sample else 1, cin % 4 == 0,
+                                   force_tile, force_split)
+        with profile.scope(label, 2.0 * n * oh * ow * cout * cin * len(ty)):
+            lib.call("fsv_conv_gather_fwd", *args)
+    else:
+        lib.call("fsv_conv_gather_fwd", *args)
     return out
 
 
@@ -180,7 +188,10 @@ def conv_wgrad(x, dout, geom, w_shape, per_sample=False, scale=None, force_split
     nb = n if per_sample else 1
     dwt = torch.empty((nb, kpad, ldw), dtype=torch.float32, device=x.device)
     lib.check_device(x, dout)
-    lib.call("fsv_conv_wgrad", lib.ptr(x), lib.ptr(dout), lib.ptr(dwt), n, h, w, cin, oh, ow, cout,
-             geom.ntaps, lib.int_array(geom.ty), lib.int_array(geom.tx), geom.stride, geom.stride,
-             ldw, kpad, kpad * ldw, 1 if per_sample else 0, force_split, lib.stream_ptr())
+    with profile.scope('fsv_conv_wgrad_kernel<BN%d,V%d>' % (32 if cout <= 32 else (64 if cout <= 64 else 128),
+                                                            4 if cin % 4 == 0 else 1),
+                       2.0 * n * oh * ow * cout * cin * geom.ntaps):
+        lib.call("fsv_conv_wgrad", lib.ptr(x), lib.ptr(dout), lib.ptr(dwt), n, h, w, cin, oh, ow, cout,
+                 geom.ntaps, lib.int_array(geom.ty), lib.int_array(geom.tx), geom.stride, geom.stride,
+                 ldw, kpad, kpad * ldw, 1 if per_sample else 0, force_split, lib.stream_ptr())
     return unprep_weight_grad(dwt, tuple(w_shape), geom, scale)

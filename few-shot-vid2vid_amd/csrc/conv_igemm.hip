@@ -466,6 +466,33 @@ static inline int fsv_tile_dims(int tile, int& bm, int& bn) {
   return 0;
 }
 
+
+// Tile / split-K plan shared by the launcher and (through the C ABI) by the host-side profiler labels.
+// tile ids: 0 = 128x128, 1 = 128x64, 2 = 128x32, 3 = 256x32, 4 = 64x64 (BM x BN, pixels x output channels).
+extern "C" int fsv_conv_plan(int Mz, int Cout, int nchunks, int nsamp, int force_tile, int force_split,
+                             int* tile_out, int* nsplit_out) {
+  int tile = force_tile;
+  if (tile < 0) {
+    if (Cout <= 32) tile = (Mz >= 256 * 256) ? 3 : 2;
+    else if (Cout <= 64) tile = 1;
+    else tile = ((long long)Mz * Cout <= 64 * 64 * 64) ? 4 : 0;
+  }
+  int bm, bn;
+  if (fsv_tile_dims(tile, bm, bn)) return -1;
+  // split-K for launches that would leave most of the 256 CUs idle
+  long long blocks = (long long)fsv_cdiv(Mz, bm) * fsv_cdiv(Cout, bn) * nsamp;
+  int nsplit = 1;
+  if (force_split > 0) nsplit = force_split;
+  else if (blocks < 256 && nchunks >= 8) {
+    nsplit = (int)((512 + blocks - 1) / blocks);
+    if (nsplit > nchunks / 4) nsplit = nchunks / 4;
+    if (nsplit < 1) nsplit = 1;
+  }
+  if (nsplit > nchunks) nsplit = nchunks;
+  *tile_out = tile; *nsplit_out = nsplit;
+  return 0;
+}
+
 extern "C" {
 
 // Generic gather-GEMM (see header comment and include/fsv2v.h: fsv_conv_gather_fwd).
@@ -491,31 +518,15 @@ int fsv_conv_gather_fwd(const float* in, const float* wt, const float* bias, con
   p.act = act; p.scale = scale;
   p.Mz = per_sample ? OH * OW : N * OH * OW;
   const int nsamp = per_sample ? N : 1;
-  // split-K for launches that would leave most of the 256 CUs idle
-  int bm = 128, bn = 128;
-  int tile = force_tile;
-  if (tile < 0) {
-    if (Cout <= 32) tile = (p.Mz >= 256 * 256) ? 3 : 2;
-    else if (Cout <= 64) tile = 1;
-    else tile = ((long long)p.Mz * Cout <= 64 * 64 * 64) ? 4 : 0;
-  }
-  if (fsv_tile_dims(tile, bm, bn)) return FSV_ERR_BAD_ARG;
-  long long blocks = (long long)fsv_cdiv(p.Mz, bm) * fsv_cdiv(Cout, bn) * nsamp;
-  int nsplit = 1;
-  if (force_split > 0) nsplit = force_split;
-  else if (blocks < 256 && p.nchunks >= 8) {
-    nsplit = (int)((512 + blocks - 1) / blocks);
-    if (nsplit > p.nchunks / 4) nsplit = p.nchunks / 4;
-    if (nsplit < 1) nsplit = 1;
-  }
-  if (nsplit > p.nchunks) nsplit = p.nchunks;
+  int tile = 0, nsplit = 1;
+  if (fsv_conv_plan(p.Mz, Cout, p.nchunks, nsamp, force_tile, force_split, &tile, &nsplit)) return FSV_ERR_BAD_ARG;
   p.nsplit = nsplit;
   const long long total = (long long)N * outH * outW * Cout;
   // accumulate != 0: `out` was zeroed by the caller and partial results are added atomically (used by the
   // four parity-class launches of a stride-2 data gradient); bias/act/res are not applied in that mode.
   if (accumulate) {
     if (bias || res || act != FSV_ACT_NONE || scale != 1.f) return FSV_ERR_BAD_ARG;
-    if (nsplit < 2) { nsplit = (p.nchunks >= 2) ? 2 : 1; p.nsplit = nsplit; }
+    // nsplit == 1: every output pixel belongs to exactly one parity class and one tile -> plain stores
   } else if (nsplit > 1) {
     if (!p.dense_out) return FSV_ERR_UNSUPPORTED;
     (void)hipMemsetAsync(out, 0, (size_t)total * sizeof(float), stream);

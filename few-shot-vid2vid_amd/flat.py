@@ -1,0 +1,144 @@
+"""Flat parameter / gradient storage, fused Adam and the RCCL gradient exchange.
+
+Replaces, for the hot path, ``torch.optim.Adam`` (models/base_model.py:39-48) and the reference's data-parallel
+wrapper (apex DistributedDataParallel with delay_allreduce=True, models/models.py:40-43; util/distributed.py).
+
+* every parameter of one optimiser is a view into ONE contiguous fp32 buffer, and so is its ``.grad``:
+  the optimiser step is a single fused HIP kernel (csrc/elementwise.hip, fsv_adam_step) and ``zero_grad`` is one
+  memset;
+* with world_size > 1 the gradient buffer is cut into large buckets (default 64 MiB - sized for the point-to-point
+  xGMI links, not for many small NCCL-style messages) and each bucket is all-reduced on a side stream as soon as
+  autograd has produced its last gradient, i.e. overlapped with the rest of backward.  Parameters are laid out in
+  reverse registration order so that buckets complete front to back during backward.  The 1/world_size average is
+  folded into the Adam kernel.  BatchNorm statistics stay per replica (DESIGN.md "Multi-GPU").
+"""
+import torch
+import torch.distributed as dist
+
+from . import ops
+
+
+class FlatAdam:
+    def __init__(self, params, lr, betas=(0.0, 0.999), world_size=1, process_group=None, eps=1e-8, bucket_mb=64):
+        params = [p for p in params if p.requires_grad]
+        if not params:
+            raise ValueError("no trainable parameters")
+        # reverse order: the last layers' gradients (first to be produced by backward) sit at the front
+        self.params = list(reversed(params))
+        self.device = params[0].device
+        self.world_size = world_size
+        self.group = process_group
+        self.betas, self.eps = betas, eps
+        total = sum(p.numel() for p in self.params)
+        self.total = total
+        self.flat_p = torch.empty(total, dtype=torch.float32, device=self.device)
+        self.flat_g = torch.zeros(total, dtype=torch.float32, device=self.device)
+        self.m = torch.zeros_like(self.flat_g)
+        self.v = torch.zeros_like(self.flat_g)
+        self.state = torch.tensor([0.0, 0.0, 0.0, float(lr)], dtype=torch.float32, device=self.device)
+        self.offsets = []
+        off = 0
+        with torch.no_grad():
+            for p in self.params:
+                n = p.numel()
+                self.flat_p[off:off + n].copy_(p.detach().reshape(-1))
+                p.data = self.flat_p[off:off + n].view(p.shape)
+                p.grad = self.flat_g[off:off + n].view(p.shape)
+                self.offsets.append((off, n))
+                off += n
+        # ---- data-parallel buckets ------------------------------------------------------------------------
+        self._armed = False
+        self.buckets = []            # (start, end) element ranges of flat_g
+        self._pending, self._handles = [], []
+        self._param_bucket = {}
+        self.side_stream = None
+        if world_size > 1:
+            cap = bucket_mb * (1 << 20) // 4
+            start, count = 0, 0
+            cur = []
+            for idx, (o, n) in enumerate(self.offsets):
+                cur.append(idx)
+                count += n
+                if count >= cap or idx == len(self.offsets) - 1:
+                    self.buckets.append((start, start + count, list(cur)))
+                    start += count
+                    count, cur = 0, []
+            for b, (_, _, idxs) in enumerate(self.buckets):
+                for i in idxs:
+                    self._param_bucket[i] = b
+            self._remaining = [len(b[2]) for b in self.buckets]
+            self._launched = [False] * len(self.buckets)
+            if self.device.type == 'cuda':
+                self.side_stream = torch.cuda.Stream(device=self.device)
+            for i, p in enumerate(self.params):
+                p.register_post_accumulate_grad_hook(self._make_hook(i))
+
+    # ------------------------------------------------------------------------------------------------ DDP
+    def _make_hook(self, i):
+        def hook(param):
+            if not self._armed:        # gradients produced for another optimiser's step (e.g. D's during the G step)
+                return
+            b = self._param_bucket[i]
+            self._remaining[b] -= 1
+            if self._remaining[b] == 0:
+                self._launch(b)
+        return hook
+
+    def _launch(self, b):
+        if self._launched[b]:
+            return
+        self._launched[b] = True
+        s, e, _ = self.buckets[b]
+        view = self.flat_g[s:e]
+        if self.side_stream is not None:
+            self.side_stream.wait_stream(torch.cuda.current_stream(self.device))
+            with torch.cuda.stream(self.side_stream):
+                h = dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        else:
+            h = dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        self._handles.append(h)
+
+    def _finish_exchange(self):
+        if self.world_size <= 1:
+            return
+        for b in range(len(self.buckets)):       # buckets whose parameters were not all touched this step
+            self._launch(b)
+        for h in self._handles:
+            h.wait()
+        if self.side_stream is not None:
+            torch.cuda.current_stream(self.device).wait_stream(self.side_stream)
+        self._handles = []
+        self._armed = False
+
+    # ------------------------------------------------------------------------------------------------ optimiser API
+    def zero_grad(self, set_to_none=False):
+        """Called by loss_backward right before backward: clears the flat gradient and arms the bucket hooks."""
+        self.flat_g.zero_()
+        if self.world_size > 1:
+            self._remaining = [len(b[2]) for b in self.buckets]
+            self._launched = [False] * len(self.buckets)
+            self._handles = []
+            self._armed = True
+
+    def set_lr(self, lr):
+        self.state[3:4].fill_(float(lr))
+
+    @property
+    def param_groups(self):
+        """torch.optim-style view used by the reference's update_learning_rate (base_model.py:253-256)."""
+        outer = self
+
+        class _Group(dict):
+            def __setitem__(self, k, v):
+                if k == 'lr':
+                    outer.set_lr(v)
+                super().__setitem__(k, v)
+        return [_Group(lr=float(self.state[3]), params=self.params)]
+
+    def step(self):
+        self._finish_exchange()
+        ops.adam_step(self.flat_p, self.flat_g, self.m, self.v, self.state, self.betas[0], self.betas[1], self.eps,
+                      1.0 / self.world_size)
+
+    def state_dict(self):
+        return dict(m=self.m, v=self.v, state=self.state)

@@ -1,0 +1,377 @@
+"""Per-step orchestration of the G/D training hot path: the drop-in for the reference's
+``models.vid2vid_model.Vid2VidModel`` (forward modes 'generator' / 'discriminator'), its loss collector
+(models/loss_collector.py) and ``loss_backward``.
+
+The call protocol is the reference's (train.py:55-62):
+
+    d_losses = model(data_list_t, mode='discriminator');   loss_backward(opt, d_losses, optimizer_D, 1)
+    g_losses, generated, prev = model(data_list_t, mode='generator');   loss_backward(opt, g_losses, optimizer_G, 0)
+
+with ``data_list_t = [tgt_label, tgt_image, flow_gt[2], conf_gt[2], ref_label, ref_image, prev_label, prev_real,
+prev_fake]`` (5-D ``[B, T, C, H, W]`` tensors).  Loss order and names follow loss_collector.py:42-45.
+Networks run on the HIP kernels (networks.py); parameters and gradients live in flat buffers (flat.py) so the
+optimiser is one fused Adam launch and the data-parallel exchange is a handful of large RCCL all-reduces.
+"""
+import os
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import networks, ops
+from .flat import FlatAdam
+
+LOSS_NAMES_G = ['G_GAN', 'G_GAN_Feat', 'G_VGG', 'Gf_GAN', 'Gf_GAN_feat', 'GT_GAN', 'GT_GAN_Feat', 'F_Flow', 'F_Warp',
+                'F_Mask']
+LOSS_NAMES_D = ['D_real', 'D_fake', 'Df_real', 'Df_fake', 'DT_real', 'DT_fake']
+
+
+# ------------------------------------------------------------------------------------------------ label helpers
+def _part_index(pose_ch):
+    """DensePose part id stored as (p / 24) * 2 - 1 in label channel 2 (models/input_process.py:71)."""
+    return (pose_ch / 2 + 0.5) * 24
+
+
+def face_mask_of(pose_ch):
+    """models/input_process.py:80-94: parts 23 / 24 are the face.  pose_ch: [B, H, W] or [B, T, H, W]."""
+    if pose_ch.dim() == 3:
+        pose_ch = pose_ch.unsqueeze(1)
+    part = _part_index(pose_ch)
+    m = ((part > 22.9) & (part < 23.1)) | ((part > 23.9) & (part < 24.1))
+    return m.float()
+
+
+PART_GROUPS = [[0], [1, 2], [3, 4], [5, 6], [7, 9, 8, 10], [11, 13, 12, 14], [15, 17, 16, 18], [19, 21, 20, 22],
+               [23, 24]]
+
+
+def part_masks(pose_ch):
+    """models/input_process.py:64-78: 9 body-part group masks.  pose_ch [B, T, H, W] -> [B, T, 9, H, W]."""
+    part = _part_index(pose_ch)
+    out = []
+    for grp in PART_GROUPS:
+        m = torch.zeros_like(part, dtype=torch.bool)
+        for j in grp:
+            m |= (part > j - 0.1) & (part < j + 0.1)
+        out.append(m)
+    return torch.stack(out, dim=2).float()
+
+
+def valid_labels(opt, pose):
+    """models/input_process.py:97-113."""
+    if 'pose' not in opt.dataset_mode or pose is None:
+        return pose
+    cdim = pose.dim() - 3
+    if opt.pose_type == 'open':
+        return pose.narrow(cdim, 3, pose.shape[cdim] - 3)
+    if opt.remove_face_labels:
+        fm = face_mask_of(pose.select(cdim, 2))
+        if pose.dim() == 5:
+            fm = fm.unsqueeze(2)
+        head = pose.narrow(cdim, 0, 3) * (1 - fm) - fm
+        return torch.cat([head, pose.narrow(cdim, 3, pose.shape[cdim] - 3)], dim=cdim)
+    return pose
+
+
+def fg_mask_of(opt, label, has_fg):
+    """models/input_process.py:52-61 (15x15 dilation of the body channel)."""
+    if not has_fg:
+        return None
+    if label.dim() == 5:
+        label = label[:, 0]
+    mask = label[:, 2:3] if opt.label_nc == 0 else -label[:, 0:1]
+    mask = F.max_pool2d(mask, 15, stride=1, padding=7)
+    return (mask > -1).float()
+
+
+def union_fg(fg, ref_fg, has_fg):
+    return ((fg > 0) | (ref_fg > 0)).float() if has_fg else 1
+
+
+def encode_label(opt, label_map):
+    """models/input_process.py:25-45."""
+    if opt.label_nc == 0:
+        return label_map
+    size = label_map.shape
+    flat = label_map.reshape(-1, *size[-3:])
+    one_hot = torch.zeros(flat.shape[0], opt.label_nc, size[-2], size[-1], dtype=torch.float32, device=label_map.device)
+    one_hot.scatter_(1, flat.long(), 1.0)
+    return one_hot.view(*size[:-3], opt.label_nc, size[-2], size[-1])
+
+
+# ------------------------------------------------------------------------------------------------ losses
+def l1(a, b):
+    return (a - b).abs().mean()
+
+
+def masked_l1(inp, target, mask):
+    """models/networks/loss.py:130-138."""
+    mask = mask.expand_as(inp)
+    if isinstance(target, (int, float)):
+        target = torch.full_like(inp, float(target))
+    return l1(inp * mask, target * mask)
+
+
+def hinge(pred, real, for_discriminator=True):
+    """models/networks/loss.py:69-83."""
+    if for_discriminator:
+        return -torch.min((pred if real else -pred) - 1, pred * 0).mean()
+    return -pred.mean()
+
+
+def gan_loss(preds, real):
+    """GANLoss.__call__ on a list-of-lists prediction (loss.py:92-104): last feature of every scale."""
+    loss = 0
+    for p in preds:
+        loss = loss + hinge(p[-1], real).view(1)
+    return loss / len(preds)
+
+
+class LossCollector:
+    """models/loss_collector.py restated on top of the HIP networks."""
+
+    def __init__(self, opt):
+        self.opt = opt
+        self.pose = 'pose' in opt.dataset_mode
+        self.has_fg = self.pose
+        self.warp_ref = opt.warp_ref
+        self.add_face_D = opt.add_face_D
+        self.concat_ref_for_D = opt.isTrain and opt.netD_subarch == 'n_layers'
+        self.concat_fg_mask_for_D = self.has_fg
+        self.loss_names_G, self.loss_names_D = LOSS_NAMES_G, LOSS_NAMES_D
+        self.loss_names = LOSS_NAMES_G + LOSS_NAMES_D
+        self.tD = 1
+        if not opt.no_vgg_loss or opt.add_face_D:
+            raise NotImplementedError("VGG perceptual loss / face discriminator are the next rows of SURVEY.md 8(f)")
+
+    @staticmethod
+    def zero(ref):
+        return torch.zeros(1, dtype=torch.float32, device=ref.device)
+
+    def discriminate(self, netD, label, fake, real, ref, for_discriminator):
+        """loss_collector.py:47-68: D sees [ref | label | image] with fake and real stacked on the batch axis."""
+        x = torch.cat([fake, real], dim=0)
+        if label is not None:
+            x = torch.cat([label.repeat(2, 1, 1, 1), x], dim=1)
+        if ref is not None and self.concat_ref_for_D:
+            x = torch.cat([ref.repeat(2, 1, 1, 1), x], dim=1)
+        out = netD(x)
+        half = x.shape[0] // 2
+        pred_fake = [[t[:half] for t in scale] for scale in out]
+        pred_real = [[t[half:] for t in scale] for scale in out]
+        if for_discriminator:
+            return [gan_loss(pred_real, True), gan_loss(pred_fake, False)]
+        feat = self.zero(fake)
+        if not self.opt.no_ganFeat_loss:
+            for sf, sr in zip(pred_fake, pred_real):
+                for a, b in zip(sf[:-1], sr[:-1]):
+                    feat = feat + l1(a, b.detach()) / len(pred_fake)
+        return [gan_loss(pred_fake, True), feat * self.opt.lambda_feat]
+
+    def gan_losses(self, netD, tgt_label, reals, fakes, ref_label, ref_image, for_discriminator):
+        """loss_collector.py:87-120 for the per-frame discriminator (no temporal / face branches)."""
+        opt = self.opt
+        total = None
+        for fake, real in zip(fakes, reals):
+            if fake is None:
+                continue
+            lab = tgt_label.reshape(-1, *tgt_label.shape[-3:])
+            real4 = real.reshape(-1, *real.shape[-3:])
+            fake4 = fake.reshape(-1, *fake.shape[-3:])
+            inp = valid_labels(opt, lab)
+            rl = ref_label
+            if self.concat_fg_mask_for_D:
+                inp = torch.cat([inp, fg_mask_of(opt, lab, True)], dim=1)
+                rl = torch.cat([ref_label, fg_mask_of(opt, ref_label, True)], dim=1)
+            ref_concat = torch.cat([rl, ref_image], dim=1)
+            losses = self.discriminate(netD, inp, fake4, real4, ref_concat, for_discriminator)
+            losses = losses + [self.zero(fake4), self.zero(fake4)]           # face-D slots
+            total = losses if total is None else [a + b for a, b in zip(total, losses)]
+        return total
+
+    def flow_losses(self, flow, warped, tgt_image, fg_mask, tgt_label, ref_label):
+        """loss_collector.py:132-162 with flow_gt = None (--no_flow_gt)."""
+        opt = self.opt
+        z = self.zero(tgt_image)
+        warp_loss = z.clone()
+        for f, wimg in zip(flow, warped):
+            if f is not None:
+                warp_loss = warp_loss + l1(wimg, tgt_image)
+        body_diff = None
+        if self.pose and flow[0] is not None:
+            body = part_masks(tgt_label[:, :, 2])
+            ref_body = part_masks(ref_label[:, 2].unsqueeze(1)).expand_as(body)
+            body = body.reshape(-1, *body.shape[-3:])
+            ref_body = ref_body.reshape(-1, *ref_body.shape[-3:])
+            ref_body_warp = ops.resample(ref_body.contiguous(), flow[0])
+            warp_loss = warp_loss + l1(ref_body_warp, body)
+            if self.has_fg:
+                fg, ref_fg = fg_mask_of(opt, tgt_label, True), fg_mask_of(opt, ref_label, True)
+                warp_loss = warp_loss + l1(ops.resample(ref_fg, flow[0]), fg)
+            body_diff = (ref_body_warp - body).abs().sum(dim=1, keepdim=True)
+        return z * opt.lambda_flow, warp_loss * opt.lambda_flow, body_diff
+
+    def mask_losses(self, flow_mask, fake_image, warped, tgt_label, tgt_image, fg_mask, ref_fg_mask, body_diff):
+        """loss_collector.py:164-204."""
+        opt = self.opt
+        loss = self.zero(tgt_image)
+        for m, wimg in zip(flow_mask, warped):
+            if m is None:
+                continue
+            conf = torch.clamp(1 - (wimg - tgt_image).abs().sum(dim=1, keepdim=True), 0, 1)
+            loss = loss + masked_l1(m, 0.0, conf) + masked_l1(m, 1.0, 1 - conf)
+        if self.pose and self.warp_ref:
+            m_ref = flow_mask[0]
+            h, w = tgt_label.shape[-2:]
+            face = face_mask_of(tgt_label[:, :, 2]).view(-1, 1, h, w)
+            face = F.avg_pool2d(face, 15, stride=1, padding=7)
+            loss = loss + masked_l1(m_ref, 0.0, face)
+            if opt.spade_combine:
+                loss = loss + masked_l1(fake_image, warped[0].detach(), face)
+            fg_diff = ((ref_fg_mask - fg_mask) > 0).float()
+            loss = loss + masked_l1(m_ref, 1.0, fg_diff) + masked_l1(m_ref, 1.0, body_diff)
+        return loss * opt.lambda_mask
+
+
+def loss_backward(opt, losses, optimizer, loss_id):
+    """models/loss_collector.py:217-228 (fp32 path): sum of means -> zero_grad -> backward -> optimiser step."""
+    losses = [torch.mean(x) if not isinstance(x, int) else x for x in losses]
+    loss = sum(losses)
+    optimizer.zero_grad()
+    loss.backward()
+    optimizer.step()
+    return losses
+
+
+# ------------------------------------------------------------------------------------------------ the model
+class Vid2VidModel(nn.Module):
+    """Drop-in for models.vid2vid_model.Vid2VidModel on the training path (modes 'generator', 'discriminator')."""
+
+    def name(self):
+        return 'Vid2VidModel'
+
+    def initialize(self, opt, epoch=0):
+        self.opt = opt
+        self.isTrain = opt.isTrain
+        self.pose = 'pose' in opt.dataset_mode
+        self.has_fg = self.pose
+        self.add_face_D = opt.add_face_D
+        self.temporal = False
+        self.old_lr = opt.lr
+        self.save_dir = os.path.join(getattr(opt, 'checkpoints_dir', './checkpoints'), getattr(opt, 'name', 'test'))
+        if getattr(opt, 'refine_face', False):
+            raise NotImplementedError("refine_face")
+        self.lossCollector = LossCollector(opt)
+        torch.manual_seed(0)            # reference: set_random_seed(0) before building so replicas start identical
+        opt.for_face = False
+        self.netG = networks.define_G(opt)
+        input_nc = opt.label_nc if (opt.label_nc != 0 and not self.pose) else opt.input_nc
+        netD_input_nc = input_nc + opt.output_nc + (1 if self.lossCollector.concat_fg_mask_for_D else 0)
+        if self.lossCollector.concat_ref_for_D:
+            netD_input_nc *= 2
+        self.netD = networks.define_D(opt, netD_input_nc, opt.ndf, opt.n_layers_D, opt.norm_D, opt.netD_subarch,
+                                      opt.num_D, not opt.no_ganFeat_loss)
+        self.netDf = None
+        self.netDT = None
+        self.optimizer_G = self.optimizer_D = None
+        return self
+
+    # optimisers are created once the module sits on its device (flat buffers are device allocations)
+    def build_optimizers(self, world_size=1, process_group=None):
+        opt = self.opt
+        if opt.no_TTUR:
+            beta1, beta2, g_lr, d_lr = opt.beta1, 0.999, opt.lr, opt.lr
+        else:
+            beta1, beta2, g_lr, d_lr = 0.0, opt.beta2, opt.lr / 2, opt.lr * 2
+        self.optimizer_G = FlatAdam(list(self.netG.parameters()), g_lr, (beta1, beta2), world_size, process_group)
+        self.optimizer_D = FlatAdam(list(self.netD.parameters()), d_lr, (beta1, beta2), world_size, process_group)
+        return self.optimizer_G, self.optimizer_D
+
+    def update_learning_rate(self, epoch):
+        """models/base_model.py:245-257."""
+        opt = self.opt
+        new_lr = opt.lr * (1 - (epoch - opt.niter) / (opt.niter_decay + 1))
+        g_lr, d_lr = (new_lr, new_lr) if opt.no_TTUR else (new_lr / 2, new_lr * 2)
+        self.optimizer_G.set_lr(g_lr)
+        self.optimizer_D.set_lr(d_lr)
+        self.old_lr = new_lr
+
+    def save_networks(self, which_epoch):
+        """models/base_model.py:219-227 (same file names, CPU state_dicts)."""
+        os.makedirs(self.save_dir, exist_ok=True)
+        for net, label in ((self.netG, 'G'), (self.netD, 'D')):
+            sd = {k: v.detach().cpu() for k, v in net.state_dict().items()}
+            torch.save(sd, os.path.join(self.save_dir, '%s_net_%s.pth' % (which_epoch, label)))
+
+    # ---------------------------------------------------------------------------------------------- forward
+    def forward(self, data_list, save_images=False, mode='inference', dummy_bs=0):
+        opt = self.opt
+        tgt_label, tgt_image, flow_gt, conf_gt, ref_label, ref_image, p_label, p_real, p_fake = data_list
+        tgt_label, ref_label = encode_label(opt, tgt_label), encode_label(opt, ref_label)
+        prevs = [p_label, p_real, p_fake]
+        if mode == 'generator':
+            losses, generated, prev = self.forward_generator(tgt_label, tgt_image, ref_label, ref_image, prevs)
+            return losses, generated if save_images else [], prev
+        if mode == 'discriminator':
+            return self.forward_discriminator(tgt_label, tgt_image, ref_label, ref_image, prevs)
+        raise NotImplementedError("inference / finetune are outside the hot-path scope (SURVEY.md section 8f rank 4)")
+
+    def generate_images(self, tgt_labels, tgt_images, ref_labels, ref_images, prevs):
+        """vid2vid_model.py:130-158 with n_frames_per_gpu == 1."""
+        opt = self.opt
+        ref_labels_valid = valid_labels(opt, ref_labels)
+        b, _, _, h, w = tgt_labels.shape
+        tgt_label_t = tgt_labels[:, 0]
+        tgt_label_valid = valid_labels(opt, tgt_label_t)
+        tgt_image = tgt_images[:, 0]
+        prev_t = [p.contiguous().view(b, -1, h, w) if p is not None else None for p in (prevs[0], prevs[2])]
+        fake, flow, mask, raw, warped, _, _, _, _ = self.netG(tgt_label_valid, ref_labels_valid, ref_images, prev_t)
+        ref_label_valid, ref_label_t, ref_image_t = ref_labels_valid[:, 0], ref_labels[:, 0], ref_images[:, 0]
+        fg, ref_fg = fg_mask_of(opt, tgt_label_t, self.has_fg), fg_mask_of(opt, ref_label_t, self.has_fg)
+        if raw is not None:
+            raw = raw * union_fg(fg, ref_fg, self.has_fg)
+        n_prev = opt.n_frames_G - 1
+        new_prevs = []
+        for old, now in zip(prevs, (tgt_label_valid, tgt_image, fake)):
+            if old is None:
+                new_prevs.append(now.detach().unsqueeze(1).repeat(1, n_prev, 1, 1, 1))
+            else:
+                new_prevs.append(torch.cat([old[:, 1:], now.detach().unsqueeze(1)], dim=1).detach())
+        return (fake, raw, warped, flow, mask), (fg, ref_fg), (ref_label_valid, ref_image_t), new_prevs
+
+    def forward_discriminator(self, tgt_label, tgt_image, ref_labels, ref_images, prevs):
+        """vid2vid_model.py:106-128."""
+        with torch.no_grad():
+            (fake, raw, _, _, _), (fg, ref_fg), (ref_label, ref_image), _ = \
+                self.generate_images(tgt_label, tgt_image, ref_labels, ref_images, prevs)
+        fg_union = union_fg(fg, ref_fg, self.has_fg)
+        real = tgt_image[:, 0]
+        losses = self.lossCollector.gan_losses(self.netD, tgt_label, [real, real * fg_union], [fake, raw], ref_label,
+                                               ref_image, for_discriminator=True)
+        return [l.view(1, 1) for l in losses]
+
+    def forward_generator(self, tgt_label, tgt_image, ref_labels, ref_images, prevs):
+        """vid2vid_model.py:62-104."""
+        lc = self.lossCollector
+        (fake, raw, warped, flow, mask), (fg, ref_fg), (ref_label, ref_image), prevs_new = \
+            self.generate_images(tgt_label, tgt_image, ref_labels, ref_images, prevs)
+        fg_union = union_fg(fg, ref_fg, self.has_fg)
+        real = tgt_image[:, 0]
+        g_gan, g_feat, gf_gan, gf_feat = lc.gan_losses(self.netD, tgt_label, [real, real * fg_union], [fake, raw],
+                                                       ref_label, ref_image, for_discriminator=False)
+        z = lc.zero(fake)
+        f_flow, f_warp, body_diff = lc.flow_losses(flow, warped, real, fg, tgt_label, ref_label)
+        f_mask = lc.mask_losses(mask, fake, warped, tgt_label, real, fg, ref_fg, body_diff)
+        losses = [g_gan, g_feat, z.clone(), gf_gan, gf_feat, z.clone(), z.clone(), f_flow, f_warp, f_mask]
+        up = lambda t: t.unsqueeze(1) if t is not None else None   # back to the reference's [B, T, ...] outputs
+        generated = [up(fake), up(raw), [up(t) for t in warped], [up(t) for t in flow], [up(t) for t in mask], None]
+        return [l.view(1, 1) for l in losses], generated, prevs_new
+
+
+def create_model(opt, epoch=0, device=None):
+    """models/models.py:16-38 without the DataParallel wrapper: returns (model, optimizers)."""
+    model = Vid2VidModel().initialize(opt, epoch)
+    if device is not None:
+        model = model.to(device)
+    model.train()
+    return model

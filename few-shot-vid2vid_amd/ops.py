@@ -14,7 +14,7 @@ import ctypes
 
 import torch
 
-from . import lib
+from . import lib, profile
 from .conv import (ACT_LRELU, ACT_NONE, ACT_SIGMOID, ACT_TANH, Geom, conv_dgrad, conv_forward, conv_wgrad, empty_nhwc,
                    prep_weight, to_nhwc)
 
@@ -312,9 +312,10 @@ class _SpadeFn(torch.autograd.Function):
             bbs_stride.append(c if per_sample else 0)
         hout = torch.empty_like(x)
         lib.check_device(x, *maps)
-        lib.call("fsv_spade_mod_fwd", lib.ptr(x), lib.ptr(mean), lib.ptr(rstd), lib.ptr(hout), nmaps, _pp(maps),
-                 _pp(wg_t), _pp(wb_t), _pp(bg_c), _pp(bb_c), lib.int_array(chs + [0]), _ll(wbs_stride + [0]),
-                 _ll(bbs_stride + [0]), n, h * w, c, ldw, 0, act, lib.stream_ptr())
+        with profile.scope('fsv_spade_mod_kernel', 2.0 * n * h * w * c * 2 * sum(chs)):
+            lib.call("fsv_spade_mod_fwd", lib.ptr(x), lib.ptr(mean), lib.ptr(rstd), lib.ptr(hout), nmaps, _pp(maps),
+                     _pp(wg_t), _pp(wb_t), _pp(bg_c), _pp(bb_c), lib.int_array(chs + [0]), _ll(wbs_stride + [0]),
+                     _ll(bbs_stride + [0]), n, h * w, c, ldw, 0, act, lib.stream_ptr())
         ctx.nmaps, ctx.act = nmaps, act
         ctx.batch_stats = bool(training or run_mean is None)
         ctx.save_for_backward(x, hout, mean, rstd, *maps, *wgs, *wbs, *bgs, *bbs)

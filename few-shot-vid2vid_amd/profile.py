@@ -1,0 +1,81 @@
+"""In-process kernel timing for bench.py's `roofline` object.
+
+When enabled, the host wrappers of the MFMA kernels bracket every launch with a pair of HIP events recorded on the
+stream the kernel is launched on (torch.cuda.Event records on torch's current stream, which is the stream handed to
+the C ABI).  `summary()` turns the pairs into per-kernel averages: algorithmic FLOPs per launch (2 * MAC of the
+convolution / GEMM the launch computes) divided by the average launch duration.
+"""
+import ctypes
+
+import torch
+
+from . import lib
+
+_enabled = False
+_records = []          # (label, flops, ev0, ev1)
+FP32_MFMA_PEAK = 157.3e12
+
+TILE_NAMES = {0: '128x128', 1: '128x64', 2: '128x32', 3: '256x32', 4: '64x64'}
+
+
+def enable():
+    global _enabled, _records
+    _enabled, _records = True, []
+
+
+def disable():
+    global _enabled
+    _enabled = False
+
+
+def enabled():
+    return _enabled
+
+
+class scope:
+    def __init__(self, label, flops):
+        self.label, self.flops = label, flops
+
+    def __enter__(self):
+        if _enabled and not lib.is_emu():
+            self.e0 = torch.cuda.Event(enable_timing=True)
+            self.e1 = torch.cuda.Event(enable_timing=True)
+            self.e0.record()
+        return self
+
+    def __exit__(self, *exc):
+        if _enabled and not lib.is_emu():
+            self.e1.record()
+            _records.append((self.label, self.flops, self.e0, self.e1))
+        return False
+
+
+def conv_label(mz, cout, nchunks, nsamp, vec4, force_tile=-1, force_split=0):
+    lib.register_sigs({"fsv_conv_plan": [ctypes.c_int] * 6 + [ctypes.POINTER(ctypes.c_int)] * 2})
+    tile, nsplit = ctypes.c_int(0), ctypes.c_int(1)
+    lib.call("fsv_conv_plan", mz, cout, nchunks, nsamp, force_tile, force_split, ctypes.byref(tile), ctypes.byref(nsplit))
+    return 'fsv_conv_igemm_kernel<%s,V%d>' % (TILE_NAMES[tile.value], 4 if vec4 else 1)
+
+
+def summary():
+    torch.cuda.synchronize()
+    agg = {}
+    for label, flops, e0, e1 in _records:
+        a = agg.setdefault(label, [0, 0.0, 0.0])
+        a[0] += 1
+        a[1] += flops
+        a[2] += e0.elapsed_time(e1) * 1e-3
+    by_kernel = {}
+    for label, (n, fl, t) in agg.items():
+        by_kernel[label] = dict(launches=n, avg_us=round(t / n * 1e6, 2), total_ms=round(t * 1e3, 3),
+                                tflops=round(fl / t / 1e12, 2) if t > 0 else 0.0,
+                                gflop_per_launch=round(fl / n / 1e9, 3))
+    dominant = None
+    if agg:
+        lab = max(agg, key=lambda k: agg[k][2])
+        n, fl, t = agg[lab]
+        ach = fl / t / 1e12
+        dominant = dict(kernel=lab, bound='mfma', achieved=round(ach, 2), peak=FP32_MFMA_PEAK / 1e12, unit='TFLOP/s',
+                        frac=round(ach / (FP32_MFMA_PEAK / 1e12), 4), traffic=None, launches=n,
+                        avg_launch_us=round(t / n * 1e6, 2), gflop_per_launch=round(fl / n / 1e9, 3))
+    return dict(dominant=dominant, by_kernel=by_kernel)

@@ -224,3 +224,78 @@ def smoke(device):
     """Used by __graft_entry__.smoke(): one tiny forward+backward of G and D on the GPU, checked against the oracle."""
     check_generator(device, tiny_opt(ngf=8, nff=8, warp_ref=True, spade_combine=True), b=2)
     check_discriminator(device, tiny_opt(ndf=8), b=1)
+
+
+def _model():
+    import fsv2v_amd  # noqa: F401
+    return import_module('few-shot-vid2vid_amd.model')
+
+
+def _oracle_iteration(sdG0, sdD0, cfg, data, dtype):
+    """One reference iteration (train.py:58-62) on the oracle: D step then G step; returns losses and gradients."""
+    tl, ti, rl, ri = [t.to(dtype) for t in data]
+
+    def leafify(sd0):
+        sd = {}
+        for k, v in sd0.items():
+            t = v.clone().to(dtype).detach() if v.is_floating_point() else v.clone()
+            if v.is_floating_point() and ('running' not in k) and not k.endswith(('_u', '_v')):
+                t.requires_grad_(True)
+            sd[k] = t
+        return sd
+    sdG, sdD = leafify(sdG0), leafify(sdD0)
+    d_losses = O.d_step_losses(sdG, sdD, cfg, tl, ti, rl, ri)
+    sum(l.mean() for l in d_losses).backward()
+    gD = {k: v.grad.clone() for k, v in sdD.items() if v.is_floating_point() and v.grad is not None}
+    # (the optimiser step is checked separately in check_adam; gradients are what the comparison needs)
+    for v in list(sdG.values()) + list(sdD.values()):
+        if v.is_floating_point() and v.grad is not None:
+            v.grad = None
+    g_losses, gen = O.g_step_losses(sdG, sdD, cfg, tl, ti, rl, ri)
+    sum(l.mean() for l in g_losses.values()).backward()
+    gG = {k: v.grad.clone() for k, v in sdG.items() if v.is_floating_point() and v.grad is not None}
+    return d_losses, gD, g_losses, gG, gen
+
+
+def check_train_step(device, opt, b=2, tol=1e-3, seed=21):
+    """Full D-step + G-step of the product model (flat Adam included) against the oracle."""
+    M = _model()
+    model = M.create_model(opt)
+    sdG0, sdD0 = fill_state(model.netG), fill_state(model.netD)
+    model = model.to(device).train()
+    opt_G, opt_D = model.build_optimizers()
+    opt_G.set_lr(0.0); opt_D.set_lr(0.0)          # keep weights fixed so that both steps see the same parameters
+    h, w = int(opt.fineSize / opt.aspect_ratio), opt.fineSize
+    nl = opt.label_nc if opt.label_nc != 0 else opt.input_nc
+    data = synth_pose_inputs(b, h, w, seed, nl)
+    cfg = O.cfg_from_opt(opt)
+    r32 = _oracle_iteration(sdG0, sdD0, cfg, data, torch.float32)
+    r64 = _oracle_iteration(sdG0, sdD0, cfg, data, torch.float64)
+    tl, ti, rl, ri = [t.to(device) for t in data]
+    data_list = [tl, ti, [None, None], [None, None], rl, ri, None, None, None]
+    d_losses = model(data_list, mode='discriminator')
+    d_losses = M.loss_backward(opt, d_losses, opt_D, 1)
+    for i, name in enumerate(('D_real', 'D_fake')):
+        _close_vs64(name, d_losses[i].view(1), r32[0][i].view(1), r64[0][i].view(1), tol)
+    sd32 = {k: _G(v) for k, v in r32[1].items()}
+    sd64 = {k: _G(v) for k, v in r64[1].items()}
+    compare_grads(model.netD, sd32, sd64, tol * 5)
+    g_losses, generated, prev = model(data_list, save_images=True, mode='generator')
+    g_losses = M.loss_backward(opt, g_losses, opt_G, 0)
+    names = M.LOSS_NAMES_G
+    for k in ('G_GAN', 'G_GAN_Feat', 'F_Warp', 'F_Mask'):
+        _close_vs64(k, g_losses[names.index(k)].view(1), r32[2][k].view(1), r64[2][k].view(1), tol)
+    sd32 = {k: _G(v) for k, v in r32[3].items()}
+    sd64 = {k: _G(v) for k, v in r64[3].items()}
+    for name, _ in model.netG.named_parameters():      # parameters the losses do not reach
+        sd32.setdefault(name, _G(None)); sd64.setdefault(name, _G(None))
+    worst = compare_grads(model.netG, sd32, sd64, tol * 5)
+    _close_vs64('fake image', generated[0][:, 0], r32[4]['fake'], r64[4]['fake'], tol)
+    return worst
+
+
+class _G:
+    """tiny adaptor so compare_grads can read `.grad` from a plain tensor dict"""
+
+    def __init__(self, g):
+        self.grad = g

@@ -17,3 +17,13 @@ def test_generator_adaptive_spade_tiny(emu_lib):
 
 def test_generator_warp_combine_tiny(emu_lib):
     mc.check_generator(DEV, mc.tiny_opt(warp_ref=True, spade_combine=True), b=2)
+
+
+def test_train_step_pose_warp_combine_tiny(emu_lib):
+    """D step + G step (losses, all gradients, flat Adam plumbing) of BASELINE configs[2] flags, tiny width."""
+    mc.check_train_step(DEV, mc.tiny_opt(warp_ref=True, spade_combine=True, remove_face_labels=True), b=2)
+
+
+def test_train_step_face_tiny(emu_lib):
+    """BASELINE configs[0] flavour: fewshot_face, adaptive_spade only, B = 1."""
+    mc.check_train_step(DEV, mc.tiny_opt(dataset_mode='fewshot_face', input_nc=1), b=1)
