@@ -1,0 +1,122 @@
+/* fsv2v.h - C ABI of libfsv2v_hip.so: the MI355X (gfx950) kernels behind the few-shot-vid2vid G/D training step.
+ *
+ * The reference (NVlabs/few-shot-vid2vid) has no FFI for this path - its operator seam is Python name binding
+ * (SURVEY.md section 8b): models.networks.base_network.{batch_conv,resample}, normalization.SPADE,
+ * architecture.SPADEResnetBlock, generator.{LabelEmbedder,FlowGenerator}, discriminator.NLayerDiscriminator, which in
+ * turn call torch ATen (F.conv2d, F.grid_sample, BatchNorm, ...).  Its only native boundary is the pybind pattern of
+ * the FlowNet2 extensions (models/networks/flownet2_pytorch/networks/resample2d_package/resample2d_cuda.cc:6-31:
+ * plain tensors in, int status out, kernels enqueued on the caller's stream).  This header follows that convention:
+ *
+ *   - every function returns 0 (FSV_OK) or a negative fsv_status; nothing throws or aborts across the boundary;
+ *   - all pointers are device pointers owned by the caller (PyTorch's caching allocator); the library allocates
+ *     nothing and keeps no state; scratch buffers are passed in explicitly;
+ *   - work is only enqueued on `stream` (a hipStream_t); calls are re-entrant and graph-capturable
+ *     (only kernels and hipMemsetAsync are issued);
+ *   - activations are fp32 NHWC ("channels last"); convolution weights are fp32 OIHW at the boundary and are
+ *     re-arranged K-major by fsv_prep_weight.
+ *
+ * Each entry point cites the reference code it replaces (paths relative to the reference root).
+ */
+#ifndef FSV2V_H
+#define FSV2V_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* fsv_stream_t; /* hipStream_t */
+
+enum fsv_status { FSV_OK = 0, FSV_ERR_BAD_ARG = -1, FSV_ERR_UNSUPPORTED = -2, FSV_ERR_LAUNCH = -3 };
+enum fsv_act { FSV_ACT_NONE = 0, FSV_ACT_LRELU = 1 /* leaky_relu(0.2), architecture.py:15-17 */, FSV_ACT_TANH = 2,
+               FSV_ACT_SIGMOID = 3 };
+
+/* ---- convolution family (csrc/conv_igemm.hip) -----------------------------------------------------------------
+ * Replaces F.conv2d at architecture.py:22-27,60,81-84; generator.py:112-131,479-504,541-572;
+ * discriminator.py:67-88; nn.Linear at generator.py:103-110; batch_conv at base_network.py:56-71 and, through
+ * autograd, their cudnn backward kernels.
+ *
+ * out[n, oy*osy+ooy, ox*osx+oox, co] = act(( sum_t sum_ci in[n, oy*sy+ty[t], ox*sx+tx[t], ci] * wt[t*Cin+ci][co]
+ *                                            + bias[co] ) * scale) + res[...]
+ * taps outside the input read as zero.  wt: K-major [Kpad][ldw] from fsv_prep_weight; per_sample != 0 selects one
+ * weight matrix (stride w_bstride) and bias (stride b_bstride) per sample n.  accumulate != 0: `out` was zeroed by
+ * the caller, results are added (used for the four parity classes of a stride-2 data gradient).
+ * force_tile / force_split: -1 / 0 = automatic. */
+int fsv_conv_gather_fwd(const float* in, const float* wt, const float* bias, const float* res, float* out,
+                        int N, int H, int W, int Cin, int OH, int OW, int Cout,
+                        int ntaps, const int* ty, const int* tx, int sy, int sx,
+                        int outH, int outW, int osy, int osx, int ooy, int oox,
+                        int ldw, long long w_bstride, long long b_bstride, int per_sample,
+                        int act, float scale, int force_tile, int force_split, int accumulate, fsv_stream_t stream);
+
+/* dwt[t*Cin+ci][co] = sum_{n,oy,ox} in[n, oy*sy+ty[t], ox*sx+tx[t], ci] * dout[n, oy, ox, co]  (weight gradient) */
+int fsv_conv_wgrad(const float* in, const float* dout, float* dwt,
+                   int N, int H, int W, int Cin, int OH, int OW, int Cout,
+                   int ntaps, const int* ty, const int* tx, int sy, int sx,
+                   int ldw, int Kpad, long long w_bstride, int per_sample, int force_split, fsv_stream_t stream);
+
+/* OIHW <-> K-major re-arrangement with an optional device scalar multiplier (the spectral-norm 1/sigma).
+ * mode 0: wt[j*Cin+ci][co] = s*w[co][ci][kh_j][kw_j]; mode 1 (data gradient): wt[j*Cout+co][ci] = ...;
+ * mode 2: inverse of mode 0 (gradients back to OIHW). */
+int fsv_prep_weight(const float* w, float* wt, const float* scale_ptr, int mode, int nbatch,
+                    int Cout, int Cin, int KH, int KW, int ntaps, const int* kh, const int* kw,
+                    int Kpad, int ldw, long long w_bstride, long long wt_bstride, fsv_stream_t stream);
+
+/* tile / split-K plan the launcher will use (exported so host-side profilers label launches consistently) */
+int fsv_conv_plan(int Mz, int Cout, int nchunks, int nsamp, int force_tile, int force_split, int* tile_out,
+                  int* nsplit_out);
+
+/* ---- SPADE (csrc/spade.hip) - replaces SPADE.forward normalization.py:37-52 + actvn architecture.py:95-97 --------
+ * h = act( (...((x - mean) * rstd) * (1 + g_0) + b_0 ...) * (1 + g_{n-1}) + b_{n-1} ),  g_k = map_k @ Wg_k + bg_k.
+ * One launch; gamma/beta are MFMA accumulators and never reach HBM. */
+int fsv_spade_mod_fwd(const float* x, const float* mean, const float* rstd, float* h,
+                      int nmaps, const float* const* maps, const float* const* wg, const float* const* wb,
+                      const float* const* bg, const float* const* bb, const int* ch, const long long* w_bstride,
+                      const long long* b_bstride, int N, int HW, int C, int ldw, long long stat_bstride, int act,
+                      fsv_stream_t stream);
+/* element-wise part of the backward: from materialised gamma|beta ([P][2C] per map) to d(gamma|beta) and d(xhat) */
+int fsv_spade_bwd_elem(const float* x, const float* mean, const float* rstd, const float* dh, const float* h,
+                       int nmaps, const float* const* gb, float* const* dgb, float* dxhat,
+                       int N, int HW, int C, long long stat_bstride, int act, fsv_stream_t stream);
+
+/* ---- normalisation (csrc/norm.hip) - BatchNorm (apex SyncBatchNorm) normalization.py:33,80; InstanceNorm :35,82 ----
+ * tensors are [G][P][C]: BatchNorm G=1, P=N*H*W; InstanceNorm G=N, P=H*W.  workspace: fsv_norm_workspace_doubles(). */
+int fsv_norm_workspace_doubles(int G, int P, int C);
+int fsv_norm_stats(const float* x, double* workspace, float* mean, float* rstd, int G, int P, int C, float eps,
+                   float* run_mean, float* run_var, float momentum, fsv_stream_t stream);
+int fsv_norm_apply(const float* x, const float* mean, const float* rstd, const float* w, const float* b, float* y,
+                   int G, int P, int C, int act, fsv_stream_t stream);
+int fsv_norm_bwd(const float* dy, const float* y, const float* x, const float* mean, const float* rstd, const float* w,
+                 double* workspace, float* s1, float* s2, float* dx, float* dw, float* db, int G, int P, int C, int act,
+                 fsv_stream_t stream);
+int fsv_colsum(const float* x, double* workspace, float* out, int G, int P, int C, fsv_stream_t stream);
+
+/* ---- flow warp (csrc/warp.hip) - replaces resample/get_grid base_network.py:13-37 (F.grid_sample bilinear, border,
+ * align_corners=True); tap indices are bit-identical to ATen's.  strides in elements: (batch, channel, y, x). ------ */
+int fsv_warp_fwd(const float* img, const float* flow, const float* lin_x, const float* lin_y, float* out, int* taps,
+                 int B, int C, int H, int W, const long long* img_strides, const long long* flow_strides,
+                 const long long* out_strides, fsv_stream_t stream);
+int fsv_warp_bwd(const float* img, const float* flow, const float* lin_x, const float* lin_y, const float* gout,
+                 float* gimg, float* gflow, int B, int C, int H, int W, const long long* img_strides,
+                 const long long* flow_strides, const long long* gout_strides, const long long* gimg_strides,
+                 const long long* gflow_strides, fsv_stream_t stream);
+
+/* ---- spectral norm (csrc/specnorm.hip) - torch.nn.utils.spectral_norm at architecture.py:60,81-84 etc. ----------- */
+int fsv_sn_power_iter(const float* W, float* u, float* v, float* scratch, float* sig, int R, int Cc, float eps,
+                      int training, fsv_stream_t stream);
+int fsv_sn_backward(const float* dWsn, const float* W, const float* u, const float* v, const float* sig, double* part,
+                    float* dW, int R, int Cc, fsv_stream_t stream);
+
+/* ---- element-wise helpers and the optimiser (csrc/elementwise.hip) ----------------------------------------------
+ * nearest x2 up-sampling (generator.py:124, nn.Upsample), activations, Adam (base_model.py:39-48). */
+int fsv_upsample2x_fwd(const float* x, float* y, int N, int H, int W, int C, fsv_stream_t stream);
+int fsv_upsample2x_bwd(const float* dy, float* dx, int N, int H, int W, int C, fsv_stream_t stream);
+int fsv_act_fwd(const float* x, float* y, long long total, int act, fsv_stream_t stream);
+int fsv_act_bwd(const float* dy, const float* y, float* dx, long long total, int act, float scale, fsv_stream_t stream);
+/* state = {t, 1-beta1^t, 1-beta2^t, lr} on the device; gscale pre-multiplies the gradient (1/world_size) */
+int fsv_adam_step(float* param, const float* grad, float* m, float* v, float* state, long long n, float beta1,
+                  float beta2, float eps, float gscale, fsv_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FSV2V_H */

@@ -27,7 +27,7 @@ def test_generator_pose_warp_combine(hip_lib):
 
 
 def test_generator_pose_warp_blend(hip_lib):
-    mc.check_generator(dev(), mc.tiny_opt(ngf=8, nff=8, warp_ref=True), b=2)
+    mc.check_generator(dev(), mc.tiny_opt(ngf=8, nff=8, warp_ref=True, fineSize=128, loadSize=128), b=2)
 
 
 def test_train_step_pose_warp_combine(hip_lib):
