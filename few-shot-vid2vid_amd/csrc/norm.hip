@@ -9,64 +9,162 @@
 // short run, fp64 across threads and blocks) followed by a one-block-per-channel-slab finalize.
 #include "fsv_common.h"
 
-#define FSV_RED_ROWS 2048   // pixels per partial-reduction block
+// ---- two-value column reductions over [G][P][C] -------------------------------------------------------------
+// One template serves the three reductions of this file:
+//   STATS  : (sum x, sum x^2)                           forward statistics
+//   BWD    : (sum d, sum d * xhat), d = dy * act'(y)     normalisation backward
+//   COLSUM : (sum x, -)                                  bias gradients
+// Grid = (pixel chunks, channel slabs, groups).  A block covers TX column units (float4 = 4 channels when
+// C % 4 == 0) x TY = 256/TX rows in flight; every thread keeps 4 independent row streams so that >= 4 vector loads
+// per input are outstanding (these kernels are pure HBM streams).  Per-thread fp32 partials over a short run are
+// combined in fp64 across the block and written as part[g][chunk][c][2]; a finalize kernel sums the chunks.
+struct RedPlan { int V, CU, TX, TY, nslabs, rows_per_blk, nchunks; };
 
-// thread mapping for [P][C] tiles: q = channel quad (or scalar channel), rows strided by 256/Q
-struct RowMap {
-  int Q, rows_per_pass, q, r;
-  bool active;
-};
-__device__ __forceinline__ RowMap fsv_rowmap(int ncolunits, int tid) {
-  RowMap m;
-  m.Q = ncolunits < 256 ? ncolunits : 256;
-  m.rows_per_pass = 256 / m.Q;
-  m.q = tid % m.Q;
-  m.r = tid / m.Q;
-  m.active = m.r < m.rows_per_pass;
-  return m;
+static inline RedPlan fsv_red_plan(int G, int P, int C) {
+  RedPlan r;
+  r.V = (C % 4 == 0) ? 4 : 1;
+  r.CU = C / r.V;
+  int cap = (r.V == 4) ? 32 : 64;
+  r.TX = r.CU < cap ? r.CU : cap;
+  r.TY = 256 / r.TX;
+  r.nslabs = (r.CU + r.TX - 1) / r.TX;
+  long long want = (2048 + (long long)r.nslabs * G - 1) / ((long long)r.nslabs * G);   // chunks for ~2048 blocks
+  long long maxc = ((long long)P + r.TY * 4 - 1) / (r.TY * 4);                          // >= 4 rows per thread
+  long long chunks = want < maxc ? want : maxc;
+  if (chunks < 1) chunks = 1;
+  r.rows_per_blk = (int)(((long long)P + chunks - 1) / chunks);
+  r.nchunks = (P + r.rows_per_blk - 1) / r.rows_per_blk;
+  return r;
 }
 
-// ---- forward statistics -------------------------------------------------------------------------------------
-// part[g][chunk][c][2] (double): sum, sum of squares over the chunk's pixel range
-__global__ __launch_bounds__(256) void fsv_stats_partial_kernel(const float* x, double* part, int P, int C, int nchunks) {
-  __shared__ double red[256 * 2];
-  const int g = blockIdx.y, chunk = blockIdx.x;
-  const int p0 = chunk * FSV_RED_ROWS;
-  const int p1 = (p0 + FSV_RED_ROWS < P) ? p0 + FSV_RED_ROWS : P;
-  const float* xg = x + (long long)g * P * C;
-  const RowMap m = fsv_rowmap(C, threadIdx.x);
-  for (int c0 = 0; c0 < C; c0 += m.Q) {
-    const int c = c0 + m.q;
-    float s = 0.f, s2 = 0.f;
-    if (m.active && c < C)
-      for (int p = p0 + m.r; p < p1; p += m.rows_per_pass) {
-        float v = xg[(long long)p * C + c];
-        s += v; s2 += v * v;
+#define FSV_RED_STATS 0
+#define FSV_RED_BWD 1
+#define FSV_RED_COLSUM 2
+
+__device__ __forceinline__ float fsv_act_grad(float dy, float y, int act) {
+  if (act == FSV_ACT_LRELU) return y > 0.f ? dy : 0.2f * dy;
+  if (act == FSV_ACT_TANH) return dy * (1.f - y * y);
+  if (act == FSV_ACT_SIGMOID) return dy * y * (1.f - y);
+  return dy;
+}
+
+struct RedP {
+  const float* a;       // STATS/COLSUM: x;  BWD: dy
+  const float* y;       // BWD: activated output (may be null when act == none)
+  const float* x;       // BWD: normalisation input
+  const float* mean;
+  const float* rstd;
+  double* part;
+  int P, C, CU, TX, TY, rows_per_blk, nchunks, act;
+};
+
+template <int MODE, int V>
+__global__ __launch_bounds__(256) void fsv_red2_kernel(RedP p) {
+  __shared__ float red[256 * 2 * V];
+  const int chunk = blockIdx.x, slab = blockIdx.y, g = blockIdx.z;
+  const int tx = threadIdx.x % p.TX, ty = threadIdx.x / p.TX;
+  const int cu = slab * p.TX + tx;
+  const bool active = ty < p.TY && cu < p.CU;
+  const int r0 = chunk * p.rows_per_blk;
+  const int r1 = (r0 + p.rows_per_blk < p.P) ? r0 + p.rows_per_blk : p.P;
+  const long long goff = (long long)g * p.P * p.C;
+  float s1[V], s2[V], mu[V], rs[V];
+#pragma unroll
+  for (int j = 0; j < V; ++j) { s1[j] = 0.f; s2[j] = 0.f; mu[j] = 0.f; rs[j] = 1.f; }
+  if (active) {
+    const int c0 = cu * V;
+    if (MODE == FSV_RED_BWD) {
+#pragma unroll
+      for (int j = 0; j < V; ++j) { mu[j] = p.mean[g * p.C + c0 + j]; rs[j] = p.rstd[g * p.C + c0 + j]; }
+    }
+    for (int r = r0 + ty; r < r1; r += p.TY * 4) {
+      float va[4][V], vy[4][V], vx[4][V];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int rr = r + u * p.TY;
+        const bool ok = rr < r1;
+        const long long off = goff + (long long)rr * p.C + c0;
+        if constexpr (V == 4) {
+          float4 t = ok ? *reinterpret_cast<const float4*>(p.a + off) : make_float4(0.f, 0.f, 0.f, 0.f);
+          va[u][0] = t.x; va[u][1] = t.y; va[u][2] = t.z; va[u][3] = t.w;
+          if (MODE == FSV_RED_BWD) {
+            float4 tx4 = ok ? *reinterpret_cast<const float4*>(p.x + off) : make_float4(0.f, 0.f, 0.f, 0.f);
+            vx[u][0] = tx4.x; vx[u][1] = tx4.y; vx[u][2] = tx4.z; vx[u][3] = tx4.w;
+            float4 ty4 = (ok && p.y) ? *reinterpret_cast<const float4*>(p.y + off) : make_float4(0.f, 0.f, 0.f, 0.f);
+            vy[u][0] = ty4.x; vy[u][1] = ty4.y; vy[u][2] = ty4.z; vy[u][3] = ty4.w;
+          }
+        } else {
+          va[u][0] = ok ? p.a[off] : 0.f;
+          if (MODE == FSV_RED_BWD) { vx[u][0] = ok ? p.x[off] : 0.f; vy[u][0] = (ok && p.y) ? p.y[off] : 0.f; }
+        }
+        if (MODE == FSV_RED_BWD && !ok) {
+#pragma unroll
+          for (int j = 0; j < V; ++j) vx[u][j] = mu[j];      // xhat = 0 for padding rows
+        }
       }
-    red[threadIdx.x * 2] = (double)s; red[threadIdx.x * 2 + 1] = (double)s2;
-    __syncthreads();
-    if (threadIdx.x < m.Q && c0 + (int)threadIdx.x < C) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int j = 0; j < V; ++j) {
+          if (MODE == FSV_RED_STATS) { s1[j] += va[u][j]; s2[j] += va[u][j] * va[u][j]; }
+          else if (MODE == FSV_RED_COLSUM) { s1[j] += va[u][j]; }
+          else {
+            float d = fsv_act_grad(va[u][j], vy[u][j], p.act);
+            s1[j] += d; s2[j] += d * ((vx[u][j] - mu[j]) * rs[j]);
+          }
+        }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < V; ++j) { red[(threadIdx.x * V + j) * 2] = s1[j]; red[(threadIdx.x * V + j) * 2 + 1] = s2[j]; }
+  __syncthreads();
+  // thread t < TX*V reduces column unit t / V, component t % V over the TY rows (fp64)
+  const int t = threadIdx.x;
+  if (t < p.TX * V) {
+    const int ux = t / V, j = t % V;
+    const int c = (slab * p.TX + ux) * V + j;
+    if (slab * p.TX + ux < p.CU) {
       double a = 0.0, b = 0.0;
-      for (int r = 0; r < m.rows_per_pass; ++r) { a += red[(r * m.Q + threadIdx.x) * 2]; b += red[(r * m.Q + threadIdx.x) * 2 + 1]; }
-      double* dst = part + (((long long)g * nchunks + chunk) * C + c0 + threadIdx.x) * 2;
+      for (int yy = 0; yy < p.TY; ++yy) {
+        const int src = yy * p.TX + ux;
+        a += (double)red[(src * V + j) * 2];
+        b += (double)red[(src * V + j) * 2 + 1];
+      }
+      double* dst = p.part + (((long long)g * p.nchunks + chunk) * p.C + c) * 2;
       dst[0] = a; dst[1] = b;
     }
-    __syncthreads();
   }
+}
+
+template <int MODE>
+static inline void fsv_launch_red(const RedPlan& pl, RedP p, int G, hipStream_t stream) {
+  p.CU = pl.CU; p.TX = pl.TX; p.TY = pl.TY; p.rows_per_blk = pl.rows_per_blk; p.nchunks = pl.nchunks;
+  dim3 grid(pl.nchunks, pl.nslabs, G);
+  if (pl.V == 4) FSV_LAUNCH((fsv_red2_kernel<MODE, 4>), grid, dim3(256), stream, p);
+  else FSV_LAUNCH((fsv_red2_kernel<MODE, 1>), grid, dim3(256), stream, p);
+}
+
+// sum of the per-chunk partials of one (g, c): executed by a whole wave, result valid in every lane
+__device__ __forceinline__ void fsv_sum_chunks(const double* part, int g, int c, int C, int nchunks, double& a, double& b) {
+  const int lane = threadIdx.x & 63;
+  a = 0.0; b = 0.0;
+  for (int k = lane; k < nchunks; k += 64) {
+    const double* src = part + (((long long)g * nchunks + k) * C + c) * 2;
+    a += src[0]; b += src[1];
+  }
+  for (int o = 32; o > 0; o >>= 1) { a += __shfl_xor(a, o); b += __shfl_xor(b, o); }
 }
 
 // mean/rstd/var per (g, c); optional running-stat update (BatchNorm momentum semantics, unbiased running var)
 __global__ __launch_bounds__(256) void fsv_stats_final_kernel(const double* part, float* mean, float* rstd, int G, int C,
                                                               int P, int nchunks, float eps, float* run_mean,
                                                               float* run_var, float momentum) {
-  int idx = blockIdx.x * 256 + threadIdx.x;
-  if (idx >= G * C) return;
-  int g = idx / C, c = idx - g * C;
-  double a = 0.0, b = 0.0;
-  for (int k = 0; k < nchunks; ++k) {
-    const double* src = part + (((long long)g * nchunks + k) * C + c) * 2;
-    a += src[0]; b += src[1];
-  }
+  const int idx = blockIdx.x * 4 + (threadIdx.x >> 6);      // one wave per (g, c)
+  const bool ok = idx < G * C;
+  const int g = ok ? idx / C : 0, c = ok ? idx - g * C : 0;
+  double a, b;
+  fsv_sum_chunks(part, g, c, C, nchunks, a, b);
+  if (!ok || (threadIdx.x & 63) != 0) return;
   double mu = a / P;
   double var = b / P - mu * mu;
   if (var < 0.0) var = 0.0;
@@ -94,63 +192,22 @@ __global__ __launch_bounds__(256) void fsv_norm_apply_kernel(const float* x, con
   }
 }
 
-// ---- backward: reductions sum(dyp), sum(dyp * xhat) with dyp = dy * act'(y) -----------------------------------
-__device__ __forceinline__ float fsv_act_grad(float dy, float y, int act) {
-  if (act == FSV_ACT_LRELU) return y > 0.f ? dy : 0.2f * dy;
-  if (act == FSV_ACT_TANH) return dy * (1.f - y * y);
-  if (act == FSV_ACT_SIGMOID) return dy * y * (1.f - y);
-  return dy;
-}
-
-__global__ __launch_bounds__(256) void fsv_norm_bwd_partial_kernel(const float* dy, const float* y, const float* x,
-                                                                   const float* mean, const float* rstd, double* part,
-                                                                   int P, int C, int nchunks, int act) {
-  __shared__ double red[256 * 2];
-  const int g = blockIdx.y, chunk = blockIdx.x;
-  const int p0 = chunk * FSV_RED_ROWS;
-  const int p1 = (p0 + FSV_RED_ROWS < P) ? p0 + FSV_RED_ROWS : P;
-  const long long goff = (long long)g * P * C;
-  const RowMap m = fsv_rowmap(C, threadIdx.x);
-  for (int c0 = 0; c0 < C; c0 += m.Q) {
-    const int c = c0 + m.q;
-    float s = 0.f, s2 = 0.f;
-    if (m.active && c < C) {
-      const float mu = mean[g * C + c], rs = rstd[g * C + c];
-      for (int p = p0 + m.r; p < p1; p += m.rows_per_pass) {
-        long long i = goff + (long long)p * C + c;
-        float d = fsv_act_grad(dy[i], y ? y[i] : 0.f, act);
-        s += d; s2 += d * ((x[i] - mu) * rs);
-      }
-    }
-    red[threadIdx.x * 2] = (double)s; red[threadIdx.x * 2 + 1] = (double)s2;
-    __syncthreads();
-    if (threadIdx.x < m.Q && c0 + (int)threadIdx.x < C) {
-      double a = 0.0, b = 0.0;
-      for (int r = 0; r < m.rows_per_pass; ++r) { a += red[(r * m.Q + threadIdx.x) * 2]; b += red[(r * m.Q + threadIdx.x) * 2 + 1]; }
-      double* dst = part + (((long long)g * nchunks + chunk) * C + c0 + threadIdx.x) * 2;
-      dst[0] = a; dst[1] = b;
-    }
-    __syncthreads();
-  }
-}
-
 // s1[g][c], s2[g][c]; optional affine grads dw[c] = sum_g s2, db[c] = sum_g s1 (one thread per channel)
 __global__ __launch_bounds__(256) void fsv_norm_bwd_final_kernel(const double* part, float* s1, float* s2, float* dw,
                                                                  float* db, int G, int C, int nchunks) {
-  int c = blockIdx.x * 256 + threadIdx.x;
-  if (c >= C) return;
+  const int cc = blockIdx.x * 4 + (threadIdx.x >> 6);        // one wave per channel
+  const bool ok = cc < C;
+  const int c = ok ? cc : 0;
+  const bool lead = ok && (threadIdx.x & 63) == 0;
   double ta = 0.0, tb = 0.0;
   for (int g = 0; g < G; ++g) {
-    double a = 0.0, b = 0.0;
-    for (int k = 0; k < nchunks; ++k) {
-      const double* src = part + (((long long)g * nchunks + k) * C + c) * 2;
-      a += src[0]; b += src[1];
-    }
-    s1[g * C + c] = (float)a; s2[g * C + c] = (float)b;
+    double a, b;
+    fsv_sum_chunks(part, g, c, C, nchunks, a, b);
+    if (lead) { s1[g * C + c] = (float)a; s2[g * C + c] = (float)b; }
     ta += a; tb += b;
   }
-  if (dw) dw[c] = (float)tb;
-  if (db) db[c] = (float)ta;
+  if (lead && dw) dw[c] = (float)tb;
+  if (lead && db) db[c] = (float)ta;
 }
 
 // dx = w * rstd * (dyp - s1/P - xhat * s2/P)
@@ -174,49 +231,32 @@ __global__ __launch_bounds__(256) void fsv_norm_bwd_apply_kernel(const float* dy
 }
 
 // ---- column sums of a [G][P][C] tensor (bias gradients): out[g][c] ----------------------------------------------
-__global__ __launch_bounds__(256) void fsv_colsum_partial_kernel(const float* x, double* part, int P, int C, int nchunks) {
-  __shared__ double red[256];
-  const int g = blockIdx.y, chunk = blockIdx.x;
-  const int p0 = chunk * FSV_RED_ROWS;
-  const int p1 = (p0 + FSV_RED_ROWS < P) ? p0 + FSV_RED_ROWS : P;
-  const float* xg = x + (long long)g * P * C;
-  const RowMap m = fsv_rowmap(C, threadIdx.x);
-  for (int c0 = 0; c0 < C; c0 += m.Q) {
-    const int c = c0 + m.q;
-    float s = 0.f;
-    if (m.active && c < C)
-      for (int p = p0 + m.r; p < p1; p += m.rows_per_pass) s += xg[(long long)p * C + c];
-    red[threadIdx.x] = (double)s;
-    __syncthreads();
-    if (threadIdx.x < m.Q && c0 + (int)threadIdx.x < C) {
-      double a = 0.0;
-      for (int r = 0; r < m.rows_per_pass; ++r) a += red[r * m.Q + threadIdx.x];
-      part[((long long)g * nchunks + chunk) * C + c0 + threadIdx.x] = a;
-    }
-    __syncthreads();
-  }
-}
 __global__ __launch_bounds__(256) void fsv_colsum_final_kernel(const double* part, float* out, int G, int C, int nchunks) {
-  int idx = blockIdx.x * 256 + threadIdx.x;
-  if (idx >= G * C) return;
-  int g = idx / C, c = idx - g * C;
-  double a = 0.0;
-  for (int k = 0; k < nchunks; ++k) a += part[((long long)g * nchunks + k) * C + c];
-  out[idx] = (float)a;
+  const int idx = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const bool ok = idx < G * C;
+  const int g = ok ? idx / C : 0, c = ok ? idx - g * C : 0;
+  double a, b;
+  fsv_sum_chunks(part, g, c, C, nchunks, a, b);
+  if (ok && (threadIdx.x & 63) == 0) out[idx] = (float)a;
 }
 
 extern "C" {
 
 int fsv_norm_workspace_doubles(int G, int P, int C) {
-  return G * fsv_cdiv(P, FSV_RED_ROWS) * C * 2;
+  if (G < 1 || P < 1 || C < 1) return 2;
+  RedPlan pl = fsv_red_plan(G, P, C);
+  return G * pl.nchunks * C * 2;
 }
 
 int fsv_norm_stats(const float* x, double* workspace, float* mean, float* rstd, int G, int P, int C, float eps,
                    float* run_mean, float* run_var, float momentum, hipStream_t stream) {
   if (!x || !workspace || !mean || !rstd || G < 1 || P < 1 || C < 1) return FSV_ERR_BAD_ARG;
-  int nchunks = fsv_cdiv(P, FSV_RED_ROWS);
-  FSV_LAUNCH(fsv_stats_partial_kernel, dim3(nchunks, G), dim3(256), stream, x, workspace, P, C, nchunks);
-  FSV_LAUNCH(fsv_stats_final_kernel, dim3(fsv_cdiv(G * C, 256)), dim3(256), stream, (const double*)workspace, mean, rstd,
+  RedPlan pl = fsv_red_plan(G, P, C);
+  const int nchunks = pl.nchunks;
+  RedP rp; rp.a = x; rp.y = nullptr; rp.x = nullptr; rp.mean = nullptr; rp.rstd = nullptr; rp.part = workspace;
+  rp.P = P; rp.C = C; rp.act = 0;
+  fsv_launch_red<FSV_RED_STATS>(pl, rp, G, stream);
+  FSV_LAUNCH(fsv_stats_final_kernel, dim3(fsv_cdiv(G * C, 4)), dim3(256), stream, (const double*)workspace, mean, rstd,
              G, C, P, nchunks, eps, run_mean, run_var, momentum);
   return fsv_check_launch();
 }
@@ -244,10 +284,12 @@ int fsv_norm_bwd(const float* dy, const float* y, const float* x, const float* m
                  hipStream_t stream) {
   if (!dy || !x || !mean || !rstd || !workspace || !s1 || !s2 || !dx) return FSV_ERR_BAD_ARG;
   if (act != FSV_ACT_NONE && !y) return FSV_ERR_BAD_ARG;
-  int nchunks = fsv_cdiv(P, FSV_RED_ROWS);
-  FSV_LAUNCH(fsv_norm_bwd_partial_kernel, dim3(nchunks, G), dim3(256), stream, dy, y, x, mean, rstd, workspace, P, C,
-             nchunks, act);
-  FSV_LAUNCH(fsv_norm_bwd_final_kernel, dim3(fsv_cdiv(C, 256)), dim3(256), stream, (const double*)workspace, s1, s2, dw,
+  RedPlan pl = fsv_red_plan(G, P, C);
+  const int nchunks = pl.nchunks;
+  RedP rp; rp.a = dy; rp.y = y; rp.x = x; rp.mean = mean; rp.rstd = rstd; rp.part = workspace;
+  rp.P = P; rp.C = C; rp.act = act;
+  fsv_launch_red<FSV_RED_BWD>(pl, rp, G, stream);
+  FSV_LAUNCH(fsv_norm_bwd_final_kernel, dim3(fsv_cdiv(C, 4)), dim3(256), stream, (const double*)workspace, s1, s2, dw,
              db, G, C, nchunks);
   long long total = (long long)G * P * C;
   FSV_LAUNCH(fsv_norm_bwd_apply_kernel, dim3(fsv_ew_grid(total)), dim3(256), stream, dy, y, x, mean, rstd, w,
@@ -257,9 +299,12 @@ int fsv_norm_bwd(const float* dy, const float* y, const float* x, const float* m
 
 int fsv_colsum(const float* x, double* workspace, float* out, int G, int P, int C, hipStream_t stream) {
   if (!x || !workspace || !out) return FSV_ERR_BAD_ARG;
-  int nchunks = fsv_cdiv(P, FSV_RED_ROWS);
-  FSV_LAUNCH(fsv_colsum_partial_kernel, dim3(nchunks, G), dim3(256), stream, x, workspace, P, C, nchunks);
-  FSV_LAUNCH(fsv_colsum_final_kernel, dim3(fsv_cdiv(G * C, 256)), dim3(256), stream, (const double*)workspace, out, G,
+  RedPlan pl = fsv_red_plan(G, P, C);
+  const int nchunks = pl.nchunks;
+  RedP rp; rp.a = x; rp.y = nullptr; rp.x = nullptr; rp.mean = nullptr; rp.rstd = nullptr; rp.part = workspace;
+  rp.P = P; rp.C = C; rp.act = 0;
+  fsv_launch_red<FSV_RED_COLSUM>(pl, rp, G, stream);
+  FSV_LAUNCH(fsv_colsum_final_kernel, dim3(fsv_cdiv(G * C, 4)), dim3(256), stream, (const double*)workspace, out, G,
              C, nchunks);
   return fsv_check_launch();
 }

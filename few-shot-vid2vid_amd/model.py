@@ -357,8 +357,17 @@ class Vid2VidModel(nn.Module):
             self.generate_images(tgt_label, tgt_image, ref_labels, ref_images, prevs)
         fg_union = union_fg(fg, ref_fg, self.has_fg)
         real = tgt_image[:, 0]
-        g_gan, g_feat, gf_gan, gf_feat = lc.gan_losses(self.netD, tgt_label, [real, real * fg_union], [fake, raw],
-                                                       ref_label, ref_image, for_discriminator=False)
+        # The G step only needs d(loss)/d(fake) from the discriminator.  The reference lets autograd also fill the
+        # discriminator's (unused, later zeroed) weight gradients; skipping them changes no result of either step.
+        d_params = [p for p in self.netD.parameters() if p.requires_grad]
+        for p in d_params:
+            p.requires_grad_(False)
+        try:
+            g_gan, g_feat, gf_gan, gf_feat = lc.gan_losses(self.netD, tgt_label, [real, real * fg_union], [fake, raw],
+                                                           ref_label, ref_image, for_discriminator=False)
+        finally:
+            for p in d_params:
+                p.requires_grad_(True)
         z = lc.zero(fake)
         f_flow, f_warp, body_diff = lc.flow_losses(flow, warped, real, fg, tgt_label, ref_label)
         f_mask = lc.mask_losses(mask, fake, warped, tgt_label, real, fg, ref_fg, body_diff)

@@ -42,12 +42,17 @@ lib.register_sigs({
     "fsv_sn_backward": [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_p],
 })
 
-RED_ROWS = 2048
+_ws_fn = None
 
 
 def _ws(g, p, c, like):
-    n = g * ((p + RED_ROWS - 1) // RED_ROWS) * c * 2
-    return torch.empty(max(n, 2), dtype=torch.float64, device=like.device)
+    """fp64 scratch for the two-stage column reductions; the size comes from the library's own launch plan."""
+    global _ws_fn
+    if _ws_fn is None:
+        _ws_fn = getattr(lib.get_lib(), "fsv_norm_workspace_doubles")
+        _ws_fn.argtypes = [c_i, c_i, c_i]
+        _ws_fn.restype = c_i
+    return torch.empty(max(int(_ws_fn(g, p, c)), 2), dtype=torch.float64, device=like.device)
 
 
 def _ll(vals):

@@ -41,6 +41,13 @@ def test_norm(emu_lib, instance, affine, act):
     oc.check_norm(DEV, instance=instance, affine=affine, act=act)
 
 
+@pytest.mark.parametrize("n,c,h,w", [(2, 40, 40, 33), (1, 260, 9, 20), (2, 10, 37, 41)])
+def test_norm_multi_chunk_multi_slab(emu_lib, n, c, h, w):
+    """pixel counts / channel counts that span several reduction chunks and channel slabs (vector and scalar paths)"""
+    oc.check_norm(DEV, instance=False, n=n, c=c, h=h, w=w)
+    oc.check_norm(DEV, instance=True, n=n, c=c, h=h, w=w)
+
+
 @pytest.mark.parametrize("nmaps,generated,act,c,ch", [(1, True, 'lrelu', 12, 8), (3, True, 'none', 12, 8),
                                                       (2, False, 'lrelu', 40, 12)])
 def test_spade(emu_lib, nmaps, generated, act, c, ch):
