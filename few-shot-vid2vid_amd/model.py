@@ -372,8 +372,10 @@ class Vid2VidModel(nn.Module):
         f_flow, f_warp, body_diff = lc.flow_losses(flow, warped, real, fg, tgt_label, ref_label)
         f_mask = lc.mask_losses(mask, fake, warped, tgt_label, real, fg, ref_fg, body_diff)
         losses = [g_gan, g_feat, z.clone(), gf_gan, gf_feat, z.clone(), z.clone(), f_flow, f_warp, f_mask]
-        up = lambda t: t.unsqueeze(1) if t is not None else None   # back to the reference's [B, T, ...] outputs
-        generated = [up(fake), up(raw), [up(t) for t in warped], [up(t) for t in flow], [up(t) for t in mask], None]
+        # the reference returns fake / raw as [B, T, ...] and - because forward_generator rebinds them through
+        # self.reshape (vid2vid_model.py:88-89) - warped / flow / mask as 4-D tensors
+        up = lambda t: t.unsqueeze(1) if t is not None else None
+        generated = [up(fake), up(raw), list(warped), list(flow), list(mask), None]
         return [l.view(1, 1) for l in losses], generated, prevs_new
 
 

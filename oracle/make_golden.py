@@ -1,0 +1,121 @@
+"""Mint the golden fixtures under tests/golden/ from the UNMODIFIED reference (NVlabs/few-shot-vid2vid).
+
+Run in the build container only (needs /root/reference):   python oracle/make_golden.py
+
+What is stored (all small):
+  * ref_state_layout.json   - state_dict keys and shapes of the reference's netG / netD for the BASELINE flag sets
+                              (checkpoint compatibility contract of the product networks);
+  * step_<cfg>.pt           - for a narrow network (ngf = ndf = nff = 8, 64x64): outputs of one reference iteration
+                              (train.py:58-62) on seeded synthetic inputs: the generated image / flow / mask / warp,
+                              the 6 discriminator and 10 generator losses, and per-parameter gradient norms.
+                              Weights are NOT stored: tests/model_checks.fill_state derives every parameter from its
+                              state_dict key with numpy's Generator, so the reference, the oracle and the product all
+                              see identical weights.
+  * warp_taps.pt            - integer bilinear tap indices selected by ATen's grid_sample through the reference's
+                              `resample` (revealed by the backward scatter pattern), for zero / integer / random flows.
+"""
+import json
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, 'tests'))
+from oracle import ref_import  # noqa: E402
+
+OUT = os.path.join(ROOT, 'tests', 'golden')
+
+CONFIGS = {
+    'pose_combine': '--dataset_mode fewshot_pose --aspect_ratio 1 --fineSize 64 --loadSize 64 --adaptive_spade --warp_ref '
+                    '--spade_combine --remove_face_labels --no_flow_gt --no_vgg_loss --gpu_ids -1 --ngf 8 --ndf 8 --nff 8 '
+                    '--batchSize 2',
+    'face': '--dataset_mode fewshot_face --fineSize 64 --loadSize 64 --adaptive_spade --no_flow_gt --no_vgg_loss '
+            '--gpu_ids -1 --ngf 8 --ndf 8 --batchSize 2',
+    'pose_blend': '--dataset_mode fewshot_pose --aspect_ratio 1 --fineSize 64 --loadSize 64 --adaptive_spade --warp_ref '
+                  '--no_flow_gt --no_vgg_loss --gpu_ids -1 --ngf 8 --ndf 8 --nff 8 --batchSize 2',
+}
+LAYOUT_CONFIGS = {
+    'C3_pose_512': '--dataset_mode fewshot_pose --aspect_ratio 1 --fineSize 512 --loadSize 512 --adaptive_spade --warp_ref '
+                   '--spade_combine --remove_face_labels --no_flow_gt --no_vgg_loss --gpu_ids -1',
+    'C1_face_128': '--dataset_mode fewshot_face --fineSize 128 --loadSize 128 --adaptive_spade --no_flow_gt --no_vgg_loss '
+                   '--gpu_ids -1',
+}
+
+
+def layout():
+    res = {}
+    for name, flags in LAYOUT_CONFIGS.items():
+        opt, model = ref_import.build_model(flags.split())
+        res[name] = dict(flags=flags,
+                         netG={k: list(v.shape) for k, v in model.netG.state_dict().items()},
+                         netD={k: list(v.shape) for k, v in model.netD.state_dict().items()})
+        del model
+    with open(os.path.join(OUT, 'ref_state_layout.json'), 'w') as f:
+        json.dump(res, f)
+
+
+def step(name, flags):
+    import model_checks as mc
+    from models.loss_collector import loss_backward
+    opt, model = ref_import.build_model(flags.split())
+    mc.fill_state(model.netG)
+    mc.fill_state(model.netD)
+    for o in (model.optimizer_G, model.optimizer_D):
+        for g in o.param_groups:
+            g['lr'] = 0.0
+    nl = opt.label_nc if opt.label_nc != 0 else opt.input_nc
+    tl, ti, rl, ri = mc.synth_pose_inputs(2, 64, 64, 4242, nl)
+    data = [tl, ti, [None, None], [None, None], rl, ri, None, None, None]
+    d_losses = model(data, mode='discriminator')
+    d_losses = loss_backward(opt, d_losses, model.optimizer_D, 1)
+    gD = {k: float(p.grad.norm()) for k, p in model.netD.named_parameters() if p.grad is not None}
+    g_losses, generated, prev = model(data, save_images=True, mode='generator')
+    g_losses = loss_backward(opt, g_losses, model.optimizer_G, 0)
+    gG = {k: float(p.grad.norm()) for k, p in model.netG.named_parameters() if p.grad is not None}
+    fake, raw, warped, flow, mask, _ = generated
+
+    def t(x):
+        return None if x is None else x.detach().clone()
+    torch.save(dict(flags=flags, seed=4242, batch=2, size=64,
+                    d_losses=[float(x) for x in d_losses], g_losses=[float(x) for x in g_losses],
+                    loss_names=model.lossCollector.loss_names,
+                    fake=t(fake), raw=t(raw), warp=[t(w) for w in warped], flow=[t(f) for f in flow],
+                    mask=[t(m) for m in mask], grad_norm_D=gD, grad_norm_G=gG),
+               os.path.join(OUT, 'step_%s.pt' % name))
+    print(name, 'D', [round(float(x), 5) for x in d_losses[:2]], 'G', [round(float(x), 5) for x in g_losses])
+
+
+def warp_taps():
+    ref_import.install_shims()
+    from models.networks.base_network import resample
+    g = torch.Generator().manual_seed(77)
+    cases = {}
+    for name, (h, w) in dict(w512=(6, 512), w128=(5, 128), w35=(7, 35)).items():
+        flow = (torch.rand(1, 2, h, w, generator=g) - 0.5) * 30.0
+        flow[:, :, 0] = 0.0                                              # zero flow: fp32 round trip of the grid
+        flow[:, :, 1] = torch.randint(-4, 5, (1, 2, w), generator=g).float()   # integer flows
+        img = torch.zeros(1, 1, h, w, requires_grad=True)
+        out = resample(img, flow)
+        taps = torch.full((h, w, 2), -1, dtype=torch.int32)
+        for y in range(h):
+            for x in range(w):
+                gsel = torch.zeros_like(out)
+                gsel[0, 0, y, x] = 1.0
+                (gi,) = torch.autograd.grad(out, img, gsel, retain_graph=True)
+                nz = gi[0, 0].nonzero()
+                # north-west tap = smallest touched (row, col); a zero-weight east/south tap is simply absent
+                taps[y, x, 0] = int(nz[:, 1].min())
+                taps[y, x, 1] = int(nz[:, 0].min())
+        cases[name] = dict(flow=flow, taps_xy_min=taps)
+    torch.save(cases, os.path.join(OUT, 'warp_taps.pt'))
+
+
+if __name__ == '__main__':
+    os.makedirs(OUT, exist_ok=True)
+    layout()
+    for n, f in CONFIGS.items():
+        step(n, f)
+    warp_taps()
+    print('goldens written to', OUT)

@@ -1,0 +1,145 @@
+"""Golden fixtures minted from the unmodified reference (oracle/make_golden.py) pin
+
+  * the CPU oracle (any box, `not gpu`): same losses / images / gradient norms / warp taps as the reference;
+  * the product networks' checkpoint layout (state_dict keys and shapes identical to the reference's);
+  * the product on a real MI355X (`gpu`): one reference iteration reproduced within 1e-3 (outputs, losses).
+"""
+import json
+import os
+
+import pytest
+import torch
+
+import model_checks as mc
+from oracle import fsv_oracle as O
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+CASES = ['pose_combine', 'face', 'pose_blend']
+
+
+def _opt_from_flags(flags):
+    """the reference's command line -> the option namespace used by the product / oracle (defaults identical)"""
+    toks = flags.split()
+    kw = {}
+    ints = {'--ngf': 'ngf', '--ndf': 'ndf', '--nff': 'nff', '--fineSize': 'fineSize', '--loadSize': 'loadSize',
+            '--batchSize': 'batchSize'}
+    i = 0
+    while i < len(toks):
+        t = toks[i]
+        if t in ints:
+            kw[ints[t]] = int(toks[i + 1]); i += 2
+        elif t == '--dataset_mode':
+            kw['dataset_mode'] = toks[i + 1]; i += 2
+        elif t == '--aspect_ratio':
+            kw['aspect_ratio'] = float(toks[i + 1]); i += 2
+        elif t == '--gpu_ids':
+            i += 2
+        elif t in ('--adaptive_spade', '--warp_ref', '--spade_combine', '--remove_face_labels', '--no_flow_gt',
+                   '--no_vgg_loss'):
+            kw[t[2:]] = True; i += 1
+        else:
+            raise ValueError(t)
+    if kw.get('dataset_mode') == 'fewshot_face':
+        kw.setdefault('input_nc', 1)
+    return mc.make_opt(**kw)
+
+
+def _load(case):
+    return torch.load(os.path.join(GOLD, 'step_%s.pt' % case), weights_only=False)
+
+
+def _t(x):
+    """reference outputs are [B, T, ...] (fake, raw) or already 4-D (warped, flow, mask)"""
+    return x[:, 0] if x.dim() == 5 else x
+
+
+def _rel(a, b):
+    a, b = _t(a), _t(b)
+    return float((a - b).abs().max() / max(float(b.abs().max()), 1e-12))
+
+
+@pytest.mark.parametrize('case', CASES)
+def test_oracle_reproduces_reference_iteration(case):
+    g = _load(case)
+    opt = _opt_from_flags(g['flags'])
+    net = mc._net()
+    M = mc._model()
+    model = M.create_model(opt)            # used only for parameter shapes / names (CPU, nothing is launched)
+    sdG0, sdD0 = mc.fill_state(model.netG), mc.fill_state(model.netD)
+    nl = opt.label_nc if opt.label_nc != 0 else opt.input_nc
+    data = mc.synth_pose_inputs(g['batch'], g['size'], g['size'], g['seed'], nl)
+    d_losses, gD, g_losses, gG, gen = mc._oracle_iteration(sdG0, sdD0, O.cfg_from_opt(opt), data, torch.float32)
+    names = g['loss_names']
+    assert abs(float(d_losses[0]) - g['d_losses'][0]) <= 1e-5 * max(1.0, abs(g['d_losses'][0]))
+    assert abs(float(d_losses[1]) - g['d_losses'][1]) <= 1e-5 * max(1.0, abs(g['d_losses'][1]))
+    for k, v in g_losses.items():
+        ref = g['g_losses'][names.index(k)]
+        assert abs(float(v) - ref) <= 1e-5 * max(1.0, abs(ref)), (k, float(v), ref)
+    assert _rel(gen['fake'], g['fake']) <= 1e-5
+    if g['flow'][0] is not None:
+        assert _rel(gen['flow'][0], g['flow'][0]) <= 1e-5
+        assert _rel(gen['mask'][0], g['mask'][0]) <= 1e-5
+        assert _rel(gen['warp'][0], g['warp'][0]) <= 1e-5
+    for k, ref in g['grad_norm_D'].items():
+        assert abs(float(gD[k].norm()) - ref) <= 1e-4 * max(ref, 1e-6), k
+    med = sorted(g['grad_norm_G'].values())[len(g['grad_norm_G']) // 2]
+    for k, ref in g['grad_norm_G'].items():
+        assert abs(float(gG[k].norm()) - ref) <= 1e-3 * max(ref, 1e-2 * med), k
+
+
+def test_oracle_warp_taps_match_aten_selection():
+    cases = torch.load(os.path.join(GOLD, 'warp_taps.pt'), weights_only=False)
+    for name, c in cases.items():
+        taps = O.resample_taps(c['flow'])[0]
+        gold = c['taps_xy_min']
+        h, w = gold.shape[:2]
+        # ATen's backward touched (y_n, x_w) unless the whole north / west weight was exactly 0 (integer coordinate),
+        # in which case the smallest touched index is the tap itself
+        assert torch.equal(taps[..., 0], gold[..., 0]) or bool(((taps[..., 0] == gold[..., 0]) |
+                                                                 (taps[..., 0] + 1 == gold[..., 0])).all()), name
+        assert bool(((taps[..., 1] == gold[..., 1]) | (taps[..., 1] + 1 == gold[..., 1])).all()), name
+        frac_exact = float((taps[..., 0] == gold[..., 0]).float().mean())
+        assert frac_exact > 0.95, (name, frac_exact)
+
+
+@pytest.mark.parametrize('cfg', ['C3_pose_512', 'C1_face_128'])
+def test_product_state_dict_layout_equals_reference(cfg):
+    layout = json.load(open(os.path.join(GOLD, 'ref_state_layout.json')))[cfg]
+    opt = _opt_from_flags(layout['flags'])
+    M = mc._model()
+    with torch.device('meta'):
+        model = M.create_model(opt)
+    for net, ref in ((model.netG, layout['netG']), (model.netD, layout['netD'])):
+        mine = {k: list(v.shape) for k, v in net.state_dict().items()}
+        assert set(mine) == set(ref), (sorted(set(mine) ^ set(ref))[:10])
+        bad = [k for k in ref if mine[k] != ref[k]]
+        assert not bad, bad[:10]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('case', CASES)
+def test_product_reproduces_reference_iteration_on_gpu(hip_lib, case):
+    g = _load(case)
+    opt = _opt_from_flags(g['flags'])
+    dev = torch.device('cuda:0')
+    M = mc._model()
+    model = M.create_model(opt)
+    mc.fill_state(model.netG); mc.fill_state(model.netD)
+    model = model.to(dev).train()
+    opt_G, opt_D = model.build_optimizers()
+    opt_G.set_lr(0.0); opt_D.set_lr(0.0)
+    nl = opt.label_nc if opt.label_nc != 0 else opt.input_nc
+    tl, ti, rl, ri = [t.to(dev) for t in mc.synth_pose_inputs(g['batch'], g['size'], g['size'], g['seed'], nl)]
+    data = [tl, ti, [None, None], [None, None], rl, ri, None, None, None]
+    d = M.loss_backward(opt, model(data, mode='discriminator'), opt_D, 1)
+    gl, generated, _ = model(data, save_images=True, mode='generator')
+    gl = M.loss_backward(opt, gl, opt_G, 0)
+    for i in range(2):
+        assert abs(float(d[i]) - g['d_losses'][i]) <= 1e-3 * max(1.0, abs(g['d_losses'][i]))
+    for i, ref in enumerate(g['g_losses']):
+        assert abs(float(gl[i]) - ref) <= 1e-3 * max(1.0, abs(ref)), (g['loss_names'][i], float(gl[i]), ref)
+    assert _rel(generated[0].cpu(), g['fake']) <= 1e-3
+    if g['flow'][0] is not None:
+        assert _rel(generated[3][0].cpu(), g['flow'][0]) <= 1e-3
+        assert _rel(generated[4][0].cpu(), g['mask'][0]) <= 1e-3
+        assert _rel(generated[2][0].cpu(), g['warp'][0]) <= 1e-3
