@@ -1,0 +1,71 @@
+"""Drop-in wiring for the reference's train.py loop (walk-through in INTEGRATION.md).
+
+The reference has no plugin / FFI registry - its operator seam is Python name binding - so the integration is a
+set of name re-bindings applied before `train.py` builds its model:
+
+    import fsv2v_amd; fsv2v_amd.integration.patch_reference()     # top of train.py, nothing else changes
+
+After that `models.models.create_model(opt, epoch)` returns this package's Vid2VidModel (behind the `.module`
+attribute train.py expects) with flat-buffer Adam optimisers, `models.loss_collector.loss_backward` is ours, and
+the four namespaces that imported `batch_conv` / `resample` by name see the HIP versions.
+"""
+import sys
+
+import torch
+
+from . import model as _model
+from . import networks as _networks
+from . import ops as _ops
+
+
+class _ModuleHandle(torch.nn.Module):
+    """train.py / trainer.py talk to `model.module.*` (DataParallel convention, models/models.py:79-117)."""
+
+    def __init__(self, module):
+        super().__init__()
+        self.module = module
+
+    def forward(self, *args, **kwargs):
+        return self.module(*args, **kwargs)
+
+
+def create_model(opt, epoch=0):
+    """models/models.py:16-38: returns (model, flowNet, [optimizer_G, optimizer_D])."""
+    device = torch.device('cuda', opt.gpu_ids[0]) if len(opt.gpu_ids) else torch.device('cpu')
+    m = _model.create_model(opt, epoch, device)
+    world = torch.distributed.get_world_size() if torch.distributed.is_available() and torch.distributed.is_initialized() else 1
+    opt_G, opt_D = m.build_optimizers(world_size=world)
+    if not opt.no_flow_gt:
+        raise NotImplementedError("FlowNet2 ground-truth flow is the next scope row (SURVEY.md 8f); pass --no_flow_gt")
+    return _ModuleHandle(m), None, [opt_G, opt_D]
+
+
+def patch_reference():
+    """Re-bind the reference's names to this package.  The reference tree must already be importable."""
+    import importlib
+    mm = importlib.import_module('models.models')
+    lc = importlib.import_module('models.loss_collector')
+    nets = importlib.import_module('models.networks')
+    patched = []
+    mm.create_model = create_model; patched.append('models.models.create_model')
+    mm.Vid2VidModel = _model.Vid2VidModel; patched.append('models.models.Vid2VidModel')
+    lc.loss_backward = _model.loss_backward; patched.append('models.loss_collector.loss_backward')
+    nets.define_G = _networks.define_G; nets.define_D = _networks.define_D
+    patched += ['models.networks.define_G', 'models.networks.define_D']
+    for modname in ('models.networks.base_network', 'models.networks.generator', 'models.networks.normalization',
+                    'models.networks.architecture', 'models.loss_collector'):
+        mod = sys.modules.get(modname) or importlib.import_module(modname)
+        if hasattr(mod, 'batch_conv'):
+            mod.batch_conv = lambda x, weight, bias=None, stride=1, group_size=-1: _ops.batch_conv(
+                x, weight if not isinstance(weight, (list, tuple)) else weight[0],
+                bias if not isinstance(weight, (list, tuple)) else weight[1])
+            patched.append(modname + '.batch_conv')
+        if hasattr(mod, 'resample'):
+            mod.resample = _ops.resample
+            patched.append(modname + '.resample')
+    # train.py binds these two names at import time (train.py:13-14)
+    tr = sys.modules.get('__main__')
+    for name, obj in (('create_model', create_model), ('loss_backward', _model.loss_backward)):
+        if tr is not None and hasattr(tr, name):
+            setattr(tr, name, obj)
+    return patched
