@@ -87,6 +87,7 @@ __global__ __launch_bounds__(256) void fsv_conv_igemm_kernel(ConvP p) {
   const int bq = tid % QB, br0 = tid / QB;
   const int bcol = bn0 + bq * 4;
   const bool bcol_ok = bcol < p.ldw;
+  const int bcol_safe = bcol_ok ? bcol : 0;
 
   // chunk range of this K split
   const int cps = (p.nchunks + p.nsplit - 1) / p.nsplit;
@@ -96,30 +97,34 @@ __global__ __launch_bounds__(256) void fsv_conv_igemm_kernel(ConvP p) {
   float areg[NPA][V];
   float4 breg[NPB];
 
+  // Loads are unconditional (out-of-range rows / taps read a valid dummy address and are zeroed by a select):
+  // no per-lane branches, so the whole K loop stays one basic block and the accumulators stay in AGPRs.
   auto load_chunk = [&](int kc) {
     const int k = kc * BK + kq * V;
     const bool kok = k < p.K;
     int t = kok ? (k / p.Cin) : 0;
-    int ci = k - t * p.Cin;
+    int ci = kok ? (k - t * p.Cin) : 0;
     int ty, tx;
     fsv_tap(p, t, ty, tx);
 #pragma unroll
     for (int i = 0; i < NPA; ++i) {
       int iy = a_iy0[i] + ty, ix = a_ix0[i] + tx;
       bool ok = kok && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-      const float* src = p.in + ((a_base[i] + (long long)iy * p.W + ix) * p.Cin + ci);
+      long long off = ok ? ((a_base[i] + (long long)iy * p.W + ix) * p.Cin + ci) : 0ll;
+      const float* src = p.in + off;
       if constexpr (V == 4) {
-        float4 v = ok ? *reinterpret_cast<const float4*>(src) : make_float4(0.f, 0.f, 0.f, 0.f);
-        areg[i][0] = v.x; areg[i][1] = v.y; areg[i][2] = v.z; areg[i][3] = v.w;
+        float4 v = *reinterpret_cast<const float4*>(src);
+        areg[i][0] = ok ? v.x : 0.f; areg[i][1] = ok ? v.y : 0.f; areg[i][2] = ok ? v.z : 0.f; areg[i][3] = ok ? v.w : 0.f;
       } else {
-        areg[i][0] = ok ? *src : 0.f;
+        float v = *src;
+        areg[i][0] = ok ? v : 0.f;
       }
     }
 #pragma unroll
     for (int i = 0; i < NPB; ++i) {
       int kr = kc * BK + br0 + i * RPB;
-      breg[i] = bcol_ok ? *reinterpret_cast<const float4*>(wt + (long long)kr * p.ldw + bcol)
-                        : make_float4(0.f, 0.f, 0.f, 0.f);
+      float4 v = *reinterpret_cast<const float4*>(wt + (long long)kr * p.ldw + bcol_safe);
+      breg[i] = bcol_ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
     }
   };
   auto store_chunk = [&]() {
@@ -145,31 +150,41 @@ __global__ __launch_bounds__(256) void fsv_conv_igemm_kernel(ConvP p) {
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   const int lrow = lane & 31, lk = lane >> 5;
+  const float* a_frag = &As[lk * LDA + wm * (TM * 32) + lrow];
+  const float* b_frag = &Bs[lk * BN + wn * (TN * 32) + lrow];
   if (c_begin < c_end) {
     load_chunk(c_begin);
     store_chunk();
     __syncthreads();
+#pragma unroll 1
     for (int kc = c_begin; kc < c_end; ++kc) {
-      const bool more = (kc + 1) < c_end;
-      if (more) load_chunk(kc + 1);
+      // prefetch the next chunk (the last iteration re-reads its own chunk; the copy it stores is never used)
+      const int knext = (kc + 1 < c_end) ? kc + 1 : kc;
+      load_chunk(knext);
+      // fragments are double-buffered in registers: the LDS reads of k-step kk+1 are in flight under the MFMAs of kk
+      float a[2][TM], b[2][TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) a[0][i] = a_frag[i * 32];
+#pragma unroll
+      for (int j = 0; j < TN; ++j) b[0][j] = b_frag[j * 32];
 #pragma unroll
       for (int kk = 0; kk < BK / 2; ++kk) {
-        float a[TM], b[TN];
+        const int cur = kk & 1, nxt = cur ^ 1;
+        if (kk + 1 < BK / 2) {
 #pragma unroll
-        for (int i = 0; i < TM; ++i) a[i] = As[(kk * 2 + lk) * LDA + wm * (TM * 32) + i * 32 + lrow];
+          for (int i = 0; i < TM; ++i) a[nxt][i] = a_frag[(kk + 1) * 2 * LDA + i * 32];
 #pragma unroll
-        for (int j = 0; j < TN; ++j) b[j] = Bs[(kk * 2 + lk) * BN + wn * (TN * 32) + j * 32 + lrow];
+          for (int j = 0; j < TN; ++j) b[nxt][j] = b_frag[(kk + 1) * 2 * BN + j * 32];
+        }
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
           for (int j = 0; j < TN; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][i], b[cur][j], acc[i][j], 0, 0, 0);
       }
       __syncthreads();
-      if (more) {
-        store_chunk();
-        __syncthreads();
-      }
+      store_chunk();
+      __syncthreads();
     }
   }
 
@@ -286,43 +301,44 @@ __global__ __launch_bounds__(256) void fsv_conv_wgrad_kernel(WgradP p) {
 
   float areg[NPA][V];
   float4 breg[NPB];
+  const bool cout4 = (p.Cout & 3) == 0;
   auto load_chunk = [&](int pc) {
 #pragma unroll
     for (int i = 0; i < NPA; ++i) {
       int m = pc * BK + apr0 + i * RPA;
       bool ok = kok && m < p.Mz;
-      const float* src = p.in;
-      if (ok) {
-        int n, rem;
-        if (p.per_sample) { n = zs; rem = m; } else { n = m / ohw; rem = m - n * ohw; }
-        int oy = rem / p.OW, ox = rem - oy * p.OW;
-        int iy = oy * p.sy + ty, ix = ox * p.sx + tx;
-        ok = (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-        src = p.in + ((((long long)n * p.H + iy) * p.W + ix) * p.Cin + ci);
-      }
+      int mm = ok ? m : 0;
+      int n, rem;
+      if (p.per_sample) { n = zs; rem = mm; } else { n = mm / ohw; rem = mm - n * ohw; }
+      int oy = rem / p.OW, ox = rem - oy * p.OW;
+      int iy = oy * p.sy + ty, ix = ox * p.sx + tx;
+      ok = ok && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+      long long off = ok ? ((((long long)n * p.H + iy) * p.W + ix) * p.Cin + ci) : 0ll;
+      const float* src = p.in + off;
       if constexpr (V == 4) {
-        float4 v = ok ? *reinterpret_cast<const float4*>(src) : make_float4(0.f, 0.f, 0.f, 0.f);
-        areg[i][0] = v.x; areg[i][1] = v.y; areg[i][2] = v.z; areg[i][3] = v.w;
+        float4 v = *reinterpret_cast<const float4*>(src);
+        areg[i][0] = ok ? v.x : 0.f; areg[i][1] = ok ? v.y : 0.f; areg[i][2] = ok ? v.z : 0.f; areg[i][3] = ok ? v.w : 0.f;
       } else {
-        areg[i][0] = ok ? *src : 0.f;
+        float v = *src;
+        areg[i][0] = ok ? v : 0.f;
       }
     }
 #pragma unroll
     for (int i = 0; i < NPB; ++i) {
       int m = pc * BK + bpr0 + i * RPB;
-      bool ok = m < p.Mz && bcol < p.Cout;   // Cout % 4 == 0 is required by the host wrapper when V4 loads are used
-      long long pix = (long long)zs * (p.per_sample ? p.Mz : 0) + m;
-      const float* src = p.dout + pix * p.Cout + bcol;
-      if ((p.Cout & 3) == 0) {
-        breg[i] = ok ? *reinterpret_cast<const float4*>(src) : make_float4(0.f, 0.f, 0.f, 0.f);
+      bool rok = m < p.Mz;
+      long long pix = (long long)zs * (p.per_sample ? p.Mz : 0) + (rok ? m : 0);
+      if (cout4) {
+        bool ok = rok && bcol < p.Cout;
+        const float* src = p.dout + (ok ? (pix * p.Cout + bcol) : 0ll);
+        float4 v = *reinterpret_cast<const float4*>(src);
+        breg[i] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
       } else {
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (m < p.Mz) {
-          if (bcol + 0 < p.Cout) v.x = src[0];
-          if (bcol + 1 < p.Cout) v.y = src[1];
-          if (bcol + 2 < p.Cout) v.z = src[2];
-          if (bcol + 3 < p.Cout) v.w = src[3];
-        }
+        const float* src = p.dout + pix * p.Cout;
+        bool o0 = rok && bcol + 0 < p.Cout, o1 = rok && bcol + 1 < p.Cout, o2 = rok && bcol + 2 < p.Cout, o3 = rok && bcol + 3 < p.Cout;
+        float t0 = src[o0 ? bcol + 0 : 0], t1 = src[o1 ? bcol + 1 : 0], t2 = src[o2 ? bcol + 2 : 0], t3 = src[o3 ? bcol + 3 : 0];
+        v.x = o0 ? t0 : 0.f; v.y = o1 ? t1 : 0.f; v.z = o2 ? t2 : 0.f; v.w = o3 ? t3 : 0.f;
         breg[i] = v;
       }
     }
@@ -350,31 +366,39 @@ __global__ __launch_bounds__(256) void fsv_conv_wgrad_kernel(WgradP p) {
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   const int lrow = lane & 31, lk = lane >> 5;
+  const float* a_frag = &As[lk * BMK + wm * (TM * 32) + lrow];
+  const float* b_frag = &Bs[lk * BN + wn * (TN * 32) + lrow];
   if (c_begin < c_end) {
     load_chunk(c_begin);
     store_chunk();
     __syncthreads();
+#pragma unroll 1
     for (int pc = c_begin; pc < c_end; ++pc) {
-      const bool more = (pc + 1) < c_end;
-      if (more) load_chunk(pc + 1);
+      const int pnext = (pc + 1 < c_end) ? pc + 1 : pc;
+      load_chunk(pnext);
+      float a[2][TM], b[2][TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) a[0][i] = a_frag[i * 32];
+#pragma unroll
+      for (int j = 0; j < TN; ++j) b[0][j] = b_frag[j * 32];
 #pragma unroll
       for (int kk = 0; kk < BK / 2; ++kk) {
-        float a[TM], b[TN];
+        const int cur = kk & 1, nxt = cur ^ 1;
+        if (kk + 1 < BK / 2) {
 #pragma unroll
-        for (int i = 0; i < TM; ++i) a[i] = As[(kk * 2 + lk) * BMK + wm * (TM * 32) + i * 32 + lrow];
+          for (int i = 0; i < TM; ++i) a[nxt][i] = a_frag[(kk + 1) * 2 * BMK + i * 32];
 #pragma unroll
-        for (int j = 0; j < TN; ++j) b[j] = Bs[(kk * 2 + lk) * BN + wn * (TN * 32) + j * 32 + lrow];
+          for (int j = 0; j < TN; ++j) b[nxt][j] = b_frag[(kk + 1) * 2 * BN + j * 32];
+        }
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
           for (int j = 0; j < TN; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][i], b[cur][j], acc[i][j], 0, 0, 0);
       }
       __syncthreads();
-      if (more) {
-        store_chunk();
-        __syncthreads();
-      }
+      store_chunk();
+      __syncthreads();
     }
   }
 #pragma unroll

@@ -58,6 +58,7 @@ __global__ __launch_bounds__(256) void fsv_spade_mod_kernel(SpadeP p) {
   const int bq = tid % QB, br0 = tid / QB;
   const int bcol = bn0 + bq * 4;
   const bool bcol_ok = bcol < p.ldw;
+  const int bcol_safe = bcol_ok ? bcol : 0;
 
   // running value of the normalised + modulated activation, in MFMA C/D layout
   f32x16 outv[TM][TN];
@@ -104,13 +105,16 @@ __global__ __launch_bounds__(256) void fsv_spade_mod_kernel(SpadeP p) {
       for (int i = 0; i < NPA; ++i) {
         int m = bm0 + ar0 + i * RPP;
         bool ok = kk < Ch && m < p.HW;
-        areg[i] = ok ? *reinterpret_cast<const float4*>(mp + (long long)m * Ch + kk) : make_float4(0.f, 0.f, 0.f, 0.f);
+        float4 v = *reinterpret_cast<const float4*>(mp + (ok ? ((long long)m * Ch + kk) : 0ll));
+        areg[i] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
       }
 #pragma unroll
       for (int i = 0; i < NPB; ++i) {
         int kr = kc * BK + br0 + i * RPB;
-        gbreg[i] = bcol_ok ? *reinterpret_cast<const float4*>(wg + (long long)kr * p.ldw + bcol) : make_float4(0.f, 0.f, 0.f, 0.f);
-        bbreg[i] = bcol_ok ? *reinterpret_cast<const float4*>(wb + (long long)kr * p.ldw + bcol) : make_float4(0.f, 0.f, 0.f, 0.f);
+        float4 vg = *reinterpret_cast<const float4*>(wg + (long long)kr * p.ldw + bcol_safe);
+        float4 vb = *reinterpret_cast<const float4*>(wb + (long long)kr * p.ldw + bcol_safe);
+        gbreg[i] = bcol_ok ? vg : make_float4(0.f, 0.f, 0.f, 0.f);
+        bbreg[i] = bcol_ok ? vb : make_float4(0.f, 0.f, 0.f, 0.f);
       }
     };
     auto store_chunk = [&]() {
@@ -133,9 +137,10 @@ __global__ __launch_bounds__(256) void fsv_spade_mod_kernel(SpadeP p) {
     load_chunk(0);
     store_chunk();
     __syncthreads();
+#pragma unroll 1
     for (int kc = 0; kc < nchunks; ++kc) {
-      const bool more = (kc + 1) < nchunks;
-      if (more) load_chunk(kc + 1);
+      const int knext = (kc + 1 < nchunks) ? kc + 1 : kc;
+      load_chunk(knext);
 #pragma unroll
       for (int kk = 0; kk < BK / 2; ++kk) {
         float a[TM], g[TN], b[TN];
@@ -155,10 +160,8 @@ __global__ __launch_bounds__(256) void fsv_spade_mod_kernel(SpadeP p) {
           }
       }
       __syncthreads();
-      if (more) {
-        store_chunk();
-        __syncthreads();
-      }
+      store_chunk();
+      __syncthreads();
     }
     // modulation epilogue for this map
     const float* bg = p.bg[k] + z * p.b_bstride[k];
