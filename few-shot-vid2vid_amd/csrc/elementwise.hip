@@ -76,6 +76,42 @@ __global__ __launch_bounds__(256) void fsv_act_bwd_kernel(const float* dy, const
   }
 }
 
+// ---- softmax over the channel (last, contiguous) dimension of an NHWC tensor: one wave per pixel row ---------------
+// (reference: nn.Softmax(dim=1) on the encoded reference label features, generator.py:384)
+__global__ __launch_bounds__(256) void fsv_softmax_rows_fwd_kernel(const float* x, float* y, long long rows, int C) {
+  const int lane = threadIdx.x & 63;
+  const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const bool ok = row < rows;
+  const float* xr = x + (ok ? row : 0) * C;
+  float m = -3.0e38f;
+  for (int j = lane; j < C; j += 64) m = fmaxf(m, xr[j]);
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+  float s = 0.f;
+  for (int j = lane; j < C; j += 64) s += expf(xr[j] - m);
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+  const float inv = 1.f / s;
+  if (ok) {
+    float* yr = y + row * C;
+    for (int j = lane; j < C; j += 64) yr[j] = expf(xr[j] - m) * inv;
+  }
+}
+
+// dx = y * (dy - sum_j dy_j y_j)
+__global__ __launch_bounds__(256) void fsv_softmax_rows_bwd_kernel(const float* dy, const float* y, float* dx, long long rows, int C) {
+  const int lane = threadIdx.x & 63;
+  const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const bool ok = row < rows;
+  const float* yr = y + (ok ? row : 0) * C;
+  const float* gr = dy + (ok ? row : 0) * C;
+  float s = 0.f;
+  for (int j = lane; j < C; j += 64) s += gr[j] * yr[j];
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+  if (ok) {
+    float* dr = dx + row * C;
+    for (int j = lane; j < C; j += 64) dr[j] = yr[j] * (gr[j] - s);
+  }
+}
+
 // ---- Adam ------------------------------------------------------------------------------------------------------
 // state[0] = step count (as float), state[1] = 1 - beta1^t, state[2] = 1 - beta2^t, state[3] = lr (set by the host)
 __global__ void fsv_adam_tick_kernel(float* state, float beta1, float beta2) {
@@ -131,6 +167,18 @@ int fsv_act_fwd(const float* x, float* y, long long total, int act, hipStream_t 
 int fsv_act_bwd(const float* dy, const float* y, float* dx, long long total, int act, float scale, hipStream_t stream) {
   if (!dy || !y || !dx || total < 0) return FSV_ERR_BAD_ARG;
   FSV_LAUNCH(fsv_act_bwd_kernel, dim3(fsv_grid_for(total / 4 + 1)), dim3(256), stream, dy, y, dx, total, act, scale);
+  return fsv_check_launch();
+}
+
+int fsv_softmax_rows_fwd(const float* x, float* y, long long rows, int C, hipStream_t stream) {
+  if (!x || !y || rows < 1 || C < 1) return FSV_ERR_BAD_ARG;
+  FSV_LAUNCH(fsv_softmax_rows_fwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), stream, x, y, rows, C);
+  return fsv_check_launch();
+}
+
+int fsv_softmax_rows_bwd(const float* dy, const float* y, float* dx, long long rows, int C, hipStream_t stream) {
+  if (!dy || !y || !dx || rows < 1 || C < 1) return FSV_ERR_BAD_ARG;
+  FSV_LAUNCH(fsv_softmax_rows_bwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), stream, dy, y, dx, rows, C);
   return fsv_check_launch();
 }
 

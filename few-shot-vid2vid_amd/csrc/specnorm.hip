@@ -138,3 +138,96 @@ int fsv_sn_backward(const float* dWsn, const float* W, const float* u, const flo
 }
 
 }  // extern "C"
+
+// ---- batched power iteration: every spectral-normalised layer of a network in three launches -------------------
+// A network's weights do not change during its forward pass, so the per-layer power iterations of the reference
+// (one forward pre-hook per module) can run up front as one grouped pass.  Layer geometry comes from device-side
+// descriptor arrays built once by the host; `tmap` maps a flat block index to (layer, tile).
+struct SnBatch {
+  const long long* W;      // [L] device pointers (as integers)
+  const long long* u;
+  const long long* v;
+  const int* rows;
+  const int* cols;
+  const int* t_off;        // offsets into scratch: t[cols]
+  const int* s_off;        //                       s[rows]
+  float* scratch;
+  float* sig;              // [L][2]
+};
+
+__global__ __launch_bounds__(256) void fsv_snb_gemv_t_kernel(SnBatch b, const int* tmap) {
+  const int layer = tmap[blockIdx.x * 2], tile = tmap[blockIdx.x * 2 + 1];
+  const int R = b.rows[layer], Cc = b.cols[layer];
+  const int ncb = (Cc + 255) / 256;
+  const int cb = tile % ncb, rs = tile / ncb;
+  const float* W = reinterpret_cast<const float*>(b.W[layer]);
+  const float* u = reinterpret_cast<const float*>(b.u[layer]);
+  float* t = b.scratch + b.t_off[layer];
+  const int j = cb * 256 + threadIdx.x;
+  const int r0 = rs * 64, r1 = (r0 + 64 < R) ? r0 + 64 : R;
+  if (j >= Cc) return;
+  float acc = 0.f;
+  for (int i = r0; i < r1; ++i) acc += W[(long long)i * Cc + j] * u[i];
+  atomicAdd(&t[j], acc);
+}
+
+__global__ __launch_bounds__(256) void fsv_snb_gemv_kernel(SnBatch b, const int* tmap) {
+  const int layer = tmap[blockIdx.x * 2], grp = tmap[blockIdx.x * 2 + 1];
+  const int R = b.rows[layer], Cc = b.cols[layer];
+  const float* W = reinterpret_cast<const float*>(b.W[layer]);
+  const float* t = b.scratch + b.t_off[layer];
+  float* s = b.scratch + b.s_off[layer];
+  const int lane = threadIdx.x & 63;
+  const int row = grp * 4 + (threadIdx.x >> 6);
+  const bool ok = row < R;
+  const float* w = W + (long long)(ok ? row : 0) * Cc;
+  float acc = 0.f;
+  if (ok) for (int j = lane; j < Cc; j += 64) acc += w[j] * t[j];
+  for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+  if (ok && lane == 0) s[row] = acc;
+}
+
+__global__ __launch_bounds__(256) void fsv_snb_finalize_kernel(SnBatch b, float eps) {
+  __shared__ float red[256];
+  const int layer = blockIdx.x;
+  const int R = b.rows[layer], Cc = b.cols[layer];
+  const float* t = b.scratch + b.t_off[layer];
+  const float* s = b.scratch + b.s_off[layer];
+  float* u = reinterpret_cast<float*>(b.u[layer]);
+  float* v = reinterpret_cast<float*>(b.v[layer]);
+  float a = 0.f;
+  for (int j = threadIdx.x; j < Cc; j += 256) a += t[j] * t[j];
+  red[threadIdx.x] = a;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) { if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o]; __syncthreads(); }
+  const float nt = fmaxf(sqrtf(red[0]), eps);
+  __syncthreads();
+  for (int j = threadIdx.x; j < Cc; j += 256) v[j] = t[j] / nt;
+  float bb = 0.f;
+  for (int i = threadIdx.x; i < R; i += 256) { float wv = s[i] / nt; bb += wv * wv; }
+  red[threadIdx.x] = bb;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) { if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o]; __syncthreads(); }
+  const float ns = fmaxf(sqrtf(red[0]), eps);
+  __syncthreads();
+  float c = 0.f;
+  for (int i = threadIdx.x; i < R; i += 256) { float wv = s[i] / nt; float ui = wv / ns; u[i] = ui; c += ui * wv; }
+  red[threadIdx.x] = c;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) { if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o]; __syncthreads(); }
+  if (threadIdx.x == 0) { b.sig[layer * 2] = red[0]; b.sig[layer * 2 + 1] = 1.f / red[0]; }
+}
+
+extern "C" int fsv_sn_power_iter_batched(const long long* W, const long long* u, const long long* v, const int* rows,
+                                         const int* cols, const int* t_off, const int* s_off, float* scratch,
+                                         long long scratch_floats, float* sig, int nlayers, const int* tmap_t,
+                                         int nblk_t, const int* tmap_s, int nblk_s, float eps, hipStream_t stream) {
+  if (!W || !u || !v || !rows || !cols || !t_off || !s_off || !scratch || !sig || nlayers < 1) return FSV_ERR_BAD_ARG;
+  SnBatch b;
+  b.W = W; b.u = u; b.v = v; b.rows = rows; b.cols = cols; b.t_off = t_off; b.s_off = s_off; b.scratch = scratch; b.sig = sig;
+  (void)hipMemsetAsync(scratch, 0, sizeof(float) * (size_t)scratch_floats, stream);
+  FSV_LAUNCH(fsv_snb_gemv_t_kernel, dim3(nblk_t), dim3(256), stream, b, tmap_t);
+  FSV_LAUNCH(fsv_snb_gemv_kernel, dim3(nblk_s), dim3(256), stream, b, tmap_s);
+  FSV_LAUNCH(fsv_snb_finalize_kernel, dim3(nlayers), dim3(256), stream, b, eps);
+  return fsv_check_launch();
+}

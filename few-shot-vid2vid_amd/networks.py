@@ -27,8 +27,14 @@ class _SpectralMixin:
         self.register_buffer('weight_u', F.normalize(torch.randn(rows), dim=0, eps=1e-12))
         self.register_buffer('weight_v', F.normalize(torch.randn(cols), dim=0, eps=1e-12))
 
+    _sig_cached = None
+
     def _sn(self):
-        sig = ops.SpectralState.update(self.weight_orig, self.weight_u, self.weight_v, self.training)
+        sig = self._sig_cached           # filled by the network-level batched pass (ops.SpectralGroup)
+        if sig is not None:
+            self._sig_cached = None
+        else:
+            sig = ops.SpectralState.update(self.weight_orig, self.weight_u, self.weight_v, self.training)
         return (sig, self.weight_u, self.weight_v)
 
 
@@ -215,6 +221,16 @@ class SPADEResnetBlock(nn.Module):
         return self.conv_1(self.bn_1(dx, act=ACT_LRELU), res=x_s)
 
 
+def spectral_layers(module):
+    """every spectral-normalised Conv2d / Linear below `module`, each once, in registration order"""
+    seen, out = set(), []
+    for m in module.modules():
+        if getattr(m, 'spectral', False) and id(m) not in seen:
+            seen.add(id(m))
+            out.append(m)
+    return out
+
+
 def _channels(nf, n, cap=1024):
     return [min(cap, nf * (2 ** i)) for i in range(n)]
 
@@ -368,6 +384,7 @@ class FewShotGenerator(nn.Module):
             setattr(self, 'up_%d' % i, SPADEResnetBlock(ch[i + 1], ch[i], hidden_nc=ch_hidden[i], spade=True,
                                                        norm_params_free=(self.adap_spade and i < self.n_adaptive_layers)))
         self.conv_img = Conv2d(nf, 3, 3, padding=1)
+        self._sn_group, self._sn_count = None, -1
         self.warp_prev = False
         self.warp_ref = opt.warp_ref and not getattr(opt, 'for_face', False)
         if self.warp_ref:
@@ -449,7 +466,7 @@ class FewShotGenerator(nn.Module):
         enc = []
         for a, l in zip(fi, fl):
             b, c, h, w = a.shape
-            sm = torch.softmax(l, dim=1)
+            sm = ops.softmax_channels(l)
             # prod[b, i, j] = sum_p a[b, i, p] * sm[b, j, p]  as a per-sample 1x1 "convolution" on the gather-GEMM
             # kernel: pixels = image channels i, input channels = positions p, generated weights = softmax rows j
             a_rows = a.reshape(b, c, 1, h * w).permute(0, 3, 1, 2)              # logical [b, hw, c, 1]
@@ -490,6 +507,10 @@ class FewShotGenerator(nn.Module):
     def forward(self, label, label_refs, img_refs, prev=(None, None), t=0, img_coarse=None):
         if img_coarse is not None:
             raise NotImplementedError("face refinement generator (refine_face) is outside the hot-path scope")
+        if self._sn_group is None or self._sn_count != sum(1 for _ in self.modules()):
+            self._sn_group = ops.SpectralGroup(spectral_layers(self))
+            self._sn_count = sum(1 for _ in self.modules())
+        self._sn_group.update(self.training)
         x, enc_label, norm_w = self.weight_generation(img_refs, label_refs, label)
         label_ref, img_ref = label_refs[:, 0], img_refs[:, 0]
         flow, mask, warp, ds = self.flow_generation(label, label_ref, img_ref, prev)
@@ -533,8 +554,12 @@ class NLayerDiscriminator(nn.Module):
         setattr(self, 'model%d' % n_layers, _seq(_seq(Conv2d(nf_prev, nf, 4, stride=1, padding=2, bias=False, spectral=True),
                                                       InstanceNorm(nf)), _Slot()))
         setattr(self, 'model%d' % (n_layers + 1), _seq(Conv2d(nf, 1, 4, stride=1, padding=2)))
+        self._sn_group = None
 
     def forward(self, x):
+        if self._sn_group is None:
+            self._sn_group = ops.SpectralGroup(spectral_layers(self))
+        self._sn_group.update(self.training)
         res = []
         x = self.model0[0](x, act=ACT_LRELU)
         res.append(x)

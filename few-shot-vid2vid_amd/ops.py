@@ -37,9 +37,12 @@ lib.register_sigs({
     "fsv_upsample2x_bwd": [c_p, c_p, c_i, c_i, c_i, c_i, c_p],
     "fsv_act_fwd": [c_p, c_p, c_ll, c_i, c_p],
     "fsv_act_bwd": [c_p, c_p, c_p, c_ll, c_i, c_f, c_p],
+    "fsv_softmax_rows_fwd": [c_p, c_p, c_ll, c_i, c_p],
+    "fsv_softmax_rows_bwd": [c_p, c_p, c_p, c_ll, c_i, c_p],
     "fsv_adam_step": [c_p, c_p, c_p, c_p, c_p, c_ll, c_f, c_f, c_f, c_f, c_p],
     "fsv_sn_power_iter": [c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_f, c_i, c_p],
     "fsv_sn_backward": [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_p],
+    "fsv_sn_power_iter_batched": [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_ll, c_p, c_i, c_p, c_i, c_p, c_i, c_f, c_p],
 })
 
 _ws_fn = None
@@ -95,6 +98,32 @@ def activation(x, act=ACT_LRELU):
     return _ActFn.apply(x, act)
 
 
+class _SoftmaxChFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        x = to_nhwc(x)
+        n, c, h, w = x.shape
+        y = torch.empty_like(x)
+        lib.check_device(x)
+        lib.call("fsv_softmax_rows_fwd", lib.ptr(x), lib.ptr(y), n * h * w, c, lib.stream_ptr())
+        ctx.save_for_backward(y)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (y,) = ctx.saved_tensors
+        dy = to_nhwc(dy)
+        n, c, h, w = y.shape
+        dx = torch.empty_like(y)
+        lib.call("fsv_softmax_rows_bwd", lib.ptr(dy), lib.ptr(y), lib.ptr(dx), n * h * w, c, lib.stream_ptr())
+        return dx
+
+
+def softmax_channels(x):
+    """nn.Softmax(dim=1) on an NCHW tensor (generator.py:384): a row softmax in channels-last memory."""
+    return _SoftmaxChFn.apply(x)
+
+
 # ------------------------------------------------------------------------------------------------ column sums
 def colsum(x2d_nhwc, groups, pixels, channels):
     """x viewed as [groups][pixels][channels] -> [groups, channels]."""
@@ -123,6 +152,66 @@ class SpectralState:
         lib.call("fsv_sn_power_iter", lib.ptr(w), lib.ptr(u), lib.ptr(v), lib.ptr(scratch), lib.ptr(sig), rows, cols,
                  float(eps), 1 if training else 0, lib.stream_ptr())
         return sig
+
+
+class SpectralGroup:
+    """All spectral-normalised layers of one network, power-iterated together in three launches
+    (csrc/specnorm.hip, fsv_sn_power_iter_batched) at the start of the network's forward pass.
+
+    `layers` are modules exposing weight_orig / weight_u / weight_v.  After `update()` every layer holds a fresh
+    (sigma, 1/sigma) view in `_sig_cached`; a layer consumes it on its first call of the forward pass and falls back
+    to its own iteration if it is called again (modules shared between two branches iterate twice, like the
+    reference's per-call forward pre-hook)."""
+
+    def __init__(self, layers):
+        self.layers = list(layers)
+        self._key = None
+
+    def _build(self, device):
+        import numpy as np
+        rows = [l.weight_orig.shape[0] for l in self.layers]
+        cols = [l.weight_orig.numel() // r for l, r in zip(self.layers, rows)]
+        t_off, s_off, off = [], [], 0
+        for r, c in zip(rows, cols):
+            t_off.append(off); off += c
+            s_off.append(off); off += r
+        self.scratch_floats = off
+        tmap_t, tmap_s = [], []
+        for li, (r, c) in enumerate(zip(rows, cols)):
+            ntile = ((c + 255) // 256) * ((r + 63) // 64)
+            tmap_t += [(li, t) for t in range(ntile)]
+            tmap_s += [(li, g) for g in range((r + 3) // 4)]
+        mk = lambda a, dt: torch.tensor(a, dtype=dt, device=device)
+        self.d_W = mk([l.weight_orig.data_ptr() for l in self.layers], torch.int64)
+        self.d_u = mk([l.weight_u.data_ptr() for l in self.layers], torch.int64)
+        self.d_v = mk([l.weight_v.data_ptr() for l in self.layers], torch.int64)
+        self.d_rows, self.d_cols = mk(rows, torch.int32), mk(cols, torch.int32)
+        self.d_toff, self.d_soff = mk(t_off, torch.int32), mk(s_off, torch.int32)
+        self.d_tmap_t = mk(tmap_t, torch.int32).reshape(-1)
+        self.d_tmap_s = mk(tmap_s, torch.int32).reshape(-1)
+        self.nblk_t, self.nblk_s = len(tmap_t), len(tmap_s)
+        self.scratch = torch.empty(off, dtype=torch.float32, device=device)
+
+    def update(self, training, eps=1e-12):
+        if not self.layers or not training:
+            return
+        w0 = self.layers[0].weight_orig
+        key = (w0.data_ptr(), self.layers[-1].weight_orig.data_ptr(), self.layers[0].weight_u.data_ptr(), str(w0.device))
+        if key != self._key:           # parameters were moved (e.g. into the flat optimiser buffer): rebuild the table
+            for l in self.layers:
+                if not l.weight_orig.is_contiguous():
+                    raise lib.FsvError("spectral weights must be contiguous")
+            self._build(w0.device)
+            self._key = key
+        n = len(self.layers)
+        sig = torch.empty((n, 2), dtype=torch.float32, device=w0.device)
+        lib.check_device(w0)
+        lib.call("fsv_sn_power_iter_batched", lib.ptr(self.d_W), lib.ptr(self.d_u), lib.ptr(self.d_v), lib.ptr(self.d_rows),
+                 lib.ptr(self.d_cols), lib.ptr(self.d_toff), lib.ptr(self.d_soff), lib.ptr(self.scratch),
+                 self.scratch_floats, lib.ptr(sig), n, lib.ptr(self.d_tmap_t), self.nblk_t, lib.ptr(self.d_tmap_s),
+                 self.nblk_s, float(eps), lib.stream_ptr())
+        for i, l in enumerate(self.layers):
+            l._sig_cached = sig[i]
 
 
 def sn_backward(dwsn, weight, u, v, sig):

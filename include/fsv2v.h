@@ -103,6 +103,12 @@ int fsv_warp_bwd(const float* img, const float* flow, const float* lin_x, const 
 /* ---- spectral norm (csrc/specnorm.hip) - torch.nn.utils.spectral_norm at architecture.py:60,81-84 etc. ----------- */
 int fsv_sn_power_iter(const float* W, float* u, float* v, float* scratch, float* sig, int R, int Cc, float eps,
                       int training, fsv_stream_t stream);
+/* every spectral-normalised layer of a network in three launches; W/u/v are arrays of device pointers (as 64-bit
+ * integers), tmap_* map a flat block index to (layer, tile) */
+int fsv_sn_power_iter_batched(const long long* W, const long long* u, const long long* v, const int* rows,
+                              const int* cols, const int* t_off, const int* s_off, float* scratch,
+                              long long scratch_floats, float* sig, int nlayers, const int* tmap_t, int nblk_t,
+                              const int* tmap_s, int nblk_s, float eps, fsv_stream_t stream);
 int fsv_sn_backward(const float* dWsn, const float* W, const float* u, const float* v, const float* sig, double* part,
                     float* dW, int R, int Cc, fsv_stream_t stream);
 
@@ -112,6 +118,9 @@ int fsv_upsample2x_fwd(const float* x, float* y, int N, int H, int W, int C, fsv
 int fsv_upsample2x_bwd(const float* dy, float* dx, int N, int H, int W, int C, fsv_stream_t stream);
 int fsv_act_fwd(const float* x, float* y, long long total, int act, fsv_stream_t stream);
 int fsv_act_bwd(const float* dy, const float* y, float* dx, long long total, int act, float scale, fsv_stream_t stream);
+/* softmax over the contiguous channel dimension of [rows][C] (nn.Softmax(dim=1) at generator.py:384) */
+int fsv_softmax_rows_fwd(const float* x, float* y, long long rows, int C, fsv_stream_t stream);
+int fsv_softmax_rows_bwd(const float* dy, const float* y, float* dx, long long rows, int C, fsv_stream_t stream);
 /* state = {t, 1-beta1^t, 1-beta2^t, lr} on the device; gscale pre-multiplies the gradient (1/world_size) */
 int fsv_adam_step(float* param, const float* grad, float* m, float* v, float* state, long long n, float beta1,
                   float beta2, float eps, float gscale, fsv_stream_t stream);

@@ -281,6 +281,21 @@ def check_warp_index_image(device, h=32, w=512, seed=8):
     assert torch.equal(taps, ref_taps)
 
 
+def check_softmax(device, n=2, c=70, h=3, w=5, seed=12):
+    ops, conv = pkg()
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(n, c, h, w, generator=g) * 3
+    xr = x.clone().requires_grad_(True)
+    ref = torch.softmax(xr, dim=1)
+    dy = torch.randn(ref.shape, generator=g)
+    ref.backward(dy)
+    xd = _dev(x, device).requires_grad_(True)
+    y = ops.softmax_channels(xd)
+    y.backward(_dev(dy, device))
+    assert_close('softmax y', y, ref, 1e-5)
+    assert_close('softmax dx', xd.grad, xr.grad, 1e-4)
+
+
 def check_adam(device, n=1000, seed=9):
     ops, conv = pkg()
     g = torch.Generator().manual_seed(seed)

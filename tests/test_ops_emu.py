@@ -69,3 +69,8 @@ def test_warp_tap_indices_bit_exact(emu_lib):
 
 def test_adam(emu_lib):
     oc.check_adam(DEV, n=300)
+
+
+def test_softmax_channels(emu_lib):
+    oc.check_softmax(DEV)
+    oc.check_softmax(DEV, n=1, c=1024, h=4, w=4)

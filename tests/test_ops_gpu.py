@@ -90,3 +90,8 @@ def test_warp_full_size_zero_flow_round_trip(hip_lib):
 
 def test_adam(hip_lib):
     oc.check_adam(dev(), n=100003)
+
+
+def test_softmax_channels(hip_lib):
+    oc.check_softmax(dev())
+    oc.check_softmax(dev(), n=1, c=1024, h=4, w=4)
