@@ -599,8 +599,10 @@ int fsv_conv_wgrad(const float* in, const float* dout, float* dwt,
   }
   if (nsplit > p.pchunks) nsplit = p.pchunks;
   p.nsplit = nsplit;
-  // the whole padded matrix is (re)written: rows >= K / cols >= Cout stay zero
-  (void)hipMemsetAsync(dwt, 0, (size_t)((per_sample ? (long long)N * w_bstride : (long long)Kpad * ldw)) * sizeof(float), stream);
+  // split reductions add into dwt atomically and need it zeroed; a single split stores every (k < K, co < Cout)
+  // entry directly and the padding rows / columns are never read back (fsv_prep_weight mode 2 skips them)
+  if (nsplit > 1)
+    (void)hipMemsetAsync(dwt, 0, (size_t)((per_sample ? (long long)N * w_bstride : (long long)Kpad * ldw)) * sizeof(float), stream);
   dim3 block(256);
   const bool vec4 = (Cin % 4 == 0);
   dim3 g(fsv_cdiv(p.K, 128), fsv_cdiv(Cout, bn), nsamp * nsplit);

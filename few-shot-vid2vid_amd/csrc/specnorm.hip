@@ -73,10 +73,17 @@ __global__ __launch_bounds__(256) void fsv_sn_sigma_kernel(const float* s, const
 // partial dot products <A, B> -> part[block] (double)
 __global__ __launch_bounds__(256) void fsv_dot_partial_kernel(const float* a, const float* b, double* part, long long n) {
   __shared__ double red[256];
-  long long i = (long long)blockIdx.x * 256 + threadIdx.x;
   const long long stride = (long long)gridDim.x * 256;
   float acc = 0.f; double dacc = 0.0; int cnt = 0;
-  for (; i < n; i += stride) { acc += a[i] * b[i]; if (++cnt == 64) { dacc += (double)acc; acc = 0.f; cnt = 0; } }
+  const long long n4 = ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b)) & 15) == 0 ? n / 4 : 0;
+  const float4* a4 = reinterpret_cast<const float4*>(a);
+  const float4* b4 = reinterpret_cast<const float4*>(b);
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
+    float4 x = a4[i], y = b4[i];
+    acc += (x.x * y.x + x.y * y.y) + (x.z * y.z + x.w * y.w);
+    if (++cnt == 16) { dacc += (double)acc; acc = 0.f; cnt = 0; }
+  }
+  for (long long i = n4 * 4 + (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) acc += a[i] * b[i];
   red[threadIdx.x] = dacc + (double)acc;
   __syncthreads();
   for (int o = 128; o > 0; o >>= 1) { if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o]; __syncthreads(); }
@@ -127,7 +134,7 @@ int fsv_sn_backward(const float* dWsn, const float* W, const float* u, const flo
                     float* dW, int R, int Cc, hipStream_t stream) {
   if (!dWsn || !W || !u || !v || !sig || !part || !dW) return FSV_ERR_BAD_ARG;
   long long n = (long long)R * Cc;
-  int nparts = (int)((n + 256 * 64 - 1) / (256 * 64));
+  int nparts = (int)((n + 256 * 16 - 1) / (256 * 16));
   if (nparts > 256) nparts = 256;
   if (nparts < 1) nparts = 1;
   FSV_LAUNCH(fsv_dot_partial_kernel, dim3(nparts), dim3(256), stream, dWsn, W, part, n);

@@ -247,7 +247,10 @@ class _ConvFn(torch.autograd.Function):
         ctx.geom, ctx.act, ctx.scale, ctx.per_sample = geom, act, scale, per_sample
         ctx.has_bias, ctx.has_res, ctx.has_sn = bias is not None, res is not None, sig is not None
         ctx.x_shape = tuple(x.shape)
+        if not any(ctx.needs_input_grad):
+            return y                     # forward under no_grad (the D step's generator pass): nothing to keep
         if ctx.has_sn:
+            # u / v are persistent buffers that the next power iteration overwrites: keep this call's copies
             ctx.save_for_backward(x, weight, y, sig, u.clone(), v.clone())
         else:
             ctx.save_for_backward(x, weight, y)
