@@ -1,0 +1,239 @@
+// Loss reductions, discriminator-input packing and label-mask pooling of the G/D step (SURVEY.md section 8a rows
+// a-10 and a-13) - all HBM-bound, all fused into single passes.
+//
+// Reference: models/networks/loss.py:69-83 (hinge), :130-138 (MaskedL1Loss), torch.nn.L1Loss at
+// models/loss_collector.py:36,152,156,206-215; D input concatenation loss_collector.py:47-58,105-110;
+// MaxPool2d(15)/AvgPool2d(15) masks input_process.py:59, loss_collector.py:180.
+#include "fsv_common.h"
+
+#define FSV_LOSS_BLOCKS 512
+
+__device__ __forceinline__ double fsv_block_sum(double v, double* red) {
+  red[threadIdx.x] = v;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) { if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o]; __syncthreads(); }
+  double r = red[0];
+  __syncthreads();
+  return r;
+}
+
+// ---- masked L1: sum_p sum_c | m_p * (a_pc - b_pc) | -----------------------------------------------------------------
+// a, b: [N][C][P] with explicit element strides (batch, channel, pixel); b may be null -> constant bconst.
+// m: [N][P] contiguous or null (-> 1).  One work-item per (n, pixel); channels are looped.
+struct L1P {
+  const float* a; const float* b; const float* m;
+  long long asn, asc, asp, bsn, bsc, bsp;
+  float bconst;
+  int N, C; long long P;
+};
+
+__global__ __launch_bounds__(256) void fsv_l1_fwd_kernel(L1P p, double* part) {
+  __shared__ double red[256];
+  const long long total = (long long)p.N * p.P;
+  double acc = 0.0;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const long long n = i / p.P, px = i - n * p.P;
+    const float mv = p.m ? p.m[i] : 1.f;
+    float s = 0.f;
+    for (int c = 0; c < p.C; ++c) {
+      float av = p.a[n * p.asn + c * p.asc + px * p.asp];
+      float bv = p.b ? p.b[n * p.bsn + c * p.bsc + px * p.bsp] : p.bconst;
+      s += fabsf(av * mv - bv * mv);
+    }
+    acc += (double)s;
+  }
+  double t = fsv_block_sum(acc, red);
+  if (threadIdx.x == 0) part[blockIdx.x] = t;
+}
+
+// out[0] = scale * sum(part)
+__global__ void fsv_loss_final_kernel(const double* part, int nparts, float* out, double scale) {
+  __shared__ double red[256];
+  double a = 0.0;
+  for (int i = threadIdx.x; i < nparts; i += 256) a += part[i];
+  double t = fsv_block_sum(a, red);
+  if (threadIdx.x == 0) out[0] = (float)(t * scale);
+}
+
+// gradients: da = g * sgn * m / cnt, db = -da, dm = g * sum_c sgn * (a - b) / cnt, sgn = sign(a*m - b*m)
+__global__ __launch_bounds__(256) void fsv_l1_bwd_kernel(L1P p, const float* gptr, float inv_cnt, float* da, float* db, float* dm) {
+  const long long total = (long long)p.N * p.P;
+  const float g = gptr[0] * inv_cnt;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const long long n = i / p.P, px = i - n * p.P;
+    const float mv = p.m ? p.m[i] : 1.f;
+    float gm = 0.f;
+    for (int c = 0; c < p.C; ++c) {
+      const long long ia = n * p.asn + c * p.asc + px * p.asp;
+      const long long ib = n * p.bsn + c * p.bsc + px * p.bsp;
+      float av = p.a[ia];
+      float bv = p.b ? p.b[ib] : p.bconst;
+      float d = av * mv - bv * mv;
+      float sg = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);
+      if (da) da[ia] = g * sg * mv;             // da / db share the layout (strides) of a / b
+      if (db) db[ib] = -g * sg * mv;
+      gm += sg * (av - bv);
+    }
+    if (dm) dm[i] = g * gm;
+  }
+}
+
+// ---- hinge: sum min(sign * x - 1, 0) ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void fsv_hinge_fwd_kernel(const float* x, long long n, float sign, double* part) {
+  __shared__ double red[256];
+  double acc = 0.0;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256)
+    acc += (double)fminf(sign * x[i] - 1.f, 0.f);
+  double t = fsv_block_sum(acc, red);
+  if (threadIdx.x == 0) part[blockIdx.x] = t;
+}
+
+// loss = -(1/n) sum min(s x - 1, 0)  ->  dx = g * (-1/n) * s * [s x - 1 < 0]   (ties: 1/2, as torch.min does)
+__global__ __launch_bounds__(256) void fsv_hinge_bwd_kernel(const float* x, long long n, float sign, const float* gptr, float* dx) {
+  const float g = -gptr[0] / (float)n * sign;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+    float v = sign * x[i] - 1.f;
+    dx[i] = v < 0.f ? g : (v == 0.f ? 0.5f * g : 0.f);
+  }
+}
+
+// ---- discriminator input: out[2B][H][W][Cr + Cl + Ci] (NHWC) = [ref | label | (fake for n < B, real otherwise)] -------------
+struct PackP {
+  const float* ref; const float* lab; const float* fake; const float* real;
+  long long rs[3], ls[3], fs[3], es[3];      // element strides (batch, channel, pixel) of each source
+  int Cr, Cl, Ci, B; long long P;
+  float* out;
+};
+
+__global__ __launch_bounds__(256) void fsv_pack_d_kernel(PackP p) {
+  const long long total = 2LL * p.B * p.P;
+  const int Ct = p.Cr + p.Cl + p.Ci;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const long long n2 = i / p.P, px = i - n2 * p.P;
+    const long long n = n2 % p.B;
+    float* o = p.out + i * Ct;
+    for (int c = 0; c < p.Cr; ++c) o[c] = p.ref[n * p.rs[0] + c * p.rs[1] + px * p.rs[2]];
+    for (int c = 0; c < p.Cl; ++c) o[p.Cr + c] = p.lab[n * p.ls[0] + c * p.ls[1] + px * p.ls[2]];
+    const bool isfake = n2 < p.B;
+    const float* src = isfake ? p.fake : p.real;
+    const long long* st = isfake ? p.fs : p.es;
+    for (int c = 0; c < p.Ci; ++c) o[p.Cr + p.Cl + c] = src[n * st[0] + c * st[1] + px * st[2]];
+  }
+}
+
+// dfake[n][c][px] (contiguous NCHW) = dout[n][px][Cr + Cl + c]
+__global__ __launch_bounds__(256) void fsv_unpack_d_kernel(const float* dout, float* dfake, int B, int Ci, int Coff, int Ct, long long P) {
+  const long long total = (long long)B * Ci * P;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const long long px = i % P;
+    const long long t = i / P;
+    const int c = (int)(t % Ci);
+    const long long n = t / Ci;
+    dfake[i] = dout[(n * P + px) * Ct + Coff + c];
+  }
+}
+
+// ---- 15x15 stride-1 pooling of single-channel masks (zero / -inf padding 7) ----------------------------------------------
+// mode 0: max pool followed by (v > thresh) ? 1 : 0 ;  mode 1: average pool (count_include_pad = True)
+__global__ __launch_bounds__(256) void fsv_pool15_kernel(const float* x, float* y, int N, int H, int W, long long sn, long long sy,
+                                                         long long sx, int mode, float thresh) {
+  const long long total = (long long)N * H * W;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int xx = (int)(i % W);
+    const int yy = (int)((i / W) % H);
+    const long long n = i / ((long long)W * H);
+    const float* base = x + n * sn;
+    float acc = mode == 0 ? -3.0e38f : 0.f;
+    for (int dy = -7; dy <= 7; ++dy) {
+      const int y2 = yy + dy;
+      if ((unsigned)y2 >= (unsigned)H) continue;
+      for (int dx = -7; dx <= 7; ++dx) {
+        const int x2 = xx + dx;
+        if ((unsigned)x2 >= (unsigned)W) continue;
+        float v = base[y2 * sy + x2 * sx];
+        acc = mode == 0 ? fmaxf(acc, v) : acc + v;
+      }
+    }
+    y[i] = mode == 0 ? (acc > thresh ? 1.f : 0.f) : acc * (1.f / 225.f);
+  }
+}
+
+static inline int fsv_loss_grid(long long n) {
+  long long g = (n + 255) / 256;
+  if (g > FSV_LOSS_BLOCKS) g = FSV_LOSS_BLOCKS;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+
+extern "C" {
+
+// loss[0] = (1 / (N*C*P)) * sum |a*m - b*m|.  strides: 3 x long long (batch, channel, pixel).  part: double[512].
+int fsv_l1_fwd(const float* a, const float* b, float bconst, const float* m, int N, int C, long long P,
+               const long long* a_strides, const long long* b_strides, double* part, float* loss, hipStream_t stream) {
+  if (!a || !part || !loss || N < 1 || C < 1 || P < 1) return FSV_ERR_BAD_ARG;
+  L1P p;
+  p.a = a; p.b = b; p.m = m; p.bconst = bconst; p.N = N; p.C = C; p.P = P;
+  p.asn = a_strides[0]; p.asc = a_strides[1]; p.asp = a_strides[2];
+  if (b) { p.bsn = b_strides[0]; p.bsc = b_strides[1]; p.bsp = b_strides[2]; } else { p.bsn = p.bsc = p.bsp = 0; }
+  const int grid = fsv_loss_grid((long long)N * P);
+  FSV_LAUNCH(fsv_l1_fwd_kernel, dim3(grid), dim3(256), stream, p, part);
+  FSV_LAUNCH(fsv_loss_final_kernel, dim3(1), dim3(256), stream, (const double*)part, grid, loss, 1.0 / ((double)N * C * P));
+  return fsv_check_launch();
+}
+
+int fsv_l1_bwd(const float* a, const float* b, float bconst, const float* m, int N, int C, long long P,
+               const long long* a_strides, const long long* b_strides, const float* gloss, float* da, float* db, float* dm,
+               hipStream_t stream) {
+  if (!a || !gloss || N < 1 || C < 1 || P < 1) return FSV_ERR_BAD_ARG;
+  L1P p;
+  p.a = a; p.b = b; p.m = m; p.bconst = bconst; p.N = N; p.C = C; p.P = P;
+  p.asn = a_strides[0]; p.asc = a_strides[1]; p.asp = a_strides[2];
+  if (b) { p.bsn = b_strides[0]; p.bsc = b_strides[1]; p.bsp = b_strides[2]; } else { p.bsn = p.bsc = p.bsp = 0; }
+  FSV_LAUNCH(fsv_l1_bwd_kernel, dim3(fsv_loss_grid((long long)N * P)), dim3(256), stream, p, gloss,
+             (float)(1.0 / ((double)N * C * P)), da, db, dm);
+  return fsv_check_launch();
+}
+
+// loss[0] = -(1/n) * sum min(sign * x - 1, 0)
+int fsv_hinge_fwd(const float* x, long long n, float sign, double* part, float* loss, hipStream_t stream) {
+  if (!x || !part || !loss || n < 1) return FSV_ERR_BAD_ARG;
+  const int grid = fsv_loss_grid(n);
+  FSV_LAUNCH(fsv_hinge_fwd_kernel, dim3(grid), dim3(256), stream, x, n, sign, part);
+  FSV_LAUNCH(fsv_loss_final_kernel, dim3(1), dim3(256), stream, (const double*)part, grid, loss, -1.0 / (double)n);
+  return fsv_check_launch();
+}
+
+int fsv_hinge_bwd(const float* x, long long n, float sign, const float* gloss, float* dx, hipStream_t stream) {
+  if (!x || !gloss || !dx || n < 1) return FSV_ERR_BAD_ARG;
+  FSV_LAUNCH(fsv_hinge_bwd_kernel, dim3(fsv_loss_grid(n)), dim3(256), stream, x, n, sign, gloss, dx);
+  return fsv_check_launch();
+}
+
+int fsv_pack_d_input(const float* ref, const float* lab, const float* fake, const float* real, float* out,
+                     int B, int Cr, int Cl, int Ci, long long P, const long long* ref_strides, const long long* lab_strides,
+                     const long long* fake_strides, const long long* real_strides, hipStream_t stream) {
+  if (!fake || !real || !out || B < 1 || Ci < 1 || P < 1 || (Cr > 0 && !ref) || (Cl > 0 && !lab)) return FSV_ERR_BAD_ARG;
+  PackP p;
+  p.ref = ref; p.lab = lab; p.fake = fake; p.real = real; p.out = out;
+  for (int i = 0; i < 3; ++i) {
+    p.rs[i] = ref ? ref_strides[i] : 0; p.ls[i] = lab ? lab_strides[i] : 0; p.fs[i] = fake_strides[i]; p.es[i] = real_strides[i];
+  }
+  p.Cr = Cr; p.Cl = Cl; p.Ci = Ci; p.B = B; p.P = P;
+  FSV_LAUNCH(fsv_pack_d_kernel, dim3(fsv_loss_grid(2LL * B * P) * 4), dim3(256), stream, p);
+  return fsv_check_launch();
+}
+
+int fsv_unpack_d_grad(const float* dout, float* dfake, int B, int Ci, int Coff, int Ct, long long P, hipStream_t stream) {
+  if (!dout || !dfake) return FSV_ERR_BAD_ARG;
+  FSV_LAUNCH(fsv_unpack_d_kernel, dim3(fsv_loss_grid((long long)B * Ci * P) * 4), dim3(256), stream, dout, dfake, B, Ci, Coff, Ct, P);
+  return fsv_check_launch();
+}
+
+int fsv_pool15(const float* x, float* y, int N, int H, int W, long long sn, long long sy, long long sx, int mode, float thresh,
+               hipStream_t stream) {
+  if (!x || !y || N < 1 || H < 1 || W < 1 || mode < 0 || mode > 1) return FSV_ERR_BAD_ARG;
+  FSV_LAUNCH(fsv_pool15_kernel, dim3(fsv_loss_grid((long long)N * H * W) * 8), dim3(256), stream, x, y, N, H, W, sn, sy, sx, mode, thresh);
+  return fsv_check_launch();
+}
+
+}  // extern "C"

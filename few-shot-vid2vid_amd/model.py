@@ -80,8 +80,7 @@ def fg_mask_of(opt, label, has_fg):
     if label.dim() == 5:
         label = label[:, 0]
     mask = label[:, 2:3] if opt.label_nc == 0 else -label[:, 0:1]
-    mask = F.max_pool2d(mask, 15, stride=1, padding=7)
-    return (mask > -1).float()
+    return ops.pool15(mask, 'max_gt', -1.0)
 
 
 def union_fg(fg, ref_fg, has_fg):
@@ -101,29 +100,21 @@ def encode_label(opt, label_map):
 
 # ------------------------------------------------------------------------------------------------ losses
 def l1(a, b):
-    return (a - b).abs().mean()
+    """nn.L1Loss (mean absolute difference) as one fused reduction (csrc/losses.hip)."""
+    return ops.l1_loss(a, b)
 
 
 def masked_l1(inp, target, mask):
-    """models/networks/loss.py:130-138."""
-    mask = mask.expand_as(inp)
-    if isinstance(target, (int, float)):
-        target = torch.full_like(inp, float(target))
-    return l1(inp * mask, target * mask)
-
-
-def hinge(pred, real, for_discriminator=True):
-    """models/networks/loss.py:69-83."""
-    if for_discriminator:
-        return -torch.min((pred if real else -pred) - 1, pred * 0).mean()
-    return -pred.mean()
+    """models/networks/loss.py:130-138: L1(input * mask, target * mask), mask [N, 1, H, W] broadcast over channels."""
+    return ops.l1_loss(inp, target, mask)
 
 
 def gan_loss(preds, real):
-    """GANLoss.__call__ on a list-of-lists prediction (loss.py:92-104): last feature of every scale."""
+    """GANLoss.__call__ with the hinge objective on a list-of-lists prediction (loss.py:69-79, 92-104): last
+    feature of every scale; the reference calls it with for_discriminator=True in both steps."""
     loss = 0
     for p in preds:
-        loss = loss + hinge(p[-1], real).view(1)
+        loss = loss + ops.hinge_loss(p[-1], real)
     return loss / len(preds)
 
 
@@ -150,11 +141,7 @@ class LossCollector:
 
     def discriminate(self, netD, label, fake, real, ref, for_discriminator):
         """loss_collector.py:47-68: D sees [ref | label | image] with fake and real stacked on the batch axis."""
-        x = torch.cat([fake, real], dim=0)
-        if label is not None:
-            x = torch.cat([label.repeat(2, 1, 1, 1), x], dim=1)
-        if ref is not None and self.concat_ref_for_D:
-            x = torch.cat([ref.repeat(2, 1, 1, 1), x], dim=1)
+        x = ops.pack_d_input(ref if self.concat_ref_for_D else None, label, fake, real)
         out = netD(x)
         half = x.shape[0] // 2
         pred_fake = [[t[:half] for t in scale] for scale in out]
@@ -224,7 +211,7 @@ class LossCollector:
             m_ref = flow_mask[0]
             h, w = tgt_label.shape[-2:]
             face = face_mask_of(tgt_label[:, :, 2]).view(-1, 1, h, w)
-            face = F.avg_pool2d(face, 15, stride=1, padding=7)
+            face = ops.pool15(face, 'avg')
             loss = loss + masked_l1(m_ref, 0.0, face)
             if opt.spade_combine:
                 loss = loss + masked_l1(fake_image, warped[0].detach(), face)

@@ -579,3 +579,160 @@ def adam_step(param, grad, m, v, state, beta1, beta2, eps, gscale=1.0):
     lib.check_device(param, grad, m, v, state)
     lib.call("fsv_adam_step", lib.ptr(param), lib.ptr(grad), lib.ptr(m), lib.ptr(v), lib.ptr(state), param.numel(),
              float(beta1), float(beta2), float(eps), float(gscale), lib.stream_ptr())
+
+
+# ------------------------------------------------------------------------------------------------ losses / packing / masks
+lib.register_sigs({
+    "fsv_l1_fwd": [c_p, c_p, c_f, c_p, c_i, c_i, c_ll, c_llp, c_llp, c_p, c_p, c_p],
+    "fsv_l1_bwd": [c_p, c_p, c_f, c_p, c_i, c_i, c_ll, c_llp, c_llp, c_p, c_p, c_p, c_p, c_p],
+    "fsv_hinge_fwd": [c_p, c_ll, c_f, c_p, c_p, c_p],
+    "fsv_hinge_bwd": [c_p, c_ll, c_f, c_p, c_p, c_p],
+    "fsv_pack_d_input": [c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_ll, c_llp, c_llp, c_llp, c_llp, c_p],
+    "fsv_unpack_d_grad": [c_p, c_p, c_i, c_i, c_i, c_i, c_ll, c_p],
+    "fsv_pool15": [c_p, c_p, c_i, c_i, c_i, c_ll, c_ll, c_ll, c_i, c_f, c_p],
+})
+
+
+def _dense4(t):
+    """a 4-D tensor whose memory is dense NCHW or dense NHWC (no copy when it already is)"""
+    if t.is_contiguous() or t.permute(0, 2, 3, 1).is_contiguous():
+        return t
+    return t.contiguous()
+
+
+def _ncp_strides(t):
+    """(batch, channel, pixel) element strides of a dense NCHW / NHWC 4-D tensor"""
+    n, c, h, w = t.shape
+    if t.is_contiguous():
+        return [c * h * w, h * w, 1]
+    return [h * w * c, 1, c]
+
+
+class _L1Fn(torch.autograd.Function):
+    """mean |a*m - b*m| (nn.L1Loss / MaskedL1Loss, models/networks/loss.py:130-138).  b: tensor or python float;
+    m: None or a [N, 1, H, W] mask broadcast over channels.  All three tensor inputs may require grad."""
+
+    @staticmethod
+    def forward(ctx, a, b, m):
+        a = _dense4(a)
+        bconst = 0.0
+        bt = None
+        if isinstance(b, torch.Tensor):
+            bt = _dense4(b)
+            if bt.shape != a.shape:
+                raise ValueError("l1: shape mismatch")
+        else:
+            bconst = float(b)
+        n, c, h, w = a.shape
+        mt = None
+        if m is not None:
+            if m.shape != (n, 1, h, w):
+                raise ValueError("l1: mask must be [N, 1, H, W]")
+            mt = m.contiguous()
+        sa = _ncp_strides(a)
+        sb = _ncp_strides(bt) if bt is not None else [0, 0, 0]
+        flat = mt is None and (bt is None or sb == sa)
+        if flat:        # same layout, no mask: one coalesced stream
+            dims, sa_, sb_ = (1, 1, a.numel()), [0, 0, 1], ([0, 0, 1] if bt is not None else [0, 0, 0])
+        else:
+            dims, sa_, sb_ = (n, c, h * w), sa, sb
+        part = torch.empty(512, dtype=torch.float64, device=a.device)
+        loss = torch.empty(1, dtype=torch.float32, device=a.device)
+        lib.check_device(a, bt, mt)
+        lib.call("fsv_l1_fwd", lib.ptr(a), lib.ptr(bt), bconst, lib.ptr(mt), dims[0], dims[1], dims[2], _ll(sa_), _ll(sb_),
+                 lib.ptr(part), lib.ptr(loss), lib.stream_ptr())
+        ctx.meta = (dims, sa_, sb_, bconst, bt is not None, mt is not None)
+        ctx.save_for_backward(a, bt if bt is not None else a, mt if mt is not None else a)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        a, bt, mt = ctx.saved_tensors
+        dims, sa_, sb_, bconst, has_b, has_m = ctx.meta
+        g = g.contiguous()
+        da = torch.empty_like(a) if ctx.needs_input_grad[0] else None
+        db = torch.empty_like(bt) if (has_b and ctx.needs_input_grad[1]) else None
+        dm = torch.empty_like(mt) if (has_m and ctx.needs_input_grad[2]) else None
+        lib.call("fsv_l1_bwd", lib.ptr(a), lib.ptr(bt) if has_b else None, bconst, lib.ptr(mt) if has_m else None,
+                 dims[0], dims[1], dims[2], _ll(sa_), _ll(sb_), lib.ptr(g), lib.ptr(da), lib.ptr(db), lib.ptr(dm),
+                 lib.stream_ptr())
+        return da, db, dm
+
+
+def l1_loss(a, b, mask=None):
+    return _L1Fn.apply(a, b, mask)
+
+
+class _HingeFn(torch.autograd.Function):
+    """-mean(min(sign * x - 1, 0))  (GANLoss hinge, models/networks/loss.py:69-79): sign = +1 real, -1 fake."""
+
+    @staticmethod
+    def forward(ctx, x, sign):
+        x = x if (x.is_contiguous() or (x.dim() == 4 and x.permute(0, 2, 3, 1).is_contiguous())) else x.contiguous()
+        part = torch.empty(512, dtype=torch.float64, device=x.device)
+        loss = torch.empty(1, dtype=torch.float32, device=x.device)
+        lib.check_device(x)
+        lib.call("fsv_hinge_fwd", lib.ptr(x), x.numel(), float(sign), lib.ptr(part), lib.ptr(loss), lib.stream_ptr())
+        ctx.sign = float(sign)
+        ctx.save_for_backward(x)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        (x,) = ctx.saved_tensors
+        dx = torch.empty_like(x)
+        lib.call("fsv_hinge_bwd", lib.ptr(x), x.numel(), ctx.sign, lib.ptr(g.contiguous()), lib.ptr(dx), lib.stream_ptr())
+        return dx, None
+
+
+def hinge_loss(x, real):
+    return _HingeFn.apply(x, 1.0 if real else -1.0)
+
+
+class _PackDFn(torch.autograd.Function):
+    """Discriminator input [ref | label | image] with fake / real stacked on the batch axis, written once in NHWC
+    (loss_collector.py:47-58 builds it with three torch.cat + two repeat).  Only `fake` receives a gradient."""
+
+    @staticmethod
+    def forward(ctx, ref, lab, fake, real):
+        fake, real = _dense4(fake), _dense4(real)
+        b, ci, h, w = fake.shape
+        cr = ref.shape[1] if ref is not None else 0
+        cl = lab.shape[1] if lab is not None else 0
+        ref = _dense4(ref) if ref is not None else None
+        lab = _dense4(lab) if lab is not None else None
+        out = empty_nhwc(2 * b, cr + cl + ci, h, w, fake)
+        z3 = _ll([0, 0, 0])
+        lib.check_device(ref, lab, fake, real)
+        lib.call("fsv_pack_d_input", lib.ptr(ref), lib.ptr(lab), lib.ptr(fake), lib.ptr(real), lib.ptr(out), b, cr, cl, ci,
+                 h * w, _ll(_ncp_strides(ref)) if ref is not None else z3, _ll(_ncp_strides(lab)) if lab is not None else z3,
+                 _ll(_ncp_strides(fake)), _ll(_ncp_strides(real)), lib.stream_ptr())
+        ctx.dims = (b, cr, cl, ci, h, w)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        b, cr, cl, ci, h, w = ctx.dims
+        dfake = None
+        if ctx.needs_input_grad[2]:
+            dout = to_nhwc(dout)
+            dfake = torch.empty((b, ci, h, w), dtype=torch.float32, device=dout.device)
+            lib.call("fsv_unpack_d_grad", lib.ptr(dout), lib.ptr(dfake), b, ci, cr + cl, cr + cl + ci, h * w, lib.stream_ptr())
+        return None, None, dfake, None
+
+
+def pack_d_input(ref, lab, fake, real):
+    return _PackDFn.apply(ref, lab, fake, real)
+
+
+def pool15(x, mode, thresh=0.0):
+    """15x15 stride-1 pooling of a [N, 1, H, W] mask: mode 'max_gt' -> (maxpool(x) > thresh).float()
+    (input_process.py:59-60), mode 'avg' -> AvgPool2d(15, padding=7, stride=1) (loss_collector.py:180)."""
+    n, c, h, w = x.shape
+    if c != 1:
+        raise ValueError("pool15 expects a single-channel mask")
+    y = torch.empty((n, 1, h, w), dtype=torch.float32, device=x.device)
+    lib.check_device(x)
+    lib.call("fsv_pool15", lib.ptr(x), lib.ptr(y), n, h, w, x.stride(0), x.stride(2), x.stride(3),
+             0 if mode == 'max_gt' else 1, float(thresh), lib.stream_ptr())
+    return y

@@ -125,6 +125,22 @@ int fsv_softmax_rows_bwd(const float* dy, const float* y, float* dx, long long r
 int fsv_adam_step(float* param, const float* grad, float* m, float* v, float* state, long long n, float beta1,
                   float beta2, float eps, float gscale, fsv_stream_t stream);
 
+/* ---- losses, D-input packing, mask pooling (csrc/losses.hip) - models/networks/loss.py:69-83,130-138;
+ * models/loss_collector.py:47-58,105-110,180; models/input_process.py:59 -------------------------------------------- */
+int fsv_l1_fwd(const float* a, const float* b, float bconst, const float* m, int N, int C, long long P,
+               const long long* a_strides, const long long* b_strides, double* part, float* loss, fsv_stream_t stream);
+int fsv_l1_bwd(const float* a, const float* b, float bconst, const float* m, int N, int C, long long P,
+               const long long* a_strides, const long long* b_strides, const float* gloss, float* da, float* db, float* dm,
+               fsv_stream_t stream);
+int fsv_hinge_fwd(const float* x, long long n, float sign, double* part, float* loss, fsv_stream_t stream);
+int fsv_hinge_bwd(const float* x, long long n, float sign, const float* gloss, float* dx, fsv_stream_t stream);
+int fsv_pack_d_input(const float* ref, const float* lab, const float* fake, const float* real, float* out,
+                     int B, int Cr, int Cl, int Ci, long long P, const long long* ref_strides, const long long* lab_strides,
+                     const long long* fake_strides, const long long* real_strides, fsv_stream_t stream);
+int fsv_unpack_d_grad(const float* dout, float* dfake, int B, int Ci, int Coff, int Ct, long long P, fsv_stream_t stream);
+int fsv_pool15(const float* x, float* y, int N, int H, int W, long long sn, long long sy, long long sx, int mode, float thresh,
+               fsv_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

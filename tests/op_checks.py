@@ -296,6 +296,60 @@ def check_softmax(device, n=2, c=70, h=3, w=5, seed=12):
     assert_close('softmax dx', xd.grad, xr.grad, 1e-4)
 
 
+def check_losses(device, seed=13):
+    """L1 / masked L1 (all three inputs differentiable, NCHW and NHWC operands), hinge, D-input packing, 15x15 pooling."""
+    ops, conv = pkg()
+    g = torch.Generator().manual_seed(seed)
+    n, c, h, w = 2, 5, 9, 7
+    a, b = torch.randn(n, c, h, w, generator=g), torch.randn(n, c, h, w, generator=g)
+    m = torch.rand(n, 1, h, w, generator=g)
+    for (use_b, use_m, nhwc) in [(True, False, False), (True, True, False), (False, True, True), (True, True, True)]:
+        ar, br, mr = (t.detach().clone().requires_grad_(True) for t in (a, b, m))
+        tgt = br if use_b else torch.full_like(ar, 0.7)
+        mm = mr.expand_as(ar) if use_m else 1.0
+        ref = F.l1_loss(ar * mm, tgt * mm)
+        ref.backward()
+        ad = _dev(a, device)
+        if nhwc:
+            ad = conv.to_nhwc(ad)
+        ad = ad.detach().requires_grad_(True)
+        bd, md = (_dev(t, device).detach().clone().requires_grad_(True) for t in (b, m))
+        out = ops.l1_loss(ad, bd if use_b else 0.7, md if use_m else None)
+        out.sum().backward()
+        assert_close('l1', out.view(()), ref, 1e-5)
+        assert_close('l1 da', ad.grad, ar.grad, 1e-5)
+        if use_b:
+            assert_close('l1 db', bd.grad, br.grad, 1e-5)
+        if use_m:
+            assert_close('l1 dm', md.grad, mr.grad, 1e-4)
+    x = torch.randn(3, 1, 6, 5, generator=g) * 2
+    for real in (True, False):
+        xr = x.detach().clone().requires_grad_(True)
+        ref = -torch.mean(torch.min((xr if real else -xr) - 1, xr * 0))
+        ref.backward()
+        xd = _dev(x, device).detach().clone().requires_grad_(True)
+        out = ops.hinge_loss(xd, real)
+        out.sum().backward()
+        assert_close('hinge', out.view(()), ref, 1e-5)
+        assert_close('hinge dx', xd.grad, xr.grad, 1e-5)
+    # D input packing
+    bsz, hh, ww = 2, 6, 5
+    ref_c, lab, fake, real = (torch.randn(bsz, k, hh, ww, generator=g) for k in (4, 3, 3, 3))
+    fr = fake.detach().clone().requires_grad_(True)
+    xref = torch.cat([ref_c.repeat(2, 1, 1, 1), torch.cat([lab.repeat(2, 1, 1, 1), torch.cat([fr, real], 0)], 1)], 1)
+    wgt = torch.randn(xref.shape, generator=g)
+    (xref * wgt).sum().backward()
+    fd = _dev(fake, device).detach().clone().requires_grad_(True)
+    xo = ops.pack_d_input(_dev(ref_c, device), conv.to_nhwc(_dev(lab, device)), fd, _dev(real, device))
+    (xo * _dev(wgt, device)).sum().backward()
+    assert_close('pack', xo, xref, 1e-7)
+    assert_close('pack dfake', fd.grad, fr.grad, 1e-6)
+    # pooling
+    lab1 = torch.randn(2, 1, 20, 17, generator=g)
+    assert_close('pool max', ops.pool15(_dev(lab1, device), 'max_gt', 0.5), (F.max_pool2d(lab1, 15, 1, 7) > 0.5).float(), 1e-7)
+    assert_close('pool avg', ops.pool15(_dev(lab1, device), 'avg'), F.avg_pool2d(lab1, 15, 1, 7), 1e-5)
+
+
 def check_adam(device, n=1000, seed=9):
     ops, conv = pkg()
     g = torch.Generator().manual_seed(seed)

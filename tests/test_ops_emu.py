@@ -74,3 +74,7 @@ def test_adam(emu_lib):
 def test_softmax_channels(emu_lib):
     oc.check_softmax(DEV)
     oc.check_softmax(DEV, n=1, c=1024, h=4, w=4)
+
+
+def test_losses_pack_pool(emu_lib):
+    oc.check_losses(DEV)

@@ -95,3 +95,7 @@ def test_adam(hip_lib):
 def test_softmax_channels(hip_lib):
     oc.check_softmax(dev())
     oc.check_softmax(dev(), n=1, c=1024, h=4, w=4)
+
+
+def test_losses_pack_pool(hip_lib):
+    oc.check_losses(dev())
