@@ -44,18 +44,18 @@ __device__ __forceinline__ void fsv_tap(const ConvP& p, int t, int& ty, int& tx)
 }
 
 template <int BM, int BN, int WM, int WN, int V>
-__global__ __launch_bounds__(256) void fsv_conv_igemm_kernel(ConvP p) {
+__global__ __launch_bounds__(64 * WM * WN) void fsv_conv_igemm_kernel(ConvP p) {
   constexpr int BK = FSV_BK;
+  constexpr int NT = 64 * WM * WN;    // work-items per workgroup (4, 8 or 16 waves)
   constexpr int TM = BM / (WM * 32), TN = BN / (WN * 32);
   constexpr int LDA = BM + 1;
   constexpr int KV = BK / V;          // A vectors per pixel row and chunk
-  constexpr int RPP = 256 / KV;       // A rows per pass
+  constexpr int RPP = NT / KV;        // A rows per pass
   constexpr int NPA = BM / RPP;       // A passes
   constexpr int QB = BN / 4;          // B float4 per k row
-  constexpr int RPB = 256 / QB;       // B rows per pass
+  constexpr int RPB = NT / QB;        // B rows per pass
   constexpr int NPB = BK / RPB;       // B passes
-  static_assert(WM * WN == 4, "4 waves per workgroup");
-  static_assert(NPA >= 1 && NPB >= 1, "tile too small");
+  static_assert(NPA >= 1 && NPB >= 1 && NPA * RPP == BM && NPB * RPB == BK, "tile / thread-count mismatch");
   __shared__ float As[BK * LDA];
   __shared__ float Bs[BK * BN];
 
@@ -467,6 +467,19 @@ static inline void fsv_pack_taps(const int* ty, const int* tx, int n, unsigned l
 template <int V>
 static int fsv_launch_conv(const ConvP& p, int M_tiles_rows, int nz, hipStream_t stream, int tile) {
   dim3 block(256);
+  if (V == 4) {
+    switch (tile) {      // experimental large tiles (8 / 16 waves); only reachable through force_tile
+      case 5: { dim3 g(fsv_cdiv(M_tiles_rows, 256), fsv_cdiv(p.Cout, 128), nz);
+        FSV_LAUNCH((fsv_conv_igemm_kernel<256, 128, 4, 2, 4>), g, dim3(512), stream, p); return fsv_check_launch(); }
+      case 6: { dim3 g(fsv_cdiv(M_tiles_rows, 128), fsv_cdiv(p.Cout, 256), nz);
+        FSV_LAUNCH((fsv_conv_igemm_kernel<128, 256, 2, 4, 4>), g, dim3(512), stream, p); return fsv_check_launch(); }
+      case 7: { dim3 g(fsv_cdiv(M_tiles_rows, 256), fsv_cdiv(p.Cout, 256), nz);
+        FSV_LAUNCH((fsv_conv_igemm_kernel<256, 256, 4, 4, 4>), g, dim3(1024), stream, p); return fsv_check_launch(); }
+      case 8: { dim3 g(fsv_cdiv(M_tiles_rows, 256), fsv_cdiv(p.Cout, 64), nz);
+        FSV_LAUNCH((fsv_conv_igemm_kernel<256, 64, 4, 2, 4>), g, dim3(512), stream, p); return fsv_check_launch(); }
+      default: break;
+    }
+  }
   switch (tile) {
     case 0: { dim3 g(fsv_cdiv(M_tiles_rows, 128), fsv_cdiv(p.Cout, 128), nz);
       FSV_LAUNCH((fsv_conv_igemm_kernel<128, 128, 2, 2, V>), g, block, stream, p); break; }
@@ -484,12 +497,28 @@ static int fsv_launch_conv(const ConvP& p, int M_tiles_rows, int nz, hipStream_t
 }
 
 static inline int fsv_tile_dims(int tile, int& bm, int& bn) {
-  static const int BMs[5] = {128, 128, 128, 256, 64}, BNs[5] = {128, 64, 32, 32, 64};
-  if (tile < 0 || tile > 4) return -1;
+  static const int BMs[9] = {128, 128, 128, 256, 64, 256, 128, 256, 256}, BNs[9] = {128, 64, 32, 32, 64, 128, 256, 256, 64};
+  if (tile < 0 || tile > 8) return -1;
   bm = BMs[tile]; bn = BNs[tile];
   return 0;
 }
 
+
+#include <stdlib.h>
+static inline long long fsv_tune(int which) {
+  static long long vals[4] = {-1, -1, -1, -1};
+  if (vals[0] < 0) {
+    const char* a = getenv("FSV_SPLIT_BELOW");
+    const char* b = getenv("FSV_SPLIT_TARGET");
+    const char* c = getenv("FSV_WG_TARGET");
+    const char* d = getenv("FSV_WG_MINCH");
+    vals[1] = b ? atoll(b) : 512;
+    vals[2] = c ? atoll(c) : 1024;
+    vals[3] = d ? atoll(d) : 8;
+    vals[0] = a ? atoll(a) : 256;
+  }
+  return vals[which];
+}
 
 // Tile / split-K plan shared by the launcher and (through the C ABI) by the host-side profiler labels.
 // tile ids: 0 = 128x128, 1 = 128x64, 2 = 128x32, 3 = 256x32, 4 = 64x64 (BM x BN, pixels x output channels).
@@ -507,8 +536,9 @@ extern "C" int fsv_conv_plan(int Mz, int Cout, int nchunks, int nsamp, int force
   long long blocks = (long long)fsv_cdiv(Mz, bm) * fsv_cdiv(Cout, bn) * nsamp;
   int nsplit = 1;
   if (force_split > 0) nsplit = force_split;
-  else if (blocks < 256 && nchunks >= 8) {
-    nsplit = (int)((512 + blocks - 1) / blocks);
+  else if (blocks < fsv_tune(0) && nchunks >= 8) {
+    // aim at a few workgroups per CU; thresholds are tunables (FSV_SPLIT_BELOW / FSV_SPLIT_TARGET) for A/B runs
+    nsplit = (int)((fsv_tune(1) + blocks - 1) / blocks);
     if (nsplit > nchunks / 4) nsplit = nchunks / 4;
     if (nsplit < 1) nsplit = 1;
   }
@@ -592,8 +622,8 @@ int fsv_conv_wgrad(const float* in, const float* dout, float* dwt,
   int nsplit = 1;
   if (force_split > 0) nsplit = force_split;
   else {
-    nsplit = (int)((1024 + blocks - 1) / blocks);
-    int maxs = p.pchunks / 8;       // keep at least 8 pixel chunks (256 pixels) per split
+    nsplit = (int)((fsv_tune(2) + blocks - 1) / blocks);
+    int maxs = p.pchunks / (int)fsv_tune(3);       // keep at least this many 32-pixel chunks per split
     if (nsplit > maxs) nsplit = maxs;
     if (nsplit < 1) nsplit = 1;
   }

@@ -226,7 +226,52 @@ def sn_backward(dwsn, weight, u, v, sig):
     return dw
 
 
-# ------------------------------------------------------------------------------------------------ convolution
+# ------------------------------------------------------------------------------------------------ backward concurrency
+# The data gradient and the weight gradient of a layer are independent, so backward CAN fork the weight-gradient chain
+# (wgrad -> re-layout -> spectral-norm correction -> bias column sums) onto a side HIP stream and join before
+# returning (two parallel branches under hipGraph capture).  Measured on MI355X at per-GPU batch 2 (in-box A/B,
+# profiles/r01_notes.md): 84.9 ms/step with the fork vs 83.4 ms without - the fp32 MFMA kernels already keep the
+# chip at its power-limited clock, co-scheduling only adds contention.  Kept as an opt-in (FSV_BWD_OVERLAP=1).
+import os as _os
+
+_OVERLAP = _os.environ.get('FSV_BWD_OVERLAP', '0') == '1'
+_side_streams = {}
+
+
+class _fork:
+    """`with _fork(ref_tensor) as f:` runs the body on the side stream of the current device (no-op on the emulator)."""
+
+    def __init__(self, ref):
+        self.on = _OVERLAP and ref.is_cuda
+        self.ref = ref
+
+    def __enter__(self):
+        if self.on:
+            dev = self.ref.device
+            self.cur = torch.cuda.current_stream(dev)
+            side = _side_streams.get(dev.index)
+            if side is None:
+                side = _side_streams[dev.index] = torch.cuda.Stream(device=dev)
+            self.side = side
+            side.wait_stream(self.cur)
+            self.ctx = torch.cuda.stream(side)
+            self.ctx.__enter__()
+        return self
+
+    def __exit__(self, *exc):
+        if self.on:
+            self.ctx.__exit__(*exc)
+        return False
+
+    def join(self, *tensors):
+        """make the main stream wait for the side stream; results produced on the side stream are handed over"""
+        if self.on:
+            self.cur.wait_stream(self.side)
+            for t in tensors:
+                if t is not None:
+                    t.record_stream(self.cur)
+
+
 class _ConvFn(torch.autograd.Function):
     """y = act((conv(x, W * inv_sigma) + bias) * scale) + res.  W: OIHW, or [B]OIHW for per-sample weights."""
 
@@ -269,18 +314,30 @@ class _ConvFn(torch.autograd.Function):
         dpre = act_backward(dy, y, ctx.act, ctx.scale) if (ctx.act != ACT_NONE or ctx.scale != 1.0) else dy
         inv = sig[1:2] if sig is not None else None
         dx = dw = db = dres = None
-        if ctx.needs_input_grad[0]:
+        want_w = ctx.needs_input_grad[1]
+        want_b = ctx.has_bias and ctx.needs_input_grad[2]
+        want_x = ctx.needs_input_grad[0]
+        fork = _fork(dpre) if (want_x and (want_w or want_b)) else None
+        if fork is not None:
+            fork.__enter__()
+        try:
+            if want_w:
+                dwsn = conv_wgrad(x, dpre, geom, tuple(weight.shape), per_sample=ctx.per_sample)
+                dw = sn_backward(dwsn, weight, u, v, sig).view_as(weight) if ctx.has_sn else dwsn
+            if want_b:
+                cout = dpre.shape[1]
+                hw = dpre.shape[2] * dpre.shape[3]
+                if ctx.per_sample:
+                    db = colsum(dpre, n, hw, cout)
+                else:
+                    db = colsum(dpre, 1, n * hw, cout).view(cout)
+        finally:
+            if fork is not None:
+                fork.__exit__(None, None, None)
+        if want_x:
             dx = conv_dgrad(dpre, weight.detach(), geom, (h, w), scale=inv, per_sample=ctx.per_sample)
-        if ctx.needs_input_grad[1]:
-            dwsn = conv_wgrad(x, dpre, geom, tuple(weight.shape), per_sample=ctx.per_sample)
-            dw = sn_backward(dwsn, weight, u, v, sig).view_as(weight) if ctx.has_sn else dwsn
-        if ctx.has_bias and ctx.needs_input_grad[2]:
-            cout = dpre.shape[1]
-            hw = dpre.shape[2] * dpre.shape[3]
-            if ctx.per_sample:
-                db = colsum(dpre, n, hw, cout)
-            else:
-                db = colsum(dpre, 1, n * hw, cout).view(cout)
+        if fork is not None:
+            fork.join(dw, db)
         if ctx.has_res and ctx.needs_input_grad[3]:
             dres = dy
         return dx, dw, db, dres, None, None, None, None, None, None
