@@ -274,6 +274,21 @@ class Vid2VidModel(nn.Module):
         self.optimizer_D = FlatAdam(list(self.netD.parameters()), d_lr, (beta1, beta2), world_size, process_group)
         return self.optimizer_G, self.optimizer_D
 
+    def init_temporal_model(self):
+        """models/base_model.py:259-279 for lambda_temp == 0 (no temporal discriminator): the generator grows its
+        previous-frame flow / embedding branches and the G optimiser is rebuilt over the new parameter set."""
+        if self.opt.lambda_temp > 0:
+            raise NotImplementedError("temporal discriminator netDT (lambda_temp > 0) is a next-scope row (SURVEY.md 8f)")
+        self.temporal = True
+        torch.manual_seed(0)
+        self.netG.init_temporal_network()
+        self.lossCollector.tD = min(self.opt.n_frames_D, self.opt.n_frames_G)
+        if self.optimizer_G is not None:
+            old = self.optimizer_G
+            lr = float(old.state[3])
+            self.optimizer_G = FlatAdam(list(self.netG.parameters()), lr, old.betas, old.world_size, old.group)
+        return self.optimizer_G
+
     def update_learning_rate(self, epoch):
         """models/base_model.py:245-257."""
         opt = self.opt

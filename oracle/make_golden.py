@@ -87,6 +87,35 @@ def step(name, flags):
     print(name, 'D', [round(float(x), 5) for x in d_losses[:2]], 'G', [round(float(x), 5) for x in g_losses])
 
 
+def temporal(name, flags):
+    """two consecutive frames with the previous-frame branch active (train.py:55-62 with data_prev fed back)"""
+    import model_checks as mc
+    from models.loss_collector import loss_backward
+    opt, model = ref_import.build_model(flags.split())
+    mc.fill_state(model.netD)
+    model.init_temporal_model()
+    mc.fill_state(model.netG)
+    for o in (model.optimizer_G, model.optimizer_D):
+        for g in o.param_groups:
+            g['lr'] = 0.0
+    frames = [mc.synth_pose_inputs(1, 64, 64, 777 + t, 6) for t in range(2)]
+    frames[1] = (frames[1][0], frames[1][1], frames[0][2], frames[0][3])
+    prev = [None, None, None]
+    for t, (tl, ti, rl, ri) in enumerate(frames):
+        data = [tl, ti, [None, None], [None, None], rl, ri] + prev
+        d_losses = loss_backward(opt, model(data, mode='discriminator'), model.optimizer_D, 1)
+        g_losses, generated, prev = model(data, save_images=True, mode='generator')
+        g_losses = loss_backward(opt, g_losses, model.optimizer_G, 0)
+    gG = {k: float(p.grad.norm()) for k, p in model.netG.named_parameters() if p.grad is not None}
+    fake, raw, warped, flow, mask, _ = generated
+    torch.save(dict(flags=flags, seed=777, batch=1, size=64, d_losses=[float(x) for x in d_losses],
+                    g_losses=[float(x) for x in g_losses], loss_names=model.lossCollector.loss_names,
+                    fake=fake.detach().clone(), warp=[w.detach().clone() for w in warped],
+                    flow=[f.detach().clone() for f in flow], mask=[m.detach().clone() for m in mask], grad_norm_G=gG),
+               os.path.join(OUT, 'temporal_%s.pt' % name))
+    print('temporal', name, 'D', [round(float(x), 5) for x in d_losses[:2]], 'G', [round(float(x), 5) for x in g_losses])
+
+
 def warp_taps():
     ref_import.install_shims()
     from models.networks.base_network import resample
@@ -117,5 +146,6 @@ if __name__ == '__main__':
     layout()
     for n, f in CONFIGS.items():
         step(n, f)
+    temporal('pose_combine', CONFIGS['pose_combine'])
     warp_taps()
     print('goldens written to', OUT)

@@ -310,3 +310,79 @@ class _G:
 
     def __init__(self, g):
         self.grad = g
+
+
+def _leafify(sd0, dtype):
+    sd = {}
+    for k, v in sd0.items():
+        t = v.clone().to(dtype).detach() if v.is_floating_point() else v.clone()
+        if v.is_floating_point() and ('running' not in k) and not k.endswith(('_u', '_v')):
+            t.requires_grad_(True)
+        sd[k] = t
+    return sd
+
+
+def _oracle_two_frames(sdG0, sdD0, cfg, frames, dtype):
+    """frame 0 without history, frame 1 with the previous-frame branch (init_temporal_network), learning rate 0."""
+    sdG, sdD = _leafify(sdG0, dtype), _leafify(sdD0, dtype)
+    prevs, out = None, None
+    for t, data in enumerate(frames):
+        tl, ti, rl, ri = [x.to(dtype) for x in data]
+        for v in list(sdG.values()) + list(sdD.values()):
+            if v.is_floating_point():
+                v.grad = None
+        p = [x.to(dtype) for x in prevs] if prevs is not None else None
+        d_losses = O.d_step_losses(sdG, sdD, cfg, tl, ti, rl, ri, p, True)
+        sum(l.mean() for l in d_losses).backward()
+        gD = {k: v.grad.clone() for k, v in sdD.items() if v.is_floating_point() and v.grad is not None}
+        for v in list(sdG.values()) + list(sdD.values()):
+            if v.is_floating_point():
+                v.grad = None
+        g_losses, gen = O.g_step_losses(sdG, sdD, cfg, tl, ti, rl, ri, p, True)
+        sum(l.mean() for l in g_losses.values()).backward()
+        gG = {k: v.grad.clone() for k, v in sdG.items() if v.is_floating_point() and v.grad is not None}
+        prevs = gen['prevs']
+        out = (d_losses, gD, g_losses, gG, gen)
+    return out
+
+
+def check_temporal_step(device, opt, b=1, tol=1e-3, seed=31, grad_tol=2e-2):
+    """Second frame of a sequence: previous-frame flow / warp / SPADE-combine embedding active (reference
+    init_temporal_model, models/base_model.py:259-279; shared flow network iterated twice per forward)."""
+    M = _model()
+    model = M.create_model(opt)
+    fill_state(model.netD)
+    model = model.to(device).train()
+    model.build_optimizers()
+    model.init_temporal_model()
+    fill_state(model.netG)
+    sdG0 = {k: v.detach().cpu().clone() for k, v in model.netG.state_dict().items()}
+    sdD0 = {k: v.detach().cpu().clone() for k, v in model.netD.state_dict().items()}
+    opt_G, opt_D = model.optimizer_G, model.optimizer_D
+    opt_G.set_lr(0.0); opt_D.set_lr(0.0)
+    h, w = int(opt.fineSize / opt.aspect_ratio), opt.fineSize
+    nl = opt.label_nc if opt.label_nc != 0 else opt.input_nc
+    frames = [synth_pose_inputs(b, h, w, seed + t, nl) for t in range(2)]
+    frames[1] = (frames[1][0], frames[1][1], frames[0][2], frames[0][3])      # same reference images for both frames
+    cfg = O.cfg_from_opt(opt)
+    r32 = _oracle_two_frames(sdG0, sdD0, cfg, frames, torch.float32)
+    r64 = _oracle_two_frames(sdG0, sdD0, cfg, frames, torch.float64)
+    prevs = [None, None, None]
+    for t, data in enumerate(frames):
+        tl, ti, rl, ri = [x.to(device) for x in data]
+        data_list = [tl, ti, [None, None], [None, None], rl, ri] + prevs
+        d_losses = M.loss_backward(opt, model(data_list, mode='discriminator'), opt_D, 1)
+        g_losses, generated, prevs = model(data_list, save_images=True, mode='generator')
+        g_losses = M.loss_backward(opt, g_losses, opt_G, 0)
+    for i, name in enumerate(('D_real', 'D_fake')):
+        _close_vs64(name, d_losses[i].view(1), r32[0][i].view(1), r64[0][i].view(1), tol)
+    names = M.LOSS_NAMES_G
+    for k in ('G_GAN', 'G_GAN_Feat', 'F_Warp', 'F_Mask'):
+        _close_vs64(k, g_losses[names.index(k)].view(1), r32[2][k].view(1), r64[2][k].view(1), tol)
+    _close_vs64('fake image', generated[0][:, 0], r32[4]['fake'], r64[4]['fake'], tol)
+    _close_vs64('prev warp', generated[2][1], r32[4]['warp'][1], r64[4]['warp'][1], tol)
+    sd32 = {k: _G(v) for k, v in r32[3].items()}
+    sd64 = {k: _G(v) for k, v in r64[3].items()}
+    for name, _ in model.netG.named_parameters():
+        sd32.setdefault(name, _G(None)); sd64.setdefault(name, _G(None))
+    return compare_grads(model.netG, sd32, sd64, grad_tol)

@@ -143,3 +143,34 @@ def test_product_reproduces_reference_iteration_on_gpu(hip_lib, case):
         assert _rel(generated[3][0].cpu(), g['flow'][0]) <= 1e-3
         assert _rel(generated[4][0].cpu(), g['mask'][0]) <= 1e-3
         assert _rel(generated[2][0].cpu(), g['warp'][0]) <= 1e-3
+
+
+def test_oracle_reproduces_reference_second_frame():
+    """previous-frame branch (init_temporal_model): two reference frames, oracle compared on the second one"""
+    g = torch.load(os.path.join(GOLD, 'temporal_pose_combine.pt'), weights_only=False)
+    opt = _opt_from_flags(g['flags'])
+    M = mc._model()
+    model = M.create_model(opt)
+    mc.fill_state(model.netD)
+    model.netG.init_temporal_network()
+    mc.fill_state(model.netG)
+    sdG0 = {k: v.detach().clone() for k, v in model.netG.state_dict().items()}
+    sdD0 = {k: v.detach().clone() for k, v in model.netD.state_dict().items()}
+    frames = [mc.synth_pose_inputs(g['batch'], g['size'], g['size'], g['seed'] + t, 6) for t in range(2)]
+    frames[1] = (frames[1][0], frames[1][1], frames[0][2], frames[0][3])
+    d_losses, gD, g_losses, gG, gen = mc._oracle_two_frames(sdG0, sdD0, O.cfg_from_opt(opt), frames, torch.float32)
+    names = g['loss_names']
+    for i in range(2):
+        assert abs(float(d_losses[i]) - g['d_losses'][i]) <= 1e-5 * max(1.0, abs(g['d_losses'][i]))
+    for k, v in g_losses.items():
+        ref = g['g_losses'][names.index(k)]
+        assert abs(float(v) - ref) <= 1e-5 * max(1.0, abs(ref)), (k, float(v), ref)
+    assert _rel(gen['fake'], g['fake']) <= 1e-5
+    assert _rel(gen['warp'][1], g['warp'][1]) <= 1e-5 and _rel(gen['flow'][1], g['flow'][1]) <= 1e-5
+    med = sorted(g['grad_norm_G'].values())[len(g['grad_norm_G']) // 2]
+    for k, ref in g['grad_norm_G'].items():
+        if k.startswith('flow_network_temp.'):
+            k2 = k.replace('flow_network_temp.', 'flow_network_ref.')      # one shared module, two names
+        else:
+            k2 = k
+        assert abs(float(gG[k2].norm()) - ref) <= 1e-3 * max(ref, 1e-2 * med), k

@@ -27,3 +27,8 @@ def test_train_step_pose_warp_combine_tiny(emu_lib):
 def test_train_step_face_tiny(emu_lib):
     """BASELINE configs[0] flavour: fewshot_face, adaptive_spade only, B = 1."""
     mc.check_train_step(DEV, mc.tiny_opt(dataset_mode='fewshot_face', input_nc=1), b=1)
+
+
+def test_temporal_second_frame_tiny(emu_lib):
+    """previous-frame flow network (shared with the reference branch), warp and SPADE-combine embedding"""
+    mc.check_temporal_step(DEV, mc.tiny_opt(warp_ref=True, spade_combine=True, remove_face_labels=True), b=1)

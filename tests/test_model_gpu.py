@@ -37,3 +37,8 @@ def test_train_step_pose_warp_combine(hip_lib):
 
 def test_train_step_face(hip_lib):
     mc.check_train_step(dev(), mc.tiny_opt(ngf=8, ndf=8, dataset_mode='fewshot_face', input_nc=1, fineSize=128, loadSize=128), b=2)
+
+
+def test_temporal_second_frame(hip_lib):
+    mc.check_temporal_step(dev(), mc.tiny_opt(ngf=8, ndf=8, nff=8, warp_ref=True, spade_combine=True, remove_face_labels=True,
+                                              fineSize=128, loadSize=128), b=2)
