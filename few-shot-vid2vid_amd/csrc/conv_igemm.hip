@@ -520,13 +520,19 @@ static inline long long fsv_tune(int which) {
   return vals[which];
 }
 
+static inline int fsv_thin_tile() {
+  static int v = -1;
+  if (v < 0) { const char* a = getenv("FSV_THIN_TILE"); v = a ? atoi(a) : 2; }   // 128x32: in-box A/B 82.2 vs 83.4 ms/step against 256x32
+  return v;
+}
+
 // Tile / split-K plan shared by the launcher and (through the C ABI) by the host-side profiler labels.
 // tile ids: 0 = 128x128, 1 = 128x64, 2 = 128x32, 3 = 256x32, 4 = 64x64 (BM x BN, pixels x output channels).
 extern "C" int fsv_conv_plan(int Mz, int Cout, int nchunks, int nsamp, int force_tile, int force_split,
                              int* tile_out, int* nsplit_out) {
   int tile = force_tile;
   if (tile < 0) {
-    if (Cout <= 32) tile = (Mz >= 256 * 256) ? 3 : 2;
+    if (Cout <= 32) tile = (Mz >= 256 * 256) ? fsv_thin_tile() : 2;
     else if (Cout <= 64) tile = 1;
     else tile = ((long long)Mz * Cout <= 64 * 64 * 64) ? 4 : 0;
   }
