@@ -102,14 +102,15 @@ def prep_weight(w, mode, geom, khs=None, kws=None, scale=None, out=None):
     return out, kpad, ldw
 
 
-def unprep_weight_grad(dwt, w_shape, geom, scale=None):
-    """Inverse of mode-0 prep for gradients: dwt[(tap, ci)][co] -> OIHW (optionally batched)."""
+def unprep_weight_grad(dwt, w_shape, geom, scale=None, out=None):
+    """Inverse of mode-0 prep for gradients: dwt[(tap, ci)][co] -> OIHW (optionally batched).  With `out` (a
+    contiguous buffer of w_shape elements, e.g. a slice of the flat gradient buffer) the result is ADDED into it."""
     batched = len(w_shape) == 5
     nb = w_shape[0] if batched else 1
     cout, cin, kh, kw = w_shape[-4:]
-    dw = torch.empty(w_shape, dtype=torch.float32, device=dwt.device)
+    dw = out if out is not None else torch.empty(w_shape, dtype=torch.float32, device=dwt.device)
     kpad, ldw = dwt.shape[-2], dwt.shape[-1]
-    lib.call("fsv_prep_weight", lib.ptr(dw), lib.ptr(dwt), lib.ptr(scale), 2, nb, cout, cin, kh, kw, geom.ntaps,
+    lib.call("fsv_prep_weight", lib.ptr(dw), lib.ptr(dwt), lib.ptr(scale), 3 if out is not None else 2, nb, cout, cin, kh, kw, geom.ntaps,
              lib.int_array(geom.khs), lib.int_array(geom.kws), kpad, ldw, cout * cin * kh * kw, kpad * ldw,
              lib.stream_ptr())
     return dw
@@ -177,7 +178,7 @@ def conv_dgrad(dout, w, geom, in_hw, scale=None, per_sample=False):
     return dx
 
 
-def conv_wgrad(x, dout, geom, w_shape, per_sample=False, scale=None, force_split=0):
+def conv_wgrad(x, dout, geom, w_shape, per_sample=False, scale=None, force_split=0, out=None):
     """Weight gradient in OIHW layout (batched when per_sample)."""
     x = to_nhwc(x)
     dout = to_nhwc(dout)
@@ -194,4 +195,4 @@ def conv_wgrad(x, dout, geom, w_shape, per_sample=False, scale=None, force_split
         lib.call("fsv_conv_wgrad", lib.ptr(x), lib.ptr(dout), lib.ptr(dwt), n, h, w, cin, oh, ow, cout,
                  geom.ntaps, lib.int_array(geom.ty), lib.int_array(geom.tx), geom.stride, geom.stride,
                  ldw, kpad, kpad * ldw, 1 if per_sample else 0, force_split, lib.stream_ptr())
-    return unprep_weight_grad(dwt, tuple(w_shape), geom, scale)
+    return unprep_weight_grad(dwt, tuple(w_shape), geom, scale, out)

@@ -422,15 +422,18 @@ __global__ __launch_bounds__(256) void fsv_conv_wgrad_kernel(WgradP p) {
 // mode 0 (forward):  wt[z][j*Cin + ci][co] = s * w[z][co][ci][kh_j][kw_j]
 // mode 1 (dgrad):    wt[z][j*Cout + co][ci] = s * w[z][co][ci][kh_j][kw_j]
 // mode 2 (inverse of mode 0, for gradients): w[z][co][ci][kh_j][kw_j] = s * wt[z][j*Cin + ci][co]
+// mode 3: as mode 2 but accumulating (+=) - gradients written straight into a flat optimiser buffer
 // taps: (kh | kw<<4) per tap.  Rows >= K and columns >= ncols of wt are written as zero (modes 0/1).
 __global__ __launch_bounds__(256) void fsv_prep_weight_kernel(const float* w, float* wt, const float* scale_ptr,
-                                                              int mode, int Cout, int Cin, int KH, int KW,
+                                                              int mode_in, int Cout, int Cin, int KH, int KW,
                                                               int ntaps, unsigned long long taps_lo,
                                                               unsigned long long taps_hi, int Kpad, int ldw,
                                                               long long w_bstride, long long wt_bstride) {
   const int z = blockIdx.z;
   const float s = scale_ptr ? *scale_ptr : 1.f;
   const long long total = (long long)Kpad * ldw;
+  const bool accum = mode_in == 3;
+  const int mode = accum ? 2 : mode_in;
   const int rowlen = (mode == 1) ? Cout : Cin;      // channels per tap in the K dimension
   const int ncols = (mode == 1) ? Cin : Cout;
   const int K = ntaps * rowlen;
@@ -447,7 +450,10 @@ __global__ __launch_bounds__(256) void fsv_prep_weight_kernel(const float* w, fl
     int co = (mode == 1) ? a : c, ci = (mode == 1) ? c : a;
     long long widx = (((long long)co * Cin + ci) * KH + kh) * KW + kw + (long long)z * w_bstride;
     if (mode == 2) {
-      if (ok) ((float*)w)[widx] = s * wt[(long long)z * wt_bstride + i];
+      if (ok) {
+        float g = s * wt[(long long)z * wt_bstride + i];
+        ((float*)w)[widx] = accum ? ((float*)w)[widx] + g : g;
+      }
     } else {
       wt[(long long)z * wt_bstride + i] = ok ? s * w[widx] : 0.f;
     }
@@ -657,7 +663,7 @@ int fsv_conv_wgrad(const float* in, const float* dout, float* dwt,
 int fsv_prep_weight(const float* w, float* wt, const float* scale_ptr, int mode, int nbatch,
                     int Cout, int Cin, int KH, int KW, int ntaps, const int* kh, const int* kw,
                     int Kpad, int ldw, long long w_bstride, long long wt_bstride, hipStream_t stream) {
-  if (!w || !wt || ntaps < 1 || ntaps > 16 || mode < 0 || mode > 2) return FSV_ERR_BAD_ARG;
+  if (!w || !wt || ntaps < 1 || ntaps > 16 || mode < 0 || mode > 3) return FSV_ERR_BAD_ARG;
   unsigned long long lo, hi;
   fsv_pack_taps(kh, kw, ntaps, lo, hi, 0);
   long long total = (long long)Kpad * ldw;

@@ -231,13 +231,13 @@ __global__ __launch_bounds__(256) void fsv_norm_bwd_apply_kernel(const float* dy
 }
 
 // ---- column sums of a [G][P][C] tensor (bias gradients): out[g][c] ----------------------------------------------
-__global__ __launch_bounds__(256) void fsv_colsum_final_kernel(const double* part, float* out, int G, int C, int nchunks) {
+__global__ __launch_bounds__(256) void fsv_colsum_final_kernel(const double* part, float* out, int G, int C, int nchunks, int accumulate) {
   const int idx = blockIdx.x * 4 + (threadIdx.x >> 6);
   const bool ok = idx < G * C;
   const int g = ok ? idx / C : 0, c = ok ? idx - g * C : 0;
   double a, b;
   fsv_sum_chunks(part, g, c, C, nchunks, a, b);
-  if (ok && (threadIdx.x & 63) == 0) out[idx] = (float)a;
+  if (ok && (threadIdx.x & 63) == 0) out[idx] = accumulate ? out[idx] + (float)a : (float)a;
 }
 
 extern "C" {
@@ -297,7 +297,7 @@ int fsv_norm_bwd(const float* dy, const float* y, const float* x, const float* m
   return fsv_check_launch();
 }
 
-int fsv_colsum(const float* x, double* workspace, float* out, int G, int P, int C, hipStream_t stream) {
+int fsv_colsum(const float* x, double* workspace, float* out, int G, int P, int C, int accumulate, hipStream_t stream) {
   if (!x || !workspace || !out) return FSV_ERR_BAD_ARG;
   RedPlan pl = fsv_red_plan(G, P, C);
   const int nchunks = pl.nchunks;
@@ -305,7 +305,7 @@ int fsv_colsum(const float* x, double* workspace, float* out, int G, int P, int 
   rp.P = P; rp.C = C; rp.act = 0;
   fsv_launch_red<FSV_RED_COLSUM>(pl, rp, G, stream);
   FSV_LAUNCH(fsv_colsum_final_kernel, dim3(fsv_cdiv(G * C, 4)), dim3(256), stream, (const double*)workspace, out, G,
-             C, nchunks);
+             C, nchunks, accumulate);
   return fsv_check_launch();
 }
 

@@ -92,7 +92,7 @@ __global__ __launch_bounds__(256) void fsv_dot_partial_kernel(const float* a, co
 
 // dW[i][j] = inv_sigma * (dWsn[i][j] - inv_sigma * dot * u[i] * v[j]),  dot = <dWsn, W>
 __global__ __launch_bounds__(256) void fsv_sn_bwd_kernel(const float* dWsn, const double* part, int nparts, const float* u,
-                                                         const float* v, const float* sig, float* dW, int R, int Cc) {
+                                                         const float* v, const float* sig, float* dW, int R, int Cc, int accumulate) {
   __shared__ float sdot;
   if (threadIdx.x == 0) { double d = 0.0; for (int k = 0; k < nparts; ++k) d += part[k]; sdot = (float)d; }
   __syncthreads();
@@ -103,7 +103,8 @@ __global__ __launch_bounds__(256) void fsv_sn_bwd_kernel(const float* dWsn, cons
   const long long stride = (long long)gridDim.x * 256;
   for (; i < total; i += stride) {
     int r = (int)(i / Cc), c = (int)(i - (long long)r * Cc);
-    dW[i] = inv * (dWsn[i] - coef * u[r] * v[c]);
+    const float g = inv * (dWsn[i] - coef * u[r] * v[c]);
+    dW[i] = accumulate ? dW[i] + g : g;
   }
 }
 
@@ -131,7 +132,7 @@ int fsv_sn_power_iter(const float* W, float* u, float* v, float* scratch, float*
 
 // part: double[256] scratch
 int fsv_sn_backward(const float* dWsn, const float* W, const float* u, const float* v, const float* sig, double* part,
-                    float* dW, int R, int Cc, hipStream_t stream) {
+                    float* dW, int R, int Cc, int accumulate, hipStream_t stream) {
   if (!dWsn || !W || !u || !v || !sig || !part || !dW) return FSV_ERR_BAD_ARG;
   long long n = (long long)R * Cc;
   int nparts = (int)((n + 256 * 16 - 1) / (256 * 16));
@@ -140,7 +141,7 @@ int fsv_sn_backward(const float* dWsn, const float* W, const float* u, const flo
   FSV_LAUNCH(fsv_dot_partial_kernel, dim3(nparts), dim3(256), stream, dWsn, W, part, n);
   long long g = (n + 1023) / 1024;
   if (g > 4096) g = 4096;
-  FSV_LAUNCH(fsv_sn_bwd_kernel, dim3((unsigned)g), dim3(256), stream, dWsn, (const double*)part, nparts, u, v, sig, dW, R, Cc);
+  FSV_LAUNCH(fsv_sn_bwd_kernel, dim3((unsigned)g), dim3(256), stream, dWsn, (const double*)part, nparts, u, v, sig, dW, R, Cc, accumulate);
   return fsv_check_launch();
 }
 
@@ -160,6 +161,9 @@ struct SnBatch {
   const int* s_off;        //                       s[rows]
   float* scratch;
   float* sig;              // [L][2]
+  float* snap;             // per-pass copies of the new u / v (kept by autograd; the persistent buffers move on)
+  const int* u_off;
+  const int* v_off;
 };
 
 __global__ __launch_bounds__(256) void fsv_snb_gemv_t_kernel(SnBatch b, const int* tmap) {
@@ -209,7 +213,9 @@ __global__ __launch_bounds__(256) void fsv_snb_finalize_kernel(SnBatch b, float 
   for (int o = 128; o > 0; o >>= 1) { if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o]; __syncthreads(); }
   const float nt = fmaxf(sqrtf(red[0]), eps);
   __syncthreads();
-  for (int j = threadIdx.x; j < Cc; j += 256) v[j] = t[j] / nt;
+  float* vs = b.snap + b.v_off[layer];
+  float* us = b.snap + b.u_off[layer];
+  for (int j = threadIdx.x; j < Cc; j += 256) { float vj = t[j] / nt; v[j] = vj; vs[j] = vj; }
   float bb = 0.f;
   for (int i = threadIdx.x; i < R; i += 256) { float wv = s[i] / nt; bb += wv * wv; }
   red[threadIdx.x] = bb;
@@ -218,7 +224,7 @@ __global__ __launch_bounds__(256) void fsv_snb_finalize_kernel(SnBatch b, float 
   const float ns = fmaxf(sqrtf(red[0]), eps);
   __syncthreads();
   float c = 0.f;
-  for (int i = threadIdx.x; i < R; i += 256) { float wv = s[i] / nt; float ui = wv / ns; u[i] = ui; c += ui * wv; }
+  for (int i = threadIdx.x; i < R; i += 256) { float wv = s[i] / nt; float ui = wv / ns; u[i] = ui; us[i] = ui; c += ui * wv; }
   red[threadIdx.x] = c;
   __syncthreads();
   for (int o = 128; o > 0; o >>= 1) { if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o]; __syncthreads(); }
@@ -227,11 +233,14 @@ __global__ __launch_bounds__(256) void fsv_snb_finalize_kernel(SnBatch b, float 
 
 extern "C" int fsv_sn_power_iter_batched(const long long* W, const long long* u, const long long* v, const int* rows,
                                          const int* cols, const int* t_off, const int* s_off, float* scratch,
-                                         long long scratch_floats, float* sig, int nlayers, const int* tmap_t,
+                                         long long scratch_floats, float* sig, float* snap, const int* u_off,
+                                         const int* v_off, int nlayers, const int* tmap_t,
                                          int nblk_t, const int* tmap_s, int nblk_s, float eps, hipStream_t stream) {
-  if (!W || !u || !v || !rows || !cols || !t_off || !s_off || !scratch || !sig || nlayers < 1) return FSV_ERR_BAD_ARG;
+  if (!W || !u || !v || !rows || !cols || !t_off || !s_off || !scratch || !sig || !snap || !u_off || !v_off || nlayers < 1)
+    return FSV_ERR_BAD_ARG;
   SnBatch b;
   b.W = W; b.u = u; b.v = v; b.rows = rows; b.cols = cols; b.t_off = t_off; b.s_off = s_off; b.scratch = scratch; b.sig = sig;
+  b.snap = snap; b.u_off = u_off; b.v_off = v_off;
   (void)hipMemsetAsync(scratch, 0, sizeof(float) * (size_t)scratch_floats, stream);
   FSV_LAUNCH(fsv_snb_gemv_t_kernel, dim3(nblk_t), dim3(256), stream, b, tmap_t);
   FSV_LAUNCH(fsv_snb_gemv_kernel, dim3(nblk_s), dim3(256), stream, b, tmap_s);

@@ -12,6 +12,8 @@ wrapper (apex DistributedDataParallel with delay_allreduce=True, models/models.p
   reverse registration order so that buckets complete front to back during backward.  The 1/world_size average is
   folded into the Adam kernel.  BatchNorm statistics stay per replica (DESIGN.md "Multi-GPU").
 """
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -44,6 +46,9 @@ class FlatAdam:
                 self.flat_p[off:off + n].copy_(p.detach().reshape(-1))
                 p.data = self.flat_p[off:off + n].view(p.shape)
                 p.grad = self.flat_g[off:off + n].view(p.shape)
+                # single process: kernels may add gradients straight into the slice (ops._ConvFn "gradient sink");
+                # with a process group the autograd hooks below have to see every gradient, so the sink stays off
+                p._fsv_sink = (world_size == 1) and os.environ.get('FSV_GRAD_SINK', '1') == '1'
                 self.offsets.append((off, n))
                 off += n
         # ---- data-parallel buckets ------------------------------------------------------------------------

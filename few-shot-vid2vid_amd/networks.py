@@ -30,12 +30,12 @@ class _SpectralMixin:
     _sig_cached = None
 
     def _sn(self):
-        sig = self._sig_cached           # filled by the network-level batched pass (ops.SpectralGroup)
-        if sig is not None:
+        cached = self._sig_cached        # (sigma pair, u snapshot, v snapshot) from the network-level batched pass
+        if cached is not None:
             self._sig_cached = None
-        else:
-            sig = ops.SpectralState.update(self.weight_orig, self.weight_u, self.weight_v, self.training)
-        return (sig, self.weight_u, self.weight_v)
+            return (cached[0], cached[1], cached[2], True)
+        sig = ops.SpectralState.update(self.weight_orig, self.weight_u, self.weight_v, self.training)
+        return (sig, self.weight_u, self.weight_v, False)
 
 
 class Conv2d(nn.Module, _SpectralMixin):

@@ -29,7 +29,7 @@ lib.register_sigs({
     "fsv_norm_stats": [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_f, c_p, c_p, c_f, c_p],
     "fsv_norm_apply": [c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p],
     "fsv_norm_bwd": [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p],
-    "fsv_colsum": [c_p, c_p, c_p, c_i, c_i, c_i, c_p],
+    "fsv_colsum": [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p],
     "fsv_spade_mod_fwd": [c_p, c_p, c_p, c_p, c_i, c_pp, c_pp, c_pp, c_pp, c_pp, c_ip, c_llp, c_llp,
                           c_i, c_i, c_i, c_i, c_ll, c_i, c_p],
     "fsv_spade_bwd_elem": [c_p, c_p, c_p, c_p, c_p, c_i, c_pp, c_pp, c_p, c_i, c_i, c_i, c_ll, c_i, c_p],
@@ -41,8 +41,8 @@ lib.register_sigs({
     "fsv_softmax_rows_bwd": [c_p, c_p, c_p, c_ll, c_i, c_p],
     "fsv_adam_step": [c_p, c_p, c_p, c_p, c_p, c_ll, c_f, c_f, c_f, c_f, c_p],
     "fsv_sn_power_iter": [c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_f, c_i, c_p],
-    "fsv_sn_backward": [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_p],
-    "fsv_sn_power_iter_batched": [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_ll, c_p, c_i, c_p, c_i, c_p, c_i, c_f, c_p],
+    "fsv_sn_backward": [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_p],
+    "fsv_sn_power_iter_batched": [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_ll, c_p, c_p, c_p, c_p, c_i, c_p, c_i, c_p, c_i, c_f, c_p],
 })
 
 _ws_fn = None
@@ -125,12 +125,15 @@ def softmax_channels(x):
 
 
 # ------------------------------------------------------------------------------------------------ column sums
-def colsum(x2d_nhwc, groups, pixels, channels):
-    """x viewed as [groups][pixels][channels] -> [groups, channels]."""
-    out = torch.empty((groups, channels), dtype=torch.float32, device=x2d_nhwc.device)
+def colsum(x2d_nhwc, groups, pixels, channels, out=None):
+    """x viewed as [groups][pixels][channels] -> [groups, channels]; with `out` the sums are ADDED into it."""
+    acc = out is not None
+    if out is None:
+        out = torch.empty((groups, channels), dtype=torch.float32, device=x2d_nhwc.device)
     lib.check_device(x2d_nhwc)
     ws = _ws(groups, pixels, channels, x2d_nhwc)     # must outlive the call (host allocator frees eagerly)
-    lib.call("fsv_colsum", lib.ptr(x2d_nhwc), lib.ptr(ws), lib.ptr(out), groups, pixels, channels, lib.stream_ptr())
+    lib.call("fsv_colsum", lib.ptr(x2d_nhwc), lib.ptr(ws), lib.ptr(out), groups, pixels, channels, 1 if acc else 0,
+             lib.stream_ptr())
     return out
 
 
@@ -176,6 +179,11 @@ class SpectralGroup:
             t_off.append(off); off += c
             s_off.append(off); off += r
         self.scratch_floats = off
+        u_off, v_off, off2 = [], [], 0
+        for r, c in zip(rows, cols):
+            u_off.append(off2); off2 += r
+            v_off.append(off2); off2 += c
+        self.snap_floats, self.u_off, self.v_off, self.rows, self.cols = off2, u_off, v_off, rows, cols
         tmap_t, tmap_s = [], []
         for li, (r, c) in enumerate(zip(rows, cols)):
             ntile = ((c + 255) // 256) * ((r + 63) // 64)
@@ -187,6 +195,7 @@ class SpectralGroup:
         self.d_v = mk([l.weight_v.data_ptr() for l in self.layers], torch.int64)
         self.d_rows, self.d_cols = mk(rows, torch.int32), mk(cols, torch.int32)
         self.d_toff, self.d_soff = mk(t_off, torch.int32), mk(s_off, torch.int32)
+        self.d_uoff, self.d_voff = mk(u_off, torch.int32), mk(v_off, torch.int32)
         self.d_tmap_t = mk(tmap_t, torch.int32).reshape(-1)
         self.d_tmap_s = mk(tmap_s, torch.int32).reshape(-1)
         self.nblk_t, self.nblk_s = len(tmap_t), len(tmap_s)
@@ -205,24 +214,29 @@ class SpectralGroup:
             self._key = key
         n = len(self.layers)
         sig = torch.empty((n, 2), dtype=torch.float32, device=w0.device)
+        # this pass's u / v: autograd keeps views of this buffer, the persistent buffers are overwritten by the next pass
+        snap = torch.empty(self.snap_floats, dtype=torch.float32, device=w0.device)
         lib.check_device(w0)
         lib.call("fsv_sn_power_iter_batched", lib.ptr(self.d_W), lib.ptr(self.d_u), lib.ptr(self.d_v), lib.ptr(self.d_rows),
                  lib.ptr(self.d_cols), lib.ptr(self.d_toff), lib.ptr(self.d_soff), lib.ptr(self.scratch),
-                 self.scratch_floats, lib.ptr(sig), n, lib.ptr(self.d_tmap_t), self.nblk_t, lib.ptr(self.d_tmap_s),
-                 self.nblk_s, float(eps), lib.stream_ptr())
+                 self.scratch_floats, lib.ptr(sig), lib.ptr(snap), lib.ptr(self.d_uoff), lib.ptr(self.d_voff), n,
+                 lib.ptr(self.d_tmap_t), self.nblk_t, lib.ptr(self.d_tmap_s), self.nblk_s, float(eps), lib.stream_ptr())
         for i, l in enumerate(self.layers):
-            l._sig_cached = sig[i]
+            l._sig_cached = (sig[i], snap[self.u_off[i]:self.u_off[i] + self.rows[i]],
+                             snap[self.v_off[i]:self.v_off[i] + self.cols[i]])
 
 
-def sn_backward(dwsn, weight, u, v, sig):
+def sn_backward(dwsn, weight, u, v, sig, out=None):
+    """dW = (dW_sn - <dW_sn, W_sn> u v^T) / sigma; with `out` (a flat-buffer gradient view) the result is ADDED into it."""
     rows = weight.shape[0]
     cols = weight.numel() // rows
     dwsn = dwsn.contiguous()
     w = weight.detach().contiguous()
     part = torch.empty(256, dtype=torch.float64, device=w.device)
-    dw = torch.empty_like(w)
+    acc = out is not None
+    dw = out if acc else torch.empty_like(w)
     lib.call("fsv_sn_backward", lib.ptr(dwsn), lib.ptr(w), lib.ptr(u), lib.ptr(v), lib.ptr(sig), lib.ptr(part),
-             lib.ptr(dw), rows, cols, lib.stream_ptr())
+             lib.ptr(dw), rows, cols, 1 if acc else 0, lib.stream_ptr())
     return dw
 
 
@@ -276,12 +290,15 @@ class _ConvFn(torch.autograd.Function):
     """y = act((conv(x, W * inv_sigma) + bias) * scale) + res.  W: OIHW, or [B]OIHW for per-sample weights."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, res, sig, u, v, geom, act, scale):
+    def forward(ctx, x, weight, bias, res, sig, u, v, geom, act, scale, uv_owned=False):
         x = to_nhwc(x)
-        per_sample = weight.dim() == 5
-        cout = weight.shape[-4]
+        w4 = weight.detach()
+        if w4.dim() == 2:                      # nn.Linear weight: a 1x1 convolution over a [1, in, 1, rows] "image"
+            w4 = w4.view(w4.shape[0], w4.shape[1], 1, 1)
+        per_sample = w4.dim() == 5
+        cout = w4.shape[-4]
         inv = sig[1:2] if sig is not None else None
-        wt, _, ldw = prep_weight(weight.detach(), 0, geom, scale=inv)
+        wt, _, ldw = prep_weight(w4, 0, geom, scale=inv)
         b = bias.detach().contiguous() if bias is not None else None
         if res is not None and act != ACT_NONE:
             raise ValueError("residual add is only fused after a linear epilogue")
@@ -291,12 +308,14 @@ class _ConvFn(torch.autograd.Function):
                          scale=scale, per_sample=per_sample)
         ctx.geom, ctx.act, ctx.scale, ctx.per_sample = geom, act, scale, per_sample
         ctx.has_bias, ctx.has_res, ctx.has_sn = bias is not None, res is not None, sig is not None
+        ctx.bias_ref = bias                      # the leaf itself (its .grad slice is the sink target), not saved data
         ctx.x_shape = tuple(x.shape)
         if not any(ctx.needs_input_grad):
             return y                     # forward under no_grad (the D step's generator pass): nothing to keep
         if ctx.has_sn:
-            # u / v are persistent buffers that the next power iteration overwrites: keep this call's copies
-            ctx.save_for_backward(x, weight, y, sig, u.clone(), v.clone())
+            # u / v of the persistent buffers are overwritten by the next power iteration: keep this call's values
+            # (the batched pass already hands out per-pass snapshots)
+            ctx.save_for_backward(x, weight, y, sig, u if uv_owned else u.clone(), v if uv_owned else v.clone())
         else:
             ctx.save_for_backward(x, weight, y)
         return y
@@ -314,6 +333,16 @@ class _ConvFn(torch.autograd.Function):
         dpre = act_backward(dy, y, ctx.act, ctx.scale) if (ctx.act != ACT_NONE or ctx.scale != 1.0) else dy
         inv = sig[1:2] if sig is not None else None
         dx = dw = db = dres = None
+        w4 = weight.detach()
+        if w4.dim() == 2:
+            w4 = w4.view(w4.shape[0], w4.shape[1], 1, 1)
+        # gradient sink: parameters owned by a FlatAdam expose their slice of the flat gradient buffer as .grad; the
+        # last kernel of the weight-gradient chain adds into it directly and autograd gets None (no AccumulateGrad add)
+        w_sink = weight.grad if (getattr(weight, '_fsv_sink', False) and weight.grad is not None) else None
+        b_sink = None
+        if ctx.has_bias:
+            bias_t = ctx.bias_ref
+            b_sink = bias_t.grad if (getattr(bias_t, '_fsv_sink', False) and bias_t.grad is not None) else None
         want_w = ctx.needs_input_grad[1]
         want_b = ctx.has_bias and ctx.needs_input_grad[2]
         want_x = ctx.needs_input_grad[0]
@@ -322,40 +351,57 @@ class _ConvFn(torch.autograd.Function):
             fork.__enter__()
         try:
             if want_w:
-                dwsn = conv_wgrad(x, dpre, geom, tuple(weight.shape), per_sample=ctx.per_sample)
-                dw = sn_backward(dwsn, weight, u, v, sig).view_as(weight) if ctx.has_sn else dwsn
+                if ctx.has_sn:
+                    dwsn = conv_wgrad(x, dpre, geom, tuple(w4.shape), per_sample=ctx.per_sample)
+                    dw = sn_backward(dwsn, weight, u, v, sig, out=w_sink)
+                    dw = None if w_sink is not None else dw.view_as(weight)
+                else:
+                    dw = conv_wgrad(x, dpre, geom, tuple(w4.shape), per_sample=ctx.per_sample, out=w_sink)
+                    dw = None if w_sink is not None else dw.view_as(weight)
             if want_b:
                 cout = dpre.shape[1]
                 hw = dpre.shape[2] * dpre.shape[3]
                 if ctx.per_sample:
                     db = colsum(dpre, n, hw, cout)
+                elif b_sink is not None:
+                    colsum(dpre, 1, n * hw, cout, out=b_sink)
                 else:
                     db = colsum(dpre, 1, n * hw, cout).view(cout)
         finally:
             if fork is not None:
                 fork.__exit__(None, None, None)
         if want_x:
-            dx = conv_dgrad(dpre, weight.detach(), geom, (h, w), scale=inv, per_sample=ctx.per_sample)
+            dx = conv_dgrad(dpre, w4, geom, (h, w), scale=inv, per_sample=ctx.per_sample)
         if fork is not None:
             fork.join(dw, db)
         if ctx.has_res and ctx.needs_input_grad[3]:
             dres = dy
-        return dx, dw, db, dres, None, None, None, None, None, None
+        return dx, dw, db, dres, None, None, None, None, None, None, None
+
+
+def _unpack_sn(sn):
+    """sn: None | (sig, u, v) from SpectralState.update | (sig, u_snapshot, v_snapshot, True) from SpectralGroup"""
+    if sn is None:
+        return None, None, None, False
+    if len(sn) == 4:
+        return sn
+    return sn[0], sn[1], sn[2], False
 
 
 def conv2d(x, weight, bias=None, stride=1, padding=0, act=ACT_NONE, scale=1.0, res=None, sn=None):
     """sn: None or (sig, u, v) from SpectralState.update for this call."""
     kh, kw = weight.shape[-2:]
     geom = Geom(kh, kw, stride, padding)
-    sig, u, v = sn if sn is not None else (None, None, None)
-    return _ConvFn.apply(x, weight, bias, res, sig, u, v, geom, act, scale)
+    sig, u, v, owned = _unpack_sn(sn)
+    return _ConvFn.apply(x, weight, bias, res, sig, u, v, geom, act, scale, owned)
 
 
 def linear(x2d, weight, bias=None, act=ACT_NONE, sn=None):
     """y[R, out] = act(x2d[R, in] @ weight[out, in]^T + bias) on the same gather-GEMM kernel (1x1, H=1, W=R)."""
     r, cin = x2d.shape
     x4 = x2d.contiguous().view(1, 1, r, cin).permute(0, 3, 1, 2)
-    y4 = conv2d(x4, weight.view(weight.shape[0], cin, 1, 1), bias, act=act, sn=sn)
+    sig, u, v, owned = _unpack_sn(sn)
+    y4 = _ConvFn.apply(x4, weight, bias, None, sig, u, v, Geom(1, 1, 1, 0), act, 1.0, owned)
     return y4.permute(0, 2, 3, 1).reshape(r, weight.shape[0])
 
 
@@ -366,7 +412,7 @@ def batch_conv(x, weight, bias=None, act=ACT_NONE):
     k = weight.shape[-1]
     geom = Geom(k, k, 1, k // 2)
     b = bias.contiguous() if bias is not None else None
-    return _ConvFn.apply(x, weight.contiguous(), b, None, None, None, None, geom, act, 1.0)
+    return _ConvFn.apply(x, weight.contiguous(), b, None, None, None, None, geom, act, 1.0, False)
 
 
 # ------------------------------------------------------------------------------------------------ normalisation

@@ -56,7 +56,7 @@ int fsv_conv_wgrad(const float* in, const float* dout, float* dwt,
 
 /* OIHW <-> K-major re-arrangement with an optional device scalar multiplier (the spectral-norm 1/sigma).
  * mode 0: wt[j*Cin+ci][co] = s*w[co][ci][kh_j][kw_j]; mode 1 (data gradient): wt[j*Cout+co][ci] = ...;
- * mode 2: inverse of mode 0 (gradients back to OIHW). */
+ * mode 2: inverse of mode 0 (gradients back to OIHW); mode 3: mode 2 accumulating into w. */
 int fsv_prep_weight(const float* w, float* wt, const float* scale_ptr, int mode, int nbatch,
                     int Cout, int Cin, int KH, int KW, int ntaps, const int* kh, const int* kw,
                     int Kpad, int ldw, long long w_bstride, long long wt_bstride, fsv_stream_t stream);
@@ -88,7 +88,7 @@ int fsv_norm_apply(const float* x, const float* mean, const float* rstd, const f
 int fsv_norm_bwd(const float* dy, const float* y, const float* x, const float* mean, const float* rstd, const float* w,
                  double* workspace, float* s1, float* s2, float* dx, float* dw, float* db, int G, int P, int C, int act,
                  fsv_stream_t stream);
-int fsv_colsum(const float* x, double* workspace, float* out, int G, int P, int C, fsv_stream_t stream);
+int fsv_colsum(const float* x, double* workspace, float* out, int G, int P, int C, int accumulate, fsv_stream_t stream);
 
 /* ---- flow warp (csrc/warp.hip) - replaces resample/get_grid base_network.py:13-37 (F.grid_sample bilinear, border,
  * align_corners=True); tap indices are bit-identical to ATen's.  strides in elements: (batch, channel, y, x). ------ */
@@ -107,10 +107,11 @@ int fsv_sn_power_iter(const float* W, float* u, float* v, float* scratch, float*
  * integers), tmap_* map a flat block index to (layer, tile) */
 int fsv_sn_power_iter_batched(const long long* W, const long long* u, const long long* v, const int* rows,
                               const int* cols, const int* t_off, const int* s_off, float* scratch,
-                              long long scratch_floats, float* sig, int nlayers, const int* tmap_t, int nblk_t,
-                              const int* tmap_s, int nblk_s, float eps, fsv_stream_t stream);
+                              long long scratch_floats, float* sig, float* snap, const int* u_off, const int* v_off,
+                              int nlayers, const int* tmap_t, int nblk_t, const int* tmap_s, int nblk_s, float eps,
+                              fsv_stream_t stream);
 int fsv_sn_backward(const float* dWsn, const float* W, const float* u, const float* v, const float* sig, double* part,
-                    float* dW, int R, int Cc, fsv_stream_t stream);
+                    float* dW, int R, int Cc, int accumulate, fsv_stream_t stream);
 
 /* ---- element-wise helpers and the optimiser (csrc/elementwise.hip) ----------------------------------------------
  * nearest x2 up-sampling (generator.py:124, nn.Upsample), activations, Adam (base_model.py:39-48). */
