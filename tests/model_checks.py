@@ -167,6 +167,31 @@ def check_generator(device, opt, b=2, tol=1e-3, grads=True, seed=7):
     return compare_grads(G, sd32, sd64, tol * 5)
 
 
+def compare_grads_l2(module, sd32, sd64, tol):
+    """Step-level gradient comparison in the relative L2 norm per parameter.  The hinge loss and the LeakyReLUs are
+    only piecewise linear: a 1e-5 difference in the generated image (or a different atomic summation order in a
+    split-K launch) moves a handful of activations across a kink, which changes a few gradient entries by O(1) of
+    their size but the vector as a whole only marginally - the L2 norm is the stable measure for that."""
+    mags = [float(sd64[n].grad.double().norm()) for n, _ in module.named_parameters() if sd64[n].grad is not None]
+    floor = 1e-2 * float(np.median(mags)) if mags else 0.0
+    worst = 0.0
+    for name, prm in module.named_parameters():
+        ref = sd64[name].grad
+        if ref is None:
+            assert prm.grad is None or float(prm.grad.abs().max()) == 0.0, name
+            continue
+        assert prm.grad is not None, 'no grad for ' + name
+        r64 = ref.detach().double()
+        got = prm.grad.detach().double().cpu()
+        noise = float((sd32[name].grad.detach().double() - r64).norm())
+        scale = max(float(r64.norm()), floor, 1e-12)
+        err = float((got - r64).norm())
+        t = tol * 5 if 'flow_network' in name else tol
+        assert err <= t * scale + 4.0 * noise, 'grad %s: ||diff|| %.3e > %.1e * %.3e + 4 * %.3e' % (name, err, t, scale, noise)
+        worst = max(worst, err / scale)
+    return worst
+
+
 def compare_grads(module, sd32, sd64, tol):
     """Parameter gradients vs the fp64 oracle, with the fp32 oracle's own rounding noise as allowance (see
     _close_vs64).  Gradients that are mathematically zero (conv bias in front of a normalisation) are noise on all
@@ -290,7 +315,7 @@ def check_train_step(device, opt, b=2, tol=1e-3, seed=21, grad_tol=2e-2):
         _close_vs64(name, d_losses[i].view(1), r32[0][i].view(1), r64[0][i].view(1), tol)
     sd32 = {k: _G(v) for k, v in r32[1].items()}
     sd64 = {k: _G(v) for k, v in r64[1].items()}
-    compare_grads(model.netD, sd32, sd64, grad_tol)
+    compare_grads_l2(model.netD, sd32, sd64, grad_tol)
     g_losses, generated, prev = model(data_list, save_images=True, mode='generator')
     g_losses = M.loss_backward(opt, g_losses, opt_G, 0)
     names = M.LOSS_NAMES_G
@@ -300,7 +325,7 @@ def check_train_step(device, opt, b=2, tol=1e-3, seed=21, grad_tol=2e-2):
     sd64 = {k: _G(v) for k, v in r64[3].items()}
     for name, _ in model.netG.named_parameters():      # parameters the losses do not reach
         sd32.setdefault(name, _G(None)); sd64.setdefault(name, _G(None))
-    worst = compare_grads(model.netG, sd32, sd64, grad_tol)
+    worst = compare_grads_l2(model.netG, sd32, sd64, grad_tol)
     _close_vs64('fake image', generated[0][:, 0], r32[4]['fake'], r64[4]['fake'], tol)
     return worst
 
@@ -385,4 +410,4 @@ def check_temporal_step(device, opt, b=1, tol=1e-3, seed=31, grad_tol=2e-2):
     sd64 = {k: _G(v) for k, v in r64[3].items()}
     for name, _ in model.netG.named_parameters():
         sd32.setdefault(name, _G(None)); sd64.setdefault(name, _G(None))
-    return compare_grads(model.netG, sd32, sd64, grad_tol)
+    return compare_grads_l2(model.netG, sd32, sd64, grad_tol)
