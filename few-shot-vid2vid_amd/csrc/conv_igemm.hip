@@ -263,13 +263,14 @@ struct WgradP {
 };
 
 template <int BMK, int BN, int WM, int WN, int V>
-__global__ __launch_bounds__(256) void fsv_conv_wgrad_kernel(WgradP p) {
+__global__ __launch_bounds__(64 * WM * WN) void fsv_conv_wgrad_kernel(WgradP p) {
   constexpr int BK = FSV_BK;   // pixels per chunk
+  constexpr int NT = 64 * WM * WN;
   constexpr int TM = BMK / (WM * 32), TN = BN / (WN * 32);
-  constexpr int QA = BMK / V, RPA = 256 / QA, NPA = BK / RPA;
-  constexpr int QB = BN / 4, RPB = 256 / QB, NPB = BK / RPB;
-  static_assert(WM * WN == 4, "4 waves");
-  static_assert(NPA >= 1 && NPB >= 1 && RPA >= 1, "tile");
+  constexpr int QA = BMK / V, RPA = NT / QA, NPA = BK / RPA;
+  constexpr int QB = BN / 4, RPB = NT / QB, NPB = BK / RPB;
+  static_assert(TM >= 1 && TN >= 1, "tile");
+  static_assert(NPA >= 1 && NPB >= 1 && RPA >= 1 && NPA * RPA == BK && NPB * RPB == BK, "tile / thread-count mismatch");
   __shared__ float As[BK * BMK];
   __shared__ float Bs[BK * BN];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -559,6 +560,8 @@ extern "C" int fsv_conv_plan(int Mz, int Cout, int nchunks, int nsamp, int force
   return 0;
 }
 
+static inline bool vec4_ok(int cin) { return (cin & 3) == 0; }
+
 extern "C" {
 
 // Generic gather-GEMM (see header comment and include/fsv2v.h: fsv_conv_gather_fwd).
@@ -629,7 +632,10 @@ int fsv_conv_wgrad(const float* in, const float* dout, float* dwt,
   p.pchunks = fsv_cdiv(p.Mz, FSV_BK);
   const int nsamp = per_sample ? N : 1;
   const int bn = (Cout <= 32) ? 32 : (Cout <= 64 ? 64 : 128);
-  const int bmk = (bn == 128) ? 128 : 128;
+  // rows of the weight-gradient tile = taps * Cin; the 1x1 SPADE / embedding layers have only 32 or 64 of them and
+  // would waste 3/4 or 1/2 of a 128-row tile's MFMA work
+  int bmk = 128;
+  if (vec4_ok(Cin) && bn >= 64) bmk = (p.K <= 32) ? 32 : (p.K <= 64 ? 64 : 128);
   long long blocks = (long long)fsv_cdiv(p.K, bmk) * fsv_cdiv(Cout, bn) * nsamp;
   int nsplit = 1;
   if (force_split > 0) nsplit = force_split;
@@ -647,9 +653,13 @@ int fsv_conv_wgrad(const float* in, const float* dout, float* dwt,
     (void)hipMemsetAsync(dwt, 0, (size_t)((per_sample ? (long long)N * w_bstride : (long long)Kpad * ldw)) * sizeof(float), stream);
   dim3 block(256);
   const bool vec4 = (Cin % 4 == 0);
-  dim3 g(fsv_cdiv(p.K, 128), fsv_cdiv(Cout, bn), nsamp * nsplit);
+  dim3 g(fsv_cdiv(p.K, bmk), fsv_cdiv(Cout, bn), nsamp * nsplit);
   if (vec4) {
-    if (bn == 128) FSV_LAUNCH((fsv_conv_wgrad_kernel<128, 128, 2, 2, 4>), g, block, stream, p);
+    if (bn == 128 && bmk == 32) FSV_LAUNCH((fsv_conv_wgrad_kernel<32, 128, 1, 4, 4>), g, block, stream, p);
+    else if (bn == 128 && bmk == 64) FSV_LAUNCH((fsv_conv_wgrad_kernel<64, 128, 2, 2, 4>), g, block, stream, p);
+    else if (bn == 64 && bmk == 32) FSV_LAUNCH((fsv_conv_wgrad_kernel<32, 64, 1, 2, 4>), g, dim3(128), stream, p);
+    else if (bn == 64 && bmk == 64) FSV_LAUNCH((fsv_conv_wgrad_kernel<64, 64, 2, 2, 4>), g, block, stream, p);
+    else if (bn == 128) FSV_LAUNCH((fsv_conv_wgrad_kernel<128, 128, 2, 2, 4>), g, block, stream, p);
     else if (bn == 64) FSV_LAUNCH((fsv_conv_wgrad_kernel<128, 64, 2, 2, 4>), g, block, stream, p);
     else FSV_LAUNCH((fsv_conv_wgrad_kernel<128, 32, 4, 1, 4>), g, block, stream, p);
   } else {

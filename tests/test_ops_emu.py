@@ -17,7 +17,10 @@ DEV = torch.device("cpu")
     (1, 6, 10, 10, 12, 3, 1, 1, 'tanh', True),       # Cin % 4 != 0 -> scalar gather path
     (1, 20, 9, 9, 32, 4, 2, 2, 'lrelu', True),        # PatchGAN first layer geometry (k4 s2 p2)
     (1, 8, 7, 7, 16, 4, 1, 2, 'sigmoid', False),      # PatchGAN last layers (k4 s1 p2)
-    (1, 64, 6, 6, 130, 1, 1, 0, 'lrelu', True),       # 1x1, Cout not a multiple of 32
+    (1, 64, 6, 6, 130, 1, 1, 0, 'lrelu', True),
+    (1, 32, 9, 9, 48, 1, 1, 0, 'none', True),        # small-K weight-gradient tiles (32 / 64 rows)
+    (1, 64, 9, 9, 64, 1, 1, 0, 'none', True),
+    (2, 32, 5, 7, 130, 1, 1, 0, 'none', False),       # 1x1, Cout not a multiple of 32
 ])
 def test_conv(emu_lib, cfg):
     n, cin, h, w, cout, k, s, p, act, bias = cfg

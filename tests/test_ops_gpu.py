@@ -18,6 +18,9 @@ def dev():
     (1, 20, 9, 9, 32, 4, 2, 2, 'lrelu', True),
     (1, 8, 7, 7, 16, 4, 1, 2, 'sigmoid', False),
     (1, 64, 6, 6, 130, 1, 1, 0, 'lrelu', True),
+    (1, 32, 9, 9, 48, 1, 1, 0, 'none', True),        # small-K weight-gradient tiles (32 / 64 rows)
+    (1, 64, 9, 9, 64, 1, 1, 0, 'none', True),
+    (2, 32, 5, 7, 130, 1, 1, 0, 'none', False),
     (2, 64, 64, 64, 32, 3, 1, 1, 'lrelu', True),      # up_0 conv_0 shape at reduced resolution
     (2, 128, 32, 32, 256, 3, 2, 1, 'none', True),     # stride-2 encoder conv
     (2, 512, 8, 8, 512, 3, 1, 1, 'none', True),       # split-K regime (few tiles, long K)
