@@ -297,6 +297,14 @@ class _ConvFn(torch.autograd.Function):
             w4 = w4.view(w4.shape[0], w4.shape[1], 1, 1)
         per_sample = w4.dim() == 5
         cout = w4.shape[-4]
+        # input channel counts that are not a multiple of 4 (labels 6, RGB 3, flow-net input 15) would fall onto the
+        # scalar gather path of the kernels; zero-pad channels (input and weights) once so the float4 path is used
+        cin = x.shape[1]
+        cpad = (-cin) % 4 if not per_sample else 0
+        if cpad:
+            x = to_nhwc(torch.nn.functional.pad(x, (0, 0, 0, 0, 0, cpad)))
+            w4 = torch.nn.functional.pad(w4, (0, 0, 0, 0, 0, cpad))
+        ctx.cpad, ctx.cin = cpad, cin
         inv = sig[1:2] if sig is not None else None
         wt, _, ldw = prep_weight(w4, 0, geom, scale=inv)
         b = bias.detach().contiguous() if bias is not None else None
@@ -329,13 +337,16 @@ class _ConvFn(torch.autograd.Function):
             sig = u = v = None
         dy = to_nhwc(dy)
         geom = ctx.geom
-        n, cin, h, w = ctx.x_shape
+        n, _, h, w = ctx.x_shape
+        cpad, cin = ctx.cpad, ctx.cin
         dpre = act_backward(dy, y, ctx.act, ctx.scale) if (ctx.act != ACT_NONE or ctx.scale != 1.0) else dy
         inv = sig[1:2] if sig is not None else None
         dx = dw = db = dres = None
         w4 = weight.detach()
         if w4.dim() == 2:
             w4 = w4.view(w4.shape[0], w4.shape[1], 1, 1)
+        if cpad:
+            w4 = torch.nn.functional.pad(w4, (0, 0, 0, 0, 0, cpad))
         # gradient sink: parameters owned by a FlatAdam expose their slice of the flat gradient buffer as .grad; the
         # last kernel of the weight-gradient chain adds into it directly and autograd gets None (no AccumulateGrad add)
         w_sink = weight.grad if (getattr(weight, '_fsv_sink', False) and weight.grad is not None) else None
@@ -351,9 +362,16 @@ class _ConvFn(torch.autograd.Function):
             fork.__enter__()
         try:
             if want_w:
-                if ctx.has_sn:
+                if ctx.has_sn or cpad:
                     dwsn = conv_wgrad(x, dpre, geom, tuple(w4.shape), per_sample=ctx.per_sample)
-                    dw = sn_backward(dwsn, weight, u, v, sig, out=w_sink)
+                    if cpad:
+                        dwsn = dwsn[:, :cin].contiguous()
+                    if ctx.has_sn:
+                        dw = sn_backward(dwsn, weight, u, v, sig, out=w_sink)
+                    elif w_sink is not None:
+                        dw = w_sink.add_(dwsn.view_as(w_sink))
+                    else:
+                        dw = dwsn
                     dw = None if w_sink is not None else dw.view_as(weight)
                 else:
                     dw = conv_wgrad(x, dpre, geom, tuple(w4.shape), per_sample=ctx.per_sample, out=w_sink)
@@ -372,6 +390,8 @@ class _ConvFn(torch.autograd.Function):
                 fork.__exit__(None, None, None)
         if want_x:
             dx = conv_dgrad(dpre, w4, geom, (h, w), scale=inv, per_sample=ctx.per_sample)
+            if cpad:
+                dx = dx[:, :cin]
         if fork is not None:
             fork.join(dw, db)
         if ctx.has_res and ctx.needs_input_grad[3]:
