@@ -192,3 +192,106 @@ int fsv_adam_step(float* param, const float* grad, float* m, float* v, float* st
 }
 
 }  // extern "C"
+
+// ---- channel concatenation into NHWC (U-Net skips generator.py:563, flow-net input :498, ds_ref :441-443) -----------------
+// out[n][px][coff + c] = src[n, c, px]  for one source (strided: batch, channel, pixel); launched once per source.
+__global__ __launch_bounds__(256) void fsv_cat_put_kernel(const float* src, float* out, long long N, int C, long long P,
+                                                          long long sn, long long sc, long long sp, int Ct, int coff) {
+  const long long total = N * P * C;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int c = (int)(i % C);
+    const long long t = i / C;
+    const long long px = t % P, n = t / P;
+    out[(n * P + px) * Ct + coff + c] = src[n * sn + c * sc + px * sp];
+  }
+}
+
+// gradient of one source: dst[n][px][c] (dense NHWC with C channels) = dout[n][px][coff + c]
+__global__ __launch_bounds__(256) void fsv_cat_get_kernel(const float* dout, float* dst, long long N, int C, long long P, int Ct, int coff) {
+  const long long total = N * P * C;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int c = (int)(i % C);
+    const long long pix = i / C;
+    dst[i] = dout[pix * Ct + coff + c];
+  }
+}
+
+// ---- occlusion-mask compositing (generator.py:217,224): out = a * m + b * (1 - m), m broadcast over channels --------------
+// a, b, out: [N][C][P] with (batch, channel, pixel) strides; m: [N][P] contiguous.
+struct BlendP {
+  const float* a; const float* b; const float* m; float* out;
+  long long asn, asc, asp, bsn, bsc, bsp, osn, osc, osp;
+  int N, C; long long P;
+};
+__global__ __launch_bounds__(256) void fsv_blend_fwd_kernel(BlendP p) {
+  const long long total = (long long)p.N * p.P;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const long long n = i / p.P, px = i - n * p.P;
+    const float mv = p.m[i];
+    for (int c = 0; c < p.C; ++c) {
+      float av = p.a[n * p.asn + c * p.asc + px * p.asp], bv = p.b[n * p.bsn + c * p.bsc + px * p.bsp];
+      p.out[n * p.osn + c * p.osc + px * p.osp] = av * mv + bv * (1.f - mv);
+    }
+  }
+}
+// da = g * m, db = g * (1 - m), dm = sum_c g * (a - b); g has the strides of `out`, da/db are dense NCHW
+__global__ __launch_bounds__(256) void fsv_blend_bwd_kernel(BlendP p, const float* g, float* da, float* db, float* dm) {
+  const long long total = (long long)p.N * p.P;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const long long n = i / p.P, px = i - n * p.P;
+    const float mv = p.m[i];
+    float acc = 0.f;
+    for (int c = 0; c < p.C; ++c) {
+      float gv = g[n * p.osn + c * p.osc + px * p.osp];
+      float av = p.a[n * p.asn + c * p.asc + px * p.asp], bv = p.b[n * p.bsn + c * p.bsc + px * p.bsp];
+      const long long o = (n * p.C + c) * p.P + px;
+      if (da) da[o] = gv * mv;
+      if (db) db[o] = gv * (1.f - mv);
+      acc += gv * (av - bv);
+    }
+    if (dm) dm[i] = acc;
+  }
+}
+
+extern "C" {
+
+int fsv_cat_put(const float* src, float* out, long long N, int C, long long P, const long long* strides, int Ct, int coff,
+                hipStream_t stream) {
+  if (!src || !out || N < 1 || C < 1 || P < 1 || coff < 0 || coff + C > Ct) return FSV_ERR_BAD_ARG;
+  FSV_LAUNCH(fsv_cat_put_kernel, dim3(fsv_grid_for(N * P * C / 4 + 1)), dim3(256), stream, src, out, N, C, P, strides[0], strides[1],
+             strides[2], Ct, coff);
+  return fsv_check_launch();
+}
+
+int fsv_cat_get(const float* dout, float* dst, long long N, int C, long long P, int Ct, int coff, hipStream_t stream) {
+  if (!dout || !dst || N < 1 || C < 1 || P < 1 || coff < 0 || coff + C > Ct) return FSV_ERR_BAD_ARG;
+  FSV_LAUNCH(fsv_cat_get_kernel, dim3(fsv_grid_for(N * P * C / 4 + 1)), dim3(256), stream, dout, dst, N, C, P, Ct, coff);
+  return fsv_check_launch();
+}
+
+int fsv_blend_fwd(const float* a, const float* b, const float* m, float* out, int N, int C, long long P,
+                  const long long* a_strides, const long long* b_strides, const long long* out_strides, hipStream_t stream) {
+  if (!a || !b || !m || !out || N < 1 || C < 1 || P < 1) return FSV_ERR_BAD_ARG;
+  BlendP p;
+  p.a = a; p.b = b; p.m = m; p.out = out; p.N = N; p.C = C; p.P = P;
+  p.asn = a_strides[0]; p.asc = a_strides[1]; p.asp = a_strides[2];
+  p.bsn = b_strides[0]; p.bsc = b_strides[1]; p.bsp = b_strides[2];
+  p.osn = out_strides[0]; p.osc = out_strides[1]; p.osp = out_strides[2];
+  FSV_LAUNCH(fsv_blend_fwd_kernel, dim3(fsv_grid_for((long long)N * P)), dim3(256), stream, p);
+  return fsv_check_launch();
+}
+
+int fsv_blend_bwd(const float* a, const float* b, const float* m, const float* g, float* da, float* db, float* dm, int N, int C,
+                  long long P, const long long* a_strides, const long long* b_strides, const long long* g_strides,
+                  hipStream_t stream) {
+  if (!a || !b || !m || !g || N < 1 || C < 1 || P < 1) return FSV_ERR_BAD_ARG;
+  BlendP p;
+  p.a = a; p.b = b; p.m = m; p.out = nullptr; p.N = N; p.C = C; p.P = P;
+  p.asn = a_strides[0]; p.asc = a_strides[1]; p.asp = a_strides[2];
+  p.bsn = b_strides[0]; p.bsc = b_strides[1]; p.bsp = b_strides[2];
+  p.osn = g_strides[0]; p.osc = g_strides[1]; p.osp = g_strides[2];
+  FSV_LAUNCH(fsv_blend_bwd_kernel, dim3(fsv_grid_for((long long)N * P)), dim3(256), stream, p, g, da, db, dm);
+  return fsv_check_launch();
+}
+
+}  // extern "C"

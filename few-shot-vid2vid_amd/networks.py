@@ -273,7 +273,7 @@ class LabelEmbedder(nn.Module):
         for i in reversed(range(n)):
             cur = out[-1]
             if self.unet and i != n - 1:
-                cur = torch.cat([cur, out[i + 1]], dim=1)
+                cur = ops.cat_channels([cur, out[i + 1]])
             if i >= self.params_free_layers:
                 out.append(getattr(self, 'up_%d' % i)[1](ops.upsample2x(cur), act=ACT_LRELU))
             else:
@@ -312,7 +312,7 @@ class FlowGenerator(nn.Module):
         self.conv_mask = _seq(Conv2d(nf, 1, 3, padding=1), _Slot())
 
     def forward(self, label, label_prev, img_prev, for_ref=False):
-        x = torch.cat([label, label_prev, img_prev], dim=1)
+        x = ops.cat_channels([label, label_prev, img_prev])
         for k in range(0, 2 * (self.nd + 1), 2):
             conv, bn = self.down_flow[k]
             x = bn(conv(x), act=ACT_LRELU)
@@ -499,9 +499,9 @@ class FewShotGenerator(nn.Module):
             warp[1] = ops.resample(img_prev[:, -3:], flow[1])
         if self.spade_combine:
             if self.warp_ref:
-                ds[0] = torch.cat([warp[0], mask[0]], dim=1)
+                ds[0] = ops.cat_channels([warp[0], mask[0]])
             if warp[1] is not None:
-                ds[1] = torch.cat([warp[1], mask[1]], dim=1)
+                ds[1] = ops.cat_channels([warp[1], mask[1]])
         return flow, mask, warp, ds
 
     def forward(self, label, label_refs, img_refs, prev=(None, None), t=0, img_coarse=None):
@@ -527,11 +527,11 @@ class FewShotGenerator(nn.Module):
         if not self.spade_combine:
             img_final = img_raw
             if self.warp_ref:
-                img_final = img_raw * mask[0] + warp[0] * (1 - mask[0])
+                img_final = ops.blend(img_raw, warp[0], mask[0])
             elif not self.warp_prev:
                 img_raw = None
             if warp[1] is not None:
-                img_final = img_final * mask[1] + warp[1] * (1 - mask[1])
+                img_final = ops.blend(img_final, warp[1], mask[1])
         else:
             img_final, img_raw = img_raw, None
         return img_final, flow, mask, img_raw, warp, None, None, None, None

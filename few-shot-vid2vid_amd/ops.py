@@ -859,3 +859,81 @@ def pool15(x, mode, thresh=0.0):
     lib.call("fsv_pool15", lib.ptr(x), lib.ptr(y), n, h, w, x.stride(0), x.stride(2), x.stride(3),
              0 if mode == 'max_gt' else 1, float(thresh), lib.stream_ptr())
     return y
+
+
+lib.register_sigs({
+    "fsv_cat_put": [c_p, c_p, c_ll, c_i, c_ll, c_llp, c_i, c_i, c_p],
+    "fsv_cat_get": [c_p, c_p, c_ll, c_i, c_ll, c_i, c_i, c_p],
+    "fsv_blend_fwd": [c_p, c_p, c_p, c_p, c_i, c_i, c_ll, c_llp, c_llp, c_llp, c_p],
+    "fsv_blend_bwd": [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_ll, c_llp, c_llp, c_llp, c_p],
+})
+
+
+class _CatFn(torch.autograd.Function):
+    """torch.cat(tensors, dim=1) written once into channels-last memory (U-Net skips, flow-network input, ds_ref)."""
+
+    @staticmethod
+    def forward(ctx, *tensors):
+        ts = [_dense4(t) for t in tensors]
+        n, _, h, w = ts[0].shape
+        cs = [t.shape[1] for t in ts]
+        ct = sum(cs)
+        out = empty_nhwc(n, ct, h, w, ts[0])
+        lib.check_device(*ts)
+        off = 0
+        for t, c in zip(ts, cs):
+            lib.call("fsv_cat_put", lib.ptr(t), lib.ptr(out), n, c, h * w, _ll(_ncp_strides(t)), ct, off, lib.stream_ptr())
+            off += c
+        ctx.meta = (n, h, w, cs, ct)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        n, h, w, cs, ct = ctx.meta
+        dout = to_nhwc(dout)
+        grads, off = [], 0
+        for i, c in enumerate(cs):
+            if ctx.needs_input_grad[i]:
+                g = empty_nhwc(n, c, h, w, dout)
+                lib.call("fsv_cat_get", lib.ptr(dout), lib.ptr(g), n, c, h * w, ct, off, lib.stream_ptr())
+                grads.append(g)
+            else:
+                grads.append(None)
+            off += c
+        return tuple(grads)
+
+
+def cat_channels(tensors):
+    return _CatFn.apply(*tensors)
+
+
+class _BlendFn(torch.autograd.Function):
+    """a * m + b * (1 - m) with a [N, 1, H, W] soft occlusion mask (generator.py:217,224)."""
+
+    @staticmethod
+    def forward(ctx, a, b, m):
+        a, b = _dense4(a), _dense4(b)
+        m = m.contiguous()
+        n, c, h, w = a.shape
+        out = torch.empty((n, c, h, w), dtype=torch.float32, device=a.device)
+        lib.check_device(a, b, m)
+        lib.call("fsv_blend_fwd", lib.ptr(a), lib.ptr(b), lib.ptr(m), lib.ptr(out), n, c, h * w, _ll(_ncp_strides(a)),
+                 _ll(_ncp_strides(b)), _ll(_ncp_strides(out)), lib.stream_ptr())
+        ctx.save_for_backward(a, b, m)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        a, b, m = ctx.saved_tensors
+        g = _dense4(g)
+        n, c, h, w = a.shape
+        da = torch.empty((n, c, h, w), dtype=torch.float32, device=a.device) if ctx.needs_input_grad[0] else None
+        db = torch.empty((n, c, h, w), dtype=torch.float32, device=a.device) if ctx.needs_input_grad[1] else None
+        dm = torch.empty_like(m) if ctx.needs_input_grad[2] else None
+        lib.call("fsv_blend_bwd", lib.ptr(a), lib.ptr(b), lib.ptr(m), lib.ptr(g), lib.ptr(da), lib.ptr(db), lib.ptr(dm), n, c,
+                 h * w, _ll(_ncp_strides(a)), _ll(_ncp_strides(b)), _ll(_ncp_strides(g)), lib.stream_ptr())
+        return da, db, dm
+
+
+def blend(a, b, mask):
+    return _BlendFn.apply(a, b, mask)

@@ -119,6 +119,16 @@ int fsv_upsample2x_fwd(const float* x, float* y, int N, int H, int W, int C, fsv
 int fsv_upsample2x_bwd(const float* dy, float* dx, int N, int H, int W, int C, fsv_stream_t stream);
 int fsv_act_fwd(const float* x, float* y, long long total, int act, fsv_stream_t stream);
 int fsv_act_bwd(const float* dy, const float* y, float* dx, long long total, int act, float scale, fsv_stream_t stream);
+/* channel concatenation into one NHWC tensor (one call per source) and its gradient slices; occlusion-mask
+ * compositing out = a*m + b*(1-m) (generator.py:217,224,441-443,498,563) */
+int fsv_cat_put(const float* src, float* out, long long N, int C, long long P, const long long* strides, int Ct, int coff,
+                fsv_stream_t stream);
+int fsv_cat_get(const float* dout, float* dst, long long N, int C, long long P, int Ct, int coff, fsv_stream_t stream);
+int fsv_blend_fwd(const float* a, const float* b, const float* m, float* out, int N, int C, long long P,
+                  const long long* a_strides, const long long* b_strides, const long long* out_strides, fsv_stream_t stream);
+int fsv_blend_bwd(const float* a, const float* b, const float* m, const float* g, float* da, float* db, float* dm, int N, int C,
+                  long long P, const long long* a_strides, const long long* b_strides, const long long* g_strides,
+                  fsv_stream_t stream);
 /* softmax over the contiguous channel dimension of [rows][C] (nn.Softmax(dim=1) at generator.py:384) */
 int fsv_softmax_rows_fwd(const float* x, float* y, long long rows, int C, fsv_stream_t stream);
 int fsv_softmax_rows_bwd(const float* dy, const float* y, float* dx, long long rows, int C, fsv_stream_t stream);
