@@ -32,10 +32,13 @@ sys.path.insert(0, os.path.join(ROOT, 'tests'))
 FP32_MFMA_PEAK_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md "Peak FP32 (matrix)"
 
 
+WITH_VGG = False       # --vgg: add the VGG19 perceptual loss (a "next" row of SURVEY.md 8f; not part of the headline)
+
+
 def build_opt(size, batch):
     import model_checks as mc
     return mc.make_opt(fineSize=size, loadSize=size, batchSize=batch, warp_ref=True, spade_combine=True,
-                       remove_face_labels=True, no_vgg_loss=True, no_flow_gt=True)
+                       remove_face_labels=True, no_vgg_loss=not WITH_VGG, no_flow_gt=True)
 
 
 def make_data(batch, size, seed, device):
@@ -92,7 +95,10 @@ def main():
     ap.add_argument('--no-graph', action='store_true')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
+    ap.add_argument('--vgg', action='store_true', help='include the VGG19 perceptual loss in the G step')
     args = ap.parse_args()
+    global WITH_VGG
+    WITH_VGG = args.vgg
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
@@ -180,7 +186,7 @@ def main():
         'dtype': 'f32',
         'data': 'synthetic',
         'config': {'workload': 'fewshot_pose %dx%d, per-GPU batch %d, adaptive_spade+warp_ref+spade_combine, '
-                               'D step + G step (train.py:58-62), Adam included, no VGG / FlowNet2 / face-D'
+                               'D step + G step (train.py:58-62), Adam included, ' + ('with VGG19 loss, ' if WITH_VGG else 'no VGG / ') + 'no FlowNet2 / face-D'
                                % (args.size, args.size, args.batch),
                    'global_batch': args.batch * world, 'parallelism': 'dp%d' % world, 'launch': mode,
                    'algorithmic_tflop_per_frame': 1.66},

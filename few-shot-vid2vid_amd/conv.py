@@ -9,7 +9,7 @@ import torch
 
 from . import lib, profile
 
-ACT_NONE, ACT_LRELU, ACT_TANH, ACT_SIGMOID = 0, 1, 2, 3
+ACT_NONE, ACT_LRELU, ACT_TANH, ACT_SIGMOID, ACT_RELU = 0, 1, 2, 3, 4
 
 
 def to_nhwc(x):

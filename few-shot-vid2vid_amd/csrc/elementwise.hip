@@ -72,6 +72,7 @@ __global__ __launch_bounds__(256) void fsv_act_bwd_kernel(const float* dy, const
     if (act == FSV_ACT_LRELU) d = v > 0.f ? d : 0.2f * d;
     else if (act == FSV_ACT_TANH) d = d * (1.f - v * v);
     else if (act == FSV_ACT_SIGMOID) d = d * v * (1.f - v);
+    else if (act == FSV_ACT_RELU) d = v > 0.f ? d : 0.f;
     dx[i] = d;
   }
 }
@@ -294,4 +295,56 @@ int fsv_blend_bwd(const float* a, const float* b, const float* m, const float* g
   return fsv_check_launch();
 }
 
+}  // extern "C"
+
+
+// ---- 2x2 stride-2 max pooling (VGG19, models/networks/vgg.py:45-59 through torchvision's feature stack), NHWC ----------
+__global__ __launch_bounds__(256) void fsv_maxpool2_fwd_kernel(const float* x, float* y, int N, int H, int W, int C) {
+  const int OH = H / 2, OW = W / 2;
+  const long long total = (long long)N * OH * OW * C;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int c = (int)(i % C);
+    long long t = i / C;
+    const int ox = (int)(t % OW); t /= OW;
+    const int oy = (int)(t % OH);
+    const long long n = t / OH;
+    const float* b = x + (((n * H + 2 * oy) * W + 2 * ox) * C + c);
+    y[i] = fmaxf(fmaxf(b[0], b[C]), fmaxf(b[(long long)W * C], b[(long long)W * C + C]));
+  }
+}
+// the gradient goes to the first maximal element in (0,0),(0,1),(1,0),(1,1) order, as ATen's max_pool2d does
+__global__ __launch_bounds__(256) void fsv_maxpool2_bwd_kernel(const float* x, const float* dy, float* dx, int N, int H, int W, int C) {
+  const int OH = H / 2, OW = W / 2;
+  const long long total = (long long)N * H * W * C;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int c = (int)(i % C);
+    long long t = i / C;
+    const int xx = (int)(t % W); t /= W;
+    const int yy = (int)(t % H);
+    const long long n = t / H;
+    const int oy = yy >> 1, ox = xx >> 1;
+    float g = 0.f;
+    if (oy < OH && ox < OW) {
+      const float* b = x + (((n * H + 2 * oy) * W + 2 * ox) * C + c);
+      float v[4] = {b[0], b[C], b[(long long)W * C], b[(long long)W * C + C]};
+      int arg = 0;
+      float m = v[0];
+      for (int k = 1; k < 4; ++k) if (v[k] > m) { m = v[k]; arg = k; }
+      if (arg == ((yy & 1) * 2 + (xx & 1))) g = dy[((n * OH + oy) * OW + ox) * C + c];
+    }
+    dx[i] = g;
+  }
+}
+
+extern "C" {
+int fsv_maxpool2_fwd(const float* x, float* y, int N, int H, int W, int C, hipStream_t stream) {
+  if (!x || !y || N < 1 || H < 2 || W < 2 || C < 1) return FSV_ERR_BAD_ARG;
+  FSV_LAUNCH(fsv_maxpool2_fwd_kernel, dim3(fsv_grid_for((long long)N * (H / 2) * (W / 2) * C / 2 + 1)), dim3(256), stream, x, y, N, H, W, C);
+  return fsv_check_launch();
+}
+int fsv_maxpool2_bwd(const float* x, const float* dy, float* dx, int N, int H, int W, int C, hipStream_t stream) {
+  if (!x || !dy || !dx || N < 1 || H < 2 || W < 2 || C < 1) return FSV_ERR_BAD_ARG;
+  FSV_LAUNCH(fsv_maxpool2_bwd_kernel, dim3(fsv_grid_for((long long)N * H * W * C / 2 + 1)), dim3(256), stream, x, dy, dx, N, H, W, C);
+  return fsv_check_launch();
+}
 }  // extern "C"

@@ -27,6 +27,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define FSV_ACT_LRELU 1   // leaky_relu(x, 0.2)  (reference models/networks/architecture.py:15-17)
 #define FSV_ACT_TANH 2
 #define FSV_ACT_SIGMOID 3
+#define FSV_ACT_RELU 4      // VGG19 feature stack (models/networks/vgg.py)
 
 static inline int fsv_check_launch() {
   hipError_t e = hipGetLastError();
@@ -37,6 +38,7 @@ __device__ __forceinline__ float fsv_act(float v, int act) {
   if (act == FSV_ACT_LRELU) return v > 0.f ? v : 0.2f * v;
   if (act == FSV_ACT_TANH) return tanhf(v);
   if (act == FSV_ACT_SIGMOID) return 1.f / (1.f + expf(-v));
+  if (act == FSV_ACT_RELU) return v > 0.f ? v : 0.f;
   return v;
 }
 

@@ -132,8 +132,26 @@ class LossCollector:
         self.loss_names_G, self.loss_names_D = LOSS_NAMES_G, LOSS_NAMES_D
         self.loss_names = LOSS_NAMES_G + LOSS_NAMES_D
         self.tD = 1
-        if not opt.no_vgg_loss or opt.add_face_D:
-            raise NotImplementedError("VGG perceptual loss / face discriminator are the next rows of SURVEY.md 8(f)")
+        if opt.add_face_D:
+            raise NotImplementedError("the face discriminator is a next row of SURVEY.md 8(f)")
+        self.vgg = None
+        if not opt.no_vgg_loss:
+            from .vgg import VGGLoss
+            self.vgg = VGGLoss()
+
+    def to(self, device):
+        if self.vgg is not None:
+            self.vgg = self.vgg.to(device)
+        return self
+
+    def vgg_losses(self, fake, raw, real, fg_union):
+        """loss_collector.py:122-130"""
+        loss = self.zero(fake)
+        if self.vgg is not None:
+            loss = loss + self.vgg(fake, real)
+            if raw is not None:
+                loss = loss + self.vgg(raw, real * fg_union)
+        return loss * self.opt.lambda_vgg
 
     @staticmethod
     def zero(ref):
@@ -263,6 +281,12 @@ class Vid2VidModel(nn.Module):
         self.optimizer_G = self.optimizer_D = None
         return self
 
+    def _apply(self, fn, *args, **kwargs):
+        out = super()._apply(fn, *args, **kwargs)
+        if getattr(self, 'lossCollector', None) is not None and self.lossCollector.vgg is not None:
+            self.lossCollector.vgg._apply(fn)
+        return out
+
     # optimisers are created once the module sits on its device (flat buffers are device allocations)
     def build_optimizers(self, world_size=1, process_group=None):
         opt = self.opt
@@ -371,9 +395,10 @@ class Vid2VidModel(nn.Module):
             for p in d_params:
                 p.requires_grad_(True)
         z = lc.zero(fake)
+        g_vgg = lc.vgg_losses(fake, raw, real, fg_union)
         f_flow, f_warp, body_diff = lc.flow_losses(flow, warped, real, fg, tgt_label, ref_label)
         f_mask = lc.mask_losses(mask, fake, warped, tgt_label, real, fg, ref_fg, body_diff)
-        losses = [g_gan, g_feat, z.clone(), gf_gan, gf_feat, z.clone(), z.clone(), f_flow, f_warp, f_mask]
+        losses = [g_gan, g_feat, g_vgg, gf_gan, gf_feat, z.clone(), z.clone(), f_flow, f_warp, f_mask]
         # the reference returns fake / raw as [B, T, ...] and - because forward_generator rebinds them through
         # self.reshape (vid2vid_model.py:88-89) - warped / flow / mask as 4-D tensors
         up = lambda t: t.unsqueeze(1) if t is not None else None

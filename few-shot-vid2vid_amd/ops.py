@@ -15,7 +15,7 @@ import ctypes
 import torch
 
 from . import lib, profile
-from .conv import (ACT_LRELU, ACT_NONE, ACT_SIGMOID, ACT_TANH, Geom, conv_dgrad, conv_forward, conv_wgrad, empty_nhwc,
+from .conv import (ACT_LRELU, ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_TANH, Geom, conv_dgrad, conv_forward, conv_wgrad, empty_nhwc,
                    prep_weight, to_nhwc)
 
 c_p, c_i, c_ll, c_f = ctypes.c_void_p, ctypes.c_int, ctypes.c_longlong, ctypes.c_float
@@ -937,3 +937,36 @@ class _BlendFn(torch.autograd.Function):
 
 def blend(a, b, mask):
     return _BlendFn.apply(a, b, mask)
+
+
+lib.register_sigs({
+    "fsv_maxpool2_fwd": [c_p, c_p, c_i, c_i, c_i, c_i, c_p],
+    "fsv_maxpool2_bwd": [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p],
+})
+
+
+class _MaxPool2Fn(torch.autograd.Function):
+    """nn.MaxPool2d(2, 2) of the VGG19 feature stack."""
+
+    @staticmethod
+    def forward(ctx, x):
+        x = to_nhwc(x)
+        n, c, h, w = x.shape
+        y = empty_nhwc(n, c, h // 2, w // 2, x)
+        lib.check_device(x)
+        lib.call("fsv_maxpool2_fwd", lib.ptr(x), lib.ptr(y), n, h, w, c, lib.stream_ptr())
+        ctx.save_for_backward(x)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        n, c, h, w = x.shape
+        dy = to_nhwc(dy)
+        dx = torch.empty_like(x)
+        lib.call("fsv_maxpool2_bwd", lib.ptr(x), lib.ptr(dy), lib.ptr(dx), n, h, w, c, lib.stream_ptr())
+        return dx
+
+
+def maxpool2(x):
+    return _MaxPool2Fn.apply(x)

@@ -28,7 +28,7 @@ typedef void* fsv_stream_t; /* hipStream_t */
 
 enum fsv_status { FSV_OK = 0, FSV_ERR_BAD_ARG = -1, FSV_ERR_UNSUPPORTED = -2, FSV_ERR_LAUNCH = -3 };
 enum fsv_act { FSV_ACT_NONE = 0, FSV_ACT_LRELU = 1 /* leaky_relu(0.2), architecture.py:15-17 */, FSV_ACT_TANH = 2,
-               FSV_ACT_SIGMOID = 3 };
+               FSV_ACT_SIGMOID = 3, FSV_ACT_RELU = 4 /* VGG19 stack */ };
 
 /* ---- convolution family (csrc/conv_igemm.hip) -----------------------------------------------------------------
  * Replaces F.conv2d at architecture.py:22-27,60,81-84; generator.py:112-131,479-504,541-572;
@@ -129,6 +129,9 @@ int fsv_blend_fwd(const float* a, const float* b, const float* m, float* out, in
 int fsv_blend_bwd(const float* a, const float* b, const float* m, const float* g, float* da, float* db, float* dm, int N, int C,
                   long long P, const long long* a_strides, const long long* b_strides, const long long* g_strides,
                   fsv_stream_t stream);
+/* 2x2 stride-2 max pooling of the VGG19 feature stack (models/networks/vgg.py:45-59), NHWC */
+int fsv_maxpool2_fwd(const float* x, float* y, int N, int H, int W, int C, fsv_stream_t stream);
+int fsv_maxpool2_bwd(const float* x, const float* dy, float* dx, int N, int H, int W, int C, fsv_stream_t stream);
 /* softmax over the contiguous channel dimension of [rows][C] (nn.Softmax(dim=1) at generator.py:384) */
 int fsv_softmax_rows_fwd(const float* x, float* y, long long rows, int C, fsv_stream_t stream);
 int fsv_softmax_rows_bwd(const float* dy, const float* y, float* dx, long long rows, int C, fsv_stream_t stream);

@@ -36,6 +36,7 @@ CONFIGS = {
     'pose_blend': '--dataset_mode fewshot_pose --aspect_ratio 1 --fineSize 64 --loadSize 64 --adaptive_spade --warp_ref '
                   '--no_flow_gt --no_vgg_loss --gpu_ids -1 --ngf 8 --ndf 8 --nff 8 --batchSize 2',
 }
+CONFIGS['pose_combine_vgg'] = CONFIGS['pose_combine'].replace(' --no_vgg_loss', '')    # + VGG19 perceptual loss
 LAYOUT_CONFIGS = {
     'C3_pose_512': '--dataset_mode fewshot_pose --aspect_ratio 1 --fineSize 512 --loadSize 512 --adaptive_spade --warp_ref '
                    '--spade_combine --remove_face_labels --no_flow_gt --no_vgg_loss --gpu_ids -1',

@@ -57,14 +57,14 @@ def install_shims():
         cfg = [64, 64, 'M', 128, 128, 'M', 256, 256, 256, 256, 'M', 512, 512, 512, 512, 'M',
                512, 512, 512, 512, 'M']
         layers, cin = [], 3
-        g = torch.Generator().manual_seed(19)
+        g = torch.Generator().manual_seed(19)       # same stream as few-shot-vid2vid_amd/vgg.py:random_vgg19_weights
         for v in cfg:
             if v == 'M':
                 layers.append(torch.nn.MaxPool2d(2, 2))
             else:
                 conv = torch.nn.Conv2d(cin, v, 3, padding=1)
                 with torch.no_grad():
-                    conv.weight.copy_(torch.randn(conv.weight.shape, generator=g) * math.sqrt(2.0 / (9 * cin)))
+                    conv.weight.copy_(torch.randn((v, cin, 3, 3), generator=g) * math.sqrt(2.0 / (9 * cin)))
                     conv.bias.zero_()
                 layers += [conv, torch.nn.ReLU(inplace=False)]
                 cin = v

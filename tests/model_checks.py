@@ -261,7 +261,14 @@ def _model():
     return import_module('few-shot-vid2vid_amd.model')
 
 
-def _oracle_iteration(sdG0, sdD0, cfg, data, dtype):
+def _vgg_weights(opt):
+    if getattr(opt, 'no_vgg_loss', True):
+        return None
+    import fsv2v_amd  # noqa: F401
+    return import_module('few-shot-vid2vid_amd.vgg').random_vgg19_weights()
+
+
+def _oracle_iteration(sdG0, sdD0, cfg, data, dtype, vgg_weights=None):
     """One reference iteration (train.py:58-62) on the oracle: D step then G step; returns losses and gradients."""
     tl, ti, rl, ri = [t.to(dtype) for t in data]
 
@@ -281,7 +288,7 @@ def _oracle_iteration(sdG0, sdD0, cfg, data, dtype):
     for v in list(sdG.values()) + list(sdD.values()):
         if v.is_floating_point() and v.grad is not None:
             v.grad = None
-    g_losses, gen = O.g_step_losses(sdG, sdD, cfg, tl, ti, rl, ri)
+    g_losses, gen = O.g_step_losses(sdG, sdD, cfg, tl, ti, rl, ri, vgg_weights=vgg_weights)
     sum(l.mean() for l in g_losses.values()).backward()
     gG = {k: v.grad.clone() for k, v in sdG.items() if v.is_floating_point() and v.grad is not None}
     return d_losses, gD, g_losses, gG, gen
@@ -305,8 +312,9 @@ def check_train_step(device, opt, b=2, tol=1e-3, seed=21, grad_tol=2e-2):
     nl = opt.label_nc if opt.label_nc != 0 else opt.input_nc
     data = synth_pose_inputs(b, h, w, seed, nl)
     cfg = O.cfg_from_opt(opt)
-    r32 = _oracle_iteration(sdG0, sdD0, cfg, data, torch.float32)
-    r64 = _oracle_iteration(sdG0, sdD0, cfg, data, torch.float64)
+    vw = _vgg_weights(opt)
+    r32 = _oracle_iteration(sdG0, sdD0, cfg, data, torch.float32, vw)
+    r64 = _oracle_iteration(sdG0, sdD0, cfg, data, torch.float64, vw)
     tl, ti, rl, ri = [t.to(device) for t in data]
     data_list = [tl, ti, [None, None], [None, None], rl, ri, None, None, None]
     d_losses = model(data_list, mode='discriminator')
@@ -319,7 +327,7 @@ def check_train_step(device, opt, b=2, tol=1e-3, seed=21, grad_tol=2e-2):
     g_losses, generated, prev = model(data_list, save_images=True, mode='generator')
     g_losses = M.loss_backward(opt, g_losses, opt_G, 0)
     names = M.LOSS_NAMES_G
-    for k in ('G_GAN', 'G_GAN_Feat', 'F_Warp', 'F_Mask'):
+    for k in r32[2]:
         _close_vs64(k, g_losses[names.index(k)].view(1), r32[2][k].view(1), r64[2][k].view(1), tol)
     sd32 = {k: _G(v) for k, v in r32[3].items()}
     sd64 = {k: _G(v) for k, v in r64[3].items()}

@@ -14,7 +14,7 @@ import model_checks as mc
 from oracle import fsv_oracle as O
 
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
-CASES = ['pose_combine', 'face', 'pose_blend']
+CASES = ['pose_combine', 'face', 'pose_blend', 'pose_combine_vgg']
 
 
 def _opt_from_flags(flags):
@@ -41,6 +41,7 @@ def _opt_from_flags(flags):
             raise ValueError(t)
     if kw.get('dataset_mode') == 'fewshot_face':
         kw.setdefault('input_nc', 1)
+    kw.setdefault('no_vgg_loss', False)          # the reference's default: VGG perceptual loss on
     return mc.make_opt(**kw)
 
 
@@ -68,7 +69,8 @@ def test_oracle_reproduces_reference_iteration(case):
     sdG0, sdD0 = mc.fill_state(model.netG), mc.fill_state(model.netD)
     nl = opt.label_nc if opt.label_nc != 0 else opt.input_nc
     data = mc.synth_pose_inputs(g['batch'], g['size'], g['size'], g['seed'], nl)
-    d_losses, gD, g_losses, gG, gen = mc._oracle_iteration(sdG0, sdD0, O.cfg_from_opt(opt), data, torch.float32)
+    d_losses, gD, g_losses, gG, gen = mc._oracle_iteration(sdG0, sdD0, O.cfg_from_opt(opt), data, torch.float32,
+                                                           mc._vgg_weights(opt))
     names = g['loss_names']
     assert abs(float(d_losses[0]) - g['d_losses'][0]) <= 1e-5 * max(1.0, abs(g['d_losses'][0]))
     assert abs(float(d_losses[1]) - g['d_losses'][1]) <= 1e-5 * max(1.0, abs(g['d_losses'][1]))

@@ -42,3 +42,8 @@ def test_train_step_face(hip_lib):
 def test_temporal_second_frame(hip_lib):
     mc.check_temporal_step(dev(), mc.tiny_opt(ngf=8, ndf=8, nff=8, warp_ref=True, spade_combine=True, remove_face_labels=True,
                                               fineSize=128, loadSize=128), b=2)
+
+
+def test_train_step_with_vgg_loss(hip_lib):
+    mc.check_train_step(dev(), mc.tiny_opt(ngf=8, ndf=8, nff=8, warp_ref=True, spade_combine=True, remove_face_labels=True,
+                                           no_vgg_loss=False, fineSize=64, loadSize=64), b=1)
