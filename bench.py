@@ -185,9 +185,9 @@ def main():
         'vs_baseline': None,
         'dtype': 'f32',
         'data': 'synthetic',
-        'config': {'workload': 'fewshot_pose %dx%d, per-GPU batch %d, adaptive_spade+warp_ref+spade_combine, '
-                               'D step + G step (train.py:58-62), Adam included, ' + ('with VGG19 loss, ' if WITH_VGG else 'no VGG / ') + 'no FlowNet2 / face-D'
-                               % (args.size, args.size, args.batch),
+        'config': {'workload': ('fewshot_pose %dx%d, per-GPU batch %d, adaptive_spade+warp_ref+spade_combine, '
+                                'D step + G step (train.py:58-62), Adam included, %sno FlowNet2 / face-D'
+                                % (args.size, args.size, args.batch, 'with VGG19 loss, ' if WITH_VGG else 'no VGG / ')),
                    'global_batch': args.batch * world, 'parallelism': 'dp%d' % world, 'launch': mode,
                    'algorithmic_tflop_per_frame': 1.66},
     }
