@@ -108,8 +108,12 @@ def main():
     torch.cuda.set_device(local_rank)
     device = torch.device('cuda', local_rank)
     group = None
-    if world > 1:
+    # FSV_FORCE_DIST=1: exercise the RCCL / bucket / side-stream path in a one-rank group (single-GPU smoke test of
+    # the code the driver runs at N > 1; results are identical to the plain path, the step runs eagerly)
+    force_dist = os.environ.get('FSV_FORCE_DIST', '0') == '1'
+    if world > 1 or force_dist:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29533')
         dist.init_process_group(backend='nccl', rank=rank, world_size=world)
 
     from importlib import import_module
@@ -119,7 +123,7 @@ def main():
 
     opt = build_opt(args.size, args.batch)
     model = M.create_model(opt).to(device).train()          # identical init on every rank (seed 0), like the reference
-    opt_G, opt_D = model.build_optimizers(world_size=world, process_group=group)
+    opt_G, opt_D = model.build_optimizers(world_size=world, process_group=group, force_exchange=force_dist)
     data = make_data(args.batch, args.size, 1234 + rank, device)
 
     def step():
@@ -128,7 +132,7 @@ def main():
         g_losses, _, _ = model(data, mode='generator')
         M.loss_backward(opt, g_losses, opt_G, 0)
 
-    use_graph = (world == 1) and not args.no_graph
+    use_graph = (world == 1) and not args.no_graph and not force_dist
     graph = None
     n_eager_warm = max(1, min(args.warmup, 2)) if use_graph else args.warmup
     side = torch.cuda.Stream()
@@ -155,7 +159,7 @@ def main():
         run()
 
     torch.cuda.synchronize()
-    if world > 1:
+    if world > 1 or force_dist:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -218,7 +222,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             result['cpu_baseline'] = cpu_baseline(args.size, min(os.cpu_count() or 1, 64))
         print(json.dumps(result))
-    if world > 1:
+    if world > 1 or force_dist:
         dist.destroy_process_group()
 
 

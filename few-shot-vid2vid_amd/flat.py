@@ -21,7 +21,8 @@ from . import ops
 
 
 class FlatAdam:
-    def __init__(self, params, lr, betas=(0.0, 0.999), world_size=1, process_group=None, eps=1e-8, bucket_mb=64):
+    def __init__(self, params, lr, betas=(0.0, 0.999), world_size=1, process_group=None, eps=1e-8, bucket_mb=64,
+                 force_exchange=False):
         params = [p for p in params if p.requires_grad]
         if not params:
             raise ValueError("no trainable parameters")
@@ -29,6 +30,9 @@ class FlatAdam:
         self.params = list(reversed(params))
         self.device = params[0].device
         self.world_size = world_size
+        # force_exchange: run the bucket / hook / side-stream machinery even in a one-rank group (smoke test of the
+        # exact multi-GPU code path on a single-GPU box: the all-reduce is then an identity)
+        self.exchange = world_size > 1 or force_exchange
         self.group = process_group
         self.betas, self.eps = betas, eps
         total = sum(p.numel() for p in self.params)
@@ -48,7 +52,7 @@ class FlatAdam:
                 p.grad = self.flat_g[off:off + n].view(p.shape)
                 # single process: kernels may add gradients straight into the slice (ops._ConvFn "gradient sink");
                 # with a process group the autograd hooks below have to see every gradient, so the sink stays off
-                p._fsv_sink = (world_size == 1) and os.environ.get('FSV_GRAD_SINK', '1') == '1'
+                p._fsv_sink = (not self.exchange) and os.environ.get('FSV_GRAD_SINK', '1') == '1'
                 self.offsets.append((off, n))
                 off += n
         # ---- data-parallel buckets ------------------------------------------------------------------------
@@ -57,7 +61,7 @@ class FlatAdam:
         self._pending, self._handles = [], []
         self._param_bucket = {}
         self.side_stream = None
-        if world_size > 1:
+        if self.exchange:
             cap = bucket_mb * (1 << 20) // 4
             start, count = 0, 0
             cur = []
@@ -104,7 +108,7 @@ class FlatAdam:
         self._handles.append(h)
 
     def _finish_exchange(self):
-        if self.world_size <= 1:
+        if not self.exchange:
             return
         for b in range(len(self.buckets)):       # buckets whose parameters were not all touched this step
             self._launch(b)
@@ -119,7 +123,7 @@ class FlatAdam:
     def zero_grad(self, set_to_none=False):
         """Called by loss_backward right before backward: clears the flat gradient and arms the bucket hooks."""
         self.flat_g.zero_()
-        if self.world_size > 1:
+        if self.exchange:
             self._remaining = [len(b[2]) for b in self.buckets]
             self._launched = [False] * len(self.buckets)
             self._handles = []
