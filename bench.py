@@ -123,17 +123,39 @@ def main():
 
     opt = build_opt(args.size, args.batch)
     model = M.create_model(opt).to(device).train()          # identical init on every rank (seed 0), like the reference
-    opt_G, opt_D = model.build_optimizers(world_size=world, process_group=group, force_exchange=force_dist)
+    distributed = world > 1 or force_dist
+    # N > 1: no autograd hooks, the step is three hipGraph segments with one whole-buffer RCCL all-reduce between them
+    segmented = distributed and not args.no_graph
+    opt_G, opt_D = model.build_optimizers(world_size=world, process_group=group, force_exchange=force_dist,
+                                          overlap=not segmented)
     data = make_data(args.batch, args.size, 1234 + rank, device)
 
-    def step():
-        d_losses = model(data, mode='discriminator')
-        M.loss_backward(opt, d_losses, opt_D, 1)
-        g_losses, _, _ = model(data, mode='generator')
-        M.loss_backward(opt, g_losses, opt_G, 0)
+    def backward_of(losses, optimizer):
+        loss = sum(torch.mean(x) for x in losses)
+        optimizer.zero_grad()
+        loss.backward()
 
-    use_graph = (world == 1) and not args.no_graph and not force_dist
-    graph = None
+    def seg_d():                       # D forward (incl. the no-grad G forward) + D backward
+        backward_of(model(data, mode='discriminator'), opt_D)
+
+    def seg_g():                       # Adam(D), then G forward + D forward + full backward
+        opt_D.adam()
+        backward_of(model(data, mode='generator')[0], opt_G)
+
+    def seg_a():                       # Adam(G)
+        opt_G.adam()
+
+    def step():
+        if segmented:
+            seg_d(); opt_D.exchange_all(); seg_g(); opt_G.exchange_all(); seg_a()
+        else:
+            d_losses = model(data, mode='discriminator')
+            M.loss_backward(opt, d_losses, opt_D, 1)
+            g_losses, _, _ = model(data, mode='generator')
+            M.loss_backward(opt, g_losses, opt_G, 0)
+
+    use_graph = not args.no_graph
+    graphs = None
     n_eager_warm = max(1, min(args.warmup, 2)) if use_graph else args.warmup
     side = torch.cuda.Stream()
     side.wait_stream(torch.cuda.current_stream())
@@ -143,18 +165,34 @@ def main():
     torch.cuda.current_stream().wait_stream(side)
     torch.cuda.synchronize()
     mode = 'eager'
+    run = step
     if use_graph:
         try:
-            graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
-                step()
-            mode = 'hipgraph'
+            if segmented:
+                graphs = [torch.cuda.CUDAGraph() for _ in range(3)]
+                with torch.cuda.graph(graphs[0]):
+                    seg_d()
+                opt_D.exchange_all()
+                with torch.cuda.graph(graphs[1], pool=graphs[0].pool()):
+                    seg_g()
+                opt_G.exchange_all()
+                with torch.cuda.graph(graphs[2], pool=graphs[0].pool()):
+                    seg_a()
+
+                def run():
+                    graphs[0].replay(); opt_D.exchange_all(); graphs[1].replay(); opt_G.exchange_all(); graphs[2].replay()
+                mode = 'hipgraph x3 + whole-buffer all-reduce'
+            else:
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph):
+                    step()
+                run = graph.replay
+                mode = 'hipgraph'
         except Exception as e:                      # capture is an optimisation; the step itself is unchanged
             if rank == 0:
                 print('graph capture failed (%s); timing the eager step' % str(e).split('\n')[0], file=sys.stderr)
-            graph = None
+            run = step
             torch.cuda.synchronize()
-    run = (graph.replay if graph is not None else step)
     for _ in range(max(0, args.warmup - n_eager_warm)):
         run()
 

@@ -11,6 +11,10 @@ wrapper (apex DistributedDataParallel with delay_allreduce=True, models/models.p
   autograd has produced its last gradient, i.e. overlapped with the rest of backward.  Parameters are laid out in
   reverse registration order so that buckets complete front to back during backward.  The 1/world_size average is
   folded into the Adam kernel.  BatchNorm statistics stay per replica (DESIGN.md "Multi-GPU").
+* `overlap=False` selects the second exchange mode used by bench.py at N > 1: no autograd hooks at all - the step is
+  captured as hipGraph segments (backward | Adam + next forward/backward | Adam) and ONE all-reduce over the whole
+  flat gradient buffer runs between the segments (`exchange()`), i.e. the fewest, largest collectives possible and
+  no per-launch host overhead; the un-overlapped transfer (0.39 GB over xGMI) costs a few ms of an 80 ms step.
 """
 import os
 
@@ -22,7 +26,7 @@ from . import ops
 
 class FlatAdam:
     def __init__(self, params, lr, betas=(0.0, 0.999), world_size=1, process_group=None, eps=1e-8, bucket_mb=64,
-                 force_exchange=False):
+                 force_exchange=False, overlap=True):
         params = [p for p in params if p.requires_grad]
         if not params:
             raise ValueError("no trainable parameters")
@@ -33,6 +37,7 @@ class FlatAdam:
         # force_exchange: run the bucket / hook / side-stream machinery even in a one-rank group (smoke test of the
         # exact multi-GPU code path on a single-GPU box: the all-reduce is then an identity)
         self.exchange = world_size > 1 or force_exchange
+        self.overlap = overlap and self.exchange
         self.group = process_group
         self.betas, self.eps = betas, eps
         total = sum(p.numel() for p in self.params)
@@ -52,7 +57,7 @@ class FlatAdam:
                 p.grad = self.flat_g[off:off + n].view(p.shape)
                 # single process: kernels may add gradients straight into the slice (ops._ConvFn "gradient sink");
                 # with a process group the autograd hooks below have to see every gradient, so the sink stays off
-                p._fsv_sink = (not self.exchange) and os.environ.get('FSV_GRAD_SINK', '1') == '1'
+                p._fsv_sink = (not self.overlap) and os.environ.get('FSV_GRAD_SINK', '1') == '1'
                 self.offsets.append((off, n))
                 off += n
         # ---- data-parallel buckets ------------------------------------------------------------------------
@@ -61,7 +66,7 @@ class FlatAdam:
         self._pending, self._handles = [], []
         self._param_bucket = {}
         self.side_stream = None
-        if self.exchange:
+        if self.overlap:
             cap = bucket_mb * (1 << 20) // 4
             start, count = 0, 0
             cur = []
@@ -108,7 +113,7 @@ class FlatAdam:
         self._handles.append(h)
 
     def _finish_exchange(self):
-        if not self.exchange:
+        if not self.overlap:
             return
         for b in range(len(self.buckets)):       # buckets whose parameters were not all touched this step
             self._launch(b)
@@ -123,7 +128,7 @@ class FlatAdam:
     def zero_grad(self, set_to_none=False):
         """Called by loss_backward right before backward: clears the flat gradient and arms the bucket hooks."""
         self.flat_g.zero_()
-        if self.exchange:
+        if self.overlap:
             self._remaining = [len(b[2]) for b in self.buckets]
             self._launched = [False] * len(self.buckets)
             self._handles = []
@@ -144,10 +149,21 @@ class FlatAdam:
                 super().__setitem__(k, v)
         return [_Group(lr=float(self.state[3]), params=self.params)]
 
-    def step(self):
-        self._finish_exchange()
+    def exchange_all(self):
+        """Non-overlapped mode: one all-reduce over the whole flat gradient buffer on the current stream."""
+        if self.exchange and not self.overlap:
+            dist.all_reduce(self.flat_g, op=dist.ReduceOp.SUM, group=self.group)
+
+    def adam(self):
         ops.adam_step(self.flat_p, self.flat_g, self.m, self.v, self.state, self.betas[0], self.betas[1], self.eps,
                       1.0 / self.world_size)
+
+    def step(self):
+        if self.overlap:
+            self._finish_exchange()
+        else:
+            self.exchange_all()
+        self.adam()
 
     def state_dict(self):
         return dict(m=self.m, v=self.v, state=self.state)

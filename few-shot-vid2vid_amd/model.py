@@ -288,16 +288,16 @@ class Vid2VidModel(nn.Module):
         return out
 
     # optimisers are created once the module sits on its device (flat buffers are device allocations)
-    def build_optimizers(self, world_size=1, process_group=None, force_exchange=False):
+    def build_optimizers(self, world_size=1, process_group=None, force_exchange=False, overlap=True):
         opt = self.opt
         if opt.no_TTUR:
             beta1, beta2, g_lr, d_lr = opt.beta1, 0.999, opt.lr, opt.lr
         else:
             beta1, beta2, g_lr, d_lr = 0.0, opt.beta2, opt.lr / 2, opt.lr * 2
         self.optimizer_G = FlatAdam(list(self.netG.parameters()), g_lr, (beta1, beta2), world_size, process_group,
-                                    force_exchange=force_exchange)
+                                    force_exchange=force_exchange, overlap=overlap)
         self.optimizer_D = FlatAdam(list(self.netD.parameters()), d_lr, (beta1, beta2), world_size, process_group,
-                                    force_exchange=force_exchange)
+                                    force_exchange=force_exchange, overlap=overlap)
         return self.optimizer_G, self.optimizer_D
 
     def init_temporal_model(self):
