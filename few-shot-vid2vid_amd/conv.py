@@ -117,7 +117,7 @@ def unprep_weight_grad(dwt, w_shape, geom, scale=None, out=None):
 
 
 def gather_gemm(x, wt, ldw, cout, oh, ow, ty, tx, sy, sx, bias=None, res=None, act=ACT_NONE, scale=1.0,
-                per_sample=False, out=None, place=None, accumulate=False, force_tile=-1, force_split=0):
+                per_sample=False, out=None, place=None, accumulate=False, force_tile=-1, force_split=0, wscale=None):
     """out[n, oy, ox, :] = act((sum_taps x[n, oy*sy+ty, ox*sx+tx, :] @ wt[tap]) + bias) * scale) + res."""
     x = to_nhwc(x)
     n, cin, h, w = x.shape
@@ -129,13 +129,13 @@ def gather_gemm(x, wt, ldw, cout, oh, ow, ty, tx, sy, sx, bias=None, res=None, a
         out = empty_nhwc(n, cout, out_h, out_w, x)
     if res is not None:
         res = to_nhwc(res)
-    lib.check_device(x, wt, bias, res, out)
+    lib.check_device(x, wt, bias, res, out, wscale)
     w_bs = wt.shape[-2] * wt.shape[-1] if per_sample else 0
     b_bs = cout if (per_sample and bias is not None) else 0
     args = (lib.ptr(x), lib.ptr(wt), lib.ptr(bias), lib.ptr(res), lib.ptr(out),
             n, h, w, cin, oh, ow, cout, len(ty), lib.int_array(ty), lib.int_array(tx), sy, sx,
             out_h, out_w, osy, osx, ooy, oox, ldw, w_bs, b_bs, 1 if per_sample else 0,
-            act, float(scale), force_tile, force_split, 1 if accumulate else 0, lib.stream_ptr())
+            act, float(scale), force_tile, force_split, 1 if accumulate else 0, lib.ptr(wscale), lib.stream_ptr())
     if profile.enabled():
         mz = oh * ow if per_sample else n * oh * ow
         label = profile.conv_label(mz, cout, (len(ty) * cin + 31) // 32, n if per_sample else 1, cin % 4 == 0,
@@ -148,33 +148,43 @@ def gather_gemm(x, wt, ldw, cout, oh, ow, ty, tx, sy, sx, bias=None, res=None, a
 
 
 def conv_forward(x, wt_f, ldw, cout, geom, bias=None, res=None, act=ACT_NONE, scale=1.0, per_sample=False,
-                 force_tile=-1, force_split=0):
+                 force_tile=-1, force_split=0, wscale=None):
     n, cin, h, w = x.shape
     oh, ow = geom.out_hw(h, w)
     return gather_gemm(x, wt_f, ldw, cout, oh, ow, geom.ty, geom.tx, geom.stride, geom.stride, bias=bias, res=res,
-                       act=act, scale=scale, per_sample=per_sample, force_tile=force_tile, force_split=force_split)
+                       act=act, scale=scale, per_sample=per_sample, force_tile=force_tile, force_split=force_split,
+                       wscale=wscale)
 
 
-def conv_dgrad(dout, w, geom, in_hw, scale=None, per_sample=False):
-    """Data gradient of a convolution: dx[n, y, x, ci] from dout (NHWC) and OIHW weights."""
+def conv_dgrad(dout, w, geom, in_hw, scale=None, per_sample=False, cached=None, cin=None):
+    """Data gradient of a convolution: dx[n, y, x, ci] from dout (NHWC) and OIHW weights.
+
+    cached: optional list (one entry per geom.dgrad_classes element, None for empty classes) of (wt, ldw) un-scaled
+    layouts kept by the optimiser's LayoutCache; `scale` (device 1/sigma) is then applied in the GEMM epilogue."""
     dout = to_nhwc(dout)
     n, cout, oh, ow = dout.shape
-    cin = w.shape[-3]
+    cin = w.shape[-3] if cin is None else cin
     h, wd = in_hw
     s = geom.stride
+
+    def layout(k, c):
+        if cached is not None:
+            return cached[k][0], cached[k][1], scale
+        wt, _, ldw = prep_weight(w, 1, geom, c['khs'], c['kws'], scale)
+        return wt, ldw, None
     if s == 1:
         c = geom.dgrad_classes[0]
-        wt, _, ldw = prep_weight(w, 1, geom, c['khs'], c['kws'], scale)
-        return gather_gemm(dout, wt, ldw, cin, h, wd, c['ty'], c['tx'], 1, 1, per_sample=per_sample)
+        wt, ldw, ws = layout(0, c)
+        return gather_gemm(dout, wt, ldw, cin, h, wd, c['ty'], c['tx'], 1, 1, per_sample=per_sample, wscale=ws)
     dx = zeros_nhwc(n, cin, h, wd, dout)
-    for c in geom.dgrad_classes:
+    for k, c in enumerate(geom.dgrad_classes):
         sub_h = (h - c['py'] + s - 1) // s
         sub_w = (wd - c['px'] + s - 1) // s
         if sub_h <= 0 or sub_w <= 0 or not c['khs']:
             continue
-        wt, _, ldw = prep_weight(w, 1, geom, c['khs'], c['kws'], scale)
+        wt, ldw, ws = layout(k, c)
         gather_gemm(dout, wt, ldw, cin, sub_h, sub_w, c['ty'], c['tx'], 1, 1, per_sample=per_sample, out=dx,
-                    place=(h, wd, s, s, c['py'], c['px']), accumulate=True)
+                    place=(h, wd, s, s, c['py'], c['px']), accumulate=True, wscale=ws)
     return dx
 
 
@@ -189,9 +199,10 @@ def conv_wgrad(x, dout, geom, w_shape, per_sample=False, scale=None, force_split
     nb = n if per_sample else 1
     dwt = torch.empty((nb, kpad, ldw), dtype=torch.float32, device=x.device)
     lib.check_device(x, dout)
-    with profile.scope('fsv_conv_wgrad_kernel<BN%d,V%d>' % (32 if cout <= 32 else (64 if cout <= 64 else 128),
-                                                            4 if cin % 4 == 0 else 1),
-                       2.0 * n * oh * ow * cout * cin * geom.ntaps):
+    label = 'fsv_conv_wgrad_kernel<BN%d,V%d>' % (32 if cout <= 32 else (64 if cout <= 64 else 128), 4 if cin % 4 == 0 else 1)
+    if profile.detail():
+        label += ' Kdim%d N%d pix%d z%d' % (geom.ntaps * cin, cout, (oh * ow) if per_sample else n * oh * ow, nb)
+    with profile.scope(label, 2.0 * n * oh * ow * cout * cin * geom.ntaps):
         lib.call("fsv_conv_wgrad", lib.ptr(x), lib.ptr(dout), lib.ptr(dwt), n, h, w, cin, oh, ow, cout,
                  geom.ntaps, lib.int_array(geom.ty), lib.int_array(geom.tx), geom.stride, geom.stride,
                  ldw, kpad, kpad * ldw, 1 if per_sample else 0, force_split, lib.stream_ptr())

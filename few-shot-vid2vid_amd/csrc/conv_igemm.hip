@@ -23,6 +23,7 @@ struct ConvP {
   const float* wt;
   const float* bias;
   const float* res;
+  const float* wscale;     // optional device scalar multiplying the accumulator (spectral-norm 1/sigma), or null
   float* out;
   int N, H, W, Cin;        // input tensor NHWC
   int OH, OW, Cout;        // iteration grid and number of output channels
@@ -190,6 +191,7 @@ __global__ __launch_bounds__(64 * WM * WN) void fsv_conv_igemm_kernel(ConvP p) {
 
   // ---- epilogue: D layout col = lane&31 (channel), row = (r&3) + 8*(r>>2) + 4*(lane>>5) (pixel) -----------
   const float* bias = p.bias ? (p.bias + (long long)zs * p.b_bstride) : nullptr;
+  const float ws = p.wscale ? p.wscale[0] : 1.f;
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
     const int co = bn0 + wn * (TN * 32) + j * 32 + lrow;
@@ -212,7 +214,7 @@ __global__ __launch_bounds__(64 * WM * WN) void fsv_conv_igemm_kernel(ConvP p) {
           opix = ((long long)n * p.outH + (oy * p.osy + p.ooy)) * p.outW + (ox * p.osx + p.oox);
         }
         float* dst = p.out + opix * p.Cout + co;
-        float v = acc[i][j][r];
+        float v = acc[i][j][r] * ws;
         if (p.nsplit > 1) {
           atomicAdd(dst, v);
         } else {
@@ -461,6 +463,49 @@ __global__ __launch_bounds__(256) void fsv_prep_weight_kernel(const float* w, fl
   }
 }
 
+// ---- grouped re-arrangement: every parameter weight of an optimiser in ONE launch (run right after the Adam step) ----
+// desc arrays (device): src / dst pointers as 64-bit integers; dims[l] = {Cout, Cin_pad, Cin_real, KH, KW, ntaps, Kpad, ldw,
+// mode}; taps[l] = {lo, hi} packed (kh | kw << 4) codes.  tmap[b] = (layer, chunk): a block re-arranges 1024 consecutive
+// destination elements of one layer.  No scaling here: the spectral-norm 1/sigma is applied in the GEMM epilogue.
+struct PrepGroup {
+  const long long* src; const long long* dst; const int* dims; const unsigned long long* taps;
+};
+__global__ __launch_bounds__(256) void fsv_prep_group_kernel(PrepGroup g, const int* tmap) {
+  const int layer = tmap[blockIdx.x * 2], chunk = tmap[blockIdx.x * 2 + 1];
+  const int* d = g.dims + layer * 9;
+  const int Cout = d[0], CinP = d[1], CinR = d[2], KH = d[3], KW = d[4], ntaps = d[5], Kpad = d[6], ldw = d[7], mode = d[8];
+  const float* w = reinterpret_cast<const float*>(g.src[layer]);
+  float* wt = reinterpret_cast<float*>(g.dst[layer]);
+  const unsigned long long lo = g.taps[layer * 2], hi = g.taps[layer * 2 + 1];
+  const long long total = (long long)Kpad * ldw;
+  const int rowlen = (mode == 1) ? Cout : CinP;
+  const int ncols = (mode == 1) ? CinP : Cout;
+  const int K = ntaps * rowlen;
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    long long i = (long long)chunk * 1024 + u * 256 + threadIdx.x;
+    if (i >= total) break;
+    int r = (int)(i / ldw), c = (int)(i - (long long)r * ldw);
+    bool ok = r < K && c < ncols;
+    int j = ok ? r / rowlen : 0;
+    int a = r - j * rowlen;
+    unsigned long long code = (j < 8) ? lo : hi;
+    int sh = (j & 7) * 8;
+    int kh = (int)((code >> sh) & 15ull), kw = (int)((code >> (sh + 4)) & 15ull);
+    int co = (mode == 1) ? a : c, ci = (mode == 1) ? c : a;
+    ok = ok && ci < CinR;
+    wt[i] = ok ? w[(((long long)co * CinR + ci) * KH + kh) * KW + kw] : 0.f;
+  }
+}
+
+extern "C" int fsv_prep_weight_grouped(const long long* src, const long long* dst, const int* dims,
+                                       const unsigned long long* taps, const int* tmap, int nblocks, hipStream_t stream) {
+  if (!src || !dst || !dims || !taps || !tmap || nblocks < 1) return FSV_ERR_BAD_ARG;
+  PrepGroup g; g.src = src; g.dst = dst; g.dims = dims; g.taps = taps;
+  FSV_LAUNCH(fsv_prep_group_kernel, dim3(nblocks), dim3(256), stream, g, tmap);
+  return fsv_check_launch();
+}
+
 // =============================================== host side ===================================================
 static inline void fsv_pack_taps(const int* ty, const int* tx, int n, unsigned long long& lo, unsigned long long& hi,
                                  int bias) {
@@ -538,10 +583,28 @@ static inline int fsv_thin_tile() {
 extern "C" int fsv_conv_plan(int Mz, int Cout, int nchunks, int nsamp, int force_tile, int force_split,
                              int* tile_out, int* nsplit_out) {
   int tile = force_tile;
+  static int plan_v = -1;
+  if (plan_v < 0) { const char* e = getenv("FSV_PLAN"); plan_v = e ? atoi(e) : 1; }
+  const long long b0 = (long long)fsv_cdiv(Mz, 128) * fsv_cdiv(Cout, 128) * nsamp;      // 128x128 tiles
+  const long long b1 = (long long)fsv_cdiv(Mz, 128) * fsv_cdiv(Cout, 64) * nsamp;       // 128x64
+  const long long b4 = (long long)fsv_cdiv(Mz, 64) * fsv_cdiv(Cout, 64) * nsamp;        // 64x64
+  bool small_tile_regime = false;
   if (tile < 0) {
-    if (Cout <= 32) tile = (Mz >= 256 * 256) ? fsv_thin_tile() : 2;
-    else if (Cout <= 64) tile = 1;
-    else tile = ((long long)Mz * Cout <= 64 * 64 * 64) ? 4 : 0;
+    if (plan_v == 0) {
+      if (Cout <= 32) tile = (Mz >= 256 * 256) ? fsv_thin_tile() : 2;
+      else if (Cout <= 64) tile = 1;
+      else tile = ((long long)Mz * Cout <= 64 * 64 * 64) ? 4 : 0;
+    } else {
+      // in-box A/B on the step's layer shapes (tools/tile_ab.py, profiles/r01_tile_ab.jsonl): with fewer than two
+      // 128-row tiles per CU the 64x64 tile without split-K beats the big tile with split-K (no atomics, no zero-fill,
+      // no separate bias pass) unless K is long enough (>= 4096) to amortise them
+      if (Cout <= 32) tile = (Mz >= 256 * 256) ? fsv_thin_tile() : 2;
+      else if (Cout <= 64) tile = (b1 < 512) ? 4 : 1;
+      else if (b0 >= 512) tile = 0;
+      else if (nchunks >= 128) tile = (b0 < 64) ? 1 : 0;
+      else { tile = 4; }
+      small_tile_regime = (tile == 4);
+    }
   }
   int bm, bn;
   if (fsv_tile_dims(tile, bm, bn)) return -1;
@@ -549,12 +612,20 @@ extern "C" int fsv_conv_plan(int Mz, int Cout, int nchunks, int nsamp, int force
   long long blocks = (long long)fsv_cdiv(Mz, bm) * fsv_cdiv(Cout, bn) * nsamp;
   int nsplit = 1;
   if (force_split > 0) nsplit = force_split;
-  else if (blocks < fsv_tune(0) && nchunks >= 8) {
+  else if (small_tile_regime) {
+    // 64x64 tiles: split only when even they leave CUs idle, and keep >= 16 chunks (512 K-elements) per split
+    if (blocks < 512 && nchunks >= 32) {
+      nsplit = (int)((1024 + blocks - 1) / blocks);
+      if (nsplit > nchunks / 16) nsplit = nchunks / 16;
+      if (nsplit < 1) nsplit = 1;
+    }
+  } else if (blocks < fsv_tune(0) && nchunks >= 8) {
     // aim at a few workgroups per CU; thresholds are tunables (FSV_SPLIT_BELOW / FSV_SPLIT_TARGET) for A/B runs
     nsplit = (int)((fsv_tune(1) + blocks - 1) / blocks);
     if (nsplit > nchunks / 4) nsplit = nchunks / 4;
     if (nsplit < 1) nsplit = 1;
   }
+  (void)b4;
   if (nsplit > nchunks) nsplit = nchunks;
   *tile_out = tile; *nsplit_out = nsplit;
   return 0;
@@ -570,13 +641,14 @@ int fsv_conv_gather_fwd(const float* in, const float* wt, const float* bias, con
                         int ntaps, const int* ty, const int* tx, int sy, int sx,
                         int outH, int outW, int osy, int osx, int ooy, int oox,
                         int ldw, long long w_bstride, long long b_bstride, int per_sample,
-                        int act, float scale, int force_tile, int force_split, int accumulate, hipStream_t stream) {
+                        int act, float scale, int force_tile, int force_split, int accumulate, const float* wscale,
+                        hipStream_t stream) {
   if (!in || !wt || !out || ntaps < 1 || ntaps > 16 || N < 1 || Cin < 1 || Cout < 1) return FSV_ERR_BAD_ARG;
   for (int t = 0; t < ntaps; ++t)
     if (ty[t] < -8 || ty[t] > 7 || tx[t] < -8 || tx[t] > 7) return FSV_ERR_UNSUPPORTED;
   if ((ldw & 3) != 0 || ldw < Cout) return FSV_ERR_BAD_ARG;
   ConvP p;
-  p.in = in; p.wt = wt; p.bias = bias; p.res = res; p.out = out;
+  p.in = in; p.wt = wt; p.bias = bias; p.res = res; p.out = out; p.wscale = wscale;
   p.N = N; p.H = H; p.W = W; p.Cin = Cin; p.OH = OH; p.OW = OW; p.Cout = Cout;
   p.K = ntaps * Cin; p.nchunks = fsv_cdiv(p.K, FSV_BK); p.ldw = ldw;
   p.sy = sy; p.sx = sx; p.ntaps = ntaps;

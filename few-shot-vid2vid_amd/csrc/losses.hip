@@ -158,6 +158,30 @@ __global__ __launch_bounds__(256) void fsv_pool15_kernel(const float* x, float* 
   }
 }
 
+// ---- DensePose body-part group masks (models/input_process.py:64-94) --------------------------------------------------------
+// pose channel value -> part = (v / 2 + 0.5) * 24; group g is hit when part lies in (j - 0.1, j + 0.1) for a member j.
+// y[(n * ngroups + g) * P + p]; groups g0 .. g0 + ngroups - 1 of the table below (the last one, {23, 24}, is the face).
+__constant__ int fsv_part_first[10] = {0, 1, 3, 5, 7, 11, 15, 19, 23, 25};        // members of group g: order below
+__constant__ int fsv_part_member[25] = {0, 1, 2, 3, 4, 5, 6, 7, 9, 8, 10, 11, 13, 12, 14, 15, 17, 16, 18, 19, 21, 20, 22, 23, 24};
+__global__ __launch_bounds__(256) void fsv_part_masks_kernel(const float* x, float* y, long long N, long long P, int T, long long sb,
+                                                             long long st, int g0, int ngroups) {
+  const long long total = N * P;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const long long n = i / P, p = i - n * P;
+    const float v = x[(n / T) * sb + (n % T) * st + p];
+    const float part = (v / 2.f + 0.5f) * 24.f;
+    for (int g = 0; g < ngroups; ++g) {
+      bool hit = false;
+      for (int m = fsv_part_first[g0 + g]; m < fsv_part_first[g0 + g + 1]; ++m) {
+        const int j = fsv_part_member[m];
+        const float lo = (float)((double)j - 0.1), hi = (float)((double)j + 0.1);   // the scalars torch compares against
+        hit = hit || (part > lo && part < hi);
+      }
+      y[(n * ngroups + g) * P + p] = hit ? 1.f : 0.f;
+    }
+  }
+}
+
 static inline int fsv_loss_grid(long long n) {
   long long g = (n + 255) / 256;
   if (g > FSV_LOSS_BLOCKS) g = FSV_LOSS_BLOCKS;
@@ -226,6 +250,13 @@ int fsv_pack_d_input(const float* ref, const float* lab, const float* fake, cons
 int fsv_unpack_d_grad(const float* dout, float* dfake, int B, int Ci, int Coff, int Ct, long long P, hipStream_t stream) {
   if (!dout || !dfake) return FSV_ERR_BAD_ARG;
   FSV_LAUNCH(fsv_unpack_d_kernel, dim3(fsv_loss_grid((long long)B * Ci * P) * 4), dim3(256), stream, dout, dfake, B, Ci, Coff, Ct, P);
+  return fsv_check_launch();
+}
+
+int fsv_part_masks(const float* x, float* y, long long N, long long P, int T, long long sb, long long st, int g0, int ngroups,
+                   hipStream_t stream) {
+  if (!x || !y || N < 1 || P < 1 || T < 1 || g0 < 0 || ngroups < 1 || g0 + ngroups > 9) return FSV_ERR_BAD_ARG;
+  FSV_LAUNCH(fsv_part_masks_kernel, dim3(fsv_loss_grid(N * P) * 8), dim3(256), stream, x, y, N, P, T, sb, st, g0, ngroups);
   return fsv_check_launch();
 }
 

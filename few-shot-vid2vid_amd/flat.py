@@ -22,6 +22,7 @@ import torch
 import torch.distributed as dist
 
 from . import ops
+from .layout_cache import LayoutCache
 
 
 class FlatAdam:
@@ -47,6 +48,8 @@ class FlatAdam:
         self.m = torch.zeros_like(self.flat_g)
         self.v = torch.zeros_like(self.flat_g)
         self.state = torch.tensor([0.0, 0.0, 0.0, float(lr)], dtype=torch.float32, device=self.device)
+        # persistent K-major layouts of every weight this optimiser owns, rewritten once per step (layout_cache.py)
+        self.layouts = LayoutCache() if os.environ.get('FSV_LAYOUT_CACHE', '1') == '1' else None
         self.offsets = []
         off = 0
         with torch.no_grad():
@@ -58,6 +61,8 @@ class FlatAdam:
                 # single process: kernels may add gradients straight into the slice (ops._ConvFn "gradient sink");
                 # with a process group the autograd hooks below have to see every gradient, so the sink stays off
                 p._fsv_sink = (not self.overlap) and os.environ.get('FSV_GRAD_SINK', '1') == '1'
+                if self.layouts is not None and p.dim() in (2, 4):
+                    p._fsv_cache = self.layouts
                 self.offsets.append((off, n))
                 off += n
         # ---- data-parallel buckets ------------------------------------------------------------------------
@@ -157,6 +162,13 @@ class FlatAdam:
     def adam(self):
         ops.adam_step(self.flat_p, self.flat_g, self.m, self.v, self.state, self.betas[0], self.betas[1], self.eps,
                       1.0 / self.world_size)
+        self.refresh_layouts()
+
+    def refresh_layouts(self):
+        """Re-derive the cached GEMM layouts from the current parameter values (also call this after modifying
+        parameters outside the optimiser when replaying a captured graph)."""
+        if self.layouts is not None:
+            self.layouts.refresh()
 
     def step(self):
         if self.overlap:

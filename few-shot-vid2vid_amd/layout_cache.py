@@ -1,0 +1,133 @@
+"""Persistent K-major weight layouts, refreshed by ONE grouped launch per optimiser step.
+
+The gather-GEMM kernels read weights as wt[(tap, ci)][co] (forward) and wt[(tap, co)][ci] (data gradient, one layout
+per stride parity class).  Parameters only change in the optimiser step, so instead of re-arranging every layer's
+weights on every use (~400 small launches per training step) the optimiser owns a cache of the layouts and rewrites
+all of them with a single `fsv_prep_weight_grouped` launch right after the fused Adam kernel.  The spectral-norm
+1/sigma (which changes every forward) is not baked into the layouts: the GEMM epilogue applies it (`wscale`).
+
+Entries are registered lazily the first time a parameter goes through ops._ConvFn (the geometry is only known there).
+Parameters modified behind the optimiser's back (load_state_dict, copy_) are detected through `Tensor._version` on the
+eager path; a captured hipGraph cannot see that, so call `FlatAdam.refresh_layouts()` after such a modification.
+"""
+import torch
+
+from . import lib
+
+
+def _pack_taps(khs, kws):
+    lo = hi = 0
+    for j, (a, b) in enumerate(zip(khs, kws)):
+        code = (a | (b << 4)) & 0xff
+        if j < 8:
+            lo |= code << (8 * j)
+        else:
+            hi |= code << (8 * (j - 8))
+    return lo, hi
+
+
+def _i64(v):
+    return v - (1 << 64) if v >= (1 << 63) else v
+
+
+def _ceil(a, b):
+    return (a + b - 1) // b * b
+
+
+class _Entry:
+    __slots__ = ("weight", "key", "src_ptr", "version", "fwd", "dgrad", "jobs")
+
+
+class LayoutCache:
+    def __init__(self):
+        self.entries = []
+        self._tables = None
+        self._nblocks = 0
+        self._dirty = True
+
+    # ------------------------------------------------------------------------------------------ registration
+    def lookup(self, weight, shape4, geom, cpad):
+        """shape4: (Cout, Cin_real, KH, KW) of the parameter seen as a convolution weight."""
+        key = (tuple(shape4), geom.kh, geom.kw, geom.stride, geom.pad, cpad)
+        e = getattr(weight, "_fsv_layout", None)
+        if e is None or e.src_ptr != weight.data_ptr() or e.key != key:
+            if e is not None and e.key != key:
+                return None                   # one parameter used with two geometries: leave it on the per-call path
+            if not lib.is_emu() and torch.cuda.is_current_stream_capturing():
+                return None                   # cannot grow the tables inside a capture; this call re-arranges itself
+            e = self._register(weight, key, shape4, geom, cpad)
+        if e.version != weight._version:
+            self._refresh_entry(e)
+        return e
+
+    def _register(self, weight, key, shape4, geom, cpad):
+        old = getattr(weight, "_fsv_layout", None)
+        if old is not None and old in self.entries:
+            self.entries.remove(old)
+        cout, cin, kh, kw = shape4
+        cinp = cin + cpad
+        dev = weight.device
+        e = _Entry()
+        e.weight, e.key, e.src_ptr, e.version = weight, key, weight.data_ptr(), None
+        e.jobs = []
+
+        def job(mode, khs, kws):
+            ntaps = len(khs)
+            rowlen, ncols = (cout, cinp) if mode == 1 else (cinp, cout)
+            kpad = _ceil(max(ntaps * rowlen, 1), 32)
+            ldw = _ceil(ncols, 32)
+            wt = torch.empty((1, kpad, ldw), dtype=torch.float32, device=dev)
+            lo, hi = _pack_taps(khs, kws)
+            e.jobs.append((wt, [cout, cinp, cin, kh, kw, ntaps, kpad, ldw, mode], lo, hi))
+            return wt, ldw
+        e.fwd = job(0, geom.khs, geom.kws)
+        e.dgrad = []
+        for c in geom.dgrad_classes:
+            e.dgrad.append(job(1, c['khs'], c['kws']) if c['khs'] else None)
+        weight._fsv_layout = e
+        self.entries.append(e)
+        self._dirty = True
+        return e
+
+    # ------------------------------------------------------------------------------------------ refresh
+    def _launch(self, tables, nblocks):
+        src, dst, dims, taps, tmap = tables
+        lib.call("fsv_prep_weight_grouped", lib.ptr(src), lib.ptr(dst), lib.ptr(dims), lib.ptr(taps), lib.ptr(tmap),
+                 nblocks, lib.stream_ptr())
+
+    @staticmethod
+    def _build(entries, dev):
+        src, dst, dims, taps, tmap = [], [], [], [], []
+        for e in entries:
+            for (wt, d, lo, hi) in e.jobs:
+                j = len(src)
+                src.append(e.src_ptr)
+                dst.append(wt.data_ptr())
+                dims += d
+                taps += [_i64(lo), _i64(hi)]
+                for ch in range((d[6] * d[7] + 1023) // 1024):
+                    tmap += [j, ch]
+        mk = lambda v, dt: torch.tensor(v, dtype=dt).to(dev)
+        return ((mk(src, torch.int64), mk(dst, torch.int64), mk(dims, torch.int32), mk(taps, torch.int64),
+                 mk(tmap, torch.int32)), len(tmap) // 2)
+
+    def _refresh_entry(self, e):
+        tables, nblocks = self._build([e], e.weight.device)
+        self._launch(tables, nblocks)
+        e.version = e.weight._version
+        if not lib.is_emu():
+            # the tables are temporaries: keep them alive until the launch has consumed them
+            torch.cuda.current_stream().synchronize()
+
+    def refresh(self):
+        """Rewrite every registered layout from the current parameter values (one launch)."""
+        if not self.entries:
+            return
+        if self._dirty:
+            if not lib.is_emu() and torch.cuda.is_current_stream_capturing():
+                raise lib.FsvError("weight-layout cache changed inside a graph capture; run one eager step first")
+            self._tables, self._nblocks = self._build(self.entries, self.entries[0].weight.device)
+            self._dirty = False
+        self._launch(self._tables, self._nblocks)
+        for e in self.entries:
+            e.version = e.weight._version

@@ -27,34 +27,20 @@ LOSS_NAMES_D = ['D_real', 'D_fake', 'Df_real', 'Df_fake', 'DT_real', 'DT_fake']
 
 
 # ------------------------------------------------------------------------------------------------ label helpers
-def _part_index(pose_ch):
-    """DensePose part id stored as (p / 24) * 2 - 1 in label channel 2 (models/input_process.py:71)."""
-    return (pose_ch / 2 + 0.5) * 24
-
-
 def face_mask_of(pose_ch):
     """models/input_process.py:80-94: parts 23 / 24 are the face.  pose_ch: [B, H, W] or [B, T, H, W]."""
     if pose_ch.dim() == 3:
         pose_ch = pose_ch.unsqueeze(1)
-    part = _part_index(pose_ch)
-    m = ((part > 22.9) & (part < 23.1)) | ((part > 23.9) & (part < 24.1))
-    return m.float()
+    return ops.part_masks(pose_ch, 8, 1).squeeze(2)
 
 
 PART_GROUPS = [[0], [1, 2], [3, 4], [5, 6], [7, 9, 8, 10], [11, 13, 12, 14], [15, 17, 16, 18], [19, 21, 20, 22],
-               [23, 24]]
+               [23, 24]]            # the table csrc/losses.hip:fsv_part_masks_kernel carries
 
 
 def part_masks(pose_ch):
     """models/input_process.py:64-78: 9 body-part group masks.  pose_ch [B, T, H, W] -> [B, T, 9, H, W]."""
-    part = _part_index(pose_ch)
-    out = []
-    for grp in PART_GROUPS:
-        m = torch.zeros_like(part, dtype=torch.bool)
-        for j in grp:
-            m |= (part > j - 0.1) & (part < j + 0.1)
-        out.append(m)
-    return torch.stack(out, dim=2).float()
+    return ops.part_masks(pose_ch, 0, 9)
 
 
 def valid_labels(opt, pose):

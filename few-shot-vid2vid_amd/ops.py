@@ -303,17 +303,28 @@ class _ConvFn(torch.autograd.Function):
         cpad = (-cin) % 4 if not per_sample else 0
         if cpad:
             x = to_nhwc(torch.nn.functional.pad(x, (0, 0, 0, 0, 0, cpad)))
-            w4 = torch.nn.functional.pad(w4, (0, 0, 0, 0, 0, cpad))
         ctx.cpad, ctx.cin = cpad, cin
         inv = sig[1:2] if sig is not None else None
-        wt, _, ldw = prep_weight(w4, 0, geom, scale=inv)
+        # parameters owned by a FlatAdam keep persistent K-major layouts (layout_cache.py); 1/sigma then rides in the
+        # GEMM epilogue instead of the re-arrangement
+        cache = getattr(weight, '_fsv_cache', None) if not per_sample else None
+        entry = cache.lookup(weight, tuple(w4.shape), geom, cpad) if cache is not None else None
+        ctx.entry = entry
+        if entry is not None:
+            wt, ldw = entry.fwd
+            wscale = inv
+        else:
+            if cpad:
+                w4 = torch.nn.functional.pad(w4, (0, 0, 0, 0, 0, cpad))
+            wt, _, ldw = prep_weight(w4, 0, geom, scale=inv)
+            wscale = None
         b = bias.detach().contiguous() if bias is not None else None
         if res is not None and act != ACT_NONE:
             raise ValueError("residual add is only fused after a linear epilogue")
         if scale != 1.0 and act != ACT_NONE:
             raise ValueError("output scale is only fused with a linear epilogue")
         y = conv_forward(x, wt, ldw, cout, geom, bias=b, res=res.detach() if res is not None else None, act=act,
-                         scale=scale, per_sample=per_sample)
+                         scale=scale, per_sample=per_sample, wscale=wscale)
         ctx.geom, ctx.act, ctx.scale, ctx.per_sample = geom, act, scale, per_sample
         ctx.has_bias, ctx.has_res, ctx.has_sn = bias is not None, res is not None, sig is not None
         ctx.bias_ref = bias                      # the leaf itself (its .grad slice is the sink target), not saved data
@@ -345,7 +356,9 @@ class _ConvFn(torch.autograd.Function):
         w4 = weight.detach()
         if w4.dim() == 2:
             w4 = w4.view(w4.shape[0], w4.shape[1], 1, 1)
-        if cpad:
+        entry = ctx.entry
+        w_shape = tuple(w4.shape[:-3]) + (w4.shape[-3] + cpad,) + tuple(w4.shape[-2:])
+        if cpad and entry is None:
             w4 = torch.nn.functional.pad(w4, (0, 0, 0, 0, 0, cpad))
         # gradient sink: parameters owned by a FlatAdam expose their slice of the flat gradient buffer as .grad; the
         # last kernel of the weight-gradient chain adds into it directly and autograd gets None (no AccumulateGrad add)
@@ -363,7 +376,7 @@ class _ConvFn(torch.autograd.Function):
         try:
             if want_w:
                 if ctx.has_sn or cpad:
-                    dwsn = conv_wgrad(x, dpre, geom, tuple(w4.shape), per_sample=ctx.per_sample)
+                    dwsn = conv_wgrad(x, dpre, geom, w_shape, per_sample=ctx.per_sample)
                     if cpad:
                         dwsn = dwsn[:, :cin].contiguous()
                     if ctx.has_sn:
@@ -374,7 +387,7 @@ class _ConvFn(torch.autograd.Function):
                         dw = dwsn
                     dw = None if w_sink is not None else dw.view_as(weight)
                 else:
-                    dw = conv_wgrad(x, dpre, geom, tuple(w4.shape), per_sample=ctx.per_sample, out=w_sink)
+                    dw = conv_wgrad(x, dpre, geom, w_shape, per_sample=ctx.per_sample, out=w_sink)
                     dw = None if w_sink is not None else dw.view_as(weight)
             if want_b:
                 cout = dpre.shape[1]
@@ -389,7 +402,8 @@ class _ConvFn(torch.autograd.Function):
             if fork is not None:
                 fork.__exit__(None, None, None)
         if want_x:
-            dx = conv_dgrad(dpre, w4, geom, (h, w), scale=inv, per_sample=ctx.per_sample)
+            dx = conv_dgrad(dpre, w4, geom, (h, w), scale=inv, per_sample=ctx.per_sample,
+                            cached=entry.dgrad if entry is not None else None, cin=w_shape[-3])
             if cpad:
                 dx = dx[:, :cin]
         if fork is not None:
@@ -713,6 +727,7 @@ lib.register_sigs({
     "fsv_pack_d_input": [c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_ll, c_llp, c_llp, c_llp, c_llp, c_p],
     "fsv_unpack_d_grad": [c_p, c_p, c_i, c_i, c_i, c_i, c_ll, c_p],
     "fsv_pool15": [c_p, c_p, c_i, c_i, c_i, c_ll, c_ll, c_ll, c_i, c_f, c_p],
+    "fsv_part_masks": [c_p, c_p, c_ll, c_ll, c_i, c_ll, c_ll, c_i, c_i, c_p],
 })
 
 
@@ -846,6 +861,19 @@ class _PackDFn(torch.autograd.Function):
 
 def pack_d_input(ref, lab, fake, real):
     return _PackDFn.apply(ref, lab, fake, real)
+
+
+def part_masks(pose_ch, g0=0, ngroups=9):
+    """pose_ch [B, T, H, W] (any batch / frame strides, contiguous rows) -> [B, T, ngroups, H, W] float masks of the
+    DensePose part groups g0 .. g0+ngroups-1 (input_process.py:64-94; group 8 = face) in one launch."""
+    b, t, h, w = pose_ch.shape
+    if pose_ch.stride(3) != 1 or pose_ch.stride(2) != w:
+        pose_ch = pose_ch.contiguous()
+    y = torch.empty((b, t, ngroups, h, w), dtype=torch.float32, device=pose_ch.device)
+    lib.check_device(pose_ch)
+    lib.call("fsv_part_masks", lib.ptr(pose_ch), lib.ptr(y), b * t, h * w, t, pose_ch.stride(0), pose_ch.stride(1), g0, ngroups,
+             lib.stream_ptr())
+    return y
 
 
 def pool15(x, mode, thresh=0.0):

@@ -12,15 +12,16 @@ import torch
 from . import lib
 
 _enabled = False
+_detail = False       # tools/shape_profile.py: append the GEMM shape to every label
 _records = []          # (label, flops, ev0, ev1)
 FP32_MFMA_PEAK = 157.3e12
 
 TILE_NAMES = {0: '128x128', 1: '128x64', 2: '128x32', 3: '256x32', 4: '64x64'}
 
 
-def enable():
-    global _enabled, _records
-    _enabled, _records = True, []
+def enable(detail=False):
+    global _enabled, _records, _detail
+    _enabled, _records, _detail = True, [], detail
 
 
 def disable():
@@ -30,6 +31,10 @@ def disable():
 
 def enabled():
     return _enabled
+
+
+def detail():
+    return _detail
 
 
 class scope:
@@ -54,7 +59,10 @@ def conv_label(mz, cout, nchunks, nsamp, vec4, force_tile=-1, force_split=0):
     lib.register_sigs({"fsv_conv_plan": [ctypes.c_int] * 6 + [ctypes.POINTER(ctypes.c_int)] * 2})
     tile, nsplit = ctypes.c_int(0), ctypes.c_int(1)
     lib.call("fsv_conv_plan", mz, cout, nchunks, nsamp, force_tile, force_split, ctypes.byref(tile), ctypes.byref(nsplit))
-    return 'fsv_conv_igemm_kernel<%s,V%d>' % (TILE_NAMES[tile.value], 4 if vec4 else 1)
+    base = 'fsv_conv_igemm_kernel<%s,V%d>' % (TILE_NAMES[tile.value], 4 if vec4 else 1)
+    if _detail:
+        base += ' M%d N%d K%d z%d split%d' % (mz, cout, nchunks * 32, nsamp, nsplit.value)
+    return base
 
 
 def summary():

@@ -40,13 +40,15 @@ enum fsv_act { FSV_ACT_NONE = 0, FSV_ACT_LRELU = 1 /* leaky_relu(0.2), architect
  * taps outside the input read as zero.  wt: K-major [Kpad][ldw] from fsv_prep_weight; per_sample != 0 selects one
  * weight matrix (stride w_bstride) and bias (stride b_bstride) per sample n.  accumulate != 0: `out` was zeroed by
  * the caller, results are added (used for the four parity classes of a stride-2 data gradient).
- * force_tile / force_split: -1 / 0 = automatic. */
+ * force_tile / force_split: -1 / 0 = automatic.  wscale: optional device scalar multiplying the accumulator before
+ * the bias (the spectral-norm 1/sigma when wt holds un-normalised weights). */
 int fsv_conv_gather_fwd(const float* in, const float* wt, const float* bias, const float* res, float* out,
                         int N, int H, int W, int Cin, int OH, int OW, int Cout,
                         int ntaps, const int* ty, const int* tx, int sy, int sx,
                         int outH, int outW, int osy, int osx, int ooy, int oox,
                         int ldw, long long w_bstride, long long b_bstride, int per_sample,
-                        int act, float scale, int force_tile, int force_split, int accumulate, fsv_stream_t stream);
+                        int act, float scale, int force_tile, int force_split, int accumulate, const float* wscale,
+                        fsv_stream_t stream);
 
 /* dwt[t*Cin+ci][co] = sum_{n,oy,ox} in[n, oy*sy+ty[t], ox*sx+tx[t], ci] * dout[n, oy, ox, co]  (weight gradient) */
 int fsv_conv_wgrad(const float* in, const float* dout, float* dwt,
@@ -61,6 +63,9 @@ int fsv_prep_weight(const float* w, float* wt, const float* scale_ptr, int mode,
                     int Cout, int Cin, int KH, int KW, int ntaps, const int* kh, const int* kw,
                     int Kpad, int ldw, long long w_bstride, long long wt_bstride, fsv_stream_t stream);
 
+/* every parameter weight of an optimiser re-arranged in one launch (un-scaled; used once per optimiser step) */
+int fsv_prep_weight_grouped(const long long* src, const long long* dst, const int* dims, const unsigned long long* taps,
+                            const int* tmap, int nblocks, fsv_stream_t stream);
 /* tile / split-K plan the launcher will use (exported so host-side profilers label launches consistently) */
 int fsv_conv_plan(int Mz, int Cout, int nchunks, int nsamp, int force_tile, int force_split, int* tile_out,
                   int* nsplit_out);
@@ -152,6 +157,10 @@ int fsv_pack_d_input(const float* ref, const float* lab, const float* fake, cons
                      int B, int Cr, int Cl, int Ci, long long P, const long long* ref_strides, const long long* lab_strides,
                      const long long* fake_strides, const long long* real_strides, fsv_stream_t stream);
 int fsv_unpack_d_grad(const float* dout, float* dfake, int B, int Ci, int Coff, int Ct, long long P, fsv_stream_t stream);
+/* DensePose part-group masks (models/input_process.py:64-94): x = pose channel [B, T, P] (strides sb, st, 1), N = B*T;
+ * y[N][ngroups][P] = 1 where (x/2+0.5)*24 is within 0.1 of a member of group g0+g (9 groups; group 8 = face parts 23/24) */
+int fsv_part_masks(const float* x, float* y, long long N, long long P, int T, long long sb, long long st, int g0, int ngroups,
+                   fsv_stream_t stream);
 int fsv_pool15(const float* x, float* y, int N, int H, int W, long long sn, long long sy, long long sx, int mode, float thresh,
                fsv_stream_t stream);
 

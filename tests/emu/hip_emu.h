@@ -26,6 +26,7 @@ static inline hipError_t hipMemsetAsync(void* p, int v, size_t n, hipStream_t) {
 
 #define __global__
 #define __device__
+#define __constant__ static const
 #define __host__
 #define __forceinline__ inline __attribute__((always_inline))
 #define __launch_bounds__(...)

@@ -419,3 +419,88 @@ def check_temporal_step(device, opt, b=1, tol=1e-3, seed=31, grad_tol=2e-2):
     for name, _ in model.netG.named_parameters():
         sd32.setdefault(name, _G(None)); sd64.setdefault(name, _G(None))
     return compare_grads_l2(model.netG, sd32, sd64, grad_tol)
+
+
+def _verify_layouts(optimizer):
+    """every cached layout == a fresh per-call re-arrangement of the parameter's current values (bit-exact)"""
+    from fsv2v_amd import conv as C
+    n = 0
+    for e in optimizer.layouts.entries:
+        w = e.weight.detach()
+        if w.dim() == 2:
+            w = w.view(w.shape[0], w.shape[1], 1, 1)
+        for (wt, d, lo, hi) in e.jobs:
+            cout, cinp, cin, kh, kw, nt, kpad, ldw, mode = d
+            wp = torch.nn.functional.pad(w, (0, 0, 0, 0, 0, cinp - cin))
+            khs = [((lo if j < 8 else hi) >> ((j & 7) * 8)) & 15 for j in range(nt)]
+            kws = [((lo if j < 8 else hi) >> ((j & 7) * 8 + 4)) & 15 for j in range(nt)]
+            ref, _, _ = C.prep_weight(wp, mode, None, khs, kws)
+            assert torch.equal(ref, wt), (d, float((ref - wt).abs().max()))
+            n += 1
+    return n
+
+
+def check_layout_cache(device, opt, b=1, seed=41, tol=1e-5):
+    """The persistent weight-layout cache (layout_cache.py: one grouped re-arrangement per optimiser step, 1/sigma in
+    the GEMM epilogue) against the per-call re-arrangement:
+      * one D + G iteration from identical weights gives the same losses (only rounding differs: (sum w x) / sigma
+        instead of sum (w / sigma) x) and the same gradients within the band the tiny networks amplify rounding to
+        (BatchNorm over a handful of values; the operator-level check in op_checks.check_layout_cache is the tight one);
+      * after every optimiser step, and after an out-of-band parameter modification followed by a forward pass, every
+        cached layout is bit-identical to a fresh re-arrangement of the current parameter values.
+    (Comparing whole multi-step trajectories is not meaningful at this width: Adam turns rounding-level gradients of
+    dead parameters into +-lr steps.)"""
+    import os
+    M = _model()
+    h, w = int(opt.fineSize / opt.aspect_ratio), opt.fineSize
+    nl = opt.label_nc if opt.label_nc != 0 else opt.input_nc
+    tl, ti, rl, ri = [t.to(device) for t in synth_pose_inputs(b, h, w, seed, nl)]
+    data_list = [tl, ti, [None, None], [None, None], rl, ri, None, None, None]
+
+    def build(cache, lr0):
+        os.environ['FSV_LAYOUT_CACHE'] = '1' if cache else '0'
+        try:
+            model = M.create_model(opt)
+            fill_state(model.netG); fill_state(model.netD)
+            model = model.to(device).train()
+            opt_G, opt_D = model.build_optimizers()
+        finally:
+            os.environ.pop('FSV_LAYOUT_CACHE', None)
+        assert (opt_G.layouts is not None) == cache
+        if lr0:
+            opt_G.set_lr(0.0); opt_D.set_lr(0.0)
+        return model, opt_G, opt_D
+
+    def iteration(model, opt_G, opt_D, check=False):
+        d_losses = M.loss_backward(opt, model(data_list, mode='discriminator'), opt_D, 1)
+        if check:
+            _verify_layouts(opt_D)
+        g_losses, _, _ = model(data_list, save_images=False, mode='generator')
+        g_losses = M.loss_backward(opt, g_losses, opt_G, 0)
+        if check:
+            assert _verify_layouts(opt_G) > 20 and _verify_layouts(opt_D) > 3
+        losses = torch.stack([x.detach().reshape(()) for x in list(d_losses) + list(g_losses) if torch.is_tensor(x)])
+        grads = torch.cat([p.grad.reshape(-1) for p in model.parameters() if p.grad is not None])
+        return losses.cpu(), grads.cpu().clone()
+    l1, g1 = iteration(*build(True, True))
+    l0, g0 = iteration(*build(False, True))
+    assert torch.allclose(l1, l0, rtol=tol, atol=tol), (l1, l0)
+    rel = float((g1 - g0).double().norm() / g0.double().norm())
+    assert rel < 1e-2, rel
+    model, opt_G, opt_D = build(True, False)
+    for it in range(2):
+        iteration(model, opt_G, opt_D, check=True)
+    with torch.no_grad():                     # out-of-band modification: the eager path has to notice (Tensor._version)
+        for p in model.netG.parameters():
+            if p.dim() == 4:
+                p.mul_(0.5)
+    with torch.no_grad():
+        model(data_list, mode='discriminator')          # runs the generator forward
+    seen = 0
+    for e in opt_G.layouts.entries:
+        if e.version == e.weight._version:
+            seen += 1
+    assert seen > 20
+    # entries the forward pass touched are fresh; after an explicit refresh all of them are
+    opt_G.refresh_layouts()
+    _verify_layouts(opt_G)

@@ -39,7 +39,7 @@ def _dev(t, device):
     return t.to(device) if t is not None else None
 
 
-def check_conv(device, n, cin, h, w, cout, k, s, p, act='lrelu', bias=True, seed=0, tol=REL_TOL):
+def check_conv(device, n, cin, h, w, cout, k, s, p, act='lrelu', bias=True, seed=0, tol=REL_TOL, cache=None):
     ops, conv = pkg()
     g = torch.Generator().manual_seed(seed)
     x = torch.randn(n, cin, h, w, generator=g)
@@ -54,6 +54,8 @@ def check_conv(device, n, cin, h, w, cout, k, s, p, act='lrelu', bias=True, seed
     ref.backward(dy)
     xd, wd = _dev(x, device).requires_grad_(True), _dev(wt, device).requires_grad_(True)
     bd = _dev(b, device).requires_grad_(True) if bias else None
+    if cache is not None:
+        wd._fsv_cache = cache
     y = ops.conv2d(xd, wd, bd, stride=s, padding=p, act=actc)
     y.backward(_dev(dy, device))
     assert_close('conv y', y, ref, tol)
@@ -63,7 +65,7 @@ def check_conv(device, n, cin, h, w, cout, k, s, p, act='lrelu', bias=True, seed
         assert_close('conv db', bd.grad, br.grad, tol)
 
 
-def check_conv_sn_res(device, seed=1):
+def check_conv_sn_res(device, seed=1, cache=None):
     """spectral-norm conv with fused residual add (SPADEResnetBlock conv_1 + shortcut)."""
     ops, conv = pkg()
     g = torch.Generator().manual_seed(seed)
@@ -83,6 +85,8 @@ def check_conv_sn_res(device, seed=1):
     ud, vd = _dev(u.clone(), device), _dev(v.clone(), device)
     wd = _dev(wt, device).requires_grad_(True)
     xd, bd, rd = (_dev(t, device).requires_grad_(True) for t in (x, b, res))
+    if cache is not None:
+        wd._fsv_cache = cache
     sig = ops.SpectralState.update(wd, ud, vd, training=True)
     y = ops.conv2d(xd, wd, bd, stride=1, padding=1, res=rd, sn=(sig, ud, vd))
     y.backward(_dev(dy, device))
@@ -93,6 +97,38 @@ def check_conv_sn_res(device, seed=1):
     assert_close('sn conv dw', wd.grad, sd['weight_orig'].grad)
     assert_close('sn conv db', bd.grad, br.grad)
     assert_close('sn conv dres', rd.grad, rr.grad)
+
+
+def check_layout_cache(device, seed=14):
+    """Persistent K-major layouts (layout_cache.py): cached forward / data-gradient operands (stride 1 and 2, padded
+    input channels, spectral norm through the epilogue scale) give the reference results, and the single grouped launch
+    re-derives every layout after the parameters changed behind autograd's back (what the fused Adam kernel does)."""
+    ops, conv = pkg()
+    from fsv2v_amd.layout_cache import LayoutCache
+    cache = LayoutCache()
+    check_conv(device, 2, 6, 9, 7, 5, 3, 2, 1, act='none', cache=cache)        # cpad 2, stride-2 parity classes
+    check_conv(device, 1, 20, 9, 9, 32, 4, 2, 2, cache=cache)
+    check_conv(device, 1, 8, 7, 7, 16, 4, 1, 2, act='sigmoid', bias=False, cache=cache)
+    check_conv(device, 1, 3, 8, 8, 8, 3, 1, 1, act='tanh', cache=cache)          # RGB input: cpad 1
+    check_conv_sn_res(device, cache=cache)
+    assert len(cache.entries) == 5
+    # raw parameter update (no version bump), then ONE grouped refresh
+    g = torch.Generator().manual_seed(seed)
+    olds = [torch.randn(e.weight.shape, generator=g) * 0.1 for e in cache.entries]
+    for e, new in zip(cache.entries, olds):
+        e.weight.data.copy_(_dev(new, device))
+    for e in cache.entries:               # .data writes do not bump _version: only refresh() can repair the layouts
+        assert e.version == e.weight._version
+    cache.refresh()
+    for e in cache.entries:
+        w4 = e.weight.detach()
+        for (wt, d, lo, hi) in e.jobs:
+            cout, cinp, cin, kh, kw, nt, kpad, ldw, mode = d
+            wp = F.pad(w4, (0, 0, 0, 0, 0, cinp - cin))
+            khs = [((lo if j < 8 else hi) >> ((j & 7) * 8)) & 15 for j in range(nt)]
+            kws = [((lo if j < 8 else hi) >> ((j & 7) * 8 + 4)) & 15 for j in range(nt)]
+            ref, _, _ = conv.prep_weight(wp, mode, None, khs, kws)
+            assert torch.equal(ref, wt), d
 
 
 def check_linear(device, r=40, cin=16, cout=50, seed=2):
@@ -350,6 +386,34 @@ def check_losses(device, seed=13):
     assert_close('pool avg', ops.pool15(_dev(lab1, device), 'avg'), F.avg_pool2d(lab1, 15, 1, 7), 1e-5)
 
 
+def check_part_masks(device, seed=15):
+    """DensePose part-group masks in one launch == the reference's 25 x (gt, lt, and, or) chain, bit for bit
+    (models/input_process.py:64-94), on part ids stored as (p / 24) * 2 - 1 plus off-grid values."""
+    ops, conv = pkg()
+    g = torch.Generator().manual_seed(seed)
+    b, t, c, h, w = 2, 2, 6, 9, 13
+    ids = torch.randint(0, 25, (b, t, h, w), generator=g).float()
+    pose = ids / 24 * 2 - 1
+    noise = (torch.rand((b, t, h, w), generator=g) < 0.2).float() * (torch.rand((b, t, h, w), generator=g) - 0.5) * 0.02
+    label = torch.randn(b, t, c, h, w, generator=g)
+    label[:, :, 2] = pose + noise
+    ch = label[:, :, 2]
+    part = (ch / 2 + 0.5) * 24
+    groups = [[0], [1, 2], [3, 4], [5, 6], [7, 9, 8, 10], [11, 13, 12, 14], [15, 17, 16, 18], [19, 21, 20, 22], [23, 24]]
+    ref = []
+    for grp in groups:
+        m = torch.zeros_like(part, dtype=torch.bool)
+        for j in grp:
+            m |= (part > j - 0.1) & (part < j + 0.1)
+        ref.append(m)
+    ref = torch.stack(ref, dim=2).float()
+    got = ops.part_masks(_dev(label, device)[:, :, 2], 0, 9).cpu()
+    assert torch.equal(got, ref)
+    face = ops.part_masks(_dev(label, device)[:, 0:1, 2], 8, 1).cpu()
+    assert torch.equal(face[:, :, 0], ref[:, 0:1, 8])
+    assert 0 < float(ref.mean()) < 1
+
+
 def check_adam(device, n=1000, seed=9):
     ops, conv = pkg()
     g = torch.Generator().manual_seed(seed)
@@ -375,6 +439,7 @@ def run_all(device, big=False):
     check_conv(device, 1, 8, 7, 7, 16, 4, 1, 2, act='sigmoid', bias=False)
     check_conv(device, 1, 64, 6, 6, 130, 1, 1, 0)
     check_conv_sn_res(device)
+    check_layout_cache(device)
     check_linear(device)
     check_batch_conv(device)
     check_norm(device, instance=False)
@@ -388,3 +453,4 @@ def run_all(device, big=False):
     check_warp(device, zero_flow=True)
     check_warp_index_image(device)
     check_adam(device)
+    check_part_masks(device)

@@ -38,3 +38,8 @@ def test_train_step_with_vgg_loss_tiny(emu_lib):
     """G step including the VGG19 perceptual loss (13 conv+ReLU, 4 max-pools, frozen weights) at 32x32"""
     mc.check_train_step(DEV, mc.tiny_opt(dataset_mode='fewshot_face', input_nc=1, no_vgg_loss=False, fineSize=32,
                                          loadSize=32, n_downsample_G=3, n_adaptive_layers=2), b=1)
+
+
+def test_layout_cache_matches_per_call_prep_tiny(emu_lib):
+    """persistent K-major weight layouts + grouped refresh after Adam == per-call re-arrangement"""
+    mc.check_layout_cache(DEV, mc.tiny_opt(warp_ref=True, spade_combine=True, remove_face_labels=True), b=1)

@@ -31,6 +31,10 @@ def test_conv_spectral_residual(emu_lib):
     oc.check_conv_sn_res(DEV)
 
 
+def test_layout_cache(emu_lib):
+    oc.check_layout_cache(DEV)
+
+
 def test_linear(emu_lib):
     oc.check_linear(DEV)
 
@@ -68,6 +72,10 @@ def test_warp_values_grads_and_taps(emu_lib):
 
 def test_warp_tap_indices_bit_exact(emu_lib):
     oc.check_warp_index_image(DEV)
+
+
+def test_part_masks(emu_lib):
+    oc.check_part_masks(DEV)
 
 
 def test_adam(emu_lib):

@@ -36,6 +36,10 @@ def test_conv_spectral_residual(hip_lib):
     oc.check_conv_sn_res(dev())
 
 
+def test_layout_cache(hip_lib):
+    oc.check_layout_cache(dev())
+
+
 def test_linear(hip_lib):
     oc.check_linear(dev())
     oc.check_linear(dev(), r=2048, cin=256, cout=514)
@@ -89,6 +93,10 @@ def test_warp_full_size_zero_flow_round_trip(hip_lib):
     # 76 of 512 columns land on x-1 at zero flow
     xs = torch.arange(w, dtype=torch.int32)
     assert int((ref[0, 0, :, 0] != xs).sum()) > 0
+
+
+def test_part_masks(hip_lib):
+    oc.check_part_masks(dev())
 
 
 def test_adam(hip_lib):

@@ -1,4 +1,8 @@
-"""A/B of conv tile / split-K configurations on C3 layer shapes at B=2 (interleaved rounds in one process)."""
+"""A/B of conv tile / split-K configurations on layer shapes of the bench step at B=2.
+
+Every configuration is captured as a hipGraph of 20 back-to-back launches (memset + GEMM + bias/activation pass when
+split-K is on, exactly what the product path issues) and the configurations are replayed interleaved, median of 5.
+Output: algorithmic TFLOP/s per configuration; 'auto' is what fsv_conv_plan picks today."""
 import json, os, sys, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -6,24 +10,43 @@ import fsv2v_amd  # noqa
 from importlib import import_module
 conv = import_module('few-shot-vid2vid_amd.conv')
 dev = torch.device('cuda:0')
-cfgs = [(0, 0), (0, 1), (0, 2), (1, 0), (1, 1), (1, 2), (4, 0), (4, 1)]
-shapes = [('up2 256->128@128', 2, 256, 128, 128, 128, 3), ('up3 512->256@64', 2, 512, 64, 64, 256, 3),
-          ('up4 1024->512@32', 2, 1024, 32, 32, 512, 3), ('up5 1024->1024@16', 2, 1024, 16, 16, 1024, 3),
-          ('flow 256->256@64', 2, 256, 64, 64, 256, 3), ('fc 1024->1024 r2048', 1, 1024, 1, 2048, 1024, 1),
-          ('emb 512->256@64 (cat)', 2, 512, 64, 64, 128, 3)]
+cfgs = [(-1, 0), (0, 1), (0, 2), (0, 4), (0, 8), (1, 1), (1, 2), (1, 4), (1, 8), (4, 1), (4, 2), (4, 4)]
+shapes = [('M8192 N256 K2304', 2, 256, 64, 64, 256, 3), ('M32768 N128 K576', 2, 64, 128, 128, 128, 3),
+          ('M32768 N128 K1152', 2, 128, 128, 128, 128, 3), ('M32768 N128 K2304', 2, 256, 128, 128, 128, 3),
+          ('M2048 N512 K9216', 2, 1024, 32, 32, 512, 3), ('M2048 N512 K2304', 2, 256, 32, 32, 512, 3),
+          ('M8192 N256 K1152', 2, 128, 64, 64, 256, 3), ('M131072 N64 K288', 2, 32, 256, 256, 64, 3),
+          ('M1024 N512 K512', 1, 512, 1, 1024, 512, 1), ('M512 N1024 K4608', 2, 512, 16, 16, 1024, 3),
+          ('M8192 N128 K512', 2, 512, 64, 64, 128, 1), ('M32768 N64 K256', 2, 256, 128, 128, 64, 1),
+          ('M32768 N256 K1152', 2, 128, 128, 128, 256, 3), ('M131072 N128 K576', 2, 64, 256, 256, 128, 3)]
+if len(sys.argv) > 1:
+    shapes = [s for s in shapes if any(a in s[0] for a in sys.argv[1:])]
+NREP = 20
 for name, n, cin, h, w, cout, k in shapes:
     x = conv.to_nhwc(torch.randn(n, cin, h, w, device=dev)); wt = torch.randn(cout, cin, k, k, device=dev) * 0.05
+    b = torch.randn(cout, device=dev)
     g = conv.Geom(k, k, 1, k // 2)
     wf, kpad, ldw = conv.prep_weight(wt, 0, g)
     flops = 2.0 * n * h * w * cout * cin * k * k
-    res = {c: [] for c in cfgs}
-    for rnd in range(3):
-        for c in cfgs:
-            f = lambda: conv.conv_forward(x, wf, ldw, cout, g, force_tile=c[0], force_split=c[1])
-            f(); f(); torch.cuda.synchronize()
+    graphs = {}
+    for c in cfgs:
+        if c[0] == 0 and cout < 128 or c[0] == 1 and cout < 64:
+            continue
+        f = lambda: conv.conv_forward(x, wf, ldw, cout, g, bias=b, act=conv.ACT_LRELU, force_tile=c[0], force_split=c[1])
+        s = torch.cuda.Stream(); s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            f(); f()
+        torch.cuda.current_stream().wait_stream(s); torch.cuda.synchronize()
+        gr = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(gr):
+            for _ in range(NREP):
+                f()
+        graphs[c] = gr
+    res = {c: [] for c in graphs}
+    for rnd in range(5):
+        for c, gr in graphs.items():
+            gr.replay(); torch.cuda.synchronize()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            for _ in range(5): f()
-            e1.record(); torch.cuda.synchronize()
-            res[c].append(flops / (e0.elapsed_time(e1) / 5 * 1e-3) / 1e12)
-    print(json.dumps({'case': name, **{'t%d/s%d' % c: round(sorted(v)[len(v) // 2], 1) for c, v in res.items()}}), flush=True)
+            e0.record(); gr.replay(); e1.record(); torch.cuda.synchronize()
+            res[c].append(flops / (e0.elapsed_time(e1) / NREP * 1e-3) / 1e12)
+    print(json.dumps({'case': name, **{('auto' if c[0] < 0 else 't%d/s%d' % c): round(sorted(v)[len(v) // 2], 1)
+                                       for c, v in res.items()}}), flush=True)
