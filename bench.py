@@ -134,6 +134,7 @@ def main():
         loss = sum(torch.mean(x) for x in losses)
         optimizer.zero_grad()
         loss.backward()
+        optimizer.finalize_grads()        # deferred weight-gradient jobs belong to the segment that queued them
 
     def seg_d():                       # D forward (incl. the no-grad G forward) + D backward
         backward_of(model(data, mode='discriminator'), opt_D)

@@ -188,8 +188,9 @@ def conv_dgrad(dout, w, geom, in_hw, scale=None, per_sample=False, cached=None, 
     return dx
 
 
-def conv_wgrad(x, dout, geom, w_shape, per_sample=False, scale=None, force_split=0, out=None):
-    """Weight gradient in OIHW layout (batched when per_sample)."""
+def conv_wgrad(x, dout, geom, w_shape, per_sample=False, scale=None, force_split=0, out=None, raw=False):
+    """Weight gradient in OIHW layout (batched when per_sample); raw=True returns the GEMM's K-major result
+    dwt[(tap, ci)][co] instead (consumed by grad_finalize.GradFinalizer)."""
     x = to_nhwc(x)
     dout = to_nhwc(dout)
     n, cin, h, w = x.shape
@@ -206,4 +207,6 @@ def conv_wgrad(x, dout, geom, w_shape, per_sample=False, scale=None, force_split
         lib.call("fsv_conv_wgrad", lib.ptr(x), lib.ptr(dout), lib.ptr(dwt), n, h, w, cin, oh, ow, cout,
                  geom.ntaps, lib.int_array(geom.ty), lib.int_array(geom.tx), geom.stride, geom.stride,
                  ldw, kpad, kpad * ldw, 1 if per_sample else 0, force_split, lib.stream_ptr())
+    if raw:
+        return dwt
     return unprep_weight_grad(dwt, tuple(w_shape), geom, scale, out)

@@ -8,8 +8,16 @@
 #include "hip_emu.h"
 #else
 #include <hip/hip_runtime.h>
-#define FSV_LAUNCH(kernel, grid, block, stream, ...) \
-  hipLaunchKernelGGL(kernel, (grid), (block), 0, (stream), __VA_ARGS__)
+// hipGetLastError() is per-thread state shared with everything else in the process (PyTorch's pinned-memory allocator
+// leaves hipErrorNotReady there after polling an event): clear it before a launch and record only what the launch
+// itself reports, so that fsv_check_launch() speaks for this library's launches alone.
+static thread_local int fsv_launch_status = 0;
+#define FSV_LAUNCH(kernel, grid, block, stream, ...)                                  \
+  do {                                                                                \
+    (void)hipGetLastError();                                                          \
+    hipLaunchKernelGGL(kernel, (grid), (block), 0, (stream), __VA_ARGS__);            \
+    if (hipGetLastError() != hipSuccess) fsv_launch_status = -3;                      \
+  } while (0)
 #endif
 #include <stdint.h>
 
@@ -29,10 +37,18 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define FSV_ACT_SIGMOID 3
 #define FSV_ACT_RELU 4      // VGG19 feature stack (models/networks/vgg.py)
 
+#ifdef FSV_EMU
 static inline int fsv_check_launch() {
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? FSV_OK : FSV_ERR_LAUNCH;
 }
+#else
+static inline int fsv_check_launch() {        // status of the launches since the previous check (this thread, this file)
+  const int s = fsv_launch_status;
+  fsv_launch_status = FSV_OK;
+  return s;
+}
+#endif
 
 __device__ __forceinline__ float fsv_act(float v, int act) {
   if (act == FSV_ACT_LRELU) return v > 0.f ? v : 0.2f * v;

@@ -1,0 +1,149 @@
+// Deferred weight-gradient finalisation: every convolution / linear weight gradient of one backward pass in two launches.
+//
+// The weight-gradient GEMM (conv_igemm.hip: fsv_conv_wgrad) leaves dW in the K-major operand layout
+// dwt[(tap, ci)][co].  Turning that into the parameter's OIHW gradient - plus, for spectral-normalised layers, the
+// correction of torch.nn.utils.spectral_norm's backward,
+//     dW = (dW_sn - <dW_sn, W> / sigma * u v^T) / sigma                       (models/networks/base_network.py:73-76
+//                                                                              wraps every conv in spectral_norm)
+// - used to cost three or four small launches per layer (~440 per training step).  The autograd functions now only
+// queue a job (pointers + geometry); before the gradient exchange / Adam step the optimiser hands the whole queue to
+// fsv_wgrad_finalize, which runs
+//   1. fsv_wfin_dot_kernel    <dW_sn, W> of every spectral-normalised job (fp64 block sums, one fp64 atomic per block;
+//                             W is read in the same K-major layout from the optimiser's layout cache: coalesced),
+//   2. fsv_wfin_apply_kernel  an LDS-tiled transpose [(tap, ci)][co] -> [co][ci][kh][kw] that adds the finished gradient
+//                             into the flat gradient buffer (both sides coalesced).
+// HBM-bound: reads 4 B (+4 B of W for the dot) and read-modify-writes 8 B per weight element.
+#include "fsv_common.h"
+
+// job descriptors (device arrays, built by the host once per backward pass):
+//   ptrs[job][6] = { dwt, wlay (K-major W, spectral jobs only), sink (OIHW gradient), u, v, sig } as 64-bit integers
+//   dims[job][8] = { Cout, CinP (channels in dwt), CinR (channels of the parameter), KH, KW, ntaps, ldw, flags }
+//                  flags bit 0: another job of this launch adds into the same sink -> atomic adds
+//   taps[job][2] = packed (kh | kw << 4) codes of dwt's tap order
+struct FinP {
+  const long long* ptrs;
+  const int* dims;
+  const unsigned long long* taps;
+  double* dots;
+};
+
+#define FSV_FIN_DOT_CHUNK 4096
+
+__global__ __launch_bounds__(256) void fsv_wfin_dot_kernel(FinP f, const int* tmap) {
+  __shared__ double red[256];
+  const int job = tmap[blockIdx.x * 2], chunk = tmap[blockIdx.x * 2 + 1];
+  const int* d = f.dims + job * 8;
+  const int Cout = d[0], CinP = d[1], ntaps = d[5], ldw = d[6];
+  const float* dwt = reinterpret_cast<const float*>(f.ptrs[job * 6]);
+  const float* wl = reinterpret_cast<const float*>(f.ptrs[job * 6 + 1]);
+  const long long total = (long long)ntaps * CinP * ldw;
+  float acc = 0.f;
+#pragma unroll 4
+  for (int s = 0; s < FSV_FIN_DOT_CHUNK / 256; ++s) {
+    const long long i = (long long)chunk * FSV_FIN_DOT_CHUNK + s * 256 + threadIdx.x;
+    if (i < total) {
+      const int c = (int)(i % ldw);
+      if (c < Cout) acc += dwt[i] * wl[i];         // padding columns of dwt are never written: skip, do not multiply
+    }
+  }
+  red[threadIdx.x] = (double)acc;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) atomicAdd(&f.dots[job], red[0]);
+}
+
+// tile: 32 output channels x CI_T input channels x all taps; CI_T = 32 for <= 8 taps, 16 otherwise (LDS <= 33.8 KB)
+__global__ __launch_bounds__(256) void fsv_wfin_apply_kernel(FinP f, const int* tmap) {
+  __shared__ float t[8 * 32 * 33];
+  __shared__ int inv_tap[16];
+  const int job = tmap[blockIdx.x * 3], cot = tmap[blockIdx.x * 3 + 1], cit = tmap[blockIdx.x * 3 + 2];
+  const int* d = f.dims + job * 8;
+  const int Cout = d[0], CinP = d[1], CinR = d[2], KW = d[4], ntaps = d[5], ldw = d[6], flags = d[7];
+  const int KK = d[3] * KW;
+  const int CI_T = ntaps <= 8 ? 32 : 16;
+  const float* dwt = reinterpret_cast<const float*>(f.ptrs[job * 6]);
+  float* sink = reinterpret_cast<float*>(f.ptrs[job * 6 + 2]);
+  const float* u = reinterpret_cast<const float*>(f.ptrs[job * 6 + 3]);
+  const float* v = reinterpret_cast<const float*>(f.ptrs[job * 6 + 4]);
+  const float* sig = reinterpret_cast<const float*>(f.ptrs[job * 6 + 5]);
+  const unsigned long long lo = f.taps[job * 2], hi = f.taps[job * 2 + 1];
+  if (threadIdx.x < 16) inv_tap[threadIdx.x] = -1;
+  __syncthreads();
+  if ((int)threadIdx.x < ntaps) {
+    const int j = threadIdx.x;
+    const unsigned long long code = (j < 8) ? lo : hi;
+    const int sh = (j & 7) * 8;
+    const int kh = (int)((code >> sh) & 15ull), kw = (int)((code >> (sh + 4)) & 15ull);
+    inv_tap[kh * KW + kw] = j;
+  }
+  const int co0 = cot * 32, ci0 = cit * CI_T;
+  // ---- read: rows (tap, ci) of dwt, 32 consecutive output channels each
+  const int lane_c = threadIdx.x & 31, row_l = threadIdx.x >> 5;       // 8 rows in flight
+  const int nrows = ntaps * CI_T;
+  for (int r = row_l; r < nrows; r += 8) {
+    const int j = r / CI_T, cil = r - j * CI_T;
+    const int ci = ci0 + cil, co = co0 + lane_c;
+    float val = 0.f;
+    if (ci < CinP && co < Cout) val = dwt[((long long)j * CinP + ci) * ldw + co];
+    t[r * 33 + lane_c] = val;
+  }
+  __syncthreads();
+  // ---- write: per output channel a contiguous run of CI_T * KK gradient elements
+  float inv = 1.f, coef = 0.f;
+  if (sig) { inv = sig[1]; coef = inv * (float)f.dots[job]; }
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int run = CI_T * KK;
+  for (int col = wave; col < 32; col += 4) {
+    const int co = co0 + col;
+    if (co >= Cout) continue;
+    const float uc = sig ? u[co] : 0.f;
+    for (int idx = lane; idx < run; idx += 64) {
+      const int cil = idx / KK, tk = idx - cil * KK;
+      const int ci = ci0 + cil;
+      if (ci >= CinR) continue;
+      const int j = inv_tap[tk];
+      if (j < 0) continue;
+      float g = t[(j * CI_T + cil) * 33 + col];
+      if (sig) g = inv * (g - coef * uc * v[ci * KK + tk]);
+      float* dst = sink + ((long long)co * CinR + ci) * KK + tk;
+      if (flags & 1) atomicAdd(dst, g); else *dst += g;
+    }
+  }
+}
+
+// ---- pointer-table upload through kernel arguments ----------------------------------------------------------------------
+// The job table holds addresses of this pass's temporaries, so it changes every eager step.  A host-to-device copy would
+// need pinned staging memory (whose allocation is illegal inside a hipGraph capture) and would make a captured graph depend
+// on a host buffer; kernel arguments are copied at launch / baked into the graph node, so the words travel in them.
+#define FSV_UPLOAD_WORDS 448
+struct UploadWords { long long w[FSV_UPLOAD_WORDS]; };
+__global__ __launch_bounds__(256) void fsv_upload_kernel(long long* dst, int n, UploadWords s) {
+  for (int i = threadIdx.x; i < n; i += 256) dst[i] = s.w[i];
+}
+
+extern "C" int fsv_upload_i64(long long* dst, const long long* host_src, int n, hipStream_t stream) {
+  if (!dst || !host_src || n < 1) return FSV_ERR_BAD_ARG;
+  for (int off = 0; off < n; off += FSV_UPLOAD_WORDS) {
+    UploadWords s;
+    const int m = (n - off < FSV_UPLOAD_WORDS) ? n - off : FSV_UPLOAD_WORDS;
+    for (int i = 0; i < m; ++i) s.w[i] = host_src[off + i];
+    for (int i = m; i < FSV_UPLOAD_WORDS; ++i) s.w[i] = 0;
+    FSV_LAUNCH(fsv_upload_kernel, dim3(1), dim3(256), stream, dst + off, m, s);
+  }
+  return fsv_check_launch();
+}
+
+extern "C" int fsv_wgrad_finalize(const long long* ptrs, const int* dims, const unsigned long long* taps, double* dots,
+                                  int njobs, const int* tmap_dot, int nblk_dot, const int* tmap_apply, int nblk_apply,
+                                  hipStream_t stream) {
+  if (!ptrs || !dims || !taps || !dots || njobs < 1 || !tmap_apply || nblk_apply < 1 || (nblk_dot > 0 && !tmap_dot))
+    return FSV_ERR_BAD_ARG;
+  FinP f; f.ptrs = ptrs; f.dims = dims; f.taps = taps; f.dots = dots;
+  (void)hipMemsetAsync(dots, 0, sizeof(double) * (size_t)njobs, stream);
+  if (nblk_dot > 0) FSV_LAUNCH(fsv_wfin_dot_kernel, dim3(nblk_dot), dim3(256), stream, f, tmap_dot);
+  FSV_LAUNCH(fsv_wfin_apply_kernel, dim3(nblk_apply), dim3(256), stream, f, tmap_apply);
+  return fsv_check_launch();
+}

@@ -23,6 +23,7 @@ import torch.distributed as dist
 
 from . import ops
 from .layout_cache import LayoutCache
+from .grad_finalize import GradFinalizer
 
 
 class FlatAdam:
@@ -50,6 +51,10 @@ class FlatAdam:
         self.state = torch.tensor([0.0, 0.0, 0.0, float(lr)], dtype=torch.float32, device=self.device)
         # persistent K-major layouts of every weight this optimiser owns, rewritten once per step (layout_cache.py)
         self.layouts = LayoutCache() if os.environ.get('FSV_LAYOUT_CACHE', '1') == '1' else None
+        # weight gradients stay in the GEMM's layout until one grouped launch folds them into flat_g (grad_finalize.py)
+        self.finalizer = (GradFinalizer() if (self.layouts is not None and not self.overlap and
+                                              os.environ.get('FSV_GRAD_SINK', '1') == '1' and
+                                              os.environ.get('FSV_DEFER_WGRAD', '1') == '1') else None)
         self.offsets = []
         off = 0
         with torch.no_grad():
@@ -63,6 +68,8 @@ class FlatAdam:
                 p._fsv_sink = (not self.overlap) and os.environ.get('FSV_GRAD_SINK', '1') == '1'
                 if self.layouts is not None and p.dim() in (2, 4):
                     p._fsv_cache = self.layouts
+                    if self.finalizer is not None:
+                        p._fsv_finalizer = self.finalizer
                 self.offsets.append((off, n))
                 off += n
         # ---- data-parallel buckets ------------------------------------------------------------------------
@@ -133,6 +140,8 @@ class FlatAdam:
     def zero_grad(self, set_to_none=False):
         """Called by loss_backward right before backward: clears the flat gradient and arms the bucket hooks."""
         self.flat_g.zero_()
+        if self.finalizer is not None:
+            self.finalizer.jobs = []          # gradients of a backward pass that was never stepped
         if self.overlap:
             self._remaining = [len(b[2]) for b in self.buckets]
             self._launched = [False] * len(self.buckets)
@@ -154,12 +163,20 @@ class FlatAdam:
                 super().__setitem__(k, v)
         return [_Group(lr=float(self.state[3]), params=self.params)]
 
+    def finalize_grads(self):
+        """Fold the queued K-major weight gradients of the last backward pass into the flat gradient buffer.  Runs by
+        itself before the exchange / Adam step; call it explicitly to read `.grad` of a weight before stepping."""
+        if self.finalizer is not None:
+            self.finalizer.run()
+
     def exchange_all(self):
         """Non-overlapped mode: one all-reduce over the whole flat gradient buffer on the current stream."""
+        self.finalize_grads()
         if self.exchange and not self.overlap:
             dist.all_reduce(self.flat_g, op=dist.ReduceOp.SUM, group=self.group)
 
     def adam(self):
+        self.finalize_grads()
         ops.adam_step(self.flat_p, self.flat_g, self.m, self.v, self.state, self.betas[0], self.betas[1], self.eps,
                       1.0 / self.world_size)
         self.refresh_layouts()

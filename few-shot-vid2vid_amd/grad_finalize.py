@@ -1,0 +1,86 @@
+"""Queue of deferred weight-gradient jobs, drained by ONE fsv_wgrad_finalize call per backward pass.
+
+ops._ConvFn.backward leaves the weight gradient of a cached, sink-enabled parameter in the K-major layout the wgrad
+GEMM produces and appends a job here instead of launching the re-layout (+ spectral-norm correction) itself;
+FlatAdam drains the queue before the gradient exchange / Adam step (csrc/wgrad_finalize.hip).  The job table holds raw
+device pointers of this pass's temporaries, so it is rebuilt per pass: geometry / block maps are cached per job
+sequence, only the pointer array is re-uploaded - through kernel arguments (fsv_upload_i64), which is legal inside a
+hipGraph capture and leaves no host buffer for a captured graph to depend on.
+"""
+import ctypes
+
+import torch
+
+from . import lib
+
+c_p, c_i = ctypes.c_void_p, ctypes.c_int
+lib.register_sigs({"fsv_wgrad_finalize": [c_p, c_p, c_p, c_p, c_i, c_p, c_i, c_p, c_i, c_p],
+                   "fsv_upload_i64": [c_p, c_p, c_i, c_p]})
+
+DOT_CHUNK = 4096
+
+
+def _i64(v):
+    return v - (1 << 64) if v >= (1 << 63) else v
+
+
+class GradFinalizer:
+    def __init__(self):
+        self.jobs = []            # (entry, dwt, sink, sig, u, v)
+        self._static = {}         # job-sequence signature -> (dims, taps, tmap_dot, nblk_dot, tmap_apply, nblk_apply)
+
+    def add(self, entry, dwt, sink, sig=None, u=None, v=None):
+        self.jobs.append((entry, dwt, sink, sig, u, v))
+
+    def pending(self):
+        return bool(self.jobs)
+
+    def _build_static(self, dev):
+        dims, taps, tmap_dot, tmap_apply = [], [], [], []
+        sinks = {}
+        for (e, dwt, sink, sig, u, v) in self.jobs:
+            sinks[sink.data_ptr()] = sinks.get(sink.data_ptr(), 0) + 1
+        for j, (e, dwt, sink, sig, u, v) in enumerate(self.jobs):
+            _, d, lo, hi = e.jobs[0]                      # the forward layout: same geometry as dwt
+            cout, cinp, cin, kh, kw, ntaps, kpad, ldw, _mode = d
+            shared = 1 if sinks[sink.data_ptr()] > 1 else 0
+            dims += [cout, cinp, cin, kh, kw, ntaps, ldw, shared]
+            taps += [_i64(lo), _i64(hi)]
+            if sig is not None:
+                total = ntaps * cinp * ldw
+                for ch in range((total + DOT_CHUNK - 1) // DOT_CHUNK):
+                    tmap_dot += [j, ch]
+            ci_t = 32 if ntaps <= 8 else 16
+            for a in range((cout + 31) // 32):
+                for b in range((cinp + ci_t - 1) // ci_t):
+                    tmap_apply += [j, a, b]
+        mk = lambda vals, dt: torch.tensor(vals if vals else [0], dtype=dt).to(dev)
+        return (mk(dims, torch.int32), mk(taps, torch.int64), mk(tmap_dot, torch.int32), len(tmap_dot) // 2,
+                mk(tmap_apply, torch.int32), len(tmap_apply) // 3)
+
+    def run(self):
+        if not self.jobs:
+            return
+        dev = self.jobs[0][1].device
+        capturing = (not lib.is_emu()) and torch.cuda.is_current_stream_capturing()
+        sig_key = tuple((id(e), s is not None) for (e, _, _, s, _, _) in self.jobs)
+        st = self._static.get(sig_key)
+        if st is None:
+            if capturing:
+                raise lib.FsvError("new weight-gradient job sequence inside a graph capture; run one eager step first")
+            if len(self._static) > 8:
+                self._static.clear()
+            st = self._static[sig_key] = self._build_static(dev)
+        dims, taps, tmap_dot, nblk_dot, tmap_apply, nblk_apply = st
+        ptrs = []
+        for (e, dwt, sink, sig, u, v) in self.jobs:
+            sn = sig is not None
+            ptrs += [dwt.data_ptr(), e.fwd[0].data_ptr() if sn else 0, sink.data_ptr(),
+                     u.data_ptr() if sn else 0, v.data_ptr() if sn else 0, sig.data_ptr() if sn else 0]
+        host = (ctypes.c_longlong * len(ptrs))(*ptrs)
+        d_ptrs = torch.empty(len(ptrs), dtype=torch.int64, device=dev)
+        lib.call("fsv_upload_i64", lib.ptr(d_ptrs), host, len(ptrs), lib.stream_ptr())
+        dots = torch.empty(len(self.jobs), dtype=torch.float64, device=dev)
+        lib.call("fsv_wgrad_finalize", lib.ptr(d_ptrs), lib.ptr(dims), lib.ptr(taps), lib.ptr(dots), len(self.jobs),
+                 lib.ptr(tmap_dot), nblk_dot, lib.ptr(tmap_apply), nblk_apply, lib.stream_ptr())
+        self.jobs = []

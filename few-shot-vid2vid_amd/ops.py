@@ -375,7 +375,16 @@ class _ConvFn(torch.autograd.Function):
             fork.__enter__()
         try:
             if want_w:
-                if ctx.has_sn or cpad:
+                fin = getattr(weight, '_fsv_finalizer', None) if (w_sink is not None and entry is not None) else None
+                if fin is not None:
+                    # deferred: leave the K-major result to the optimiser's grouped finalisation (grad_finalize.py)
+                    dwt = conv_wgrad(x, dpre, geom, w_shape, raw=True)
+                    if ctx.has_sn:
+                        fin.add(entry, dwt, w_sink, sig, u, v)
+                    else:
+                        fin.add(entry, dwt, w_sink)
+                    dw = None
+                elif ctx.has_sn or cpad:
                     dwsn = conv_wgrad(x, dpre, geom, w_shape, per_sample=ctx.per_sample)
                     if cpad:
                         dwsn = dwsn[:, :cin].contiguous()

@@ -66,6 +66,16 @@ int fsv_prep_weight(const float* w, float* wt, const float* scale_ptr, int mode,
 /* every parameter weight of an optimiser re-arranged in one launch (un-scaled; used once per optimiser step) */
 int fsv_prep_weight_grouped(const long long* src, const long long* dst, const int* dims, const unsigned long long* taps,
                             const int* tmap, int nblocks, fsv_stream_t stream);
+/* Deferred weight-gradient finalisation (csrc/wgrad_finalize.hip): njobs K-major weight gradients -> OIHW, added into
+ * their parameter-gradient slices, with torch.nn.utils.spectral_norm's backward correction where sig != 0.
+ * ptrs[job][6] = {dwt, K-major W, sink, u, v, sig}; dims[job][8] = {Cout, CinP, CinR, KH, KW, ntaps, ldw, flags};
+ * taps[job][2] packed (kh | kw << 4); dots: double[njobs] scratch; tmap_dot (job, 4096-element chunk) pairs over the
+ * spectral jobs; tmap_apply (job, 32-co tile, ci tile) triples (ci tile = 32 channels for <= 8 taps, else 16). */
+int fsv_wgrad_finalize(const long long* ptrs, const int* dims, const unsigned long long* taps, double* dots, int njobs,
+                       const int* tmap_dot, int nblk_dot, const int* tmap_apply, int nblk_apply, fsv_stream_t stream);
+/* n 64-bit words from host memory into a device array, carried in kernel arguments (legal inside a graph capture,
+ * no staging buffer); used for the per-pass pointer table of fsv_wgrad_finalize */
+int fsv_upload_i64(long long* dst, const long long* host_src, int n, fsv_stream_t stream);
 /* tile / split-K plan the launcher will use (exported so host-side profilers label launches consistently) */
 int fsv_conv_plan(int Mz, int Cout, int nchunks, int nsamp, int force_tile, int force_split, int* tile_out,
                   int* nsplit_out);

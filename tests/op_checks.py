@@ -39,7 +39,17 @@ def _dev(t, device):
     return t.to(device) if t is not None else None
 
 
-def check_conv(device, n, cin, h, w, cout, k, s, p, act='lrelu', bias=True, seed=0, tol=REL_TOL, cache=None):
+def _sinkify(t, cache, fin):
+    """what FlatAdam does to a parameter: persistent layouts, gradient sink, deferred weight-gradient jobs"""
+    if cache is not None:
+        t._fsv_cache = cache
+    if fin is not None:
+        t.grad = torch.zeros_like(t)
+        t._fsv_sink = True
+        t._fsv_finalizer = fin
+
+
+def check_conv(device, n, cin, h, w, cout, k, s, p, act='lrelu', bias=True, seed=0, tol=REL_TOL, cache=None, fin=None):
     ops, conv = pkg()
     g = torch.Generator().manual_seed(seed)
     x = torch.randn(n, cin, h, w, generator=g)
@@ -54,10 +64,12 @@ def check_conv(device, n, cin, h, w, cout, k, s, p, act='lrelu', bias=True, seed
     ref.backward(dy)
     xd, wd = _dev(x, device).requires_grad_(True), _dev(wt, device).requires_grad_(True)
     bd = _dev(b, device).requires_grad_(True) if bias else None
-    if cache is not None:
-        wd._fsv_cache = cache
+    _sinkify(wd, cache, fin)
     y = ops.conv2d(xd, wd, bd, stride=s, padding=p, act=actc)
     y.backward(_dev(dy, device))
+    if fin is not None:
+        assert fin.pending()
+        fin.run()
     assert_close('conv y', y, ref, tol)
     assert_close('conv dx', xd.grad, xr.grad, tol)
     assert_close('conv dw', wd.grad, wr.grad, tol)
@@ -65,7 +77,7 @@ def check_conv(device, n, cin, h, w, cout, k, s, p, act='lrelu', bias=True, seed
         assert_close('conv db', bd.grad, br.grad, tol)
 
 
-def check_conv_sn_res(device, seed=1, cache=None):
+def check_conv_sn_res(device, seed=1, cache=None, fin=None):
     """spectral-norm conv with fused residual add (SPADEResnetBlock conv_1 + shortcut)."""
     ops, conv = pkg()
     g = torch.Generator().manual_seed(seed)
@@ -85,11 +97,13 @@ def check_conv_sn_res(device, seed=1, cache=None):
     ud, vd = _dev(u.clone(), device), _dev(v.clone(), device)
     wd = _dev(wt, device).requires_grad_(True)
     xd, bd, rd = (_dev(t, device).requires_grad_(True) for t in (x, b, res))
-    if cache is not None:
-        wd._fsv_cache = cache
+    _sinkify(wd, cache, fin)
     sig = ops.SpectralState.update(wd, ud, vd, training=True)
     y = ops.conv2d(xd, wd, bd, stride=1, padding=1, res=rd, sn=(sig, ud, vd))
     y.backward(_dev(dy, device))
+    if fin is not None:
+        assert fin.pending()
+        fin.run()
     assert_close('sn u', ud, sd['weight_u'])
     assert_close('sn v', vd, sd['weight_v'])
     assert_close('sn conv y', y, ref)
@@ -129,6 +143,46 @@ def check_layout_cache(device, seed=14):
             kws = [((lo if j < 8 else hi) >> ((j & 7) * 8 + 4)) & 15 for j in range(nt)]
             ref, _, _ = conv.prep_weight(wp, mode, None, khs, kws)
             assert torch.equal(ref, wt), d
+
+
+def check_deferred_wgrad(device, seed=16):
+    """grad_finalize.GradFinalizer + csrc/wgrad_finalize.hip: K-major weight gradients queued by backward and folded
+    into the (flat-buffer) gradient by one grouped call - plain, channel-padded, 16-tap, spectral-normalised layers, a
+    queue holding several layers at once, and one weight used twice in a pass (shared sink -> atomic adds)."""
+    ops, conv = pkg()
+    from fsv2v_amd.layout_cache import LayoutCache
+    from fsv2v_amd.grad_finalize import GradFinalizer
+    cache, fin = LayoutCache(), GradFinalizer()
+    check_conv(device, 2, 6, 9, 7, 5, 3, 2, 1, act='none', cache=cache, fin=fin)
+    check_conv(device, 1, 20, 9, 9, 40, 4, 2, 2, cache=cache, fin=fin)
+    check_conv(device, 1, 64, 6, 6, 130, 1, 1, 0, cache=cache, fin=fin)
+    check_conv(device, 1, 3, 8, 8, 8, 3, 1, 1, act='tanh', cache=cache, fin=fin)
+    check_conv_sn_res(device, cache=cache, fin=fin)
+    # several jobs in one queue, one weight used twice, spectral + plain mixed
+    g = torch.Generator().manual_seed(seed)
+    x1, x2 = torch.randn(2, 8, 7, 6, generator=g), torch.randn(2, 8, 7, 6, generator=g)
+    w1 = torch.randn(12, 8, 3, 3, generator=g) * 0.2
+    w2 = torch.randn(5, 12, 3, 3, generator=g) * 0.2
+    u = F.normalize(torch.randn(5, generator=g), dim=0)
+    v = F.normalize(torch.randn(12 * 9, generator=g), dim=0)
+    sd = {'weight_orig': w2.clone().requires_grad_(True), 'weight_u': u.clone(), 'weight_v': v.clone()}
+    w1r = w1.clone().requires_grad_(True)
+    ref = F.conv2d(F.conv2d(x1, w1r, padding=1) + F.conv2d(x2, w1r, padding=1), O.spectral_weight(sd, '', training=True),
+                   padding=1)
+    dy = torch.randn(ref.shape, generator=g)
+    ref.backward(dy)
+    w1d, w2d = _dev(w1, device).requires_grad_(True), _dev(w2, device).requires_grad_(True)
+    _sinkify(w1d, cache, fin); _sinkify(w2d, cache, fin)
+    ud, vd = _dev(u.clone(), device), _dev(v.clone(), device)
+    sig = ops.SpectralState.update(w2d, ud, vd, training=True)
+    y = ops.conv2d(ops.conv2d(_dev(x1, device), w1d, None, padding=1) + ops.conv2d(_dev(x2, device), w1d, None, padding=1),
+                   w2d, None, padding=1, sn=(sig, ud, vd))
+    y.backward(_dev(dy, device))
+    assert len(fin.jobs) == 3
+    fin.run()
+    assert_close('deferred y', y, ref)
+    assert_close('deferred shared dw', w1d.grad, w1r.grad)
+    assert_close('deferred sn dw', w2d.grad, sd['weight_orig'].grad)
 
 
 def check_linear(device, r=40, cin=16, cout=50, seed=2):
@@ -440,6 +494,7 @@ def run_all(device, big=False):
     check_conv(device, 1, 64, 6, 6, 130, 1, 1, 0)
     check_conv_sn_res(device)
     check_layout_cache(device)
+    check_deferred_wgrad(device)
     check_linear(device)
     check_batch_conv(device)
     check_norm(device, instance=False)

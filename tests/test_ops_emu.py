@@ -35,6 +35,10 @@ def test_layout_cache(emu_lib):
     oc.check_layout_cache(DEV)
 
 
+def test_deferred_wgrad_finalize(emu_lib):
+    oc.check_deferred_wgrad(DEV)
+
+
 def test_linear(emu_lib):
     oc.check_linear(DEV)
 

@@ -40,6 +40,10 @@ def test_layout_cache(hip_lib):
     oc.check_layout_cache(dev())
 
 
+def test_deferred_wgrad_finalize(hip_lib):
+    oc.check_deferred_wgrad(dev())
+
+
 def test_linear(hip_lib):
     oc.check_linear(dev())
     oc.check_linear(dev(), r=2048, cin=256, cout=514)
