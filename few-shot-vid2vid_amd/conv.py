@@ -188,7 +188,7 @@ def conv_dgrad(dout, w, geom, in_hw, scale=None, per_sample=False, cached=None, 
     return dx
 
 
-def conv_wgrad(x, dout, geom, w_shape, per_sample=False, scale=None, force_split=0, out=None, raw=False):
+def conv_wgrad(x, dout, geom, w_shape, per_sample=False, scale=None, force_split=0, out=None, raw=False, arena=None):
     """Weight gradient in OIHW layout (batched when per_sample); raw=True returns the GEMM's K-major result
     dwt[(tap, ci)][co] instead (consumed by grad_finalize.GradFinalizer)."""
     x = to_nhwc(x)
@@ -198,7 +198,10 @@ def conv_wgrad(x, dout, geom, w_shape, per_sample=False, scale=None, force_split
     kpad = _ceil(geom.ntaps * cin, 32)
     ldw = _ceil(cout, 32)
     nb = n if per_sample else 1
-    dwt = torch.empty((nb, kpad, ldw), dtype=torch.float32, device=x.device)
+    dwt = arena.take(kpad * ldw) if (arena is not None and raw and not per_sample) else None
+    prezeroed = dwt is not None
+    if dwt is None:
+        dwt = torch.empty((nb, kpad, ldw), dtype=torch.float32, device=x.device)
     lib.check_device(x, dout)
     label = 'fsv_conv_wgrad_kernel<BN%d,V%d>' % (32 if cout <= 32 else (64 if cout <= 64 else 128), 4 if cin % 4 == 0 else 1)
     if profile.detail():
@@ -206,7 +209,7 @@ def conv_wgrad(x, dout, geom, w_shape, per_sample=False, scale=None, force_split
     with profile.scope(label, 2.0 * n * oh * ow * cout * cin * geom.ntaps):
         lib.call("fsv_conv_wgrad", lib.ptr(x), lib.ptr(dout), lib.ptr(dwt), n, h, w, cin, oh, ow, cout,
                  geom.ntaps, lib.int_array(geom.ty), lib.int_array(geom.tx), geom.stride, geom.stride,
-                 ldw, kpad, kpad * ldw, 1 if per_sample else 0, force_split, lib.stream_ptr())
+                 ldw, kpad, kpad * ldw, 1 if per_sample else 0, force_split, 1 if prezeroed else 0, lib.stream_ptr())
     if raw:
         return dwt
     return unprep_weight_grad(dwt, tuple(w_shape), geom, scale, out)

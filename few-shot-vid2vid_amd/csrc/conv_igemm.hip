@@ -690,7 +690,8 @@ int fsv_conv_gather_fwd(const float* in, const float* wt, const float* bias, con
 int fsv_conv_wgrad(const float* in, const float* dout, float* dwt,
                    int N, int H, int W, int Cin, int OH, int OW, int Cout,
                    int ntaps, const int* ty, const int* tx, int sy, int sx,
-                   int ldw, int Kpad, long long w_bstride, int per_sample, int force_split, hipStream_t stream) {
+                   int ldw, int Kpad, long long w_bstride, int per_sample, int force_split, int prezeroed,
+                   hipStream_t stream) {
   if (!in || !dout || !dwt || ntaps < 1 || ntaps > 16) return FSV_ERR_BAD_ARG;
   for (int t = 0; t < ntaps; ++t)
     if (ty[t] < -8 || ty[t] > 7 || tx[t] < -8 || tx[t] > 7) return FSV_ERR_UNSUPPORTED;
@@ -721,7 +722,7 @@ int fsv_conv_wgrad(const float* in, const float* dout, float* dwt,
   p.nsplit = nsplit;
   // split reductions add into dwt atomically and need it zeroed; a single split stores every (k < K, co < Cout)
   // entry directly and the padding rows / columns are never read back (fsv_prep_weight mode 2 skips them)
-  if (nsplit > 1)
+  if (nsplit > 1 && !prezeroed)
     (void)hipMemsetAsync(dwt, 0, (size_t)((per_sample ? (long long)N * w_bstride : (long long)Kpad * ldw)) * sizeof(float), stream);
   dim3 block(256);
   const bool vec4 = (Cin % 4 == 0);

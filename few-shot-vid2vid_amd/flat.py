@@ -141,7 +141,7 @@ class FlatAdam:
         """Called by loss_backward right before backward: clears the flat gradient and arms the bucket hooks."""
         self.flat_g.zero_()
         if self.finalizer is not None:
-            self.finalizer.jobs = []          # gradients of a backward pass that was never stepped
+            self.finalizer.begin_pass()       # drops jobs of a pass that was never stepped, zeroes the wgrad arena
         if self.overlap:
             self._remaining = [len(b[2]) for b in self.buckets]
             self._launched = [False] * len(self.buckets)

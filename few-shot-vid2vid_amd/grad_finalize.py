@@ -28,9 +28,37 @@ class GradFinalizer:
     def __init__(self):
         self.jobs = []            # (entry, dwt, sink, sig, u, v)
         self._static = {}         # job-sequence signature -> (dims, taps, tmap_dot, nblk_dot, tmap_apply, nblk_apply)
+        # per-pass arena for the K-major gradients: zeroed by ONE fill in begin_pass() instead of a zero-fill in front
+        # of every split-K wgrad launch; sized from the previous pass (the first pass allocates per layer)
+        self.arena = None
+        self._arena_off = 0
+        self._arena_need = 0
 
     def add(self, entry, dwt, sink, sig=None, u=None, v=None):
+        self._arena_dev = dwt.device
         self.jobs.append((entry, dwt, sink, sig, u, v))
+
+    def begin_pass(self):
+        """Called by FlatAdam.zero_grad right before a backward pass."""
+        self.jobs = []
+        capturing = (not lib.is_emu()) and torch.cuda.is_current_stream_capturing()
+        if self._arena_need and not capturing and (self.arena is None or self.arena.numel() < self._arena_need):
+            self.arena = None
+            self.arena = torch.empty(self._arena_need, dtype=torch.float32, device=self._arena_dev)
+        if self.arena is not None:
+            self.arena.zero_()
+        self._arena_off = 0
+        self._arena_need = 0
+
+    def take(self, nfloats):
+        """A zeroed [1, nfloats] slice of the arena, or None when it does not fit (caller allocates and zero-fills)."""
+        nfloats = (nfloats + 63) // 64 * 64
+        self._arena_need += nfloats
+        if self.arena is None or self._arena_off + nfloats > self.arena.numel():
+            return None
+        out = self.arena[self._arena_off:self._arena_off + nfloats]
+        self._arena_off += nfloats
+        return out
 
     def pending(self):
         return bool(self.jobs)

@@ -378,7 +378,7 @@ class _ConvFn(torch.autograd.Function):
                 fin = getattr(weight, '_fsv_finalizer', None) if (w_sink is not None and entry is not None) else None
                 if fin is not None:
                     # deferred: leave the K-major result to the optimiser's grouped finalisation (grad_finalize.py)
-                    dwt = conv_wgrad(x, dpre, geom, w_shape, raw=True)
+                    dwt = conv_wgrad(x, dpre, geom, w_shape, raw=True, arena=fin)
                     if ctx.has_sn:
                         fin.add(entry, dwt, w_sink, sig, u, v)
                     else:

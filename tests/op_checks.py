@@ -158,7 +158,9 @@ def check_deferred_wgrad(device, seed=16):
     check_conv(device, 1, 64, 6, 6, 130, 1, 1, 0, cache=cache, fin=fin)
     check_conv(device, 1, 3, 8, 8, 8, 3, 1, 1, act='tanh', cache=cache, fin=fin)
     check_conv_sn_res(device, cache=cache, fin=fin)
-    # several jobs in one queue, one weight used twice, spectral + plain mixed
+    # several jobs in one queue, one weight used twice, spectral + plain mixed; K-major results in the per-pass arena
+    fin.begin_pass()
+    assert fin.arena is not None and fin.arena.numel() > 0
     g = torch.Generator().manual_seed(seed)
     x1, x2 = torch.randn(2, 8, 7, 6, generator=g), torch.randn(2, 8, 7, 6, generator=g)
     w1 = torch.randn(12, 8, 3, 3, generator=g) * 0.2
@@ -178,7 +180,8 @@ def check_deferred_wgrad(device, seed=16):
     y = ops.conv2d(ops.conv2d(_dev(x1, device), w1d, None, padding=1) + ops.conv2d(_dev(x2, device), w1d, None, padding=1),
                    w2d, None, padding=1, sn=(sig, ud, vd))
     y.backward(_dev(dy, device))
-    assert len(fin.jobs) == 3
+    assert len(fin.jobs) == 3 and fin._arena_off > 0
+    assert all(j[1].data_ptr() >= fin.arena.data_ptr() for j in fin.jobs)
     fin.run()
     assert_close('deferred y', y, ref)
     assert_close('deferred shared dw', w1d.grad, w1r.grad)

@@ -48,6 +48,7 @@ def test_product_path_refuses_to_run_without_the_hip_library(monkeypatch, tmp_pa
     lib = importlib.import_module('few-shot-vid2vid_amd.lib')
     monkeypatch.setenv('FSV2V_EMU', '0')
     monkeypatch.setattr(lib, '_lib', None)
+    monkeypatch.setattr(lib, '_is_emu', lib._is_emu)      # get_lib() rewrites it: have it restored afterwards
     monkeypatch.setattr(lib, '_HERE', str(tmp_path))
     with pytest.raises(lib.FsvError):
         lib.get_lib()
