@@ -188,7 +188,8 @@ def conv_dgrad(dout, w, geom, in_hw, scale=None, per_sample=False, cached=None, 
     return dx
 
 
-def conv_wgrad(x, dout, geom, w_shape, per_sample=False, scale=None, force_split=0, out=None, raw=False, arena=None):
+def conv_wgrad(x, dout, geom, w_shape, per_sample=False, scale=None, force_split=0, out=None, raw=False, arena=None,
+               force_tile=0):
     """Weight gradient in OIHW layout (batched when per_sample); raw=True returns the GEMM's K-major result
     dwt[(tap, ci)][co] instead (consumed by grad_finalize.GradFinalizer)."""
     x = to_nhwc(x)
@@ -209,7 +210,7 @@ def conv_wgrad(x, dout, geom, w_shape, per_sample=False, scale=None, force_split
     with profile.scope(label, 2.0 * n * oh * ow * cout * cin * geom.ntaps):
         lib.call("fsv_conv_wgrad", lib.ptr(x), lib.ptr(dout), lib.ptr(dwt), n, h, w, cin, oh, ow, cout,
                  geom.ntaps, lib.int_array(geom.ty), lib.int_array(geom.tx), geom.stride, geom.stride,
-                 ldw, kpad, kpad * ldw, 1 if per_sample else 0, force_split, 1 if prezeroed else 0, lib.stream_ptr())
+                 ldw, kpad, kpad * ldw, 1 if per_sample else 0, force_split, 1 if prezeroed else 0, force_tile, lib.stream_ptr())
     if raw:
         return dwt
     return unprep_weight_grad(dwt, tuple(w_shape), geom, scale, out)

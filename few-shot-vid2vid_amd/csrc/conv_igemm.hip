@@ -691,7 +691,7 @@ int fsv_conv_wgrad(const float* in, const float* dout, float* dwt,
                    int N, int H, int W, int Cin, int OH, int OW, int Cout,
                    int ntaps, const int* ty, const int* tx, int sy, int sx,
                    int ldw, int Kpad, long long w_bstride, int per_sample, int force_split, int prezeroed,
-                   hipStream_t stream) {
+                   int force_tile, hipStream_t stream) {
   if (!in || !dout || !dwt || ntaps < 1 || ntaps > 16) return FSV_ERR_BAD_ARG;
   for (int t = 0; t < ntaps; ++t)
     if (ty[t] < -8 || ty[t] > 7 || tx[t] < -8 || tx[t] > 7) return FSV_ERR_UNSUPPORTED;
@@ -704,16 +704,30 @@ int fsv_conv_wgrad(const float* in, const float* dout, float* dwt,
   p.Mz = per_sample ? OH * OW : N * OH * OW;
   p.pchunks = fsv_cdiv(p.Mz, FSV_BK);
   const int nsamp = per_sample ? N : 1;
-  const int bn = (Cout <= 32) ? 32 : (Cout <= 64 ? 64 : 128);
+  int bn = (Cout <= 32) ? 32 : (Cout <= 64 ? 64 : 128);
   // rows of the weight-gradient tile = taps * Cin; the 1x1 SPADE / embedding layers have only 32 or 64 of them and
   // would waste 3/4 or 1/2 of a 128-row tile's MFMA work
   int bmk = 128;
   if (vec4_ok(Cin) && bn >= 64) bmk = (p.K <= 32) ? 32 : (p.K <= 64 ? 64 : 128);
+  // force_tile (A/B runs, tools/wgrad_ab.py): 1 = 64x64, 2 = 128x64, 3 = 64x128 (rows x columns), vec4 layers only
+  if (force_tile == 1 && vec4_ok(Cin) && Cout > 32) { bmk = 64; bn = 64; }
+  else if (force_tile == 2 && vec4_ok(Cin) && Cout > 32) { bmk = 128; bn = 64; }
+  else if (force_tile == 3 && vec4_ok(Cin) && Cout > 64) { bmk = 64; bn = 128; }
+  long long target = fsv_tune(2);
+  static int wplan_v = -1;
+  if (wplan_v < 0) { const char* e = getenv("FSV_WGRAD_PLAN"); wplan_v = e ? atoi(e) : 1; }
+  if (force_tile == 0 && wplan_v == 1 && vec4_ok(Cin) && Cout >= 64 && p.K > 64) {
+    // in-box A/B on the step's layer shapes (tools/wgrad_ab.py, profiles/r01_wgrad_ab.jsonl): 64-row tiles with ~2048
+    // (64x64) / ~1024 (64x128) workgroups beat 128-row tiles at ~1024 by 11 ... 23 % - four times fewer atomic adds per
+    // FLOP than the same workgroup count of split 128x128 tiles, and every CU gets several workgroups
+    if (Cout >= 128 && p.K >= 2304 && p.pchunks >= 64) { bmk = 64; bn = 128; target = 1024; }
+    else { bmk = 64; bn = 64; target = 2048; }
+  }
   long long blocks = (long long)fsv_cdiv(p.K, bmk) * fsv_cdiv(Cout, bn) * nsamp;
   int nsplit = 1;
   if (force_split > 0) nsplit = force_split;
   else {
-    nsplit = (int)((fsv_tune(2) + blocks - 1) / blocks);
+    nsplit = (int)((target + blocks - 1) / blocks);
     int maxs = p.pchunks / (int)fsv_tune(3);       // keep at least this many 32-pixel chunks per split
     if (nsplit > maxs) nsplit = maxs;
     if (nsplit < 1) nsplit = 1;

@@ -51,12 +51,13 @@ int fsv_conv_gather_fwd(const float* in, const float* wt, const float* bias, con
                         fsv_stream_t stream);
 
 /* dwt[t*Cin+ci][co] = sum_{n,oy,ox} in[n, oy*sy+ty[t], ox*sx+tx[t], ci] * dout[n, oy, ox, co]  (weight gradient)
- * prezeroed: dwt already holds zeros (a slice of the optimiser's per-pass arena), skip the split-K zero-fill */
+ * prezeroed: dwt already holds zeros (a slice of the optimiser's per-pass arena), skip the split-K zero-fill;
+ * force_tile: 0 = automatic (1 / 2 / 3 = 64x64 / 128x64 / 64x128 rows x columns, for A/B runs) */
 int fsv_conv_wgrad(const float* in, const float* dout, float* dwt,
                    int N, int H, int W, int Cin, int OH, int OW, int Cout,
                    int ntaps, const int* ty, const int* tx, int sy, int sx,
                    int ldw, int Kpad, long long w_bstride, int per_sample, int force_split, int prezeroed,
-                   fsv_stream_t stream);
+                   int force_tile, fsv_stream_t stream);
 
 /* OIHW <-> K-major re-arrangement with an optional device scalar multiplier (the spectral-norm 1/sigma).
  * mode 0: wt[j*Cin+ci][co] = s*w[co][ci][kh_j][kw_j]; mode 1 (data gradient): wt[j*Cout+co][ci] = ...;
