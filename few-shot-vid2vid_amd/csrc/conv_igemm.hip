@@ -529,9 +529,12 @@ static int fsv_launch_conv(const ConvP& p, int M_tiles_rows, int nz, hipStream_t
         FSV_LAUNCH((fsv_conv_igemm_kernel<256, 256, 4, 4, 4>), g, dim3(1024), stream, p); return fsv_check_launch(); }
       case 8: { dim3 g(fsv_cdiv(M_tiles_rows, 256), fsv_cdiv(p.Cout, 64), nz);
         FSV_LAUNCH((fsv_conv_igemm_kernel<256, 64, 4, 2, 4>), g, dim3(512), stream, p); return fsv_check_launch(); }
+      case 9: { dim3 g(fsv_cdiv(M_tiles_rows, 64), fsv_cdiv(p.Cout, 128), nz);
+        FSV_LAUNCH((fsv_conv_igemm_kernel<64, 128, 2, 2, 4>), g, block, stream, p); return fsv_check_launch(); }
       default: break;
     }
   }
+  if (tile == 9) tile = 4;      // scalar-gather layers (Cin % 4 != 0): only the basic tiles are instantiated
   switch (tile) {
     case 0: { dim3 g(fsv_cdiv(M_tiles_rows, 128), fsv_cdiv(p.Cout, 128), nz);
       FSV_LAUNCH((fsv_conv_igemm_kernel<128, 128, 2, 2, V>), g, block, stream, p); break; }
@@ -549,8 +552,8 @@ static int fsv_launch_conv(const ConvP& p, int M_tiles_rows, int nz, hipStream_t
 }
 
 static inline int fsv_tile_dims(int tile, int& bm, int& bn) {
-  static const int BMs[9] = {128, 128, 128, 256, 64, 256, 128, 256, 256}, BNs[9] = {128, 64, 32, 32, 64, 128, 256, 256, 64};
-  if (tile < 0 || tile > 8) return -1;
+  static const int BMs[10] = {128, 128, 128, 256, 64, 256, 128, 256, 256, 64}, BNs[10] = {128, 64, 32, 32, 64, 128, 256, 256, 64, 128};
+  if (tile < 0 || tile > 9) return -1;
   bm = BMs[tile]; bn = BNs[tile];
   return 0;
 }
@@ -584,11 +587,12 @@ extern "C" int fsv_conv_plan(int Mz, int Cout, int nchunks, int nsamp, int force
                              int* tile_out, int* nsplit_out) {
   int tile = force_tile;
   static int plan_v = -1;
-  if (plan_v < 0) { const char* e = getenv("FSV_PLAN"); plan_v = e ? atoi(e) : 1; }
+  if (plan_v < 0) { const char* e = getenv("FSV_PLAN"); plan_v = e ? atoi(e) : 2; }
   const long long b0 = (long long)fsv_cdiv(Mz, 128) * fsv_cdiv(Cout, 128) * nsamp;      // 128x128 tiles
   const long long b1 = (long long)fsv_cdiv(Mz, 128) * fsv_cdiv(Cout, 64) * nsamp;       // 128x64
   const long long b4 = (long long)fsv_cdiv(Mz, 64) * fsv_cdiv(Cout, 64) * nsamp;        // 64x64
-  bool small_tile_regime = false;
+  const long long b9 = (long long)fsv_cdiv(Mz, 64) * fsv_cdiv(Cout, 128) * nsamp;       // 64x128
+  bool small_tile_regime = false, mid_tile_regime = false;
   if (tile < 0) {
     if (plan_v == 0) {
       if (Cout <= 32) tile = (Mz >= 256 * 256) ? fsv_thin_tile() : 2;
@@ -600,10 +604,21 @@ extern "C" int fsv_conv_plan(int Mz, int Cout, int nchunks, int nsamp, int force
       // no separate bias pass) unless K is long enough (>= 4096) to amortise them
       if (Cout <= 32) tile = (Mz >= 256 * 256) ? fsv_thin_tile() : 2;
       else if (Cout <= 64) tile = (b1 < 512) ? 4 : 1;
-      else if (b0 >= 512) tile = 0;
-      else if (nchunks >= 128) tile = (b0 < 64) ? 1 : 0;
-      else { tile = 4; }
+      else if (plan_v == 1) {
+        if (b0 >= 512) tile = 0;
+        else if (nchunks >= 128) tile = (b0 < 64) ? 1 : 0;
+        else { tile = 4; }
+      } else {
+        // plan 2 adds the 64x128 tile (profiles/r01_tile_ab.jsonl, second table): half the A-tile re-reads of 64x64
+        if (b0 > 1024) tile = 0;
+        else if (nchunks >= 128) tile = (b0 < 64) ? 1 : ((b0 <= 128 && nchunks >= 256) ? 0 : 9);
+        else if (b0 >= 512) tile = (Cout <= 128) ? 9 : 0;
+        else if (b9 >= 512) tile = 9;
+        else if (b9 >= 256 && nchunks >= 72) tile = 9;
+        else tile = 4;
+      }
       small_tile_regime = (tile == 4);
+      mid_tile_regime = (tile == 9);
     }
   }
   int bm, bn;
@@ -617,6 +632,13 @@ extern "C" int fsv_conv_plan(int Mz, int Cout, int nchunks, int nsamp, int force
     if (blocks < 512 && nchunks >= 32) {
       nsplit = (int)((1024 + blocks - 1) / blocks);
       if (nsplit > nchunks / 16) nsplit = nchunks / 16;
+      if (nsplit < 1) nsplit = 1;
+    }
+  } else if (mid_tile_regime) {
+    // 64x128 tiles: ~1024 workgroups, at least 18 chunks (576 K-elements) per split
+    if (blocks < 768 && nchunks >= 36) {
+      nsplit = (int)((1024 + blocks - 1) / blocks);
+      if (nsplit > nchunks / 18) nsplit = nchunks / 18;
       if (nsplit < 1) nsplit = 1;
     }
   } else if (blocks < fsv_tune(0) && nchunks >= 8) {

@@ -16,7 +16,7 @@ _detail = False       # tools/shape_profile.py: append the GEMM shape to every l
 _records = []          # (label, flops, ev0, ev1)
 FP32_MFMA_PEAK = 157.3e12
 
-TILE_NAMES = {0: '128x128', 1: '128x64', 2: '128x32', 3: '256x32', 4: '64x64'}
+TILE_NAMES = {0: '128x128', 1: '128x64', 2: '128x32', 3: '256x32', 4: '64x64', 9: '64x128'}
 
 
 def enable(detail=False):

@@ -10,14 +10,17 @@ import fsv2v_amd  # noqa
 from importlib import import_module
 conv = import_module('few-shot-vid2vid_amd.conv')
 dev = torch.device('cuda:0')
-cfgs = [(-1, 0), (0, 1), (0, 2), (0, 4), (0, 8), (1, 1), (1, 2), (1, 4), (1, 8), (4, 1), (4, 2), (4, 4)]
+cfgs = [(-1, 0), (0, 1), (0, 4), (1, 1), (1, 2), (1, 4), (4, 1), (4, 2), (4, 4), (9, 1), (9, 2), (9, 4), (9, 8)]
 shapes = [('M8192 N256 K2304', 2, 256, 64, 64, 256, 3), ('M32768 N128 K576', 2, 64, 128, 128, 128, 3),
           ('M32768 N128 K1152', 2, 128, 128, 128, 128, 3), ('M32768 N128 K2304', 2, 256, 128, 128, 128, 3),
           ('M2048 N512 K9216', 2, 1024, 32, 32, 512, 3), ('M2048 N512 K2304', 2, 256, 32, 32, 512, 3),
           ('M8192 N256 K1152', 2, 128, 64, 64, 256, 3), ('M131072 N64 K288', 2, 32, 256, 256, 64, 3),
           ('M1024 N512 K512', 1, 512, 1, 1024, 512, 1), ('M512 N1024 K4608', 2, 512, 16, 16, 1024, 3),
           ('M8192 N128 K512', 2, 512, 64, 64, 128, 1), ('M32768 N64 K256', 2, 256, 128, 128, 64, 1),
-          ('M32768 N256 K1152', 2, 128, 128, 128, 256, 3), ('M131072 N128 K576', 2, 64, 256, 256, 128, 3)]
+          ('M32768 N256 K1152', 2, 128, 128, 128, 256, 3), ('M131072 N128 K576', 2, 64, 256, 256, 128, 3),
+          ('M8192 N256 K4608', 2, 512, 64, 64, 256, 3), ('M8192 N256 K9216', 2, 1024, 64, 64, 256, 3),
+          ('M2048 N1024 K4608', 2, 512, 32, 32, 1024, 3), ('M8192 N1024 K2304', 2, 256, 64, 64, 1024, 3),
+          ('M32768 N128 K4608', 2, 512, 128, 128, 128, 3), ('M512 N1024 K9216', 2, 1024, 16, 16, 1024, 3)]
 if len(sys.argv) > 1:
     shapes = [s for s in shapes if any(a in s[0] for a in sys.argv[1:])]
 NREP = 20
@@ -29,7 +32,7 @@ for name, n, cin, h, w, cout, k in shapes:
     flops = 2.0 * n * h * w * cout * cin * k * k
     graphs = {}
     for c in cfgs:
-        if c[0] == 0 and cout < 128 or c[0] == 1 and cout < 64:
+        if c[0] in (0, 9) and cout < 128 or c[0] == 1 and cout < 64:
             continue
         f = lambda: conv.conv_forward(x, wf, ldw, cout, g, bias=b, act=conv.ACT_LRELU, force_tile=c[0], force_split=c[1])
         s = torch.cuda.Stream(); s.wait_stream(torch.cuda.current_stream())
