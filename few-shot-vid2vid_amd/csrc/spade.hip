@@ -243,7 +243,55 @@ __global__ __launch_bounds__(256) void fsv_spade_bwd_elem_kernel(SpadeBwdP p) {
   }
 }
 
+// ---- one-launch operand preparation for a (gamma, beta) weight pair ------------------------------------------------------
+// wg / wb: [B][C][Ch] (1x1 OIHW, sample strides swg / swb; 0 = shared), bg / bb: [B][C].  Outputs (per sample):
+//   wcat_t [Kt = ceil32(Ch)][2C]      forward operand of the combined convolution  map -> [gamma | beta]
+//   wcat_d [ceil32(2C)][Ld = ceil32(Ch)]  data-gradient operand (optional)
+//   bcat   [2C]
+// The modulation kernel reads gamma weights from columns [0, C) and beta weights from [C, 2C) of wcat_t, the backward
+// pass re-uses all three as they are (no concatenation / re-arrangement launches).  Needs C % 16 == 0.
+__global__ __launch_bounds__(256) void fsv_spade_prep_kernel(const float* wg, const float* wb, const float* bg, const float* bb,
+                                                             long long swg, long long swb, long long sbg, long long sbb,
+                                                             float* wcat_t, float* wcat_d, float* bcat, int C, int Ch) {
+  const int z = blockIdx.y;
+  const int Kt = (Ch + 31) / 32 * 32, Lt = 2 * C;
+  const int Kd = (2 * C + 31) / 32 * 32, Ld = (Ch + 31) / 32 * 32;
+  const long long nt = (long long)Kt * Lt, nd = wcat_d ? (long long)Kd * Ld : 0, nb = 2 * C;
+  const float* g = wg + z * swg;
+  const float* b = wb + z * swb;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < nt + nd + nb; i += (long long)gridDim.x * 256) {
+    if (i < nt) {
+      const int k = (int)(i / Lt), j = (int)(i - (long long)k * Lt);
+      float v = 0.f;
+      if (k < Ch) v = j < C ? g[(long long)j * Ch + k] : b[(long long)(j - C) * Ch + k];
+      wcat_t[z * nt + i] = v;
+    } else if (i < nt + nd) {
+      const long long e = i - nt;
+      const int r = (int)(e / Ld), k = (int)(e - (long long)r * Ld);
+      float v = 0.f;
+      if (k < Ch && r < 2 * C) v = r < C ? g[(long long)r * Ch + k] : b[(long long)(r - C) * Ch + k];
+      wcat_d[z * nd + e] = v;
+    } else {
+      const int j = (int)(i - nt - nd);
+      bcat[z * nb + j] = j < C ? bg[z * sbg + j] : bb[z * sbb + (j - C)];
+    }
+  }
+}
+
 extern "C" {
+
+int fsv_spade_prep(const float* wg, const float* wb, const float* bg, const float* bb, long long swg, long long swb,
+                   long long sbg, long long sbb, float* wcat_t, float* wcat_d, float* bcat, int B, int C, int Ch,
+                   hipStream_t stream) {
+  if (!wg || !wb || !bg || !bb || !wcat_t || !bcat || B < 1 || C < 16 || (C & 15) || Ch < 1) return FSV_ERR_BAD_ARG;
+  const long long Kt = (Ch + 31) / 32 * 32, Kd = (2 * C + 31) / 32 * 32;
+  long long total = Kt * 2 * C + (wcat_d ? Kd * Kt : 0) + 2 * C;
+  long long g = (total + 255) / 256;
+  if (g > 1024) g = 1024;
+  FSV_LAUNCH(fsv_spade_prep_kernel, dim3((unsigned)g, B), dim3(256), stream, wg, wb, bg, bb, swg, swb, sbg, sbb, wcat_t,
+             wcat_d, bcat, C, Ch);
+  return fsv_check_launch();
+}
 
 // maps/wg/wb/bg/bb: arrays of nmaps device pointers; ch / w_bstride / b_bstride: per-map ints / strides.
 int fsv_spade_mod_fwd(const float* x, const float* mean, const float* rstd, float* h,

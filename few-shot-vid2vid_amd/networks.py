@@ -179,7 +179,9 @@ class SPADE(nn.Module):
                 # generated weights of map 0: the reference indexes weights[0][j] / weights[1][j], i.e. the weight
                 # tensors only - the generated biases never reach batch_conv (normalization.py:48-50)
                 wg, wb = weights[0][0], weights[1][0]
-                zb = torch.zeros(wg.shape[0], self.norm_nc, dtype=wg.dtype, device=wg.device)
+                zb = getattr(self, '_zero_bias', None)
+                if zb is None or zb.shape[0] != wg.shape[0] or zb.device != wg.device:
+                    zb = self._zero_bias = torch.zeros(wg.shape[0], self.norm_nc, dtype=wg.dtype, device=wg.device)
                 use_w.append((wg, wb, zb, zb))
             use_maps.append(m)
         self.norm.note_forward()

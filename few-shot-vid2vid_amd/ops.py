@@ -30,6 +30,7 @@ lib.register_sigs({
     "fsv_norm_apply": [c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p],
     "fsv_norm_bwd": [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p],
     "fsv_colsum": [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p],
+    "fsv_spade_prep": [c_p, c_p, c_p, c_p, c_ll, c_ll, c_ll, c_ll, c_p, c_p, c_p, c_i, c_i, c_i, c_p],
     "fsv_spade_mod_fwd": [c_p, c_p, c_p, c_p, c_i, c_pp, c_pp, c_pp, c_pp, c_pp, c_ip, c_llp, c_llp,
                           c_i, c_i, c_i, c_i, c_ll, c_i, c_p],
     "fsv_spade_bwd_elem": [c_p, c_p, c_p, c_p, c_p, c_i, c_pp, c_pp, c_p, c_i, c_i, c_i, c_ll, c_i, c_p],
@@ -540,21 +541,70 @@ class _SpadeFn(torch.autograd.Function):
             mean = run_mean.detach().clone()
             rstd = torch.rsqrt(run_var.detach() + eps)
         g1 = Geom(1, 1, 1, 0)
-        wg_t, wb_t, bg_c, bb_c, chs, wbs_stride, bbs_stride = [], [], [], [], [], [], []
-        ldw = (c + 31) // 32 * 32
         for k in range(nmaps):
             if maps[k].shape[2:] != x.shape[2:]:
                 raise ValueError("SPADE maps must already be at the resolution of x")
+        chs = [m.shape[1] for m in maps]
+        hout = torch.empty_like(x)
+        lib.check_device(x, *maps)
+        # fast path (every production width): ONE preparation launch per map builds the combined [gamma | beta] operands
+        # that the modulation kernel, the backward recompute and the data gradient all use as they are
+        ctx.fast = (c % 16 == 0) and _os.environ.get('FSV_SPADE_FAST', '1') == '1'
+        if ctx.fast:
+            ldw = 2 * c
+            prepped, wg_p, wb_p, bg_p, bb_p, wstr, bstr = [], [], [], [], [], [], []
+            for k in range(nmaps):
+                wg, wb, bg, bb = wgs[k].detach(), wbs[k].detach(), bgs[k].detach(), bbs[k].detach()
+                per_sample = wg.dim() == 5
+                ch = chs[k]
+
+                def inner_ok(t):
+                    return t.stride(-4) == ch and t.stride(-3) == 1
+                if not inner_ok(wg):
+                    wg = wg.contiguous()
+                if not inner_ok(wb):
+                    wb = wb.contiguous()
+                if bg.stride(-1) != 1:
+                    bg = bg.contiguous()
+                if bb.stride(-1) != 1:
+                    bb = bb.contiguous()
+                nb = n if per_sample else 1
+                kt, kd, ld = (ch + 31) // 32 * 32, (2 * c + 31) // 32 * 32, (ch + 31) // 32 * 32
+                wcat_t = torch.empty((nb, kt, 2 * c), dtype=torch.float32, device=x.device)
+                need_d = ctx.needs_input_grad[7 + 5 * k]
+                wcat_d = torch.empty((nb, kd, ld), dtype=torch.float32, device=x.device) if need_d else None
+                bcat = torch.empty((nb, 2 * c), dtype=torch.float32, device=x.device)
+                lib.check_device(wg, wb, bg, bb)
+                lib.call("fsv_spade_prep", lib.ptr(wg), lib.ptr(wb), lib.ptr(bg), lib.ptr(bb),
+                         wg.stride(0) if per_sample else 0, wb.stride(0) if per_sample else 0,
+                         bg.stride(0) if per_sample else 0, bb.stride(0) if per_sample else 0,
+                         lib.ptr(wcat_t), lib.ptr(wcat_d), lib.ptr(bcat), nb, c, ch, lib.stream_ptr())
+                prepped += [wcat_t, wcat_d if need_d else wcat_t[:0], bcat]
+                wg_p.append(wcat_t.data_ptr()); wb_p.append(wcat_t.data_ptr() + 4 * c)
+                bg_p.append(bcat.data_ptr()); bb_p.append(bcat.data_ptr() + 4 * c)
+                wstr.append(kt * 2 * c if per_sample else 0)
+                bstr.append(2 * c if per_sample else 0)
+            arr = lambda v: (ctypes.c_void_p * max(len(v), 1))(*v)
+            with profile.scope('fsv_spade_mod_kernel', 2.0 * n * h * w * c * 2 * sum(chs)):
+                lib.call("fsv_spade_mod_fwd", lib.ptr(x), lib.ptr(mean), lib.ptr(rstd), lib.ptr(hout), nmaps, _pp(maps),
+                         arr(wg_p), arr(wb_p), arr(bg_p), arr(bb_p), lib.int_array(chs + [0]), _ll(wstr + [0]),
+                         _ll(bstr + [0]), n, h * w, c, ldw, 0, act, lib.stream_ptr())
+            ctx.nmaps, ctx.act = nmaps, act
+            ctx.batch_stats = bool(training or run_mean is None)
+            ctx.per_sample = [wgs[k].dim() == 5 for k in range(nmaps)]
+            ctx.w_shapes = [tuple(wgs[k].shape) for k in range(nmaps)]
+            ctx.save_for_backward(x, hout, mean, rstd, *maps, *prepped)
+            return hout
+        wg_t, wb_t, bg_c, bb_c, wbs_stride, bbs_stride = [], [], [], [], [], []
+        ldw = (c + 31) // 32 * 32
+        for k in range(nmaps):
             per_sample = wgs[k].dim() == 5
             tg, kpad, _ = prep_weight(wgs[k].detach(), 0, g1)
             tb, _, _ = prep_weight(wbs[k].detach(), 0, g1)
             wg_t.append(tg); wb_t.append(tb)
             bg_c.append(bgs[k].detach().contiguous()); bb_c.append(bbs[k].detach().contiguous())
-            chs.append(maps[k].shape[1])
             wbs_stride.append(kpad * ldw if per_sample else 0)
             bbs_stride.append(c if per_sample else 0)
-        hout = torch.empty_like(x)
-        lib.check_device(x, *maps)
         with profile.scope('fsv_spade_mod_kernel', 2.0 * n * h * w * c * 2 * sum(chs)):
             lib.call("fsv_spade_mod_fwd", lib.ptr(x), lib.ptr(mean), lib.ptr(rstd), lib.ptr(hout), nmaps, _pp(maps),
                      _pp(wg_t), _pp(wb_t), _pp(bg_c), _pp(bb_c), lib.int_array(chs + [0]), _ll(wbs_stride + [0]),
@@ -570,22 +620,29 @@ class _SpadeFn(torch.autograd.Function):
         saved = ctx.saved_tensors
         x, hout, mean, rstd = saved[:4]
         maps = saved[4:4 + nm]
-        wgs = saved[4 + nm:4 + 2 * nm]
-        wbs = saved[4 + 2 * nm:4 + 3 * nm]
-        bgs = saved[4 + 3 * nm:4 + 4 * nm]
-        bbs = saved[4 + 4 * nm:4 + 5 * nm]
         dh = to_nhwc(dh)
         n, c, h, w = x.shape
         g1 = Geom(1, 1, 1, 0)
-        # 1) recompute gamma|beta of every map with the gather-GEMM kernel ([P][2C] each)
+        fast = ctx.fast
         gbs, wcats = [], []
-        for k in range(nm):
-            per_sample = wgs[k].dim() == 5
-            wcat = torch.cat([wgs[k].detach(), wbs[k].detach()], dim=-4)
-            bcat = torch.cat([bgs[k].detach(), bbs[k].detach()], dim=-1).contiguous()
-            wt, _, ldw = prep_weight(wcat, 0, g1)
-            gbs.append(conv_forward(maps[k], wt, ldw, 2 * c, g1, bias=bcat, per_sample=per_sample))
-            wcats.append(wcat)
+        if fast:
+            prepped = saved[4 + nm:]
+            for k in range(nm):
+                wcat_t, bcat = prepped[3 * k], prepped[3 * k + 2]
+                gbs.append(conv_forward(maps[k], wcat_t, 2 * c, 2 * c, g1, bias=bcat, per_sample=ctx.per_sample[k]))
+        else:
+            wgs = saved[4 + nm:4 + 2 * nm]
+            wbs = saved[4 + 2 * nm:4 + 3 * nm]
+            bgs = saved[4 + 3 * nm:4 + 4 * nm]
+            bbs = saved[4 + 4 * nm:4 + 5 * nm]
+            # 1) recompute gamma|beta of every map with the gather-GEMM kernel ([P][2C] each)
+            for k in range(nm):
+                per_sample = wgs[k].dim() == 5
+                wcat = torch.cat([wgs[k].detach(), wbs[k].detach()], dim=-4)
+                bcat = torch.cat([bgs[k].detach(), bbs[k].detach()], dim=-1).contiguous()
+                wt, _, ldw = prep_weight(wcat, 0, g1)
+                gbs.append(conv_forward(maps[k], wt, ldw, 2 * c, g1, bias=bcat, per_sample=per_sample))
+                wcats.append(wcat)
         # 2) elementwise chain backward
         dgbs = [torch.empty_like(gb) for gb in gbs]
         dxhat = torch.empty_like(x)
@@ -606,14 +663,30 @@ class _SpadeFn(torch.autograd.Function):
                 dx = dxhat * rstd.view(1, c, 1, 1)
         grads = []
         for k in range(nm):
-            per_sample = wgs[k].dim() == 5
+            per_sample = ctx.per_sample[k] if fast else wgs[k].dim() == 5
             base = 7 + 5 * k
             dm = dwg = dwb = dbg = dbb = None
-            if ctx.needs_input_grad[base]:
-                dm = conv_dgrad(dgbs[k], wcats[k], g1, (h, w), per_sample=per_sample)
-            if ctx.needs_input_grad[base + 1] or ctx.needs_input_grad[base + 2]:
-                dwcat = conv_wgrad(maps[k], dgbs[k], g1, tuple(wcats[k].shape), per_sample=per_sample)
-                dwg, dwb = torch.split(dwcat, c, dim=-4)
+            if fast:
+                ch = maps[k].shape[1]
+                if ctx.needs_input_grad[base]:
+                    wcat_d = prepped[3 * k + 1]
+                    dm = conv_dgrad(dgbs[k], None, g1, (h, w), per_sample=per_sample,
+                                    cached=[(wcat_d, wcat_d.shape[-1])], cin=ch)
+                if ctx.needs_input_grad[base + 1] or ctx.needs_input_grad[base + 2]:
+                    # operands swapped: rows = the 2C gamma|beta channels, columns = map channels, which IS the OIHW
+                    # layout of a 1x1 weight - no re-arrangement pass afterwards
+                    dwt = conv_wgrad(dgbs[k], maps[k], g1, (ch, 2 * c, 1, 1), per_sample=per_sample, raw=True)
+                    dwcat = dwt[:, :2 * c, :ch]
+                    dwcat = dwcat.unsqueeze(-1).unsqueeze(-1) if per_sample else dwcat[0].unsqueeze(-1).unsqueeze(-1)
+                    dwg, dwb = dwcat.narrow(-4, 0, c), dwcat.narrow(-4, c, c)
+                    if dwg.shape != ctx.w_shapes[k]:
+                        dwg, dwb = dwg.reshape(ctx.w_shapes[k]), dwb.reshape(ctx.w_shapes[k])
+            else:
+                if ctx.needs_input_grad[base]:
+                    dm = conv_dgrad(dgbs[k], wcats[k], g1, (h, w), per_sample=per_sample)
+                if ctx.needs_input_grad[base + 1] or ctx.needs_input_grad[base + 2]:
+                    dwcat = conv_wgrad(maps[k], dgbs[k], g1, tuple(wcats[k].shape), per_sample=per_sample)
+                    dwg, dwb = torch.split(dwcat, c, dim=-4)
             if ctx.needs_input_grad[base + 3] or ctx.needs_input_grad[base + 4]:
                 if per_sample:
                     dbcat = colsum(dgbs[k], n, h * w, 2 * c)

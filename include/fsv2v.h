@@ -83,6 +83,12 @@ int fsv_upload_i64(long long* dst, const long long* host_src, int n, fsv_stream_
 int fsv_conv_plan(int Mz, int Cout, int nchunks, int nsamp, int force_tile, int force_split, int* tile_out,
                   int* nsplit_out);
 
+/* One-launch operand preparation of a SPADE (gamma, beta) 1x1 weight pair (normalization.py:37-52): wg / wb [B][C][Ch]
+ * (sample strides swg / swb, 0 = shared), bg / bb [B][C] -> wcat_t [B][ceil32(Ch)][2C] (forward operand of map -> [gamma|beta]),
+ * wcat_d [B][ceil32(2C)][ceil32(Ch)] (data-gradient operand, may be NULL), bcat [B][2C].  C % 16 == 0. */
+int fsv_spade_prep(const float* wg, const float* wb, const float* bg, const float* bb, long long swg, long long swb,
+                   long long sbg, long long sbb, float* wcat_t, float* wcat_d, float* bcat, int B, int C, int Ch,
+                   fsv_stream_t stream);
 /* ---- SPADE (csrc/spade.hip) - replaces SPADE.forward normalization.py:37-52 + actvn architecture.py:95-97 --------
  * h = act( (...((x - mean) * rstd) * (1 + g_0) + b_0 ...) * (1 + g_{n-1}) + b_{n-1} ),  g_k = map_k @ Wg_k + bg_k.
  * One launch; gamma/beta are MFMA accumulators and never reach HBM. */

@@ -261,8 +261,10 @@ def check_norm(device, instance, n=3, c=10, h=7, w=5, affine=True, act='lrelu', 
         assert_close('running_var', rvd, rv)
 
 
-def check_spade(device, nmaps=1, generated=True, n=2, c=12, ch=8, h=6, w=5, act='lrelu', seed=5):
-    """SPADE with per-sample generated weights for map 0 and fixed weights for the extra maps."""
+def check_spade(device, nmaps=1, generated=True, n=2, c=12, ch=8, h=6, w=5, act='lrelu', seed=5, strided=False):
+    """SPADE with per-sample generated weights for map 0 and fixed weights for the extra maps.  strided: the generated
+    weights / biases are views into one [n, L] tensor, the way the weight-generating FC hands them over
+    (generator.py reshape_weight); c % 16 == 0 takes the single-preparation-launch path of ops._SpadeFn."""
     ops, conv = pkg()
     g = torch.Generator().manual_seed(seed)
     x = torch.randn(n, c, h, w, generator=g) + 0.3
@@ -280,7 +282,18 @@ def check_spade(device, nmaps=1, generated=True, n=2, c=12, ch=8, h=6, w=5, act=
     for k in range(nmaps):
         mr, md = leaf(maps[k])
         maps_r.append(mr); maps_d.append(md)
-        if k == 0 and generated:
+        if k == 0 and generated and strided:
+            half = c * ch + c
+            f_r, f_d = leaf(torch.randn(n, 2 * half + 3, generator=g) * 0.3)
+
+            def views(f):
+                a, b = f[:, :half], f[:, half:2 * half]
+                return (a[:, :-c].view(n, c, ch, 1, 1), b[:, :-c].view(n, c, ch, 1, 1), a[:, -c:], b[:, -c:])
+            wg_r, wb_r, bg_r, bb_r = views(f_r)
+            wg_d, wb_d, bg_d, bb_d = views(f_d)
+            gen_r = ((wg_r, bg_r), (wb_r, bb_r))
+            fixed_r.append(None)
+        elif k == 0 and generated:
             wg_r, wg_d = leaf(torch.randn(n, c, ch, 1, 1, generator=g) * 0.3)
             wb_r, wb_d = leaf(torch.randn(n, c, ch, 1, 1, generator=g) * 0.3)
             bg_r, bg_d = leaf(torch.randn(n, c, generator=g) * 0.3)

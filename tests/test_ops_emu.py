@@ -60,9 +60,12 @@ def test_norm_multi_chunk_multi_slab(emu_lib, n, c, h, w):
 
 
 @pytest.mark.parametrize("nmaps,generated,act,c,ch", [(1, True, 'lrelu', 12, 8), (3, True, 'none', 12, 8),
-                                                      (2, False, 'lrelu', 40, 12)])
+                                                      (2, False, 'lrelu', 40, 12), (3, True, 'lrelu', 32, 20),
+                                                      (2, False, 'none', 48, 12), (1, True, 'lrelu', 64, 32)])
 def test_spade(emu_lib, nmaps, generated, act, c, ch):
     oc.check_spade(DEV, nmaps=nmaps, generated=generated, act=act, c=c, ch=ch)
+    if generated:
+        oc.check_spade(DEV, nmaps=nmaps, generated=True, act=act, c=c, ch=ch, strided=True)
 
 
 def test_upsample(emu_lib):

@@ -66,6 +66,9 @@ def test_spade(hip_lib, nmaps, generated, act, c, ch):
     oc.check_spade(dev(), nmaps=nmaps, generated=generated, act=act, c=c, ch=ch)
     if c == 64:
         oc.check_spade(dev(), nmaps=nmaps, generated=generated, act=act, c=c, ch=ch, h=32, w=48)
+        oc.check_spade(dev(), nmaps=nmaps, generated=generated, act=act, c=c, ch=20, h=32, w=48, strided=True)
+    if generated:
+        oc.check_spade(dev(), nmaps=nmaps, generated=True, act=act, c=c, ch=ch, strided=True)
 
 
 def test_upsample(hip_lib):
