@@ -136,6 +136,26 @@ extern "C" int fsv_upload_i64(long long* dst, const long long* host_src, int n, 
   return fsv_check_launch();
 }
 
+// ---- grouped dst += src over many small tensors (norm weights / biases, fixed SPADE weights) ------------------------------------
+// table[job][3] = { src, dst, n }; tmap (job, 4096-element chunk).  Replaces one autograd AccumulateGrad add per parameter.
+__global__ __launch_bounds__(256) void fsv_gather_add_kernel(const long long* table, const int* tmap) {
+  const int job = tmap[blockIdx.x * 2], chunk = tmap[blockIdx.x * 2 + 1];
+  const float* src = reinterpret_cast<const float*>(table[job * 3]);
+  float* dst = reinterpret_cast<float*>(table[job * 3 + 1]);
+  const long long n = table[job * 3 + 2];
+#pragma unroll 4
+  for (int s = 0; s < 16; ++s) {
+    const long long i = (long long)chunk * 4096 + s * 256 + threadIdx.x;
+    if (i < n) dst[i] += src[i];
+  }
+}
+
+extern "C" int fsv_gather_add(const long long* table, int njobs, const int* tmap, int nblk, hipStream_t stream) {
+  if (!table || !tmap || njobs < 1 || nblk < 1) return FSV_ERR_BAD_ARG;
+  FSV_LAUNCH(fsv_gather_add_kernel, dim3(nblk), dim3(256), stream, table, tmap);
+  return fsv_check_launch();
+}
+
 extern "C" int fsv_wgrad_finalize(const long long* ptrs, const int* dims, const unsigned long long* taps, double* dots,
                                   int njobs, const int* tmap_dot, int nblk_dot, const int* tmap_apply, int nblk_apply,
                                   hipStream_t stream) {

@@ -56,6 +56,9 @@ class FlatAdam:
                                               os.environ.get('FSV_GRAD_SINK', '1') == '1' and
                                               os.environ.get('FSV_DEFER_WGRAD', '1') == '1') else None)
         self.offsets = []
+        self._grad_views = []          # the flat_g slice of every parameter (its .grad outside a backward pass)
+        self._loose = []               # parameters whose .grad is detached from flat_g for the current pass
+        self._steps_done = 0
         off = 0
         with torch.no_grad():
             for p in self.params:
@@ -63,6 +66,7 @@ class FlatAdam:
                 self.flat_p[off:off + n].copy_(p.detach().reshape(-1))
                 p.data = self.flat_p[off:off + n].view(p.shape)
                 p.grad = self.flat_g[off:off + n].view(p.shape)
+                self._grad_views.append(p.grad)
                 # single process: kernels may add gradients straight into the slice (ops._ConvFn "gradient sink");
                 # with a process group the autograd hooks below have to see every gradient, so the sink stays off
                 p._fsv_sink = (not self.overlap) and os.environ.get('FSV_GRAD_SINK', '1') == '1'
@@ -142,6 +146,16 @@ class FlatAdam:
         self.flat_g.zero_()
         if self.finalizer is not None:
             self.finalizer.begin_pass()       # drops jobs of a pass that was never stepped, zeroes the wgrad arena
+            # Small parameters that do not take their gradient through a kernel-side sink (norm weights / biases, fixed
+            # SPADE weights) would each cost an AccumulateGrad add launch into their flat_g slice.  Detach .grad for the
+            # pass instead - autograd then just keeps the incoming tensor - and fold all of them into flat_g with one
+            # grouped launch in finalize_grads().  Which parameters are sink-fed is known after the first step.
+            self._reattach()
+            if self._steps_done >= 1 and os.environ.get('FSV_LOOSE_GRADS', '1') == '1':
+                for i, p in enumerate(self.params):
+                    if not getattr(p, '_fsv_conv_param', False):
+                        p.grad = None
+                        self._loose.append(i)
         if self.overlap:
             self._remaining = [len(b[2]) for b in self.buckets]
             self._launched = [False] * len(self.buckets)
@@ -168,6 +182,19 @@ class FlatAdam:
         itself before the exchange / Adam step; call it explicitly to read `.grad` of a weight before stepping."""
         if self.finalizer is not None:
             self.finalizer.run()
+            if self._loose:
+                pairs = []
+                for i in self._loose:
+                    g = self.params[i].grad
+                    if g is not None:
+                        pairs.append((g.contiguous().view(-1), self._grad_views[i].view(-1)))
+                self.finalizer.gather_dense(pairs)
+                self._reattach()
+
+    def _reattach(self):
+        for i in self._loose:
+            self.params[i].grad = self._grad_views[i]
+        self._loose = []
 
     def exchange_all(self):
         """Non-overlapped mode: one all-reduce over the whole flat gradient buffer on the current stream."""
@@ -179,6 +206,7 @@ class FlatAdam:
         self.finalize_grads()
         ops.adam_step(self.flat_p, self.flat_g, self.m, self.v, self.state, self.betas[0], self.betas[1], self.eps,
                       1.0 / self.world_size)
+        self._steps_done += 1
         self.refresh_layouts()
 
     def refresh_layouts(self):

@@ -15,7 +15,8 @@ from . import lib
 
 c_p, c_i = ctypes.c_void_p, ctypes.c_int
 lib.register_sigs({"fsv_wgrad_finalize": [c_p, c_p, c_p, c_p, c_i, c_p, c_i, c_p, c_i, c_p],
-                   "fsv_upload_i64": [c_p, c_p, c_i, c_p]})
+                   "fsv_upload_i64": [c_p, c_p, c_i, c_p],
+                   "fsv_gather_add": [c_p, c_i, c_p, c_i, c_p]})
 
 DOT_CHUNK = 4096
 
@@ -85,6 +86,33 @@ class GradFinalizer:
         mk = lambda vals, dt: torch.tensor(vals if vals else [0], dtype=dt).to(dev)
         return (mk(dims, torch.int32), mk(taps, torch.int64), mk(tmap_dot, torch.int32), len(tmap_dot) // 2,
                 mk(tmap_apply, torch.int32), len(tmap_apply) // 3)
+
+    def gather_dense(self, pairs):
+        """pairs: [(src, dst)] contiguous fp32 tensors of equal numel; dst += src for all of them in one launch."""
+        pairs = [(a, b) for a, b in pairs if a.numel() > 0]
+        if not pairs:
+            return
+        dev = pairs[0][1].device
+        capturing = (not lib.is_emu()) and torch.cuda.is_current_stream_capturing()
+        key = ('dense',) + tuple(a.numel() for a, _ in pairs)
+        st = self._static.get(key)
+        if st is None:
+            if capturing:
+                raise lib.FsvError("new dense-gradient set inside a graph capture; run one eager step first")
+            tmap = []
+            for j, (a, _) in enumerate(pairs):
+                for ch in range((a.numel() + 4095) // 4096):
+                    tmap += [j, ch]
+            st = self._static[key] = (torch.tensor(tmap, dtype=torch.int32).to(dev), len(tmap) // 2)
+        tmap, nblk = st
+        words = []
+        for a, b in pairs:
+            lib.check_device(a, b)
+            words += [a.data_ptr(), b.data_ptr(), a.numel()]
+        host = (ctypes.c_longlong * len(words))(*words)
+        table = torch.empty(len(words), dtype=torch.int64, device=dev)
+        lib.call("fsv_upload_i64", lib.ptr(table), host, len(words), lib.stream_ptr())
+        lib.call("fsv_gather_add", lib.ptr(table), len(pairs), lib.ptr(tmap), nblk, lib.stream_ptr())
 
     def run(self):
         if not self.jobs:

@@ -435,8 +435,15 @@ class FewShotGenerator(nn.Module):
         return layers[last](x)
 
     @staticmethod
-    def _pair(x, cout, cin):
-        return [x[:, :-cout].reshape(x.shape[0], cout, cin, 1, 1), x[:, -cout:]]
+    def _pairs(f, npairs, cout, cin):
+        """f [b, L] -> npairs x [weight [b, cout, cin, 1, 1], bias [b, cout]] read off the front of each row
+        (generator.py reshape_weight slices the flattened FC output the same way).  torch.split instead of nested
+        slicing: its backward is ONE concatenation instead of a zero-fill + copy + add per slice."""
+        sizes = [cout * cin, cout] * npairs
+        rest = f.shape[1] - sum(sizes)
+        parts = torch.split(f, sizes + ([rest] if rest > 0 else []), dim=1)
+        b = f.shape[0]
+        return [[parts[2 * k].reshape(b, cout, cin, 1, 1), parts[2 * k + 1]] for k in range(npairs)]
 
     def get_SPADE_weights(self, feat, i):
         ch_in, ch_out = self.ch[i], self.ch[i + 1]
@@ -446,12 +453,12 @@ class FewShotGenerator(nn.Module):
         embedding_weights = None
         if self.adap_embed:
             fe = self._mlp('fc_spade_e', i, rows).view(b, -1)
-            embedding_weights = self._pair(fe[:, :-ch_in], ch_in, ch_out)
+            # the reference drops the trailing ch_in entries, then reads weight | bias off what is left: the same split
+            embedding_weights = self._pairs(fe, 1, ch_in, ch_out)[0]
 
         def two(name, co):
             f = self._mlp(name, i, rows).view(b, -1)
-            half = co * ch_h + co
-            return [self._pair(f[:, :half], co, ch_h), self._pair(f[:, half:2 * half], co, ch_h)]
+            return self._pairs(f, 2, co, ch_h)
         return embedding_weights, [two('fc_spade_0', ch_out), two('fc_spade_1', ch_in), two('fc_spade_s', ch_out)]
 
     def reference_encoding(self, img_ref, label_ref):

@@ -293,6 +293,9 @@ class _ConvFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, res, sig, u, v, geom, act, scale, uv_owned=False):
         x = to_nhwc(x)
+        weight._fsv_conv_param = True          # FlatAdam: these parameters take their gradients through the sink
+        if bias is not None:
+            bias._fsv_conv_param = True
         w4 = weight.detach()
         if w4.dim() == 2:                      # nn.Linear weight: a 1x1 convolution over a [1, in, 1, rows] "image"
             w4 = w4.view(w4.shape[0], w4.shape[1], 1, 1)

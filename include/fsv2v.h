@@ -76,6 +76,9 @@ int fsv_prep_weight_grouped(const long long* src, const long long* dst, const in
  * spectral jobs; tmap_apply (job, 32-co tile, ci tile) triples (ci tile = 32 channels for <= 8 taps, else 16). */
 int fsv_wgrad_finalize(const long long* ptrs, const int* dims, const unsigned long long* taps, double* dots, int njobs,
                        const int* tmap_dot, int nblk_dot, const int* tmap_apply, int nblk_apply, fsv_stream_t stream);
+/* dst += src over njobs small contiguous fp32 tensors in one launch: table[job][3] = {src, dst, n}, tmap (job, 4096-element
+ * chunk) pairs.  Folds the separately accumulated gradients of small parameters into the flat gradient buffer. */
+int fsv_gather_add(const long long* table, int njobs, const int* tmap, int nblk, fsv_stream_t stream);
 /* n 64-bit words from host memory into a device array, carried in kernel arguments (legal inside a graph capture,
  * no staging buffer); used for the per-pass pointer table of fsv_wgrad_finalize */
 int fsv_upload_i64(long long* dst, const long long* host_src, int n, fsv_stream_t stream);

@@ -482,7 +482,21 @@ def check_layout_cache(device, opt, b=1, seed=41, tol=1e-5):
         losses = torch.stack([x.detach().reshape(()) for x in list(d_losses) + list(g_losses) if torch.is_tensor(x)])
         grads = torch.cat([p.grad.reshape(-1) for p in model.parameters() if p.grad is not None])
         return losses.cpu(), grads.cpu().clone()
-    l1, g1 = iteration(*build(True, True))
+    m1 = build(True, True)
+    l1, g1 = iteration(*m1)
+    # second pass: small parameters now collect their gradients outside flat_g and are folded in by one grouped launch
+    # (flat.py zero_grad / finalize_grads); same numbers as a second pass with that switched off
+    assert m1[1]._steps_done >= 1
+    _, g1b = iteration(*m1)
+    assert all(p.grad is not None and p.grad.data_ptr() == v.data_ptr() for p, v in zip(m1[1].params, m1[1]._grad_views))
+    os.environ['FSV_LOOSE_GRADS'] = '0'
+    try:
+        m2 = build(True, True)
+        iteration(*m2)
+        _, g2b = iteration(*m2)
+    finally:
+        os.environ.pop('FSV_LOOSE_GRADS', None)
+    assert float((g1b - g2b).double().norm() / g2b.double().norm()) < 1e-6
     l0, g0 = iteration(*build(False, True))
     assert torch.allclose(l1, l0, rtol=tol, atol=tol), (l1, l0)
     rel = float((g1 - g0).double().norm() / g0.double().norm())
