@@ -37,6 +37,9 @@ CONFIGS = {
                   '--no_flow_gt --no_vgg_loss --gpu_ids -1 --ngf 8 --ndf 8 --nff 8 --batchSize 2',
 }
 CONFIGS['pose_combine_vgg'] = CONFIGS['pose_combine'].replace(' --no_vgg_loss', '')    # + VGG19 perceptual loss
+# street: integer class maps, one-hot encoded by encode_label (input_process.py:25-45); default aspect_ratio 2 -> 32 x 64
+CONFIGS['street'] = ('--dataset_mode fewshot_street --label_nc 7 --fineSize 64 --loadSize 64 --adaptive_spade --no_flow_gt '
+                     '--no_vgg_loss --gpu_ids -1 --ngf 8 --ndf 8 --batchSize 2')
 LAYOUT_CONFIGS = {
     'C3_pose_512': '--dataset_mode fewshot_pose --aspect_ratio 1 --fineSize 512 --loadSize 512 --adaptive_spade --warp_ref '
                    '--spade_combine --remove_face_labels --no_flow_gt --no_vgg_loss --gpu_ids -1',
@@ -59,6 +62,7 @@ def layout():
 
 def step(name, flags):
     import model_checks as mc
+    ref_import.install_shims()
     from models.loss_collector import loss_backward
     opt, model = ref_import.build_model(flags.split())
     mc.fill_state(model.netG)
@@ -67,7 +71,12 @@ def step(name, flags):
         for g in o.param_groups:
             g['lr'] = 0.0
     nl = opt.label_nc if opt.label_nc != 0 else opt.input_nc
-    tl, ti, rl, ri = mc.synth_pose_inputs(2, 64, 64, 4242, nl)
+    h, w = int(opt.fineSize / opt.aspect_ratio), opt.fineSize
+    if 'street' in opt.dataset_mode:
+        tl, ti, rl, ri = mc.synth_street_inputs(2, h, w, 4242, opt.label_nc)
+    else:
+        h = w = 64                       # the pose / face goldens were minted square (pose: --aspect_ratio 1)
+        tl, ti, rl, ri = mc.synth_pose_inputs(2, 64, 64, 4242, nl)
     data = [tl, ti, [None, None], [None, None], rl, ri, None, None, None]
     d_losses = model(data, mode='discriminator')
     d_losses = loss_backward(opt, d_losses, model.optimizer_D, 1)
@@ -79,7 +88,7 @@ def step(name, flags):
 
     def t(x):
         return None if x is None else x.detach().clone()
-    torch.save(dict(flags=flags, seed=4242, batch=2, size=64,
+    torch.save(dict(flags=flags, seed=4242, batch=2, size=64, hw=(h, w),
                     d_losses=[float(x) for x in d_losses], g_losses=[float(x) for x in g_losses],
                     loss_names=model.lossCollector.loss_names,
                     fake=t(fake), raw=t(raw), warp=[t(w) for w in warped], flow=[t(f) for f in flow],
@@ -144,6 +153,10 @@ def warp_taps():
 
 if __name__ == '__main__':
     os.makedirs(OUT, exist_ok=True)
+    if len(sys.argv) > 1:                # mint only the named step cases (keeps the other fixtures byte-identical)
+        for n in sys.argv[1:]:
+            step(n, CONFIGS[n])
+        sys.exit(0)
     layout()
     for n, f in CONFIGS.items():
         step(n, f)

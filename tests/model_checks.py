@@ -97,6 +97,17 @@ def synth_pose_inputs(b, h, w, seed=1234, n_label=6):
     return tgt_label, tgt_image, ref_label, ref_image
 
 
+def synth_street_inputs(b, h, w, seed=1234, n_classes=20):
+    """SURVEY.md section 8(d) C5-style tensors: integer class maps (as float, blocky regions) and images U(-1,1)."""
+    g = torch.Generator().manual_seed(seed)
+
+    def label():
+        coarse = torch.randint(0, n_classes, (b, 1, max(h // 8, 2), max(w // 8, 2)), generator=g).float()
+        return torch.nn.functional.interpolate(coarse, size=(h, w), mode='nearest').unsqueeze(1)
+    _, ti, _, ri = synth_pose_inputs(b, h, w, seed + 1, 1)
+    return label(), ti, label(), ri
+
+
 def _net():
     import fsv2v_amd  # noqa: F401
     return import_module('few-shot-vid2vid_amd.networks')
@@ -310,7 +321,7 @@ def check_train_step(device, opt, b=2, tol=1e-3, seed=21, grad_tol=2e-2):
     opt_G.set_lr(0.0); opt_D.set_lr(0.0)          # keep weights fixed so that both steps see the same parameters
     h, w = int(opt.fineSize / opt.aspect_ratio), opt.fineSize
     nl = opt.label_nc if opt.label_nc != 0 else opt.input_nc
-    data = synth_pose_inputs(b, h, w, seed, nl)
+    data = synth_street_inputs(b, h, w, seed, opt.label_nc) if opt.label_nc != 0 else synth_pose_inputs(b, h, w, seed, nl)
     cfg = O.cfg_from_opt(opt)
     vw = _vgg_weights(opt)
     r32 = _oracle_iteration(sdG0, sdD0, cfg, data, torch.float32, vw)

@@ -14,7 +14,7 @@ import model_checks as mc
 from oracle import fsv_oracle as O
 
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
-CASES = ['pose_combine', 'face', 'pose_blend', 'pose_combine_vgg']
+CASES = ['pose_combine', 'face', 'pose_blend', 'pose_combine_vgg', 'street']
 
 
 def _opt_from_flags(flags):
@@ -30,6 +30,8 @@ def _opt_from_flags(flags):
             kw[ints[t]] = int(toks[i + 1]); i += 2
         elif t == '--dataset_mode':
             kw['dataset_mode'] = toks[i + 1]; i += 2
+        elif t == '--label_nc':
+            kw['label_nc'] = int(toks[i + 1]); i += 2
         elif t == '--aspect_ratio':
             kw['aspect_ratio'] = float(toks[i + 1]); i += 2
         elif t == '--gpu_ids':
@@ -41,8 +43,20 @@ def _opt_from_flags(flags):
             raise ValueError(t)
     if kw.get('dataset_mode') == 'fewshot_face':
         kw.setdefault('input_nc', 1)
+    if kw.get('dataset_mode') == 'fewshot_street':          # data/fewshot_street_dataset.py:18-22 defaults
+        kw.setdefault('input_nc', 3)
+        kw.setdefault('aspect_ratio', 2.0)
     kw.setdefault('no_vgg_loss', False)          # the reference's default: VGG perceptual loss on
     return mc.make_opt(**kw)
+
+
+def _inputs(g, opt):
+    """the seeded synthetic tensors the fixture was minted on"""
+    if 'street' in opt.dataset_mode:
+        h, w = g['hw']
+        return mc.synth_street_inputs(g['batch'], h, w, g['seed'], opt.label_nc)
+    nl = opt.label_nc if opt.label_nc != 0 else opt.input_nc
+    return mc.synth_pose_inputs(g['batch'], g['size'], g['size'], g['seed'], nl)
 
 
 def _load(case):
@@ -67,8 +81,7 @@ def test_oracle_reproduces_reference_iteration(case):
     M = mc._model()
     model = M.create_model(opt)            # used only for parameter shapes / names (CPU, nothing is launched)
     sdG0, sdD0 = mc.fill_state(model.netG), mc.fill_state(model.netD)
-    nl = opt.label_nc if opt.label_nc != 0 else opt.input_nc
-    data = mc.synth_pose_inputs(g['batch'], g['size'], g['size'], g['seed'], nl)
+    data = _inputs(g, opt)
     d_losses, gD, g_losses, gG, gen = mc._oracle_iteration(sdG0, sdD0, O.cfg_from_opt(opt), data, torch.float32,
                                                            mc._vgg_weights(opt))
     names = g['loss_names']
@@ -131,7 +144,7 @@ def test_product_reproduces_reference_iteration_on_gpu(hip_lib, case):
     opt_G, opt_D = model.build_optimizers()
     opt_G.set_lr(0.0); opt_D.set_lr(0.0)
     nl = opt.label_nc if opt.label_nc != 0 else opt.input_nc
-    tl, ti, rl, ri = [t.to(dev) for t in mc.synth_pose_inputs(g['batch'], g['size'], g['size'], g['seed'], nl)]
+    tl, ti, rl, ri = [t.to(dev) for t in _inputs(g, opt)]
     data = [tl, ti, [None, None], [None, None], rl, ri, None, None, None]
     d = M.loss_backward(opt, model(data, mode='discriminator'), opt_D, 1)
     gl, generated, _ = model(data, save_images=True, mode='generator')

@@ -43,3 +43,9 @@ def test_train_step_with_vgg_loss_tiny(emu_lib):
 def test_layout_cache_matches_per_call_prep_tiny(emu_lib):
     """persistent K-major weight layouts + grouped refresh after Adam == per-call re-arrangement"""
     mc.check_layout_cache(DEV, mc.tiny_opt(warp_ref=True, spade_combine=True, remove_face_labels=True), b=1)
+
+
+def test_train_step_street_one_hot_tiny(emu_lib):
+    """BASELINE configs[4] flavour: fewshot_street, integer class maps one-hot encoded on the way in (label_nc classes),
+    adaptive_spade only, 2:1 aspect."""
+    mc.check_train_step(DEV, mc.tiny_opt(dataset_mode='fewshot_street', label_nc=7, input_nc=3, aspect_ratio=2.0), b=1)
