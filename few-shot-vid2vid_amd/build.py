@@ -65,20 +65,33 @@ def build_hip(force=False, verbose=False):
             for r in ex.map(_run, jobs):
                 if verbose and r.stderr:
                     print(r.stderr)
-    stamp = os.path.join(OBJ_DIR, "hip.link." + _digest(objs)[:16])
-    if force or jobs or not os.path.exists(HIP_LIB) or not os.path.exists(stamp):
+    # one "current" record per library (not one stamp per digest: after switching sources back and forth an old stamp
+    # would claim that the library on disk still matches)
+    if force or jobs or not os.path.exists(HIP_LIB) or _current("hip") != _digest(objs):
         _run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", HIP_LIB] + objs)
-        open(stamp, "w").close()
+        _set_current("hip", _digest(objs))
     return HIP_LIB
+
+
+def _current(which):
+    try:
+        with open(os.path.join(OBJ_DIR, which + ".current")) as f:
+            return f.read().strip()
+    except OSError:
+        return None
+
+
+def _set_current(which, digest):
+    with open(os.path.join(OBJ_DIR, which + ".current"), "w") as f:
+        f.write(digest)
 
 
 def build_emu(force=False):
     os.makedirs(OBJ_DIR, exist_ok=True)
     srcs = _sources()
     emu_h = os.path.join(ROOT, "tests", "emu", "hip_emu.h")
-    tag = _digest(srcs + _headers() + [emu_h], "emu")[:16]
-    stamp = os.path.join(OBJ_DIR, "emu." + tag)
-    if not force and os.path.exists(EMU_LIB) and os.path.exists(stamp):
+    tag = _digest(srcs + _headers() + [emu_h], "emu")
+    if not force and os.path.exists(EMU_LIB) and _current("emu") == tag:
         return EMU_LIB
     unity = os.path.join(OBJ_DIR, "fsv_emu_unity.cpp")
     with open(unity, "w") as f:
@@ -87,7 +100,7 @@ def build_emu(force=False):
     _run([CLANGXX, "-x", "c++", "-DFSV_EMU", "-O2", "-std=c++17", "-fPIC", "-ffp-contract=off", "-mfma",
           "-Wno-unused-value", "-I", CSRC, "-I", os.path.join(ROOT, "include"), "-I", os.path.join(ROOT, "tests", "emu"),
           "-shared", "-o", EMU_LIB, unity])
-    open(stamp, "w").close()
+    _set_current("emu", tag)
     return EMU_LIB
 
 

@@ -118,8 +118,12 @@ class LossCollector:
         self.loss_names_G, self.loss_names_D = LOSS_NAMES_G, LOSS_NAMES_D
         self.loss_names = LOSS_NAMES_G + LOSS_NAMES_D
         self.tD = 1
-        if opt.add_face_D:
-            raise NotImplementedError("the face discriminator is a next row of SURVEY.md 8(f)")
+        self.face_size = int(opt.fineSize / opt.aspect_ratio) // 4                  # face_refiner.py:21
+        self.use_openpose = not opt.basic_point_only and not opt.remove_face_labels     # face_refiner.py:62
+        if opt.add_face_D and opt.no_vgg_loss:
+            # the reference adds criterionVGG(fake_region, real_region) unconditionally (loss_collector.py:83) and
+            # fails with an AttributeError in this combination
+            raise ValueError("--add_face_D needs the VGG loss (drop --no_vgg_loss), as in the reference")
         self.vgg = None
         if not opt.no_vgg_loss:
             from .vgg import VGGLoss
@@ -159,8 +163,32 @@ class LossCollector:
                     feat = feat + l1(a, b.detach()) / len(pred_fake)
         return [gan_loss(pred_fake, True), feat * self.opt.lambda_feat]
 
-    def gan_losses(self, netD, tgt_label, reals, fakes, ref_label, ref_image, for_discriminator):
-        """loss_collector.py:87-120 for the per-frame discriminator (no temporal / face branches)."""
+    def crop_face_region(self, image, label):
+        """face_refiner.py:32-39: device-side boxes + one crop/resize launch (csrc/face.hip)."""
+        boxes = ops.face_boxes(label, self.use_openpose)
+        if isinstance(image, (list, tuple)):
+            return [ops.crop_face(im, boxes, self.face_size) for im in image]
+        return ops.crop_face(image, boxes, self.face_size)
+
+    def discriminate_face(self, netDf, fake, tgt_label, real, ref_label, ref_image, for_discriminator):
+        """loss_collector.py:69-85.  ref_label is what compute_GAN_losses holds at that point: the valid-label version
+        with the foreground mask appended (so the OpenPose branch of get_face_region reads shifted channels and the
+        DensePose branch sees the face already blanked by --remove_face_labels) - reproduced as is."""
+        if not self.add_face_D:
+            return [self.zero(fake), self.zero(fake)]
+        real_region, fake_region = self.crop_face_region([real, fake], tgt_label)
+        ref_region = self.crop_face_region(ref_image, ref_label)
+        losses = self.discriminate(netDf, ref_region, fake_region, real_region, None, for_discriminator)
+        losses = [l * self.opt.lambda_face for l in losses]
+        if for_discriminator:
+            return losses
+        gf_gan, gf_feat = losses
+        gf_feat = gf_feat + l1(fake_region, real_region) * self.opt.lambda_feat
+        gf_feat = gf_feat + self.vgg(fake_region, real_region) * self.opt.lambda_vgg
+        return [gf_gan, gf_feat]
+
+    def gan_losses(self, netD, tgt_label, reals, fakes, ref_label, ref_image, for_discriminator, netDf=None):
+        """loss_collector.py:87-120 for the per-frame discriminator and the face discriminator (no temporal branch)."""
         opt = self.opt
         total = None
         for fake, real in zip(fakes, reals):
@@ -176,7 +204,7 @@ class LossCollector:
                 rl = torch.cat([ref_label, fg_mask_of(opt, ref_label, True)], dim=1)
             ref_concat = torch.cat([rl, ref_image], dim=1)
             losses = self.discriminate(netD, inp, fake4, real4, ref_concat, for_discriminator)
-            losses = losses + [self.zero(fake4), self.zero(fake4)]           # face-D slots
+            losses = losses + self.discriminate_face(netDf, fake4, lab, real4, rl, ref_image, for_discriminator)
             total = losses if total is None else [a + b for a, b in zip(total, losses)]
         return total
 
@@ -263,6 +291,9 @@ class Vid2VidModel(nn.Module):
         self.netD = networks.define_D(opt, netD_input_nc, opt.ndf, opt.n_layers_D, opt.norm_D, opt.netD_subarch,
                                       opt.num_D, not opt.no_ganFeat_loss)
         self.netDf = None
+        if self.add_face_D:                # base_model.py:191-193: 6 channels = reference face region | image face region
+            self.netDf = networks.define_D(opt, opt.output_nc * 2, opt.ndf, opt.n_layers_D, opt.norm_D, 'n_layers', 1,
+                                           not opt.no_ganFeat_loss)
         self.netDT = None
         self.optimizer_G = self.optimizer_D = None
         return self
@@ -282,7 +313,10 @@ class Vid2VidModel(nn.Module):
             beta1, beta2, g_lr, d_lr = 0.0, opt.beta2, opt.lr / 2, opt.lr * 2
         self.optimizer_G = FlatAdam(list(self.netG.parameters()), g_lr, (beta1, beta2), world_size, process_group,
                                     force_exchange=force_exchange, overlap=overlap)
-        self.optimizer_D = FlatAdam(list(self.netD.parameters()), d_lr, (beta1, beta2), world_size, process_group,
+        d_params = list(self.netD.parameters())
+        if self.netDf is not None:         # base_model.py:209-211
+            d_params += list(self.netDf.parameters())
+        self.optimizer_D = FlatAdam(d_params, d_lr, (beta1, beta2), world_size, process_group,
                                     force_exchange=force_exchange, overlap=overlap)
         return self.optimizer_G, self.optimizer_D
 
@@ -361,7 +395,7 @@ class Vid2VidModel(nn.Module):
         fg_union = union_fg(fg, ref_fg, self.has_fg)
         real = tgt_image[:, 0]
         losses = self.lossCollector.gan_losses(self.netD, tgt_label, [real, real * fg_union], [fake, raw], ref_label,
-                                               ref_image, for_discriminator=True)
+                                               ref_image, for_discriminator=True, netDf=self.netDf)
         return [l.view(1, 1) for l in losses]
 
     def forward_generator(self, tgt_label, tgt_image, ref_labels, ref_images, prevs):
@@ -374,11 +408,14 @@ class Vid2VidModel(nn.Module):
         # The G step only needs d(loss)/d(fake) from the discriminator.  The reference lets autograd also fill the
         # discriminator's (unused, later zeroed) weight gradients; skipping them changes no result of either step.
         d_params = [p for p in self.netD.parameters() if p.requires_grad]
+        if self.netDf is not None:
+            d_params += [p for p in self.netDf.parameters() if p.requires_grad]
         for p in d_params:
             p.requires_grad_(False)
         try:
             g_gan, g_feat, gf_gan, gf_feat = lc.gan_losses(self.netD, tgt_label, [real, real * fg_union], [fake, raw],
-                                                           ref_label, ref_image, for_discriminator=False)
+                                                           ref_label, ref_image, for_discriminator=False,
+                                                           netDf=self.netDf)
         finally:
             for p in d_params:
                 p.requires_grad_(True)

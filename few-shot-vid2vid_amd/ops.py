@@ -16,7 +16,7 @@ import torch
 
 from . import lib, profile
 from .conv import (ACT_LRELU, ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_TANH, Geom, conv_dgrad, conv_forward, conv_wgrad, empty_nhwc,
-                   prep_weight, to_nhwc)
+                   prep_weight, to_nhwc, zeros_nhwc)
 
 c_p, c_i, c_ll, c_f = ctypes.c_void_p, ctypes.c_int, ctypes.c_longlong, ctypes.c_float
 c_llp = ctypes.POINTER(ctypes.c_longlong)
@@ -573,7 +573,11 @@ class _SpadeFn(torch.autograd.Function):
                     bb = bb.contiguous()
                 nb = n if per_sample else 1
                 kt, kd, ld = (ch + 31) // 32 * 32, (2 * c + 31) // 32 * 32, (ch + 31) // 32 * 32
-                wcat_t = torch.empty((nb, kt, 2 * c), dtype=torch.float32, device=x.device)
+                # + 64 floats of slack: the beta half is addressed as (wcat_t + C) with the same row stride, so a channel
+                # tile that overhangs C (C not a multiple of the 32 / 64-wide tile) reads past the last row's end; those
+                # columns only feed output channels >= C, which are never stored
+                flat_t = torch.empty(nb * kt * 2 * c + 64, dtype=torch.float32, device=x.device)
+                wcat_t = flat_t[:nb * kt * 2 * c].view(nb, kt, 2 * c)
                 need_d = ctx.needs_input_grad[7 + 5 * k]
                 wcat_d = torch.empty((nb, kd, ld), dtype=torch.float32, device=x.device) if need_d else None
                 bcat = torch.empty((nb, 2 * c), dtype=torch.float32, device=x.device)
@@ -959,6 +963,55 @@ def part_masks(pose_ch, g0=0, ngroups=9):
     lib.call("fsv_part_masks", lib.ptr(pose_ch), lib.ptr(y), b * t, h * w, t, pose_ch.stride(0), pose_ch.stride(1), g0, ngroups,
              lib.stream_ptr())
     return y
+
+
+lib.register_sigs({
+    "fsv_face_boxes": [c_p, c_ll, c_ll, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_p],
+    "fsv_crop_resize_fwd": [c_p, c_ll, c_ll, c_ll, c_ll, c_i, c_p, c_p, c_i, c_i, c_p],
+    "fsv_crop_resize_bwd": [c_p, c_p, c_p, c_ll, c_ll, c_ll, c_ll, c_i, c_i, c_i, c_p],
+})
+
+
+def face_boxes(label, use_openpose, crop_smaller=0):
+    """face_refiner.py:56-87 get_face_region for every sample of label [N, C, H, W]: int32 [N, 4] = (ys, ye, xs, xe),
+    computed and kept on the device (the reference syncs the host through .nonzero() / .item() per sample)."""
+    n, c, h, w = label.shape
+    if label.stride(3) != 1 or label.stride(2) != w:
+        label = label.contiguous()
+    boxes = torch.empty((n, 4), dtype=torch.int32, device=label.device)
+    lib.check_device(label)
+    lib.call("fsv_face_boxes", lib.ptr(label), label.stride(0), label.stride(1), n, c, h, w, 1 if use_openpose else 0,
+             int(crop_smaller), lib.ptr(boxes), lib.stream_ptr())
+    return boxes
+
+
+class _CropFaceFn(torch.autograd.Function):
+    """face_refiner.py:32-39 crop_face_region: F.interpolate(image[i, -3:, ys:ye, xs:xe], size=(S, S)) for all i."""
+
+    @staticmethod
+    def forward(ctx, image, boxes, size):
+        n, c, h, w = image.shape
+        out = torch.empty((n, 3, size, size), dtype=torch.float32, device=image.device)
+        lib.check_device(image, boxes)
+        lib.call("fsv_crop_resize_fwd", lib.ptr(image), image.stride(0), image.stride(1), image.stride(2), image.stride(3),
+                 c, lib.ptr(boxes), lib.ptr(out), n, size, lib.stream_ptr())
+        ctx.save_for_backward(boxes)
+        ctx.meta = (tuple(image.shape), size)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        (boxes,) = ctx.saved_tensors
+        (n, c, h, w), size = ctx.meta
+        dimg = zeros_nhwc(n, c, h, w, dout)
+        dout = dout.contiguous()
+        lib.call("fsv_crop_resize_bwd", lib.ptr(dout), lib.ptr(boxes), lib.ptr(dimg), dimg.stride(0), dimg.stride(1),
+                 dimg.stride(2), dimg.stride(3), c, n, size, lib.stream_ptr())
+        return dimg, None, None
+
+
+def crop_face(image, boxes, size):
+    return _CropFaceFn.apply(image, boxes, size)
 
 
 def pool15(x, mode, thresh=0.0):

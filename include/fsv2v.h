@@ -186,6 +186,17 @@ int fsv_part_masks(const float* x, float* y, long long N, long long P, int T, lo
 int fsv_pool15(const float* x, float* y, int N, int H, int W, long long sn, long long sy, long long sx, int mode, float thresh,
                fsv_stream_t stream);
 
+/* ---- face-region discriminator inputs (--add_face_D; models/face_refiner.py:32-39, 56-87), csrc/face.hip ----
+ * boxes[n] = {ys, ye, xs, xe} of the face in label map n (pose [N][C][H][W], strides sn / sc, rows contiguous), computed
+ * on the device; crop + F.interpolate(nearest, size S) of the last three channels of img for every sample in one launch,
+ * and its gradient scattered into a zero-initialised dimg of img's layout. */
+int fsv_face_boxes(const float* pose, long long sn, long long sc, int N, int C, int H, int W, int use_openpose,
+                   int crop_smaller, int* boxes, fsv_stream_t stream);
+int fsv_crop_resize_fwd(const float* img, long long sn, long long sc, long long sy, long long sx, int C, const int* boxes,
+                        float* out, int N, int S, fsv_stream_t stream);
+int fsv_crop_resize_bwd(const float* dout, const int* boxes, float* dimg, long long sn, long long sc, long long sy,
+                        long long sx, int C, int N, int S, fsv_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

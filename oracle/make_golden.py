@@ -37,6 +37,10 @@ CONFIGS = {
                   '--no_flow_gt --no_vgg_loss --gpu_ids -1 --ngf 8 --ndf 8 --nff 8 --batchSize 2',
 }
 CONFIGS['pose_combine_vgg'] = CONFIGS['pose_combine'].replace(' --no_vgg_loss', '')    # + VGG19 perceptual loss
+# BASELINE configs[3] flavour: the face discriminator on top of the pose flags (needs the VGG loss, see loss_collector.py:83)
+# 128 x 128 so that the 32 x 32 face crops survive torchvision-style VGG19's five max-pools
+CONFIGS['pose_face_d'] = CONFIGS['pose_combine_vgg'].replace('--fineSize 64 --loadSize 64', '--fineSize 128 --loadSize 128') \
+    + ' --add_face_D'
 # street: integer class maps, one-hot encoded by encode_label (input_process.py:25-45); default aspect_ratio 2 -> 32 x 64
 CONFIGS['street'] = ('--dataset_mode fewshot_street --label_nc 7 --fineSize 64 --loadSize 64 --adaptive_spade --no_flow_gt '
                      '--no_vgg_loss --gpu_ids -1 --ngf 8 --ndf 8 --batchSize 2')
@@ -67,6 +71,8 @@ def step(name, flags):
     opt, model = ref_import.build_model(flags.split())
     mc.fill_state(model.netG)
     mc.fill_state(model.netD)
+    if model.netDf is not None:
+        mc.fill_state(model.netDf)
     for o in (model.optimizer_G, model.optimizer_D):
         for g in o.param_groups:
             g['lr'] = 0.0
@@ -75,12 +81,13 @@ def step(name, flags):
     if 'street' in opt.dataset_mode:
         tl, ti, rl, ri = mc.synth_street_inputs(2, h, w, 4242, opt.label_nc)
     else:
-        h = w = 64                       # the pose / face goldens were minted square (pose: --aspect_ratio 1)
-        tl, ti, rl, ri = mc.synth_pose_inputs(2, 64, 64, 4242, nl)
+        tl, ti, rl, ri = mc.synth_pose_inputs(2, h, w, 4242, nl)
     data = [tl, ti, [None, None], [None, None], rl, ri, None, None, None]
     d_losses = model(data, mode='discriminator')
     d_losses = loss_backward(opt, d_losses, model.optimizer_D, 1)
     gD = {k: float(p.grad.norm()) for k, p in model.netD.named_parameters() if p.grad is not None}
+    gDf = {k: float(p.grad.norm()) for k, p in model.netDf.named_parameters() if p.grad is not None} \
+        if model.netDf is not None else {}
     g_losses, generated, prev = model(data, save_images=True, mode='generator')
     g_losses = loss_backward(opt, g_losses, model.optimizer_G, 0)
     gG = {k: float(p.grad.norm()) for k, p in model.netG.named_parameters() if p.grad is not None}
@@ -88,11 +95,11 @@ def step(name, flags):
 
     def t(x):
         return None if x is None else x.detach().clone()
-    torch.save(dict(flags=flags, seed=4242, batch=2, size=64, hw=(h, w),
+    torch.save(dict(flags=flags, seed=4242, batch=2, size=w, hw=(h, w),
                     d_losses=[float(x) for x in d_losses], g_losses=[float(x) for x in g_losses],
                     loss_names=model.lossCollector.loss_names,
                     fake=t(fake), raw=t(raw), warp=[t(w) for w in warped], flow=[t(f) for f in flow],
-                    mask=[t(m) for m in mask], grad_norm_D=gD, grad_norm_G=gG),
+                    mask=[t(m) for m in mask], grad_norm_D=gD, grad_norm_G=gG, grad_norm_Df=gDf),
                os.path.join(OUT, 'step_%s.pt' % name))
     print(name, 'D', [round(float(x), 5) for x in d_losses[:2]], 'G', [round(float(x), 5) for x in g_losses])
 

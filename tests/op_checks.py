@@ -484,6 +484,44 @@ def check_part_masks(device, seed=15):
     assert 0 < float(ref.mean()) < 1
 
 
+def check_face_ops(device, seed=17):
+    """csrc/face.hip: device-side face boxes == the reference's get_face_region integers for DensePose / OpenPose / empty
+    label maps, and the one-launch crop + nearest resize (and its gradient) == the per-sample slicing + F.interpolate."""
+    ops, conv = pkg()
+    g = torch.Generator().manual_seed(seed)
+    n, c, h, w, size = 5, 6, 64, 48, 16
+    label = torch.rand(n, c, h, w, generator=g) * 2 - 1
+    label[:, 2] = -1.0
+    label[:, 3:] = -1.0
+    label[0, 2, 10:31, 20:29] = 0.95                 # tall DensePose face
+    label[1, 2, 60:64, 0:3] = 1.0                    # at the border -> clamped centre
+    label[1, 3:, 5:12, 30:44] = 0.5                  # OpenPose key-points present
+    label[2, 2, 3, 3] = 0.92                         # single pixel -> minimum size 32
+    label[3, 2, 0:64, 0:48] = 0.91                   # everything -> capped at the width
+    # sample 4: no face at all -> default box
+    image = torch.randn(n, 5, h, w, generator=g)
+    for remove_face_labels in (True, False):
+        cfg = O.Cfg(fineSize=size * 4, aspect_ratio=1.0, remove_face_labels=remove_face_labels)
+        for crop_smaller in (0, 4):
+            want = [O.get_face_region(cfg, label[i:i + 1], crop_smaller) for i in range(n)]
+            got = ops.face_boxes(_dev(label, device), use_openpose=not remove_face_labels, crop_smaller=crop_smaller).cpu()
+            assert got.tolist() == [list(b) for b in want], (remove_face_labels, crop_smaller, got.tolist(), want)
+        img_r = image.clone().requires_grad_(True)
+        ref = O.crop_face_region(cfg, img_r, label)
+        dy = torch.randn(ref.shape, generator=g)
+        ref.backward(dy)
+        for nhwc in (False, True):
+            img_d = _dev(image, device)
+            if nhwc:
+                img_d = conv.to_nhwc(img_d)
+            img_d = img_d.detach().requires_grad_(True)
+            boxes = ops.face_boxes(_dev(label, device), use_openpose=not remove_face_labels)
+            out = ops.crop_face(img_d, boxes, size)
+            out.backward(_dev(dy, device))
+            assert torch.equal(out.detach().cpu(), ref.detach())
+            assert_close('crop face grad', img_d.grad, img_r.grad, 1e-6)
+
+
 def check_adam(device, n=1000, seed=9):
     ops, conv = pkg()
     g = torch.Generator().manual_seed(seed)
@@ -525,3 +563,4 @@ def run_all(device, big=False):
     check_warp_index_image(device)
     check_adam(device)
     check_part_masks(device)
+    check_face_ops(device)

@@ -14,7 +14,7 @@ import model_checks as mc
 from oracle import fsv_oracle as O
 
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
-CASES = ['pose_combine', 'face', 'pose_blend', 'pose_combine_vgg', 'street']
+CASES = ['pose_combine', 'face', 'pose_blend', 'pose_combine_vgg', 'street', 'pose_face_d']
 
 
 def _opt_from_flags(flags):
@@ -37,7 +37,7 @@ def _opt_from_flags(flags):
         elif t == '--gpu_ids':
             i += 2
         elif t in ('--adaptive_spade', '--warp_ref', '--spade_combine', '--remove_face_labels', '--no_flow_gt',
-                   '--no_vgg_loss'):
+                   '--no_vgg_loss', '--add_face_D'):
             kw[t[2:]] = True; i += 1
         else:
             raise ValueError(t)
@@ -82,9 +82,14 @@ def test_oracle_reproduces_reference_iteration(case):
     model = M.create_model(opt)            # used only for parameter shapes / names (CPU, nothing is launched)
     sdG0, sdD0 = mc.fill_state(model.netG), mc.fill_state(model.netD)
     data = _inputs(g, opt)
-    d_losses, gD, g_losses, gG, gen = mc._oracle_iteration(sdG0, sdD0, O.cfg_from_opt(opt), data, torch.float32,
-                                                           mc._vgg_weights(opt))
+    sdDf0 = mc.fill_state(model.netDf) if model.netDf is not None else None
+    d_losses, gD, g_losses, gG, gen, gDf = mc._oracle_iteration(sdG0, sdD0, O.cfg_from_opt(opt), data, torch.float32,
+                                                           mc._vgg_weights(opt), sdDf0)
     names = g['loss_names']
+    for i in range(2, len(d_losses)):              # Df_real, Df_fake with --add_face_D
+        assert abs(float(d_losses[i]) - g['d_losses'][i]) <= 1e-5 * max(1.0, abs(g['d_losses'][i])), i
+    for k, ref in g.get('grad_norm_Df', {}).items():
+        assert abs(float(gDf[k].norm()) - ref) <= 1e-4 * max(ref, 1e-6), k
     assert abs(float(d_losses[0]) - g['d_losses'][0]) <= 1e-5 * max(1.0, abs(g['d_losses'][0]))
     assert abs(float(d_losses[1]) - g['d_losses'][1]) <= 1e-5 * max(1.0, abs(g['d_losses'][1]))
     for k, v in g_losses.items():
@@ -140,6 +145,8 @@ def test_product_reproduces_reference_iteration_on_gpu(hip_lib, case):
     M = mc._model()
     model = M.create_model(opt)
     mc.fill_state(model.netG); mc.fill_state(model.netD)
+    if model.netDf is not None:
+        mc.fill_state(model.netDf)
     model = model.to(dev).train()
     opt_G, opt_D = model.build_optimizers()
     opt_G.set_lr(0.0); opt_D.set_lr(0.0)
@@ -149,8 +156,8 @@ def test_product_reproduces_reference_iteration_on_gpu(hip_lib, case):
     d = M.loss_backward(opt, model(data, mode='discriminator'), opt_D, 1)
     gl, generated, _ = model(data, save_images=True, mode='generator')
     gl = M.loss_backward(opt, gl, opt_G, 0)
-    for i in range(2):
-        assert abs(float(d[i]) - g['d_losses'][i]) <= 1e-3 * max(1.0, abs(g['d_losses'][i]))
+    for i in range(len(d)):
+        assert abs(float(d[i]) - g['d_losses'][i]) <= 1e-3 * max(1.0, abs(g['d_losses'][i])), i
     for i, ref in enumerate(g['g_losses']):
         assert abs(float(gl[i]) - ref) <= 1e-3 * max(1.0, abs(ref)), (g['loss_names'][i], float(gl[i]), ref)
     assert _rel(generated[0].cpu(), g['fake']) <= 1e-3

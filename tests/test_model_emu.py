@@ -49,3 +49,10 @@ def test_train_step_street_one_hot_tiny(emu_lib):
     """BASELINE configs[4] flavour: fewshot_street, integer class maps one-hot encoded on the way in (label_nc classes),
     adaptive_spade only, 2:1 aspect."""
     mc.check_train_step(DEV, mc.tiny_opt(dataset_mode='fewshot_street', label_nc=7, input_nc=3, aspect_ratio=2.0), b=1)
+
+
+def test_train_step_with_face_discriminator_tiny(emu_lib):
+    """BASELINE configs[3] flavour: --add_face_D (face boxes + crops on the device, 6-channel face discriminator, its
+    GAN / feature-matching / L1 / VGG terms) on top of the pose flags, VGG loss on (the reference requires it)."""
+    mc.check_train_step(DEV, mc.tiny_opt(warp_ref=True, spade_combine=True, remove_face_labels=True, add_face_D=True,
+                                         no_vgg_loss=False), b=1)

@@ -85,6 +85,10 @@ def test_part_masks(emu_lib):
     oc.check_part_masks(DEV)
 
 
+def test_face_boxes_and_crop(emu_lib):
+    oc.check_face_ops(DEV)
+
+
 def test_adam(emu_lib):
     oc.check_adam(DEV, n=300)
 

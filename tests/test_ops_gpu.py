@@ -106,6 +106,10 @@ def test_part_masks(hip_lib):
     oc.check_part_masks(dev())
 
 
+def test_face_boxes_and_crop(hip_lib):
+    oc.check_face_ops(dev())
+
+
 def test_adam(hip_lib):
     oc.check_adam(dev(), n=100003)
 
