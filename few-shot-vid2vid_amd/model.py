@@ -362,7 +362,39 @@ class Vid2VidModel(nn.Module):
             return losses, generated if save_images else [], prev
         if mode == 'discriminator':
             return self.forward_discriminator(tgt_label, tgt_image, ref_label, ref_image, prevs)
-        raise NotImplementedError("inference / finetune are outside the hot-path scope (SURVEY.md section 8f rank 4)")
+        return self.inference(tgt_label, ref_label, ref_image)
+
+    def inference(self, tgt_label, ref_labels, ref_images):
+        """vid2vid_model.py:179-205 (test.py:39-41): one frame per call, previous labels / outputs carried in self.prevs;
+        call reset_inference() between sequences.  --finetune and --refine_face are not part of this build."""
+        opt = self.opt
+        if getattr(opt, 'finetune', False):
+            raise NotImplementedError("test-time finetune (vid2vid_model.py:207-237)")
+        if getattr(self, 'prevs', None) is None:
+            self.prevs = [None, None]
+            prevs = [None, None]
+            self.t = 0
+        else:
+            b, _, _, h, w = tgt_label.shape
+            prevs = [p.contiguous().view(b, -1, h, w) for p in self.prevs]
+            self.t += 1
+        tgt_label_valid = valid_labels(opt, tgt_label[:, -1])
+        ref_labels_valid = valid_labels(opt, ref_labels)
+        with torch.no_grad():
+            fake, flow, mask, raw, warped, _, _, atn_score, _ = self.netG(tgt_label_valid, ref_labels_valid, ref_images,
+                                                                          prevs, t=self.t)
+            n_prev = opt.n_frames_G - 1
+            new = []
+            for old, now in zip(self.prevs, (tgt_label_valid, fake)):          # concat_prev, vid2vid_model.py:169-176
+                if old is None:
+                    new.append(now.unsqueeze(1).repeat(1, n_prev, 1, 1, 1).detach())
+                else:
+                    new.append(torch.cat([old[:, 1:], now.unsqueeze(1)], dim=1).detach())
+            self.prevs = new
+        return fake, raw, warped, flow, mask, atn_score
+
+    def reset_inference(self):
+        self.prevs = None
 
     def generate_images(self, tgt_labels, tgt_images, ref_labels, ref_images, prevs):
         """vid2vid_model.py:130-158 with n_frames_per_gpu == 1."""

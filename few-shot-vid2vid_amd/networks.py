@@ -461,13 +461,15 @@ class FewShotGenerator(nn.Module):
             return self._pairs(f, 2, co, ch_h)
         return embedding_weights, [two('fc_spade_0', ch_out), two('fc_spade_1', ch_in), two('fc_spade_s', ch_out)]
 
-    def reference_encoding(self, img_ref, label_ref):
+    def reference_encoding(self, img_ref, label_ref, encode=True):
         n = self.n_downsample_G
         x = self.ref_img_first(img_ref)
         xl = self.ref_label_first(label_ref)
         for i in range(n):
             x = getattr(self, 'ref_img_down_%d' % i)(x)
             xl = getattr(self, 'ref_label_down_%d' % i)(xl)
+        if not encode:           # generator.py:370: test-time frames after the first re-use the cached weights
+            return x, None
         fi, fl = [x], [xl]
         for i in reversed(range(n)):
             fi.append(getattr(self, 'ref_img_up_%d' % i)(fi[-1]))
@@ -484,16 +486,24 @@ class FewShotGenerator(nn.Module):
             enc.append(prod.permute(0, 2, 1, 3))                                  # [b, c(i), c(j), 1]
         return x, enc[::-1]
 
-    def weight_generation(self, img_ref, label_ref, label):
+    def weight_generation(self, img_ref, label_ref, label, t=0):
         b, n, c, h, w = img_ref.shape
         img_ref, label_ref = img_ref.reshape(b * n, -1, h, w), label_ref.reshape(b * n, -1, h, w)
-        x, enc = self.reference_encoding(img_ref, label_ref)
-        embed_w, norm_w = [], []
-        if self.adap_spade:
-            for i in range(self.n_adaptive_layers):
-                e, nw = self.get_SPADE_weights(enc[min(len(enc) - 1, i + 1)], i)
-                embed_w.append(e)
-                norm_w.append(nw)
+        # generator.py:370,403-416: at test time (isTrain False, one reference) the generated weights of frame 0 are kept
+        # and every later frame only runs the down path of the reference encoder
+        fresh = bool(self.opt.isTrain) or n > 1 or t == 0
+        x, enc = self.reference_encoding(img_ref, label_ref, encode=fresh)
+        if fresh:
+            embed_w, norm_w = [], []
+            if self.adap_spade:
+                for i in range(self.n_adaptive_layers):
+                    e, nw = self.get_SPADE_weights(enc[min(len(enc) - 1, i + 1)], i)
+                    embed_w.append(e)
+                    norm_w.append(nw)
+            if not self.opt.isTrain:
+                self._cached_weights = (embed_w, norm_w)
+        else:
+            embed_w, norm_w = self._cached_weights
         enc_label = self.label_embedding(label, weights=(embed_w if self.adap_embed else None))
         return x, enc_label, norm_w
 
@@ -520,7 +530,7 @@ class FewShotGenerator(nn.Module):
             self._sn_group = ops.SpectralGroup(spectral_layers(self))
             self._sn_count = sum(1 for _ in self.modules())
         self._sn_group.update(self.training)
-        x, enc_label, norm_w = self.weight_generation(img_refs, label_refs, label)
+        x, enc_label, norm_w = self.weight_generation(img_refs, label_refs, label, t=t)
         label_ref, img_ref = label_refs[:, 0], img_refs[:, 0]
         flow, mask, warp, ds = self.flow_generation(label, label_ref, img_ref, prev)
         if self.spade_combine:

@@ -133,6 +133,38 @@ def temporal(name, flags):
     print('temporal', name, 'D', [round(float(x), 5) for x in d_losses[:2]], 'G', [round(float(x), 5) for x in g_losses])
 
 
+def inference(name, flags):
+    """test.py:27,39-41: model.eval(), three consecutive model.inference() calls (first frame, then two frames with the
+    previous-frame branch).  opt.isTrain is switched off after construction so that the test-time weight caching of
+    generator.py:370,403-416 is what produces frames 1 and 2."""
+    import model_checks as mc
+    ref_import.install_shims()
+    opt, model = ref_import.build_model(flags.split())
+    model.init_temporal_model()
+    mc.fill_state(model.netG)
+    frames = [mc.synth_pose_inputs(1, 64, 64, 909 + t, 6) for t in range(3)]
+    ref_label, ref_image = frames[0][2], frames[0][3]
+    # eval-mode networks need meaningful buffers: let the running statistics and the spectral-norm vectors settle with
+    # a few training-mode passes, and ship those buffers in the fixture (the weights are reproducible from fill_state)
+    model.train()
+    for it in range(10):
+        model.prevs = None
+        for (tl, _, _, _) in frames:
+            model.inference(tl, ref_label, ref_image)
+    model.prevs = None
+    buffers = {k: v.detach().clone() for k, v in model.netG.state_dict().items()
+               if k.endswith(('running_mean', 'running_var', 'weight_u', 'weight_v'))}
+    model.eval()
+    opt.isTrain = False
+    fakes = []
+    for (tl, _, _, _) in frames:
+        fake, raw, warped, flow, mask, _ = model.inference(tl, ref_label, ref_image)
+        fakes.append(fake.detach().clone())
+    torch.save(dict(flags=flags, seed=909, batch=1, size=64, fakes=fakes, buffers=buffers),
+               os.path.join(OUT, 'inference_%s.pt' % name))
+    print('inference', name, [round(float(f.abs().mean()), 5) for f in fakes])
+
+
 def warp_taps():
     ref_import.install_shims()
     from models.networks.base_network import resample
@@ -162,11 +194,15 @@ if __name__ == '__main__':
     os.makedirs(OUT, exist_ok=True)
     if len(sys.argv) > 1:                # mint only the named step cases (keeps the other fixtures byte-identical)
         for n in sys.argv[1:]:
-            step(n, CONFIGS[n])
+            if n.startswith('inference:'):
+                inference(n[10:], CONFIGS[n[10:]])
+            else:
+                step(n, CONFIGS[n])
         sys.exit(0)
     layout()
     for n, f in CONFIGS.items():
         step(n, f)
     temporal('pose_combine', CONFIGS['pose_combine'])
+    inference('pose_combine', CONFIGS['pose_combine'])
     warp_taps()
     print('goldens written to', OUT)

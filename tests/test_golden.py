@@ -196,3 +196,50 @@ def test_oracle_reproduces_reference_second_frame():
         else:
             k2 = k
         assert abs(float(gG[k2].norm()) - ref) <= 1e-3 * max(ref, 1e-2 * med), k
+
+
+def _inference_setup(g, device=None):
+    """product model with the fixture's state: fill_state weights + the settled eval-mode buffers of the reference"""
+    opt = _opt_from_flags(g['flags'])
+    M = mc._model()
+    model = M.create_model(opt)
+    model.netG.init_temporal_network()
+    mc.fill_state(model.netG)
+    sd = model.netG.state_dict()
+    for k, v in g['buffers'].items():
+        sd[k].copy_(v)
+    frames = [mc.synth_pose_inputs(g['batch'], g['size'], g['size'], g['seed'] + t, 6) for t in range(3)]
+    return opt, model, frames
+
+
+def test_oracle_reproduces_reference_inference():
+    """test.py path: model.eval(), three Vid2VidModel.inference() frames (first frame, then previous-frame warping)"""
+    g = torch.load(os.path.join(GOLD, 'inference_pose_combine.pt'), weights_only=False)
+    opt, model, frames = _inference_setup(g)
+    sdG = {k: v.detach().clone() for k, v in model.netG.state_dict().items()}
+    outs = O.inference_frames(sdG, O.cfg_from_opt(opt), [f[0] for f in frames], frames[0][2], frames[0][3],
+                              warp_prev=True, n_frames_G=opt.n_frames_G)
+    for got, ref in zip(outs, g['fakes']):
+        assert _rel(got, ref) <= 1e-5
+
+
+def _check_product_inference(dev):
+    g = torch.load(os.path.join(GOLD, 'inference_pose_combine.pt'), weights_only=False)
+    opt, model, frames = _inference_setup(g)
+    model = model.to(dev).eval()
+    opt.isTrain = False                    # test-time weight caching (generator.py:370,403-416)
+    ref_label, ref_image = frames[0][2].to(dev), frames[0][3].to(dev)
+    for t, (f, ref) in enumerate(zip(frames, g['fakes'])):
+        data = [f[0].to(dev), None, None, None, ref_label, ref_image, None, None, None]
+        fake = model(data)[0]              # default mode = inference, like test.py:40
+        assert _rel(fake.cpu(), ref) <= 1e-3, t
+    assert model.t == 2 and model.netG._cached_weights is not None
+
+
+def test_product_inference_emu(emu_lib):
+    _check_product_inference(torch.device('cpu'))
+
+
+@pytest.mark.gpu
+def test_product_inference_on_gpu(hip_lib):
+    _check_product_inference(torch.device('cuda:0'))
