@@ -187,6 +187,25 @@ class LossCollector:
         gf_feat = gf_feat + self.vgg(fake_region, real_region) * self.opt.lambda_vgg
         return [gf_gan, gf_feat]
 
+    def temporal_losses(self, netDT, real_all, fake_all, for_discriminator):
+        """loss_collector.py:87-90,109-113 with for_temporal=True: the temporal discriminator sees tD consecutive frames
+        stacked on the channel axis ([B, t, 3, H, W] -> reshape of base_model.py:120-139), no label / reference input."""
+        if self.tD < 2:
+            return [self.zero(real_all), self.zero(real_all)]
+
+        def stack(x):
+            bs, t, ch, h, w = x.shape
+            nd = self.tD
+            if t > nd:
+                if t % nd != 0:
+                    x = x[:, -(t // nd) * nd:]
+                return x.contiguous().view(-1, ch * nd, h, w)
+            return x.contiguous().view(bs, ch * t, h, w)
+        losses = self.discriminate(netDT, None, stack(fake_all), stack(real_all), None, for_discriminator)
+        if not for_discriminator:
+            losses = [l * self.opt.lambda_temp for l in losses]
+        return losses
+
     def gan_losses(self, netD, tgt_label, reals, fakes, ref_label, ref_image, for_discriminator, netDf=None):
         """loss_collector.py:87-120 for the per-frame discriminator and the face discriminator (no temporal branch)."""
         opt = self.opt
@@ -321,18 +340,28 @@ class Vid2VidModel(nn.Module):
         return self.optimizer_G, self.optimizer_D
 
     def init_temporal_model(self):
-        """models/base_model.py:259-279 for lambda_temp == 0 (no temporal discriminator): the generator grows its
-        previous-frame flow / embedding branches and the G optimiser is rebuilt over the new parameter set."""
-        if self.opt.lambda_temp > 0:
-            raise NotImplementedError("temporal discriminator netDT (lambda_temp > 0) is a next-scope row (SURVEY.md 8f)")
+        """models/base_model.py:259-279: the generator grows its previous-frame flow / embedding branches, the temporal
+        discriminator netDT (input = tD stacked frames) is created, and both optimisers are rebuilt over the new
+        parameter sets (fresh Adam state, as in the reference)."""
+        opt = self.opt
         self.temporal = True
         torch.manual_seed(0)
         self.netG.init_temporal_network()
-        self.lossCollector.tD = min(self.opt.n_frames_D, self.opt.n_frames_G)
+        self.lossCollector.tD = min(opt.n_frames_D, opt.n_frames_G)
+        dev = next(self.netG.parameters()).device
+        self.netG.to(dev)
+        self.netDT = networks.define_D(opt, opt.output_nc * self.lossCollector.tD, opt.ndf, opt.n_layers_D, opt.norm_D,
+                                       'n_layers', 1, not opt.no_ganFeat_loss).to(dev)
         if self.optimizer_G is not None:
             old = self.optimizer_G
-            lr = float(old.state[3])
-            self.optimizer_G = FlatAdam(list(self.netG.parameters()), lr, old.betas, old.world_size, old.group)
+            self.optimizer_G = FlatAdam(list(self.netG.parameters()), float(old.state[3]), old.betas, old.world_size,
+                                        old.group, force_exchange=old.exchange and old.world_size == 1, overlap=old.overlap)
+            old = self.optimizer_D
+            d_params = list(self.netD.parameters()) + list(self.netDT.parameters())
+            if self.netDf is not None:
+                d_params += list(self.netDf.parameters())
+            self.optimizer_D = FlatAdam(d_params, float(old.state[3]), old.betas, old.world_size, old.group,
+                                        force_exchange=old.exchange and old.world_size == 1, overlap=old.overlap)
         return self.optimizer_G
 
     def update_learning_rate(self, epoch):
@@ -428,6 +457,10 @@ class Vid2VidModel(nn.Module):
         real = tgt_image[:, 0]
         losses = self.lossCollector.gan_losses(self.netD, tgt_label, [real, real * fg_union], [fake, raw], ref_label,
                                                ref_image, for_discriminator=True, netDf=self.netDf)
+        if self.opt.lambda_temp > 0 and prevs[0] is not None and self.netDT is not None:      # vid2vid_model.py:115-119
+            real_all = torch.cat([prevs[1], tgt_image], dim=1)
+            fake_all = torch.cat([prevs[2], fake.unsqueeze(1)], dim=1)
+            losses = list(losses) + self.lossCollector.temporal_losses(self.netDT, real_all, fake_all, True)
         return [l.view(1, 1) for l in losses]
 
     def forward_generator(self, tgt_label, tgt_image, ref_labels, ref_images, prevs):
@@ -442,12 +475,19 @@ class Vid2VidModel(nn.Module):
         d_params = [p for p in self.netD.parameters() if p.requires_grad]
         if self.netDf is not None:
             d_params += [p for p in self.netDf.parameters() if p.requires_grad]
+        if self.netDT is not None:
+            d_params += [p for p in self.netDT.parameters() if p.requires_grad]
         for p in d_params:
             p.requires_grad_(False)
+        gt_gan = gt_feat = None
         try:
             g_gan, g_feat, gf_gan, gf_feat = lc.gan_losses(self.netD, tgt_label, [real, real * fg_union], [fake, raw],
                                                            ref_label, ref_image, for_discriminator=False,
                                                            netDf=self.netDf)
+            if self.opt.lambda_temp > 0 and prevs[0] is not None and self.netDT is not None:  # vid2vid_model.py:70-75
+                real_all = torch.cat([prevs[1], tgt_image], dim=1)
+                fake_all = torch.cat([prevs[2], fake.unsqueeze(1)], dim=1)
+                gt_gan, gt_feat = lc.temporal_losses(self.netDT, real_all, fake_all, False)
         finally:
             for p in d_params:
                 p.requires_grad_(True)
@@ -455,7 +495,8 @@ class Vid2VidModel(nn.Module):
         g_vgg = lc.vgg_losses(fake, raw, real, fg_union)
         f_flow, f_warp, body_diff = lc.flow_losses(flow, warped, real, fg, tgt_label, ref_label)
         f_mask = lc.mask_losses(mask, fake, warped, tgt_label, real, fg, ref_fg, body_diff)
-        losses = [g_gan, g_feat, g_vgg, gf_gan, gf_feat, z.clone(), z.clone(), f_flow, f_warp, f_mask]
+        losses = [g_gan, g_feat, g_vgg, gf_gan, gf_feat, gt_gan if gt_gan is not None else z.clone(),
+                  gt_feat if gt_feat is not None else z.clone(), f_flow, f_warp, f_mask]
         # the reference returns fake / raw as [B, T, ...] and - because forward_generator rebinds them through
         # self.reshape (vid2vid_model.py:88-89) - warped / flow / mask as 4-D tensors
         up = lambda t: t.unsqueeze(1) if t is not None else None

@@ -41,6 +41,8 @@ CONFIGS['pose_combine_vgg'] = CONFIGS['pose_combine'].replace(' --no_vgg_loss', 
 # 128 x 128 so that the 32 x 32 face crops survive torchvision-style VGG19's five max-pools
 CONFIGS['pose_face_d'] = CONFIGS['pose_combine_vgg'].replace('--fineSize 64 --loadSize 64', '--fineSize 128 --loadSize 128') \
     + ' --add_face_D'
+# temporal discriminator netDT on two stacked frames (base_model.py:270-276); only used by temporal()
+CONFIGS['pose_combine_dt'] = CONFIGS['pose_combine'] + ' --lambda_temp 2'
 # street: integer class maps, one-hot encoded by encode_label (input_process.py:25-45); default aspect_ratio 2 -> 32 x 64
 CONFIGS['street'] = ('--dataset_mode fewshot_street --label_nc 7 --fineSize 64 --loadSize 64 --adaptive_spade --no_flow_gt '
                      '--no_vgg_loss --gpu_ids -1 --ngf 8 --ndf 8 --batchSize 2')
@@ -107,11 +109,14 @@ def step(name, flags):
 def temporal(name, flags):
     """two consecutive frames with the previous-frame branch active (train.py:55-62 with data_prev fed back)"""
     import model_checks as mc
+    ref_import.install_shims()
     from models.loss_collector import loss_backward
     opt, model = ref_import.build_model(flags.split())
     mc.fill_state(model.netD)
     model.init_temporal_model()
     mc.fill_state(model.netG)
+    if opt.lambda_temp > 0:
+        mc.fill_state(model.netDT)
     for o in (model.optimizer_G, model.optimizer_D):
         for g in o.param_groups:
             g['lr'] = 0.0
@@ -121,11 +126,13 @@ def temporal(name, flags):
     for t, (tl, ti, rl, ri) in enumerate(frames):
         data = [tl, ti, [None, None], [None, None], rl, ri] + prev
         d_losses = loss_backward(opt, model(data, mode='discriminator'), model.optimizer_D, 1)
+        gDT = {k: float(p.grad.norm()) for k, p in model.netDT.named_parameters() if p.grad is not None} \
+            if opt.lambda_temp > 0 else {}
         g_losses, generated, prev = model(data, save_images=True, mode='generator')
         g_losses = loss_backward(opt, g_losses, model.optimizer_G, 0)
     gG = {k: float(p.grad.norm()) for k, p in model.netG.named_parameters() if p.grad is not None}
     fake, raw, warped, flow, mask, _ = generated
-    torch.save(dict(flags=flags, seed=777, batch=1, size=64, d_losses=[float(x) for x in d_losses],
+    torch.save(dict(flags=flags, seed=777, batch=1, size=64, grad_norm_DT=gDT, d_losses=[float(x) for x in d_losses],
                     g_losses=[float(x) for x in g_losses], loss_names=model.lossCollector.loss_names,
                     fake=fake.detach().clone(), warp=[w.detach().clone() for w in warped],
                     flow=[f.detach().clone() for f in flow], mask=[m.detach().clone() for m in mask], grad_norm_G=gG),
@@ -196,13 +203,17 @@ if __name__ == '__main__':
         for n in sys.argv[1:]:
             if n.startswith('inference:'):
                 inference(n[10:], CONFIGS[n[10:]])
+            elif n.startswith('temporal:'):
+                temporal(n[9:], CONFIGS[n[9:]])
             else:
                 step(n, CONFIGS[n])
         sys.exit(0)
     layout()
     for n, f in CONFIGS.items():
-        step(n, f)
+        if n != 'pose_combine_dt':
+            step(n, f)
     temporal('pose_combine', CONFIGS['pose_combine'])
+    temporal('pose_combine_dt', CONFIGS['pose_combine_dt'])
     inference('pose_combine', CONFIGS['pose_combine'])
     warp_taps()
     print('goldens written to', OUT)

@@ -386,9 +386,11 @@ def _leafify(sd0, dtype):
     return sd
 
 
-def _oracle_two_frames(sdG0, sdD0, cfg, frames, dtype):
-    """frame 0 without history, frame 1 with the previous-frame branch (init_temporal_network), learning rate 0."""
+def _oracle_two_frames(sdG0, sdD0, cfg, frames, dtype, sdDT0=None):
+    """frame 0 without history, frame 1 with the previous-frame branch (init_temporal_network), learning rate 0.
+    With sdDT0 (lambda_temp > 0) the temporal discriminator's gradients are returned as a 6th entry."""
     sdG, sdD = _leafify(sdG0, dtype), _leafify(sdD0, dtype)
+    sdDT = _leafify(sdDT0, dtype) if sdDT0 is not None else None
     prevs, out = None, None
     for t, data in enumerate(frames):
         tl, ti, rl, ri = [x.to(dtype) for x in data]
@@ -396,17 +398,21 @@ def _oracle_two_frames(sdG0, sdD0, cfg, frames, dtype):
             if v.is_floating_point():
                 v.grad = None
         p = [x.to(dtype) for x in prevs] if prevs is not None else None
-        d_losses = O.d_step_losses(sdG, sdD, cfg, tl, ti, rl, ri, p, True)
-        sum(l.mean() for l in d_losses).backward()
-        gD = {k: v.grad.clone() for k, v in sdD.items() if v.is_floating_point() and v.grad is not None}
-        for v in list(sdG.values()) + list(sdD.values()):
+        for v in (sdDT or {}).values():
             if v.is_floating_point():
                 v.grad = None
-        g_losses, gen = O.g_step_losses(sdG, sdD, cfg, tl, ti, rl, ri, p, True)
+        d_losses = O.d_step_losses(sdG, sdD, cfg, tl, ti, rl, ri, p, True, sdDT=sdDT)
+        sum(l.mean() for l in d_losses).backward()
+        gD = {k: v.grad.clone() for k, v in sdD.items() if v.is_floating_point() and v.grad is not None}
+        gDT = {k: v.grad.clone() for k, v in (sdDT or {}).items() if v.is_floating_point() and v.grad is not None}
+        for v in list(sdG.values()) + list(sdD.values()) + list((sdDT or {}).values()):
+            if v.is_floating_point():
+                v.grad = None
+        g_losses, gen = O.g_step_losses(sdG, sdD, cfg, tl, ti, rl, ri, p, True, sdDT=sdDT)
         sum(l.mean() for l in g_losses.values()).backward()
         gG = {k: v.grad.clone() for k, v in sdG.items() if v.is_floating_point() and v.grad is not None}
         prevs = gen['prevs']
-        out = (d_losses, gD, g_losses, gG, gen)
+        out = (d_losses, gD, g_losses, gG, gen, gDT)
     return out
 
 
@@ -420,6 +426,10 @@ def check_temporal_step(device, opt, b=1, tol=1e-3, seed=31, grad_tol=2e-2):
     model.build_optimizers()
     model.init_temporal_model()
     fill_state(model.netG)
+    sdDT0 = None
+    if opt.lambda_temp > 0:
+        fill_state(model.netDT)
+        sdDT0 = {k: v.detach().cpu().clone() for k, v in model.netDT.state_dict().items()}
     sdG0 = {k: v.detach().cpu().clone() for k, v in model.netG.state_dict().items()}
     sdD0 = {k: v.detach().cpu().clone() for k, v in model.netD.state_dict().items()}
     opt_G, opt_D = model.optimizer_G, model.optimizer_D
@@ -429,8 +439,8 @@ def check_temporal_step(device, opt, b=1, tol=1e-3, seed=31, grad_tol=2e-2):
     frames = [synth_pose_inputs(b, h, w, seed + t, nl) for t in range(2)]
     frames[1] = (frames[1][0], frames[1][1], frames[0][2], frames[0][3])      # same reference images for both frames
     cfg = O.cfg_from_opt(opt)
-    r32 = _oracle_two_frames(sdG0, sdD0, cfg, frames, torch.float32)
-    r64 = _oracle_two_frames(sdG0, sdD0, cfg, frames, torch.float64)
+    r32 = _oracle_two_frames(sdG0, sdD0, cfg, frames, torch.float32, sdDT0)
+    r64 = _oracle_two_frames(sdG0, sdD0, cfg, frames, torch.float64, sdDT0)
     prevs = [None, None, None]
     for t, data in enumerate(frames):
         tl, ti, rl, ri = [x.to(device) for x in data]
@@ -441,7 +451,14 @@ def check_temporal_step(device, opt, b=1, tol=1e-3, seed=31, grad_tol=2e-2):
     for i, name in enumerate(('D_real', 'D_fake')):
         _close_vs64(name, d_losses[i].view(1), r32[0][i].view(1), r64[0][i].view(1), tol)
     names = M.LOSS_NAMES_G
-    for k in ('G_GAN', 'G_GAN_Feat', 'F_Warp', 'F_Mask'):
+    keys = ['G_GAN', 'G_GAN_Feat', 'F_Warp', 'F_Mask']
+    if opt.lambda_temp > 0:
+        keys += ['GT_GAN', 'GT_GAN_Feat']
+        for i, name in ((4, 'DT_real'), (5, 'DT_fake')):
+            _close_vs64(name, d_losses[i].view(1), r32[0][i].view(1), r64[0][i].view(1), tol)
+        compare_grads_l2(model.netDT, {k: _G(v) for k, v in r32[5].items()}, {k: _G(v) for k, v in r64[5].items()},
+                         grad_tol)
+    for k in keys:
         _close_vs64(k, g_losses[names.index(k)].view(1), r32[2][k].view(1), r64[2][k].view(1), tol)
     _close_vs64('fake image', generated[0][:, 0], r32[4]['fake'], r64[4]['fake'], tol)
     _close_vs64('prev warp', generated[2][1], r32[4]['warp'][1], r64[4]['warp'][1], tol)

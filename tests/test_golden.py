@@ -32,6 +32,8 @@ def _opt_from_flags(flags):
             kw['dataset_mode'] = toks[i + 1]; i += 2
         elif t == '--label_nc':
             kw['label_nc'] = int(toks[i + 1]); i += 2
+        elif t == '--lambda_temp':
+            kw['lambda_temp'] = float(toks[i + 1]); i += 2
         elif t == '--aspect_ratio':
             kw['aspect_ratio'] = float(toks[i + 1]); i += 2
         elif t == '--gpu_ids':
@@ -167,23 +169,34 @@ def test_product_reproduces_reference_iteration_on_gpu(hip_lib, case):
         assert _rel(generated[2][0].cpu(), g['warp'][0]) <= 1e-3
 
 
-def test_oracle_reproduces_reference_second_frame():
-    """previous-frame branch (init_temporal_model): two reference frames, oracle compared on the second one"""
-    g = torch.load(os.path.join(GOLD, 'temporal_pose_combine.pt'), weights_only=False)
+@pytest.mark.parametrize('case', ['pose_combine', 'pose_combine_dt'])
+def test_oracle_reproduces_reference_second_frame(case):
+    """previous-frame branch (init_temporal_model): two reference frames, oracle compared on the second one; the _dt
+    case adds the temporal discriminator (--lambda_temp 2: DT_real / DT_fake, GT_GAN / GT_GAN_Feat)"""
+    g = torch.load(os.path.join(GOLD, 'temporal_%s.pt' % case), weights_only=False)
     opt = _opt_from_flags(g['flags'])
     M = mc._model()
     model = M.create_model(opt)
     mc.fill_state(model.netD)
-    model.netG.init_temporal_network()
+    model.init_temporal_model()
     mc.fill_state(model.netG)
+    sdDT0 = None
+    if opt.lambda_temp > 0:
+        mc.fill_state(model.netDT)
+        sdDT0 = {k: v.detach().clone() for k, v in model.netDT.state_dict().items()}
     sdG0 = {k: v.detach().clone() for k, v in model.netG.state_dict().items()}
     sdD0 = {k: v.detach().clone() for k, v in model.netD.state_dict().items()}
     frames = [mc.synth_pose_inputs(g['batch'], g['size'], g['size'], g['seed'] + t, 6) for t in range(2)]
     frames[1] = (frames[1][0], frames[1][1], frames[0][2], frames[0][3])
-    d_losses, gD, g_losses, gG, gen = mc._oracle_two_frames(sdG0, sdD0, O.cfg_from_opt(opt), frames, torch.float32)
+    d_losses, gD, g_losses, gG, gen, gDT = mc._oracle_two_frames(sdG0, sdD0, O.cfg_from_opt(opt), frames, torch.float32,
+                                                                 sdDT0)
     names = g['loss_names']
-    for i in range(2):
-        assert abs(float(d_losses[i]) - g['d_losses'][i]) <= 1e-5 * max(1.0, abs(g['d_losses'][i]))
+    for i in range(len(d_losses)):
+        assert abs(float(d_losses[i]) - g['d_losses'][i]) <= 1e-5 * max(1.0, abs(g['d_losses'][i])), i
+    if opt.lambda_temp > 0:
+        assert len(d_losses) == 6 and 'GT_GAN' in g_losses and g['g_losses'][names.index('GT_GAN_Feat')] > 0
+    for k, ref in g.get('grad_norm_DT', {}).items():
+        assert abs(float(gDT[k].norm()) - ref) <= 1e-4 * max(ref, 1e-6), k
     for k, v in g_losses.items():
         ref = g['g_losses'][names.index(k)]
         assert abs(float(v) - ref) <= 1e-5 * max(1.0, abs(ref)), (k, float(v), ref)
@@ -195,7 +208,9 @@ def test_oracle_reproduces_reference_second_frame():
             k2 = k.replace('flow_network_temp.', 'flow_network_ref.')      # one shared module, two names
         else:
             k2 = k
-        assert abs(float(gG[k2].norm()) - ref) <= 1e-3 * max(ref, 1e-2 * med), k
+        # (parameters whose true gradient is zero - conv biases in front of a BatchNorm - hold rounding noise on both
+        # sides: the floor keeps them out of the relative comparison)
+        assert abs(float(gG[k2].norm()) - ref) <= 1e-3 * max(ref, 5e-2 * med), k
 
 
 def _inference_setup(g, device=None):

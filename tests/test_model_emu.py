@@ -56,3 +56,9 @@ def test_train_step_with_face_discriminator_tiny(emu_lib):
     GAN / feature-matching / L1 / VGG terms) on top of the pose flags, VGG loss on (the reference requires it)."""
     mc.check_train_step(DEV, mc.tiny_opt(warp_ref=True, spade_combine=True, remove_face_labels=True, add_face_D=True,
                                          no_vgg_loss=False), b=1)
+
+
+def test_temporal_discriminator_tiny(emu_lib):
+    """--lambda_temp > 0: netDT on two stacked frames (D terms DT_real / DT_fake, G terms GT_GAN / GT_GAN_Feat)"""
+    mc.check_temporal_step(DEV, mc.tiny_opt(warp_ref=True, spade_combine=True, remove_face_labels=True, lambda_temp=2.0),
+                           b=2)
