@@ -47,3 +47,21 @@ def test_temporal_second_frame(hip_lib):
 def test_train_step_with_vgg_loss(hip_lib):
     mc.check_train_step(dev(), mc.tiny_opt(ngf=8, ndf=8, nff=8, warp_ref=True, spade_combine=True, remove_face_labels=True,
                                            no_vgg_loss=False, fineSize=64, loadSize=64), b=1)
+
+
+def test_train_step_street_one_hot(hip_lib):
+    """BASELINE configs[4] flavour (fp32): integer class maps -> one-hot, 2:1 aspect"""
+    mc.check_train_step(dev(), mc.tiny_opt(ngf=8, ndf=8, dataset_mode='fewshot_street', label_nc=12, input_nc=3,
+                                           aspect_ratio=2.0, fineSize=128, loadSize=128), b=2)
+
+
+def test_train_step_with_face_discriminator(hip_lib):
+    """BASELINE configs[3] flavour: --add_face_D on the pose flags (device-side face boxes, crop kernels, netDf)"""
+    mc.check_train_step(dev(), mc.tiny_opt(ngf=8, ndf=8, nff=8, warp_ref=True, spade_combine=True, remove_face_labels=True,
+                                           add_face_D=True, no_vgg_loss=False, fineSize=128, loadSize=128), b=2)
+
+
+def test_temporal_discriminator(hip_lib):
+    """--lambda_temp > 0: netDT on two stacked frames"""
+    mc.check_temporal_step(dev(), mc.tiny_opt(ngf=8, ndf=8, nff=8, warp_ref=True, spade_combine=True,
+                                              remove_face_labels=True, lambda_temp=2.0, fineSize=128, loadSize=128), b=2)
