@@ -5,6 +5,8 @@ generator.py:541-572, discriminator.py:67-88), ``nn.Linear`` (generator.py:103-1
 (models/networks/base_network.py:56-71).  Tensors keep the reference's logical NCHW shape but live in
 channels-last memory (NHWC), which is the layout the kernels in csrc/conv_igemm.hip read and write.
 """
+import os
+
 import torch
 
 from . import lib, profile
@@ -204,7 +206,16 @@ def conv_wgrad(x, dout, geom, w_shape, per_sample=False, scale=None, force_split
     if dwt is None:
         dwt = torch.empty((nb, kpad, ldw), dtype=torch.float32, device=x.device)
     lib.check_device(x, dout)
-    label = 'fsv_conv_wgrad_kernel<BN%d,V%d>' % (32 if cout <= 32 else (64 if cout <= 64 else 128), 4 if cin % 4 == 0 else 1)
+    # tile the launcher picks (csrc/conv_igemm.hip fsv_conv_wgrad): rows = taps * Cin, columns = Cout
+    kdim, vec4 = geom.ntaps * cin, cin % 4 == 0
+    bn = 32 if cout <= 32 else (64 if cout <= 64 else 128)
+    bm = 128
+    if vec4 and bn >= 64:
+        bm = 32 if kdim <= 32 else (64 if kdim <= 64 else 128)
+    if force_tile == 0 and vec4 and cout >= 64 and kdim > 64 and os.environ.get('FSV_WGRAD_PLAN', '1') == '1':
+        pch = ((oh * ow if per_sample else n * oh * ow) + 31) // 32
+        bm, bn = (64, 128) if (cout >= 128 and kdim >= 2304 and pch >= 64) else (64, 64)
+    label = 'fsv_conv_wgrad_kernel<%dx%d,V%d>' % (bm, bn, 4 if vec4 else 1)
     if profile.detail():
         label += ' Kdim%d N%d pix%d z%d' % (geom.ntaps * cin, cout, (oh * ow) if per_sample else n * oh * ow, nb)
     with profile.scope(label, 2.0 * n * oh * ow * cout * cin * geom.ntaps):
