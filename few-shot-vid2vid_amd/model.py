@@ -434,8 +434,12 @@ class Vid2VidModel(nn.Module):
         tgt_label_valid = valid_labels(opt, tgt_label_t)
         tgt_image = tgt_images[:, 0]
         prev_t = [p.contiguous().view(b, -1, h, w) if p is not None else None for p in (prevs[0], prevs[2])]
-        fake, flow, mask, raw, warped, _, _, _, _ = self.netG(tgt_label_valid, ref_labels_valid, ref_images, prev_t)
-        ref_label_valid, ref_label_t, ref_image_t = ref_labels_valid[:, 0], ref_labels[:, 0], ref_images[:, 0]
+        fake, flow, mask, raw, warped, _, _, atn_score, ref_idx = self.netG(tgt_label_valid, ref_labels_valid, ref_images,
+                                                                            prev_t)
+        self.atn_score = atn_score
+        pick = networks.pick_ref                     # vid2vid_model.py:144 (the attended reference when n_shot > 1)
+        ref_label_valid, ref_label_t, ref_image_t = pick(ref_labels_valid, ref_idx), pick(ref_labels, ref_idx), \
+            pick(ref_images, ref_idx)
         fg, ref_fg = fg_mask_of(opt, tgt_label_t, self.has_fg), fg_mask_of(opt, ref_label_t, self.has_fg)
         if raw is not None:
             raw = raw * union_fg(fg, ref_fg, self.has_fg)
@@ -500,7 +504,7 @@ class Vid2VidModel(nn.Module):
         # the reference returns fake / raw as [B, T, ...] and - because forward_generator rebinds them through
         # self.reshape (vid2vid_model.py:88-89) - warped / flow / mask as 4-D tensors
         up = lambda t: t.unsqueeze(1) if t is not None else None
-        generated = [up(fake), up(raw), list(warped), list(flow), list(mask), None]
+        generated = [up(fake), up(raw), list(warped), list(flow), list(mask), self.atn_score]
         return [l.view(1, 1) for l in losses], generated, prevs_new
 
 

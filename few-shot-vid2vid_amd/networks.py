@@ -328,14 +328,24 @@ class FlowGenerator(nn.Module):
         return flow, mask
 
 
+def pick_ref(refs, ref_idx):
+    """base_network.py:40-47: the reference with the largest attention mass per sample (the first one for n_shot == 1)"""
+    if ref_idx is None:
+        return refs[:, 0]
+    return refs[torch.arange(refs.shape[0], device=refs.device), ref_idx.long()]
+
+
 class FewShotGenerator(nn.Module):
-    """Reference generator.py:20-454 for n_shot == 1, use_label_ref == 'mul', no KLD, no adaptive_conv."""
+    """Reference generator.py:20-454 for use_label_ref == 'mul', no KLD, no adaptive_conv; n_shot >= 1 (with more than one
+    reference image the attention module of generator.py:291-316 merges the reference features)."""
 
     def __init__(self, opt):
         super().__init__()
         self.opt = opt
-        if getattr(opt, 'n_shot', 1) != 1 or getattr(opt, 'adaptive_conv', False) or getattr(opt, 'lambda_kld', 0) > 0:
-            raise NotImplementedError("n_shot > 1, adaptive_conv and the KLD branch are outside the hot-path scope")
+        if getattr(opt, 'adaptive_conv', False) or getattr(opt, 'lambda_kld', 0) > 0:
+            raise NotImplementedError("adaptive_conv and the KLD branch are outside the hot-path scope")
+        self.n_shot = getattr(opt, 'n_shot', 1)
+        self.n_downsample_A = getattr(opt, 'n_downsample_A', 2)
         if getattr(opt, 'use_label_ref', 'mul') != 'mul' or getattr(opt, 'res_for_ref', False):
             raise NotImplementedError("only use_label_ref='mul' with SPADEConv2d encoders is on the hot path")
         if opt.spade_ks != 1 or opt.embed_ks != 1 or opt.conv_ks != 3:
@@ -386,6 +396,12 @@ class FewShotGenerator(nn.Module):
             setattr(self, 'up_%d' % i, SPADEResnetBlock(ch[i + 1], ch[i], hidden_nc=ch_hidden[i], spade=True,
                                                        norm_params_free=(self.adap_spade and i < self.n_adaptive_layers)))
         self.conv_img = Conv2d(nf, 3, 3, padding=1)
+        if self.n_shot > 1:                # generator.py:128-134: key / query encoders of the attention module
+            self.atn_query_first = SPADEConv2d(input_nc, nf)
+            self.atn_key_first = SPADEConv2d(input_nc, nf)
+            for i in range(self.n_downsample_A):
+                setattr(self, 'atn_key_%d' % i, SPADEConv2d(ch[i], ch[i + 1], stride=2))
+                setattr(self, 'atn_query_%d' % i, SPADEConv2d(ch[i], ch[i + 1], stride=2))
         self._sn_group, self._sn_count = None, -1
         self.warp_prev = False
         self.warp_ref = opt.warp_ref and not getattr(opt, 'for_face', False)
@@ -461,13 +477,45 @@ class FewShotGenerator(nn.Module):
             return self._pairs(f, 2, co, ch_h)
         return embedding_weights, [two('fc_spade_0', ch_out), two('fc_spade_1', ch_in), two('fc_spade_s', ch_out)]
 
-    def reference_encoding(self, img_ref, label_ref, encode=True):
+    def attention_encode(self, img, name):
+        x = getattr(self, name + '_first')(img)
+        for i in range(self.n_downsample_A):
+            x = getattr(self, '%s_%d' % (name, i))(x)
+        return x
+
+    def attention_module(self, x, label, label_ref, attention=None):
+        """generator.py:298-316.  energy = key^T query over all N*HW reference positions, softmax over them, then the
+        attention-weighted sum of the N reference feature maps.  Both batched matrix products run on the gather-GEMM
+        kernel as per-sample 1x1 convolutions over the h x w query positions, kept in the transposed arrangement
+        attention_t[b, (n, p_key), y, x] so that the softmax is the channel softmax kernel."""
+        bn, c, h, w = x.shape
+        n = self.n_shot
+        b = bn // n
+        hw = h * w
+        if attention is None:
+            key = self.attention_encode(label_ref, 'atn_key')            # [b*n, c, h, w]
+            query = self.attention_encode(label, 'atn_query')            # [b, c, h, w]
+            kmat = key.reshape(b, n, c, hw).permute(0, 1, 3, 2).reshape(b, n * hw, c, 1, 1)
+            energy_t = ops.batch_conv(query, kmat)                        # [b, n*hw, h, w]
+            attention = ops.softmax_channels(energy_t)
+        xmat = x.reshape(b, n, c, hw).permute(0, 2, 1, 3).reshape(b, c, n * hw, 1, 1)
+        out = ops.batch_conv(attention, xmat)                             # [b, c, h, w]
+        atn_vis = attention.reshape(b, n, hw, h, w).sum(2)[-1:, 0:1]
+        return out, attention, atn_vis
+
+    def reference_encoding(self, img_ref, label_ref, encode=True, label=None):
         n = self.n_downsample_G
         x = self.ref_img_first(img_ref)
         xl = self.ref_label_first(label_ref)
+        atn = atn_vis = ref_idx = None
         for i in range(n):
             x = getattr(self, 'ref_img_down_%d' % i)(x)
             xl = getattr(self, 'ref_label_down_%d' % i)(xl)
+            if self.n_shot > 1 and i == self.n_downsample_A - 1:          # generator.py:359-366
+                x, atn, atn_vis = self.attention_module(x, label, label_ref)
+                xl, _, _ = self.attention_module(xl, None, None, atn)
+                ref_idx = torch.argmax(atn.reshape(label.shape[0], self.n_shot, -1).sum(2), dim=1)
+        self._atn = (atn_vis, ref_idx)
         if not encode:           # generator.py:370: test-time frames after the first re-use the cached weights
             return x, None
         fi, fl = [x], [xl]
@@ -492,7 +540,7 @@ class FewShotGenerator(nn.Module):
         # generator.py:370,403-416: at test time (isTrain False, one reference) the generated weights of frame 0 are kept
         # and every later frame only runs the down path of the reference encoder
         fresh = bool(self.opt.isTrain) or n > 1 or t == 0
-        x, enc = self.reference_encoding(img_ref, label_ref, encode=fresh)
+        x, enc = self.reference_encoding(img_ref, label_ref, encode=fresh, label=label)
         if fresh:
             embed_w, norm_w = [], []
             if self.adap_spade:
@@ -531,7 +579,8 @@ class FewShotGenerator(nn.Module):
             self._sn_count = sum(1 for _ in self.modules())
         self._sn_group.update(self.training)
         x, enc_label, norm_w = self.weight_generation(img_refs, label_refs, label, t=t)
-        label_ref, img_ref = label_refs[:, 0], img_refs[:, 0]
+        atn_vis, ref_idx = self._atn
+        label_ref, img_ref = pick_ref(label_refs, ref_idx), pick_ref(img_refs, ref_idx)
         flow, mask, warp, ds = self.flow_generation(label, label_ref, img_ref, prev)
         if self.spade_combine:
             emb = [self.img_ref_embedding(ds[0]), self.img_prev_embedding(ds[1]) if ds[1] is not None else None]
@@ -553,7 +602,7 @@ class FewShotGenerator(nn.Module):
                 img_final = ops.blend(img_final, warp[1], mask[1])
         else:
             img_final, img_raw = img_raw, None
-        return img_final, flow, mask, img_raw, warp, None, None, None, None
+        return img_final, flow, mask, img_raw, warp, None, None, atn_vis, ref_idx
 
 
 # ------------------------------------------------------------------------------------------------ discriminator

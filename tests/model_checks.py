@@ -97,6 +97,17 @@ def synth_pose_inputs(b, h, w, seed=1234, n_label=6):
     return tgt_label, tgt_image, ref_label, ref_image
 
 
+def with_n_shot(data, n_shot, b, h, w, seed, n_label):
+    """n_shot > 1: n_shot different reference (label, image) pairs per sample, [B, n_shot, C, H, W]"""
+    if n_shot <= 1:
+        return data
+    tl, ti, rl, ri = data
+    extra = [synth_pose_inputs(b, h, w, seed + 100 * k, n_label) for k in range(1, n_shot)]
+    rl = torch.cat([rl] + [e[2] for e in extra], dim=1)
+    ri = torch.cat([ri] + [e[3] for e in extra], dim=1)
+    return tl, ti, rl, ri
+
+
 def synth_street_inputs(b, h, w, seed=1234, n_classes=20):
     """SURVEY.md section 8(d) C5-style tensors: integer class maps (as float, blocky regions) and images U(-1,1)."""
     g = torch.Generator().manual_seed(seed)
@@ -339,6 +350,7 @@ def check_train_step(device, opt, b=2, tol=1e-3, seed=21, grad_tol=2e-2):
     h, w = int(opt.fineSize / opt.aspect_ratio), opt.fineSize
     nl = opt.label_nc if opt.label_nc != 0 else opt.input_nc
     data = synth_street_inputs(b, h, w, seed, opt.label_nc) if opt.label_nc != 0 else synth_pose_inputs(b, h, w, seed, nl)
+    data = with_n_shot(data, opt.n_shot, b, h, w, seed, nl)
     cfg = O.cfg_from_opt(opt)
     vw = _vgg_weights(opt)
     r32 = _oracle_iteration(sdG0, sdD0, cfg, data, torch.float32, vw, sdDf0)

@@ -14,7 +14,7 @@ import model_checks as mc
 from oracle import fsv_oracle as O
 
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
-CASES = ['pose_combine', 'face', 'pose_blend', 'pose_combine_vgg', 'street', 'pose_face_d']
+CASES = ['pose_combine', 'face', 'pose_blend', 'pose_combine_vgg', 'street', 'pose_face_d', 'face_nshot2']
 
 
 def _opt_from_flags(flags):
@@ -34,6 +34,8 @@ def _opt_from_flags(flags):
             kw['label_nc'] = int(toks[i + 1]); i += 2
         elif t == '--lambda_temp':
             kw['lambda_temp'] = float(toks[i + 1]); i += 2
+        elif t == '--n_shot':
+            kw['n_shot'] = int(toks[i + 1]); i += 2
         elif t == '--aspect_ratio':
             kw['aspect_ratio'] = float(toks[i + 1]); i += 2
         elif t == '--gpu_ids':
@@ -58,7 +60,8 @@ def _inputs(g, opt):
         h, w = g['hw']
         return mc.synth_street_inputs(g['batch'], h, w, g['seed'], opt.label_nc)
     nl = opt.label_nc if opt.label_nc != 0 else opt.input_nc
-    return mc.synth_pose_inputs(g['batch'], g['size'], g['size'], g['seed'], nl)
+    return mc.with_n_shot(mc.synth_pose_inputs(g['batch'], g['size'], g['size'], g['seed'], nl), opt.n_shot, g['batch'],
+                          g['size'], g['size'], g['seed'], nl)
 
 
 def _load(case):

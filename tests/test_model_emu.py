@@ -62,3 +62,9 @@ def test_temporal_discriminator_tiny(emu_lib):
     """--lambda_temp > 0: netDT on two stacked frames (D terms DT_real / DT_fake, G terms GT_GAN / GT_GAN_Feat)"""
     mc.check_temporal_step(DEV, mc.tiny_opt(warp_ref=True, spade_combine=True, remove_face_labels=True, lambda_temp=2.0),
                            b=2)
+
+
+def test_train_step_two_reference_images_tiny(emu_lib):
+    """--n_shot 2: attention module (key / query encoders, energy over 2 * HW reference positions, softmax, weighted
+    sum of the reference features), flow / losses on the attended reference"""
+    mc.check_train_step(DEV, mc.tiny_opt(dataset_mode='fewshot_face', input_nc=1, n_shot=2, warp_ref=True), b=2)

@@ -65,3 +65,9 @@ def test_temporal_discriminator(hip_lib):
     """--lambda_temp > 0: netDT on two stacked frames"""
     mc.check_temporal_step(dev(), mc.tiny_opt(ngf=8, ndf=8, nff=8, warp_ref=True, spade_combine=True,
                                               remove_face_labels=True, lambda_temp=2.0, fineSize=128, loadSize=128), b=2)
+
+
+def test_train_step_two_reference_images(hip_lib):
+    """--n_shot 2: attention over two reference images (two per-sample GEMMs + channel softmax), attended-reference warp"""
+    mc.check_train_step(dev(), mc.tiny_opt(ngf=8, ndf=8, nff=8, dataset_mode='fewshot_face', input_nc=1, n_shot=2,
+                                           warp_ref=True, fineSize=128, loadSize=128), b=2)
