@@ -197,6 +197,19 @@ int fsv_crop_resize_fwd(const float* img, long long sn, long long sc, long long 
 int fsv_crop_resize_bwd(const float* dout, const int* boxes, float* dimg, long long sn, long long sc, long long sy,
                         long long sx, int C, int N, int S, fsv_stream_t stream);
 
+/* ---- the FlowNet2 teacher's three native operators, forward only (csrc/flownet_ops.hip) ----
+ * correlation (correlation_cuda_kernel.cu:74-147; kernel_size 1): f1 / f2 NHWC [N][H][W][C] -> out NHWC
+ *   [N][OH][OW][D*D], D = 2*(max_disp/stride2)+1, OH = ceil((H + 2*pad - 2*max_disp)/stride1), value = mean_c f1*f2.
+ * resample2d (resample2d_kernel.cu:16-64): pixel-unit flow, clamped tap indices; strides = 4 x long long (n, c, y, x).
+ * channelnorm (channelnorm_kernel.cu:18-60): out[n][p] = sqrt(sum_c x^2); x strides (sn, sc, sp). */
+int fsv_correlation_fwd(const float* f1, const float* f2, float* out, int N, int H, int W, int C, int pad, int kernel_size,
+                        int max_disp, int stride1, int stride2, fsv_stream_t stream);
+int fsv_resample2d_fwd(const float* img, const float* flow, float* out, int N, int C, int H, int W,
+                       const long long* img_strides, const long long* flow_strides, const long long* out_strides,
+                       fsv_stream_t stream);
+int fsv_channelnorm_fwd(const float* x, float* out, int N, int C, long long HW, long long sn, long long sc, long long sp,
+                        fsv_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

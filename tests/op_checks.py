@@ -522,6 +522,41 @@ def check_face_ops(device, seed=17):
             assert_close('crop face grad', img_d.grad, img_r.grad, 1e-6)
 
 
+def check_flownet_ops(device, seed=18):
+    """FlowNet2's native operators (csrc/flownet_ops.hip) vs the restatement of the reference CUDA kernels
+    (oracle/flownet_oracle.py): cost volume 1e-5 (summation order), warp and channel norm bit-exact."""
+    from importlib import import_module
+    import fsv2v_amd  # noqa: F401
+    fo = import_module('few-shot-vid2vid_amd.flownet_ops')
+    from oracle import flownet_oracle as FO
+    g = torch.Generator().manual_seed(seed)
+    with torch.no_grad():
+        # FlowNetC's configuration (FlowNetC.py:28-31) on a small map, plus odd sizes / strides
+        for (n, c, h, w, pad, md, s1, s2) in [(2, 70, 9, 37, 20, 20, 1, 2), (1, 64, 12, 40, 4, 4, 1, 1),
+                                               (1, 5, 11, 13, 6, 6, 2, 3)]:
+            f1, f2 = torch.randn(n, c, h, w, generator=g), torch.randn(n, c, h, w, generator=g)
+            ref = FO.correlation(f1, f2, pad, 1, md, s1, s2)
+            got = fo.correlation(_dev(f1, device), _dev(f2, device), pad, 1, md, s1, s2)
+            assert tuple(got.shape) == tuple(ref.shape), (got.shape, ref.shape)
+            assert_close('correlation', got, ref, 1e-5)
+        for (n, c, h, w, mag) in [(2, 3, 17, 23, 6.0), (1, 2, 8, 64, 80.0)]:
+            img = torch.randn(n, c, h, w, generator=g)
+            flow = (torch.rand(n, 2, h, w, generator=g) - 0.5) * mag
+            flow[:, :, 0] = torch.round(flow[:, :, 0])               # integer displacements: alpha = beta = 0
+            ref = FO.resample2d(img, flow)
+            got = fo.resample2d(_dev(img, device), _dev(flow, device)).cpu()
+            assert torch.equal(got, ref), float((got - ref).abs().max())
+            nhwc = fo.resample2d(conv_nhwc(_dev(img, device)), _dev(flow, device)).cpu()
+            assert torch.equal(nhwc, ref)
+        x = torch.randn(2, 7, 5, 9, generator=g) * 3
+        assert torch.equal(fo.channelnorm(_dev(x, device)).cpu(), FO.channelnorm(x))
+        assert torch.equal(fo.channelnorm(conv_nhwc(_dev(x, device))).cpu(), FO.channelnorm(x))
+
+
+def conv_nhwc(t):
+    return pkg()[1].to_nhwc(t)
+
+
 def check_adam(device, n=1000, seed=9):
     ops, conv = pkg()
     g = torch.Generator().manual_seed(seed)
@@ -564,3 +599,4 @@ def run_all(device, big=False):
     check_adam(device)
     check_part_masks(device)
     check_face_ops(device)
+    check_flownet_ops(device)

@@ -89,6 +89,10 @@ def test_face_boxes_and_crop(emu_lib):
     oc.check_face_ops(DEV)
 
 
+def test_flownet2_native_operators(emu_lib):
+    oc.check_flownet_ops(DEV)
+
+
 def test_adam(emu_lib):
     oc.check_adam(DEV, n=300)
 

@@ -110,6 +110,10 @@ def test_face_boxes_and_crop(hip_lib):
     oc.check_face_ops(dev())
 
 
+def test_flownet2_native_operators(hip_lib):
+    oc.check_flownet_ops(dev())
+
+
 def test_adam(hip_lib):
     oc.check_adam(dev(), n=100003)
 
