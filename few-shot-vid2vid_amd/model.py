@@ -227,14 +227,23 @@ class LossCollector:
             total = losses if total is None else [a + b for a, b in zip(total, losses)]
         return total
 
-    def flow_losses(self, flow, warped, tgt_image, fg_mask, tgt_label, ref_label):
-        """loss_collector.py:132-162 with flow_gt = None (--no_flow_gt)."""
+    def flow_losses(self, flow, warped, tgt_image, fg_mask, tgt_label, ref_label, flow_gt=(None, None),
+                    conf_gt=(None, None)):
+        """loss_collector.py:132-162.  flow_gt / conf_gt: the FlowNet2 teacher's flow and confidence for the reference
+        and the previous-frame branch ([B, T, 2|1, H, W] or None each; None with --no_flow_gt)."""
         opt = self.opt
         z = self.zero(tgt_image)
         warp_loss = z.clone()
-        for f, wimg in zip(flow, warped):
+        flow_loss = z.clone()
+        flow_gt = list(flow_gt) if flow_gt is not None else [None, None]
+        conf_gt = list(conf_gt) if conf_gt is not None else [None, None]
+        for k, (f, wimg) in enumerate(zip(flow, warped)):
             if f is not None:
                 warp_loss = warp_loss + l1(wimg, tgt_image)
+                if flow_gt[k] is not None and getattr(opt, 'n_shot', 1) == 1:      # loss_collector.py:158-159
+                    gt = flow_gt[k].reshape(-1, *flow_gt[k].shape[-3:])
+                    conf = conf_gt[k].reshape(-1, *conf_gt[k].shape[-3:])
+                    flow_loss = flow_loss + masked_l1(f, gt, conf * fg_mask if fg_mask is not None else conf)
         body_diff = None
         if self.pose and flow[0] is not None:
             body = part_masks(tgt_label[:, :, 2])
@@ -247,7 +256,7 @@ class LossCollector:
                 fg, ref_fg = fg_mask_of(opt, tgt_label, True), fg_mask_of(opt, ref_label, True)
                 warp_loss = warp_loss + l1(ops.resample(ref_fg, flow[0]), fg)
             body_diff = (ref_body_warp - body).abs().sum(dim=1, keepdim=True)
-        return z * opt.lambda_flow, warp_loss * opt.lambda_flow, body_diff
+        return flow_loss * opt.lambda_flow, warp_loss * opt.lambda_flow, body_diff
 
     def mask_losses(self, flow_mask, fake_image, warped, tgt_label, tgt_image, fg_mask, ref_fg_mask, body_diff):
         """loss_collector.py:164-204."""
@@ -387,7 +396,8 @@ class Vid2VidModel(nn.Module):
         tgt_label, ref_label = encode_label(opt, tgt_label), encode_label(opt, ref_label)
         prevs = [p_label, p_real, p_fake]
         if mode == 'generator':
-            losses, generated, prev = self.forward_generator(tgt_label, tgt_image, ref_label, ref_image, prevs)
+            losses, generated, prev = self.forward_generator(tgt_label, tgt_image, ref_label, ref_image, prevs,
+                                                             flow_gt, conf_gt)
             return losses, generated if save_images else [], prev
         if mode == 'discriminator':
             return self.forward_discriminator(tgt_label, tgt_image, ref_label, ref_image, prevs)
@@ -467,7 +477,8 @@ class Vid2VidModel(nn.Module):
             losses = list(losses) + self.lossCollector.temporal_losses(self.netDT, real_all, fake_all, True)
         return [l.view(1, 1) for l in losses]
 
-    def forward_generator(self, tgt_label, tgt_image, ref_labels, ref_images, prevs):
+    def forward_generator(self, tgt_label, tgt_image, ref_labels, ref_images, prevs, flow_gt=(None, None),
+                          conf_gt=(None, None)):
         """vid2vid_model.py:62-104."""
         lc = self.lossCollector
         (fake, raw, warped, flow, mask), (fg, ref_fg), (ref_label, ref_image), prevs_new = \
@@ -497,7 +508,7 @@ class Vid2VidModel(nn.Module):
                 p.requires_grad_(True)
         z = lc.zero(fake)
         g_vgg = lc.vgg_losses(fake, raw, real, fg_union)
-        f_flow, f_warp, body_diff = lc.flow_losses(flow, warped, real, fg, tgt_label, ref_label)
+        f_flow, f_warp, body_diff = lc.flow_losses(flow, warped, real, fg, tgt_label, ref_label, flow_gt, conf_gt)
         f_mask = lc.mask_losses(mask, fake, warped, tgt_label, real, fg, ref_fg, body_diff)
         losses = [g_gan, g_feat, g_vgg, gf_gan, gf_feat, gt_gan if gt_gan is not None else z.clone(),
                   gt_feat if gt_feat is not None else z.clone(), f_flow, f_warp, f_mask]

@@ -45,6 +45,8 @@ CONFIGS['pose_face_d'] = CONFIGS['pose_combine_vgg'].replace('--fineSize 64 --lo
 CONFIGS['pose_combine_dt'] = CONFIGS['pose_combine'] + ' --lambda_temp 2'
 # two reference images: the attention module of generator.py:291-316 and pick_ref
 CONFIGS['face_nshot2'] = CONFIGS['face'] + ' --n_shot 2 --warp_ref'
+# teacher flow present (training without --no_flow_gt): flow_gt / conf_gt are synthetic stand-ins fed through data_list
+CONFIGS['pose_combine_flowgt'] = CONFIGS['pose_combine'].replace(' --no_flow_gt', '')
 # street: integer class maps, one-hot encoded by encode_label (input_process.py:25-45); default aspect_ratio 2 -> 32 x 64
 CONFIGS['street'] = ('--dataset_mode fewshot_street --label_nc 7 --fineSize 64 --loadSize 64 --adaptive_spade --no_flow_gt '
                      '--no_vgg_loss --gpu_ids -1 --ngf 8 --ndf 8 --batchSize 2')
@@ -86,7 +88,10 @@ def step(name, flags):
         tl, ti, rl, ri = mc.synth_street_inputs(2, h, w, 4242, opt.label_nc)
     else:
         tl, ti, rl, ri = mc.with_n_shot(mc.synth_pose_inputs(2, h, w, 4242, nl), opt.n_shot, 2, h, w, 4242, nl)
-    data = [tl, ti, [None, None], [None, None], rl, ri, None, None, None]
+    flow_gt, conf_gt = [None, None], [None, None]
+    if name.endswith('_flowgt'):
+        flow_gt[0], conf_gt[0] = mc.synth_flow_gt(2, h, w, 4247)
+    data = [tl, ti, flow_gt, conf_gt, rl, ri, None, None, None]
     d_losses = model(data, mode='discriminator')
     d_losses = loss_backward(opt, d_losses, model.optimizer_D, 1)
     gD = {k: float(p.grad.norm()) for k, p in model.netD.named_parameters() if p.grad is not None}

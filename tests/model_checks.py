@@ -303,7 +303,7 @@ def _vgg_weights(opt):
     return import_module('few-shot-vid2vid_amd.vgg').random_vgg19_weights()
 
 
-def _oracle_iteration(sdG0, sdD0, cfg, data, dtype, vgg_weights=None, sdDf0=None):
+def _oracle_iteration(sdG0, sdD0, cfg, data, dtype, vgg_weights=None, sdDf0=None, flow_gt=None, conf_gt=None):
     """One reference iteration (train.py:58-62) on the oracle: D step then G step; returns losses and gradients
     (the face discriminator's gradients, when present, as a 6th entry)."""
     tl, ti, rl, ri = [t.to(dtype) for t in data]
@@ -326,13 +326,25 @@ def _oracle_iteration(sdG0, sdD0, cfg, data, dtype, vgg_weights=None, sdDf0=None
     for v in list(sdG.values()) + list(sdD.values()) + list((sdDf or {}).values()):
         if v.is_floating_point() and v.grad is not None:
             v.grad = None
-    g_losses, gen = O.g_step_losses(sdG, sdD, cfg, tl, ti, rl, ri, vgg_weights=vgg_weights, sdDf=sdDf)
+    fg = [None if f is None else f.to(dtype) for f in (flow_gt or [None, None])]
+    cg = [None if f is None else f.to(dtype) for f in (conf_gt or [None, None])]
+    g_losses, gen = O.g_step_losses(sdG, sdD, cfg, tl, ti, rl, ri, vgg_weights=vgg_weights, sdDf=sdDf, flow_gt=fg,
+                                    conf_gt=cg)
     sum(l.mean() for l in g_losses.values()).backward()
     gG = {k: v.grad.clone() for k, v in sdG.items() if v.is_floating_point() and v.grad is not None}
     return d_losses, gD, g_losses, gG, gen, gDf
 
 
-def check_train_step(device, opt, b=2, tol=1e-3, seed=21, grad_tol=2e-2):
+def synth_flow_gt(b, h, w, seed):
+    """stand-in for the FlowNet2 teacher's output: a smooth flow of a few pixels and a binary confidence map"""
+    g = torch.Generator().manual_seed(seed)
+    coarse = (torch.rand(b, 2, max(h // 8, 2), max(w // 8, 2), generator=g) - 0.5) * 6
+    flow = torch.nn.functional.interpolate(coarse, size=(h, w), mode='bilinear', align_corners=True).unsqueeze(1)
+    conf = (torch.rand(b, 1, 1, h, w, generator=g) < 0.7).float()
+    return flow, conf
+
+
+def check_train_step(device, opt, b=2, tol=1e-3, seed=21, grad_tol=2e-2, with_flow_gt=False):
     """Full D-step + G-step of the product model (flat Adam included) against the oracle.
 
     Losses and images are held to `tol` (1e-3 relative, BASELINE.json).  Parameter gradients of the *step* get the
@@ -353,10 +365,14 @@ def check_train_step(device, opt, b=2, tol=1e-3, seed=21, grad_tol=2e-2):
     data = with_n_shot(data, opt.n_shot, b, h, w, seed, nl)
     cfg = O.cfg_from_opt(opt)
     vw = _vgg_weights(opt)
-    r32 = _oracle_iteration(sdG0, sdD0, cfg, data, torch.float32, vw, sdDf0)
-    r64 = _oracle_iteration(sdG0, sdD0, cfg, data, torch.float64, vw, sdDf0)
+    flow_gt, conf_gt = [None, None], [None, None]
+    if with_flow_gt:                       # teacher flow for the reference branch (train.py:44-48 without --no_flow_gt)
+        flow_gt[0], conf_gt[0] = synth_flow_gt(b, h, w, seed + 5)
+    r32 = _oracle_iteration(sdG0, sdD0, cfg, data, torch.float32, vw, sdDf0, flow_gt, conf_gt)
+    r64 = _oracle_iteration(sdG0, sdD0, cfg, data, torch.float64, vw, sdDf0, flow_gt, conf_gt)
     tl, ti, rl, ri = [t.to(device) for t in data]
-    data_list = [tl, ti, [None, None], [None, None], rl, ri, None, None, None]
+    dv = lambda lst: [None if t is None else t.to(device) for t in lst]
+    data_list = [tl, ti, dv(flow_gt), dv(conf_gt), rl, ri, None, None, None]
     d_losses = model(data_list, mode='discriminator')
     d_losses = M.loss_backward(opt, d_losses, opt_D, 1)
     for i, name in enumerate(('D_real', 'D_fake', 'Df_real', 'Df_fake')[:len(r32[0])]):

@@ -14,7 +14,8 @@ import model_checks as mc
 from oracle import fsv_oracle as O
 
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
-CASES = ['pose_combine', 'face', 'pose_blend', 'pose_combine_vgg', 'street', 'pose_face_d', 'face_nshot2']
+CASES = ['pose_combine', 'face', 'pose_blend', 'pose_combine_vgg', 'street', 'pose_face_d', 'face_nshot2',
+         'pose_combine_flowgt']
 
 
 def _opt_from_flags(flags):
@@ -64,6 +65,13 @@ def _inputs(g, opt):
                           g['size'], g['size'], g['seed'], nl)
 
 
+def _flow_gt(case, g):
+    if not case.endswith('_flowgt'):
+        return [None, None], [None, None]
+    flow, conf = mc.synth_flow_gt(g['batch'], g['size'], g['size'], g['seed'] + 5)
+    return [flow, None], [conf, None]
+
+
 def _load(case):
     return torch.load(os.path.join(GOLD, 'step_%s.pt' % case), weights_only=False)
 
@@ -89,7 +97,7 @@ def test_oracle_reproduces_reference_iteration(case):
     data = _inputs(g, opt)
     sdDf0 = mc.fill_state(model.netDf) if model.netDf is not None else None
     d_losses, gD, g_losses, gG, gen, gDf = mc._oracle_iteration(sdG0, sdD0, O.cfg_from_opt(opt), data, torch.float32,
-                                                           mc._vgg_weights(opt), sdDf0)
+                                                           mc._vgg_weights(opt), sdDf0, *_flow_gt(case, g))
     names = g['loss_names']
     for i in range(2, len(d_losses)):              # Df_real, Df_fake with --add_face_D
         assert abs(float(d_losses[i]) - g['d_losses'][i]) <= 1e-5 * max(1.0, abs(g['d_losses'][i])), i
@@ -157,7 +165,9 @@ def test_product_reproduces_reference_iteration_on_gpu(hip_lib, case):
     opt_G.set_lr(0.0); opt_D.set_lr(0.0)
     nl = opt.label_nc if opt.label_nc != 0 else opt.input_nc
     tl, ti, rl, ri = [t.to(dev) for t in _inputs(g, opt)]
-    data = [tl, ti, [None, None], [None, None], rl, ri, None, None, None]
+    fgt, cgt = _flow_gt(case, g)
+    data = [tl, ti, [None if t is None else t.to(dev) for t in fgt], [None if t is None else t.to(dev) for t in cgt], rl,
+            ri, None, None, None]
     d = M.loss_backward(opt, model(data, mode='discriminator'), opt_D, 1)
     gl, generated, _ = model(data, save_images=True, mode='generator')
     gl = M.loss_backward(opt, gl, opt_G, 0)

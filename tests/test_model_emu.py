@@ -68,3 +68,9 @@ def test_train_step_two_reference_images_tiny(emu_lib):
     """--n_shot 2: attention module (key / query encoders, energy over 2 * HW reference positions, softmax, weighted
     sum of the reference features), flow / losses on the attended reference"""
     mc.check_train_step(DEV, mc.tiny_opt(dataset_mode='fewshot_face', input_nc=1, n_shot=2, warp_ref=True), b=2)
+
+
+def test_train_step_with_teacher_flow_tiny(emu_lib):
+    """flow_gt / conf_gt present (training without --no_flow_gt): the masked-L1 flow loss F_Flow against the teacher"""
+    mc.check_train_step(DEV, mc.tiny_opt(warp_ref=True, spade_combine=True, remove_face_labels=True, no_flow_gt=False), b=2,
+                        with_flow_gt=True)
