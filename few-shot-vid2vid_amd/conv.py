@@ -11,7 +11,7 @@ import torch
 
 from . import lib, profile
 
-ACT_NONE, ACT_LRELU, ACT_TANH, ACT_SIGMOID, ACT_RELU = 0, 1, 2, 3, 4
+ACT_NONE, ACT_LRELU, ACT_TANH, ACT_SIGMOID, ACT_RELU, ACT_LRELU01 = 0, 1, 2, 3, 4, 5
 
 
 def to_nhwc(x):

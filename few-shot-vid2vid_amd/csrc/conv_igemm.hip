@@ -709,6 +709,18 @@ int fsv_conv_gather_fwd(const float* in, const float* wt, const float* bias, con
   return rc;
 }
 
+// In-place x = act(x + bias[c]) over an NHWC tensor of `total` elements (the split-K finishing pass, exposed for operators
+// that accumulate several launches into one output: > 16-tap convolutions, transposed convolutions)
+int fsv_bias_act(float* x, const float* bias, long long total, int C, int act, hipStream_t stream) {
+  if (!x || total < 1 || C < 1) return FSV_ERR_BAD_ARG;
+  int grid = (int)((total + 256 * 8 - 1) / (256 * 8));
+  if (grid > 4096) grid = 4096;
+  if (grid < 1) grid = 1;
+  FSV_LAUNCH(fsv_bias_act_kernel, dim3(grid), dim3(256), stream, x, bias, (const float*)nullptr, total, C, 1ll, 0ll, act,
+             1.f);
+  return fsv_check_launch();
+}
+
 int fsv_conv_wgrad(const float* in, const float* dout, float* dwt,
                    int N, int H, int W, int Cin, int OH, int OW, int Cout,
                    int ntaps, const int* ty, const int* tx, int sy, int sx,

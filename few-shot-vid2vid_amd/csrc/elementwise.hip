@@ -73,6 +73,7 @@ __global__ __launch_bounds__(256) void fsv_act_bwd_kernel(const float* dy, const
     else if (act == FSV_ACT_TANH) d = d * (1.f - v * v);
     else if (act == FSV_ACT_SIGMOID) d = d * v * (1.f - v);
     else if (act == FSV_ACT_RELU) d = v > 0.f ? d : 0.f;
+    else if (act == FSV_ACT_LRELU01) d = v > 0.f ? d : 0.1f * d;
     dx[i] = d;
   }
 }

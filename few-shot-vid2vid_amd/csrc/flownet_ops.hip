@@ -118,6 +118,20 @@ __global__ __launch_bounds__(256) void fsv_resample2d_kernel(const float* img, c
   }
 }
 
+// Correctly rounded float square root from basic IEEE operations: the device sqrt (float and, as measured on gfx950, the
+// float rounding of the double one) can be 1 ulp off the CPU / CUDA result.  y is within 1 ulp; the midpoints to its
+// neighbours have 25 significant bits, so their squares are exact in double and decide the rounding.
+__device__ __forceinline__ float fsv_sqrt_rn(float r) {
+  float y = sqrtf(r);
+  if (!(r > 0.f) || !(y > 0.f)) return y;
+  const float lo = nextafterf(y, 0.f), hi = nextafterf(y, 3.0e38f);
+  const double rd = (double)r;
+  const double m1 = 0.5 * ((double)y + (double)lo), m2 = 0.5 * ((double)y + (double)hi);
+  if (rd < m1 * m1) y = lo;
+  else if (rd > m2 * m2) y = hi;
+  return y;
+}
+
 __global__ __launch_bounds__(256) void fsv_channelnorm_kernel(const float* x, float* out, int N, int C, long long HW,
                                                               long long sn, long long sc, long long sp) {
   const long long total = (long long)N * HW;
@@ -128,7 +142,7 @@ __global__ __launch_bounds__(256) void fsv_channelnorm_kernel(const float* x, fl
       const float v = x[n * sn + c * sc + p * sp];
       r += v * v;
     }
-    out[i] = sqrtf(r);
+    out[i] = fsv_sqrt_rn(r);
   }
 }
 

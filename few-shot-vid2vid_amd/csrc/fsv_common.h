@@ -36,6 +36,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define FSV_ACT_TANH 2
 #define FSV_ACT_SIGMOID 3
 #define FSV_ACT_RELU 4      // VGG19 feature stack (models/networks/vgg.py)
+#define FSV_ACT_LRELU01 5   // leaky_relu(x, 0.1): FlowNet2 teacher (flownet2_pytorch/networks/submodules.py:16,39)
 
 #ifdef FSV_EMU
 static inline int fsv_check_launch() {
@@ -55,6 +56,7 @@ __device__ __forceinline__ float fsv_act(float v, int act) {
   if (act == FSV_ACT_TANH) return tanhf(v);
   if (act == FSV_ACT_SIGMOID) return 1.f / (1.f + expf(-v));
   if (act == FSV_ACT_RELU) return v > 0.f ? v : 0.f;
+  if (act == FSV_ACT_LRELU01) return v > 0.f ? v : 0.1f * v;
   return v;
 }
 

@@ -46,6 +46,7 @@ __device__ __forceinline__ float fsv_act_grad(float dy, float y, int act) {
   if (act == FSV_ACT_TANH) return dy * (1.f - y * y);
   if (act == FSV_ACT_SIGMOID) return dy * y * (1.f - y);
   if (act == FSV_ACT_RELU) return y > 0.f ? dy : 0.f;
+  if (act == FSV_ACT_LRELU01) return y > 0.f ? dy : 0.1f * dy;
   return dy;
 }
 

@@ -35,9 +35,19 @@ def create_model(opt, epoch=0):
     m = _model.create_model(opt, epoch, device)
     world = torch.distributed.get_world_size() if torch.distributed.is_available() and torch.distributed.is_initialized() else 1
     opt_G, opt_D = m.build_optimizers(world_size=world)
+    flow_net = None
     if not opt.no_flow_gt:
-        raise NotImplementedError("FlowNet2 ground-truth flow is the next scope row (SURVEY.md 8f); pass --no_flow_gt")
-    return _ModuleHandle(m), None, [opt_G, opt_D]
+        # models/models.py:31-35: the FlowNet2 teacher.  Its checkpoint is looked up where the reference keeps it
+        # (models/flownet.py:28); without it the teacher would run on random weights, which is refused.
+        from .flownet2 import FlowNet
+        import os
+        ckpt = getattr(opt, 'flownet2_checkpoint', 'models/networks/flownet2_pytorch/FlowNet2_checkpoint.pth.tar')
+        if not os.path.exists(ckpt):
+            raise FileNotFoundError("FlowNet2 checkpoint %s not found: pass --no_flow_gt or provide it" % ckpt)
+        flow_net = FlowNet(opt)
+        flow_net.flowNet.load_state_dict(torch.load(ckpt, map_location='cpu')['state_dict'])
+        flow_net = _ModuleHandle(flow_net.to(device))
+    return _ModuleHandle(m), flow_net, [opt_G, opt_D]
 
 
 def patch_reference():

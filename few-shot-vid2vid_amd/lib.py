@@ -31,6 +31,7 @@ _SIGS = {
                        c_i, c_i, c_i, c_i, c_i, c_i, c_i,
                        c_i, c_ip, c_ip, c_i, c_i,
                        c_i, c_i, c_ll, c_i, c_i, c_i, c_i, c_p],
+    "fsv_bias_act": [c_p, c_p, c_ll, c_i, c_i, c_p],
     "fsv_prep_weight_grouped": [c_p, c_p, c_p, c_p, c_p, c_i, c_p],
     "fsv_prep_weight": [c_p, c_p, c_p, c_i, c_i,
                         c_i, c_i, c_i, c_i, c_i, c_ip, c_ip,

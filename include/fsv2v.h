@@ -50,6 +50,9 @@ int fsv_conv_gather_fwd(const float* in, const float* wt, const float* bias, con
                         int act, float scale, int force_tile, int force_split, int accumulate, const float* wscale,
                         fsv_stream_t stream);
 
+/* in place: x = act(x + bias[c]) over an NHWC tensor (finishing pass of operators that add several GEMM launches into one
+ * output: convolutions with more than 16 taps, transposed convolutions); act codes as in the conv epilogue, 5 = leaky 0.1 */
+int fsv_bias_act(float* x, const float* bias, long long total, int C, int act, fsv_stream_t stream);
 /* dwt[t*Cin+ci][co] = sum_{n,oy,ox} in[n, oy*sy+ty[t], ox*sx+tx[t], ci] * dout[n, oy, ox, co]  (weight gradient)
  * prezeroed: dwt already holds zeros (a slice of the optimiser's per-pass arena), skip the split-K zero-fill;
  * force_tile: 0 = automatic (1 / 2 / 3 = 64x64 / 128x64 / 64x128 rows x columns, for A/B runs) */

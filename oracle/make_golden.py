@@ -179,6 +179,26 @@ def inference(name, flags):
     print('inference', name, [round(float(f.abs().mean()), 5) for f in fakes])
 
 
+def flownet2():
+    """FlowNet2 teacher (models/networks/flownet2_pytorch/models.py) on CPU: the reference's network python unmodified,
+    its three CUDA extensions replaced by oracle/flownet_oracle.py (ref_import.install_flownet_shims).  The fixture holds
+    the output flow and the state_dict layout (162.5 M parameters: weights come from fill_state)."""
+    import model_checks as mc
+    net = ref_import.build_flownet2()
+    mc.fill_state(net, scale=0.6)
+    g = torch.Generator().manual_seed(51)
+    size, b = 128, 1
+    coarse = torch.rand(b, 3, 2, size // 8, size // 8, generator=g)
+    frames = torch.nn.functional.interpolate(coarse.view(b, 6, size // 8, size // 8), size=(size, size), mode='bilinear',
+                                             align_corners=True).view(b, 3, 2, size, size)
+    with torch.no_grad():
+        flow = net(frames)
+    torch.save(dict(seed=51, size=size, batch=b, flow=flow.clone(),
+                    layout={k: list(v.shape) for k, v in net.state_dict().items()}),
+               os.path.join(OUT, 'flownet2.pt'))
+    print('flownet2', tuple(flow.shape), float(flow.abs().max()), sum(v.numel() for v in net.state_dict().values()))
+
+
 def warp_taps():
     ref_import.install_shims()
     from models.networks.base_network import resample
@@ -208,7 +228,9 @@ if __name__ == '__main__':
     os.makedirs(OUT, exist_ok=True)
     if len(sys.argv) > 1:                # mint only the named step cases (keeps the other fixtures byte-identical)
         for n in sys.argv[1:]:
-            if n.startswith('inference:'):
+            if n == 'flownet2':
+                flownet2()
+            elif n.startswith('inference:'):
                 inference(n[10:], CONFIGS[n[10:]])
             elif n.startswith('temporal:'):
                 temporal(n[9:], CONFIGS[n[9:]])
@@ -223,4 +245,5 @@ if __name__ == '__main__':
     temporal('pose_combine_dt', CONFIGS['pose_combine_dt'])
     inference('pose_combine', CONFIGS['pose_combine'])
     warp_taps()
+    flownet2()
     print('goldens written to', OUT)

@@ -104,6 +104,39 @@ def install_shims():
     _installed = True
 
 
+def install_flownet_shims():
+    """The reference's FlowNet2 python (models/networks/flownet2_pytorch) imports three compiled CUDA extensions.  They
+    cannot be built here (no nvcc / CUDA device), so the *compiled modules* - and only those - are replaced by python
+    modules backed by the CPU restatements of their kernels in oracle/flownet_oracle.py; the reference's own autograd
+    Function / Module wrappers and all network code then run unmodified on CPU tensors."""
+    install_shims()
+    from oracle import flownet_oracle as FO
+
+    def resample_fwd(input1, input2, output, kernel_size):
+        assert kernel_size == 1
+        output.copy_(FO.resample2d(input1, input2))
+
+    def channelnorm_fwd(input1, output, norm_deg):
+        assert norm_deg == 2
+        output.copy_(FO.channelnorm(input1))
+
+    def correlation_fwd(input1, input2, rbot1, rbot2, output, pad_size, kernel_size, max_displacement, stride1, stride2,
+                        corr_multiply):
+        res = FO.correlation(input1, input2, pad_size, kernel_size, max_displacement, stride1, stride2)
+        output.resize_(res.shape).copy_(res)
+    _stub("resample2d_cuda", forward=resample_fwd)
+    _stub("channelnorm_cuda", forward=channelnorm_fwd)
+    _stub("correlation_cuda", forward=correlation_fwd)
+
+
+def build_flownet2():
+    install_flownet_shims()
+    from models.networks.flownet2_pytorch import models as flownet2_models
+    net = flownet2_models.FlowNet2()
+    net.eval()
+    return net
+
+
 def make_opt(argv):
     """Build the reference's ``opt`` Namespace from a flag list, without touching disk.
 

@@ -42,33 +42,36 @@ def make_opt(**kw):
     return argparse.Namespace(**d)
 
 
+def fill_value(k, shape, scale=1.0):
+    """the deterministic value of state_dict entry `k` (see fill_state)"""
+    shape = tuple(shape)
+    seed = int(hashlib.sha1(k.encode()).hexdigest()[:8], 16)
+    rng = np.random.default_rng(seed)
+    if k.endswith('num_batches_tracked'):
+        return torch.zeros(shape, dtype=torch.long)
+    if k.endswith('running_mean'):
+        return torch.zeros(shape)
+    if k.endswith('running_var'):
+        return torch.ones(shape)
+    if k.endswith('weight_u') or k.endswith('weight_v'):
+        a = rng.standard_normal(shape).astype(np.float32)
+        return torch.from_numpy(a / max(np.linalg.norm(a), 1e-12))
+    if len(shape) == 1 and k.endswith('weight'):
+        return torch.from_numpy((1.0 + 0.1 * rng.standard_normal(shape)).astype(np.float32))
+    if len(shape) == 1:
+        return torch.from_numpy((0.05 * rng.standard_normal(shape)).astype(np.float32))
+    fan_in = int(np.prod(shape[1:]))
+    std = scale * (1.5 / np.sqrt(fan_in))
+    if 'conv_flow' in k:
+        std *= 0.05      # keep synthetic flows at a few pixels: the warp is only piecewise smooth
+    return torch.from_numpy((std * rng.standard_normal(shape)).astype(np.float32))
+
+
 def fill_state(module, scale=1.0):
     """Overwrite every parameter/buffer with values that depend only on its state_dict key (numpy Generator is
     stable across platforms), so that the product, the oracle and the golden fixtures see identical weights."""
     sd = module.state_dict()
-    new = {}
-    for k, v in sd.items():
-        seed = int(hashlib.sha1(k.encode()).hexdigest()[:8], 16)
-        rng = np.random.default_rng(seed)
-        if k.endswith('num_batches_tracked'):
-            new[k] = torch.zeros_like(v)
-        elif k.endswith('running_mean'):
-            new[k] = torch.zeros_like(v)
-        elif k.endswith('running_var'):
-            new[k] = torch.ones_like(v)
-        elif k.endswith('weight_u') or k.endswith('weight_v'):
-            a = rng.standard_normal(v.shape).astype(np.float32)
-            new[k] = torch.from_numpy(a / max(np.linalg.norm(a), 1e-12))
-        elif v.dim() == 1 and k.endswith('weight'):
-            new[k] = torch.from_numpy((1.0 + 0.1 * rng.standard_normal(v.shape)).astype(np.float32))
-        elif v.dim() == 1:
-            new[k] = torch.from_numpy((0.05 * rng.standard_normal(v.shape)).astype(np.float32))
-        else:
-            fan_in = int(np.prod(v.shape[1:]))
-            std = scale * (1.5 / np.sqrt(fan_in))
-            if 'conv_flow' in k:
-                std *= 0.05      # keep synthetic flows at a few pixels: the warp is only piecewise smooth
-            new[k] = torch.from_numpy((std * rng.standard_normal(v.shape)).astype(np.float32))
+    new = {k: fill_value(k, v.shape, scale).to(v.dtype) for k, v in sd.items()}
     module.load_state_dict(new)
     return new
 
@@ -596,3 +599,55 @@ def check_layout_cache(device, opt, b=1, seed=41, tol=1e-5):
     # entries the forward pass touched are fresh; after an explicit refresh all of them are
     opt_G.refresh_layouts()
     _verify_layouts(opt_G)
+
+
+def check_flownet2(device, width_div=8, size=64, b=1, seed=51, tol=1e-3):
+    """FlowNet2 teacher on the HIP kernels (few-shot-vid2vid_amd/flownet2.py) vs the functional restatement of the
+    reference network (oracle/flownet_oracle.py) on the same state dict: FlowNetC (7x7 / 5x5 convolutions as tap groups,
+    cost volume), two FlowNetS, FlowNetSD, fusion; transposed convolutions; resample2d / channelnorm between stages."""
+    from importlib import import_module
+    import fsv2v_amd  # noqa: F401
+    fn = import_module('few-shot-vid2vid_amd.flownet2')
+    from oracle import flownet_oracle as FO
+    net = fn.FlowNet2(width_div=width_div)
+    sd = fill_state(net, scale=0.6)
+    g = torch.Generator().manual_seed(seed)
+    coarse = torch.rand(b, 3, 2, size // 8, size // 8, generator=g)
+    frames = torch.nn.functional.interpolate(coarse.view(b, 6, size // 8, size // 8), size=(size, size), mode='bilinear',
+                                             align_corners=True).view(b, 3, 2, size, size)
+    with torch.no_grad():
+        ref = FO.flownet2({k: v.clone() for k, v in sd.items()}, frames)
+        got = net.to(device)(frames.to(device)).cpu()
+    assert got.shape == ref.shape == (b, 2, size, size)
+    err = float((got - ref).abs().max()) / max(float(ref.abs().max()), 1e-12)
+    assert err <= tol, (err, float(ref.abs().max()))
+    return float(ref.abs().max())
+
+
+def check_flownet_wrapper(device, size=64, b=2, seed=52):
+    """models/flownet.py restated (flownet2.FlowNet): [image_now, image_ref] -> teacher flow / confidence lists in the
+    shapes train.py:44-48 feeds to the model, and a training iteration that consumes them."""
+    from importlib import import_module
+    import fsv2v_amd  # noqa: F401
+    fn = import_module('few-shot-vid2vid_amd.flownet2')
+    M = _model()
+    opt = tiny_opt(warp_ref=True, spade_combine=True, remove_face_labels=True, no_flow_gt=False, fineSize=size, loadSize=size)
+    teacher = fn.FlowNet(opt, width_div=16)
+    fill_state(teacher.flowNet, scale=0.6)
+    teacher = teacher.to(device)
+    tl, ti, rl, ri = [t.to(device) for t in synth_pose_inputs(b, size, size, seed, 6)]
+    flow_gt, conf_gt = teacher([ti, ri], epoch=0)
+    assert flow_gt[1] is None and conf_gt[1] is None                       # single-frame phase: no previous-frame flow
+    assert tuple(flow_gt[0].shape) == (b, 1, 2, size, size) and tuple(conf_gt[0].shape) == (b, 1, 1, size, size)
+    assert set(conf_gt[0].unique().tolist()) <= {0.0, 1.0}
+    model = M.create_model(opt)
+    fill_state(model.netG); fill_state(model.netD)
+    model = model.to(device).train()
+    opt_G, opt_D = model.build_optimizers()
+    data = [tl, ti, flow_gt, conf_gt, rl, ri, None, None, None]
+    M.loss_backward(opt, model(data, mode='discriminator'), opt_D, 1)
+    g_losses, _, _ = model(data, mode='generator')
+    g_losses = M.loss_backward(opt, g_losses, opt_G, 0)
+    f_flow = float(g_losses[M.LOSS_NAMES_G.index('F_Flow')])
+    assert f_flow > 0 or float(conf_gt[0].sum()) == 0
+    return f_flow

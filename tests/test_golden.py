@@ -271,3 +271,44 @@ def test_product_inference_emu(emu_lib):
 @pytest.mark.gpu
 def test_product_inference_on_gpu(hip_lib):
     _check_product_inference(torch.device('cuda:0'))
+
+
+def _flownet2_frames(g):
+    gen = torch.Generator().manual_seed(g['seed'])
+    size, b = g['size'], g['batch']
+    coarse = torch.rand(b, 3, 2, size // 8, size // 8, generator=gen)
+    return torch.nn.functional.interpolate(coarse.view(b, 6, size // 8, size // 8), size=(size, size), mode='bilinear',
+                                           align_corners=True).view(b, 3, 2, size, size)
+
+
+def test_flownet2_oracle_and_layout_match_reference():
+    """FlowNet2 teacher: the reference's network python (its CUDA extensions replaced by oracle/flownet_oracle.py) vs the
+    functional restatement, and the product module's state_dict layout vs the reference's (checkpoint compatibility)."""
+    from oracle import flownet_oracle as FO
+    from importlib import import_module
+    import fsv2v_amd  # noqa: F401
+    fn = import_module('few-shot-vid2vid_amd.flownet2')
+    g = torch.load(os.path.join(GOLD, 'flownet2.pt'), weights_only=False)
+    with torch.device('meta'):
+        net = fn.FlowNet2()
+    mine = {k: list(v.shape) for k, v in net.state_dict().items()}
+    assert mine == g['layout'], sorted(set(mine) ^ set(g['layout']))[:10]
+    sd = {k: mc.fill_value(k, shape, 0.6) for k, shape in g['layout'].items()}
+    with torch.no_grad():
+        flow = FO.flownet2(sd, _flownet2_frames(g))
+    assert _rel(flow, g['flow']) <= 1e-5
+
+
+@pytest.mark.gpu
+def test_product_flownet2_on_gpu(hip_lib):
+    """full-width FlowNet2 (162.5 M parameters) on the HIP kernels vs the reference fixture"""
+    from importlib import import_module
+    import fsv2v_amd  # noqa: F401
+    fn = import_module('few-shot-vid2vid_amd.flownet2')
+    g = torch.load(os.path.join(GOLD, 'flownet2.pt'), weights_only=False)
+    with torch.device('meta'):
+        net = fn.FlowNet2()
+    net = net.to_empty(device='cuda:0')
+    net.load_state_dict({k: mc.fill_value(k, shape, 0.6) for k, shape in g['layout'].items()})
+    flow = net(_flownet2_frames(g).to('cuda:0')).cpu()
+    assert _rel(flow, g['flow']) <= 1e-3

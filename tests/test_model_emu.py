@@ -74,3 +74,13 @@ def test_train_step_with_teacher_flow_tiny(emu_lib):
     """flow_gt / conf_gt present (training without --no_flow_gt): the masked-L1 flow loss F_Flow against the teacher"""
     mc.check_train_step(DEV, mc.tiny_opt(warp_ref=True, spade_combine=True, remove_face_labels=True, no_flow_gt=False), b=2,
                         with_flow_gt=True)
+
+
+def test_flownet2_teacher_reduced_width(emu_lib):
+    """FlowNet2 (all five sub-networks, tap-grouped 7x7 / 5x5 convolutions, transposed convolutions, cost volume, warps)
+    at 1/8 width on the emulator vs the oracle restatement"""
+    mc.check_flownet2(DEV, width_div=8, size=64, tol=1e-4)
+
+
+def test_flownet_teacher_feeds_the_flow_loss(emu_lib):
+    mc.check_flownet_wrapper(DEV)

@@ -71,3 +71,7 @@ def test_train_step_two_reference_images(hip_lib):
     """--n_shot 2: attention over two reference images (two per-sample GEMMs + channel softmax), attended-reference warp"""
     mc.check_train_step(dev(), mc.tiny_opt(ngf=8, ndf=8, nff=8, dataset_mode='fewshot_face', input_nc=1, n_shot=2,
                                            warp_ref=True, fineSize=128, loadSize=128), b=2)
+
+
+def test_flownet2_teacher_reduced_width(hip_lib):
+    mc.check_flownet2(dev(), width_div=4, size=128, b=2, tol=1e-3)
