@@ -216,7 +216,8 @@ __global__ __launch_bounds__(256) void fsv_norm_bwd_final_kernel(const double* p
 __global__ __launch_bounds__(256) void fsv_norm_bwd_apply_kernel(const float* dy, const float* y, const float* x,
                                                                  const float* mean, const float* rstd, const float* w,
                                                                  const float* s1, const float* s2, float* dx,
-                                                                 long long total, long long PC, int C, int P, int act) {
+                                                                 long long total, long long PC, int C, int P, int act,
+                                                                 int fixed_stats) {
   long long i = (long long)blockIdx.x * 256 + threadIdx.x;
   const long long stride = (long long)gridDim.x * 256;
   const float invP = 1.0f / (float)P;
@@ -228,7 +229,8 @@ __global__ __launch_bounds__(256) void fsv_norm_bwd_apply_kernel(const float* dy
     float xh = (x[i] - mean[gc]) * rs;
     float d = fsv_act_grad(dy[i], y ? y[i] : 0.f, act);
     float wv = w ? w[c] : 1.f;
-    dx[i] = wv * rs * (d - s1[gc] * invP - xh * (s2[gc] * invP));
+    // fixed_stats: eval-mode normalisation (running statistics are constants): only the affine scale remains
+    dx[i] = fixed_stats ? wv * rs * d : wv * rs * (d - s1[gc] * invP - xh * (s2[gc] * invP));
   }
 }
 
@@ -283,7 +285,7 @@ int fsv_norm_apply(const float* x, const float* mean, const float* rstd, const f
 // dw/db are non-null, the affine parameter gradients.  s1/s2: [G*C] scratch.
 int fsv_norm_bwd(const float* dy, const float* y, const float* x, const float* mean, const float* rstd, const float* w,
                  double* workspace, float* s1, float* s2, float* dx, float* dw, float* db, int G, int P, int C, int act,
-                 hipStream_t stream) {
+                 int fixed_stats, hipStream_t stream) {
   if (!dy || !x || !mean || !rstd || !workspace || !s1 || !s2 || !dx) return FSV_ERR_BAD_ARG;
   if (act != FSV_ACT_NONE && !y) return FSV_ERR_BAD_ARG;
   RedPlan pl = fsv_red_plan(G, P, C);
@@ -295,7 +297,7 @@ int fsv_norm_bwd(const float* dy, const float* y, const float* x, const float* m
              db, G, C, nchunks);
   long long total = (long long)G * P * C;
   FSV_LAUNCH(fsv_norm_bwd_apply_kernel, dim3(fsv_ew_grid(total)), dim3(256), stream, dy, y, x, mean, rstd, w,
-             (const float*)s1, (const float*)s2, dx, total, (long long)P * C, C, P, act);
+             (const float*)s1, (const float*)s2, dx, total, (long long)P * C, C, P, act, fixed_stats);
   return fsv_check_launch();
 }
 

@@ -113,7 +113,7 @@ class LossCollector:
         self.has_fg = self.pose
         self.warp_ref = opt.warp_ref
         self.add_face_D = opt.add_face_D
-        self.concat_ref_for_D = opt.isTrain and opt.netD_subarch == 'n_layers'
+        self.concat_ref_for_D = (opt.isTrain or getattr(opt, 'finetune', False)) and opt.netD_subarch == 'n_layers'
         self.concat_fg_mask_for_D = self.has_fg
         self.loss_names_G, self.loss_names_D = LOSS_NAMES_G, LOSS_NAMES_D
         self.loss_names = LOSS_NAMES_G + LOSS_NAMES_D
@@ -237,6 +237,8 @@ class LossCollector:
         flow_loss = z.clone()
         flow_gt = list(flow_gt) if flow_gt is not None else [None, None]
         conf_gt = list(conf_gt) if conf_gt is not None else [None, None]
+        if not opt.isTrain:               # loss_collector.py:141,158: test-time finetune has no flow / warp terms
+            return flow_loss * opt.lambda_flow, warp_loss * opt.lambda_flow, None
         for k, (f, wimg) in enumerate(zip(flow, warped)):
             if f is not None:
                 warp_loss = warp_loss + l1(wimg, tgt_image)
@@ -262,6 +264,8 @@ class LossCollector:
         """loss_collector.py:164-204."""
         opt = self.opt
         loss = self.zero(tgt_image)
+        if not opt.isTrain:               # loss_collector.py:172,192
+            return loss * opt.lambda_mask
         for m, wimg in zip(flow_mask, warped):
             if m is None:
                 continue
@@ -407,8 +411,6 @@ class Vid2VidModel(nn.Module):
         """vid2vid_model.py:179-205 (test.py:39-41): one frame per call, previous labels / outputs carried in self.prevs;
         call reset_inference() between sequences.  --finetune and --refine_face are not part of this build."""
         opt = self.opt
-        if getattr(opt, 'finetune', False):
-            raise NotImplementedError("test-time finetune (vid2vid_model.py:207-237)")
         if getattr(self, 'prevs', None) is None:
             self.prevs = [None, None]
             prevs = [None, None]
@@ -419,6 +421,8 @@ class Vid2VidModel(nn.Module):
             self.t += 1
         tgt_label_valid = valid_labels(opt, tgt_label[:, -1])
         ref_labels_valid = valid_labels(opt, ref_labels)
+        if getattr(opt, 'finetune', False) and self.t == 0:
+            self.finetune(ref_labels, ref_images)
         with torch.no_grad():
             fake, flow, mask, raw, warped, _, _, atn_score, _ = self.netG(tgt_label_valid, ref_labels_valid, ref_images,
                                                                           prevs, t=self.t)
@@ -434,6 +438,50 @@ class Vid2VidModel(nn.Module):
 
     def reset_inference(self):
         self.prevs = None
+
+    def finetune(self, ref_labels, ref_images):
+        """vid2vid_model.py:207-237: test-time adaptation on the reference images - the generator layers whose names
+        contain 'fc' / 'conv_img' / 'up' (base_model.py:149-165) and the discriminator(s), 100 iterations (opt.
+        finetune_iterations to override), target = a randomly rolled / flipped reference (util/util.py:157-168, Python's
+        `random` stream, same draw order as the reference), G step before D step."""
+        import random
+        opt = self.opt
+        names = ('fc', 'conv_img', 'up')
+        g_params = [p for n, p in self.netG.named_parameters() if any(t in n for t in names)]
+        frozen = [p for n, p in self.netG.named_parameters() if not any(t in n for t in names) and p.requires_grad]
+        for p in frozen:                 # the reference leaves them trainable but never steps them: same result, less work
+            p.requires_grad_(False)
+        if opt.no_TTUR:
+            beta1, beta2, g_lr, d_lr = opt.beta1, 0.999, opt.lr, opt.lr
+        else:
+            beta1, beta2, g_lr, d_lr = 0.0, opt.beta2, opt.lr / 2, opt.lr * 2
+        self.optimizer_G = FlatAdam(g_params, g_lr, (beta1, beta2))
+        d_params = list(self.netD.parameters()) + (list(self.netDf.parameters()) if self.netDf is not None else [])
+        self.optimizer_D = FlatAdam(d_params, d_lr, (beta1, beta2))
+
+        def roll(t, ny, nx, flip):
+            t = torch.cat([t[:, :, -ny:], t[:, :, :-ny]], dim=2)
+            t = torch.cat([t[:, :, :, -nx:], t[:, :, :, :-nx]], dim=3)
+            return torch.flip(t, dims=[3]) if flip else t
+        history = []
+        try:
+            for it in range(1, int(getattr(opt, 'finetune_iterations', 100)) + 1):
+                idx = random.randrange(ref_labels.size(1))
+                h, w = ref_labels.shape[-2:]
+                ny = random.choice([random.randrange(h // 16), h - random.randrange(h // 16)])
+                nx = random.choice([random.randrange(w // 16), w - random.randrange(w // 16)])
+                flip = random.random() > 0.5
+                tgt_label = roll(ref_labels[:, idx], ny, nx, flip).unsqueeze(1)
+                tgt_image = roll(ref_images[:, idx], ny, nx, flip).unsqueeze(1)
+                g_losses, _, _ = self.forward_generator(tgt_label, tgt_image, ref_labels, ref_images, [None] * 3)
+                g_losses = loss_backward(opt, g_losses, self.optimizer_G, 0)
+                d_losses = self.forward_discriminator(tgt_label, tgt_image, ref_labels, ref_images, [None] * 3)
+                d_losses = loss_backward(opt, d_losses, self.optimizer_D, 1)
+                history.append([float(x) for x in list(g_losses) + list(d_losses)])
+        finally:
+            for p in frozen:
+                p.requires_grad_(True)
+        return history
 
     def generate_images(self, tgt_labels, tgt_images, ref_labels, ref_images, prevs):
         """vid2vid_model.py:130-158 with n_frames_per_gpu == 1."""
@@ -471,7 +519,7 @@ class Vid2VidModel(nn.Module):
         real = tgt_image[:, 0]
         losses = self.lossCollector.gan_losses(self.netD, tgt_label, [real, real * fg_union], [fake, raw], ref_label,
                                                ref_image, for_discriminator=True, netDf=self.netDf)
-        if self.opt.lambda_temp > 0 and prevs[0] is not None and self.netDT is not None:      # vid2vid_model.py:115-119
+        if self.isTrain and self.opt.lambda_temp > 0 and prevs[0] is not None and self.netDT is not None:   # vid2vid_model.py:115
             real_all = torch.cat([prevs[1], tgt_image], dim=1)
             fake_all = torch.cat([prevs[2], fake.unsqueeze(1)], dim=1)
             losses = list(losses) + self.lossCollector.temporal_losses(self.netDT, real_all, fake_all, True)
@@ -499,7 +547,7 @@ class Vid2VidModel(nn.Module):
             g_gan, g_feat, gf_gan, gf_feat = lc.gan_losses(self.netD, tgt_label, [real, real * fg_union], [fake, raw],
                                                            ref_label, ref_image, for_discriminator=False,
                                                            netDf=self.netDf)
-            if self.opt.lambda_temp > 0 and prevs[0] is not None and self.netDT is not None:  # vid2vid_model.py:70-75
+            if self.isTrain and self.opt.lambda_temp > 0 and prevs[0] is not None and self.netDT is not None:  # :70-75
                 real_all = torch.cat([prevs[1], tgt_image], dim=1)
                 fake_all = torch.cat([prevs[2], fake.unsqueeze(1)], dim=1)
                 gt_gan, gt_feat = lc.temporal_losses(self.netDT, real_all, fake_all, False)

@@ -28,7 +28,7 @@ lib.register_sigs({
     "fsv_warp_bwd": [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_llp, c_llp, c_llp, c_llp, c_llp, c_p],
     "fsv_norm_stats": [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_f, c_p, c_p, c_f, c_p],
     "fsv_norm_apply": [c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p],
-    "fsv_norm_bwd": [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p],
+    "fsv_norm_bwd": [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p],
     "fsv_colsum": [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p],
     "fsv_spade_prep": [c_p, c_p, c_p, c_p, c_ll, c_ll, c_ll, c_ll, c_p, c_p, c_p, c_i, c_i, c_i, c_p],
     "fsv_spade_mod_fwd": [c_p, c_p, c_p, c_p, c_i, c_pp, c_pp, c_pp, c_pp, c_pp, c_ip, c_llp, c_llp,
@@ -502,8 +502,6 @@ class _NormActFn(torch.autograd.Function):
         x, y, mean, rstd, wd = ctx.saved_tensors
         g, p, c = ctx.dims
         dy = to_nhwc(dy)
-        if not ctx.batch_stats:
-            raise NotImplementedError("eval-mode normalisation backward is not on the training hot path")
         dx = torch.empty_like(x)
         s1 = torch.empty(g * c, dtype=torch.float32, device=x.device)
         s2 = torch.empty_like(s1)
@@ -512,7 +510,7 @@ class _NormActFn(torch.autograd.Function):
         ws = _ws(g, p, c, x)
         lib.call("fsv_norm_bwd", lib.ptr(dy), lib.ptr(y), lib.ptr(x), lib.ptr(mean), lib.ptr(rstd),
                  lib.ptr(wd) if ctx.affine else None, lib.ptr(ws), lib.ptr(s1), lib.ptr(s2), lib.ptr(dx),
-                 lib.ptr(dw), lib.ptr(db), g, p, c, ctx.act, lib.stream_ptr())
+                 lib.ptr(dw), lib.ptr(db), g, p, c, ctx.act, 0 if ctx.batch_stats else 1, lib.stream_ptr())
         return dx, dw, db, None, None, None, None, None, None, None
 
 
@@ -665,7 +663,7 @@ class _SpadeFn(torch.autograd.Function):
                 ws = _ws(1, n * h * w, c, x)
                 lib.call("fsv_norm_bwd", lib.ptr(dxhat), None, lib.ptr(x), lib.ptr(mean), lib.ptr(rstd), None,
                          lib.ptr(ws), lib.ptr(s1), lib.ptr(s2), lib.ptr(dx), None, None,
-                         1, n * h * w, c, ACT_NONE, lib.stream_ptr())
+                         1, n * h * w, c, ACT_NONE, 0, lib.stream_ptr())
             else:
                 dx = dxhat * rstd.view(1, c, 1, 1)
         grads = []

@@ -117,7 +117,7 @@ int fsv_norm_apply(const float* x, const float* mean, const float* rstd, const f
                    int G, int P, int C, int act, fsv_stream_t stream);
 int fsv_norm_bwd(const float* dy, const float* y, const float* x, const float* mean, const float* rstd, const float* w,
                  double* workspace, float* s1, float* s2, float* dx, float* dw, float* db, int G, int P, int C, int act,
-                 fsv_stream_t stream);
+                 int fixed_stats, fsv_stream_t stream);   /* fixed_stats: eval mode, mean / rstd are constants */
 int fsv_colsum(const float* x, double* workspace, float* out, int G, int P, int C, int accumulate, fsv_stream_t stream);
 
 /* ---- flow warp (csrc/warp.hip) - replaces resample/get_grid base_network.py:13-37 (F.grid_sample bilinear, border,

@@ -199,6 +199,53 @@ def flownet2():
     print('flownet2', tuple(flow.shape), float(flow.abs().max()), sum(v.numel() for v in net.state_dict().values()))
 
 
+def finetune(name, flags, iterations=3):
+    """test.py with --finetune (scripts/pose/test.sh): eval-mode model, opt.isTrain False, the first inference() call
+    adapts 'fc' / 'conv_img' / 'up' layers and the discriminator on the reference image.  The reference hard-codes 100
+    iterations (vid2vid_model.py:219); the fixture limits them by shadowing `range` in that module's namespace - the
+    reference source itself is untouched."""
+    import builtins
+    import random
+    import model_checks as mc
+    ref_import.install_shims()
+    opt, model = ref_import.build_model(flags.split())
+    mc.fill_state(model.netG)
+    mc.fill_state(model.netD)
+    frames = [mc.synth_pose_inputs(1, 64, 64, 1313 + t, 6) for t in range(2)]
+    ref_label, ref_image = frames[0][2], frames[0][3]
+    model.train()
+    with torch.no_grad():
+        for it in range(10):              # settle running statistics / spectral-norm vectors of G and D
+            for (tl, ti, _, _) in frames:
+                data = [tl, ti, [None, None], [None, None], ref_label, ref_image, None, None, None]
+                model(data, mode='generator')
+    buffers = {}
+    for net, tag in ((model.netG, 'G'), (model.netD, 'D')):
+        buffers[tag] = {k: v.detach().clone() for k, v in net.state_dict().items()
+                        if k.endswith(('running_mean', 'running_var', 'weight_u', 'weight_v'))}
+    model.eval()
+    opt.isTrain = False
+    opt.finetune = True
+    model.isTrain = model.lossCollector.isTrain = False
+    import models.vid2vid_model as vm
+    # only finetune's `range(1, iterations + 1)` (two arguments, starting at 1) is shortened
+    vm.range = lambda *a: (builtins.range(1, min(a[1], iterations + 1)) if len(a) == 2 and a[0] == 1
+                           else builtins.range(*a))
+    random.seed(4321)
+    fakes = []
+    try:
+        for (tl, _, _, _) in frames:
+            fake, _, _, _, _, _ = model.inference(tl, ref_label, ref_image)
+            fakes.append(fake.detach().clone())
+    finally:
+        del vm.range
+    torch.save(dict(flags=flags, seed=1313, rng_seed=4321, iterations=iterations, batch=1, size=64, fakes=fakes,
+                    buffers=buffers, conv_img_weight=model.netG.conv_img.weight.detach().clone(),
+                    d_first_weight=model.netD.discriminator_0.model0[0].weight.detach().clone()),
+               os.path.join(OUT, 'finetune_%s.pt' % name))
+    print('finetune', name, [round(float(f.abs().mean()), 5) for f in fakes])
+
+
 def warp_taps():
     ref_import.install_shims()
     from models.networks.base_network import resample
@@ -230,6 +277,8 @@ if __name__ == '__main__':
         for n in sys.argv[1:]:
             if n == 'flownet2':
                 flownet2()
+            elif n.startswith('finetune:'):
+                finetune(n[9:], CONFIGS[n[9:]])
             elif n.startswith('inference:'):
                 inference(n[10:], CONFIGS[n[10:]])
             elif n.startswith('temporal:'):
@@ -246,4 +295,5 @@ if __name__ == '__main__':
     inference('pose_combine', CONFIGS['pose_combine'])
     warp_taps()
     flownet2()
+    finetune('pose_combine', CONFIGS['pose_combine'])
     print('goldens written to', OUT)

@@ -312,3 +312,67 @@ def test_product_flownet2_on_gpu(hip_lib):
     net.load_state_dict({k: mc.fill_value(k, shape, 0.6) for k, shape in g['layout'].items()})
     flow = net(_flownet2_frames(g).to('cuda:0')).cpu()
     assert _rel(flow, g['flow']) <= 1e-3
+
+
+def _finetune_setup(g):
+    import argparse
+    opt = _opt_from_flags(g['flags'])
+    opt = argparse.Namespace(**{**vars(opt), 'finetune': True, 'finetune_iterations': g['iterations']})
+    M = mc._model()
+    model = M.create_model(opt)
+    mc.fill_state(model.netG); mc.fill_state(model.netD)
+    for net, tag in ((model.netG, 'G'), (model.netD, 'D')):
+        sd = net.state_dict()
+        for k, v in g['buffers'][tag].items():
+            sd[k].copy_(v)
+    frames = [mc.synth_pose_inputs(g['batch'], g['size'], g['size'], g['seed'] + t, 6) for t in range(2)]
+    return opt, model, frames
+
+
+def test_oracle_reproduces_reference_finetune():
+    """test.py --finetune (scripts/pose/test.sh): three adaptation iterations (G step then D step on rolled / flipped
+    reference images, Python `random` stream), then two inference frames"""
+    import random
+    g = torch.load(os.path.join(GOLD, 'finetune_pose_combine.pt'), weights_only=False)
+    opt, model, frames = _finetune_setup(g)
+    sdG = mc._leafify({k: v.detach().clone() for k, v in model.netG.state_dict().items()}, torch.float32)
+    sdD = mc._leafify({k: v.detach().clone() for k, v in model.netD.state_dict().items()}, torch.float32)
+    cfg = O.cfg_from_opt(opt)
+    cfg.isTrain = False
+    random.seed(g['rng_seed'])
+    O.finetune(sdG, sdD, cfg, frames[0][2], frames[0][3], iterations=g['iterations'])
+    assert _rel(sdG['conv_img.weight'].detach(), g['conv_img_weight']) <= 1e-5
+    assert _rel(sdD['discriminator_0.model0.0.weight'].detach(), g['d_first_weight']) <= 1e-5
+    with torch.no_grad():
+        outs = O.inference_frames({k: v.detach() for k, v in sdG.items()}, cfg, [f[0] for f in frames], frames[0][2],
+                                  frames[0][3], n_frames_G=opt.n_frames_G)
+    for got, ref in zip(outs, g['fakes']):
+        assert _rel(got, ref) <= 1e-5
+
+
+def _check_product_finetune(dev):
+    import random
+    g = torch.load(os.path.join(GOLD, 'finetune_pose_combine.pt'), weights_only=False)
+    opt, model, frames = _finetune_setup(g)
+    model = model.to(dev).eval()
+    opt.isTrain = False
+    model.isTrain = False
+    random.seed(g['rng_seed'])
+    ref_label, ref_image = frames[0][2].to(dev), frames[0][3].to(dev)
+    for t, (f, ref) in enumerate(zip(frames, g['fakes'])):
+        fake = model([f[0].to(dev), None, None, None, ref_label, ref_image, None, None, None])[0]
+        assert _rel(fake.cpu(), ref) <= 1e-3, t
+    assert _rel(model.netG.conv_img.weight.detach().cpu(), g['conv_img_weight']) <= 1e-3
+    # Adam turns rounding-level gradients into +-lr steps, so individual discriminator weights can differ by lr x
+    # iterations; the tensor as a whole is compared
+    dw = model.netD.discriminator_0.model0[0].weight.detach().cpu()
+    assert float((dw - g['d_first_weight']).norm() / g['d_first_weight'].norm()) <= 2e-3
+
+
+def test_product_finetune_emu(emu_lib):
+    _check_product_finetune(torch.device('cpu'))
+
+
+@pytest.mark.gpu
+def test_product_finetune_on_gpu(hip_lib):
+    _check_product_finetune(torch.device('cuda:0'))
