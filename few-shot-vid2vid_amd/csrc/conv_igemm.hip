@@ -465,36 +465,60 @@ __global__ __launch_bounds__(256) void fsv_prep_weight_kernel(const float* w, fl
 
 // ---- grouped re-arrangement: every parameter weight of an optimiser in ONE launch (run right after the Adam step) ----
 // desc arrays (device): src / dst pointers as 64-bit integers; dims[l] = {Cout, Cin_pad, Cin_real, KH, KW, ntaps, Kpad, ldw,
-// mode}; taps[l] = {lo, hi} packed (kh | kw << 4) codes.  tmap[b] = (layer, chunk): a block re-arranges 1024 consecutive
-// destination elements of one layer.  No scaling here: the spectral-norm 1/sigma is applied in the GEMM epilogue.
+// mode}; taps[l] = {lo, hi} packed (kh | kw << 4) codes.  No scaling here: the spectral-norm 1/sigma is applied in the GEMM
+// epilogue.
 struct PrepGroup {
   const long long* src; const long long* dst; const int* dims; const unsigned long long* taps;
 };
+// tmap[b] = (layout, 32-wide co tile, ci tile): the OIHW source tile [32 co][CI_T ci][KH*KW] is read in contiguous runs of
+// CI_T * KK floats per output channel, staged in LDS and written out as rows of the K-major layout (CI_T = 32 for <= 8 source
+// taps, else 16).  Only the valid region is written: the padding rows / columns of a layout are zero from allocation on.
 __global__ __launch_bounds__(256) void fsv_prep_group_kernel(PrepGroup g, const int* tmap) {
-  const int layer = tmap[blockIdx.x * 2], chunk = tmap[blockIdx.x * 2 + 1];
+  __shared__ float t[32 * 257];
+  const int layer = tmap[blockIdx.x * 3], cot = tmap[blockIdx.x * 3 + 1], cit = tmap[blockIdx.x * 3 + 2];
   const int* d = g.dims + layer * 9;
-  const int Cout = d[0], CinP = d[1], CinR = d[2], KH = d[3], KW = d[4], ntaps = d[5], Kpad = d[6], ldw = d[7], mode = d[8];
+  const int Cout = d[0], CinP = d[1], CinR = d[2], KW = d[4], ntaps = d[5], ldw = d[7], mode = d[8];
+  const int KK = d[3] * KW;
+  const int CI_T = KK <= 8 ? 32 : 16;
+  const int run = CI_T * KK, lds = run + 1;
   const float* w = reinterpret_cast<const float*>(g.src[layer]);
   float* wt = reinterpret_cast<float*>(g.dst[layer]);
   const unsigned long long lo = g.taps[layer * 2], hi = g.taps[layer * 2 + 1];
-  const long long total = (long long)Kpad * ldw;
-  const int rowlen = (mode == 1) ? Cout : CinP;
-  const int ncols = (mode == 1) ? CinP : Cout;
-  const int K = ntaps * rowlen;
-#pragma unroll
-  for (int u = 0; u < 4; ++u) {
-    long long i = (long long)chunk * 1024 + u * 256 + threadIdx.x;
-    if (i >= total) break;
-    int r = (int)(i / ldw), c = (int)(i - (long long)r * ldw);
-    bool ok = r < K && c < ncols;
-    int j = ok ? r / rowlen : 0;
-    int a = r - j * rowlen;
-    unsigned long long code = (j < 8) ? lo : hi;
-    int sh = (j & 7) * 8;
-    int kh = (int)((code >> sh) & 15ull), kw = (int)((code >> (sh + 4)) & 15ull);
-    int co = (mode == 1) ? a : c, ci = (mode == 1) ? c : a;
-    ok = ok && ci < CinR;
-    wt[i] = ok ? w[(((long long)co * CinR + ci) * KH + kh) * KW + kw] : 0.f;
+  const int co0 = cot * 32, ci0 = cit * CI_T;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  for (int col = wave; col < 32; col += 4) {
+    const int co = co0 + col;
+    for (int idx = lane; idx < run; idx += 64) {
+      const int ci = ci0 + idx / KK;
+      t[col * lds + idx] = (co < Cout && ci < CinR) ? w[((long long)co * CinR + ci0) * KK + idx] : 0.f;
+    }
+  }
+  __syncthreads();
+  if (mode == 0) {          // rows (tap j, ci), 32 consecutive output channels each
+    const int col = threadIdx.x & 31, r0 = threadIdx.x >> 5;
+    const int co = co0 + col;
+    for (int r = r0; r < ntaps * CI_T; r += 8) {
+      const int j = r / CI_T, cil = r - j * CI_T;
+      const int ci = ci0 + cil;
+      if (ci >= CinP || co >= Cout) continue;
+      const unsigned long long code = (j < 8) ? lo : hi;
+      const int sh = (j & 7) * 8;
+      const int tk = (int)((code >> sh) & 15ull) * KW + (int)((code >> (sh + 4)) & 15ull);
+      wt[((long long)j * CinP + ci) * ldw + co] = t[col * lds + cil * KK + tk];
+    }
+  } else {                  // rows (tap j, co), CI_T consecutive input channels each
+    const int cil = threadIdx.x % CI_T, c0 = threadIdx.x / CI_T, cstep = 256 / CI_T;
+    const int ci = ci0 + cil;
+    for (int j = 0; j < ntaps; ++j) {
+      const unsigned long long code = (j < 8) ? lo : hi;
+      const int sh = (j & 7) * 8;
+      const int tk = (int)((code >> sh) & 15ull) * KW + (int)((code >> (sh + 4)) & 15ull);
+      for (int col = c0; col < 32; col += cstep) {
+        const int co = co0 + col;
+        if (co >= Cout || ci >= CinP) continue;
+        wt[((long long)j * Cout + co) * ldw + ci] = t[col * lds + cil * KK + tk];
+      }
+    }
   }
 }
 

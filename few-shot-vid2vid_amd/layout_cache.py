@@ -76,7 +76,8 @@ class LayoutCache:
             rowlen, ncols = (cout, cinp) if mode == 1 else (cinp, cout)
             kpad = _ceil(max(ntaps * rowlen, 1), 32)
             ldw = _ceil(ncols, 32)
-            wt = torch.empty((1, kpad, ldw), dtype=torch.float32, device=dev)
+            # zero once: the refresh kernel only rewrites the valid region, padding rows / columns stay zero
+            wt = torch.zeros((1, kpad, ldw), dtype=torch.float32, device=dev)
             lo, hi = _pack_taps(khs, kws)
             e.jobs.append((wt, [cout, cinp, cin, kh, kw, ntaps, kpad, ldw, mode], lo, hi))
             return wt, ldw
@@ -105,11 +106,13 @@ class LayoutCache:
                 dst.append(wt.data_ptr())
                 dims += d
                 taps += [_i64(lo), _i64(hi)]
-                for ch in range((d[6] * d[7] + 1023) // 1024):
-                    tmap += [j, ch]
+                ci_t = 32 if d[3] * d[4] <= 8 else 16            # source taps KH * KW
+                for a in range((d[0] + 31) // 32):
+                    for b in range((d[1] + ci_t - 1) // ci_t):
+                        tmap += [j, a, b]
         mk = lambda v, dt: torch.tensor(v, dtype=dt).to(dev)
         return ((mk(src, torch.int64), mk(dst, torch.int64), mk(dims, torch.int32), mk(taps, torch.int64),
-                 mk(tmap, torch.int32)), len(tmap) // 2)
+                 mk(tmap, torch.int32)), len(tmap) // 3)
 
     def _refresh_entry(self, e):
         tables, nblocks = self._build([e], e.weight.device)

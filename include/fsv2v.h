@@ -69,7 +69,9 @@ int fsv_prep_weight(const float* w, float* wt, const float* scale_ptr, int mode,
                     int Cout, int Cin, int KH, int KW, int ntaps, const int* kh, const int* kw,
                     int Kpad, int ldw, long long w_bstride, long long wt_bstride, fsv_stream_t stream);
 
-/* every parameter weight of an optimiser re-arranged in one launch (un-scaled; used once per optimiser step) */
+/* every parameter weight of an optimiser re-arranged in one launch (un-scaled; used once per optimiser step).  dims[l] =
+ * {Cout, Cin_pad, Cin_real, KH, KW, ntaps, Kpad, ldw, mode}; tmap = (layout, 32-co tile, ci tile) triples (ci tile = 32
+ * channels for KH*KW <= 8, else 16); only the valid region of each (pre-zeroed) layout is written */
 int fsv_prep_weight_grouped(const long long* src, const long long* dst, const int* dims, const unsigned long long* taps,
                             const int* tmap, int nblocks, fsv_stream_t stream);
 /* Deferred weight-gradient finalisation (csrc/wgrad_finalize.hip): njobs K-major weight gradients -> OIHW, added into

@@ -454,6 +454,9 @@ def check_losses(device, seed=13):
     lab1 = torch.randn(2, 1, 20, 17, generator=g)
     assert_close('pool max', ops.pool15(_dev(lab1, device), 'max_gt', 0.5), (F.max_pool2d(lab1, 15, 1, 7) > 0.5).float(), 1e-7)
     assert_close('pool avg', ops.pool15(_dev(lab1, device), 'avg'), F.avg_pool2d(lab1, 15, 1, 7), 1e-5)
+    lab2 = torch.randn(1, 3, 70, 45, generator=g)[:, 1:2]          # several 32x32 tiles, ragged edges, strided input
+    assert_close('pool max tiles', ops.pool15(_dev(lab2, device), 'max_gt', -0.2), (F.max_pool2d(lab2, 15, 1, 7) > -0.2).float(), 1e-7)
+    assert_close('pool avg tiles', ops.pool15(_dev(lab2, device), 'avg'), F.avg_pool2d(lab2, 15, 1, 7), 1e-5)
 
 
 def check_part_masks(device, seed=15):
