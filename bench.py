@@ -170,14 +170,20 @@ def main():
     if use_graph:
         try:
             if segmented:
+                # The RCCL watchdog thread polls its events while a collective is in flight; under the default global
+                # capture mode that poll is an illegal call "during capture" and invalidates it.  So: no collective may be
+                # pending when a capture starts (synchronize), and the captures only police their own thread.
                 graphs = [torch.cuda.CUDAGraph() for _ in range(3)]
-                with torch.cuda.graph(graphs[0]):
+                torch.cuda.synchronize()
+                with torch.cuda.graph(graphs[0], capture_error_mode='thread_local'):
                     seg_d()
                 opt_D.exchange_all()
-                with torch.cuda.graph(graphs[1], pool=graphs[0].pool()):
+                torch.cuda.synchronize()
+                with torch.cuda.graph(graphs[1], pool=graphs[0].pool(), capture_error_mode='thread_local'):
                     seg_g()
                 opt_G.exchange_all()
-                with torch.cuda.graph(graphs[2], pool=graphs[0].pool()):
+                torch.cuda.synchronize()
+                with torch.cuda.graph(graphs[2], pool=graphs[0].pool(), capture_error_mode='thread_local'):
                     seg_a()
 
                 def run():
@@ -234,15 +240,20 @@ def main():
                    'global_batch': args.batch * world, 'parallelism': 'dp%d' % world, 'launch': mode,
                    'algorithmic_tflop_per_frame': 1.66},
     }
-    if rank == 0:
-        result['step_tflops'] = round(1.66 * frames / elapsed, 2)
-        if not args.no_roofline:
-            # instrumented eager pass: HIP events around every launch of the dominant kernel, on its launch stream
+    rl = None
+    if not args.no_roofline:
+        # instrumented eager pass: HIP events around every launch of the dominant kernel, on its launch stream.  Every rank
+        # runs the step (it contains the gradient exchange), only rank 0 records.
+        if rank == 0:
             prof.enable()
-            step()
-            torch.cuda.synchronize()
+        step()
+        torch.cuda.synchronize()
+        if rank == 0:
             rl = prof.summary()
             prof.disable()
+    if rank == 0:
+        result['step_tflops'] = round(1.66 * frames / elapsed, 2)
+        if rl is not None:
             result['roofline'] = rl['dominant']
             result['kernels'] = rl['by_kernel']
             # HBM bytes per launch of the same kernel from the rocprofv3 PMC passes of this command
@@ -260,9 +271,17 @@ def main():
                 pass
         if world == 1 and not args.no_cpu_baseline:
             result['cpu_baseline'] = cpu_baseline(args.size, min(os.cpu_count() or 1, 64))
-        print(json.dumps(result))
     if world > 1 or force_dist:
         dist.destroy_process_group()
+    if rank == 0:
+        # RCCL prints its version banner through C stdio (flushed at exit): flush it first so that the JSON line is the
+        # last line of stdout
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        print(json.dumps(result), flush=True)
 
 
 if __name__ == '__main__':
