@@ -33,12 +33,14 @@ FP32_MFMA_PEAK_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md "Pea
 
 
 WITH_VGG = False       # --vgg: add the VGG19 perceptual loss (a "next" row of SURVEY.md 8f; not part of the headline)
+WITH_FACE_D = False    # --face-d: BASELINE configs[3] flags (--add_face_D, which needs the VGG loss); not the headline
 
 
 def build_opt(size, batch):
     import model_checks as mc
     return mc.make_opt(fineSize=size, loadSize=size, batchSize=batch, warp_ref=True, spade_combine=True,
-                       remove_face_labels=True, no_vgg_loss=not WITH_VGG, no_flow_gt=True)
+                       remove_face_labels=True, no_vgg_loss=not (WITH_VGG or WITH_FACE_D), no_flow_gt=True,
+                       add_face_D=WITH_FACE_D)
 
 
 def make_data(batch, size, seed, device):
@@ -96,9 +98,11 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
     ap.add_argument('--vgg', action='store_true', help='include the VGG19 perceptual loss in the G step')
+    ap.add_argument('--face-d', action='store_true', help='config 3: --add_face_D (face discriminator + VGG19 loss)')
     args = ap.parse_args()
-    global WITH_VGG
+    global WITH_VGG, WITH_FACE_D
     WITH_VGG = args.vgg
+    WITH_FACE_D = args.face_d
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
@@ -235,8 +239,10 @@ def main():
         'dtype': 'f32',
         'data': 'synthetic',
         'config': {'workload': ('fewshot_pose %dx%d, per-GPU batch %d, adaptive_spade+warp_ref+spade_combine, '
-                                'D step + G step (train.py:58-62), Adam included, %sno FlowNet2 / face-D'
-                                % (args.size, args.size, args.batch, 'with VGG19 loss, ' if WITH_VGG else 'no VGG / ')),
+                                'D step + G step (train.py:58-62), Adam included, %sno FlowNet2%s'
+                                % (args.size, args.size, args.batch,
+                                   ('with VGG19 loss + face discriminator, ' if WITH_FACE_D else 'with VGG19 loss, ')
+                                   if (WITH_VGG or WITH_FACE_D) else 'no VGG / ', '' if WITH_FACE_D else ' / face-D')),
                    'global_batch': args.batch * world, 'parallelism': 'dp%d' % world, 'launch': mode,
                    'algorithmic_tflop_per_frame': 1.66},
     }

@@ -386,12 +386,65 @@ class Vid2VidModel(nn.Module):
         self.optimizer_D.set_lr(d_lr)
         self.old_lr = new_lr
 
-    def save_networks(self, which_epoch):
-        """models/base_model.py:219-227 (same file names, CPU state_dicts)."""
+    def save_network(self, network, network_label, epoch_label):
+        """models/base_model.py:51-56: `<epoch>_net_<label>.pth` holding the CPU state_dict (same keys as the reference)"""
         os.makedirs(self.save_dir, exist_ok=True)
-        for net, label in ((self.netG, 'G'), (self.netD, 'D')):
-            sd = {k: v.detach().cpu() for k, v in net.state_dict().items()}
-            torch.save(sd, os.path.join(self.save_dir, '%s_net_%s.pth' % (which_epoch, label)))
+        sd = {k: v.detach().cpu() for k, v in network.state_dict().items()}
+        torch.save(sd, os.path.join(self.save_dir, '%s_net_%s.pth' % (epoch_label, network_label)))
+
+    def save_networks(self, which_epoch):
+        """models/base_model.py:219-227"""
+        self.save_network(self.netG, 'G', which_epoch)
+        self.save_network(self.netD, 'D', which_epoch)
+        if self.temporal and self.netDT is not None:
+            self.save_network(self.netDT, 'DT', which_epoch)
+        if self.add_face_D:
+            self.save_network(self.netDf, 'Df', which_epoch)
+
+    def load_network(self, network, network_label, epoch_label, save_dir=''):
+        """models/base_model.py:59-93: exact load, else only the keys the network has, else every tensor whose shape
+        matches (a checkpoint from before init_temporal_model leaves flow_network_temp uninitialised).  Returns the set
+        of layers that were not initialised (empty on an exact load), None when the file does not exist."""
+        path = os.path.join(save_dir or self.save_dir, '%s_net_%s.pth' % (epoch_label, network_label))
+        if not os.path.isfile(path):
+            return None
+        loaded = torch.load(path, map_location='cpu')
+        try:
+            network.load_state_dict(loaded)
+            return set()
+        except Exception:
+            pass
+        model_dict = network.state_dict()
+        try:
+            network.load_state_dict({k: v for k, v in loaded.items() if k in model_dict})
+            return set()
+        except Exception:
+            pass
+        not_initialized = set()
+        for k, v in loaded.items():
+            if k in model_dict and v.shape == model_dict[k].shape:
+                model_dict[k] = v
+        for k, v in model_dict.items():
+            if k not in loaded or v.shape != loaded[k].shape:
+                not_initialized.add('.'.join(k.split('.')[:2]))
+                if 'flow_network_temp' in k:
+                    network.flow_temp_is_initalized = False
+        network.load_state_dict(model_dict)
+        return not_initialized
+
+    def load_networks(self):
+        """models/base_model.py:229-243"""
+        opt = self.opt
+        if not self.isTrain or getattr(opt, 'continue_train', False) or getattr(opt, 'load_pretrain', ''):
+            path = '' if (not self.isTrain or getattr(opt, 'continue_train', False)) else opt.load_pretrain
+            epoch = getattr(opt, 'which_epoch', 'latest')
+            self.load_network(self.netG, 'G', epoch, path)
+            if (self.isTrain and not getattr(opt, 'load_pretrain', '')) or getattr(opt, 'finetune', False):
+                self.load_network(self.netD, 'D', epoch, path)
+                if self.isTrain and self.temporal and self.netDT is not None:
+                    self.load_network(self.netDT, 'DT', epoch, path)
+                if self.add_face_D:
+                    self.load_network(self.netDf, 'Df', epoch, path)
 
     # ---------------------------------------------------------------------------------------------- forward
     def forward(self, data_list, save_images=False, mode='inference', dummy_bs=0):
