@@ -96,7 +96,91 @@ __global__ __launch_bounds__(256) void fsv_crop_resize_bwd_kernel(const float* d
   }
 }
 
+// ---- face refinement paste (face_refiner.py:42-54 replace_face_region) -------------------------------------------------------
+// out = img everywhere except inside box n, where out = clamp(bilinear_resize(face[n] -> box size), -1, 1)
+// (F.interpolate(mode='bilinear', align_corners=False): src = (dst + 0.5) * in / out - 0.5, clamped at 0).
+struct PasteTap { int y0, y1, x0, x1; float ly0, ly1, lx0, lx1; };
+__device__ __forceinline__ void fsv_lin_src(int dst, int in_size, int out_size, int& i0, int& i1, float& l0, float& l1) {
+  const float scale = (float)in_size / (float)out_size;
+  float src = scale * ((float)dst + 0.5f) - 0.5f;
+  if (src < 0.f) src = 0.f;
+  i0 = (int)src;
+  if (i0 > in_size - 1) i0 = in_size - 1;
+  i1 = i0 + (i0 < in_size - 1 ? 1 : 0);
+  l1 = src - (float)i0;
+  l1 = l1 < 0.f ? 0.f : (l1 > 1.f ? 1.f : l1);
+  l0 = 1.f - l1;
+}
+
+// img / out: [N][3][H][W] with strides (sn, sc, sy, sx) each; face: contiguous [N][3][S][S]
+__global__ __launch_bounds__(256) void fsv_paste_face_fwd_kernel(const float* img, const float* face, const int* boxes, float* out,
+                                                                 int N, int H, int W, int S, long long isn, long long isc,
+                                                                 long long isy, long long isx) {
+  const long long total = (long long)N * 3 * H * W;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int x = (int)(i % W), y = (int)((i / W) % H), c = (int)((i / ((long long)W * H)) % 3);
+    const int n = (int)(i / ((long long)3 * H * W));
+    const int ys = boxes[n * 4], ye = boxes[n * 4 + 1], xs = boxes[n * 4 + 2], xe = boxes[n * 4 + 3];
+    float v = img[n * isn + c * isc + y * isy + x * isx];
+    if (y >= ys && y < ye && x >= xs && x < xe) {
+      int y0, y1, x0, x1; float ly0, ly1, lx0, lx1;
+      fsv_lin_src(y - ys, S, ye - ys, y0, y1, ly0, ly1);
+      fsv_lin_src(x - xs, S, xe - xs, x0, x1, lx0, lx1);
+      const float* f = face + ((long long)n * 3 + c) * S * S;
+      v = ly0 * (lx0 * f[y0 * S + x0] + lx1 * f[y0 * S + x1]) + ly1 * (lx0 * f[y1 * S + x0] + lx1 * f[y1 * S + x1]);
+      v = v < -1.f ? -1.f : (v > 1.f ? 1.f : v);
+    }
+    out[i] = v;
+  }
+}
+
+// dimg (contiguous NCHW) = dout outside the boxes, 0 inside; dface (zero-initialised) += bilinear weights * dout where the
+// clamp was inactive (out strictly inside (-1, 1))
+__global__ __launch_bounds__(256) void fsv_paste_face_bwd_kernel(const float* dout, const float* out, const int* boxes, float* dimg,
+                                                                 float* dface, int N, int H, int W, int S) {
+  const long long total = (long long)N * 3 * H * W;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int x = (int)(i % W), y = (int)((i / W) % H), c = (int)((i / ((long long)W * H)) % 3);
+    const int n = (int)(i / ((long long)3 * H * W));
+    const int ys = boxes[n * 4], ye = boxes[n * 4 + 1], xs = boxes[n * 4 + 2], xe = boxes[n * 4 + 3];
+    const float d = dout[i];
+    if (y >= ys && y < ye && x >= xs && x < xe) {
+      dimg[i] = 0.f;
+      const float o = out[i];
+      if (o > -1.f && o < 1.f) {
+        int y0, y1, x0, x1; float ly0, ly1, lx0, lx1;
+        fsv_lin_src(y - ys, S, ye - ys, y0, y1, ly0, ly1);
+        fsv_lin_src(x - xs, S, xe - xs, x0, x1, lx0, lx1);
+        float* f = dface + ((long long)n * 3 + c) * S * S;
+        atomicAdd(&f[y0 * S + x0], d * ly0 * lx0); atomicAdd(&f[y0 * S + x1], d * ly0 * lx1);
+        atomicAdd(&f[y1 * S + x0], d * ly1 * lx0); atomicAdd(&f[y1 * S + x1], d * ly1 * lx1);
+      }
+    } else {
+      dimg[i] = d;
+    }
+  }
+}
+
 extern "C" {
+
+int fsv_paste_face_fwd(const float* img, const float* face, const int* boxes, float* out, int N, int H, int W, int S,
+                       long long isn, long long isc, long long isy, long long isx, hipStream_t stream) {
+  if (!img || !face || !boxes || !out || N < 1 || S < 1) return FSV_ERR_BAD_ARG;
+  long long g = ((long long)N * 3 * H * W + 255) / 256;
+  if (g > 8192) g = 8192;
+  FSV_LAUNCH(fsv_paste_face_fwd_kernel, dim3((unsigned)g), dim3(256), stream, img, face, boxes, out, N, H, W, S, isn, isc, isy,
+             isx);
+  return fsv_check_launch();
+}
+
+int fsv_paste_face_bwd(const float* dout, const float* out, const int* boxes, float* dimg, float* dface, int N, int H, int W,
+                       int S, hipStream_t stream) {
+  if (!dout || !out || !boxes || !dimg || !dface || N < 1 || S < 1) return FSV_ERR_BAD_ARG;
+  long long g = ((long long)N * 3 * H * W + 255) / 256;
+  if (g > 8192) g = 8192;
+  FSV_LAUNCH(fsv_paste_face_bwd_kernel, dim3((unsigned)g), dim3(256), stream, dout, out, boxes, dimg, dface, N, H, W, S);
+  return fsv_check_launch();
+}
 
 int fsv_face_boxes(const float* pose, long long sn, long long sc, int N, int C, int H, int W, int use_openpose,
                    int crop_smaller, int* boxes, hipStream_t stream) {

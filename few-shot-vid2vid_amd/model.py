@@ -310,12 +310,23 @@ class Vid2VidModel(nn.Module):
         self.temporal = False
         self.old_lr = opt.lr
         self.save_dir = os.path.join(getattr(opt, 'checkpoints_dir', './checkpoints'), getattr(opt, 'name', 'test'))
-        if getattr(opt, 'refine_face', False):
-            raise NotImplementedError("refine_face")
+        self.refine_face = bool(getattr(opt, 'refine_face', False))
         self.lossCollector = LossCollector(opt)
         torch.manual_seed(0)            # reference: set_random_seed(0) before building so replicas start identical
         opt.for_face = False
         self.netG = networks.define_G(opt)
+        self.netGf = None
+        if self.refine_face:               # base_model.py:174-182: a smaller generator on face_size x face_size crops
+            import copy
+            opt_face = copy.deepcopy(opt)
+            opt_face.n_downsample_G -= 1
+            if opt_face.n_adaptive_layers > 0:
+                opt_face.n_adaptive_layers -= 1
+            opt_face.input_nc = opt.output_nc
+            opt_face.fineSize = self.lossCollector.face_size
+            opt_face.aspect_ratio = 1
+            opt_face.for_face = True
+            self.netGf = networks.define_G(opt_face)
         input_nc = opt.label_nc if (opt.label_nc != 0 and not self.pose) else opt.input_nc
         netD_input_nc = input_nc + opt.output_nc + (1 if self.lossCollector.concat_fg_mask_for_D else 0)
         if self.lossCollector.concat_ref_for_D:
@@ -343,7 +354,10 @@ class Vid2VidModel(nn.Module):
             beta1, beta2, g_lr, d_lr = opt.beta1, 0.999, opt.lr, opt.lr
         else:
             beta1, beta2, g_lr, d_lr = 0.0, opt.beta2, opt.lr / 2, opt.lr * 2
-        self.optimizer_G = FlatAdam(list(self.netG.parameters()), g_lr, (beta1, beta2), world_size, process_group,
+        g_params = list(self.netG.parameters())
+        if self.netGf is not None:         # base_model.py:204-205
+            g_params += list(self.netGf.parameters())
+        self.optimizer_G = FlatAdam(g_params, g_lr, (beta1, beta2), world_size, process_group,
                                     force_exchange=force_exchange, overlap=overlap)
         d_params = list(self.netD.parameters())
         if self.netDf is not None:         # base_model.py:209-211
@@ -367,7 +381,8 @@ class Vid2VidModel(nn.Module):
                                        'n_layers', 1, not opt.no_ganFeat_loss).to(dev)
         if self.optimizer_G is not None:
             old = self.optimizer_G
-            self.optimizer_G = FlatAdam(list(self.netG.parameters()), float(old.state[3]), old.betas, old.world_size,
+            g_params = list(self.netG.parameters()) + (list(self.netGf.parameters()) if self.netGf is not None else [])
+            self.optimizer_G = FlatAdam(g_params, float(old.state[3]), old.betas, old.world_size,
                                         old.group, force_exchange=old.exchange and old.world_size == 1, overlap=old.overlap)
             old = self.optimizer_D
             d_params = list(self.netD.parameters()) + list(self.netDT.parameters())
@@ -395,6 +410,8 @@ class Vid2VidModel(nn.Module):
     def save_networks(self, which_epoch):
         """models/base_model.py:219-227"""
         self.save_network(self.netG, 'G', which_epoch)
+        if self.netGf is not None:
+            self.save_network(self.netGf, 'Gf', which_epoch)
         self.save_network(self.netD, 'D', which_epoch)
         if self.temporal and self.netDT is not None:
             self.save_network(self.netDT, 'DT', which_epoch)
@@ -439,6 +456,8 @@ class Vid2VidModel(nn.Module):
             path = '' if (not self.isTrain or getattr(opt, 'continue_train', False)) else opt.load_pretrain
             epoch = getattr(opt, 'which_epoch', 'latest')
             self.load_network(self.netG, 'G', epoch, path)
+            if self.netGf is not None:
+                self.load_network(self.netGf, 'Gf', epoch, path)
             if (self.isTrain and not getattr(opt, 'load_pretrain', '')) or getattr(opt, 'finetune', False):
                 self.load_network(self.netD, 'D', epoch, path)
                 if self.isTrain and self.temporal and self.netDT is not None:
@@ -477,8 +496,12 @@ class Vid2VidModel(nn.Module):
         if getattr(opt, 'finetune', False) and self.t == 0:
             self.finetune(ref_labels, ref_images)
         with torch.no_grad():
-            fake, flow, mask, raw, warped, _, _, atn_score, _ = self.netG(tgt_label_valid, ref_labels_valid, ref_images,
-                                                                          prevs, t=self.t)
+            fake, flow, mask, raw, warped, _, _, atn_score, ref_idx = self.netG(tgt_label_valid, ref_labels_valid,
+                                                                                ref_images, prevs, t=self.t)
+            if self.refine_face:                     # vid2vid_model.py:198-201
+                pick = networks.pick_ref
+                fake = self.refine_face_region(tgt_label_valid, fake, tgt_label[:, -1], pick(ref_labels_valid, ref_idx),
+                                               pick(ref_images, ref_idx), pick(ref_labels, ref_idx))
             n_prev = opt.n_frames_G - 1
             new = []
             for old, now in zip(self.prevs, (tgt_label_valid, fake)):          # concat_prev, vid2vid_model.py:169-176
@@ -491,6 +514,20 @@ class Vid2VidModel(nn.Module):
 
     def reset_inference(self):
         self.prevs = None
+
+    def refine_face_region(self, label_valid, fake_image, label, ref_label_valid, ref_image, ref_label):
+        """face_refiner.py:24-30: crop (4 px inside the face box) label / coarse output and the reference's, run the face
+        generator on the crops, paste `coarse + refinement` back (bilinear resize to the box, clamp)."""
+        lc = self.lossCollector
+        boxes = ops.face_boxes(label, lc.use_openpose, crop_smaller=4)
+        ref_boxes = ops.face_boxes(ref_label, lc.use_openpose, crop_smaller=4)
+        size = lc.face_size
+        label_face = ops.crop_face(label_valid, boxes, size)
+        coarse = ops.crop_face(fake_image, boxes, size).detach()
+        ref_label_face = ops.crop_face(ref_label_valid, ref_boxes, size)
+        ref_image_face = ops.crop_face(ref_image, ref_boxes, size)
+        fake_face = self.netGf(label_face, ref_label_face.unsqueeze(1), ref_image_face.unsqueeze(1), img_coarse=coarse)
+        return ops.paste_face(fake_image, fake_face + coarse, boxes)
 
     def finetune(self, ref_labels, ref_images):
         """vid2vid_model.py:207-237: test-time adaptation on the reference images - the generator layers whose names
@@ -551,6 +588,8 @@ class Vid2VidModel(nn.Module):
         pick = networks.pick_ref                     # vid2vid_model.py:144 (the attended reference when n_shot > 1)
         ref_label_valid, ref_label_t, ref_image_t = pick(ref_labels_valid, ref_idx), pick(ref_labels, ref_idx), \
             pick(ref_images, ref_idx)
+        if self.refine_face:                         # vid2vid_model.py:146-148
+            fake = self.refine_face_region(tgt_label_valid, fake, tgt_label_t, ref_label_valid, ref_image_t, ref_label_t)
         fg, ref_fg = fg_mask_of(opt, tgt_label_t, self.has_fg), fg_mask_of(opt, ref_label_t, self.has_fg)
         if raw is not None:
             raw = raw * union_fg(fg, ref_fg, self.has_fg)

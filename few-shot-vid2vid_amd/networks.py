@@ -555,6 +555,21 @@ class FewShotGenerator(nn.Module):
         enc_label = self.label_embedding(label, weights=(embed_w if self.adap_embed else None))
         return x, enc_label, norm_w
 
+    def forward_face(self, label, label_refs, img_refs, img_coarse):
+        """generator.py:232-242 (the --refine_face generator): the decoder starts from the encoding of the COARSE face
+        (compute_kld with img_coarse, generator.py:321-325: reference-image encoder applied to it) instead of the
+        reference image's; SPADE weights still come from the reference crops."""
+        _, enc_label, norm_w = self.weight_generation(img_refs, label_refs, label)
+        x = self.ref_img_first(img_coarse)
+        for i in range(self.n_downsample_G):
+            x = getattr(self, 'ref_img_down_%d' % i)(x)
+        for i in range(self.n_downsample_G, -1, -1):
+            nw = norm_w[i] if (self.adap_spade and i < self.n_adaptive_layers) else None
+            x = getattr(self, 'up_%d' % i)(x, enc_label[i], nw)
+            if i != 0:
+                x = ops.upsample2x(x)
+        return self.conv_img(ops.activation(x, ACT_LRELU), act=ACT_TANH)
+
     def flow_generation(self, label, label_ref, img_ref, prev):
         label_prev, img_prev = prev
         flow, mask, warp, ds = [None, None], [None, None], [None, None], [None, None]
@@ -572,12 +587,12 @@ class FewShotGenerator(nn.Module):
         return flow, mask, warp, ds
 
     def forward(self, label, label_refs, img_refs, prev=(None, None), t=0, img_coarse=None):
-        if img_coarse is not None:
-            raise NotImplementedError("face refinement generator (refine_face) is outside the hot-path scope")
         if self._sn_group is None or self._sn_count != sum(1 for _ in self.modules()):
             self._sn_group = ops.SpectralGroup(spectral_layers(self))
             self._sn_count = sum(1 for _ in self.modules())
         self._sn_group.update(self.training)
+        if img_coarse is not None:
+            return self.forward_face(label, label_refs, img_refs, img_coarse)
         x, enc_label, norm_w = self.weight_generation(img_refs, label_refs, label, t=t)
         atn_vis, ref_idx = self._atn
         label_ref, img_ref = pick_ref(label_refs, ref_idx), pick_ref(img_refs, ref_idx)

@@ -967,6 +967,8 @@ lib.register_sigs({
     "fsv_face_boxes": [c_p, c_ll, c_ll, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_p],
     "fsv_crop_resize_fwd": [c_p, c_ll, c_ll, c_ll, c_ll, c_i, c_p, c_p, c_i, c_i, c_p],
     "fsv_crop_resize_bwd": [c_p, c_p, c_p, c_ll, c_ll, c_ll, c_ll, c_i, c_i, c_i, c_p],
+    "fsv_paste_face_fwd": [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_ll, c_ll, c_ll, c_ll, c_p],
+    "fsv_paste_face_bwd": [c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p],
 })
 
 
@@ -1010,6 +1012,38 @@ class _CropFaceFn(torch.autograd.Function):
 
 def crop_face(image, boxes, size):
     return _CropFaceFn.apply(image, boxes, size)
+
+
+class _PasteFaceFn(torch.autograd.Function):
+    """face_refiner.py:42-54 replace_face_region for the whole batch: the refined face (face [N, 3, S, S], already
+    `fake_face + coarse`) is resized bilinearly to each sample's box, clamped to [-1, 1] and written over the image."""
+
+    @staticmethod
+    def forward(ctx, image, face, boxes):
+        n, c, h, w = image.shape
+        face = face.contiguous()
+        out = torch.empty((n, 3, h, w), dtype=torch.float32, device=image.device)
+        lib.check_device(image, face, boxes)
+        lib.call("fsv_paste_face_fwd", lib.ptr(image), lib.ptr(face), lib.ptr(boxes), lib.ptr(out), n, h, w, face.shape[-1],
+                 image.stride(0), image.stride(1), image.stride(2), image.stride(3), lib.stream_ptr())
+        ctx.save_for_backward(out, boxes)
+        ctx.size = face.shape[-1]
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        out, boxes = ctx.saved_tensors
+        n, _, h, w = out.shape
+        dout = dout.contiguous()
+        dimg = torch.empty_like(out)
+        dface = torch.zeros((n, 3, ctx.size, ctx.size), dtype=torch.float32, device=out.device)
+        lib.call("fsv_paste_face_bwd", lib.ptr(dout), lib.ptr(out), lib.ptr(boxes), lib.ptr(dimg), lib.ptr(dface), n, h, w,
+                 ctx.size, lib.stream_ptr())
+        return dimg, dface, None
+
+
+def paste_face(image, face, boxes):
+    return _PasteFaceFn.apply(image, face, boxes)
 
 
 def pool15(x, mode, thresh=0.0):

@@ -201,6 +201,13 @@ int fsv_crop_resize_fwd(const float* img, long long sn, long long sc, long long 
                         float* out, int N, int S, fsv_stream_t stream);
 int fsv_crop_resize_bwd(const float* dout, const int* boxes, float* dimg, long long sn, long long sc, long long sy,
                         long long sx, int C, int N, int S, fsv_stream_t stream);
+/* --refine_face (face_refiner.py:42-54 replace_face_region): out = img outside box n, clamp(bilinear resize of face[n]
+ * [3][S][S] to the box size, -1, 1) inside (align_corners False); backward: dimg = dout outside the boxes, dface
+ * (zero-initialised) receives the weighted dout where the clamp was inactive */
+int fsv_paste_face_fwd(const float* img, const float* face, const int* boxes, float* out, int N, int H, int W, int S,
+                       long long isn, long long isc, long long isy, long long isx, fsv_stream_t stream);
+int fsv_paste_face_bwd(const float* dout, const float* out, const int* boxes, float* dimg, float* dface, int N, int H, int W,
+                       int S, fsv_stream_t stream);
 
 /* ---- the FlowNet2 teacher's three native operators, forward only (csrc/flownet_ops.hip) ----
  * correlation (correlation_cuda_kernel.cu:74-147; kernel_size 1): f1 / f2 NHWC [N][H][W][C] -> out NHWC

@@ -47,6 +47,9 @@ CONFIGS['pose_combine_dt'] = CONFIGS['pose_combine'] + ' --lambda_temp 2'
 CONFIGS['face_nshot2'] = CONFIGS['face'] + ' --n_shot 2 --warp_ref'
 # teacher flow present (training without --no_flow_gt): flow_gt / conf_gt are synthetic stand-ins fed through data_list
 CONFIGS['pose_combine_flowgt'] = CONFIGS['pose_combine'].replace(' --no_flow_gt', '')
+# second generator on the face crops (face_refiner.py:24-30); 128 x 128 so that the 32 x 32 face survives four stride-2 layers
+CONFIGS['pose_refine_face'] = CONFIGS['pose_combine'].replace('--fineSize 64 --loadSize 64', '--fineSize 128 --loadSize 128') \
+    + ' --refine_face --n_downsample_G 4 --n_adaptive_layers 3'
 # street: integer class maps, one-hot encoded by encode_label (input_process.py:25-45); default aspect_ratio 2 -> 32 x 64
 CONFIGS['street'] = ('--dataset_mode fewshot_street --label_nc 7 --fineSize 64 --loadSize 64 --adaptive_spade --no_flow_gt '
                      '--no_vgg_loss --gpu_ids -1 --ngf 8 --ndf 8 --batchSize 2')
@@ -79,6 +82,8 @@ def step(name, flags):
     mc.fill_state(model.netD)
     if model.netDf is not None:
         mc.fill_state(model.netDf)
+    if getattr(model, 'refine_face', False):
+        mc.fill_state(model.netGf)
     for o in (model.optimizer_G, model.optimizer_D):
         for g in o.param_groups:
             g['lr'] = 0.0
@@ -100,6 +105,8 @@ def step(name, flags):
     g_losses, generated, prev = model(data, save_images=True, mode='generator')
     g_losses = loss_backward(opt, g_losses, model.optimizer_G, 0)
     gG = {k: float(p.grad.norm()) for k, p in model.netG.named_parameters() if p.grad is not None}
+    if getattr(model, 'refine_face', False):
+        gG.update({'netGf.' + k: float(p.grad.norm()) for k, p in model.netGf.named_parameters() if p.grad is not None})
     fake, raw, warped, flow, mask, _ = generated
 
     def t(x):

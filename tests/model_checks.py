@@ -306,7 +306,7 @@ def _vgg_weights(opt):
     return import_module('few-shot-vid2vid_amd.vgg').random_vgg19_weights()
 
 
-def _oracle_iteration(sdG0, sdD0, cfg, data, dtype, vgg_weights=None, sdDf0=None, flow_gt=None, conf_gt=None):
+def _oracle_iteration(sdG0, sdD0, cfg, data, dtype, vgg_weights=None, sdDf0=None, flow_gt=None, conf_gt=None, sdGf0=None):
     """One reference iteration (train.py:58-62) on the oracle: D step then G step; returns losses and gradients
     (the face discriminator's gradients, when present, as a 6th entry)."""
     tl, ti, rl, ri = [t.to(dtype) for t in data]
@@ -321,7 +321,8 @@ def _oracle_iteration(sdG0, sdD0, cfg, data, dtype, vgg_weights=None, sdDf0=None
         return sd
     sdG, sdD = leafify(sdG0), leafify(sdD0)
     sdDf = leafify(sdDf0) if sdDf0 is not None else None
-    d_losses = O.d_step_losses(sdG, sdD, cfg, tl, ti, rl, ri, sdDf=sdDf)
+    sdGf = leafify(sdGf0) if sdGf0 is not None else None
+    d_losses = O.d_step_losses(sdG, sdD, cfg, tl, ti, rl, ri, sdDf=sdDf, sdGf=sdGf)
     sum(l.mean() for l in d_losses).backward()
     gD = {k: v.grad.clone() for k, v in sdD.items() if v.is_floating_point() and v.grad is not None}
     gDf = {k: v.grad.clone() for k, v in (sdDf or {}).items() if v.is_floating_point() and v.grad is not None}
@@ -332,9 +333,11 @@ def _oracle_iteration(sdG0, sdD0, cfg, data, dtype, vgg_weights=None, sdDf0=None
     fg = [None if f is None else f.to(dtype) for f in (flow_gt or [None, None])]
     cg = [None if f is None else f.to(dtype) for f in (conf_gt or [None, None])]
     g_losses, gen = O.g_step_losses(sdG, sdD, cfg, tl, ti, rl, ri, vgg_weights=vgg_weights, sdDf=sdDf, flow_gt=fg,
-                                    conf_gt=cg)
+                                    conf_gt=cg, sdGf=sdGf)
     sum(l.mean() for l in g_losses.values()).backward()
     gG = {k: v.grad.clone() for k, v in sdG.items() if v.is_floating_point() and v.grad is not None}
+    if sdGf is not None:                         # the face generator's gradients ride along under a 'netGf.' prefix
+        gG.update({'netGf.' + k: v.grad.clone() for k, v in sdGf.items() if v.is_floating_point() and v.grad is not None})
     return d_losses, gD, g_losses, gG, gen, gDf
 
 
@@ -359,6 +362,7 @@ def check_train_step(device, opt, b=2, tol=1e-3, seed=21, grad_tol=2e-2, with_fl
     model = M.create_model(opt)
     sdG0, sdD0 = fill_state(model.netG), fill_state(model.netD)
     sdDf0 = fill_state(model.netDf) if model.netDf is not None else None
+    sdGf0 = fill_state(model.netGf) if getattr(model, 'netGf', None) is not None else None
     model = model.to(device).train()
     opt_G, opt_D = model.build_optimizers()
     opt_G.set_lr(0.0); opt_D.set_lr(0.0)          # keep weights fixed so that both steps see the same parameters
@@ -371,8 +375,8 @@ def check_train_step(device, opt, b=2, tol=1e-3, seed=21, grad_tol=2e-2, with_fl
     flow_gt, conf_gt = [None, None], [None, None]
     if with_flow_gt:                       # teacher flow for the reference branch (train.py:44-48 without --no_flow_gt)
         flow_gt[0], conf_gt[0] = synth_flow_gt(b, h, w, seed + 5)
-    r32 = _oracle_iteration(sdG0, sdD0, cfg, data, torch.float32, vw, sdDf0, flow_gt, conf_gt)
-    r64 = _oracle_iteration(sdG0, sdD0, cfg, data, torch.float64, vw, sdDf0, flow_gt, conf_gt)
+    r32 = _oracle_iteration(sdG0, sdD0, cfg, data, torch.float32, vw, sdDf0, flow_gt, conf_gt, sdGf0)
+    r64 = _oracle_iteration(sdG0, sdD0, cfg, data, torch.float64, vw, sdDf0, flow_gt, conf_gt, sdGf0)
     tl, ti, rl, ri = [t.to(device) for t in data]
     dv = lambda lst: [None if t is None else t.to(device) for t in lst]
     data_list = [tl, ti, dv(flow_gt), dv(conf_gt), rl, ri, None, None, None]
@@ -396,6 +400,12 @@ def check_train_step(device, opt, b=2, tol=1e-3, seed=21, grad_tol=2e-2, with_fl
     for name, _ in model.netG.named_parameters():      # parameters the losses do not reach
         sd32.setdefault(name, _G(None)); sd64.setdefault(name, _G(None))
     worst = compare_grads_l2(model.netG, sd32, sd64, grad_tol)
+    if getattr(model, 'netGf', None) is not None:
+        f32 = {k[6:]: v for k, v in sd32.items() if k.startswith('netGf.')}
+        f64 = {k[6:]: v for k, v in sd64.items() if k.startswith('netGf.')}
+        for name, _ in model.netGf.named_parameters():
+            f32.setdefault(name, _G(None)); f64.setdefault(name, _G(None))
+        compare_grads_l2(model.netGf, f32, f64, grad_tol)
     _close_vs64('fake image', generated[0][:, 0], r32[4]['fake'], r64[4]['fake'], tol)
     return worst
 

@@ -523,6 +523,20 @@ def check_face_ops(device, seed=17):
             out.backward(_dev(dy, device))
             assert torch.equal(out.detach().cpu(), ref.detach())
             assert_close('crop face grad', img_d.grad, img_r.grad, 1e-6)
+        # --refine_face: paste the (coarse + refined) face back (replace_face_region, crop_smaller 4)
+        fake = torch.randn(n, 3, h, w, generator=g).clamp(-1.2, 1.2)
+        face = torch.randn(n, 3, size, size, generator=g) * 0.8
+        fr, cr = fake.clone().requires_grad_(True), face.clone().requires_grad_(True)
+        ref = O.replace_face_region(cfg, fr, cr, label, None, crop_smaller=4)
+        dy = torch.randn(ref.shape, generator=g)
+        ref.backward(dy)
+        fd, cd = _dev(fake, device).requires_grad_(True), _dev(face, device).requires_grad_(True)
+        boxes = ops.face_boxes(_dev(label, device), use_openpose=not remove_face_labels, crop_smaller=4)
+        out = ops.paste_face(fd, cd, boxes)
+        out.backward(_dev(dy, device))
+        assert_close('paste face', out, ref, 1e-5)       # (ATen evaluates the same bilinear weights in another order)
+        assert_close('paste face dimg', fd.grad, fr.grad, 1e-5)
+        assert_close('paste face dface', cd.grad, cr.grad, 1e-5)
 
 
 def check_flownet_ops(device, seed=18):

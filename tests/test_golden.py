@@ -15,7 +15,7 @@ from oracle import fsv_oracle as O
 
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
 CASES = ['pose_combine', 'face', 'pose_blend', 'pose_combine_vgg', 'street', 'pose_face_d', 'face_nshot2',
-         'pose_combine_flowgt']
+         'pose_combine_flowgt', 'pose_refine_face']
 
 
 def _opt_from_flags(flags):
@@ -23,7 +23,7 @@ def _opt_from_flags(flags):
     toks = flags.split()
     kw = {}
     ints = {'--ngf': 'ngf', '--ndf': 'ndf', '--nff': 'nff', '--fineSize': 'fineSize', '--loadSize': 'loadSize',
-            '--batchSize': 'batchSize'}
+            '--batchSize': 'batchSize', '--n_downsample_G': 'n_downsample_G', '--n_adaptive_layers': 'n_adaptive_layers'}
     i = 0
     while i < len(toks):
         t = toks[i]
@@ -42,7 +42,7 @@ def _opt_from_flags(flags):
         elif t == '--gpu_ids':
             i += 2
         elif t in ('--adaptive_spade', '--warp_ref', '--spade_combine', '--remove_face_labels', '--no_flow_gt',
-                   '--no_vgg_loss', '--add_face_D'):
+                   '--no_vgg_loss', '--add_face_D', '--refine_face'):
             kw[t[2:]] = True; i += 1
         else:
             raise ValueError(t)
@@ -96,8 +96,9 @@ def test_oracle_reproduces_reference_iteration(case):
     sdG0, sdD0 = mc.fill_state(model.netG), mc.fill_state(model.netD)
     data = _inputs(g, opt)
     sdDf0 = mc.fill_state(model.netDf) if model.netDf is not None else None
+    sdGf0 = mc.fill_state(model.netGf) if model.netGf is not None else None
     d_losses, gD, g_losses, gG, gen, gDf = mc._oracle_iteration(sdG0, sdD0, O.cfg_from_opt(opt), data, torch.float32,
-                                                           mc._vgg_weights(opt), sdDf0, *_flow_gt(case, g))
+                                                           mc._vgg_weights(opt), sdDf0, *_flow_gt(case, g), sdGf0=sdGf0)
     names = g['loss_names']
     for i in range(2, len(d_losses)):              # Df_real, Df_fake with --add_face_D
         assert abs(float(d_losses[i]) - g['d_losses'][i]) <= 1e-5 * max(1.0, abs(g['d_losses'][i])), i
@@ -160,6 +161,8 @@ def test_product_reproduces_reference_iteration_on_gpu(hip_lib, case):
     mc.fill_state(model.netG); mc.fill_state(model.netD)
     if model.netDf is not None:
         mc.fill_state(model.netDf)
+    if model.netGf is not None:
+        mc.fill_state(model.netGf)
     model = model.to(dev).train()
     opt_G, opt_D = model.build_optimizers()
     opt_G.set_lr(0.0); opt_D.set_lr(0.0)

@@ -84,3 +84,10 @@ def test_flownet2_teacher_reduced_width(emu_lib):
 
 def test_flownet_teacher_feeds_the_flow_loss(emu_lib):
     mc.check_flownet_wrapper(DEV)
+
+
+def test_train_step_with_face_refinement_tiny(emu_lib):
+    """--refine_face: second generator on the face crops (decoder fed by the encoding of the coarse face), paste-back with
+    bilinear resize + clamp; its gradients and the main generator's through the pasted image"""
+    mc.check_train_step(DEV, mc.tiny_opt(warp_ref=True, spade_combine=True, remove_face_labels=True, refine_face=True,
+                                         fineSize=128, loadSize=128, n_downsample_G=4, n_adaptive_layers=3), b=1)

@@ -75,3 +75,10 @@ def test_train_step_two_reference_images(hip_lib):
 
 def test_flownet2_teacher_reduced_width(hip_lib):
     mc.check_flownet2(dev(), width_div=4, size=128, b=2, tol=1e-3)
+
+
+def test_train_step_with_face_refinement(hip_lib):
+    """--refine_face: face generator on device-cropped faces, bilinear paste-back"""
+    mc.check_train_step(dev(), mc.tiny_opt(ngf=8, ndf=8, nff=8, warp_ref=True, spade_combine=True, remove_face_labels=True,
+                                           refine_face=True, fineSize=128, loadSize=128, n_downsample_G=4,
+                                           n_adaptive_layers=3), b=2)
