@@ -11,7 +11,7 @@ import torch.multiprocessing as mp
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _worker(rank, world, port, out_dir):
+def _worker(rank, world, port, out_dir, overlap=True, iters=1):
     os.environ['FSV2V_EMU'] = '1'
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(port)
@@ -25,12 +25,15 @@ def _worker(rank, world, port, out_dir):
     model = M.create_model(opt)
     mc.fill_state(model.netG); mc.fill_state(model.netD)
     model.train()
-    opt_G, opt_D = model.build_optimizers(world_size=world)
+    opt_G, opt_D = model.build_optimizers(world_size=world, overlap=overlap)
+    assert (opt_G.finalizer is not None) == (not overlap)       # deferred weight gradients only without autograd hooks
     tl, ti, rl, ri = mc.synth_pose_inputs(1, 32, 32, 100 + rank, 1)
     data = [tl, ti, [None, None], [None, None], rl, ri, None, None, None]
-    d = model(data, mode='discriminator'); M.loss_backward(opt, d, opt_D, 1)
-    gD = opt_D.flat_g.clone()
-    g, _, _ = model(data, mode='generator'); M.loss_backward(opt, g, opt_G, 0)
+    for it in range(iters):
+        d = model(data, mode='discriminator'); M.loss_backward(opt, d, opt_D, 1)
+        if it == 0:
+            gD = opt_D.flat_g.clone()
+        g, _, _ = model(data, mode='generator'); M.loss_backward(opt, g, opt_G, 0)
     torch.save(dict(gD=gD, gG=opt_G.flat_g.clone(), pD=opt_D.flat_p.clone(), pG=opt_G.flat_p.clone(),
                     nb=len(opt_G.buckets)), os.path.join(out_dir, 'rank%d.pt' % rank))
     dist.destroy_process_group()
@@ -65,6 +68,21 @@ def test_two_rank_gradient_exchange(emu_lib, tmp_path):
     assert torch.equal(r0['gD'], r1['gD']) and torch.equal(r0['gG'], r1['gG'])
     assert torch.equal(r0['pD'], r1['pD']) and torch.equal(r0['pG'], r1['pG'])
     # ... and the sum equals the two local gradients added (D step: weights identical on both ranks at that point)
+    local = _single(0, None) + _single(1, None)
+    scale = float(local.abs().max())
+    assert float((r0['gD'] - local).abs().max()) <= 1e-5 * scale
+
+
+def test_two_rank_whole_buffer_exchange(emu_lib, tmp_path):
+    """the mode bench.py uses at N > 1 (overlap=False): kernel-side gradient sinks, deferred weight-gradient finalisation
+    and the detached small-parameter gradients (second iteration) all land in the flat buffer before ONE all-reduce"""
+    world, port = 2, 29613
+    mp.spawn(_worker, args=(world, port, str(tmp_path), False, 2), nprocs=world, join=True)
+    r0 = torch.load(os.path.join(tmp_path, 'rank0.pt'))
+    r1 = torch.load(os.path.join(tmp_path, 'rank1.pt'))
+    assert r0['nb'] == 0
+    assert torch.equal(r0['gD'], r1['gD']) and torch.equal(r0['gG'], r1['gG'])
+    assert torch.equal(r0['pD'], r1['pD']) and torch.equal(r0['pG'], r1['pG'])
     local = _single(0, None) + _single(1, None)
     scale = float(local.abs().max())
     assert float((r0['gD'] - local).abs().max()) <= 1e-5 * scale
