@@ -5,6 +5,7 @@ generator.py:541-572, discriminator.py:67-88), ``nn.Linear`` (generator.py:103-1
 (models/networks/base_network.py:56-71).  Tensors keep the reference's logical NCHW shape but live in
 channels-last memory (NHWC), which is the layout the kernels in csrc/conv_igemm.hip read and write.
 """
+import ctypes
 import os
 
 import torch
@@ -92,7 +93,13 @@ def prep_weight(w, mode, geom, khs=None, kws=None, scale=None, out=None):
     rowlen, ncols = (cout, cin) if mode == 1 else (cin, cout)
     kpad = _ceil(max(ntaps * rowlen, 1), 32)
     ldw = _ceil(ncols, 32)
-    w = w.contiguous()
+    # per-sample (generated) weights are views into the weight-generating FC's output: each sample's [Cout][Cin][k][k]
+    # block is contiguous, only the sample stride is larger - read them in place instead of copying
+    w_bstride = cout * cin * kh * kw
+    if batched and w[0].is_contiguous() and w.stride(0) >= w_bstride:
+        w_bstride = w.stride(0)
+    else:
+        w = w.contiguous()
     lib.check_device(w, scale)
     if out is None:
         out = torch.empty((nb, kpad, ldw), dtype=torch.float32, device=w.device)
@@ -100,7 +107,7 @@ def prep_weight(w, mode, geom, khs=None, kws=None, scale=None, out=None):
         out.zero_()
         return out, kpad, ldw
     lib.call("fsv_prep_weight", lib.ptr(w), lib.ptr(out), lib.ptr(scale), mode, nb, cout, cin, kh, kw, ntaps,
-             lib.int_array(khs), lib.int_array(kws), kpad, ldw, cout * cin * kh * kw, kpad * ldw, lib.stream_ptr())
+             lib.int_array(khs), lib.int_array(kws), kpad, ldw, w_bstride, kpad * ldw, lib.stream_ptr())
     return out, kpad, ldw
 
 
@@ -133,7 +140,13 @@ def gather_gemm(x, wt, ldw, cout, oh, ow, ty, tx, sy, sx, bias=None, res=None, a
         res = to_nhwc(res)
     lib.check_device(x, wt, bias, res, out, wscale)
     w_bs = wt.shape[-2] * wt.shape[-1] if per_sample else 0
-    b_bs = cout if (per_sample and bias is not None) else 0
+    b_bs = 0
+    if per_sample and bias is not None:
+        if bias.dim() == 2 and bias.stride(1) == 1:
+            b_bs = bias.stride(0)               # rows of the FC output: read in place
+        else:
+            bias = bias.contiguous()
+            b_bs = cout
     args = (lib.ptr(x), lib.ptr(wt), lib.ptr(bias), lib.ptr(res), lib.ptr(out),
             n, h, w, cin, oh, ow, cout, len(ty), lib.int_array(ty), lib.int_array(tx), sy, sx,
             out_h, out_w, osy, osx, ooy, oox, ldw, w_bs, b_bs, 1 if per_sample else 0,
@@ -158,6 +171,14 @@ def conv_forward(x, wt_f, ldw, cout, geom, bias=None, res=None, act=ACT_NONE, sc
                        wscale=wscale)
 
 
+def _planned_split(mz, cout, nchunks, nsamp):
+    """the split-K factor fsv_conv_gather_fwd will pick for this launch (csrc/conv_igemm.hip fsv_conv_plan)"""
+    lib.register_sigs({"fsv_conv_plan": [ctypes.c_int] * 6 + [ctypes.POINTER(ctypes.c_int)] * 2})
+    tile, nsplit = ctypes.c_int(0), ctypes.c_int(1)
+    lib.call("fsv_conv_plan", mz, cout, nchunks, nsamp, -1, 0, ctypes.byref(tile), ctypes.byref(nsplit))
+    return nsplit.value
+
+
 def conv_dgrad(dout, w, geom, in_hw, scale=None, per_sample=False, cached=None, cin=None):
     """Data gradient of a convolution: dx[n, y, x, ci] from dout (NHWC) and OIHW weights.
 
@@ -178,15 +199,23 @@ def conv_dgrad(dout, w, geom, in_hw, scale=None, per_sample=False, cached=None, 
         c = geom.dgrad_classes[0]
         wt, ldw, ws = layout(0, c)
         return gather_gemm(dout, wt, ldw, cin, h, wd, c['ty'], c['tx'], 1, 1, per_sample=per_sample, wscale=ws)
-    dx = zeros_nhwc(n, cin, h, wd, dout)
-    for k, c in enumerate(geom.dgrad_classes):
-        sub_h = (h - c['py'] + s - 1) // s
-        sub_w = (wd - c['px'] + s - 1) // s
+    # every output pixel belongs to exactly one parity class: when all classes have taps and none of their launches
+    # needs split-K (atomics), each class stores its own pixels and the zero fill of dx is unnecessary
+    subs = [((h - c['py'] + s - 1) // s, (wd - c['px'] + s - 1) // s) for c in geom.dgrad_classes]
+    plain = all(c['khs'] and sh > 0 and sw > 0 for c, (sh, sw) in zip(geom.dgrad_classes, subs))
+    if plain:
+        for c, (sh, sw) in zip(geom.dgrad_classes, subs):
+            mz = sh * sw if per_sample else n * sh * sw
+            if _planned_split(mz, cin, (len(c['khs']) * cout + 31) // 32, n if per_sample else 1) > 1:
+                plain = False
+                break
+    dx = empty_nhwc(n, cin, h, wd, dout) if plain else zeros_nhwc(n, cin, h, wd, dout)
+    for k, (c, (sub_h, sub_w)) in enumerate(zip(geom.dgrad_classes, subs)):
         if sub_h <= 0 or sub_w <= 0 or not c['khs']:
             continue
         wt, ldw, ws = layout(k, c)
         gather_gemm(dout, wt, ldw, cin, sub_h, sub_w, c['ty'], c['tx'], 1, 1, per_sample=per_sample, out=dx,
-                    place=(h, wd, s, s, c['py'], c['px']), accumulate=True, wscale=ws)
+                    place=(h, wd, s, s, c['py'], c['px']), accumulate=not plain, wscale=ws)
     return dx
 
 

@@ -244,7 +244,97 @@ __global__ __launch_bounds__(256) void fsv_colsum_final_kernel(const double* par
   if (ok && (threadIdx.x & 63) == 0) out[idx] = accumulate ? out[idx] + (float)a : (float)a;
 }
 
+// ---- grouped column sums: the bias gradients of every convolution of a backward pass in two launches -----------------------
+// table[job][8] = { src ([P][C] NHWC rows), dst (float[C], accumulated into), part offset (doubles), P, C, rows_per_blk,
+// nchunks, V | shared << 8 }.  tmap1 = (job, chunk, slab) triples, tmap2 = (job, block of 4 channels) pairs.  Same two-stage fp64 scheme
+// and the same launch plan (fsv_red_plan) as fsv_colsum, so the sums are bit-identical to the per-layer path.
+__global__ __launch_bounds__(256) void fsv_colsum_group_kernel(const long long* table, const int* tmap, double* part) {
+  __shared__ float red[256 * 4];
+  const int job = tmap[blockIdx.x * 3], chunk = tmap[blockIdx.x * 3 + 1], slab = tmap[blockIdx.x * 3 + 2];
+  const long long* t = table + (long long)job * 8;
+  const float* a = reinterpret_cast<const float*>(t[0]);
+  double* pj = part + t[2];
+  const int P = (int)t[3], C = (int)t[4], rpb = (int)t[5], V = (int)(t[7] & 0xff);
+  const int CU = C / V;
+  const int cap = (V == 4) ? 32 : 64;
+  const int TX = CU < cap ? CU : cap, TY = 256 / TX;
+  const int tx = threadIdx.x % TX, ty = threadIdx.x / TX;
+  const int cu = slab * TX + tx;
+  const bool active = ty < TY && cu < CU;
+  const int r0 = chunk * rpb;
+  const int r1 = (r0 + rpb < P) ? r0 + rpb : P;
+  float s[4] = {0.f, 0.f, 0.f, 0.f};
+  if (active) {
+    const int c0 = cu * V;
+    for (int r = r0 + ty; r < r1; r += TY * 4) {
+      float va[4][4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int rr = r + u * TY;
+        const bool ok = rr < r1;
+        const long long off = (long long)rr * C + c0;
+        if (V == 4) {
+          float4 q = ok ? *reinterpret_cast<const float4*>(a + off) : make_float4(0.f, 0.f, 0.f, 0.f);
+          va[u][0] = q.x; va[u][1] = q.y; va[u][2] = q.z; va[u][3] = q.w;
+        } else {
+          va[u][0] = ok ? a[off] : 0.f; va[u][1] = va[u][2] = va[u][3] = 0.f;
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) s[j] += va[u][j];
+    }
+  }
+  for (int j = 0; j < V; ++j) red[threadIdx.x * V + j] = s[j];
+  __syncthreads();
+  const int tt = threadIdx.x;
+  if (tt < TX * V) {
+    const int ux = tt / V, j = tt % V;
+    if (slab * TX + ux < CU) {
+      const int c = (slab * TX + ux) * V + j;
+      double acc = 0.0;
+      for (int yy = 0; yy < TY; ++yy) acc += (double)red[(yy * TX + ux) * V + j];
+      pj[(long long)chunk * C + c] = acc;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void fsv_colsum_group_final_kernel(const long long* table, const int* tmap, const double* part) {
+  const int job = tmap[blockIdx.x * 2], cb = tmap[blockIdx.x * 2 + 1];
+  const long long* t = table + (long long)job * 8;
+  float* dst = reinterpret_cast<float*>(t[1]);
+  const double* pj = part + t[2];
+  const int C = (int)t[4], nchunks = (int)t[6];
+  const bool shared = ((t[7] >> 8) & 1) != 0;          // another job of this launch adds into the same dst (a module used twice)
+  const int c = cb * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const bool ok = c < C;
+  double a = 0.0;
+  if (ok)
+    for (int k = lane; k < nchunks; k += 64) a += pj[(long long)k * C + c];
+  for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o);
+  if (ok && lane == 0) {
+    if (shared) atomicAdd(&dst[c], (float)a); else dst[c] += (float)a;
+  }
+}
+
 extern "C" {
+
+// launch plan of the column reductions for a [P][C] tensor: out = {V, TX, nslabs, rows_per_blk, nchunks}
+int fsv_colsum_plan(int P, int C, int* out) {
+  if (P < 1 || C < 1 || !out) return FSV_ERR_BAD_ARG;
+  RedPlan pl = fsv_red_plan(1, P, C);
+  out[0] = pl.V; out[1] = pl.TX; out[2] = pl.nslabs; out[3] = pl.rows_per_blk; out[4] = pl.nchunks;
+  return FSV_OK;
+}
+
+int fsv_colsum_grouped(const long long* table, int njobs, const int* tmap1, int nblk1, const int* tmap2, int nblk2,
+                       double* part, hipStream_t stream) {
+  if (!table || !tmap1 || !tmap2 || !part || njobs < 1 || nblk1 < 1 || nblk2 < 1) return FSV_ERR_BAD_ARG;
+  FSV_LAUNCH(fsv_colsum_group_kernel, dim3(nblk1), dim3(256), stream, table, tmap1, part);
+  FSV_LAUNCH(fsv_colsum_group_final_kernel, dim3(nblk2), dim3(256), stream, table, tmap2, (const double*)part);
+  return fsv_check_launch();
+}
 
 int fsv_norm_workspace_doubles(int G, int P, int C) {
   if (G < 1 || P < 1 || C < 1) return 2;

@@ -74,6 +74,8 @@ class FlatAdam:
                     p._fsv_cache = self.layouts
                     if self.finalizer is not None:
                         p._fsv_finalizer = self.finalizer
+                if self.finalizer is not None and p.dim() == 1:
+                    p._fsv_finalizer = self.finalizer      # conv biases: grouped column sums (grad_finalize.add_bias)
                 self.offsets.append((off, n))
                 off += n
         # ---- data-parallel buckets ------------------------------------------------------------------------

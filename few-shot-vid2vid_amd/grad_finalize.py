@@ -16,7 +16,9 @@ from . import lib
 c_p, c_i = ctypes.c_void_p, ctypes.c_int
 lib.register_sigs({"fsv_wgrad_finalize": [c_p, c_p, c_p, c_p, c_i, c_p, c_i, c_p, c_i, c_p],
                    "fsv_upload_i64": [c_p, c_p, c_i, c_p],
-                   "fsv_gather_add": [c_p, c_i, c_p, c_i, c_p]})
+                   "fsv_gather_add": [c_p, c_i, c_p, c_i, c_p],
+                   "fsv_colsum_plan": [c_i, c_i, ctypes.POINTER(c_i)],
+                   "fsv_colsum_grouped": [c_p, c_i, c_p, c_i, c_p, c_i, c_p, c_p]})
 
 DOT_CHUNK = 4096
 
@@ -28,6 +30,7 @@ def _i64(v):
 class GradFinalizer:
     def __init__(self):
         self.jobs = []            # (entry, dwt, sink, sig, u, v)
+        self.bias_jobs = []       # (dpre [P][C] NHWC rows, sink float[C]): bias gradients = column sums, grouped like the rest
         self._static = {}         # job-sequence signature -> (dims, taps, tmap_dot, nblk_dot, tmap_apply, nblk_apply)
         # per-pass arena for the K-major gradients: zeroed by ONE fill in begin_pass() instead of a zero-fill in front
         # of every split-K wgrad launch; sized from the previous pass (the first pass allocates per layer)
@@ -39,9 +42,56 @@ class GradFinalizer:
         self._arena_dev = dwt.device
         self.jobs.append((entry, dwt, sink, sig, u, v))
 
+    def add_bias(self, dpre, sink):
+        """bias gradient of a convolution: sink[c] += sum over the pixels of dpre[:, c] (dpre is kept alive until run())"""
+        self.bias_jobs.append((dpre, sink))
+
+    def _run_bias(self):
+        jobs, self.bias_jobs = self.bias_jobs, []
+        if not jobs:
+            return
+        dev = jobs[0][0].device
+        capturing = (not lib.is_emu()) and torch.cuda.is_current_stream_capturing()
+        shapes = tuple((t.numel() // t.shape[1], t.shape[1]) for t, _ in jobs)
+        key = ('bias',) + shapes
+        st = self._static.get(key)
+        if st is None:
+            if capturing:
+                raise lib.FsvError("new bias-gradient job sequence inside a graph capture; run one eager step first")
+            plans, tmap1, tmap2, off = [], [], [], 0
+            out = (c_i * 5)()
+            for j, (p_rows, c) in enumerate(shapes):
+                lib.call("fsv_colsum_plan", p_rows, c, out)
+                v, tx, nslabs, rpb, nch = [int(x) for x in out]
+                plans.append((off, p_rows, c, rpb, nch, v))
+                for ch in range(nch):
+                    for sl in range(nslabs):
+                        tmap1 += [j, ch, sl]
+                for cb in range((c + 3) // 4):
+                    tmap2 += [j, cb]
+                off += nch * c
+            mk = lambda vals: torch.tensor(vals, dtype=torch.int32).to(dev)
+            st = self._static[key] = (plans, mk(tmap1), len(tmap1) // 3, mk(tmap2), len(tmap2) // 2, off)
+        plans, tmap1, nblk1, tmap2, nblk2, ndoubles = st
+        words = []
+        uses = {}
+        for _, sink in jobs:
+            uses[sink.data_ptr()] = uses.get(sink.data_ptr(), 0) + 1
+        for (t, sink), (off, p_rows, c, rpb, nch, v) in zip(jobs, plans):
+            lib.check_device(t, sink)
+            shared = 1 if uses[sink.data_ptr()] > 1 else 0            # a module used twice in the pass: atomic adds
+            words += [t.data_ptr(), sink.data_ptr(), off, p_rows, c, rpb, nch, v | (shared << 8)]
+        host = (ctypes.c_longlong * len(words))(*words)
+        table = torch.empty(len(words), dtype=torch.int64, device=dev)
+        part = torch.empty(max(ndoubles, 1), dtype=torch.float64, device=dev)
+        lib.call("fsv_upload_i64", lib.ptr(table), host, len(words), lib.stream_ptr())
+        lib.call("fsv_colsum_grouped", lib.ptr(table), len(jobs), lib.ptr(tmap1), nblk1, lib.ptr(tmap2), nblk2,
+                 lib.ptr(part), lib.stream_ptr())
+
     def begin_pass(self):
         """Called by FlatAdam.zero_grad right before a backward pass."""
         self.jobs = []
+        self.bias_jobs = []
         capturing = (not lib.is_emu()) and torch.cuda.is_current_stream_capturing()
         if self._arena_need and not capturing and (self.arena is None or self.arena.numel() < self._arena_need):
             self.arena = None
@@ -62,7 +112,7 @@ class GradFinalizer:
         return out
 
     def pending(self):
-        return bool(self.jobs)
+        return bool(self.jobs) or bool(self.bias_jobs)
 
     def _build_static(self, dev):
         dims, taps, tmap_dot, tmap_apply = [], [], [], []
@@ -115,6 +165,7 @@ class GradFinalizer:
         lib.call("fsv_gather_add", lib.ptr(table), len(pairs), lib.ptr(tmap), nblk, lib.stream_ptr())
 
     def run(self):
+        self._run_bias()
         if not self.jobs:
             return
         dev = self.jobs[0][1].device

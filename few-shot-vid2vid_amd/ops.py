@@ -322,7 +322,9 @@ class _ConvFn(torch.autograd.Function):
                 w4 = torch.nn.functional.pad(w4, (0, 0, 0, 0, 0, cpad))
             wt, _, ldw = prep_weight(w4, 0, geom, scale=inv)
             wscale = None
-        b = bias.detach().contiguous() if bias is not None else None
+        b = bias.detach() if bias is not None else None
+        if b is not None and not (per_sample and b.dim() == 2 and b.stride(1) == 1):
+            b = b.contiguous()       # (per-sample bias rows are read in place by gather_gemm)
         if res is not None and act != ACT_NONE:
             raise ValueError("residual add is only fused after a linear epilogue")
         if scale != 1.0 and act != ACT_NONE:
@@ -408,7 +410,11 @@ class _ConvFn(torch.autograd.Function):
                 if ctx.per_sample:
                     db = colsum(dpre, n, hw, cout)
                 elif b_sink is not None:
-                    colsum(dpre, 1, n * hw, cout, out=b_sink)
+                    fin_b = getattr(bias_t, '_fsv_finalizer', None) if _os.environ.get('FSV_DEFER_BIAS', '1') == '1' else None
+                    if fin_b is not None and dpre.is_contiguous(memory_format=torch.channels_last):
+                        fin_b.add_bias(dpre, b_sink)          # one grouped column-sum pass for the whole backward
+                    else:
+                        colsum(dpre, 1, n * hw, cout, out=b_sink)
                 else:
                     db = colsum(dpre, 1, n * hw, cout).view(cout)
         finally:
@@ -458,8 +464,9 @@ def batch_conv(x, weight, bias=None, act=ACT_NONE):
         return x
     k = weight.shape[-1]
     geom = Geom(k, k, 1, k // 2)
-    b = bias.contiguous() if bias is not None else None
-    return _ConvFn.apply(x, weight.contiguous(), b, None, None, None, None, geom, act, 1.0, False)
+    # weights / biases are usually strided views into the weight-generating FC's output: conv.prep_weight / gather_gemm
+    # read them in place (sample stride), no copies here
+    return _ConvFn.apply(x, weight, bias, None, None, None, None, geom, act, 1.0, False)
 
 
 # ------------------------------------------------------------------------------------------------ normalisation

@@ -121,6 +121,12 @@ int fsv_norm_bwd(const float* dy, const float* y, const float* x, const float* m
                  double* workspace, float* s1, float* s2, float* dx, float* dw, float* db, int G, int P, int C, int act,
                  int fixed_stats, fsv_stream_t stream);   /* fixed_stats: eval mode, mean / rstd are constants */
 int fsv_colsum(const float* x, double* workspace, float* out, int G, int P, int C, int accumulate, fsv_stream_t stream);
+/* the bias gradients of a whole backward pass in two launches: table[job][8] = {src [P][C] rows, dst float[C] (added into),
+ * offset of the job's partials in `part` (doubles), P, C, rows_per_blk, nchunks, V | shared << 8}; tmap1 (job, chunk, slab) triples,
+ * tmap2 (job, 4-channel block) pairs; fsv_colsum_plan gives {V, TX, nslabs, rows_per_blk, nchunks} for one [P][C] */
+int fsv_colsum_plan(int P, int C, int* out);
+int fsv_colsum_grouped(const long long* table, int njobs, const int* tmap1, int nblk1, const int* tmap2, int nblk2,
+                       double* part, fsv_stream_t stream);
 
 /* ---- flow warp (csrc/warp.hip) - replaces resample/get_grid base_network.py:13-37 (F.grid_sample bilinear, border,
  * align_corners=True); tap indices are bit-identical to ATen's.  strides in elements: (batch, channel, y, x). ------ */

@@ -65,10 +65,12 @@ def check_conv(device, n, cin, h, w, cout, k, s, p, act='lrelu', bias=True, seed
     xd, wd = _dev(x, device).requires_grad_(True), _dev(wt, device).requires_grad_(True)
     bd = _dev(b, device).requires_grad_(True) if bias else None
     _sinkify(wd, cache, fin)
+    if bias:
+        _sinkify(bd, None, fin)             # bias gradient: deferred grouped column sums
     y = ops.conv2d(xd, wd, bd, stride=s, padding=p, act=actc)
     y.backward(_dev(dy, device))
     if fin is not None:
-        assert fin.pending()
+        assert fin.pending() and len(fin.bias_jobs) == (1 if bias else 0)
         fin.run()
     assert_close('conv y', y, ref, tol)
     assert_close('conv dx', xd.grad, xr.grad, tol)
@@ -98,6 +100,7 @@ def check_conv_sn_res(device, seed=1, cache=None, fin=None):
     wd = _dev(wt, device).requires_grad_(True)
     xd, bd, rd = (_dev(t, device).requires_grad_(True) for t in (x, b, res))
     _sinkify(wd, cache, fin)
+    _sinkify(bd, None, fin)
     sig = ops.SpectralState.update(wd, ud, vd, training=True)
     y = ops.conv2d(xd, wd, bd, stride=1, padding=1, res=rd, sn=(sig, ud, vd))
     y.backward(_dev(dy, device))
@@ -169,22 +172,26 @@ def check_deferred_wgrad(device, seed=16):
     v = F.normalize(torch.randn(12 * 9, generator=g), dim=0)
     sd = {'weight_orig': w2.clone().requires_grad_(True), 'weight_u': u.clone(), 'weight_v': v.clone()}
     w1r = w1.clone().requires_grad_(True)
-    ref = F.conv2d(F.conv2d(x1, w1r, padding=1) + F.conv2d(x2, w1r, padding=1), O.spectral_weight(sd, '', training=True),
-                   padding=1)
+    b1 = torch.randn(12, generator=g)
+    b1r = b1.clone().requires_grad_(True)
+    ref = F.conv2d(F.conv2d(x1, w1r, b1r, padding=1) + F.conv2d(x2, w1r, b1r, padding=1),
+                   O.spectral_weight(sd, '', training=True), padding=1)
     dy = torch.randn(ref.shape, generator=g)
     ref.backward(dy)
     w1d, w2d = _dev(w1, device).requires_grad_(True), _dev(w2, device).requires_grad_(True)
-    _sinkify(w1d, cache, fin); _sinkify(w2d, cache, fin)
+    b1d = _dev(b1, device).requires_grad_(True)
+    _sinkify(w1d, cache, fin); _sinkify(w2d, cache, fin); _sinkify(b1d, None, fin)
     ud, vd = _dev(u.clone(), device), _dev(v.clone(), device)
     sig = ops.SpectralState.update(w2d, ud, vd, training=True)
-    y = ops.conv2d(ops.conv2d(_dev(x1, device), w1d, None, padding=1) + ops.conv2d(_dev(x2, device), w1d, None, padding=1),
+    y = ops.conv2d(ops.conv2d(_dev(x1, device), w1d, b1d, padding=1) + ops.conv2d(_dev(x2, device), w1d, b1d, padding=1),
                    w2d, None, padding=1, sn=(sig, ud, vd))
     y.backward(_dev(dy, device))
-    assert len(fin.jobs) == 3 and fin._arena_off > 0
+    assert len(fin.jobs) == 3 and fin._arena_off > 0 and len(fin.bias_jobs) == 2     # one bias used twice: shared sink
     assert all(j[1].data_ptr() >= fin.arena.data_ptr() for j in fin.jobs)
     fin.run()
     assert_close('deferred y', y, ref)
     assert_close('deferred shared dw', w1d.grad, w1r.grad)
+    assert_close('deferred shared db', b1d.grad, b1r.grad)
     assert_close('deferred sn dw', w2d.grad, sd['weight_orig'].grad)
 
 
@@ -224,6 +231,21 @@ def check_batch_conv(device, b=2, cin=8, cout=12, h=5, w=6, seed=3):
     assert_close('batch_conv dx', xd.grad, xr.grad)
     assert_close('batch_conv dw', wd.grad, wr.grad)
     assert_close('batch_conv db', bd.grad, br.grad)
+    # weights / bias as strided views of one FC output row per sample (read in place, no copies)
+    f = torch.randn(b, cout * cin + cout + 5, generator=g) * 0.3
+    fr, fd = f.clone().requires_grad_(True), _dev(f, device).requires_grad_(True)
+
+    def parts(t):
+        wp, bp, _ = torch.split(t, [cout * cin, cout, 5], dim=1)
+        return wp.reshape(b, cout, cin, 1, 1), bp
+    ref = O.actvn(O.batch_conv(xr.detach(), *parts(fr)))
+    ref.backward(dy)
+    wv, bv = parts(fd)
+    assert not wv.is_contiguous()
+    y = ops.batch_conv(_dev(x, device), wv, bv, act=conv.ACT_LRELU)
+    y.backward(_dev(dy, device))
+    assert_close('batch_conv strided y', y, ref)
+    assert_close('batch_conv strided df', fd.grad, fr.grad)
 
 
 def check_norm(device, instance, n=3, c=10, h=7, w=5, affine=True, act='lrelu', seed=4):
