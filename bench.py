@@ -34,13 +34,14 @@ FP32_MFMA_PEAK_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md "Pea
 
 WITH_VGG = False       # --vgg: add the VGG19 perceptual loss (a "next" row of SURVEY.md 8f; not part of the headline)
 WITH_FACE_D = False    # --face-d: BASELINE configs[3] flags (--add_face_D, which needs the VGG loss); not the headline
+AMP = 'O0'             # --amp: the reference's apex level string ('O1': fp16 GEMM operands + loss scale; 'bf16x3'); not the headline
 
 
 def build_opt(size, batch):
     import model_checks as mc
     return mc.make_opt(fineSize=size, loadSize=size, batchSize=batch, warp_ref=True, spade_combine=True,
                        remove_face_labels=True, no_vgg_loss=not (WITH_VGG or WITH_FACE_D), no_flow_gt=True,
-                       add_face_D=WITH_FACE_D)
+                       add_face_D=WITH_FACE_D, amp=AMP)
 
 
 def make_data(batch, size, seed, device):
@@ -99,10 +100,13 @@ def main():
     ap.add_argument('--no-roofline', action='store_true')
     ap.add_argument('--vgg', action='store_true', help='include the VGG19 perceptual loss in the G step')
     ap.add_argument('--face-d', action='store_true', help='config 3: --add_face_D (face discriminator + VGG19 loss)')
+    ap.add_argument('--amp', default='O0', help="reference --amp level: O1 = fp16 GEMM operands (fp32 accumulate) + dynamic "
+                    "loss scale, bf16x3 = split-bf16 operands; O0 (default, the headline) = exact fp32")
     args = ap.parse_args()
-    global WITH_VGG, WITH_FACE_D
+    global WITH_VGG, WITH_FACE_D, AMP
     WITH_VGG = args.vgg
     WITH_FACE_D = args.face_d
+    AMP = args.amp
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
@@ -137,7 +141,7 @@ def main():
     def backward_of(losses, optimizer):
         loss = sum(torch.mean(x) for x in losses)
         optimizer.zero_grad()
-        loss.backward()
+        optimizer.scale_loss(loss).backward()      # identity unless --amp O1
         optimizer.finalize_grads()        # deferred weight-gradient jobs belong to the segment that queued them
 
     def seg_d():                       # D forward (incl. the no-grad G forward) + D backward
@@ -236,7 +240,7 @@ def main():
         'higher_is_better': True,
         'scaling': 'weak',
         'vs_baseline': None,
-        'dtype': 'f32',
+        'dtype': {0: 'f32', 1: 'f16 operands / f32 accumulate (--amp, not the headline)', 2: 'bf16x3 operands / f32 accumulate (not the headline)'}[M.amp_mode(opt)],
         'data': 'synthetic',
         'config': {'workload': ('fewshot_pose %dx%d, per-GPU batch %d, adaptive_spade+warp_ref+spade_combine, '
                                 'D step + G step (train.py:58-62), Adam included, %sno FlowNet2%s'

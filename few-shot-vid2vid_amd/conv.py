@@ -14,6 +14,29 @@ from . import lib, profile
 
 ACT_NONE, ACT_LRELU, ACT_TANH, ACT_SIGMOID, ACT_RELU, ACT_LRELU01 = 0, 1, 2, 3, 4, 5
 
+# Arithmetic of the GEMM operands (csrc/conv_np.hip).  0: exact fp32 MFMA (default, the measured path);
+# 1: "f16" - operands rounded to half while staged through LDS, fp32 accumulate (the reference's --amp contract, needs the
+# loss scale of flat.FlatAdam); 2: "bf16x3" - operands split into two bf16 terms, three MFMAs, fp32 accumulate.
+MFMA_F32, MFMA_F16, MFMA_BF16X3 = 0, 1, 2
+_MFMA_NAMES = {'': 0, '0': 0, 'f32': 0, 'fp32': 0, '1': 1, 'f16': 1, 'fp16': 1, '2': 2, 'bf16x3': 2}
+_mfma_mode = _MFMA_NAMES[os.environ.get('FSV_MFMA_MODE', '').lower()]
+
+
+def set_mfma_mode(mode):
+    """Select the operand arithmetic of every convolution / linear / batch_conv GEMM launched from this process (like
+    apex's amp.initialize, models/models.py:22-26, this is process-wide).  Returns the previous mode."""
+    global _mfma_mode
+    prev = _mfma_mode
+    _mfma_mode = _MFMA_NAMES[str(mode).lower()] if not isinstance(mode, int) else int(mode)
+    if _mfma_mode not in (0, 1, 2):
+        _mfma_mode = prev
+        raise ValueError("unknown MFMA operand mode %r" % (mode,))
+    return prev
+
+
+def mfma_mode():
+    return _mfma_mode
+
 
 def to_nhwc(x):
     """Return a tensor with the same logical NCHW shape whose memory is dense NHWC."""
@@ -151,14 +174,20 @@ def gather_gemm(x, wt, ldw, cout, oh, ow, ty, tx, sy, sx, bias=None, res=None, a
             n, h, w, cin, oh, ow, cout, len(ty), lib.int_array(ty), lib.int_array(tx), sy, sx,
             out_h, out_w, osy, osx, ooy, oox, ldw, w_bs, b_bs, 1 if per_sample else 0,
             act, float(scale), force_tile, force_split, 1 if accumulate else 0, lib.ptr(wscale), lib.stream_ptr())
+    entry = "fsv_conv_gather_fwd"
+    if _mfma_mode and cin % 4 == 0:               # scalar-gather layers (3-channel images, labels) stay on the fp32 kernel
+        entry = "fsv_conv_gather_fwd_np"
+        args = args[:-1] + (_mfma_mode, args[-1])
     if profile.enabled():
         mz = oh * ow if per_sample else n * oh * ow
         label = profile.conv_label(mz, cout, (len(ty) * cin + 31) // 32, n if per_sample else 1, cin % 4 == 0,
                                    force_tile, force_split)
+        if entry.endswith('_np'):
+            label = label.replace('fsv_conv_igemm_kernel', 'fsv_np_conv_kernel[%s]' % ('f16' if _mfma_mode == 1 else 'bf16x3'))
         with profile.scope(label, 2.0 * n * oh * ow * cout * cin * len(ty)):
-            lib.call("fsv_conv_gather_fwd", *args)
+            lib.call(entry, *args)
     else:
-        lib.call("fsv_conv_gather_fwd", *args)
+        lib.call(entry, *args)
     return out
 
 
@@ -247,10 +276,17 @@ def conv_wgrad(x, dout, geom, w_shape, per_sample=False, scale=None, force_split
     label = 'fsv_conv_wgrad_kernel<%dx%d,V%d>' % (bm, bn, 4 if vec4 else 1)
     if profile.detail():
         label += ' Kdim%d N%d pix%d z%d' % (geom.ntaps * cin, cout, (oh * ow) if per_sample else n * oh * ow, nb)
+    narrow = _mfma_mode and vec4
+    if narrow:
+        label = 'fsv_np_wgrad_kernel[%s]' % ('f16' if _mfma_mode == 1 else 'bf16x3')
     with profile.scope(label, 2.0 * n * oh * ow * cout * cin * geom.ntaps):
-        lib.call("fsv_conv_wgrad", lib.ptr(x), lib.ptr(dout), lib.ptr(dwt), n, h, w, cin, oh, ow, cout,
+        wargs = (lib.ptr(x), lib.ptr(dout), lib.ptr(dwt), n, h, w, cin, oh, ow, cout,
                  geom.ntaps, lib.int_array(geom.ty), lib.int_array(geom.tx), geom.stride, geom.stride,
-                 ldw, kpad, kpad * ldw, 1 if per_sample else 0, force_split, 1 if prezeroed else 0, force_tile, lib.stream_ptr())
+                 ldw, kpad, kpad * ldw, 1 if per_sample else 0, force_split, 1 if prezeroed else 0, force_tile)
+        if narrow:
+            lib.call("fsv_conv_wgrad_np", *wargs, _mfma_mode, lib.stream_ptr())
+        else:
+            lib.call("fsv_conv_wgrad", *wargs, lib.stream_ptr())
     if raw:
         return dwt
     return unprep_weight_grad(dwt, tuple(w_shape), geom, scale, out)

@@ -28,7 +28,7 @@ from .grad_finalize import GradFinalizer
 
 class FlatAdam:
     def __init__(self, params, lr, betas=(0.0, 0.999), world_size=1, process_group=None, eps=1e-8, bucket_mb=64,
-                 force_exchange=False, overlap=True):
+                 force_exchange=False, overlap=True, loss_scale=None):
         params = [p for p in params if p.requires_grad]
         if not params:
             raise ValueError("no trainable parameters")
@@ -49,6 +49,13 @@ class FlatAdam:
         self.m = torch.zeros_like(self.flat_g)
         self.v = torch.zeros_like(self.flat_g)
         self.state = torch.tensor([0.0, 0.0, 0.0, float(lr)], dtype=torch.float32, device=self.device)
+        # fp16-operand mode (conv.MFMA_F16): apex-style dynamic loss scale kept on the device (csrc/amp.hip);
+        # scaler = [scale, good_steps, found_inf, window, max_scale, min_scale].  None: plain fp32 step.
+        self.scaler = None
+        if loss_scale is not None:
+            init, window = (2.0 ** 16, 2000) if loss_scale is True else loss_scale
+            self.scaler = torch.tensor([float(init), 0.0, 0.0, float(window), 2.0 ** 24, 1.0], dtype=torch.float32,
+                                       device=self.device)
         # persistent K-major layouts of every weight this optimiser owns, rewritten once per step (layout_cache.py)
         self.layouts = LayoutCache() if os.environ.get('FSV_LAYOUT_CACHE', '1') == '1' else None
         # weight gradients stay in the GEMM's layout until one grouped launch folds them into flat_g (grad_finalize.py)
@@ -204,10 +211,20 @@ class FlatAdam:
         if self.exchange and not self.overlap:
             dist.all_reduce(self.flat_g, op=dist.ReduceOp.SUM, group=self.group)
 
+    def scale_loss(self, loss):
+        """models/loss_collector.py:221-224 `amp.scale_loss`: the loss times this optimiser's current scale (a device
+        scalar - nothing is read back); identity without a scaler."""
+        return loss if self.scaler is None else loss * self.scaler[0]
+
     def adam(self):
         self.finalize_grads()
-        ops.adam_step(self.flat_p, self.flat_g, self.m, self.v, self.state, self.betas[0], self.betas[1], self.eps,
-                      1.0 / self.world_size)
+        if self.scaler is not None:
+            # gradients carry the loss scale: test them, step with grad / scale unless one is inf / nan, adapt the scale
+            ops.amp_adam_step(self.flat_p, self.flat_g, self.m, self.v, self.state, self.scaler, self.betas[0],
+                              self.betas[1], self.eps, 1.0 / self.world_size)
+        else:
+            ops.adam_step(self.flat_p, self.flat_g, self.m, self.v, self.state, self.betas[0], self.betas[1], self.eps,
+                          1.0 / self.world_size)
         self._steps_done += 1
         self.refresh_layouts()
 
@@ -225,4 +242,7 @@ class FlatAdam:
         self.adam()
 
     def state_dict(self):
-        return dict(m=self.m, v=self.v, state=self.state)
+        d = dict(m=self.m, v=self.v, state=self.state)
+        if self.scaler is not None:
+            d['scaler'] = self.scaler
+        return d

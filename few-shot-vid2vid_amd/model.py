@@ -18,7 +18,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from . import networks, ops
+from . import conv, networks, ops
 from .flat import FlatAdam
 
 LOSS_NAMES_G = ['G_GAN', 'G_GAN_Feat', 'G_VGG', 'Gf_GAN', 'Gf_GAN_feat', 'GT_GAN', 'GT_GAN_Feat', 'F_Flow', 'F_Warp',
@@ -284,12 +284,29 @@ class LossCollector:
         return loss * opt.lambda_mask
 
 
+def amp_mode(opt):
+    """`--amp` (options/base_options.py:127: an apex opt-level string, '' = off) -> operand arithmetic of the GEMM kernels.
+    Every apex level that computes in half ('O1' ... 'O3') selects the fp16-operand kernels; 'bf16x3' (not an apex level)
+    selects the split-bf16 kernels, which need no loss scale."""
+    level = str(getattr(opt, 'amp', '') or '').lower()
+    if level in ('', 'o0', 'fp32', 'f32'):
+        return conv.MFMA_F32
+    if level in ('o1', 'o2', 'o3', 'fp16', 'f16'):
+        return conv.MFMA_F16
+    if level == 'bf16x3':
+        return conv.MFMA_BF16X3
+    raise ValueError("unknown --amp level %r" % (getattr(opt, 'amp', ''),))
+
+
 def loss_backward(opt, losses, optimizer, loss_id):
-    """models/loss_collector.py:217-228 (fp32 path): sum of means -> zero_grad -> backward -> optimiser step."""
+    """models/loss_collector.py:217-228: sum of means -> zero_grad -> backward -> optimiser step.  With `--amp` the
+    reference scales the loss per `loss_id` (:221-224); here every optimiser owns its scaler (flat.FlatAdam.scale_loss:
+    identity unless the fp16-operand mode is on) and un-scales inside its fused step."""
     losses = [torch.mean(x) if not isinstance(x, int) else x for x in losses]
     loss = sum(losses)
     optimizer.zero_grad()
-    loss.backward()
+    scale_loss = getattr(optimizer, 'scale_loss', None)
+    (scale_loss(loss) if scale_loss is not None else loss).backward()
     optimizer.step()
     return losses
 
@@ -354,16 +371,21 @@ class Vid2VidModel(nn.Module):
             beta1, beta2, g_lr, d_lr = opt.beta1, 0.999, opt.lr, opt.lr
         else:
             beta1, beta2, g_lr, d_lr = 0.0, opt.beta2, opt.lr / 2, opt.lr * 2
+        # models/models.py:22-26 `amp.initialize(model, [optimizer_G, optimizer_D], opt_level=opt.amp, num_losses=2)`:
+        # process-wide operand arithmetic + one dynamic loss scale per optimiser (fp16 only)
+        mode = amp_mode(opt)
+        conv.set_mfma_mode(mode)
+        loss_scale = True if mode == conv.MFMA_F16 else None
         g_params = list(self.netG.parameters())
         if self.netGf is not None:         # base_model.py:204-205
             g_params += list(self.netGf.parameters())
         self.optimizer_G = FlatAdam(g_params, g_lr, (beta1, beta2), world_size, process_group,
-                                    force_exchange=force_exchange, overlap=overlap)
+                                    force_exchange=force_exchange, overlap=overlap, loss_scale=loss_scale)
         d_params = list(self.netD.parameters())
         if self.netDf is not None:         # base_model.py:209-211
             d_params += list(self.netDf.parameters())
         self.optimizer_D = FlatAdam(d_params, d_lr, (beta1, beta2), world_size, process_group,
-                                    force_exchange=force_exchange, overlap=overlap)
+                                    force_exchange=force_exchange, overlap=overlap, loss_scale=loss_scale)
         return self.optimizer_G, self.optimizer_D
 
     def init_temporal_model(self):
@@ -382,14 +404,18 @@ class Vid2VidModel(nn.Module):
         if self.optimizer_G is not None:
             old = self.optimizer_G
             g_params = list(self.netG.parameters()) + (list(self.netGf.parameters()) if self.netGf is not None else [])
+            def carried(o):                # the loss scale found so far carries over to the rebuilt optimiser
+                return None if o.scaler is None else (float(o.scaler[0]), int(o.scaler[3]))
             self.optimizer_G = FlatAdam(g_params, float(old.state[3]), old.betas, old.world_size,
-                                        old.group, force_exchange=old.exchange and old.world_size == 1, overlap=old.overlap)
+                                        old.group, force_exchange=old.exchange and old.world_size == 1, overlap=old.overlap,
+                                        loss_scale=carried(old))
             old = self.optimizer_D
             d_params = list(self.netD.parameters()) + list(self.netDT.parameters())
             if self.netDf is not None:
                 d_params += list(self.netDf.parameters())
             self.optimizer_D = FlatAdam(d_params, float(old.state[3]), old.betas, old.world_size, old.group,
-                                        force_exchange=old.exchange and old.world_size == 1, overlap=old.overlap)
+                                        force_exchange=old.exchange and old.world_size == 1, overlap=old.overlap,
+                                        loss_scale=carried(old))
         return self.optimizer_G
 
     def update_learning_rate(self, epoch):

@@ -812,6 +812,24 @@ def adam_step(param, grad, m, v, state, beta1, beta2, eps, gscale=1.0):
              float(beta1), float(beta2), float(eps), float(gscale), lib.stream_ptr())
 
 
+lib.register_sigs({
+    "fsv_amp_check": [c_p, c_ll, c_p, c_p],
+    "fsv_amp_adam": [c_p, c_p, c_p, c_p, c_p, c_p, c_ll, c_f, c_f, c_f, c_f, c_p],
+    "fsv_amp_update": [c_p, c_p],
+})
+
+
+def amp_adam_step(param, grad, m, v, state, scaler, beta1, beta2, eps, gscale=1.0):
+    """Adam step of the fp16-operand mode (csrc/amp.hip): overflow test of the scaled gradients, the step with
+    grad * gscale / scale (skipped when a gradient is not finite), and apex's scale update - all on the device."""
+    lib.check_device(param, grad, m, v, state, scaler)
+    st = lib.stream_ptr()
+    lib.call("fsv_amp_check", lib.ptr(grad), grad.numel(), lib.ptr(scaler), st)
+    lib.call("fsv_amp_adam", lib.ptr(param), lib.ptr(grad), lib.ptr(m), lib.ptr(v), lib.ptr(state), lib.ptr(scaler),
+             param.numel(), float(beta1), float(beta2), float(eps), float(gscale), st)
+    lib.call("fsv_amp_update", lib.ptr(scaler), st)
+
+
 # ------------------------------------------------------------------------------------------------ losses / packing / masks
 lib.register_sigs({
     "fsv_l1_fwd": [c_p, c_p, c_f, c_p, c_i, c_i, c_ll, c_llp, c_llp, c_p, c_p, c_p],

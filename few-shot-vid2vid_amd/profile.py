@@ -15,6 +15,7 @@ _enabled = False
 _detail = False       # tools/shape_profile.py: append the GEMM shape to every label
 _records = []          # (label, flops, ev0, ev1)
 FP32_MFMA_PEAK = 157.3e12
+F16_MFMA_PEAK = 2.5e15        # dense f16 / bf16 matrix peak (MI355X_MICROARCH.md; the 2:1-sparse figure is not used)
 
 TILE_NAMES = {0: '128x128', 1: '128x64', 2: '128x32', 3: '256x32', 4: '64x64', 9: '64x128'}
 
@@ -83,7 +84,12 @@ def summary():
         lab = max(agg, key=lambda k: agg[k][2])
         n, fl, t = agg[lab]
         ach = fl / t / 1e12
-        dominant = dict(kernel=lab, bound='mfma', achieved=round(ach, 2), peak=FP32_MFMA_PEAK / 1e12, unit='TFLOP/s',
-                        frac=round(ach / (FP32_MFMA_PEAK / 1e12), 4), traffic=None, launches=n,
+        peak = FP32_MFMA_PEAK / 1e12
+        if '[f16]' in lab:
+            peak = F16_MFMA_PEAK / 1e12                 # narrow-operand kernels (csrc/conv_np.hip) against the 16-bit dense peak
+        elif '[bf16x3]' in lab:
+            peak = F16_MFMA_PEAK / 3e12                 # three MFMAs per algorithmic product
+        dominant = dict(kernel=lab, bound='mfma', achieved=round(ach, 2), peak=round(peak, 1), unit='TFLOP/s',
+                        frac=round(ach / peak, 4), traffic=None, launches=n,
                         avg_launch_us=round(t / n * 1e6, 2), gflop_per_launch=round(fl / n / 1e9, 3))
     return dict(dominant=dominant, by_kernel=by_kernel)

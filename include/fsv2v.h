@@ -62,6 +62,35 @@ int fsv_conv_wgrad(const float* in, const float* dout, float* dwt,
                    int ldw, int Kpad, long long w_bstride, int per_sample, int force_split, int prezeroed,
                    int force_tile, fsv_stream_t stream);
 
+/* ---- narrow-operand GEMMs (csrc/conv_np.hip): the reference's `--amp` arithmetic (options/base_options.py:127,
+ * models/models.py:22-26 `amp.initialize(..., opt_level=opt.amp, num_losses=2)`; BASELINE.json configs[4]).  Same
+ * contracts and arguments as fsv_conv_gather_fwd / fsv_conv_wgrad plus `mode`: 1 = operands rounded to IEEE half while a
+ * tile is staged through LDS, 2 = operands split into two bf16 terms (three MFMAs per tile pair); fp32 accumulation,
+ * fp32 tensors in HBM.  Only float4-gather layers (Cin % 4 == 0) are implemented: FSV_ERR_UNSUPPORTED otherwise, callers
+ * keep those on the fp32 entry points.  force_tile of the weight gradient: 1 / 2 / 3 / 4 = 64x64 / 128x64 / 64x128 /
+ * 128x128. */
+int fsv_conv_gather_fwd_np(const float* in, const float* wt, const float* bias, const float* res, float* out,
+                           int N, int H, int W, int Cin, int OH, int OW, int Cout,
+                           int ntaps, const int* ty, const int* tx, int sy, int sx,
+                           int outH, int outW, int osy, int osx, int ooy, int oox,
+                           int ldw, long long w_bstride, long long b_bstride, int per_sample,
+                           int act, float scale, int force_tile, int force_split, int accumulate, const float* wscale,
+                           int mode, fsv_stream_t stream);
+int fsv_conv_wgrad_np(const float* in, const float* dout, float* dwt,
+                      int N, int H, int W, int Cin, int OH, int OW, int Cout,
+                      int ntaps, const int* ty, const int* tx, int sy, int sx,
+                      int ldw, int Kpad, long long w_bstride, int per_sample, int force_split, int prezeroed,
+                      int force_tile, int mode, fsv_stream_t stream);
+
+/* ---- dynamic loss scale of the fp16 mode (csrc/amp.hip) - models/loss_collector.py:221-224 `amp.scale_loss(loss,
+ * optimizer, loss_id)`; apex rule: skip the step and halve on inf / nan, double after `window` good steps.
+ * scaler = {scale, good_steps, found_inf, window, max_scale, min_scale} on the device (no host read: graph-capturable).
+ * fsv_amp_adam is fsv_adam_step with grad * gscale / scale, and does nothing when found_inf is set. */
+int fsv_amp_check(const float* grad, long long n, float* scaler, fsv_stream_t stream);
+int fsv_amp_adam(float* param, const float* grad, float* m, float* v, float* state, float* scaler, long long n,
+                 float beta1, float beta2, float eps, float gscale, fsv_stream_t stream);
+int fsv_amp_update(float* scaler, fsv_stream_t stream);
+
 /* OIHW <-> K-major re-arrangement with an optional device scalar multiplier (the spectral-norm 1/sigma).
  * mode 0: wt[j*Cin+ci][co] = s*w[co][ci][kh_j][kw_j]; mode 1 (data gradient): wt[j*Cout+co][ci] = ...;
  * mode 2: inverse of mode 0 (gradients back to OIHW); mode 3: mode 2 accumulating into w. */

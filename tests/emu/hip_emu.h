@@ -58,6 +58,7 @@ struct WaveSlot {           // rendezvous area for one wave
   int arrived = 0;
   unsigned gen = 0;
   float a[64], b[64];
+  float a8[64][8], b8[64][8];
   float c[64][16];
   float d[64][16];
   double dv[64];
@@ -235,6 +236,37 @@ static inline emu_f32x4 __builtin_amdgcn_mfma_f32_16x16x4f32(float a, float b, e
   emu_f32x4 d;
   for (int r = 0; r < 4; ++r) d[r] = w.d[l][r];
   return d;
+}
+
+// v_mfma_f32_32x32x16_{f16,bf16} (gfx950): A[i=l&31][k=8*(l>>5)+e], B[k=8*(l>>5)+e][j=l&31], e = element 0..7 of the lane's
+// operand vector; C/D as the fp32 32x32 form.  Products of two 16-bit floats are exact in fp32; the hardware's internal
+// summation order over the 16 k is not documented, the emulator adds them in k order in fp32.
+template <class V8>
+static inline emu_f32x16 emu_mfma_32x32x16(V8 a, V8 b, emu_f32x16 c) {
+  emu::WaveSlot& w = emu::my_wave();
+  int l = emu::my_lane();
+  for (int e = 0; e < 8; ++e) { w.a8[l][e] = (float)a[e]; w.b8[l][e] = (float)b[e]; }
+  for (int r = 0; r < 16; ++r) w.c[l][r] = c[r];
+  emu::wave_collective([](emu::WaveSlot& ws) {
+    for (int lane = 0; lane < 64; ++lane)
+      for (int r = 0; r < 16; ++r) {
+        int col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        float acc = ws.c[lane][r];
+        for (int k = 0; k < 16; ++k) acc += ws.a8[row + 32 * (k >> 3)][k & 7] * ws.b8[col + 32 * (k >> 3)][k & 7];
+        ws.d[lane][r] = acc;
+      }
+  });
+  emu_f32x16 d;
+  for (int r = 0; r < 16; ++r) d[r] = w.d[l][r];
+  return d;
+}
+typedef _Float16 emu_f16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 emu_bf16x8 __attribute__((ext_vector_type(8)));
+static inline emu_f32x16 __builtin_amdgcn_mfma_f32_32x32x16_f16(emu_f16x8 a, emu_f16x8 b, emu_f32x16 c, int, int, int) {
+  return emu_mfma_32x32x16(a, b, c);
+}
+static inline emu_f32x16 __builtin_amdgcn_mfma_f32_32x32x16_bf16(emu_bf16x8 a, emu_bf16x8 b, emu_f32x16 c, int, int, int) {
+  return emu_mfma_32x32x16(a, b, c);
 }
 
 template <class T>

@@ -661,3 +661,94 @@ def check_flownet_wrapper(device, size=64, b=2, seed=52):
     f_flow = float(g_losses[M.LOSS_NAMES_G.index('F_Flow')])
     assert f_flow > 0 or float(conf_gt[0].sum()) == 0
     return f_flow
+
+
+def check_amp_step(device, opt_kw, level, b=1, seed=61, loss_tol=2e-2, image_tol=3e-2, grad_l2_tol=0.15):
+    """One training iteration (D step + G step, Adam included) with `--amp level` against the same iteration in exact fp32:
+    the narrow-operand kernels must be the ones running (results differ from fp32) yet stay within the mode's error budget;
+    the fp16 mode must carry a loss scale through `loss_backward` and un-scale inside its step."""
+    M = _model()
+    conv = import_module('few-shot-vid2vid_amd.conv')
+    results = {}
+    try:
+        for lvl in ('O0', level):
+            opt = tiny_opt(amp=lvl, **opt_kw)
+            model = M.create_model(opt)
+            fill_state(model.netG); fill_state(model.netD)
+            model = model.to(device).train()
+            opt_G, opt_D = model.build_optimizers()
+            assert conv.mfma_mode() == M.amp_mode(opt)
+            for o in (opt_G, opt_D):        # apex starts at 2^16 and backs off through skipped steps (covered by
+                if o.scaler is not None:    # check_amp_overflow_skip); start where a step goes through
+                    assert float(o.scaler[0]) == 65536.0
+                    o.scaler[0] = 128.0
+            h, w = int(opt.fineSize / opt.aspect_ratio), opt.fineSize
+            data = synth_pose_inputs(b, h, w, seed, opt.input_nc)
+            tl, ti, rl, ri = [t.to(device) for t in data]
+            data_list = [tl, ti, [None, None], [None, None], rl, ri, None, None, None]
+            p0_G, p0_D = opt_G.flat_p.clone(), opt_D.flat_p.clone()
+            d_losses = M.loss_backward(opt, model(data_list, mode='discriminator'), opt_D, 1)
+            gD = opt_D.flat_g.clone() / (1.0 if opt_D.scaler is None else 128.0)
+            g_losses, generated, _ = model(data_list, save_images=True, mode='generator')
+            g_losses = M.loss_backward(opt, g_losses, opt_G, 0)
+            gG = opt_G.flat_g.clone() / (1.0 if opt_G.scaler is None else 128.0)
+            results[lvl] = dict(d=[float(x.detach()) for x in d_losses], g=[float(x.detach()) for x in g_losses if not isinstance(x, int)],
+                                img=generated[0].detach().clone(), gD=gD, gG=gG,
+                                dG=(opt_G.flat_p - p0_G), dD=(opt_D.flat_p - p0_D), opt_G=opt_G, opt_D=opt_D)
+    finally:
+        conv.set_mfma_mode(0)
+    ref, got = results['O0'], results[level]
+    for o in (got['opt_G'], got['opt_D']):
+        if M.amp_mode(tiny_opt(amp=level)) == conv.MFMA_F16:
+            sc = o.scaler.cpu().tolist()
+            assert sc[:4] == [128.0, 1.0, 0.0, 2000.0], sc          # one good step, no overflow, scale unchanged
+        else:
+            assert o.scaler is None
+        assert float(o.state[0]) == 1.0                               # Adam really stepped
+    assert ref['opt_G'].scaler is None
+    for k in ('d', 'g'):
+        for a, r in zip(got[k], ref[k]):
+            assert abs(a - r) <= loss_tol * max(abs(r), 1e-3), (k, got[k], ref[k])
+    scale = float(ref['img'].norm())
+    err = float((got['img'] - ref['img']).norm())            # relative L2: a few saturated tanh pixels dominate max|diff|
+    print('amp %s: image rel L2 %.3e, grads rel L2 D %.3e G %.3e' % (
+        level, err / scale, float((got['gD'] - ref['gD']).norm() / ref['gD'].norm()),
+        float((got['gG'] - ref['gG']).norm() / ref['gG'].norm())))
+    assert err <= image_tol * scale, (err, scale)
+    assert err > 1e-7 * scale, "the --amp iteration is bit-identical to fp32: the narrow kernels did not run"
+    for k in ('gD', 'gG'):
+        rel = float((got[k] - ref[k]).norm() / ref[k].norm())
+        assert rel <= grad_l2_tol, (k, rel)
+    # Adam with lr > 0 moved (almost) every weight by +-lr in both runs; the directions agree wherever the gradient is
+    # not rounding noise
+    for k in ('dG', 'dD'):
+        assert float(got[k].abs().max()) > 0
+    return got
+
+
+def check_amp_overflow_skip(device, seed=62):
+    """an inf in the (scaled) gradient: the step is skipped (weights, moments and the step counter untouched), the scale is
+    halved and the good-step counter restarts; the next clean step goes through with the new scale"""
+    flat = import_module('few-shot-vid2vid_amd.flat')
+    g = torch.Generator().manual_seed(seed)
+    p = torch.nn.Parameter(torch.randn(1000, generator=g).to(device))
+    o = flat.FlatAdam([p], 1e-2, (0.5, 0.999), loss_scale=(1024.0, 2))
+    ref = torch.optim.Adam([torch.nn.Parameter(p.detach().clone())], 1e-2, (0.5, 0.999))
+    from oracle import np_oracle as NO
+    rs = NO.LossScaler(1024.0, 2)
+    grads = [torch.randn(1000, generator=g) for _ in range(6)]
+    grads[1][17] = float('inf')
+    grads[4][3] = float('nan')
+    for it, gr in enumerate(grads):
+        o.zero_grad()
+        o.flat_g.copy_((gr * rs.scale).to(device))              # what a backward pass of the scaled loss leaves behind
+        o.step()
+        found, un = rs.unscale_and_check([gr * rs.scale])
+        if not rs.update(found):
+            ref.param_groups[0]['params'][0].grad = un[0]
+            ref.step()
+        assert float(o.scaler[0]) == rs.scale and float(o.scaler[1]) == rs.good and float(o.scaler[2]) == 0.0, (it, o.scaler)
+        got, want = o.flat_p.cpu(), ref.param_groups[0]['params'][0].detach()
+        assert float((got - want).abs().max()) <= 1e-6, (it, float((got - want).abs().max()))
+    assert float(o.state[0]) == 4.0                                 # 6 iterations, 2 skipped
+    assert rs.scale == 1024.0 * 0.5 * 2.0 * 0.5                     # halve, double after 2 good steps, halve

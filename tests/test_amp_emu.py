@@ -1,0 +1,31 @@
+"""`--amp` end to end under the SIMT emulator: operand-mode selection from the option string, the loss scale through
+loss_backward and the fused step, overflow handling against apex's rule (oracle/np_oracle.LossScaler)."""
+import pytest
+import torch
+
+import model_checks as mc
+
+DEV = torch.device("cpu")
+
+
+def test_amp_level_parsing(emu_lib):
+    M = mc._model()
+    assert M.amp_mode(mc.tiny_opt()) == 0                   # the reference's default 'O0'
+    assert M.amp_mode(mc.tiny_opt(amp='O1')) == 1
+    assert M.amp_mode(mc.tiny_opt(amp='O2')) == 1
+    assert M.amp_mode(mc.tiny_opt(amp='bf16x3')) == 2
+    with pytest.raises(ValueError):
+        M.amp_mode(mc.tiny_opt(amp='O9'))
+
+
+def test_overflow_skips_step_and_adapts_scale(emu_lib):
+    mc.check_amp_overflow_skip(DEV)
+
+
+def test_train_step_f16_operands_tiny(emu_lib):
+    mc.check_amp_step(DEV, dict(warp_ref=True, spade_combine=True, remove_face_labels=True), 'O1')
+
+
+def test_train_step_bf16x3_operands_tiny(emu_lib):
+    mc.check_amp_step(DEV, dict(warp_ref=True, spade_combine=True, remove_face_labels=True), 'bf16x3',
+                      loss_tol=1e-3, image_tol=1e-3, grad_l2_tol=2e-2)
