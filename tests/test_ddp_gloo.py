@@ -86,3 +86,43 @@ def test_two_rank_whole_buffer_exchange(emu_lib, tmp_path):
     local = _single(0, None) + _single(1, None)
     scale = float(local.abs().max())
     assert float((r0['gD'] - local).abs().max()) <= 1e-5 * scale
+
+
+def _amp_worker(rank, world, port, out_dir):
+    """--amp O1 across two ranks: rank 1's second gradient overflows; the overflow test runs on the all-reduced buffer, so
+    both ranks must skip that step together and come out with identical weights and loss scales"""
+    os.environ['FSV2V_EMU'] = '1'
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    torch.set_num_threads(1)
+    from importlib import import_module
+    import fsv2v_amd  # noqa: F401
+    flat = import_module('few-shot-vid2vid_amd.flat')
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    g = torch.Generator().manual_seed(5)
+    p = torch.nn.Parameter(torch.randn(300, generator=g))
+    o = flat.FlatAdam([p], 1e-2, (0.5, 0.999), world_size=world, overlap=False, loss_scale=(64.0, 2))
+    g = torch.Generator().manual_seed(10 + rank)
+    log = []
+    for it in range(4):
+        gr = torch.randn(300, generator=g)
+        if it == 1 and rank == 1:
+            gr[7] = float('inf')
+        o.zero_grad()
+        o.flat_g.copy_(gr * float(o.scaler[0]))
+        o.step()
+        log.append((float(o.scaler[0]), float(o.scaler[1]), float(o.state[0])))
+    torch.save(dict(p=o.flat_p.clone(), log=log), os.path.join(out_dir, 'amp%d.pt' % rank))
+    dist.destroy_process_group()
+
+
+def test_two_rank_amp_overflow_is_skipped_on_every_rank(emu_lib, tmp_path):
+    world, port = 2, 29617
+    mp.spawn(_amp_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    r0 = torch.load(os.path.join(tmp_path, 'amp0.pt'))
+    r1 = torch.load(os.path.join(tmp_path, 'amp1.pt'))
+    assert torch.equal(r0['p'], r1['p'])
+    assert r0['log'] == r1['log']
+    # (scale, good steps, Adam t): good / overflow -> halve, no step / good / good -> window of 2 reached, double
+    assert r0['log'] == [(64.0, 1.0, 1.0), (32.0, 0.0, 1.0), (32.0, 1.0, 2.0), (64.0, 0.0, 3.0)], r0['log']
