@@ -555,10 +555,19 @@ static int fsv_launch_conv(const ConvP& p, int M_tiles_rows, int nz, hipStream_t
         FSV_LAUNCH((fsv_conv_igemm_kernel<256, 64, 4, 2, 4>), g, dim3(512), stream, p); return fsv_check_launch(); }
       case 9: { dim3 g(fsv_cdiv(M_tiles_rows, 64), fsv_cdiv(p.Cout, 128), nz);
         FSV_LAUNCH((fsv_conv_igemm_kernel<64, 128, 2, 2, 4>), g, block, stream, p); return fsv_check_launch(); }
+      // few-wave workgroups (every wave owns a 64x64 sub-tile: one LDS fragment read per MFMA, and a one-wave workgroup needs
+      // no cross-wave barrier traffic); not yet measured, only reachable through force_tile
+      case 10: { dim3 g(fsv_cdiv(M_tiles_rows, 64), fsv_cdiv(p.Cout, 64), nz);
+        FSV_LAUNCH((fsv_conv_igemm_kernel<64, 64, 1, 1, 4>), g, dim3(64), stream, p); return fsv_check_launch(); }
+      case 11: { dim3 g(fsv_cdiv(M_tiles_rows, 64), fsv_cdiv(p.Cout, 128), nz);
+        FSV_LAUNCH((fsv_conv_igemm_kernel<64, 128, 1, 2, 4>), g, dim3(128), stream, p); return fsv_check_launch(); }
+      case 12: { dim3 g(fsv_cdiv(M_tiles_rows, 128), fsv_cdiv(p.Cout, 64), nz);
+        FSV_LAUNCH((fsv_conv_igemm_kernel<128, 64, 2, 1, 4>), g, dim3(128), stream, p); return fsv_check_launch(); }
       default: break;
     }
   }
-  if (tile == 9) tile = 4;      // scalar-gather layers (Cin % 4 != 0): only the basic tiles are instantiated
+  if (tile == 9 || tile == 10 || tile == 11) tile = 4;      // scalar-gather layers (Cin % 4 != 0): only the basic tiles are instantiated
+  if (tile == 12) tile = 1;
   switch (tile) {
     case 0: { dim3 g(fsv_cdiv(M_tiles_rows, 128), fsv_cdiv(p.Cout, 128), nz);
       FSV_LAUNCH((fsv_conv_igemm_kernel<128, 128, 2, 2, V>), g, block, stream, p); break; }
@@ -576,8 +585,9 @@ static int fsv_launch_conv(const ConvP& p, int M_tiles_rows, int nz, hipStream_t
 }
 
 static inline int fsv_tile_dims(int tile, int& bm, int& bn) {
-  static const int BMs[10] = {128, 128, 128, 256, 64, 256, 128, 256, 256, 64}, BNs[10] = {128, 64, 32, 32, 64, 128, 256, 256, 64, 128};
-  if (tile < 0 || tile > 9) return -1;
+  static const int BMs[13] = {128, 128, 128, 256, 64, 256, 128, 256, 256, 64, 64, 64, 128},
+                   BNs[13] = {128, 64, 32, 32, 64, 128, 256, 256, 64, 128, 64, 128, 64};
+  if (tile < 0 || tile > 12) return -1;
   bm = BMs[tile]; bn = BNs[tile];
   return 0;
 }
@@ -771,6 +781,10 @@ int fsv_conv_wgrad(const float* in, const float* dout, float* dwt,
   if (force_tile == 1 && vec4_ok(Cin) && Cout > 32) { bmk = 64; bn = 64; }
   else if (force_tile == 2 && vec4_ok(Cin) && Cout > 32) { bmk = 128; bn = 64; }
   else if (force_tile == 3 && vec4_ok(Cin) && Cout > 64) { bmk = 64; bn = 128; }
+  // 5 / 6: the 64x64 and 64x128 tiles as one- / two-wave workgroups (every wave owns a 64x64 sub-tile); not yet measured
+  int few_waves = 0;
+  if (force_tile == 5 && vec4_ok(Cin) && Cout > 32) { bmk = 64; bn = 64; few_waves = 1; }
+  else if (force_tile == 6 && vec4_ok(Cin) && Cout > 64) { bmk = 64; bn = 128; few_waves = 1; }
   long long target = fsv_tune(2);
   static int wplan_v = -1;
   if (wplan_v < 0) { const char* e = getenv("FSV_WGRAD_PLAN"); wplan_v = e ? atoi(e) : 1; }
@@ -800,7 +814,9 @@ int fsv_conv_wgrad(const float* in, const float* dout, float* dwt,
   const bool vec4 = (Cin % 4 == 0);
   dim3 g(fsv_cdiv(p.K, bmk), fsv_cdiv(Cout, bn), nsamp * nsplit);
   if (vec4) {
-    if (bn == 128 && bmk == 32) FSV_LAUNCH((fsv_conv_wgrad_kernel<32, 128, 1, 4, 4>), g, block, stream, p);
+    if (few_waves && bn == 64) FSV_LAUNCH((fsv_conv_wgrad_kernel<64, 64, 1, 1, 4>), g, dim3(64), stream, p);
+    else if (few_waves) FSV_LAUNCH((fsv_conv_wgrad_kernel<64, 128, 1, 2, 4>), g, dim3(128), stream, p);
+    else if (bn == 128 && bmk == 32) FSV_LAUNCH((fsv_conv_wgrad_kernel<32, 128, 1, 4, 4>), g, block, stream, p);
     else if (bn == 128 && bmk == 64) FSV_LAUNCH((fsv_conv_wgrad_kernel<64, 128, 2, 2, 4>), g, block, stream, p);
     else if (bn == 64 && bmk == 32) FSV_LAUNCH((fsv_conv_wgrad_kernel<32, 64, 1, 2, 4>), g, dim3(128), stream, p);
     else if (bn == 64 && bmk == 64) FSV_LAUNCH((fsv_conv_wgrad_kernel<64, 64, 2, 2, 4>), g, block, stream, p);

@@ -40,7 +40,8 @@ enum fsv_act { FSV_ACT_NONE = 0, FSV_ACT_LRELU = 1 /* leaky_relu(0.2), architect
  * taps outside the input read as zero.  wt: K-major [Kpad][ldw] from fsv_prep_weight; per_sample != 0 selects one
  * weight matrix (stride w_bstride) and bias (stride b_bstride) per sample n.  accumulate != 0: `out` was zeroed by
  * the caller, results are added (used for the four parity classes of a stride-2 data gradient).
- * force_tile / force_split: -1 / 0 = automatic.  wscale: optional device scalar multiplying the accumulator before
+ * force_tile / force_split: -1 / 0 = automatic (tile ids: 0 128x128, 1 128x64, 2 128x32, 3 256x32, 4 64x64, 5-8 8 / 16-wave
+ * experiments, 9 64x128, 10 / 11 / 12 = 64x64 / 64x128 / 128x64 as one- / two-wave workgroups).  wscale: optional device scalar multiplying the accumulator before
  * the bias (the spectral-norm 1/sigma when wt holds un-normalised weights). */
 int fsv_conv_gather_fwd(const float* in, const float* wt, const float* bias, const float* res, float* out,
                         int N, int H, int W, int Cin, int OH, int OW, int Cout,
@@ -55,7 +56,8 @@ int fsv_conv_gather_fwd(const float* in, const float* wt, const float* bias, con
 int fsv_bias_act(float* x, const float* bias, long long total, int C, int act, fsv_stream_t stream);
 /* dwt[t*Cin+ci][co] = sum_{n,oy,ox} in[n, oy*sy+ty[t], ox*sx+tx[t], ci] * dout[n, oy, ox, co]  (weight gradient)
  * prezeroed: dwt already holds zeros (a slice of the optimiser's per-pass arena), skip the split-K zero-fill;
- * force_tile: 0 = automatic (1 / 2 / 3 = 64x64 / 128x64 / 64x128 rows x columns, for A/B runs) */
+ * force_tile: 0 = automatic (1 / 2 / 3 = 64x64 / 128x64 / 64x128 rows x columns, 5 / 6 = 64x64 / 64x128 as one- / two-wave
+ * workgroups; for A/B runs) */
 int fsv_conv_wgrad(const float* in, const float* dout, float* dwt,
                    int N, int H, int W, int Cin, int OH, int OW, int Cout,
                    int ntaps, const int* ty, const int* tx, int sy, int sx,

@@ -19,12 +19,11 @@ GEOMS = [  # n, cin, h, w, cout, k, stride, pad
 
 
 @pytest.mark.parametrize("geom", GEOMS)
-@pytest.mark.parametrize("tile,split", [(0, 1), (0, 3), (1, 1), (1, 2), (2, 1), (4, 1), (4, 2), (9, 1), (9, 2)])
+@pytest.mark.parametrize("tile,split", [(0, 1), (0, 3), (1, 1), (1, 2), (2, 1), (4, 1), (4, 2), (9, 1), (9, 2),
+                                        (10, 1), (10, 2), (11, 1), (11, 3), (12, 1), (12, 2)])
 def test_forward_tiles(emu_lib, geom, tile, split):
     ops, conv = oc.pkg()
     n, cin, h, w, cout, k, s, p = geom
-    if tile == 9 and cin % 4 != 0:
-        pytest.skip("64x128 is instantiated for the float4 gather only (the launcher falls back to 64x64)")
     g = torch.Generator().manual_seed(1000 + tile * 10 + split)
     x = torch.randn(n, cin, h, w, generator=g)
     wt = torch.randn(cout, cin, k, k, generator=g) * 0.2
@@ -39,7 +38,7 @@ def test_forward_tiles(emu_lib, geom, tile, split):
 
 
 @pytest.mark.parametrize("geom", GEOMS[:4])
-@pytest.mark.parametrize("tile,split", [(0, 0), (1, 1), (1, 3), (2, 2), (3, 1), (3, 2)])
+@pytest.mark.parametrize("tile,split", [(0, 0), (1, 1), (1, 3), (2, 2), (3, 1), (3, 2), (5, 1), (5, 3), (6, 1), (6, 2)])
 def test_wgrad_tiles(emu_lib, geom, tile, split):
     ops, conv = oc.pkg()
     n, cin, h, w, cout, k, s, p = geom
