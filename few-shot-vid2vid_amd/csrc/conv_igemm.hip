@@ -14,35 +14,7 @@
 // A-fragment read (32 consecutive m per half-wave) and the staging writes are both bank-conflict free.
 // The MFMA result is bitwise an fp32 fma chain (guide section 3), which is what lets the parity tests use a
 // 1e-3 relative tolerance against the fp32 CPU oracle with a wide margin.
-#include "fsv_common.h"
-
-#define FSV_BK 32
-
-struct ConvP {
-  const float* in;
-  const float* wt;
-  const float* bias;
-  const float* res;
-  const float* wscale;     // optional device scalar multiplying the accumulator (spectral-norm 1/sigma), or null
-  float* out;
-  int N, H, W, Cin;        // input tensor NHWC
-  int OH, OW, Cout;        // iteration grid and number of output channels
-  int K, nchunks, ldw;     // K = ntaps*Cin; nchunks = ceil(K/32); ldw = weight row stride
-  int sy, sx, ntaps;
-  unsigned long long taps_lo, taps_hi;   // (ty+8) | (tx+8)<<4 per tap, 8 taps per word
-  int outH, outW, osy, osx, ooy, oox, dense_out;
-  long long w_bstride, b_bstride;        // per-sample weight / bias strides (0: shared)
-  int per_sample, nsplit;                // blockIdx.z = sample*nsplit + ksplit
-  int act; float scale;
-  int Mz;                                // rows (pixels) per z group
-};
-
-__device__ __forceinline__ void fsv_tap(const ConvP& p, int t, int& ty, int& tx) {
-  unsigned long long code = (t < 8) ? p.taps_lo : p.taps_hi;
-  int sh = (t & 7) * 8;
-  ty = (int)((code >> sh) & 15ull) - 8;
-  tx = (int)((code >> (sh + 4)) & 15ull) - 8;
-}
+#include "conv_igemm.h"
 
 template <int BM, int BN, int WM, int WN, int V>
 __global__ __launch_bounds__(64 * WM * WN) void fsv_conv_igemm_kernel(ConvP p) {
@@ -563,11 +535,12 @@ static int fsv_launch_conv(const ConvP& p, int M_tiles_rows, int nz, hipStream_t
         FSV_LAUNCH((fsv_conv_igemm_kernel<64, 128, 1, 2, 4>), g, dim3(128), stream, p); return fsv_check_launch(); }
       case 12: { dim3 g(fsv_cdiv(M_tiles_rows, 128), fsv_cdiv(p.Cout, 64), nz);
         FSV_LAUNCH((fsv_conv_igemm_kernel<128, 64, 2, 1, 4>), g, dim3(128), stream, p); return fsv_check_launch(); }
+      case 13: case 14: case 15: return fsv_launch_conv_db(p, nz, stream, tile);      // double-buffered LDS (conv_igemm_db.hip)
       default: break;
     }
   }
-  if (tile == 9 || tile == 10 || tile == 11) tile = 4;      // scalar-gather layers (Cin % 4 != 0): only the basic tiles are instantiated
-  if (tile == 12) tile = 1;
+  if (tile == 9 || tile == 10 || tile == 11 || tile == 13 || tile == 14) tile = 4;      // scalar-gather layers (Cin % 4 != 0): only the basic tiles are instantiated
+  if (tile == 12 || tile == 15) tile = 1;
   switch (tile) {
     case 0: { dim3 g(fsv_cdiv(M_tiles_rows, 128), fsv_cdiv(p.Cout, 128), nz);
       FSV_LAUNCH((fsv_conv_igemm_kernel<128, 128, 2, 2, V>), g, block, stream, p); break; }
@@ -585,9 +558,9 @@ static int fsv_launch_conv(const ConvP& p, int M_tiles_rows, int nz, hipStream_t
 }
 
 static inline int fsv_tile_dims(int tile, int& bm, int& bn) {
-  static const int BMs[13] = {128, 128, 128, 256, 64, 256, 128, 256, 256, 64, 64, 64, 128},
-                   BNs[13] = {128, 64, 32, 32, 64, 128, 256, 256, 64, 128, 64, 128, 64};
-  if (tile < 0 || tile > 12) return -1;
+  static const int BMs[16] = {128, 128, 128, 256, 64, 256, 128, 256, 256, 64, 64, 64, 128, 64, 64, 128},
+                   BNs[16] = {128, 64, 32, 32, 64, 128, 256, 256, 64, 128, 64, 128, 64, 64, 128, 64};
+  if (tile < 0 || tile > 15) return -1;
   bm = BMs[tile]; bn = BNs[tile];
   return 0;
 }

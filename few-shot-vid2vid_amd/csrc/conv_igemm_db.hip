@@ -1,0 +1,202 @@
+// Double-buffered variant of the fp32 implicit-GEMM kernel (conv_igemm.hip): two LDS images of the A / B tiles, so a K chunk
+// costs ONE workgroup barrier instead of two - while the waves run the MFMAs of chunk c out of image c&1, the staging registers
+// (filled by the global loads issued at the top of the iteration) are written into the other image, which every wave stopped
+// reading at the previous barrier.  Same operands, same order of the fma chain per output element, same epilogue: results are
+// bitwise those of fsv_conv_igemm_kernel.  LDS: 2 x (32 x (BM+1) + 32 x BN) floats = 33 KB (64x64) / 49 KB (64x128, 128x64),
+// i.e. 3-4 workgroups per CU; the 128x128 tile would need 66 KB (more than a static allocation allows) and is not offered.
+//
+// Experimental: reachable only through force_tile (ids 13 / 14 / 15) until an A/B on the hardware says where it pays
+// (tools/tile_ab.py).  float4-gather layers only (Cin % 4 == 0).
+#include "conv_igemm.h"
+
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(64 * WM * WN) void fsv_conv_igemm_db_kernel(ConvP p) {
+  constexpr int BK = FSV_BK;
+  constexpr int NT = 64 * WM * WN;
+  constexpr int TM = BM / (WM * 32), TN = BN / (WN * 32);
+  constexpr int LDA = BM + 1;
+  constexpr int KV = BK / 4;
+  constexpr int RPP = NT / KV;
+  constexpr int NPA = BM / RPP;
+  constexpr int QB = BN / 4;
+  constexpr int RPB = NT / QB;
+  constexpr int NPB = BK / RPB;
+  constexpr int ASZ = BK * LDA, BSZ = BK * BN;
+  static_assert(NPA >= 1 && NPB >= 1 && NPA * RPP == BM && NPB * RPB == BK, "tile / thread-count mismatch");
+  static_assert(2 * (ASZ + BSZ) * 4 <= 65536, "two LDS images must fit a static allocation");
+  __shared__ float As[2 * ASZ];
+  __shared__ float Bs[2 * BSZ];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int zs = blockIdx.z / p.nsplit, zk = blockIdx.z % p.nsplit;
+  const int bm0 = blockIdx.x * BM, bn0 = blockIdx.y * BN;
+  const float* wt = p.wt + (long long)zs * p.w_bstride;
+
+  const int kq = tid % KV, ar0 = tid / KV;
+  int a_iy0[NPA], a_ix0[NPA];
+  long long a_base[NPA];
+  const int ohw = p.OH * p.OW;
+#pragma unroll
+  for (int i = 0; i < NPA; ++i) {
+    int m = bm0 + ar0 + i * RPP;
+    if (m < p.Mz) {
+      int n, rem;
+      if (p.per_sample) { n = zs; rem = m; } else { n = m / ohw; rem = m - n * ohw; }
+      int oy = rem / p.OW, ox = rem - oy * p.OW;
+      a_iy0[i] = oy * p.sy; a_ix0[i] = ox * p.sx;
+      a_base[i] = (long long)n * p.H * p.W;
+    } else {
+      a_iy0[i] = -(1 << 28); a_ix0[i] = 0; a_base[i] = 0;
+    }
+  }
+  const int bq = tid % QB, br0 = tid / QB;
+  const int bcol = bn0 + bq * 4;
+  const bool bcol_ok = bcol < p.ldw;
+  const int bcol_safe = bcol_ok ? bcol : 0;
+
+  const int cps = (p.nchunks + p.nsplit - 1) / p.nsplit;
+  const int c_begin = zk * cps;
+  const int c_end = (c_begin + cps < p.nchunks) ? (c_begin + cps) : p.nchunks;
+
+  float areg[NPA][4];
+  float4 breg[NPB];
+
+  auto load_chunk = [&](int kc) {
+    const int k = kc * BK + kq * 4;
+    const bool kok = k < p.K;
+    int t = kok ? (k / p.Cin) : 0;
+    int ci = kok ? (k - t * p.Cin) : 0;
+    int ty, tx;
+    fsv_tap(p, t, ty, tx);
+#pragma unroll
+    for (int i = 0; i < NPA; ++i) {
+      int iy = a_iy0[i] + ty, ix = a_ix0[i] + tx;
+      bool ok = kok && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+      long long off = ok ? ((a_base[i] + (long long)iy * p.W + ix) * p.Cin + ci) : 0ll;
+      float4 v = *reinterpret_cast<const float4*>(p.in + off);
+      areg[i][0] = ok ? v.x : 0.f; areg[i][1] = ok ? v.y : 0.f; areg[i][2] = ok ? v.z : 0.f; areg[i][3] = ok ? v.w : 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < NPB; ++i) {
+      int kr = kc * BK + br0 + i * RPB;
+      float4 v = *reinterpret_cast<const float4*>(wt + (long long)kr * p.ldw + bcol_safe);
+      breg[i] = bcol_ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  };
+  auto store_chunk = [&](int buf) {
+    float* as = As + buf * ASZ;
+    float* bs = Bs + buf * BSZ;
+#pragma unroll
+    for (int i = 0; i < NPA; ++i) {
+      int r = ar0 + i * RPP;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) as[(kq * 4 + j) * LDA + r] = areg[i][j];
+    }
+#pragma unroll
+    for (int i = 0; i < NPB; ++i) {
+      int kr = br0 + i * RPB;
+      *reinterpret_cast<float4*>(&bs[kr * BN + bq * 4]) = breg[i];
+    }
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int lrow = lane & 31, lk = lane >> 5;
+  const int a_off = lk * LDA + wm * (TM * 32) + lrow;
+  const int b_off = lk * BN + wn * (TN * 32) + lrow;
+  if (c_begin < c_end) {
+    load_chunk(c_begin);
+    store_chunk(0);
+    __syncthreads();
+#pragma unroll 1
+    for (int kc = c_begin; kc < c_end; ++kc) {
+      const int cur = (kc - c_begin) & 1;
+      const bool more = kc + 1 < c_end;
+      // the last iteration re-reads its own chunk (no per-lane branch around the loads); that copy is never stored
+      load_chunk(more ? kc + 1 : kc);
+      const float* a_frag = As + cur * ASZ + a_off;
+      const float* b_frag = Bs + cur * BSZ + b_off;
+      float a[2][TM], b[2][TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) a[0][i] = a_frag[i * 32];
+#pragma unroll
+      for (int j = 0; j < TN; ++j) b[0][j] = b_frag[j * 32];
+#pragma unroll
+      for (int kk = 0; kk < BK / 2; ++kk) {
+        const int c = kk & 1, nx = c ^ 1;
+        if (kk + 1 < BK / 2) {
+#pragma unroll
+          for (int i = 0; i < TM; ++i) a[nx][i] = a_frag[(kk + 1) * 2 * LDA + i * 32];
+#pragma unroll
+          for (int j = 0; j < TN; ++j) b[nx][j] = b_frag[(kk + 1) * 2 * BN + j * 32];
+        }
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[c][i], b[c][j], acc[i][j], 0, 0, 0);
+      }
+      if (more) store_chunk(cur ^ 1);       // uniform over the workgroup
+      __syncthreads();
+    }
+  }
+
+  const float* bias = p.bias ? (p.bias + (long long)zs * p.b_bstride) : nullptr;
+  const float ws = p.wscale ? p.wscale[0] : 1.f;
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int co = bn0 + wn * (TN * 32) + j * 32 + lrow;
+    if (co >= p.Cout) continue;
+    const float bv = (bias && p.nsplit == 1) ? bias[co] : 0.f;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * lk;
+        const int m = bm0 + wm * (TM * 32) + i * 32 + row;
+        if (m >= p.Mz) continue;
+        long long opix;
+        if (p.dense_out) {
+          opix = (long long)zs * (p.per_sample ? p.Mz : 0) + m;
+        } else {
+          int n, rem;
+          if (p.per_sample) { n = zs; rem = m; } else { n = m / ohw; rem = m - n * ohw; }
+          int oy = rem / p.OW, ox = rem - oy * p.OW;
+          opix = ((long long)n * p.outH + (oy * p.osy + p.ooy)) * p.outW + (ox * p.osx + p.oox);
+        }
+        float* dst = p.out + opix * p.Cout + co;
+        float v = acc[i][j][r] * ws;
+        if (p.nsplit > 1) {
+          atomicAdd(dst, v);
+        } else {
+          v = (v + bv) * p.scale;
+          v = fsv_act(v, p.act);
+          if (p.res) v += p.res[opix * p.Cout + co];
+          *dst = v;
+        }
+      }
+    }
+  }
+}
+
+int fsv_launch_conv_db(const ConvP& p, int nz, hipStream_t stream, int tile) {
+  dim3 block(256);
+  switch (tile) {
+    case 13: { dim3 g(fsv_cdiv(p.Mz, 64), fsv_cdiv(p.Cout, 64), nz);
+      FSV_LAUNCH((fsv_conv_igemm_db_kernel<64, 64, 2, 2>), g, block, stream, p); break; }
+    case 14: { dim3 g(fsv_cdiv(p.Mz, 64), fsv_cdiv(p.Cout, 128), nz);
+      FSV_LAUNCH((fsv_conv_igemm_db_kernel<64, 128, 2, 2>), g, block, stream, p); break; }
+    case 15: { dim3 g(fsv_cdiv(p.Mz, 128), fsv_cdiv(p.Cout, 64), nz);
+      FSV_LAUNCH((fsv_conv_igemm_db_kernel<128, 64, 2, 2>), g, block, stream, p); break; }
+    default: return FSV_ERR_BAD_ARG;
+  }
+  return fsv_check_launch();
+}

@@ -20,7 +20,7 @@ GEOMS = [  # n, cin, h, w, cout, k, stride, pad
 
 @pytest.mark.parametrize("geom", GEOMS)
 @pytest.mark.parametrize("tile,split", [(0, 1), (0, 3), (1, 1), (1, 2), (2, 1), (4, 1), (4, 2), (9, 1), (9, 2),
-                                        (10, 1), (10, 2), (11, 1), (11, 3), (12, 1), (12, 2)])
+                                        (10, 1), (10, 2), (11, 1), (11, 3), (12, 1), (12, 2), (13, 1), (13, 2), (14, 1), (14, 3), (15, 1), (15, 2)])
 def test_forward_tiles(emu_lib, geom, tile, split):
     ops, conv = oc.pkg()
     n, cin, h, w, cout, k, s, p = geom
@@ -51,3 +51,19 @@ def test_wgrad_tiles(emu_lib, geom, tile, split):
     geo = conv.Geom(k, k, s, p)
     dw = conv.conv_wgrad(conv.to_nhwc(x), conv.to_nhwc(dy), geo, (cout, cin, k, k), force_tile=tile, force_split=split)
     oc.assert_close('wgrad tile %d split %d' % (tile, split), dw, wt.grad, 1e-4)
+
+
+def test_all_tiles_are_bitwise_identical_without_split(emu_lib):
+    """every tile template walks K in the same order (chunk by chunk, two k per MFMA, one fma chain per output element), so
+    without split-K the choice of tile - including the few-wave and double-buffered variants - cannot change a single bit"""
+    ops, conv = oc.pkg()
+    g = torch.Generator().manual_seed(77)
+    x = torch.randn(2, 24, 9, 11, generator=g)
+    wt = torch.randn(136, 24, 3, 3, generator=g) * 0.2
+    b = torch.randn(136, generator=g)
+    geo = conv.Geom(3, 3, 1, 1)
+    wf, _, ldw = conv.prep_weight(wt, 0, geo)
+    outs = [conv.conv_forward(conv.to_nhwc(x), wf, ldw, 136, geo, bias=b, act=conv.ACT_LRELU, force_tile=t, force_split=1)
+            for t in (0, 1, 2, 4, 9, 10, 11, 12, 13, 14, 15)]
+    for o in outs[1:]:
+        assert torch.equal(o, outs[0])
