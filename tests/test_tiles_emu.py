@@ -53,17 +53,15 @@ def test_wgrad_tiles(emu_lib, geom, tile, split):
     oc.assert_close('wgrad tile %d split %d' % (tile, split), dw, wt.grad, 1e-4)
 
 
+
 def test_all_tiles_are_bitwise_identical_without_split(emu_lib):
     """every tile template walks K in the same order (chunk by chunk, two k per MFMA, one fma chain per output element), so
     without split-K the choice of tile - including the few-wave and double-buffered variants - cannot change a single bit"""
-    ops, conv = oc.pkg()
-    g = torch.Generator().manual_seed(77)
-    x = torch.randn(2, 24, 9, 11, generator=g)
-    wt = torch.randn(136, 24, 3, 3, generator=g) * 0.2
-    b = torch.randn(136, generator=g)
-    geo = conv.Geom(3, 3, 1, 1)
-    wf, _, ldw = conv.prep_weight(wt, 0, geo)
-    outs = [conv.conv_forward(conv.to_nhwc(x), wf, ldw, 136, geo, bias=b, act=conv.ACT_LRELU, force_tile=t, force_split=1)
-            for t in (0, 1, 2, 4, 9, 10, 11, 12, 13, 14, 15)]
-    for o in outs[1:]:
-        assert torch.equal(o, outs[0])
+    import tile_checks as tc
+    tc.check_bitwise_tiles(DEV)
+
+
+def test_experimental_tiles_with_split(emu_lib):
+    import tile_checks as tc
+    tc.check_split_tiles(DEV)
+    tc.check_wgrad_few_wave(DEV)

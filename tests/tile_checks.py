@@ -1,0 +1,65 @@
+"""Forced-tile checks of the fp32 convolution kernels shared by the emulator test (test_tiles_emu.py) and - run as a script -
+the first hardware run of the experimental tile variants (few-wave workgroups 10-12, double-buffered LDS 13-15, weight-gradient
+5 / 6), which were added after the round-1 GPU budget was spent."""
+import torch
+import torch.nn.functional as F
+
+import op_checks as oc
+
+FWD_TILES = (0, 1, 2, 4, 9, 10, 11, 12, 13, 14, 15)
+
+
+def check_bitwise_tiles(device, shape=(2, 24, 9, 11, 136, 3), seed=77):
+    """without split-K every tile walks K in the same order: identical bits, and equal to torch within fp32 rounding"""
+    ops, conv = oc.pkg()
+    n, cin, h, w, cout, k = shape
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(n, cin, h, w, generator=g)
+    wt = torch.randn(cout, cin, k, k, generator=g) * 0.2
+    b = torch.randn(cout, generator=g)
+    geo = conv.Geom(k, k, 1, k // 2)
+    wf, _, ldw = conv.prep_weight(wt.to(device), 0, geo)
+    outs = [conv.conv_forward(conv.to_nhwc(x.to(device)), wf, ldw, cout, geo, bias=b.to(device), act=conv.ACT_LRELU,
+                              force_tile=t, force_split=1) for t in FWD_TILES]
+    oc.assert_close('tile 0 vs torch', outs[0], F.leaky_relu(F.conv2d(x, wt, b, padding=k // 2), 0.2), 1e-4)
+    for t, o in zip(FWD_TILES[1:], outs[1:]):
+        assert torch.equal(o, outs[0]), 'tile %d differs from tile 0' % t
+
+
+def check_split_tiles(device, seed=78):
+    ops, conv = oc.pkg()
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(2, 64, 16, 16, generator=g)
+    wt = torch.randn(192, 64, 3, 3, generator=g) * 0.1
+    ref = F.conv2d(x, wt, padding=1)
+    geo = conv.Geom(3, 3, 1, 1)
+    wf, _, ldw = conv.prep_weight(wt.to(device), 0, geo)
+    for t in (10, 11, 12, 13, 14, 15):
+        for sp in (2, 3):
+            y = conv.conv_forward(conv.to_nhwc(x.to(device)), wf, ldw, 192, geo, force_tile=t, force_split=sp)
+            oc.assert_close('tile %d split %d' % (t, sp), y, ref, 1e-4)
+
+
+def check_wgrad_few_wave(device, seed=79):
+    ops, conv = oc.pkg()
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(2, 64, 16, 16, generator=g)
+    wt = (torch.randn(192, 64, 3, 3, generator=g) * 0.1).requires_grad_(True)
+    y = F.conv2d(x, wt, padding=1)
+    dy = torch.randn(y.shape, generator=g)
+    y.backward(dy)
+    geo = conv.Geom(3, 3, 1, 1)
+    for t in (5, 6):
+        for sp in (1, 4):
+            dw = conv.conv_wgrad(conv.to_nhwc(x.to(device)), conv.to_nhwc(dy.to(device)), geo, (192, 64, 3, 3), force_tile=t,
+                                 force_split=sp)
+            oc.assert_close('wgrad tile %d split %d' % (t, sp), dw, wt.grad, 1e-4)
+
+
+if __name__ == '__main__':
+    dev = torch.device('cuda', 0)
+    check_bitwise_tiles(dev)
+    check_bitwise_tiles(dev, shape=(2, 128, 32, 32, 256, 3), seed=80)
+    check_split_tiles(dev)
+    check_wgrad_few_wave(dev)
+    print('TILES_GPU_OK', flush=True)
