@@ -30,5 +30,21 @@ __device__ __forceinline__ void fsv_tap(const ConvP& p, int t, int& ty, int& tx)
   tx = (int)((code >> (sh + 4)) & 15ull) - 8;
 }
 
+struct WgradP {
+  const float* in;
+  const float* dout;
+  float* dwt;              // [K_pad][ldw] per z-sample
+  int N, H, W, Cin;
+  int OH, OW, Cout;
+  int K, ldw;
+  int sy, sx, ntaps;
+  unsigned long long taps_lo, taps_hi;
+  long long w_bstride;
+  int per_sample, nsplit;
+  int Mz;                  // pixels per z group
+  int pchunks;             // ceil(Mz/32)
+};
+
 // double-buffered variants (conv_igemm_db.hip); tile ids 13 / 14 / 15 = 64x64 / 64x128 / 128x64
 int fsv_launch_conv_db(const ConvP& p, int nz, hipStream_t stream, int tile);
+int fsv_launch_wgrad_db(const WgradP& p, int bmk, int bn, dim3 grid, hipStream_t stream);      // 64x64 / 64x128, force_tile 7 / 8

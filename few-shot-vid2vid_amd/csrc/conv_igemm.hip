@@ -221,21 +221,6 @@ __global__ __launch_bounds__(256) void fsv_bias_act_kernel(float* out, const flo
 }
 
 // ---- weight gradient: dwt[z][t*Cin+ci][co] (+)= sum_pixels in[n, oy*sy+ty, ox*sx+tx, ci] * dout[n,oy,ox,co] ----
-struct WgradP {
-  const float* in;
-  const float* dout;
-  float* dwt;              // [K_pad][ldw] per z-sample
-  int N, H, W, Cin;
-  int OH, OW, Cout;
-  int K, ldw;
-  int sy, sx, ntaps;
-  unsigned long long taps_lo, taps_hi;
-  long long w_bstride;
-  int per_sample, nsplit;
-  int Mz;                  // pixels per z group
-  int pchunks;             // ceil(Mz/32)
-};
-
 template <int BMK, int BN, int WM, int WN, int V>
 __global__ __launch_bounds__(64 * WM * WN) void fsv_conv_wgrad_kernel(WgradP p) {
   constexpr int BK = FSV_BK;   // pixels per chunk
@@ -758,6 +743,10 @@ int fsv_conv_wgrad(const float* in, const float* dout, float* dwt,
   int few_waves = 0;
   if (force_tile == 5 && vec4_ok(Cin) && Cout > 32) { bmk = 64; bn = 64; few_waves = 1; }
   else if (force_tile == 6 && vec4_ok(Cin) && Cout > 64) { bmk = 64; bn = 128; few_waves = 1; }
+  // 7 / 8: 64x64 / 64x128 with double-buffered LDS (conv_igemm_db.hip); not yet measured
+  int dbuf = 0;
+  if (force_tile == 7 && vec4_ok(Cin) && Cout > 32) { bmk = 64; bn = 64; dbuf = 1; }
+  else if (force_tile == 8 && vec4_ok(Cin) && Cout > 64) { bmk = 64; bn = 128; dbuf = 1; }
   long long target = fsv_tune(2);
   static int wplan_v = -1;
   if (wplan_v < 0) { const char* e = getenv("FSV_WGRAD_PLAN"); wplan_v = e ? atoi(e) : 1; }
@@ -786,6 +775,7 @@ int fsv_conv_wgrad(const float* in, const float* dout, float* dwt,
   dim3 block(256);
   const bool vec4 = (Cin % 4 == 0);
   dim3 g(fsv_cdiv(p.K, bmk), fsv_cdiv(Cout, bn), nsamp * nsplit);
+  if (vec4 && dbuf) return fsv_launch_wgrad_db(p, bmk, bn, g, stream);
   if (vec4) {
     if (few_waves && bn == 64) FSV_LAUNCH((fsv_conv_wgrad_kernel<64, 64, 1, 1, 4>), g, dim3(64), stream, p);
     else if (few_waves) FSV_LAUNCH((fsv_conv_wgrad_kernel<64, 128, 1, 2, 4>), g, dim3(128), stream, p);

@@ -200,3 +200,167 @@ int fsv_launch_conv_db(const ConvP& p, int nz, hipStream_t stream, int tile) {
   }
   return fsv_check_launch();
 }
+
+// ---- weight gradient, double-buffered: same restructuring of fsv_conv_wgrad_kernel (one barrier per 32-pixel chunk) ---------
+template <int BMK, int BN, int WM, int WN>
+__global__ __launch_bounds__(64 * WM * WN) void fsv_conv_wgrad_db_kernel(WgradP p) {
+  constexpr int BK = FSV_BK;   // pixels per chunk
+  constexpr int NT = 64 * WM * WN;
+  constexpr int TM = BMK / (WM * 32), TN = BN / (WN * 32);
+  constexpr int QA = BMK / 4, RPA = NT / QA, NPA = BK / RPA;
+  constexpr int QB = BN / 4, RPB = NT / QB, NPB = BK / RPB;
+  constexpr int ASZ = BK * BMK, BSZ = BK * BN;
+  static_assert(TM >= 1 && TN >= 1, "tile");
+  static_assert(NPA >= 1 && NPB >= 1 && RPA >= 1 && NPA * RPA == BK && NPB * RPB == BK, "tile / thread-count mismatch");
+  __shared__ float As[2 * ASZ];
+  __shared__ float Bs[2 * BSZ];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int zs = blockIdx.z / p.nsplit, zk = blockIdx.z % p.nsplit;
+  const int bi0 = blockIdx.x * BMK, bn0 = blockIdx.y * BN;
+  float* dwt = p.dwt + (long long)zs * p.w_bstride;
+  const int ohw = p.OH * p.OW;
+
+  const int aq = tid % QA, apr0 = tid / QA;
+  const int kcol = bi0 + aq * 4;
+  const bool kok = kcol < p.K;
+  int t = kok ? kcol / p.Cin : 0;
+  const int ci = kcol - t * p.Cin;
+  int ty, tx;
+  {
+    unsigned long long code = (t < 8) ? p.taps_lo : p.taps_hi;
+    int sh = (t & 7) * 8;
+    ty = (int)((code >> sh) & 15ull) - 8;
+    tx = (int)((code >> (sh + 4)) & 15ull) - 8;
+  }
+  const int bq = tid % QB, bpr0 = tid / QB;
+  const int bcol = bn0 + bq * 4;
+
+  const int cps = (p.pchunks + p.nsplit - 1) / p.nsplit;
+  const int c_begin = zk * cps;
+  const int c_end = (c_begin + cps < p.pchunks) ? (c_begin + cps) : p.pchunks;
+
+  float areg[NPA][4];
+  float4 breg[NPB];
+  const bool cout4 = (p.Cout & 3) == 0;
+  auto load_chunk = [&](int pc) {
+#pragma unroll
+    for (int i = 0; i < NPA; ++i) {
+      int m = pc * BK + apr0 + i * RPA;
+      bool ok = kok && m < p.Mz;
+      int mm = ok ? m : 0;
+      int n, rem;
+      if (p.per_sample) { n = zs; rem = mm; } else { n = mm / ohw; rem = mm - n * ohw; }
+      int oy = rem / p.OW, ox = rem - oy * p.OW;
+      int iy = oy * p.sy + ty, ix = ox * p.sx + tx;
+      ok = ok && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+      long long off = ok ? ((((long long)n * p.H + iy) * p.W + ix) * p.Cin + ci) : 0ll;
+      float4 v = *reinterpret_cast<const float4*>(p.in + off);
+      areg[i][0] = ok ? v.x : 0.f; areg[i][1] = ok ? v.y : 0.f; areg[i][2] = ok ? v.z : 0.f; areg[i][3] = ok ? v.w : 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < NPB; ++i) {
+      int m = pc * BK + bpr0 + i * RPB;
+      bool rok = m < p.Mz;
+      long long pix = (long long)zs * (p.per_sample ? p.Mz : 0) + (rok ? m : 0);
+      if (cout4) {
+        bool ok = rok && bcol < p.Cout;
+        const float* src = p.dout + (ok ? (pix * p.Cout + bcol) : 0ll);
+        float4 v = *reinterpret_cast<const float4*>(src);
+        breg[i] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+      } else {
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        const float* src = p.dout + pix * p.Cout;
+        bool o0 = rok && bcol + 0 < p.Cout, o1 = rok && bcol + 1 < p.Cout, o2 = rok && bcol + 2 < p.Cout, o3 = rok && bcol + 3 < p.Cout;
+        float t0 = src[o0 ? bcol + 0 : 0], t1 = src[o1 ? bcol + 1 : 0], t2 = src[o2 ? bcol + 2 : 0], t3 = src[o3 ? bcol + 3 : 0];
+        v.x = o0 ? t0 : 0.f; v.y = o1 ? t1 : 0.f; v.z = o2 ? t2 : 0.f; v.w = o3 ? t3 : 0.f;
+        breg[i] = v;
+      }
+    }
+  };
+  auto store_chunk = [&](int buf) {
+    float* as = As + buf * ASZ;
+    float* bs = Bs + buf * BSZ;
+#pragma unroll
+    for (int i = 0; i < NPA; ++i) {
+      int pr = apr0 + i * RPA;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) as[pr * BMK + aq * 4 + j] = areg[i][j];
+    }
+#pragma unroll
+    for (int i = 0; i < NPB; ++i) {
+      int pr = bpr0 + i * RPB;
+      *reinterpret_cast<float4*>(&bs[pr * BN + bq * 4]) = breg[i];
+    }
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int lrow = lane & 31, lk = lane >> 5;
+  const int a_off = lk * BMK + wm * (TM * 32) + lrow;
+  const int b_off = lk * BN + wn * (TN * 32) + lrow;
+  if (c_begin < c_end) {
+    load_chunk(c_begin);
+    store_chunk(0);
+    __syncthreads();
+#pragma unroll 1
+    for (int pc = c_begin; pc < c_end; ++pc) {
+      const int cur = (pc - c_begin) & 1;
+      const bool more = pc + 1 < c_end;
+      load_chunk(more ? pc + 1 : pc);
+      const float* a_frag = As + cur * ASZ + a_off;
+      const float* b_frag = Bs + cur * BSZ + b_off;
+      float a[2][TM], b[2][TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) a[0][i] = a_frag[i * 32];
+#pragma unroll
+      for (int j = 0; j < TN; ++j) b[0][j] = b_frag[j * 32];
+#pragma unroll
+      for (int kk = 0; kk < BK / 2; ++kk) {
+        const int c = kk & 1, nx = c ^ 1;
+        if (kk + 1 < BK / 2) {
+#pragma unroll
+          for (int i = 0; i < TM; ++i) a[nx][i] = a_frag[(kk + 1) * 2 * BMK + i * 32];
+#pragma unroll
+          for (int j = 0; j < TN; ++j) b[nx][j] = b_frag[(kk + 1) * 2 * BN + j * 32];
+        }
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[c][i], b[c][j], acc[i][j], 0, 0, 0);
+      }
+      if (more) store_chunk(cur ^ 1);
+      __syncthreads();
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int co = bn0 + wn * (TN * 32) + j * 32 + lrow;
+    if (co >= p.Cout) continue;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * lk;
+        const int k = bi0 + wm * (TM * 32) + i * 32 + row;
+        if (k >= p.K) continue;
+        float* dst = dwt + (long long)k * p.ldw + co;
+        if (p.nsplit > 1) atomicAdd(dst, acc[i][j][r]); else *dst = acc[i][j][r];
+      }
+  }
+}
+
+int fsv_launch_wgrad_db(const WgradP& p, int bmk, int bn, dim3 grid, hipStream_t stream) {
+  dim3 block(256);
+  if (bmk == 64 && bn == 64) FSV_LAUNCH((fsv_conv_wgrad_db_kernel<64, 64, 2, 2>), grid, block, stream, p);
+  else if (bmk == 64 && bn == 128) FSV_LAUNCH((fsv_conv_wgrad_db_kernel<64, 128, 2, 2>), grid, block, stream, p);
+  else return FSV_ERR_BAD_ARG;
+  return fsv_check_launch();
+}

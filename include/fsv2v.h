@@ -58,7 +58,7 @@ int fsv_bias_act(float* x, const float* bias, long long total, int C, int act, f
 /* dwt[t*Cin+ci][co] = sum_{n,oy,ox} in[n, oy*sy+ty[t], ox*sx+tx[t], ci] * dout[n, oy, ox, co]  (weight gradient)
  * prezeroed: dwt already holds zeros (a slice of the optimiser's per-pass arena), skip the split-K zero-fill;
  * force_tile: 0 = automatic (1 / 2 / 3 = 64x64 / 128x64 / 64x128 rows x columns, 5 / 6 = 64x64 / 64x128 as one- / two-wave
- * workgroups; for A/B runs) */
+ * workgroups, 7 / 8 = the same two tiles with double-buffered LDS; for A/B runs) */
 int fsv_conv_wgrad(const float* in, const float* dout, float* dwt,
                    int N, int H, int W, int Cin, int OH, int OW, int Cout,
                    int ntaps, const int* ty, const int* tx, int sy, int sx,

@@ -38,7 +38,7 @@ def test_forward_tiles(emu_lib, geom, tile, split):
 
 
 @pytest.mark.parametrize("geom", GEOMS[:4])
-@pytest.mark.parametrize("tile,split", [(0, 0), (1, 1), (1, 3), (2, 2), (3, 1), (3, 2), (5, 1), (5, 3), (6, 1), (6, 2)])
+@pytest.mark.parametrize("tile,split", [(0, 0), (1, 1), (1, 3), (2, 2), (3, 1), (3, 2), (5, 1), (5, 3), (6, 1), (6, 2), (7, 1), (7, 3), (8, 1), (8, 2)])
 def test_wgrad_tiles(emu_lib, geom, tile, split):
     ops, conv = oc.pkg()
     n, cin, h, w, cout, k, s, p = geom

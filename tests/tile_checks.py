@@ -1,6 +1,6 @@
 """Forced-tile checks of the fp32 convolution kernels shared by the emulator test (test_tiles_emu.py) and - run as a script -
 the first hardware run of the experimental tile variants (few-wave workgroups 10-12, double-buffered LDS 13-15, weight-gradient
-5 / 6), which were added after the round-1 GPU budget was spent."""
+5 - 8), which were added after the round-1 GPU budget was spent."""
 import torch
 import torch.nn.functional as F
 
@@ -49,7 +49,7 @@ def check_wgrad_few_wave(device, seed=79):
     dy = torch.randn(y.shape, generator=g)
     y.backward(dy)
     geo = conv.Geom(3, 3, 1, 1)
-    for t in (5, 6):
+    for t in (5, 6, 7, 8):
         for sp in (1, 4):
             dw = conv.conv_wgrad(conv.to_nhwc(x.to(device)), conv.to_nhwc(dy.to(device)), geo, (192, 64, 3, 3), force_tile=t,
                                  force_split=sp)
