@@ -22,6 +22,10 @@ import os
 import sys
 import time
 
+# the host driver only supports dmabuf IPC: without this RCCL's cross-process buffer registration fails
+# (hipIpcGetMemHandle: invalid argument).  Already exported on the GPU boxes; kept here for bare launches.
+os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+
 import torch
 import torch.distributed as dist
 
