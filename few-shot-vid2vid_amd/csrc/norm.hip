@@ -404,3 +404,82 @@ int fsv_colsum(const float* x, double* workspace, float* out, int G, int P, int 
 }
 
 }  // extern "C"
+
+// ---- cross-replica BatchNorm ("SyncBN", opt-in): the statistics of one BatchNorm site split into reduce | exchange | finish ----
+// The reference's multi-process path uses apex.parallel.SyncBatchNorm for every BatchNorm of the generator
+// (models/networks/normalization.py:15,33,80): per-channel sums are exchanged between the ranks in the
+// forward pass and the two gradient sums in the backward pass.  The exchange itself is the host's business (one small
+// all-reduce of 2C doubles, torch.distributed over RCCL); these entry points are the device halves on either side of it.
+__global__ __launch_bounds__(256) void fsv_sums_final_kernel(const double* part, double* sums, int C, int nchunks) {
+  const int cc = blockIdx.x * 4 + (threadIdx.x >> 6);        // one wave per channel
+  const bool ok = cc < C;
+  double a, b;
+  fsv_sum_chunks(part, 0, ok ? cc : 0, C, nchunks, a, b);
+  if (ok && (threadIdx.x & 63) == 0) { sums[cc] = a; sums[C + cc] = b; }
+}
+
+// sums = {sum x [C], sum x^2 [C]} over `count` values per channel (all ranks together)
+__global__ __launch_bounds__(256) void fsv_stats_from_sums_kernel(const double* sums, double count, float* mean, float* rstd,
+                                                                  int C, float eps, float* run_mean, float* run_var,
+                                                                  float momentum) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  double mu = sums[c] / count;
+  double var = sums[C + c] / count - mu * mu;
+  if (var < 0.0) var = 0.0;
+  mean[c] = (float)mu;
+  rstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+  if (run_mean) {
+    double unb = count > 1.0 ? var * (count / (count - 1.0)) : var;
+    run_mean[c] = (1.f - momentum) * run_mean[c] + momentum * (float)mu;
+    run_var[c] = (1.f - momentum) * run_var[c] + momentum * (float)unb;
+  }
+}
+
+extern "C" {
+
+// local {sum x, sum x^2} of a [P][C] tensor as doubles [2C]
+int fsv_norm_sums(const float* x, double* workspace, double* sums, int P, int C, hipStream_t stream) {
+  if (!x || !workspace || !sums || P < 1 || C < 1) return FSV_ERR_BAD_ARG;
+  RedPlan pl = fsv_red_plan(1, P, C);
+  RedP rp; rp.a = x; rp.y = nullptr; rp.x = nullptr; rp.mean = nullptr; rp.rstd = nullptr; rp.part = workspace;
+  rp.P = P; rp.C = C; rp.act = 0;
+  fsv_launch_red<FSV_RED_STATS>(pl, rp, 1, stream);
+  FSV_LAUNCH(fsv_sums_final_kernel, dim3(fsv_cdiv(C, 4)), dim3(256), stream, (const double*)workspace, sums, C, pl.nchunks);
+  return fsv_check_launch();
+}
+
+// mean / rstd (and the running statistics, momentum semantics of nn.BatchNorm2d) from exchanged sums over `count` values
+int fsv_norm_stats_from_sums(const double* sums, double count, float* mean, float* rstd, int C, float eps, float* run_mean,
+                             float* run_var, float momentum, hipStream_t stream) {
+  if (!sums || !mean || !rstd || C < 1 || !(count >= 1.0)) return FSV_ERR_BAD_ARG;
+  FSV_LAUNCH(fsv_stats_from_sums_kernel, dim3(fsv_cdiv(C, 256)), dim3(256), stream, sums, count, mean, rstd, C, eps, run_mean,
+             run_var, momentum);
+  return fsv_check_launch();
+}
+
+// local {sum d, sum d * xhat} (d = dy * act'(y)) as doubles [2C]: the two sums of the BatchNorm backward before the exchange
+int fsv_norm_bwd_sums(const float* dy, const float* y, const float* x, const float* mean, const float* rstd,
+                      double* workspace, double* sums, int P, int C, int act, hipStream_t stream) {
+  if (!dy || !x || !mean || !rstd || !workspace || !sums || P < 1 || C < 1) return FSV_ERR_BAD_ARG;
+  if (act != FSV_ACT_NONE && !y) return FSV_ERR_BAD_ARG;
+  RedPlan pl = fsv_red_plan(1, P, C);
+  RedP rp; rp.a = dy; rp.y = y; rp.x = x; rp.mean = mean; rp.rstd = rstd; rp.part = workspace;
+  rp.P = P; rp.C = C; rp.act = act;
+  fsv_launch_red<FSV_RED_BWD>(pl, rp, 1, stream);
+  FSV_LAUNCH(fsv_sums_final_kernel, dim3(fsv_cdiv(C, 4)), dim3(256), stream, (const double*)workspace, sums, C, pl.nchunks);
+  return fsv_check_launch();
+}
+
+// dx = w * rstd * (d - s1 / count - xhat * s2 / count) over the local [P][C] tensor with the exchanged sums s1, s2 [C]
+int fsv_norm_bwd_apply(const float* dy, const float* y, const float* x, const float* mean, const float* rstd, const float* w,
+                       const float* s1, const float* s2, float* dx, int P, int C, int count, int act, hipStream_t stream) {
+  if (!dy || !x || !mean || !rstd || !s1 || !s2 || !dx || P < 1 || C < 1 || count < 1) return FSV_ERR_BAD_ARG;
+  if (act != FSV_ACT_NONE && !y) return FSV_ERR_BAD_ARG;
+  long long total = (long long)P * C;
+  FSV_LAUNCH(fsv_norm_bwd_apply_kernel, dim3(fsv_ew_grid(total)), dim3(256), stream, dy, y, x, mean, rstd, w, s1, s2, dx,
+             total, total, C, count, act, 0);
+  return fsv_check_launch();
+}
+
+}  // extern "C"

@@ -365,8 +365,14 @@ class Vid2VidModel(nn.Module):
         return out
 
     # optimisers are created once the module sits on its device (flat buffers are device allocations)
-    def build_optimizers(self, world_size=1, process_group=None, force_exchange=False, overlap=True):
+    def build_optimizers(self, world_size=1, process_group=None, force_exchange=False, overlap=True, sync_bn=None):
+        """sync_bn: pool the BatchNorm statistics over the replicas (the reference's apex SyncBatchNorm under its
+        multi-process path, normalization.py:15,33,80) instead of the default per-replica statistics; None reads
+        FSV_SYNC_BN.  Needs equal per-rank batches and the eager step (collectives inside forward / backward)."""
         opt = self.opt
+        if sync_bn is None:
+            sync_bn = os.environ.get('FSV_SYNC_BN', '0') == '1'
+        ops.set_bn_sync(world_size if sync_bn else 1, process_group)
         if opt.no_TTUR:
             beta1, beta2, g_lr, d_lr = opt.beta1, 0.999, opt.lr, opt.lr
         else:

@@ -29,6 +29,10 @@ lib.register_sigs({
     "fsv_norm_stats": [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_f, c_p, c_p, c_f, c_p],
     "fsv_norm_apply": [c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p],
     "fsv_norm_bwd": [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p],
+    "fsv_norm_sums": [c_p, c_p, c_p, c_i, c_i, c_p],
+    "fsv_norm_stats_from_sums": [c_p, ctypes.c_double, c_p, c_p, c_i, c_f, c_p, c_p, c_f, c_p],
+    "fsv_norm_bwd_sums": [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_p],
+    "fsv_norm_bwd_apply": [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p],
     "fsv_colsum": [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p],
     "fsv_spade_prep": [c_p, c_p, c_p, c_p, c_ll, c_ll, c_ll, c_ll, c_p, c_p, c_p, c_i, c_i, c_i, c_p],
     "fsv_spade_mod_fwd": [c_p, c_p, c_p, c_p, c_i, c_pp, c_pp, c_pp, c_pp, c_pp, c_ip, c_llp, c_llp,
@@ -470,15 +474,69 @@ def batch_conv(x, weight, bias=None, act=ACT_NONE):
 
 
 # ------------------------------------------------------------------------------------------------ normalisation
+# Cross-replica BatchNorm statistics (opt-in).  The reference's multi-process path makes every BatchNorm of the generator an
+# apex.parallel.SyncBatchNorm (models/networks/normalization.py:15,33,80): statistics over the GLOBAL batch.  Default here is
+# per-replica statistics (DESIGN.md "Multi-GPU"); set_bn_sync(world, group) switches every train-mode BatchNorm site (affine,
+# and the parameter-free one inside SPADE) to: local fp64 sums -> one all-reduce of 2C doubles -> mean / rstd, and the same for
+# the two sums of the backward pass.  Every rank must hold the same number of pixels per site (equal per-rank batches).
+_bn_sync = None        # (world_size, process group) or None
+
+
+def set_bn_sync(world_size=1, group=None):
+    global _bn_sync
+    _bn_sync = (int(world_size), group) if world_size and int(world_size) > 1 else None
+
+
+def bn_sync_world(groups=1):
+    """number of replicas whose statistics are pooled for a normalisation with `groups` groups (InstanceNorm is never pooled)"""
+    return _bn_sync[0] if (_bn_sync is not None and groups == 1) else 1
+
+
 def norm_stats(x, groups, pixels, channels, eps, run_mean=None, run_var=None, momentum=0.1):
     mean = torch.empty(groups * channels, dtype=torch.float32, device=x.device)
     rstd = torch.empty_like(mean)
     lib.check_device(x, run_mean, run_var)
     ws = _ws(groups, pixels, channels, x)
+    if bn_sync_world(groups) > 1:
+        import torch.distributed as dist
+        sums = torch.empty(2 * channels, dtype=torch.float64, device=x.device)
+        lib.call("fsv_norm_sums", lib.ptr(x), lib.ptr(ws), lib.ptr(sums), pixels, channels, lib.stream_ptr())
+        dist.all_reduce(sums, op=dist.ReduceOp.SUM, group=_bn_sync[1])
+        lib.call("fsv_norm_stats_from_sums", lib.ptr(sums), float(pixels) * _bn_sync[0], lib.ptr(mean), lib.ptr(rstd),
+                 channels, float(eps), lib.ptr(run_mean), lib.ptr(run_var), float(momentum), lib.stream_ptr())
+        return mean, rstd
     lib.call("fsv_norm_stats", lib.ptr(x), lib.ptr(ws), lib.ptr(mean), lib.ptr(rstd),
              groups, pixels, channels, float(eps), lib.ptr(run_mean), lib.ptr(run_var), float(momentum),
              lib.stream_ptr())
     return mean, rstd
+
+
+def bn_backward(dy, y, x, mean, rstd, w, g, p, c, act, fixed_stats, affine, world=1):
+    """dx (and dw, db when affine) of a normalisation whose forward pooled its statistics over `world` replicas"""
+    dx = torch.empty_like(x)
+    if world > 1 and not fixed_stats:
+        import torch.distributed as dist
+        ws = _ws(1, p, c, x)
+        sums = torch.empty(2 * c, dtype=torch.float64, device=x.device)
+        lib.call("fsv_norm_bwd_sums", lib.ptr(dy), lib.ptr(y), lib.ptr(x), lib.ptr(mean), lib.ptr(rstd), lib.ptr(ws),
+                 lib.ptr(sums), p, c, act, lib.stream_ptr())
+        # parameter gradients are the local sums: they are averaged over the replicas with every other gradient
+        db = sums[:c].float() if affine else None
+        dw = sums[c:].float() if affine else None
+        dist.all_reduce(sums, op=dist.ReduceOp.SUM, group=_bn_sync[1])
+        s = sums.float()
+        lib.call("fsv_norm_bwd_apply", lib.ptr(dy), lib.ptr(y), lib.ptr(x), lib.ptr(mean), lib.ptr(rstd), lib.ptr(w),
+                 lib.ptr(s[:c]), lib.ptr(s[c:]), lib.ptr(dx), p, c, p * world, act, lib.stream_ptr())
+        return dx, dw, db
+    s1 = torch.empty(g * c, dtype=torch.float32, device=x.device)
+    s2 = torch.empty_like(s1)
+    dw = torch.empty(c, dtype=torch.float32, device=x.device) if affine else None
+    db = torch.empty_like(dw) if affine else None
+    ws = _ws(g, p, c, x)
+    lib.call("fsv_norm_bwd", lib.ptr(dy), lib.ptr(y), lib.ptr(x), lib.ptr(mean), lib.ptr(rstd), lib.ptr(w), lib.ptr(ws),
+             lib.ptr(s1), lib.ptr(s2), lib.ptr(dx), lib.ptr(dw), lib.ptr(db), g, p, c, act, 1 if fixed_stats else 0,
+             lib.stream_ptr())
+    return dx, dw, db
 
 
 class _NormActFn(torch.autograd.Function):
@@ -501,6 +559,7 @@ class _NormActFn(torch.autograd.Function):
         ctx.dims = (g, p, c)
         ctx.act, ctx.affine = act, weight is not None
         ctx.batch_stats = bool(training or instance or run_mean is None)
+        ctx.world = bn_sync_world(g) if ctx.batch_stats else 1
         ctx.save_for_backward(x, y, mean, rstd, wd if wd is not None else mean)
         return y
 
@@ -509,15 +568,8 @@ class _NormActFn(torch.autograd.Function):
         x, y, mean, rstd, wd = ctx.saved_tensors
         g, p, c = ctx.dims
         dy = to_nhwc(dy)
-        dx = torch.empty_like(x)
-        s1 = torch.empty(g * c, dtype=torch.float32, device=x.device)
-        s2 = torch.empty_like(s1)
-        dw = torch.empty(c, dtype=torch.float32, device=x.device) if ctx.affine else None
-        db = torch.empty_like(dw) if ctx.affine else None
-        ws = _ws(g, p, c, x)
-        lib.call("fsv_norm_bwd", lib.ptr(dy), lib.ptr(y), lib.ptr(x), lib.ptr(mean), lib.ptr(rstd),
-                 lib.ptr(wd) if ctx.affine else None, lib.ptr(ws), lib.ptr(s1), lib.ptr(s2), lib.ptr(dx),
-                 lib.ptr(dw), lib.ptr(db), g, p, c, ctx.act, 0 if ctx.batch_stats else 1, lib.stream_ptr())
+        dx, dw, db = bn_backward(dy, y, x, mean, rstd, wd if ctx.affine else None, g, p, c, ctx.act, not ctx.batch_stats,
+                                 ctx.affine, ctx.world)
         return dx, dw, db, None, None, None, None, None, None, None
 
 
@@ -603,6 +655,7 @@ class _SpadeFn(torch.autograd.Function):
                          _ll(bstr + [0]), n, h * w, c, ldw, 0, act, lib.stream_ptr())
             ctx.nmaps, ctx.act = nmaps, act
             ctx.batch_stats = bool(training or run_mean is None)
+            ctx.world = bn_sync_world(1) if ctx.batch_stats else 1
             ctx.per_sample = [wgs[k].dim() == 5 for k in range(nmaps)]
             ctx.w_shapes = [tuple(wgs[k].shape) for k in range(nmaps)]
             ctx.save_for_backward(x, hout, mean, rstd, *maps, *prepped)
@@ -623,6 +676,7 @@ class _SpadeFn(torch.autograd.Function):
                      _ll(bbs_stride + [0]), n, h * w, c, ldw, 0, act, lib.stream_ptr())
         ctx.nmaps, ctx.act = nmaps, act
         ctx.batch_stats = bool(training or run_mean is None)
+        ctx.world = bn_sync_world(1) if ctx.batch_stats else 1
         ctx.save_for_backward(x, hout, mean, rstd, *maps, *wgs, *wbs, *bgs, *bbs)
         return hout
 
@@ -664,13 +718,7 @@ class _SpadeFn(torch.autograd.Function):
         dx = None
         if ctx.needs_input_grad[4]:
             if ctx.batch_stats:
-                dx = torch.empty_like(x)
-                s1 = torch.empty(c, dtype=torch.float32, device=x.device)
-                s2 = torch.empty_like(s1)
-                ws = _ws(1, n * h * w, c, x)
-                lib.call("fsv_norm_bwd", lib.ptr(dxhat), None, lib.ptr(x), lib.ptr(mean), lib.ptr(rstd), None,
-                         lib.ptr(ws), lib.ptr(s1), lib.ptr(s2), lib.ptr(dx), None, None,
-                         1, n * h * w, c, ACT_NONE, 0, lib.stream_ptr())
+                dx, _, _ = bn_backward(dxhat, None, x, mean, rstd, None, 1, n * h * w, c, ACT_NONE, False, False, ctx.world)
             else:
                 dx = dxhat * rstd.view(1, c, 1, 1)
         grads = []

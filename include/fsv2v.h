@@ -153,6 +153,16 @@ int fsv_norm_bwd(const float* dy, const float* y, const float* x, const float* m
                  double* workspace, float* s1, float* s2, float* dx, float* dw, float* db, int G, int P, int C, int act,
                  int fixed_stats, fsv_stream_t stream);   /* fixed_stats: eval mode, mean / rstd are constants */
 int fsv_colsum(const float* x, double* workspace, float* out, int G, int P, int C, int accumulate, fsv_stream_t stream);
+/* cross-replica BatchNorm (opt-in; apex.parallel.SyncBatchNorm of the reference's multi-process path, normalization.py:15,33,80):
+ * the device halves on either side of the host's all-reduce.  sums: doubles [2C] = {sum x, sum x^2} resp. {sum d, sum d*xhat};
+ * count: values per channel over all ranks.  dw / db of an affine layer are the LOCAL sums (they travel with the gradients). */
+int fsv_norm_sums(const float* x, double* workspace, double* sums, int P, int C, fsv_stream_t stream);
+int fsv_norm_stats_from_sums(const double* sums, double count, float* mean, float* rstd, int C, float eps, float* run_mean,
+                             float* run_var, float momentum, fsv_stream_t stream);
+int fsv_norm_bwd_sums(const float* dy, const float* y, const float* x, const float* mean, const float* rstd,
+                      double* workspace, double* sums, int P, int C, int act, fsv_stream_t stream);
+int fsv_norm_bwd_apply(const float* dy, const float* y, const float* x, const float* mean, const float* rstd, const float* w,
+                       const float* s1, const float* s2, float* dx, int P, int C, int count, int act, fsv_stream_t stream);
 /* the bias gradients of a whole backward pass in two launches: table[job][8] = {src [P][C] rows, dst float[C] (added into),
  * offset of the job's partials in `part` (doubles), P, C, rows_per_blk, nchunks, V | shared << 8}; tmap1 (job, chunk, slab) triples,
  * tmap2 (job, 4-channel block) pairs; fsv_colsum_plan gives {V, TX, nslabs, rows_per_blk, nchunks} for one [P][C] */

@@ -126,3 +126,74 @@ def test_two_rank_amp_overflow_is_skipped_on_every_rank(emu_lib, tmp_path):
     assert r0['log'] == r1['log']
     # (scale, good steps, Adam t): good / overflow -> halve, no step / good / good -> window of 2 reached, double
     assert r0['log'] == [(64.0, 1.0, 1.0), (32.0, 0.0, 1.0), (32.0, 1.0, 2.0), (64.0, 0.0, 3.0)], r0['log']
+
+
+def _syncbn_worker(rank, world, port, out_dir):
+    os.environ['FSV2V_EMU'] = '1'
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    torch.set_num_threads(1)
+    import model_checks as mc
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    M = mc._model()
+    opt = mc.tiny_opt(ngf=4, ndf=4, warp_ref=True, spade_combine=True, remove_face_labels=True, fineSize=32, loadSize=32,
+                      n_downsample_G=3, n_adaptive_layers=2)
+    model = M.create_model(opt)
+    mc.fill_state(model.netG); mc.fill_state(model.netD)
+    model.train()
+    opt_G, opt_D = model.build_optimizers(world_size=world, overlap=False, sync_bn=True)
+    opt_G.set_lr(0.0); opt_D.set_lr(0.0)
+    tl, ti, rl, ri = [t[rank:rank + 1] for t in mc.synth_pose_inputs(2, 32, 32, 300, opt.input_nc)]
+    data = [tl, ti, [None, None], [None, None], rl, ri, None, None, None]
+    d = M.loss_backward(opt, model(data, mode='discriminator'), opt_D, 1)
+    gD = opt_D.flat_g.clone()
+    g, generated, _ = model(data, save_images=True, mode='generator')
+    g = M.loss_backward(opt, g, opt_G, 0)
+    bn = {k: v.clone() for k, v in model.netG.state_dict().items() if 'running_' in k}
+    torch.save(dict(gD=gD, gG=opt_G.flat_g.clone(), img=generated[0].detach().clone(), bn=bn,
+                    g=[float(x.detach()) for x in g if not isinstance(x, int)]), os.path.join(out_dir, 'sbn%d.pt' % rank))
+    dist.destroy_process_group()
+
+
+def _syncbn_single():
+    os.environ['FSV2V_EMU'] = '1'
+    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    import model_checks as mc
+    M = mc._model()
+    opt = mc.tiny_opt(ngf=4, ndf=4, warp_ref=True, spade_combine=True, remove_face_labels=True, fineSize=32, loadSize=32,
+                      n_downsample_G=3, n_adaptive_layers=2)
+    model = M.create_model(opt)
+    mc.fill_state(model.netG); mc.fill_state(model.netD)
+    model.train()
+    opt_G, opt_D = model.build_optimizers(world_size=1)
+    opt_G.set_lr(0.0); opt_D.set_lr(0.0)
+    tl, ti, rl, ri = mc.synth_pose_inputs(2, 32, 32, 300, opt.input_nc)
+    data = [tl, ti, [None, None], [None, None], rl, ri, None, None, None]
+    M.loss_backward(opt, model(data, mode='discriminator'), opt_D, 1)
+    gD = opt_D.flat_g.clone()
+    g, generated, _ = model(data, save_images=True, mode='generator')
+    M.loss_backward(opt, g, opt_G, 0)
+    bn = {k: v.clone() for k, v in model.netG.state_dict().items() if 'running_' in k}
+    return dict(gD=gD, gG=opt_G.flat_g.clone(), img=generated[0].detach().clone(), bn=bn)
+
+
+def test_two_rank_sync_batchnorm_equals_one_process_on_the_whole_batch(emu_lib, tmp_path):
+    """opt-in cross-replica BatchNorm (the reference's apex SyncBatchNorm under DDP): two ranks with one sample each produce
+    the images, running statistics and (summed) gradients of ONE process that sees both samples"""
+    world, port = 2, 29619
+    mp.spawn(_syncbn_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    r0 = torch.load(os.path.join(tmp_path, 'sbn0.pt'))
+    r1 = torch.load(os.path.join(tmp_path, 'sbn1.pt'))
+    one = _syncbn_single()
+    img = torch.cat([r0['img'], r1['img']])
+    assert float((img - one['img']).abs().max()) <= 2e-5 * float(one['img'].abs().max())
+    for k, v in one['bn'].items():
+        assert float((r0['bn'][k] - v).abs().max()) <= 1e-5 * max(float(v.abs().max()), 1e-3), k
+        assert torch.equal(r0['bn'][k], r1['bn'][k]), k
+    # flat_g after the exchange = sum over ranks of the per-rank mean-loss gradients = 2 x the gradient of the batch-mean loss
+    for key in ('gD', 'gG'):
+        assert torch.equal(r0[key], r1[key])
+        ref = 2.0 * one[key]
+        rel = float((r0[key] - ref).norm() / ref.norm())
+        assert rel <= 2e-3, (key, rel)
