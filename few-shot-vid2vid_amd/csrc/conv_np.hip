@@ -22,6 +22,9 @@
 //     pixel in the weight-gradient kernel) and is transposed on the way in: a work-item owns two consecutive k of four
 //     consecutive rows and writes four packed pairs, with the 16 k-pairs of a chunk on consecutive lanes.  A 32-lane store group
 //     then covers the 16 dwords of two rows of equal parity: 2-way, which a 4-byte LDS store absorbs (same section).
+// Both tiles are double-buffered (two LDS images, 16-64 KB per workgroup): a K chunk of 8 (x3) MFMAs per wave is short, so it
+// pays for ONE barrier instead of two - the staging registers of chunk c+1 are stored into the idle image while chunk c is
+// still being multiplied by the slower waves.
 // The k <-> (lane, element) assignment inside one MFMA is the same for A and B, so the sum over k does not depend on it; the
 // C/D layout is the dtype-independent 32x32 map already used by the fp32 kernels.
 //
@@ -108,8 +111,10 @@ __global__ __launch_bounds__(64 * WM * WN) void fsv_np_conv_kernel(NpConvP p) {
   constexpr int QPB = NT / KP;         // B column quads per pass
   constexpr int NPB = BN / (4 * QPB);  // B passes
   static_assert(NPA >= 1 && NPB >= 1 && NPA * RPP == BM && NPB * 4 * QPB == BN, "tile / thread-count mismatch");
-  __shared__ __attribute__((aligned(16))) H As[NP][BM * LDK];
-  __shared__ __attribute__((aligned(16))) H Bs[NP][BN * LDK];
+  // two images of each tile (double buffering, one workgroup barrier per K chunk): [image][plane]
+  __shared__ __attribute__((aligned(16))) H As[2 * NP][BM * LDK];
+  __shared__ __attribute__((aligned(16))) H Bs[2 * NP][BN * LDK];
+  static_assert(2 * NP * (BM + BN) * LDK * 2 <= 65536, "LDS images must fit a static allocation");
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
@@ -172,7 +177,9 @@ __global__ __launch_bounds__(64 * WM * WN) void fsv_np_conv_kernel(NpConvP p) {
       breg[i][1] = bcol_ok ? v1 : zero4;
     }
   };
-  auto store_chunk = [&]() {
+  auto store_chunk = [&](int buf) {
+    H (*as)[BM * LDK] = As + buf * NP;
+    H (*bs)[BN * LDK] = Bs + buf * NP;
 #pragma unroll
     for (int i = 0; i < NPA; ++i) {
       const int r = ar0 + i * RPP;
@@ -180,8 +187,8 @@ __global__ __launch_bounds__(64 * WM * WN) void fsv_np_conv_kernel(NpConvP p) {
       H4 hi, lo;
 #pragma unroll
       for (int j = 0; j < 4; ++j) { H h, l; np_split<MODE>(v[j], h, l); hi[j] = h; lo[j] = l; }
-      *reinterpret_cast<H4*>(&As[0][np_sw(r, kq * 4)]) = hi;
-      if constexpr (NP == 2) *reinterpret_cast<H4*>(&As[NP - 1][np_sw(r, kq * 4)]) = lo;
+      *reinterpret_cast<H4*>(&as[0][np_sw(r, kq * 4)]) = hi;
+      if constexpr (NP == 2) *reinterpret_cast<H4*>(&as[NP - 1][np_sw(r, kq * 4)]) = lo;
     }
 #pragma unroll
     for (int i = 0; i < NPB; ++i) {
@@ -195,8 +202,8 @@ __global__ __launch_bounds__(64 * WM * WN) void fsv_np_conv_kernel(NpConvP p) {
         np_split<MODE>(v1[j], h1, l1);
         H2 hi, lo;
         hi[0] = h0; hi[1] = h1; lo[0] = l0; lo[1] = l1;
-        *reinterpret_cast<H2*>(&Bs[0][np_sw(row0 + j, 2 * bkp)]) = hi;
-        if constexpr (NP == 2) *reinterpret_cast<H2*>(&Bs[NP - 1][np_sw(row0 + j, 2 * bkp)]) = lo;
+        *reinterpret_cast<H2*>(&bs[0][np_sw(row0 + j, 2 * bkp)]) = hi;
+        if constexpr (NP == 2) *reinterpret_cast<H2*>(&bs[NP - 1][np_sw(row0 + j, 2 * bkp)]) = lo;
       }
     }
   };
@@ -213,21 +220,25 @@ __global__ __launch_bounds__(64 * WM * WN) void fsv_np_conv_kernel(NpConvP p) {
   const int a_row = wm * (TM * 32) + lrow, b_row = wn * (TN * 32) + lrow;
   if (c_begin < c_end) {
     load_chunk(c_begin);
-    store_chunk();
+    store_chunk(0);
     __syncthreads();
 #pragma unroll 1
     for (int kc = c_begin; kc < c_end; ++kc) {
-      const int knext = (kc + 1 < c_end) ? kc + 1 : kc;
-      load_chunk(knext);
+      const int cur = (kc - c_begin) & 1;
+      const bool more = kc + 1 < c_end;
+      // the last iteration re-reads its own chunk (no per-lane branch around the loads); that copy is never stored
+      load_chunk(more ? kc + 1 : kc);
+      const H (*as)[BM * LDK] = As + cur * NP;
+      const H (*bs)[BN * LDK] = Bs + cur * NP;
 #pragma unroll
       for (int ks = 0; ks < BK / 16; ++ks) {
         H8 a[NP][TM], b[NP][TN];
 #pragma unroll
         for (int q = 0; q < NP; ++q) {
 #pragma unroll
-          for (int i = 0; i < TM; ++i) a[q][i] = *reinterpret_cast<const H8*>(&As[q][np_sw(a_row + i * 32, ks * 16 + lk * 8)]);
+          for (int i = 0; i < TM; ++i) a[q][i] = *reinterpret_cast<const H8*>(&as[q][np_sw(a_row + i * 32, ks * 16 + lk * 8)]);
 #pragma unroll
-          for (int j = 0; j < TN; ++j) b[q][j] = *reinterpret_cast<const H8*>(&Bs[q][np_sw(b_row + j * 32, ks * 16 + lk * 8)]);
+          for (int j = 0; j < TN; ++j) b[q][j] = *reinterpret_cast<const H8*>(&bs[q][np_sw(b_row + j * 32, ks * 16 + lk * 8)]);
         }
 #pragma unroll
         for (int i = 0; i < TM; ++i)
@@ -240,8 +251,8 @@ __global__ __launch_bounds__(64 * WM * WN) void fsv_np_conv_kernel(NpConvP p) {
             acc[i][j] = np_mfma(a[0][i], b[0][j], acc[i][j]);
           }
       }
-      __syncthreads();
-      store_chunk();
+      // the other image was last read before the previous barrier: fill it while the slower waves finish this chunk
+      if (more) store_chunk(cur ^ 1);
       __syncthreads();
     }
   }
@@ -339,8 +350,9 @@ __global__ __launch_bounds__(64 * WM * WN) void fsv_np_wgrad_kernel(NpWgradP p) 
   constexpr int NPA = BMK / (4 * QPP), NPB = BN / (4 * QPP);
   static_assert(TM >= 1 && TN >= 1, "tile");
   static_assert(NPA >= 1 && NPB >= 1 && NPA * 4 * QPP == BMK && NPB * 4 * QPP == BN, "tile / thread-count mismatch");
-  __shared__ __attribute__((aligned(16))) H As[NP][BMK * LDK];
-  __shared__ __attribute__((aligned(16))) H Bs[NP][BN * LDK];
+  __shared__ __attribute__((aligned(16))) H As[2 * NP][BMK * LDK];       // [image][plane], double-buffered like the forward kernel
+  __shared__ __attribute__((aligned(16))) H Bs[2 * NP][BN * LDK];
+  static_assert(2 * NP * (BMK + BN) * LDK * 2 <= 65536, "LDS images must fit a static allocation");
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
   const int zs = blockIdx.z / p.nsplit, zk = blockIdx.z % p.nsplit;
@@ -408,7 +420,9 @@ __global__ __launch_bounds__(64 * WM * WN) void fsv_np_wgrad_kernel(NpWgradP p) 
         }
       }
   };
-  auto store_chunk = [&]() {
+  auto store_chunk = [&](int buf) {
+    H (*as)[BMK * LDK] = As + buf * NP;
+    H (*bs)[BN * LDK] = Bs + buf * NP;
 #pragma unroll
     for (int i = 0; i < NPA; ++i) {
       const int pr = 2 * pp, aq = q0 + i * QPP;
@@ -421,8 +435,8 @@ __global__ __launch_bounds__(64 * WM * WN) void fsv_np_wgrad_kernel(NpWgradP p) 
         np_split<MODE>(v1[j], h1, l1);
         H2 hi, lo;
         hi[0] = h0; hi[1] = h1; lo[0] = l0; lo[1] = l1;
-        *reinterpret_cast<H2*>(&As[0][np_sw(aq * 4 + j, pr)]) = hi;
-        if constexpr (NP == 2) *reinterpret_cast<H2*>(&As[NP - 1][np_sw(aq * 4 + j, pr)]) = lo;
+        *reinterpret_cast<H2*>(&as[0][np_sw(aq * 4 + j, pr)]) = hi;
+        if constexpr (NP == 2) *reinterpret_cast<H2*>(&as[NP - 1][np_sw(aq * 4 + j, pr)]) = lo;
       }
     }
 #pragma unroll
@@ -437,8 +451,8 @@ __global__ __launch_bounds__(64 * WM * WN) void fsv_np_wgrad_kernel(NpWgradP p) 
         np_split<MODE>(v1[j], h1, l1);
         H2 hi, lo;
         hi[0] = h0; hi[1] = h1; lo[0] = l0; lo[1] = l1;
-        *reinterpret_cast<H2*>(&Bs[0][np_sw(bq * 4 + j, pr)]) = hi;
-        if constexpr (NP == 2) *reinterpret_cast<H2*>(&Bs[NP - 1][np_sw(bq * 4 + j, pr)]) = lo;
+        *reinterpret_cast<H2*>(&bs[0][np_sw(bq * 4 + j, pr)]) = hi;
+        if constexpr (NP == 2) *reinterpret_cast<H2*>(&bs[NP - 1][np_sw(bq * 4 + j, pr)]) = lo;
       }
     }
   };
@@ -455,21 +469,24 @@ __global__ __launch_bounds__(64 * WM * WN) void fsv_np_wgrad_kernel(NpWgradP p) 
   const int a_row = wm * (TM * 32) + lrow, b_row = wn * (TN * 32) + lrow;
   if (c_begin < c_end) {
     load_chunk(c_begin);
-    store_chunk();
+    store_chunk(0);
     __syncthreads();
 #pragma unroll 1
     for (int pc = c_begin; pc < c_end; ++pc) {
-      const int pnext = (pc + 1 < c_end) ? pc + 1 : pc;
-      load_chunk(pnext);
+      const int cur = (pc - c_begin) & 1;
+      const bool more = pc + 1 < c_end;
+      load_chunk(more ? pc + 1 : pc);
+      const H (*as)[BMK * LDK] = As + cur * NP;
+      const H (*bs)[BN * LDK] = Bs + cur * NP;
 #pragma unroll
       for (int ks = 0; ks < BK / 16; ++ks) {
         H8 a[NP][TM], b[NP][TN];
 #pragma unroll
         for (int q = 0; q < NP; ++q) {
 #pragma unroll
-          for (int i = 0; i < TM; ++i) a[q][i] = *reinterpret_cast<const H8*>(&As[q][np_sw(a_row + i * 32, ks * 16 + lk * 8)]);
+          for (int i = 0; i < TM; ++i) a[q][i] = *reinterpret_cast<const H8*>(&as[q][np_sw(a_row + i * 32, ks * 16 + lk * 8)]);
 #pragma unroll
-          for (int j = 0; j < TN; ++j) b[q][j] = *reinterpret_cast<const H8*>(&Bs[q][np_sw(b_row + j * 32, ks * 16 + lk * 8)]);
+          for (int j = 0; j < TN; ++j) b[q][j] = *reinterpret_cast<const H8*>(&bs[q][np_sw(b_row + j * 32, ks * 16 + lk * 8)]);
         }
 #pragma unroll
         for (int i = 0; i < TM; ++i)
@@ -482,8 +499,7 @@ __global__ __launch_bounds__(64 * WM * WN) void fsv_np_wgrad_kernel(NpWgradP p) 
             acc[i][j] = np_mfma(a[0][i], b[0][j], acc[i][j]);
           }
       }
-      __syncthreads();
-      store_chunk();
+      if (more) store_chunk(cur ^ 1);
       __syncthreads();
     }
   }
@@ -530,8 +546,11 @@ template <int MODE>
 static int np_launch_conv(const NpConvP& p, int nz, hipStream_t stream, int tile) {
   dim3 block(256);
   switch (tile) {
-    case 0: { dim3 g(fsv_cdiv(p.Mz, 128), fsv_cdiv(p.Cout, 128), nz);
-      FSV_LAUNCH((fsv_np_conv_kernel<128, 128, 2, 2, MODE>), g, block, stream, p); break; }
+    case 0: {
+      if constexpr (MODE == 2) return FSV_ERR_UNSUPPORTED;      // 64 KB of LDS: not instantiated (callers map it to 128x64)
+      else { dim3 g(fsv_cdiv(p.Mz, 128), fsv_cdiv(p.Cout, 128), nz);
+        FSV_LAUNCH((fsv_np_conv_kernel<128, 128, 2, 2, MODE>), g, block, stream, p); }
+      break; }
     case 1: { dim3 g(fsv_cdiv(p.Mz, 128), fsv_cdiv(p.Cout, 64), nz);
       FSV_LAUNCH((fsv_np_conv_kernel<128, 64, 2, 2, MODE>), g, block, stream, p); break; }
     case 9: { dim3 g(fsv_cdiv(p.Mz, 64), fsv_cdiv(p.Cout, 128), nz);
@@ -546,8 +565,10 @@ static int np_launch_conv(const NpConvP& p, int nz, hipStream_t stream, int tile
 template <int MODE>
 static int np_launch_wgrad(const NpWgradP& p, int bmk, int bn, dim3 g, hipStream_t stream) {
   dim3 block(256);
-  if (bmk == 128 && bn == 128) FSV_LAUNCH((fsv_np_wgrad_kernel<128, 128, 2, 2, MODE>), g, block, stream, p);
-  else if (bmk == 128 && bn == 64) FSV_LAUNCH((fsv_np_wgrad_kernel<128, 64, 2, 2, MODE>), g, block, stream, p);
+  if (bmk == 128 && bn == 128) {
+    if constexpr (MODE == 2) return FSV_ERR_UNSUPPORTED;
+    else FSV_LAUNCH((fsv_np_wgrad_kernel<128, 128, 2, 2, MODE>), g, block, stream, p);
+  } else if (bmk == 128 && bn == 64) FSV_LAUNCH((fsv_np_wgrad_kernel<128, 64, 2, 2, MODE>), g, block, stream, p);
   else if (bmk == 64 && bn == 128) FSV_LAUNCH((fsv_np_wgrad_kernel<64, 128, 2, 2, MODE>), g, block, stream, p);
   else if (bmk == 64 && bn == 64) FSV_LAUNCH((fsv_np_wgrad_kernel<64, 64, 2, 2, MODE>), g, block, stream, p);
   else return FSV_ERR_BAD_ARG;
@@ -586,6 +607,7 @@ int fsv_conv_gather_fwd_np(const float* in, const float* wt, const float* bias, 
   int tile = 0, nsplit = 1;
   if (fsv_conv_plan(p.Mz, Cout, p.nchunks, nsamp, force_tile, force_split, &tile, &nsplit)) return FSV_ERR_BAD_ARG;
   tile = np_tile_of(tile);
+  if (mode == 2 && tile == 0) tile = 1;      // two planes x two images of a 128x128 tile would take all 64 KB of a static allocation
   p.nsplit = nsplit;
   const long long total = (long long)N * outH * outW * Cout;
   if (accumulate) {
@@ -634,7 +656,7 @@ int fsv_conv_wgrad_np(const float* in, const float* dout, float* dwt,
   if (force_tile == 1) { bmk = 64; bn = 64; }
   else if (force_tile == 2) { bmk = 128; bn = 64; }
   else if (force_tile == 3) { bmk = 64; bn = 128; }
-  else if (force_tile == 4) { bmk = 128; bn = 128; }
+  else if (force_tile == 4) { bmk = 128; bn = (mode == 2) ? 64 : 128; }      // (mode 2: see fsv_conv_gather_fwd_np)
   long long blocks = (long long)fsv_cdiv(p.K, bmk) * fsv_cdiv(Cout, bn) * nsamp;
   int nsplit = 1;
   if (force_split > 0) nsplit = force_split;
