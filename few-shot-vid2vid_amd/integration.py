@@ -50,6 +50,33 @@ def create_model(opt, epoch=0):
     return _ModuleHandle(m), flow_net, [opt_G, opt_D]
 
 
+def init_dist(launcher='pytorch', backend='nccl', **kwargs):
+    """util/distributed.py:15-26, made to work (the reference's raises on its first line): one process per GPU, launched
+    by torchrun - bind this process to its GPU, join the process group (backend 'nccl' is RCCL over xGMI on ROCm), and
+    de-correlate the per-rank random streams like the reference intends (`set_random_seed(get_rank())` :20; the model
+    weights are still initialised under seed 0 on every rank, vid2vid_model.py:27).  Returns the GPU index."""
+    import os
+    import random
+    import numpy as np
+    import torch.distributed as dist
+    # dmabuf IPC is the only mode the host driver supports for RCCL's cross-process buffers
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    gpu_id = 0
+    if torch.cuda.is_available():
+        local = os.environ.get('LOCAL_RANK')
+        gpu_id = int(local) if local is not None else int(os.environ.get('RANK', '0')) % max(torch.cuda.device_count(), 1)
+        torch.cuda.set_device(gpu_id)
+    if not dist.is_initialized():
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29500')
+        dist.init_process_group(backend=backend, **kwargs)
+    seed = dist.get_rank()
+    random.seed(seed); np.random.seed(seed); torch.manual_seed(seed)
+    if torch.cuda.is_available():
+        torch.cuda.manual_seed_all(seed)
+    return gpu_id
+
+
 def patch_reference():
     """Re-bind the reference's names to this package.  The reference tree must already be importable."""
     import importlib
@@ -73,9 +100,14 @@ def patch_reference():
         if hasattr(mod, 'resample'):
             mod.resample = _ops.resample
             patched.append(modname + '.resample')
-    # train.py binds these two names at import time (train.py:13-14)
+    try:                                   # `--distributed`: train.py:22-23 calls util.distributed.init_dist()
+        ud = importlib.import_module('util.distributed')
+        ud.init_dist = init_dist; patched.append('util.distributed.init_dist')
+    except ImportError:
+        pass
+    # train.py binds these names at import time (train.py:13-16)
     tr = sys.modules.get('__main__')
-    for name, obj in (('create_model', create_model), ('loss_backward', _model.loss_backward)):
+    for name, obj in (('create_model', create_model), ('loss_backward', _model.loss_backward), ('init_dist', init_dist)):
         if tr is not None and hasattr(tr, name):
             setattr(tr, name, obj)
     return patched

@@ -197,3 +197,26 @@ def test_two_rank_sync_batchnorm_equals_one_process_on_the_whole_batch(emu_lib, 
         ref = 2.0 * one[key]
         rel = float((r0[key] - ref).norm() / ref.norm())
         assert rel <= 2e-3, (key, rel)
+
+
+def _init_dist_worker(rank, world, port, out_dir):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), FSV2V_EMU='1')
+    sys.path.insert(0, ROOT)
+    from importlib import import_module
+    import fsv2v_amd  # noqa: F401
+    integ = import_module('few-shot-vid2vid_amd.integration')
+    gpu = integ.init_dist(backend='gloo')
+    t = torch.tensor([float(rank + 1)])
+    dist.all_reduce(t)
+    torch.save(dict(gpu=gpu, rank=dist.get_rank(), world=dist.get_world_size(), sum=float(t), rnd=torch.rand(3)),
+               os.path.join(out_dir, 'init%d.pt' % rank))
+    dist.destroy_process_group()
+
+
+def test_init_dist_replacement(tmp_path):
+    """the working stand-in for the reference's util/distributed.py:init_dist (which raises): group joined, per-rank seeds"""
+    world, port = 2, 29621
+    mp.spawn(_init_dist_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    r = [torch.load(os.path.join(tmp_path, 'init%d.pt' % i)) for i in range(world)]
+    assert [x['rank'] for x in r] == [0, 1] and all(x['world'] == 2 and x['sum'] == 3.0 and x['gpu'] == 0 for x in r)
+    assert not torch.equal(r[0]['rnd'], r[1]['rnd'])
