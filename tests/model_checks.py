@@ -663,7 +663,7 @@ def check_flownet_wrapper(device, size=64, b=2, seed=52):
     return f_flow
 
 
-def check_amp_step(device, opt_kw, level, b=1, seed=61, loss_tol=2e-2, image_tol=3e-2, grad_l2_tol=0.15):
+def check_amp_step(device, opt_kw, level, b=1, seed=61, loss_tol=2e-2, image_tol=5e-2, grad_l2_tol=0.3):
     """One training iteration (D step + G step, Adam included) with `--amp level` against the same iteration in exact fp32:
     the narrow-operand kernels must be the ones running (results differ from fp32) yet stay within the mode's error budget;
     the fp16 mode must carry a loss scale through `loss_backward` and un-scale inside its step."""
