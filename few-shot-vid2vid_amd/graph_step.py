@@ -1,0 +1,196 @@
+"""The body of the reference's training loop (train.py:58-62) as replayable hipGraphs.
+
+    d_losses = model(data_list_t, mode='discriminator');  loss_backward(opt, d_losses, optimizer_D, 1)
+    g_losses, generated, prevs = model(data_list_t, save_images=..., mode='generator');  loss_backward(opt, g_losses, optimizer_G, 0)
+
+Launched eagerly this body is host-bound on the ROCm stack (about 2500 launches per iteration: 116 ms against 67 ms as a graph
+on the C3 bench workload), so a drop-in training loop should not pay for it on every iteration.  `GraphedIteration` keeps one
+captured graph per *signature* of `data_list_t` (which entries are None, the shapes of the others, the save_images flag - the
+first frame of a sequence has no previous frames and therefore its own graph), copies each call's tensors into the static
+input buffers and replays.  The first `warmup` calls of a new signature run eagerly (real iterations on real data; they also
+settle lazily-built caches such as the optimisers' layout tables), the next call captures and replays.
+
+With a process group the step is cut into three graphs around the two whole-buffer gradient all-reduces (the optimisers must
+have been built with `overlap=False`), exactly like bench.py does at N > 1: no collective is captured.
+
+Everything that changes between iterations lives on the device and is read by the captured kernels: learning rate and Adam
+step count (`FlatAdam.state`), loss scale (`FlatAdam.scaler`), BatchNorm / spectral-norm buffers.  Rebuilding the optimisers
+(`init_temporal_model`) or changing the networks invalidates the graphs: call `reset()` (done automatically when the model's
+optimiser objects are no longer the captured ones).
+
+The returned losses / images are the graphs' static output tensors: consume (or clone) them before the next call.
+"""
+import torch
+
+from . import lib
+from . import model as _model
+
+
+def _flat(data_list):
+    out = []
+    for item in data_list:
+        if isinstance(item, (list, tuple)):
+            out.extend(item)
+        else:
+            out.append(item)
+    return out
+
+
+def _like(data_list, flat):
+    it = iter(flat)
+    out = []
+    for item in data_list:
+        if isinstance(item, (list, tuple)):
+            out.append([next(it) for _ in item])
+        else:
+            out.append(next(it))
+    return out
+
+
+class _Entry:
+    def __init__(self):
+        self.static = None          # data_list with static device tensors
+        self.calls = 0
+        self.graphs = None
+        self.outputs = None
+
+
+class GraphedIteration:
+    def __init__(self, model, opt, warmup=2):
+        self.model = getattr(model, 'module', model)
+        self.opt = opt
+        self.warmup = max(int(warmup), 1)
+        self.entries = {}
+        self._bind()
+        # the SIMT-emulated library (CPU test infrastructure) has no graphs: the body is re-run eagerly on the static buffers,
+        # which exercises everything here except the capture itself
+        self._emulated = lib.emu_requested()
+        if not self._emulated and not torch.cuda.is_available():
+            raise RuntimeError("GraphedIteration needs a GPU (hipGraph capture)")
+
+    # ------------------------------------------------------------------------------------------------ bookkeeping
+    def _bind(self):
+        self.opt_G, self.opt_D = self.model.optimizer_G, self.model.optimizer_D
+        if self.opt_G is None or self.opt_D is None:
+            raise RuntimeError("build the optimisers (model.build_optimizers) before graphing the iteration")
+        self.segmented = bool(self.opt_G.exchange)
+        if self.segmented and self.opt_G.overlap:
+            raise RuntimeError("with a process group build the optimisers with overlap=False: bucket hooks issue collectives "
+                               "inside backward, which cannot be captured")
+
+    def reset(self):
+        """drop every captured graph (after init_temporal_model, load_networks, architecture changes)"""
+        self.entries = {}
+        self._bind()
+
+    @staticmethod
+    def _signature(flat, save_images):
+        return (bool(save_images),) + tuple(None if t is None else (tuple(t.shape), t.dtype) for t in flat)
+
+    # ------------------------------------------------------------------------------------------------ the body
+    def _backward(self, losses, optimizer):
+        losses = [torch.mean(x) if not isinstance(x, int) else x for x in losses]
+        loss = sum(losses)
+        optimizer.zero_grad()
+        optimizer.scale_loss(loss).backward()
+        optimizer.finalize_grads()
+        return losses
+
+    def _seg_d(self, e):
+        e.out_d = self._backward(self.model(e.static, mode='discriminator'), self.opt_D)
+
+    def _seg_g(self, e, save_images):
+        self.opt_D.adam()
+        g_losses, generated, prevs = self.model(e.static, save_images=save_images, mode='generator')
+        e.out_g = self._backward(g_losses, self.opt_G)
+        e.out_gen, e.out_prev = generated, prevs
+
+    def _seg_a(self):
+        self.opt_G.adam()
+
+    def _eager(self, e, save_images):
+        self._seg_d(e)
+        if self.segmented:
+            self.opt_D.exchange_all()
+        self._seg_g(e, save_images)
+        if self.segmented:
+            self.opt_G.exchange_all()
+        self._seg_a()
+
+    def _capture(self, e, save_images):
+        dev = self.opt_G.device
+        torch.cuda.synchronize(dev)
+        if not self.segmented:
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self._eager(e, save_images)
+            e.graphs = [g]
+            return
+        # no collective may be pending when a capture starts, and the captures only police their own thread (the RCCL watchdog
+        # polls its events from another one)
+        gs = [torch.cuda.CUDAGraph() for _ in range(3)]
+        with torch.cuda.graph(gs[0], capture_error_mode='thread_local'):
+            self._seg_d(e)
+        gs[0].replay(); self.opt_D.exchange_all()
+        torch.cuda.synchronize(dev)
+        with torch.cuda.graph(gs[1], pool=gs[0].pool(), capture_error_mode='thread_local'):
+            self._seg_g(e, save_images)
+        gs[1].replay(); self.opt_G.exchange_all()
+        torch.cuda.synchronize(dev)
+        with torch.cuda.graph(gs[2], pool=gs[0].pool(), capture_error_mode='thread_local'):
+            self._seg_a()
+        gs[2].replay()
+        e.graphs = gs
+        e.replayed_by_capture = True
+
+    def _replay(self, e):
+        if len(e.graphs) == 1:
+            e.graphs[0].replay()
+        else:
+            e.graphs[0].replay(); self.opt_D.exchange_all()
+            e.graphs[1].replay(); self.opt_G.exchange_all()
+            e.graphs[2].replay()
+
+    # ------------------------------------------------------------------------------------------------ call
+    def __call__(self, data_list, save_images=False):
+        """one iteration; returns (d_losses, g_losses, generated, prevs_new) like the two model calls of train.py:58-62"""
+        if self.model.optimizer_G is not self.opt_G or self.model.optimizer_D is not self.opt_D:
+            self.reset()
+        flat = _flat(data_list)
+        key = self._signature(flat, save_images)
+        e = self.entries.get(key)
+        if e is None:
+            e = self.entries[key] = _Entry()
+            dev = self.opt_G.device
+            e.static = _like(data_list, [None if t is None else t.detach().to(dev).clone() for t in flat])
+        else:
+            for dst, src in zip(_flat(e.static), flat):
+                if dst is not None:
+                    dst.copy_(src, non_blocking=True)
+        e.calls += 1
+        if self._emulated or e.calls <= self.warmup:
+            if not self._emulated and e.calls == 1:
+                # warm-up runs on a side stream so that allocations made now do not end up in the capture's private pool
+                s = torch.cuda.Stream(self.opt_G.device)
+                s.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(s):
+                    self._eager(e, save_images)
+                torch.cuda.current_stream().wait_stream(s)
+            else:
+                self._eager(e, save_images)
+        elif e.graphs is None:
+            e.replayed_by_capture = False
+            self._capture(e, save_images)
+            if not e.replayed_by_capture:
+                self._replay(e)
+        else:
+            self._replay(e)
+        return e.out_d, e.out_g, e.out_gen, e.out_prev
+
+
+def graphed_iteration(model, opt, warmup=2):
+    """convenience: `step = graphed_iteration(model, opt); d, g, generated, prevs = step(data_list_t, save_images)`"""
+    return GraphedIteration(model, opt, warmup)
+
+
+loss_backward = _model.loss_backward      # the eager counterpart, for loops that mix both

@@ -1,0 +1,65 @@
+"""GraphedIteration (few-shot-vid2vid_amd/graph_step.py) against the plain eager loop of train.py:58-62: same losses, images and
+weights over several iterations with changing data and changing learning rate.  Under the emulator the "graph" is an eager
+re-run on the static buffers (buffer plumbing only); run as a script on a GPU it captures and replays real hipGraphs."""
+import torch
+
+import model_checks as mc
+
+
+def _run(device, graphed, iters, seed, opt_kw, b=1):
+    from importlib import import_module
+    M = mc._model()
+    gs = import_module('few-shot-vid2vid_amd.graph_step')
+    opt = mc.tiny_opt(**opt_kw)
+    model = M.create_model(opt)
+    mc.fill_state(model.netG); mc.fill_state(model.netD)
+    model = model.to(device).train()
+    opt_G, opt_D = model.build_optimizers()
+    step = gs.GraphedIteration(model, opt, warmup=2) if graphed else None
+    h, w = int(opt.fineSize / opt.aspect_ratio), opt.fineSize
+    log = []
+    for it in range(iters):
+        tl, ti, rl, ri = mc.synth_pose_inputs(b, h, w, seed + it, opt.input_nc)
+        data = [tl, ti, [None, None], [None, None], rl, ri, None, None, None]
+        if it == iters - 2:
+            opt_G.set_lr(1e-5); opt_D.set_lr(3e-5)               # the device-side lr must reach a replayed graph
+        if graphed:
+            d, g, gen, prev = step(data, save_images=True)
+        else:
+            data = [None if t is None else ([x if x is None else x.to(device) for x in t] if isinstance(t, list) else t.to(device))
+                    for t in data]
+            d = M.loss_backward(opt, model(data, mode='discriminator'), opt_D, 1)
+            g, gen, prev = model(data, save_images=True, mode='generator')
+            g = M.loss_backward(opt, g, opt_G, 0)
+        log.append(dict(d=[float(x.detach()) for x in d], g=[float(x.detach()) for x in g if not isinstance(x, int)],
+                        img=gen[0].detach().clone().cpu()))
+    return log, opt_G.flat_p.detach().clone().cpu(), opt_D.flat_p.detach().clone().cpu(), step
+
+
+def check_graphed_iteration(device, iters=5, seed=500, tol=0.0):
+    kw = dict(warp_ref=True, spade_combine=True, remove_face_labels=True)
+    ref, pG, pD, _ = _run(device, False, iters, seed, kw)
+    got, qG, qD, step = _run(device, True, iters, seed, kw)
+    assert len(step.entries) == 1
+    for it, (a, b) in enumerate(zip(ref, got)):
+        for k in ('d', 'g'):
+            for x, y in zip(a[k], b[k]):
+                assert abs(x - y) <= tol * max(abs(x), 1.0) + 0.0, (it, k, a[k], b[k])
+        assert float((a['img'] - b['img']).abs().max()) <= tol * 2.0 + 0.0, it
+    assert float((pG - qG).abs().max()) <= tol and float((pD - qD).abs().max()) <= tol
+    return step
+
+
+if __name__ == '__main__':
+    dev = torch.device('cuda', 0)
+    # atomics (split-K, scatter-add) make GPU runs differ in the last bits from run to run, and Adam turns a rounding-level
+    # gradient difference into a +-lr step: compare losses / images loosely and not the weights
+    kw = dict(warp_ref=True, spade_combine=True, remove_face_labels=True)
+    ref, _, _, _ = _run(dev, False, 5, 500, kw)
+    got, _, _, step = _run(dev, True, 5, 500, kw)
+    assert any(e.graphs is not None for e in step.entries.values()), "nothing was captured"
+    for it, (a, b) in enumerate(zip(ref, got)):
+        for k in ('d', 'g'):
+            for x, y in zip(a[k], b[k]):
+                assert abs(x - y) <= 5e-2 * max(abs(x), 1.0), (it, k, a[k], b[k])
+    print('GRAPH_STEP_GPU_OK', flush=True)

@@ -34,3 +34,15 @@ def test_experimental_tiles_on_hardware():
     sys.stdout.write(r.stdout[-4000:])
     sys.stderr.write(r.stderr[-4000:])
     assert r.returncode == 0 and 'TILES_GPU_OK' in r.stdout
+
+
+@pytest.mark.gpu
+@pytest.mark.xfail(strict=False, reason="GraphedIteration's hipGraph capture not yet validated on MI355X (plumbing emulator-verified)")
+def test_graphed_iteration_on_hardware():
+    env = dict(os.environ)
+    env.pop('FSV2V_EMU', None)
+    r = subprocess.run([sys.executable, os.path.join(HERE, 'graph_step_checks.py')], cwd=HERE, env=env, capture_output=True,
+                       text=True, timeout=600)
+    sys.stdout.write(r.stdout[-4000:])
+    sys.stderr.write(r.stderr[-4000:])
+    assert r.returncode == 0 and 'GRAPH_STEP_GPU_OK' in r.stdout

@@ -16,7 +16,7 @@ run() {  # name, seconds, command...
   timeout "$secs" "$@" > "$OUT/$name.log" 2>&1
   echo "   exit $? ($(tail -n 1 "$OUT/$name.log" | cut -c1-300))" | tee -a "$OUT/summary.txt"
 }
-run pytest_new      420 python -m pytest tests/test_zz_np_gpu.py -q -m gpu -rxX
+run pytest_new      900 python -m pytest tests/test_zz_np_gpu.py -q -m gpu -rxX
 run pytest_all      600 python -m pytest tests -x -q -m gpu -rxX
 run np_ab           240 python tools/np_ab.py
 run tile_ab         300 python tools/tile_ab.py "M8192 N256 K2304" "M32768 N128 K1152" "M2048 N512 K2304" "M8192 N128 K512" "M32768 N64 K256" "M131072 N128 K576" "M512 N1024 K4608"
