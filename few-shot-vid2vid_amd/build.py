@@ -70,6 +70,14 @@ def build_hip(force=False, verbose=False):
     if force or jobs or not os.path.exists(HIP_LIB) or _current("hip") != _digest(objs):
         _run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", HIP_LIB] + objs)
         _set_current("hip", _digest(objs))
+    # objects of older source revisions are dead weight (the directory travels with every gpurun snapshot)
+    keep = set(objs)
+    for old in glob.glob(os.path.join(OBJ_DIR, "*.hip.*.o")):
+        if old not in keep:
+            try:
+                os.remove(old)
+            except OSError:
+                pass
     return HIP_LIB
 
 
