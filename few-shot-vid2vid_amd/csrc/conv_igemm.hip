@@ -520,12 +520,13 @@ static int fsv_launch_conv(const ConvP& p, int M_tiles_rows, int nz, hipStream_t
         FSV_LAUNCH((fsv_conv_igemm_kernel<64, 128, 1, 2, 4>), g, dim3(128), stream, p); return fsv_check_launch(); }
       case 12: { dim3 g(fsv_cdiv(M_tiles_rows, 128), fsv_cdiv(p.Cout, 64), nz);
         FSV_LAUNCH((fsv_conv_igemm_kernel<128, 64, 2, 1, 4>), g, dim3(128), stream, p); return fsv_check_launch(); }
-      case 13: case 14: case 15: return fsv_launch_conv_db(p, nz, stream, tile);      // double-buffered LDS (conv_igemm_db.hip)
+      case 13: case 14: case 15: case 16: case 17: case 18:      // double-buffered LDS, prefetch distance 1 / 2 (conv_igemm_db.hip)
+        return fsv_launch_conv_db(p, nz, stream, tile);
       default: break;
     }
   }
-  if (tile == 9 || tile == 10 || tile == 11 || tile == 13 || tile == 14) tile = 4;      // scalar-gather layers (Cin % 4 != 0): only the basic tiles are instantiated
-  if (tile == 12 || tile == 15) tile = 1;
+  if (tile == 9 || tile == 10 || tile == 11 || tile == 13 || tile == 14 || tile == 16 || tile == 17) tile = 4;      // scalar-gather layers (Cin % 4 != 0): only the basic tiles are instantiated
+  if (tile == 12 || tile == 15 || tile == 18) tile = 1;
   switch (tile) {
     case 0: { dim3 g(fsv_cdiv(M_tiles_rows, 128), fsv_cdiv(p.Cout, 128), nz);
       FSV_LAUNCH((fsv_conv_igemm_kernel<128, 128, 2, 2, V>), g, block, stream, p); break; }
@@ -543,9 +544,9 @@ static int fsv_launch_conv(const ConvP& p, int M_tiles_rows, int nz, hipStream_t
 }
 
 static inline int fsv_tile_dims(int tile, int& bm, int& bn) {
-  static const int BMs[16] = {128, 128, 128, 256, 64, 256, 128, 256, 256, 64, 64, 64, 128, 64, 64, 128},
-                   BNs[16] = {128, 64, 32, 32, 64, 128, 256, 256, 64, 128, 64, 128, 64, 64, 128, 64};
-  if (tile < 0 || tile > 15) return -1;
+  static const int BMs[19] = {128, 128, 128, 256, 64, 256, 128, 256, 256, 64, 64, 64, 128, 64, 64, 128, 64, 64, 128},
+                   BNs[19] = {128, 64, 32, 32, 64, 128, 256, 256, 64, 128, 64, 128, 64, 64, 128, 64, 64, 128, 64};
+  if (tile < 0 || tile > 18) return -1;
   bm = BMs[tile]; bn = BNs[tile];
   return 0;
 }

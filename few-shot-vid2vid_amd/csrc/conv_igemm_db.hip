@@ -8,9 +8,11 @@
 // Experimental: reachable only through force_tile (ids 13 / 14 / 15) until an A/B on the hardware says where it pays
 // (tools/tile_ab.py).  float4-gather layers only (Cin % 4 == 0).
 #include "conv_igemm.h"
+#include <type_traits>
 
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, int PF>
 __global__ __launch_bounds__(64 * WM * WN) void fsv_conv_igemm_db_kernel(ConvP p) {
+  static_assert(PF == 1 || PF == 2, "prefetch distance");
   constexpr int BK = FSV_BK;
   constexpr int NT = 64 * WM * WN;
   constexpr int TM = BM / (WM * 32), TN = BN / (WN * 32);
@@ -60,10 +62,11 @@ __global__ __launch_bounds__(64 * WM * WN) void fsv_conv_igemm_db_kernel(ConvP p
   const int c_begin = zk * cps;
   const int c_end = (c_begin + cps < p.nchunks) ? (c_begin + cps) : p.nchunks;
 
-  float areg[NPA][4];
-  float4 breg[NPB];
+  float areg[PF][NPA][4];       // PF register stages: chunk j waits in stage (j - c_begin) % PF until it is stored to LDS
+  float4 breg[PF][NPB];
 
-  auto load_chunk = [&](int kc) {
+  auto load_chunk = [&](int kc, auto stage) {
+    constexpr int S = decltype(stage)::value;
     const int k = kc * BK + kq * 4;
     const bool kok = k < p.K;
     int t = kok ? (k / p.Cin) : 0;
@@ -76,28 +79,29 @@ __global__ __launch_bounds__(64 * WM * WN) void fsv_conv_igemm_db_kernel(ConvP p
       bool ok = kok && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
       long long off = ok ? ((a_base[i] + (long long)iy * p.W + ix) * p.Cin + ci) : 0ll;
       float4 v = *reinterpret_cast<const float4*>(p.in + off);
-      areg[i][0] = ok ? v.x : 0.f; areg[i][1] = ok ? v.y : 0.f; areg[i][2] = ok ? v.z : 0.f; areg[i][3] = ok ? v.w : 0.f;
+      areg[S][i][0] = ok ? v.x : 0.f; areg[S][i][1] = ok ? v.y : 0.f; areg[S][i][2] = ok ? v.z : 0.f; areg[S][i][3] = ok ? v.w : 0.f;
     }
 #pragma unroll
     for (int i = 0; i < NPB; ++i) {
       int kr = kc * BK + br0 + i * RPB;
       float4 v = *reinterpret_cast<const float4*>(wt + (long long)kr * p.ldw + bcol_safe);
-      breg[i] = bcol_ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+      breg[S][i] = bcol_ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
     }
   };
-  auto store_chunk = [&](int buf) {
+  auto store_chunk = [&](int buf, auto stage) {
+    constexpr int S = decltype(stage)::value;
     float* as = As + buf * ASZ;
     float* bs = Bs + buf * BSZ;
 #pragma unroll
     for (int i = 0; i < NPA; ++i) {
       int r = ar0 + i * RPP;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) as[(kq * 4 + j) * LDA + r] = areg[i][j];
+      for (int j = 0; j < 4; ++j) as[(kq * 4 + j) * LDA + r] = areg[S][i][j];
     }
 #pragma unroll
     for (int i = 0; i < NPB; ++i) {
       int kr = br0 + i * RPB;
-      *reinterpret_cast<float4*>(&bs[kr * BN + bq * 4]) = breg[i];
+      *reinterpret_cast<float4*>(&bs[kr * BN + bq * 4]) = breg[S][i];
     }
   };
 
@@ -112,40 +116,67 @@ __global__ __launch_bounds__(64 * WM * WN) void fsv_conv_igemm_db_kernel(ConvP p
   const int lrow = lane & 31, lk = lane >> 5;
   const int a_off = lk * LDA + wm * (TM * 32) + lrow;
   const int b_off = lk * BN + wn * (TN * 32) + lrow;
-  if (c_begin < c_end) {
-    load_chunk(c_begin);
-    store_chunk(0);
-    __syncthreads();
-#pragma unroll 1
-    for (int kc = c_begin; kc < c_end; ++kc) {
-      const int cur = (kc - c_begin) & 1;
-      const bool more = kc + 1 < c_end;
-      // the last iteration re-reads its own chunk (no per-lane branch around the loads); that copy is never stored
-      load_chunk(more ? kc + 1 : kc);
-      const float* a_frag = As + cur * ASZ + a_off;
-      const float* b_frag = Bs + cur * BSZ + b_off;
-      float a[2][TM], b[2][TN];
+  auto compute = [&](int cur) {
+    const float* a_frag = As + cur * ASZ + a_off;
+    const float* b_frag = Bs + cur * BSZ + b_off;
+    float a[2][TM], b[2][TN];
 #pragma unroll
-      for (int i = 0; i < TM; ++i) a[0][i] = a_frag[i * 32];
+    for (int i = 0; i < TM; ++i) a[0][i] = a_frag[i * 32];
 #pragma unroll
-      for (int j = 0; j < TN; ++j) b[0][j] = b_frag[j * 32];
+    for (int j = 0; j < TN; ++j) b[0][j] = b_frag[j * 32];
 #pragma unroll
-      for (int kk = 0; kk < BK / 2; ++kk) {
-        const int c = kk & 1, nx = c ^ 1;
-        if (kk + 1 < BK / 2) {
+    for (int kk = 0; kk < BK / 2; ++kk) {
+      const int c = kk & 1, nx = c ^ 1;
+      if (kk + 1 < BK / 2) {
 #pragma unroll
-          for (int i = 0; i < TM; ++i) a[nx][i] = a_frag[(kk + 1) * 2 * LDA + i * 32];
+        for (int i = 0; i < TM; ++i) a[nx][i] = a_frag[(kk + 1) * 2 * LDA + i * 32];
 #pragma unroll
-          for (int j = 0; j < TN; ++j) b[nx][j] = b_frag[(kk + 1) * 2 * BN + j * 32];
-        }
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-          for (int j = 0; j < TN; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[c][i], b[c][j], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < TN; ++j) b[nx][j] = b_frag[(kk + 1) * 2 * BN + j * 32];
       }
-      if (more) store_chunk(cur ^ 1);       // uniform over the workgroup
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[c][i], b[c][j], acc[i][j], 0, 0, 0);
+    }
+  };
+  using S0 = std::integral_constant<int, 0>;
+  using S1 = std::integral_constant<int, PF - 1>;
+  if (c_begin < c_end) {
+    const int c_last = c_end - 1;
+    load_chunk(c_begin, S0());
+    store_chunk(0, S0());
+    if constexpr (PF == 1) {
       __syncthreads();
+#pragma unroll 1
+      for (int kc = c_begin; kc < c_end; ++kc) {
+        const int cur = (kc - c_begin) & 1;
+        const bool more = kc + 1 < c_end;
+        // the last iteration re-reads its own chunk (no per-lane branch around the loads); that copy is never stored
+        load_chunk(more ? kc + 1 : kc, S0());
+        compute(cur);
+        if (more) store_chunk(cur ^ 1, S0());       // uniform over the workgroup
+        __syncthreads();
+      }
+    } else {
+      // prefetch distance 2: the global loads of chunk c+2 are issued before the MFMAs of chunk c, so they have two chunks of
+      // matrix work (about 2 us) to arrive - what a lone workgroup on a CU needs to ride out an HBM miss.  Chunk j waits in
+      // register stage (j - c_begin) & 1 and is stored into LDS image (j - c_begin) & 1 one iteration before it is multiplied.
+      // Loads and stores past the last chunk repeat it (valid addresses, an image nobody reads any more): no branches.
+      load_chunk(c_begin + 1 < c_end ? c_begin + 1 : c_last, S1());
+      __syncthreads();
+#pragma unroll 1
+      for (int kc = c_begin; kc < c_end; kc += 2) {
+        load_chunk(kc + 2 < c_end ? kc + 2 : c_last, S0());
+        compute(0);
+        store_chunk(1, S1());
+        __syncthreads();
+        if (kc + 1 >= c_end) break;                    // uniform
+        load_chunk(kc + 3 < c_end ? kc + 3 : c_last, S1());
+        compute(1);
+        store_chunk(0, S0());
+        __syncthreads();
+      }
     }
   }
 
@@ -191,11 +222,18 @@ int fsv_launch_conv_db(const ConvP& p, int nz, hipStream_t stream, int tile) {
   dim3 block(256);
   switch (tile) {
     case 13: { dim3 g(fsv_cdiv(p.Mz, 64), fsv_cdiv(p.Cout, 64), nz);
-      FSV_LAUNCH((fsv_conv_igemm_db_kernel<64, 64, 2, 2>), g, block, stream, p); break; }
+      FSV_LAUNCH((fsv_conv_igemm_db_kernel<64, 64, 2, 2, 1>), g, block, stream, p); break; }
     case 14: { dim3 g(fsv_cdiv(p.Mz, 64), fsv_cdiv(p.Cout, 128), nz);
-      FSV_LAUNCH((fsv_conv_igemm_db_kernel<64, 128, 2, 2>), g, block, stream, p); break; }
+      FSV_LAUNCH((fsv_conv_igemm_db_kernel<64, 128, 2, 2, 1>), g, block, stream, p); break; }
     case 15: { dim3 g(fsv_cdiv(p.Mz, 128), fsv_cdiv(p.Cout, 64), nz);
-      FSV_LAUNCH((fsv_conv_igemm_db_kernel<128, 64, 2, 2>), g, block, stream, p); break; }
+      FSV_LAUNCH((fsv_conv_igemm_db_kernel<128, 64, 2, 2, 1>), g, block, stream, p); break; }
+    // 16 / 17 / 18: the same three tiles with the global loads issued two chunks ahead (two register stages)
+    case 16: { dim3 g(fsv_cdiv(p.Mz, 64), fsv_cdiv(p.Cout, 64), nz);
+      FSV_LAUNCH((fsv_conv_igemm_db_kernel<64, 64, 2, 2, 2>), g, block, stream, p); break; }
+    case 17: { dim3 g(fsv_cdiv(p.Mz, 64), fsv_cdiv(p.Cout, 128), nz);
+      FSV_LAUNCH((fsv_conv_igemm_db_kernel<64, 128, 2, 2, 2>), g, block, stream, p); break; }
+    case 18: { dim3 g(fsv_cdiv(p.Mz, 128), fsv_cdiv(p.Cout, 64), nz);
+      FSV_LAUNCH((fsv_conv_igemm_db_kernel<128, 64, 2, 2, 2>), g, block, stream, p); break; }
     default: return FSV_ERR_BAD_ARG;
   }
   return fsv_check_launch();
