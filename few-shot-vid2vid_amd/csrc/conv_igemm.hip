@@ -553,6 +553,7 @@ static inline int fsv_tile_dims(int tile, int& bm, int& bn) {
 
 
 #include <stdlib.h>
+#include <string.h>
 static inline long long fsv_tune(int which) {
   static long long vals[4] = {-1, -1, -1, -1};
   if (vals[0] < 0) {
@@ -648,6 +649,29 @@ extern "C" int fsv_conv_plan(int Mz, int Cout, int nchunks, int nsamp, int force
 
 static inline bool vec4_ok(int cin) { return (cin & 3) == 0; }
 
+// FSV_TILE_REMAP="4:13,9:14,1:15": run the launches the plan gives to tile a with tile b of the same shape instead (whole-step
+// A/B of the experimental variants without touching the plan; split-K factors stay those of the planned tile)
+static inline int fsv_tile_remap(int tile) {
+  static int map[19];
+  static int ready = 0;
+  if (!ready) {
+    for (int i = 0; i < 19; ++i) map[i] = i;
+    const char* e = getenv("FSV_TILE_REMAP");
+    while (e && *e) {
+      int a = atoi(e);
+      const char* c = strchr(e, ':');
+      if (!c) break;
+      int b = atoi(c + 1);
+      int am, an, bm, bn;
+      if (!fsv_tile_dims(a, am, an) && !fsv_tile_dims(b, bm, bn) && am == bm && an == bn) map[a] = b;
+      e = strchr(c, ',');
+      if (e) ++e;
+    }
+    ready = 1;
+  }
+  return (tile >= 0 && tile < 19) ? map[tile] : tile;
+}
+
 extern "C" {
 
 // Generic gather-GEMM (see header comment and include/fsv2v.h: fsv_conv_gather_fwd).
@@ -677,6 +701,7 @@ int fsv_conv_gather_fwd(const float* in, const float* wt, const float* bias, con
   int tile = 0, nsplit = 1;
   if (fsv_conv_plan(p.Mz, Cout, p.nchunks, nsamp, force_tile, force_split, &tile, &nsplit)) return FSV_ERR_BAD_ARG;
   p.nsplit = nsplit;
+  if (force_tile < 0) tile = fsv_tile_remap(tile);
   const long long total = (long long)N * outH * outW * Cout;
   // accumulate != 0: `out` was zeroed by the caller and partial results are added atomically (used by the
   // four parity-class launches of a stride-2 data gradient); bias/act/res are not applied in that mode.
@@ -757,6 +782,12 @@ int fsv_conv_wgrad(const float* in, const float* dout, float* dwt,
     // FLOP than the same workgroup count of split 128x128 tiles, and every CU gets several workgroups
     if (Cout >= 128 && p.K >= 2304 && p.pchunks >= 64) { bmk = 64; bn = 128; target = 1024; }
     else { bmk = 64; bn = 64; target = 2048; }
+  }
+  // FSV_WGRAD_VARIANT=db | fw: run the automatically chosen 64-row tiles as their double-buffered / few-wave variants
+  if (force_tile == 0 && vec4_ok(Cin) && bmk == 64 && (bn == 64 || bn == 128)) {
+    static int variant = -1;
+    if (variant < 0) { const char* e = getenv("FSV_WGRAD_VARIANT"); variant = !e ? 0 : (!strcmp(e, "db") ? 1 : (!strcmp(e, "fw") ? 2 : 0)); }
+    if (variant == 1) dbuf = 1; else if (variant == 2) few_waves = 1;
   }
   long long blocks = (long long)fsv_cdiv(p.K, bmk) * fsv_cdiv(Cout, bn) * nsamp;
   int nsplit = 1;
