@@ -22,15 +22,16 @@
 //     pixel in the weight-gradient kernel) and is transposed on the way in: a work-item owns two consecutive k of four
 //     consecutive rows and writes four packed pairs, with the 16 k-pairs of a chunk on consecutive lanes.  A 32-lane store group
 //     then covers the 16 dwords of two rows of equal parity: 2-way, which a 4-byte LDS store absorbs (same section).
-// Both tiles are double-buffered (two LDS images, 16-64 KB per workgroup): a K chunk of 8 (x3) MFMAs per wave is short, so it
-// pays for ONE barrier instead of two - the staging registers of chunk c+1 are stored into the idle image while chunk c is
-// still being multiplied by the slower waves.
+// Both tiles are double-buffered (two LDS images, 16-48 KB per workgroup) and the global loads run two chunks ahead (two
+// register stages): a K chunk of 8 (x3) MFMAs per wave is short, so it pays for ONE barrier instead of two - chunk c+1 is stored
+// into the idle image while chunk c is still being multiplied by the slower waves, and chunk c+2 is already in flight.
 // The k <-> (lane, element) assignment inside one MFMA is the same for A and B, so the sum over k does not depend on it; the
 // C/D layout is the dtype-independent 32x32 map already used by the fp32 kernels.
 //
 // Entry points mirror fsv_conv_gather_fwd / fsv_conv_wgrad with one extra `mode` argument and only accept what the
 // narrow kernels implement (Cin % 4 == 0); callers route everything else to the fp32 entry points.
 #include "fsv_common.h"
+#include <type_traits>
 
 #define FSV_NP_BK 32
 #define FSV_NP_LDK 32   // elements per LDS row (64 bytes, slots swizzled by np_sw)
@@ -66,6 +67,47 @@ __device__ __forceinline__ int np_sw(int row, int k) {
   return row * FSV_NP_LDK + ((((k >> 3) ^ (row >> 2)) & 3) << 3) + (k & 7);
 }
 
+// v or zeros, component by component (a ?: between two float4 STRUCTS makes the compiler keep a zero struct in scratch memory
+// and select between addresses)
+__device__ __forceinline__ float4 np_keep(bool ok, const float4& v) {
+  return make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f);
+}
+
+// four values -> 4-element hi / lo vectors; two values -> a packed pair (no local arrays: they would live in scratch memory)
+template <int MODE>
+__device__ __forceinline__ void np_split4(const float4& v, typename NpTypes<MODE>::H4& hi, typename NpTypes<MODE>::H4& lo) {
+  typename NpTypes<MODE>::H h0, l0, h1, l1, h2, l2, h3, l3;
+  np_split<MODE>(v.x, h0, l0); np_split<MODE>(v.y, h1, l1); np_split<MODE>(v.z, h2, l2); np_split<MODE>(v.w, h3, l3);
+  hi = typename NpTypes<MODE>::H4{h0, h1, h2, h3};
+  lo = typename NpTypes<MODE>::H4{l0, l1, l2, l3};
+}
+template <int MODE>
+__device__ __forceinline__ void np_pair(float a, float b, typename NpTypes<MODE>::H2& hi, typename NpTypes<MODE>::H2& lo) {
+  typename NpTypes<MODE>::H h0, l0, h1, l1;
+  np_split<MODE>(a, h0, l0); np_split<MODE>(b, h1, l1);
+  hi = typename NpTypes<MODE>::H2{h0, h1};
+  lo = typename NpTypes<MODE>::H2{l0, l1};
+}
+// the four packed pairs of two float4 (same channels, two consecutive k) into rows row0 .. row0+3 at column k of plane images
+template <int MODE, int NP, int ROWLEN>
+__device__ __forceinline__ void np_store_pairs(typename NpTypes<MODE>::H (*img)[ROWLEN], const float4& v0, const float4& v1,
+                                               int row0, int k) {
+  typedef typename NpTypes<MODE>::H2 H2;
+  H2 hi, lo;
+  np_pair<MODE>(v0.x, v1.x, hi, lo);
+  *reinterpret_cast<H2*>(&img[0][np_sw(row0 + 0, k)]) = hi;
+  if constexpr (NP == 2) *reinterpret_cast<H2*>(&img[NP - 1][np_sw(row0 + 0, k)]) = lo;
+  np_pair<MODE>(v0.y, v1.y, hi, lo);
+  *reinterpret_cast<H2*>(&img[0][np_sw(row0 + 1, k)]) = hi;
+  if constexpr (NP == 2) *reinterpret_cast<H2*>(&img[NP - 1][np_sw(row0 + 1, k)]) = lo;
+  np_pair<MODE>(v0.z, v1.z, hi, lo);
+  *reinterpret_cast<H2*>(&img[0][np_sw(row0 + 2, k)]) = hi;
+  if constexpr (NP == 2) *reinterpret_cast<H2*>(&img[NP - 1][np_sw(row0 + 2, k)]) = lo;
+  np_pair<MODE>(v0.w, v1.w, hi, lo);
+  *reinterpret_cast<H2*>(&img[0][np_sw(row0 + 3, k)]) = hi;
+  if constexpr (NP == 2) *reinterpret_cast<H2*>(&img[NP - 1][np_sw(row0 + 3, k)]) = lo;
+}
+
 struct NpConvP {
   const float* in;
   const float* wt;
@@ -94,7 +136,7 @@ __device__ __forceinline__ void np_tap(unsigned long long lo, unsigned long long
 
 // out[z][m][co] = sum_k in[gather(m, k)] * wt[z][k][co]; same contract as fsv_conv_igemm_kernel (V = 4 gathers only)
 template <int BM, int BN, int WM, int WN, int MODE>
-__global__ __launch_bounds__(64 * WM * WN) void fsv_np_conv_kernel(NpConvP p) {
+__global__ __launch_bounds__(64 * WM * WN, 2) void fsv_np_conv_kernel(NpConvP p) {
   typedef NpTypes<MODE> T;
   typedef typename T::H H;
   typedef typename T::H8 H8;
@@ -146,11 +188,13 @@ __global__ __launch_bounds__(64 * WM * WN) void fsv_np_conv_kernel(NpConvP p) {
   const int c_begin = zk * cps;
   const int c_end = (c_begin + cps < p.nchunks) ? (c_begin + cps) : p.nchunks;
 
-  float4 areg[NPA];
-  float4 breg[NPB][2];
-  const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  // two register stages: the global loads of chunk c+2 are issued before the MFMAs of chunk c (a chunk is only 8 (x3) MFMAs
+  // per wave = 0.1-0.3 us of matrix work, far less than an HBM miss); chunk j waits in stage (j - c_begin) & 1
+  float4 areg[2][NPA];
+  float4 breg[2][NPB][2];
 
-  auto load_chunk = [&](int kc) {
+  auto load_chunk = [&](int kc, auto stage) {
+    constexpr int S = decltype(stage)::value;
     const int k = kc * BK + kq * 4;
     const bool kok = k < p.K;
     int t = kok ? (k / p.Cin) : 0;
@@ -163,7 +207,7 @@ __global__ __launch_bounds__(64 * WM * WN) void fsv_np_conv_kernel(NpConvP p) {
       bool ok = kok && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
       long long off = ok ? ((a_base[i] + (long long)iy * p.W + ix) * p.Cin + ci) : 0ll;
       float4 v = *reinterpret_cast<const float4*>(p.in + off);
-      areg[i] = ok ? v : zero4;
+      areg[S][i] = np_keep(ok, v);
     }
     const long long krow = (long long)(kc * BK + 2 * bkp) * p.ldw;
 #pragma unroll
@@ -173,38 +217,26 @@ __global__ __launch_bounds__(64 * WM * WN) void fsv_np_conv_kernel(NpConvP p) {
       const int bcol_safe = bcol_ok ? bcol : 0;
       float4 v0 = *reinterpret_cast<const float4*>(wt + krow + bcol_safe);
       float4 v1 = *reinterpret_cast<const float4*>(wt + krow + p.ldw + bcol_safe);
-      breg[i][0] = bcol_ok ? v0 : zero4;
-      breg[i][1] = bcol_ok ? v1 : zero4;
+      breg[S][i][0] = np_keep(bcol_ok, v0);
+      breg[S][i][1] = np_keep(bcol_ok, v1);
     }
   };
-  auto store_chunk = [&](int buf) {
+  auto store_chunk = [&](int buf, auto stage) {
+    constexpr int S = decltype(stage)::value;
     H (*as)[BM * LDK] = As + buf * NP;
     H (*bs)[BN * LDK] = Bs + buf * NP;
 #pragma unroll
     for (int i = 0; i < NPA; ++i) {
       const int r = ar0 + i * RPP;
-      const float v[4] = {areg[i].x, areg[i].y, areg[i].z, areg[i].w};
       H4 hi, lo;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) { H h, l; np_split<MODE>(v[j], h, l); hi[j] = h; lo[j] = l; }
+      np_split4<MODE>(areg[S][i], hi, lo);
       *reinterpret_cast<H4*>(&as[0][np_sw(r, kq * 4)]) = hi;
       if constexpr (NP == 2) *reinterpret_cast<H4*>(&as[NP - 1][np_sw(r, kq * 4)]) = lo;
     }
 #pragma unroll
     for (int i = 0; i < NPB; ++i) {
       const int row0 = (bq0 + i * QPB) * 4;
-      const float v0[4] = {breg[i][0].x, breg[i][0].y, breg[i][0].z, breg[i][0].w};
-      const float v1[4] = {breg[i][1].x, breg[i][1].y, breg[i][1].z, breg[i][1].w};
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        H h0, l0, h1, l1;
-        np_split<MODE>(v0[j], h0, l0);
-        np_split<MODE>(v1[j], h1, l1);
-        H2 hi, lo;
-        hi[0] = h0; hi[1] = h1; lo[0] = l0; lo[1] = l1;
-        *reinterpret_cast<H2*>(&bs[0][np_sw(row0 + j, 2 * bkp)]) = hi;
-        if constexpr (NP == 2) *reinterpret_cast<H2*>(&bs[NP - 1][np_sw(row0 + j, 2 * bkp)]) = lo;
-      }
+      np_store_pairs<MODE, NP, BN * LDK>(bs, breg[S][i][0], breg[S][i][1], row0, 2 * bkp);
     }
   };
 
@@ -218,41 +250,52 @@ __global__ __launch_bounds__(64 * WM * WN) void fsv_np_conv_kernel(NpConvP p) {
 
   const int lrow = lane & 31, lk = lane >> 5;
   const int a_row = wm * (TM * 32) + lrow, b_row = wn * (TN * 32) + lrow;
+  auto compute = [&](int cur) {
+    const H (*as)[BM * LDK] = As + cur * NP;
+    const H (*bs)[BN * LDK] = Bs + cur * NP;
+#pragma unroll
+    for (int ks = 0; ks < BK / 16; ++ks) {
+      H8 a[NP][TM], b[NP][TN];
+#pragma unroll
+      for (int q = 0; q < NP; ++q) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) a[q][i] = *reinterpret_cast<const H8*>(&as[q][np_sw(a_row + i * 32, ks * 16 + lk * 8)]);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) b[q][j] = *reinterpret_cast<const H8*>(&bs[q][np_sw(b_row + j * 32, ks * 16 + lk * 8)]);
+      }
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          if constexpr (NP == 2) {
+            acc[i][j] = np_mfma(a[NP - 1][i], b[0][j], acc[i][j]);
+            acc[i][j] = np_mfma(a[0][i], b[NP - 1][j], acc[i][j]);
+          }
+          acc[i][j] = np_mfma(a[0][i], b[0][j], acc[i][j]);
+        }
+    }
+  };
+  using S0 = std::integral_constant<int, 0>;
+  using S1 = std::integral_constant<int, 1>;
   if (c_begin < c_end) {
-    load_chunk(c_begin);
-    store_chunk(0);
+    // Chunk j is stored into LDS image (j - c_begin) & 1 one iteration before it is multiplied; the image being filled was
+    // last read before the previous barrier.  Loads and stores past the last chunk repeat it (valid addresses, an image that
+    // nobody reads any more), so the loop body has no branch around memory operations.
+    const int c_last = c_end - 1;
+    load_chunk(c_begin, S0());
+    store_chunk(0, S0());
+    load_chunk(c_begin + 1 < c_end ? c_begin + 1 : c_last, S1());
     __syncthreads();
 #pragma unroll 1
-    for (int kc = c_begin; kc < c_end; ++kc) {
-      const int cur = (kc - c_begin) & 1;
-      const bool more = kc + 1 < c_end;
-      // the last iteration re-reads its own chunk (no per-lane branch around the loads); that copy is never stored
-      load_chunk(more ? kc + 1 : kc);
-      const H (*as)[BM * LDK] = As + cur * NP;
-      const H (*bs)[BN * LDK] = Bs + cur * NP;
-#pragma unroll
-      for (int ks = 0; ks < BK / 16; ++ks) {
-        H8 a[NP][TM], b[NP][TN];
-#pragma unroll
-        for (int q = 0; q < NP; ++q) {
-#pragma unroll
-          for (int i = 0; i < TM; ++i) a[q][i] = *reinterpret_cast<const H8*>(&as[q][np_sw(a_row + i * 32, ks * 16 + lk * 8)]);
-#pragma unroll
-          for (int j = 0; j < TN; ++j) b[q][j] = *reinterpret_cast<const H8*>(&bs[q][np_sw(b_row + j * 32, ks * 16 + lk * 8)]);
-        }
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-          for (int j = 0; j < TN; ++j) {
-            if constexpr (NP == 2) {
-              acc[i][j] = np_mfma(a[NP - 1][i], b[0][j], acc[i][j]);
-              acc[i][j] = np_mfma(a[0][i], b[NP - 1][j], acc[i][j]);
-            }
-            acc[i][j] = np_mfma(a[0][i], b[0][j], acc[i][j]);
-          }
-      }
-      // the other image was last read before the previous barrier: fill it while the slower waves finish this chunk
-      if (more) store_chunk(cur ^ 1);
+    for (int kc = c_begin; kc < c_end; kc += 2) {
+      load_chunk(kc + 2 < c_end ? kc + 2 : c_last, S0());
+      compute(0);
+      store_chunk(1, S1());
+      __syncthreads();
+      if (kc + 1 >= c_end) break;                    // uniform
+      load_chunk(kc + 3 < c_end ? kc + 3 : c_last, S1());
+      compute(1);
+      store_chunk(0, S0());
       __syncthreads();
     }
   }
@@ -335,7 +378,7 @@ struct NpWgradP {
 // Both operands arrive with the reduction index (the pixel) as the slow HBM index, so both tiles are transposed on the way
 // into LDS; a work-item owns two consecutive pixels of four channels and writes packed pairs.
 template <int BMK, int BN, int WM, int WN, int MODE>
-__global__ __launch_bounds__(64 * WM * WN) void fsv_np_wgrad_kernel(NpWgradP p) {
+__global__ __launch_bounds__(64 * WM * WN, 2) void fsv_np_wgrad_kernel(NpWgradP p) {
   typedef NpTypes<MODE> T;
   typedef typename T::H H;
   typedef typename T::H8 H8;
@@ -377,11 +420,11 @@ __global__ __launch_bounds__(64 * WM * WN) void fsv_np_wgrad_kernel(NpWgradP p) 
   const int c_begin = zk * cps;
   const int c_end = (c_begin + cps < p.pchunks) ? (c_begin + cps) : p.pchunks;
 
-  float4 areg[NPA][2];
-  float4 breg[NPB][2];
-  const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  float4 areg[2][NPA][2];      // two register stages, as in the forward kernel
+  float4 breg[2][NPB][2];
   const bool cout4 = (p.Cout & 3) == 0;
-  auto load_chunk = [&](int pc) {
+  auto load_chunk = [&](int pc, auto stage) {
+    constexpr int S = decltype(stage)::value;
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       // the two pixels of this work-item's pair: one decomposition each, shared by all its column quads
@@ -397,7 +440,7 @@ __global__ __launch_bounds__(64 * WM * WN) void fsv_np_wgrad_kernel(NpWgradP p) 
         const bool ok = mok && kok[i] && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
         const long long off = ok ? ((((long long)n * p.H + iy) * p.W + ix) * p.Cin + a_ci[i]) : 0ll;
         float4 v = *reinterpret_cast<const float4*>(p.in + off);
-        areg[i][h] = ok ? v : zero4;
+        areg[S][i][h] = np_keep(ok, v);
       }
     }
 #pragma unroll
@@ -411,49 +454,28 @@ __global__ __launch_bounds__(64 * WM * WN) void fsv_np_wgrad_kernel(NpWgradP p) 
         if (cout4) {
           bool ok = rok && bcol < p.Cout;
           float4 v = *reinterpret_cast<const float4*>(p.dout + (ok ? (pix * p.Cout + bcol) : 0ll));
-          breg[i][h] = ok ? v : zero4;
+          breg[S][i][h] = np_keep(ok, v);
         } else {
           const float* src = p.dout + pix * p.Cout;
           bool o0 = rok && bcol + 0 < p.Cout, o1 = rok && bcol + 1 < p.Cout, o2 = rok && bcol + 2 < p.Cout, o3 = rok && bcol + 3 < p.Cout;
           float t0 = src[o0 ? bcol + 0 : 0], t1 = src[o1 ? bcol + 1 : 0], t2 = src[o2 ? bcol + 2 : 0], t3 = src[o3 ? bcol + 3 : 0];
-          breg[i][h] = make_float4(o0 ? t0 : 0.f, o1 ? t1 : 0.f, o2 ? t2 : 0.f, o3 ? t3 : 0.f);
+          breg[S][i][h] = make_float4(o0 ? t0 : 0.f, o1 ? t1 : 0.f, o2 ? t2 : 0.f, o3 ? t3 : 0.f);
         }
       }
   };
-  auto store_chunk = [&](int buf) {
+  auto store_chunk = [&](int buf, auto stage) {
+    constexpr int S = decltype(stage)::value;
     H (*as)[BMK * LDK] = As + buf * NP;
     H (*bs)[BN * LDK] = Bs + buf * NP;
 #pragma unroll
     for (int i = 0; i < NPA; ++i) {
       const int pr = 2 * pp, aq = q0 + i * QPP;
-      const float v0[4] = {areg[i][0].x, areg[i][0].y, areg[i][0].z, areg[i][0].w};
-      const float v1[4] = {areg[i][1].x, areg[i][1].y, areg[i][1].z, areg[i][1].w};
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        H h0, l0, h1, l1;
-        np_split<MODE>(v0[j], h0, l0);
-        np_split<MODE>(v1[j], h1, l1);
-        H2 hi, lo;
-        hi[0] = h0; hi[1] = h1; lo[0] = l0; lo[1] = l1;
-        *reinterpret_cast<H2*>(&as[0][np_sw(aq * 4 + j, pr)]) = hi;
-        if constexpr (NP == 2) *reinterpret_cast<H2*>(&as[NP - 1][np_sw(aq * 4 + j, pr)]) = lo;
-      }
+      np_store_pairs<MODE, NP, BMK * LDK>(as, areg[S][i][0], areg[S][i][1], aq * 4, pr);
     }
 #pragma unroll
     for (int i = 0; i < NPB; ++i) {
       const int pr = 2 * pp, bq = q0 + i * QPP;
-      const float v0[4] = {breg[i][0].x, breg[i][0].y, breg[i][0].z, breg[i][0].w};
-      const float v1[4] = {breg[i][1].x, breg[i][1].y, breg[i][1].z, breg[i][1].w};
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        H h0, l0, h1, l1;
-        np_split<MODE>(v0[j], h0, l0);
-        np_split<MODE>(v1[j], h1, l1);
-        H2 hi, lo;
-        hi[0] = h0; hi[1] = h1; lo[0] = l0; lo[1] = l1;
-        *reinterpret_cast<H2*>(&bs[0][np_sw(bq * 4 + j, pr)]) = hi;
-        if constexpr (NP == 2) *reinterpret_cast<H2*>(&bs[NP - 1][np_sw(bq * 4 + j, pr)]) = lo;
-      }
+      np_store_pairs<MODE, NP, BN * LDK>(bs, breg[S][i][0], breg[S][i][1], bq * 4, pr);
     }
   };
 
@@ -467,39 +489,49 @@ __global__ __launch_bounds__(64 * WM * WN) void fsv_np_wgrad_kernel(NpWgradP p) 
 
   const int lrow = lane & 31, lk = lane >> 5;
   const int a_row = wm * (TM * 32) + lrow, b_row = wn * (TN * 32) + lrow;
+  auto compute = [&](int cur) {
+    const H (*as)[BMK * LDK] = As + cur * NP;
+    const H (*bs)[BN * LDK] = Bs + cur * NP;
+#pragma unroll
+    for (int ks = 0; ks < BK / 16; ++ks) {
+      H8 a[NP][TM], b[NP][TN];
+#pragma unroll
+      for (int q = 0; q < NP; ++q) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) a[q][i] = *reinterpret_cast<const H8*>(&as[q][np_sw(a_row + i * 32, ks * 16 + lk * 8)]);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) b[q][j] = *reinterpret_cast<const H8*>(&bs[q][np_sw(b_row + j * 32, ks * 16 + lk * 8)]);
+      }
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          if constexpr (NP == 2) {
+            acc[i][j] = np_mfma(a[NP - 1][i], b[0][j], acc[i][j]);
+            acc[i][j] = np_mfma(a[0][i], b[NP - 1][j], acc[i][j]);
+          }
+          acc[i][j] = np_mfma(a[0][i], b[0][j], acc[i][j]);
+        }
+    }
+  };
+  using S0 = std::integral_constant<int, 0>;
+  using S1 = std::integral_constant<int, 1>;
   if (c_begin < c_end) {
-    load_chunk(c_begin);
-    store_chunk(0);
+    const int c_last = c_end - 1;
+    load_chunk(c_begin, S0());
+    store_chunk(0, S0());
+    load_chunk(c_begin + 1 < c_end ? c_begin + 1 : c_last, S1());
     __syncthreads();
 #pragma unroll 1
-    for (int pc = c_begin; pc < c_end; ++pc) {
-      const int cur = (pc - c_begin) & 1;
-      const bool more = pc + 1 < c_end;
-      load_chunk(more ? pc + 1 : pc);
-      const H (*as)[BMK * LDK] = As + cur * NP;
-      const H (*bs)[BN * LDK] = Bs + cur * NP;
-#pragma unroll
-      for (int ks = 0; ks < BK / 16; ++ks) {
-        H8 a[NP][TM], b[NP][TN];
-#pragma unroll
-        for (int q = 0; q < NP; ++q) {
-#pragma unroll
-          for (int i = 0; i < TM; ++i) a[q][i] = *reinterpret_cast<const H8*>(&as[q][np_sw(a_row + i * 32, ks * 16 + lk * 8)]);
-#pragma unroll
-          for (int j = 0; j < TN; ++j) b[q][j] = *reinterpret_cast<const H8*>(&bs[q][np_sw(b_row + j * 32, ks * 16 + lk * 8)]);
-        }
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-          for (int j = 0; j < TN; ++j) {
-            if constexpr (NP == 2) {
-              acc[i][j] = np_mfma(a[NP - 1][i], b[0][j], acc[i][j]);
-              acc[i][j] = np_mfma(a[0][i], b[NP - 1][j], acc[i][j]);
-            }
-            acc[i][j] = np_mfma(a[0][i], b[0][j], acc[i][j]);
-          }
-      }
-      if (more) store_chunk(cur ^ 1);
+    for (int pc = c_begin; pc < c_end; pc += 2) {
+      load_chunk(pc + 2 < c_end ? pc + 2 : c_last, S0());
+      compute(0);
+      store_chunk(1, S1());
+      __syncthreads();
+      if (pc + 1 >= c_end) break;                    // uniform
+      load_chunk(pc + 3 < c_end ? pc + 3 : c_last, S1());
+      compute(1);
+      store_chunk(0, S0());
       __syncthreads();
     }
   }
