@@ -378,7 +378,7 @@ struct NpWgradP {
 // Both operands arrive with the reduction index (the pixel) as the slow HBM index, so both tiles are transposed on the way
 // into LDS; a work-item owns two consecutive pixels of four channels and writes packed pairs.
 template <int BMK, int BN, int WM, int WN, int MODE>
-__global__ __launch_bounds__(64 * WM * WN, 2) void fsv_np_wgrad_kernel(NpWgradP p) {
+__global__ __launch_bounds__(64 * WM * WN, (BMK * BN >= 128 * 128) ? 1 : 2) void fsv_np_wgrad_kernel(NpWgradP p) {
   typedef NpTypes<MODE> T;
   typedef typename T::H H;
   typedef typename T::H8 H8;
