@@ -3,7 +3,8 @@
 // (filled by the global loads issued at the top of the iteration) are written into the other image, which every wave stopped
 // reading at the previous barrier.  Same operands, same order of the fma chain per output element, same epilogue: results are
 // bitwise those of fsv_conv_igemm_kernel.  LDS: 2 x (32 x (BM+1) + 32 x BN) floats = 33 KB (64x64) / 49 KB (64x128, 128x64),
-// i.e. 3-4 workgroups per CU; the 128x128 tile would need 66 KB (more than a static allocation allows) and is not offered.
+// i.e. 3-4 workgroups per CU; the 128x128 tile would need 66 KB (2 workgroups per CU) and is not offered: it only carries the
+// launches that already fill the chip.
 //
 // Experimental: reachable only through force_tile (ids 13 / 14 / 15) until an A/B on the hardware says where it pays
 // (tools/tile_ab.py).  float4-gather layers only (Cin % 4 == 0).
@@ -25,7 +26,6 @@ __global__ __launch_bounds__(64 * WM * WN) void fsv_conv_igemm_db_kernel(ConvP p
   constexpr int NPB = BK / RPB;
   constexpr int ASZ = BK * LDA, BSZ = BK * BN;
   static_assert(NPA >= 1 && NPB >= 1 && NPA * RPP == BM && NPB * RPB == BK, "tile / thread-count mismatch");
-  static_assert(2 * (ASZ + BSZ) * 4 <= 65536, "two LDS images must fit a static allocation");
   __shared__ float As[2 * ASZ];
   __shared__ float Bs[2 * BSZ];
 
