@@ -153,6 +153,17 @@ int fsv_norm_bwd(const float* dy, const float* y, const float* x, const float* m
                  double* workspace, float* s1, float* s2, float* dx, float* dw, float* db, int G, int P, int C, int act,
                  int fixed_stats, fsv_stream_t stream);   /* fixed_stats: eval mode, mean / rstd are constants */
 int fsv_colsum(const float* x, double* workspace, float* out, int G, int P, int C, int accumulate, fsv_stream_t stream);
+/* BatchNorm-shaped reductions (G = 1) with the second stage fused into the reduction launch (opt-in; the workgroup that finishes
+ * last for a channel slab sums the slab's partials, bit-identical to the two-launch form).  counters: fsv_red_slabs(P, C) ints,
+ * zero between launches. */
+int fsv_red_slabs(int P, int C);
+int fsv_norm_stats_fused(const float* x, double* workspace, int* counters, float* mean, float* rstd, int P, int C, float eps,
+                         float* run_mean, float* run_var, float momentum, fsv_stream_t stream);
+int fsv_norm_bwd_fused(const float* dy, const float* y, const float* x, const float* mean, const float* rstd, const float* w,
+                       double* workspace, int* counters, float* s1, float* s2, float* dx, float* dw, float* db, int P, int C,
+                       int act, fsv_stream_t stream);
+int fsv_colsum_fused(const float* x, double* workspace, int* counters, float* out, int P, int C, int accumulate,
+                     fsv_stream_t stream);
 /* cross-replica BatchNorm (opt-in; apex.parallel.SyncBatchNorm of the reference's multi-process path, normalization.py:15,33,80):
  * the device halves on either side of the host's all-reduce.  sums: doubles [2C] = {sum x, sum x^2} resp. {sum d, sum d*xhat};
  * count: values per channel over all ranks.  dw / db of an affine layer are the LOCAL sums (they travel with the gradients). */

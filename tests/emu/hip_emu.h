@@ -193,6 +193,7 @@ inline void launch(dim3 grid, dim3 block, F&& body) {
 #define blockDim (emu::S().block)
 #define gridDim (emu::S().grid)
 static inline void __syncthreads() { emu::barrier_wg(); }
+static inline void __threadfence() {}      // one workgroup runs at a time and to completion: every store is already visible
 
 typedef float emu_f32x16 __attribute__((ext_vector_type(16)));
 typedef float emu_f32x4 __attribute__((ext_vector_type(4)));
@@ -296,5 +297,23 @@ static inline float __frcp_rn(float a) { return 1.0f / a; }
 static inline float rsqrtf(float a) { return 1.0f / sqrtf(a); }
 static inline float fminf_(float a, float b) { return a < b ? a : b; }
 
+// number of kernel launches since the library was loaded (the emulated library is one translation unit): lets the CPU tests
+// watch the launch count of a training step, which is what bounds the eager step on the real stack
+inline long long& fsv_emu_launches() { static long long n = 0; return n; }
+extern "C" __attribute__((used, visibility("default"))) long long fsv_emu_launch_count() { return fsv_emu_launches(); }
+#include <map>
+#include <string>
+inline std::map<std::string, long long>& fsv_emu_by_kernel() { static std::map<std::string, long long> m; return m; }
+// "name count\n" lines of the launches since the last reset (reset != 0 clears the table after writing it)
+extern "C" __attribute__((used, visibility("default"))) int fsv_emu_launch_report(char* buf, int cap, int reset) {
+  std::string out;
+  for (auto& kv : fsv_emu_by_kernel()) out += kv.first + " " + std::to_string(kv.second) + "\n";
+  if (reset) fsv_emu_by_kernel().clear();
+  int n = (int)out.size() < cap - 1 ? (int)out.size() : cap - 1;
+  if (buf && cap > 0) { memcpy(buf, out.data(), n); buf[n] = 0; }
+  return (int)out.size();
+}
+
 #define FSV_LAUNCH(kernel, grid, block, stream, ...)                         \
-  do { (void)(stream); emu::launch((grid), (block), [=]() { kernel(__VA_ARGS__); }); } while (0)
+  do { (void)(stream); ++fsv_emu_launches(); ++fsv_emu_by_kernel()[#kernel];                                         \
+       emu::launch((grid), (block), [=]() { kernel(__VA_ARGS__); }); } while (0)

@@ -46,3 +46,15 @@ def test_graphed_iteration_on_hardware():
     sys.stdout.write(r.stdout[-4000:])
     sys.stderr.write(r.stderr[-4000:])
     assert r.returncode == 0 and 'GRAPH_STEP_GPU_OK' in r.stdout
+
+
+@pytest.mark.gpu
+@pytest.mark.xfail(strict=False, reason="fused reduction second stage not yet validated on MI355X (emulator-verified only)")
+def test_fused_final_on_hardware():
+    env = dict(os.environ)
+    env.pop('FSV2V_EMU', None)
+    r = subprocess.run([sys.executable, os.path.join(HERE, 'fused_final_checks.py')], cwd=HERE, env=env, capture_output=True,
+                       text=True, timeout=300)
+    sys.stdout.write(r.stdout[-4000:])
+    sys.stderr.write(r.stderr[-4000:])
+    assert r.returncode == 0 and 'FUSED_FINAL_GPU_OK' in r.stdout
