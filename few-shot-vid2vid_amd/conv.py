@@ -200,6 +200,23 @@ def conv_forward(x, wt_f, ldw, cout, geom, bias=None, res=None, act=ACT_NONE, sc
                        wscale=wscale)
 
 
+_DGRAD_MERGE = None
+
+
+def _dgrad_merge():
+    global _DGRAD_MERGE
+    if _DGRAD_MERGE is None:
+        _DGRAD_MERGE = int(os.environ.get('FSV_DGRAD_MERGE', '0') or 0)
+    return _DGRAD_MERGE
+
+
+def set_dgrad_merge(v):
+    global _DGRAD_MERGE
+    prev = _dgrad_merge()
+    _DGRAD_MERGE = int(v)
+    return prev
+
+
 def _planned_split(mz, cout, nchunks, nsamp):
     """the split-K factor fsv_conv_gather_fwd will pick for this launch (csrc/conv_igemm.hip fsv_conv_plan)"""
     lib.register_sigs({"fsv_conv_plan": [ctypes.c_int] * 6 + [ctypes.POINTER(ctypes.c_int)] * 2})
@@ -238,6 +255,29 @@ def conv_dgrad(dout, w, geom, in_hw, scale=None, per_sample=False, cached=None, 
             if _planned_split(mz, cin, (len(c['khs']) * cout + 31) // 32, n if per_sample else 1) > 1:
                 plain = False
                 break
+    if plain and s == 2 and len(geom.dgrad_classes) == 4 and cout % 4 == 0 and _dgrad_merge():
+        # opt-in (FSV_DGRAD_MERGE=1 | 2 = with two-chunk prefetch): the four parity classes in ONE launch; the entry point
+        # declines (FSV_ERR_UNSUPPORTED) when its tile has no double-buffered variant and the per-class loop below takes over
+        dx = empty_nhwc(n, cin, h, wd, dout)
+        lays = [layout(k, c) for k, c in enumerate(geom.dgrad_classes)]
+        ldw, ws = lays[0][1], lays[0][2]
+        if all(l[1] == ldw for l in lays):
+            ty, tx = [0] * 64, [0] * 64
+            for k, c in enumerate(geom.dgrad_classes):
+                ty[k * 16:k * 16 + len(c['ty'])] = c['ty']
+                tx[k * 16:k * 16 + len(c['tx'])] = c['tx']
+            wts = (ctypes.c_void_p * 4)(*[l[0].data_ptr() for l in lays])
+            wbs = (ctypes.c_longlong * 4)(*[(l[0].shape[-2] * l[0].shape[-1] if per_sample else 0) for l in lays])
+            lib.check_device(dout, dx, ws, *[l[0] for l in lays])
+            rc = lib.call_status("fsv_conv_dgrad_s2", lib.ptr(dout), wts, lib.ptr(dx), n, oh, ow, cout, cin,
+                                 lib.int_array([len(c['khs']) for c in geom.dgrad_classes]), lib.int_array(ty), lib.int_array(tx),
+                                 lib.int_array([sh for sh, _ in subs]), lib.int_array([sw for _, sw in subs]),
+                                 lib.int_array([c['py'] for c in geom.dgrad_classes]), lib.int_array([c['px'] for c in geom.dgrad_classes]),
+                                 h, wd, ldw, wbs, 1 if per_sample else 0, lib.ptr(ws), _dgrad_merge(), lib.stream_ptr())
+            if rc == 0:
+                return dx
+            if rc != -2:
+                raise lib.FsvError("fsv_conv_dgrad_s2 failed with fsv_status %d" % rc)
     dx = empty_nhwc(n, cin, h, wd, dout) if plain else zeros_nhwc(n, cin, h, wd, dout)
     for k, (c, (sub_h, sub_w)) in enumerate(zip(geom.dgrad_classes, subs)):
         if sub_h <= 0 or sub_w <= 0 or not c['khs']:

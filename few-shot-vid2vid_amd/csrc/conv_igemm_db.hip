@@ -11,8 +11,10 @@
 #include "conv_igemm.h"
 #include <type_traits>
 
+// the workgroup's work, parameterised by its tile coordinates so that one launch can serve several problems (see the
+// merged stride-2 data gradient below); `p` lives in kernel-argument (scalar) memory in both callers
 template <int BM, int BN, int WM, int WN, int PF>
-__global__ __launch_bounds__(64 * WM * WN) void fsv_conv_igemm_db_kernel(ConvP p) {
+__device__ __forceinline__ void fsv_conv_db_body(const ConvP& p, const int bx, const int by, const int bz) {
   static_assert(PF == 1 || PF == 2, "prefetch distance");
   constexpr int BK = FSV_BK;
   constexpr int NT = 64 * WM * WN;
@@ -32,8 +34,8 @@ __global__ __launch_bounds__(64 * WM * WN) void fsv_conv_igemm_db_kernel(ConvP p
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
-  const int zs = blockIdx.z / p.nsplit, zk = blockIdx.z % p.nsplit;
-  const int bm0 = blockIdx.x * BM, bn0 = blockIdx.y * BN;
+  const int zs = bz / p.nsplit, zk = bz % p.nsplit;
+  const int bm0 = bx * BM, bn0 = by * BN;
   const float* wt = p.wt + (long long)zs * p.w_bstride;
 
   const int kq = tid % KV, ar0 = tid / KV;
@@ -218,6 +220,29 @@ __global__ __launch_bounds__(64 * WM * WN) void fsv_conv_igemm_db_kernel(ConvP p
   }
 }
 
+template <int BM, int BN, int WM, int WN, int PF>
+__global__ __launch_bounds__(64 * WM * WN) void fsv_conv_igemm_db_kernel(ConvP p) {
+  fsv_conv_db_body<BM, BN, WM, WN, PF>(p, blockIdx.x, blockIdx.y, blockIdx.z);
+}
+
+// ---- merged stride-2 data gradient: the four output-parity classes of one layer in ONE launch ----------------------------------
+// A stride-2 convolution's data gradient is four independent gather-GEMMs (one per parity class of the output pixel, each with
+// its own taps, weight layout and strided placement).  Launched one by one they are four small grids; here blockIdx.z selects
+// the class (and, within it, the sample of a per-sample problem), blockIdx.x walks the tiles of the largest class - workgroups
+// beyond a smaller class's tile count leave at once.  Only for the no-split case (every class stores its own pixels).
+struct ConvP4 {
+  ConvP c[4];
+  int nz;                 // z extent of one class (samples of a per-sample problem, else 1)
+};
+
+template <int BM, int BN, int WM, int WN, int PF>
+__global__ __launch_bounds__(64 * WM * WN) void fsv_conv_igemm_db4_kernel(ConvP4 q) {
+  const int cls = blockIdx.z / q.nz;
+  const ConvP& p = q.c[cls];
+  if ((int)blockIdx.x * BM >= p.Mz) return;          // uniform per workgroup
+  fsv_conv_db_body<BM, BN, WM, WN, PF>(p, blockIdx.x, blockIdx.y, blockIdx.z - cls * q.nz);
+}
+
 int fsv_launch_conv_db(const ConvP& p, int nz, hipStream_t stream, int tile) {
   dim3 block(256);
   switch (tile) {
@@ -400,5 +425,72 @@ int fsv_launch_wgrad_db(const WgradP& p, int bmk, int bn, dim3 grid, hipStream_t
   if (bmk == 64 && bn == 64) FSV_LAUNCH((fsv_conv_wgrad_db_kernel<64, 64, 2, 2>), grid, block, stream, p);
   else if (bmk == 64 && bn == 128) FSV_LAUNCH((fsv_conv_wgrad_db_kernel<64, 128, 2, 2>), grid, block, stream, p);
   else return FSV_ERR_BAD_ARG;
+  return fsv_check_launch();
+}
+
+
+extern "C" int fsv_conv_plan(int Mz, int Cout, int nchunks, int nsamp, int force_tile, int force_split, int* tile_out,
+                             int* nsplit_out);
+
+static inline void fsv_db_pack_taps(const int* ty, const int* tx, int n, unsigned long long& lo, unsigned long long& hi) {
+  lo = 0; hi = 0;
+  for (int t = 0; t < n; ++t) {
+    unsigned long long c = (unsigned long long)((ty[t] + 8) & 15) | ((unsigned long long)((tx[t] + 8) & 15) << 4);
+    if (t < 8) lo |= c << (t * 8); else hi |= c << ((t - 8) * 8);
+  }
+}
+
+// The four parity classes of a stride-2 data gradient in one launch (see fsv_conv_igemm_db4_kernel).  Class k: weights wt[k]
+// ([Kpad_k][ldw], K-major), ntaps[k] taps ty/tx[k*16 ..], iteration grid sub_h[k] x sub_w[k], output pixel (2*y + py[k], 2*x + px[k])
+// of the [N][outH][outW][Cout] tensor.  Returns FSV_ERR_UNSUPPORTED when the launch plan wants split-K or a tile that has no
+// double-buffered variant: the caller then issues the classes one by one.
+extern "C" int fsv_conv_dgrad_s2(const float* in, const float* const* wt, float* out, int N, int H, int W, int Cin, int Cout,
+                                 const int* ntaps, const int* ty, const int* tx, const int* sub_h, const int* sub_w, const int* py,
+                                 const int* px, int outH, int outW, int ldw, const long long* w_bstride, int per_sample,
+                                 const float* wscale, int prefetch, hipStream_t stream) {
+  if (!in || !wt || !out || !ntaps || !ty || !tx || !sub_h || !sub_w || !py || !px || N < 1 || Cin < 1 || Cout < 1) return FSV_ERR_BAD_ARG;
+  if ((Cin & 3) != 0) return FSV_ERR_UNSUPPORTED;
+  if ((ldw & 3) != 0 || ldw < Cout) return FSV_ERR_BAD_ARG;
+  ConvP4 q;
+  const int nsamp = per_sample ? N : 1;
+  q.nz = nsamp;
+  int tile = -1, max_mz = 0;
+  for (int k = 0; k < 4; ++k) {
+    if (ntaps[k] < 1 || ntaps[k] > 16 || sub_h[k] < 1 || sub_w[k] < 1 || !wt[k]) return FSV_ERR_UNSUPPORTED;
+    for (int t = 0; t < ntaps[k]; ++t)
+      if (ty[k * 16 + t] < -8 || ty[k * 16 + t] > 7 || tx[k * 16 + t] < -8 || tx[k * 16 + t] > 7) return FSV_ERR_UNSUPPORTED;
+    ConvP& p = q.c[k];
+    p.in = in; p.wt = wt[k]; p.bias = nullptr; p.res = nullptr; p.out = out; p.wscale = wscale;
+    p.N = N; p.H = H; p.W = W; p.Cin = Cin; p.OH = sub_h[k]; p.OW = sub_w[k]; p.Cout = Cout;
+    p.K = ntaps[k] * Cin; p.nchunks = fsv_cdiv(p.K, FSV_BK); p.ldw = ldw;
+    p.sy = 1; p.sx = 1; p.ntaps = ntaps[k];
+    fsv_db_pack_taps(ty + k * 16, tx + k * 16, ntaps[k], p.taps_lo, p.taps_hi);
+    p.outH = outH; p.outW = outW; p.osy = 2; p.osx = 2; p.ooy = py[k]; p.oox = px[k]; p.dense_out = 0;
+    p.w_bstride = w_bstride ? w_bstride[k] : 0; p.b_bstride = 0; p.per_sample = per_sample ? 1 : 0;
+    p.act = FSV_ACT_NONE; p.scale = 1.f;
+    p.Mz = per_sample ? sub_h[k] * sub_w[k] : N * sub_h[k] * sub_w[k];
+    int t = 0, ns = 1;
+    if (fsv_conv_plan(p.Mz, Cout, p.nchunks, nsamp, -1, 0, &t, &ns)) return FSV_ERR_BAD_ARG;
+    if (ns != 1) return FSV_ERR_UNSUPPORTED;
+    p.nsplit = 1;
+    if (p.Mz > max_mz) { max_mz = p.Mz; tile = t; }
+  }
+  dim3 block(256);
+  const int pf = prefetch == 2 ? 2 : 1;
+  if (tile == 4) {
+    dim3 g(fsv_cdiv(max_mz, 64), fsv_cdiv(Cout, 64), 4 * nsamp);
+    if (pf == 2) FSV_LAUNCH((fsv_conv_igemm_db4_kernel<64, 64, 2, 2, 2>), g, block, stream, q);
+    else FSV_LAUNCH((fsv_conv_igemm_db4_kernel<64, 64, 2, 2, 1>), g, block, stream, q);
+  } else if (tile == 9) {
+    dim3 g(fsv_cdiv(max_mz, 64), fsv_cdiv(Cout, 128), 4 * nsamp);
+    if (pf == 2) FSV_LAUNCH((fsv_conv_igemm_db4_kernel<64, 128, 2, 2, 2>), g, block, stream, q);
+    else FSV_LAUNCH((fsv_conv_igemm_db4_kernel<64, 128, 2, 2, 1>), g, block, stream, q);
+  } else if (tile == 1) {
+    dim3 g(fsv_cdiv(max_mz, 128), fsv_cdiv(Cout, 64), 4 * nsamp);
+    if (pf == 2) FSV_LAUNCH((fsv_conv_igemm_db4_kernel<128, 64, 2, 2, 2>), g, block, stream, q);
+    else FSV_LAUNCH((fsv_conv_igemm_db4_kernel<128, 64, 2, 2, 1>), g, block, stream, q);
+  } else {
+    return FSV_ERR_UNSUPPORTED;          // 128x128 / thin tiles have no double-buffered variant
+  }
   return fsv_check_launch();
 }

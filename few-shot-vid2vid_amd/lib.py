@@ -32,6 +32,10 @@ _SIGS = {
                        c_i, c_ip, c_ip, c_i, c_i,
                        c_i, c_i, c_ll, c_i, c_i, c_i, c_i, c_p],
     "fsv_bias_act": [c_p, c_p, c_ll, c_i, c_i, c_p],
+    # merged stride-2 data gradient (csrc/conv_igemm_db.hip): in, wt[4], out, N, H, W, Cin, Cout, ntaps[4], ty[64], tx[64],
+    # sub_h[4], sub_w[4], py[4], px[4], outH, outW, ldw, w_bstride[4], per_sample, wscale, prefetch, stream
+    "fsv_conv_dgrad_s2": [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_ip, c_ip, c_ip, c_ip, c_ip, c_ip, c_ip, c_i, c_i, c_i,
+                          c_p, c_i, c_p, c_i, c_p],
     # narrow-operand (--amp) variants, csrc/conv_np.hip: the same arguments plus `mode` before the stream
     "fsv_conv_gather_fwd_np": [c_p, c_p, c_p, c_p, c_p,
                                c_i, c_i, c_i, c_i, c_i, c_i, c_i,
@@ -123,6 +127,11 @@ def ptr(t):
 
 def int_array(vals):
     return (ctypes.c_int * len(vals))(*[int(v) for v in vals])
+
+
+def call_status(name, *args):
+    """like call(), but returns the fsv_status instead of raising (entry points that may decline with FSV_ERR_UNSUPPORTED)"""
+    return int(getattr(get_lib(), name)(*args))
 
 
 def call(name, *args):

@@ -52,6 +52,15 @@ int fsv_conv_gather_fwd(const float* in, const float* wt, const float* bias, con
                         int act, float scale, int force_tile, int force_split, int accumulate, const float* wscale,
                         fsv_stream_t stream);
 
+/* The four output-parity classes of a stride-2 data gradient in ONE launch (opt-in; csrc/conv_igemm_db.hip).  Class k: K-major
+ * weights wt[k], ntaps[k] taps at ty / tx[16*k ...], iteration grid sub_h[k] x sub_w[k], output pixel (2y + py[k], 2x + px[k]) of the
+ * [N][outH][outW][Cout] tensor; `in` is the incoming gradient [N][H][W][Cin].  Returns FSV_ERR_UNSUPPORTED (-2) when the launch plan
+ * wants split-K or a tile without a double-buffered variant: issue the classes one by one then.  prefetch: 1 or 2 chunks ahead. */
+int fsv_conv_dgrad_s2(const float* in, const float* const* wt, float* out, int N, int H, int W, int Cin, int Cout,
+                      const int* ntaps, const int* ty, const int* tx, const int* sub_h, const int* sub_w, const int* py,
+                      const int* px, int outH, int outW, int ldw, const long long* w_bstride, int per_sample,
+                      const float* wscale, int prefetch, fsv_stream_t stream);
+
 /* in place: x = act(x + bias[c]) over an NHWC tensor (finishing pass of operators that add several GEMM launches into one
  * output: convolutions with more than 16 taps, transposed convolutions); act codes as in the conv epilogue, 5 = leaky 0.1 */
 int fsv_bias_act(float* x, const float* bias, long long total, int C, int act, fsv_stream_t stream);

@@ -62,4 +62,25 @@ if __name__ == '__main__':
     check_bitwise_tiles(dev, shape=(2, 128, 32, 32, 256, 3), seed=80)
     check_split_tiles(dev)
     check_wgrad_few_wave(dev)
+    check_dgrad_merge(dev)
     print('TILES_GPU_OK', flush=True)
+
+
+def check_dgrad_merge(device, seed=81):
+    """merged stride-2 data gradient == per-class launches, bit for bit (no split-K on either side)"""
+    ops, conv = oc.pkg()
+    g = torch.Generator().manual_seed(seed)
+    for (n, cin, h, w, cout, k, p) in ((2, 64, 32, 32, 96, 3, 1), (2, 128, 24, 24, 64, 4, 1), (2, 64, 16, 16, 64, 3, 1),
+                                       (2, 256, 64, 64, 128, 3, 1), (2, 128, 65, 63, 256, 4, 2)):
+        geo = conv.Geom(k, k, 2, p)
+        oh, ow = geo.out_hw(h, w)
+        wt = (torch.randn(cout, cin, k, k, generator=g) * 0.2).to(device)
+        dout = conv.to_nhwc(torch.randn(n, cout, oh, ow, generator=g).to(device))
+        res = []
+        for m in (0, 1, 2):
+            prev = conv.set_dgrad_merge(m)
+            try:
+                res.append(conv.conv_dgrad(dout, wt, geo, (h, w)).cpu())
+            finally:
+                conv.set_dgrad_merge(prev)
+        assert torch.equal(res[0], res[1]) and torch.equal(res[0], res[2]), (n, cin, h, w, cout, k, p)

@@ -26,6 +26,7 @@ run bench_db        300 env FSV_TILE_REMAP=4:13,9:14,1:15 FSV_WGRAD_VARIANT=db p
 run bench_pf2       300 env FSV_TILE_REMAP=4:16,9:17,1:18 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-roofline
 run bench_fewwave   300 env FSV_TILE_REMAP=4:10,9:11,1:12 FSV_WGRAD_VARIANT=fw python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-roofline
 run bench_fusedfin  300 env FSV_FUSED_FINAL=1 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-roofline
+run bench_dgradmrg  300 env FSV_DGRAD_MERGE=2 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-roofline
 run bench_amp_o1    300 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --amp O1
 run bench_bf16x3    300 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --amp bf16x3
 cat "$OUT/summary.txt"
