@@ -73,7 +73,7 @@ def test_step_is_bit_identical_with_fewer_launches(emu_lib):
             mc.fill_state(model.netG); mc.fill_state(model.netD)
             model.train()
             opt_G, opt_D = model.build_optimizers()
-            tl, ti, rl, ri = mc.synth_pose_inputs(2, 64, 64, 902, opt.input_nc)
+            tl, ti, rl, ri = mc.synth_pose_inputs(1, 64, 64, 902, opt.input_nc)
             data = [tl, ti, [None, None], [None, None], rl, ri, None, None, None]
             for it in range(2):
                 n0 = _launches()
