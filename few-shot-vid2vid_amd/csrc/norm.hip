@@ -147,8 +147,6 @@ struct RedFinal {
   float* dw; float* db;    // BWD (affine)
   int accumulate;          // COLSUM
 };
-__device__ __forceinline__ void fsv_sum_chunks(const double* part, int g, int c, int C, int nchunks, double& a, double& b);
-
 template <int MODE, int V>
 __global__ __launch_bounds__(256) void fsv_red2f_kernel(RedP p, RedFinal f) {
   __shared__ float red[256 * 2 * V];
@@ -243,8 +241,16 @@ __global__ __launch_bounds__(256) void fsv_red2f_kernel(RedP p, RedFinal f) {
   const int c_begin = slab * p.TX * V;
   const int c_stop = (c_begin + p.TX * V < p.C) ? c_begin + p.TX * V : p.C;
   for (int c = c_begin + wave; c < c_stop; c += 4) {
-    double a, b;
-    fsv_sum_chunks(p.part, 0, c, p.C, p.nchunks, a, b);          // same order as the stand-alone second stage: same bits
+    // same order as the stand-alone second stage (fsv_sum_chunks): same bits.  The partials were written by other workgroups
+    // of this launch: read them with agent-scope atomic loads (on top of the fence above) so that no cache level private to
+    // this CU can answer
+    double a = 0.0, b = 0.0;
+    for (int k = lane; k < p.nchunks; k += 64) {
+      const double* src = p.part + ((long long)k * p.C + c) * 2;
+      a += __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      b += __hip_atomic_load(src + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    for (int o = 32; o > 0; o >>= 1) { a += __shfl_xor(a, o); b += __shfl_xor(b, o); }
     if (lane != 0) continue;
     if (MODE == FSV_RED_STATS) {
       double mu = a / p.P;

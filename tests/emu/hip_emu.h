@@ -193,6 +193,8 @@ inline void launch(dim3 grid, dim3 block, F&& body) {
 #define blockDim (emu::S().block)
 #define gridDim (emu::S().grid)
 static inline void __syncthreads() { emu::barrier_wg(); }
+#define __HIP_MEMORY_SCOPE_AGENT 4
+#define __hip_atomic_load(ptr, order, scope) (*(ptr))
 static inline void __threadfence() {}      // one workgroup runs at a time and to completion: every store is already visible
 
 typedef float emu_f32x16 __attribute__((ext_vector_type(16)));
