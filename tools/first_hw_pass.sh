@@ -5,7 +5,7 @@
 #   3. do the few-wave / double-buffered tiles beat the shipped ones anywhere?                          (tools/tile_ab.py, wgrad_ab.py)
 #   4. whole step: fp32 (headline), the experimental tiles swapped in (FSV_TILE_REMAP), --amp O1, --amp bf16x3   (bench.py)
 # Every step has its own timeout; results land in gpurun_out/first_hw/.  Usage:
-#   /usr/local/graft/bin/gpurun --timeout 3000 -- 'bash tools/first_hw_pass.sh'
+#   /usr/local/graft/bin/gpurun --timeout 3600 -- 'bash tools/first_hw_pass.sh'
 set -u
 OUT=gpurun_out/first_hw
 mkdir -p "$OUT"
@@ -17,7 +17,7 @@ run() {  # name, seconds, command...
   echo "   exit $? ($(tail -n 1 "$OUT/$name.log" | cut -c1-300))" | tee -a "$OUT/summary.txt"
 }
 run pytest_new      900 python -m pytest tests/test_zz_np_gpu.py -q -m gpu -rxX
-run pytest_all      600 python -m pytest tests -x -q -m gpu -rxX
+run pytest_all     1200 python -m pytest tests -x -q -m gpu -rxX
 run np_ab           240 python tools/np_ab.py
 run tile_ab         300 python tools/tile_ab.py "M8192 N256 K2304" "M32768 N128 K1152" "M2048 N512 K2304" "M8192 N128 K512" "M32768 N64 K256" "M131072 N128 K576" "M512 N1024 K4608"
 run wgrad_ab        400 python tools/wgrad_ab.py
@@ -29,4 +29,5 @@ run bench_fusedfin  300 env FSV_FUSED_FINAL=1 python bench.py --steps 10 --warmu
 run bench_dgradmrg  300 env FSV_DGRAD_MERGE=2 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-roofline
 run bench_amp_o1    300 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --amp O1
 run bench_bf16x3    300 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --amp bf16x3
+run bench_f32_again 300 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-roofline      # drift check: same box, same code as bench_f32
 cat "$OUT/summary.txt"
