@@ -520,13 +520,13 @@ static int fsv_launch_conv(const ConvP& p, int M_tiles_rows, int nz, hipStream_t
         FSV_LAUNCH((fsv_conv_igemm_kernel<64, 128, 1, 2, 4>), g, dim3(128), stream, p); return fsv_check_launch(); }
       case 12: { dim3 g(fsv_cdiv(M_tiles_rows, 128), fsv_cdiv(p.Cout, 64), nz);
         FSV_LAUNCH((fsv_conv_igemm_kernel<128, 64, 2, 1, 4>), g, dim3(128), stream, p); return fsv_check_launch(); }
-      case 13: case 14: case 15: case 16: case 17: case 18:      // double-buffered LDS, prefetch distance 1 / 2 (conv_igemm_db.hip)
+      case 13: case 14: case 15: case 16: case 17: case 18: case 19: case 20: case 21:      // double-buffered LDS; 16-18 prefetch distance 2, 19-21 XCD-aware order
         return fsv_launch_conv_db(p, nz, stream, tile);
       default: break;
     }
   }
-  if (tile == 9 || tile == 10 || tile == 11 || tile == 13 || tile == 14 || tile == 16 || tile == 17) tile = 4;      // scalar-gather layers (Cin % 4 != 0): only the basic tiles are instantiated
-  if (tile == 12 || tile == 15 || tile == 18) tile = 1;
+  if (tile == 9 || tile == 10 || tile == 11 || tile == 13 || tile == 14 || tile == 16 || tile == 17 || tile == 19 || tile == 20) tile = 4;      // scalar-gather layers (Cin % 4 != 0): only the basic tiles are instantiated
+  if (tile == 12 || tile == 15 || tile == 18 || tile == 21) tile = 1;
   switch (tile) {
     case 0: { dim3 g(fsv_cdiv(M_tiles_rows, 128), fsv_cdiv(p.Cout, 128), nz);
       FSV_LAUNCH((fsv_conv_igemm_kernel<128, 128, 2, 2, V>), g, block, stream, p); break; }
@@ -544,9 +544,9 @@ static int fsv_launch_conv(const ConvP& p, int M_tiles_rows, int nz, hipStream_t
 }
 
 static inline int fsv_tile_dims(int tile, int& bm, int& bn) {
-  static const int BMs[19] = {128, 128, 128, 256, 64, 256, 128, 256, 256, 64, 64, 64, 128, 64, 64, 128, 64, 64, 128},
-                   BNs[19] = {128, 64, 32, 32, 64, 128, 256, 256, 64, 128, 64, 128, 64, 64, 128, 64, 64, 128, 64};
-  if (tile < 0 || tile > 18) return -1;
+  static const int BMs[22] = {128, 128, 128, 256, 64, 256, 128, 256, 256, 64, 64, 64, 128, 64, 64, 128, 64, 64, 128, 64, 64, 128},
+                   BNs[22] = {128, 64, 32, 32, 64, 128, 256, 256, 64, 128, 64, 128, 64, 64, 128, 64, 64, 128, 64, 64, 128, 64};
+  if (tile < 0 || tile > 21) return -1;
   bm = BMs[tile]; bn = BNs[tile];
   return 0;
 }
@@ -652,10 +652,10 @@ static inline bool vec4_ok(int cin) { return (cin & 3) == 0; }
 // FSV_TILE_REMAP="4:13,9:14,1:15": run the launches the plan gives to tile a with tile b of the same shape instead (whole-step
 // A/B of the experimental variants without touching the plan; split-K factors stay those of the planned tile)
 static inline int fsv_tile_remap(int tile) {
-  static int map[19];
+  static int map[22];
   static int ready = 0;
   if (!ready) {
-    for (int i = 0; i < 19; ++i) map[i] = i;
+    for (int i = 0; i < 22; ++i) map[i] = i;
     const char* e = getenv("FSV_TILE_REMAP");
     while (e && *e) {
       int a = atoi(e);
@@ -669,7 +669,7 @@ static inline int fsv_tile_remap(int tile) {
     }
     ready = 1;
   }
-  return (tile >= 0 && tile < 19) ? map[tile] : tile;
+  return (tile >= 0 && tile < 22) ? map[tile] : tile;
 }
 
 extern "C" {

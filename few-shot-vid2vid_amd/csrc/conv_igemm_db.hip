@@ -225,6 +225,21 @@ __global__ __launch_bounds__(64 * WM * WN) void fsv_conv_igemm_db_kernel(ConvP p
   fsv_conv_db_body<BM, BN, WM, WN, PF>(p, blockIdx.x, blockIdx.y, blockIdx.z);
 }
 
+// ---- XCD-aware tile order -------------------------------------------------------------------------------------------------------
+// The 256 CUs sit in 8 XCDs with one L2 each, and consecutive workgroup ids are dealt to the XCDs round-robin.  In the plain
+// (x = pixel tile, y = channel tile) grid the workgroups that share a pixel tile - the expensive operand: the gathered activations -
+// have ids GX apart and land on different XCDs unless GX is a multiple of 8, so that tile is fetched from HBM once per L2 that
+// needs it.  Here the grid is one-dimensional in x and id L is decoded as xcd = L % 8, slot = L / 8, channel tile = slot % GY,
+// pixel tile = (slot / GY) * 8 + xcd: all channel tiles of a pixel tile run back to back on ONE XCD.
+template <int BM, int BN, int WM, int WN, int PF>
+__global__ __launch_bounds__(64 * WM * WN) void fsv_conv_igemm_dbx_kernel(ConvP p, int GX, int GY) {
+  const int L = blockIdx.x;
+  const int xcd = L & 7, slot = L >> 3;
+  const int by = slot % GY, bx = (slot / GY) * 8 + xcd;
+  if (bx >= GX) return;                              // padding of the last group of 8 pixel tiles (uniform per workgroup)
+  fsv_conv_db_body<BM, BN, WM, WN, PF>(p, bx, by, blockIdx.z);
+}
+
 // ---- merged stride-2 data gradient: the four output-parity classes of one layer in ONE launch ----------------------------------
 // A stride-2 convolution's data gradient is four independent gather-GEMMs (one per parity class of the output pixel, each with
 // its own taps, weight layout and strided placement).  Launched one by one they are four small grids; here blockIdx.z selects
@@ -259,6 +274,13 @@ int fsv_launch_conv_db(const ConvP& p, int nz, hipStream_t stream, int tile) {
       FSV_LAUNCH((fsv_conv_igemm_db_kernel<64, 128, 2, 2, 2>), g, block, stream, p); break; }
     case 18: { dim3 g(fsv_cdiv(p.Mz, 128), fsv_cdiv(p.Cout, 64), nz);
       FSV_LAUNCH((fsv_conv_igemm_db_kernel<128, 64, 2, 2, 2>), g, block, stream, p); break; }
+    // 19 / 20 / 21: double-buffered + XCD-aware tile order
+    case 19: { const int gx = fsv_cdiv(p.Mz, 64), gy = fsv_cdiv(p.Cout, 64);
+      FSV_LAUNCH((fsv_conv_igemm_dbx_kernel<64, 64, 2, 2, 1>), dim3(fsv_cdiv(gx, 8) * 8 * gy, 1, nz), block, stream, p, gx, gy); break; }
+    case 20: { const int gx = fsv_cdiv(p.Mz, 64), gy = fsv_cdiv(p.Cout, 128);
+      FSV_LAUNCH((fsv_conv_igemm_dbx_kernel<64, 128, 2, 2, 1>), dim3(fsv_cdiv(gx, 8) * 8 * gy, 1, nz), block, stream, p, gx, gy); break; }
+    case 21: { const int gx = fsv_cdiv(p.Mz, 128), gy = fsv_cdiv(p.Cout, 64);
+      FSV_LAUNCH((fsv_conv_igemm_dbx_kernel<128, 64, 2, 2, 1>), dim3(fsv_cdiv(gx, 8) * 8 * gy, 1, nz), block, stream, p, gx, gy); break; }
     default: return FSV_ERR_BAD_ARG;
   }
   return fsv_check_launch();

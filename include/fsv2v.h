@@ -42,7 +42,8 @@ enum fsv_act { FSV_ACT_NONE = 0, FSV_ACT_LRELU = 1 /* leaky_relu(0.2), architect
  * the caller, results are added (used for the four parity classes of a stride-2 data gradient).
  * force_tile / force_split: -1 / 0 = automatic (tile ids: 0 128x128, 1 128x64, 2 128x32, 3 256x32, 4 64x64, 5-8 8 / 16-wave
  * experiments, 9 64x128, 10 / 11 / 12 = 64x64 / 64x128 / 128x64 as one- / two-wave workgroups, 13 / 14 / 15 = the same three tiles with
- * double-buffered LDS, 16 / 17 / 18 = double-buffered with the global loads issued two chunks ahead).  wscale: optional device scalar multiplying the accumulator before
+ * double-buffered LDS, 16 / 17 / 18 = double-buffered with the global loads issued two chunks ahead,
+ * 19 / 20 / 21 = double-buffered with an XCD-aware tile order).  wscale: optional device scalar multiplying the accumulator before
  * the bias (the spectral-norm 1/sigma when wt holds un-normalised weights). */
 int fsv_conv_gather_fwd(const float* in, const float* wt, const float* bias, const float* res, float* out,
                         int N, int H, int W, int Cin, int OH, int OW, int Cout,

@@ -21,7 +21,7 @@ GEOMS = [  # n, cin, h, w, cout, k, stride, pad
 @pytest.mark.parametrize("geom", GEOMS)
 @pytest.mark.parametrize("tile,split", [(0, 1), (0, 3), (1, 1), (1, 2), (2, 1), (4, 1), (4, 2), (9, 1), (9, 2),
                                         (10, 1), (10, 2), (11, 1), (11, 3), (12, 1), (12, 2), (13, 1), (13, 2), (14, 1), (14, 3), (15, 1), (15, 2),
-                                        (16, 1), (16, 2), (16, 5), (17, 1), (17, 3), (18, 1), (18, 2)])
+                                        (16, 1), (16, 2), (16, 5), (17, 1), (17, 3), (18, 1), (18, 2), (19, 1), (19, 2), (20, 1), (20, 3), (21, 1), (21, 2)])
 def test_forward_tiles(emu_lib, geom, tile, split):
     ops, conv = oc.pkg()
     n, cin, h, w, cout, k, s, p = geom

@@ -6,7 +6,7 @@ import torch.nn.functional as F
 
 import op_checks as oc
 
-FWD_TILES = (0, 1, 2, 4, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18)
+FWD_TILES = (0, 1, 2, 4, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21)
 
 
 def check_bitwise_tiles(device, shape=(2, 24, 9, 11, 136, 3), seed=77):
@@ -34,7 +34,7 @@ def check_split_tiles(device, seed=78):
     ref = F.conv2d(x, wt, padding=1)
     geo = conv.Geom(3, 3, 1, 1)
     wf, _, ldw = conv.prep_weight(wt.to(device), 0, geo)
-    for t in (10, 11, 12, 13, 14, 15, 16, 17, 18):
+    for t in (10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21):
         for sp in (2, 3):
             y = conv.conv_forward(conv.to_nhwc(x.to(device)), wf, ldw, 192, geo, force_tile=t, force_split=sp)
             oc.assert_close('tile %d split %d' % (t, sp), y, ref, 1e-4)

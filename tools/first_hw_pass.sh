@@ -24,6 +24,7 @@ run wgrad_ab        400 python tools/wgrad_ab.py
 run bench_f32       300 python bench.py --steps 10 --warmup 3 --no-cpu-baseline
 run bench_db        300 env FSV_TILE_REMAP=4:13,9:14,1:15 FSV_WGRAD_VARIANT=db python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-roofline
 run bench_pf2       300 env FSV_TILE_REMAP=4:16,9:17,1:18 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-roofline
+run bench_xcd       300 env FSV_TILE_REMAP=4:19,9:20,1:21 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-roofline
 run bench_fewwave   300 env FSV_TILE_REMAP=4:10,9:11,1:12 FSV_WGRAD_VARIANT=fw python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-roofline
 run bench_fusedfin  300 env FSV_FUSED_FINAL=1 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-roofline
 run bench_dgradmrg  300 env FSV_DGRAD_MERGE=2 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-roofline

@@ -49,7 +49,7 @@ for name in ('tile_ab', 'wgrad_ab'):
         case = row.pop('case')
         auto = row.get('auto')
         best = max(row.items(), key=lambda kv: kv[1])
-        exp = {k: v for k, v in row.items() if any(t in k for t in ('t10', 't11', 't12', 't13', 't14', 't15', 't16', 't17', 't18', 'fw', 'db'))}
+        exp = {k: v for k, v in row.items() if any(t in k for t in ('t10', 't11', 't12', 't13', 't14', 't15', 't16', 't17', 't18', 't19', 't20', 't21', 'fw', 'db'))}
         bexp = max(exp.items(), key=lambda kv: kv[1]) if exp else ('-', 0.0)
         print('%-9s %-24s auto %6.1f  best %-12s %6.1f  best experimental %-12s %6.1f' % (name, case, auto or 0.0, best[0], best[1], bexp[0], bexp[1]))
     print()
