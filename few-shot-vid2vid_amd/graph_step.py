@@ -73,6 +73,10 @@ class GraphedIteration:
         self.opt_G, self.opt_D = self.model.optimizer_G, self.model.optimizer_D
         if self.opt_G is None or self.opt_D is None:
             raise RuntimeError("build the optimisers (model.build_optimizers) before graphing the iteration")
+        from . import ops
+        if ops.bn_sync_world() > 1 and not lib.emu_requested():
+            raise RuntimeError("cross-replica BatchNorm issues collectives inside forward / backward, which cannot be captured: "
+                               "use the eager loop with sync_bn, or per-replica statistics with GraphedIteration")
         self.segmented = bool(self.opt_G.exchange)
         if self.segmented and self.opt_G.overlap:
             raise RuntimeError("with a process group build the optimisers with overlap=False: bucket hooks issue collectives "
