@@ -174,6 +174,21 @@ def gather_gemm(x, wt, ldw, cout, oh, ow, ty, tx, sy, sx, bias=None, res=None, a
             n, h, w, cin, oh, ow, cout, len(ty), lib.int_array(ty), lib.int_array(tx), sy, sx,
             out_h, out_w, osy, osx, ooy, oox, ldw, w_bs, b_bs, 1 if per_sample else 0,
             act, float(scale), force_tile, force_split, 1 if accumulate else 0, lib.ptr(wscale), lib.stream_ptr())
+    if (_splitk_ws() and not accumulate and not _mfma_mode and cin % 4 == 0 and force_tile < 0 and force_split == 0):
+        wsf, nt = ctypes.c_longlong(0), ctypes.c_int(0)
+        sargs = args[:29] + (lib.ptr(wscale),)
+        rc = lib.call_status("fsv_conv_gather_fwd_splitws", *sargs, None, None, ctypes.byref(wsf), ctypes.byref(nt), _splitk_ws(),
+                             lib.stream_ptr())
+        if rc == 0 and wsf.value > 0:
+            skw = torch.empty(wsf.value, dtype=torch.float32, device=x.device)
+            tk = _tickets(nt.value, x)
+            rc = lib.call_status("fsv_conv_gather_fwd_splitws", *sargs, lib.ptr(skw), lib.ptr(tk), ctypes.byref(wsf),
+                                 ctypes.byref(nt), _splitk_ws(), lib.stream_ptr())
+            if rc != 0:
+                raise lib.FsvError("fsv_conv_gather_fwd_splitws failed with fsv_status %d" % rc)
+            return out
+        if rc not in (0, -2):
+            raise lib.FsvError("fsv_conv_gather_fwd_splitws failed with fsv_status %d" % rc)
     entry = "fsv_conv_gather_fwd"
     if _mfma_mode and cin % 4 == 0:               # scalar-gather layers (3-channel images, labels) stay on the fp32 kernel
         entry = "fsv_conv_gather_fwd_np"
@@ -198,6 +213,34 @@ def conv_forward(x, wt_f, ldw, cout, geom, bias=None, res=None, act=ACT_NONE, sc
     return gather_gemm(x, wt_f, ldw, cout, oh, ow, geom.ty, geom.tx, geom.stride, geom.stride, bias=bias, res=res,
                        act=act, scale=scale, per_sample=per_sample, force_tile=force_tile, force_split=force_split,
                        wscale=wscale)
+
+
+# FSV_SPLITK_WS=1 | 2 (opt-in; 2 = with two-chunk prefetch): split-K launches go through a workspace instead of zero fill +
+# atomics + finishing pass (csrc/conv_igemm_db.hip fsv_conv_gather_fwd_splitws) - one launch instead of three, and a fixed
+# summation order (bit-reproducible from run to run, which atomics are not)
+_SPLITK_WS = None
+_sk_tickets = {}
+
+
+def _splitk_ws():
+    global _SPLITK_WS
+    if _SPLITK_WS is None:
+        _SPLITK_WS = int(os.environ.get('FSV_SPLITK_WS', '0') or 0)
+    return _SPLITK_WS
+
+
+def set_splitk_ws(v):
+    global _SPLITK_WS
+    prev = _splitk_ws()
+    _SPLITK_WS = int(v)
+    return prev
+
+
+def _tickets(n, like):
+    t = _sk_tickets.get(like.device)
+    if t is None or t.numel() < n:
+        t = _sk_tickets[like.device] = torch.zeros(max(n, 1 << 16), dtype=torch.int32, device=like.device)
+    return t
 
 
 _DGRAD_MERGE = None

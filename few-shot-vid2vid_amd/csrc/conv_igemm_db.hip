@@ -13,8 +13,13 @@
 
 // the workgroup's work, parameterised by its tile coordinates so that one launch can serve several problems (see the
 // merged stride-2 data gradient below); `p` lives in kernel-argument (scalar) memory in both callers
-template <int BM, int BN, int WM, int WN, int PF>
-__device__ __forceinline__ void fsv_conv_db_body(const ConvP& p, const int bx, const int by, const int bz) {
+// WSK (split-K through a workspace): instead of adding its partial tile into a zeroed output with atomics, every K split stores
+// it to skw[split][tile] and takes a ticket; the workgroup that draws the tile's last ticket adds the splits in the fixed order
+// 0, 1, 2, ... and runs the full epilogue (bias, activation, residual) - no zero fill, no finishing launch, and the result does
+// not depend on which workgroup arrived when.  tile_lin: index of this output tile among all tiles of the launch.
+template <int BM, int BN, int WM, int WN, int PF, bool WSK = false>
+__device__ __forceinline__ void fsv_conv_db_body(const ConvP& p, const int bx, const int by, const int bz, float* skw = nullptr,
+                                                 int* sk_tickets = nullptr, const int tile_lin = 0, const int ntiles = 0) {
   static_assert(PF == 1 || PF == 2, "prefetch distance");
   constexpr int BK = FSV_BK;
   constexpr int NT = 64 * WM * WN;
@@ -182,13 +187,48 @@ __device__ __forceinline__ void fsv_conv_db_body(const ConvP& p, const int bx, c
     }
   }
 
+  bool finish = (p.nsplit == 1);          // this workgroup applies bias / activation / residual and stores the final values
+  if constexpr (WSK) {
+    __shared__ int s_last;
+    constexpr int FR = TM * TN * 16;        // accumulator values per lane
+    float* mine = skw + ((long long)zk * ntiles + tile_lin) * (BM * BN) + (wave * FR) * 64 + lane;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) mine[((i * TN + j) * 16 + r) * 64] = acc[i][j][r];      // 64 lanes: 256 contiguous bytes
+    __threadfence();
+    __syncthreads();
+    if (tid == 0) {
+      const int ticket = atomicAdd(sk_tickets + tile_lin, 1);
+      s_last = (ticket == p.nsplit - 1) ? 1 : 0;
+    }
+    __syncthreads();
+    if (!s_last) return;
+    __threadfence();
+    if (tid == 0) sk_tickets[tile_lin] = 0;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          float v = 0.f;
+          for (int sp = 0; sp < p.nsplit; ++sp)
+            v += __hip_atomic_load(skw + ((long long)sp * ntiles + tile_lin) * (BM * BN) + (wave * FR + (i * TN + j) * 16 + r) * 64 + lane,
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          acc[i][j][r] = v;
+        }
+    finish = true;
+  }
   const float* bias = p.bias ? (p.bias + (long long)zs * p.b_bstride) : nullptr;
   const float ws = p.wscale ? p.wscale[0] : 1.f;
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
     const int co = bn0 + wn * (TN * 32) + j * 32 + lrow;
     if (co >= p.Cout) continue;
-    const float bv = (bias && p.nsplit == 1) ? bias[co] : 0.f;
+    const float bv = (bias && finish) ? bias[co] : 0.f;
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -207,7 +247,7 @@ __device__ __forceinline__ void fsv_conv_db_body(const ConvP& p, const int bx, c
         }
         float* dst = p.out + opix * p.Cout + co;
         float v = acc[i][j][r] * ws;
-        if (p.nsplit > 1) {
+        if (!finish) {
           atomicAdd(dst, v);
         } else {
           v = (v + bv) * p.scale;
@@ -238,6 +278,15 @@ __global__ __launch_bounds__(64 * WM * WN) void fsv_conv_igemm_dbx_kernel(ConvP 
   const int by = slot % GY, bx = (slot / GY) * 8 + xcd;
   if (bx >= GX) return;                              // padding of the last group of 8 pixel tiles (uniform per workgroup)
   fsv_conv_db_body<BM, BN, WM, WN, PF>(p, bx, by, blockIdx.z);
+}
+
+// ---- split-K through a workspace (see WSK above) ------------------------------------------------------------------------------
+template <int BM, int BN, int WM, int WN, int PF>
+__global__ __launch_bounds__(64 * WM * WN) void fsv_conv_igemm_dbk_kernel(ConvP p, float* skw, int* sk_tickets) {
+  const int zs = blockIdx.z / p.nsplit;
+  const int tile_lin = (zs * (int)gridDim.y + (int)blockIdx.y) * (int)gridDim.x + (int)blockIdx.x;
+  const int ntiles = (int)(gridDim.z / p.nsplit) * (int)gridDim.y * (int)gridDim.x;
+  fsv_conv_db_body<BM, BN, WM, WN, PF, true>(p, blockIdx.x, blockIdx.y, blockIdx.z, skw, sk_tickets, tile_lin, ntiles);
 }
 
 // ---- merged stride-2 data gradient: the four output-parity classes of one layer in ONE launch ----------------------------------
@@ -513,6 +562,60 @@ extern "C" int fsv_conv_dgrad_s2(const float* in, const float* const* wt, float*
     else FSV_LAUNCH((fsv_conv_igemm_db4_kernel<128, 64, 2, 2, 1>), g, block, stream, q);
   } else {
     return FSV_ERR_UNSUPPORTED;          // 128x128 / thin tiles have no double-buffered variant
+  }
+  return fsv_check_launch();
+}
+
+
+// Split-K convolution / linear layer WITHOUT zero fill, atomics and finishing pass (opt-in): same arguments as
+// fsv_conv_gather_fwd (no `accumulate` mode) plus the workspace - skw: nsplit x tiles x BM*BN floats, sk_tickets: one int per
+// output tile, zero between launches.  *ws_floats / *n_tickets: when skw is null the call only reports the sizes this launch
+// needs (0 / 0 and FSV_ERR_UNSUPPORTED when the plan does not split or its tile has no double-buffered variant).
+extern "C" int fsv_conv_gather_fwd_splitws(const float* in, const float* wt, const float* bias, const float* res, float* out,
+                                           int N, int H, int W, int Cin, int OH, int OW, int Cout,
+                                           int ntaps, const int* ty, const int* tx, int sy, int sx,
+                                           int outH, int outW, int osy, int osx, int ooy, int oox,
+                                           int ldw, long long w_bstride, long long b_bstride, int per_sample,
+                                           int act, float scale, const float* wscale, float* skw, int* sk_tickets,
+                                           long long* ws_floats, int* n_tickets, int prefetch, hipStream_t stream) {
+  if (!in || !wt || !out || ntaps < 1 || ntaps > 16 || N < 1 || Cin < 1 || Cout < 1 || !ws_floats || !n_tickets) return FSV_ERR_BAD_ARG;
+  *ws_floats = 0; *n_tickets = 0;
+  if ((Cin & 3) != 0) return FSV_ERR_UNSUPPORTED;
+  for (int t = 0; t < ntaps; ++t)
+    if (ty[t] < -8 || ty[t] > 7 || tx[t] < -8 || tx[t] > 7) return FSV_ERR_UNSUPPORTED;
+  if ((ldw & 3) != 0 || ldw < Cout) return FSV_ERR_BAD_ARG;
+  ConvP p;
+  p.in = in; p.wt = wt; p.bias = bias; p.res = res; p.out = out; p.wscale = wscale;
+  p.N = N; p.H = H; p.W = W; p.Cin = Cin; p.OH = OH; p.OW = OW; p.Cout = Cout;
+  p.K = ntaps * Cin; p.nchunks = fsv_cdiv(p.K, FSV_BK); p.ldw = ldw;
+  p.sy = sy; p.sx = sx; p.ntaps = ntaps;
+  fsv_db_pack_taps(ty, tx, ntaps, p.taps_lo, p.taps_hi);
+  p.outH = outH; p.outW = outW; p.osy = osy; p.osx = osx; p.ooy = ooy; p.oox = oox;
+  p.dense_out = (osy == 1 && osx == 1 && ooy == 0 && oox == 0 && outH == OH && outW == OW) ? 1 : 0;
+  p.w_bstride = w_bstride; p.b_bstride = b_bstride; p.per_sample = per_sample ? 1 : 0;
+  p.act = act; p.scale = scale;
+  p.Mz = per_sample ? OH * OW : N * OH * OW;
+  const int nsamp = per_sample ? N : 1;
+  int tile = 0, nsplit = 1;
+  if (fsv_conv_plan(p.Mz, Cout, p.nchunks, nsamp, -1, 0, &tile, &nsplit)) return FSV_ERR_BAD_ARG;
+  if (nsplit < 2 || (tile != 4 && tile != 9 && tile != 1)) return FSV_ERR_UNSUPPORTED;
+  p.nsplit = nsplit;
+  const int bm = (tile == 1) ? 128 : 64, bn = (tile == 9) ? 128 : 64;
+  const int gx = fsv_cdiv(p.Mz, bm), gy = fsv_cdiv(Cout, bn);
+  *n_tickets = gx * gy * nsamp;
+  *ws_floats = (long long)nsplit * gx * gy * nsamp * bm * bn;
+  if (!skw || !sk_tickets) return FSV_OK;            // size query
+  dim3 g(gx, gy, nsamp * nsplit), block(256);
+  const int pf = prefetch == 2 ? 2 : 1;
+  if (tile == 4) {
+    if (pf == 2) FSV_LAUNCH((fsv_conv_igemm_dbk_kernel<64, 64, 2, 2, 2>), g, block, stream, p, skw, sk_tickets);
+    else FSV_LAUNCH((fsv_conv_igemm_dbk_kernel<64, 64, 2, 2, 1>), g, block, stream, p, skw, sk_tickets);
+  } else if (tile == 9) {
+    if (pf == 2) FSV_LAUNCH((fsv_conv_igemm_dbk_kernel<64, 128, 2, 2, 2>), g, block, stream, p, skw, sk_tickets);
+    else FSV_LAUNCH((fsv_conv_igemm_dbk_kernel<64, 128, 2, 2, 1>), g, block, stream, p, skw, sk_tickets);
+  } else {
+    if (pf == 2) FSV_LAUNCH((fsv_conv_igemm_dbk_kernel<128, 64, 2, 2, 2>), g, block, stream, p, skw, sk_tickets);
+    else FSV_LAUNCH((fsv_conv_igemm_dbk_kernel<128, 64, 2, 2, 1>), g, block, stream, p, skw, sk_tickets);
   }
   return fsv_check_launch();
 }

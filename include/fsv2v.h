@@ -53,6 +53,19 @@ int fsv_conv_gather_fwd(const float* in, const float* wt, const float* bias, con
                         int act, float scale, int force_tile, int force_split, int accumulate, const float* wscale,
                         fsv_stream_t stream);
 
+/* Split-K WITHOUT zero fill, atomics and finishing pass (opt-in; csrc/conv_igemm_db.hip): the contract of fsv_conv_gather_fwd
+ * (no accumulate mode) plus a workspace.  Every K split stores its partial tile to skw and takes a ticket; the workgroup drawing a
+ * tile's last ticket adds the splits in the order 0, 1, 2, ... and applies bias / activation / residual: one launch, and a result that
+ * is bit-reproducible from run to run.  skw == NULL: only report the sizes (*ws_floats, *n_tickets; tickets must be zero between
+ * launches).  FSV_ERR_UNSUPPORTED when the launch plan does not split or picks a tile without a double-buffered variant. */
+int fsv_conv_gather_fwd_splitws(const float* in, const float* wt, const float* bias, const float* res, float* out,
+                                int N, int H, int W, int Cin, int OH, int OW, int Cout,
+                                int ntaps, const int* ty, const int* tx, int sy, int sx,
+                                int outH, int outW, int osy, int osx, int ooy, int oox,
+                                int ldw, long long w_bstride, long long b_bstride, int per_sample,
+                                int act, float scale, const float* wscale, float* skw, int* sk_tickets,
+                                long long* ws_floats, int* n_tickets, int prefetch, fsv_stream_t stream);
+
 /* The four output-parity classes of a stride-2 data gradient in ONE launch (opt-in; csrc/conv_igemm_db.hip).  Class k: K-major
  * weights wt[k], ntaps[k] taps at ty / tx[16*k ...], iteration grid sub_h[k] x sub_w[k], output pixel (2y + py[k], 2x + px[k]) of the
  * [N][outH][outW][Cout] tensor; `in` is the incoming gradient [N][H][W][Cin].  Returns FSV_ERR_UNSUPPORTED (-2) when the launch plan

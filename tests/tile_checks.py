@@ -63,6 +63,7 @@ if __name__ == '__main__':
     check_split_tiles(dev)
     check_wgrad_few_wave(dev)
     check_dgrad_merge(dev)
+    check_splitk_ws(dev, reps=10)
     print('TILES_GPU_OK', flush=True)
 
 
@@ -84,3 +85,28 @@ def check_dgrad_merge(device, seed=81):
             finally:
                 conv.set_dgrad_merge(prev)
         assert torch.equal(res[0], res[1]) and torch.equal(res[0], res[2]), (n, cin, h, w, cout, k, p)
+
+
+def check_splitk_ws(device, seed=82, reps=3):
+    """split-K through a workspace: equal to torch, and (unlike the atomic path) bit-reproducible from run to run"""
+    import torch.nn.functional as F
+    ops, conv = oc.pkg()
+    g = torch.Generator().manual_seed(seed)
+    for (n, cin, h, w, cout, k, s, p) in ((2, 256, 8, 8, 256, 3, 1, 1), (1, 512, 4, 4, 192, 3, 1, 1), (2, 128, 9, 7, 72, 3, 1, 1),
+                                          (2, 1024, 16, 16, 512, 3, 1, 1), (2, 512, 32, 32, 512, 3, 1, 1)):
+        x = torch.randn(n, cin, h, w, generator=g)
+        wt = torch.randn(cout, cin, k, k, generator=g) * 0.05
+        b = torch.randn(cout, generator=g)
+        ref = F.leaky_relu(F.conv2d(x, wt, b, stride=s, padding=p), 0.2)
+        geo = conv.Geom(k, k, s, p)
+        wf, _, ldw = conv.prep_weight(wt.to(device), 0, geo)
+        for m in (1, 2):
+            prev = conv.set_splitk_ws(m)
+            try:
+                ys = [conv.conv_forward(conv.to_nhwc(x.to(device)), wf, ldw, cout, geo, bias=b.to(device), act=conv.ACT_LRELU).cpu()
+                      for _ in range(reps)]
+            finally:
+                conv.set_splitk_ws(prev)
+            oc.assert_close('workspace split-K', ys[0], ref, 1e-4)
+            for y in ys[1:]:
+                assert torch.equal(y, ys[0]), 'workspace split-K is not reproducible'

@@ -28,6 +28,8 @@ run bench_xcd       300 env FSV_TILE_REMAP=4:19,9:20,1:21 python bench.py --step
 run bench_fewwave   300 env FSV_TILE_REMAP=4:10,9:11,1:12 FSV_WGRAD_VARIANT=fw python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-roofline
 run bench_fusedfin  300 env FSV_FUSED_FINAL=1 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-roofline
 run bench_dgradmrg  300 env FSV_DGRAD_MERGE=2 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-roofline
+run bench_splitws   300 env FSV_SPLITK_WS=1 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-roofline
+run bench_allopt    300 env FSV_SPLITK_WS=2 FSV_DGRAD_MERGE=2 FSV_FUSED_FINAL=1 FSV_TILE_REMAP=4:16,9:17,1:18 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-roofline
 run bench_amp_o1    300 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --amp O1
 run bench_bf16x3    300 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --amp bf16x3
 run bench_f32_again 300 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-roofline      # drift check: same box, same code as bench_f32
