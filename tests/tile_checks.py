@@ -108,5 +108,14 @@ def check_splitk_ws(device, seed=82, reps=3):
             finally:
                 conv.set_splitk_ws(prev)
             oc.assert_close('workspace split-K', ys[0], ref, 1e-4)
-            for y in ys[1:]:
-                assert torch.equal(y, ys[0]), 'workspace split-K is not reproducible'
+            # reproducibility only holds where the workspace path really ran (the entry point declines launches that the plan does
+            # not split or gives a tile without a double-buffered variant; those keep the atomic path)
+            import ctypes
+            lib = __import__('importlib').import_module(conv.__name__.rsplit('.', 1)[0] + '.lib')
+            lib.register_sigs({"fsv_conv_plan": [ctypes.c_int] * 6 + [ctypes.POINTER(ctypes.c_int)] * 2})
+            tile, nsplit = ctypes.c_int(0), ctypes.c_int(1)
+            oh, ow = geo.out_hw(h, w)
+            lib.call("fsv_conv_plan", n * oh * ow, cout, (k * k * cin + 31) // 32, 1, -1, 0, ctypes.byref(tile), ctypes.byref(nsplit))
+            if nsplit.value > 1 and tile.value in (1, 4, 9):
+                for y in ys[1:]:
+                    assert torch.equal(y, ys[0]), 'workspace split-K is not reproducible'
