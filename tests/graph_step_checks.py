@@ -37,7 +37,7 @@ def _run(device, graphed, iters, seed, opt_kw, b=1):
 
 
 def check_graphed_iteration(device, iters=5, seed=500, tol=0.0):
-    kw = dict(warp_ref=True, spade_combine=True, remove_face_labels=True)
+    kw = dict(warp_ref=True, spade_combine=True, remove_face_labels=True, fineSize=32, loadSize=32, n_downsample_G=3, n_adaptive_layers=2)
     ref, pG, pD, _ = _run(device, False, iters, seed, kw)
     got, qG, qD, step = _run(device, True, iters, seed, kw)
     assert len(step.entries) == 1

@@ -49,12 +49,12 @@ def test_training_step_is_bit_identical_with_fewer_launches(emu_lib):
     for fused in (False, True):
         prev = ops.set_fused_final(fused)
         try:
-            opt = mc.tiny_opt(warp_ref=True, spade_combine=True, remove_face_labels=True)
+            opt = mc.tiny_opt(warp_ref=True, spade_combine=True, remove_face_labels=True, fineSize=32, loadSize=32, n_downsample_G=3, n_adaptive_layers=2)
             model = M.create_model(opt)
             mc.fill_state(model.netG); mc.fill_state(model.netD)
             model.train()
             opt_G, opt_D = model.build_optimizers()
-            tl, ti, rl, ri = mc.synth_pose_inputs(1, 64, 64, 901, opt.input_nc)
+            tl, ti, rl, ri = mc.synth_pose_inputs(1, 32, 32, 901, opt.input_nc)
             data = [tl, ti, [None, None], [None, None], rl, ri, None, None, None]
             counts = []
             for it in range(2):
@@ -70,4 +70,4 @@ def test_training_step_is_bit_identical_with_fewer_launches(emu_lib):
     a, b = out
     assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and a[2] == b[2] and a[3] == b[3]
     print('launches per iteration: two-stage %d, fused %d' % (a[4], b[4]))
-    assert b[4] <= a[4] - 100, (a[4], b[4])
+    assert b[4] <= a[4] - 60, (a[4], b[4])

@@ -62,13 +62,13 @@ def test_step_matches_and_saves_launches(emu_lib):
     for m in (0, 1):
         prev = conv.set_splitk_ws(m)
         try:
-            opt = mc.tiny_opt(warp_ref=True, spade_combine=True, remove_face_labels=True, ngf=8, nff=8, ndf=8)
+            opt = mc.tiny_opt(warp_ref=True, spade_combine=True, remove_face_labels=True, ngf=16, nff=16, ndf=8, fineSize=32, loadSize=32, n_downsample_G=3, n_adaptive_layers=2)
             model = M.create_model(opt)
             mc.fill_state(model.netG); mc.fill_state(model.netD)
             model.train()
             opt_G, opt_D = model.build_optimizers()
             opt_G.set_lr(0.0); opt_D.set_lr(0.0)
-            tl, ti, rl, ri = mc.synth_pose_inputs(1, 64, 64, 903, opt.input_nc)
+            tl, ti, rl, ri = mc.synth_pose_inputs(1, 32, 32, 903, opt.input_nc)
             data = [tl, ti, [None, None], [None, None], rl, ri, None, None, None]
             for it in range(2):
                 n0 = _launches()
