@@ -18,7 +18,7 @@ def test_narrow_operand_kernels_on_hardware():
     env = dict(os.environ)
     env.pop('FSV2V_EMU', None)
     r = subprocess.run([sys.executable, os.path.join(HERE, 'np_checks.py')], cwd=HERE, env=env, capture_output=True, text=True,
-                       timeout=600)
+                       timeout=420)
     sys.stdout.write(r.stdout[-4000:])
     sys.stderr.write(r.stderr[-4000:])
     assert r.returncode == 0 and 'NP_GPU_OK' in r.stdout
@@ -30,7 +30,7 @@ def test_experimental_tiles_on_hardware():
     env = dict(os.environ)
     env.pop('FSV2V_EMU', None)
     r = subprocess.run([sys.executable, os.path.join(HERE, 'tile_checks.py')], cwd=HERE, env=env, capture_output=True, text=True,
-                       timeout=300)
+                       timeout=240)
     sys.stdout.write(r.stdout[-4000:])
     sys.stderr.write(r.stderr[-4000:])
     assert r.returncode == 0 and 'TILES_GPU_OK' in r.stdout
@@ -42,7 +42,7 @@ def test_graphed_iteration_on_hardware():
     env = dict(os.environ)
     env.pop('FSV2V_EMU', None)
     r = subprocess.run([sys.executable, os.path.join(HERE, 'graph_step_checks.py')], cwd=HERE, env=env, capture_output=True,
-                       text=True, timeout=600)
+                       text=True, timeout=300)
     sys.stdout.write(r.stdout[-4000:])
     sys.stderr.write(r.stderr[-4000:])
     assert r.returncode == 0 and 'GRAPH_STEP_GPU_OK' in r.stdout
@@ -54,7 +54,7 @@ def test_fused_final_on_hardware():
     env = dict(os.environ)
     env.pop('FSV2V_EMU', None)
     r = subprocess.run([sys.executable, os.path.join(HERE, 'fused_final_checks.py')], cwd=HERE, env=env, capture_output=True,
-                       text=True, timeout=300)
+                       text=True, timeout=180)
     sys.stdout.write(r.stdout[-4000:])
     sys.stderr.write(r.stderr[-4000:])
     assert r.returncode == 0 and 'FUSED_FINAL_GPU_OK' in r.stdout
