@@ -174,21 +174,6 @@ def gather_gemm(x, wt, ldw, cout, oh, ow, ty, tx, sy, sx, bias=None, res=None, a
             n, h, w, cin, oh, ow, cout, len(ty), lib.int_array(ty), lib.int_array(tx), sy, sx,
             out_h, out_w, osy, osx, ooy, oox, ldw, w_bs, b_bs, 1 if per_sample else 0,
             act, float(scale), force_tile, force_split, 1 if accumulate else 0, lib.ptr(wscale), lib.stream_ptr())
-    if (_splitk_ws() and not accumulate and not _mfma_mode and cin % 4 == 0 and force_tile < 0 and force_split == 0):
-        wsf, nt = ctypes.c_longlong(0), ctypes.c_int(0)
-        sargs = args[:29] + (lib.ptr(wscale),)
-        rc = lib.call_status("fsv_conv_gather_fwd_splitws", *sargs, None, None, ctypes.byref(wsf), ctypes.byref(nt), _splitk_ws(),
-                             lib.stream_ptr())
-        if rc == 0 and wsf.value > 0:
-            skw = torch.empty(wsf.value, dtype=torch.float32, device=x.device)
-            tk = _tickets(nt.value, x)
-            rc = lib.call_status("fsv_conv_gather_fwd_splitws", *sargs, lib.ptr(skw), lib.ptr(tk), ctypes.byref(wsf),
-                                 ctypes.byref(nt), _splitk_ws(), lib.stream_ptr())
-            if rc != 0:
-                raise lib.FsvError("fsv_conv_gather_fwd_splitws failed with fsv_status %d" % rc)
-            return out
-        if rc not in (0, -2):
-            raise lib.FsvError("fsv_conv_gather_fwd_splitws failed with fsv_status %d" % rc)
     entry = "fsv_conv_gather_fwd"
     if _mfma_mode and cin % 4 == 0:               # scalar-gather layers (3-channel images, labels) stay on the fp32 kernel
         entry = "fsv_conv_gather_fwd_np"
@@ -213,51 +198,6 @@ def conv_forward(x, wt_f, ldw, cout, geom, bias=None, res=None, act=ACT_NONE, sc
     return gather_gemm(x, wt_f, ldw, cout, oh, ow, geom.ty, geom.tx, geom.stride, geom.stride, bias=bias, res=res,
                        act=act, scale=scale, per_sample=per_sample, force_tile=force_tile, force_split=force_split,
                        wscale=wscale)
-
-
-# FSV_SPLITK_WS=1 | 2 (opt-in; 2 = with two-chunk prefetch): split-K launches go through a workspace instead of zero fill +
-# atomics + finishing pass (csrc/conv_igemm_db.hip fsv_conv_gather_fwd_splitws) - one launch instead of three, and a fixed
-# summation order (bit-reproducible from run to run, which atomics are not)
-_SPLITK_WS = None
-_sk_tickets = {}
-
-
-def _splitk_ws():
-    global _SPLITK_WS
-    if _SPLITK_WS is None:
-        _SPLITK_WS = int(os.environ.get('FSV_SPLITK_WS', '0') or 0)
-    return _SPLITK_WS
-
-
-def set_splitk_ws(v):
-    global _SPLITK_WS
-    prev = _splitk_ws()
-    _SPLITK_WS = int(v)
-    return prev
-
-
-def _tickets(n, like):
-    t = _sk_tickets.get(like.device)
-    if t is None or t.numel() < n:
-        t = _sk_tickets[like.device] = torch.zeros(max(n, 1 << 16), dtype=torch.int32, device=like.device)
-    return t
-
-
-_DGRAD_MERGE = None
-
-
-def _dgrad_merge():
-    global _DGRAD_MERGE
-    if _DGRAD_MERGE is None:
-        _DGRAD_MERGE = int(os.environ.get('FSV_DGRAD_MERGE', '0') or 0)
-    return _DGRAD_MERGE
-
-
-def set_dgrad_merge(v):
-    global _DGRAD_MERGE
-    prev = _dgrad_merge()
-    _DGRAD_MERGE = int(v)
-    return prev
 
 
 def _planned_split(mz, cout, nchunks, nsamp):
@@ -298,29 +238,6 @@ def conv_dgrad(dout, w, geom, in_hw, scale=None, per_sample=False, cached=None, 
             if _planned_split(mz, cin, (len(c['khs']) * cout + 31) // 32, n if per_sample else 1) > 1:
                 plain = False
                 break
-    if plain and s == 2 and len(geom.dgrad_classes) == 4 and cout % 4 == 0 and _dgrad_merge():
-        # opt-in (FSV_DGRAD_MERGE=1 | 2 = with two-chunk prefetch): the four parity classes in ONE launch; the entry point
-        # declines (FSV_ERR_UNSUPPORTED) when its tile has no double-buffered variant and the per-class loop below takes over
-        dx = empty_nhwc(n, cin, h, wd, dout)
-        lays = [layout(k, c) for k, c in enumerate(geom.dgrad_classes)]
-        ldw, ws = lays[0][1], lays[0][2]
-        if all(l[1] == ldw for l in lays):
-            ty, tx = [0] * 64, [0] * 64
-            for k, c in enumerate(geom.dgrad_classes):
-                ty[k * 16:k * 16 + len(c['ty'])] = c['ty']
-                tx[k * 16:k * 16 + len(c['tx'])] = c['tx']
-            wts = (ctypes.c_void_p * 4)(*[l[0].data_ptr() for l in lays])
-            wbs = (ctypes.c_longlong * 4)(*[(l[0].shape[-2] * l[0].shape[-1] if per_sample else 0) for l in lays])
-            lib.check_device(dout, dx, ws, *[l[0] for l in lays])
-            rc = lib.call_status("fsv_conv_dgrad_s2", lib.ptr(dout), wts, lib.ptr(dx), n, oh, ow, cout, cin,
-                                 lib.int_array([len(c['khs']) for c in geom.dgrad_classes]), lib.int_array(ty), lib.int_array(tx),
-                                 lib.int_array([sh for sh, _ in subs]), lib.int_array([sw for _, sw in subs]),
-                                 lib.int_array([c['py'] for c in geom.dgrad_classes]), lib.int_array([c['px'] for c in geom.dgrad_classes]),
-                                 h, wd, ldw, wbs, 1 if per_sample else 0, lib.ptr(ws), _dgrad_merge(), lib.stream_ptr())
-            if rc == 0:
-                return dx
-            if rc != -2:
-                raise lib.FsvError("fsv_conv_dgrad_s2 failed with fsv_status %d" % rc)
     dx = empty_nhwc(n, cin, h, wd, dout) if plain else zeros_nhwc(n, cin, h, wd, dout)
     for k, (c, (sub_h, sub_w)) in enumerate(zip(geom.dgrad_classes, subs)):
         if sub_h <= 0 or sub_w <= 0 or not c['khs']:

@@ -1,8 +1,48 @@
-// Parameter block and tap decoding shared by the implicit-GEMM convolution kernels (conv_igemm.hip, conv_igemm_db.hip).
+// Parameter block and tap decoding shared by the implicit-GEMM convolution kernels (conv_igemm.hip, conv_np.hip).
 #pragma once
 #include "fsv_common.h"
 
 #define FSV_BK 32
+
+// ---- 16-byte loads through a buffer descriptor -------------------------------------------------------------------------
+// The gather-GEMM kernels need "this row / tap / column does not exist -> zeros".  A select on the LOADED value makes the
+// compiler wait for the load right where it was issued, and a select between two POINTERS is turned into a branch around
+// two loads with a vmcnt(0) each (round-2 ISA audit; cdna_hip_programming.md section 5 trap 4c).  A buffer load solves it in
+// hardware: the per-lane byte offset is range-checked against the descriptor and an out-of-range lane returns zeros
+// without touching memory - so "absent" is just the offset FSV_BUF_OOB, an integer select before the load.  Descriptors
+// are built from kernel arguments and blockIdx only (provably wave-uniform: no waterfall loop, guide T20).
+#define FSV_BUF_OOB 0x80000000u
+#define FSV_BUF_MAX_BYTES 0x80000000ll      // one descriptor covers at most 2 GiB
+#ifdef FSV_EMU
+struct fsv_buf { const char* base; unsigned bytes; };
+static inline fsv_buf fsv_make_buf(const void* p, long long bytes) { fsv_buf b; b.base = (const char*)p; b.bytes = (unsigned)bytes; return b; }
+static inline float4 fsv_buf_load4(const fsv_buf& b, unsigned off) {
+  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (off < b.bytes && (unsigned long long)off + 16ull <= (unsigned long long)b.bytes) memcpy(&v, b.base + off, 16);
+  return v;
+}
+static inline float fsv_buf_load1(const fsv_buf& b, unsigned off) {
+  float v = 0.f;
+  if (off < b.bytes && (unsigned long long)off + 4ull <= (unsigned long long)b.bytes) memcpy(&v, b.base + off, 4);
+  return v;
+}
+#define FSV_SCHED_FENCE() ((void)0)
+#else
+typedef __amdgpu_buffer_rsrc_t fsv_buf;
+typedef unsigned int fsv_u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ fsv_buf fsv_make_buf(const void* p, long long bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), (short)0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ float4 fsv_buf_load4(fsv_buf b, unsigned off) {
+  return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(b, off, 0, 0));
+}
+__device__ __forceinline__ float fsv_buf_load1(fsv_buf b, unsigned off) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(b, off, 0, 0));
+}
+// nothing is scheduled across this point: keeps the next chunk's loads at the top of the K loop and their LDS stores (with
+// the vmcnt waits they carry) behind the MFMAs that cover the latency
+#define FSV_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+#endif
 
 struct ConvP {
   const float* in;
@@ -44,7 +84,3 @@ struct WgradP {
   int Mz;                  // pixels per z group
   int pchunks;             // ceil(Mz/32)
 };
-
-// double-buffered variants (conv_igemm_db.hip); tile ids 13 / 14 / 15 = 64x64 / 64x128 / 128x64
-int fsv_launch_conv_db(const ConvP& p, int nz, hipStream_t stream, int tile);
-int fsv_launch_wgrad_db(const WgradP& p, int bmk, int bn, dim3 grid, hipStream_t stream);      // 64x64 / 64x128, force_tile 7 / 8

@@ -16,8 +16,278 @@
 // 1e-3 relative tolerance against the fp32 CPU oracle with a wide margin.
 #include "conv_igemm.h"
 
-template <int BM, int BN, int WM, int WN, int V>
+// Byte offsets inside one tensor are 32-bit (checked on the host: tensor < 2 GiB); rows / taps outside the image, K-tail
+// columns and weight columns beyond ldw are loaded at the out-of-range offset FSV_BUF_OOB (hardware zero fill, conv_igemm.h)
+// instead of being zeroed after the load.  That matters: a select on the LOADED value makes the compiler wait for the load
+// right where it was issued (s_waitcnt vmcnt(0) at the top of the MFMA block - the whole L2 / HBM latency exposed once per
+// K chunk, measured round 2: an fp16-operand twin of the old loop ran only 1.3x faster than fp32 although its MFMA work
+// is 1/16); now the loaded registers are first touched by the LDS stores behind the chunk's MFMAs.
+
+// XCD-aware tile order (MI355X_MICROARCH.md "Workgroup dispatch": linear workgroup b runs on XCD b % 8, each XCD has its
+// own L2).  The workgroups that share the activation tile of one pixel tile (all `ny` channel tiles) are given ids that
+// are congruent mod 8 and adjacent in dispatch order, so the gathered activations are fetched into ONE L2.
+__device__ __forceinline__ void fsv_xcd_tile(int nx, int ny, int& bx, int& by) {
+  const int b = blockIdx.x + blockIdx.y * nx;
+  if ((nx & 7) != 0 || ny == 1) { bx = blockIdx.x; by = blockIdx.y; return; }
+  const int xcd = b & 7, j = b >> 3;
+  by = j % ny;
+  bx = xcd + 8 * (j / ny);
+}
+
+// V4 kernel (Cin % 4 == 0).  LDS images, two buffers each (one barrier per 32-wide K chunk):
+//   A [BM rows][8 quads of 4 k]: quad q of row r sits in slot q ^ ((r >> 1) & 7) - written with ds_write_b128 (8 lanes = one
+//     row = 8 distinct slots) and read back as MFMA fragments with ds_read_b128 (16-lane service groups see 16 distinct
+//     (row parity, slot) pairs): both conflict free, and 4x fewer LDS instructions than a transposed [k][m] image;
+//   B [32 k][BN] as it lies in HBM: ds_write_b128 rows, ds_read_b32 fragments (32 consecutive columns).
+// MFMA k order inside a chunk: step (g, t) multiplies k = 8g + t (lanes 0-31) and k = 8g + 4 + t (lanes 32-63), so that
+// one b128 read of A feeds four MFMA steps.  The sum over k is still one fp32 fma chain per output (order permuted).
+// PIPE = 1: the LDS fragment reads of k-group g + 1 are issued (into a second register set) BEFORE the MFMAs of group g and
+// pinned there with scheduling fences - left alone the compiler sinks every read next to its MFMAs and waits for it
+// (read, s_waitcnt lgkmcnt(0), two MFMAs, read, ...), which exposes the LDS latency whenever a SIMD holds a single wave.
+template <int BM, int BN, int WM, int WN, int PIPE>
 __global__ __launch_bounds__(64 * WM * WN) void fsv_conv_igemm_kernel(ConvP p) {
+  constexpr int BK = FSV_BK;
+  constexpr int NT = 64 * WM * WN;    // 4 or 8 waves
+  constexpr int RPA = NT / 8;         // A rows per pass (8 threads per row)
+  constexpr int TM = BM / (WM * 32), TN = BN / (WN * 32);
+  constexpr int NPA = BM / RPA;       // A rows per thread and chunk
+  constexpr int QB = BN / 4;          // B float4 per k row
+  constexpr int RPB = NT / QB;        // B rows per pass
+  constexpr int NPB = BK / RPB;       // B passes
+  constexpr int A_ST = BM * BK, B_ST = BK * BN;
+  static_assert(TM >= 1 && TN >= 1 && NPA >= 1 && NPA * RPA == BM && NPB >= 1 && NPB * RPB == BK, "tile / thread-count mismatch");
+  __shared__ __attribute__((aligned(16))) float smem[2 * (A_ST + B_ST)];
+  float* const As = smem;
+  float* const Bs = smem + 2 * A_ST;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int zs = blockIdx.z / p.nsplit, zk = blockIdx.z % p.nsplit;
+  int bx, by;
+  fsv_xcd_tile(gridDim.x, gridDim.y, bx, by);
+  const int bm0 = bx * BM, bn0 = by * BN;
+  const float* wt = p.wt + (long long)zs * p.w_bstride;
+
+  // ---- per-thread A row bookkeeping ------------------------------------------------------------------
+  const int kq = tid & 7, ar0 = tid >> 3;
+  int a_iy0[NPA], a_ix0[NPA], a_pix[NPA];
+  const int ohw = p.OH * p.OW;
+#pragma unroll
+  for (int i = 0; i < NPA; ++i) {
+    int m = bm0 + ar0 + i * RPA;
+    if (m < p.Mz) {
+      int n, rem;
+      if (p.per_sample) { n = zs; rem = m; } else { n = m / ohw; rem = m - n * ohw; }
+      int oy = rem / p.OW, ox = rem - oy * p.OW;
+      a_iy0[i] = oy * p.sy; a_ix0[i] = ox * p.sx;
+      a_pix[i] = ((n * p.H + a_iy0[i]) * p.W + a_ix0[i]) * p.Cin * 4;      // byte offset of tap (0, 0), channel 0
+    } else {
+      a_iy0[i] = -(1 << 28); a_ix0[i] = 0; a_pix[i] = 0;
+    }
+  }
+  const int bq = tid % QB, br0 = tid / QB;
+  const int bcol = bn0 + bq * 4;
+  const bool bcol_ok = bcol < p.ldw;
+  const fsv_buf abuf = fsv_make_buf(p.in, (long long)p.N * p.H * p.W * p.Cin * 4);
+  const fsv_buf bbuf = fsv_make_buf(wt, (long long)p.nchunks * BK * p.ldw * 4);
+
+  // chunk range of this K split
+  const int cps = (p.nchunks + p.nsplit - 1) / p.nsplit;
+  const int c_begin = zk * cps;
+  const int c_end = (c_begin + cps < p.nchunks) ? (c_begin + cps) : p.nchunks;
+
+  float4 areg[NPA], breg[NPB];
+  unsigned aoff[NPA], boff[NPB];
+  // Byte offsets of one chunk's loads (FSV_BUF_OOB = "absent": hardware zero fill), computed one chunk ahead of their loads
+  // so that this VALU work sits between the MFMAs instead of in front of them.  Branch-free on purpose (a guarded integer
+  // division becomes a basic block of its own, which the scheduler cannot interleave with the MFMAs): the thread's K
+  // position (tap t, channel ci) is advanced by 32 per chunk with precomputed 32 / Cin and 32 % Cin.  Chunks past c_end
+  // are harmless: k >= K and weight rows >= nchunks * 32 are out of range for their descriptors.
+  int cur_k = c_begin * BK + kq * 4;
+  int cur_t = cur_k / p.Cin;
+  int cur_ci = cur_k - cur_t * p.Cin;
+  const int q32 = BK / p.Cin, r32 = BK - q32 * p.Cin;
+  int cur_b = (c_begin * BK + br0) * p.ldw + bcol;      // element offset of this thread's first weight row
+  auto calc_offsets = [&]() {
+    const bool kok = cur_k < p.K;
+    int ty, tx;
+    fsv_tap(p, cur_t, ty, tx);
+    const int toff = ((ty * p.W + tx) * p.Cin + cur_ci) * 4;
+#pragma unroll
+    for (int i = 0; i < NPA; ++i) {
+      const int iy = a_iy0[i] + ty, ix = a_ix0[i] + tx;
+      // `&`, not `&&`: a short-circuit here turns the whole offset computation into a guarded basic block
+      const bool ok = kok & ((unsigned)iy < (unsigned)p.H) & ((unsigned)ix < (unsigned)p.W);
+      aoff[i] = ok ? (unsigned)(a_pix[i] + toff) : FSV_BUF_OOB;
+    }
+#pragma unroll
+    for (int i = 0; i < NPB; ++i) boff[i] = bcol_ok ? (unsigned)((cur_b + i * RPB * p.ldw) * 4) : FSV_BUF_OOB;
+    cur_k += BK;
+    cur_t += q32;
+    cur_ci += r32;
+    const bool wrap = cur_ci >= p.Cin;
+    cur_ci = wrap ? cur_ci - p.Cin : cur_ci;
+    cur_t = wrap ? cur_t + 1 : cur_t;
+    cur_b += BK * p.ldw;
+  };
+  auto issue_loads = [&]() {
+#pragma unroll
+    for (int i = 0; i < NPA; ++i) areg[i] = fsv_buf_load4(abuf, aoff[i]);
+#pragma unroll
+    for (int i = 0; i < NPB; ++i) breg[i] = fsv_buf_load4(bbuf, boff[i]);
+  };
+  auto store_chunk = [&](int buf) {
+    float* a_dst = As + buf * A_ST;
+    float* b_dst = Bs + buf * B_ST;
+#pragma unroll
+    for (int i = 0; i < NPA; ++i) {
+      const int r = ar0 + i * RPA;
+      *reinterpret_cast<float4*>(&a_dst[r * BK + ((kq ^ ((r >> 1) & 7)) << 2)]) = areg[i];
+    }
+#pragma unroll
+    for (int i = 0; i < NPB; ++i) {
+      const int kr = br0 + i * RPB;
+      *reinterpret_cast<float4*>(&b_dst[kr * BN + bq * 4]) = breg[i];
+    }
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int lrow = lane & 31, lk = lane >> 5;
+  // fragment addresses inside a buffer: A row (wm, i, lrow), quad 2g + lk; B row 8g + 4lk + t, column (wn, j, lrow)
+  int a_off[TM], a_swz[TM];
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    const int r = wm * (TM * 32) + i * 32 + lrow;
+    a_off[i] = r * BK;
+    a_swz[i] = (r >> 1) & 7;
+  }
+  const int b_off = (4 * lk) * BN + wn * (TN * 32) + lrow;
+
+  // fragments of one k-group (8 k): one quad of A per row tile, four B values per column tile
+  auto read_group = [&](const float* a_src, const float* b_src, int g, float4 (&a4)[TM], float (&b)[4][TN]) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+      a4[i] = *reinterpret_cast<const float4*>(&a_src[a_off[i] + (((2 * g + lk) ^ a_swz[i]) << 2)]);
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) b[t][j] = b_src[b_off + (8 * g + t) * BN + j * 32];
+  };
+  auto mma_group = [&](const float4 (&a4)[TM], const float (&b)[4][TN]) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        const float a = (t == 0) ? a4[i].x : (t == 1) ? a4[i].y : (t == 2) ? a4[i].z : a4[i].w;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b[t][j], acc[i][j], 0, 0, 0);
+      }
+  };
+
+  if (c_begin < c_end) {
+    calc_offsets();
+    issue_loads();
+    calc_offsets();
+    store_chunk(0);
+    __syncthreads();
+    int buf = 0;
+#pragma unroll 1
+    for (int kc = c_begin; kc < c_end; ++kc) {
+      // the next chunk's loads are issued first (offsets were computed during the previous iteration) and land in
+      // registers under the first three quarters of this chunk's MFMAs; they are stored into the OTHER buffer (nobody
+      // reads it during this iteration), so one barrier per chunk suffices.  The copy stored by the last iteration is never
+      // used.
+      issue_loads();
+      const float* a_src = As + buf * A_ST;
+      const float* b_src = Bs + buf * B_ST;
+      float4 fa[2][TM];
+      float fb[2][4][TN];
+      if constexpr (PIPE) {
+        read_group(a_src, b_src, 0, fa[0], fb[0]);
+        FSV_SCHED_FENCE();
+        calc_offsets();
+        read_group(a_src, b_src, 1, fa[1], fb[1]);
+        FSV_SCHED_FENCE();
+        mma_group(fa[0], fb[0]);
+        FSV_SCHED_FENCE();
+        read_group(a_src, b_src, 2, fa[0], fb[0]);
+        FSV_SCHED_FENCE();
+        mma_group(fa[1], fb[1]);
+        FSV_SCHED_FENCE();
+        read_group(a_src, b_src, 3, fa[1], fb[1]);
+        FSV_SCHED_FENCE();
+        mma_group(fa[0], fb[0]);
+        FSV_SCHED_FENCE();
+        store_chunk(buf ^ 1);
+        FSV_SCHED_FENCE();
+        mma_group(fa[1], fb[1]);
+      } else {
+        FSV_SCHED_FENCE();
+        calc_offsets();
+        read_group(a_src, b_src, 0, fa[0], fb[0]); mma_group(fa[0], fb[0]);
+        read_group(a_src, b_src, 1, fa[0], fb[0]); mma_group(fa[0], fb[0]);
+        read_group(a_src, b_src, 2, fa[0], fb[0]); mma_group(fa[0], fb[0]);
+        FSV_SCHED_FENCE();
+        store_chunk(buf ^ 1);
+        read_group(a_src, b_src, 3, fa[0], fb[0]); mma_group(fa[0], fb[0]);
+      }
+      __syncthreads();
+      buf ^= 1;
+    }
+  }
+
+  // ---- epilogue: D layout col = lane&31 (channel), row = (r&3) + 8*(r>>2) + 4*(lane>>5) (pixel) -----------
+  const float* bias = p.bias ? (p.bias + (long long)zs * p.b_bstride) : nullptr;
+  const float ws = p.wscale ? p.wscale[0] : 1.f;
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int co = bn0 + wn * (TN * 32) + j * 32 + lrow;
+    if (co >= p.Cout) continue;
+    const float bv = (bias && p.nsplit == 1) ? bias[co] : 0.f;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * lk;
+        const int m = bm0 + wm * (TM * 32) + i * 32 + row;
+        if (m >= p.Mz) continue;
+        long long opix;
+        if (p.dense_out) {
+          opix = (long long)zs * (p.per_sample ? p.Mz : 0) + m;
+        } else {
+          int n, rem;
+          if (p.per_sample) { n = zs; rem = m; } else { n = m / ohw; rem = m - n * ohw; }
+          int oy = rem / p.OW, ox = rem - oy * p.OW;
+          opix = ((long long)n * p.outH + (oy * p.osy + p.ooy)) * p.outW + (ox * p.osx + p.oox);
+        }
+        float* dst = p.out + opix * p.Cout + co;
+        float v = acc[i][j][r] * ws;
+        if (p.nsplit > 1) {
+          atomicAdd(dst, v);
+        } else {
+          v = (v + bv) * p.scale;
+          v = fsv_act(v, p.act);
+          if (p.res) v += p.res[opix * p.Cout + co];
+          *dst = v;
+        }
+      }
+    }
+  }
+}
+
+// Scalar-gather twin for Cin % 4 != 0 (image / label inputs that were not channel-padded): single LDS buffer, A transposed
+// [k][m] with row stride BM + 1.  A handful of small launches per step.
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(64 * WM * WN) void fsv_conv_igemm_v1_kernel(ConvP p) {
+  constexpr int V = 1;
   constexpr int BK = FSV_BK;
   constexpr int NT = 64 * WM * WN;    // work-items per workgroup (4, 8 or 16 waves)
   constexpr int TM = BM / (WM * 32), TN = BN / (WN * 32);
@@ -60,7 +330,8 @@ __global__ __launch_bounds__(64 * WM * WN) void fsv_conv_igemm_kernel(ConvP p) {
   const int bq = tid % QB, br0 = tid / QB;
   const int bcol = bn0 + bq * 4;
   const bool bcol_ok = bcol < p.ldw;
-  const int bcol_safe = bcol_ok ? bcol : 0;
+  const fsv_buf abuf = fsv_make_buf(p.in, (long long)p.N * p.H * p.W * p.Cin * 4);
+  const fsv_buf bbuf = fsv_make_buf(wt, (long long)p.nchunks * BK * p.ldw * 4);
 
   // chunk range of this K split
   const int cps = (p.nchunks + p.nsplit - 1) / p.nsplit;
@@ -83,21 +354,12 @@ __global__ __launch_bounds__(64 * WM * WN) void fsv_conv_igemm_kernel(ConvP p) {
     for (int i = 0; i < NPA; ++i) {
       int iy = a_iy0[i] + ty, ix = a_ix0[i] + tx;
       bool ok = kok && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-      long long off = ok ? ((a_base[i] + (long long)iy * p.W + ix) * p.Cin + ci) : 0ll;
-      const float* src = p.in + off;
-      if constexpr (V == 4) {
-        float4 v = *reinterpret_cast<const float4*>(src);
-        areg[i][0] = ok ? v.x : 0.f; areg[i][1] = ok ? v.y : 0.f; areg[i][2] = ok ? v.z : 0.f; areg[i][3] = ok ? v.w : 0.f;
-      } else {
-        float v = *src;
-        areg[i][0] = ok ? v : 0.f;
-      }
+      areg[i][0] = fsv_buf_load1(abuf, ok ? (unsigned)(((a_base[i] + (long long)iy * p.W + ix) * p.Cin + ci) * 4) : FSV_BUF_OOB);
     }
 #pragma unroll
     for (int i = 0; i < NPB; ++i) {
       int kr = kc * BK + br0 + i * RPB;
-      float4 v = *reinterpret_cast<const float4*>(wt + (long long)kr * p.ldw + bcol_safe);
-      breg[i] = bcol_ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+      breg[i] = fsv_buf_load4(bbuf, bcol_ok ? (unsigned)((kr * p.ldw + bcol) * 4) : FSV_BUF_OOB);
     }
   };
   auto store_chunk = [&]() {
@@ -221,8 +483,178 @@ __global__ __launch_bounds__(256) void fsv_bias_act_kernel(float* out, const flo
 }
 
 // ---- weight gradient: dwt[z][t*Cin+ci][co] (+)= sum_pixels in[n, oy*sy+ty, ox*sx+tx, ci] * dout[n,oy,ox,co] ----
-template <int BMK, int BN, int WM, int WN, int V>
+// All workgroups of one pixel range (blockIdx.z) read the same x pixels (shifted by their taps) and the same dout rows:
+// they are mapped onto ONE XCD so that x and dout are fetched from HBM once per range instead of once per L2
+// (round 1 PMC: 2.2x the algorithmic bytes on the Cout <= 64 full-resolution layers, which are HBM-bound).
+__device__ __forceinline__ void fsv_xcd_range(int& kt, int& nt, int& z) {
+  const int gx = gridDim.x, gy = gridDim.y, gz = gridDim.z;
+  const int G = gx * gy;
+  const int b = blockIdx.x + gx * (blockIdx.y + gy * blockIdx.z);
+  int w;
+  if (b < (gz >> 3) * 8 * G) {
+    const int xcd = b & 7, j = b >> 3;
+    z = xcd + 8 * (j / G);
+    w = j % G;
+  } else {
+    z = b / G;
+    w = b - z * G;
+  }
+  kt = w % gx;
+  nt = w / gx;
+}
+
+// V4 kernel: both operands are pixel-major in HBM and in LDS ([32 pixels][columns], ds_write_b128 / ds_read_b32, conflict
+// free); two LDS buffers, one barrier per 32-pixel chunk, absent rows / columns are loaded at FSV_BUF_OOB.
+template <int BMK, int BN, int WM, int WN>
 __global__ __launch_bounds__(64 * WM * WN) void fsv_conv_wgrad_kernel(WgradP p) {
+  constexpr int BK = FSV_BK;   // pixels per chunk
+  constexpr int NT = 64 * WM * WN;
+  constexpr int TM = BMK / (WM * 32), TN = BN / (WN * 32);
+  constexpr int QA = BMK / 4, RPA = NT / QA, NPA = BK / RPA;
+  constexpr int QB = BN / 4, RPB = NT / QB, NPB = BK / RPB;
+  constexpr int A_ST = BK * BMK, B_ST = BK * BN;
+  static_assert(TM >= 1 && TN >= 1, "tile");
+  static_assert(NPA >= 1 && NPB >= 1 && RPA >= 1 && NPA * RPA == BK && NPB * RPB == BK, "tile / thread-count mismatch");
+  __shared__ __attribute__((aligned(16))) float smem[2 * (A_ST + B_ST)];
+  float* const As = smem;
+  float* const Bs = smem + 2 * A_ST;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  int kt, nt, bz;
+  fsv_xcd_range(kt, nt, bz);
+  const int zs = bz / p.nsplit, zk = bz % p.nsplit;
+  const int bi0 = kt * BMK, bn0 = nt * BN;
+  float* dwt = p.dwt + (long long)zs * p.w_bstride;
+  const int ohw = p.OH * p.OW;
+
+  // A: column (t,ci) handled by this thread is fixed for the whole reduction
+  const int aq = tid % QA, apr0 = tid / QA;
+  const int kcol = bi0 + aq * 4;
+  const bool kok = kcol < p.K;
+  int t = kok ? kcol / p.Cin : 0;
+  const int ci = kcol - t * p.Cin;
+  int ty, tx;
+  {
+    unsigned long long code = (t < 8) ? p.taps_lo : p.taps_hi;
+    int sh = (t & 7) * 8;
+    ty = (int)((code >> sh) & 15ull) - 8;
+    tx = (int)((code >> (sh + 4)) & 15ull) - 8;
+  }
+  const int bq = tid % QB, bpr0 = tid / QB;
+  const int bcol = bn0 + bq * 4;
+  const bool cout4 = (p.Cout & 3) == 0;
+  const long long dout_base = (long long)zs * (p.per_sample ? p.Mz : 0);
+  const fsv_buf abuf = fsv_make_buf(p.in, (long long)p.N * p.H * p.W * p.Cin * 4);
+  const fsv_buf bbuf = fsv_make_buf(p.dout + dout_base * p.Cout, (long long)p.Mz * p.Cout * 4);
+
+  const int cps = (p.pchunks + p.nsplit - 1) / p.nsplit;
+  const int c_begin = zk * cps;
+  const int c_end = (c_begin + cps < p.pchunks) ? (c_begin + cps) : p.pchunks;
+
+  float4 areg[NPA], breg[NPB];
+  auto load_chunk = [&](int pc) {
+#pragma unroll
+    for (int i = 0; i < NPA; ++i) {
+      int m = pc * BK + apr0 + i * RPA;
+      bool ok = kok && m < p.Mz;
+      int mm = ok ? m : 0;
+      int n, rem;
+      if (p.per_sample) { n = zs; rem = mm; } else { n = mm / ohw; rem = mm - n * ohw; }
+      int oy = rem / p.OW, ox = rem - oy * p.OW;
+      int iy = oy * p.sy + ty, ix = ox * p.sx + tx;
+      ok = ok && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+      areg[i] = fsv_buf_load4(abuf, ok ? (unsigned)((((n * p.H + iy) * p.W + ix) * p.Cin + ci) * 4) : FSV_BUF_OOB);
+    }
+#pragma unroll
+    for (int i = 0; i < NPB; ++i) {
+      int m = pc * BK + bpr0 + i * RPB;
+      bool rok = m < p.Mz;
+      if (cout4) {
+        breg[i] = fsv_buf_load4(bbuf, (rok && bcol < p.Cout) ? (unsigned)((m * p.Cout + bcol) * 4) : FSV_BUF_OOB);
+      } else {
+        const unsigned e = (unsigned)((m * p.Cout + bcol) * 4);
+        breg[i] = make_float4(fsv_buf_load1(bbuf, (rok && bcol + 0 < p.Cout) ? e : FSV_BUF_OOB),
+                              fsv_buf_load1(bbuf, (rok && bcol + 1 < p.Cout) ? e + 4 : FSV_BUF_OOB),
+                              fsv_buf_load1(bbuf, (rok && bcol + 2 < p.Cout) ? e + 8 : FSV_BUF_OOB),
+                              fsv_buf_load1(bbuf, (rok && bcol + 3 < p.Cout) ? e + 12 : FSV_BUF_OOB));
+      }
+    }
+  };
+  auto store_chunk = [&](int buf) {
+    float* a_dst = As + buf * A_ST;
+    float* b_dst = Bs + buf * B_ST;
+#pragma unroll
+    for (int i = 0; i < NPA; ++i) *reinterpret_cast<float4*>(&a_dst[(apr0 + i * RPA) * BMK + aq * 4]) = areg[i];
+#pragma unroll
+    for (int i = 0; i < NPB; ++i) *reinterpret_cast<float4*>(&b_dst[(bpr0 + i * RPB) * BN + bq * 4]) = breg[i];
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int lrow = lane & 31, lk = lane >> 5;
+  const int a_off = lk * BMK + wm * (TM * 32) + lrow;
+  const int b_off = lk * BN + wn * (TN * 32) + lrow;
+  auto mma_steps = [&](const float* a_src, const float* b_src, int kk0, int kk1) {
+#pragma unroll
+    for (int kk = kk0; kk < kk1; ++kk) {
+      float a[TM], b[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) a[i] = a_src[a_off + kk * 2 * BMK + i * 32];
+#pragma unroll
+      for (int j = 0; j < TN; ++j) b[j] = b_src[b_off + kk * 2 * BN + j * 32];
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+  };
+  if (c_begin < c_end) {
+    load_chunk(c_begin);
+    store_chunk(0);
+    __syncthreads();
+    int buf = 0;
+#pragma unroll 1
+    for (int pc = c_begin; pc < c_end; ++pc) {
+      const int pnext = (pc + 1 < c_end) ? pc + 1 : pc;
+      load_chunk(pnext);
+      FSV_SCHED_FENCE();
+      const float* a_src = As + buf * A_ST;
+      const float* b_src = Bs + buf * B_ST;
+      mma_steps(a_src, b_src, 0, 12);
+      FSV_SCHED_FENCE();
+      store_chunk(buf ^ 1);
+      mma_steps(a_src, b_src, 12, 16);
+      __syncthreads();
+      buf ^= 1;
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int co = bn0 + wn * (TN * 32) + j * 32 + lrow;
+    if (co >= p.Cout) continue;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * lk;
+        const int k = bi0 + wm * (TM * 32) + i * 32 + row;
+        if (k >= p.K) continue;
+        float* dst = dwt + (long long)k * p.ldw + co;
+        if (p.nsplit > 1) atomicAdd(dst, acc[i][j][r]); else *dst = acc[i][j][r];
+      }
+  }
+}
+
+// scalar-gather twin (Cin % 4 != 0), single LDS buffer
+template <int BMK, int BN, int WM, int WN>
+__global__ __launch_bounds__(64 * WM * WN) void fsv_conv_wgrad_v1_kernel(WgradP p) {
+  constexpr int V = 1;
   constexpr int BK = FSV_BK;   // pixels per chunk
   constexpr int NT = 64 * WM * WN;
   constexpr int TM = BMK / (WM * 32), TN = BN / (WN * 32);
@@ -262,6 +694,9 @@ __global__ __launch_bounds__(64 * WM * WN) void fsv_conv_wgrad_kernel(WgradP p) 
   float areg[NPA][V];
   float4 breg[NPB];
   const bool cout4 = (p.Cout & 3) == 0;
+  const long long dout_base = (long long)zs * (p.per_sample ? p.Mz : 0);
+  const fsv_buf abuf = fsv_make_buf(p.in, (long long)p.N * p.H * p.W * p.Cin * 4);
+  const fsv_buf bbuf = fsv_make_buf(p.dout + dout_base * p.Cout, (long long)p.Mz * p.Cout * 4);
   auto load_chunk = [&](int pc) {
 #pragma unroll
     for (int i = 0; i < NPA; ++i) {
@@ -273,33 +708,20 @@ __global__ __launch_bounds__(64 * WM * WN) void fsv_conv_wgrad_kernel(WgradP p) 
       int oy = rem / p.OW, ox = rem - oy * p.OW;
       int iy = oy * p.sy + ty, ix = ox * p.sx + tx;
       ok = ok && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-      long long off = ok ? ((((long long)n * p.H + iy) * p.W + ix) * p.Cin + ci) : 0ll;
-      const float* src = p.in + off;
-      if constexpr (V == 4) {
-        float4 v = *reinterpret_cast<const float4*>(src);
-        areg[i][0] = ok ? v.x : 0.f; areg[i][1] = ok ? v.y : 0.f; areg[i][2] = ok ? v.z : 0.f; areg[i][3] = ok ? v.w : 0.f;
-      } else {
-        float v = *src;
-        areg[i][0] = ok ? v : 0.f;
-      }
+      areg[i][0] = fsv_buf_load1(abuf, ok ? (unsigned)(((((long long)n * p.H + iy) * p.W + ix) * p.Cin + ci) * 4) : FSV_BUF_OOB);
     }
 #pragma unroll
     for (int i = 0; i < NPB; ++i) {
       int m = pc * BK + bpr0 + i * RPB;
       bool rok = m < p.Mz;
-      long long pix = (long long)zs * (p.per_sample ? p.Mz : 0) + (rok ? m : 0);
       if (cout4) {
-        bool ok = rok && bcol < p.Cout;
-        const float* src = p.dout + (ok ? (pix * p.Cout + bcol) : 0ll);
-        float4 v = *reinterpret_cast<const float4*>(src);
-        breg[i] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+        breg[i] = fsv_buf_load4(bbuf, (rok && bcol < p.Cout) ? (unsigned)((m * p.Cout + bcol) * 4) : FSV_BUF_OOB);
       } else {
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        const float* src = p.dout + pix * p.Cout;
-        bool o0 = rok && bcol + 0 < p.Cout, o1 = rok && bcol + 1 < p.Cout, o2 = rok && bcol + 2 < p.Cout, o3 = rok && bcol + 3 < p.Cout;
-        float t0 = src[o0 ? bcol + 0 : 0], t1 = src[o1 ? bcol + 1 : 0], t2 = src[o2 ? bcol + 2 : 0], t3 = src[o3 ? bcol + 3 : 0];
-        v.x = o0 ? t0 : 0.f; v.y = o1 ? t1 : 0.f; v.z = o2 ? t2 : 0.f; v.w = o3 ? t3 : 0.f;
-        breg[i] = v;
+        const unsigned e = (unsigned)((m * p.Cout + bcol) * 4);
+        breg[i] = make_float4(fsv_buf_load1(bbuf, (rok && bcol + 0 < p.Cout) ? e : FSV_BUF_OOB),
+                              fsv_buf_load1(bbuf, (rok && bcol + 1 < p.Cout) ? e + 4 : FSV_BUF_OOB),
+                              fsv_buf_load1(bbuf, (rok && bcol + 2 < p.Cout) ? e + 8 : FSV_BUF_OOB),
+                              fsv_buf_load1(bbuf, (rok && bcol + 3 < p.Cout) ? e + 12 : FSV_BUF_OOB));
       }
     }
   };
@@ -497,58 +919,54 @@ static inline void fsv_pack_taps(const int* ty, const int* tx, int n, unsigned l
   }
 }
 
-template <int V>
-static int fsv_launch_conv(const ConvP& p, int M_tiles_rows, int nz, hipStream_t stream, int tile) {
-  dim3 block(256);
-  if (V == 4) {
-    switch (tile) {      // experimental large tiles (8 / 16 waves); only reachable through force_tile
-      case 5: { dim3 g(fsv_cdiv(M_tiles_rows, 256), fsv_cdiv(p.Cout, 128), nz);
-        FSV_LAUNCH((fsv_conv_igemm_kernel<256, 128, 4, 2, 4>), g, dim3(512), stream, p); return fsv_check_launch(); }
-      case 6: { dim3 g(fsv_cdiv(M_tiles_rows, 128), fsv_cdiv(p.Cout, 256), nz);
-        FSV_LAUNCH((fsv_conv_igemm_kernel<128, 256, 2, 4, 4>), g, dim3(512), stream, p); return fsv_check_launch(); }
-      case 7: { dim3 g(fsv_cdiv(M_tiles_rows, 256), fsv_cdiv(p.Cout, 256), nz);
-        FSV_LAUNCH((fsv_conv_igemm_kernel<256, 256, 4, 4, 4>), g, dim3(1024), stream, p); return fsv_check_launch(); }
-      case 8: { dim3 g(fsv_cdiv(M_tiles_rows, 256), fsv_cdiv(p.Cout, 64), nz);
-        FSV_LAUNCH((fsv_conv_igemm_kernel<256, 64, 4, 2, 4>), g, dim3(512), stream, p); return fsv_check_launch(); }
-      case 9: { dim3 g(fsv_cdiv(M_tiles_rows, 64), fsv_cdiv(p.Cout, 128), nz);
-        FSV_LAUNCH((fsv_conv_igemm_kernel<64, 128, 2, 2, 4>), g, block, stream, p); return fsv_check_launch(); }
-      // few-wave workgroups (every wave owns a 64x64 sub-tile: one LDS fragment read per MFMA, and a one-wave workgroup needs
-      // no cross-wave barrier traffic); not yet measured, only reachable through force_tile
-      case 10: { dim3 g(fsv_cdiv(M_tiles_rows, 64), fsv_cdiv(p.Cout, 64), nz);
-        FSV_LAUNCH((fsv_conv_igemm_kernel<64, 64, 1, 1, 4>), g, dim3(64), stream, p); return fsv_check_launch(); }
-      case 11: { dim3 g(fsv_cdiv(M_tiles_rows, 64), fsv_cdiv(p.Cout, 128), nz);
-        FSV_LAUNCH((fsv_conv_igemm_kernel<64, 128, 1, 2, 4>), g, dim3(128), stream, p); return fsv_check_launch(); }
-      case 12: { dim3 g(fsv_cdiv(M_tiles_rows, 128), fsv_cdiv(p.Cout, 64), nz);
-        FSV_LAUNCH((fsv_conv_igemm_kernel<128, 64, 2, 1, 4>), g, dim3(128), stream, p); return fsv_check_launch(); }
-      case 13: case 14: case 15: case 16: case 17: case 18: case 19: case 20: case 21:      // double-buffered LDS; 16-18 prefetch distance 2, 19-21 XCD-aware order
-        return fsv_launch_conv_db(p, nz, stream, tile);
-      default: break;
-    }
+// tile ids: 0 = 128x128, 1 = 128x64, 2 = 128x32, 4 = 64x64, 9 = 64x128 (BM pixels x BN output channels).  Round-2 A/B ids,
+// force_tile only: 10 / 11 / 12 = 128x128 / 128x64 / 64x128 as 8-wave workgroups (two waves per SIMD cover each other's LDS
+// latency); +20 = the same tile without the explicit fragment pipeline (PIPE = 0).
+static inline int fsv_tile_dims(int tile, int& bm, int& bn) {
+  switch (tile % 20) {
+    case 0: case 10: bm = 128; bn = 128; return 0;
+    case 1: case 11: bm = 128; bn = 64; return 0;
+    case 2: bm = 128; bn = 32; return 0;
+    case 4: bm = 64; bn = 64; return 0;
+    case 9: case 12: bm = 64; bn = 128; return 0;
+    default: return -1;
   }
-  if (tile == 9 || tile == 10 || tile == 11 || tile == 13 || tile == 14 || tile == 16 || tile == 17 || tile == 19 || tile == 20) tile = 4;      // scalar-gather layers (Cin % 4 != 0): only the basic tiles are instantiated
-  if (tile == 12 || tile == 15 || tile == 18 || tile == 21) tile = 1;
-  switch (tile) {
-    case 0: { dim3 g(fsv_cdiv(M_tiles_rows, 128), fsv_cdiv(p.Cout, 128), nz);
-      FSV_LAUNCH((fsv_conv_igemm_kernel<128, 128, 2, 2, V>), g, block, stream, p); break; }
-    case 1: { dim3 g(fsv_cdiv(M_tiles_rows, 128), fsv_cdiv(p.Cout, 64), nz);
-      FSV_LAUNCH((fsv_conv_igemm_kernel<128, 64, 2, 2, V>), g, block, stream, p); break; }
-    case 2: { dim3 g(fsv_cdiv(M_tiles_rows, 128), fsv_cdiv(p.Cout, 32), nz);
-      FSV_LAUNCH((fsv_conv_igemm_kernel<128, 32, 4, 1, V>), g, block, stream, p); break; }
-    case 3: { dim3 g(fsv_cdiv(M_tiles_rows, 256), fsv_cdiv(p.Cout, 32), nz);
-      FSV_LAUNCH((fsv_conv_igemm_kernel<256, 32, 4, 1, V>), g, block, stream, p); break; }
-    case 4: { dim3 g(fsv_cdiv(M_tiles_rows, 64), fsv_cdiv(p.Cout, 64), nz);
-      FSV_LAUNCH((fsv_conv_igemm_kernel<64, 64, 2, 2, V>), g, block, stream, p); break; }
-    default: return FSV_ERR_BAD_ARG;
-  }
-  return fsv_check_launch();
 }
 
-static inline int fsv_tile_dims(int tile, int& bm, int& bn) {
-  static const int BMs[22] = {128, 128, 128, 256, 64, 256, 128, 256, 256, 64, 64, 64, 128, 64, 64, 128, 64, 64, 128, 64, 64, 128},
-                   BNs[22] = {128, 64, 32, 32, 64, 128, 256, 256, 64, 128, 64, 128, 64, 64, 128, 64, 64, 128, 64, 64, 128, 64};
-  if (tile < 0 || tile > 21) return -1;
-  bm = BMs[tile]; bn = BNs[tile];
-  return 0;
+static int fsv_launch_conv(const ConvP& p, bool vec4, int nz, hipStream_t stream, int tile) {
+  int bm, bn;
+  if (tile < 0 || tile >= 40 || fsv_tile_dims(tile, bm, bn)) return FSV_ERR_BAD_ARG;
+  dim3 g(fsv_cdiv(p.Mz, bm), fsv_cdiv(p.Cout, bn), nz);
+  if (vec4) {
+    switch (tile) {
+      case 0: FSV_LAUNCH((fsv_conv_igemm_kernel<128, 128, 2, 2, 1>), g, dim3(256), stream, p); break;
+      case 1: FSV_LAUNCH((fsv_conv_igemm_kernel<128, 64, 2, 2, 1>), g, dim3(256), stream, p); break;
+      case 2: FSV_LAUNCH((fsv_conv_igemm_kernel<128, 32, 4, 1, 1>), g, dim3(256), stream, p); break;
+      case 4: FSV_LAUNCH((fsv_conv_igemm_kernel<64, 64, 2, 2, 1>), g, dim3(256), stream, p); break;
+      case 9: FSV_LAUNCH((fsv_conv_igemm_kernel<64, 128, 2, 2, 1>), g, dim3(256), stream, p); break;
+      case 10: FSV_LAUNCH((fsv_conv_igemm_kernel<128, 128, 2, 4, 1>), g, dim3(512), stream, p); break;
+      case 11: FSV_LAUNCH((fsv_conv_igemm_kernel<128, 64, 4, 2, 1>), g, dim3(512), stream, p); break;
+      case 12: FSV_LAUNCH((fsv_conv_igemm_kernel<64, 128, 2, 4, 1>), g, dim3(512), stream, p); break;
+      case 20: FSV_LAUNCH((fsv_conv_igemm_kernel<128, 128, 2, 2, 0>), g, dim3(256), stream, p); break;
+      case 21: FSV_LAUNCH((fsv_conv_igemm_kernel<128, 64, 2, 2, 0>), g, dim3(256), stream, p); break;
+      case 22: FSV_LAUNCH((fsv_conv_igemm_kernel<128, 32, 4, 1, 0>), g, dim3(256), stream, p); break;
+      case 24: FSV_LAUNCH((fsv_conv_igemm_kernel<64, 64, 2, 2, 0>), g, dim3(256), stream, p); break;
+      case 29: FSV_LAUNCH((fsv_conv_igemm_kernel<64, 128, 2, 2, 0>), g, dim3(256), stream, p); break;
+      case 30: FSV_LAUNCH((fsv_conv_igemm_kernel<128, 128, 2, 4, 0>), g, dim3(512), stream, p); break;
+      case 31: FSV_LAUNCH((fsv_conv_igemm_kernel<128, 64, 4, 2, 0>), g, dim3(512), stream, p); break;
+      case 32: FSV_LAUNCH((fsv_conv_igemm_kernel<64, 128, 2, 4, 0>), g, dim3(512), stream, p); break;
+      default: return FSV_ERR_BAD_ARG;
+    }
+  } else {
+    switch (tile % 20) {
+      case 0: case 10: FSV_LAUNCH((fsv_conv_igemm_v1_kernel<128, 128, 2, 2>), g, dim3(256), stream, p); break;
+      case 1: case 11: FSV_LAUNCH((fsv_conv_igemm_v1_kernel<128, 64, 2, 2>), g, dim3(256), stream, p); break;
+      case 2: FSV_LAUNCH((fsv_conv_igemm_v1_kernel<128, 32, 4, 1>), g, dim3(256), stream, p); break;
+      case 4: FSV_LAUNCH((fsv_conv_igemm_v1_kernel<64, 64, 2, 2>), g, dim3(256), stream, p); break;
+      default: FSV_LAUNCH((fsv_conv_igemm_v1_kernel<64, 128, 2, 2>), g, dim3(256), stream, p); break;
+    }
+  }
+  return fsv_check_launch();
 }
 
 
@@ -569,12 +987,6 @@ static inline long long fsv_tune(int which) {
   return vals[which];
 }
 
-static inline int fsv_thin_tile() {
-  static int v = -1;
-  if (v < 0) { const char* a = getenv("FSV_THIN_TILE"); v = a ? atoi(a) : 2; }   // 128x32: in-box A/B 82.2 vs 83.4 ms/step against 256x32
-  return v;
-}
-
 // Tile / split-K plan shared by the launcher and (through the C ABI) by the host-side profiler labels.
 // tile ids: 0 = 128x128, 1 = 128x64, 2 = 128x32, 3 = 256x32, 4 = 64x64 (BM x BN, pixels x output channels).
 extern "C" int fsv_conv_plan(int Mz, int Cout, int nchunks, int nsamp, int force_tile, int force_split,
@@ -589,14 +1001,14 @@ extern "C" int fsv_conv_plan(int Mz, int Cout, int nchunks, int nsamp, int force
   bool small_tile_regime = false, mid_tile_regime = false;
   if (tile < 0) {
     if (plan_v == 0) {
-      if (Cout <= 32) tile = (Mz >= 256 * 256) ? fsv_thin_tile() : 2;
+      if (Cout <= 32) tile = 2;
       else if (Cout <= 64) tile = 1;
       else tile = ((long long)Mz * Cout <= 64 * 64 * 64) ? 4 : 0;
     } else {
       // in-box A/B on the step's layer shapes (tools/tile_ab.py, profiles/r01_tile_ab.jsonl): with fewer than two
       // 128-row tiles per CU the 64x64 tile without split-K beats the big tile with split-K (no atomics, no zero-fill,
       // no separate bias pass) unless K is long enough (>= 4096) to amortise them
-      if (Cout <= 32) tile = (Mz >= 256 * 256) ? fsv_thin_tile() : 2;
+      if (Cout <= 32) tile = 2;
       else if (Cout <= 64) tile = (b1 < 512) ? 4 : 1;
       else if (plan_v == 1) {
         if (b0 >= 512) tile = 0;
@@ -649,29 +1061,6 @@ extern "C" int fsv_conv_plan(int Mz, int Cout, int nchunks, int nsamp, int force
 
 static inline bool vec4_ok(int cin) { return (cin & 3) == 0; }
 
-// FSV_TILE_REMAP="4:13,9:14,1:15": run the launches the plan gives to tile a with tile b of the same shape instead (whole-step
-// A/B of the experimental variants without touching the plan; split-K factors stay those of the planned tile)
-static inline int fsv_tile_remap(int tile) {
-  static int map[22];
-  static int ready = 0;
-  if (!ready) {
-    for (int i = 0; i < 22; ++i) map[i] = i;
-    const char* e = getenv("FSV_TILE_REMAP");
-    while (e && *e) {
-      int a = atoi(e);
-      const char* c = strchr(e, ':');
-      if (!c) break;
-      int b = atoi(c + 1);
-      int am, an, bm, bn;
-      if (!fsv_tile_dims(a, am, an) && !fsv_tile_dims(b, bm, bn) && am == bm && an == bn) map[a] = b;
-      e = strchr(c, ',');
-      if (e) ++e;
-    }
-    ready = 1;
-  }
-  return (tile >= 0 && tile < 22) ? map[tile] : tile;
-}
-
 extern "C" {
 
 // Generic gather-GEMM (see header comment and include/fsv2v.h: fsv_conv_gather_fwd).
@@ -686,6 +1075,8 @@ int fsv_conv_gather_fwd(const float* in, const float* wt, const float* bias, con
   for (int t = 0; t < ntaps; ++t)
     if (ty[t] < -8 || ty[t] > 7 || tx[t] < -8 || tx[t] > 7) return FSV_ERR_UNSUPPORTED;
   if ((ldw & 3) != 0 || ldw < Cout) return FSV_ERR_BAD_ARG;
+  // the V4 kernels index one tensor / one weight matrix with 32-bit element offsets
+  if ((long long)N * H * W * Cin * 4 > FSV_BUF_MAX_BYTES || (long long)(ntaps * Cin + 32) * ldw * 4 > FSV_BUF_MAX_BYTES) return FSV_ERR_UNSUPPORTED;
   ConvP p;
   p.in = in; p.wt = wt; p.bias = bias; p.res = res; p.out = out; p.wscale = wscale;
   p.N = N; p.H = H; p.W = W; p.Cin = Cin; p.OH = OH; p.OW = OW; p.Cout = Cout;
@@ -701,7 +1092,6 @@ int fsv_conv_gather_fwd(const float* in, const float* wt, const float* bias, con
   int tile = 0, nsplit = 1;
   if (fsv_conv_plan(p.Mz, Cout, p.nchunks, nsamp, force_tile, force_split, &tile, &nsplit)) return FSV_ERR_BAD_ARG;
   p.nsplit = nsplit;
-  if (force_tile < 0) tile = fsv_tile_remap(tile);
   const long long total = (long long)N * outH * outW * Cout;
   // accumulate != 0: `out` was zeroed by the caller and partial results are added atomically (used by the
   // four parity-class launches of a stride-2 data gradient); bias/act/res are not applied in that mode.
@@ -713,8 +1103,7 @@ int fsv_conv_gather_fwd(const float* in, const float* wt, const float* bias, con
     (void)hipMemsetAsync(out, 0, (size_t)total * sizeof(float), stream);
   }
   const bool vec4 = (Cin % 4 == 0);
-  int rc = vec4 ? fsv_launch_conv<4>(p, p.Mz, nsamp * nsplit, stream, tile)
-                : fsv_launch_conv<1>(p, p.Mz, nsamp * nsplit, stream, tile);
+  int rc = fsv_launch_conv(p, vec4, nsamp * nsplit, stream, tile);
   if (rc) return rc;
   if (!accumulate && nsplit > 1 && (bias || res || act != FSV_ACT_NONE || scale != 1.f)) {
     int grid = (int)((total + 256 * 8 - 1) / (256 * 8));
@@ -747,6 +1136,7 @@ int fsv_conv_wgrad(const float* in, const float* dout, float* dwt,
   if (!in || !dout || !dwt || ntaps < 1 || ntaps > 16) return FSV_ERR_BAD_ARG;
   for (int t = 0; t < ntaps; ++t)
     if (ty[t] < -8 || ty[t] > 7 || tx[t] < -8 || tx[t] > 7) return FSV_ERR_UNSUPPORTED;
+  if ((long long)N * H * W * Cin * 4 > FSV_BUF_MAX_BYTES || (long long)N * OH * OW * Cout * 4 > FSV_BUF_MAX_BYTES) return FSV_ERR_UNSUPPORTED;      // 32-bit byte offsets
   WgradP p;
   p.in = in; p.dout = dout; p.dwt = dwt;
   p.N = N; p.H = H; p.W = W; p.Cin = Cin; p.OH = OH; p.OW = OW; p.Cout = Cout;
@@ -765,14 +1155,6 @@ int fsv_conv_wgrad(const float* in, const float* dout, float* dwt,
   if (force_tile == 1 && vec4_ok(Cin) && Cout > 32) { bmk = 64; bn = 64; }
   else if (force_tile == 2 && vec4_ok(Cin) && Cout > 32) { bmk = 128; bn = 64; }
   else if (force_tile == 3 && vec4_ok(Cin) && Cout > 64) { bmk = 64; bn = 128; }
-  // 5 / 6: the 64x64 and 64x128 tiles as one- / two-wave workgroups (every wave owns a 64x64 sub-tile); not yet measured
-  int few_waves = 0;
-  if (force_tile == 5 && vec4_ok(Cin) && Cout > 32) { bmk = 64; bn = 64; few_waves = 1; }
-  else if (force_tile == 6 && vec4_ok(Cin) && Cout > 64) { bmk = 64; bn = 128; few_waves = 1; }
-  // 7 / 8: 64x64 / 64x128 with double-buffered LDS (conv_igemm_db.hip); not yet measured
-  int dbuf = 0;
-  if (force_tile == 7 && vec4_ok(Cin) && Cout > 32) { bmk = 64; bn = 64; dbuf = 1; }
-  else if (force_tile == 8 && vec4_ok(Cin) && Cout > 64) { bmk = 64; bn = 128; dbuf = 1; }
   long long target = fsv_tune(2);
   static int wplan_v = -1;
   if (wplan_v < 0) { const char* e = getenv("FSV_WGRAD_PLAN"); wplan_v = e ? atoi(e) : 1; }
@@ -782,12 +1164,6 @@ int fsv_conv_wgrad(const float* in, const float* dout, float* dwt,
     // FLOP than the same workgroup count of split 128x128 tiles, and every CU gets several workgroups
     if (Cout >= 128 && p.K >= 2304 && p.pchunks >= 64) { bmk = 64; bn = 128; target = 1024; }
     else { bmk = 64; bn = 64; target = 2048; }
-  }
-  // FSV_WGRAD_VARIANT=db | fw: run the automatically chosen 64-row tiles as their double-buffered / few-wave variants
-  if (force_tile == 0 && vec4_ok(Cin) && bmk == 64 && (bn == 64 || bn == 128)) {
-    static int variant = -1;
-    if (variant < 0) { const char* e = getenv("FSV_WGRAD_VARIANT"); variant = !e ? 0 : (!strcmp(e, "db") ? 1 : (!strcmp(e, "fw") ? 2 : 0)); }
-    if (variant == 1) dbuf = 1; else if (variant == 2) few_waves = 1;
   }
   long long blocks = (long long)fsv_cdiv(p.K, bmk) * fsv_cdiv(Cout, bn) * nsamp;
   int nsplit = 1;
@@ -807,21 +1183,18 @@ int fsv_conv_wgrad(const float* in, const float* dout, float* dwt,
   dim3 block(256);
   const bool vec4 = (Cin % 4 == 0);
   dim3 g(fsv_cdiv(p.K, bmk), fsv_cdiv(Cout, bn), nsamp * nsplit);
-  if (vec4 && dbuf) return fsv_launch_wgrad_db(p, bmk, bn, g, stream);
   if (vec4) {
-    if (few_waves && bn == 64) FSV_LAUNCH((fsv_conv_wgrad_kernel<64, 64, 1, 1, 4>), g, dim3(64), stream, p);
-    else if (few_waves) FSV_LAUNCH((fsv_conv_wgrad_kernel<64, 128, 1, 2, 4>), g, dim3(128), stream, p);
-    else if (bn == 128 && bmk == 32) FSV_LAUNCH((fsv_conv_wgrad_kernel<32, 128, 1, 4, 4>), g, block, stream, p);
-    else if (bn == 128 && bmk == 64) FSV_LAUNCH((fsv_conv_wgrad_kernel<64, 128, 2, 2, 4>), g, block, stream, p);
-    else if (bn == 64 && bmk == 32) FSV_LAUNCH((fsv_conv_wgrad_kernel<32, 64, 1, 2, 4>), g, dim3(128), stream, p);
-    else if (bn == 64 && bmk == 64) FSV_LAUNCH((fsv_conv_wgrad_kernel<64, 64, 2, 2, 4>), g, block, stream, p);
-    else if (bn == 128) FSV_LAUNCH((fsv_conv_wgrad_kernel<128, 128, 2, 2, 4>), g, block, stream, p);
-    else if (bn == 64) FSV_LAUNCH((fsv_conv_wgrad_kernel<128, 64, 2, 2, 4>), g, block, stream, p);
-    else FSV_LAUNCH((fsv_conv_wgrad_kernel<128, 32, 4, 1, 4>), g, block, stream, p);
+    if (bn == 128 && bmk == 32) FSV_LAUNCH((fsv_conv_wgrad_kernel<32, 128, 1, 4>), g, block, stream, p);
+    else if (bn == 128 && bmk == 64) FSV_LAUNCH((fsv_conv_wgrad_kernel<64, 128, 2, 2>), g, block, stream, p);
+    else if (bn == 64 && bmk == 32) FSV_LAUNCH((fsv_conv_wgrad_kernel<32, 64, 1, 2>), g, dim3(128), stream, p);
+    else if (bn == 64 && bmk == 64) FSV_LAUNCH((fsv_conv_wgrad_kernel<64, 64, 2, 2>), g, block, stream, p);
+    else if (bn == 128) FSV_LAUNCH((fsv_conv_wgrad_kernel<128, 128, 2, 2>), g, block, stream, p);
+    else if (bn == 64) FSV_LAUNCH((fsv_conv_wgrad_kernel<128, 64, 2, 2>), g, block, stream, p);
+    else FSV_LAUNCH((fsv_conv_wgrad_kernel<128, 32, 4, 1>), g, block, stream, p);
   } else {
-    if (bn == 128) FSV_LAUNCH((fsv_conv_wgrad_kernel<128, 128, 2, 2, 1>), g, block, stream, p);
-    else if (bn == 64) FSV_LAUNCH((fsv_conv_wgrad_kernel<128, 64, 2, 2, 1>), g, block, stream, p);
-    else FSV_LAUNCH((fsv_conv_wgrad_kernel<128, 32, 4, 1, 1>), g, block, stream, p);
+    if (bn == 128) FSV_LAUNCH((fsv_conv_wgrad_v1_kernel<128, 128, 2, 2>), g, block, stream, p);
+    else if (bn == 64) FSV_LAUNCH((fsv_conv_wgrad_v1_kernel<128, 64, 2, 2>), g, block, stream, p);
+    else FSV_LAUNCH((fsv_conv_wgrad_v1_kernel<128, 32, 4, 1>), g, block, stream, p);
   }
   return fsv_check_launch();
 }

@@ -138,141 +138,6 @@ __global__ __launch_bounds__(256) void fsv_red2_kernel(RedP p) {
   }
 }
 
-// second-stage parameters of the fused variant (G = 1 only): the block holding the last ticket of a channel slab finishes it
-struct RedFinal {
-  int* counter;            // [nslabs] tickets, zero between launches
-  float* out1;             // STATS: mean, BWD: s1, COLSUM: out
-  float* out2;             // STATS: rstd, BWD: s2
-  float* run_mean; float* run_var; float eps, momentum;      // STATS
-  float* dw; float* db;    // BWD (affine)
-  int accumulate;          // COLSUM
-};
-template <int MODE, int V>
-__global__ __launch_bounds__(256) void fsv_red2f_kernel(RedP p, RedFinal f) {
-  __shared__ float red[256 * 2 * V];
-  const int chunk = blockIdx.x, slab = blockIdx.y, g = blockIdx.z;
-  const int tx = threadIdx.x % p.TX, ty = threadIdx.x / p.TX;
-  const int cu = slab * p.TX + tx;
-  const bool active = ty < p.TY && cu < p.CU;
-  const int r0 = chunk * p.rows_per_blk;
-  const int r1 = (r0 + p.rows_per_blk < p.P) ? r0 + p.rows_per_blk : p.P;
-  const long long goff = (long long)g * p.P * p.C;
-  float s1[V], s2[V], mu[V], rs[V];
-#pragma unroll
-  for (int j = 0; j < V; ++j) { s1[j] = 0.f; s2[j] = 0.f; mu[j] = 0.f; rs[j] = 1.f; }
-  if (active) {
-    const int c0 = cu * V;
-    if (MODE == FSV_RED_BWD) {
-#pragma unroll
-      for (int j = 0; j < V; ++j) { mu[j] = p.mean[g * p.C + c0 + j]; rs[j] = p.rstd[g * p.C + c0 + j]; }
-    }
-    for (int r = r0 + ty; r < r1; r += p.TY * 4) {
-      float va[4][V], vy[4][V], vx[4][V];
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int rr = r + u * p.TY;
-        const bool ok = rr < r1;
-        const long long off = goff + (long long)rr * p.C + c0;
-        if constexpr (V == 4) {
-          float4 t = ok ? *reinterpret_cast<const float4*>(p.a + off) : make_float4(0.f, 0.f, 0.f, 0.f);
-          va[u][0] = t.x; va[u][1] = t.y; va[u][2] = t.z; va[u][3] = t.w;
-          if (MODE == FSV_RED_BWD) {
-            float4 tx4 = ok ? *reinterpret_cast<const float4*>(p.x + off) : make_float4(0.f, 0.f, 0.f, 0.f);
-            vx[u][0] = tx4.x; vx[u][1] = tx4.y; vx[u][2] = tx4.z; vx[u][3] = tx4.w;
-            float4 ty4 = (ok && p.y) ? *reinterpret_cast<const float4*>(p.y + off) : make_float4(0.f, 0.f, 0.f, 0.f);
-            vy[u][0] = ty4.x; vy[u][1] = ty4.y; vy[u][2] = ty4.z; vy[u][3] = ty4.w;
-          }
-        } else {
-          va[u][0] = ok ? p.a[off] : 0.f;
-          if (MODE == FSV_RED_BWD) { vx[u][0] = ok ? p.x[off] : 0.f; vy[u][0] = (ok && p.y) ? p.y[off] : 0.f; }
-        }
-        if (MODE == FSV_RED_BWD && !ok) {
-#pragma unroll
-          for (int j = 0; j < V; ++j) vx[u][j] = mu[j];      // xhat = 0 for padding rows
-        }
-      }
-#pragma unroll
-      for (int u = 0; u < 4; ++u)
-#pragma unroll
-        for (int j = 0; j < V; ++j) {
-          if (MODE == FSV_RED_STATS) { s1[j] += va[u][j]; s2[j] += va[u][j] * va[u][j]; }
-          else if (MODE == FSV_RED_COLSUM) { s1[j] += va[u][j]; }
-          else {
-            float d = fsv_act_grad(va[u][j], vy[u][j], p.act);
-            s1[j] += d; s2[j] += d * ((vx[u][j] - mu[j]) * rs[j]);
-          }
-        }
-    }
-  }
-#pragma unroll
-  for (int j = 0; j < V; ++j) { red[(threadIdx.x * V + j) * 2] = s1[j]; red[(threadIdx.x * V + j) * 2 + 1] = s2[j]; }
-  __syncthreads();
-  // thread t < TX*V reduces column unit t / V, component t % V over the TY rows (fp64)
-  const int t = threadIdx.x;
-  if (t < p.TX * V) {
-    const int ux = t / V, j = t % V;
-    const int c = (slab * p.TX + ux) * V + j;
-    if (slab * p.TX + ux < p.CU) {
-      double a = 0.0, b = 0.0;
-      for (int yy = 0; yy < p.TY; ++yy) {
-        const int src = yy * p.TX + ux;
-        a += (double)red[(src * V + j) * 2];
-        b += (double)red[(src * V + j) * 2 + 1];
-      }
-      double* dst = p.part + (((long long)g * p.nchunks + chunk) * p.C + c) * 2;
-      dst[0] = a; dst[1] = b;
-    }
-  }
-  // ---- the block that finishes last (per channel slab) also runs the second stage ---------------------------------------
-  // every block publishes its partials (fence), takes a ticket; the holder of the last ticket sees all of them (fence) and
-  // leaves the ticket counter at zero for the next launch that uses it
-  __shared__ int s_last;
-  __threadfence();
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    const int ticket = atomicAdd(f.counter + slab, 1);
-    s_last = (ticket == (int)gridDim.x - 1) ? 1 : 0;
-  }
-  __syncthreads();
-  if (!s_last) return;
-  __threadfence();
-  if (threadIdx.x == 0) f.counter[slab] = 0;
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int c_begin = slab * p.TX * V;
-  const int c_stop = (c_begin + p.TX * V < p.C) ? c_begin + p.TX * V : p.C;
-  for (int c = c_begin + wave; c < c_stop; c += 4) {
-    // same order as the stand-alone second stage (fsv_sum_chunks): same bits.  The partials were written by other workgroups
-    // of this launch: read them with agent-scope atomic loads (on top of the fence above) so that no cache level private to
-    // this CU can answer
-    double a = 0.0, b = 0.0;
-    for (int k = lane; k < p.nchunks; k += 64) {
-      const double* src = p.part + ((long long)k * p.C + c) * 2;
-      a += __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      b += __hip_atomic_load(src + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    for (int o = 32; o > 0; o >>= 1) { a += __shfl_xor(a, o); b += __shfl_xor(b, o); }
-    if (lane != 0) continue;
-    if (MODE == FSV_RED_STATS) {
-      double mu = a / p.P;
-      double var = b / p.P - mu * mu;
-      if (var < 0.0) var = 0.0;
-      f.out1[c] = (float)mu;
-      f.out2[c] = (float)(1.0 / sqrt(var + (double)f.eps));
-      if (f.run_mean) {
-        double unb = p.P > 1 ? var * ((double)p.P / (double)(p.P - 1)) : var;
-        f.run_mean[c] = (1.f - f.momentum) * f.run_mean[c] + f.momentum * (float)mu;
-        f.run_var[c] = (1.f - f.momentum) * f.run_var[c] + f.momentum * (float)unb;
-      }
-    } else if (MODE == FSV_RED_BWD) {
-      f.out1[c] = (float)a; f.out2[c] = (float)b;
-      if (f.dw) f.dw[c] = (float)b;
-      if (f.db) f.db[c] = (float)a;
-    } else {
-      f.out1[c] = f.accumulate ? f.out1[c] + (float)a : (float)a;
-    }
-  }
-}
-
 template <int MODE>
 static inline void fsv_launch_red(const RedPlan& pl, RedP p, int G, hipStream_t stream) {
   p.CU = pl.CU; p.TX = pl.TX; p.TY = pl.TY; p.rows_per_blk = pl.rows_per_blk; p.nchunks = pl.nchunks;
@@ -614,69 +479,6 @@ int fsv_norm_bwd_apply(const float* dy, const float* y, const float* x, const fl
   long long total = (long long)P * C;
   FSV_LAUNCH(fsv_norm_bwd_apply_kernel, dim3(fsv_ew_grid(total)), dim3(256), stream, dy, y, x, mean, rstd, w, s1, s2, dx,
              total, total, C, count, act, 0);
-  return fsv_check_launch();
-}
-
-}  // extern "C"
-
-// ---- fused second stage (opt-in, FSV_FUSED_FINAL=1 on the host side): BatchNorm-shaped reductions (G = 1) in ONE launch ------
-// The two-stage reductions above cost two launches each (about 200 second-stage launches per training iteration).  In the
-// fused twin fsv_red2f_kernel the block that finishes last for a channel slab sums the slab's partials itself - with
-// fsv_sum_chunks, i.e. in the order of the stand-alone second stage, so the results are bit-identical.  `counters`: at least
-// fsv_red_slabs(P, C) ints that are zero between launches (the finishing block resets its ticket).
-template <int MODE>
-static inline void fsv_launch_redf(const RedPlan& pl, RedP p, const RedFinal& f, hipStream_t stream) {
-  p.CU = pl.CU; p.TX = pl.TX; p.TY = pl.TY; p.rows_per_blk = pl.rows_per_blk; p.nchunks = pl.nchunks;
-  dim3 grid(pl.nchunks, pl.nslabs, 1);
-  if (pl.V == 4) FSV_LAUNCH((fsv_red2f_kernel<MODE, 4>), grid, dim3(256), stream, p, f);
-  else FSV_LAUNCH((fsv_red2f_kernel<MODE, 1>), grid, dim3(256), stream, p, f);
-}
-
-extern "C" {
-
-int fsv_red_slabs(int P, int C) {
-  if (P < 1 || C < 1) return 1;
-  return fsv_red_plan(1, P, C).nslabs;
-}
-
-int fsv_norm_stats_fused(const float* x, double* workspace, int* counters, float* mean, float* rstd, int P, int C, float eps,
-                         float* run_mean, float* run_var, float momentum, hipStream_t stream) {
-  if (!x || !workspace || !counters || !mean || !rstd || P < 1 || C < 1) return FSV_ERR_BAD_ARG;
-  RedPlan pl = fsv_red_plan(1, P, C);
-  RedP rp; rp.a = x; rp.y = nullptr; rp.x = nullptr; rp.mean = nullptr; rp.rstd = nullptr; rp.part = workspace;
-  rp.P = P; rp.C = C; rp.act = 0;
-  RedFinal f; f.counter = counters; f.out1 = mean; f.out2 = rstd; f.run_mean = run_mean; f.run_var = run_var; f.eps = eps;
-  f.momentum = momentum; f.dw = nullptr; f.db = nullptr; f.accumulate = 0;
-  fsv_launch_redf<FSV_RED_STATS>(pl, rp, f, stream);
-  return fsv_check_launch();
-}
-
-int fsv_norm_bwd_fused(const float* dy, const float* y, const float* x, const float* mean, const float* rstd, const float* w,
-                       double* workspace, int* counters, float* s1, float* s2, float* dx, float* dw, float* db, int P, int C,
-                       int act, hipStream_t stream) {
-  if (!dy || !x || !mean || !rstd || !workspace || !counters || !s1 || !s2 || !dx) return FSV_ERR_BAD_ARG;
-  if (act != FSV_ACT_NONE && !y) return FSV_ERR_BAD_ARG;
-  RedPlan pl = fsv_red_plan(1, P, C);
-  RedP rp; rp.a = dy; rp.y = y; rp.x = x; rp.mean = mean; rp.rstd = rstd; rp.part = workspace;
-  rp.P = P; rp.C = C; rp.act = act;
-  RedFinal f; f.counter = counters; f.out1 = s1; f.out2 = s2; f.run_mean = nullptr; f.run_var = nullptr; f.eps = 0.f;
-  f.momentum = 0.f; f.dw = dw; f.db = db; f.accumulate = 0;
-  fsv_launch_redf<FSV_RED_BWD>(pl, rp, f, stream);
-  long long total = (long long)P * C;
-  FSV_LAUNCH(fsv_norm_bwd_apply_kernel, dim3(fsv_ew_grid(total)), dim3(256), stream, dy, y, x, mean, rstd, w,
-             (const float*)s1, (const float*)s2, dx, total, total, C, P, act, 0);
-  return fsv_check_launch();
-}
-
-int fsv_colsum_fused(const float* x, double* workspace, int* counters, float* out, int P, int C, int accumulate,
-                     hipStream_t stream) {
-  if (!x || !workspace || !counters || !out || P < 1 || C < 1) return FSV_ERR_BAD_ARG;
-  RedPlan pl = fsv_red_plan(1, P, C);
-  RedP rp; rp.a = x; rp.y = nullptr; rp.x = nullptr; rp.mean = nullptr; rp.rstd = nullptr; rp.part = workspace;
-  rp.P = P; rp.C = C; rp.act = 0;
-  RedFinal f; f.counter = counters; f.out1 = out; f.out2 = nullptr; f.run_mean = nullptr; f.run_var = nullptr; f.eps = 0.f;
-  f.momentum = 0.f; f.dw = nullptr; f.db = nullptr; f.accumulate = accumulate;
-  fsv_launch_redf<FSV_RED_COLSUM>(pl, rp, f, stream);
   return fsv_check_launch();
 }
 

@@ -29,12 +29,6 @@ from .grad_finalize import GradFinalizer
 class FlatAdam:
     def __init__(self, params, lr, betas=(0.0, 0.999), world_size=1, process_group=None, eps=1e-8, bucket_mb=64,
                  force_exchange=False, overlap=True, loss_scale=None):
-        params = [p for p in params if p.requires_grad]
-        if not params:
-            raise ValueError("no trainable parameters")
-        # reverse order: the last layers' gradients (first to be produced by backward) sit at the front
-        self.params = list(reversed(params))
-        self.device = params[0].device
         self.world_size = world_size
         # force_exchange: run the bucket / hook / side-stream machinery even in a one-rank group (smoke test of the
         # exact multi-GPU code path on a single-GPU box: the all-reduce is then an identity)
@@ -42,6 +36,41 @@ class FlatAdam:
         self.overlap = overlap and self.exchange
         self.group = process_group
         self.betas, self.eps = betas, eps
+        self.bucket_mb = bucket_mb
+        # bumped by rebuild(): captured graphs / cached pointers of an older layout are stale (graph_step.py checks it)
+        self.generation = 0
+        self._hook_handles = []
+        self._lay_out(params, lr, loss_scale)
+
+    def rebuild(self, params, lr=None, loss_scale='keep'):
+        """Re-lay this optimiser over a new parameter set IN PLACE: fresh flat buffers, Adam moments and step count
+        (what the reference's `get_optimizer` call inside init_temporal_model does, base_model.py:259-279), but the
+        Python object stays the one train.py got from create_model (train.py:36 keeps those handles for the whole
+        run - a second FlatAdam over the same parameters would leave the first one stepping orphaned buffers)."""
+        for h in self._hook_handles:
+            h.remove()
+        self._hook_handles = []
+        self._reattach()
+        for p in self.params:
+            for a in ('_fsv_sink', '_fsv_cache', '_fsv_finalizer'):
+                if hasattr(p, a):
+                    delattr(p, a)
+        if lr is None:
+            lr = float(self.state[3])
+        if loss_scale == 'keep':
+            loss_scale = None if self.scaler is None else (float(self.scaler[0]), int(self.scaler[3]))
+        self.generation += 1
+        self._lay_out(params, lr, loss_scale)
+        return self
+
+    def _lay_out(self, params, lr, loss_scale):
+        world_size, bucket_mb = self.world_size, self.bucket_mb
+        params = [p for p in params if p.requires_grad]
+        if not params:
+            raise ValueError("no trainable parameters")
+        # reverse order: the last layers' gradients (first to be produced by backward) sit at the front
+        self.params = list(reversed(params))
+        self.device = params[0].device
         total = sum(p.numel() for p in self.params)
         self.total = total
         self.flat_p = torch.empty(total, dtype=torch.float32, device=self.device)
@@ -110,7 +139,7 @@ class FlatAdam:
             if self.device.type == 'cuda':
                 self.side_stream = torch.cuda.Stream(device=self.device)
             for i, p in enumerate(self.params):
-                p.register_post_accumulate_grad_hook(self._make_hook(i))
+                self._hook_handles.append(p.register_post_accumulate_grad_hook(self._make_hook(i)))
 
     # ------------------------------------------------------------------------------------------------ DDP
     def _make_hook(self, i):

@@ -32,7 +32,11 @@ class _ModuleHandle(torch.nn.Module):
 def create_model(opt, epoch=0):
     """models/models.py:16-38: returns (model, flowNet, [optimizer_G, optimizer_D])."""
     device = torch.device('cuda', opt.gpu_ids[0]) if len(opt.gpu_ids) else torch.device('cpu')
+    # Vid2VidModel.initialize(opt, epoch) already started temporal when the run resumes past the single-frame epochs
+    # (base_model.py:213-215); the checkpoints are read once the networks sit on their device and before the optimisers
+    # copy the parameters into their flat buffers (vid2vid_model.py:44 `self.load_networks()`)
     m = _model.create_model(opt, epoch, device)
+    m.load_networks()
     world = torch.distributed.get_world_size() if torch.distributed.is_available() and torch.distributed.is_initialized() else 1
     opt_G, opt_D = m.build_optimizers(world_size=world)
     flow_net = None
@@ -77,6 +81,21 @@ def init_dist(launcher='pytorch', backend='nccl', **kwargs):
     return gpu_id
 
 
+def batch_conv(x, weight, bias=None, stride=1, group_size=-1):
+    """models/networks/base_network.py:56-71 on the per-sample gather-GEMM: stride 1 (every call site under the flags of
+    the shipped scripts) and stride 2 (generator.py:552, architecture.py:35).  The transposed form (stride < 1) and grouped
+    weights (group_size != -1) are not built and raise instead of silently computing something else."""
+    if isinstance(weight, (list, tuple)):
+        weight, bias = weight[0], weight[1]
+    if weight is None:
+        return x
+    if stride not in (1, 2):
+        raise NotImplementedError("batch_conv: stride %r (1 and 2 are built)" % (stride,))
+    if group_size != -1:
+        raise NotImplementedError("batch_conv: group_size %r" % (group_size,))
+    return _ops.batch_conv(x, weight, bias, stride=stride)
+
+
 def patch_reference():
     """Re-bind the reference's names to this package.  The reference tree must already be importable."""
     import importlib
@@ -93,9 +112,7 @@ def patch_reference():
                     'models.networks.architecture', 'models.loss_collector'):
         mod = sys.modules.get(modname) or importlib.import_module(modname)
         if hasattr(mod, 'batch_conv'):
-            mod.batch_conv = lambda x, weight, bias=None, stride=1, group_size=-1: _ops.batch_conv(
-                x, weight if not isinstance(weight, (list, tuple)) else weight[0],
-                bias if not isinstance(weight, (list, tuple)) else weight[1])
+            mod.batch_conv = batch_conv
             patched.append(modname + '.batch_conv')
         if hasattr(mod, 'resample'):
             mod.resample = _ops.resample

@@ -32,18 +32,6 @@ _SIGS = {
                        c_i, c_ip, c_ip, c_i, c_i,
                        c_i, c_i, c_ll, c_i, c_i, c_i, c_i, c_p],
     "fsv_bias_act": [c_p, c_p, c_ll, c_i, c_i, c_p],
-    # split-K through a workspace (csrc/conv_igemm_db.hip): fsv_conv_gather_fwd's arguments without force_tile / force_split /
-    # accumulate, then wscale, skw, sk_tickets, ws_floats*, n_tickets*, prefetch, stream
-    "fsv_conv_gather_fwd_splitws": [c_p, c_p, c_p, c_p, c_p,
-                                    c_i, c_i, c_i, c_i, c_i, c_i, c_i,
-                                    c_i, c_ip, c_ip, c_i, c_i,
-                                    c_i, c_i, c_i, c_i, c_i, c_i,
-                                    c_i, c_ll, c_ll, c_i,
-                                    c_i, c_f, c_p, c_p, c_p, ctypes.POINTER(ctypes.c_longlong), c_ip, c_i, c_p],
-    # merged stride-2 data gradient (csrc/conv_igemm_db.hip): in, wt[4], out, N, H, W, Cin, Cout, ntaps[4], ty[64], tx[64],
-    # sub_h[4], sub_w[4], py[4], px[4], outH, outW, ldw, w_bstride[4], per_sample, wscale, prefetch, stream
-    "fsv_conv_dgrad_s2": [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_ip, c_ip, c_ip, c_ip, c_ip, c_ip, c_ip, c_i, c_i, c_i,
-                          c_p, c_i, c_p, c_i, c_p],
     # narrow-operand (--amp) variants, csrc/conv_np.hip: the same arguments plus `mode` before the stream
     "fsv_conv_gather_fwd_np": [c_p, c_p, c_p, c_p, c_p,
                                c_i, c_i, c_i, c_i, c_i, c_i, c_i,

@@ -311,6 +311,29 @@ def loss_backward(opt, losses, optimizer, loss_id):
     return losses
 
 
+def set_random_seed(seed):
+    """util/distributed.py `set_random_seed`: Python, numpy and torch streams together."""
+    import random
+    import numpy as np
+    random.seed(seed)
+    np.random.seed(seed)
+    torch.manual_seed(seed)
+    if torch.cuda.is_available():
+        torch.cuda.manual_seed_all(seed)
+
+
+def get_rank():
+    import torch.distributed as dist
+    return dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
+
+
+def optimizer_rates(opt):
+    """models/base_model.py:39-48 `get_optimizer`: (beta1, beta2, lr_G, lr_D), always derived from opt.lr."""
+    if opt.no_TTUR:
+        return opt.beta1, 0.999, opt.lr, opt.lr
+    return 0.0, opt.beta2, opt.lr / 2, opt.lr * 2
+
+
 # ------------------------------------------------------------------------------------------------ the model
 class Vid2VidModel(nn.Module):
     """Drop-in for models.vid2vid_model.Vid2VidModel on the training path (modes 'generator', 'discriminator')."""
@@ -329,7 +352,7 @@ class Vid2VidModel(nn.Module):
         self.save_dir = os.path.join(getattr(opt, 'checkpoints_dir', './checkpoints'), getattr(opt, 'name', 'test'))
         self.refine_face = bool(getattr(opt, 'refine_face', False))
         self.lossCollector = LossCollector(opt)
-        torch.manual_seed(0)            # reference: set_random_seed(0) before building so replicas start identical
+        set_random_seed(0)              # vid2vid_model.py:27: every replica builds identical weights
         opt.for_face = False
         self.netG = networks.define_G(opt)
         self.netGf = None
@@ -356,7 +379,13 @@ class Vid2VidModel(nn.Module):
                                            not opt.no_ganFeat_loss)
         self.netDT = None
         self.optimizer_G = self.optimizer_D = None
-        return self
+        # base_model.py:213-215 (inside define_networks): test mode, or a run resumed past the single-frame epochs,
+        # starts temporal.  The optimisers do not exist yet here: build_optimizers() covers whatever networks exist then.
+        self.start_epoch = epoch
+        if (not opt.isTrain or epoch > getattr(opt, 'niter_single', 0)) and opt.n_frames_G > 1:
+            self.init_temporal_model()
+        set_random_seed(get_rank())     # vid2vid_model.py:45: per-rank streams from here on (load_networks() runs once the
+        return self                     # module sits on its device: integration.create_model / Vid2VidModel.load_networks)
 
     def _apply(self, fn, *args, **kwargs):
         out = super()._apply(fn, *args, **kwargs)
@@ -373,10 +402,7 @@ class Vid2VidModel(nn.Module):
         if sync_bn is None:
             sync_bn = os.environ.get('FSV_SYNC_BN', '0') == '1'
         ops.set_bn_sync(world_size if sync_bn else 1, process_group)
-        if opt.no_TTUR:
-            beta1, beta2, g_lr, d_lr = opt.beta1, 0.999, opt.lr, opt.lr
-        else:
-            beta1, beta2, g_lr, d_lr = 0.0, opt.beta2, opt.lr / 2, opt.lr * 2
+        beta1, beta2, g_lr, d_lr = optimizer_rates(opt)
         # models/models.py:22-26 `amp.initialize(model, [optimizer_G, optimizer_D], opt_level=opt.amp, num_losses=2)`:
         # process-wide operand arithmetic + one dynamic loss scale per optimiser (fp16 only)
         mode = amp_mode(opt)
@@ -388,6 +414,8 @@ class Vid2VidModel(nn.Module):
         self.optimizer_G = FlatAdam(g_params, g_lr, (beta1, beta2), world_size, process_group,
                                     force_exchange=force_exchange, overlap=overlap, loss_scale=loss_scale)
         d_params = list(self.netD.parameters())
+        if self.netDT is not None:         # built temporal from the start (resume past niter_single): base_model.py:274
+            d_params += list(self.netDT.parameters())
         if self.netDf is not None:         # base_model.py:209-211
             d_params += list(self.netDf.parameters())
         self.optimizer_D = FlatAdam(d_params, d_lr, (beta1, beta2), world_size, process_group,
@@ -396,32 +424,29 @@ class Vid2VidModel(nn.Module):
 
     def init_temporal_model(self):
         """models/base_model.py:259-279: the generator grows its previous-frame flow / embedding branches, the temporal
-        discriminator netDT (input = tD stacked frames) is created, and both optimisers are rebuilt over the new
-        parameter sets (fresh Adam state, as in the reference)."""
+        discriminator netDT (input = tD stacked frames) is created, and both optimisers are re-laid over the new
+        parameter sets with fresh Adam state and the opt.lr-derived rates of `get_optimizer`.  The optimiser OBJECTS stay
+        the ones create_model handed to train.py (train.py:36 keeps them for the whole run; models.update_models calls
+        this method at epoch niter_single + 1), so the loop keeps stepping live parameters."""
         opt = self.opt
         self.temporal = True
-        torch.manual_seed(0)
+        set_random_seed(0)                 # generator.py:157
         self.netG.init_temporal_network()
-        self.lossCollector.tD = min(opt.n_frames_D, opt.n_frames_G)
         dev = next(self.netG.parameters()).device
         self.netG.to(dev)
-        self.netDT = networks.define_D(opt, opt.output_nc * self.lossCollector.tD, opt.ndf, opt.n_layers_D, opt.norm_D,
-                                       'n_layers', 1, not opt.no_ganFeat_loss).to(dev)
+        if opt.isTrain:
+            self.lossCollector.tD = min(opt.n_frames_D, opt.n_frames_G)
+            self.netDT = networks.define_D(opt, opt.output_nc * self.lossCollector.tD, opt.ndf, opt.n_layers_D, opt.norm_D,
+                                           'n_layers', 1, not opt.no_ganFeat_loss).to(dev)
+        set_random_seed(get_rank())        # generator.py:179
         if self.optimizer_G is not None:
-            old = self.optimizer_G
+            _, _, g_lr, d_lr = optimizer_rates(opt)
             g_params = list(self.netG.parameters()) + (list(self.netGf.parameters()) if self.netGf is not None else [])
-            def carried(o):                # the loss scale found so far carries over to the rebuilt optimiser
-                return None if o.scaler is None else (float(o.scaler[0]), int(o.scaler[3]))
-            self.optimizer_G = FlatAdam(g_params, float(old.state[3]), old.betas, old.world_size,
-                                        old.group, force_exchange=old.exchange and old.world_size == 1, overlap=old.overlap,
-                                        loss_scale=carried(old))
-            old = self.optimizer_D
-            d_params = list(self.netD.parameters()) + list(self.netDT.parameters())
+            self.optimizer_G.rebuild(g_params, lr=g_lr)          # the loss scale found so far carries over
+            d_params = list(self.netD.parameters()) + (list(self.netDT.parameters()) if self.netDT is not None else [])
             if self.netDf is not None:
                 d_params += list(self.netDf.parameters())
-            self.optimizer_D = FlatAdam(d_params, float(old.state[3]), old.betas, old.world_size, old.group,
-                                        force_exchange=old.exchange and old.world_size == 1, overlap=old.overlap,
-                                        loss_scale=carried(old))
+            self.optimizer_D.rebuild(d_params, lr=d_lr)
         return self.optimizer_G
 
     def update_learning_rate(self, epoch):
@@ -488,6 +513,8 @@ class Vid2VidModel(nn.Module):
             path = '' if (not self.isTrain or getattr(opt, 'continue_train', False)) else opt.load_pretrain
             epoch = getattr(opt, 'which_epoch', 'latest')
             self.load_network(self.netG, 'G', epoch, path)
+            if self.temporal and opt.warp_ref and not self.netG.flow_temp_is_initalized:     # base_model.py:234-235
+                self.netG.load_pretrained_net(self.netG.flow_network_ref, self.netG.flow_network_temp)
             if self.netGf is not None:
                 self.load_network(self.netGf, 'Gf', epoch, path)
             if (self.isTrain and not getattr(opt, 'load_pretrain', '')) or getattr(opt, 'finetune', False):
@@ -496,6 +523,9 @@ class Vid2VidModel(nn.Module):
                     self.load_network(self.netDT, 'DT', epoch, path)
                 if self.add_face_D:
                     self.load_network(self.netDf, 'Df', epoch, path)
+            for o in (self.optimizer_G, self.optimizer_D):      # cached GEMM layouts follow the loaded values
+                if o is not None:
+                    o.refresh_layouts()
 
     # ---------------------------------------------------------------------------------------------- forward
     def forward(self, data_list, save_images=False, mode='inference', dummy_bs=0):
@@ -573,13 +603,13 @@ class Vid2VidModel(nn.Module):
         frozen = [p for n, p in self.netG.named_parameters() if not any(t in n for t in names) and p.requires_grad]
         for p in frozen:                 # the reference leaves them trainable but never steps them: same result, less work
             p.requires_grad_(False)
-        if opt.no_TTUR:
-            beta1, beta2, g_lr, d_lr = opt.beta1, 0.999, opt.lr, opt.lr
-        else:
-            beta1, beta2, g_lr, d_lr = 0.0, opt.beta2, opt.lr / 2, opt.lr * 2
-        self.optimizer_G = FlatAdam(g_params, g_lr, (beta1, beta2))
+        beta1, beta2, g_lr, d_lr = optimizer_rates(opt)
+        mode = amp_mode(opt)               # models/models.py:22-26: amp.initialize covers the finetune optimisers too
+        conv.set_mfma_mode(mode)
+        loss_scale = True if mode == conv.MFMA_F16 else None
+        self.optimizer_G = FlatAdam(g_params, g_lr, (beta1, beta2), loss_scale=loss_scale)
         d_params = list(self.netD.parameters()) + (list(self.netDf.parameters()) if self.netDf is not None else [])
-        self.optimizer_D = FlatAdam(d_params, d_lr, (beta1, beta2))
+        self.optimizer_D = FlatAdam(d_params, d_lr, (beta1, beta2), loss_scale=loss_scale)
 
         def roll(t, ny, nx, flip):
             t = torch.cat([t[:, :, -ny:], t[:, :, :-ny]], dim=2)

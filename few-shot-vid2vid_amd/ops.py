@@ -29,10 +29,6 @@ lib.register_sigs({
     "fsv_norm_stats": [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_f, c_p, c_p, c_f, c_p],
     "fsv_norm_apply": [c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p],
     "fsv_norm_bwd": [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p],
-    "fsv_red_slabs": [c_i, c_i],
-    "fsv_norm_stats_fused": [c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_f, c_p, c_p, c_f, c_p],
-    "fsv_norm_bwd_fused": [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_p],
-    "fsv_colsum_fused": [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_p],
     "fsv_norm_sums": [c_p, c_p, c_p, c_i, c_i, c_p],
     "fsv_norm_stats_from_sums": [c_p, ctypes.c_double, c_p, c_p, c_i, c_f, c_p, c_p, c_f, c_p],
     "fsv_norm_bwd_sums": [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_p],
@@ -65,34 +61,6 @@ def _ws(g, p, c, like):
         _ws_fn.argtypes = [c_i, c_i, c_i]
         _ws_fn.restype = c_i
     return torch.empty(max(int(_ws_fn(g, p, c)), 2), dtype=torch.float64, device=like.device)
-
-
-# FSV_FUSED_FINAL=1 (opt-in): BatchNorm-shaped reductions run their second stage inside the reduction launch
-# (csrc/norm.hip fsv_red2f_kernel); the ticket counters are one zeroed int buffer per device, reset by the kernels themselves
-_FUSED_FINAL = None
-_tickets = {}
-
-
-def fused_final():
-    global _FUSED_FINAL
-    if _FUSED_FINAL is None:
-        import os
-        _FUSED_FINAL = os.environ.get('FSV_FUSED_FINAL', '0') == '1'
-    return _FUSED_FINAL
-
-
-def set_fused_final(on):
-    global _FUSED_FINAL
-    prev = fused_final()
-    _FUSED_FINAL = bool(on)
-    return prev
-
-
-def _ticket_counters(like):
-    t = _tickets.get(like.device)
-    if t is None:
-        t = _tickets[like.device] = torch.zeros(4096, dtype=torch.int32, device=like.device)      # >= any channel-slab count
-    return t
 
 
 def _ll(vals):
@@ -169,10 +137,6 @@ def colsum(x2d_nhwc, groups, pixels, channels, out=None):
         out = torch.empty((groups, channels), dtype=torch.float32, device=x2d_nhwc.device)
     lib.check_device(x2d_nhwc)
     ws = _ws(groups, pixels, channels, x2d_nhwc)     # must outlive the call (host allocator frees eagerly)
-    if groups == 1 and fused_final():
-        lib.call("fsv_colsum_fused", lib.ptr(x2d_nhwc), lib.ptr(ws), lib.ptr(_ticket_counters(x2d_nhwc)), lib.ptr(out), pixels,
-                 channels, 1 if acc else 0, lib.stream_ptr())
-        return out
     lib.call("fsv_colsum", lib.ptr(x2d_nhwc), lib.ptr(ws), lib.ptr(out), groups, pixels, channels, 1 if acc else 0,
              lib.stream_ptr())
     return out
@@ -498,12 +462,13 @@ def linear(x2d, weight, bias=None, act=ACT_NONE, sn=None):
     return y4.permute(0, 2, 3, 1).reshape(r, weight.shape[0])
 
 
-def batch_conv(x, weight, bias=None, act=ACT_NONE):
-    """Per-sample 1x1 (or kxk) convolution with generated weights [B, Cout, Cin, k, k] (base_network.py:56-71)."""
+def batch_conv(x, weight, bias=None, act=ACT_NONE, stride=1):
+    """Per-sample 1x1 (or kxk) convolution with generated weights [B, Cout, Cin, k, k] (base_network.py:56-71);
+    stride 1 or 2 (padding k // 2, as the reference)."""
     if weight is None:
         return x
     k = weight.shape[-1]
-    geom = Geom(k, k, 1, k // 2)
+    geom = Geom(k, k, int(stride), k // 2)
     # weights / biases are usually strided views into the weight-generating FC's output: conv.prep_weight / gather_gemm
     # read them in place (sample stride), no copies here
     return _ConvFn.apply(x, weight, bias, None, None, None, None, geom, act, 1.0, False)
@@ -541,10 +506,6 @@ def norm_stats(x, groups, pixels, channels, eps, run_mean=None, run_var=None, mo
         lib.call("fsv_norm_stats_from_sums", lib.ptr(sums), float(pixels) * _bn_sync[0], lib.ptr(mean), lib.ptr(rstd),
                  channels, float(eps), lib.ptr(run_mean), lib.ptr(run_var), float(momentum), lib.stream_ptr())
         return mean, rstd
-    if groups == 1 and fused_final():
-        lib.call("fsv_norm_stats_fused", lib.ptr(x), lib.ptr(ws), lib.ptr(_ticket_counters(x)), lib.ptr(mean), lib.ptr(rstd),
-                 pixels, channels, float(eps), lib.ptr(run_mean), lib.ptr(run_var), float(momentum), lib.stream_ptr())
-        return mean, rstd
     lib.call("fsv_norm_stats", lib.ptr(x), lib.ptr(ws), lib.ptr(mean), lib.ptr(rstd),
              groups, pixels, channels, float(eps), lib.ptr(run_mean), lib.ptr(run_var), float(momentum),
              lib.stream_ptr())
@@ -573,11 +534,6 @@ def bn_backward(dy, y, x, mean, rstd, w, g, p, c, act, fixed_stats, affine, worl
     dw = torch.empty(c, dtype=torch.float32, device=x.device) if affine else None
     db = torch.empty_like(dw) if affine else None
     ws = _ws(g, p, c, x)
-    if g == 1 and not fixed_stats and fused_final():
-        lib.call("fsv_norm_bwd_fused", lib.ptr(dy), lib.ptr(y), lib.ptr(x), lib.ptr(mean), lib.ptr(rstd), lib.ptr(w), lib.ptr(ws),
-                 lib.ptr(_ticket_counters(x)), lib.ptr(s1), lib.ptr(s2), lib.ptr(dx), lib.ptr(dw), lib.ptr(db), p, c, act,
-                 lib.stream_ptr())
-        return dx, dw, db
     lib.call("fsv_norm_bwd", lib.ptr(dy), lib.ptr(y), lib.ptr(x), lib.ptr(mean), lib.ptr(rstd), lib.ptr(w), lib.ptr(ws),
              lib.ptr(s1), lib.ptr(s2), lib.ptr(dx), lib.ptr(dw), lib.ptr(db), g, p, c, act, 1 if fixed_stats else 0,
              lib.stream_ptr())

@@ -40,10 +40,8 @@ enum fsv_act { FSV_ACT_NONE = 0, FSV_ACT_LRELU = 1 /* leaky_relu(0.2), architect
  * taps outside the input read as zero.  wt: K-major [Kpad][ldw] from fsv_prep_weight; per_sample != 0 selects one
  * weight matrix (stride w_bstride) and bias (stride b_bstride) per sample n.  accumulate != 0: `out` was zeroed by
  * the caller, results are added (used for the four parity classes of a stride-2 data gradient).
- * force_tile / force_split: -1 / 0 = automatic (tile ids: 0 128x128, 1 128x64, 2 128x32, 3 256x32, 4 64x64, 5-8 8 / 16-wave
- * experiments, 9 64x128, 10 / 11 / 12 = 64x64 / 64x128 / 128x64 as one- / two-wave workgroups, 13 / 14 / 15 = the same three tiles with
- * double-buffered LDS, 16 / 17 / 18 = double-buffered with the global loads issued two chunks ahead,
- * 19 / 20 / 21 = double-buffered with an XCD-aware tile order).  wscale: optional device scalar multiplying the accumulator before
+ * force_tile / force_split: -1 / 0 = automatic (tile ids, pixels x channels: 0 128x128, 1 128x64, 2 128x32, 4 64x64, 9 64x128).
+ * One activation tensor / weight matrix may hold at most 2 GiB (32-bit byte offsets): FSV_ERR_UNSUPPORTED beyond.  wscale: optional device scalar multiplying the accumulator before
  * the bias (the spectral-norm 1/sigma when wt holds un-normalised weights). */
 int fsv_conv_gather_fwd(const float* in, const float* wt, const float* bias, const float* res, float* out,
                         int N, int H, int W, int Cin, int OH, int OW, int Cout,
@@ -52,28 +50,6 @@ int fsv_conv_gather_fwd(const float* in, const float* wt, const float* bias, con
                         int ldw, long long w_bstride, long long b_bstride, int per_sample,
                         int act, float scale, int force_tile, int force_split, int accumulate, const float* wscale,
                         fsv_stream_t stream);
-
-/* Split-K WITHOUT zero fill, atomics and finishing pass (opt-in; csrc/conv_igemm_db.hip): the contract of fsv_conv_gather_fwd
- * (no accumulate mode) plus a workspace.  Every K split stores its partial tile to skw and takes a ticket; the workgroup drawing a
- * tile's last ticket adds the splits in the order 0, 1, 2, ... and applies bias / activation / residual: one launch, and a result that
- * is bit-reproducible from run to run.  skw == NULL: only report the sizes (*ws_floats, *n_tickets; tickets must be zero between
- * launches).  FSV_ERR_UNSUPPORTED when the launch plan does not split or picks a tile without a double-buffered variant. */
-int fsv_conv_gather_fwd_splitws(const float* in, const float* wt, const float* bias, const float* res, float* out,
-                                int N, int H, int W, int Cin, int OH, int OW, int Cout,
-                                int ntaps, const int* ty, const int* tx, int sy, int sx,
-                                int outH, int outW, int osy, int osx, int ooy, int oox,
-                                int ldw, long long w_bstride, long long b_bstride, int per_sample,
-                                int act, float scale, const float* wscale, float* skw, int* sk_tickets,
-                                long long* ws_floats, int* n_tickets, int prefetch, fsv_stream_t stream);
-
-/* The four output-parity classes of a stride-2 data gradient in ONE launch (opt-in; csrc/conv_igemm_db.hip).  Class k: K-major
- * weights wt[k], ntaps[k] taps at ty / tx[16*k ...], iteration grid sub_h[k] x sub_w[k], output pixel (2y + py[k], 2x + px[k]) of the
- * [N][outH][outW][Cout] tensor; `in` is the incoming gradient [N][H][W][Cin].  Returns FSV_ERR_UNSUPPORTED (-2) when the launch plan
- * wants split-K or a tile without a double-buffered variant: issue the classes one by one then.  prefetch: 1 or 2 chunks ahead. */
-int fsv_conv_dgrad_s2(const float* in, const float* const* wt, float* out, int N, int H, int W, int Cin, int Cout,
-                      const int* ntaps, const int* ty, const int* tx, const int* sub_h, const int* sub_w, const int* py,
-                      const int* px, int outH, int outW, int ldw, const long long* w_bstride, int per_sample,
-                      const float* wscale, int prefetch, fsv_stream_t stream);
 
 /* in place: x = act(x + bias[c]) over an NHWC tensor (finishing pass of operators that add several GEMM launches into one
  * output: convolutions with more than 16 taps, transposed convolutions); act codes as in the conv epilogue, 5 = leaky 0.1 */
@@ -176,17 +152,6 @@ int fsv_norm_bwd(const float* dy, const float* y, const float* x, const float* m
                  double* workspace, float* s1, float* s2, float* dx, float* dw, float* db, int G, int P, int C, int act,
                  int fixed_stats, fsv_stream_t stream);   /* fixed_stats: eval mode, mean / rstd are constants */
 int fsv_colsum(const float* x, double* workspace, float* out, int G, int P, int C, int accumulate, fsv_stream_t stream);
-/* BatchNorm-shaped reductions (G = 1) with the second stage fused into the reduction launch (opt-in; the workgroup that finishes
- * last for a channel slab sums the slab's partials, bit-identical to the two-launch form).  counters: fsv_red_slabs(P, C) ints,
- * zero between launches. */
-int fsv_red_slabs(int P, int C);
-int fsv_norm_stats_fused(const float* x, double* workspace, int* counters, float* mean, float* rstd, int P, int C, float eps,
-                         float* run_mean, float* run_var, float momentum, fsv_stream_t stream);
-int fsv_norm_bwd_fused(const float* dy, const float* y, const float* x, const float* mean, const float* rstd, const float* w,
-                       double* workspace, int* counters, float* s1, float* s2, float* dx, float* dw, float* db, int P, int C,
-                       int act, fsv_stream_t stream);
-int fsv_colsum_fused(const float* x, double* workspace, int* counters, float* out, int P, int C, int accumulate,
-                     fsv_stream_t stream);
 /* cross-replica BatchNorm (opt-in; apex.parallel.SyncBatchNorm of the reference's multi-process path, normalization.py:15,33,80):
  * the device halves on either side of the host's all-reduce.  sums: doubles [2C] = {sum x, sum x^2} resp. {sum d, sum d*xhat};
  * count: values per channel over all ranks.  dw / db of an affine layer are the LOCAL sums (they travel with the gradients). */

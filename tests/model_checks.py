@@ -733,7 +733,7 @@ def check_amp_overflow_skip(device, seed=62):
     g = torch.Generator().manual_seed(seed)
     p = torch.nn.Parameter(torch.randn(1000, generator=g).to(device))
     o = flat.FlatAdam([p], 1e-2, (0.5, 0.999), loss_scale=(1024.0, 2))
-    ref = torch.optim.Adam([torch.nn.Parameter(p.detach().clone())], 1e-2, (0.5, 0.999))
+    ref = torch.optim.Adam([torch.nn.Parameter(p.detach().cpu().clone())], 1e-2, (0.5, 0.999))       # the CPU side of the comparison
     from oracle import np_oracle as NO
     rs = NO.LossScaler(1024.0, 2)
     grads = [torch.randn(1000, generator=g) for _ in range(6)]

@@ -125,3 +125,10 @@ def test_softmax_channels(hip_lib):
 
 def test_losses_pack_pool(hip_lib):
     oc.check_losses(dev())
+
+
+@pytest.mark.gpu
+def test_every_gemm_tile(hip_lib):
+    """all instantiated forward / weight-gradient tiles (incl. split-K atomics and per-sample weights) on ragged geometries"""
+    import tile_checks as tc
+    tc.run_all(DEV)

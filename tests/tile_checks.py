@@ -1,121 +1,96 @@
-"""Forced-tile checks of the fp32 convolution kernels shared by the emulator test (test_tiles_emu.py) and - run as a script -
-the first hardware run of the experimental tile variants (few-wave workgroups 10-12, double-buffered LDS 13-15, weight-gradient
-5 - 8), which were added after the round-1 GPU budget was spent."""
+"""Forced-tile parity of the fp32 gather-GEMM and weight-gradient kernels: every tile the launcher instantiates (the plan only
+ever picks a few per shape) against F.conv2d on ragged geometries - partial row / column tiles, K not a multiple of 32, taps
+that leave the image, split-K with atomics, stride 2, per-sample weights.  Shared by test_tiles_emu.py (SIMT emulator) and the
+GPU suite; `python tests/tile_checks.py` runs it on cuda:0."""
+import os
+import sys
+
 import torch
 import torch.nn.functional as F
 
-import op_checks as oc
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+for p in (ROOT, HERE):
+    if p not in sys.path:
+        sys.path.insert(0, p)
 
-FWD_TILES = (0, 1, 2, 4, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21)
+import op_checks as oc  # noqa: E402
+
+# (n, cin, h, w, cout, k, stride, pad)
+GEOMS = [(2, 8, 9, 11, 40, 3, 1, 1),          # K = 72 (tail chunk), ragged M and N
+         (1, 36, 7, 5, 130, 3, 1, 1),         # Cin not a multiple of 32: a chunk spans two taps; N > 128
+         (2, 64, 6, 6, 64, 1, 1, 0),          # 1x1
+         (1, 16, 10, 9, 33, 4, 2, 2),         # discriminator geometry (k4 s2 p2)
+         (1, 4, 13, 12, 96, 3, 1, 1)]         # Cin = 4: eight taps per chunk
+FWD_TILES = (0, 1, 2, 4, 9, 10, 11, 12, 20, 21, 22, 24, 29, 30, 31, 32)
+WGRAD_TILES = (0, 1, 2, 3)
 
 
-def check_bitwise_tiles(device, shape=(2, 24, 9, 11, 136, 3), seed=77):
-    """without split-K every tile walks K in the same order: identical bits, and equal to torch within fp32 rounding"""
+def _fwd_case(device, geom, tile, split, seed):
     ops, conv = oc.pkg()
-    n, cin, h, w, cout, k = shape
+    n, cin, h, w, cout, k, s, p = geom
     g = torch.Generator().manual_seed(seed)
     x = torch.randn(n, cin, h, w, generator=g)
-    wt = torch.randn(cout, cin, k, k, generator=g) * 0.2
+    wt = torch.randn(cout, cin, k, k, generator=g) * (1.0 / (cin * k * k) ** 0.5)
     b = torch.randn(cout, generator=g)
-    geo = conv.Geom(k, k, 1, k // 2)
-    wf, _, ldw = conv.prep_weight(wt.to(device), 0, geo)
-    outs = [conv.conv_forward(conv.to_nhwc(x.to(device)), wf, ldw, cout, geo, bias=b.to(device), act=conv.ACT_LRELU,
-                              force_tile=t, force_split=1) for t in FWD_TILES]
-    oc.assert_close('tile 0 vs torch', outs[0], F.leaky_relu(F.conv2d(x, wt, b, padding=k // 2), 0.2), 1e-4)
-    for t, o in zip(FWD_TILES[1:], outs[1:]):
-        assert torch.equal(o, outs[0]), 'tile %d differs from tile 0' % t
+    ref = F.leaky_relu(F.conv2d(x, wt, b, stride=s, padding=p), 0.2)
+    ge = conv.Geom(k, k, s, p)
+    wf, kpad, ldw = conv.prep_weight(wt.to(device), 0, ge)
+    nchunks = (k * k * cin + 31) // 32
+    y = conv.conv_forward(conv.to_nhwc(x.to(device)), wf, ldw, cout, ge, bias=b.to(device), act=conv.ACT_LRELU,
+                          force_tile=tile, force_split=min(split, nchunks))
+    oc.assert_close('tile %d split %d %s' % (tile, split, geom), y, ref, 2e-5)
 
 
-def check_split_tiles(device, seed=78):
+def check_forward_tiles(device, tiles=FWD_TILES, geoms=GEOMS):
+    for gi, geom in enumerate(geoms):
+        for tile in tiles:
+            bn = {0: 128, 1: 64, 2: 32, 4: 64, 9: 128, 10: 128, 11: 64, 12: 128}[tile % 20]
+            if geom[4] < bn // 2 and bn > 32:
+                continue                       # a tile twice as wide as the layer: not a configuration the plan can produce
+            for split in (1, 3):
+                _fwd_case(device, geom, tile, split, 100 + gi)
+
+
+def check_per_sample(device, tiles=(4, 9, 12, 24)):
+    """batch_conv form: one weight matrix per sample (grid.z = sample)"""
     ops, conv = oc.pkg()
-    g = torch.Generator().manual_seed(seed)
-    x = torch.randn(2, 64, 16, 16, generator=g)
-    wt = torch.randn(192, 64, 3, 3, generator=g) * 0.1
-    ref = F.conv2d(x, wt, padding=1)
-    geo = conv.Geom(3, 3, 1, 1)
-    wf, _, ldw = conv.prep_weight(wt.to(device), 0, geo)
-    for t in (10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21):
-        for sp in (2, 3):
-            y = conv.conv_forward(conv.to_nhwc(x.to(device)), wf, ldw, 192, geo, force_tile=t, force_split=sp)
-            oc.assert_close('tile %d split %d' % (t, sp), y, ref, 1e-4)
+    g = torch.Generator().manual_seed(7)
+    n, cin, h, w, cout = 3, 16, 9, 10, 72
+    x = torch.randn(n, cin, h, w, generator=g)
+    wt = torch.randn(n, cout, cin, 1, 1, generator=g) * 0.2
+    ref = torch.cat([F.conv2d(x[i:i + 1], wt[i]) for i in range(n)])
+    ge = conv.Geom(1, 1, 1, 0)
+    wf, kpad, ldw = conv.prep_weight(wt.to(device), 0, ge)
+    for tile in tiles:
+        y = conv.conv_forward(conv.to_nhwc(x.to(device)), wf, ldw, cout, ge, per_sample=True, force_tile=tile)
+        oc.assert_close('per-sample tile %d' % tile, y, ref, 2e-5)
 
 
-def check_wgrad_few_wave(device, seed=79):
+def check_wgrad_tiles(device, tiles=WGRAD_TILES, geoms=GEOMS):
     ops, conv = oc.pkg()
-    g = torch.Generator().manual_seed(seed)
-    x = torch.randn(2, 64, 16, 16, generator=g)
-    wt = (torch.randn(192, 64, 3, 3, generator=g) * 0.1).requires_grad_(True)
-    y = F.conv2d(x, wt, padding=1)
-    dy = torch.randn(y.shape, generator=g)
-    y.backward(dy)
-    geo = conv.Geom(3, 3, 1, 1)
-    for t in (5, 6, 7, 8):
-        for sp in (1, 4):
-            dw = conv.conv_wgrad(conv.to_nhwc(x.to(device)), conv.to_nhwc(dy.to(device)), geo, (192, 64, 3, 3), force_tile=t,
-                                 force_split=sp)
-            oc.assert_close('wgrad tile %d split %d' % (t, sp), dw, wt.grad, 1e-4)
+    for gi, geom in enumerate(geoms):
+        n, cin, h, w, cout, k, s, p = geom
+        g = torch.Generator().manual_seed(200 + gi)
+        x = torch.randn(n, cin, h, w, generator=g)
+        wt = torch.zeros(cout, cin, k, k, requires_grad=True)
+        y = F.conv2d(x, wt, stride=s, padding=p)
+        dy = torch.randn(y.shape, generator=g)
+        y.backward(dy)
+        ge = conv.Geom(k, k, s, p)
+        for tile in tiles:
+            for split in (1, 2):
+                dw = conv.conv_wgrad(conv.to_nhwc(x.to(device)), conv.to_nhwc(dy.to(device)), ge, (cout, cin, k, k),
+                                     force_tile=tile, force_split=split)
+                oc.assert_close('wgrad tile %d split %d %s' % (tile, split, geom), dw, wt.grad, 2e-5)
+
+
+def run_all(device):
+    check_forward_tiles(device)
+    check_per_sample(device)
+    check_wgrad_tiles(device)
 
 
 if __name__ == '__main__':
-    dev = torch.device('cuda', 0)
-    check_bitwise_tiles(dev)
-    check_bitwise_tiles(dev, shape=(2, 128, 32, 32, 256, 3), seed=80)
-    check_split_tiles(dev)
-    check_wgrad_few_wave(dev)
-    check_dgrad_merge(dev)
-    check_splitk_ws(dev, reps=10)
-    print('TILES_GPU_OK', flush=True)
-
-
-def check_dgrad_merge(device, seed=81):
-    """merged stride-2 data gradient == per-class launches, bit for bit (no split-K on either side)"""
-    ops, conv = oc.pkg()
-    g = torch.Generator().manual_seed(seed)
-    for (n, cin, h, w, cout, k, p) in ((2, 64, 32, 32, 96, 3, 1), (2, 128, 24, 24, 64, 4, 1), (2, 64, 16, 16, 64, 3, 1),
-                                       (2, 256, 64, 64, 128, 3, 1), (2, 128, 65, 63, 256, 4, 2)):
-        geo = conv.Geom(k, k, 2, p)
-        oh, ow = geo.out_hw(h, w)
-        wt = (torch.randn(cout, cin, k, k, generator=g) * 0.2).to(device)
-        dout = conv.to_nhwc(torch.randn(n, cout, oh, ow, generator=g).to(device))
-        res = []
-        for m in (0, 1, 2):
-            prev = conv.set_dgrad_merge(m)
-            try:
-                res.append(conv.conv_dgrad(dout, wt, geo, (h, w)).cpu())
-            finally:
-                conv.set_dgrad_merge(prev)
-        assert torch.equal(res[0], res[1]) and torch.equal(res[0], res[2]), (n, cin, h, w, cout, k, p)
-
-
-def check_splitk_ws(device, seed=82, reps=3):
-    """split-K through a workspace: equal to torch, and (unlike the atomic path) bit-reproducible from run to run"""
-    import torch.nn.functional as F
-    ops, conv = oc.pkg()
-    g = torch.Generator().manual_seed(seed)
-    for (n, cin, h, w, cout, k, s, p) in ((2, 256, 8, 8, 256, 3, 1, 1), (1, 512, 4, 4, 192, 3, 1, 1), (2, 128, 9, 7, 72, 3, 1, 1),
-                                          (2, 1024, 16, 16, 512, 3, 1, 1), (2, 512, 32, 32, 512, 3, 1, 1)):
-        x = torch.randn(n, cin, h, w, generator=g)
-        wt = torch.randn(cout, cin, k, k, generator=g) * 0.05
-        b = torch.randn(cout, generator=g)
-        ref = F.leaky_relu(F.conv2d(x, wt, b, stride=s, padding=p), 0.2)
-        geo = conv.Geom(k, k, s, p)
-        wf, _, ldw = conv.prep_weight(wt.to(device), 0, geo)
-        for m in (1, 2):
-            prev = conv.set_splitk_ws(m)
-            try:
-                ys = [conv.conv_forward(conv.to_nhwc(x.to(device)), wf, ldw, cout, geo, bias=b.to(device), act=conv.ACT_LRELU).cpu()
-                      for _ in range(reps)]
-            finally:
-                conv.set_splitk_ws(prev)
-            oc.assert_close('workspace split-K', ys[0], ref, 1e-4)
-            # reproducibility only holds where the workspace path really ran (the entry point declines launches that the plan does
-            # not split or gives a tile without a double-buffered variant; those keep the atomic path)
-            import ctypes
-            lib = __import__('importlib').import_module(conv.__name__.rsplit('.', 1)[0] + '.lib')
-            lib.register_sigs({"fsv_conv_plan": [ctypes.c_int] * 6 + [ctypes.POINTER(ctypes.c_int)] * 2})
-            tile, nsplit = ctypes.c_int(0), ctypes.c_int(1)
-            oh, ow = geo.out_hw(h, w)
-            lib.call("fsv_conv_plan", n * oh * ow, cout, (k * k * cin + 31) // 32, 1, -1, 0, ctypes.byref(tile), ctypes.byref(nsplit))
-            if nsplit.value > 1 and tile.value in (1, 4, 9):
-                for y in ys[1:]:
-                    assert torch.equal(y, ys[0]), 'workspace split-K is not reproducible'
+    run_all(torch.device('cuda:0'))
+    print('TILES_GPU_OK')

@@ -10,11 +10,7 @@ import fsv2v_amd  # noqa
 from importlib import import_module
 conv = import_module('few-shot-vid2vid_amd.conv')
 dev = torch.device('cuda:0')
-cfgs = [(-1, 0), (0, 1), (0, 4), (1, 1), (1, 2), (1, 4), (4, 1), (4, 2), (4, 4), (9, 1), (9, 2), (9, 4), (9, 8),
-        (10, 1), (10, 2), (10, 4), (11, 1), (11, 2), (11, 4), (12, 1), (12, 2),      # 10-12: few-wave workgroups (64x64/1w, 64x128/2w, 128x64/2w)
-        (13, 1), (13, 2), (13, 4), (14, 1), (14, 2), (14, 4), (15, 1), (15, 2),      # 13-15: double-buffered LDS (64x64, 64x128, 128x64)
-        (16, 1), (16, 2), (16, 4), (17, 1), (17, 2), (17, 4), (18, 1), (18, 2),      # 16-18: + global loads two chunks ahead
-        (19, 1), (19, 2), (19, 4), (20, 1), (20, 2), (20, 4), (21, 1), (21, 2)]      # 19-21: double-buffered + XCD-aware tile order
+cfgs = [(-1, 0), (0, 1), (0, 2), (0, 4), (1, 1), (1, 2), (1, 4), (4, 1), (4, 2), (4, 4), (9, 1), (9, 2), (9, 4), (9, 8)]
 shapes = [('M8192 N256 K2304', 2, 256, 64, 64, 256, 3), ('M32768 N128 K576', 2, 64, 128, 128, 128, 3),
           ('M32768 N128 K1152', 2, 128, 128, 128, 128, 3), ('M32768 N128 K2304', 2, 256, 128, 128, 128, 3),
           ('M2048 N512 K9216', 2, 1024, 32, 32, 512, 3), ('M2048 N512 K2304', 2, 256, 32, 32, 512, 3),
@@ -36,7 +32,7 @@ for name, n, cin, h, w, cout, k in shapes:
     flops = 2.0 * n * h * w * cout * cin * k * k
     graphs = {}
     for c in cfgs:
-        if c[0] in (0, 9, 11, 14, 17, 20) and cout < 128 or c[0] in (1, 12, 15, 18, 21) and cout < 64:
+        if c[0] in (0, 9) and cout < 128 or c[0] == 1 and cout < 64:
             continue
         f = lambda: conv.conv_forward(x, wf, ldw, cout, g, bias=b, act=conv.ACT_LRELU, force_tile=c[0], force_split=c[1])
         s = torch.cuda.Stream(); s.wait_stream(torch.cuda.current_stream())

@@ -16,7 +16,7 @@ shapes = [('Kdim2304 N256 pix8192', 2, 256, 64, 64, 256, 3), ('Kdim1152 N256 pix
           ('Kdim1152 N64 pix131072', 2, 128, 256, 256, 64, 3), ('Kdim512 N512 pix1024', 1, 512, 1, 1024, 512, 1)]
 if len(sys.argv) > 1:
     shapes = [s for s in shapes if any(a in s[0] for a in sys.argv[1:])]
-TILES = {0: None, 1: (64, 64), 2: (128, 64), 3: (64, 128), 5: (64, 64), 6: (64, 128), 7: (64, 64), 8: (64, 128)}      # 5 / 6: one- / two-wave workgroups, 7 / 8: double-buffered LDS
+TILES = {0: None, 1: (64, 64), 2: (128, 64), 3: (64, 128)}
 NREP = 20
 for name, n, cin, h, w, cout, k in shapes:
     x = conv.to_nhwc(torch.randn(n, cin, h, w, device=dev))
@@ -25,7 +25,7 @@ for name, n, cin, h, w, cout, k in shapes:
     flops = 2.0 * n * h * w * cout * cin * k * k
     kdim, pch = k * k * cin, (n * h * w + 31) // 32
     cfgs = [(0, 0)]
-    for t in (1, 2, 3, 5, 6, 7, 8):
+    for t in (1, 2, 3):
         bm, bn = TILES[t]
         if cout < bn:
             continue
@@ -52,5 +52,5 @@ for name, n, cin, h, w, cout, k in shapes:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record(); gr.replay(); e1.record(); torch.cuda.synchronize()
             res[c].append(flops / (e0.elapsed_time(e1) / NREP * 1e-3) / 1e12)
-    print(json.dumps({'case': name, **{('auto' if c[0] == 0 else '%dx%d%s/s%d' % (TILES[c[0]] + ({5: 'fw', 6: 'fw', 7: 'db', 8: 'db'}.get(c[0], ''), c[1]))): round(sorted(v)[len(v) // 2], 1)
+    print(json.dumps({'case': name, **{('auto' if c[0] == 0 else '%dx%d/s%d' % (TILES[c[0]] + (c[1],))): round(sorted(v)[len(v) // 2], 1)
                                        for c, v in res.items()}}), flush=True)
