@@ -12,9 +12,17 @@ MFMA).  Weak scaling: the per-GPU batch is fixed, gradients are all-reduced over
 Besides the contract fields the JSON line carries
   roofline     - the dominant kernel (the fp32 MFMA implicit-GEMM convolution) priced against the 157.3 TFLOP/s
                  fp32 matrix peak: algorithmic FLOPs per launch / average launch duration, measured with HIP events
-                 on the launch stream in an instrumented pass of the same step;
-  cpu_baseline - the CPU oracle (oracle/fsv_oracle.py, a port of the reference's algorithm; kind "port") timed on
-                 the host cores on a bounded sample of the same workload (rank 0, N=1 only).
+                 on the launch stream in an instrumented pass of the same step; `traffic` is null here - HBM bytes per
+                 launch need rocprofv3 PMC passes (profiles/r02_pmc_hbm_traffic.json holds them for this command);
+  cpu_baseline - the CPU oracle (oracle/fsv_oracle.py, a port of the reference's algorithm; kind "port": the Python
+                 reference cannot travel to the GPU box) timed on the host cores on ONE iteration of the very same
+                 workload (512x512, B = 2, same flags; rank 0, N=1 only);
+  extras       - (N=1) measurements beside the headline: the north-star target (SPADE-generator forward at 512x512,
+                 batch 8, both flag sets, as fractions of the fp32 MFMA peak) and the step the reference's shipped
+                 script trains (scripts/pose/train_g1.sh: + face discriminator, VGG19 loss, FlowNet2 teacher).
+
+    python bench.py --cpu-baseline-only [--use-reference]    # CPU leg alone (no GPU needed; --use-reference: time the
+                                                             # unmodified reference through oracle/ref_import.py instead)
 """
 import argparse
 import json
@@ -31,7 +39,6 @@ import torch.distributed as dist
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, 'tests'))
 
 FP32_MFMA_PEAK_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md "Peak FP32 (matrix)"
 
@@ -41,55 +48,148 @@ WITH_FACE_D = False    # --face-d: BASELINE configs[3] flags (--add_face_D, whic
 AMP = 'O0'             # --amp: the reference's apex level string ('O1': fp16 GEMM operands + loss scale; 'bf16x3'); not the headline
 
 
-def build_opt(size, batch):
-    import model_checks as mc
-    return mc.make_opt(fineSize=size, loadSize=size, batchSize=batch, warp_ref=True, spade_combine=True,
-                       remove_face_labels=True, no_vgg_loss=not (WITH_VGG or WITH_FACE_D), no_flow_gt=True,
-                       add_face_D=WITH_FACE_D, amp=AMP)
+def _synth():
+    from importlib import import_module
+    import fsv2v_amd  # noqa: F401
+    return import_module('few-shot-vid2vid_amd.synth')
+
+
+def build_opt(size, batch, vgg=None, face_d=None, flow_gt=False):
+    vgg = WITH_VGG if vgg is None else vgg
+    face_d = WITH_FACE_D if face_d is None else face_d
+    return _synth().make_opt(fineSize=size, loadSize=size, batchSize=batch, warp_ref=True, spade_combine=True,
+                             remove_face_labels=True, no_vgg_loss=not (vgg or face_d), no_flow_gt=not flow_gt,
+                             add_face_D=face_d, amp=AMP)
 
 
 def make_data(batch, size, seed, device):
-    import model_checks as mc
-    tl, ti, rl, ri = mc.synth_pose_inputs(batch, size, size, seed)
+    tl, ti, rl, ri = _synth().synth_pose_inputs(batch, size, size, seed)
     tl, ti, rl, ri = [t.to(device) for t in (tl, ti, rl, ri)]
     return [tl, ti, [None, None], [None, None], rl, ri, None, None, None]
 
 
-def cpu_baseline(size, threads, budget_s=30.0):
-    """The CPU oracle (a port of the reference's algorithm) on the host cores: one full iteration (D step + G step,
-    both backward passes) at B=1.  The sample is bounded: a 128x128 probe predicts the cost (work scales with the
-    pixel count) and the largest of 512 / 256 / 128 that fits the budget is timed; the result is reported as
-    `size`x`size`-equivalent frames/s (measured frames/s scaled by the pixel ratio)."""
-    import model_checks as mc
-    from oracle import fsv_oracle as O
+def cpu_baseline(size, batch, threads, use_reference=False):
+    """One full iteration (D step + G step, both backward passes - the body of train.py:58-62) of the bench workload on
+    the host cores, at the bench configuration itself (no scaling).  kind "port": oracle/fsv_oracle.py, the CPU
+    restatement of the reference's algorithm (pinned to the reference by tests/golden/); kind "reference": the
+    unmodified reference modules imported from /root/reference through oracle/ref_import.py (build container only -
+    the Python reference does not exist on the GPU box).  A 64x64 iteration first pays the one-time initialisation."""
+    syn = _synth()
+    torch.set_num_threads(threads)
+    if use_reference:
+        from oracle import ref_import
+        ref_import.install_shims()
+        from models.loss_collector import loss_backward
+
+        def one(sz, b):
+            flags = ('--dataset_mode fewshot_pose --aspect_ratio 1 --fineSize %d --loadSize %d --adaptive_spade --warp_ref '
+                     '--spade_combine --remove_face_labels --no_flow_gt --no_vgg_loss --gpu_ids -1 --batchSize %d' % (sz, sz, b))
+            opt, model = ref_import.build_model(flags.split())
+            tl, ti, rl, ri = syn.synth_pose_inputs(b, sz, sz, 99)
+            data = [tl, ti, [None, None], [None, None], rl, ri, None, None, None]
+            t0 = time.perf_counter()
+            loss_backward(opt, model(data, mode='discriminator'), model.optimizer_D, 1)
+            g_losses, _, _ = model(data, mode='generator')
+            loss_backward(opt, g_losses, model.optimizer_G, 0)
+            return time.perf_counter() - t0
+        kind, what = 'reference', 'unmodified reference modules (oracle/ref_import.py)'
+    else:
+        from oracle import fsv_oracle as O
+        from importlib import import_module
+        M = import_module('few-shot-vid2vid_amd.model')
+
+        def one(sz, b):
+            opt = build_opt(sz, b, vgg=False, face_d=False)
+            model = M.create_model(opt)           # only a source of random-init weights with the right shapes (CPU tensors)
+            sdG = {k: v.detach().clone() for k, v in model.netG.state_dict().items()}
+            sdD = {k: v.detach().clone() for k, v in model.netD.state_dict().items()}
+            del model
+            data = syn.synth_pose_inputs(b, sz, sz, 99)
+            cfg = O.cfg_from_opt(opt)
+            t0 = time.perf_counter()
+            O.iteration(sdG, sdD, cfg, data, torch.float32)
+            return time.perf_counter() - t0
+        kind, what = 'port', 'oracle/fsv_oracle.py'
+    one(64, 1)
+    dt = one(size, batch)
+    return dict(value=round(batch / dt, 4), unit='frames/s', cores=threads, kind=kind,
+                sample='1 iteration (D step + G step, fwd+bwd, train.py:58-62) of the bench workload itself: %dx%d, B=%d, '
+                       'same flags, %s: %.1f s' % (size, size, batch, what, dt))
+
+
+def _time_graph(fn, n=5):
+    """ms per call of fn() replayed as a hipGraph (eager warm-up on a side stream first)"""
+    side = torch.cuda.Stream(); side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(2):
+            fn()
+    torch.cuda.current_stream().wait_stream(side); torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        fn()
+    g.replay(); torch.cuda.synchronize()
+    t = time.perf_counter()
+    for _ in range(n):
+        g.replay()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t) / n * 1e3
+
+
+def extras(device, size, steps=5):
+    """Measurements beside the headline (rank 0, N=1): see the module docstring.  Each in its own try: a failure is
+    reported as a string, the headline line is never lost."""
     from importlib import import_module
     import fsv2v_amd  # noqa: F401
+    syn = _synth()
+    net = import_module('few-shot-vid2vid_amd.networks')
     M = import_module('few-shot-vid2vid_amd.model')
-    torch.set_num_threads(threads)
+    out = {}
+    # ---- north-star target: SPADE-generator forward, 512x512, batch 8, training-mode statistics, no autograd tape ----------
+    for name, combine, gflop in (('g_forward_bs8_warp_combine', True, 386.6), ('g_forward_bs8_adaptive_spade_only', False, 179.2)):
+        try:
+            opt = syn.make_opt(fineSize=size, loadSize=size, warp_ref=combine, spade_combine=combine)
+            torch.manual_seed(0)
+            G = net.define_G(opt).to(device).train()
+            tl, ti, rl, ri = syn.synth_pose_inputs(8, size, size, 1)
+            label, rl, ri = tl[:, 0].to(device), rl.to(device), ri.to(device)
 
-    def one(sz):
-        opt = build_opt(sz, 1)
-        model = M.create_model(opt)           # only a source of random-init weights with the right shapes (CPU tensors)
-        sdG = {k: v.detach().clone() for k, v in model.netG.state_dict().items()}
-        sdD = {k: v.detach().clone() for k, v in model.netD.state_dict().items()}
-        del model
-        data = mc.synth_pose_inputs(1, sz, sz, 99)
-        cfg = O.cfg_from_opt(opt)
-        t0 = time.perf_counter()
-        mc._oracle_iteration(sdG, sdD, cfg, data, torch.float32)
-        return time.perf_counter() - t0
-    t128 = one(128)
-    t128 = min(t128, one(128))                # first call pays one-time initialisation
-    sz = 128
-    for cand, factor in ((size, (size / 128.0) ** 2), (256, 4.0)):
-        if cand > 128 and t128 * factor <= budget_s:
-            sz = cand
-            break
-    dt = one(sz) if sz != 128 else t128
-    equiv = (1.0 / dt) * (sz * sz) / float(size * size)
-    return dict(value=round(equiv, 4), unit='frames/s', cores=threads, kind='port',
-                sample='1 iteration (D step + G step, fwd+bwd) at B=1, %dx%d, same flags, oracle/fsv_oracle.py: %.1f s; '
-                       'reported as %dx%d-equivalent frames/s (x pixel ratio %.3f)' % (sz, sz, dt, size, size, (sz * sz) / float(size * size)))
+            def fwd():
+                with torch.no_grad():
+                    return G(label, rl, ri, [None, None])
+            ms = _time_graph(fwd, steps)
+            tf = gflop * 8 * (size / 512.0) ** 2 / ms
+            out[name] = dict(ms=round(ms, 2), gflop_per_frame=gflop, tflops=round(tf, 2), peak_tflops=FP32_MFMA_PEAK_TFLOPS,
+                             frac_fp32_mfma_peak=round(tf / FP32_MFMA_PEAK_TFLOPS, 4), frames_per_s=round(8e3 / ms, 2))
+            del G, fwd
+        except Exception as e:          # noqa: BLE001
+            out[name] = 'failed: %s' % str(e).split('\n')[0][:200]
+        torch.cuda.empty_cache()
+    # ---- the step scripts/pose/train_g1.sh trains: + face discriminator, VGG19 loss, FlowNet2 teacher (random weights) ------
+    try:
+        fn = import_module('few-shot-vid2vid_amd.flownet2')
+        opt = build_opt(size, 2, vgg=True, face_d=True, flow_gt=True)
+        model = M.create_model(opt).to(device).train()
+        opt_G, opt_D = model.build_optimizers()
+        teacher = fn.FlowNet(opt).to(device).eval()
+        data = make_data(2, size, 4321, device)
+
+        def full_step():
+            with torch.no_grad():           # train.py:44-48: teacher flow / confidence of (reference, target), no prev frame
+                flow_gt, conf_gt = teacher([data[1], data[5]], 0)
+            d = list(data)
+            d[2], d[3] = flow_gt, conf_gt
+            M.loss_backward(opt, model(d, mode='discriminator'), opt_D, 1)
+            g_losses, _, _ = model(d, mode='generator')
+            M.loss_backward(opt, g_losses, opt_G, 0)
+        ms = _time_graph(full_step, steps)
+        out['shipped_step_face_d_vgg_flownet2'] = dict(ms_per_step=round(ms, 2), frames_per_s=round(2e3 / ms, 2), batch=2,
+                                                       note='scripts/pose/train_g1.sh flags at 512x512: --add_face_D, VGG19 '
+                                                            'loss, FlowNet2 teacher forward (162.5 M random weights) inside '
+                                                            'the timed step')
+    except Exception as e:              # noqa: BLE001
+        out['shipped_step_face_d_vgg_flownet2'] = 'failed: %s' % str(e).split('\n')[0][:200]
+    torch.cuda.empty_cache()
+    return out
 
 
 def main():
@@ -102,6 +202,9 @@ def main():
     ap.add_argument('--no-graph', action='store_true')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
+    ap.add_argument('--no-extras', action='store_true')
+    ap.add_argument('--cpu-baseline-only', action='store_true', help='run only the CPU leg (no GPU needed)')
+    ap.add_argument('--use-reference', action='store_true', help='CPU leg: time the unmodified reference (build container)')
     ap.add_argument('--vgg', action='store_true', help='include the VGG19 perceptual loss in the G step')
     ap.add_argument('--face-d', action='store_true', help='config 3: --add_face_D (face discriminator + VGG19 loss)')
     ap.add_argument('--amp', default='O0', help="reference --amp level: O1 = fp16 GEMM operands (fp32 accumulate) + dynamic "
@@ -112,6 +215,9 @@ def main():
     WITH_FACE_D = args.face_d
     AMP = args.amp
 
+    if args.cpu_baseline_only:
+        print(json.dumps(cpu_baseline(args.size, args.batch, min(os.cpu_count() or 1, 64), args.use_reference)), flush=True)
+        return
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
@@ -270,21 +376,11 @@ def main():
         if rl is not None:
             result['roofline'] = rl['dominant']
             result['kernels'] = rl['by_kernel']
-            # HBM bytes per launch of the same kernel from the rocprofv3 PMC passes of this command
-            # (profiles/r01_pmc_hbm_traffic.json: FETCH_SIZE doubled per the gfx950 note, + WRITE_SIZE)
-            try:
-                with open(os.path.join(ROOT, 'profiles', 'r01_pmc_hbm_traffic.json')) as f:
-                    pmc = json.load(f)
-                want = result['roofline']['kernel'].split('<')[1].split(',V')[0].replace('x', ', ')
-                for name, v in pmc.items():
-                    if 'fsv_conv_igemm_kernel<' + want in name and name.rstrip().endswith(result['roofline']['kernel'][-2] + '>'):
-                        result['roofline']['traffic'] = round((v['read_MB_corrected'] + v['write_MB']) * 1e6)
-                        result['roofline']['traffic_unit'] = 'bytes/launch (PMC, profiles/r01_pmc_hbm_traffic.json)'
-                        break
-            except Exception:
-                pass
+            result['roofline']['traffic'] = None        # needs PMC passes: see profiles/ (not measurable in-run)
         if world == 1 and not args.no_cpu_baseline:
-            result['cpu_baseline'] = cpu_baseline(args.size, min(os.cpu_count() or 1, 64))
+            result['cpu_baseline'] = cpu_baseline(args.size, args.batch, min(os.cpu_count() or 1, 64))
+        if world == 1 and not args.no_extras and not (WITH_VGG or WITH_FACE_D) and AMP == 'O0':
+            result['extras'] = extras(device, args.size)
     if world > 1 or force_dist:
         dist.destroy_process_group()
     if rank == 0:

@@ -174,6 +174,9 @@ def gather_gemm(x, wt, ldw, cout, oh, ow, ty, tx, sy, sx, bias=None, res=None, a
             n, h, w, cin, oh, ow, cout, len(ty), lib.int_array(ty), lib.int_array(tx), sy, sx,
             out_h, out_w, osy, osx, ooy, oox, ldw, w_bs, b_bs, 1 if per_sample else 0,
             act, float(scale), force_tile, force_split, 1 if accumulate else 0, lib.ptr(wscale), lib.stream_ptr())
+    if _plan_log is not None:
+        _plan_log.append(planned(oh * ow if per_sample else n * oh * ow, cout, (len(ty) * cin + 31) // 32, n if per_sample else 1,
+                                 force_tile, force_split) + (cin % 4 == 0,))
     entry = "fsv_conv_gather_fwd"
     if _mfma_mode and cin % 4 == 0:               # scalar-gather layers (3-channel images, labels) stay on the fp32 kernel
         entry = "fsv_conv_gather_fwd_np"
@@ -200,12 +203,31 @@ def conv_forward(x, wt_f, ldw, cout, geom, bias=None, res=None, act=ACT_NONE, sc
                        wscale=wscale)
 
 
-def _planned_split(mz, cout, nchunks, nsamp):
-    """the split-K factor fsv_conv_gather_fwd will pick for this launch (csrc/conv_igemm.hip fsv_conv_plan)"""
+def planned(mz, cout, nchunks, nsamp, force_tile=-1, force_split=0):
+    """(tile id, split-K factor) fsv_conv_gather_fwd will use for this launch (csrc/conv_igemm.hip fsv_conv_plan)"""
     lib.register_sigs({"fsv_conv_plan": [ctypes.c_int] * 6 + [ctypes.POINTER(ctypes.c_int)] * 2})
     tile, nsplit = ctypes.c_int(0), ctypes.c_int(1)
-    lib.call("fsv_conv_plan", mz, cout, nchunks, nsamp, -1, 0, ctypes.byref(tile), ctypes.byref(nsplit))
-    return nsplit.value
+    lib.call("fsv_conv_plan", mz, cout, nchunks, nsamp, force_tile, force_split, ctypes.byref(tile), ctypes.byref(nsplit))
+    return tile.value, nsplit.value
+
+
+def _planned_split(mz, cout, nchunks, nsamp):
+    return planned(mz, cout, nchunks, nsamp)[1]
+
+
+# tests: which (tile, split-K, vectorised gather) combinations a piece of work actually launched
+_plan_log = None
+
+
+def start_plan_log():
+    global _plan_log
+    _plan_log = []
+
+
+def stop_plan_log():
+    global _plan_log
+    log, _plan_log = _plan_log, None
+    return log or []
 
 
 def conv_dgrad(dout, w, geom, in_hw, scale=None, per_sample=False, cached=None, cin=None):

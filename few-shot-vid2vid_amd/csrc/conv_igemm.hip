@@ -41,10 +41,10 @@ __device__ __forceinline__ void fsv_xcd_tile(int nx, int ny, int& bx, int& by) {
 //   B [32 k][BN] as it lies in HBM: ds_write_b128 rows, ds_read_b32 fragments (32 consecutive columns).
 // MFMA k order inside a chunk: step (g, t) multiplies k = 8g + t (lanes 0-31) and k = 8g + 4 + t (lanes 32-63), so that
 // one b128 read of A feeds four MFMA steps.  The sum over k is still one fp32 fma chain per output (order permuted).
-// PIPE = 1: the LDS fragment reads of k-group g + 1 are issued (into a second register set) BEFORE the MFMAs of group g and
-// pinned there with scheduling fences - left alone the compiler sinks every read next to its MFMAs and waits for it
-// (read, s_waitcnt lgkmcnt(0), two MFMAs, read, ...), which exposes the LDS latency whenever a SIMD holds a single wave.
-template <int BM, int BN, int WM, int WN, int PIPE>
+// The LDS fragment reads of k-group g + 1 are issued (into a second register set) BEFORE the MFMAs of group g and pinned
+// there with scheduling fences - left alone the compiler sinks every read next to its MFMAs and waits for it (read,
+// s_waitcnt lgkmcnt(0), two MFMAs, read, ...), which exposes the LDS latency whenever a SIMD holds a single wave.
+template <int BM, int BN, int WM, int WN>
 __global__ __launch_bounds__(64 * WM * WN) void fsv_conv_igemm_kernel(ConvP p) {
   constexpr int BK = FSV_BK;
   constexpr int NT = 64 * WM * WN;    // 4 or 8 waves
@@ -210,35 +210,24 @@ __global__ __launch_bounds__(64 * WM * WN) void fsv_conv_igemm_kernel(ConvP p) {
       const float* b_src = Bs + buf * B_ST;
       float4 fa[2][TM];
       float fb[2][4][TN];
-      if constexpr (PIPE) {
-        read_group(a_src, b_src, 0, fa[0], fb[0]);
-        FSV_SCHED_FENCE();
-        calc_offsets();
-        read_group(a_src, b_src, 1, fa[1], fb[1]);
-        FSV_SCHED_FENCE();
-        mma_group(fa[0], fb[0]);
-        FSV_SCHED_FENCE();
-        read_group(a_src, b_src, 2, fa[0], fb[0]);
-        FSV_SCHED_FENCE();
-        mma_group(fa[1], fb[1]);
-        FSV_SCHED_FENCE();
-        read_group(a_src, b_src, 3, fa[1], fb[1]);
-        FSV_SCHED_FENCE();
-        mma_group(fa[0], fb[0]);
-        FSV_SCHED_FENCE();
-        store_chunk(buf ^ 1);
-        FSV_SCHED_FENCE();
-        mma_group(fa[1], fb[1]);
-      } else {
-        FSV_SCHED_FENCE();
-        calc_offsets();
-        read_group(a_src, b_src, 0, fa[0], fb[0]); mma_group(fa[0], fb[0]);
-        read_group(a_src, b_src, 1, fa[0], fb[0]); mma_group(fa[0], fb[0]);
-        read_group(a_src, b_src, 2, fa[0], fb[0]); mma_group(fa[0], fb[0]);
-        FSV_SCHED_FENCE();
-        store_chunk(buf ^ 1);
-        read_group(a_src, b_src, 3, fa[0], fb[0]); mma_group(fa[0], fb[0]);
-      }
+      read_group(a_src, b_src, 0, fa[0], fb[0]);
+      FSV_SCHED_FENCE();
+      calc_offsets();
+      read_group(a_src, b_src, 1, fa[1], fb[1]);
+      FSV_SCHED_FENCE();
+      mma_group(fa[0], fb[0]);
+      FSV_SCHED_FENCE();
+      read_group(a_src, b_src, 2, fa[0], fb[0]);
+      FSV_SCHED_FENCE();
+      mma_group(fa[1], fb[1]);
+      FSV_SCHED_FENCE();
+      read_group(a_src, b_src, 3, fa[1], fb[1]);
+      FSV_SCHED_FENCE();
+      mma_group(fa[0], fb[0]);
+      FSV_SCHED_FENCE();
+      store_chunk(buf ^ 1);
+      FSV_SCHED_FENCE();
+      mma_group(fa[1], fb[1]);
       __syncthreads();
       buf ^= 1;
     }
@@ -505,7 +494,7 @@ __device__ __forceinline__ void fsv_xcd_range(int& kt, int& nt, int& z) {
 
 // V4 kernel: both operands are pixel-major in HBM and in LDS ([32 pixels][columns], ds_write_b128 / ds_read_b32, conflict
 // free); two LDS buffers, one barrier per 32-pixel chunk, absent rows / columns are loaded at FSV_BUF_OOB.
-template <int BMK, int BN, int WM, int WN>
+template <int BMK, int BN, int WM, int WN, bool COUT4>
 __global__ __launch_bounds__(64 * WM * WN) void fsv_conv_wgrad_kernel(WgradP p) {
   constexpr int BK = FSV_BK;   // pixels per chunk
   constexpr int NT = 64 * WM * WN;
@@ -542,7 +531,6 @@ __global__ __launch_bounds__(64 * WM * WN) void fsv_conv_wgrad_kernel(WgradP p) 
   }
   const int bq = tid % QB, bpr0 = tid / QB;
   const int bcol = bn0 + bq * 4;
-  const bool cout4 = (p.Cout & 3) == 0;
   const long long dout_base = (long long)zs * (p.per_sample ? p.Mz : 0);
   const fsv_buf abuf = fsv_make_buf(p.in, (long long)p.N * p.H * p.W * p.Cin * 4);
   const fsv_buf bbuf = fsv_make_buf(p.dout + dout_base * p.Cout, (long long)p.Mz * p.Cout * 4);
@@ -552,31 +540,58 @@ __global__ __launch_bounds__(64 * WM * WN) void fsv_conv_wgrad_kernel(WgradP p) 
   const int c_end = (c_begin + cps < p.pchunks) ? (c_begin + cps) : p.pchunks;
 
   float4 areg[NPA], breg[NPB];
-  auto load_chunk = [&](int pc) {
+  unsigned aoff[NPA], boff[NPB];
+  // Branch-free, incremental addressing (see the forward kernel): every A row of this thread walks the output pixels in
+  // steps of 32; (n, oy, ox) are advanced with 32 / OW and 32 % OW and one conditional subtract per level - the host
+  // sends geometries with 32 / OW + 1 > OH to the scalar twin, where a step could cross two images.  Offsets are
+  // computed one chunk ahead of their loads.
+  int a_m[NPA], a_n[NPA], a_oy[NPA], a_ox[NPA];
+#pragma unroll
+  for (int i = 0; i < NPA; ++i) {
+    const int m = c_begin * BK + apr0 + i * RPA;
+    int n, rem;
+    if (p.per_sample) { n = zs; rem = m; } else { n = m / ohw; rem = m - n * ohw; }
+    a_m[i] = m; a_n[i] = n; a_oy[i] = rem / p.OW; a_ox[i] = rem - a_oy[i] * p.OW;
+  }
+  const int qw = BK / p.OW, rw = BK - qw * p.OW;
+  int b_m = c_begin * BK + bpr0;
+  auto calc_offsets = [&]() {
 #pragma unroll
     for (int i = 0; i < NPA; ++i) {
-      int m = pc * BK + apr0 + i * RPA;
-      bool ok = kok && m < p.Mz;
-      int mm = ok ? m : 0;
-      int n, rem;
-      if (p.per_sample) { n = zs; rem = mm; } else { n = mm / ohw; rem = mm - n * ohw; }
-      int oy = rem / p.OW, ox = rem - oy * p.OW;
-      int iy = oy * p.sy + ty, ix = ox * p.sx + tx;
-      ok = ok && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-      areg[i] = fsv_buf_load4(abuf, ok ? (unsigned)((((n * p.H + iy) * p.W + ix) * p.Cin + ci) * 4) : FSV_BUF_OOB);
+      const int iy = a_oy[i] * p.sy + ty, ix = a_ox[i] * p.sx + tx;
+      const bool ok = kok & (a_m[i] < p.Mz) & ((unsigned)iy < (unsigned)p.H) & ((unsigned)ix < (unsigned)p.W);
+      aoff[i] = ok ? (unsigned)((((a_n[i] * p.H + iy) * p.W + ix) * p.Cin + ci) * 4) : FSV_BUF_OOB;
+      a_m[i] += BK;
+      int ox = a_ox[i] + rw, oy = a_oy[i] + qw;
+      const bool cx = ox >= p.OW;
+      ox = cx ? ox - p.OW : ox;
+      oy = cx ? oy + 1 : oy;
+      const bool cy = oy >= p.OH;
+      a_oy[i] = cy ? oy - p.OH : oy;
+      a_n[i] = cy ? a_n[i] + 1 : a_n[i];
+      a_ox[i] = ox;
     }
 #pragma unroll
     for (int i = 0; i < NPB; ++i) {
-      int m = pc * BK + bpr0 + i * RPB;
-      bool rok = m < p.Mz;
-      if (cout4) {
-        breg[i] = fsv_buf_load4(bbuf, (rok && bcol < p.Cout) ? (unsigned)((m * p.Cout + bcol) * 4) : FSV_BUF_OOB);
-      } else {
-        const unsigned e = (unsigned)((m * p.Cout + bcol) * 4);
-        breg[i] = make_float4(fsv_buf_load1(bbuf, (rok && bcol + 0 < p.Cout) ? e : FSV_BUF_OOB),
-                              fsv_buf_load1(bbuf, (rok && bcol + 1 < p.Cout) ? e + 4 : FSV_BUF_OOB),
-                              fsv_buf_load1(bbuf, (rok && bcol + 2 < p.Cout) ? e + 8 : FSV_BUF_OOB),
-                              fsv_buf_load1(bbuf, (rok && bcol + 3 < p.Cout) ? e + 12 : FSV_BUF_OOB));
+      const int m = b_m + i * RPB;
+      boff[i] = ((m < p.Mz) & (bcol < p.Cout)) ? (unsigned)((m * p.Cout + bcol) * 4) : FSV_BUF_OOB;
+    }
+    b_m += BK;
+  };
+  auto issue_loads = [&]() {
+#pragma unroll
+    for (int i = 0; i < NPA; ++i) areg[i] = fsv_buf_load4(abuf, aoff[i]);
+#pragma unroll
+    for (int i = 0; i < NPB; ++i) {
+      if constexpr (COUT4) {
+        breg[i] = fsv_buf_load4(bbuf, boff[i]);
+      } else {       // Cout = 1 ... 3 (image / flow / mask heads): element loads, each column range-checked on its own
+        const unsigned e = boff[i];
+        const bool rok = e != FSV_BUF_OOB;
+        breg[i] = make_float4(fsv_buf_load1(bbuf, e),
+                              fsv_buf_load1(bbuf, (rok & (bcol + 1 < p.Cout)) ? e + 4 : FSV_BUF_OOB),
+                              fsv_buf_load1(bbuf, (rok & (bcol + 2 < p.Cout)) ? e + 8 : FSV_BUF_OOB),
+                              fsv_buf_load1(bbuf, (rok & (bcol + 3 < p.Cout)) ? e + 12 : FSV_BUF_OOB));
       }
     }
   };
@@ -600,36 +615,58 @@ __global__ __launch_bounds__(64 * WM * WN) void fsv_conv_wgrad_kernel(WgradP p) 
   const int lrow = lane & 31, lk = lane >> 5;
   const int a_off = lk * BMK + wm * (TM * 32) + lrow;
   const int b_off = lk * BN + wn * (TN * 32) + lrow;
-  auto mma_steps = [&](const float* a_src, const float* b_src, int kk0, int kk1) {
+  // fragments of four k steps (8 pixels); read one group ahead of its MFMAs, pinned by scheduling fences (see the forward kernel)
+  auto read_group = [&](const float* a_src, const float* b_src, int g, float (&fa)[4][TM], float (&fb)[4][TN]) {
 #pragma unroll
-    for (int kk = kk0; kk < kk1; ++kk) {
-      float a[TM], b[TN];
+    for (int s = 0; s < 4; ++s) {
 #pragma unroll
-      for (int i = 0; i < TM; ++i) a[i] = a_src[a_off + kk * 2 * BMK + i * 32];
+      for (int i = 0; i < TM; ++i) fa[s][i] = a_src[a_off + (4 * g + s) * 2 * BMK + i * 32];
 #pragma unroll
-      for (int j = 0; j < TN; ++j) b[j] = b_src[b_off + kk * 2 * BN + j * 32];
+      for (int j = 0; j < TN; ++j) fb[s][j] = b_src[b_off + (4 * g + s) * 2 * BN + j * 32];
+    }
+  };
+  auto mma_group = [&](const float (&fa)[4][TM], const float (&fb)[4][TN]) {
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
-    }
+        for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[s][i], fb[s][j], acc[i][j], 0, 0, 0);
   };
   if (c_begin < c_end) {
-    load_chunk(c_begin);
+    calc_offsets();
+    issue_loads();
+    calc_offsets();
     store_chunk(0);
     __syncthreads();
     int buf = 0;
 #pragma unroll 1
     for (int pc = c_begin; pc < c_end; ++pc) {
-      const int pnext = (pc + 1 < c_end) ? pc + 1 : pc;
-      load_chunk(pnext);
-      FSV_SCHED_FENCE();
+      // the next chunk's loads land in registers under the first three quarters of this chunk's MFMAs and are stored into
+      // the other LDS buffer: one barrier per chunk.  Chunks past c_end are past the descriptors (zeros) or another
+      // split's pixels; the copy stored by the last iteration is never used.
+      issue_loads();
       const float* a_src = As + buf * A_ST;
       const float* b_src = Bs + buf * B_ST;
-      mma_steps(a_src, b_src, 0, 12);
+      float fa[2][4][TM], fb[2][4][TN];
+      read_group(a_src, b_src, 0, fa[0], fb[0]);
+      FSV_SCHED_FENCE();
+      calc_offsets();
+      read_group(a_src, b_src, 1, fa[1], fb[1]);
+      FSV_SCHED_FENCE();
+      mma_group(fa[0], fb[0]);
+      FSV_SCHED_FENCE();
+      read_group(a_src, b_src, 2, fa[0], fb[0]);
+      FSV_SCHED_FENCE();
+      mma_group(fa[1], fb[1]);
+      FSV_SCHED_FENCE();
+      read_group(a_src, b_src, 3, fa[1], fb[1]);
+      FSV_SCHED_FENCE();
+      mma_group(fa[0], fb[0]);
       FSV_SCHED_FENCE();
       store_chunk(buf ^ 1);
-      mma_steps(a_src, b_src, 12, 16);
+      FSV_SCHED_FENCE();
+      mma_group(fa[1], fb[1]);
       __syncthreads();
       buf ^= 1;
     }
@@ -919,48 +956,36 @@ static inline void fsv_pack_taps(const int* ty, const int* tx, int n, unsigned l
   }
 }
 
-// tile ids: 0 = 128x128, 1 = 128x64, 2 = 128x32, 4 = 64x64, 9 = 64x128 (BM pixels x BN output channels).  Round-2 A/B ids,
-// force_tile only: 10 / 11 / 12 = 128x128 / 128x64 / 64x128 as 8-wave workgroups (two waves per SIMD cover each other's LDS
-// latency); +20 = the same tile without the explicit fragment pipeline (PIPE = 0).
+// tile ids: 0 = 128x128, 1 = 128x64, 2 = 128x32, 4 = 64x64, 9 = 64x128 (BM pixels x BN output channels).  0 / 1 / 9 are
+// 8-wave workgroups (two waves per SIMD cover each other's LDS latency and barrier: +8 ... +14 % in-box over the same
+// tiles with 4 waves, profiles/r02_tile_ab.jsonl), 2 / 4 are 4-wave workgroups.
 static inline int fsv_tile_dims(int tile, int& bm, int& bn) {
-  switch (tile % 20) {
-    case 0: case 10: bm = 128; bn = 128; return 0;
-    case 1: case 11: bm = 128; bn = 64; return 0;
+  switch (tile) {
+    case 0: bm = 128; bn = 128; return 0;
+    case 1: bm = 128; bn = 64; return 0;
     case 2: bm = 128; bn = 32; return 0;
     case 4: bm = 64; bn = 64; return 0;
-    case 9: case 12: bm = 64; bn = 128; return 0;
+    case 9: bm = 64; bn = 128; return 0;
     default: return -1;
   }
 }
 
 static int fsv_launch_conv(const ConvP& p, bool vec4, int nz, hipStream_t stream, int tile) {
   int bm, bn;
-  if (tile < 0 || tile >= 40 || fsv_tile_dims(tile, bm, bn)) return FSV_ERR_BAD_ARG;
+  if (fsv_tile_dims(tile, bm, bn)) return FSV_ERR_BAD_ARG;
   dim3 g(fsv_cdiv(p.Mz, bm), fsv_cdiv(p.Cout, bn), nz);
   if (vec4) {
     switch (tile) {
-      case 0: FSV_LAUNCH((fsv_conv_igemm_kernel<128, 128, 2, 2, 1>), g, dim3(256), stream, p); break;
-      case 1: FSV_LAUNCH((fsv_conv_igemm_kernel<128, 64, 2, 2, 1>), g, dim3(256), stream, p); break;
-      case 2: FSV_LAUNCH((fsv_conv_igemm_kernel<128, 32, 4, 1, 1>), g, dim3(256), stream, p); break;
-      case 4: FSV_LAUNCH((fsv_conv_igemm_kernel<64, 64, 2, 2, 1>), g, dim3(256), stream, p); break;
-      case 9: FSV_LAUNCH((fsv_conv_igemm_kernel<64, 128, 2, 2, 1>), g, dim3(256), stream, p); break;
-      case 10: FSV_LAUNCH((fsv_conv_igemm_kernel<128, 128, 2, 4, 1>), g, dim3(512), stream, p); break;
-      case 11: FSV_LAUNCH((fsv_conv_igemm_kernel<128, 64, 4, 2, 1>), g, dim3(512), stream, p); break;
-      case 12: FSV_LAUNCH((fsv_conv_igemm_kernel<64, 128, 2, 4, 1>), g, dim3(512), stream, p); break;
-      case 20: FSV_LAUNCH((fsv_conv_igemm_kernel<128, 128, 2, 2, 0>), g, dim3(256), stream, p); break;
-      case 21: FSV_LAUNCH((fsv_conv_igemm_kernel<128, 64, 2, 2, 0>), g, dim3(256), stream, p); break;
-      case 22: FSV_LAUNCH((fsv_conv_igemm_kernel<128, 32, 4, 1, 0>), g, dim3(256), stream, p); break;
-      case 24: FSV_LAUNCH((fsv_conv_igemm_kernel<64, 64, 2, 2, 0>), g, dim3(256), stream, p); break;
-      case 29: FSV_LAUNCH((fsv_conv_igemm_kernel<64, 128, 2, 2, 0>), g, dim3(256), stream, p); break;
-      case 30: FSV_LAUNCH((fsv_conv_igemm_kernel<128, 128, 2, 4, 0>), g, dim3(512), stream, p); break;
-      case 31: FSV_LAUNCH((fsv_conv_igemm_kernel<128, 64, 4, 2, 0>), g, dim3(512), stream, p); break;
-      case 32: FSV_LAUNCH((fsv_conv_igemm_kernel<64, 128, 2, 4, 0>), g, dim3(512), stream, p); break;
-      default: return FSV_ERR_BAD_ARG;
+      case 0: FSV_LAUNCH((fsv_conv_igemm_kernel<128, 128, 2, 4>), g, dim3(512), stream, p); break;
+      case 1: FSV_LAUNCH((fsv_conv_igemm_kernel<128, 64, 4, 2>), g, dim3(512), stream, p); break;
+      case 2: FSV_LAUNCH((fsv_conv_igemm_kernel<128, 32, 4, 1>), g, dim3(256), stream, p); break;
+      case 4: FSV_LAUNCH((fsv_conv_igemm_kernel<64, 64, 2, 2>), g, dim3(256), stream, p); break;
+      default: FSV_LAUNCH((fsv_conv_igemm_kernel<64, 128, 2, 4>), g, dim3(512), stream, p); break;
     }
   } else {
-    switch (tile % 20) {
-      case 0: case 10: FSV_LAUNCH((fsv_conv_igemm_v1_kernel<128, 128, 2, 2>), g, dim3(256), stream, p); break;
-      case 1: case 11: FSV_LAUNCH((fsv_conv_igemm_v1_kernel<128, 64, 2, 2>), g, dim3(256), stream, p); break;
+    switch (tile) {
+      case 0: FSV_LAUNCH((fsv_conv_igemm_v1_kernel<128, 128, 2, 2>), g, dim3(256), stream, p); break;
+      case 1: FSV_LAUNCH((fsv_conv_igemm_v1_kernel<128, 64, 2, 2>), g, dim3(256), stream, p); break;
       case 2: FSV_LAUNCH((fsv_conv_igemm_v1_kernel<128, 32, 4, 1>), g, dim3(256), stream, p); break;
       case 4: FSV_LAUNCH((fsv_conv_igemm_v1_kernel<64, 64, 2, 2>), g, dim3(256), stream, p); break;
       default: FSV_LAUNCH((fsv_conv_igemm_v1_kernel<64, 128, 2, 2>), g, dim3(256), stream, p); break;
@@ -992,68 +1017,31 @@ static inline long long fsv_tune(int which) {
 extern "C" int fsv_conv_plan(int Mz, int Cout, int nchunks, int nsamp, int force_tile, int force_split,
                              int* tile_out, int* nsplit_out) {
   int tile = force_tile;
-  static int plan_v = -1;
-  if (plan_v < 0) { const char* e = getenv("FSV_PLAN"); plan_v = e ? atoi(e) : 2; }
   const long long b0 = (long long)fsv_cdiv(Mz, 128) * fsv_cdiv(Cout, 128) * nsamp;      // 128x128 tiles
   const long long b1 = (long long)fsv_cdiv(Mz, 128) * fsv_cdiv(Cout, 64) * nsamp;       // 128x64
-  const long long b4 = (long long)fsv_cdiv(Mz, 64) * fsv_cdiv(Cout, 64) * nsamp;        // 64x64
   const long long b9 = (long long)fsv_cdiv(Mz, 64) * fsv_cdiv(Cout, 128) * nsamp;       // 64x128
-  bool small_tile_regime = false, mid_tile_regime = false;
   if (tile < 0) {
-    if (plan_v == 0) {
-      if (Cout <= 32) tile = 2;
-      else if (Cout <= 64) tile = 1;
-      else tile = ((long long)Mz * Cout <= 64 * 64 * 64) ? 4 : 0;
-    } else {
-      // in-box A/B on the step's layer shapes (tools/tile_ab.py, profiles/r01_tile_ab.jsonl): with fewer than two
-      // 128-row tiles per CU the 64x64 tile without split-K beats the big tile with split-K (no atomics, no zero-fill,
-      // no separate bias pass) unless K is long enough (>= 4096) to amortise them
-      if (Cout <= 32) tile = 2;
-      else if (Cout <= 64) tile = (b1 < 512) ? 4 : 1;
-      else if (plan_v == 1) {
-        if (b0 >= 512) tile = 0;
-        else if (nchunks >= 128) tile = (b0 < 64) ? 1 : 0;
-        else { tile = 4; }
-      } else {
-        // plan 2 adds the 64x128 tile (profiles/r01_tile_ab.jsonl, second table): half the A-tile re-reads of 64x64
-        if (b0 > 1024) tile = 0;
-        else if (nchunks >= 128) tile = (b0 < 64) ? 1 : ((b0 <= 128 && nchunks >= 256) ? 0 : 9);
-        else if (b0 >= 512) tile = (Cout <= 128) ? 9 : 0;
-        else if (b9 >= 512) tile = 9;
-        else if (b9 >= 256 && nchunks >= 72) tile = 9;
-        else tile = 4;
-      }
-      small_tile_regime = (tile == 4);
-      mid_tile_regime = (tile == 9);
-    }
+    // in-box A/B on the step's layer shapes (tools/tile_ab.py, profiles/r02_tile_ab.jsonl): the largest tile that still
+    // gives every CU a workgroup wins (128x128 and 64x128 as 8-wave workgroups: 112-124 TFLOP/s at >= 256 workgroups
+    // against 50-60 at 128); below that the 64x64 tile, and split-K only when even it leaves CUs idle
+    if (Cout <= 32) tile = 2;
+    else if (Cout <= 64) tile = (b1 >= 256) ? 1 : 4;
+    else if (b0 >= 256) tile = 0;
+    else if (b9 >= 256) tile = 9;
+    else tile = 4;
   }
   int bm, bn;
   if (fsv_tile_dims(tile, bm, bn)) return -1;
-  // split-K for launches that would leave most of the 256 CUs idle
+  // split-K for launches that would leave most of the 256 CUs idle: ~512 workgroups, at least 16 chunks (512 K-elements)
+  // per split (zero fill + atomics + a finishing pass are the price)
   long long blocks = (long long)fsv_cdiv(Mz, bm) * fsv_cdiv(Cout, bn) * nsamp;
   int nsplit = 1;
   if (force_split > 0) nsplit = force_split;
-  else if (small_tile_regime) {
-    // 64x64 tiles: split only when even they leave CUs idle, and keep >= 16 chunks (512 K-elements) per split
-    if (blocks < 512 && nchunks >= 32) {
-      nsplit = (int)((1024 + blocks - 1) / blocks);
-      if (nsplit > nchunks / 16) nsplit = nchunks / 16;
-      if (nsplit < 1) nsplit = 1;
-    }
-  } else if (mid_tile_regime) {
-    // 64x128 tiles: ~1024 workgroups, at least 18 chunks (576 K-elements) per split
-    if (blocks < 768 && nchunks >= 36) {
-      nsplit = (int)((1024 + blocks - 1) / blocks);
-      if (nsplit > nchunks / 18) nsplit = nchunks / 18;
-      if (nsplit < 1) nsplit = 1;
-    }
-  } else if (blocks < fsv_tune(0) && nchunks >= 8) {
-    // aim at a few workgroups per CU; thresholds are tunables (FSV_SPLIT_BELOW / FSV_SPLIT_TARGET) for A/B runs
-    nsplit = (int)((fsv_tune(1) + blocks - 1) / blocks);
-    if (nsplit > nchunks / 4) nsplit = nchunks / 4;
+  else if (blocks < 256 && nchunks >= 32) {
+    nsplit = (int)((512 + blocks - 1) / blocks);
+    if (nsplit > nchunks / 16) nsplit = nchunks / 16;
     if (nsplit < 1) nsplit = 1;
   }
-  (void)b4;
   if (nsplit > nchunks) nsplit = nchunks;
   *tile_out = tile; *nsplit_out = nsplit;
   return 0;
@@ -1155,15 +1143,14 @@ int fsv_conv_wgrad(const float* in, const float* dout, float* dwt,
   if (force_tile == 1 && vec4_ok(Cin) && Cout > 32) { bmk = 64; bn = 64; }
   else if (force_tile == 2 && vec4_ok(Cin) && Cout > 32) { bmk = 128; bn = 64; }
   else if (force_tile == 3 && vec4_ok(Cin) && Cout > 64) { bmk = 64; bn = 128; }
+  else if (force_tile == 4 && vec4_ok(Cin) && Cout > 64) { bmk = 128; bn = 128; }
   long long target = fsv_tune(2);
   static int wplan_v = -1;
   if (wplan_v < 0) { const char* e = getenv("FSV_WGRAD_PLAN"); wplan_v = e ? atoi(e) : 1; }
   if (force_tile == 0 && wplan_v == 1 && vec4_ok(Cin) && Cout >= 64 && p.K > 64) {
-    // in-box A/B on the step's layer shapes (tools/wgrad_ab.py, profiles/r01_wgrad_ab.jsonl): 64-row tiles with ~2048
-    // (64x64) / ~1024 (64x128) workgroups beat 128-row tiles at ~1024 by 11 ... 23 % - four times fewer atomic adds per
-    // FLOP than the same workgroup count of split 128x128 tiles, and every CU gets several workgroups
-    if (Cout >= 128 && p.K >= 2304 && p.pchunks >= 64) { bmk = 64; bn = 128; target = 1024; }
-    else { bmk = 64; bn = 64; target = 2048; }
+    // in-box A/B on the step's layer shapes (tools/wgrad_ab.py, profiles/r02_wgrad_ab.jsonl): the 64x64 tile with ~2048
+    // workgroups is best or within 2 % of the best on every shape (83 ... 111 TFLOP/s); 128-row tiles lose 10 ... 25 %
+    bmk = 64; bn = 64; target = 2048;
   }
   long long blocks = (long long)fsv_cdiv(p.K, bmk) * fsv_cdiv(Cout, bn) * nsamp;
   int nsplit = 1;
@@ -1181,16 +1168,18 @@ int fsv_conv_wgrad(const float* in, const float* dout, float* dwt,
   if (nsplit > 1 && !prezeroed)
     (void)hipMemsetAsync(dwt, 0, (size_t)((per_sample ? (long long)N * w_bstride : (long long)Kpad * ldw)) * sizeof(float), stream);
   dim3 block(256);
-  const bool vec4 = (Cin % 4 == 0);
+  // the V4 kernel advances (n, oy, ox) by 32 pixels with one conditional subtract per level: needs 32 / OW + 1 <= OH
+  const bool vec4 = (Cin % 4 == 0) && (FSV_BK / OW + 1 <= OH) && ((Cout & 3) == 0 || bn == 32);
   dim3 g(fsv_cdiv(p.K, bmk), fsv_cdiv(Cout, bn), nsamp * nsplit);
   if (vec4) {
-    if (bn == 128 && bmk == 32) FSV_LAUNCH((fsv_conv_wgrad_kernel<32, 128, 1, 4>), g, block, stream, p);
-    else if (bn == 128 && bmk == 64) FSV_LAUNCH((fsv_conv_wgrad_kernel<64, 128, 2, 2>), g, block, stream, p);
-    else if (bn == 64 && bmk == 32) FSV_LAUNCH((fsv_conv_wgrad_kernel<32, 64, 1, 2>), g, dim3(128), stream, p);
-    else if (bn == 64 && bmk == 64) FSV_LAUNCH((fsv_conv_wgrad_kernel<64, 64, 2, 2>), g, block, stream, p);
-    else if (bn == 128) FSV_LAUNCH((fsv_conv_wgrad_kernel<128, 128, 2, 2>), g, block, stream, p);
-    else if (bn == 64) FSV_LAUNCH((fsv_conv_wgrad_kernel<128, 64, 2, 2>), g, block, stream, p);
-    else FSV_LAUNCH((fsv_conv_wgrad_kernel<128, 32, 4, 1>), g, block, stream, p);
+    if (bn == 128 && bmk == 32) FSV_LAUNCH((fsv_conv_wgrad_kernel<32, 128, 1, 4, true>), g, block, stream, p);
+    else if (bn == 128 && bmk == 64) FSV_LAUNCH((fsv_conv_wgrad_kernel<64, 128, 2, 2, true>), g, block, stream, p);
+    else if (bn == 64 && bmk == 32) FSV_LAUNCH((fsv_conv_wgrad_kernel<32, 64, 1, 2, true>), g, dim3(128), stream, p);
+    else if (bn == 64 && bmk == 64) FSV_LAUNCH((fsv_conv_wgrad_kernel<64, 64, 2, 2, true>), g, block, stream, p);
+    else if (bn == 128) FSV_LAUNCH((fsv_conv_wgrad_kernel<128, 128, 2, 2, true>), g, block, stream, p);
+    else if (bn == 64) FSV_LAUNCH((fsv_conv_wgrad_kernel<128, 64, 2, 2, true>), g, block, stream, p);
+    else if ((Cout & 3) == 0) FSV_LAUNCH((fsv_conv_wgrad_kernel<128, 32, 4, 1, true>), g, block, stream, p);
+    else FSV_LAUNCH((fsv_conv_wgrad_kernel<128, 32, 4, 1, false>), g, block, stream, p);
   } else {
     if (bn == 128) FSV_LAUNCH((fsv_conv_wgrad_v1_kernel<128, 128, 2, 2>), g, block, stream, p);
     else if (bn == 64) FSV_LAUNCH((fsv_conv_wgrad_v1_kernel<128, 64, 2, 2>), g, block, stream, p);

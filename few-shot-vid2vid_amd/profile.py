@@ -17,8 +17,7 @@ _records = []          # (label, flops, ev0, ev1)
 FP32_MFMA_PEAK = 157.3e12
 F16_MFMA_PEAK = 2.5e15        # dense f16 / bf16 matrix peak (MI355X_MICROARCH.md; the 2:1-sparse figure is not used)
 
-TILE_NAMES = {0: '128x128', 1: '128x64', 2: '128x32', 3: '256x32', 4: '64x64', 5: '256x128', 6: '128x256', 7: '256x256', 8: '256x64',
-              9: '64x128', 10: '64x64/1w', 11: '64x128/2w', 12: '128x64/2w', 13: '64x64/db', 14: '64x128/db', 15: '128x64/db', 16: '64x64/pf2', 17: '64x128/pf2', 18: '128x64/pf2', 19: '64x64/xcd', 20: '64x128/xcd', 21: '128x64/xcd'}
+TILE_NAMES = {0: '128x128', 1: '128x64', 2: '128x32', 4: '64x64', 9: '64x128'}
 
 
 def enable(detail=False):

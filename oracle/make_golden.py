@@ -53,6 +53,10 @@ CONFIGS['pose_refine_face'] = CONFIGS['pose_combine'].replace('--fineSize 64 --l
 # street: integer class maps, one-hot encoded by encode_label (input_process.py:25-45); default aspect_ratio 2 -> 32 x 64
 CONFIGS['street'] = ('--dataset_mode fewshot_street --label_nc 7 --fineSize 64 --loadSize 64 --adaptive_spade --no_flow_gt '
                      '--no_vgg_loss --gpu_ids -1 --ngf 8 --ndf 8 --batchSize 2')
+# BASELINE configs[0] / SURVEY 8(d) C1 at FULL width (ngf = ndf = 32 defaults), 128 x 128, batch 1: pins the kernels' full-width
+# tile plans (128 ... 1024 channels) to the reference itself, not only to the oracle
+CONFIGS['face_fullwidth'] = ('--dataset_mode fewshot_face --fineSize 128 --loadSize 128 --adaptive_spade --no_flow_gt --no_vgg_loss '
+                             '--gpu_ids -1 --batchSize 1')
 LAYOUT_CONFIGS = {
     'C3_pose_512': '--dataset_mode fewshot_pose --aspect_ratio 1 --fineSize 512 --loadSize 512 --adaptive_spade --warp_ref '
                    '--spade_combine --remove_face_labels --no_flow_gt --no_vgg_loss --gpu_ids -1',
@@ -89,13 +93,14 @@ def step(name, flags):
             g['lr'] = 0.0
     nl = opt.label_nc if opt.label_nc != 0 else opt.input_nc
     h, w = int(opt.fineSize / opt.aspect_ratio), opt.fineSize
+    b = opt.batchSize
     if 'street' in opt.dataset_mode:
-        tl, ti, rl, ri = mc.synth_street_inputs(2, h, w, 4242, opt.label_nc)
+        tl, ti, rl, ri = mc.synth_street_inputs(b, h, w, 4242, opt.label_nc)
     else:
-        tl, ti, rl, ri = mc.with_n_shot(mc.synth_pose_inputs(2, h, w, 4242, nl), opt.n_shot, 2, h, w, 4242, nl)
+        tl, ti, rl, ri = mc.with_n_shot(mc.synth_pose_inputs(b, h, w, 4242, nl), opt.n_shot, b, h, w, 4242, nl)
     flow_gt, conf_gt = [None, None], [None, None]
     if name.endswith('_flowgt'):
-        flow_gt[0], conf_gt[0] = mc.synth_flow_gt(2, h, w, 4247)
+        flow_gt[0], conf_gt[0] = mc.synth_flow_gt(b, h, w, 4247)
     data = [tl, ti, flow_gt, conf_gt, rl, ri, None, None, None]
     d_losses = model(data, mode='discriminator')
     d_losses = loss_backward(opt, d_losses, model.optimizer_D, 1)
@@ -111,7 +116,7 @@ def step(name, flags):
 
     def t(x):
         return None if x is None else x.detach().clone()
-    torch.save(dict(flags=flags, seed=4242, batch=2, size=w, hw=(h, w),
+    torch.save(dict(flags=flags, seed=4242, batch=b, size=w, hw=(h, w),
                     d_losses=[float(x) for x in d_losses], g_losses=[float(x) for x in g_losses],
                     loss_names=model.lossCollector.loss_names,
                     fake=t(fake), raw=t(raw), warp=[t(w) for w in warped], flow=[t(f) for f in flow],

@@ -16,30 +16,11 @@ for p in (ROOT, os.path.join(ROOT, 'tests')):
 
 from oracle import fsv_oracle as O  # noqa: E402
 from op_checks import assert_close  # noqa: E402
-
-
-def make_opt(**kw):
-    """The reference's option namespace (options/base_options.py:21-132, train_options.py) with its defaults."""
-    d = dict(
-        ngf=32, ndf=32, nff=32, n_downsample_G=5, n_downsample_F=3, n_blocks_F=6, flow_multiplier=20,
-        norm_G='spectralspadesyncbatch', norm_F='spectralsyncbatch', norm_D='spectralinstance',
-        conv_ks=3, embed_ks=1, spade_ks=1, netS='encoderdecoder', sc_arch='unet', use_label_ref='mul',
-        res_for_ref=False, adaptive_conv=False, adaptive_spade=True, no_adaptive_embed=False, n_adaptive_layers=4,
-        n_fc_layers=2, n_frames_G=2, n_frames_per_gpu=1, n_frames_D=2, no_flow_gt=True, spade_combine=False,
-        n_sc_layers=2, add_raw_output_loss=False, sep_flow_prev=False, no_sep_warp_embed=False, n_shot=1,
-        n_downsample_A=2, warp_ref=False, which_model_netD='multiscale', netD_subarch='n_layers', num_D=1,
-        n_layers_D=4, gan_mode='hinge', add_face_D=False, lambda_kld=0.0, lambda_feat=10.0, lambda_temp=0.0,
-        lambda_flow=10.0, lambda_mask=10.0, lambda_vgg=10.0, lambda_face=10.0, no_ganFeat_loss=False,
-        no_vgg_loss=True, no_TTUR=False, lr=0.0004, beta1=0.5, beta2=0.999, isTrain=True, finetune=False,
-        dataset_mode='fewshot_pose', label_nc=0, input_nc=6, output_nc=3, aspect_ratio=1.0, fineSize=64, loadSize=64,
-        pose_type='both', remove_face_labels=False, refine_face=False, basic_point_only=False, batchSize=2,
-        gpu_ids=[0], distributed=False, amp='O0', niter_single=50,
-    )
-    for k, v in kw.items():
-        if k not in d:
-            raise KeyError(k)
-        d[k] = v
-    return argparse.Namespace(**d)
+import fsv2v_amd  # noqa: E402,F401
+_synth = import_module('few-shot-vid2vid_amd.synth')
+make_opt, synth_pose_inputs, synth_street_inputs, synth_flow_gt, with_n_shot = (
+    _synth.make_opt, _synth.synth_pose_inputs, _synth.synth_street_inputs, _synth.synth_flow_gt, _synth.with_n_shot)
+_oracle_iteration = O.iteration
 
 
 def fill_value(k, shape, scale=1.0):
@@ -76,52 +57,6 @@ def fill_state(module, scale=1.0):
     return new
 
 
-def synth_pose_inputs(b, h, w, seed=1234, n_label=6):
-    """SURVEY.md section 8(d) C3-style synthetic tensors: labels U(-1,1) with a DensePose part-id channel, images U(-1,1)."""
-    g = torch.Generator().manual_seed(seed)
-
-    def label():
-        l = torch.rand(b, 1, n_label, h, w, generator=g) * 2 - 1
-        if n_label >= 3:
-            part = torch.round(torch.rand(b, 1, h, w, generator=g) * 24) / 24 * 2 - 1
-            bg = torch.ones(b, 1, h, w, dtype=torch.bool)
-            bg[:, :, h // 8: h - h // 8, w // 6: w - w // 6] = False
-            part[bg] = -1.0
-            l[:, :, 2] = part
-        return l
-    def image():
-        # band-limited content (bilinearly up-sampled coarse noise) + a little pixel noise, in [-1, 1]
-        coarse = torch.rand(b, 3, max(h // 8, 2), max(w // 8, 2), generator=g) * 2 - 1
-        img = torch.nn.functional.interpolate(coarse, size=(h, w), mode='bilinear', align_corners=True)
-        img = (img + 0.05 * (torch.rand(b, 3, h, w, generator=g) * 2 - 1)).clamp(-1, 1)
-        return img.unsqueeze(1)
-    tgt_label, ref_label = label(), label()
-    tgt_image, ref_image = image(), image()
-    return tgt_label, tgt_image, ref_label, ref_image
-
-
-def with_n_shot(data, n_shot, b, h, w, seed, n_label):
-    """n_shot > 1: n_shot different reference (label, image) pairs per sample, [B, n_shot, C, H, W]"""
-    if n_shot <= 1:
-        return data
-    tl, ti, rl, ri = data
-    extra = [synth_pose_inputs(b, h, w, seed + 100 * k, n_label) for k in range(1, n_shot)]
-    rl = torch.cat([rl] + [e[2] for e in extra], dim=1)
-    ri = torch.cat([ri] + [e[3] for e in extra], dim=1)
-    return tl, ti, rl, ri
-
-
-def synth_street_inputs(b, h, w, seed=1234, n_classes=20):
-    """SURVEY.md section 8(d) C5-style tensors: integer class maps (as float, blocky regions) and images U(-1,1)."""
-    g = torch.Generator().manual_seed(seed)
-
-    def label():
-        coarse = torch.randint(0, n_classes, (b, 1, max(h // 8, 2), max(w // 8, 2)), generator=g).float()
-        return torch.nn.functional.interpolate(coarse, size=(h, w), mode='nearest').unsqueeze(1)
-    _, ti, _, ri = synth_pose_inputs(b, h, w, seed + 1, 1)
-    return label(), ti, label(), ri
-
-
 def _net():
     import fsv2v_amd  # noqa: F401
     return import_module('few-shot-vid2vid_amd.networks')
@@ -156,7 +91,7 @@ def _close_vs64(name, got, ref32, ref64, tol, floor=0.0):
     return err / scale
 
 
-def check_generator(device, opt, b=2, tol=1e-3, grads=True, seed=7):
+def check_generator(device, opt, b=2, tol=1e-3, grads=True, seed=7, ref64=True):
     net = _net()
     torch.manual_seed(0)
     G = net.define_G(opt)
@@ -171,7 +106,9 @@ def check_generator(device, opt, b=2, tol=1e-3, grads=True, seed=7):
     lw = (torch.randn(b, 3, h, w, generator=gen), torch.randn(b, 2, h, w, generator=gen) * 0.1,
           torch.randn(b, 1, h, w, generator=gen))
     sd32, o32 = _oracle_generator(sd0, cfg, label, ref_label, ref_image, torch.float32, lw if grads else None, opt.warp_ref)
-    sd64, o64 = _oracle_generator(sd0, cfg, label, ref_label, ref_image, torch.float64, lw if grads else None, opt.warp_ref)
+    # ref64=False (full-size cases): the fp32 oracle alone is the reference, no fp64 noise allowance
+    sd64, o64 = (_oracle_generator(sd0, cfg, label, ref_label, ref_image, torch.float64, lw if grads else None, opt.warp_ref)
+                 if ref64 else (sd32, o32))
     out = G(label.to(device), ref_label.to(device), ref_image.to(device), [None, None])
     _close_vs64('G img', out[0], o32[0], o64[0], tol)
     if opt.warp_ref:
@@ -306,51 +243,7 @@ def _vgg_weights(opt):
     return import_module('few-shot-vid2vid_amd.vgg').random_vgg19_weights()
 
 
-def _oracle_iteration(sdG0, sdD0, cfg, data, dtype, vgg_weights=None, sdDf0=None, flow_gt=None, conf_gt=None, sdGf0=None):
-    """One reference iteration (train.py:58-62) on the oracle: D step then G step; returns losses and gradients
-    (the face discriminator's gradients, when present, as a 6th entry)."""
-    tl, ti, rl, ri = [t.to(dtype) for t in data]
-
-    def leafify(sd0):
-        sd = {}
-        for k, v in sd0.items():
-            t = v.clone().to(dtype).detach() if v.is_floating_point() else v.clone()
-            if v.is_floating_point() and ('running' not in k) and not k.endswith(('_u', '_v')):
-                t.requires_grad_(True)
-            sd[k] = t
-        return sd
-    sdG, sdD = leafify(sdG0), leafify(sdD0)
-    sdDf = leafify(sdDf0) if sdDf0 is not None else None
-    sdGf = leafify(sdGf0) if sdGf0 is not None else None
-    d_losses = O.d_step_losses(sdG, sdD, cfg, tl, ti, rl, ri, sdDf=sdDf, sdGf=sdGf)
-    sum(l.mean() for l in d_losses).backward()
-    gD = {k: v.grad.clone() for k, v in sdD.items() if v.is_floating_point() and v.grad is not None}
-    gDf = {k: v.grad.clone() for k, v in (sdDf or {}).items() if v.is_floating_point() and v.grad is not None}
-    # (the optimiser step is checked separately in check_adam; gradients are what the comparison needs)
-    for v in list(sdG.values()) + list(sdD.values()) + list((sdDf or {}).values()):
-        if v.is_floating_point() and v.grad is not None:
-            v.grad = None
-    fg = [None if f is None else f.to(dtype) for f in (flow_gt or [None, None])]
-    cg = [None if f is None else f.to(dtype) for f in (conf_gt or [None, None])]
-    g_losses, gen = O.g_step_losses(sdG, sdD, cfg, tl, ti, rl, ri, vgg_weights=vgg_weights, sdDf=sdDf, flow_gt=fg,
-                                    conf_gt=cg, sdGf=sdGf)
-    sum(l.mean() for l in g_losses.values()).backward()
-    gG = {k: v.grad.clone() for k, v in sdG.items() if v.is_floating_point() and v.grad is not None}
-    if sdGf is not None:                         # the face generator's gradients ride along under a 'netGf.' prefix
-        gG.update({'netGf.' + k: v.grad.clone() for k, v in sdGf.items() if v.is_floating_point() and v.grad is not None})
-    return d_losses, gD, g_losses, gG, gen, gDf
-
-
-def synth_flow_gt(b, h, w, seed):
-    """stand-in for the FlowNet2 teacher's output: a smooth flow of a few pixels and a binary confidence map"""
-    g = torch.Generator().manual_seed(seed)
-    coarse = (torch.rand(b, 2, max(h // 8, 2), max(w // 8, 2), generator=g) - 0.5) * 6
-    flow = torch.nn.functional.interpolate(coarse, size=(h, w), mode='bilinear', align_corners=True).unsqueeze(1)
-    conf = (torch.rand(b, 1, 1, h, w, generator=g) < 0.7).float()
-    return flow, conf
-
-
-def check_train_step(device, opt, b=2, tol=1e-3, seed=21, grad_tol=2e-2, with_flow_gt=False):
+def check_train_step(device, opt, b=2, tol=1e-3, seed=21, grad_tol=2e-2, with_flow_gt=False, ref64=True):
     """Full D-step + G-step of the product model (flat Adam included) against the oracle.
 
     Losses and images are held to `tol` (1e-3 relative, BASELINE.json).  Parameter gradients of the *step* get the
@@ -376,7 +269,7 @@ def check_train_step(device, opt, b=2, tol=1e-3, seed=21, grad_tol=2e-2, with_fl
     if with_flow_gt:                       # teacher flow for the reference branch (train.py:44-48 without --no_flow_gt)
         flow_gt[0], conf_gt[0] = synth_flow_gt(b, h, w, seed + 5)
     r32 = _oracle_iteration(sdG0, sdD0, cfg, data, torch.float32, vw, sdDf0, flow_gt, conf_gt, sdGf0)
-    r64 = _oracle_iteration(sdG0, sdD0, cfg, data, torch.float64, vw, sdDf0, flow_gt, conf_gt, sdGf0)
+    r64 = _oracle_iteration(sdG0, sdD0, cfg, data, torch.float64, vw, sdDf0, flow_gt, conf_gt, sdGf0) if ref64 else r32
     tl, ti, rl, ri = [t.to(device) for t in data]
     dv = lambda lst: [None if t is None else t.to(device) for t in lst]
     data_list = [tl, ti, dv(flow_gt), dv(conf_gt), rl, ri, None, None, None]

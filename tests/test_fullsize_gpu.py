@@ -1,0 +1,54 @@
+"""Parity at the configurations that are benchmarked (BASELINE.json configs[0..2]): full network
+width (ngf = ndf = nff = 32), full resolution, the batch of the config - the product on the MI355X against the CPU oracle
+running on the GPU box's host cores, same seeded inputs and weights.
+
+  C1  fewshot_face 128x128  B=1  adaptive_spade          full D step + G step   (fp32 and fp64 oracle: noise-floor form)
+  C2  fewshot_face 256x256  B=4  adaptive_spade          generator forward + backward (the config is defined G-only)
+  C3  fewshot_pose 512x512  B=2  adaptive_spade + warp_ref + spade_combine   full D step + G step = the bench.py workload
+
+Tolerances: losses and images 1e-3 relative (BASELINE.json north_star); per-parameter gradients in the relative L2 norm
+(model_checks.compare_grads_l2), 1e-2 for the full step.  The oracle runs in fp32 and fp64 (C3: ~11 + ~22 GB of host memory):
+a bias gradient is a sum of 10^5 ... 10^6 terms with cancellation, where the fp32 CPU reference itself carries more rounding
+error than the kernels' fp64 block sums - the allowance is 4x the fp32 oracle's own distance to the fp64 run.  C3 also checks that the step really went through the tiles and split-K
+paths the launch plan is built from - the small-network tests never reach them.  The C1 step is additionally pinned to the
+reference itself by tests/golden/step_face_fullwidth.pt (tests/test_golden.py)."""
+import pytest
+import torch
+
+import model_checks as mc
+
+pytestmark = pytest.mark.gpu
+
+DEV = torch.device('cuda:0')
+
+
+def _conv():
+    import fsv2v_amd  # noqa: F401
+    from importlib import import_module
+    return import_module('few-shot-vid2vid_amd.conv')
+
+
+def test_c1_face_128_full_step(hip_lib):
+    opt = mc.make_opt(dataset_mode='fewshot_face', input_nc=1, fineSize=128, loadSize=128, batchSize=1)
+    worst = mc.check_train_step(DEV, opt, b=1, tol=1e-3, grad_tol=1e-2)
+    assert worst < 1e-2, worst
+
+
+def test_c2_face_256_b4_generator_fwd_bwd(hip_lib):
+    opt = mc.make_opt(dataset_mode='fewshot_face', input_nc=1, fineSize=256, loadSize=256, batchSize=4)
+    mc.check_generator(DEV, opt, b=4, tol=1e-3, grads=True)
+
+
+def test_c3_pose_512_b2_full_step_is_the_bench_workload(hip_lib):
+    conv = _conv()
+    opt = mc.make_opt(warp_ref=True, spade_combine=True, remove_face_labels=True, fineSize=512, loadSize=512, batchSize=2)
+    conv.start_plan_log()
+    try:
+        worst = mc.check_train_step(DEV, opt, b=2, tol=1e-3, grad_tol=1e-2)
+    finally:
+        log = conv.stop_plan_log()
+    assert worst < 1e-2, worst
+    tiles = {t for t, _, v4 in log if v4}
+    assert {0, 1, 2, 4, 9} <= tiles, sorted(tiles)                    # every tile of the plan is exercised by this step
+    assert any(s > 1 for _, s, _ in log), "no split-K launch in the 512x512 step"
+    assert any(not v4 for _, _, v4 in log), "no scalar-gather launch (3-channel / odd-channel inputs)"

@@ -15,7 +15,7 @@ from oracle import fsv_oracle as O
 
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
 CASES = ['pose_combine', 'face', 'pose_blend', 'pose_combine_vgg', 'street', 'pose_face_d', 'face_nshot2',
-         'pose_combine_flowgt', 'pose_refine_face']
+         'pose_combine_flowgt', 'pose_refine_face', 'face_fullwidth']      # face_fullwidth: ngf = ndf = 32, 128 x 128, B = 1 (C1)
 
 
 def _opt_from_flags(flags):
@@ -150,6 +150,24 @@ def test_product_state_dict_layout_equals_reference(cfg):
         assert not bad, bad[:10]
 
 
+def _check_grad_norms(net, ref_norms, tag, tol=1e-2):
+    """per-parameter gradient norms of the reference iteration (lr = 0, so .grad survives the optimiser step).  The band
+    is relative to max(norm, 1 % of the network's median norm): gradients that are mathematically zero (a conv bias in
+    front of a normalisation) are rounding noise on both sides."""
+    if not ref_norms:
+        return
+    med = sorted(ref_norms.values())[len(ref_norms) // 2]
+    seen = 0
+    for name, prm in net.named_parameters():
+        if name not in ref_norms:
+            continue
+        assert prm.grad is not None, (tag, name)
+        got, ref = float(prm.grad.norm()), ref_norms[name]
+        assert abs(got - ref) <= tol * max(ref, 1e-2 * med), (tag, name, got, ref)
+        seen += 1
+    assert seen == len(ref_norms), (tag, seen, len(ref_norms))
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize('case', CASES)
 def test_product_reproduces_reference_iteration_on_gpu(hip_lib, case):
@@ -172,8 +190,14 @@ def test_product_reproduces_reference_iteration_on_gpu(hip_lib, case):
     data = [tl, ti, [None if t is None else t.to(dev) for t in fgt], [None if t is None else t.to(dev) for t in cgt], rl,
             ri, None, None, None]
     d = M.loss_backward(opt, model(data, mode='discriminator'), opt_D, 1)
+    _check_grad_norms(model.netD, g['grad_norm_D'], 'netD')
+    if model.netDf is not None:
+        _check_grad_norms(model.netDf, g.get('grad_norm_Df', {}), 'netDf')
     gl, generated, _ = model(data, save_images=True, mode='generator')
     gl = M.loss_backward(opt, gl, opt_G, 0)
+    _check_grad_norms(model.netG, {k: v for k, v in g['grad_norm_G'].items() if not k.startswith('netGf.')}, 'netG')
+    if model.netGf is not None:
+        _check_grad_norms(model.netGf, {k[6:]: v for k, v in g['grad_norm_G'].items() if k.startswith('netGf.')}, 'netGf')
     for i in range(len(d)):
         assert abs(float(d[i]) - g['d_losses'][i]) <= 1e-3 * max(1.0, abs(g['d_losses'][i])), i
     for i, ref in enumerate(g['g_losses']):

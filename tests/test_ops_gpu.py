@@ -131,4 +131,4 @@ def test_losses_pack_pool(hip_lib):
 def test_every_gemm_tile(hip_lib):
     """all instantiated forward / weight-gradient tiles (incl. split-K atomics and per-sample weights) on ragged geometries"""
     import tile_checks as tc
-    tc.run_all(DEV)
+    tc.run_all(torch.device('cuda:0'))

@@ -10,7 +10,7 @@ import fsv2v_amd  # noqa
 from importlib import import_module
 conv = import_module('few-shot-vid2vid_amd.conv')
 dev = torch.device('cuda:0')
-cfgs = [(-1, 0), (0, 1), (0, 2), (0, 4), (1, 1), (1, 2), (1, 4), (4, 1), (4, 2), (4, 4), (9, 1), (9, 2), (9, 4), (9, 8)]
+cfgs = [(-1, 0)] + [(t_, s_) for t_ in (0, 1, 2, 4, 9) for s_ in (1, 2, 4)]
 shapes = [('M8192 N256 K2304', 2, 256, 64, 64, 256, 3), ('M32768 N128 K576', 2, 64, 128, 128, 128, 3),
           ('M32768 N128 K1152', 2, 128, 128, 128, 128, 3), ('M32768 N128 K2304', 2, 256, 128, 128, 128, 3),
           ('M2048 N512 K9216', 2, 1024, 32, 32, 512, 3), ('M2048 N512 K2304', 2, 256, 32, 32, 512, 3),
@@ -32,7 +32,7 @@ for name, n, cin, h, w, cout, k in shapes:
     flops = 2.0 * n * h * w * cout * cin * k * k
     graphs = {}
     for c in cfgs:
-        if c[0] in (0, 9) and cout < 128 or c[0] == 1 and cout < 64:
+        if c[0] in (0, 9) and cout < 128 or c[0] == 1 and cout < 64 or c[0] == 2 and cout > 32:
             continue
         f = lambda: conv.conv_forward(x, wf, ldw, cout, g, bias=b, act=conv.ACT_LRELU, force_tile=c[0], force_split=c[1])
         s = torch.cuda.Stream(); s.wait_stream(torch.cuda.current_stream())

@@ -16,7 +16,7 @@ shapes = [('Kdim2304 N256 pix8192', 2, 256, 64, 64, 256, 3), ('Kdim1152 N256 pix
           ('Kdim1152 N64 pix131072', 2, 128, 256, 256, 64, 3), ('Kdim512 N512 pix1024', 1, 512, 1, 1024, 512, 1)]
 if len(sys.argv) > 1:
     shapes = [s for s in shapes if any(a in s[0] for a in sys.argv[1:])]
-TILES = {0: None, 1: (64, 64), 2: (128, 64), 3: (64, 128)}
+TILES = {0: None, 1: (64, 64), 2: (128, 64), 3: (64, 128), 4: (128, 128)}
 NREP = 20
 for name, n, cin, h, w, cout, k in shapes:
     x = conv.to_nhwc(torch.randn(n, cin, h, w, device=dev))
@@ -25,12 +25,12 @@ for name, n, cin, h, w, cout, k in shapes:
     flops = 2.0 * n * h * w * cout * cin * k * k
     kdim, pch = k * k * cin, (n * h * w + 31) // 32
     cfgs = [(0, 0)]
-    for t in (1, 2, 3):
+    for t in (1, 2, 3, 4):
         bm, bn = TILES[t]
         if cout < bn:
             continue
         tiles = ((kdim + bm - 1) // bm) * ((cout + bn - 1) // bn)
-        for target in (512, 1024, 2048):
+        for target in (1024, 2048, 4096):
             sp = max(1, min((target + tiles - 1) // tiles, pch // 4))
             cfgs.append((t, sp))
     graphs = {}
