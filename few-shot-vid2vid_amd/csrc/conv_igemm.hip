@@ -39,8 +39,7 @@ __device__ __forceinline__ void fsv_xcd_tile(int nx, int ny, int& bx, int& by) {
 //     row = 8 distinct slots) and read back as MFMA fragments with ds_read_b128 (16-lane service groups see 16 distinct
 //     (row parity, slot) pairs): both conflict free, and 4x fewer LDS instructions than a transposed [k][m] image;
 //   B [32 k][BN] as it lies in HBM: ds_write_b128 rows, ds_read_b32 fragments (32 consecutive columns).
-// MFMA k order inside a chunk: step (g, t) multiplies k = 8g + t (lanes 0-31) and k = 8g + 4 + t (lanes 32-63), so that
-// one b128 read of A feeds four MFMA steps.  The sum over k is still one fp32 fma chain per output (order permuted).
+// Two b128 reads of A feed the four MFMA steps of a k-group; the k order of every output's fma chain is ascending.
 // The LDS fragment reads of k-group g + 1 are issued (into a second register set) BEFORE the MFMAs of group g and pinned
 // there with scheduling fences - left alone the compiler sinks every read next to its MFMAs and waits for it (read,
 // s_waitcnt lgkmcnt(0), two MFMAs, read, ...), which exposes the LDS latency whenever a SIMD holds a single wave.
@@ -161,7 +160,7 @@ __global__ __launch_bounds__(64 * WM * WN) void fsv_conv_igemm_kernel(ConvP p) {
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   const int lrow = lane & 31, lk = lane >> 5;
-  // fragment addresses inside a buffer: A row (wm, i, lrow), quad 2g + lk; B row 8g + 4lk + t, column (wn, j, lrow)
+  // fragment addresses inside a buffer: A row (wm, i, lrow), quads 2g and 2g + 1; B row 8g + 2s + lk, column (wn, j, lrow)
   int a_off[TM], a_swz[TM];
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
@@ -169,24 +168,30 @@ __global__ __launch_bounds__(64 * WM * WN) void fsv_conv_igemm_kernel(ConvP p) {
     a_off[i] = r * BK;
     a_swz[i] = (r >> 1) & 7;
   }
-  const int b_off = (4 * lk) * BN + wn * (TN * 32) + lrow;
+  const int b_off = lk * BN + wn * (TN * 32) + lrow;
 
-  // fragments of one k-group (8 k): one quad of A per row tile, four B values per column tile
-  auto read_group = [&](const float* a_src, const float* b_src, int g, float4 (&a4)[TM], float (&b)[4][TN]) {
+  // fragments of one k-group (8 k): the two quads of A per row tile, four B values per column tile.  MFMA step s of the
+  // group multiplies k = 8g + 2s (lanes 0-31) and k = 8g + 2s + 1 (lanes 32-63): the sum over k stays ONE ascending fp32 fma
+  // chain per output, the order of the reference's own arithmetic (a permuted order moved LeakyReLU kinks of near-zero
+  // activations in the reference's finetune fixture and its gradients by 1 %).
+  auto read_group = [&](const float* a_src, const float* b_src, int g, float4 (&a4)[2][TM], float (&b)[4][TN]) {
 #pragma unroll
-    for (int i = 0; i < TM; ++i)
-      a4[i] = *reinterpret_cast<const float4*>(&a_src[a_off[i] + (((2 * g + lk) ^ a_swz[i]) << 2)]);
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+        a4[q][i] = *reinterpret_cast<const float4*>(&a_src[a_off[i] + (((2 * g + q) ^ a_swz[i]) << 2)]);
 #pragma unroll
     for (int t = 0; t < 4; ++t)
 #pragma unroll
-      for (int j = 0; j < TN; ++j) b[t][j] = b_src[b_off + (8 * g + t) * BN + j * 32];
+      for (int j = 0; j < TN; ++j) b[t][j] = b_src[b_off + (8 * g + 2 * t) * BN + j * 32];
   };
-  auto mma_group = [&](const float4 (&a4)[TM], const float (&b)[4][TN]) {
+  auto mma_group = [&](const float4 (&a4)[2][TM], const float (&b)[4][TN]) {
 #pragma unroll
     for (int t = 0; t < 4; ++t)
 #pragma unroll
       for (int i = 0; i < TM; ++i) {
-        const float a = (t == 0) ? a4[i].x : (t == 1) ? a4[i].y : (t == 2) ? a4[i].z : a4[i].w;
+        const float4 v = a4[t >> 1][i];
+        const float a = (t & 1) ? (lk ? v.w : v.z) : (lk ? v.y : v.x);
 #pragma unroll
         for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b[t][j], acc[i][j], 0, 0, 0);
       }
@@ -208,7 +213,7 @@ __global__ __launch_bounds__(64 * WM * WN) void fsv_conv_igemm_kernel(ConvP p) {
       issue_loads();
       const float* a_src = As + buf * A_ST;
       const float* b_src = Bs + buf * B_ST;
-      float4 fa[2][TM];
+      float4 fa[2][2][TM];
       float fb[2][4][TN];
       read_group(a_src, b_src, 0, fa[0], fb[0]);
       FSV_SCHED_FENCE();
