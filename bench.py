@@ -232,7 +232,9 @@ def main():
     if world > 1 or force_dist:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29533')
-        dist.init_process_group(backend='nccl', rank=rank, world_size=world)
+        import datetime
+        dist.init_process_group(backend='nccl', rank=rank, world_size=world, timeout=datetime.timedelta(seconds=180),
+                                device_id=device)
 
     from importlib import import_module
     import fsv2v_amd  # noqa: F401
@@ -242,82 +244,56 @@ def main():
     opt = build_opt(args.size, args.batch)
     model = M.create_model(opt).to(device).train()          # identical init on every rank (seed 0), like the reference
     distributed = world > 1 or force_dist
-    # N > 1: no autograd hooks, the step is three hipGraph segments with one whole-buffer RCCL all-reduce between them
+    # N > 1: no autograd hooks; the step runs as hipGraph segments (graph_step.GraphedIteration) - D | Adam(D) + G forward +
+    # first piece of the G backward | rest of the G backward | Adam(G) - with the RCCL all-reduces between them; the
+    # exchange of the decoder-stage gradients (51 % of the generator's parameters) runs on a side stream next to the third
+    # graph.  No collective is captured.
     segmented = distributed and not args.no_graph
     opt_G, opt_D = model.build_optimizers(world_size=world, process_group=group, force_exchange=force_dist,
-                                          overlap=not segmented)
+                                          overlap=not segmented, split_backward=segmented)
     data = make_data(args.batch, args.size, 1234 + rank, device)
 
-    def backward_of(losses, optimizer):
-        loss = sum(torch.mean(x) for x in losses)
-        optimizer.zero_grad()
-        optimizer.scale_loss(loss).backward()      # identity unless --amp O1
-        optimizer.finalize_grads()        # deferred weight-gradient jobs belong to the segment that queued them
-
-    def seg_d():                       # D forward (incl. the no-grad G forward) + D backward
-        backward_of(model(data, mode='discriminator'), opt_D)
-
-    def seg_g():                       # Adam(D), then G forward + D forward + full backward
-        opt_D.adam()
-        backward_of(model(data, mode='generator')[0], opt_G)
-
-    def seg_a():                       # Adam(G)
-        opt_G.adam()
-
     def step():
-        if segmented:
-            seg_d(); opt_D.exchange_all(); seg_g(); opt_G.exchange_all(); seg_a()
-        else:
-            d_losses = model(data, mode='discriminator')
-            M.loss_backward(opt, d_losses, opt_D, 1)
-            g_losses, _, _ = model(data, mode='generator')
-            M.loss_backward(opt, g_losses, opt_G, 0)
+        d_losses = model(data, mode='discriminator')
+        M.loss_backward(opt, d_losses, opt_D, 1)
+        g_losses, _, _ = model(data, mode='generator')
+        M.loss_backward(opt, g_losses, opt_G, 0)
 
     use_graph = not args.no_graph
-    graphs = None
-    n_eager_warm = max(1, min(args.warmup, 2)) if use_graph else args.warmup
-    side = torch.cuda.Stream()
-    side.wait_stream(torch.cuda.current_stream())
-    with torch.cuda.stream(side):
-        for _ in range(n_eager_warm):
-            step()
-    torch.cuda.current_stream().wait_stream(side)
-    torch.cuda.synchronize()
     mode = 'eager'
     run = step
-    if use_graph:
-        try:
-            if segmented:
-                # The RCCL watchdog thread polls its events while a collective is in flight; under the default global
-                # capture mode that poll is an illegal call "during capture" and invalidates it.  So: no collective may be
-                # pending when a capture starts (synchronize), and the captures only police their own thread.
-                graphs = [torch.cuda.CUDAGraph() for _ in range(3)]
-                torch.cuda.synchronize()
-                with torch.cuda.graph(graphs[0], capture_error_mode='thread_local'):
-                    seg_d()
-                opt_D.exchange_all()
-                torch.cuda.synchronize()
-                with torch.cuda.graph(graphs[1], pool=graphs[0].pool(), capture_error_mode='thread_local'):
-                    seg_g()
-                opt_G.exchange_all()
-                torch.cuda.synchronize()
-                with torch.cuda.graph(graphs[2], pool=graphs[0].pool(), capture_error_mode='thread_local'):
-                    seg_a()
+    if segmented:
+        gs = import_module('few-shot-vid2vid_amd.graph_step')
+        n_eager_warm = max(1, min(args.warmup, 2))
+        gi = gs.GraphedIteration(model, opt, warmup=n_eager_warm)
 
-                def run():
-                    graphs[0].replay(); opt_D.exchange_all(); graphs[1].replay(); opt_G.exchange_all(); graphs[2].replay()
-                mode = 'hipgraph x3 + whole-buffer all-reduce'
-            else:
+        def run():
+            gi(data)
+        for _ in range(n_eager_warm + 1):          # eager warm-up calls, then the capture (which replays once)
+            run()
+        n_eager_warm += 1
+        mode = 'hipgraph x%d + RCCL all-reduce between segments (decoder-stage range on a side stream)' % (4 if gi.split else 3)
+    else:
+        n_eager_warm = max(1, min(args.warmup, 2)) if use_graph else args.warmup
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(n_eager_warm):
+                step()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        if use_graph:
+            try:
                 graph = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(graph):
                     step()
                 run = graph.replay
                 mode = 'hipgraph'
-        except Exception as e:                      # capture is an optimisation; the step itself is unchanged
-            if rank == 0:
-                print('graph capture failed (%s); timing the eager step' % str(e).split('\n')[0], file=sys.stderr)
-            run = step
-            torch.cuda.synchronize()
+            except Exception as e:                      # capture is an optimisation; the step itself is unchanged
+                if rank == 0:
+                    print('graph capture failed (%s); timing the eager step' % str(e).split('\n')[0], file=sys.stderr)
+                run = step
+                torch.cuda.synchronize()
     for _ in range(max(0, args.warmup - n_eager_warm)):
         run()
 

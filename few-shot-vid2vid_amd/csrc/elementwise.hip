@@ -349,3 +349,66 @@ int fsv_maxpool2_bwd(const float* x, const float* dy, float* dx, int N, int H, i
   return fsv_check_launch();
 }
 }  // extern "C"
+
+// ---- 3x3 stride-2 average pooling, padding 1, count_include_pad = False (MultiscaleDiscriminator's pyramid between its
+// discriminators, models/networks/discriminator.py:28,56), NHWC; OH = (H - 1) / 2 + 1 -------------------------------------
+__device__ __forceinline__ int fsv_ap_count(int o, int extent) {      // valid taps of output index o along one axis
+  const int lo = 2 * o - 1, hi = 2 * o + 1;
+  return (hi < extent ? hi : extent - 1) - (lo > 0 ? lo : 0) + 1;
+}
+__global__ __launch_bounds__(256) void fsv_avgpool3s2_fwd_kernel(const float* x, float* y, int N, int H, int W, int C) {
+  const int OH = (H - 1) / 2 + 1, OW = (W - 1) / 2 + 1;
+  const long long total = (long long)N * OH * OW * C;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int c = (int)(i % C);
+    long long t = i / C;
+    const int ox = (int)(t % OW); t /= OW;
+    const int oy = (int)(t % OH);
+    const long long n = t / OH;
+    float s = 0.f;
+    for (int dy = -1; dy <= 1; ++dy) {
+      const int yy = 2 * oy + dy;
+      if ((unsigned)yy >= (unsigned)H) continue;
+      for (int dx = -1; dx <= 1; ++dx) {
+        const int xx = 2 * ox + dx;
+        if ((unsigned)xx < (unsigned)W) s += x[((n * H + yy) * W + xx) * C + c];
+      }
+    }
+    y[i] = s / (float)(fsv_ap_count(oy, H) * fsv_ap_count(ox, W));
+  }
+}
+__global__ __launch_bounds__(256) void fsv_avgpool3s2_bwd_kernel(const float* dy, float* dx, int N, int H, int W, int C) {
+  const int OH = (H - 1) / 2 + 1, OW = (W - 1) / 2 + 1;
+  const long long total = (long long)N * H * W * C;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int c = (int)(i % C);
+    long long t = i / C;
+    const int xx = (int)(t % W); t /= W;
+    const int yy = (int)(t % H);
+    const long long n = t / H;
+    // an even row belongs to the window of output yy / 2 only, an odd row to those of (yy - 1) / 2 and (yy + 1) / 2
+    const int oy0 = yy >> 1, oy1 = (yy & 1) ? oy0 + 1 : oy0;
+    const int ox0 = xx >> 1, ox1 = (xx & 1) ? ox0 + 1 : ox0;
+    float g = 0.f;
+    for (int oy = oy0; oy <= oy1; ++oy) {
+      if (oy >= OH) continue;
+      for (int ox = ox0; ox <= ox1; ++ox)
+        if (ox < OW) g += dy[((n * OH + oy) * OW + ox) * C + c] / (float)(fsv_ap_count(oy, H) * fsv_ap_count(ox, W));
+    }
+    dx[i] = g;
+  }
+}
+
+extern "C" {
+int fsv_avgpool3s2_fwd(const float* x, float* y, int N, int H, int W, int C, hipStream_t stream) {
+  if (!x || !y || N < 1 || H < 1 || W < 1 || C < 1) return FSV_ERR_BAD_ARG;
+  FSV_LAUNCH(fsv_avgpool3s2_fwd_kernel, dim3(fsv_grid_for((long long)N * ((H - 1) / 2 + 1) * ((W - 1) / 2 + 1) * C)), dim3(256), stream,
+             x, y, N, H, W, C);
+  return fsv_check_launch();
+}
+int fsv_avgpool3s2_bwd(const float* dy, float* dx, int N, int H, int W, int C, hipStream_t stream) {
+  if (!dy || !dx || N < 1 || H < 1 || W < 1 || C < 1) return FSV_ERR_BAD_ARG;
+  FSV_LAUNCH(fsv_avgpool3s2_bwd_kernel, dim3(fsv_grid_for((long long)N * H * W * C)), dim3(256), stream, dy, dx, N, H, W, C);
+  return fsv_check_launch();
+}
+}  // extern "C"

@@ -40,6 +40,9 @@ class FlatAdam:
         # bumped by rebuild(): captured graphs / cached pointers of an older layout are stale (graph_step.py checks it)
         self.generation = 0
         self._hook_handles = []
+        # split_at: element offset in the flat buffers below which the gradients are complete after the FIRST piece of a
+        # two-piece backward (set by Vid2VidModel.build_optimizers(split_backward=True): stage-2 parameters are laid out first)
+        self.split_at = 0
         self._lay_out(params, lr, loss_scale)
 
     def rebuild(self, params, lr=None, loss_scale='keep'):
@@ -215,19 +218,28 @@ class FlatAdam:
                 super().__setitem__(k, v)
         return [_Group(lr=float(self.state[3]), params=self.params)]
 
-    def finalize_grads(self):
+    def finalize_grads(self, partial=False):
         """Fold the queued K-major weight gradients of the last backward pass into the flat gradient buffer.  Runs by
-        itself before the exchange / Adam step; call it explicitly to read `.grad` of a weight before stepping."""
+        itself before the exchange / Adam step; call it explicitly to read `.grad` of a weight before stepping.
+        partial=True: the backward pass is not over (two-piece backward, networks.BackwardCut) - fold what has been
+        produced so far and leave the parameters that have no gradient yet detached."""
         if self.finalizer is not None:
             self.finalizer.run()
             if self._loose:
-                pairs = []
+                pairs, done = [], []
                 for i in self._loose:
                     g = self.params[i].grad
                     if g is not None:
                         pairs.append((g.contiguous().view(-1), self._grad_views[i].view(-1)))
+                        done.append(i)
                 self.finalizer.gather_dense(pairs)
-                self._reattach()
+                if partial:
+                    for i in done:
+                        self.params[i].grad = self._grad_views[i]
+                    keep = set(done)
+                    self._loose = [i for i in self._loose if i not in keep]
+                else:
+                    self._reattach()
 
     def _reattach(self):
         for i in self._loose:
@@ -239,6 +251,28 @@ class FlatAdam:
         self.finalize_grads()
         if self.exchange and not self.overlap:
             dist.all_reduce(self.flat_g, op=dist.ReduceOp.SUM, group=self.group)
+
+    def exchange_range(self, lo, hi, side=False):
+        """All-reduce flat_g[lo:hi] (hook-free mode; the caller has finalised the gradients in that range).  side=True:
+        on this optimiser's side stream, which first waits for the work queued on the current stream - the collective then
+        runs next to whatever the caller enqueues on the current stream afterwards; join with wait_exchange()."""
+        if not (self.exchange and not self.overlap) or hi <= lo:
+            return
+        view = self.flat_g[lo:hi]
+        if side and self.device.type == 'cuda':
+            if self.side_stream is None:
+                self.side_stream = torch.cuda.Stream(device=self.device)
+            self.side_stream.wait_stream(torch.cuda.current_stream(self.device))
+            with torch.cuda.stream(self.side_stream):
+                dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group)
+            self._side_pending = True
+        else:
+            dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group)
+
+    def wait_exchange(self):
+        if getattr(self, '_side_pending', False):
+            torch.cuda.current_stream(self.device).wait_stream(self.side_stream)
+            self._side_pending = False
 
     def scale_loss(self, loss):
         """models/loss_collector.py:221-224 `amp.scale_loss`: the loss times this optimiser's current scale (a device

@@ -10,8 +10,11 @@ first frame of a sequence has no previous frames and therefore its own graph), c
 input buffers and replays.  The first `warmup` calls of a new signature run eagerly (real iterations on real data; they also
 settle lazily-built caches such as the optimisers' layout tables), the next call captures and replays.
 
-With a process group the step is cut into three graphs around the two whole-buffer gradient all-reduces (the optimisers must
-have been built with `overlap=False`), exactly like bench.py does at N > 1: no collective is captured.
+With a process group the step is cut into graphs around the gradient all-reduces (the optimisers must have been built with
+`overlap=False`), exactly like bench.py does at N > 1: no collective is captured.  With `build_optimizers(split_backward=True)`
+the generator's backward pass itself is two graphs (networks.BackwardCut): D | Adam(D) + G forward + first piece of backward |
+rest of backward | Adam(G) - the all-reduce of the decoder-stage gradients (half of the generator's parameters) runs on a side
+stream next to the third graph, the remaining ranges follow it, and the fused Adam waits for both.
 
 Everything that changes between iterations lives on the device and is read by the captured kernels: learning rate and Adam
 step count (`FlatAdam.state`), loss scale (`FlatAdam.scaler`), BatchNorm / spectral-norm buffers.  Rebuilding the optimisers
@@ -73,11 +76,14 @@ class GraphedIteration:
         self.opt_G, self.opt_D = self.model.optimizer_G, self.model.optimizer_D
         if self.opt_G is None or self.opt_D is None:
             raise RuntimeError("build the optimisers (model.build_optimizers) before graphing the iteration")
+        self._generations = (self.opt_G.generation, self.opt_D.generation)      # bumped by FlatAdam.rebuild (init_temporal_model)
         from . import ops
         if ops.bn_sync_world() > 1 and not lib.emu_requested():
             raise RuntimeError("cross-replica BatchNorm issues collectives inside forward / backward, which cannot be captured: "
                                "use the eager loop with sync_bn, or per-replica statistics with GraphedIteration")
         self.segmented = bool(self.opt_G.exchange)
+        # two-piece generator backward (model.build_optimizers(split_backward=True)); pointless without an exchange to overlap
+        self.split = bool(getattr(self.model, 'split_backward', False)) and self.segmented
         if self.segmented and self.opt_G.overlap:
             raise RuntimeError("with a process group build the optimisers with overlap=False: bucket hooks issue collectives "
                                "inside backward, which cannot be captured")
@@ -106,18 +112,40 @@ class GraphedIteration:
     def _seg_g(self, e, save_images):
         self.opt_D.adam()
         g_losses, generated, prevs = self.model(e.static, save_images=save_images, mode='generator')
-        e.out_g = self._backward(g_losses, self.opt_G)
+        if not self.split:
+            e.out_g = self._backward(g_losses, self.opt_G)
+        else:                                  # first piece: down to the generator's stage boundary
+            losses = [torch.mean(x) if not isinstance(x, int) else x for x in g_losses]
+            self.opt_G.zero_grad()
+            self.opt_G.scale_loss(sum(losses)).backward()
+            self.opt_G.finalize_grads(partial=True)
+            e.out_g = losses
         e.out_gen, e.out_prev = generated, prevs
+
+    def _seg_g2(self):
+        self.model.netG.bwd_cut.backward_rest()
+        self.opt_G.finalize_grads()
 
     def _seg_a(self):
         self.opt_G.adam()
+
+    def _exchange_g_first(self):
+        self.opt_G.exchange_range(0, self.opt_G.split_at, side=True)
+
+    def _exchange_g_rest(self):
+        self.opt_G.exchange_range(self.opt_G.split_at, self.opt_G.total)
+        self.opt_G.wait_exchange()
 
     def _eager(self, e, save_images):
         self._seg_d(e)
         if self.segmented:
             self.opt_D.exchange_all()
         self._seg_g(e, save_images)
-        if self.segmented:
+        if self.split:
+            self._exchange_g_first()
+            self._seg_g2()
+            self._exchange_g_rest()
+        elif self.segmented:
             self.opt_G.exchange_all()
         self._seg_a()
 
@@ -132,33 +160,47 @@ class GraphedIteration:
             return
         # no collective may be pending when a capture starts, and the captures only police their own thread (the RCCL watchdog
         # polls its events from another one)
-        gs = [torch.cuda.CUDAGraph() for _ in range(3)]
+        gs = [torch.cuda.CUDAGraph() for _ in range(4 if self.split else 3)]
         with torch.cuda.graph(gs[0], capture_error_mode='thread_local'):
             self._seg_d(e)
         gs[0].replay(); self.opt_D.exchange_all()
         torch.cuda.synchronize(dev)
         with torch.cuda.graph(gs[1], pool=gs[0].pool(), capture_error_mode='thread_local'):
             self._seg_g(e, save_images)
-        gs[1].replay(); self.opt_G.exchange_all()
+        gs[1].replay()
+        if self.split:
+            self._exchange_g_first()
+            torch.cuda.synchronize(dev)
+            with torch.cuda.graph(gs[2], pool=gs[0].pool(), capture_error_mode='thread_local'):
+                self._seg_g2()
+            gs[2].replay(); self._exchange_g_rest()
+        else:
+            self.opt_G.exchange_all()
         torch.cuda.synchronize(dev)
-        with torch.cuda.graph(gs[2], pool=gs[0].pool(), capture_error_mode='thread_local'):
+        with torch.cuda.graph(gs[-1], pool=gs[0].pool(), capture_error_mode='thread_local'):
             self._seg_a()
-        gs[2].replay()
+        gs[-1].replay()
         e.graphs = gs
         e.replayed_by_capture = True
 
     def _replay(self, e):
         if len(e.graphs) == 1:
             e.graphs[0].replay()
-        else:
+        elif len(e.graphs) == 3:
             e.graphs[0].replay(); self.opt_D.exchange_all()
             e.graphs[1].replay(); self.opt_G.exchange_all()
             e.graphs[2].replay()
+        else:
+            e.graphs[0].replay(); self.opt_D.exchange_all()
+            e.graphs[1].replay(); self._exchange_g_first()          # side stream: overlaps the next graph
+            e.graphs[2].replay(); self._exchange_g_rest()
+            e.graphs[3].replay()
 
     # ------------------------------------------------------------------------------------------------ call
     def __call__(self, data_list, save_images=False):
         """one iteration; returns (d_losses, g_losses, generated, prevs_new) like the two model calls of train.py:58-62"""
-        if self.model.optimizer_G is not self.opt_G or self.model.optimizer_D is not self.opt_D:
+        if (self.model.optimizer_G is not self.opt_G or self.model.optimizer_D is not self.opt_D or
+                (self.opt_G.generation, self.opt_D.generation) != self._generations):
             self.reset()
         flat = _flat(data_list)
         key = self._signature(flat, save_images)

@@ -307,6 +307,9 @@ def loss_backward(opt, losses, optimizer, loss_id):
     optimizer.zero_grad()
     scale_loss = getattr(optimizer, 'scale_loss', None)
     (scale_loss(loss) if scale_loss is not None else loss).backward()
+    cut = getattr(optimizer, 'bwd_cut', None)
+    if cut is not None:                 # two-piece backward (build_optimizers(split_backward=True)): run the second piece too
+        cut.backward_rest()
     optimizer.step()
     return losses
 
@@ -394,7 +397,8 @@ class Vid2VidModel(nn.Module):
         return out
 
     # optimisers are created once the module sits on its device (flat buffers are device allocations)
-    def build_optimizers(self, world_size=1, process_group=None, force_exchange=False, overlap=True, sync_bn=None):
+    def build_optimizers(self, world_size=1, process_group=None, force_exchange=False, overlap=True, sync_bn=None,
+                         split_backward=False):
         """sync_bn: pool the BatchNorm statistics over the replicas (the reference's apex SyncBatchNorm under its
         multi-process path, normalization.py:15,33,80) instead of the default per-replica statistics; None reads
         FSV_SYNC_BN.  Needs equal per-rank batches and the eager step (collectives inside forward / backward)."""
@@ -408,11 +412,10 @@ class Vid2VidModel(nn.Module):
         mode = amp_mode(opt)
         conv.set_mfma_mode(mode)
         loss_scale = True if mode == conv.MFMA_F16 else None
-        g_params = list(self.netG.parameters())
-        if self.netGf is not None:         # base_model.py:204-205
-            g_params += list(self.netGf.parameters())
+        g_params = self._g_params(split_backward)
         self.optimizer_G = FlatAdam(g_params, g_lr, (beta1, beta2), world_size, process_group,
                                     force_exchange=force_exchange, overlap=overlap, loss_scale=loss_scale)
+        self._set_split(split_backward)
         d_params = list(self.netD.parameters())
         if self.netDT is not None:         # built temporal from the start (resume past niter_single): base_model.py:274
             d_params += list(self.netDT.parameters())
@@ -421,6 +424,25 @@ class Vid2VidModel(nn.Module):
         self.optimizer_D = FlatAdam(d_params, d_lr, (beta1, beta2), world_size, process_group,
                                     force_exchange=force_exchange, overlap=overlap, loss_scale=loss_scale)
         return self.optimizer_G, self.optimizer_D
+
+    def _g_params(self, split_backward):
+        """generator parameters in optimiser order.  split_backward: the generator's stage-2 parameters (below its
+        BackwardCut boundary) go LAST - FlatAdam lays its buffers out in reverse order, so their gradients occupy
+        flat_g[:split_at] and can be exchanged while the rest of backward is still running (graph_step.py)."""
+        g_params = list(self.netG.parameters())
+        if split_backward:
+            late = set(id(p) for p in self.netG.stage2_parameters())
+            g_params = [p for p in g_params if id(p) not in late] + [p for p in g_params if id(p) in late]
+        if self.netGf is not None:         # base_model.py:204-205
+            g_params = list(self.netGf.parameters()) + g_params if split_backward else g_params + list(self.netGf.parameters())
+        return g_params
+
+    def _set_split(self, split_backward):
+        self.split_backward = bool(split_backward)
+        self.netG.bwd_cut = networks.BackwardCut() if split_backward else None
+        self.optimizer_G.bwd_cut = self.netG.bwd_cut
+        self.optimizer_G.split_at = (sum(p.numel() for p in self.netG.stage2_parameters() if p.requires_grad)
+                                     if split_backward else 0)
 
     def init_temporal_model(self):
         """models/base_model.py:259-279: the generator grows its previous-frame flow / embedding branches, the temporal
@@ -441,8 +463,9 @@ class Vid2VidModel(nn.Module):
         set_random_seed(get_rank())        # generator.py:179
         if self.optimizer_G is not None:
             _, _, g_lr, d_lr = optimizer_rates(opt)
-            g_params = list(self.netG.parameters()) + (list(self.netGf.parameters()) if self.netGf is not None else [])
-            self.optimizer_G.rebuild(g_params, lr=g_lr)          # the loss scale found so far carries over
+            split = getattr(self, 'split_backward', False)
+            self.optimizer_G.rebuild(self._g_params(split), lr=g_lr)          # the loss scale found so far carries over
+            self._set_split(split)
             d_params = list(self.netD.parameters()) + (list(self.netDT.parameters()) if self.netDT is not None else [])
             if self.netDf is not None:
                 d_params += list(self.netDf.parameters())

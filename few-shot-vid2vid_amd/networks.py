@@ -586,6 +586,11 @@ class FewShotGenerator(nn.Module):
                 ds[1] = ops.cat_channels([warp[1], mask[1]])
         return flow, mask, warp, ds
 
+    def stage2_parameters(self):
+        """parameters below the BackwardCut boundary of forward(): SPADE-combine image embeddings, decoder blocks, output conv"""
+        names = ('up_', 'conv_img', 'img_ref_embedding', 'img_prev_embedding')
+        return [p for n, p in self.named_parameters() if n.startswith(names)]
+
     def forward(self, label, label_refs, img_refs, prev=(None, None), t=0, img_coarse=None):
         if self._sn_group is None or self._sn_count != sum(1 for _ in self.modules()):
             self._sn_group = ops.SpectralGroup(spectral_layers(self))
@@ -597,6 +602,12 @@ class FewShotGenerator(nn.Module):
         atn_vis, ref_idx = self._atn
         label_ref, img_ref = pick_ref(label_refs, ref_idx), pick_ref(img_refs, ref_idx)
         flow, mask, warp, ds = self.flow_generation(label, label_ref, img_ref, prev)
+        cut = getattr(self, 'bwd_cut', None)
+        if cut is not None and torch.is_grad_enabled():
+            # stage boundary (see BackwardCut): everything above is "stage 1", the image embeddings and the decoder below
+            # are "stage 2" (stage2_parameters)
+            x, enc_label, norm_w, flow, mask, warp, ds = cut.split((x, enc_label, norm_w, flow, mask, warp, ds))
+            enc_label = list(enc_label)
         if self.spade_combine:
             emb = [self.img_ref_embedding(ds[0]), self.img_prev_embedding(ds[1]) if ds[1] is not None else None]
             for i in range(self.n_sc_layers):
@@ -618,6 +629,36 @@ class FewShotGenerator(nn.Module):
         else:
             img_final, img_raw = img_raw, None
         return img_final, flow, mask, img_raw, warp, None, None, atn_vis, ref_idx
+
+
+class BackwardCut:
+    """A stage boundary inside one forward pass, for backward passes that run in two pieces (graph_step / bench.py at
+    N > 1: the gradients of the decoder stage are complete after the first piece and are all-reduced on a side stream
+    while the second piece - the encoders, weight generators and the flow network - is still running).
+
+    split() replaces every tensor that crosses the boundary by a detached leaf; `loss.backward()` then stops at the leaves
+    (first piece), and backward_rest() continues from the recorded originals with the gradients the leaves collected."""
+
+    def __init__(self):
+        self.pairs = []
+
+    def split(self, obj):
+        if torch.is_tensor(obj):
+            if not obj.requires_grad:
+                return obj
+            leaf = obj.detach().requires_grad_(True)
+            self.pairs.append((obj, leaf))
+            return leaf
+        if isinstance(obj, (list, tuple)):
+            return type(obj)(self.split(o) for o in obj)
+        return obj
+
+    def backward_rest(self):
+        outs = [o for o, l in self.pairs if l.grad is not None]
+        grads = [l.grad for o, l in self.pairs if l.grad is not None]
+        self.pairs = []
+        if outs:
+            torch.autograd.backward(outs, grads)
 
 
 # ------------------------------------------------------------------------------------------------ discriminator
@@ -670,8 +711,7 @@ class MultiscaleDiscriminator(nn.Module):
             out = getattr(self, 'discriminator_%d' % i)(x)
             result.append(out if self.getIntermFeat else [out])
             if i + 1 < self.num_D:
-                # TODO(next): HIP avg-pool; num_D = 1 in every BASELINE config so this is off the measured path
-                x = F.avg_pool2d(x, 3, stride=2, padding=1, count_include_pad=False)
+                x = ops.avgpool3s2(x)            # discriminator.py:28,56 (scripts/face/train_g8_512.sh: --num_D 2)
         return result
 
 

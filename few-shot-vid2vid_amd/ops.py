@@ -1242,3 +1242,36 @@ class _MaxPool2Fn(torch.autograd.Function):
 
 def maxpool2(x):
     return _MaxPool2Fn.apply(x)
+
+
+lib.register_sigs({
+    "fsv_avgpool3s2_fwd": [c_p, c_p, c_i, c_i, c_i, c_i, c_p],
+    "fsv_avgpool3s2_bwd": [c_p, c_p, c_i, c_i, c_i, c_i, c_p],
+})
+
+
+class _AvgPool3s2Fn(torch.autograd.Function):
+    """nn.AvgPool2d(3, stride=2, padding=[1, 1], count_include_pad=False): the pyramid step between the discriminators of
+    the reference's MultiscaleDiscriminator (discriminator.py:28,56)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        x = to_nhwc(x)
+        n, c, h, w = x.shape
+        y = empty_nhwc(n, c, (h - 1) // 2 + 1, (w - 1) // 2 + 1, x)
+        lib.check_device(x)
+        lib.call("fsv_avgpool3s2_fwd", lib.ptr(x), lib.ptr(y), n, h, w, c, lib.stream_ptr())
+        ctx.dims = (n, c, h, w)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        n, c, h, w = ctx.dims
+        dy = to_nhwc(dy)
+        dx = empty_nhwc(n, c, h, w, dy)
+        lib.call("fsv_avgpool3s2_bwd", lib.ptr(dy), lib.ptr(dx), n, h, w, c, lib.stream_ptr())
+        return dx
+
+
+def avgpool3s2(x):
+    return _AvgPool3s2Fn.apply(x)

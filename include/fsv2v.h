@@ -211,6 +211,10 @@ int fsv_blend_bwd(const float* a, const float* b, const float* m, const float* g
 /* 2x2 stride-2 max pooling of the VGG19 feature stack (models/networks/vgg.py:45-59), NHWC */
 int fsv_maxpool2_fwd(const float* x, float* y, int N, int H, int W, int C, fsv_stream_t stream);
 int fsv_maxpool2_bwd(const float* x, const float* dy, float* dx, int N, int H, int W, int C, fsv_stream_t stream);
+/* nn.AvgPool2d(3, stride=2, padding=1, count_include_pad=False) between the discriminators of a multi-scale pyramid
+ * (reference models/networks/discriminator.py:28,56), NHWC; output (H - 1) / 2 + 1 by (W - 1) / 2 + 1 */
+int fsv_avgpool3s2_fwd(const float* x, float* y, int N, int H, int W, int C, fsv_stream_t stream);
+int fsv_avgpool3s2_bwd(const float* dy, float* dx, int N, int H, int W, int C, fsv_stream_t stream);
 /* softmax over the contiguous channel dimension of [rows][C] (nn.Softmax(dim=1) at generator.py:384) */
 int fsv_softmax_rows_fwd(const float* x, float* y, long long rows, int C, fsv_stream_t stream);
 int fsv_softmax_rows_bwd(const float* dy, const float* y, float* dx, long long rows, int C, fsv_stream_t stream);

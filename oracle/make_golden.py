@@ -57,6 +57,8 @@ CONFIGS['street'] = ('--dataset_mode fewshot_street --label_nc 7 --fineSize 64 -
 # tile plans (128 ... 1024 channels) to the reference itself, not only to the oracle
 CONFIGS['face_fullwidth'] = ('--dataset_mode fewshot_face --fineSize 128 --loadSize 128 --adaptive_spade --no_flow_gt --no_vgg_loss '
                              '--gpu_ids -1 --batchSize 1')
+# two-scale discriminator pyramid (scripts/face/train_g8_512.sh): AvgPool2d(3, 2, 1, count_include_pad=False) between the scales
+CONFIGS['face_numD2'] = CONFIGS['face'] + ' --num_D 2'
 LAYOUT_CONFIGS = {
     'C3_pose_512': '--dataset_mode fewshot_pose --aspect_ratio 1 --fineSize 512 --loadSize 512 --adaptive_spade --warp_ref '
                    '--spade_combine --remove_face_labels --no_flow_gt --no_vgg_loss --gpu_ids -1',

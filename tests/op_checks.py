@@ -639,3 +639,20 @@ def run_all(device, big=False):
     check_part_masks(device)
     check_face_ops(device)
     check_flownet_ops(device)
+
+
+def check_avgpool3s2(device, seed=90):
+    """MultiscaleDiscriminator's pyramid step: AvgPool2d(3, stride 2, padding 1, count_include_pad=False), odd and even sizes"""
+    ops, conv = pkg()
+    g = torch.Generator().manual_seed(seed)
+    for shp in [(2, 5, 9, 7), (1, 20, 64, 64), (2, 3, 8, 10), (1, 4, 1, 5)]:
+        x = torch.randn(*shp, generator=g)
+        xr = x.clone().requires_grad_(True)
+        ref = F.avg_pool2d(xr, 3, stride=2, padding=1, count_include_pad=False)
+        dy = torch.randn(ref.shape, generator=g)
+        ref.backward(dy)
+        xd = _dev(x, device).requires_grad_(True)
+        y = ops.avgpool3s2(xd)
+        y.backward(_dev(dy, device))
+        assert_close('avgpool y %s' % (shp,), y, ref, 1e-6)
+        assert_close('avgpool dx %s' % (shp,), xd.grad, xr.grad, 1e-6)

@@ -88,6 +88,53 @@ def test_two_rank_whole_buffer_exchange(emu_lib, tmp_path):
     assert float((r0['gD'] - local).abs().max()) <= 1e-5 * scale
 
 
+def _split_worker(rank, world, port, out_dir, split):
+    """the N > 1 bench path: GraphedIteration over hook-free optimisers; split=True adds the two-piece generator backward
+    with the decoder-stage range exchanged on its own (on a GPU: on a side stream next to the second piece)"""
+    os.environ['FSV2V_EMU'] = '1'
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    torch.set_num_threads(1)
+    import model_checks as mc
+    from importlib import import_module
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    M = mc._model()
+    gs = import_module('few-shot-vid2vid_amd.graph_step')
+    opt = mc.tiny_opt(ngf=4, ndf=4, nff=4, warp_ref=True, spade_combine=True, fineSize=32, loadSize=32, n_downsample_G=3,
+                      n_adaptive_layers=2)
+    model = M.create_model(opt)
+    mc.fill_state(model.netG); mc.fill_state(model.netD)
+    model.train()
+    opt_G, opt_D = model.build_optimizers(world_size=world, overlap=False, split_backward=split)
+    gi = gs.GraphedIteration(model, opt, warmup=1)
+    assert gi.segmented and gi.split == split
+    tl, ti, rl, ri = mc.synth_pose_inputs(1, 32, 32, 200 + rank, 6)
+    data = [tl, ti, [None, None], [None, None], rl, ri, None, None, None]
+    for it in range(2):
+        gi(data)
+    torch.save(dict(g={n: p.grad.clone() for n, p in model.netG.named_parameters()},
+                    p={n: p.detach().clone() for n, p in model.netG.named_parameters()}, split_at=opt_G.split_at,
+                    total=opt_G.total), os.path.join(out_dir, 'split%d_rank%d.pt' % (int(split), rank)))
+    dist.destroy_process_group()
+
+
+def test_two_rank_two_piece_backward_equals_whole_backward(emu_lib, tmp_path):
+    world = 2
+    mp.spawn(_split_worker, args=(world, 29621, str(tmp_path), False), nprocs=world, join=True)
+    mp.spawn(_split_worker, args=(world, 29623, str(tmp_path), True), nprocs=world, join=True)
+    w0 = torch.load(os.path.join(tmp_path, 'split0_rank0.pt'))
+    s0 = torch.load(os.path.join(tmp_path, 'split1_rank0.pt'))
+    s1 = torch.load(os.path.join(tmp_path, 'split1_rank1.pt'))
+    assert 0 < s0['split_at'] < s0['total'] and w0['split_at'] == 0
+    for n in s0['g']:
+        assert torch.equal(s0['g'][n], s1['g'][n]) and torch.equal(s0['p'][n], s1['p'][n]), n      # replicas in lock-step
+        # same exchanged gradients and same weights after two iterations as with one whole-buffer all-reduce
+        scale = max(float(w0['g'][n].abs().max()), 1e-12)
+        assert float((s0['g'][n] - w0['g'][n]).abs().max()) <= 1e-6 * scale, n
+        assert torch.equal(s0['p'][n], w0['p'][n]), n
+
+
 def _amp_worker(rank, world, port, out_dir):
     """--amp O1 across two ranks: rank 1's second gradient overflows; the overflow test runs on the all-reduced buffer, so
     both ranks must skip that step together and come out with identical weights and loss scales"""

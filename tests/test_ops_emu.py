@@ -104,3 +104,7 @@ def test_softmax_channels(emu_lib):
 
 def test_losses_pack_pool(emu_lib):
     oc.check_losses(DEV)
+
+
+def test_avgpool3s2(emu_lib):
+    oc.check_avgpool3s2(torch.device('cpu'))

@@ -132,3 +132,8 @@ def test_every_gemm_tile(hip_lib):
     """all instantiated forward / weight-gradient tiles (incl. split-K atomics and per-sample weights) on ragged geometries"""
     import tile_checks as tc
     tc.run_all(torch.device('cuda:0'))
+
+
+@pytest.mark.gpu
+def test_avgpool3s2(hip_lib):
+    oc.check_avgpool3s2(torch.device('cuda:0'))

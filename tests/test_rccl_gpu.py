@@ -1,0 +1,76 @@
+"""The data-parallel path on real hardware (RCCL = torch's 'nccl' backend on ROCm).
+
+* one rank (any GPU box): bench.py's N > 1 code path - hook-free optimisers, four hipGraph segments, the decoder-stage
+  gradient range all-reduced on a side stream next to the third graph - forced in a one-rank RCCL group (FSV_FORCE_DIST=1);
+* two ranks (only when the box shows >= 2 devices; the driver's single-GPU boxes skip it): the same path on two GPUs keeps the
+  replicas in lock-step and produces the gradients of one process that sees both shards (mirror of test_ddp_gloo.py)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+
+
+def test_one_rank_rccl_runs_the_segmented_bench_path(hip_lib):
+    env = dict(os.environ, FSV_FORCE_DIST='1', MASTER_ADDR='127.0.0.1', MASTER_PORT='29641', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    env.pop('FSV2V_EMU', None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--steps', '2', '--warmup', '2', '--size', '128',
+                        '--no-cpu-baseline', '--no-extras', '--no-roofline'], cwd=ROOT, env=env, capture_output=True, text=True,
+                       timeout=420)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])
+    line = [l for l in r.stdout.splitlines() if l.startswith('{')][-1]
+    res = json.loads(line)
+    assert res['value'] > 0 and 'hipgraph x4' in res['config']['launch'], res['config']
+    # and the same step without the process group gives the same throughput class (sanity, not a benchmark)
+    assert res['n_gpus'] == 1
+
+
+def _worker(rank, world, port, out_dir, split):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY='0')
+    os.environ.pop('FSV2V_EMU', None)
+    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    import datetime
+    import torch.distributed as dist
+    import model_checks as mc
+    from importlib import import_module
+    torch.cuda.set_device(rank)
+    dev = torch.device('cuda', rank)
+    dist.init_process_group('nccl', rank=rank, world_size=world, timeout=datetime.timedelta(seconds=120), device_id=dev)
+    M = mc._model()
+    gs = import_module('few-shot-vid2vid_amd.graph_step')
+    opt = mc.tiny_opt(ngf=8, ndf=8, nff=8, warp_ref=True, spade_combine=True, fineSize=64, loadSize=64)
+    model = M.create_model(opt)
+    mc.fill_state(model.netG); mc.fill_state(model.netD)
+    model = model.to(dev).train()
+    opt_G, opt_D = model.build_optimizers(world_size=world, overlap=False, split_backward=split)
+    gi = gs.GraphedIteration(model, opt, warmup=1)
+    tl, ti, rl, ri = [t.to(dev) for t in mc.synth_pose_inputs(1, 64, 64, 300 + rank, 6)]
+    data = [tl, ti, [None, None], [None, None], rl, ri, None, None, None]
+    for it in range(3):                  # eager, capture (+ replay), replay
+        gi(data)
+    torch.cuda.synchronize()
+    torch.save(dict(g={n: p.grad.detach().cpu() for n, p in model.netG.named_parameters()},
+                    p={n: p.detach().cpu() for n, p in model.netG.named_parameters()}),
+               os.path.join(out_dir, 'rccl%d_rank%d.pt' % (int(split), rank)))
+    dist.destroy_process_group()
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs (RCCL over xGMI)")
+def test_two_rank_rccl_two_piece_backward(hip_lib, tmp_path):
+    import torch.multiprocessing as mp
+    world = 2
+    mp.spawn(_worker, args=(world, 29643, str(tmp_path), False), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, 29645, str(tmp_path), True), nprocs=world, join=True)
+    w0 = torch.load(os.path.join(tmp_path, 'rccl0_rank0.pt'))
+    s0 = torch.load(os.path.join(tmp_path, 'rccl1_rank0.pt'))
+    s1 = torch.load(os.path.join(tmp_path, 'rccl1_rank1.pt'))
+    for n in s0['g']:
+        assert torch.equal(s0['g'][n], s1['g'][n]) and torch.equal(s0['p'][n], s1['p'][n]), n
+        scale = max(float(w0['g'][n].abs().max()), 1e-12)
+        # split-K atomics make two runs differ at rounding level; the exchange itself is exact
+        assert float((s0['g'][n] - w0['g'][n]).abs().max()) <= 1e-4 * scale, n
