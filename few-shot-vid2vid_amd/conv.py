@@ -293,8 +293,7 @@ def conv_wgrad(x, dout, geom, w_shape, per_sample=False, scale=None, force_split
     if vec4 and bn >= 64:
         bm = 32 if kdim <= 32 else (64 if kdim <= 64 else 128)
     if force_tile == 0 and vec4 and cout >= 64 and kdim > 64 and os.environ.get('FSV_WGRAD_PLAN', '1') == '1':
-        pch = ((oh * ow if per_sample else n * oh * ow) + 31) // 32
-        bm, bn = (64, 128) if (cout >= 128 and kdim >= 2304 and pch >= 64) else (64, 64)
+        bm, bn = 64, 64
     label = 'fsv_conv_wgrad_kernel<%dx%d,V%d>' % (bm, bn, 4 if vec4 else 1)
     if profile.detail():
         label += ' Kdim%d N%d pix%d z%d' % (geom.ntaps * cin, cout, (oh * ow) if per_sample else n * oh * ow, nb)

@@ -1019,35 +1019,65 @@ static inline long long fsv_tune(int which) {
 
 // Tile / split-K plan shared by the launcher and (through the C ABI) by the host-side profiler labels.
 // tile ids: 0 = 128x128, 1 = 128x64, 2 = 128x32, 3 = 256x32, 4 = 64x64 (BM x BN, pixels x output channels).
+// Predicted duration (seconds) of one gather-GEMM launch with tile `tile` and `nsplit` K splits - a small cost model
+// calibrated on the in-box A/B tables (tools/tile_ab.py, profiles/r02_tile_ab.jsonl: mean error 8 %, picks within 4 % of
+// the best measured configuration on every shape):
+//   * the launch takes as long as its busiest CU: L = ceil(workgroups / 256) workgroups share one CU's matrix pipes - a
+//     launch of 276 workgroups costs as much as one of 512, which is what made the discriminator's 33x33 layers run at
+//     half speed under a rule that only looked at "at least 256 workgroups";
+//   * one K chunk of a BM x BN tile is BM * BN / 4 matrix-pipe cycles; a lone 4-wave workgroup reaches ~78 % of that
+//     rate (LDS latency and the barrier are exposed), two waves per SIMD ~90 %, several workgroups per CU ~95 %;
+//   * prologue + epilogue per workgroup (partly hidden when other workgroups are co-resident), a launch floor, and for
+//     split-K the zero fill, the atomics and the finishing pass.
+static inline double fsv_conv_cost(int Mz, int Cout, int nchunks, int nsamp, int tile, int nsplit) {
+  int bm, bn;
+  if (fsv_tile_dims(tile, bm, bn)) return 1e30;
+  const bool w8 = (tile == 0 || tile == 1 || tile == 9);
+  const double wgs = (double)fsv_cdiv(Mz, bm) * fsv_cdiv(Cout, bn) * nsamp * nsplit;
+  const double L = (double)((long long)((wgs + 255.0) / 256.0));
+  const double cps = (double)fsv_cdiv(nchunks, nsplit);
+  const double cyc = (double)bm * bn / 4.0;
+  const double eff = w8 ? (L <= 1.0 ? 0.91 : 0.97) : (L <= 1.0 ? 0.78 : (L <= 2.0 ? 0.88 : 0.95));
+  const double ovh = (5000.0 + bm * bn / 8.0) * (L <= 1.0 ? 1.0 : 0.45);
+  double t = L * (cps * cyc / eff + ovh) / 1.95e9 + 4e-6;
+  if (nsplit > 1) t += 6e-6 + 0.5e-6 * nsplit + (double)Mz * Cout * nsamp * 4.0 * (2.0 + 0.25 * nsplit) / 3.0e12;
+  return t;
+}
+
 extern "C" int fsv_conv_plan(int Mz, int Cout, int nchunks, int nsamp, int force_tile, int force_split,
                              int* tile_out, int* nsplit_out) {
-  int tile = force_tile;
-  const long long b0 = (long long)fsv_cdiv(Mz, 128) * fsv_cdiv(Cout, 128) * nsamp;      // 128x128 tiles
-  const long long b1 = (long long)fsv_cdiv(Mz, 128) * fsv_cdiv(Cout, 64) * nsamp;       // 128x64
-  const long long b9 = (long long)fsv_cdiv(Mz, 64) * fsv_cdiv(Cout, 128) * nsamp;       // 64x128
-  if (tile < 0) {
-    // in-box A/B on the step's layer shapes (tools/tile_ab.py, profiles/r02_tile_ab.jsonl): the largest tile that still
-    // gives every CU a workgroup wins (128x128 and 64x128 as 8-wave workgroups: 112-124 TFLOP/s at >= 256 workgroups
-    // against 50-60 at 128); below that the 64x64 tile, and split-K only when even it leaves CUs idle
-    if (Cout <= 32) tile = 2;
-    else if (Cout <= 64) tile = (b1 >= 256) ? 1 : 4;
-    else if (b0 >= 256) tile = 0;
-    else if (b9 >= 256) tile = 9;
-    else tile = 4;
+  int tile = force_tile, nsplit = force_split > 0 ? force_split : 1;
+  if (tile < 0 || force_split <= 0) {
+    // candidates: every tile that is not wider than the layer needs (a forced tile: only that one) x split factors that
+    // leave at least 8 chunks (256 K-elements) per split; ties go to the larger tile (less operand traffic per FLOP)
+    static const int tiles[5] = {0, 9, 1, 4, 2};
+    static const int splits[6] = {1, 2, 3, 4, 6, 8};
+    double best = 1e30;
+    int bt = -1, bs = 1;
+    for (int ti = 0; ti < 5; ++ti) {
+      const int t = tiles[ti];
+      if (force_tile >= 0 && t != force_tile) continue;
+      if (force_tile < 0) {
+        if ((t == 0 || t == 9) && Cout <= 64) continue;
+        if (t == 1 && Cout <= 32) continue;
+        if (t == 2 && Cout > 32) continue;
+      }
+      for (int si = 0; si < 6; ++si) {
+        const int sp = splits[si];
+        if (force_split > 0 && sp != 1) break;
+        const int use = force_split > 0 ? force_split : sp;
+        if (use > 1 && nchunks / use < 8) break;
+        const double c = fsv_conv_cost(Mz, Cout, nchunks, nsamp, t, use) * (1.0 + 0.01 * ti);
+        if (c < best) { best = c; bt = t; bs = use; }
+      }
+    }
+    if (bt < 0) { bt = force_tile >= 0 ? force_tile : (Cout <= 32 ? 2 : 4); bs = force_split > 0 ? force_split : 1; }
+    tile = bt; nsplit = bs;
   }
   int bm, bn;
   if (fsv_tile_dims(tile, bm, bn)) return -1;
-  // split-K for launches that would leave most of the 256 CUs idle: ~512 workgroups, at least 16 chunks (512 K-elements)
-  // per split (zero fill + atomics + a finishing pass are the price)
-  long long blocks = (long long)fsv_cdiv(Mz, bm) * fsv_cdiv(Cout, bn) * nsamp;
-  int nsplit = 1;
-  if (force_split > 0) nsplit = force_split;
-  else if (blocks < 256 && nchunks >= 32) {
-    nsplit = (int)((512 + blocks - 1) / blocks);
-    if (nsplit > nchunks / 16) nsplit = nchunks / 16;
-    if (nsplit < 1) nsplit = 1;
-  }
   if (nsplit > nchunks) nsplit = nchunks;
+  if (nsplit < 1) nsplit = 1;
   *tile_out = tile; *nsplit_out = nsplit;
   return 0;
 }

@@ -10,7 +10,7 @@ import fsv2v_amd  # noqa
 from importlib import import_module
 conv = import_module('few-shot-vid2vid_amd.conv')
 dev = torch.device('cuda:0')
-cfgs = [(-1, 0)] + [(t_, s_) for t_ in (0, 1, 2, 4, 9) for s_ in (1, 2, 4)]
+cfgs = [(-1, 0)] + [(t_, s_) for t_ in (0, 1, 2, 4, 9) for s_ in (1, 2, 4, 8)]
 shapes = [('M8192 N256 K2304', 2, 256, 64, 64, 256, 3), ('M32768 N128 K576', 2, 64, 128, 128, 128, 3),
           ('M32768 N128 K1152', 2, 128, 128, 128, 128, 3), ('M32768 N128 K2304', 2, 256, 128, 128, 128, 3),
           ('M2048 N512 K9216', 2, 1024, 32, 32, 512, 3), ('M2048 N512 K2304', 2, 256, 32, 32, 512, 3),
@@ -20,7 +20,10 @@ shapes = [('M8192 N256 K2304', 2, 256, 64, 64, 256, 3), ('M32768 N128 K576', 2, 
           ('M32768 N256 K1152', 2, 128, 128, 128, 256, 3), ('M131072 N128 K576', 2, 64, 256, 256, 128, 3),
           ('M8192 N256 K4608', 2, 512, 64, 64, 256, 3), ('M8192 N256 K9216', 2, 1024, 64, 64, 256, 3),
           ('M2048 N1024 K4608', 2, 512, 32, 32, 1024, 3), ('M8192 N1024 K2304', 2, 256, 64, 64, 1024, 3),
-          ('M32768 N128 K4608', 2, 512, 128, 128, 128, 3), ('M512 N1024 K9216', 2, 1024, 16, 16, 1024, 3)]
+          ('M32768 N128 K4608', 2, 512, 128, 128, 128, 3), ('M512 N1024 K9216', 2, 1024, 16, 16, 1024, 3),
+          # awkward workgroup counts (discriminator 33 x 66 / 17 x 34 maps, k4 s1 p2)
+          ('M4356 N256 K8192', 2, 512, 32, 65, 256, 4), ('M4624 N512 K4096', 2, 256, 33, 67, 512, 4),
+          ('M2048 N512 K9216', 2, 1024, 32, 32, 512, 3)]
 if len(sys.argv) > 1:
     shapes = [s for s in shapes if any(a in s[0] for a in sys.argv[1:])]
 NREP = 20
