@@ -158,9 +158,11 @@ __device__ __forceinline__ void fsv_sum_chunks(const double* part, int g, int c,
 }
 
 // mean/rstd/var per (g, c); optional running-stat update (BatchNorm momentum semantics, unbiased running var)
+// rep: the tensor the statistics describe holds every value `rep` times (statistics of a nearest x2 up-sampled tensor taken
+// from its source: rep = 4) - mean and biased variance are those of the source, the unbiased correction counts P * rep values
 __global__ __launch_bounds__(256) void fsv_stats_final_kernel(const double* part, float* mean, float* rstd, int G, int C,
                                                               int P, int nchunks, float eps, float* run_mean,
-                                                              float* run_var, float momentum) {
+                                                              float* run_var, float momentum, int rep) {
   const int idx = blockIdx.x * 4 + (threadIdx.x >> 6);      // one wave per (g, c)
   const bool ok = idx < G * C;
   const int g = ok ? idx / C : 0, c = ok ? idx - g * C : 0;
@@ -173,7 +175,8 @@ __global__ __launch_bounds__(256) void fsv_stats_final_kernel(const double* part
   mean[idx] = (float)mu;
   rstd[idx] = (float)(1.0 / sqrt(var + (double)eps));
   if (run_mean && G == 1) {
-    double unb = P > 1 ? var * ((double)P / (double)(P - 1)) : var;
+    const double cnt = (double)P * (double)rep;
+    double unb = cnt > 1.0 ? var * (cnt / (cnt - 1.0)) : var;
     run_mean[c] = (1.f - momentum) * run_mean[c] + momentum * (float)mu;
     run_var[c] = (1.f - momentum) * run_var[c] + momentum * (float)unb;
   }
@@ -342,16 +345,23 @@ int fsv_norm_workspace_doubles(int G, int P, int C) {
   return G * pl.nchunks * C * 2;
 }
 
+int fsv_norm_stats_rep(const float* x, double* workspace, float* mean, float* rstd, int G, int P, int C, float eps,
+                       float* run_mean, float* run_var, float momentum, int rep, hipStream_t stream);
 int fsv_norm_stats(const float* x, double* workspace, float* mean, float* rstd, int G, int P, int C, float eps,
                    float* run_mean, float* run_var, float momentum, hipStream_t stream) {
-  if (!x || !workspace || !mean || !rstd || G < 1 || P < 1 || C < 1) return FSV_ERR_BAD_ARG;
+  return fsv_norm_stats_rep(x, workspace, mean, rstd, G, P, C, eps, run_mean, run_var, momentum, 1, stream);
+}
+
+int fsv_norm_stats_rep(const float* x, double* workspace, float* mean, float* rstd, int G, int P, int C, float eps,
+                       float* run_mean, float* run_var, float momentum, int rep, hipStream_t stream) {
+  if (!x || !workspace || !mean || !rstd || G < 1 || P < 1 || C < 1 || rep < 1) return FSV_ERR_BAD_ARG;
   RedPlan pl = fsv_red_plan(G, P, C);
   const int nchunks = pl.nchunks;
   RedP rp; rp.a = x; rp.y = nullptr; rp.x = nullptr; rp.mean = nullptr; rp.rstd = nullptr; rp.part = workspace;
   rp.P = P; rp.C = C; rp.act = 0;
   fsv_launch_red<FSV_RED_STATS>(pl, rp, G, stream);
   FSV_LAUNCH(fsv_stats_final_kernel, dim3(fsv_cdiv(G * C, 4)), dim3(256), stream, (const double*)workspace, mean, rstd,
-             G, C, P, nchunks, eps, run_mean, run_var, momentum);
+             G, C, P, nchunks, eps, run_mean, run_var, momentum, rep);
   return fsv_check_launch();
 }
 

@@ -35,7 +35,16 @@ struct SpadeP {
   int N, HW, C, ldw;
   long long stat_bstride;
   int act;
+  int W, up;              // up = 1: x is the HALF-resolution tensor [N][H/2][W/2][C] and is read through the nearest-x2
+                          // up-sampling index (generator.py:124 folded into this kernel: the up-sampled tensor is never written)
 };
+
+// source element of x for output pixel m of sample z (identity, or the parent pixel of the nearest x2 up-sampling)
+__device__ __forceinline__ long long fsv_sp_xpix(const SpadeP& p, int z, int m) {
+  if (!p.up) return (long long)z * p.HW + m;
+  const int y = m / p.W, xx = m - y * p.W;
+  return (long long)z * (p.HW >> 2) + (long long)(y >> 1) * (p.W >> 1) + (xx >> 1);
+}
 
 template <int BM, int BN, int WM, int WN>
 __global__ __launch_bounds__(256) void fsv_spade_mod_kernel(SpadeP p) {
@@ -77,7 +86,7 @@ __global__ __launch_bounds__(256) void fsv_spade_mod_kernel(SpadeP p) {
         const int row = (r & 3) + 8 * (r >> 2) + 4 * lk;
         const int m = bm0 + wm * (TM * 32) + i * 32 + row;
         float v = 0.f;
-        if (cok && m < p.HW) v = (p.x[(pix0 + m) * p.C + c] - mu) * rs;
+        if (cok && m < p.HW) v = (p.x[fsv_sp_xpix(p, z, m) * p.C + c] - mu) * rs;
         outv[i][j][r] = v;
       }
   }
@@ -207,6 +216,7 @@ struct SpadeBwdP {
   long long total;        // N*HW*C
   long long HWC;          // per-sample elements (for per-sample statistics)
   long long stat_bstride;
+  int HW, W, up;          // up = 1: x is the half-resolution tensor (see SpadeP); dxhat is still written per full-resolution pixel
 };
 
 __global__ __launch_bounds__(256) void fsv_spade_bwd_elem_kernel(SpadeBwdP p) {
@@ -219,7 +229,13 @@ __global__ __launch_bounds__(256) void fsv_spade_bwd_elem_kernel(SpadeBwdP p) {
     const float mu = p.mean[n * p.stat_bstride + c], rs = p.rstd[n * p.stat_bstride + c];
     float o[FSV_SP_MAXMAPS + 1];
     float g[FSV_SP_MAXMAPS];
-    o[0] = (p.x[i] - mu) * rs;
+    long long xi = i;
+    if (p.up) {
+      const int rem = (int)(pix - n * p.HW);
+      const int y = rem / p.W, xx = rem - y * p.W;
+      xi = ((n * (p.HW >> 2)) + (long long)(y >> 1) * (p.W >> 1) + (xx >> 1)) * p.C + c;
+    }
+    o[0] = (p.x[xi] - mu) * rs;
 #pragma unroll
     for (int k = 0; k < FSV_SP_MAXMAPS; ++k) {
       if (k < p.nmaps) {
@@ -298,8 +314,9 @@ int fsv_spade_mod_fwd(const float* x, const float* mean, const float* rstd, floa
                       int nmaps, const float* const* maps, const float* const* wg, const float* const* wb,
                       const float* const* bg, const float* const* bb, const int* ch, const long long* w_bstride,
                       const long long* b_bstride, int N, int HW, int C, int ldw, long long stat_bstride, int act,
-                      hipStream_t stream) {
+                      int W, int up, hipStream_t stream) {
   if (!x || !mean || !rstd || !h || nmaps < 0 || nmaps > FSV_SP_MAXMAPS || C < 1 || (ldw & 3)) return FSV_ERR_BAD_ARG;
+  if (up && (W < 2 || (W & 1) || HW % W != 0 || ((HW / W) & 1))) return FSV_ERR_BAD_ARG;
   SpadeP p;
   p.x = x; p.mean = mean; p.rstd = rstd; p.h = h; p.nmaps = nmaps;
   for (int k = 0; k < FSV_SP_MAXMAPS; ++k) {
@@ -310,6 +327,7 @@ int fsv_spade_mod_fwd(const float* x, const float* mean, const float* rstd, floa
     if (on && ((ch[k] & 3) || !maps[k] || !wg[k] || !wb[k] || !bg[k] || !bb[k])) return FSV_ERR_UNSUPPORTED;
   }
   p.N = N; p.HW = HW; p.C = C; p.ldw = ldw; p.stat_bstride = stat_bstride; p.act = act;
+  p.W = up ? W : 1; p.up = up ? 1 : 0;
   if (C <= 32) {
     dim3 g(fsv_cdiv(HW, 128), fsv_cdiv(C, 32), N);
     FSV_LAUNCH((fsv_spade_mod_kernel<128, 32, 4, 1>), g, dim3(256), stream, p);
@@ -322,8 +340,9 @@ int fsv_spade_mod_fwd(const float* x, const float* mean, const float* rstd, floa
 
 int fsv_spade_bwd_elem(const float* x, const float* mean, const float* rstd, const float* dh, const float* h,
                        int nmaps, const float* const* gb, float* const* dgb, float* dxhat,
-                       int N, int HW, int C, long long stat_bstride, int act, hipStream_t stream) {
+                       int N, int HW, int C, long long stat_bstride, int act, int W, int up, hipStream_t stream) {
   if (!x || !mean || !rstd || !dh || !dxhat || nmaps < 0 || nmaps > FSV_SP_MAXMAPS) return FSV_ERR_BAD_ARG;
+  if (up && (W < 2 || (W & 1) || HW % W != 0 || ((HW / W) & 1))) return FSV_ERR_BAD_ARG;
   if (act == FSV_ACT_LRELU && !h) return FSV_ERR_BAD_ARG;
   if (act != FSV_ACT_LRELU && act != FSV_ACT_NONE) return FSV_ERR_UNSUPPORTED;
   SpadeBwdP p;
@@ -331,6 +350,7 @@ int fsv_spade_bwd_elem(const float* x, const float* mean, const float* rstd, con
   for (int k = 0; k < FSV_SP_MAXMAPS; ++k) { p.gb[k] = k < nmaps ? gb[k] : nullptr; p.dgb[k] = k < nmaps ? dgb[k] : nullptr; }
   p.nmaps = nmaps; p.C = C; p.act = act;
   p.total = (long long)N * HW * C; p.HWC = (long long)HW * C; p.stat_bstride = stat_bstride;
+  p.HW = HW; p.W = up ? W : 1; p.up = up ? 1 : 0;
   long long g = (p.total + 256 * 4 - 1) / (256 * 4);
   if (g > 8192) g = 8192;
   if (g < 1) g = 1;

@@ -164,7 +164,7 @@ class SPADE(nn.Module):
         self.norm = BatchNorm(norm_nc, affine=False)
         self.norm_nc = norm_nc
 
-    def forward(self, x, maps, weights=None, act=ACT_NONE):
+    def forward(self, x, maps, weights=None, act=ACT_NONE, up=False):
         if not isinstance(maps, list):
             maps = [maps]
         use_maps, use_w = [], []
@@ -186,7 +186,7 @@ class SPADE(nn.Module):
             use_maps.append(m)
         self.norm.note_forward()
         return ops.spade_mod(x, use_maps, use_w, self.norm.running_mean, self.norm.running_var, act=act,
-                             training=self.training)
+                             training=self.training, up=up)
 
 
 class SPADEResnetBlock(nn.Module):
@@ -212,11 +212,17 @@ class SPADEResnetBlock(nn.Module):
             if self.learned_shortcut:
                 self.bn_s = BatchNorm(fin)
 
-    def forward(self, x, label=None, norm_weights=None):
+    def forward(self, x, label=None, norm_weights=None, up=False):
+        """up=True: x is the block input BEFORE the nearest x2 up-sampling of generator.py:124.  With a learned shortcut
+        the up-sampled tensor is consumed only by bn_0 and bn_s, which read x through the up-sampling index (ops.spade_mod
+        up=True) - it is never written; otherwise it is materialised here."""
         nw = norm_weights if norm_weights else [None] * 3
+        fold = up and self.spade and self.learned_shortcut and x.shape[1] % 16 == 0 and ops.spade_can_fold_upsample()
+        if up and not fold:
+            x = ops.upsample2x(x)
         if self.spade:
-            x_s = self.conv_s(self.bn_s(x, label, nw[2], act=ACT_NONE)) if self.learned_shortcut else x
-            dx = self.conv_0(self.bn_0(x, label, nw[0], act=ACT_LRELU))
+            x_s = self.conv_s(self.bn_s(x, label, nw[2], act=ACT_NONE, up=fold)) if self.learned_shortcut else x
+            dx = self.conv_0(self.bn_0(x, label, nw[0], act=ACT_LRELU, up=fold))
             return self.conv_1(self.bn_1(dx, label, nw[1], act=ACT_LRELU), res=x_s)
         x_s = self.conv_s(self.bn_s(x)) if self.learned_shortcut else x
         dx = self.conv_0(self.bn_0(x, act=ACT_LRELU))
@@ -565,9 +571,7 @@ class FewShotGenerator(nn.Module):
             x = getattr(self, 'ref_img_down_%d' % i)(x)
         for i in range(self.n_downsample_G, -1, -1):
             nw = norm_w[i] if (self.adap_spade and i < self.n_adaptive_layers) else None
-            x = getattr(self, 'up_%d' % i)(x, enc_label[i], nw)
-            if i != 0:
-                x = ops.upsample2x(x)
+            x = getattr(self, 'up_%d' % i)(x, enc_label[i], nw, up=(i != self.n_downsample_G))
         return self.conv_img(ops.activation(x, ACT_LRELU), act=ACT_TANH)
 
     def flow_generation(self, label, label_ref, img_ref, prev):
@@ -614,9 +618,9 @@ class FewShotGenerator(nn.Module):
                 enc_label[i] = [enc_label[i]] + [e[i] if e is not None else None for e in emb]
         for i in range(self.n_downsample_G, -1, -1):
             nw = norm_w[i] if (self.adap_spade and i < self.n_adaptive_layers) else None
-            x = getattr(self, 'up_%d' % i)(x, enc_label[i], nw)
-            if i != 0:
-                x = ops.upsample2x(x)
+            # generator.py:121-124: the nearest x2 up-sampling after block i + 1 is handed to block i (up=True), whose SPADE
+            # kernels read through the up-sampling index
+            x = getattr(self, 'up_%d' % i)(x, enc_label[i], nw, up=(i != self.n_downsample_G))
         img_raw = self.conv_img(ops.activation(x, ACT_LRELU), act=ACT_TANH)
         if not self.spade_combine:
             img_final = img_raw

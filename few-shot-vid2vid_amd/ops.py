@@ -27,6 +27,7 @@ lib.register_sigs({
     "fsv_warp_fwd": [c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_llp, c_llp, c_llp, c_p],
     "fsv_warp_bwd": [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_llp, c_llp, c_llp, c_llp, c_llp, c_p],
     "fsv_norm_stats": [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_f, c_p, c_p, c_f, c_p],
+    "fsv_norm_stats_rep": [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_f, c_p, c_p, c_f, c_i, c_p],
     "fsv_norm_apply": [c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p],
     "fsv_norm_bwd": [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p],
     "fsv_norm_sums": [c_p, c_p, c_p, c_i, c_i, c_p],
@@ -36,8 +37,8 @@ lib.register_sigs({
     "fsv_colsum": [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p],
     "fsv_spade_prep": [c_p, c_p, c_p, c_p, c_ll, c_ll, c_ll, c_ll, c_p, c_p, c_p, c_i, c_i, c_i, c_p],
     "fsv_spade_mod_fwd": [c_p, c_p, c_p, c_p, c_i, c_pp, c_pp, c_pp, c_pp, c_pp, c_ip, c_llp, c_llp,
-                          c_i, c_i, c_i, c_i, c_ll, c_i, c_p],
-    "fsv_spade_bwd_elem": [c_p, c_p, c_p, c_p, c_p, c_i, c_pp, c_pp, c_p, c_i, c_i, c_i, c_ll, c_i, c_p],
+                          c_i, c_i, c_i, c_i, c_ll, c_i, c_i, c_i, c_p],
+    "fsv_spade_bwd_elem": [c_p, c_p, c_p, c_p, c_p, c_i, c_pp, c_pp, c_p, c_i, c_i, c_i, c_ll, c_i, c_i, c_i, c_p],
     "fsv_upsample2x_fwd": [c_p, c_p, c_i, c_i, c_i, c_i, c_p],
     "fsv_upsample2x_bwd": [c_p, c_p, c_i, c_i, c_i, c_i, c_p],
     "fsv_act_fwd": [c_p, c_p, c_ll, c_i, c_p],
@@ -493,7 +494,8 @@ def bn_sync_world(groups=1):
     return _bn_sync[0] if (_bn_sync is not None and groups == 1) else 1
 
 
-def norm_stats(x, groups, pixels, channels, eps, run_mean=None, run_var=None, momentum=0.1):
+def norm_stats(x, groups, pixels, channels, eps, run_mean=None, run_var=None, momentum=0.1, rep=1):
+    """rep > 1: the normalised tensor repeats every value of x `rep` times (nearest x2 up-sampling folded into the consumer)"""
     mean = torch.empty(groups * channels, dtype=torch.float32, device=x.device)
     rstd = torch.empty_like(mean)
     lib.check_device(x, run_mean, run_var)
@@ -505,6 +507,11 @@ def norm_stats(x, groups, pixels, channels, eps, run_mean=None, run_var=None, mo
         dist.all_reduce(sums, op=dist.ReduceOp.SUM, group=_bn_sync[1])
         lib.call("fsv_norm_stats_from_sums", lib.ptr(sums), float(pixels) * _bn_sync[0], lib.ptr(mean), lib.ptr(rstd),
                  channels, float(eps), lib.ptr(run_mean), lib.ptr(run_var), float(momentum), lib.stream_ptr())
+        return mean, rstd
+    if rep != 1:
+        lib.call("fsv_norm_stats_rep", lib.ptr(x), lib.ptr(ws), lib.ptr(mean), lib.ptr(rstd),
+                 groups, pixels, channels, float(eps), lib.ptr(run_mean), lib.ptr(run_var), float(momentum), int(rep),
+                 lib.stream_ptr())
         return mean, rstd
     lib.call("fsv_norm_stats", lib.ptr(x), lib.ptr(ws), lib.ptr(mean), lib.ptr(rstd),
              groups, pixels, channels, float(eps), lib.ptr(run_mean), lib.ptr(run_var), float(momentum),
@@ -588,8 +595,17 @@ class _SpadeFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, act, training, eps, momentum, x, run_mean, run_var, *rest):
+        # act may be (act, up): up = 1 -> x is the HALF-resolution tensor; the kernels read it through the nearest x2
+        # up-sampling index (generator.py:124 folded into SPADE: the up-sampled tensor is never written) and the statistics
+        # are those of x with every value counted four times
+        up = 0
+        if isinstance(act, tuple):
+            act, up = act
         x = to_nhwc(x)
         n, c, h, w = x.shape
+        xs_h, xs_w = h, w                   # geometry of x as stored
+        if up:
+            h, w = 2 * h, 2 * w             # geometry of the normalised / modulated tensor
         nmaps = len(rest) // 5
         maps = [to_nhwc(rest[5 * k]) for k in range(nmaps)]
         wgs = [rest[5 * k + 1] for k in range(nmaps)]
@@ -597,16 +613,17 @@ class _SpadeFn(torch.autograd.Function):
         bgs = [rest[5 * k + 3] for k in range(nmaps)]
         bbs = [rest[5 * k + 4] for k in range(nmaps)]
         if training or run_mean is None:
-            mean, rstd = norm_stats(x, 1, n * h * w, c, eps, run_mean, run_var, momentum)
+            mean, rstd = norm_stats(x, 1, n * xs_h * xs_w, c, eps, run_mean, run_var, momentum, rep=4 if up else 1)
         else:
             mean = run_mean.detach().clone()
             rstd = torch.rsqrt(run_var.detach() + eps)
         g1 = Geom(1, 1, 1, 0)
         for k in range(nmaps):
-            if maps[k].shape[2:] != x.shape[2:]:
+            if tuple(maps[k].shape[2:]) != (h, w):
                 raise ValueError("SPADE maps must already be at the resolution of x")
         chs = [m.shape[1] for m in maps]
-        hout = torch.empty_like(x)
+        hout = empty_nhwc(n, c, h, w, x)
+        ctx.up = up
         lib.check_device(x, *maps)
         # fast path (every production width): ONE preparation launch per map builds the combined [gamma | beta] operands
         # that the modulation kernel, the backward recompute and the data gradient all use as they are
@@ -653,7 +670,7 @@ class _SpadeFn(torch.autograd.Function):
             with profile.scope('fsv_spade_mod_kernel', 2.0 * n * h * w * c * 2 * sum(chs)):
                 lib.call("fsv_spade_mod_fwd", lib.ptr(x), lib.ptr(mean), lib.ptr(rstd), lib.ptr(hout), nmaps, _pp(maps),
                          arr(wg_p), arr(wb_p), arr(bg_p), arr(bb_p), lib.int_array(chs + [0]), _ll(wstr + [0]),
-                         _ll(bstr + [0]), n, h * w, c, ldw, 0, act, lib.stream_ptr())
+                         _ll(bstr + [0]), n, h * w, c, ldw, 0, act, w, up, lib.stream_ptr())
             ctx.nmaps, ctx.act = nmaps, act
             ctx.batch_stats = bool(training or run_mean is None)
             ctx.world = bn_sync_world(1) if ctx.batch_stats else 1
@@ -674,7 +691,7 @@ class _SpadeFn(torch.autograd.Function):
         with profile.scope('fsv_spade_mod_kernel', 2.0 * n * h * w * c * 2 * sum(chs)):
             lib.call("fsv_spade_mod_fwd", lib.ptr(x), lib.ptr(mean), lib.ptr(rstd), lib.ptr(hout), nmaps, _pp(maps),
                      _pp(wg_t), _pp(wb_t), _pp(bg_c), _pp(bb_c), lib.int_array(chs + [0]), _ll(wbs_stride + [0]),
-                     _ll(bbs_stride + [0]), n, h * w, c, ldw, 0, act, lib.stream_ptr())
+                     _ll(bbs_stride + [0]), n, h * w, c, ldw, 0, act, w, up, lib.stream_ptr())
         ctx.nmaps, ctx.act = nmaps, act
         ctx.batch_stats = bool(training or run_mean is None)
         ctx.world = bn_sync_world(1) if ctx.batch_stats else 1
@@ -688,7 +705,9 @@ class _SpadeFn(torch.autograd.Function):
         x, hout, mean, rstd = saved[:4]
         maps = saved[4:4 + nm]
         dh = to_nhwc(dh)
-        n, c, h, w = x.shape
+        n, c, xs_h, xs_w = x.shape
+        up = ctx.up
+        h, w = (2 * xs_h, 2 * xs_w) if up else (xs_h, xs_w)
         g1 = Geom(1, 1, 1, 0)
         fast = ctx.fast
         gbs, wcats = [], []
@@ -712,14 +731,21 @@ class _SpadeFn(torch.autograd.Function):
                 wcats.append(wcat)
         # 2) elementwise chain backward
         dgbs = [torch.empty_like(gb) for gb in gbs]
-        dxhat = torch.empty_like(x)
+        dxhat = torch.empty_like(hout)
         lib.call("fsv_spade_bwd_elem", lib.ptr(x), lib.ptr(mean), lib.ptr(rstd), lib.ptr(dh), lib.ptr(hout), nm,
-                 _pp(gbs), _pp(dgbs), lib.ptr(dxhat), n, h * w, c, 0, ctx.act, lib.stream_ptr())
-        # 3) param-free BatchNorm backward
+                 _pp(gbs), _pp(dgbs), lib.ptr(dxhat), n, h * w, c, 0, ctx.act, w, up, lib.stream_ptr())
+        # 3) param-free BatchNorm backward.  With the up-sampling folded in, xhat of the four children of a source pixel
+        # is the same value, so with dxhat summed over the children the backward is exactly the BatchNorm backward of
+        # the half-resolution tensor (s1 = sum dxhat, s2 = sum dxhat * xhat, count = source pixels).
         dx = None
         if ctx.needs_input_grad[4]:
+            if up:
+                pooled = empty_nhwc(n, c, xs_h, xs_w, dxhat)
+                lib.call("fsv_upsample2x_bwd", lib.ptr(dxhat), lib.ptr(pooled), n, xs_h, xs_w, c, lib.stream_ptr())
+                dxhat = pooled
             if ctx.batch_stats:
-                dx, _, _ = bn_backward(dxhat, None, x, mean, rstd, None, 1, n * h * w, c, ACT_NONE, False, False, ctx.world)
+                dx, _, _ = bn_backward(dxhat, None, x, mean, rstd, None, 1, n * xs_h * xs_w, c, ACT_NONE, False, False,
+                                       ctx.world)
             else:
                 dx = dxhat * rstd.view(1, c, 1, 1)
         grads = []
@@ -758,12 +784,18 @@ class _SpadeFn(torch.autograd.Function):
         return (None, None, None, None, dx, None, None, *grads)
 
 
-def spade_mod(x, maps, weights, run_mean=None, run_var=None, act=ACT_LRELU, training=True, eps=1e-5, momentum=0.1):
-    """maps: list of tensors; weights: list of (wg, wb, bg, bb) per map (see _SpadeFn)."""
+def spade_mod(x, maps, weights, run_mean=None, run_var=None, act=ACT_LRELU, training=True, eps=1e-5, momentum=0.1, up=False):
+    """maps: list of tensors; weights: list of (wg, wb, bg, bb) per map (see _SpadeFn).  up=True: x is at half the
+    resolution of the maps and stands for its nearest x2 up-sampling (never materialised)."""
     flat = []
     for m, (wg, wb, bg, bb) in zip(maps, weights):
         flat += [m, wg, wb, bg, bb]
-    return _SpadeFn.apply(act, training, eps, momentum, x, run_mean, run_var, *flat)
+    return _SpadeFn.apply((act, 1) if up else act, training, eps, momentum, x, run_mean, run_var, *flat)
+
+
+def spade_can_fold_upsample():
+    """the folded form needs per-replica statistics (the cross-replica path exchanges sums of the materialised tensor)"""
+    return bn_sync_world(1) == 1
 
 
 # ------------------------------------------------------------------------------------------------ upsample

@@ -130,22 +130,30 @@ int fsv_spade_prep(const float* wg, const float* wb, const float* bg, const floa
                    fsv_stream_t stream);
 /* ---- SPADE (csrc/spade.hip) - replaces SPADE.forward normalization.py:37-52 + actvn architecture.py:95-97 --------
  * h = act( (...((x - mean) * rstd) * (1 + g_0) + b_0 ...) * (1 + g_{n-1}) + b_{n-1} ),  g_k = map_k @ Wg_k + bg_k.
- * One launch; gamma/beta are MFMA accumulators and never reach HBM. */
+ * One launch; gamma/beta are MFMA accumulators and never reach HBM.
+ * up != 0: x is the half-resolution tensor [N][H/2][W/2][C] (H = HW / W) and is read through the nearest x2 up-sampling
+ * index - F.interpolate(scale_factor=2) of generator.py:124 folded into its consumer; W is only used then. */
 int fsv_spade_mod_fwd(const float* x, const float* mean, const float* rstd, float* h,
                       int nmaps, const float* const* maps, const float* const* wg, const float* const* wb,
                       const float* const* bg, const float* const* bb, const int* ch, const long long* w_bstride,
                       const long long* b_bstride, int N, int HW, int C, int ldw, long long stat_bstride, int act,
-                      fsv_stream_t stream);
-/* element-wise part of the backward: from materialised gamma|beta ([P][2C] per map) to d(gamma|beta) and d(xhat) */
+                      int W, int up, fsv_stream_t stream);
+/* element-wise part of the backward: from materialised gamma|beta ([P][2C] per map) to d(gamma|beta) and d(xhat) (dxhat is
+ * written per full-resolution pixel also when up != 0: summing it over the 2x2 children gives the gradient of the
+ * half-resolution normalised tensor) */
 int fsv_spade_bwd_elem(const float* x, const float* mean, const float* rstd, const float* dh, const float* h,
                        int nmaps, const float* const* gb, float* const* dgb, float* dxhat,
-                       int N, int HW, int C, long long stat_bstride, int act, fsv_stream_t stream);
+                       int N, int HW, int C, long long stat_bstride, int act, int W, int up, fsv_stream_t stream);
 
 /* ---- normalisation (csrc/norm.hip) - BatchNorm (apex SyncBatchNorm) normalization.py:33,80; InstanceNorm :35,82 ----
  * tensors are [G][P][C]: BatchNorm G=1, P=N*H*W; InstanceNorm G=N, P=H*W.  workspace: fsv_norm_workspace_doubles(). */
 int fsv_norm_workspace_doubles(int G, int P, int C);
 int fsv_norm_stats(const float* x, double* workspace, float* mean, float* rstd, int G, int P, int C, float eps,
                    float* run_mean, float* run_var, float momentum, fsv_stream_t stream);
+/* statistics of a tensor that repeats every value of x `rep` times (nearest x2 up-sampling: rep = 4): mean / rstd are those
+ * of x, the unbiased running-variance correction counts P * rep values */
+int fsv_norm_stats_rep(const float* x, double* workspace, float* mean, float* rstd, int G, int P, int C, float eps,
+                       float* run_mean, float* run_var, float momentum, int rep, fsv_stream_t stream);
 int fsv_norm_apply(const float* x, const float* mean, const float* rstd, const float* w, const float* b, float* y,
                    int G, int P, int C, int act, fsv_stream_t stream);
 int fsv_norm_bwd(const float* dy, const float* y, const float* x, const float* mean, const float* rstd, const float* w,

@@ -283,13 +283,15 @@ def check_norm(device, instance, n=3, c=10, h=7, w=5, affine=True, act='lrelu', 
         assert_close('running_var', rvd, rv)
 
 
-def check_spade(device, nmaps=1, generated=True, n=2, c=12, ch=8, h=6, w=5, act='lrelu', seed=5, strided=False):
+def check_spade(device, nmaps=1, generated=True, n=2, c=12, ch=8, h=6, w=5, act='lrelu', seed=5, strided=False, up=False):
     """SPADE with per-sample generated weights for map 0 and fixed weights for the extra maps.  strided: the generated
     weights / biases are views into one [n, L] tensor, the way the weight-generating FC hands them over
-    (generator.py reshape_weight); c % 16 == 0 takes the single-preparation-launch path of ops._SpadeFn."""
+    (generator.py reshape_weight); c % 16 == 0 takes the single-preparation-launch path of ops._SpadeFn.  up: x is handed
+    over at half resolution and the kernels read it through the nearest x2 up-sampling index (generator.py:124 folded in);
+    the reference up-samples explicitly (h, w must be even)."""
     ops, conv = pkg()
     g = torch.Generator().manual_seed(seed)
-    x = torch.randn(n, c, h, w, generator=g) + 0.3
+    x = torch.randn(n, c, h // 2, w // 2, generator=g) + 0.3 if up else torch.randn(n, c, h, w, generator=g) + 0.3
     maps = [torch.randn(n, ch, h, w, generator=g) for _ in range(nmaps)]
     leaves_ref, leaves_dev = [], []
 
@@ -329,14 +331,21 @@ def check_spade(device, nmaps=1, generated=True, n=2, c=12, ch=8, h=6, w=5, act=
             bb_r, bb_d = leaf(torch.randn(c, generator=g) * 0.3)
             fixed_r.append((wg_r, bg_r, wb_r, bb_r))
         weights_d.append((wg_d, wb_d, bg_d, bb_d))
-    ref = O.spade(xr, maps_r, fixed_r, gen_r)
+    run_mean_r, run_var_r = torch.zeros(c), torch.ones(c)
+    x_in = F.interpolate(xr, scale_factor=2, mode='nearest') if up else xr
+    ref = O.spade(x_in, maps_r, fixed_r, gen_r)
+    F.batch_norm(x_in.detach(), run_mean_r, run_var_r, training=True, momentum=0.1, eps=1e-5)      # running statistics
     if act == 'lrelu':
         ref = O.actvn(ref)
     dy = torch.randn(ref.shape, generator=g)
     ref.backward(dy)
-    y = ops.spade_mod(xd, maps_d, weights_d, act=conv.ACT_LRELU if act == 'lrelu' else conv.ACT_NONE)
+    run_mean_d, run_var_d = _dev(torch.zeros(c), device), _dev(torch.ones(c), device)
+    y = ops.spade_mod(xd, maps_d, weights_d, run_mean_d, run_var_d, act=conv.ACT_LRELU if act == 'lrelu' else conv.ACT_NONE,
+                      up=up)
     y.backward(_dev(dy, device))
     assert_close('spade h', y, ref)
+    assert_close('spade running mean', run_mean_d, run_mean_r, 1e-5)
+    assert_close('spade running var', run_var_d, run_var_r, 1e-5)
     for i, (a, d) in enumerate(zip(leaves_ref, leaves_dev)):
         assert_close('spade grad %d' % i, d.grad, a.grad)
 

@@ -137,3 +137,10 @@ def test_every_gemm_tile(hip_lib):
 @pytest.mark.gpu
 def test_avgpool3s2(hip_lib):
     oc.check_avgpool3s2(torch.device('cuda:0'))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('nmaps,generated,c,ch', [(1, True, 32, 16), (3, True, 64, 32), (2, False, 16, 8), (1, True, 12, 8)])
+def test_spade_with_folded_upsample(hip_lib, nmaps, generated, c, ch):
+    """x at half resolution, read through the nearest x2 index; c = 12 takes the general (non-prepared) path"""
+    oc.check_spade(torch.device('cuda:0'), nmaps=nmaps, generated=generated, c=c, ch=ch, h=12, w=10, up=True)
