@@ -13,7 +13,7 @@
 // denormalisation, the (1 + gamma) * . + beta modulation of every map in sequence and the activation before
 // the single write of h.  gamma/beta never touch HBM.  Layout NHWC; grid.z = sample so that per-sample and
 // shared weights can be mixed (a per-map batch stride of 0 means shared).
-#include "fsv_common.h"
+#include "conv_igemm.h"
 
 #define FSV_SP_BK 32
 #define FSV_SP_MAXMAPS 3
@@ -35,6 +35,11 @@ struct SpadeP {
   int N, HW, C, ldw;
   long long stat_bstride;
   int act;
+  // backward twin (BWD = true): upstream gradient in, d(gamma|beta) per map ([P][2C]: gamma columns [0, C), beta [C, 2C)) and
+  // d(xhat) out; h is not written
+  const float* dh;
+  float* dgb[FSV_SP_MAXMAPS];
+  float* dxhat;
   int W, up;              // up = 1: x is the HALF-resolution tensor [N][H/2][W/2][C] and is read through the nearest-x2
                           // up-sampling index (generator.py:124 folded into this kernel: the up-sampled tensor is never written)
 };
@@ -46,7 +51,12 @@ __device__ __forceinline__ long long fsv_sp_xpix(const SpadeP& p, int z, int m) 
   return (long long)z * (p.HW >> 2) + (long long)(y >> 1) * (p.W >> 1) + (xx >> 1);
 }
 
-template <int BM, int BN, int WM, int WN>
+// BWD = true is the backward twin: the same two GEMMs recompute gamma / beta of every map in registers (they never reach HBM
+// in either direction), the forward chain o_0 = xhat, o_{k+1} = o_k (1 + g_k) + b_k is replayed keeping g_k and o_k, and the
+// epilogue walks it backwards:  d = dh * act'(o_n);  for k = n-1 .. 0:  dbeta_k = d,  dgamma_k = d * o_k,  d *= (1 + g_k);
+// dxhat = d.  (Round 1 materialised gamma | beta as [P][2C] per map with the gather-GEMM kernel and read them back in an
+// element-wise pass: 236 MB read + 175 MB written per launch more than this.)
+template <int BM, int BN, int WM, int WN, bool BWD>
 __global__ __launch_bounds__(256) void fsv_spade_mod_kernel(SpadeP p) {
   constexpr int BK = FSV_SP_BK;
   constexpr int TM = BM / (WM * 32), TN = BN / (WN * 32);
@@ -71,6 +81,8 @@ __global__ __launch_bounds__(256) void fsv_spade_mod_kernel(SpadeP p) {
 
   // running value of the normalised + modulated activation, in MFMA C/D layout
   f32x16 outv[TM][TN];
+  // backward twin: g_k and o_k of every map (BWD only; dead code otherwise)
+  f32x16 keep_g[BWD ? FSV_SP_MAXMAPS : 1][TM][TN], keep_o[BWD ? FSV_SP_MAXMAPS : 1][TM][TN];
   const float* mean = p.mean + z * p.stat_bstride;
   const float* rstd = p.rstd + z * p.stat_bstride;
   const long long pix0 = (long long)z * p.HW;
@@ -182,9 +194,42 @@ __global__ __launch_bounds__(256) void fsv_spade_mod_kernel(SpadeP p) {
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int r = 0; r < 16; ++r)
-          outv[i][j][r] = outv[i][j][r] * (1.f + (accg[i][j][r] + bgv)) + (accb[i][j][r] + bbv);
+        for (int r = 0; r < 16; ++r) {
+          const float gk = accg[i][j][r] + bgv;
+          if constexpr (BWD) { keep_g[k][i][j][r] = gk; keep_o[k][i][j][r] = outv[i][j][r]; }
+          outv[i][j][r] = outv[i][j][r] * (1.f + gk) + (accb[i][j][r] + bbv);
+        }
     }
+  }
+
+  if constexpr (BWD) {
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int c = bn0 + wn * (TN * 32) + j * 32 + lrow;
+      if (c >= p.C) continue;
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = (r & 3) + 8 * (r >> 2) + 4 * lk;
+          const int m = bm0 + wm * (TM * 32) + i * 32 + row;
+          if (m >= p.HW) continue;
+          const long long pix = pix0 + m;
+          float d = p.dh[pix * p.C + c];
+          if (p.act == FSV_ACT_LRELU) d = (outv[i][j][r] > 0.f) ? d : 0.2f * d;
+#pragma unroll
+          for (int k = FSV_SP_MAXMAPS - 1; k >= 0; --k) {
+            if (k < p.nmaps) {
+              float* dg = p.dgb[k] + pix * 2 * p.C;
+              dg[p.C + c] = d;
+              dg[c] = d * keep_o[k][i][j][r];
+              d = d * (1.f + keep_g[k][i][j][r]);
+            }
+          }
+          p.dxhat[pix * p.C + c] = d;
+        }
+    }
+    return;
   }
 
 #pragma unroll
@@ -330,11 +375,38 @@ int fsv_spade_mod_fwd(const float* x, const float* mean, const float* rstd, floa
   p.W = up ? W : 1; p.up = up ? 1 : 0;
   if (C <= 32) {
     dim3 g(fsv_cdiv(HW, 128), fsv_cdiv(C, 32), N);
-    FSV_LAUNCH((fsv_spade_mod_kernel<128, 32, 4, 1>), g, dim3(256), stream, p);
+    FSV_LAUNCH((fsv_spade_mod_kernel<128, 32, 4, 1, false>), g, dim3(256), stream, p);
   } else {
     dim3 g(fsv_cdiv(HW, 128), fsv_cdiv(C, 64), N);
-    FSV_LAUNCH((fsv_spade_mod_kernel<128, 64, 2, 2>), g, dim3(256), stream, p);
+    FSV_LAUNCH((fsv_spade_mod_kernel<128, 64, 2, 2, false>), g, dim3(256), stream, p);
   }
+  return fsv_check_launch();
+}
+
+// Backward twin of fsv_spade_mod_fwd (see the kernel comment): same operands, dh in, dgb[k] ([P][2C] per map) and dxhat out.
+int fsv_spade_mod_bwd(const float* x, const float* mean, const float* rstd, const float* dh,
+                      int nmaps, const float* const* maps, const float* const* wg, const float* const* wb,
+                      const float* const* bg, const float* const* bb, const int* ch, const long long* w_bstride,
+                      const long long* b_bstride, float* const* dgb, float* dxhat, int N, int HW, int C, int ldw,
+                      long long stat_bstride, int act, int W, int up, hipStream_t stream) {
+  if (!x || !mean || !rstd || !dh || !dgb || !dxhat || nmaps < 0 || nmaps > FSV_SP_MAXMAPS || C < 1 || (ldw & 3)) return FSV_ERR_BAD_ARG;
+  if (act != FSV_ACT_LRELU && act != FSV_ACT_NONE) return FSV_ERR_UNSUPPORTED;
+  if (up && (W < 2 || (W & 1) || HW % W != 0 || ((HW / W) & 1))) return FSV_ERR_BAD_ARG;
+  SpadeP p;
+  p.x = x; p.mean = mean; p.rstd = rstd; p.h = nullptr; p.nmaps = nmaps; p.dh = dh; p.dxhat = dxhat;
+  for (int k = 0; k < FSV_SP_MAXMAPS; ++k) {
+    bool on = k < nmaps;
+    p.map[k] = on ? maps[k] : nullptr; p.wg[k] = on ? wg[k] : nullptr; p.wb[k] = on ? wb[k] : nullptr;
+    p.bg[k] = on ? bg[k] : nullptr; p.bb[k] = on ? bb[k] : nullptr; p.dgb[k] = on ? dgb[k] : nullptr;
+    p.ch[k] = on ? ch[k] : 0; p.w_bstride[k] = on ? w_bstride[k] : 0; p.b_bstride[k] = on ? b_bstride[k] : 0;
+    if (on && ((ch[k] & 3) || !maps[k] || !wg[k] || !wb[k] || !bg[k] || !bb[k] || !dgb[k])) return FSV_ERR_UNSUPPORTED;
+  }
+  p.N = N; p.HW = HW; p.C = C; p.ldw = ldw; p.stat_bstride = stat_bstride; p.act = act;
+  p.W = up ? W : 1; p.up = up ? 1 : 0;
+  // 64 x 64 tiles: every wave keeps g_k and o_k of up to three maps for a 32 x 32 sub-tile (96 + 48 accumulator registers),
+  // which leaves room for several workgroups per CU - the kernel is HBM bound
+  dim3 g(fsv_cdiv(HW, 64), fsv_cdiv(C, 64), N);
+  FSV_LAUNCH((fsv_spade_mod_kernel<64, 64, 2, 2, true>), g, dim3(256), stream, p);
   return fsv_check_launch();
 }
 

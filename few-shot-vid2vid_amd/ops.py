@@ -39,6 +39,8 @@ lib.register_sigs({
     "fsv_spade_mod_fwd": [c_p, c_p, c_p, c_p, c_i, c_pp, c_pp, c_pp, c_pp, c_pp, c_ip, c_llp, c_llp,
                           c_i, c_i, c_i, c_i, c_ll, c_i, c_i, c_i, c_p],
     "fsv_spade_bwd_elem": [c_p, c_p, c_p, c_p, c_p, c_i, c_pp, c_pp, c_p, c_i, c_i, c_i, c_ll, c_i, c_i, c_i, c_p],
+    "fsv_spade_mod_bwd": [c_p, c_p, c_p, c_p, c_i, c_pp, c_pp, c_pp, c_pp, c_pp, c_ip, c_llp, c_llp, c_pp, c_p,
+                          c_i, c_i, c_i, c_i, c_ll, c_i, c_i, c_i, c_p],
     "fsv_upsample2x_fwd": [c_p, c_p, c_i, c_i, c_i, c_i, c_p],
     "fsv_upsample2x_bwd": [c_p, c_p, c_i, c_i, c_i, c_i, c_p],
     "fsv_act_fwd": [c_p, c_p, c_ll, c_i, c_p],
@@ -711,29 +713,48 @@ class _SpadeFn(torch.autograd.Function):
         g1 = Geom(1, 1, 1, 0)
         fast = ctx.fast
         gbs, wcats = [], []
-        if fast:
+        dxhat = torch.empty_like(hout)
+        fused = fast and _os.environ.get('FSV_SPADE_FUSED_BWD', '1') == '1'          # in-box A/B switch
+        if fused:
+            # fused backward twin of the modulation kernel: gamma / beta are recomputed in registers, never materialised
             prepped = saved[4 + nm:]
+            dgbs = [empty_nhwc(n, 2 * c, h, w, x) for _ in range(nm)]
+            wg_p, wb_p, bg_p, bb_p, wstr, bstr, chs = [], [], [], [], [], [], []
             for k in range(nm):
                 wcat_t, bcat = prepped[3 * k], prepped[3 * k + 2]
-                gbs.append(conv_forward(maps[k], wcat_t, 2 * c, 2 * c, g1, bias=bcat, per_sample=ctx.per_sample[k]))
+                wg_p.append(wcat_t.data_ptr()); wb_p.append(wcat_t.data_ptr() + 4 * c)
+                bg_p.append(bcat.data_ptr()); bb_p.append(bcat.data_ptr() + 4 * c)
+                wstr.append(wcat_t.shape[-2] * 2 * c if ctx.per_sample[k] else 0)
+                bstr.append(2 * c if ctx.per_sample[k] else 0)
+                chs.append(maps[k].shape[1])
+            arr = lambda v: (ctypes.c_void_p * max(len(v), 1))(*v)
+            lib.check_device(x, dh, *maps)
+            lib.call("fsv_spade_mod_bwd", lib.ptr(x), lib.ptr(mean), lib.ptr(rstd), lib.ptr(dh), nm, _pp(maps), arr(wg_p),
+                     arr(wb_p), arr(bg_p), arr(bb_p), lib.int_array(chs + [0]), _ll(wstr + [0]), _ll(bstr + [0]), _pp(dgbs),
+                     lib.ptr(dxhat), n, h * w, c, 2 * c, 0, ctx.act, w, up, lib.stream_ptr())
         else:
-            wgs = saved[4 + nm:4 + 2 * nm]
-            wbs = saved[4 + 2 * nm:4 + 3 * nm]
-            bgs = saved[4 + 3 * nm:4 + 4 * nm]
-            bbs = saved[4 + 4 * nm:4 + 5 * nm]
-            # 1) recompute gamma|beta of every map with the gather-GEMM kernel ([P][2C] each)
-            for k in range(nm):
-                per_sample = wgs[k].dim() == 5
-                wcat = torch.cat([wgs[k].detach(), wbs[k].detach()], dim=-4)
-                bcat = torch.cat([bgs[k].detach(), bbs[k].detach()], dim=-1).contiguous()
-                wt, _, ldw = prep_weight(wcat, 0, g1)
-                gbs.append(conv_forward(maps[k], wt, ldw, 2 * c, g1, bias=bcat, per_sample=per_sample))
-                wcats.append(wcat)
-        # 2) elementwise chain backward
-        dgbs = [torch.empty_like(gb) for gb in gbs]
-        dxhat = torch.empty_like(hout)
-        lib.call("fsv_spade_bwd_elem", lib.ptr(x), lib.ptr(mean), lib.ptr(rstd), lib.ptr(dh), lib.ptr(hout), nm,
-                 _pp(gbs), _pp(dgbs), lib.ptr(dxhat), n, h * w, c, 0, ctx.act, w, up, lib.stream_ptr())
+            if fast:
+                prepped = saved[4 + nm:]
+                for k in range(nm):
+                    wcat_t, bcat = prepped[3 * k], prepped[3 * k + 2]
+                    gbs.append(conv_forward(maps[k], wcat_t, 2 * c, 2 * c, g1, bias=bcat, per_sample=ctx.per_sample[k]))
+            else:
+                wgs = saved[4 + nm:4 + 2 * nm]
+                wbs = saved[4 + 2 * nm:4 + 3 * nm]
+                bgs = saved[4 + 3 * nm:4 + 4 * nm]
+                bbs = saved[4 + 4 * nm:4 + 5 * nm]
+                # 1) recompute gamma|beta of every map with the gather-GEMM kernel ([P][2C] each)
+                for k in range(nm):
+                    per_sample = wgs[k].dim() == 5
+                    wcat = torch.cat([wgs[k].detach(), wbs[k].detach()], dim=-4)
+                    bcat = torch.cat([bgs[k].detach(), bbs[k].detach()], dim=-1).contiguous()
+                    wt, _, ldw = prep_weight(wcat, 0, g1)
+                    gbs.append(conv_forward(maps[k], wt, ldw, 2 * c, g1, bias=bcat, per_sample=per_sample))
+                    wcats.append(wcat)
+            # 2) elementwise chain backward
+            dgbs = [torch.empty_like(gb) for gb in gbs]
+            lib.call("fsv_spade_bwd_elem", lib.ptr(x), lib.ptr(mean), lib.ptr(rstd), lib.ptr(dh), lib.ptr(hout), nm,
+                     _pp(gbs), _pp(dgbs), lib.ptr(dxhat), n, h * w, c, 0, ctx.act, w, up, lib.stream_ptr())
         # 3) param-free BatchNorm backward.  With the up-sampling folded in, xhat of the four children of a source pixel
         # is the same value, so with dxhat summed over the children the backward is exactly the BatchNorm backward of
         # the half-resolution tensor (s1 = sum dxhat, s2 = sum dxhat * xhat, count = source pixels).
@@ -795,7 +816,7 @@ def spade_mod(x, maps, weights, run_mean=None, run_var=None, act=ACT_LRELU, trai
 
 def spade_can_fold_upsample():
     """the folded form needs per-replica statistics (the cross-replica path exchanges sums of the materialised tensor)"""
-    return bn_sync_world(1) == 1
+    return bn_sync_world(1) == 1 and _os.environ.get('FSV_SPADE_FOLD', '1') == '1'            # env: in-box A/B switch
 
 
 # ------------------------------------------------------------------------------------------------ upsample

@@ -138,7 +138,15 @@ int fsv_spade_mod_fwd(const float* x, const float* mean, const float* rstd, floa
                       const float* const* bg, const float* const* bb, const int* ch, const long long* w_bstride,
                       const long long* b_bstride, int N, int HW, int C, int ldw, long long stat_bstride, int act,
                       int W, int up, fsv_stream_t stream);
-/* element-wise part of the backward: from materialised gamma|beta ([P][2C] per map) to d(gamma|beta) and d(xhat) (dxhat is
+/* backward twin of fsv_spade_mod_fwd: the same operands plus the upstream gradient dh; gamma / beta are recomputed in
+ * registers, outputs are dgb[k] = d(gamma | beta) of every map ([P][2C], gamma in columns [0, C)) and dxhat [P][C] (per
+ * full-resolution pixel also when up != 0).  act: FSV_ACT_NONE or FSV_ACT_LRELU. */
+int fsv_spade_mod_bwd(const float* x, const float* mean, const float* rstd, const float* dh,
+                      int nmaps, const float* const* maps, const float* const* wg, const float* const* wb,
+                      const float* const* bg, const float* const* bb, const int* ch, const long long* w_bstride,
+                      const long long* b_bstride, float* const* dgb, float* dxhat, int N, int HW, int C, int ldw,
+                      long long stat_bstride, int act, int W, int up, fsv_stream_t stream);
+/* element-wise part of the backward (general path, C % 16 != 0): from materialised gamma|beta ([P][2C] per map) to d(gamma|beta) and d(xhat) (dxhat is
  * written per full-resolution pixel also when up != 0: summing it over the 2x2 children gives the gradient of the
  * half-resolution normalised tensor) */
 int fsv_spade_bwd_elem(const float* x, const float* mean, const float* rstd, const float* dh, const float* h,
