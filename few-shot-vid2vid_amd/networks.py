@@ -14,7 +14,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from . import ops
+from . import ops, streams
 from .conv import ACT_LRELU, ACT_NONE, ACT_SIGMOID, ACT_TANH
 
 
@@ -265,6 +265,11 @@ class LabelEmbedder(nn.Module):
                     setattr(self, 'up_%d' % i, _seq(_Slot(), Conv2d(ch_i, ch[i], 3, padding=1), _Slot()))
 
     def forward(self, x, weights=None):
+        return self.decode_maps(self.encode_maps(x), weights)
+
+    def encode_maps(self, x):
+        """the part that needs no generated weights: the encoder and the decoder levels with parameters of their own (it
+        runs next to the reference encoders that produce those weights, see FewShotGenerator.flow_branch)"""
         if x is None:
             return None
         n = self.n
@@ -276,21 +281,35 @@ class LabelEmbedder(nn.Module):
                 raise NotImplementedError("adaptive strided embedding convs are not used by any shipped config")
         if not self.decode:
             return out
+        skips = out
         if not self.unet:
             out = [out[-1]]
+        out = list(out)
         for i in reversed(range(n)):
-            cur = out[-1]
-            if self.unet and i != n - 1:
-                cur = ops.cat_channels([cur, out[i + 1]])
-            if i >= self.params_free_layers:
-                out.append(getattr(self, 'up_%d' % i)[1](ops.upsample2x(cur), act=ACT_LRELU))
-            else:
-                # a 1x1 convolution commutes with nearest up-sampling: run the generated-weight conv on the
-                # quarter-size tensor, then up-sample (bit-identical, 4x fewer MACs and bytes)
-                w, b = weights[i]
-                out.append(ops.upsample2x(ops.batch_conv(cur, w, b, act=ACT_LRELU)))
+            if i < self.params_free_layers:
+                break
+            out.append(self._up(i, out[-1], skips, None))
+        return out, skips
+
+    def _up(self, i, cur, skips, weights):
+        if self.unet and i != self.n - 1:
+            cur = ops.cat_channels([cur, skips[i + 1]])
+        if i >= self.params_free_layers:
+            return getattr(self, 'up_%d' % i)[1](ops.upsample2x(cur), act=ACT_LRELU)
+        # a 1x1 convolution commutes with nearest up-sampling: run the generated-weight conv on the quarter-size
+        # tensor, then up-sample (bit-identical, 4x fewer MACs and bytes)
+        w, b = weights[i]
+        return ops.upsample2x(ops.batch_conv(cur, w, b, act=ACT_LRELU))
+
+    def decode_maps(self, state, weights=None):
+        if state is None or not self.decode:
+            return state
+        out, skips = state
+        out = list(out)
+        for i in reversed(range(min(self.n, self.params_free_layers))):
+            out.append(self._up(i, out[-1], skips, weights))
         if self.unet:
-            out = out[n:]
+            out = out[self.n:]
         return out[::-1]
 
 
@@ -540,7 +559,9 @@ class FewShotGenerator(nn.Module):
             enc.append(prod.permute(0, 2, 1, 3))                                  # [b, c(i), c(j), 1]
         return x, enc[::-1]
 
-    def weight_generation(self, img_ref, label_ref, label, t=0):
+    def weight_generation(self, img_ref, label_ref, label, t=0, label_maps_elsewhere=False):
+        """returns (x, label maps, SPADE weights); with `label_maps_elsewhere` the middle entry is the generated embedding
+        weights instead (label_embedding.encode_maps runs next to the flow network, forward() finishes with decode_maps)"""
         b, n, c, h, w = img_ref.shape
         img_ref, label_ref = img_ref.reshape(b * n, -1, h, w), label_ref.reshape(b * n, -1, h, w)
         # generator.py:370,403-416: at test time (isTrain False, one reference) the generated weights of frame 0 are kept
@@ -558,8 +579,10 @@ class FewShotGenerator(nn.Module):
                 self._cached_weights = (embed_w, norm_w)
         else:
             embed_w, norm_w = self._cached_weights
-        enc_label = self.label_embedding(label, weights=(embed_w if self.adap_embed else None))
-        return x, enc_label, norm_w
+        embed_w = embed_w if self.adap_embed else None
+        if label_maps_elsewhere:
+            return x, embed_w, norm_w
+        return x, self.label_embedding(label, weights=embed_w), norm_w
 
     def forward_face(self, label, label_refs, img_refs, img_coarse):
         """generator.py:232-242 (the --refine_face generator): the decoder starts from the encoding of the COARSE face
@@ -590,9 +613,22 @@ class FewShotGenerator(nn.Module):
                 ds[1] = ops.cat_channels([warp[1], mask[1]])
         return flow, mask, warp, ds
 
+    def combine_embeddings(self, ds):
+        """generator.py:218-225 (--spade_combine): SPADE maps from the warped reference / previous image"""
+        if not self.spade_combine:
+            return None
+        return [self.img_ref_embedding(ds[0]), self.img_prev_embedding(ds[1]) if ds[1] is not None else None]
+
+    def flow_branch(self, label, label_ref, img_ref, prev, with_label_maps=False):
+        """everything of the forward pass that needs neither the reference encoders nor the generated weights: flow network,
+        warp, the SPADE maps of the warped image and (with_label_maps) the weight-free part of the label embedding"""
+        flow, mask, warp, ds = self.flow_generation(label, label_ref, img_ref, prev)
+        emb = self.combine_embeddings(ds)
+        return flow, mask, warp, emb, (self.label_embedding.encode_maps(label) if with_label_maps else None)
+
     def stage2_parameters(self):
-        """parameters below the BackwardCut boundary of forward(): SPADE-combine image embeddings, decoder blocks, output conv"""
-        names = ('up_', 'conv_img', 'img_ref_embedding', 'img_prev_embedding')
+        """parameters below the BackwardCut boundary of forward(): decoder blocks, output conv"""
+        names = ('up_', 'conv_img')
         return [p for n, p in self.named_parameters() if n.startswith(names)]
 
     def forward(self, label, label_refs, img_refs, prev=(None, None), t=0, img_coarse=None):
@@ -602,18 +638,27 @@ class FewShotGenerator(nn.Module):
         self._sn_group.update(self.training)
         if img_coarse is not None:
             return self.forward_face(label, label_refs, img_refs, img_coarse)
-        x, enc_label, norm_w = self.weight_generation(img_refs, label_refs, label, t=t)
-        atn_vis, ref_idx = self._atn
-        label_ref, img_ref = pick_ref(label_refs, ref_idx), pick_ref(img_refs, ref_idx)
-        flow, mask, warp, ds = self.flow_generation(label, label_ref, img_ref, prev)
+        if self.n_shot == 1 and label_refs.shape[1] == 1:
+            # The flow branch (flow network, warp, the SPADE maps of the warped image) depends on nothing the reference
+            # encoders / weight generators produce: two parallel branches (streams.fork).  With attention (n_shot > 1) it
+            # needs ref_idx first.
+            (x, embed_w, norm_w), (flow, mask, warp, emb, maps) = streams.fork(label, [
+                lambda: self.weight_generation(img_refs, label_refs, label, t=t, label_maps_elsewhere=True),
+                lambda: self.flow_branch(label, label_refs[:, 0], img_refs[:, 0], prev, with_label_maps=True)])
+            enc_label = self.label_embedding.decode_maps(maps, embed_w)
+            atn_vis, ref_idx = self._atn
+        else:
+            x, enc_label, norm_w = self.weight_generation(img_refs, label_refs, label, t=t)
+            atn_vis, ref_idx = self._atn
+            label_ref, img_ref = pick_ref(label_refs, ref_idx), pick_ref(img_refs, ref_idx)
+            flow, mask, warp, emb, _ = self.flow_branch(label, label_ref, img_ref, prev)
         cut = getattr(self, 'bwd_cut', None)
         if cut is not None and torch.is_grad_enabled():
-            # stage boundary (see BackwardCut): everything above is "stage 1", the image embeddings and the decoder below
-            # are "stage 2" (stage2_parameters)
-            x, enc_label, norm_w, flow, mask, warp, ds = cut.split((x, enc_label, norm_w, flow, mask, warp, ds))
+            # stage boundary (see BackwardCut): everything above is "stage 1", the decoder below is "stage 2"
+            # (stage2_parameters)
+            x, enc_label, norm_w, flow, mask, warp, emb = cut.split((x, enc_label, norm_w, flow, mask, warp, emb))
             enc_label = list(enc_label)
         if self.spade_combine:
-            emb = [self.img_ref_embedding(ds[0]), self.img_prev_embedding(ds[1]) if ds[1] is not None else None]
             for i in range(self.n_sc_layers):
                 enc_label[i] = [enc_label[i]] + [e[i] if e is not None else None for e in emb]
         for i in range(self.n_downsample_G, -1, -1):

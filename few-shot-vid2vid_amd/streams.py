@@ -1,0 +1,72 @@
+"""Independent branches of one forward pass on side HIP streams.
+
+The few-shot generator is a wide graph of small problems: most launches of the reference encoders and weight generators
+(16x16 ... 64x64 maps, weight-generator MLPs, per-channel reductions) fill a fraction of the 256 CUs, and the flow network /
+warp / image-embedding branch does not depend on them.  `fork` issues such branches on different streams, so that they become
+parallel branches of the captured hipGraph (and overlap in the eager loop as far as the host keeps up).  Autograd runs every
+backward node on the stream of its forward op and orders the streams itself, so the backward pass overlaps the same way.
+
+Measured on the C3 bench step (profiles/r02_notes.md): one coarse fork with few tensors crossing it pays (-3.6 ms of 60);
+finer forks (the two reference encoders against each other, the loss terms against the discriminator pass) each cost 2-3 ms
+with the ROCm 7.2 graph executor - every cross-stream edge autograd adds splits the graph's packet batches - and were dropped.
+
+Results are bit-identical to the sequential order: the same kernels run on the same data, only concurrently; no kernel of the
+library shares scratch memory with another launch (workspaces come from the stream-aware caching allocator).
+
+FSV_BRANCH_STREAMS=0 restores the single-stream order (A/B measurements, debugging).
+"""
+import os
+
+import torch
+
+ENABLED = os.environ.get('FSV_BRANCH_STREAMS', '1') == '1'
+_pool = {}
+_busy = []          # side streams with an open (not yet joined) branch: nested forks take others
+
+
+def _side_streams(device, n, avoid):
+    got = _pool.setdefault(device, [])
+    out, k = [], 0
+    while len(out) < n:
+        if k == len(got):
+            got.append(torch.cuda.Stream(device=device))
+        if got[k] != avoid and not any(got[k] is b for b in _busy):
+            out.append(got[k])
+        k += 1
+    return out
+
+
+def _record(obj, stream):
+    if torch.is_tensor(obj):
+        if obj.is_cuda:
+            obj.record_stream(stream)
+    elif isinstance(obj, (list, tuple)):
+        for o in obj:
+            _record(o, stream)
+    elif isinstance(obj, dict):
+        for o in obj.values():
+            _record(o, stream)
+
+
+def fork(ref, fns):
+    """[f() for f in fns]; on a GPU fns[1:] run on side streams next to fns[0] on the current one and are joined before the
+    return.  `ref` is any tensor of the pass (it names the device; CPU / emulated tensors run the branches in order)."""
+    if not (ENABLED and torch.is_tensor(ref) and ref.is_cuda) or len(fns) < 2:
+        return [f() for f in fns]
+    cur = torch.cuda.current_stream(ref.device)
+    sides = _side_streams(ref.device, len(fns) - 1, cur)
+    outs = [None] * len(fns)
+    _busy.extend(sides)
+    try:
+        for s, i in zip(sides, range(1, len(fns))):
+            s.wait_stream(cur)
+            with torch.cuda.stream(s):
+                outs[i] = fns[i]()
+        outs[0] = fns[0]()
+    finally:
+        for s in sides:
+            _busy.remove(s)
+    for s, i in zip(sides, range(1, len(fns))):
+        cur.wait_stream(s)
+        _record(outs[i], cur)
+    return outs

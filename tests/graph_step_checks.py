@@ -62,4 +62,20 @@ if __name__ == '__main__':
         for k in ('d', 'g'):
             for x, y in zip(a[k], b[k]):
                 assert abs(x - y) <= 5e-2 * max(abs(x), 1.0), (it, k, a[k], b[k])
+    # the same loop on one stream (streams.ENABLED off): the forked branches only reorder launches in time
+    from importlib import import_module
+    streams = import_module('few-shot-vid2vid_amd.streams')
+    assert streams.ENABLED, "branch streams are expected on by default"
+    streams.ENABLED = False
+    one, _, _, _ = _run(dev, False, 5, 500, kw)
+    streams.ENABLED = True
+    for it, (a, b, c) in enumerate(zip(one, ref, got)):
+        for other in (b, c):
+            for k in ('d', 'g'):
+                for x, y in zip(a[k], other[k]):
+                    assert abs(x - y) <= 5e-2 * max(abs(x), 1.0), (it, k, a[k], other[k])
+    for other in (ref, got):      # first iteration, before any weight update: rounding-level agreement
+        assert float((one[0]['img'] - other[0]['img']).abs().max()) <= 1e-4
+        for x, y in zip(one[0]['d'] + one[0]['g'], other[0]['d'] + other[0]['g']):
+            assert abs(x - y) <= 1e-4 * max(abs(x), 1.0), (one[0], other[0])
     print('GRAPH_STEP_GPU_OK', flush=True)
