@@ -20,7 +20,7 @@
 // combined in fp64 across the block and written as part[g][chunk][c][2]; a finalize kernel sums the chunks.
 struct RedPlan { int V, CU, TX, TY, nslabs, rows_per_blk, nchunks; };
 
-static inline RedPlan fsv_red_plan(int G, int P, int C) {
+static inline RedPlan fsv_red_plan(int G, int P, int C, int max_chunks = 0) {
   RedPlan r;
   r.V = (C % 4 == 0) ? 4 : 1;
   r.CU = C / r.V;
@@ -31,6 +31,7 @@ static inline RedPlan fsv_red_plan(int G, int P, int C) {
   long long want = (2048 + (long long)r.nslabs * G - 1) / ((long long)r.nslabs * G);   // chunks for ~2048 blocks
   long long maxc = ((long long)P + r.TY * 4 - 1) / (r.TY * 4);                          // >= 4 rows per thread
   long long chunks = want < maxc ? want : maxc;
+  if (max_chunks > 0 && chunks > max_chunks) chunks = max_chunks;
   if (chunks < 1) chunks = 1;
   r.rows_per_blk = (int)(((long long)P + chunks - 1) / chunks);
   r.nchunks = (P + r.rows_per_blk - 1) / r.rows_per_blk;
@@ -58,7 +59,16 @@ struct RedP {
   const float* rstd;
   double* part;
   int P, C, CU, TX, TY, rows_per_blk, nchunks, act;
+  // fused second stage (counter != null): the workgroup that finishes last on a channel slab sums the partials of that
+  // slab and writes the final values, so the reduction is ONE launch.  o0..o3 by mode:
+  //   STATS : mean, rstd, run_mean, run_var      BWD : s1, s2, dw, db      COLSUM : out
+  int* counter;         // one zeroed int per channel slab; the last workgroup resets it
+  float *o0, *o1, *o2, *o3;
+  float eps, momentum;
+  int rep, accumulate;
 };
+
+__device__ __forceinline__ void fsv_sum_chunks(const double* part, int g, int c, int C, int nchunks, double& a, double& b);
 
 template <int MODE, int V>
 __global__ __launch_bounds__(256) void fsv_red2_kernel(RedP p) {
@@ -136,6 +146,81 @@ __global__ __launch_bounds__(256) void fsv_red2_kernel(RedP p) {
       dst[0] = a; dst[1] = b;
     }
   }
+  if (p.counter == nullptr) return;
+  // ---- fused second stage: last workgroup of this slab (over all chunks and groups) ------------------------------------
+  __shared__ int is_last;
+  __threadfence();                       // this thread's partials are visible device-wide before the ticket is taken
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const int total = (int)(gridDim.x * gridDim.z);
+    const int prev = atomicAdd(p.counter + slab, 1);
+    is_last = (prev == total - 1) ? 1 : 0;
+    if (is_last) p.counter[slab] = 0;    // nobody else touches the ticket any more: leave it ready for the next launch
+  }
+  __syncthreads();
+  if (!is_last) return;
+  __threadfence();                       // acquire: the other workgroups' partials
+  const int G = (int)gridDim.z;
+  const int wave = threadIdx.x >> 6;
+  const bool lead = (threadIdx.x & 63) == 0;
+  for (int cc = wave; cc < p.TX * V; cc += 4) {
+    const int c = slab * p.TX * V + cc;
+    if (c >= p.C) break;
+    if (MODE == FSV_RED_BWD) {
+      double ta = 0.0, tb = 0.0;
+      for (int gg = 0; gg < G; ++gg) {
+        double a, b;
+        fsv_sum_chunks(p.part, gg, c, p.C, p.nchunks, a, b);
+        if (lead) { p.o0[gg * p.C + c] = (float)a; p.o1[gg * p.C + c] = (float)b; }
+        ta += a; tb += b;
+      }
+      if (lead && p.o2) p.o2[c] = (float)tb;
+      if (lead && p.o3) p.o3[c] = (float)ta;
+    } else {
+      for (int gg = 0; gg < G; ++gg) {
+        double a, b;
+        fsv_sum_chunks(p.part, gg, c, p.C, p.nchunks, a, b);
+        if (!lead) continue;
+        const int idx = gg * p.C + c;
+        if (MODE == FSV_RED_COLSUM) {
+          p.o0[idx] = p.accumulate ? p.o0[idx] + (float)a : (float)a;
+        } else {
+          double mu = a / p.P;
+          double var = b / p.P - mu * mu;
+          if (var < 0.0) var = 0.0;
+          p.o0[idx] = (float)mu;
+          p.o1[idx] = (float)(1.0 / sqrt(var + (double)p.eps));
+          if (p.o2 && G == 1) {
+            const double cnt = (double)p.P * (double)p.rep;
+            double unb = cnt > 1.0 ? var * (cnt / (cnt - 1.0)) : var;
+            p.o2[c] = (1.f - p.momentum) * p.o2[c] + p.momentum * (float)mu;
+            p.o3[c] = (1.f - p.momentum) * p.o3[c] + p.momentum * (float)unb;
+          }
+        }
+      }
+    }
+  }
+}
+
+static inline void fsv_red_no_tail(RedP& p) {
+  p.counter = nullptr; p.o0 = p.o1 = p.o2 = p.o3 = nullptr; p.eps = 0.f; p.momentum = 0.f; p.rep = 1; p.accumulate = 0;
+}
+
+// The fused second stage pays while the whole reduction is launch-bound: the last workgroup of a slab reads nchunks x slab
+// partials alone, so the chunk count is capped and tensors above FSV_NORM_FUSE_MAX_MB (default 16 MB) keep two launches.
+#define FSV_RED_FUSED_CHUNKS 64
+#define FSV_RED_COUNTERS 64
+static inline long long fsv_red_fuse_max_elems() {
+  static long long v = -1;
+  if (v < 0) {
+    const char* e = getenv("FSV_NORM_FUSE_MAX_MB");
+    double mb = e ? atof(e) : 16.0;
+    v = (long long)(mb * 1024.0 * 1024.0 / 4.0);
+  }
+  return v;
+}
+static inline bool fsv_red_fused(const int* counters, int G, int P, int C) {
+  return counters != nullptr && (long long)G * P * C <= fsv_red_fuse_max_elems();
 }
 
 template <int MODE>
@@ -358,7 +443,7 @@ int fsv_norm_stats_rep(const float* x, double* workspace, float* mean, float* rs
   RedPlan pl = fsv_red_plan(G, P, C);
   const int nchunks = pl.nchunks;
   RedP rp; rp.a = x; rp.y = nullptr; rp.x = nullptr; rp.mean = nullptr; rp.rstd = nullptr; rp.part = workspace;
-  rp.P = P; rp.C = C; rp.act = 0;
+  rp.P = P; rp.C = C; rp.act = 0; fsv_red_no_tail(rp);
   fsv_launch_red<FSV_RED_STATS>(pl, rp, G, stream);
   FSV_LAUNCH(fsv_stats_final_kernel, dim3(fsv_cdiv(G * C, 4)), dim3(256), stream, (const double*)workspace, mean, rstd,
              G, C, P, nchunks, eps, run_mean, run_var, momentum, rep);
@@ -391,7 +476,7 @@ int fsv_norm_bwd(const float* dy, const float* y, const float* x, const float* m
   RedPlan pl = fsv_red_plan(G, P, C);
   const int nchunks = pl.nchunks;
   RedP rp; rp.a = dy; rp.y = y; rp.x = x; rp.mean = mean; rp.rstd = rstd; rp.part = workspace;
-  rp.P = P; rp.C = C; rp.act = act;
+  rp.P = P; rp.C = C; rp.act = act; fsv_red_no_tail(rp);
   fsv_launch_red<FSV_RED_BWD>(pl, rp, G, stream);
   FSV_LAUNCH(fsv_norm_bwd_final_kernel, dim3(fsv_cdiv(C, 4)), dim3(256), stream, (const double*)workspace, s1, s2, dw,
              db, G, C, nchunks);
@@ -406,10 +491,58 @@ int fsv_colsum(const float* x, double* workspace, float* out, int G, int P, int 
   RedPlan pl = fsv_red_plan(G, P, C);
   const int nchunks = pl.nchunks;
   RedP rp; rp.a = x; rp.y = nullptr; rp.x = nullptr; rp.mean = nullptr; rp.rstd = nullptr; rp.part = workspace;
-  rp.P = P; rp.C = C; rp.act = 0;
+  rp.P = P; rp.C = C; rp.act = 0; fsv_red_no_tail(rp);
   fsv_launch_red<FSV_RED_COLSUM>(pl, rp, G, stream);
   FSV_LAUNCH(fsv_colsum_final_kernel, dim3(fsv_cdiv(G * C, 4)), dim3(256), stream, (const double*)workspace, out, G,
              C, nchunks, accumulate);
+  return fsv_check_launch();
+}
+
+// ---- one-launch forms: `counters` = zeroed ints (>= FSV_RED_COUNTERS, owned by the caller, left zeroed) -----------------------
+int fsv_norm_stats_fused(const float* x, double* workspace, float* mean, float* rstd, int G, int P, int C, float eps,
+                         float* run_mean, float* run_var, float momentum, int rep, int* counters, hipStream_t stream) {
+  if (!fsv_red_fused(counters, G, P, C))
+    return fsv_norm_stats_rep(x, workspace, mean, rstd, G, P, C, eps, run_mean, run_var, momentum, rep, stream);
+  if (!x || !workspace || !mean || !rstd || G < 1 || P < 1 || C < 1 || rep < 1) return FSV_ERR_BAD_ARG;
+  RedPlan pl = fsv_red_plan(G, P, C, FSV_RED_FUSED_CHUNKS);
+  if (pl.nslabs > FSV_RED_COUNTERS) return FSV_ERR_UNSUPPORTED;
+  RedP rp; rp.a = x; rp.y = nullptr; rp.x = nullptr; rp.mean = nullptr; rp.rstd = nullptr; rp.part = workspace;
+  rp.P = P; rp.C = C; rp.act = 0; fsv_red_no_tail(rp);
+  rp.counter = counters; rp.o0 = mean; rp.o1 = rstd; rp.o2 = run_mean; rp.o3 = run_var; rp.eps = eps; rp.momentum = momentum;
+  rp.rep = rep;
+  fsv_launch_red<FSV_RED_STATS>(pl, rp, G, stream);
+  return fsv_check_launch();
+}
+
+int fsv_norm_bwd_fused(const float* dy, const float* y, const float* x, const float* mean, const float* rstd, const float* w,
+                       double* workspace, float* s1, float* s2, float* dx, float* dw, float* db, int G, int P, int C, int act,
+                       int fixed_stats, int* counters, hipStream_t stream) {
+  if (!fsv_red_fused(counters, G, P, C))
+    return fsv_norm_bwd(dy, y, x, mean, rstd, w, workspace, s1, s2, dx, dw, db, G, P, C, act, fixed_stats, stream);
+  if (!dy || !x || !mean || !rstd || !workspace || !s1 || !s2 || !dx) return FSV_ERR_BAD_ARG;
+  if (act != FSV_ACT_NONE && !y) return FSV_ERR_BAD_ARG;
+  RedPlan pl = fsv_red_plan(G, P, C, FSV_RED_FUSED_CHUNKS);
+  if (pl.nslabs > FSV_RED_COUNTERS) return FSV_ERR_UNSUPPORTED;
+  RedP rp; rp.a = dy; rp.y = y; rp.x = x; rp.mean = mean; rp.rstd = rstd; rp.part = workspace;
+  rp.P = P; rp.C = C; rp.act = act; fsv_red_no_tail(rp);
+  rp.counter = counters; rp.o0 = s1; rp.o1 = s2; rp.o2 = dw; rp.o3 = db;
+  fsv_launch_red<FSV_RED_BWD>(pl, rp, G, stream);
+  long long total = (long long)G * P * C;
+  FSV_LAUNCH(fsv_norm_bwd_apply_kernel, dim3(fsv_ew_grid(total)), dim3(256), stream, dy, y, x, mean, rstd, w,
+             (const float*)s1, (const float*)s2, dx, total, (long long)P * C, C, P, act, fixed_stats);
+  return fsv_check_launch();
+}
+
+int fsv_colsum_fused(const float* x, double* workspace, float* out, int G, int P, int C, int accumulate, int* counters,
+                     hipStream_t stream) {
+  if (!fsv_red_fused(counters, G, P, C)) return fsv_colsum(x, workspace, out, G, P, C, accumulate, stream);
+  if (!x || !workspace || !out) return FSV_ERR_BAD_ARG;
+  RedPlan pl = fsv_red_plan(G, P, C, FSV_RED_FUSED_CHUNKS);
+  if (pl.nslabs > FSV_RED_COUNTERS) return FSV_ERR_UNSUPPORTED;
+  RedP rp; rp.a = x; rp.y = nullptr; rp.x = nullptr; rp.mean = nullptr; rp.rstd = nullptr; rp.part = workspace;
+  rp.P = P; rp.C = C; rp.act = 0; fsv_red_no_tail(rp);
+  rp.counter = counters; rp.o0 = out; rp.accumulate = accumulate;
+  fsv_launch_red<FSV_RED_COLSUM>(pl, rp, G, stream);
   return fsv_check_launch();
 }
 
@@ -453,7 +586,7 @@ int fsv_norm_sums(const float* x, double* workspace, double* sums, int P, int C,
   if (!x || !workspace || !sums || P < 1 || C < 1) return FSV_ERR_BAD_ARG;
   RedPlan pl = fsv_red_plan(1, P, C);
   RedP rp; rp.a = x; rp.y = nullptr; rp.x = nullptr; rp.mean = nullptr; rp.rstd = nullptr; rp.part = workspace;
-  rp.P = P; rp.C = C; rp.act = 0;
+  rp.P = P; rp.C = C; rp.act = 0; fsv_red_no_tail(rp);
   fsv_launch_red<FSV_RED_STATS>(pl, rp, 1, stream);
   FSV_LAUNCH(fsv_sums_final_kernel, dim3(fsv_cdiv(C, 4)), dim3(256), stream, (const double*)workspace, sums, C, pl.nchunks);
   return fsv_check_launch();
@@ -475,7 +608,7 @@ int fsv_norm_bwd_sums(const float* dy, const float* y, const float* x, const flo
   if (act != FSV_ACT_NONE && !y) return FSV_ERR_BAD_ARG;
   RedPlan pl = fsv_red_plan(1, P, C);
   RedP rp; rp.a = dy; rp.y = y; rp.x = x; rp.mean = mean; rp.rstd = rstd; rp.part = workspace;
-  rp.P = P; rp.C = C; rp.act = act;
+  rp.P = P; rp.C = C; rp.act = act; fsv_red_no_tail(rp);
   fsv_launch_red<FSV_RED_BWD>(pl, rp, 1, stream);
   FSV_LAUNCH(fsv_sums_final_kernel, dim3(fsv_cdiv(C, 4)), dim3(256), stream, (const double*)workspace, sums, C, pl.nchunks);
   return fsv_check_launch();

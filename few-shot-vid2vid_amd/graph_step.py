@@ -99,8 +99,7 @@ class GraphedIteration:
 
     # ------------------------------------------------------------------------------------------------ the body
     def _backward(self, losses, optimizer):
-        losses = [torch.mean(x) if not isinstance(x, int) else x for x in losses]
-        loss = sum(losses)
+        losses, loss = _model.mean_and_total(losses)
         optimizer.zero_grad()
         optimizer.scale_loss(loss).backward()
         optimizer.finalize_grads()
@@ -115,9 +114,9 @@ class GraphedIteration:
         if not self.split:
             e.out_g = self._backward(g_losses, self.opt_G)
         else:                                  # first piece: down to the generator's stage boundary
-            losses = [torch.mean(x) if not isinstance(x, int) else x for x in g_losses]
+            losses, loss = _model.mean_and_total(g_losses)
             self.opt_G.zero_grad()
-            self.opt_G.scale_loss(sum(losses)).backward()
+            self.opt_G.scale_loss(loss).backward()
             self.opt_G.finalize_grads(partial=True)
             e.out_g = losses
         e.out_gen, e.out_prev = generated, prevs

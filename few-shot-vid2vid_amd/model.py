@@ -98,10 +98,10 @@ def masked_l1(inp, target, mask):
 def gan_loss(preds, real):
     """GANLoss.__call__ with the hinge objective on a list-of-lists prediction (loss.py:69-79, 92-104): last
     feature of every scale; the reference calls it with for_discriminator=True in both steps."""
-    loss = 0
-    for p in preds:
-        loss = loss + ops.hinge_loss(p[-1], real)
-    return loss / len(preds)
+    return ops.weighted_sum([ops.hinge_loss(p[-1], real) for p in preds], [1.0 / len(preds)] * len(preds))
+
+
+_ZEROS = {}
 
 
 class LossCollector:
@@ -136,16 +136,20 @@ class LossCollector:
 
     def vgg_losses(self, fake, raw, real, fg_union):
         """loss_collector.py:122-130"""
-        loss = self.zero(fake)
-        if self.vgg is not None:
-            loss = loss + self.vgg(fake, real)
-            if raw is not None:
-                loss = loss + self.vgg(raw, real * fg_union)
-        return loss * self.opt.lambda_vgg
+        if self.vgg is None:
+            return self.zero(fake)
+        terms = [self.vgg(fake, real)]
+        if raw is not None:
+            terms.append(self.vgg(raw, real * fg_union))
+        return ops.weighted_sum(terms, [self.opt.lambda_vgg] * len(terms))
 
     @staticmethod
     def zero(ref):
-        return torch.zeros(1, dtype=torch.float32, device=ref.device)
+        """the constant 0 of absent loss terms (one shared read-only tensor per device: no fill launch per use)"""
+        z = _ZEROS.get(ref.device)
+        if z is None:
+            z = _ZEROS[ref.device] = torch.zeros(1, dtype=torch.float32, device=ref.device)
+        return z
 
     def discriminate(self, netD, label, fake, real, ref, for_discriminator):
         """loss_collector.py:47-68: D sees [ref | label | image] with fake and real stacked on the batch axis."""
@@ -156,12 +160,13 @@ class LossCollector:
         pred_real = [[t[half:] for t in scale] for scale in out]
         if for_discriminator:
             return [gan_loss(pred_real, True), gan_loss(pred_fake, False)]
-        feat = self.zero(fake)
+        terms = []
         if not self.opt.no_ganFeat_loss:
             for sf, sr in zip(pred_fake, pred_real):
                 for a, b in zip(sf[:-1], sr[:-1]):
-                    feat = feat + l1(a, b.detach()) / len(pred_fake)
-        return [gan_loss(pred_fake, True), feat * self.opt.lambda_feat]
+                    terms.append(l1(a, b.detach()))
+        feat = ops.weighted_sum(terms, [self.opt.lambda_feat / len(pred_fake)] * len(terms)) if terms else self.zero(fake)
+        return [gan_loss(pred_fake, True), feat]
 
     def crop_face_region(self, image, label):
         """face_refiner.py:32-39: device-side boxes + one crop/resize launch (csrc/face.hip)."""
@@ -232,20 +237,21 @@ class LossCollector:
         """loss_collector.py:132-162.  flow_gt / conf_gt: the FlowNet2 teacher's flow and confidence for the reference
         and the previous-frame branch ([B, T, 2|1, H, W] or None each; None with --no_flow_gt)."""
         opt = self.opt
-        z = self.zero(tgt_image)
-        warp_loss = z.clone()
-        flow_loss = z.clone()
+        warp_terms, flow_terms = [], []
         flow_gt = list(flow_gt) if flow_gt is not None else [None, None]
         conf_gt = list(conf_gt) if conf_gt is not None else [None, None]
+
+        def total(terms):                 # lambda_flow * sum of the terms
+            return ops.weighted_sum(terms, [opt.lambda_flow] * len(terms)) if terms else self.zero(tgt_image)
         if not opt.isTrain:               # loss_collector.py:141,158: test-time finetune has no flow / warp terms
-            return flow_loss * opt.lambda_flow, warp_loss * opt.lambda_flow, None
+            return total([]), total([]), None
         for k, (f, wimg) in enumerate(zip(flow, warped)):
             if f is not None:
-                warp_loss = warp_loss + l1(wimg, tgt_image)
+                warp_terms.append(l1(wimg, tgt_image))
                 if flow_gt[k] is not None and getattr(opt, 'n_shot', 1) == 1:      # loss_collector.py:158-159
                     gt = flow_gt[k].reshape(-1, *flow_gt[k].shape[-3:])
                     conf = conf_gt[k].reshape(-1, *conf_gt[k].shape[-3:])
-                    flow_loss = flow_loss + masked_l1(f, gt, conf * fg_mask if fg_mask is not None else conf)
+                    flow_terms.append(masked_l1(f, gt, conf * fg_mask if fg_mask is not None else conf))
         body_diff = None
         if self.pose and flow[0] is not None:
             body = part_masks(tgt_label[:, :, 2])
@@ -253,35 +259,35 @@ class LossCollector:
             body = body.reshape(-1, *body.shape[-3:])
             ref_body = ref_body.reshape(-1, *ref_body.shape[-3:])
             ref_body_warp = ops.resample(ref_body.contiguous(), flow[0])
-            warp_loss = warp_loss + l1(ref_body_warp, body)
+            warp_terms.append(l1(ref_body_warp, body))
             if self.has_fg:
                 fg, ref_fg = fg_mask_of(opt, tgt_label, True), fg_mask_of(opt, ref_label, True)
-                warp_loss = warp_loss + l1(ops.resample(ref_fg, flow[0]), fg)
+                warp_terms.append(l1(ops.resample(ref_fg, flow[0]), fg))
             body_diff = (ref_body_warp - body).abs().sum(dim=1, keepdim=True)
-        return flow_loss * opt.lambda_flow, warp_loss * opt.lambda_flow, body_diff
+        return total(flow_terms), total(warp_terms), body_diff
 
     def mask_losses(self, flow_mask, fake_image, warped, tgt_label, tgt_image, fg_mask, ref_fg_mask, body_diff):
         """loss_collector.py:164-204."""
         opt = self.opt
-        loss = self.zero(tgt_image)
+        terms = []
         if not opt.isTrain:               # loss_collector.py:172,192
-            return loss * opt.lambda_mask
+            return self.zero(tgt_image)
         for m, wimg in zip(flow_mask, warped):
             if m is None:
                 continue
             conf = torch.clamp(1 - (wimg - tgt_image).abs().sum(dim=1, keepdim=True), 0, 1)
-            loss = loss + masked_l1(m, 0.0, conf) + masked_l1(m, 1.0, 1 - conf)
+            terms += [masked_l1(m, 0.0, conf), masked_l1(m, 1.0, 1 - conf)]
         if self.pose and self.warp_ref:
             m_ref = flow_mask[0]
             h, w = tgt_label.shape[-2:]
             face = face_mask_of(tgt_label[:, :, 2]).view(-1, 1, h, w)
             face = ops.pool15(face, 'avg')
-            loss = loss + masked_l1(m_ref, 0.0, face)
+            terms.append(masked_l1(m_ref, 0.0, face))
             if opt.spade_combine:
-                loss = loss + masked_l1(fake_image, warped[0].detach(), face)
+                terms.append(masked_l1(fake_image, warped[0].detach(), face))
             fg_diff = ((ref_fg_mask - fg_mask) > 0).float()
-            loss = loss + masked_l1(m_ref, 1.0, fg_diff) + masked_l1(m_ref, 1.0, body_diff)
-        return loss * opt.lambda_mask
+            terms += [masked_l1(m_ref, 1.0, fg_diff), masked_l1(m_ref, 1.0, body_diff)]
+        return ops.weighted_sum(terms, [opt.lambda_mask] * len(terms)) if terms else self.zero(tgt_image)
 
 
 def amp_mode(opt):
@@ -298,12 +304,21 @@ def amp_mode(opt):
     raise ValueError("unknown --amp level %r" % (getattr(opt, 'amp', ''),))
 
 
+def mean_and_total(losses):
+    """loss_collector.py:218-219: `losses = [torch.mean(x) ...]; loss = sum(losses)`.  Without DataParallel every loss is one
+    element: its mean is itself (a view), and the total is one cat + sum instead of a chain of scalar adds."""
+    means = [x if isinstance(x, int) else (x.reshape(()) if x.numel() == 1 else torch.mean(x)) for x in losses]
+    tensors = [m for m in means if not isinstance(m, int)]
+    total = ops.weighted_sum(tensors).reshape(()) if tensors else 0
+    extra = sum(m for m in means if isinstance(m, int))
+    return means, (total + extra if extra else total)
+
+
 def loss_backward(opt, losses, optimizer, loss_id):
     """models/loss_collector.py:217-228: sum of means -> zero_grad -> backward -> optimiser step.  With `--amp` the
     reference scales the loss per `loss_id` (:221-224); here every optimiser owns its scaler (flat.FlatAdam.scale_loss:
     identity unless the fp16-operand mode is on) and un-scales inside its fused step."""
-    losses = [torch.mean(x) if not isinstance(x, int) else x for x in losses]
-    loss = sum(losses)
+    losses, loss = mean_and_total(losses)
     optimizer.zero_grad()
     scale_loss = getattr(optimizer, 'scale_loss', None)
     (scale_loss(loss) if scale_loss is not None else loss).backward()
@@ -735,8 +750,8 @@ class Vid2VidModel(nn.Module):
         g_vgg = lc.vgg_losses(fake, raw, real, fg_union)
         f_flow, f_warp, body_diff = lc.flow_losses(flow, warped, real, fg, tgt_label, ref_label, flow_gt, conf_gt)
         f_mask = lc.mask_losses(mask, fake, warped, tgt_label, real, fg, ref_fg, body_diff)
-        losses = [g_gan, g_feat, g_vgg, gf_gan, gf_feat, gt_gan if gt_gan is not None else z.clone(),
-                  gt_feat if gt_feat is not None else z.clone(), f_flow, f_warp, f_mask]
+        losses = [g_gan, g_feat, g_vgg, gf_gan, gf_feat, gt_gan if gt_gan is not None else z,
+                  gt_feat if gt_feat is not None else z, f_flow, f_warp, f_mask]
         # the reference returns fake / raw as [B, T, ...] and - because forward_generator rebinds them through
         # self.reshape (vid2vid_model.py:88-89) - warped / flow / mask as 4-D tensors
         up = lambda t: t.unsqueeze(1) if t is not None else None

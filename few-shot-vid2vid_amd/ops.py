@@ -28,6 +28,9 @@ lib.register_sigs({
     "fsv_warp_bwd": [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_llp, c_llp, c_llp, c_llp, c_llp, c_p],
     "fsv_norm_stats": [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_f, c_p, c_p, c_f, c_p],
     "fsv_norm_stats_rep": [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_f, c_p, c_p, c_f, c_i, c_p],
+    "fsv_norm_stats_fused": [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_f, c_p, c_p, c_f, c_i, c_p, c_p],
+    "fsv_norm_bwd_fused": [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_p],
+    "fsv_colsum_fused": [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p, c_p],
     "fsv_norm_apply": [c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p],
     "fsv_norm_bwd": [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p],
     "fsv_norm_sums": [c_p, c_p, c_p, c_i, c_i, c_p],
@@ -64,6 +67,22 @@ def _ws(g, p, c, like):
         _ws_fn.argtypes = [c_i, c_i, c_i]
         _ws_fn.restype = c_i
     return torch.empty(max(int(_ws_fn(g, p, c)), 2), dtype=torch.float64, device=like.device)
+
+
+_tickets = {}
+_TICKET_SLOTS, _TICKET_POOL = 64, 1 << 16
+
+
+def _ticket(like):
+    """address of 64 zeroed ints for one fused reduction launch (include/fsv2v.h, fsv_norm_stats_fused): a ring over a
+    per-device pool, so that launches which may overlap (branch streams, neighbouring graph nodes) never share a range; every
+    launch leaves its range zeroed"""
+    ent = _tickets.get(like.device)
+    if ent is None:
+        ent = _tickets[like.device] = [torch.zeros(_TICKET_POOL, dtype=torch.int32, device=like.device), 0]
+    pool, cur = ent
+    ent[1] = (cur + _TICKET_SLOTS) % _TICKET_POOL
+    return ctypes.c_void_p(pool.data_ptr() + 4 * cur)
 
 
 def _ll(vals):
@@ -140,8 +159,8 @@ def colsum(x2d_nhwc, groups, pixels, channels, out=None):
         out = torch.empty((groups, channels), dtype=torch.float32, device=x2d_nhwc.device)
     lib.check_device(x2d_nhwc)
     ws = _ws(groups, pixels, channels, x2d_nhwc)     # must outlive the call (host allocator frees eagerly)
-    lib.call("fsv_colsum", lib.ptr(x2d_nhwc), lib.ptr(ws), lib.ptr(out), groups, pixels, channels, 1 if acc else 0,
-             lib.stream_ptr())
+    lib.call("fsv_colsum_fused", lib.ptr(x2d_nhwc), lib.ptr(ws), lib.ptr(out), groups, pixels, channels, 1 if acc else 0,
+             _ticket(out), lib.stream_ptr())
     return out
 
 
@@ -249,49 +268,12 @@ def sn_backward(dwsn, weight, u, v, sig, out=None):
 
 
 # ------------------------------------------------------------------------------------------------ backward concurrency
-# The data gradient and the weight gradient of a layer are independent, so backward CAN fork the weight-gradient chain
-# (wgrad -> re-layout -> spectral-norm correction -> bias column sums) onto a side HIP stream and join before
-# returning (two parallel branches under hipGraph capture).  Measured on MI355X at per-GPU batch 2 (in-box A/B,
-# profiles/r01_notes.md): 84.9 ms/step with the fork vs 83.4 ms without - the fp32 MFMA kernels already keep the
-# chip at its power-limited clock, co-scheduling only adds contention.  Kept as an opt-in (FSV_BWD_OVERLAP=1).
+# The data gradient and the weight gradient of a layer are independent, and the weight-gradient chain only feeds the
+# optimiser's gradient sinks, so backward COULD run it on a side HIP stream.  Measured twice on MI355X and removed:
+# round 1, joined per layer: 84.9 ms/step against 83.4 ms without; round 2 (profiles/r02_notes.md), joined once before the
+# gradient finalisation: 60.0 ms against 56.5 ms, and the per-layer variant crashed inside the ROCm 7.2 graph executor.
+# Every cross-stream edge of a captured graph costs tens of microseconds there; only coarse forks pay (streams.py).
 import os as _os
-
-_OVERLAP = _os.environ.get('FSV_BWD_OVERLAP', '0') == '1'
-_side_streams = {}
-
-
-class _fork:
-    """`with _fork(ref_tensor) as f:` runs the body on the side stream of the current device (no-op on the emulator)."""
-
-    def __init__(self, ref):
-        self.on = _OVERLAP and ref.is_cuda
-        self.ref = ref
-
-    def __enter__(self):
-        if self.on:
-            dev = self.ref.device
-            self.cur = torch.cuda.current_stream(dev)
-            side = _side_streams.get(dev.index)
-            if side is None:
-                side = _side_streams[dev.index] = torch.cuda.Stream(device=dev)
-            self.side = side
-            side.wait_stream(self.cur)
-            self.ctx = torch.cuda.stream(side)
-            self.ctx.__enter__()
-        return self
-
-    def __exit__(self, *exc):
-        if self.on:
-            self.ctx.__exit__(*exc)
-        return False
-
-    def join(self, *tensors):
-        """make the main stream wait for the side stream; results produced on the side stream are handed over"""
-        if self.on:
-            self.cur.wait_stream(self.side)
-            for t in tensors:
-                if t is not None:
-                    t.record_stream(self.cur)
 
 
 class _ConvFn(torch.autograd.Function):
@@ -383,57 +365,48 @@ class _ConvFn(torch.autograd.Function):
         want_w = ctx.needs_input_grad[1]
         want_b = ctx.has_bias and ctx.needs_input_grad[2]
         want_x = ctx.needs_input_grad[0]
-        fork = _fork(dpre) if (want_x and (want_w or want_b)) else None
-        if fork is not None:
-            fork.__enter__()
-        try:
-            if want_w:
-                fin = getattr(weight, '_fsv_finalizer', None) if (w_sink is not None and entry is not None) else None
-                if fin is not None:
-                    # deferred: leave the K-major result to the optimiser's grouped finalisation (grad_finalize.py)
-                    dwt = conv_wgrad(x, dpre, geom, w_shape, raw=True, arena=fin)
-                    if ctx.has_sn:
-                        fin.add(entry, dwt, w_sink, sig, u, v)
-                    else:
-                        fin.add(entry, dwt, w_sink)
-                    dw = None
-                elif ctx.has_sn or cpad:
-                    dwsn = conv_wgrad(x, dpre, geom, w_shape, per_sample=ctx.per_sample)
-                    if cpad:
-                        dwsn = dwsn[:, :cin].contiguous()
-                    if ctx.has_sn:
-                        dw = sn_backward(dwsn, weight, u, v, sig, out=w_sink)
-                    elif w_sink is not None:
-                        dw = w_sink.add_(dwsn.view_as(w_sink))
-                    else:
-                        dw = dwsn
-                    dw = None if w_sink is not None else dw.view_as(weight)
+        if want_w:
+            fin = getattr(weight, '_fsv_finalizer', None) if (w_sink is not None and entry is not None) else None
+            if fin is not None:
+                # deferred: leave the K-major result to the optimiser's grouped finalisation (grad_finalize.py)
+                dwt = conv_wgrad(x, dpre, geom, w_shape, raw=True, arena=fin)
+                if ctx.has_sn:
+                    fin.add(entry, dwt, w_sink, sig, u, v)
                 else:
-                    dw = conv_wgrad(x, dpre, geom, w_shape, per_sample=ctx.per_sample, out=w_sink)
-                    dw = None if w_sink is not None else dw.view_as(weight)
-            if want_b:
-                cout = dpre.shape[1]
-                hw = dpre.shape[2] * dpre.shape[3]
-                if ctx.per_sample:
-                    db = colsum(dpre, n, hw, cout)
-                elif b_sink is not None:
-                    fin_b = getattr(bias_t, '_fsv_finalizer', None) if _os.environ.get('FSV_DEFER_BIAS', '1') == '1' else None
-                    if fin_b is not None and dpre.is_contiguous(memory_format=torch.channels_last):
-                        fin_b.add_bias(dpre, b_sink)          # one grouped column-sum pass for the whole backward
-                    else:
-                        colsum(dpre, 1, n * hw, cout, out=b_sink)
+                    fin.add(entry, dwt, w_sink)
+                dw = None
+            elif ctx.has_sn or cpad:
+                dwsn = conv_wgrad(x, dpre, geom, w_shape, per_sample=ctx.per_sample)
+                if cpad:
+                    dwsn = dwsn[:, :cin].contiguous()
+                if ctx.has_sn:
+                    dw = sn_backward(dwsn, weight, u, v, sig, out=w_sink)
+                elif w_sink is not None:
+                    dw = w_sink.add_(dwsn.view_as(w_sink))
                 else:
-                    db = colsum(dpre, 1, n * hw, cout).view(cout)
-        finally:
-            if fork is not None:
-                fork.__exit__(None, None, None)
+                    dw = dwsn
+                dw = None if w_sink is not None else dw.view_as(weight)
+            else:
+                dw = conv_wgrad(x, dpre, geom, w_shape, per_sample=ctx.per_sample, out=w_sink)
+                dw = None if w_sink is not None else dw.view_as(weight)
+        if want_b:
+            cout = dpre.shape[1]
+            hw = dpre.shape[2] * dpre.shape[3]
+            if ctx.per_sample:
+                db = colsum(dpre, n, hw, cout)
+            elif b_sink is not None:
+                fin_b = getattr(bias_t, '_fsv_finalizer', None) if _os.environ.get('FSV_DEFER_BIAS', '1') == '1' else None
+                if fin_b is not None and dpre.is_contiguous(memory_format=torch.channels_last):
+                    fin_b.add_bias(dpre, b_sink)          # one grouped column-sum pass for the whole backward
+                else:
+                    colsum(dpre, 1, n * hw, cout, out=b_sink)
+            else:
+                db = colsum(dpre, 1, n * hw, cout).view(cout)
         if want_x:
             dx = conv_dgrad(dpre, w4, geom, (h, w), scale=inv, per_sample=ctx.per_sample,
                             cached=entry.dgrad if entry is not None else None, cin=w_shape[-3])
             if cpad:
                 dx = dx[:, :cin]
-        if fork is not None:
-            fork.join(dw, db)
         if ctx.has_res and ctx.needs_input_grad[3]:
             dres = dy
         return dx, dw, db, dres, None, None, None, None, None, None, None
@@ -510,14 +483,9 @@ def norm_stats(x, groups, pixels, channels, eps, run_mean=None, run_var=None, mo
         lib.call("fsv_norm_stats_from_sums", lib.ptr(sums), float(pixels) * _bn_sync[0], lib.ptr(mean), lib.ptr(rstd),
                  channels, float(eps), lib.ptr(run_mean), lib.ptr(run_var), float(momentum), lib.stream_ptr())
         return mean, rstd
-    if rep != 1:
-        lib.call("fsv_norm_stats_rep", lib.ptr(x), lib.ptr(ws), lib.ptr(mean), lib.ptr(rstd),
-                 groups, pixels, channels, float(eps), lib.ptr(run_mean), lib.ptr(run_var), float(momentum), int(rep),
-                 lib.stream_ptr())
-        return mean, rstd
-    lib.call("fsv_norm_stats", lib.ptr(x), lib.ptr(ws), lib.ptr(mean), lib.ptr(rstd),
-             groups, pixels, channels, float(eps), lib.ptr(run_mean), lib.ptr(run_var), float(momentum),
-             lib.stream_ptr())
+    lib.call("fsv_norm_stats_fused", lib.ptr(x), lib.ptr(ws), lib.ptr(mean), lib.ptr(rstd),
+             groups, pixels, channels, float(eps), lib.ptr(run_mean), lib.ptr(run_var), float(momentum), int(rep),
+             _ticket(x), lib.stream_ptr())
     return mean, rstd
 
 
@@ -543,9 +511,9 @@ def bn_backward(dy, y, x, mean, rstd, w, g, p, c, act, fixed_stats, affine, worl
     dw = torch.empty(c, dtype=torch.float32, device=x.device) if affine else None
     db = torch.empty_like(dw) if affine else None
     ws = _ws(g, p, c, x)
-    lib.call("fsv_norm_bwd", lib.ptr(dy), lib.ptr(y), lib.ptr(x), lib.ptr(mean), lib.ptr(rstd), lib.ptr(w), lib.ptr(ws),
+    lib.call("fsv_norm_bwd_fused", lib.ptr(dy), lib.ptr(y), lib.ptr(x), lib.ptr(mean), lib.ptr(rstd), lib.ptr(w), lib.ptr(ws),
              lib.ptr(s1), lib.ptr(s2), lib.ptr(dx), lib.ptr(dw), lib.ptr(db), g, p, c, act, 1 if fixed_stats else 0,
-             lib.stream_ptr())
+             _ticket(x), lib.stream_ptr())
     return dx, dw, db
 
 
@@ -1013,6 +981,30 @@ class _L1Fn(torch.autograd.Function):
 
 def l1_loss(a, b, mask=None):
     return _L1Fn.apply(a, b, mask)
+
+
+_wvec_cache = {}
+
+
+def weighted_sum(terms, weights=None):
+    """sum_i weights[i] * terms[i] over one-element loss tensors -> shape [1].  The loss collector combines two dozen such
+    scalars per iteration; one add / mul / div launch per term (and as many again in backward) becomes cat + mul + sum."""
+    terms = [t.reshape(1) for t in terms]
+    if weights is None:
+        weights = [1.0] * len(terms)
+    weights = [float(w) for w in weights]
+    if len(terms) == 1:
+        return terms[0] if weights[0] == 1.0 else terms[0] * weights[0]
+    cat = torch.cat(terms)
+    if any(w != 1.0 for w in weights):
+        key = (tuple(weights), cat.device, cat.dtype)
+        wv = _wvec_cache.get(key)
+        if wv is None:
+            if len(_wvec_cache) > 256:
+                _wvec_cache.clear()
+            wv = _wvec_cache[key] = torch.tensor(weights, dtype=cat.dtype).to(cat.device)
+        cat = cat * wv
+    return cat.sum(dim=0, keepdim=True)
 
 
 class _HingeFn(torch.autograd.Function):

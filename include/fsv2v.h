@@ -168,6 +168,18 @@ int fsv_norm_bwd(const float* dy, const float* y, const float* x, const float* m
                  double* workspace, float* s1, float* s2, float* dx, float* dw, float* db, int G, int P, int C, int act,
                  int fixed_stats, fsv_stream_t stream);   /* fixed_stats: eval mode, mean / rstd are constants */
 int fsv_colsum(const float* x, double* workspace, float* out, int G, int P, int C, int accumulate, fsv_stream_t stream);
+/* one-launch forms of the three reductions above: the workgroup that finishes last on a channel slab (a ticket per slab in
+ * `counters`) sums that slab's partials and writes the final values, so the separate finalize launch disappears.  counters:
+ * at least 64 ints, zero before the first use; every launch leaves them zero again (launches that may run concurrently need
+ * different ranges).  counters == NULL, or a tensor above FSV_NORM_FUSE_MAX_MB (default 16 MB; one workgroup per slab reads all
+ * partials, which only pays while the reduction is launch-bound): the two-launch path above. */
+int fsv_norm_stats_fused(const float* x, double* workspace, float* mean, float* rstd, int G, int P, int C, float eps,
+                         float* run_mean, float* run_var, float momentum, int rep, int* counters, fsv_stream_t stream);
+int fsv_norm_bwd_fused(const float* dy, const float* y, const float* x, const float* mean, const float* rstd, const float* w,
+                       double* workspace, float* s1, float* s2, float* dx, float* dw, float* db, int G, int P, int C, int act,
+                       int fixed_stats, int* counters, fsv_stream_t stream);
+int fsv_colsum_fused(const float* x, double* workspace, float* out, int G, int P, int C, int accumulate, int* counters,
+                     fsv_stream_t stream);
 /* cross-replica BatchNorm (opt-in; apex.parallel.SyncBatchNorm of the reference's multi-process path, normalization.py:15,33,80):
  * the device halves on either side of the host's all-reduce.  sums: doubles [2C] = {sum x, sum x^2} resp. {sum d, sum d*xhat};
  * count: values per channel over all ranks.  dw / db of an affine layer are the LOCAL sums (they travel with the gradients). */

@@ -665,3 +665,36 @@ def check_avgpool3s2(device, seed=90):
         y.backward(_dev(dy, device))
         assert_close('avgpool y %s' % (shp,), y, ref, 1e-6)
         assert_close('avgpool dx %s' % (shp,), xd.grad, xr.grad, 1e-6)
+
+
+def check_fused_reductions(device, shapes=((1, 4096, 32), (2, 1000, 7), (1, 300, 260), (4, 64, 512), (1, 70000, 64)),
+                           repeats=3, seed=91):
+    """One-launch statistics / column sums (last-workgroup second stage, csrc/norm.hip) against fp64 torch, repeatedly on the
+    same buffers (a stale ticket or a partial read too early would show as a changing result), and the ticket pool is left
+    zeroed."""
+    ops, conv = pkg()
+    g = torch.Generator().manual_seed(seed)
+    for (G, P, C) in shapes:
+        x = torch.randn(G, P, C, generator=g) * 1.5 + 0.25
+        x64 = x.double()
+        mean_ref = x64.mean(dim=1)
+        var_ref = x64.var(dim=1, unbiased=False)
+        rstd_ref = 1.0 / torch.sqrt(var_ref + 1e-5)
+        col_ref = x64.sum(dim=1)
+        xd = _dev(x, device)
+        for it in range(repeats):
+            rm, rv = _dev(torch.zeros(C), device), _dev(torch.ones(C), device)
+            mean, rstd = ops.norm_stats(xd, G, P, C, 1e-5, rm if G == 1 else None, rv if G == 1 else None, 0.1)
+            assert_close('fused mean %s #%d' % ((G, P, C), it), mean.view(G, C), mean_ref.float(), tol=1e-5)
+            assert_close('fused rstd %s #%d' % ((G, P, C), it), rstd.view(G, C), rstd_ref.float(), tol=1e-5)
+            if G == 1:
+                unb = var_ref[0] * (P / (P - 1.0))
+                assert_close('fused running_mean', rm, (0.1 * mean_ref[0]).float(), tol=1e-5)
+                assert_close('fused running_var', rv, (0.9 + 0.1 * unb).float(), tol=1e-5)
+            cs = ops.colsum(xd, G, P, C)
+            assert_close('fused colsum %s #%d' % ((G, P, C), it), cs, col_ref.float(), tol=1e-5)
+            acc = _dev(torch.ones(G, C), device)
+            ops.colsum(xd, G, P, C, out=acc)
+            assert_close('fused colsum accumulate', acc, (col_ref + 1.0).float(), tol=1e-5)
+    pool = ops._tickets[xd.device][0]
+    assert int(pool.abs().sum()) == 0, "a fused reduction left its ticket range dirty"

@@ -59,6 +59,10 @@ def test_norm_multi_chunk_multi_slab(emu_lib, n, c, h, w):
     oc.check_norm(DEV, instance=True, n=n, c=c, h=h, w=w)
 
 
+def test_fused_reductions(emu_lib):
+    oc.check_fused_reductions(DEV, shapes=((1, 4096, 32), (2, 1000, 7), (1, 300, 260), (4, 64, 512)), repeats=2)
+
+
 @pytest.mark.parametrize("nmaps,generated,act,c,ch", [(1, True, 'lrelu', 12, 8), (3, True, 'none', 12, 8),
                                                       (2, False, 'lrelu', 40, 12), (3, True, 'lrelu', 32, 20),
                                                       (2, False, 'none', 48, 12), (1, True, 'lrelu', 64, 32)])

@@ -60,6 +60,13 @@ def test_norm(hip_lib, instance, affine, act):
     oc.check_norm(dev(), instance=instance, affine=affine, act=act, n=2, c=64, h=65, w=33)
 
 
+def test_fused_reductions(hip_lib):
+    """last-workgroup second stage across the 8 XCDs: many repeats on the same buffers, sizes on both sides of the threshold"""
+    oc.check_fused_reductions(dev(), repeats=25)
+    oc.check_fused_reductions(dev(), shapes=((1, 2 * 512 * 512, 32), (2, 256 * 256, 128)), repeats=3)
+    oc.check_norm(dev(), instance=False, n=2, c=64, h=300, w=300)          # above the threshold: two launches
+
+
 @pytest.mark.parametrize("nmaps,generated,act,c,ch", [(1, True, 'lrelu', 12, 8), (3, True, 'none', 12, 8),
                                                       (2, False, 'lrelu', 40, 12), (3, True, 'lrelu', 64, 32)])
 def test_spade(hip_lib, nmaps, generated, act, c, ch):
