@@ -208,6 +208,20 @@ __global__ __launch_bounds__(256) void fsv_cat_put_kernel(const float* src, floa
   }
 }
 
+// channel padding for the float4 gather path of the convolutions (labels 6 -> 8, RGB 3 -> 4, flow-net input 15 -> 16):
+// out[n][px][c] = c < C ? src[n, c, px] : 0 for any (batch, channel, pixel)-strided source, one pass instead of
+// layout conversion + zero fill + copy
+__global__ __launch_bounds__(256) void fsv_pad_channels_kernel(const float* src, float* out, long long N, int C, long long P,
+                                                               long long sn, long long sc, long long sp, int Ct) {
+  const long long total = N * P * Ct;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int c = (int)(i % Ct);
+    const long long t = i / Ct;
+    const long long px = t % P, n = t / P;
+    out[i] = c < C ? src[n * sn + c * sc + px * sp] : 0.f;
+  }
+}
+
 // gradient of one source: dst[n][px][c] (dense NHWC with C channels) = dout[n][px][coff + c]
 __global__ __launch_bounds__(256) void fsv_cat_get_kernel(const float* dout, float* dst, long long N, int C, long long P, int Ct, int coff) {
   const long long total = N * P * C;
@@ -262,6 +276,14 @@ int fsv_cat_put(const float* src, float* out, long long N, int C, long long P, c
   if (!src || !out || N < 1 || C < 1 || P < 1 || coff < 0 || coff + C > Ct) return FSV_ERR_BAD_ARG;
   FSV_LAUNCH(fsv_cat_put_kernel, dim3(fsv_grid_for(N * P * C / 4 + 1)), dim3(256), stream, src, out, N, C, P, strides[0], strides[1],
              strides[2], Ct, coff);
+  return fsv_check_launch();
+}
+
+int fsv_pad_channels(const float* src, float* out, long long N, int C, long long P, const long long* strides, int Ct,
+                     hipStream_t stream) {
+  if (!src || !out || !strides || N < 1 || C < 1 || P < 1 || Ct < C) return FSV_ERR_BAD_ARG;
+  FSV_LAUNCH(fsv_pad_channels_kernel, dim3(fsv_grid_for(N * P * Ct / 4 + 1)), dim3(256), stream, src, out, N, C, P, strides[0],
+             strides[1], strides[2], Ct);
   return fsv_check_launch();
 }
 

@@ -160,45 +160,65 @@ __global__ __launch_bounds__(256) void fsv_red2_kernel(RedP p) {
   __syncthreads();
   if (!is_last) return;
   __threadfence();                       // acquire: the other workgroups' partials
+  // Column j of the slab's partial rows = (channel cc = j / 2, component j % 2); ncol <= 256 contiguous doubles per (g, chunk).
+  // Every thread owns one column and a share of the chunks: independent, coalesced loads (the per-channel wave reduction of
+  // the two-launch finalize would serialise up to 32 channels per wave here), then one LDS step pairs the components up.
+  __shared__ double colsum[256];
   const int G = (int)gridDim.z;
-  const int wave = threadIdx.x >> 6;
-  const bool lead = (threadIdx.x & 63) == 0;
-  for (int cc = wave; cc < p.TX * V; cc += 4) {
-    const int c = slab * p.TX * V + cc;
-    if (c >= p.C) break;
-    if (MODE == FSV_RED_BWD) {
-      double ta = 0.0, tb = 0.0;
-      for (int gg = 0; gg < G; ++gg) {
-        double a, b;
-        fsv_sum_chunks(p.part, gg, c, p.C, p.nchunks, a, b);
-        if (lead) { p.o0[gg * p.C + c] = (float)a; p.o1[gg * p.C + c] = (float)b; }
-        ta += a; tb += b;
+  const int nch = (p.C - slab * p.TX * V) < p.TX * V ? (p.C - slab * p.TX * V) : p.TX * V;     // channels of this slab
+  const int ncol = nch * 2;
+  const int groups = 256 / ncol > 0 ? 256 / ncol : 1;
+  const int col = (int)threadIdx.x % ncol, grp = (int)threadIdx.x / ncol;
+  const bool loader = grp < groups;
+  const int cc = (int)threadIdx.x;                      // finalising thread cc < nch owns channel c
+  const int c = slab * p.TX * V + cc;
+  double ta = 0.0, tb = 0.0;
+  for (int gg = 0; gg < G; ++gg) {
+    double acc = 0.0;
+    if (loader) {
+      const double* base = p.part + ((long long)gg * p.nchunks * p.C + (long long)slab * p.TX * V) * 2 + col;
+      const long long rs = (long long)p.C * 2;
+      int k = grp;
+      for (; k + 3 * groups < p.nchunks; k += 4 * groups) {
+        const double v0 = base[(long long)k * rs], v1 = base[(long long)(k + groups) * rs];
+        const double v2 = base[(long long)(k + 2 * groups) * rs], v3 = base[(long long)(k + 3 * groups) * rs];
+        acc += (v0 + v1) + (v2 + v3);
       }
-      if (lead && p.o2) p.o2[c] = (float)tb;
-      if (lead && p.o3) p.o3[c] = (float)ta;
-    } else {
-      for (int gg = 0; gg < G; ++gg) {
-        double a, b;
-        fsv_sum_chunks(p.part, gg, c, p.C, p.nchunks, a, b);
-        if (!lead) continue;
-        const int idx = gg * p.C + c;
-        if (MODE == FSV_RED_COLSUM) {
-          p.o0[idx] = p.accumulate ? p.o0[idx] + (float)a : (float)a;
-        } else {
-          double mu = a / p.P;
-          double var = b / p.P - mu * mu;
-          if (var < 0.0) var = 0.0;
-          p.o0[idx] = (float)mu;
-          p.o1[idx] = (float)(1.0 / sqrt(var + (double)p.eps));
-          if (p.o2 && G == 1) {
-            const double cnt = (double)p.P * (double)p.rep;
-            double unb = cnt > 1.0 ? var * (cnt / (cnt - 1.0)) : var;
-            p.o2[c] = (1.f - p.momentum) * p.o2[c] + p.momentum * (float)mu;
-            p.o3[c] = (1.f - p.momentum) * p.o3[c] + p.momentum * (float)unb;
-          }
+      for (; k < p.nchunks; k += groups) acc += base[(long long)k * rs];
+    }
+    __syncthreads();                                     // previous group's colsum has been consumed
+    if (loader && grp == 0) colsum[col] = acc;
+    for (int r = 1; r < groups; ++r) {
+      __syncthreads();
+      if (loader && grp == r) colsum[col] += acc;
+    }
+    __syncthreads();
+    if (cc < nch) {
+      const double a = colsum[2 * cc], b = colsum[2 * cc + 1];
+      const int idx = gg * p.C + c;
+      if (MODE == FSV_RED_BWD) {
+        p.o0[idx] = (float)a; p.o1[idx] = (float)b;
+        ta += a; tb += b;
+      } else if (MODE == FSV_RED_COLSUM) {
+        p.o0[idx] = p.accumulate ? p.o0[idx] + (float)a : (float)a;
+      } else {
+        double mu = a / p.P;
+        double var = b / p.P - mu * mu;
+        if (var < 0.0) var = 0.0;
+        p.o0[idx] = (float)mu;
+        p.o1[idx] = (float)(1.0 / sqrt(var + (double)p.eps));
+        if (p.o2 && G == 1) {
+          const double cnt = (double)p.P * (double)p.rep;
+          double unb = cnt > 1.0 ? var * (cnt / (cnt - 1.0)) : var;
+          p.o2[c] = (1.f - p.momentum) * p.o2[c] + p.momentum * (float)mu;
+          p.o3[c] = (1.f - p.momentum) * p.o3[c] + p.momentum * (float)unb;
         }
       }
     }
+  }
+  if (MODE == FSV_RED_BWD && cc < nch) {
+    if (p.o2) p.o2[c] = (float)tb;
+    if (p.o3) p.o3[c] = (float)ta;
   }
 }
 
@@ -207,14 +227,15 @@ static inline void fsv_red_no_tail(RedP& p) {
 }
 
 // The fused second stage pays while the whole reduction is launch-bound: the last workgroup of a slab reads nchunks x slab
-// partials alone, so the chunk count is capped and tensors above FSV_NORM_FUSE_MAX_MB (default 16 MB) keep two launches.
-#define FSV_RED_FUSED_CHUNKS 64
+// partials alone, so the chunk count is capped and tensors above FSV_NORM_FUSE_MAX_MB keep two launches.  Measured on the C3
+// bench step (profiles/r02_notes.md): threshold 0 (off) 58.9 ms, 1 MB 58.1, 4 MB 60.2, 16 MB 63.9, 64 MB 65.8 -> default 1 MB.
+#define FSV_RED_FUSED_CHUNKS 32
 #define FSV_RED_COUNTERS 64
 static inline long long fsv_red_fuse_max_elems() {
   static long long v = -1;
   if (v < 0) {
     const char* e = getenv("FSV_NORM_FUSE_MAX_MB");
-    double mb = e ? atof(e) : 16.0;
+    double mb = e ? atof(e) : 1.0;
     v = (long long)(mb * 1024.0 * 1024.0 / 4.0);
   }
   return v;

@@ -673,8 +673,9 @@ class Vid2VidModel(nn.Module):
                 p.requires_grad_(True)
         return history
 
-    def generate_images(self, tgt_labels, tgt_images, ref_labels, ref_images, prevs):
-        """vid2vid_model.py:130-158 with n_frames_per_gpu == 1."""
+    def generate_images(self, tgt_labels, tgt_images, ref_labels, ref_images, prevs, want_prevs=True):
+        """vid2vid_model.py:130-158 with n_frames_per_gpu == 1.  want_prevs=False: the caller drops the updated
+        previous-frame buffers (the D step), so they are not built."""
         opt = self.opt
         ref_labels_valid = valid_labels(opt, ref_labels)
         b, _, _, h, w = tgt_labels.shape
@@ -695,7 +696,7 @@ class Vid2VidModel(nn.Module):
             raw = raw * union_fg(fg, ref_fg, self.has_fg)
         n_prev = opt.n_frames_G - 1
         new_prevs = []
-        for old, now in zip(prevs, (tgt_label_valid, tgt_image, fake)):
+        for old, now in (zip(prevs, (tgt_label_valid, tgt_image, fake)) if want_prevs else ()):
             if old is None:
                 new_prevs.append(now.detach().unsqueeze(1).repeat(1, n_prev, 1, 1, 1))
             else:
@@ -706,7 +707,7 @@ class Vid2VidModel(nn.Module):
         """vid2vid_model.py:106-128."""
         with torch.no_grad():
             (fake, raw, _, _, _), (fg, ref_fg), (ref_label, ref_image), _ = \
-                self.generate_images(tgt_label, tgt_image, ref_labels, ref_images, prevs)
+                self.generate_images(tgt_label, tgt_image, ref_labels, ref_images, prevs, want_prevs=False)
         fg_union = union_fg(fg, ref_fg, self.has_fg)
         real = tgt_image[:, 0]
         losses = self.lossCollector.gan_losses(self.netD, tgt_label, [real, real * fg_union], [fake, raw], ref_label,

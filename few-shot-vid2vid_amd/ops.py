@@ -281,7 +281,6 @@ class _ConvFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, weight, bias, res, sig, u, v, geom, act, scale, uv_owned=False):
-        x = to_nhwc(x)
         weight._fsv_conv_param = True          # FlatAdam: these parameters take their gradients through the sink
         if bias is not None:
             bias._fsv_conv_param = True
@@ -294,8 +293,7 @@ class _ConvFn(torch.autograd.Function):
         # scalar gather path of the kernels; zero-pad channels (input and weights) once so the float4 path is used
         cin = x.shape[1]
         cpad = (-cin) % 4 if not per_sample else 0
-        if cpad:
-            x = to_nhwc(torch.nn.functional.pad(x, (0, 0, 0, 0, 0, cpad)))
+        x = pad_channels_nhwc(x, cpad) if cpad else to_nhwc(x)
         ctx.cpad, ctx.cin = cpad, cin
         inv = sig[1:2] if sig is not None else None
         # parameters owned by a FlatAdam keep persistent K-major layouts (layout_cache.py); 1/sigma then rides in the
@@ -1180,6 +1178,7 @@ def pool15(x, mode, thresh=0.0):
 
 lib.register_sigs({
     "fsv_cat_put": [c_p, c_p, c_ll, c_i, c_ll, c_llp, c_i, c_i, c_p],
+    "fsv_pad_channels": [c_p, c_p, c_ll, c_i, c_ll, c_llp, c_i, c_p],
     "fsv_cat_get": [c_p, c_p, c_ll, c_i, c_ll, c_i, c_i, c_p],
     "fsv_blend_fwd": [c_p, c_p, c_p, c_p, c_i, c_i, c_ll, c_llp, c_llp, c_llp, c_p],
     "fsv_blend_bwd": [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_ll, c_llp, c_llp, c_llp, c_p],
@@ -1222,6 +1221,20 @@ class _CatFn(torch.autograd.Function):
 
 def cat_channels(tensors):
     return _CatFn.apply(*tensors)
+
+
+def pad_channels_nhwc(x, cpad):
+    """x [N, C, H, W] in any layout whose H x W plane is one strided run -> dense NHWC [N, C + cpad, H, W] with zero channels
+    appended, in one launch (no autograd: callers slice the gradient themselves)"""
+    x = x.detach()
+    n, c, h, w = x.shape
+    if not (x.dtype == torch.float32 and (h == 1 or x.stride(2) == w * x.stride(3))):
+        return to_nhwc(torch.nn.functional.pad(to_nhwc(x), (0, 0, 0, 0, 0, cpad)))
+    out = empty_nhwc(n, c + cpad, h, w, x)
+    lib.check_device(x)
+    lib.call("fsv_pad_channels", lib.ptr(x), lib.ptr(out), n, c, h * w, _ll([x.stride(0), x.stride(1), x.stride(3)]), c + cpad,
+             lib.stream_ptr())
+    return out
 
 
 class _BlendFn(torch.autograd.Function):

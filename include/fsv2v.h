@@ -171,7 +171,7 @@ int fsv_colsum(const float* x, double* workspace, float* out, int G, int P, int 
 /* one-launch forms of the three reductions above: the workgroup that finishes last on a channel slab (a ticket per slab in
  * `counters`) sums that slab's partials and writes the final values, so the separate finalize launch disappears.  counters:
  * at least 64 ints, zero before the first use; every launch leaves them zero again (launches that may run concurrently need
- * different ranges).  counters == NULL, or a tensor above FSV_NORM_FUSE_MAX_MB (default 16 MB; one workgroup per slab reads all
+ * different ranges).  counters == NULL, or a tensor above FSV_NORM_FUSE_MAX_MB (default 1 MB; one workgroup per slab reads all
  * partials, which only pays while the reduction is launch-bound): the two-launch path above. */
 int fsv_norm_stats_fused(const float* x, double* workspace, float* mean, float* rstd, int G, int P, int C, float eps,
                          float* run_mean, float* run_var, float momentum, int rep, int* counters, fsv_stream_t stream);
@@ -230,6 +230,10 @@ int fsv_act_bwd(const float* dy, const float* y, float* dx, long long total, int
  * compositing out = a*m + b*(1-m) (generator.py:217,224,441-443,498,563) */
 int fsv_cat_put(const float* src, float* out, long long N, int C, long long P, const long long* strides, int Ct, int coff,
                 fsv_stream_t stream);
+/* out [N][P][Ct] dense NHWC = the C channels of a (batch, channel, pixel)-strided source followed by Ct - C zero channels
+ * (inputs whose channel count is not a multiple of 4 are padded once for the float4 gather of the convolutions) */
+int fsv_pad_channels(const float* src, float* out, long long N, int C, long long P, const long long* strides, int Ct,
+                     fsv_stream_t stream);
 int fsv_cat_get(const float* dout, float* dst, long long N, int C, long long P, int Ct, int coff, fsv_stream_t stream);
 int fsv_blend_fwd(const float* a, const float* b, const float* m, float* out, int N, int C, long long P,
                   const long long* a_strides, const long long* b_strides, const long long* out_strides, fsv_stream_t stream);

@@ -148,8 +148,8 @@ def compare_grads_l2(module, sd32, sd64, tol):
         noise = float((sd32[name].grad.detach().double() - r64).norm())
         scale = max(float(r64.norm()), floor, 1e-12)
         err = float((got - r64).norm())
-        t = tol * 5 if 'flow_network' in name else tol
-        assert err <= t * scale + 4.0 * noise, 'grad %s: ||diff|| %.3e > %.1e * %.3e + 4 * %.3e' % (name, err, t, scale, noise)
+        t = tol * 2 if 'flow_network' in name else tol
+        assert err <= t * scale + 2.0 * noise, 'grad %s: ||diff|| %.3e > %.1e * %.3e + 2 * %.3e' % (name, err, t, scale, noise)
         worst = max(worst, err / scale)
     return worst
 
@@ -169,23 +169,12 @@ def compare_grads(module, sd32, sd64, tol):
         assert prm.grad is not None, 'no grad for ' + name
         # The bilinear warp is only piecewise differentiable in the flow: a 1e-6 px difference in the predicted flow
         # moves a few pixels across an integer boundary and changes their d(out)/d(flow) by O(1).  Everything
-        # upstream of the flow (the flow network) therefore gets a 10x wider band; tap indices themselves are
-        # checked bit-exactly in the warp tests.
+        # upstream of the flow (the flow network) therefore gets a 10x wider band (the emulated kernels sit inside the plain
+        # band; on an MI355X, where the warp backward's scatter-adds arrive in any order, 5x the plain band was observed);
+        # tap indices themselves are checked bit-exactly in the warp tests.  No retry at a wider band: a parameter outside
+        # max-abs `t` + 2x fp32-noise fails the test.
         t = tol * 10 if 'flow_network' in name else tol
-        try:
-            worst = max(worst, _close_vs64('grad ' + name, prm.grad, sd32[name].grad, ref, t, floor))
-        except AssertionError:
-            # LeakyReLU / hinge kinks: rounding-level differences in the forward activations flip the slope of a few
-            # units, which moves gradient entries upstream by more than the max-abs band (which units flip depends on the
-            # summation order: tile plan, split-K atomics).  Verified for the case that prompted this (ngf=8 face
-            # generator, ref_img_first.conv): every single kernel call agrees with the reference tile to 1e-4 while the
-            # end-to-end gradient moves by 0.7 %.  The tensor as a whole has to stay within the relative-L2 band the
-            # step-level checks use (check_train_step grad_tol); operator-level tests hold the kernels to ~1e-4.
-            got = prm.grad.detach().double().cpu()
-            rel = float((got - ref.double()).norm() / max(float(ref.double().norm()), 1e-30))
-            if rel > max(t, 2e-2):
-                raise
-            worst = max(worst, rel)
+        worst = max(worst, _close_vs64('grad ' + name, prm.grad, sd32[name].grad, ref, t, floor))
     return worst
 
 
@@ -250,7 +239,10 @@ def check_train_step(device, opt, b=2, tol=1e-3, seed=21, grad_tol=2e-2, with_fl
     wider `grad_tol`: the hinge loss and the LeakyReLUs are only piecewise linear, and the ~1e-5 difference between
     the two generated images moves a few discriminator activations across a kink, which changes individual gradient
     entries by up to a percent (tools/diag_step.py: on identical discriminator inputs the same gradients agree to
-    3e-6).  The network-level tests above compare gradients on identical inputs at 5e-3 / noise floor."""
+    3e-6).  The network-level tests above compare gradients on identical inputs at 5e-3 / noise floor.
+    Hardware record (round 2, MI355X, split-K through atomics): worst relative L2 over all step tests 1.56e-2
+    (face-refinement step, fc_spade_1_1.0.bias), 7e-3 for ref_img_first.conv.weight; the band is 2e-2 + 2x fp32-noise
+    (round 1: + 4x), with no retry at a wider band."""
     M = _model()
     model = M.create_model(opt)
     sdG0, sdD0 = fill_state(model.netG), fill_state(model.netD)
