@@ -12,8 +12,10 @@ MFMA).  Weak scaling: the per-GPU batch is fixed, gradients are all-reduced over
 Besides the contract fields the JSON line carries
   roofline     - the dominant kernel (the fp32 MFMA implicit-GEMM convolution) priced against the 157.3 TFLOP/s
                  fp32 matrix peak: algorithmic FLOPs per launch / average launch duration, measured with HIP events
-                 on the launch stream in an instrumented pass of the same step; `traffic` is null here - HBM bytes per
-                 launch need rocprofv3 PMC passes (profiles/r02_pmc_hbm_traffic.json holds them for this command);
+                 on the launch stream: the step's launches of that kernel re-issued back to back under one event pair
+                 (`avg_launch_us`; the per-launch brackets of the eager instrumented pass, which idles between launches,
+                 stay in the line as `bracketed_us`); `traffic` is null here - HBM bytes per launch need rocprofv3 PMC
+                 passes (profiles/r02_pmc_hbm_traffic.json holds them for this command);
   cpu_baseline - the CPU oracle (oracle/fsv_oracle.py, a port of the reference's algorithm; kind "port": the Python
                  reference cannot travel to the GPU box) timed on the host cores on ONE iteration of the very same
                  workload (512x512, B = 2, same flags; rank 0, N=1 only);
@@ -338,12 +340,17 @@ def main():
     }
     rl = None
     if not args.no_roofline:
-        # instrumented eager pass: HIP events around every launch of the dominant kernel, on its launch stream.  Every rank
-        # runs the step (it contains the gradient exchange), only rank 0 records.
+        # instrumented eager pass: HIP events around every launch of the MFMA kernels, on their launch stream; the dominant
+        # kernel's launches are then re-issued back to back under one event pair (profile.summary: an eager pass idles
+        # between launches and reads ~12 % long).  Every rank runs the step (it contains the gradient exchange), only rank 0
+        # records.
+        streams = import_module('few-shot-vid2vid_amd.streams')
+        forked, streams.ENABLED = streams.ENABLED, False        # one stream: the brackets / the replay see every launch
         if rank == 0:
             prof.enable()
         step()
         torch.cuda.synchronize()
+        streams.ENABLED = forked
         if rank == 0:
             rl = prof.summary()
             prof.disable()

@@ -187,7 +187,9 @@ def gather_gemm(x, wt, ldw, cout, oh, ow, ty, tx, sy, sx, bias=None, res=None, a
                                    force_tile, force_split)
         if entry.endswith('_np'):
             label = label.replace('fsv_conv_igemm_kernel', 'fsv_np_conv_kernel[%s]' % ('f16' if _mfma_mode == 1 else 'bf16x3'))
-        with profile.scope(label, 2.0 * n * oh * ow * cout * cin * len(ty)):
+        keep = (x, wt, bias, res, out, wscale)          # the replay re-issues the launch on the same buffers
+        with profile.scope(label, 2.0 * n * oh * ow * cout * cin * len(ty),
+                           replay=lambda entry=entry, args=args, keep=keep: lib.call(entry, *args)):
             lib.call(entry, *args)
     else:
         lib.call(entry, *args)
