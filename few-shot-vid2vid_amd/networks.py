@@ -598,19 +598,23 @@ class FewShotGenerator(nn.Module):
         return self.conv_img(ops.activation(x, ACT_LRELU), act=ACT_TANH)
 
     def flow_generation(self, label, label_ref, img_ref, prev):
+        """generator.py:430-449.  The warp is fused with what consumes it (ops.warp_concat / ops.warp_blend, csrc/warp.hip):
+        with --spade_combine the warped image and ds = cat([warp, mask]) come out of one launch here; otherwise the warp is
+        left to the blend in forward() (`sources` carries the images to warp)."""
         label_prev, img_prev = prev
         flow, mask, warp, ds = [None, None], [None, None], [None, None], [None, None]
+        sources = [None, None]
         if self.warp_ref:
             flow[0], mask[0] = self.flow_network_ref(label, label_ref, img_ref, for_ref=True)
-            warp[0] = ops.resample(img_ref, flow[0])[:, :3]
+            sources[0] = img_ref[:, :3]
         if self.warp_prev and label_prev is not None:
             flow[1], mask[1] = self.flow_network_temp(label, label_prev, img_prev)
-            warp[1] = ops.resample(img_prev[:, -3:], flow[1])
+            sources[1] = img_prev[:, -3:]
         if self.spade_combine:
-            if self.warp_ref:
-                ds[0] = ops.cat_channels([warp[0], mask[0]])
-            if warp[1] is not None:
-                ds[1] = ops.cat_channels([warp[1], mask[1]])
+            for k in range(2):
+                if sources[k] is not None:
+                    warp[k], ds[k] = ops.warp_concat(sources[k], flow[k], mask[k])
+        self._warp_sources = sources
         return flow, mask, warp, ds
 
     def combine_embeddings(self, ds):
@@ -669,12 +673,14 @@ class FewShotGenerator(nn.Module):
         img_raw = self.conv_img(ops.activation(x, ACT_LRELU), act=ACT_TANH)
         if not self.spade_combine:
             img_final = img_raw
+            sources = self._warp_sources
+            warp = list(warp)
             if self.warp_ref:
-                img_final = ops.blend(img_raw, warp[0], mask[0])
+                warp[0], img_final = ops.warp_blend(img_raw, sources[0], flow[0], mask[0])
             elif not self.warp_prev:
                 img_raw = None
-            if warp[1] is not None:
-                img_final = ops.blend(img_final, warp[1], mask[1])
+            if sources[1] is not None:
+                warp[1], img_final = ops.warp_blend(img_final, sources[1], flow[1], mask[1])
         else:
             img_final, img_raw = img_raw, None
         return img_final, flow, mask, img_raw, warp, None, None, atn_vis, ref_idx

@@ -872,6 +872,77 @@ def resample(image, flow):
     return _WarpFn.apply(image, flow)
 
 
+lib.register_sigs({
+    "fsv_warp_compose_fwd": [c_p] * 8 + [c_i] * 5 + [c_llp] * 6 + [c_p],
+    "fsv_warp_compose_bwd": [c_p] * 12 + [c_i] * 5 + [c_llp] * 7 + [c_p],
+})
+COMPOSE_CONCAT, COMPOSE_BLEND = 0, 1
+
+
+class _WarpComposeFn(torch.autograd.Function):
+    """(warp, comp) = the flow warp of `image` and its composite with the occlusion mask in one launch (csrc/warp.hip):
+    comp = cat([warp, mask], 1) (mode 0, --spade_combine: generator.py:441-443) or raw * mask + warp * (1 - mask) (mode 1,
+    generator.py:217,224).  Same taps as resample()."""
+
+    @staticmethod
+    def forward(ctx, image, flow, mask, raw, mode):
+        b, c, h, w = image.shape
+        if flow.shape != (b, 2, h, w) or mask.shape != (b, 1, h, w):
+            raise ValueError("flow must be [B, 2, H, W] and mask [B, 1, H, W]")
+        warp = torch.empty((b, c, h, w), dtype=torch.float32, device=image.device)
+        if mode == COMPOSE_CONCAT:
+            comp = empty_nhwc(b, c + 1, h, w, image)
+            raw_t, cstr = None, None
+        else:
+            raw_t = raw
+            comp = torch.empty((b, c, h, w), dtype=torch.float32, device=image.device)
+            cstr = _ll(comp.stride())
+        lib.check_device(image, flow, mask, raw_t)
+        mstr = _ll([mask.stride(0), mask.stride(2), mask.stride(3)])
+        lib.call("fsv_warp_compose_fwd", lib.ptr(image), lib.ptr(flow), lib.ptr(_linspace(w, image.device)),
+                 lib.ptr(_linspace(h, image.device)), lib.ptr(mask), lib.ptr(raw_t), lib.ptr(warp), lib.ptr(comp), mode,
+                 b, c, h, w, _ll(image.stride()), _ll(flow.stride()), mstr,
+                 _ll(raw_t.stride()) if raw_t is not None else None, _ll(warp.stride()), cstr, lib.stream_ptr())
+        ctx.mode = mode
+        ctx.save_for_backward(image, flow, mask, raw_t if raw_t is not None else image)
+        return warp, comp
+
+    @staticmethod
+    def backward(ctx, g_warp, g_comp):
+        image, flow, mask, raw_t = ctx.saved_tensors
+        mode = ctx.mode
+        b, c, h, w = image.shape
+        if mode == COMPOSE_CONCAT:
+            raw_t = None
+            if g_comp is not None:
+                g_comp = to_nhwc(g_comp)
+        dev = image.device
+        gimg = torch.zeros_like(image) if ctx.needs_input_grad[0] else None
+        gflow = torch.empty((b, 2, h, w), dtype=torch.float32, device=dev) if ctx.needs_input_grad[1] else None
+        gmask = torch.empty((b, 1, h, w), dtype=torch.float32, device=dev) if ctx.needs_input_grad[2] else None
+        graw = torch.empty((b, c, h, w), dtype=torch.float32, device=dev) if (mode == COMPOSE_BLEND and
+                                                                                ctx.needs_input_grad[3]) else None
+        mstr = _ll([mask.stride(0), mask.stride(2), mask.stride(3)])
+        lib.call("fsv_warp_compose_bwd", lib.ptr(image), lib.ptr(flow), lib.ptr(_linspace(w, dev)), lib.ptr(_linspace(h, dev)),
+                 lib.ptr(mask), lib.ptr(raw_t), lib.ptr(g_warp), lib.ptr(g_comp), lib.ptr(gimg), lib.ptr(gflow), lib.ptr(gmask),
+                 lib.ptr(graw), mode, b, c, h, w, _ll(image.stride()), _ll(flow.stride()), mstr,
+                 _ll(raw_t.stride()) if raw_t is not None else None,
+                 _ll(g_warp.stride()) if g_warp is not None else None,
+                 _ll(g_comp.stride()) if (g_comp is not None and mode == COMPOSE_BLEND) else None,
+                 _ll(gimg.stride()) if gimg is not None else None, lib.stream_ptr())
+        return gimg, gflow, gmask, graw, None
+
+
+def warp_concat(image, flow, mask):
+    """(resample(image, flow), cat([that, mask], dim=1)) - the warped image and the image-embedding input - in one launch"""
+    return _WarpComposeFn.apply(image, flow, mask, None, COMPOSE_CONCAT)
+
+
+def warp_blend(raw, image, flow, mask):
+    """(resample(image, flow), raw * mask + that * (1 - mask)) in one launch"""
+    return _WarpComposeFn.apply(image, flow, mask, raw, COMPOSE_BLEND)
+
+
 # ------------------------------------------------------------------------------------------------ Adam
 def adam_step(param, grad, m, v, state, beta1, beta2, eps, gscale=1.0):
     """Fused Adam on flat buffers; state = [t, 1-b1^t, 1-b2^t, lr] (device, fp32)."""

@@ -206,6 +206,23 @@ int fsv_warp_bwd(const float* img, const float* flow, const float* lin_x, const 
                  float* gimg, float* gflow, int B, int C, int H, int W, const long long* img_strides,
                  const long long* flow_strides, const long long* gout_strides, const long long* gimg_strides,
                  const long long* gflow_strides, fsv_stream_t stream);
+/* warp + occlusion-mask compositing in one pass (generator.py:214-227, :441-443 on top of resample): writes the warped image
+ * AND the composite.  mode 0 (--spade_combine): comp = dense NHWC [B][H*W][C+1] = (warp, mask), the input of the image
+ * embedding; mode 1: comp = raw * mask + warp * (1 - mask) with the given strides.  mask: [B,1,H,W], mask_strides = (batch, y,
+ * x); C <= 8; tap indices as fsv_warp_fwd.  Backward: g_warp / g_comp are the upstream gradients (either may be NULL), the
+ * outputs gimg (scatter-add, zero-initialised, gimg_strides), gflow [B,2,H,W], gmask [B,H,W], graw [B,C,H,W] (dense) are
+ * each optional. */
+int fsv_warp_compose_fwd(const float* img, const float* flow, const float* lin_x, const float* lin_y, const float* mask,
+                         const float* raw, float* warp, float* comp, int mode, int B, int C, int H, int W,
+                         const long long* img_strides, const long long* flow_strides, const long long* mask_strides,
+                         const long long* raw_strides, const long long* warp_strides, const long long* comp_strides,
+                         fsv_stream_t stream);
+int fsv_warp_compose_bwd(const float* img, const float* flow, const float* lin_x, const float* lin_y, const float* mask,
+                         const float* raw, const float* g_warp, const float* g_comp, float* gimg, float* gflow, float* gmask,
+                         float* graw, int mode, int B, int C, int H, int W, const long long* img_strides,
+                         const long long* flow_strides, const long long* mask_strides, const long long* raw_strides,
+                         const long long* g_warp_strides, const long long* g_comp_strides, const long long* gimg_strides,
+                         fsv_stream_t stream);
 
 /* ---- spectral norm (csrc/specnorm.hip) - torch.nn.utils.spectral_norm at architecture.py:60,81-84 etc. ----------- */
 int fsv_sn_power_iter(const float* W, float* u, float* v, float* scratch, float* sig, int R, int Cc, float eps,

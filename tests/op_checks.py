@@ -698,3 +698,54 @@ def check_fused_reductions(device, shapes=((1, 4096, 32), (2, 1000, 7), (1, 300,
             assert_close('fused colsum accumulate', acc, (col_ref + 1.0).float(), tol=1e-5)
     pool = ops._tickets[xd.device][0]
     assert int(pool.abs().sum()) == 0, "a fused reduction left its ticket range dirty"
+
+
+def check_warp_compose(device, b=2, h=16, w=24, mag=5.0, seed=93):
+    """Fused warp + compositing (ops.warp_concat / ops.warp_blend) against the oracle's op chain
+    (generator.py:214-227, :441-443): resample -> cat([warp, mask]) resp. raw * mask + warp * (1 - mask), with gradients
+    arriving through the warped image AND the composite (the losses read the former, the decoder the latter); forward values
+    bit-equal to the separate kernels of this library."""
+    ops, conv = pkg()
+    g = torch.Generator().manual_seed(seed)
+    img5 = torch.randn(b, 5, h, w, generator=g)           # a channel slice is what the generator passes in
+    flow = (torch.rand(b, 2, h, w, generator=g) - 0.5) * 2 * mag
+    mask = torch.rand(b, 1, h, w, generator=g)
+    raw = torch.randn(b, 3, h, w, generator=g)
+    for mode in ('concat', 'blend'):
+        ir, fr, mr, rr = [t.clone().requires_grad_(True) for t in (img5, flow, mask, raw)]
+        wref = O.resample(ir[:, :3], fr)
+        cref = torch.cat([wref, mr], dim=1) if mode == 'concat' else rr * mr + wref * (1 - mr)
+        gw = torch.randn(wref.shape, generator=g)
+        gc = torch.randn(cref.shape, generator=g)
+        ((wref * gw).sum() + (cref * gc).sum()).backward()
+        idv, fd, md, rd = [_dev(t.clone(), device).requires_grad_(True) for t in (img5, flow, mask, raw)]
+        if mode == 'concat':
+            wv, cv = ops.warp_concat(idv[:, :3], fd, md)
+            sep_w = ops.resample(idv[:, :3].detach(), fd.detach())
+            sep_c = ops.cat_channels([sep_w, md.detach()])
+        else:
+            wv, cv = ops.warp_blend(rd, idv[:, :3], fd, md)
+            sep_w = ops.resample(idv[:, :3].detach(), fd.detach())
+            sep_c = ops.blend(rd.detach(), sep_w, md.detach())
+        assert torch.equal(wv.detach().cpu(), sep_w.cpu()) and torch.equal(cv.detach().cpu(), sep_c.cpu()), mode
+        ((wv * _dev(gw, device)).sum() + (cv * _dev(gc, device)).sum()).backward()
+        assert_close(mode + ' warp', wv, wref, 1e-5)
+        assert_close(mode + ' comp', cv, cref, 1e-5)
+        assert_close(mode + ' dimg', idv.grad, ir.grad, 1e-5)
+        assert_close(mode + ' dflow', fd.grad, fr.grad, 1e-4)
+        assert_close(mode + ' dmask', md.grad, mr.grad, 1e-5)
+        if mode == 'blend':
+            assert_close('blend draw', rd.grad, rr.grad, 1e-5)
+        # gradient through one output only
+        fd2, md2 = _dev(flow.clone(), device).requires_grad_(True), _dev(mask.clone(), device).requires_grad_(True)
+        if mode == 'concat':
+            wv2, cv2 = ops.warp_concat(_dev(img5, device)[:, :3], fd2, md2)
+        else:
+            wv2, cv2 = ops.warp_blend(_dev(raw, device), _dev(img5, device)[:, :3], fd2, md2)
+        (cv2 * _dev(gc, device)).sum().backward()
+        fr2, mr2 = flow.clone().requires_grad_(True), mask.clone().requires_grad_(True)
+        w2 = O.resample(img5[:, :3], fr2)
+        c2 = torch.cat([w2, mr2], dim=1) if mode == 'concat' else raw * mr2 + w2 * (1 - mr2)
+        (c2 * gc).sum().backward()
+        assert_close(mode + ' dflow (comp only)', fd2.grad, fr2.grad, 1e-4)
+        assert_close(mode + ' dmask (comp only)', md2.grad, mr2.grad, 1e-5)

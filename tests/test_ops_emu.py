@@ -72,6 +72,10 @@ def test_spade(emu_lib, nmaps, generated, act, c, ch):
         oc.check_spade(DEV, nmaps=nmaps, generated=True, act=act, c=c, ch=ch, strided=True)
 
 
+def test_warp_compose(emu_lib):
+    oc.check_warp_compose(DEV)
+
+
 def test_upsample(emu_lib):
     oc.check_upsample(DEV)
 

@@ -79,6 +79,10 @@ def test_spade(hip_lib, nmaps, generated, act, c, ch):
         oc.check_spade(dev(), nmaps=nmaps, generated=True, act=act, c=c, ch=ch, strided=True)
 
 
+def test_warp_compose(hip_lib):
+    oc.check_warp_compose(dev())
+    oc.check_warp_compose(dev(), b=2, h=96, w=130)
+
 def test_upsample(hip_lib):
     oc.check_upsample(dev())
     oc.check_upsample(dev(), n=2, c=64, h=16, w=16)
