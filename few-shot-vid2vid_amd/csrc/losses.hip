@@ -103,10 +103,11 @@ struct PackP {
   long long rs[3], ls[3], fs[3], es[3];      // element strides (batch, channel, pixel) of each source
   int Cr, Cl, Ci, B; long long P;
   float* out;
+  int halves;        // 2: [fake | real] on the batch axis; 1: `fake` only (out [B])
 };
 
 __global__ __launch_bounds__(256) void fsv_pack_d_kernel(PackP p) {
-  const long long total = 2LL * p.B * p.P;
+  const long long total = (long long)p.halves * p.B * p.P;
   const int Ct = p.Cr + p.Cl + p.Ci;
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
     const long long n2 = i / p.P, px = i - n2 * p.P;
@@ -255,8 +256,24 @@ int fsv_pack_d_input(const float* ref, const float* lab, const float* fake, cons
   for (int i = 0; i < 3; ++i) {
     p.rs[i] = ref ? ref_strides[i] : 0; p.ls[i] = lab ? lab_strides[i] : 0; p.fs[i] = fake_strides[i]; p.es[i] = real_strides[i];
   }
-  p.Cr = Cr; p.Cl = Cl; p.Ci = Ci; p.B = B; p.P = P;
+  p.Cr = Cr; p.Cl = Cl; p.Ci = Ci; p.B = B; p.P = P; p.halves = 2;
   FSV_LAUNCH(fsv_pack_d_kernel, dim3(fsv_loss_grid(2LL * B * P) * 4), dim3(256), stream, p);
+  return fsv_check_launch();
+}
+
+// one half only: out [B][P][Cr + Cl + Ci] = [ref | label | img] (the G step runs the discriminator on the real and on the
+// generated images in separate passes: only the latter needs a backward pass)
+int fsv_pack_d_single(const float* ref, const float* lab, const float* img, float* out, int B, int Cr, int Cl, int Ci,
+                      long long P, const long long* ref_strides, const long long* lab_strides, const long long* img_strides,
+                      hipStream_t stream) {
+  if (!img || !out || B < 1 || Ci < 1 || P < 1 || (Cr > 0 && !ref) || (Cl > 0 && !lab)) return FSV_ERR_BAD_ARG;
+  PackP p;
+  p.ref = ref; p.lab = lab; p.fake = img; p.real = img; p.out = out;
+  for (int i = 0; i < 3; ++i) {
+    p.rs[i] = ref ? ref_strides[i] : 0; p.ls[i] = lab ? lab_strides[i] : 0; p.fs[i] = img_strides[i]; p.es[i] = img_strides[i];
+  }
+  p.Cr = Cr; p.Cl = Cl; p.Ci = Ci; p.B = B; p.P = P; p.halves = 1;
+  FSV_LAUNCH(fsv_pack_d_kernel, dim3(fsv_loss_grid((long long)B * P) * 4), dim3(256), stream, p);
   return fsv_check_launch();
 }
 

@@ -18,7 +18,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from . import conv, networks, ops
+from . import conv, networks, ops, streams
 from .flat import FlatAdam
 
 LOSS_NAMES_G = ['G_GAN', 'G_GAN_Feat', 'G_VGG', 'Gf_GAN', 'Gf_GAN_feat', 'GT_GAN', 'GT_GAN_Feat', 'F_Flow', 'F_Warp',
@@ -102,6 +102,7 @@ def gan_loss(preds, real):
 
 
 _ZEROS = {}
+_SPLIT_D_PASS = os.environ.get('FSV_SPLIT_D_PASS', '1') == '1'       # in-box A/B switch (profiles/r02_notes.md)
 
 
 class LossCollector:
@@ -151,13 +152,19 @@ class LossCollector:
             z = _ZEROS[ref.device] = torch.zeros(1, dtype=torch.float32, device=ref.device)
         return z
 
-    def discriminate(self, netD, label, fake, real, ref, for_discriminator):
-        """loss_collector.py:47-68: D sees [ref | label | image] with fake and real stacked on the batch axis."""
-        x = ops.pack_d_input(ref if self.concat_ref_for_D else None, label, fake, real)
-        out = netD(x)
-        half = x.shape[0] // 2
-        pred_fake = [[t[:half] for t in scale] for scale in out]
-        pred_real = [[t[half:] for t in scale] for scale in out]
+    def discriminate(self, netD, label, fake, real, ref, for_discriminator, real_out=None):
+        """loss_collector.py:47-68: D sees [ref | label | image] with fake and real stacked on the batch axis.  real_out:
+        (outputs, sigmas) of the discriminator for the real images from real_pass() - then only the generated images go through
+        it here, on the same sigmas."""
+        if real_out is not None:
+            x = ops.pack_d_single(ref if self.concat_ref_for_D else None, label, fake)
+            pred_fake, pred_real = netD(x, sn=real_out[1]), real_out[0]
+        else:
+            x = ops.pack_d_input(ref if self.concat_ref_for_D else None, label, fake, real)
+            out = netD(x)
+            half = x.shape[0] // 2
+            pred_fake = [[t[:half] for t in scale] for scale in out]
+            pred_real = [[t[half:] for t in scale] for scale in out]
         if for_discriminator:
             return [gan_loss(pred_real, True), gan_loss(pred_fake, False)]
         terms = []
@@ -211,23 +218,47 @@ class LossCollector:
             losses = [l * self.opt.lambda_temp for l in losses]
         return losses
 
-    def gan_losses(self, netD, tgt_label, reals, fakes, ref_label, ref_image, for_discriminator, netDf=None):
-        """loss_collector.py:87-120 for the per-frame discriminator and the face discriminator (no temporal branch)."""
+    def d_conditioning(self, tgt_label, ref_label, ref_image):
+        """what the per-frame discriminator sees next to the image (loss_collector.py:92-104): the valid target labels
+        (+ foreground mask) and [reference labels (+ mask) | reference image]"""
         opt = self.opt
+        lab = tgt_label.reshape(-1, *tgt_label.shape[-3:])
+        inp = valid_labels(opt, lab)
+        rl = ref_label
+        if self.concat_fg_mask_for_D:
+            inp = torch.cat([inp, fg_mask_of(opt, lab, True)], dim=1)
+            rl = torch.cat([ref_label, fg_mask_of(opt, ref_label, True)], dim=1)
+        return lab, inp, rl, torch.cat([rl, ref_image], dim=1)
+
+    def real_pass(self, netD, tgt_label, reals, ref_label, ref_image, sigmas):
+        """The G step's discriminator pass over the REAL images, without autograd (only their features are needed, as
+        feature-matching targets): it depends on the data alone, so Vid2VidModel.forward_generator issues it next to the
+        generator's forward pass, and the backward pass of the step no longer drags a zero gradient through the real half
+        of a stacked batch.  `sigmas`: one netD.begin_pass() per entry of `reals` (every stacked call of the reference is one
+        power iteration); returns (outputs, sigmas) per entry (None for absent ones) for discriminate(real_out=...)."""
+        with torch.no_grad():
+            _, inp, _, ref_concat = self.d_conditioning(tgt_label, ref_label, ref_image)
+            outs = []
+            for real, sn in zip(reals, sigmas):
+                if real is None:
+                    outs.append(None)
+                    continue
+                real4 = real.reshape(-1, *real.shape[-3:])
+                x = ops.pack_d_single(ref_concat if self.concat_ref_for_D else None, inp, real4)
+                outs.append((netD(x, sn=sn), sn))
+        return outs
+
+    def gan_losses(self, netD, tgt_label, reals, fakes, ref_label, ref_image, for_discriminator, netDf=None, real_outs=None):
+        """loss_collector.py:87-120 for the per-frame discriminator and the face discriminator (no temporal branch)."""
         total = None
-        for fake, real in zip(fakes, reals):
+        lab, inp, rl, ref_concat = self.d_conditioning(tgt_label, ref_label, ref_image)
+        for k, (fake, real) in enumerate(zip(fakes, reals)):
             if fake is None:
                 continue
-            lab = tgt_label.reshape(-1, *tgt_label.shape[-3:])
             real4 = real.reshape(-1, *real.shape[-3:])
             fake4 = fake.reshape(-1, *fake.shape[-3:])
-            inp = valid_labels(opt, lab)
-            rl = ref_label
-            if self.concat_fg_mask_for_D:
-                inp = torch.cat([inp, fg_mask_of(opt, lab, True)], dim=1)
-                rl = torch.cat([ref_label, fg_mask_of(opt, ref_label, True)], dim=1)
-            ref_concat = torch.cat([rl, ref_image], dim=1)
-            losses = self.discriminate(netD, inp, fake4, real4, ref_concat, for_discriminator)
+            losses = self.discriminate(netD, inp, fake4, real4, ref_concat, for_discriminator,
+                                       real_out=real_outs[k] if real_outs is not None else None)
             losses = losses + self.discriminate_face(netDf, fake4, lab, real4, rl, ref_image, for_discriminator)
             total = losses if total is None else [a + b for a, b in zip(total, losses)]
         return total
@@ -673,11 +704,12 @@ class Vid2VidModel(nn.Module):
                 p.requires_grad_(True)
         return history
 
-    def generate_images(self, tgt_labels, tgt_images, ref_labels, ref_images, prevs, want_prevs=True):
+    def generate_images(self, tgt_labels, tgt_images, ref_labels, ref_images, prevs, want_prevs=True, ref_labels_valid=None):
         """vid2vid_model.py:130-158 with n_frames_per_gpu == 1.  want_prevs=False: the caller drops the updated
         previous-frame buffers (the D step), so they are not built."""
         opt = self.opt
-        ref_labels_valid = valid_labels(opt, ref_labels)
+        if ref_labels_valid is None:
+            ref_labels_valid = valid_labels(opt, ref_labels)
         b, _, _, h, w = tgt_labels.shape
         tgt_label_t = tgt_labels[:, 0]
         tgt_label_valid = valid_labels(opt, tgt_label_t)
@@ -722,9 +754,7 @@ class Vid2VidModel(nn.Module):
                           conf_gt=(None, None)):
         """vid2vid_model.py:62-104."""
         lc = self.lossCollector
-        (fake, raw, warped, flow, mask), (fg, ref_fg), (ref_label, ref_image), prevs_new = \
-            self.generate_images(tgt_label, tgt_image, ref_labels, ref_images, prevs)
-        fg_union = union_fg(fg, ref_fg, self.has_fg)
+        opt = self.opt
         real = tgt_image[:, 0]
         # The G step only needs d(loss)/d(fake) from the discriminator.  The reference lets autograd also fill the
         # discriminator's (unused, later zeroed) weight gradients; skipping them changes no result of either step.
@@ -733,13 +763,38 @@ class Vid2VidModel(nn.Module):
             d_params += [p for p in self.netDf.parameters() if p.requires_grad]
         if self.netDT is not None:
             d_params += [p for p in self.netDT.parameters() if p.requires_grad]
+        real_outs = None
+        if _SPLIT_D_PASS and getattr(opt, 'n_shot', 1) == 1 and ref_labels.shape[1] == 1:
+            # The discriminator's pass over the real images needs the data only (with one reference image; with attention the
+            # conditioning is the attended reference, known after the generator ran): it is issued as a branch next to the
+            # generator's forward pass (streams.fork) and carries no autograd graph - loss_collector.py:47-68 stacks real and
+            # generated images into one batch, whose backward pass then moves a zero gradient through the real half.
+            ref_labels_valid = valid_labels(opt, ref_labels)
+            fg0 = fg_mask_of(opt, tgt_label[:, 0], self.has_fg)
+            ref_fg0 = fg_mask_of(opt, ref_labels[:, 0], self.has_fg)
+            G = self.netG
+            with_raw = (not G.spade_combine) and (G.warp_ref or G.warp_prev)
+            reals0 = [real, real * union_fg(fg0, ref_fg0, self.has_fg) if with_raw else None]
+            # ONE power iteration per stacked call of the reference, shared by its real and its generated half
+            sigmas = [self.netD.begin_pass() if r is not None else None for r in reals0]
+
+            def real_branch():
+                return lc.real_pass(self.netD, tgt_label, reals0, ref_labels_valid[:, 0], ref_images[:, 0], sigmas)
+            gen, real_outs = streams.fork(tgt_label, [
+                lambda: self.generate_images(tgt_label, tgt_image, ref_labels, ref_images, prevs,
+                                             ref_labels_valid=ref_labels_valid), real_branch])
+            (fake, raw, warped, flow, mask), (fg, ref_fg), (ref_label, ref_image), prevs_new = gen
+        else:
+            (fake, raw, warped, flow, mask), (fg, ref_fg), (ref_label, ref_image), prevs_new = \
+                self.generate_images(tgt_label, tgt_image, ref_labels, ref_images, prevs)
+        fg_union = union_fg(fg, ref_fg, self.has_fg)
         for p in d_params:
             p.requires_grad_(False)
         gt_gan = gt_feat = None
         try:
             g_gan, g_feat, gf_gan, gf_feat = lc.gan_losses(self.netD, tgt_label, [real, real * fg_union], [fake, raw],
                                                            ref_label, ref_image, for_discriminator=False,
-                                                           netDf=self.netDf)
+                                                           netDf=self.netDf, real_outs=real_outs)
             if self.isTrain and self.opt.lambda_temp > 0 and prevs[0] is not None and self.netDT is not None:  # :70-75
                 real_all = torch.cat([prevs[1], tgt_image], dim=1)
                 fake_all = torch.cat([prevs[2], fake.unsqueeze(1)], dim=1)

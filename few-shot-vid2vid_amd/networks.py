@@ -735,10 +735,30 @@ class NLayerDiscriminator(nn.Module):
         setattr(self, 'model%d' % (n_layers + 1), _seq(Conv2d(nf, 1, 4, stride=1, padding=2)))
         self._sn_group = None
 
-    def forward(self, x):
+    def forward(self, x, sn=None):
+        """sn: None - one power iteration, then the pass (the reference's forward pre-hook); or the sigmas of an earlier
+        begin_pass() - Vid2VidModel's G step runs the real and the generated images in separate passes that count as ONE
+        forward of the reference's batched call."""
+        snap = self.begin_pass() if sn is None else sn
+        for l, c in snap:
+            l._sig_cached = c
+        try:
+            return self._run(x)
+        finally:
+            for l, _ in snap:
+                l._sig_cached = None
+
+    def begin_pass(self):
+        """one power iteration of every spectral layer; returns the (layer, sigma / u / v snapshot) list for forward(sn=...)"""
         if self._sn_group is None:
             self._sn_group = ops.SpectralGroup(spectral_layers(self))
         self._sn_group.update(self.training)
+        snap = [(l, l._sig_cached) for l in self._sn_group.layers]
+        for l, _ in snap:
+            l._sig_cached = None
+        return snap
+
+    def _run(self, x):
         res = []
         x = self.model0[0](x, act=ACT_LRELU)
         res.append(x)
@@ -760,10 +780,13 @@ class MultiscaleDiscriminator(nn.Module):
         for i in range(num_D):
             setattr(self, 'discriminator_%d' % i, NLayerDiscriminator(input_nc, ndf, n_layers, getIntermFeat, stride))
 
-    def forward(self, x, ref=None):
+    def begin_pass(self):
+        return [getattr(self, 'discriminator_%d' % i).begin_pass() for i in range(self.num_D)]
+
+    def forward(self, x, ref=None, sn=None):
         result = []
         for i in range(self.num_D):
-            out = getattr(self, 'discriminator_%d' % i)(x)
+            out = getattr(self, 'discriminator_%d' % i)(x, sn=sn[i] if sn is not None else None)
             result.append(out if self.getIntermFeat else [out])
             if i + 1 < self.num_D:
                 x = ops.avgpool3s2(x)            # discriminator.py:28,56 (scripts/face/train_g8_512.sh: --num_D 2)

@@ -462,18 +462,19 @@ def set_bn_sync(world_size=1, group=None):
     _bn_sync = (int(world_size), group) if world_size and int(world_size) > 1 else None
 
 
-def bn_sync_world(groups=1):
-    """number of replicas whose statistics are pooled for a normalisation with `groups` groups (InstanceNorm is never pooled)"""
-    return _bn_sync[0] if (_bn_sync is not None and groups == 1) else 1
+def bn_sync_world(groups=1, instance=False):
+    """number of replicas whose statistics are pooled for a BatchNorm site (InstanceNorm is never pooled - also not at one
+    sample per replica, where it has a single group like BatchNorm)"""
+    return _bn_sync[0] if (_bn_sync is not None and groups == 1 and not instance) else 1
 
 
-def norm_stats(x, groups, pixels, channels, eps, run_mean=None, run_var=None, momentum=0.1, rep=1):
+def norm_stats(x, groups, pixels, channels, eps, run_mean=None, run_var=None, momentum=0.1, rep=1, instance=False):
     """rep > 1: the normalised tensor repeats every value of x `rep` times (nearest x2 up-sampling folded into the consumer)"""
     mean = torch.empty(groups * channels, dtype=torch.float32, device=x.device)
     rstd = torch.empty_like(mean)
     lib.check_device(x, run_mean, run_var)
     ws = _ws(groups, pixels, channels, x)
-    if bn_sync_world(groups) > 1:
+    if bn_sync_world(groups, instance) > 1:
         import torch.distributed as dist
         sums = torch.empty(2 * channels, dtype=torch.float64, device=x.device)
         lib.call("fsv_norm_sums", lib.ptr(x), lib.ptr(ws), lib.ptr(sums), pixels, channels, lib.stream_ptr())
@@ -523,7 +524,7 @@ class _NormActFn(torch.autograd.Function):
         g, p = (n, h * w) if instance else (1, n * h * w)
         if training or instance or run_mean is None:
             mean, rstd = norm_stats(x, g, p, c, eps, None if instance else run_mean, None if instance else run_var,
-                                    momentum)
+                                    momentum, instance=instance)
         else:
             mean = run_mean.detach().clone()
             rstd = torch.rsqrt(run_var.detach() + eps)
@@ -535,7 +536,7 @@ class _NormActFn(torch.autograd.Function):
         ctx.dims = (g, p, c)
         ctx.act, ctx.affine = act, weight is not None
         ctx.batch_stats = bool(training or instance or run_mean is None)
-        ctx.world = bn_sync_world(g) if ctx.batch_stats else 1
+        ctx.world = bn_sync_world(g, instance) if ctx.batch_stats else 1
         ctx.save_for_backward(x, y, mean, rstd, wd if wd is not None else mean)
         return y
 
@@ -1136,6 +1137,45 @@ class _PackDFn(torch.autograd.Function):
 
 def pack_d_input(ref, lab, fake, real):
     return _PackDFn.apply(ref, lab, fake, real)
+
+
+lib.register_sigs({"fsv_pack_d_single": [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_ll, c_llp, c_llp, c_llp, c_p]})
+
+
+class _PackDSingleFn(torch.autograd.Function):
+    """[ref | label | image] for one image set ([B, ...], NHWC): the G step's two discriminator passes (real images without
+    autograd, generated images with) each pack their own input.  Only `img` receives a gradient."""
+
+    @staticmethod
+    def forward(ctx, ref, lab, img):
+        img = _dense4(img)
+        b, ci, h, w = img.shape
+        cr = ref.shape[1] if ref is not None else 0
+        cl = lab.shape[1] if lab is not None else 0
+        ref = _dense4(ref) if ref is not None else None
+        lab = _dense4(lab) if lab is not None else None
+        out = empty_nhwc(b, cr + cl + ci, h, w, img)
+        z3 = _ll([0, 0, 0])
+        lib.check_device(ref, lab, img)
+        lib.call("fsv_pack_d_single", lib.ptr(ref), lib.ptr(lab), lib.ptr(img), lib.ptr(out), b, cr, cl, ci, h * w,
+                 _ll(_ncp_strides(ref)) if ref is not None else z3, _ll(_ncp_strides(lab)) if lab is not None else z3,
+                 _ll(_ncp_strides(img)), lib.stream_ptr())
+        ctx.dims = (b, cr, cl, ci, h, w)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        b, cr, cl, ci, h, w = ctx.dims
+        dimg = None
+        if ctx.needs_input_grad[2]:
+            dout = to_nhwc(dout)
+            dimg = torch.empty((b, ci, h, w), dtype=torch.float32, device=dout.device)
+            lib.call("fsv_unpack_d_grad", lib.ptr(dout), lib.ptr(dimg), b, ci, cr + cl, cr + cl + ci, h * w, lib.stream_ptr())
+        return None, None, dimg
+
+
+def pack_d_single(ref, lab, img):
+    return _PackDSingleFn.apply(ref, lab, img)
 
 
 def part_masks(pose_ch, g0=0, ngroups=9):

@@ -283,6 +283,10 @@ int fsv_hinge_bwd(const float* x, long long n, float sign, const float* gloss, f
 int fsv_pack_d_input(const float* ref, const float* lab, const float* fake, const float* real, float* out,
                      int B, int Cr, int Cl, int Ci, long long P, const long long* ref_strides, const long long* lab_strides,
                      const long long* fake_strides, const long long* real_strides, fsv_stream_t stream);
+/* the same for one image set only: out [B][P][Cr+Cl+Ci] = [ref | label | img] */
+int fsv_pack_d_single(const float* ref, const float* lab, const float* img, float* out, int B, int Cr, int Cl, int Ci,
+                      long long P, const long long* ref_strides, const long long* lab_strides, const long long* img_strides,
+                      fsv_stream_t stream);
 int fsv_unpack_d_grad(const float* dout, float* dfake, int B, int Ci, int Coff, int Ct, long long P, fsv_stream_t stream);
 /* DensePose part-group masks (models/input_process.py:64-94): x = pose channel [B, T, P] (strides sb, st, 1), N = B*T;
  * y[N][ngroups][P] = 1 where (x/2+0.5)*24 is within 0.1 of a member of group g0+g (9 groups; group 8 = face parts 23/24) */
