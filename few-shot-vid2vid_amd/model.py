@@ -102,7 +102,7 @@ def gan_loss(preds, real):
 
 
 _ZEROS = {}
-_SPLIT_D_PASS = os.environ.get('FSV_SPLIT_D_PASS', '1') == '1'       # in-box A/B switch (profiles/r02_notes.md)
+_SPLIT_D_PASS = os.environ.get('FSV_SPLIT_D_PASS', '1') == '1'       # in-box A/B switch (profiles/r02_notes.md section 10)
 
 
 class LossCollector:
