@@ -106,19 +106,48 @@ struct PackP {
   int halves;        // 2: [fake | real] on the batch axis; 1: `fake` only (out [B])
 };
 
+// A workgroup owns 64 consecutive pixels of one sample: per source channel the 64 values are read as one run (coalesced for
+// planar sources, the layout the data loader delivers), staged in LDS and written out as 64 * Ct consecutive floats (the
+// one-thread-per-pixel form of round 1 wrote 4-byte words Ct floats apart: 225 us for the 512x512 B=2 input).
+#define FSV_PACK_PX 64
+#define FSV_PACK_MAXC 64
 __global__ __launch_bounds__(256) void fsv_pack_d_kernel(PackP p) {
-  const long long total = (long long)p.halves * p.B * p.P;
+  __shared__ float t[FSV_PACK_PX * (FSV_PACK_MAXC + 1)];
   const int Ct = p.Cr + p.Cl + p.Ci;
-  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
-    const long long n2 = i / p.P, px = i - n2 * p.P;
+  const long long tiles = (p.P + FSV_PACK_PX - 1) / FSV_PACK_PX;
+  const long long ntile = (long long)p.halves * p.B * tiles;
+  const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
+  for (long long tile = blockIdx.x; tile < ntile; tile += gridDim.x) {
+    const long long n2 = tile / tiles, px0 = (tile - n2 * tiles) * FSV_PACK_PX;
     const long long n = n2 % p.B;
-    float* o = p.out + i * Ct;
-    for (int c = 0; c < p.Cr; ++c) o[c] = p.ref[n * p.rs[0] + c * p.rs[1] + px * p.rs[2]];
-    for (int c = 0; c < p.Cl; ++c) o[p.Cr + c] = p.lab[n * p.ls[0] + c * p.ls[1] + px * p.ls[2]];
     const bool isfake = n2 < p.B;
-    const float* src = isfake ? p.fake : p.real;
-    const long long* st = isfake ? p.fs : p.es;
-    for (int c = 0; c < p.Ci; ++c) o[p.Cr + p.Cl + c] = src[n * st[0] + c * st[1] + px * st[2]];
+    const long long px = px0 + lane;
+    const bool ok = px < p.P;
+    const long long npx = (p.P - px0) < FSV_PACK_PX ? (p.P - px0) : FSV_PACK_PX;
+    float* o = p.out + (n2 * p.P + px0) * Ct;
+    for (int c0 = 0; c0 < Ct; c0 += FSV_PACK_MAXC) {           // 64 channels per round (one-hot street labels: Ct = 76)
+      const int cw = (Ct - c0) < FSV_PACK_MAXC ? (Ct - c0) : FSV_PACK_MAXC;
+      for (int cl = grp; cl < cw; cl += 4) {
+        const int c = c0 + cl;
+        float v = 0.f;
+        if (ok) {
+          if (c < p.Cr) v = p.ref[n * p.rs[0] + c * p.rs[1] + px * p.rs[2]];
+          else if (c < p.Cr + p.Cl) v = p.lab[n * p.ls[0] + (c - p.Cr) * p.ls[1] + px * p.ls[2]];
+          else {
+            const float* src = isfake ? p.fake : p.real;
+            const long long* st = isfake ? p.fs : p.es;
+            v = src[n * st[0] + (c - p.Cr - p.Cl) * st[1] + px * st[2]];
+          }
+        }
+        t[lane * (FSV_PACK_MAXC + 1) + cl] = v;
+      }
+      __syncthreads();
+      for (int i = threadIdx.x; i < (int)npx * cw; i += 256) {
+        const int pl = i / cw, cl = i - pl * cw;
+        o[(long long)pl * Ct + c0 + cl] = t[pl * (FSV_PACK_MAXC + 1) + cl];
+      }
+      __syncthreads();
+    }
   }
 }
 
@@ -247,6 +276,8 @@ int fsv_hinge_bwd(const float* x, long long n, float sign, const float* gloss, f
   return fsv_check_launch();
 }
 
+static inline int fsv_pack_grid(long long tiles) { return (int)(tiles < 16384 ? (tiles < 1 ? 1 : tiles) : 16384); }
+
 int fsv_pack_d_input(const float* ref, const float* lab, const float* fake, const float* real, float* out,
                      int B, int Cr, int Cl, int Ci, long long P, const long long* ref_strides, const long long* lab_strides,
                      const long long* fake_strides, const long long* real_strides, hipStream_t stream) {
@@ -257,7 +288,7 @@ int fsv_pack_d_input(const float* ref, const float* lab, const float* fake, cons
     p.rs[i] = ref ? ref_strides[i] : 0; p.ls[i] = lab ? lab_strides[i] : 0; p.fs[i] = fake_strides[i]; p.es[i] = real_strides[i];
   }
   p.Cr = Cr; p.Cl = Cl; p.Ci = Ci; p.B = B; p.P = P; p.halves = 2;
-  FSV_LAUNCH(fsv_pack_d_kernel, dim3(fsv_loss_grid(2LL * B * P) * 4), dim3(256), stream, p);
+  FSV_LAUNCH(fsv_pack_d_kernel, dim3(fsv_pack_grid(2LL * B * ((P + FSV_PACK_PX - 1) / FSV_PACK_PX))), dim3(256), stream, p);
   return fsv_check_launch();
 }
 
@@ -273,7 +304,7 @@ int fsv_pack_d_single(const float* ref, const float* lab, const float* img, floa
     p.rs[i] = ref ? ref_strides[i] : 0; p.ls[i] = lab ? lab_strides[i] : 0; p.fs[i] = img_strides[i]; p.es[i] = img_strides[i];
   }
   p.Cr = Cr; p.Cl = Cl; p.Ci = Ci; p.B = B; p.P = P; p.halves = 1;
-  FSV_LAUNCH(fsv_pack_d_kernel, dim3(fsv_loss_grid((long long)B * P) * 4), dim3(256), stream, p);
+  FSV_LAUNCH(fsv_pack_d_kernel, dim3(fsv_pack_grid((long long)B * ((P + FSV_PACK_PX - 1) / FSV_PACK_PX))), dim3(256), stream, p);
   return fsv_check_launch();
 }
 
