@@ -149,7 +149,7 @@ class LossCollector:
         """the constant 0 of absent loss terms (one shared read-only tensor per device: no fill launch per use)"""
         z = _ZEROS.get(ref.device)
         if z is None:
-            z = _ZEROS[ref.device] = torch.zeros(1, dtype=torch.float32, device=ref.device)
+            z = _ZEROS[ref.device] = streams.shared(lambda: torch.zeros(1, dtype=torch.float32, device=ref.device))
         return z
 
     def discriminate(self, netD, label, fake, real, ref, for_discriminator, real_out=None):

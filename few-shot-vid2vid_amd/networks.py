@@ -181,7 +181,8 @@ class SPADE(nn.Module):
                 wg, wb = weights[0][0], weights[1][0]
                 zb = getattr(self, '_zero_bias', None)
                 if zb is None or zb.shape[0] != wg.shape[0] or zb.device != wg.device:
-                    zb = self._zero_bias = torch.zeros(wg.shape[0], self.norm_nc, dtype=wg.dtype, device=wg.device)
+                    zb = self._zero_bias = streams.shared(
+                        lambda: torch.zeros(wg.shape[0], self.norm_nc, dtype=wg.dtype, device=wg.device))
                 use_w.append((wg, wb, zb, zb))
             use_maps.append(m)
         self.norm.note_forward()

@@ -79,7 +79,8 @@ def _ticket(like):
     launch leaves its range zeroed"""
     ent = _tickets.get(like.device)
     if ent is None:
-        ent = _tickets[like.device] = [torch.zeros(_TICKET_POOL, dtype=torch.int32, device=like.device), 0]
+        from . import streams
+        ent = _tickets[like.device] = [streams.shared(lambda: torch.zeros(_TICKET_POOL, dtype=torch.int32, device=like.device)), 0]
     pool, cur = ent
     ent[1] = (cur + _TICKET_SLOTS) % _TICKET_POOL
     return ctypes.c_void_p(pool.data_ptr() + 4 * cur)
@@ -820,7 +821,8 @@ def _linspace(n, device):
     t = _lin_cache.get(key)
     if t is None:
         # built on the host exactly like the reference's get_grid (base_network.py:13-26), then uploaded
-        t = torch.linspace(-1.0, 1.0, n).to(device)
+        from . import streams
+        t = streams.shared(lambda: torch.linspace(-1.0, 1.0, n).to(device))
         _lin_cache[key] = t
     return t
 
@@ -1072,7 +1074,8 @@ def weighted_sum(terms, weights=None):
         if wv is None:
             if len(_wvec_cache) > 256:
                 _wvec_cache.clear()
-            wv = _wvec_cache[key] = torch.tensor(weights, dtype=cat.dtype).to(cat.device)
+            from . import streams
+            wv = _wvec_cache[key] = streams.shared(lambda: torch.tensor(weights, dtype=cat.dtype).to(cat.device))
         cat = cat * wv
     return cat.sum(dim=0, keepdim=True)
 

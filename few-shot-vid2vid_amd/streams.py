@@ -48,6 +48,19 @@ def _record(obj, stream):
             _record(o, stream)
 
 
+def shared(make):
+    """A device tensor that is created once and then read by kernels of ANY stream (zero constants, the ticket pool of the
+    fused reductions): `make()` enqueues its fill on the current stream only, so the fill is waited for here - otherwise the
+    first use on another stream races with it (seen on hardware: a first iteration whose branch zeroed the ticket pool
+    while the other branch was already counting in it)."""
+    t = make()
+    if torch.is_tensor(t) and t.is_cuda:
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("a shared device constant was first needed inside a graph capture: run one eager iteration first")
+        torch.cuda.current_stream(t.device).synchronize()
+    return t
+
+
 def fork(ref, fns):
     """[f() for f in fns]; on a GPU fns[1:] run on side streams next to fns[0] on the current one and are joined before the
     return.  `ref` is any tensor of the pass (it names the device; CPU / emulated tensors run the branches in order)."""
