@@ -148,9 +148,19 @@ class GraphedIteration:
             self.opt_G.exchange_all()
         self._seg_a()
 
+    def _quiesce(self):
+        """Before a capture that follows collectives: wait for the device AND let the process group's watchdog thread reap the
+        finished work objects (it polls their events every 100 ms).  A watchdog `hipEventQuery` that lands inside a capture was
+        seen to fail with hipErrorCapturedEvent on ROCm 7 (one run in eight, once the captured body itself records and
+        destroys events - the branch streams) and takes the process down; with nothing left to poll it stays quiet."""
+        torch.cuda.synchronize(self.opt_G.device)
+        if self.segmented:
+            import time
+            time.sleep(0.35)
+
     def _capture(self, e, save_images):
         dev = self.opt_G.device
-        torch.cuda.synchronize(dev)
+        self._quiesce()
         if not self.segmented:
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
@@ -163,19 +173,19 @@ class GraphedIteration:
         with torch.cuda.graph(gs[0], capture_error_mode='thread_local'):
             self._seg_d(e)
         gs[0].replay(); self.opt_D.exchange_all()
-        torch.cuda.synchronize(dev)
+        self._quiesce()
         with torch.cuda.graph(gs[1], pool=gs[0].pool(), capture_error_mode='thread_local'):
             self._seg_g(e, save_images)
         gs[1].replay()
         if self.split:
             self._exchange_g_first()
-            torch.cuda.synchronize(dev)
+            self._quiesce()
             with torch.cuda.graph(gs[2], pool=gs[0].pool(), capture_error_mode='thread_local'):
                 self._seg_g2()
             gs[2].replay(); self._exchange_g_rest()
         else:
             self.opt_G.exchange_all()
-        torch.cuda.synchronize(dev)
+        self._quiesce()
         with torch.cuda.graph(gs[-1], pool=gs[0].pool(), capture_error_mode='thread_local'):
             self._seg_a()
         gs[-1].replay()
