@@ -303,6 +303,27 @@ __global__ __launch_bounds__(256) void fsv_norm_apply_kernel(const float* x, con
   }
 }
 
+// the same for C % 4 == 0: four consecutive channels per work-item (16-byte loads / stores, one index division per four
+// elements; 32-bit index arithmetic - the host takes this form only below 2^31 elements)
+__global__ __launch_bounds__(256) void fsv_norm_apply4_kernel(const float* x, const float* mean, const float* rstd,
+                                                              const float* w, const float* b, float* y, unsigned total4,
+                                                              unsigned PC4, unsigned C4, int act) {
+  const unsigned stride = gridDim.x * 256u;
+  for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < total4; i += stride) {
+    const unsigned c = (i % C4) * 4u, g = i / PC4;
+    const unsigned gc = g * C4 * 4u + c;
+    const float4 xv = *reinterpret_cast<const float4*>(x + (size_t)i * 4);
+    const float4 mu = *reinterpret_cast<const float4*>(mean + gc), rs = *reinterpret_cast<const float4*>(rstd + gc);
+    float4 v = make_float4((xv.x - mu.x) * rs.x, (xv.y - mu.y) * rs.y, (xv.z - mu.z) * rs.z, (xv.w - mu.w) * rs.w);
+    if (w) {
+      const float4 wv = *reinterpret_cast<const float4*>(w + c), bv = *reinterpret_cast<const float4*>(b + c);
+      v = make_float4(v.x * wv.x + bv.x, v.y * wv.y + bv.y, v.z * wv.z + bv.z, v.w * wv.w + bv.w);
+    }
+    *reinterpret_cast<float4*>(y + (size_t)i * 4) = make_float4(fsv_act(v.x, act), fsv_act(v.y, act), fsv_act(v.z, act),
+                                                                fsv_act(v.w, act));
+  }
+}
+
 // s1[g][c], s2[g][c]; optional affine grads dw[c] = sum_g s2, db[c] = sum_g s1 (one thread per channel)
 __global__ __launch_bounds__(256) void fsv_norm_bwd_final_kernel(const double* part, float* s1, float* s2, float* dw,
                                                                  float* db, int G, int C, int nchunks) {
@@ -340,6 +361,34 @@ __global__ __launch_bounds__(256) void fsv_norm_bwd_apply_kernel(const float* dy
     float wv = w ? w[c] : 1.f;
     // fixed_stats: eval-mode normalisation (running statistics are constants): only the affine scale remains
     dx[i] = fixed_stats ? wv * rs * d : wv * rs * (d - s1[gc] * invP - xh * (s2[gc] * invP));
+  }
+}
+
+// four consecutive channels per work-item (C % 4 == 0, fewer than 2^31 elements)
+__global__ __launch_bounds__(256) void fsv_norm_bwd_apply4_kernel(const float* dy, const float* y, const float* x,
+                                                                  const float* mean, const float* rstd, const float* w,
+                                                                  const float* s1, const float* s2, float* dx,
+                                                                  unsigned total4, unsigned PC4, unsigned C4, int P, int act,
+                                                                  int fixed_stats) {
+  const unsigned stride = gridDim.x * 256u;
+  const float invP = 1.0f / (float)P;
+  for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < total4; i += stride) {
+    const unsigned c = (i % C4) * 4u, g = i / PC4;
+    const unsigned gc = g * C4 * 4u + c;
+    const size_t o = (size_t)i * 4;
+    const float4 xv = *reinterpret_cast<const float4*>(x + o), dv = *reinterpret_cast<const float4*>(dy + o);
+    const float4 yv = y ? *reinterpret_cast<const float4*>(y + o) : make_float4(0.f, 0.f, 0.f, 0.f);
+    const float xa[4] = {xv.x, xv.y, xv.z, xv.w}, da[4] = {dv.x, dv.y, dv.z, dv.w}, ya[4] = {yv.x, yv.y, yv.z, yv.w};
+    float r[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float rs = rstd[gc + j];
+      const float xh = (xa[j] - mean[gc + j]) * rs;
+      const float d = fsv_act_grad(da[j], ya[j], act);
+      const float wv = w ? w[c + j] : 1.f;
+      r[j] = fixed_stats ? wv * rs * d : wv * rs * (d - s1[gc + j] * invP - xh * (s2[gc + j] * invP));
+    }
+    *reinterpret_cast<float4*>(dx + o) = make_float4(r[0], r[1], r[2], r[3]);
   }
 }
 
@@ -478,12 +527,35 @@ static inline int fsv_ew_grid(long long total) {
   return (int)g;
 }
 
+static inline bool fsv_ew_vec4(long long total, int C) {
+  static int on = -1;            // FSV_NORM_VEC4=0: in-box A/B switch (profiles/r02_notes.md section 13)
+  if (on < 0) { const char* e = getenv("FSV_NORM_VEC4"); on = (e && e[0] == '0') ? 0 : 1; }
+  return on && C % 4 == 0 && total < (1LL << 31);
+}
+
+static inline void fsv_launch_bwd_apply(const float* dy, const float* y, const float* x, const float* mean, const float* rstd,
+                                        const float* w, const float* s1, const float* s2, float* dx, long long total,
+                                        long long PC, int C, int P, int act, int fixed_stats, hipStream_t stream) {
+  if (fsv_ew_vec4(total, C)) {
+    FSV_LAUNCH(fsv_norm_bwd_apply4_kernel, dim3(fsv_ew_grid(total / 4)), dim3(256), stream, dy, y, x, mean, rstd, w, s1, s2, dx,
+               (unsigned)(total / 4), (unsigned)(PC / 4), (unsigned)(C / 4), P, act, fixed_stats);
+  } else {
+    FSV_LAUNCH(fsv_norm_bwd_apply_kernel, dim3(fsv_ew_grid(total)), dim3(256), stream, dy, y, x, mean, rstd, w, s1, s2, dx,
+               total, PC, C, P, act, fixed_stats);
+  }
+}
+
 int fsv_norm_apply(const float* x, const float* mean, const float* rstd, const float* w, const float* b, float* y,
                    int G, int P, int C, int act, hipStream_t stream) {
   if (!x || !mean || !rstd || !y || (w && !b)) return FSV_ERR_BAD_ARG;
   long long total = (long long)G * P * C;
-  FSV_LAUNCH(fsv_norm_apply_kernel, dim3(fsv_ew_grid(total)), dim3(256), stream, x, mean, rstd, w, b, y, total,
-             (long long)P * C, C, act);
+  if (fsv_ew_vec4(total, C)) {
+    FSV_LAUNCH(fsv_norm_apply4_kernel, dim3(fsv_ew_grid(total / 4)), dim3(256), stream, x, mean, rstd, w, b, y,
+               (unsigned)(total / 4), (unsigned)((long long)P * C / 4), (unsigned)(C / 4), act);
+  } else {
+    FSV_LAUNCH(fsv_norm_apply_kernel, dim3(fsv_ew_grid(total)), dim3(256), stream, x, mean, rstd, w, b, y, total,
+               (long long)P * C, C, act);
+  }
   return fsv_check_launch();
 }
 
@@ -502,8 +574,8 @@ int fsv_norm_bwd(const float* dy, const float* y, const float* x, const float* m
   FSV_LAUNCH(fsv_norm_bwd_final_kernel, dim3(fsv_cdiv(C, 4)), dim3(256), stream, (const double*)workspace, s1, s2, dw,
              db, G, C, nchunks);
   long long total = (long long)G * P * C;
-  FSV_LAUNCH(fsv_norm_bwd_apply_kernel, dim3(fsv_ew_grid(total)), dim3(256), stream, dy, y, x, mean, rstd, w,
-             (const float*)s1, (const float*)s2, dx, total, (long long)P * C, C, P, act, fixed_stats);
+  fsv_launch_bwd_apply(dy, y, x, mean, rstd, w, (const float*)s1, (const float*)s2, dx, total, (long long)P * C, C, P, act,
+                       fixed_stats, stream);
   return fsv_check_launch();
 }
 
@@ -549,8 +621,8 @@ int fsv_norm_bwd_fused(const float* dy, const float* y, const float* x, const fl
   rp.counter = counters; rp.o0 = s1; rp.o1 = s2; rp.o2 = dw; rp.o3 = db;
   fsv_launch_red<FSV_RED_BWD>(pl, rp, G, stream);
   long long total = (long long)G * P * C;
-  FSV_LAUNCH(fsv_norm_bwd_apply_kernel, dim3(fsv_ew_grid(total)), dim3(256), stream, dy, y, x, mean, rstd, w,
-             (const float*)s1, (const float*)s2, dx, total, (long long)P * C, C, P, act, fixed_stats);
+  fsv_launch_bwd_apply(dy, y, x, mean, rstd, w, (const float*)s1, (const float*)s2, dx, total, (long long)P * C, C, P, act,
+                       fixed_stats, stream);
   return fsv_check_launch();
 }
 
@@ -641,8 +713,7 @@ int fsv_norm_bwd_apply(const float* dy, const float* y, const float* x, const fl
   if (!dy || !x || !mean || !rstd || !s1 || !s2 || !dx || P < 1 || C < 1 || count < 1) return FSV_ERR_BAD_ARG;
   if (act != FSV_ACT_NONE && !y) return FSV_ERR_BAD_ARG;
   long long total = (long long)P * C;
-  FSV_LAUNCH(fsv_norm_bwd_apply_kernel, dim3(fsv_ew_grid(total)), dim3(256), stream, dy, y, x, mean, rstd, w, s1, s2, dx,
-             total, total, C, count, act, 0);
+  fsv_launch_bwd_apply(dy, y, x, mean, rstd, w, s1, s2, dx, total, total, C, count, act, 0, stream);
   return fsv_check_launch();
 }
 
