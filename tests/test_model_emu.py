@@ -42,7 +42,8 @@ def test_train_step_with_vgg_loss_tiny(emu_lib):
 
 def test_layout_cache_matches_per_call_prep_tiny(emu_lib):
     """persistent K-major weight layouts + grouped refresh after Adam == per-call re-arrangement"""
-    mc.check_layout_cache(DEV, mc.tiny_opt(warp_ref=True, spade_combine=True, remove_face_labels=True), b=1)
+    mc.check_layout_cache(DEV, mc.tiny_opt(warp_ref=True, spade_combine=True, remove_face_labels=True, fineSize=32, loadSize=32,
+                                           n_downsample_G=3, n_adaptive_layers=2), b=1)
 
 
 def test_train_step_street_one_hot_tiny(emu_lib):
@@ -60,8 +61,8 @@ def test_train_step_with_face_discriminator_tiny(emu_lib):
 
 def test_temporal_discriminator_tiny(emu_lib):
     """--lambda_temp > 0: netDT on two stacked frames (D terms DT_real / DT_fake, G terms GT_GAN / GT_GAN_Feat)"""
-    mc.check_temporal_step(DEV, mc.tiny_opt(warp_ref=True, spade_combine=True, remove_face_labels=True, lambda_temp=2.0),
-                           b=2)
+    mc.check_temporal_step(DEV, mc.tiny_opt(warp_ref=True, spade_combine=True, remove_face_labels=True, lambda_temp=2.0,
+                                            fineSize=32, loadSize=32, n_downsample_G=3, n_adaptive_layers=2), b=2)
 
 
 def test_train_step_two_reference_images_tiny(emu_lib):
