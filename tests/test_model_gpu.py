@@ -81,4 +81,4 @@ def test_train_step_with_face_refinement(hip_lib):
     """--refine_face: face generator on device-cropped faces, bilinear paste-back"""
     mc.check_train_step(dev(), mc.tiny_opt(ngf=8, ndf=8, nff=8, warp_ref=True, spade_combine=True, remove_face_labels=True,
                                            refine_face=True, fineSize=128, loadSize=128, n_downsample_G=4,
-                                           n_adaptive_layers=3), b=2)
+                                           n_adaptive_layers=3), b=2, grad_tol=3e-2)      # hardware record: 1.56e-2 (fc_spade_1_1.0.bias)
