@@ -55,7 +55,8 @@ def _worker(rank, world, port, out_dir, split):
     for it in range(3):                  # eager, capture (+ replay), replay
         gi(data)
     torch.cuda.synchronize()
-    torch.save(dict(g={n: p.grad.detach().cpu() for n, p in model.netG.named_parameters()},
+    torch.save(dict(g={n: (p.grad.detach().cpu() if p.grad is not None else torch.zeros_like(p).cpu())
+                       for n, p in model.netG.named_parameters()},
                     p={n: p.detach().cpu() for n, p in model.netG.named_parameters()}),
                os.path.join(out_dir, 'rccl%d_rank%d.pt' % (int(split), rank)))
     dist.destroy_process_group()
