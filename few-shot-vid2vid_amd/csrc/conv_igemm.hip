@@ -43,7 +43,12 @@ __device__ __forceinline__ void fsv_xcd_tile(int nx, int ny, int& bx, int& by) {
 // The LDS fragment reads of k-group g + 1 are issued (into a second register set) BEFORE the MFMAs of group g and pinned
 // there with scheduling fences - left alone the compiler sinks every read next to its MFMAs and waits for it (read,
 // s_waitcnt lgkmcnt(0), two MFMAs, read, ...), which exposes the LDS latency whenever a SIMD holds a single wave.
-template <int BM, int BN, int WM, int WN>
+// PF: prefetch distance of the global loads in chunks.  PF = 1 (every tile of the launch plan): the loads of chunk k + 1 are
+// issued at the top of chunk k and stored to LDS behind its 12th MFMA.  PF = 2 (tile ids 10 - 12, reachable through force_tile
+// only - built at the end of round 2 from the ISA reading in profiles/r02_notes.md section 15, NOT yet measured on hardware):
+// two register sets, the loads of chunk k + 2 are issued at the top of chunk k and the set stored behind the 12th MFMA was
+// loaded a whole chunk earlier, for grids with one workgroup per CU where nothing else covers the HBM latency.
+template <int BM, int BN, int WM, int WN, int PF = 1>
 __global__ __launch_bounds__(64 * WM * WN) void fsv_conv_igemm_kernel(ConvP p) {
   constexpr int BK = FSV_BK;
   constexpr int NT = 64 * WM * WN;    // 4 or 8 waves
@@ -96,7 +101,7 @@ __global__ __launch_bounds__(64 * WM * WN) void fsv_conv_igemm_kernel(ConvP p) {
   const int c_begin = zk * cps;
   const int c_end = (c_begin + cps < p.nchunks) ? (c_begin + cps) : p.nchunks;
 
-  float4 areg[NPA], breg[NPB];
+  float4 areg[PF][NPA], breg[PF][NPB];
   unsigned aoff[NPA], boff[NPB];
   // Byte offsets of one chunk's loads (FSV_BUF_OOB = "absent": hardware zero fill), computed one chunk ahead of their loads
   // so that this VALU work sits between the MFMAs instead of in front of them.  Branch-free on purpose (a guarded integer
@@ -130,24 +135,24 @@ __global__ __launch_bounds__(64 * WM * WN) void fsv_conv_igemm_kernel(ConvP p) {
     cur_t = wrap ? cur_t + 1 : cur_t;
     cur_b += BK * p.ldw;
   };
-  auto issue_loads = [&]() {
+  auto issue_loads = [&](float4 (&ar)[NPA], float4 (&br)[NPB]) {
 #pragma unroll
-    for (int i = 0; i < NPA; ++i) areg[i] = fsv_buf_load4(abuf, aoff[i]);
+    for (int i = 0; i < NPA; ++i) ar[i] = fsv_buf_load4(abuf, aoff[i]);
 #pragma unroll
-    for (int i = 0; i < NPB; ++i) breg[i] = fsv_buf_load4(bbuf, boff[i]);
+    for (int i = 0; i < NPB; ++i) br[i] = fsv_buf_load4(bbuf, boff[i]);
   };
-  auto store_chunk = [&](int buf) {
+  auto store_chunk = [&](int buf, const float4 (&ar)[NPA], const float4 (&br)[NPB]) {
     float* a_dst = As + buf * A_ST;
     float* b_dst = Bs + buf * B_ST;
 #pragma unroll
     for (int i = 0; i < NPA; ++i) {
       const int r = ar0 + i * RPA;
-      *reinterpret_cast<float4*>(&a_dst[r * BK + ((kq ^ ((r >> 1) & 7)) << 2)]) = areg[i];
+      *reinterpret_cast<float4*>(&a_dst[r * BK + ((kq ^ ((r >> 1) & 7)) << 2)]) = ar[i];
     }
 #pragma unroll
     for (int i = 0; i < NPB; ++i) {
       const int kr = br0 + i * RPB;
-      *reinterpret_cast<float4*>(&b_dst[kr * BN + bq * 4]) = breg[i];
+      *reinterpret_cast<float4*>(&b_dst[kr * BN + bq * 4]) = br[i];
     }
   };
 
@@ -197,44 +202,93 @@ __global__ __launch_bounds__(64 * WM * WN) void fsv_conv_igemm_kernel(ConvP p) {
       }
   };
 
-  if (c_begin < c_end) {
+  // one K chunk: the loads issued at its top go into (lar, lbr); (sar, sbr) is the set stored into the other LDS buffer behind
+  // three quarters of its MFMAs - the same set for PF = 1, the one loaded a chunk earlier for PF = 2
+  auto chunk = [&](int buf, float4 (&lar)[NPA], float4 (&lbr)[NPB], const float4 (&sar)[NPA], const float4 (&sbr)[NPB]) {
+    issue_loads(lar, lbr);
+    const float* a_src = As + buf * A_ST;
+    const float* b_src = Bs + buf * B_ST;
+    float4 fa[2][2][TM];
+    float fb[2][4][TN];
+    read_group(a_src, b_src, 0, fa[0], fb[0]);
+    FSV_SCHED_FENCE();
     calc_offsets();
-    issue_loads();
-    calc_offsets();
-    store_chunk(0);
+    read_group(a_src, b_src, 1, fa[1], fb[1]);
+    FSV_SCHED_FENCE();
+    mma_group(fa[0], fb[0]);
+    FSV_SCHED_FENCE();
+    read_group(a_src, b_src, 2, fa[0], fb[0]);
+    FSV_SCHED_FENCE();
+    mma_group(fa[1], fb[1]);
+    FSV_SCHED_FENCE();
+    read_group(a_src, b_src, 3, fa[1], fb[1]);
+    FSV_SCHED_FENCE();
+    mma_group(fa[0], fb[0]);
+    FSV_SCHED_FENCE();
+    store_chunk(buf ^ 1, sar, sbr);
+    FSV_SCHED_FENCE();
+    mma_group(fa[1], fb[1]);
     __syncthreads();
-    int buf = 0;
-#pragma unroll 1
-    for (int kc = c_begin; kc < c_end; ++kc) {
-      // the next chunk's loads are issued first (offsets were computed during the previous iteration) and land in
-      // registers under the first three quarters of this chunk's MFMAs; they are stored into the OTHER buffer (nobody
-      // reads it during this iteration), so one barrier per chunk suffices.  The copy stored by the last iteration is never
-      // used.
-      issue_loads();
-      const float* a_src = As + buf * A_ST;
-      const float* b_src = Bs + buf * B_ST;
-      float4 fa[2][2][TM];
-      float fb[2][4][TN];
-      read_group(a_src, b_src, 0, fa[0], fb[0]);
-      FSV_SCHED_FENCE();
+  };
+
+  if (c_begin < c_end) {
+    if constexpr (PF == 1) {
       calc_offsets();
-      read_group(a_src, b_src, 1, fa[1], fb[1]);
-      FSV_SCHED_FENCE();
-      mma_group(fa[0], fb[0]);
-      FSV_SCHED_FENCE();
-      read_group(a_src, b_src, 2, fa[0], fb[0]);
-      FSV_SCHED_FENCE();
-      mma_group(fa[1], fb[1]);
-      FSV_SCHED_FENCE();
-      read_group(a_src, b_src, 3, fa[1], fb[1]);
-      FSV_SCHED_FENCE();
-      mma_group(fa[0], fb[0]);
-      FSV_SCHED_FENCE();
-      store_chunk(buf ^ 1);
-      FSV_SCHED_FENCE();
-      mma_group(fa[1], fb[1]);
+      issue_loads(areg[0], breg[0]);
+      calc_offsets();
+      store_chunk(0, areg[0], breg[0]);
       __syncthreads();
-      buf ^= 1;
+      int buf = 0;
+#pragma unroll 1
+      for (int kc = c_begin; kc < c_end; ++kc) {
+        // the next chunk's loads are issued first (offsets were computed during the previous iteration) and land in
+        // registers under the first three quarters of this chunk's MFMAs; they are stored into the OTHER buffer (nobody
+        // reads it during this iteration), so one barrier per chunk suffices.  The copy stored by the last iteration is never
+        // used.  (Written out instead of calling chunk(): the plan's kernels keep the exact instruction stream that was
+        // validated on hardware.)
+        issue_loads(areg[0], breg[0]);
+        const float* a_src = As + buf * A_ST;
+        const float* b_src = Bs + buf * B_ST;
+        float4 fa[2][2][TM];
+        float fb[2][4][TN];
+        read_group(a_src, b_src, 0, fa[0], fb[0]);
+        FSV_SCHED_FENCE();
+        calc_offsets();
+        read_group(a_src, b_src, 1, fa[1], fb[1]);
+        FSV_SCHED_FENCE();
+        mma_group(fa[0], fb[0]);
+        FSV_SCHED_FENCE();
+        read_group(a_src, b_src, 2, fa[0], fb[0]);
+        FSV_SCHED_FENCE();
+        mma_group(fa[1], fb[1]);
+        FSV_SCHED_FENCE();
+        read_group(a_src, b_src, 3, fa[1], fb[1]);
+        FSV_SCHED_FENCE();
+        mma_group(fa[0], fb[0]);
+        FSV_SCHED_FENCE();
+        store_chunk(buf ^ 1, areg[0], breg[0]);
+        FSV_SCHED_FENCE();
+        mma_group(fa[1], fb[1]);
+        __syncthreads();
+        buf ^= 1;
+      }
+    } else {
+      // chunk c_begin -> LDS buffer 0, chunk c_begin + 1 -> register set 1, offsets of c_begin + 2 ready; then two chunks per
+      // trip so that the register sets are addressed statically: an even step loads c + 2 into set 0 and stores set 1 (c + 1),
+      // an odd step the other way round.  Chunks past c_end read zeros (see calc_offsets) and are never multiplied.
+      calc_offsets();
+      issue_loads(areg[0], breg[0]);
+      calc_offsets();
+      store_chunk(0, areg[0], breg[0]);
+      issue_loads(areg[PF - 1], breg[PF - 1]);
+      calc_offsets();
+      __syncthreads();
+#pragma unroll 1
+      for (int kc = c_begin; kc < c_end; kc += 2) {
+        chunk(0, areg[0], breg[0], areg[PF - 1], breg[PF - 1]);
+        if (kc + 1 >= c_end) break;
+        chunk(1, areg[PF - 1], breg[PF - 1], areg[0], breg[0]);
+      }
     }
   }
 
@@ -971,6 +1025,10 @@ static inline int fsv_tile_dims(int tile, int& bm, int& bn) {
     case 2: bm = 128; bn = 32; return 0;
     case 4: bm = 64; bn = 64; return 0;
     case 9: bm = 64; bn = 128; return 0;
+    // experimental, force_tile only (never chosen by fsv_conv_plan): the 8-wave tiles with a prefetch distance of two chunks
+    case 10: bm = 64; bn = 128; return 0;
+    case 11: bm = 128; bn = 128; return 0;
+    case 12: bm = 128; bn = 64; return 0;
     default: return -1;
   }
 }
@@ -985,9 +1043,13 @@ static int fsv_launch_conv(const ConvP& p, bool vec4, int nz, hipStream_t stream
       case 1: FSV_LAUNCH((fsv_conv_igemm_kernel<128, 64, 4, 2>), g, dim3(512), stream, p); break;
       case 2: FSV_LAUNCH((fsv_conv_igemm_kernel<128, 32, 4, 1>), g, dim3(256), stream, p); break;
       case 4: FSV_LAUNCH((fsv_conv_igemm_kernel<64, 64, 2, 2>), g, dim3(256), stream, p); break;
+      case 10: FSV_LAUNCH((fsv_conv_igemm_kernel<64, 128, 2, 4, 2>), g, dim3(512), stream, p); break;
+      case 11: FSV_LAUNCH((fsv_conv_igemm_kernel<128, 128, 2, 4, 2>), g, dim3(512), stream, p); break;
+      case 12: FSV_LAUNCH((fsv_conv_igemm_kernel<128, 64, 4, 2, 2>), g, dim3(512), stream, p); break;
       default: FSV_LAUNCH((fsv_conv_igemm_kernel<64, 128, 2, 4>), g, dim3(512), stream, p); break;
     }
   } else {
+    if (tile == 10) tile = 9; else if (tile == 11) tile = 0; else if (tile == 12) tile = 1;     // scalar gather: no PF variants
     switch (tile) {
       case 0: FSV_LAUNCH((fsv_conv_igemm_v1_kernel<128, 128, 2, 2>), g, dim3(256), stream, p); break;
       case 1: FSV_LAUNCH((fsv_conv_igemm_v1_kernel<128, 64, 2, 2>), g, dim3(256), stream, p); break;
@@ -1032,7 +1094,7 @@ static inline long long fsv_tune(int which) {
 static inline double fsv_conv_cost(int Mz, int Cout, int nchunks, int nsamp, int tile, int nsplit) {
   int bm, bn;
   if (fsv_tile_dims(tile, bm, bn)) return 1e30;
-  const bool w8 = (tile == 0 || tile == 1 || tile == 9);
+  const bool w8 = (tile == 0 || tile == 1 || tile == 9 || tile >= 10);
   const double wgs = (double)fsv_cdiv(Mz, bm) * fsv_cdiv(Cout, bn) * nsamp * nsplit;
   const double L = (double)((long long)((wgs + 255.0) / 256.0));
   const double cps = (double)fsv_cdiv(nchunks, nsplit);

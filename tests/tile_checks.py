@@ -25,6 +25,9 @@ GEOMS = [(2, 8, 9, 11, 40, 3, 1, 1),          # K = 72 (tail chunk), ragged M an
          (3, 32, 1, 40, 64, 1, 1, 0),         # one image row (nn.Linear as a 1x1 convolution): 32-pixel steps cross images
          (2, 8, 3, 5, 64, 3, 1, 1)]           # 15 pixels per image: the weight-gradient kernel's scalar-twin geometry
 FWD_TILES = (0, 1, 2, 4, 9)
+# force_tile-only variants that the launch plan never picks (prefetch distance 2, csrc/conv_igemm.hip): checked on the emulator
+# only until they have been measured on hardware; (variant, the plan's tile with the same dimensions)
+EXPERIMENTAL_FWD_TILES = ((10, 9), (11, 0), (12, 1))
 WGRAD_TILES = (0, 1, 2, 3, 4)
 
 
@@ -47,11 +50,29 @@ def _fwd_case(device, geom, tile, split, seed):
 def check_forward_tiles(device, tiles=FWD_TILES, geoms=GEOMS):
     for gi, geom in enumerate(geoms):
         for tile in tiles:
-            bn = {0: 128, 1: 64, 2: 32, 4: 64, 9: 128}[tile]
+            bn = {0: 128, 1: 64, 2: 32, 4: 64, 9: 128, 10: 128, 11: 128, 12: 64}[tile]
             if geom[4] < bn // 2 and bn > 32:
                 continue                       # a tile twice as wide as the layer: not a configuration the plan can produce
             for split in (1, 3):
                 _fwd_case(device, geom, tile, split, 100 + gi)
+
+
+def check_variant_equals_plan_tile(device, variant, base, geoms=GEOMS):
+    """a variant that only moves the global loads in time must reproduce the plan's tile bit for bit (same fma chains)"""
+    ops, conv = oc.pkg()
+    for gi, geom in enumerate(geoms):
+        n, cin, h, w, cout, k, s, p = geom
+        g = torch.Generator().manual_seed(300 + gi)
+        x = conv.to_nhwc(torch.randn(n, cin, h, w, generator=g).to(device))
+        wt = torch.randn(cout, cin, k, k, generator=g) * (1.0 / (cin * k * k) ** 0.5)
+        ge = conv.Geom(k, k, s, p)
+        wf, kpad, ldw = conv.prep_weight(wt.to(device), 0, ge)
+        nchunks = (k * k * cin + 31) // 32
+        for split in (1, 2, 3, 5):
+            sp = min(split, nchunks)
+            a = conv.conv_forward(x, wf, ldw, cout, ge, force_tile=variant, force_split=sp)
+            b = conv.conv_forward(x, wf, ldw, cout, ge, force_tile=base, force_split=sp)
+            assert torch.equal(a.cpu(), b.cpu()), (variant, base, geom, split)
 
 
 def check_per_sample(device, tiles=(1, 4, 9)):
