@@ -14,6 +14,7 @@
 // A-fragment read (32 consecutive m per half-wave) and the staging writes are both bank-conflict free.
 // The MFMA result is bitwise an fp32 fma chain (guide section 3), which is what lets the parity tests use a
 // 1e-3 relative tolerance against the fp32 CPU oracle with a wide margin.
+#include <stdlib.h>
 #include "conv_igemm.h"
 
 // Byte offsets inside one tensor are 32-bit (checked on the host: tensor < 2 GiB); rows / taps outside the image, K-tail
@@ -45,7 +46,8 @@ __device__ __forceinline__ void fsv_xcd_tile(int nx, int ny, int& bx, int& by) {
 // s_waitcnt lgkmcnt(0), two MFMAs, read, ...), which exposes the LDS latency whenever a SIMD holds a single wave.
 // PF: prefetch distance of the global loads in chunks.  PF = 1 (every tile of the launch plan): the loads of chunk k + 1 are
 // issued at the top of chunk k and stored to LDS behind its 12th MFMA.  PF = 2 (tile ids 10 - 12, reachable through force_tile
-// only - built at the end of round 2 from the ISA reading in profiles/r02_notes.md section 15, NOT yet measured on hardware):
+// or FSV_CONV_PF2=1 - built at the end of round 2 from the ISA reading in profiles/r02_notes.md section 15; measured there:
+// section 16):
 // two register sets, the loads of chunk k + 2 are issued at the top of chunk k and the set stored behind the 12th MFMA was
 // loaded a whole chunk earlier, for grids with one workgroup per CU where nothing else covers the HBM latency.
 template <int BM, int BN, int WM, int WN, int PF = 1>
@@ -1033,6 +1035,16 @@ static inline int fsv_tile_dims(int tile, int& bm, int& bn) {
   }
 }
 
+// FSV_CONV_PF2=1: the plan's 8-wave tiles run as their prefetch-distance-2 variants (ids 10 - 12).  Measured in the last GPU
+// seconds of round 2 (profiles/r02_notes.md section 16): +5 ... +6 % on the two dominant shapes in isolation, 55.19 -> 54.95 ms
+// on the whole step, correct and bit-equal to the plan's tiles on hardware - but the full GPU suite has not run with them, so
+// the default stays the kernels it has run with.
+static inline bool fsv_conv_pf2() {
+  static int on = -1;
+  if (on < 0) { const char* e = getenv("FSV_CONV_PF2"); on = (e && e[0] == '1') ? 1 : 0; }
+  return on != 0;
+}
+
 static int fsv_launch_conv(const ConvP& p, bool vec4, int nz, hipStream_t stream, int tile) {
   int bm, bn;
   if (fsv_tile_dims(tile, bm, bn)) return FSV_ERR_BAD_ARG;
@@ -1188,6 +1200,8 @@ int fsv_conv_gather_fwd(const float* in, const float* wt, const float* bias, con
     (void)hipMemsetAsync(out, 0, (size_t)total * sizeof(float), stream);
   }
   const bool vec4 = (Cin % 4 == 0);
+  // the plan's 8-wave tiles run as their prefetch-distance-2 variants (a forced tile id is taken literally)
+  if (force_tile < 0 && vec4 && fsv_conv_pf2()) tile = (tile == 9) ? 10 : (tile == 0) ? 11 : (tile == 1) ? 12 : tile;
   int rc = fsv_launch_conv(p, vec4, nsamp * nsplit, stream, tile);
   if (rc) return rc;
   if (!accumulate && nsplit > 1 && (bias || res || act != FSV_ACT_NONE || scale != 1.f)) {

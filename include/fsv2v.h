@@ -41,7 +41,7 @@ enum fsv_act { FSV_ACT_NONE = 0, FSV_ACT_LRELU = 1 /* leaky_relu(0.2), architect
  * weight matrix (stride w_bstride) and bias (stride b_bstride) per sample n.  accumulate != 0: `out` was zeroed by
  * the caller, results are added (used for the four parity classes of a stride-2 data gradient).
  * force_tile / force_split: -1 / 0 = automatic (tile ids, pixels x channels: 0 128x128, 1 128x64, 2 128x32, 4 64x64, 9 64x128;
- * 10 / 11 / 12 = 64x128 / 128x128 / 128x64 with the global loads two chunks ahead: never chosen automatically, unmeasured).
+ * 10 / 11 / 12 = 64x128 / 128x128 / 128x64 with the global loads two chunks ahead: chosen only with FSV_CONV_PF2=1).
  * One activation tensor / weight matrix may hold at most 2 GiB (32-bit byte offsets): FSV_ERR_UNSUPPORTED beyond.  wscale: optional device scalar multiplying the accumulator before
  * the bias (the spectral-norm 1/sigma when wt holds un-normalised weights). */
 int fsv_conv_gather_fwd(const float* in, const float* wt, const float* bias, const float* res, float* out,

@@ -57,7 +57,7 @@ def check_forward_tiles(device, tiles=FWD_TILES, geoms=GEOMS):
                 _fwd_case(device, geom, tile, split, 100 + gi)
 
 
-def check_variant_equals_plan_tile(device, variant, base, geoms=GEOMS):
+def check_variant_equals_plan_tile(device, variant, base, geoms=GEOMS, splits=(1, 2, 3, 5)):
     """a variant that only moves the global loads in time must reproduce the plan's tile bit for bit (same fma chains)"""
     ops, conv = oc.pkg()
     for gi, geom in enumerate(geoms):
@@ -68,7 +68,7 @@ def check_variant_equals_plan_tile(device, variant, base, geoms=GEOMS):
         ge = conv.Geom(k, k, s, p)
         wf, kpad, ldw = conv.prep_weight(wt.to(device), 0, ge)
         nchunks = (k * k * cin + 31) // 32
-        for split in (1, 2, 3, 5):
+        for split in splits:
             sp = min(split, nchunks)
             a = conv.conv_forward(x, wf, ldw, cout, ge, force_tile=variant, force_split=sp)
             b = conv.conv_forward(x, wf, ldw, cout, ge, force_tile=base, force_split=sp)
