@@ -23,6 +23,9 @@ Besides the contract fields the JSON line carries
                  batch 8, both flag sets, as fractions of the fp32 MFMA peak) and the step the reference's shipped
                  script trains (scripts/pose/train_g1.sh: + face discriminator, VGG19 loss, FlowNet2 teacher).
 
+`--gpus N` with N > 1 and no WORLD_SIZE in the environment (a bare launch) re-executes itself through
+`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ...`: one rank per GPU either way.
+
     python bench.py --cpu-baseline-only [--use-reference]    # CPU leg alone (no GPU needed; --use-reference: time the
                                                              # unmodified reference through oracle/ref_import.py instead)
 """
@@ -194,6 +197,19 @@ def extras(device, size, steps=5):
     return out
 
 
+def spawn_ranks(n):
+    """Bare `python bench.py --gpus N` (N > 1, no launcher environment): re-execute this command line as N ranks of one node
+    through torch.distributed.run, exactly the command the driver uses; rank 0 of the children prints the JSON line."""
+    import socket
+    import subprocess
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sock:
+        sock.bind(('127.0.0.1', 0))
+        port = sock.getsockname()[1]
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(n),
+           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -211,7 +227,11 @@ def main():
     ap.add_argument('--face-d', action='store_true', help='config 3: --add_face_D (face discriminator + VGG19 loss)')
     ap.add_argument('--amp', default='O0', help="reference --amp level: O1 = fp16 GEMM operands (fp32 accumulate) + dynamic "
                     "loss scale, bf16x3 = split-bf16 operands; O0 (default, the headline) = exact fp32")
+    ap.add_argument('--ngf', type=int, default=32, help='network width (32 = the reference default = the headline; smaller '
+                    'values only for the emulated launcher test)')
     args = ap.parse_args()
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ and not args.cpu_baseline_only:
+        raise SystemExit(spawn_ranks(args.gpus))
     global WITH_VGG, WITH_FACE_D, AMP
     WITH_VGG = args.vgg
     WITH_FACE_D = args.face_d
@@ -223,10 +243,21 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    device = torch.device('cuda', local_rank)
+    # FSV2V_EMU=1 (CPU test-suite only): the SIMT-emulated build of the kernel library on host tensors, gloo instead of
+    # RCCL, eager step - exercises the launcher / rank / JSON plumbing of this script without a GPU (tests/test_tools.py);
+    # the line it prints says so and is never a measurement
+    emulated = os.environ.get('FSV2V_EMU', '0') == '1'
+    if emulated:
+        device = torch.device('cpu')
+        args.no_graph = args.no_roofline = args.no_cpu_baseline = args.no_extras = True
+    else:
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
+        if world > torch.cuda.device_count():
+            raise SystemExit("bench.py: %d ranks but %d visible GPUs (one rank per GPU)" % (world, torch.cuda.device_count()))
+        torch.cuda.set_device(local_rank)
+        device = torch.device('cuda', local_rank)
+    sync = (lambda: None) if emulated else torch.cuda.synchronize
     group = None
     # FSV_FORCE_DIST=1: exercise the RCCL / bucket / side-stream path in a one-rank group (single-GPU smoke test of
     # the code the driver runs at N > 1; results are identical to the plain path, the step runs eagerly)
@@ -235,8 +266,11 @@ def main():
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29533')
         import datetime
-        dist.init_process_group(backend='nccl', rank=rank, world_size=world, timeout=datetime.timedelta(seconds=180),
-                                device_id=device)
+        if emulated:
+            dist.init_process_group(backend='gloo', rank=rank, world_size=world, timeout=datetime.timedelta(seconds=180))
+        else:
+            dist.init_process_group(backend='nccl', rank=rank, world_size=world, timeout=datetime.timedelta(seconds=180),
+                                    device_id=device)
 
     from importlib import import_module
     import fsv2v_amd  # noqa: F401
@@ -244,13 +278,14 @@ def main():
     prof = import_module('few-shot-vid2vid_amd.profile')
 
     opt = build_opt(args.size, args.batch)
+    opt.ngf = opt.ndf = opt.nff = args.ngf
     model = M.create_model(opt).to(device).train()          # identical init on every rank (seed 0), like the reference
     distributed = world > 1 or force_dist
     # N > 1: no autograd hooks; the step runs as hipGraph segments (graph_step.GraphedIteration) - D | Adam(D) + G forward +
     # first piece of the G backward | rest of the G backward | Adam(G) - with the RCCL all-reduces between them; the
     # exchange of the decoder-stage gradients (51 % of the generator's parameters) runs on a side stream next to the third
     # graph.  No collective is captured.
-    segmented = distributed and not args.no_graph
+    segmented = distributed and (emulated or not args.no_graph)
     opt_G, opt_D = model.build_optimizers(world_size=world, process_group=group, force_exchange=force_dist,
                                           overlap=not segmented, split_backward=segmented)
     data = make_data(args.batch, args.size, 1234 + rank, device)
@@ -275,6 +310,11 @@ def main():
             run()
         n_eager_warm += 1
         mode = 'hipgraph x%d + RCCL all-reduce between segments (decoder-stage range on a side stream)' % (4 if gi.split else 3)
+        if emulated:
+            mode = 'emulated kernels on host tensors + gloo, %d eager segments (CPU test infrastructure, not a measurement)' % (4 if gi.split else 3)
+    elif emulated:
+        n_eager_warm = 0
+        mode = 'emulated kernels on host tensors + gloo (CPU test infrastructure, not a measurement)'
     else:
         n_eager_warm = max(1, min(args.warmup, 2)) if use_graph else args.warmup
         side = torch.cuda.Stream()
@@ -299,17 +339,17 @@ def main():
     for _ in range(max(0, args.warmup - n_eager_warm)):
         run()
 
-    torch.cuda.synchronize()
+    sync()
     if world > 1 or force_dist:
         dist.barrier()
-    torch.cuda.synchronize()
+    sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         run()
-    torch.cuda.synchronize()
+    sync()
     if world > 1:
         dist.barrier()
-    torch.cuda.synchronize()
+    sync()
     elapsed = time.perf_counter() - t0
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)

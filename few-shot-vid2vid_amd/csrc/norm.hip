@@ -598,7 +598,9 @@ int fsv_norm_stats_fused(const float* x, double* workspace, float* mean, float* 
     return fsv_norm_stats_rep(x, workspace, mean, rstd, G, P, C, eps, run_mean, run_var, momentum, rep, stream);
   if (!x || !workspace || !mean || !rstd || G < 1 || P < 1 || C < 1 || rep < 1) return FSV_ERR_BAD_ARG;
   RedPlan pl = fsv_red_plan(G, P, C, FSV_RED_FUSED_CHUNKS);
-  if (pl.nslabs > FSV_RED_COUNTERS) return FSV_ERR_UNSUPPORTED;
+  // more channel slabs than ticket counters (C > 8192 on a small tensor): the two-launch form has no such limit
+  if (pl.nslabs > FSV_RED_COUNTERS)
+    return fsv_norm_stats_rep(x, workspace, mean, rstd, G, P, C, eps, run_mean, run_var, momentum, rep, stream);
   RedP rp; rp.a = x; rp.y = nullptr; rp.x = nullptr; rp.mean = nullptr; rp.rstd = nullptr; rp.part = workspace;
   rp.P = P; rp.C = C; rp.act = 0; fsv_red_no_tail(rp);
   rp.counter = counters; rp.o0 = mean; rp.o1 = rstd; rp.o2 = run_mean; rp.o3 = run_var; rp.eps = eps; rp.momentum = momentum;
@@ -615,7 +617,8 @@ int fsv_norm_bwd_fused(const float* dy, const float* y, const float* x, const fl
   if (!dy || !x || !mean || !rstd || !workspace || !s1 || !s2 || !dx) return FSV_ERR_BAD_ARG;
   if (act != FSV_ACT_NONE && !y) return FSV_ERR_BAD_ARG;
   RedPlan pl = fsv_red_plan(G, P, C, FSV_RED_FUSED_CHUNKS);
-  if (pl.nslabs > FSV_RED_COUNTERS) return FSV_ERR_UNSUPPORTED;
+  if (pl.nslabs > FSV_RED_COUNTERS)
+    return fsv_norm_bwd(dy, y, x, mean, rstd, w, workspace, s1, s2, dx, dw, db, G, P, C, act, fixed_stats, stream);
   RedP rp; rp.a = dy; rp.y = y; rp.x = x; rp.mean = mean; rp.rstd = rstd; rp.part = workspace;
   rp.P = P; rp.C = C; rp.act = act; fsv_red_no_tail(rp);
   rp.counter = counters; rp.o0 = s1; rp.o1 = s2; rp.o2 = dw; rp.o3 = db;
@@ -631,7 +634,7 @@ int fsv_colsum_fused(const float* x, double* workspace, float* out, int G, int P
   if (!fsv_red_fused(counters, G, P, C)) return fsv_colsum(x, workspace, out, G, P, C, accumulate, stream);
   if (!x || !workspace || !out) return FSV_ERR_BAD_ARG;
   RedPlan pl = fsv_red_plan(G, P, C, FSV_RED_FUSED_CHUNKS);
-  if (pl.nslabs > FSV_RED_COUNTERS) return FSV_ERR_UNSUPPORTED;
+  if (pl.nslabs > FSV_RED_COUNTERS) return fsv_colsum(x, workspace, out, G, P, C, accumulate, stream);
   RedP rp; rp.a = x; rp.y = nullptr; rp.x = nullptr; rp.mean = nullptr; rp.rstd = nullptr; rp.part = workspace;
   rp.P = P; rp.C = C; rp.act = 0; fsv_red_no_tail(rp);
   rp.counter = counters; rp.o0 = out; rp.accumulate = accumulate;

@@ -27,6 +27,7 @@ import torch
 
 from . import lib
 from . import model as _model
+from . import networks as _networks
 
 
 def _flat(data_list):
@@ -82,8 +83,9 @@ class GraphedIteration:
             raise RuntimeError("cross-replica BatchNorm issues collectives inside forward / backward, which cannot be captured: "
                                "use the eager loop with sync_bn, or per-replica statistics with GraphedIteration")
         self.segmented = bool(self.opt_G.exchange)
-        # two-piece generator backward (model.build_optimizers(split_backward=True)); pointless without an exchange to overlap
-        self.split = bool(getattr(self.model, 'split_backward', False)) and self.segmented
+        # two-piece generator backward (model.build_optimizers(split_backward=True)): the generator's forward pass detaches at
+        # its stage boundary whether or not there is an exchange to overlap, so the second piece always has to run
+        self.split = bool(getattr(self.model, 'split_backward', False))
         if self.segmented and self.opt_G.overlap:
             raise RuntimeError("with a process group build the optimisers with overlap=False: bucket hooks issue collectives "
                                "inside backward, which cannot be captured")
@@ -102,6 +104,7 @@ class GraphedIteration:
         losses, loss = _model.mean_and_total(losses)
         optimizer.zero_grad()
         optimizer.scale_loss(loss).backward()
+        _networks.BackwardCut.finish_all()      # a forward pass that detached at a stage boundary (no-op otherwise)
         optimizer.finalize_grads()
         return losses
 

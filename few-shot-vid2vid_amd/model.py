@@ -152,6 +152,15 @@ class LossCollector:
             z = _ZEROS[ref.device] = streams.shared(lambda: torch.zeros(1, dtype=torch.float32, device=ref.device))
         return z
 
+    @classmethod
+    def outward(cls, losses):
+        """the loss list as it leaves the module: [1, 1] views, except that entries which ARE the shared zero constant are
+        handed out as copies - a caller that reduces or scales its losses in place (the reference's dist_all_reduce_tensor
+        does all_reduce + div_ on the tensor it is given, util/distributed.py:66-72) must not corrupt the constant that later
+        iterations and captured graphs read"""
+        shared = set(z.data_ptr() for z in _ZEROS.values())
+        return [(l.clone() if l.data_ptr() in shared else l).view(1, 1) for l in losses]
+
     def discriminate(self, netD, label, fake, real, ref, for_discriminator, real_out=None):
         """loss_collector.py:47-68: D sees [ref | label | image] with fake and real stacked on the batch axis.  real_out:
         (outputs, sigmas) of the discriminator for the real images from real_pass() - then only the generated images go through
@@ -353,9 +362,9 @@ def loss_backward(opt, losses, optimizer, loss_id):
     optimizer.zero_grad()
     scale_loss = getattr(optimizer, 'scale_loss', None)
     (scale_loss(loss) if scale_loss is not None else loss).backward()
-    cut = getattr(optimizer, 'bwd_cut', None)
-    if cut is not None:                 # two-piece backward (build_optimizers(split_backward=True)): run the second piece too
-        cut.backward_rest()
+    # two-piece backward (build_optimizers(split_backward=True)): the forward pass detached at the generator's stage boundary,
+    # run the second piece too - whichever optimiser is being stepped (finetune() builds its own)
+    networks.BackwardCut.finish_all()
     optimizer.step()
     return losses
 
@@ -748,7 +757,7 @@ class Vid2VidModel(nn.Module):
             real_all = torch.cat([prevs[1], tgt_image], dim=1)
             fake_all = torch.cat([prevs[2], fake.unsqueeze(1)], dim=1)
             losses = list(losses) + self.lossCollector.temporal_losses(self.netDT, real_all, fake_all, True)
-        return [l.view(1, 1) for l in losses]
+        return LossCollector.outward(losses)
 
     def forward_generator(self, tgt_label, tgt_image, ref_labels, ref_images, prevs, flow_gt=(None, None),
                           conf_gt=(None, None)):
@@ -812,7 +821,7 @@ class Vid2VidModel(nn.Module):
         # self.reshape (vid2vid_model.py:88-89) - warped / flow / mask as 4-D tensors
         up = lambda t: t.unsqueeze(1) if t is not None else None
         generated = [up(fake), up(raw), list(warped), list(flow), list(mask), self.atn_score]
-        return [l.view(1, 1) for l in losses], generated, prevs_new
+        return LossCollector.outward(losses), generated, prevs_new
 
 
 def create_model(opt, epoch=0, device=None):

@@ -9,6 +9,7 @@ of the reference are folded into kernel epilogues (bias+LeakyReLU, tanh, sigmoid
 BN+LeakyReLU, SPADE denorm+modulate+LeakyReLU).
 """
 import math
+import weakref
 
 import torch
 import torch.nn as nn
@@ -659,6 +660,7 @@ class FewShotGenerator(nn.Module):
             flow, mask, warp, emb, _ = self.flow_branch(label, label_ref, img_ref, prev)
         cut = getattr(self, 'bwd_cut', None)
         if cut is not None and torch.is_grad_enabled():
+            cut.begin_forward()
             # stage boundary (see BackwardCut): everything above is "stage 1", the decoder below is "stage 2"
             # (stage2_parameters)
             x, enc_label, norm_w, flow, mask, warp, emb = cut.split((x, enc_label, norm_w, flow, mask, warp, emb))
@@ -695,8 +697,18 @@ class BackwardCut:
     split() replaces every tensor that crosses the boundary by a detached leaf; `loss.backward()` then stops at the leaves
     (first piece), and backward_rest() continues from the recorded originals with the gradients the leaves collected."""
 
+    # cuts that hold an unfinished second piece.  Every backward driver (model.loss_backward, graph_step, a caller's own
+    # `.backward()` followed by finish_all()) completes them from here, so the forward pass that detached at the boundary -
+    # not an attribute of whichever optimiser happens to be stepped - decides whether a second piece has to run.
+    _live = weakref.WeakSet()
+
     def __init__(self):
         self.pairs = []
+
+    def begin_forward(self):
+        """a new forward pass supersedes the boundary tensors of one whose backward never ran"""
+        self.pairs = []
+        BackwardCut._live.discard(self)
 
     def split(self, obj):
         if torch.is_tensor(obj):
@@ -704,6 +716,7 @@ class BackwardCut:
                 return obj
             leaf = obj.detach().requires_grad_(True)
             self.pairs.append((obj, leaf))
+            BackwardCut._live.add(self)
             return leaf
         if isinstance(obj, (list, tuple)):
             return type(obj)(self.split(o) for o in obj)
@@ -713,8 +726,15 @@ class BackwardCut:
         outs = [o for o, l in self.pairs if l.grad is not None]
         grads = [l.grad for o, l in self.pairs if l.grad is not None]
         self.pairs = []
+        BackwardCut._live.discard(self)
         if outs:
             torch.autograd.backward(outs, grads)
+
+    @classmethod
+    def finish_all(cls):
+        """run the second piece of every forward pass that detached at a stage boundary and has not been completed"""
+        for cut in list(cls._live):
+            cut.backward_rest()
 
 
 # ------------------------------------------------------------------------------------------------ discriminator

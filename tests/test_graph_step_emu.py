@@ -9,3 +9,7 @@ DEV = torch.device("cpu")
 
 def test_graphed_iteration_matches_the_eager_loop(emu_lib):
     gc.check_graphed_iteration(DEV, iters=3)
+
+
+def test_split_backward_without_exchange_keeps_every_gradient(emu_lib):
+    gc.check_split_backward_single_rank(DEV, iters=2)

@@ -63,6 +63,12 @@ def test_fused_reductions(emu_lib):
     oc.check_fused_reductions(DEV, shapes=((1, 4096, 32), (2, 1000, 7), (1, 300, 260), (4, 64, 512)), repeats=2)
 
 
+def test_fused_reductions_wide_rows_fall_back(emu_lib):
+    # C > 8192 on a small tensor needs more channel slabs than there are ticket counters: the one-launch entry points hand
+    # over to the two-launch form instead of refusing (round-2 advisor finding)
+    oc.check_fused_reductions(DEV, shapes=((1, 12, 8196), (1, 9, 16384), (2, 10, 20000)), repeats=1)
+
+
 @pytest.mark.parametrize("nmaps,generated,act,c,ch", [(1, True, 'lrelu', 12, 8), (3, True, 'none', 12, 8),
                                                       (2, False, 'lrelu', 40, 12), (3, True, 'lrelu', 32, 20),
                                                       (2, False, 'none', 48, 12), (1, True, 'lrelu', 64, 32)])

@@ -64,6 +64,7 @@ def test_fused_reductions(hip_lib):
     """last-workgroup second stage across the 8 XCDs: many repeats on the same buffers, sizes on both sides of the threshold"""
     oc.check_fused_reductions(dev(), repeats=25)
     oc.check_fused_reductions(dev(), shapes=((1, 2 * 512 * 512, 32), (2, 256 * 256, 128)), repeats=3)
+    oc.check_fused_reductions(dev(), shapes=((1, 12, 8196), (2, 10, 20000)), repeats=2)      # two-launch fallback (C > 8192)
     # above the threshold: two launches (no activation: at 11.5 M elements some land within rounding of the LeakyReLU kink)
     oc.check_norm(dev(), instance=False, n=2, c=64, h=300, w=300, act='none')
 
