@@ -7,6 +7,7 @@ channels-last memory (NHWC), which is the layout the kernels in csrc/conv_igemm.
 """
 import ctypes
 import os
+import threading
 
 import torch
 
@@ -148,6 +149,127 @@ def unprep_weight_grad(dwt, w_shape, geom, scale=None, out=None):
     return dw
 
 
+# ------------------------------------------------------------------------------------------------ grouped launches
+class ConvDesc(ctypes.Structure):
+    """include/fsv2v.h fsv_conv_desc"""
+    _fields_ = ([(k, ctypes.c_void_p) for k in ('inp', 'wt', 'bias', 'res', 'out', 'wscale')] +
+                [(k, ctypes.c_int) for k in ('N', 'H', 'W', 'Cin', 'OH', 'OW', 'Cout', 'ntaps')] +
+                [('ty', ctypes.c_int * 16), ('tx', ctypes.c_int * 16)] +
+                [(k, ctypes.c_int) for k in ('sy', 'sx', 'outH', 'outW', 'osy', 'osx', 'ooy', 'oox', 'ldw',
+                                             'per_sample', 'act', 'accumulate')] +
+                [('scale', ctypes.c_float), ('w_bstride', ctypes.c_longlong), ('b_bstride', ctypes.c_longlong)])
+
+
+class WgradDesc(ctypes.Structure):
+    """include/fsv2v.h fsv_wgrad_desc"""
+    _fields_ = ([(k, ctypes.c_void_p) for k in ('inp', 'dout', 'dwt')] +
+                [(k, ctypes.c_int) for k in ('N', 'H', 'W', 'Cin', 'OH', 'OW', 'Cout', 'ntaps')] +
+                [('ty', ctypes.c_int * 16), ('tx', ctypes.c_int * 16)] +
+                [(k, ctypes.c_int) for k in ('sy', 'sx', 'ldw', 'Kpad', 'per_sample', 'reserved')] +
+                [('w_bstride', ctypes.c_longlong)])
+
+
+lib.register_sigs({
+    "fsv_conv_gather_group": [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p],
+    "fsv_conv_wgrad_group": [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p],
+    "fsv_conv_group_plan": [ctypes.POINTER(ctypes.c_int)] * 4 + [ctypes.c_int, ctypes.POINTER(ctypes.c_int)],
+})
+
+GROUP_LIMIT = 64          # FSV_GROUP_LIMIT (csrc/conv_igemm.hip)
+_TILE_DIMS = {0: (128, 128), 1: (128, 64), 2: (128, 32), 4: (64, 64), 9: (64, 128)}
+_tls = threading.local()  # autograd runs backward on its own thread: the active group is per thread
+
+
+def group_enabled():
+    return os.environ.get('FSV_CONV_GROUPS', '1') == '1'
+
+
+class launch_group:
+    """`with launch_group():` - the gather-GEMM / weight-gradient launches issued inside are collected and go to the device as
+    ONE grid per kind when the block ends (csrc/conv_igemm.hip fsv_conv_igemm_group_kernel).  The caller guarantees that the
+    launches are independent (none reads what another writes) and that nobody reads their outputs before the block ends;
+    fills / copies issued inside run BEFORE the grouped launch (stream order).  Launches the grouped kernels cannot take
+    (narrow-operand modes, forced tiles / splits) are issued at once.  Nested blocks join the outer one."""
+
+    def __init__(self, enabled=True, force_tile=-1):
+        self.on = enabled and group_enabled()
+        self.convs, self.wgrads = [], []
+        self.outer = None
+        self.force_tile = force_tile          # tests: tile id for the grouped gather-GEMM grid (-1: the library's plan)
+
+    def __enter__(self):
+        if self.on:
+            self.outer = getattr(_tls, 'group', None)
+            if self.outer is None:
+                _tls.group = self
+        return self
+
+    def __exit__(self, et, ev, tb):
+        if self.on and self.outer is None:
+            _tls.group = None
+            if et is None:
+                self.flush()
+        return False
+
+    def flush(self):
+        for kind, items in (('conv', self.convs), ('wgrad', self.wgrads)):
+            for i in range(0, len(items), GROUP_LIMIT):
+                self._issue(kind, items[i:i + GROUP_LIMIT], self.force_tile)
+        self.convs, self.wgrads = [], []
+
+    @staticmethod
+    def _issue(kind, items, force_tile=-1):
+        if not items:
+            return
+        if len(items) == 1:
+            entry, args = items[0][1], items[0][2]
+            with profile.scope(items[0][3], items[0][4], replay=lambda: lib.call(entry, *args)):
+                lib.call(entry, *args)
+            return
+        Desc = ConvDesc if kind == 'conv' else WgradDesc
+        arr = (Desc * len(items))(*[it[0] for it in items])
+        if kind == 'conv':
+            gargs = (ctypes.cast(arr, ctypes.c_void_p), len(items), force_tile, lib.stream_ptr())
+            name = "fsv_conv_gather_group"
+            label = 'fsv_conv_igemm_group_kernel'
+            if profile.enabled() or _plan_log is not None:
+                tile = force_tile if force_tile >= 0 else group_planned([(it[0].OH * it[0].OW * (1 if it[0].per_sample else it[0].N), it[0].Cout,
+                                       (it[0].ntaps * it[0].Cin + 31) // 32, it[0].N if it[0].per_sample else 1) for it in items])
+                vec4 = all(it[0].Cin % 4 == 0 for it in items)
+                label = 'fsv_conv_igemm_group_kernel<%s,V%d>' % (profile.TILE_NAMES[tile], 4 if vec4 else 1)
+                if _plan_log is not None:
+                    _plan_log.append(('group', tile, vec4, len(items)))
+        else:
+            gargs = (ctypes.cast(arr, ctypes.c_void_p), len(items), lib.stream_ptr())
+            name = "fsv_conv_wgrad_group"
+            label = 'fsv_conv_wgrad_group_kernel<64x64,V4>'
+        keep = [it[5] for it in items]
+        flops = sum(it[4] for it in items)
+
+        def go(arr=arr, keep=keep):
+            rc = lib.call_status(name, *gargs)
+            if rc == -2:                     # FSV_ERR_UNSUPPORTED, nothing was launched: one by one
+                for it in items:
+                    lib.call(it[1], *it[2])
+            elif rc != 0:
+                raise lib.FsvError("%s failed with fsv_status %d" % (name, rc))
+        with profile.scope(label, flops, replay=go):
+            go()
+
+
+def group_planned(shapes):
+    """tile id of a grouped gather-GEMM launch over problems (Mz, Cout, nchunks, nsamp)"""
+    n = len(shapes)
+    cols = [lib.int_array([s[k] for s in shapes]) for k in range(4)]
+    tile = ctypes.c_int(0)
+    lib.call("fsv_conv_group_plan", cols[0], cols[1], cols[2], cols[3], n, ctypes.byref(tile))
+    return tile.value
+
+
+def _active_group():
+    return getattr(_tls, 'group', None)
+
+
 def gather_gemm(x, wt, ldw, cout, oh, ow, ty, tx, sy, sx, bias=None, res=None, act=ACT_NONE, scale=1.0,
                 per_sample=False, out=None, place=None, accumulate=False, force_tile=-1, force_split=0, wscale=None):
     """out[n, oy, ox, :] = act((sum_taps x[n, oy*sy+ty, ox*sx+tx, :] @ wt[tap]) + bias) * scale) + res."""
@@ -181,6 +303,23 @@ def gather_gemm(x, wt, ldw, cout, oh, ow, ty, tx, sy, sx, bias=None, res=None, a
     if _mfma_mode and cin % 4 == 0:               # scalar-gather layers (3-channel images, labels) stay on the fp32 kernel
         entry = "fsv_conv_gather_fwd_np"
         args = args[:-1] + (_mfma_mode, args[-1])
+    grp = _active_group()
+    if grp is not None and entry == "fsv_conv_gather_fwd" and force_tile < 0 and force_split == 0:
+        d = ConvDesc()
+        d.inp, d.wt, d.bias, d.res, d.out, d.wscale = (t.data_ptr() if t is not None else None
+                                                       for t in (x, wt, bias, res, out, wscale))
+        d.N, d.H, d.W, d.Cin, d.OH, d.OW, d.Cout, d.ntaps = n, h, w, cin, oh, ow, cout, len(ty)
+        for i, (a, b) in enumerate(zip(ty, tx)):
+            d.ty[i], d.tx[i] = a, b
+        d.sy, d.sx, d.outH, d.outW, d.osy, d.osx, d.ooy, d.oox, d.ldw = sy, sx, out_h, out_w, osy, osx, ooy, oox, ldw
+        d.per_sample, d.act, d.accumulate, d.scale = (1 if per_sample else 0), act, (1 if accumulate else 0), float(scale)
+        d.w_bstride, d.b_bstride = w_bs, b_bs
+        label = 'fsv_conv_igemm_kernel'
+        if profile.enabled():
+            label = profile.conv_label(oh * ow if per_sample else n * oh * ow, cout, (len(ty) * cin + 31) // 32,
+                                       n if per_sample else 1, cin % 4 == 0, force_tile, force_split)
+        grp.convs.append((d, entry, args, label, 2.0 * n * oh * ow * cout * cin * len(ty), (x, wt, bias, res, out, wscale)))
+        return out
     if profile.enabled():
         mz = oh * ow if per_sample else n * oh * ow
         label = profile.conv_label(mz, cout, (len(ty) * cin + 31) // 32, n if per_sample else 1, cin % 4 == 0,
@@ -256,19 +395,30 @@ def conv_dgrad(dout, w, geom, in_hw, scale=None, per_sample=False, cached=None, 
     # needs split-K (atomics), each class stores its own pixels and the zero fill of dx is unnecessary
     subs = [((h - c['py'] + s - 1) // s, (wd - c['px'] + s - 1) // s) for c in geom.dgrad_classes]
     plain = all(c['khs'] and sh > 0 and sw > 0 for c, (sh, sw) in zip(geom.dgrad_classes, subs))
-    if plain:
+    # the parity classes are independent problems (disjoint output pixels): ONE grouped launch instead of s * s small ones.
+    # The group splits K (atomics into a zeroed dx) only when all classes together would leave most CUs idle.
+    grouped = group_enabled() and not _mfma_mode and cout % 4 == 0
+    if grouped:
+        live = [(c, sub) for c, sub in zip(geom.dgrad_classes, subs) if sub[0] > 0 and sub[1] > 0 and c['khs']]
+        shapes = [((sh * sw) if per_sample else n * sh * sw, cin, (len(c['khs']) * cout + 31) // 32, n if per_sample else 1)
+                  for c, (sh, sw) in live]
+        bm, bn = _TILE_DIMS[group_planned(shapes)]
+        wgs = sum(-(-m // bm) * -(-co // bn) * z for m, co, _, z in shapes)
+        plain = plain and not (wgs < 256 and max(k for _, _, k, _ in shapes) >= 16)
+    elif plain:
         for c, (sh, sw) in zip(geom.dgrad_classes, subs):
             mz = sh * sw if per_sample else n * sh * sw
             if _planned_split(mz, cin, (len(c['khs']) * cout + 31) // 32, n if per_sample else 1) > 1:
                 plain = False
                 break
     dx = empty_nhwc(n, cin, h, wd, dout) if plain else zeros_nhwc(n, cin, h, wd, dout)
-    for k, (c, (sub_h, sub_w)) in enumerate(zip(geom.dgrad_classes, subs)):
-        if sub_h <= 0 or sub_w <= 0 or not c['khs']:
-            continue
-        wt, ldw, ws = layout(k, c)
-        gather_gemm(dout, wt, ldw, cin, sub_h, sub_w, c['ty'], c['tx'], 1, 1, per_sample=per_sample, out=dx,
-                    place=(h, wd, s, s, c['py'], c['px']), accumulate=not plain, wscale=ws)
+    with launch_group(grouped):
+        for k, (c, (sub_h, sub_w)) in enumerate(zip(geom.dgrad_classes, subs)):
+            if sub_h <= 0 or sub_w <= 0 or not c['khs']:
+                continue
+            wt, ldw, ws = layout(k, c)
+            gather_gemm(dout, wt, ldw, cin, sub_h, sub_w, c['ty'], c['tx'], 1, 1, per_sample=per_sample, out=dx,
+                        place=(h, wd, s, s, c['py'], c['px']), accumulate=not plain, wscale=ws)
     return dx
 
 
@@ -302,10 +452,22 @@ def conv_wgrad(x, dout, geom, w_shape, per_sample=False, scale=None, force_split
     narrow = _mfma_mode and vec4
     if narrow:
         label = 'fsv_np_wgrad_kernel[%s]' % ('f16' if _mfma_mode == 1 else 'bf16x3')
+    wargs = (lib.ptr(x), lib.ptr(dout), lib.ptr(dwt), n, h, w, cin, oh, ow, cout,
+             geom.ntaps, lib.int_array(geom.ty), lib.int_array(geom.tx), geom.stride, geom.stride,
+             ldw, kpad, kpad * ldw, 1 if per_sample else 0, force_split, 1 if prezeroed else 0, force_tile)
+    grp = _active_group()
+    if (grp is not None and not narrow and prezeroed and raw and vec4 and force_split == 0 and force_tile == 0
+            and 32 // ow + 1 <= oh):
+        d = WgradDesc()
+        d.inp, d.dout, d.dwt = x.data_ptr(), dout.data_ptr(), dwt.data_ptr()
+        d.N, d.H, d.W, d.Cin, d.OH, d.OW, d.Cout, d.ntaps = n, h, w, cin, oh, ow, cout, geom.ntaps
+        for i, (a, b) in enumerate(zip(geom.ty, geom.tx)):
+            d.ty[i], d.tx[i] = a, b
+        d.sy, d.sx, d.ldw, d.Kpad, d.per_sample, d.reserved, d.w_bstride = geom.stride, geom.stride, ldw, kpad, 0, 0, kpad * ldw
+        grp.wgrads.append((d, "fsv_conv_wgrad", wargs + (lib.stream_ptr(),), label,
+                           2.0 * n * oh * ow * cout * cin * geom.ntaps, (x, dout, dwt)))
+        return dwt
     with profile.scope(label, 2.0 * n * oh * ow * cout * cin * geom.ntaps):
-        wargs = (lib.ptr(x), lib.ptr(dout), lib.ptr(dwt), n, h, w, cin, oh, ow, cout,
-                 geom.ntaps, lib.int_array(geom.ty), lib.int_array(geom.tx), geom.stride, geom.stride,
-                 ldw, kpad, kpad * ldw, 1 if per_sample else 0, force_split, 1 if prezeroed else 0, force_tile)
         if narrow:
             lib.call("fsv_conv_wgrad_np", *wargs, _mfma_mode, lib.stream_ptr())
         else:

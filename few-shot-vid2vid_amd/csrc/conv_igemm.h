@@ -3,6 +3,7 @@
 #include "fsv_common.h"
 
 #define FSV_BK 32
+#define FSV_GROUP_MAX 16      // problems per grouped launch (the table is a kernel argument: 16 x 192 B + header < 4 KB)
 
 // ---- 16-byte loads through a buffer descriptor -------------------------------------------------------------------------
 // The gather-GEMM kernels need "this row / tap / column does not exist -> zeros".  A select on the LOADED value makes the
@@ -69,6 +70,26 @@ __device__ __forceinline__ void fsv_tap(const ConvP& p, int t, int& ty, int& tx)
   ty = (int)((code >> sh) & 15ull) - 8;
   tx = (int)((code >> (sh + 4)) & 15ull) - 8;
 }
+
+// One problem of a grouped launch at the C ABI: the arguments of fsv_conv_gather_fwd / fsv_conv_wgrad as plain structs.
+// MUST match include/fsv2v.h (fsv_conv_desc / fsv_wgrad_desc) and the ctypes mirrors in few-shot-vid2vid_amd/conv.py.
+struct fsv_conv_desc {
+  const float* in; const float* wt; const float* bias; const float* res; float* out; const float* wscale;
+  int N, H, W, Cin, OH, OW, Cout, ntaps;
+  int ty[16], tx[16];
+  int sy, sx, outH, outW, osy, osx, ooy, oox, ldw;
+  int per_sample, act, accumulate;
+  float scale;
+  long long w_bstride, b_bstride;
+};
+struct fsv_wgrad_desc {
+  const float* in; const float* dout; float* dwt;
+  int N, H, W, Cin, OH, OW, Cout, ntaps;
+  int ty[16], tx[16];
+  int sy, sx, ldw, Kpad;
+  int per_sample, reserved;
+  long long w_bstride;
+};
 
 struct WgradP {
   const float* in;

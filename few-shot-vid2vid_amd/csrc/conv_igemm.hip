@@ -50,8 +50,8 @@ __device__ __forceinline__ void fsv_xcd_tile(int nx, int ny, int& bx, int& by) {
 // section 16):
 // two register sets, the loads of chunk k + 2 are issued at the top of chunk k and the set stored behind the 12th MFMA was
 // loaded a whole chunk earlier, for grids with one workgroup per CU where nothing else covers the HBM latency.
-template <int BM, int BN, int WM, int WN, int PF = 1>
-__global__ __launch_bounds__(64 * WM * WN) void fsv_conv_igemm_kernel(ConvP p) {
+template <int BM, int BN, int WM, int WN, int PF>
+__device__ __forceinline__ void fsv_conv_igemm_body(const ConvP& p, const int bx, const int by, const int bz) {
   constexpr int BK = FSV_BK;
   constexpr int NT = 64 * WM * WN;    // 4 or 8 waves
   constexpr int RPA = NT / 8;         // A rows per pass (8 threads per row)
@@ -69,9 +69,7 @@ __global__ __launch_bounds__(64 * WM * WN) void fsv_conv_igemm_kernel(ConvP p) {
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
-  const int zs = blockIdx.z / p.nsplit, zk = blockIdx.z % p.nsplit;
-  int bx, by;
-  fsv_xcd_tile(gridDim.x, gridDim.y, bx, by);
+  const int zs = bz / p.nsplit, zk = bz % p.nsplit;
   const int bm0 = bx * BM, bn0 = by * BN;
   const float* wt = p.wt + (long long)zs * p.w_bstride;
 
@@ -324,8 +322,12 @@ __global__ __launch_bounds__(64 * WM * WN) void fsv_conv_igemm_kernel(ConvP p) {
           atomicAdd(dst, v);
         } else {
           v = (v + bv) * p.scale;
-          v = fsv_act(v, p.act);
-          if (p.res) v += p.res[opix * p.Cout + co];
+          if (p.act == FSV_ACT_DLRELU) {        // data gradient handed straight to the layer below: times LeakyReLU'(its output)
+            v = p.res[opix * p.Cout + co] > 0.f ? v : 0.2f * v;
+          } else {
+            v = fsv_act(v, p.act);
+            if (p.res) v += p.res[opix * p.Cout + co];
+          }
           *dst = v;
         }
       }
@@ -333,10 +335,43 @@ __global__ __launch_bounds__(64 * WM * WN) void fsv_conv_igemm_kernel(ConvP p) {
   }
 }
 
+template <int BM, int BN, int WM, int WN, int PF = 1>
+__global__ __launch_bounds__(64 * WM * WN) void fsv_conv_igemm_kernel(ConvP p) {
+  int bx, by;
+  fsv_xcd_tile(gridDim.x, gridDim.y, bx, by);
+  fsv_conv_igemm_body<BM, BN, WM, WN, PF>(p, bx, by, (int)blockIdx.z);
+}
+
+// Grouped launch: up to FSV_GROUP_MAX INDEPENDENT gather-GEMM problems in one 1-D grid (the problem table travels in the
+// kernel arguments: no device-side table, nothing to keep alive, legal inside a graph capture).  What it is for: the step
+// holds ~250 launches whose grids cover a fraction of the chip - the 16 weight-generator MLPs (generator.py:103-110,
+// 245-273: three small GEMMs each), the four output-parity classes of every stride-2 data gradient - and a launch lasts as
+// long as its longest workgroup (prologue + K loop + epilogue, ~10 us even for two K chunks), so 16 of them back to back
+// cost 16 critical paths where one grid with all their tiles costs one.  Workgroup b belongs to problem i with
+// tile_end[i - 1] <= b < tile_end[i]; inside a problem the tiles are ordered pixel tile fastest, then channel tile, then
+// (sample, K split).  Problems with nsplit > 1 add their partial sums atomically into a zeroed output (no epilogue).
+struct ConvGroup {
+  int nprob;
+  int tile_end[FSV_GROUP_MAX];
+  ConvP p[FSV_GROUP_MAX];
+};
+
+template <int BM, int BN, int WM, int WN, int PF = 1>
+__global__ __launch_bounds__(64 * WM * WN) void fsv_conv_igemm_group_kernel(ConvGroup g) {
+  const int b = blockIdx.x;
+  int i = 0;
+  while (i + 1 < g.nprob && b >= g.tile_end[i]) ++i;            // wave-uniform: scalar loads from the kernel arguments
+  const int t = b - (i ? g.tile_end[i - 1] : 0);
+  const ConvP& p = g.p[i];
+  const int gx = (p.Mz + BM - 1) / BM, gy = (p.Cout + BN - 1) / BN;
+  const int r = t / gx;
+  fsv_conv_igemm_body<BM, BN, WM, WN, PF>(p, t - r * gx, r % gy, r / gy);
+}
+
 // Scalar-gather twin for Cin % 4 != 0 (image / label inputs that were not channel-padded): single LDS buffer, A transposed
 // [k][m] with row stride BM + 1.  A handful of small launches per step.
 template <int BM, int BN, int WM, int WN>
-__global__ __launch_bounds__(64 * WM * WN) void fsv_conv_igemm_v1_kernel(ConvP p) {
+__device__ __forceinline__ void fsv_conv_igemm_v1_body(const ConvP& p, const int bx, const int by, const int bz) {
   constexpr int V = 1;
   constexpr int BK = FSV_BK;
   constexpr int NT = 64 * WM * WN;    // work-items per workgroup (4, 8 or 16 waves)
@@ -355,8 +390,8 @@ __global__ __launch_bounds__(64 * WM * WN) void fsv_conv_igemm_v1_kernel(ConvP p
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
-  const int zs = blockIdx.z / p.nsplit, zk = blockIdx.z % p.nsplit;
-  const int bm0 = blockIdx.x * BM, bn0 = blockIdx.y * BN;
+  const int zs = bz / p.nsplit, zk = bz % p.nsplit;
+  const int bm0 = bx * BM, bn0 = by * BN;
   const float* wt = p.wt + (long long)zs * p.w_bstride;
 
   // ---- per-thread A row bookkeeping ------------------------------------------------------------------
@@ -503,13 +538,36 @@ __global__ __launch_bounds__(64 * WM * WN) void fsv_conv_igemm_v1_kernel(ConvP p
           atomicAdd(dst, v);
         } else {
           v = (v + bv) * p.scale;
-          v = fsv_act(v, p.act);
-          if (p.res) v += p.res[opix * p.Cout + co];
+          if (p.act == FSV_ACT_DLRELU) {
+            v = p.res[opix * p.Cout + co] > 0.f ? v : 0.2f * v;
+          } else {
+            v = fsv_act(v, p.act);
+            if (p.res) v += p.res[opix * p.Cout + co];
+          }
           *dst = v;
         }
       }
     }
   }
+}
+
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(64 * WM * WN) void fsv_conv_igemm_v1_kernel(ConvP p) {
+  fsv_conv_igemm_v1_body<BM, BN, WM, WN>(p, (int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z);
+}
+
+// grouped form of the scalar-gather twin (a group that holds a problem with Cin % 4 != 0: the data gradients of the weight
+// generators' last layers, whose "input" is the gradient of a 2 * (c + 1)-wide FC output)
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(64 * WM * WN) void fsv_conv_igemm_v1_group_kernel(ConvGroup g) {
+  const int b = blockIdx.x;
+  int i = 0;
+  while (i + 1 < g.nprob && b >= g.tile_end[i]) ++i;
+  const int t = b - (i ? g.tile_end[i - 1] : 0);
+  const ConvP& p = g.p[i];
+  const int gx = (p.Mz + BM - 1) / BM, gy = (p.Cout + BN - 1) / BN;
+  const int r = t / gx;
+  fsv_conv_igemm_v1_body<BM, BN, WM, WN>(p, t - r * gx, r % gy, r / gy);
 }
 
 // ---- finishing pass for split-K launches: out = act((out + bias) * scale) + res ---------------------------
@@ -556,7 +614,7 @@ __device__ __forceinline__ void fsv_xcd_range(int& kt, int& nt, int& z) {
 // V4 kernel: both operands are pixel-major in HBM and in LDS ([32 pixels][columns], ds_write_b128 / ds_read_b32, conflict
 // free); two LDS buffers, one barrier per 32-pixel chunk, absent rows / columns are loaded at FSV_BUF_OOB.
 template <int BMK, int BN, int WM, int WN, bool COUT4>
-__global__ __launch_bounds__(64 * WM * WN) void fsv_conv_wgrad_kernel(WgradP p) {
+__device__ __forceinline__ void fsv_conv_wgrad_body(const WgradP& p, const int kt, const int nt, const int bz) {
   constexpr int BK = FSV_BK;   // pixels per chunk
   constexpr int NT = 64 * WM * WN;
   constexpr int TM = BMK / (WM * 32), TN = BN / (WN * 32);
@@ -570,8 +628,6 @@ __global__ __launch_bounds__(64 * WM * WN) void fsv_conv_wgrad_kernel(WgradP p) 
   float* const Bs = smem + 2 * A_ST;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
-  int kt, nt, bz;
-  fsv_xcd_range(kt, nt, bz);
   const int zs = bz / p.nsplit, zk = bz % p.nsplit;
   const int bi0 = kt * BMK, bn0 = nt * BN;
   float* dwt = p.dwt + (long long)zs * p.w_bstride;
@@ -747,6 +803,34 @@ __global__ __launch_bounds__(64 * WM * WN) void fsv_conv_wgrad_kernel(WgradP p) 
         if (p.nsplit > 1) atomicAdd(dst, acc[i][j][r]); else *dst = acc[i][j][r];
       }
   }
+}
+
+template <int BMK, int BN, int WM, int WN, bool COUT4>
+__global__ __launch_bounds__(64 * WM * WN) void fsv_conv_wgrad_kernel(WgradP p) {
+  int kt, nt, bz;
+  fsv_xcd_range(kt, nt, bz);
+  fsv_conv_wgrad_body<BMK, BN, WM, WN, COUT4>(p, kt, nt, bz);
+}
+
+// Grouped weight gradients (see fsv_conv_igemm_group_kernel): the problems' tiles in one 1-D grid, inside a problem ordered
+// (row tile, column tile) fastest and pixel range slowest, so that consecutive workgroups share a pixel range; every problem
+// adds into its own zeroed dwt when its reduction is split.
+struct WgradGroup {
+  int nprob;
+  int tile_end[FSV_GROUP_MAX];
+  WgradP p[FSV_GROUP_MAX];
+};
+
+template <int BMK, int BN, int WM, int WN, bool COUT4>
+__global__ __launch_bounds__(64 * WM * WN) void fsv_conv_wgrad_group_kernel(WgradGroup g) {
+  const int b = blockIdx.x;
+  int i = 0;
+  while (i + 1 < g.nprob && b >= g.tile_end[i]) ++i;
+  const int t = b - (i ? g.tile_end[i - 1] : 0);
+  const WgradP& p = g.p[i];
+  const int gx = (p.K + BMK - 1) / BMK, gy = (p.Cout + BN - 1) / BN;
+  const int r = t / gx;
+  fsv_conv_wgrad_body<BMK, BN, WM, WN, COUT4>(p, t - r * gx, r % gy, r / gy);
 }
 
 // scalar-gather twin (Cin % 4 != 0), single LDS buffer
@@ -1035,13 +1119,12 @@ static inline int fsv_tile_dims(int tile, int& bm, int& bn) {
   }
 }
 
-// FSV_CONV_PF2=1: the plan's 8-wave tiles run as their prefetch-distance-2 variants (ids 10 - 12).  Measured in the last GPU
-// seconds of round 2 (profiles/r02_notes.md section 16): +5 ... +6 % on the two dominant shapes in isolation, 55.19 -> 54.95 ms
-// on the whole step, correct and bit-equal to the plan's tiles on hardware - but the full GPU suite has not run with them, so
-// the default stays the kernels it has run with.
+// The plan's 8-wave tiles run as their prefetch-distance-2 variants (ids 10 - 12) unless FSV_CONV_PF2=0.  Measured at the
+// end of round 2 (profiles/r02_notes.md section 16): +5 ... +6 % on the two dominant shapes in isolation, bit-equal to the
+// PF = 1 tiles; made the default in round 3 after the whole GPU suite ran with them (profiles/r03_notes.md).
 static inline bool fsv_conv_pf2() {
   static int on = -1;
-  if (on < 0) { const char* e = getenv("FSV_CONV_PF2"); on = (e && e[0] == '1') ? 1 : 0; }
+  if (on < 0) { const char* e = getenv("FSV_CONV_PF2"); on = (e && e[0] == '0') ? 0 : 1; }
   return on != 0;
 }
 
@@ -1156,6 +1239,24 @@ extern "C" int fsv_conv_plan(int Mz, int Cout, int nchunks, int nsamp, int force
   return 0;
 }
 
+static inline void fsv_fill_convp(ConvP& p, const float* in, const float* wt, const float* bias, const float* res, float* out,
+                                  const float* wscale, int N, int H, int W, int Cin, int OH, int OW, int Cout, int ntaps,
+                                  const int* ty, const int* tx, int sy, int sx, int outH, int outW, int osy, int osx, int ooy,
+                                  int oox, int ldw, long long w_bstride, long long b_bstride, int per_sample, int act,
+                                  float scale) {
+  p.in = in; p.wt = wt; p.bias = bias; p.res = res; p.out = out; p.wscale = wscale;
+  p.N = N; p.H = H; p.W = W; p.Cin = Cin; p.OH = OH; p.OW = OW; p.Cout = Cout;
+  p.K = ntaps * Cin; p.nchunks = fsv_cdiv(p.K, FSV_BK); p.ldw = ldw;
+  p.sy = sy; p.sx = sx; p.ntaps = ntaps;
+  fsv_pack_taps(ty, tx, ntaps, p.taps_lo, p.taps_hi, 8);
+  p.outH = outH; p.outW = outW; p.osy = osy; p.osx = osx; p.ooy = ooy; p.oox = oox;
+  p.dense_out = (osy == 1 && osx == 1 && ooy == 0 && oox == 0 && outH == OH && outW == OW) ? 1 : 0;
+  p.w_bstride = w_bstride; p.b_bstride = b_bstride; p.per_sample = per_sample ? 1 : 0;
+  p.act = act; p.scale = scale;
+  p.Mz = per_sample ? OH * OW : N * OH * OW;
+  p.nsplit = 1;
+}
+
 static inline bool vec4_ok(int cin) { return (cin & 3) == 0; }
 
 extern "C" {
@@ -1175,18 +1276,14 @@ int fsv_conv_gather_fwd(const float* in, const float* wt, const float* bias, con
   // the V4 kernels index one tensor / one weight matrix with 32-bit element offsets
   if ((long long)N * H * W * Cin * 4 > FSV_BUF_MAX_BYTES || (long long)(ntaps * Cin + 32) * ldw * 4 > FSV_BUF_MAX_BYTES) return FSV_ERR_UNSUPPORTED;
   ConvP p;
-  p.in = in; p.wt = wt; p.bias = bias; p.res = res; p.out = out; p.wscale = wscale;
-  p.N = N; p.H = H; p.W = W; p.Cin = Cin; p.OH = OH; p.OW = OW; p.Cout = Cout;
-  p.K = ntaps * Cin; p.nchunks = fsv_cdiv(p.K, FSV_BK); p.ldw = ldw;
-  p.sy = sy; p.sx = sx; p.ntaps = ntaps;
-  fsv_pack_taps(ty, tx, ntaps, p.taps_lo, p.taps_hi, 8);
-  p.outH = outH; p.outW = outW; p.osy = osy; p.osx = osx; p.ooy = ooy; p.oox = oox;
-  p.dense_out = (osy == 1 && osx == 1 && ooy == 0 && oox == 0 && outH == OH && outW == OW) ? 1 : 0;
-  p.w_bstride = w_bstride; p.b_bstride = b_bstride; p.per_sample = per_sample ? 1 : 0;
-  p.act = act; p.scale = scale;
-  p.Mz = per_sample ? OH * OW : N * OH * OW;
+  fsv_fill_convp(p, in, wt, bias, res, out, wscale, N, H, W, Cin, OH, OW, Cout, ntaps, ty, tx, sy, sx, outH, outW, osy, osx, ooy,
+                 oox, ldw, w_bstride, b_bstride, per_sample, act, scale);
   const int nsamp = per_sample ? N : 1;
   int tile = 0, nsplit = 1;
+  if (act == FSV_ACT_DLRELU) {       // epilogue-only form: the finishing pass of a split launch does not know it
+    if (!res || accumulate) return FSV_ERR_BAD_ARG;
+    force_split = 1;
+  }
   if (fsv_conv_plan(p.Mz, Cout, p.nchunks, nsamp, force_tile, force_split, &tile, &nsplit)) return FSV_ERR_BAD_ARG;
   p.nsplit = nsplit;
   const long long total = (long long)N * outH * outW * Cout;
@@ -1310,6 +1407,230 @@ int fsv_prep_weight(const float* w, float* wt, const float* scale_ptr, int mode,
   if (grid > 2048) grid = 2048;
   FSV_LAUNCH(fsv_prep_weight_kernel, dim3(grid, 1, nbatch), dim3(256), stream, w, wt, scale_ptr, mode, Cout, Cin,
              KH, KW, ntaps, lo, hi, Kpad, ldw, w_bstride, wt_bstride);
+  return fsv_check_launch();
+}
+
+
+// ---- grouped launches (include/fsv2v.h: fsv_conv_gather_group / fsv_conv_wgrad_group) ------------------------------------
+static inline double fsv_group_cost(const ConvP* ps, const int* nsamp, int n, int tile) {
+  int bm, bn;
+  if (fsv_tile_dims(tile, bm, bn)) return 1e30;
+  const bool w8 = (tile == 0 || tile == 1 || tile == 9);
+  const double cyc = (double)bm * bn / 4.0;
+  const double ovh = 5000.0 + bm * bn / 8.0;
+  double load = 0.0, crit = 0.0;
+  for (int i = 0; i < n; ++i) {
+    const double wgs = (double)fsv_cdiv(ps[i].Mz, bm) * fsv_cdiv(ps[i].Cout, bn) * nsamp[i];
+    const double one = ps[i].nchunks * cyc;
+    load += wgs * (one / 0.95 + 0.45 * ovh);
+    const double lone = one / (w8 ? 0.91 : 0.78) + ovh;
+    if (lone > crit) crit = lone;
+  }
+  load /= 256.0;
+  return (load > crit ? load : crit) / 1.95e9 + 4e-6;
+}
+
+static inline void fsv_group_order(const long long* weight, int n, int* order) {
+  // longest problems first: the dispatcher hands workgroups out in grid order, so the long tiles start first and the short
+  // ones fill the gaps (LPT)
+  for (int i = 0; i < n; ++i) order[i] = i;
+  for (int i = 1; i < n; ++i) {
+    const int v = order[i];
+    int j = i - 1;
+    while (j >= 0 && weight[order[j]] < weight[v]) { order[j + 1] = order[j]; --j; }
+    order[j + 1] = v;
+  }
+}
+
+#define FSV_GROUP_LIMIT 64
+
+int fsv_conv_gather_group(const fsv_conv_desc* d, int n, int force_tile, hipStream_t stream) {
+  if (!d || n < 1 || n > FSV_GROUP_LIMIT) return FSV_ERR_BAD_ARG;
+  ConvP ps[FSV_GROUP_LIMIT];
+  int nsamp[FSV_GROUP_LIMIT];
+  long long weight[FSV_GROUP_LIMIT];
+  bool vec4 = true;
+  int max_cout = 0;
+  for (int i = 0; i < n; ++i) {
+    const fsv_conv_desc& q = d[i];
+    if (!q.in || !q.wt || !q.out || q.ntaps < 1 || q.ntaps > 16 || q.N < 1 || q.Cin < 1 || q.Cout < 1) return FSV_ERR_BAD_ARG;
+    for (int t = 0; t < q.ntaps; ++t)
+      if (q.ty[t] < -8 || q.ty[t] > 7 || q.tx[t] < -8 || q.tx[t] > 7) return FSV_ERR_UNSUPPORTED;
+    if ((q.ldw & 3) != 0 || q.ldw < q.Cout) return FSV_ERR_BAD_ARG;
+    if ((long long)q.N * q.H * q.W * q.Cin * 4 > FSV_BUF_MAX_BYTES || (long long)(q.ntaps * q.Cin + 32) * q.ldw * 4 > FSV_BUF_MAX_BYTES)
+      return FSV_ERR_UNSUPPORTED;
+    if (q.accumulate && (q.bias || q.res || q.act != FSV_ACT_NONE || q.scale != 1.f)) return FSV_ERR_BAD_ARG;
+    if (q.act == FSV_ACT_DLRELU && !q.res) return FSV_ERR_BAD_ARG;
+    fsv_fill_convp(ps[i], q.in, q.wt, q.bias, q.res, q.out, q.wscale, q.N, q.H, q.W, q.Cin, q.OH, q.OW, q.Cout, q.ntaps, q.ty,
+                   q.tx, q.sy, q.sx, q.outH, q.outW, q.osy, q.osx, q.ooy, q.oox, q.ldw, q.w_bstride, q.b_bstride, q.per_sample,
+                   q.act, q.scale);
+    nsamp[i] = q.per_sample ? q.N : 1;
+    vec4 = vec4 && vec4_ok(q.Cin);
+    if (q.Cout > max_cout) max_cout = q.Cout;
+  }
+  // one tile shape for the whole group
+  int tile = force_tile;
+  if (tile < 0) {
+    static const int tiles[5] = {0, 9, 1, 4, 2};
+    double best = 1e30;
+    for (int ti = 0; ti < 5; ++ti) {
+      const int t = tiles[ti];
+      if ((t == 0 || t == 9) && max_cout <= 64) continue;
+      if (t == 1 && max_cout <= 32) continue;
+      if (t == 2 && max_cout > 32) continue;
+      const double c = fsv_group_cost(ps, nsamp, n, t) * (1.0 + 0.01 * ti);
+      if (c < best) { best = c; tile = t; }
+    }
+    if (tile < 0) tile = 4;
+  }
+  if (tile >= 10) tile = (tile == 10) ? 9 : (tile == 11) ? 0 : 1;
+  int bm, bn;
+  if (fsv_tile_dims(tile, bm, bn)) return FSV_ERR_BAD_ARG;
+  // K splits: only problems that accumulate into a zeroed output, and only when the whole group would leave CUs idle
+  long long wgs1 = 0;
+  for (int i = 0; i < n; ++i) wgs1 += (long long)fsv_cdiv(ps[i].Mz, bm) * fsv_cdiv(ps[i].Cout, bn) * nsamp[i];
+  int want = 1;
+  if (wgs1 < 256) { want = (int)(512 / (wgs1 > 0 ? wgs1 : 1)); if (want > 8) want = 8; if (want < 1) want = 1; }
+  for (int i = 0; i < n; ++i) {
+    int sp = 1;
+    if (d[i].accumulate && want > 1) {
+      sp = want;
+      if (sp > ps[i].nchunks / 8) sp = ps[i].nchunks / 8;
+      if (sp < 1) sp = 1;
+    }
+    ps[i].nsplit = sp;
+    weight[i] = (long long)fsv_cdiv(ps[i].nchunks, sp);
+  }
+  int order[FSV_GROUP_LIMIT];
+  fsv_group_order(weight, n, order);
+  const bool pf2 = vec4 && fsv_conv_pf2();
+  for (int b0 = 0; b0 < n; b0 += FSV_GROUP_MAX) {
+    ConvGroup g;
+    g.nprob = (n - b0 < FSV_GROUP_MAX) ? (n - b0) : FSV_GROUP_MAX;
+    int tiles = 0;
+    for (int j = 0; j < FSV_GROUP_MAX; ++j) {
+      if (j < g.nprob) {
+        const int i = order[b0 + j];
+        g.p[j] = ps[i];
+        tiles += fsv_cdiv(ps[i].Mz, bm) * fsv_cdiv(ps[i].Cout, bn) * nsamp[i] * ps[i].nsplit;
+      } else {
+        g.p[j] = ps[order[b0]];
+      }
+      g.tile_end[j] = tiles;
+    }
+    const dim3 grid(tiles);
+    if (vec4) {
+      switch (tile) {
+        case 0:
+          if (pf2) FSV_LAUNCH((fsv_conv_igemm_group_kernel<128, 128, 2, 4, 2>), grid, dim3(512), stream, g);
+          else FSV_LAUNCH((fsv_conv_igemm_group_kernel<128, 128, 2, 4>), grid, dim3(512), stream, g);
+          break;
+        case 1:
+          if (pf2) FSV_LAUNCH((fsv_conv_igemm_group_kernel<128, 64, 4, 2, 2>), grid, dim3(512), stream, g);
+          else FSV_LAUNCH((fsv_conv_igemm_group_kernel<128, 64, 4, 2>), grid, dim3(512), stream, g);
+          break;
+        case 2: FSV_LAUNCH((fsv_conv_igemm_group_kernel<128, 32, 4, 1>), grid, dim3(256), stream, g); break;
+        case 4: FSV_LAUNCH((fsv_conv_igemm_group_kernel<64, 64, 2, 2>), grid, dim3(256), stream, g); break;
+        default:
+          if (pf2) FSV_LAUNCH((fsv_conv_igemm_group_kernel<64, 128, 2, 4, 2>), grid, dim3(512), stream, g);
+          else FSV_LAUNCH((fsv_conv_igemm_group_kernel<64, 128, 2, 4>), grid, dim3(512), stream, g);
+          break;
+      }
+    } else {
+      switch (tile) {
+        case 0: FSV_LAUNCH((fsv_conv_igemm_v1_group_kernel<128, 128, 2, 2>), grid, dim3(256), stream, g); break;
+        case 1: FSV_LAUNCH((fsv_conv_igemm_v1_group_kernel<128, 64, 2, 2>), grid, dim3(256), stream, g); break;
+        case 2: FSV_LAUNCH((fsv_conv_igemm_v1_group_kernel<128, 32, 4, 1>), grid, dim3(256), stream, g); break;
+        case 4: FSV_LAUNCH((fsv_conv_igemm_v1_group_kernel<64, 64, 2, 2>), grid, dim3(256), stream, g); break;
+        default: FSV_LAUNCH((fsv_conv_igemm_v1_group_kernel<64, 128, 2, 2>), grid, dim3(256), stream, g); break;
+      }
+    }
+  }
+  return fsv_check_launch();
+}
+
+// Tile of the grouped launch the planner would pick (tests / profiler labels)
+int fsv_conv_group_plan(const int* Mz, const int* Cout, const int* nchunks, const int* nsamp, int n, int* tile_out) {
+  if (!Mz || !Cout || !nchunks || !nsamp || !tile_out || n < 1 || n > FSV_GROUP_LIMIT) return FSV_ERR_BAD_ARG;
+  ConvP ps[FSV_GROUP_LIMIT];
+  int max_cout = 0;
+  for (int i = 0; i < n; ++i) { ps[i].Mz = Mz[i]; ps[i].Cout = Cout[i]; ps[i].nchunks = nchunks[i]; if (Cout[i] > max_cout) max_cout = Cout[i]; }
+  static const int tiles[5] = {0, 9, 1, 4, 2};
+  double best = 1e30;
+  int tile = 4;
+  for (int ti = 0; ti < 5; ++ti) {
+    const int t = tiles[ti];
+    if ((t == 0 || t == 9) && max_cout <= 64) continue;
+    if (t == 1 && max_cout <= 32) continue;
+    if (t == 2 && max_cout > 32) continue;
+    const double c = fsv_group_cost(ps, nsamp, n, t) * (1.0 + 0.01 * ti);
+    if (c < best) { best = c; tile = t; }
+  }
+  *tile_out = tile;
+  return FSV_OK;
+}
+
+// Grouped weight gradients: every dwt is a ZEROED [Kpad][ldw] matrix (slices of the optimiser's per-pass arena); 64x64 tiles
+// (the tile the single launches use wherever it applies, profiles/r02_wgrad_ab.jsonl), pixel ranges split so that the group
+// as a whole fills the chip.  FSV_ERR_UNSUPPORTED (nothing launched) when a problem needs the scalar gather: callers then
+// issue the problems one by one.
+int fsv_conv_wgrad_group(const fsv_wgrad_desc* d, int n, hipStream_t stream) {
+  if (!d || n < 1 || n > FSV_GROUP_LIMIT) return FSV_ERR_BAD_ARG;
+  WgradP ps[FSV_GROUP_LIMIT];
+  int nsamp[FSV_GROUP_LIMIT];
+  long long weight[FSV_GROUP_LIMIT];
+  bool cout4 = true;
+  long long blocks = 0;
+  for (int i = 0; i < n; ++i) {
+    const fsv_wgrad_desc& q = d[i];
+    if (!q.in || !q.dout || !q.dwt || q.ntaps < 1 || q.ntaps > 16) return FSV_ERR_BAD_ARG;
+    for (int t = 0; t < q.ntaps; ++t)
+      if (q.ty[t] < -8 || q.ty[t] > 7 || q.tx[t] < -8 || q.tx[t] > 7) return FSV_ERR_UNSUPPORTED;
+    if ((long long)q.N * q.H * q.W * q.Cin * 4 > FSV_BUF_MAX_BYTES || (long long)q.N * q.OH * q.OW * q.Cout * 4 > FSV_BUF_MAX_BYTES)
+      return FSV_ERR_UNSUPPORTED;
+    if (!vec4_ok(q.Cin) || !(FSV_BK / q.OW + 1 <= q.OH)) return FSV_ERR_UNSUPPORTED;
+    WgradP& p = ps[i];
+    p.in = q.in; p.dout = q.dout; p.dwt = q.dwt;
+    p.N = q.N; p.H = q.H; p.W = q.W; p.Cin = q.Cin; p.OH = q.OH; p.OW = q.OW; p.Cout = q.Cout;
+    p.K = q.ntaps * q.Cin; p.ldw = q.ldw; p.sy = q.sy; p.sx = q.sx; p.ntaps = q.ntaps;
+    fsv_pack_taps(q.ty, q.tx, q.ntaps, p.taps_lo, p.taps_hi, 8);
+    p.w_bstride = q.w_bstride; p.per_sample = q.per_sample ? 1 : 0;
+    p.Mz = q.per_sample ? q.OH * q.OW : q.N * q.OH * q.OW;
+    p.pchunks = fsv_cdiv(p.Mz, FSV_BK);
+    nsamp[i] = q.per_sample ? q.N : 1;
+    cout4 = cout4 && (q.Cout & 3) == 0;
+    blocks += (long long)fsv_cdiv(p.K, 64) * fsv_cdiv(q.Cout, 64) * nsamp[i];
+  }
+  // the same ~2048-workgroup target as the single launches, for the group as a whole; at least 8 pixel chunks per split
+  int want = (int)((2048 + blocks - 1) / (blocks > 0 ? blocks : 1));
+  if (want < 1) want = 1;
+  for (int i = 0; i < n; ++i) {
+    int sp = want;
+    const int maxs = ps[i].pchunks / 8;
+    if (sp > maxs) sp = maxs;
+    if (sp < 1) sp = 1;
+    ps[i].nsplit = sp;
+    weight[i] = (long long)fsv_cdiv(ps[i].pchunks, sp);
+  }
+  int order[FSV_GROUP_LIMIT];
+  fsv_group_order(weight, n, order);
+  for (int b0 = 0; b0 < n; b0 += FSV_GROUP_MAX) {
+    WgradGroup g;
+    g.nprob = (n - b0 < FSV_GROUP_MAX) ? (n - b0) : FSV_GROUP_MAX;
+    int tiles = 0;
+    for (int j = 0; j < FSV_GROUP_MAX; ++j) {
+      if (j < g.nprob) {
+        const int i = order[b0 + j];
+        g.p[j] = ps[i];
+        tiles += fsv_cdiv(ps[i].K, 64) * fsv_cdiv(ps[i].Cout, 64) * nsamp[i] * ps[i].nsplit;
+      } else {
+        g.p[j] = ps[order[b0]];
+      }
+      g.tile_end[j] = tiles;
+    }
+    if (cout4) FSV_LAUNCH((fsv_conv_wgrad_group_kernel<64, 64, 2, 2, true>), dim3(tiles), dim3(256), stream, g);
+    else FSV_LAUNCH((fsv_conv_wgrad_group_kernel<64, 64, 2, 2, false>), dim3(tiles), dim3(256), stream, g);
+  }
   return fsv_check_launch();
 }
 

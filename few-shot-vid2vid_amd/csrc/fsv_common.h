@@ -37,6 +37,10 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define FSV_ACT_SIGMOID 3
 #define FSV_ACT_RELU 4      // VGG19 feature stack (models/networks/vgg.py)
 #define FSV_ACT_LRELU01 5   // leaky_relu(x, 0.1): FlowNet2 teacher (flownet2_pytorch/networks/submodules.py:16,39)
+// gather-GEMM epilogue only (V4 kernel): out = v * leaky_relu'(aux), aux = the `res` operand (the OUTPUT of the layer whose
+// pre-activation gradient this launch produces) - the act-backward pass of a Linear + LeakyReLU chain folded into the data
+// gradient that feeds it.  Same arithmetic as fsv_act_bwd_kernel: aux > 0 ? v : 0.2 * v.
+#define FSV_ACT_DLRELU 6
 
 #ifdef FSV_EMU
 static inline int fsv_check_launch() {

@@ -488,19 +488,42 @@ class FewShotGenerator(nn.Module):
         b = f.shape[0]
         return [[parts[2 * k].reshape(b, cout, cin, 1, 1), parts[2 * k + 1]] for k in range(npairs)]
 
-    def get_SPADE_weights(self, feat, i):
+    _MLP_NAMES = ('fc_spade_e', 'fc_spade_0', 'fc_spade_1', 'fc_spade_s')
+
+    def _mlp_names(self):
+        return self._MLP_NAMES if self.adap_embed else self._MLP_NAMES[1:]
+
+    def _mlp_bank(self, feats):
+        """All weight-generator MLPs of all adaptive levels, advanced layer by layer with one grouped launch per layer
+        (ops.mlp_bank) instead of one small launch per Linear; {(name, level): FC output} or None when the grouped path does
+        not apply (no optimiser-owned layouts yet, narrow-operand modes, FSV_CONV_GROUPS=0)."""
+        rows = [f.reshape(f.shape[0] * f.shape[1], -1) for f in feats]
+        chains, keys = [], []
+        for i in range(len(feats)):
+            for name in self._mlp_names():
+                layers = getattr(self, '%s_%d' % (name, i))
+                chains.append((i, [layers[k] for k in range(0, len(layers), 2)]))
+                keys.append((name, i))
+        outs = ops.mlp_bank(rows, chains)
+        return None if outs is None else dict(zip(keys, outs))
+
+    def get_SPADE_weights(self, feat, i, fc=None):
+        """fc: {(name, level): FC output rows} from _mlp_bank, or None: run this level's MLPs here"""
         ch_in, ch_out = self.ch[i], self.ch[i + 1]
         ch_h = self.ch_hidden[i][0]
         b = feat.shape[0]
-        rows = feat.reshape(b * feat.shape[1], -1)
+        rows = feat.reshape(b * feat.shape[1], -1) if fc is None else None
+
+        def mlp(name):
+            return fc[(name, i)] if fc is not None else self._mlp(name, i, rows)
         embedding_weights = None
         if self.adap_embed:
-            fe = self._mlp('fc_spade_e', i, rows).view(b, -1)
+            fe = mlp('fc_spade_e').view(b, -1)
             # the reference drops the trailing ch_in entries, then reads weight | bias off what is left: the same split
             embedding_weights = self._pairs(fe, 1, ch_in, ch_out)[0]
 
         def two(name, co):
-            f = self._mlp(name, i, rows).view(b, -1)
+            f = mlp(name).view(b, -1)
             return self._pairs(f, 2, co, ch_h)
         return embedding_weights, [two('fc_spade_0', ch_out), two('fc_spade_1', ch_in), two('fc_spade_s', ch_out)]
 
@@ -573,8 +596,10 @@ class FewShotGenerator(nn.Module):
         if fresh:
             embed_w, norm_w = [], []
             if self.adap_spade:
+                feats = [enc[min(len(enc) - 1, i + 1)] for i in range(self.n_adaptive_layers)]
+                fc = self._mlp_bank(feats)
                 for i in range(self.n_adaptive_layers):
-                    e, nw = self.get_SPADE_weights(enc[min(len(enc) - 1, i + 1)], i)
+                    e, nw = self.get_SPADE_weights(feats[i], i, fc)
                     embed_w.append(e)
                     norm_w.append(nw)
             if not self.opt.isTrain:

@@ -16,6 +16,7 @@ import torch
 
 from . import lib, profile
 from .conv import (ACT_LRELU, ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_TANH, Geom, conv_dgrad, conv_forward, conv_wgrad, empty_nhwc,
+                   gather_gemm, launch_group,
                    prep_weight, to_nhwc, zeros_nhwc)
 
 c_p, c_i, c_ll, c_f = ctypes.c_void_p, ctypes.c_int, ctypes.c_longlong, ctypes.c_float
@@ -435,6 +436,177 @@ def linear(x2d, weight, bias=None, act=ACT_NONE, sn=None):
     sig, u, v, owned = _unpack_sn(sn)
     y4 = _ConvFn.apply(x4, weight, bias, None, sig, u, v, Geom(1, 1, 1, 0), act, 1.0, owned)
     return y4.permute(0, 2, 3, 1).reshape(r, weight.shape[0])
+
+
+# ------------------------------------------------------------------------------------------------ banks of small MLPs
+ACT_DLRELU = 6       # FSV_ACT_DLRELU (include/fsv2v.h): gather-GEMM epilogue v * leaky_relu'(res)
+
+
+class _MlpBankFn(torch.autograd.Function):
+    """Several independent Linear(+LeakyReLU) chains - the weight generators of generator.py:103-110, 245-273: per adaptive
+    level four MLPs of `n_fc_layers` + 1 spectral-normalised Linears on the same rows - advanced LAYER BY LAYER with one
+    grouped launch per layer (conv.launch_group) instead of one small launch per Linear: 3 launches forward instead of 48
+    at C3, and in backward per layer one grouped weight-gradient launch and one grouped data-gradient launch whose epilogue
+    already multiplies by LeakyReLU'(output of the layer below) (FSV_ACT_DLRELU; no separate activation-backward pass).
+    Arithmetic per output element is that of ops.linear (same kernels, same k order).
+
+    apply(meta, rows_0 .. rows_{L-1}, (weight, bias) per chain per layer ...).  meta: dict(chains=[(level, nlayers)],
+    sn=[[(sig, u, v) per layer] per chain], entries=[[layout-cache entry per layer] per chain]).  Requirements (checked by
+    the caller, networks.FewShotGenerator._mlp_bank): every weight is owned by a FlatAdam with layout cache; for a pass that
+    records gradients also the gradient sinks + deferred finalisation."""
+
+    @staticmethod
+    def forward(ctx, meta, *tensors):
+        chains, sns, entries = meta['chains'], meta['sn'], meta['entries']
+        nlev = meta['nlevels']
+        rows = tensors[:nlev]
+        params = tensors[nlev:]
+        geom = Geom(1, 1, 1, 0)
+        # per chain: list of (weight, bias)
+        wb, k = [], 0
+        for (_, nl) in chains:
+            wb.append([(params[k + 2 * j], params[k + 2 * j + 1]) for j in range(nl)])
+            k += 2 * nl
+        for ch in wb:
+            for w, b in ch:
+                w._fsv_conv_param = True
+                b._fsv_conv_param = True
+        nl_max = max(nl for _, nl in chains)
+        x4 = [None] * nlev
+        for l, r in enumerate(rows):
+            r = r.detach().contiguous()
+            x4[l] = r.view(1, 1, r.shape[0], r.shape[1]).permute(0, 3, 1, 2)
+        cur = [x4[lev] for (lev, _) in chains]
+        xs = [[] for _ in chains]          # input of every layer
+        ys = [[] for _ in chains]          # output of every layer
+        for j in range(nl_max):
+            with launch_group():
+                for c, (lev, nl) in enumerate(chains):
+                    if j >= nl:
+                        continue
+                    w, b = wb[c][j]
+                    e = entries[c][j]
+                    wt, ldw = e.fwd
+                    sig = sns[c][j][0]
+                    act = ACT_LRELU if j < nl - 1 else ACT_NONE
+                    y = gather_gemm(cur[c], wt, ldw, w.shape[0], 1, cur[c].shape[3], geom.ty, geom.tx, 1, 1,
+                                    bias=b.detach(), act=act, wscale=sig[1:2])
+                    xs[c].append(cur[c]); ys[c].append(y)
+                    cur[c] = y
+        ctx.meta, ctx.geom = meta, geom
+        ctx.wb = wb
+        ctx.xs, ctx.ys = (xs, ys) if any(ctx.needs_input_grad) else (None, None)
+        return tuple(y[-1].permute(0, 2, 3, 1).reshape(y[-1].shape[3], y[-1].shape[1]) for y in ys)
+
+    @staticmethod
+    def backward(ctx, *douts):
+        meta, geom, wb, xs, ys = ctx.meta, ctx.geom, ctx.wb, ctx.xs, ctx.ys
+        chains, sns, entries, nlev = meta['chains'], meta['sn'], meta['entries'], meta['nlevels']
+        d = []
+        for c, g in enumerate(douts):
+            y = ys[c][-1]
+            if g is None:
+                g = torch.zeros((y.shape[3], y.shape[1]), dtype=torch.float32, device=y.device)
+            g = g.contiguous()
+            d.append(g.view(1, 1, g.shape[0], g.shape[1]).permute(0, 3, 1, 2))
+        nl_max = max(nl for _, nl in chains)
+        cls0 = geom.dgrad_classes[0]
+        drows = [None] * nlev
+        for j in reversed(range(nl_max)):
+            live = [c for c, (_, nl) in enumerate(chains) if j < nl]
+            # weight + bias gradients of layer j (deferred finalisation: K-major result + job, grouped column sums)
+            with launch_group():
+                for c in live:
+                    w, b = wb[c][j]
+                    e = entries[c][j]
+                    fin = w._fsv_finalizer
+                    w_shape = (w.shape[0], w.shape[1], 1, 1)
+                    dwt = conv_wgrad(xs[c][j], d[c], geom, w_shape, raw=True, arena=fin)
+                    sig, u, v = sns[c][j]
+                    fin.add(e, dwt, w.grad, sig, u, v)
+                    b._fsv_finalizer.add_bias(d[c], b.grad)
+            # data gradient of layer j.  j > 0: handed to layer j - 1 as its pre-activation gradient (x LeakyReLU'(y_{j-1}) in the
+            # epilogue).  j == 0: the chains of one level share their input rows; their gradients are summed in a fixed
+            # order by chaining the residual operand through one grouped launch per chain position.
+            if j > 0:
+                with launch_group():
+                    nxt = {}
+                    for c in live:
+                        w, _ = wb[c][j]
+                        wt, ldw = entries[c][j].dgrad[0]
+                        sig = sns[c][j][0]
+                        nxt[c] = gather_gemm(d[c], wt, ldw, w.shape[1], 1, d[c].shape[3], cls0['ty'], cls0['tx'], 1, 1,
+                                             act=ACT_DLRELU, res=ys[c][j - 1], wscale=sig[1:2])
+                for c in live:
+                    d[c] = nxt[c]
+            else:
+                by_level = {}
+                for c in live:
+                    by_level.setdefault(chains[c][0], []).append(c)
+                pos = 0
+                while True:
+                    batch = [(lev, cs[pos]) for lev, cs in by_level.items() if pos < len(cs)]
+                    if not batch:
+                        break
+                    with launch_group():
+                        for lev, c in batch:
+                            w, _ = wb[c][0]
+                            wt, ldw = entries[c][0].dgrad[0]
+                            sig = sns[c][0][0]
+                            drows[lev] = gather_gemm(d[c], wt, ldw, w.shape[1], 1, d[c].shape[3], cls0['ty'], cls0['tx'], 1, 1,
+                                                     res=drows[lev], wscale=sig[1:2])
+                    pos += 1
+        outs = [None]
+        for lev in range(nlev):
+            g = drows[lev]
+            outs.append(None if g is None or not ctx.needs_input_grad[1 + lev]
+                        else g.permute(0, 2, 3, 1).reshape(g.shape[3], g.shape[1]))
+        outs += [None] * (len(ctx.needs_input_grad) - len(outs))
+        return tuple(outs)
+
+
+def mlp_bank(rows, chains):
+    """rows: list of [R_l, c_l] tensors (one per level); chains: list of (level, [modules with weight_orig / bias / _sn()]).
+    Returns one [R_l, out] tensor per chain, or None when the grouped path does not apply (the caller then runs the chains
+    Linear by Linear through ops.linear)."""
+    from . import conv as _conv
+    if not _conv.group_enabled() or _conv.mfma_mode() != 0:
+        return None
+    grad = torch.is_grad_enabled() and (any(r.requires_grad for r in rows) or
+                                        any(m.weight_orig.requires_grad for _, ms in chains for m in ms))
+    geom = Geom(1, 1, 1, 0)
+    entries = []
+    for lev, ms in chains:
+        es = []
+        for m in ms:
+            w, b = m.weight_orig, m.bias
+            if not getattr(m, 'spectral', False) or b is None or w.dim() != 2 or rows[lev].shape[1] % 4 != 0 and m is ms[0]:
+                return None
+            cache = getattr(w, '_fsv_cache', None)
+            e = cache.lookup(w, (w.shape[0], w.shape[1], 1, 1), geom, 0) if cache is not None else None
+            if e is None or w.shape[1] % 4 != 0:
+                return None
+            if grad:
+                ok = (getattr(w, '_fsv_sink', False) and w.grad is not None and getattr(w, '_fsv_finalizer', None) is not None
+                      and getattr(b, '_fsv_sink', False) and b.grad is not None and getattr(b, '_fsv_finalizer', None) is not None
+                      and w.requires_grad and b.requires_grad)
+                if not ok:
+                    return None
+            es.append(e)
+        entries.append(es)
+    sns = []
+    for lev, ms in chains:
+        per = []
+        for m in ms:
+            sig, u, v, owned = _unpack_sn(m._sn())
+            per.append((sig, u if owned else u.clone(), v if owned else v.clone()))
+        sns.append(per)
+    meta = dict(chains=[(lev, len(ms)) for lev, ms in chains], sn=sns, entries=entries, nlevels=len(rows))
+    flat = list(rows)
+    for lev, ms in chains:
+        for m in ms:
+            flat += [m.weight_orig, m.bias]
+    return list(_MlpBankFn.apply(meta, *flat))
 
 
 def batch_conv(x, weight, bias=None, act=ACT_NONE, stride=1):

@@ -28,7 +28,10 @@ typedef void* fsv_stream_t; /* hipStream_t */
 
 enum fsv_status { FSV_OK = 0, FSV_ERR_BAD_ARG = -1, FSV_ERR_UNSUPPORTED = -2, FSV_ERR_LAUNCH = -3 };
 enum fsv_act { FSV_ACT_NONE = 0, FSV_ACT_LRELU = 1 /* leaky_relu(0.2), architecture.py:15-17 */, FSV_ACT_TANH = 2,
-               FSV_ACT_SIGMOID = 3, FSV_ACT_RELU = 4 /* VGG19 stack */ };
+               FSV_ACT_SIGMOID = 3, FSV_ACT_RELU = 4 /* VGG19 stack */, FSV_ACT_LRELU01 = 5 /* leaky_relu(0.1), FlowNet2 */,
+               /* gather-GEMM epilogue only: out = v * leaky_relu'(res) (res = the activated output of the layer below): the
+                * activation-backward pass of a Linear + LeakyReLU chain (generator.py:103-110) folded into the data gradient */
+               FSV_ACT_DLRELU = 6 };
 
 /* ---- convolution family (csrc/conv_igemm.hip) -----------------------------------------------------------------
  * Replaces F.conv2d at architecture.py:22-27,60,81-84; generator.py:112-131,479-504,541-572;
@@ -41,7 +44,8 @@ enum fsv_act { FSV_ACT_NONE = 0, FSV_ACT_LRELU = 1 /* leaky_relu(0.2), architect
  * weight matrix (stride w_bstride) and bias (stride b_bstride) per sample n.  accumulate != 0: `out` was zeroed by
  * the caller, results are added (used for the four parity classes of a stride-2 data gradient).
  * force_tile / force_split: -1 / 0 = automatic (tile ids, pixels x channels: 0 128x128, 1 128x64, 2 128x32, 4 64x64, 9 64x128;
- * 10 / 11 / 12 = 64x128 / 128x128 / 128x64 with the global loads two chunks ahead: chosen only with FSV_CONV_PF2=1).
+ * 10 / 11 / 12 = 64x128 / 128x128 / 128x64 with the global loads two chunks ahead: what the plan's 9 / 0 / 1 run as unless
+ * FSV_CONV_PF2=0).
  * One activation tensor / weight matrix may hold at most 2 GiB (32-bit byte offsets): FSV_ERR_UNSUPPORTED beyond.  wscale: optional device scalar multiplying the accumulator before
  * the bias (the spectral-norm 1/sigma when wt holds un-normalised weights). */
 int fsv_conv_gather_fwd(const float* in, const float* wt, const float* bias, const float* res, float* out,
@@ -51,6 +55,37 @@ int fsv_conv_gather_fwd(const float* in, const float* wt, const float* bias, con
                         int ldw, long long w_bstride, long long b_bstride, int per_sample,
                         int act, float scale, int force_tile, int force_split, int accumulate, const float* wscale,
                         fsv_stream_t stream);
+
+/* ---- grouped launches: up to 64 INDEPENDENT problems in one grid --------------------------------------------------------
+ * The reference issues the 16 weight-generator MLPs (generator.py:103-110,245-273: three nn.Linear each, per adaptive level
+ * and per SPADE site) and the transposed-convolution data gradients of its stride-2 layers one cudnn call at a time; on this
+ * device every such launch lasts as long as its longest workgroup while most of the 256 CUs idle.  A group puts the tiles of
+ * all its problems into one grid (longest problems first).  fsv_conv_desc = the arguments of fsv_conv_gather_fwd;
+ * accumulate != 0: `out` was zeroed by the caller and the problem may be K-split (atomic adds, no epilogue).  No problem of a
+ * group may read what another one writes.  A problem with Cin % 4 != 0 sends the whole group to the scalar-gather kernel. */
+typedef struct fsv_conv_desc {
+  const float* in; const float* wt; const float* bias; const float* res; float* out; const float* wscale;
+  int N, H, W, Cin, OH, OW, Cout, ntaps;
+  int ty[16], tx[16];
+  int sy, sx, outH, outW, osy, osx, ooy, oox, ldw;
+  int per_sample, act, accumulate;
+  float scale;
+  long long w_bstride, b_bstride;
+} fsv_conv_desc;
+int fsv_conv_gather_group(const fsv_conv_desc* problems, int n, int force_tile, fsv_stream_t stream);
+/* tile id the grouped launch uses for problems of these sizes (Mz = pixels per sample group, nchunks = ceil(taps * Cin / 32)) */
+int fsv_conv_group_plan(const int* Mz, const int* Cout, const int* nchunks, const int* nsamp, int n, int* tile_out);
+/* grouped weight gradients (arguments of fsv_conv_wgrad): every dwt is a ZEROED [Kpad][ldw] matrix; float4-gather layers only
+ * (Cin % 4 == 0), FSV_ERR_UNSUPPORTED with nothing launched otherwise - issue the problems one by one then */
+typedef struct fsv_wgrad_desc {
+  const float* in; const float* dout; float* dwt;
+  int N, H, W, Cin, OH, OW, Cout, ntaps;
+  int ty[16], tx[16];
+  int sy, sx, ldw, Kpad;
+  int per_sample, reserved;
+  long long w_bstride;
+} fsv_wgrad_desc;
+int fsv_conv_wgrad_group(const fsv_wgrad_desc* problems, int n, fsv_stream_t stream);
 
 /* in place: x = act(x + bias[c]) over an NHWC tensor (finishing pass of operators that add several GEMM launches into one
  * output: convolutions with more than 16 taps, transposed convolutions); act codes as in the conv epilogue, 5 = leaky 0.1 */

@@ -749,3 +749,103 @@ def check_warp_compose(device, b=2, h=16, w=24, mag=5.0, seed=93):
         (c2 * gc).sum().backward()
         assert_close(mode + ' dflow (comp only)', fd2.grad, fr2.grad, 1e-4)
         assert_close(mode + ' dmask (comp only)', md2.grad, mr2.grad, 1e-5)
+
+
+def check_conv_groups(device, seed=77, big=False):
+    """Grouped launches (conv.launch_group -> fsv_conv_gather_group / fsv_conv_wgrad_group): heterogeneous independent problems in
+    one grid give, bit for bit, what the same launches give one by one (same kernels, same k order; split problems to rounding),
+    and both equal F.conv2d.  Covers: float4 and scalar-gather groups, strided placement (the parity classes of a stride-2 data
+    gradient), K-split accumulating problems, per-sample weights, the LeakyReLU'-multiplying epilogue, > 16 problems (two
+    grids), grouped weight gradients with and without Cout % 4 == 0."""
+    ops, conv = pkg()
+    g = torch.Generator().manual_seed(seed)
+    sc = 2 if big else 1
+
+    def problem(n, cin, h, w, cout, k, act, with_res, with_bias):
+        x = torch.randn(n, cin, h, w, generator=g)
+        wt = torch.randn(cout, cin, k, k, generator=g) * (1.0 / (cin * k * k) ** 0.5)
+        b = torch.randn(cout, generator=g) if with_bias else None
+        r = torch.randn(n, cout, h, w, generator=g) if with_res else None
+        return x, wt, b, r, k, act
+
+    specs = [problem(2, 16 * sc, 9, 7, 40, 3, conv.ACT_LRELU, False, True),
+             problem(1, 32, 5, 33 * sc, 24, 1, conv.ACT_NONE, True, True),
+             problem(3, 8, 4, 4, 130, 3, conv.ACT_TANH, False, False),
+             problem(1, 64 * sc, 1, 50, 66, 1, conv.ACT_LRELU, False, True)]
+    specs += [problem(1, 8, 3, 5 + i, 12 + 4 * i, 1, conv.ACT_NONE, False, True) for i in range(16)]     # 20 problems: two grids
+
+    def run(grouped, specs, tile=-1):
+        outs = []
+        with conv.launch_group(grouped, force_tile=tile):
+            for x, wt, b, r, k, act in specs:
+                geom = conv.Geom(k, k, 1, k // 2)
+                wk, _, ldw = conv.prep_weight(_dev(wt, device), 0, geom)
+                outs.append(conv.conv_forward(_dev(x, device), wk, ldw, wt.shape[0], geom, bias=_dev(b, device) if b is not None else None,
+                                              res=_dev(r, device) if r is not None else None, act=act))
+        return outs
+    specs_s0 = [problem(2, 6, 6, 5, 20, 3, conv.ACT_LRELU, False, True), problem(1, 16, 4, 9, 33, 1, conv.ACT_NONE, True, True)]
+    one, grp = run(False, specs), run(True, specs)
+    for i, ((x, wt, b, r, k, act), a, bb) in enumerate(zip(specs, one, grp)):
+        ref = F.conv2d(x, wt, b, padding=k // 2)
+        ref = {conv.ACT_NONE: lambda t: t, conv.ACT_LRELU: O.actvn, conv.ACT_TANH: torch.tanh}[act](ref)
+        if r is not None:
+            ref = ref + r
+        assert_close('group conv %d vs torch' % i, bb, ref)
+        assert float((a.cpu() - bb.cpu()).abs().max()) == 0.0, 'grouped launch differs from the single launch (problem %d)' % i
+    for tile in (0, 1, 2, 9):               # every tile shape of the grouped kernel (the plan picked 64x64 above)
+        for i, (a, bb) in enumerate(zip(one, run(True, specs[:6], tile))):
+            assert float((a.cpu() - bb.cpu()).abs().max()) == 0.0, 'grouped launch, tile %d, problem %d' % (tile, i)
+        for i, (a, bb) in enumerate(zip(run(False, specs_s0), run(True, specs_s0, tile))):
+            assert float((a.cpu() - bb.cpu()).abs().max()) == 0.0, 'scalar-gather group, tile %d, problem %d' % (tile, i)
+    # scalar-gather group (Cin % 4 != 0 in one problem sends the whole group to the v1 kernel)
+    specs_s = [problem(2, 6, 6, 5, 20, 3, conv.ACT_LRELU, False, True), problem(1, 16, 4, 9, 33, 1, conv.ACT_NONE, True, True)]
+    one, grp = run(False, specs_s), run(True, specs_s)
+    for i, (a, bb) in enumerate(zip(one, grp)):
+        assert float((a.cpu() - bb.cpu()).abs().max()) == 0.0, 'scalar-gather group differs (problem %d)' % i
+    # stride-2 data gradient: four parity classes in one launch, plain stores and (small maps, long K) K-split atomics
+    for (n, cin, h, w, cout, k, p) in ((2, 16, 12, 10, 32, 3, 1), (1, 8, 9, 9, 24, 4, 2), (1, 128 * sc, 6, 6, 64, 3, 1)):
+        x = torch.randn(n, cin, h, w, generator=g, requires_grad=True)
+        wt = torch.randn(cout, cin, k, k, generator=g) * (1.0 / (cin * k * k) ** 0.5)
+        y = F.conv2d(x, wt, None, stride=2, padding=p)
+        dy = torch.randn(y.shape, generator=g)
+        y.backward(dy)
+        geom = conv.Geom(k, k, 2, p)
+        dx = conv.conv_dgrad(_dev(dy, device), _dev(wt, device), geom, (h, w))
+        assert_close('grouped stride-2 dgrad %s' % ((n, cin, h, w, cout, k),), dx, x.grad)
+    # the epilogue that multiplies by LeakyReLU'(aux): dgrad + act-backward of the layer below in one launch
+    for cin in (24, 18):                      # float4 and scalar gather
+        d = torch.randn(1, cin, 1, 70, generator=g)
+        wt = torch.randn(cin, 40, 1, 1, generator=g) * 0.2        # [Cout_fwd = cin of the dgrad GEMM][Cin_fwd]
+        ybelow = torch.randn(1, 40, 1, 70, generator=g)
+        geom = conv.Geom(1, 1, 1, 0)
+        wk, _, ldw = conv.prep_weight(_dev(wt, device), 1, geom)
+        got = conv.gather_gemm(_dev(d, device), wk, ldw, 40, 1, 70, [0], [0], 1, 1, act=ops.ACT_DLRELU,
+                               res=_dev(ybelow, device).contiguous(memory_format=torch.channels_last))
+        ref = torch.einsum('nchw,co->nohw', d, wt[:, :, 0, 0]) * torch.where(ybelow > 0, 1.0, 0.2)
+        assert_close('dgrad x leaky_relu\'(y) cin %d' % cin, got, ref)
+    # grouped weight gradients against the single launches and torch
+    class Arena:
+        def take(self, nfloats):
+            return torch.zeros(nfloats, dtype=torch.float32, device=device)
+    wspecs = [(1, 32, 1, 96, 64, 1), (1, 64, 1, 40 * sc, 130, 1), (2, 16, 7, 9, 72, 3), (1, 8, 1, 64, 66, 1)]
+
+    def wrun(grouped):
+        outs = []
+        with conv.launch_group(grouped):
+            for (n, cin, h, w, cout, k) in wspecs:
+                gg = torch.Generator().manual_seed(seed + cin + cout)
+                x = torch.randn(n, cin, h, w, generator=gg)
+                dy = torch.randn(n, cout, h, w, generator=gg)
+                geom = conv.Geom(k, k, 1, k // 2)
+                dwt = conv.conv_wgrad(_dev(x, device), _dev(dy, device), geom, (cout, cin, k, k), raw=True, arena=Arena())
+                outs.append((x, dy, geom, dwt, (cout, cin, k, k)))
+        return outs
+    for (x, dy, geom, dwt_s, shp), (_, _, _, dwt_g, _) in zip(wrun(False), wrun(True)):
+        xr = x.clone()
+        wr = torch.zeros(shp, requires_grad=True)
+        F.conv2d(xr, wr, None, padding=shp[-1] // 2).backward(dy)
+        kpad, ldw = -(-geom.ntaps * shp[1] // 32) * 32, -(-shp[0] // 32) * 32
+        got = conv.unprep_weight_grad(dwt_g.view(1, kpad, ldw), shp, geom)
+        assert_close('grouped wgrad %s' % (shp,), got, wr.grad, tol=2e-5)
+        one = conv.unprep_weight_grad(dwt_s.view(1, kpad, ldw), shp, geom)
+        assert_close('grouped wgrad vs single %s' % (shp,), got, one, tol=2e-6)

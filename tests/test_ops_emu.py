@@ -128,3 +128,7 @@ def test_avgpool3s2(emu_lib):
 def test_spade_with_folded_upsample(emu_lib, nmaps, generated, c, ch):
     """x at half resolution, read through the nearest x2 index; c = 12 takes the general (non-prepared) path"""
     oc.check_spade(DEV, nmaps=nmaps, generated=generated, c=c, ch=ch, h=12, w=10, up=True)
+
+
+def test_conv_groups(emu_lib):
+    oc.check_conv_groups(DEV)

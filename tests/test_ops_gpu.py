@@ -157,3 +157,7 @@ def test_avgpool3s2(hip_lib):
 def test_spade_with_folded_upsample(hip_lib, nmaps, generated, c, ch):
     """x at half resolution, read through the nearest x2 index; c = 12 takes the general (non-prepared) path"""
     oc.check_spade(torch.device('cuda:0'), nmaps=nmaps, generated=generated, c=c, ch=ch, h=12, w=10, up=True)
+
+
+def test_conv_groups(hip_lib):
+    oc.check_conv_groups(dev(), big=True)
