@@ -404,7 +404,7 @@ def conv_dgrad(dout, w, geom, in_hw, scale=None, per_sample=False, cached=None, 
                   for c, (sh, sw) in live]
         bm, bn = _TILE_DIMS[group_planned(shapes)]
         wgs = sum(-(-m // bm) * -(-co // bn) * z for m, co, _, z in shapes)
-        plain = plain and not (wgs < 256 and max(k for _, _, k, _ in shapes) >= 16)
+        plain = plain and not (wgs <= 384 and max(k for _, _, k, _ in shapes) >= 16)
     elif plain:
         for c, (sh, sw) in zip(geom.dgrad_classes, subs):
             mz = sh * sw if per_sample else n * sh * sw

@@ -1489,8 +1489,10 @@ int fsv_conv_gather_group(const fsv_conv_desc* d, int n, int force_tile, hipStre
   // K splits: only problems that accumulate into a zeroed output, and only when the whole group would leave CUs idle
   long long wgs1 = 0;
   for (int i = 0; i < n; ++i) wgs1 += (long long)fsv_cdiv(ps[i].Mz, bm) * fsv_cdiv(ps[i].Cout, bn) * nsamp[i];
+  // (in-box, round 3: the parity classes of a 16x16 / 32x32 stride-2 data gradient as 256 unsplit tiles of up to 128 chunks
+  // took 188 us - as long as the four split launches they replaced)
   int want = 1;
-  if (wgs1 < 256) { want = (int)(512 / (wgs1 > 0 ? wgs1 : 1)); if (want > 8) want = 8; if (want < 1) want = 1; }
+  if (wgs1 <= 384) { want = (int)((768 + wgs1 - 1) / (wgs1 > 0 ? wgs1 : 1)); if (want > 8) want = 8; if (want < 1) want = 1; }
   for (int i = 0; i < n; ++i) {
     int sp = 1;
     if (d[i].accumulate && want > 1) {

@@ -18,23 +18,24 @@
 #define FSV_SP_BK 32
 #define FSV_SP_MAXMAPS 3
 
+#define FSV_SP_SITES 2
 struct SpadeP {
   const float* x;         // [N][HW][C]
   const float* mean;      // [C] (or [N][C] when stat_bstride != 0)
   const float* rstd;
-  float* h;               // [N][HW][C]
+  float* h[FSV_SP_SITES]; // [N][HW][C] per norm site
   const float* map[FSV_SP_MAXMAPS];    // [N][HW][Ch_k]
-  const float* wg[FSV_SP_MAXMAPS];     // K-major [Kpad_k][ldw] (+ z * w_bstride_k)
-  const float* wb[FSV_SP_MAXMAPS];
-  const float* bg[FSV_SP_MAXMAPS];     // [C] (+ z * b_bstride_k)
-  const float* bb[FSV_SP_MAXMAPS];
+  const float* wg[FSV_SP_SITES][FSV_SP_MAXMAPS];     // K-major [Kpad_k][ldw] (+ z * w_bstride_k)
+  const float* wb[FSV_SP_SITES][FSV_SP_MAXMAPS];
+  const float* bg[FSV_SP_SITES][FSV_SP_MAXMAPS];     // [C] (+ z * b_bstride_k)
+  const float* bb[FSV_SP_SITES][FSV_SP_MAXMAPS];
   int ch[FSV_SP_MAXMAPS];
-  long long w_bstride[FSV_SP_MAXMAPS];
-  long long b_bstride[FSV_SP_MAXMAPS];
+  long long w_bstride[FSV_SP_SITES][FSV_SP_MAXMAPS];
+  long long b_bstride[FSV_SP_SITES][FSV_SP_MAXMAPS];
   int nmaps;
   int N, HW, C, ldw;
   long long stat_bstride;
-  int act;
+  int act[FSV_SP_SITES];
   // backward twin (BWD = true): upstream gradient in, d(gamma|beta) per map ([P][2C]: gamma columns [0, C), beta [C, 2C)) and
   // d(xhat) out; h is not written
   const float* dh;
@@ -51,158 +52,312 @@ __device__ __forceinline__ long long fsv_sp_xpix(const SpadeP& p, int z, int m) 
   return (long long)z * (p.HW >> 2) + (long long)(y >> 1) * (p.W >> 1) + (xx >> 1);
 }
 
+// NS norm sites per launch (NS = 2: bn_0 and bn_s of one SPADEResnetBlock, architecture.py:95-96,103 - the same x, the same
+// statistics, the same maps, their own gamma / beta weights and activation: x, the statistics and the label-map tiles are read
+// once for both, the map tile in LDS feeds four GEMMs instead of two).
 // BWD = true is the backward twin: the same two GEMMs recompute gamma / beta of every map in registers (they never reach HBM
 // in either direction), the forward chain o_0 = xhat, o_{k+1} = o_k (1 + g_k) + b_k is replayed keeping g_k and o_k, and the
 // epilogue walks it backwards:  d = dh * act'(o_n);  for k = n-1 .. 0:  dbeta_k = d,  dgamma_k = d * o_k,  d *= (1 + g_k);
 // dxhat = d.  (Round 1 materialised gamma | beta as [P][2C] per map with the gather-GEMM kernel and read them back in an
 // element-wise pass: 236 MB read + 175 MB written per launch more than this.)
-template <int BM, int BN, int WM, int WN, bool BWD>
-__global__ __launch_bounds__(256) void fsv_spade_mod_kernel(SpadeP p) {
+//
+// Main loop (round 3: the structure of the gather-GEMM kernel, conv_igemm.hip).  The K chunks of ALL maps form one sequence
+// (the full-resolution levels have one or two 32-wide chunks per map: a per-map loop never gets a pipeline going): the loads of
+// chunk t + 1 - label-map rows and the gamma / beta weight rows of every site, through buffer descriptors with hardware zero
+// fill for rows / columns that do not exist - are issued at the top of chunk t and stored into the OTHER LDS buffer behind its
+// MFMAs (one barrier per chunk).  A image [BM rows][8 quads], quad q of row r in slot q ^ ((r >> 1) & 7): ds_write_b128 /
+// ds_read_b128 (two reads feed the four k steps of a k-group), B images [32 k][BN] as they lie in HBM.  The modulation of a
+// map (registers only) runs when its last chunk has been multiplied.
+template <int BM, int BN, int WM, int WN, int NS, bool BWD>
+__global__ __launch_bounds__(256, 2) void fsv_spade_mod_kernel(SpadeP p) {
   constexpr int BK = FSV_SP_BK;
   constexpr int TM = BM / (WM * 32), TN = BN / (WN * 32);
-  constexpr int LDA = BM + 1;
-  constexpr int KV = BK / 4, RPP = 256 / KV, NPA = BM / RPP;
+  constexpr int RPA = 256 / 8, NPA = BM / RPA;          // A: 8 work-items per row (one quad of 4 k each)
   constexpr int QB = BN / 4, RPB = 256 / QB, NPB = BK / RPB;
+  constexpr int NB = NS * 2;                            // B images per chunk: (site, gamma | beta)
+  constexpr int A_ST = BM * BK, B_ST = BK * BN;
   static_assert(WM * WN == 4, "4 waves");
-  static_assert(NPA >= 1 && NPB >= 1, "tile");
-  __shared__ float As[BK * LDA];
-  __shared__ float Bg[BK * BN];
-  __shared__ float Bb[BK * BN];
+  static_assert(NPA >= 1 && NPB >= 1 && NPA * RPA == BM && NPB * RPB == BK, "tile");
+  static_assert(!BWD || NS == 1, "the backward twin handles one site");
+  __shared__ __attribute__((aligned(16))) float smem[2 * (A_ST + NB * B_ST)];
+  float* const As = smem;
+  float* const Bs = smem + 2 * A_ST;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
   const int z = blockIdx.z;
   const int bm0 = blockIdx.x * BM, bn0 = blockIdx.y * BN;
   const int lrow = lane & 31, lk = lane >> 5;
-  const int kq = tid % KV, ar0 = tid / KV;
+  const int kq = tid & 7, ar0 = tid >> 3;
   const int bq = tid % QB, br0 = tid / QB;
   const int bcol = bn0 + bq * 4;
-  const bool bcol_ok = bcol < p.ldw;
-  const int bcol_safe = bcol_ok ? bcol : 0;
-
-  // running value of the normalised + modulated activation, in MFMA C/D layout
-  f32x16 outv[TM][TN];
-  // backward twin: g_k and o_k of every map (BWD only; dead code otherwise)
-  f32x16 keep_g[BWD ? FSV_SP_MAXMAPS : 1][TM][TN], keep_o[BWD ? FSV_SP_MAXMAPS : 1][TM][TN];
-  const float* mean = p.mean + z * p.stat_bstride;
-  const float* rstd = p.rstd + z * p.stat_bstride;
+  const bool bcol_ok = bcol < p.C;        // columns >= C only feed output channels that are never stored
   const long long pix0 = (long long)z * p.HW;
-#pragma unroll
-  for (int j = 0; j < TN; ++j) {
-    const int c = bn0 + wn * (TN * 32) + j * 32 + lrow;
-    const bool cok = c < p.C;
-    const float mu = cok ? mean[c] : 0.f, rs = cok ? rstd[c] : 0.f;
+
+  // ---- x (raw) into registers first: consumed by the first modulation, i.e. behind the first map's MFMAs ----------------------
+  // A lane's 16 rows are four runs of four consecutive pixels (D layout: row = (r & 3) + 8 * (r >> 2) + 4 * lk) that start at a
+  // multiple of 4: with W % 4 == 0 a run lies in one image row, so the up-sampling index costs one division per run.
+  float xv[TM][TN][16];
+  float mu[TN], rs[TN];
+  {
+    const float* mean = p.mean + z * p.stat_bstride;
+    const float* rstd = p.rstd + z * p.stat_bstride;
+    const long long xpix_n = p.up ? (p.HW >> 2) : p.HW;
+    const fsv_buf xbuf = fsv_make_buf(p.x + (long long)z * xpix_n * p.C, xpix_n * p.C * 4);
+    const bool runs = (p.W & 3) == 0;
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = (r & 3) + 8 * (r >> 2) + 4 * lk;
-        const int m = bm0 + wm * (TM * 32) + i * 32 + row;
-        float v = 0.f;
-        if (cok && m < p.HW) v = (p.x[fsv_sp_xpix(p, z, m) * p.C + c] - mu) * rs;
-        outv[i][j][r] = v;
+      for (int q = 0; q < 4; ++q) {
+        const int m0 = bm0 + wm * (TM * 32) + i * 32 + 8 * q + 4 * lk;
+        int src[4];
+        if (!p.up) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) src[e] = m0 + e;
+        } else if (runs) {
+          const int y = m0 / p.W, xx = m0 - y * p.W;
+          const int b = (y >> 1) * (p.W >> 1) + (xx >> 1);
+          src[0] = b; src[1] = b; src[2] = b + 1; src[3] = b + 1;
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int y = (m0 + e) / p.W, xx = (m0 + e) - y * p.W;
+            src[e] = (y >> 1) * (p.W >> 1) + (xx >> 1);
+          }
+        }
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          const int c = bn0 + wn * (TN * 32) + j * 32 + lrow;
+          const bool cok = c < p.C;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const bool ok = cok & (m0 + e < p.HW);
+            xv[i][j][4 * q + e] = fsv_buf_load1(xbuf, ok ? (unsigned)((src[e] * p.C + c) * 4) : FSV_BUF_OOB);
+          }
+        }
       }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int c = bn0 + wn * (TN * 32) + j * 32 + lrow;
+      const bool cok = c < p.C;
+      mu[j] = cok ? mean[c] : 0.f; rs[j] = cok ? rstd[c] : 0.f;
+    }
   }
 
+  // ---- the flat chunk sequence -------------------------------------------------------------------------------------------------
+  int nch[FSV_SP_MAXMAPS], total = 0;
 #pragma unroll
-  for (int k = 0; k < FSV_SP_MAXMAPS; ++k) {
-    if (k >= p.nmaps) break;
-    const float* mp = p.map[k] + pix0 * p.ch[k];
-    const float* wg = p.wg[k] + z * p.w_bstride[k];
-    const float* wb = p.wb[k] + z * p.w_bstride[k];
+  for (int k = 0; k < FSV_SP_MAXMAPS; ++k) { nch[k] = (k < p.nmaps) ? (p.ch[k] + BK - 1) / BK : 0; total += nch[k]; }
+  // loader state: (map lk_, chunk lc_) of the NEXT chunk to load
+  int ld_k = 0, ld_c = 0;
+  float4 areg[NPA], breg[NB][NPB];
+  auto issue_loads = [&]() {
+    // uniform: descriptors of the loader's current map
+    const int k = ld_k < p.nmaps ? ld_k : 0;
     const int Ch = p.ch[k];
-    const int nchunks = (Ch + BK - 1) / BK;
-    f32x16 accg[TM][TN], accb[TM][TN];
+    const fsv_buf abuf = fsv_make_buf(p.map[k] + pix0 * Ch, (long long)p.HW * Ch * 4);
+    const int kk = ld_c * BK + kq * 4;
+    const bool live = ld_k < p.nmaps;
+#pragma unroll
+    for (int i = 0; i < NPA; ++i) {
+      const int m = bm0 + ar0 + i * RPA;
+      const bool ok = live & (kk < Ch) & (m < p.HW);
+      areg[i] = fsv_buf_load4(abuf, ok ? (unsigned)((m * Ch + kk) * 4) : FSV_BUF_OOB);
+    }
+    const long long wbytes = (long long)((Ch + BK - 1) / BK) * BK * p.ldw * 4;
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+      const fsv_buf gbuf = fsv_make_buf(p.wg[s][k] + z * p.w_bstride[s][k], wbytes);
+      const fsv_buf bbuf = fsv_make_buf(p.wb[s][k] + z * p.w_bstride[s][k], wbytes);
+#pragma unroll
+      for (int i = 0; i < NPB; ++i) {
+        const int kr = ld_c * BK + br0 + i * RPB;
+        const unsigned off = (live & bcol_ok) ? (unsigned)((kr * p.ldw + bcol) * 4) : FSV_BUF_OOB;
+        breg[2 * s][i] = fsv_buf_load4(gbuf, off);
+        breg[2 * s + 1][i] = fsv_buf_load4(bbuf, off);
+      }
+    }
+    // advance to the chunk after this one
+    ++ld_c;
+    if (ld_k < p.nmaps && ld_c >= nch[ld_k]) { ld_c = 0; ++ld_k; }
+  };
+  auto store_chunk = [&](int buf) {
+    float* a_dst = As + buf * A_ST;
+    float* b_dst = Bs + buf * (NB * B_ST);
+#pragma unroll
+    for (int i = 0; i < NPA; ++i) {
+      const int r = ar0 + i * RPA;
+      *reinterpret_cast<float4*>(&a_dst[r * BK + ((kq ^ ((r >> 1) & 7)) << 2)]) = areg[i];
+    }
+#pragma unroll
+    for (int q = 0; q < NB; ++q)
+#pragma unroll
+      for (int i = 0; i < NPB; ++i)
+        *reinterpret_cast<float4*>(&b_dst[q * B_ST + (br0 + i * RPB) * BN + bq * 4]) = breg[q][i];
+  };
+
+  // running value of the normalised + modulated activation per site, in MFMA C/D layout
+  f32x16 outv[NS][TM][TN];
+  // backward twin: g_k and o_k of every map (BWD only; dead code otherwise)
+  f32x16 keep_g[BWD ? FSV_SP_MAXMAPS : 1][TM][TN], keep_o[BWD ? FSV_SP_MAXMAPS : 1][TM][TN];
+  f32x16 acc[NB][TM][TN];
+#pragma unroll
+  for (int q = 0; q < NB; ++q)
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
       for (int j = 0; j < TN; ++j)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { accg[i][j][r] = 0.f; accb[i][j][r] = 0.f; }
+        for (int r = 0; r < 16; ++r) acc[q][i][j][r] = 0.f;
 
-    float4 areg[NPA], gbreg[NPB], bbreg[NPB];
-    auto load_chunk = [&](int kc) {
-      const int kk = kc * BK + kq * 4;
+  int a_off[TM], a_swz[TM];
 #pragma unroll
-      for (int i = 0; i < NPA; ++i) {
-        int m = bm0 + ar0 + i * RPP;
-        bool ok = kk < Ch && m < p.HW;
-        float4 v = *reinterpret_cast<const float4*>(mp + (ok ? ((long long)m * Ch + kk) : 0ll));
-        areg[i] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int i = 0; i < TM; ++i) {
+    const int r = wm * (TM * 32) + i * 32 + lrow;
+    a_off[i] = r * BK;
+    a_swz[i] = (r >> 1) & 7;
+  }
+  const int b_off = lk * BN + wn * (TN * 32) + lrow;
+
+  // fragments of one k-group (8 k): two quads of A per row tile, four B values per (image, column tile); read one group ahead
+  // of their MFMAs and pinned there with scheduling fences (conv_igemm.hip)
+  auto read_group = [&](const float* a_src, const float* b_src, int g, float4 (&a4)[2][TM], float (&b)[4][NB][TN]) {
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+        a4[q][i] = *reinterpret_cast<const float4*>(&a_src[a_off[i] + (((2 * g + q) ^ a_swz[i]) << 2)]);
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4)
+#pragma unroll
+      for (int q = 0; q < NB; ++q)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) b[s4][q][j] = b_src[q * B_ST + b_off + (8 * g + 2 * s4) * BN + j * 32];
+  };
+  auto mma_group = [&](const float4 (&a4)[2][TM], const float (&b)[4][NB][TN]) {
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4)
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        const float4 v = a4[s4 >> 1][i];
+        const float a = (s4 & 1) ? (lk ? v.w : v.z) : (lk ? v.y : v.x);
+#pragma unroll
+        for (int q = 0; q < NB; ++q)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            acc[q][i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b[s4][q][j], acc[q][i][j], 0, 0, 0);
       }
+  };
+
+  // modulation of map k: every site folds its gamma / beta accumulators into its running value and clears them
+  auto modulate = [&](int k, bool first) {
 #pragma unroll
-      for (int i = 0; i < NPB; ++i) {
-        int kr = kc * BK + br0 + i * RPB;
-        float4 vg = *reinterpret_cast<const float4*>(wg + (long long)kr * p.ldw + bcol_safe);
-        float4 vb = *reinterpret_cast<const float4*>(wb + (long long)kr * p.ldw + bcol_safe);
-        gbreg[i] = bcol_ok ? vg : make_float4(0.f, 0.f, 0.f, 0.f);
-        bbreg[i] = bcol_ok ? vb : make_float4(0.f, 0.f, 0.f, 0.f);
-      }
-    };
-    auto store_chunk = [&]() {
+    for (int s = 0; s < NS; ++s) {
+      const float* bg = p.bg[s][k] + z * p.b_bstride[s][k];
+      const float* bb = p.bb[s][k] + z * p.b_bstride[s][k];
 #pragma unroll
-      for (int i = 0; i < NPA; ++i) {
-        int r = ar0 + i * RPP;
-        As[(kq * 4 + 0) * LDA + r] = areg[i].x;
-        As[(kq * 4 + 1) * LDA + r] = areg[i].y;
-        As[(kq * 4 + 2) * LDA + r] = areg[i].z;
-        As[(kq * 4 + 3) * LDA + r] = areg[i].w;
-      }
-#pragma unroll
-      for (int i = 0; i < NPB; ++i) {
-        int kr = br0 + i * RPB;
-        *reinterpret_cast<float4*>(&Bg[kr * BN + bq * 4]) = gbreg[i];
-        *reinterpret_cast<float4*>(&Bb[kr * BN + bq * 4]) = bbreg[i];
-      }
-    };
-    __syncthreads();            // previous map's LDS reads are finished
-    load_chunk(0);
-    store_chunk();
-    __syncthreads();
-#pragma unroll 1
-    for (int kc = 0; kc < nchunks; ++kc) {
-      const int knext = (kc + 1 < nchunks) ? kc + 1 : kc;
-      load_chunk(knext);
-#pragma unroll
-      for (int kk = 0; kk < BK / 2; ++kk) {
-        float a[TM], g[TN], b[TN];
-#pragma unroll
-        for (int i = 0; i < TM; ++i) a[i] = As[(kk * 2 + lk) * LDA + wm * (TM * 32) + i * 32 + lrow];
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-          g[j] = Bg[(kk * 2 + lk) * BN + wn * (TN * 32) + j * 32 + lrow];
-          b[j] = Bb[(kk * 2 + lk) * BN + wn * (TN * 32) + j * 32 + lrow];
-        }
+      for (int j = 0; j < TN; ++j) {
+        const int c = bn0 + wn * (TN * 32) + j * 32 + lrow;
+        const float bgv = (c < p.C) ? bg[c] : 0.f, bbv = (c < p.C) ? bb[c] : 0.f;
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
-          for (int j = 0; j < TN; ++j) {
-            accg[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], g[j], accg[i][j], 0, 0, 0);
-            accb[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], accb[i][j], 0, 0, 0);
+          for (int r = 0; r < 16; ++r) {
+            const float o = first ? (xv[i][j][r] - mu[j]) * rs[j] : outv[s][i][j][r];
+            const float gk = acc[2 * s][i][j][r] + bgv;
+            if constexpr (BWD) { keep_g[k][i][j][r] = gk; keep_o[k][i][j][r] = o; }
+            outv[s][i][j][r] = o * (1.f + gk) + (acc[2 * s + 1][i][j][r] + bbv);
+            acc[2 * s][i][j][r] = 0.f; acc[2 * s + 1][i][j][r] = 0.f;
           }
       }
-      __syncthreads();
-      store_chunk();
-      __syncthreads();
     }
-    // modulation epilogue for this map
-    const float* bg = p.bg[k] + z * p.b_bstride[k];
-    const float* bb = p.bb[k] + z * p.b_bstride[k];
+  };
+
+  // The backward twin normalises x up front (its 96 registers of g_k / o_k leave no room to carry the raw values through the
+  // loop); the forward forms leave x in flight until the first modulation.
+  constexpr bool XFIRST = true;
+  if constexpr (!XFIRST) {
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-      const int c = bn0 + wn * (TN * 32) + j * 32 + lrow;
-      const float bgv = (c < p.C) ? bg[c] : 0.f, bbv = (c < p.C) ? bb[c] : 0.f;
+    for (int j = 0; j < TN; ++j)
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const float gk = accg[i][j][r] + bgv;
-          if constexpr (BWD) { keep_g[k][i][j][r] = gk; keep_o[k][i][j][r] = outv[i][j][r]; }
-          outv[i][j][r] = outv[i][j][r] * (1.f + gk) + (accb[i][j][r] + bbv);
+        for (int r = 0; r < 16; ++r) outv[0][i][j][r] = (xv[i][j][r] - mu[j]) * rs[j];
+  }
+  if (total > 0) {
+    issue_loads();
+    store_chunk(0);
+    __syncthreads();
+    int buf = 0;
+    // one chunk: loads of the NEXT chunk of the flat sequence (whatever map it belongs to) at the top, MFMAs of this one,
+    // the loaded registers stored into the other LDS buffer behind three quarters of them
+    auto chunk = [&]() {
+      issue_loads();                      // past the end: every lane is out of range -> zeros, never used
+      const float* a_src = As + buf * A_ST;
+      const float* b_src = Bs + buf * (NB * B_ST);
+      if constexpr (NS == 1 && !BWD) {
+        // fragments one k-group ahead of their MFMAs (two register sets)
+        float4 fa[2][2][TM];
+        float fb[2][4][NB][TN];
+        read_group(a_src, b_src, 0, fa[0], fb[0]);
+        FSV_SCHED_FENCE();
+        read_group(a_src, b_src, 1, fa[1], fb[1]);
+        FSV_SCHED_FENCE();
+        mma_group(fa[0], fb[0]);
+        FSV_SCHED_FENCE();
+        read_group(a_src, b_src, 2, fa[0], fb[0]);
+        FSV_SCHED_FENCE();
+        mma_group(fa[1], fb[1]);
+        FSV_SCHED_FENCE();
+        read_group(a_src, b_src, 3, fa[1], fb[1]);
+        FSV_SCHED_FENCE();
+        mma_group(fa[0], fb[0]);
+        FSV_SCHED_FENCE();
+        store_chunk(buf ^ 1);
+        FSV_SCHED_FENCE();
+        mma_group(fa[1], fb[1]);
+      } else {
+        // the two-site / backward forms carry 64 - 144 more live registers (four accumulators, or g_k / o_k of three maps):
+        // one fragment set, two workgroups per CU cover each other's LDS latency
+        float4 fa[2][TM];
+        float fb[4][NB][TN];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          read_group(a_src, b_src, g, fa, fb);
+          mma_group(fa, fb);
+          if (g == 2) { FSV_SCHED_FENCE(); store_chunk(buf ^ 1); FSV_SCHED_FENCE(); }
         }
+      }
+      __syncthreads();
+      buf ^= 1;
+    };
+    // per map: its chunks, then its modulation (registers only; the next map's first chunk is already in LDS)
+#pragma unroll
+    for (int k = 0; k < FSV_SP_MAXMAPS; ++k) {
+      if (k < p.nmaps) {
+#pragma unroll 1
+        for (int c = 0; c < nch[k]; ++c) chunk();
+        modulate(k, XFIRST && k == 0);
+      }
     }
+  } else if constexpr (XFIRST) {
+#pragma unroll
+    for (int s = 0; s < NS; ++s)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) outv[s][i][j][r] = (xv[i][j][r] - mu[j]) * rs[j];
   }
 
+  // epilogues: per-sample base pointers are uniform (scalar registers), the per-lane part is a 32-bit element offset (the host
+  // checked that one sample of every tensor stays below 2^31 bytes)
   if constexpr (BWD) {
+    const float* dh_z = p.dh + pix0 * p.C;
+    float* dx_z = p.dxhat + pix0 * p.C;
+    float* dg_z[FSV_SP_MAXMAPS];
+#pragma unroll
+    for (int k = 0; k < FSV_SP_MAXMAPS; ++k) dg_z[k] = (k < p.nmaps) ? p.dgb[k] + pix0 * 2 * p.C : nullptr;
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
       const int c = bn0 + wn * (TN * 32) + j * 32 + lrow;
@@ -214,36 +369,41 @@ __global__ __launch_bounds__(256) void fsv_spade_mod_kernel(SpadeP p) {
           const int row = (r & 3) + 8 * (r >> 2) + 4 * lk;
           const int m = bm0 + wm * (TM * 32) + i * 32 + row;
           if (m >= p.HW) continue;
-          const long long pix = pix0 + m;
-          float d = p.dh[pix * p.C + c];
-          if (p.act == FSV_ACT_LRELU) d = (outv[i][j][r] > 0.f) ? d : 0.2f * d;
+          const int e = m * p.C + c;
+          float d = dh_z[e];
+          if (p.act[0] == FSV_ACT_LRELU) d = (outv[0][i][j][r] > 0.f) ? d : 0.2f * d;
 #pragma unroll
           for (int k = FSV_SP_MAXMAPS - 1; k >= 0; --k) {
             if (k < p.nmaps) {
-              float* dg = p.dgb[k] + pix * 2 * p.C;
-              dg[p.C + c] = d;
-              dg[c] = d * keep_o[k][i][j][r];
+              float* dg = dg_z[k];
+              const int e2 = m * 2 * p.C + c;
+              dg[e2 + p.C] = d;
+              dg[e2] = d * keep_o[k][i][j][r];
               d = d * (1.f + keep_g[k][i][j][r]);
             }
           }
-          p.dxhat[pix * p.C + c] = d;
+          dx_z[e] = d;
         }
     }
     return;
   }
 
 #pragma unroll
-  for (int j = 0; j < TN; ++j) {
-    const int c = bn0 + wn * (TN * 32) + j * 32 + lrow;
-    if (c >= p.C) continue;
+  for (int s = 0; s < NS; ++s) {
+    float* h_z = p.h[s] + pix0 * p.C;
 #pragma unroll
-    for (int i = 0; i < TM; ++i)
+    for (int j = 0; j < TN; ++j) {
+      const int c = bn0 + wn * (TN * 32) + j * 32 + lrow;
+      if (c >= p.C) continue;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = (r & 3) + 8 * (r >> 2) + 4 * lk;
-        const int m = bm0 + wm * (TM * 32) + i * 32 + row;
-        if (m < p.HW) p.h[(pix0 + m) * p.C + c] = fsv_act(outv[i][j][r], p.act);
-      }
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = (r & 3) + 8 * (r >> 2) + 4 * lk;
+          const int m = bm0 + wm * (TM * 32) + i * 32 + row;
+          if (m < p.HW) h_z[m * p.C + c] = fsv_act(outv[s][i][j][r], p.act[s]);
+        }
+    }
   }
 }
 
@@ -354,31 +514,93 @@ int fsv_spade_prep(const float* wg, const float* wb, const float* bg, const floa
   return fsv_check_launch();
 }
 
+static inline int fsv_sp_fill_site(SpadeP& p, int s, int nmaps, const float* const* wg, const float* const* wb,
+                                   const float* const* bg, const float* const* bb, const long long* w_bstride,
+                                   const long long* b_bstride) {
+  for (int k = 0; k < FSV_SP_MAXMAPS; ++k) {
+    const bool on = k < nmaps;
+    p.wg[s][k] = on ? wg[k] : nullptr; p.wb[s][k] = on ? wb[k] : nullptr;
+    p.bg[s][k] = on ? bg[k] : nullptr; p.bb[s][k] = on ? bb[k] : nullptr;
+    p.w_bstride[s][k] = on ? w_bstride[k] : 0; p.b_bstride[s][k] = on ? b_bstride[k] : 0;
+    if (on && (!wg[k] || !wb[k] || !bg[k] || !bb[k])) return FSV_ERR_UNSUPPORTED;
+  }
+  return FSV_OK;
+}
+
+static inline int fsv_sp_fill_common(SpadeP& p, const float* x, const float* mean, const float* rstd, int nmaps,
+                                     const float* const* maps, const int* ch, int N, int HW, int C, int ldw,
+                                     long long stat_bstride, int W, int up) {
+  if (!x || !mean || !rstd || nmaps < 0 || nmaps > FSV_SP_MAXMAPS || C < 1 || (ldw & 3)) return FSV_ERR_BAD_ARG;
+  if (up && (W < 2 || (W & 1) || HW % W != 0 || ((HW / W) & 1))) return FSV_ERR_BAD_ARG;
+  // 32-bit byte offsets inside one sample of a map / inside x (buffer descriptors)
+  if ((long long)N * HW * C * 4 > FSV_BUF_MAX_BYTES || (long long)HW * 2 * C * 4 > FSV_BUF_MAX_BYTES) return FSV_ERR_UNSUPPORTED;
+  p.x = x; p.mean = mean; p.rstd = rstd; p.nmaps = nmaps;
+  for (int s = 0; s < FSV_SP_SITES; ++s) {
+    p.h[s] = nullptr; p.act[s] = FSV_ACT_NONE;
+    for (int k = 0; k < FSV_SP_MAXMAPS; ++k) {
+      p.wg[s][k] = p.wb[s][k] = p.bg[s][k] = p.bb[s][k] = nullptr;
+      p.w_bstride[s][k] = p.b_bstride[s][k] = 0;
+    }
+  }
+  for (int k = 0; k < FSV_SP_MAXMAPS; ++k) {
+    const bool on = k < nmaps;
+    p.map[k] = on ? maps[k] : nullptr; p.ch[k] = on ? ch[k] : 0; p.dgb[k] = nullptr;
+    if (on && ((ch[k] & 3) || !maps[k])) return FSV_ERR_UNSUPPORTED;
+    if (on && (long long)HW * ch[k] * 4 > FSV_BUF_MAX_BYTES) return FSV_ERR_UNSUPPORTED;
+  }
+  p.N = N; p.HW = HW; p.C = C; p.ldw = ldw; p.stat_bstride = stat_bstride;
+  p.W = up ? W : 1; p.up = up ? 1 : 0;
+  p.dh = nullptr; p.dxhat = nullptr;
+  return FSV_OK;
+}
+
 // maps/wg/wb/bg/bb: arrays of nmaps device pointers; ch / w_bstride / b_bstride: per-map ints / strides.
 int fsv_spade_mod_fwd(const float* x, const float* mean, const float* rstd, float* h,
                       int nmaps, const float* const* maps, const float* const* wg, const float* const* wb,
                       const float* const* bg, const float* const* bb, const int* ch, const long long* w_bstride,
                       const long long* b_bstride, int N, int HW, int C, int ldw, long long stat_bstride, int act,
                       int W, int up, hipStream_t stream) {
-  if (!x || !mean || !rstd || !h || nmaps < 0 || nmaps > FSV_SP_MAXMAPS || C < 1 || (ldw & 3)) return FSV_ERR_BAD_ARG;
-  if (up && (W < 2 || (W & 1) || HW % W != 0 || ((HW / W) & 1))) return FSV_ERR_BAD_ARG;
+  if (!h) return FSV_ERR_BAD_ARG;
   SpadeP p;
-  p.x = x; p.mean = mean; p.rstd = rstd; p.h = h; p.nmaps = nmaps;
-  for (int k = 0; k < FSV_SP_MAXMAPS; ++k) {
-    bool on = k < nmaps;
-    p.map[k] = on ? maps[k] : nullptr; p.wg[k] = on ? wg[k] : nullptr; p.wb[k] = on ? wb[k] : nullptr;
-    p.bg[k] = on ? bg[k] : nullptr; p.bb[k] = on ? bb[k] : nullptr;
-    p.ch[k] = on ? ch[k] : 0; p.w_bstride[k] = on ? w_bstride[k] : 0; p.b_bstride[k] = on ? b_bstride[k] : 0;
-    if (on && ((ch[k] & 3) || !maps[k] || !wg[k] || !wb[k] || !bg[k] || !bb[k])) return FSV_ERR_UNSUPPORTED;
-  }
-  p.N = N; p.HW = HW; p.C = C; p.ldw = ldw; p.stat_bstride = stat_bstride; p.act = act;
-  p.W = up ? W : 1; p.up = up ? 1 : 0;
+  int rc = fsv_sp_fill_common(p, x, mean, rstd, nmaps, maps, ch, N, HW, C, ldw, stat_bstride, W, up);
+  if (rc) return rc;
+  rc = fsv_sp_fill_site(p, 0, nmaps, wg, wb, bg, bb, w_bstride, b_bstride);
+  if (rc) return rc;
+  p.h[0] = h; p.act[0] = act;
   if (C <= 32) {
     dim3 g(fsv_cdiv(HW, 128), fsv_cdiv(C, 32), N);
-    FSV_LAUNCH((fsv_spade_mod_kernel<128, 32, 4, 1, false>), g, dim3(256), stream, p);
+    FSV_LAUNCH((fsv_spade_mod_kernel<128, 32, 4, 1, 1, false>), g, dim3(256), stream, p);
   } else {
-    dim3 g(fsv_cdiv(HW, 128), fsv_cdiv(C, 64), N);
-    FSV_LAUNCH((fsv_spade_mod_kernel<128, 64, 2, 2, false>), g, dim3(256), stream, p);
+    dim3 g(fsv_cdiv(HW, 64), fsv_cdiv(C, 64), N);
+    FSV_LAUNCH((fsv_spade_mod_kernel<64, 64, 2, 2, 1, false>), g, dim3(256), stream, p);
+  }
+  return fsv_check_launch();
+}
+
+// Two norm sites of one SPADEResnetBlock in ONE launch (architecture.py:95-96,103: bn_0 and bn_s normalise the same x with the
+// same statistics and read the same maps): h0 = act0(SPADE_0(x)), h1 = act1(SPADE_s(x)).  Arrays are [2 * nmaps]: site 0's
+// entries first.
+int fsv_spade_mod_fwd2(const float* x, const float* mean, const float* rstd, float* h0, float* h1,
+                       int nmaps, const float* const* maps, const float* const* wg, const float* const* wb,
+                       const float* const* bg, const float* const* bb, const int* ch, const long long* w_bstride,
+                       const long long* b_bstride, int N, int HW, int C, int ldw, long long stat_bstride, int act0, int act1,
+                       int W, int up, hipStream_t stream) {
+  if (!h0 || !h1 || nmaps < 1) return FSV_ERR_BAD_ARG;
+  SpadeP p;
+  int rc = fsv_sp_fill_common(p, x, mean, rstd, nmaps, maps, ch, N, HW, C, ldw, stat_bstride, W, up);
+  if (rc) return rc;
+  for (int s = 0; s < 2; ++s) {
+    rc = fsv_sp_fill_site(p, s, nmaps, wg + s * nmaps, wb + s * nmaps, bg + s * nmaps, bb + s * nmaps, w_bstride + s * nmaps,
+                          b_bstride + s * nmaps);
+    if (rc) return rc;
+  }
+  p.h[0] = h0; p.h[1] = h1; p.act[0] = act0; p.act[1] = act1;
+  if (C <= 32) {
+    dim3 g(fsv_cdiv(HW, 128), fsv_cdiv(C, 32), N);
+    FSV_LAUNCH((fsv_spade_mod_kernel<128, 32, 4, 1, 2, false>), g, dim3(256), stream, p);
+  } else {
+    dim3 g(fsv_cdiv(HW, 64), fsv_cdiv(C, 64), N);
+    FSV_LAUNCH((fsv_spade_mod_kernel<64, 64, 2, 2, 2, false>), g, dim3(256), stream, p);
   }
   return fsv_check_launch();
 }
@@ -389,24 +611,22 @@ int fsv_spade_mod_bwd(const float* x, const float* mean, const float* rstd, cons
                       const float* const* bg, const float* const* bb, const int* ch, const long long* w_bstride,
                       const long long* b_bstride, float* const* dgb, float* dxhat, int N, int HW, int C, int ldw,
                       long long stat_bstride, int act, int W, int up, hipStream_t stream) {
-  if (!x || !mean || !rstd || !dh || !dgb || !dxhat || nmaps < 0 || nmaps > FSV_SP_MAXMAPS || C < 1 || (ldw & 3)) return FSV_ERR_BAD_ARG;
+  if (!dh || !dgb || !dxhat) return FSV_ERR_BAD_ARG;
   if (act != FSV_ACT_LRELU && act != FSV_ACT_NONE) return FSV_ERR_UNSUPPORTED;
-  if (up && (W < 2 || (W & 1) || HW % W != 0 || ((HW / W) & 1))) return FSV_ERR_BAD_ARG;
   SpadeP p;
-  p.x = x; p.mean = mean; p.rstd = rstd; p.h = nullptr; p.nmaps = nmaps; p.dh = dh; p.dxhat = dxhat;
-  for (int k = 0; k < FSV_SP_MAXMAPS; ++k) {
-    bool on = k < nmaps;
-    p.map[k] = on ? maps[k] : nullptr; p.wg[k] = on ? wg[k] : nullptr; p.wb[k] = on ? wb[k] : nullptr;
-    p.bg[k] = on ? bg[k] : nullptr; p.bb[k] = on ? bb[k] : nullptr; p.dgb[k] = on ? dgb[k] : nullptr;
-    p.ch[k] = on ? ch[k] : 0; p.w_bstride[k] = on ? w_bstride[k] : 0; p.b_bstride[k] = on ? b_bstride[k] : 0;
-    if (on && ((ch[k] & 3) || !maps[k] || !wg[k] || !wb[k] || !bg[k] || !bb[k] || !dgb[k])) return FSV_ERR_UNSUPPORTED;
+  int rc = fsv_sp_fill_common(p, x, mean, rstd, nmaps, maps, ch, N, HW, C, ldw, stat_bstride, W, up);
+  if (rc) return rc;
+  rc = fsv_sp_fill_site(p, 0, nmaps, wg, wb, bg, bb, w_bstride, b_bstride);
+  if (rc) return rc;
+  p.dh = dh; p.dxhat = dxhat; p.act[0] = act;
+  for (int k = 0; k < nmaps; ++k) {
+    if (!dgb[k]) return FSV_ERR_UNSUPPORTED;
+    p.dgb[k] = dgb[k];
   }
-  p.N = N; p.HW = HW; p.C = C; p.ldw = ldw; p.stat_bstride = stat_bstride; p.act = act;
-  p.W = up ? W : 1; p.up = up ? 1 : 0;
   // 64 x 64 tiles: every wave keeps g_k and o_k of up to three maps for a 32 x 32 sub-tile (96 + 48 accumulator registers),
-  // which leaves room for several workgroups per CU - the kernel is HBM bound
+  // which leaves room for several workgroups per CU
   dim3 g(fsv_cdiv(HW, 64), fsv_cdiv(C, 64), N);
-  FSV_LAUNCH((fsv_spade_mod_kernel<64, 64, 2, 2, true>), g, dim3(256), stream, p);
+  FSV_LAUNCH((fsv_spade_mod_kernel<64, 64, 2, 2, 1, true>), g, dim3(256), stream, p);
   return fsv_check_launch();
 }
 

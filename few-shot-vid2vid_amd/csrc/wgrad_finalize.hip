@@ -156,6 +156,65 @@ extern "C" int fsv_gather_add(const long long* table, int njobs, const int* tmap
   return fsv_check_launch();
 }
 
+// ---- grouped fixed-order sums: dst_j = src_j[0] + src_j[1] + ... (left to right) for up to 8 jobs of up to 4 terms ------------
+// (the data gradients of the weight-generator chains that share their input rows, ops._MlpBankFn: one grouped GEMM launch
+// writes every chain's term, this launch adds them in a fixed order - no atomics, no chain of dependent GEMM launches)
+struct SumJobs {
+  int njobs;
+  int blk_end[8];            // cumulative 1024-element blocks
+  int nsrc[8];
+  long long count[8];
+  float* dst[8];
+  const float* src[8][4];
+};
+
+__global__ __launch_bounds__(256) void fsv_sum_terms_kernel(SumJobs g) {
+  const int b = blockIdx.x;
+  int j = 0;
+  while (j + 1 < g.njobs && b >= g.blk_end[j]) ++j;
+  const long long i0 = (long long)(b - (j ? g.blk_end[j - 1] : 0)) * 1024 + threadIdx.x * 4;
+  const long long n = g.count[j];
+  if (i0 >= n) return;
+  const int ns = g.nsrc[j];
+  if (i0 + 4 <= n) {
+    float4 a = *reinterpret_cast<const float4*>(g.src[j][0] + i0);
+    for (int t = 1; t < ns; ++t) {
+      const float4 v = *reinterpret_cast<const float4*>(g.src[j][t] + i0);
+      a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+    }
+    *reinterpret_cast<float4*>(g.dst[j] + i0) = a;
+  } else {
+    for (long long i = i0; i < n; ++i) {
+      float a = g.src[j][0][i];
+      for (int t = 1; t < ns; ++t) a += g.src[j][t][i];
+      g.dst[j][i] = a;
+    }
+  }
+}
+
+// dst[j] / src[j * 4 + t]: device pointers (16-byte aligned), nsrc[j] in 1..4 terms, count[j] elements; njobs <= 8
+extern "C" int fsv_sum_terms(float* const* dst, const float* const* src, const int* nsrc, const long long* count, int njobs,
+                             hipStream_t stream) {
+  if (!dst || !src || !nsrc || !count || njobs < 1 || njobs > 8) return FSV_ERR_BAD_ARG;
+  SumJobs g;
+  g.njobs = njobs;
+  int blocks = 0;
+  for (int j = 0; j < 8; ++j) {
+    const int k = j < njobs ? j : 0;
+    if (nsrc[k] < 1 || nsrc[k] > 4 || count[k] < 1 || !dst[k]) return FSV_ERR_BAD_ARG;
+    g.nsrc[j] = nsrc[k]; g.count[j] = count[k]; g.dst[j] = dst[k];
+    for (int t = 0; t < 4; ++t) {
+      g.src[j][t] = src[k * 4 + (t < nsrc[k] ? t : 0)];
+      if (!g.src[j][t] || ((uintptr_t)g.src[j][t] & 15)) return FSV_ERR_BAD_ARG;
+    }
+    if ((uintptr_t)g.dst[j] & 15) return FSV_ERR_BAD_ARG;
+    if (j < njobs) blocks += (int)((count[k] + 1023) / 1024);
+    g.blk_end[j] = blocks;
+  }
+  FSV_LAUNCH(fsv_sum_terms_kernel, dim3(blocks), dim3(256), stream, g);
+  return fsv_check_launch();
+}
+
 extern "C" int fsv_wgrad_finalize(const long long* ptrs, const int* dims, const unsigned long long* taps, double* dots,
                                   int njobs, const int* tmap_dot, int nblk_dot, const int* tmap_apply, int nblk_apply,
                                   hipStream_t stream) {

@@ -223,8 +223,16 @@ class SPADEResnetBlock(nn.Module):
         if up and not fold:
             x = ops.upsample2x(x)
         if self.spade:
-            x_s = self.conv_s(self.bn_s(x, label, nw[2], act=ACT_NONE, up=fold)) if self.learned_shortcut else x
-            dx = self.conv_0(self.bn_0(x, label, nw[0], act=ACT_LRELU, up=fold))
+            if self.learned_shortcut:
+                # bn_s and bn_0 normalise the same x with the same maps: one two-site launch (ops.spade_pair)
+                with ops.spade_pair():
+                    hs = self.bn_s(x, label, nw[2], act=ACT_NONE, up=fold)
+                    h0 = self.bn_0(x, label, nw[0], act=ACT_LRELU, up=fold)
+                x_s = self.conv_s(hs)
+            else:
+                x_s = x
+                h0 = self.bn_0(x, label, nw[0], act=ACT_LRELU, up=fold)
+            dx = self.conv_0(h0)
             return self.conv_1(self.bn_1(dx, label, nw[1], act=ACT_LRELU), res=x_s)
         x_s = self.conv_s(self.bn_s(x)) if self.learned_shortcut else x
         dx = self.conv_0(self.bn_0(x, act=ACT_LRELU))

@@ -42,6 +42,8 @@ lib.register_sigs({
     "fsv_spade_prep": [c_p, c_p, c_p, c_p, c_ll, c_ll, c_ll, c_ll, c_p, c_p, c_p, c_i, c_i, c_i, c_p],
     "fsv_spade_mod_fwd": [c_p, c_p, c_p, c_p, c_i, c_pp, c_pp, c_pp, c_pp, c_pp, c_ip, c_llp, c_llp,
                           c_i, c_i, c_i, c_i, c_ll, c_i, c_i, c_i, c_p],
+    "fsv_spade_mod_fwd2": [c_p, c_p, c_p, c_p, c_p, c_i, c_pp, c_pp, c_pp, c_pp, c_pp, c_ip, c_llp, c_llp,
+                           c_i, c_i, c_i, c_i, c_ll, c_i, c_i, c_i, c_i, c_p],
     "fsv_spade_bwd_elem": [c_p, c_p, c_p, c_p, c_p, c_i, c_pp, c_pp, c_p, c_i, c_i, c_i, c_ll, c_i, c_i, c_i, c_p],
     "fsv_spade_mod_bwd": [c_p, c_p, c_p, c_p, c_i, c_pp, c_pp, c_pp, c_pp, c_pp, c_ip, c_llp, c_llp, c_pp, c_p,
                           c_i, c_i, c_i, c_i, c_ll, c_i, c_i, c_i, c_p],
@@ -540,22 +542,21 @@ class _MlpBankFn(torch.autograd.Function):
                 for c in live:
                     d[c] = nxt[c]
             else:
-                by_level = {}
-                for c in live:
-                    by_level.setdefault(chains[c][0], []).append(c)
-                pos = 0
-                while True:
-                    batch = [(lev, cs[pos]) for lev, cs in by_level.items() if pos < len(cs)]
-                    if not batch:
-                        break
-                    with launch_group():
-                        for lev, c in batch:
-                            w, _ = wb[c][0]
-                            wt, ldw = entries[c][0].dgrad[0]
-                            sig = sns[c][0][0]
-                            drows[lev] = gather_gemm(d[c], wt, ldw, w.shape[1], 1, d[c].shape[3], cls0['ty'], cls0['tx'], 1, 1,
-                                                     res=drows[lev], wscale=sig[1:2])
-                    pos += 1
+                terms = {}
+                with launch_group():
+                    for c in live:
+                        w, _ = wb[c][0]
+                        wt, ldw = entries[c][0].dgrad[0]
+                        sig = sns[c][0][0]
+                        terms.setdefault(chains[c][0], []).append(
+                            gather_gemm(d[c], wt, ldw, w.shape[1], 1, d[c].shape[3], cls0['ty'], cls0['tx'], 1, 1,
+                                        wscale=sig[1:2]))
+                jobs = [(lev, ts) for lev, ts in sorted(terms.items()) if ctx.needs_input_grad[1 + lev]]
+                for lev, ts in jobs:
+                    drows[lev] = ts[0] if len(ts) == 1 else empty_nhwc(1, ts[0].shape[1], 1, ts[0].shape[3], ts[0])
+                multi = [(lev, ts) for lev, ts in jobs if len(ts) > 1]
+                for i in range(0, len(multi), 8):
+                    _sum_terms([(drows[lev], ts) for lev, ts in multi[i:i + 8]])
         outs = [None]
         for lev in range(nlev):
             g = drows[lev]
@@ -563,6 +564,24 @@ class _MlpBankFn(torch.autograd.Function):
                         else g.permute(0, 2, 3, 1).reshape(g.shape[3], g.shape[1]))
         outs += [None] * (len(ctx.needs_input_grad) - len(outs))
         return tuple(outs)
+
+
+def _sum_terms(jobs):
+    """jobs: [(dst, [src ...])] dense fp32 tensors of equal numel per job (at most 8 jobs, any number of terms): dst = sum of
+    its terms, left to right, in one launch per four terms (csrc/wgrad_finalize.hip fsv_sum_terms)"""
+    lib.register_sigs({"fsv_sum_terms": [c_p, c_p, c_p, c_p, c_i, c_p]})
+    while jobs:
+        dsts = (ctypes.c_void_p * len(jobs))(*[d.data_ptr() for d, _ in jobs])
+        srcs = (ctypes.c_void_p * (4 * len(jobs)))()
+        ns = []
+        for j, (d, ts) in enumerate(jobs):
+            take = ts[:4]
+            ns.append(len(take))
+            for t, src in enumerate(take):
+                srcs[4 * j + t] = src.data_ptr()
+        lib.check_device(*[d for d, _ in jobs])
+        lib.call("fsv_sum_terms", dsts, srcs, lib.int_array(ns), _ll([d.numel() for d, _ in jobs]), len(jobs), lib.stream_ptr())
+        jobs = [(d, [d] + ts[4:]) for d, ts in jobs if len(ts) > 4]
 
 
 def mlp_bank(rows, chains):
@@ -729,6 +748,52 @@ def norm_act(x, weight=None, bias=None, run_mean=None, run_var=None, instance=Fa
 
 
 # ------------------------------------------------------------------------------------------------ SPADE
+import threading as _threading
+_spade_tls = _threading.local()
+
+
+class spade_pair:
+    """`with spade_pair():` around the two SPADE sites of one SPADEResnetBlock that normalise the SAME tensor with the same
+    maps (bn_s and bn_0, architecture.py:95-96,103): the first site's modulation launch is held back and issued together with
+    the second one's as ONE two-site launch (csrc/spade.hip NS = 2: x, the statistics and the label-map tiles are read once).
+    Nobody may read the first site's output before the block ends.  Autograd is untouched (two nodes, two backward twins)."""
+
+    def __enter__(self):
+        self.pending = None
+        self.outer = getattr(_spade_tls, 'pair', None)
+        _spade_tls.pair = self if _os.environ.get('FSV_SPADE_PAIR', '1') == '1' else None
+        return self
+
+    def __exit__(self, et, ev, tb):
+        _spade_tls.pair = self.outer
+        if self.pending is not None and et is None:
+            site, self.pending = self.pending, None
+            _spade_launch(site)
+        return False
+
+
+def _spade_same_input(a, b):
+    return (a['x'].data_ptr() == b['x'].data_ptr() and a['dims'] == b['dims'] and a['chs'] == b['chs'] and
+            [m.data_ptr() for m in a['maps']] == [m.data_ptr() for m in b['maps']])
+
+
+def _spade_launch(a, b=None):
+    arr = lambda v: (ctypes.c_void_p * max(len(v), 1))(*v)
+    n, hw, c, ldw, w, up = a['dims']
+    chs = a['chs']
+    if b is None:
+        with profile.scope('fsv_spade_mod_kernel', a['flops']):
+            lib.call("fsv_spade_mod_fwd", lib.ptr(a['x']), lib.ptr(a['mean']), lib.ptr(a['rstd']), lib.ptr(a['h']), len(chs),
+                     _pp(a['maps']), arr(a['wg']), arr(a['wb']), arr(a['bg']), arr(a['bb']), lib.int_array(chs + [0]),
+                     _ll(a['wstr'] + [0]), _ll(a['bstr'] + [0]), n, hw, c, ldw, 0, a['act'], w, up, lib.stream_ptr())
+        return
+    with profile.scope('fsv_spade_mod_kernel', a['flops'] + b['flops']):
+        lib.call("fsv_spade_mod_fwd2", lib.ptr(a['x']), lib.ptr(a['mean']), lib.ptr(a['rstd']), lib.ptr(a['h']), lib.ptr(b['h']),
+                 len(chs), _pp(a['maps']), arr(a['wg'] + b['wg']), arr(a['wb'] + b['wb']), arr(a['bg'] + b['bg']),
+                 arr(a['bb'] + b['bb']), lib.int_array(chs + [0]), _ll(a['wstr'] + b['wstr'] + [0]),
+                 _ll(a['bstr'] + b['bstr'] + [0]), n, hw, c, ldw, 0, a['act'], b['act'], w, up, lib.stream_ptr())
+
+
 class _SpadeFn(torch.autograd.Function):
     """h = act(spade(x; maps, weights)).  Argument list: x, run_mean, run_var, then per map (map, wg, wb, bg, bb).
 
@@ -808,11 +873,21 @@ class _SpadeFn(torch.autograd.Function):
                 bg_p.append(bcat.data_ptr()); bb_p.append(bcat.data_ptr() + 4 * c)
                 wstr.append(kt * 2 * c if per_sample else 0)
                 bstr.append(2 * c if per_sample else 0)
-            arr = lambda v: (ctypes.c_void_p * max(len(v), 1))(*v)
-            with profile.scope('fsv_spade_mod_kernel', 2.0 * n * h * w * c * 2 * sum(chs)):
-                lib.call("fsv_spade_mod_fwd", lib.ptr(x), lib.ptr(mean), lib.ptr(rstd), lib.ptr(hout), nmaps, _pp(maps),
-                         arr(wg_p), arr(wb_p), arr(bg_p), arr(bb_p), lib.int_array(chs + [0]), _ll(wstr + [0]),
-                         _ll(bstr + [0]), n, h * w, c, ldw, 0, act, w, up, lib.stream_ptr())
+            site = dict(x=x, mean=mean, rstd=rstd, h=hout, maps=maps, wg=wg_p, wb=wb_p, bg=bg_p, bb=bb_p, chs=chs, wstr=wstr,
+                        bstr=bstr, dims=(n, h * w, c, ldw, w, up), act=act, keep=prepped,
+                        flops=2.0 * n * h * w * c * 2 * sum(chs))
+            pair = getattr(_spade_tls, 'pair', None)
+            if pair is None or nmaps == 0:
+                _spade_launch(site)
+            elif pair.pending is None:
+                pair.pending = site             # the partner site of this block issues both (spade_pair)
+            else:
+                first, pair.pending = pair.pending, None
+                if _spade_same_input(first, site):
+                    _spade_launch(first, site)
+                else:
+                    _spade_launch(first)
+                    _spade_launch(site)
             ctx.nmaps, ctx.act = nmaps, act
             ctx.batch_stats = bool(training or run_mean is None)
             ctx.world = bn_sync_world(1) if ctx.batch_stats else 1

@@ -141,6 +141,11 @@ int fsv_prep_weight(const float* w, float* wt, const float* scale_ptr, int mode,
  * channels for KH*KW <= 8, else 16); only the valid region of each (pre-zeroed) layout is written */
 int fsv_prep_weight_grouped(const long long* src, const long long* dst, const int* dims, const unsigned long long* taps,
                             const int* tmap, int nblocks, fsv_stream_t stream);
+/* grouped fixed-order sums: dst[j] = src[4 j] + src[4 j + 1] + ... (nsrc[j] in 1..4 terms, left to right) over count[j] floats,
+ * njobs <= 8, one launch; pointers 16-byte aligned.  Adds the data gradients of the weight-generator MLPs that share their input
+ * rows (generator.py:245-273: four FC stacks per level on the same encoded reference) without atomics. */
+int fsv_sum_terms(float* const* dst, const float* const* src, const int* nsrc, const long long* count, int njobs,
+                  fsv_stream_t stream);
 /* Deferred weight-gradient finalisation (csrc/wgrad_finalize.hip): njobs K-major weight gradients -> OIHW, added into
  * their parameter-gradient slices, with torch.nn.utils.spectral_norm's backward correction where sig != 0.
  * ptrs[job][6] = {dwt, K-major W, sink, u, v, sig}; dims[job][8] = {Cout, CinP, CinR, KH, KW, ntaps, ldw, flags};
@@ -174,6 +179,15 @@ int fsv_spade_mod_fwd(const float* x, const float* mean, const float* rstd, floa
                       const float* const* bg, const float* const* bb, const int* ch, const long long* w_bstride,
                       const long long* b_bstride, int N, int HW, int C, int ldw, long long stat_bstride, int act,
                       int W, int up, fsv_stream_t stream);
+/* Two norm sites of one SPADEResnetBlock in one launch - bn_0 and bn_s (architecture.py:95-96,103) normalise the same x
+ * with the same statistics and read the same maps; only the gamma / beta weights and the activation differ:
+ * h0 = act0(SPADE_0(x)), h1 = act1(SPADE_s(x)).  x, the statistics and the label-map tiles are read once, the map tile in LDS
+ * feeds four GEMMs.  wg / wb / bg / bb / w_bstride / b_bstride hold 2 * nmaps entries, site 0's first. */
+int fsv_spade_mod_fwd2(const float* x, const float* mean, const float* rstd, float* h0, float* h1,
+                       int nmaps, const float* const* maps, const float* const* wg, const float* const* wb,
+                       const float* const* bg, const float* const* bb, const int* ch, const long long* w_bstride,
+                       const long long* b_bstride, int N, int HW, int C, int ldw, long long stat_bstride, int act0, int act1,
+                       int W, int up, fsv_stream_t stream);
 /* backward twin of fsv_spade_mod_fwd: the same operands plus the upstream gradient dh; gamma / beta are recomputed in
  * registers, outputs are dgb[k] = d(gamma | beta) of every map ([P][2C], gamma in columns [0, C)) and dxhat [P][C] (per
  * full-resolution pixel also when up != 0).  act: FSV_ACT_NONE or FSV_ACT_LRELU. */

@@ -849,3 +849,52 @@ def check_conv_groups(device, seed=77, big=False):
         assert_close('grouped wgrad %s' % (shp,), got, wr.grad, tol=2e-5)
         one = conv.unprep_weight_grad(dwt_s.view(1, kpad, ldw), shp, geom)
         assert_close('grouped wgrad vs single %s' % (shp,), got, one, tol=2e-6)
+
+
+def check_spade_pair(device, n=2, c=64, chs=(16, 8, 8), h=10, w=12, up=True, seed=55):
+    """Two SPADE sites on the same x and maps (bn_s / bn_0 of a SPADEResnetBlock) through ops.spade_pair - ONE two-site launch -
+    against the same two sites launched one by one: outputs bit-equal (same arithmetic per element), gradients equal (the
+    backward passes are the single-site twins either way).  The single-site form is held to the oracle by check_spade."""
+    ops, conv = pkg()
+    g = torch.Generator().manual_seed(seed)
+    xs_h, xs_w = (h // 2, w // 2) if up else (h, w)
+    x = torch.randn(n, c, xs_h, xs_w, generator=g)
+    maps = [torch.randn(n, ch, h, w, generator=g) for ch in chs]
+
+    def site_weights(gen0):
+        ws = []
+        for k, ch in enumerate(chs):
+            if k == 0 and gen0:
+                ws.append((torch.randn(n, c, ch, 1, 1, generator=g) * 0.3, torch.randn(n, c, ch, 1, 1, generator=g) * 0.3,
+                           torch.randn(n, c, generator=g) * 0.3, torch.randn(n, c, generator=g) * 0.3))
+            else:
+                ws.append((torch.randn(c, ch, 1, 1, generator=g) * 0.3, torch.randn(c, ch, 1, 1, generator=g) * 0.3,
+                           torch.randn(c, generator=g) * 0.3, torch.randn(c, generator=g) * 0.3))
+        return ws
+    w_s, w_0 = site_weights(True), site_weights(True)
+    dy_s, dy_0 = torch.randn(n, c, h, w, generator=g), torch.randn(n, c, h, w, generator=g)
+
+    def run(paired):
+        # channels-last tensors, as between the layers of the network: both sites then see the SAME x / map buffers
+        cl = lambda t: _dev(t, device).contiguous(memory_format=torch.channels_last)
+        xd = cl(x).requires_grad_(True)
+        md = [cl(m).requires_grad_(True) for m in maps]
+        wd_s = [tuple(_dev(t, device).requires_grad_(True) for t in ws) for ws in w_s]
+        wd_0 = [tuple(_dev(t, device).requires_grad_(True) for t in ws) for ws in w_0]
+        rm = [_dev(torch.zeros(c), device) for _ in range(2)]
+        rv = [_dev(torch.ones(c), device) for _ in range(2)]
+        import contextlib
+        with (ops.spade_pair() if paired else contextlib.nullcontext()):
+            hs = ops.spade_mod(xd, md, wd_s, rm[0], rv[0], act=conv.ACT_NONE, up=up)
+            h0 = ops.spade_mod(xd, md, wd_0, rm[1], rv[1], act=conv.ACT_LRELU, up=up)
+        ((hs * _dev(dy_s, device)).sum() + (h0 * _dev(dy_0, device)).sum()).backward()
+        grads = [xd.grad] + [m.grad for m in md] + [t.grad for ws in wd_s + wd_0 for t in ws]
+        return hs.detach(), h0.detach(), grads, rm, rv
+    hs1, h01, g1, rm1, rv1 = run(False)
+    hs2, h02, g2, rm2, rv2 = run(True)
+    assert float((hs1.cpu() - hs2.cpu()).abs().max()) == 0.0 and float((h01.cpu() - h02.cpu()).abs().max()) == 0.0, \
+        'two-site launch differs from the single-site launches'
+    for i, (a, b) in enumerate(zip(g1, g2)):
+        assert_close('paired spade grad %d' % i, b, a, tol=1e-6)
+    for a, b in zip(rm1 + rv1, rm2 + rv2):
+        assert float((a.cpu() - b.cpu()).abs().max()) == 0.0

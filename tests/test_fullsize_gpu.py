@@ -54,7 +54,13 @@ def test_c3_pose_512_b2_full_step_is_the_bench_workload(hip_lib):
     finally:
         log = conv.stop_plan_log()
     assert worst < 1e-2, worst
+    groups = [e for e in log if e[0] == 'group']                      # ('group', tile, float4 gather, problems)
+    log = [e for e in log if e[0] != 'group']
     tiles = {t for t, _, v4 in log if v4}
     assert {0, 1, 2, 4, 9} <= tiles, sorted(tiles)                    # every tile of the plan is exercised by this step
     assert any(s > 1 for _, s, _ in log), "no split-K launch in the 512x512 step"
     assert any(not v4 for _, _, v4 in log), "no scalar-gather launch (3-channel / odd-channel inputs)"
+    # grouped launches: the weight-generator bank (16 problems, float4 and - the last layers' data gradients - scalar gather)
+    # and the stride-2 data gradients (4 parity classes)
+    assert any(n == 16 and v4 for _, _, v4, n in groups) and any(n == 16 and not v4 for _, _, v4, n in groups), groups[:8]
+    assert any(n == 4 for _, _, _, n in groups), groups[:8]

@@ -132,3 +132,8 @@ def test_spade_with_folded_upsample(emu_lib, nmaps, generated, c, ch):
 
 def test_conv_groups(emu_lib):
     oc.check_conv_groups(DEV)
+
+
+def test_spade_two_site_launch(emu_lib):
+    oc.check_spade_pair(DEV)
+    oc.check_spade_pair(DEV, c=32, chs=(8,), h=9, w=7, up=False)

@@ -161,3 +161,8 @@ def test_spade_with_folded_upsample(hip_lib, nmaps, generated, c, ch):
 
 def test_conv_groups(hip_lib):
     oc.check_conv_groups(dev(), big=True)
+
+
+def test_spade_two_site_launch(hip_lib):
+    oc.check_spade_pair(dev())
+    oc.check_spade_pair(dev(), c=32, chs=(8,), h=9, w=7, up=False)
