@@ -173,6 +173,9 @@ lib.register_sigs({
     "fsv_conv_gather_group": [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p],
     "fsv_conv_wgrad_group": [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p],
     "fsv_conv_group_plan": [ctypes.POINTER(ctypes.c_int)] * 4 + [ctypes.c_int, ctypes.POINTER(ctypes.c_int)],
+    "fsv_conv_gather_fwd_stats": [ctypes.c_void_p] * 5 + [ctypes.c_int] * 8 + [ctypes.POINTER(ctypes.c_int)] * 2 +
+                                 [ctypes.c_int] * 4 + [ctypes.c_float, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int,
+                                                       ctypes.POINTER(ctypes.c_int), ctypes.c_void_p],
 })
 
 GROUP_LIMIT = 64          # FSV_GROUP_LIMIT (csrc/conv_igemm.hip)
@@ -182,6 +185,12 @@ _tls = threading.local()  # autograd runs backward on its own thread: the active
 
 def group_enabled():
     return os.environ.get('FSV_CONV_GROUPS', '1') == '1'
+
+
+def stats_enabled():
+    """FSV_CONV_STATS=0: in-box A/B switch - normalisation statistics from their own read pass instead of the producing
+    convolution's epilogue"""
+    return os.environ.get('FSV_CONV_STATS', '1') == '1'
 
 
 class launch_group:
@@ -270,9 +279,17 @@ def _active_group():
     return getattr(_tls, 'group', None)
 
 
+STATS_SLOTS = 32      # partial-sum slots per (group, channel) of the statistics a convolution leaves for its normalisation
+
+
 def gather_gemm(x, wt, ldw, cout, oh, ow, ty, tx, sy, sx, bias=None, res=None, act=ACT_NONE, scale=1.0,
-                per_sample=False, out=None, place=None, accumulate=False, force_tile=-1, force_split=0, wscale=None):
-    """out[n, oy, ox, :] = act((sum_taps x[n, oy*sy+ty, ox*sx+tx, :] @ wt[tap]) + bias) * scale) + res."""
+                per_sample=False, out=None, place=None, accumulate=False, force_tile=-1, force_split=0, wscale=None,
+                stats=None):
+    """out[n, oy, ox, :] = act((sum_taps x[n, oy*sy+ty, ox*sx+tx, :] @ wt[tap]) + bias) * scale) + res.
+
+    stats: None, or a dict with 'groups' (1: BatchNorm, n: InstanceNorm) - the launch then also leaves the per-channel sums of
+    its output (csrc/conv_igemm.hip ConvP::stats) and fills stats['part'] (fp64 partials), stats['slots']; when the launch
+    cannot (K-split plan, scalar gather, narrow-operand modes, inside a launch group) 'part' stays absent."""
     x = to_nhwc(x)
     n, cin, h, w = x.shape
     if place is None:
@@ -304,6 +321,24 @@ def gather_gemm(x, wt, ldw, cout, oh, ow, ty, tx, sy, sx, bias=None, res=None, a
         entry = "fsv_conv_gather_fwd_np"
         args = args[:-1] + (_mfma_mode, args[-1])
     grp = _active_group()
+    if (stats is not None and grp is None and entry == "fsv_conv_gather_fwd" and place is None and not per_sample
+            and not accumulate and force_tile < 0 and force_split == 0 and cin % 4 == 0 and stats_enabled()):
+        groups = int(stats['groups'])
+        part = torch.empty(groups * STATS_SLOTS * cout * 2, dtype=torch.float64, device=x.device)
+        produced = ctypes.c_int(0)
+        sargs = (lib.ptr(x), lib.ptr(wt), lib.ptr(bias), lib.ptr(res), lib.ptr(out), n, h, w, cin, oh, ow, cout, len(ty),
+                 lib.int_array(ty), lib.int_array(tx), sy, sx, ldw, act, float(scale), lib.ptr(wscale), lib.ptr(part), groups,
+                 STATS_SLOTS, ctypes.byref(produced), lib.stream_ptr())
+        label = 'fsv_conv_igemm_kernel'
+        if profile.enabled():
+            label = profile.conv_label(n * oh * ow, cout, (len(ty) * cin + 31) // 32, 1, True, force_tile, force_split)
+        keep = (x, wt, bias, res, out, wscale, part)
+        with profile.scope(label, 2.0 * n * oh * ow * cout * cin * len(ty),
+                           replay=lambda sargs=sargs, keep=keep: lib.call("fsv_conv_gather_fwd_stats", *sargs)):
+            lib.call("fsv_conv_gather_fwd_stats", *sargs)
+        if produced.value:
+            stats['part'], stats['slots'] = part, STATS_SLOTS
+        return out
     if grp is not None and entry == "fsv_conv_gather_fwd" and force_tile < 0 and force_split == 0:
         d = ConvDesc()
         d.inp, d.wt, d.bias, d.res, d.out, d.wscale = (t.data_ptr() if t is not None else None
@@ -336,12 +371,12 @@ def gather_gemm(x, wt, ldw, cout, oh, ow, ty, tx, sy, sx, bias=None, res=None, a
 
 
 def conv_forward(x, wt_f, ldw, cout, geom, bias=None, res=None, act=ACT_NONE, scale=1.0, per_sample=False,
-                 force_tile=-1, force_split=0, wscale=None):
+                 force_tile=-1, force_split=0, wscale=None, stats=None):
     n, cin, h, w = x.shape
     oh, ow = geom.out_hw(h, w)
     return gather_gemm(x, wt_f, ldw, cout, oh, ow, geom.ty, geom.tx, geom.stride, geom.stride, bias=bias, res=res,
                        act=act, scale=scale, per_sample=per_sample, force_tile=force_tile, force_split=force_split,
-                       wscale=wscale)
+                       wscale=wscale, stats=stats)
 
 
 def planned(mz, cout, nchunks, nsamp, force_tile=-1, force_split=0):
@@ -404,7 +439,7 @@ def conv_dgrad(dout, w, geom, in_hw, scale=None, per_sample=False, cached=None, 
                   for c, (sh, sw) in live]
         bm, bn = _TILE_DIMS[group_planned(shapes)]
         wgs = sum(-(-m // bm) * -(-co // bn) * z for m, co, _, z in shapes)
-        plain = plain and not (wgs <= 384 and max(k for _, _, k, _ in shapes) >= 16)
+        plain = plain and not (wgs <= 384 and max(k for _, _, k, _ in shapes) >= 16 and os.environ.get('FSV_DETERMINISTIC') != '1')
     elif plain:
         for c, (sh, sw) in zip(geom.dgrad_classes, subs):
             mz = sh * sw if per_sample else n * sh * sw

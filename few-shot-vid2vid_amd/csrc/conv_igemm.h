@@ -62,6 +62,12 @@ struct ConvP {
   int per_sample, nsplit;                // blockIdx.z = sample*nsplit + ksplit
   int act; float scale;
   int Mz;                                // rows (pixels) per z group
+  // optional: per-channel sums of the stored output for the normalisation that follows (BatchNorm / InstanceNorm statistics
+  // from the producing convolution's epilogue instead of a read pass over its output): zeroed partials
+  // stats[group][slot][Cout][2] = (sum v, sum v^2), the layout fsv_stats_final_kernel (norm.hip) finishes; a pixel tile adds into
+  // slot (tile index % stats_slots); group = pixel / stats_ohw (one group for BatchNorm, one per sample for InstanceNorm)
+  double* stats;
+  int stats_slots, stats_ohw;
 };
 
 __device__ __forceinline__ void fsv_tap(const ConvP& p, int t, int& ty, int& tx) {

@@ -295,18 +295,23 @@ __device__ __forceinline__ void fsv_conv_igemm_body(const ConvP& p, const int bx
   // ---- epilogue: D layout col = lane&31 (channel), row = (r&3) + 8*(r>>2) + 4*(lane>>5) (pixel) -----------
   const float* bias = p.bias ? (p.bias + (long long)zs * p.b_bstride) : nullptr;
   const float ws = p.wscale ? p.wscale[0] : 1.f;
+  // statistics for the normalisation that follows (p.stats, host side: only with nsplit == 1): rows below `gsplit` belong to the
+  // tile's first group, the rest (InstanceNorm, a tile that straddles two samples) to the next one
+  const int st_g0 = p.stats ? bm0 / p.stats_ohw : 0;
+  const int st_split = (st_g0 + 1) * (p.stats ? p.stats_ohw : 0);
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
     const int co = bn0 + wn * (TN * 32) + j * 32 + lrow;
-    if (co >= p.Cout) continue;
-    const float bv = (bias && p.nsplit == 1) ? bias[co] : 0.f;
+    const bool cok = co < p.Cout;
+    const float bv = (bias && p.nsplit == 1 && cok) ? bias[co] : 0.f;
+    float s0 = 0.f, q0 = 0.f, s1 = 0.f, q1 = 0.f;
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = (r & 3) + 8 * (r >> 2) + 4 * lk;
         const int m = bm0 + wm * (TM * 32) + i * 32 + row;
-        if (m >= p.Mz) continue;
+        if (m >= p.Mz || !cok) continue;
         long long opix;
         if (p.dense_out) {
           opix = (long long)zs * (p.per_sample ? p.Mz : 0) + m;
@@ -329,6 +334,23 @@ __device__ __forceinline__ void fsv_conv_igemm_body(const ConvP& p, const int bx
             if (p.res) v += p.res[opix * p.Cout + co];
           }
           *dst = v;
+          if (p.stats) {
+            if (m < st_split) { s0 += v; q0 += v * v; } else { s1 += v; q1 += v * v; }
+          }
+        }
+      }
+    }
+    if (p.stats) {            // uniform
+      // the two half-waves hold the same 32 channels (rows 4 lk + ...): fold them, then one fp64 atomic pair per channel
+      s0 += __shfl_xor(s0, 32); q0 += __shfl_xor(q0, 32);
+      s1 += __shfl_xor(s1, 32); q1 += __shfl_xor(q1, 32);
+      if (lk == 0 && cok) {
+        const int slot = bx % p.stats_slots;
+        double* d = p.stats + (((long long)st_g0 * p.stats_slots + slot) * p.Cout + co) * 2;
+        atomicAdd(d, (double)s0); atomicAdd(d + 1, (double)q0);
+        if (bm0 + BM > st_split && st_split < p.Mz) {       // uniform: the tile reaches into the next group
+          d += (long long)p.stats_slots * p.Cout * 2;
+          atomicAdd(d, (double)s1); atomicAdd(d + 1, (double)q1);
         }
       }
     }
@@ -1201,8 +1223,18 @@ static inline double fsv_conv_cost(int Mz, int Cout, int nchunks, int nsamp, int
   return t;
 }
 
+// FSV_DETERMINISTIC=1 (read at every call: tests switch it at run time): no reduction is split across workgroups, so no sum
+// depends on the arrival order of atomic adds - every gradient is a fixed-order fp32 sum.  For parity runs: exact cancellations
+// that sit ON a LeakyReLU kink otherwise take the sign the atomics' order gives them (profiles/r02_notes.md section 11: one
+// weight gradient of the C1 step 3.6e-2 off in one run of eight).  Slower (small grids), never the measured configuration.
+static inline bool fsv_deterministic() {
+  const char* e = getenv("FSV_DETERMINISTIC");
+  return e && e[0] == '1';
+}
+
 extern "C" int fsv_conv_plan(int Mz, int Cout, int nchunks, int nsamp, int force_tile, int force_split,
                              int* tile_out, int* nsplit_out) {
+  if (force_split <= 0 && fsv_deterministic()) force_split = 1;
   int tile = force_tile, nsplit = force_split > 0 ? force_split : 1;
   if (tile < 0 || force_split <= 0) {
     // candidates: every tile that is not wider than the layer needs (a forced tile: only that one) x split factors that
@@ -1255,19 +1287,21 @@ static inline void fsv_fill_convp(ConvP& p, const float* in, const float* wt, co
   p.act = act; p.scale = scale;
   p.Mz = per_sample ? OH * OW : N * OH * OW;
   p.nsplit = 1;
+  p.stats = nullptr; p.stats_slots = 1; p.stats_ohw = 1;
 }
 
 static inline bool vec4_ok(int cin) { return (cin & 3) == 0; }
 
-extern "C" {
-
-// Generic gather-GEMM (see header comment and include/fsv2v.h: fsv_conv_gather_fwd).
-int fsv_conv_gather_fwd(const float* in, const float* wt, const float* bias, const float* res, float* out,
+// Generic gather-GEMM (see header comment and include/fsv2v.h: fsv_conv_gather_fwd).  stats / stats_groups / stats_slots:
+// optional statistics partials for the normalisation that follows (ConvP::stats); *produced tells whether this launch wrote
+// them (not when the plan splits K or the layer takes the scalar-gather kernel: the caller then runs its reduction pass).
+static int fsv_conv_gather_impl(const float* in, const float* wt, const float* bias, const float* res, float* out,
                         int N, int H, int W, int Cin, int OH, int OW, int Cout,
                         int ntaps, const int* ty, const int* tx, int sy, int sx,
                         int outH, int outW, int osy, int osx, int ooy, int oox,
                         int ldw, long long w_bstride, long long b_bstride, int per_sample,
                         int act, float scale, int force_tile, int force_split, int accumulate, const float* wscale,
+                        double* stats, int stats_groups, int stats_slots, int* produced,
                         hipStream_t stream) {
   if (!in || !wt || !out || ntaps < 1 || ntaps > 16 || N < 1 || Cin < 1 || Cout < 1) return FSV_ERR_BAD_ARG;
   for (int t = 0; t < ntaps; ++t)
@@ -1297,6 +1331,14 @@ int fsv_conv_gather_fwd(const float* in, const float* wt, const float* bias, con
     (void)hipMemsetAsync(out, 0, (size_t)total * sizeof(float), stream);
   }
   const bool vec4 = (Cin % 4 == 0);
+  if (produced) *produced = 0;
+  if (stats && vec4 && nsplit == 1 && !accumulate && !per_sample && p.dense_out && stats_groups >= 1 && stats_slots >= 1 &&
+      p.Mz % stats_groups == 0 && (stats_groups == 1 || p.Mz / stats_groups >= 128)) {      // a pixel tile (<= 128 rows) touches
+                                                                                              // at most two groups
+    p.stats = stats; p.stats_slots = stats_slots; p.stats_ohw = p.Mz / stats_groups;
+    (void)hipMemsetAsync(stats, 0, (size_t)stats_groups * stats_slots * Cout * 2 * sizeof(double), stream);
+    if (produced) *produced = 1;
+  }
   // the plan's 8-wave tiles run as their prefetch-distance-2 variants (a forced tile id is taken literally)
   if (force_tile < 0 && vec4 && fsv_conv_pf2()) tile = (tile == 9) ? 10 : (tile == 0) ? 11 : (tile == 1) ? 12 : tile;
   int rc = fsv_launch_conv(p, vec4, nsamp * nsplit, stream, tile);
@@ -1310,6 +1352,30 @@ int fsv_conv_gather_fwd(const float* in, const float* wt, const float* bias, con
     rc = fsv_check_launch();
   }
   return rc;
+}
+
+extern "C" {
+
+int fsv_conv_gather_fwd(const float* in, const float* wt, const float* bias, const float* res, float* out,
+                        int N, int H, int W, int Cin, int OH, int OW, int Cout,
+                        int ntaps, const int* ty, const int* tx, int sy, int sx,
+                        int outH, int outW, int osy, int osx, int ooy, int oox,
+                        int ldw, long long w_bstride, long long b_bstride, int per_sample,
+                        int act, float scale, int force_tile, int force_split, int accumulate, const float* wscale,
+                        hipStream_t stream) {
+  return fsv_conv_gather_impl(in, wt, bias, res, out, N, H, W, Cin, OH, OW, Cout, ntaps, ty, tx, sy, sx, outH, outW, osy, osx,
+                              ooy, oox, ldw, w_bstride, b_bstride, per_sample, act, scale, force_tile, force_split, accumulate,
+                              wscale, nullptr, 0, 0, nullptr, stream);
+}
+
+int fsv_conv_gather_fwd_stats(const float* in, const float* wt, const float* bias, const float* res, float* out,
+                              int N, int H, int W, int Cin, int OH, int OW, int Cout,
+                              int ntaps, const int* ty, const int* tx, int sy, int sx,
+                              int ldw, int act, float scale, const float* wscale,
+                              double* stats, int stats_groups, int stats_slots, int* produced, hipStream_t stream) {
+  if (!stats || !produced) return FSV_ERR_BAD_ARG;
+  return fsv_conv_gather_impl(in, wt, bias, res, out, N, H, W, Cin, OH, OW, Cout, ntaps, ty, tx, sy, sx, OH, OW, 1, 1, 0, 0, ldw,
+                              0, 0, 0, act, scale, -1, 0, 0, wscale, stats, stats_groups, stats_slots, produced, stream);
 }
 
 // In-place x = act(x + bias[c]) over an NHWC tensor of `total` elements (the split-K finishing pass, exposed for operators
@@ -1363,6 +1429,7 @@ int fsv_conv_wgrad(const float* in, const float* dout, float* dwt,
   long long blocks = (long long)fsv_cdiv(p.K, bmk) * fsv_cdiv(Cout, bn) * nsamp;
   int nsplit = 1;
   if (force_split > 0) nsplit = force_split;
+  else if (fsv_deterministic()) nsplit = 1;
   else {
     nsplit = (int)((target + blocks - 1) / blocks);
     int maxs = p.pchunks / (int)fsv_tune(3);       // keep at least this many 32-pixel chunks per split
@@ -1492,7 +1559,7 @@ int fsv_conv_gather_group(const fsv_conv_desc* d, int n, int force_tile, hipStre
   // (in-box, round 3: the parity classes of a 16x16 / 32x32 stride-2 data gradient as 256 unsplit tiles of up to 128 chunks
   // took 188 us - as long as the four split launches they replaced)
   int want = 1;
-  if (wgs1 <= 384) { want = (int)((768 + wgs1 - 1) / (wgs1 > 0 ? wgs1 : 1)); if (want > 8) want = 8; if (want < 1) want = 1; }
+  if (wgs1 <= 384 && !fsv_deterministic()) { want = (int)((768 + wgs1 - 1) / (wgs1 > 0 ? wgs1 : 1)); if (want > 8) want = 8; if (want < 1) want = 1; }
   for (int i = 0; i < n; ++i) {
     int sp = 1;
     if (d[i].accumulate && want > 1) {
@@ -1605,7 +1672,7 @@ int fsv_conv_wgrad_group(const fsv_wgrad_desc* d, int n, hipStream_t stream) {
   }
   // the same ~2048-workgroup target as the single launches, for the group as a whole; at least 8 pixel chunks per split
   int want = (int)((2048 + blocks - 1) / (blocks > 0 ? blocks : 1));
-  if (want < 1) want = 1;
+  if (want < 1 || fsv_deterministic()) want = 1;
   for (int i = 0; i < n; ++i) {
     int sp = want;
     const int maxs = ps[i].pchunks / 8;

@@ -520,6 +520,16 @@ int fsv_norm_stats_rep(const float* x, double* workspace, float* mean, float* rs
   return fsv_check_launch();
 }
 
+// mean / rstd / running statistics from per-slot partial sums part[g][slot][c] = (sum x, sum x^2) that a producing kernel left
+// behind (the gather-GEMM epilogue, fsv_conv_gather_fwd_stats): the second stage of fsv_norm_stats alone
+int fsv_norm_stats_finish(const double* part, float* mean, float* rstd, int G, int P, int C, int nslots, float eps,
+                          float* run_mean, float* run_var, float momentum, int rep, hipStream_t stream) {
+  if (!part || !mean || !rstd || G < 1 || P < 1 || C < 1 || nslots < 1 || rep < 1) return FSV_ERR_BAD_ARG;
+  FSV_LAUNCH(fsv_stats_final_kernel, dim3(fsv_cdiv(G * C, 4)), dim3(256), stream, part, mean, rstd, G, C, P, nslots, eps,
+             run_mean, run_var, momentum, rep);
+  return fsv_check_launch();
+}
+
 static inline int fsv_ew_grid(long long total) {
   long long g = (total + 256 * 4 - 1) / (256 * 4);
   if (g > 8192) g = 8192;

@@ -54,10 +54,12 @@ class Conv2d(nn.Module, _SpectralMixin):
             self.weight = nn.Parameter(w)
         self.bias = nn.Parameter(torch.zeros(cout)) if bias else None
 
-    def forward(self, x, act=ACT_NONE, res=None, scale=1.0):
+    def forward(self, x, act=ACT_NONE, res=None, scale=1.0, stats=0):
+        """stats: 1 / -1 when a BatchNorm / InstanceNorm consumes the output next (ops.conv2d stats_groups: the statistics then
+        come out of this launch's epilogue instead of a read pass over the output)"""
         if self.spectral:
-            return ops.conv2d(x, self.weight_orig, self.bias, self.stride, self.padding, act, scale, res, self._sn())
-        return ops.conv2d(x, self.weight, self.bias, self.stride, self.padding, act, scale, res, None)
+            return ops.conv2d(x, self.weight_orig, self.bias, self.stride, self.padding, act, scale, res, self._sn(), stats)
+        return ops.conv2d(x, self.weight, self.bias, self.stride, self.padding, act, scale, res, None, stats)
 
 
 class Linear(nn.Module, _SpectralMixin):
@@ -145,7 +147,7 @@ class SPADEConv2d(nn.Module):
         self.bn = BatchNorm(fout, affine=True)
 
     def forward(self, x):
-        return self.bn(self.conv(x), act=ACT_LRELU)
+        return self.bn(self.conv(x, stats=1), act=ACT_LRELU)
 
 
 class SPADE(nn.Module):
@@ -214,7 +216,7 @@ class SPADEResnetBlock(nn.Module):
             if self.learned_shortcut:
                 self.bn_s = BatchNorm(fin)
 
-    def forward(self, x, label=None, norm_weights=None, up=False):
+    def forward(self, x, label=None, norm_weights=None, up=False, feeds_norm=True):
         """up=True: x is the block input BEFORE the nearest x2 up-sampling of generator.py:124.  With a learned shortcut
         the up-sampled tensor is consumed only by bn_0 and bn_s, which read x through the up-sampling index (ops.spade_mod
         up=True) - it is never written; otherwise it is materialised here."""
@@ -232,11 +234,12 @@ class SPADEResnetBlock(nn.Module):
             else:
                 x_s = x
                 h0 = self.bn_0(x, label, nw[0], act=ACT_LRELU, up=fold)
-            dx = self.conv_0(h0)
-            return self.conv_1(self.bn_1(dx, label, nw[1], act=ACT_LRELU), res=x_s)
+            # conv_0 feeds bn_1, conv_1 (+ shortcut) the next block's bn_0 / bn_s: BatchNorm statistics from their epilogues
+            dx = self.conv_0(h0, stats=1)
+            return self.conv_1(self.bn_1(dx, label, nw[1], act=ACT_LRELU), res=x_s, stats=1 if feeds_norm else 0)
         x_s = self.conv_s(self.bn_s(x)) if self.learned_shortcut else x
-        dx = self.conv_0(self.bn_0(x, act=ACT_LRELU))
-        return self.conv_1(self.bn_1(dx, act=ACT_LRELU), res=x_s)
+        dx = self.conv_0(self.bn_0(x, act=ACT_LRELU), stats=1)
+        return self.conv_1(self.bn_1(dx, act=ACT_LRELU), res=x_s, stats=1 if feeds_norm else 0)
 
 
 def spectral_layers(module):
@@ -352,12 +355,12 @@ class FlowGenerator(nn.Module):
         x = ops.cat_channels([label, label_prev, img_prev])
         for k in range(0, 2 * (self.nd + 1), 2):
             conv, bn = self.down_flow[k]
-            x = bn(conv(x), act=ACT_LRELU)
-        for blk in self.res_flow:
-            x = blk(x)
+            x = bn(conv(x, stats=1), act=ACT_LRELU)
+        for k, blk in enumerate(self.res_flow):
+            x = blk(x, feeds_norm=k + 1 < len(self.res_flow))
         for k in range(1, 3 * self.nd, 3):
             conv, bn = self.up_flow[k]
-            x = bn(conv(ops.upsample2x(x)), act=ACT_LRELU)
+            x = bn(conv(ops.upsample2x(x), stats=1), act=ACT_LRELU)
         flow = self.conv_flow[0](x, scale=float(self.flow_multiplier))
         mask = self.conv_mask[0](x, act=ACT_SIGMOID)
         return flow, mask
@@ -705,7 +708,7 @@ class FewShotGenerator(nn.Module):
             nw = norm_w[i] if (self.adap_spade and i < self.n_adaptive_layers) else None
             # generator.py:121-124: the nearest x2 up-sampling after block i + 1 is handed to block i (up=True), whose SPADE
             # kernels read through the up-sampling index
-            x = getattr(self, 'up_%d' % i)(x, enc_label[i], nw, up=(i != self.n_downsample_G))
+            x = getattr(self, 'up_%d' % i)(x, enc_label[i], nw, up=(i != self.n_downsample_G), feeds_norm=i > 0)
         img_raw = self.conv_img(ops.activation(x, ACT_LRELU), act=ACT_TANH)
         if not self.spade_combine:
             img_final = img_raw
@@ -818,7 +821,7 @@ class NLayerDiscriminator(nn.Module):
         res.append(x)
         for n in range(1, self.n_layers + 1):
             conv, norm = getattr(self, 'model%d' % n)[0]
-            x = norm(conv(x), act=ACT_LRELU)
+            x = norm(conv(x, stats=-1), act=ACT_LRELU)
             res.append(x)
         x = getattr(self, 'model%d' % (self.n_layers + 1))[0](x)
         res.append(x)

@@ -11,6 +11,7 @@ All tensors are fp32, logical NCHW, channels-last memory.  No CPU fallback: lib.
 tensors unless the emulated test library was requested explicitly.
 """
 import ctypes
+import threading as _threading
 
 import torch
 
@@ -280,11 +281,32 @@ def sn_backward(dwsn, weight, u, v, sig, out=None):
 import os as _os
 
 
+_conv_stats_tls = _threading.local()
+
+
+def _stats_from_producer(x, groups, pixels, channels, eps, run_mean, run_var, momentum, rep=1):
+    """(mean, rstd) from the partial sums the producing convolution's epilogue attached to x (`_fsv_stats`, conv2d), or None:
+    the second stage of the statistics alone, no read pass over x"""
+    st = getattr(x, '_fsv_stats', None)
+    if st is None or bn_sync_world(groups) > 1:
+        return None
+    part, g, slots, p, c = st
+    if (g, p, c) != (groups, pixels, channels):
+        return None
+    lib.register_sigs({"fsv_norm_stats_finish": [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_f, c_p, c_p, c_f, c_i, c_p]})
+    mean = torch.empty(groups * channels, dtype=torch.float32, device=x.device)
+    rstd = torch.empty_like(mean)
+    lib.check_device(x, run_mean, run_var)
+    lib.call("fsv_norm_stats_finish", lib.ptr(part), lib.ptr(mean), lib.ptr(rstd), groups, pixels, channels, slots, float(eps),
+             lib.ptr(run_mean), lib.ptr(run_var), float(momentum), int(rep), lib.stream_ptr())
+    return mean, rstd
+
+
 class _ConvFn(torch.autograd.Function):
     """y = act((conv(x, W * inv_sigma) + bias) * scale) + res.  W: OIHW, or [B]OIHW for per-sample weights."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, res, sig, u, v, geom, act, scale, uv_owned=False):
+    def forward(ctx, x, weight, bias, res, sig, u, v, geom, act, scale, uv_owned=False, stats_groups=0):
         weight._fsv_conv_param = True          # FlatAdam: these parameters take their gradients through the sink
         if bias is not None:
             bias._fsv_conv_param = True
@@ -320,8 +342,11 @@ class _ConvFn(torch.autograd.Function):
             raise ValueError("residual add is only fused after a linear epilogue")
         if scale != 1.0 and act != ACT_NONE:
             raise ValueError("output scale is only fused with a linear epilogue")
+        st = dict(groups=stats_groups) if (stats_groups and not per_sample) else None
         y = conv_forward(x, wt, ldw, cout, geom, bias=b, res=res.detach() if res is not None else None, act=act,
-                         scale=scale, per_sample=per_sample, wscale=wscale)
+                         scale=scale, per_sample=per_sample, wscale=wscale, stats=st)
+        # statistics of y left by the epilogue (conv2d() hands them to the normalisation that follows through the output tensor)
+        _conv_stats_tls.last = st if (st is not None and 'part' in st) else None
         ctx.geom, ctx.act, ctx.scale, ctx.per_sample = geom, act, scale, per_sample
         ctx.has_bias, ctx.has_res, ctx.has_sn = bias is not None, res is not None, sig is not None
         ctx.bias_ref = bias                      # the leaf itself (its .grad slice is the sink target), not saved data
@@ -411,7 +436,7 @@ class _ConvFn(torch.autograd.Function):
                 dx = dx[:, :cin]
         if ctx.has_res and ctx.needs_input_grad[3]:
             dres = dy
-        return dx, dw, db, dres, None, None, None, None, None, None, None
+        return dx, dw, db, dres, None, None, None, None, None, None, None, None
 
 
 def _unpack_sn(sn):
@@ -423,12 +448,23 @@ def _unpack_sn(sn):
     return sn[0], sn[1], sn[2], False
 
 
-def conv2d(x, weight, bias=None, stride=1, padding=0, act=ACT_NONE, scale=1.0, res=None, sn=None):
-    """sn: None or (sig, u, v) from SpectralState.update for this call."""
+def conv2d(x, weight, bias=None, stride=1, padding=0, act=ACT_NONE, scale=1.0, res=None, sn=None, stats_groups=0):
+    """sn: None or (sig, u, v) from SpectralState.update for this call.
+
+    stats_groups: 1 (a BatchNorm follows) / -1 (an InstanceNorm follows: one group per sample) - the convolution's epilogue
+    then also leaves the per-channel sums of its output (csrc/conv_igemm.hip ConvP::stats) and the returned tensor carries them
+    as `_fsv_stats` for norm_act / spade_mod, which skip their own reduction pass over it.  Only a hint: launches that cannot
+    produce them (K-split plans, scalar gather) leave the attribute off."""
     kh, kw = weight.shape[-2:]
     geom = Geom(kh, kw, stride, padding)
     sig, u, v, owned = _unpack_sn(sn)
-    return _ConvFn.apply(x, weight, bias, res, sig, u, v, geom, act, scale, owned)
+    groups = (x.shape[0] if stats_groups < 0 else stats_groups) if stats_groups else 0
+    y = _ConvFn.apply(x, weight, bias, res, sig, u, v, geom, act, scale, owned, groups)
+    st = getattr(_conv_stats_tls, 'last', None)
+    if groups and st is not None:
+        _conv_stats_tls.last = None
+        y._fsv_stats = (st['part'], groups, st['slots'], y.shape[0] * y.shape[2] * y.shape[3] // groups, y.shape[1])
+    return y
 
 
 def linear(x2d, weight, bias=None, act=ACT_NONE, sn=None):
@@ -711,12 +747,15 @@ def bn_backward(dy, y, x, mean, rstd, w, g, p, c, act, fixed_stats, affine, worl
 class _NormActFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, run_mean, run_var, instance, eps, momentum, act, training):
+        x_arg = x
         x = to_nhwc(x)
         n, c, h, w = x.shape
         g, p = (n, h * w) if instance else (1, n * h * w)
         if training or instance or run_mean is None:
-            mean, rstd = norm_stats(x, g, p, c, eps, None if instance else run_mean, None if instance else run_var,
-                                    momentum, instance=instance)
+            got = None if (instance and bn_sync_world(g, True) > 1) else _stats_from_producer(
+                x_arg, g, p, c, eps, None if instance else run_mean, None if instance else run_var, momentum)
+            mean, rstd = got if got is not None else norm_stats(
+                x, g, p, c, eps, None if instance else run_mean, None if instance else run_var, momentum, instance=instance)
         else:
             mean = run_mean.detach().clone()
             rstd = torch.rsqrt(run_var.detach() + eps)
@@ -748,7 +787,6 @@ def norm_act(x, weight=None, bias=None, run_mean=None, run_var=None, instance=Fa
 
 
 # ------------------------------------------------------------------------------------------------ SPADE
-import threading as _threading
 _spade_tls = _threading.local()
 
 
@@ -808,6 +846,7 @@ class _SpadeFn(torch.autograd.Function):
         up = 0
         if isinstance(act, tuple):
             act, up = act
+        x_arg = x
         x = to_nhwc(x)
         n, c, h, w = x.shape
         xs_h, xs_w = h, w                   # geometry of x as stored
@@ -820,7 +859,9 @@ class _SpadeFn(torch.autograd.Function):
         bgs = [rest[5 * k + 3] for k in range(nmaps)]
         bbs = [rest[5 * k + 4] for k in range(nmaps)]
         if training or run_mean is None:
-            mean, rstd = norm_stats(x, 1, n * xs_h * xs_w, c, eps, run_mean, run_var, momentum, rep=4 if up else 1)
+            got = _stats_from_producer(x_arg, 1, n * xs_h * xs_w, c, eps, run_mean, run_var, momentum, rep=4 if up else 1)
+            mean, rstd = got if got is not None else norm_stats(x, 1, n * xs_h * xs_w, c, eps, run_mean, run_var, momentum,
+                                                                rep=4 if up else 1)
         else:
             mean = run_mean.detach().clone()
             rstd = torch.rsqrt(run_var.detach() + eps)

@@ -87,6 +87,17 @@ typedef struct fsv_wgrad_desc {
 } fsv_wgrad_desc;
 int fsv_conv_wgrad_group(const fsv_wgrad_desc* problems, int n, fsv_stream_t stream);
 
+/* fsv_conv_gather_fwd (dense output, shared weights) that also leaves the per-channel sums of its output for the
+ * normalisation that follows - conv -> BatchNorm (architecture.py:57-69, generator.py:479-496) and conv -> InstanceNorm
+ * (discriminator.py:67-88) read the convolution's output a second time only to reduce it; here the epilogue adds
+ * (sum y, sum y^2) per channel into stats[group][slot][Cout][2] (doubles; zeroed by this call; slot = pixel tile % stats_slots,
+ * group = sample block: stats_groups = 1 for BatchNorm, N for InstanceNorm) and fsv_norm_stats_finish turns them into
+ * mean / rstd.  *produced = 0: this launch could not (K-split plan, Cin % 4 != 0) - run fsv_norm_stats instead. */
+int fsv_conv_gather_fwd_stats(const float* in, const float* wt, const float* bias, const float* res, float* out,
+                              int N, int H, int W, int Cin, int OH, int OW, int Cout,
+                              int ntaps, const int* ty, const int* tx, int sy, int sx,
+                              int ldw, int act, float scale, const float* wscale,
+                              double* stats, int stats_groups, int stats_slots, int* produced, fsv_stream_t stream);
 /* in place: x = act(x + bias[c]) over an NHWC tensor (finishing pass of operators that add several GEMM launches into one
  * output: convolutions with more than 16 taps, transposed convolutions); act codes as in the conv epilogue, 5 = leaky 0.1 */
 int fsv_bias_act(float* x, const float* bias, long long total, int C, int act, fsv_stream_t stream);
@@ -208,6 +219,9 @@ int fsv_spade_bwd_elem(const float* x, const float* mean, const float* rstd, con
 int fsv_norm_workspace_doubles(int G, int P, int C);
 int fsv_norm_stats(const float* x, double* workspace, float* mean, float* rstd, int G, int P, int C, float eps,
                    float* run_mean, float* run_var, float momentum, fsv_stream_t stream);
+/* second stage alone: mean / rstd (+ running statistics) from partial sums part[g][slot][c][2] left by a producing kernel */
+int fsv_norm_stats_finish(const double* part, float* mean, float* rstd, int G, int P, int C, int nslots, float eps,
+                          float* run_mean, float* run_var, float momentum, int rep, fsv_stream_t stream);
 /* statistics of a tensor that repeats every value of x `rep` times (nearest x2 up-sampling: rep = 4): mean / rstd are those
  * of x, the unbiased running-variance correction counts P * rep values */
 int fsv_norm_stats_rep(const float* x, double* workspace, float* mean, float* rstd, int G, int P, int C, float eps,

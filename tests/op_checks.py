@@ -898,3 +898,48 @@ def check_spade_pair(device, n=2, c=64, chs=(16, 8, 8), h=10, w=12, up=True, see
         assert_close('paired spade grad %d' % i, b, a, tol=1e-6)
     for a, b in zip(rm1 + rv1, rm2 + rv2):
         assert float((a.cpu() - b.cpu()).abs().max()) == 0.0
+
+
+def check_conv_stats(device, seed=61):
+    """BatchNorm / InstanceNorm statistics from the producing convolution's epilogue (ops.conv2d stats_groups -> `_fsv_stats` ->
+    norm_act / spade_mod) against the separate reduction pass: same normalised output, running statistics and gradients; the
+    InstanceNorm geometry makes pixel tiles straddle two samples; K-split plans and scalar-gather layers fall back silently."""
+    ops, conv = pkg()
+    g = torch.Generator().manual_seed(seed)
+    cases = [  # n, cin, h, w, cout, k, stride, pad, instance, residual
+        (2, 16, 12, 10, 24, 3, 1, 1, False, False),
+        (3, 8, 23, 23, 40, 4, 2, 2, True, False),         # 3 samples of 12 * 12 = 144 pixels: pixel tiles straddle two samples
+        (3, 8, 9, 7, 40, 4, 2, 2, True, False),           # 20 pixels per sample: a tile would span three groups -> fallback
+        (2, 32, 8, 8, 32, 3, 1, 1, False, True),
+        (2, 6, 8, 8, 16, 3, 1, 1, False, False),          # padded input channels still take the float4 path
+        (1, 512, 4, 4, 64, 3, 1, 1, False, False),        # deep K on a tiny map: the plan splits K -> no statistics, fallback
+    ]
+    for (n, cin, h, w, cout, k, s, p, inst, with_res) in cases:
+        x = torch.randn(n, cin, h, w, generator=g)
+        wt = torch.randn(cout, cin, k, k, generator=g) * (1.0 / (cin * k * k) ** 0.5)
+        b = torch.randn(cout, generator=g)
+        gam, bet = torch.rand(cout, generator=g) + 0.5, torch.randn(cout, generator=g) * 0.1
+        oh, ow = (h + 2 * p - k) // s + 1, (w + 2 * p - k) // s + 1
+        res = torch.randn(n, cout, oh, ow, generator=g) if with_res else None
+        dy = torch.randn(n, cout, oh, ow, generator=g)
+
+        def run(stats):
+            xd, wd, bd = [_dev(t, device).requires_grad_(True) for t in (x, wt, b)]
+            gd, be = _dev(gam, device).requires_grad_(True), _dev(bet, device).requires_grad_(True)
+            rm, rv = _dev(torch.zeros(cout), device), _dev(torch.ones(cout), device)
+            y = ops.conv2d(xd, wd, bd, stride=s, padding=p, res=_dev(res, device) if with_res else None,
+                           stats_groups=(-1 if inst else 1) if stats else 0)
+            had = hasattr(y, '_fsv_stats')
+            z = ops.norm_act(y, gd, be, None if inst else rm, None if inst else rv, instance=inst, eps=0.1 if inst else 1e-5,
+                             act=conv.ACT_LRELU)
+            z.backward(_dev(dy, device))
+            return z.detach(), [t.grad for t in (xd, wd, bd, gd, be)], rm, rv, had
+        z0, g0, rm0, rv0, _ = run(False)
+        z1, g1, rm1, rv1, had = run(True)
+        assert had == (cin != 512 and not (inst and h == 9)), ('statistics attribute', cin, had)
+        assert_close('norm(conv) with epilogue statistics %s' % ((n, cin, h, w, cout),), z1, z0, tol=2e-6)
+        for i, (a, bb) in enumerate(zip(g0, g1)):
+            assert_close('grad %d with epilogue statistics' % i, bb, a, tol=2e-5)
+        if not inst:
+            assert_close('running mean', rm1, rm0, tol=1e-6)
+            assert_close('running var', rv1, rv0, tol=1e-6)

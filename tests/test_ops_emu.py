@@ -137,3 +137,7 @@ def test_conv_groups(emu_lib):
 def test_spade_two_site_launch(emu_lib):
     oc.check_spade_pair(DEV)
     oc.check_spade_pair(DEV, c=32, chs=(8,), h=9, w=7, up=False)
+
+
+def test_norm_statistics_from_the_conv_epilogue(emu_lib):
+    oc.check_conv_stats(DEV)

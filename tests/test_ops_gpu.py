@@ -166,3 +166,7 @@ def test_conv_groups(hip_lib):
 def test_spade_two_site_launch(hip_lib):
     oc.check_spade_pair(dev())
     oc.check_spade_pair(dev(), c=32, chs=(8,), h=9, w=7, up=False)
+
+
+def test_norm_statistics_from_the_conv_epilogue(hip_lib):
+    oc.check_conv_stats(dev())
