@@ -12,10 +12,11 @@ MFMA).  Weak scaling: the per-GPU batch is fixed, gradients are all-reduced over
 Besides the contract fields the JSON line carries
   roofline     - the dominant kernel (the fp32 MFMA implicit-GEMM convolution) priced against the 157.3 TFLOP/s
                  fp32 matrix peak: algorithmic FLOPs per launch / average launch duration, measured with HIP events
-                 on the launch stream: the step's launches of that kernel re-issued back to back under one event pair
-                 (`avg_launch_us`; the per-launch brackets of the eager instrumented pass, which idles between launches,
-                 stay in the line as `bracketed_us`); `traffic` is null here - HBM bytes per launch need rocprofv3 PMC
-                 passes (profiles/r02_pmc_hbm_traffic.json holds them for this command);
+                 on the launch stream around every launch of that kernel in an instrumented eager pass of the step
+                 (`avg_launch_us`; the same launches re-issued back to back - warm caches, an upper bound - are reported as
+                 `replay_us_warm_cache_upper_bound`); `traffic`: HBM bytes per launch from the committed rocprofv3 PMC passes
+                 of this command (profiles/r03_pmc_hbm_traffic.json, keyed by kernel and commit), null when that file does
+                 not describe the running build;
   cpu_baseline - the CPU oracle (oracle/fsv_oracle.py, a port of the reference's algorithm; kind "port": the Python
                  reference cannot travel to the GPU box) timed on the host cores on ONE iteration of the very same
                  workload (512x512, B = 2, same flags; rank 0, N=1 only);
@@ -120,6 +121,29 @@ def cpu_baseline(size, batch, threads, use_reference=False):
     return dict(value=round(batch / dt, 4), unit='frames/s', cores=threads, kind=kind,
                 sample='1 iteration (D step + G step, fwd+bwd, train.py:58-62) of the bench workload itself: %dx%d, B=%d, '
                        'same flags, %s: %.1f s' % (size, size, batch, what, dt))
+
+
+def pmc_traffic(label):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of this command (FETCH_SIZE x 2 per
+    the gfx950 note of MI355X_MICROARCH.md + WRITE_SIZE, tools/pmc_traffic.py) - only when that file was recorded for the very
+    kernel sources this library was built from (source digest); None otherwise: counters cannot be collected in-run."""
+    try:
+        from importlib import import_module
+        build = import_module('few-shot-vid2vid_amd.build')
+        with open(os.path.join(ROOT, 'profiles', 'r03_pmc_hbm_traffic.json')) as f:
+            d = json.load(f)
+        if d.get('_build', {}).get('source_digest') != build.source_digest():
+            return None
+        # label 'fsv_conv_igemm_kernel<64x128,V4>' -> PMC key 'void fsv_conv_igemm_kernel<64, 128, ...'
+        name, dims = label.split('<')[0], label.split('<')[1].split(',')[0].replace('pf2', '').split('x')
+        for k, v in d.items():
+            if k.startswith('void %s<%s, %s,' % (name, dims[0], dims[1])):
+                return dict(read_MB=v['read_MB_corrected'], write_MB=v['write_MB'],
+                            total_MB=round(v['read_MB_corrected'] + v['write_MB'], 2), unit='MB per launch',
+                            source='profiles/r03_pmc_hbm_traffic.json', commit=d['_build'].get('commit'))
+    except Exception:
+        return None
+    return None
 
 
 def _time_graph(fn, n=5):
@@ -399,7 +423,7 @@ def main():
         if rl is not None:
             result['roofline'] = rl['dominant']
             result['kernels'] = rl['by_kernel']
-            result['roofline']['traffic'] = None        # needs PMC passes: see profiles/ (not measurable in-run)
+            result['roofline']['traffic'] = pmc_traffic(result['roofline']['kernel'])
         if world == 1 and not args.no_cpu_baseline:
             result['cpu_baseline'] = cpu_baseline(args.size, args.batch, min(os.cpu_count() or 1, 64))
         if world == 1 and not args.no_extras and not (WITH_VGG or WITH_FACE_D) and AMP == 'O0':

@@ -42,6 +42,11 @@ def _headers():
     return sorted(glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(ROOT, "include", "*.h")))
 
 
+def source_digest():
+    """digest of every kernel source and header: names the build a profile / counter file under profiles/ describes"""
+    return _digest(_sources() + _headers(), "src")[:16]
+
+
 def _run(cmd):
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:

@@ -113,7 +113,9 @@ __global__ __launch_bounds__(256) void fsv_resample2d_kernel(const float* img, c
     val += (float)(a1 * b1 * (double)b[yT * is[2] + xL * is[3]]);
     val += (float)((double)alpha * b1 * (double)b[yT * is[2] + xR * is[3]]);
     val += (float)(a1 * (double)beta * (double)b[yB * is[2] + xL * is[3]]);
-    val += (float)((double)alpha * (double)beta * (double)b[yB * is[2] + xR * is[3]]);
+    // the fourth tap of the reference is `(alpha)*(beta) * x` - no double literal in it: float products (resample2d_kernel.cu:60;
+    // found by holding this kernel to the reference's own kernel compiled for the host, oracle/build_ref.py)
+    val += (alpha * beta) * b[yB * is[2] + xR * is[3]];
     out[n * os[0] + c * os[1] + y * os[2] + x * os[3]] = val;
   }
 }

@@ -1,8 +1,10 @@
 """CPU restatement of the FlowNet2 teacher's three native operators (forward).  TEST INFRASTRUCTURE ONLY.
 
 The reference implements them as CUDA kernels (models/networks/flownet2_pytorch/networks/*_package/*.cu) that cannot be
-built or run here (no nvcc, no CUDA device), and its repository holds no test vectors for them: **parity unpinned**
-for these three operators - the restatements below follow the kernel sources line by line instead.
+built with nvcc or run on a CUDA device here, and its repository holds no test vectors for them.  They are pinned instead to
+the reference's own kernel templates compiled FOR THE HOST from the reference tree (oracle/build_ref.py ->
+oracle/_ref/libflownet2_ref.so, tests/test_flownet_ref.py): the restatements below follow the kernel sources line by line and
+agree with that build bit for bit (resample2d, channelnorm) resp. to summation order (correlation).
 """
 import numpy as np
 import torch
@@ -39,8 +41,10 @@ def correlation(f1, f2, pad_size=20, kernel_size=1, max_displacement=20, stride1
 
 
 def resample2d(img, flow):
-    """resample2d_kernel.cu:16-64, kernel_size 1, bit for bit: alpha / beta in float, each weighted tap evaluated in
-    double (the `1. - alpha` literals) and rounded to float, accumulated in float in the order LT, RT, LB, RB."""
+    """resample2d_kernel.cu:16-64, kernel_size 1, bit for bit: alpha / beta in float; the three weighted taps that carry a
+    `1. - alpha` / `1. - beta` literal are evaluated in double and rounded to float, the fourth (`alpha * beta * x`) in float;
+    accumulated in float in the order LT, RT, LB, RB.  Pinned to the reference's own kernel compiled for the host
+    (oracle/build_ref.py, tests/test_flownet_ref.py)."""
     n, c, h, w = img.shape
     im = img.numpy().astype(np.float32)
     fl = flow.numpy().astype(np.float32)
@@ -63,7 +67,8 @@ def resample2d(img, flow):
         val = (val + ((1.0 - a) * (1.0 - b) * v[bi, yT, xL].astype(np.float64)).astype(np.float32)).astype(np.float32)
         val = (val + (a * (1.0 - b) * v[bi, yT, xR].astype(np.float64)).astype(np.float32)).astype(np.float32)
         val = (val + ((1.0 - a) * b * v[bi, yB, xL].astype(np.float64)).astype(np.float32)).astype(np.float32)
-        val = (val + (a * b * v[bi, yB, xR].astype(np.float64)).astype(np.float32)).astype(np.float32)
+        # `(alpha)*(beta) * x` carries no double literal: float products (resample2d_kernel.cu:60)
+        val = (val + ((alpha * beta).astype(np.float32) * v[bi, yB, xR]).astype(np.float32)).astype(np.float32)
         out[:, ch] = val
     return torch.from_numpy(out)
 

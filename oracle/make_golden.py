@@ -194,9 +194,10 @@ def inference(name, flags):
 
 
 def flownet2():
-    """FlowNet2 teacher (models/networks/flownet2_pytorch/models.py) on CPU: the reference's network python unmodified,
-    its three CUDA extensions replaced by oracle/flownet_oracle.py (ref_import.install_flownet_shims).  The fixture holds
-    the output flow and the state_dict layout (162.5 M parameters: weights come from fill_state)."""
+    """FlowNet2 teacher (models/networks/flownet2_pytorch/models.py) on CPU: the reference's network python unmodified, its
+    three CUDA extension modules backed by the reference's own kernel templates compiled for the host (oracle/build_ref.py,
+    ref_import.install_flownet_shims).  The fixture holds the output flow and the state_dict layout (162.5 M parameters:
+    weights come from fill_state)."""
     import model_checks as mc
     net = ref_import.build_flownet2()
     mc.fill_state(net, scale=0.6)

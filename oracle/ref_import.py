@@ -104,29 +104,37 @@ def install_shims():
     _installed = True
 
 
-def install_flownet_shims():
+def install_flownet_shims(use_ref_kernels=True):
     """The reference's FlowNet2 python (models/networks/flownet2_pytorch) imports three compiled CUDA extensions.  They
-    cannot be built here (no nvcc / CUDA device), so the *compiled modules* - and only those - are replaced by python
-    modules backed by the CPU restatements of their kernels in oracle/flownet_oracle.py; the reference's own autograd
-    Function / Module wrappers and all network code then run unmodified on CPU tensors."""
+    cannot be built with nvcc here, so the *compiled modules* - and only those - are replaced by python modules backed by
+    the reference's OWN kernel templates compiled for the host from the reference tree (oracle/build_ref.py ->
+    oracle/flownet_ref.py); the reference's autograd Function / Module wrappers and all network code then run unmodified on
+    CPU tensors.  use_ref_kernels=False (or no reference tree / prebuilt library): the Python restatements of the kernels in
+    oracle/flownet_oracle.py instead."""
     install_shims()
     from oracle import flownet_oracle as FO
+    K = FO
+    if use_ref_kernels:
+        from oracle import flownet_ref
+        if flownet_ref.load() is not None:
+            K = flownet_ref
 
     def resample_fwd(input1, input2, output, kernel_size):
         assert kernel_size == 1
-        output.copy_(FO.resample2d(input1, input2))
+        output.copy_(K.resample2d(input1, input2))
 
     def channelnorm_fwd(input1, output, norm_deg):
         assert norm_deg == 2
-        output.copy_(FO.channelnorm(input1))
+        output.copy_(K.channelnorm(input1))
 
     def correlation_fwd(input1, input2, rbot1, rbot2, output, pad_size, kernel_size, max_displacement, stride1, stride2,
                         corr_multiply):
-        res = FO.correlation(input1, input2, pad_size, kernel_size, max_displacement, stride1, stride2)
+        res = K.correlation(input1, input2, pad_size, kernel_size, max_displacement, stride1, stride2)
         output.resize_(res.shape).copy_(res)
     _stub("resample2d_cuda", forward=resample_fwd)
     _stub("channelnorm_cuda", forward=channelnorm_fwd)
     _stub("correlation_cuda", forward=correlation_fwd)
+    return K.__name__
 
 
 def build_flownet2():

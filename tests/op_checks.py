@@ -570,13 +570,17 @@ def check_face_ops(device, seed=17):
         assert_close('paste face dface', cd.grad, cr.grad, 1e-5)
 
 
-def check_flownet_ops(device, seed=18):
-    """FlowNet2's native operators (csrc/flownet_ops.hip) vs the restatement of the reference CUDA kernels
-    (oracle/flownet_oracle.py): cost volume 1e-5 (summation order), warp and channel norm bit-exact."""
+def check_flownet_ops(device, seed=18, checker=None):
+    """FlowNet2's native operators (csrc/flownet_ops.hip) vs `checker`: the reference's own CUDA kernels compiled for the host
+    (oracle/flownet_ref.py, built by oracle/build_ref.py) when given, else their Python restatement (oracle/flownet_oracle.py,
+    itself held to that build by tests/test_flownet_ref.py): cost volume 1e-5 (summation order), warp and channel norm
+    bit-exact."""
     from importlib import import_module
     import fsv2v_amd  # noqa: F401
     fo = import_module('few-shot-vid2vid_amd.flownet_ops')
     from oracle import flownet_oracle as FO
+    if checker is not None:
+        FO = checker
     g = torch.Generator().manual_seed(seed)
     with torch.no_grad():
         # FlowNetC's configuration (FlowNetC.py:28-31) on a small map, plus odd sizes / strides

@@ -5,6 +5,8 @@ running on the GPU box's host cores, same seeded inputs and weights.
   C1  fewshot_face 128x128  B=1  adaptive_spade          full D step + G step   (fp32 and fp64 oracle: noise-floor form)
   C2  fewshot_face 256x256  B=4  adaptive_spade          generator forward + backward (the config is defined G-only)
   C3  fewshot_pose 512x512  B=2  adaptive_spade + warp_ref + spade_combine   full D step + G step = the bench.py workload
+  C4  C3 + --add_face_D (+ VGG19 loss)  B=2 (the per-rank batch of the 8-GPU config)   full D step + G step
+  C5  fewshot_street 1024x512  label_nc 35  B=1 (per rank)  adaptive_spade   full D step + G step, fp32
 
 Tolerances: losses and images 1e-3 relative (BASELINE.json north_star); per-parameter gradients in the relative L2 norm
 (model_checks.compare_grads_l2), 1e-2 for the full step.  The oracle runs in fp32 and fp64 (C3: ~11 + ~22 GB of host memory):
@@ -69,3 +71,24 @@ def test_c3_pose_512_b2_full_step_is_the_bench_workload(hip_lib):
     # and the stride-2 data gradients (4 parity classes)
     assert any(n == 16 and v4 for _, _, v4, n in groups) and any(n == 16 and not v4 for _, _, v4, n in groups), groups[:8]
     assert any(n == 4 for _, _, _, n in groups), groups[:8]
+
+
+def test_c4_pose_512_face_d_vgg(hip_lib):
+    """BASELINE.json configs[3] per rank (scripts/pose/train_g8.sh:8-10: the C3 flags + --add_face_D, which brings the VGG19 loss
+    with it - loss_collector.py:70-85): full width, 512x512, the per-GPU batch of 2, full D step (netD + netDf) + G step against
+    the oracle in fp32 and fp64.  VGG19 runs on seeded random weights (no checkpoint in this environment; the oracle gets the
+    same tensors)."""
+    opt = mc.make_opt(warp_ref=True, spade_combine=True, remove_face_labels=True, add_face_D=True, no_vgg_loss=False,
+                      fineSize=512, loadSize=512, batchSize=2)
+    worst = mc.check_train_step(DEV, opt, b=2, tol=1e-3, grad_tol=1e-2)
+    assert worst < 1e-2, worst
+
+
+def test_c5_street_1024x512_nc35_fp32(hip_lib):
+    """BASELINE.json configs[4] per rank in fp32 (data/fewshot_street_dataset.py:19-27: W 1024 x H 512, --label_nc 35 one-hot
+    labels, --adaptive_spade; one sample per GPU of the 8-GPU batch of 8): full width, full D step + G step against the oracle.
+    The fp16 arithmetic of that config (--amp O1) is checked at operator level only (tests/test_zz_np_gpu.py)."""
+    opt = mc.make_opt(dataset_mode='fewshot_street', label_nc=35, input_nc=3, aspect_ratio=2.0, fineSize=1024, loadSize=1024,
+                      batchSize=1)
+    worst = mc.check_train_step(DEV, opt, b=1, tol=1e-3, grad_tol=1e-2)
+    assert worst < 1e-2, worst

@@ -28,8 +28,21 @@ def main():
         res[name] = dict(launches=n, fetch_kib_raw_per_launch=round(tot / n, 1),
                          read_MB_corrected=round(2 * tot / n * 1024 / 1e6, 2),
                          write_MB=round(w[1] / max(w[0], 1) * 1024 / 1e6, 2))
+    # which build these counters describe: the digest of the kernel sources (few-shot-vid2vid_amd/build.py source_digest) and,
+    # where a git checkout is at hand, the commit - bench.py only quotes `roofline.traffic` from a file whose digest matches
+    # the library it is running
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import fsv2v_amd  # noqa: F401
+    from importlib import import_module
+    meta = dict(source_digest=import_module('few-shot-vid2vid_amd.build').source_digest())
+    try:
+        import subprocess
+        meta['commit'] = subprocess.run(['git', 'rev-parse', 'HEAD'], capture_output=True, text=True, timeout=5,
+                                        cwd=os.path.dirname(os.path.abspath(__file__))).stdout.strip() or None
+    except Exception:
+        meta['commit'] = None
     with open(sys.argv[3], 'w') as f:
-        json.dump(res, f, indent=1)
+        json.dump(dict(_build=meta, **res), f, indent=1)
     for k in list(res)[:12]:
         print(k[:70], res[k])
 
