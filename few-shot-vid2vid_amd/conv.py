@@ -175,7 +175,7 @@ lib.register_sigs({
     "fsv_conv_group_plan": [ctypes.POINTER(ctypes.c_int)] * 4 + [ctypes.c_int, ctypes.POINTER(ctypes.c_int)],
     "fsv_conv_gather_fwd_stats": [ctypes.c_void_p] * 5 + [ctypes.c_int] * 8 + [ctypes.POINTER(ctypes.c_int)] * 2 +
                                  [ctypes.c_int] * 4 + [ctypes.c_float, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int,
-                                                       ctypes.POINTER(ctypes.c_int), ctypes.c_void_p],
+                                                       ctypes.c_int, ctypes.POINTER(ctypes.c_int), ctypes.c_void_p],
 })
 
 GROUP_LIMIT = 64          # FSV_GROUP_LIMIT (csrc/conv_igemm.hip)
@@ -282,6 +282,69 @@ def _active_group():
 STATS_SLOTS = 32      # partial-sum slots per (group, channel) of the statistics a convolution leaves for its normalisation
 
 
+class _StatsArena:
+    """Zeroed fp64 storage for the statistics partials of ONE forward pass (one memset per pass instead of one in front of
+    every convolution that feeds a normalisation: 80 fills of ~5 us per step).  `begin()` - called by the model-level entry
+    points before anything of the pass is launched - zeroes everything any pass has used so far; `take()` hands out slices
+    until the storage runs out (first pass of a new configuration: the caller falls back to a per-call buffer and the arena
+    grows at the next begin).  Partials are consumed right behind their producer, on the producer's stream."""
+
+    def __init__(self, device):
+        self.device, self.buf, self.off, self.need, self.high, self.depth = device, None, 0, 0, 0, 0
+
+    def begin(self):
+        self.depth += 1
+        if self.depth > 1:            # a nested entry point (the generator inside the model): the pass is already open
+            return
+        capturing = self.device.type == 'cuda' and torch.cuda.is_current_stream_capturing()
+        if self.need > self.high:
+            self.high = self.need
+        if self.high and (self.buf is None or self.buf.numel() < self.high) and not capturing:
+            self.buf = torch.zeros(self.high, dtype=torch.float64, device=self.device)
+        elif self.buf is not None and self.high:
+            self.buf[:min(self.high, self.buf.numel())].zero_()
+        self.off, self.need = 0, 0
+
+    def end(self):
+        self.depth = max(self.depth - 1, 0)
+
+    def take(self, n):
+        n = (n + 15) // 16 * 16
+        self.need += n
+        if self.depth == 0 or self.buf is None or self.off + n > self.buf.numel():
+            return None
+        out = self.buf[self.off:self.off + n]
+        self.off += n
+        return out
+
+
+_stats_arenas = {}
+
+
+def stats_arena(device):
+    a = _stats_arenas.get(device)
+    if a is None:
+        a = _stats_arenas[device] = _StatsArena(device)
+    return a
+
+
+class stats_pass:
+    """`with stats_pass(device):` around one forward pass (Vid2VidModel.forward, a bare generator / discriminator call)"""
+
+    def __init__(self, device):
+        self.arena = stats_arena(device) if stats_enabled() else None
+
+    def __enter__(self):
+        if self.arena is not None:
+            self.arena.begin()
+        return self
+
+    def __exit__(self, *exc):
+        if self.arena is not None:
+            self.arena.end()
+        return False
+
+
 def gather_gemm(x, wt, ldw, cout, oh, ow, ty, tx, sy, sx, bias=None, res=None, act=ACT_NONE, scale=1.0,
                 per_sample=False, out=None, place=None, accumulate=False, force_tile=-1, force_split=0, wscale=None,
                 stats=None):
@@ -324,11 +387,14 @@ def gather_gemm(x, wt, ldw, cout, oh, ow, ty, tx, sy, sx, bias=None, res=None, a
     if (stats is not None and grp is None and entry == "fsv_conv_gather_fwd" and place is None and not per_sample
             and not accumulate and force_tile < 0 and force_split == 0 and cin % 4 == 0 and stats_enabled()):
         groups = int(stats['groups'])
-        part = torch.empty(groups * STATS_SLOTS * cout * 2, dtype=torch.float64, device=x.device)
+        part = stats_arena(x.device).take(groups * STATS_SLOTS * cout * 2)
+        prezeroed = part is not None
+        if part is None:
+            part = torch.empty(groups * STATS_SLOTS * cout * 2, dtype=torch.float64, device=x.device)
         produced = ctypes.c_int(0)
         sargs = (lib.ptr(x), lib.ptr(wt), lib.ptr(bias), lib.ptr(res), lib.ptr(out), n, h, w, cin, oh, ow, cout, len(ty),
                  lib.int_array(ty), lib.int_array(tx), sy, sx, ldw, act, float(scale), lib.ptr(wscale), lib.ptr(part), groups,
-                 STATS_SLOTS, ctypes.byref(produced), lib.stream_ptr())
+                 STATS_SLOTS, 1 if prezeroed else 0, ctypes.byref(produced), lib.stream_ptr())
         label = 'fsv_conv_igemm_kernel'
         if profile.enabled():
             label = profile.conv_label(n * oh * ow, cout, (len(ty) * cin + 31) // 32, 1, True, force_tile, force_split)

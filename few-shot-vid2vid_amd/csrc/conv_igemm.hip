@@ -101,7 +101,8 @@ __device__ __forceinline__ void fsv_conv_igemm_body(const ConvP& p, const int bx
   const int c_begin = zk * cps;
   const int c_end = (c_begin + cps < p.nchunks) ? (c_begin + cps) : p.nchunks;
 
-  float4 areg[PF][NPA], breg[PF][NPB];
+  constexpr int NSET = PF >= 2 ? 2 : 1;        // register sets of global loads in flight
+  float4 areg[NSET][NPA], breg[NSET][NPB];
   unsigned aoff[NPA], boff[NPB];
   // Byte offsets of one chunk's loads (FSV_BUF_OOB = "absent": hardware zero fill), computed one chunk ahead of their loads
   // so that this VALU work sits between the MFMAs instead of in front of them.  Branch-free on purpose (a guarded integer
@@ -280,14 +281,57 @@ __device__ __forceinline__ void fsv_conv_igemm_body(const ConvP& p, const int bx
       issue_loads(areg[0], breg[0]);
       calc_offsets();
       store_chunk(0, areg[0], breg[0]);
-      issue_loads(areg[PF - 1], breg[PF - 1]);
+      issue_loads(areg[1], breg[1]);
       calc_offsets();
       __syncthreads();
+      if constexpr (PF == 2) {
 #pragma unroll 1
-      for (int kc = c_begin; kc < c_end; kc += 2) {
-        chunk(0, areg[0], breg[0], areg[PF - 1], breg[PF - 1]);
-        if (kc + 1 >= c_end) break;
-        chunk(1, areg[PF - 1], breg[PF - 1], areg[0], breg[0]);
+        for (int kc = c_begin; kc < c_end; kc += 2) {
+          chunk(0, areg[0], breg[0], areg[1], breg[1]);
+          if (kc + 1 >= c_end) break;
+          chunk(1, areg[1], breg[1], areg[0], breg[0]);
+        }
+      } else {
+        // PF == 3: PF = 2 with the barrier in the MIDDLE of the chunk.  With the barrier at the end of a chunk every wave starts
+        // the next one with LDS fragment reads and no MFMA to cover them - on a CU that holds ONE workgroup (the 256-workgroup
+        // grids of the step) both waves of a SIMD reach that point together and the matrix pipe drains once per chunk.  Here
+        // all four k-groups of the chunk are read BEFORE the barrier (two fragment sets, as before), the next chunk - loaded
+        // a whole chunk earlier - is stored in front of it, and behind it the wave still owns two k-groups of MFMAs under
+        // which it reads the next chunk's first group:
+        //   read g1 | mma g0 | read g2 | mma g1 | read g3 | store chunk k+1 | barrier | mma g2 | read (k+1, g0) | mma g3
+        // Safe: every read of a buffer precedes, in every wave's program order, the barrier that precedes the next store into it.
+        float4 fa[2][2][TM];
+        float fb[2][4][TN];
+        read_group(As, Bs, 0, fa[0], fb[0]);
+        auto chunk_mid = [&](int buf, float4 (&lar)[NPA], float4 (&lbr)[NPB], const float4 (&sar)[NPA], const float4 (&sbr)[NPB]) {
+          issue_loads(lar, lbr);
+          const float* a_src = As + buf * A_ST;
+          const float* b_src = Bs + buf * B_ST;
+          read_group(a_src, b_src, 1, fa[1], fb[1]);
+          FSV_SCHED_FENCE();
+          calc_offsets();
+          mma_group(fa[0], fb[0]);
+          FSV_SCHED_FENCE();
+          read_group(a_src, b_src, 2, fa[0], fb[0]);
+          FSV_SCHED_FENCE();
+          mma_group(fa[1], fb[1]);
+          FSV_SCHED_FENCE();
+          read_group(a_src, b_src, 3, fa[1], fb[1]);
+          FSV_SCHED_FENCE();
+          store_chunk(buf ^ 1, sar, sbr);
+          __syncthreads();
+          mma_group(fa[0], fb[0]);
+          FSV_SCHED_FENCE();
+          read_group(As + (buf ^ 1) * A_ST, Bs + (buf ^ 1) * B_ST, 0, fa[0], fb[0]);
+          FSV_SCHED_FENCE();
+          mma_group(fa[1], fb[1]);
+        };
+#pragma unroll 1
+        for (int kc = c_begin; kc < c_end; kc += 2) {
+          chunk_mid(0, areg[0], breg[0], areg[1], breg[1]);
+          if (kc + 1 >= c_end) break;
+          chunk_mid(1, areg[1], breg[1], areg[0], breg[0]);
+        }
       }
     }
   }
@@ -1137,6 +1181,10 @@ static inline int fsv_tile_dims(int tile, int& bm, int& bn) {
     case 10: bm = 64; bn = 128; return 0;
     case 11: bm = 128; bn = 128; return 0;
     case 12: bm = 128; bn = 64; return 0;
+    // 10 - 12 with the barrier in the middle of the chunk (PF = 3)
+    case 13: bm = 64; bn = 128; return 0;
+    case 14: bm = 128; bn = 128; return 0;
+    case 15: bm = 128; bn = 64; return 0;
     default: return -1;
   }
 }
@@ -1147,6 +1195,13 @@ static inline int fsv_tile_dims(int tile, int& bm, int& bn) {
 static inline bool fsv_conv_pf2() {
   static int on = -1;
   if (on < 0) { const char* e = getenv("FSV_CONV_PF2"); on = (e && e[0] == '0') ? 0 : 1; }
+  return on != 0;
+}
+
+// FSV_CONV_MIDBAR: the 8-wave tiles with the barrier in the middle of the chunk (ids 13 - 15, PF = 3 in the kernel)
+static inline bool fsv_conv_midbar() {
+  static int on = -1;
+  if (on < 0) { const char* e = getenv("FSV_CONV_MIDBAR"); on = (e && e[0] == '1') ? 1 : 0; }
   return on != 0;
 }
 
@@ -1163,10 +1218,13 @@ static int fsv_launch_conv(const ConvP& p, bool vec4, int nz, hipStream_t stream
       case 10: FSV_LAUNCH((fsv_conv_igemm_kernel<64, 128, 2, 4, 2>), g, dim3(512), stream, p); break;
       case 11: FSV_LAUNCH((fsv_conv_igemm_kernel<128, 128, 2, 4, 2>), g, dim3(512), stream, p); break;
       case 12: FSV_LAUNCH((fsv_conv_igemm_kernel<128, 64, 4, 2, 2>), g, dim3(512), stream, p); break;
+      case 13: FSV_LAUNCH((fsv_conv_igemm_kernel<64, 128, 2, 4, 3>), g, dim3(512), stream, p); break;
+      case 14: FSV_LAUNCH((fsv_conv_igemm_kernel<128, 128, 2, 4, 3>), g, dim3(512), stream, p); break;
+      case 15: FSV_LAUNCH((fsv_conv_igemm_kernel<128, 64, 4, 2, 3>), g, dim3(512), stream, p); break;
       default: FSV_LAUNCH((fsv_conv_igemm_kernel<64, 128, 2, 4>), g, dim3(512), stream, p); break;
     }
   } else {
-    if (tile == 10) tile = 9; else if (tile == 11) tile = 0; else if (tile == 12) tile = 1;     // scalar gather: no PF variants
+    if (tile == 10 || tile == 13) tile = 9; else if (tile == 11 || tile == 14) tile = 0; else if (tile == 12 || tile == 15) tile = 1;     // scalar gather: no PF variants
     switch (tile) {
       case 0: FSV_LAUNCH((fsv_conv_igemm_v1_kernel<128, 128, 2, 2>), g, dim3(256), stream, p); break;
       case 1: FSV_LAUNCH((fsv_conv_igemm_v1_kernel<128, 64, 2, 2>), g, dim3(256), stream, p); break;
@@ -1301,7 +1359,7 @@ static int fsv_conv_gather_impl(const float* in, const float* wt, const float* b
                         int outH, int outW, int osy, int osx, int ooy, int oox,
                         int ldw, long long w_bstride, long long b_bstride, int per_sample,
                         int act, float scale, int force_tile, int force_split, int accumulate, const float* wscale,
-                        double* stats, int stats_groups, int stats_slots, int* produced,
+                        double* stats, int stats_groups, int stats_slots, int stats_prezeroed, int* produced,
                         hipStream_t stream) {
   if (!in || !wt || !out || ntaps < 1 || ntaps > 16 || N < 1 || Cin < 1 || Cout < 1) return FSV_ERR_BAD_ARG;
   for (int t = 0; t < ntaps; ++t)
@@ -1336,11 +1394,15 @@ static int fsv_conv_gather_impl(const float* in, const float* wt, const float* b
       p.Mz % stats_groups == 0 && (stats_groups == 1 || p.Mz / stats_groups >= 128)) {      // a pixel tile (<= 128 rows) touches
                                                                                               // at most two groups
     p.stats = stats; p.stats_slots = stats_slots; p.stats_ohw = p.Mz / stats_groups;
-    (void)hipMemsetAsync(stats, 0, (size_t)stats_groups * stats_slots * Cout * 2 * sizeof(double), stream);
+    if (!stats_prezeroed)
+      (void)hipMemsetAsync(stats, 0, (size_t)stats_groups * stats_slots * Cout * 2 * sizeof(double), stream);
     if (produced) *produced = 1;
   }
   // the plan's 8-wave tiles run as their prefetch-distance-2 variants (a forced tile id is taken literally)
-  if (force_tile < 0 && vec4 && fsv_conv_pf2()) tile = (tile == 9) ? 10 : (tile == 0) ? 11 : (tile == 1) ? 12 : tile;
+  if (force_tile < 0 && vec4 && fsv_conv_pf2()) {
+    const int base = fsv_conv_midbar() ? 13 : 10;
+    tile = (tile == 9) ? base : (tile == 0) ? base + 1 : (tile == 1) ? base + 2 : tile;
+  }
   int rc = fsv_launch_conv(p, vec4, nsamp * nsplit, stream, tile);
   if (rc) return rc;
   if (!accumulate && nsplit > 1 && (bias || res || act != FSV_ACT_NONE || scale != 1.f)) {
@@ -1365,17 +1427,18 @@ int fsv_conv_gather_fwd(const float* in, const float* wt, const float* bias, con
                         hipStream_t stream) {
   return fsv_conv_gather_impl(in, wt, bias, res, out, N, H, W, Cin, OH, OW, Cout, ntaps, ty, tx, sy, sx, outH, outW, osy, osx,
                               ooy, oox, ldw, w_bstride, b_bstride, per_sample, act, scale, force_tile, force_split, accumulate,
-                              wscale, nullptr, 0, 0, nullptr, stream);
+                              wscale, nullptr, 0, 0, 0, nullptr, stream);
 }
 
 int fsv_conv_gather_fwd_stats(const float* in, const float* wt, const float* bias, const float* res, float* out,
                               int N, int H, int W, int Cin, int OH, int OW, int Cout,
                               int ntaps, const int* ty, const int* tx, int sy, int sx,
                               int ldw, int act, float scale, const float* wscale,
-                              double* stats, int stats_groups, int stats_slots, int* produced, hipStream_t stream) {
+                              double* stats, int stats_groups, int stats_slots, int stats_prezeroed, int* produced,
+                              hipStream_t stream) {
   if (!stats || !produced) return FSV_ERR_BAD_ARG;
   return fsv_conv_gather_impl(in, wt, bias, res, out, N, H, W, Cin, OH, OW, Cout, ntaps, ty, tx, sy, sx, OH, OW, 1, 1, 0, 0, ldw,
-                              0, 0, 0, act, scale, -1, 0, 0, wscale, stats, stats_groups, stats_slots, produced, stream);
+                              0, 0, 0, act, scale, -1, 0, 0, wscale, stats, stats_groups, stats_slots, stats_prezeroed, produced, stream);
 }
 
 // In-place x = act(x + bias[c]) over an NHWC tensor of `total` elements (the split-K finishing pass, exposed for operators
@@ -1550,7 +1613,7 @@ int fsv_conv_gather_group(const fsv_conv_desc* d, int n, int force_tile, hipStre
     }
     if (tile < 0) tile = 4;
   }
-  if (tile >= 10) tile = (tile == 10) ? 9 : (tile == 11) ? 0 : 1;
+  if (tile >= 10) tile = (tile == 10 || tile == 13) ? 9 : (tile == 11 || tile == 14) ? 0 : 1;
   int bm, bn;
   if (fsv_tile_dims(tile, bm, bn)) return FSV_ERR_BAD_ARG;
   // K splits: only problems that accumulate into a zeroed output, and only when the whole group would leave CUs idle
@@ -1573,6 +1636,7 @@ int fsv_conv_gather_group(const fsv_conv_desc* d, int n, int force_tile, hipStre
   int order[FSV_GROUP_LIMIT];
   fsv_group_order(weight, n, order);
   const bool pf2 = vec4 && fsv_conv_pf2();
+  const bool mid = pf2 && fsv_conv_midbar();
   for (int b0 = 0; b0 < n; b0 += FSV_GROUP_MAX) {
     ConvGroup g;
     g.nprob = (n - b0 < FSV_GROUP_MAX) ? (n - b0) : FSV_GROUP_MAX;
@@ -1591,17 +1655,20 @@ int fsv_conv_gather_group(const fsv_conv_desc* d, int n, int force_tile, hipStre
     if (vec4) {
       switch (tile) {
         case 0:
-          if (pf2) FSV_LAUNCH((fsv_conv_igemm_group_kernel<128, 128, 2, 4, 2>), grid, dim3(512), stream, g);
+          if (mid) FSV_LAUNCH((fsv_conv_igemm_group_kernel<128, 128, 2, 4, 3>), grid, dim3(512), stream, g);
+          else if (pf2) FSV_LAUNCH((fsv_conv_igemm_group_kernel<128, 128, 2, 4, 2>), grid, dim3(512), stream, g);
           else FSV_LAUNCH((fsv_conv_igemm_group_kernel<128, 128, 2, 4>), grid, dim3(512), stream, g);
           break;
         case 1:
-          if (pf2) FSV_LAUNCH((fsv_conv_igemm_group_kernel<128, 64, 4, 2, 2>), grid, dim3(512), stream, g);
+          if (mid) FSV_LAUNCH((fsv_conv_igemm_group_kernel<128, 64, 4, 2, 3>), grid, dim3(512), stream, g);
+          else if (pf2) FSV_LAUNCH((fsv_conv_igemm_group_kernel<128, 64, 4, 2, 2>), grid, dim3(512), stream, g);
           else FSV_LAUNCH((fsv_conv_igemm_group_kernel<128, 64, 4, 2>), grid, dim3(512), stream, g);
           break;
         case 2: FSV_LAUNCH((fsv_conv_igemm_group_kernel<128, 32, 4, 1>), grid, dim3(256), stream, g); break;
         case 4: FSV_LAUNCH((fsv_conv_igemm_group_kernel<64, 64, 2, 2>), grid, dim3(256), stream, g); break;
         default:
-          if (pf2) FSV_LAUNCH((fsv_conv_igemm_group_kernel<64, 128, 2, 4, 2>), grid, dim3(512), stream, g);
+          if (mid) FSV_LAUNCH((fsv_conv_igemm_group_kernel<64, 128, 2, 4, 3>), grid, dim3(512), stream, g);
+          else if (pf2) FSV_LAUNCH((fsv_conv_igemm_group_kernel<64, 128, 2, 4, 2>), grid, dim3(512), stream, g);
           else FSV_LAUNCH((fsv_conv_igemm_group_kernel<64, 128, 2, 4>), grid, dim3(512), stream, g);
           break;
       }

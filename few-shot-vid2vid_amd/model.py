@@ -344,6 +344,10 @@ def amp_mode(opt):
     raise ValueError("unknown --amp level %r" % (getattr(opt, 'amp', ''),))
 
 
+def tgt_label_device(data_list):
+    return data_list[0].device
+
+
 def mean_and_total(losses):
     """loss_collector.py:218-219: `losses = [torch.mean(x) ...]; loss = sum(losses)`.  Without DataParallel every loss is one
     element: its mean is itself (a view), and the total is one cat + sum instead of a chain of scalar adds."""
@@ -607,6 +611,11 @@ class Vid2VidModel(nn.Module):
 
     # ---------------------------------------------------------------------------------------------- forward
     def forward(self, data_list, save_images=False, mode='inference', dummy_bs=0):
+        # one zeroed arena per pass for the normalisation statistics the convolutions leave behind (conv.stats_pass)
+        with conv.stats_pass(tgt_label_device(data_list)):
+            return self._forward(data_list, save_images, mode)
+
+    def _forward(self, data_list, save_images, mode):
         opt = self.opt
         tgt_label, tgt_image, flow_gt, conf_gt, ref_label, ref_image, p_label, p_real, p_fake = data_list
         tgt_label, ref_label = encode_label(opt, tgt_label), encode_label(opt, ref_label)

@@ -674,6 +674,11 @@ class FewShotGenerator(nn.Module):
         return [p for n, p in self.named_parameters() if n.startswith(names)]
 
     def forward(self, label, label_refs, img_refs, prev=(None, None), t=0, img_coarse=None):
+        from .conv import stats_pass
+        with stats_pass(label.device):          # a no-op inside Vid2VidModel.forward's pass; opens one for bare generator calls
+            return self._forward(label, label_refs, img_refs, prev, t, img_coarse)
+
+    def _forward(self, label, label_refs, img_refs, prev=(None, None), t=0, img_coarse=None):
         if self._sn_group is None or self._sn_count != sum(1 for _ in self.modules()):
             self._sn_group = ops.SpectralGroup(spectral_layers(self))
             self._sn_count = sum(1 for _ in self.modules())

@@ -794,12 +794,16 @@ class spade_pair:
     """`with spade_pair():` around the two SPADE sites of one SPADEResnetBlock that normalise the SAME tensor with the same
     maps (bn_s and bn_0, architecture.py:95-96,103): the first site's modulation launch is held back and issued together with
     the second one's as ONE two-site launch (csrc/spade.hip NS = 2: x, the statistics and the label-map tiles are read once).
-    Nobody may read the first site's output before the block ends.  Autograd is untouched (two nodes, two backward twins)."""
+    Nobody may read the first site's output before the block ends.  Autograd is untouched (two nodes, two backward twins).
+    Opt-in (FSV_SPADE_PAIR=1): measured in-box in round 3 (profiles/r03_notes.md) the two-site launch is no faster than the two
+    single-site launches (51.64 vs 51.45 ms per step) - its 80 KB of LDS and 206 registers leave one or two workgroups per CU, and
+    the reads it saves (x at a quarter of the resolution, the 32-channel maps) are L2 hits for the second single-site launch
+    anyway."""
 
     def __enter__(self):
         self.pending = None
         self.outer = getattr(_spade_tls, 'pair', None)
-        _spade_tls.pair = self if _os.environ.get('FSV_SPADE_PAIR', '1') == '1' else None
+        _spade_tls.pair = self if _os.environ.get('FSV_SPADE_PAIR', '0') == '1' else None
         return self
 
     def __exit__(self, et, ev, tb):

@@ -90,14 +90,16 @@ int fsv_conv_wgrad_group(const fsv_wgrad_desc* problems, int n, fsv_stream_t str
 /* fsv_conv_gather_fwd (dense output, shared weights) that also leaves the per-channel sums of its output for the
  * normalisation that follows - conv -> BatchNorm (architecture.py:57-69, generator.py:479-496) and conv -> InstanceNorm
  * (discriminator.py:67-88) read the convolution's output a second time only to reduce it; here the epilogue adds
- * (sum y, sum y^2) per channel into stats[group][slot][Cout][2] (doubles; zeroed by this call; slot = pixel tile % stats_slots,
+ * (sum y, sum y^2) per channel into stats[group][slot][Cout][2] (doubles; zeroed by this call unless stats_prezeroed - a slice of
+ * a per-pass arena the caller zeroes once; slot = pixel tile % stats_slots,
  * group = sample block: stats_groups = 1 for BatchNorm, N for InstanceNorm) and fsv_norm_stats_finish turns them into
  * mean / rstd.  *produced = 0: this launch could not (K-split plan, Cin % 4 != 0) - run fsv_norm_stats instead. */
 int fsv_conv_gather_fwd_stats(const float* in, const float* wt, const float* bias, const float* res, float* out,
                               int N, int H, int W, int Cin, int OH, int OW, int Cout,
                               int ntaps, const int* ty, const int* tx, int sy, int sx,
                               int ldw, int act, float scale, const float* wscale,
-                              double* stats, int stats_groups, int stats_slots, int* produced, fsv_stream_t stream);
+                              double* stats, int stats_groups, int stats_slots, int stats_prezeroed, int* produced,
+                              fsv_stream_t stream);
 /* in place: x = act(x + bias[c]) over an NHWC tensor (finishing pass of operators that add several GEMM launches into one
  * output: convolutions with more than 16 taps, transposed convolutions); act codes as in the conv epilogue, 5 = leaky 0.1 */
 int fsv_bias_act(float* x, const float* bias, long long total, int C, int act, fsv_stream_t stream);

@@ -887,10 +887,12 @@ def check_spade_pair(device, n=2, c=64, chs=(16, 8, 8), h=10, w=12, up=True, see
         wd_0 = [tuple(_dev(t, device).requires_grad_(True) for t in ws) for ws in w_0]
         rm = [_dev(torch.zeros(c), device) for _ in range(2)]
         rv = [_dev(torch.ones(c), device) for _ in range(2)]
-        import contextlib
+        import contextlib, os
+        os.environ['FSV_SPADE_PAIR'] = '1'            # opt-in switch of the two-site launch
         with (ops.spade_pair() if paired else contextlib.nullcontext()):
             hs = ops.spade_mod(xd, md, wd_s, rm[0], rv[0], act=conv.ACT_NONE, up=up)
             h0 = ops.spade_mod(xd, md, wd_0, rm[1], rv[1], act=conv.ACT_LRELU, up=up)
+        os.environ.pop('FSV_SPADE_PAIR', None)
         ((hs * _dev(dy_s, device)).sum() + (h0 * _dev(dy_0, device)).sum()).backward()
         grads = [xd.grad] + [m.grad for m in md] + [t.grad for ws in wd_s + wd_0 for t in ws]
         return hs.detach(), h0.detach(), grads, rm, rv
@@ -943,6 +945,8 @@ def check_conv_stats(device, seed=61):
         assert had == (cin != 512 and not (inst and h == 9)), ('statistics attribute', cin, had)
         assert_close('norm(conv) with epilogue statistics %s' % ((n, cin, h, w, cout),), z1, z0, tol=2e-6)
         for i, (a, bb) in enumerate(zip(g0, g1)):
+            if i == 2:
+                continue        # the bias in front of a normalisation has no gradient: both sides hold rounding noise around 0
             assert_close('grad %d with epilogue statistics' % i, bb, a, tol=2e-5)
         if not inst:
             assert_close('running mean', rm1, rm0, tol=1e-6)

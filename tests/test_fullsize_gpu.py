@@ -30,18 +30,15 @@ def _conv():
     return import_module('few-shot-vid2vid_amd.conv')
 
 
-def test_c1_face_128_full_step(hip_lib, monkeypatch):
+def test_c1_face_128_full_step(hip_lib):
     opt = mc.make_opt(dataset_mode='fewshot_face', input_nc=1, fineSize=128, loadSize=128, batchSize=1)
-    # Gradients: with split reductions this configuration (one sample, 128x128, flat regions in the synthetic edge map) has two
-    # outcomes on hardware (12 + 8 runs, profiles/r02_notes.md section 11): every parameter inside 1e-2 relative L2, or
-    # ref_img_up_2.conv.weight off by exactly 3.6e-2 - activations that cancel to zero exactly sit ON the LeakyReLU kink and
-    # the arrival order of the split reductions' atomic adds decides their sign for a whole region at once.  The parity run
-    # therefore uses the library's fixed-order mode (FSV_DETERMINISTIC=1: no reduction is split across workgroups) and the
-    # band is the 1e-2 of every other configuration; the split-reduction build is held to 5e-2 right after.
-    monkeypatch.setenv('FSV_DETERMINISTIC', '1')
-    worst = mc.check_train_step(DEV, opt, b=1, tol=1e-3, grad_tol=1e-2)
-    assert worst < 1e-2, worst
-    monkeypatch.setenv('FSV_DETERMINISTIC', '0')
+    # Gradients: this configuration (one sample, 128x128) has two outcomes on hardware (12 + 8 runs in round 2,
+    # profiles/r02_notes.md section 11): every parameter inside 1e-2 relative L2, or ref_img_up_2.conv.weight off by exactly
+    # 3.6e-2 - a whole region of one layer's activations sits ON the LeakyReLU kink and takes its slope from rounding.  Round 3
+    # ruled out the suspected cause: with every split reduction switched off (FSV_DETERMINISTIC=1: fixed-order sums, no atomics
+    # in any GEMM) the SAME 3.6e-2 outcome came up on the first run (profiles/r03_notes.md), so it is the rounding of an
+    # upstream value (BatchNorm statistics of a single-sample batch are the candidate), not the order of split-K atomics.
+    # Losses and images hold 1e-3 in both outcomes; the band for this configuration stays 5e-2 and says why.
     worst = mc.check_train_step(DEV, opt, b=1, tol=1e-3, grad_tol=5e-2)
     assert worst < 5e-2, worst
 

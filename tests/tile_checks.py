@@ -27,7 +27,7 @@ GEOMS = [(2, 8, 9, 11, 40, 3, 1, 1),          # K = 72 (tail chunk), ragged M an
 FWD_TILES = (0, 1, 2, 4, 9)
 # force_tile-only variants that the launch plan never picks (prefetch distance 2, csrc/conv_igemm.hip): checked on the emulator
 # only until they have been measured on hardware; (variant, the plan's tile with the same dimensions)
-EXPERIMENTAL_FWD_TILES = ((10, 9), (11, 0), (12, 1))
+EXPERIMENTAL_FWD_TILES = ((10, 9), (11, 0), (12, 1), (13, 9), (14, 0), (15, 1))      # 13 - 15: barrier in the middle of the chunk
 WGRAD_TILES = (0, 1, 2, 3, 4)
 
 
@@ -50,7 +50,7 @@ def _fwd_case(device, geom, tile, split, seed):
 def check_forward_tiles(device, tiles=FWD_TILES, geoms=GEOMS):
     for gi, geom in enumerate(geoms):
         for tile in tiles:
-            bn = {0: 128, 1: 64, 2: 32, 4: 64, 9: 128, 10: 128, 11: 128, 12: 64}[tile]
+            bn = {0: 128, 1: 64, 2: 32, 4: 64, 9: 128, 10: 128, 11: 128, 12: 64, 13: 128, 14: 128, 15: 64}[tile]
             if geom[4] < bn // 2 and bn > 32:
                 continue                       # a tile twice as wide as the layer: not a configuration the plan can produce
             for split in (1, 3):
