@@ -142,13 +142,25 @@ __device__ __forceinline__ void fsv_conv_igemm_body(const ConvP& p, const int bx
 #pragma unroll
     for (int i = 0; i < NPB; ++i) br[i] = fsv_buf_load4(bbuf, boff[i]);
   };
+  // AF = 1 (PF == 3, round 3): the quad (k0 k1 k2 k3) of a row is stored as (k0 k2 | k1 k3) - rows with bit 4 set as
+  // (k1 k3 | k0 k2) - so that a lane reads exactly the two values its MFMA steps multiply with ONE ds_read_b64 (lanes 0-31 take
+  // the even k of a quad, lanes 32-63 the odd ones; the bit-4 swap spreads the 32 lanes of a ds_read_b64 service group over
+  // all 32 bank pairs).  The b128 form makes every MFMA wait for a v_cndmask + s_nop that picks its operand out of the quad -
+  // an issue slot between two MFMAs on the SAME accumulator, which costs the matrix pipe ~40 cycles each time
+  // (MI355X_MICROARCH.md, instruction timing); with the operands read in place the four MFMAs of a k-group issue back to back.
+  constexpr bool AF = (PF == 3);
   auto store_chunk = [&](int buf, const float4 (&ar)[NPA], const float4 (&br)[NPB]) {
     float* a_dst = As + buf * A_ST;
     float* b_dst = Bs + buf * B_ST;
 #pragma unroll
     for (int i = 0; i < NPA; ++i) {
       const int r = ar0 + i * RPA;
-      *reinterpret_cast<float4*>(&a_dst[r * BK + ((kq ^ ((r >> 1) & 7)) << 2)]) = ar[i];
+      float4 v = ar[i];
+      if constexpr (AF) {
+        const bool hi = (r >> 4) & 1;
+        v = hi ? make_float4(ar[i].y, ar[i].w, ar[i].x, ar[i].z) : make_float4(ar[i].x, ar[i].z, ar[i].y, ar[i].w);
+      }
+      *reinterpret_cast<float4*>(&a_dst[r * BK + ((kq ^ ((r >> 1) & 7)) << 2)]) = v;
     }
 #pragma unroll
     for (int i = 0; i < NPB; ++i) {
@@ -171,7 +183,7 @@ __device__ __forceinline__ void fsv_conv_igemm_body(const ConvP& p, const int bx
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
     const int r = wm * (TM * 32) + i * 32 + lrow;
-    a_off[i] = r * BK;
+    a_off[i] = r * BK + (AF ? 2 * (lk ^ ((r >> 4) & 1)) : 0);       // AF: this lane's half of every quad
     a_swz[i] = (r >> 1) & 7;
   }
   const int b_off = lk * BN + wn * (TN * 32) + lrow;
@@ -184,8 +196,14 @@ __device__ __forceinline__ void fsv_conv_igemm_body(const ConvP& p, const int bx
 #pragma unroll
     for (int q = 0; q < 2; ++q)
 #pragma unroll
-      for (int i = 0; i < TM; ++i)
-        a4[q][i] = *reinterpret_cast<const float4*>(&a_src[a_off[i] + (((2 * g + q) ^ a_swz[i]) << 2)]);
+      for (int i = 0; i < TM; ++i) {
+        if constexpr (AF) {
+          const float2 v = *reinterpret_cast<const float2*>(&a_src[a_off[i] + (((2 * g + q) ^ a_swz[i]) << 2)]);
+          a4[q][i].x = v.x; a4[q][i].y = v.y;
+        } else {
+          a4[q][i] = *reinterpret_cast<const float4*>(&a_src[a_off[i] + (((2 * g + q) ^ a_swz[i]) << 2)]);
+        }
+      }
 #pragma unroll
     for (int t = 0; t < 4; ++t)
 #pragma unroll
@@ -197,7 +215,7 @@ __device__ __forceinline__ void fsv_conv_igemm_body(const ConvP& p, const int bx
 #pragma unroll
       for (int i = 0; i < TM; ++i) {
         const float4 v = a4[t >> 1][i];
-        const float a = (t & 1) ? (lk ? v.w : v.z) : (lk ? v.y : v.x);
+        const float a = AF ? ((t & 1) ? v.y : v.x) : ((t & 1) ? (lk ? v.w : v.z) : (lk ? v.y : v.x));
 #pragma unroll
         for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b[t][j], acc[i][j], 0, 0, 0);
       }
@@ -284,54 +302,11 @@ __device__ __forceinline__ void fsv_conv_igemm_body(const ConvP& p, const int bx
       issue_loads(areg[1], breg[1]);
       calc_offsets();
       __syncthreads();
-      if constexpr (PF == 2) {
 #pragma unroll 1
-        for (int kc = c_begin; kc < c_end; kc += 2) {
-          chunk(0, areg[0], breg[0], areg[1], breg[1]);
-          if (kc + 1 >= c_end) break;
-          chunk(1, areg[1], breg[1], areg[0], breg[0]);
-        }
-      } else {
-        // PF == 3: PF = 2 with the barrier in the MIDDLE of the chunk.  With the barrier at the end of a chunk every wave starts
-        // the next one with LDS fragment reads and no MFMA to cover them - on a CU that holds ONE workgroup (the 256-workgroup
-        // grids of the step) both waves of a SIMD reach that point together and the matrix pipe drains once per chunk.  Here
-        // all four k-groups of the chunk are read BEFORE the barrier (two fragment sets, as before), the next chunk - loaded
-        // a whole chunk earlier - is stored in front of it, and behind it the wave still owns two k-groups of MFMAs under
-        // which it reads the next chunk's first group:
-        //   read g1 | mma g0 | read g2 | mma g1 | read g3 | store chunk k+1 | barrier | mma g2 | read (k+1, g0) | mma g3
-        // Safe: every read of a buffer precedes, in every wave's program order, the barrier that precedes the next store into it.
-        float4 fa[2][2][TM];
-        float fb[2][4][TN];
-        read_group(As, Bs, 0, fa[0], fb[0]);
-        auto chunk_mid = [&](int buf, float4 (&lar)[NPA], float4 (&lbr)[NPB], const float4 (&sar)[NPA], const float4 (&sbr)[NPB]) {
-          issue_loads(lar, lbr);
-          const float* a_src = As + buf * A_ST;
-          const float* b_src = Bs + buf * B_ST;
-          read_group(a_src, b_src, 1, fa[1], fb[1]);
-          FSV_SCHED_FENCE();
-          calc_offsets();
-          mma_group(fa[0], fb[0]);
-          FSV_SCHED_FENCE();
-          read_group(a_src, b_src, 2, fa[0], fb[0]);
-          FSV_SCHED_FENCE();
-          mma_group(fa[1], fb[1]);
-          FSV_SCHED_FENCE();
-          read_group(a_src, b_src, 3, fa[1], fb[1]);
-          FSV_SCHED_FENCE();
-          store_chunk(buf ^ 1, sar, sbr);
-          __syncthreads();
-          mma_group(fa[0], fb[0]);
-          FSV_SCHED_FENCE();
-          read_group(As + (buf ^ 1) * A_ST, Bs + (buf ^ 1) * B_ST, 0, fa[0], fb[0]);
-          FSV_SCHED_FENCE();
-          mma_group(fa[1], fb[1]);
-        };
-#pragma unroll 1
-        for (int kc = c_begin; kc < c_end; kc += 2) {
-          chunk_mid(0, areg[0], breg[0], areg[1], breg[1]);
-          if (kc + 1 >= c_end) break;
-          chunk_mid(1, areg[1], breg[1], areg[0], breg[0]);
-        }
+      for (int kc = c_begin; kc < c_end; kc += 2) {
+        chunk(0, areg[0], breg[0], areg[1], breg[1]);
+        if (kc + 1 >= c_end) break;
+        chunk(1, areg[1], breg[1], areg[0], breg[0]);
       }
     }
   }
@@ -1181,7 +1156,7 @@ static inline int fsv_tile_dims(int tile, int& bm, int& bn) {
     case 10: bm = 64; bn = 128; return 0;
     case 11: bm = 128; bn = 128; return 0;
     case 12: bm = 128; bn = 64; return 0;
-    // 10 - 12 with the barrier in the middle of the chunk (PF = 3)
+    // 10 - 12 with the A fragments read in place (ds_read_b64 of a re-ordered quad: no select between the MFMAs; PF = 3)
     case 13: bm = 64; bn = 128; return 0;
     case 14: bm = 128; bn = 128; return 0;
     case 15: bm = 128; bn = 64; return 0;
@@ -1198,10 +1173,10 @@ static inline bool fsv_conv_pf2() {
   return on != 0;
 }
 
-// FSV_CONV_MIDBAR: the 8-wave tiles with the barrier in the middle of the chunk (ids 13 - 15, PF = 3 in the kernel)
+// FSV_CONV_AF: the 8-wave tiles with in-place A fragments (ids 13 - 15, PF = 3 in the kernel)
 static inline bool fsv_conv_midbar() {
   static int on = -1;
-  if (on < 0) { const char* e = getenv("FSV_CONV_MIDBAR"); on = (e && e[0] == '1') ? 1 : 0; }
+  if (on < 0) { const char* e = getenv("FSV_CONV_AF"); on = (e && e[0] == '1') ? 1 : 0; }
   return on != 0;
 }
 

@@ -112,6 +112,11 @@ def run_all(device):
     check_forward_tiles(device)
     check_per_sample(device)
     check_wgrad_tiles(device)
+    # the prefetch-distance-2 tiles (10 - 12: what the plan's 9 / 0 / 1 run as) and the in-place-fragment tiles (13 - 15):
+    # against F.conv2d and bit-equal to the plan's tile of the same shape
+    for variant, base in EXPERIMENTAL_FWD_TILES:
+        check_forward_tiles(device, tiles=(variant,))
+        check_variant_equals_plan_tile(device, variant, base, splits=(1, 3))
 
 
 if __name__ == '__main__':
