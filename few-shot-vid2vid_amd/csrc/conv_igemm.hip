@@ -50,7 +50,7 @@ __device__ __forceinline__ void fsv_xcd_tile(int nx, int ny, int& bx, int& by) {
 // section 16):
 // two register sets, the loads of chunk k + 2 are issued at the top of chunk k and the set stored behind the 12th MFMA was
 // loaded a whole chunk earlier, for grids with one workgroup per CU where nothing else covers the HBM latency.
-template <int BM, int BN, int WM, int WN, int PF>
+template <int BM, int BN, int WM, int WN, int PF, bool AF>
 __device__ __forceinline__ void fsv_conv_igemm_body(const ConvP& p, const int bx, const int by, const int bz) {
   constexpr int BK = FSV_BK;
   constexpr int NT = 64 * WM * WN;    // 4 or 8 waves
@@ -142,13 +142,12 @@ __device__ __forceinline__ void fsv_conv_igemm_body(const ConvP& p, const int bx
 #pragma unroll
     for (int i = 0; i < NPB; ++i) br[i] = fsv_buf_load4(bbuf, boff[i]);
   };
-  // AF = 1 (PF == 3, round 3): the quad (k0 k1 k2 k3) of a row is stored as (k0 k2 | k1 k3) - rows with bit 4 set as
+  // AF (round 3): the quad (k0 k1 k2 k3) of a row is stored as (k0 k2 | k1 k3) - rows with bit 4 set as
   // (k1 k3 | k0 k2) - so that a lane reads exactly the two values its MFMA steps multiply with ONE ds_read_b64 (lanes 0-31 take
   // the even k of a quad, lanes 32-63 the odd ones; the bit-4 swap spreads the 32 lanes of a ds_read_b64 service group over
   // all 32 bank pairs).  The b128 form makes every MFMA wait for a v_cndmask + s_nop that picks its operand out of the quad -
   // an issue slot between two MFMAs on the SAME accumulator, which costs the matrix pipe ~40 cycles each time
   // (MI355X_MICROARCH.md, instruction timing); with the operands read in place the four MFMAs of a k-group issue back to back.
-  constexpr bool AF = (PF == 3);
   auto store_chunk = [&](int buf, const float4 (&ar)[NPA], const float4 (&br)[NPB]) {
     float* a_dst = As + buf * A_ST;
     float* b_dst = Bs + buf * B_ST;
@@ -376,11 +375,11 @@ __device__ __forceinline__ void fsv_conv_igemm_body(const ConvP& p, const int bx
   }
 }
 
-template <int BM, int BN, int WM, int WN, int PF = 1>
+template <int BM, int BN, int WM, int WN, int PF = 1, bool AF = false>
 __global__ __launch_bounds__(64 * WM * WN) void fsv_conv_igemm_kernel(ConvP p) {
   int bx, by;
   fsv_xcd_tile(gridDim.x, gridDim.y, bx, by);
-  fsv_conv_igemm_body<BM, BN, WM, WN, PF>(p, bx, by, (int)blockIdx.z);
+  fsv_conv_igemm_body<BM, BN, WM, WN, PF, AF>(p, bx, by, (int)blockIdx.z);
 }
 
 // Grouped launch: up to FSV_GROUP_MAX INDEPENDENT gather-GEMM problems in one 1-D grid (the problem table travels in the
@@ -397,7 +396,7 @@ struct ConvGroup {
   ConvP p[FSV_GROUP_MAX];
 };
 
-template <int BM, int BN, int WM, int WN, int PF = 1>
+template <int BM, int BN, int WM, int WN, int PF = 1, bool AF = false>
 __global__ __launch_bounds__(64 * WM * WN) void fsv_conv_igemm_group_kernel(ConvGroup g) {
   const int b = blockIdx.x;
   int i = 0;
@@ -406,7 +405,7 @@ __global__ __launch_bounds__(64 * WM * WN) void fsv_conv_igemm_group_kernel(Conv
   const ConvP& p = g.p[i];
   const int gx = (p.Mz + BM - 1) / BM, gy = (p.Cout + BN - 1) / BN;
   const int r = t / gx;
-  fsv_conv_igemm_body<BM, BN, WM, WN, PF>(p, t - r * gx, r % gy, r / gy);
+  fsv_conv_igemm_body<BM, BN, WM, WN, PF, AF>(p, t - r * gx, r % gy, r / gy);
 }
 
 // Scalar-gather twin for Cin % 4 != 0 (image / label inputs that were not channel-padded): single LDS buffer, A transposed
@@ -1160,24 +1159,32 @@ static inline int fsv_tile_dims(int tile, int& bm, int& bn) {
     case 13: bm = 64; bn = 128; return 0;
     case 14: bm = 128; bn = 128; return 0;
     case 15: bm = 128; bn = 64; return 0;
+    // the tiles that keep their global loads one chunk ahead, with in-place A fragments
+    case 16: bm = 128; bn = 128; return 0;
+    case 17: bm = 64; bn = 64; return 0;
+    case 18: bm = 128; bn = 32; return 0;
     default: return -1;
   }
 }
 
-// The plan's 8-wave tiles run as their prefetch-distance-2 variants (ids 10 - 12) unless FSV_CONV_PF2=0.  Measured at the
-// end of round 2 (profiles/r02_notes.md section 16): +5 ... +6 % on the two dominant shapes in isolation, bit-equal to the
-// PF = 1 tiles; made the default in round 3 after the whole GPU suite ran with them (profiles/r03_notes.md).
-static inline bool fsv_conv_pf2() {
-  static int on = -1;
-  if (on < 0) { const char* e = getenv("FSV_CONV_PF2"); on = (e && e[0] == '0') ? 0 : 1; }
-  return on != 0;
-}
-
-// FSV_CONV_AF: the 8-wave tiles with in-place A fragments (ids 13 - 15, PF = 3 in the kernel)
-static inline bool fsv_conv_midbar() {
-  static int on = -1;
-  if (on < 0) { const char* e = getenv("FSV_CONV_AF"); on = (e && e[0] == '1') ? 1 : 0; }
-  return on != 0;
+// Kernel variant a tile SHAPE of the plan (0 = 128x128, 1 = 128x64, 2 = 128x32, 4 = 64x64, 9 = 64x128) runs as.  Variants differ in
+// the prefetch distance of the global loads (PF: 1 or 2 chunks) and the A-fragment format (AF: b128 quad + per-MFMA select, or
+// re-ordered quad read in place with ds_read_b64); all are bit-equal.  Defaults = the in-box A/B of round 3
+// (profiles/r03_notes.md, tools/tile_ab.py): 64x128 and 128x64 -> PF 2 + AF (ids 13 / 15: +6 ... +8 % over PF 2 alone, which
+// round 2 measured at +5 % over the base tile); 128x128 -> PF 1 + AF (id 16: its PF 2 forms lose occupancy - 168 registers - on
+// the multi-workgroup grids it is picked for).  FSV_CONV_V<shape>=<id> overrides one shape (A/B runs).
+static inline int fsv_conv_variant(int shape) {
+  static int map[10] = {-2, -2, -2, -2, -2, -2, -2, -2, -2, -2};
+  if (shape < 0 || shape > 9) return shape;
+  if (map[shape] == -2) {
+    static const int dflt[10] = {16, 15, 18, -1, 17, -1, -1, -1, -1, 13};
+    char name[16];
+    snprintf(name, sizeof(name), "FSV_CONV_V%d", shape);
+    const char* e = getenv(name);
+    map[shape] = e ? atoi(e) : dflt[shape];
+    if (map[shape] < 0) map[shape] = shape;
+  }
+  return map[shape];
 }
 
 static int fsv_launch_conv(const ConvP& p, bool vec4, int nz, hipStream_t stream, int tile) {
@@ -1193,13 +1200,17 @@ static int fsv_launch_conv(const ConvP& p, bool vec4, int nz, hipStream_t stream
       case 10: FSV_LAUNCH((fsv_conv_igemm_kernel<64, 128, 2, 4, 2>), g, dim3(512), stream, p); break;
       case 11: FSV_LAUNCH((fsv_conv_igemm_kernel<128, 128, 2, 4, 2>), g, dim3(512), stream, p); break;
       case 12: FSV_LAUNCH((fsv_conv_igemm_kernel<128, 64, 4, 2, 2>), g, dim3(512), stream, p); break;
-      case 13: FSV_LAUNCH((fsv_conv_igemm_kernel<64, 128, 2, 4, 3>), g, dim3(512), stream, p); break;
-      case 14: FSV_LAUNCH((fsv_conv_igemm_kernel<128, 128, 2, 4, 3>), g, dim3(512), stream, p); break;
-      case 15: FSV_LAUNCH((fsv_conv_igemm_kernel<128, 64, 4, 2, 3>), g, dim3(512), stream, p); break;
+      case 13: FSV_LAUNCH((fsv_conv_igemm_kernel<64, 128, 2, 4, 2, true>), g, dim3(512), stream, p); break;
+      case 14: FSV_LAUNCH((fsv_conv_igemm_kernel<128, 128, 2, 4, 2, true>), g, dim3(512), stream, p); break;
+      case 15: FSV_LAUNCH((fsv_conv_igemm_kernel<128, 64, 4, 2, 2, true>), g, dim3(512), stream, p); break;
+      case 16: FSV_LAUNCH((fsv_conv_igemm_kernel<128, 128, 2, 4, 1, true>), g, dim3(512), stream, p); break;
+      case 17: FSV_LAUNCH((fsv_conv_igemm_kernel<64, 64, 2, 2, 1, true>), g, dim3(256), stream, p); break;
+      case 18: FSV_LAUNCH((fsv_conv_igemm_kernel<128, 32, 4, 1, 1, true>), g, dim3(256), stream, p); break;
       default: FSV_LAUNCH((fsv_conv_igemm_kernel<64, 128, 2, 4>), g, dim3(512), stream, p); break;
     }
   } else {
-    if (tile == 10 || tile == 13) tile = 9; else if (tile == 11 || tile == 14) tile = 0; else if (tile == 12 || tile == 15) tile = 1;     // scalar gather: no PF variants
+    if (tile == 10 || tile == 13) tile = 9; else if (tile == 11 || tile == 14 || tile == 16) tile = 0; else if (tile == 12 || tile == 15) tile = 1;     // scalar gather: no variants
+    else if (tile == 17) tile = 4; else if (tile == 18) tile = 2;
     switch (tile) {
       case 0: FSV_LAUNCH((fsv_conv_igemm_v1_kernel<128, 128, 2, 2>), g, dim3(256), stream, p); break;
       case 1: FSV_LAUNCH((fsv_conv_igemm_v1_kernel<128, 64, 2, 2>), g, dim3(256), stream, p); break;
@@ -1374,10 +1385,7 @@ static int fsv_conv_gather_impl(const float* in, const float* wt, const float* b
     if (produced) *produced = 1;
   }
   // the plan's 8-wave tiles run as their prefetch-distance-2 variants (a forced tile id is taken literally)
-  if (force_tile < 0 && vec4 && fsv_conv_pf2()) {
-    const int base = fsv_conv_midbar() ? 13 : 10;
-    tile = (tile == 9) ? base : (tile == 0) ? base + 1 : (tile == 1) ? base + 2 : tile;
-  }
+  if (force_tile < 0 && vec4) tile = fsv_conv_variant(tile);
   int rc = fsv_launch_conv(p, vec4, nsamp * nsplit, stream, tile);
   if (rc) return rc;
   if (!accumulate && nsplit > 1 && (bias || res || act != FSV_ACT_NONE || scale != 1.f)) {
@@ -1588,7 +1596,7 @@ int fsv_conv_gather_group(const fsv_conv_desc* d, int n, int force_tile, hipStre
     }
     if (tile < 0) tile = 4;
   }
-  if (tile >= 10) tile = (tile == 10 || tile == 13) ? 9 : (tile == 11 || tile == 14) ? 0 : 1;
+  if (tile >= 10) tile = (tile == 10 || tile == 13) ? 9 : (tile == 11 || tile == 14 || tile == 16) ? 0 : (tile == 17) ? 4 : (tile == 18) ? 2 : 1;
   int bm, bn;
   if (fsv_tile_dims(tile, bm, bn)) return FSV_ERR_BAD_ARG;
   // K splits: only problems that accumulate into a zeroed output, and only when the whole group would leave CUs idle
@@ -1610,8 +1618,7 @@ int fsv_conv_gather_group(const fsv_conv_desc* d, int n, int force_tile, hipStre
   }
   int order[FSV_GROUP_LIMIT];
   fsv_group_order(weight, n, order);
-  const bool pf2 = vec4 && fsv_conv_pf2();
-  const bool mid = pf2 && fsv_conv_midbar();
+  const int variant = vec4 ? fsv_conv_variant(tile) : tile;
   for (int b0 = 0; b0 < n; b0 += FSV_GROUP_MAX) {
     ConvGroup g;
     g.nprob = (n - b0 < FSV_GROUP_MAX) ? (n - b0) : FSV_GROUP_MAX;
@@ -1628,24 +1635,22 @@ int fsv_conv_gather_group(const fsv_conv_desc* d, int n, int force_tile, hipStre
     }
     const dim3 grid(tiles);
     if (vec4) {
-      switch (tile) {
-        case 0:
-          if (mid) FSV_LAUNCH((fsv_conv_igemm_group_kernel<128, 128, 2, 4, 3>), grid, dim3(512), stream, g);
-          else if (pf2) FSV_LAUNCH((fsv_conv_igemm_group_kernel<128, 128, 2, 4, 2>), grid, dim3(512), stream, g);
-          else FSV_LAUNCH((fsv_conv_igemm_group_kernel<128, 128, 2, 4>), grid, dim3(512), stream, g);
-          break;
-        case 1:
-          if (mid) FSV_LAUNCH((fsv_conv_igemm_group_kernel<128, 64, 4, 2, 3>), grid, dim3(512), stream, g);
-          else if (pf2) FSV_LAUNCH((fsv_conv_igemm_group_kernel<128, 64, 4, 2, 2>), grid, dim3(512), stream, g);
-          else FSV_LAUNCH((fsv_conv_igemm_group_kernel<128, 64, 4, 2>), grid, dim3(512), stream, g);
-          break;
+      switch (variant) {
+        case 0: FSV_LAUNCH((fsv_conv_igemm_group_kernel<128, 128, 2, 4>), grid, dim3(512), stream, g); break;
+        case 1: FSV_LAUNCH((fsv_conv_igemm_group_kernel<128, 64, 4, 2>), grid, dim3(512), stream, g); break;
         case 2: FSV_LAUNCH((fsv_conv_igemm_group_kernel<128, 32, 4, 1>), grid, dim3(256), stream, g); break;
         case 4: FSV_LAUNCH((fsv_conv_igemm_group_kernel<64, 64, 2, 2>), grid, dim3(256), stream, g); break;
-        default:
-          if (mid) FSV_LAUNCH((fsv_conv_igemm_group_kernel<64, 128, 2, 4, 3>), grid, dim3(512), stream, g);
-          else if (pf2) FSV_LAUNCH((fsv_conv_igemm_group_kernel<64, 128, 2, 4, 2>), grid, dim3(512), stream, g);
-          else FSV_LAUNCH((fsv_conv_igemm_group_kernel<64, 128, 2, 4>), grid, dim3(512), stream, g);
-          break;
+        case 9: FSV_LAUNCH((fsv_conv_igemm_group_kernel<64, 128, 2, 4>), grid, dim3(512), stream, g); break;
+        case 10: FSV_LAUNCH((fsv_conv_igemm_group_kernel<64, 128, 2, 4, 2>), grid, dim3(512), stream, g); break;
+        case 11: FSV_LAUNCH((fsv_conv_igemm_group_kernel<128, 128, 2, 4, 2>), grid, dim3(512), stream, g); break;
+        case 12: FSV_LAUNCH((fsv_conv_igemm_group_kernel<128, 64, 4, 2, 2>), grid, dim3(512), stream, g); break;
+        case 13: FSV_LAUNCH((fsv_conv_igemm_group_kernel<64, 128, 2, 4, 2, true>), grid, dim3(512), stream, g); break;
+        case 14: FSV_LAUNCH((fsv_conv_igemm_group_kernel<128, 128, 2, 4, 2, true>), grid, dim3(512), stream, g); break;
+        case 15: FSV_LAUNCH((fsv_conv_igemm_group_kernel<128, 64, 4, 2, 2, true>), grid, dim3(512), stream, g); break;
+        case 16: FSV_LAUNCH((fsv_conv_igemm_group_kernel<128, 128, 2, 4, 1, true>), grid, dim3(512), stream, g); break;
+        case 17: FSV_LAUNCH((fsv_conv_igemm_group_kernel<64, 64, 2, 2, 1, true>), grid, dim3(256), stream, g); break;
+        case 18: FSV_LAUNCH((fsv_conv_igemm_group_kernel<128, 32, 4, 1, 1, true>), grid, dim3(256), stream, g); break;
+        default: return FSV_ERR_BAD_ARG;
       }
     } else {
       switch (tile) {

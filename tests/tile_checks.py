@@ -27,7 +27,9 @@ GEOMS = [(2, 8, 9, 11, 40, 3, 1, 1),          # K = 72 (tail chunk), ragged M an
 FWD_TILES = (0, 1, 2, 4, 9)
 # force_tile-only variants that the launch plan never picks (prefetch distance 2, csrc/conv_igemm.hip): checked on the emulator
 # only until they have been measured on hardware; (variant, the plan's tile with the same dimensions)
-EXPERIMENTAL_FWD_TILES = ((10, 9), (11, 0), (12, 1), (13, 9), (14, 0), (15, 1))      # 13 - 15: barrier in the middle of the chunk
+# kernel variants of the plan's tile shapes (csrc/conv_igemm.hip fsv_conv_variant): 10 - 12 prefetch distance 2, 13 - 15 the same with
+# in-place A fragments, 16 - 18 in-place A fragments on the prefetch-distance-1 tiles; (variant, the base tile of the same shape)
+EXPERIMENTAL_FWD_TILES = ((10, 9), (11, 0), (12, 1), (13, 9), (14, 0), (15, 1), (16, 0), (17, 4), (18, 2))
 WGRAD_TILES = (0, 1, 2, 3, 4)
 
 
@@ -50,7 +52,7 @@ def _fwd_case(device, geom, tile, split, seed):
 def check_forward_tiles(device, tiles=FWD_TILES, geoms=GEOMS):
     for gi, geom in enumerate(geoms):
         for tile in tiles:
-            bn = {0: 128, 1: 64, 2: 32, 4: 64, 9: 128, 10: 128, 11: 128, 12: 64, 13: 128, 14: 128, 15: 64}[tile]
+            bn = {0: 128, 1: 64, 2: 32, 4: 64, 9: 128, 10: 128, 11: 128, 12: 64, 13: 128, 14: 128, 15: 64, 16: 128, 17: 64, 18: 32}[tile]
             if geom[4] < bn // 2 and bn > 32:
                 continue                       # a tile twice as wide as the layer: not a configuration the plan can produce
             for split in (1, 3):
@@ -112,11 +114,11 @@ def run_all(device):
     check_forward_tiles(device)
     check_per_sample(device)
     check_wgrad_tiles(device)
-    # the prefetch-distance-2 tiles (10 - 12: what the plan's 9 / 0 / 1 run as) and the in-place-fragment tiles (13 - 15):
-    # against F.conv2d and bit-equal to the plan's tile of the same shape
+    # the kernel variants the plan's shapes run as: against F.conv2d and (unsplit: split launches add through atomics, whose
+    # order is not reproducible on hardware) bit-equal to the base tile of the same shape
     for variant, base in EXPERIMENTAL_FWD_TILES:
         check_forward_tiles(device, tiles=(variant,))
-        check_variant_equals_plan_tile(device, variant, base, splits=(1, 3))
+        check_variant_equals_plan_tile(device, variant, base, splits=(1,))
 
 
 if __name__ == '__main__':

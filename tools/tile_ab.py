@@ -12,7 +12,7 @@ conv = import_module('few-shot-vid2vid_amd.conv')
 dev = torch.device('cuda:0')
 # FSV_AB_EXPERIMENTAL=1 adds the force_tile-only variants (10 / 11 / 12: 64x128 / 128x128 / 128x64 with a prefetch distance of two
 # chunks) next to the tiles of the plan
-EXPERIMENTAL = (10, 11, 12, 13, 14, 15) if os.environ.get('FSV_AB_EXPERIMENTAL', '0') == '1' else ()      # 13 - 15: mid-chunk barrier
+EXPERIMENTAL = (10, 11, 12, 13, 14, 15, 16, 17, 18) if os.environ.get('FSV_AB_EXPERIMENTAL', '0') == '1' else ()      # 13 - 15: mid-chunk barrier
 cfgs = [(-1, 0)] + [(t_, s_) for t_ in (0, 1, 2, 4, 9) + EXPERIMENTAL for s_ in (1, 2, 4, 8)]
 shapes = [('M8192 N256 K2304', 2, 256, 64, 64, 256, 3), ('M32768 N128 K576', 2, 64, 128, 128, 128, 3),
           ('M32768 N128 K1152', 2, 128, 128, 128, 128, 3), ('M32768 N128 K2304', 2, 256, 128, 128, 128, 3),
@@ -26,7 +26,10 @@ shapes = [('M8192 N256 K2304', 2, 256, 64, 64, 256, 3), ('M32768 N128 K576', 2, 
           ('M32768 N128 K4608', 2, 512, 128, 128, 128, 3), ('M512 N1024 K9216', 2, 1024, 16, 16, 1024, 3),
           # awkward workgroup counts (discriminator 33 x 66 / 17 x 34 maps, k4 s1 p2)
           ('M4356 N256 K8192', 2, 512, 32, 65, 256, 4), ('M4624 N512 K4096', 2, 256, 33, 67, 512, 4),
-          ('M2048 N512 K9216', 2, 1024, 32, 32, 512, 3)]
+          ('M2048 N512 K9216', 2, 1024, 32, 32, 512, 3),
+          # full-resolution thin layers (Cout 32)
+          ('M524288 N32 K576', 2, 64, 512, 512, 32, 3), ('M524288 N32 K288', 2, 32, 512, 512, 32, 3),
+          ('M131072 N32 K128', 2, 128, 256, 256, 32, 1)]
 if len(sys.argv) > 1:
     shapes = [s for s in shapes if any(a in s[0] for a in sys.argv[1:])]
 NREP = 20
@@ -38,7 +41,7 @@ for name, n, cin, h, w, cout, k in shapes:
     flops = 2.0 * n * h * w * cout * cin * k * k
     graphs = {}
     for c in cfgs:
-        if c[0] in (0, 9, 10, 11, 13, 14) and cout < 128 or c[0] in (1, 12, 15) and cout < 64 or c[0] == 2 and cout > 32:
+        if c[0] in (0, 9, 10, 11, 13, 14, 16) and cout < 128 or c[0] in (1, 12, 15) and cout < 64 or c[0] in (2, 18) and cout > 32:
             continue
         f = lambda: conv.conv_forward(x, wf, ldw, cout, g, bias=b, act=conv.ACT_LRELU, force_tile=c[0], force_split=c[1])
         s = torch.cuda.Stream(); s.wait_stream(torch.cuda.current_stream())
