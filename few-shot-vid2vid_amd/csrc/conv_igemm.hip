@@ -157,7 +157,8 @@ __device__ __forceinline__ void fsv_conv_igemm_body(const ConvP& p, const int bx
       float4 v = ar[i];
       if constexpr (AF) {
         const bool hi = (r >> 4) & 1;
-        v = hi ? make_float4(ar[i].y, ar[i].w, ar[i].x, ar[i].z) : make_float4(ar[i].x, ar[i].z, ar[i].y, ar[i].w);
+        v.x = hi ? ar[i].y : ar[i].x; v.y = hi ? ar[i].w : ar[i].z;
+        v.z = hi ? ar[i].x : ar[i].y; v.w = hi ? ar[i].z : ar[i].w;
       }
       *reinterpret_cast<float4*>(&a_dst[r * BK + ((kq ^ ((r >> 1) & 7)) << 2)]) = v;
     }

@@ -186,7 +186,13 @@ __global__ __launch_bounds__(256, 2) void fsv_spade_mod_kernel(SpadeP p) {
 #pragma unroll
     for (int i = 0; i < NPA; ++i) {
       const int r = ar0 + i * RPA;
-      *reinterpret_cast<float4*>(&a_dst[r * BK + ((kq ^ ((r >> 1) & 7)) << 2)]) = areg[i];
+      // quad (k0 k1 k2 k3) stored as (k0 k2 | k1 k3), rows with bit 4 set as (k1 k3 | k0 k2): a lane reads the two values its
+      // MFMA steps need with one ds_read_b64, no select between the MFMAs (conv_igemm.hip, AF)
+      const bool hi = (r >> 4) & 1;
+      float4 v;
+      v.x = hi ? areg[i].y : areg[i].x; v.y = hi ? areg[i].w : areg[i].z;
+      v.z = hi ? areg[i].x : areg[i].y; v.w = hi ? areg[i].z : areg[i].w;
+      *reinterpret_cast<float4*>(&a_dst[r * BK + ((kq ^ ((r >> 1) & 7)) << 2)]) = v;
     }
 #pragma unroll
     for (int q = 0; q < NB; ++q)
@@ -213,19 +219,19 @@ __global__ __launch_bounds__(256, 2) void fsv_spade_mod_kernel(SpadeP p) {
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
     const int r = wm * (TM * 32) + i * 32 + lrow;
-    a_off[i] = r * BK;
+    a_off[i] = r * BK + 2 * (lk ^ ((r >> 4) & 1));        // this lane's half of every quad
     a_swz[i] = (r >> 1) & 7;
   }
   const int b_off = lk * BN + wn * (TN * 32) + lrow;
 
   // fragments of one k-group (8 k): two quads of A per row tile, four B values per (image, column tile); read one group ahead
   // of their MFMAs and pinned there with scheduling fences (conv_igemm.hip)
-  auto read_group = [&](const float* a_src, const float* b_src, int g, float4 (&a4)[2][TM], float (&b)[4][NB][TN]) {
+  auto read_group = [&](const float* a_src, const float* b_src, int g, float2 (&a4)[2][TM], float (&b)[4][NB][TN]) {
 #pragma unroll
     for (int q = 0; q < 2; ++q)
 #pragma unroll
       for (int i = 0; i < TM; ++i)
-        a4[q][i] = *reinterpret_cast<const float4*>(&a_src[a_off[i] + (((2 * g + q) ^ a_swz[i]) << 2)]);
+        a4[q][i] = *reinterpret_cast<const float2*>(&a_src[a_off[i] + (((2 * g + q) ^ a_swz[i]) << 2)]);
 #pragma unroll
     for (int s4 = 0; s4 < 4; ++s4)
 #pragma unroll
@@ -233,13 +239,13 @@ __global__ __launch_bounds__(256, 2) void fsv_spade_mod_kernel(SpadeP p) {
 #pragma unroll
         for (int j = 0; j < TN; ++j) b[s4][q][j] = b_src[q * B_ST + b_off + (8 * g + 2 * s4) * BN + j * 32];
   };
-  auto mma_group = [&](const float4 (&a4)[2][TM], const float (&b)[4][NB][TN]) {
+  auto mma_group = [&](const float2 (&a4)[2][TM], const float (&b)[4][NB][TN]) {
 #pragma unroll
     for (int s4 = 0; s4 < 4; ++s4)
 #pragma unroll
       for (int i = 0; i < TM; ++i) {
-        const float4 v = a4[s4 >> 1][i];
-        const float a = (s4 & 1) ? (lk ? v.w : v.z) : (lk ? v.y : v.x);
+        const float2 v = a4[s4 >> 1][i];
+        const float a = (s4 & 1) ? v.y : v.x;
 #pragma unroll
         for (int q = 0; q < NB; ++q)
 #pragma unroll
@@ -296,7 +302,7 @@ __global__ __launch_bounds__(256, 2) void fsv_spade_mod_kernel(SpadeP p) {
       const float* b_src = Bs + buf * (NB * B_ST);
       if constexpr (NS == 1 && !BWD) {
         // fragments one k-group ahead of their MFMAs (two register sets)
-        float4 fa[2][2][TM];
+        float2 fa[2][2][TM];
         float fb[2][4][NB][TN];
         read_group(a_src, b_src, 0, fa[0], fb[0]);
         FSV_SCHED_FENCE();
@@ -318,7 +324,7 @@ __global__ __launch_bounds__(256, 2) void fsv_spade_mod_kernel(SpadeP p) {
       } else {
         // the two-site / backward forms carry 64 - 144 more live registers (four accumulators, or g_k / o_k of three maps):
         // one fragment set, two workgroups per CU cover each other's LDS latency
-        float4 fa[2][TM];
+        float2 fa[2][TM];
         float fb[4][NB][TN];
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
