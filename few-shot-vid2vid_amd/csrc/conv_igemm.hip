@@ -10,8 +10,10 @@
 //
 // Layout: activations NHWC (channels contiguous) so the K dimension of the GEMM is contiguous in HBM;
 // weights are pre-arranged K-major ([K_pad][ldw]) by fsv_prep_weight (which also applies the spectral-norm
-// 1/sigma).  Tiles are staged through LDS: A is stored transposed ([k][m], row stride BM+1) so that the MFMA
-// A-fragment read (32 consecutive m per half-wave) and the staging writes are both bank-conflict free.
+// 1/sigma).  Tiles are staged through two LDS buffers (one barrier per 32-wide K chunk): A as [row][8 quads of 4 k] with the
+// quads XOR-swizzled by the row (ds_write_b128 stores; fragments read with ds_read_b128 + a per-MFMA select, or - the AF
+// variants every tile shape runs as since round 3 - as a re-ordered quad read in place with ds_read_b64), B as [k][n] as it
+// lies in HBM; the scalar-gather twin (Cin % 4 != 0) keeps round 1's transposed [k][m] image.  Details at the kernels below.
 // The MFMA result is bitwise an fp32 fma chain (guide section 3), which is what lets the parity tests use a
 // 1e-3 relative tolerance against the fp32 CPU oracle with a wide margin.
 #include <stdlib.h>

@@ -120,6 +120,31 @@ __global__ __launch_bounds__(256) void fsv_resample2d_kernel(const float* img, c
   }
 }
 
+// Bilinear resize, align_corners = False - F.interpolate(mode='bilinear') as FlowNet2 uses it (models.py:119,137-142 x4 flow
+// up-sampling; models/flownet.py:66-77 resize to a multiple of 64 and back).  ATen's op sequence (UpSample.h
+// area_pixel_compute_source_index: src = scale * (dst + 0.5) - 0.5 clamped at 0, scale = in / out; UpSampleBilinear2d.cu: the
+// four taps weighted (1 - l) / l in float, h-major), one work-item per output element, explicit (n, c, y, x) strides.
+__global__ __launch_bounds__(256) void fsv_bilinear_resize_kernel(const float* in, float* out, int N, int C, int IH, int IW,
+                                                                  int OH, int OW, float rh, float rw, Str4 is_, Str4 os_) {
+  const long long* is = is_.v;
+  const long long* os = os_.v;
+  const long long total = (long long)N * C * OH * OW;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int x = (int)(i % OW), y = (int)((i / OW) % OH), c = (int)((i / ((long long)OW * OH)) % C);
+    const int n = (int)(i / ((long long)OW * OH * C));
+    float sy = rh * ((float)y + 0.5f) - 0.5f, sx = rw * ((float)x + 0.5f) - 0.5f;
+    sy = sy < 0.f ? 0.f : sy; sx = sx < 0.f ? 0.f : sx;
+    const int y0 = (int)sy, x0 = (int)sx;
+    const int y1 = y0 + (y0 < IH - 1 ? 1 : 0), x1 = x0 + (x0 < IW - 1 ? 1 : 0);
+    const float ly = sy - (float)y0, lx = sx - (float)x0;
+    const float hy = 1.f - ly, hx = 1.f - lx;
+    const float* b = in + n * is[0] + c * is[1];
+    const float v = hy * (hx * b[y0 * is[2] + x0 * is[3]] + lx * b[y0 * is[2] + x1 * is[3]]) +
+                    ly * (hx * b[y1 * is[2] + x0 * is[3]] + lx * b[y1 * is[2] + x1 * is[3]]);
+    out[n * os[0] + c * os[1] + y * os[2] + x * os[3]] = v;
+  }
+}
+
 // Correctly rounded float square root from basic IEEE operations: the device sqrt (float and, as measured on gfx950, the
 // float rounding of the double one) can be 1 ulp off the CPU / CUDA result.  y is within 1 ulp; the midpoints to its
 // neighbours have 25 significant bits, so their squares are exact in double and decide the rounding.
@@ -178,6 +203,19 @@ int fsv_resample2d_fwd(const float* img, const float* flow, float* out, int N, i
   long long g = ((long long)N * C * H * W + 255) / 256;
   if (g > 8192) g = 8192;
   FSV_LAUNCH(fsv_resample2d_kernel, dim3((unsigned)g), dim3(256), stream, img, flow, out, N, C, H, W, is, fs, os);
+  return fsv_check_launch();
+}
+
+int fsv_bilinear_resize_fwd(const float* in, float* out, int N, int C, int IH, int IW, int OH, int OW,
+                            const long long* in_strides, const long long* out_strides, hipStream_t stream) {
+  if (!in || !out || N < 1 || C < 1 || IH < 1 || IW < 1 || OH < 1 || OW < 1 || !in_strides || !out_strides) return FSV_ERR_BAD_ARG;
+  Str4 is, os;
+  for (int k = 0; k < 4; ++k) { is.v[k] = in_strides[k]; os.v[k] = out_strides[k]; }
+  long long g = ((long long)N * C * OH * OW + 255) / 256;
+  if (g > 8192) g = 8192;
+  // ATen computes the scale in float as (float)in / out
+  FSV_LAUNCH(fsv_bilinear_resize_kernel, dim3((unsigned)g), dim3(256), stream, in, out, N, C, IH, IW, OH, OW,
+             (float)IH / (float)OH, (float)IW / (float)OW, is, os);
   return fsv_check_launch();
 }
 

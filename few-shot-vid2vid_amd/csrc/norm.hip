@@ -324,38 +324,9 @@ __global__ __launch_bounds__(256) void fsv_norm_apply4_kernel(const float* x, co
   }
 }
 
-// Unrolled form (round 3): a block owns 256 * U consecutive float4; every work-item issues its U loads of x (256 float4 apart:
-// coalesced) before it touches the first one.  The grid-stride form above keeps ONE 16-byte load in flight per work-item and
-// measured 2.65 TB/s on a 67 MB tensor (rocprofv3, profiles/r03_notes.md) where the Adam kernel - four independent streams per
-// element - reaches 5.9 TB/s.
-template <int U>
-__global__ __launch_bounds__(256) void fsv_norm_apply4u_kernel(const float* x, const float* mean, const float* rstd,
-                                                               const float* w, const float* b, float* y, unsigned total4,
-                                                               unsigned PC4, unsigned C4, int act) {
-  const unsigned base = blockIdx.x * (256u * U) + threadIdx.x;
-  float4 xv[U];
-#pragma unroll
-  for (int k = 0; k < U; ++k) {
-    const unsigned i = base + k * 256u;
-    xv[k] = i < total4 ? *reinterpret_cast<const float4*>(x + (size_t)i * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
-  }
-#pragma unroll
-  for (int k = 0; k < U; ++k) {
-    const unsigned i = base + k * 256u;
-    if (i >= total4) continue;
-    const unsigned c = (i % C4) * 4u, g = i / PC4;
-    const unsigned gc = g * C4 * 4u + c;
-    const float4 mu = *reinterpret_cast<const float4*>(mean + gc), rs = *reinterpret_cast<const float4*>(rstd + gc);
-    float4 v = make_float4((xv[k].x - mu.x) * rs.x, (xv[k].y - mu.y) * rs.y, (xv[k].z - mu.z) * rs.z, (xv[k].w - mu.w) * rs.w);
-    if (w) {
-      const float4 wv = *reinterpret_cast<const float4*>(w + c), bv = *reinterpret_cast<const float4*>(b + c);
-      v = make_float4(v.x * wv.x + bv.x, v.y * wv.y + bv.y, v.z * wv.z + bv.z, v.w * wv.w + bv.w);
-    }
-    *reinterpret_cast<float4*>(y + (size_t)i * 4) = make_float4(fsv_act(v.x, act), fsv_act(v.y, act), fsv_act(v.z, act),
-                                                                fsv_act(v.w, act));
-  }
-}
-
+// (Round 3 tried a form with four 16-byte loads in flight per work-item - a block owning 1024 consecutive float4 - for this
+// kernel and its backward twin: 213 vs 183 us for a forward + backward pair on a 67 MB tensor, +0.4 ms on the step, in-box;
+// profiles/r03_notes.md.  The grid-stride form stays.)
 // s1[g][c], s2[g][c]; optional affine grads dw[c] = sum_g s2, db[c] = sum_g s1 (one thread per channel)
 __global__ __launch_bounds__(256) void fsv_norm_bwd_final_kernel(const double* part, float* s1, float* s2, float* dw,
                                                                  float* db, int G, int C, int nchunks) {
@@ -421,47 +392,6 @@ __global__ __launch_bounds__(256) void fsv_norm_bwd_apply4_kernel(const float* d
       r[j] = fixed_stats ? wv * rs * d : wv * rs * (d - s1[gc + j] * invP - xh * (s2[gc + j] * invP));
     }
     *reinterpret_cast<float4*>(dx + o) = make_float4(r[0], r[1], r[2], r[3]);
-  }
-}
-
-// unrolled form (see fsv_norm_apply4u_kernel): the U x 3 loads of dy / y / x are in flight together
-template <int U>
-__global__ __launch_bounds__(256) void fsv_norm_bwd_apply4u_kernel(const float* dy, const float* y, const float* x,
-                                                                   const float* mean, const float* rstd, const float* w,
-                                                                   const float* s1, const float* s2, float* dx,
-                                                                   unsigned total4, unsigned PC4, unsigned C4, int P, int act,
-                                                                   int fixed_stats) {
-  const unsigned base = blockIdx.x * (256u * U) + threadIdx.x;
-  const float invP = 1.0f / (float)P;
-  const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
-  float4 xv[U], dv[U], yv[U];
-#pragma unroll
-  for (int k = 0; k < U; ++k) {
-    const unsigned i = base + k * 256u;
-    const bool ok = i < total4;
-    const size_t o = (size_t)(ok ? i : 0) * 4;
-    xv[k] = ok ? *reinterpret_cast<const float4*>(x + o) : z4;
-    dv[k] = ok ? *reinterpret_cast<const float4*>(dy + o) : z4;
-    yv[k] = (ok && y) ? *reinterpret_cast<const float4*>(y + o) : z4;
-  }
-#pragma unroll
-  for (int k = 0; k < U; ++k) {
-    const unsigned i = base + k * 256u;
-    if (i >= total4) continue;
-    const unsigned c = (i % C4) * 4u, g = i / PC4;
-    const unsigned gc = g * C4 * 4u + c;
-    const float xa[4] = {xv[k].x, xv[k].y, xv[k].z, xv[k].w}, da[4] = {dv[k].x, dv[k].y, dv[k].z, dv[k].w},
-                ya[4] = {yv[k].x, yv[k].y, yv[k].z, yv[k].w};
-    float r[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const float rs = rstd[gc + j];
-      const float xh = (xa[j] - mean[gc + j]) * rs;
-      const float d = fsv_act_grad(da[j], ya[j], act);
-      const float wv = w ? w[c + j] : 1.f;
-      r[j] = fixed_stats ? wv * rs * d : wv * rs * (d - s1[gc + j] * invP - xh * (s2[gc + j] * invP));
-    }
-    *reinterpret_cast<float4*>(dx + (size_t)i * 4) = make_float4(r[0], r[1], r[2], r[3]);
   }
 }
 
@@ -616,20 +546,10 @@ static inline bool fsv_ew_vec4(long long total, int C) {
   return on && C % 4 == 0 && total < (1LL << 31);
 }
 
-// FSV_EW_UNROLL=0 (read at every call: in-process A/B, tools/ew_ab.py): the grid-stride forms of the normalisation apply kernels
-static inline bool fsv_ew_unroll() {
-  const char* e = getenv("FSV_EW_UNROLL");
-  return !(e && e[0] == '0');
-}
-
 static inline void fsv_launch_bwd_apply(const float* dy, const float* y, const float* x, const float* mean, const float* rstd,
                                         const float* w, const float* s1, const float* s2, float* dx, long long total,
                                         long long PC, int C, int P, int act, int fixed_stats, hipStream_t stream) {
-  if (fsv_ew_vec4(total, C) && fsv_ew_unroll()) {
-    const unsigned t4 = (unsigned)(total / 4);
-    FSV_LAUNCH((fsv_norm_bwd_apply4u_kernel<2>), dim3((t4 + 511u) / 512u), dim3(256), stream, dy, y, x, mean, rstd, w, s1, s2, dx,
-               t4, (unsigned)(PC / 4), (unsigned)(C / 4), P, act, fixed_stats);
-  } else if (fsv_ew_vec4(total, C)) {
+  if (fsv_ew_vec4(total, C)) {
     FSV_LAUNCH(fsv_norm_bwd_apply4_kernel, dim3(fsv_ew_grid(total / 4)), dim3(256), stream, dy, y, x, mean, rstd, w, s1, s2, dx,
                (unsigned)(total / 4), (unsigned)(PC / 4), (unsigned)(C / 4), P, act, fixed_stats);
   } else {
@@ -642,11 +562,7 @@ int fsv_norm_apply(const float* x, const float* mean, const float* rstd, const f
                    int G, int P, int C, int act, hipStream_t stream) {
   if (!x || !mean || !rstd || !y || (w && !b)) return FSV_ERR_BAD_ARG;
   long long total = (long long)G * P * C;
-  if (fsv_ew_vec4(total, C) && fsv_ew_unroll()) {
-    const unsigned t4 = (unsigned)(total / 4);
-    FSV_LAUNCH((fsv_norm_apply4u_kernel<4>), dim3((t4 + 1023u) / 1024u), dim3(256), stream, x, mean, rstd, w, b, y, t4,
-               (unsigned)((long long)P * C / 4), (unsigned)(C / 4), act);
-  } else if (fsv_ew_vec4(total, C)) {
+  if (fsv_ew_vec4(total, C)) {
     FSV_LAUNCH(fsv_norm_apply4_kernel, dim3(fsv_ew_grid(total / 4)), dim3(256), stream, x, mean, rstd, w, b, y,
                (unsigned)(total / 4), (unsigned)((long long)P * C / 4), (unsigned)(C / 4), act);
   } else {

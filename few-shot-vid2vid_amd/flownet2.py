@@ -19,9 +19,9 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from . import lib
+from . import lib, ops
 from .conv import (ACT_LRELU01, ACT_NONE, Geom, conv_dgrad, gather_gemm, prep_weight, to_nhwc)
-from .flownet_ops import channelnorm, correlation, resample2d
+from .flownet_ops import bilinear_resize, channelnorm, correlation, resample2d
 
 
 def _pad4(t, dim):
@@ -352,7 +352,10 @@ class FlowNet2(nn.Module):
         x = (inputs - rgb_mean) / self.rgb_max
         x = torch.cat((x[:, :, 0], x[:, :, 1]), dim=1)
         img0, img1 = x[:, :3], x[:, 3:]
-        up = lambda t, mode: F.interpolate(t, scale_factor=4, mode=mode)
+        def up(t, mode):            # nn.Upsample(scale_factor=4, mode=...) of models.py:119-120, on the HIP kernels
+            if mode == 'bilinear':
+                return bilinear_resize(t, scale_factor=4)
+            return ops.upsample2x(ops.upsample2x(t))          # nearest x4 = nearest x2 twice
 
         def stage(flow):                                 # models.py:127-135
             warped = resample2d(img1, flow)
@@ -402,12 +405,12 @@ class FlowNet(nn.Module):
         old_h, old_w = im1.shape[2:]
         new_h, new_w = old_h // 64 * 64, old_w // 64 * 64
         if old_h != new_h:                               # (the reference tests the height only, flownet.py:66)
-            im1 = F.interpolate(im1, size=(new_h, new_w), mode='bilinear')
-            im2 = F.interpolate(im2, size=(new_h, new_w), mode='bilinear')
+            im1 = bilinear_resize(im1, size=(new_h, new_w))
+            im2 = bilinear_resize(im2, size=(new_h, new_w))
         flow1 = self.flowNet(torch.cat([im1.unsqueeze(2), im2.unsqueeze(2)], dim=2))
         diff = im1 - resample2d(im2, flow1)
         conf = (torch.sum(diff * diff, dim=1, keepdim=True) < 0.02).float()
         if old_h != new_h:
-            flow1 = F.interpolate(flow1, size=(old_h, old_w), mode='bilinear') * old_h / new_h
-            conf = F.interpolate(conf, size=(old_h, old_w), mode='bilinear')
+            flow1 = bilinear_resize(flow1, size=(old_h, old_w)) * old_h / new_h
+            conf = bilinear_resize(conf, size=(old_h, old_w))
         return flow1, conf

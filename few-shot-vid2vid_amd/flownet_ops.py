@@ -19,6 +19,7 @@ lib.register_sigs({
     "fsv_correlation_fwd": [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p],
     "fsv_resample2d_fwd": [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_llp, c_llp, c_llp, c_p],
     "fsv_channelnorm_fwd": [c_p, c_p, c_i, c_i, c_ll, c_ll, c_ll, c_ll, c_p],
+    "fsv_bilinear_resize_fwd": [c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_llp, c_llp, c_p],
 })
 
 
@@ -58,6 +59,18 @@ def resample2d(img, flow):
     lib.check_device(img, flow)
     lib.call("fsv_resample2d_fwd", lib.ptr(img), lib.ptr(flow), lib.ptr(out), n, c, h, w, _ll4(img), _ll4(flow), _ll4(out),
              lib.stream_ptr())
+    return out
+
+
+def bilinear_resize(x, size=None, scale_factor=None):
+    """F.interpolate(x, size / scale_factor, mode='bilinear') with align_corners=False (the default the reference relies on:
+    flownet2_pytorch/models.py:119 `nn.Upsample(scale_factor=4, mode='bilinear')`, models/flownet.py:66-77)"""
+    _no_grad(x)
+    n, c, h, w = x.shape
+    oh, ow = (int(h * scale_factor), int(w * scale_factor)) if size is None else (int(size[0]), int(size[1]))
+    out = torch.empty((n, c, oh, ow), dtype=torch.float32, device=x.device)
+    lib.check_device(x)
+    lib.call("fsv_bilinear_resize_fwd", lib.ptr(x), lib.ptr(out), n, c, h, w, oh, ow, _ll4(x), _ll4(out), lib.stream_ptr())
     return out
 
 

@@ -389,6 +389,10 @@ int fsv_correlation_fwd(const float* f1, const float* f2, float* out, int N, int
 int fsv_resample2d_fwd(const float* img, const float* flow, float* out, int N, int C, int H, int W,
                        const long long* img_strides, const long long* flow_strides, const long long* out_strides,
                        fsv_stream_t stream);
+/* F.interpolate(mode='bilinear', align_corners=False) of the FlowNet2 teacher (flownet2_pytorch/models.py:119,137-142: x4 flow
+ * up-sampling; models/flownet.py:66-77: resize to a multiple of 64 and back); element strides (n, c, y, x) */
+int fsv_bilinear_resize_fwd(const float* in, float* out, int N, int C, int IH, int IW, int OH, int OW,
+                            const long long* in_strides, const long long* out_strides, fsv_stream_t stream);
 int fsv_channelnorm_fwd(const float* x, float* out, int N, int C, long long HW, long long sn, long long sc, long long sp,
                         fsv_stream_t stream);
 

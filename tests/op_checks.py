@@ -600,6 +600,14 @@ def check_flownet_ops(device, seed=18, checker=None):
             assert torch.equal(got, ref), float((got - ref).abs().max())
             nhwc = fo.resample2d(conv_nhwc(_dev(img, device)), _dev(flow, device)).cpu()
             assert torch.equal(nhwc, ref)
+        # bilinear resize (align_corners = False): x4 up-sampling of a flow field, resize to a multiple of 64 and back
+        for (n, c, h, w, size, sf) in [(2, 2, 8, 12, None, 4), (1, 3, 70, 90, (64, 64), None), (1, 2, 64, 64, (70, 90), None),
+                                        (1, 1, 5, 7, (11, 3), None)]:
+            t = torch.randn(n, c, h, w, generator=g)
+            ref = F.interpolate(t, size=size, scale_factor=sf, mode='bilinear')
+            got = fo.bilinear_resize(_dev(t, device), size=size, scale_factor=sf).cpu()
+            assert got.shape == ref.shape and float((got - ref).abs().max()) <= 1e-5 * max(float(ref.abs().max()), 1.0), \
+                ('bilinear resize', (n, c, h, w), size, sf, float((got - ref).abs().max()))
         x = torch.randn(2, 7, 5, 9, generator=g) * 3
         assert torch.equal(fo.channelnorm(_dev(x, device)).cpu(), FO.channelnorm(x))
         assert torch.equal(fo.channelnorm(conv_nhwc(_dev(x, device))).cpu(), FO.channelnorm(x))
