@@ -1025,6 +1025,134 @@ __global__ __launch_bounds__(64 * WM * WN) void fsv_conv_wgrad_v1_kernel(WgradP 
   }
 }
 
+// ---- thin-output convolutions (Cout <= 4: the image / flow / mask heads, generator.py:126-131, 479-496) ------------------------
+// On the matrix cores a Cout = 3 layer pays for a 32-wide tile: 29 of 32 MFMA columns multiply padding (M524288 N3 K288 took 130 us
+// forward, 112 us for its weight gradient - 9.7 GFLOP of MFMA work for 0.9 GFLOP of arithmetic).  These two kernels do the 0.9 GFLOP
+// on the vector ALUs, memory-bound: one work-item per output pixel, the K dimension walked tap by tap and four channels per 16-byte
+// load, the CO weights of a k as UNIFORM operands (scalar loads through the constant cache).  The sum over k is the same ascending
+// chain of fused multiply-adds the MFMA path performs (fmaf, k = tap * Cin + ci), taps outside the image contribute exact zeros
+// through the buffer descriptor's out-of-range zero fill: results are bit-equal to the gather-GEMM kernels.
+template <int CO>
+__global__ __launch_bounds__(256) void fsv_conv_thin_fwd_kernel(ConvP p) {
+  const int m = blockIdx.x * 256 + threadIdx.x;
+  const int ohw = p.OH * p.OW;
+  const bool live = m < p.Mz;
+  const int mm = live ? m : 0;
+  const int n = mm / ohw, rem = mm - n * ohw;
+  const int oy = rem / p.OW, ox = rem - oy * p.OW;
+  const fsv_buf abuf = fsv_make_buf(p.in, (long long)p.N * p.H * p.W * p.Cin * 4);
+  float acc[CO];
+#pragma unroll
+  for (int c = 0; c < CO; ++c) acc[c] = 0.f;
+  const float* wt = p.wt;
+#pragma unroll 1
+  for (int t = 0; t < p.ntaps; ++t) {
+    int ty, tx;
+    fsv_tap(p, t, ty, tx);
+    const int iy = oy * p.sy + ty, ix = ox * p.sx + tx;
+    const bool ok = live & ((unsigned)iy < (unsigned)p.H) & ((unsigned)ix < (unsigned)p.W);
+    const unsigned base = ok ? (unsigned)((((n * p.H + iy) * p.W + ix) * p.Cin) * 4) : FSV_BUF_OOB;
+    const float* wrow = wt + (long long)t * p.Cin * p.ldw;
+#pragma unroll 2
+    for (int ci = 0; ci < p.Cin; ci += 4) {
+      const float4 v = fsv_buf_load4(abuf, ok ? base + (unsigned)ci * 4u : FSV_BUF_OOB);
+      const float* w0 = wrow + (long long)ci * p.ldw;       // uniform: rows ci .. ci + 3 of the K-major weights
+#pragma unroll
+      for (int c = 0; c < CO; ++c) {
+        acc[c] = fmaf(v.x, w0[c], acc[c]);
+        acc[c] = fmaf(v.y, w0[p.ldw + c], acc[c]);
+        acc[c] = fmaf(v.z, w0[2 * p.ldw + c], acc[c]);
+        acc[c] = fmaf(v.w, w0[3 * p.ldw + c], acc[c]);
+      }
+    }
+  }
+  if (!live) return;
+  const float ws = p.wscale ? p.wscale[0] : 1.f;
+#pragma unroll
+  for (int c = 0; c < CO; ++c) {
+    if (c >= p.Cout) break;
+    float v = acc[c] * ws;
+    v = (v + (p.bias ? p.bias[c] : 0.f)) * p.scale;
+    v = fsv_act(v, p.act);
+    if (p.res) v += p.res[(long long)m * p.Cout + c];
+    p.out[(long long)m * p.Cout + c] = v;
+  }
+}
+
+// Weight gradient of a thin-output convolution into the K-major layout dwt[(tap, ci)][co] (ZEROED by the caller / the launcher):
+// a workgroup owns a run of `chunk` pixels; work-item = (group of 8 * ntaps lanes -> one (tap, ci quad) each ... ) see below.
+// Lanes are laid out as tid = g * QK + q: q = tap * (Cin / 4) + ci / 4 walks the K quads (the 8 quads of a pixel-tap are adjacent
+// lanes: one 128-byte line), g = 0 .. NG - 1 are pixel sub-streams.  Every work-item keeps 4 * CO partial sums over its pixels;
+// the NG sub-streams are folded through LDS and one atomic add per (k, co) and workgroup lands in dwt.
+template <int CO>
+__global__ __launch_bounds__(256) void fsv_conv_thin_wgrad_kernel(WgradP p, int chunk) {
+  __shared__ float red[256 * 4 * CO];
+  const int QK = p.ntaps * (p.Cin >> 2);          // K quads (host: QK <= 256)
+  const int NG = 256 / QK;                        // pixel sub-streams per workgroup
+  const int tid = threadIdx.x;
+  const int q = tid % QK, g = tid / QK;
+  const bool lane_on = g < NG;
+  const int t = q / (p.Cin >> 2), ci = (q - t * (p.Cin >> 2)) * 4;
+  int ty, tx;
+  {
+    unsigned long long code = (t < 8) ? p.taps_lo : p.taps_hi;
+    int sh = (t & 7) * 8;
+    ty = (int)((code >> sh) & 15ull) - 8;
+    tx = (int)((code >> (sh + 4)) & 15ull) - 8;
+  }
+  const fsv_buf abuf = fsv_make_buf(p.in, (long long)p.N * p.H * p.W * p.Cin * 4);
+  const fsv_buf dbuf = fsv_make_buf(p.dout, (long long)p.Mz * p.Cout * 4);
+  const int ohw = p.OH * p.OW;
+  const int m0 = blockIdx.x * chunk;
+  const int m1 = (m0 + chunk < p.Mz) ? m0 + chunk : p.Mz;
+  float acc[4][CO];
+#pragma unroll
+  for (int e = 0; e < 4; ++e)
+#pragma unroll
+    for (int c = 0; c < CO; ++c) acc[e][c] = 0.f;
+  if (lane_on) {
+#pragma unroll 2
+    for (int m = m0 + g; m < m1; m += NG) {
+      const int n = m / ohw, rem = m - n * ohw;
+      const int oy = rem / p.OW, ox = rem - oy * p.OW;
+      const int iy = oy * p.sy + ty, ix = ox * p.sx + tx;
+      const bool ok = ((unsigned)iy < (unsigned)p.H) & ((unsigned)ix < (unsigned)p.W);
+      const float4 v = fsv_buf_load4(abuf, ok ? (unsigned)((((n * p.H + iy) * p.W + ix) * p.Cin + ci) * 4) : FSV_BUF_OOB);
+      float d[CO];
+#pragma unroll
+      for (int c = 0; c < CO; ++c) d[c] = fsv_buf_load1(dbuf, (c < p.Cout) ? (unsigned)((m * p.Cout + c) * 4) : FSV_BUF_OOB);
+#pragma unroll
+      for (int c = 0; c < CO; ++c) {
+        acc[0][c] = fmaf(v.x, d[c], acc[0][c]);
+        acc[1][c] = fmaf(v.y, d[c], acc[1][c]);
+        acc[2][c] = fmaf(v.z, d[c], acc[2][c]);
+        acc[3][c] = fmaf(v.w, d[c], acc[3][c]);
+      }
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 4; ++e)
+#pragma unroll
+    for (int c = 0; c < CO; ++c) red[(e * CO + c) * 256 + tid] = acc[e][c];
+  __syncthreads();
+  if (g == 0) {            // fold the sub-streams of this K quad in a fixed order, then one atomic per (k, co)
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+      for (int c = 0; c < CO; ++c) {
+        float s = 0.f;
+        for (int gg = 0; gg < NG; ++gg) s += red[(e * CO + c) * 256 + gg * QK + q];
+        if (c < p.Cout) atomicAdd(p.dwt + (long long)(t * p.Cin + ci + e) * p.ldw + c, s);
+      }
+  }
+}
+
+static inline bool fsv_conv_thin() {
+  static int on = -1;
+  if (on < 0) { const char* e = getenv("FSV_CONV_THIN"); on = (e && e[0] == '0') ? 0 : 1; }
+  return on != 0;
+}
+
 // ---- weight re-arrangement --------------------------------------------------------------------------------
 // mode 0 (forward):  wt[z][j*Cin + ci][co] = s * w[z][co][ci][kh_j][kw_j]
 // mode 1 (dgrad):    wt[z][j*Cout + co][ci] = s * w[z][co][ci][kh_j][kw_j]
@@ -1361,6 +1489,20 @@ static int fsv_conv_gather_impl(const float* in, const float* wt, const float* b
                  oox, ldw, w_bstride, b_bstride, per_sample, act, scale);
   const int nsamp = per_sample ? N : 1;
   int tile = 0, nsplit = 1;
+  // thin-output layers (image / flow / mask heads) run on the vector ALUs: see fsv_conv_thin_fwd_kernel
+  if (Cout <= 4 && (Cin % 4 == 0) && !per_sample && p.dense_out && !accumulate && force_tile < 0 && force_split <= 0 && !stats &&
+      act != FSV_ACT_DLRELU && fsv_conv_thin()) {
+    p.nsplit = 1;
+    if (produced) *produced = 0;
+    const dim3 g(fsv_cdiv(p.Mz, 256));
+    switch (Cout) {
+      case 1: FSV_LAUNCH((fsv_conv_thin_fwd_kernel<1>), g, dim3(256), stream, p); break;
+      case 2: FSV_LAUNCH((fsv_conv_thin_fwd_kernel<2>), g, dim3(256), stream, p); break;
+      case 3: FSV_LAUNCH((fsv_conv_thin_fwd_kernel<3>), g, dim3(256), stream, p); break;
+      default: FSV_LAUNCH((fsv_conv_thin_fwd_kernel<4>), g, dim3(256), stream, p); break;
+    }
+    return fsv_check_launch();
+  }
   if (act == FSV_ACT_DLRELU) {       // epilogue-only form: the finishing pass of a split launch does not know it
     if (!res || accumulate) return FSV_ERR_BAD_ARG;
     force_split = 1;
@@ -1457,6 +1599,22 @@ int fsv_conv_wgrad(const float* in, const float* dout, float* dwt,
   p.Mz = per_sample ? OH * OW : N * OH * OW;
   p.pchunks = fsv_cdiv(p.Mz, FSV_BK);
   const int nsamp = per_sample ? N : 1;
+  if (Cout <= 4 && vec4_ok(Cin) && !per_sample && force_tile == 0 && force_split <= 0 && ntaps * (Cin >> 2) <= 256 &&
+      fsv_conv_thin()) {
+    // thin-output layers: vector-ALU reduction (fsv_conv_thin_wgrad_kernel), ~512 workgroups, atomics into the zeroed matrix
+    p.nsplit = 1;
+    if (!prezeroed) (void)hipMemsetAsync(dwt, 0, (size_t)Kpad * ldw * sizeof(float), stream);
+    int chunk = fsv_cdiv(p.Mz, 512);
+    if (chunk < 64) chunk = 64;
+    const dim3 g(fsv_cdiv(p.Mz, chunk));
+    switch (Cout) {
+      case 1: FSV_LAUNCH((fsv_conv_thin_wgrad_kernel<1>), g, dim3(256), stream, p, chunk); break;
+      case 2: FSV_LAUNCH((fsv_conv_thin_wgrad_kernel<2>), g, dim3(256), stream, p, chunk); break;
+      case 3: FSV_LAUNCH((fsv_conv_thin_wgrad_kernel<3>), g, dim3(256), stream, p, chunk); break;
+      default: FSV_LAUNCH((fsv_conv_thin_wgrad_kernel<4>), g, dim3(256), stream, p, chunk); break;
+    }
+    return fsv_check_launch();
+  }
   int bn = (Cout <= 32) ? 32 : (Cout <= 64 ? 64 : 128);
   // rows of the weight-gradient tile = taps * Cin; the 1x1 SPADE / embedding layers have only 32 or 64 of them and
   // would waste 3/4 or 1/2 of a 128-row tile's MFMA work

@@ -959,3 +959,37 @@ def check_conv_stats(device, seed=61):
         if not inst:
             assert_close('running mean', rm1, rm0, tol=1e-6)
             assert_close('running var', rv1, rv0, tol=1e-6)
+
+
+def check_thin_conv(device, seed=88):
+    """Thin-output convolutions (Cout <= 4: image / flow / mask heads) on the vector-ALU kernels (csrc/conv_igemm.hip
+    fsv_conv_thin_*): forward + gradients against F.conv2d, and the forward bit-equal to the gather-GEMM kernel (same ascending
+    fma chain; a forced tile keeps a launch on the MFMA path)."""
+    ops, conv = pkg()
+    g = torch.Generator().manual_seed(seed)
+    cases = [(2, 32, 17, 19, 3, 3, 1, 1, conv.ACT_TANH, 1.0), (1, 32, 9, 33, 2, 3, 1, 1, conv.ACT_NONE, 20.0),
+             (2, 16, 12, 10, 1, 3, 1, 1, conv.ACT_SIGMOID, 1.0), (1, 8, 7, 9, 4, 1, 1, 0, conv.ACT_LRELU, 1.0),
+             (1, 64, 10, 12, 3, 3, 2, 1, conv.ACT_NONE, 1.0), (2, 12, 6, 5, 2, 4, 2, 2, conv.ACT_NONE, 1.0)]
+    for (n, cin, h, w, cout, k, s, p, act, scale) in cases:
+        x = torch.randn(n, cin, h, w, generator=g)
+        wt = torch.randn(cout, cin, k, k, generator=g) * (1.0 / (cin * k * k) ** 0.5)
+        b = torch.randn(cout, generator=g)
+        xr, wr, br = (t.clone().requires_grad_(True) for t in (x, wt, b))
+        ref = F.conv2d(xr, wr, br, stride=s, padding=p) * scale
+        ref = {conv.ACT_NONE: lambda t: t, conv.ACT_TANH: torch.tanh, conv.ACT_SIGMOID: torch.sigmoid, conv.ACT_LRELU: O.actvn}[act](ref)
+        dy = torch.randn(ref.shape, generator=g)
+        ref.backward(dy)
+        xd, wd, bd = (_dev(t, device).requires_grad_(True) for t in (x, wt, b))
+        y = ops.conv2d(xd, wd, bd, stride=s, padding=p, act=act, scale=scale)
+        y.backward(_dev(dy, device))
+        name = 'thin conv %s' % ((n, cin, h, w, cout, k, s),)
+        assert_close(name + ' y', y, ref)
+        assert_close(name + ' dx', xd.grad, xr.grad)
+        assert_close(name + ' dw', wd.grad, wr.grad, tol=2e-5)
+        assert_close(name + ' db', bd.grad, br.grad)
+        ge = conv.Geom(k, k, s, p)
+        wf, kpad, ldw = conv.prep_weight(_dev(wt, device), 0, ge)
+        xn = conv.to_nhwc(_dev(x, device))
+        thin = conv.conv_forward(xn, wf, ldw, cout, ge, bias=_dev(b, device))
+        mfma = conv.conv_forward(xn, wf, ldw, cout, ge, bias=_dev(b, device), force_tile=4, force_split=1)
+        assert torch.equal(thin.cpu(), mfma.cpu()), name + ': vector-ALU kernel differs from the gather-GEMM kernel'

@@ -141,3 +141,7 @@ def test_spade_two_site_launch(emu_lib):
 
 def test_norm_statistics_from_the_conv_epilogue(emu_lib):
     oc.check_conv_stats(DEV)
+
+
+def test_thin_output_convolutions(emu_lib):
+    oc.check_thin_conv(DEV)

@@ -170,3 +170,7 @@ def test_spade_two_site_launch(hip_lib):
 
 def test_norm_statistics_from_the_conv_epilogue(hip_lib):
     oc.check_conv_stats(dev())
+
+
+def test_thin_output_convolutions(hip_lib):
+    oc.check_thin_conv(dev())
