@@ -1147,10 +1147,14 @@ __global__ __launch_bounds__(256) void fsv_conv_thin_wgrad_kernel(WgradP p, int 
   }
 }
 
-static inline bool fsv_conv_thin() {
-  static int on = -1;
-  if (on < 0) { const char* e = getenv("FSV_CONV_THIN"); on = (e && e[0] == '0') ? 0 : 1; }
-  return on != 0;
+// Worth it only where the layer is wide in pixels and short in K (one work-item walks the whole K of its pixel: a 512 -> 1
+// discriminator head with K = 8192 over 4900 pixels would be a handful of latency-bound work-items).  FSV_CONV_THIN (read at every
+// call: tests switch it): 0 = never, 2 = whenever the layer is eligible (unit tests on small maps), default = the size rule.
+static inline bool fsv_conv_thin(int Mz, int K) {
+  const char* e = getenv("FSV_CONV_THIN");
+  if (e && e[0] == '0') return false;
+  if (e && e[0] == '2') return true;
+  return K <= 1152 && (long long)Mz >= 64ll * K;
 }
 
 // ---- weight re-arrangement --------------------------------------------------------------------------------
@@ -1491,7 +1495,7 @@ static int fsv_conv_gather_impl(const float* in, const float* wt, const float* b
   int tile = 0, nsplit = 1;
   // thin-output layers (image / flow / mask heads) run on the vector ALUs: see fsv_conv_thin_fwd_kernel
   if (Cout <= 4 && (Cin % 4 == 0) && !per_sample && p.dense_out && !accumulate && force_tile < 0 && force_split <= 0 && !stats &&
-      act != FSV_ACT_DLRELU && fsv_conv_thin()) {
+      act != FSV_ACT_DLRELU && fsv_conv_thin(p.Mz, p.K)) {
     p.nsplit = 1;
     if (produced) *produced = 0;
     const dim3 g(fsv_cdiv(p.Mz, 256));
@@ -1600,7 +1604,7 @@ int fsv_conv_wgrad(const float* in, const float* dout, float* dwt,
   p.pchunks = fsv_cdiv(p.Mz, FSV_BK);
   const int nsamp = per_sample ? N : 1;
   if (Cout <= 4 && vec4_ok(Cin) && !per_sample && force_tile == 0 && force_split <= 0 && ntaps * (Cin >> 2) <= 256 &&
-      fsv_conv_thin()) {
+      fsv_conv_thin(p.Mz, p.K)) {
     // thin-output layers: vector-ALU reduction (fsv_conv_thin_wgrad_kernel), ~512 workgroups, atomics into the zeroed matrix
     p.nsplit = 1;
     if (!prezeroed) (void)hipMemsetAsync(dwt, 0, (size_t)Kpad * ldw * sizeof(float), stream);

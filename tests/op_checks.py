@@ -966,7 +966,16 @@ def check_thin_conv(device, seed=88):
     fsv_conv_thin_*): forward + gradients against F.conv2d, and the forward bit-equal to the gather-GEMM kernel (same ascending
     fma chain; a forced tile keeps a launch on the MFMA path)."""
     ops, conv = pkg()
+    import os
     g = torch.Generator().manual_seed(seed)
+    os.environ['FSV_CONV_THIN'] = '2'        # every eligible layer (the library's size rule keeps small maps on the MFMA path)
+    try:
+        _check_thin_conv(device, ops, conv, g)
+    finally:
+        os.environ.pop('FSV_CONV_THIN', None)
+
+
+def _check_thin_conv(device, ops, conv, g):
     cases = [(2, 32, 17, 19, 3, 3, 1, 1, conv.ACT_TANH, 1.0), (1, 32, 9, 33, 2, 3, 1, 1, conv.ACT_NONE, 20.0),
              (2, 16, 12, 10, 1, 3, 1, 1, conv.ACT_SIGMOID, 1.0), (1, 8, 7, 9, 4, 1, 1, 0, conv.ACT_LRELU, 1.0),
              (1, 64, 10, 12, 3, 3, 2, 1, conv.ACT_NONE, 1.0), (2, 12, 6, 5, 2, 4, 2, 2, conv.ACT_NONE, 1.0)]
