@@ -1029,53 +1029,72 @@ __global__ __launch_bounds__(64 * WM * WN) void fsv_conv_wgrad_v1_kernel(WgradP 
 // On the matrix cores a Cout = 3 layer pays for a 32-wide tile: 29 of 32 MFMA columns multiply padding (M524288 N3 K288 took 130 us
 // forward, 112 us for its weight gradient - 9.7 GFLOP of MFMA work for 0.9 GFLOP of arithmetic).  These two kernels do the 0.9 GFLOP
 // on the vector ALUs, memory-bound: one work-item per output pixel, the K dimension walked tap by tap and four channels per 16-byte
-// load, the CO weights of a k as UNIFORM operands (scalar loads through the constant cache).  The sum over k is the same ascending
-// chain of fused multiply-adds the MFMA path performs (fmaf, k = tap * Cin + ci), taps outside the image contribute exact zeros
-// through the buffer descriptor's out-of-range zero fill: results are bit-equal to the gather-GEMM kernels.
+// load; taps outside the image contribute exact zeros through the buffer descriptor's out-of-range zero fill.
+// Forward: Cin / 4 adjacent lanes share one output pixel (lane = (pixel of the wave, channel quad): a load instruction covers
+// whole 128-byte lines - the first version, one work-item per pixel walking its K alone, touched 64 different lines per load and
+// was no faster than the padded MFMA tile, profiles/r03_notes.md), the tap weights of a lane's four channels come from an LDS copy
+// of the K-major weight columns, and the per-lane partial sums are folded over the pixel's lanes with xor-shuffles (a fixed
+// order, but not the ascending-k chain of the MFMA path: these heads feed tanh / sigmoid / a scale, no LeakyReLU kink).
+// Host: Cin / 4 a power of two <= 64, K <= FSV_THIN_MAXK.
+#define FSV_THIN_MAXK 1152
 template <int CO>
-__global__ __launch_bounds__(256) void fsv_conv_thin_fwd_kernel(ConvP p) {
-  const int m = blockIdx.x * 256 + threadIdx.x;
+__global__ __launch_bounds__(256) void fsv_conv_thin_fwd_kernel(ConvP p, int iters) {
+  __shared__ float wl[FSV_THIN_MAXK * CO];        // [k][co]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int i = tid; i < p.K * CO; i += 256) {
+    const int k = i / CO, c = i - k * CO;
+    wl[i] = (c < p.Cout) ? p.wt[(long long)k * p.ldw + c] : 0.f;
+  }
+  __syncthreads();
+  const int QC = p.Cin >> 2;
+  const int PPW = 64 / QC;                         // pixels per wave
+  const int cq = lane % QC, pl = lane / QC;
   const int ohw = p.OH * p.OW;
-  const bool live = m < p.Mz;
-  const int mm = live ? m : 0;
-  const int n = mm / ohw, rem = mm - n * ohw;
-  const int oy = rem / p.OW, ox = rem - oy * p.OW;
   const fsv_buf abuf = fsv_make_buf(p.in, (long long)p.N * p.H * p.W * p.Cin * 4);
-  float acc[CO];
-#pragma unroll
-  for (int c = 0; c < CO; ++c) acc[c] = 0.f;
-  const float* wt = p.wt;
+  const float ws = p.wscale ? p.wscale[0] : 1.f;
+  const int m_base = blockIdx.x * (4 * PPW * iters);
 #pragma unroll 1
-  for (int t = 0; t < p.ntaps; ++t) {
-    int ty, tx;
-    fsv_tap(p, t, ty, tx);
-    const int iy = oy * p.sy + ty, ix = ox * p.sx + tx;
-    const bool ok = live & ((unsigned)iy < (unsigned)p.H) & ((unsigned)ix < (unsigned)p.W);
-    const unsigned base = ok ? (unsigned)((((n * p.H + iy) * p.W + ix) * p.Cin) * 4) : FSV_BUF_OOB;
-    const float* wrow = wt + (long long)t * p.Cin * p.ldw;
-#pragma unroll 2
-    for (int ci = 0; ci < p.Cin; ci += 4) {
-      const float4 v = fsv_buf_load4(abuf, ok ? base + (unsigned)ci * 4u : FSV_BUF_OOB);
-      const float* w0 = wrow + (long long)ci * p.ldw;       // uniform: rows ci .. ci + 3 of the K-major weights
+  for (int it = 0; it < iters; ++it) {
+    const int m = m_base + (it * 4 + wave) * PPW + pl;
+    const bool live = m < p.Mz;
+    const int mm = live ? m : 0;
+    const int n = mm / ohw, rem = mm - n * ohw;
+    const int oy = rem / p.OW, ox = rem - oy * p.OW;
+    float acc[CO];
+#pragma unroll
+    for (int c = 0; c < CO; ++c) acc[c] = 0.f;
+#pragma unroll 3
+    for (int t = 0; t < p.ntaps; ++t) {
+      int ty, tx;
+      fsv_tap(p, t, ty, tx);
+      const int iy = oy * p.sy + ty, ix = ox * p.sx + tx;
+      const bool ok = live & ((unsigned)iy < (unsigned)p.H) & ((unsigned)ix < (unsigned)p.W);
+      const float4 v = fsv_buf_load4(abuf, ok ? (unsigned)((((n * p.H + iy) * p.W + ix) * p.Cin + cq * 4) * 4) : FSV_BUF_OOB);
+      const float* w0 = wl + (t * p.Cin + cq * 4) * CO;
 #pragma unroll
       for (int c = 0; c < CO; ++c) {
         acc[c] = fmaf(v.x, w0[c], acc[c]);
-        acc[c] = fmaf(v.y, w0[p.ldw + c], acc[c]);
-        acc[c] = fmaf(v.z, w0[2 * p.ldw + c], acc[c]);
-        acc[c] = fmaf(v.w, w0[3 * p.ldw + c], acc[c]);
+        acc[c] = fmaf(v.y, w0[CO + c], acc[c]);
+        acc[c] = fmaf(v.z, w0[2 * CO + c], acc[c]);
+        acc[c] = fmaf(v.w, w0[3 * CO + c], acc[c]);
       }
     }
-  }
-  if (!live) return;
-  const float ws = p.wscale ? p.wscale[0] : 1.f;
+    // fold the channel quads of a pixel (adjacent lanes)
+    for (int o = 1; o < QC; o <<= 1) {
 #pragma unroll
-  for (int c = 0; c < CO; ++c) {
-    if (c >= p.Cout) break;
-    float v = acc[c] * ws;
-    v = (v + (p.bias ? p.bias[c] : 0.f)) * p.scale;
-    v = fsv_act(v, p.act);
-    if (p.res) v += p.res[(long long)m * p.Cout + c];
-    p.out[(long long)m * p.Cout + c] = v;
+      for (int c = 0; c < CO; ++c) acc[c] += __shfl_xor(acc[c], o);
+    }
+    if (live && cq == 0) {
+#pragma unroll
+      for (int c = 0; c < CO; ++c) {
+        if (c >= p.Cout) break;
+        float v = acc[c] * ws;
+        v = (v + (p.bias ? p.bias[c] : 0.f)) * p.scale;
+        v = fsv_act(v, p.act);
+        if (p.res) v += p.res[(long long)m * p.Cout + c];
+        p.out[(long long)m * p.Cout + c] = v;
+      }
+    }
   }
 }
 
@@ -1494,16 +1513,20 @@ static int fsv_conv_gather_impl(const float* in, const float* wt, const float* b
   const int nsamp = per_sample ? N : 1;
   int tile = 0, nsplit = 1;
   // thin-output layers (image / flow / mask heads) run on the vector ALUs: see fsv_conv_thin_fwd_kernel
-  if (Cout <= 4 && (Cin % 4 == 0) && !per_sample && p.dense_out && !accumulate && force_tile < 0 && force_split <= 0 && !stats &&
+  if (Cout <= 4 && (Cin % 4 == 0) && Cin <= 256 && ((Cin >> 2) & ((Cin >> 2) - 1)) == 0 && p.K <= FSV_THIN_MAXK && !per_sample &&
+      p.dense_out && !accumulate && force_tile < 0 && force_split <= 0 && !stats &&
       act != FSV_ACT_DLRELU && fsv_conv_thin(p.Mz, p.K)) {
     p.nsplit = 1;
     if (produced) *produced = 0;
-    const dim3 g(fsv_cdiv(p.Mz, 256));
+    const int ppb = 4 * (64 / (Cin >> 2));                  // pixels per workgroup and iteration
+    int iters = 16;
+    while (iters > 1 && fsv_cdiv(p.Mz, ppb * iters) < 1024) iters >>= 1;
+    const dim3 g(fsv_cdiv(p.Mz, ppb * iters));
     switch (Cout) {
-      case 1: FSV_LAUNCH((fsv_conv_thin_fwd_kernel<1>), g, dim3(256), stream, p); break;
-      case 2: FSV_LAUNCH((fsv_conv_thin_fwd_kernel<2>), g, dim3(256), stream, p); break;
-      case 3: FSV_LAUNCH((fsv_conv_thin_fwd_kernel<3>), g, dim3(256), stream, p); break;
-      default: FSV_LAUNCH((fsv_conv_thin_fwd_kernel<4>), g, dim3(256), stream, p); break;
+      case 1: FSV_LAUNCH((fsv_conv_thin_fwd_kernel<1>), g, dim3(256), stream, p, iters); break;
+      case 2: FSV_LAUNCH((fsv_conv_thin_fwd_kernel<2>), g, dim3(256), stream, p, iters); break;
+      case 3: FSV_LAUNCH((fsv_conv_thin_fwd_kernel<3>), g, dim3(256), stream, p, iters); break;
+      default: FSV_LAUNCH((fsv_conv_thin_fwd_kernel<4>), g, dim3(256), stream, p, iters); break;
     }
     return fsv_check_launch();
   }

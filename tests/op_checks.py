@@ -963,8 +963,8 @@ def check_conv_stats(device, seed=61):
 
 def check_thin_conv(device, seed=88):
     """Thin-output convolutions (Cout <= 4: image / flow / mask heads) on the vector-ALU kernels (csrc/conv_igemm.hip
-    fsv_conv_thin_*): forward + gradients against F.conv2d, and the forward bit-equal to the gather-GEMM kernel (same ascending
-    fma chain; a forced tile keeps a launch on the MFMA path)."""
+    fsv_conv_thin_*): forward + gradients against F.conv2d, and the forward against the gather-GEMM kernel to summation order
+    (a forced tile keeps a launch on the MFMA path)."""
     ops, conv = pkg()
     import os
     g = torch.Generator().manual_seed(seed)
@@ -1001,4 +1001,4 @@ def _check_thin_conv(device, ops, conv, g):
         xn = conv.to_nhwc(_dev(x, device))
         thin = conv.conv_forward(xn, wf, ldw, cout, ge, bias=_dev(b, device))
         mfma = conv.conv_forward(xn, wf, ldw, cout, ge, bias=_dev(b, device), force_tile=4, force_split=1)
-        assert torch.equal(thin.cpu(), mfma.cpu()), name + ': vector-ALU kernel differs from the gather-GEMM kernel'
+        assert_close(name + ': vector-ALU kernel vs the gather-GEMM kernel (summation order)', thin, mfma, tol=2e-6)
