@@ -1586,7 +1586,9 @@ static int fsv_conv_gather_impl(const float* in, const float* wt, const float* b
   const int nsamp = per_sample ? N : 1;
   int tile = 0, nsplit = 1;
   // short-K layers with a wide output (first convolutions, data gradients of the heads): see fsv_conv_think_fwd_kernel
-  if (Cin <= 16 && (Cout & 3) == 0 && Cout <= 256 && ((Cout >> 2) & ((Cout >> 2) - 1)) == 0 && p.K * Cout <= FSV_THINK_MAXW &&
+  // (K <= 48: in-box, with the K = 72 ... 144 first layers on this kernel the step was 0.3 ms SLOWER - one LDS weight read per
+  // four fmas is more than the LDS pipe sustains next to the MFMA kernels' own rate for those K)
+  if (Cin <= 16 && p.K <= 48 && (Cout & 3) == 0 && Cout <= 256 && ((Cout >> 2) & ((Cout >> 2) - 1)) == 0 && p.K * Cout <= FSV_THINK_MAXW &&
       !per_sample && p.dense_out && !accumulate && force_tile < 0 && force_split <= 0 && !stats &&
       (act != FSV_ACT_DLRELU || res) && fsv_conv_thin(p.Mz, p.K) && fsv_conv_think()) {
     p.nsplit = 1;
