@@ -1098,74 +1098,9 @@ __global__ __launch_bounds__(256) void fsv_conv_thin_fwd_kernel(ConvP p, int ite
   }
 }
 
-// Short-K layers with a wide output (the first convolutions on 3 / 4 / 6 / 8 / 16-channel inputs, K = 36 ... 144, and the data
-// gradients of the thin-output heads, K = taps * Cout = 9 ... 36): on the matrix cores K is padded to a multiple of 32 and the
-// launch is two or three chunks of prologue / epilogue.  Here Cout / 4 adjacent lanes share a pixel, each lane owns four output
-// channels (one 16-byte store: whole 128-byte lines per pixel), walks the K of its pixel with the input values broadcast over the
-// pixel's lanes and the K-major weight rows in LDS.  Ascending-k fma chain per output: bit-equal to the gather-GEMM kernels.
-// Host: Cout % 4 == 0, Cout / 4 a power of two <= 64, K * Cout <= FSV_THINK_MAXW.
-#define FSV_THINK_MAXW 8192
-__global__ __launch_bounds__(256) void fsv_conv_think_fwd_kernel(ConvP p, int iters) {
-  __shared__ __attribute__((aligned(16))) float wl[FSV_THINK_MAXW];        // [k][Cout]
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  for (int i = tid; i < p.K * p.Cout; i += 256) {
-    const int k = i / p.Cout, c = i - k * p.Cout;
-    wl[i] = p.wt[(long long)k * p.ldw + c];
-  }
-  __syncthreads();
-  const int QO = p.Cout >> 2;
-  const int PPW = 64 / QO;
-  const int oq = lane % QO, pl = lane / QO;
-  const int ohw = p.OH * p.OW;
-  const fsv_buf abuf = fsv_make_buf(p.in, (long long)p.N * p.H * p.W * p.Cin * 4);
-  const float ws = p.wscale ? p.wscale[0] : 1.f;
-  float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (p.bias) bv = *reinterpret_cast<const float4*>(p.bias + oq * 4);
-  const int m_base = blockIdx.x * (4 * PPW * iters);
-#pragma unroll 1
-  for (int it = 0; it < iters; ++it) {
-    const int m = m_base + (it * 4 + wave) * PPW + pl;
-    const bool live = m < p.Mz;
-    const int mm = live ? m : 0;
-    const int n = mm / ohw, rem = mm - n * ohw;
-    const int oy = rem / p.OW, ox = rem - oy * p.OW;
-    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll 1
-    for (int t = 0; t < p.ntaps; ++t) {
-      int ty, tx;
-      fsv_tap(p, t, ty, tx);
-      const int iy = oy * p.sy + ty, ix = ox * p.sx + tx;
-      const bool ok = live & ((unsigned)iy < (unsigned)p.H) & ((unsigned)ix < (unsigned)p.W);
-      const unsigned base = ok ? (unsigned)((((n * p.H + iy) * p.W + ix) * p.Cin) * 4) : FSV_BUF_OOB;
-      const float* wrow = wl + t * p.Cin * p.Cout + oq * 4;
-#pragma unroll 4
-      for (int ci = 0; ci < p.Cin; ++ci) {
-        const float xv = fsv_buf_load1(abuf, ok ? base + (unsigned)ci * 4u : FSV_BUF_OOB);
-        const float4 w = *reinterpret_cast<const float4*>(wrow + ci * p.Cout);
-        acc.x = fmaf(xv, w.x, acc.x); acc.y = fmaf(xv, w.y, acc.y);
-        acc.z = fmaf(xv, w.z, acc.z); acc.w = fmaf(xv, w.w, acc.w);
-      }
-    }
-    if (live) {
-      const long long o = (long long)m * p.Cout + oq * 4;
-      float4 v = make_float4((acc.x * ws + bv.x) * p.scale, (acc.y * ws + bv.y) * p.scale, (acc.z * ws + bv.z) * p.scale,
-                             (acc.w * ws + bv.w) * p.scale);
-      if (p.act == FSV_ACT_DLRELU) {
-        const float4 y = *reinterpret_cast<const float4*>(p.res + o);
-        v = make_float4(y.x > 0.f ? v.x : 0.2f * v.x, y.y > 0.f ? v.y : 0.2f * v.y, y.z > 0.f ? v.z : 0.2f * v.z,
-                        y.w > 0.f ? v.w : 0.2f * v.w);
-      } else {
-        v = make_float4(fsv_act(v.x, p.act), fsv_act(v.y, p.act), fsv_act(v.z, p.act), fsv_act(v.w, p.act));
-        if (p.res) {
-          const float4 r = *reinterpret_cast<const float4*>(p.res + o);
-          v = make_float4(v.x + r.x, v.y + r.y, v.z + r.z, v.w + r.w);
-        }
-      }
-      *reinterpret_cast<float4*>(p.out + o) = v;
-    }
-  }
-}
-
+// (A second vector-ALU kernel for SHORT-K layers with a wide output - the first convolutions on 4 ... 16-channel inputs, the data
+// gradients of these heads - was built and measured in round 3: bit-equal, but 0.1 ... 0.3 ms slower on the step than the padded
+// MFMA tiles at every K limit tried (one LDS weight read per four fmas); removed.  profiles/r03_notes.md.)
 // Weight gradient of a thin-output convolution into the K-major layout dwt[(tap, ci)][co] (ZEROED by the caller / the launcher):
 // a workgroup owns a run of `chunk` pixels; work-item = (group of 8 * ntaps lanes -> one (tap, ci quad) each ... ) see below.
 // Lanes are laid out as tid = g * QK + q: q = tap * (Cin / 4) + ci / 4 walks the K quads (the 8 quads of a pixel-tap are adjacent
@@ -1558,11 +1493,6 @@ static inline void fsv_fill_convp(ConvP& p, const float* in, const float* wt, co
 
 static inline bool vec4_ok(int cin) { return (cin & 3) == 0; }
 
-static inline bool fsv_conv_think() {          // FSV_CONV_THINK=0: in-box A/B switch of the short-K kernel alone
-  const char* e = getenv("FSV_CONV_THINK");
-  return !(e && e[0] == '0');
-}
-
 // Generic gather-GEMM (see header comment and include/fsv2v.h: fsv_conv_gather_fwd).  stats / stats_groups / stats_slots:
 // optional statistics partials for the normalisation that follows (ConvP::stats); *produced tells whether this launch wrote
 // them (not when the plan splits K or the layer takes the scalar-gather kernel: the caller then runs its reduction pass).
@@ -1585,20 +1515,6 @@ static int fsv_conv_gather_impl(const float* in, const float* wt, const float* b
                  oox, ldw, w_bstride, b_bstride, per_sample, act, scale);
   const int nsamp = per_sample ? N : 1;
   int tile = 0, nsplit = 1;
-  // short-K layers with a wide output (first convolutions, data gradients of the heads): see fsv_conv_think_fwd_kernel
-  // (K <= 48: in-box, with the K = 72 ... 144 first layers on this kernel the step was 0.3 ms SLOWER - one LDS weight read per
-  // four fmas is more than the LDS pipe sustains next to the MFMA kernels' own rate for those K)
-  if (Cin <= 16 && p.K <= 48 && (Cout & 3) == 0 && Cout <= 256 && ((Cout >> 2) & ((Cout >> 2) - 1)) == 0 && p.K * Cout <= FSV_THINK_MAXW &&
-      !per_sample && p.dense_out && !accumulate && force_tile < 0 && force_split <= 0 && !stats &&
-      (act != FSV_ACT_DLRELU || res) && fsv_conv_thin(p.Mz, p.K) && fsv_conv_think()) {
-    p.nsplit = 1;
-    if (produced) *produced = 0;
-    const int ppb = 4 * (64 / (Cout >> 2));
-    int iters = 16;
-    while (iters > 1 && fsv_cdiv(p.Mz, ppb * iters) < 1024) iters >>= 1;
-    FSV_LAUNCH(fsv_conv_think_fwd_kernel, dim3(fsv_cdiv(p.Mz, ppb * iters)), dim3(256), stream, p, iters);
-    return fsv_check_launch();
-  }
   // thin-output layers (image / flow / mask heads) run on the vector ALUs: see fsv_conv_thin_fwd_kernel
   if (Cout <= 4 && (Cin % 4 == 0) && Cin <= 256 && ((Cin >> 2) & ((Cin >> 2) - 1)) == 0 && p.K <= FSV_THIN_MAXK && !per_sample &&
       p.dense_out && !accumulate && force_tile < 0 && force_split <= 0 && !stats &&
