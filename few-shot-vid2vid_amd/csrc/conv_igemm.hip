@@ -1231,53 +1231,86 @@ struct PrepGroup {
 // tmap[b] = (layout, 32-wide co tile, ci tile): the OIHW source tile [32 co][CI_T ci][KH*KW] is read in contiguous runs of
 // CI_T * KK floats per output channel, staged in LDS and written out as rows of the K-major layout (CI_T = 32 for <= 8 source
 // taps, else 16).  Only the valid region is written: the padding rows / columns of a layout are zero from allocation on.
-__global__ __launch_bounds__(256) void fsv_prep_group_kernel(PrepGroup g, const int* tmap) {
-  __shared__ float t[32 * 257];
-  const int layer = tmap[blockIdx.x * 3], cot = tmap[blockIdx.x * 3 + 1], cit = tmap[blockIdx.x * 3 + 2];
+// The kernel is a pure HBM stream (4 B read + 4 B written per element and layout), so what matters is the number of loads a
+// work-item has in flight and the width of its stores: the tile is walked as a flat element sequence with four loads issued
+// before the first LDS write, index arithmetic is by compile-time constants for the three source tap counts that hold all but a
+// few KB of the parameters (1x1 / linear, 3x3, 4x4; KKT = 0: any other, run-time divisions), and the layouts are written as
+// float4 (round 3: 805 -> see profiles/r03_notes.md).
+template <int KKT>
+__device__ __forceinline__ void fsv_prep_tile(const PrepGroup& g, const int layer, const int cot, const int cit, float* t) {
   const int* d = g.dims + layer * 9;
   const int Cout = d[0], CinP = d[1], CinR = d[2], KW = d[4], ntaps = d[5], ldw = d[7], mode = d[8];
-  const int KK = d[3] * KW;
+  const int KK = KKT ? KKT : d[3] * KW;
   const int CI_T = KK <= 8 ? 32 : 16;
   const int run = CI_T * KK, lds = run + 1;
   const float* w = reinterpret_cast<const float*>(g.src[layer]);
   float* wt = reinterpret_cast<float*>(g.dst[layer]);
   const unsigned long long lo = g.taps[layer * 2], hi = g.taps[layer * 2 + 1];
   const int co0 = cot * 32, ci0 = cit * CI_T;
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  for (int col = wave; col < 32; col += 4) {
-    const int co = co0 + col;
-    for (int idx = lane; idx < run; idx += 64) {
-      const int ci = ci0 + idx / KK;
-      t[col * lds + idx] = (co < Cout && ci < CinR) ? w[((long long)co * CinR + ci0) * KK + idx] : 0.f;
+  const int tid = threadIdx.x;
+  const int total = 32 * run;
+  for (int e0 = tid; e0 < total; e0 += 1024) {
+    float val[4];
+    int dst[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int e = e0 + 256 * u;
+      const int col = e / run, idx = e - col * run;
+      const int co = co0 + col, ci = ci0 + idx / KK;
+      const bool ok = (e < total) & (co < Cout) & (ci < CinR);
+      val[u] = ok ? w[((long long)co * CinR + ci0) * KK + idx] : 0.f;
+      dst[u] = (e < total) ? col * lds + idx : -1;
     }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if (dst[u] >= 0) t[dst[u]] = val[u];
   }
   __syncthreads();
-  if (mode == 0) {          // rows (tap j, ci), 32 consecutive output channels each
-    const int col = threadIdx.x & 31, r0 = threadIdx.x >> 5;
-    const int co = co0 + col;
-    for (int r = r0; r < ntaps * CI_T; r += 8) {
+  if (mode == 0) {          // rows (tap j, ci), 32 consecutive output channels each: 8 work-items x float4 per row
+    const int q = tid & 7, r0 = tid >> 3;
+    const int nrows = ntaps * CI_T;
+    for (int r = r0; r < nrows; r += 32) {
       const int j = r / CI_T, cil = r - j * CI_T;
       const int ci = ci0 + cil;
-      if (ci >= CinP || co >= Cout) continue;
+      if (ci >= CinP) continue;
       const unsigned long long code = (j < 8) ? lo : hi;
       const int sh = (j & 7) * 8;
       const int tk = (int)((code >> sh) & 15ull) * KW + (int)((code >> (sh + 4)) & 15ull);
-      wt[((long long)j * CinP + ci) * ldw + co] = t[col * lds + cil * KK + tk];
+      const float* src = t + (4 * q) * lds + cil * KK + tk;
+      // columns at or beyond Cout hold zeros in LDS and land in the layout's zero padding (ldw is a multiple of 32)
+      *reinterpret_cast<float4*>(&wt[((long long)j * CinP + ci) * ldw + co0 + 4 * q]) =
+          make_float4(src[0], src[lds], src[2 * lds], src[3 * lds]);
     }
-  } else {                  // rows (tap j, co), CI_T consecutive input channels each
-    const int cil = threadIdx.x % CI_T, c0 = threadIdx.x / CI_T, cstep = 256 / CI_T;
-    const int ci = ci0 + cil;
-    for (int j = 0; j < ntaps; ++j) {
+  } else {                  // rows (tap j, co), CI_T consecutive input channels each: CI_T / 4 work-items x float4 per row
+    const int QN = CI_T / 4;
+    const int q = tid % QN, r0 = tid / QN, rstep = 256 / QN;
+    const int nrows = ntaps * 32;
+    for (int r = r0; r < nrows; r += rstep) {
+      const int j = r >> 5, col = r & 31;
+      const int co = co0 + col, ci = ci0 + 4 * q;
+      if (co >= Cout || ci >= CinP) continue;
       const unsigned long long code = (j < 8) ? lo : hi;
       const int sh = (j & 7) * 8;
       const int tk = (int)((code >> sh) & 15ull) * KW + (int)((code >> (sh + 4)) & 15ull);
-      for (int col = c0; col < 32; col += cstep) {
-        const int co = co0 + col;
-        if (co >= Cout || ci >= CinP) continue;
-        wt[((long long)j * Cout + co) * ldw + ci] = t[col * lds + cil * KK + tk];
+      const float* src = t + col * lds + (4 * q) * KK + tk;
+      float* dstp = &wt[((long long)j * Cout + co) * ldw + ci];
+      if (ci + 3 < CinP) {
+        *reinterpret_cast<float4*>(dstp) = make_float4(src[0], src[KK], src[2 * KK], src[3 * KK]);
+      } else {
+        for (int k = 0; ci + k < CinP; ++k) dstp[k] = src[k * KK];
       }
     }
   }
+}
+
+__global__ __launch_bounds__(256) void fsv_prep_group_kernel(PrepGroup g, const int* tmap) {
+  __shared__ float t[32 * 257];
+  const int layer = tmap[blockIdx.x * 3], cot = tmap[blockIdx.x * 3 + 1], cit = tmap[blockIdx.x * 3 + 2];
+  const int KK = g.dims[layer * 9 + 3] * g.dims[layer * 9 + 4];
+  if (KK == 9) fsv_prep_tile<9>(g, layer, cot, cit, t);
+  else if (KK == 1) fsv_prep_tile<1>(g, layer, cot, cit, t);
+  else if (KK == 16) fsv_prep_tile<16>(g, layer, cot, cit, t);
+  else fsv_prep_tile<0>(g, layer, cot, cit, t);
 }
 
 extern "C" int fsv_prep_weight_grouped(const long long* src, const long long* dst, const int* dims,

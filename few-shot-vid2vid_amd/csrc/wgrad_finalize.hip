@@ -55,20 +55,93 @@ __global__ __launch_bounds__(256) void fsv_wfin_dot_kernel(FinP f, const int* tm
   if (threadIdx.x == 0) atomicAdd(&f.dots[job], red[0]);
 }
 
-// tile: 32 output channels x CI_T input channels x all taps; CI_T = 32 for <= 8 taps, 16 otherwise (LDS <= 33.8 KB)
-__global__ __launch_bounds__(256) void fsv_wfin_apply_kernel(FinP f, const int* tmap) {
-  __shared__ float t[8 * 32 * 33];
-  __shared__ int inv_tap[16];
-  const int job = tmap[blockIdx.x * 3], cot = tmap[blockIdx.x * 3 + 1], cit = tmap[blockIdx.x * 3 + 2];
+// tile: 32 output channels x CI_T input channels x all taps; CI_T = 32 for <= 8 taps, 16 otherwise (LDS <= 33.8 KB).
+// A pure HBM stream (4 B read, 8 B read-modify-written per element): rows of dwt are read as float4 with every load of a
+// work-item issued before the first LDS write, and the gradient runs are walked as a flat element sequence, four sink elements
+// in flight per work-item; KKT = source tap count as a compile-time constant (0: any, run-time divisions).
+template <int KKT>
+__device__ __forceinline__ void fsv_wfin_tile(const FinP& f, const int job, const int cot, const int cit, float* t,
+                                              const int* inv_tap) {
   const int* d = f.dims + job * 8;
   const int Cout = d[0], CinP = d[1], CinR = d[2], KW = d[4], ntaps = d[5], ldw = d[6], flags = d[7];
-  const int KK = d[3] * KW;
+  const int KK = KKT ? KKT : d[3] * KW;
   const int CI_T = ntaps <= 8 ? 32 : 16;
   const float* dwt = reinterpret_cast<const float*>(f.ptrs[job * 6]);
   float* sink = reinterpret_cast<float*>(f.ptrs[job * 6 + 2]);
   const float* u = reinterpret_cast<const float*>(f.ptrs[job * 6 + 3]);
   const float* v = reinterpret_cast<const float*>(f.ptrs[job * 6 + 4]);
   const float* sig = reinterpret_cast<const float*>(f.ptrs[job * 6 + 5]);
+  const int co0 = cot * 32, ci0 = cit * CI_T;
+  const int tid = threadIdx.x;
+  // ---- read: rows (tap, ci) of dwt, 32 consecutive output channels each: 8 work-items x float4 per row, 32 rows per pass
+  {
+    const int q = tid & 7, r0 = tid >> 3;
+    const int nrows = ntaps * CI_T;
+    for (int rb = r0; rb < nrows; rb += 128) {
+      float4 val[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int r = rb + 32 * k;
+        const int j = r / CI_T, cil = r - j * CI_T;
+        const int ci = ci0 + cil, co = co0 + 4 * q;
+        // columns in [Cout, ldw) were never written by the weight-gradient kernel: they are masked per element below
+        val[k] = (r < nrows && ci < CinP && co < ldw) ? *reinterpret_cast<const float4*>(&dwt[((long long)j * CinP + ci) * ldw + co])
+                                                      : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int r = rb + 32 * k;
+        if (r < nrows) {
+          float* dst = t + r * 33 + 4 * q;
+          const int co = co0 + 4 * q;
+          dst[0] = co < Cout ? val[k].x : 0.f; dst[1] = co + 1 < Cout ? val[k].y : 0.f;
+          dst[2] = co + 2 < Cout ? val[k].z : 0.f; dst[3] = co + 3 < Cout ? val[k].w : 0.f;
+        }
+      }
+    }
+  }
+  __syncthreads();
+  // ---- write: per output channel a contiguous run of CI_T * KK gradient elements
+  float inv = 1.f, coef = 0.f;
+  if (sig) { inv = sig[1]; coef = inv * (float)f.dots[job]; }
+  const int run = CI_T * KK;
+  const int total = 32 * run;
+  for (int e0 = tid; e0 < total; e0 += 1024) {
+    float g[4], old[4];
+    float* dst[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int e = e0 + 256 * k;
+      const int col = e / run, idx = e - col * run;
+      const int cil = idx / KK, tk = idx - cil * KK;
+      const int co = co0 + col, ci = ci0 + cil;
+      const int j = (e < total) ? inv_tap[tk] : -1;
+      const bool ok = (e < total) & (co < Cout) & (ci < CinR) & (j >= 0);
+      dst[k] = nullptr; g[k] = 0.f; old[k] = 0.f;
+      if (ok) {
+        float gv = t[(j * CI_T + cil) * 33 + col];
+        if (sig) gv = inv * (gv - coef * u[co] * v[ci * KK + tk]);
+        g[k] = gv;
+        dst[k] = sink + ((long long)co * CinR + ci) * KK + tk;
+        if (!(flags & 1)) old[k] = *dst[k];
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      if (dst[k]) {
+        if (flags & 1) atomicAdd(dst[k], g[k]); else *dst[k] = old[k] + g[k];
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void fsv_wfin_apply_kernel(FinP f, const int* tmap) {
+  __shared__ float t[8 * 32 * 33];
+  __shared__ int inv_tap[16];
+  const int job = tmap[blockIdx.x * 3], cot = tmap[blockIdx.x * 3 + 1], cit = tmap[blockIdx.x * 3 + 2];
+  const int* d = f.dims + job * 8;
+  const int KW = d[4], ntaps = d[5];
+  const int KK = d[3] * KW;
   const unsigned long long lo = f.taps[job * 2], hi = f.taps[job * 2 + 1];
   if (threadIdx.x < 16) inv_tap[threadIdx.x] = -1;
   __syncthreads();
@@ -79,39 +152,11 @@ __global__ __launch_bounds__(256) void fsv_wfin_apply_kernel(FinP f, const int* 
     const int kh = (int)((code >> sh) & 15ull), kw = (int)((code >> (sh + 4)) & 15ull);
     inv_tap[kh * KW + kw] = j;
   }
-  const int co0 = cot * 32, ci0 = cit * CI_T;
-  // ---- read: rows (tap, ci) of dwt, 32 consecutive output channels each
-  const int lane_c = threadIdx.x & 31, row_l = threadIdx.x >> 5;       // 8 rows in flight
-  const int nrows = ntaps * CI_T;
-  for (int r = row_l; r < nrows; r += 8) {
-    const int j = r / CI_T, cil = r - j * CI_T;
-    const int ci = ci0 + cil, co = co0 + lane_c;
-    float val = 0.f;
-    if (ci < CinP && co < Cout) val = dwt[((long long)j * CinP + ci) * ldw + co];
-    t[r * 33 + lane_c] = val;
-  }
   __syncthreads();
-  // ---- write: per output channel a contiguous run of CI_T * KK gradient elements
-  float inv = 1.f, coef = 0.f;
-  if (sig) { inv = sig[1]; coef = inv * (float)f.dots[job]; }
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int run = CI_T * KK;
-  for (int col = wave; col < 32; col += 4) {
-    const int co = co0 + col;
-    if (co >= Cout) continue;
-    const float uc = sig ? u[co] : 0.f;
-    for (int idx = lane; idx < run; idx += 64) {
-      const int cil = idx / KK, tk = idx - cil * KK;
-      const int ci = ci0 + cil;
-      if (ci >= CinR) continue;
-      const int j = inv_tap[tk];
-      if (j < 0) continue;
-      float g = t[(j * CI_T + cil) * 33 + col];
-      if (sig) g = inv * (g - coef * uc * v[ci * KK + tk]);
-      float* dst = sink + ((long long)co * CinR + ci) * KK + tk;
-      if (flags & 1) atomicAdd(dst, g); else *dst += g;
-    }
-  }
+  if (KK == 9) fsv_wfin_tile<9>(f, job, cot, cit, t, inv_tap);
+  else if (KK == 1) fsv_wfin_tile<1>(f, job, cot, cit, t, inv_tap);
+  else if (KK == 16) fsv_wfin_tile<16>(f, job, cot, cit, t, inv_tap);
+  else fsv_wfin_tile<0>(f, job, cot, cit, t, inv_tap);
 }
 
 // ---- pointer-table upload through kernel arguments ----------------------------------------------------------------------

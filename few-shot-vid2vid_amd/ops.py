@@ -11,6 +11,7 @@ All tensors are fp32, logical NCHW, channels-last memory.  No CPU fallback: lib.
 tensors unless the emulated test library was requested explicitly.
 """
 import ctypes
+import os
 import threading as _threading
 
 import torch
@@ -33,6 +34,9 @@ lib.register_sigs({
     "fsv_norm_stats_fused": [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_f, c_p, c_p, c_f, c_i, c_p, c_p],
     "fsv_norm_bwd_fused": [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_p],
     "fsv_colsum_fused": [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p, c_p],
+    "fsv_norm_stats_slotted": [c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_f, c_p, c_p, c_f, c_i, c_p, c_p],
+    "fsv_norm_bwd_slotted": [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_p],
+    "fsv_colsum_slotted": [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p, c_p],
     "fsv_norm_apply": [c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p],
     "fsv_norm_bwd": [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p],
     "fsv_norm_sums": [c_p, c_p, c_p, c_i, c_i, c_p],
@@ -88,6 +92,43 @@ def _ticket(like):
     pool, cur = ent
     ent[1] = (cur + _TICKET_SLOTS) % _TICKET_POOL
     return ctypes.c_void_p(pool.data_ptr() + 4 * cur)
+
+
+_slot_pools = {}
+_SLOT_POOL = 1 << 23          # doubles (64 MB): more than one training step takes, so launches of one step never share a range
+
+
+def red_slots_enabled():
+    """FSV_RED_SLOTS=0: column reductions keep the round-2 forms (two launches above FSV_NORM_FUSE_MAX_MB); also off in the
+    fixed-order mode (FSV_DETERMINISTIC=1): the slots are filled with atomics"""
+    return os.environ.get('FSV_RED_SLOTS', '1') != '0' and os.environ.get('FSV_DETERMINISTIC', '0') != '1'
+
+
+def _slots(g, c, like):
+    """address of g * 32 * c * 2 zeroed doubles for one slotted reduction launch (include/fsv2v.h, fsv_norm_stats_slotted): a ring
+    over a per-device pool like `_ticket`; every launch leaves its range zeroed.  None: not enabled / too large for the pool"""
+    global _red_slots_n
+    if not red_slots_enabled():
+        return None
+    if _red_slots_n is None:
+        fn = getattr(lib.get_lib(), "fsv_norm_red_slots")
+        fn.argtypes, fn.restype = [], c_i
+        _red_slots_n = int(fn())
+    n = (g * _red_slots_n * c * 2 + 31) // 32 * 32
+    if n > _SLOT_POOL // 8:
+        return None
+    ent = _slot_pools.get(like.device)
+    if ent is None:
+        from . import streams
+        ent = _slot_pools[like.device] = [streams.shared(lambda: torch.zeros(_SLOT_POOL, dtype=torch.float64, device=like.device)), 0]
+    pool, cur = ent
+    if cur + n > _SLOT_POOL:
+        cur = 0
+    ent[1] = cur + n
+    return ctypes.c_void_p(pool.data_ptr() + 8 * cur)
+
+
+_red_slots_n = None
 
 
 def _ll(vals):
@@ -164,8 +205,8 @@ def colsum(x2d_nhwc, groups, pixels, channels, out=None):
         out = torch.empty((groups, channels), dtype=torch.float32, device=x2d_nhwc.device)
     lib.check_device(x2d_nhwc)
     ws = _ws(groups, pixels, channels, x2d_nhwc)     # must outlive the call (host allocator frees eagerly)
-    lib.call("fsv_colsum_fused", lib.ptr(x2d_nhwc), lib.ptr(ws), lib.ptr(out), groups, pixels, channels, 1 if acc else 0,
-             _ticket(out), lib.stream_ptr())
+    lib.call("fsv_colsum_slotted", lib.ptr(x2d_nhwc), lib.ptr(ws), _slots(groups, channels, out), lib.ptr(out), groups, pixels,
+             channels, 1 if acc else 0, _ticket(out), lib.stream_ptr())
     return out
 
 
@@ -710,7 +751,7 @@ def norm_stats(x, groups, pixels, channels, eps, run_mean=None, run_var=None, mo
         lib.call("fsv_norm_stats_from_sums", lib.ptr(sums), float(pixels) * _bn_sync[0], lib.ptr(mean), lib.ptr(rstd),
                  channels, float(eps), lib.ptr(run_mean), lib.ptr(run_var), float(momentum), lib.stream_ptr())
         return mean, rstd
-    lib.call("fsv_norm_stats_fused", lib.ptr(x), lib.ptr(ws), lib.ptr(mean), lib.ptr(rstd),
+    lib.call("fsv_norm_stats_slotted", lib.ptr(x), lib.ptr(ws), _slots(groups, channels, x), lib.ptr(mean), lib.ptr(rstd),
              groups, pixels, channels, float(eps), lib.ptr(run_mean), lib.ptr(run_var), float(momentum), int(rep),
              _ticket(x), lib.stream_ptr())
     return mean, rstd
@@ -738,9 +779,9 @@ def bn_backward(dy, y, x, mean, rstd, w, g, p, c, act, fixed_stats, affine, worl
     dw = torch.empty(c, dtype=torch.float32, device=x.device) if affine else None
     db = torch.empty_like(dw) if affine else None
     ws = _ws(g, p, c, x)
-    lib.call("fsv_norm_bwd_fused", lib.ptr(dy), lib.ptr(y), lib.ptr(x), lib.ptr(mean), lib.ptr(rstd), lib.ptr(w), lib.ptr(ws),
-             lib.ptr(s1), lib.ptr(s2), lib.ptr(dx), lib.ptr(dw), lib.ptr(db), g, p, c, act, 1 if fixed_stats else 0,
-             _ticket(x), lib.stream_ptr())
+    lib.call("fsv_norm_bwd_slotted", lib.ptr(dy), lib.ptr(y), lib.ptr(x), lib.ptr(mean), lib.ptr(rstd), lib.ptr(w), lib.ptr(ws),
+             _slots(g, c, x), lib.ptr(s1), lib.ptr(s2), lib.ptr(dx), lib.ptr(dw), lib.ptr(db), g, p, c, act,
+             1 if fixed_stats else 0, _ticket(x), lib.stream_ptr())
     return dx, dw, db
 
 

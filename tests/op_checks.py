@@ -127,8 +127,9 @@ def check_layout_cache(device, seed=14):
     check_conv(device, 1, 20, 9, 9, 32, 4, 2, 2, cache=cache)
     check_conv(device, 1, 8, 7, 7, 16, 4, 1, 2, act='sigmoid', bias=False, cache=cache)
     check_conv(device, 1, 3, 8, 8, 8, 3, 1, 1, act='tanh', cache=cache)          # RGB input: cpad 1
+    check_conv(device, 1, 8, 6, 6, 36, 2, 1, 0, act='none', cache=cache)         # 2x2: the tap count without a compiled-in constant
     check_conv_sn_res(device, cache=cache)
-    assert len(cache.entries) == 5
+    assert len(cache.entries) == 6
     # raw parameter update (no version bump), then ONE grouped refresh
     g = torch.Generator().manual_seed(seed)
     olds = [torch.randn(e.weight.shape, generator=g) * 0.1 for e in cache.entries]
@@ -160,6 +161,7 @@ def check_deferred_wgrad(device, seed=16):
     check_conv(device, 1, 20, 9, 9, 40, 4, 2, 2, cache=cache, fin=fin)
     check_conv(device, 1, 64, 6, 6, 130, 1, 1, 0, cache=cache, fin=fin)
     check_conv(device, 1, 3, 8, 8, 8, 3, 1, 1, act='tanh', cache=cache, fin=fin)
+    check_conv(device, 1, 8, 6, 6, 36, 2, 1, 0, act='none', cache=cache, fin=fin)
     check_conv_sn_res(device, cache=cache, fin=fin)
     # several jobs in one queue, one weight used twice, spectral + plain mixed; K-major results in the per-pass arena
     fin.begin_pass()
@@ -710,6 +712,8 @@ def check_fused_reductions(device, shapes=((1, 4096, 32), (2, 1000, 7), (1, 300,
             assert_close('fused colsum accumulate', acc, (col_ref + 1.0).float(), tol=1e-5)
     pool = ops._tickets[xd.device][0]
     assert int(pool.abs().sum()) == 0, "a fused reduction left its ticket range dirty"
+    if ops.red_slots_enabled() and xd.device in ops._slot_pools:
+        assert float(ops._slot_pools[xd.device][0].abs().sum()) == 0.0, "a slotted reduction left its slot range dirty"
 
 
 def check_warp_compose(device, b=2, h=16, w=24, mag=5.0, seed=93):

@@ -48,6 +48,9 @@ class Census(TorchDispatchMode):
                 if 'few-shot-vid2vid_amd' in fr.filename and 'aten_census' not in fr.filename:
                     where = '%s:%d %s' % (os.path.basename(fr.filename), fr.lineno, fr.name)
                     break
+            if where == 'autograd engine' or 'loss_backward' in where:
+                node = torch._C._current_autograd_node()
+                where = 'engine, node %s' % (type(node).__name__ if node is not None else 'none (gradient accumulation)')
             kind = 'scalar' if numel <= 8 else 'tensor'
             if self.shapes and kind == 'tensor':
                 kind = 'x'.join(str(d) for d in (out.shape if torch.is_tensor(out) else ()))
