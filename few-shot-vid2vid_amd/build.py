@@ -86,6 +86,26 @@ def build_hip(force=False, verbose=False):
     return HIP_LIB
 
 
+def build_hip_diag():
+    """tools/_diag/libfsv2v_hip_diag.so: the library with -DFSV_DIAG (knock-out forms of the dominant kernel behind force_tile ids
+    30+, tools/knockout.py).  Never loaded by the product path: lib.get_lib() takes it only through FSV2V_LIB."""
+    out_dir = os.path.join(ROOT, "tools", "_diag")
+    os.makedirs(out_dir, exist_ok=True)
+    objs = []
+    jobs = []
+    for s in _sources():
+        o = os.path.join(out_dir, os.path.basename(s) + ".o")
+        objs.append(o)
+        jobs.append([HIPCC, "--offload-arch=gfx950"] + COMMON + ["-DFSV_DIAG", "-c", s, "-o", o])
+    with ThreadPoolExecutor(max_workers=8) as ex:
+        list(ex.map(_run, jobs))
+    out = os.path.join(out_dir, "libfsv2v_hip_diag.so")
+    _run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + objs)
+    for o in objs:
+        os.remove(o)
+    return out
+
+
 def _current(which):
     try:
         with open(os.path.join(OBJ_DIR, which + ".current")) as f:

@@ -52,7 +52,9 @@ __device__ __forceinline__ void fsv_xcd_tile(int nx, int ny, int& bx, int& by) {
 // section 16):
 // two register sets, the loads of chunk k + 2 are issued at the top of chunk k and the set stored behind the 12th MFMA was
 // loaded a whole chunk earlier, for grids with one workgroup per CU where nothing else covers the HBM latency.
-template <int BM, int BN, int WM, int WN, int PF, bool AF>
+// DBG (only with -DFSV_DIAG, tools/knockout.py): bit mask of the loop's parts that are left out to see what each costs -
+// 1 barrier, 2 LDS stores, 4 global loads, 8 fragment reads, 16 offset arithmetic, 32 epilogue stores (PF = 2 loop only)
+template <int BM, int BN, int WM, int WN, int PF, bool AF, int DBG = 0>
 __device__ __forceinline__ void fsv_conv_igemm_body(const ConvP& p, const int bx, const int by, const int bz) {
   constexpr int BK = FSV_BK;
   constexpr int NT = 64 * WM * WN;    // 4 or 8 waves
@@ -226,14 +228,30 @@ __device__ __forceinline__ void fsv_conv_igemm_body(const ConvP& p, const int bx
   // one K chunk: the loads issued at its top go into (lar, lbr); (sar, sbr) is the set stored into the other LDS buffer behind
   // three quarters of its MFMAs - the same set for PF = 1, the one loaded a chunk earlier for PF = 2
   auto chunk = [&](int buf, float4 (&lar)[NPA], float4 (&lbr)[NPB], const float4 (&sar)[NPA], const float4 (&sbr)[NPB]) {
-    issue_loads(lar, lbr);
+    if constexpr (!(DBG & 4)) issue_loads(lar, lbr);
     const float* a_src = As + buf * A_ST;
     const float* b_src = Bs + buf * B_ST;
     float4 fa[2][2][TM];
     float fb[2][4][TN];
+    if constexpr (DBG & 8) {
+      // one read per chunk instead of four: the operands stay defined, the LDS traffic of the fragments goes
+      read_group(a_src, b_src, 0, fa[0], fb[0]);
+      read_group(a_src, b_src, 1, fa[1], fb[1]);
+      FSV_SCHED_FENCE();
+      if constexpr (!(DBG & 16)) calc_offsets();
+      mma_group(fa[0], fb[0]);
+      FSV_SCHED_FENCE();
+      mma_group(fa[1], fb[1]);
+      FSV_SCHED_FENCE();
+      mma_group(fa[0], fb[0]);
+      FSV_SCHED_FENCE();
+      if constexpr (!(DBG & 2)) store_chunk(buf ^ 1, sar, sbr);
+      FSV_SCHED_FENCE();
+      mma_group(fa[1], fb[1]);
+    } else {
     read_group(a_src, b_src, 0, fa[0], fb[0]);
     FSV_SCHED_FENCE();
-    calc_offsets();
+    if constexpr (!(DBG & 16)) calc_offsets();
     read_group(a_src, b_src, 1, fa[1], fb[1]);
     FSV_SCHED_FENCE();
     mma_group(fa[0], fb[0]);
@@ -246,10 +264,11 @@ __device__ __forceinline__ void fsv_conv_igemm_body(const ConvP& p, const int bx
     FSV_SCHED_FENCE();
     mma_group(fa[0], fb[0]);
     FSV_SCHED_FENCE();
-    store_chunk(buf ^ 1, sar, sbr);
+    if constexpr (!(DBG & 2)) store_chunk(buf ^ 1, sar, sbr);
     FSV_SCHED_FENCE();
     mma_group(fa[1], fb[1]);
-    __syncthreads();
+    }
+    if constexpr (!(DBG & 1)) __syncthreads();
   };
 
   if (c_begin < c_end) {
@@ -354,7 +373,7 @@ __device__ __forceinline__ void fsv_conv_igemm_body(const ConvP& p, const int bx
             v = fsv_act(v, p.act);
             if (p.res) v += p.res[opix * p.Cout + co];
           }
-          *dst = v;
+          if constexpr (!(DBG & 32)) *dst = v; else if (v == 1.2345e30f) *dst = v;      // keeps the arithmetic alive
           if (p.stats) {
             if (m < st_split) { s0 += v; q0 += v * v; } else { s1 += v; q1 += v * v; }
           }
@@ -378,11 +397,11 @@ __device__ __forceinline__ void fsv_conv_igemm_body(const ConvP& p, const int bx
   }
 }
 
-template <int BM, int BN, int WM, int WN, int PF = 1, bool AF = false>
+template <int BM, int BN, int WM, int WN, int PF = 1, bool AF = false, int DBG = 0>
 __global__ __launch_bounds__(64 * WM * WN) void fsv_conv_igemm_kernel(ConvP p) {
   int bx, by;
   fsv_xcd_tile(gridDim.x, gridDim.y, bx, by);
-  fsv_conv_igemm_body<BM, BN, WM, WN, PF, AF>(p, bx, by, (int)blockIdx.z);
+  fsv_conv_igemm_body<BM, BN, WM, WN, PF, AF, DBG>(p, bx, by, (int)blockIdx.z);
 }
 
 // Grouped launch: up to FSV_GROUP_MAX INDEPENDENT gather-GEMM problems in one 1-D grid (the problem table travels in the
@@ -1353,6 +1372,9 @@ static inline int fsv_tile_dims(int tile, int& bm, int& bn) {
     case 16: bm = 128; bn = 128; return 0;
     case 17: bm = 64; bn = 64; return 0;
     case 18: bm = 128; bn = 32; return 0;
+#ifdef FSV_DIAG
+    case 30: case 31: case 32: case 33: case 34: case 35: case 36: case 37: bm = 64; bn = 128; return 0;
+#endif
     default: return -1;
   }
 }
@@ -1396,6 +1418,17 @@ static int fsv_launch_conv(const ConvP& p, bool vec4, int nz, hipStream_t stream
       case 16: FSV_LAUNCH((fsv_conv_igemm_kernel<128, 128, 2, 4, 1, true>), g, dim3(512), stream, p); break;
       case 17: FSV_LAUNCH((fsv_conv_igemm_kernel<64, 64, 2, 2, 1, true>), g, dim3(256), stream, p); break;
       case 18: FSV_LAUNCH((fsv_conv_igemm_kernel<128, 32, 4, 1, 1, true>), g, dim3(256), stream, p); break;
+#ifdef FSV_DIAG
+      // knock-out forms of the dominant kernel (tools/knockout.py; results are wrong by construction, only the time is read)
+      case 30: FSV_LAUNCH((fsv_conv_igemm_kernel<64, 128, 2, 4, 2, true, 1>), g, dim3(512), stream, p); break;
+      case 31: FSV_LAUNCH((fsv_conv_igemm_kernel<64, 128, 2, 4, 2, true, 2>), g, dim3(512), stream, p); break;
+      case 32: FSV_LAUNCH((fsv_conv_igemm_kernel<64, 128, 2, 4, 2, true, 4>), g, dim3(512), stream, p); break;
+      case 33: FSV_LAUNCH((fsv_conv_igemm_kernel<64, 128, 2, 4, 2, true, 8>), g, dim3(512), stream, p); break;
+      case 34: FSV_LAUNCH((fsv_conv_igemm_kernel<64, 128, 2, 4, 2, true, 16>), g, dim3(512), stream, p); break;
+      case 35: FSV_LAUNCH((fsv_conv_igemm_kernel<64, 128, 2, 4, 2, true, 30>), g, dim3(512), stream, p); break;
+      case 36: FSV_LAUNCH((fsv_conv_igemm_kernel<64, 128, 2, 4, 2, true, 31>), g, dim3(512), stream, p); break;
+      case 37: FSV_LAUNCH((fsv_conv_igemm_kernel<64, 128, 2, 4, 2, true, 32>), g, dim3(512), stream, p); break;
+#endif
       default: FSV_LAUNCH((fsv_conv_igemm_kernel<64, 128, 2, 4>), g, dim3(512), stream, p); break;
     }
   } else {

@@ -42,14 +42,6 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // gradient that feeds it.  Same arithmetic as fsv_act_bwd_kernel: aux > 0 ? v : 0.2 * v.
 #define FSV_ACT_DLRELU 6
 
-// fp64 load that is served by the device-coherent level (L2): for values other workgroups produced with atomics or stores
-// followed by __threadfence() in the SAME launch (last-workgroup tails)
-#ifdef FSV_EMU
-#define FSV_LOAD_COHERENT_F64(ptr) (*(ptr))
-#else
-#define FSV_LOAD_COHERENT_F64(ptr) __hip_atomic_load((ptr), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
-#endif
-
 #ifdef FSV_EMU
 static inline int fsv_check_launch() {
   hipError_t e = hipGetLastError();

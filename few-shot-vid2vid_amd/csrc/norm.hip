@@ -66,10 +66,6 @@ struct RedP {
   float *o0, *o1, *o2, *o3;
   float eps, momentum;
   int rep, accumulate;
-  // slots > 0 (fused form only): part is [g][slot][c][2], ZERO on entry; a workgroup adds its partials into slot chunk % slots
-  // with fp64 atomics and the last workgroup of a slab sums `slots` values per channel - its share no longer grows with the chunk
-  // count, so the one-launch form holds for tensors of any size - and leaves the slots zeroed for the next launch.
-  int slots;
 };
 
 __device__ __forceinline__ void fsv_sum_chunks(const double* part, int g, int c, int C, int nchunks, double& a, double& b);
@@ -146,13 +142,8 @@ __global__ __launch_bounds__(256) void fsv_red2_kernel(RedP p) {
         a += (double)red[(src * V + j) * 2];
         b += (double)red[(src * V + j) * 2 + 1];
       }
-      if (p.slots > 0) {
-        double* dst = p.part + (((long long)g * p.slots + chunk % p.slots) * p.C + c) * 2;
-        atomicAdd(dst, a); atomicAdd(dst + 1, b);
-      } else {
-        double* dst = p.part + (((long long)g * p.nchunks + chunk) * p.C + c) * 2;
-        dst[0] = a; dst[1] = b;
-      }
+      double* dst = p.part + (((long long)g * p.nchunks + chunk) * p.C + c) * 2;
+      dst[0] = a; dst[1] = b;
     }
   }
   if (p.counter == nullptr) return;
@@ -184,19 +175,6 @@ __global__ __launch_bounds__(256) void fsv_red2_kernel(RedP p) {
   double ta = 0.0, tb = 0.0;
   for (int gg = 0; gg < G; ++gg) {
     double acc = 0.0;
-    if (p.slots > 0) {
-      // one work-item per (channel, component): `slots` device-coherent loads, summed in slot order, slots re-zeroed
-      if ((int)threadIdx.x < ncol) {
-        double* base = p.part + ((long long)gg * p.slots * p.C + (long long)slab * p.TX * V) * 2 + threadIdx.x;
-        for (int k = 0; k < p.slots; ++k) {
-          double* q = base + (long long)k * p.C * 2;
-          acc += FSV_LOAD_COHERENT_F64(q);
-          *q = 0.0;
-        }
-      }
-      __syncthreads();
-      if ((int)threadIdx.x < ncol) colsum[threadIdx.x] = acc;
-    } else {
     if (loader) {
       const double* base = p.part + ((long long)gg * p.nchunks * p.C + (long long)slab * p.TX * V) * 2 + col;
       const long long rs = (long long)p.C * 2;
@@ -213,7 +191,6 @@ __global__ __launch_bounds__(256) void fsv_red2_kernel(RedP p) {
     for (int r = 1; r < groups; ++r) {
       __syncthreads();
       if (loader && grp == r) colsum[col] += acc;
-    }
     }
     __syncthreads();
     if (cc < nch) {
@@ -247,7 +224,6 @@ __global__ __launch_bounds__(256) void fsv_red2_kernel(RedP p) {
 
 static inline void fsv_red_no_tail(RedP& p) {
   p.counter = nullptr; p.o0 = p.o1 = p.o2 = p.o3 = nullptr; p.eps = 0.f; p.momentum = 0.f; p.rep = 1; p.accumulate = 0;
-  p.slots = 0;
 }
 
 // The fused second stage pays while the whole reduction is launch-bound: the last workgroup of a slab reads nchunks x slab
@@ -675,59 +651,6 @@ int fsv_colsum_fused(const float* x, double* workspace, float* out, int G, int P
   RedP rp; rp.a = x; rp.y = nullptr; rp.x = nullptr; rp.mean = nullptr; rp.rstd = nullptr; rp.part = workspace;
   rp.P = P; rp.C = C; rp.act = 0; fsv_red_no_tail(rp);
   rp.counter = counters; rp.o0 = out; rp.accumulate = accumulate;
-  fsv_launch_red<FSV_RED_COLSUM>(pl, rp, G, stream);
-  return fsv_check_launch();
-}
-
-// ---- one-launch forms for tensors of any size: `slots` = G * FSV_RED_SLOTS * C * 2 zeroed doubles (owned by the caller, left
-// zeroed); the partial sums are added into them with fp64 atomics (the order of the additions inside a slot is the only thing
-// that varies between runs: ~1e-16 relative) and the last workgroup of a slab sums FSV_RED_SLOTS values per channel.  Falls back
-// to the forms above (with `workspace`) when there are more slabs than counters or slots / counters are NULL.
-#define FSV_RED_SLOTS 32
-int fsv_norm_red_slots() { return FSV_RED_SLOTS; }
-
-int fsv_norm_stats_slotted(const float* x, double* workspace, double* slots, float* mean, float* rstd, int G, int P, int C,
-                           float eps, float* run_mean, float* run_var, float momentum, int rep, int* counters,
-                           hipStream_t stream) {
-  if (!x || !workspace || !mean || !rstd || G < 1 || P < 1 || C < 1 || rep < 1) return FSV_ERR_BAD_ARG;
-  RedPlan pl = fsv_red_plan(G, P, C);
-  if (!slots || !counters || pl.nslabs > FSV_RED_COUNTERS)
-    return fsv_norm_stats_fused(x, workspace, mean, rstd, G, P, C, eps, run_mean, run_var, momentum, rep, counters, stream);
-  RedP rp; rp.a = x; rp.y = nullptr; rp.x = nullptr; rp.mean = nullptr; rp.rstd = nullptr; rp.part = slots;
-  rp.P = P; rp.C = C; rp.act = 0; fsv_red_no_tail(rp);
-  rp.counter = counters; rp.o0 = mean; rp.o1 = rstd; rp.o2 = run_mean; rp.o3 = run_var; rp.eps = eps; rp.momentum = momentum;
-  rp.rep = rep; rp.slots = FSV_RED_SLOTS;
-  fsv_launch_red<FSV_RED_STATS>(pl, rp, G, stream);
-  return fsv_check_launch();
-}
-
-int fsv_norm_bwd_slotted(const float* dy, const float* y, const float* x, const float* mean, const float* rstd, const float* w,
-                         double* workspace, double* slots, float* s1, float* s2, float* dx, float* dw, float* db, int G, int P,
-                         int C, int act, int fixed_stats, int* counters, hipStream_t stream) {
-  if (!dy || !x || !mean || !rstd || !workspace || !s1 || !s2 || !dx) return FSV_ERR_BAD_ARG;
-  if (act != FSV_ACT_NONE && !y) return FSV_ERR_BAD_ARG;
-  RedPlan pl = fsv_red_plan(G, P, C);
-  if (!slots || !counters || pl.nslabs > FSV_RED_COUNTERS)
-    return fsv_norm_bwd_fused(dy, y, x, mean, rstd, w, workspace, s1, s2, dx, dw, db, G, P, C, act, fixed_stats, counters, stream);
-  RedP rp; rp.a = dy; rp.y = y; rp.x = x; rp.mean = mean; rp.rstd = rstd; rp.part = slots;
-  rp.P = P; rp.C = C; rp.act = act; fsv_red_no_tail(rp);
-  rp.counter = counters; rp.o0 = s1; rp.o1 = s2; rp.o2 = dw; rp.o3 = db; rp.slots = FSV_RED_SLOTS;
-  fsv_launch_red<FSV_RED_BWD>(pl, rp, G, stream);
-  long long total = (long long)G * P * C;
-  fsv_launch_bwd_apply(dy, y, x, mean, rstd, w, (const float*)s1, (const float*)s2, dx, total, (long long)P * C, C, P, act,
-                       fixed_stats, stream);
-  return fsv_check_launch();
-}
-
-int fsv_colsum_slotted(const float* x, double* workspace, double* slots, float* out, int G, int P, int C, int accumulate,
-                       int* counters, hipStream_t stream) {
-  if (!x || !workspace || !out) return FSV_ERR_BAD_ARG;
-  RedPlan pl = fsv_red_plan(G, P, C);
-  if (!slots || !counters || pl.nslabs > FSV_RED_COUNTERS)
-    return fsv_colsum_fused(x, workspace, out, G, P, C, accumulate, counters, stream);
-  RedP rp; rp.a = x; rp.y = nullptr; rp.x = nullptr; rp.mean = nullptr; rp.rstd = nullptr; rp.part = slots;
-  rp.P = P; rp.C = C; rp.act = 0; fsv_red_no_tail(rp);
-  rp.counter = counters; rp.o0 = out; rp.accumulate = accumulate; rp.slots = FSV_RED_SLOTS;
   fsv_launch_red<FSV_RED_COLSUM>(pl, rp, G, stream);
   return fsv_check_launch();
 }

@@ -66,7 +66,8 @@ def get_lib():
         path = os.path.join(_HERE, "libfsv2v_emu.so")
         _is_emu = True
     else:
-        path = os.path.join(_HERE, "libfsv2v_hip.so")
+        # FSV2V_LIB: a diagnostic build of the SAME sources (build.build_hip_diag, tools/knockout.py); never set by the product
+        path = os.environ.get("FSV2V_LIB") or os.path.join(_HERE, "libfsv2v_hip.so")
         _is_emu = False
     if not os.path.exists(path):
         raise FsvError("fsv2v kernel library %s is missing; run `python __graft_entry__.py` (build()) first. "

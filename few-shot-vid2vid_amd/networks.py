@@ -491,11 +491,11 @@ class FewShotGenerator(nn.Module):
     @staticmethod
     def _pairs(f, npairs, cout, cin):
         """f [b, L] -> npairs x [weight [b, cout, cin, 1, 1], bias [b, cout]] read off the front of each row
-        (generator.py reshape_weight slices the flattened FC output the same way).  torch.split instead of nested
-        slicing: its backward is ONE concatenation instead of a zero-fill + copy + add per slice."""
+        (generator.py reshape_weight slices the flattened FC output the same way).  One split instead of nested slicing:
+        its backward is ONE concatenation (ops.split_cols) instead of a zero-fill + copy + add per slice."""
         sizes = [cout * cin, cout] * npairs
         rest = f.shape[1] - sum(sizes)
-        parts = torch.split(f, sizes + ([rest] if rest > 0 else []), dim=1)
+        parts = ops.split_cols(f, sizes + ([rest] if rest > 0 else []))
         b = f.shape[0]
         return [[parts[2 * k].reshape(b, cout, cin, 1, 1), parts[2 * k + 1]] for k in range(npairs)]
 

@@ -34,9 +34,6 @@ lib.register_sigs({
     "fsv_norm_stats_fused": [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_f, c_p, c_p, c_f, c_i, c_p, c_p],
     "fsv_norm_bwd_fused": [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_p],
     "fsv_colsum_fused": [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p, c_p],
-    "fsv_norm_stats_slotted": [c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_f, c_p, c_p, c_f, c_i, c_p, c_p],
-    "fsv_norm_bwd_slotted": [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_p],
-    "fsv_colsum_slotted": [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p, c_p],
     "fsv_norm_apply": [c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p],
     "fsv_norm_bwd": [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p],
     "fsv_norm_sums": [c_p, c_p, c_p, c_i, c_i, c_p],
@@ -94,41 +91,31 @@ def _ticket(like):
     return ctypes.c_void_p(pool.data_ptr() + 4 * cur)
 
 
-_slot_pools = {}
-_SLOT_POOL = 1 << 23          # doubles (64 MB): more than one training step takes, so launches of one step never share a range
+class _SplitColsFn(torch.autograd.Function):
+    """torch.split(f, sizes, dim=1) whose backward is ONE concatenation: pieces nobody used (the unread tail of an FC output,
+    weights of a site that is switched off) come back as slices of a cached zero row block instead of one zero-fill launch
+    each (autograd's SplitWithSizesBackward materialises every undefined gradient first)"""
+    _zeros = {}
+
+    @staticmethod
+    def forward(ctx, f, sizes):
+        ctx.set_materialize_grads(False)
+        ctx.sizes, ctx.rows, ctx.meta = sizes, f.shape[0], (f.dtype, f.device)
+        return torch.split(f, sizes, dim=1)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        dtype, device = ctx.meta
+        need = max([n for n, g in zip(ctx.sizes, grads) if g is None] + [0])
+        key = (dtype, device, ctx.rows)
+        z = _SplitColsFn._zeros.get(key)
+        if need and (z is None or z.shape[1] < need):
+            z = _SplitColsFn._zeros[key] = torch.zeros(ctx.rows, need, dtype=dtype, device=device)
+        return torch.cat([g if g is not None else z[:, :n] for n, g in zip(ctx.sizes, grads)], dim=1), None
 
 
-def red_slots_enabled():
-    """FSV_RED_SLOTS=0: column reductions keep the round-2 forms (two launches above FSV_NORM_FUSE_MAX_MB); also off in the
-    fixed-order mode (FSV_DETERMINISTIC=1): the slots are filled with atomics"""
-    return os.environ.get('FSV_RED_SLOTS', '1') != '0' and os.environ.get('FSV_DETERMINISTIC', '0') != '1'
-
-
-def _slots(g, c, like):
-    """address of g * 32 * c * 2 zeroed doubles for one slotted reduction launch (include/fsv2v.h, fsv_norm_stats_slotted): a ring
-    over a per-device pool like `_ticket`; every launch leaves its range zeroed.  None: not enabled / too large for the pool"""
-    global _red_slots_n
-    if not red_slots_enabled():
-        return None
-    if _red_slots_n is None:
-        fn = getattr(lib.get_lib(), "fsv_norm_red_slots")
-        fn.argtypes, fn.restype = [], c_i
-        _red_slots_n = int(fn())
-    n = (g * _red_slots_n * c * 2 + 31) // 32 * 32
-    if n > _SLOT_POOL // 8:
-        return None
-    ent = _slot_pools.get(like.device)
-    if ent is None:
-        from . import streams
-        ent = _slot_pools[like.device] = [streams.shared(lambda: torch.zeros(_SLOT_POOL, dtype=torch.float64, device=like.device)), 0]
-    pool, cur = ent
-    if cur + n > _SLOT_POOL:
-        cur = 0
-    ent[1] = cur + n
-    return ctypes.c_void_p(pool.data_ptr() + 8 * cur)
-
-
-_red_slots_n = None
+def split_cols(f, sizes):
+    return _SplitColsFn.apply(f, list(sizes))
 
 
 def _ll(vals):
@@ -205,8 +192,8 @@ def colsum(x2d_nhwc, groups, pixels, channels, out=None):
         out = torch.empty((groups, channels), dtype=torch.float32, device=x2d_nhwc.device)
     lib.check_device(x2d_nhwc)
     ws = _ws(groups, pixels, channels, x2d_nhwc)     # must outlive the call (host allocator frees eagerly)
-    lib.call("fsv_colsum_slotted", lib.ptr(x2d_nhwc), lib.ptr(ws), _slots(groups, channels, out), lib.ptr(out), groups, pixels,
-             channels, 1 if acc else 0, _ticket(out), lib.stream_ptr())
+    lib.call("fsv_colsum_fused", lib.ptr(x2d_nhwc), lib.ptr(ws), lib.ptr(out), groups, pixels, channels, 1 if acc else 0,
+             _ticket(out), lib.stream_ptr())
     return out
 
 
@@ -751,7 +738,7 @@ def norm_stats(x, groups, pixels, channels, eps, run_mean=None, run_var=None, mo
         lib.call("fsv_norm_stats_from_sums", lib.ptr(sums), float(pixels) * _bn_sync[0], lib.ptr(mean), lib.ptr(rstd),
                  channels, float(eps), lib.ptr(run_mean), lib.ptr(run_var), float(momentum), lib.stream_ptr())
         return mean, rstd
-    lib.call("fsv_norm_stats_slotted", lib.ptr(x), lib.ptr(ws), _slots(groups, channels, x), lib.ptr(mean), lib.ptr(rstd),
+    lib.call("fsv_norm_stats_fused", lib.ptr(x), lib.ptr(ws), lib.ptr(mean), lib.ptr(rstd),
              groups, pixels, channels, float(eps), lib.ptr(run_mean), lib.ptr(run_var), float(momentum), int(rep),
              _ticket(x), lib.stream_ptr())
     return mean, rstd
@@ -779,9 +766,9 @@ def bn_backward(dy, y, x, mean, rstd, w, g, p, c, act, fixed_stats, affine, worl
     dw = torch.empty(c, dtype=torch.float32, device=x.device) if affine else None
     db = torch.empty_like(dw) if affine else None
     ws = _ws(g, p, c, x)
-    lib.call("fsv_norm_bwd_slotted", lib.ptr(dy), lib.ptr(y), lib.ptr(x), lib.ptr(mean), lib.ptr(rstd), lib.ptr(w), lib.ptr(ws),
-             _slots(g, c, x), lib.ptr(s1), lib.ptr(s2), lib.ptr(dx), lib.ptr(dw), lib.ptr(db), g, p, c, act,
-             1 if fixed_stats else 0, _ticket(x), lib.stream_ptr())
+    lib.call("fsv_norm_bwd_fused", lib.ptr(dy), lib.ptr(y), lib.ptr(x), lib.ptr(mean), lib.ptr(rstd), lib.ptr(w), lib.ptr(ws),
+             lib.ptr(s1), lib.ptr(s2), lib.ptr(dx), lib.ptr(dw), lib.ptr(db), g, p, c, act, 1 if fixed_stats else 0,
+             _ticket(x), lib.stream_ptr())
     return dx, dw, db
 
 

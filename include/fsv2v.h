@@ -246,20 +246,6 @@ int fsv_norm_bwd_fused(const float* dy, const float* y, const float* x, const fl
                        int fixed_stats, int* counters, fsv_stream_t stream);
 int fsv_colsum_fused(const float* x, double* workspace, float* out, int G, int P, int C, int accumulate, int* counters,
                      fsv_stream_t stream);
-/* one-launch forms for tensors of ANY size (round 3): slots = G * fsv_norm_red_slots() * C * 2 doubles, zero before the first use,
- * left zero by every launch (launches that may run concurrently need different ranges, like `counters`).  Workgroups add their
- * partial sums into slot (chunk % 32) with fp64 atomics and the last workgroup of a channel slab sums 32 values per channel -
- * its share no longer grows with the tensor.  The order of the additions inside a slot is the only thing that can vary between
- * two runs (~1e-16 relative, fp64).  slots == NULL, counters == NULL or more than 64 channel slabs: the forms above. */
-int fsv_norm_red_slots(void);
-int fsv_norm_stats_slotted(const float* x, double* workspace, double* slots, float* mean, float* rstd, int G, int P, int C,
-                           float eps, float* run_mean, float* run_var, float momentum, int rep, int* counters,
-                           fsv_stream_t stream);
-int fsv_norm_bwd_slotted(const float* dy, const float* y, const float* x, const float* mean, const float* rstd, const float* w,
-                         double* workspace, double* slots, float* s1, float* s2, float* dx, float* dw, float* db, int G, int P,
-                         int C, int act, int fixed_stats, int* counters, fsv_stream_t stream);
-int fsv_colsum_slotted(const float* x, double* workspace, double* slots, float* out, int G, int P, int C, int accumulate,
-                       int* counters, fsv_stream_t stream);
 /* cross-replica BatchNorm (opt-in; apex.parallel.SyncBatchNorm of the reference's multi-process path, normalization.py:15,33,80):
  * the device halves on either side of the host's all-reduce.  sums: doubles [2C] = {sum x, sum x^2} resp. {sum d, sum d*xhat};
  * count: values per channel over all ranks.  dw / db of an affine layer are the LOCAL sums (they travel with the gradients). */

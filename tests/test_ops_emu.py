@@ -63,14 +63,9 @@ def test_fused_reductions(emu_lib):
     oc.check_fused_reductions(DEV, shapes=((1, 4096, 32), (2, 1000, 7), (1, 300, 260), (4, 64, 512)), repeats=2)
 
 
-def test_slotted_reductions_many_chunks_per_slot(emu_lib):
-    # 70000 rows of 64 channels: ~128 pixel chunks share the 32 slots four by four; 3 groups x 40000 rows: InstanceNorm form
-    oc.check_fused_reductions(DEV, shapes=((1, 70000, 64), (3, 40000, 8)), repeats=2)
-
-
-def test_reductions_without_slots_keep_the_two_launch_forms(emu_lib, monkeypatch):
-    monkeypatch.setenv('FSV_RED_SLOTS', '0')
-    oc.check_fused_reductions(DEV, shapes=((1, 4096, 32), (1, 70000, 64)), repeats=1)
+def test_reductions_of_large_tensors(emu_lib):
+    # 70000 rows of 64 channels, 3 groups x 40000 rows (InstanceNorm form): above the one-launch threshold, many pixel chunks
+    oc.check_fused_reductions(DEV, shapes=((1, 70000, 64), (3, 40000, 8)), repeats=1)
 
 
 def test_fused_reductions_wide_rows_fall_back(emu_lib):

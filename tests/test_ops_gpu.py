@@ -65,15 +65,7 @@ def test_fused_reductions(hip_lib):
     oc.check_fused_reductions(dev(), repeats=25)
     oc.check_fused_reductions(dev(), shapes=((1, 2 * 512 * 512, 32), (2, 256 * 256, 128)), repeats=3)
     oc.check_fused_reductions(dev(), shapes=((1, 12, 8196), (2, 10, 20000)), repeats=2)      # two-launch fallback (C > 8192)
-    # a large tensor (round 3: one launch at any size - 32 fp64 slots filled with atomics, last workgroup sums the slots; no
-    # activation: at 11.5 M elements some values land within rounding of the LeakyReLU kink)
-    oc.check_norm(dev(), instance=False, n=2, c=64, h=300, w=300, act='none')
-
-
-def test_reductions_without_slots(hip_lib, monkeypatch):
-    """FSV_RED_SLOTS=0: the round-2 forms (last-workgroup tail below 1 MB, two launches above)"""
-    monkeypatch.setenv('FSV_RED_SLOTS', '0')
-    oc.check_fused_reductions(dev(), shapes=((1, 4096, 32), (1, 2 * 512 * 512, 32)), repeats=3)
+    # above the threshold: two launches (no activation: at 11.5 M elements some land within rounding of the LeakyReLU kink)
     oc.check_norm(dev(), instance=False, n=2, c=64, h=300, w=300, act='none')
 
 

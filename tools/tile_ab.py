@@ -13,7 +13,9 @@ dev = torch.device('cuda:0')
 # FSV_AB_EXPERIMENTAL=1 adds the force_tile-only variants (10 / 11 / 12: 64x128 / 128x128 / 128x64 with a prefetch distance of two
 # chunks) next to the tiles of the plan
 EXPERIMENTAL = (10, 11, 12, 13, 14, 15, 16, 17, 18) if os.environ.get('FSV_AB_EXPERIMENTAL', '0') == '1' else ()      # 13 - 15: mid-chunk barrier
-cfgs = [(-1, 0)] + [(t_, s_) for t_ in (0, 1, 2, 4, 9) + EXPERIMENTAL for s_ in (1, 2, 4, 8)]
+ONLY = tuple(int(t) for t in os.environ.get('FSV_AB_TILES', '').split(',') if t)          # restrict the tile ids (short runs)
+SPLITS = tuple(int(t) for t in os.environ.get('FSV_AB_SPLITS', '1,2,4,8').split(','))
+cfgs = [(-1, 0)] + [(t_, s_) for t_ in (0, 1, 2, 4, 9) + EXPERIMENTAL if not ONLY or t_ in ONLY for s_ in SPLITS]
 shapes = [('M8192 N256 K2304', 2, 256, 64, 64, 256, 3), ('M32768 N128 K576', 2, 64, 128, 128, 128, 3),
           ('M32768 N128 K1152', 2, 128, 128, 128, 128, 3), ('M32768 N128 K2304', 2, 256, 128, 128, 128, 3),
           ('M2048 N512 K9216', 2, 1024, 32, 32, 512, 3), ('M2048 N512 K2304', 2, 256, 32, 32, 512, 3),
@@ -53,6 +55,20 @@ for name, n, cin, h, w, cout, k in shapes:
             for _ in range(NREP):
                 f()
         graphs[c] = gr
+    if os.environ.get('FSV_AB_STATS', '0') == '1' and cin % 4 == 0:
+        # the plan's configuration with the BatchNorm statistics of the output taken in the epilogue (fp64 atomics into 32 slots)
+        f = lambda: conv.conv_forward(x, wf, ldw, cout, g, bias=b, act=conv.ACT_NONE, stats={'groups': 1})
+        for _ in range(2):
+            with conv.stats_pass(dev):
+                for _ in range(NREP):
+                    f()
+        torch.cuda.synchronize()
+        gr = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(gr):
+            with conv.stats_pass(dev):
+                for _ in range(NREP):
+                    f()
+        graphs[('stats', 0)] = gr
     res = {c: [] for c in graphs}
     for rnd in range(5):
         for c, gr in graphs.items():
@@ -60,5 +76,5 @@ for name, n, cin, h, w, cout, k in shapes:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record(); gr.replay(); e1.record(); torch.cuda.synchronize()
             res[c].append(flops / (e0.elapsed_time(e1) / NREP * 1e-3) / 1e12)
-    print(json.dumps({'case': name, **{('auto' if c[0] < 0 else 't%d/s%d' % c): round(sorted(v)[len(v) // 2], 1)
+    print(json.dumps({'case': name, **{('auto' if c[0] == -1 else 'auto+stats' if c[0] == 'stats' else 't%d/s%d' % c): round(sorted(v)[len(v) // 2], 1)
                                        for c, v in res.items()}}), flush=True)
