@@ -190,7 +190,8 @@ def group_enabled():
 def stats_enabled():
     """FSV_CONV_STATS=0: in-box A/B switch - normalisation statistics from their own read pass instead of the producing
     convolution's epilogue"""
-    return os.environ.get('FSV_CONV_STATS', '1') == '1'
+    # the fixed-order mode (FSV_DETERMINISTIC=1) takes the read pass: the epilogue adds its partial sums with fp64 atomics
+    return os.environ.get('FSV_CONV_STATS', '1') == '1' and os.environ.get('FSV_DETERMINISTIC', '0') != '1'
 
 
 class launch_group:

@@ -8,15 +8,28 @@
 // Backward (u, v constant):  dW = (dW_sn - <dW_sn, W_sn> u v^T) / sigma.
 #include "fsv_common.h"
 
-// t[j] += sum_{i in row slab} W[i][j] u[i]      (t zero-initialised)
-__global__ __launch_bounds__(256) void fsv_sn_gemv_t_kernel(const float* W, const float* u, float* t, int R, int Cc, int rows_per_blk) {
+// W^T u in two deterministic steps (round 3; the row slabs used to be added into t with fp32 atomics, whose arrival order
+// changed v, u and sigma in the last bits from run to run - enough to flip exact cancellations that sit on a LeakyReLU kink
+// downstream: the two-outcome gradients of the C1 full-size step, tests/test_fullsize_gpu.py):
+//   part[slab][j] = sum_{i in row slab} W[i][j] u[i]          fsv_sn_gemv_t_kernel
+//   t[j]          = sum_{slab} part[slab][j], ascending slabs  fsv_sn_sum_t_kernel
+#define FSV_SN_SLAB 64
+__global__ __launch_bounds__(256) void fsv_sn_gemv_t_kernel(const float* W, const float* u, float* part, int R, int Cc) {
   int j = blockIdx.x * 256 + threadIdx.x;
-  int r0 = blockIdx.y * rows_per_blk;
-  int r1 = (r0 + rows_per_blk < R) ? r0 + rows_per_blk : R;
+  int r0 = blockIdx.y * FSV_SN_SLAB;
+  int r1 = (r0 + FSV_SN_SLAB < R) ? r0 + FSV_SN_SLAB : R;
   if (j >= Cc) return;
   float acc = 0.f;
   for (int i = r0; i < r1; ++i) acc += W[(long long)i * Cc + j] * u[i];
-  atomicAdd(&t[j], acc);
+  part[(long long)blockIdx.y * Cc + j] = acc;
+}
+
+__global__ __launch_bounds__(256) void fsv_sn_sum_t_kernel(const float* part, float* t, int Cc, int nslab) {
+  int j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= Cc) return;
+  float acc = part[j];
+  for (int k = 1; k < nslab; ++k) acc += part[(long long)k * Cc + j];
+  t[j] = acc;
 }
 
 // s[i] = sum_j W[i][j] t[j]      one wave per row
@@ -110,17 +123,20 @@ __global__ __launch_bounds__(256) void fsv_sn_bwd_kernel(const float* dWsn, cons
 
 extern "C" {
 
-// scratch: float[R + Cc] device scratch; sig: float[2] -> (sigma, 1/sigma)
+// scratch: float[fsv_sn_scratch_floats(R, Cc)] device scratch (R + Cc * (1 + ceil(R / 64))); sig: float[2] -> (sigma, 1/sigma)
+int fsv_sn_scratch_floats(int R, int Cc) { return R + Cc * (1 + fsv_cdiv(R, FSV_SN_SLAB)); }
+
 int fsv_sn_power_iter(const float* W, float* u, float* v, float* scratch, float* sig, int R, int Cc, float eps,
                       int training, hipStream_t stream) {
   if (!W || !u || !v || !scratch || !sig || R < 1 || Cc < 1) return FSV_ERR_BAD_ARG;
   float* t = scratch;          // [Cc]
   float* s = scratch + Cc;     // [R]
+  float* part = s + R;         // [ceil(R / 64)][Cc]
   if (training) {
-    (void)hipMemsetAsync(t, 0, sizeof(float) * (size_t)Cc, stream);
-    int rows_per_blk = 64;
-    dim3 g(fsv_cdiv(Cc, 256), fsv_cdiv(R, rows_per_blk));
-    FSV_LAUNCH(fsv_sn_gemv_t_kernel, g, dim3(256), stream, W, (const float*)u, t, R, Cc, rows_per_blk);
+    const int nslab = fsv_cdiv(R, FSV_SN_SLAB);
+    dim3 g(fsv_cdiv(Cc, 256), nslab);
+    FSV_LAUNCH(fsv_sn_gemv_t_kernel, g, dim3(256), stream, W, (const float*)u, part, R, Cc);
+    FSV_LAUNCH(fsv_sn_sum_t_kernel, dim3(fsv_cdiv(Cc, 256)), dim3(256), stream, (const float*)part, t, Cc, nslab);
     FSV_LAUNCH(fsv_sn_gemv_kernel, dim3(fsv_cdiv(R, 4)), dim3(256), stream, W, (const float*)t, s, R, Cc);
     FSV_LAUNCH(fsv_sn_finalize_kernel, dim3(1), dim3(256), stream, (const float*)t, (const float*)s, u, v, sig, R, Cc, eps);
   } else {
@@ -173,13 +189,29 @@ __global__ __launch_bounds__(256) void fsv_snb_gemv_t_kernel(SnBatch b, const in
   const int cb = tile % ncb, rs = tile / ncb;
   const float* W = reinterpret_cast<const float*>(b.W[layer]);
   const float* u = reinterpret_cast<const float*>(b.u[layer]);
-  float* t = b.scratch + b.t_off[layer];
+  float* part = b.scratch + b.t_off[layer] + Cc;        // the layer's t region: t[Cc], then part[ceil(R / 64)][Cc]
   const int j = cb * 256 + threadIdx.x;
-  const int r0 = rs * 64, r1 = (r0 + 64 < R) ? r0 + 64 : R;
+  const int r0 = rs * FSV_SN_SLAB, r1 = (r0 + FSV_SN_SLAB < R) ? r0 + FSV_SN_SLAB : R;
   if (j >= Cc) return;
   float acc = 0.f;
   for (int i = r0; i < r1; ++i) acc += W[(long long)i * Cc + j] * u[i];
-  atomicAdd(&t[j], acc);
+  part[(long long)rs * Cc + j] = acc;
+}
+
+// t[j] = sum over the row slabs in ascending order (same block map as fsv_snb_gemv_t_kernel: the blocks of slab 0 do the work)
+__global__ __launch_bounds__(256) void fsv_snb_sum_t_kernel(SnBatch b, const int* tmap) {
+  const int layer = tmap[blockIdx.x * 2], tile = tmap[blockIdx.x * 2 + 1];
+  const int R = b.rows[layer], Cc = b.cols[layer];
+  const int ncb = (Cc + 255) / 256;
+  if (tile >= ncb) return;                                // row slab != 0
+  const int j = tile * 256 + threadIdx.x;
+  if (j >= Cc) return;
+  float* t = b.scratch + b.t_off[layer];
+  const float* part = t + Cc;
+  const int nslab = (R + FSV_SN_SLAB - 1) / FSV_SN_SLAB;
+  float acc = part[j];
+  for (int k = 1; k < nslab; ++k) acc += part[(long long)k * Cc + j];
+  t[j] = acc;
 }
 
 __global__ __launch_bounds__(256) void fsv_snb_gemv_kernel(SnBatch b, const int* tmap) {
@@ -241,8 +273,9 @@ extern "C" int fsv_sn_power_iter_batched(const long long* W, const long long* u,
   SnBatch b;
   b.W = W; b.u = u; b.v = v; b.rows = rows; b.cols = cols; b.t_off = t_off; b.s_off = s_off; b.scratch = scratch; b.sig = sig;
   b.snap = snap; b.u_off = u_off; b.v_off = v_off;
-  (void)hipMemsetAsync(scratch, 0, sizeof(float) * (size_t)scratch_floats, stream);
+  (void)scratch_floats;       // every value that is read is written first: nothing to zero
   FSV_LAUNCH(fsv_snb_gemv_t_kernel, dim3(nblk_t), dim3(256), stream, b, tmap_t);
+  FSV_LAUNCH(fsv_snb_sum_t_kernel, dim3(nblk_t), dim3(256), stream, b, tmap_t);
   FSV_LAUNCH(fsv_snb_gemv_kernel, dim3(nblk_s), dim3(256), stream, b, tmap_s);
   FSV_LAUNCH(fsv_snb_finalize_kernel, dim3(nlayers), dim3(256), stream, b, eps);
   return fsv_check_launch();

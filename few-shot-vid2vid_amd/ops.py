@@ -209,7 +209,7 @@ class SpectralState:
         w = weight.detach()
         if not w.is_contiguous():
             w = w.contiguous()
-        scratch = torch.empty(rows + cols, dtype=torch.float32, device=w.device)
+        scratch = torch.empty(rows + cols * (1 + (rows + 63) // 64), dtype=torch.float32, device=w.device)   # fsv_sn_scratch_floats
         sig = torch.empty(2, dtype=torch.float32, device=w.device)
         lib.check_device(w, u, v)
         lib.call("fsv_sn_power_iter", lib.ptr(w), lib.ptr(u), lib.ptr(v), lib.ptr(scratch), lib.ptr(sig), rows, cols,
@@ -236,7 +236,9 @@ class SpectralGroup:
         cols = [l.weight_orig.numel() // r for l, r in zip(self.layers, rows)]
         t_off, s_off, off = [], [], 0
         for r, c in zip(rows, cols):
-            t_off.append(off); off += c
+            # the layer's t region: t[c], then one partial row per 64-row slab of W (csrc/specnorm.hip: W^T u is summed over the
+            # slabs in a fixed order, no atomics)
+            t_off.append(off); off += c * (1 + (r + 63) // 64)
             s_off.append(off); off += r
         self.scratch_floats = off
         u_off, v_off, off2 = [], [], 0

@@ -291,10 +291,14 @@ int fsv_warp_compose_bwd(const float* img, const float* flow, const float* lin_x
                          fsv_stream_t stream);
 
 /* ---- spectral norm (csrc/specnorm.hip) - torch.nn.utils.spectral_norm at architecture.py:60,81-84 etc. ----------- */
+/* scratch: fsv_sn_scratch_floats(R, Cc) floats (t[Cc], s[R] and one partial row of W^T u per 64-row slab of W: the slabs are
+ * summed in ascending order, no atomics - u, v and sigma are the same bits on every run) */
+int fsv_sn_scratch_floats(int R, int Cc);
 int fsv_sn_power_iter(const float* W, float* u, float* v, float* scratch, float* sig, int R, int Cc, float eps,
                       int training, fsv_stream_t stream);
-/* every spectral-normalised layer of a network in three launches; W/u/v are arrays of device pointers (as 64-bit
- * integers), tmap_* map a flat block index to (layer, tile) */
+/* every spectral-normalised layer of a network in four launches; W/u/v are arrays of device pointers (as 64-bit
+ * integers), tmap_* map a flat block index to (layer, tile).  t_off[l]: the layer's t region in `scratch`,
+ * cols * (1 + ceil(rows / 64)) floats (t, then the per-slab partials of W^T u); s_off[l]: rows floats */
 int fsv_sn_power_iter_batched(const long long* W, const long long* u, const long long* v, const int* rows,
                               const int* cols, const int* t_off, const int* s_off, float* scratch,
                               long long scratch_floats, float* sig, float* snap, const int* u_off, const int* v_off,

@@ -197,6 +197,54 @@ def check_deferred_wgrad(device, seed=16):
     assert_close('deferred sn dw', w2d.grad, sd['weight_orig'].grad)
 
 
+def check_spectral_power_iteration(device, shapes=((40, 300), (130, 70), (512, 4608)), repeats=1, seed=21):
+    """One power iteration of torch.nn.utils.spectral_norm (v = normalize(W^T u), u = normalize(W v), sigma = u.W v): the single-layer
+    entry and the grouped one (ops.SpectralGroup) against the same arithmetic in torch, and - `repeats` > 1, on hardware - the SAME
+    bits on every run from the same state: W^T u is summed over 64-row slabs in a fixed order (the slabs used to arrive through
+    fp32 atomics, which made sigma - and with it every normalised weight of the network - differ in the last bits between two
+    runs of the same step)."""
+    ops, conv = pkg()
+    g = torch.Generator().manual_seed(seed)
+
+    class _L:
+        pass
+    layers, refs = [], []
+    for (r, c) in shapes:
+        w = torch.randn(r, c, generator=g) * 0.1
+        u = F.normalize(torch.randn(r, generator=g), dim=0)
+        v = F.normalize(torch.randn(c, generator=g), dim=0)
+        v_ref = F.normalize(torch.mv(w.double().t(), u.double()), dim=0, eps=1e-12)
+        u_ref = F.normalize(torch.mv(w.double(), v_ref), dim=0, eps=1e-12)
+        refs.append((float(torch.dot(u_ref, torch.mv(w.double(), v_ref))), u_ref.float(), v_ref.float()))
+        l = _L()
+        l.weight_orig, l.weight_u, l.weight_v = _dev(w, device), _dev(u.clone(), device), _dev(v.clone(), device)
+        l.u0, l.v0 = u, v
+        layers.append(l)
+    first = None
+    for it in range(repeats):
+        outs = []
+        for l in layers:                                  # single-layer entry, from the initial state
+            ud, vd = _dev(l.u0.clone(), device), _dev(l.v0.clone(), device)
+            sig = ops.SpectralState.update(l.weight_orig, ud, vd, training=True)
+            outs.append((sig.cpu().clone(), ud.cpu().clone(), vd.cpu().clone()))
+        for l in layers:
+            l.weight_u.copy_(_dev(l.u0, device)); l.weight_v.copy_(_dev(l.v0, device))
+        grp = ops.SpectralGroup(layers)
+        grp.update(training=True)
+        for l, (sg, uu, vv), (s_ref, u_ref, v_ref) in zip(layers, outs, refs):
+            sb, ub, vb = l._sig_cached
+            assert abs(float(sg[0]) - s_ref) <= 2e-5 * abs(s_ref), (float(sg[0]), s_ref)
+            assert_close('sn u', uu, u_ref, tol=2e-5)
+            assert_close('sn v', vv, v_ref, tol=2e-5)
+            assert torch.equal(sb.cpu(), sg) and torch.equal(ub.cpu(), uu) and torch.equal(vb.cpu(), vv), 'grouped != single-layer'
+            assert torch.equal(l.weight_u.cpu(), uu) and torch.equal(l.weight_v.cpu(), vv)
+        if first is None:
+            first = outs
+        else:
+            for a, b in zip(first, outs):
+                assert all(torch.equal(x, y) for x, y in zip(a, b)), 'power iteration differs between two runs from the same state'
+
+
 def check_linear(device, r=40, cin=16, cout=50, seed=2):
     ops, conv = pkg()
     g = torch.Generator().manual_seed(seed)

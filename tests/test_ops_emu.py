@@ -35,6 +35,10 @@ def test_layout_cache(emu_lib):
     oc.check_layout_cache(DEV)
 
 
+def test_spectral_power_iteration(emu_lib):
+    oc.check_spectral_power_iteration(DEV, shapes=((40, 300), (130, 70), (200, 520)))
+
+
 def test_deferred_wgrad_finalize(emu_lib):
     oc.check_deferred_wgrad(DEV)
 

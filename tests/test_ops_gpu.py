@@ -60,6 +60,11 @@ def test_norm(hip_lib, instance, affine, act):
     oc.check_norm(dev(), instance=instance, affine=affine, act=act, n=2, c=64, h=65, w=33)
 
 
+def test_spectral_power_iteration_is_reproducible(hip_lib):
+    """same bits on every run (25 runs of three layers up to 512 x 4608, single-layer and grouped entry)"""
+    oc.check_spectral_power_iteration(dev(), repeats=25)
+
+
 def test_fused_reductions(hip_lib):
     """last-workgroup second stage across the 8 XCDs: many repeats on the same buffers, sizes on both sides of the threshold"""
     oc.check_fused_reductions(dev(), repeats=25)
