@@ -675,7 +675,9 @@ __device__ __forceinline__ void fsv_xcd_range(int& kt, int& nt, int& z) {
 
 // V4 kernel: both operands are pixel-major in HBM and in LDS ([32 pixels][columns], ds_write_b128 / ds_read_b32, conflict
 // free); two LDS buffers, one barrier per 32-pixel chunk, absent rows / columns are loaded at FSV_BUF_OOB.
-template <int BMK, int BN, int WM, int WN, bool COUT4>
+// PF: prefetch distance of the global loads in chunks of 32 pixels (see the forward kernel): 1 = one register set, the loads of
+// chunk c + 1 issued at the top of chunk c; 2 = two sets, the set stored behind the 12th MFMA was loaded a whole chunk earlier.
+template <int BMK, int BN, int WM, int WN, bool COUT4, int PF = 1>
 __device__ __forceinline__ void fsv_conv_wgrad_body(const WgradP& p, const int kt, const int nt, const int bz) {
   constexpr int BK = FSV_BK;   // pixels per chunk
   constexpr int NT = 64 * WM * WN;
@@ -718,7 +720,8 @@ __device__ __forceinline__ void fsv_conv_wgrad_body(const WgradP& p, const int k
   const int c_begin = zk * cps;
   const int c_end = (c_begin + cps < p.pchunks) ? (c_begin + cps) : p.pchunks;
 
-  float4 areg[NPA], breg[NPB];
+  constexpr int NSET = PF >= 2 ? 2 : 1;
+  float4 areg[NSET][NPA], breg[NSET][NPB];
   unsigned aoff[NPA], boff[NPB];
   // Branch-free, incremental addressing (see the forward kernel): every A row of this thread walks the output pixels in
   // steps of 32; (n, oy, ox) are advanced with 32 / OW and 32 % OW and one conditional subtract per level - the host
@@ -757,7 +760,7 @@ __device__ __forceinline__ void fsv_conv_wgrad_body(const WgradP& p, const int k
     }
     b_m += BK;
   };
-  auto issue_loads = [&]() {
+  auto issue_loads = [&](float4 (&areg)[NPA], float4 (&breg)[NPB]) {
 #pragma unroll
     for (int i = 0; i < NPA; ++i) areg[i] = fsv_buf_load4(abuf, aoff[i]);
 #pragma unroll
@@ -774,7 +777,7 @@ __device__ __forceinline__ void fsv_conv_wgrad_body(const WgradP& p, const int k
       }
     }
   };
-  auto store_chunk = [&](int buf) {
+  auto store_chunk = [&](int buf, const float4 (&areg)[NPA], const float4 (&breg)[NPB]) {
     float* a_dst = As + buf * A_ST;
     float* b_dst = Bs + buf * B_ST;
 #pragma unroll
@@ -812,42 +815,84 @@ __device__ __forceinline__ void fsv_conv_wgrad_body(const WgradP& p, const int k
 #pragma unroll
         for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[s][i], fb[s][j], acc[i][j], 0, 0, 0);
   };
-  if (c_begin < c_end) {
+  // one chunk: the loads issued at its top go into (lar, lbr); (sar, sbr) is the set stored into the other LDS buffer behind three
+  // quarters of its MFMAs - the same set for PF = 1, the one loaded a chunk earlier for PF = 2.  One barrier per chunk.  Chunks past
+  // c_end are past the descriptors (zeros) or another split's pixels; what the last iterations store is never used.
+  auto chunk = [&](int buf, float4 (&lar)[NPA], float4 (&lbr)[NPB], const float4 (&sar)[NPA], const float4 (&sbr)[NPB]) {
+    issue_loads(lar, lbr);
+    const float* a_src = As + buf * A_ST;
+    const float* b_src = Bs + buf * B_ST;
+    float fa[2][4][TM], fb[2][4][TN];
+    read_group(a_src, b_src, 0, fa[0], fb[0]);
+    FSV_SCHED_FENCE();
     calc_offsets();
-    issue_loads();
-    calc_offsets();
-    store_chunk(0);
+    read_group(a_src, b_src, 1, fa[1], fb[1]);
+    FSV_SCHED_FENCE();
+    mma_group(fa[0], fb[0]);
+    FSV_SCHED_FENCE();
+    read_group(a_src, b_src, 2, fa[0], fb[0]);
+    FSV_SCHED_FENCE();
+    mma_group(fa[1], fb[1]);
+    FSV_SCHED_FENCE();
+    read_group(a_src, b_src, 3, fa[1], fb[1]);
+    FSV_SCHED_FENCE();
+    mma_group(fa[0], fb[0]);
+    FSV_SCHED_FENCE();
+    store_chunk(buf ^ 1, sar, sbr);
+    FSV_SCHED_FENCE();
+    mma_group(fa[1], fb[1]);
     __syncthreads();
-    int buf = 0;
-#pragma unroll 1
-    for (int pc = c_begin; pc < c_end; ++pc) {
-      // the next chunk's loads land in registers under the first three quarters of this chunk's MFMAs and are stored into
-      // the other LDS buffer: one barrier per chunk.  Chunks past c_end are past the descriptors (zeros) or another
-      // split's pixels; the copy stored by the last iteration is never used.
-      issue_loads();
-      const float* a_src = As + buf * A_ST;
-      const float* b_src = Bs + buf * B_ST;
-      float fa[2][4][TM], fb[2][4][TN];
-      read_group(a_src, b_src, 0, fa[0], fb[0]);
-      FSV_SCHED_FENCE();
+  };
+  if (c_begin < c_end) {
+    if constexpr (PF == 1) {
       calc_offsets();
-      read_group(a_src, b_src, 1, fa[1], fb[1]);
-      FSV_SCHED_FENCE();
-      mma_group(fa[0], fb[0]);
-      FSV_SCHED_FENCE();
-      read_group(a_src, b_src, 2, fa[0], fb[0]);
-      FSV_SCHED_FENCE();
-      mma_group(fa[1], fb[1]);
-      FSV_SCHED_FENCE();
-      read_group(a_src, b_src, 3, fa[1], fb[1]);
-      FSV_SCHED_FENCE();
-      mma_group(fa[0], fb[0]);
-      FSV_SCHED_FENCE();
-      store_chunk(buf ^ 1);
-      FSV_SCHED_FENCE();
-      mma_group(fa[1], fb[1]);
+      issue_loads(areg[0], breg[0]);
+      calc_offsets();
+      store_chunk(0, areg[0], breg[0]);
       __syncthreads();
-      buf ^= 1;
+      int buf = 0;
+#pragma unroll 1
+      for (int pc = c_begin; pc < c_end; ++pc) {
+        // (written out instead of calling chunk(): the instruction stream that was validated on hardware, 80 registers)
+        issue_loads(areg[0], breg[0]);
+        const float* a_src = As + buf * A_ST;
+        const float* b_src = Bs + buf * B_ST;
+        float fa[2][4][TM], fb[2][4][TN];
+        read_group(a_src, b_src, 0, fa[0], fb[0]);
+        FSV_SCHED_FENCE();
+        calc_offsets();
+        read_group(a_src, b_src, 1, fa[1], fb[1]);
+        FSV_SCHED_FENCE();
+        mma_group(fa[0], fb[0]);
+        FSV_SCHED_FENCE();
+        read_group(a_src, b_src, 2, fa[0], fb[0]);
+        FSV_SCHED_FENCE();
+        mma_group(fa[1], fb[1]);
+        FSV_SCHED_FENCE();
+        read_group(a_src, b_src, 3, fa[1], fb[1]);
+        FSV_SCHED_FENCE();
+        mma_group(fa[0], fb[0]);
+        FSV_SCHED_FENCE();
+        store_chunk(buf ^ 1, areg[0], breg[0]);
+        FSV_SCHED_FENCE();
+        mma_group(fa[1], fb[1]);
+        __syncthreads();
+        buf ^= 1;
+      }
+    } else {
+      calc_offsets();
+      issue_loads(areg[0], breg[0]);
+      calc_offsets();
+      store_chunk(0, areg[0], breg[0]);
+      issue_loads(areg[1], breg[1]);
+      calc_offsets();
+      __syncthreads();
+#pragma unroll 1
+      for (int pc = c_begin; pc < c_end; pc += 2) {
+        chunk(0, areg[0], breg[0], areg[1], breg[1]);
+        if (pc + 1 >= c_end) break;
+        chunk(1, areg[1], breg[1], areg[0], breg[0]);
+      }
     }
   }
 #pragma unroll
@@ -867,11 +912,11 @@ __device__ __forceinline__ void fsv_conv_wgrad_body(const WgradP& p, const int k
   }
 }
 
-template <int BMK, int BN, int WM, int WN, bool COUT4>
+template <int BMK, int BN, int WM, int WN, bool COUT4, int PF = 1>
 __global__ __launch_bounds__(64 * WM * WN) void fsv_conv_wgrad_kernel(WgradP p) {
   int kt, nt, bz;
   fsv_xcd_range(kt, nt, bz);
-  fsv_conv_wgrad_body<BMK, BN, WM, WN, COUT4>(p, kt, nt, bz);
+  fsv_conv_wgrad_body<BMK, BN, WM, WN, COUT4, PF>(p, kt, nt, bz);
 }
 
 // Grouped weight gradients (see fsv_conv_igemm_group_kernel): the problems' tiles in one 1-D grid, inside a problem ordered
@@ -883,7 +928,7 @@ struct WgradGroup {
   WgradP p[FSV_GROUP_MAX];
 };
 
-template <int BMK, int BN, int WM, int WN, bool COUT4>
+template <int BMK, int BN, int WM, int WN, bool COUT4, int PF = 1>
 __global__ __launch_bounds__(64 * WM * WN) void fsv_conv_wgrad_group_kernel(WgradGroup g) {
   const int b = blockIdx.x;
   int i = 0;
@@ -892,7 +937,7 @@ __global__ __launch_bounds__(64 * WM * WN) void fsv_conv_wgrad_group_kernel(Wgra
   const WgradP& p = g.p[i];
   const int gx = (p.K + BMK - 1) / BMK, gy = (p.Cout + BN - 1) / BN;
   const int r = t / gx;
-  fsv_conv_wgrad_body<BMK, BN, WM, WN, COUT4>(p, t - r * gx, r % gy, r / gy);
+  fsv_conv_wgrad_body<BMK, BN, WM, WN, COUT4, PF>(p, t - r * gx, r % gy, r / gy);
 }
 
 // scalar-gather twin (Cin % 4 != 0), single LDS buffer
@@ -1372,6 +1417,8 @@ static inline int fsv_tile_dims(int tile, int& bm, int& bn) {
     case 16: bm = 128; bn = 128; return 0;
     case 17: bm = 64; bn = 64; return 0;
     case 18: bm = 128; bn = 32; return 0;
+    // 64x64 with a prefetch distance of two chunks + in-place A fragments
+    case 20: bm = 64; bn = 64; return 0;
 #ifdef FSV_DIAG
     case 30: case 31: case 32: case 33: case 34: case 35: case 36: case 37: bm = 64; bn = 128; return 0;
 #endif
@@ -1384,12 +1431,14 @@ static inline int fsv_tile_dims(int tile, int& bm, int& bn) {
 // re-ordered quad read in place with ds_read_b64); all are bit-equal.  Defaults = the in-box A/B of round 3
 // (profiles/r03_notes.md, tools/tile_ab.py): 64x128 and 128x64 -> PF 2 + AF (ids 13 / 15: +6 ... +8 % over PF 2 alone, which
 // round 2 measured at +5 % over the base tile); 128x128 -> PF 1 + AF (id 16: its PF 2 forms lose occupancy - 168 registers - on
-// the multi-workgroup grids it is picked for).  FSV_CONV_V<shape>=<id> overrides one shape (A/B runs).
+// the multi-workgroup grids it is picked for); 64x64 -> PF 2 + AF (id 20): per shape with warm caches it equals PF 1 + AF (id 17:
+// 78.9 vs 81.4 ... 86.4 vs 85.7 TFLOP/s), inside the step - every layer's weights cold - it is worth 0.3 ms (49.19 vs 49.48, two
+// in-box pairs); the same form of the 128x32 tile loses 0.2 ms there and was removed.  FSV_CONV_V<shape>=<id> overrides one shape (A/B runs).
 static inline int fsv_conv_variant(int shape) {
   static int map[10] = {-2, -2, -2, -2, -2, -2, -2, -2, -2, -2};
   if (shape < 0 || shape > 9) return shape;
   if (map[shape] == -2) {
-    static const int dflt[10] = {16, 15, 18, -1, 17, -1, -1, -1, -1, 13};
+    static const int dflt[10] = {16, 15, 18, -1, 20, -1, -1, -1, -1, 13};
     char name[16];
     snprintf(name, sizeof(name), "FSV_CONV_V%d", shape);
     const char* e = getenv(name);
@@ -1418,6 +1467,7 @@ static int fsv_launch_conv(const ConvP& p, bool vec4, int nz, hipStream_t stream
       case 16: FSV_LAUNCH((fsv_conv_igemm_kernel<128, 128, 2, 4, 1, true>), g, dim3(512), stream, p); break;
       case 17: FSV_LAUNCH((fsv_conv_igemm_kernel<64, 64, 2, 2, 1, true>), g, dim3(256), stream, p); break;
       case 18: FSV_LAUNCH((fsv_conv_igemm_kernel<128, 32, 4, 1, 1, true>), g, dim3(256), stream, p); break;
+      case 20: FSV_LAUNCH((fsv_conv_igemm_kernel<64, 64, 2, 2, 2, true>), g, dim3(256), stream, p); break;
 #ifdef FSV_DIAG
       // knock-out forms of the dominant kernel (tools/knockout.py; results are wrong by construction, only the time is read)
       case 30: FSV_LAUNCH((fsv_conv_igemm_kernel<64, 128, 2, 4, 2, true, 1>), g, dim3(512), stream, p); break;
@@ -1433,7 +1483,7 @@ static int fsv_launch_conv(const ConvP& p, bool vec4, int nz, hipStream_t stream
     }
   } else {
     if (tile == 10 || tile == 13) tile = 9; else if (tile == 11 || tile == 14 || tile == 16) tile = 0; else if (tile == 12 || tile == 15) tile = 1;     // scalar gather: no variants
-    else if (tile == 17) tile = 4; else if (tile == 18) tile = 2;
+    else if (tile == 17 || tile == 20) tile = 4; else if (tile == 18) tile = 2;
     switch (tile) {
       case 0: FSV_LAUNCH((fsv_conv_igemm_v1_kernel<128, 128, 2, 2>), g, dim3(256), stream, p); break;
       case 1: FSV_LAUNCH((fsv_conv_igemm_v1_kernel<128, 64, 2, 2>), g, dim3(256), stream, p); break;
@@ -1677,6 +1727,15 @@ int fsv_bias_act(float* x, const float* bias, long long total, int C, int act, h
   return fsv_check_launch();
 }
 
+// FSV_WGRAD_PF = 1 | 2: prefetch distance of the 64x64 and 128x32 weight-gradient kernels.  2 is opt-in: 128 / 144 registers
+// instead of 80 / 92 (3 instead of 5 - 6 waves per SIMD) for 49.12 / 49.30 vs 49.31 / 49.34 ms per step in-box (round 3, pass r3w)
+// - inside the noise of the pair.
+static inline int fsv_wgrad_pf() {
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("FSV_WGRAD_PF"); v = e ? atoi(e) : 1; if (v != 2) v = 1; }
+  return v;
+}
+
 int fsv_conv_wgrad(const float* in, const float* dout, float* dwt,
                    int N, int H, int W, int Cin, int OH, int OW, int Cout,
                    int ntaps, const int* ty, const int* tx, int sy, int sx,
@@ -1753,9 +1812,11 @@ int fsv_conv_wgrad(const float* in, const float* dout, float* dwt,
     if (bn == 128 && bmk == 32) FSV_LAUNCH((fsv_conv_wgrad_kernel<32, 128, 1, 4, true>), g, block, stream, p);
     else if (bn == 128 && bmk == 64) FSV_LAUNCH((fsv_conv_wgrad_kernel<64, 128, 2, 2, true>), g, block, stream, p);
     else if (bn == 64 && bmk == 32) FSV_LAUNCH((fsv_conv_wgrad_kernel<32, 64, 1, 2, true>), g, dim3(128), stream, p);
+    else if (bn == 64 && bmk == 64 && fsv_wgrad_pf() == 2) FSV_LAUNCH((fsv_conv_wgrad_kernel<64, 64, 2, 2, true, 2>), g, block, stream, p);
     else if (bn == 64 && bmk == 64) FSV_LAUNCH((fsv_conv_wgrad_kernel<64, 64, 2, 2, true>), g, block, stream, p);
     else if (bn == 128) FSV_LAUNCH((fsv_conv_wgrad_kernel<128, 128, 2, 2, true>), g, block, stream, p);
     else if (bn == 64) FSV_LAUNCH((fsv_conv_wgrad_kernel<128, 64, 2, 2, true>), g, block, stream, p);
+    else if ((Cout & 3) == 0 && fsv_wgrad_pf() == 2) FSV_LAUNCH((fsv_conv_wgrad_kernel<128, 32, 4, 1, true, 2>), g, block, stream, p);
     else if ((Cout & 3) == 0) FSV_LAUNCH((fsv_conv_wgrad_kernel<128, 32, 4, 1, true>), g, block, stream, p);
     else FSV_LAUNCH((fsv_conv_wgrad_kernel<128, 32, 4, 1, false>), g, block, stream, p);
   } else {
@@ -1853,7 +1914,7 @@ int fsv_conv_gather_group(const fsv_conv_desc* d, int n, int force_tile, hipStre
     }
     if (tile < 0) tile = 4;
   }
-  if (tile >= 10) tile = (tile == 10 || tile == 13) ? 9 : (tile == 11 || tile == 14 || tile == 16) ? 0 : (tile == 17) ? 4 : (tile == 18) ? 2 : 1;
+  if (tile >= 10) tile = (tile == 10 || tile == 13) ? 9 : (tile == 11 || tile == 14 || tile == 16) ? 0 : (tile == 17 || tile == 20) ? 4 : (tile == 18) ? 2 : 1;
   int bm, bn;
   if (fsv_tile_dims(tile, bm, bn)) return FSV_ERR_BAD_ARG;
   // K splits: only problems that accumulate into a zeroed output, and only when the whole group would leave CUs idle
@@ -1907,6 +1968,7 @@ int fsv_conv_gather_group(const fsv_conv_desc* d, int n, int force_tile, hipStre
         case 16: FSV_LAUNCH((fsv_conv_igemm_group_kernel<128, 128, 2, 4, 1, true>), grid, dim3(512), stream, g); break;
         case 17: FSV_LAUNCH((fsv_conv_igemm_group_kernel<64, 64, 2, 2, 1, true>), grid, dim3(256), stream, g); break;
         case 18: FSV_LAUNCH((fsv_conv_igemm_group_kernel<128, 32, 4, 1, 1, true>), grid, dim3(256), stream, g); break;
+        case 20: FSV_LAUNCH((fsv_conv_igemm_group_kernel<64, 64, 2, 2, 2, true>), grid, dim3(256), stream, g); break;
         default: return FSV_ERR_BAD_ARG;
       }
     } else {

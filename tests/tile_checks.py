@@ -29,7 +29,7 @@ FWD_TILES = (0, 1, 2, 4, 9)
 # only until they have been measured on hardware; (variant, the plan's tile with the same dimensions)
 # kernel variants of the plan's tile shapes (csrc/conv_igemm.hip fsv_conv_variant): 10 - 12 prefetch distance 2, 13 - 15 the same with
 # in-place A fragments, 16 - 18 in-place A fragments on the prefetch-distance-1 tiles; (variant, the base tile of the same shape)
-EXPERIMENTAL_FWD_TILES = ((10, 9), (11, 0), (12, 1), (13, 9), (14, 0), (15, 1), (16, 0), (17, 4), (18, 2))
+EXPERIMENTAL_FWD_TILES = ((10, 9), (11, 0), (12, 1), (13, 9), (14, 0), (15, 1), (16, 0), (17, 4), (18, 2), (20, 4))
 WGRAD_TILES = (0, 1, 2, 3, 4)
 
 
@@ -52,7 +52,7 @@ def _fwd_case(device, geom, tile, split, seed):
 def check_forward_tiles(device, tiles=FWD_TILES, geoms=GEOMS):
     for gi, geom in enumerate(geoms):
         for tile in tiles:
-            bn = {0: 128, 1: 64, 2: 32, 4: 64, 9: 128, 10: 128, 11: 128, 12: 64, 13: 128, 14: 128, 15: 64, 16: 128, 17: 64, 18: 32}[tile]
+            bn = {0: 128, 1: 64, 2: 32, 4: 64, 9: 128, 10: 128, 11: 128, 12: 64, 13: 128, 14: 128, 15: 64, 16: 128, 17: 64, 18: 32, 20: 64}[tile]
             if geom[4] < bn // 2 and bn > 32:
                 continue                       # a tile twice as wide as the layer: not a configuration the plan can produce
             for split in (1, 3):
