@@ -27,6 +27,14 @@ static inline float fsv_buf_load1(const fsv_buf& b, unsigned off) {
   if (off < b.bytes && (unsigned long long)off + 4ull <= (unsigned long long)b.bytes) memcpy(&v, b.base + off, 4);
   return v;
 }
+// LDS-direct form: the lane's 16 bytes land at lds_wave_base + lane * 16 (out-of-range lanes write zeros)
+typedef fsv_buf fsv_rawbuf;
+static inline fsv_rawbuf fsv_make_rawbuf(const void* p, long long bytes) { return fsv_make_buf(p, bytes); }
+static inline void fsv_buf_load4_lds(const fsv_rawbuf& b, unsigned off, float* lds_wave_base) {
+  const float4 v = fsv_buf_load4(b, off);
+  memcpy(lds_wave_base + (threadIdx.x & 63) * 4, &v, 16);
+}
+#define FSV_WAIT_VMCNT(n) ((void)0)
 #define FSV_SCHED_FENCE() ((void)0)
 #else
 typedef __amdgpu_buffer_rsrc_t fsv_buf;
@@ -40,6 +48,25 @@ __device__ __forceinline__ float4 fsv_buf_load4(fsv_buf b, unsigned off) {
 __device__ __forceinline__ float fsv_buf_load1(fsv_buf b, unsigned off) {
   return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(b, off, 0, 0));
 }
+// buffer_load_dwordx4 ... lds: no destination registers; the wave's 64 quads are written to 1 KB of LDS starting at the wave-uniform
+// address lds_wave_base (M0), lane l at + 16 l; counted by vmcnt like any other buffer load.  Issued through inline assembly on
+// purpose: with the builtin the compiler's wait-count pass treats every later ds_read as a possible reader of the data in flight
+// and puts s_waitcnt vmcnt(0) in front of it (alias scopes did not survive the loop structure); the kernel that uses this waits for
+// its own loads explicitly (FSV_WAIT_VMCNT) in front of the barrier that publishes them.
+typedef int fsv_rawbuf __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ fsv_rawbuf fsv_make_rawbuf(const void* p, long long bytes) {
+  const unsigned long long a = (unsigned long long)p;
+  fsv_rawbuf r;
+  r.x = (int)(unsigned)a; r.y = (int)(unsigned)((a >> 32) & 0xffffull); r.z = (int)bytes; r.w = 0x00020000;
+  return r;
+}
+__device__ __forceinline__ void fsv_buf_load4_lds(fsv_rawbuf b, unsigned off, float* lds_wave_base) {
+  const unsigned l = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long long)lds_wave_base);
+  // (the descriptor is built from kernel arguments only: uniform, the "s" constraint needs no readfirstlane)
+  asm volatile("s_mov_b32 m0, %0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" ::"s"(l), "v"(off), "s"(b) : "memory");
+}
+// s_waitcnt vmcnt(n) alone (gfx9 encoding: vmcnt in bits 3:0 and 15:14, expcnt 6:4 and lgkmcnt 11:8 left at "no wait")
+#define FSV_WAIT_VMCNT(n) __builtin_amdgcn_s_waitcnt(((n) & 15) | (((n) >> 4) << 14) | (7 << 4) | (15 << 8))
 // nothing is scheduled across this point: keeps the next chunk's loads at the top of the K loop and their LDS stores (with
 // the vmcnt waits they carry) behind the MFMAs that cover the latency
 #define FSV_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)

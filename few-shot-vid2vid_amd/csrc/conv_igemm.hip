@@ -13,7 +13,9 @@
 // 1/sigma).  Tiles are staged through two LDS buffers (one barrier per 32-wide K chunk): A as [row][8 quads of 4 k] with the
 // quads XOR-swizzled by the row (ds_write_b128 stores; fragments read with ds_read_b128 + a per-MFMA select, or - the AF
 // variants every tile shape runs as since round 3 - as a re-ordered quad read in place with ds_read_b64), B as [k][n] as it
-// lies in HBM; the scalar-gather twin (Cin % 4 != 0) keeps round 1's transposed [k][m] image.  Details at the kernels below.
+// lies in HBM; the scalar-gather twin (Cin % 4 != 0) keeps round 1's transposed [k][m] image.  The 64x128 tile - the template most of
+// the step's time is spent in - loads straight into LDS (buffer_load_dwordx4 ... lds, three buffers, no register staging: the LD
+// form below).  Details at the kernels below.
 // The MFMA result is bitwise an fp32 fma chain (guide section 3), which is what lets the parity tests use a
 // 1e-3 relative tolerance against the fp32 CPU oracle with a wide margin.
 #include <stdlib.h>
@@ -54,8 +56,18 @@ __device__ __forceinline__ void fsv_xcd_tile(int nx, int ny, int& bx, int& by) {
 // loaded a whole chunk earlier, for grids with one workgroup per CU where nothing else covers the HBM latency.
 // DBG (only with -DFSV_DIAG, tools/knockout.py): bit mask of the loop's parts that are left out to see what each costs -
 // 1 barrier, 2 LDS stores, 4 global loads, 8 fragment reads, 16 offset arithmetic, 32 epilogue stores (PF = 2 loop only)
-template <int BM, int BN, int WM, int WN, int PF, bool AF, int DBG = 0>
+// LD (experimental, 8-wave tiles, PF = 2 + AF only): the global loads write LDS directly (buffer_load_dwordx4 ... lds: a wave's 64
+// quads land in 1 KB of consecutive LDS, so lanes are mapped to the LDS image and the slot swizzle of A moves to the GLOBAL side - lane
+// (row r, slot s) fetches quad s ^ swz(r)); no register staging, no ds_write, three LDS buffers instead of two register sets.  The
+// quad of a row then lies in memory order (k0 k1 k2 k3), so in-place fragments pair the k of an MFMA step as (k, k + 2): lanes 0-31
+// read (k0 k1), lanes 32-63 (k2 k3) - every output's fp32 chain sums the same products in the order k0 k2 k1 k3 instead of ascending.
+// MODE 1 (PF = 2): whole trips - the loop always runs its two chunks per trip; chunks past the end of the K range (or of this
+// split's share of it) load zeros and are multiplied like the others.  The exit between the two chunks of a trip made the compiler
+// keep the accumulators in two register sets and copy one into the other after every first chunk (s_nop 16 + 8 v_mov_b64 + s_nop:
+// the wave waits for its last MFMA).  MODE 2 = LD, whole trips of three.
+template <int BM, int BN, int WM, int WN, int PF, bool AF, int DBG = 0, int MODE = 0>
 __device__ __forceinline__ void fsv_conv_igemm_body(const ConvP& p, const int bx, const int by, const int bz) {
+  constexpr bool LD = MODE == 2, WT = MODE >= 1;
   constexpr int BK = FSV_BK;
   constexpr int NT = 64 * WM * WN;    // 4 or 8 waves
   constexpr int RPA = NT / 8;         // A rows per pass (8 threads per row)
@@ -66,9 +78,11 @@ __device__ __forceinline__ void fsv_conv_igemm_body(const ConvP& p, const int bx
   constexpr int NPB = BK / RPB;       // B passes
   constexpr int A_ST = BM * BK, B_ST = BK * BN;
   static_assert(TM >= 1 && TN >= 1 && NPA >= 1 && NPA * RPA == BM && NPB >= 1 && NPB * RPB == BK, "tile / thread-count mismatch");
-  __shared__ __attribute__((aligned(16))) float smem[2 * (A_ST + B_ST)];
+  constexpr int NBUF = LD ? 3 : 2;
+  static_assert(!LD || (PF == 2 && AF), "LD form: prefetch distance 2, in-place fragments");
+  __shared__ __attribute__((aligned(16))) float smem[NBUF * (A_ST + B_ST)];
   float* const As = smem;
-  float* const Bs = smem + 2 * A_ST;
+  float* const Bs = smem + NBUF * A_ST;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
@@ -78,7 +92,10 @@ __device__ __forceinline__ void fsv_conv_igemm_body(const ConvP& p, const int bx
   const float* wt = p.wt + (long long)zs * p.w_bstride;
 
   // ---- per-thread A row bookkeeping ------------------------------------------------------------------
-  const int kq = tid & 7, ar0 = tid >> 3;
+  // LD: the lane's LDS slot is fixed by its lane id; the quad it fetches is the one that belongs there (rows of one thread are
+  // RPA = 64 apart: the same swizzle for all of them)
+  const int ar0 = tid >> 3;
+  const int kq = LD ? ((tid & 7) ^ ((ar0 >> 1) & 7)) : (tid & 7);
   int a_iy0[NPA], a_ix0[NPA], a_pix[NPA];
   const int ohw = p.OH * p.OW;
 #pragma unroll
@@ -99,13 +116,15 @@ __device__ __forceinline__ void fsv_conv_igemm_body(const ConvP& p, const int bx
   const bool bcol_ok = bcol < p.ldw;
   const fsv_buf abuf = fsv_make_buf(p.in, (long long)p.N * p.H * p.W * p.Cin * 4);
   const fsv_buf bbuf = fsv_make_buf(wt, (long long)p.nchunks * BK * p.ldw * 4);
+  const fsv_rawbuf araw = fsv_make_rawbuf(p.in, (long long)p.N * p.H * p.W * p.Cin * 4);          // LD form only
+  const fsv_rawbuf braw = fsv_make_rawbuf(wt, (long long)p.nchunks * BK * p.ldw * 4);
 
   // chunk range of this K split
   const int cps = (p.nchunks + p.nsplit - 1) / p.nsplit;
   const int c_begin = zk * cps;
   const int c_end = (c_begin + cps < p.nchunks) ? (c_begin + cps) : p.nchunks;
 
-  constexpr int NSET = PF >= 2 ? 2 : 1;        // register sets of global loads in flight
+  constexpr int NSET = LD ? 1 : (PF >= 2 ? 2 : 1);        // register sets of global loads in flight (LD: unused)
   float4 areg[NSET][NPA], breg[NSET][NPB];
   unsigned aoff[NPA], boff[NPB];
   // Byte offsets of one chunk's loads (FSV_BUF_OOB = "absent": hardware zero fill), computed one chunk ahead of their loads
@@ -118,8 +137,12 @@ __device__ __forceinline__ void fsv_conv_igemm_body(const ConvP& p, const int bx
   int cur_ci = cur_k - cur_t * p.Cin;
   const int q32 = BK / p.Cin, r32 = BK - q32 * p.Cin;
   int cur_b = (c_begin * BK + br0) * p.ldw + bcol;      // element offset of this thread's first weight row
+  // whole trips: chunks at or past c_end load zeros on both sides (another split's share of K must not be multiplied here)
+  const int k_lim = WT ? (c_end * BK < p.K ? c_end * BK : p.K) : p.K;
+  const int kb_lim = c_end * BK + kq * 4;
   auto calc_offsets = [&]() {
-    const bool kok = cur_k < p.K;
+    const bool kok = cur_k < k_lim;
+    const bool b_live = WT ? (bcol_ok & (cur_k < kb_lim)) : bcol_ok;
     int ty, tx;
     fsv_tap(p, cur_t, ty, tx);
     const int toff = ((ty * p.W + tx) * p.Cin + cur_ci) * 4;
@@ -128,10 +151,11 @@ __device__ __forceinline__ void fsv_conv_igemm_body(const ConvP& p, const int bx
       const int iy = a_iy0[i] + ty, ix = a_ix0[i] + tx;
       // `&`, not `&&`: a short-circuit here turns the whole offset computation into a guarded basic block
       const bool ok = kok & ((unsigned)iy < (unsigned)p.H) & ((unsigned)ix < (unsigned)p.W);
-      aoff[i] = ok ? (unsigned)(a_pix[i] + toff) : FSV_BUF_OOB;
+      if constexpr (WT) aoff[i] = (unsigned)(a_pix[i] + toff) | (ok ? 0u : FSV_BUF_OOB);      // any offset >= 2^31 is out of range
+      else aoff[i] = ok ? (unsigned)(a_pix[i] + toff) : FSV_BUF_OOB;
     }
 #pragma unroll
-    for (int i = 0; i < NPB; ++i) boff[i] = bcol_ok ? (unsigned)((cur_b + i * RPB * p.ldw) * 4) : FSV_BUF_OOB;
+    for (int i = 0; i < NPB; ++i) boff[i] = b_live ? (unsigned)((cur_b + i * RPB * p.ldw) * 4) : FSV_BUF_OOB;
     cur_k += BK;
     cur_t += q32;
     cur_ci += r32;
@@ -145,6 +169,16 @@ __device__ __forceinline__ void fsv_conv_igemm_body(const ConvP& p, const int bx
     for (int i = 0; i < NPA; ++i) ar[i] = fsv_buf_load4(abuf, aoff[i]);
 #pragma unroll
     for (int i = 0; i < NPB; ++i) br[i] = fsv_buf_load4(bbuf, boff[i]);
+  };
+  // LD: the same loads straight into LDS buffer nb; a wave's lanes cover 8 consecutive A rows (8 slots each) resp. 64 / QB
+  // consecutive B rows - exactly the 1 KB the instruction writes
+  auto issue_loads_lds = [&](float* a_buf, float* b_buf) {
+    float* a_dst = a_buf + wave * (8 * BK);
+    float* b_dst = b_buf + wave * ((64 / QB) * BN);
+#pragma unroll
+    for (int i = 0; i < NPA; ++i) fsv_buf_load4_lds(araw, aoff[i], a_dst + i * (RPA * BK));
+#pragma unroll
+    for (int i = 0; i < NPB; ++i) fsv_buf_load4_lds(braw, boff[i], b_dst + i * (RPB * BN));
   };
   // AF (round 3): the quad (k0 k1 k2 k3) of a row is stored as (k0 k2 | k1 k3) - rows with bit 4 set as
   // (k1 k3 | k0 k2) - so that a lane reads exactly the two values its MFMA steps multiply with ONE ds_read_b64 (lanes 0-31 take
@@ -187,10 +221,11 @@ __device__ __forceinline__ void fsv_conv_igemm_body(const ConvP& p, const int bx
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
     const int r = wm * (TM * 32) + i * 32 + lrow;
-    a_off[i] = r * BK + (AF ? 2 * (lk ^ ((r >> 4) & 1)) : 0);       // AF: this lane's half of every quad
+    a_off[i] = r * BK + (LD ? 2 * lk : (AF ? 2 * (lk ^ ((r >> 4) & 1)) : 0));       // AF: this lane's half of every quad
     a_swz[i] = (r >> 1) & 7;
   }
-  const int b_off = lk * BN + wn * (TN * 32) + lrow;
+  // LD: lanes 32-63 multiply k + 2 of a quad (rows 2 apart), not k + 1
+  const int b_off = (LD ? 2 * lk : lk) * BN + wn * (TN * 32) + lrow;
 
   // fragments of one k-group (8 k): the two quads of A per row tile, four B values per column tile.  MFMA step s of the
   // group multiplies k = 8g + 2s (lanes 0-31) and k = 8g + 2s + 1 (lanes 32-63): the sum over k stays ONE ascending fp32 fma
@@ -211,7 +246,7 @@ __device__ __forceinline__ void fsv_conv_igemm_body(const ConvP& p, const int bx
 #pragma unroll
     for (int t = 0; t < 4; ++t)
 #pragma unroll
-      for (int j = 0; j < TN; ++j) b[t][j] = b_src[b_off + (8 * g + 2 * t) * BN + j * 32];
+      for (int j = 0; j < TN; ++j) b[t][j] = b_src[b_off + (LD ? 8 * g + 4 * (t >> 1) + (t & 1) : 8 * g + 2 * t) * BN + j * 32];
   };
   auto mma_group = [&](const float4 (&a4)[2][TM], const float (&b)[4][TN]) {
 #pragma unroll
@@ -271,8 +306,55 @@ __device__ __forceinline__ void fsv_conv_igemm_body(const ConvP& p, const int bx
     if constexpr (!(DBG & 1)) __syncthreads();
   };
 
+  // LD: chunk c is multiplied out of LDS buffer c % 3 while the loads of chunk c + 2 fill buffer (c + 2) % 3 - the one chunk c - 1 was
+  // read from, free since the barrier that closed it; before this chunk's barrier only the loads of chunk c + 1 are waited for
+  // one chunk out of (a_src, b_src) while the loads of the chunk after next fill (a_dma, b_dma)
+  auto chunk_lds = [&](float* a_dma, float* b_dma, const float* a_src, const float* b_src) {
+    issue_loads_lds(a_dma, b_dma);
+    float4 fa[2][2][TM];
+    float fb[2][4][TN];
+    read_group(a_src, b_src, 0, fa[0], fb[0]);
+    FSV_SCHED_FENCE();
+    calc_offsets();
+    read_group(a_src, b_src, 1, fa[1], fb[1]);
+    FSV_SCHED_FENCE();
+    mma_group(fa[0], fb[0]);
+    FSV_SCHED_FENCE();
+    read_group(a_src, b_src, 2, fa[0], fb[0]);
+    FSV_SCHED_FENCE();
+    mma_group(fa[1], fb[1]);
+    FSV_SCHED_FENCE();
+    read_group(a_src, b_src, 3, fa[1], fb[1]);
+    FSV_SCHED_FENCE();
+    mma_group(fa[0], fb[0]);
+    FSV_SCHED_FENCE();
+    mma_group(fa[1], fb[1]);
+    FSV_WAIT_VMCNT(NPA + NPB);
+    __syncthreads();
+  };
+  // the loop over three LDS buffers (a fourth - loads three chunks ahead, 96 KB - costs 0.6 ... 1.1 ms per step in occupancy); the loads of a chunk are waited for explicitly (FSV_WAIT_VMCNT) in front of the barrier that
+  // publishes them - issued through inline assembly, they are invisible to the compiler's own wait-count pass (conv_igemm.h)
+  auto loop_lds = [&]() {
+    float* const A0 = As, * const A1 = As + A_ST, * const A2 = As + 2 * A_ST;
+    float* const B0 = Bs, * const B1 = Bs + B_ST, * const B2 = Bs + 2 * B_ST;
+    calc_offsets();
+    issue_loads_lds(A0, B0);
+    calc_offsets();
+    issue_loads_lds(A1, B1);
+    calc_offsets();
+    FSV_WAIT_VMCNT(NPA + NPB);
+    __syncthreads();
+#pragma unroll 1
+    for (int kc = c_begin; kc < c_end; kc += 3) {
+      chunk_lds(A2, B2, A0, B0);
+      chunk_lds(A0, B0, A1, B1);
+      chunk_lds(A1, B1, A2, B2);
+    }
+  };
   if (c_begin < c_end) {
-    if constexpr (PF == 1) {
+    if constexpr (LD) {
+      loop_lds();
+    } else if constexpr (PF == 1) {
       calc_offsets();
       issue_loads(areg[0], breg[0]);
       calc_offsets();
@@ -326,7 +408,7 @@ __device__ __forceinline__ void fsv_conv_igemm_body(const ConvP& p, const int bx
 #pragma unroll 1
       for (int kc = c_begin; kc < c_end; kc += 2) {
         chunk(0, areg[0], breg[0], areg[1], breg[1]);
-        if (kc + 1 >= c_end) break;
+        if constexpr (!WT) { if (kc + 1 >= c_end) break; }
         chunk(1, areg[1], breg[1], areg[0], breg[0]);
       }
     }
@@ -397,11 +479,11 @@ __device__ __forceinline__ void fsv_conv_igemm_body(const ConvP& p, const int bx
   }
 }
 
-template <int BM, int BN, int WM, int WN, int PF = 1, bool AF = false, int DBG = 0>
+template <int BM, int BN, int WM, int WN, int PF = 1, bool AF = false, int DBG = 0, int MODE = 0>
 __global__ __launch_bounds__(64 * WM * WN) void fsv_conv_igemm_kernel(ConvP p) {
   int bx, by;
   fsv_xcd_tile(gridDim.x, gridDim.y, bx, by);
-  fsv_conv_igemm_body<BM, BN, WM, WN, PF, AF, DBG>(p, bx, by, (int)blockIdx.z);
+  fsv_conv_igemm_body<BM, BN, WM, WN, PF, AF, DBG, MODE>(p, bx, by, (int)blockIdx.z);
 }
 
 // Grouped launch: up to FSV_GROUP_MAX INDEPENDENT gather-GEMM problems in one 1-D grid (the problem table travels in the
@@ -418,7 +500,7 @@ struct ConvGroup {
   ConvP p[FSV_GROUP_MAX];
 };
 
-template <int BM, int BN, int WM, int WN, int PF = 1, bool AF = false>
+template <int BM, int BN, int WM, int WN, int PF = 1, bool AF = false, int MODE = 0>
 __global__ __launch_bounds__(64 * WM * WN) void fsv_conv_igemm_group_kernel(ConvGroup g) {
   const int b = blockIdx.x;
   int i = 0;
@@ -427,7 +509,7 @@ __global__ __launch_bounds__(64 * WM * WN) void fsv_conv_igemm_group_kernel(Conv
   const ConvP& p = g.p[i];
   const int gx = (p.Mz + BM - 1) / BM, gy = (p.Cout + BN - 1) / BN;
   const int r = t / gx;
-  fsv_conv_igemm_body<BM, BN, WM, WN, PF, AF>(p, t - r * gx, r % gy, r / gy);
+  fsv_conv_igemm_body<BM, BN, WM, WN, PF, AF, 0, MODE>(p, t - r * gx, r % gy, r / gy);
 }
 
 // Scalar-gather twin for Cin % 4 != 0 (image / label inputs that were not channel-padded): single LDS buffer, A transposed
@@ -677,6 +759,8 @@ __device__ __forceinline__ void fsv_xcd_range(int& kt, int& nt, int& z) {
 // free); two LDS buffers, one barrier per 32-pixel chunk, absent rows / columns are loaded at FSV_BUF_OOB.
 // PF: prefetch distance of the global loads in chunks of 32 pixels (see the forward kernel): 1 = one register set, the loads of
 // chunk c + 1 issued at the top of chunk c; 2 = two sets, the set stored behind the 12th MFMA was loaded a whole chunk earlier.
+// (A form with the loads written straight into LDS - the forward kernel's LD - was built and measured in round 3: 2 ... 15 % SLOWER per
+// shape, +0.45 ms on the step: its whole trips of three chunks pad reductions that are split into pieces of 8 - 16 chunks.  Removed.)
 template <int BMK, int BN, int WM, int WN, bool COUT4, int PF = 1>
 __device__ __forceinline__ void fsv_conv_wgrad_body(const WgradP& p, const int kt, const int nt, const int bz) {
   constexpr int BK = FSV_BK;   // pixels per chunk
@@ -1419,6 +1503,10 @@ static inline int fsv_tile_dims(int tile, int& bm, int& bn) {
     case 18: bm = 128; bn = 32; return 0;
     // 64x64 with a prefetch distance of two chunks + in-place A fragments
     case 20: bm = 64; bn = 64; return 0;
+    // global loads straight into LDS (three buffers); the same form of the 128x128 and 128x32 tiles lost (96 / 60 KB of LDS) and was removed
+    case 21: bm = 64; bn = 128; return 0;
+    case 22: bm = 128; bn = 64; return 0;
+    case 27: bm = 64; bn = 64; return 0;
 #ifdef FSV_DIAG
     case 30: case 31: case 32: case 33: case 34: case 35: case 36: case 37: bm = 64; bn = 128; return 0;
 #endif
@@ -1433,12 +1521,15 @@ static inline int fsv_tile_dims(int tile, int& bm, int& bn) {
 // round 2 measured at +5 % over the base tile); 128x128 -> PF 1 + AF (id 16: its PF 2 forms lose occupancy - 168 registers - on
 // the multi-workgroup grids it is picked for); 64x64 -> PF 2 + AF (id 20): per shape with warm caches it equals PF 1 + AF (id 17:
 // 78.9 vs 81.4 ... 86.4 vs 85.7 TFLOP/s), inside the step - every layer's weights cold - it is worth 0.3 ms (49.19 vs 49.48, two
-// in-box pairs); the same form of the 128x32 tile loses 0.2 ms there and was removed.  FSV_CONV_V<shape>=<id> overrides one shape (A/B runs).
+// in-box pairs); the same form of the 128x32 tile loses 0.2 ms there and was removed.  64x128 -> loads straight into LDS (id 21, LD in
+// the kernel's header comment): +3 ... +6 % per shape over id 13 (111 - 121 TFLOP/s), -0.17 ... -0.25 ms on the step (three in-box
+// triples); the LD forms of 128x64 (22) and 64x64 (27) gain per shape (+4 %, +17 % on M2048 N512 K2304) and nothing inside the step:
+// reachable, not default.  FSV_CONV_V<shape>=<id> overrides one shape (A/B runs).
 static inline int fsv_conv_variant(int shape) {
   static int map[10] = {-2, -2, -2, -2, -2, -2, -2, -2, -2, -2};
   if (shape < 0 || shape > 9) return shape;
   if (map[shape] == -2) {
-    static const int dflt[10] = {16, 15, 18, -1, 20, -1, -1, -1, -1, 13};
+    static const int dflt[10] = {16, 15, 18, -1, 20, -1, -1, -1, -1, 21};
     char name[16];
     snprintf(name, sizeof(name), "FSV_CONV_V%d", shape);
     const char* e = getenv(name);
@@ -1468,6 +1559,9 @@ static int fsv_launch_conv(const ConvP& p, bool vec4, int nz, hipStream_t stream
       case 17: FSV_LAUNCH((fsv_conv_igemm_kernel<64, 64, 2, 2, 1, true>), g, dim3(256), stream, p); break;
       case 18: FSV_LAUNCH((fsv_conv_igemm_kernel<128, 32, 4, 1, 1, true>), g, dim3(256), stream, p); break;
       case 20: FSV_LAUNCH((fsv_conv_igemm_kernel<64, 64, 2, 2, 2, true>), g, dim3(256), stream, p); break;
+      case 21: FSV_LAUNCH((fsv_conv_igemm_kernel<64, 128, 2, 4, 2, true, 0, 2>), g, dim3(512), stream, p); break;
+      case 22: FSV_LAUNCH((fsv_conv_igemm_kernel<128, 64, 4, 2, 2, true, 0, 2>), g, dim3(512), stream, p); break;
+      case 27: FSV_LAUNCH((fsv_conv_igemm_kernel<64, 64, 2, 2, 2, true, 0, 2>), g, dim3(256), stream, p); break;
 #ifdef FSV_DIAG
       // knock-out forms of the dominant kernel (tools/knockout.py; results are wrong by construction, only the time is read)
       case 30: FSV_LAUNCH((fsv_conv_igemm_kernel<64, 128, 2, 4, 2, true, 1>), g, dim3(512), stream, p); break;
@@ -1482,8 +1576,8 @@ static int fsv_launch_conv(const ConvP& p, bool vec4, int nz, hipStream_t stream
       default: FSV_LAUNCH((fsv_conv_igemm_kernel<64, 128, 2, 4>), g, dim3(512), stream, p); break;
     }
   } else {
-    if (tile == 10 || tile == 13) tile = 9; else if (tile == 11 || tile == 14 || tile == 16) tile = 0; else if (tile == 12 || tile == 15) tile = 1;     // scalar gather: no variants
-    else if (tile == 17 || tile == 20) tile = 4; else if (tile == 18) tile = 2;
+    if (tile == 10 || tile == 13 || tile == 21) tile = 9; else if (tile == 11 || tile == 14 || tile == 16) tile = 0; else if (tile == 12 || tile == 15 || tile == 22) tile = 1;     // scalar gather: no variants
+    else if (tile == 17 || tile == 20 || tile == 27) tile = 4; else if (tile == 18) tile = 2;
     switch (tile) {
       case 0: FSV_LAUNCH((fsv_conv_igemm_v1_kernel<128, 128, 2, 2>), g, dim3(256), stream, p); break;
       case 1: FSV_LAUNCH((fsv_conv_igemm_v1_kernel<128, 64, 2, 2>), g, dim3(256), stream, p); break;
@@ -1914,7 +2008,7 @@ int fsv_conv_gather_group(const fsv_conv_desc* d, int n, int force_tile, hipStre
     }
     if (tile < 0) tile = 4;
   }
-  if (tile >= 10) tile = (tile == 10 || tile == 13) ? 9 : (tile == 11 || tile == 14 || tile == 16) ? 0 : (tile == 17 || tile == 20) ? 4 : (tile == 18) ? 2 : 1;
+  if (tile >= 10) tile = (tile == 10 || tile == 13 || tile == 21) ? 9 : (tile == 11 || tile == 14 || tile == 16) ? 0 : (tile == 17 || tile == 20 || tile == 27) ? 4 : (tile == 18) ? 2 : 1;
   int bm, bn;
   if (fsv_tile_dims(tile, bm, bn)) return FSV_ERR_BAD_ARG;
   // K splits: only problems that accumulate into a zeroed output, and only when the whole group would leave CUs idle
@@ -1969,6 +2063,9 @@ int fsv_conv_gather_group(const fsv_conv_desc* d, int n, int force_tile, hipStre
         case 17: FSV_LAUNCH((fsv_conv_igemm_group_kernel<64, 64, 2, 2, 1, true>), grid, dim3(256), stream, g); break;
         case 18: FSV_LAUNCH((fsv_conv_igemm_group_kernel<128, 32, 4, 1, 1, true>), grid, dim3(256), stream, g); break;
         case 20: FSV_LAUNCH((fsv_conv_igemm_group_kernel<64, 64, 2, 2, 2, true>), grid, dim3(256), stream, g); break;
+        case 21: FSV_LAUNCH((fsv_conv_igemm_group_kernel<64, 128, 2, 4, 2, true, 2>), grid, dim3(512), stream, g); break;
+        case 22: FSV_LAUNCH((fsv_conv_igemm_group_kernel<128, 64, 4, 2, 2, true, 2>), grid, dim3(512), stream, g); break;
+        case 27: FSV_LAUNCH((fsv_conv_igemm_group_kernel<64, 64, 2, 2, 2, true, 2>), grid, dim3(256), stream, g); break;
         default: return FSV_ERR_BAD_ARG;
       }
     } else {

@@ -218,7 +218,7 @@ class SpectralState:
 
 
 class SpectralGroup:
-    """All spectral-normalised layers of one network, power-iterated together in three launches
+    """All spectral-normalised layers of one network, power-iterated together in four launches
     (csrc/specnorm.hip, fsv_sn_power_iter_batched) at the start of the network's forward pass.
 
     `layers` are modules exposing weight_orig / weight_u / weight_v.  After `update()` every layer holds a fresh

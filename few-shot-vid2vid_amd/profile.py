@@ -26,7 +26,7 @@ FP32_MFMA_PEAK = 157.3e12
 F16_MFMA_PEAK = 2.5e15        # dense f16 / bf16 matrix peak (MI355X_MICROARCH.md; the 2:1-sparse figure is not used)
 
 TILE_NAMES = {0: '128x128', 1: '128x64', 2: '128x32', 4: '64x64', 9: '64x128', 10: '64x128pf2', 11: '128x128pf2', 12: '128x64pf2',
-              13: '64x128pf2af', 14: '128x128pf2af', 15: '128x64pf2af', 16: '128x128af', 17: '64x64af', 18: '128x32af', 20: '64x64pf2af'}
+              13: '64x128pf2af', 14: '128x128pf2af', 15: '128x64pf2af', 16: '128x128af', 17: '64x64af', 18: '128x32af', 20: '64x64pf2af', 21: '64x128lds', 22: '128x64lds', 27: '64x64lds'}
 
 
 def enable(detail=False):

@@ -856,6 +856,11 @@ def check_conv_groups(device, seed=77, big=False):
         assert float((a.cpu() - bb.cpu()).abs().max()) == 0.0, 'grouped launch differs from the single launch (problem %d)' % i
     for tile in (0, 1, 2, 9):               # every tile shape of the grouped kernel (the plan picked 64x64 above)
         for i, (a, bb) in enumerate(zip(one, run(True, specs[:6], tile))):
+            if tile == 9:
+                # the 64x128 shape runs as the loads-straight-into-LDS variant, which sums every output's products in the order
+                # k0 k2 k1 k3 per quad instead of ascending (csrc/conv_igemm.hip, LD): same products, not the same bits
+                assert_close('grouped launch, tile 9, problem %d' % i, bb, a, tol=2e-5)
+                continue
             assert float((a.cpu() - bb.cpu()).abs().max()) == 0.0, 'grouped launch, tile %d, problem %d' % (tile, i)
         for i, (a, bb) in enumerate(zip(run(False, specs_s0), run(True, specs_s0, tile))):
             assert float((a.cpu() - bb.cpu()).abs().max()) == 0.0, 'scalar-gather group, tile %d, problem %d' % (tile, i)

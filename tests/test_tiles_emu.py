@@ -27,3 +27,9 @@ def test_prefetch_two_variant(variant, base):
     chunk counts 1 ... 11 per K split (odd and even: the loop runs two chunks per trip)"""
     tc.check_forward_tiles(CPU, tiles=(variant,), geoms=tc.GEOMS)
     tc.check_variant_equals_plan_tile(CPU, variant, base)
+
+
+@pytest.mark.parametrize('tile', tc.REORDERED_FWD_TILES)
+def test_lds_direct_variant(tile):
+    """loads straight into LDS, three buffers, whole trips of three chunks (chunk counts 1 ... 11 per split: every remainder)"""
+    tc.check_forward_tiles(CPU, tiles=(tile,), geoms=tc.GEOMS)

@@ -12,7 +12,7 @@ conv = import_module('few-shot-vid2vid_amd.conv')
 dev = torch.device('cuda:0')
 # FSV_AB_EXPERIMENTAL=1 adds the force_tile-only variants (10 / 11 / 12: 64x128 / 128x128 / 128x64 with a prefetch distance of two
 # chunks) next to the tiles of the plan
-EXPERIMENTAL = (10, 11, 12, 13, 14, 15, 16, 17, 18, 20) if os.environ.get('FSV_AB_EXPERIMENTAL', '0') == '1' else ()      # 13 - 15: mid-chunk barrier
+EXPERIMENTAL = (10, 11, 12, 13, 14, 15, 16, 17, 18, 20, 21, 22, 27) if os.environ.get('FSV_AB_EXPERIMENTAL', '0') == '1' else ()      # 13 - 15: mid-chunk barrier
 ONLY = tuple(int(t) for t in os.environ.get('FSV_AB_TILES', '').split(',') if t)          # restrict the tile ids (short runs)
 SPLITS = tuple(int(t) for t in os.environ.get('FSV_AB_SPLITS', '1,2,4,8').split(','))
 cfgs = [(-1, 0)] + [(t_, s_) for t_ in (0, 1, 2, 4, 9) + EXPERIMENTAL if not ONLY or t_ in ONLY for s_ in SPLITS]
@@ -43,7 +43,7 @@ for name, n, cin, h, w, cout, k in shapes:
     flops = 2.0 * n * h * w * cout * cin * k * k
     graphs = {}
     for c in cfgs:
-        if c[0] in (0, 9, 10, 11, 13, 14, 16) and cout < 128 or c[0] in (1, 12, 15) and cout < 64 or c[0] in (2, 18) and cout > 32:
+        if c[0] in (0, 9, 10, 11, 13, 14, 16, 21) and cout < 128 or c[0] in (1, 12, 15, 22) and cout < 64 or c[0] in (2, 18) and cout > 32:
             continue
         f = lambda: conv.conv_forward(x, wf, ldw, cout, g, bias=b, act=conv.ACT_LRELU, force_tile=c[0], force_split=c[1])
         s = torch.cuda.Stream(); s.wait_stream(torch.cuda.current_stream())
