@@ -20,6 +20,7 @@ import torch
 from . import lib
 
 _enabled = False
+_only = None          # second pass of bench.py: bracket the launches of ONE kernel label only
 _detail = False       # tools/shape_profile.py: append the GEMM shape to every label
 _records = []          # (label, flops, ev0, ev1)
 FP32_MFMA_PEAK = 157.3e12
@@ -29,9 +30,11 @@ TILE_NAMES = {0: '128x128', 1: '128x64', 2: '128x32', 4: '64x64', 9: '64x128', 1
               13: '64x128pf2af', 14: '128x128pf2af', 15: '128x64pf2af', 16: '128x128af', 17: '64x64af', 18: '128x32af', 20: '64x64pf2af', 21: '64x128lds', 22: '128x64lds', 27: '64x64lds'}
 
 
-def enable(detail=False):
-    global _enabled, _records, _detail
-    _enabled, _records, _detail = True, [], detail
+def enable(detail=False, only=None):
+    """only: bracket the launches with this label alone (no replay closures kept) - with ~130 event pairs instead of ~450 in the
+    pass the eager step idles less between launches and the brackets read closer to the kernel's time inside the replayed graph"""
+    global _enabled, _records, _detail, _only
+    _enabled, _records, _detail, _only = True, [], detail, only
 
 
 def disable():
@@ -53,17 +56,26 @@ class scope:
         self.label, self.flops, self.replay = label, flops, replay
 
     def __enter__(self):
-        if _enabled and not lib.is_emu():
+        self.on = _enabled and not lib.is_emu() and (_only is None or self.label == _only)
+        if self.on:
             self.e0 = torch.cuda.Event(enable_timing=True)
             self.e1 = torch.cuda.Event(enable_timing=True)
             self.e0.record()
         return self
 
     def __exit__(self, *exc):
-        if _enabled and not lib.is_emu():
+        if self.on:
             self.e1.record()
-            _records.append((self.label, self.flops, self.e0, self.e1, self.replay))
+            _records.append((self.label, self.flops, self.e0, self.e1, None if _only is not None else self.replay))
         return False
+
+
+def bracket_average(label):
+    """(launches, average seconds) of the recorded launches of `label`; clears the records"""
+    torch.cuda.synchronize()
+    ts = [e0.elapsed_time(e1) * 1e-3 for lab, _, e0, e1, _ in _records if lab == label]
+    _records.clear()
+    return len(ts), (sum(ts) / len(ts) if ts else 0.0)
 
 
 def conv_label(mz, cout, nchunks, nsamp, vec4, force_tile=-1, force_split=0):
@@ -125,6 +137,8 @@ def summary():
                         replay_us_warm_cache_upper_bound=None if replay_us is None else round(replay_us, 2),
                         gflop_per_launch=round(fl / n / 1e9, 3),
                         timing='HIP events around every launch of this kernel in an instrumented eager pass of the step '
-                               '(avg_launch_us); replay_us_warm_cache_upper_bound = the same launches re-issued back to back')
+                               '(bracketed_us: every MFMA kernel of the step bracketed; avg_launch_us, when bench.py ran its second '
+                               'pass: this kernel alone bracketed); replay_us_warm_cache_upper_bound = the same launches re-issued '
+                               'back to back')
     _records.clear()          # the replay closures pin every operand of the step
     return dict(dominant=dominant, by_kernel=by_kernel)
