@@ -245,6 +245,38 @@ def check_spectral_power_iteration(device, shapes=((40, 300), (130, 70), (512, 4
                 assert all(torch.equal(x, y) for x, y in zip(a, b)), 'power iteration differs between two runs from the same state'
 
 
+def check_cat_and_pad(device, seed=33):
+    """ops.cat_channels (forward + gradient slices) and ops.pad_channels_nhwc against torch, bit for bit, over the layouts the step
+    produces: channels-last sources with channel counts that are / are not multiples of four (float4 and element forms of
+    csrc/elementwise.hip), NCHW sources, channel slices of a wider tensor, an odd pixel count."""
+    ops, conv = pkg()
+    g = torch.Generator().manual_seed(seed)
+    cases = [((2, 8, 5, 7), (2, 12, 5, 7), True), ((2, 8, 5, 7), (2, 3, 5, 7), True), ((1, 16, 4, 6), (1, 4, 4, 6), False),
+             ((3, 5, 3, 3), (3, 6, 3, 3), False)]
+    for sa, sb, nhwc in cases:
+        a, b = torch.randn(sa, generator=g), torch.randn(sb, generator=g)
+        wide = torch.randn(sa[0], sa[1] + 8, sa[2], sa[3], generator=g)
+        ad, bd, wd = _dev(a, device), _dev(b, device), _dev(wide, device)
+        if nhwc:
+            ad, bd, wd = conv.to_nhwc(ad), conv.to_nhwc(bd), conv.to_nhwc(wd)
+        ad.requires_grad_(True); bd.requires_grad_(True)
+        sl = wd[:, 4:4 + sa[1]]                       # a channel slice: strided source (offset multiple of four)
+        y = ops.cat_channels([ad, bd, sl])
+        ref = torch.cat([a, b, wide[:, 4:4 + sa[1]]], dim=1)
+        assert torch.equal(y.detach().cpu(), ref), ('cat', sa, sb, nhwc)
+        dy = torch.randn(ref.shape, generator=g)
+        y.backward(_dev(dy, device))
+        assert torch.equal(ad.grad.cpu(), dy[:, :sa[1]]) and torch.equal(bd.grad.cpu(), dy[:, sa[1]:sa[1] + sb[1]]), ('cat grad', sa, sb)
+    for shape, cpad, nhwc in (((2, 3, 6, 5), 1, False), ((2, 6, 6, 5), 2, False), ((1, 10, 4, 4), 2, False), ((2, 15, 3, 5), 1, False),
+                              ((2, 6, 6, 5), 2, True), ((1, 17, 4, 4), 3, False)):
+        x = torch.randn(shape, generator=g)
+        xd = conv.to_nhwc(_dev(x, device)) if nhwc else _dev(x, device)
+        y = ops.pad_channels_nhwc(xd, cpad)
+        ref = F.pad(x, (0, 0, 0, 0, 0, cpad))
+        assert y.shape == ref.shape and torch.equal(y.cpu(), ref), ('pad', shape, cpad, nhwc)
+        assert y.permute(0, 2, 3, 1).is_contiguous()
+
+
 def check_linear(device, r=40, cin=16, cout=50, seed=2):
     ops, conv = pkg()
     g = torch.Generator().manual_seed(seed)

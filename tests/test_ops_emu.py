@@ -39,6 +39,10 @@ def test_spectral_power_iteration(emu_lib):
     oc.check_spectral_power_iteration(DEV, shapes=((40, 300), (130, 70), (200, 520)))
 
 
+def test_cat_and_pad_forms(emu_lib):
+    oc.check_cat_and_pad(DEV)
+
+
 def test_deferred_wgrad_finalize(emu_lib):
     oc.check_deferred_wgrad(DEV)
 

@@ -65,6 +65,10 @@ def test_spectral_power_iteration_is_reproducible(hip_lib):
     oc.check_spectral_power_iteration(dev(), repeats=25)
 
 
+def test_cat_and_pad_forms(hip_lib):
+    oc.check_cat_and_pad(dev())
+
+
 def test_fused_reductions(hip_lib):
     """last-workgroup second stage across the 8 XCDs: many repeats on the same buffers, sizes on both sides of the threshold"""
     oc.check_fused_reductions(dev(), repeats=25)
