@@ -39,6 +39,28 @@ def test_spectral_power_iteration(emu_lib):
     oc.check_spectral_power_iteration(DEV, shapes=((40, 300), (130, 70), (200, 520)))
 
 
+def test_split_cols_backward_is_one_concatenation_with_zeros_for_unused_pieces(emu_lib):
+    """ops.split_cols == torch.split(dim=1) in values and gradients, including pieces nobody reads (undefined gradients: the
+    custom backward fills them from a cached zero block instead of one zero-fill launch each)"""
+    ops, conv = oc.pkg()
+    g = torch.Generator().manual_seed(3)
+    f = torch.randn(3, 40, generator=g)
+    sizes = [12, 4, 12, 4, 8]
+    a = f.clone().requires_grad_(True)
+    b = f.clone().requires_grad_(True)
+    pa, pb = ops.split_cols(a, sizes), torch.split(b, sizes, dim=1)
+    assert all(torch.equal(x, y) for x, y in zip(pa, pb))
+    wts = [torch.randn(3, n, generator=g) for n in sizes]
+    use = (0, 1, 3)                                    # pieces 2 and 4 (the tail) are never read
+    sum((pa[i] * wts[i]).sum() for i in use).backward()
+    sum((pb[i] * wts[i]).sum() for i in use).backward()
+    assert torch.equal(a.grad, b.grad)
+    # a second call re-uses the cached zeros and must not have been written to
+    a2 = f.clone().requires_grad_(True)
+    (ops.split_cols(a2, sizes)[4] * wts[4]).sum().backward()
+    assert torch.equal(a2.grad[:, :32], torch.zeros(3, 32)) and torch.equal(a2.grad[:, 32:], wts[4])
+
+
 def test_cat_and_pad_forms(emu_lib):
     oc.check_cat_and_pad(DEV)
 
