@@ -15,7 +15,7 @@ Besides the contract fields the JSON line carries
                  on the launch stream around every launch of that kernel in an instrumented eager pass of the step
                  (`avg_launch_us`; the same launches re-issued back to back - warm caches, an upper bound - are reported as
                  `replay_us_warm_cache_upper_bound`); `traffic`: HBM bytes per launch from the committed rocprofv3 PMC passes
-                 of this command (profiles/r03_pmc_hbm_traffic.json, keyed by kernel and commit), null when that file does
+                 of this command (profiles/r0N_pmc_hbm_traffic*.json, keyed by kernel, source digest and workload), null when no file does
                  not describe the running build;
   cpu_baseline - the CPU oracle (oracle/fsv_oracle.py, a port of the reference's algorithm; kind "port": the Python
                  reference cannot travel to the GPU box) timed on the host cores on ONE iteration of the very same
@@ -60,16 +60,43 @@ def _synth():
     return import_module('few-shot-vid2vid_amd.synth')
 
 
-def build_opt(size, batch, vgg=None, face_d=None, flow_gt=False):
+# --workload: the BASELINE.json configs a single GPU can run.  `pose` (configs[2], C3) is the headline and the
+# default; the others print the same line for their own configuration (their `metric` names it) so that C1 / C2 / C5 are
+# driver-reproducible next to C3.  tflop = algorithmic work per frame of what the step runs (BASELINE.md section 2:
+# D step = G fwd + D fwd + D bwd, G step = G fwd + D fwd + D bwd + G bwd; face256 is defined generator-only).
+WORKLOADS = {
+    'pose':    dict(size=512, batch=2, tflop=1.66, g_only=False, what='fewshot_pose %dx%d, per-GPU batch %d, adaptive_spade+warp_ref+spade_combine'),
+    'face128': dict(size=128, batch=1, tflop=0.0655, g_only=False, what='fewshot_face %dx%d, per-GPU batch %d, adaptive_spade (BASELINE configs[0] on the GPU)'),
+    'face256': dict(size=256, batch=4, tflop=0.1407, g_only=True, what='fewshot_face %dx%d, per-GPU batch %d, adaptive_spade, generator forward + backward only (BASELINE configs[1])'),
+    'street':  dict(size=1024, batch=1, tflop=1.7845, g_only=False, what='fewshot_street %dx%d (W x H = 1024x512), label_nc 35, per-GPU batch %d, adaptive_spade (BASELINE configs[4] per rank)'),
+}
+WORKLOAD = 'pose'
+
+
+def build_opt(size, batch, vgg=None, face_d=None, flow_gt=False, workload=None):
     vgg = WITH_VGG if vgg is None else vgg
     face_d = WITH_FACE_D if face_d is None else face_d
+    workload = WORKLOAD if workload is None else workload
+    if workload in ('face128', 'face256'):
+        return _synth().make_opt(dataset_mode='fewshot_face', input_nc=1, fineSize=size, loadSize=size, batchSize=batch,
+                                 no_vgg_loss=not vgg, amp=AMP)
+    if workload == 'street':      # data/fewshot_street_dataset.py:19-27: aspect_ratio 2 (W = fineSize, H = fineSize / 2), one-hot labels
+        return _synth().make_opt(dataset_mode='fewshot_street', label_nc=35, input_nc=3, aspect_ratio=2.0, fineSize=size,
+                                 loadSize=size, batchSize=batch, no_vgg_loss=not vgg, amp=AMP)
     return _synth().make_opt(fineSize=size, loadSize=size, batchSize=batch, warp_ref=True, spade_combine=True,
                              remove_face_labels=True, no_vgg_loss=not (vgg or face_d), no_flow_gt=not flow_gt,
                              add_face_D=face_d, amp=AMP)
 
 
-def make_data(batch, size, seed, device):
-    tl, ti, rl, ri = _synth().synth_pose_inputs(batch, size, size, seed)
+def synth_inputs(opt, batch, seed):
+    h, w = int(opt.fineSize / opt.aspect_ratio), opt.fineSize
+    if opt.label_nc != 0:
+        return _synth().synth_street_inputs(batch, h, w, seed, opt.label_nc)
+    return _synth().synth_pose_inputs(batch, h, w, seed, opt.input_nc)
+
+
+def make_data(batch, size, seed, device, opt=None):
+    tl, ti, rl, ri = _synth().synth_pose_inputs(batch, size, size, seed) if opt is None else synth_inputs(opt, batch, seed)
     tl, ti, rl, ri = [t.to(device) for t in (tl, ti, rl, ri)]
     return [tl, ti, [None, None], [None, None], rl, ri, None, None, None]
 
@@ -106,16 +133,19 @@ def cpu_baseline(size, batch, threads, use_reference=False):
 
         def one(sz, b):
             opt = build_opt(sz, b, vgg=False, face_d=False)
+            opt.amp = 'O0'                        # the CPU leg is the reference's fp32 arithmetic whatever the GPU leg runs
             model = M.create_model(opt)           # only a source of random-init weights with the right shapes (CPU tensors)
             sdG = {k: v.detach().clone() for k, v in model.netG.state_dict().items()}
             sdD = {k: v.detach().clone() for k, v in model.netD.state_dict().items()}
             del model
-            data = syn.synth_pose_inputs(b, sz, sz, 99)
+            data = synth_inputs(opt, b, 99)
             cfg = O.cfg_from_opt(opt)
             t0 = time.perf_counter()
             O.iteration(sdG, sdD, cfg, data, torch.float32)
             return time.perf_counter() - t0
         kind, what = 'port', 'oracle/fsv_oracle.py'
+    if WORKLOAD != 'pose' and use_reference:
+        raise SystemExit("--use-reference times the headline workload only")
     one(64, 1)
     dt = one(size, batch)
     return dict(value=round(batch / dt, 4), unit='frames/s', cores=threads, kind=kind,
@@ -125,22 +155,28 @@ def cpu_baseline(size, batch, threads, use_reference=False):
 
 def pmc_traffic(label):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of this command (FETCH_SIZE x 2 per
-    the gfx950 note of MI355X_MICROARCH.md + WRITE_SIZE, tools/pmc_traffic.py) - only when that file was recorded for the very
-    kernel sources this library was built from (source digest); None otherwise: counters cannot be collected in-run."""
+    the gfx950 note of MI355X_MICROARCH.md + WRITE_SIZE, tools/pmc_traffic.py) - only from a file that was recorded for the very
+    kernel sources this library was built from (source digest) and for this workload; None otherwise: counters cannot be
+    collected in-run."""
+    import glob
     try:
         from importlib import import_module
         build = import_module('few-shot-vid2vid_amd.build')
-        with open(os.path.join(ROOT, 'profiles', 'r03_pmc_hbm_traffic.json')) as f:
-            d = json.load(f)
-        if d.get('_build', {}).get('source_digest') != build.source_digest():
-            return None
-        # label 'fsv_conv_igemm_kernel<64x128,V4>' -> PMC key 'void fsv_conv_igemm_kernel<64, 128, ...'
-        name, dims = label.split('<')[0], label.split('<')[1].split(',')[0].replace('pf2', '').split('x')
-        for k, v in d.items():
-            if k.startswith('void %s<%s, %s,' % (name, dims[0], dims[1])):
-                return dict(read_MB=v['read_MB_corrected'], write_MB=v['write_MB'],
-                            total_MB=round(v['read_MB_corrected'] + v['write_MB'], 2), unit='MB per launch',
-                            source='profiles/r03_pmc_hbm_traffic.json', commit=d['_build'].get('commit'))
+        digest = build.source_digest()
+        # label 'fsv_conv_igemm_kernel<64x128lds,V4>' -> PMC key 'void fsv_conv_igemm_kernel<64, 128, ...'
+        name, dims = label.split('<')[0], label.split('<')[1].split(',')[0]
+        dims = ''.join(ch if (ch.isdigit() or ch == 'x') else ' ' for ch in dims).split()[0].split('x')
+        for path in sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_pmc_hbm_traffic*.json')), reverse=True):
+            with open(path) as f:
+                d = json.load(f)
+            b = d.get('_build', {})
+            if b.get('source_digest') != digest or b.get('workload', 'pose') != WORKLOAD or b.get('amp', 'O0') != AMP:
+                continue
+            for k, v in d.items():
+                if k.startswith('void %s<%s, %s,' % (name, dims[0], dims[1])):
+                    return dict(read_MB=v['read_MB_corrected'], write_MB=v['write_MB'],
+                                total_MB=round(v['read_MB_corrected'] + v['write_MB'], 2), unit='MB per launch',
+                                source='profiles/' + os.path.basename(path), commit=b.get('commit'))
     except Exception:
         return None
     return None
@@ -239,8 +275,11 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=10)
     ap.add_argument('--warmup', type=int, default=3)
-    ap.add_argument('--size', type=int, default=512)
-    ap.add_argument('--batch', type=int, default=2, help='per-GPU batch')
+    ap.add_argument('--workload', default='pose', choices=sorted(WORKLOADS),
+                    help='pose = BASELINE configs[2] (the headline, default); face128 / face256 / street = configs[0] / [1] / [4] '
+                         'per rank on one GPU, each with its own metric string')
+    ap.add_argument('--size', type=int, default=None, help='fineSize (default: the workload\'s)')
+    ap.add_argument('--batch', type=int, default=None, help='per-GPU batch (default: the workload\'s)')
     ap.add_argument('--no-graph', action='store_true')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
@@ -256,10 +295,18 @@ def main():
     args = ap.parse_args()
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ and not args.cpu_baseline_only:
         raise SystemExit(spawn_ranks(args.gpus))
-    global WITH_VGG, WITH_FACE_D, AMP
+    global WITH_VGG, WITH_FACE_D, AMP, WORKLOAD
     WITH_VGG = args.vgg
     WITH_FACE_D = args.face_d
     AMP = args.amp
+    WORKLOAD = args.workload
+    wl = WORKLOADS[WORKLOAD]
+    if args.size is None:
+        args.size = wl['size']
+    if args.batch is None:
+        args.batch = wl['batch']
+    if WORKLOAD != 'pose' and WITH_FACE_D:
+        raise SystemExit("--face-d belongs to the pose workload")
 
     if args.cpu_baseline_only:
         print(json.dumps(cpu_baseline(args.size, args.batch, min(os.cpu_count() or 1, 64), args.use_reference)), flush=True)
@@ -290,6 +337,10 @@ def main():
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29533')
         import datetime
+        # a CUDA/HIP error inside the process group's watchdog thread (the event query that can collide with a graph capture,
+        # graph_step._quiesce) is logged instead of re-thrown: it must not take the benchmark process down - the step falls back
+        # to the eager exchange below and the JSON line says so
+        os.environ.setdefault('TORCH_NCCL_RETHROW_CUDA_ERRORS', '0')
         if emulated:
             dist.init_process_group(backend='gloo', rank=rank, world_size=world, timeout=datetime.timedelta(seconds=180))
         else:
@@ -310,9 +361,15 @@ def main():
     # exchange of the decoder-stage gradients (51 % of the generator's parameters) runs on a side stream next to the third
     # graph.  No collective is captured.
     segmented = distributed and (emulated or not args.no_graph)
-    opt_G, opt_D = model.build_optimizers(world_size=world, process_group=group, force_exchange=force_dist,
-                                          overlap=not segmented, split_backward=segmented)
-    data = make_data(args.batch, args.size, 1234 + rank, device)
+    g_only = wl['g_only']
+    if g_only and distributed:
+        raise SystemExit("--workload %s is a single-GPU generator-only measurement" % WORKLOAD)
+
+    def build_optimizers(seg):
+        return model.build_optimizers(world_size=world, process_group=group, force_exchange=force_dist,
+                                      overlap=not seg, split_backward=seg)
+    opt_G, opt_D = build_optimizers(segmented)
+    data = make_data(args.batch, args.size, 1234 + rank, device, opt)
 
     def step():
         d_losses = model(data, mode='discriminator')
@@ -320,22 +377,59 @@ def main():
         g_losses, _, _ = model(data, mode='generator')
         M.loss_backward(opt, g_losses, opt_G, 0)
 
+    if g_only:
+        # BASELINE configs[1]: "G-only fwd/bwd": the generator called directly, the mean of its image as the scalar, Adam(G) included
+        conv_mod = import_module('few-shot-vid2vid_amd.conv')
+        label, ref_label, ref_img = data[0][:, 0], data[4], data[5]
+
+        def step():              # noqa: F811
+            with conv_mod.stats_pass(device):
+                img = model.netG(label, ref_label, ref_img, [None, None])[0]
+            M.loss_backward(opt, [img.mean().view(1, 1)], opt_G, 0)
+
     use_graph = not args.no_graph
     mode = 'eager'
     run = step
+    n_eager_warm = 0
     if segmented:
-        gs = import_module('few-shot-vid2vid_amd.graph_step')
-        n_eager_warm = max(1, min(args.warmup, 2))
-        gi = gs.GraphedIteration(model, opt, warmup=n_eager_warm)
+        # N > 1: hipGraph segments with the RCCL all-reduces between them.  Nothing in here may cost the scaling line: if
+        # building, warming or capturing the segmented iteration fails, the optimisers are re-laid for the eager overlapped
+        # exchange (bucket hooks on a side stream, flat.py) and the step runs eagerly - `config.launch` says which one ran.
+        try:
+            gs = import_module('few-shot-vid2vid_amd.graph_step')
+            n_eager_warm = max(1, min(args.warmup, 2))
+            gi = gs.GraphedIteration(model, opt, warmup=n_eager_warm)
+            inject = os.environ.get('FSV_BENCH_INJECT_CAPTURE_FAILURE', '')       # tests/test_tools.py
+            if inject == '1':
+                gi._can_capture = True
 
-        def run():
-            gi(data)
-        for _ in range(n_eager_warm + 1):          # eager warm-up calls, then the capture (which replays once)
-            run()
-        n_eager_warm += 1
-        mode = 'hipgraph x%d + RCCL all-reduce between segments (decoder-stage range on a side stream)' % (4 if gi.split else 3)
-        if emulated:
-            mode = 'emulated kernels on host tensors + gloo, %d eager segments (CPU test infrastructure, not a measurement)' % (4 if gi.split else 3)
+                def _boom(e, save_images):
+                    raise RuntimeError("injected capture failure (hipErrorCapturedEvent stand-in)")
+                gi._capture = _boom
+            if inject == '2':
+                raise RuntimeError("injected GraphedIteration construction failure")
+
+            def run():               # noqa: F811
+                gi(data)
+            for _ in range(n_eager_warm + 1):          # eager warm-up calls, then the capture (followed by its first replay)
+                run()
+            n_eager_warm += 1
+            mode = gi.launch_mode()
+            if emulated:
+                mode += ' + gloo (CPU test infrastructure, not a measurement)'
+        except Exception as e:                          # noqa: BLE001
+            if rank == 0:
+                print('segmented graph step failed (%s); eager step with the overlapped bucket exchange' % str(e).split('\n')[0],
+                      file=sys.stderr)
+            sync()
+            segmented = False
+            import_module('few-shot-vid2vid_amd.networks').BackwardCut.abandon_all()
+            opt_G, opt_D = build_optimizers(False)
+            run = step
+            n_eager_warm = 0
+            mode = 'eager fallback (segmented graph step failed: %s), overlapped RCCL bucket exchange' % str(e).split('\n')[0][:160]
+            if emulated:
+                mode += ' + gloo, emulated kernels (CPU test infrastructure, not a measurement)'
     elif emulated:
         n_eager_warm = 0
         mode = 'emulated kernels on host tensors + gloo (CPU test infrastructure, not a measurement)'
@@ -381,8 +475,21 @@ def main():
         elapsed = float(t.item())
 
     frames = args.batch * world * args.steps
+    hh, ww = int(opt.fineSize / opt.aspect_ratio), opt.fineSize
+    if WORKLOAD == 'pose':
+        metric = 'frames/sec G+D fwd+bwd step, 512x512 fewshot_pose'
+        what = (wl['what'] % (args.size, args.size, args.batch) +
+                ', D step + G step (train.py:58-62), Adam included, %sno FlowNet2%s'
+                % (('with VGG19 loss + face discriminator, ' if WITH_FACE_D else 'with VGG19 loss, ')
+                   if (WITH_VGG or WITH_FACE_D) else 'no VGG / ', '' if WITH_FACE_D else ' / face-D'))
+    else:
+        metric = ('frames/sec %s, %dx%d %s' % ('G fwd+bwd' if g_only else 'G+D fwd+bwd step', ww, hh, opt.dataset_mode))
+        what = (wl['what'] % (ww, hh, args.batch) + (', Adam(G) included' if g_only else
+                                                     ', D step + G step (train.py:58-62), Adam included, %s'
+                                                     % ('with VGG19 loss' if WITH_VGG else 'no VGG')))
+    tflop_per_frame = wl['tflop'] * (args.size / float(wl['size'])) ** 2
     result = {
-        'metric': 'frames/sec G+D fwd+bwd step, 512x512 fewshot_pose',
+        'metric': metric,
         'value': round(frames / elapsed, 4),
         'unit': 'frames/s',
         'n_gpus': world,
@@ -392,16 +499,15 @@ def main():
         'higher_is_better': True,
         'scaling': 'weak',
         'vs_baseline': None,
-        'dtype': {0: 'f32', 1: 'f16 operands / f32 accumulate (--amp, not the headline)', 2: 'bf16x3 operands / f32 accumulate (not the headline)'}[M.amp_mode(opt)],
+        'dtype': {0: 'f32', 1: 'f16', 2: 'bf16x3 operands / f32 accumulate (not the headline)'}[M.amp_mode(opt)],
         'data': 'synthetic',
-        'config': {'workload': ('fewshot_pose %dx%d, per-GPU batch %d, adaptive_spade+warp_ref+spade_combine, '
-                                'D step + G step (train.py:58-62), Adam included, %sno FlowNet2%s'
-                                % (args.size, args.size, args.batch,
-                                   ('with VGG19 loss + face discriminator, ' if WITH_FACE_D else 'with VGG19 loss, ')
-                                   if (WITH_VGG or WITH_FACE_D) else 'no VGG / ', '' if WITH_FACE_D else ' / face-D')),
+        'config': {'workload': what,
                    'global_batch': args.batch * world, 'parallelism': 'dp%d' % world, 'launch': mode,
-                   'algorithmic_tflop_per_frame': 1.66},
+                   'algorithmic_tflop_per_frame': round(tflop_per_frame, 4)},
     }
+    if M.amp_mode(opt) == 1:
+        result['config']['arithmetic'] = ('--amp O1: GEMM operands and activations between the narrow layers in IEEE half, fp32 '
+                                          'accumulation (v_mfma_f32_32x32x16_f16), dynamic loss scale; not the fp32 headline')
     rl = None
     if not args.no_roofline:
         # instrumented eager pass: HIP events around every launch of the MFMA kernels, on their launch stream; the dominant
@@ -438,14 +544,14 @@ def main():
                 d['achieved'] = round(d['gflop_per_launch'] * 1e9 / t2 / 1e12, 2)
                 d['frac'] = round(d['achieved'] / d['peak'], 4)
     if rank == 0:
-        result['step_tflops'] = round(1.66 * frames / elapsed, 2)
+        result['step_tflops'] = round(tflop_per_frame * frames / elapsed, 2)
         if rl is not None:
             result['roofline'] = rl['dominant']
             result['kernels'] = rl['by_kernel']
             result['roofline']['traffic'] = pmc_traffic(result['roofline']['kernel'])
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and not g_only:
             result['cpu_baseline'] = cpu_baseline(args.size, args.batch, min(os.cpu_count() or 1, 64))
-        if world == 1 and not args.no_extras and not (WITH_VGG or WITH_FACE_D) and AMP == 'O0':
+        if world == 1 and not args.no_extras and not (WITH_VGG or WITH_FACE_D) and AMP == 'O0' and WORKLOAD == 'pose':
             result['extras'] = extras(device, args.size)
     if world > 1 or force_dist:
         dist.destroy_process_group()

@@ -13,7 +13,7 @@ import torch
 
 from . import lib, profile
 
-ACT_NONE, ACT_LRELU, ACT_TANH, ACT_SIGMOID, ACT_RELU, ACT_LRELU01 = 0, 1, 2, 3, 4, 5
+ACT_NONE, ACT_LRELU, ACT_TANH, ACT_SIGMOID, ACT_RELU, ACT_LRELU01, ACT_DLRELU = 0, 1, 2, 3, 4, 5, 6
 
 # Arithmetic of the GEMM operands (csrc/conv_np.hip).  0: exact fp32 MFMA (default, the measured path);
 # 1: "f16" - operands rounded to half while staged through LDS, fp32 accumulate (the reference's --amp contract, needs the
@@ -284,14 +284,23 @@ STATS_SLOTS = 32      # partial-sum slots per (group, channel) of the statistics
 
 
 class _StatsArena:
-    """Zeroed fp64 storage for the statistics partials of ONE forward pass (one memset per pass instead of one in front of
-    every convolution that feeds a normalisation: 80 fills of ~5 us per step).  `begin()` - called by the model-level entry
-    points before anything of the pass is launched - zeroes everything any pass has used so far; `take()` hands out slices
-    until the storage runs out (first pass of a new configuration: the caller falls back to a per-call buffer and the arena
-    grows at the next begin).  Partials are consumed right behind their producer, on the producer's stream."""
+    """Zeroed fp64 storage for the statistics partials of ONE forward pass (one memset per chunk and pass instead of one in front
+    of every convolution that feeds a normalisation: 80 fills of ~5 us per step).  `begin()` - called by the model-level entry
+    points before anything of the pass is launched - zeroes the storage; `take()` hands out slices until it runs out (first
+    pass of a new configuration: the caller falls back to a per-call buffer and the arena grows at the next begin).  Partials
+    are consumed right behind their producer, on the producer's stream.
+
+    The storage only ever GROWS BY APPENDING CHUNKS and no chunk is ever released: a hipGraph captured earlier has the raw
+    addresses of the chunks it saw baked into its memsets, the fp64 atomics of the convolution epilogues and
+    fsv_norm_stats_finish, and keeps replaying into them (round-3 advisor: a buffer that was re-allocated when a later eager
+    pass needed more slots left those graphs writing into freed caching-allocator memory).  Slices are handed out in the same
+    order every pass, so a replayed graph and an eager pass of the same configuration use the same slots."""
 
     def __init__(self, device):
-        self.device, self.buf, self.off, self.need, self.high, self.depth = device, None, 0, 0, 0, 0
+        self.device, self.chunks, self.cur, self.off, self.need, self.high, self.depth = device, [], 0, 0, 0, 0, 0
+
+    def capacity(self):
+        return sum(c.numel() for c in self.chunks)
 
     def begin(self):
         self.depth += 1
@@ -300,21 +309,30 @@ class _StatsArena:
         capturing = self.device.type == 'cuda' and torch.cuda.is_current_stream_capturing()
         if self.need > self.high:
             self.high = self.need
-        if self.high and (self.buf is None or self.buf.numel() < self.high) and not capturing:
-            self.buf = torch.zeros(self.high, dtype=torch.float64, device=self.device)
-        elif self.buf is not None and self.high:
-            self.buf[:min(self.high, self.buf.numel())].zero_()
-        self.off, self.need = 0, 0
+        short = self.high - self.capacity()
+        if short > 0 and not capturing:
+            # (allocated outside any capture: eager allocations are never recycled while the chunk list holds them)
+            self.chunks.append(torch.zeros(max(short, 4096), dtype=torch.float64, device=self.device))
+        for c in self.chunks:
+            c.zero_()
+        self.cur, self.off, self.need = 0, 0, 0
 
     def end(self):
         self.depth = max(self.depth - 1, 0)
 
     def take(self, n):
         n = (n + 15) // 16 * 16
-        self.need += n
-        if self.depth == 0 or self.buf is None or self.off + n > self.buf.numel():
+        if self.depth == 0:           # a bare op call outside a pass: per-call buffer, and nothing to plan for
             return None
-        out = self.buf[self.off:self.off + n]
+        self.need += n
+        while self.cur < len(self.chunks) and self.off + n > self.chunks[self.cur].numel():
+            # (the tail of a chunk that cannot hold the request stays unused; `need` counts requests, so the next growth
+            # may over-allocate by those tails - a few KB)
+            self.need += self.chunks[self.cur].numel() - self.off
+            self.cur, self.off = self.cur + 1, 0
+        if self.cur >= len(self.chunks):
+            return None
+        out = self.chunks[self.cur][self.off:self.off + n]
         self.off += n
         return out
 
@@ -425,7 +443,9 @@ def gather_gemm(x, wt, ldw, cout, oh, ow, ty, tx, sy, sx, bias=None, res=None, a
     if profile.enabled():
         mz = oh * ow if per_sample else n * oh * ow
         label = profile.conv_label(mz, cout, (len(ty) * cin + 31) // 32, n if per_sample else 1, cin % 4 == 0,
-                                   force_tile, force_split)
+                                   force_tile, force_split,
+                                   thin=0 if entry.endswith('_np') else _thin_k(cout, cin, len(ty), per_sample, place, accumulate,
+                                                                                force_tile, force_split, act))
         if entry.endswith('_np'):
             label = label.replace('fsv_conv_igemm_kernel', 'fsv_np_conv_kernel[%s]' % ('f16' if _mfma_mode == 1 else 'bf16x3'))
         keep = (x, wt, bias, res, out, wscale)          # the replay re-issues the launch on the same buffers
@@ -435,6 +455,15 @@ def gather_gemm(x, wt, ldw, cout, oh, ow, ty, tx, sy, sx, bias=None, res=None, a
     else:
         lib.call(entry, *args)
     return out
+
+
+def _thin_k(cout, cin, ntaps, per_sample, place, accumulate, force_tile, force_split, act):
+    """K of a launch that fsv_conv_gather_fwd hands to the thin-output (vector-ALU) kernels if the size rule agrees
+    (csrc/conv_igemm.hip fsv_conv_gather_impl), else 0 - for profiler labels only"""
+    q = cin >> 2
+    ok = (cout <= 4 and cin % 4 == 0 and cin <= 256 and q & (q - 1) == 0 and ntaps * cin <= 1152 and not per_sample and
+          place is None and not accumulate and force_tile < 0 and force_split <= 0 and act != ACT_DLRELU)
+    return ntaps * cin if ok else 0
 
 
 def conv_forward(x, wt_f, ldw, cout, geom, bias=None, res=None, act=ACT_NONE, scale=1.0, per_sample=False,
@@ -549,6 +578,9 @@ def conv_wgrad(x, dout, geom, w_shape, per_sample=False, scale=None, force_split
     if force_tile == 0 and vec4 and cout >= 64 and kdim > 64 and os.environ.get('FSV_WGRAD_PLAN', '1') == '1':
         bm, bn = 64, 64
     label = 'fsv_conv_wgrad_kernel<%dx%d,V%d>' % (bm, bn, 4 if vec4 else 1)
+    if (profile.enabled() and cout <= 4 and vec4 and not per_sample and force_tile == 0 and force_split <= 0 and
+            geom.ntaps * (cin >> 2) <= 256 and not _mfma_mode and profile.thin_rule(n * oh * ow, kdim)):
+        label = 'fsv_conv_thin_wgrad_kernel<Cout%d>' % cout          # csrc/conv_igemm.hip fsv_conv_wgrad: vector-ALU reduction
     if profile.detail():
         label += ' Kdim%d N%d pix%d z%d' % (geom.ntaps * cin, cout, (oh * ow) if per_sample else n * oh * ow, nb)
     narrow = _mfma_mode and vec4

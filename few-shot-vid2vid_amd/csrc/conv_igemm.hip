@@ -1643,6 +1643,10 @@ static inline bool fsv_deterministic() {
   return e && e[0] == '1';
 }
 
+// size rule of the thin-output (vector-ALU) kernels, exported so that host-side profilers label those launches as what they
+// are; returns 1 / 0, not a status
+extern "C" int fsv_conv_thin_rule(int Mz, int K) { return fsv_conv_thin(Mz, K) ? 1 : 0; }
+
 extern "C" int fsv_conv_plan(int Mz, int Cout, int nchunks, int nsamp, int force_tile, int force_split,
                              int* tile_out, int* nsplit_out) {
   if (force_split <= 0 && fsv_deterministic()) force_split = 1;

@@ -121,6 +121,7 @@ class FlatAdam:
         self._armed = False
         self.buckets = []            # (start, end) element ranges of flat_g
         self._pending, self._handles = [], []
+        self._works = []             # hook-free mode: work handles of the collectives issued since the last drain_works()
         self._param_bucket = {}
         self.side_stream = None
         if self.overlap:
@@ -246,11 +247,36 @@ class FlatAdam:
             self.params[i].grad = self._grad_views[i]
         self._loose = []
 
+    def _all_reduce(self, view):
+        """hook-free mode: the collective is issued with a work handle (async_op=True), the issuing stream waits for it at once
+        (`wait()` on an RCCL work is a stream-side dependency, the host does not block) and the handle is kept until
+        drain_works(): graph_step waits for every handle to report completion before it starts a hipGraph capture, so the
+        process group's watchdog thread has nothing of ours left in flight while streams are capturing."""
+        h = dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        if h is not None:
+            h.wait()
+            if len(self._works) >= 16:         # a long replay loop never drains: keep only what is still in flight
+                self._works = [w for w in self._works if not w.is_completed()]
+            self._works.append(h)
+
+    def drain_works(self, timeout_s=60.0):
+        """Block the host until every collective issued through _all_reduce has completed (work.is_completed(): the end event of
+        the collective has been reached on the device); returns the number of handles that were outstanding."""
+        import time
+        works, self._works = self._works, []
+        t0 = time.monotonic()
+        for h in works:
+            while not h.is_completed():
+                if time.monotonic() - t0 > timeout_s:
+                    raise RuntimeError("gradient exchange did not complete within %.0f s" % timeout_s)
+                time.sleep(0.001)
+        return len(works)
+
     def exchange_all(self):
         """Non-overlapped mode: one all-reduce over the whole flat gradient buffer on the current stream."""
         self.finalize_grads()
         if self.exchange and not self.overlap:
-            dist.all_reduce(self.flat_g, op=dist.ReduceOp.SUM, group=self.group)
+            self._all_reduce(self.flat_g)
 
     def exchange_range(self, lo, hi, side=False):
         """All-reduce flat_g[lo:hi] (hook-free mode; the caller has finalised the gradients in that range).  side=True:
@@ -264,10 +290,10 @@ class FlatAdam:
                 self.side_stream = torch.cuda.Stream(device=self.device)
             self.side_stream.wait_stream(torch.cuda.current_stream(self.device))
             with torch.cuda.stream(self.side_stream):
-                dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group)
+                self._all_reduce(view)
             self._side_pending = True
         else:
-            dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group)
+            self._all_reduce(view)
 
     def wait_exchange(self):
         if getattr(self, '_side_pending', False):

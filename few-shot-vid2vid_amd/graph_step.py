@@ -57,6 +57,7 @@ class _Entry:
         self.calls = 0
         self.graphs = None
         self.outputs = None
+        self.eager_only = False     # a capture failed for this signature: the step keeps running eagerly
 
 
 class GraphedIteration:
@@ -65,12 +66,14 @@ class GraphedIteration:
         self.opt = opt
         self.warmup = max(int(warmup), 1)
         self.entries = {}
+        self.capture_failures = []      # (signature, first line of the error) of every capture that fell back to the eager step
         self._bind()
         # the SIMT-emulated library (CPU test infrastructure) has no graphs: the body is re-run eagerly on the static buffers,
         # which exercises everything here except the capture itself
         self._emulated = lib.emu_requested()
         if not self._emulated and not torch.cuda.is_available():
             raise RuntimeError("GraphedIteration needs a GPU (hipGraph capture)")
+        self._can_capture = not self._emulated
 
     # ------------------------------------------------------------------------------------------------ bookkeeping
     def _bind(self):
@@ -151,49 +154,49 @@ class GraphedIteration:
             self.opt_G.exchange_all()
         self._seg_a()
 
+    # one poll period of ProcessGroupNCCL's watchdog thread (kWatchdogThreadSleepMillis = 100 ms in torch 2.x) plus margin
+    WATCHDOG_PERIOD_S = 0.15
+
     def _quiesce(self):
-        """Before a capture that follows collectives: wait for the device AND let the process group's watchdog thread reap the
-        finished work objects (it polls their events every 100 ms).  A watchdog `hipEventQuery` that lands inside a capture was
-        seen to fail with hipErrorCapturedEvent on ROCm 7 (one run in eight, once the captured body itself records and
-        destroys events - the branch streams) and takes the process down; with nothing left to poll it stays quiet."""
+        """Before the captures: nothing of ours may be in flight on the process group while a stream captures.  A watchdog
+        `hipEventQuery` that lands inside a capture was seen to fail with hipErrorCapturedEvent on ROCm 7 (one run in eight,
+        once the captured body itself records and destroys events - the branch streams).  Round 3 slept 0.35 s in front of each
+        of the four captures and hoped; now (1) every exchange collective carries a work handle (FlatAdam._all_reduce) and this
+        function blocks until each handle reports completion, (2) the segments are captured back to back with NO collective
+        between them (a capture only records: it does not need the previous segment's results), so the process group sees no
+        new work from the first capture to the last, (3) if handles were outstanding the watchdog gets one poll period to reap
+        them - it drops a work object at the first poll that finds it complete -, and (4) a capture that fails all the same is
+        caught by __call__, which falls back to the eager segmented step for that signature (`launch_mode()` says so)."""
         torch.cuda.synchronize(self.opt_G.device)
         if self.segmented:
-            import time
-            time.sleep(0.35)
+            pending = self.opt_D.drain_works() + self.opt_G.drain_works()
+            if pending:
+                import time
+                time.sleep(self.WATCHDOG_PERIOD_S)
 
     def _capture(self, e, save_images):
-        dev = self.opt_G.device
         self._quiesce()
         if not self.segmented:
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
                 self._eager(e, save_images)
             e.graphs = [g]
+            e.replayed_by_capture = False
             return
-        # no collective may be pending when a capture starts, and the captures only police their own thread (the RCCL watchdog
-        # polls its events from another one)
+        # the captures only police their own thread (the RCCL watchdog polls its events from another one); the caller replays
+        # the whole sequence - with the all-reduces between the graphs - once all of them exist
         gs = [torch.cuda.CUDAGraph() for _ in range(4 if self.split else 3)]
         with torch.cuda.graph(gs[0], capture_error_mode='thread_local'):
             self._seg_d(e)
-        gs[0].replay(); self.opt_D.exchange_all()
-        self._quiesce()
         with torch.cuda.graph(gs[1], pool=gs[0].pool(), capture_error_mode='thread_local'):
             self._seg_g(e, save_images)
-        gs[1].replay()
         if self.split:
-            self._exchange_g_first()
-            self._quiesce()
             with torch.cuda.graph(gs[2], pool=gs[0].pool(), capture_error_mode='thread_local'):
                 self._seg_g2()
-            gs[2].replay(); self._exchange_g_rest()
-        else:
-            self.opt_G.exchange_all()
-        self._quiesce()
         with torch.cuda.graph(gs[-1], pool=gs[0].pool(), capture_error_mode='thread_local'):
             self._seg_a()
-        gs[-1].replay()
         e.graphs = gs
-        e.replayed_by_capture = True
+        e.replayed_by_capture = False
 
     def _replay(self, e):
         if len(e.graphs) == 1:
@@ -207,6 +210,32 @@ class GraphedIteration:
             e.graphs[1].replay(); self._exchange_g_first()          # side stream: overlaps the next graph
             e.graphs[2].replay(); self._exchange_g_rest()
             e.graphs[3].replay()
+
+    def _capture_failed(self, e, key, ex):
+        """a capture raised (e.g. hipErrorCapturedEvent from a foreign event query, an allocation the capture could not make):
+        drop the half-built graphs, clear what the interrupted body left behind and keep this signature on the eager step"""
+        e.graphs, e.eager_only = None, True
+        self.capture_failures.append((key, str(ex).split('\n')[0][:200]))
+        if torch.cuda.is_available() and not self._emulated:
+            try:
+                torch.cuda.synchronize(self.opt_G.device)
+            except Exception:                # noqa: BLE001
+                pass
+        _networks.BackwardCut.abandon_all()      # boundary tensors of the interrupted forward pass
+        for o in (self.opt_D, self.opt_G):
+            o._reattach()
+
+    def launch_mode(self):
+        """how the iterations of this object reach the device - for bench.py's `config.launch`"""
+        n = 4 if self.split else 3
+        if self.capture_failures:
+            return ('eager fallback (hipGraph capture failed: %s)%s' % (self.capture_failures[-1][1],
+                    ', all-reduce between %d eager segments' % n if self.segmented else ''))
+        if self._emulated:
+            return 'emulated kernels on host tensors, %d eager segments' % n if self.segmented else 'emulated kernels, eager'
+        if not self.segmented:
+            return 'hipgraph'
+        return 'hipgraph x%d + RCCL all-reduce between segments%s' % (n, ' (decoder-stage range on a side stream)' if self.split else '')
 
     # ------------------------------------------------------------------------------------------------ call
     def __call__(self, data_list, save_images=False):
@@ -226,8 +255,8 @@ class GraphedIteration:
                 if dst is not None:
                     dst.copy_(src, non_blocking=True)
         e.calls += 1
-        if self._emulated or e.calls <= self.warmup:
-            if not self._emulated and e.calls == 1:
+        if not self._can_capture or e.eager_only or e.calls <= self.warmup:
+            if not self._emulated and e.calls == 1 and torch.cuda.is_available():
                 # warm-up runs on a side stream so that allocations made now do not end up in the capture's private pool
                 s = torch.cuda.Stream(self.opt_G.device)
                 s.wait_stream(torch.cuda.current_stream())
@@ -237,9 +266,12 @@ class GraphedIteration:
             else:
                 self._eager(e, save_images)
         elif e.graphs is None:
-            e.replayed_by_capture = False
-            self._capture(e, save_images)
-            if not e.replayed_by_capture:
+            try:
+                self._capture(e, save_images)
+            except Exception as ex:          # noqa: BLE001 - a capture fault must never cost the caller its iteration
+                self._capture_failed(e, key, ex)
+                self._eager(e, save_images)
+            else:
                 self._replay(e)
         else:
             self._replay(e)

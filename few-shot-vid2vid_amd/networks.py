@@ -147,7 +147,8 @@ class SPADEConv2d(nn.Module):
         self.bn = BatchNorm(fout, affine=True)
 
     def forward(self, x):
-        return self.bn(self.conv(x, stats=1), act=ACT_LRELU)
+        # (the hint only pays when the consumer reduces batch statistics: eval-mode BatchNorm takes its running buffers)
+        return self.bn(self.conv(x, stats=1 if self.training else 0), act=ACT_LRELU)
 
 
 class SPADE(nn.Module):
@@ -235,11 +236,15 @@ class SPADEResnetBlock(nn.Module):
                 x_s = x
                 h0 = self.bn_0(x, label, nw[0], act=ACT_LRELU, up=fold)
             # conv_0 feeds bn_1, conv_1 (+ shortcut) the next block's bn_0 / bn_s: BatchNorm statistics from their epilogues
-            dx = self.conv_0(h0, stats=1)
-            return self.conv_1(self.bn_1(dx, label, nw[1], act=ACT_LRELU), res=x_s, stats=1 if feeds_norm else 0)
+            # (in training mode only: eval-mode BatchNorm takes its running buffers and would leave the partials unused; a next
+            # block that materialises the up-sampling - up and not fold - reduces over the up-sampled tensor itself)
+            hint = 1 if self.training else 0
+            dx = self.conv_0(h0, stats=hint)
+            return self.conv_1(self.bn_1(dx, label, nw[1], act=ACT_LRELU), res=x_s, stats=hint if feeds_norm else 0)
+        hint = 1 if self.training else 0
         x_s = self.conv_s(self.bn_s(x)) if self.learned_shortcut else x
-        dx = self.conv_0(self.bn_0(x, act=ACT_LRELU), stats=1)
-        return self.conv_1(self.bn_1(dx, act=ACT_LRELU), res=x_s, stats=1 if feeds_norm else 0)
+        dx = self.conv_0(self.bn_0(x, act=ACT_LRELU), stats=hint)
+        return self.conv_1(self.bn_1(dx, act=ACT_LRELU), res=x_s, stats=hint if feeds_norm else 0)
 
 
 def spectral_layers(module):
@@ -355,12 +360,12 @@ class FlowGenerator(nn.Module):
         x = ops.cat_channels([label, label_prev, img_prev])
         for k in range(0, 2 * (self.nd + 1), 2):
             conv, bn = self.down_flow[k]
-            x = bn(conv(x, stats=1), act=ACT_LRELU)
+            x = bn(conv(x, stats=1 if self.training else 0), act=ACT_LRELU)
         for k, blk in enumerate(self.res_flow):
             x = blk(x, feeds_norm=k + 1 < len(self.res_flow))
         for k in range(1, 3 * self.nd, 3):
             conv, bn = self.up_flow[k]
-            x = bn(conv(ops.upsample2x(x), stats=1), act=ACT_LRELU)
+            x = bn(conv(ops.upsample2x(x), stats=1 if self.training else 0), act=ACT_LRELU)
         flow = self.conv_flow[0](x, scale=float(self.flow_multiplier))
         mask = self.conv_mask[0](x, act=ACT_SIGMOID)
         return flow, mask
@@ -764,18 +769,32 @@ class BackwardCut:
         return obj
 
     def backward_rest(self):
+        """second piece: continue from the recorded originals with the gradients the leaves collected.  A cut whose leaves have
+        no gradient yet stays registered: its own backward pass has not run (a G forward with grad followed by a D
+        loss_backward - whose finish_all() reaches every live cut - and only then the G backward: round-3 advisor)."""
         outs = [o for o, l in self.pairs if l.grad is not None]
         grads = [l.grad for o, l in self.pairs if l.grad is not None]
+        if not outs:
+            return
         self.pairs = []
         BackwardCut._live.discard(self)
-        if outs:
-            torch.autograd.backward(outs, grads)
+        torch.autograd.backward(outs, grads)
+
+    def abandon(self):
+        """drop the boundary tensors of a forward pass whose backward will never run (an interrupted graph capture)"""
+        self.pairs = []
+        BackwardCut._live.discard(self)
 
     @classmethod
     def finish_all(cls):
-        """run the second piece of every forward pass that detached at a stage boundary and has not been completed"""
+        """run the second piece of every forward pass that detached at a stage boundary and whose first piece has run"""
         for cut in list(cls._live):
             cut.backward_rest()
+
+    @classmethod
+    def abandon_all(cls):
+        for cut in list(cls._live):
+            cut.abandon()
 
 
 # ------------------------------------------------------------------------------------------------ discriminator

@@ -1019,9 +1019,11 @@ class _SpadeFn(torch.autograd.Function):
                 chs.append(maps[k].shape[1])
             arr = lambda v: (ctypes.c_void_p * max(len(v), 1))(*v)
             lib.check_device(x, dh, *maps)
-            lib.call("fsv_spade_mod_bwd", lib.ptr(x), lib.ptr(mean), lib.ptr(rstd), lib.ptr(dh), nm, _pp(maps), arr(wg_p),
-                     arr(wb_p), arr(bg_p), arr(bb_p), lib.int_array(chs + [0]), _ll(wstr + [0]), _ll(bstr + [0]), _pp(dgbs),
-                     lib.ptr(dxhat), n, h * w, c, 2 * c, 0, ctx.act, w, up, lib.stream_ptr())
+            # (labelled as the backward twin; FLOPs = the gamma / beta GEMMs it recomputes)
+            with profile.scope('fsv_spade_mod_kernel<bwd>', 2.0 * n * h * w * c * 2 * sum(chs)):
+                lib.call("fsv_spade_mod_bwd", lib.ptr(x), lib.ptr(mean), lib.ptr(rstd), lib.ptr(dh), nm, _pp(maps), arr(wg_p),
+                         arr(wb_p), arr(bg_p), arr(bb_p), lib.int_array(chs + [0]), _ll(wstr + [0]), _ll(bstr + [0]), _pp(dgbs),
+                         lib.ptr(dxhat), n, h * w, c, 2 * c, 0, ctx.act, w, up, lib.stream_ptr())
         else:
             if fast:
                 prepped = saved[4 + nm:]

@@ -78,7 +78,20 @@ def bracket_average(label):
     return len(ts), (sum(ts) / len(ts) if ts else 0.0)
 
 
-def conv_label(mz, cout, nchunks, nsamp, vec4, force_tile=-1, force_split=0):
+def thin_rule(mz, k):
+    """csrc/conv_igemm.hip fsv_conv_thin: the size rule of the vector-ALU kernels for Cout <= 4 layers"""
+    lib.register_sigs({"fsv_conv_thin_rule": [ctypes.c_int] * 2})
+    return lib.call_status("fsv_conv_thin_rule", int(mz), int(k)) == 1
+
+
+def conv_label(mz, cout, nchunks, nsamp, vec4, force_tile=-1, force_split=0, thin=0):
+    """thin: K = taps * Cin when the caller's launch meets every condition of the thin-output dispatch inside
+    fsv_conv_gather_fwd but the size rule (0: it does not)"""
+    if thin and thin_rule(mz, thin):
+        base = 'fsv_conv_thin_fwd_kernel<Cout%d>' % cout
+        if _detail:
+            base += ' M%d N%d K%d' % (mz, cout, nchunks * 32)
+        return base
     lib.register_sigs({"fsv_conv_plan": [ctypes.c_int] * 6 + [ctypes.POINTER(ctypes.c_int)] * 2})
     tile, nsplit = ctypes.c_int(0), ctypes.c_int(1)
     lib.call("fsv_conv_plan", mz, cout, nchunks, nsamp, force_tile, force_split, ctypes.byref(tile), ctypes.byref(nsplit))

@@ -175,6 +175,9 @@ int fsv_upload_i64(long long* dst, const long long* host_src, int n, fsv_stream_
 /* tile / split-K plan the launcher will use (exported so host-side profilers label launches consistently) */
 int fsv_conv_plan(int Mz, int Cout, int nchunks, int nsamp, int force_tile, int force_split, int* tile_out,
                   int* nsplit_out);
+/* 1 when a Cout <= 4 layer of Mz pixels and K = taps * Cin takes the vector-ALU kernels (fsv_conv_thin_*), else 0 - NOT a status;
+ * for profiler labels, like fsv_conv_plan */
+int fsv_conv_thin_rule(int Mz, int K);
 
 /* One-launch operand preparation of a SPADE (gamma, beta) 1x1 weight pair (normalization.py:37-52): wg / wb [B][C][Ch]
  * (sample strides swg / swb, 0 = shared), bg / bb [B][C] -> wcat_t [B][ceil32(Ch)][2C] (forward operand of map -> [gamma|beta]),

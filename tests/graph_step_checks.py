@@ -50,6 +50,51 @@ def check_graphed_iteration(device, iters=5, seed=500, tol=0.0):
     return step
 
 
+def check_capture_failure_falls_back(device, iters=4, seed=540):
+    """A capture that raises half-way through the iteration body (what a foreign hipEventQuery inside a capture does) must not
+    cost the caller its iteration: GraphedIteration drops to the eager step for that signature, says so (launch_mode,
+    capture_failures) and the loop's losses and weights stay those of the plain eager loop - with the two-piece backward on."""
+    from importlib import import_module
+    gs = import_module('few-shot-vid2vid_amd.graph_step')
+    kw = dict(warp_ref=True, spade_combine=True, remove_face_labels=True, fineSize=32, loadSize=32, n_downsample_G=3, n_adaptive_layers=2)
+    ref, pG, pD, _ = _run(device, False, iters, seed, kw, split=True)
+    orig_init = gs.GraphedIteration.__init__
+
+    def patched(self, *a, **k):
+        orig_init(self, *a, **k)
+        self._can_capture = True                     # the emulator has no graphs: force the capture branch ...
+
+        def broken_capture(e, save_images):          # ... and interrupt the body after the generator's forward + first piece
+            # a capture RECORDS the body, it does not execute it: the emulator runs it for real, so the device-side state the
+            # body touched is put back before the "capture" fails - what stays behind is exactly what a failed capture leaves
+            # on the host (autograd tape, detached .grad slots, queued finaliser jobs, live BackwardCut pairs)
+            import torch
+            sd = {k: v.detach().clone() for k, v in self.model.state_dict().items()}
+            os_ = [(o, o.m.clone(), o.v.clone(), o.state.clone(), o.flat_g.clone()) for o in (self.opt_G, self.opt_D)]
+            try:
+                self._seg_d(e)
+                self._seg_g(e, save_images)
+            finally:
+                with torch.no_grad():
+                    self.model.load_state_dict(sd)
+                    for o, m, v, st, g in os_:
+                        o.m.copy_(m); o.v.copy_(v); o.state.copy_(st); o.flat_g.copy_(g)
+                        o.refresh_layouts()
+            raise RuntimeError("injected: operation not permitted on an event last recorded in a capturing stream")
+        self._capture = broken_capture
+    gs.GraphedIteration.__init__ = patched
+    try:
+        got, qG, qD, step = _run(device, True, iters, seed, kw, split=True)
+    finally:
+        gs.GraphedIteration.__init__ = orig_init
+    assert len(step.capture_failures) == 1 and 'eager fallback' in step.launch_mode(), step.launch_mode()
+    assert all(e.eager_only and e.graphs is None for e in step.entries.values())
+    for it, (a, b) in enumerate(zip(ref, got)):
+        for k in ('d', 'g'):
+            assert a[k] == b[k], (it, k, a[k], b[k])
+    assert float((pG - qG).abs().max()) == 0.0 and float((pD - qD).abs().max()) == 0.0
+
+
 def check_split_backward_single_rank(device, iters=3, seed=520):
     """build_optimizers(split_backward=True) WITHOUT a gradient exchange: the generator's forward pass still detaches at its
     stage boundary, so both drivers (the eager loss_backward and GraphedIteration) have to run the second backward piece -

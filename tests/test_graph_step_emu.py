@@ -13,3 +13,7 @@ def test_graphed_iteration_matches_the_eager_loop(emu_lib):
 
 def test_split_backward_without_exchange_keeps_every_gradient(emu_lib):
     gc.check_split_backward_single_rank(DEV, iters=2)
+
+
+def test_capture_failure_falls_back_to_the_eager_step(emu_lib):
+    gc.check_capture_failure_falls_back(DEV)

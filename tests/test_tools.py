@@ -53,3 +53,34 @@ def test_bench_bare_launch_spawns_one_rank_per_gpu(emu_lib):
     rec = json.loads(lines[0])
     assert rec['n_gpus'] == 2 and rec['config']['global_batch'] == 2 and rec['config']['parallelism'] == 'dp2'
     assert rec['steps'] == 1 and rec['scaling'] == 'weak' and 'emulated' in rec['config']['launch']
+
+
+def _bench_one_rank(extra_env, *extra_args):
+    env = dict(os.environ)
+    for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT'):
+        env.pop(k, None)
+    env.update(FSV2V_EMU='1', MASTER_PORT='29547', **extra_env)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--steps', '1', '--warmup', '1', '--batch', '1', '--ngf', '4']
+                       + list(extra_args), capture_output=True, text=True, env=env, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1, r.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_bench_segmented_path_survives_a_capture_failure(emu_lib):
+    """The N > 1 path of bench.py (here: a one-rank gloo group on the emulated kernels, FSV_FORCE_DIST=1) with a capture that
+    raises: the line is still printed, `value` is a measurement of the fallback step and `config.launch` names the fallback
+    (round-3 review: a capture fault there would have lost the scaling curve)."""
+    rec = _bench_one_rank(dict(FSV_FORCE_DIST='1', FSV_BENCH_INJECT_CAPTURE_FAILURE='1'), '--size', '64')
+    assert rec['value'] > 0 and 'eager fallback (hipGraph capture failed' in rec['config']['launch'], rec['config']
+    rec = _bench_one_rank(dict(FSV_FORCE_DIST='1', FSV_BENCH_INJECT_CAPTURE_FAILURE='2'), '--size', '64')
+    assert rec['value'] > 0 and 'eager fallback (segmented graph step failed' in rec['config']['launch'], rec['config']
+    assert 'overlapped RCCL bucket exchange' in rec['config']['launch']
+
+
+def test_bench_workloads_name_their_configuration(emu_lib):
+    rec = _bench_one_rank({}, '--workload', 'street', '--size', '64')
+    assert 'fewshot_street' in rec['metric'] and '64x32' in rec['metric'] and 'label_nc 35' in rec['config']['workload']
+    rec = _bench_one_rank({}, '--workload', 'face256', '--size', '32')
+    assert 'G fwd+bwd' in rec['metric'] and 'fewshot_face' in rec['metric'] and rec['value'] > 0

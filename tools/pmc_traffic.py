@@ -1,6 +1,6 @@
 """Per-kernel HBM traffic from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) of the same command.
 
-usage: python tools/pmc_traffic.py <dir of the FETCH_SIZE pass> <dir of the WRITE_SIZE pass> <out.json>
+usage: python tools/pmc_traffic.py <dir of the FETCH_SIZE pass> <dir of the WRITE_SIZE pass> <out.json> [workload [amp]]
 Both counters are reported in KiB per dispatch.  On gfx950 FETCH_SIZE counts 64 B per 128-B request of a wide coalesced
 read (MI355X_MICROARCH.md, HBM section): the read figure is doubled ("read_MB_corrected"); WRITE_SIZE is taken as is."""
 import csv, glob, json, os, sys
@@ -41,6 +41,16 @@ def main():
                                         cwd=os.path.dirname(os.path.abspath(__file__))).stdout.strip() or None
     except Exception:
         meta['commit'] = None
+    if not meta['commit']:
+        # the GPU box's snapshot has no .git: the commit the snapshot was cut from travels in .build_commit (written in the build
+        # container right before the gpurun call, `git rev-parse HEAD`, suffixed "+dirty" when the tree had uncommitted changes)
+        try:
+            with open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), '.build_commit')) as f:
+                meta['commit'] = f.read().strip() or None
+        except OSError:
+            pass
+    meta['workload'] = sys.argv[4] if len(sys.argv) > 4 else 'pose'
+    meta['amp'] = sys.argv[5] if len(sys.argv) > 5 else 'O0'
     with open(sys.argv[3], 'w') as f:
         json.dump(dict(_build=meta, **res), f, indent=1)
     for k in list(res)[:12]:
