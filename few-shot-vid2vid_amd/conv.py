@@ -39,6 +39,48 @@ def mfma_mode():
     return _mfma_mode
 
 
+# Round 4: in the f16 mode the operators (ops._ConvFn and friends) hand HALF activations to these functions, which then run the
+# half-precision kernels of csrc/conv_h.hip (activations and weights 16-bit in HBM, hconv.py); an fp32 activation tensor stays on
+# the exact fp32 kernels.  FSV_HCONV=0 / set_h_kernels(False) restores round 2's behaviour - fp32 tensors narrowed while staged
+# (csrc/conv_np.hip) - for A/B runs and for the tests that pin those kernels to the definition.
+_h_kernels = os.environ.get('FSV_HCONV', '1') == '1'
+
+
+def set_h_kernels(on):
+    global _h_kernels
+    prev, _h_kernels = _h_kernels, bool(on)
+    return prev
+
+
+def h_kernels():
+    """True when the f16 mode runs on the half-precision kernels (activations cast to / kept in half by the operators)"""
+    return _h_kernels and _mfma_mode == MFMA_F16
+
+
+def narrow_staging_mode():
+    """operand mode of the staging-time narrowing kernels (csrc/conv_np.hip) for an fp32 activation tensor: bf16x3 always,
+    f16 only with the half kernels switched off"""
+    if _mfma_mode == MFMA_BF16X3 or (_mfma_mode == MFMA_F16 and not _h_kernels):
+        return _mfma_mode
+    return 0
+
+
+def half_twin(wt):
+    """(wh, Kpad64, nrows): the N-major half operand (hconv.py) of a K-major fp32 layout.  Layouts owned by a LayoutCache get a
+    persistent twin that the cache rewrites with the layout itself once per optimiser step; any other (a per-call
+    re-arrangement of generated weights) is converted now and the twin kept on the tensor."""
+    t = getattr(wt, '_fsv_half', None)
+    if t is None:
+        owner = getattr(wt, '_fsv_owner', None)
+        if owner is not None:
+            t = owner.add_half(wt)
+        else:
+            from . import hconv
+            t = hconv.prep_weight_h(wt)
+        wt._fsv_half = t
+    return t
+
+
 def to_nhwc(x):
     """Return a tensor with the same logical NCHW shape whose memory is dense NHWC."""
     if x.dim() != 4:
@@ -203,7 +245,7 @@ class launch_group:
 
     def __init__(self, enabled=True, force_tile=-1):
         self.on = enabled and group_enabled()
-        self.convs, self.wgrads = [], []
+        self.convs, self.wgrads, self.hconvs = [], [], []
         self.outer = None
         self.force_tile = force_tile          # tests: tile id for the grouped gather-GEMM grid (-1: the library's plan)
 
@@ -226,6 +268,10 @@ class launch_group:
             for i in range(0, len(items), GROUP_LIMIT):
                 self._issue(kind, items[i:i + GROUP_LIMIT], self.force_tile)
         self.convs, self.wgrads = [], []
+        if self.hconvs:             # half-precision problems (hconv.gather_gemm_h): their own grid
+            from . import hconv
+            items, self.hconvs = self.hconvs, []
+            hconv.issue_group(items)
 
     @staticmethod
     def _issue(kind, items, force_tile=-1):
@@ -373,6 +419,14 @@ def gather_gemm(x, wt, ldw, cout, oh, ow, ty, tx, sy, sx, bias=None, res=None, a
     its output (csrc/conv_igemm.hip ConvP::stats) and fills stats['part'] (fp64 partials), stats['slots']; when the launch
     cannot (K-split plan, scalar gather, narrow-operand modes, inside a launch group) 'part' stays absent."""
     x = to_nhwc(x)
+    if x.dtype == torch.float16:
+        # half activations: the half-precision kernels (fp32 output unless `out` is a half tensor)
+        from . import hconv
+        wh, k64, nrows = half_twin(wt)
+        if accumulate:
+            raise ValueError("half launches store plainly (placed outputs never split K)")
+        return hconv.gather_gemm_h(x, wh, k64, nrows, cout, oh, ow, ty, tx, sy, sx, bias=bias, res=res, act=act, scale=scale,
+                                   per_sample=per_sample, out=out, place=place, out_half=False, wscale=wscale, stats=stats)
     n, cin, h, w = x.shape
     if place is None:
         out_h, out_w, osy, osx, ooy, oox = oh, ow, 1, 1, 0, 0
@@ -383,6 +437,7 @@ def gather_gemm(x, wt, ldw, cout, oh, ow, ty, tx, sy, sx, bias=None, res=None, a
     if res is not None:
         res = to_nhwc(res)
     lib.check_device(x, wt, bias, res, out, wscale)
+    _np_mode = narrow_staging_mode()
     w_bs = wt.shape[-2] * wt.shape[-1] if per_sample else 0
     b_bs = 0
     if per_sample and bias is not None:
@@ -399,9 +454,9 @@ def gather_gemm(x, wt, ldw, cout, oh, ow, ty, tx, sy, sx, bias=None, res=None, a
         _plan_log.append(planned(oh * ow if per_sample else n * oh * ow, cout, (len(ty) * cin + 31) // 32, n if per_sample else 1,
                                  force_tile, force_split) + (cin % 4 == 0,))
     entry = "fsv_conv_gather_fwd"
-    if _mfma_mode and cin % 4 == 0:               # scalar-gather layers (3-channel images, labels) stay on the fp32 kernel
+    if _np_mode and cin % 4 == 0:                 # scalar-gather layers (3-channel images, labels) stay on the fp32 kernel
         entry = "fsv_conv_gather_fwd_np"
-        args = args[:-1] + (_mfma_mode, args[-1])
+        args = args[:-1] + (_np_mode, args[-1])
     grp = _active_group()
     if (stats is not None and grp is None and entry == "fsv_conv_gather_fwd" and place is None and not per_sample
             and not accumulate and force_tile < 0 and force_split == 0 and cin % 4 == 0 and stats_enabled()):
@@ -447,7 +502,7 @@ def gather_gemm(x, wt, ldw, cout, oh, ow, ty, tx, sy, sx, bias=None, res=None, a
                                    thin=0 if entry.endswith('_np') else _thin_k(cout, cin, len(ty), per_sample, place, accumulate,
                                                                                 force_tile, force_split, act))
         if entry.endswith('_np'):
-            label = label.replace('fsv_conv_igemm_kernel', 'fsv_np_conv_kernel[%s]' % ('f16' if _mfma_mode == 1 else 'bf16x3'))
+            label = label.replace('fsv_conv_igemm_kernel', 'fsv_np_conv_kernel[%s]' % ('f16' if _np_mode == 1 else 'bf16x3'))
         keep = (x, wt, bias, res, out, wscale)          # the replay re-issues the launch on the same buffers
         with profile.scope(label, 2.0 * n * oh * ow * cout * cin * len(ty),
                            replay=lambda entry=entry, args=args, keep=keep: lib.call(entry, *args)):
@@ -502,7 +557,7 @@ def stop_plan_log():
     return log or []
 
 
-def conv_dgrad(dout, w, geom, in_hw, scale=None, per_sample=False, cached=None, cin=None):
+def conv_dgrad(dout, w, geom, in_hw, scale=None, per_sample=False, cached=None, cin=None, out_half=False):
     """Data gradient of a convolution: dx[n, y, x, ci] from dout (NHWC) and OIHW weights.
 
     cached: optional list (one entry per geom.dgrad_classes element, None for empty classes) of (wt, ldw) un-scaled
@@ -512,6 +567,19 @@ def conv_dgrad(dout, w, geom, in_hw, scale=None, per_sample=False, cached=None, 
     cin = w.shape[-3] if cin is None else cin
     h, wd = in_hw
     s = geom.stride
+    if dout.dtype == torch.float16:
+        from . import hconv
+        layouts = []
+        for k, c in enumerate(geom.dgrad_classes):
+            if not c['khs']:
+                layouts.append(None)
+            elif cached is not None:
+                layouts.append(half_twin(cached[k][0]))
+            else:
+                wt_k, _, _ = prep_weight(w, 1, geom, c['khs'], c['kws'], scale)
+                layouts.append(half_twin(wt_k))
+        return hconv.conv_dgrad_h(dout, layouts, geom, in_hw, cin, scale=scale if cached is not None else None,
+                                  per_sample=per_sample, out_half=out_half)
 
     def layout(k, c):
         if cached is not None:
@@ -528,7 +596,7 @@ def conv_dgrad(dout, w, geom, in_hw, scale=None, per_sample=False, cached=None, 
     plain = all(c['khs'] and sh > 0 and sw > 0 for c, (sh, sw) in zip(geom.dgrad_classes, subs))
     # the parity classes are independent problems (disjoint output pixels): ONE grouped launch instead of s * s small ones.
     # The group splits K (atomics into a zeroed dx) only when all classes together would leave most CUs idle.
-    grouped = group_enabled() and not _mfma_mode and cout % 4 == 0
+    grouped = group_enabled() and not narrow_staging_mode() and cout % 4 == 0
     if grouped:
         live = [(c, sub) for c, sub in zip(geom.dgrad_classes, subs) if sub[0] > 0 and sub[1] > 0 and c['khs']]
         shapes = [((sh * sw) if per_sample else n * sh * sw, cin, (len(c['khs']) * cout + 31) // 32, n if per_sample else 1)
@@ -561,6 +629,15 @@ def conv_wgrad(x, dout, geom, w_shape, per_sample=False, scale=None, force_split
     dout = to_nhwc(dout)
     n, cin, h, w = x.shape
     _, cout, oh, ow = dout.shape
+    if x.dtype == torch.float16 or dout.dtype == torch.float16:
+        from . import hconv
+        if hconv.wgrad_eligible(cin, cout, oh, ow) and force_tile == 0:
+            dwt = hconv.conv_wgrad_h(hconv.to_half_nhwc(x), hconv.to_half_nhwc(dout), geom, per_sample=per_sample,
+                                     force_split=force_split, arena=arena if raw else None)
+            if raw:
+                return dwt
+            return unprep_weight_grad(dwt, tuple(w_shape), geom, scale, out)
+        x, dout = hconv.cast(x, torch.float32), hconv.cast(dout, torch.float32)       # geometry outside the half kernels' contract
     kpad = _ceil(geom.ntaps * cin, 32)
     ldw = _ceil(cout, 32)
     nb = n if per_sample else 1
@@ -579,13 +656,14 @@ def conv_wgrad(x, dout, geom, w_shape, per_sample=False, scale=None, force_split
         bm, bn = 64, 64
     label = 'fsv_conv_wgrad_kernel<%dx%d,V%d>' % (bm, bn, 4 if vec4 else 1)
     if (profile.enabled() and cout <= 4 and vec4 and not per_sample and force_tile == 0 and force_split <= 0 and
-            geom.ntaps * (cin >> 2) <= 256 and not _mfma_mode and profile.thin_rule(n * oh * ow, kdim)):
+            geom.ntaps * (cin >> 2) <= 256 and not narrow_staging_mode() and profile.thin_rule(n * oh * ow, kdim)):
         label = 'fsv_conv_thin_wgrad_kernel<Cout%d>' % cout          # csrc/conv_igemm.hip fsv_conv_wgrad: vector-ALU reduction
     if profile.detail():
         label += ' Kdim%d N%d pix%d z%d' % (geom.ntaps * cin, cout, (oh * ow) if per_sample else n * oh * ow, nb)
-    narrow = _mfma_mode and vec4
+    _np_mode = narrow_staging_mode()
+    narrow = _np_mode and vec4
     if narrow:
-        label = 'fsv_np_wgrad_kernel[%s]' % ('f16' if _mfma_mode == 1 else 'bf16x3')
+        label = 'fsv_np_wgrad_kernel[%s]' % ('f16' if _np_mode == 1 else 'bf16x3')
     wargs = (lib.ptr(x), lib.ptr(dout), lib.ptr(dwt), n, h, w, cin, oh, ow, cout,
              geom.ntaps, lib.int_array(geom.ty), lib.int_array(geom.tx), geom.stride, geom.stride,
              ldw, kpad, kpad * ldw, 1 if per_sample else 0, force_split, 1 if prezeroed else 0, force_tile)
@@ -603,7 +681,7 @@ def conv_wgrad(x, dout, geom, w_shape, per_sample=False, scale=None, force_split
         return dwt
     with profile.scope(label, 2.0 * n * oh * ow * cout * cin * geom.ntaps):
         if narrow:
-            lib.call("fsv_conv_wgrad_np", *wargs, _mfma_mode, lib.stream_ptr())
+            lib.call("fsv_conv_wgrad_np", *wargs, _np_mode, lib.stream_ptr())
         else:
             lib.call("fsv_conv_wgrad", *wargs, lib.stream_ptr())
     if raw:

@@ -224,7 +224,8 @@ __global__ __launch_bounds__(256) void fsv_cat_put4_kernel(const float* src, flo
 // pixel-contiguous source planes (an NCHW tensor: sp == 1) -> dense [px][Ct]: one work-item per pixel reads its C values from the C
 // planes (each plane read is coalesced across the wave) and writes its Ct values as float4 (consecutive work-items, consecutive
 // addresses).  The element form reads C different planes within one wave instruction.
-template <int CT>
+typedef _Float16 fsv_ew_h16x4 __attribute__((ext_vector_type(4)));
+template <int CT, bool HALF = false>
 __global__ __launch_bounds__(256) void fsv_pad_channels_px_kernel(const float* src, float* out, unsigned N, int C, unsigned P, long long sn,
                                                                   long long sc) {
   const unsigned total = N * P;
@@ -234,9 +235,49 @@ __global__ __launch_bounds__(256) void fsv_pad_channels_px_kernel(const float* s
     float v[CT];
 #pragma unroll
     for (int c = 0; c < CT; ++c) v[c] = c < C ? s0[c * sc] : 0.f;
-    float4* o = reinterpret_cast<float4*>(out + (long long)i * CT);
+    if constexpr (HALF) {            // the `--amp` path: the padded tensor is a convolution input - rounded to half right here
+      fsv_ew_h16x4* o = reinterpret_cast<fsv_ew_h16x4*>(reinterpret_cast<_Float16*>(out) + (long long)i * CT);
 #pragma unroll
-    for (int q = 0; q < CT / 4; ++q) o[q] = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
+      for (int q = 0; q < CT / 4; ++q) {
+        fsv_ew_h16x4 t;
+        t[0] = (_Float16)v[4 * q]; t[1] = (_Float16)v[4 * q + 1]; t[2] = (_Float16)v[4 * q + 2]; t[3] = (_Float16)v[4 * q + 3];
+        o[q] = t;
+      }
+    } else {
+      float4* o = reinterpret_cast<float4*>(out + (long long)i * CT);
+#pragma unroll
+      for (int q = 0; q < CT / 4; ++q) o[q] = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
+    }
+  }
+}
+
+// any channel count, plane-strided source (NCHW labels: 35 -> 40, a packed 76 -> 80): one work-item per (pixel, group of 8 output
+// channels) - consecutive work-items take consecutive pixels of the same group, so every plane read is coalesced across the wave -
+// and one 16-byte (half) resp. two 16-byte (fp32) stores per work-item
+template <bool HALF>
+__global__ __launch_bounds__(256) void fsv_pad_channels_g8_kernel(const float* src, float* out, unsigned N, int C, unsigned P, long long sn,
+                                                                  long long sc, int Ct) {
+  const unsigned G = (unsigned)Ct >> 3;
+  const unsigned long long total = (unsigned long long)N * P * G;
+  for (unsigned long long i = (unsigned long long)blockIdx.x * 256u + threadIdx.x; i < total; i += (unsigned long long)gridDim.x * 256u) {
+    const unsigned px = (unsigned)(i % P);
+    const unsigned long long t = i / P;
+    const unsigned g = (unsigned)(t % G), n = (unsigned)(t / G);
+    const float* s0 = src + n * sn + px;
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { const int c = (int)g * 8 + e; v[e] = c < C ? s0[c * sc] : 0.f; }
+    const long long o = ((long long)n * P + px) * Ct + g * 8;
+    if constexpr (HALF) {
+      fsv_ew_h16x4 a, b;
+      a[0] = (_Float16)v[0]; a[1] = (_Float16)v[1]; a[2] = (_Float16)v[2]; a[3] = (_Float16)v[3];
+      b[0] = (_Float16)v[4]; b[1] = (_Float16)v[5]; b[2] = (_Float16)v[6]; b[3] = (_Float16)v[7];
+      fsv_ew_h16x4* d = reinterpret_cast<fsv_ew_h16x4*>(reinterpret_cast<_Float16*>(out) + o);
+      d[0] = a; d[1] = b;
+    } else {
+      float4* d = reinterpret_cast<float4*>(out + o);
+      d[0] = make_float4(v[0], v[1], v[2], v[3]); d[1] = make_float4(v[4], v[5], v[6], v[7]);
+    }
   }
 }
 
@@ -325,9 +366,26 @@ int fsv_cat_put(const float* src, float* out, long long N, int C, long long P, c
   return fsv_check_launch();
 }
 
+// fsv_pad_channels with the padded tensor written as IEEE half (the `--amp` path: it is a convolution input); pixel-contiguous
+// planes (strides[2] == 1) and Ct % 8 == 0 only
+int fsv_pad_channels_h(const float* src, void* out, long long N, int C, long long P, const long long* strides, int Ct,
+                       hipStream_t stream) {
+  if (!src || !out || !strides || N < 1 || C < 1 || P < 1 || Ct < C) return FSV_ERR_BAD_ARG;
+  if (strides[2] != 1 || (Ct & 7) != 0 || N * P >= (1ll << 31) || ((uintptr_t)out & 15) != 0) return FSV_ERR_UNSUPPORTED;
+  float* o = reinterpret_cast<float*>(out);
+  if (Ct == 8) FSV_LAUNCH((fsv_pad_channels_px_kernel<8, true>), dim3(fsv_grid_for(N * P)), dim3(256), stream, src, o, (unsigned)N, C, (unsigned)P, strides[0], strides[1]);
+  else if (Ct == 16) FSV_LAUNCH((fsv_pad_channels_px_kernel<16, true>), dim3(fsv_grid_for(N * P)), dim3(256), stream, src, o, (unsigned)N, C, (unsigned)P, strides[0], strides[1]);
+  else FSV_LAUNCH((fsv_pad_channels_g8_kernel<true>), dim3(fsv_grid_for(N * P * (Ct >> 3))), dim3(256), stream, src, o, (unsigned)N, C, (unsigned)P, strides[0], strides[1], Ct);
+  return fsv_check_launch();
+}
+
 int fsv_pad_channels(const float* src, float* out, long long N, int C, long long P, const long long* strides, int Ct,
                      hipStream_t stream) {
   if (!src || !out || !strides || N < 1 || C < 1 || P < 1 || Ct < C) return FSV_ERR_BAD_ARG;
+  if (strides[2] == 1 && (Ct & 7) == 0 && Ct > 16 && N * P < (1ll << 31) && ((uintptr_t)out & 15) == 0) {
+    FSV_LAUNCH((fsv_pad_channels_g8_kernel<false>), dim3(fsv_grid_for(N * P * (Ct >> 3))), dim3(256), stream, src, out, (unsigned)N, C, (unsigned)P, strides[0], strides[1], Ct);
+    return fsv_check_launch();
+  }
   if (strides[2] == 1 && (Ct == 4 || Ct == 8 || Ct == 12 || Ct == 16) && N * P < (1ll << 31) && ((uintptr_t)out & 15) == 0) {
     const dim3 g(fsv_grid_for(N * P));
     switch (Ct) {

@@ -104,6 +104,8 @@ struct PackP {
   int Cr, Cl, Ci, B; long long P;
   float* out;
   int halves;        // 2: [fake | real] on the batch axis; 1: `fake` only (out [B])
+  int Cto;           // channels of `out` (>= Cr + Cl + Ci: zero channels appended - the padding of the first discriminator convolution)
+  int out_half;      // `out` as IEEE half (the `--amp` path: the packed tensor is a convolution input)
 };
 
 // A workgroup owns 64 consecutive pixels of one sample: per source channel the 64 values are read as one run (coalesced for
@@ -124,13 +126,15 @@ __global__ __launch_bounds__(256) void fsv_pack_d_kernel(PackP p) {
     const long long px = px0 + lane;
     const bool ok = px < p.P;
     const long long npx = (p.P - px0) < FSV_PACK_PX ? (p.P - px0) : FSV_PACK_PX;
-    float* o = p.out + (n2 * p.P + px0) * Ct;
-    for (int c0 = 0; c0 < Ct; c0 += FSV_PACK_MAXC) {           // 64 channels per round (one-hot street labels: Ct = 76)
-      const int cw = (Ct - c0) < FSV_PACK_MAXC ? (Ct - c0) : FSV_PACK_MAXC;
+    const long long obase = (n2 * p.P + px0) * p.Cto;
+    float* o = p.out + obase;
+    _Float16* oh = reinterpret_cast<_Float16*>(p.out) + obase;
+    for (int c0 = 0; c0 < p.Cto; c0 += FSV_PACK_MAXC) {        // 64 channels per round (one-hot street labels: Ct = 76)
+      const int cw = (p.Cto - c0) < FSV_PACK_MAXC ? (p.Cto - c0) : FSV_PACK_MAXC;
       for (int cl = grp; cl < cw; cl += 4) {
         const int c = c0 + cl;
         float v = 0.f;
-        if (ok) {
+        if (ok && c < Ct) {
           if (c < p.Cr) v = p.ref[n * p.rs[0] + c * p.rs[1] + px * p.rs[2]];
           else if (c < p.Cr + p.Cl) v = p.lab[n * p.ls[0] + (c - p.Cr) * p.ls[1] + px * p.ls[2]];
           else {
@@ -144,7 +148,8 @@ __global__ __launch_bounds__(256) void fsv_pack_d_kernel(PackP p) {
       __syncthreads();
       for (int i = threadIdx.x; i < (int)npx * cw; i += 256) {
         const int pl = i / cw, cl = i - pl * cw;
-        o[(long long)pl * Ct + c0 + cl] = t[pl * (FSV_PACK_MAXC + 1) + cl];
+        const float v = t[pl * (FSV_PACK_MAXC + 1) + cl];
+        if (p.out_half) oh[(long long)pl * p.Cto + c0 + cl] = (_Float16)v; else o[(long long)pl * p.Cto + c0 + cl] = v;
       }
       __syncthreads();
     }
@@ -152,6 +157,7 @@ __global__ __launch_bounds__(256) void fsv_pack_d_kernel(PackP p) {
 }
 
 // dfake[n][c][px] (contiguous NCHW) = dout[n][px][Cr + Cl + c]
+template <bool HALF>
 __global__ __launch_bounds__(256) void fsv_unpack_d_kernel(const float* dout, float* dfake, int B, int Ci, int Coff, int Ct, long long P) {
   const long long total = (long long)B * Ci * P;
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
@@ -159,7 +165,8 @@ __global__ __launch_bounds__(256) void fsv_unpack_d_kernel(const float* dout, fl
     const long long t = i / P;
     const int c = (int)(t % Ci);
     const long long n = t / Ci;
-    dfake[i] = dout[(n * P + px) * Ct + Coff + c];
+    if constexpr (HALF) dfake[i] = (float)reinterpret_cast<const _Float16*>(dout)[(n * P + px) * Ct + Coff + c];
+    else dfake[i] = dout[(n * P + px) * Ct + Coff + c];
   }
 }
 
@@ -278,11 +285,38 @@ int fsv_hinge_bwd(const float* x, long long n, float sign, const float* gloss, f
 
 static inline int fsv_pack_grid(long long tiles) { return (int)(tiles < 16384 ? (tiles < 1 ? 1 : tiles) : 16384); }
 
+static int fsv_pack_d_impl(const float* ref, const float* lab, const float* fake, const float* real, float* out,
+                           int B, int Cr, int Cl, int Ci, long long P, const long long* ref_strides, const long long* lab_strides,
+                           const long long* fake_strides, const long long* real_strides, int halves, int Cto, int out_half,
+                           hipStream_t stream) {
+  if (!fake || !real || !out || B < 1 || Ci < 1 || P < 1 || (Cr > 0 && !ref) || (Cl > 0 && !lab) || Cto < Cr + Cl + Ci) return FSV_ERR_BAD_ARG;
+  PackP p;
+  p.ref = ref; p.lab = lab; p.fake = fake; p.real = real; p.out = out;
+  for (int i = 0; i < 3; ++i) {
+    p.rs[i] = ref ? ref_strides[i] : 0; p.ls[i] = lab ? lab_strides[i] : 0; p.fs[i] = fake_strides[i]; p.es[i] = real_strides[i];
+  }
+  p.Cr = Cr; p.Cl = Cl; p.Ci = Ci; p.B = B; p.P = P; p.halves = halves; p.Cto = Cto; p.out_half = out_half ? 1 : 0;
+  FSV_LAUNCH(fsv_pack_d_kernel, dim3(fsv_pack_grid((long long)halves * B * ((P + FSV_PACK_PX - 1) / FSV_PACK_PX))), dim3(256), stream, p);
+  return fsv_check_launch();
+}
+
+// the two packing entry points below with `Cto` >= Cr + Cl + Ci output channels (zero channels appended: the channel padding of the
+// first discriminator convolution done here) and, out_half != 0, `out` as IEEE half - the `--amp` path, where the packed tensor
+// is read by a half-precision convolution.  halves: 2 = [fake | real] on the batch axis, 1 = `fake` only.
+int fsv_pack_d_x(const float* ref, const float* lab, const float* fake, const float* real, void* out,
+                 int B, int Cr, int Cl, int Ci, long long P, const long long* ref_strides, const long long* lab_strides,
+                 const long long* fake_strides, const long long* real_strides, int halves, int Cto, int out_half, hipStream_t stream) {
+  if (halves != 1 && halves != 2) return FSV_ERR_BAD_ARG;
+  return fsv_pack_d_impl(ref, lab, fake, real ? real : fake, reinterpret_cast<float*>(out), B, Cr, Cl, Ci, P, ref_strides, lab_strides,
+                         fake_strides, real ? real_strides : fake_strides, halves, Cto, out_half, stream);
+}
+
 int fsv_pack_d_input(const float* ref, const float* lab, const float* fake, const float* real, float* out,
                      int B, int Cr, int Cl, int Ci, long long P, const long long* ref_strides, const long long* lab_strides,
                      const long long* fake_strides, const long long* real_strides, hipStream_t stream) {
   if (!fake || !real || !out || B < 1 || Ci < 1 || P < 1 || (Cr > 0 && !ref) || (Cl > 0 && !lab)) return FSV_ERR_BAD_ARG;
   PackP p;
+  p.Cto = Cr + Cl + Ci; p.out_half = 0;
   p.ref = ref; p.lab = lab; p.fake = fake; p.real = real; p.out = out;
   for (int i = 0; i < 3; ++i) {
     p.rs[i] = ref ? ref_strides[i] : 0; p.ls[i] = lab ? lab_strides[i] : 0; p.fs[i] = fake_strides[i]; p.es[i] = real_strides[i];
@@ -299,6 +333,7 @@ int fsv_pack_d_single(const float* ref, const float* lab, const float* img, floa
                       hipStream_t stream) {
   if (!img || !out || B < 1 || Ci < 1 || P < 1 || (Cr > 0 && !ref) || (Cl > 0 && !lab)) return FSV_ERR_BAD_ARG;
   PackP p;
+  p.Cto = Cr + Cl + Ci; p.out_half = 0;
   p.ref = ref; p.lab = lab; p.fake = img; p.real = img; p.out = out;
   for (int i = 0; i < 3; ++i) {
     p.rs[i] = ref ? ref_strides[i] : 0; p.ls[i] = lab ? lab_strides[i] : 0; p.fs[i] = img_strides[i]; p.es[i] = img_strides[i];
@@ -310,7 +345,15 @@ int fsv_pack_d_single(const float* ref, const float* lab, const float* img, floa
 
 int fsv_unpack_d_grad(const float* dout, float* dfake, int B, int Ci, int Coff, int Ct, long long P, hipStream_t stream) {
   if (!dout || !dfake) return FSV_ERR_BAD_ARG;
-  FSV_LAUNCH(fsv_unpack_d_kernel, dim3(fsv_loss_grid((long long)B * Ci * P) * 4), dim3(256), stream, dout, dfake, B, Ci, Coff, Ct, P);
+  FSV_LAUNCH(fsv_unpack_d_kernel<false>, dim3(fsv_loss_grid((long long)B * Ci * P) * 4), dim3(256), stream, dout, dfake, B, Ci, Coff, Ct, P);
+  return fsv_check_launch();
+}
+
+// the same from a half gradient tensor dout [B][P][Ct] (the data gradient of a half-precision convolution)
+int fsv_unpack_d_grad_h(const void* dout, float* dfake, int B, int Ci, int Coff, int Ct, long long P, hipStream_t stream) {
+  if (!dout || !dfake) return FSV_ERR_BAD_ARG;
+  FSV_LAUNCH(fsv_unpack_d_kernel<true>, dim3(fsv_loss_grid((long long)B * Ci * P) * 4), dim3(256), stream,
+             reinterpret_cast<const float*>(dout), dfake, B, Ci, Coff, Ct, P);
   return fsv_check_launch();
 }
 

@@ -41,6 +41,8 @@ struct SpadeP {
   const float* dh;
   float* dgb[FSV_SP_MAXMAPS];
   float* dxhat;
+  int h_half;             // forward: h is written as IEEE half (the `--amp` path: its only consumers are convolutions that read half);
+                          // backward twin: bit 0 - dh arrives as half, bit 1 - d(gamma|beta) is written as half
   int W, up;              // up = 1: x is the HALF-resolution tensor [N][H/2][W/2][C] and is read through the nearest-x2
                           // up-sampling index (generator.py:124 folded into this kernel: the up-sampled tensor is never written)
 };
@@ -376,15 +378,21 @@ __global__ __launch_bounds__(256, 2) void fsv_spade_mod_kernel(SpadeP p) {
           const int m = bm0 + wm * (TM * 32) + i * 32 + row;
           if (m >= p.HW) continue;
           const int e = m * p.C + c;
-          float d = dh_z[e];
+          float d = (p.h_half & 1) ? (float)reinterpret_cast<const _Float16*>(p.dh)[pix0 * p.C + e] : dh_z[e];
           if (p.act[0] == FSV_ACT_LRELU) d = (outv[0][i][j][r] > 0.f) ? d : 0.2f * d;
 #pragma unroll
           for (int k = FSV_SP_MAXMAPS - 1; k >= 0; --k) {
             if (k < p.nmaps) {
               float* dg = dg_z[k];
               const int e2 = m * 2 * p.C + c;
-              dg[e2 + p.C] = d;
-              dg[e2] = d * keep_o[k][i][j][r];
+              if (p.h_half & 2) {
+                _Float16* dgh = reinterpret_cast<_Float16*>(p.dgb[k]) + pix0 * 2 * p.C;
+                dgh[e2 + p.C] = (_Float16)d;
+                dgh[e2] = (_Float16)(d * keep_o[k][i][j][r]);
+              } else {
+                dg[e2 + p.C] = d;
+                dg[e2] = d * keep_o[k][i][j][r];
+              }
               d = d * (1.f + keep_g[k][i][j][r]);
             }
           }
@@ -407,7 +415,10 @@ __global__ __launch_bounds__(256, 2) void fsv_spade_mod_kernel(SpadeP p) {
         for (int r = 0; r < 16; ++r) {
           const int row = (r & 3) + 8 * (r >> 2) + 4 * lk;
           const int m = bm0 + wm * (TM * 32) + i * 32 + row;
-          if (m < p.HW) h_z[m * p.C + c] = fsv_act(outv[s][i][j][r], p.act[s]);
+          if (m < p.HW) {
+            const float v = fsv_act(outv[s][i][j][r], p.act[s]);
+            if (p.h_half) reinterpret_cast<_Float16*>(p.h[s])[(pix0 + m) * p.C + c] = (_Float16)v; else h_z[m * p.C + c] = v;
+          }
         }
     }
   }
@@ -557,22 +568,23 @@ static inline int fsv_sp_fill_common(SpadeP& p, const float* x, const float* mea
   p.N = N; p.HW = HW; p.C = C; p.ldw = ldw; p.stat_bstride = stat_bstride;
   p.W = up ? W : 1; p.up = up ? 1 : 0;
   p.dh = nullptr; p.dxhat = nullptr;
+  p.h_half = 0;
   return FSV_OK;
 }
 
 // maps/wg/wb/bg/bb: arrays of nmaps device pointers; ch / w_bstride / b_bstride: per-map ints / strides.
-int fsv_spade_mod_fwd(const float* x, const float* mean, const float* rstd, float* h,
+static int fsv_spade_mod_fwd_impl(const float* x, const float* mean, const float* rstd, float* h,
                       int nmaps, const float* const* maps, const float* const* wg, const float* const* wb,
                       const float* const* bg, const float* const* bb, const int* ch, const long long* w_bstride,
                       const long long* b_bstride, int N, int HW, int C, int ldw, long long stat_bstride, int act,
-                      int W, int up, hipStream_t stream) {
+                      int W, int up, int out_half, hipStream_t stream) {
   if (!h) return FSV_ERR_BAD_ARG;
   SpadeP p;
   int rc = fsv_sp_fill_common(p, x, mean, rstd, nmaps, maps, ch, N, HW, C, ldw, stat_bstride, W, up);
   if (rc) return rc;
   rc = fsv_sp_fill_site(p, 0, nmaps, wg, wb, bg, bb, w_bstride, b_bstride);
   if (rc) return rc;
-  p.h[0] = h; p.act[0] = act;
+  p.h[0] = h; p.act[0] = act; p.h_half = out_half ? 1 : 0;
   if (C <= 32) {
     dim3 g(fsv_cdiv(HW, 128), fsv_cdiv(C, 32), N);
     FSV_LAUNCH((fsv_spade_mod_kernel<128, 32, 4, 1, 1, false>), g, dim3(256), stream, p);
@@ -581,6 +593,26 @@ int fsv_spade_mod_fwd(const float* x, const float* mean, const float* rstd, floa
     FSV_LAUNCH((fsv_spade_mod_kernel<64, 64, 2, 2, 1, false>), g, dim3(256), stream, p);
   }
   return fsv_check_launch();
+}
+
+int fsv_spade_mod_fwd(const float* x, const float* mean, const float* rstd, float* h,
+                      int nmaps, const float* const* maps, const float* const* wg, const float* const* wb,
+                      const float* const* bg, const float* const* bb, const int* ch, const long long* w_bstride,
+                      const long long* b_bstride, int N, int HW, int C, int ldw, long long stat_bstride, int act,
+                      int W, int up, hipStream_t stream) {
+  return fsv_spade_mod_fwd_impl(x, mean, rstd, h, nmaps, maps, wg, wb, bg, bb, ch, w_bstride, b_bstride, N, HW, C, ldw, stat_bstride,
+                                act, W, up, 0, stream);
+}
+
+// the same with h written as IEEE half ([N][HW][C] halves): the `--amp` path, where the modulated tensor is only ever read by the
+// half-precision convolutions (csrc/conv_h.hip) - one rounding at the store instead of a fp32 tensor + a conversion pass
+int fsv_spade_mod_fwd_h(const float* x, const float* mean, const float* rstd, void* h,
+                        int nmaps, const float* const* maps, const float* const* wg, const float* const* wb,
+                        const float* const* bg, const float* const* bb, const int* ch, const long long* w_bstride,
+                        const long long* b_bstride, int N, int HW, int C, int ldw, long long stat_bstride, int act,
+                        int W, int up, hipStream_t stream) {
+  return fsv_spade_mod_fwd_impl(x, mean, rstd, reinterpret_cast<float*>(h), nmaps, maps, wg, wb, bg, bb, ch, w_bstride, b_bstride, N,
+                                HW, C, ldw, stat_bstride, act, W, up, 1, stream);
 }
 
 // Two norm sites of one SPADEResnetBlock in ONE launch (architecture.py:95-96,103: bn_0 and bn_s normalise the same x with the
@@ -612,11 +644,11 @@ int fsv_spade_mod_fwd2(const float* x, const float* mean, const float* rstd, flo
 }
 
 // Backward twin of fsv_spade_mod_fwd (see the kernel comment): same operands, dh in, dgb[k] ([P][2C] per map) and dxhat out.
-int fsv_spade_mod_bwd(const float* x, const float* mean, const float* rstd, const float* dh,
+static int fsv_spade_mod_bwd_impl(const float* x, const float* mean, const float* rstd, const float* dh,
                       int nmaps, const float* const* maps, const float* const* wg, const float* const* wb,
                       const float* const* bg, const float* const* bb, const int* ch, const long long* w_bstride,
                       const long long* b_bstride, float* const* dgb, float* dxhat, int N, int HW, int C, int ldw,
-                      long long stat_bstride, int act, int W, int up, hipStream_t stream) {
+                      long long stat_bstride, int act, int W, int up, int flags, hipStream_t stream) {
   if (!dh || !dgb || !dxhat) return FSV_ERR_BAD_ARG;
   if (act != FSV_ACT_LRELU && act != FSV_ACT_NONE) return FSV_ERR_UNSUPPORTED;
   SpadeP p;
@@ -624,7 +656,7 @@ int fsv_spade_mod_bwd(const float* x, const float* mean, const float* rstd, cons
   if (rc) return rc;
   rc = fsv_sp_fill_site(p, 0, nmaps, wg, wb, bg, bb, w_bstride, b_bstride);
   if (rc) return rc;
-  p.dh = dh; p.dxhat = dxhat; p.act[0] = act;
+  p.dh = dh; p.dxhat = dxhat; p.act[0] = act; p.h_half = flags & 3;
   for (int k = 0; k < nmaps; ++k) {
     if (!dgb[k]) return FSV_ERR_UNSUPPORTED;
     p.dgb[k] = dgb[k];
@@ -634,6 +666,27 @@ int fsv_spade_mod_bwd(const float* x, const float* mean, const float* rstd, cons
   dim3 g(fsv_cdiv(HW, 64), fsv_cdiv(C, 64), N);
   FSV_LAUNCH((fsv_spade_mod_kernel<64, 64, 2, 2, 1, true>), g, dim3(256), stream, p);
   return fsv_check_launch();
+}
+
+int fsv_spade_mod_bwd(const float* x, const float* mean, const float* rstd, const float* dh,
+                      int nmaps, const float* const* maps, const float* const* wg, const float* const* wb,
+                      const float* const* bg, const float* const* bb, const int* ch, const long long* w_bstride,
+                      const long long* b_bstride, float* const* dgb, float* dxhat, int N, int HW, int C, int ldw,
+                      long long stat_bstride, int act, int W, int up, hipStream_t stream) {
+  return fsv_spade_mod_bwd_impl(x, mean, rstd, dh, nmaps, maps, wg, wb, bg, bb, ch, w_bstride, b_bstride, dgb, dxhat, N, HW, C, ldw,
+                                stat_bstride, act, W, up, 0, stream);
+}
+
+// the `--amp` forms: flags bit 0 - dh is IEEE half (the gradient of a half h), bit 1 - every d(gamma|beta) tensor is written as half
+// ([P][2C] halves: its consumers are the half-precision data / weight gradient GEMMs and a column sum)
+int fsv_spade_mod_bwd_h(const float* x, const float* mean, const float* rstd, const void* dh,
+                        int nmaps, const float* const* maps, const float* const* wg, const float* const* wb,
+                        const float* const* bg, const float* const* bb, const int* ch, const long long* w_bstride,
+                        const long long* b_bstride, void* const* dgb, float* dxhat, int N, int HW, int C, int ldw,
+                        long long stat_bstride, int act, int W, int up, int flags, hipStream_t stream) {
+  return fsv_spade_mod_bwd_impl(x, mean, rstd, reinterpret_cast<const float*>(dh), nmaps, maps, wg, wb, bg, bb, ch, w_bstride,
+                                b_bstride, reinterpret_cast<float* const*>(dgb), dxhat, N, HW, C, ldw, stat_bstride, act, W, up,
+                                flags, stream);
 }
 
 int fsv_spade_bwd_elem(const float* x, const float* mean, const float* rstd, const float* dh, const float* h,

@@ -44,6 +44,11 @@ class LayoutCache:
         self._tables = None
         self._nblocks = 0
         self._dirty = True
+        # half-precision twins (hconv.py: N-major half operands of the `--amp` kernels) of the layouts above, created the first
+        # time a half activation meets a layout (conv.half_twin) and rewritten right behind the layouts themselves
+        self.half_jobs = []
+        self._half_tables = None
+        self._half_dirty = True
 
     # ------------------------------------------------------------------------------------------ registration
     def lookup(self, weight, shape4, geom, cpad):
@@ -64,6 +69,10 @@ class LayoutCache:
         old = getattr(weight, "_fsv_layout", None)
         if old is not None and old in self.entries:
             self.entries.remove(old)
+            stale = [j[0] for j in old.jobs]
+            if any(any(wt is t for t in stale) for wt, _ in self.half_jobs):
+                self.half_jobs = [(wt, wh) for wt, wh in self.half_jobs if not any(wt is t for t in stale)]
+                self._half_dirty = True
         cout, cin, kh, kw = shape4
         cinp = cin + cpad
         dev = weight.device
@@ -78,6 +87,7 @@ class LayoutCache:
             ldw = _ceil(ncols, 32)
             # zero once: the refresh kernel only rewrites the valid region, padding rows / columns stay zero
             wt = torch.zeros((1, kpad, ldw), dtype=torch.float32, device=dev)
+            wt._fsv_owner = self
             lo, hi = _pack_taps(khs, kws)
             e.jobs.append((wt, [cout, cinp, cin, kh, kw, ntaps, kpad, ldw, mode], lo, hi))
             return wt, ldw
@@ -114,9 +124,37 @@ class LayoutCache:
         return ((mk(src, torch.int64), mk(dst, torch.int64), mk(dims, torch.int32), mk(taps, torch.int64),
                  mk(tmap, torch.int32)), len(tmap) // 3)
 
+    def add_half(self, wt):
+        """persistent half twin of the cached layout wt (one conversion now; from here on refresh() rewrites it)"""
+        from . import hconv
+        if not lib.is_emu() and torch.cuda.is_current_stream_capturing():
+            raise lib.FsvError("a half twin of a cached weight layout is needed inside a graph capture; run one eager step first")
+        wh, k64, nrows = hconv.prep_weight_h(wt)
+        self.half_jobs.append((wt, wh))
+        self._half_dirty = True
+        return wh, k64, nrows
+
+    def _refresh_half(self, only=None):
+        if not self.half_jobs:
+            return
+        from . import hconv
+        if only is not None:
+            jobs = [(wt, wh) for wt, wh in self.half_jobs if any(wt is j[0] for j in only.jobs)]
+            if jobs:
+                tables = hconv._prep_tables(jobs, jobs[0][0].device)
+                hconv.launch_prep(tables)
+            return
+        if self._half_dirty:
+            if not lib.is_emu() and torch.cuda.is_current_stream_capturing():
+                raise lib.FsvError("weight-layout cache changed inside a graph capture; run one eager step first")
+            self._half_tables = hconv._prep_tables(self.half_jobs, self.half_jobs[0][0].device)
+            self._half_dirty = False
+        hconv.launch_prep(self._half_tables)
+
     def _refresh_entry(self, e):
         tables, nblocks = self._build([e], e.weight.device)
         self._launch(tables, nblocks)
+        self._refresh_half(only=e)
         e.version = e.weight._version
         if not lib.is_emu():
             # the tables are temporaries: keep them alive until the launch has consumed them
@@ -132,5 +170,6 @@ class LayoutCache:
             self._tables, self._nblocks = self._build(self.entries, self.entries[0].weight.device)
             self._dirty = False
         self._launch(self._tables, self._nblocks)
+        self._refresh_half()
         for e in self.entries:
             e.version = e.weight._version

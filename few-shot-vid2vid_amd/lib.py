@@ -114,7 +114,7 @@ def check_device(*tensors):
                 raise FsvError("emulated library got a device tensor")
         elif not t.is_cuda:
             raise FsvError("fsv2v HIP kernels need device tensors (got a CPU tensor); no CPU fallback exists")
-        if t.dtype != torch.float32 and t.dtype != torch.int32 and t.dtype != torch.float64:
+        if t.dtype not in (torch.float32, torch.int32, torch.float64, torch.float16):
             raise FsvError("unsupported dtype %s" % t.dtype)
 
 

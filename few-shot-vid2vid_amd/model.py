@@ -166,10 +166,10 @@ class LossCollector:
         (outputs, sigmas) of the discriminator for the real images from real_pass() - then only the generated images go through
         it here, on the same sigmas."""
         if real_out is not None:
-            x = ops.pack_d_single(ref if self.concat_ref_for_D else None, label, fake)
+            x = ops.pack_d_single(ref if self.concat_ref_for_D else None, label, fake, for_conv=_single_scale(netD))
             pred_fake, pred_real = netD(x, sn=real_out[1]), real_out[0]
         else:
-            x = ops.pack_d_input(ref if self.concat_ref_for_D else None, label, fake, real)
+            x = ops.pack_d_input(ref if self.concat_ref_for_D else None, label, fake, real, for_conv=_single_scale(netD))
             out = netD(x)
             half = x.shape[0] // 2
             pred_fake = [[t[:half] for t in scale] for scale in out]
@@ -253,7 +253,7 @@ class LossCollector:
                     outs.append(None)
                     continue
                 real4 = real.reshape(-1, *real.shape[-3:])
-                x = ops.pack_d_single(ref_concat if self.concat_ref_for_D else None, inp, real4)
+                x = ops.pack_d_single(ref_concat if self.concat_ref_for_D else None, inp, real4, for_conv=_single_scale(netD))
                 outs.append((netD(x, sn=sn), sn))
         return outs
 
@@ -328,6 +328,12 @@ class LossCollector:
             fg_diff = ((ref_fg_mask - fg_mask) > 0).float()
             terms += [masked_l1(m_ref, 1.0, fg_diff), masked_l1(m_ref, 1.0, body_diff)]
         return ops.weighted_sum(terms, [opt.lambda_mask] * len(terms)) if terms else self.zero(tgt_image)
+
+
+def _single_scale(netD):
+    """the packed discriminator input is read by ONE convolution and nothing else (a multi-scale pyramid, --num_D > 1, also
+    average-pools it): ops.pack_d_* may then hand it over padded and - under `--amp` - as half"""
+    return getattr(netD, 'num_D', 2) == 1
 
 
 def amp_mode(opt):

@@ -17,6 +17,8 @@ import threading as _threading
 import torch
 
 from . import lib, profile
+from . import conv as _conv
+from . import hconv as _hconv
 from .conv import (ACT_LRELU, ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_TANH, Geom, conv_dgrad, conv_forward, conv_wgrad, empty_nhwc,
                    gather_gemm, launch_group,
                    prep_weight, to_nhwc, zeros_nhwc)
@@ -44,6 +46,10 @@ lib.register_sigs({
     "fsv_spade_prep": [c_p, c_p, c_p, c_p, c_ll, c_ll, c_ll, c_ll, c_p, c_p, c_p, c_i, c_i, c_i, c_p],
     "fsv_spade_mod_fwd": [c_p, c_p, c_p, c_p, c_i, c_pp, c_pp, c_pp, c_pp, c_pp, c_ip, c_llp, c_llp,
                           c_i, c_i, c_i, c_i, c_ll, c_i, c_i, c_i, c_p],
+    "fsv_spade_mod_fwd_h": [c_p, c_p, c_p, c_p, c_i, c_pp, c_pp, c_pp, c_pp, c_pp, c_ip, c_llp, c_llp,
+                            c_i, c_i, c_i, c_i, c_ll, c_i, c_i, c_i, c_p],
+    "fsv_spade_mod_bwd_h": [c_p, c_p, c_p, c_p, c_i, c_pp, c_pp, c_pp, c_pp, c_pp, c_ip, c_llp, c_llp, c_pp, c_p,
+                            c_i, c_i, c_i, c_i, c_ll, c_i, c_i, c_i, c_i, c_p],
     "fsv_spade_mod_fwd2": [c_p, c_p, c_p, c_p, c_p, c_i, c_pp, c_pp, c_pp, c_pp, c_pp, c_ip, c_llp, c_llp,
                            c_i, c_i, c_i, c_i, c_ll, c_i, c_i, c_i, c_i, c_p],
     "fsv_spade_bwd_elem": [c_p, c_p, c_p, c_p, c_p, c_i, c_pp, c_pp, c_p, c_i, c_i, c_i, c_ll, c_i, c_i, c_i, c_p],
@@ -348,9 +354,31 @@ class _ConvFn(torch.autograd.Function):
         # input channel counts that are not a multiple of 4 (labels 6, RGB 3, flow-net input 15) would fall onto the
         # scalar gather path of the kernels; zero-pad channels (input and weights) once so the float4 path is used
         cin = x.shape[1]
-        cpad = (-cin) % 4 if not per_sample else 0
-        x = pad_channels_nhwc(x, cpad) if cpad else to_nhwc(x)
-        ctx.cpad, ctx.cin = cpad, cin
+        # `--amp O1` on the half-precision kernels (csrc/conv_h.hip): this layer's activations go to HBM as IEEE half - x here
+        # (cast once, kept for the weight gradient), the pre-activation gradient in backward (cast once, shared by the data and
+        # the weight gradient) - when its GEMMs fit the kernels' contract: input channels padded to a multiple of 8, output
+        # channels a multiple of 8 (the data gradient gathers over them; the image / flow / mask heads and the
+        # discriminator's one-channel output layer stay on the exact fp32 kernels).  Outputs are fp32: every consumer of a
+        # convolution here (normalisation, SPADE, residual sums, losses) computes in fp32, like apex O1's fp32 list.
+        # a producer may hand over an input that already carries the zero channels (ops.pack_d_* under `--amp`: padding and
+        # conversion done while packing): the weight says how many channels are real
+        cin_w = w4.shape[-3]
+        prepadded = (not per_sample) and cin > cin_w
+        half = (_conv.h_kernels() and cout % 8 == 0 and (per_sample and cin % 8 == 0 or not per_sample) and
+                x.dtype in (torch.float32, torch.float16))
+        if prepadded:
+            cpad, cin = cin - cin_w, cin_w
+            if (cin + cpad) % (8 if half else 4) != 0:
+                raise ValueError("pre-padded convolution input with %d channels for a weight of %d" % (cin + cpad, cin))
+        else:
+            cpad = ((-cin) % 8 if half else (-cin) % 4) if not per_sample else 0
+        ctx.x_half = x.dtype == torch.float16          # a half input (a producer that rounded at its store) gets a half gradient
+        if x.dtype == torch.float16 and not half:
+            x = _hconv.cast(x, torch.float32)
+        x = pad_channels_nhwc(x, cpad, half=half) if (cpad and not prepadded) else to_nhwc(x)
+        if half:
+            x = _hconv.to_half_nhwc(x)
+        ctx.cpad, ctx.cin, ctx.half, ctx.prepadded = cpad, cin, half, prepadded
         inv = sig[1:2] if sig is not None else None
         # parameters owned by a FlatAdam keep persistent K-major layouts (layout_cache.py); 1/sigma then rides in the
         # GEMM epilogue instead of the re-arrangement
@@ -403,6 +431,9 @@ class _ConvFn(torch.autograd.Function):
         n, _, h, w = ctx.x_shape
         cpad, cin = ctx.cpad, ctx.cin
         dpre = act_backward(dy, y, ctx.act, ctx.scale) if (ctx.act != ACT_NONE or ctx.scale != 1.0) else dy
+        # half path: ONE rounding of the pre-activation gradient, shared by the data gradient and the weight gradient (the bias
+        # gradient below is the fp32 column sum of the unrounded tensor: the bias add is fp32 epilogue work)
+        dpre_g = _hconv.to_half_nhwc(dpre) if ctx.half else dpre
         inv = sig[1:2] if sig is not None else None
         dx = dw = db = dres = None
         w4 = weight.detach()
@@ -426,14 +457,14 @@ class _ConvFn(torch.autograd.Function):
             fin = getattr(weight, '_fsv_finalizer', None) if (w_sink is not None and entry is not None) else None
             if fin is not None:
                 # deferred: leave the K-major result to the optimiser's grouped finalisation (grad_finalize.py)
-                dwt = conv_wgrad(x, dpre, geom, w_shape, raw=True, arena=fin)
+                dwt = conv_wgrad(x, dpre_g, geom, w_shape, raw=True, arena=fin)
                 if ctx.has_sn:
                     fin.add(entry, dwt, w_sink, sig, u, v)
                 else:
                     fin.add(entry, dwt, w_sink)
                 dw = None
             elif ctx.has_sn or cpad:
-                dwsn = conv_wgrad(x, dpre, geom, w_shape, per_sample=ctx.per_sample)
+                dwsn = conv_wgrad(x, dpre_g, geom, w_shape, per_sample=ctx.per_sample)
                 if cpad:
                     dwsn = dwsn[:, :cin].contiguous()
                 if ctx.has_sn:
@@ -444,7 +475,7 @@ class _ConvFn(torch.autograd.Function):
                     dw = dwsn
                 dw = None if w_sink is not None else dw.view_as(weight)
             else:
-                dw = conv_wgrad(x, dpre, geom, w_shape, per_sample=ctx.per_sample, out=w_sink)
+                dw = conv_wgrad(x, dpre_g, geom, w_shape, per_sample=ctx.per_sample, out=w_sink)
                 dw = None if w_sink is not None else dw.view_as(weight)
         if want_b:
             cout = dpre.shape[1]
@@ -460,9 +491,10 @@ class _ConvFn(torch.autograd.Function):
             else:
                 db = colsum(dpre, 1, n * hw, cout).view(cout)
         if want_x:
-            dx = conv_dgrad(dpre, w4, geom, (h, w), scale=inv, per_sample=ctx.per_sample,
-                            cached=entry.dgrad if entry is not None else None, cin=w_shape[-3])
-            if cpad:
+            dx = conv_dgrad(dpre_g, w4, geom, (h, w), scale=inv, per_sample=ctx.per_sample,
+                            cached=entry.dgrad if entry is not None else None, cin=w_shape[-3],
+                            out_half=ctx.x_half and ctx.half)
+            if cpad and not ctx.prepadded:
                 dx = dx[:, :cin]
         if ctx.has_res and ctx.needs_input_grad[3]:
             dres = dy
@@ -655,7 +687,10 @@ def mlp_bank(rows, chains):
     Returns one [R_l, out] tensor per chain, or None when the grouped path does not apply (the caller then runs the chains
     Linear by Linear through ops.linear)."""
     from . import conv as _conv
-    if not _conv.group_enabled() or _conv.mfma_mode() != 0:
+    # the staging-time narrowing kernels have no grouped form; under `--amp` on the half-precision kernels the bank runs as in the
+    # exact mode - grouped fp32 launches: the weight generators (6 GFLOP of the step's 1.8 TFLOP per frame) produce PARAMETERS of
+    # the SPADE layers, 100 small GEMMs that one by one cost more in launches than in arithmetic
+    if not _conv.group_enabled() or _conv.narrow_staging_mode() != 0:
         return None
     grad = torch.is_grad_enabled() and (any(r.requires_grad for r in rows) or
                                         any(m.weight_orig.requires_grad for _, ms in chains for m in ms))
@@ -855,7 +890,7 @@ def _spade_launch(a, b=None):
     chs = a['chs']
     if b is None:
         with profile.scope('fsv_spade_mod_kernel', a['flops']):
-            lib.call("fsv_spade_mod_fwd", lib.ptr(a['x']), lib.ptr(a['mean']), lib.ptr(a['rstd']), lib.ptr(a['h']), len(chs),
+            lib.call("fsv_spade_mod_fwd_h" if a.get('half') else "fsv_spade_mod_fwd", lib.ptr(a['x']), lib.ptr(a['mean']), lib.ptr(a['rstd']), lib.ptr(a['h']), len(chs),
                      _pp(a['maps']), arr(a['wg']), arr(a['wb']), arr(a['bg']), arr(a['bb']), lib.int_array(chs + [0]),
                      _ll(a['wstr'] + [0]), _ll(a['bstr'] + [0]), n, hw, c, ldw, 0, a['act'], w, up, lib.stream_ptr())
         return
@@ -904,12 +939,18 @@ class _SpadeFn(torch.autograd.Function):
             if tuple(maps[k].shape[2:]) != (h, w):
                 raise ValueError("SPADE maps must already be at the resolution of x")
         chs = [m.shape[1] for m in maps]
-        hout = empty_nhwc(n, c, h, w, x)
         ctx.up = up
         lib.check_device(x, *maps)
         # fast path (every production width): ONE preparation launch per map builds the combined [gamma | beta] operands
         # that the modulation kernel, the backward recompute and the data gradient all use as they are
         ctx.fast = (c % 16 == 0) and _os.environ.get('FSV_SPADE_FAST', '1') == '1'
+        # `--amp` on the half-precision kernels: the modulated tensor is only ever read by convolutions (conv_0 / conv_1 / conv_s of
+        # a SPADEResnetBlock, architecture.py:92-99) that would round it to half anyway - the kernel rounds at the store and the
+        # fp32 tensor + conversion pass disappear; its gradient then arrives as half (the convolutions' data gradient) and the
+        # backward twin reads it as such
+        ctx.half_out = bool(_conv.h_kernels() and ctx.fast and _os.environ.get('FSV_SPADE_FUSED_BWD', '1') == '1'
+                            and getattr(_spade_tls, 'pair', None) is None and nmaps > 0)
+        hout = _hconv.empty_nhwc_h(n, c, h, w, x) if ctx.half_out else empty_nhwc(n, c, h, w, x)
         if ctx.fast:
             ldw = 2 * c
             prepped, wg_p, wb_p, bg_p, bb_p, wstr, bstr = [], [], [], [], [], [], []
@@ -949,7 +990,7 @@ class _SpadeFn(torch.autograd.Function):
                 wstr.append(kt * 2 * c if per_sample else 0)
                 bstr.append(2 * c if per_sample else 0)
             site = dict(x=x, mean=mean, rstd=rstd, h=hout, maps=maps, wg=wg_p, wb=wb_p, bg=bg_p, bb=bb_p, chs=chs, wstr=wstr,
-                        bstr=bstr, dims=(n, h * w, c, ldw, w, up), act=act, keep=prepped,
+                        bstr=bstr, dims=(n, h * w, c, ldw, w, up), act=act, keep=prepped, half=ctx.half_out,
                         flops=2.0 * n * h * w * c * 2 * sum(chs))
             pair = getattr(_spade_tls, 'pair', None)
             if pair is None or nmaps == 0:
@@ -1003,7 +1044,7 @@ class _SpadeFn(torch.autograd.Function):
         g1 = Geom(1, 1, 1, 0)
         fast = ctx.fast
         gbs, wcats = [], []
-        dxhat = torch.empty_like(hout)
+        dxhat = empty_nhwc(n, c, h, w, x)
         fused = fast and _os.environ.get('FSV_SPADE_FUSED_BWD', '1') == '1'          # in-box A/B switch
         if fused:
             # fused backward twin of the modulation kernel: gamma / beta are recomputed in registers, never materialised
@@ -1021,9 +1062,14 @@ class _SpadeFn(torch.autograd.Function):
             lib.check_device(x, dh, *maps)
             # (labelled as the backward twin; FLOPs = the gamma / beta GEMMs it recomputes)
             with profile.scope('fsv_spade_mod_kernel<bwd>', 2.0 * n * h * w * c * 2 * sum(chs)):
-                lib.call("fsv_spade_mod_bwd", lib.ptr(x), lib.ptr(mean), lib.ptr(rstd), lib.ptr(dh), nm, _pp(maps), arr(wg_p),
-                         arr(wb_p), arr(bg_p), arr(bb_p), lib.int_array(chs + [0]), _ll(wstr + [0]), _ll(bstr + [0]), _pp(dgbs),
-                         lib.ptr(dxhat), n, h * w, c, 2 * c, 0, ctx.act, w, up, lib.stream_ptr())
+                if dh.dtype == torch.float16:
+                    lib.call("fsv_spade_mod_bwd_h", lib.ptr(x), lib.ptr(mean), lib.ptr(rstd), lib.ptr(dh), nm, _pp(maps), arr(wg_p),
+                             arr(wb_p), arr(bg_p), arr(bb_p), lib.int_array(chs + [0]), _ll(wstr + [0]), _ll(bstr + [0]),
+                             _pp(dgbs), lib.ptr(dxhat), n, h * w, c, 2 * c, 0, ctx.act, w, up, 1, lib.stream_ptr())
+                else:
+                    lib.call("fsv_spade_mod_bwd", lib.ptr(x), lib.ptr(mean), lib.ptr(rstd), lib.ptr(dh), nm, _pp(maps), arr(wg_p),
+                             arr(wb_p), arr(bg_p), arr(bb_p), lib.int_array(chs + [0]), _ll(wstr + [0]), _ll(bstr + [0]),
+                             _pp(dgbs), lib.ptr(dxhat), n, h * w, c, 2 * c, 0, ctx.act, w, up, lib.stream_ptr())
         else:
             if fast:
                 prepped = saved[4 + nm:]
@@ -1431,78 +1477,59 @@ def hinge_loss(x, real):
 
 
 class _PackDFn(torch.autograd.Function):
-    """Discriminator input [ref | label | image] with fake / real stacked on the batch axis, written once in NHWC
-    (loss_collector.py:47-58 builds it with three torch.cat + two repeat).  Only `fake` receives a gradient."""
+    """Discriminator input [ref | label | image] written once in NHWC (loss_collector.py:47-58 builds it with three torch.cat +
+    two repeat): fake and real stacked on the batch axis (real given), or one image set (real None: the G step's two
+    discriminator passes - real images without autograd, generated images with - each pack their own input).  Only `fake`
+    receives a gradient.  for_conv: the `--amp` form on the half-precision kernels - the tensor goes straight into the
+    discriminator's first convolution, so it is written with the zero channels that convolution's float / half gather needs
+    (76 -> 80) and as IEEE half: no padding pass, no conversion pass (ops._ConvFn recognises the pre-padded input)."""
 
     @staticmethod
-    def forward(ctx, ref, lab, fake, real):
-        fake, real = _dense4(fake), _dense4(real)
+    def forward(ctx, ref, lab, fake, real, for_conv):
+        fake = _dense4(fake)
+        real = _dense4(real) if real is not None else None
         b, ci, h, w = fake.shape
         cr = ref.shape[1] if ref is not None else 0
         cl = lab.shape[1] if lab is not None else 0
         ref = _dense4(ref) if ref is not None else None
         lab = _dense4(lab) if lab is not None else None
-        out = empty_nhwc(2 * b, cr + cl + ci, h, w, fake)
+        halves = 2 if real is not None else 1
+        ct = cr + cl + ci
+        half = bool(for_conv and _conv.h_kernels())
+        cto = (ct + 7) // 8 * 8 if half else ct
+        out = (_hconv.empty_nhwc_h if half else empty_nhwc)(halves * b, cto, h, w, fake)
         z3 = _ll([0, 0, 0])
         lib.check_device(ref, lab, fake, real)
-        lib.call("fsv_pack_d_input", lib.ptr(ref), lib.ptr(lab), lib.ptr(fake), lib.ptr(real), lib.ptr(out), b, cr, cl, ci,
+        lib.call("fsv_pack_d_x", lib.ptr(ref), lib.ptr(lab), lib.ptr(fake), lib.ptr(real), lib.ptr(out), b, cr, cl, ci,
                  h * w, _ll(_ncp_strides(ref)) if ref is not None else z3, _ll(_ncp_strides(lab)) if lab is not None else z3,
-                 _ll(_ncp_strides(fake)), _ll(_ncp_strides(real)), lib.stream_ptr())
-        ctx.dims = (b, cr, cl, ci, h, w)
+                 _ll(_ncp_strides(fake)), _ll(_ncp_strides(real)) if real is not None else z3, halves, cto, 1 if half else 0,
+                 lib.stream_ptr())
+        ctx.dims = (b, cr, cl, ci, h, w, cto)
         return out
 
     @staticmethod
     def backward(ctx, dout):
-        b, cr, cl, ci, h, w = ctx.dims
+        b, cr, cl, ci, h, w, cto = ctx.dims
         dfake = None
         if ctx.needs_input_grad[2]:
             dout = to_nhwc(dout)
             dfake = torch.empty((b, ci, h, w), dtype=torch.float32, device=dout.device)
-            lib.call("fsv_unpack_d_grad", lib.ptr(dout), lib.ptr(dfake), b, ci, cr + cl, cr + cl + ci, h * w, lib.stream_ptr())
-        return None, None, dfake, None
+            lib.check_device(dout)
+            lib.call("fsv_unpack_d_grad_h" if dout.dtype == torch.float16 else "fsv_unpack_d_grad", lib.ptr(dout), lib.ptr(dfake),
+                     b, ci, cr + cl, cto, h * w, lib.stream_ptr())
+        return None, None, dfake, None, None
 
 
-def pack_d_input(ref, lab, fake, real):
-    return _PackDFn.apply(ref, lab, fake, real)
+lib.register_sigs({"fsv_pack_d_x": [c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_ll, c_llp, c_llp, c_llp, c_llp, c_i, c_i, c_i, c_p],
+                   "fsv_unpack_d_grad_h": [c_p, c_p, c_i, c_i, c_i, c_i, c_ll, c_p]})
 
 
-lib.register_sigs({"fsv_pack_d_single": [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_ll, c_llp, c_llp, c_llp, c_p]})
+def pack_d_input(ref, lab, fake, real, for_conv=False):
+    return _PackDFn.apply(ref, lab, fake, real, for_conv)
 
 
-class _PackDSingleFn(torch.autograd.Function):
-    """[ref | label | image] for one image set ([B, ...], NHWC): the G step's two discriminator passes (real images without
-    autograd, generated images with) each pack their own input.  Only `img` receives a gradient."""
-
-    @staticmethod
-    def forward(ctx, ref, lab, img):
-        img = _dense4(img)
-        b, ci, h, w = img.shape
-        cr = ref.shape[1] if ref is not None else 0
-        cl = lab.shape[1] if lab is not None else 0
-        ref = _dense4(ref) if ref is not None else None
-        lab = _dense4(lab) if lab is not None else None
-        out = empty_nhwc(b, cr + cl + ci, h, w, img)
-        z3 = _ll([0, 0, 0])
-        lib.check_device(ref, lab, img)
-        lib.call("fsv_pack_d_single", lib.ptr(ref), lib.ptr(lab), lib.ptr(img), lib.ptr(out), b, cr, cl, ci, h * w,
-                 _ll(_ncp_strides(ref)) if ref is not None else z3, _ll(_ncp_strides(lab)) if lab is not None else z3,
-                 _ll(_ncp_strides(img)), lib.stream_ptr())
-        ctx.dims = (b, cr, cl, ci, h, w)
-        return out
-
-    @staticmethod
-    def backward(ctx, dout):
-        b, cr, cl, ci, h, w = ctx.dims
-        dimg = None
-        if ctx.needs_input_grad[2]:
-            dout = to_nhwc(dout)
-            dimg = torch.empty((b, ci, h, w), dtype=torch.float32, device=dout.device)
-            lib.call("fsv_unpack_d_grad", lib.ptr(dout), lib.ptr(dimg), b, ci, cr + cl, cr + cl + ci, h * w, lib.stream_ptr())
-        return None, None, dimg
-
-
-def pack_d_single(ref, lab, img):
-    return _PackDSingleFn.apply(ref, lab, img)
+def pack_d_single(ref, lab, img, for_conv=False):
+    return _PackDFn.apply(ref, lab, img, None, for_conv)
 
 
 def part_masks(pose_ch, g0=0, ngroups=9):
@@ -1617,6 +1644,7 @@ def pool15(x, mode, thresh=0.0):
 lib.register_sigs({
     "fsv_cat_put": [c_p, c_p, c_ll, c_i, c_ll, c_llp, c_i, c_i, c_p],
     "fsv_pad_channels": [c_p, c_p, c_ll, c_i, c_ll, c_llp, c_i, c_p],
+    "fsv_pad_channels_h": [c_p, c_p, c_ll, c_i, c_ll, c_llp, c_i, c_p],
     "fsv_cat_get": [c_p, c_p, c_ll, c_i, c_ll, c_i, c_i, c_p],
     "fsv_blend_fwd": [c_p, c_p, c_p, c_p, c_i, c_i, c_ll, c_llp, c_llp, c_llp, c_p],
     "fsv_blend_bwd": [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_ll, c_llp, c_llp, c_llp, c_p],
@@ -1661,15 +1689,22 @@ def cat_channels(tensors):
     return _CatFn.apply(*tensors)
 
 
-def pad_channels_nhwc(x, cpad):
+def pad_channels_nhwc(x, cpad, half=False):
     """x [N, C, H, W] in any layout whose H x W plane is one strided run -> dense NHWC [N, C + cpad, H, W] with zero channels
-    appended, in one launch (no autograd: callers slice the gradient themselves)"""
+    appended, in one launch (no autograd: callers slice the gradient themselves).  half: the result as IEEE half (the `--amp`
+    path: padding + conversion of a convolution input in one pass) when the source planes are pixel-contiguous; otherwise the
+    fp32 result (the caller converts)."""
     x = x.detach()
     n, c, h, w = x.shape
     if not (x.dtype == torch.float32 and (h == 1 or x.stride(2) == w * x.stride(3))):
         return to_nhwc(torch.nn.functional.pad(to_nhwc(x), (0, 0, 0, 0, 0, cpad)))
-    out = empty_nhwc(n, c + cpad, h, w, x)
     lib.check_device(x)
+    if half and x.stride(3) == 1 and (c + cpad) % 8 == 0 and n * h * w < (1 << 31):
+        out = _hconv.empty_nhwc_h(n, c + cpad, h, w, x)
+        lib.call("fsv_pad_channels_h", lib.ptr(x), lib.ptr(out), n, c, h * w, _ll([x.stride(0), x.stride(1), 1]), c + cpad,
+                 lib.stream_ptr())
+        return out
+    out = empty_nhwc(n, c + cpad, h, w, x)
     lib.call("fsv_pad_channels", lib.ptr(x), lib.ptr(out), n, c, h * w, _ll([x.stride(0), x.stride(1), x.stride(3)]), c + cpad,
              lib.stream_ptr())
     return out

@@ -113,6 +113,52 @@ int fsv_conv_wgrad(const float* in, const float* dout, float* dwt,
                    int ldw, int Kpad, long long w_bstride, int per_sample, int force_split, int prezeroed,
                    int force_tile, fsv_stream_t stream);
 
+/* ---- half-precision path (csrc/conv_h.hip): the reference's `--amp O1` arithmetic (options/base_options.py:127,
+ * models/models.py:22-26, loss_collector.py:221-224; BASELINE.json configs[4] "fp16 MFMA path") with activations AND weights
+ * 16-bit in HBM.  Contract of one convolution: operands are IEEE half in memory (whoever produced them rounded once), products are
+ * exact, accumulation is fp32 (v_mfma_f32_32x32x16_f16), (acc * wscale + bias) * scale -> act -> + res in fp32, one rounding at
+ * the store when out_h.  Activations NHWC half with Cin % 8 == 0; weights N-MAJOR half wt[z][nrows][Kpad] (K = taps * Cin
+ * contiguous, Kpad % 64 == 0, zero padded) as written by fsv_hconv_prep_weight from the K-major fp32 layout of fsv_prep_weight.
+ * fsv_hconv_desc = one problem; n == 1: a single launch that may split K (partial sums in fp32: `ws` when the output is half) and
+ * may leave normalisation statistics (stats / *produced as fsv_conv_gather_fwd_stats); n > 1: ONE grid over independent
+ * problems (fsv_conv_gather_group).  res / out are half when res_h / out_h, else fp32; act FSV_ACT_DLRELU reads res as the aux
+ * tensor.  FSV_ERR_UNSUPPORTED (nothing launched) for geometries outside this contract: callers keep those on the fp32 path. */
+typedef struct fsv_hconv_desc {
+  const void* in; const void* wt; const float* bias; const void* res; void* out; const float* wscale;
+  float* ws; double* stats;
+  int N, H, W, Cin, OH, OW, Cout, ntaps;
+  int ty[16], tx[16];
+  int sy, sx, outH, outW, osy, osx, ooy, oox;
+  int Kpad, nrows;
+  int per_sample, act, accumulate;
+  int out_h, res_h;
+  int force_tile, force_split;
+  int stats_groups, stats_slots, stats_prezeroed;
+  float scale;
+  long long w_bstride, b_bstride;
+} fsv_hconv_desc;
+int fsv_hconv_gather(const fsv_hconv_desc* problems, int n, int* produced, fsv_stream_t stream);
+/* tile id (0 = 128x128, 1 = 128x64, 2 = 128x32, 4 = 64x64, 9 = 64x128; + 16: two LDS buffers instead of three) and K split the
+ * single launch will use; nchunks = ceil(taps * Cin / 64) */
+int fsv_hconv_plan(int Mz, int Cout, int nchunks, int nsamp, int force_tile, int force_split, int can_split, int* tile_out,
+                   int* nsplit_out);
+/* weight gradient from half activations `in` (NHWC, Cin % 8 == 0) and half output gradients `dout` ([pixels][Cout], Cout % 8 == 0)
+ * into the fp32 K-major matrix dwt[Kpad][ldw] of fsv_conv_wgrad (same arguments); force_tile 1 / 2 / 3 / 4 / 5 = 64x64 / 128x64 /
+ * 64x128 / 128x128 / 128x32 */
+int fsv_hconv_wgrad(const void* in, const void* dout, float* dwt,
+                    int N, int H, int W, int Cin, int OH, int OW, int Cout,
+                    int ntaps, const int* ty, const int* tx, int sy, int sx,
+                    int ldw, int Kpad, long long w_bstride, int per_sample, int force_split, int prezeroed,
+                    int force_tile, fsv_stream_t stream);
+/* K-major fp32 wt[z][Kpad32][ldw] -> N-major half wh[z][nrows][Kpad64], table-driven (one launch for a whole layout cache):
+ * jobs[j] = {src, dst, Kpad32, ldw, nrows, Kpad64, nbatch, 0} as 64-bit words (device), tmap[b] = (job, 64-k tile, 64-n tile, z) */
+int fsv_hconv_prep_weight(const long long* jobs, const int* tmap, int nblocks, fsv_stream_t stream);
+/* the same for ONE layout with the geometry in the arguments (no device table: legal inside a graph capture) */
+int fsv_hconv_prep_weight_one(const float* src, void* dst, int Kpad32, int ldw, int nrows, int Kpad64, int nbatch,
+                              fsv_stream_t stream);
+/* dense element conversion, dir 0: fp32 -> half (round to nearest even), 1: half -> fp32 */
+int fsv_cast_half(const void* x, void* y, long long n, int dir, fsv_stream_t stream);
+
 /* ---- narrow-operand GEMMs (csrc/conv_np.hip): the reference's `--amp` arithmetic (options/base_options.py:127,
  * models/models.py:22-26 `amp.initialize(..., opt_level=opt.amp, num_losses=2)`; BASELINE.json configs[4]).  Same
  * contracts and arguments as fsv_conv_gather_fwd / fsv_conv_wgrad plus `mode`: 1 = operands rounded to IEEE half while a
@@ -195,6 +241,12 @@ int fsv_spade_mod_fwd(const float* x, const float* mean, const float* rstd, floa
                       const float* const* bg, const float* const* bb, const int* ch, const long long* w_bstride,
                       const long long* b_bstride, int N, int HW, int C, int ldw, long long stat_bstride, int act,
                       int W, int up, fsv_stream_t stream);
+/* fsv_spade_mod_fwd with h written as IEEE half (the `--amp` path: h is only read by half-precision convolutions) */
+int fsv_spade_mod_fwd_h(const float* x, const float* mean, const float* rstd, void* h,
+                      int nmaps, const float* const* maps, const float* const* wg, const float* const* wb,
+                      const float* const* bg, const float* const* bb, const int* ch, const long long* w_bstride,
+                      const long long* b_bstride, int N, int HW, int C, int ldw, long long stat_bstride, int act,
+                      int W, int up, fsv_stream_t stream);
 /* Two norm sites of one SPADEResnetBlock in one launch - bn_0 and bn_s (architecture.py:95-96,103) normalise the same x
  * with the same statistics and read the same maps; only the gamma / beta weights and the activation differ:
  * h0 = act0(SPADE_0(x)), h1 = act1(SPADE_s(x)).  x, the statistics and the label-map tiles are read once, the map tile in LDS
@@ -212,6 +264,12 @@ int fsv_spade_mod_bwd(const float* x, const float* mean, const float* rstd, cons
                       const float* const* bg, const float* const* bb, const int* ch, const long long* w_bstride,
                       const long long* b_bstride, float* const* dgb, float* dxhat, int N, int HW, int C, int ldw,
                       long long stat_bstride, int act, int W, int up, fsv_stream_t stream);
+/* fsv_spade_mod_bwd for the `--amp` path: flags bit 0 - dh is IEEE half, bit 1 - the d(gamma|beta) tensors are written as half */
+int fsv_spade_mod_bwd_h(const float* x, const float* mean, const float* rstd, const void* dh,
+                      int nmaps, const float* const* maps, const float* const* wg, const float* const* wb,
+                      const float* const* bg, const float* const* bb, const int* ch, const long long* w_bstride,
+                      const long long* b_bstride, void* const* dgb, float* dxhat, int N, int HW, int C, int ldw,
+                      long long stat_bstride, int act, int W, int up, int flags, fsv_stream_t stream);
 /* element-wise part of the backward (general path, C % 16 != 0): from materialised gamma|beta ([P][2C] per map) to d(gamma|beta) and d(xhat) (dxhat is
  * written per full-resolution pixel also when up != 0: summing it over the 2x2 children gives the gradient of the
  * half-resolution normalised tensor) */
@@ -324,6 +382,10 @@ int fsv_cat_put(const float* src, float* out, long long N, int C, long long P, c
  * (inputs whose channel count is not a multiple of 4 are padded once for the float4 gather of the convolutions) */
 int fsv_pad_channels(const float* src, float* out, long long N, int C, long long P, const long long* strides, int Ct,
                      fsv_stream_t stream);
+/* the same with `out` written as IEEE half ([N][P][Ct] halves; the `--amp` path: the padded tensor is a convolution input).
+ * Pixel-contiguous source planes (strides[2] == 1) and Ct % 8 == 0 only: FSV_ERR_UNSUPPORTED otherwise */
+int fsv_pad_channels_h(const float* src, void* out, long long N, int C, long long P, const long long* strides, int Ct,
+                       fsv_stream_t stream);
 int fsv_cat_get(const float* dout, float* dst, long long N, int C, long long P, int Ct, int coff, fsv_stream_t stream);
 int fsv_blend_fwd(const float* a, const float* b, const float* m, float* out, int N, int C, long long P,
                   const long long* a_strides, const long long* b_strides, const long long* out_strides, fsv_stream_t stream);
@@ -361,6 +423,14 @@ int fsv_pack_d_single(const float* ref, const float* lab, const float* img, floa
                       long long P, const long long* ref_strides, const long long* lab_strides, const long long* img_strides,
                       fsv_stream_t stream);
 int fsv_unpack_d_grad(const float* dout, float* dfake, int B, int Ci, int Coff, int Ct, long long P, fsv_stream_t stream);
+/* `--amp` forms: the packed discriminator input with Cto >= Cr + Cl + Ci channels (zero channels appended = the channel padding of
+ * the first discriminator convolution) and, out_half != 0, as IEEE half; halves 2: [fake | real] on the batch axis (out [2B][P][Cto]),
+ * 1: fake only (real may be NULL).  fsv_unpack_d_grad_h reads the half data gradient of that convolution. */
+int fsv_pack_d_x(const float* ref, const float* lab, const float* fake, const float* real, void* out,
+                 int B, int Cr, int Cl, int Ci, long long P, const long long* ref_strides, const long long* lab_strides,
+                 const long long* fake_strides, const long long* real_strides, int halves, int Cto, int out_half,
+                 fsv_stream_t stream);
+int fsv_unpack_d_grad_h(const void* dout, float* dfake, int B, int Ci, int Coff, int Ct, long long P, fsv_stream_t stream);
 /* DensePose part-group masks (models/input_process.py:64-94): x = pose channel [B, T, P] (strides sb, st, 1), N = B*T;
  * y[N][ngroups][P] = 1 where (x/2+0.5)*24 is within 0.1 of a member of group g0+g (9 groups; group 8 = face parts 23/24) */
 int fsv_part_masks(const float* x, float* y, long long N, long long P, int T, long long sb, long long st, int g0, int ngroups,

@@ -275,6 +275,15 @@ def check_cat_and_pad(device, seed=33):
         ref = F.pad(x, (0, 0, 0, 0, 0, cpad))
         assert y.shape == ref.shape and torch.equal(y.cpu(), ref), ('pad', shape, cpad, nhwc)
         assert y.permute(0, 2, 3, 1).is_contiguous()
+    # wide paddings (one-hot labels 35 -> 40, a packed discriminator input 76 -> 80) and the half-output form of the `--amp` path
+    for shape, cpad in (((2, 35, 6, 5), 5), ((1, 76, 4, 7), 4), ((2, 3, 6, 5), 5), ((1, 11, 3, 9), 5), ((1, 20, 5, 5), 4)):
+        x = torch.randn(shape, generator=g)
+        ref = F.pad(x, (0, 0, 0, 0, 0, cpad))
+        y = ops.pad_channels_nhwc(_dev(x, device), cpad)
+        assert torch.equal(y.cpu(), ref) and y.permute(0, 2, 3, 1).is_contiguous(), ('pad wide', shape, cpad)
+        yh = ops.pad_channels_nhwc(_dev(x, device), cpad, half=True)
+        assert yh.dtype == torch.float16 and yh.permute(0, 2, 3, 1).is_contiguous(), ('pad half', shape, cpad)
+        assert torch.equal(yh.cpu(), ref.to(torch.float16)), ('pad half values', shape, cpad)
 
 
 def check_linear(device, r=40, cin=16, cout=50, seed=2):
@@ -365,12 +374,15 @@ def check_norm(device, instance, n=3, c=10, h=7, w=5, affine=True, act='lrelu', 
         assert_close('running_var', rvd, rv)
 
 
-def check_spade(device, nmaps=1, generated=True, n=2, c=12, ch=8, h=6, w=5, act='lrelu', seed=5, strided=False, up=False):
+def check_spade(device, nmaps=1, generated=True, n=2, c=12, ch=8, h=6, w=5, act='lrelu', seed=5, strided=False, up=False,
+                half_out=False):
     """SPADE with per-sample generated weights for map 0 and fixed weights for the extra maps.  strided: the generated
     weights / biases are views into one [n, L] tensor, the way the weight-generating FC hands them over
     (generator.py reshape_weight); c % 16 == 0 takes the single-preparation-launch path of ops._SpadeFn.  up: x is handed
     over at half resolution and the kernels read it through the nearest x2 up-sampling index (generator.py:124 folded in);
-    the reference up-samples explicitly (h, w must be even)."""
+    the reference up-samples explicitly (h, w must be even).  half_out: the `--amp` form on the half-precision kernels - h is
+    stored as IEEE half (one rounding) and its gradient arrives as half; the arithmetic in between stays fp32, so with the
+    gradient rounded beforehand on both sides the gradients agree at the fp32 tolerance (c % 16 == 0 required)."""
     ops, conv = pkg()
     g = torch.Generator().manual_seed(seed)
     x = torch.randn(n, c, h // 2, w // 2, generator=g) + 0.3 if up else torch.randn(n, c, h, w, generator=g) + 0.3
@@ -420,12 +432,24 @@ def check_spade(device, nmaps=1, generated=True, n=2, c=12, ch=8, h=6, w=5, act=
     if act == 'lrelu':
         ref = O.actvn(ref)
     dy = torch.randn(ref.shape, generator=g)
+    if half_out:
+        dy = dy.to(torch.float16).to(torch.float32)
     ref.backward(dy)
     run_mean_d, run_var_d = _dev(torch.zeros(c), device), _dev(torch.ones(c), device)
-    y = ops.spade_mod(xd, maps_d, weights_d, run_mean_d, run_var_d, act=conv.ACT_LRELU if act == 'lrelu' else conv.ACT_NONE,
-                      up=up)
-    y.backward(_dev(dy, device))
-    assert_close('spade h', y, ref)
+    prev = conv.set_mfma_mode(1 if half_out else conv.mfma_mode())
+    try:
+        y = ops.spade_mod(xd, maps_d, weights_d, run_mean_d, run_var_d, act=conv.ACT_LRELU if act == 'lrelu' else conv.ACT_NONE,
+                          up=up)
+        if half_out:
+            assert y.dtype == torch.float16, 'the modulated tensor should have been stored as half'
+            y.backward(_dev(dy, device).to(torch.float16))
+            err = (y.detach().float().cpu() - ref.detach()).abs()
+            assert bool((err <= 2.0 ** -10 * ref.detach().abs() * 1.01 + 1e-5 * float(ref.detach().abs().max())).all()), float(err.max())
+        else:
+            y.backward(_dev(dy, device))
+            assert_close('spade h', y, ref)
+    finally:
+        conv.set_mfma_mode(prev)
     assert_close('spade running mean', run_mean_d, run_mean_r, 1e-5)
     assert_close('spade running var', run_var_d, run_var_r, 1e-5)
     for i, (a, d) in enumerate(zip(leaves_ref, leaves_dev)):

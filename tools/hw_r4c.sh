@@ -1,0 +1,14 @@
+#!/bin/bash
+# round 4, pass c: XCD bands (1-D padded grid) + 8-wave 128x128 / 256x128 tiles of the half kernels: correctness, forward tile A/B
+set -u
+ROOT=${GRAFT_REPO_ROOT:-$PWD}
+OUT=$ROOT/gpurun_out/${1:-r4c}
+mkdir -p "$OUT"
+cd "$ROOT/tests"
+timeout 300 python h_checks.py > "$OUT/h_checks.log" 2>&1
+echo "h_checks: exit $? $(tail -n 1 "$OUT/h_checks.log" | cut -c1-300)" | tee -a "$OUT/summary.txt"
+cd "$ROOT"
+FSV_HAB=${FSV_HAB:-fwd} timeout 600 python tools/h_ab.py ${HAB_SHAPES:-} > "$OUT/h_ab.jsonl" 2> "$OUT/h_ab.err"
+echo "h_ab: exit $?" | tee -a "$OUT/summary.txt"
+cat "$OUT/h_ab.jsonl"
+tail -5 "$OUT/h_ab.err"

@@ -19,11 +19,17 @@ import bench  # noqa: E402
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument('--size', type=int, default=512)
-    ap.add_argument('--batch', type=int, default=2)
+    ap.add_argument('--workload', default='pose', choices=sorted(bench.WORKLOADS))
+    ap.add_argument('--amp', default='O0')
+    ap.add_argument('--size', type=int, default=None)
+    ap.add_argument('--batch', type=int, default=None)
     ap.add_argument('--top', type=int, default=60)
     ap.add_argument('--out', default='')
     args = ap.parse_args()
+    bench.WORKLOAD, bench.AMP = args.workload, args.amp
+    wl = bench.WORKLOADS[args.workload]
+    args.size = wl['size'] if args.size is None else args.size
+    args.batch = wl['batch'] if args.batch is None else args.batch
     from importlib import import_module
     import fsv2v_amd  # noqa: F401
     M = import_module('few-shot-vid2vid_amd.model')
@@ -32,7 +38,7 @@ def main():
     opt = bench.build_opt(args.size, args.batch)
     model = M.create_model(opt).to(dev).train()
     opt_G, opt_D = model.build_optimizers()
-    data = bench.make_data(args.batch, args.size, 1234, dev)
+    data = bench.make_data(args.batch, args.size, 1234, dev, opt)
 
     def step():
         M.loss_backward(opt, model(data, mode='discriminator'), opt_D, 1)
