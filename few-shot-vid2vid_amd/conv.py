@@ -576,10 +576,9 @@ def conv_dgrad(dout, w, geom, in_hw, scale=None, per_sample=False, cached=None, 
             elif cached is not None:
                 layouts.append(half_twin(cached[k][0]))
             else:
-                wt_k, _, _ = prep_weight(w, 1, geom, c['khs'], c['kws'], scale)
+                wt_k, _, _ = prep_weight(w, 1, geom, c['khs'], c['kws'], None)
                 layouts.append(half_twin(wt_k))
-        return hconv.conv_dgrad_h(dout, layouts, geom, in_hw, cin, scale=scale if cached is not None else None,
-                                  per_sample=per_sample, out_half=out_half)
+        return hconv.conv_dgrad_h(dout, layouts, geom, in_hw, cin, scale=scale, per_sample=per_sample, out_half=out_half)
 
     def layout(k, c):
         if cached is not None:

@@ -975,20 +975,28 @@ int fsv_hconv_wgrad(const void* in, const void* dout, float* dwt,
   p.Mz = per_sample ? OH * OW : N * OH * OW;
   p.pchunks = fsv_cdiv(p.Mz, FSV_HBK);
   const int nsamp = per_sample ? N : 1;
-  // tiles (rows = taps * Cin, columns = Cout): force_tile 1 = 64x64, 2 = 128x64, 3 = 64x128, 4 = 128x128, 5 = 128x32
+  // tiles (rows = taps * Cin, columns = Cout): force_tile 1 = 64x64, 2 = 128x64, 3 = 64x128, 4 = 128x128, 5 = 128x32, 6 = 128x64 as an
+  // 8-wave workgroup.  Plan (in-box A/B of round 4, tools/h_ab.py): 128x64 beats 128x128 wherever the tile count is small (the
+  // deep layers) under the fp32 kernel's 1024-workgroup split rule, but with ONE wave of workgroups
+  // over the chip (~288) with as many 64-pixel chunks per workgroup as that leaves beats both the 1024-workgroup target of the fp32
+  // kernel (short reductions drown in their atomic epilogues: 142 -> 194 on pix8192 N256 K2304) and too few workgroups.
   int bmk = 128, bn = Cout > 64 ? 128 : (Cout > 32 ? 64 : 32);
   if (p.K <= 64 && bn >= 64) bmk = 64;
+  int w8 = 0;
   if (force_tile == 1) { bmk = 64; bn = 64; }
   else if (force_tile == 2) { bmk = 128; bn = 64; }
   else if (force_tile == 3) { bmk = 64; bn = 128; }
   else if (force_tile == 4) { bmk = 128; bn = 128; }
   else if (force_tile == 5) { bmk = 128; bn = 32; }
+  else if (force_tile == 6) { bmk = 128; bn = 64; w8 = 1; }
   const long long blocks = (long long)fsv_cdiv(p.K, bmk) * fsv_cdiv(Cout, bn) * nsamp;
   int nsplit = 1;
   const char* det = getenv("FSV_DETERMINISTIC");
   if (force_split > 0) nsplit = force_split;
   else if (!(det && det[0] == '1')) {
-    nsplit = (int)((1024 + blocks - 1) / blocks);
+    // (the 128x32 tile - 40 KB of LDS, four workgroups per CU - wants them all: 138 against 92 TFLOP/s on pix524288 N32 K288)
+    const long long target = bn == 32 ? 1024 : 288;
+    nsplit = (int)((target + blocks - 1) / blocks);
     const int maxs = p.pchunks / 4;                 // at least 4 chunks (256 pixels) per split
     if (nsplit > maxs) nsplit = maxs;
     if (nsplit < 1) nsplit = 1;
@@ -998,7 +1006,8 @@ int fsv_hconv_wgrad(const void* in, const void* dout, float* dwt,
   if (nsplit > 1 && !prezeroed)
     (void)hipMemsetAsync(dwt, 0, (size_t)((per_sample ? (long long)N * w_bstride : (long long)Kpad * ldw)) * sizeof(float), stream);
   const dim3 g(fsv_cdiv(p.K, bmk), fsv_cdiv(Cout, bn), nsamp * nsplit), block(256);
-  if (bmk == 128 && bn == 128) FSV_LAUNCH((fsv_hconv_wgrad_kernel<128, 128, 2, 2>), g, block, stream, p);
+  if (w8) FSV_LAUNCH((fsv_hconv_wgrad_kernel<128, 64, 4, 2>), g, dim3(512), stream, p);
+  else if (bmk == 128 && bn == 128) FSV_LAUNCH((fsv_hconv_wgrad_kernel<128, 128, 2, 2>), g, block, stream, p);
   else if (bmk == 128 && bn == 64) FSV_LAUNCH((fsv_hconv_wgrad_kernel<128, 64, 2, 2>), g, block, stream, p);
   else if (bmk == 64 && bn == 128) FSV_LAUNCH((fsv_hconv_wgrad_kernel<64, 128, 2, 2>), g, block, stream, p);
   else if (bmk == 64 && bn == 64) FSV_LAUNCH((fsv_hconv_wgrad_kernel<64, 64, 2, 2>), g, block, stream, p);

@@ -36,6 +36,11 @@ lib.register_sigs({
     "fsv_cast_half": [c_p, c_p, c_ll, c_i, c_p],
 })
 
+# tests: called as _launch_hook(kind, info) behind every launch ('conv': x, wh, kpad, nrows, cout, oh, ow, ty, tx, sy, sx, bias, res,
+# act, scale, per_sample, place, wscale, out; 'wgrad': x, dout, geom, per_sample, dwt) - tests/model_checks.verify_half_launches
+# recomputes each launch of a real iteration from the same operands with plain torch
+_launch_hook = None
+
 H_TILE_NAMES = {0: '128x128', 1: '128x64', 2: '128x32', 3: '128x128w8', 4: '64x64', 5: '256x128w8', 9: '64x128'}
 
 
@@ -156,10 +161,14 @@ def gather_gemm_h(x, wh, kpad, nrows, cout, oh, ow, ty, tx, sy, sx, bias=None, r
     dense = place is None
     flops = 2.0 * n * oh * ow * cout * cin * len(ty)
     keep = [x, wh, bias, res, out, wscale]
+    info = None
+    if _launch_hook is not None:
+        info = dict(x=x, wh=wh, kpad=kpad, nrows=nrows, cout=cout, oh=oh, ow=ow, ty=list(ty), tx=list(tx), sy=sy, sx=sx, bias=bias,
+                    res=res, act=act, scale=scale, per_sample=per_sample, place=place, wscale=wscale, out=out)
     grp = conv._active_group()
     if grp is not None and force_tile < 0 and force_split == 0:
         label = 'fsv_hconv_kernel'
-        grp.hconvs.append((d, label, flops, keep))
+        grp.hconvs.append((d, label, flops, keep, info))
         return out
     # split-K plans of a half output accumulate in an fp32 workspace
     ws = None
@@ -189,6 +198,8 @@ def gather_gemm_h(x, wh, kpad, nrows, cout, oh, ow, ty, tx, sy, sx, bias=None, r
         go()
     if part is not None and produced.value:
         stats['part'], stats['slots'] = part, conv.STATS_SLOTS
+    if info is not None:
+        _launch_hook('conv', info)
     return out
 
 
@@ -206,6 +217,10 @@ def issue_group(items):
             lib.call("fsv_hconv_gather", ctypes.cast(arr, c_p), n, None, lib.stream_ptr())
         with profile.scope('fsv_hconv_group_kernel' if len(chunk) > 1 else chunk[0][1], flops, replay=go):
             go()
+        if _launch_hook is not None:
+            for it in chunk:
+                if it[4] is not None:
+                    _launch_hook('conv', it[4])
 
 
 def conv_forward_h(x, wh, kpad, nrows, cout, geom, **kw):
@@ -269,4 +284,6 @@ def conv_wgrad_h(x, dout, geom, per_sample=False, force_split=0, arena=None, for
     with profile.scope(label, 2.0 * n * oh * ow * cout * cin * geom.ntaps,
                        replay=lambda args=args, keep=keep: lib.call("fsv_hconv_wgrad", *args)):
         lib.call("fsv_hconv_wgrad", *args)
+    if _launch_hook is not None:
+        _launch_hook('wgrad', dict(x=x, dout=dout, geom=geom, per_sample=per_sample, dwt=dwt, kpad=kpad, ldw=ldw))
     return dwt

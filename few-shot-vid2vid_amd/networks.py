@@ -562,10 +562,10 @@ class FewShotGenerator(nn.Module):
             key = self.attention_encode(label_ref, 'atn_key')            # [b*n, c, h, w]
             query = self.attention_encode(label, 'atn_query')            # [b, c, h, w]
             kmat = key.reshape(b, n, c, hw).permute(0, 1, 3, 2).reshape(b, n * hw, c, 1, 1)
-            energy_t = ops.batch_conv(query, kmat)                        # [b, n*hw, h, w]
+            energy_t = ops.batch_conv(query, kmat, allow_half=False)                        # [b, n*hw, h, w]
             attention = ops.softmax_channels(energy_t)
         xmat = x.reshape(b, n, c, hw).permute(0, 2, 1, 3).reshape(b, c, n * hw, 1, 1)
-        out = ops.batch_conv(attention, xmat)                             # [b, c, h, w]
+        out = ops.batch_conv(attention, xmat, allow_half=False)                             # [b, c, h, w]
         atn_vis = attention.reshape(b, n, hw, h, w).sum(2)[-1:, 0:1]
         return out, attention, atn_vis
 
@@ -596,7 +596,7 @@ class FewShotGenerator(nn.Module):
             # kernel: pixels = image channels i, input channels = positions p, generated weights = softmax rows j
             a_rows = a.reshape(b, c, 1, h * w).permute(0, 3, 1, 2)              # logical [b, hw, c, 1]
             wts = sm.reshape(b, c, h * w, 1, 1)
-            prod = ops.batch_conv(a_rows, wts)                                    # logical [b, c(j), c(i), 1]
+            prod = ops.batch_conv(a_rows, wts, allow_half=False)                                    # logical [b, c(j), c(i), 1]
             enc.append(prod.permute(0, 2, 1, 3))                                  # [b, c(i), c(j), 1]
         return x, enc[::-1]
 

@@ -342,7 +342,7 @@ class _ConvFn(torch.autograd.Function):
     """y = act((conv(x, W * inv_sigma) + bias) * scale) + res.  W: OIHW, or [B]OIHW for per-sample weights."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, res, sig, u, v, geom, act, scale, uv_owned=False, stats_groups=0):
+    def forward(ctx, x, weight, bias, res, sig, u, v, geom, act, scale, uv_owned=False, stats_groups=0, allow_half=True):
         weight._fsv_conv_param = True          # FlatAdam: these parameters take their gradients through the sink
         if bias is not None:
             bias._fsv_conv_param = True
@@ -364,7 +364,7 @@ class _ConvFn(torch.autograd.Function):
         # conversion done while packing): the weight says how many channels are real
         cin_w = w4.shape[-3]
         prepadded = (not per_sample) and cin > cin_w
-        half = (_conv.h_kernels() and cout % 8 == 0 and (per_sample and cin % 8 == 0 or not per_sample) and
+        half = (allow_half and _conv.h_kernels() and cout % 8 == 0 and (per_sample and cin % 8 == 0 or not per_sample) and
                 x.dtype in (torch.float32, torch.float16))
         if prepadded:
             cpad, cin = cin - cin_w, cin_w
@@ -391,8 +391,10 @@ class _ConvFn(torch.autograd.Function):
         else:
             if cpad:
                 w4 = torch.nn.functional.pad(w4, (0, 0, 0, 0, 0, cpad))
-            wt, _, ldw = prep_weight(w4, 0, geom, scale=inv)
-            wscale = None
+            # (half path: W itself is rounded and 1 / sigma applied to the fp32 accumulator, like the cached layouts - the
+            # arithmetic must not depend on whether an optimiser's layout cache owns the weight)
+            wt, _, ldw = prep_weight(w4, 0, geom, scale=None if half else inv)
+            wscale = inv if half else None
         b = bias.detach() if bias is not None else None
         if b is not None and not (per_sample and b.dim() == 2 and b.stride(1) == 1):
             b = b.contiguous()       # (per-sample bias rows are read in place by gather_gemm)
@@ -498,7 +500,7 @@ class _ConvFn(torch.autograd.Function):
                 dx = dx[:, :cin]
         if ctx.has_res and ctx.needs_input_grad[3]:
             dres = dy
-        return dx, dw, db, dres, None, None, None, None, None, None, None, None
+        return dx, dw, db, dres, None, None, None, None, None, None, None, None, None
 
 
 def _unpack_sn(sn):
@@ -534,7 +536,8 @@ def linear(x2d, weight, bias=None, act=ACT_NONE, sn=None):
     r, cin = x2d.shape
     x4 = x2d.contiguous().view(1, 1, r, cin).permute(0, 3, 1, 2)
     sig, u, v, owned = _unpack_sn(sn)
-    y4 = _ConvFn.apply(x4, weight, bias, None, sig, u, v, Geom(1, 1, 1, 0), act, 1.0, owned)
+    # (nn.Linear = the weight generators: fp32 also under `--amp`, like the grouped bank below - see mlp_bank)
+    y4 = _ConvFn.apply(x4, weight, bias, None, sig, u, v, Geom(1, 1, 1, 0), act, 1.0, owned, 0, False)
     return y4.permute(0, 2, 3, 1).reshape(r, weight.shape[0])
 
 
@@ -729,16 +732,17 @@ def mlp_bank(rows, chains):
     return list(_MlpBankFn.apply(meta, *flat))
 
 
-def batch_conv(x, weight, bias=None, act=ACT_NONE, stride=1):
+def batch_conv(x, weight, bias=None, act=ACT_NONE, stride=1, allow_half=True):
     """Per-sample 1x1 (or kxk) convolution with generated weights [B, Cout, Cin, k, k] (base_network.py:56-71);
-    stride 1 or 2 (padding k // 2, as the reference)."""
+    stride 1 or 2 (padding k // 2, as the reference).  allow_half=False: a call site that only borrows the kernel for a
+    batched matrix product (torch.bmm in the reference: softmax pooling, attention) and stays fp32 under `--amp`."""
     if weight is None:
         return x
     k = weight.shape[-1]
     geom = Geom(k, k, int(stride), k // 2)
     # weights / biases are usually strided views into the weight-generating FC's output: conv.prep_weight / gather_gemm
     # read them in place (sample stride), no copies here
-    return _ConvFn.apply(x, weight, bias, None, None, None, None, geom, act, 1.0, False)
+    return _ConvFn.apply(x, weight, bias, None, None, None, None, geom, act, 1.0, False, 0, allow_half)
 
 
 # ------------------------------------------------------------------------------------------------ normalisation

@@ -120,8 +120,8 @@ def summary():
         n, fl, t = agg[lab]
         ach = fl / t / 1e12
         peak = FP32_MFMA_PEAK / 1e12
-        if '[f16]' in lab:
-            peak = F16_MFMA_PEAK / 1e12                 # narrow-operand kernels (csrc/conv_np.hip) against the 16-bit dense peak
+        if '[f16]' in lab or lab.startswith('fsv_hconv'):
+            peak = F16_MFMA_PEAK / 1e12                 # half-precision / narrow-operand kernels against the dense 16-bit matrix peak
         elif '[bf16x3]' in lab:
             peak = F16_MFMA_PEAK / 3e12                 # three MFMAs per algorithmic product
         bracketed = t / n

@@ -20,11 +20,12 @@ import torch.nn.functional as F
 
 def planes(x, mode):
     """the fp32 values of the operand planes the kernel stages for tensor x"""
+    # (back in the tensor's own dtype: the fp64 runs of the whole-iteration oracle keep exact products and fp64 sums)
     if mode == 1:
-        return [x.to(torch.float16).to(torch.float32)]
+        return [x.to(torch.float16).to(x.dtype)]
     if mode == 2:
-        hi = x.to(torch.bfloat16).to(torch.float32)
-        lo = (x - hi).to(torch.bfloat16).to(torch.float32)
+        hi = x.to(torch.bfloat16).to(x.dtype)
+        lo = (x - hi).to(torch.bfloat16).to(x.dtype)
         return [hi, lo]
     return [x]
 
@@ -38,9 +39,10 @@ def _pairs(a, b):
 
 class _Conv2dNp(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, w, stride, padding, mode):
+    def forward(ctx, x, w, stride, padding, mode, dx_half=False):
         ctx.save_for_backward(x, w)
         ctx.cfg = (stride, padding, mode)
+        ctx.dx_half = dx_half
         y = 0
         for xa, wb in _pairs(planes(x, mode), planes(w, mode)):
             y = y + F.conv2d(xa, wb, None, stride=stride, padding=padding)
@@ -55,16 +57,30 @@ class _Conv2dNp(torch.autograd.Function):
             dx = dx + torch.nn.grad.conv2d_input(x.shape, wb, ga, stride=stride, padding=padding)
         for xa, gb in _pairs(planes(x, mode), planes(dy, mode)):
             dw = dw + torch.nn.grad.conv2d_weight(xa, w.shape, gb, stride=stride, padding=padding)
-        return dx, dw, None, None, None
+        if ctx.dx_half:            # the gradient of an input that lives in HBM as half is stored as half
+            dx = dx.to(torch.float16).to(dx.dtype)
+        return dx, dw, None, None, None, None
 
 
-def conv2d(x, w, bias=None, stride=1, padding=0, mode=1):
+def conv2d(x, w, bias=None, stride=1, padding=0, mode=1, dx_half=False):
     """convolution whose three GEMMs (forward, data gradient, weight gradient) use narrowed operands; the bias and its
     gradient are fp32 (they are applied in the kernel epilogue / reduced by a separate fp32 kernel)"""
-    y = _Conv2dNp.apply(x, w, stride, padding, mode)
+    y = _Conv2dNp.apply(x, w, stride, padding, mode, dx_half)
     if bias is not None:
         y = y + bias.view(1, -1, 1, 1)
     return y
+
+
+def amp_conv2d(x, w, b, stride, padding, dx_half=False, per_sample=False):
+    """The convolution arithmetic of the product's `--amp O1` path on the half-precision kernels (csrc/conv_h.hip; installed into
+    oracle/fsv_oracle.py with `fsv_oracle.arithmetic(amp_conv2d)`): layers whose GEMMs fit those kernels - output channels a
+    multiple of 8 (per-sample generated weights: input channels too) - run with operands rounded to IEEE half, exact products
+    and fp32 sums (mode 1 above; the output stays fp32, the bias is added in fp32), every other convolution exactly.
+    *Parity unpinned* against apex (not vendored, no CUDA): this is the definition the product is held to."""
+    cout, cin = w.shape[0], w.shape[1]
+    if cout % 8 != 0 or (per_sample and cin % 8 != 0):
+        return F.conv2d(x, w, b, stride=stride, padding=padding)
+    return conv2d(x, w, b, stride, padding, mode=1, dx_half=dx_half)
 
 
 class LossScaler:

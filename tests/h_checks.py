@@ -31,7 +31,7 @@ BIG_GEOMS = [(2, 64, 64, 64, 128, 3, 1, 1), (2, 128, 32, 32, 256, 3, 2, 1), (1, 
              (1, 32, 96, 128, 32, 3, 1, 1)]
 FWD_TILES = [(-1, 0), (0, 1), (0, 3), (1, 1), (2, 1), (3, 1), (3, 2), (4, 2), (5, 1), (5, 3), (9, 1), (16, 1), (16, 2), (17, 1), (18, 1), (19, 1),
              (20, 3), (21, 2), (25, 1)]
-WGRAD_TILES = [(0, 0), (1, 1), (1, 3), (2, 2), (3, 1), (4, 1), (4, 2), (5, 1)]
+WGRAD_TILES = [(0, 0), (1, 1), (1, 3), (2, 2), (3, 1), (4, 1), (4, 2), (5, 1), (6, 1), (6, 2)]
 
 
 def _mods():

@@ -305,6 +305,177 @@ def check_train_step(device, opt, b=2, tol=1e-3, seed=21, grad_tol=2e-2, with_fl
     return worst
 
 
+class verify_half_launches:
+    """`with verify_half_launches() as v:` - every launch of the half-precision kernels (few-shot-vid2vid_amd/hconv.py: forward /
+    data-gradient gather-GEMMs, single and grouped, and weight gradients) issued inside the block is recomputed from the SAME
+    operand tensors with plain torch (fp32 matmuls of the half values: exact products, fp32 sums) and compared element by
+    element.  Where the whole-iteration comparison has to allow for the definition's rounding-boundary noise, this one does
+    not: identical inputs, so kernel and recomputation differ by the fp32 summation order only (`tol` relative to the launch's
+    largest output; a half output in addition by one half ulp).  v.count = launches verified."""
+
+    def __init__(self, tol=3e-5, every=1):
+        self.tol, self.every, self.count, self.seen, self.worst = tol, every, {'conv': 0, 'wgrad': 0}, 0, 0.0
+
+    def __enter__(self):
+        from importlib import import_module
+        self.hc = import_module('few-shot-vid2vid_amd.hconv')
+        self.prev = self.hc._launch_hook
+        self.hc._launch_hook = self._hook
+        return self
+
+    def __exit__(self, *exc):
+        self.hc._launch_hook = self.prev
+        return False
+
+    @staticmethod
+    def _gather(x, ty, tx, sy, sx, oh, ow):
+        """x [n, c, h, w] -> [n, oh, ow, taps, c] (zeros outside the image)"""
+        n, c, h, w = x.shape
+        lo_y, hi_y = min(ty), max(ty) + (oh - 1) * sy
+        lo_x, hi_x = min(tx), max(tx) + (ow - 1) * sx
+        pt, pb = max(0, -lo_y), max(0, hi_y - (h - 1))
+        pl, pr = max(0, -lo_x), max(0, hi_x - (w - 1))
+        xp = torch.nn.functional.pad(x, (pl, pr, pt, pb))
+        cols = []
+        for a, b_ in zip(ty, tx):
+            cols.append(xp[:, :, pt + a: pt + a + (oh - 1) * sy + 1: sy, pl + b_: pl + b_ + (ow - 1) * sx + 1: sx])
+        return torch.stack(cols, dim=1).permute(0, 3, 4, 1, 2)          # [n, oh, ow, taps, c]
+
+    def _hook(self, kind, i):
+        self.seen += 1
+        if self.seen % self.every:
+            return
+        with torch.no_grad():
+            if kind == 'conv':
+                x = i['x'].float()
+                n, cin = x.shape[0], x.shape[1]
+                taps = len(i['ty'])
+                k = taps * cin
+                a = self._gather(x, i['ty'], i['tx'], i['sy'], i['sx'], i['oh'], i['ow']).reshape(n, i['oh'] * i['ow'], k)
+                wh = i['wh'].float()[:, :i['cout'], :k]                                  # [nb, cout, k]
+                y = torch.matmul(a, wh.transpose(1, 2) if i['per_sample'] else wh[0].t())       # [n, px, cout]
+                if i['wscale'] is not None:
+                    y = y * i['wscale'].float()
+                if i['bias'] is not None:
+                    y = y + (i['bias'].float().view(n, 1, -1) if i['per_sample'] else i['bias'].float().view(1, 1, -1))
+                y = y * i['scale']
+                y = y.view(n, i['oh'], i['ow'], i['cout']).permute(0, 3, 1, 2)
+                out = i['out'].float()
+                if i['place'] is not None:
+                    _, _, osy, osx, ooy, oox = i['place']
+                    out = out[:, :, ooy::osy, oox::osx][:, :, :i['oh'], :i['ow']]
+                res = i['res']
+                if i['act'] == 6:
+                    y = torch.where(res.float() > 0, y, 0.2 * y)
+                else:
+                    if i['act'] == 1:
+                        y = torch.nn.functional.leaky_relu(y, 0.2)
+                    elif i['act'] == 2:
+                        y = torch.tanh(y)
+                    elif i['act'] == 3:
+                        y = torch.sigmoid(y)
+                    elif i['act'] == 4:
+                        y = torch.relu(y)
+                    elif i['act'] == 5:
+                        y = torch.nn.functional.leaky_relu(y, 0.1)
+                    if res is not None:
+                        y = y + res.float()
+                half_out = i['out'].dtype == torch.float16
+            else:
+                x, dy, g = i['x'].float(), i['dout'].float(), i['geom']
+                n, cin = x.shape[0], x.shape[1]
+                cout, oh, ow = dy.shape[1], dy.shape[2], dy.shape[3]
+                a = self._gather(x, g.ty, g.tx, g.stride, g.stride, oh, ow).reshape(n, oh * ow, g.ntaps * cin)
+                d = dy.permute(0, 2, 3, 1).reshape(n, oh * ow, cout)
+                y = torch.matmul(a.transpose(1, 2), d)                                     # [n, k, cout]
+                if not i['per_sample']:
+                    y = y.sum(dim=0, keepdim=True)
+                out = i['dwt'].view(-1, i['kpad'], i['ldw'])[:, :g.ntaps * cin, :cout]
+                half_out = False
+            scale = max(float(y.abs().max()), 1e-20)
+            err = (out - y).abs()
+            lim = self.tol * scale + (2.0 ** -10 * 1.01 * y.abs() if half_out else 0.0)
+            bad = err > lim
+            assert not bool(bad.any()), ('half %s launch differs from its recomputation: max|diff| %.3e at scale %.3e (%d elements), x %s'
+                                         % (kind, float(err.max()), scale, int(bad.sum()), tuple(i['x'].shape)))
+            self.worst = max(self.worst, float((err / scale).max()))
+        self.count[kind] += 1
+
+
+def check_amp_train_step(device, opt, b=1, tol=1e-3, grad_tol=1e-2, seed=21, loss_scale=1024.0):
+    """Full D step + G step of the product under `--amp O1` (the half-precision kernels, csrc/conv_h.hip) against a WHOLE-ITERATION run
+    of the oracle in the same arithmetic: oracle/fsv_oracle.py with oracle/np_oracle.amp_conv2d installed at every convolution
+    the product runs in half (operands rounded to IEEE half, exact products; W rounded before 1 / sigma; the gradient of a
+    half-stored input rounded to half) and the same loss scale through both backward passes.
+
+    *Parity unpinned against apex*: the reference reaches fp16 through NVIDIA apex (models/models.py:22-26), which is neither
+    vendored nor installable here and has no CPU path - no reference output exists for this mode.  What this test pins is that
+    the product's iteration IS the stated definition.
+
+    Tolerances are those of the fp32 full-step test (check_train_step): losses / image `tol` relative, per-parameter gradients
+    `grad_tol` relative L2, each plus a multiple of the definition's own noise floor - the distance between the oracle summing
+    the (exact) products in fp32 and in fp64.  That floor is larger here than in fp32: a 1e-7 difference in an activation that
+    sits on a half rounding boundary moves the operand the next layer sees by a whole half ulp (5e-4 of its value)."""
+    M = _model()
+    from importlib import import_module
+    conv = import_module('few-shot-vid2vid_amd.conv')
+    from oracle import np_oracle as NO
+    assert M.amp_mode(opt) == conv.MFMA_F16, "pass an option namespace with amp='O1'"
+    try:
+        model = M.create_model(opt)
+        sdG0, sdD0 = fill_state(model.netG), fill_state(model.netD)
+        model = model.to(device).train()
+        opt_G, opt_D = model.build_optimizers()
+        assert conv.h_kernels(), "the half-precision kernels are switched off"
+        opt_G.set_lr(0.0); opt_D.set_lr(0.0)
+        for o in (opt_G, opt_D):
+            o.scaler[0] = float(loss_scale)
+        h, w = int(opt.fineSize / opt.aspect_ratio), opt.fineSize
+        nl = opt.label_nc if opt.label_nc != 0 else opt.input_nc
+        data = synth_street_inputs(b, h, w, seed, opt.label_nc) if opt.label_nc != 0 else synth_pose_inputs(b, h, w, seed, nl)
+        cfg = O.cfg_from_opt(opt)
+        with O.arithmetic(NO.amp_conv2d):
+            r32 = O.iteration(sdG0, sdD0, cfg, data, torch.float32, None, None, [None, None], [None, None], None,
+                              loss_scale=float(loss_scale))
+            r64 = O.iteration(sdG0, sdD0, cfg, data, torch.float64, None, None, [None, None], [None, None], None,
+                              loss_scale=float(loss_scale))
+        tl, ti, rl, ri = [t.to(device) for t in data]
+        data_list = [tl, ti, [None, None], [None, None], rl, ri, None, None, None]
+        verifier = verify_half_launches()
+        verifier.__enter__()
+        d_losses = M.loss_backward(opt, model(data_list, mode='discriminator'), opt_D, 1)
+        assert float(opt_D.scaler[0]) == loss_scale and float(opt_D.scaler[2]) == 0.0, opt_D.scaler      # no overflow at this scale
+        for i, name in enumerate(('D_real', 'D_fake')):
+            _close_vs64(name, d_losses[i].view(1), r32[0][i].view(1), r64[0][i].view(1), tol)
+        for p in model.netD.parameters():
+            if p.grad is not None:
+                p.grad.div_(loss_scale)           # lr = 0: the step has run, the flat gradient buffer is only read below
+        worst_d = compare_grads_l2(model.netD, {k: _G(v) for k, v in r32[1].items()}, {k: _G(v) for k, v in r64[1].items()}, grad_tol)
+        g_losses, generated, _ = model(data_list, save_images=True, mode='generator')
+        g_losses = M.loss_backward(opt, g_losses, opt_G, 0)
+        verifier.__exit__(None, None, None)
+        assert verifier.count['conv'] >= 40 and verifier.count['wgrad'] >= 15, verifier.count       # the half kernels did run
+        assert float(opt_G.scaler[0]) == loss_scale and float(opt_G.scaler[2]) == 0.0, opt_G.scaler
+        names = M.LOSS_NAMES_G
+        for k in r32[2]:
+            _close_vs64(k, g_losses[names.index(k)].view(1), r32[2][k].view(1), r64[2][k].view(1), tol)
+        for p in model.netG.parameters():
+            if p.grad is not None:
+                p.grad.div_(loss_scale)
+        sd32 = {k: _G(v) for k, v in r32[3].items()}
+        sd64 = {k: _G(v) for k, v in r64[3].items()}
+        for name, _ in model.netG.named_parameters():
+            sd32.setdefault(name, _G(None)); sd64.setdefault(name, _G(None))
+        worst = compare_grads_l2(model.netG, sd32, sd64, grad_tol)
+        img = _close_vs64('fake image', generated[0][:, 0], r32[4]['fake'], r64[4]['fake'], tol)
+        noise = float((r32[4]['fake'].detach().double() - r64[4]['fake'].detach().double()).abs().max())
+    finally:
+        conv.set_mfma_mode(0)
+    print('amp step vs the definition: image %.2e (definition noise %.2e), worst gradient rel L2 G %.2e D %.2e; %d + %d half launches '
+          'recomputed from their own operands, worst %.1e' % (img, noise, worst, worst_d, verifier.count['conv'], verifier.count['wgrad'], verifier.worst))
+    return worst
+
+
 class _G:
     """tiny adaptor so compare_grads can read `.grad` from a plain tensor dict"""
 

@@ -88,10 +88,10 @@ for name, n, cin, h, w, cout, k in shapes:
     if 'wgrad' in WHAT and hc.wgrad_eligible(cin, cout, oh, ow):
         dy = conv.to_nhwc(torch.randn(n, cout, oh, ow, device=dev)); dyh = hc.to_half_nhwc(dy)
         graphs = {'f32 auto': graph_of(lambda: conv.conv_wgrad(x, dy, g, (cout, cin, k, k), raw=True))}
-        for t in (0, 1, 2, 3, 4, 5):
-            bn = {0: 0, 1: 64, 2: 64, 3: 128, 4: 128, 5: 32}[t]
+        for t in (0, 1, 2, 3, 4, 5, 6):
+            bn = {0: 0, 1: 64, 2: 64, 3: 128, 4: 128, 5: 32, 6: 64}[t]
             if (bn == 128 and cout < 128) or (bn == 64 and cout < 64) or (bn == 32 and cout > 32):
                 continue
-            for sp in (0, 4, 16):
+            for sp in ((0,) if t == 0 else (0, 4, 16)):
                 graphs['t%d/s%d' % (t, sp)] = graph_of(lambda: hc.conv_wgrad_h(xh, dyh, g, force_tile=t, force_split=sp))
         print(json.dumps({'case': name, 'kind': 'wgrad', **measure(graphs, flops)}), flush=True)
