@@ -43,6 +43,11 @@ struct SpadeP {
   float* dxhat;
   int h_half;             // forward: h is written as IEEE half (the `--amp` path: its only consumers are convolutions that read half);
                           // backward twin: bit 0 - dh arrives as half, bit 1 - d(gamma|beta) is written as half
+  // backward twin, optional: per-channel sums of d(gamma|beta) = the bias gradients, added (fp64 atomics) into the ZEROED buffer
+  // dbsum + z * db_zstride[k] + k * 2C  ([gamma sums (C) | beta sums (C)] per map; db_zstride 0: summed over the batch) - the
+  // column-sum pass over the [P][2C] tensors disappears
+  double* dbsum;
+  long long db_zstride[FSV_SP_MAXMAPS];
   int W, up;              // up = 1: x is the HALF-resolution tensor [N][H/2][W/2][C] and is read through the nearest-x2
                           // up-sampling index (generator.py:124 folded into this kernel: the up-sampled tensor is never written)
 };
@@ -70,7 +75,13 @@ __device__ __forceinline__ long long fsv_sp_xpix(const SpadeP& p, int z, int m) 
 // MFMAs (one barrier per chunk).  A image [BM rows][8 quads], quad q of row r in slot q ^ ((r >> 1) & 7): ds_write_b128 /
 // ds_read_b128 (two reads feed the four k steps of a k-group), B images [32 k][BN] as they lie in HBM.  The modulation of a
 // map (registers only) runs when its last chunk has been multiplied.
-template <int BM, int BN, int WM, int WN, int NS, bool BWD>
+// F16 (the `--amp` path): the gamma / beta GEMMs on v_mfma_f32_32x32x16_f16 - the label maps arrive as IEEE half ([N][HW][Ch] halves),
+// the weights as the N-major half operand of fsv_spade_prep_h (wcat_h [2C][Kh], K contiguous: p.wg / p.wb point into it, Kh =
+// ceil32(Ch) halves per row; p.ldw unused), both tiles are [rows][32 k] halves (64-byte rows, the four 16-byte slots XOR-swizzled by (row >> 2) & 3: conflict-free
+// ds_read_b128 fragments, csrc/conv_np.hip) staged through registers as 16-byte vectors; accumulation, normalisation, modulation and
+// the backward chain stay fp32.  At the deep levels (512 ... 2048 pixels, Ch up to 1024) the fp32 form is MFMA-latency bound - 128
+// workgroups, 32 chunks of 32 fp32 MFMAs each: 61 us for 4 GFLOP - which this removes.
+template <int BM, int BN, int WM, int WN, int NS, bool BWD, bool F16 = false>
 __global__ __launch_bounds__(256, 2) void fsv_spade_mod_kernel(SpadeP p) {
   constexpr int BK = FSV_SP_BK;
   constexpr int TM = BM / (WM * 32), TN = BN / (WN * 32);
@@ -81,10 +92,17 @@ __global__ __launch_bounds__(256, 2) void fsv_spade_mod_kernel(SpadeP p) {
   static_assert(WM * WN == 4, "4 waves");
   static_assert(NPA >= 1 && NPB >= 1 && NPA * RPA == BM && NPB * RPB == BK, "tile");
   static_assert(!BWD || NS == 1, "the backward twin handles one site");
-  __shared__ __attribute__((aligned(16))) float smem[2 * (A_ST + NB * B_ST)];
+  static_assert(!F16 || NS == 1, "the half form handles one site");
+  __shared__ __attribute__((aligned(16))) float smem[(F16 ? 1 : 2) * (A_ST + NB * B_ST)];
   float* const As = smem;
   float* const Bs = smem + 2 * A_ST;
+  typedef _Float16 h16;
+  typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
+  h16* const Ah = reinterpret_cast<h16*>(smem);                  // F16: [2 buffers][BM][32] halves, then [2][NB][BN][32]
+  h16* const Bh = Ah + 2 * A_ST;
+  constexpr int HNPA = (BM + 63) / 64, HNPB = (BN + 63) / 64;    // 16-byte vectors per work-item: 4 per 64-byte row, 64 rows per pass
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int hr0 = tid >> 2, hs = tid & 3;
   const int wm = wave / WN, wn = wave % WN;
   const int z = blockIdx.z;
   const int bm0 = blockIdx.x * BM, bn0 = blockIdx.y * BN;
@@ -152,6 +170,53 @@ __global__ __launch_bounds__(256, 2) void fsv_spade_mod_kernel(SpadeP p) {
   // loader state: (map lk_, chunk lc_) of the NEXT chunk to load
   int ld_k = 0, ld_c = 0;
   float4 areg[NPA], breg[NB][NPB];
+  float4 hareg[HNPA], hbreg[NB][HNPB];
+  auto issue_loads_h = [&]() {
+    const int k = ld_k < p.nmaps ? ld_k : 0;
+    const int Ch = p.ch[k];
+    const fsv_buf abuf = fsv_make_buf(reinterpret_cast<const h16*>(p.map[k]) + pix0 * Ch, (long long)p.HW * Ch * 2);
+    const int kk = ld_c * BK + hs * 8;
+    const bool live = ld_k < p.nmaps;
+#pragma unroll
+    for (int i = 0; i < HNPA; ++i) {
+      const int r = hr0 + i * 64;
+      const int m = bm0 + r;
+      const bool ok = live & (kk < Ch) & (m < p.HW) & (r < BM);
+      hareg[i] = fsv_buf_load4(abuf, ok ? (unsigned)((m * Ch + kk) * 2) : FSV_BUF_OOB);
+    }
+    const int ldk = (Ch + 31) & ~31;                              // row length Kh of this map's operand
+    const long long wbytes = (long long)p.C * ldk * 2;            // one half (gamma or beta) of the operand: C rows of Kh halves
+#pragma unroll
+    for (int q = 0; q < NB; ++q) {
+      const h16* w = reinterpret_cast<const h16*>(q ? p.wb[0][k] : p.wg[0][k]) + z * p.w_bstride[0][k];
+      const fsv_buf wbuf = fsv_make_buf(w, wbytes);
+#pragma unroll
+      for (int i = 0; i < HNPB; ++i) {
+        const int r = hr0 + i * 64;
+        const int c = bn0 + r;
+        const bool ok = live & (c < p.C) & (r < BN);
+        hbreg[q][i] = fsv_buf_load4(wbuf, ok ? (unsigned)((c * ldk + kk) * 2) : FSV_BUF_OOB);
+      }
+    }
+    ++ld_c;
+    if (ld_k < p.nmaps && ld_c >= nch[ld_k]) { ld_c = 0; ++ld_k; }
+  };
+  auto store_chunk_h = [&](int buf) {
+    h16* a_dst = Ah + buf * A_ST;
+    h16* b_dst = Bh + buf * (NB * B_ST);
+#pragma unroll
+    for (int i = 0; i < HNPA; ++i) {
+      const int r = hr0 + i * 64;
+      if (r < BM) *reinterpret_cast<float4*>(&a_dst[r * BK + (((hs ^ (r >> 2)) & 3) << 3)]) = hareg[i];
+    }
+#pragma unroll
+    for (int q = 0; q < NB; ++q)
+#pragma unroll
+      for (int i = 0; i < HNPB; ++i) {
+        const int r = hr0 + i * 64;
+        if (r < BN) *reinterpret_cast<float4*>(&b_dst[q * B_ST + r * BK + (((hs ^ (r >> 2)) & 3) << 3)]) = hbreg[q][i];
+      }
+  };
   auto issue_loads = [&]() {
     // uniform: descriptors of the loader's current map
     const int k = ld_k < p.nmaps ? ld_k : 0;
@@ -292,13 +357,46 @@ __global__ __launch_bounds__(256, 2) void fsv_spade_mod_kernel(SpadeP p) {
         for (int r = 0; r < 16; ++r) outv[0][i][j][r] = (xv[i][j][r] - mu[j]) * rs[j];
   }
   if (total > 0) {
-    issue_loads();
-    store_chunk(0);
+    if constexpr (F16) { issue_loads_h(); store_chunk_h(0); } else { issue_loads(); store_chunk(0); }
     __syncthreads();
     int buf = 0;
     // one chunk: loads of the NEXT chunk of the flat sequence (whatever map it belongs to) at the top, MFMAs of this one,
     // the loaded registers stored into the other LDS buffer behind three quarters of them
     auto chunk = [&]() {
+      if constexpr (F16) {
+        issue_loads_h();
+        const h16* a_src = Ah + buf * A_ST;
+        const h16* b_src = Bh + buf * (NB * B_ST);
+        h16x8 fa[2][TM], fb[2][NB][TN];
+#pragma unroll
+        for (int st = 0; st < 2; ++st) {
+#pragma unroll
+          for (int i = 0; i < TM; ++i) {
+            const int r = wm * (TM * 32) + i * 32 + lrow;
+            fa[st][i] = *reinterpret_cast<const h16x8*>(&a_src[r * BK + ((((2 * st + lk) ^ (r >> 2)) & 3) << 3)]);
+          }
+#pragma unroll
+          for (int q = 0; q < NB; ++q)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+              const int r = wn * (TN * 32) + j * 32 + lrow;
+              fb[st][q][j] = *reinterpret_cast<const h16x8*>(&b_src[q * B_ST + r * BK + ((((2 * st + lk) ^ (r >> 2)) & 3) << 3)]);
+            }
+        }
+#pragma unroll
+        for (int st = 0; st < 2; ++st)
+#pragma unroll
+          for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int q = 0; q < NB; ++q)
+#pragma unroll
+              for (int j = 0; j < TN; ++j)
+                acc[q][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[st][i], fb[st][q][j], acc[q][i][j], 0, 0, 0);
+        store_chunk_h(buf ^ 1);
+        __syncthreads();
+        buf ^= 1;
+        return;
+      }
       issue_loads();                      // past the end: every lane is out of range -> zeros, never used
       const float* a_src = As + buf * A_ST;
       const float* b_src = Bs + buf * (NB * B_ST);
@@ -369,14 +467,17 @@ __global__ __launch_bounds__(256, 2) void fsv_spade_mod_kernel(SpadeP p) {
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
       const int c = bn0 + wn * (TN * 32) + j * 32 + lrow;
-      if (c >= p.C) continue;
+      const bool cok = c < p.C;
+      float sg[FSV_SP_MAXMAPS], sb[FSV_SP_MAXMAPS];
+#pragma unroll
+      for (int k = 0; k < FSV_SP_MAXMAPS; ++k) { sg[k] = 0.f; sb[k] = 0.f; }
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int row = (r & 3) + 8 * (r >> 2) + 4 * lk;
           const int m = bm0 + wm * (TM * 32) + i * 32 + row;
-          if (m >= p.HW) continue;
+          if (m >= p.HW || !cok) continue;
           const int e = m * p.C + c;
           float d = (p.h_half & 1) ? (float)reinterpret_cast<const _Float16*>(p.dh)[pix0 * p.C + e] : dh_z[e];
           if (p.act[0] == FSV_ACT_LRELU) d = (outv[0][i][j][r] > 0.f) ? d : 0.2f * d;
@@ -385,19 +486,34 @@ __global__ __launch_bounds__(256, 2) void fsv_spade_mod_kernel(SpadeP p) {
             if (k < p.nmaps) {
               float* dg = dg_z[k];
               const int e2 = m * 2 * p.C + c;
+              const float dgam = d * keep_o[k][i][j][r];
               if (p.h_half & 2) {
                 _Float16* dgh = reinterpret_cast<_Float16*>(p.dgb[k]) + pix0 * 2 * p.C;
                 dgh[e2 + p.C] = (_Float16)d;
-                dgh[e2] = (_Float16)(d * keep_o[k][i][j][r]);
+                dgh[e2] = (_Float16)dgam;
               } else {
                 dg[e2 + p.C] = d;
-                dg[e2] = d * keep_o[k][i][j][r];
+                dg[e2] = dgam;
               }
+              sb[k] += d; sg[k] += dgam;
               d = d * (1.f + keep_g[k][i][j][r]);
             }
           }
           dx_z[e] = d;
         }
+      if (p.dbsum) {               // uniform: bias gradients from here (the two half-waves hold the same 32 channels)
+#pragma unroll
+        for (int k = 0; k < FSV_SP_MAXMAPS; ++k) {
+          if (k < p.nmaps) {
+            const float g2 = sg[k] + __shfl_xor(sg[k], 32), b2 = sb[k] + __shfl_xor(sb[k], 32);
+            if (lk == 0 && cok) {
+              double* dst = p.dbsum + z * p.db_zstride[k] + (long long)k * 2 * p.C;
+              atomicAdd(dst + c, (double)g2);
+              atomicAdd(dst + p.C + c, (double)b2);
+            }
+          }
+        }
+      }
     }
     return;
   }
@@ -569,6 +685,8 @@ static inline int fsv_sp_fill_common(SpadeP& p, const float* x, const float* mea
   p.W = up ? W : 1; p.up = up ? 1 : 0;
   p.dh = nullptr; p.dxhat = nullptr;
   p.h_half = 0;
+  p.dbsum = nullptr;
+  for (int k = 0; k < FSV_SP_MAXMAPS; ++k) p.db_zstride[k] = 0;
   return FSV_OK;
 }
 
@@ -577,20 +695,27 @@ static int fsv_spade_mod_fwd_impl(const float* x, const float* mean, const float
                       int nmaps, const float* const* maps, const float* const* wg, const float* const* wb,
                       const float* const* bg, const float* const* bb, const int* ch, const long long* w_bstride,
                       const long long* b_bstride, int N, int HW, int C, int ldw, long long stat_bstride, int act,
-                      int W, int up, int out_half, hipStream_t stream) {
+                      int W, int up, int flags, hipStream_t stream) {
   if (!h) return FSV_ERR_BAD_ARG;
   SpadeP p;
   int rc = fsv_sp_fill_common(p, x, mean, rstd, nmaps, maps, ch, N, HW, C, ldw, stat_bstride, W, up);
   if (rc) return rc;
   rc = fsv_sp_fill_site(p, 0, nmaps, wg, wb, bg, bb, w_bstride, b_bstride);
   if (rc) return rc;
-  p.h[0] = h; p.act[0] = act; p.h_half = out_half ? 1 : 0;
+  p.h[0] = h; p.act[0] = act; p.h_half = flags & 1;
+  const bool f16 = (flags & 4) != 0;
+  if (f16) {            // half maps / half N-major weights: 16-byte vectors of 8 k
+    for (int k = 0; k < nmaps; ++k)
+      if (ch[k] & 7) return FSV_ERR_UNSUPPORTED;
+  }
   if (C <= 32) {
     dim3 g(fsv_cdiv(HW, 128), fsv_cdiv(C, 32), N);
-    FSV_LAUNCH((fsv_spade_mod_kernel<128, 32, 4, 1, 1, false>), g, dim3(256), stream, p);
+    if (f16) FSV_LAUNCH((fsv_spade_mod_kernel<128, 32, 4, 1, 1, false, true>), g, dim3(256), stream, p);
+    else FSV_LAUNCH((fsv_spade_mod_kernel<128, 32, 4, 1, 1, false>), g, dim3(256), stream, p);
   } else {
     dim3 g(fsv_cdiv(HW, 64), fsv_cdiv(C, 64), N);
-    FSV_LAUNCH((fsv_spade_mod_kernel<64, 64, 2, 2, 1, false>), g, dim3(256), stream, p);
+    if (f16) FSV_LAUNCH((fsv_spade_mod_kernel<64, 64, 2, 2, 1, false, true>), g, dim3(256), stream, p);
+    else FSV_LAUNCH((fsv_spade_mod_kernel<64, 64, 2, 2, 1, false>), g, dim3(256), stream, p);
   }
   return fsv_check_launch();
 }
@@ -604,15 +729,18 @@ int fsv_spade_mod_fwd(const float* x, const float* mean, const float* rstd, floa
                                 act, W, up, 0, stream);
 }
 
-// the same with h written as IEEE half ([N][HW][C] halves): the `--amp` path, where the modulated tensor is only ever read by the
-// half-precision convolutions (csrc/conv_h.hip) - one rounding at the store instead of a fp32 tensor + a conversion pass
+// the `--amp` forms.  flags bit 0: h written as IEEE half ([N][HW][C] halves) - the modulated tensor is only ever read by the
+// half-precision convolutions (csrc/conv_h.hip): one rounding at the store instead of a fp32 tensor + a conversion pass.  bit 2:
+// the gamma / beta GEMMs on the f16 matrix instructions - `maps` are IEEE half ([N][HW][Ch], Ch % 8 == 0), wg / wb point at the
+// gamma rows / beta rows of the N-major half operand of fsv_spade_prep_h (row length ceil32(Ch) halves; ldw unused, w_bstride in halves).
 int fsv_spade_mod_fwd_h(const float* x, const float* mean, const float* rstd, void* h,
-                        int nmaps, const float* const* maps, const float* const* wg, const float* const* wb,
+                        int nmaps, const void* const* maps, const void* const* wg, const void* const* wb,
                         const float* const* bg, const float* const* bb, const int* ch, const long long* w_bstride,
                         const long long* b_bstride, int N, int HW, int C, int ldw, long long stat_bstride, int act,
-                        int W, int up, hipStream_t stream) {
-  return fsv_spade_mod_fwd_impl(x, mean, rstd, reinterpret_cast<float*>(h), nmaps, maps, wg, wb, bg, bb, ch, w_bstride, b_bstride, N,
-                                HW, C, ldw, stat_bstride, act, W, up, 1, stream);
+                        int W, int up, int flags, hipStream_t stream) {
+  return fsv_spade_mod_fwd_impl(x, mean, rstd, reinterpret_cast<float*>(h), nmaps, reinterpret_cast<const float* const*>(maps),
+                                reinterpret_cast<const float* const*>(wg), reinterpret_cast<const float* const*>(wb), bg, bb, ch,
+                                w_bstride, b_bstride, N, HW, C, ldw, stat_bstride, act, W, up, flags, stream);
 }
 
 // Two norm sites of one SPADEResnetBlock in ONE launch (architecture.py:95-96,103: bn_0 and bn_s normalise the same x with the
@@ -648,7 +776,8 @@ static int fsv_spade_mod_bwd_impl(const float* x, const float* mean, const float
                       int nmaps, const float* const* maps, const float* const* wg, const float* const* wb,
                       const float* const* bg, const float* const* bb, const int* ch, const long long* w_bstride,
                       const long long* b_bstride, float* const* dgb, float* dxhat, int N, int HW, int C, int ldw,
-                      long long stat_bstride, int act, int W, int up, int flags, hipStream_t stream) {
+                      long long stat_bstride, int act, int W, int up, int flags, double* dbsum, const long long* db_zstride,
+                      hipStream_t stream) {
   if (!dh || !dgb || !dxhat) return FSV_ERR_BAD_ARG;
   if (act != FSV_ACT_LRELU && act != FSV_ACT_NONE) return FSV_ERR_UNSUPPORTED;
   SpadeP p;
@@ -657,14 +786,31 @@ static int fsv_spade_mod_bwd_impl(const float* x, const float* mean, const float
   rc = fsv_sp_fill_site(p, 0, nmaps, wg, wb, bg, bb, w_bstride, b_bstride);
   if (rc) return rc;
   p.dh = dh; p.dxhat = dxhat; p.act[0] = act; p.h_half = flags & 3;
+  const bool f16 = (flags & 4) != 0;
+  if (f16) {
+    for (int k = 0; k < nmaps; ++k)
+      if (ch[k] & 7) return FSV_ERR_UNSUPPORTED;
+  }
   for (int k = 0; k < nmaps; ++k) {
     if (!dgb[k]) return FSV_ERR_UNSUPPORTED;
     p.dgb[k] = dgb[k];
   }
+  if (dbsum) {
+    if (!db_zstride) return FSV_ERR_BAD_ARG;
+    long long span = 0;
+    for (int k = 0; k < nmaps; ++k) {
+      p.db_zstride[k] = db_zstride[k];
+      const long long e = (long long)(N - 1) * db_zstride[k] + (long long)(k + 1) * 2 * C;
+      if (e > span) span = e;
+    }
+    p.dbsum = dbsum;
+    (void)hipMemsetAsync(dbsum, 0, (size_t)span * sizeof(double), stream);
+  }
   // 64 x 64 tiles: every wave keeps g_k and o_k of up to three maps for a 32 x 32 sub-tile (96 + 48 accumulator registers),
   // which leaves room for several workgroups per CU
   dim3 g(fsv_cdiv(HW, 64), fsv_cdiv(C, 64), N);
-  FSV_LAUNCH((fsv_spade_mod_kernel<64, 64, 2, 2, 1, true>), g, dim3(256), stream, p);
+  if (f16) FSV_LAUNCH((fsv_spade_mod_kernel<64, 64, 2, 2, 1, true, true>), g, dim3(256), stream, p);
+  else FSV_LAUNCH((fsv_spade_mod_kernel<64, 64, 2, 2, 1, true>), g, dim3(256), stream, p);
   return fsv_check_launch();
 }
 
@@ -674,19 +820,49 @@ int fsv_spade_mod_bwd(const float* x, const float* mean, const float* rstd, cons
                       const long long* b_bstride, float* const* dgb, float* dxhat, int N, int HW, int C, int ldw,
                       long long stat_bstride, int act, int W, int up, hipStream_t stream) {
   return fsv_spade_mod_bwd_impl(x, mean, rstd, dh, nmaps, maps, wg, wb, bg, bb, ch, w_bstride, b_bstride, dgb, dxhat, N, HW, C, ldw,
-                                stat_bstride, act, W, up, 0, stream);
+                                stat_bstride, act, W, up, 0, nullptr, nullptr, stream);
 }
 
-// the `--amp` forms: flags bit 0 - dh is IEEE half (the gradient of a half h), bit 1 - every d(gamma|beta) tensor is written as half
-// ([P][2C] halves: its consumers are the half-precision data / weight gradient GEMMs and a column sum)
+// General form of the backward twin.  flags bit 0: dh is IEEE half (the gradient of a half h); bit 1: every d(gamma|beta) tensor is
+// written as half ([P][2C] halves: its consumers are the half-precision data / weight gradient GEMMs); bit 2: f16 GEMMs (maps / wg /
+// wb as in fsv_spade_mod_fwd_h).  dbsum (optional, any flags): the bias gradients from this launch - per-channel sums of
+// d(gamma|beta) added into dbsum + z * db_zstride[k] + k * 2C as doubles (zeroed here; db_zstride[k] = 0 sums map k over the batch).
 int fsv_spade_mod_bwd_h(const float* x, const float* mean, const float* rstd, const void* dh,
-                        int nmaps, const float* const* maps, const float* const* wg, const float* const* wb,
+                        int nmaps, const void* const* maps, const void* const* wg, const void* const* wb,
                         const float* const* bg, const float* const* bb, const int* ch, const long long* w_bstride,
                         const long long* b_bstride, void* const* dgb, float* dxhat, int N, int HW, int C, int ldw,
-                        long long stat_bstride, int act, int W, int up, int flags, hipStream_t stream) {
-  return fsv_spade_mod_bwd_impl(x, mean, rstd, reinterpret_cast<const float*>(dh), nmaps, maps, wg, wb, bg, bb, ch, w_bstride,
-                                b_bstride, reinterpret_cast<float* const*>(dgb), dxhat, N, HW, C, ldw, stat_bstride, act, W, up,
-                                flags, stream);
+                        long long stat_bstride, int act, int W, int up, int flags, double* dbsum, const long long* db_zstride,
+                        hipStream_t stream) {
+  return fsv_spade_mod_bwd_impl(x, mean, rstd, reinterpret_cast<const float*>(dh), nmaps, reinterpret_cast<const float* const*>(maps),
+                                reinterpret_cast<const float* const*>(wg), reinterpret_cast<const float* const*>(wb), bg, bb, ch,
+                                w_bstride, b_bstride, reinterpret_cast<float* const*>(dgb), dxhat, N, HW, C, ldw, stat_bstride, act, W,
+                                up, flags, dbsum, db_zstride, stream);
+}
+
+// half N-major operand of the f16 forms: wcat_h [B][2C][Kh] (Kh = ceil32(Ch) halves per row, zero padded): row j < C = gamma weights
+// of channel j, row C + j = beta weights - from wg / wb [B][C][Ch] (sample strides swg / swb; 0 = shared)
+__global__ __launch_bounds__(256) void fsv_spade_prep_h_kernel(const float* wg, const float* wb, long long swg, long long swb,
+                                                               _Float16* wcat_h, int C, int Ch, int Kh) {
+  const int z = blockIdx.y;
+  const long long total = (long long)2 * C * Kh;
+  const float* g = wg + z * swg;
+  const float* b = wb + z * swb;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int j = (int)(i / Kh), k = (int)(i - (long long)j * Kh);
+    float v = 0.f;
+    if (k < Ch) v = j < C ? g[(long long)j * Ch + k] : b[(long long)(j - C) * Ch + k];
+    wcat_h[z * total + i] = (_Float16)v;
+  }
+}
+
+int fsv_spade_prep_h(const float* wg, const float* wb, long long swg, long long swb, void* wcat_h, int B, int C, int Ch,
+                     hipStream_t stream) {
+  if (!wg || !wb || !wcat_h || B < 1 || C < 16 || (C & 15) || Ch < 1) return FSV_ERR_BAD_ARG;
+  const int Kh = (Ch + 31) / 32 * 32;
+  long long g = ((long long)2 * C * Kh + 255) / 256;
+  if (g > 1024) g = 1024;
+  FSV_LAUNCH(fsv_spade_prep_h_kernel, dim3((unsigned)g, B), dim3(256), stream, wg, wb, swg, swb, reinterpret_cast<_Float16*>(wcat_h), C, Ch, Kh);
+  return fsv_check_launch();
 }
 
 int fsv_spade_bwd_elem(const float* x, const float* mean, const float* rstd, const float* dh, const float* h,

@@ -888,15 +888,35 @@ def _spade_same_input(a, b):
             [m.data_ptr() for m in a['maps']] == [m.data_ptr() for m in b['maps']])
 
 
+def _half_map(key, m):
+    """IEEE-half copy of a label map (NHWC), made once per map tensor: every SPADE site of a block and their backward twins and
+    weight-gradient GEMMs read the same copy"""
+    got = getattr(key, '_fsv_h16', None)
+    if got is not None and got[0] == key._version and got[1].shape == m.shape:
+        return got[1]
+    mh = _hconv.to_half_nhwc(m)
+    try:
+        key._fsv_h16 = (key._version, mh)
+    except Exception:
+        pass
+    return mh
+
+
 def _spade_launch(a, b=None):
     arr = lambda v: (ctypes.c_void_p * max(len(v), 1))(*v)
     n, hw, c, ldw, w, up = a['dims']
     chs = a['chs']
     if b is None:
         with profile.scope('fsv_spade_mod_kernel', a['flops']):
-            lib.call("fsv_spade_mod_fwd_h" if a.get('half') else "fsv_spade_mod_fwd", lib.ptr(a['x']), lib.ptr(a['mean']), lib.ptr(a['rstd']), lib.ptr(a['h']), len(chs),
-                     _pp(a['maps']), arr(a['wg']), arr(a['wb']), arr(a['bg']), arr(a['bb']), lib.int_array(chs + [0]),
-                     _ll(a['wstr'] + [0]), _ll(a['bstr'] + [0]), n, hw, c, ldw, 0, a['act'], w, up, lib.stream_ptr())
+            if a.get('half'):
+                lib.call("fsv_spade_mod_fwd_h", lib.ptr(a['x']), lib.ptr(a['mean']), lib.ptr(a['rstd']), lib.ptr(a['h']), len(chs),
+                         _pp(a['maps']), arr(a['wg']), arr(a['wb']), arr(a['bg']), arr(a['bb']), lib.int_array(chs + [0]),
+                         _ll(a['wstr'] + [0]), _ll(a['bstr'] + [0]), n, hw, c, ldw, 0, a['act'], w, up,
+                         1 | (4 if a.get('f16') else 0), lib.stream_ptr())
+            else:
+                lib.call("fsv_spade_mod_fwd", lib.ptr(a['x']), lib.ptr(a['mean']), lib.ptr(a['rstd']), lib.ptr(a['h']), len(chs),
+                         _pp(a['maps']), arr(a['wg']), arr(a['wb']), arr(a['bg']), arr(a['bb']), lib.int_array(chs + [0]),
+                         _ll(a['wstr'] + [0]), _ll(a['bstr'] + [0]), n, hw, c, ldw, 0, a['act'], w, up, lib.stream_ptr())
         return
     with profile.scope('fsv_spade_mod_kernel', a['flops'] + b['flops']):
         lib.call("fsv_spade_mod_fwd2", lib.ptr(a['x']), lib.ptr(a['mean']), lib.ptr(a['rstd']), lib.ptr(a['h']), lib.ptr(b['h']),
@@ -955,6 +975,12 @@ class _SpadeFn(torch.autograd.Function):
         ctx.half_out = bool(_conv.h_kernels() and ctx.fast and _os.environ.get('FSV_SPADE_FUSED_BWD', '1') == '1'
                             and getattr(_spade_tls, 'pair', None) is None and nmaps > 0)
         hout = _hconv.empty_nhwc_h(n, c, h, w, x) if ctx.half_out else empty_nhwc(n, c, h, w, x)
+        # ... and the gamma / beta GEMMs themselves on the f16 matrix instructions: half label maps (one conversion per map tensor,
+        # shared by every SPADE site that reads it and by the backward), half weights, half d(gamma|beta) for the half data /
+        # weight-gradient kernels, the bias gradients from the backward twin's own epilogue
+        ctx.f16 = bool(ctx.half_out and all(ch % 8 == 0 for ch in chs) and _os.environ.get('FSV_SPADE_F16', '1') == '1')
+        if ctx.f16:
+            maps = [_half_map(rest[5 * k], maps[k]) for k in range(nmaps)]
         if ctx.fast:
             ldw = 2 * c
             prepped, wg_p, wb_p, bg_p, bb_p, wstr, bstr = [], [], [], [], [], [], []
@@ -988,13 +1014,22 @@ class _SpadeFn(torch.autograd.Function):
                          wg.stride(0) if per_sample else 0, wb.stride(0) if per_sample else 0,
                          bg.stride(0) if per_sample else 0, bb.stride(0) if per_sample else 0,
                          lib.ptr(wcat_t), lib.ptr(wcat_d), lib.ptr(bcat), nb, c, ch, lib.stream_ptr())
-                prepped += [wcat_t, wcat_d if need_d else wcat_t[:0], bcat]
-                wg_p.append(wcat_t.data_ptr()); wb_p.append(wcat_t.data_ptr() + 4 * c)
+                if ctx.f16:
+                    # N-major half operand [nb][gamma rows (C) | beta rows (C)][Kh]
+                    wcat_h = torch.empty((nb, 2 * c, kt), dtype=torch.float16, device=x.device)
+                    lib.call("fsv_spade_prep_h", lib.ptr(wg), lib.ptr(wb), wg.stride(0) if per_sample else 0,
+                             wb.stride(0) if per_sample else 0, lib.ptr(wcat_h), nb, c, ch, lib.stream_ptr())
+                    prepped += [wcat_h, wcat_d if need_d else flat_t[:0], bcat]
+                    wg_p.append(wcat_h.data_ptr()); wb_p.append(wcat_h.data_ptr() + 2 * c * kt)
+                    wstr.append(2 * c * kt if per_sample else 0)
+                else:
+                    prepped += [wcat_t, wcat_d if need_d else wcat_t[:0], bcat]
+                    wg_p.append(wcat_t.data_ptr()); wb_p.append(wcat_t.data_ptr() + 4 * c)
+                    wstr.append(kt * 2 * c if per_sample else 0)
                 bg_p.append(bcat.data_ptr()); bb_p.append(bcat.data_ptr() + 4 * c)
-                wstr.append(kt * 2 * c if per_sample else 0)
                 bstr.append(2 * c if per_sample else 0)
             site = dict(x=x, mean=mean, rstd=rstd, h=hout, maps=maps, wg=wg_p, wb=wb_p, bg=bg_p, bb=bb_p, chs=chs, wstr=wstr,
-                        bstr=bstr, dims=(n, h * w, c, ldw, w, up), act=act, keep=prepped, half=ctx.half_out,
+                        bstr=bstr, dims=(n, h * w, c, ldw, w, up), act=act, keep=prepped, half=ctx.half_out, f16=ctx.f16,
                         flops=2.0 * n * h * w * c * 2 * sum(chs))
             pair = getattr(_spade_tls, 'pair', None)
             if pair is None or nmaps == 0:
@@ -1053,23 +1088,34 @@ class _SpadeFn(torch.autograd.Function):
         if fused:
             # fused backward twin of the modulation kernel: gamma / beta are recomputed in registers, never materialised
             prepped = saved[4 + nm:]
-            dgbs = [empty_nhwc(n, 2 * c, h, w, x) for _ in range(nm)]
+            f16 = getattr(ctx, 'f16', False)
+            dgbs = [(_hconv.empty_nhwc_h if f16 else empty_nhwc)(n, 2 * c, h, w, x) for _ in range(nm)]
             wg_p, wb_p, bg_p, bb_p, wstr, bstr, chs = [], [], [], [], [], [], []
             for k in range(nm):
-                wcat_t, bcat = prepped[3 * k], prepped[3 * k + 2]
-                wg_p.append(wcat_t.data_ptr()); wb_p.append(wcat_t.data_ptr() + 4 * c)
+                wcat_t, bcat = prepped[3 * k], prepped[3 * k + 2]            # f16: the half operand [nb][2C][Kh]
+                wg_p.append(wcat_t.data_ptr())
+                wb_p.append(wcat_t.data_ptr() + (2 * c * wcat_t.shape[-1] if f16 else 4 * c))
                 bg_p.append(bcat.data_ptr()); bb_p.append(bcat.data_ptr() + 4 * c)
-                wstr.append(wcat_t.shape[-2] * 2 * c if ctx.per_sample[k] else 0)
+                wstr.append(wcat_t.shape[-2] * wcat_t.shape[-1] if ctx.per_sample[k] else 0)
                 bstr.append(2 * c if ctx.per_sample[k] else 0)
                 chs.append(maps[k].shape[1])
             arr = lambda v: (ctypes.c_void_p * max(len(v), 1))(*v)
             lib.check_device(x, dh, *maps)
+            dbsum = None
+            if f16 and nm:
+                dbsum = torch.empty((n, nm, 2 * c), dtype=torch.float64, device=x.device)
+                zstr = [nm * 2 * c if ctx.per_sample[k] else 0 for k in range(nm)]
             # (labelled as the backward twin; FLOPs = the gamma / beta GEMMs it recomputes)
             with profile.scope('fsv_spade_mod_kernel<bwd>', 2.0 * n * h * w * c * 2 * sum(chs)):
-                if dh.dtype == torch.float16:
+                if dh.dtype == torch.float16 or f16:
+                    flags = (1 if dh.dtype == torch.float16 else 0) | (6 if f16 else 0)
                     lib.call("fsv_spade_mod_bwd_h", lib.ptr(x), lib.ptr(mean), lib.ptr(rstd), lib.ptr(dh), nm, _pp(maps), arr(wg_p),
                              arr(wb_p), arr(bg_p), arr(bb_p), lib.int_array(chs + [0]), _ll(wstr + [0]), _ll(bstr + [0]),
-                             _pp(dgbs), lib.ptr(dxhat), n, h * w, c, 2 * c, 0, ctx.act, w, up, 1, lib.stream_ptr())
+                             _pp(dgbs), lib.ptr(dxhat), n, h * w, c, 2 * c, 0, ctx.act, w, up, flags,
+                             lib.ptr(dbsum) if dbsum is not None else None, _ll(zstr + [0]) if dbsum is not None else None,
+                             lib.stream_ptr())
+                    if dbsum is not None:
+                        dbsum = dbsum.float()
                 else:
                     lib.call("fsv_spade_mod_bwd", lib.ptr(x), lib.ptr(mean), lib.ptr(rstd), lib.ptr(dh), nm, _pp(maps), arr(wg_p),
                              arr(wb_p), arr(bg_p), arr(bb_p), lib.int_array(chs + [0]), _ll(wstr + [0]), _ll(bstr + [0]),
@@ -1138,7 +1184,9 @@ class _SpadeFn(torch.autograd.Function):
                     dwcat = conv_wgrad(maps[k], dgbs[k], g1, tuple(wcats[k].shape), per_sample=per_sample)
                     dwg, dwb = torch.split(dwcat, c, dim=-4)
             if ctx.needs_input_grad[base + 3] or ctx.needs_input_grad[base + 4]:
-                if per_sample:
+                if fused and dbsum is not None:
+                    dbcat = dbsum[:, k] if per_sample else dbsum[0, k]
+                elif per_sample:
                     dbcat = colsum(dgbs[k], n, h * w, 2 * c)
                 else:
                     dbcat = colsum(dgbs[k], 1, n * h * w, 2 * c).view(2 * c)

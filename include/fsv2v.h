@@ -241,12 +241,17 @@ int fsv_spade_mod_fwd(const float* x, const float* mean, const float* rstd, floa
                       const float* const* bg, const float* const* bb, const int* ch, const long long* w_bstride,
                       const long long* b_bstride, int N, int HW, int C, int ldw, long long stat_bstride, int act,
                       int W, int up, fsv_stream_t stream);
-/* fsv_spade_mod_fwd with h written as IEEE half (the `--amp` path: h is only read by half-precision convolutions) */
+/* `--amp` forms of fsv_spade_mod_fwd.  flags bit 0: h written as IEEE half (h is only read by half-precision convolutions);
+ * bit 2: gamma / beta GEMMs on the f16 matrix instructions - maps IEEE half ([N][HW][Ch], Ch % 8 == 0), wg / wb = gamma rows / beta
+ * rows of the N-major half operand of fsv_spade_prep_h (row length ceil32(Ch) halves; ldw unused), w_bstride in halves */
 int fsv_spade_mod_fwd_h(const float* x, const float* mean, const float* rstd, void* h,
-                      int nmaps, const float* const* maps, const float* const* wg, const float* const* wb,
-                      const float* const* bg, const float* const* bb, const int* ch, const long long* w_bstride,
-                      const long long* b_bstride, int N, int HW, int C, int ldw, long long stat_bstride, int act,
-                      int W, int up, fsv_stream_t stream);
+                        int nmaps, const void* const* maps, const void* const* wg, const void* const* wb,
+                        const float* const* bg, const float* const* bb, const int* ch, const long long* w_bstride,
+                        const long long* b_bstride, int N, int HW, int C, int ldw, long long stat_bstride, int act,
+                        int W, int up, int flags, fsv_stream_t stream);
+/* wcat_h [B][2C][Kh = ceil32(Ch)] halves, K contiguous, zero padded: rows [0, C) gamma weights, [C, 2C) beta weights */
+int fsv_spade_prep_h(const float* wg, const float* wb, long long swg, long long swb, void* wcat_h, int B, int C, int Ch,
+                     fsv_stream_t stream);
 /* Two norm sites of one SPADEResnetBlock in one launch - bn_0 and bn_s (architecture.py:95-96,103) normalise the same x
  * with the same statistics and read the same maps; only the gamma / beta weights and the activation differ:
  * h0 = act0(SPADE_0(x)), h1 = act1(SPADE_s(x)).  x, the statistics and the label-map tiles are read once, the map tile in LDS
@@ -264,12 +269,15 @@ int fsv_spade_mod_bwd(const float* x, const float* mean, const float* rstd, cons
                       const float* const* bg, const float* const* bb, const int* ch, const long long* w_bstride,
                       const long long* b_bstride, float* const* dgb, float* dxhat, int N, int HW, int C, int ldw,
                       long long stat_bstride, int act, int W, int up, fsv_stream_t stream);
-/* fsv_spade_mod_bwd for the `--amp` path: flags bit 0 - dh is IEEE half, bit 1 - the d(gamma|beta) tensors are written as half */
+/* general form of fsv_spade_mod_bwd.  flags bit 0: dh is IEEE half; bit 1: the d(gamma|beta) tensors are written as half; bit 2: f16
+ * GEMMs (operands as fsv_spade_mod_fwd_h).  dbsum (optional): the bias gradients from this launch - per-channel sums of
+ * d(gamma|beta) as doubles at dbsum + z * db_zstride[k] + k * 2C (zeroed by the call; db_zstride[k] = 0: summed over the batch) */
 int fsv_spade_mod_bwd_h(const float* x, const float* mean, const float* rstd, const void* dh,
-                      int nmaps, const float* const* maps, const float* const* wg, const float* const* wb,
-                      const float* const* bg, const float* const* bb, const int* ch, const long long* w_bstride,
-                      const long long* b_bstride, void* const* dgb, float* dxhat, int N, int HW, int C, int ldw,
-                      long long stat_bstride, int act, int W, int up, int flags, fsv_stream_t stream);
+                        int nmaps, const void* const* maps, const void* const* wg, const void* const* wb,
+                        const float* const* bg, const float* const* bb, const int* ch, const long long* w_bstride,
+                        const long long* b_bstride, void* const* dgb, float* dxhat, int N, int HW, int C, int ldw,
+                        long long stat_bstride, int act, int W, int up, int flags, double* dbsum, const long long* db_zstride,
+                        fsv_stream_t stream);
 /* element-wise part of the backward (general path, C % 16 != 0): from materialised gamma|beta ([P][2C] per map) to d(gamma|beta) and d(xhat) (dxhat is
  * written per full-resolution pixel also when up != 0: summing it over the 2x2 children gives the gradient of the
  * half-resolution normalised tensor) */

@@ -375,15 +375,22 @@ def check_norm(device, instance, n=3, c=10, h=7, w=5, affine=True, act='lrelu', 
 
 
 def check_spade(device, nmaps=1, generated=True, n=2, c=12, ch=8, h=6, w=5, act='lrelu', seed=5, strided=False, up=False,
-                half_out=False):
+                half_out=False, f16=False):
     """SPADE with per-sample generated weights for map 0 and fixed weights for the extra maps.  strided: the generated
     weights / biases are views into one [n, L] tensor, the way the weight-generating FC hands them over
     (generator.py reshape_weight); c % 16 == 0 takes the single-preparation-launch path of ops._SpadeFn.  up: x is handed
     over at half resolution and the kernels read it through the nearest x2 up-sampling index (generator.py:124 folded in);
     the reference up-samples explicitly (h, w must be even).  half_out: the `--amp` form on the half-precision kernels - h is
     stored as IEEE half (one rounding) and its gradient arrives as half; the arithmetic in between stays fp32, so with the
-    gradient rounded beforehand on both sides the gradients agree at the fp32 tolerance (c % 16 == 0 required)."""
+    gradient rounded beforehand on both sides the gradients agree at the fp32 tolerance (c % 16 == 0 required).  f16 (with
+    half_out; ch % 8 == 0): the gamma / beta GEMMs on the f16 matrix instructions too - half maps, half weights, half
+    d(gamma|beta), bias gradients from the backward twin's epilogue - against the oracle with the `--amp` arithmetic installed."""
+    import contextlib
+    from oracle import np_oracle
     ops, conv = pkg()
+    assert half_out or not f16
+    os.environ['FSV_SPADE_F16'] = '1' if f16 else '0'
+    arith = (lambda: O.arithmetic(np_oracle.amp_conv2d)) if f16 else contextlib.nullcontext
     g = torch.Generator().manual_seed(seed)
     x = torch.randn(n, c, h // 2, w // 2, generator=g) + 0.3 if up else torch.randn(n, c, h, w, generator=g) + 0.3
     maps = [torch.randn(n, ch, h, w, generator=g) for _ in range(nmaps)]
@@ -427,16 +434,25 @@ def check_spade(device, nmaps=1, generated=True, n=2, c=12, ch=8, h=6, w=5, act=
         weights_d.append((wg_d, wb_d, bg_d, bb_d))
     run_mean_r, run_var_r = torch.zeros(c), torch.ones(c)
     x_in = F.interpolate(xr, scale_factor=2, mode='nearest') if up else xr
-    ref = O.spade(x_in, maps_r, fixed_r, gen_r)
-    F.batch_norm(x_in.detach(), run_mean_r, run_var_r, training=True, momentum=0.1, eps=1e-5)      # running statistics
-    if act == 'lrelu':
-        ref = O.actvn(ref)
-    dy = torch.randn(ref.shape, generator=g)
-    if half_out:
-        dy = dy.to(torch.float16).to(torch.float32)
-    ref.backward(dy)
+    with arith():
+        ref = O.spade(x_in, maps_r, fixed_r, gen_r)
+        F.batch_norm(x_in.detach(), run_mean_r, run_var_r, training=True, momentum=0.1, eps=1e-5)      # running statistics
+        if act == 'lrelu':
+            ref = O.actvn(ref)
+        dy = torch.randn(ref.shape, generator=g)
+        if half_out:
+            dy = dy.to(torch.float16).to(torch.float32)
+        ref.backward(dy)
     run_mean_d, run_var_d = _dev(torch.zeros(c), device), _dev(torch.ones(c), device)
     prev = conv.set_mfma_mode(1 if half_out else conv.mfma_mode())
+    from importlib import import_module
+    lib = import_module('few-shot-vid2vid_amd.lib')
+    seen, real_call = [], lib.call
+
+    def recording_call(name, *a):
+        seen.append((name, a))
+        return real_call(name, *a)
+    lib.call = recording_call
     try:
         y = ops.spade_mod(xd, maps_d, weights_d, run_mean_d, run_var_d, act=conv.ACT_LRELU if act == 'lrelu' else conv.ACT_NONE,
                           up=up)
@@ -449,7 +465,15 @@ def check_spade(device, nmaps=1, generated=True, n=2, c=12, ch=8, h=6, w=5, act=
             y.backward(_dev(dy, device))
             assert_close('spade h', y, ref)
     finally:
+        lib.call = real_call
         conv.set_mfma_mode(prev)
+        os.environ.pop('FSV_SPADE_F16', None)
+    if f16:                    # the launches really were the f16 forms (flags bit 2), with half d(gamma|beta) and fused bias sums
+        fw = [a for nm_, a in seen if nm_ == 'fsv_spade_mod_fwd_h']
+        bw = [a for nm_, a in seen if nm_ == 'fsv_spade_mod_bwd_h']
+        assert fw and bw and all(a[-2] & 4 for a in fw) and all((a[-4] & 6) == 6 and a[-3] is not None for a in bw), \
+            [nm_ for nm_, _ in seen]
+        assert not any(nm_ == 'fsv_colsum_fused' for nm_, _ in seen)
     assert_close('spade running mean', run_mean_d, run_mean_r, 1e-5)
     assert_close('spade running var', run_var_d, run_var_r, 1e-5)
     for i, (a, d) in enumerate(zip(leaves_ref, leaves_dev)):

@@ -101,3 +101,20 @@ def test_c5_street_1024x512_nc35_fp32(hip_lib):
                       batchSize=1)
     worst = mc.check_train_step(DEV, opt, b=1, tol=1e-3, grad_tol=1e-2)
     assert worst < 1e-2, worst
+
+
+def test_c5_street_1024x512_nc35_amp(hip_lib):
+    """BASELINE.json configs[4] per rank in its stated arithmetic - `--amp O1`, fp16 MFMA (options/base_options.py:127,
+    models/models.py:22-26, loss_collector.py:221-224): full width, W 1024 x H 512, 35 one-hot classes, one sample, full D step + G
+    step of the product on the half-precision kernels (csrc/conv_h.hip) against a WHOLE-ITERATION run of the oracle in the same
+    arithmetic (oracle/np_oracle.amp_conv2d installed into oracle/fsv_oracle.py; same loss scale), summing in fp32 and in fp64 -
+    tolerances of the fp32 test above plus the definition's own fp32-vs-fp64 distance (model_checks.check_amp_train_step) - and
+    every half launch of the iteration recomputed from its own operands with plain torch (model_checks.verify_half_launches).
+
+    *Parity unpinned against apex*: apex is neither vendored by the reference nor installable here and has no CPU path, so no
+    reference output exists for this mode; the oracle states the definition (operands and half-stored activations rounded to
+    IEEE half, exact products, fp32 accumulation, fp32 everywhere else) and this test pins the product to it."""
+    opt = mc.make_opt(dataset_mode='fewshot_street', label_nc=35, input_nc=3, aspect_ratio=2.0, fineSize=1024, loadSize=1024,
+                      batchSize=1, amp='O1')
+    worst = mc.check_amp_train_step(DEV, opt, b=1, tol=1e-3, grad_tol=1e-2)
+    assert worst < 0.5, worst

@@ -57,3 +57,13 @@ def test_stats(emu_lib):
 def test_spade_half_output_and_half_gradient(emu_lib, nmaps, up):
     import op_checks as oc
     oc.check_spade(DEV, nmaps=nmaps, generated=True, c=32, ch=16, h=8, w=10, up=up, half_out=True)
+
+
+@pytest.mark.parametrize('nmaps,up,c,ch,generated', [(1, False, 32, 16, True), (3, True, 64, 40, True), (2, False, 96, 72, False),
+                                                     (1, True, 16, 8, True)])
+def test_spade_f16_gemms(emu_lib, nmaps, up, c, ch, generated):
+    """gamma / beta GEMMs of the fused modulation kernel and its backward twin on the f16 matrix instructions (csrc/spade.hip F16):
+    both tile shapes (C <= 32: 128 x 32; else 64 x 64), K tails (Ch = 8, 40, 72: partial 32-wide chunks), partial channel tiles
+    (C = 96 on 64-wide tiles), three maps, per-sample and shared weights"""
+    import op_checks as oc
+    oc.check_spade(DEV, nmaps=nmaps, generated=generated, c=c, ch=ch, h=8, w=10, up=up, half_out=True, f16=True)

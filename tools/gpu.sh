@@ -6,4 +6,6 @@ cd "$(dirname "$0")/.."
 c=$(git rev-parse HEAD 2>/dev/null)
 if [ -n "$(git status --porcelain 2>/dev/null | grep -v '^??' | head -1)" ]; then c="$c+dirty"; fi
 echo "$c" > .build_commit
+# the GPU box runs the prebuilt in-tree libraries: make sure they are the current sources'
+python -c "import importlib, fsv2v_amd; b = importlib.import_module('few-shot-vid2vid_amd.build'); b.build_hip(); b.build_emu()" || exit 1
 exec /usr/local/graft/bin/gpurun "$@"
