@@ -51,6 +51,7 @@ struct HConvP {
   int act; float scale;
   int Mz;
   int out_h, res_h;
+  long long res_bytes;     // extent of the residual tensor (0 without one)
   double* stats;
   int stats_slots, stats_ohw;
 };
@@ -283,21 +284,24 @@ __device__ __forceinline__ void fsv_hconv_body(const HConvP& p, const int bx, co
   const int st_split = (st_g0 + 1) * (p.stats ? p.stats_ohw : 0);
   fsv_h16* const out_h = reinterpret_cast<fsv_h16*>(p.out);
   float* const out_f = reinterpret_cast<float*>(p.out);
-  const fsv_h16* const res_h = reinterpret_cast<const fsv_h16*>(p.res);
-  const float* const res_f = reinterpret_cast<const float*>(p.res);
+  // the residual / LeakyReLU-mask operand through a descriptor (the host checked that the output stays below 2^31 bytes when
+  // there is one): all of a lane's values are loaded BEFORE its first store - the stores may alias p.res as far as the compiler
+  // can tell, so a load inside the store loop waits for its full memory latency once per element (16 - 32 times per tile)
+  const fsv_buf rbuf = fsv_make_buf(p.res, p.res ? p.res_bytes : 0);
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
     const int co = bn0 + wn * (TN * 32) + j * 32 + lrow;
     const bool cok = co < p.Cout;
     const float bv = (bias && p.nsplit == 1 && cok) ? bias[co] : 0.f;
     float s0 = 0.f, q0 = 0.f, s1 = 0.f, q1 = 0.f;
+    int oix[TM][16];          // element index of the output (the host checked < 2^31 elements), -1: not stored
+    float aux[TM][16];
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = (r & 3) + 8 * (r >> 2) + 4 * lk;
         const int m = bm0 + wm * (TM * 32) + i * 32 + row;
-        if (m >= p.Mz || !cok) continue;
         long long opix;
         if (p.dense_out) {
           opix = (long long)zs * (p.per_sample ? p.Mz : 0) + m;
@@ -307,18 +311,37 @@ __device__ __forceinline__ void fsv_hconv_body(const HConvP& p, const int bx, co
           const int oy = rem / p.OW, ox = rem - oy * p.OW;
           opix = ((long long)n * p.outH + (oy * p.osy + p.ooy)) * p.outW + (ox * p.osx + p.oox);
         }
-        const long long oidx = opix * p.Cout + co;
+        const bool ok = cok & (m < p.Mz);
+        oix[i][r] = ok ? (int)(opix * p.Cout + co) : -1;
+        aux[i][r] = 0.f;
+      }
+    }
+    if (p.res) {              // uniform
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const unsigned off = oix[i][r] >= 0 ? (unsigned)oix[i][r] * (p.res_h ? 2u : 4u) : FSV_BUF_OOB;
+          aux[i][r] = p.res_h ? fsv_buf_load_h(rbuf, off) : fsv_buf_load1(rbuf, off);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * lk;
+        const int m = bm0 + wm * (TM * 32) + i * 32 + row;
+        if (oix[i][r] < 0) continue;
+        const int oidx = oix[i][r];
         float v = acc[i][j][r] * ws;
         if (p.nsplit > 1) {
           atomicAdd(out_f + oidx, v);            // split launches accumulate into a zeroed fp32 buffer (the host's workspace)
         } else {
           v = (v + bv) * p.scale;
           if (p.act == FSV_ACT_DLRELU) {
-            const float aux = p.res_h ? (float)res_h[oidx] : res_f[oidx];
-            v = aux > 0.f ? v : 0.2f * v;
+            v = aux[i][r] > 0.f ? v : 0.2f * v;
           } else {
-            v = fsv_act(v, p.act);
-            if (p.res) v += p.res_h ? (float)res_h[oidx] : res_f[oidx];
+            v = fsv_act(v, p.act) + aux[i][r];
           }
           if (p.out_h) {
             const fsv_h16 hv = (fsv_h16)v;
@@ -812,6 +835,12 @@ static int fsv_h_fill(HConvP& p, const fsv_hconv_desc& d) {
   if ((long long)d.N * d.H * d.W * d.Cin * 2 > FSV_BUF_MAX_BYTES || (long long)d.nrows * d.Kpad * 2 > FSV_BUF_MAX_BYTES) return FSV_ERR_UNSUPPORTED;
   if (d.accumulate && (d.bias || d.res || d.act != FSV_ACT_NONE || d.scale != 1.f || d.out_h)) return FSV_ERR_BAD_ARG;
   if (d.act == FSV_ACT_DLRELU && !d.res) return FSV_ERR_BAD_ARG;
+  {
+    // the epilogue addresses the output with 32-bit element indices and the residual through one descriptor
+    const long long oelems = (long long)d.N * d.outH * d.outW * d.Cout;
+    if (oelems >= 0x7fffffffll || (d.res && oelems * (d.res_h ? 2 : 4) > FSV_BUF_MAX_BYTES)) return FSV_ERR_UNSUPPORTED;
+    p.res_bytes = d.res ? oelems * (d.res_h ? 2 : 4) : 0;
+  }
   p.in = reinterpret_cast<const fsv_h16*>(d.in); p.wt = reinterpret_cast<const fsv_h16*>(d.wt);
   p.bias = d.bias; p.res = d.res; p.wscale = d.wscale; p.out = d.out;
   p.N = d.N; p.H = d.H; p.W = d.W; p.Cin = d.Cin; p.OH = d.OH; p.OW = d.OW; p.Cout = d.Cout;

@@ -27,6 +27,11 @@ static inline float fsv_buf_load1(const fsv_buf& b, unsigned off) {
   if (off < b.bytes && (unsigned long long)off + 4ull <= (unsigned long long)b.bytes) memcpy(&v, b.base + off, 4);
   return v;
 }
+static inline float fsv_buf_load_h(const fsv_buf& b, unsigned off) {        // one IEEE half, widened
+  _Float16 v = (_Float16)0.f;
+  if (off < b.bytes && (unsigned long long)off + 2ull <= (unsigned long long)b.bytes) memcpy(&v, b.base + off, 2);
+  return (float)v;
+}
 // LDS-direct form: the lane's 16 bytes land at lds_wave_base + lane * 16 (out-of-range lanes write zeros)
 typedef fsv_buf fsv_rawbuf;
 static inline fsv_rawbuf fsv_make_rawbuf(const void* p, long long bytes) { return fsv_make_buf(p, bytes); }
@@ -47,6 +52,9 @@ __device__ __forceinline__ float4 fsv_buf_load4(fsv_buf b, unsigned off) {
 }
 __device__ __forceinline__ float fsv_buf_load1(fsv_buf b, unsigned off) {
   return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(b, off, 0, 0));
+}
+__device__ __forceinline__ float fsv_buf_load_h(fsv_buf b, unsigned off) {   // one IEEE half, widened
+  return (float)__builtin_bit_cast(_Float16, __builtin_amdgcn_raw_buffer_load_b16(b, off, 0, 0));
 }
 // buffer_load_dwordx4 ... lds: no destination registers; the wave's 64 quads are written to 1 KB of LDS starting at the wave-uniform
 // address lds_wave_base (M0), lane l at + 16 l; counted by vmcnt like any other buffer load.  Issued through inline assembly on
@@ -95,6 +103,7 @@ struct ConvP {
   // slot (tile index % stats_slots); group = pixel / stats_ohw (one group for BatchNorm, one per sample for InstanceNorm)
   double* stats;
   int stats_slots, stats_ohw;
+  long long res_bytes;                   // extent of the residual tensor when one descriptor covers it (else 0: loaded per element)
 };
 
 __device__ __forceinline__ void fsv_tap(const ConvP& p, int t, int& ty, int& tx) {

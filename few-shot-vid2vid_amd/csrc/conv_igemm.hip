@@ -421,12 +421,36 @@ __device__ __forceinline__ void fsv_conv_igemm_body(const ConvP& p, const int bx
   // tile's first group, the rest (InstanceNorm, a tile that straddles two samples) to the next one
   const int st_g0 = p.stats ? bm0 / p.stats_ohw : 0;
   const int st_split = (st_g0 + 1) * (p.stats ? p.stats_ohw : 0);
+  auto out_pixel = [&](int m) -> long long {
+    if (p.dense_out) return (long long)zs * (p.per_sample ? p.Mz : 0) + m;
+    int n, rem;
+    if (p.per_sample) { n = zs; rem = m; } else { n = m / ohw; rem = m - n * ohw; }
+    const int oy = rem / p.OW, ox = rem - oy * p.OW;
+    return ((long long)n * p.outH + (oy * p.osy + p.ooy)) * p.outW + (ox * p.osx + p.oox);
+  };
+  // residual / LeakyReLU-mask operand: all of a lane's values are loaded (through a descriptor, absent ones as zero fill) BEFORE
+  // its first store - the stores may alias p.res as far as the compiler can tell, so a load inside the store loop waits for its
+  // full memory latency once per element, 16 - 32 times per tile (round 4)
+  const bool pre = p.res_bytes > 0;
+  const fsv_buf rbuf = fsv_make_buf(p.res, pre ? p.res_bytes : 0);
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
     const int co = bn0 + wn * (TN * 32) + j * 32 + lrow;
     const bool cok = co < p.Cout;
     const float bv = (bias && p.nsplit == 1 && cok) ? bias[co] : 0.f;
     float s0 = 0.f, q0 = 0.f, s1 = 0.f, q1 = 0.f;
+    float aux[TM][16];
+    if (pre) {                // uniform
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = (r & 3) + 8 * (r >> 2) + 4 * lk;
+          const int m = bm0 + wm * (TM * 32) + i * 32 + row;
+          const bool ok = cok & (m < p.Mz);
+          aux[i][r] = fsv_buf_load1(rbuf, ok ? (unsigned)((out_pixel(m) * p.Cout + co) * 4) : FSV_BUF_OOB);
+        }
+    }
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -434,15 +458,7 @@ __device__ __forceinline__ void fsv_conv_igemm_body(const ConvP& p, const int bx
         const int row = (r & 3) + 8 * (r >> 2) + 4 * lk;
         const int m = bm0 + wm * (TM * 32) + i * 32 + row;
         if (m >= p.Mz || !cok) continue;
-        long long opix;
-        if (p.dense_out) {
-          opix = (long long)zs * (p.per_sample ? p.Mz : 0) + m;
-        } else {
-          int n, rem;
-          if (p.per_sample) { n = zs; rem = m; } else { n = m / ohw; rem = m - n * ohw; }
-          int oy = rem / p.OW, ox = rem - oy * p.OW;
-          opix = ((long long)n * p.outH + (oy * p.osy + p.ooy)) * p.outW + (ox * p.osx + p.oox);
-        }
+        const long long opix = out_pixel(m);
         float* dst = p.out + opix * p.Cout + co;
         float v = acc[i][j][r] * ws;
         if (p.nsplit > 1) {
@@ -450,10 +466,11 @@ __device__ __forceinline__ void fsv_conv_igemm_body(const ConvP& p, const int bx
         } else {
           v = (v + bv) * p.scale;
           if (p.act == FSV_ACT_DLRELU) {        // data gradient handed straight to the layer below: times LeakyReLU'(its output)
-            v = p.res[opix * p.Cout + co] > 0.f ? v : 0.2f * v;
+            const float a = pre ? aux[i][r] : p.res[opix * p.Cout + co];
+            v = a > 0.f ? v : 0.2f * v;
           } else {
             v = fsv_act(v, p.act);
-            if (p.res) v += p.res[opix * p.Cout + co];
+            if (p.res) v += pre ? aux[i][r] : p.res[opix * p.Cout + co];
           }
           if constexpr (!(DBG & 32)) *dst = v; else if (v == 1.2345e30f) *dst = v;      // keeps the arithmetic alive
           if (p.stats) {
@@ -1703,6 +1720,10 @@ static inline void fsv_fill_convp(ConvP& p, const float* in, const float* wt, co
   p.Mz = per_sample ? OH * OW : N * OH * OW;
   p.nsplit = 1;
   p.stats = nullptr; p.stats_slots = 1; p.stats_ohw = 1;
+  {
+    const long long obytes = (long long)N * outH * outW * Cout * 4;
+    p.res_bytes = (res && obytes <= FSV_BUF_MAX_BYTES) ? obytes : 0;
+  }
 }
 
 static inline bool vec4_ok(int cin) { return (cin & 3) == 0; }

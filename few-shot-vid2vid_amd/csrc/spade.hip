@@ -48,6 +48,9 @@ struct SpadeP {
   // column-sum pass over the [P][2C] tensors disappears
   double* dbsum;
   long long db_zstride[FSV_SP_MAXMAPS];
+  int dbg;                // FSV_SPADE_DBG (in-box experiments only; 0 in production): 1 no output stores, 2 no x loads, 4 no dh loads
+  int db_slots;           // power of two: pixel tile t adds into copy t % db_slots of the buffer (db_slot_stride doubles apart)
+  long long db_slot_stride;
   int W, up;              // up = 1: x is the HALF-resolution tensor [N][H/2][W/2][C] and is read through the nearest-x2
                           // up-sampling index (generator.py:124 folded into this kernel: the up-sampled tensor is never written)
 };
@@ -75,15 +78,26 @@ __device__ __forceinline__ long long fsv_sp_xpix(const SpadeP& p, int z, int m) 
 // MFMAs (one barrier per chunk).  A image [BM rows][8 quads], quad q of row r in slot q ^ ((r >> 1) & 7): ds_write_b128 /
 // ds_read_b128 (two reads feed the four k steps of a k-group), B images [32 k][BN] as they lie in HBM.  The modulation of a
 // map (registers only) runs when its last chunk has been multiplied.
+// Pixel tiles (round 4): a workgroup walks the tiles blockIdx.x, + gridDim.x, ... of its channel tile, and the chunk sequence runs
+// ACROSS tiles - the first chunk of the next tile is loaded and stored behind the last MFMAs of this one, x of the next tile is
+// requested as soon as the first modulation has consumed this tile's, the per-channel constants (statistics, gamma / beta biases)
+// are loaded once.  At the full-resolution levels a tile is ONE chunk: with a workgroup per tile nothing overlapped - kernel
+// arguments, one load round trip, four MFMAs, a bias round trip, stores; 6 us per workgroup, 60 us for 17 us worth of traffic at
+// 512 K pixels (profiles/r04_notes.md).  The host launches as many workgroups as stay resident (fsv_sp_grid_x).
 // F16 (the `--amp` path): the gamma / beta GEMMs on v_mfma_f32_32x32x16_f16 - the label maps arrive as IEEE half ([N][HW][Ch] halves),
 // the weights as the N-major half operand of fsv_spade_prep_h (wcat_h [2C][Kh], K contiguous: p.wg / p.wb point into it, Kh =
 // ceil32(Ch) halves per row; p.ldw unused), both tiles are [rows][32 k] halves (64-byte rows, the four 16-byte slots XOR-swizzled by (row >> 2) & 3: conflict-free
 // ds_read_b128 fragments, csrc/conv_np.hip) staged through registers as 16-byte vectors; accumulation, normalisation, modulation and
 // the backward chain stay fp32.  At the deep levels (512 ... 2048 pixels, Ch up to 1024) the fp32 form is MFMA-latency bound - 128
 // workgroups, 32 chunks of 32 fp32 MFMAs each: 61 us for 4 GFLOP - which this removes.
-template <int BM, int BN, int WM, int WN, int NS, bool BWD, bool F16 = false>
-__global__ __launch_bounds__(256, 2) void fsv_spade_mod_kernel(SpadeP p) {
+template <int BM, int BN, int WM, int WN, int NS, bool BWD, bool F16 = false, int NM = FSV_SP_MAXMAPS>
+__global__ __launch_bounds__(256, (NS == 2 || (BWD && NM > 1)) ? 2 : (BWD || !F16 || BM == 128) ? 3 : 4) void fsv_spade_mod_kernel(SpadeP p) {
   constexpr int BK = FSV_SP_BK;
+  // NM: the most maps this instantiation handles (the backward twin keeps g_k and o_k of every map in registers: 32 per map;
+  // the one-map form - every layer without warp_ref / spade_combine - has room to keep the next tile's x and this tile's dh in
+  // flight across the chunks, the three-map form requests them late)
+  constexpr bool XEARLY = NS == 1 && !BWD;
+  constexpr bool DVEARLY = false;
   constexpr int TM = BM / (WM * 32), TN = BN / (WN * 32);
   constexpr int RPA = 256 / 8, NPA = BM / RPA;          // A: 8 work-items per row (one quad of 4 k each)
   constexpr int QB = BN / 4, RPB = 256 / QB, NPB = BK / RPB;
@@ -93,19 +107,33 @@ __global__ __launch_bounds__(256, 2) void fsv_spade_mod_kernel(SpadeP p) {
   static_assert(NPA >= 1 && NPB >= 1 && NPA * RPA == BM && NPB * RPB == BK, "tile");
   static_assert(!BWD || NS == 1, "the backward twin handles one site");
   static_assert(!F16 || NS == 1, "the half form handles one site");
+  static_assert(FSV_SP_MAXMAPS == 3, "advance_loader selects among three maps");
   __shared__ __attribute__((aligned(16))) float smem[(F16 ? 1 : 2) * (A_ST + NB * B_ST)];
   float* const As = smem;
   float* const Bs = smem + 2 * A_ST;
   typedef _Float16 h16;
   typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
+  typedef _Float16 h16x2 __attribute__((ext_vector_type(2)));
   h16* const Ah = reinterpret_cast<h16*>(smem);                  // F16: [2 buffers][BM][32] halves, then [2][NB][BN][32]
   h16* const Bh = Ah + 2 * A_ST;
   constexpr int HNPA = (BM + 63) / 64, HNPB = (BN + 63) / 64;    // 16-byte vectors per work-item: 4 per 64-byte row, 64 rows per pass
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int hr0 = tid >> 2, hs = tid & 3;
+  // Half tensors are written two channels per work-item: in the MFMA C / D layout a lane holds ONE channel of consecutive pixels,
+  // its neighbour (lane ^ 1) the next channel of the same pixels - for a pair of pixels (p0, p1) the even lane stores (c, c + 1)
+  // of p0 and the odd lane (c - 1, c) of p1, one exchange each way.  (2-byte stores: the backward twin with half d(gamma|beta) took
+  // 219 us where the same launch writing twice the bytes as fp32 took 134.)  e0 / e1: element index of this lane's own value.
+  auto store_pair_h = [&](h16* base, int e0, int e1, float v0, float v1, bool ok0, bool ok1) {
+    const float n0 = __shfl_xor(v0, 1), n1 = __shfl_xor(v1, 1);
+    const bool odd = (lane & 1) != 0;
+    h16x2 pk;
+    pk.x = (h16)(odd ? n1 : v0); pk.y = (h16)(odd ? v1 : n0);
+    if (odd ? ok1 : ok0) *reinterpret_cast<h16x2*>(base + (odd ? e1 - 1 : e0)) = pk;
+  };
   const int wm = wave / WN, wn = wave % WN;
   const int z = blockIdx.z;
-  const int bm0 = blockIdx.x * BM, bn0 = blockIdx.y * BN;
+  const int bn0 = blockIdx.y * BN;
+  const int tile_step = gridDim.x * BM;   // a workgroup walks the pixel tiles blockIdx.x, + gridDim.x, ... (see the header comment)
   const int lrow = lane & 31, lk = lane >> 5;
   const int kq = tid & 7, ar0 = tid >> 3;
   const int bq = tid % QB, br0 = tid / QB;
@@ -113,22 +141,19 @@ __global__ __launch_bounds__(256, 2) void fsv_spade_mod_kernel(SpadeP p) {
   const bool bcol_ok = bcol < p.C;        // columns >= C only feed output channels that are never stored
   const long long pix0 = (long long)z * p.HW;
 
-  // ---- x (raw) into registers first: consumed by the first modulation, i.e. behind the first map's MFMAs ----------------------
+  // ---- x (raw) of one pixel tile into registers: consumed by the tile's first modulation ------------------------------------------
   // A lane's 16 rows are four runs of four consecutive pixels (D layout: row = (r & 3) + 8 * (r >> 2) + 4 * lk) that start at a
   // multiple of 4: with W % 4 == 0 a run lies in one image row, so the up-sampling index costs one division per run.
   float xv[TM][TN][16];
-  float mu[TN], rs[TN];
-  {
-    const float* mean = p.mean + z * p.stat_bstride;
-    const float* rstd = p.rstd + z * p.stat_bstride;
-    const long long xpix_n = p.up ? (p.HW >> 2) : p.HW;
-    const fsv_buf xbuf = fsv_make_buf(p.x + (long long)z * xpix_n * p.C, xpix_n * p.C * 4);
-    const bool runs = (p.W & 3) == 0;
+  const long long xpix_n = p.up ? (p.HW >> 2) : p.HW;
+  const fsv_buf xbuf = fsv_make_buf(p.x + (long long)z * xpix_n * p.C, xpix_n * p.C * 4);
+  const bool runs = (p.W & 3) == 0;
+  auto load_x = [&](int tb0) {
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        const int m0 = bm0 + wm * (TM * 32) + i * 32 + 8 * q + 4 * lk;
+        const int m0 = tb0 + wm * (TM * 32) + i * 32 + 8 * q + 4 * lk;
         int src[4];
         if (!p.up) {
 #pragma unroll
@@ -150,38 +175,61 @@ __global__ __launch_bounds__(256, 2) void fsv_spade_mod_kernel(SpadeP p) {
           const bool cok = c < p.C;
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
-            const bool ok = cok & (m0 + e < p.HW);
+            const bool ok = cok & (m0 + e < p.HW) & !(p.dbg & 2);
             xv[i][j][4 * q + e] = fsv_buf_load1(xbuf, ok ? (unsigned)((src[e] * p.C + c) * 4) : FSV_BUF_OOB);
           }
         }
       }
+  };
+  // per-channel constants of this workgroup's channel tile, once: statistics and the gamma / beta biases of every map (a bias
+  // loaded where it is used costs a full memory latency between the last MFMA of a map and its modulation)
+  constexpr bool BIAS_REGS = NS == 1;     // (the two-site form has no registers to spare: it loads the biases where it uses them)
+  float mu[TN], rs[TN], bgv[BIAS_REGS ? NS : 1][NM][TN], bbv[BIAS_REGS ? NS : 1][NM][TN];
+  {
+    const float* mean = p.mean + z * p.stat_bstride;
+    const float* rstd = p.rstd + z * p.stat_bstride;
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
       const int c = bn0 + wn * (TN * 32) + j * 32 + lrow;
       const bool cok = c < p.C;
       mu[j] = cok ? mean[c] : 0.f; rs[j] = cok ? rstd[c] : 0.f;
+#pragma unroll
+      for (int s = 0; s < (BIAS_REGS ? NS : 0); ++s)
+#pragma unroll
+        for (int k = 0; k < NM; ++k) {
+          const bool on = cok & (k < p.nmaps);
+          bgv[s][k][j] = on ? (p.bg[s][k] + z * p.b_bstride[s][k])[c] : 0.f;
+          bbv[s][k][j] = on ? (p.bb[s][k] + z * p.b_bstride[s][k])[c] : 0.f;
+        }
     }
   }
 
-  // ---- the flat chunk sequence -------------------------------------------------------------------------------------------------
+  // ---- the flat chunk sequence: (pixel tile, map, K chunk) ---------------------------------------------------------------------
   int nch[FSV_SP_MAXMAPS], total = 0;
 #pragma unroll
   for (int k = 0; k < FSV_SP_MAXMAPS; ++k) { nch[k] = (k < p.nmaps) ? (p.ch[k] + BK - 1) / BK : 0; total += nch[k]; }
-  // loader state: (map lk_, chunk lc_) of the NEXT chunk to load
-  int ld_k = 0, ld_c = 0;
+  // loader state: (tile ld_bm0, map ld_k, chunk ld_c) of the NEXT chunk to load; past the last tile every row is out of range
+  int ld_k = 0, ld_c = 0, ld_bm0 = blockIdx.x * BM;
+  auto advance_loader = [&]() {
+    ++ld_c;
+    const int n_k = ld_k == 0 ? nch[0] : (ld_k == 1 ? nch[1] : nch[2]);
+    if (ld_c >= n_k) {
+      ld_c = 0; ++ld_k;
+      if (ld_k >= p.nmaps) { ld_k = 0; ld_bm0 += tile_step; }
+    }
+  };
   float4 areg[NPA], breg[NB][NPB];
   float4 hareg[HNPA], hbreg[NB][HNPB];
   auto issue_loads_h = [&]() {
-    const int k = ld_k < p.nmaps ? ld_k : 0;
+    const int k = ld_k;
     const int Ch = p.ch[k];
     const fsv_buf abuf = fsv_make_buf(reinterpret_cast<const h16*>(p.map[k]) + pix0 * Ch, (long long)p.HW * Ch * 2);
     const int kk = ld_c * BK + hs * 8;
-    const bool live = ld_k < p.nmaps;
 #pragma unroll
     for (int i = 0; i < HNPA; ++i) {
       const int r = hr0 + i * 64;
-      const int m = bm0 + r;
-      const bool ok = live & (kk < Ch) & (m < p.HW) & (r < BM);
+      const int m = ld_bm0 + r;
+      const bool ok = (kk < Ch) & (m < p.HW) & (r < BM);
       hareg[i] = fsv_buf_load4(abuf, ok ? (unsigned)((m * Ch + kk) * 2) : FSV_BUF_OOB);
     }
     const int ldk = (Ch + 31) & ~31;                              // row length Kh of this map's operand
@@ -194,12 +242,11 @@ __global__ __launch_bounds__(256, 2) void fsv_spade_mod_kernel(SpadeP p) {
       for (int i = 0; i < HNPB; ++i) {
         const int r = hr0 + i * 64;
         const int c = bn0 + r;
-        const bool ok = live & (c < p.C) & (r < BN);
+        const bool ok = (ld_bm0 < p.HW) & (c < p.C) & (r < BN);
         hbreg[q][i] = fsv_buf_load4(wbuf, ok ? (unsigned)((c * ldk + kk) * 2) : FSV_BUF_OOB);
       }
     }
-    ++ld_c;
-    if (ld_k < p.nmaps && ld_c >= nch[ld_k]) { ld_c = 0; ++ld_k; }
+    advance_loader();
   };
   auto store_chunk_h = [&](int buf) {
     h16* a_dst = Ah + buf * A_ST;
@@ -219,15 +266,15 @@ __global__ __launch_bounds__(256, 2) void fsv_spade_mod_kernel(SpadeP p) {
   };
   auto issue_loads = [&]() {
     // uniform: descriptors of the loader's current map
-    const int k = ld_k < p.nmaps ? ld_k : 0;
+    const int k = ld_k;
     const int Ch = p.ch[k];
     const fsv_buf abuf = fsv_make_buf(p.map[k] + pix0 * Ch, (long long)p.HW * Ch * 4);
     const int kk = ld_c * BK + kq * 4;
-    const bool live = ld_k < p.nmaps;
+    const bool live = ld_bm0 < p.HW;
 #pragma unroll
     for (int i = 0; i < NPA; ++i) {
-      const int m = bm0 + ar0 + i * RPA;
-      const bool ok = live & (kk < Ch) & (m < p.HW);
+      const int m = ld_bm0 + ar0 + i * RPA;
+      const bool ok = (kk < Ch) & (m < p.HW);
       areg[i] = fsv_buf_load4(abuf, ok ? (unsigned)((m * Ch + kk) * 4) : FSV_BUF_OOB);
     }
     const long long wbytes = (long long)((Ch + BK - 1) / BK) * BK * p.ldw * 4;
@@ -243,9 +290,7 @@ __global__ __launch_bounds__(256, 2) void fsv_spade_mod_kernel(SpadeP p) {
         breg[2 * s + 1][i] = fsv_buf_load4(bbuf, off);
       }
     }
-    // advance to the chunk after this one
-    ++ld_c;
-    if (ld_k < p.nmaps && ld_c >= nch[ld_k]) { ld_c = 0; ++ld_k; }
+    advance_loader();
   };
   auto store_chunk = [&](int buf) {
     float* a_dst = As + buf * A_ST;
@@ -271,7 +316,7 @@ __global__ __launch_bounds__(256, 2) void fsv_spade_mod_kernel(SpadeP p) {
   // running value of the normalised + modulated activation per site, in MFMA C/D layout
   f32x16 outv[NS][TM][TN];
   // backward twin: g_k and o_k of every map (BWD only; dead code otherwise)
-  f32x16 keep_g[BWD ? FSV_SP_MAXMAPS : 1][TM][TN], keep_o[BWD ? FSV_SP_MAXMAPS : 1][TM][TN];
+  f32x16 keep_g[BWD ? NM : 1][TM][TN], keep_o[BWD ? NM : 1][TM][TN];
   f32x16 acc[NB][TM][TN];
 #pragma unroll
   for (int q = 0; q < NB; ++q)
@@ -325,218 +370,285 @@ __global__ __launch_bounds__(256, 2) void fsv_spade_mod_kernel(SpadeP p) {
   auto modulate = [&](int k, bool first) {
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
-      const float* bg = p.bg[s][k] + z * p.b_bstride[s][k];
-      const float* bb = p.bb[s][k] + z * p.b_bstride[s][k];
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
-        const int c = bn0 + wn * (TN * 32) + j * 32 + lrow;
-        const float bgv = (c < p.C) ? bg[c] : 0.f, bbv = (c < p.C) ? bb[c] : 0.f;
+        if constexpr (BIAS_REGS) {
 #pragma unroll
-        for (int i = 0; i < TM; ++i)
+          for (int i = 0; i < TM; ++i)
 #pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const float o = first ? (xv[i][j][r] - mu[j]) * rs[j] : outv[s][i][j][r];
-            const float gk = acc[2 * s][i][j][r] + bgv;
-            if constexpr (BWD) { keep_g[k][i][j][r] = gk; keep_o[k][i][j][r] = o; }
-            outv[s][i][j][r] = o * (1.f + gk) + (acc[2 * s + 1][i][j][r] + bbv);
-            acc[2 * s][i][j][r] = 0.f; acc[2 * s + 1][i][j][r] = 0.f;
-          }
+            for (int r = 0; r < 16; ++r) {
+              const float o = first ? (xv[i][j][r] - mu[j]) * rs[j] : outv[s][i][j][r];
+              const float gk = acc[2 * s][i][j][r] + bgv[s][k][j];
+              if constexpr (BWD) { keep_g[k][i][j][r] = gk; keep_o[k][i][j][r] = o; }
+              outv[s][i][j][r] = o * (1.f + gk) + (acc[2 * s + 1][i][j][r] + bbv[s][k][j]);
+              acc[2 * s][i][j][r] = 0.f; acc[2 * s + 1][i][j][r] = 0.f;
+            }
+        } else {
+          const int c = bn0 + wn * (TN * 32) + j * 32 + lrow;
+          const float bg_l = (c < p.C) ? (p.bg[s][k] + z * p.b_bstride[s][k])[c] : 0.f;
+          const float bb_l = (c < p.C) ? (p.bb[s][k] + z * p.b_bstride[s][k])[c] : 0.f;
+#pragma unroll
+          for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const float o = first ? (xv[i][j][r] - mu[j]) * rs[j] : outv[s][i][j][r];
+              const float gk = acc[2 * s][i][j][r] + bg_l;
+              outv[s][i][j][r] = o * (1.f + gk) + (acc[2 * s + 1][i][j][r] + bb_l);
+              acc[2 * s][i][j][r] = 0.f; acc[2 * s + 1][i][j][r] = 0.f;
+            }
+        }
       }
     }
   };
 
-  // The backward twin normalises x up front (its 96 registers of g_k / o_k leave no room to carry the raw values through the
-  // loop); the forward forms leave x in flight until the first modulation.
-  constexpr bool XFIRST = true;
-  if constexpr (!XFIRST) {
+  int buf = 0;
+  // one chunk: loads of the NEXT chunk of the flat sequence (whatever map and pixel tile it belongs to) at the top, MFMAs of
+  // this one, the loaded registers stored into the other LDS buffer behind three quarters of them
+  auto chunk = [&]() {
+    if constexpr (F16) {
+      issue_loads_h();
+      const h16* a_src = Ah + buf * A_ST;
+      const h16* b_src = Bh + buf * (NB * B_ST);
+      h16x8 fa[2][TM], fb[2][NB][TN];
 #pragma unroll
-    for (int j = 0; j < TN; ++j)
+      for (int st = 0; st < 2; ++st) {
 #pragma unroll
-      for (int i = 0; i < TM; ++i)
+        for (int i = 0; i < TM; ++i) {
+          const int r = wm * (TM * 32) + i * 32 + lrow;
+          fa[st][i] = *reinterpret_cast<const h16x8*>(&a_src[r * BK + ((((2 * st + lk) ^ (r >> 2)) & 3) << 3)]);
+        }
 #pragma unroll
-        for (int r = 0; r < 16; ++r) outv[0][i][j][r] = (xv[i][j][r] - mu[j]) * rs[j];
-  }
-  if (total > 0) {
-    if constexpr (F16) { issue_loads_h(); store_chunk_h(0); } else { issue_loads(); store_chunk(0); }
-    __syncthreads();
-    int buf = 0;
-    // one chunk: loads of the NEXT chunk of the flat sequence (whatever map it belongs to) at the top, MFMAs of this one,
-    // the loaded registers stored into the other LDS buffer behind three quarters of them
-    auto chunk = [&]() {
-      if constexpr (F16) {
-        issue_loads_h();
-        const h16* a_src = Ah + buf * A_ST;
-        const h16* b_src = Bh + buf * (NB * B_ST);
-        h16x8 fa[2][TM], fb[2][NB][TN];
+        for (int q = 0; q < NB; ++q)
 #pragma unroll
-        for (int st = 0; st < 2; ++st) {
-#pragma unroll
-          for (int i = 0; i < TM; ++i) {
-            const int r = wm * (TM * 32) + i * 32 + lrow;
-            fa[st][i] = *reinterpret_cast<const h16x8*>(&a_src[r * BK + ((((2 * st + lk) ^ (r >> 2)) & 3) << 3)]);
+          for (int j = 0; j < TN; ++j) {
+            const int r = wn * (TN * 32) + j * 32 + lrow;
+            fb[st][q][j] = *reinterpret_cast<const h16x8*>(&b_src[q * B_ST + r * BK + ((((2 * st + lk) ^ (r >> 2)) & 3) << 3)]);
           }
-#pragma unroll
-          for (int q = 0; q < NB; ++q)
-#pragma unroll
-            for (int j = 0; j < TN; ++j) {
-              const int r = wn * (TN * 32) + j * 32 + lrow;
-              fb[st][q][j] = *reinterpret_cast<const h16x8*>(&b_src[q * B_ST + r * BK + ((((2 * st + lk) ^ (r >> 2)) & 3) << 3)]);
-            }
-        }
-#pragma unroll
-        for (int st = 0; st < 2; ++st)
-#pragma unroll
-          for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int q = 0; q < NB; ++q)
-#pragma unroll
-              for (int j = 0; j < TN; ++j)
-                acc[q][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[st][i], fb[st][q][j], acc[q][i][j], 0, 0, 0);
-        store_chunk_h(buf ^ 1);
-        __syncthreads();
-        buf ^= 1;
-        return;
       }
-      issue_loads();                      // past the end: every lane is out of range -> zeros, never used
-      const float* a_src = As + buf * A_ST;
-      const float* b_src = Bs + buf * (NB * B_ST);
-      if constexpr (NS == 1 && !BWD) {
-        // fragments one k-group ahead of their MFMAs (two register sets)
-        float2 fa[2][2][TM];
-        float fb[2][4][NB][TN];
-        read_group(a_src, b_src, 0, fa[0], fb[0]);
-        FSV_SCHED_FENCE();
-        read_group(a_src, b_src, 1, fa[1], fb[1]);
-        FSV_SCHED_FENCE();
-        mma_group(fa[0], fb[0]);
-        FSV_SCHED_FENCE();
-        read_group(a_src, b_src, 2, fa[0], fb[0]);
-        FSV_SCHED_FENCE();
-        mma_group(fa[1], fb[1]);
-        FSV_SCHED_FENCE();
-        read_group(a_src, b_src, 3, fa[1], fb[1]);
-        FSV_SCHED_FENCE();
-        mma_group(fa[0], fb[0]);
-        FSV_SCHED_FENCE();
-        store_chunk(buf ^ 1);
-        FSV_SCHED_FENCE();
-        mma_group(fa[1], fb[1]);
-      } else {
-        // the two-site / backward forms carry 64 - 144 more live registers (four accumulators, or g_k / o_k of three maps):
-        // one fragment set, two workgroups per CU cover each other's LDS latency
-        float2 fa[2][TM];
-        float fb[4][NB][TN];
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          read_group(a_src, b_src, g, fa, fb);
-          mma_group(fa, fb);
-          if (g == 2) { FSV_SCHED_FENCE(); store_chunk(buf ^ 1); FSV_SCHED_FENCE(); }
-        }
-      }
-      __syncthreads();
-      buf ^= 1;
-    };
-    // per map: its chunks, then its modulation (registers only; the next map's first chunk is already in LDS)
-#pragma unroll
-    for (int k = 0; k < FSV_SP_MAXMAPS; ++k) {
-      if (k < p.nmaps) {
-#pragma unroll 1
-        for (int c = 0; c < nch[k]; ++c) chunk();
-        modulate(k, XFIRST && k == 0);
-      }
-    }
-  } else if constexpr (XFIRST) {
-#pragma unroll
-    for (int s = 0; s < NS; ++s)
-#pragma unroll
-      for (int j = 0; j < TN; ++j)
+      for (int st = 0; st < 2; ++st)
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
-          for (int r = 0; r < 16; ++r) outv[s][i][j][r] = (xv[i][j][r] - mu[j]) * rs[j];
-  }
+          for (int q = 0; q < NB; ++q)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+              acc[q][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[st][i], fb[st][q][j], acc[q][i][j], 0, 0, 0);
+      store_chunk_h(buf ^ 1);
+      __syncthreads();
+      buf ^= 1;
+      return;
+    }
+    issue_loads();                      // past the end: every lane is out of range -> zeros, never used
+    const float* a_src = As + buf * A_ST;
+    const float* b_src = Bs + buf * (NB * B_ST);
+    if constexpr (NS == 1 && !BWD) {
+      // fragments one k-group ahead of their MFMAs (two register sets)
+      float2 fa[2][2][TM];
+      float fb[2][4][NB][TN];
+      read_group(a_src, b_src, 0, fa[0], fb[0]);
+      FSV_SCHED_FENCE();
+      read_group(a_src, b_src, 1, fa[1], fb[1]);
+      FSV_SCHED_FENCE();
+      mma_group(fa[0], fb[0]);
+      FSV_SCHED_FENCE();
+      read_group(a_src, b_src, 2, fa[0], fb[0]);
+      FSV_SCHED_FENCE();
+      mma_group(fa[1], fb[1]);
+      FSV_SCHED_FENCE();
+      read_group(a_src, b_src, 3, fa[1], fb[1]);
+      FSV_SCHED_FENCE();
+      mma_group(fa[0], fb[0]);
+      FSV_SCHED_FENCE();
+      store_chunk(buf ^ 1);
+      FSV_SCHED_FENCE();
+      mma_group(fa[1], fb[1]);
+    } else {
+      // the two-site / backward forms carry 64 - 144 more live registers (four accumulators, or g_k / o_k of three maps):
+      // one fragment set, two workgroups per CU cover each other's LDS latency
+      float2 fa[2][TM];
+      float fb[4][NB][TN];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        read_group(a_src, b_src, g, fa, fb);
+        mma_group(fa, fb);
+        if (g == 2) { FSV_SCHED_FENCE(); store_chunk(buf ^ 1); FSV_SCHED_FENCE(); }
+      }
+    }
+    __syncthreads();
+    buf ^= 1;
+  };
 
-  // epilogues: per-sample base pointers are uniform (scalar registers), the per-lane part is a 32-bit element offset (the host
-  // checked that one sample of every tensor stays below 2^31 bytes)
-  if constexpr (BWD) {
-    const float* dh_z = p.dh + pix0 * p.C;
-    float* dx_z = p.dxhat + pix0 * p.C;
-    float* dg_z[FSV_SP_MAXMAPS];
+  // ---- the workgroup's pixel tiles ---------------------------------------------------------------------------------------------
+  load_x(blockIdx.x * BM);
+  if (total > 0) {
+    if constexpr (F16) { issue_loads_h(); store_chunk_h(0); } else { issue_loads(); store_chunk(0); }
+    __syncthreads();
+  }
+  const bool dh_half = (p.h_half & 1) != 0;
+  const fsv_buf dhbuf = !BWD ? fsv_make_buf(nullptr, 0)
+                             : (dh_half ? fsv_make_buf(reinterpret_cast<const _Float16*>(p.dh) + pix0 * p.C, (long long)p.HW * p.C * 2)
+                                        : fsv_make_buf(p.dh + pix0 * p.C, (long long)p.HW * p.C * 4));
+#pragma unroll 1
+  for (int bm0 = blockIdx.x * BM; bm0 < p.HW; bm0 += tile_step) {
+    // backward twin: this tile's dh values, requested before its chunks when there is room (the stores of the epilogue may alias
+    // p.dh as far as the compiler can tell: a load inside the store loop would wait for its full latency once per element)
+    float dv[BWD ? TM : 1][BWD ? TN : 1][16];
+    auto load_dv = [&]() {
+      if constexpr (BWD) {
 #pragma unroll
-    for (int k = 0; k < FSV_SP_MAXMAPS; ++k) dg_z[k] = (k < p.nmaps) ? p.dgb[k] + pix0 * 2 * p.C : nullptr;
+        for (int j = 0; j < TN; ++j) {
+          const int c = bn0 + wn * (TN * 32) + j * 32 + lrow;
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-      const int c = bn0 + wn * (TN * 32) + j * 32 + lrow;
-      const bool cok = c < p.C;
-      float sg[FSV_SP_MAXMAPS], sb[FSV_SP_MAXMAPS];
+          for (int i = 0; i < TM; ++i) {
+            if (dh_half) {          // uniform.  One dword = channels (c & ~1, + 1) of one pixel; the lane pair shares its two loads
 #pragma unroll
-      for (int k = 0; k < FSV_SP_MAXMAPS; ++k) { sg[k] = 0.f; sb[k] = 0.f; }
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int row = (r & 3) + 8 * (r >> 2) + 4 * lk;
-          const int m = bm0 + wm * (TM * 32) + i * 32 + row;
-          if (m >= p.HW || !cok) continue;
-          const int e = m * p.C + c;
-          float d = (p.h_half & 1) ? (float)reinterpret_cast<const _Float16*>(p.dh)[pix0 * p.C + e] : dh_z[e];
-          if (p.act[0] == FSV_ACT_LRELU) d = (outv[0][i][j][r] > 0.f) ? d : 0.2f * d;
-#pragma unroll
-          for (int k = FSV_SP_MAXMAPS - 1; k >= 0; --k) {
-            if (k < p.nmaps) {
-              float* dg = dg_z[k];
-              const int e2 = m * 2 * p.C + c;
-              const float dgam = d * keep_o[k][i][j][r];
-              if (p.h_half & 2) {
-                _Float16* dgh = reinterpret_cast<_Float16*>(p.dgb[k]) + pix0 * 2 * p.C;
-                dgh[e2 + p.C] = (_Float16)d;
-                dgh[e2] = (_Float16)dgam;
-              } else {
-                dg[e2 + p.C] = d;
-                dg[e2] = dgam;
+              for (int r = 0; r < 16; r += 2) {
+                const int row = (r & 3) + 8 * (r >> 2) + 4 * lk;
+                const int m = bm0 + wm * (TM * 32) + i * 32 + row + (lane & 1);        // even lane: pixel r, odd lane: pixel r + 1
+                const bool ok = (c < p.C) & (m < p.HW) & !(p.dbg & 4);
+                const float w = fsv_buf_load1(dhbuf, ok ? (unsigned)(m * p.C + (c & ~1)) * 2u : FSV_BUF_OOB);
+                const float nw = __shfl_xor(w, 1);
+                const h16x2 mine = __builtin_bit_cast(h16x2, w), theirs = __builtin_bit_cast(h16x2, nw);
+                dv[i][j][r] = (lane & 1) ? (float)theirs.y : (float)mine.x;
+                dv[i][j][r + 1] = (lane & 1) ? (float)mine.y : (float)theirs.x;
               }
-              sb[k] += d; sg[k] += dgam;
-              d = d * (1.f + keep_g[k][i][j][r]);
-            }
-          }
-          dx_z[e] = d;
-        }
-      if (p.dbsum) {               // uniform: bias gradients from here (the two half-waves hold the same 32 channels)
+            } else {
 #pragma unroll
-        for (int k = 0; k < FSV_SP_MAXMAPS; ++k) {
-          if (k < p.nmaps) {
-            const float g2 = sg[k] + __shfl_xor(sg[k], 32), b2 = sb[k] + __shfl_xor(sb[k], 32);
-            if (lk == 0 && cok) {
-              double* dst = p.dbsum + z * p.db_zstride[k] + (long long)k * 2 * p.C;
-              atomicAdd(dst + c, (double)g2);
-              atomicAdd(dst + p.C + c, (double)b2);
+              for (int r = 0; r < 16; ++r) {
+                const int row = (r & 3) + 8 * (r >> 2) + 4 * lk;
+                const int m = bm0 + wm * (TM * 32) + i * 32 + row;
+                const bool ok = (c < p.C) & (m < p.HW) & !(p.dbg & 4);
+                dv[i][j][r] = fsv_buf_load1(dhbuf, ok ? (unsigned)(m * p.C + c) * 4u : FSV_BUF_OOB);
+              }
             }
           }
         }
       }
+    };
+    if constexpr (DVEARLY) load_dv();
+    if (total > 0) {
+      // per map: its chunks, then its modulation (registers only; the next chunk - of the next map or of the next pixel tile -
+      // is already in LDS); x of the next tile is requested as soon as the first modulation has consumed this tile's
+#pragma unroll
+      for (int k = 0; k < NM; ++k) {
+        if (k < p.nmaps) {
+#pragma unroll 1
+          for (int c = 0; c < nch[k]; ++c) chunk();
+          modulate(k, k == 0);
+          if constexpr (XEARLY) { if (k == 0) load_x(bm0 + tile_step); }
+        }
+      }
+    } else {
+#pragma unroll
+      for (int s = 0; s < NS; ++s)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+          for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) outv[s][i][j][r] = (xv[i][j][r] - mu[j]) * rs[j];
+      if constexpr (XEARLY) load_x(bm0 + tile_step);
     }
-    return;
-  }
+    if constexpr (!DVEARLY) load_dv();
 
+    // epilogues: per-sample base pointers are uniform (scalar registers), the per-lane part is a 32-bit element offset (the host
+    // checked that one sample of every tensor stays below 2^31 bytes)
+    if constexpr (BWD) {
+      float* dx_z = p.dxhat + pix0 * p.C;
+      float* dg_z[FSV_SP_MAXMAPS];
 #pragma unroll
-  for (int s = 0; s < NS; ++s) {
-    float* h_z = p.h[s] + pix0 * p.C;
+      for (int k = 0; k < FSV_SP_MAXMAPS; ++k) dg_z[k] = (k < p.nmaps) ? p.dgb[k] + pix0 * 2 * p.C : nullptr;
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-      const int c = bn0 + wn * (TN * 32) + j * 32 + lrow;
-      if (c >= p.C) continue;
+      for (int j = 0; j < TN; ++j) {
+        const int c = bn0 + wn * (TN * 32) + j * 32 + lrow;
+        const bool cok = c < p.C;
+        float sg[FSV_SP_MAXMAPS], sb[FSV_SP_MAXMAPS];
 #pragma unroll
-      for (int i = 0; i < TM; ++i)
+        for (int k = 0; k < FSV_SP_MAXMAPS; ++k) { sg[k] = 0.f; sb[k] = 0.f; }
+        const bool dg_half = (p.h_half & 2) != 0;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int row = (r & 3) + 8 * (r >> 2) + 4 * lk;
-          const int m = bm0 + wm * (TM * 32) + i * 32 + row;
-          if (m < p.HW) {
-            const float v = fsv_act(outv[s][i][j][r], p.act[s]);
-            if (p.h_half) reinterpret_cast<_Float16*>(p.h[s])[(pix0 + m) * p.C + c] = (_Float16)v; else h_z[m * p.C + c] = v;
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int r = 0; r < 16; r += 2) {
+            // two consecutive pixels at a time (the half stores pair them); every lane runs the arithmetic, the stores and the
+            // bias sums are predicated
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * lk;
+            const int m = bm0 + wm * (TM * 32) + i * 32 + row;
+            const bool ok0 = cok & (m < p.HW), ok1 = cok & (m + 1 < p.HW);
+            float d0 = dv[i][j][r], d1 = dv[i][j][r + 1];
+            if ((p.dbg & 1) && d0 != 1.2345e30f) { sb[0] += d0 * keep_o[0][i][j][r] + keep_g[0][i][j][r] + d1; continue; }
+            if (p.act[0] == FSV_ACT_LRELU) {
+              d0 = (outv[0][i][j][r] > 0.f) ? d0 : 0.2f * d0;
+              d1 = (outv[0][i][j][r + 1] > 0.f) ? d1 : 0.2f * d1;
+            }
+#pragma unroll
+            for (int k = NM - 1; k >= 0; --k) {
+              if (k < p.nmaps) {
+                const int e2 = m * 2 * p.C + c;
+                const float g0 = d0 * keep_o[k][i][j][r], g1 = d1 * keep_o[k][i][j][r + 1];
+                if (dg_half) {
+                  h16* dgh = reinterpret_cast<h16*>(p.dgb[k]) + pix0 * 2 * p.C;
+                  store_pair_h(dgh + p.C, e2, e2 + 2 * p.C, d0, d1, ok0, ok1);
+                  store_pair_h(dgh, e2, e2 + 2 * p.C, g0, g1, ok0, ok1);
+                } else {
+                  float* dg = dg_z[k];
+                  if (ok0) { dg[e2 + p.C] = d0; dg[e2] = g0; }
+                  if (ok1) { dg[e2 + 3 * p.C] = d1; dg[e2 + 2 * p.C] = g1; }
+                }
+                sb[k] += (ok0 ? d0 : 0.f) + (ok1 ? d1 : 0.f); sg[k] += (ok0 ? g0 : 0.f) + (ok1 ? g1 : 0.f);
+                d0 = d0 * (1.f + keep_g[k][i][j][r]); d1 = d1 * (1.f + keep_g[k][i][j][r + 1]);
+              }
+            }
+            if (ok0) dx_z[m * p.C + c] = d0;
+            if (ok1) dx_z[(m + 1) * p.C + c] = d1;
+          }
+        if (p.dbsum) {               // uniform: bias gradients from here (the two half-waves hold the same 32 channels)
+          // 2 * HW / 64 adds per address and sample would serialise in the L2 (measured + 120 us at 512 K pixels): the pixel tiles
+          // spread over db_slots copies of the buffer, which the caller sums
+          double* slot = p.dbsum + (long long)((bm0 / BM) & (p.db_slots - 1)) * p.db_slot_stride;
+#pragma unroll
+          for (int k = 0; k < NM; ++k) {
+            if (k < p.nmaps) {
+              const float g2 = sg[k] + __shfl_xor(sg[k], 32), b2 = sb[k] + __shfl_xor(sb[k], 32);
+              if (lk == 0 && cok) {
+                double* dst = slot + z * p.db_zstride[k] + (long long)k * 2 * p.C;
+                atomicAdd(dst + c, (double)g2);
+                atomicAdd(dst + p.C + c, (double)b2);
+              }
+            }
           }
         }
+      }
+    } else {
+#pragma unroll
+      for (int s = 0; s < NS; ++s) {
+        float* h_z = p.h[s] + pix0 * p.C;
+        h16* h_zh = reinterpret_cast<h16*>(p.h[s]) + pix0 * p.C;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          const int c = bn0 + wn * (TN * 32) + j * 32 + lrow;
+          const bool cok = c < p.C;
+#pragma unroll
+          for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; r += 2) {
+              const int row = (r & 3) + 8 * (r >> 2) + 4 * lk;
+              const int m = bm0 + wm * (TM * 32) + i * 32 + row;
+              const bool ok0 = cok & (m < p.HW), ok1 = cok & (m + 1 < p.HW);
+              const float v0 = fsv_act(outv[s][i][j][r], p.act[s]), v1 = fsv_act(outv[s][i][j][r + 1], p.act[s]);
+              if ((p.dbg & 1) && v0 != 1.2345e30f) continue;
+              if (NS == 1 && p.h_half) {          // (the two-site form has no half output)
+                store_pair_h(h_zh, m * p.C + c, (m + 1) * p.C + c, v0, v1, ok0, ok1);
+              } else {
+                if (ok0) h_z[m * p.C + c] = v0;
+                if (ok1) h_z[(m + 1) * p.C + c] = v1;
+              }
+            }
+        }
+      }
     }
+    if constexpr (!XEARLY) load_x(bm0 + tile_step);
   }
 }
 
@@ -685,9 +797,25 @@ static inline int fsv_sp_fill_common(SpadeP& p, const float* x, const float* mea
   p.W = up ? W : 1; p.up = up ? 1 : 0;
   p.dh = nullptr; p.dxhat = nullptr;
   p.h_half = 0;
-  p.dbsum = nullptr;
+  p.dbsum = nullptr; p.db_slots = 1; p.db_slot_stride = 0;
   for (int k = 0; k < FSV_SP_MAXMAPS; ++k) p.db_zstride[k] = 0;
+  {
+    const char* e = getenv("FSV_SPADE_DBG");
+    p.dbg = e ? atoi(e) : 0;
+  }
   return FSV_OK;
+}
+
+// pixel-tile workgroups of a launch: as many as stay resident at once (256 CUs x wgs_per_cu), each walking its share of the tiles
+static inline unsigned fsv_sp_grid_x(int ntiles, int gy, int n, int wgs_per_cu) {
+  const char* e = getenv("FSV_SPADE_WGS_PER_CU");           // in-box experiments; 0 = one workgroup per tile
+  if (e) wgs_per_cu = atoi(e);
+  if (wgs_per_cu <= 0) return (unsigned)ntiles;
+  long long cap = (256ll * wgs_per_cu) / ((long long)gy * n);
+  const char* m = getenv("FSV_SPADE_MAX_GX");               // tests: a multi-tile walk on a small map
+  if (m && atoi(m) > 0) cap = atoi(m);
+  if (cap < 1) cap = 1;
+  return (unsigned)(ntiles < cap ? ntiles : cap);
 }
 
 // maps/wg/wb/bg/bb: arrays of nmaps device pointers; ch / w_bstride / b_bstride: per-map ints / strides.
@@ -709,11 +837,13 @@ static int fsv_spade_mod_fwd_impl(const float* x, const float* mean, const float
       if (ch[k] & 7) return FSV_ERR_UNSUPPORTED;
   }
   if (C <= 32) {
-    dim3 g(fsv_cdiv(HW, 128), fsv_cdiv(C, 32), N);
+    const int gy = fsv_cdiv(C, 32);
+    dim3 g(fsv_sp_grid_x(fsv_cdiv(HW, 128), gy, N, 3), gy, N);
     if (f16) FSV_LAUNCH((fsv_spade_mod_kernel<128, 32, 4, 1, 1, false, true>), g, dim3(256), stream, p);
     else FSV_LAUNCH((fsv_spade_mod_kernel<128, 32, 4, 1, 1, false>), g, dim3(256), stream, p);
   } else {
-    dim3 g(fsv_cdiv(HW, 64), fsv_cdiv(C, 64), N);
+    const int gy = fsv_cdiv(C, 64);
+    dim3 g(fsv_sp_grid_x(fsv_cdiv(HW, 64), gy, N, f16 ? 4 : 3), gy, N);
     if (f16) FSV_LAUNCH((fsv_spade_mod_kernel<64, 64, 2, 2, 1, false, true>), g, dim3(256), stream, p);
     else FSV_LAUNCH((fsv_spade_mod_kernel<64, 64, 2, 2, 1, false>), g, dim3(256), stream, p);
   }
@@ -777,7 +907,7 @@ static int fsv_spade_mod_bwd_impl(const float* x, const float* mean, const float
                       const float* const* bg, const float* const* bb, const int* ch, const long long* w_bstride,
                       const long long* b_bstride, float* const* dgb, float* dxhat, int N, int HW, int C, int ldw,
                       long long stat_bstride, int act, int W, int up, int flags, double* dbsum, const long long* db_zstride,
-                      hipStream_t stream) {
+                      int db_slots, long long db_slot_stride, hipStream_t stream) {
   if (!dh || !dgb || !dxhat) return FSV_ERR_BAD_ARG;
   if (act != FSV_ACT_LRELU && act != FSV_ACT_NONE) return FSV_ERR_UNSUPPORTED;
   SpadeP p;
@@ -803,14 +933,21 @@ static int fsv_spade_mod_bwd_impl(const float* x, const float* mean, const float
       const long long e = (long long)(N - 1) * db_zstride[k] + (long long)(k + 1) * 2 * C;
       if (e > span) span = e;
     }
-    p.dbsum = dbsum;
-    (void)hipMemsetAsync(dbsum, 0, (size_t)span * sizeof(double), stream);
+    if (db_slots < 1 || (db_slots & (db_slots - 1)) || (db_slots > 1 && db_slot_stride < span)) return FSV_ERR_BAD_ARG;
+    p.dbsum = dbsum; p.db_slots = db_slots; p.db_slot_stride = db_slots > 1 ? db_slot_stride : 0;
+    (void)hipMemsetAsync(dbsum, 0, (size_t)((long long)(db_slots - 1) * p.db_slot_stride + span) * sizeof(double), stream);
   }
   // 64 x 64 tiles: every wave keeps g_k and o_k of up to three maps for a 32 x 32 sub-tile (96 + 48 accumulator registers),
   // which leaves room for several workgroups per CU
-  dim3 g(fsv_cdiv(HW, 64), fsv_cdiv(C, 64), N);
-  if (f16) FSV_LAUNCH((fsv_spade_mod_kernel<64, 64, 2, 2, 1, true, true>), g, dim3(256), stream, p);
-  else FSV_LAUNCH((fsv_spade_mod_kernel<64, 64, 2, 2, 1, true>), g, dim3(256), stream, p);
+  const int gy = fsv_cdiv(C, 64);
+  dim3 g(fsv_sp_grid_x(fsv_cdiv(HW, 64), gy, N, nmaps <= 1 ? 3 : 2), gy, N);
+  if (nmaps <= 1) {
+    if (f16) FSV_LAUNCH((fsv_spade_mod_kernel<64, 64, 2, 2, 1, true, true, 1>), g, dim3(256), stream, p);
+    else FSV_LAUNCH((fsv_spade_mod_kernel<64, 64, 2, 2, 1, true, false, 1>), g, dim3(256), stream, p);
+  } else {
+    if (f16) FSV_LAUNCH((fsv_spade_mod_kernel<64, 64, 2, 2, 1, true, true>), g, dim3(256), stream, p);
+    else FSV_LAUNCH((fsv_spade_mod_kernel<64, 64, 2, 2, 1, true>), g, dim3(256), stream, p);
+  }
   return fsv_check_launch();
 }
 
@@ -820,23 +957,25 @@ int fsv_spade_mod_bwd(const float* x, const float* mean, const float* rstd, cons
                       const long long* b_bstride, float* const* dgb, float* dxhat, int N, int HW, int C, int ldw,
                       long long stat_bstride, int act, int W, int up, hipStream_t stream) {
   return fsv_spade_mod_bwd_impl(x, mean, rstd, dh, nmaps, maps, wg, wb, bg, bb, ch, w_bstride, b_bstride, dgb, dxhat, N, HW, C, ldw,
-                                stat_bstride, act, W, up, 0, nullptr, nullptr, stream);
+                                stat_bstride, act, W, up, 0, nullptr, nullptr, 1, 0, stream);
 }
 
 // General form of the backward twin.  flags bit 0: dh is IEEE half (the gradient of a half h); bit 1: every d(gamma|beta) tensor is
 // written as half ([P][2C] halves: its consumers are the half-precision data / weight gradient GEMMs); bit 2: f16 GEMMs (maps / wg /
 // wb as in fsv_spade_mod_fwd_h).  dbsum (optional, any flags): the bias gradients from this launch - per-channel sums of
-// d(gamma|beta) added into dbsum + z * db_zstride[k] + k * 2C as doubles (zeroed here; db_zstride[k] = 0 sums map k over the batch).
+// d(gamma|beta) added into dbsum + z * db_zstride[k] + k * 2C as doubles (zeroed here; db_zstride[k] = 0 sums map k over the batch);
+// with db_slots > 1 (a power of two) pixel tile t adds into the copy at + (t % db_slots) * db_slot_stride and the caller sums the
+// copies - thousands of adds per address serialise in the L2 otherwise.
 int fsv_spade_mod_bwd_h(const float* x, const float* mean, const float* rstd, const void* dh,
                         int nmaps, const void* const* maps, const void* const* wg, const void* const* wb,
                         const float* const* bg, const float* const* bb, const int* ch, const long long* w_bstride,
                         const long long* b_bstride, void* const* dgb, float* dxhat, int N, int HW, int C, int ldw,
                         long long stat_bstride, int act, int W, int up, int flags, double* dbsum, const long long* db_zstride,
-                        hipStream_t stream) {
+                        int db_slots, long long db_slot_stride, hipStream_t stream) {
   return fsv_spade_mod_bwd_impl(x, mean, rstd, reinterpret_cast<const float*>(dh), nmaps, reinterpret_cast<const float* const*>(maps),
                                 reinterpret_cast<const float* const*>(wg), reinterpret_cast<const float* const*>(wb), bg, bb, ch,
                                 w_bstride, b_bstride, reinterpret_cast<float* const*>(dgb), dxhat, N, HW, C, ldw, stat_bstride, act, W,
-                                up, flags, dbsum, db_zstride, stream);
+                                up, flags, dbsum, db_zstride, db_slots, db_slot_stride, stream);
 }
 
 // half N-major operand of the f16 forms: wcat_h [B][2C][Kh] (Kh = ceil32(Ch) halves per row, zero padded): row j < C = gamma weights

@@ -907,7 +907,8 @@ def _spade_launch(a, b=None):
     n, hw, c, ldw, w, up = a['dims']
     chs = a['chs']
     if b is None:
-        with profile.scope('fsv_spade_mod_kernel', a['flops']):
+        with profile.scope('fsv_spade_mod_kernel' + (' P%d C%d K%s' % (n * hw, c, '+'.join(map(str, chs))) if profile.detail() else ''),
+                           a['flops']):
             if a.get('half'):
                 lib.call("fsv_spade_mod_fwd_h", lib.ptr(a['x']), lib.ptr(a['mean']), lib.ptr(a['rstd']), lib.ptr(a['h']), len(chs),
                          _pp(a['maps']), arr(a['wg']), arr(a['wb']), arr(a['bg']), arr(a['bb']), lib.int_array(chs + [0]),
@@ -1103,19 +1104,24 @@ class _SpadeFn(torch.autograd.Function):
             lib.check_device(x, dh, *maps)
             dbsum = None
             if f16 and nm:
-                dbsum = torch.empty((n, nm, 2 * c), dtype=torch.float64, device=x.device)
+                # (h w / 64 pixel tiles) x 2 waves add into every address: spread over copies beyond 512 adds per address
+                slots = int(_os.environ.get('FSV_SPADE_DB_SLOTS', '0'))          # (tests force the multi-copy form on small maps)
+                while slots < 64 and (slots < 1 or (h * w // 32) // slots > 512):
+                    slots = max(1, slots * 2)
+                dbsum = torch.empty((slots, n, nm, 2 * c), dtype=torch.float64, device=x.device)
                 zstr = [nm * 2 * c if ctx.per_sample[k] else 0 for k in range(nm)]
             # (labelled as the backward twin; FLOPs = the gamma / beta GEMMs it recomputes)
-            with profile.scope('fsv_spade_mod_kernel<bwd>', 2.0 * n * h * w * c * 2 * sum(chs)):
+            with profile.scope('fsv_spade_mod_kernel<bwd>' + (' P%d C%d K%s' % (n * h * w, c, '+'.join(map(str, chs)))
+                                                              if profile.detail() else ''), 2.0 * n * h * w * c * 2 * sum(chs)):
                 if dh.dtype == torch.float16 or f16:
                     flags = (1 if dh.dtype == torch.float16 else 0) | (6 if f16 else 0)
                     lib.call("fsv_spade_mod_bwd_h", lib.ptr(x), lib.ptr(mean), lib.ptr(rstd), lib.ptr(dh), nm, _pp(maps), arr(wg_p),
                              arr(wb_p), arr(bg_p), arr(bb_p), lib.int_array(chs + [0]), _ll(wstr + [0]), _ll(bstr + [0]),
                              _pp(dgbs), lib.ptr(dxhat), n, h * w, c, 2 * c, 0, ctx.act, w, up, flags,
                              lib.ptr(dbsum) if dbsum is not None else None, _ll(zstr + [0]) if dbsum is not None else None,
-                             lib.stream_ptr())
+                             slots if dbsum is not None else 1, ctypes.c_longlong(n * nm * 2 * c), lib.stream_ptr())
                     if dbsum is not None:
-                        dbsum = dbsum.float()
+                        dbsum = dbsum.sum(0, dtype=torch.float32) if slots > 1 else dbsum[0].float()
                 else:
                     lib.call("fsv_spade_mod_bwd", lib.ptr(x), lib.ptr(mean), lib.ptr(rstd), lib.ptr(dh), nm, _pp(maps), arr(wg_p),
                              arr(wb_p), arr(bg_p), arr(bb_p), lib.int_array(chs + [0]), _ll(wstr + [0]), _ll(bstr + [0]),

@@ -271,13 +271,14 @@ int fsv_spade_mod_bwd(const float* x, const float* mean, const float* rstd, cons
                       long long stat_bstride, int act, int W, int up, fsv_stream_t stream);
 /* general form of fsv_spade_mod_bwd.  flags bit 0: dh is IEEE half; bit 1: the d(gamma|beta) tensors are written as half; bit 2: f16
  * GEMMs (operands as fsv_spade_mod_fwd_h).  dbsum (optional): the bias gradients from this launch - per-channel sums of
- * d(gamma|beta) as doubles at dbsum + z * db_zstride[k] + k * 2C (zeroed by the call; db_zstride[k] = 0: summed over the batch) */
+ * d(gamma|beta) as doubles at dbsum + z * db_zstride[k] + k * 2C (zeroed by the call; db_zstride[k] = 0: summed over the batch);
+ * db_slots > 1 (a power of two): pixel tile t adds into the copy at + (t % db_slots) * db_slot_stride, the caller sums the copies */
 int fsv_spade_mod_bwd_h(const float* x, const float* mean, const float* rstd, const void* dh,
                         int nmaps, const void* const* maps, const void* const* wg, const void* const* wb,
                         const float* const* bg, const float* const* bb, const int* ch, const long long* w_bstride,
                         const long long* b_bstride, void* const* dgb, float* dxhat, int N, int HW, int C, int ldw,
                         long long stat_bstride, int act, int W, int up, int flags, double* dbsum, const long long* db_zstride,
-                        fsv_stream_t stream);
+                        int db_slots, long long db_slot_stride, fsv_stream_t stream);
 /* element-wise part of the backward (general path, C % 16 != 0): from materialised gamma|beta ([P][2C] per map) to d(gamma|beta) and d(xhat) (dxhat is
  * written per full-resolution pixel also when up != 0: summing it over the 2x2 children gives the gradient of the
  * half-resolution normalised tensor) */

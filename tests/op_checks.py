@@ -471,7 +471,7 @@ def check_spade(device, nmaps=1, generated=True, n=2, c=12, ch=8, h=6, w=5, act=
     if f16:                    # the launches really were the f16 forms (flags bit 2), with half d(gamma|beta) and fused bias sums
         fw = [a for nm_, a in seen if nm_ == 'fsv_spade_mod_fwd_h']
         bw = [a for nm_, a in seen if nm_ == 'fsv_spade_mod_bwd_h']
-        assert fw and bw and all(a[-2] & 4 for a in fw) and all((a[-4] & 6) == 6 and a[-3] is not None for a in bw), \
+        assert fw and bw and all(a[-2] & 4 for a in fw) and all((a[-6] & 6) == 6 and a[-5] is not None for a in bw), \
             [nm_ for nm_, _ in seen]
         assert not any(nm_ == 'fsv_colsum_fused' for nm_, _ in seen)
     assert_close('spade running mean', run_mean_d, run_mean_r, 1e-5)

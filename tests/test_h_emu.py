@@ -67,3 +67,25 @@ def test_spade_f16_gemms(emu_lib, nmaps, up, c, ch, generated):
     (C = 96 on 64-wide tiles), three maps, per-sample and shared weights"""
     import op_checks as oc
     oc.check_spade(DEV, nmaps=nmaps, generated=generated, c=c, ch=ch, h=8, w=10, up=up, half_out=True, f16=True)
+
+
+@pytest.mark.parametrize('gx', [1, 2, 4])
+@pytest.mark.parametrize('f16', [False, True])
+def test_spade_workgroups_walk_several_pixel_tiles(emu_lib, monkeypatch, gx, f16):
+    """a workgroup of the modulation kernels walks the pixel tiles blockIdx.x, + gridDim.x, ...; the chunk sequence (and the
+    prefetch of x) runs across tile boundaries: 6 tiles of 64 pixels over 1 / 2 / 4 workgroups (even and uneven shares), three
+    maps and one map (the two forms of the backward twin), with and without the folded up-sampling"""
+    import op_checks as oc
+    monkeypatch.setenv('FSV_SPADE_MAX_GX', str(gx))
+    for nmaps, up, c in ((3, True, 64), (1, False, 64), (2, True, 32)):
+        if f16:
+            oc.check_spade(DEV, nmaps=nmaps, generated=True, c=c, ch=16, h=16, w=24, up=up, half_out=True, f16=True)
+        else:
+            oc.check_spade(DEV, nmaps=nmaps, generated=True, c=c, ch=16, h=16, w=24, up=up)
+
+
+def test_spade_f16_bias_sums_over_copies(emu_lib, monkeypatch):
+    """the bias sums of the backward twin spread over 4 copies of the buffer (what maps beyond 16 K pixels do)"""
+    import op_checks as oc
+    monkeypatch.setenv('FSV_SPADE_DB_SLOTS', '4')
+    oc.check_spade(DEV, nmaps=2, generated=True, c=32, ch=16, h=16, w=24, up=False, half_out=True, f16=True)
