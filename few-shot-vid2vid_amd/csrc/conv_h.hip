@@ -316,42 +316,79 @@ __device__ __forceinline__ void fsv_hconv_body(const HConvP& p, const int bx, co
         aux[i][r] = 0.f;
       }
     }
+    // Half tensors move two channels per work-item: a lane holds ONE channel of consecutive pixels, its neighbour (lane ^ 1) the
+    // next channel of the same pixels - for a pair of rows (r, r + 1) the even lane handles channels (co, co + 1) of row r and the
+    // odd lane (co - 1, co) of row r + 1, one exchange each way (Cout is a multiple of 8 here).  2-byte loads / stores run at half
+    // the rate of the same launch moving twice the bytes as fp32 (csrc/spade.hip, round 4).
+    const bool odd = (lane & 1) != 0;
+    const int oddm = -(int)(lane & 1);          // bit mux between the two rows' indices: a select of two array elements would be
+                                                // turned into a dynamically indexed load and send the array to scratch memory
+    const bool pairs = (p.Cout & 1) == 0;       // uniform (an odd channel count: one element per access)
     if (p.res) {              // uniform
 #pragma unroll
-      for (int i = 0; i < TM; ++i)
+      for (int i = 0; i < TM; ++i) {
+        if (p.res_h && !pairs) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const unsigned off = oix[i][r] >= 0 ? (unsigned)oix[i][r] * (p.res_h ? 2u : 4u) : FSV_BUF_OOB;
-          aux[i][r] = p.res_h ? fsv_buf_load_h(rbuf, off) : fsv_buf_load1(rbuf, off);
+          for (int r = 0; r < 16; ++r)
+            aux[i][r] = fsv_buf_load_h(rbuf, oix[i][r] >= 0 ? (unsigned)oix[i][r] * 2u : FSV_BUF_OOB);
+        } else if (p.res_h) {        // uniform
+#pragma unroll
+          for (int r = 0; r < 16; r += 2) {
+            const int src = oix[i][r] ^ ((oix[i][r] ^ oix[i][r + 1]) & oddm);        // odd lanes: row r + 1
+            const float w = fsv_buf_load1(rbuf, src >= 0 ? (unsigned)(src + oddm) * 2u : FSV_BUF_OOB);
+            const float nw = __shfl_xor(w, 1);
+            const fsv_h16x2 mine = __builtin_bit_cast(fsv_h16x2, w), theirs = __builtin_bit_cast(fsv_h16x2, nw);
+            aux[i][r] = odd ? (float)theirs.y : (float)mine.x;
+            aux[i][r + 1] = odd ? (float)mine.y : (float)theirs.x;
+          }
+        } else {
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+            aux[i][r] = fsv_buf_load1(rbuf, oix[i][r] >= 0 ? (unsigned)oix[i][r] * 4u : FSV_BUF_OOB);
         }
+      }
     }
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
+      for (int r = 0; r < 16; r += 2) {
         const int row = (r & 3) + 8 * (r >> 2) + 4 * lk;
         const int m = bm0 + wm * (TM * 32) + i * 32 + row;
-        if (oix[i][r] < 0) continue;
-        const int oidx = oix[i][r];
-        float v = acc[i][j][r] * ws;
-        if (p.nsplit > 1) {
-          atomicAdd(out_f + oidx, v);            // split launches accumulate into a zeroed fp32 buffer (the host's workspace)
+        const bool ok0 = oix[i][r] >= 0, ok1 = oix[i][r + 1] >= 0;
+        float v0 = acc[i][j][r] * ws, v1 = acc[i][j][r + 1] * ws;
+        if (p.nsplit > 1) {                      // uniform
+          // split launches accumulate into a zeroed fp32 buffer (the host's workspace)
+          if (ok0) atomicAdd(out_f + oix[i][r], v0);
+          if (ok1) atomicAdd(out_f + oix[i][r + 1], v1);
         } else {
-          v = (v + bv) * p.scale;
+          v0 = (v0 + bv) * p.scale; v1 = (v1 + bv) * p.scale;
           if (p.act == FSV_ACT_DLRELU) {
-            v = aux[i][r] > 0.f ? v : 0.2f * v;
+            v0 = aux[i][r] > 0.f ? v0 : 0.2f * v0;
+            v1 = aux[i][r + 1] > 0.f ? v1 : 0.2f * v1;
           } else {
-            v = fsv_act(v, p.act) + aux[i][r];
+            v0 = fsv_act(v0, p.act) + aux[i][r];
+            v1 = fsv_act(v1, p.act) + aux[i][r + 1];
           }
-          if (p.out_h) {
-            const fsv_h16 hv = (fsv_h16)v;
-            out_h[oidx] = hv;
-            v = (float)hv;                       // the statistics are those of the stored tensor
+          if (p.out_h) {                         // uniform
+            const fsv_h16 h0 = (fsv_h16)v0, h1 = (fsv_h16)v1;
+            v0 = (float)h0; v1 = (float)h1;      // the statistics are those of the stored tensor
+            if (pairs) {
+              const float n0 = __shfl_xor(v0, 1), n1 = __shfl_xor(v1, 1);
+              fsv_h16x2 pk;
+              pk.x = (fsv_h16)(odd ? n1 : v0); pk.y = (fsv_h16)(odd ? v1 : n0);
+              const int src = oix[i][r] ^ ((oix[i][r] ^ oix[i][r + 1]) & oddm);      // odd lanes: row r + 1, one channel down
+              if (src >= 0) *reinterpret_cast<fsv_h16x2*>(out_h + (src + oddm)) = pk;
+            } else {
+              if (ok0) out_h[oix[i][r]] = h0;
+              if (ok1) out_h[oix[i][r + 1]] = h1;
+            }
           } else {
-            out_f[oidx] = v;
+            if (ok0) out_f[oix[i][r]] = v0;
+            if (ok1) out_f[oix[i][r + 1]] = v1;
           }
           if (p.stats) {
-            if (m < st_split) { s0 += v; q0 += v * v; } else { s1 += v; q1 += v * v; }
+            if (ok0) { if (m < st_split) { s0 += v0; q0 += v0 * v0; } else { s1 += v0; q1 += v0 * v0; } }
+            if (ok1) { if (m + 1 < st_split) { s0 += v1; q0 += v1 * v1; } else { s1 += v1; q1 += v1 * v1; } }
           }
         }
       }
