@@ -93,6 +93,144 @@ __device__ __forceinline__ void fsv_hbuf_load_lds(fsv_rawbuf b, unsigned off, fs
 }
 #endif
 
+// Epilogue of the gather-GEMM kernels.  D layout: col = lane & 31 (channel), row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5) (tile
+// row).  row_m(tile row) -> linear pixel index m of that row (the output pixel follows from m as in the main loop), or -1 for rows
+// outside the problem.  Statistics: rows with m < st_split belong to group st_g0, the others (straddles) to the next one.
+template <int TM, int TN, class RowM>
+__device__ __forceinline__ void fsv_hconv_epilogue(const HConvP& p, f32x16 (&acc)[TM][TN], const int zs, const int bn0, const int wm,
+                                                   const int wn, const int lane, const int bx, const int st_g0, const int st_split,
+                                                   const bool straddles, RowM row_m) {
+  const int lrow = lane & 31, lk = lane >> 5;
+  const int ohw = p.OH * p.OW;
+  const float* bias = p.bias ? (p.bias + (long long)zs * p.b_bstride) : nullptr;
+  const float ws = p.wscale ? p.wscale[0] : 1.f;
+  fsv_h16* const out_h = reinterpret_cast<fsv_h16*>(p.out);
+  float* const out_f = reinterpret_cast<float*>(p.out);
+  // the residual / LeakyReLU-mask operand through a descriptor (the host checked that the output stays below 2^31 bytes when
+  // there is one): all of a lane's values are loaded BEFORE its first store - the stores may alias p.res as far as the compiler
+  // can tell, so a load inside the store loop waits for its full memory latency once per element (16 - 32 times per tile)
+  const fsv_buf rbuf = fsv_make_buf(p.res, p.res ? p.res_bytes : 0);
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int co = bn0 + wn * (TN * 32) + j * 32 + lrow;
+    const bool cok = co < p.Cout;
+    const float bv = (bias && p.nsplit == 1 && cok) ? bias[co] : 0.f;
+    float s0 = 0.f, q0 = 0.f, s1 = 0.f, q1 = 0.f;
+    int oix[TM][16];          // element index of the output (the host checked < 2^31 elements), -1: not stored
+    float aux[TM][16];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * lk;
+        const int m = row_m(wm * (TM * 32) + i * 32 + row);          // linear pixel index of this tile row, or -1
+        long long opix;
+        if (p.dense_out) {
+          opix = (long long)zs * (p.per_sample ? p.Mz : 0) + m;
+        } else {
+          int n, rem;
+          if (p.per_sample) { n = zs; rem = m; } else { n = m / ohw; rem = m - n * ohw; }
+          const int oy = rem / p.OW, ox = rem - oy * p.OW;
+          opix = ((long long)n * p.outH + (oy * p.osy + p.ooy)) * p.outW + (ox * p.osx + p.oox);
+        }
+        const bool ok = cok & (m >= 0);
+        oix[i][r] = ok ? (int)(opix * p.Cout + co) : -1;
+        aux[i][r] = 0.f;
+      }
+    }
+    // Half tensors move two channels per work-item: a lane holds ONE channel of consecutive pixels, its neighbour (lane ^ 1) the
+    // next channel of the same pixels - for a pair of rows (r, r + 1) the even lane handles channels (co, co + 1) of row r and the
+    // odd lane (co - 1, co) of row r + 1, one exchange each way (Cout is a multiple of 8 here).  2-byte loads / stores run at half
+    // the rate of the same launch moving twice the bytes as fp32 (csrc/spade.hip, round 4).
+    const bool odd = (lane & 1) != 0;
+    const int oddm = -(int)(lane & 1);          // bit mux between the two rows' indices: a select of two array elements would be
+                                                // turned into a dynamically indexed load and send the array to scratch memory
+    const bool pairs = (p.Cout & 1) == 0;       // uniform (an odd channel count: one element per access)
+    if (p.res) {              // uniform
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        if (p.res_h && !pairs) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+            aux[i][r] = fsv_buf_load_h(rbuf, oix[i][r] >= 0 ? (unsigned)oix[i][r] * 2u : FSV_BUF_OOB);
+        } else if (p.res_h) {        // uniform
+#pragma unroll
+          for (int r = 0; r < 16; r += 2) {
+            const int src = oix[i][r] ^ ((oix[i][r] ^ oix[i][r + 1]) & oddm);        // odd lanes: row r + 1
+            const float w = fsv_buf_load1(rbuf, src >= 0 ? (unsigned)(src + oddm) * 2u : FSV_BUF_OOB);
+            const float nw = __shfl_xor(w, 1);
+            const fsv_h16x2 mine = __builtin_bit_cast(fsv_h16x2, w), theirs = __builtin_bit_cast(fsv_h16x2, nw);
+            aux[i][r] = odd ? (float)theirs.y : (float)mine.x;
+            aux[i][r + 1] = odd ? (float)mine.y : (float)theirs.x;
+          }
+        } else {
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+            aux[i][r] = fsv_buf_load1(rbuf, oix[i][r] >= 0 ? (unsigned)oix[i][r] * 4u : FSV_BUF_OOB);
+        }
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+      for (int r = 0; r < 16; r += 2) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * lk;
+        const int m = row_m(wm * (TM * 32) + i * 32 + row);
+        const bool ok0 = oix[i][r] >= 0, ok1 = oix[i][r + 1] >= 0;
+        float v0 = acc[i][j][r] * ws, v1 = acc[i][j][r + 1] * ws;
+        if (p.nsplit > 1) {                      // uniform
+          // split launches accumulate into a zeroed fp32 buffer (the host's workspace)
+          if (ok0) atomicAdd(out_f + oix[i][r], v0);
+          if (ok1) atomicAdd(out_f + oix[i][r + 1], v1);
+        } else {
+          v0 = (v0 + bv) * p.scale; v1 = (v1 + bv) * p.scale;
+          if (p.act == FSV_ACT_DLRELU) {
+            v0 = aux[i][r] > 0.f ? v0 : 0.2f * v0;
+            v1 = aux[i][r + 1] > 0.f ? v1 : 0.2f * v1;
+          } else {
+            v0 = fsv_act(v0, p.act) + aux[i][r];
+            v1 = fsv_act(v1, p.act) + aux[i][r + 1];
+          }
+          if (p.out_h) {                         // uniform
+            const fsv_h16 h0 = (fsv_h16)v0, h1 = (fsv_h16)v1;
+            v0 = (float)h0; v1 = (float)h1;      // the statistics are those of the stored tensor
+            if (pairs) {
+              const float n0 = __shfl_xor(v0, 1), n1 = __shfl_xor(v1, 1);
+              fsv_h16x2 pk;
+              pk.x = (fsv_h16)(odd ? n1 : v0); pk.y = (fsv_h16)(odd ? v1 : n0);
+              const int src = oix[i][r] ^ ((oix[i][r] ^ oix[i][r + 1]) & oddm);      // odd lanes: row r + 1, one channel down
+              if (src >= 0) *reinterpret_cast<fsv_h16x2*>(out_h + (src + oddm)) = pk;
+            } else {
+              if (ok0) out_h[oix[i][r]] = h0;
+              if (ok1) out_h[oix[i][r + 1]] = h1;
+            }
+          } else {
+            if (ok0) out_f[oix[i][r]] = v0;
+            if (ok1) out_f[oix[i][r + 1]] = v1;
+          }
+          if (p.stats) {
+            if (ok0) { if (m < st_split) { s0 += v0; q0 += v0 * v0; } else { s1 += v0; q1 += v0 * v0; } }
+            if (ok1) { if (m + 1 < st_split) { s0 += v1; q0 += v1 * v1; } else { s1 += v1; q1 += v1 * v1; } }
+          }
+        }
+      }
+    }
+    if (p.stats) {            // uniform
+      s0 += __shfl_xor(s0, 32); q0 += __shfl_xor(q0, 32);
+      s1 += __shfl_xor(s1, 32); q1 += __shfl_xor(q1, 32);
+      if (lk == 0 && cok) {
+        const int slot = bx % p.stats_slots;
+        double* d = p.stats + (((long long)st_g0 * p.stats_slots + slot) * p.Cout + co) * 2;
+        atomicAdd(d, (double)s0); atomicAdd(d + 1, (double)q0);
+        if (straddles) {
+          d += (long long)p.stats_slots * p.Cout * 2;
+          atomicAdd(d, (double)s1); atomicAdd(d + 1, (double)q1);
+        }
+      }
+    }
+  }
+}
+
 // One output tile.  BM x BN pixels x channels, WM x WN waves, NBUF LDS buffers (2: loads one chunk ahead, 3: two chunks ahead).
 // Whole trips of NBUF chunks: chunks at or past the end of this split's K range load zeros on both sides (out-of-range offsets)
 // and are multiplied like the others - no exit inside a trip, buffers addressed statically.
@@ -277,136 +415,11 @@ __device__ __forceinline__ void fsv_hconv_body(const HConvP& p, const int bx, co
   }
   FSV_WAIT_VMCNT(0);          // loads of chunks past the end are still landing in LDS: they must not outlive the workgroup's allocation
 
-  // ---- epilogue: D layout col = lane&31 (channel), row = (r&3) + 8*(r>>2) + 4*(lane>>5) (pixel) -----------
-  const float* bias = p.bias ? (p.bias + (long long)zs * p.b_bstride) : nullptr;
-  const float ws = p.wscale ? p.wscale[0] : 1.f;
+  // ---- epilogue ---------------------------------------------------------------------------------------------------------------
   const int st_g0 = p.stats ? bm0 / p.stats_ohw : 0;
   const int st_split = (st_g0 + 1) * (p.stats ? p.stats_ohw : 0);
-  fsv_h16* const out_h = reinterpret_cast<fsv_h16*>(p.out);
-  float* const out_f = reinterpret_cast<float*>(p.out);
-  // the residual / LeakyReLU-mask operand through a descriptor (the host checked that the output stays below 2^31 bytes when
-  // there is one): all of a lane's values are loaded BEFORE its first store - the stores may alias p.res as far as the compiler
-  // can tell, so a load inside the store loop waits for its full memory latency once per element (16 - 32 times per tile)
-  const fsv_buf rbuf = fsv_make_buf(p.res, p.res ? p.res_bytes : 0);
-#pragma unroll
-  for (int j = 0; j < TN; ++j) {
-    const int co = bn0 + wn * (TN * 32) + j * 32 + lrow;
-    const bool cok = co < p.Cout;
-    const float bv = (bias && p.nsplit == 1 && cok) ? bias[co] : 0.f;
-    float s0 = 0.f, q0 = 0.f, s1 = 0.f, q1 = 0.f;
-    int oix[TM][16];          // element index of the output (the host checked < 2^31 elements), -1: not stored
-    float aux[TM][16];
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = (r & 3) + 8 * (r >> 2) + 4 * lk;
-        const int m = bm0 + wm * (TM * 32) + i * 32 + row;
-        long long opix;
-        if (p.dense_out) {
-          opix = (long long)zs * (p.per_sample ? p.Mz : 0) + m;
-        } else {
-          int n, rem;
-          if (p.per_sample) { n = zs; rem = m; } else { n = m / ohw; rem = m - n * ohw; }
-          const int oy = rem / p.OW, ox = rem - oy * p.OW;
-          opix = ((long long)n * p.outH + (oy * p.osy + p.ooy)) * p.outW + (ox * p.osx + p.oox);
-        }
-        const bool ok = cok & (m < p.Mz);
-        oix[i][r] = ok ? (int)(opix * p.Cout + co) : -1;
-        aux[i][r] = 0.f;
-      }
-    }
-    // Half tensors move two channels per work-item: a lane holds ONE channel of consecutive pixels, its neighbour (lane ^ 1) the
-    // next channel of the same pixels - for a pair of rows (r, r + 1) the even lane handles channels (co, co + 1) of row r and the
-    // odd lane (co - 1, co) of row r + 1, one exchange each way (Cout is a multiple of 8 here).  2-byte loads / stores run at half
-    // the rate of the same launch moving twice the bytes as fp32 (csrc/spade.hip, round 4).
-    const bool odd = (lane & 1) != 0;
-    const int oddm = -(int)(lane & 1);          // bit mux between the two rows' indices: a select of two array elements would be
-                                                // turned into a dynamically indexed load and send the array to scratch memory
-    const bool pairs = (p.Cout & 1) == 0;       // uniform (an odd channel count: one element per access)
-    if (p.res) {              // uniform
-#pragma unroll
-      for (int i = 0; i < TM; ++i) {
-        if (p.res_h && !pairs) {
-#pragma unroll
-          for (int r = 0; r < 16; ++r)
-            aux[i][r] = fsv_buf_load_h(rbuf, oix[i][r] >= 0 ? (unsigned)oix[i][r] * 2u : FSV_BUF_OOB);
-        } else if (p.res_h) {        // uniform
-#pragma unroll
-          for (int r = 0; r < 16; r += 2) {
-            const int src = oix[i][r] ^ ((oix[i][r] ^ oix[i][r + 1]) & oddm);        // odd lanes: row r + 1
-            const float w = fsv_buf_load1(rbuf, src >= 0 ? (unsigned)(src + oddm) * 2u : FSV_BUF_OOB);
-            const float nw = __shfl_xor(w, 1);
-            const fsv_h16x2 mine = __builtin_bit_cast(fsv_h16x2, w), theirs = __builtin_bit_cast(fsv_h16x2, nw);
-            aux[i][r] = odd ? (float)theirs.y : (float)mine.x;
-            aux[i][r + 1] = odd ? (float)mine.y : (float)theirs.x;
-          }
-        } else {
-#pragma unroll
-          for (int r = 0; r < 16; ++r)
-            aux[i][r] = fsv_buf_load1(rbuf, oix[i][r] >= 0 ? (unsigned)oix[i][r] * 4u : FSV_BUF_OOB);
-        }
-      }
-    }
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-#pragma unroll
-      for (int r = 0; r < 16; r += 2) {
-        const int row = (r & 3) + 8 * (r >> 2) + 4 * lk;
-        const int m = bm0 + wm * (TM * 32) + i * 32 + row;
-        const bool ok0 = oix[i][r] >= 0, ok1 = oix[i][r + 1] >= 0;
-        float v0 = acc[i][j][r] * ws, v1 = acc[i][j][r + 1] * ws;
-        if (p.nsplit > 1) {                      // uniform
-          // split launches accumulate into a zeroed fp32 buffer (the host's workspace)
-          if (ok0) atomicAdd(out_f + oix[i][r], v0);
-          if (ok1) atomicAdd(out_f + oix[i][r + 1], v1);
-        } else {
-          v0 = (v0 + bv) * p.scale; v1 = (v1 + bv) * p.scale;
-          if (p.act == FSV_ACT_DLRELU) {
-            v0 = aux[i][r] > 0.f ? v0 : 0.2f * v0;
-            v1 = aux[i][r + 1] > 0.f ? v1 : 0.2f * v1;
-          } else {
-            v0 = fsv_act(v0, p.act) + aux[i][r];
-            v1 = fsv_act(v1, p.act) + aux[i][r + 1];
-          }
-          if (p.out_h) {                         // uniform
-            const fsv_h16 h0 = (fsv_h16)v0, h1 = (fsv_h16)v1;
-            v0 = (float)h0; v1 = (float)h1;      // the statistics are those of the stored tensor
-            if (pairs) {
-              const float n0 = __shfl_xor(v0, 1), n1 = __shfl_xor(v1, 1);
-              fsv_h16x2 pk;
-              pk.x = (fsv_h16)(odd ? n1 : v0); pk.y = (fsv_h16)(odd ? v1 : n0);
-              const int src = oix[i][r] ^ ((oix[i][r] ^ oix[i][r + 1]) & oddm);      // odd lanes: row r + 1, one channel down
-              if (src >= 0) *reinterpret_cast<fsv_h16x2*>(out_h + (src + oddm)) = pk;
-            } else {
-              if (ok0) out_h[oix[i][r]] = h0;
-              if (ok1) out_h[oix[i][r + 1]] = h1;
-            }
-          } else {
-            if (ok0) out_f[oix[i][r]] = v0;
-            if (ok1) out_f[oix[i][r + 1]] = v1;
-          }
-          if (p.stats) {
-            if (ok0) { if (m < st_split) { s0 += v0; q0 += v0 * v0; } else { s1 += v0; q1 += v0 * v0; } }
-            if (ok1) { if (m + 1 < st_split) { s0 += v1; q0 += v1 * v1; } else { s1 += v1; q1 += v1 * v1; } }
-          }
-        }
-      }
-    }
-    if (p.stats) {            // uniform
-      s0 += __shfl_xor(s0, 32); q0 += __shfl_xor(q0, 32);
-      s1 += __shfl_xor(s1, 32); q1 += __shfl_xor(q1, 32);
-      if (lk == 0 && cok) {
-        const int slot = bx % p.stats_slots;
-        double* d = p.stats + (((long long)st_g0 * p.stats_slots + slot) * p.Cout + co) * 2;
-        atomicAdd(d, (double)s0); atomicAdd(d + 1, (double)q0);
-        if (bm0 + BM > st_split && st_split < p.Mz) {
-          d += (long long)p.stats_slots * p.Cout * 2;
-          atomicAdd(d, (double)s1); atomicAdd(d + 1, (double)q1);
-        }
-      }
-    }
-  }
+  fsv_hconv_epilogue<TM, TN>(p, acc, zs, bn0, wm, wn, lane, bx, st_g0, st_split, bm0 + BM > st_split && st_split < p.Mz,
+                             [&](int rt) { const int m = bm0 + rt; return m < p.Mz ? m : -1; });
 }
 
 template <int BM, int BN, int WM, int WN, int NBUF>
@@ -414,6 +427,177 @@ __global__ __launch_bounds__(64 * WM * WN) void fsv_hconv_kernel(HConvP p) {
   int bx, by;
   if (!fsv_h_xcd_tile((p.Mz + BM - 1) / BM, (p.Cout + BN - 1) / BN, bx, by)) return;
   fsv_hconv_body<BM, BN, WM, WN, NBUF>(p, bx, by, (int)blockIdx.z);
+}
+
+// ---- patch-resident form (round 4) ------------------------------------------------------------------------------------------------
+// Stride-1 convolutions whose taps reach one pixel in every direction (every 3x3 convolution of the generators and its data
+// gradient).  The form above gathers the A tile once PER TAP - the nine taps of a 3x3 read the same activations nine times through
+// the L2 -> LDS path, and that path is what bounds the kernel (~10 - 13 TB/s over the chip whatever the tile, profiles/r04_notes.md).
+// Here a workgroup owns a TH x TW patch of output pixels of one image.  K runs channel-chunk-major: for every 32 input channels the
+// (TH + 2) x (TW + 2) input pixels of the patch go to LDS ONCE (64-byte rows, out-of-image pixels as hardware zero fill), and the
+// taps are steps over it - tap (ty, tx) reads row (y + ty + 1) * (TW + 2) + (x + tx + 1) for the lane's pixel (y, x): 16 consecutive
+// lanes are 16 consecutive patch rows whatever the tap, so the slot swizzle (slot ^ (row >> 2) & 3) keeps the ds_read_b128
+// fragments conflict-free.  Only the weights (32 k x BN per tap, L2 resident) are loaded per step.  LDS fill per 32 channels of a
+// 256-pixel x 64-channel tile: 20 KB of activations + 9 x 4 KB of weights against 9 x (16 + 4) KB.  An experiment that did not pay
+// (see fsv_h_patch_pick): kept opt-in, with its parity tests, as the measured answer to "is the gather form fill-bound".
+// Pipeline: step s = (chunk c, tap t).  Weights of step s + 2 are requested at the top of step s (three buffers); the patch of
+// chunk c + 1 goes out one load instruction per step during the first taps of chunk c (second patch buffer).  The memory pipe
+// returns in order: at the end of step s everything older than [patch piece of step s - 1, weights s + 2, patch piece of step s]
+// has landed - the weights of step s + 1 among it.
+template <int TH, int TW, int BN, int WM, int WN>
+__global__ __launch_bounds__(64 * WM * WN, 2) void fsv_hconv_patch_kernel(HConvP p, int tiles_y, int tiles_x) {
+  constexpr int BK = 32;
+  constexpr int PH = TH + 2, PW = TW + 2;
+  constexpr int BM = TH * TW, NT = 64 * WM * WN;
+  constexpr int RPP = NT / 4;                                    // LDS rows per load pass: 4 lanes x 16 B = one 64-byte row
+  constexpr int PROWS = (PH * PW + RPP - 1) / RPP * RPP;         // patch rows, whole passes (the padding rows load zeros)
+  constexpr int BROWS = BN > RPP ? BN : RPP;
+  constexpr int NPA = PROWS / RPP, NPB = BROWS / RPP;
+  constexpr int TM = BM / (WM * 32), TN = BN / (WN * 32);
+  constexpr int A_ST = PROWS * BK, B_ST = BROWS * BK;            // halves per buffer
+  static_assert(TW == 16 && TM >= 1 && TN >= 1 && BM % (WM * 32) == 0 && BN % (WN * 32) == 0, "tile");
+  __shared__ __attribute__((aligned(16))) fsv_h16 smem[2 * A_ST + 3 * B_ST];
+  fsv_h16* const As = smem;
+  fsv_h16* const Bs = smem + 2 * A_ST;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int lrow = lane & 31, lk = lane >> 5;
+  int bx, by;
+  if (!fsv_h_xcd_tile((p.per_sample ? 1 : p.N) * tiles_y * tiles_x, (p.Cout + BN - 1) / BN, bx, by)) return;
+  const int zs = blockIdx.z;
+  const int bn0 = by * BN;
+  const int tpi = tiles_y * tiles_x;
+  const int n_img = p.per_sample ? zs : bx / tpi;
+  const int trem = p.per_sample ? bx : bx - n_img * tpi;
+  const int oy0 = (trem / tiles_x) * TH, ox0 = (trem % tiles_x) * TW;
+  const fsv_h16* wt = p.wt + (long long)zs * p.w_bstride;
+  const fsv_rawbuf araw = fsv_make_rawbuf(p.in, (long long)p.N * p.H * p.W * p.Cin * 2);
+  const fsv_rawbuf braw = fsv_make_rawbuf(wt, (long long)p.nrows * p.Kpad * 2);
+
+  // this thread's rows of a load pass and the logical slot (8 k) that belongs in its physical one
+  const int r0 = tid >> 2;
+  const int ls = (tid & 3) ^ ((r0 >> 2) & 3);
+  unsigned a_base[NPA], b_base[NPB];
+#pragma unroll
+  for (int i = 0; i < NPA; ++i) {
+    const int pp = r0 + i * RPP;
+    const int py = pp / PW, px = pp - py * PW;
+    const int iy = oy0 - 1 + py, ix = ox0 - 1 + px;
+    const bool ok = (pp < PH * PW) & ((unsigned)iy < (unsigned)p.H) & ((unsigned)ix < (unsigned)p.W);
+    a_base[i] = ok ? (unsigned)((((n_img * p.H + iy) * p.W + ix) * p.Cin + ls * 8) * 2) : FSV_BUF_OOB;
+  }
+#pragma unroll
+  for (int i = 0; i < NPB; ++i) {
+    const int r = r0 + i * RPP;
+    const int n = bn0 + r;
+    b_base[i] = (r < BN && n < p.nrows) ? (unsigned)((n * p.Kpad + ls * 8) * 2) : FSV_BUF_OOB;
+  }
+  const int nck = p.Cin / BK;
+  auto issue_a = [&](fsv_h16* a_buf, int c, int i) {           // piece i of the patch of chunk c (past the last chunk: zeros)
+    const unsigned off = (c < nck) ? a_base[i] + (unsigned)(c * BK * 2) : FSV_BUF_OOB;
+    fsv_hbuf_load_lds(araw, off | (a_base[i] & FSV_BUF_OOB), a_buf + (wave * 16 + i * RPP) * BK);
+  };
+  auto issue_b = [&](fsv_h16* b_buf, int c, int t) {
+    const unsigned koff = (unsigned)((t * p.Cin + c * BK) * 2);
+#pragma unroll
+    for (int i = 0; i < NPB; ++i) {
+      const unsigned off = (c < nck) ? b_base[i] + koff : FSV_BUF_OOB;
+      fsv_hbuf_load_lds(braw, off | (b_base[i] & FSV_BUF_OOB), b_buf + (wave * 16 + i * RPP) * BK);
+    }
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  int pp0[TM], b_off[TN], b_swz[TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    const int rt = wm * (TM * 32) + i * 32 + lrow;               // tile row -> pixel (rt / TW, rt % TW) of the patch interior
+    pp0[i] = ((rt / TW) + 1) * PW + (rt % TW) + 1;
+  }
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int r = wn * (TN * 32) + j * 32 + lrow;
+    b_off[j] = r * BK; b_swz[j] = (r >> 2) & 3;
+  }
+
+  // prologue: the first patch, the weights of the first two steps
+#pragma unroll
+  for (int i = 0; i < NPA; ++i) issue_a(As, 0, i);
+  {
+    issue_b(Bs, 0, 0);
+    const bool two = p.ntaps > 1;
+    issue_b(Bs + B_ST, two ? 0 : 1, two ? 1 : 0);
+  }
+  FSV_WAIT_VMCNT(0);
+  __syncthreads();
+
+  int bi = 0;                   // weight buffer of the current step; s + 2 goes to (bi + 2) % 3
+  int c2 = 0, t2 = 2;           // (chunk, tap) of step s + 2
+  if (t2 >= p.ntaps) { t2 -= p.ntaps; c2 = 1; if (t2 >= p.ntaps) { t2 -= p.ntaps; c2 = 2; } }
+  bool prev_piece = false;
+#pragma unroll 1
+  for (int c = 0; c < nck; ++c) {
+    const fsv_h16* a_src = As + (c & 1) * A_ST;
+    fsv_h16* a_next = As + ((c + 1) & 1) * A_ST;
+#pragma unroll 1
+    for (int t = 0; t < p.ntaps; ++t) {
+      const int b2 = bi >= 1 ? bi - 1 : 2;                       // (bi + 2) % 3
+      issue_b(Bs + b2 * B_ST, c2, t2);
+      const bool piece = t < NPA;
+      if (piece) {                                               // uniform
+        // (a switch over t keeps the piece index a constant: the offsets live in registers)
+#pragma unroll
+        for (int i = 0; i < NPA; ++i)
+          if (t == i) issue_a(a_next, c + 1, i);
+      }
+      ++t2;
+      if (t2 >= p.ntaps) { t2 = 0; ++c2; }
+      int ty, tx;
+      fsv_htap(p, t, ty, tx);
+      const int shift = ty * PW + tx;
+      const fsv_h16* b_src = Bs + bi * B_ST;
+      fsv_h16x8 fa[2][TM], fb[2][TN];
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+          const int pp = pp0[i] + shift;
+          fa[ks][i] = *reinterpret_cast<const fsv_h16x8*>(&a_src[pp * BK + ((((2 * ks + lk) ^ (pp >> 2)) & 3) << 3)]);
+        }
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          fb[ks][j] = *reinterpret_cast<const fsv_h16x8*>(&b_src[b_off[j] + (((2 * ks + lk) ^ b_swz[j]) << 3)]);
+      }
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[ks][i], fb[ks][j], acc[i][j], 0, 0, 0);
+      // everything older than [piece of the previous step, weights of s + 2, piece of this step] must have landed
+      const int after = (prev_piece ? 1 : 0) + (piece ? 1 : 0);
+      if (after == 2) FSV_WAIT_VMCNT(NPB + 2);
+      else if (after == 1) FSV_WAIT_VMCNT(NPB + 1);
+      else FSV_WAIT_VMCNT(NPB);
+      __syncthreads();
+      prev_piece = piece;
+      bi = bi == 2 ? 0 : bi + 1;
+    }
+  }
+  FSV_WAIT_VMCNT(0);          // (loads past the end are still landing in LDS: they must not outlive the workgroup's allocation)
+
+  const long long m_img = p.per_sample ? 0 : (long long)n_img * p.OH * p.OW;
+  const int st_g0 = p.stats ? (int)(m_img / p.stats_ohw) : 0;
+  fsv_hconv_epilogue<TM, TN>(p, acc, zs, bn0, wm, wn, lane, bx, st_g0, 0x7fffffff, false, [&](int rt) {
+    const int oy = oy0 + rt / TW, ox = ox0 + rt % TW;
+    return (oy < p.OH && ox < p.OW) ? (int)(m_img + (long long)oy * p.OW + ox) : -1;
+  });
 }
 
 // grouped launch (see fsv_conv_igemm_group_kernel): up to FSV_GROUP_MAX independent problems in one 1-D grid
@@ -895,6 +1079,45 @@ static int fsv_h_fill(HConvP& p, const fsv_hconv_desc& d) {
   return FSV_OK;
 }
 
+// ---- patch-resident form: tile ids 32 = 8x16 pixels x 128 channels, 33 = 16x16 x 64, 34 = 16x16 x 32 (4-wave workgroups) ----------
+static inline int fsv_h_patch_dims(int tile, int& th, int& tw, int& bn) {
+  switch (tile) {
+    case 32: th = 8; tw = 16; bn = 128; return 0;
+    case 33: th = 16; tw = 16; bn = 64; return 0;
+    case 34: th = 16; tw = 16; bn = 32; return 0;
+    default: return -1;
+  }
+}
+
+// the geometry the patch kernel covers: stride 1, output = input size, every tap within one pixel, whole 32-channel chunks, and
+// enough taps for its load schedule (the patch of the next chunk leaves one instruction per tap: up to six, landed two taps later)
+static inline bool fsv_h_patch_geometry(const fsv_hconv_desc& d) {
+  if (d.sy != 1 || d.sx != 1 || d.osy != 1 || d.osx != 1 || d.ooy != 0 || d.oox != 0) return false;
+  if (d.outH != d.OH || d.outW != d.OW || d.OH != d.H || d.OW != d.W || d.accumulate) return false;
+  if ((d.Cin & 31) != 0 || d.ntaps < 8) return false;
+  for (int t = 0; t < d.ntaps; ++t)
+    if (d.ty[t] < -1 || d.ty[t] > 1 || d.tx[t] < -1 || d.tx[t] > 1) return false;
+  return true;
+}
+
+// patch tile of a single launch, or -1: the plan above decides first (a launch it would split along K is too small for this form)
+static inline int fsv_h_patch_pick(const fsv_hconv_desc& d) {
+  // opt-in (FSV_HCONV_PATCH=1).  Measured in-box in round 4 (tools/h_ab.py, profiles/r04_notes.md): the form is correct and moves
+  // 2 - 4x fewer bytes from L2 to LDS, and it is SLOWER than the gather form on every layer shape of the two workloads (372 against
+  // 625 TFLOP/s on M32768 N128 K2304, 260 against 332 on M524288 N32 K576; the street --amp step 22.03 against 21.64 ms) - one
+  // barrier per 32 k with eight MFMAs per wave between barriers and two workgroups per CU.  The fill volume is not what bounds the
+  // gather form.
+  static int on = -1;
+  if (on < 0) { const char* e = getenv("FSV_HCONV_PATCH"); on = (e && e[0] == '1') ? 1 : 0; }
+  if (d.force_tile >= 32) return fsv_h_patch_geometry(d) ? d.force_tile : -2;
+  if (!on || d.force_tile >= 0 || d.force_split > 0 || !fsv_h_patch_geometry(d)) return -1;
+  const int tile = d.Cout <= 32 ? 34 : (d.Cout <= 64 ? 33 : 32);
+  int th, tw, bn;
+  fsv_h_patch_dims(tile, th, tw, bn);
+  const long long wgs = (long long)d.N * fsv_cdiv(d.OH, th) * fsv_cdiv(d.OW, tw) * fsv_cdiv(d.Cout, bn);
+  return wgs >= 256 ? tile : -1;
+}
+
 #define FSV_H_CASES(KERNEL, G, P)                                                                                     \
   switch (tile) {                                                                                                     \
     case 0: FSV_LAUNCH((KERNEL<128, 128, 2, 2, 3>), G, dim3(256), stream, P); break;                                  \
@@ -916,6 +1139,13 @@ static int fsv_h_fill(HConvP& p, const fsv_hconv_desc& d) {
 
 extern "C" {
 
+// the patch tile (32 .. 34) a single launch of this problem takes, or -1 (labels of the profiling layer)
+int fsv_hconv_patch_tile(const fsv_hconv_desc* d) {
+  if (!d) return -1;
+  const int t = fsv_h_patch_pick(*d);
+  return t >= 32 ? t : -1;
+}
+
 // n == 1: one launch (split-K allowed when d->ws is given or the output is fp32); n > 1: ONE grouped launch of independent problems
 // (no K splits; every problem as the tile the group's widest member takes).  Returns *produced = 1 when the statistics partials
 // were written (single launches only).
@@ -931,7 +1161,13 @@ int fsv_hconv_gather(const fsv_hconv_desc* d, int n, int* produced, hipStream_t 
     // a K split adds partial sums into a zeroed fp32 buffer: the output itself when it is fp32 and dense, else the workspace
     const bool can_split = !d->accumulate && p.dense_out && d->act != FSV_ACT_DLRELU && (!d->out_h || d->ws);
     int tile = 0, nsplit = 1;
-    if (fsv_hconv_plan(p.Mz, d->Cout, p.nchunks, nsamp, d->force_tile, d->force_split, can_split ? 1 : 0, &tile, &nsplit)) return FSV_ERR_BAD_ARG;
+    const int ptile = fsv_h_patch_pick(d[0]);
+    if (ptile == -2) return FSV_ERR_UNSUPPORTED;
+    if (ptile >= 32) {
+      tile = ptile;
+    } else {
+      if (fsv_hconv_plan(p.Mz, d->Cout, p.nchunks, nsamp, d->force_tile, d->force_split, can_split ? 1 : 0, &tile, &nsplit)) return FSV_ERR_BAD_ARG;
+    }
     if (nsplit > 1 && !can_split) nsplit = 1;
     p.nsplit = nsplit;
     void* final_out = p.out;
@@ -946,6 +1182,19 @@ int fsv_hconv_gather(const fsv_hconv_desc* d, int n, int* produced, hipStream_t 
       if (!d->stats_prezeroed)
         (void)hipMemsetAsync(d->stats, 0, (size_t)d->stats_groups * d->stats_slots * d->Cout * 2 * sizeof(double), stream);
       if (produced) *produced = 1;
+    }
+    if (tile >= 32) {
+      int th, tw, pbn;
+      if (fsv_h_patch_dims(tile, th, tw, pbn)) return FSV_ERR_BAD_ARG;
+      const int tiles_y = fsv_cdiv(d->OH, th), tiles_x = fsv_cdiv(d->OW, tw);
+      const int tiles_xy = (d->per_sample ? 1 : d->N) * tiles_y * tiles_x * fsv_cdiv(d->Cout, pbn);
+      const dim3 g(8 * fsv_cdiv(tiles_xy, 8), 1, nsamp);
+      switch (tile) {
+        case 32: FSV_LAUNCH((fsv_hconv_patch_kernel<8, 16, 128, 2, 2>), g, dim3(256), stream, p, tiles_y, tiles_x); break;
+        case 33: FSV_LAUNCH((fsv_hconv_patch_kernel<16, 16, 64, 4, 1>), g, dim3(256), stream, p, tiles_y, tiles_x); break;
+        default: FSV_LAUNCH((fsv_hconv_patch_kernel<16, 16, 32, 4, 1>), g, dim3(256), stream, p, tiles_y, tiles_x); break;
+      }
+      return fsv_check_launch();
     }
     int bm, bn;
     if (fsv_h_tile_dims(tile, bm, bn)) return FSV_ERR_BAD_ARG;
