@@ -159,6 +159,36 @@ int fsv_upsample2x_bwd(const float* dy, float* dx, int N, int H, int W, int C, h
   return fsv_check_launch();
 }
 
+typedef _Float16 fsv_eh16x4 __attribute__((ext_vector_type(4)));
+
+// four elements per work-item, optional half side output (fsv_common.h)
+__global__ __launch_bounds__(256) void fsv_act_bwd4_kernel(const float* dy, const float* y, float* dx, long long total4, int act,
+                                                           float scale, _Float16* dxh) {
+  const long long stride = (long long)gridDim.x * 256;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total4; i += stride) {
+    const float4 dv = *reinterpret_cast<const float4*>(dy + i * 4), yv = *reinterpret_cast<const float4*>(y + i * 4);
+    const float da[4] = {dv.x, dv.y, dv.z, dv.w}, ya[4] = {yv.x, yv.y, yv.z, yv.w};
+    float r[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float d = da[j] * scale;
+      const float v = ya[j];
+      if (act == FSV_ACT_LRELU) d = v > 0.f ? d : 0.2f * d;
+      else if (act == FSV_ACT_TANH) d = d * (1.f - v * v);
+      else if (act == FSV_ACT_SIGMOID) d = d * v * (1.f - v);
+      else if (act == FSV_ACT_RELU) d = v > 0.f ? d : 0.f;
+      else if (act == FSV_ACT_LRELU01) d = v > 0.f ? d : 0.1f * d;
+      r[j] = d;
+    }
+    *reinterpret_cast<float4*>(dx + i * 4) = make_float4(r[0], r[1], r[2], r[3]);
+    if (dxh) {
+      fsv_eh16x4 h;
+      h.x = (_Float16)r[0]; h.y = (_Float16)r[1]; h.z = (_Float16)r[2]; h.w = (_Float16)r[3];
+      *reinterpret_cast<fsv_eh16x4*>(dxh + i * 4) = h;
+    }
+  }
+}
+
 int fsv_act_fwd(const float* x, float* y, long long total, int act, hipStream_t stream) {
   if (!x || !y || total < 0) return FSV_ERR_BAD_ARG;
   FSV_LAUNCH(fsv_act_fwd_kernel, dim3(fsv_grid_for(total / 4 + 1)), dim3(256), stream, x, y, total, act);
@@ -168,7 +198,10 @@ int fsv_act_fwd(const float* x, float* y, long long total, int act, hipStream_t 
 // dx = dy * scale * act'(y)   (y is the activation OUTPUT)
 int fsv_act_bwd(const float* dy, const float* y, float* dx, long long total, int act, float scale, hipStream_t stream) {
   if (!dy || !y || !dx || total < 0) return FSV_ERR_BAD_ARG;
-  FSV_LAUNCH(fsv_act_bwd_kernel, dim3(fsv_grid_for(total / 4 + 1)), dim3(256), stream, dy, y, dx, total, act, scale);
+  const bool v4 = (total & 3) == 0 && total > 0;
+  _Float16* dxh = reinterpret_cast<_Float16*>(fsv_sidecar_take(v4));
+  if (v4) FSV_LAUNCH(fsv_act_bwd4_kernel, dim3(fsv_grid_for(total / 4)), dim3(256), stream, dy, y, dx, total / 4, act, scale, dxh);
+  else FSV_LAUNCH(fsv_act_bwd_kernel, dim3(fsv_grid_for(total / 4 + 1)), dim3(256), stream, dy, y, dx, total, act, scale);
   return fsv_check_launch();
 }
 

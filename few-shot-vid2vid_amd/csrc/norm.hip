@@ -305,9 +305,11 @@ __global__ __launch_bounds__(256) void fsv_norm_apply_kernel(const float* x, con
 
 // the same for C % 4 == 0: four consecutive channels per work-item (16-byte loads / stores, one index division per four
 // elements; 32-bit index arithmetic - the host takes this form only below 2^31 elements)
+typedef _Float16 fsv_nh16x4 __attribute__((ext_vector_type(4)));
+
 __global__ __launch_bounds__(256) void fsv_norm_apply4_kernel(const float* x, const float* mean, const float* rstd,
                                                               const float* w, const float* b, float* y, unsigned total4,
-                                                              unsigned PC4, unsigned C4, int act) {
+                                                              unsigned PC4, unsigned C4, int act, _Float16* yh) {
   const unsigned stride = gridDim.x * 256u;
   for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < total4; i += stride) {
     const unsigned c = (i % C4) * 4u, g = i / PC4;
@@ -319,8 +321,13 @@ __global__ __launch_bounds__(256) void fsv_norm_apply4_kernel(const float* x, co
       const float4 wv = *reinterpret_cast<const float4*>(w + c), bv = *reinterpret_cast<const float4*>(b + c);
       v = make_float4(v.x * wv.x + bv.x, v.y * wv.y + bv.y, v.z * wv.z + bv.z, v.w * wv.w + bv.w);
     }
-    *reinterpret_cast<float4*>(y + (size_t)i * 4) = make_float4(fsv_act(v.x, act), fsv_act(v.y, act), fsv_act(v.z, act),
-                                                                fsv_act(v.w, act));
+    const float4 o = make_float4(fsv_act(v.x, act), fsv_act(v.y, act), fsv_act(v.z, act), fsv_act(v.w, act));
+    *reinterpret_cast<float4*>(y + (size_t)i * 4) = o;
+    if (yh) {                   // uniform: the half side output (fsv_common.h)
+      fsv_nh16x4 h;
+      h.x = (_Float16)o.x; h.y = (_Float16)o.y; h.z = (_Float16)o.z; h.w = (_Float16)o.w;
+      *reinterpret_cast<fsv_nh16x4*>(yh + (size_t)i * 4) = h;
+    }
   }
 }
 
@@ -372,7 +379,7 @@ __global__ __launch_bounds__(256) void fsv_norm_bwd_apply4_kernel(const float* d
                                                                   const float* mean, const float* rstd, const float* w,
                                                                   const float* s1, const float* s2, float* dx,
                                                                   unsigned total4, unsigned PC4, unsigned C4, int P, int act,
-                                                                  int fixed_stats) {
+                                                                  int fixed_stats, _Float16* dxh) {
   const unsigned stride = gridDim.x * 256u;
   const float invP = 1.0f / (float)P;
   for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < total4; i += stride) {
@@ -392,6 +399,11 @@ __global__ __launch_bounds__(256) void fsv_norm_bwd_apply4_kernel(const float* d
       r[j] = fixed_stats ? wv * rs * d : wv * rs * (d - s1[gc + j] * invP - xh * (s2[gc + j] * invP));
     }
     *reinterpret_cast<float4*>(dx + o) = make_float4(r[0], r[1], r[2], r[3]);
+    if (dxh) {
+      fsv_nh16x4 h;
+      h.x = (_Float16)r[0]; h.y = (_Float16)r[1]; h.z = (_Float16)r[2]; h.w = (_Float16)r[3];
+      *reinterpret_cast<fsv_nh16x4*>(dxh + o) = h;
+    }
   }
 }
 
@@ -549,22 +561,29 @@ static inline bool fsv_ew_vec4(long long total, int C) {
 static inline void fsv_launch_bwd_apply(const float* dy, const float* y, const float* x, const float* mean, const float* rstd,
                                         const float* w, const float* s1, const float* s2, float* dx, long long total,
                                         long long PC, int C, int P, int act, int fixed_stats, hipStream_t stream) {
-  if (fsv_ew_vec4(total, C)) {
+  const bool v4 = fsv_ew_vec4(total, C);
+  _Float16* dxh = reinterpret_cast<_Float16*>(fsv_sidecar_take(v4));
+  if (v4) {
     FSV_LAUNCH(fsv_norm_bwd_apply4_kernel, dim3(fsv_ew_grid(total / 4)), dim3(256), stream, dy, y, x, mean, rstd, w, s1, s2, dx,
-               (unsigned)(total / 4), (unsigned)(PC / 4), (unsigned)(C / 4), P, act, fixed_stats);
+               (unsigned)(total / 4), (unsigned)(PC / 4), (unsigned)(C / 4), P, act, fixed_stats, dxh);
   } else {
     FSV_LAUNCH(fsv_norm_bwd_apply_kernel, dim3(fsv_ew_grid(total)), dim3(256), stream, dy, y, x, mean, rstd, w, s1, s2, dx,
                total, PC, C, P, act, fixed_stats);
   }
 }
 
+void fsv_half_sidecar_set(void* p) { fsv_sidecar_slot() = p; fsv_sidecar_flag() = 0; }
+int fsv_half_sidecar_taken(void) { return fsv_sidecar_flag(); }
+
 int fsv_norm_apply(const float* x, const float* mean, const float* rstd, const float* w, const float* b, float* y,
                    int G, int P, int C, int act, hipStream_t stream) {
   if (!x || !mean || !rstd || !y || (w && !b)) return FSV_ERR_BAD_ARG;
   long long total = (long long)G * P * C;
-  if (fsv_ew_vec4(total, C)) {
+  const bool v4 = fsv_ew_vec4(total, C);
+  _Float16* yh = reinterpret_cast<_Float16*>(fsv_sidecar_take(v4));
+  if (v4) {
     FSV_LAUNCH(fsv_norm_apply4_kernel, dim3(fsv_ew_grid(total / 4)), dim3(256), stream, x, mean, rstd, w, b, y,
-               (unsigned)(total / 4), (unsigned)((long long)P * C / 4), (unsigned)(C / 4), act);
+               (unsigned)(total / 4), (unsigned)((long long)P * C / 4), (unsigned)(C / 4), act, yh);
   } else {
     FSV_LAUNCH(fsv_norm_apply_kernel, dim3(fsv_ew_grid(total)), dim3(256), stream, x, mean, rstd, w, b, y, total,
                (long long)P * C, C, act);

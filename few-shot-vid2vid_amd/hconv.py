@@ -6,6 +6,7 @@ Mirrors conv.py (gather_gemm / conv_forward / conv_dgrad / conv_wgrad) for half 
 layouts of conv.prep_weight / layout_cache (one table-driven launch per call, or per optimiser step for a whole cache).
 """
 import ctypes
+import os
 
 import torch
 
@@ -61,9 +62,41 @@ def cast(x, dtype):
 
 
 def to_half_nhwc(x):
-    """NHWC half tensor with the logical shape of x (no-op for one that already is)"""
+    """NHWC half tensor with the logical shape of x (no-op for one that already is; the copy its producer left beside an fp32
+    tensor - half_side_output - when there is one)"""
+    side = getattr(x, '_fsv_h16', None)
+    if side is not None and side[0] == x._version and side[1].shape == x.shape:
+        return side[1]
     x = to_nhwc(x)
     return x if x.dtype == torch.float16 else cast(x, torch.float16)
+
+
+class half_side_output:
+    """`with half_side_output(t):` around ONE fsv_norm_apply / fsv_norm_bwd* / fsv_act_bwd call that writes the fp32 NHWC tensor t:
+    under `--amp` on the half-precision kernels the call also stores t as IEEE half (include/fsv2v.h fsv_half_sidecar_set) and the
+    copy rides on the tensor (`_fsv_h16`) - the convolution that reads t next finds its operand already converted.  Same values as
+    the conversion pass it replaces (one rounding of the fp32 result)."""
+
+    def __init__(self, t):
+        self.t = t
+        self.h = None
+        if (conv.h_kernels() and t.dim() == 4 and t.shape[1] % 8 == 0 and t.numel() < 2 ** 31 and t.dtype == torch.float32
+                and os.environ.get('FSV_HALF_SIDE', '1') == '1' and t.permute(0, 2, 3, 1).is_contiguous()):
+            n, c, h, w = t.shape
+            self.h = empty_nhwc_h(n, c, h, w, t)
+
+    def __enter__(self):
+        if self.h is not None:
+            getattr(lib.get_lib(), "fsv_half_sidecar_set")(ctypes.c_void_p(self.h.data_ptr()))
+        return self
+
+    def __exit__(self, et, ev, tb):
+        if self.h is not None:
+            taken = int(getattr(lib.get_lib(), "fsv_half_sidecar_taken")())
+            getattr(lib.get_lib(), "fsv_half_sidecar_set")(None)            # (never leave a pointer armed behind an exception)
+            if taken and et is None:
+                self.t._fsv_h16 = (self.t._version, self.h)
+        return False
 
 
 def planned(mz, cout, nchunks, nsamp, force_tile=-1, force_split=0, can_split=True):

@@ -139,7 +139,8 @@ def act_backward(dy, y, act, scale=1.0):
     dy = to_nhwc(dy) if dy.dim() == 4 else dy.contiguous()
     dx = torch.empty_like(y)
     lib.check_device(dy, y)
-    lib.call("fsv_act_bwd", lib.ptr(dy), lib.ptr(y), lib.ptr(dx), y.numel(), act, float(scale), lib.stream_ptr())
+    with _hconv.half_side_output(dx):
+        lib.call("fsv_act_bwd", lib.ptr(dy), lib.ptr(y), lib.ptr(dx), y.numel(), act, float(scale), lib.stream_ptr())
     return dx
 
 
@@ -807,9 +808,10 @@ def bn_backward(dy, y, x, mean, rstd, w, g, p, c, act, fixed_stats, affine, worl
     dw = torch.empty(c, dtype=torch.float32, device=x.device) if affine else None
     db = torch.empty_like(dw) if affine else None
     ws = _ws(g, p, c, x)
-    lib.call("fsv_norm_bwd_fused", lib.ptr(dy), lib.ptr(y), lib.ptr(x), lib.ptr(mean), lib.ptr(rstd), lib.ptr(w), lib.ptr(ws),
-             lib.ptr(s1), lib.ptr(s2), lib.ptr(dx), lib.ptr(dw), lib.ptr(db), g, p, c, act, 1 if fixed_stats else 0,
-             _ticket(x), lib.stream_ptr())
+    with _hconv.half_side_output(dx):
+        lib.call("fsv_norm_bwd_fused", lib.ptr(dy), lib.ptr(y), lib.ptr(x), lib.ptr(mean), lib.ptr(rstd), lib.ptr(w), lib.ptr(ws),
+                 lib.ptr(s1), lib.ptr(s2), lib.ptr(dx), lib.ptr(dw), lib.ptr(db), g, p, c, act, 1 if fixed_stats else 0,
+                 _ticket(x), lib.stream_ptr())
     return dx, dw, db
 
 
@@ -831,8 +833,9 @@ class _NormActFn(torch.autograd.Function):
         y = torch.empty_like(x)
         wd = weight.detach().contiguous() if weight is not None else None
         bd = bias.detach().contiguous() if bias is not None else None
-        lib.call("fsv_norm_apply", lib.ptr(x), lib.ptr(mean), lib.ptr(rstd), lib.ptr(wd), lib.ptr(bd), lib.ptr(y), g, p,
-                 c, act, lib.stream_ptr())
+        with _hconv.half_side_output(y):
+            lib.call("fsv_norm_apply", lib.ptr(x), lib.ptr(mean), lib.ptr(rstd), lib.ptr(wd), lib.ptr(bd), lib.ptr(y), g, p,
+                     c, act, lib.stream_ptr())
         ctx.dims = (g, p, c)
         ctx.act, ctx.affine = act, weight is not None
         ctx.batch_stats = bool(training or instance or run_mean is None)

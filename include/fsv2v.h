@@ -388,6 +388,12 @@ int fsv_upsample2x_fwd(const float* x, float* y, int N, int H, int W, int C, fsv
 int fsv_upsample2x_bwd(const float* dy, float* dx, int N, int H, int W, int C, fsv_stream_t stream);
 int fsv_act_fwd(const float* x, float* y, long long total, int act, fsv_stream_t stream);
 int fsv_act_bwd(const float* dy, const float* y, float* dx, long long total, int act, float scale, fsv_stream_t stream);
+/* Half side output of the element-wise producers (`--amp`): arms the NEXT fsv_norm_apply / fsv_norm_bwd / fsv_norm_bwd_fused /
+ * fsv_act_bwd call of the calling thread to also store its result (y, dx) as IEEE half at p, same element order - the consumer
+ * convolution reads that copy instead of converting the fp32 tensor.  The call consumes the pointer whether it can honour it or
+ * not (C % 4 == 0 and fewer than 2^31 elements; fsv_act_bwd: total % 4 == 0); fsv_half_sidecar_taken() tells which. */
+void fsv_half_sidecar_set(void* p);
+int fsv_half_sidecar_taken(void);
 /* channel concatenation into one NHWC tensor (one call per source) and its gradient slices; occlusion-mask
  * compositing out = a*m + b*(1-m) (generator.py:217,224,441-443,498,563) */
 int fsv_cat_put(const float* src, float* out, long long N, int C, long long P, const long long* strides, int Ct, int coff,

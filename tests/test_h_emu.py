@@ -109,3 +109,52 @@ def test_spade_f16_bias_sums_over_copies(emu_lib, monkeypatch):
     import op_checks as oc
     monkeypatch.setenv('FSV_SPADE_DB_SLOTS', '4')
     oc.check_spade(DEV, nmaps=2, generated=True, c=32, ch=16, h=16, w=24, up=False, half_out=True, f16=True)
+
+
+def test_half_side_output_of_the_elementwise_producers(emu_lib):
+    """under the half-precision kernels norm_act / its backward / act_backward also store their fp32 result as IEEE half
+    (include/fsv2v.h fsv_half_sidecar_set): the copy equals the conversion pass it replaces and the consumer's to_half_nhwc takes
+    it without a launch"""
+    from importlib import import_module
+    ops = import_module('few-shot-vid2vid_amd.ops')
+    conv = import_module('few-shot-vid2vid_amd.conv')
+    hconv = import_module('few-shot-vid2vid_amd.hconv')
+    lib = emu_lib
+    prev = conv.set_mfma_mode(1)
+    try:
+        assert conv.h_kernels()
+        g = torch.Generator().manual_seed(3)
+        x = conv.to_nhwc(torch.randn(2, 16, 5, 7, generator=g)).requires_grad_(True)
+        w = torch.randn(16, generator=g).requires_grad_(True)
+        b = torch.randn(16, generator=g).requires_grad_(True)
+        y = ops.norm_act(x, w, b, None, None, instance=True, act=conv.ACT_LRELU)
+        side = getattr(y, '_fsv_h16', None)
+        assert side is not None and bool((side[1] == y.detach().to(torch.float16)).all())
+        calls, real = [], lib.call
+
+        def rec(name, *a):
+            calls.append(name)
+            return real(name, *a)
+        lib.call = rec
+        try:
+            yh = hconv.to_half_nhwc(y)
+        finally:
+            lib.call = real
+        assert yh is side[1] and 'fsv_cast_half' not in calls
+        seen = {}
+        y.register_hook(lambda gr: None)
+        x.register_hook(lambda gr: seen.setdefault('dx', gr))
+        dy = conv.to_nhwc(torch.randn(2, 16, 5, 7, generator=g))
+        y.backward(dy)
+        dx = seen['dx']
+        side = getattr(dx, '_fsv_h16', None)
+        assert side is not None and bool((side[1] == dx.to(torch.float16)).all())
+        # odd channel counts / fp32 mode: no side output, the conversion pass runs as before
+        x3 = conv.to_nhwc(torch.randn(1, 12, 4, 4, generator=g))
+        assert getattr(ops.norm_act(x3, None, None, None, None, instance=True, act=conv.ACT_NONE), '_fsv_h16', None) is None
+        d = ops.act_backward(dy, y.detach(), conv.ACT_LRELU)
+        assert bool((d._fsv_h16[1] == d.to(torch.float16)).all())
+    finally:
+        conv.set_mfma_mode(prev)
+    y2 = ops.norm_act(x.detach(), None, None, None, None, instance=True, act=conv.ACT_NONE)
+    assert getattr(y2, '_fsv_h16', None) is None
