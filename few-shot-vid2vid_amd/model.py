@@ -797,7 +797,7 @@ class Vid2VidModel(nn.Module):
             fg0 = fg_mask_of(opt, tgt_label[:, 0], self.has_fg)
             ref_fg0 = fg_mask_of(opt, ref_labels[:, 0], self.has_fg)
             G = self.netG
-            with_raw = (not G.spade_combine) and (G.warp_ref or G.warp_prev)
+            with_raw = ((not G.spade_combine) and (G.warp_ref or G.warp_prev)) or G.add_raw_output_loss
             reals0 = [real, real * union_fg(fg0, ref_fg0, self.has_fg) if with_raw else None]
             # ONE power iteration per stacked call of the reference, shared by its real and its generated half
             sigmas = [self.netD.begin_pass() if r is not None else None for r in reals0]

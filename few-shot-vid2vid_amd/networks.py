@@ -400,8 +400,6 @@ class FewShotGenerator(nn.Module):
         self.spade_combine = opt.spade_combine
         self.n_sc_layers = opt.n_sc_layers
         self.add_raw_output_loss = getattr(opt, 'add_raw_output_loss', False) and opt.spade_combine
-        if self.add_raw_output_loss:
-            raise NotImplementedError("add_raw_output_loss")
         ch_hidden = []
         for i in range(n + 1):
             ch_hidden += [[ch[i]]] if not self.spade_combine or i >= self.n_sc_layers else [[ch[i]] * 3]
@@ -711,6 +709,11 @@ class FewShotGenerator(nn.Module):
             # (stage2_parameters)
             x, enc_label, norm_w, flow, mask, warp, emb = cut.split((x, enc_label, norm_w, flow, mask, warp, emb))
             enc_label = list(enc_label)
+        # --add_raw_output_loss (generator.py:195, 202-205, 227): the last n_sc_layers blocks run a second time on the label
+        # embedding alone (no warped-image maps) - same modules, so their spectral norms and BatchNorm running statistics take a
+        # second update, as the reference's do
+        enc_raw = [enc_label[i] for i in range(self.n_sc_layers)] if self.add_raw_output_loss else None
+        x_raw = None
         if self.spade_combine:
             for i in range(self.n_sc_layers):
                 enc_label[i] = [enc_label[i]] + [e[i] if e is not None else None for e in emb]
@@ -718,6 +721,10 @@ class FewShotGenerator(nn.Module):
             nw = norm_w[i] if (self.adap_spade and i < self.n_adaptive_layers) else None
             # generator.py:121-124: the nearest x2 up-sampling after block i + 1 is handed to block i (up=True), whose SPADE
             # kernels read through the up-sampling index
+            if enc_raw is not None and i < self.n_sc_layers:
+                if i == self.n_sc_layers - 1:
+                    x_raw = x
+                x_raw = getattr(self, 'up_%d' % i)(x_raw, enc_raw[i], nw, up=(i != self.n_downsample_G), feeds_norm=i > 0)
             x = getattr(self, 'up_%d' % i)(x, enc_label[i], nw, up=(i != self.n_downsample_G), feeds_norm=i > 0)
         img_raw = self.conv_img(ops.activation(x, ACT_LRELU), act=ACT_TANH)
         if not self.spade_combine:
@@ -731,7 +738,8 @@ class FewShotGenerator(nn.Module):
             if sources[1] is not None:
                 warp[1], img_final = ops.warp_blend(img_final, sources[1], flow[1], mask[1])
         else:
-            img_final, img_raw = img_raw, None
+            img_final = img_raw
+            img_raw = self.conv_img(ops.activation(x_raw, ACT_LRELU), act=ACT_TANH) if x_raw is not None else None
         return img_final, flow, mask, img_raw, warp, None, None, atn_vis, ref_idx
 
 

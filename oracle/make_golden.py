@@ -59,6 +59,9 @@ CONFIGS['face_fullwidth'] = ('--dataset_mode fewshot_face --fineSize 128 --loadS
                              '--gpu_ids -1 --batchSize 1')
 # two-scale discriminator pyramid (scripts/face/train_g8_512.sh): AvgPool2d(3, 2, 1, count_include_pad=False) between the scales
 CONFIGS['face_numD2'] = CONFIGS['face'] + ' --num_D 2'
+# --add_raw_output_loss (generator.py:195-227): the last n_sc_layers blocks a second time on the label embedding alone, the raw
+# image through the GAN / feature-matching losses next to the combined one
+CONFIGS['pose_combine_raw'] = CONFIGS['pose_combine'] + ' --add_raw_output_loss'
 LAYOUT_CONFIGS = {
     'C3_pose_512': '--dataset_mode fewshot_pose --aspect_ratio 1 --fineSize 512 --loadSize 512 --adaptive_spade --warp_ref '
                    '--spade_combine --remove_face_labels --no_flow_gt --no_vgg_loss --gpu_ids -1',

@@ -15,7 +15,7 @@ from oracle import fsv_oracle as O
 
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
 CASES = ['pose_combine', 'face', 'pose_blend', 'pose_combine_vgg', 'street', 'pose_face_d', 'face_nshot2',
-         'pose_combine_flowgt', 'pose_refine_face', 'face_fullwidth', 'face_numD2']      # face_fullwidth: ngf = ndf = 32, 128 x 128, B = 1 (C1)
+         'pose_combine_flowgt', 'pose_refine_face', 'face_fullwidth', 'face_numD2', 'pose_combine_raw']      # face_fullwidth: ngf = ndf = 32, 128 x 128, B = 1 (C1)
 
 
 def _opt_from_flags(flags):
@@ -43,7 +43,7 @@ def _opt_from_flags(flags):
         elif t == '--gpu_ids':
             i += 2
         elif t in ('--adaptive_spade', '--warp_ref', '--spade_combine', '--remove_face_labels', '--no_flow_gt',
-                   '--no_vgg_loss', '--add_face_D', '--refine_face'):
+                   '--no_vgg_loss', '--add_face_D', '--refine_face', '--add_raw_output_loss'):
             kw[t[2:]] = True; i += 1
         else:
             raise ValueError(t)

@@ -29,6 +29,13 @@ def test_train_step_face_tiny(emu_lib):
     mc.check_train_step(DEV, mc.tiny_opt(dataset_mode='fewshot_face', input_nc=1), b=1)
 
 
+def test_train_step_add_raw_output_loss(emu_lib):
+    """--add_raw_output_loss (generator.py:195-227): the last n_sc_layers blocks a second time on the label embedding alone (second
+    spectral-norm power iteration and BatchNorm running-statistics update of the same modules), the raw image through the GAN and
+    feature-matching losses; pinned to the reference itself by tests/golden/step_pose_combine_raw.pt"""
+    mc.check_train_step(DEV, mc.tiny_opt(warp_ref=True, spade_combine=True, remove_face_labels=True, add_raw_output_loss=True), b=2)
+
+
 def test_temporal_second_frame_tiny(emu_lib):
     """previous-frame flow network (shared with the reference branch), warp and SPADE-combine embedding"""
     mc.check_temporal_step(DEV, mc.tiny_opt(warp_ref=True, spade_combine=True, remove_face_labels=True), b=1)
