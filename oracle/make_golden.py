@@ -62,6 +62,8 @@ CONFIGS['face_numD2'] = CONFIGS['face'] + ' --num_D 2'
 # --add_raw_output_loss (generator.py:195-227): the last n_sc_layers blocks a second time on the label embedding alone, the raw
 # image through the GAN / feature-matching losses next to the combined one
 CONFIGS['pose_combine_raw'] = CONFIGS['pose_combine'] + ' --add_raw_output_loss'
+# --netD_subarch adaptive (discriminator.py:104-209): the first discriminator layer's weights generated from the reference image
+CONFIGS['face_adaptive_D'] = CONFIGS['face'] + ' --netD_subarch adaptive'
 LAYOUT_CONFIGS = {
     'C3_pose_512': '--dataset_mode fewshot_pose --aspect_ratio 1 --fineSize 512 --loadSize 512 --adaptive_spade --warp_ref '
                    '--spade_combine --remove_face_labels --no_flow_gt --no_vgg_loss --gpu_ids -1',
