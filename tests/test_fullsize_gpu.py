@@ -6,7 +6,8 @@ running on the GPU box's host cores, same seeded inputs and weights.
   C2  fewshot_face 256x256  B=4  adaptive_spade          generator forward + backward (the config is defined G-only)
   C3  fewshot_pose 512x512  B=2  adaptive_spade + warp_ref + spade_combine   full D step + G step = the bench.py workload
   C4  C3 + --add_face_D (+ VGG19 loss)  B=2 (the per-rank batch of the 8-GPU config)   full D step + G step
-  C5  fewshot_street 1024x512  label_nc 35  B=1 (per rank)  adaptive_spade   full D step + G step, fp32
+  C5  fewshot_street 1024x512  label_nc 35  B=1 (per rank)  adaptive_spade   full D step + G step, in fp32 and in the config's
+      stated arithmetic (--amp O1, half-precision kernels: against a whole-iteration oracle run in that arithmetic)
 
 Tolerances: losses and images 1e-3 relative (BASELINE.json north_star); per-parameter gradients in the relative L2 norm
 (model_checks.compare_grads_l2), 1e-2 for the full step.  The oracle runs in fp32 and fp64 (C3: ~11 + ~22 GB of host memory):
@@ -96,7 +97,7 @@ def test_c4_pose_512_face_d_vgg(hip_lib):
 def test_c5_street_1024x512_nc35_fp32(hip_lib):
     """BASELINE.json configs[4] per rank in fp32 (data/fewshot_street_dataset.py:19-27: W 1024 x H 512, --label_nc 35 one-hot
     labels, --adaptive_spade; one sample per GPU of the 8-GPU batch of 8): full width, full D step + G step against the oracle.
-    The fp16 arithmetic of that config (--amp O1) is checked at operator level only (tests/test_zz_np_gpu.py)."""
+    The config's own arithmetic (--amp O1) is the next test."""
     opt = mc.make_opt(dataset_mode='fewshot_street', label_nc=35, input_nc=3, aspect_ratio=2.0, fineSize=1024, loadSize=1024,
                       batchSize=1)
     worst = mc.check_train_step(DEV, opt, b=1, tol=1e-3, grad_tol=1e-2)
