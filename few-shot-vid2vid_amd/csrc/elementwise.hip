@@ -574,6 +574,73 @@ __global__ __launch_bounds__(256) void fsv_avgpool3s2_bwd_kernel(const float* dy
 }
 
 extern "C" {
+// nn.AdaptiveAvgPool2d((OH, OW)) on NHWC (discriminator.py:146,153: the pooled reference encoding the AdaptiveDiscriminator's weight
+// generator reads): output (oy, ox) averages rows [floor(oy H / OH), ceil((oy + 1) H / OH)) x the same in x - ATen's window rule
+__device__ __forceinline__ void fsv_adapt_win(int o, int in, int out, int& s, int& e) {
+  s = (int)(((long long)o * in) / out);
+  e = (int)((((long long)(o + 1)) * in + out - 1) / out);
+}
+
+__global__ __launch_bounds__(256) void fsv_adaptive_avgpool_fwd_kernel(const float* x, float* y, int N, int H, int W, int C, int OH,
+                                                                       int OW) {
+  const long long total = (long long)N * OH * OW * C;
+  const long long stride = (long long)gridDim.x * 256;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += stride) {
+    const int c = (int)(i % C);
+    long long r = i / C;
+    const int ox = (int)(r % OW); r /= OW;
+    const int oy = (int)(r % OH);
+    const int n = (int)(r / OH);
+    int ys, ye, xs, xe;
+    fsv_adapt_win(oy, H, OH, ys, ye);
+    fsv_adapt_win(ox, W, OW, xs, xe);
+    float acc = 0.f;
+    for (int yy = ys; yy < ye; ++yy)
+      for (int xx = xs; xx < xe; ++xx) acc += x[(((long long)n * H + yy) * W + xx) * C + c];
+    y[i] = acc / (float)((ye - ys) * (xe - xs));
+  }
+}
+
+// every input element collects dy / window size of the (at most 2 x 2) windows that contain it: no atomics
+__global__ __launch_bounds__(256) void fsv_adaptive_avgpool_bwd_kernel(const float* dy, float* dx, int N, int H, int W, int C, int OH,
+                                                                       int OW) {
+  const long long total = (long long)N * H * W * C;
+  const long long stride = (long long)gridDim.x * 256;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += stride) {
+    const int c = (int)(i % C);
+    long long r = i / C;
+    const int xx = (int)(r % W); r /= W;
+    const int yy = (int)(r % H);
+    const int n = (int)(r / H);
+    const int oy0 = (int)(((long long)yy * OH) / H), ox0 = (int)(((long long)xx * OW) / W);
+    float acc = 0.f;
+    for (int oy = (oy0 > 0 ? oy0 - 1 : 0); oy <= oy0 + 1 && oy < OH; ++oy) {
+      int ys, ye;
+      fsv_adapt_win(oy, H, OH, ys, ye);
+      if (yy < ys || yy >= ye) continue;
+      for (int ox = (ox0 > 0 ? ox0 - 1 : 0); ox <= ox0 + 1 && ox < OW; ++ox) {
+        int xs, xe;
+        fsv_adapt_win(ox, W, OW, xs, xe);
+        if (xx < xs || xx >= xe) continue;
+        acc += dy[(((long long)n * OH + oy) * OW + ox) * C + c] / (float)((ye - ys) * (xe - xs));
+      }
+    }
+    dx[i] = acc;
+  }
+}
+
+int fsv_adaptive_avgpool_fwd(const float* x, float* y, int N, int H, int W, int C, int OH, int OW, hipStream_t stream) {
+  if (!x || !y || N < 1 || H < 1 || W < 1 || C < 1 || OH < 1 || OW < 1 || OH > H || OW > W) return FSV_ERR_BAD_ARG;
+  FSV_LAUNCH(fsv_adaptive_avgpool_fwd_kernel, dim3(fsv_grid_for((long long)N * OH * OW * C)), dim3(256), stream, x, y, N, H, W, C, OH, OW);
+  return fsv_check_launch();
+}
+
+int fsv_adaptive_avgpool_bwd(const float* dy, float* dx, int N, int H, int W, int C, int OH, int OW, hipStream_t stream) {
+  if (!dy || !dx || N < 1 || H < 1 || W < 1 || C < 1 || OH < 1 || OW < 1 || OH > H || OW > W) return FSV_ERR_BAD_ARG;
+  FSV_LAUNCH(fsv_adaptive_avgpool_bwd_kernel, dim3(fsv_grid_for((long long)N * H * W * C)), dim3(256), stream, dy, dx, N, H, W, C, OH, OW);
+  return fsv_check_launch();
+}
+
 int fsv_avgpool3s2_fwd(const float* x, float* y, int N, int H, int W, int C, hipStream_t stream) {
   if (!x || !y || N < 1 || H < 1 || W < 1 || C < 1) return FSV_ERR_BAD_ARG;
   FSV_LAUNCH(fsv_avgpool3s2_fwd_kernel, dim3(fsv_grid_for((long long)N * ((H - 1) / 2 + 1) * ((W - 1) / 2 + 1) * C)), dim3(256), stream,

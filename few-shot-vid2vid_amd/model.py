@@ -165,12 +165,14 @@ class LossCollector:
         """loss_collector.py:47-68: D sees [ref | label | image] with fake and real stacked on the batch axis.  real_out:
         (outputs, sigmas) of the discriminator for the real images from real_pass() - then only the generated images go through
         it here, on the same sigmas."""
+        # --netD_subarch adaptive: the reference tensor is the discriminator's second input instead of extra channels
+        side = ref if (ref is not None and not self.concat_ref_for_D) else None
         if real_out is not None:
             x = ops.pack_d_single(ref if self.concat_ref_for_D else None, label, fake, for_conv=_single_scale(netD))
-            pred_fake, pred_real = netD(x, sn=real_out[1]), real_out[0]
+            pred_fake, pred_real = netD(x, side, sn=real_out[1]), real_out[0]
         else:
             x = ops.pack_d_input(ref if self.concat_ref_for_D else None, label, fake, real, for_conv=_single_scale(netD))
-            out = netD(x)
+            out = netD(x, side.repeat(2, 1, 1, 1) if side is not None else None)
             half = x.shape[0] // 2
             pred_fake = [[t[:half] for t in scale] for scale in out]
             pred_real = [[t[half:] for t in scale] for scale in out]
@@ -254,7 +256,7 @@ class LossCollector:
                     continue
                 real4 = real.reshape(-1, *real.shape[-3:])
                 x = ops.pack_d_single(ref_concat if self.concat_ref_for_D else None, inp, real4, for_conv=_single_scale(netD))
-                outs.append((netD(x, sn=sn), sn))
+                outs.append((netD(x, None if self.concat_ref_for_D else ref_concat, sn=sn), sn))
         return outs
 
     def gan_losses(self, netD, tgt_label, reals, fakes, ref_label, ref_image, for_discriminator, netDf=None, real_outs=None):
@@ -333,7 +335,7 @@ class LossCollector:
 def _single_scale(netD):
     """the packed discriminator input is read by ONE convolution and nothing else (a multi-scale pyramid, --num_D > 1, also
     average-pools it): ops.pack_d_* may then hand it over padded and - under `--amp` - as half"""
-    return getattr(netD, 'num_D', 2) == 1
+    return getattr(netD, 'num_D', 2) == 1 and getattr(netD, 'subarch', 'n_layers') == 'n_layers'
 
 
 def amp_mode(opt):

@@ -860,25 +860,99 @@ class NLayerDiscriminator(nn.Module):
         return res if self.getIntermFeat else res[-1]
 
 
-class MultiscaleDiscriminator(nn.Module):
-    """Reference discriminator.py:16-58 (subarch 'n_layers')."""
+class AdaptiveDiscriminator(NLayerDiscriminator):
+    """Reference discriminator.py:104-209 (`--netD_subarch adaptive`): the first `adaptive_layers` convolutions take weights
+    GENERATED from the reference image - encoder_n (k4 s2 p2 + LeakyReLU) on [ref label | ref image], adaptive average pooling of
+    every encoded channel to (fineSize / 8 / aspect, fineSize / 8), one Linear per layer from the pooled map to a k4 x k4 filter
+    row - applied per sample with stride 2, InstanceNorm (no affine) and LeakyReLU; the remaining layers are the spectral
+    PatchGAN's.  Same attribute names / state_dict keys as the reference."""
 
-    def __init__(self, opt, input_nc, ndf=64, n_layers=3, num_D=1, getIntermFeat=False, stride=2):
+    def __init__(self, opt, input_nc, ndf=64, n_layers=3, getIntermFeat=False, adaptive_layers=1):
+        nn.Module.__init__(self)
+        self.getIntermFeat, self.n_layers, self.adaptive_layers = getIntermFeat, n_layers, adaptive_layers
+        self.input_nc, self.ndf = input_nc, ndf
+        self.sw = opt.fineSize // 8
+        self.sh = int(self.sw / opt.aspect_ratio)
+        ch = self.sh * self.sw
+        nf = ndf
+        self.fc_0 = Linear(ch, input_nc * 16, spectral=False)
+        self.encoder_0 = _seq(Conv2d(input_nc, ndf, 4, stride=2, padding=2), _Slot())
+        for n in range(1, adaptive_layers):
+            nf_prev, nf = nf, min(nf * 2, 512)
+            setattr(self, 'fc_%d' % n, Linear(ch, nf_prev * 16, spectral=False))
+            setattr(self, 'encoder_%d' % n, _seq(Conv2d(nf_prev, nf, 4, stride=2, padding=2), _Slot()))
+        nf = ndf * (2 ** (adaptive_layers - 1))
+        for n in range(adaptive_layers, n_layers + 1):
+            nf_prev, nf = nf, min(nf * 2, 512)
+            setattr(self, 'model%d' % n, _seq(_seq(Conv2d(nf_prev, nf, 4, stride=2 if n != n_layers else 1, padding=2, bias=False,
+                                                          spectral=True), InstanceNorm(nf)), _Slot()))
+        setattr(self, 'model%d' % (n_layers + 1), _seq(Conv2d(nf, 1, 4, stride=1, padding=2)))
+        self._sn_group = None
+
+    def forward(self, x, ref=None, sn=None):
+        if ref is None:
+            raise ValueError("the adaptive discriminator needs the reference [label | image] tensor")
+        snap = self.begin_pass() if sn is None else sn
+        for l, c in snap:
+            l._sig_cached = c
+        try:
+            return self._run_adaptive(x, ref)
+        finally:
+            for l, _ in snap:
+                l._sig_cached = None
+
+    def _run_adaptive(self, x, ref):
+        enc, r = [], ref
+        for n in range(self.adaptive_layers):                       # encode (discriminator.py:186-190)
+            r = getattr(self, 'encoder_%d' % n)[0](r, act=ACT_LRELU)
+            enc.append(r)
+        res = []
+        nf, nf_prev = self.ndf, self.input_nc
+        for n in range(self.adaptive_layers):                       # gen_conv_weights + batch_conv (discriminator.py:142-170,192-197)
+            e = enc[n]
+            b, ch = e.shape[0], e.shape[1]
+            pooled = ops.adaptive_avgpool(e, self.sh, self.sw).reshape(b * ch, self.sh * self.sw)
+            wgt = getattr(self, 'fc_%d' % n)(pooled).view(b, nf, nf_prev, 4, 4)
+            x = ops.batch_conv(x, wgt, None, stride=2, allow_half=False)
+            x = ops.norm_act(x, None, None, None, None, instance=True, eps=1e-5, act=ACT_LRELU)
+            res.append(x)
+            nf_prev, nf = nf, min(nf * 2, 512)
+        for n in range(self.adaptive_layers, self.n_layers + 1):
+            conv, norm = getattr(self, 'model%d' % n)[0]
+            x = norm(conv(x, stats=-1), act=ACT_LRELU)
+            res.append(x)
+        x = getattr(self, 'model%d' % (self.n_layers + 1))[0](x)
+        res.append(x)
+        return res if self.getIntermFeat else res[-1]
+
+
+class MultiscaleDiscriminator(nn.Module):
+    """Reference discriminator.py:16-58 (subarch 'n_layers' or 'adaptive')."""
+
+    def __init__(self, opt, input_nc, ndf=64, n_layers=3, num_D=1, getIntermFeat=False, stride=2, subarch='n_layers'):
         super().__init__()
-        self.num_D, self.getIntermFeat = num_D, getIntermFeat
+        self.num_D, self.getIntermFeat, self.subarch = num_D, getIntermFeat, subarch
         for i in range(num_D):
-            setattr(self, 'discriminator_%d' % i, NLayerDiscriminator(input_nc, ndf, n_layers, getIntermFeat, stride))
+            if subarch == 'adaptive':
+                d = AdaptiveDiscriminator(opt, input_nc, ndf, n_layers, getIntermFeat, getattr(opt, 'adaptive_D_layers', 1))
+            else:
+                d = NLayerDiscriminator(input_nc, ndf, n_layers, getIntermFeat, stride)
+            setattr(self, 'discriminator_%d' % i, d)
 
     def begin_pass(self):
         return [getattr(self, 'discriminator_%d' % i).begin_pass() for i in range(self.num_D)]
 
     def forward(self, x, ref=None, sn=None):
         result = []
+        adaptive = self.subarch == 'adaptive'
         for i in range(self.num_D):
-            out = getattr(self, 'discriminator_%d' % i)(x, sn=sn[i] if sn is not None else None)
+            d = getattr(self, 'discriminator_%d' % i)
+            out = d(x, ref, sn=sn[i] if sn is not None else None) if adaptive else d(x, sn=sn[i] if sn is not None else None)
             result.append(out if self.getIntermFeat else [out])
             if i + 1 < self.num_D:
                 x = ops.avgpool3s2(x)            # discriminator.py:28,56 (scripts/face/train_g8_512.sh: --num_D 2)
+                if adaptive:
+                    ref = ops.avgpool3s2(ref)
         return result
 
 
@@ -890,6 +964,8 @@ def define_G(opt):
 def define_D(opt, input_nc, ndf, n_layers_D, norm='spectralinstance', subarch='n_layers', num_D=1, getIntermFeat=False,
              stride=2, gpu_ids=()):
     """Reference models/networks/__init__.py:41-55."""
-    if norm != 'spectralinstance' or subarch != 'n_layers':
-        raise NotImplementedError("only the shipped 'spectralinstance' n_layers PatchGAN is on the hot path")
-    return MultiscaleDiscriminator(opt, input_nc, ndf, n_layers_D, num_D, getIntermFeat, stride)
+    if norm != 'spectralinstance' or subarch not in ('n_layers', 'adaptive'):
+        raise NotImplementedError("only the 'spectralinstance' PatchGANs (n_layers, adaptive) are on the hot path")
+    if subarch == 'adaptive' and str(getattr(opt, 'amp', 'O0')) != 'O0':
+        raise NotImplementedError("--netD_subarch adaptive under --amp")
+    return MultiscaleDiscriminator(opt, input_nc, ndf, n_layers_D, num_D, getIntermFeat, stride, subarch)

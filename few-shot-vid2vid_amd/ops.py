@@ -1867,3 +1867,29 @@ class _AvgPool3s2Fn(torch.autograd.Function):
 
 def avgpool3s2(x):
     return _AvgPool3s2Fn.apply(x)
+
+
+class _AdaptiveAvgPoolFn(torch.autograd.Function):
+    """nn.AdaptiveAvgPool2d((oh, ow)) (discriminator.py:146,153)"""
+
+    @staticmethod
+    def forward(ctx, x, oh, ow):
+        x = to_nhwc(x)
+        n, c, h, w = x.shape
+        y = empty_nhwc(n, c, oh, ow, x)
+        lib.check_device(x)
+        lib.call("fsv_adaptive_avgpool_fwd", lib.ptr(x), lib.ptr(y), n, h, w, c, oh, ow, lib.stream_ptr())
+        ctx.dims = (n, c, h, w, oh, ow)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        n, c, h, w, oh, ow = ctx.dims
+        dy = to_nhwc(dy)
+        dx = empty_nhwc(n, c, h, w, dy)
+        lib.call("fsv_adaptive_avgpool_bwd", lib.ptr(dy), lib.ptr(dx), n, h, w, c, oh, ow, lib.stream_ptr())
+        return dx, None, None
+
+
+def adaptive_avgpool(x, oh, ow):
+    return _AdaptiveAvgPoolFn.apply(x, int(oh), int(ow))

@@ -17,7 +17,7 @@ def make_opt(**kw):
         res_for_ref=False, adaptive_conv=False, adaptive_spade=True, no_adaptive_embed=False, n_adaptive_layers=4,
         n_fc_layers=2, n_frames_G=2, n_frames_per_gpu=1, n_frames_D=2, no_flow_gt=True, spade_combine=False,
         n_sc_layers=2, add_raw_output_loss=False, sep_flow_prev=False, no_sep_warp_embed=False, n_shot=1,
-        n_downsample_A=2, warp_ref=False, which_model_netD='multiscale', netD_subarch='n_layers', num_D=1,
+        n_downsample_A=2, warp_ref=False, which_model_netD='multiscale', netD_subarch='n_layers', adaptive_D_layers=1, num_D=1,
         n_layers_D=4, gan_mode='hinge', add_face_D=False, lambda_kld=0.0, lambda_feat=10.0, lambda_temp=0.0,
         lambda_flow=10.0, lambda_mask=10.0, lambda_vgg=10.0, lambda_face=10.0, no_ganFeat_loss=False,
         no_vgg_loss=True, no_TTUR=False, lr=0.0004, beta1=0.5, beta2=0.999, isTrain=True, finetune=False,

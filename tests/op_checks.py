@@ -809,6 +809,25 @@ def check_avgpool3s2(device, seed=90):
         assert_close('avgpool dx %s' % (shp,), xd.grad, xr.grad, 1e-6)
 
 
+def check_adaptive_avgpool(device, seed=92):
+    """nn.AdaptiveAvgPool2d (AdaptiveDiscriminator.gen_conv_weights): windows that do not divide (33 -> 8), that do (32 -> 8),
+    identity, and a rectangular case"""
+    ops, conv = pkg()
+    g = torch.Generator().manual_seed(seed)
+    for shp, out in [((2, 8, 33, 33), (8, 8)), ((1, 16, 32, 32), (8, 8)), ((2, 4, 8, 8), (8, 8)), ((1, 5, 17, 33), (4, 8)),
+                     ((1, 3, 9, 5), (1, 1))]:
+        x = torch.randn(*shp, generator=g)
+        xr = x.clone().requires_grad_(True)
+        ref = F.adaptive_avg_pool2d(xr, out)
+        dy = torch.randn(ref.shape, generator=g)
+        ref.backward(dy)
+        xd = _dev(x, device).requires_grad_(True)
+        y = ops.adaptive_avgpool(xd, *out)
+        y.backward(_dev(dy, device))
+        assert_close('adaptive avgpool y %s' % (shp,), y, ref, 1e-6)
+        assert_close('adaptive avgpool dx %s' % (shp,), xd.grad, xr.grad, 1e-6)
+
+
 def check_fused_reductions(device, shapes=((1, 4096, 32), (2, 1000, 7), (1, 300, 260), (4, 64, 512), (1, 70000, 64)),
                            repeats=3, seed=91):
     """One-launch statistics / column sums (last-workgroup second stage, csrc/norm.hip) against fp64 torch, repeatedly on the

@@ -15,7 +15,7 @@ from oracle import fsv_oracle as O
 
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
 CASES = ['pose_combine', 'face', 'pose_blend', 'pose_combine_vgg', 'street', 'pose_face_d', 'face_nshot2',
-         'pose_combine_flowgt', 'pose_refine_face', 'face_fullwidth', 'face_numD2', 'pose_combine_raw']      # face_fullwidth: ngf = ndf = 32, 128 x 128, B = 1 (C1)
+         'pose_combine_flowgt', 'pose_refine_face', 'face_fullwidth', 'face_numD2', 'pose_combine_raw', 'face_adaptive_D']      # face_fullwidth: ngf = ndf = 32, 128 x 128, B = 1 (C1)
 
 
 def _opt_from_flags(flags):
@@ -38,6 +38,8 @@ def _opt_from_flags(flags):
             kw['lambda_temp'] = float(toks[i + 1]); i += 2
         elif t == '--n_shot':
             kw['n_shot'] = int(toks[i + 1]); i += 2
+        elif t == '--netD_subarch':
+            kw['netD_subarch'] = toks[i + 1]; i += 2
         elif t == '--aspect_ratio':
             kw['aspect_ratio'] = float(toks[i + 1]); i += 2
         elif t == '--gpu_ids':

@@ -29,6 +29,13 @@ def test_train_step_face_tiny(emu_lib):
     mc.check_train_step(DEV, mc.tiny_opt(dataset_mode='fewshot_face', input_nc=1), b=1)
 
 
+def test_train_step_adaptive_discriminator(emu_lib):
+    """--netD_subarch adaptive (discriminator.py:104-209): first discriminator layer with weights generated from the reference
+    image (encoder, adaptive average pool, Linear, per-sample stride-2 convolution, InstanceNorm); pinned to the reference itself
+    by tests/golden/step_face_adaptive_D.pt"""
+    mc.check_train_step(DEV, mc.tiny_opt(dataset_mode='fewshot_face', input_nc=1, netD_subarch='adaptive'), b=2)
+
+
 def test_train_step_add_raw_output_loss(emu_lib):
     """--add_raw_output_loss (generator.py:195-227): the last n_sc_layers blocks a second time on the label embedding alone (second
     spectral-norm power iteration and BatchNorm running-statistics update of the same modules), the raw image through the GAN and

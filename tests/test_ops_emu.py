@@ -180,3 +180,7 @@ def test_norm_statistics_from_the_conv_epilogue(emu_lib):
 
 def test_thin_output_convolutions(emu_lib):
     oc.check_thin_conv(DEV)
+
+
+def test_adaptive_avgpool(emu_lib):
+    oc.check_adaptive_avgpool(DEV)

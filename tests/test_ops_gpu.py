@@ -183,3 +183,7 @@ def test_norm_statistics_from_the_conv_epilogue(hip_lib):
 
 def test_thin_output_convolutions(hip_lib):
     oc.check_thin_conv(dev())
+
+
+def test_adaptive_avgpool(hip_lib):
+    oc.check_adaptive_avgpool(dev())
