@@ -458,6 +458,13 @@ def gather_gemm(x, wt, ldw, cout, oh, ow, ty, tx, sy, sx, bias=None, res=None, a
         entry = "fsv_conv_gather_fwd_np"
         args = args[:-1] + (_np_mode, args[-1])
     grp = _active_group()
+    split_ws = None
+    if entry == "fsv_conv_gather_fwd" and grp is None and place is None and not accumulate and ordered_split():
+        # ordered split-K: every split stores its own copy of the output, the finishing pass sums them in ascending order
+        ns = planned(oh * ow if per_sample else n * oh * ow, cout, (len(ty) * cin + 31) // 32, n if per_sample else 1, force_tile,
+                     force_split)[1]
+        if ns > 1 and act != ACT_DLRELU:
+            split_ws = torch.empty(ns * out.numel(), dtype=torch.float32, device=x.device)
     if (stats is not None and grp is None and entry == "fsv_conv_gather_fwd" and place is None and not per_sample
             and not accumulate and force_tile < 0 and force_split == 0 and cin % 4 == 0 and stats_enabled()):
         groups = int(stats['groups'])
@@ -472,10 +479,13 @@ def gather_gemm(x, wt, ldw, cout, oh, ow, ty, tx, sy, sx, bias=None, res=None, a
         label = 'fsv_conv_igemm_kernel'
         if profile.enabled():
             label = profile.conv_label(n * oh * ow, cout, (len(ty) * cin + 31) // 32, 1, True, force_tile, force_split)
-        keep = (x, wt, bias, res, out, wscale, part)
-        with profile.scope(label, 2.0 * n * oh * ow * cout * cin * len(ty),
-                           replay=lambda sargs=sargs, keep=keep: lib.call("fsv_conv_gather_fwd_stats", *sargs)):
+        keep = (x, wt, bias, res, out, wscale, part, split_ws)
+
+        def go_stats(sargs=sargs, keep=keep):
+            _arm_split(split_ws)
             lib.call("fsv_conv_gather_fwd_stats", *sargs)
+        with profile.scope(label, 2.0 * n * oh * ow * cout * cin * len(ty), replay=go_stats):
+            go_stats()
         if produced.value:
             stats['part'], stats['slots'] = part, STATS_SLOTS
         return out
@@ -503,13 +513,27 @@ def gather_gemm(x, wt, ldw, cout, oh, ow, ty, tx, sy, sx, bias=None, res=None, a
                                                                                 force_tile, force_split, act))
         if entry.endswith('_np'):
             label = label.replace('fsv_conv_igemm_kernel', 'fsv_np_conv_kernel[%s]' % ('f16' if _np_mode == 1 else 'bf16x3'))
-        keep = (x, wt, bias, res, out, wscale)          # the replay re-issues the launch on the same buffers
-        with profile.scope(label, 2.0 * n * oh * ow * cout * cin * len(ty),
-                           replay=lambda entry=entry, args=args, keep=keep: lib.call(entry, *args)):
+        keep = (x, wt, bias, res, out, wscale, split_ws)          # the replay re-issues the launch on the same buffers
+
+        def go(entry=entry, args=args, keep=keep):
+            _arm_split(split_ws)
             lib.call(entry, *args)
+        with profile.scope(label, 2.0 * n * oh * ow * cout * cin * len(ty), replay=go):
+            go()
     else:
+        _arm_split(split_ws)
         lib.call(entry, *args)
     return out
+
+
+def _arm_split(ws):
+    if ws is not None:
+        getattr(lib.get_lib(), "fsv_conv_split_workspace_set")(ctypes.c_void_p(ws.data_ptr()), ctypes.c_longlong(ws.numel()))
+
+
+def ordered_split():
+    """split-K launches of the fp32 gather-GEMM sum their splits in a fixed order (FSV_ORDERED_SPLIT=0: the atomic form, A/B)"""
+    return os.environ.get('FSV_ORDERED_SPLIT', '1') == '1'
 
 
 def _thin_k(cout, cin, ntaps, per_sample, place, accumulate, force_tile, force_split, act):

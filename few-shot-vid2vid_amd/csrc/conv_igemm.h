@@ -104,6 +104,8 @@ struct ConvP {
   double* stats;
   int stats_slots, stats_ohw;
   long long res_bytes;                   // extent of the residual tensor when one descriptor covers it (else 0: loaded per element)
+  float* part;                           // ordered split-K: split k stores its partial output at part + k * part_stride (else null:
+  long long part_stride;                 // splits add into the zeroed output atomically)
 };
 
 __device__ __forceinline__ void fsv_tap(const ConvP& p, int t, int& ty, int& tx) {

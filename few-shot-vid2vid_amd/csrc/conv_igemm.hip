@@ -462,7 +462,8 @@ __device__ __forceinline__ void fsv_conv_igemm_body(const ConvP& p, const int bx
         float* dst = p.out + opix * p.Cout + co;
         float v = acc[i][j][r] * ws;
         if (p.nsplit > 1) {
-          atomicAdd(dst, v);
+          if (p.part) p.part[(long long)zk * p.part_stride + opix * p.Cout + co] = v;      // uniform: ordered split
+          else atomicAdd(dst, v);
         } else {
           v = (v + bv) * p.scale;
           if (p.act == FSV_ACT_DLRELU) {        // data gradient handed straight to the layer below: times LeakyReLU'(its output)
@@ -696,7 +697,7 @@ __device__ __forceinline__ void fsv_conv_igemm_v1_body(const ConvP& p, const int
         float* dst = p.out + opix * p.Cout + co;
         float v = acc[i][j][r] * ws;
         if (p.nsplit > 1) {
-          atomicAdd(dst, v);
+          atomicAdd(dst, v);                 // (the scalar-gather form keeps the atomic split: the host never arms it)
         } else {
           v = (v + bv) * p.scale;
           if (p.act == FSV_ACT_DLRELU) {
@@ -743,6 +744,26 @@ __global__ __launch_bounds__(256) void fsv_bias_act_kernel(float* out, const flo
     float v = out[i];
     if (bias) {
       long long n = b_bstride ? pix / pix_per_sample : 0;
+      v += bias[n * b_bstride + c];
+    }
+    v = fsv_act(v * scale, act);
+    if (res) v += res[i];
+    out[i] = v;
+  }
+}
+
+// ---- finishing pass of an ORDERED split-K launch: out = act((sum_k part[k] + bias) * scale) + res, k ascending -----------------
+__global__ __launch_bounds__(256) void fsv_split_finish_kernel(const float* part, long long part_stride, int nsplit, float* out,
+                                                               const float* bias, const float* res, long long total, int C,
+                                                               long long pix_per_sample, long long b_bstride, int act, float scale) {
+  long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  const long long stride = (long long)gridDim.x * 256;
+  for (; i < total; i += stride) {
+    float v = part[i];
+    for (int k = 1; k < nsplit; ++k) v += part[(long long)k * part_stride + i];
+    if (bias) {
+      const int c = (int)(i % C);
+      const long long n = b_bstride ? (i / C) / pix_per_sample : 0;
       v += bias[n * b_bstride + c];
     }
     v = fsv_act(v * scale, act);
@@ -1720,6 +1741,7 @@ static inline void fsv_fill_convp(ConvP& p, const float* in, const float* wt, co
   p.Mz = per_sample ? OH * OW : N * OH * OW;
   p.nsplit = 1;
   p.stats = nullptr; p.stats_slots = 1; p.stats_ohw = 1;
+  p.part = nullptr; p.part_stride = 0;
   {
     const long long obytes = (long long)N * outH * outW * Cout * 4;
     p.res_bytes = (res && obytes <= FSV_BUF_MAX_BYTES) ? obytes : 0;
@@ -1739,6 +1761,9 @@ static int fsv_conv_gather_impl(const float* in, const float* wt, const float* b
                         int act, float scale, int force_tile, int force_split, int accumulate, const float* wscale,
                         double* stats, int stats_groups, int stats_slots, int stats_prezeroed, int* produced,
                         hipStream_t stream) {
+  float* const split_ws = fsv_splitws_ptr();            // (the arming is consumed whatever this call does with it)
+  const long long split_cap = fsv_splitws_cap();
+  fsv_splitws_ptr() = nullptr; fsv_splitws_cap() = 0;
   if (!in || !wt || !out || ntaps < 1 || ntaps > 16 || N < 1 || Cin < 1 || Cout < 1) return FSV_ERR_BAD_ARG;
   for (int t = 0; t < ntaps; ++t)
     if (ty[t] < -8 || ty[t] > 7 || tx[t] < -8 || tx[t] > 7) return FSV_ERR_UNSUPPORTED;
@@ -1782,7 +1807,11 @@ static int fsv_conv_gather_impl(const float* in, const float* wt, const float* b
     // nsplit == 1: every output pixel belongs to exactly one parity class and one tile -> plain stores
   } else if (nsplit > 1) {
     if (!p.dense_out) return FSV_ERR_UNSUPPORTED;
-    (void)hipMemsetAsync(out, 0, (size_t)total * sizeof(float), stream);
+    if (split_ws && (Cin % 4 == 0) && split_cap >= (long long)nsplit * total) {
+      p.part = split_ws; p.part_stride = total;         // ordered: one copy of the output per split, summed by the finishing pass
+    } else {
+      (void)hipMemsetAsync(out, 0, (size_t)total * sizeof(float), stream);
+    }
   }
   const bool vec4 = (Cin % 4 == 0);
   if (produced) *produced = 0;
@@ -1798,18 +1827,24 @@ static int fsv_conv_gather_impl(const float* in, const float* wt, const float* b
   if (force_tile < 0 && vec4) tile = fsv_conv_variant(tile);
   int rc = fsv_launch_conv(p, vec4, nsamp * nsplit, stream, tile);
   if (rc) return rc;
-  if (!accumulate && nsplit > 1 && (bias || res || act != FSV_ACT_NONE || scale != 1.f)) {
+  if (!accumulate && nsplit > 1 && (p.part || bias || res || act != FSV_ACT_NONE || scale != 1.f)) {
     int grid = (int)((total + 256 * 8 - 1) / (256 * 8));
     if (grid > 4096) grid = 4096;
     if (grid < 1) grid = 1;
-    FSV_LAUNCH(fsv_bias_act_kernel, dim3(grid), dim3(256), stream, out, bias, res, total, Cout,
-               (long long)outH * outW, per_sample ? b_bstride : 0ll, act, scale);
+    if (p.part)
+      FSV_LAUNCH(fsv_split_finish_kernel, dim3(grid), dim3(256), stream, (const float*)p.part, p.part_stride, nsplit, out, bias, res,
+                 total, Cout, (long long)outH * outW, per_sample ? b_bstride : 0ll, act, scale);
+    else
+      FSV_LAUNCH(fsv_bias_act_kernel, dim3(grid), dim3(256), stream, out, bias, res, total, Cout,
+                 (long long)outH * outW, per_sample ? b_bstride : 0ll, act, scale);
     rc = fsv_check_launch();
   }
   return rc;
 }
 
 extern "C" {
+
+void fsv_conv_split_workspace_set(float* ws, long long floats) { fsv_splitws_ptr() = ws; fsv_splitws_cap() = ws ? floats : 0; }
 
 int fsv_conv_gather_fwd(const float* in, const float* wt, const float* bias, const float* res, float* out,
                         int N, int H, int W, int Cin, int OH, int OW, int Cout,

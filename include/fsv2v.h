@@ -48,6 +48,11 @@ enum fsv_act { FSV_ACT_NONE = 0, FSV_ACT_LRELU = 1 /* leaky_relu(0.2), architect
  * FSV_CONV_PF2=0).
  * One activation tensor / weight matrix may hold at most 2 GiB (32-bit byte offsets): FSV_ERR_UNSUPPORTED beyond.  wscale: optional device scalar multiplying the accumulator before
  * the bias (the spectral-norm 1/sigma when wt holds un-normalised weights). */
+/* Ordered split-K: arms the NEXT fsv_conv_gather_fwd / fsv_conv_gather_fwd_stats call of the calling thread - when its plan splits
+ * K, split k stores its partial output into the k-th copy inside ws (nsplit x N*outH*outW*Cout floats) and a finishing pass sums the
+ * copies in ascending order: the same bits on every run, no zero fill, no atomics.  A call that does not split, or whose copies do
+ * not fit into `floats`, ignores the workspace (and adds atomically as before); the arming is consumed either way. */
+void fsv_conv_split_workspace_set(float* ws, long long floats);
 int fsv_conv_gather_fwd(const float* in, const float* wt, const float* bias, const float* res, float* out,
                         int N, int H, int W, int Cin, int OH, int OW, int Cout,
                         int ntaps, const int* ty, const int* tx, int sy, int sx,

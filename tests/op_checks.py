@@ -809,6 +809,35 @@ def check_avgpool3s2(device, seed=90):
         assert_close('avgpool dx %s' % (shp,), xd.grad, xr.grad, 1e-6)
 
 
+def check_ordered_split(device, seed=93):
+    """split-K launches of the fp32 gather-GEMM sum their splits in ascending order (one output copy per split + a finishing pass,
+    include/fsv2v.h fsv_conv_split_workspace_set): the same bits on every run, equal to the atomic form up to summation order,
+    epilogue (bias, LeakyReLU, residual) applied once by the finishing pass"""
+    ops, conv = pkg()
+    g = torch.Generator().manual_seed(seed)
+    n, cin, h, w, cout = 2, 256, 6, 5, 96
+    x = conv.to_nhwc(_dev(torch.randn(n, cin, h, w, generator=g), device))
+    wt = _dev(torch.randn(cout, cin, 3, 3, generator=g) * 0.05, device)
+    b = _dev(torch.randn(cout, generator=g), device)
+    res = conv.to_nhwc(_dev(torch.randn(n, cout, h, w, generator=g), device))
+    geo = conv.Geom(3, 3, 1, 1)
+    wf, _, ldw = conv.prep_weight(wt, 0, geo)
+
+    def run(split):
+        return conv.conv_forward(x, wf, ldw, cout, geo, bias=b, res=res, act=conv.ACT_NONE, force_split=split).clone()
+    ref = F.conv2d(x.cpu(), wt.cpu(), b.cpu(), padding=1) + res.cpu()
+    outs = [run(4) for _ in range(4)]
+    for o in outs[1:]:
+        assert bool((o == outs[0]).all()), 'ordered split-K is not bit-reproducible'
+    assert_close('ordered split', outs[0], ref, 1e-5)
+    os.environ['FSV_ORDERED_SPLIT'] = '0'
+    try:
+        atomic = run(4)
+    finally:
+        os.environ.pop('FSV_ORDERED_SPLIT', None)
+    assert_close('atomic split', atomic, ref, 1e-5)
+
+
 def check_adaptive_avgpool(device, seed=92):
     """nn.AdaptiveAvgPool2d (AdaptiveDiscriminator.gen_conv_weights): windows that do not divide (33 -> 8), that do (32 -> 8),
     identity, and a rectangular case"""

@@ -2,7 +2,7 @@
 width (ngf = ndf = nff = 32), full resolution, the batch of the config - the product on the MI355X against the CPU oracle
 running on the GPU box's host cores, same seeded inputs and weights.
 
-  C1  fewshot_face 128x128  B=1  adaptive_spade          full D step + G step   (fp32 and fp64 oracle: noise-floor form)
+  C1  fewshot_face 128x128  B=1  adaptive_spade          full D step + G step   (fp32 and fp64 oracle: noise-floor form; four seeds)
   C2  fewshot_face 256x256  B=4  adaptive_spade          generator forward + backward (the config is defined G-only)
   C3  fewshot_pose 512x512  B=2  adaptive_spade + warp_ref + spade_combine   full D step + G step = the bench.py workload
   C4  C3 + --add_face_D (+ VGG19 loss)  B=2 (the per-rank batch of the 8-GPU config)   full D step + G step
@@ -31,25 +31,34 @@ def _conv():
     return import_module('few-shot-vid2vid_amd.conv')
 
 
-def test_c1_face_128_full_step(hip_lib):
+@pytest.mark.parametrize('seed', [23, 24])
+def test_c1_face_128_full_step(hip_lib, seed):
+    """C1 in the DEFAULT mode at the 1e-2 gradient bar.  Since round 4 the split-K launches of the fp32 gather-GEMM sum their
+    splits in a fixed order (csrc/conv_igemm.hip fsv_split_finish_kernel) - the source of the run-to-run variation round 3 traced
+    (tests/c1_kink.py): the step now lands on the same side of every LeakyReLU kink on every run (two runs per seed on hardware:
+    1.65e-3 / 1.87e-3 and 2.79e-3 / 2.80e-3 - what still varies is the weight gradients' pixel-split atomics, 1e-4)."""
     opt = mc.make_opt(dataset_mode='fewshot_face', input_nc=1, fineSize=128, loadSize=128, batchSize=1)
-    # Gradients: this configuration (ONE sample, 128x128: the up path of the reference-image encoder normalises 16 pixels per
-    # channel) has two outcomes on hardware: every parameter inside 1e-2 relative L2 (typically 2e-3), or ref_img_up_2.conv.weight
-    # off by exactly 3.58e-2.  Round 3 found the cause (tests/c1_kink.py, profiles/r03_notes.md section 8): ONE pre-activation of
-    # that layer - channel 46, pixel 6 of 16 - is -1e-6 in most runs and +3e-6 in the others, 25 ulp from the LeakyReLU kink, and
-    # its slope (1 or 0.2) carries 3.6 % of the layer's weight gradient.  Which side it lands on depends on the order of the
-    # split-K atomics upstream (the fixed-order mode always produces +3e-6).  Both are correct fp32 evaluations; no implementation
-    # can be held to 1e-2 on this input.  Losses and images hold 1e-3 in both outcomes; the band of this seed stays 5e-2, and the
-    # 1e-2 bar is checked in the reproducible mode below.
-    worst = mc.check_train_step(DEV, opt, b=1, tol=1e-3, grad_tol=5e-2)
-    assert worst < 5e-2, worst
+    worst = mc.check_train_step(DEV, opt, b=1, tol=1e-3, grad_tol=1e-2, seed=seed)
+    assert worst < 1e-2, worst
+
+
+@pytest.mark.parametrize('seed,band', [(21, 5e-2), (22, 1.5e-2)])
+def test_c1_face_128_full_step_inputs_on_a_kink(hip_lib, seed, band):
+    """The two seeds of the same configuration whose input puts ONE pre-activation of a 16-pixel layer (ONE sample, 128x128: the
+    up path of the reference-image encoder normalises 16 pixels per channel) within rounding of the LeakyReLU kink: seed 21 -
+    channel 46, pixel 6 of ref_img_up_2 is -1e-6 in the oracle and +3e-6 here, 25 ulp from the kink, and its slope (1 or 0.2)
+    carries 3.6 % of that layer's weight gradient (profiles/r03_notes.md section 8): 3.58e-2, the same value on every run since the
+    ordered split; seed 22: 1.03e-2, again one activation.  Both sides are correct fp32 evaluations; no implementation can be held
+    to 1e-2 on these inputs.  Losses and images hold 1e-3 here too; the gradient band is the measured outcome plus margin."""
+    opt = mc.make_opt(dataset_mode='fewshot_face', input_nc=1, fineSize=128, loadSize=128, batchSize=1)
+    worst = mc.check_train_step(DEV, opt, b=1, tol=1e-3, grad_tol=band, seed=seed)
+    assert worst < band, worst
 
 
 def test_c1_face_128_full_step_fixed_order(hip_lib, monkeypatch):
-    """C1 at the 1e-2 gradient bar in the fixed-order mode (FSV_DETERMINISTIC=1: no reduction is split across workgroups, spectral
-    norm sums its row slabs in order, normalisation statistics from their own pass - ten runs of this step from the same state are
-    bit-equal, tests/c1_repro.py), on a seed whose nearest-to-the-kink activation of the 16-pixel layers is not within rounding of
-    it (seeds 21 / 22 / 23 / 24 in this mode: 3.58e-2 / 1.04e-2 / 1.00e-2 / 5.5e-3, each the slope of a single activation)."""
+    """C1 at the 1e-2 gradient bar in the fully fixed-order mode (FSV_DETERMINISTIC=1: additionally no reduction split across
+    workgroups in the weight gradients, normalisation statistics from their own pass - ten runs of this step from the same state
+    are bit-equal, tests/c1_repro.py)."""
     monkeypatch.setenv('FSV_DETERMINISTIC', '1')
     opt = mc.make_opt(dataset_mode='fewshot_face', input_nc=1, fineSize=128, loadSize=128, batchSize=1)
     worst = mc.check_train_step(DEV, opt, b=1, tol=1e-3, grad_tol=1e-2, seed=24)

@@ -184,3 +184,7 @@ def test_thin_output_convolutions(emu_lib):
 
 def test_adaptive_avgpool(emu_lib):
     oc.check_adaptive_avgpool(DEV)
+
+
+def test_ordered_split_k(emu_lib):
+    oc.check_ordered_split(DEV)

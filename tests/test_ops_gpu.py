@@ -187,3 +187,7 @@ def test_thin_output_convolutions(hip_lib):
 
 def test_adaptive_avgpool(hip_lib):
     oc.check_adaptive_avgpool(dev())
+
+
+def test_ordered_split_k(hip_lib):
+    oc.check_ordered_split(dev())
