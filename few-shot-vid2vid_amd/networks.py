@@ -228,10 +228,16 @@ class SPADEResnetBlock(nn.Module):
         if self.spade:
             if self.learned_shortcut:
                 # bn_s and bn_0 normalise the same x with the same maps: one two-site launch (ops.spade_pair)
-                with ops.spade_pair():
-                    hs = self.bn_s(x, label, nw[2], act=ACT_NONE, up=fold)
+                if ops.spade_pair_enabled():
+                    with ops.spade_pair():
+                        hs = self.bn_s(x, label, nw[2], act=ACT_NONE, up=fold)
+                        h0 = self.bn_0(x, label, nw[0], act=ACT_LRELU, up=fold)
+                    x_s = self.conv_s(hs)
+                else:
+                    # bn_s -> conv_s as ONE kernel where csrc/spade_conv.hip covers the widths (ops.spade_into_conv)
+                    with ops.spade_into_conv():
+                        x_s = self.conv_s(self.bn_s(x, label, nw[2], act=ACT_NONE, up=fold))
                     h0 = self.bn_0(x, label, nw[0], act=ACT_LRELU, up=fold)
-                x_s = self.conv_s(hs)
             else:
                 x_s = x
                 h0 = self.bn_0(x, label, nw[0], act=ACT_LRELU, up=fold)

@@ -55,6 +55,9 @@ lib.register_sigs({
     "fsv_spade_bwd_elem": [c_p, c_p, c_p, c_p, c_p, c_i, c_pp, c_pp, c_p, c_i, c_i, c_i, c_ll, c_i, c_i, c_i, c_p],
     "fsv_spade_mod_bwd": [c_p, c_p, c_p, c_p, c_i, c_pp, c_pp, c_pp, c_pp, c_pp, c_ip, c_llp, c_llp, c_pp, c_p,
                           c_i, c_i, c_i, c_i, c_ll, c_i, c_i, c_i, c_p],
+    "fsv_spade_conv_s_supported": [c_i, c_i, c_i],
+    "fsv_spade_conv_s_fwd": [c_p, c_p, c_p, c_p, c_p, c_i, c_pp, c_pp, c_pp, c_pp, c_pp, c_ip, c_llp, c_llp,
+                             c_i, c_i, c_i, c_i, c_ll, c_i, c_i, c_p, c_i, c_i, c_p, c_p],
     "fsv_upsample2x_fwd": [c_p, c_p, c_i, c_i, c_i, c_i, c_p],
     "fsv_upsample2x_bwd": [c_p, c_p, c_i, c_i, c_i, c_i, c_p],
     "fsv_act_fwd": [c_p, c_p, c_ll, c_i, c_p],
@@ -404,8 +407,19 @@ class _ConvFn(torch.autograd.Function):
         if scale != 1.0 and act != ACT_NONE:
             raise ValueError("output scale is only fused with a linear epilogue")
         st = dict(groups=stats_groups) if (stats_groups and not per_sample) else None
-        y = conv_forward(x, wt, ldw, cout, geom, bias=b, res=res.detach() if res is not None else None, act=act,
-                         scale=scale, per_sample=per_sample, wscale=wscale, stats=st)
+        y = None
+        site = _spade_pending_for(x)
+        if site is not None:
+            # x is the output of a held-back bn_s modulation (spade_into_conv): both in one kernel when it covers the geometry
+            if (geom.kh == 1 and geom.kw == 1 and geom.stride == 1 and geom.pad == 0 and not per_sample and b is None and
+                    res is None and act == ACT_NONE and scale == 1.0 and not half and cpad == 0 and st is None and
+                    lib.call_status("fsv_spade_conv_s_supported", site['dims'][2], cout, len(site['chs'])) == 1):
+                y = _spade_conv_s_launch(site, wt, ldw, cout, wscale, want_hs=any(ctx.needs_input_grad))
+            else:
+                _spade_launch(site)
+        if y is None:
+            y = conv_forward(x, wt, ldw, cout, geom, bias=b, res=res.detach() if res is not None else None, act=act,
+                             scale=scale, per_sample=per_sample, wscale=wscale, stats=st)
         # statistics of y left by the epilogue (conv2d() hands them to the normalisation that follows through the output tensor)
         _conv_stats_tls.last = st if (st is not None and 'part' in st) else None
         ctx.geom, ctx.act, ctx.scale, ctx.per_sample = geom, act, scale, per_sample
@@ -886,6 +900,64 @@ class spade_pair:
         return False
 
 
+class spade_into_conv:
+    """`with spade_into_conv():` around `x_s = conv_s(bn_s(x, maps))` of a SPADEResnetBlock (architecture.py:103-108): the
+    modulation launch of bn_s is held back, and the 1x1 convolution that consumes its output issues BOTH as one kernel
+    (csrc/spade_conv.hip: the modulated tensor stays in registers between the two GEMMs).  In a forward that keeps no graph the
+    modulated tensor is never written; a training forward gets it as a side output (conv_s' weight gradient reads it) - autograd
+    is untouched (the same two nodes, the same two backward passes).  A consumer the fused kernel does not cover (other widths,
+    `--amp`, a convolution with bias / residual) launches the held-back modulation first and proceeds as usual.
+    FSV_SPADE_CONV_S=0 switches the fusion off (in-box A/B)."""
+
+    def __enter__(self):
+        self.pending = None
+        self.outer = getattr(_spade_tls, 'defer', None)
+        _spade_tls.defer = self if _os.environ.get('FSV_SPADE_CONV_S', '1') == '1' else None
+        return self
+
+    def __exit__(self, et, ev, tb):
+        _spade_tls.defer = self.outer
+        if self.pending is not None and et is None:
+            site, self.pending = self.pending, None
+            _spade_launch(site)
+        return False
+
+
+def spade_pair_enabled():
+    return _os.environ.get('FSV_SPADE_PAIR', '0') == '1'
+
+
+def _spade_pending_for(x):
+    """the held-back modulation whose output tensor is `x` (consumed: the caller launches it, fused or not), or None"""
+    defer = getattr(_spade_tls, 'defer', None)
+    site = defer.pending if defer is not None else None
+    if site is None:
+        return None
+    defer.pending = None
+    if site['h'].data_ptr() != x.data_ptr():
+        _spade_launch(site)                 # somebody else's input: nothing to fuse with
+        return None
+    return site
+
+
+def _spade_conv_s_launch(site, wt, ldws, cout, wscale, want_hs):
+    """x_s = conv_s(bn_s(x)) in one launch; returns x_s (NHWC storage, logical NCHW)"""
+    arr = lambda v: (ctypes.c_void_p * max(len(v), 1))(*v)
+    n, hw, c, ldw, w, up = site['dims']
+    chs = site['chs']
+    hgt = hw // w
+    xs = empty_nhwc(n, cout, hgt, w, site['x'])
+    lib.check_device(site['x'], wt, wscale)
+    with profile.scope('fsv_spade_conv_s_kernel' + (' P%d C%d N%d K%s' % (n * hw, c, cout, '+'.join(map(str, chs)))
+                                                      if profile.detail() else ''),
+                       site['flops'] + 2.0 * n * hw * c * cout):
+        lib.call("fsv_spade_conv_s_fwd", lib.ptr(site['x']), lib.ptr(site['mean']), lib.ptr(site['rstd']),
+                 lib.ptr(site['h']) if want_hs else None, lib.ptr(xs), len(chs), _pp(site['maps']), arr(site['wg']),
+                 arr(site['wb']), arr(site['bg']), arr(site['bb']), lib.int_array(chs + [0]), _ll(site['wstr'] + [0]),
+                 _ll(site['bstr'] + [0]), n, hw, c, ldw, 0, w, up, lib.ptr(wt), ldws, cout, lib.ptr(wscale), lib.stream_ptr())
+    return xs
+
+
 def _spade_same_input(a, b):
     return (a['x'].data_ptr() == b['x'].data_ptr() and a['dims'] == b['dims'] and a['chs'] == b['chs'] and
             [m.data_ptr() for m in a['maps']] == [m.data_ptr() for m in b['maps']])
@@ -1036,7 +1108,11 @@ class _SpadeFn(torch.autograd.Function):
                         bstr=bstr, dims=(n, h * w, c, ldw, w, up), act=act, keep=prepped, half=ctx.half_out, f16=ctx.f16,
                         flops=2.0 * n * h * w * c * 2 * sum(chs))
             pair = getattr(_spade_tls, 'pair', None)
-            if pair is None or nmaps == 0:
+            defer = getattr(_spade_tls, 'defer', None)
+            if (defer is not None and defer.pending is None and pair is None and nmaps > 0 and not ctx.half_out and
+                    act == ACT_NONE and c in (64, 128)):
+                defer.pending = site            # the 1x1 convolution that reads hout issues both (spade_into_conv)
+            elif pair is None or nmaps == 0:
                 _spade_launch(site)
             elif pair.pending is None:
                 pair.pending = site             # the partner site of this block issues both (spade_pair)

@@ -271,6 +271,21 @@ int fsv_spade_mod_fwd2(const float* x, const float* mean, const float* rstd, flo
                        const float* const* bg, const float* const* bb, const int* ch, const long long* w_bstride,
                        const long long* b_bstride, int N, int HW, int C, int ldw, long long stat_bstride, int act0, int act1,
                        int W, int up, fsv_stream_t stream);
+/* ---- bn_s modulation fused with conv_s (csrc/spade_conv.hip) - replaces `x_s = self.conv_s(self.bn_s(x, ...))`,
+ * architecture.py:103-108 (SPADE.forward normalization.py:37-52 followed by the bias-free spectral-norm 1x1 convolution) ------
+ * ONE launch: the gamma / beta GEMMs run with swapped operands (accumulators = [channel][pixel]), the modulated values are the A
+ * fragments of a second chain of matrix instructions against the conv_s weight rows kept in registers; the modulated tensor
+ * is written only when hs != NULL (a training forward: conv_s' weight gradient reads it).  Operands of the modulation as
+ * fsv_spade_mod_fwd (no activation: bn_s has none); ws = K-major forward operand of the 1x1 weight ([>= C rows][ldws],
+ * fsv_prep_weight mode 0), wscale = optional device scalar (1 / sigma) on the result; xs [N][HW][Cout].
+ * fsv_spade_conv_s_supported: 1 when a kernel exists for (C, Cout, nmaps) - C in {64, 128}, Cout in {32, 64}, 1..3 maps;
+ * fsv_spade_conv_s_fwd returns FSV_ERR_UNSUPPORTED otherwise (the caller runs the two launches). */
+int fsv_spade_conv_s_supported(int C, int Cout, int nmaps);
+int fsv_spade_conv_s_fwd(const float* x, const float* mean, const float* rstd, float* hs, float* xs,
+                         int nmaps, const float* const* maps, const float* const* wg, const float* const* wb,
+                         const float* const* bg, const float* const* bb, const int* ch, const long long* w_bstride,
+                         const long long* b_bstride, int N, int HW, int C, int ldw, long long stat_bstride, int W, int up,
+                         const float* ws, int ldws, int Cout, const float* wscale, fsv_stream_t stream);
 /* backward twin of fsv_spade_mod_fwd: the same operands plus the upstream gradient dh; gamma / beta are recomputed in
  * registers, outputs are dgb[k] = d(gamma | beta) of every map ([P][2C], gamma in columns [0, C)) and dxhat [P][C] (per
  * full-resolution pixel also when up != 0).  act: FSV_ACT_NONE or FSV_ACT_LRELU. */

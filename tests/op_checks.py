@@ -1097,6 +1097,82 @@ def check_spade_pair(device, n=2, c=64, chs=(16, 8, 8), h=10, w=12, up=True, see
         assert float((a.cpu() - b.cpu()).abs().max()) == 0.0
 
 
+def check_spade_conv_s(device, n=2, c=64, cout=32, chs=(16, 8), h=10, w=12, up=True, grad=True, spectral=True, seed=57,
+                       max_gx=None):
+    """x_s = conv_s(bn_s(x, maps)) (architecture.py:103-108) through ops.spade_into_conv - ONE launch of csrc/spade_conv.hip -
+    against the same two operators launched one after the other (each held to the oracle by check_spade / check_conv): x_s within
+    the fp32 summation-order band (the fused kernel sums the 64 channels of a tile as two interleaved halves), gradients equal
+    (the backward passes are the same two nodes; the training forward writes the modulated tensor as a side output for conv_s'
+    weight gradient).  grad=False: the forward that keeps no graph - the call must not hand the kernel an hs pointer at all.
+    max_gx: FSV_SPADE_MAX_GX, a workgroup then walks several pixel tiles."""
+    import contextlib
+    from importlib import import_module
+    ops, conv = pkg()
+    lib = import_module('few-shot-vid2vid_amd.lib')
+    g = torch.Generator().manual_seed(seed)
+    xs_h, xs_w = (h // 2, w // 2) if up else (h, w)
+    x = torch.randn(n, c, xs_h, xs_w, generator=g) + 0.2
+    maps = [torch.randn(n, ch, h, w, generator=g) for ch in chs]
+    wts = []
+    for k, ch in enumerate(chs):
+        if k == 0:
+            wts.append((torch.randn(n, c, ch, 1, 1, generator=g) * 0.3, torch.randn(n, c, ch, 1, 1, generator=g) * 0.3,
+                        torch.randn(n, c, generator=g) * 0.3, torch.randn(n, c, generator=g) * 0.3))
+        else:
+            wts.append((torch.randn(c, ch, 1, 1, generator=g) * 0.3, torch.randn(c, ch, 1, 1, generator=g) * 0.3,
+                        torch.randn(c, generator=g) * 0.3, torch.randn(c, generator=g) * 0.3))
+    wconv = torch.randn(cout, c, 1, 1, generator=g) * (1.0 / c ** 0.5)
+    u0 = F.normalize(torch.randn(cout, generator=g), dim=0)
+    v0 = F.normalize(torch.randn(c, generator=g), dim=0)
+    dy = torch.randn(n, cout, h, w, generator=g)
+
+    def run(fused):
+        cl = lambda t: _dev(t, device).contiguous(memory_format=torch.channels_last)
+        xd = cl(x).requires_grad_(grad)
+        md = [cl(m).requires_grad_(grad) for m in maps]
+        wd = [tuple(_dev(t, device).requires_grad_(grad) for t in ws) for ws in wts]
+        wc = _dev(wconv, device).requires_grad_(grad)
+        rm, rv = _dev(torch.zeros(c), device), _dev(torch.ones(c), device)
+        u, v = _dev(u0.clone(), device), _dev(v0.clone(), device)
+        seen, real_call = [], lib.call
+
+        def recording_call(name, *a):
+            seen.append((name, a))
+            return real_call(name, *a)
+        lib.call = recording_call
+        os.environ['FSV_SPADE_CONV_S'] = '1' if fused else '0'
+        if max_gx:
+            os.environ['FSV_SPADE_MAX_GX'] = str(max_gx)
+        try:
+            with (contextlib.nullcontext() if grad else torch.no_grad()):
+                with ops.spade_into_conv():
+                    hs = ops.spade_mod(xd, md, wd, rm, rv, act=conv.ACT_NONE, up=up)
+                    sn = ops.SpectralState.update(wc, u, v, True) if spectral else None
+                    y = ops.conv2d(hs, wc, None, 1, 0, sn=(sn, u, v) if spectral else None)
+            grads = None
+            if grad:
+                (y * _dev(dy, device)).sum().backward()
+                grads = [xd.grad] + [m.grad for m in md] + [t.grad for ws in wd for t in ws] + [wc.grad]
+        finally:
+            lib.call = real_call
+            os.environ.pop('FSV_SPADE_CONV_S', None)
+            os.environ.pop('FSV_SPADE_MAX_GX', None)
+        return y.detach(), grads, seen, (rm, rv)
+    y1, g1, seen1, st1 = run(False)
+    y2, g2, seen2, st2 = run(True)
+    names1, names2 = [s_[0] for s_ in seen1], [s_[0] for s_ in seen2]
+    assert 'fsv_spade_conv_s_fwd' not in names1 and 'fsv_spade_mod_fwd' in names1
+    assert 'fsv_spade_conv_s_fwd' in names2 and 'fsv_spade_mod_fwd' not in names2, names2
+    fused_args = [a for (nm, a) in seen2 if nm == 'fsv_spade_conv_s_fwd'][0]
+    assert (fused_args[3] is not None) == grad, 'the modulated tensor is a side output of the training forward only'
+    assert_close('fused bn_s -> conv_s output', y2, y1, tol=2e-5)
+    for a, b in zip(st1, st2):
+        assert float((a.cpu() - b.cpu()).abs().max()) == 0.0
+    if grad:
+        for i, (a, b) in enumerate(zip(g1, g2)):
+            assert_close('fused bn_s -> conv_s grad %d' % i, b, a, tol=2e-5)
+
+
 def check_conv_stats(device, seed=61):
     """BatchNorm / InstanceNorm statistics from the producing convolution's epilogue (ops.conv2d stats_groups -> `_fsv_stats` ->
     norm_act / spade_mod) against the separate reduction pass: same normalised output, running statistics and gradients; the

@@ -169,6 +169,14 @@ def test_conv_groups(emu_lib):
     oc.check_conv_groups(DEV)
 
 
+def test_spade_modulation_fused_with_the_shortcut_convolution(emu_lib):
+    """bn_s -> conv_s as one kernel (csrc/spade_conv.hip) == the two launches"""
+    oc.check_spade_conv_s(DEV)                                                     # level-0 widths, folded up-sampling, two maps
+    oc.check_spade_conv_s(DEV, c=128, cout=64, chs=(8,), h=9, w=7, up=False)        # two channel tiles, ragged pixel tile
+    oc.check_spade_conv_s(DEV, c=64, cout=64, chs=(8, 8, 4), h=12, w=8, up=True, spectral=False, max_gx=1)   # tile walk, three maps
+    oc.check_spade_conv_s(DEV, c=128, cout=32, chs=(36,), h=8, w=8, up=False, grad=False)     # no graph: hs is never written
+
+
 def test_spade_two_site_launch(emu_lib):
     oc.check_spade_pair(DEV)
     oc.check_spade_pair(DEV, c=32, chs=(8,), h=9, w=7, up=False)
