@@ -371,6 +371,10 @@ def main():
     opt_G, opt_D = build_optimizers(segmented)
     data = make_data(args.batch, args.size, 1234 + rank, device, opt)
 
+    # one GPU: the generator-mode forward pass starts on a side stream next to the discriminator step (model.early_generator;
+    # FSV_EARLY_G=0: the sequential order, in-box A/B).  With a process group the exchange sits between the two steps.
+    model.early_generator = (not distributed) and os.environ.get('FSV_EARLY_G', '1') == '1'
+
     def step():
         d_losses = model(data, mode='discriminator')
         M.loss_backward(opt, d_losses, opt_D, 1)

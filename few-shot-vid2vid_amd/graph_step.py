@@ -23,11 +23,16 @@ optimiser objects are no longer the captured ones).
 
 The returned losses / images are the graphs' static output tensors: consume (or clone) them before the next call.
 """
+import os
+
 import torch
 
 from . import lib
 from . import model as _model
 from . import networks as _networks
+
+
+_EARLY_G = os.environ.get('FSV_EARLY_G', '1') == '1'          # in-box A/B switch
 
 
 def _flat(data_list):
@@ -104,18 +109,32 @@ class GraphedIteration:
 
     # ------------------------------------------------------------------------------------------------ the body
     def _backward(self, losses, optimizer):
-        losses, loss = _model.mean_and_total(losses)
-        optimizer.zero_grad()
-        optimizer.scale_loss(loss).backward()
-        _networks.BackwardCut.finish_all()      # a forward pass that detached at a stage boundary (no-op otherwise)
-        optimizer.finalize_grads()
+        with _model.branch_of(losses):          # (the discriminator step of a single-graph iteration lives on a side stream)
+            losses, loss = _model.mean_and_total(losses)
+            optimizer.zero_grad()
+            optimizer.scale_loss(loss).backward()
+            _networks.BackwardCut.finish_all()      # a forward pass that detached at a stage boundary (no-op otherwise)
+            optimizer.finalize_grads()
+            if optimizer is self.opt_D and self.model._pre_g is not None:
+                optimizer.adam()                    # ... together with its Adam step (else issued at the top of _seg_g)
+                self._d_stepped = True
         return losses
 
     def _seg_d(self, e):
-        e.out_d = self._backward(self.model(e.static, mode='discriminator'), self.opt_D)
+        # iterations without a gradient exchange: the discriminator step runs on a side stream next to the generator-mode forward
+        # pass (model.early_generator); with segments the branch would have to cross the all-reduce between two graphs
+        was = self.model.early_generator
+        self.model.early_generator = (not self.segmented) and _EARLY_G
+        self._d_stepped = False
+        try:
+            e.out_d = self._backward(self.model(e.static, mode='discriminator'), self.opt_D)
+        finally:
+            self.model.early_generator = was
 
     def _seg_g(self, e, save_images):
-        self.opt_D.adam()
+        if not getattr(self, '_d_stepped', False):
+            self.opt_D.adam()
+        self._d_stepped = False
         g_losses, generated, prevs = self.model(e.static, save_images=save_images, mode='generator')
         if not self.split:
             e.out_g = self._backward(g_losses, self.opt_G)
@@ -222,6 +241,10 @@ class GraphedIteration:
             except Exception:                # noqa: BLE001
                 pass
         _networks.BackwardCut.abandon_all()      # boundary tensors of the interrupted forward pass
+        try:
+            self.model.join_early()              # a side-stream discriminator step the interrupted body left open
+        except Exception:                        # noqa: BLE001
+            self.model._pre_g = None
         for o in (self.opt_D, self.opt_G):
             o._reattach()
 

@@ -12,6 +12,7 @@ prev_fake]`` (5-D ``[B, T, C, H, W]`` tensors).  Loss order and names follow los
 Networks run on the HIP kernels (networks.py); parameters and gradients live in flat buffers (flat.py) so the
 optimiser is one fused Adam launch and the data-parallel exchange is a handful of large RCCL all-reduces.
 """
+import contextlib
 import os
 
 import torch
@@ -370,15 +371,24 @@ def loss_backward(opt, losses, optimizer, loss_id):
     """models/loss_collector.py:217-228: sum of means -> zero_grad -> backward -> optimiser step.  With `--amp` the
     reference scales the loss per `loss_id` (:221-224); here every optimiser owns its scaler (flat.FlatAdam.scale_loss:
     identity unless the fp16-operand mode is on) and un-scales inside its fused step."""
-    losses, loss = mean_and_total(losses)
-    optimizer.zero_grad()
-    scale_loss = getattr(optimizer, 'scale_loss', None)
-    (scale_loss(loss) if scale_loss is not None else loss).backward()
-    # two-piece backward (build_optimizers(split_backward=True)): the forward pass detached at the generator's stage boundary,
-    # run the second piece too - whichever optimiser is being stepped (finetune() builds its own)
-    networks.BackwardCut.finish_all()
-    optimizer.step()
+    with branch_of(losses):
+        losses, loss = mean_and_total(losses)
+        optimizer.zero_grad()
+        scale_loss = getattr(optimizer, 'scale_loss', None)
+        (scale_loss(loss) if scale_loss is not None else loss).backward()
+        # two-piece backward (build_optimizers(split_backward=True)): the forward pass detached at the generator's stage boundary,
+        # run the second piece too - whichever optimiser is being stepped (finetune() builds its own)
+        networks.BackwardCut.finish_all()
+        optimizer.step()
     return losses
+
+
+def branch_of(losses):
+    """context of the stream a list of losses was computed on: the discriminator step of an iteration with
+    `Vid2VidModel.early_generator` lives on a side stream (its forward pass tagged the first loss), everything else on the
+    caller's"""
+    branch = getattr(losses[0], '_fsv_branch', None) if len(losses) and torch.is_tensor(losses[0]) else None
+    return branch.on() if (branch is not None and branch.stream is not None) else contextlib.nullcontext()
 
 
 def set_random_seed(seed):
@@ -618,22 +628,54 @@ class Vid2VidModel(nn.Module):
                     o.refresh_layouts()
 
     # ---------------------------------------------------------------------------------------------- forward
+    # Discriminator step next to the generator pass (opt-in: bench.py / GraphedIteration set `early_generator` for iterations
+    # without a gradient exchange).  The generator-mode forward pass of train.py:61 depends on nothing the discriminator step of
+    # train.py:58-59 produces: the generator's weights, spectral-norm vectors and BatchNorm buffers are final once the step's own
+    # (no-grad) generator pass has run.  With the switch on, `mode='discriminator'` puts the discriminator's forward pass on a
+    # side stream and issues the generator-mode pass of the SAME data_list right behind the no-grad one on the caller's stream;
+    # loss_backward runs the rest of the discriminator step (backward, finalisation, Adam, layout refresh - hundreds of launches
+    # that each fill a fraction of the chip) on that side stream too, and the following `mode='generator'` call joins it and picks
+    # the generator pass up.  Same kernels on the same data in the same per-network order: bit-identical results.  The returned
+    # discriminator losses live on the side stream: read them after the generator-mode call (or after `join_early()`).
+    early_generator = False
+    _pre_g = None
+
+    @staticmethod
+    def _data_key(data_list):
+        flat = []
+        for item in data_list:
+            flat.extend(item if isinstance(item, (list, tuple)) else [item])
+        return tuple(None if t is None else (id(t), t.data_ptr(), t._version) for t in flat)
+
+    def join_early(self, data_list=None):
+        """join the discriminator step's side stream into the current one; returns the generator pass that was issued next to
+        it if `data_list` is the data it was computed from (else None: the pass is dropped)"""
+        if self._pre_g is None:
+            return None
+        key, branch, gen = self._pre_g
+        self._pre_g = None
+        branch.finish()
+        return gen if (data_list is not None and key == self._data_key(data_list)) else None
+
     def forward(self, data_list, save_images=False, mode='inference', dummy_bs=0):
+        # (joined BEFORE this pass zeroes the statistics arena the side stream may still be working in)
+        pre = self.join_early(data_list if mode == 'generator' else None)
         # one zeroed arena per pass for the normalisation statistics the convolutions leave behind (conv.stats_pass)
         with conv.stats_pass(tgt_label_device(data_list)):
-            return self._forward(data_list, save_images, mode)
+            return self._forward(data_list, save_images, mode, pre)
 
-    def _forward(self, data_list, save_images, mode):
+    def _forward(self, data_list, save_images, mode, pre=None):
         opt = self.opt
         tgt_label, tgt_image, flow_gt, conf_gt, ref_label, ref_image, p_label, p_real, p_fake = data_list
         tgt_label, ref_label = encode_label(opt, tgt_label), encode_label(opt, ref_label)
         prevs = [p_label, p_real, p_fake]
         if mode == 'generator':
             losses, generated, prev = self.forward_generator(tgt_label, tgt_image, ref_label, ref_image, prevs,
-                                                             flow_gt, conf_gt)
+                                                             flow_gt, conf_gt, pre=pre)
             return losses, generated if save_images else [], prev
         if mode == 'discriminator':
-            return self.forward_discriminator(tgt_label, tgt_image, ref_label, ref_image, prevs)
+            early = self._data_key(data_list) if (self.early_generator and self.isTrain and torch.is_grad_enabled()) else None
+            return self.forward_discriminator(tgt_label, tgt_image, ref_label, ref_image, prevs, early=early)
         return self.inference(tgt_label, ref_label, ref_image)
 
     def inference(self, tgt_label, ref_labels, ref_images):
@@ -761,24 +803,35 @@ class Vid2VidModel(nn.Module):
                 new_prevs.append(torch.cat([old[:, 1:], now.detach().unsqueeze(1)], dim=1).detach())
         return (fake, raw, warped, flow, mask), (fg, ref_fg), (ref_label_valid, ref_image_t), new_prevs
 
-    def forward_discriminator(self, tgt_label, tgt_image, ref_labels, ref_images, prevs):
-        """vid2vid_model.py:106-128."""
+    def forward_discriminator(self, tgt_label, tgt_image, ref_labels, ref_images, prevs, early=None):
+        """vid2vid_model.py:106-128.  early: key of the data_list when the discriminator's part goes to a side stream and the
+        generator-mode pass is issued here (see `early_generator`)."""
         with torch.no_grad():
             (fake, raw, _, _, _), (fg, ref_fg), (ref_label, ref_image), _ = \
                 self.generate_images(tgt_label, tgt_image, ref_labels, ref_images, prevs, want_prevs=False)
-        fg_union = union_fg(fg, ref_fg, self.has_fg)
-        real = tgt_image[:, 0]
-        losses = self.lossCollector.gan_losses(self.netD, tgt_label, [real, real * fg_union], [fake, raw], ref_label,
-                                               ref_image, for_discriminator=True, netDf=self.netDf)
-        if self.isTrain and self.opt.lambda_temp > 0 and prevs[0] is not None and self.netDT is not None:   # vid2vid_model.py:115
-            real_all = torch.cat([prevs[1], tgt_image], dim=1)
-            fake_all = torch.cat([prevs[2], fake.unsqueeze(1)], dim=1)
-            losses = list(losses) + self.lossCollector.temporal_losses(self.netDT, real_all, fake_all, True)
-        return LossCollector.outward(losses)
+        branch = streams.Branch(tgt_label) if early is not None else None
+        if branch is not None:
+            branch.uses([fake, raw, fg, ref_fg, ref_label, ref_image, tgt_label])
+        with (branch.on() if branch is not None else contextlib.nullcontext()):
+            fg_union = union_fg(fg, ref_fg, self.has_fg)
+            real = tgt_image[:, 0]
+            losses = self.lossCollector.gan_losses(self.netD, tgt_label, [real, real * fg_union], [fake, raw], ref_label,
+                                                   ref_image, for_discriminator=True, netDf=self.netDf)
+            if self.isTrain and self.opt.lambda_temp > 0 and prevs[0] is not None and self.netDT is not None:   # vid2vid_model.py:115
+                real_all = torch.cat([prevs[1], tgt_image], dim=1)
+                fake_all = torch.cat([prevs[2], fake.unsqueeze(1)], dim=1)
+                losses = list(losses) + self.lossCollector.temporal_losses(self.netDT, real_all, fake_all, True)
+            losses = LossCollector.outward(losses)
+        if branch is not None:
+            with torch.enable_grad():
+                gen = self.generate_images(tgt_label, tgt_image, ref_labels, ref_images, prevs)
+            self._pre_g = (early, branch, gen)
+            losses[0]._fsv_branch = branch       # loss_backward continues the discriminator step on the branch's stream
+        return losses
 
     def forward_generator(self, tgt_label, tgt_image, ref_labels, ref_images, prevs, flow_gt=(None, None),
-                          conf_gt=(None, None)):
-        """vid2vid_model.py:62-104."""
+                          conf_gt=(None, None), pre=None):
+        """vid2vid_model.py:62-104.  pre: the result of generate_images when the discriminator-mode call already issued it."""
         lc = self.lossCollector
         opt = self.opt
         real = tgt_image[:, 0]
@@ -806,13 +859,16 @@ class Vid2VidModel(nn.Module):
 
             def real_branch():
                 return lc.real_pass(self.netD, tgt_label, reals0, ref_labels_valid[:, 0], ref_images[:, 0], sigmas)
-            gen, real_outs = streams.fork(tgt_label, [
-                lambda: self.generate_images(tgt_label, tgt_image, ref_labels, ref_images, prevs,
-                                             ref_labels_valid=ref_labels_valid), real_branch])
+            if pre is not None:
+                gen, real_outs = pre, real_branch()
+            else:
+                gen, real_outs = streams.fork(tgt_label, [
+                    lambda: self.generate_images(tgt_label, tgt_image, ref_labels, ref_images, prevs,
+                                                 ref_labels_valid=ref_labels_valid), real_branch])
             (fake, raw, warped, flow, mask), (fg, ref_fg), (ref_label, ref_image), prevs_new = gen
         else:
             (fake, raw, warped, flow, mask), (fg, ref_fg), (ref_label, ref_image), prevs_new = \
-                self.generate_images(tgt_label, tgt_image, ref_labels, ref_images, prevs)
+                pre if pre is not None else self.generate_images(tgt_label, tgt_image, ref_labels, ref_images, prevs)
         fg_union = union_fg(fg, ref_fg, self.has_fg)
         for p in d_params:
             p.requires_grad_(False)

@@ -83,3 +83,34 @@ def fork(ref, fns):
         cur.wait_stream(s)
         _record(outs[i], cur)
     return outs
+
+
+class Branch:
+    """An open-ended branch: a side stream that stays reserved from `start` to `finish`, possibly across several entry points of
+    the model (the discriminator step of an iteration next to the generator-mode forward pass, model.Vid2VidModel).  Work is put
+    on it with `with branch.on():`; nested forks - on the branch and on the caller's stream - take other streams meanwhile."""
+
+    def __init__(self, ref):
+        self.stream = None
+        if ENABLED and torch.is_tensor(ref) and ref.is_cuda:
+            cur = torch.cuda.current_stream(ref.device)
+            self.stream = _side_streams(ref.device, 1, cur)[0]
+            _busy.append(self.stream)
+            self.stream.wait_stream(cur)
+
+    def on(self):
+        import contextlib
+        return torch.cuda.stream(self.stream) if self.stream is not None else contextlib.nullcontext()
+
+    def uses(self, obj):
+        """tensors made on the caller's stream that the branch reads: their memory must not be recycled under it"""
+        if self.stream is not None:
+            _record(obj, self.stream)
+
+    def finish(self):
+        """the current stream waits for everything the branch has been given"""
+        if self.stream is not None:
+            torch.cuda.current_stream(self.stream.device).wait_stream(self.stream)
+            if any(self.stream is b for b in _busy):
+                _busy.remove(self.stream)
+            self.stream = None

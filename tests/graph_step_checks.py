@@ -6,7 +6,7 @@ import torch
 import model_checks as mc
 
 
-def _run(device, graphed, iters, seed, opt_kw, b=1, split=False):
+def _run(device, graphed, iters, seed, opt_kw, b=1, split=False, early=False):
     from importlib import import_module
     M = mc._model()
     gs = import_module('few-shot-vid2vid_amd.graph_step')
@@ -15,6 +15,7 @@ def _run(device, graphed, iters, seed, opt_kw, b=1, split=False):
     mc.fill_state(model.netG); mc.fill_state(model.netD)
     model = model.to(device).train()
     opt_G, opt_D = model.build_optimizers(split_backward=split)
+    model.early_generator = early        # the plain loop with the discriminator step on a side stream (model.py)
     step = gs.GraphedIteration(model, opt, warmup=2) if graphed else None
     h, w = int(opt.fineSize / opt.aspect_ratio), opt.fineSize
     log = []
@@ -48,6 +49,22 @@ def check_graphed_iteration(device, iters=5, seed=500, tol=0.0):
         assert float((a['img'] - b['img']).abs().max()) <= tol * 2.0 + 0.0, it
     assert float((pG - qG).abs().max()) <= tol and float((pD - qD).abs().max()) <= tol
     return step
+
+
+def check_early_generator(device, iters=3, seed=560, tol=0.0):
+    """Vid2VidModel.early_generator in the plain train.py loop: the discriminator step on a side stream next to the
+    generator-mode forward pass issued behind the step's own no-grad pass - the same kernels on the same data in the same
+    per-network order, so losses, images and both networks' weights equal the sequential loop (bit for bit under the emulator,
+    which runs the branches in issue order)."""
+    kw = dict(warp_ref=True, spade_combine=True, remove_face_labels=True, fineSize=32, loadSize=32, n_downsample_G=3, n_adaptive_layers=2)
+    ref, pG, pD, _ = _run(device, False, iters, seed, kw)
+    got, qG, qD, _ = _run(device, False, iters, seed, kw, early=True)
+    for it, (a, b) in enumerate(zip(ref, got)):
+        for k in ('d', 'g'):
+            for x, y in zip(a[k], b[k]):
+                assert abs(x - y) <= tol * max(abs(x), 1.0), (it, k, a[k], b[k])
+        assert float((a['img'] - b['img']).abs().max()) <= tol * 2.0, it
+    assert float((pG - qG).abs().max()) <= tol and float((pD - qD).abs().max()) <= tol
 
 
 def check_capture_failure_falls_back(device, iters=4, seed=540):
@@ -132,12 +149,14 @@ if __name__ == '__main__':
     streams.ENABLED = False
     one, _, _, _ = _run(dev, False, 5, 500, kw)
     streams.ENABLED = True
-    for it, (a, b, c) in enumerate(zip(one, ref, got)):
-        for other in (b, c):
+    # the plain loop with the discriminator step on a side stream next to the generator-mode forward pass (early_generator)
+    early, _, _, _ = _run(dev, False, 5, 500, kw, early=True)
+    for it, (a, b, c, d) in enumerate(zip(one, ref, got, early)):
+        for other in (b, c, d):
             for k in ('d', 'g'):
                 for x, y in zip(a[k], other[k]):
                     assert abs(x - y) <= 5e-2 * max(abs(x), 1.0), (it, k, a[k], other[k])
-    for other in (ref, got):      # first iteration, before any weight update: rounding-level agreement
+    for other in (ref, got, early):      # first iteration, before any weight update: rounding-level agreement
         assert float((one[0]['img'] - other[0]['img']).abs().max()) <= 1e-4
         for x, y in zip(one[0]['d'] + one[0]['g'], other[0]['d'] + other[0]['g']):
             assert abs(x - y) <= 1e-4 * max(abs(x), 1.0), (one[0], other[0])

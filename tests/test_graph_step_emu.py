@@ -17,3 +17,7 @@ def test_split_backward_without_exchange_keeps_every_gradient(emu_lib):
 
 def test_capture_failure_falls_back_to_the_eager_step(emu_lib):
     gc.check_capture_failure_falls_back(DEV)
+
+
+def test_discriminator_step_next_to_the_generator_pass_changes_no_result(emu_lib):
+    gc.check_early_generator(DEV)
