@@ -106,6 +106,7 @@ struct ConvP {
   long long res_bytes;                   // extent of the residual tensor when one descriptor covers it (else 0: loaded per element)
   float* part;                           // ordered split-K: split k stores its partial output at part + k * part_stride (else null:
   long long part_stride;                 // splits add into the zeroed output atomically)
+  int band;                              // XCD bands: an XCD owns a CONTIGUOUS run of (pixel tile, channel tile) pairs (conv_igemm.hip)
 };
 
 __device__ __forceinline__ void fsv_tap(const ConvP& p, int t, int& ty, int& tx) {

@@ -497,10 +497,27 @@ __device__ __forceinline__ void fsv_conv_igemm_body(const ConvP& p, const int bx
   }
 }
 
+// XCD bands (round 4; the half-precision kernel's order, conv_h.hip): XCD x - the workgroups with linear id b % 8 == x - owns the
+// CONTIGUOUS run of tiles [start(x), start(x + 1)) in (pixel tile, channel tile) order with the channel tile fastest, so the pixel
+// tiles resident on one XCD are neighbours: the rows above and below that the 3x3 / 4x4 taps reach into are in the SAME L2.  With
+// the interleaved order above an XCD holds every eighth pixel tile and shares nothing between its resident tiles (PMC, round 3:
+// 213 - 265 MB fetched per launch for 67 MB of activations at the Cout <= 64 full-resolution layers).  No padding workgroups:
+// the first (total % 8) XCDs own one tile more.
+__device__ __forceinline__ void fsv_xcd_band(int nx, int ny, int& bx, int& by) {
+  const int total = nx * ny;
+  const int b = blockIdx.x + blockIdx.y * nx;
+  const int q = total >> 3, r = total & 7;
+  const int x = b & 7;
+  const int t = x * q + (x < r ? x : r) + (b >> 3);
+  by = t % ny;
+  bx = t / ny;
+}
+
 template <int BM, int BN, int WM, int WN, int PF = 1, bool AF = false, int DBG = 0, int MODE = 0>
 __global__ __launch_bounds__(64 * WM * WN) void fsv_conv_igemm_kernel(ConvP p) {
   int bx, by;
-  fsv_xcd_tile(gridDim.x, gridDim.y, bx, by);
+  if (p.band) fsv_xcd_band(gridDim.x, gridDim.y, bx, by);
+  else fsv_xcd_tile(gridDim.x, gridDim.y, bx, by);
   fsv_conv_igemm_body<BM, BN, WM, WN, PF, AF, DBG, MODE>(p, bx, by, (int)blockIdx.z);
 }
 
@@ -1724,6 +1741,14 @@ extern "C" int fsv_conv_plan(int Mz, int Cout, int nchunks, int nsamp, int force
   return 0;
 }
 
+// XCD order of the single-problem launches: 1 = bands (fsv_xcd_band), 0 = interleaved (fsv_xcd_tile); FSV_CONV_BAND: in-box A/B
+static inline int fsv_conv_band() {
+  static int v = -1;
+  // (measured in-box, profiles/r04_notes.md section 9: neutral on both bench steps - the interleaved order stays the default)
+  if (v < 0) { const char* e = getenv("FSV_CONV_BAND"); v = e ? (atoi(e) != 0) : 0; }
+  return v;
+}
+
 static inline void fsv_fill_convp(ConvP& p, const float* in, const float* wt, const float* bias, const float* res, float* out,
                                   const float* wscale, int N, int H, int W, int Cin, int OH, int OW, int Cout, int ntaps,
                                   const int* ty, const int* tx, int sy, int sx, int outH, int outW, int osy, int osx, int ooy,
@@ -1742,6 +1767,7 @@ static inline void fsv_fill_convp(ConvP& p, const float* in, const float* wt, co
   p.nsplit = 1;
   p.stats = nullptr; p.stats_slots = 1; p.stats_ohw = 1;
   p.part = nullptr; p.part_stride = 0;
+  p.band = fsv_conv_band();
   {
     const long long obytes = (long long)N * outH * outW * Cout * 4;
     p.res_bytes = (res && obytes <= FSV_BUF_MAX_BYTES) ? obytes : 0;
