@@ -45,13 +45,24 @@ struct SpadeConvP {
   int nmaps, N, HW, C, ldw;
   long long stat_bstride;
   int W, up;
-  const float* ws;        // conv_s weight, K-major [>= C rows][ldws]
+  const float* ws;        // conv_s weight, K-major [>= C rows][ldws]  (F16: N-major IEEE half [>= Cout rows][ldws], K contiguous)
   const float* wscale;    // optional device scalar on the result (spectral-norm 1 / sigma)
   int Cout, ldws;
 };
 
+// F16 (the `--amp` path): the gamma / beta GEMMs on v_mfma_f32_32x32x16_f16 exactly as the F16 form of fsv_spade_mod_kernel - maps
+// IEEE half ([N][HW][Ch]), wg / wb pointing at the gamma rows / beta rows of the N-major half operand of fsv_spade_prep_h (row length
+// ceil32(Ch) halves, w_bstride in halves), tiles [rows][32 k] halves with the four 16-byte slots XOR-swizzled by (row >> 2) & 3 - again
+// with the operands swapped.  The modulated values are rounded to half ONCE (what the two-launch form does at its store) and the
+// eight registers (8 t .. 8 t + 7) of the two half-waves are the A fragment of one 32x32x16 step over 16 channels; the conv_s weight
+// arrives as the N-major half operand of the half-precision convolutions (hconv.prep_weight_h), accumulation and epilogue fp32, the
+// side output hs is written as half.
+typedef _Float16 fsv_sc_h16;
+typedef _Float16 fsv_sc_h16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 fsv_sc_h16x4 __attribute__((ext_vector_type(4)));
+
 // NCT channel tiles of 64 (C = 64 NCT), TN2 output column tiles of 32 (Cout = 32 TN2)
-template <int NCT, int TN2>
+template <int NCT, int TN2, bool F16 = false>
 __global__ __launch_bounds__(256, 2) void fsv_spade_conv_s_kernel(SpadeConvP p) {
   constexpr int BM = 64, BN = 64, BK = FSV_SC_BK;
   constexpr int A_ST = BM * BK, B_ST = BK * BN;
@@ -59,12 +70,15 @@ __global__ __launch_bounds__(256, 2) void fsv_spade_conv_s_kernel(SpadeConvP p) 
   constexpr int QB = BN / 4, RPB = 256 / QB, NPB = BK / RPB;
   constexpr int NKIND = 2 + 2 * FSV_SC_MAXMAPS;         // mean, rstd, (gamma bias, beta bias) per map
   constexpr int CT = 64 * NCT;
-  __shared__ __attribute__((aligned(16))) float smem[2 * (A_ST + 2 * B_ST)];
+  __shared__ __attribute__((aligned(16))) float smem[(F16 ? 1 : 2) * (A_ST + 2 * B_ST)];
   __shared__ __attribute__((aligned(16))) float cst[NKIND * CT];
   __shared__ __attribute__((aligned(16))) float xch[4 * 8 * TN2 * 64];
   float* const As = smem;
   float* const Bs = smem + 2 * A_ST;
+  fsv_sc_h16* const Ah = reinterpret_cast<fsv_sc_h16*>(smem);       // F16: [2 buffers][BM][32] halves, then [2][2][BN][32]
+  fsv_sc_h16* const Bh = Ah + 2 * A_ST;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int hr0 = tid >> 2, hs4 = tid & 3;              // F16 loads: 64 rows x 4 slots of 16 bytes per pass
   const int wm = wave >> 1, wn = wave & 1;              // pixel half / channel half of the 64 x 64 tile
   const int lrow = lane & 31, lk = lane >> 5;
   const int z = blockIdx.z;
@@ -86,14 +100,32 @@ __global__ __launch_bounds__(256, 2) void fsv_spade_conv_s_kernel(SpadeConvP p) 
     }
     cst[i] = v;
   }
-  float wsf[NCT][16][TN2];
+  float wsf[F16 ? 1 : NCT][F16 ? 1 : 16][TN2];
+  fsv_sc_h16x8 wsh[F16 ? NCT : 1][2][TN2];
+  if constexpr (F16) {
+    // element e of step t: channel (r & 3) + 8 (r >> 2) + 4 lk with r = 8 t + e, i.e. two runs of four consecutive k of row n
+    const fsv_sc_h16* wh = reinterpret_cast<const fsv_sc_h16*>(p.ws);
 #pragma unroll
-  for (int ct = 0; ct < NCT; ++ct)
+    for (int ct = 0; ct < NCT; ++ct)
 #pragma unroll
-    for (int r = 0; r < 16; ++r)
+      for (int t = 0; t < 2; ++t)
 #pragma unroll
-      for (int jn = 0; jn < TN2; ++jn)
-        wsf[ct][r][jn] = p.ws[(long long)(64 * ct + 32 * wn + (r & 3) + 8 * (r >> 2) + 4 * lk) * p.ldws + 32 * jn + lrow];
+        for (int jn = 0; jn < TN2; ++jn) {
+          const fsv_sc_h16* row = wh + (long long)(32 * jn + lrow) * p.ldws + 64 * ct + 32 * wn + 16 * t + 4 * lk;
+          const fsv_sc_h16x4 lo = *reinterpret_cast<const fsv_sc_h16x4*>(row), hi = *reinterpret_cast<const fsv_sc_h16x4*>(row + 8);
+          fsv_sc_h16x8 v;
+          v[0] = lo[0]; v[1] = lo[1]; v[2] = lo[2]; v[3] = lo[3]; v[4] = hi[0]; v[5] = hi[1]; v[6] = hi[2]; v[7] = hi[3];
+          wsh[ct][t][jn] = v;
+        }
+  } else {
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+#pragma unroll
+        for (int jn = 0; jn < TN2; ++jn)
+          wsf[ct][r][jn] = p.ws[(long long)(64 * ct + 32 * wn + (r & 3) + 8 * (r >> 2) + 4 * lk) * p.ldws + 32 * jn + lrow];
+  }
   const float sc = p.wscale ? *p.wscale : 1.f;
 
   // ---- x of one (pixel tile, channel tile): four 16-byte vectors per lane ---------------------------------------------------------
@@ -176,6 +208,34 @@ __global__ __launch_bounds__(256, 2) void fsv_spade_conv_s_kernel(SpadeConvP p) 
         *reinterpret_cast<float4*>(&b_dst[q * B_ST + (br0 + i * RPB) * BN + bq * 4]) = breg[q][i];
   };
 
+  float4 hareg, hbreg[2];
+  auto issue_loads_h = [&]() {
+    const int k = ld_k;
+    const int Ch = p.ch[k];
+    const fsv_buf abuf = fsv_make_buf(reinterpret_cast<const fsv_sc_h16*>(p.map[k]) + pix0 * Ch, (long long)p.HW * Ch * 2);
+    const int kk = ld_c * BK + hs4 * 8;
+    const int m = ld_bm0 + hr0;
+    hareg = fsv_buf_load4(abuf, ((kk < Ch) & (m < p.HW)) ? (unsigned)((m * Ch + kk) * 2) : FSV_BUF_OOB);
+    const int ldk = (Ch + 31) & ~31;
+    const long long wbytes = (long long)C * ldk * 2;
+    const int c = 64 * ld_ct + hr0;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const fsv_sc_h16* w = reinterpret_cast<const fsv_sc_h16*>(q ? p.wb[k] : p.wg[k]) + z * p.w_bstride[k];
+      const fsv_buf wbuf = fsv_make_buf(w, wbytes);
+      hbreg[q] = fsv_buf_load4(wbuf, (ld_bm0 < p.HW) ? (unsigned)((c * ldk + kk) * 2) : FSV_BUF_OOB);
+    }
+    advance_loader();
+  };
+  auto store_chunk_h = [&](int buf) {
+    fsv_sc_h16* a_dst = Ah + buf * A_ST;
+    fsv_sc_h16* b_dst = Bh + buf * (2 * B_ST);
+    const int slot = ((hs4 ^ (hr0 >> 2)) & 3) << 3;
+    *reinterpret_cast<float4*>(&a_dst[hr0 * BK + slot]) = hareg;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) *reinterpret_cast<float4*>(&b_dst[q * B_ST + hr0 * BK + slot]) = hbreg[q];
+  };
+
   f32x16 acc[2];            // gamma^T, beta^T of the wave's [32 channels][32 pixels] block
 #pragma unroll
   for (int q = 0; q < 2; ++q)
@@ -207,6 +267,29 @@ __global__ __launch_bounds__(256, 2) void fsv_spade_conv_s_kernel(SpadeConvP p) 
 
   int buf = 0;
   auto chunk = [&]() {
+    if constexpr (F16) {
+      issue_loads_h();
+      const fsv_sc_h16* a_src = Ah + buf * A_ST;
+      const fsv_sc_h16* b_src = Bh + buf * (2 * B_ST);
+      const int ar = wm * 32 + lrow, br = wn * 32 + lrow;
+      fsv_sc_h16x8 fa[2], fb[2][2];
+#pragma unroll
+      for (int st = 0; st < 2; ++st) {
+        fa[st] = *reinterpret_cast<const fsv_sc_h16x8*>(&a_src[ar * BK + ((((2 * st + lk) ^ (ar >> 2)) & 3) << 3)]);
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+          fb[st][q] = *reinterpret_cast<const fsv_sc_h16x8*>(&b_src[q * B_ST + br * BK + ((((2 * st + lk) ^ (br >> 2)) & 3) << 3)]);
+      }
+#pragma unroll
+      for (int st = 0; st < 2; ++st)
+#pragma unroll
+        for (int q = 0; q < 2; ++q)      // operands swapped: rows of D = channels, columns = pixels
+          acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fb[st][q], fa[st], acc[q], 0, 0, 0);
+      store_chunk_h(buf ^ 1);
+      __syncthreads();
+      buf ^= 1;
+      return;
+    }
     issue_loads();                      // past the end: every lane is out of range -> zeros, never used
     const float* a_src = As + buf * A_ST;
     const float* b_src = Bs + buf * (2 * B_ST);
@@ -277,8 +360,7 @@ __global__ __launch_bounds__(256, 2) void fsv_spade_conv_s_kernel(SpadeConvP p) 
 
   // ---- the workgroup's pixel tiles ----------------------------------------------------------------------------------------------------
   load_x(blockIdx.x * BM, 0);
-  issue_loads();
-  store_chunk(0);
+  if constexpr (F16) { issue_loads_h(); store_chunk_h(0); } else { issue_loads(); store_chunk(0); }
   __syncthreads();                       // (also publishes cst)
 #pragma unroll 1
   for (int bm0 = blockIdx.x * BM; bm0 < p.HW; bm0 += tile_step) {
@@ -301,18 +383,41 @@ __global__ __launch_bounds__(256, 2) void fsv_spade_conv_s_kernel(SpadeConvP p) 
           }
         }
       }
-      if (p.hs && m < p.HW) {             // side output for the weight gradient of conv_s (training forward)
-        float* hrow = p.hs + (pix0 + m) * C + 64 * ct + 32 * wn + 4 * lk;
+      if constexpr (F16) {
+        fsv_sc_h16x8 ha[2];
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
-          *reinterpret_cast<float4*>(hrow + 8 * q) = make_float4(outv[4 * q], outv[4 * q + 1], outv[4 * q + 2], outv[4 * q + 3]);
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+          for (int e = 0; e < 8; ++e) ha[t][e] = (fsv_sc_h16)outv[8 * t + e];       // the one rounding of the modulated value
+        if (p.hs && m < p.HW) {           // side output (half) for the weight gradient of conv_s
+          fsv_sc_h16* hrow = reinterpret_cast<fsv_sc_h16*>(p.hs) + (pix0 + m) * C + 64 * ct + 32 * wn + 4 * lk;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            fsv_sc_h16x4 v;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = ha[q >> 1][4 * (q & 1) + e];
+            *reinterpret_cast<fsv_sc_h16x4*>(hrow + 8 * q) = v;
+          }
+        }
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+          for (int jn = 0; jn < TN2; ++jn)
+            acc2[jn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ha[t], wsh[ct][t][jn], acc2[jn], 0, 0, 0);
+      } else {
+        if (p.hs && m < p.HW) {           // side output for the weight gradient of conv_s (training forward)
+          float* hrow = p.hs + (pix0 + m) * C + 64 * ct + 32 * wn + 4 * lk;
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+            *reinterpret_cast<float4*>(hrow + 8 * q) = make_float4(outv[4 * q], outv[4 * q + 1], outv[4 * q + 2], outv[4 * q + 3]);
+        }
+        // second GEMM: register r of the two half-waves = the channel pair (c(r, 0), c(r, 1)) of 32 pixels
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+#pragma unroll
+          for (int jn = 0; jn < TN2; ++jn)
+            acc2[jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(outv[r], wsf[ct][r][jn], acc2[jn], 0, 0, 0);
       }
-      // second GEMM: register r of the two half-waves = the channel pair (c(r, 0), c(r, 1)) of 32 pixels
-#pragma unroll
-      for (int r = 0; r < 16; ++r)
-#pragma unroll
-        for (int jn = 0; jn < TN2; ++jn)
-          acc2[jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(outv[r], wsf[ct][r][jn], acc2[jn], 0, 0, 0);
     }
     // the two channel halves of a pixel block meet in LDS: wave (wm, wn) finishes rows with (r >> 3) == wn and hands the others over
     auto hand_over = [&](auto WNC) {
@@ -354,12 +459,13 @@ int fsv_spade_conv_s_supported(int C, int Cout, int nmaps) {
 // FSV_ACT_NONE: bn_s has no activation, architecture.py:103); ws = the K-major forward operand of conv_s' 1x1 weight ([>= C rows][ldws],
 // fsv_prep_weight), wscale = optional device scalar (1 / sigma), xs [N][HW][Cout].  hs (optional) receives the modulated tensor.
 // FSV_ERR_UNSUPPORTED for geometries without a kernel (fsv_spade_conv_s_supported).
-int fsv_spade_conv_s_fwd(const float* x, const float* mean, const float* rstd, float* hs, float* xs,
+static int fsv_spade_conv_s_impl(const float* x, const float* mean, const float* rstd, float* hs, float* xs,
                          int nmaps, const float* const* maps, const float* const* wg, const float* const* wb,
                          const float* const* bg, const float* const* bb, const int* ch, const long long* w_bstride,
                          const long long* b_bstride, int N, int HW, int C, int ldw, long long stat_bstride, int W, int up,
-                         const float* ws, int ldws, int Cout, const float* wscale, hipStream_t stream) {
-  if (!x || !mean || !rstd || !xs || !ws || !maps || !wg || !wb || !bg || !bb || !ch || N < 1 || HW < 1 || (ldw & 3) || ldws < Cout)
+                         const float* ws, int ldws, int Cout, const float* wscale, bool f16, hipStream_t stream) {
+  if (!x || !mean || !rstd || !xs || !ws || !maps || !wg || !wb || !bg || !bb || !ch || N < 1 || HW < 1 || (ldw & 3) ||
+      ldws < (f16 ? C : Cout))
     return FSV_ERR_BAD_ARG;
   if (!fsv_spade_conv_s_supported(C, Cout, nmaps)) return FSV_ERR_UNSUPPORTED;
   if (up && (W < 2 || (W & 1) || HW % W != 0 || ((HW / W) & 1))) return FSV_ERR_BAD_ARG;
@@ -371,7 +477,7 @@ int fsv_spade_conv_s_fwd(const float* x, const float* mean, const float* rstd, f
     p.map[k] = on ? maps[k] : nullptr; p.wg[k] = on ? wg[k] : nullptr; p.wb[k] = on ? wb[k] : nullptr;
     p.bg[k] = on ? bg[k] : nullptr; p.bb[k] = on ? bb[k] : nullptr;
     p.ch[k] = on ? ch[k] : 0; p.w_bstride[k] = on ? w_bstride[k] : 0; p.b_bstride[k] = on ? b_bstride[k] : 0;
-    if (on && (!maps[k] || !wg[k] || !wb[k] || !bg[k] || !bb[k] || ch[k] < 1 || (ch[k] & 3))) return FSV_ERR_UNSUPPORTED;
+    if (on && (!maps[k] || !wg[k] || !wb[k] || !bg[k] || !bb[k] || ch[k] < 1 || (ch[k] & (f16 ? 7 : 3)))) return FSV_ERR_UNSUPPORTED;
     if (on && (long long)HW * ch[k] * 4 > FSV_BUF_MAX_BYTES) return FSV_ERR_UNSUPPORTED;
   }
   p.nmaps = nmaps; p.N = N; p.HW = HW; p.C = C; p.ldw = ldw; p.stat_bstride = stat_bstride;
@@ -384,11 +490,41 @@ int fsv_spade_conv_s_fwd(const float* x, const float* mean, const float* rstd, f
   if (e && atoi(e) > 0) cap = atoi(e);
   if (cap < 1) cap = 1;
   dim3 g((unsigned)(ntiles < cap ? ntiles : cap), 1, N);
-  if (C == 64 && Cout == 32) FSV_LAUNCH((fsv_spade_conv_s_kernel<1, 1>), g, dim3(256), stream, p);
-  else if (C == 64) FSV_LAUNCH((fsv_spade_conv_s_kernel<1, 2>), g, dim3(256), stream, p);
-  else if (Cout == 32) FSV_LAUNCH((fsv_spade_conv_s_kernel<2, 1>), g, dim3(256), stream, p);
-  else FSV_LAUNCH((fsv_spade_conv_s_kernel<2, 2>), g, dim3(256), stream, p);
+  if (f16) {
+    if (C == 64 && Cout == 32) FSV_LAUNCH((fsv_spade_conv_s_kernel<1, 1, true>), g, dim3(256), stream, p);
+    else if (C == 64) FSV_LAUNCH((fsv_spade_conv_s_kernel<1, 2, true>), g, dim3(256), stream, p);
+    else if (Cout == 32) FSV_LAUNCH((fsv_spade_conv_s_kernel<2, 1, true>), g, dim3(256), stream, p);
+    else FSV_LAUNCH((fsv_spade_conv_s_kernel<2, 2, true>), g, dim3(256), stream, p);
+  } else {
+    if (C == 64 && Cout == 32) FSV_LAUNCH((fsv_spade_conv_s_kernel<1, 1>), g, dim3(256), stream, p);
+    else if (C == 64) FSV_LAUNCH((fsv_spade_conv_s_kernel<1, 2>), g, dim3(256), stream, p);
+    else if (Cout == 32) FSV_LAUNCH((fsv_spade_conv_s_kernel<2, 1>), g, dim3(256), stream, p);
+    else FSV_LAUNCH((fsv_spade_conv_s_kernel<2, 2>), g, dim3(256), stream, p);
+  }
   return fsv_check_launch();
+}
+
+int fsv_spade_conv_s_fwd(const float* x, const float* mean, const float* rstd, float* hs, float* xs,
+                         int nmaps, const float* const* maps, const float* const* wg, const float* const* wb,
+                         const float* const* bg, const float* const* bb, const int* ch, const long long* w_bstride,
+                         const long long* b_bstride, int N, int HW, int C, int ldw, long long stat_bstride, int W, int up,
+                         const float* ws, int ldws, int Cout, const float* wscale, hipStream_t stream) {
+  return fsv_spade_conv_s_impl(x, mean, rstd, hs, xs, nmaps, maps, wg, wb, bg, bb, ch, w_bstride, b_bstride, N, HW, C, ldw,
+                               stat_bstride, W, up, ws, ldws, Cout, wscale, false, stream);
+}
+
+// the `--amp` form: maps / wg / wb as fsv_spade_mod_fwd_h with the f16 GEMMs (IEEE half maps, N-major half gamma | beta operand of
+// fsv_spade_prep_h; Ch % 8 == 0), ws_h = N-major half operand of conv_s ([>= Cout rows][ldws halves], K contiguous,
+// fsv_hconv_prep_weight), hs_h (optional) receives the modulated tensor as half; xs stays fp32
+int fsv_spade_conv_s_fwd_h(const float* x, const float* mean, const float* rstd, void* hs_h, float* xs,
+                           int nmaps, const void* const* maps, const void* const* wg, const void* const* wb,
+                           const float* const* bg, const float* const* bb, const int* ch, const long long* w_bstride,
+                           const long long* b_bstride, int N, int HW, int C, long long stat_bstride, int W, int up,
+                           const void* ws_h, int ldws, int Cout, const float* wscale, hipStream_t stream) {
+  return fsv_spade_conv_s_impl(x, mean, rstd, reinterpret_cast<float*>(hs_h), xs, nmaps, reinterpret_cast<const float* const*>(maps),
+                               reinterpret_cast<const float* const*>(wg), reinterpret_cast<const float* const*>(wb), bg, bb, ch,
+                               w_bstride, b_bstride, N, HW, C, 0, stat_bstride, W, up, reinterpret_cast<const float*>(ws_h), ldws,
+                               Cout, wscale, true, stream);
 }
 
 }  // extern "C"

@@ -58,6 +58,8 @@ lib.register_sigs({
     "fsv_spade_conv_s_supported": [c_i, c_i, c_i],
     "fsv_spade_conv_s_fwd": [c_p, c_p, c_p, c_p, c_p, c_i, c_pp, c_pp, c_pp, c_pp, c_pp, c_ip, c_llp, c_llp,
                              c_i, c_i, c_i, c_i, c_ll, c_i, c_i, c_p, c_i, c_i, c_p, c_p],
+    "fsv_spade_conv_s_fwd_h": [c_p, c_p, c_p, c_p, c_p, c_i, c_pp, c_pp, c_pp, c_pp, c_pp, c_ip, c_llp, c_llp,
+                               c_i, c_i, c_i, c_ll, c_i, c_i, c_p, c_i, c_i, c_p, c_p],
     "fsv_upsample2x_fwd": [c_p, c_p, c_i, c_i, c_i, c_i, c_p],
     "fsv_upsample2x_bwd": [c_p, c_p, c_i, c_i, c_i, c_i, c_p],
     "fsv_act_fwd": [c_p, c_p, c_ll, c_i, c_p],
@@ -412,9 +414,14 @@ class _ConvFn(torch.autograd.Function):
         if site is not None:
             # x is the output of a held-back bn_s modulation (spade_into_conv): both in one kernel when it covers the geometry
             if (geom.kh == 1 and geom.kw == 1 and geom.stride == 1 and geom.pad == 0 and not per_sample and b is None and
-                    res is None and act == ACT_NONE and scale == 1.0 and not half and cpad == 0 and st is None and
+                    res is None and act == ACT_NONE and scale == 1.0 and half == bool(site.get('f16')) and
+                    bool(site.get('half')) == bool(site.get('f16')) and cpad == 0 and st is None and
                     lib.call_status("fsv_spade_conv_s_supported", site['dims'][2], cout, len(site['chs'])) == 1):
-                y = _spade_conv_s_launch(site, wt, ldw, cout, wscale, want_hs=any(ctx.needs_input_grad))
+                if half:          # the N-major half twin of the layout the half-precision convolution would read
+                    wh, kpad_h, _ = _conv.half_twin(wt)
+                    y = _spade_conv_s_launch(site, wh, kpad_h, cout, wscale, want_hs=any(ctx.needs_input_grad))
+                else:
+                    y = _spade_conv_s_launch(site, wt, ldw, cout, wscale, want_hs=any(ctx.needs_input_grad))
             else:
                 _spade_launch(site)
         if y is None:
@@ -941,20 +948,28 @@ def _spade_pending_for(x):
 
 
 def _spade_conv_s_launch(site, wt, ldws, cout, wscale, want_hs):
-    """x_s = conv_s(bn_s(x)) in one launch; returns x_s (NHWC storage, logical NCHW)"""
+    """x_s = conv_s(bn_s(x)) in one launch; returns x_s (NHWC storage, logical NCHW).  wt / ldws: the K-major fp32 forward operand of
+    the 1x1 weight, or - for a site on the f16 GEMMs (`--amp`) - its N-major half twin and row length"""
     arr = lambda v: (ctypes.c_void_p * max(len(v), 1))(*v)
     n, hw, c, ldw, w, up = site['dims']
     chs = site['chs']
     hgt = hw // w
     xs = empty_nhwc(n, cout, hgt, w, site['x'])
     lib.check_device(site['x'], wt, wscale)
-    with profile.scope('fsv_spade_conv_s_kernel' + (' P%d C%d N%d K%s' % (n * hw, c, cout, '+'.join(map(str, chs)))
-                                                      if profile.detail() else ''),
+    f16 = bool(site.get('f16'))
+    with profile.scope('fsv_spade_conv_s_kernel' + ('[f16]' if f16 else '') +
+                       (' P%d C%d N%d K%s' % (n * hw, c, cout, '+'.join(map(str, chs))) if profile.detail() else ''),
                        site['flops'] + 2.0 * n * hw * c * cout):
-        lib.call("fsv_spade_conv_s_fwd", lib.ptr(site['x']), lib.ptr(site['mean']), lib.ptr(site['rstd']),
-                 lib.ptr(site['h']) if want_hs else None, lib.ptr(xs), len(chs), _pp(site['maps']), arr(site['wg']),
-                 arr(site['wb']), arr(site['bg']), arr(site['bb']), lib.int_array(chs + [0]), _ll(site['wstr'] + [0]),
-                 _ll(site['bstr'] + [0]), n, hw, c, ldw, 0, w, up, lib.ptr(wt), ldws, cout, lib.ptr(wscale), lib.stream_ptr())
+        if f16:
+            lib.call("fsv_spade_conv_s_fwd_h", lib.ptr(site['x']), lib.ptr(site['mean']), lib.ptr(site['rstd']),
+                     lib.ptr(site['h']) if want_hs else None, lib.ptr(xs), len(chs), _pp(site['maps']), arr(site['wg']),
+                     arr(site['wb']), arr(site['bg']), arr(site['bb']), lib.int_array(chs + [0]), _ll(site['wstr'] + [0]),
+                     _ll(site['bstr'] + [0]), n, hw, c, 0, w, up, lib.ptr(wt), ldws, cout, lib.ptr(wscale), lib.stream_ptr())
+        else:
+            lib.call("fsv_spade_conv_s_fwd", lib.ptr(site['x']), lib.ptr(site['mean']), lib.ptr(site['rstd']),
+                     lib.ptr(site['h']) if want_hs else None, lib.ptr(xs), len(chs), _pp(site['maps']), arr(site['wg']),
+                     arr(site['wb']), arr(site['bg']), arr(site['bb']), lib.int_array(chs + [0]), _ll(site['wstr'] + [0]),
+                     _ll(site['bstr'] + [0]), n, hw, c, ldw, 0, w, up, lib.ptr(wt), ldws, cout, lib.ptr(wscale), lib.stream_ptr())
     return xs
 
 
@@ -1109,7 +1124,7 @@ class _SpadeFn(torch.autograd.Function):
                         flops=2.0 * n * h * w * c * 2 * sum(chs))
             pair = getattr(_spade_tls, 'pair', None)
             defer = getattr(_spade_tls, 'defer', None)
-            if (defer is not None and defer.pending is None and pair is None and nmaps > 0 and not ctx.half_out and
+            if (defer is not None and defer.pending is None and pair is None and nmaps > 0 and (ctx.f16 or not ctx.half_out) and
                     act == ACT_NONE and c in (64, 128)):
                 defer.pending = site            # the 1x1 convolution that reads hout issues both (spade_into_conv)
             elif pair is None or nmaps == 0:

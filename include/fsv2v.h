@@ -286,6 +286,15 @@ int fsv_spade_conv_s_fwd(const float* x, const float* mean, const float* rstd, f
                          const float* const* bg, const float* const* bb, const int* ch, const long long* w_bstride,
                          const long long* b_bstride, int N, int HW, int C, int ldw, long long stat_bstride, int W, int up,
                          const float* ws, int ldws, int Cout, const float* wscale, fsv_stream_t stream);
+/* `--amp` form of fsv_spade_conv_s_fwd: f16 GEMMs - maps / wg / wb as fsv_spade_mod_fwd_h with flags bit 2 (IEEE half maps, N-major
+ * half gamma | beta operand of fsv_spade_prep_h, Ch % 8 == 0), ws_h = N-major half operand of conv_s ([>= Cout rows][ldws halves],
+ * K contiguous: fsv_hconv_prep_weight); the modulated value is rounded to half once (as the two-launch form does at its store),
+ * hs_h (optional) receives it as half, xs is fp32 */
+int fsv_spade_conv_s_fwd_h(const float* x, const float* mean, const float* rstd, void* hs_h, float* xs,
+                           int nmaps, const void* const* maps, const void* const* wg, const void* const* wb,
+                           const float* const* bg, const float* const* bb, const int* ch, const long long* w_bstride,
+                           const long long* b_bstride, int N, int HW, int C, long long stat_bstride, int W, int up,
+                           const void* ws_h, int ldws, int Cout, const float* wscale, fsv_stream_t stream);
 /* backward twin of fsv_spade_mod_fwd: the same operands plus the upstream gradient dh; gamma / beta are recomputed in
  * registers, outputs are dgb[k] = d(gamma | beta) of every map ([P][2C], gamma in columns [0, C)) and dxhat [P][C] (per
  * full-resolution pixel also when up != 0).  act: FSV_ACT_NONE or FSV_ACT_LRELU. */

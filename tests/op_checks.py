@@ -1098,16 +1098,29 @@ def check_spade_pair(device, n=2, c=64, chs=(16, 8, 8), h=10, w=12, up=True, see
 
 
 def check_spade_conv_s(device, n=2, c=64, cout=32, chs=(16, 8), h=10, w=12, up=True, grad=True, spectral=True, seed=57,
-                       max_gx=None):
+                       max_gx=None, amp=False):
     """x_s = conv_s(bn_s(x, maps)) (architecture.py:103-108) through ops.spade_into_conv - ONE launch of csrc/spade_conv.hip -
     against the same two operators launched one after the other (each held to the oracle by check_spade / check_conv): x_s within
     the fp32 summation-order band (the fused kernel sums the 64 channels of a tile as two interleaved halves), gradients equal
     (the backward passes are the same two nodes; the training forward writes the modulated tensor as a side output for conv_s'
     weight gradient).  grad=False: the forward that keeps no graph - the call must not hand the kernel an hs pointer at all.
-    max_gx: FSV_SPADE_MAX_GX, a workgroup then walks several pixel tiles."""
+    max_gx: FSV_SPADE_MAX_GX, a workgroup then walks several pixel tiles.  amp: the `--amp` arithmetic on the half-precision
+    kernels - both forms round the maps, the weights and the modulated value to half at the same places and accumulate in fp32, so
+    they still agree to summation order (map channels a multiple of 8)."""
     import contextlib
     from importlib import import_module
     ops, conv = pkg()
+    prev_mode = conv.set_mfma_mode(1 if amp else conv.mfma_mode())
+    os.environ['FSV_SPADE_F16'] = '1'
+    try:
+        _check_spade_conv_s(device, ops, conv, n, c, cout, chs, h, w, up, grad, spectral, seed, max_gx, amp)
+    finally:
+        conv.set_mfma_mode(prev_mode)
+
+
+def _check_spade_conv_s(device, ops, conv, n, c, cout, chs, h, w, up, grad, spectral, seed, max_gx, amp):
+    import contextlib
+    from importlib import import_module
     lib = import_module('few-shot-vid2vid_amd.lib')
     g = torch.Generator().manual_seed(seed)
     xs_h, xs_w = (h // 2, w // 2) if up else (h, w)
@@ -1161,9 +1174,10 @@ def check_spade_conv_s(device, n=2, c=64, cout=32, chs=(16, 8), h=10, w=12, up=T
     y1, g1, seen1, st1 = run(False)
     y2, g2, seen2, st2 = run(True)
     names1, names2 = [s_[0] for s_ in seen1], [s_[0] for s_ in seen2]
-    assert 'fsv_spade_conv_s_fwd' not in names1 and 'fsv_spade_mod_fwd' in names1
-    assert 'fsv_spade_conv_s_fwd' in names2 and 'fsv_spade_mod_fwd' not in names2, names2
-    fused_args = [a for (nm, a) in seen2 if nm == 'fsv_spade_conv_s_fwd'][0]
+    sfx = '_h' if amp else ''
+    assert 'fsv_spade_conv_s_fwd' + sfx not in names1 and 'fsv_spade_mod_fwd' + sfx in names1, names1
+    assert 'fsv_spade_conv_s_fwd' + sfx in names2 and 'fsv_spade_mod_fwd' + sfx not in names2, names2
+    fused_args = [a for (nm, a) in seen2 if nm == 'fsv_spade_conv_s_fwd' + sfx][0]
     assert (fused_args[3] is not None) == grad, 'the modulated tensor is a side output of the training forward only'
     assert_close('fused bn_s -> conv_s output', y2, y1, tol=2e-5)
     for a, b in zip(st1, st2):

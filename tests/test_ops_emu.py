@@ -175,6 +175,8 @@ def test_spade_modulation_fused_with_the_shortcut_convolution(emu_lib):
     oc.check_spade_conv_s(DEV, c=128, cout=64, chs=(8,), h=9, w=7, up=False)        # two channel tiles, ragged pixel tile
     oc.check_spade_conv_s(DEV, c=64, cout=64, chs=(8, 8, 4), h=12, w=8, up=True, spectral=False, max_gx=1)   # tile walk, three maps
     oc.check_spade_conv_s(DEV, c=128, cout=32, chs=(36,), h=8, w=8, up=False, grad=False)     # no graph: hs is never written
+    oc.check_spade_conv_s(DEV, chs=(16, 8), amp=True)                              # `--amp`: f16 GEMMs, half side output
+    oc.check_spade_conv_s(DEV, c=128, cout=64, chs=(40,), h=9, w=7, up=False, grad=False, amp=True)
 
 
 def test_spade_two_site_launch(emu_lib):

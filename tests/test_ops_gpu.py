@@ -178,6 +178,8 @@ def test_spade_modulation_fused_with_the_shortcut_convolution(hip_lib):
     oc.check_spade_conv_s(dev(), c=128, cout=64, chs=(8,), h=9, w=7, up=False)        # two channel tiles, ragged pixel tile
     oc.check_spade_conv_s(dev(), c=64, cout=64, chs=(8, 8, 4), h=12, w=8, up=True, spectral=False, max_gx=1)   # tile walk, three maps
     oc.check_spade_conv_s(dev(), c=128, cout=32, chs=(36,), h=8, w=8, up=False, grad=False)     # no graph: hs is never written
+    oc.check_spade_conv_s(dev(), chs=(16, 8), amp=True)                              # `--amp`: f16 GEMMs, half side output
+    oc.check_spade_conv_s(dev(), c=128, cout=64, chs=(40,), h=9, w=7, up=False, grad=False, amp=True)
     oc.check_spade_conv_s(dev(), n=2, c=64, cout=32, chs=(32, 32), h=64, w=96, up=True)
     oc.check_spade_conv_s(dev(), n=1, c=128, cout=64, chs=(64, 64), h=48, w=64, up=True, grad=False)
 

@@ -25,6 +25,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--reps', type=int, default=20)
     ap.add_argument('--rounds', type=int, default=5)
+    ap.add_argument('--amp', type=int, default=0, help='1: the --amp arithmetic (half maps / weights, f16 GEMMs)')
     args = ap.parse_args()
     from importlib import import_module
     import fsv2v_amd  # noqa: F401
@@ -33,7 +34,9 @@ def main():
     lib = import_module('few-shot-vid2vid_amd.lib')
     dev = torch.device('cuda:0')
     g = torch.Generator().manual_seed(1)
-    watch = ('fsv_spade_mod_fwd', 'fsv_conv_gather_fwd', 'fsv_spade_conv_s_fwd')
+    watch = ('fsv_spade_mod_fwd', 'fsv_conv_gather_fwd', 'fsv_spade_conv_s_fwd', 'fsv_spade_mod_fwd_h', 'fsv_hconv_gather',
+             'fsv_spade_conv_s_fwd_h')
+    conv.set_mfma_mode(1 if args.amp else 0)
     for (tag, n, c, cout, chs, h, w, up) in SHAPES:
         xs = (h // 2, w // 2) if up else (h, w)
         cl = lambda t: t.to(dev).contiguous(memory_format=torch.channels_last)
@@ -83,8 +86,10 @@ def main():
         t1g, _ = run(True, True)
         out['two_launches_us'] = {k.replace('fsv_', ''): round(v, 1) for k, v in t2.items()}
         out['two_launches_total_us'] = round(sum(t2.values()), 1)
-        out['fused_us'] = round(t1.get('fsv_spade_conv_s_fwd', float('nan')), 1)
-        out['fused_with_side_output_us'] = round(t1g.get('fsv_spade_conv_s_fwd', float('nan')), 1)
+        fk = 'fsv_spade_conv_s_fwd_h' if args.amp else 'fsv_spade_conv_s_fwd'
+        out['arithmetic'] = 'amp O1 (f16 GEMMs)' if args.amp else 'fp32'
+        out['fused_us'] = round(t1.get(fk, float('nan')), 1)
+        out['fused_with_side_output_us'] = round(t1g.get(fk, float('nan')), 1)
         out['max_rel_diff'] = float((y1 - y2).abs().max() / y2.abs().max())
         # algorithmic HBM bytes: x (a quarter of the pixels when the up-sampling is folded in) + maps + x_s (+ the modulated tensor)
         px = n * h * w
