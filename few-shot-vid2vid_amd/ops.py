@@ -1197,7 +1197,13 @@ class _SpadeFn(torch.autograd.Function):
             arr = lambda v: (ctypes.c_void_p * max(len(v), 1))(*v)
             lib.check_device(x, dh, *maps)
             dbsum = None
-            if f16 and nm:
+            # bias gradients (per-channel sums of d(gamma|beta)) from the twin's own epilogue instead of a column-sum pass over the
+            # [P][2C] tensors it writes: always on the f16 GEMMs; on the exact-fp32 kernels unless the fixed-order mode asks for the
+            # read pass (fp64 atomics: the sum of fp32 terms is exact to fp32 rounding in any order, but not bit-pinned)
+            twin_sums = f16 or (_os.environ.get('FSV_SPADE_DBSUM', '1') == '1' and _os.environ.get('FSV_DETERMINISTIC', '0') != '1'
+                                and any(ctx.needs_input_grad[7 + 5 * k + 3] or ctx.needs_input_grad[7 + 5 * k + 4]
+                                        for k in range(nm)))
+            if twin_sums and nm:
                 # (h w / 64 pixel tiles) x 2 waves add into every address: spread over copies beyond 512 adds per address
                 slots = int(_os.environ.get('FSV_SPADE_DB_SLOTS', '0'))          # (tests force the multi-copy form on small maps)
                 while slots < 64 and (slots < 1 or (h * w // 32) // slots > 512):
@@ -1207,7 +1213,7 @@ class _SpadeFn(torch.autograd.Function):
             # (labelled as the backward twin; FLOPs = the gamma / beta GEMMs it recomputes)
             with profile.scope('fsv_spade_mod_kernel<bwd>' + (' P%d C%d K%s' % (n * h * w, c, '+'.join(map(str, chs)))
                                                               if profile.detail() else ''), 2.0 * n * h * w * c * 2 * sum(chs)):
-                if dh.dtype == torch.float16 or f16:
+                if dh.dtype == torch.float16 or f16 or dbsum is not None:
                     flags = (1 if dh.dtype == torch.float16 else 0) | (6 if f16 else 0)
                     lib.call("fsv_spade_mod_bwd_h", lib.ptr(x), lib.ptr(mean), lib.ptr(rstd), lib.ptr(dh), nm, _pp(maps), arr(wg_p),
                              arr(wb_p), arr(bg_p), arr(bb_p), lib.int_array(chs + [0]), _ll(wstr + [0]), _ll(bstr + [0]),

@@ -1,28 +1,17 @@
 #!/bin/bash
-# round 4, pass v: ordered split-K - operator test, the C1 step over seeds in the default mode (twice each), pose bench A/B
+# round 4, second session: bias gradients of the SPADE backward from the twin's epilogue on the fp32 kernels (FSV_SPADE_DBSUM)
 set -u
 ROOT=${GRAFT_REPO_ROOT:-$PWD}
-OUT=$ROOT/gpurun_out/${1:-r4v}
+OUT=$ROOT/gpurun_out/r4v
 mkdir -p "$OUT"
 cd "$ROOT"
-timeout 600 python -m pytest tests/test_ops_gpu.py tests/test_golden.py tests/test_model_gpu.py -q -m gpu -x > "$OUT/pytest.log" 2>&1
-echo "tests: exit $? $(tail -n 2 "$OUT/pytest.log" | cut -c1-300)" | tee -a "$OUT/summary.txt"
-cd tests
-timeout 900 python - > "$OUT/c1_seeds.txt" 2>&1 <<'PY'
-import torch, model_checks as mc
-DEV = torch.device('cuda:0')
-opt = mc.make_opt(dataset_mode='fewshot_face', input_nc=1, fineSize=128, loadSize=128, batchSize=1)
-for seed in (21, 22, 23, 24):
-    for rep in range(2):
-        try:
-            worst = mc.check_train_step(DEV, opt, b=1, tol=1e-3, grad_tol=1.0, seed=seed)
-            print('seed', seed, 'rep', rep, 'worst grad rel L2 %.4e' % worst, flush=True)
-        except AssertionError as e:
-            print('seed', seed, 'rep', rep, 'FAILED', str(e)[:200], flush=True)
-PY
-cd "$ROOT"
-cat "$OUT/c1_seeds.txt" | grep -v amdgpu | tee -a "$OUT/summary.txt"
-for v in 1 0; do
-  FSV_ORDERED_SPLIT=$v timeout 300 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-roofline > "$OUT/bench.json" 2> "$OUT/bench.err"
-  echo "pose fp32 ordered=$v: $(tail -n 1 "$OUT/bench.json" | cut -c1-200)" | tee -a "$OUT/summary.txt"
+timeout 300 python -m pytest tests/test_ops_gpu.py -x -q -k "spade" > "$OUT/pytest_ops.txt" 2>&1
+tail -n 4 "$OUT/pytest_ops.txt"
+for f in 0 1 0 1; do
+  FSV_SPADE_DBSUM=$f timeout 200 python bench.py --steps 20 --warmup 5 --no-cpu-baseline > "$OUT/bench_$f.tmp" 2> "$OUT/bench_$f.err"
+  echo "FSV_SPADE_DBSUM=$f $(tail -n 1 "$OUT/bench_$f.tmp" | cut -c1-200)" | tee -a "$OUT/step_ab.txt"
+done
+for f in 0 1; do
+  FSV_SPADE_DBSUM=$f timeout 200 python bench.py --workload street --steps 20 --warmup 5 --no-cpu-baseline > "$OUT/bench_s$f.tmp" 2> "$OUT/bench_s$f.err"
+  echo "street FSV_SPADE_DBSUM=$f $(tail -n 1 "$OUT/bench_s$f.tmp" | cut -c1-200)" | tee -a "$OUT/step_ab.txt"
 done
