@@ -1198,9 +1198,10 @@ class _SpadeFn(torch.autograd.Function):
             lib.check_device(x, dh, *maps)
             dbsum = None
             # bias gradients (per-channel sums of d(gamma|beta)) from the twin's own epilogue instead of a column-sum pass over the
-            # [P][2C] tensors it writes: always on the f16 GEMMs; on the exact-fp32 kernels unless the fixed-order mode asks for the
-            # read pass (fp64 atomics: the sum of fp32 terms is exact to fp32 rounding in any order, but not bit-pinned)
-            twin_sums = f16 or (_os.environ.get('FSV_SPADE_DBSUM', '1') == '1' and _os.environ.get('FSV_DETERMINISTIC', '0') != '1'
+            # [P][2C] tensors it writes: on the f16 GEMMs always; on the exact-fp32 kernels an opt-in (FSV_SPADE_DBSUM=1) - measured
+            # neutral there (profiles/r04_notes.md section 10: the grouped column-sum pass costs what the fp64 atomics cost), and
+            # the fixed-order mode wants the read pass anyway
+            twin_sums = f16 or (_os.environ.get('FSV_SPADE_DBSUM', '0') == '1' and _os.environ.get('FSV_DETERMINISTIC', '0') != '1'
                                 and any(ctx.needs_input_grad[7 + 5 * k + 3] or ctx.needs_input_grad[7 + 5 * k + 4]
                                         for k in range(nm)))
             if twin_sums and nm:
