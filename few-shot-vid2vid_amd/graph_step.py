@@ -109,7 +109,7 @@ class GraphedIteration:
 
     # ------------------------------------------------------------------------------------------------ the body
     def _backward(self, losses, optimizer):
-        with _model.branch_of(losses):          # (the discriminator step of a single-graph iteration lives on a side stream)
+        with _model.branch_of(losses, optimizer):   # (the discriminator step of a single-graph iteration lives on a side stream)
             losses, loss = _model.mean_and_total(losses)
             optimizer.zero_grad()
             optimizer.scale_loss(loss).backward()

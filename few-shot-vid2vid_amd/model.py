@@ -371,7 +371,7 @@ def loss_backward(opt, losses, optimizer, loss_id):
     """models/loss_collector.py:217-228: sum of means -> zero_grad -> backward -> optimiser step.  With `--amp` the
     reference scales the loss per `loss_id` (:221-224); here every optimiser owns its scaler (flat.FlatAdam.scale_loss:
     identity unless the fp16-operand mode is on) and un-scales inside its fused step."""
-    with branch_of(losses):
+    with branch_of(losses, optimizer):
         losses, loss = mean_and_total(losses)
         optimizer.zero_grad()
         scale_loss = getattr(optimizer, 'scale_loss', None)
@@ -383,11 +383,13 @@ def loss_backward(opt, losses, optimizer, loss_id):
     return losses
 
 
-def branch_of(losses):
+def branch_of(losses, optimizer=None):
     """context of the stream a list of losses was computed on: the discriminator step of an iteration with
-    `Vid2VidModel.early_generator` lives on a side stream (its forward pass tagged the first loss), everything else on the
-    caller's"""
+    `Vid2VidModel.early_generator` lives on a side stream (its forward pass tagged the first loss and the discriminator's
+    optimiser), everything else on the caller's"""
     branch = getattr(losses[0], '_fsv_branch', None) if len(losses) and torch.is_tensor(losses[0]) else None
+    if branch is None or branch.stream is None:
+        branch = getattr(optimizer, '_fsv_branch', None)
     return branch.on() if (branch is not None and branch.stream is not None) else contextlib.nullcontext()
 
 
@@ -655,6 +657,8 @@ class Vid2VidModel(nn.Module):
         key, branch, gen = self._pre_g
         self._pre_g = None
         branch.finish()
+        if self.optimizer_D is not None:
+            self.optimizer_D._fsv_branch = None
         return gen if (data_list is not None and key == self._data_key(data_list)) else None
 
     def forward(self, data_list, save_images=False, mode='inference', dummy_bs=0):
@@ -826,7 +830,11 @@ class Vid2VidModel(nn.Module):
             with torch.enable_grad():
                 gen = self.generate_images(tgt_label, tgt_image, ref_labels, ref_images, prevs)
             self._pre_g = (early, branch, gen)
-            losses[0]._fsv_branch = branch       # loss_backward continues the discriminator step on the branch's stream
+            # loss_backward continues the discriminator step on the branch's stream: the tag rides on the losses AND on the
+            # optimiser that will step them (a caller may hand loss_backward clones of the losses)
+            losses[0]._fsv_branch = branch
+            if self.optimizer_D is not None:
+                self.optimizer_D._fsv_branch = branch
         return losses
 
     def forward_generator(self, tgt_label, tgt_image, ref_labels, ref_images, prevs, flow_gt=(None, None),
