@@ -509,6 +509,9 @@ def main():
                    'global_batch': args.batch * world, 'parallelism': 'dp%d' % world, 'launch': mode,
                    'algorithmic_tflop_per_frame': round(tflop_per_frame, 4)},
     }
+    if getattr(model, 'early_generator', False) and not g_only:
+        result['config']['schedule'] = ('discriminator step (forward, backward, Adam) on a side stream next to the generator-mode forward '
+                                        'pass: parallel branches of the captured graph, same kernels and per-network order')
     if M.amp_mode(opt) == 1:
         result['config']['arithmetic'] = ('--amp O1: GEMM operands and activations between the narrow layers in IEEE half, fp32 '
                                           'accumulation (v_mfma_f32_32x32x16_f16), dynamic loss scale; not the fp32 headline')
