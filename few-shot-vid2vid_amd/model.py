@@ -650,16 +650,43 @@ class Vid2VidModel(nn.Module):
         return tuple(None if t is None else (id(t), t.data_ptr(), t._version) for t in flat)
 
     def join_early(self, data_list=None):
-        """join the discriminator step's side stream into the current one; returns the generator pass that was issued next to
-        it if `data_list` is the data it was computed from (else None: the pass is dropped)"""
+        """join the discriminator step's side stream into the current one; returns (generator pass, real-image pass or None) if
+        `data_list` is the data the early passes were computed from (else None: they are dropped)"""
         if self._pre_g is None:
             return None
         key, branch, gen = self._pre_g
+        ours = data_list is not None and key == self._data_key(data_list)
+        real_outs = None
+        if ours and branch.stream is not None and _SPLIT_D_PASS and os.environ.get('FSV_EARLY_REAL', '1') == '1':     # (in-box A/B)
+            # the G step's discriminator pass over the REAL images (no autograd; needs the discriminator as the step that is
+            # finishing on the side stream leaves it): behind that step on the same stream, i.e. still next to the generator pass
+            tgt_label, tgt_image, _, _, ref_label, ref_image = data_list[:6]
+            with branch.on():
+                rb = self._real_branch(encode_label(self.opt, tgt_label), tgt_image, encode_label(self.opt, ref_label), ref_image)
+                real_outs = rb() if rb is not None else None
         self._pre_g = None
-        branch.finish()
+        branch.finish(real_outs)
         if self.optimizer_D is not None:
             self.optimizer_D._fsv_branch = None
-        return gen if (data_list is not None and key == self._data_key(data_list)) else None
+        return (gen, real_outs) if ours else None
+
+    def _real_branch(self, tgt_label, tgt_image, ref_labels, ref_images):
+        """closure for the G step's discriminator pass over the real images (LossCollector.real_pass), or None when the pass
+        cannot be split off (attention picks the conditioning reference after the generator ran)"""
+        opt = self.opt
+        if not (_SPLIT_D_PASS and getattr(opt, 'n_shot', 1) == 1 and ref_labels.shape[1] == 1):
+            return None
+        real = tgt_image[:, 0]
+        ref_labels_valid = valid_labels(opt, ref_labels)
+        fg0 = fg_mask_of(opt, tgt_label[:, 0], self.has_fg)
+        ref_fg0 = fg_mask_of(opt, ref_labels[:, 0], self.has_fg)
+        G = self.netG
+        with_raw = ((not G.spade_combine) and (G.warp_ref or G.warp_prev)) or G.add_raw_output_loss
+        reals0 = [real, real * union_fg(fg0, ref_fg0, self.has_fg) if with_raw else None]
+        # ONE power iteration per stacked call of the reference, shared by its real and its generated half
+        sigmas = [self.netD.begin_pass() if r is not None else None for r in reals0]
+        lc = self.lossCollector
+        return lambda: lc.real_pass(self.netD, tgt_label, reals0, ref_labels_valid[:, 0], ref_images[:, 0], sigmas)
 
     def forward(self, data_list, save_images=False, mode='inference', dummy_bs=0):
         # (joined BEFORE this pass zeroes the statistics arena the side stream may still be working in)
@@ -851,32 +878,21 @@ class Vid2VidModel(nn.Module):
         if self.netDT is not None:
             d_params += [p for p in self.netDT.parameters() if p.requires_grad]
         real_outs = None
-        if _SPLIT_D_PASS and getattr(opt, 'n_shot', 1) == 1 and ref_labels.shape[1] == 1:
-            # The discriminator's pass over the real images needs the data only (with one reference image; with attention the
-            # conditioning is the attended reference, known after the generator ran): it is issued as a branch next to the
-            # generator's forward pass (streams.fork) and carries no autograd graph - loss_collector.py:47-68 stacks real and
-            # generated images into one batch, whose backward pass then moves a zero gradient through the real half.
-            ref_labels_valid = valid_labels(opt, ref_labels)
-            fg0 = fg_mask_of(opt, tgt_label[:, 0], self.has_fg)
-            ref_fg0 = fg_mask_of(opt, ref_labels[:, 0], self.has_fg)
-            G = self.netG
-            with_raw = ((not G.spade_combine) and (G.warp_ref or G.warp_prev)) or G.add_raw_output_loss
-            reals0 = [real, real * union_fg(fg0, ref_fg0, self.has_fg) if with_raw else None]
-            # ONE power iteration per stacked call of the reference, shared by its real and its generated half
-            sigmas = [self.netD.begin_pass() if r is not None else None for r in reals0]
-
-            def real_branch():
-                return lc.real_pass(self.netD, tgt_label, reals0, ref_labels_valid[:, 0], ref_images[:, 0], sigmas)
-            if pre is not None:
-                gen, real_outs = pre, real_branch()
-            else:
-                gen, real_outs = streams.fork(tgt_label, [
-                    lambda: self.generate_images(tgt_label, tgt_image, ref_labels, ref_images, prevs,
-                                                 ref_labels_valid=ref_labels_valid), real_branch])
-            (fake, raw, warped, flow, mask), (fg, ref_fg), (ref_label, ref_image), prevs_new = gen
+        pre_gen, pre_real = pre if pre is not None else (None, None)
+        # The discriminator's pass over the real images needs the data only (with one reference image; with attention the
+        # conditioning is the attended reference, known after the generator ran): it is issued as a branch next to the
+        # generator's forward pass (streams.fork; with an early generator pass: behind the discriminator step on ITS side stream,
+        # join_early) and carries no autograd graph - loss_collector.py:47-68 stacks real and generated images into one batch,
+        # whose backward pass then moves a zero gradient through the real half.
+        real_branch = self._real_branch(tgt_label, tgt_image, ref_labels, ref_images) if pre_real is None else None
+        if pre_gen is not None:
+            gen, real_outs = pre_gen, (pre_real if pre_real is not None else (real_branch() if real_branch is not None else None))
+        elif real_branch is not None:
+            gen, real_outs = streams.fork(tgt_label, [
+                lambda: self.generate_images(tgt_label, tgt_image, ref_labels, ref_images, prevs), real_branch])
         else:
-            (fake, raw, warped, flow, mask), (fg, ref_fg), (ref_label, ref_image), prevs_new = \
-                pre if pre is not None else self.generate_images(tgt_label, tgt_image, ref_labels, ref_images, prevs)
+            gen = self.generate_images(tgt_label, tgt_image, ref_labels, ref_images, prevs)
+        (fake, raw, warped, flow, mask), (fg, ref_fg), (ref_label, ref_image), prevs_new = gen
         fg_union = union_fg(fg, ref_fg, self.has_fg)
         for p in d_params:
             p.requires_grad_(False)

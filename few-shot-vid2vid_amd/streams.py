@@ -107,10 +107,13 @@ class Branch:
         if self.stream is not None:
             _record(obj, self.stream)
 
-    def finish(self):
-        """the current stream waits for everything the branch has been given"""
+    def finish(self, made=None):
+        """the current stream waits for everything the branch has been given; `made`: tensors produced on the branch that the
+        caller's stream reads from now on"""
         if self.stream is not None:
-            torch.cuda.current_stream(self.stream.device).wait_stream(self.stream)
+            cur = torch.cuda.current_stream(self.stream.device)
+            cur.wait_stream(self.stream)
+            _record(made, cur)
             if any(self.stream is b for b in _busy):
                 _busy.remove(self.stream)
             self.stream = None
