@@ -367,7 +367,7 @@ def main():
 
     def build_optimizers(seg):
         return model.build_optimizers(world_size=world, process_group=group, force_exchange=force_dist,
-                                      overlap=not seg, split_backward=seg)
+                                      overlap=not seg, split_backward=seg or (not g_only and os.environ.get('FSV_BENCH_SPLIT', '1') == '1'))
     opt_G, opt_D = build_optimizers(segmented)
     data = make_data(args.batch, args.size, 1234 + rank, device, opt)
 

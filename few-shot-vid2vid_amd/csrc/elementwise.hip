@@ -226,6 +226,19 @@ int fsv_adam_step(float* param, const float* grad, float* m, float* v, float* st
   return fsv_check_launch();
 }
 
+// One optimiser step issued in several pieces (ranges of the flat buffers whose gradients become final at different times): the
+// piece with tick != 0 advances the step count / bias corrections in `state`, the others - ordered behind it by the caller - only
+// read them.  Same arithmetic per element as fsv_adam_step.
+int fsv_adam_step_range(float* param, const float* grad, float* m, float* v, float* state, long long n, float beta1,
+                        float beta2, float eps, float gscale, int tick, hipStream_t stream) {
+  if (!param || !grad || !m || !v || !state || n < 0) return FSV_ERR_BAD_ARG;
+  if (tick) FSV_LAUNCH(fsv_adam_tick_kernel, dim3(1), dim3(64), stream, state, beta1, beta2);
+  if (n > 0)
+    FSV_LAUNCH(fsv_adam_kernel, dim3(fsv_grid_for(n / 4 + 1)), dim3(256), stream, param, grad, m, v, (const float*)state, n,
+               beta1, beta2, eps, gscale);
+  return fsv_check_launch();
+}
+
 }  // extern "C"
 
 // ---- channel concatenation into NHWC (U-Net skips generator.py:563, flow-net input :498, ds_ref :441-443) -----------------

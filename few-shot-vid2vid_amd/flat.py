@@ -185,6 +185,7 @@ class FlatAdam:
     # ------------------------------------------------------------------------------------------------ optimiser API
     def zero_grad(self, set_to_none=False):
         """Called by loss_backward right before backward: clears the flat gradient and arms the bucket hooks."""
+        self.abandon_early()
         self.flat_g.zero_()
         if self.finalizer is not None:
             self.finalizer.begin_pass()       # drops jobs of a pass that was never stepped, zeroes the wgrad arena
@@ -305,8 +306,54 @@ class FlatAdam:
         scalar - nothing is read back); identity without a scaler."""
         return loss if self.scaler is None else loss * self.scaler[0]
 
+    # ---- the step of the decoder stage between the two pieces of a split backward (one GPU) -------------------------------
+    # With build_optimizers(split_backward=True) the gradients of flat_g[:split_at] (the generator's decoder stage) are final
+    # once the first piece of the backward pass has run.  Without a gradient exchange nothing else has to happen to them: their
+    # Adam launch and the refresh of their GEMM layouts go to a side stream (streams.Branch) and run next to the second piece
+    # (encoders, weight generators, flow network: several ms of MFMA kernels); adam() then joins the branch and steps the rest.
+    # Same arithmetic per parameter: bit-identical weights.  Never under `--amp` (the overflow test spans all gradients) or with an
+    # exchange (the ranges are all-reduced first).  Measured neutral on one GPU (profiles/r04_notes.md section 11: 47.04 / 47.10 ms
+    # without, 47.08 / 47.14 ms with - the optimiser's streaming kernels take from the second piece what they hide), hence an
+    # opt-in: FSV_EARLY_ADAM=1.
+    _early = None
+
+    def abandon_early(self):
+        """a pass whose second piece / Adam never ran (an interrupted capture, an exception): join the branch, forget it"""
+        if self._early is not None:
+            branch, self._early = self._early, None
+            branch.finish()
+
+    def early_step_ready(self):
+        return (self.split_at > 0 and self.scaler is None and not self.exchange and self.layouts is not None and
+                os.environ.get('FSV_EARLY_ADAM', '0') == '1')
+
+    def step_stage2_early(self):
+        if not self.early_step_ready() or self._early is not None:
+            return False
+        from . import streams
+        self.finalize_grads(partial=True)          # (on the caller's stream: its temporaries belong to that stream's allocator)
+        s = self.split_at
+        branch = streams.Branch(self.flat_g)
+        with branch.on():
+            ops.adam_step(self.flat_p[:s], self.flat_g[:s], self.m[:s], self.v[:s], self.state, self.betas[0], self.betas[1],
+                          self.eps, 1.0 / self.world_size, tick=True)
+            base = self.flat_p.data_ptr()
+            self.layouts.refresh_split(0, base, base + 4 * s)
+        self._early = branch
+        return True
+
     def adam(self):
         self.finalize_grads()
+        if self._early is not None:
+            branch, self._early = self._early, None
+            branch.finish()                         # (the state was ticked on the branch; the second piece took ms longer than it)
+            s = self.split_at
+            ops.adam_step(self.flat_p[s:], self.flat_g[s:], self.m[s:], self.v[s:], self.state, self.betas[0], self.betas[1],
+                          self.eps, 1.0 / self.world_size, tick=False)
+            self._steps_done += 1
+            base = self.flat_p.data_ptr()
+            self.layouts.refresh_split(1, base, base + 4 * s)
+            return
         if self.scaler is not None:
             # gradients carry the loss scale: test them, step with grad / scale unless one is inf / nan, adapt the scale
             ops.amp_adam_step(self.flat_p, self.flat_g, self.m, self.v, self.state, self.scaler, self.betas[0],

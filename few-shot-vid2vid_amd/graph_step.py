@@ -142,7 +142,8 @@ class GraphedIteration:
             losses, loss = _model.mean_and_total(g_losses)
             self.opt_G.zero_grad()
             self.opt_G.scale_loss(loss).backward()
-            self.opt_G.finalize_grads(partial=True)
+            if not self.opt_G.step_stage2_early():      # (one GPU: the decoder stage's Adam + layouts next to the second piece)
+                self.opt_G.finalize_grads(partial=True)
             e.out_g = losses
         e.out_gen, e.out_prev = generated, prevs
 
@@ -247,6 +248,10 @@ class GraphedIteration:
             self.model._pre_g = None
         for o in (self.opt_D, self.opt_G):
             o._reattach()
+            try:
+                o.abandon_early()                # a decoder-stage step the interrupted body issued
+            except Exception:                    # noqa: BLE001
+                o._early = None
 
     def launch_mode(self):
         """how the iterations of this object reach the device - for bench.py's `config.launch`"""

@@ -160,6 +160,31 @@ class LayoutCache:
             # the tables are temporaries: keep them alive until the launch has consumed them
             torch.cuda.current_stream().synchronize()
 
+    def refresh_split(self, part, lo, hi):
+        """Rewrite the layouts of the weights that lie in bytes [lo, hi) of the optimiser's flat parameter buffer (part 0) or
+        outside of it (part 1): an optimiser step issued in two pieces refreshes each piece's layouts behind its own Adam
+        launch (FlatAdam.step_stage2_early).  fp32 layouts only (the caller keeps `--amp` on the one-piece step)."""
+        if not self.entries:
+            return
+        key = (lo, hi)
+        if self._dirty or getattr(self, '_split_key', None) != key:
+            if not lib.is_emu() and torch.cuda.is_current_stream_capturing():
+                raise lib.FsvError("weight-layout cache changed inside a graph capture; run one eager step first")
+            inside = [e for e in self.entries if lo <= e.src_ptr < hi]
+            outside = [e for e in self.entries if not (lo <= e.src_ptr < hi)]
+            dev = self.entries[0].weight.device
+            self._split_tables = [self._build(es, dev) if es else None for es in (inside, outside)]
+            self._split_entries = (inside, outside)
+            self._split_key = key
+            if self._dirty:           # keep the whole-cache tables in step (refresh() may still be called)
+                self._tables, self._nblocks = self._build(self.entries, dev)
+                self._dirty = False
+        t = self._split_tables[part]
+        if t is not None:
+            self._launch(t[0], t[1])
+        for e in self._split_entries[part]:
+            e.version = e.weight._version
+
     def refresh(self):
         """Rewrite every registered layout from the current parameter values (one launch)."""
         if not self.entries:

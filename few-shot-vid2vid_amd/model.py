@@ -377,7 +377,11 @@ def loss_backward(opt, losses, optimizer, loss_id):
         scale_loss = getattr(optimizer, 'scale_loss', None)
         (scale_loss(loss) if scale_loss is not None else loss).backward()
         # two-piece backward (build_optimizers(split_backward=True)): the forward pass detached at the generator's stage boundary,
-        # run the second piece too - whichever optimiser is being stepped (finetune() builds its own)
+        # run the second piece too - whichever optimiser is being stepped (finetune() builds its own).  Between the pieces the
+        # decoder stage's gradients are final: on one GPU its Adam launch and layout refresh start now, on a side stream
+        cut = getattr(optimizer, 'bwd_cut', None)
+        if cut is not None and cut.has_grads() and hasattr(optimizer, 'step_stage2_early'):
+            optimizer.step_stage2_early()
         networks.BackwardCut.finish_all()
         optimizer.step()
     return losses

@@ -782,6 +782,10 @@ class BackwardCut:
             return type(obj)(self.split(o) for o in obj)
         return obj
 
+    def has_grads(self):
+        """the first piece of THIS cut's backward pass has run and the second is still due"""
+        return any(l.grad is not None for _, l in self.pairs)
+
     def backward_rest(self):
         """second piece: continue from the recorded originals with the gradients the leaves collected.  A cut whose leaves have
         no gradient yet stays registered: its own backward pass has not run (a G forward with grad followed by a D

@@ -67,6 +67,7 @@ lib.register_sigs({
     "fsv_softmax_rows_fwd": [c_p, c_p, c_ll, c_i, c_p],
     "fsv_softmax_rows_bwd": [c_p, c_p, c_p, c_ll, c_i, c_p],
     "fsv_adam_step": [c_p, c_p, c_p, c_p, c_p, c_ll, c_f, c_f, c_f, c_f, c_p],
+    "fsv_adam_step_range": [c_p, c_p, c_p, c_p, c_p, c_ll, c_f, c_f, c_f, c_f, c_i, c_p],
     "fsv_sn_power_iter": [c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_f, c_i, c_p],
     "fsv_sn_backward": [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_p],
     "fsv_sn_power_iter_batched": [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_ll, c_p, c_p, c_p, c_p, c_i, c_p, c_i, c_p, c_i, c_f, c_p],
@@ -1476,11 +1477,16 @@ def warp_blend(raw, image, flow, mask):
 
 
 # ------------------------------------------------------------------------------------------------ Adam
-def adam_step(param, grad, m, v, state, beta1, beta2, eps, gscale=1.0):
-    """Fused Adam on flat buffers; state = [t, 1-b1^t, 1-b2^t, lr] (device, fp32)."""
+def adam_step(param, grad, m, v, state, beta1, beta2, eps, gscale=1.0, tick=None):
+    """Fused Adam on flat buffers; state = [t, 1-b1^t, 1-b2^t, lr] (device, fp32).  tick (True / False): one piece of a step
+    issued range by range - exactly one piece advances the step count, the others are ordered behind it (FlatAdam)."""
     lib.check_device(param, grad, m, v, state)
-    lib.call("fsv_adam_step", lib.ptr(param), lib.ptr(grad), lib.ptr(m), lib.ptr(v), lib.ptr(state), param.numel(),
-             float(beta1), float(beta2), float(eps), float(gscale), lib.stream_ptr())
+    if tick is None:
+        lib.call("fsv_adam_step", lib.ptr(param), lib.ptr(grad), lib.ptr(m), lib.ptr(v), lib.ptr(state), param.numel(),
+                 float(beta1), float(beta2), float(eps), float(gscale), lib.stream_ptr())
+    else:
+        lib.call("fsv_adam_step_range", lib.ptr(param), lib.ptr(grad), lib.ptr(m), lib.ptr(v), lib.ptr(state), param.numel(),
+                 float(beta1), float(beta2), float(eps), float(gscale), 1 if tick else 0, lib.stream_ptr())
 
 
 lib.register_sigs({

@@ -458,6 +458,10 @@ int fsv_softmax_rows_bwd(const float* dy, const float* y, float* dx, long long r
 /* state = {t, 1-beta1^t, 1-beta2^t, lr} on the device; gscale pre-multiplies the gradient (1/world_size) */
 int fsv_adam_step(float* param, const float* grad, float* m, float* v, float* state, long long n, float beta1,
                   float beta2, float eps, float gscale, fsv_stream_t stream);
+/* the same step issued in pieces (ranges of the flat buffers): tick != 0 advances the step count / bias corrections in `state`
+ * (exactly one piece of a step), the other pieces - ordered behind it by the caller - only read them */
+int fsv_adam_step_range(float* param, const float* grad, float* m, float* v, float* state, long long n, float beta1,
+                        float beta2, float eps, float gscale, int tick, fsv_stream_t stream);
 
 /* ---- losses, D-input packing, mask pooling (csrc/losses.hip) - models/networks/loss.py:69-83,130-138;
  * models/loss_collector.py:47-58,105-110,180; models/input_process.py:59 -------------------------------------------- */

@@ -21,3 +21,10 @@ def test_capture_failure_falls_back_to_the_eager_step(emu_lib):
 
 def test_discriminator_step_next_to_the_generator_pass_changes_no_result(emu_lib):
     gc.check_early_generator(DEV)
+
+
+def test_decoder_stage_step_between_the_backward_pieces_changes_no_weight(emu_lib, monkeypatch):
+    """FSV_EARLY_ADAM=1: Adam + layout refresh of flat_g[:split_at] on a side stream between the two pieces of a split backward
+    (FlatAdam.step_stage2_early) - weights equal to the unsplit loop bit for bit, eager and graphed driver"""
+    monkeypatch.setenv('FSV_EARLY_ADAM', '1')
+    gc.check_split_backward_single_rank(DEV, iters=2)
