@@ -847,7 +847,7 @@ class Vid2VidModel(nn.Module):
         branch = streams.Branch(tgt_label) if early is not None else None
         if branch is not None:
             branch.uses([fake, raw, fg, ref_fg, ref_label, ref_image, tgt_label])
-        with (branch.on() if branch is not None else contextlib.nullcontext()):
+        with (branch.guarded() if branch is not None else contextlib.nullcontext()):
             fg_union = union_fg(fg, ref_fg, self.has_fg)
             real = tgt_image[:, 0]
             losses = self.lossCollector.gan_losses(self.netD, tgt_label, [real, real * fg_union], [fake, raw], ref_label,
@@ -858,8 +858,12 @@ class Vid2VidModel(nn.Module):
                 losses = list(losses) + self.lossCollector.temporal_losses(self.netDT, real_all, fake_all, True)
             losses = LossCollector.outward(losses)
         if branch is not None:
-            with torch.enable_grad():
-                gen = self.generate_images(tgt_label, tgt_image, ref_labels, ref_images, prevs)
+            try:
+                with torch.enable_grad():
+                    gen = self.generate_images(tgt_label, tgt_image, ref_labels, ref_images, prevs)
+            except BaseException:
+                branch.finish()              # (never leave the side stream reserved behind an exception)
+                raise
             self._pre_g = (early, branch, gen)
             # loss_backward continues the discriminator step on the branch's stream: the tag rides on the losses AND on the
             # optimiser that will step them (a caller may hand loss_backward clones of the losses)

@@ -102,6 +102,20 @@ class Branch:
         import contextlib
         return torch.cuda.stream(self.stream) if self.stream is not None else contextlib.nullcontext()
 
+    def guarded(self):
+        """`on()` that gives the stream back (finish) if the block raises"""
+        import contextlib
+
+        @contextlib.contextmanager
+        def ctx():
+            try:
+                with self.on():
+                    yield self
+            except BaseException:
+                self.finish()
+                raise
+        return ctx()
+
     def uses(self, obj):
         """tensors made on the caller's stream that the branch reads: their memory must not be recycled under it"""
         if self.stream is not None:
