@@ -92,6 +92,16 @@ def test_c3_pose_512_b2_full_step_is_the_bench_workload(hip_lib):
     assert any(n == 4 for _, _, _, n in groups), groups[:8]
 
 
+def test_c3_pose_512_b2_in_the_schedule_bench_py_runs(hip_lib):
+    """The same step issued the way bench.py issues it on one GPU (round 4): the discriminator step on a side stream next to the
+    generator-mode forward pass, the G step's real-image pass behind it, the generator's backward in two pieces - against the
+    oracle at the same bars.  (The kernels are the ones of the test above - the fused bn_s -> conv_s kernel included, which both
+    run; what this adds is the schedule.)"""
+    opt = mc.make_opt(warp_ref=True, spade_combine=True, remove_face_labels=True, fineSize=512, loadSize=512, batchSize=2)
+    worst = mc.check_train_step(DEV, opt, b=2, tol=1e-3, grad_tol=1e-2, bench_schedule=True)
+    assert worst < 1e-2, worst
+
+
 def test_c4_pose_512_face_d_vgg(hip_lib):
     """BASELINE.json configs[3] per rank (scripts/pose/train_g8.sh:8-10: the C3 flags + --add_face_D, which brings the VGG19 loss
     with it - loss_collector.py:70-85): full width, 512x512, the per-GPU batch of 2, full D step (netD + netDf) + G step against

@@ -22,6 +22,10 @@ def test_generator_warp_combine_tiny(emu_lib):
 def test_train_step_pose_warp_combine_tiny(emu_lib):
     """D step + G step (losses, all gradients, flat Adam plumbing) of BASELINE configs[2] flags, tiny width."""
     mc.check_train_step(DEV, mc.tiny_opt(warp_ref=True, spade_combine=True, remove_face_labels=True), b=2)
+def test_train_step_in_the_schedule_bench_py_runs(emu_lib):
+    """the discriminator step "on a side stream" (issue order on the emulator), the early generator pass picked up by the
+    generator-mode call, the two-piece backward - against the oracle like the plain step"""
+    mc.check_train_step(DEV, mc.tiny_opt(warp_ref=True, spade_combine=True, remove_face_labels=True), b=2, bench_schedule=True)
 
 
 def test_train_step_face_tiny(emu_lib):
