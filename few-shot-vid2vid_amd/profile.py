@@ -30,11 +30,14 @@ TILE_NAMES = {0: '128x128', 1: '128x64', 2: '128x32', 4: '64x64', 9: '64x128', 1
               13: '64x128pf2af', 14: '128x128pf2af', 15: '128x64pf2af', 16: '128x128af', 17: '64x64af', 18: '128x32af', 20: '64x64pf2af', 21: '64x128lds', 22: '128x64lds', 27: '64x64lds'}
 
 
-def enable(detail=False, only=None):
+_events = True        # False: labels are produced (scopes are entered) but no HIP events are recorded - a stamped graph capture
+
+
+def enable(detail=False, only=None, events=True):
     """only: bracket the launches with this label alone (no replay closures kept) - with ~130 event pairs instead of ~450 in the
     pass the eager step idles less between launches and the brackets read closer to the kernel's time inside the replayed graph"""
-    global _enabled, _records, _detail, _only
-    _enabled, _records, _detail, _only = True, [], detail, only
+    global _enabled, _records, _detail, _only, _events
+    _enabled, _records, _detail, _only, _events = True, [], detail, only, events
 
 
 def disable():
@@ -50,13 +53,62 @@ def detail():
     return _detail
 
 
+# ---- brackets inside a captured graph: device-side time stamps (csrc/stamp.hip) -----------------------------------------------------
+# HIP events cannot be recorded into a replayable graph; a one-work-item kernel that writes the GPU's wall clock can.  stamp_begin(label,
+# slots) makes every scope of `label` launch such a kernel in front of and behind its launch (slot 2i, 2i + 1 of a device buffer), plus
+# `calibration` empty pairs per real pair (two stamps with nothing between them: the pair's own cost).  bench.py captures the step
+# once more that way, replays it and prices the dominant kernel on the in-graph durations.
+_stamp = None          # dict(label, buf, n, cal) while a stamped capture is being recorded
+
+lib.register_sigs({"fsv_stamp": [ctypes.c_void_p, ctypes.c_void_p], "fsv_stamp_rate_khz": []})
+
+
+def stamp_begin(label, max_launches, device):
+    global _stamp
+    buf = torch.zeros(4 * max_launches + 8, dtype=torch.int64, device=device)
+    _stamp = dict(label=label, buf=buf, n=0, cap=max_launches)
+    return buf
+
+
+def stamp_end():
+    global _stamp
+    st, _stamp = _stamp, None
+    return st
+
+
+def _stamp_slot(st, k):
+    return ctypes.c_void_p(st['buf'].data_ptr() + 8 * k)
+
+
+def stamp_result(st):
+    """(launches, average seconds per launch, average seconds of an empty pair) from the slots of the last replay"""
+    torch.cuda.synchronize()
+    n = st['n']
+    if n == 0:
+        return 0, 0.0, 0.0
+    khz = int(lib.get_lib().fsv_stamp_rate_khz())
+    if khz <= 0:
+        return 0, 0.0, 0.0
+    t = st['buf'][:4 * n].cpu().view(n, 4).double()
+    full = (t[:, 1] - t[:, 0]).mean().item() / (khz * 1e3)
+    empty = (t[:, 3] - t[:, 2]).mean().item() / (khz * 1e3)
+    return n, full, empty
+
+
 class scope:
     def __init__(self, label, flops, replay=None):
         """replay: callable that re-issues this launch (it must keep its operand tensors alive)"""
         self.label, self.flops, self.replay = label, flops, replay
 
     def __enter__(self):
-        self.on = _enabled and not lib.is_emu() and (_only is None or self.label == _only)
+        self.on = _enabled and _events and not lib.is_emu() and (_only is None or self.label == _only)
+        self.st = _stamp if (_stamp is not None and self.label == _stamp['label'] and _stamp['n'] < _stamp['cap']) else None
+        if self.st is not None:
+            k = 4 * self.st['n']
+            # an empty pair first (its second stamp also separates the launch from whatever ran before), then the real one
+            lib.call("fsv_stamp", _stamp_slot(self.st, k + 2), lib.stream_ptr())
+            lib.call("fsv_stamp", _stamp_slot(self.st, k + 3), lib.stream_ptr())
+            lib.call("fsv_stamp", _stamp_slot(self.st, k), lib.stream_ptr())
         if self.on:
             self.e0 = torch.cuda.Event(enable_timing=True)
             self.e1 = torch.cuda.Event(enable_timing=True)
@@ -67,6 +119,9 @@ class scope:
         if self.on:
             self.e1.record()
             _records.append((self.label, self.flops, self.e0, self.e1, None if _only is not None else self.replay))
+        if self.st is not None:
+            lib.call("fsv_stamp", _stamp_slot(self.st, 4 * self.st['n'] + 1), lib.stream_ptr())
+            self.st['n'] += 1
         return False
 
 

@@ -320,6 +320,11 @@ int fsv_spade_bwd_elem(const float* x, const float* mean, const float* rstd, con
                        int nmaps, const float* const* gb, float* const* dgb, float* dxhat,
                        int N, int HW, int C, long long stat_bstride, int act, int W, int up, fsv_stream_t stream);
 
+/* ---- measurement only (csrc/stamp.hip): device-side time stamps, graph-capturable brackets for bench.py's roofline object ----
+ * fsv_stamp: *slot = the GPU's constant-rate wall clock when the stream reaches this point; fsv_stamp_rate_khz: its rate. */
+int fsv_stamp(unsigned long long* slot, fsv_stream_t stream);
+int fsv_stamp_rate_khz(void);
+
 /* ---- normalisation (csrc/norm.hip) - BatchNorm (apex SyncBatchNorm) normalization.py:33,80; InstanceNorm :35,82 ----
  * tensors are [G][P][C]: BatchNorm G=1, P=N*H*W; InstanceNorm G=N, P=H*W.  workspace: fsv_norm_workspace_doubles(). */
 int fsv_norm_workspace_doubles(int G, int P, int C);
