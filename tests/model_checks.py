@@ -412,7 +412,7 @@ class verify_half_launches:
         self.count[kind] += 1
 
 
-def check_amp_train_step(device, opt, b=1, tol=1e-3, grad_tol=1e-2, seed=21, loss_scale=1024.0):
+def check_amp_train_step(device, opt, b=1, tol=1e-3, grad_tol=1e-2, seed=21, loss_scale=1024.0, bench_schedule=False):
     """Full D step + G step of the product under `--amp O1` (the half-precision kernels, csrc/conv_h.hip) against a WHOLE-ITERATION run
     of the oracle in the same arithmetic: oracle/fsv_oracle.py with oracle/np_oracle.amp_conv2d installed at every convolution
     the product runs in half (operands rounded to IEEE half, exact products; W rounded before 1 / sigma; the gradient of a
@@ -435,7 +435,9 @@ def check_amp_train_step(device, opt, b=1, tol=1e-3, grad_tol=1e-2, seed=21, los
         model = M.create_model(opt)
         sdG0, sdD0 = fill_state(model.netG), fill_state(model.netD)
         model = model.to(device).train()
-        opt_G, opt_D = model.build_optimizers()
+        # bench_schedule: as in check_train_step - the iteration the way bench.py issues it on one GPU
+        opt_G, opt_D = model.build_optimizers(split_backward=bool(bench_schedule))
+        model.early_generator = bool(bench_schedule)
         assert conv.h_kernels(), "the half-precision kernels are switched off"
         opt_G.set_lr(0.0); opt_D.set_lr(0.0)
         for o in (opt_G, opt_D):
@@ -454,6 +456,10 @@ def check_amp_train_step(device, opt, b=1, tol=1e-3, grad_tol=1e-2, seed=21, los
         verifier = verify_half_launches()
         verifier.__enter__()
         d_losses = M.loss_backward(opt, model(data_list, mode='discriminator'), opt_D, 1)
+        early_g = None
+        if bench_schedule:          # the discriminator step lives on the side stream until the generator-mode call joins it
+            assert model._pre_g is not None, "the early generator pass was not issued"
+            early_g = model(data_list, save_images=True, mode='generator')
         assert float(opt_D.scaler[0]) == loss_scale and float(opt_D.scaler[2]) == 0.0, opt_D.scaler      # no overflow at this scale
         for i, name in enumerate(('D_real', 'D_fake')):
             _close_vs64(name, d_losses[i].view(1), r32[0][i].view(1), r64[0][i].view(1), tol)
@@ -461,7 +467,7 @@ def check_amp_train_step(device, opt, b=1, tol=1e-3, grad_tol=1e-2, seed=21, los
             if p.grad is not None:
                 p.grad.div_(loss_scale)           # lr = 0: the step has run, the flat gradient buffer is only read below
         worst_d = compare_grads_l2(model.netD, {k: _G(v) for k, v in r32[1].items()}, {k: _G(v) for k, v in r64[1].items()}, grad_tol)
-        g_losses, generated, _ = model(data_list, save_images=True, mode='generator')
+        g_losses, generated, _ = early_g if early_g is not None else model(data_list, save_images=True, mode='generator')
         g_losses = M.loss_backward(opt, g_losses, opt_G, 0)
         verifier.__exit__(None, None, None)
         assert verifier.count['conv'] >= 40 and verifier.count['wgrad'] >= 15, verifier.count       # the half kernels did run

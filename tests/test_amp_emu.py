@@ -38,3 +38,11 @@ def test_amp_step_is_the_stated_definition_small(emu_lib):
     opt = mc.tiny_opt(dataset_mode='fewshot_street', label_nc=35, input_nc=3, aspect_ratio=2.0, fineSize=64, loadSize=64, batchSize=1,
                       amp='O1', ngf=16, ndf=16, nff=16, n_downsample_G=3, n_adaptive_layers=2)
     mc.check_amp_train_step(DEV, opt, b=1, tol=1e-3, grad_tol=2e-2)
+
+
+def test_amp_step_is_the_stated_definition_small_in_the_schedule_bench_py_runs(emu_lib):
+    """the whole --amp O1 iteration of the product against the whole-iteration oracle in the same arithmetic (model_checks.
+    check_amp_train_step) at a width where every layer class takes the half-precision kernels (channels multiples of 8)"""
+    opt = mc.tiny_opt(dataset_mode='fewshot_street', label_nc=35, input_nc=3, aspect_ratio=2.0, fineSize=64, loadSize=64, batchSize=1,
+                      amp='O1', ngf=16, ndf=16, nff=16, n_downsample_G=3, n_adaptive_layers=2)
+    mc.check_amp_train_step(DEV, opt, b=1, tol=1e-3, grad_tol=2e-2, bench_schedule=True)

@@ -138,3 +138,14 @@ def test_c5_street_1024x512_nc35_amp(hip_lib):
                       batchSize=1, amp='O1')
     worst = mc.check_amp_train_step(DEV, opt, b=1, tol=1e-3, grad_tol=1e-2)
     assert worst < 0.5, worst
+
+
+def test_c5_street_1024x512_nc35_amp_in_the_schedule_bench_py_runs(hip_lib):
+    """configs[4] per rank in its stated arithmetic, issued the way `bench.py --workload street --amp O1` issues it on one GPU
+    (discriminator step on a side stream next to the generator-mode forward pass, real-image pass behind it, two-piece backward):
+    the same whole-iteration oracle run, the same bars.  *Parity unpinned against apex* (see the test above)."""
+    opt = mc.make_opt(dataset_mode='fewshot_street', label_nc=35, input_nc=3, aspect_ratio=2.0, fineSize=1024, loadSize=1024,
+                      batchSize=1, amp='O1')
+    worst = mc.check_amp_train_step(DEV, opt, b=1, tol=1e-3, grad_tol=1e-2, bench_schedule=True)
+    assert worst < 0.5, worst
+
