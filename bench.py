@@ -365,9 +365,13 @@ def main():
     if g_only and distributed:
         raise SystemExit("--workload %s is a single-GPU generator-only measurement" % WORKLOAD)
 
+    # pieces of the generator's backward pass: 2 (the stage boundary in front of the decoder) or, FSV_BENCH_PIECES=3, a second
+    # boundary behind the reference encoders (the middle range of the gradient exchange then overlaps the third piece too)
+    _PIECES = 3 if os.environ.get('FSV_BENCH_PIECES', '2') == '3' else True
+
     def build_optimizers(seg):
         return model.build_optimizers(world_size=world, process_group=group, force_exchange=force_dist,
-                                      overlap=not seg, split_backward=seg or (not g_only and os.environ.get('FSV_BENCH_SPLIT', '1') == '1'))
+                                      overlap=not seg, split_backward=(_PIECES if (seg or (not g_only and os.environ.get('FSV_BENCH_SPLIT', '1') == '1')) else False))
     opt_G, opt_D = build_optimizers(segmented)
     data = make_data(args.batch, args.size, 1234 + rank, device, opt)
 

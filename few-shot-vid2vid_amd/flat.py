@@ -43,6 +43,7 @@ class FlatAdam:
         # split_at: element offset in the flat buffers below which the gradients are complete after the FIRST piece of a
         # two-piece backward (set by Vid2VidModel.build_optimizers(split_backward=True): stage-2 parameters are laid out first)
         self.split_at = 0
+        self.split_at2 = 0           # three-piece backward: flat_g[split_at:split_at2] is complete after the second piece
         self._lay_out(params, lr, loss_scale)
 
     def rebuild(self, params, lr=None, loss_scale='keep'):

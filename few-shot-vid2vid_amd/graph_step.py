@@ -94,6 +94,10 @@ class GraphedIteration:
         # two-piece generator backward (model.build_optimizers(split_backward=True)): the generator's forward pass detaches at
         # its stage boundary whether or not there is an exchange to overlap, so the second piece always has to run
         self.split = bool(getattr(self.model, 'split_backward', False))
+        # three pieces (build_optimizers(split_backward=3)): a second boundary behind the reference encoders - the exchange of the
+        # middle range (weight generators, embeddings, flow network) runs next to the encoders' backward as well
+        self.pieces = 3 if getattr(self.model, 'split_backward', False) is not True and getattr(self.model, 'split_backward', 0) == 3 \
+            else (2 if self.split else 1)
         if self.segmented and self.opt_G.overlap:
             raise RuntimeError("with a process group build the optimisers with overlap=False: bucket hooks issue collectives "
                                "inside backward, which cannot be captured")
@@ -149,6 +153,10 @@ class GraphedIteration:
 
     def _seg_g2(self):
         self.model.netG.bwd_cut.backward_rest()
+        self.opt_G.finalize_grads(partial=self.pieces == 3)
+
+    def _seg_g3(self):
+        self.model.netG.bwd_cut2.backward_rest()
         self.opt_G.finalize_grads()
 
     def _seg_a(self):
@@ -157,8 +165,12 @@ class GraphedIteration:
     def _exchange_g_first(self):
         self.opt_G.exchange_range(0, self.opt_G.split_at, side=True)
 
+    def _exchange_g_middle(self):
+        # (the side stream runs its collectives in order: this one queues behind the first range)
+        self.opt_G.exchange_range(self.opt_G.split_at, self.opt_G.split_at2, side=True)
+
     def _exchange_g_rest(self):
-        self.opt_G.exchange_range(self.opt_G.split_at, self.opt_G.total)
+        self.opt_G.exchange_range(self.opt_G.split_at2 if self.pieces == 3 else self.opt_G.split_at, self.opt_G.total)
         self.opt_G.wait_exchange()
 
     def _eager(self, e, save_images):
@@ -169,6 +181,9 @@ class GraphedIteration:
         if self.split:
             self._exchange_g_first()
             self._seg_g2()
+            if self.pieces == 3:
+                self._exchange_g_middle()
+                self._seg_g3()
             self._exchange_g_rest()
         elif self.segmented:
             self.opt_G.exchange_all()
@@ -205,7 +220,7 @@ class GraphedIteration:
             return
         # the captures only police their own thread (the RCCL watchdog polls its events from another one); the caller replays
         # the whole sequence - with the all-reduces between the graphs - once all of them exist
-        gs = [torch.cuda.CUDAGraph() for _ in range(4 if self.split else 3)]
+        gs = [torch.cuda.CUDAGraph() for _ in range(2 + self.pieces if self.split else 3)]
         with torch.cuda.graph(gs[0], capture_error_mode='thread_local'):
             self._seg_d(e)
         with torch.cuda.graph(gs[1], pool=gs[0].pool(), capture_error_mode='thread_local'):
@@ -213,6 +228,9 @@ class GraphedIteration:
         if self.split:
             with torch.cuda.graph(gs[2], pool=gs[0].pool(), capture_error_mode='thread_local'):
                 self._seg_g2()
+            if self.pieces == 3:
+                with torch.cuda.graph(gs[3], pool=gs[0].pool(), capture_error_mode='thread_local'):
+                    self._seg_g3()
         with torch.cuda.graph(gs[-1], pool=gs[0].pool(), capture_error_mode='thread_local'):
             self._seg_a()
         e.graphs = gs
@@ -225,11 +243,17 @@ class GraphedIteration:
             e.graphs[0].replay(); self.opt_D.exchange_all()
             e.graphs[1].replay(); self.opt_G.exchange_all()
             e.graphs[2].replay()
-        else:
+        elif len(e.graphs) == 4:
             e.graphs[0].replay(); self.opt_D.exchange_all()
             e.graphs[1].replay(); self._exchange_g_first()          # side stream: overlaps the next graph
             e.graphs[2].replay(); self._exchange_g_rest()
             e.graphs[3].replay()
+        else:
+            e.graphs[0].replay(); self.opt_D.exchange_all()
+            e.graphs[1].replay(); self._exchange_g_first()          # side stream: overlaps the second piece
+            e.graphs[2].replay(); self._exchange_g_middle()         # side stream, behind the first range: overlaps the third piece
+            e.graphs[3].replay(); self._exchange_g_rest()
+            e.graphs[4].replay()
 
     def _capture_failed(self, e, key, ex):
         """a capture raised (e.g. hipErrorCapturedEvent from a foreign event query, an allocation the capture could not make):
@@ -255,7 +279,7 @@ class GraphedIteration:
 
     def launch_mode(self):
         """how the iterations of this object reach the device - for bench.py's `config.launch`"""
-        n = 4 if self.split else 3
+        n = 2 + self.pieces if self.split else 3
         if self.capture_failures:
             return ('eager fallback (hipGraph capture failed: %s)%s' % (self.capture_failures[-1][1],
                     ', all-reduce between %d eager segments' % n if self.segmented else ''))

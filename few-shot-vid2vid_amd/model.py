@@ -515,17 +515,28 @@ class Vid2VidModel(nn.Module):
         g_params = list(self.netG.parameters())
         if split_backward:
             late = set(id(p) for p in self.netG.stage2_parameters())
-            g_params = [p for p in g_params if id(p) not in late] + [p for p in g_params if id(p) in late]
+            # three pieces (split_backward=3): the reference / attention encoders - reached last by the backward pass - first in
+            # the list, i.e. LAST in the flat buffers: flat_g = [decoder stage | weight generators, embeddings, flow | encoders]
+            last = set(id(p) for p in self.netG.stage3_parameters()) if int(split_backward) >= 3 else set()
+            g_params = ([p for p in g_params if id(p) in last] + [p for p in g_params if id(p) not in late and id(p) not in last] +
+                        [p for p in g_params if id(p) in late])
         if self.netGf is not None:         # base_model.py:204-205
             g_params = list(self.netGf.parameters()) + g_params if split_backward else g_params + list(self.netGf.parameters())
         return g_params
 
     def _set_split(self, split_backward):
-        self.split_backward = bool(split_backward)
-        self.netG.bwd_cut = networks.BackwardCut() if split_backward else None
+        """split_backward: False / True (= 2) / 3 - the number of pieces of the generator's backward pass"""
+        pieces = 0 if not split_backward else max(2, int(split_backward))
+        self.split_backward = pieces if pieces >= 3 else bool(pieces)
+        self.netG.bwd_cut = networks.BackwardCut() if pieces else None
+        self.netG.bwd_cut2 = networks.BackwardCut() if pieces >= 3 else None
         self.optimizer_G.bwd_cut = self.netG.bwd_cut
         self.optimizer_G.split_at = (sum(p.numel() for p in self.netG.stage2_parameters() if p.requires_grad)
-                                     if split_backward else 0)
+                                     if pieces else 0)
+        # gradients of flat_g[:split_at2] are complete after the SECOND piece (three pieces only; else = split_at)
+        self.optimizer_G.split_at2 = (self.optimizer_G.total - sum(p.numel() for p in self.netG.stage3_parameters() if p.requires_grad)
+                                      - (sum(p.numel() for p in self.netGf.parameters() if p.requires_grad) if self.netGf is not None else 0)
+                                      if pieces >= 3 else self.optimizer_G.split_at)
 
     def init_temporal_model(self):
         """models/base_model.py:259-279: the generator grows its previous-frame flow / embedding branches, the temporal

@@ -613,6 +613,12 @@ class FewShotGenerator(nn.Module):
         # and every later frame only runs the down path of the reference encoder
         fresh = bool(self.opt.isTrain) or n > 1 or t == 0
         x, enc = self.reference_encoding(img_ref, label_ref, encode=fresh, label=label)
+        cut2 = getattr(self, 'bwd_cut2', None)
+        if cut2 is not None and fresh and torch.is_grad_enabled():
+            # second stage boundary (three-piece backward): what the reference encoders hand on - the deepest feature map and
+            # the pooled products the weight generators read - becomes detached leaves; the encoders' backward is the third piece
+            cut2.begin_forward()
+            x, enc = cut2.split((x, enc))
         if fresh:
             embed_w, norm_w = [], []
             if self.adap_spade:
@@ -680,6 +686,12 @@ class FewShotGenerator(nn.Module):
     def stage2_parameters(self):
         """parameters below the BackwardCut boundary of forward(): decoder blocks, output conv"""
         names = ('up_', 'conv_img')
+        return [p for n, p in self.named_parameters() if n.startswith(names)]
+
+    def stage3_parameters(self):
+        """parameters above the SECOND boundary (three-piece backward, `bwd_cut2` on the outputs of reference_encoding): the
+        reference encoders and the attention encoders - the last part of the network the backward pass reaches"""
+        names = ('ref_img_', 'ref_label_', 'atn_')
         return [p for n, p in self.named_parameters() if n.startswith(names)]
 
     def forward(self, label, label_refs, img_refs, prev=(None, None), t=0, img_coarse=None):
@@ -805,9 +817,15 @@ class BackwardCut:
 
     @classmethod
     def finish_all(cls):
-        """run the second piece of every forward pass that detached at a stage boundary and whose first piece has run"""
-        for cut in list(cls._live):
-            cut.backward_rest()
+        """run the remaining pieces of every forward pass that detached at a stage boundary and whose first piece has run (a cut
+        inside the region behind another cut gets its gradients from that one's piece: repeat until nothing moves)"""
+        moved = True
+        while moved:
+            moved = False
+            for cut in list(cls._live):
+                if cut.has_grads():
+                    cut.backward_rest()
+                    moved = True
 
     @classmethod
     def abandon_all(cls):

@@ -108,14 +108,14 @@ def _split_worker(rank, world, port, out_dir, split):
     model.train()
     opt_G, opt_D = model.build_optimizers(world_size=world, overlap=False, split_backward=split)
     gi = gs.GraphedIteration(model, opt, warmup=1)
-    assert gi.segmented and gi.split == split
+    assert gi.segmented and gi.split == bool(split) and gi.pieces == (3 if split == 3 else (2 if split else 1))
     tl, ti, rl, ri = mc.synth_pose_inputs(1, 32, 32, 200 + rank, 6)
     data = [tl, ti, [None, None], [None, None], rl, ri, None, None, None]
     for it in range(2):
         gi(data)
     torch.save(dict(g={n: p.grad.clone() for n, p in model.netG.named_parameters()},
                     p={n: p.detach().clone() for n, p in model.netG.named_parameters()}, split_at=opt_G.split_at,
-                    total=opt_G.total), os.path.join(out_dir, 'split%d_rank%d.pt' % (int(split), rank)))
+                    total=opt_G.total, split_at2=opt_G.split_at2), os.path.join(out_dir, 'split%d_rank%d.pt' % (int(split), rank)))
     dist.destroy_process_group()
 
 
@@ -130,6 +130,23 @@ def test_two_rank_two_piece_backward_equals_whole_backward(emu_lib, tmp_path):
     for n in s0['g']:
         assert torch.equal(s0['g'][n], s1['g'][n]) and torch.equal(s0['p'][n], s1['p'][n]), n      # replicas in lock-step
         # same exchanged gradients and same weights after two iterations as with one whole-buffer all-reduce
+        scale = max(float(w0['g'][n].abs().max()), 1e-12)
+        assert float((s0['g'][n] - w0['g'][n]).abs().max()) <= 1e-6 * scale, n
+        assert torch.equal(s0['p'][n], w0['p'][n]), n
+
+
+def test_two_rank_three_piece_backward_equals_whole_backward(emu_lib, tmp_path):
+    """split_backward=3: decoder range | middle range | encoder range exchanged one after the other (on a GPU the first two on a
+    side stream next to the following piece) - same exchanged gradients and weights as one whole-buffer all-reduce"""
+    world = 2
+    mp.spawn(_split_worker, args=(world, 29631, str(tmp_path), False), nprocs=world, join=True)
+    mp.spawn(_split_worker, args=(world, 29633, str(tmp_path), 3), nprocs=world, join=True)
+    w0 = torch.load(os.path.join(tmp_path, 'split0_rank0.pt'))
+    s0 = torch.load(os.path.join(tmp_path, 'split3_rank0.pt'))
+    s1 = torch.load(os.path.join(tmp_path, 'split3_rank1.pt'))
+    assert 0 < s0['split_at'] < s0['split_at2'] < s0['total'], (s0['split_at'], s0['split_at2'], s0['total'])
+    for n in s0['g']:
+        assert torch.equal(s0['g'][n], s1['g'][n]) and torch.equal(s0['p'][n], s1['p'][n]), n
         scale = max(float(w0['g'][n].abs().max()), 1e-12)
         assert float((s0['g'][n] - w0['g'][n]).abs().max()) <= 1e-6 * scale, n
         assert torch.equal(s0['p'][n], w0['p'][n]), n

@@ -28,3 +28,9 @@ def test_decoder_stage_step_between_the_backward_pieces_changes_no_weight(emu_li
     (FlatAdam.step_stage2_early) - weights equal to the unsplit loop bit for bit, eager and graphed driver"""
     monkeypatch.setenv('FSV_EARLY_ADAM', '1')
     gc.check_split_backward_single_rank(DEV, iters=2)
+
+
+def test_three_piece_backward_keeps_every_gradient(emu_lib):
+    """build_optimizers(split_backward=3): a second stage boundary behind the reference encoders - weights equal to the one-piece
+    loop bit for bit, eager and graphed driver"""
+    gc.check_split_backward_single_rank(DEV, iters=2, pieces=3)
