@@ -25,6 +25,9 @@ def main():
     ap.add_argument('--batch', type=int, default=None)
     ap.add_argument('--top', type=int, default=60)
     ap.add_argument('--out', default='')
+    ap.add_argument('--streams', type=int, default=0,
+                    help='1: keep the branch streams on - a launch that shares the chip with another stream then reads long (the '
+                         'K64 / K96 rows of round 3); default 0: one stream, every launch timed alone')
     args = ap.parse_args()
     bench.WORKLOAD, bench.AMP = args.workload, args.amp
     wl = bench.WORKLOADS[args.workload]
@@ -34,6 +37,7 @@ def main():
     import fsv2v_amd  # noqa: F401
     M = import_module('few-shot-vid2vid_amd.model')
     prof = import_module('few-shot-vid2vid_amd.profile')
+    import_module('few-shot-vid2vid_amd.streams').ENABLED = bool(args.streams)
     dev = torch.device('cuda:0')
     opt = bench.build_opt(args.size, args.batch)
     model = M.create_model(opt).to(dev).train()
