@@ -217,7 +217,8 @@ lib.register_sigs({
     "fsv_conv_group_plan": [ctypes.POINTER(ctypes.c_int)] * 4 + [ctypes.c_int, ctypes.POINTER(ctypes.c_int)],
     "fsv_conv_gather_fwd_stats": [ctypes.c_void_p] * 5 + [ctypes.c_int] * 8 + [ctypes.POINTER(ctypes.c_int)] * 2 +
                                  [ctypes.c_int] * 4 + [ctypes.c_float, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int,
-                                                       ctypes.c_int, ctypes.POINTER(ctypes.c_int), ctypes.c_void_p],
+                                                       ctypes.c_int, ctypes.POINTER(ctypes.c_int), ctypes.c_void_p,
+                                                       ctypes.c_longlong, ctypes.c_void_p],
 })
 
 GROUP_LIMIT = 64          # FSV_GROUP_LIMIT (csrc/conv_igemm.hip)
@@ -446,17 +447,16 @@ def gather_gemm(x, wt, ldw, cout, oh, ow, ty, tx, sy, sx, bias=None, res=None, a
         else:
             bias = bias.contiguous()
             b_bs = cout
-    args = (lib.ptr(x), lib.ptr(wt), lib.ptr(bias), lib.ptr(res), lib.ptr(out),
+    head = (lib.ptr(x), lib.ptr(wt), lib.ptr(bias), lib.ptr(res), lib.ptr(out),
             n, h, w, cin, oh, ow, cout, len(ty), lib.int_array(ty), lib.int_array(tx), sy, sx,
             out_h, out_w, osy, osx, ooy, oox, ldw, w_bs, b_bs, 1 if per_sample else 0,
-            act, float(scale), force_tile, force_split, 1 if accumulate else 0, lib.ptr(wscale), lib.stream_ptr())
+            act, float(scale), force_tile, force_split, 1 if accumulate else 0, lib.ptr(wscale))
     if _plan_log is not None:
         _plan_log.append(planned(oh * ow if per_sample else n * oh * ow, cout, (len(ty) * cin + 31) // 32, n if per_sample else 1,
                                  force_tile, force_split) + (cin % 4 == 0,))
     entry = "fsv_conv_gather_fwd"
     if _np_mode and cin % 4 == 0:                 # scalar-gather layers (3-channel images, labels) stay on the fp32 kernel
         entry = "fsv_conv_gather_fwd_np"
-        args = args[:-1] + (_np_mode, args[-1])
     grp = _active_group()
     split_ws = None
     if entry == "fsv_conv_gather_fwd" and grp is None and place is None and not accumulate and ordered_split():
@@ -465,6 +465,12 @@ def gather_gemm(x, wt, ldw, cout, oh, ow, ty, tx, sy, sx, bias=None, res=None, a
                      force_split)[1]
         if ns > 1 and act != ACT_DLRELU:
             split_ws = torch.empty(ns * out.numel(), dtype=torch.float32, device=x.device)
+    # the ordered-split workspace is an explicit (nullable) argument of the call that may use it (include/fsv2v.h)
+    ws_args = (lib.ptr(split_ws), split_ws.numel() if split_ws is not None else 0)
+    if entry == "fsv_conv_gather_fwd_np":
+        args = head + (_np_mode, lib.stream_ptr())
+    else:
+        args = head + ws_args + (lib.stream_ptr(),)
     if (stats is not None and grp is None and entry == "fsv_conv_gather_fwd" and place is None and not per_sample
             and not accumulate and force_tile < 0 and force_split == 0 and cin % 4 == 0 and stats_enabled()):
         groups = int(stats['groups'])
@@ -475,14 +481,13 @@ def gather_gemm(x, wt, ldw, cout, oh, ow, ty, tx, sy, sx, bias=None, res=None, a
         produced = ctypes.c_int(0)
         sargs = (lib.ptr(x), lib.ptr(wt), lib.ptr(bias), lib.ptr(res), lib.ptr(out), n, h, w, cin, oh, ow, cout, len(ty),
                  lib.int_array(ty), lib.int_array(tx), sy, sx, ldw, act, float(scale), lib.ptr(wscale), lib.ptr(part), groups,
-                 STATS_SLOTS, 1 if prezeroed else 0, ctypes.byref(produced), lib.stream_ptr())
+                 STATS_SLOTS, 1 if prezeroed else 0, ctypes.byref(produced)) + ws_args + (lib.stream_ptr(),)
         label = 'fsv_conv_igemm_kernel'
         if profile.enabled():
             label = profile.conv_label(n * oh * ow, cout, (len(ty) * cin + 31) // 32, 1, True, force_tile, force_split)
         keep = (x, wt, bias, res, out, wscale, part, split_ws)
 
         def go_stats(sargs=sargs, keep=keep):
-            _arm_split(split_ws)
             lib.call("fsv_conv_gather_fwd_stats", *sargs)
         with profile.scope(label, 2.0 * n * oh * ow * cout * cin * len(ty), replay=go_stats):
             go_stats()
@@ -516,19 +521,12 @@ def gather_gemm(x, wt, ldw, cout, oh, ow, ty, tx, sy, sx, bias=None, res=None, a
         keep = (x, wt, bias, res, out, wscale, split_ws)          # the replay re-issues the launch on the same buffers
 
         def go(entry=entry, args=args, keep=keep):
-            _arm_split(split_ws)
             lib.call(entry, *args)
         with profile.scope(label, 2.0 * n * oh * ow * cout * cin * len(ty), replay=go):
             go()
     else:
-        _arm_split(split_ws)
         lib.call(entry, *args)
     return out
-
-
-def _arm_split(ws):
-    if ws is not None:
-        getattr(lib.get_lib(), "fsv_conv_split_workspace_set")(ctypes.c_void_p(ws.data_ptr()), ctypes.c_longlong(ws.numel()))
 
 
 def ordered_split():

@@ -1786,10 +1786,7 @@ static int fsv_conv_gather_impl(const float* in, const float* wt, const float* b
                         int ldw, long long w_bstride, long long b_bstride, int per_sample,
                         int act, float scale, int force_tile, int force_split, int accumulate, const float* wscale,
                         double* stats, int stats_groups, int stats_slots, int stats_prezeroed, int* produced,
-                        hipStream_t stream) {
-  float* const split_ws = fsv_splitws_ptr();            // (the arming is consumed whatever this call does with it)
-  const long long split_cap = fsv_splitws_cap();
-  fsv_splitws_ptr() = nullptr; fsv_splitws_cap() = 0;
+                        float* split_ws, long long split_cap, hipStream_t stream) {
   if (!in || !wt || !out || ntaps < 1 || ntaps > 16 || N < 1 || Cin < 1 || Cout < 1) return FSV_ERR_BAD_ARG;
   for (int t = 0; t < ntaps; ++t)
     if (ty[t] < -8 || ty[t] > 7 || tx[t] < -8 || tx[t] > 7) return FSV_ERR_UNSUPPORTED;
@@ -1870,18 +1867,19 @@ static int fsv_conv_gather_impl(const float* in, const float* wt, const float* b
 
 extern "C" {
 
-void fsv_conv_split_workspace_set(float* ws, long long floats) { fsv_splitws_ptr() = ws; fsv_splitws_cap() = ws ? floats : 0; }
-
+// split_ws / split_ws_floats (nullable): ordered split-K - when the plan splits K, split k stores its partial output into the k-th
+// copy inside split_ws (nsplit x N*outH*outW*Cout floats) and a finishing pass sums the copies in ascending order (the same bits on
+// every run, no zero fill, no atomics); a call that does not split, or whose copies do not fit, ignores the workspace.
 int fsv_conv_gather_fwd(const float* in, const float* wt, const float* bias, const float* res, float* out,
                         int N, int H, int W, int Cin, int OH, int OW, int Cout,
                         int ntaps, const int* ty, const int* tx, int sy, int sx,
                         int outH, int outW, int osy, int osx, int ooy, int oox,
                         int ldw, long long w_bstride, long long b_bstride, int per_sample,
                         int act, float scale, int force_tile, int force_split, int accumulate, const float* wscale,
-                        hipStream_t stream) {
+                        float* split_ws, long long split_ws_floats, hipStream_t stream) {
   return fsv_conv_gather_impl(in, wt, bias, res, out, N, H, W, Cin, OH, OW, Cout, ntaps, ty, tx, sy, sx, outH, outW, osy, osx,
                               ooy, oox, ldw, w_bstride, b_bstride, per_sample, act, scale, force_tile, force_split, accumulate,
-                              wscale, nullptr, 0, 0, 0, nullptr, stream);
+                              wscale, nullptr, 0, 0, 0, nullptr, split_ws, split_ws ? split_ws_floats : 0, stream);
 }
 
 int fsv_conv_gather_fwd_stats(const float* in, const float* wt, const float* bias, const float* res, float* out,
@@ -1889,10 +1887,11 @@ int fsv_conv_gather_fwd_stats(const float* in, const float* wt, const float* bia
                               int ntaps, const int* ty, const int* tx, int sy, int sx,
                               int ldw, int act, float scale, const float* wscale,
                               double* stats, int stats_groups, int stats_slots, int stats_prezeroed, int* produced,
-                              hipStream_t stream) {
+                              float* split_ws, long long split_ws_floats, hipStream_t stream) {
   if (!stats || !produced) return FSV_ERR_BAD_ARG;
   return fsv_conv_gather_impl(in, wt, bias, res, out, N, H, W, Cin, OH, OW, Cout, ntaps, ty, tx, sy, sx, OH, OW, 1, 1, 0, 0, ldw,
-                              0, 0, 0, act, scale, -1, 0, 0, wscale, stats, stats_groups, stats_slots, stats_prezeroed, produced, stream);
+                              0, 0, 0, act, scale, -1, 0, 0, wscale, stats, stats_groups, stats_slots, stats_prezeroed, produced,
+                              split_ws, split_ws ? split_ws_floats : 0, stream);
 }
 
 // In-place x = act(x + bias[c]) over an NHWC tensor of `total` elements (the split-K finishing pass, exposed for operators

@@ -196,10 +196,13 @@ int fsv_act_fwd(const float* x, float* y, long long total, int act, hipStream_t 
 }
 
 // dx = dy * scale * act'(y)   (y is the activation OUTPUT)
-int fsv_act_bwd(const float* dy, const float* y, float* dx, long long total, int act, float scale, hipStream_t stream) {
+// dx_half != null: dx is also stored as IEEE half there (total % 4 == 0 only: FSV_ERR_UNSUPPORTED otherwise, nothing launched)
+int fsv_act_bwd(const float* dy, const float* y, float* dx, long long total, int act, float scale, void* dx_half,
+                hipStream_t stream) {
   if (!dy || !y || !dx || total < 0) return FSV_ERR_BAD_ARG;
   const bool v4 = (total & 3) == 0 && total > 0;
-  _Float16* dxh = reinterpret_cast<_Float16*>(fsv_sidecar_take(v4));
+  if (dx_half && !v4) return FSV_ERR_UNSUPPORTED;
+  _Float16* dxh = reinterpret_cast<_Float16*>(dx_half);
   if (v4) FSV_LAUNCH(fsv_act_bwd4_kernel, dim3(fsv_grid_for(total / 4)), dim3(256), stream, dy, y, dx, total / 4, act, scale, dxh);
   else FSV_LAUNCH(fsv_act_bwd_kernel, dim3(fsv_grid_for(total / 4 + 1)), dim3(256), stream, dy, y, dx, total, act, scale);
   return fsv_check_launch();

@@ -65,23 +65,3 @@ __device__ __forceinline__ float fsv_act(float v, int act) {
 }
 
 static inline int fsv_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
-
-// Half side output of the element-wise producers (`--amp`): fsv_half_sidecar_set(p) arms the NEXT fsv_norm_apply / fsv_norm_bwd* /
-// fsv_act_bwd call of this thread to also store its result as IEEE half at p (same element order) - the consumer convolution reads
-// that copy instead of running a conversion pass over the fp32 tensor.  The call consumes the pointer whether it honours it or not
-// (only the four-channels-per-work-item forms do); fsv_half_sidecar_taken() tells.  (inline functions: one instance per library)
-// Ordered split-K (round 4): fsv_conv_split_workspace_set(ws, floats) arms the NEXT fsv_conv_gather_fwd* call of this thread - if
-// its plan splits K, every split stores its partial tile into its own copy of the output inside ws and a finishing pass sums the
-// copies in ascending order (same bits on every run; no zero fill, no atomics); a call that does not split, or whose nsplit copies
-// do not fit, ignores it.  The call consumes the arming either way.
-inline float*& fsv_splitws_ptr() { static thread_local float* p = nullptr; return p; }
-inline long long& fsv_splitws_cap() { static thread_local long long n = 0; return n; }
-
-inline void*& fsv_sidecar_slot() { static thread_local void* p = nullptr; return p; }
-inline int& fsv_sidecar_flag() { static thread_local int t = 0; return t; }
-static inline void* fsv_sidecar_take(bool honoured) {
-  void* p = fsv_sidecar_slot();
-  fsv_sidecar_slot() = nullptr;
-  fsv_sidecar_flag() = (p && honoured) ? 1 : 0;
-  return honoured ? p : nullptr;
-}

@@ -560,9 +560,11 @@ static inline bool fsv_ew_vec4(long long total, int C) {
 
 static inline void fsv_launch_bwd_apply(const float* dy, const float* y, const float* x, const float* mean, const float* rstd,
                                         const float* w, const float* s1, const float* s2, float* dx, long long total,
-                                        long long PC, int C, int P, int act, int fixed_stats, hipStream_t stream) {
-  const bool v4 = fsv_ew_vec4(total, C);
-  _Float16* dxh = reinterpret_cast<_Float16*>(fsv_sidecar_take(v4));
+                                        long long PC, int C, int P, int act, int fixed_stats, void* dx_half,
+                                        hipStream_t stream) {
+  // (a half side output only exists in the four-channels-per-work-item form: fsv_half_side_ok was checked by the entry point)
+  const bool v4 = dx_half ? true : fsv_ew_vec4(total, C);
+  _Float16* dxh = reinterpret_cast<_Float16*>(dx_half);
   if (v4) {
     FSV_LAUNCH(fsv_norm_bwd_apply4_kernel, dim3(fsv_ew_grid(total / 4)), dim3(256), stream, dy, y, x, mean, rstd, w, s1, s2, dx,
                (unsigned)(total / 4), (unsigned)(PC / 4), (unsigned)(C / 4), P, act, fixed_stats, dxh);
@@ -572,15 +574,21 @@ static inline void fsv_launch_bwd_apply(const float* dy, const float* y, const f
   }
 }
 
-void fsv_half_sidecar_set(void* p) { fsv_sidecar_slot() = p; fsv_sidecar_flag() = 0; }
-int fsv_half_sidecar_taken(void) { return fsv_sidecar_flag(); }
+// Half side output (`--amp`): y_half / dx_half != null -> the result is ALSO stored as IEEE half there, same element order (the
+// consumer convolution reads that copy instead of converting the fp32 tensor).  An explicit, nullable argument of the entry point
+// that writes the tensor - the library keeps no "armed" pointer between calls.  Only the four-channels-per-work-item kernels
+// carry it: C % 4 == 0 and fewer than 2^31 elements, FSV_ERR_UNSUPPORTED (nothing launched) otherwise.
+static inline bool fsv_half_side_ok(const void* h, long long total, int C) {
+  return !h || (C % 4 == 0 && total < (1LL << 31));
+}
 
 int fsv_norm_apply(const float* x, const float* mean, const float* rstd, const float* w, const float* b, float* y,
-                   int G, int P, int C, int act, hipStream_t stream) {
+                   int G, int P, int C, int act, void* y_half, hipStream_t stream) {
   if (!x || !mean || !rstd || !y || (w && !b)) return FSV_ERR_BAD_ARG;
   long long total = (long long)G * P * C;
-  const bool v4 = fsv_ew_vec4(total, C);
-  _Float16* yh = reinterpret_cast<_Float16*>(fsv_sidecar_take(v4));
+  if (!fsv_half_side_ok(y_half, total, C)) return FSV_ERR_UNSUPPORTED;
+  const bool v4 = y_half ? true : fsv_ew_vec4(total, C);
+  _Float16* yh = reinterpret_cast<_Float16*>(y_half);
   if (v4) {
     FSV_LAUNCH(fsv_norm_apply4_kernel, dim3(fsv_ew_grid(total / 4)), dim3(256), stream, x, mean, rstd, w, b, y,
                (unsigned)(total / 4), (unsigned)((long long)P * C / 4), (unsigned)(C / 4), act, yh);
@@ -595,9 +603,10 @@ int fsv_norm_apply(const float* x, const float* mean, const float* rstd, const f
 // dw/db are non-null, the affine parameter gradients.  s1/s2: [G*C] scratch.
 int fsv_norm_bwd(const float* dy, const float* y, const float* x, const float* mean, const float* rstd, const float* w,
                  double* workspace, float* s1, float* s2, float* dx, float* dw, float* db, int G, int P, int C, int act,
-                 int fixed_stats, hipStream_t stream) {
+                 int fixed_stats, void* dx_half, hipStream_t stream) {
   if (!dy || !x || !mean || !rstd || !workspace || !s1 || !s2 || !dx) return FSV_ERR_BAD_ARG;
   if (act != FSV_ACT_NONE && !y) return FSV_ERR_BAD_ARG;
+  if (!fsv_half_side_ok(dx_half, (long long)G * P * C, C)) return FSV_ERR_UNSUPPORTED;
   RedPlan pl = fsv_red_plan(G, P, C);
   const int nchunks = pl.nchunks;
   RedP rp; rp.a = dy; rp.y = y; rp.x = x; rp.mean = mean; rp.rstd = rstd; rp.part = workspace;
@@ -607,7 +616,7 @@ int fsv_norm_bwd(const float* dy, const float* y, const float* x, const float* m
              db, G, C, nchunks);
   long long total = (long long)G * P * C;
   fsv_launch_bwd_apply(dy, y, x, mean, rstd, w, (const float*)s1, (const float*)s2, dx, total, (long long)P * C, C, P, act,
-                       fixed_stats, stream);
+                       fixed_stats, dx_half, stream);
   return fsv_check_launch();
 }
 
@@ -643,21 +652,22 @@ int fsv_norm_stats_fused(const float* x, double* workspace, float* mean, float* 
 
 int fsv_norm_bwd_fused(const float* dy, const float* y, const float* x, const float* mean, const float* rstd, const float* w,
                        double* workspace, float* s1, float* s2, float* dx, float* dw, float* db, int G, int P, int C, int act,
-                       int fixed_stats, int* counters, hipStream_t stream) {
+                       int fixed_stats, int* counters, void* dx_half, hipStream_t stream) {
   if (!fsv_red_fused(counters, G, P, C))
-    return fsv_norm_bwd(dy, y, x, mean, rstd, w, workspace, s1, s2, dx, dw, db, G, P, C, act, fixed_stats, stream);
+    return fsv_norm_bwd(dy, y, x, mean, rstd, w, workspace, s1, s2, dx, dw, db, G, P, C, act, fixed_stats, dx_half, stream);
   if (!dy || !x || !mean || !rstd || !workspace || !s1 || !s2 || !dx) return FSV_ERR_BAD_ARG;
   if (act != FSV_ACT_NONE && !y) return FSV_ERR_BAD_ARG;
+  if (!fsv_half_side_ok(dx_half, (long long)G * P * C, C)) return FSV_ERR_UNSUPPORTED;
   RedPlan pl = fsv_red_plan(G, P, C, FSV_RED_FUSED_CHUNKS);
   if (pl.nslabs > FSV_RED_COUNTERS)
-    return fsv_norm_bwd(dy, y, x, mean, rstd, w, workspace, s1, s2, dx, dw, db, G, P, C, act, fixed_stats, stream);
+    return fsv_norm_bwd(dy, y, x, mean, rstd, w, workspace, s1, s2, dx, dw, db, G, P, C, act, fixed_stats, dx_half, stream);
   RedP rp; rp.a = dy; rp.y = y; rp.x = x; rp.mean = mean; rp.rstd = rstd; rp.part = workspace;
   rp.P = P; rp.C = C; rp.act = act; fsv_red_no_tail(rp);
   rp.counter = counters; rp.o0 = s1; rp.o1 = s2; rp.o2 = dw; rp.o3 = db;
   fsv_launch_red<FSV_RED_BWD>(pl, rp, G, stream);
   long long total = (long long)G * P * C;
   fsv_launch_bwd_apply(dy, y, x, mean, rstd, w, (const float*)s1, (const float*)s2, dx, total, (long long)P * C, C, P, act,
-                       fixed_stats, stream);
+                       fixed_stats, dx_half, stream);
   return fsv_check_launch();
 }
 
@@ -744,11 +754,13 @@ int fsv_norm_bwd_sums(const float* dy, const float* y, const float* x, const flo
 
 // dx = w * rstd * (d - s1 / count - xhat * s2 / count) over the local [P][C] tensor with the exchanged sums s1, s2 [C]
 int fsv_norm_bwd_apply(const float* dy, const float* y, const float* x, const float* mean, const float* rstd, const float* w,
-                       const float* s1, const float* s2, float* dx, int P, int C, int count, int act, hipStream_t stream) {
+                       const float* s1, const float* s2, float* dx, int P, int C, int count, int act, void* dx_half,
+                       hipStream_t stream) {
   if (!dy || !x || !mean || !rstd || !s1 || !s2 || !dx || P < 1 || C < 1 || count < 1) return FSV_ERR_BAD_ARG;
   if (act != FSV_ACT_NONE && !y) return FSV_ERR_BAD_ARG;
   long long total = (long long)P * C;
-  fsv_launch_bwd_apply(dy, y, x, mean, rstd, w, s1, s2, dx, total, total, C, count, act, 0, stream);
+  if (!fsv_half_side_ok(dx_half, total, C)) return FSV_ERR_UNSUPPORTED;
+  fsv_launch_bwd_apply(dy, y, x, mean, rstd, w, s1, s2, dx, total, total, C, count, act, 0, dx_half, stream);
   return fsv_check_launch();
 }
 

@@ -72,10 +72,12 @@ def to_half_nhwc(x):
 
 
 class half_side_output:
-    """`with half_side_output(t):` around ONE fsv_norm_apply / fsv_norm_bwd* / fsv_act_bwd call that writes the fp32 NHWC tensor t:
-    under `--amp` on the half-precision kernels the call also stores t as IEEE half (include/fsv2v.h fsv_half_sidecar_set) and the
-    copy rides on the tensor (`_fsv_h16`) - the convolution that reads t next finds its operand already converted.  Same values as
-    the conversion pass it replaces (one rounding of the fp32 result)."""
+    """`with half_side_output(t) as side:` around ONE fsv_norm_apply / fsv_norm_bwd* / fsv_act_bwd call that writes the fp32 NHWC
+    tensor t: under `--amp` on the half-precision kernels `side.ptr()` is a half buffer the call is handed as its explicit
+    `y_half` / `dx_half` argument (include/fsv2v.h: the library keeps no armed pointer between calls) - it then also stores t as
+    IEEE half, and the copy rides on the tensor (`_fsv_h16`): the convolution that reads t next finds its operand already
+    converted.  Same values as the conversion pass it replaces (one rounding of the fp32 result).  The conditions below are the
+    entry points' contract (C % 4 == 0, fewer than 2^31 elements), so a pointer that is handed over is always honoured."""
 
     def __init__(self, t):
         self.t = t
@@ -85,17 +87,15 @@ class half_side_output:
             n, c, h, w = t.shape
             self.h = empty_nhwc_h(n, c, h, w, t)
 
+    def ptr(self):
+        return lib.ptr(self.h)
+
     def __enter__(self):
-        if self.h is not None:
-            getattr(lib.get_lib(), "fsv_half_sidecar_set")(ctypes.c_void_p(self.h.data_ptr()))
         return self
 
     def __exit__(self, et, ev, tb):
-        if self.h is not None:
-            taken = int(getattr(lib.get_lib(), "fsv_half_sidecar_taken")())
-            getattr(lib.get_lib(), "fsv_half_sidecar_set")(None)            # (never leave a pointer armed behind an exception)
-            if taken and et is None:
-                self.t._fsv_h16 = (self.t._version, self.h)
+        if self.h is not None and et is None:
+            self.t._fsv_h16 = (self.t._version, self.h)
         return False
 
 

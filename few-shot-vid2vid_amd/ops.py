@@ -34,14 +34,14 @@ lib.register_sigs({
     "fsv_norm_stats": [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_f, c_p, c_p, c_f, c_p],
     "fsv_norm_stats_rep": [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_f, c_p, c_p, c_f, c_i, c_p],
     "fsv_norm_stats_fused": [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_f, c_p, c_p, c_f, c_i, c_p, c_p],
-    "fsv_norm_bwd_fused": [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_p],
+    "fsv_norm_bwd_fused": [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_p],
     "fsv_colsum_fused": [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p, c_p],
-    "fsv_norm_apply": [c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p],
-    "fsv_norm_bwd": [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p],
+    "fsv_norm_apply": [c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p, c_p],
+    "fsv_norm_bwd": [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_p],
     "fsv_norm_sums": [c_p, c_p, c_p, c_i, c_i, c_p],
     "fsv_norm_stats_from_sums": [c_p, ctypes.c_double, c_p, c_p, c_i, c_f, c_p, c_p, c_f, c_p],
     "fsv_norm_bwd_sums": [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_p],
-    "fsv_norm_bwd_apply": [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p],
+    "fsv_norm_bwd_apply": [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p, c_p],
     "fsv_colsum": [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p],
     "fsv_spade_prep": [c_p, c_p, c_p, c_p, c_ll, c_ll, c_ll, c_ll, c_p, c_p, c_p, c_i, c_i, c_i, c_p],
     "fsv_spade_mod_fwd": [c_p, c_p, c_p, c_p, c_i, c_pp, c_pp, c_pp, c_pp, c_pp, c_ip, c_llp, c_llp,
@@ -63,7 +63,7 @@ lib.register_sigs({
     "fsv_upsample2x_fwd": [c_p, c_p, c_i, c_i, c_i, c_i, c_p],
     "fsv_upsample2x_bwd": [c_p, c_p, c_i, c_i, c_i, c_i, c_p],
     "fsv_act_fwd": [c_p, c_p, c_ll, c_i, c_p],
-    "fsv_act_bwd": [c_p, c_p, c_p, c_ll, c_i, c_f, c_p],
+    "fsv_act_bwd": [c_p, c_p, c_p, c_ll, c_i, c_f, c_p, c_p],
     "fsv_softmax_rows_fwd": [c_p, c_p, c_ll, c_i, c_p],
     "fsv_softmax_rows_bwd": [c_p, c_p, c_p, c_ll, c_i, c_p],
     "fsv_adam_step": [c_p, c_p, c_p, c_p, c_p, c_ll, c_f, c_f, c_f, c_f, c_p],
@@ -145,8 +145,8 @@ def act_backward(dy, y, act, scale=1.0):
     dy = to_nhwc(dy) if dy.dim() == 4 else dy.contiguous()
     dx = torch.empty_like(y)
     lib.check_device(dy, y)
-    with _hconv.half_side_output(dx):
-        lib.call("fsv_act_bwd", lib.ptr(dy), lib.ptr(y), lib.ptr(dx), y.numel(), act, float(scale), lib.stream_ptr())
+    with _hconv.half_side_output(dx) as side:
+        lib.call("fsv_act_bwd", lib.ptr(dy), lib.ptr(y), lib.ptr(dx), y.numel(), act, float(scale), side.ptr(), lib.stream_ptr())
     return dx
 
 
@@ -823,17 +823,17 @@ def bn_backward(dy, y, x, mean, rstd, w, g, p, c, act, fixed_stats, affine, worl
         dist.all_reduce(sums, op=dist.ReduceOp.SUM, group=_bn_sync[1])
         s = sums.float()
         lib.call("fsv_norm_bwd_apply", lib.ptr(dy), lib.ptr(y), lib.ptr(x), lib.ptr(mean), lib.ptr(rstd), lib.ptr(w),
-                 lib.ptr(s[:c]), lib.ptr(s[c:]), lib.ptr(dx), p, c, p * world, act, lib.stream_ptr())
+                 lib.ptr(s[:c]), lib.ptr(s[c:]), lib.ptr(dx), p, c, p * world, act, None, lib.stream_ptr())
         return dx, dw, db
     s1 = torch.empty(g * c, dtype=torch.float32, device=x.device)
     s2 = torch.empty_like(s1)
     dw = torch.empty(c, dtype=torch.float32, device=x.device) if affine else None
     db = torch.empty_like(dw) if affine else None
     ws = _ws(g, p, c, x)
-    with _hconv.half_side_output(dx):
+    with _hconv.half_side_output(dx) as side:
         lib.call("fsv_norm_bwd_fused", lib.ptr(dy), lib.ptr(y), lib.ptr(x), lib.ptr(mean), lib.ptr(rstd), lib.ptr(w), lib.ptr(ws),
                  lib.ptr(s1), lib.ptr(s2), lib.ptr(dx), lib.ptr(dw), lib.ptr(db), g, p, c, act, 1 if fixed_stats else 0,
-                 _ticket(x), lib.stream_ptr())
+                 _ticket(x), side.ptr(), lib.stream_ptr())
     return dx, dw, db
 
 
@@ -855,9 +855,9 @@ class _NormActFn(torch.autograd.Function):
         y = torch.empty_like(x)
         wd = weight.detach().contiguous() if weight is not None else None
         bd = bias.detach().contiguous() if bias is not None else None
-        with _hconv.half_side_output(y):
+        with _hconv.half_side_output(y) as side:
             lib.call("fsv_norm_apply", lib.ptr(x), lib.ptr(mean), lib.ptr(rstd), lib.ptr(wd), lib.ptr(bd), lib.ptr(y), g, p,
-                     c, act, lib.stream_ptr())
+                     c, act, side.ptr(), lib.stream_ptr())
         ctx.dims = (g, p, c)
         ctx.act, ctx.affine = act, weight is not None
         ctx.batch_stats = bool(training or instance or run_mean is None)

@@ -9,7 +9,8 @@
  *
  *   - every function returns 0 (FSV_OK) or a negative fsv_status; nothing throws or aborts across the boundary;
  *   - all pointers are device pointers owned by the caller (PyTorch's caching allocator); the library allocates
- *     nothing and keeps no state; scratch buffers are passed in explicitly;
+ *     nothing and keeps no state between calls - no setter-style entry points, nothing "armed" for a later call; scratch
+ *     buffers, optional workspaces and optional side outputs are explicit (nullable) arguments of the call that uses them;
  *   - work is only enqueued on `stream` (a hipStream_t); calls are re-entrant and graph-capturable
  *     (only kernels and hipMemsetAsync are issued);
  *   - activations are fp32 NHWC ("channels last"); convolution weights are fp32 OIHW at the boundary and are
@@ -48,18 +49,17 @@ enum fsv_act { FSV_ACT_NONE = 0, FSV_ACT_LRELU = 1 /* leaky_relu(0.2), architect
  * FSV_CONV_PF2=0).
  * One activation tensor / weight matrix may hold at most 2 GiB (32-bit byte offsets): FSV_ERR_UNSUPPORTED beyond.  wscale: optional device scalar multiplying the accumulator before
  * the bias (the spectral-norm 1/sigma when wt holds un-normalised weights). */
-/* Ordered split-K: arms the NEXT fsv_conv_gather_fwd / fsv_conv_gather_fwd_stats call of the calling thread - when its plan splits
- * K, split k stores its partial output into the k-th copy inside ws (nsplit x N*outH*outW*Cout floats) and a finishing pass sums the
- * copies in ascending order: the same bits on every run, no zero fill, no atomics.  A call that does not split, or whose copies do
- * not fit into `floats`, ignores the workspace (and adds atomically as before); the arming is consumed either way. */
-void fsv_conv_split_workspace_set(float* ws, long long floats);
+/* split_ws / split_ws_floats (nullable; ordered split-K): when the call's plan splits K, split k stores its partial output into
+ * the k-th copy inside split_ws (nsplit x N*outH*outW*Cout floats) and a finishing pass sums the copies in ascending order: the
+ * same bits on every run, no zero fill, no atomics.  A call that does not split, or whose copies do not fit into
+ * split_ws_floats, ignores the workspace (and adds atomically into a zeroed output). */
 int fsv_conv_gather_fwd(const float* in, const float* wt, const float* bias, const float* res, float* out,
                         int N, int H, int W, int Cin, int OH, int OW, int Cout,
                         int ntaps, const int* ty, const int* tx, int sy, int sx,
                         int outH, int outW, int osy, int osx, int ooy, int oox,
                         int ldw, long long w_bstride, long long b_bstride, int per_sample,
                         int act, float scale, int force_tile, int force_split, int accumulate, const float* wscale,
-                        fsv_stream_t stream);
+                        float* split_ws, long long split_ws_floats, fsv_stream_t stream);
 
 /* ---- grouped launches: up to 64 INDEPENDENT problems in one grid --------------------------------------------------------
  * The reference issues the 16 weight-generator MLPs (generator.py:103-110,245-273: three nn.Linear each, per adaptive level
@@ -104,7 +104,7 @@ int fsv_conv_gather_fwd_stats(const float* in, const float* wt, const float* bia
                               int ntaps, const int* ty, const int* tx, int sy, int sx,
                               int ldw, int act, float scale, const float* wscale,
                               double* stats, int stats_groups, int stats_slots, int stats_prezeroed, int* produced,
-                              fsv_stream_t stream);
+                              float* split_ws, long long split_ws_floats, fsv_stream_t stream);
 /* in place: x = act(x + bias[c]) over an NHWC tensor (finishing pass of operators that add several GEMM launches into one
  * output: convolutions with more than 16 taps, transposed convolutions); act codes as in the conv epilogue, 5 = leaky 0.1 */
 int fsv_bias_act(float* x, const float* bias, long long total, int C, int act, fsv_stream_t stream);
@@ -337,11 +337,12 @@ int fsv_norm_stats_finish(const double* part, float* mean, float* rstd, int G, i
  * of x, the unbiased running-variance correction counts P * rep values */
 int fsv_norm_stats_rep(const float* x, double* workspace, float* mean, float* rstd, int G, int P, int C, float eps,
                        float* run_mean, float* run_var, float momentum, int rep, fsv_stream_t stream);
+/* y_half / dx_half (nullable): half side output, see fsv_act_bwd below */
 int fsv_norm_apply(const float* x, const float* mean, const float* rstd, const float* w, const float* b, float* y,
-                   int G, int P, int C, int act, fsv_stream_t stream);
+                   int G, int P, int C, int act, void* y_half, fsv_stream_t stream);
 int fsv_norm_bwd(const float* dy, const float* y, const float* x, const float* mean, const float* rstd, const float* w,
                  double* workspace, float* s1, float* s2, float* dx, float* dw, float* db, int G, int P, int C, int act,
-                 int fixed_stats, fsv_stream_t stream);   /* fixed_stats: eval mode, mean / rstd are constants */
+                 int fixed_stats, void* dx_half, fsv_stream_t stream);   /* fixed_stats: eval mode, mean / rstd are constants */
 int fsv_colsum(const float* x, double* workspace, float* out, int G, int P, int C, int accumulate, fsv_stream_t stream);
 /* one-launch forms of the three reductions above: the workgroup that finishes last on a channel slab (a ticket per slab in
  * `counters`) sums that slab's partials and writes the final values, so the separate finalize launch disappears.  counters:
@@ -352,7 +353,7 @@ int fsv_norm_stats_fused(const float* x, double* workspace, float* mean, float* 
                          float* run_mean, float* run_var, float momentum, int rep, int* counters, fsv_stream_t stream);
 int fsv_norm_bwd_fused(const float* dy, const float* y, const float* x, const float* mean, const float* rstd, const float* w,
                        double* workspace, float* s1, float* s2, float* dx, float* dw, float* db, int G, int P, int C, int act,
-                       int fixed_stats, int* counters, fsv_stream_t stream);
+                       int fixed_stats, int* counters, void* dx_half, fsv_stream_t stream);
 int fsv_colsum_fused(const float* x, double* workspace, float* out, int G, int P, int C, int accumulate, int* counters,
                      fsv_stream_t stream);
 /* cross-replica BatchNorm (opt-in; apex.parallel.SyncBatchNorm of the reference's multi-process path, normalization.py:15,33,80):
@@ -364,7 +365,8 @@ int fsv_norm_stats_from_sums(const double* sums, double count, float* mean, floa
 int fsv_norm_bwd_sums(const float* dy, const float* y, const float* x, const float* mean, const float* rstd,
                       double* workspace, double* sums, int P, int C, int act, fsv_stream_t stream);
 int fsv_norm_bwd_apply(const float* dy, const float* y, const float* x, const float* mean, const float* rstd, const float* w,
-                       const float* s1, const float* s2, float* dx, int P, int C, int count, int act, fsv_stream_t stream);
+                       const float* s1, const float* s2, float* dx, int P, int C, int count, int act, void* dx_half,
+                       fsv_stream_t stream);
 /* the bias gradients of a whole backward pass in two launches: table[job][8] = {src [P][C] rows, dst float[C] (added into),
  * offset of the job's partials in `part` (doubles), P, C, rows_per_blk, nchunks, V | shared << 8}; tmap1 (job, chunk, slab) triples,
  * tmap2 (job, 4-channel block) pairs; fsv_colsum_plan gives {V, TX, nslabs, rows_per_blk, nchunks} for one [P][C] */
@@ -421,13 +423,13 @@ int fsv_sn_backward(const float* dWsn, const float* W, const float* u, const flo
 int fsv_upsample2x_fwd(const float* x, float* y, int N, int H, int W, int C, fsv_stream_t stream);
 int fsv_upsample2x_bwd(const float* dy, float* dx, int N, int H, int W, int C, fsv_stream_t stream);
 int fsv_act_fwd(const float* x, float* y, long long total, int act, fsv_stream_t stream);
-int fsv_act_bwd(const float* dy, const float* y, float* dx, long long total, int act, float scale, fsv_stream_t stream);
-/* Half side output of the element-wise producers (`--amp`): arms the NEXT fsv_norm_apply / fsv_norm_bwd / fsv_norm_bwd_fused /
- * fsv_act_bwd call of the calling thread to also store its result (y, dx) as IEEE half at p, same element order - the consumer
- * convolution reads that copy instead of converting the fp32 tensor.  The call consumes the pointer whether it can honour it or
- * not (C % 4 == 0 and fewer than 2^31 elements; fsv_act_bwd: total % 4 == 0); fsv_half_sidecar_taken() tells which. */
-void fsv_half_sidecar_set(void* p);
-int fsv_half_sidecar_taken(void);
+/* Half side output of the element-wise producers (`--amp`): fsv_norm_apply (y_half), fsv_norm_bwd / fsv_norm_bwd_fused /
+ * fsv_norm_bwd_apply and fsv_act_bwd (dx_half) take a nullable pointer - when set, the call also stores its result as IEEE half
+ * there, same element order, one rounding of the fp32 value: the consumer convolution reads that copy instead of converting the
+ * fp32 tensor.  Contract: C % 4 == 0 and fewer than 2^31 elements (fsv_act_bwd: total % 4 == 0); FSV_ERR_UNSUPPORTED with nothing
+ * launched otherwise. */
+int fsv_act_bwd(const float* dy, const float* y, float* dx, long long total, int act, float scale, void* dx_half,
+                fsv_stream_t stream);
 /* channel concatenation into one NHWC tensor (one call per source) and its gradient slices; occlusion-mask
  * compositing out = a*m + b*(1-m) (generator.py:217,224,441-443,498,563) */
 int fsv_cat_put(const float* src, float* out, long long N, int C, long long P, const long long* strides, int Ct, int coff,

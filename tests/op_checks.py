@@ -811,7 +811,7 @@ def check_avgpool3s2(device, seed=90):
 
 def check_ordered_split(device, seed=93):
     """split-K launches of the fp32 gather-GEMM sum their splits in ascending order (one output copy per split + a finishing pass,
-    include/fsv2v.h fsv_conv_split_workspace_set): the same bits on every run, equal to the atomic form up to summation order,
+    the explicit split_ws argument of include/fsv2v.h fsv_conv_gather_fwd): the same bits on every run, equal to the atomic form up to summation order,
     epilogue (bias, LeakyReLU, residual) applied once by the finishing pass"""
     ops, conv = pkg()
     g = torch.Generator().manual_seed(seed)

@@ -19,6 +19,26 @@ def test_header_declares_entry_points():
     assert len(syms) >= 20 and 'fsv_conv_gather_fwd' in syms and 'fsv_warp_fwd' in syms
 
 
+def test_no_setter_style_entry_points():
+    """The header promises a library without state between calls (the resample2d_cuda.cc:6-31 convention): no entry point
+    "arms" a later call - workspaces and side outputs are explicit, nullable arguments of the call that uses them.  Every
+    declared function returns an int status (a `void` or pointer-returning function would be a setter / getter), none is
+    named like one, and no kernel source keeps thread-local hand-over slots (the per-thread launch STATUS is the one
+    thread_local the sources may hold: it is written and consumed inside one call)."""
+    text = open(os.path.join(ROOT, 'include', 'fsv2v.h')).read()
+    text = re.sub(r'/\*.*?\*/', '', text, flags=re.S)
+    non_int = re.findall(r'^\s*(?:void|float|double|long long|const \w+|\w+)\s*\*?\s+\*?(fsv_[a-z0-9_]+)\s*\(', text, flags=re.M)
+    non_int = [n for n in non_int if n not in declared_symbols()]
+    assert not non_int, non_int
+    bad = [s for s in declared_symbols() if re.search(r'_(set|arm|armed|taken)$', s) or re.search(r'_(set|arm)_', s)]
+    assert not bad, bad
+    csrc = os.path.join(ROOT, 'few-shot-vid2vid_amd', 'csrc')
+    for name in sorted(os.listdir(csrc)):
+        src = open(os.path.join(csrc, name)).read()
+        for m in re.finditer(r'thread_local\s+[^;=]+', src):
+            assert 'fsv_launch_status' in m.group(0), (name, m.group(0))
+
+
 @pytest.mark.parametrize('libname', ['libfsv2v_hip.so'])
 def test_library_exports_every_declared_symbol(libname):
     import importlib

@@ -113,7 +113,7 @@ def test_spade_f16_bias_sums_over_copies(emu_lib, monkeypatch):
 
 def test_half_side_output_of_the_elementwise_producers(emu_lib):
     """under the half-precision kernels norm_act / its backward / act_backward also store their fp32 result as IEEE half
-    (include/fsv2v.h fsv_half_sidecar_set): the copy equals the conversion pass it replaces and the consumer's to_half_nhwc takes
+    (the explicit y_half / dx_half arguments of include/fsv2v.h): the copy equals the conversion pass it replaces and the consumer's to_half_nhwc takes
     it without a launch"""
     from importlib import import_module
     ops = import_module('few-shot-vid2vid_amd.ops')
