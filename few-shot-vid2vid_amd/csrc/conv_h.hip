@@ -429,176 +429,10 @@ __global__ __launch_bounds__(64 * WM * WN) void fsv_hconv_kernel(HConvP p) {
   fsv_hconv_body<BM, BN, WM, WN, NBUF>(p, bx, by, (int)blockIdx.z);
 }
 
-// ---- patch-resident form (round 4) ------------------------------------------------------------------------------------------------
-// Stride-1 convolutions whose taps reach one pixel in every direction (every 3x3 convolution of the generators and its data
-// gradient).  The form above gathers the A tile once PER TAP - the nine taps of a 3x3 read the same activations nine times through
-// the L2 -> LDS path, and that path is what bounds the kernel (~10 - 13 TB/s over the chip whatever the tile, profiles/r04_notes.md).
-// Here a workgroup owns a TH x TW patch of output pixels of one image.  K runs channel-chunk-major: for every 32 input channels the
-// (TH + 2) x (TW + 2) input pixels of the patch go to LDS ONCE (64-byte rows, out-of-image pixels as hardware zero fill), and the
-// taps are steps over it - tap (ty, tx) reads row (y + ty + 1) * (TW + 2) + (x + tx + 1) for the lane's pixel (y, x): 16 consecutive
-// lanes are 16 consecutive patch rows whatever the tap, so the slot swizzle (slot ^ (row >> 2) & 3) keeps the ds_read_b128
-// fragments conflict-free.  Only the weights (32 k x BN per tap, L2 resident) are loaded per step.  LDS fill per 32 channels of a
-// 256-pixel x 64-channel tile: 20 KB of activations + 9 x 4 KB of weights against 9 x (16 + 4) KB.  An experiment that did not pay
-// (see fsv_h_patch_pick): kept opt-in, with its parity tests, as the measured answer to "is the gather form fill-bound".
-// Pipeline: step s = (chunk c, tap t).  Weights of step s + 2 are requested at the top of step s (three buffers); the patch of
-// chunk c + 1 goes out one load instruction per step during the first taps of chunk c (second patch buffer).  The memory pipe
-// returns in order: at the end of step s everything older than [patch piece of step s - 1, weights s + 2, patch piece of step s]
-// has landed - the weights of step s + 1 among it.
-template <int TH, int TW, int BN, int WM, int WN>
-__global__ __launch_bounds__(64 * WM * WN, 2) void fsv_hconv_patch_kernel(HConvP p, int tiles_y, int tiles_x) {
-  constexpr int BK = 32;
-  constexpr int PH = TH + 2, PW = TW + 2;
-  constexpr int BM = TH * TW, NT = 64 * WM * WN;
-  constexpr int RPP = NT / 4;                                    // LDS rows per load pass: 4 lanes x 16 B = one 64-byte row
-  constexpr int PROWS = (PH * PW + RPP - 1) / RPP * RPP;         // patch rows, whole passes (the padding rows load zeros)
-  constexpr int BROWS = BN > RPP ? BN : RPP;
-  constexpr int NPA = PROWS / RPP, NPB = BROWS / RPP;
-  constexpr int TM = BM / (WM * 32), TN = BN / (WN * 32);
-  constexpr int A_ST = PROWS * BK, B_ST = BROWS * BK;            // halves per buffer
-  static_assert(TW == 16 && TM >= 1 && TN >= 1 && BM % (WM * 32) == 0 && BN % (WN * 32) == 0, "tile");
-  __shared__ __attribute__((aligned(16))) fsv_h16 smem[2 * A_ST + 3 * B_ST];
-  fsv_h16* const As = smem;
-  fsv_h16* const Bs = smem + 2 * A_ST;
-
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave / WN, wn = wave % WN;
-  const int lrow = lane & 31, lk = lane >> 5;
-  int bx, by;
-  if (!fsv_h_xcd_tile((p.per_sample ? 1 : p.N) * tiles_y * tiles_x, (p.Cout + BN - 1) / BN, bx, by)) return;
-  const int zs = blockIdx.z;
-  const int bn0 = by * BN;
-  const int tpi = tiles_y * tiles_x;
-  const int n_img = p.per_sample ? zs : bx / tpi;
-  const int trem = p.per_sample ? bx : bx - n_img * tpi;
-  const int oy0 = (trem / tiles_x) * TH, ox0 = (trem % tiles_x) * TW;
-  const fsv_h16* wt = p.wt + (long long)zs * p.w_bstride;
-  const fsv_rawbuf araw = fsv_make_rawbuf(p.in, (long long)p.N * p.H * p.W * p.Cin * 2);
-  const fsv_rawbuf braw = fsv_make_rawbuf(wt, (long long)p.nrows * p.Kpad * 2);
-
-  // this thread's rows of a load pass and the logical slot (8 k) that belongs in its physical one
-  const int r0 = tid >> 2;
-  const int ls = (tid & 3) ^ ((r0 >> 2) & 3);
-  unsigned a_base[NPA], b_base[NPB];
-#pragma unroll
-  for (int i = 0; i < NPA; ++i) {
-    const int pp = r0 + i * RPP;
-    const int py = pp / PW, px = pp - py * PW;
-    const int iy = oy0 - 1 + py, ix = ox0 - 1 + px;
-    const bool ok = (pp < PH * PW) & ((unsigned)iy < (unsigned)p.H) & ((unsigned)ix < (unsigned)p.W);
-    a_base[i] = ok ? (unsigned)((((n_img * p.H + iy) * p.W + ix) * p.Cin + ls * 8) * 2) : FSV_BUF_OOB;
-  }
-#pragma unroll
-  for (int i = 0; i < NPB; ++i) {
-    const int r = r0 + i * RPP;
-    const int n = bn0 + r;
-    b_base[i] = (r < BN && n < p.nrows) ? (unsigned)((n * p.Kpad + ls * 8) * 2) : FSV_BUF_OOB;
-  }
-  const int nck = p.Cin / BK;
-  auto issue_a = [&](fsv_h16* a_buf, int c, int i) {           // piece i of the patch of chunk c (past the last chunk: zeros)
-    const unsigned off = (c < nck) ? a_base[i] + (unsigned)(c * BK * 2) : FSV_BUF_OOB;
-    fsv_hbuf_load_lds(araw, off | (a_base[i] & FSV_BUF_OOB), a_buf + (wave * 16 + i * RPP) * BK);
-  };
-  auto issue_b = [&](fsv_h16* b_buf, int c, int t) {
-    const unsigned koff = (unsigned)((t * p.Cin + c * BK) * 2);
-#pragma unroll
-    for (int i = 0; i < NPB; ++i) {
-      const unsigned off = (c < nck) ? b_base[i] + koff : FSV_BUF_OOB;
-      fsv_hbuf_load_lds(braw, off | (b_base[i] & FSV_BUF_OOB), b_buf + (wave * 16 + i * RPP) * BK);
-    }
-  };
-
-  f32x16 acc[TM][TN];
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-  int pp0[TM], b_off[TN], b_swz[TN];
-#pragma unroll
-  for (int i = 0; i < TM; ++i) {
-    const int rt = wm * (TM * 32) + i * 32 + lrow;               // tile row -> pixel (rt / TW, rt % TW) of the patch interior
-    pp0[i] = ((rt / TW) + 1) * PW + (rt % TW) + 1;
-  }
-#pragma unroll
-  for (int j = 0; j < TN; ++j) {
-    const int r = wn * (TN * 32) + j * 32 + lrow;
-    b_off[j] = r * BK; b_swz[j] = (r >> 2) & 3;
-  }
-
-  // prologue: the first patch, the weights of the first two steps
-#pragma unroll
-  for (int i = 0; i < NPA; ++i) issue_a(As, 0, i);
-  {
-    issue_b(Bs, 0, 0);
-    const bool two = p.ntaps > 1;
-    issue_b(Bs + B_ST, two ? 0 : 1, two ? 1 : 0);
-  }
-  FSV_WAIT_VMCNT(0);
-  __syncthreads();
-
-  int bi = 0;                   // weight buffer of the current step; s + 2 goes to (bi + 2) % 3
-  int c2 = 0, t2 = 2;           // (chunk, tap) of step s + 2
-  if (t2 >= p.ntaps) { t2 -= p.ntaps; c2 = 1; if (t2 >= p.ntaps) { t2 -= p.ntaps; c2 = 2; } }
-  bool prev_piece = false;
-#pragma unroll 1
-  for (int c = 0; c < nck; ++c) {
-    const fsv_h16* a_src = As + (c & 1) * A_ST;
-    fsv_h16* a_next = As + ((c + 1) & 1) * A_ST;
-#pragma unroll 1
-    for (int t = 0; t < p.ntaps; ++t) {
-      const int b2 = bi >= 1 ? bi - 1 : 2;                       // (bi + 2) % 3
-      issue_b(Bs + b2 * B_ST, c2, t2);
-      const bool piece = t < NPA;
-      if (piece) {                                               // uniform
-        // (a switch over t keeps the piece index a constant: the offsets live in registers)
-#pragma unroll
-        for (int i = 0; i < NPA; ++i)
-          if (t == i) issue_a(a_next, c + 1, i);
-      }
-      ++t2;
-      if (t2 >= p.ntaps) { t2 = 0; ++c2; }
-      int ty, tx;
-      fsv_htap(p, t, ty, tx);
-      const int shift = ty * PW + tx;
-      const fsv_h16* b_src = Bs + bi * B_ST;
-      fsv_h16x8 fa[2][TM], fb[2][TN];
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-          const int pp = pp0[i] + shift;
-          fa[ks][i] = *reinterpret_cast<const fsv_h16x8*>(&a_src[pp * BK + ((((2 * ks + lk) ^ (pp >> 2)) & 3) << 3)]);
-        }
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-          fb[ks][j] = *reinterpret_cast<const fsv_h16x8*>(&b_src[b_off[j] + (((2 * ks + lk) ^ b_swz[j]) << 3)]);
-      }
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-          for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[ks][i], fb[ks][j], acc[i][j], 0, 0, 0);
-      // everything older than [piece of the previous step, weights of s + 2, piece of this step] must have landed
-      const int after = (prev_piece ? 1 : 0) + (piece ? 1 : 0);
-      if (after == 2) FSV_WAIT_VMCNT(NPB + 2);
-      else if (after == 1) FSV_WAIT_VMCNT(NPB + 1);
-      else FSV_WAIT_VMCNT(NPB);
-      __syncthreads();
-      prev_piece = piece;
-      bi = bi == 2 ? 0 : bi + 1;
-    }
-  }
-  FSV_WAIT_VMCNT(0);          // (loads past the end are still landing in LDS: they must not outlive the workgroup's allocation)
-
-  const long long m_img = p.per_sample ? 0 : (long long)n_img * p.OH * p.OW;
-  const int st_g0 = p.stats ? (int)(m_img / p.stats_ohw) : 0;
-  fsv_hconv_epilogue<TM, TN>(p, acc, zs, bn0, wm, wn, lane, bx, st_g0, 0x7fffffff, false, [&](int rt) {
-    const int oy = oy0 + rt / TW, ox = ox0 + rt % TW;
-    return (oy < p.OH && ox < p.OW) ? (int)(m_img + (long long)oy * p.OW + ox) : -1;
-  });
-}
+// (A patch-resident form of the stride-1 3x3 convolutions - the (TH + 2) x (TW + 2) input patch of a pixel tile in LDS once per 32
+// channels, the taps as steps over it: 2 - 4x fewer bytes from L2 to LDS - was built and measured in round 4 (profiles/r04_notes.md
+// section 2, r04_h_ab_patch.jsonl): correct on hardware and SLOWER on every layer shape (372 against 625 TFLOP/s on M32768 N128 K2304;
+// street --amp step 22.03 against 21.64 ms).  The fill volume does not bound the gather form; the kernel was removed in round 5.)
 
 // grouped launch (see fsv_conv_igemm_group_kernel): up to FSV_GROUP_MAX independent problems in one 1-D grid
 struct HConvGroup {
@@ -1079,45 +913,6 @@ static int fsv_h_fill(HConvP& p, const fsv_hconv_desc& d) {
   return FSV_OK;
 }
 
-// ---- patch-resident form: tile ids 32 = 8x16 pixels x 128 channels, 33 = 16x16 x 64, 34 = 16x16 x 32 (4-wave workgroups) ----------
-static inline int fsv_h_patch_dims(int tile, int& th, int& tw, int& bn) {
-  switch (tile) {
-    case 32: th = 8; tw = 16; bn = 128; return 0;
-    case 33: th = 16; tw = 16; bn = 64; return 0;
-    case 34: th = 16; tw = 16; bn = 32; return 0;
-    default: return -1;
-  }
-}
-
-// the geometry the patch kernel covers: stride 1, output = input size, every tap within one pixel, whole 32-channel chunks, and
-// enough taps for its load schedule (the patch of the next chunk leaves one instruction per tap: up to six, landed two taps later)
-static inline bool fsv_h_patch_geometry(const fsv_hconv_desc& d) {
-  if (d.sy != 1 || d.sx != 1 || d.osy != 1 || d.osx != 1 || d.ooy != 0 || d.oox != 0) return false;
-  if (d.outH != d.OH || d.outW != d.OW || d.OH != d.H || d.OW != d.W || d.accumulate) return false;
-  if ((d.Cin & 31) != 0 || d.ntaps < 8) return false;
-  for (int t = 0; t < d.ntaps; ++t)
-    if (d.ty[t] < -1 || d.ty[t] > 1 || d.tx[t] < -1 || d.tx[t] > 1) return false;
-  return true;
-}
-
-// patch tile of a single launch, or -1: the plan above decides first (a launch it would split along K is too small for this form)
-static inline int fsv_h_patch_pick(const fsv_hconv_desc& d) {
-  // opt-in (FSV_HCONV_PATCH=1).  Measured in-box in round 4 (tools/h_ab.py, profiles/r04_notes.md): the form is correct and moves
-  // 2 - 4x fewer bytes from L2 to LDS, and it is SLOWER than the gather form on every layer shape of the two workloads (372 against
-  // 625 TFLOP/s on M32768 N128 K2304, 260 against 332 on M524288 N32 K576; the street --amp step 22.03 against 21.64 ms) - one
-  // barrier per 32 k with eight MFMAs per wave between barriers and two workgroups per CU.  The fill volume is not what bounds the
-  // gather form.
-  static int on = -1;
-  if (on < 0) { const char* e = getenv("FSV_HCONV_PATCH"); on = (e && e[0] == '1') ? 1 : 0; }
-  if (d.force_tile >= 32) return fsv_h_patch_geometry(d) ? d.force_tile : -2;
-  if (!on || d.force_tile >= 0 || d.force_split > 0 || !fsv_h_patch_geometry(d)) return -1;
-  const int tile = d.Cout <= 32 ? 34 : (d.Cout <= 64 ? 33 : 32);
-  int th, tw, bn;
-  fsv_h_patch_dims(tile, th, tw, bn);
-  const long long wgs = (long long)d.N * fsv_cdiv(d.OH, th) * fsv_cdiv(d.OW, tw) * fsv_cdiv(d.Cout, bn);
-  return wgs >= 256 ? tile : -1;
-}
-
 #define FSV_H_CASES(KERNEL, G, P)                                                                                     \
   switch (tile) {                                                                                                     \
     case 0: FSV_LAUNCH((KERNEL<128, 128, 2, 2, 3>), G, dim3(256), stream, P); break;                                  \
@@ -1139,13 +934,6 @@ static inline int fsv_h_patch_pick(const fsv_hconv_desc& d) {
 
 extern "C" {
 
-// the patch tile (32 .. 34) a single launch of this problem takes, or -1 (labels of the profiling layer)
-int fsv_hconv_patch_tile(const fsv_hconv_desc* d) {
-  if (!d) return -1;
-  const int t = fsv_h_patch_pick(*d);
-  return t >= 32 ? t : -1;
-}
-
 // n == 1: one launch (split-K allowed when d->ws is given or the output is fp32); n > 1: ONE grouped launch of independent problems
 // (no K splits; every problem as the tile the group's widest member takes).  Returns *produced = 1 when the statistics partials
 // were written (single launches only).
@@ -1161,13 +949,7 @@ int fsv_hconv_gather(const fsv_hconv_desc* d, int n, int* produced, hipStream_t 
     // a K split adds partial sums into a zeroed fp32 buffer: the output itself when it is fp32 and dense, else the workspace
     const bool can_split = !d->accumulate && p.dense_out && d->act != FSV_ACT_DLRELU && (!d->out_h || d->ws);
     int tile = 0, nsplit = 1;
-    const int ptile = fsv_h_patch_pick(d[0]);
-    if (ptile == -2) return FSV_ERR_UNSUPPORTED;
-    if (ptile >= 32) {
-      tile = ptile;
-    } else {
-      if (fsv_hconv_plan(p.Mz, d->Cout, p.nchunks, nsamp, d->force_tile, d->force_split, can_split ? 1 : 0, &tile, &nsplit)) return FSV_ERR_BAD_ARG;
-    }
+    if (fsv_hconv_plan(p.Mz, d->Cout, p.nchunks, nsamp, d->force_tile, d->force_split, can_split ? 1 : 0, &tile, &nsplit)) return FSV_ERR_BAD_ARG;
     if (nsplit > 1 && !can_split) nsplit = 1;
     p.nsplit = nsplit;
     void* final_out = p.out;
@@ -1182,19 +964,6 @@ int fsv_hconv_gather(const fsv_hconv_desc* d, int n, int* produced, hipStream_t 
       if (!d->stats_prezeroed)
         (void)hipMemsetAsync(d->stats, 0, (size_t)d->stats_groups * d->stats_slots * d->Cout * 2 * sizeof(double), stream);
       if (produced) *produced = 1;
-    }
-    if (tile >= 32) {
-      int th, tw, pbn;
-      if (fsv_h_patch_dims(tile, th, tw, pbn)) return FSV_ERR_BAD_ARG;
-      const int tiles_y = fsv_cdiv(d->OH, th), tiles_x = fsv_cdiv(d->OW, tw);
-      const int tiles_xy = (d->per_sample ? 1 : d->N) * tiles_y * tiles_x * fsv_cdiv(d->Cout, pbn);
-      const dim3 g(8 * fsv_cdiv(tiles_xy, 8), 1, nsamp);
-      switch (tile) {
-        case 32: FSV_LAUNCH((fsv_hconv_patch_kernel<8, 16, 128, 2, 2>), g, dim3(256), stream, p, tiles_y, tiles_x); break;
-        case 33: FSV_LAUNCH((fsv_hconv_patch_kernel<16, 16, 64, 4, 1>), g, dim3(256), stream, p, tiles_y, tiles_x); break;
-        default: FSV_LAUNCH((fsv_hconv_patch_kernel<16, 16, 32, 4, 1>), g, dim3(256), stream, p, tiles_y, tiles_x); break;
-      }
-      return fsv_check_launch();
     }
     int bm, bn;
     if (fsv_h_tile_dims(tile, bm, bn)) return FSV_ERR_BAD_ARG;

@@ -150,7 +150,6 @@ def eligible(cin, per_sample=False):
     return cin % 8 == 0
 
 
-H_PATCH_NAMES = {32: '8x16x128', 33: '16x16x64', 34: '16x16x32'}
 
 
 def gather_gemm_h(x, wh, kpad, nrows, cout, oh, ow, ty, tx, sy, sx, bias=None, res=None, act=ACT_NONE, scale=1.0,
@@ -224,12 +223,7 @@ def gather_gemm_h(x, wh, kpad, nrows, cout, oh, ow, ty, tx, sy, sx, bias=None, r
         d.stats, d.stats_groups, d.stats_slots = part.data_ptr(), groups, conv.STATS_SLOTS
         keep.append(part)
     produced = c_i(0)
-    ptile = int(getattr(lib.get_lib(), "fsv_hconv_patch_tile")(ctypes.byref(d))) if (dense and sy == 1 and sx == 1) else -1
-    if ptile >= 32:
-        label = 'fsv_hconv_patch_kernel<%s>' % H_PATCH_NAMES[ptile]
-        nsplit = 1
-    else:
-        label = 'fsv_hconv_kernel<%s>' % H_TILE_NAMES[tile & 15]
+    label = 'fsv_hconv_kernel<%s>' % H_TILE_NAMES[tile & 15]
     if profile.detail():
         label += ' M%d N%d K%d z%d split%d' % (mz, cout, nchunks * 64, nsamp, nsplit)
 

@@ -143,11 +143,6 @@ typedef struct fsv_hconv_desc {
   long long w_bstride, b_bstride;
 } fsv_hconv_desc;
 int fsv_hconv_gather(const fsv_hconv_desc* problems, int n, int* produced, fsv_stream_t stream);
-/* patch-resident form of a single launch (stride 1, taps within one pixel, Cin % 32 == 0, >= 8 taps: every 3x3 convolution and
- * its data gradient): the tile id it takes - 32 = 8x16 pixels x 128 channels, 33 = 16x16 x 64, 34 = 16x16 x 32 (force_tile of
- * fsv_hconv_desc accepts them) - or -1 when the launch goes through the gather form below.  Opt-in (FSV_HCONV_PATCH=1): measured
- * slower than the gather form on the layer shapes of both workloads (profiles/r04_notes.md). */
-int fsv_hconv_patch_tile(const fsv_hconv_desc* problem);
 /* tile id (0 = 128x128, 1 = 128x64, 2 = 128x32, 4 = 64x64, 9 = 64x128; + 16: two LDS buffers instead of three) and K split the
  * single launch will use; nchunks = ceil(taps * Cin / 64) */
 int fsv_hconv_plan(int Mz, int Cout, int nchunks, int nsamp, int force_tile, int force_split, int can_split, int* tile_out,

@@ -29,9 +29,6 @@ GEOMS = [  # n, cin, h, w, cout, k, stride, pad
 WG_GEOMS = [(2, 16, 21, 27, 136, 3, 2, 1), (1, 64, 8, 8, 64, 3, 1, 1), (1, 24, 30, 17, 40, 4, 2, 2), (3, 8, 9, 16, 200, 1, 1, 0)]
 BIG_GEOMS = [(2, 64, 64, 64, 128, 3, 1, 1), (2, 128, 32, 32, 256, 3, 2, 1), (1, 256, 16, 16, 512, 4, 2, 1), (2, 512, 16, 16, 64, 1, 1, 0),
              (1, 32, 96, 128, 32, 3, 1, 1)]
-# the patch-resident form (3x3, stride 1, Cin % 32 == 0): ragged patches on every side, several images, a ragged channel tile
-PATCH_GEOMS = [(2, 32, 19, 37, 72, 3, 1, 1), (1, 64, 8, 16, 128, 3, 1, 1), (1, 96, 33, 18, 40, 3, 1, 1), (3, 32, 5, 7, 32, 3, 1, 1)]
-PATCH_TILES = [32, 33, 34]
 FWD_TILES = [(-1, 0), (0, 1), (0, 3), (1, 1), (2, 1), (3, 1), (3, 2), (4, 2), (5, 1), (5, 3), (9, 1), (16, 1), (16, 2), (17, 1), (18, 1), (19, 1),
              (20, 3), (21, 2), (25, 1)]
 WGRAD_TILES = [(0, 0), (1, 1), (1, 3), (2, 2), (3, 1), (4, 1), (4, 2), (5, 1), (6, 1), (6, 2)]
@@ -87,29 +84,6 @@ def check_forward(device, geom, tile, split, out_half, seed=7000, res_half=None,
         close_half(name, y, ref)
     else:
         oc.assert_close(name, y, ref, TOL)
-
-
-def check_patch_dgrad(device, geom, tile, seed=9100):
-    """the data gradient of a 3x3 stride-1 convolution through the patch-resident form (taps flipped, half or fp32 output with the
-    LeakyReLU mask operand)"""
-    conv, hc = _mods()
-    n, cin, h, w, cout, k, s, p = geom
-    g = torch.Generator().manual_seed(seed + tile)
-    dy = _h(torch.randn(n, cout, h, w, generator=g))
-    wt = torch.randn(cout, cin, k, k, generator=g) * 0.2
-    ref = torch.nn.grad.conv2d_input((n, cin, h, w), _h(wt), dy, stride=s, padding=p)
-    geo = conv.Geom(k, k, s, p)
-    c = geo.dgrad_classes[0]
-    wf, _, _ = conv.prep_weight(wt.to(device), 1, geo, c['khs'], c['kws'], None)
-    wh, kpad, nrows = hc.prep_weight_h(wf)
-    for out_half in (True, False):
-        dx = hc.gather_gemm_h(hc.to_half_nhwc(dy.to(device)), wh, kpad, nrows, cin, h, w, c['ty'], c['tx'], 1, 1, out_half=out_half,
-                              force_tile=tile)
-        name = 'h patch dgrad tile %d half %d %s' % (tile, out_half, geom)
-        if out_half:
-            close_half(name, dx, ref)
-        else:
-            oc.assert_close(name, dx, ref, TOL)
 
 
 def check_wgrad(device, geom, tile, split, seed=8000):

@@ -24,26 +24,6 @@ def test_forward_tiles(emu_lib, tile, split):
     hc.check_forward(DEV, hc.GEOMS[4], tile, split, False, res_half=False)
 
 
-@pytest.mark.parametrize('tile', hc.PATCH_TILES)
-@pytest.mark.parametrize('gi', range(len(hc.PATCH_GEOMS)))
-def test_patch_resident_forward_and_dgrad(emu_lib, gi, tile):
-    """csrc/conv_h.hip fsv_hconv_patch_kernel: the input patch of a tile of output pixels goes to LDS once per 32 channels and the
-    nine taps step over it"""
-    geom = hc.PATCH_GEOMS[gi]
-    hc.check_forward(DEV, geom, tile, 0, True)
-    hc.check_forward(DEV, geom, tile, 0, False, res_half=(gi % 2 == 0))
-    if geom[4] % 32 == 0:              # (the data gradient's K runs over the convolution's output channels)
-        hc.check_patch_dgrad(DEV, geom, tile)
-
-
-def test_patch_form_declines_other_geometries(emu_lib):
-    lib = emu_lib
-    with pytest.raises(lib.FsvError):
-        hc.check_forward(DEV, hc.GEOMS[1], 32, 0, True)            # stride 2
-    with pytest.raises(lib.FsvError):
-        hc.check_forward(DEV, hc.GEOMS[0], 33, 0, True)            # 8 input channels
-
-
 def test_forward_half_residual_no_activation(emu_lib):
     hc.check_forward(DEV, hc.GEOMS[0], -1, 0, True, res_half=True, act=False)
 

@@ -38,16 +38,6 @@ def test_wgrad_tiles(hip_lib, tile, split):
     assert hc.check_wgrad(DEV, hc.BIG_GEOMS[1], tile, split)
 
 
-@pytest.mark.parametrize('tile', hc.PATCH_TILES)
-@pytest.mark.parametrize('gi', range(len(hc.PATCH_GEOMS) + 2))
-def test_patch_resident_forward_and_dgrad(hip_lib, gi, tile):
-    geom = (hc.PATCH_GEOMS + [(2, 64, 64, 64, 128, 3, 1, 1), (1, 32, 96, 128, 32, 3, 1, 1)])[gi]
-    hc.check_forward(DEV, geom, tile, 0, True)
-    hc.check_forward(DEV, geom, tile, 0, False, res_half=(gi % 2 == 0))
-    if geom[4] % 32 == 0:
-        hc.check_patch_dgrad(DEV, geom, tile)
-
-
 def test_group_and_stats(hip_lib):
     hc.check_group(DEV)
     hc.check_stats(DEV)

@@ -76,8 +76,6 @@ for name, n, cin, h, w, cout, k in shapes:
                     for _ in range(NREP):
                         hc.conv_forward_h(xh, wh, kp, nrows, cout, g, bias=b, out_half=False, stats={'groups': 1})
             graphs['h f +stats'] = gr
-        for t in ((32, 33, 34) if (k == 3 and cin % 32 == 0) else ()):          # the patch-resident form
-            graphs['t%d/s1' % t] = graph_of(lambda: hc.conv_forward_h(xh, wh, kp, nrows, cout, g, bias=b, act=conv.ACT_LRELU, out_half=True, force_tile=t))
         for t in ((0, 1, 2, 3, 4, 5, 9, 16, 17, 18, 19, 20, 21, 25) if 'tiles' in WHAT or 'epi' not in WHAT else ()):
             bn = {0: 128, 1: 64, 2: 32, 3: 128, 4: 64, 5: 128, 9: 128}[t & 15]
             if (bn == 128 and cout < 128) or (bn == 64 and cout < 64) or (bn == 32 and cout > 32):
