@@ -81,6 +81,17 @@ def half_twin(wt):
     return t
 
 
+def drop_half_side(t):
+    """A kernel is about to write into the EXISTING tensor t through its raw pointer (`out=` / `place=` / accumulate paths): that
+    does not bump t._version, so a half copy a producer left beside it (hconv.half_side_output: `_fsv_h16`, validated by version and
+    shape only) would silently go stale - drop it (round-4 advisor)."""
+    if getattr(t, '_fsv_h16', None) is not None:
+        try:
+            del t._fsv_h16
+        except AttributeError:
+            t._fsv_h16 = None
+
+
 def to_nhwc(x):
     """Return a tensor with the same logical NCHW shape whose memory is dense NHWC."""
     if x.dim() != 4:
@@ -435,6 +446,8 @@ def gather_gemm(x, wt, ldw, cout, oh, ow, ty, tx, sy, sx, bias=None, res=None, a
         out_h, out_w, osy, osx, ooy, oox = place
     if out is None:
         out = empty_nhwc(n, cout, out_h, out_w, x)
+    else:
+        drop_half_side(out)
     if res is not None:
         res = to_nhwc(res)
     lib.check_device(x, wt, bias, res, out, wscale)

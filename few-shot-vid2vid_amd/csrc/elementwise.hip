@@ -617,7 +617,10 @@ __global__ __launch_bounds__(256) void fsv_adaptive_avgpool_fwd_kernel(const flo
   }
 }
 
-// every input element collects dy / window size of the (at most 2 x 2) windows that contain it: no atomics
+// every input element collects dy / window size of the windows that contain it (no atomics).  ATen's rule - window oy covers
+// [floor(oy H / OH), ceil((oy + 1) H / OH)) - puts input row yy into the outputs floor(yy OH / H) ... ceil((yy + 1) OH / H) - 1: at
+// most two per axis when the map shrinks, ~OH / H + 1 when it GROWS (OH > H: discriminator.py:146,153 pool to fineSize / 8 whatever
+// the encoded map's size - with adaptive_D_layers = 3 and num_D = 2 the second scale's 33-pixel map is pooled UP to 64)
 __global__ __launch_bounds__(256) void fsv_adaptive_avgpool_bwd_kernel(const float* dy, float* dx, int N, int H, int W, int C, int OH,
                                                                        int OW) {
   const long long total = (long long)N * H * W * C;
@@ -628,13 +631,14 @@ __global__ __launch_bounds__(256) void fsv_adaptive_avgpool_bwd_kernel(const flo
     const int xx = (int)(r % W); r /= W;
     const int yy = (int)(r % H);
     const int n = (int)(r / H);
-    const int oy0 = (int)(((long long)yy * OH) / H), ox0 = (int)(((long long)xx * OW) / W);
+    const int oy_lo = (int)(((long long)yy * OH) / H), oy_hi = (int)((((long long)yy + 1) * OH + H - 1) / H) - 1;
+    const int ox_lo = (int)(((long long)xx * OW) / W), ox_hi = (int)((((long long)xx + 1) * OW + W - 1) / W) - 1;
     float acc = 0.f;
-    for (int oy = (oy0 > 0 ? oy0 - 1 : 0); oy <= oy0 + 1 && oy < OH; ++oy) {
+    for (int oy = oy_lo; oy <= oy_hi && oy < OH; ++oy) {
       int ys, ye;
       fsv_adapt_win(oy, H, OH, ys, ye);
       if (yy < ys || yy >= ye) continue;
-      for (int ox = (ox0 > 0 ? ox0 - 1 : 0); ox <= ox0 + 1 && ox < OW; ++ox) {
+      for (int ox = ox_lo; ox <= ox_hi && ox < OW; ++ox) {
         int xs, xe;
         fsv_adapt_win(ox, W, OW, xs, xe);
         if (xx < xs || xx >= xe) continue;
@@ -646,13 +650,13 @@ __global__ __launch_bounds__(256) void fsv_adaptive_avgpool_bwd_kernel(const flo
 }
 
 int fsv_adaptive_avgpool_fwd(const float* x, float* y, int N, int H, int W, int C, int OH, int OW, hipStream_t stream) {
-  if (!x || !y || N < 1 || H < 1 || W < 1 || C < 1 || OH < 1 || OW < 1 || OH > H || OW > W) return FSV_ERR_BAD_ARG;
+  if (!x || !y || N < 1 || H < 1 || W < 1 || C < 1 || OH < 1 || OW < 1) return FSV_ERR_BAD_ARG;
   FSV_LAUNCH(fsv_adaptive_avgpool_fwd_kernel, dim3(fsv_grid_for((long long)N * OH * OW * C)), dim3(256), stream, x, y, N, H, W, C, OH, OW);
   return fsv_check_launch();
 }
 
 int fsv_adaptive_avgpool_bwd(const float* dy, float* dx, int N, int H, int W, int C, int OH, int OW, hipStream_t stream) {
-  if (!dy || !dx || N < 1 || H < 1 || W < 1 || C < 1 || OH < 1 || OW < 1 || OH > H || OW > W) return FSV_ERR_BAD_ARG;
+  if (!dy || !dx || N < 1 || H < 1 || W < 1 || C < 1 || OH < 1 || OW < 1) return FSV_ERR_BAD_ARG;
   FSV_LAUNCH(fsv_adaptive_avgpool_bwd_kernel, dim3(fsv_grid_for((long long)N * H * W * C)), dim3(256), stream, dy, dx, N, H, W, C, OH, OW);
   return fsv_check_launch();
 }

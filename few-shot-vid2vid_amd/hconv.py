@@ -168,6 +168,7 @@ def gather_gemm_h(x, wh, kpad, nrows, cout, oh, ow, ty, tx, sy, sx, bias=None, r
         out = (empty_nhwc_h if out_half else empty_nhwc)(n, cout, out_h, out_w, x)
     else:
         out_half = out.dtype == torch.float16
+        conv.drop_half_side(out)          # (written through its raw pointer: a half copy beside it would go stale)
     if res is not None:
         res = to_nhwc(res)
     lib.check_device(x, wh, bias, res, out, wscale)

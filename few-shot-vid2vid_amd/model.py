@@ -384,7 +384,24 @@ def loss_backward(opt, losses, optimizer, loss_id):
             optimizer.step_stage2_early()
         networks.BackwardCut.finish_all()
         optimizer.step()
+    _order_behind_branch(losses, optimizer)
     return losses
+
+
+def _order_behind_branch(losses, optimizer):
+    """The discriminator step of an iteration with `early_generator` ran on a side stream: whoever reads the returned losses on
+    the caller's stream (train.py logs float(loss) right after loss_backward and synchronises only ITS stream) must come behind it.
+    One stream wait, no host synchronisation; the generator-mode pass was issued before this point and still runs next to the
+    step, and the branch stays open for the real-image pass (join_early).  Round-4 advisor finding."""
+    branch = getattr(losses[0], '_fsv_branch', None) if len(losses) and torch.is_tensor(losses[0]) else None
+    if branch is None or branch.stream is None:
+        branch = getattr(optimizer, '_fsv_branch', None)
+    if branch is not None and branch.stream is not None:
+        cur = torch.cuda.current_stream(branch.stream.device)
+        cur.wait_stream(branch.stream)
+        for t in losses:
+            if torch.is_tensor(t) and t.is_cuda:
+                t.record_stream(cur)
 
 
 def branch_of(losses, optimizer=None):

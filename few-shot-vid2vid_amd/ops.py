@@ -379,6 +379,15 @@ class _ConvFn(torch.autograd.Function):
                 raise ValueError("pre-padded convolution input with %d channels for a weight of %d" % (cin + cpad, cin))
         else:
             cpad = ((-cin) % 8 if half else (-cin) % 4) if not per_sample else 0
+        # x may be the (still unwritten) output of a held-back bn_s modulation (spade_into_conv): settle that BEFORE anything below
+        # reads or converts x - either this convolution issues both as one kernel (it then never reads x), or the modulation is
+        # launched now (round-4 advisor: with `--amp` and the unfused backward A/B switch the cast below used to read the unwritten
+        # fp32 tensor, the pointer comparison then failed and the modulation ran after its consumer)
+        st_wanted = bool(stats_groups and not per_sample)
+        site = _spade_pending_for(x)
+        if site is not None and not _spade_conv_s_fits(site, geom, per_sample, bias, res, act, scale, half, cpad, st_wanted, cout):
+            _spade_launch(site)
+            site = None
         ctx.x_half = x.dtype == torch.float16          # a half input (a producer that rounded at its store) gets a half gradient
         if x.dtype == torch.float16 and not half:
             x = _hconv.cast(x, torch.float32)
@@ -409,22 +418,15 @@ class _ConvFn(torch.autograd.Function):
             raise ValueError("residual add is only fused after a linear epilogue")
         if scale != 1.0 and act != ACT_NONE:
             raise ValueError("output scale is only fused with a linear epilogue")
-        st = dict(groups=stats_groups) if (stats_groups and not per_sample) else None
+        st = dict(groups=stats_groups) if st_wanted else None
         y = None
-        site = _spade_pending_for(x)
         if site is not None:
-            # x is the output of a held-back bn_s modulation (spade_into_conv): both in one kernel when it covers the geometry
-            if (geom.kh == 1 and geom.kw == 1 and geom.stride == 1 and geom.pad == 0 and not per_sample and b is None and
-                    res is None and act == ACT_NONE and scale == 1.0 and half == bool(site.get('f16')) and
-                    bool(site.get('half')) == bool(site.get('f16')) and cpad == 0 and st is None and
-                    lib.call_status("fsv_spade_conv_s_supported", site['dims'][2], cout, len(site['chs'])) == 1):
-                if half:          # the N-major half twin of the layout the half-precision convolution would read
-                    wh, kpad_h, _ = _conv.half_twin(wt)
-                    y = _spade_conv_s_launch(site, wh, kpad_h, cout, wscale, want_hs=any(ctx.needs_input_grad))
-                else:
-                    y = _spade_conv_s_launch(site, wt, ldw, cout, wscale, want_hs=any(ctx.needs_input_grad))
+            # x is the output of the held-back bn_s modulation and the fused kernel covers the pair (checked above)
+            if half:          # the N-major half twin of the layout the half-precision convolution would read
+                wh, kpad_h, _ = _conv.half_twin(wt)
+                y = _spade_conv_s_launch(site, wh, kpad_h, cout, wscale, want_hs=any(ctx.needs_input_grad))
             else:
-                _spade_launch(site)
+                y = _spade_conv_s_launch(site, wt, ldw, cout, wscale, want_hs=any(ctx.needs_input_grad))
         if y is None:
             y = conv_forward(x, wt, ldw, cout, geom, bias=b, res=res.detach() if res is not None else None, act=act,
                              scale=scale, per_sample=per_sample, wscale=wscale, stats=st)
@@ -946,6 +948,31 @@ def _spade_pending_for(x):
         _spade_launch(site)                 # somebody else's input: nothing to fuse with
         return None
     return site
+
+
+def _spade_conv_s_fits(site, geom, per_sample, bias, res, act, scale, half, cpad, st_wanted, cout):
+    """every condition of the fused bn_s -> conv_s launch (csrc/spade_conv.hip fsv_spade_conv_s_impl), evaluated from shapes alone
+    before anything is launched: the widths the kernel is instantiated for AND the per-launch limits the entry point checks (map
+    channels a multiple of 4 / 8, tensors below the 2 GiB descriptor range, even geometry behind a folded up-sampling) - a site
+    that passes here cannot come back FSV_ERR_UNSUPPORTED after the held-back modulation has been given up (round-4 advisor)"""
+    if not (geom.kh == 1 and geom.kw == 1 and geom.stride == 1 and geom.pad == 0 and not per_sample and bias is None and
+            res is None and act == ACT_NONE and scale == 1.0 and cpad == 0 and not st_wanted):
+        return False
+    f16 = bool(site.get('f16'))
+    if half != f16 or bool(site.get('half')) != f16:
+        return False
+    n, hw, c, _, w, up = site['dims']
+    chs = site['chs']
+    if lib.call_status("fsv_spade_conv_s_supported", c, cout, len(chs)) != 1:
+        return False
+    if any(ch < 1 or ch % (8 if f16 else 4) for ch in chs):
+        return False
+    lim = 2 ** 31
+    if hw * c * 4 > lim or any(hw * ch * 4 > lim for ch in chs):
+        return False
+    if up and (w < 2 or w % 2 or hw % w or (hw // w) % 2):
+        return False
+    return True
 
 
 def _spade_conv_s_launch(site, wt, ldws, cout, wscale, want_hs):

@@ -450,7 +450,7 @@ int fsv_maxpool2_bwd(const float* x, const float* dy, float* dx, int N, int H, i
  * (reference models/networks/discriminator.py:28,56), NHWC; output (H - 1) / 2 + 1 by (W - 1) / 2 + 1 */
 int fsv_avgpool3s2_fwd(const float* x, float* y, int N, int H, int W, int C, fsv_stream_t stream);
 int fsv_avgpool3s2_bwd(const float* dy, float* dx, int N, int H, int W, int C, fsv_stream_t stream);
-/* nn.AdaptiveAvgPool2d((OH, OW)) on NHWC tensors, OH <= H, OW <= W (discriminator.py:146,153: AdaptiveDiscriminator.gen_conv_weights);
+/* nn.AdaptiveAvgPool2d((OH, OW)) on NHWC tensors, any OH / OW - shrinking or growing (discriminator.py:146,153: AdaptiveDiscriminator.gen_conv_weights);
  * windows [floor(o in / out), ceil((o + 1) in / out)) as in ATen; the backward pass is a gather (no atomics) */
 int fsv_adaptive_avgpool_fwd(const float* x, float* y, int N, int H, int W, int C, int OH, int OW, fsv_stream_t stream);
 int fsv_adaptive_avgpool_bwd(const float* dy, float* dx, int N, int H, int W, int C, int OH, int OW, fsv_stream_t stream);

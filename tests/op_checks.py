@@ -840,11 +840,12 @@ def check_ordered_split(device, seed=93):
 
 def check_adaptive_avgpool(device, seed=92):
     """nn.AdaptiveAvgPool2d (AdaptiveDiscriminator.gen_conv_weights): windows that do not divide (33 -> 8), that do (32 -> 8),
-    identity, and a rectangular case"""
+    identity, a rectangular case, and maps that GROW (discriminator.py:146,153 pool to fineSize / 8 whatever the encoded map's
+    size: 33 -> 64 at the second scale with adaptive_D_layers = 3, a non-integer ratio, and growth on one axis only)"""
     ops, conv = pkg()
     g = torch.Generator().manual_seed(seed)
     for shp, out in [((2, 8, 33, 33), (8, 8)), ((1, 16, 32, 32), (8, 8)), ((2, 4, 8, 8), (8, 8)), ((1, 5, 17, 33), (4, 8)),
-                     ((1, 3, 9, 5), (1, 1))]:
+                     ((1, 3, 9, 5), (1, 1)), ((1, 4, 33, 33), (64, 64)), ((2, 3, 5, 7), (8, 16)), ((1, 2, 6, 20), (9, 4))]:
         x = torch.randn(*shp, generator=g)
         xr = x.clone().requires_grad_(True)
         ref = F.adaptive_avg_pool2d(xr, out)
@@ -1140,11 +1141,13 @@ def _check_spade_conv_s(device, ops, conv, n, c, cout, chs, h, w, up, grad, spec
     dy = torch.randn(n, cout, h, w, generator=g)
 
     def run(fused):
-        cl = lambda t: _dev(t, device).contiguous(memory_format=torch.channels_last)
+        # (fresh leaves per run: on the emulator `.to(device)` hands back the host tensor itself, and two runs that share leaves
+        # would add their gradients up in the same .grad)
+        cl = lambda t: _dev(t, device).detach().clone().contiguous(memory_format=torch.channels_last)
         xd = cl(x).requires_grad_(grad)
         md = [cl(m).requires_grad_(grad) for m in maps]
-        wd = [tuple(_dev(t, device).requires_grad_(grad) for t in ws) for ws in wts]
-        wc = _dev(wconv, device).requires_grad_(grad)
+        wd = [tuple(_dev(t, device).detach().clone().requires_grad_(grad) for t in ws) for ws in wts]
+        wc = _dev(wconv, device).detach().clone().requires_grad_(grad)
         rm, rv = _dev(torch.zeros(c), device), _dev(torch.ones(c), device)
         u, v = _dev(u0.clone(), device), _dev(v0.clone(), device)
         seen, real_call = [], lib.call
@@ -1185,6 +1188,33 @@ def _check_spade_conv_s(device, ops, conv, n, c, cout, chs, h, w, up, grad, spec
     if grad:
         for i, (a, b) in enumerate(zip(g1, g2)):
             assert_close('fused bn_s -> conv_s grad %d' % i, b, a, tol=2e-5)
+    # ... and the fused launch against the ORACLE directly (round-4 review: the comparison above holds the product to the product):
+    # normalization.py:37-52 + architecture.py:103-108 restated by oracle/fsv_oracle.py (spade, _sn_conv), in the `--amp` arithmetic
+    # (oracle/np_oracle.amp_conv2d: operands and the half-stored modulated tensor rounded once) when amp.  fp32: the kernels' fp32
+    # band; amp: two fp32 evaluations of the modulated value that straddle a half rounding boundary differ by a whole half ulp of it
+    # (5e-4 of ONE of the 64 - 128 terms of an output), and the gradient of a half-stored tensor is rounded to half on both sides.
+    from oracle import np_oracle
+    arith = (lambda: O.arithmetic(np_oracle.amp_conv2d)) if amp else contextlib.nullcontext
+    leaf = lambda t: t.detach().clone().requires_grad_(grad)
+    xr, mr = leaf(x), [leaf(m) for m in maps]
+    wr = [tuple(leaf(t) for t in ws) for ws in wts]
+    wcr = leaf(wconv)
+    fixed_r = [None if k == 0 else (wr[k][0], wr[k][2], wr[k][1], wr[k][3]) for k in range(len(chs))]
+    gen_r = ((wr[0][0], wr[0][2]), (wr[0][1], wr[0][3]))
+    sd = {'weight_orig': wcr, 'weight_u': u0.clone(), 'weight_v': v0.clone()}
+    with (contextlib.nullcontext() if grad else torch.no_grad()):
+        with arith():
+            x_in = F.interpolate(xr, scale_factor=2, mode='nearest') if up else xr
+            h_ref = O.spade(x_in, mr, fixed_r, gen_r)
+            y_ref = O._sn_conv(sd, '', h_ref, 1, 0, dx_half=True) if spectral else O._conv2d(h_ref, wcr, None, 1, 0, dx_half=True)
+            if grad:
+                (y_ref * dy).sum().backward()
+    otol = 3e-3 if amp else 2e-5
+    assert_close('fused bn_s -> conv_s output vs the oracle', y2, y_ref, tol=otol)
+    if grad:
+        refs = [xr.grad] + [m.grad for m in mr] + [t.grad for ws in wr for t in ws] + [wcr.grad]
+        for i, (a, b) in enumerate(zip(refs, g2)):
+            assert_close('fused bn_s -> conv_s grad %d vs the oracle' % i, b, a, tol=otol * 2)
 
 
 def check_conv_stats(device, seed=61):
