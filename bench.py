@@ -21,8 +21,10 @@ Besides the contract fields the JSON line carries
                  reference cannot travel to the GPU box) timed on the host cores on ONE iteration of the very same
                  workload (512x512, B = 2, same flags; rank 0, N=1 only);
   extras       - (N=1) measurements beside the headline: the north-star target (SPADE-generator forward at 512x512,
-                 batch 8, both flag sets, as fractions of the fp32 MFMA peak) and the step the reference's shipped
-                 script trains (scripts/pose/train_g1.sh: + face discriminator, VGG19 loss, FlowNet2 teacher).
+                 batch 8, both flag sets, as fractions of the fp32 MFMA peak), the step the reference's shipped
+                 script trains (scripts/pose/train_g1.sh: + face discriminator, VGG19 loss, FlowNet2 teacher), and BASELINE
+                 configs[4] per rank in its stated arithmetic (`--workload street --amp O1`, run as a child process: value + roofline
+                 against the f16 matrix peak).
 
 `--gpus N` with N > 1 and no WORLD_SIZE in the environment (a bare launch) re-executes itself through
 `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ...`: one rank per GPU either way.
@@ -254,6 +256,26 @@ def extras(device, size, steps=5):
     except Exception as e:              # noqa: BLE001
         out['shipped_step_face_d_vgg_flownet2'] = 'failed: %s' % str(e).split('\n')[0][:200]
     torch.cuda.empty_cache()
+    # ---- BASELINE configs[4] per rank in its stated arithmetic: street 1024x512, label_nc 35, `--amp O1` (fp16 MFMA path) -------
+    # the same script in a child process (the operand arithmetic is process-wide, like apex's amp.initialize): its own line,
+    # value + roofline against the f16 peak, so that the driver's default command records this configuration too
+    try:
+        import subprocess
+        cmd = [sys.executable, os.path.abspath(__file__), '--workload', 'street', '--amp', 'O1', '--steps', '10', '--warmup', '3',
+               '--no-cpu-baseline', '--no-extras']
+        pr = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
+        lines = [ln for ln in pr.stdout.splitlines() if ln.startswith('{')]
+        if pr.returncode != 0 or not lines:
+            raise RuntimeError('exit %d: %s' % (pr.returncode, (pr.stderr or pr.stdout).strip().split('\n')[-1][:160]))
+        d = json.loads(lines[-1])
+        keep = {k: d.get(k) for k in ('metric', 'value', 'unit', 'ms_per_step', 'dtype', 'steps', 'warmup', 'step_tflops')}
+        keep['config'] = d.get('config')
+        rf = d.get('roofline') or {}
+        keep['roofline'] = {k: rf.get(k) for k in ('kernel', 'bound', 'launches', 'gflop_per_launch', 'avg_launch_us', 'achieved', 'peak',
+                                                   'unit', 'frac', 'in_timed_schedule', 'traffic') if k in rf}
+        out['street_1024x512_nc35_amp_O1'] = keep
+    except Exception as e:              # noqa: BLE001
+        out['street_1024x512_nc35_amp_O1'] = 'failed: %s' % str(e).split('\n')[0][:200]
     return out
 
 
@@ -587,11 +609,36 @@ def main():
                     d['achieved'] = round(d['gflop_per_launch'] * 1e9 / t3 / 1e12, 2)
                     d['frac'] = round(d['achieved'] / d['peak'], 4)
                     d['timing'] = ('device-side time stamps (wall clock written by one-work-item kernels, csrc/stamp.hip) around every '
-                                   'launch of this kernel INSIDE a replayed hipGraph of the step, minus the cost of an empty stamp pair '
-                                   '(stamp_pair_us); eager_bracket_us / bracketed_us: HIP events around the launches in instrumented '
+                                   'launch of this kernel INSIDE a replayed hipGraph of the step captured on ONE stream, minus the cost '
+                                   'of an empty stamp pair (stamp_pair_us); in_timed_schedule: the same stamps in a capture with the side '
+                                   'streams ON - the schedule whose ms_per_step is the headline -, where the bracket of a launch also '
+                                   'holds the time its workgroups wait for / share the chip with the other branches\' kernels '
+                                   '(rocprofv3\'s per-dispatch duration in that schedule lies between the two: profiles/); '
+                                   'eager_bracket_us / bracketed_us: HIP events around the launches in instrumented '
                                    'eager passes (this kernel alone / every MFMA kernel bracketed); '
                                    'replay_us_warm_cache_upper_bound: the same launches re-issued back to back')
                 del g2
+                # ... and the same stamped capture in the schedule that was TIMED (side streams on; round-4 review item 7): both are
+                # reported, `frac` stays the one-stream figure (the kernel), `in_timed_schedule.frac` is the kernel + its neighbours
+                if forked and n3 == d['launches'] and full > empty > 0:
+                    prof.enable(only=dom, events=False)
+                    prof.stamp_begin(dom, int(d['launches']) + 8, device)
+                    try:
+                        g3 = torch.cuda.CUDAGraph()
+                        with torch.cuda.graph(g3):
+                            step()
+                    finally:
+                        st = prof.stamp_end()
+                        prof.disable()
+                    for _ in range(3):
+                        g3.replay()
+                    n4, full4, empty4 = prof.stamp_result(st)
+                    if n4 == d['launches'] and full4 > empty4 > 0:
+                        t4 = full4 - empty4
+                        a4 = d['gflop_per_launch'] * 1e9 / t4 / 1e12
+                        d['in_timed_schedule'] = dict(avg_launch_us=round(t4 * 1e6, 2), achieved=round(a4, 2),
+                                                      frac=round(a4 / d['peak'], 4), stamp_pair_us=round(empty4 * 1e6, 2))
+                    del g3
             except Exception as e:                      # noqa: BLE001 - the measurement must never cost the bench line
                 prof.stamp_end(); prof.disable()
                 print('stamped capture failed (%s); roofline priced on the eager brackets' % str(e).split('\n')[0], file=sys.stderr)
