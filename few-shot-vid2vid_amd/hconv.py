@@ -39,8 +39,15 @@ lib.register_sigs({
 
 # tests: called as _launch_hook(kind, info) behind every launch ('conv': x, wh, kpad, nrows, cout, oh, ow, ty, tx, sy, sx, bias, res,
 # act, scale, per_sample, place, wscale, out; 'wgrad': x, dout, geom, per_sample, dwt) - tests/model_checks.verify_half_launches
-# recomputes each launch of a real iteration from the same operands with plain torch
+# recomputes each launch of a real iteration from the same operands with plain torch.  Round 5: every other launch that produces a
+# half tensor or belongs to the `--amp` arithmetic reports too - 'side' (t, h: the half side output of norm-apply / norm-backward /
+# activation-backward), 'pack' (the packed half discriminator input), 'adam' (csrc/amp.hip: operands before, buffers after),
+# 'spade_fwd' / 'spade_bwd' / 'spade_conv_s' (the SPADE kernels on the f16 matrix instructions / with half tensors; ops.py)
 _launch_hook = None
+
+
+def launch_hook():
+    return _launch_hook
 
 H_TILE_NAMES = {0: '128x128', 1: '128x64', 2: '128x32', 3: '128x128w8', 4: '64x64', 5: '256x128w8', 9: '64x128'}
 
@@ -96,6 +103,8 @@ class half_side_output:
     def __exit__(self, et, ev, tb):
         if self.h is not None and et is None:
             self.t._fsv_h16 = (self.t._version, self.h)
+            if _launch_hook is not None:
+                _launch_hook('side', dict(t=self.t, h=self.h))
         return False
 
 

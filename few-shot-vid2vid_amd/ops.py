@@ -993,6 +993,8 @@ def _spade_conv_s_launch(site, wt, ldws, cout, wscale, want_hs):
                      lib.ptr(site['h']) if want_hs else None, lib.ptr(xs), len(chs), _pp(site['maps']), arr(site['wg']),
                      arr(site['wb']), arr(site['bg']), arr(site['bb']), lib.int_array(chs + [0]), _ll(site['wstr'] + [0]),
                      _ll(site['bstr'] + [0]), n, hw, c, 0, w, up, lib.ptr(wt), ldws, cout, lib.ptr(wscale), lib.stream_ptr())
+            if _hconv.launch_hook() is not None:
+                _hconv.launch_hook()('spade_conv_s', dict(site=site, wt=wt, cout=cout, wscale=wscale, xs=xs, want_hs=want_hs))
         else:
             lib.call("fsv_spade_conv_s_fwd", lib.ptr(site['x']), lib.ptr(site['mean']), lib.ptr(site['rstd']),
                      lib.ptr(site['h']) if want_hs else None, lib.ptr(xs), len(chs), _pp(site['maps']), arr(site['wg']),
@@ -1032,6 +1034,8 @@ def _spade_launch(a, b=None):
                          _pp(a['maps']), arr(a['wg']), arr(a['wb']), arr(a['bg']), arr(a['bb']), lib.int_array(chs + [0]),
                          _ll(a['wstr'] + [0]), _ll(a['bstr'] + [0]), n, hw, c, ldw, 0, a['act'], w, up,
                          1 | (4 if a.get('f16') else 0), lib.stream_ptr())
+                if _hconv.launch_hook() is not None:
+                    _hconv.launch_hook()('spade_fwd', dict(site=a))
             else:
                 lib.call("fsv_spade_mod_fwd", lib.ptr(a['x']), lib.ptr(a['mean']), lib.ptr(a['rstd']), lib.ptr(a['h']), len(chs),
                          _pp(a['maps']), arr(a['wg']), arr(a['wb']), arr(a['bg']), arr(a['bb']), lib.int_array(chs + [0]),
@@ -1251,6 +1255,10 @@ class _SpadeFn(torch.autograd.Function):
                              slots if dbsum is not None else 1, ctypes.c_longlong(n * nm * 2 * c), lib.stream_ptr())
                     if dbsum is not None:
                         dbsum = dbsum.sum(0, dtype=torch.float32) if slots > 1 else dbsum[0].float()
+                    if _hconv.launch_hook() is not None:
+                        _hconv.launch_hook()('spade_bwd', dict(x=x, mean=mean, rstd=rstd, dh=dh, maps=list(maps), prepped=list(prepped),
+                                                              per_sample=list(ctx.per_sample), dgbs=dgbs, dxhat=dxhat, dbsum=dbsum,
+                                                              act=ctx.act, up=up, f16=f16))
                 else:
                     lib.call("fsv_spade_mod_bwd", lib.ptr(x), lib.ptr(mean), lib.ptr(rstd), lib.ptr(dh), nm, _pp(maps), arr(wg_p),
                              arr(wb_p), arr(bg_p), arr(bb_p), lib.int_array(chs + [0]), _ll(wstr + [0]), _ll(bstr + [0]),
@@ -1528,10 +1536,15 @@ def amp_adam_step(param, grad, m, v, state, scaler, beta1, beta2, eps, gscale=1.
     grad * gscale / scale (skipped when a gradient is not finite), and apex's scale update - all on the device."""
     lib.check_device(param, grad, m, v, state, scaler)
     st = lib.stream_ptr()
+    hook = _hconv.launch_hook()
+    before = dict(param=param.clone(), m=m.clone(), v=v.clone(), state=state.clone(), scaler=scaler.clone()) if hook is not None else None
     lib.call("fsv_amp_check", lib.ptr(grad), grad.numel(), lib.ptr(scaler), st)
     lib.call("fsv_amp_adam", lib.ptr(param), lib.ptr(grad), lib.ptr(m), lib.ptr(v), lib.ptr(state), lib.ptr(scaler),
              param.numel(), float(beta1), float(beta2), float(eps), float(gscale), st)
     lib.call("fsv_amp_update", lib.ptr(scaler), st)
+    if hook is not None:
+        hook('adam', dict(before=before, param=param, grad=grad, m=m, v=v, state=state, scaler=scaler, beta1=float(beta1),
+                          beta2=float(beta2), eps=float(eps), gscale=float(gscale)))
 
 
 # ------------------------------------------------------------------------------------------------ losses / packing / masks
@@ -1696,6 +1709,8 @@ class _PackDFn(torch.autograd.Function):
                  h * w, _ll(_ncp_strides(ref)) if ref is not None else z3, _ll(_ncp_strides(lab)) if lab is not None else z3,
                  _ll(_ncp_strides(fake)), _ll(_ncp_strides(real)) if real is not None else z3, halves, cto, 1 if half else 0,
                  lib.stream_ptr())
+        if half and _hconv.launch_hook() is not None:
+            _hconv.launch_hook()('pack', dict(ref=ref, lab=lab, fake=fake, real=real, out=out, cto=cto))
         ctx.dims = (b, cr, cl, ci, h, w, cto)
         return out
 

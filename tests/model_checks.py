@@ -79,7 +79,7 @@ def _oracle_generator(sd0, cfg, label, ref_label, ref_image, dtype, loss_weights
     return sd, (img, flow, mask, warp)
 
 
-def _close_vs64(name, got, ref32, ref64, tol, floor=0.0):
+def _close_vs64(name, got, ref32, ref64, tol, floor=0.0, noise_factor=4.0):
     """|got - ref64| <= tol * scale + 4 * |ref32 - ref64|: the product has to be as close to the exact answer as the
     fp32 CPU reference itself is (the tiny test networks normalise over a handful of values and are ill-conditioned)."""
     got = got.detach().double().cpu()
@@ -87,8 +87,23 @@ def _close_vs64(name, got, ref32, ref64, tol, floor=0.0):
     noise = float((ref32.detach().double() - r64).abs().max())
     scale = max(float(r64.abs().max()), floor, 1e-12)
     err = float((got - r64).abs().max())
-    assert err <= tol * scale + 4.0 * noise, '%s: max|diff| %.3e > %.1e * %.3e + 4 * %.3e' % (name, err, tol, scale, noise)
+    assert err <= tol * scale + noise_factor * noise, '%s: max|diff| %.3e > %.1e * %.3e + %g * %.3e' % (name, err, tol, scale, noise_factor,
+                                                                                                      noise)
     return err / scale
+
+
+def _l2_vs64(name, got, ref32, ref64, tol, factor=2.0):
+    """statistical form of _close_vs64 for a free-running comparison in an arithmetic with rounding boundaries (`--amp`): the
+    product's relative L2 distance to the fp64 evaluation of the definition has to be within `factor` x the fp32 evaluation's own
+    (+ tol) - two correct fp32 evaluations are equally far from the exact answer in the L2 norm, whereas the max-abs distance is
+    decided by the single element that happened to cross a half rounding boundary.  Returns (distance, the fp32 oracle's)."""
+    r64 = ref64.detach().double()
+    scale = max(float(r64.norm()), 1e-30)
+    err = float((got.detach().double().cpu() - r64).norm()) / scale
+    noise = float((ref32.detach().double() - r64).norm()) / scale
+    assert err <= tol + factor * noise, '%s: relative L2 %.3e > %.1e + %.1f x %.3e (the fp32 oracle\'s own distance to fp64)' % (
+        name, err, tol, factor, noise)
+    return err, noise
 
 
 def check_generator(device, opt, b=2, tol=1e-3, grads=True, seed=7, ref64=True, grad_l2_band=None):
@@ -334,8 +349,10 @@ class verify_half_launches:
     not: identical inputs, so kernel and recomputation differ by the fp32 summation order only (`tol` relative to the launch's
     largest output; a half output in addition by one half ulp).  v.count = launches verified."""
 
+    KINDS = ('conv', 'wgrad', 'side', 'pack', 'adam', 'spade_fwd', 'spade_bwd', 'spade_conv_s')
+
     def __init__(self, tol=3e-5, every=1):
-        self.tol, self.every, self.count, self.seen, self.worst = tol, every, {'conv': 0, 'wgrad': 0}, 0, 0.0
+        self.tol, self.every, self.count, self.seen, self.worst = tol, every, {k: 0 for k in self.KINDS}, 0, 0.0
 
     def __enter__(self):
         from importlib import import_module
@@ -362,9 +379,141 @@ class verify_half_launches:
             cols.append(xp[:, :, pt + a: pt + a + (oh - 1) * sy + 1: sy, pl + b_: pl + b_ + (ow - 1) * sx + 1: sx])
         return torch.stack(cols, dim=1).permute(0, 3, 4, 1, 2)          # [n, oh, ow, taps, c]
 
+    # ---- round 5: the launches beside the gather-GEMMs (round-4 review: "not recomputed per launch in the full-size iteration") --
+    def _close(self, what, got, ref, half_out, tol=None, outliers=0.0):
+        """|got - ref| <= tol * max|ref| (+ one half ulp of |ref| where the kernel rounded its fp32 value to half at the store: the
+        recomputation's fp32 value may sit on the other side of a rounding boundary); outliers: admitted fraction of elements
+        beyond the band (only where a LeakyReLU kink decides an element - see the caller)"""
+        tol = self.tol if tol is None else tol
+        got, ref = got.float(), ref.float()
+        scale = max(float(ref.abs().max()), 1e-20)
+        err = (got - ref).abs()
+        lim = tol * scale + (2.0 ** -10 * 1.01 * ref.abs() if half_out else 0.0)
+        bad = int((err > lim).sum())
+        assert bad <= outliers * err.numel(), ('%s differs from its recomputation: max|diff| %.3e at scale %.3e (%d of %d elements beyond the band)'
+                                               % (what, float(err.max()), scale, bad, err.numel()))
+        if bad == 0:
+            self.worst = max(self.worst, float(((err - (lim - tol * scale)).clamp_min(0) / scale).max()))
+
+    @staticmethod
+    def _spade_terms(x, mean, rstd, maps, prepped, up, f16):
+        """xhat [n, c, H, W] and the (gamma | beta) tensors [n, 2c, H, W] of every map from the launch's own operands: maps and
+        weights as they lie in memory (half under the f16 GEMMs: exact products, fp32 sums), biases fp32"""
+        xf = x.float()
+        if up:
+            xf = torch.nn.functional.interpolate(xf, scale_factor=2, mode='nearest')
+        n, c = xf.shape[0], xf.shape[1]
+        xhat = (xf - mean.float().view(1, c, 1, 1)) * rstd.float().view(1, c, 1, 1)
+        gbs = []
+        for k, m in enumerate(maps):
+            w, bcat = prepped[3 * k], prepped[3 * k + 2]
+            ch = m.shape[1]
+            W = w.float()[:, :, :ch] if f16 else w.float()[:, :ch, :].transpose(1, 2)       # [nb, 2c, ch]
+            gb = torch.einsum('nkhw,nok->nohw', m.float(), W.expand(n, -1, -1)) + bcat.float().view(-1, 2 * c, 1, 1)
+            gbs.append(gb)
+        return xhat, gbs
+
+    @staticmethod
+    def _spade_chain(xhat, gbs, act):
+        c = xhat.shape[1]
+        h = xhat
+        for gb in gbs:
+            h = h * (1 + gb[:, :c]) + gb[:, c:]
+        if act == 1:
+            h = torch.nn.functional.leaky_relu(h, 0.2)
+        elif act != 0:
+            raise AssertionError('SPADE activation code %d' % act)
+        return h
+
+    def _other(self, kind, i):
+        if kind == 'side':                  # the half side copy IS one rounding of the fp32 tensor the same launch wrote
+            assert bool((i['h'] == i['t'].to(torch.float16)).all()), 'half side output is not the rounded fp32 result'
+        elif kind == 'pack':
+            parts = [t for t in (i['ref'], i['lab']) if t is not None]
+            rows = [torch.cat(parts + [i['fake']], dim=1)]
+            if i['real'] is not None:
+                rows.append(torch.cat(parts + [i['real']], dim=1))
+            ref = torch.cat(rows, dim=0)
+            ref = torch.nn.functional.pad(ref, (0, 0, 0, 0, 0, i['cto'] - ref.shape[1])).to(torch.float16)
+            assert i['out'].dtype == torch.float16 and bool((i['out'] == ref).all()), 'packed half discriminator input'
+        elif kind == 'adam':
+            b, g = i['before'], i['grad']
+            found = (not bool(torch.isfinite(g).all())) or float(b['scaler'][2]) != 0.0
+            sc0 = b['scaler'].double()
+            if found:
+                for k in ('param', 'm', 'v', 'state'):
+                    assert bool((i[k] == b[k]).all()), 'overflow step changed ' + k
+                assert float(i['scaler'][0]) == max(float(sc0[0]) * 0.5, float(sc0[5])) and float(i['scaler'][1]) == 0.0
+            else:
+                # the kernel's own fp32 sequence (csrc/amp.hip fsv_amp_adam_kernel; -ffp-contract=off: no fused multiply-adds), with
+                # the bias corrections the tick kernel left in `state`
+                t = float(b['state'][0]) + 1.0
+                f32 = lambda x: torch.tensor(float(x), dtype=torch.float32, device=g.device)
+                b1, b2, one = f32(i['beta1']), f32(i['beta2']), f32(1.0)
+                bc1, bc2, lr = i['state'][1], i['state'][2], b['state'][3]
+                assert abs(float(bc1) - (1.0 - i['beta1'] ** t)) <= 1e-6 and abs(float(bc2) - (1.0 - i['beta2'] ** t)) <= 1e-6 * max(1.0, t)
+                gs = f32(i['gscale']) / b['scaler'][0]
+                gg = g * gs
+                m1 = b1 * b['m'] + (one - b1) * gg
+                v1 = b2 * b['v'] + (one - b2) * gg * gg
+                p1 = b['param'] - (lr / bc1) * (m1 / (v1.sqrt() * (one / bc2.sqrt()) + f32(i['eps'])))
+                self._close('amp Adam m', i['m'], m1, False, 1e-6)
+                self._close('amp Adam v', i['v'], v1, False, 1e-6)
+                self._close('amp Adam param', i['param'], p1, False, 1e-6)
+                assert float(i['state'][0]) == t
+                good = float(sc0[1]) + 1.0
+                want = (min(float(sc0[0]) * 2.0, float(sc0[4])), 0.0) if good >= float(sc0[3]) else (float(sc0[0]), good)
+                assert (float(i['scaler'][0]), float(i['scaler'][1])) == want, (i['scaler'], want)
+            assert float(i['scaler'][2]) == 0.0
+        elif kind in ('spade_fwd', 'spade_conv_s'):
+            site = i['site']
+            n, hw, c, _, w, up = site['dims']
+            f16 = bool(site.get('f16'))
+            xhat, gbs = self._spade_terms(site['x'], site['mean'], site['rstd'], site['maps'], site['keep'], up, f16)
+            h = self._spade_chain(xhat, gbs, site['act'])
+            if kind == 'spade_fwd':
+                self._close('SPADE modulation (half store)', site['h'], h, site['h'].dtype == torch.float16)
+            else:
+                cout = i['cout']
+                if i['want_hs']:            # the modulated tensor as the training forward's side output, and as the 1x1's operand
+                    self._close('fused bn_s -> conv_s: modulated side output', site['h'], h, True)
+                    a = site['h'].float()
+                else:
+                    a = h.to(torch.float16).float()
+                wt = i['wt'].float()[0, :cout, :c]                                         # N-major half twin [nrows][Kpad]
+                xs = torch.einsum('nchw,oc->nohw', a, wt)
+                if i['wscale'] is not None:
+                    xs = xs * i['wscale'].float()
+                # without the side output the operand is the recomputation's own rounding of h: an element on a half rounding
+                # boundary moves ONE of the C terms of an output by half an ulp of it
+                self._close('fused bn_s -> conv_s: x_s', i['xs'], xs, False, self.tol if i['want_hs'] else 5e-4)
+        elif kind == 'spade_bwd':
+            f16 = bool(i['f16'])
+            with torch.enable_grad():
+                xhat, gbs = self._spade_terms(i['x'], i['mean'], i['rstd'], i['maps'], i['prepped'], i['up'], f16)
+                xhat = xhat.detach().requires_grad_(True)
+                gbs = [gb.detach().requires_grad_(True) for gb in gbs]
+                self._spade_chain(xhat, gbs, i['act']).backward(i['dh'].float())
+            # an element whose pre-activation lies within rounding of the LeakyReLU kink takes slope 1 on one side and 0.2 on the
+            # other: admitted for one element in 10^5 (their gradient is a legitimate fp32 evaluation either way)
+            self._close('SPADE backward twin: dxhat', i['dxhat'], xhat.grad, False, outliers=1e-5)
+            for k, (got, gb) in enumerate(zip(i['dgbs'], gbs)):
+                self._close('SPADE backward twin: d(gamma|beta) of map %d' % k, got, gb.grad, got.dtype == torch.float16, outliers=1e-5)
+                if i['dbsum'] is not None:
+                    want = gb.grad.double().sum(dim=(2, 3)) if i['per_sample'][k] else gb.grad.double().sum(dim=(0, 2, 3))
+                    have = i['dbsum'][:, k] if i['per_sample'][k] else i['dbsum'][0, k]
+                    self._close('SPADE backward twin: bias sums of map %d' % k, have, want, False, 2e-4)
+        else:
+            raise AssertionError('unknown half launch kind %r' % (kind,))
+        self.count[kind] += 1
+
     def _hook(self, kind, i):
         self.seen += 1
         if self.seen % self.every:
+            return
+        if kind not in ('conv', 'wgrad'):
+            with torch.no_grad():
+                self._other(kind, i)
             return
         with torch.no_grad():
             if kind == 'conv':
@@ -479,7 +628,7 @@ def check_amp_train_step(device, opt, b=1, tol=1e-3, grad_tol=1e-2, seed=21, los
             early_g = model(data_list, save_images=True, mode='generator')
         assert float(opt_D.scaler[0]) == loss_scale and float(opt_D.scaler[2]) == 0.0, opt_D.scaler      # no overflow at this scale
         for i, name in enumerate(('D_real', 'D_fake')):
-            _close_vs64(name, d_losses[i].view(1), r32[0][i].view(1), r64[0][i].view(1), tol)
+            _close_vs64(name, d_losses[i].view(1), r32[0][i].view(1), r64[0][i].view(1), tol, noise_factor=2.0)
         for p in model.netD.parameters():
             if p.grad is not None:
                 p.grad.div_(loss_scale)           # lr = 0: the step has run, the flat gradient buffer is only read below
@@ -488,10 +637,14 @@ def check_amp_train_step(device, opt, b=1, tol=1e-3, grad_tol=1e-2, seed=21, los
         g_losses = M.loss_backward(opt, g_losses, opt_G, 0)
         verifier.__exit__(None, None, None)
         assert verifier.count['conv'] >= 40 and verifier.count['wgrad'] >= 15, verifier.count       # the half kernels did run
+        # ... and so did every other producer of half tensors: SPADE on the f16 GEMMs forward + backward twin, half side outputs of
+        # the element-wise producers, the packed discriminator input, both optimisers' `--amp` Adam
+        cnt = verifier.count
+        assert cnt['spade_fwd'] >= 6 and cnt['spade_bwd'] >= 6 and cnt['side'] >= 10 and cnt['pack'] >= 2 and cnt['adam'] == 2, cnt
         assert float(opt_G.scaler[0]) == loss_scale and float(opt_G.scaler[2]) == 0.0, opt_G.scaler
         names = M.LOSS_NAMES_G
         for k in r32[2]:
-            _close_vs64(k, g_losses[names.index(k)].view(1), r32[2][k].view(1), r64[2][k].view(1), tol)
+            _close_vs64(k, g_losses[names.index(k)].view(1), r32[2][k].view(1), r64[2][k].view(1), tol, noise_factor=2.0)
         for p in model.netG.parameters():
             if p.grad is not None:
                 p.grad.div_(loss_scale)
@@ -500,12 +653,18 @@ def check_amp_train_step(device, opt, b=1, tol=1e-3, grad_tol=1e-2, seed=21, los
         for name, _ in model.netG.named_parameters():
             sd32.setdefault(name, _G(None)); sd64.setdefault(name, _G(None))
         worst = compare_grads_l2(model.netG, sd32, sd64, grad_tol)
-        img = _close_vs64('fake image', generated[0][:, 0], r32[4]['fake'], r64[4]['fake'], tol)
-        noise = float((r32[4]['fake'].detach().double() - r64[4]['fake'].detach().double()).abs().max())
+        # the free-running image: a STATISTICAL bar (round-4 review: the max-abs allowance of 4 x the definition's noise was as
+        # large as the signal) - relative L2 to the fp64 evaluation within 2 x the fp32 evaluation's own; what pins every launch
+        # is the per-launch recomputation above
+        img, noise = _l2_vs64('fake image', generated[0][:, 0], r32[4]['fake'], r64[4]['fake'], tol, factor=2.0)
+        img_max = float((generated[0][:, 0].detach().double().cpu() - r64[4]['fake'].detach().double()).abs().max())
+        noise_max = float((r32[4]['fake'].detach().double() - r64[4]['fake'].detach().double()).abs().max())
     finally:
         conv.set_mfma_mode(0)
-    print('amp step vs the definition: image %.2e (definition noise %.2e), worst gradient rel L2 G %.2e D %.2e; %d + %d half launches '
-          'recomputed from their own operands, worst %.1e' % (img, noise, worst, worst_d, verifier.count['conv'], verifier.count['wgrad'], verifier.worst))
+    print('amp step vs the definition: image rel L2 %.2e (the fp32 oracle\'s own: %.2e; max-abs %.2e vs %.2e), worst gradient rel L2 G %.2e '
+          'D %.2e; %d + %d half launches recomputed from their own operands, worst %.1e; other half launches recomputed: %s'
+          % (img, noise, img_max, noise_max, worst, worst_d, verifier.count['conv'], verifier.count['wgrad'], verifier.worst,
+             ', '.join('%s %d' % (k, v) for k, v in verifier.count.items() if k not in ('conv', 'wgrad'))))
     return worst
 
 

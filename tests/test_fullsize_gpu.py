@@ -127,17 +127,23 @@ def test_c5_street_1024x512_nc35_amp(hip_lib):
     """BASELINE.json configs[4] per rank in its stated arithmetic - `--amp O1`, fp16 MFMA (options/base_options.py:127,
     models/models.py:22-26, loss_collector.py:221-224): full width, W 1024 x H 512, 35 one-hot classes, one sample, full D step + G
     step of the product on the half-precision kernels (csrc/conv_h.hip) against a WHOLE-ITERATION run of the oracle in the same
-    arithmetic (oracle/np_oracle.amp_conv2d installed into oracle/fsv_oracle.py; same loss scale), summing in fp32 and in fp64 -
-    tolerances of the fp32 test above plus the definition's own fp32-vs-fp64 distance (model_checks.check_amp_train_step) - and
-    every half launch of the iteration recomputed from its own operands with plain torch (model_checks.verify_half_launches).
+    arithmetic (oracle/np_oracle.amp_conv2d installed into oracle/fsv_oracle.py; same loss scale), summing in fp32 and in fp64.
+    Two kinds of bars, both stated in model_checks.check_amp_train_step: (1) EVERY launch that computes in or stores half - the
+    gather-GEMMs forward / data / weight gradient, the SPADE kernels on the f16 matrix instructions forward and backward, the fused
+    bn_s -> conv_s kernel, the half side outputs of norm-apply / norm-backward / activation-backward, the packed discriminator
+    input, both `--amp` Adam steps - is recomputed from its OWN operands with plain torch and held to fp32 summation order (+ one
+    half ulp where the kernel rounds at its store): identical inputs, no allowance for the arithmetic's rounding boundaries
+    (model_checks.verify_half_launches); (2) the free-running iteration against the oracle as a STATISTICAL bar: image and
+    per-parameter gradients in the relative L2 norm within 2 x the fp32 oracle's own distance to its fp64 run (+ the fp32 test's
+    1e-3 / 1e-2), losses within 2 x that distance - two correct evaluations of an arithmetic with rounding boundaries are equally
+    far from the exact answer in L2, while any max-abs bar is decided by the one activation that crossed a boundary.
 
     *Parity unpinned against apex*: apex is neither vendored by the reference nor installable here and has no CPU path, so no
     reference output exists for this mode; the oracle states the definition (operands and half-stored activations rounded to
     IEEE half, exact products, fp32 accumulation, fp32 everywhere else) and this test pins the product to it."""
     opt = mc.make_opt(dataset_mode='fewshot_street', label_nc=35, input_nc=3, aspect_ratio=2.0, fineSize=1024, loadSize=1024,
                       batchSize=1, amp='O1')
-    worst = mc.check_amp_train_step(DEV, opt, b=1, tol=1e-3, grad_tol=1e-2)
-    assert worst < 0.5, worst
+    mc.check_amp_train_step(DEV, opt, b=1, tol=1e-3, grad_tol=1e-2)
 
 
 def test_c5_street_1024x512_nc35_amp_in_the_schedule_bench_py_runs(hip_lib):
@@ -146,6 +152,5 @@ def test_c5_street_1024x512_nc35_amp_in_the_schedule_bench_py_runs(hip_lib):
     the same whole-iteration oracle run, the same bars.  *Parity unpinned against apex* (see the test above)."""
     opt = mc.make_opt(dataset_mode='fewshot_street', label_nc=35, input_nc=3, aspect_ratio=2.0, fineSize=1024, loadSize=1024,
                       batchSize=1, amp='O1')
-    worst = mc.check_amp_train_step(DEV, opt, b=1, tol=1e-3, grad_tol=1e-2, bench_schedule=True)
-    assert worst < 0.5, worst
+    mc.check_amp_train_step(DEV, opt, b=1, tol=1e-3, grad_tol=1e-2, bench_schedule=True)
 
