@@ -291,12 +291,61 @@ def warp_taps():
     torch.save(cases, os.path.join(OUT, 'warp_taps.pt'))
 
 
+# ---- `--amp O1`: which operations a half-precision policy casts ---------------------------------------------------------------------
+# apex (models/models.py:22-26) is neither vendored nor installable, so the `--amp` arithmetic of the oracle (oracle/np_oracle.py)
+# cannot be pinned to it.  What CAN be pinned is its cast list: apex O1 patches torch functions by white / black lists
+# (apex/amp/lists/functional_overrides.py: conv*, linear, matmul-family in half; losses, softmax, norms, pointwise transcendental ops
+# in fp32) and torch.autocast is that policy's descendant inside torch itself.  This fixture runs the UNMODIFIED reference modules
+# under torch.autocast('cpu', dtype=torch.float16) and records, per aten operation, the dtype it ran in, and for every convolution /
+# linear / batched product its weight shape - tests/test_golden.py::test_amp_cast_list_against_torch_autocast compares the oracle's
+# cast list with it.
+AUTOCAST_CONFIGS = {
+    'street': ('--dataset_mode fewshot_street --label_nc 35 --fineSize 64 --loadSize 64 --adaptive_spade --no_flow_gt --no_vgg_loss '
+               '--gpu_ids -1 --ngf 16 --ndf 16 --batchSize 1 --n_downsample_G 3 --n_adaptive_layers 2'),
+    'pose_combine': ('--dataset_mode fewshot_pose --aspect_ratio 1 --fineSize 64 --loadSize 64 --adaptive_spade --warp_ref '
+                     '--spade_combine --remove_face_labels --no_flow_gt --no_vgg_loss --gpu_ids -1 --ngf 16 --ndf 16 --nff 16 '
+                     '--batchSize 1 --n_downsample_G 3 --n_adaptive_layers 2'),
+}
+
+
+def autocast_ops():
+    import model_checks as mc
+    ref_import.install_shims()
+    res = {}
+    for name, flags in AUTOCAST_CONFIGS.items():
+        opt, model = ref_import.build_model(flags.split())
+        mc.fill_state(model.netG)
+        mc.fill_state(model.netD)
+        nl = opt.label_nc if opt.label_nc != 0 else opt.input_nc
+        h, w = int(opt.fineSize / opt.aspect_ratio), opt.fineSize
+        b = opt.batchSize
+        if 'street' in opt.dataset_mode:
+            tl, ti, rl, ri = mc.synth_street_inputs(b, h, w, 4242, opt.label_nc)
+        else:
+            tl, ti, rl, ri = mc.synth_pose_inputs(b, h, w, 4242, nl)
+        data = [tl, ti, [None, None], [None, None], rl, ri, None, None, None]
+        from oracle.op_census import census_mode
+        cen = census_mode()
+        with torch.autocast('cpu', dtype=torch.float16):
+            with cen:
+                model(data, save_images=True, mode='generator')          # G forward, D forward on (real, fake), every loss
+        res[name] = dict(flags=flags, torch=torch.__version__, ops=cen.ops,
+                         convs=sorted(cen.convs), mms=sorted(cen.mms, key=repr))
+        half = sum(1 for c in cen.convs if c[2] == 'float16')
+        print(name, 'convolutions:', len(cen.convs), 'in half:', half, '| matrix products:', len(cen.mms),
+              '| fp32 ops:', sorted(k for k, v in cen.ops.items() if 'float32' in v))
+    with open(os.path.join(OUT, 'autocast_ops.json'), 'w') as f:
+        json.dump(res, f, indent=0, sort_keys=True)
+
+
 if __name__ == '__main__':
     os.makedirs(OUT, exist_ok=True)
     if len(sys.argv) > 1:                # mint only the named step cases (keeps the other fixtures byte-identical)
         for n in sys.argv[1:]:
             if n == 'flownet2':
                 flownet2()
+            elif n == 'autocast_ops':
+                autocast_ops()
             elif n.startswith('finetune:'):
                 finetune(n[9:], CONFIGS[n[9:]])
             elif n.startswith('inference:'):
@@ -316,4 +365,5 @@ if __name__ == '__main__':
     warp_taps()
     flownet2()
     finetune('pose_combine', CONFIGS['pose_combine'])
+    autocast_ops()
     print('goldens written to', OUT)

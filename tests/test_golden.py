@@ -406,3 +406,76 @@ def test_product_finetune_emu(emu_lib):
 @pytest.mark.gpu
 def test_product_finetune_on_gpu(hip_lib):
     _check_product_finetune(torch.device('cuda:0'))
+
+
+# ------------------------------------------------------------------------------------------------ `--amp O1`: the cast list
+@pytest.mark.parametrize('name', ['street', 'pose_combine'])
+def test_amp_cast_list_against_torch_autocast(name):
+    """*Parity unpinned vs apex* (not vendored, not installable, no CPU path) - but the CAST LIST of the `--amp O1` definition
+    (oracle/np_oracle.amp_conv2d installed into oracle/fsv_oracle.py) is pinned here against torch's own half-precision cast policy:
+    tests/golden/autocast_ops.json records, for the UNMODIFIED reference modules run under torch.autocast('cpu', float16)
+    (oracle/make_golden.py autocast_ops), which aten operations ran in half and which in fp32.  apex O1 patches torch functions by
+    the same kind of white / black lists (convolutions, linear and the matmul family in half; losses, norms of vectors, pooling,
+    grid_sample in fp32) - torch.autocast is that policy inside torch.
+
+    What is asserted: (1) the oracle executes the same contraction layers as the reference (multiset of convolution weight shapes
+    and of matrix products); (2) every convolution the definition runs on half operands is one autocast runs in half - the
+    definition never narrows what the policy keeps in fp32; (3) what autocast runs in half and the definition keeps in fp32 is
+    exactly the documented set: convolutions the half kernels' contract does not cover (output channels not a multiple of 8 -
+    image / flow / mask heads, the discriminators' one-channel output -, per-sample products whose input channels are not a
+    multiple of 8, SPADE layers below 16 normalised / 8 map channels) and the nn.Linear weight generators (generator.py:103-110),
+    i.e. places where the definition is MORE precise; (4) every operation on the policy's fp32 side that occurs on this path
+    (spectral-norm power iteration, loss reductions, grid_sample, pooling) is fp32 in the definition too - it computes nothing
+    but the routed convolutions in half; (5) element-wise / normalisation operations that autocast runs in half only because
+    their INPUT arrived as half (batch_norm, leaky_relu, add, mul, upsample, tanh ...) are fp32 in the definition (it keeps
+    convolution outputs fp32, like the product's kernels: fp32 accumulator and epilogue) - listed, not asserted equal."""
+    from collections import Counter
+    from oracle import np_oracle as NO
+    from oracle.op_census import census_mode
+    with open(os.path.join(GOLD, 'autocast_ops.json')) as f:
+        gold = json.load(f)[name]
+    opt = _opt_from_flags(gold['flags'])
+    model = mc._model().create_model(opt)
+    sdG, sdD = mc.fill_state(model.netG), mc.fill_state(model.netD)
+    nl = opt.label_nc if opt.label_nc != 0 else opt.input_nc
+    h, w = int(opt.fineSize / opt.aspect_ratio), opt.fineSize
+    b = opt.batchSize
+    data = mc.synth_street_inputs(b, h, w, 4242, opt.label_nc) if opt.label_nc != 0 else mc.synth_pose_inputs(b, h, w, 4242, nl)
+    cfg = O.cfg_from_opt(opt)
+    routed = []            # (weight shape, ran on half operands) of every convolution the installed arithmetic was asked for
+
+    def recording(x, wt, bias, stride, padding, dx_half=False, per_sample=False):
+        cout, cin = wt.shape[0], wt.shape[1]
+        routed.append((tuple(wt.shape), int(stride), not (cout % 8 != 0 or (per_sample and cin % 8 != 0))))
+        return NO.amp_conv2d(x, wt, bias, stride, padding, dx_half, per_sample)
+    cen = census_mode()
+    with torch.no_grad(), O.arithmetic(recording), cen:
+        O.g_step_losses(sdG, sdD, cfg, *data)
+    # (1) the same layers
+    key = lambda c: (tuple(c[0]), int(c[1]))
+    ref_convs = Counter(key(c) for c in gold['convs'])
+    ours_all = Counter(key(c) for c in cen.convs)
+    assert ours_all == ref_convs, (ours_all - ref_convs, ref_convs - ours_all)
+    ref_mm = Counter(repr(m[1]) for m in gold['mms'])
+    ours_mm = Counter(repr(m[1]) for m in cen.mms)
+    assert ours_mm == ref_mm, (ours_mm - ref_mm, ref_mm - ours_mm)
+    # (2) half in the definition -> half under autocast
+    auto_half = Counter(key(c) for c in gold['convs'] if c[2] == 'float16')
+    ours_half = Counter((shape, st) for shape, st, half in routed if half)
+    assert not (ours_half - auto_half), ours_half - auto_half
+    # (3) the complement is the documented set
+    kept_fp32 = auto_half - ours_half
+    for (shape, st), n in kept_fp32.items():
+        cout, cin = shape[0], shape[1]
+        assert cout % 8 != 0 or cin % 8 != 0 or shape[2:] == (1, 1), ('the definition keeps %s fp32 without a stated reason' % (shape,))
+    assert all(m[2] == 'float16' for m in gold['mms'])                  # autocast: every nn.Linear in half ...
+    assert all(d == {'float32': n} for k, v in cen.ops.items() if k in ('addmm', 'mm', 'bmm') for d, n in [(v, sum(v.values()))])   # ... the definition: fp32
+    # (4) the policy's fp32 side
+    for op, dt in gold['ops'].items():
+        if set(dt) == {'float32'} and op in cen.ops:
+            assert set(cen.ops[op]) == {'float32'}, (op, cen.ops[op])
+    for op in ('grid_sampler_2d', 'mv', 'dot', 'linalg_vector_norm', 'abs', 'avg_pool2d'):
+        if op in gold['ops']:
+            assert set(gold['ops'][op]) == {'float32'}, (op, gold['ops'][op])
+    # (5) everything that is not a routed convolution is fp32 in the definition
+    assert all(set(v) <= {'float32'} for k, v in cen.ops.items() if k != 'convolution'), {k: v for k, v in cen.ops.items() if set(v) - {'float32'}}
