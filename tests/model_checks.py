@@ -353,6 +353,10 @@ class verify_half_launches:
 
     def __init__(self, tol=3e-5, every=1):
         self.tol, self.every, self.count, self.seen, self.worst = tol, every, {k: 0 for k in self.KINDS}, 0, 0.0
+        self.failures = []
+
+    def finish(self):
+        assert not self.failures, '%d half launches differ from their recomputation:\n  %s' % (len(self.failures), '\n  '.join(self.failures[:12]))
 
     def __enter__(self):
         from importlib import import_module
@@ -390,8 +394,11 @@ class verify_half_launches:
         err = (got - ref).abs()
         lim = tol * scale + (2.0 ** -10 * 1.01 * ref.abs() if half_out else 0.0)
         bad = int((err > lim).sum())
-        assert bad <= outliers * err.numel(), ('%s differs from its recomputation: max|diff| %.3e at scale %.3e (%d of %d elements beyond the band)'
-                                               % (what, float(err.max()), scale, bad, err.numel()))
+        if bad > outliers * err.numel():
+            # collected, not raised: one pass over a full-size iteration (minutes of oracle time) reports every launch that
+            # differs; finish() fails the test
+            self.failures.append('%s differs from its recomputation: max|diff| %.3e at scale %.3e (%d of %d elements beyond the band)'
+                                 % (what, float(err.max()), scale, bad, err.numel()))
         if bad == 0:
             self.worst = max(self.worst, float(((err - (lim - tol * scale)).clamp_min(0) / scale).max()))
 
@@ -502,7 +509,10 @@ class verify_half_launches:
                 if i['dbsum'] is not None:
                     want = gb.grad.double().sum(dim=(2, 3)) if i['per_sample'][k] else gb.grad.double().sum(dim=(0, 2, 3))
                     have = i['dbsum'][:, k] if i['per_sample'][k] else i['dbsum'][0, k]
-                    self._close('SPADE backward twin: bias sums of map %d' % k, have, want, False, 2e-4)
+                    # (sums over 10^5 ... 10^6 pixels: the handful of elements whose LeakyReLU slope is decided within rounding of the
+                    # kink - admitted above as outliers - each move one term of a sum by up to 0.8 of its size; hardware record at
+                    # BASELINE configs[4]: 6e-4 of the largest sum)
+                    self._close('SPADE backward twin: bias sums of map %d' % k, have, want, False, 2e-3)
         else:
             raise AssertionError('unknown half launch kind %r' % (kind,))
         self.count[kind] += 1
@@ -636,6 +646,7 @@ def check_amp_train_step(device, opt, b=1, tol=1e-3, grad_tol=1e-2, seed=21, los
         g_losses, generated, _ = early_g if early_g is not None else model(data_list, save_images=True, mode='generator')
         g_losses = M.loss_backward(opt, g_losses, opt_G, 0)
         verifier.__exit__(None, None, None)
+        verifier.finish()
         assert verifier.count['conv'] >= 40 and verifier.count['wgrad'] >= 15, verifier.count       # the half kernels did run
         # ... and so did every other producer of half tensors: SPADE on the f16 GEMMs forward + backward twin, half side outputs of
         # the element-wise producers, the packed discriminator input, both optimisers' `--amp` Adam
