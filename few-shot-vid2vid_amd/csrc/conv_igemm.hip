@@ -495,6 +495,48 @@ __device__ __forceinline__ void fsv_conv_igemm_body(const ConvP& p, const int bx
       }
     }
   }
+  // ---- ordered split-K without a finishing launch (round 5): every split of a tile has stored its partial copy above; the workgroup
+  // that takes the tile's last ticket sums the copies - ALL of them from memory, its own included, in ascending split order: the same
+  // bits whichever workgroup comes last - and applies the epilogue.  The pattern of the fused reductions (norm.hip): device-scope
+  // fence, ticket, fence.  Split-K grids are small by construction (the plan splits when the tiles do not fill the chip), so the
+  // fence per workgroup that cost 10 ms when EVERY convolution paid it (round 3) is a few hundred workgroups per launch here.
+  if (p.nsplit > 1 && p.part && p.tickets) {          // uniform
+    __shared__ int s_last;
+    __threadfence();
+    __syncthreads();
+    if (tid == 0) {
+      const int gx = (p.Mz + BM - 1) / BM, gy = (p.Cout + BN - 1) / BN;
+      int* t = p.tickets + ((long long)zs * gy + by) * gx + bx;
+      const int prev = atomicAdd(t, 1);
+      s_last = (prev == p.nsplit - 1) ? 1 : 0;
+      if (s_last) *t = 0;                              // nobody else touches it any more: ready for the next launch
+    }
+    __syncthreads();
+    if (!s_last) return;
+    __threadfence();                                   // acquire: the other splits' copies
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int co = bn0 + wn * (TN * 32) + j * 32 + lrow;
+      if (co >= p.Cout) continue;
+      const float bvf = bias ? bias[co] : 0.f;
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = (r & 3) + 8 * (r >> 2) + 4 * lk;
+          const int m = bm0 + wm * (TM * 32) + i * 32 + row;
+          if (m >= p.Mz) continue;
+          const long long e = out_pixel(m) * p.Cout + co;
+          float v = p.part[e];
+          for (int k = 1; k < p.nsplit; ++k) v += p.part[(long long)k * p.part_stride + e];
+          if (bias) v += bvf;
+          v = fsv_act(v * p.scale, p.act);
+          if (p.res) v += p.res[e];
+          p.out[e] = v;
+        }
+      }
+    }
+  }
 }
 
 // XCD bands (round 4; the half-precision kernel's order, conv_h.hip): XCD x - the workgroups with linear id b % 8 == x - owns the
@@ -1741,6 +1783,14 @@ extern "C" int fsv_conv_plan(int Mz, int Cout, int nchunks, int nsamp, int force
   return 0;
 }
 
+// number of tickets (output tiles over all samples) a split launch of this shape needs, 0 when the plan does not split
+extern "C" int fsv_conv_split_tiles(int Mz, int Cout, int nchunks, int nsamp, int force_tile, int force_split) {
+  int tile = 0, nsplit = 1, bm, bn;
+  if (fsv_conv_plan(Mz, Cout, nchunks, nsamp, force_tile, force_split, &tile, &nsplit) || nsplit <= 1) return 0;
+  if (fsv_tile_dims(tile, bm, bn)) return 0;
+  return fsv_cdiv(Mz, bm) * fsv_cdiv(Cout, bn) * nsamp;
+}
+
 // XCD order of the single-problem launches: 1 = bands (fsv_xcd_band), 0 = interleaved (fsv_xcd_tile); FSV_CONV_BAND: in-box A/B
 static inline int fsv_conv_band() {
   static int v = -1;
@@ -1766,7 +1816,7 @@ static inline void fsv_fill_convp(ConvP& p, const float* in, const float* wt, co
   p.Mz = per_sample ? OH * OW : N * OH * OW;
   p.nsplit = 1;
   p.stats = nullptr; p.stats_slots = 1; p.stats_ohw = 1;
-  p.part = nullptr; p.part_stride = 0;
+  p.part = nullptr; p.part_stride = 0; p.tickets = nullptr;
   p.band = fsv_conv_band();
   {
     const long long obytes = (long long)N * outH * outW * Cout * 4;
@@ -1786,7 +1836,7 @@ static int fsv_conv_gather_impl(const float* in, const float* wt, const float* b
                         int ldw, long long w_bstride, long long b_bstride, int per_sample,
                         int act, float scale, int force_tile, int force_split, int accumulate, const float* wscale,
                         double* stats, int stats_groups, int stats_slots, int stats_prezeroed, int* produced,
-                        float* split_ws, long long split_cap, hipStream_t stream) {
+                        float* split_ws, long long split_cap, int* split_tickets, hipStream_t stream) {
   if (!in || !wt || !out || ntaps < 1 || ntaps > 16 || N < 1 || Cin < 1 || Cout < 1) return FSV_ERR_BAD_ARG;
   for (int t = 0; t < ntaps; ++t)
     if (ty[t] < -8 || ty[t] > 7 || tx[t] < -8 || tx[t] > 7) return FSV_ERR_UNSUPPORTED;
@@ -1832,6 +1882,7 @@ static int fsv_conv_gather_impl(const float* in, const float* wt, const float* b
     if (!p.dense_out) return FSV_ERR_UNSUPPORTED;
     if (split_ws && (Cin % 4 == 0) && split_cap >= (long long)nsplit * total) {
       p.part = split_ws; p.part_stride = total;         // ordered: one copy of the output per split, summed by the finishing pass
+      p.tickets = split_tickets;                        // ... or, with tickets, by the tile's last workgroup (no finishing launch)
     } else {
       (void)hipMemsetAsync(out, 0, (size_t)total * sizeof(float), stream);
     }
@@ -1850,7 +1901,7 @@ static int fsv_conv_gather_impl(const float* in, const float* wt, const float* b
   if (force_tile < 0 && vec4) tile = fsv_conv_variant(tile);
   int rc = fsv_launch_conv(p, vec4, nsamp * nsplit, stream, tile);
   if (rc) return rc;
-  if (!accumulate && nsplit > 1 && (p.part || bias || res || act != FSV_ACT_NONE || scale != 1.f)) {
+  if (!accumulate && nsplit > 1 && !(p.part && p.tickets) && (p.part || bias || res || act != FSV_ACT_NONE || scale != 1.f)) {
     int grid = (int)((total + 256 * 8 - 1) / (256 * 8));
     if (grid > 4096) grid = 4096;
     if (grid < 1) grid = 1;
@@ -1868,18 +1919,21 @@ static int fsv_conv_gather_impl(const float* in, const float* wt, const float* b
 extern "C" {
 
 // split_ws / split_ws_floats (nullable): ordered split-K - when the plan splits K, split k stores its partial output into the k-th
-// copy inside split_ws (nsplit x N*outH*outW*Cout floats) and a finishing pass sums the copies in ascending order (the same bits on
-// every run, no zero fill, no atomics); a call that does not split, or whose copies do not fit, ignores the workspace.
+// copy inside split_ws (nsplit x N*outH*outW*Cout floats) and the copies are summed in ascending order (the same bits on every run,
+// no zero fill, no atomics on the data); a call that does not split, or whose copies do not fit, ignores the workspace.
+// split_tickets (nullable, with split_ws): zeroed ints, one per output tile (fsv_conv_split_tiles) - the workgroup that arrives last
+// at a tile sums and finishes it, and leaves the ticket zeroed again; null: a finishing launch does.
 int fsv_conv_gather_fwd(const float* in, const float* wt, const float* bias, const float* res, float* out,
                         int N, int H, int W, int Cin, int OH, int OW, int Cout,
                         int ntaps, const int* ty, const int* tx, int sy, int sx,
                         int outH, int outW, int osy, int osx, int ooy, int oox,
                         int ldw, long long w_bstride, long long b_bstride, int per_sample,
                         int act, float scale, int force_tile, int force_split, int accumulate, const float* wscale,
-                        float* split_ws, long long split_ws_floats, hipStream_t stream) {
+                        float* split_ws, long long split_ws_floats, int* split_tickets, hipStream_t stream) {
   return fsv_conv_gather_impl(in, wt, bias, res, out, N, H, W, Cin, OH, OW, Cout, ntaps, ty, tx, sy, sx, outH, outW, osy, osx,
                               ooy, oox, ldw, w_bstride, b_bstride, per_sample, act, scale, force_tile, force_split, accumulate,
-                              wscale, nullptr, 0, 0, 0, nullptr, split_ws, split_ws ? split_ws_floats : 0, stream);
+                              wscale, nullptr, 0, 0, 0, nullptr, split_ws, split_ws ? split_ws_floats : 0,
+                              split_ws ? split_tickets : nullptr, stream);
 }
 
 int fsv_conv_gather_fwd_stats(const float* in, const float* wt, const float* bias, const float* res, float* out,
@@ -1887,11 +1941,11 @@ int fsv_conv_gather_fwd_stats(const float* in, const float* wt, const float* bia
                               int ntaps, const int* ty, const int* tx, int sy, int sx,
                               int ldw, int act, float scale, const float* wscale,
                               double* stats, int stats_groups, int stats_slots, int stats_prezeroed, int* produced,
-                              float* split_ws, long long split_ws_floats, hipStream_t stream) {
+                              float* split_ws, long long split_ws_floats, int* split_tickets, hipStream_t stream) {
   if (!stats || !produced) return FSV_ERR_BAD_ARG;
   return fsv_conv_gather_impl(in, wt, bias, res, out, N, H, W, Cin, OH, OW, Cout, ntaps, ty, tx, sy, sx, OH, OW, 1, 1, 0, 0, ldw,
                               0, 0, 0, act, scale, -1, 0, 0, wscale, stats, stats_groups, stats_slots, stats_prezeroed, produced,
-                              split_ws, split_ws ? split_ws_floats : 0, stream);
+                              split_ws, split_ws ? split_ws_floats : 0, split_ws ? split_tickets : nullptr, stream);
 }
 
 // In-place x = act(x + bias[c]) over an NHWC tensor of `total` elements (the split-K finishing pass, exposed for operators

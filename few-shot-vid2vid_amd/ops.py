@@ -86,21 +86,10 @@ def _ws(g, p, c, like):
     return torch.empty(max(int(_ws_fn(g, p, c)), 2), dtype=torch.float64, device=like.device)
 
 
-_tickets = {}
-_TICKET_SLOTS, _TICKET_POOL = 64, 1 << 16
-
-
 def _ticket(like):
-    """address of 64 zeroed ints for one fused reduction launch (include/fsv2v.h, fsv_norm_stats_fused): a ring over a
-    per-device pool, so that launches which may overlap (branch streams, neighbouring graph nodes) never share a range; every
-    launch leaves its range zeroed"""
-    ent = _tickets.get(like.device)
-    if ent is None:
-        from . import streams
-        ent = _tickets[like.device] = [streams.shared(lambda: torch.zeros(_TICKET_POOL, dtype=torch.int32, device=like.device)), 0]
-    pool, cur = ent
-    ent[1] = (cur + _TICKET_SLOTS) % _TICKET_POOL
-    return ctypes.c_void_p(pool.data_ptr() + 4 * cur)
+    """address of 64 zeroed ints for one fused reduction launch (include/fsv2v.h, fsv_norm_stats_fused): a range of the per-device
+    ticket ring (conv.ticket_range)"""
+    return _conv.ticket_range(like, 64)
 
 
 class _SplitColsFn(torch.autograd.Function):
