@@ -229,7 +229,7 @@ lib.register_sigs({
     "fsv_conv_gather_fwd_stats": [ctypes.c_void_p] * 5 + [ctypes.c_int] * 8 + [ctypes.POINTER(ctypes.c_int)] * 2 +
                                  [ctypes.c_int] * 4 + [ctypes.c_float, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int,
                                                        ctypes.c_int, ctypes.POINTER(ctypes.c_int), ctypes.c_void_p,
-                                                       ctypes.c_longlong, ctypes.c_void_p, ctypes.c_void_p],
+                                                       ctypes.c_longlong, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p],
 })
 
 GROUP_LIMIT = 64          # FSV_GROUP_LIMIT (csrc/conv_igemm.hip)
@@ -422,9 +422,20 @@ class stats_pass:
         return False
 
 
+def up_foldable(cin, cout, per_sample=False, out_hw=None):
+    """can a nearest x2 up-sampling in front of this convolution be folded into the gather (csrc/conv_igemm.hip ConvP::up)?
+    The exact-fp32 float4-gather MFMA launches only - forward AND weight gradient (whose float4 kernel walks the output pixels 32
+    at a time and wants 32 / OW + 1 <= OH: tiny maps take its scalar twin, which has no fold); FSV_UP_FOLD=0: materialise (in-box
+    A/B)."""
+    if out_hw is not None and 32 // out_hw[1] + 1 > out_hw[0]:
+        return False
+    return (os.environ.get('FSV_UP_FOLD', '1') == '1' and cin % 4 == 0 and cout > 4 and cout % 4 == 0 and not per_sample and
+            _mfma_mode == MFMA_F32 and _active_group() is None)
+
+
 def gather_gemm(x, wt, ldw, cout, oh, ow, ty, tx, sy, sx, bias=None, res=None, act=ACT_NONE, scale=1.0,
                 per_sample=False, out=None, place=None, accumulate=False, force_tile=-1, force_split=0, wscale=None,
-                stats=None):
+                stats=None, up=False):
     """out[n, oy, ox, :] = act((sum_taps x[n, oy*sy+ty, ox*sx+tx, :] @ wt[tap]) + bias) * scale) + res.
 
     stats: None, or a dict with 'groups' (1: BatchNorm, n: InstanceNorm) - the launch then also leaves the per-channel sums of
@@ -433,6 +444,8 @@ def gather_gemm(x, wt, ldw, cout, oh, ow, ty, tx, sy, sx, bias=None, res=None, a
     x = to_nhwc(x)
     if x.dtype == torch.float16:
         # half activations: the half-precision kernels (fp32 output unless `out` is a half tensor)
+        if up:
+            raise ValueError("a folded up-sampling needs the exact-fp32 kernels (conv.up_foldable)")
         from . import hconv
         wh, k64, nrows = half_twin(wt)
         if accumulate:
@@ -440,6 +453,10 @@ def gather_gemm(x, wt, ldw, cout, oh, ow, ty, tx, sy, sx, bias=None, res=None, a
         return hconv.gather_gemm_h(x, wh, k64, nrows, cout, oh, ow, ty, tx, sy, sx, bias=bias, res=res, act=act, scale=scale,
                                    per_sample=per_sample, out=out, place=place, out_half=False, wscale=wscale, stats=stats)
     n, cin, h, w = x.shape
+    if up:            # x is stored at half the size the convolution sees (the nearest x2 up-sampling is folded into the gather)
+        if x.dtype != torch.float32 or place is not None or accumulate or per_sample or _active_group() is not None:
+            raise ValueError("a folded up-sampling needs a plain fp32 launch (conv.up_foldable)")
+        h, w = 2 * h, 2 * w
     if place is None:
         out_h, out_w, osy, osx, ooy, oox = oh, ow, 1, 1, 0, 0
     else:
@@ -488,9 +505,11 @@ def gather_gemm(x, wt, ldw, cout, oh, ow, ty, tx, sy, sx, bias=None, res=None, a
         tickets = ticket_range(x, -(-mz_ // bm_) * -(-cout // bn_) * ns_)
     ws_args = (lib.ptr(split_ws), split_ws.numel() if split_ws is not None else 0, tickets)
     if entry == "fsv_conv_gather_fwd_np":
+        if up:
+            raise ValueError("a folded up-sampling needs the exact-fp32 kernels (conv.up_foldable)")
         args = head + (_np_mode, lib.stream_ptr())
     else:
-        args = head + ws_args + (lib.stream_ptr(),)
+        args = head + ws_args + (1 if up else 0, lib.stream_ptr())
     if (stats is not None and grp is None and entry == "fsv_conv_gather_fwd" and place is None and not per_sample
             and not accumulate and force_tile < 0 and force_split == 0 and cin % 4 == 0 and stats_enabled()):
         groups = int(stats['groups'])
@@ -501,7 +520,7 @@ def gather_gemm(x, wt, ldw, cout, oh, ow, ty, tx, sy, sx, bias=None, res=None, a
         produced = ctypes.c_int(0)
         sargs = (lib.ptr(x), lib.ptr(wt), lib.ptr(bias), lib.ptr(res), lib.ptr(out), n, h, w, cin, oh, ow, cout, len(ty),
                  lib.int_array(ty), lib.int_array(tx), sy, sx, ldw, act, float(scale), lib.ptr(wscale), lib.ptr(part), groups,
-                 STATS_SLOTS, 1 if prezeroed else 0, ctypes.byref(produced)) + ws_args + (lib.stream_ptr(),)
+                 STATS_SLOTS, 1 if prezeroed else 0, ctypes.byref(produced)) + ws_args + (1 if up else 0, lib.stream_ptr())
         label = 'fsv_conv_igemm_kernel'
         if profile.enabled():
             label = profile.conv_label(n * oh * ow, cout, (len(ty) * cin + 31) // 32, 1, True, force_tile, force_split)
@@ -592,12 +611,13 @@ def _thin_k(cout, cin, ntaps, per_sample, place, accumulate, force_tile, force_s
 
 
 def conv_forward(x, wt_f, ldw, cout, geom, bias=None, res=None, act=ACT_NONE, scale=1.0, per_sample=False,
-                 force_tile=-1, force_split=0, wscale=None, stats=None):
+                 force_tile=-1, force_split=0, wscale=None, stats=None, up=False):
+    """up: x stands for its nearest x2 up-sampling (gather_gemm)"""
     n, cin, h, w = x.shape
-    oh, ow = geom.out_hw(h, w)
+    oh, ow = geom.out_hw(2 * h, 2 * w) if up else geom.out_hw(h, w)
     return gather_gemm(x, wt_f, ldw, cout, oh, ow, geom.ty, geom.tx, geom.stride, geom.stride, bias=bias, res=res,
                        act=act, scale=scale, per_sample=per_sample, force_tile=force_tile, force_split=force_split,
-                       wscale=wscale, stats=stats)
+                       wscale=wscale, stats=stats, up=up)
 
 
 def planned(mz, cout, nchunks, nsamp, force_tile=-1, force_split=0):
@@ -691,12 +711,17 @@ def conv_dgrad(dout, w, geom, in_hw, scale=None, per_sample=False, cached=None, 
 
 
 def conv_wgrad(x, dout, geom, w_shape, per_sample=False, scale=None, force_split=0, out=None, raw=False, arena=None,
-               force_tile=0):
+               force_tile=0, up=False):
     """Weight gradient in OIHW layout (batched when per_sample); raw=True returns the GEMM's K-major result
-    dwt[(tap, ci)][co] instead (consumed by grad_finalize.GradFinalizer)."""
+    dwt[(tap, ci)][co] instead (consumed by grad_finalize.GradFinalizer).  up: x stands for its nearest x2 up-sampling (the
+    forward pass read it through the folded index, gather_gemm)."""
     x = to_nhwc(x)
     dout = to_nhwc(dout)
     n, cin, h, w = x.shape
+    if up:
+        if x.dtype != torch.float32 or dout.dtype != torch.float32 or per_sample or narrow_staging_mode():
+            raise ValueError("a folded up-sampling needs the exact-fp32 kernels (conv.up_foldable)")
+        h, w = 2 * h, 2 * w
     _, cout, oh, ow = dout.shape
     if x.dtype == torch.float16 or dout.dtype == torch.float16:
         from . import hconv
@@ -738,21 +763,21 @@ def conv_wgrad(x, dout, geom, w_shape, per_sample=False, scale=None, force_split
              ldw, kpad, kpad * ldw, 1 if per_sample else 0, force_split, 1 if prezeroed else 0, force_tile)
     grp = _active_group()
     if (grp is not None and not narrow and prezeroed and raw and vec4 and force_split == 0 and force_tile == 0
-            and 32 // ow + 1 <= oh):
+            and 32 // ow + 1 <= oh and not up):
         d = WgradDesc()
         d.inp, d.dout, d.dwt = x.data_ptr(), dout.data_ptr(), dwt.data_ptr()
         d.N, d.H, d.W, d.Cin, d.OH, d.OW, d.Cout, d.ntaps = n, h, w, cin, oh, ow, cout, geom.ntaps
         for i, (a, b) in enumerate(zip(geom.ty, geom.tx)):
             d.ty[i], d.tx[i] = a, b
         d.sy, d.sx, d.ldw, d.Kpad, d.per_sample, d.reserved, d.w_bstride = geom.stride, geom.stride, ldw, kpad, 0, 0, kpad * ldw
-        grp.wgrads.append((d, "fsv_conv_wgrad", wargs + (lib.stream_ptr(),), label,
+        grp.wgrads.append((d, "fsv_conv_wgrad", wargs + (0, lib.stream_ptr()), label,
                            2.0 * n * oh * ow * cout * cin * geom.ntaps, (x, dout, dwt)))
         return dwt
     with profile.scope(label, 2.0 * n * oh * ow * cout * cin * geom.ntaps):
         if narrow:
             lib.call("fsv_conv_wgrad_np", *wargs, _np_mode, lib.stream_ptr())
         else:
-            lib.call("fsv_conv_wgrad", *wargs, lib.stream_ptr())
+            lib.call("fsv_conv_wgrad", *wargs, 1 if up else 0, lib.stream_ptr())
     if raw:
         return dwt
     return unprep_weight_grad(dwt, tuple(w_shape), geom, scale, out)

@@ -110,6 +110,9 @@ struct ConvP {
                                          // a tile's last ticket sums the splits in ascending order and applies the epilogue itself (no
                                          // finishing launch); null: the finishing pass does
   int band;                              // XCD bands: an XCD owns a CONTIGUOUS run of (pixel tile, channel tile) pairs (conv_igemm.hip)
+  int up;                                // 1: `in` is stored at HALF the resolution (H / 2 x W / 2) and read through the nearest x2
+                                         // up-sampling index (y >> 1, x >> 1) - the up-sampled tensor (generator.py:124, 497-504, 541-572:
+                                         // nn.Upsample in front of a 3x3 convolution) is never written; H, W stay the logical size
 };
 
 __device__ __forceinline__ void fsv_tap(const ConvP& p, int t, int& ty, int& tx) {
@@ -152,4 +155,5 @@ struct WgradP {
   int per_sample, nsplit;
   int Mz;                  // pixels per z group
   int pchunks;             // ceil(Mz/32)
+  int up;                  // as ConvP::up: `in` at half resolution behind a folded nearest x2 up-sampling (shift amount 0 / 1)
 };

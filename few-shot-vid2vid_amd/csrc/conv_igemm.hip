@@ -65,7 +65,11 @@ __device__ __forceinline__ void fsv_xcd_tile(int nx, int ny, int& bx, int& by) {
 // split's share of it) load zeros and are multiplied like the others.  The exit between the two chunks of a trip made the compiler
 // keep the accumulators in two register sets and copy one into the other after every first chunk (s_nop 16 + 8 v_mov_b64 + s_nop:
 // the wave waits for its last MFMA).  MODE 2 = LD, whole trips of three.
-template <int BM, int BN, int WM, int WN, int PF, bool AF, int DBG = 0, int MODE = 0>
+// UP (round 5): the input tensor is stored at half the resolution and read through the nearest x2 up-sampling index - p.H / p.W are
+// the logical (up-sampled) size, tap validity is tested against them, the address is that of source pixel (iy >> 1, ix >> 1).  The
+// offset is no longer (pixel base + tap offset): two shifts, a multiply-add and a multiply per row and chunk, computed one chunk
+// ahead like the others; its own instantiations, so that the instruction streams of the plain kernels stay what was validated.
+template <int BM, int BN, int WM, int WN, int PF, bool AF, int DBG = 0, int MODE = 0, bool UP = false>
 __device__ __forceinline__ void fsv_conv_igemm_body(const ConvP& p, const int bx, const int by, const int bz) {
   constexpr bool LD = MODE == 2, WT = MODE >= 1;
   constexpr int BK = FSV_BK;
@@ -106,7 +110,8 @@ __device__ __forceinline__ void fsv_conv_igemm_body(const ConvP& p, const int bx
       if (p.per_sample) { n = zs; rem = m; } else { n = m / ohw; rem = m - n * ohw; }
       int oy = rem / p.OW, ox = rem - oy * p.OW;
       a_iy0[i] = oy * p.sy; a_ix0[i] = ox * p.sx;
-      a_pix[i] = ((n * p.H + a_iy0[i]) * p.W + a_ix0[i]) * p.Cin * 4;      // byte offset of tap (0, 0), channel 0
+      a_pix[i] = UP ? n * (p.H >> 1)                                       // UP: first source row of the sample
+                    : ((n * p.H + a_iy0[i]) * p.W + a_ix0[i]) * p.Cin * 4;      // byte offset of tap (0, 0), channel 0
     } else {
       a_iy0[i] = -(1 << 28); a_ix0[i] = 0; a_pix[i] = 0;
     }
@@ -114,9 +119,10 @@ __device__ __forceinline__ void fsv_conv_igemm_body(const ConvP& p, const int bx
   const int bq = tid % QB, br0 = tid / QB;
   const int bcol = bn0 + bq * 4;
   const bool bcol_ok = bcol < p.ldw;
-  const fsv_buf abuf = fsv_make_buf(p.in, (long long)p.N * p.H * p.W * p.Cin * 4);
+  const long long in_bytes = UP ? (long long)p.N * (p.H >> 1) * (p.W >> 1) * p.Cin * 4 : (long long)p.N * p.H * p.W * p.Cin * 4;
+  const fsv_buf abuf = fsv_make_buf(p.in, in_bytes);
   const fsv_buf bbuf = fsv_make_buf(wt, (long long)p.nchunks * BK * p.ldw * 4);
-  const fsv_rawbuf araw = fsv_make_rawbuf(p.in, (long long)p.N * p.H * p.W * p.Cin * 4);          // LD form only
+  const fsv_rawbuf araw = fsv_make_rawbuf(p.in, in_bytes);          // LD form only
   const fsv_rawbuf braw = fsv_make_rawbuf(wt, (long long)p.nchunks * BK * p.ldw * 4);
 
   // chunk range of this K split
@@ -151,7 +157,10 @@ __device__ __forceinline__ void fsv_conv_igemm_body(const ConvP& p, const int bx
       const int iy = a_iy0[i] + ty, ix = a_ix0[i] + tx;
       // `&`, not `&&`: a short-circuit here turns the whole offset computation into a guarded basic block
       const bool ok = kok & ((unsigned)iy < (unsigned)p.H) & ((unsigned)ix < (unsigned)p.W);
-      if constexpr (WT) aoff[i] = (unsigned)(a_pix[i] + toff) | (ok ? 0u : FSV_BUF_OOB);      // any offset >= 2^31 is out of range
+      if constexpr (UP) {
+        const unsigned off = (unsigned)((((a_pix[i] + (iy >> 1)) * (p.W >> 1) + (ix >> 1)) * p.Cin + cur_ci) * 4);
+        aoff[i] = ok ? off : FSV_BUF_OOB;
+      } else if constexpr (WT) aoff[i] = (unsigned)(a_pix[i] + toff) | (ok ? 0u : FSV_BUF_OOB);      // any offset >= 2^31 is out of range
       else aoff[i] = ok ? (unsigned)(a_pix[i] + toff) : FSV_BUF_OOB;
     }
 #pragma unroll
@@ -555,12 +564,12 @@ __device__ __forceinline__ void fsv_xcd_band(int nx, int ny, int& bx, int& by) {
   bx = t / ny;
 }
 
-template <int BM, int BN, int WM, int WN, int PF = 1, bool AF = false, int DBG = 0, int MODE = 0>
+template <int BM, int BN, int WM, int WN, int PF = 1, bool AF = false, int DBG = 0, int MODE = 0, bool UP = false>
 __global__ __launch_bounds__(64 * WM * WN) void fsv_conv_igemm_kernel(ConvP p) {
   int bx, by;
   if (p.band) fsv_xcd_band(gridDim.x, gridDim.y, bx, by);
   else fsv_xcd_tile(gridDim.x, gridDim.y, bx, by);
-  fsv_conv_igemm_body<BM, BN, WM, WN, PF, AF, DBG, MODE>(p, bx, by, (int)blockIdx.z);
+  fsv_conv_igemm_body<BM, BN, WM, WN, PF, AF, DBG, MODE, UP>(p, bx, by, (int)blockIdx.z);
 }
 
 // Grouped launch: up to FSV_GROUP_MAX INDEPENDENT gather-GEMM problems in one 1-D grid (the problem table travels in the
@@ -894,7 +903,7 @@ __device__ __forceinline__ void fsv_conv_wgrad_body(const WgradP& p, const int k
   const int bq = tid % QB, bpr0 = tid / QB;
   const int bcol = bn0 + bq * 4;
   const long long dout_base = (long long)zs * (p.per_sample ? p.Mz : 0);
-  const fsv_buf abuf = fsv_make_buf(p.in, (long long)p.N * p.H * p.W * p.Cin * 4);
+  const fsv_buf abuf = fsv_make_buf(p.in, (long long)p.N * (p.H >> p.up) * (p.W >> p.up) * p.Cin * 4);
   const fsv_buf bbuf = fsv_make_buf(p.dout + dout_base * p.Cout, (long long)p.Mz * p.Cout * 4);
 
   const int cps = (p.pchunks + p.nsplit - 1) / p.nsplit;
@@ -923,7 +932,8 @@ __device__ __forceinline__ void fsv_conv_wgrad_body(const WgradP& p, const int k
     for (int i = 0; i < NPA; ++i) {
       const int iy = a_oy[i] * p.sy + ty, ix = a_ox[i] * p.sx + tx;
       const bool ok = kok & (a_m[i] < p.Mz) & ((unsigned)iy < (unsigned)p.H) & ((unsigned)ix < (unsigned)p.W);
-      aoff[i] = ok ? (unsigned)((((a_n[i] * p.H + iy) * p.W + ix) * p.Cin + ci) * 4) : FSV_BUF_OOB;
+      // (p.up = 1: the tensor lies at half the resolution behind a folded nearest x2 up-sampling - two shifts, see ConvP::up)
+      aoff[i] = ok ? (unsigned)((((a_n[i] * (p.H >> p.up) + (iy >> p.up)) * (p.W >> p.up) + (ix >> p.up)) * p.Cin + ci) * 4) : FSV_BUF_OOB;
       a_m[i] += BK;
       int ox = a_ox[i] + rw, oy = a_oy[i] + qw;
       const bool cx = ox >= p.OW;
@@ -1640,6 +1650,19 @@ static int fsv_launch_conv(const ConvP& p, bool vec4, int nz, hipStream_t stream
   int bm, bn;
   if (fsv_tile_dims(tile, bm, bn)) return FSV_ERR_BAD_ARG;
   dim3 g(fsv_cdiv(p.Mz, bm), fsv_cdiv(p.Cout, bn), nz);
+  if (p.up) {
+    // the folded up-sampling exists for the float4 gather, as the variants the plan's five tile shapes run as
+    if (!vec4) return FSV_ERR_UNSUPPORTED;
+    switch (tile) {
+      case 0: case 11: case 14: case 16: FSV_LAUNCH((fsv_conv_igemm_kernel<128, 128, 2, 4, 1, true, 0, 0, true>), g, dim3(512), stream, p); break;
+      case 1: case 12: case 15: case 22: FSV_LAUNCH((fsv_conv_igemm_kernel<128, 64, 4, 2, 2, true, 0, 0, true>), g, dim3(512), stream, p); break;
+      case 2: case 18: FSV_LAUNCH((fsv_conv_igemm_kernel<128, 32, 4, 1, 1, true, 0, 0, true>), g, dim3(256), stream, p); break;
+      case 4: case 17: case 20: case 27: FSV_LAUNCH((fsv_conv_igemm_kernel<64, 64, 2, 2, 2, true, 0, 0, true>), g, dim3(256), stream, p); break;
+      case 9: case 10: case 13: case 21: FSV_LAUNCH((fsv_conv_igemm_kernel<64, 128, 2, 4, 2, true, 0, 2, true>), g, dim3(512), stream, p); break;
+      default: return FSV_ERR_BAD_ARG;
+    }
+    return fsv_check_launch();
+  }
   if (vec4) {
     switch (tile) {
       case 0: FSV_LAUNCH((fsv_conv_igemm_kernel<128, 128, 2, 4>), g, dim3(512), stream, p); break;
@@ -1817,7 +1840,7 @@ static inline void fsv_fill_convp(ConvP& p, const float* in, const float* wt, co
   p.nsplit = 1;
   p.stats = nullptr; p.stats_slots = 1; p.stats_ohw = 1;
   p.part = nullptr; p.part_stride = 0; p.tickets = nullptr;
-  p.band = fsv_conv_band();
+  p.band = fsv_conv_band(); p.up = 0;
   {
     const long long obytes = (long long)N * outH * outW * Cout * 4;
     p.res_bytes = (res && obytes <= FSV_BUF_MAX_BYTES) ? obytes : 0;
@@ -1836,16 +1859,19 @@ static int fsv_conv_gather_impl(const float* in, const float* wt, const float* b
                         int ldw, long long w_bstride, long long b_bstride, int per_sample,
                         int act, float scale, int force_tile, int force_split, int accumulate, const float* wscale,
                         double* stats, int stats_groups, int stats_slots, int stats_prezeroed, int* produced,
-                        float* split_ws, long long split_cap, int* split_tickets, hipStream_t stream) {
+                        float* split_ws, long long split_cap, int* split_tickets, int in_up, hipStream_t stream) {
   if (!in || !wt || !out || ntaps < 1 || ntaps > 16 || N < 1 || Cin < 1 || Cout < 1) return FSV_ERR_BAD_ARG;
   for (int t = 0; t < ntaps; ++t)
     if (ty[t] < -8 || ty[t] > 7 || tx[t] < -8 || tx[t] > 7) return FSV_ERR_UNSUPPORTED;
   if ((ldw & 3) != 0 || ldw < Cout) return FSV_ERR_BAD_ARG;
+  // in_up: the input is stored at H / 2 x W / 2 and read through the nearest x2 index (ConvP::up); float4 gather, MFMA tiles only
+  if (in_up && ((H & 1) || (W & 1) || (Cin % 4 != 0) || per_sample || accumulate || Cout <= 4)) return FSV_ERR_UNSUPPORTED;
   // the V4 kernels index one tensor / one weight matrix with 32-bit element offsets
   if ((long long)N * H * W * Cin * 4 > FSV_BUF_MAX_BYTES || (long long)(ntaps * Cin + 32) * ldw * 4 > FSV_BUF_MAX_BYTES) return FSV_ERR_UNSUPPORTED;
   ConvP p;
   fsv_fill_convp(p, in, wt, bias, res, out, wscale, N, H, W, Cin, OH, OW, Cout, ntaps, ty, tx, sy, sx, outH, outW, osy, osx, ooy,
                  oox, ldw, w_bstride, b_bstride, per_sample, act, scale);
+  p.up = in_up ? 1 : 0;
   const int nsamp = per_sample ? N : 1;
   int tile = 0, nsplit = 1;
   // thin-output layers (image / flow / mask heads) run on the vector ALUs: see fsv_conv_thin_fwd_kernel
@@ -1929,11 +1955,11 @@ int fsv_conv_gather_fwd(const float* in, const float* wt, const float* bias, con
                         int outH, int outW, int osy, int osx, int ooy, int oox,
                         int ldw, long long w_bstride, long long b_bstride, int per_sample,
                         int act, float scale, int force_tile, int force_split, int accumulate, const float* wscale,
-                        float* split_ws, long long split_ws_floats, int* split_tickets, hipStream_t stream) {
+                        float* split_ws, long long split_ws_floats, int* split_tickets, int in_up, hipStream_t stream) {
   return fsv_conv_gather_impl(in, wt, bias, res, out, N, H, W, Cin, OH, OW, Cout, ntaps, ty, tx, sy, sx, outH, outW, osy, osx,
                               ooy, oox, ldw, w_bstride, b_bstride, per_sample, act, scale, force_tile, force_split, accumulate,
                               wscale, nullptr, 0, 0, 0, nullptr, split_ws, split_ws ? split_ws_floats : 0,
-                              split_ws ? split_tickets : nullptr, stream);
+                              split_ws ? split_tickets : nullptr, in_up, stream);
 }
 
 int fsv_conv_gather_fwd_stats(const float* in, const float* wt, const float* bias, const float* res, float* out,
@@ -1941,11 +1967,11 @@ int fsv_conv_gather_fwd_stats(const float* in, const float* wt, const float* bia
                               int ntaps, const int* ty, const int* tx, int sy, int sx,
                               int ldw, int act, float scale, const float* wscale,
                               double* stats, int stats_groups, int stats_slots, int stats_prezeroed, int* produced,
-                              float* split_ws, long long split_ws_floats, int* split_tickets, hipStream_t stream) {
+                              float* split_ws, long long split_ws_floats, int* split_tickets, int in_up, hipStream_t stream) {
   if (!stats || !produced) return FSV_ERR_BAD_ARG;
   return fsv_conv_gather_impl(in, wt, bias, res, out, N, H, W, Cin, OH, OW, Cout, ntaps, ty, tx, sy, sx, OH, OW, 1, 1, 0, 0, ldw,
                               0, 0, 0, act, scale, -1, 0, 0, wscale, stats, stats_groups, stats_slots, stats_prezeroed, produced,
-                              split_ws, split_ws ? split_ws_floats : 0, split_ws ? split_tickets : nullptr, stream);
+                              split_ws, split_ws ? split_ws_floats : 0, split_ws ? split_tickets : nullptr, in_up, stream);
 }
 
 // In-place x = act(x + bias[c]) over an NHWC tensor of `total` elements (the split-K finishing pass, exposed for operators
@@ -1973,8 +1999,11 @@ int fsv_conv_wgrad(const float* in, const float* dout, float* dwt,
                    int N, int H, int W, int Cin, int OH, int OW, int Cout,
                    int ntaps, const int* ty, const int* tx, int sy, int sx,
                    int ldw, int Kpad, long long w_bstride, int per_sample, int force_split, int prezeroed,
-                   int force_tile, hipStream_t stream) {
+                   int force_tile, int in_up, hipStream_t stream) {
   if (!in || !dout || !dwt || ntaps < 1 || ntaps > 16) return FSV_ERR_BAD_ARG;
+  // in_up: `in` at H / 2 x W / 2 behind a folded nearest x2 up-sampling (ConvP::up): the float4 MFMA kernels only
+  if (in_up && ((H & 1) || (W & 1) || (Cin % 4 != 0) || (Cout & 3) != 0 || Cout <= 4 || per_sample || FSV_BK / OW + 1 > OH))
+    return FSV_ERR_UNSUPPORTED;
   for (int t = 0; t < ntaps; ++t)
     if (ty[t] < -8 || ty[t] > 7 || tx[t] < -8 || tx[t] > 7) return FSV_ERR_UNSUPPORTED;
   if ((long long)N * H * W * Cin * 4 > FSV_BUF_MAX_BYTES || (long long)N * OH * OW * Cout * 4 > FSV_BUF_MAX_BYTES) return FSV_ERR_UNSUPPORTED;      // 32-bit byte offsets
@@ -1986,6 +2015,7 @@ int fsv_conv_wgrad(const float* in, const float* dout, float* dwt,
   p.w_bstride = w_bstride; p.per_sample = per_sample ? 1 : 0;
   p.Mz = per_sample ? OH * OW : N * OH * OW;
   p.pchunks = fsv_cdiv(p.Mz, FSV_BK);
+  p.up = in_up ? 1 : 0;
   const int nsamp = per_sample ? N : 1;
   if (Cout <= 4 && vec4_ok(Cin) && !per_sample && force_tile == 0 && force_split <= 0 && ntaps * (Cin >> 2) <= 256 &&
       fsv_conv_thin(p.Mz, p.K)) {
@@ -2267,7 +2297,7 @@ int fsv_conv_wgrad_group(const fsv_wgrad_desc* d, int n, hipStream_t stream) {
     fsv_pack_taps(q.ty, q.tx, q.ntaps, p.taps_lo, p.taps_hi, 8);
     p.w_bstride = q.w_bstride; p.per_sample = q.per_sample ? 1 : 0;
     p.Mz = q.per_sample ? q.OH * q.OW : q.N * q.OH * q.OW;
-    p.pchunks = fsv_cdiv(p.Mz, FSV_BK);
+    p.pchunks = fsv_cdiv(p.Mz, FSV_BK); p.up = 0;
     nsamp[i] = q.per_sample ? q.N : 1;
     cout4 = cout4 && (q.Cout & 3) == 0;
     blocks += (long long)fsv_cdiv(p.K, 64) * fsv_cdiv(q.Cout, 64) * nsamp[i];

@@ -26,11 +26,11 @@ _SIGS = {
                             c_i, c_ip, c_ip, c_i, c_i,
                             c_i, c_i, c_i, c_i, c_i, c_i,
                             c_i, c_ll, c_ll, c_i,
-                            c_i, c_f, c_i, c_i, c_i, c_p, c_p, c_ll, c_p, c_p],
+                            c_i, c_f, c_i, c_i, c_i, c_p, c_p, c_ll, c_p, c_i, c_p],
     "fsv_conv_wgrad": [c_p, c_p, c_p,
                        c_i, c_i, c_i, c_i, c_i, c_i, c_i,
                        c_i, c_ip, c_ip, c_i, c_i,
-                       c_i, c_i, c_ll, c_i, c_i, c_i, c_i, c_p],
+                       c_i, c_i, c_ll, c_i, c_i, c_i, c_i, c_i, c_p],
     "fsv_bias_act": [c_p, c_p, c_ll, c_i, c_i, c_p],
     # narrow-operand (--amp) variants, csrc/conv_np.hip: the same arguments plus `mode` before the stream
     "fsv_conv_gather_fwd_np": [c_p, c_p, c_p, c_p, c_p,

@@ -54,12 +54,13 @@ class Conv2d(nn.Module, _SpectralMixin):
             self.weight = nn.Parameter(w)
         self.bias = nn.Parameter(torch.zeros(cout)) if bias else None
 
-    def forward(self, x, act=ACT_NONE, res=None, scale=1.0, stats=0):
+    def forward(self, x, act=ACT_NONE, res=None, scale=1.0, stats=0, up=False):
         """stats: 1 / -1 when a BatchNorm / InstanceNorm consumes the output next (ops.conv2d stats_groups: the statistics then
-        come out of this launch's epilogue instead of a read pass over the output)"""
+        come out of this launch's epilogue instead of a read pass over the output).  up: the convolution of the nearest x2
+        up-sampling of x (nn.Upsample in front of this layer in the reference: ops.conv2d folds it into the gather)"""
         if self.spectral:
-            return ops.conv2d(x, self.weight_orig, self.bias, self.stride, self.padding, act, scale, res, self._sn(), stats)
-        return ops.conv2d(x, self.weight, self.bias, self.stride, self.padding, act, scale, res, None, stats)
+            return ops.conv2d(x, self.weight_orig, self.bias, self.stride, self.padding, act, scale, res, self._sn(), stats, up)
+        return ops.conv2d(x, self.weight, self.bias, self.stride, self.padding, act, scale, res, None, stats, up)
 
 
 class Linear(nn.Module, _SpectralMixin):
@@ -319,7 +320,7 @@ class LabelEmbedder(nn.Module):
         if self.unet and i != self.n - 1:
             cur = ops.cat_channels([cur, skips[i + 1]])
         if i >= self.params_free_layers:
-            return getattr(self, 'up_%d' % i)[1](ops.upsample2x(cur), act=ACT_LRELU)
+            return getattr(self, 'up_%d' % i)[1](cur, act=ACT_LRELU, up=True)      # generator.py:559-563: Upsample -> conv3x3
         # a 1x1 convolution commutes with nearest up-sampling: run the generated-weight conv on the quarter-size
         # tensor, then up-sample (bit-identical, 4x fewer MACs and bytes)
         w, b = weights[i]
@@ -371,7 +372,7 @@ class FlowGenerator(nn.Module):
             x = blk(x, feeds_norm=k + 1 < len(self.res_flow))
         for k in range(1, 3 * self.nd, 3):
             conv, bn = self.up_flow[k]
-            x = bn(conv(ops.upsample2x(x), stats=1 if self.training else 0), act=ACT_LRELU)
+            x = bn(conv(x, stats=1 if self.training else 0, up=True), act=ACT_LRELU)           # generator.py:489-493: Upsample -> conv
         flow = self.conv_flow[0](x, scale=float(self.flow_multiplier))
         mask = self.conv_mask[0](x, act=ACT_SIGMOID)
         return flow, mask

@@ -338,7 +338,7 @@ class _ConvFn(torch.autograd.Function):
     """y = act((conv(x, W * inv_sigma) + bias) * scale) + res.  W: OIHW, or [B]OIHW for per-sample weights."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, res, sig, u, v, geom, act, scale, uv_owned=False, stats_groups=0, allow_half=True):
+    def forward(ctx, x, weight, bias, res, sig, u, v, geom, act, scale, uv_owned=False, stats_groups=0, allow_half=True, up=False):
         weight._fsv_conv_param = True          # FlatAdam: these parameters take their gradients through the sink
         if bias is not None:
             bias._fsv_conv_param = True
@@ -377,6 +377,18 @@ class _ConvFn(torch.autograd.Function):
         if site is not None and not _spade_conv_s_fits(site, geom, per_sample, bias, res, act, scale, half, cpad, st_wanted, cout):
             _spade_launch(site)
             site = None
+        # up: x stands for its nearest x2 up-sampling (generator.py:124,497-504,541-572: nn.Upsample in front of a 3x3
+        # convolution).  Folded into the gather where the launch allows (round 5, csrc/conv_igemm.hip ConvP::up: the kernels read x
+        # at (y >> 1, x >> 1), forward and weight gradient; the up-sampled tensor is never written), materialised here otherwise
+        # (the half-precision path, scalar-gather layers).  Either way the data gradient is pooled 2 x 2 in backward.
+        fold = bool(up and not half and cpad == 0 and not prepadded and site is None and x.dtype == torch.float32 and
+                    _conv.up_foldable(cin, cout, per_sample, geom.out_hw(2 * x.shape[2], 2 * x.shape[3])))
+        if up and not fold:
+            xs = to_nhwc(_hconv.cast(x, torch.float32) if x.dtype == torch.float16 else x)
+            x = empty_nhwc(xs.shape[0], xs.shape[1], 2 * xs.shape[2], 2 * xs.shape[3], xs)
+            lib.check_device(xs)
+            lib.call("fsv_upsample2x_fwd", lib.ptr(xs), lib.ptr(x), xs.shape[0], xs.shape[2], xs.shape[3], xs.shape[1], lib.stream_ptr())
+        ctx.up, ctx.fold = bool(up), fold
         ctx.x_half = x.dtype == torch.float16          # a half input (a producer that rounded at its store) gets a half gradient
         if x.dtype == torch.float16 and not half:
             x = _hconv.cast(x, torch.float32)
@@ -418,7 +430,7 @@ class _ConvFn(torch.autograd.Function):
                 y = _spade_conv_s_launch(site, wt, ldw, cout, wscale, want_hs=any(ctx.needs_input_grad))
         if y is None:
             y = conv_forward(x, wt, ldw, cout, geom, bias=b, res=res.detach() if res is not None else None, act=act,
-                             scale=scale, per_sample=per_sample, wscale=wscale, stats=st)
+                             scale=scale, per_sample=per_sample, wscale=wscale, stats=st, up=fold)
         # statistics of y left by the epilogue (conv2d() hands them to the normalisation that follows through the output tensor)
         _conv_stats_tls.last = st if (st is not None and 'part' in st) else None
         ctx.geom, ctx.act, ctx.scale, ctx.per_sample = geom, act, scale, per_sample
@@ -445,6 +457,8 @@ class _ConvFn(torch.autograd.Function):
         dy = to_nhwc(dy)
         geom = ctx.geom
         n, _, h, w = ctx.x_shape
+        if ctx.fold:                # x was kept at half the size the convolution saw
+            h, w = 2 * h, 2 * w
         cpad, cin = ctx.cpad, ctx.cin
         dpre = act_backward(dy, y, ctx.act, ctx.scale) if (ctx.act != ACT_NONE or ctx.scale != 1.0) else dy
         # half path: ONE rounding of the pre-activation gradient, shared by the data gradient and the weight gradient (the bias
@@ -473,14 +487,14 @@ class _ConvFn(torch.autograd.Function):
             fin = getattr(weight, '_fsv_finalizer', None) if (w_sink is not None and entry is not None) else None
             if fin is not None:
                 # deferred: leave the K-major result to the optimiser's grouped finalisation (grad_finalize.py)
-                dwt = conv_wgrad(x, dpre_g, geom, w_shape, raw=True, arena=fin)
+                dwt = conv_wgrad(x, dpre_g, geom, w_shape, raw=True, arena=fin, up=ctx.fold)
                 if ctx.has_sn:
                     fin.add(entry, dwt, w_sink, sig, u, v)
                 else:
                     fin.add(entry, dwt, w_sink)
                 dw = None
             elif ctx.has_sn or cpad:
-                dwsn = conv_wgrad(x, dpre_g, geom, w_shape, per_sample=ctx.per_sample)
+                dwsn = conv_wgrad(x, dpre_g, geom, w_shape, per_sample=ctx.per_sample, up=ctx.fold)
                 if cpad:
                     dwsn = dwsn[:, :cin].contiguous()
                 if ctx.has_sn:
@@ -491,7 +505,7 @@ class _ConvFn(torch.autograd.Function):
                     dw = dwsn
                 dw = None if w_sink is not None else dw.view_as(weight)
             else:
-                dw = conv_wgrad(x, dpre_g, geom, w_shape, per_sample=ctx.per_sample, out=w_sink)
+                dw = conv_wgrad(x, dpre_g, geom, w_shape, per_sample=ctx.per_sample, out=w_sink, up=ctx.fold)
                 dw = None if w_sink is not None else dw.view_as(weight)
         if want_b:
             cout = dpre.shape[1]
@@ -512,9 +526,13 @@ class _ConvFn(torch.autograd.Function):
                             out_half=ctx.x_half and ctx.half)
             if cpad and not ctx.prepadded:
                 dx = dx[:, :cin]
+            if ctx.up:              # the gradient of the nearest x2 up-sampling: 2 x 2 sums (exact fp32, fixed order)
+                dxu = to_nhwc(_hconv.cast(dx, torch.float32) if dx.dtype == torch.float16 else dx)
+                dx = empty_nhwc(n, dxu.shape[1], h // 2, w // 2, dxu)
+                lib.call("fsv_upsample2x_bwd", lib.ptr(dxu), lib.ptr(dx), n, h // 2, w // 2, dxu.shape[1], lib.stream_ptr())
         if ctx.has_res and ctx.needs_input_grad[3]:
             dres = dy
-        return dx, dw, db, dres, None, None, None, None, None, None, None, None, None
+        return dx, dw, db, dres, None, None, None, None, None, None, None, None, None, None
 
 
 def _unpack_sn(sn):
@@ -526,7 +544,7 @@ def _unpack_sn(sn):
     return sn[0], sn[1], sn[2], False
 
 
-def conv2d(x, weight, bias=None, stride=1, padding=0, act=ACT_NONE, scale=1.0, res=None, sn=None, stats_groups=0):
+def conv2d(x, weight, bias=None, stride=1, padding=0, act=ACT_NONE, scale=1.0, res=None, sn=None, stats_groups=0, up=False):
     """sn: None or (sig, u, v) from SpectralState.update for this call.
 
     stats_groups: 1 (a BatchNorm follows) / -1 (an InstanceNorm follows: one group per sample) - the convolution's epilogue
@@ -537,7 +555,8 @@ def conv2d(x, weight, bias=None, stride=1, padding=0, act=ACT_NONE, scale=1.0, r
     geom = Geom(kh, kw, stride, padding)
     sig, u, v, owned = _unpack_sn(sn)
     groups = (x.shape[0] if stats_groups < 0 else stats_groups) if stats_groups else 0
-    y = _ConvFn.apply(x, weight, bias, res, sig, u, v, geom, act, scale, owned, groups)
+    # up: the convolution of nearest_x2(x) (ops._ConvFn.forward: folded into the gather where the launch allows)
+    y = _ConvFn.apply(x, weight, bias, res, sig, u, v, geom, act, scale, owned, groups, True, bool(up))
     st = getattr(_conv_stats_tls, 'last', None)
     if groups and st is not None:
         _conv_stats_tls.last = None

@@ -79,6 +79,82 @@ def check_conv(device, n, cin, h, w, cout, k, s, p, act='lrelu', bias=True, seed
         assert_close('conv db', bd.grad, br.grad, tol)
 
 
+def check_conv_up(device, n=2, cin=16, h=6, w=10, cout=24, k=3, act='lrelu', stats=0, tile=-1, split=0, seed=71, expect_fold=True,
+                  amp=False):
+    """conv(nearest_x2(x)) (nn.Upsample in front of a convolution: generator.py:124,489-493,559-563) with the up-sampling folded
+    into the gather (csrc/conv_igemm.hip ConvP::up, forward and weight gradient; round 5) against F.conv2d(F.interpolate(x)):
+    output, dx (the 2 x 2 pooled data gradient), dw, db; bit-equal to the same convolution on the materialised tensor
+    (FSV_UP_FOLD=0) - the fold changes addresses, not arithmetic.  h, w: size of x (the convolution sees 2h x 2w).  stats: the
+    BatchNorm-statistics epilogue rides along.  expect_fold=False: layers the fold does not cover materialise silently."""
+    from importlib import import_module
+    ops, conv = pkg()
+    lib = import_module('few-shot-vid2vid_amd.lib')
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(n, cin, h, w, generator=g)
+    wt = torch.randn(cout, cin, k, k, generator=g) * (1.0 / (cin * k * k) ** 0.5)
+    b = torch.randn(cout, generator=g)
+    xr, wr, br = x.clone().requires_grad_(True), wt.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    ref = F.conv2d(F.interpolate(xr, scale_factor=2, mode='nearest'), wr, br, padding=k // 2)
+    actc = {'none': conv.ACT_NONE, 'lrelu': conv.ACT_LRELU}[act]
+    ref = O.actvn(ref) if act == 'lrelu' else ref
+    dy = torch.randn(ref.shape, generator=g)
+    ref.backward(dy)
+
+    def run(fold):
+        xd = _dev(x, device).detach().clone().requires_grad_(True)
+        wd = _dev(wt, device).detach().clone().requires_grad_(True)
+        bd = _dev(b, device).detach().clone().requires_grad_(True)
+        seen, real_call = [], lib.call
+
+        def recording_call(name, *a):
+            seen.append((name, a))
+            return real_call(name, *a)
+        os.environ['FSV_UP_FOLD'] = '1' if fold else '0'
+        lib.call = recording_call
+        try:
+            with conv.stats_pass(xd.device):
+                y = ops.conv2d(xd, wd, bd, stride=1, padding=k // 2, act=actc, stats_groups=stats, up=True)
+            got_stats = getattr(y, '_fsv_stats', None) is not None
+            y.backward(_dev(dy, device))
+        finally:
+            lib.call = real_call
+            os.environ.pop('FSV_UP_FOLD', None)
+        return y.detach(), xd.grad, wd.grad, bd.grad, [s_[0] for s_ in seen], got_stats
+    prev = conv.set_mfma_mode(1 if amp else conv.mfma_mode())
+    try:
+        a = run(True)
+        bm = run(False)
+    finally:
+        conv.set_mfma_mode(prev)
+    folded = 'fsv_upsample2x_fwd' not in a[4]
+    assert folded == expect_fold, a[4]
+    assert 'fsv_upsample2x_fwd' in bm[4] and 'fsv_upsample2x_bwd' in a[4] and 'fsv_upsample2x_bwd' in bm[4]
+    if stats and not amp:
+        assert a[5] == bm[5]
+    tol = 3e-3 if amp else REL_TOL
+    for name, got, want in (('y', a[0], ref), ('dx', a[1], xr.grad), ('dw', a[2], wr.grad), ('db', a[3], br.grad)):
+        assert_close('conv(up2x) %s' % name, got, want, tol)
+    if folded and not amp:
+        for name, u, v in zip(('y', 'dx', 'db'), (a[0], a[1], a[3]), (bm[0], bm[1], bm[3])):
+            assert bool((u == v).all()), 'folded up-sampling changed the bits of %s' % name
+        assert_close('conv(up2x) dw folded vs materialised', a[2], bm[2], 1e-6)      # (pixel-split atomics: summation order)
+    if expect_fold and not amp and cin % 4 == 0 and cout % 32 == 0:
+        # every tile shape of the plan has its own UP instantiation (and the LD form its own address swizzle): forced, forward,
+        # against the same tile on the materialised tensor - bit for bit, K splits included
+        geo = conv.Geom(k, k, 1, k // 2)
+        xd = conv.to_nhwc(_dev(x, device))
+        xu = conv.to_nhwc(_dev(F.interpolate(x, scale_factor=2, mode='nearest'), device))
+        wf, _, ldw = conv.prep_weight(_dev(wt, device), 0, geo)
+        for tile in (16, 15, 18, 20, 21):          # the variants the plan's shapes run as (fsv_conv_variant): same template either way
+            for sp in (1, 2):
+                if sp == 2 and (k * k * cin + 31) // 32 < 2:
+                    continue
+                u = conv.conv_forward(xd, wf, ldw, cout, geo, bias=_dev(b, device), act=actc, force_tile=tile, force_split=sp, up=True)
+                v = conv.conv_forward(xu, wf, ldw, cout, geo, bias=_dev(b, device), act=actc, force_tile=tile, force_split=sp)
+                assert bool((u == v).all()), 'folded up-sampling, tile %d split %d' % (tile, sp)
+                assert_close('conv(up2x) tile %d' % tile, u, ref, REL_TOL)
+
+
 def check_conv_sn_res(device, seed=1, cache=None, fin=None):
     """spectral-norm conv with fused residual add (SPADEResnetBlock conv_1 + shortcut)."""
     ops, conv = pkg()
@@ -850,10 +926,10 @@ def check_ordered_split(device, seed=93):
                 os.environ.pop('FSV_SPLIT_TICKETS', None)
         del seen[:]
         a = run2(True)
-        assert [s_[1][-2] is not None for s_ in seen if s_[0] == 'fsv_conv_gather_fwd'] == [True], 'no tickets were handed over'
+        assert [s_[1][-3] is not None for s_ in seen if s_[0] == 'fsv_conv_gather_fwd'] == [True], 'no tickets were handed over'
         del seen[:]
         bb = run2(False)
-        assert [s_[1][-2] is None for s_ in seen if s_[0] == 'fsv_conv_gather_fwd'] == [True]
+        assert [s_[1][-3] is None for s_ in seen if s_[0] == 'fsv_conv_gather_fwd'] == [True]
         assert bool((a == bb).all()), 'ticketed split-K differs from the finishing launch (tile %d)' % tile
         assert_close('ticketed split tile %d' % tile, a, F.leaky_relu(F.conv2d(x.cpu(), wt.cpu(), b.cpu(), padding=1), 0.2), 1e-5)
     pool = conv._tickets[x.device][0]
