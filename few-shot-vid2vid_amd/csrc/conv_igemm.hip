@@ -523,26 +523,42 @@ __device__ __forceinline__ void fsv_conv_igemm_body(const ConvP& p, const int bx
     __syncthreads();
     if (!s_last) return;
     __threadfence();                                   // acquire: the other splits' copies
+    // The whole workgroup walks the tile row-major - consecutive work-items take consecutive channels of one pixel: coalesced -
+    // and, per batch of four elements, ALL of their nsplit loads are issued before the first sum: a lane that summed its own
+    // accumulator layout one dependent load at a time took ~100 us per tile (first hardware run of the round: +5 ms per step).
+    // Loads through a descriptor over the copies: splits >= nsplit are out of range -> zero fill, never added (the sum is
+    // part[0] + part[1] + ... in ascending order, the finishing kernel's bits).
+    const fsv_buf pbuf = fsv_make_buf(p.part, (long long)p.nsplit * p.part_stride * 4);
+    constexpr int EPT = BM * BN / NT;                  // elements per work-item
+    static_assert(EPT % 4 == 0, "tile / thread-count mismatch");
+    const int ns = p.nsplit;
+#pragma unroll 1
+    for (int e0 = 0; e0 < EPT; e0 += 4) {
+      float v[4][8];
+      long long eo[4];
+      bool ok[4];
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-      const int co = bn0 + wn * (TN * 32) + j * 32 + lrow;
-      if (co >= p.Cout) continue;
-      const float bvf = bias ? bias[co] : 0.f;
+      for (int u = 0; u < 4; ++u) {
+        const int e = (e0 + u) * NT + tid;             // element of the tile, row-major [BM][BN]
+        const int row = e / BN, col = e - row * BN;
+        const int m = bm0 + row, co = bn0 + col;
+        ok[u] = (m < p.Mz) & (co < p.Cout);
+        eo[u] = ok[u] ? out_pixel(m) * p.Cout + co : 0;
 #pragma unroll
-      for (int i = 0; i < TM; ++i) {
+        for (int k = 0; k < 8; ++k)
+          v[u][k] = fsv_buf_load1(pbuf, (ok[u] & (k < ns)) ? (unsigned)(((long long)k * p.part_stride + eo[u]) * 4) : FSV_BUF_OOB);
+      }
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int row = (r & 3) + 8 * (r >> 2) + 4 * lk;
-          const int m = bm0 + wm * (TM * 32) + i * 32 + row;
-          if (m >= p.Mz) continue;
-          const long long e = out_pixel(m) * p.Cout + co;
-          float v = p.part[e];
-          for (int k = 1; k < p.nsplit; ++k) v += p.part[(long long)k * p.part_stride + e];
-          if (bias) v += bvf;
-          v = fsv_act(v * p.scale, p.act);
-          if (p.res) v += p.res[e];
-          p.out[e] = v;
-        }
+      for (int u = 0; u < 4; ++u) {
+        if (!ok[u]) continue;
+        float acc = v[u][0];
+#pragma unroll
+        for (int k = 1; k < 8; ++k) if (k < ns) acc += v[u][k];
+        const int co = bn0 + ((e0 + u) * NT + tid) % BN;
+        if (bias) acc += bias[co];
+        acc = fsv_act(acc * p.scale, p.act);
+        if (p.res) acc += p.res[eo[u]];
+        p.out[eo[u]] = acc;
       }
     }
   }
@@ -1908,7 +1924,9 @@ static int fsv_conv_gather_impl(const float* in, const float* wt, const float* b
     if (!p.dense_out) return FSV_ERR_UNSUPPORTED;
     if (split_ws && (Cin % 4 == 0) && split_cap >= (long long)nsplit * total) {
       p.part = split_ws; p.part_stride = total;         // ordered: one copy of the output per split, summed by the finishing pass
-      p.tickets = split_tickets;                        // ... or, with tickets, by the tile's last workgroup (no finishing launch)
+      // ... or, with tickets, by the tile's last workgroup (no finishing launch): up to 8 splits (its register batch), copies
+      // within one buffer descriptor
+      p.tickets = (nsplit <= 8 && (long long)nsplit * total * 4 <= FSV_BUF_MAX_BYTES) ? split_tickets : nullptr;
     } else {
       (void)hipMemsetAsync(out, 0, (size_t)total * sizeof(float), stream);
     }

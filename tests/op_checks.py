@@ -132,12 +132,14 @@ def check_conv_up(device, n=2, cin=16, h=6, w=10, cout=24, k=3, act='lrelu', sta
     if stats and not amp:
         assert a[5] == bm[5]
     tol = 3e-3 if amp else REL_TOL
-    for name, got, want in (('y', a[0], ref), ('dx', a[1], xr.grad), ('dw', a[2], wr.grad), ('db', a[3], br.grad)):
-        assert_close('conv(up2x) %s' % name, got, want, tol)
     if folded and not amp:
         for name, u, v in zip(('y', 'dx', 'db'), (a[0], a[1], a[3]), (bm[0], bm[1], bm[3])):
             assert bool((u == v).all()), 'folded up-sampling changed the bits of %s' % name
         assert_close('conv(up2x) dw folded vs materialised', a[2], bm[2], 1e-6)      # (pixel-split atomics: summation order)
+    # (with a LeakyReLU epilogue and ~10^6 outputs a few pre-activations lie within rounding of the kink: their gradient takes slope 1
+    # on one side and 0.2 on the other - the large cases are run with act='none'; hardware record: 7.5e-3 of max|dx| on one element)
+    for name, got, want in (('y', a[0], ref), ('dx', a[1], xr.grad), ('dw', a[2], wr.grad), ('db', a[3], br.grad)):
+        assert_close('conv(up2x) %s' % name, got, want, tol)
     if expect_fold and not amp and cin % 4 == 0 and cout % 32 == 0:
         # every tile shape of the plan has its own UP instantiation (and the LD form its own address swizzle): forced, forward,
         # against the same tile on the materialised tensor - bit for bit, K splits included
