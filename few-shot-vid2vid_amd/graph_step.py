@@ -35,6 +35,12 @@ from . import networks as _networks
 _EARLY_G = os.environ.get('FSV_EARLY_G', '1') == '1'          # in-box A/B switch
 
 
+def _seg_early_g():
+    """N > 1 (segmented): the generator-mode forward pass as a segment of its own next to the discriminator's gradient exchange
+    (FSV_SEG_EARLY_G=0: the serial order of round 4, for the bit-identity tests and A/B runs; read at bind time)"""
+    return os.environ.get('FSV_SEG_EARLY_G', '1') == '1'
+
+
 def _flat(data_list):
     out = []
     for item in data_list:
@@ -98,6 +104,7 @@ class GraphedIteration:
         # middle range (weight generators, embeddings, flow network) runs next to the encoders' backward as well
         self.pieces = 3 if getattr(self.model, 'split_backward', False) is not True and getattr(self.model, 'split_backward', 0) == 3 \
             else (2 if self.split else 1)
+        self.seg_early = self.segmented and _seg_early_g()
         if self.segmented and self.opt_G.overlap:
             raise RuntimeError("with a process group build the optimisers with overlap=False: bucket hooks issue collectives "
                                "inside backward, which cannot be captured")
@@ -126,7 +133,8 @@ class GraphedIteration:
 
     def _seg_d(self, e):
         # iterations without a gradient exchange: the discriminator step runs on a side stream next to the generator-mode forward
-        # pass (model.early_generator); with segments the branch would have to cross the all-reduce between two graphs
+        # pass (model.early_generator); with segments the branch would have to cross the all-reduce between two graphs - there the
+        # generator-mode pass becomes a segment of its own next to that all-reduce (_seg_gf)
         was = self.model.early_generator
         self.model.early_generator = (not self.segmented) and _EARLY_G
         self._d_stepped = False
@@ -134,6 +142,10 @@ class GraphedIteration:
             e.out_d = self._backward(self.model(e.static, mode='discriminator'), self.opt_D)
         finally:
             self.model.early_generator = was
+
+    def _seg_gf(self, e):
+        # N > 1: the generator-mode forward pass of train.py:61 while the discriminator's gradients are being exchanged
+        self.model.early_generate(e.static)
 
     def _seg_g(self, e, save_images):
         if not getattr(self, '_d_stepped', False):
@@ -162,6 +174,17 @@ class GraphedIteration:
     def _seg_a(self):
         self.opt_G.adam()
 
+    # ---- the collectives between the segments (host side; never captured) -------------------------------------------------
+    def _exchange_d(self):
+        # the discriminator's 11 MB on the optimiser's side stream: it runs next to the segment that follows (_seg_gf)
+        self.opt_D.exchange_range(0, self.opt_D.total, side=True)
+
+    def _wait_d(self):
+        self.opt_D.wait_exchange()
+
+    def _exchange_d_serial(self):
+        self.opt_D.exchange_all()
+
     def _exchange_g_first(self):
         self.opt_G.exchange_range(0, self.opt_G.split_at, side=True)
 
@@ -173,21 +196,46 @@ class GraphedIteration:
         self.opt_G.exchange_range(self.opt_G.split_at2 if self.pieces == 3 else self.opt_G.split_at, self.opt_G.total)
         self.opt_G.wait_exchange()
 
-    def _eager(self, e, save_images):
-        self._seg_d(e)
-        if self.segmented:
-            self.opt_D.exchange_all()
-        self._seg_g(e, save_images)
+    def _exchange_g_all(self):
+        self.opt_G.exchange_all()
+
+    def _steps(self, e, save_images):
+        """The iteration as (body, after) pairs: `body` is what one hipGraph segment captures, `after` runs on the host behind it
+        (the RCCL calls and the stream waits for them - nothing of that is captured).  Per iteration at N > 1 (two-piece backward):
+
+            D fwd + bwd             | all-reduce(D) -> side stream
+            G forward (train.py:61) |                   ... runs next to it | wait
+            Adam(D), D pass, losses, backward piece 1 | all-reduce(G decoder range) -> side stream
+            backward piece 2        |                   ... runs next to it | all-reduce(G rest), wait      <- the one on the critical path
+            Adam(G)
+        """
+        seg = self.segmented
+        steps = []
+        if seg and self.seg_early:
+            steps.append((lambda: self._seg_d(e), self._exchange_d))
+            steps.append((lambda: self._seg_gf(e), self._wait_d))
+        else:
+            steps.append((lambda: self._seg_d(e), self._exchange_d_serial if seg else None))
         if self.split:
-            self._exchange_g_first()
-            self._seg_g2()
+            steps.append((lambda: self._seg_g(e, save_images), self._exchange_g_first))
             if self.pieces == 3:
-                self._exchange_g_middle()
-                self._seg_g3()
-            self._exchange_g_rest()
-        elif self.segmented:
-            self.opt_G.exchange_all()
-        self._seg_a()
+                steps.append((self._seg_g2, self._exchange_g_middle))
+                steps.append((self._seg_g3, self._exchange_g_rest))
+            else:
+                steps.append((self._seg_g2, self._exchange_g_rest))
+        else:
+            steps.append((lambda: self._seg_g(e, save_images), self._exchange_g_all if seg else None))
+        steps.append((self._seg_a, None))
+        return steps
+
+    def n_segments(self):
+        return (3 + (self.pieces - 1 if self.split else 0) + (1 if (self.segmented and self.seg_early) else 0))
+
+    def _eager(self, e, save_images):
+        for body, after in self._steps(e, save_images):
+            body()
+            if after is not None:
+                after()
 
     # one poll period of ProcessGroupNCCL's watchdog thread (kWatchdogThreadSleepMillis = 100 ms in torch 2.x) plus margin
     WATCHDOG_PERIOD_S = 0.15
@@ -216,44 +264,26 @@ class GraphedIteration:
             with torch.cuda.graph(g):
                 self._eager(e, save_images)
             e.graphs = [g]
-            e.replayed_by_capture = False
+            e.afters = [None]
             return
         # the captures only police their own thread (the RCCL watchdog polls its events from another one); the caller replays
         # the whole sequence - with the all-reduces between the graphs - once all of them exist
-        gs = [torch.cuda.CUDAGraph() for _ in range(2 + self.pieces if self.split else 3)]
-        with torch.cuda.graph(gs[0], capture_error_mode='thread_local'):
-            self._seg_d(e)
-        with torch.cuda.graph(gs[1], pool=gs[0].pool(), capture_error_mode='thread_local'):
-            self._seg_g(e, save_images)
-        if self.split:
-            with torch.cuda.graph(gs[2], pool=gs[0].pool(), capture_error_mode='thread_local'):
-                self._seg_g2()
-            if self.pieces == 3:
-                with torch.cuda.graph(gs[3], pool=gs[0].pool(), capture_error_mode='thread_local'):
-                    self._seg_g3()
-        with torch.cuda.graph(gs[-1], pool=gs[0].pool(), capture_error_mode='thread_local'):
-            self._seg_a()
+        steps = self._steps(e, save_images)
+        gs = [torch.cuda.CUDAGraph() for _ in steps]
+        for k, (body, _) in enumerate(steps):
+            kw = dict(capture_error_mode='thread_local')
+            if k:
+                kw['pool'] = gs[0].pool()
+            with torch.cuda.graph(gs[k], **kw):
+                body()
         e.graphs = gs
-        e.replayed_by_capture = False
+        e.afters = [after for _, after in steps]
 
     def _replay(self, e):
-        if len(e.graphs) == 1:
-            e.graphs[0].replay()
-        elif len(e.graphs) == 3:
-            e.graphs[0].replay(); self.opt_D.exchange_all()
-            e.graphs[1].replay(); self.opt_G.exchange_all()
-            e.graphs[2].replay()
-        elif len(e.graphs) == 4:
-            e.graphs[0].replay(); self.opt_D.exchange_all()
-            e.graphs[1].replay(); self._exchange_g_first()          # side stream: overlaps the next graph
-            e.graphs[2].replay(); self._exchange_g_rest()
-            e.graphs[3].replay()
-        else:
-            e.graphs[0].replay(); self.opt_D.exchange_all()
-            e.graphs[1].replay(); self._exchange_g_first()          # side stream: overlaps the second piece
-            e.graphs[2].replay(); self._exchange_g_middle()         # side stream, behind the first range: overlaps the third piece
-            e.graphs[3].replay(); self._exchange_g_rest()
-            e.graphs[4].replay()
+        for g, after in zip(e.graphs, e.afters):
+            g.replay()
+            if after is not None:
+                after()
 
     def _capture_failed(self, e, key, ex):
         """a capture raised (e.g. hipErrorCapturedEvent from a foreign event query, an allocation the capture could not make):
@@ -279,7 +309,7 @@ class GraphedIteration:
 
     def launch_mode(self):
         """how the iterations of this object reach the device - for bench.py's `config.launch`"""
-        n = 2 + self.pieces if self.split else 3
+        n = self.n_segments()
         if self.capture_failures:
             return ('eager fallback (hipGraph capture failed: %s)%s' % (self.capture_failures[-1][1],
                     ', all-reduce between %d eager segments' % n if self.segmented else ''))
@@ -287,7 +317,9 @@ class GraphedIteration:
             return 'emulated kernels on host tensors, %d eager segments' % n if self.segmented else 'emulated kernels, eager'
         if not self.segmented:
             return 'hipgraph'
-        return 'hipgraph x%d + RCCL all-reduce between segments%s' % (n, ' (decoder-stage range on a side stream)' if self.split else '')
+        return 'hipgraph x%d + RCCL all-reduce between segments%s%s' % (
+            n, ' (decoder-stage range on a side stream)' if self.split else '',
+            ' (discriminator range on a side stream next to the generator-mode forward pass)' if self.seg_early else '')
 
     # ------------------------------------------------------------------------------------------------ call
     def __call__(self, data_list, save_images=False):

@@ -681,6 +681,18 @@ class Vid2VidModel(nn.Module):
             flat.extend(item if isinstance(item, (list, tuple)) else [item])
         return tuple(None if t is None else (id(t), t.data_ptr(), t._version) for t in flat)
 
+    def early_generate(self, data_list):
+        """The generator-mode forward pass of train.py:61 issued AHEAD of the `mode='generator'` call that will use it, on the
+        caller's stream (no side stream): graph_step.GraphedIteration puts it, as a segment of its own, between the launch of the
+        discriminator's gradient all-reduce and the wait for it - at N > 1 the exchange then runs next to the generator's whole
+        forward pass instead of in front of it.  The pass depends on nothing the discriminator step produces (see
+        `early_generator`); same kernels, same per-network order: bit-identical to the serial schedule."""
+        tgt_label, tgt_image, _, _, ref_label, ref_image, p_label, p_real, p_fake = data_list
+        with conv.stats_pass(tgt_label_device(data_list)):
+            gen = self.generate_images(encode_label(self.opt, tgt_label), tgt_image, encode_label(self.opt, ref_label), ref_image,
+                                       [p_label, p_real, p_fake])
+        self._pre_g = (self._data_key(data_list), streams.Branch(None), gen)
+
     def join_early(self, data_list=None):
         """join the discriminator step's side stream into the current one; returns (generator pass, real-image pass or None) if
         `data_list` is the data the early passes were computed from (else None: they are dropped)"""

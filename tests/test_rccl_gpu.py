@@ -1,7 +1,9 @@
 """The data-parallel path on real hardware (RCCL = torch's 'nccl' backend on ROCm).
 
-* one rank (any GPU box): bench.py's N > 1 code path - hook-free optimisers, four hipGraph segments, the decoder-stage
-  gradient range all-reduced on a side stream next to the third graph - forced in a one-rank RCCL group (FSV_FORCE_DIST=1);
+* one rank (any GPU box): bench.py's N > 1 code path - hook-free optimisers, five hipGraph segments, the discriminator's
+  gradients all-reduced on a side stream next to the generator-mode forward pass, the decoder-stage range next to the second
+  backward piece - forced in a one-rank RCCL group (FSV_FORCE_DIST=1), and (round 5) the weights after three real Adam steps of
+  that path held BIT FOR BIT to the plain single-graph run;
 * two ranks (only when the box shows >= 2 devices; the driver's single-GPU boxes skip it): the same path on two GPUs keeps the
   replicas in lock-step and produces the gradients of one process that sees both shards (mirror of test_ddp_gloo.py)."""
 import json
@@ -25,9 +27,66 @@ def test_one_rank_rccl_runs_the_segmented_bench_path(hip_lib):
     assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])
     line = [l for l in r.stdout.splitlines() if l.startswith('{')][-1]
     res = json.loads(line)
-    assert res['value'] > 0 and 'hipgraph x4' in res['config']['launch'], res['config']
+    assert res['value'] > 0 and 'hipgraph x5' in res['config']['launch'] and 'next to the generator-mode forward pass' in res['config']['launch'], res['config']
     # and the same step without the process group gives the same throughput class (sanity, not a benchmark)
     assert res['n_gpus'] == 1
+
+
+def _one_rank(rank, port, out_dir, mode):
+    """three iterations (eager warm-up, capture + replay, replay) with real Adam steps in the fixed-order mode; mode 'plain': one
+    hipGraph, no process group; 'rccl': the N > 1 schedule in a one-rank RCCL group; 'rccl_serial': that schedule in round 4's order"""
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY='0', FSV_DETERMINISTIC='1')
+    os.environ.pop('FSV2V_EMU', None)
+    if mode == 'rccl_serial':
+        os.environ['FSV_SEG_EARLY_G'] = '0'
+    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    import datetime
+    import torch.distributed as dist
+    import model_checks as mc
+    from importlib import import_module
+    torch.cuda.set_device(0)
+    dev = torch.device('cuda', 0)
+    if mode != 'plain':
+        dist.init_process_group('nccl', rank=0, world_size=1, timeout=datetime.timedelta(seconds=120), device_id=dev)
+    M = mc._model()
+    gs = import_module('few-shot-vid2vid_amd.graph_step')
+    opt = mc.tiny_opt(ngf=8, ndf=8, nff=8, warp_ref=True, spade_combine=True, fineSize=64, loadSize=64)
+    model = M.create_model(opt)
+    mc.fill_state(model.netG); mc.fill_state(model.netD)
+    model = model.to(dev).train()
+    if mode == 'plain':
+        model.build_optimizers(split_backward=True)
+    else:
+        model.build_optimizers(world_size=1, force_exchange=True, overlap=False, split_backward=True)
+    gi = gs.GraphedIteration(model, opt, warmup=1)
+    tl, ti, rl, ri = [t.to(dev) for t in mc.synth_pose_inputs(1, 64, 64, 300, 6)]
+    data = [tl, ti, [None, None], [None, None], rl, ri, None, None, None]
+    for it in range(3):
+        gi(data)
+    torch.cuda.synchronize()
+    torch.save(dict(launch=gi.launch_mode(),
+                    G={n: p.detach().cpu() for n, p in model.netG.named_parameters()},
+                    D={n: p.detach().cpu() for n, p in model.netD.named_parameters()}),
+               os.path.join(out_dir, 'one_rank_%s.pt' % mode))
+    if mode != 'plain':
+        dist.destroy_process_group()
+
+
+def test_one_rank_rccl_schedule_reproduces_the_single_graph_weights(hip_lib, tmp_path):
+    """round-4 review: the one-rank run asserted `value > 0`.  Now: three iterations with real Adam steps (fixed-order mode, so that
+    a run is bit-reproducible) through (a) one hipGraph without a process group, (b) the N > 1 schedule - five segments, the
+    discriminator range exchanged on a side stream next to the generator-mode forward pass, the decoder-stage range next to
+    the second backward piece - in a one-rank RCCL group: all weights of G and D equal bit for bit.  (Round 4's serial order against
+    this one, and the sum over ranks that a one-rank group cannot show: two gloo ranks, tests/test_ddp_gloo.py.)"""
+    import torch.multiprocessing as mp
+    for k, mode in enumerate(('plain', 'rccl')):
+        mp.spawn(_one_rank, args=(29651 + 2 * k, str(tmp_path), mode), nprocs=1, join=True)
+    a = torch.load(os.path.join(tmp_path, 'one_rank_plain.pt'))
+    b = torch.load(os.path.join(tmp_path, 'one_rank_rccl.pt'))
+    assert a['launch'] == 'hipgraph' and 'hipgraph x5' in b['launch'], (a['launch'], b['launch'])
+    for net in ('G', 'D'):
+        for n in a[net]:
+            assert torch.equal(a[net][n], b[net][n]), 'one-rank RCCL schedule: %s.%s differs from the single-graph run' % (net, n)
 
 
 def _worker(rank, world, port, out_dir, split):
