@@ -31,13 +31,47 @@ def _conv():
     return import_module('few-shot-vid2vid_amd.conv')
 
 
+# ---- the configurations, and the oracle runs their tests will ask for (conftest.py hands ORACLE_SPECS to tests/oracle_worker.py,
+# which computes the pairs on the host cores while the GPU runs the rest of the suite; a test whose pair is not there computes it
+# inline - model_checks.oracle_pair) --------------------------------------------------------------------------------------------
+def _c1():
+    return mc.make_opt(dataset_mode='fewshot_face', input_nc=1, fineSize=128, loadSize=128, batchSize=1)
+
+
+def _c3():
+    return mc.make_opt(warp_ref=True, spade_combine=True, remove_face_labels=True, fineSize=512, loadSize=512, batchSize=2)
+
+
+def _c4():
+    return mc.make_opt(warp_ref=True, spade_combine=True, remove_face_labels=True, add_face_D=True, no_vgg_loss=False,
+                       fineSize=512, loadSize=512, batchSize=2)
+
+
+def _c5(amp='O0'):
+    return mc.make_opt(dataset_mode='fewshot_street', label_nc=35, input_nc=3, aspect_ratio=2.0, fineSize=1024, loadSize=1024,
+                       batchSize=1, amp=amp)
+
+
+ORACLE_SPECS = {
+    'test_c1_face_128_full_step': lambda it: [mc.oracle_spec('fp32', _c1(), 1, it.callspec.params['seed'])],
+    'test_c1_face_128_full_step_inputs_on_a_kink': lambda it: [mc.oracle_spec('fp32', _c1(), 1, it.callspec.params['seed'])],
+    'test_c1_face_128_full_step_fixed_order': lambda it: [mc.oracle_spec('fp32', _c1(), 1, 24)],
+    'test_c3_pose_512_b2_full_step_is_the_bench_workload': lambda it: [mc.oracle_spec('fp32', _c3(), 2, 21)],
+    'test_c3_pose_512_b2_in_the_schedule_bench_py_runs': lambda it: [mc.oracle_spec('fp32', _c3(), 2, 21)],
+    'test_c4_pose_512_face_d_vgg': lambda it: [mc.oracle_spec('fp32', _c4(), 2, 21)],
+    'test_c5_street_1024x512_nc35_fp32': lambda it: [mc.oracle_spec('fp32', _c5(), 1, 21)],
+    'test_c5_street_1024x512_nc35_amp': lambda it: [mc.oracle_spec('amp', _c5('O1'), 1, 21, loss_scale=1024.0)],
+    'test_c5_street_1024x512_nc35_amp_in_the_schedule_bench_py_runs': lambda it: [mc.oracle_spec('amp', _c5('O1'), 1, 21, loss_scale=1024.0)],
+}
+
+
 @pytest.mark.parametrize('seed', [23, 24])
 def test_c1_face_128_full_step(hip_lib, seed):
     """C1 in the DEFAULT mode at the 1e-2 gradient bar.  Since round 4 the split-K launches of the fp32 gather-GEMM sum their
     splits in a fixed order (csrc/conv_igemm.hip fsv_split_finish_kernel) - the source of the run-to-run variation round 3 traced
     (tests/c1_kink.py): the step now lands on the same side of every LeakyReLU kink on every run (two runs per seed on hardware:
     1.65e-3 / 1.87e-3 and 2.79e-3 / 2.80e-3 - what still varies is the weight gradients' pixel-split atomics, 1e-4)."""
-    opt = mc.make_opt(dataset_mode='fewshot_face', input_nc=1, fineSize=128, loadSize=128, batchSize=1)
+    opt = _c1()
     worst = mc.check_train_step(DEV, opt, b=1, tol=1e-3, grad_tol=1e-2, seed=seed)
     assert worst < 1e-2, worst
 
@@ -50,7 +84,7 @@ def test_c1_face_128_full_step_inputs_on_a_kink(hip_lib, seed, band):
     carries 3.6 % of that layer's weight gradient (profiles/r03_notes.md section 8): 3.58e-2, the same value on every run since the
     ordered split; seed 22: 1.03e-2, again one activation.  Both sides are correct fp32 evaluations; no implementation can be held
     to 1e-2 on these inputs.  Losses and images hold 1e-3 here too; the gradient band is the measured outcome plus margin."""
-    opt = mc.make_opt(dataset_mode='fewshot_face', input_nc=1, fineSize=128, loadSize=128, batchSize=1)
+    opt = _c1()
     worst = mc.check_train_step(DEV, opt, b=1, tol=1e-3, grad_tol=band, seed=seed)
     assert worst < band, worst
 
@@ -60,7 +94,7 @@ def test_c1_face_128_full_step_fixed_order(hip_lib, monkeypatch):
     workgroups in the weight gradients, normalisation statistics from their own pass - ten runs of this step from the same state
     are bit-equal, tests/c1_repro.py)."""
     monkeypatch.setenv('FSV_DETERMINISTIC', '1')
-    opt = mc.make_opt(dataset_mode='fewshot_face', input_nc=1, fineSize=128, loadSize=128, batchSize=1)
+    opt = _c1()
     worst = mc.check_train_step(DEV, opt, b=1, tol=1e-3, grad_tol=1e-2, seed=24)
     assert worst < 1e-2, worst
 
@@ -73,7 +107,7 @@ def test_c2_face_256_b4_generator_fwd_bwd(hip_lib):
 
 def test_c3_pose_512_b2_full_step_is_the_bench_workload(hip_lib):
     conv = _conv()
-    opt = mc.make_opt(warp_ref=True, spade_combine=True, remove_face_labels=True, fineSize=512, loadSize=512, batchSize=2)
+    opt = _c3()
     conv.start_plan_log()
     try:
         worst = mc.check_train_step(DEV, opt, b=2, tol=1e-3, grad_tol=1e-2)
@@ -97,7 +131,7 @@ def test_c3_pose_512_b2_in_the_schedule_bench_py_runs(hip_lib):
     generator-mode forward pass, the G step's real-image pass behind it, the generator's backward in two pieces - against the
     oracle at the same bars.  (The kernels are the ones of the test above - the fused bn_s -> conv_s kernel included, which both
     run; what this adds is the schedule.)"""
-    opt = mc.make_opt(warp_ref=True, spade_combine=True, remove_face_labels=True, fineSize=512, loadSize=512, batchSize=2)
+    opt = _c3()
     worst = mc.check_train_step(DEV, opt, b=2, tol=1e-3, grad_tol=1e-2, bench_schedule=True)
     assert worst < 1e-2, worst
 
@@ -107,8 +141,7 @@ def test_c4_pose_512_face_d_vgg(hip_lib):
     with it - loss_collector.py:70-85): full width, 512x512, the per-GPU batch of 2, full D step (netD + netDf) + G step against
     the oracle in fp32 and fp64.  VGG19 runs on seeded random weights (no checkpoint in this environment; the oracle gets the
     same tensors)."""
-    opt = mc.make_opt(warp_ref=True, spade_combine=True, remove_face_labels=True, add_face_D=True, no_vgg_loss=False,
-                      fineSize=512, loadSize=512, batchSize=2)
+    opt = _c4()
     worst = mc.check_train_step(DEV, opt, b=2, tol=1e-3, grad_tol=1e-2)
     assert worst < 1e-2, worst
 
@@ -117,8 +150,7 @@ def test_c5_street_1024x512_nc35_fp32(hip_lib):
     """BASELINE.json configs[4] per rank in fp32 (data/fewshot_street_dataset.py:19-27: W 1024 x H 512, --label_nc 35 one-hot
     labels, --adaptive_spade; one sample per GPU of the 8-GPU batch of 8): full width, full D step + G step against the oracle.
     The config's own arithmetic (--amp O1) is the next test."""
-    opt = mc.make_opt(dataset_mode='fewshot_street', label_nc=35, input_nc=3, aspect_ratio=2.0, fineSize=1024, loadSize=1024,
-                      batchSize=1)
+    opt = _c5()
     worst = mc.check_train_step(DEV, opt, b=1, tol=1e-3, grad_tol=1e-2)
     assert worst < 1e-2, worst
 
@@ -141,8 +173,7 @@ def test_c5_street_1024x512_nc35_amp(hip_lib):
     *Parity unpinned against apex*: apex is neither vendored by the reference nor installable here and has no CPU path, so no
     reference output exists for this mode; the oracle states the definition (operands and half-stored activations rounded to
     IEEE half, exact products, fp32 accumulation, fp32 everywhere else) and this test pins the product to it."""
-    opt = mc.make_opt(dataset_mode='fewshot_street', label_nc=35, input_nc=3, aspect_ratio=2.0, fineSize=1024, loadSize=1024,
-                      batchSize=1, amp='O1')
+    opt = _c5('O1')
     mc.check_amp_train_step(DEV, opt, b=1, tol=1e-3, grad_tol=1e-2)
 
 
@@ -150,7 +181,6 @@ def test_c5_street_1024x512_nc35_amp_in_the_schedule_bench_py_runs(hip_lib):
     """configs[4] per rank in its stated arithmetic, issued the way `bench.py --workload street --amp O1` issues it on one GPU
     (discriminator step on a side stream next to the generator-mode forward pass, real-image pass behind it, two-piece backward):
     the same whole-iteration oracle run, the same bars.  *Parity unpinned against apex* (see the test above)."""
-    opt = mc.make_opt(dataset_mode='fewshot_street', label_nc=35, input_nc=3, aspect_ratio=2.0, fineSize=1024, loadSize=1024,
-                      batchSize=1, amp='O1')
+    opt = _c5('O1')
     mc.check_amp_train_step(DEV, opt, b=1, tol=1e-3, grad_tol=1e-2, bench_schedule=True)
 

@@ -84,3 +84,46 @@ def test_bench_workloads_name_their_configuration(emu_lib):
     assert 'fewshot_street' in rec['metric'] and '64x32' in rec['metric'] and 'label_nc 35' in rec['config']['workload']
     rec = _bench_one_rank({}, '--workload', 'face256', '--size', '32')
     assert 'G fwd+bwd' in rec['metric'] and 'fewshot_face' in rec['metric'] and rec['value'] > 0
+
+
+def test_oracle_worker_round_trip(tmp_path, monkeypatch):
+    """tests/oracle_worker.py (started by conftest.py next to a hardware session) leaves a whole-iteration oracle pair in the cache
+    directory and model_checks.oracle_pair picks it up: the same tensors as the inline computation; a spec nobody queued is computed
+    inline; every full-size test that compares against such a pair is declared in test_fullsize_gpu.ORACLE_SPECS"""
+    import inspect
+    import json
+    import torch
+    import model_checks as mc
+    import test_fullsize_gpu as tf
+    opt = mc.tiny_opt(ngf=4, ndf=4, nff=4, fineSize=32, loadSize=32, n_downsample_G=3, n_adaptive_layers=2, batchSize=1)
+    spec = mc.oracle_spec('fp32', opt, 1, 77)
+    assert json.loads(json.dumps(spec)) == spec
+    spec_file = tmp_path / 'specs.json'
+    spec_file.write_text(json.dumps([spec]))
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'tests', 'oracle_worker.py'), str(tmp_path), '2', str(spec_file)],
+                       cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    key = mc.oracle_key(spec)
+    assert os.path.exists(tmp_path / (key + '.pt')) and not os.path.exists(tmp_path / (key + '.queued'))
+    inline = mc.compute_oracle_pair(spec)
+    monkeypatch.setenv('FSV_ORACLE_CACHE', str(tmp_path))
+    mc._ORACLE_CACHE.clear()
+    got = mc.oracle_pair(spec)
+    assert not os.path.exists(tmp_path / (key + '.pt'))              # consumed
+    # (the host library's summation order depends on the thread count - 2 in the worker above, all cores inline: the runs agree
+    # to rounding, which is what the tests' fp32-vs-fp64 noise allowance measures anyway)
+    for (a, b), tol in zip(zip(got, inline), (1e-4, 1e-10)):          # (fp32 run, fp64 run)
+        close = lambda u, v: float((u.double() - v.double()).abs().max()) <= tol * max(float(v.double().abs().max()), 1e-30)
+        assert a[4]['fake'].dtype == b[4]['fake'].dtype and close(a[4]['fake'], b[4]['fake'])
+        # (gradients that are mathematically zero - a convolution bias in front of a normalisation - are rounding noise on both
+        # sides: compare the parameters that carry a gradient)
+        big = sorted(b[3], key=lambda k: -float(b[3][k].double().norm()))[:20]
+        assert set(a[3]) == set(b[3]) and all(close(a[3][k], b[3][k]) for k in big)
+    other = mc.oracle_spec('fp32', opt, 1, 78)
+    mc._ORACLE_CACHE.clear()
+    assert mc.oracle_pair(other)[0][4]['fake'].shape == inline[0][4]['fake'].shape       # not queued: computed inline, no wait
+    mc._ORACLE_CACHE.clear()
+    names = {n for n, f in inspect.getmembers(tf, inspect.isfunction) if n.startswith('test_')}
+    assert set(tf.ORACLE_SPECS) <= names, set(tf.ORACLE_SPECS) - names
+    uses = {n for n in names if 'check_train_step' in inspect.getsource(getattr(tf, n)) or 'check_amp_train_step' in inspect.getsource(getattr(tf, n))}
+    assert uses == set(tf.ORACLE_SPECS), uses ^ set(tf.ORACLE_SPECS)
