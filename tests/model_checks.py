@@ -345,7 +345,8 @@ def oracle_pair(spec, wait_s=1500.0):
     return val
 
 
-def check_train_step(device, opt, b=2, tol=1e-3, seed=21, grad_tol=2e-2, with_flow_gt=False, ref64=True, bench_schedule=False):
+def check_train_step(device, opt, b=2, tol=1e-3, seed=21, grad_tol=2e-2, with_flow_gt=False, ref64=True, bench_schedule=False,
+                     capture=None):
     """Full D-step + G-step of the product model (flat Adam included) against the oracle.
 
     Losses and images are held to `tol` (1e-3 relative, BASELINE.json).  Parameter gradients of the *step* get the
@@ -362,6 +363,11 @@ def check_train_step(device, opt, b=2, tol=1e-3, seed=21, grad_tol=2e-2, with_fl
     sdDf0 = fill_state(model.netDf) if model.netDf is not None else None
     sdGf0 = fill_state(model.netGf) if getattr(model, 'netGf', None) is not None else None
     model = model.to(device).train()
+    if capture is not None:          # {module name under netG: None} -> filled with the module's last output (diagnostics of a test)
+        mods = dict(model.netG.named_modules())
+        for name in list(capture):
+            mods[name].register_forward_hook(lambda m, i, o, name=name: capture.__setitem__(name, o.detach().double().cpu()))
+        capture['_netG'] = model.netG
     # bench_schedule: the iteration the way bench.py issues it on one GPU - the discriminator step on a side stream next to the
     # generator-mode forward pass (model.early_generator), the real-image pass behind it, the generator's backward in two pieces
     opt_G, opt_D = model.build_optimizers(split_backward=bool(bench_schedule))

@@ -78,15 +78,30 @@ def test_c1_face_128_full_step(hip_lib, seed):
 
 @pytest.mark.parametrize('seed,band', [(21, 5e-2)])
 def test_c1_face_128_full_step_inputs_on_a_kink(hip_lib, seed, band):
-    """The two seeds of the same configuration whose input puts ONE pre-activation of a 16-pixel layer (ONE sample, 128x128: the
-    up path of the reference-image encoder normalises 16 pixels per channel) within rounding of the LeakyReLU kink: seed 21 -
-    channel 46, pixel 6 of ref_img_up_2 is -1e-6 in the oracle and +3e-6 here, 25 ulp from the kink, and its slope (1 or 0.2)
-    carries 3.6 % of that layer's weight gradient (profiles/r03_notes.md section 8): 3.58e-2, the same value on every run since the
-    ordered split; seed 22: 1.03e-2, again one activation.  Both sides are correct fp32 evaluations; no implementation can be held
-    to 1e-2 on these inputs.  Losses and images hold 1e-3 here too; the gradient band is the measured outcome plus margin."""
+    """A seed of the same configuration whose input puts ONE pre-activation of a 16-pixel layer (ONE sample, 128x128: the up path of
+    the reference-image encoder normalises 16 pixels per channel) within rounding of the LeakyReLU kink: seed 21 - channel 46,
+    pixel 6 of ref_img_up_2 is -1e-6 in the oracle and +3e-6 here, 25 ulp from the kink, and its slope (1 or 0.2) carries 3.6 % of
+    that layer's weight gradient (profiles/r03_notes.md section 8): 3.58e-2, the same value on every run since the ordered split.
+    Both sides are correct fp32 evaluations; no implementation can be held to 1e-2 on these inputs.  Losses and images hold 1e-3
+    here too.  Round 5: the kink condition is ASSERTED, not narrated - the product's own pre-activation z = BatchNorm(conv(x)) of
+    that layer is captured in the step, and the wide band is admitted only if an element of it lies within 2e-5 of zero (25 ulp
+    of the layer's unit-variance values is 3e-6); without such an element the step is held to the plain 1e-2."""
     opt = _c1()
-    worst = mc.check_train_step(DEV, opt, b=1, tol=1e-3, grad_tol=band, seed=seed)
-    assert worst < band, worst
+    cap = {'ref_img_up_2.conv': None}
+    try:
+        worst = mc.check_train_step(DEV, opt, b=1, tol=1e-3, grad_tol=band, seed=seed, capture=cap)
+    finally:
+        y, net = cap.get('ref_img_up_2.conv'), cap.get('_netG')
+    assert y is not None, 'the layer was not captured'
+    bn = net.ref_img_up_2.bn
+    yy = y.permute(1, 0, 2, 3).reshape(y.shape[1], -1)                                   # [C, N*H*W]: 16 pixels per channel
+    assert yy.shape[1] == 16, yy.shape
+    z = ((yy - yy.mean(1, keepdim=True)) / torch.sqrt(yy.var(1, unbiased=False, keepdim=True) + 1e-5) *
+         bn.weight.detach().double().cpu()[:, None] + bn.bias.detach().double().cpu()[:, None])
+    zmin = float(z.abs().min())
+    print('seed %d: min |pre-activation| of ref_img_up_2 = %.2e, worst gradient rel L2 %.3e' % (seed, zmin, worst))
+    on_kink = zmin < 2e-5
+    assert worst < (band if on_kink else 1e-2), (worst, zmin)
 
 
 def test_c1_face_128_full_step_fixed_order(hip_lib, monkeypatch):
