@@ -229,7 +229,7 @@ lib.register_sigs({
     "fsv_conv_gather_fwd_stats": [ctypes.c_void_p] * 5 + [ctypes.c_int] * 8 + [ctypes.POINTER(ctypes.c_int)] * 2 +
                                  [ctypes.c_int] * 4 + [ctypes.c_float, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int,
                                                        ctypes.c_int, ctypes.POINTER(ctypes.c_int), ctypes.c_void_p,
-                                                       ctypes.c_longlong, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p],
+                                                       ctypes.c_longlong, ctypes.c_int, ctypes.c_void_p],
 })
 
 GROUP_LIMIT = 64          # FSV_GROUP_LIMIT (csrc/conv_igemm.hip)
@@ -495,15 +495,8 @@ def gather_gemm(x, wt, ldw, cout, oh, ow, ty, tx, sy, sx, bias=None, res=None, a
                      force_split)[1]
         if ns > 1 and act != ACT_DLRELU:
             split_ws = torch.empty(ns * out.numel(), dtype=torch.float32, device=x.device)
-    # the ordered-split workspace is an explicit (nullable) argument of the call that may use it (include/fsv2v.h); with tickets
-    # (round 5) the tile's last workgroup sums the splits and finishes - no finishing launch (FSV_SPLIT_TICKETS=0: in-box A/B)
-    tickets = None
-    if split_ws is not None and cin % 4 == 0 and os.environ.get('FSV_SPLIT_TICKETS', '1') == '1':
-        mz_, ns_ = (oh * ow if per_sample else n * oh * ow), (n if per_sample else 1)
-        bm_, bn_ = _TILE_DIMS[planned(mz_, cout, (len(ty) * cin + 31) // 32, ns_, force_tile, force_split)[0] if force_tile < 0
-                              else _shape_of_tile(force_tile)]
-        tickets = ticket_range(x, -(-mz_ // bm_) * -(-cout // bn_) * ns_)
-    ws_args = (lib.ptr(split_ws), split_ws.numel() if split_ws is not None else 0, tickets)
+    # the ordered-split workspace is an explicit (nullable) argument of the call that may use it (include/fsv2v.h)
+    ws_args = (lib.ptr(split_ws), split_ws.numel() if split_ws is not None else 0)
     if entry == "fsv_conv_gather_fwd_np":
         if up:
             raise ValueError("a folded up-sampling needs the exact-fp32 kernels (conv.up_foldable)")
@@ -574,7 +567,7 @@ _TICKET_POOL = 1 << 16
 
 def ticket_range(like, n):
     """address of n (rounded up to 64) ZEROED ints for one launch that finishes in its last workgroup (the fused reductions of
-    csrc/norm.hip, the ordered split-K of csrc/conv_igemm.hip): a ring over a per-device pool, so that launches which may overlap
+    csrc/norm.hip): a ring over a per-device pool, so that launches which may overlap
     (branch streams, neighbouring graph nodes) never share a range; every launch leaves its range zeroed.  None when n does not
     fit the pool (the caller takes its two-launch form)."""
     n = (max(int(n), 1) + 63) // 64 * 64
@@ -589,11 +582,6 @@ def ticket_range(like, n):
         cur = 0
     ent[1] = (cur + n) % _TICKET_POOL
     return ctypes.c_void_p(pool.data_ptr() + 4 * cur)
-
-
-def _shape_of_tile(tile):
-    """tile SHAPE id (a key of _TILE_DIMS) of a forced tile id (csrc/conv_igemm.hip fsv_tile_dims)"""
-    return {10: 9, 13: 9, 21: 9, 11: 0, 14: 0, 16: 0, 12: 1, 15: 1, 22: 1, 17: 4, 20: 4, 27: 4, 18: 2}.get(tile, tile)
 
 
 def ordered_split():

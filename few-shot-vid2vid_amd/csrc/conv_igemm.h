@@ -106,9 +106,6 @@ struct ConvP {
   long long res_bytes;                   // extent of the residual tensor when one descriptor covers it (else 0: loaded per element)
   float* part;                           // ordered split-K: split k stores its partial output at part + k * part_stride (else null:
   long long part_stride;                 // splits add into the zeroed output atomically)
-  int* tickets;                          // with `part`: one zeroed int per (sample, channel tile, pixel tile) - the workgroup that takes
-                                         // a tile's last ticket sums the splits in ascending order and applies the epilogue itself (no
-                                         // finishing launch); null: the finishing pass does
   int band;                              // XCD bands: an XCD owns a CONTIGUOUS run of (pixel tile, channel tile) pairs (conv_igemm.hip)
   int up;                                // 1: `in` is stored at HALF the resolution (H / 2 x W / 2) and read through the nearest x2
                                          // up-sampling index (y >> 1, x >> 1) - the up-sampled tensor (generator.py:124, 497-504, 541-572:

@@ -504,65 +504,13 @@ __device__ __forceinline__ void fsv_conv_igemm_body(const ConvP& p, const int bx
       }
     }
   }
-  // ---- ordered split-K without a finishing launch (round 5): every split of a tile has stored its partial copy above; the workgroup
-  // that takes the tile's last ticket sums the copies - ALL of them from memory, its own included, in ascending split order: the same
-  // bits whichever workgroup comes last - and applies the epilogue.  The pattern of the fused reductions (norm.hip): device-scope
-  // fence, ticket, fence.  Split-K grids are small by construction (the plan splits when the tiles do not fill the chip), so the
-  // fence per workgroup that cost 10 ms when EVERY convolution paid it (round 3) is a few hundred workgroups per launch here.
-  if (p.nsplit > 1 && p.part && p.tickets) {          // uniform
-    __shared__ int s_last;
-    __threadfence();
-    __syncthreads();
-    if (tid == 0) {
-      const int gx = (p.Mz + BM - 1) / BM, gy = (p.Cout + BN - 1) / BN;
-      int* t = p.tickets + ((long long)zs * gy + by) * gx + bx;
-      const int prev = atomicAdd(t, 1);
-      s_last = (prev == p.nsplit - 1) ? 1 : 0;
-      if (s_last) *t = 0;                              // nobody else touches it any more: ready for the next launch
-    }
-    __syncthreads();
-    if (!s_last) return;
-    __threadfence();                                   // acquire: the other splits' copies
-    // The whole workgroup walks the tile row-major - consecutive work-items take consecutive channels of one pixel: coalesced -
-    // and, per batch of four elements, ALL of their nsplit loads are issued before the first sum: a lane that summed its own
-    // accumulator layout one dependent load at a time took ~100 us per tile (first hardware run of the round: +5 ms per step).
-    // Loads through a descriptor over the copies: splits >= nsplit are out of range -> zero fill, never added (the sum is
-    // part[0] + part[1] + ... in ascending order, the finishing kernel's bits).
-    const fsv_buf pbuf = fsv_make_buf(p.part, (long long)p.nsplit * p.part_stride * 4);
-    constexpr int EPT = BM * BN / NT;                  // elements per work-item
-    static_assert(EPT % 4 == 0, "tile / thread-count mismatch");
-    const int ns = p.nsplit;
-#pragma unroll 1
-    for (int e0 = 0; e0 < EPT; e0 += 4) {
-      float v[4][8];
-      long long eo[4];
-      bool ok[4];
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int e = (e0 + u) * NT + tid;             // element of the tile, row-major [BM][BN]
-        const int row = e / BN, col = e - row * BN;
-        const int m = bm0 + row, co = bn0 + col;
-        ok[u] = (m < p.Mz) & (co < p.Cout);
-        eo[u] = ok[u] ? out_pixel(m) * p.Cout + co : 0;
-#pragma unroll
-        for (int k = 0; k < 8; ++k)
-          v[u][k] = fsv_buf_load1(pbuf, (ok[u] & (k < ns)) ? (unsigned)(((long long)k * p.part_stride + eo[u]) * 4) : FSV_BUF_OOB);
-      }
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        if (!ok[u]) continue;
-        float acc = v[u][0];
-#pragma unroll
-        for (int k = 1; k < 8; ++k) if (k < ns) acc += v[u][k];
-        const int co = bn0 + ((e0 + u) * NT + tid) % BN;
-        if (bias) acc += bias[co];
-        acc = fsv_act(acc * p.scale, p.act);
-        if (p.res) acc += p.res[eo[u]];
-        p.out[eo[u]] = acc;
-      }
-    }
-  }
 }
+
+// (Round 5 measured a finishing-pass-free form of the ordered split - the workgroup that takes a tile's last ticket sums the copies
+// and applies the epilogue: device-scope fence, ticket, fence, as in the fused reductions of norm.hip.  Bit-identical, and +4.4 ...
+// +5.1 ms per step in two forms (per-lane dependent loads; cooperative walk with 4 x nsplit loads in flight): isolated, M512 N1024
+// K4608 split 8 ran at 31 TFLOP/s against 65 with the finishing launch - the device-scope release every split workgroup pays (an L2
+// write-back on this part) costs more than the 16 us launch it saves.  profiles/r05_notes.md section 4; removed.)
 
 // XCD bands (round 4; the half-precision kernel's order, conv_h.hip): XCD x - the workgroups with linear id b % 8 == x - owns the
 // CONTIGUOUS run of tiles [start(x), start(x + 1)) in (pixel tile, channel tile) order with the channel tile fastest, so the pixel
@@ -1822,14 +1770,6 @@ extern "C" int fsv_conv_plan(int Mz, int Cout, int nchunks, int nsamp, int force
   return 0;
 }
 
-// number of tickets (output tiles over all samples) a split launch of this shape needs, 0 when the plan does not split
-extern "C" int fsv_conv_split_tiles(int Mz, int Cout, int nchunks, int nsamp, int force_tile, int force_split) {
-  int tile = 0, nsplit = 1, bm, bn;
-  if (fsv_conv_plan(Mz, Cout, nchunks, nsamp, force_tile, force_split, &tile, &nsplit) || nsplit <= 1) return 0;
-  if (fsv_tile_dims(tile, bm, bn)) return 0;
-  return fsv_cdiv(Mz, bm) * fsv_cdiv(Cout, bn) * nsamp;
-}
-
 // XCD order of the single-problem launches: 1 = bands (fsv_xcd_band), 0 = interleaved (fsv_xcd_tile); FSV_CONV_BAND: in-box A/B
 static inline int fsv_conv_band() {
   static int v = -1;
@@ -1855,7 +1795,7 @@ static inline void fsv_fill_convp(ConvP& p, const float* in, const float* wt, co
   p.Mz = per_sample ? OH * OW : N * OH * OW;
   p.nsplit = 1;
   p.stats = nullptr; p.stats_slots = 1; p.stats_ohw = 1;
-  p.part = nullptr; p.part_stride = 0; p.tickets = nullptr;
+  p.part = nullptr; p.part_stride = 0;
   p.band = fsv_conv_band(); p.up = 0;
   {
     const long long obytes = (long long)N * outH * outW * Cout * 4;
@@ -1875,7 +1815,7 @@ static int fsv_conv_gather_impl(const float* in, const float* wt, const float* b
                         int ldw, long long w_bstride, long long b_bstride, int per_sample,
                         int act, float scale, int force_tile, int force_split, int accumulate, const float* wscale,
                         double* stats, int stats_groups, int stats_slots, int stats_prezeroed, int* produced,
-                        float* split_ws, long long split_cap, int* split_tickets, int in_up, hipStream_t stream) {
+                        float* split_ws, long long split_cap, int in_up, hipStream_t stream) {
   if (!in || !wt || !out || ntaps < 1 || ntaps > 16 || N < 1 || Cin < 1 || Cout < 1) return FSV_ERR_BAD_ARG;
   for (int t = 0; t < ntaps; ++t)
     if (ty[t] < -8 || ty[t] > 7 || tx[t] < -8 || tx[t] > 7) return FSV_ERR_UNSUPPORTED;
@@ -1924,9 +1864,6 @@ static int fsv_conv_gather_impl(const float* in, const float* wt, const float* b
     if (!p.dense_out) return FSV_ERR_UNSUPPORTED;
     if (split_ws && (Cin % 4 == 0) && split_cap >= (long long)nsplit * total) {
       p.part = split_ws; p.part_stride = total;         // ordered: one copy of the output per split, summed by the finishing pass
-      // ... or, with tickets, by the tile's last workgroup (no finishing launch): up to 8 splits (its register batch), copies
-      // within one buffer descriptor
-      p.tickets = (nsplit <= 8 && (long long)nsplit * total * 4 <= FSV_BUF_MAX_BYTES) ? split_tickets : nullptr;
     } else {
       (void)hipMemsetAsync(out, 0, (size_t)total * sizeof(float), stream);
     }
@@ -1945,7 +1882,7 @@ static int fsv_conv_gather_impl(const float* in, const float* wt, const float* b
   if (force_tile < 0 && vec4) tile = fsv_conv_variant(tile);
   int rc = fsv_launch_conv(p, vec4, nsamp * nsplit, stream, tile);
   if (rc) return rc;
-  if (!accumulate && nsplit > 1 && !(p.part && p.tickets) && (p.part || bias || res || act != FSV_ACT_NONE || scale != 1.f)) {
+  if (!accumulate && nsplit > 1 && (p.part || bias || res || act != FSV_ACT_NONE || scale != 1.f)) {
     int grid = (int)((total + 256 * 8 - 1) / (256 * 8));
     if (grid > 4096) grid = 4096;
     if (grid < 1) grid = 1;
@@ -1963,21 +1900,18 @@ static int fsv_conv_gather_impl(const float* in, const float* wt, const float* b
 extern "C" {
 
 // split_ws / split_ws_floats (nullable): ordered split-K - when the plan splits K, split k stores its partial output into the k-th
-// copy inside split_ws (nsplit x N*outH*outW*Cout floats) and the copies are summed in ascending order (the same bits on every run,
-// no zero fill, no atomics on the data); a call that does not split, or whose copies do not fit, ignores the workspace.
-// split_tickets (nullable, with split_ws): zeroed ints, one per output tile (fsv_conv_split_tiles) - the workgroup that arrives last
-// at a tile sums and finishes it, and leaves the ticket zeroed again; null: a finishing launch does.
+// copy inside split_ws (nsplit x N*outH*outW*Cout floats) and a finishing pass sums the copies in ascending order (the same bits on
+// every run, no zero fill, no atomics); a call that does not split, or whose copies do not fit, ignores the workspace.
 int fsv_conv_gather_fwd(const float* in, const float* wt, const float* bias, const float* res, float* out,
                         int N, int H, int W, int Cin, int OH, int OW, int Cout,
                         int ntaps, const int* ty, const int* tx, int sy, int sx,
                         int outH, int outW, int osy, int osx, int ooy, int oox,
                         int ldw, long long w_bstride, long long b_bstride, int per_sample,
                         int act, float scale, int force_tile, int force_split, int accumulate, const float* wscale,
-                        float* split_ws, long long split_ws_floats, int* split_tickets, int in_up, hipStream_t stream) {
+                        float* split_ws, long long split_ws_floats, int in_up, hipStream_t stream) {
   return fsv_conv_gather_impl(in, wt, bias, res, out, N, H, W, Cin, OH, OW, Cout, ntaps, ty, tx, sy, sx, outH, outW, osy, osx,
                               ooy, oox, ldw, w_bstride, b_bstride, per_sample, act, scale, force_tile, force_split, accumulate,
-                              wscale, nullptr, 0, 0, 0, nullptr, split_ws, split_ws ? split_ws_floats : 0,
-                              split_ws ? split_tickets : nullptr, in_up, stream);
+                              wscale, nullptr, 0, 0, 0, nullptr, split_ws, split_ws ? split_ws_floats : 0, in_up, stream);
 }
 
 int fsv_conv_gather_fwd_stats(const float* in, const float* wt, const float* bias, const float* res, float* out,
@@ -1985,11 +1919,11 @@ int fsv_conv_gather_fwd_stats(const float* in, const float* wt, const float* bia
                               int ntaps, const int* ty, const int* tx, int sy, int sx,
                               int ldw, int act, float scale, const float* wscale,
                               double* stats, int stats_groups, int stats_slots, int stats_prezeroed, int* produced,
-                              float* split_ws, long long split_ws_floats, int* split_tickets, int in_up, hipStream_t stream) {
+                              float* split_ws, long long split_ws_floats, int in_up, hipStream_t stream) {
   if (!stats || !produced) return FSV_ERR_BAD_ARG;
   return fsv_conv_gather_impl(in, wt, bias, res, out, N, H, W, Cin, OH, OW, Cout, ntaps, ty, tx, sy, sx, OH, OW, 1, 1, 0, 0, ldw,
                               0, 0, 0, act, scale, -1, 0, 0, wscale, stats, stats_groups, stats_slots, stats_prezeroed, produced,
-                              split_ws, split_ws ? split_ws_floats : 0, split_ws ? split_tickets : nullptr, in_up, stream);
+                              split_ws, split_ws ? split_ws_floats : 0, in_up, stream);
 }
 
 // In-place x = act(x + bias[c]) over an NHWC tensor of `total` elements (the split-K finishing pass, exposed for operators

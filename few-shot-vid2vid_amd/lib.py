@@ -26,7 +26,7 @@ _SIGS = {
                             c_i, c_ip, c_ip, c_i, c_i,
                             c_i, c_i, c_i, c_i, c_i, c_i,
                             c_i, c_ll, c_ll, c_i,
-                            c_i, c_f, c_i, c_i, c_i, c_p, c_p, c_ll, c_p, c_i, c_p],
+                            c_i, c_f, c_i, c_i, c_i, c_p, c_p, c_ll, c_i, c_p],
     "fsv_conv_wgrad": [c_p, c_p, c_p,
                        c_i, c_i, c_i, c_i, c_i, c_i, c_i,
                        c_i, c_ip, c_ip, c_i, c_i,

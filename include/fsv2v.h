@@ -51,10 +51,8 @@ enum fsv_act { FSV_ACT_NONE = 0, FSV_ACT_LRELU = 1 /* leaky_relu(0.2), architect
  * the bias (the spectral-norm 1/sigma when wt holds un-normalised weights). */
 /* split_ws / split_ws_floats (nullable; ordered split-K): when the call's plan splits K, split k stores its partial output into
  * the k-th copy inside split_ws (nsplit x N*outH*outW*Cout floats) and the copies are summed in ascending order: the same bits on
- * every run, no zero fill, no atomics on the data.  A call that does not split, or whose copies do not fit into split_ws_floats,
- * ignores the workspace (and adds atomically into a zeroed output).  split_tickets (nullable, with split_ws): ZEROED ints, one per
- * output tile (fsv_conv_split_tiles of the shape) - the workgroup that arrives last at a tile sums its copies and applies the
- * epilogue itself, no finishing launch; every ticket is left zeroed again (launches that may overlap need different ranges).
+ * every run, no zero fill, no atomics (a finishing pass sums the copies).  A call that does not split, or whose copies do not fit into split_ws_floats,
+ * ignores the workspace (and adds atomically into a zeroed output).
  * in_up != 0: nn.Upsample(scale_factor=2) in front of the convolution (generator.py:124,497-504,541-572) folded into the gather -
  * `in` is stored at H / 2 x W / 2 (H, W stay the size the convolution sees: even) and read at (y >> 1, x >> 1); the up-sampled
  * tensor is never written.  Float4-gather MFMA launches only (Cin % 4 == 0, Cout > 4, shared weights, no accumulate):
@@ -65,8 +63,7 @@ int fsv_conv_gather_fwd(const float* in, const float* wt, const float* bias, con
                         int outH, int outW, int osy, int osx, int ooy, int oox,
                         int ldw, long long w_bstride, long long b_bstride, int per_sample,
                         int act, float scale, int force_tile, int force_split, int accumulate, const float* wscale,
-                        float* split_ws, long long split_ws_floats, int* split_tickets, int in_up, fsv_stream_t stream);
-int fsv_conv_split_tiles(int Mz, int Cout, int nchunks, int nsamp, int force_tile, int force_split);
+                        float* split_ws, long long split_ws_floats, int in_up, fsv_stream_t stream);
 
 /* ---- grouped launches: up to 64 INDEPENDENT problems in one grid --------------------------------------------------------
  * The reference issues the 16 weight-generator MLPs (generator.py:103-110,245-273: three nn.Linear each, per adaptive level
@@ -111,7 +108,7 @@ int fsv_conv_gather_fwd_stats(const float* in, const float* wt, const float* bia
                               int ntaps, const int* ty, const int* tx, int sy, int sx,
                               int ldw, int act, float scale, const float* wscale,
                               double* stats, int stats_groups, int stats_slots, int stats_prezeroed, int* produced,
-                              float* split_ws, long long split_ws_floats, int* split_tickets, int in_up, fsv_stream_t stream);
+                              float* split_ws, long long split_ws_floats, int in_up, fsv_stream_t stream);
 /* in place: x = act(x + bias[c]) over an NHWC tensor (finishing pass of operators that add several GEMM launches into one
  * output: convolutions with more than 16 taps, transposed convolutions); act codes as in the conv epilogue, 5 = leaky 0.1 */
 int fsv_bias_act(float* x, const float* bias, long long total, int C, int act, fsv_stream_t stream);

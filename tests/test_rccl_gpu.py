@@ -2,7 +2,7 @@
 
 * one rank (any GPU box): bench.py's N > 1 code path - hook-free optimisers, five hipGraph segments, the discriminator's
   gradients all-reduced on a side stream next to the generator-mode forward pass, the decoder-stage range next to the second
-  backward piece - forced in a one-rank RCCL group (FSV_FORCE_DIST=1), and (round 5) the weights after three real Adam steps of
+  backward piece - forced in a one-rank RCCL group (FSV_FORCE_DIST=1), and (round 5) the weights after four real Adam steps of
   that path held BIT FOR BIT to the plain single-graph run;
 * two ranks (only when the box shows >= 2 devices; the driver's single-GPU boxes skip it): the same path on two GPUs keeps the
   replicas in lock-step and produces the gradients of one process that sees both shards (mirror of test_ddp_gloo.py)."""
@@ -33,7 +33,7 @@ def test_one_rank_rccl_runs_the_segmented_bench_path(hip_lib):
 
 
 def _one_rank(rank, port, out_dir, mode):
-    """three iterations (eager warm-up, capture + replay, replay) with real Adam steps in the fixed-order mode; mode 'plain': one
+    """four iterations (two eager warm-ups, capture + replay, replay) with real Adam steps in the fixed-order mode; mode 'plain': one
     hipGraph, no process group; 'rccl': the N > 1 schedule in a one-rank RCCL group; 'rccl_serial': that schedule in round 4's order"""
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY='0', FSV_DETERMINISTIC='1')
     os.environ.pop('FSV2V_EMU', None)
@@ -58,10 +58,10 @@ def _one_rank(rank, port, out_dir, mode):
         model.build_optimizers(split_backward=True)
     else:
         model.build_optimizers(world_size=1, force_exchange=True, overlap=False, split_backward=True)
-    gi = gs.GraphedIteration(model, opt, warmup=1)
+    gi = gs.GraphedIteration(model, opt, warmup=2)       # (the optimisers settle their gradient routing with the first step)
     tl, ti, rl, ri = [t.to(dev) for t in mc.synth_pose_inputs(1, 64, 64, 300, 6)]
     data = [tl, ti, [None, None], [None, None], rl, ri, None, None, None]
-    for it in range(3):
+    for it in range(4):                                  # eager, eager, capture + replay, replay
         gi(data)
     torch.cuda.synchronize()
     torch.save(dict(launch=gi.launch_mode(),
@@ -73,7 +73,7 @@ def _one_rank(rank, port, out_dir, mode):
 
 
 def test_one_rank_rccl_schedule_reproduces_the_single_graph_weights(hip_lib, tmp_path):
-    """round-4 review: the one-rank run asserted `value > 0`.  Now: three iterations with real Adam steps (fixed-order mode, so that
+    """round-4 review: the one-rank run asserted `value > 0`.  Now: four iterations with real Adam steps (fixed-order mode, so that
     a run is bit-reproducible) through (a) one hipGraph without a process group, (b) the N > 1 schedule - five segments, the
     discriminator range exchanged on a side stream next to the generator-mode forward pass, the decoder-stage range next to
     the second backward piece - in a one-rank RCCL group: all weights of G and D equal bit for bit.  (Round 4's serial order against
@@ -108,10 +108,10 @@ def _worker(rank, world, port, out_dir, split):
     model = model.to(dev).train()
     opt_G, opt_D = model.build_optimizers(world_size=world, overlap=False, split_backward=split)
     opt_G.set_lr(0.0); opt_D.set_lr(0.0)          # fixed weights: the two runs below then differ by summation order only
-    gi = gs.GraphedIteration(model, opt, warmup=1)
+    gi = gs.GraphedIteration(model, opt, warmup=2)
     tl, ti, rl, ri = [t.to(dev) for t in mc.synth_pose_inputs(1, 64, 64, 300 + rank, 6)]
     data = [tl, ti, [None, None], [None, None], rl, ri, None, None, None]
-    for it in range(3):                  # eager, capture (+ replay), replay
+    for it in range(4):                  # eager, eager (the optimisers settle their gradient routing), capture + replay, replay
         gi(data)
     torch.cuda.synchronize()
     torch.save(dict(g={n: (p.grad.detach().cpu() if p.grad is not None else torch.zeros_like(p).cpu())
