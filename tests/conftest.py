@@ -28,19 +28,21 @@ def pytest_collection_modifyitems(config, items):
     for item in items:
         if "gpu" in item.keywords and not HAS_GPU:
             item.add_marker(skip_gpu)
-    if not HAS_GPU:
+    if not HAS_GPU or os.environ.get('FSV_ORACLE_WORKER', '0') != '1' or config.getoption('collectonly', False):
         return
-    # Hardware session: the full-size tests go LAST, and the whole-iteration oracle runs they compare against (minutes of host time
-    # each, no GPU involved) are computed meanwhile by a worker process on the host cores (tests/oracle_worker.py,
-    # model_checks.oracle_pair) - the suite's wall time was 806 s of the driver's 1200 s in round 4, most of it the GPU idling
-    # behind the CPU oracle.  FSV_ORACLE_WORKER=0: everything inline, as before.
+    # OPT-IN (FSV_ORACLE_WORKER=1; round 5).  The full-size tests spend minutes each in the CPU oracle while the GPU idles; with the
+    # switch on they go LAST and tests/oracle_worker.py computes their (fp32, fp64) oracle pairs meanwhile (model_checks.oracle_pair
+    # loads / waits / falls back to the inline run).  Why it is not the default: two processes that both run OpenMP regions on the
+    # same cores do not share them - they spin against each other (measured in the build container: a CPU-oracle test group 11 s
+    # alone, 291 s next to a plain worker, 48 s next to a niced passive one; the first hardware run of the suite with a plain worker
+    # did not finish in 1500 s).  So the cores are PARTITIONED here (tests on the lower half, worker pinned to the upper half: 12 s
+    # against 9.4 s for that group) - which halves the worker's speed and, with the tail of the suite waiting for it, brings the
+    # session's wall time back to about what the inline runs cost.  Kept for boxes with cores to spare.
     full = [it for it in items if it.fspath.basename == 'test_fullsize_gpu.py']
     if not full:
         return
     rest = [it for it in items if it.fspath.basename != 'test_fullsize_gpu.py']
     items[:] = rest + full
-    if os.environ.get('FSV_ORACLE_WORKER', '1') != '1' or config.getoption('collectonly', False):
-        return
     try:
         import json
         import subprocess
@@ -52,17 +54,20 @@ def pytest_collection_modifyitems(config, items):
             for sp in (fn(it) if fn else []):
                 if sp not in specs:
                     specs.append(sp)
-        if not specs:
+        cores = sorted(os.sched_getaffinity(0))
+        if not specs or len(cores) < 8:
             return
+        mine, theirs = cores[:len(cores) // 2], cores[len(cores) // 2:]
         base = '/dev/shm' if os.path.isdir('/dev/shm') and os.access('/dev/shm', os.W_OK) else None
         cdir = tempfile.mkdtemp(prefix='fsv_oracle_', dir=base)
         spec_file = os.path.join(cdir, 'specs.json')
         with open(spec_file, 'w') as f:
             json.dump(specs, f)
         os.environ['FSV_ORACLE_CACHE'] = cdir
-        threads = max(8, (os.cpu_count() or 16) * 3 // 4)
-        proc = subprocess.Popen([sys.executable, os.path.join(ROOT, 'tests', 'oracle_worker.py'), cdir, str(threads), spec_file],
-                                cwd=ROOT, stdout=subprocess.DEVNULL)
+        os.sched_setaffinity(0, mine)
+        torch.set_num_threads(len(mine))
+        proc = subprocess.Popen([sys.executable, os.path.join(ROOT, 'tests', 'oracle_worker.py'), cdir, str(len(theirs)), spec_file,
+                                 ','.join(map(str, theirs))], cwd=ROOT, stdout=subprocess.DEVNULL)
         _worker.update(proc=proc, dir=cdir)
     except Exception as e:                           # noqa: BLE001 - never cost the session its tests
         print('oracle worker not started: %s' % e)

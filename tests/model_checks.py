@@ -320,7 +320,7 @@ def compute_oracle_pair(spec):
     return _detached(r32), _detached(r64)
 
 
-def oracle_pair(spec, wait_s=1500.0):
+def oracle_pair(spec, wait_s=600.0):
     key = oracle_key(spec)
     if _ORACLE_CACHE.get('key') == key:
         return _ORACLE_CACHE['val']
@@ -330,8 +330,16 @@ def oracle_pair(spec, wait_s=1500.0):
     if cdir and os.path.isdir(cdir):
         import time
         path, t0 = os.path.join(cdir, key + '.pt'), time.monotonic()
-        # the worker announces its whole queue up front (<key>.queued) and removes the marker when the pair is written or failed
-        while not os.path.exists(path) and os.path.exists(os.path.join(cdir, key + '.queued')) and time.monotonic() - t0 < wait_s:
+        # the worker announces its whole queue up front (<key>.queued) and removes the marker when the pair is written or failed;
+        # a worker that died (alive.pid gone / stale) is not waited for
+        def worker_alive():
+            try:
+                os.kill(int(open(os.path.join(cdir, 'worker.pid')).read()), 0)
+                return True
+            except Exception:                         # noqa: BLE001
+                return False
+        while (not os.path.exists(path) and os.path.exists(os.path.join(cdir, key + '.queued')) and worker_alive() and
+               time.monotonic() - t0 < wait_s):
             time.sleep(0.5)
         if os.path.exists(path):
             try:
