@@ -512,16 +512,17 @@ class verify_half_launches:
         return xhat, gbs
 
     @staticmethod
-    def _spade_chain(xhat, gbs, act):
+    def _spade_chain(xhat, gbs, act, want_pre=False):
         c = xhat.shape[1]
         h = xhat
         for gb in gbs:
             h = h * (1 + gb[:, :c]) + gb[:, c:]
+        pre = h
         if act == 1:
             h = torch.nn.functional.leaky_relu(h, 0.2)
         elif act != 0:
             raise AssertionError('SPADE activation code %d' % act)
-        return h
+        return (h, pre) if want_pre else h
 
     def _other(self, kind, i):
         if kind == 'side':                  # the half side copy IS one rounding of the fp32 tensor the same launch wrote
@@ -591,19 +592,33 @@ class verify_half_launches:
                 xhat, gbs = self._spade_terms(i['x'], i['mean'], i['rstd'], i['maps'], i['prepped'], i['up'], f16)
                 xhat = xhat.detach().requires_grad_(True)
                 gbs = [gb.detach().requires_grad_(True) for gb in gbs]
-                self._spade_chain(xhat, gbs, i['act']).backward(i['dh'].float())
+                h, pre = self._spade_chain(xhat, gbs, i['act'], want_pre=True)
+                h.backward(i['dh'].float())
+            pre = pre.detach()
+            # elements whose pre-activation lies within rounding of the LeakyReLU kink: the kernel's fp32 evaluation may take the
+            # other slope there - for the element-wise outputs one such element in 10^5 is admitted below; for the per-channel bias
+            # SUMS the admitted slack is exactly what those elements can move the sum by (slope 1 <-> 0.2: 0.8 / slope of the term)
+            amb = (pre.abs() < 2e-5 * max(float(pre.abs().max()), 1e-20)) if i['act'] == 1 else None
             # an element whose pre-activation lies within rounding of the LeakyReLU kink takes slope 1 on one side and 0.2 on the
             # other: admitted for one element in 10^5 (their gradient is a legitimate fp32 evaluation either way)
             self._close('SPADE backward twin: dxhat', i['dxhat'], xhat.grad, False, outliers=1e-5)
             for k, (got, gb) in enumerate(zip(i['dgbs'], gbs)):
                 self._close('SPADE backward twin: d(gamma|beta) of map %d' % k, got, gb.grad, got.dtype == torch.float16, outliers=1e-5)
                 if i['dbsum'] is not None:
-                    want = gb.grad.double().sum(dim=(2, 3)) if i['per_sample'][k] else gb.grad.double().sum(dim=(0, 2, 3))
+                    dims = (2, 3) if i['per_sample'][k] else (0, 2, 3)
+                    want = gb.grad.double().sum(dim=dims)
                     have = i['dbsum'][:, k] if i['per_sample'][k] else i['dbsum'][0, k]
-                    # (sums over 10^5 ... 10^6 pixels: the handful of elements whose LeakyReLU slope is decided within rounding of the
-                    # kink - admitted above as outliers - each move one term of a sum by up to 0.8 of its size; hardware record at
-                    # BASELINE configs[4]: 6e-4 of the largest sum)
-                    self._close('SPADE backward twin: bias sums of map %d' % k, have, want, False, 2e-3)
+                    if amb is not None and bool(amb.any()):
+                        fac = torch.where(pre > 0, 0.8, 4.0) * amb
+                        slack = (gb.grad.abs().double() * torch.cat([fac, fac], dim=1)).sum(dim=dims)
+                        err = (have.double() - want).abs()
+                        lim = 2e-4 * max(float(want.abs().max()), 1e-20) + slack
+                        if bool((err > lim).any()):
+                            self.failures.append('SPADE backward twin: bias sums of map %d differ from their recomputation beyond what '
+                                                 'the %d kink-ambiguous elements can move them: max excess %.3e at scale %.3e'
+                                                 % (k, int(amb.sum()), float((err - lim).max()), float(want.abs().max())))
+                        continue
+                    self._close('SPADE backward twin: bias sums of map %d' % k, have, want, False, 2e-4)
         else:
             raise AssertionError('unknown half launch kind %r' % (kind,))
         self.count[kind] += 1
