@@ -100,7 +100,7 @@ def check_conv_up(device, n=2, cin=16, h=6, w=10, cout=24, k=3, act='lrelu', sta
     dy = torch.randn(ref.shape, generator=g)
     ref.backward(dy)
 
-    def run(fold):
+    def run(fold, direct=True):
         xd = _dev(x, device).detach().clone().requires_grad_(True)
         wd = _dev(wt, device).detach().clone().requires_grad_(True)
         bd = _dev(b, device).detach().clone().requires_grad_(True)
@@ -110,6 +110,7 @@ def check_conv_up(device, n=2, cin=16, h=6, w=10, cout=24, k=3, act='lrelu', sta
             seen.append((name, a))
             return real_call(name, *a)
         os.environ['FSV_UP_FOLD'] = '1' if fold else '0'
+        os.environ['FSV_UP_DGRAD'] = '1' if direct else '0'
         lib.call = recording_call
         try:
             with conv.stats_pass(xd.device):
@@ -119,16 +120,23 @@ def check_conv_up(device, n=2, cin=16, h=6, w=10, cout=24, k=3, act='lrelu', sta
         finally:
             lib.call = real_call
             os.environ.pop('FSV_UP_FOLD', None)
+            os.environ.pop('FSV_UP_DGRAD', None)
         return y.detach(), xd.grad, wd.grad, bd.grad, [s_[0] for s_ in seen], got_stats
     prev = conv.set_mfma_mode(1 if amp else conv.mfma_mode())
     try:
         a = run(True)
         bm = run(False)
+        pooled = run(True, direct=False)
     finally:
         conv.set_mfma_mode(prev)
     folded = 'fsv_upsample2x_fwd' not in a[4]
     assert folded == expect_fold, a[4]
-    assert 'fsv_upsample2x_fwd' in bm[4] and 'fsv_upsample2x_bwd' in a[4] and 'fsv_upsample2x_bwd' in bm[4]
+    # the data gradient w.r.t. x: ONE gather-GEMM (4x4 stride-2 convolution over dy with the 2 x 2 pooling folded into summed weights,
+    # ops._up_dgrad_weight) where the layer allows - 3x3, exact fp32, float4 channels -, else data gradient at the up-sampled size +
+    # fsv_upsample2x_bwd; the two agree to the rounding of the summed weights
+    direct = k == 3 and not amp and cout % 4 == 0 and cin % 4 == 0 and cin > 4
+    assert 'fsv_upsample2x_fwd' in bm[4] and ('fsv_upsample2x_bwd' in a[4]) == (not direct) and 'fsv_upsample2x_bwd' in pooled[4], (a[4], pooled[4])
+    assert_close('conv(up2x) dx: one-launch data gradient vs pooled', a[1], pooled[1], 1e-5 if not amp else 3e-3)
     if stats and not amp:
         assert a[5] == bm[5]
     tol = 3e-3 if amp else REL_TOL
