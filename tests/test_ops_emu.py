@@ -204,7 +204,8 @@ def test_conv_with_the_upsampling_folded_into_the_gather(emu_lib):
     """round 5: nn.Upsample(2) -> conv3x3 of the label / image embedding decoders and the flow network's decoder as ONE launch"""
     oc.check_conv_up(DEV)                                                           # 64x64-tile class, LeakyReLU epilogue
     oc.check_conv_up(DEV, n=1, cin=32, h=9, w=7, cout=32, act='none', stats=1)       # odd source size, BatchNorm statistics ride along
-    oc.check_conv_up(DEV, n=2, cin=64, h=4, w=4, cout=160, k=3)                      # wide output: the 8-wave tiles
+    oc.check_conv_up(DEV, n=2, cin=64, h=4, w=4, cout=160, k=3)
+    oc.check_conv_up_spectral(DEV)                      # wide output: the 8-wave tiles
     oc.check_conv_up(DEV, n=1, cin=8, h=5, w=6, cout=8, k=1)                         # 1x1
     oc.check_conv_up(DEV, n=1, cin=6, h=5, w=6, cout=8, expect_fold=False)           # scalar-gather channels: materialised
     oc.check_conv_up(DEV, n=1, cin=16, h=5, w=6, cout=3, expect_fold=False)          # thin head: materialised

@@ -210,6 +210,7 @@ def test_conv_with_the_upsampling_folded_into_the_gather(hip_lib):
     oc.check_conv_up(dev())
     oc.check_conv_up(dev(), n=1, cin=32, h=9, w=7, cout=32, act='none', stats=1)
     oc.check_conv_up(dev(), n=2, cin=64, h=4, w=4, cout=160, k=3)
+    oc.check_conv_up_spectral(dev())
     oc.check_conv_up(dev(), n=1, cin=6, h=5, w=6, cout=8, expect_fold=False)
     oc.check_conv_up(dev(), n=1, cin=16, h=6, w=6, cout=16, amp=True, expect_fold=False)
     oc.check_conv_up(dev(), n=2, cin=64, h=64, w=64, cout=32, stats=1, act='none')               # flow decoder 64 -> 32 at a quarter of its size
