@@ -428,11 +428,6 @@ class _ConvFn(torch.autograd.Function):
                 y = _spade_conv_s_launch(site, wh, kpad_h, cout, wscale, want_hs=any(ctx.needs_input_grad))
             else:
                 y = _spade_conv_s_launch(site, wt, ldw, cout, wscale, want_hs=any(ctx.needs_input_grad))
-        if y is None and fold and _up_subpixel_mode() and geom.kh == 3 and geom.kw == 3 and geom.stride == 1 and geom.pad == 1:
-            # conv3x3(nearest_x2(x)) as four 2x2-tap convolutions over x itself, one per output parity class (the sub-pixel form;
-            # round 5): 16 taps instead of 36 per source pixel = 2.25x fewer MACs than the gather through the up-sampling index
-            # (1 / sigma always as the epilogue scalar here: the summed weights are built from the un-normalised W)
-            y = _up_subpixel_forward(x, w4, cout, b, res.detach() if res is not None else None, act, scale, inv)
         if y is None:
             y = conv_forward(x, wt, ldw, cout, geom, bias=b, res=res.detach() if res is not None else None, act=act,
                              scale=scale, per_sample=per_sample, wscale=wscale, stats=st, up=fold)
@@ -548,46 +543,11 @@ class _ConvFn(torch.autograd.Function):
         return dx, dw, db, dres, None, None, None, None, None, None, None, None, None, None
 
 
-def _up_subpixel_mode():
-    """FSV_UP_SUBPIXEL: 'group' (default) - the four parity classes of conv3x3(nearest_x2(x)) as ONE grouped launch, 'plain' - four
-    launches, '0' - the single gather through the up-sampling index (csrc/conv_igemm.hip ConvP::up); in-box A/B"""
-    m = _os.environ.get('FSV_UP_SUBPIXEL', 'group')
-    return '' if m in ('0', 'off', '') else m
-
-
-_subpixel_s = {}
-
-
-def _up_subpixel_forward(x, w4, cout, bias, res, act, scale, wscale):
-    """y = act((conv3x3(nearest_x2(x), W) * wscale + bias) * scale) + res without the up-sampled tensor AND without its redundant
-    products: output pixel 2s + r (r in {0,1} per axis) sees x[s - 1], x[s] (r = 0: weights W0, W1 + W2) resp. x[s], x[s + 1]
-    (r = 1: W0 + W1, W2) - per parity class (ry, rx) a 2x2-tap convolution over x whose outputs are placed at stride 2
-    (generator.py:489-493, 559-563: nn.Upsample(2) -> conv3x3).  The summed weights carry one fp32 rounding each against the
-    reference's sum of the separate products.  x: NHWC fp32 at source resolution; w4: OIHW (un-normalised under spectral norm:
-    1 / sigma rides in wscale)."""
-    n, cin, h, w = x.shape
-    dev = x.device
-    sm = _subpixel_s.get(dev)
-    if sm is None:
-        from . import streams as _streams
-        sm = _subpixel_s[dev] = _streams.shared(lambda: torch.tensor([[1., 0., 0.], [0., 1., 1.], [1., 1., 0.], [0., 0., 1.]], device=dev))
-    v = torch.einsum('oikl,pk,ql->oipq', w4, sm, sm).contiguous()              # [cout, cin, 4, 4]: rows / columns (r, tap)
-    y = empty_nhwc(n, cout, 2 * h, 2 * w, x)
-    g1 = Geom(3, 3, 1, 1)
-    grouped = _up_subpixel_mode() == 'group'
-    with _conv.launch_group(grouped):
-        for ry in (0, 1):
-            for rx in (0, 1):
-                khs = [2 * ry + iy for iy in (0, 1) for _ in (0, 1)]
-                kws = [2 * rx + ix for _ in (0, 1) for ix in (0, 1)]
-                ty = [ry - 1 + iy for iy in (0, 1) for _ in (0, 1)]                 # r = 0: x[s - 1], x[s]; r = 1: x[s], x[s + 1]
-                tx = [rx - 1 + ix for _ in (0, 1) for ix in (0, 1)]
-                wt, _, ldw = prep_weight(v, 0, g1, khs, kws, None)
-                _conv.gather_gemm(x, wt, ldw, cout, h, w, ty, tx, 1, 1, bias=bias, res=res, act=act, scale=scale, out=y,
-                                  place=(2 * h, 2 * w, 2, 2, ry, rx), wscale=wscale)
-    return y
-
-
+# (The FORWARD pass has the same algebra - conv3x3(nearest_x2(x)) = four 2x2-tap convolutions over x with summed weights, one per
+# output parity class: 16 instead of 36 taps per source pixel.  Built in round 5 as one grouped launch of four placed problems and
+# measured: 46.42 ms per step against 45.84 for the single gather through the up-sampling index - the grouped kernel's rate on
+# short-K placed problems, four extra weight re-arrangements per call and the lost statistics epilogue cost more than the MACs
+# save.  Removed; profiles/r05_notes.md section 10.)
 def _up_dgrad_direct(ctx, geom, dpre, w4, cpad):
     """the one-launch data gradient of conv(nearest_x2(x)) covers: 3x3 / stride 1 / padding 1, shared weights, the exact-fp32
     float4 gather (FSV_UP_DGRAD=0: data gradient at the up-sampled size + 2 x 2 pooling, in-box A/B)"""
