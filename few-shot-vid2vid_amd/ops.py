@@ -485,16 +485,20 @@ class _ConvFn(torch.autograd.Function):
         want_x = ctx.needs_input_grad[0]
         if want_w:
             fin = getattr(weight, '_fsv_finalizer', None) if (w_sink is not None and entry is not None) else None
+            # conv3x3(nearest_x2(x)): four 2x2-tap weight gradients over the source pixels instead of one 3x3 over the up-sampled
+            # ones (2.25x fewer MACs; _up_wgrad_classes)
+            up_dwt = _up_wgrad_classes(x, dpre_g) if (ctx.up and _up_wgrad_direct(ctx, geom, x, dpre_g, cpad)) else None
             if fin is not None:
                 # deferred: leave the K-major result to the optimiser's grouped finalisation (grad_finalize.py)
-                dwt = conv_wgrad(x, dpre_g, geom, w_shape, raw=True, arena=fin, up=ctx.fold)
+                dwt = up_dwt if up_dwt is not None else conv_wgrad(x, dpre_g, geom, w_shape, raw=True, arena=fin, up=ctx.fold)
                 if ctx.has_sn:
                     fin.add(entry, dwt, w_sink, sig, u, v)
                 else:
                     fin.add(entry, dwt, w_sink)
                 dw = None
             elif ctx.has_sn or cpad:
-                dwsn = conv_wgrad(x, dpre_g, geom, w_shape, per_sample=ctx.per_sample, up=ctx.fold)
+                dwsn = (_conv.unprep_weight_grad(up_dwt, tuple(w_shape), geom) if up_dwt is not None else
+                        conv_wgrad(x, dpre_g, geom, w_shape, per_sample=ctx.per_sample, up=ctx.fold))
                 if cpad:
                     dwsn = dwsn[:, :cin].contiguous()
                 if ctx.has_sn:
@@ -505,7 +509,8 @@ class _ConvFn(torch.autograd.Function):
                     dw = dwsn
                 dw = None if w_sink is not None else dw.view_as(weight)
             else:
-                dw = conv_wgrad(x, dpre_g, geom, w_shape, per_sample=ctx.per_sample, out=w_sink, up=ctx.fold)
+                dw = (_conv.unprep_weight_grad(up_dwt, tuple(w_shape), geom, None, w_sink) if up_dwt is not None else
+                      conv_wgrad(x, dpre_g, geom, w_shape, per_sample=ctx.per_sample, out=w_sink, up=ctx.fold))
                 dw = None if w_sink is not None else dw.view_as(weight)
         if want_b:
             cout = dpre.shape[1]
@@ -548,6 +553,57 @@ class _ConvFn(torch.autograd.Function):
 # measured: 46.42 ms per step against 45.84 for the single gather through the up-sampling index - the grouped kernel's rate on
 # short-K placed problems, four extra weight re-arrangements per call and the lost statistics epilogue cost more than the MACs
 # save.  Removed; profiles/r05_notes.md section 10.)
+class _TapGeom:
+    """the part of conv.Geom the raw weight-gradient launch reads, for an explicit tap list"""
+
+    def __init__(self, ty, tx):
+        self.ntaps, self.ty, self.tx, self.stride = len(ty), list(ty), list(tx), 1
+
+
+_up_wgrad_m = {}
+
+
+def _up_wgrad_direct(ctx, geom, x, dpre, cpad):
+    """the class-wise weight gradient of conv3x3(nearest_x2(x)) covers: x kept at source resolution (the folded forward), 3x3 /
+    stride 1 / padding 1, shared weights, exact fp32, float4 channels (FSV_UP_WGRAD=0: the gather through the up-sampling index, A/B)"""
+    return (_os.environ.get('FSV_UP_WGRAD', '1') == '1' and ctx.fold and geom.kh == 3 and geom.kw == 3 and geom.stride == 1 and
+            geom.pad == 1 and not ctx.per_sample and not ctx.half and cpad == 0 and x.dtype == torch.float32 and
+            dpre.dtype == torch.float32 and x.shape[1] % 4 == 0 and dpre.shape[1] % 4 == 0 and dpre.shape[1] > 4 and
+            32 // x.shape[3] + 1 <= x.shape[2] and _conv.narrow_staging_mode() == 0 and _os.environ.get('FSV_DETERMINISTIC', '0') != '1')
+
+
+def _up_wgrad_classes(x, dy):
+    """Weight gradient of y = conv3x3(nearest_x2(x)) in the K-major layout of the plain launch ([(tap, ci)][co], 9 taps), from
+    FOUR 2x2-tap weight gradients over the source pixels - one per output parity class r: the pixels 2s + r of dy against x[s + d],
+    d in {-1, 0} (r = 0) resp. {0, 1} (r = 1) per axis - 16 instead of 36 products per source pixel, channel pair.  The 3x3 taps are
+    sums of those blocks: tap t of the kernel is seen by class r through offset d = floor((r + t) / 2) (the transpose of the forward
+    relation W0 | W1 + W2 and W0 + W1 | W2).  x: NHWC fp32 at source resolution, dy: NHWC fp32 at twice that."""
+    n, cin, h, w = x.shape
+    cout = dy.shape[1]
+    # the four parity classes of dy as dense NHWC tensors: ONE strided copy
+    d6 = dy.permute(0, 2, 3, 1).reshape(n, h, 2, w, 2, cout).permute(2, 4, 0, 1, 3, 5).contiguous()        # [2, 2, n, h, w, cout]
+    parts = []
+    for ry in (0, 1):
+        for rx in (0, 1):
+            ty = [ry - 1 + iy for iy in (0, 1) for _ in (0, 1)]
+            tx = [rx - 1 + ix for _ in (0, 1) for ix in (0, 1)]
+            dwt = conv_wgrad(x, d6[ry, rx].permute(0, 3, 1, 2), _TapGeom(ty, tx), (cout, cin, 2, 2), raw=True)   # [1, Kpad, ldw]
+            parts.append(dwt[0, :4 * cin].view(4, cin, -1))
+    g = torch.stack(parts)                                                                   # [class, tap of the class, cin, ldw]
+    m = _up_wgrad_m.get(x.device)
+    if m is None:
+        from . import streams as _streams
+        sm = torch.tensor([[1., 0., 0.], [0., 1., 1.], [1., 1., 0.], [0., 0., 1.]])          # rows (r, d), columns kernel index
+        mm = torch.einsum('pk,ql->pqkl', sm, sm).reshape(2, 2, 2, 2, 9).permute(0, 2, 1, 3, 4).reshape(4, 4, 9)   # [(ry, rx)][(iy, ix)][t]
+        m = _up_wgrad_m[x.device] = _streams.shared(lambda: mm.to(x.device).contiguous())
+    ldw = g.shape[-1]
+    dwt9 = torch.einsum('cjil,cjt->til', g, m).reshape(1, 9 * cin, ldw)
+    kpad = (9 * cin + 31) // 32 * 32
+    if kpad != 9 * cin:
+        dwt9 = torch.nn.functional.pad(dwt9, (0, 0, 0, kpad - 9 * cin))
+    return dwt9.contiguous()
+
+
 def _up_dgrad_direct(ctx, geom, dpre, w4, cpad):
     """the one-launch data gradient of conv(nearest_x2(x)) covers: 3x3 / stride 1 / padding 1, shared weights, the exact-fp32
     float4 gather (FSV_UP_DGRAD=0: data gradient at the up-sampled size + 2 x 2 pooling, in-box A/B)"""
