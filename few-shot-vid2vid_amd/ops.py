@@ -428,6 +428,8 @@ class _ConvFn(torch.autograd.Function):
                 y = _spade_conv_s_launch(site, wh, kpad_h, cout, wscale, want_hs=any(ctx.needs_input_grad))
             else:
                 y = _spade_conv_s_launch(site, wt, ldw, cout, wscale, want_hs=any(ctx.needs_input_grad))
+        if y is None and fold and _up_subpixel_wanted(x.shape[0], x.shape[2], x.shape[3], cin, cout, geom, per_sample, res):
+            y = _up_subpixel_forward(x, w4, cout, b, act, scale, inv)
         if y is None:
             y = conv_forward(x, wt, ldw, cout, geom, bias=b, res=res.detach() if res is not None else None, act=act,
                              scale=scale, per_sample=per_sample, wscale=wscale, stats=st, up=fold)
@@ -602,6 +604,52 @@ def _up_wgrad_classes(x, dy):
     if kpad != 9 * cin:
         dwt9 = torch.nn.functional.pad(dwt9, (0, 0, 0, kpad - 9 * cin))
     return dwt9.contiguous()
+
+
+def _up_subpixel_wanted(n, h, w, cin, cout, geom, per_sample, res):
+    """conv3x3(nearest_x2(x)) forward as four plain 2x2-tap launches over the source pixels (one per output parity class) where
+    every class is a chip-filling GEMM of its own (>= 8192 source pixels: no K split, which a placed launch cannot take).
+    FSV_UP_SUBPIXEL=0 / FSV_UP_SUBPIXEL_MIN: in-box A/B switches (profiles/r05_notes.md section 11: -0.65 ms per step at 8192,
+    nothing at 2048; section 10: ONE grouped launch of the four classes measured slower than the single gather)"""
+    return (_os.environ.get('FSV_UP_SUBPIXEL', '1') == '1' and not per_sample and res is None and geom.kh == 3 and geom.kw == 3 and
+            geom.stride == 1 and geom.pad == 1 and n * h * w >= int(_os.environ.get('FSV_UP_SUBPIXEL_MIN', '8192')) and cin % 4 == 0)
+
+
+_subpixel_s = {}
+
+
+def _up_subpixel_forward(x, w4, cout, bias, act, scale, wscale):
+    """y = act((conv3x3(nearest_x2(x), W) * wscale + bias) * scale) without the up-sampled tensor AND without its redundant
+    products: output pixel 2s + r (r in {0,1} per axis) sees x[s - 1], x[s] (r = 0: weights W0, W1 + W2) resp. x[s], x[s + 1]
+    (r = 1: W0 + W1, W2) - per parity class (ry, rx) a 2x2-tap convolution over x whose outputs are placed at stride 2
+    (generator.py:489-493, 559-563: nn.Upsample(2) -> conv3x3).  The summed weights carry one fp32 rounding each against the
+    reference's sum of the separate products.  x: NHWC fp32 at source resolution; w4: OIHW (un-normalised under spectral norm:
+    1 / sigma rides in wscale)."""
+    n, cin, h, w = x.shape
+    dev = x.device
+    sm = _subpixel_s.get(dev)
+    if sm is None:
+        from . import streams as _streams
+        sm = _subpixel_s[dev] = _streams.shared(lambda: torch.tensor([[1., 0., 0.], [0., 1., 1.], [1., 1., 0.], [0., 0., 1.]], device=dev))
+    v = torch.einsum('oikl,pk,ql->oipq', w4, sm, sm).contiguous()              # [cout, cin, 4, 4]: rows / columns (r, tap)
+    y = empty_nhwc(n, cout, 2 * h, 2 * w, x)
+    # ONE re-arrangement for the four classes: 16 taps in class-major order, class c = K rows [c * 4 cin, (c + 1) * 4 cin)
+    cls = [(ry, rx) for ry in (0, 1) for rx in (0, 1)]
+    khs = [2 * ry + iy for ry, rx in cls for iy in (0, 1) for _ in (0, 1)]
+    kws = [2 * rx + ix for ry, rx in cls for _ in (0, 1) for ix in (0, 1)]
+    one = (4 * cin) % 32 == 0
+    if one:
+        wall, _, ldw = prep_weight(v, 0, Geom(3, 3, 1, 1), khs, kws, None)
+    for c, (ry, rx) in enumerate(cls):
+        ty = [ry - 1 + iy for iy in (0, 1) for _ in (0, 1)]                 # r = 0: x[s - 1], x[s]; r = 1: x[s], x[s + 1]
+        tx = [rx - 1 + ix for _ in (0, 1) for ix in (0, 1)]
+        if one:
+            wt = wall[0, c * 4 * cin:(c + 1) * 4 * cin]
+        else:
+            wt, _, ldw = prep_weight(v, 0, Geom(3, 3, 1, 1), khs[4 * c:4 * c + 4], kws[4 * c:4 * c + 4], None)
+        _conv.gather_gemm(x, wt, ldw, cout, h, w, ty, tx, 1, 1, bias=bias, act=act, scale=scale, out=y,
+                          place=(2 * h, 2 * w, 2, 2, ry, rx), force_split=1, wscale=wscale)
+    return y
 
 
 def _up_dgrad_direct(ctx, geom, dpre, w4, cpad):

@@ -100,7 +100,7 @@ def check_conv_up(device, n=2, cin=16, h=6, w=10, cout=24, k=3, act='lrelu', sta
     dy = torch.randn(ref.shape, generator=g)
     ref.backward(dy)
 
-    def run(fold, direct=True):
+    def run(fold, direct=True, subpixel=False):
         xd = _dev(x, device).detach().clone().requires_grad_(True)
         wd = _dev(wt, device).detach().clone().requires_grad_(True)
         bd = _dev(b, device).detach().clone().requires_grad_(True)
@@ -111,6 +111,7 @@ def check_conv_up(device, n=2, cin=16, h=6, w=10, cout=24, k=3, act='lrelu', sta
             return real_call(name, *a)
         os.environ['FSV_UP_FOLD'] = '1' if fold else '0'
         os.environ['FSV_UP_DGRAD'] = '1' if direct else '0'
+        os.environ['FSV_UP_SUBPIXEL'] = '1' if subpixel else '0'
         lib.call = recording_call
         try:
             with conv.stats_pass(xd.device):
@@ -121,14 +122,26 @@ def check_conv_up(device, n=2, cin=16, h=6, w=10, cout=24, k=3, act='lrelu', sta
             lib.call = real_call
             os.environ.pop('FSV_UP_FOLD', None)
             os.environ.pop('FSV_UP_DGRAD', None)
+            os.environ.pop('FSV_UP_SUBPIXEL', None)
         return y.detach(), xd.grad, wd.grad, bd.grad, [s_[0] for s_ in seen], got_stats
     prev = conv.set_mfma_mode(1 if amp else conv.mfma_mode())
     try:
         a = run(True)
         bm = run(False)
         pooled = run(True, direct=False)
+        sub = run(True, subpixel=True)
     finally:
         conv.set_mfma_mode(prev)
+    # the forward of the large layers: four 2x2-tap launches over the source pixels, one per output parity class, with summed
+    # weights (ops._up_subpixel_forward: 2.25x fewer MACs) - one fp32 rounding per summed weight away from the single gather
+    want_sub = bool(a[4].count('fsv_conv_gather_fwd') and not amp and k == 3 and n * h * w >= 8192 and cin % 4 == 0 and
+                    'fsv_upsample2x_fwd' not in a[4])
+    assert (sub[4].count('fsv_conv_gather_fwd') == a[4].count('fsv_conv_gather_fwd') + 3) == want_sub, (want_sub, sub[4])
+    for name, u, v in zip(('y', 'dx', 'dw', 'db'), sub[:4], a[:4]):
+        if want_sub:
+            assert_close('conv(up2x) %s: sub-pixel forward vs one gather' % name, u, v, 2e-6 if act == 'none' else REL_TOL)
+        else:
+            assert bool((u == v).all()), name
     folded = 'fsv_upsample2x_fwd' not in a[4]
     assert folded == expect_fold, a[4]
     # the data gradient w.r.t. x: ONE gather-GEMM (4x4 stride-2 convolution over dy with the 2 x 2 pooling folded into summed weights,
@@ -167,7 +180,7 @@ def check_conv_up(device, n=2, cin=16, h=6, w=10, cout=24, k=3, act='lrelu', sta
                 assert_close('conv(up2x) tile %d' % tile, u, ref, REL_TOL)
 
 
-def check_conv_up_spectral(device, n=2, cin=16, h=6, w=5, cout=24, seed=72):
+def check_conv_up_spectral(device, n=2, cin=16, h=6, w=5, cout=24, seed=72, with_res=True):
     """conv3x3(nearest_x2(x)) of a SPECTRAL-NORMALISED layer (every up-sampling decoder convolution of the flow network,
     generator.py:479-496) with a residual: 1 / sigma reaches the sub-pixel forward and the one-launch data gradient as the epilogue
     scalar (their summed weights are built from the un-normalised W), the weight gradient carries the spectral-norm correction"""
@@ -180,19 +193,21 @@ def check_conv_up_spectral(device, n=2, cin=16, h=6, w=5, cout=24, seed=72):
     v = F.normalize(torch.randn(cin * 9, generator=g), dim=0)
     sd = {'weight_orig': wt.clone().requires_grad_(True), 'weight_u': u.clone(), 'weight_v': v.clone()}
     xr, rr = x.clone().requires_grad_(True), res.clone().requires_grad_(True)
-    ref = F.conv2d(F.interpolate(xr, scale_factor=2, mode='nearest'), O.spectral_weight(sd, '', training=True), None, padding=1) + rr
+    ref = F.conv2d(F.interpolate(xr, scale_factor=2, mode='nearest'), O.spectral_weight(sd, '', training=True), None, padding=1)
+    ref = ref + rr if with_res else ref
     dy = torch.randn(ref.shape, generator=g)
     ref.backward(dy)
     ud, vd = _dev(u.clone(), device), _dev(v.clone(), device)
     wd = _dev(wt, device).detach().clone().requires_grad_(True)
     xd, rd = (_dev(t, device).detach().clone().requires_grad_(True) for t in (x, res))
     sig = ops.SpectralState.update(wd, ud, vd, training=True)
-    y = ops.conv2d(xd, wd, None, stride=1, padding=1, res=rd, sn=(sig, ud, vd), up=True)
+    y = ops.conv2d(xd, wd, None, stride=1, padding=1, res=rd if with_res else None, sn=(sig, ud, vd), up=True)
     y.backward(_dev(dy, device))
     assert_close('sn conv(up2x) y', y, ref)
     assert_close('sn conv(up2x) dx', xd.grad, xr.grad)
     assert_close('sn conv(up2x) dw', wd.grad, sd['weight_orig'].grad)
-    assert_close('sn conv(up2x) dres', rd.grad, rr.grad)
+    if with_res:
+        assert_close('sn conv(up2x) dres', rd.grad, rr.grad)
 
 
 def check_conv_sn_res(device, seed=1, cache=None, fin=None):

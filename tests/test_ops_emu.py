@@ -210,3 +210,5 @@ def test_conv_with_the_upsampling_folded_into_the_gather(emu_lib):
     oc.check_conv_up(DEV, n=1, cin=6, h=5, w=6, cout=8, expect_fold=False)           # scalar-gather channels: materialised
     oc.check_conv_up(DEV, n=1, cin=16, h=5, w=6, cout=3, expect_fold=False)          # thin head: materialised
     oc.check_conv_up(DEV, n=1, cin=16, h=6, w=6, cout=16, amp=True, expect_fold=False)   # half-precision path: materialised
+    oc.check_conv_up(DEV, n=2, cin=8, h=64, w=64, cout=8, act='none')                # >= 8192 source pixels: the sub-pixel forward
+    oc.check_conv_up_spectral(DEV, n=2, cin=8, h=64, w=64, cout=8, with_res=False)   # ... of a spectral-normalised layer

@@ -216,3 +216,5 @@ def test_conv_with_the_upsampling_folded_into_the_gather(hip_lib):
     oc.check_conv_up(dev(), n=2, cin=64, h=64, w=64, cout=32, stats=1, act='none')               # flow decoder 64 -> 32 at a quarter of its size
     oc.check_conv_up(dev(), n=2, cin=256, h=32, w=32, cout=128, act='none')                     # 256 -> 128 at 64x64: the dominant (LD) tile
     oc.check_conv_up(dev(), n=1, cin=128, h=64, w=48, cout=64, act='none')                      # 128x64 tile
+    oc.check_conv_up_spectral(dev(), n=2, cin=64, h=64, w=64, cout=32, with_res=False)          # sub-pixel forward under spectral norm
+    oc.check_conv_up(dev(), n=2, cin=128, h=128, w=128, cout=32, act='none')                    # image-embedding decoder 128 -> 32 at 256x256
