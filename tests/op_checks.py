@@ -134,9 +134,9 @@ def check_conv_up(device, n=2, cin=16, h=6, w=10, cout=24, k=3, act='lrelu', sta
         conv.set_mfma_mode(prev)
     # the forward of the large layers: four 2x2-tap launches over the source pixels, one per output parity class, with summed
     # weights (ops._up_subpixel_forward: 2.25x fewer MACs) - one fp32 rounding per summed weight away from the single gather
-    want_sub = bool(a[4].count('fsv_conv_gather_fwd') and not amp and k == 3 and n * h * w >= 8192 and cin % 4 == 0 and
-                    'fsv_upsample2x_fwd' not in a[4])
-    assert (sub[4].count('fsv_conv_gather_fwd') == a[4].count('fsv_conv_gather_fwd') + 3) == want_sub, (want_sub, sub[4])
+    want_sub = bool(not amp and k == 3 and n * h * w >= 8192 and cin % 4 == 0 and 'fsv_upsample2x_fwd' not in a[4])
+    gathers = lambda names: sum(1 for s_ in names if s_.startswith('fsv_conv_gather_fwd'))      # (..._stats: the statistics epilogue)
+    assert (gathers(sub[4]) == gathers(a[4]) + 3) == want_sub, (want_sub, sub[4])
     for name, u, v in zip(('y', 'dx', 'dw', 'db'), sub[:4], a[:4]):
         if want_sub:
             assert_close('conv(up2x) %s: sub-pixel forward vs one gather' % name, u, v, 2e-6 if act == 'none' else REL_TOL)
