@@ -140,6 +140,8 @@ def check_conv_up(device, n=2, cin=16, h=6, w=10, cout=24, k=3, act='lrelu', sta
     for name, u, v in zip(('y', 'dx', 'dw', 'db'), sub[:4], a[:4]):
         if want_sub:
             assert_close('conv(up2x) %s: sub-pixel forward vs one gather' % name, u, v, 2e-6 if act == 'none' else REL_TOL)
+        elif name == 'dw':
+            assert_close('conv(up2x) dw, same launches twice', u, v, 1e-6)            # (pixel-split atomics: summation order)
         else:
             assert bool((u == v).all()), name
     folded = 'fsv_upsample2x_fwd' not in a[4]
