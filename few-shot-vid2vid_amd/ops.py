@@ -584,26 +584,38 @@ def _up_wgrad_classes(x, dy):
     cout = dy.shape[1]
     # the four parity classes of dy as dense NHWC tensors: ONE strided copy
     d6 = dy.permute(0, 2, 3, 1).reshape(n, h, 2, w, 2, cout).permute(2, 4, 0, 1, 3, 5).contiguous()        # [2, 2, n, h, w, cout]
-    parts = []
+    kpad_c, ldw = (4 * cin + 31) // 32 * 32, (cout + 31) // 32 * 32
+    slab = _Slab(torch.zeros(4 * kpad_c * ldw, dtype=torch.float32, device=x.device))        # ONE fill for the four results
     for ry in (0, 1):
         for rx in (0, 1):
             ty = [ry - 1 + iy for iy in (0, 1) for _ in (0, 1)]
             tx = [rx - 1 + ix for _ in (0, 1) for ix in (0, 1)]
-            dwt = conv_wgrad(x, d6[ry, rx].permute(0, 3, 1, 2), _TapGeom(ty, tx), (cout, cin, 2, 2), raw=True)   # [1, Kpad, ldw]
-            parts.append(dwt[0, :4 * cin].view(4, cin, -1))
-    g = torch.stack(parts)                                                                   # [class, tap of the class, cin, ldw]
+            conv_wgrad(x, d6[ry, rx].permute(0, 3, 1, 2), _TapGeom(ty, tx), (cout, cin, 2, 2), raw=True, arena=slab)
+    g = slab.buf.view(4, kpad_c, ldw)[:, :4 * cin]                                     # [class][(tap of the class, cin)][ldw]
     m = _up_wgrad_m.get(x.device)
     if m is None:
         from . import streams as _streams
         sm = torch.tensor([[1., 0., 0.], [0., 1., 1.], [1., 1., 0.], [0., 0., 1.]])          # rows (r, d), columns kernel index
-        mm = torch.einsum('pk,ql->pqkl', sm, sm).reshape(2, 2, 2, 2, 9).permute(0, 2, 1, 3, 4).reshape(4, 4, 9)   # [(ry, rx)][(iy, ix)][t]
-        m = _up_wgrad_m[x.device] = _streams.shared(lambda: mm.to(x.device).contiguous())
-    ldw = g.shape[-1]
-    dwt9 = torch.einsum('cjil,cjt->til', g, m).reshape(1, 9 * cin, ldw)
+        mm = torch.einsum('pk,ql->pqkl', sm, sm).reshape(2, 2, 2, 2, 9).permute(0, 2, 1, 3, 4).reshape(16, 9)   # [(ry, rx), (iy, ix)][t]
+        m = _up_wgrad_m[x.device] = _streams.shared(lambda: mm.t().contiguous().to(x.device))
+    # dW[t] = sum_{class, tap of the class} M[t][(class, tap)] G[(class, tap)]: one [9 x 16] x [16 x cin ldw] product
+    dwt9 = torch.mm(m, g.reshape(16, cin * ldw)).view(1, 9 * cin, ldw)
     kpad = (9 * cin + 31) // 32 * 32
     if kpad != 9 * cin:
         dwt9 = torch.nn.functional.pad(dwt9, (0, 0, 0, kpad - 9 * cin))
-    return dwt9.contiguous()
+    return dwt9
+
+
+class _Slab:
+    """conv.conv_wgrad's `arena` protocol over one zeroed buffer: consecutive slices"""
+
+    def __init__(self, buf):
+        self.buf, self.off = buf, 0
+
+    def take(self, nfloats):
+        out = self.buf[self.off:self.off + nfloats]
+        self.off += nfloats
+        return out
 
 
 def _up_subpixel_wanted(n, h, w, cin, cout, geom, per_sample, res):
@@ -615,7 +627,26 @@ def _up_subpixel_wanted(n, h, w, cin, cout, geom, per_sample, res):
             geom.stride == 1 and geom.pad == 1 and n * h * w >= int(_os.environ.get('FSV_UP_SUBPIXEL_MIN', '8192')) and cin % 4 == 0)
 
 
-_subpixel_s = {}
+_SUBPIXEL_ROWS = ((1., 0., 0.), (0., 1., 1.), (1., 1., 0.), (0., 0., 1.))      # per axis (r, tap): W0 | W1 + W2 || W0 + W1 | W2
+_DGRAD_ROWS = ((1., 0., 0.), (1., 1., 0.), (0., 1., 1.), (0., 0., 1.))         # per axis: W0, W0 + W1, W1 + W2, W2
+_tap_sum_m = {}
+
+
+def _tap_sums(w4, rows):
+    """V[o, i, p, q] = sum_{k, l} rows[p][k] rows[q][l] W[o, i, k, l] for a 3x3 OIHW kernel - the summed weights of the sub-pixel
+    forms of conv3x3(nearest_x2(x)) - as ONE product [Cout Cin x 9] x [9 x 16] (0 / 1 coefficients: exact products, the sums are
+    the additions themselves)"""
+    key = (w4.device, rows)
+    k = _tap_sum_m.get(key)
+    if k is None:
+        from . import streams as _streams
+        r = torch.tensor(rows)
+        kk = torch.einsum('pk,ql->klpq', r, r).reshape(9, 16).contiguous()
+        k = _tap_sum_m[key] = _streams.shared(lambda: kk.to(w4.device))
+    cout, cin = w4.shape[:2]
+    return torch.mm(w4.reshape(cout * cin, 9), k).view(cout, cin, 4, 4)
+
+
 
 
 def _up_subpixel_forward(x, w4, cout, bias, act, scale, wscale):
@@ -627,11 +658,7 @@ def _up_subpixel_forward(x, w4, cout, bias, act, scale, wscale):
     1 / sigma rides in wscale)."""
     n, cin, h, w = x.shape
     dev = x.device
-    sm = _subpixel_s.get(dev)
-    if sm is None:
-        from . import streams as _streams
-        sm = _subpixel_s[dev] = _streams.shared(lambda: torch.tensor([[1., 0., 0.], [0., 1., 1.], [1., 1., 0.], [0., 0., 1.]], device=dev))
-    v = torch.einsum('oikl,pk,ql->oipq', w4, sm, sm).contiguous()              # [cout, cin, 4, 4]: rows / columns (r, tap)
+    v = _tap_sums(w4, _SUBPIXEL_ROWS)                                          # [cout, cin, 4, 4]: rows / columns (r, tap)
     y = empty_nhwc(n, cout, 2 * h, 2 * w, x)
     # ONE re-arrangement for the four classes: 16 taps in class-major order, class c = K rows [c * 4 cin, (c + 1) * 4 cin)
     cls = [(ry, rx) for ry in (0, 1) for rx in (0, 1)]
@@ -666,7 +693,7 @@ def _up_dgrad_weight(w4):
     with V[o] = sum_{r - t = o} W[t] - per axis (W0, W1, W2) -> o = -1: W2, 0: W1 + W2, 1: W0 + W1, 2: W0: the 2-wide running sums of
     the zero-padded kernel, read backwards.  Returns (V as a 4x4 OIHW tensor, kernel rows / columns of the 16 taps, their offsets
     into dy).  Sums of at most four weights: one fp32 rounding each, against the reference's sum of four products."""
-    v = torch.nn.functional.avg_pool2d(torch.nn.functional.pad(w4, (1, 1, 1, 1)), 2, 1) * 4.0       # v[a] = (W0, W0+W1, W1+W2, W2)
+    v = _tap_sums(w4, _DGRAD_ROWS)                                                                  # v[a] = (W0, W0+W1, W1+W2, W2)
     khs = [a for a in range(4) for _ in range(4)]
     kws = [b for _ in range(4) for b in range(4)]
     return v.contiguous(), khs, kws, [2 - a for a in khs], [2 - b for b in kws]
