@@ -226,7 +226,11 @@ def extras(device, size, steps=5):
             ms = _time_graph(fwd, steps)
             tf = gflop * 8 * (size / 512.0) ** 2 / ms
             out[name] = dict(ms=round(ms, 2), gflop_per_frame=gflop, tflops=round(tf, 2), peak_tflops=FP32_MFMA_PEAK_TFLOPS,
-                             frac_fp32_mfma_peak=round(tf / FP32_MFMA_PEAK_TFLOPS, 4), frames_per_s=round(8e3 / ms, 2))
+                             frac_fp32_mfma_peak=round(tf / FP32_MFMA_PEAK_TFLOPS, 4), frames_per_s=round(8e3 / ms, 2),
+                             arithmetic="gflop_per_frame counts the REFERENCE's multiply-adds (nn.Upsample(2) -> conv3x3 as 36 "
+                                        "products per source pixel and channel pair); the device executes 16 of them in the large "
+                                        "up-sampling layers (DESIGN.md 4d): the rate of the reference's work, an upper reading of "
+                                        "the matrix pipe's utilisation")
             del G, fwd
         except Exception as e:          # noqa: BLE001
             out[name] = 'failed: %s' % str(e).split('\n')[0][:200]
