@@ -551,10 +551,10 @@ class _ConvFn(torch.autograd.Function):
 
 
 # (The FORWARD pass has the same algebra - conv3x3(nearest_x2(x)) = four 2x2-tap convolutions over x with summed weights, one per
-# output parity class: 16 instead of 36 taps per source pixel.  Built in round 5 as one grouped launch of four placed problems and
-# measured: 46.42 ms per step against 45.84 for the single gather through the up-sampling index - the grouped kernel's rate on
-# short-K placed problems, four extra weight re-arrangements per call and the lost statistics epilogue cost more than the MACs
-# save.  Removed; profiles/r05_notes.md section 10.)
+# output parity class: 16 instead of 36 taps per source pixel.  As ONE grouped launch of four placed problems it measured slower than
+# the single gather through the up-sampling index (46.42 against 45.84 ms per step: the grouped kernel's rate on short-K placed
+# problems) and was removed; as four PLAIN launches on the layers large enough not to K-split it wins 0.65 ms: _up_subpixel_forward
+# below; profiles/r05_notes.md sections 10 - 11.)
 class _TapGeom:
     """the part of conv.Geom the raw weight-gradient launch reads, for an explicit tap list"""
 
