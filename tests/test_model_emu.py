@@ -22,6 +22,20 @@ def test_generator_warp_combine_tiny(emu_lib):
 def test_train_step_pose_warp_combine_tiny(emu_lib):
     """D step + G step (losses, all gradients, flat Adam plumbing) of BASELINE configs[2] flags, tiny width."""
     mc.check_train_step(DEV, mc.tiny_opt(warp_ref=True, spade_combine=True, remove_face_labels=True), b=2)
+
+
+def test_train_step_with_the_subpixel_forward_on_every_up_layer(emu_lib, monkeypatch):
+    """the forward of nn.Upsample(2) -> conv3x3 as four 2x2-tap launches per parity class (ops._up_subpixel_forward: the layers of
+    >= 8192 source pixels at full size) forced onto every such layer of the tiny network: the whole iteration against the oracle"""
+    from importlib import import_module
+    ops = import_module('few-shot-vid2vid_amd.ops')
+    calls, real = [], ops._up_subpixel_forward
+    monkeypatch.setattr(ops, '_up_subpixel_forward', lambda *a, **k: (calls.append(1), real(*a, **k))[1])
+    monkeypatch.setenv('FSV_UP_SUBPIXEL_MIN', '1')
+    mc.check_train_step(DEV, mc.tiny_opt(warp_ref=True, spade_combine=True, remove_face_labels=True), b=2)
+    assert len(calls) >= 8, calls          # embedding / flow decoders, both generator passes
+
+
 def test_train_step_in_the_schedule_bench_py_runs(emu_lib):
     """the discriminator step "on a side stream" (issue order on the emulator), the early generator pass picked up by the
     generator-mode call, the two-piece backward - against the oracle like the plain step"""
