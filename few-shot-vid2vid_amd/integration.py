@@ -13,6 +13,7 @@ import sys
 
 import torch
 
+from . import lib as _lib
 from . import model as _model
 from . import networks as _networks
 from . import ops as _ops
@@ -31,7 +32,12 @@ class _ModuleHandle(torch.nn.Module):
 
 def create_model(opt, epoch=0):
     """models/models.py:16-38: returns (model, flowNet, [optimizer_G, optimizer_D])."""
-    device = torch.device('cuda', opt.gpu_ids[0]) if len(opt.gpu_ids) else torch.device('cpu')
+    if len(opt.gpu_ids) and (torch.cuda.is_available() or not _lib.is_emu()):
+        device = torch.device('cuda', opt.gpu_ids[0])
+    else:
+        # host tensors exist for the emulated kernel library only (FSV2V_EMU=1, the test-suite's explicit opt-in); the product
+        # library refuses them (lib.check_device), so there is no silent CPU path behind this branch
+        device = torch.device('cpu')
     # Vid2VidModel.initialize(opt, epoch) already started temporal when the run resumes past the single-frame epochs
     # (base_model.py:213-215); the checkpoints are read once the networks sit on their device and before the optimisers
     # copy the parameters into their flat buffers (vid2vid_model.py:44 `self.load_networks()`)
