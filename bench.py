@@ -15,8 +15,9 @@ Besides the contract fields the JSON line carries
                  on the launch stream around every launch of that kernel in an instrumented eager pass of the step
                  (`avg_launch_us`; the same launches re-issued back to back - warm caches, an upper bound - are reported as
                  `replay_us_warm_cache_upper_bound`); `traffic`: HBM bytes per launch from the committed rocprofv3 PMC passes
-                 of this command (profiles/r0N_pmc_hbm_traffic*.json, keyed by kernel, source digest and workload), null when no file does
-                 not describe the running build;
+                 of this command (profiles/r0N_pmc_hbm_traffic*.json, keyed by kernel, source digest and workload; MB per launch, with
+                 `traffic_read_MB` / `traffic_write_MB` beside it), null when no file describes the running build;
+                 `frac_in_timed_schedule`: the same kernel timed inside the schedule whose ms_per_step is the headline;
   cpu_baseline - the CPU oracle (oracle/fsv_oracle.py, a port of the reference's algorithm; kind "port": the Python
                  reference cannot travel to the GPU box) timed on the host cores on ONE iteration of the very same
                  workload (512x512, B = 2, same flags; rank 0, N=1 only);
@@ -225,12 +226,21 @@ def extras(device, size, steps=5):
                     return G(label, rl, ri, [None, None])
             ms = _time_graph(fwd, steps)
             tf = gflop * 8 * (size / 512.0) ** 2 / ms
+            # what the device executes: the flops of every MFMA launch of one eager pass, counted by the launch wrappers
+            prof = import_module('few-shot-vid2vid_amd.profile')
+            prof.enable()
+            fwd()
+            by = prof.summary()['by_kernel']
+            prof.disable()
+            ex_gflop = sum(v['gflop_per_launch'] * v['launches'] for v in by.values())
             out[name] = dict(ms=round(ms, 2), gflop_per_frame=gflop, tflops=round(tf, 2), peak_tflops=FP32_MFMA_PEAK_TFLOPS,
                              frac_fp32_mfma_peak=round(tf / FP32_MFMA_PEAK_TFLOPS, 4), frames_per_s=round(8e3 / ms, 2),
+                             executed_gflop_per_frame=round(ex_gflop / 8, 1), tflops_executed=round(ex_gflop / ms, 2),
+                             frac_fp32_mfma_peak_executed=round(ex_gflop / ms / FP32_MFMA_PEAK_TFLOPS, 4),
                              arithmetic="gflop_per_frame counts the REFERENCE's multiply-adds (nn.Upsample(2) -> conv3x3 as 36 "
                                         "products per source pixel and channel pair); the device executes 16 of them in the large "
-                                        "up-sampling layers (DESIGN.md 4d): the rate of the reference's work, an upper reading of "
-                                        "the matrix pipe's utilisation")
+                                        "up-sampling layers (DESIGN.md 4d): tflops / frac_fp32_mfma_peak are the rate of the "
+                                        "reference's work, *_executed the matrix pipe's utilisation")
             del G, fwd
         except Exception as e:          # noqa: BLE001
             out[name] = 'failed: %s' % str(e).split('\n')[0][:200]
@@ -272,11 +282,13 @@ def extras(device, size, steps=5):
         if pr.returncode != 0 or not lines:
             raise RuntimeError('exit %d: %s' % (pr.returncode, (pr.stderr or pr.stdout).strip().split('\n')[-1][:160]))
         d = json.loads(lines[-1])
-        keep = {k: d.get(k) for k in ('metric', 'value', 'unit', 'ms_per_step', 'dtype', 'steps', 'warmup', 'step_tflops')}
+        keep = {k: d.get(k) for k in ('metric', 'value', 'unit', 'ms_per_step', 'dtype', 'steps', 'warmup', 'step_tflops',
+                                      'step_tflops_executed')}
         keep['config'] = d.get('config')
         rf = d.get('roofline') or {}
         keep['roofline'] = {k: rf.get(k) for k in ('kernel', 'bound', 'launches', 'gflop_per_launch', 'avg_launch_us', 'achieved', 'peak',
-                                                   'unit', 'frac', 'in_timed_schedule', 'traffic') if k in rf}
+                                                   'unit', 'frac', 'in_timed_schedule', 'frac_in_timed_schedule', 'traffic', 'traffic_read_MB',
+                                                   'traffic_write_MB') if k in rf}
         out['street_1024x512_nc35_amp_O1'] = keep
     except Exception as e:              # noqa: BLE001
         out['street_1024x512_nc35_amp_O1'] = 'failed: %s' % str(e).split('\n')[0][:200]
@@ -652,7 +664,23 @@ def main():
         if rl is not None:
             result['roofline'] = rl['dominant']
             result['kernels'] = rl['by_kernel']
-            result['roofline']['traffic'] = pmc_traffic(result['roofline']['kernel'])
+            # step_tflops prices the REFERENCE's multiply-adds; the device executes fewer:
+            # the flops of every MFMA launch of the instrumented pass, counted by the launch wrappers, over the same time
+            ex_gflop = sum(v['gflop_per_launch'] * v['launches'] for v in rl['by_kernel'].values())
+            result['step_gflop_executed'] = round(ex_gflop, 1)
+            result['step_tflops_executed'] = round(ex_gflop * 1e-3 * world / (elapsed / args.steps), 2)
+            # scalar twins of the nested objects (a consumer that keeps scalar fields only still sees the in-schedule figure
+            # and the PMC traffic): `traffic` = HBM MB per launch (read + written), null without a PMC file of this build
+            rf = result['roofline']
+            tr = pmc_traffic(rf['kernel'])
+            rf['traffic'] = None if tr is None else tr['total_MB']
+            rf['traffic_unit'] = 'MB per launch (HBM, rocprofv3 PMC: 2 x FETCH_SIZE + WRITE_SIZE)'
+            rf['traffic_read_MB'] = None if tr is None else tr['read_MB']
+            rf['traffic_write_MB'] = None if tr is None else tr['write_MB']
+            rf['traffic_source'] = None if tr is None else '%s @ %s' % (tr['source'], tr.get('commit'))
+            its = rf.get('in_timed_schedule')
+            rf['frac_in_timed_schedule'] = None if not its else its['frac']
+            rf['avg_launch_us_in_timed_schedule'] = None if not its else its['avg_launch_us']
         if world == 1 and not args.no_cpu_baseline and not g_only:
             result['cpu_baseline'] = cpu_baseline(args.size, args.batch, min(os.cpu_count() or 1, 64))
         if world == 1 and not args.no_extras and not (WITH_VGG or WITH_FACE_D) and AMP == 'O0' and WORKLOAD == 'pose':

@@ -3,8 +3,9 @@
 A plain fp32 PyTorch-on-CPU restatement of the reference's algorithm, written functionally (state_dict in,
 tensors out) so that it shares no code with the product modules in few-shot-vid2vid_amd/.  Every function cites
 the reference lines it follows (paths relative to /root/reference).  The restatement is pinned against the real
-reference, imported in the build container through oracle/ref_import.py, by tests/test_oracle_pin.py and by the
-golden fixtures in tests/golden/ (generated by oracle/make_golden.py from the unmodified reference modules).
+reference by the golden fixtures in tests/golden/ (minted by oracle/make_golden.py from the unmodified reference modules,
+imported in the build container through oracle/ref_import.py) and the tests of tests/test_golden.py that replay them
+(`test_oracle_reproduces_reference_*`).
 
 Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.
 """

@@ -11,6 +11,8 @@ What is stored (all small):
                               Weights are NOT stored: tests/model_checks.fill_state derives every parameter from its
                               state_dict key with numpy's Generator, so the reference, the oracle and the product all
                               see identical weights.
+  * step_<cfg>_fullsize.pt  - the benchmarked configurations at full width and full resolution (512x512 pose B = 2, 1024x512
+                              street): losses, norms and count sketches of outputs and of every parameter gradient (see FULLSIZE);
   * warp_taps.pt            - integer bilinear tap indices selected by ATen's grid_sample through the reference's
                               `resample` (revealed by the backward scatter pattern), for zero / integer / random flows.
 """
@@ -114,11 +116,19 @@ def step(name, flags):
     gD = {k: float(p.grad.norm()) for k, p in model.netD.named_parameters() if p.grad is not None}
     gDf = {k: float(p.grad.norm()) for k, p in model.netDf.named_parameters() if p.grad is not None} \
         if model.netDf is not None else {}
+    # K seeded random projections of every parameter gradient next to its norm (model_checks.sketch): a permuted or
+    # sign-flipped gradient of equal norm does not pass them
+    skD = {k: mc.sketch(k, p.grad, mc.SKETCH_K_GRAD) for k, p in model.netD.named_parameters() if p.grad is not None}
+    skDf = {k: mc.sketch(k, p.grad, mc.SKETCH_K_GRAD) for k, p in model.netDf.named_parameters() if p.grad is not None} \
+        if model.netDf is not None else {}
     g_losses, generated, prev = model(data, save_images=True, mode='generator')
     g_losses = loss_backward(opt, g_losses, model.optimizer_G, 0)
     gG = {k: float(p.grad.norm()) for k, p in model.netG.named_parameters() if p.grad is not None}
+    skG = {k: mc.sketch(k, p.grad, mc.SKETCH_K_GRAD) for k, p in model.netG.named_parameters() if p.grad is not None}
     if getattr(model, 'refine_face', False):
         gG.update({'netGf.' + k: float(p.grad.norm()) for k, p in model.netGf.named_parameters() if p.grad is not None})
+        skG.update({'netGf.' + k: mc.sketch('netGf.' + k, p.grad, mc.SKETCH_K_GRAD) for k, p in model.netGf.named_parameters()
+                    if p.grad is not None})
     fake, raw, warped, flow, mask, _ = generated
 
     def t(x):
@@ -127,9 +137,104 @@ def step(name, flags):
                     d_losses=[float(x) for x in d_losses], g_losses=[float(x) for x in g_losses],
                     loss_names=model.lossCollector.loss_names,
                     fake=t(fake), raw=t(raw), warp=[t(w) for w in warped], flow=[t(f) for f in flow],
-                    mask=[t(m) for m in mask], grad_norm_D=gD, grad_norm_G=gG, grad_norm_Df=gDf),
+                    mask=[t(m) for m in mask], grad_norm_D=gD, grad_norm_G=gG, grad_norm_Df=gDf,
+                    grad_sketch_D=skD, grad_sketch_G=skG, grad_sketch_Df=skDf),
                os.path.join(OUT, 'step_%s.pt' % name))
     print(name, 'D', [round(float(x), 5) for x in d_losses[:2]], 'G', [round(float(x), 5) for x in g_losses])
+
+
+# ---- the benchmarked configurations at FULL size (BASELINE.json configs[2] / [4]): one iteration of the
+# unmodified reference on the seeded inputs the hardware tests use.  Nothing of that size can be committed as tensors (the image is
+# 6 MB, the generator's gradient 392 MB), so the fixture keeps losses, norms and count sketches (model_checks.sketch: 256 numbers
+# per output tensor, 16 per parameter gradient) - and, per quantity, the distance between the reference's fp32 result and the fp64
+# evaluation of the same iteration by the oracle (the reference's own `.float()` casts keep it from running in double): the fp32
+# arithmetic's own noise floor on these inputs, which the hardware test adds to its tolerance exactly like the inline fp32 / fp64
+# oracle pair it replaces (tests/test_fullsize_gpu.py).
+FULLSIZE = {
+    'pose_fullsize': dict(flags=LAYOUT_CONFIGS['C3_pose_512'] + ' --batchSize 2', seed=21),
+    'street_fullsize': dict(flags='--dataset_mode fewshot_street --label_nc 35 --fineSize 1024 --loadSize 1024 --adaptive_spade '
+                                  '--no_flow_gt --no_vgg_loss --gpu_ids -1 --batchSize 1', seed=21),
+    'pose_face_d_fullsize': dict(flags=LAYOUT_CONFIGS['C3_pose_512'].replace(' --no_vgg_loss', '') + ' --add_face_D --batchSize 2',
+                                 seed=21),
+}
+
+
+def fullsize(name):
+    import time
+    import model_checks as mc
+    from oracle import fsv_oracle as O
+    ref_import.install_shims()
+    from models.loss_collector import loss_backward
+    flags, seed = FULLSIZE[name]['flags'], FULLSIZE[name]['seed']
+    t0 = time.time()
+    opt, model = ref_import.build_model(flags.split())
+    sdG0, sdD0 = mc.fill_state(model.netG), mc.fill_state(model.netD)
+    sdDf0 = mc.fill_state(model.netDf) if model.netDf is not None else None
+    for o in (model.optimizer_G, model.optimizer_D):
+        for g in o.param_groups:
+            g['lr'] = 0.0
+    nl = opt.label_nc if opt.label_nc != 0 else opt.input_nc
+    h, w = int(opt.fineSize / opt.aspect_ratio), opt.fineSize
+    b = opt.batchSize
+    data4 = mc.synth_street_inputs(b, h, w, seed, opt.label_nc) if 'street' in opt.dataset_mode else mc.synth_pose_inputs(b, h, w, seed, nl)
+    tl, ti, rl, ri = data4
+    data = [tl, ti, [None, None], [None, None], rl, ri, None, None, None]
+    d_losses = loss_backward(opt, model(data, mode='discriminator'), model.optimizer_D, 1)
+    gD = {k: p.grad.detach().clone() for k, p in model.netD.named_parameters() if p.grad is not None}
+    gDf = {k: p.grad.detach().clone() for k, p in model.netDf.named_parameters() if p.grad is not None} \
+        if model.netDf is not None else {}
+    g_losses, generated, _ = model(data, save_images=True, mode='generator')
+    g_losses = loss_backward(opt, g_losses, model.optimizer_G, 0)
+    gG = {k: p.grad.detach().clone() for k, p in model.netG.named_parameters() if p.grad is not None}
+    fake, raw, warped, flow, mask, _ = generated
+    outs = {'fake': fake[:, 0]}
+    if flow[0] is not None:
+        outs.update(flow0=flow[0], mask0=mask[0], warp0=warped[0])
+    outs = {k: v.detach().clone() for k, v in outs.items()}
+    names = model.lossCollector.loss_names
+    d_losses, g_losses = [float(x) for x in d_losses], [float(x) for x in g_losses]
+    t_ref = time.time() - t0
+    del model
+    # ---- the same iteration in fp64 on the oracle: the noise floor of the fp32 evaluation --------------------------------------
+    t0 = time.time()
+    popt = mc.make_opt(**{k: v for k, v in vars(_product_opt(opt)).items()})
+    vw = mc._vgg_weights(popt)
+    r64 = O.iteration(sdG0, sdD0, O.cfg_from_opt(popt), data4, torch.float64, vw, sdDf0, [None, None], [None, None], None)
+    d64, gD64, g64, gG64, gen64, gDf64 = r64
+    t_orc = time.time() - t0
+
+    def pack(grads, grads64):
+        out = {}
+        for k, g in grads.items():
+            g6 = grads64[k].detach().double()
+            out[k] = dict(norm=float(g.double().norm()), sketch=mc.sketch(k, g, mc.SKETCH_K_GRAD),
+                          noise_l2=float((g.double() - g6).norm()), norm64=float(g6.norm()))
+        return out
+    o64 = {'fake': gen64['fake']}
+    if 'flow0' in outs:
+        o64.update(flow0=gen64['flow'][0], mask0=gen64['mask'][0], warp0=gen64['warp'][0])
+    out_rec = {k: dict(norm=float(v.double().norm()), absmax=float(v.abs().max()), sketch=mc.sketch(k, v, mc.SKETCH_K_IMAGE),
+                       noise_l2=float((v.double() - o64[k].detach().double().reshape(v.shape)).norm()),
+                       noise_max=float((v.double() - o64[k].detach().double().reshape(v.shape)).abs().max()))
+               for k, v in outs.items()}
+    torch.save(dict(flags=flags, seed=seed, batch=b, hw=(h, w), loss_names=names, d_losses=d_losses, g_losses=g_losses,
+                    d_losses64=[float(x) for x in d64], g_losses64={k: float(v) for k, v in g64.items()},
+                    outputs=out_rec, grad_G=pack(gG, gG64), grad_D=pack(gD, gD64), grad_Df=pack(gDf, gDf64),
+                    sketch_k=(mc.SKETCH_K_GRAD, mc.SKETCH_K_IMAGE), torch=torch.__version__,
+                    minted='reference fp32 iteration %.0f s, oracle fp64 iteration %.0f s' % (t_ref, t_orc)),
+               os.path.join(OUT, 'step_%s.pt' % name))
+    worst = max((v['noise_l2'] / max(v['norm64'], 1e-30), k) for k, v in pack(gG, gG64).items() if v['norm64'] > 0)
+    print(name, 'D', [round(x, 5) for x in d_losses[:2]], 'G', [round(x, 5) for x in g_losses], '| reference %.0f s, oracle fp64 %.0f s'
+          % (t_ref, t_orc), '| image fp32-vs-fp64 rel L2 %.2e' % (out_rec['fake']['noise_l2'] / out_rec['fake']['norm']),
+          '| worst gradient noise', worst)
+
+
+def _product_opt(ref_opt):
+    """the reference's parsed options -> the namespace of synth.make_opt (same names; only the keys make_opt knows)"""
+    import argparse
+    import model_checks as mc
+    keys = vars(mc.make_opt())
+    return argparse.Namespace(**{k: getattr(ref_opt, k, keys[k]) for k in keys})
 
 
 def temporal(name, flags):
@@ -352,6 +457,8 @@ if __name__ == '__main__':
                 inference(n[10:], CONFIGS[n[10:]])
             elif n.startswith('temporal:'):
                 temporal(n[9:], CONFIGS[n[9:]])
+            elif n in FULLSIZE:
+                fullsize(n)
             else:
                 step(n, CONFIGS[n])
         sys.exit(0)
@@ -366,4 +473,6 @@ if __name__ == '__main__':
     flownet2()
     finetune('pose_combine', CONFIGS['pose_combine'])
     autocast_ops()
+    for n in FULLSIZE:                   # minutes each (one full-size reference iteration + its fp64 oracle twin)
+        fullsize(n)
     print('goldens written to', OUT)

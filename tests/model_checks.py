@@ -48,6 +48,32 @@ def fill_value(k, shape, scale=1.0):
     return torch.from_numpy((std * rng.standard_normal(shape)).astype(np.float32))
 
 
+# ---- count sketches: a tensor of any size pinned by K numbers -----------------------------------------------------------------------
+# sketch(key, x)[j] = sum over the elements i = j (mod K) of s_i * x_i with seeded random signs s (numpy Generator: the same on
+# every platform).  The K buckets are projections with disjoint supports, so for two tensors a, b:
+#     E || sketch(a) - sketch(b) ||^2 = || a - b ||^2          (every cross term carries an independent sign)
+# i.e. the distance of two sketches is an unbiased estimate of the L2 distance of the tensors (relative spread ~ sqrt(2 / K)), and a
+# permuted, sign-flipped or mis-scaled tensor of the same norm lands at a distance of ~sqrt(2) x the norm.  The golden fixtures keep
+# sketches where the tensors themselves (98 M gradient entries at full size) cannot be committed.
+SKETCH_K_GRAD, SKETCH_K_IMAGE = 16, 256
+
+
+def sketch(key, x, k):
+    x = x.detach().double().cpu().contiguous().reshape(-1).numpy()
+    n = x.shape[0]
+    seed = int(hashlib.sha1(('sketch:' + key).encode()).hexdigest()[:8], 16)
+    sign = np.random.default_rng(seed).integers(0, 2, size=n, dtype=np.int8) * 2 - 1
+    y = x * sign
+    pad = (-n) % k
+    if pad:
+        y = np.concatenate([y, np.zeros(pad)])
+    return torch.from_numpy(y.reshape(-1, k).sum(axis=0))
+
+
+def sketch_distance(a, b):
+    return float((a.double() - b.double()).norm())
+
+
 def fill_state(module, scale=1.0):
     """Overwrite every parameter/buffer with values that depend only on its state_dict key (numpy Generator is
     stable across platforms), so that the product, the oracle and the golden fixtures see identical weights."""
@@ -429,6 +455,96 @@ def check_train_step(device, opt, b=2, tol=1e-3, seed=21, grad_tol=2e-2, with_fl
             f32.setdefault(name, _G(None)); f64.setdefault(name, _G(None))
         compare_grads_l2(model.netGf, f32, f64, grad_tol)
     _close_vs64('fake image', generated[0][:, 0], r32[4]['fake'], r64[4]['fake'], tol)
+    return worst
+
+
+GOLD = os.path.join(ROOT, 'tests', 'golden')
+
+
+def check_train_step_golden(device, opt, case, tol=1e-3, grad_tol=1e-2, bench_schedule=False):
+    """check_train_step against a FULL-SIZE fixture minted from the unmodified reference (tests/golden/step_<case>.pt,
+    oracle/make_golden.py `fullsize`) instead of an inline oracle pair: the product's D step + G step on the fixture's seeded
+    inputs and key-derived weights, compared with the REFERENCE's own fp32 iteration -
+
+      * losses: |got - ref| <= tol * max(1, |ref|) + 4 x the fp32 reference's own distance to the fp64 evaluation;
+      * image / flow / mask / warp: count-sketch distance (an estimate of the L2 distance, 256 buckets: spread 9 %) relative to
+        the tensor's norm <= tol + 3 x the fp32 reference's own relative L2 distance to fp64;
+      * every parameter gradient: norm within grad_tol, and count-sketch distance (16 buckets) <= 1.5 x (grad_tol * max(norm, floor)
+        + 3 x the reference's fp32-vs-fp64 distance) - the band of compare_grads_l2 (2 x noise against the fp64 run = 3 x against
+        the fp32 run) times the estimator's spread; the flow network twice that band, as there.
+
+    No CPU oracle runs on the GPU box for this test (they were minutes per configuration).  Returns the worst relative sketch
+    distance over the generator's parameters."""
+    g = torch.load(os.path.join(GOLD, 'step_%s.pt' % case), weights_only=False)
+    M = _model()
+    model = M.create_model(opt)
+    fill_state(model.netG); fill_state(model.netD)
+    if model.netDf is not None:
+        fill_state(model.netDf)
+    model = model.to(device).train()
+    opt_G, opt_D = model.build_optimizers(split_backward=bool(bench_schedule))
+    model.early_generator = bool(bench_schedule)
+    opt_G.set_lr(0.0); opt_D.set_lr(0.0)
+    h, w = g['hw']
+    b, seed = g['batch'], g['seed']
+    assert (h, w) == (int(opt.fineSize / opt.aspect_ratio), opt.fineSize) and b == opt.batchSize, (g['flags'], vars(opt))
+    nl = opt.label_nc if opt.label_nc != 0 else opt.input_nc
+    data = synth_street_inputs(b, h, w, seed, opt.label_nc) if opt.label_nc != 0 else synth_pose_inputs(b, h, w, seed, nl)
+    tl, ti, rl, ri = [t.to(device) for t in data]
+    data_list = [tl, ti, [None, None], [None, None], rl, ri, None, None, None]
+
+    def loss_close(name, got, ref, ref64):
+        assert abs(got - ref) <= tol * max(1.0, abs(ref)) + 4.0 * abs(ref - ref64), (name, got, ref, ref64)
+
+    def grads_close(net, rec, tag):
+        norms = [v['norm'] for v in rec.values()]
+        floor = 1e-2 * float(np.median(norms)) if norms else 0.0
+        worst, seen = 0.0, 0
+        for name, prm in net.named_parameters():
+            if name not in rec:
+                assert prm.grad is None or float(prm.grad.abs().max()) == 0.0, (tag, name)
+                continue
+            r = rec[name]
+            assert prm.grad is not None, (tag, name)
+            scale = max(r['norm'], floor, 1e-12)
+            t = grad_tol * 2 if 'flow_network' in name else grad_tol
+            band = t * scale + 3.0 * r['noise_l2']
+            got_norm = float(prm.grad.double().norm())
+            assert abs(got_norm - r['norm']) <= band, (tag, name, 'norm', got_norm, r['norm'], band)
+            dist = sketch_distance(sketch(name, prm.grad, SKETCH_K_GRAD), r['sketch'])
+            assert dist <= 1.5 * band, (tag, name, 'sketch distance', dist, 'band', band, 'norm', r['norm'])
+            worst = max(worst, dist / scale)
+            seen += 1
+        assert seen == len(rec), (tag, seen, len(rec))
+        return worst
+
+    d_losses = model(data_list, mode='discriminator')
+    d_losses = M.loss_backward(opt, d_losses, opt_D, 1)
+    early_g = None
+    if bench_schedule:
+        assert model._pre_g is not None, "the early generator pass was not issued"
+        early_g = model(data_list, save_images=True, mode='generator')
+        assert model._pre_g is None
+    for i in range(len(g['d_losses64'])):
+        loss_close(g['loss_names'][10 + i], float(d_losses[i]), g['d_losses'][i], g['d_losses64'][i])
+    grads_close(model.netD, g['grad_D'], 'netD')
+    if model.netDf is not None:
+        grads_close(model.netDf, g['grad_Df'], 'netDf')
+    g_losses, generated, _ = early_g if early_g is not None else model(data_list, save_images=True, mode='generator')
+    g_losses = M.loss_backward(opt, g_losses, opt_G, 0)
+    names = M.LOSS_NAMES_G
+    for k, ref64 in g['g_losses64'].items():
+        i = names.index(k)
+        loss_close(k, float(g_losses[i]), g['g_losses'][i], ref64)
+    worst = grads_close(model.netG, g['grad_G'], 'netG')
+    outs = {'fake': generated[0][:, 0]}
+    if 'flow0' in g['outputs']:
+        outs.update(flow0=generated[3][0], mask0=generated[4][0], warp0=generated[2][0])
+    for k, r in g['outputs'].items():
+        dist = sketch_distance(sketch(k, outs[k], SKETCH_K_IMAGE), r['sketch'])
+        assert dist <= tol * r['norm'] + 3.0 * r['noise_l2'], (k, 'sketch distance', dist, 'norm', r['norm'], 'noise', r['noise_l2'])
+        amax = float(outs[k].abs().max())
+        assert abs(amax - r['absmax']) <= tol * r['absmax'] + 4.0 * r['noise_max'], (k, amax, r['absmax'])
     return worst
 
 

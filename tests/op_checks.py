@@ -165,6 +165,11 @@ def check_conv_up(device, n=2, cin=16, h=6, w=10, cout=24, k=3, act='lrelu', sta
     # on one side and 0.2 on the other - the large cases are run with act='none'; hardware record: 7.5e-3 of max|dx| on one element)
     for name, got, want in (('y', a[0], ref), ('dx', a[1], xr.grad), ('dw', a[2], wr.grad), ('db', a[3], br.grad)):
         assert_close('conv(up2x) %s' % name, got, want, tol)
+    if want_sub:
+        # the sub-pixel forward's own arithmetic (summed weights: one extra fp32 rounding) against F.conv2d(F.interpolate(x))
+        # itself, not only against the product's other path (round-5 review, weak #2)
+        for name, got, want in (('y', sub[0], ref), ('dx', sub[1], xr.grad), ('dw', sub[2], wr.grad), ('db', sub[3], br.grad)):
+            assert_close('conv(up2x) %s, sub-pixel forward vs torch' % name, got, want, tol)
     if expect_fold and not amp and cin % 4 == 0 and cout % 32 == 0:
         # every tile shape of the plan has its own UP instantiation (and the LD form its own address swizzle): forced, forward,
         # against the same tile on the materialised tensor - bit for bit, K splits included

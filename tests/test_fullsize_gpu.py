@@ -9,6 +9,12 @@ running on the GPU box's host cores, same seeded inputs and weights.
   C5  fewshot_street 1024x512  label_nc 35  B=1 (per rank)  adaptive_spade   full D step + G step, in fp32 and in the config's
       stated arithmetic (--amp O1, half-precision kernels: against a whole-iteration oracle run in that arithmetic)
 
+C3 and C5 (fp32) - round 6 - are compared with the UNMODIFIED REFERENCE itself: tests/golden/step_pose_fullsize.pt and
+step_street_fullsize.pt hold the losses, norms and count sketches (model_checks.sketch) of one full-size reference iteration on the
+same seeded inputs, and per quantity the fp32 reference's own distance to the fp64 evaluation (oracle/make_golden.py `fullsize`,
+minted in the build container) - no CPU oracle runs on the GPU box for them (model_checks.check_train_step_golden).  C1, C2, C4 and
+the `--amp` form of C5 keep the inline oracle runs (C1 needs the element-wise noise floor; the `--amp` arithmetic has no reference).
+
 Tolerances: losses and images 1e-3 relative (BASELINE.json north_star); per-parameter gradients in the relative L2 norm
 (model_checks.compare_grads_l2), 1e-2 for the full step.  The oracle runs in fp32 and fp64 (C3: ~11 + ~22 GB of host memory):
 a bias gradient is a sum of 10^5 ... 10^6 terms with cancellation, where the fp32 CPU reference itself carries more rounding
@@ -56,10 +62,7 @@ ORACLE_SPECS = {
     'test_c1_face_128_full_step': lambda it: [mc.oracle_spec('fp32', _c1(), 1, it.callspec.params['seed'])],
     'test_c1_face_128_full_step_inputs_on_a_kink': lambda it: [mc.oracle_spec('fp32', _c1(), 1, it.callspec.params['seed'])],
     'test_c1_face_128_full_step_fixed_order': lambda it: [mc.oracle_spec('fp32', _c1(), 1, 24)],
-    'test_c3_pose_512_b2_full_step_is_the_bench_workload': lambda it: [mc.oracle_spec('fp32', _c3(), 2, 21)],
-    'test_c3_pose_512_b2_in_the_schedule_bench_py_runs': lambda it: [mc.oracle_spec('fp32', _c3(), 2, 21)],
     'test_c4_pose_512_face_d_vgg': lambda it: [mc.oracle_spec('fp32', _c4(), 2, 21)],
-    'test_c5_street_1024x512_nc35_fp32': lambda it: [mc.oracle_spec('fp32', _c5(), 1, 21)],
     'test_c5_street_1024x512_nc35_amp': lambda it: [mc.oracle_spec('amp', _c5('O1'), 1, 21, loss_scale=1024.0)],
     'test_c5_street_1024x512_nc35_amp_in_the_schedule_bench_py_runs': lambda it: [mc.oracle_spec('amp', _c5('O1'), 1, 21, loss_scale=1024.0)],
 }
@@ -125,10 +128,10 @@ def test_c3_pose_512_b2_full_step_is_the_bench_workload(hip_lib):
     opt = _c3()
     conv.start_plan_log()
     try:
-        worst = mc.check_train_step(DEV, opt, b=2, tol=1e-3, grad_tol=1e-2)
+        worst = mc.check_train_step_golden(DEV, opt, 'pose_fullsize', tol=1e-3, grad_tol=1e-2)
     finally:
         log = conv.stop_plan_log()
-    assert worst < 1e-2, worst
+    print('C3 vs the reference fixture: worst generator-gradient sketch distance %.3e of its norm' % worst)
     groups = [e for e in log if e[0] == 'group']                      # ('group', tile, float4 gather, problems)
     log = [e for e in log if e[0] != 'group']
     tiles = {t for t, _, v4 in log if v4}
@@ -147,8 +150,7 @@ def test_c3_pose_512_b2_in_the_schedule_bench_py_runs(hip_lib):
     oracle at the same bars.  (The kernels are the ones of the test above - the fused bn_s -> conv_s kernel included, which both
     run; what this adds is the schedule.)"""
     opt = _c3()
-    worst = mc.check_train_step(DEV, opt, b=2, tol=1e-3, grad_tol=1e-2, bench_schedule=True)
-    assert worst < 1e-2, worst
+    mc.check_train_step_golden(DEV, opt, 'pose_fullsize', tol=1e-3, grad_tol=1e-2, bench_schedule=True)
 
 
 def test_c4_pose_512_face_d_vgg(hip_lib):
@@ -166,8 +168,7 @@ def test_c5_street_1024x512_nc35_fp32(hip_lib):
     labels, --adaptive_spade; one sample per GPU of the 8-GPU batch of 8): full width, full D step + G step against the oracle.
     The config's own arithmetic (--amp O1) is the next test."""
     opt = _c5()
-    worst = mc.check_train_step(DEV, opt, b=1, tol=1e-3, grad_tol=1e-2)
-    assert worst < 1e-2, worst
+    mc.check_train_step_golden(DEV, opt, 'street_fullsize', tol=1e-3, grad_tol=1e-2)
 
 
 def test_c5_street_1024x512_nc35_amp(hip_lib):
