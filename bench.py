@@ -503,6 +503,12 @@ def main():
     for _ in range(max(0, args.warmup - n_eager_warm)):
         run()
 
+    # N > 1: every collective of the timed steps is logged (bytes, issue -> complete time on its stream) so that a scaling
+    # record explains itself: `exchange` in the JSON line
+    xlog = None
+    if distributed:
+        xlog = []
+        opt_G.exchange_log = opt_D.exchange_log = xlog
     sync()
     if world > 1 or force_dist:
         dist.barrier()
@@ -659,6 +665,15 @@ def main():
                 prof.stamp_end(); prof.disable()
                 print('stamped capture failed (%s); roofline priced on the eager brackets' % str(e).split('\n')[0], file=sys.stderr)
                 torch.cuda.synchronize()
+    if xlog is not None:
+        opt_G.exchange_log = opt_D.exchange_log = None
+        if rank == 0:
+            from importlib import import_module as _im
+            ex = _im('few-shot-vid2vid_amd.flat').FlatAdam.exchange_summary(xlog)
+            result['exchange'] = ex
+            result['exchange_note'] = ('gradient all-reduces per step (RCCL; sum, the 1/world factor sits in the Adam kernel): bytes and '
+                                       'average issue -> complete ms of each; side_stream: runs next to the following graph segment. '
+                                       'ranks %d; critical-path collective: the last generator range' % world)
     if rank == 0:
         result['step_tflops'] = round(tflop_per_frame * frames / elapsed, 2)
         if rl is not None:

@@ -1447,7 +1447,7 @@ __global__ __launch_bounds__(256) void fsv_prep_weight_kernel(const float* w, fl
 struct PrepGroup {
   const long long* src; const long long* dst; const int* dims; const unsigned long long* taps;
 };
-// tmap[b] = (layout, 32-wide co tile, ci tile): the OIHW source tile [32 co][CI_T ci][KH*KW] is read in contiguous runs of
+// tmap[b] = (first layout of the layer, layouts of the layer, 32-wide co tile, ci tile): the OIHW source tile [32 co][CI_T ci][KH*KW] is read in contiguous runs of
 // CI_T * KK floats per output channel, staged in LDS and written out as rows of the K-major layout (CI_T = 32 for <= 8 source
 // taps, else 16).  Only the valid region is written: the padding rows / columns of a layout are zero from allocation on.
 // The kernel is a pure HBM stream (4 B read + 4 B written per element and layout), so what matters is the number of loads a
@@ -1455,16 +1455,21 @@ struct PrepGroup {
 // before the first LDS write, index arithmetic is by compile-time constants for the three source tap counts that hold all but a
 // few KB of the parameters (1x1 / linear, 3x3, 4x4; KKT = 0: any other, run-time divisions), and the layouts are written as
 // float4 (round 3: 805 -> see profiles/r03_notes.md).
+// Round 6: a workgroup stages its OIHW source tile ONCE and writes every layout of the layer from it (forward + data gradient, the
+// four parity classes of a stride-2 layer, the summed-tap layouts below): tmap[b] = (first job of the layer, number of jobs, co tile,
+// ci tile); the jobs of a layer are consecutive in the tables and share source pointer and source geometry (dims[0..4]).  Before, every
+// job re-read and re-staged the source (16 B per weight of HBM traffic and two staging passes for a stride-1 layer: now 12 B and one).
+// mode & 4 (summed taps - conv3x3(nearest_x2(x)) without its redundant products): the two nibbles of a tap code are
+// MASKS over kh resp. kw and the written value is the sum of the selected source taps, kh ascending outside, kw ascending inside
+// (sums of at most four weights: V = R W R^T with 0 / 1 rows R - ops._SUBPIXEL_ROWS / _DGRAD_ROWS).
 template <int KKT>
-__device__ __forceinline__ void fsv_prep_tile(const PrepGroup& g, const int layer, const int cot, const int cit, float* t) {
+__device__ __forceinline__ void fsv_prep_stage(const PrepGroup& g, const int layer, const int cot, const int cit, float* t) {
   const int* d = g.dims + layer * 9;
-  const int Cout = d[0], CinP = d[1], CinR = d[2], KW = d[4], ntaps = d[5], ldw = d[7], mode = d[8];
+  const int Cout = d[0], CinR = d[2], KW = d[4];
   const int KK = KKT ? KKT : d[3] * KW;
   const int CI_T = KK <= 8 ? 32 : 16;
   const int run = CI_T * KK, lds = run + 1;
   const float* w = reinterpret_cast<const float*>(g.src[layer]);
-  float* wt = reinterpret_cast<float*>(g.dst[layer]);
-  const unsigned long long lo = g.taps[layer * 2], hi = g.taps[layer * 2 + 1];
   const int co0 = cot * 32, ci0 = cit * CI_T;
   const int tid = threadIdx.x;
   const int total = 32 * run;
@@ -1484,7 +1489,39 @@ __device__ __forceinline__ void fsv_prep_tile(const PrepGroup& g, const int laye
     for (int u = 0; u < 4; ++u)
       if (dst[u] >= 0) t[dst[u]] = val[u];
   }
-  __syncthreads();
+}
+
+// one weight of a layout out of the staged tile: a single source tap, or (masked) the sum of the taps the two masks select
+__device__ __forceinline__ float fsv_prep_pick(const float* src, const int code, const int KW, const bool masked) {
+  if (!masked) return src[(code & 15) * KW + (code >> 4)];
+  const int mh = code & 15, mw = code >> 4;
+  float s = 0.f;
+  bool first = true;
+  for (int kh = 0; kh < 4; ++kh) {
+    if (!((mh >> kh) & 1)) continue;
+    for (int kw = 0; kw < 4; ++kw) {
+      if (!((mw >> kw) & 1)) continue;
+      const float v = src[kh * KW + kw];
+      s = first ? v : s + v;
+      first = false;
+    }
+  }
+  return s;
+}
+
+template <int KKT>
+__device__ __forceinline__ void fsv_prep_emit(const PrepGroup& g, const int layer, const int cot, const int cit, const float* t) {
+  const int* d = g.dims + layer * 9;
+  const int Cout = d[0], CinP = d[1], KW = d[4], ntaps = d[5], ldw = d[7];
+  const int mode = d[8] & 1;
+  const bool masked = (d[8] & 4) != 0;
+  const int KK = KKT ? KKT : d[3] * KW;
+  const int CI_T = KK <= 8 ? 32 : 16;
+  const int run = CI_T * KK, lds = run + 1;
+  float* wt = reinterpret_cast<float*>(g.dst[layer]);
+  const unsigned long long lo = g.taps[layer * 2], hi = g.taps[layer * 2 + 1];
+  const int co0 = cot * 32, ci0 = cit * CI_T;
+  const int tid = threadIdx.x;
   if (mode == 0) {          // rows (tap j, ci), 32 consecutive output channels each: 8 work-items x float4 per row
     const int q = tid & 7, r0 = tid >> 3;
     const int nrows = ntaps * CI_T;
@@ -1492,13 +1529,13 @@ __device__ __forceinline__ void fsv_prep_tile(const PrepGroup& g, const int laye
       const int j = r / CI_T, cil = r - j * CI_T;
       const int ci = ci0 + cil;
       if (ci >= CinP) continue;
-      const unsigned long long code = (j < 8) ? lo : hi;
-      const int sh = (j & 7) * 8;
-      const int tk = (int)((code >> sh) & 15ull) * KW + (int)((code >> (sh + 4)) & 15ull);
-      const float* src = t + (4 * q) * lds + cil * KK + tk;
+      const unsigned long long code8 = (j < 8) ? lo : hi;
+      const int code = (int)((code8 >> ((j & 7) * 8)) & 255ull);
+      const float* src = t + (4 * q) * lds + cil * KK;
       // columns at or beyond Cout hold zeros in LDS and land in the layout's zero padding (ldw is a multiple of 32)
       *reinterpret_cast<float4*>(&wt[((long long)j * CinP + ci) * ldw + co0 + 4 * q]) =
-          make_float4(src[0], src[lds], src[2 * lds], src[3 * lds]);
+          make_float4(fsv_prep_pick(src, code, KW, masked), fsv_prep_pick(src + lds, code, KW, masked),
+                      fsv_prep_pick(src + 2 * lds, code, KW, masked), fsv_prep_pick(src + 3 * lds, code, KW, masked));
     }
   } else {                  // rows (tap j, co), CI_T consecutive input channels each: CI_T / 4 work-items x float4 per row
     const int QN = CI_T / 4;
@@ -1508,28 +1545,38 @@ __device__ __forceinline__ void fsv_prep_tile(const PrepGroup& g, const int laye
       const int j = r >> 5, col = r & 31;
       const int co = co0 + col, ci = ci0 + 4 * q;
       if (co >= Cout || ci >= CinP) continue;
-      const unsigned long long code = (j < 8) ? lo : hi;
-      const int sh = (j & 7) * 8;
-      const int tk = (int)((code >> sh) & 15ull) * KW + (int)((code >> (sh + 4)) & 15ull);
-      const float* src = t + col * lds + (4 * q) * KK + tk;
+      const unsigned long long code8 = (j < 8) ? lo : hi;
+      const int code = (int)((code8 >> ((j & 7) * 8)) & 255ull);
+      const float* src = t + col * lds + (4 * q) * KK;
       float* dstp = &wt[((long long)j * Cout + co) * ldw + ci];
       if (ci + 3 < CinP) {
-        *reinterpret_cast<float4*>(dstp) = make_float4(src[0], src[KK], src[2 * KK], src[3 * KK]);
+        *reinterpret_cast<float4*>(dstp) =
+            make_float4(fsv_prep_pick(src, code, KW, masked), fsv_prep_pick(src + KK, code, KW, masked),
+                        fsv_prep_pick(src + 2 * KK, code, KW, masked), fsv_prep_pick(src + 3 * KK, code, KW, masked));
       } else {
-        for (int k = 0; ci + k < CinP; ++k) dstp[k] = src[k * KK];
+        for (int k = 0; ci + k < CinP; ++k) dstp[k] = fsv_prep_pick(src + k * KK, code, KW, masked);
       }
     }
   }
 }
 
+template <int KKT>
+__device__ __forceinline__ void fsv_prep_layer(const PrepGroup& g, const int first, const int njobs, const int cot, const int cit,
+                                               float* t) {
+  fsv_prep_stage<KKT>(g, first, cot, cit, t);
+  __syncthreads();
+  for (int j = 0; j < njobs; ++j) fsv_prep_emit<KKT>(g, first + j, cot, cit, t);
+}
+
 __global__ __launch_bounds__(256) void fsv_prep_group_kernel(PrepGroup g, const int* tmap) {
   __shared__ float t[32 * 257];
-  const int layer = tmap[blockIdx.x * 3], cot = tmap[blockIdx.x * 3 + 1], cit = tmap[blockIdx.x * 3 + 2];
-  const int KK = g.dims[layer * 9 + 3] * g.dims[layer * 9 + 4];
-  if (KK == 9) fsv_prep_tile<9>(g, layer, cot, cit, t);
-  else if (KK == 1) fsv_prep_tile<1>(g, layer, cot, cit, t);
-  else if (KK == 16) fsv_prep_tile<16>(g, layer, cot, cit, t);
-  else fsv_prep_tile<0>(g, layer, cot, cit, t);
+  const int first = tmap[blockIdx.x * 4], njobs = tmap[blockIdx.x * 4 + 1];
+  const int cot = tmap[blockIdx.x * 4 + 2], cit = tmap[blockIdx.x * 4 + 3];
+  const int KK = g.dims[first * 9 + 3] * g.dims[first * 9 + 4];
+  if (KK == 9) fsv_prep_layer<9>(g, first, njobs, cot, cit, t);
+  else if (KK == 1) fsv_prep_layer<1>(g, first, njobs, cot, cit, t);
+  else if (KK == 16) fsv_prep_layer<16>(g, first, njobs, cot, cit, t);
+  else fsv_prep_layer<0>(g, first, njobs, cot, cit, t);
 }
 
 extern "C" int fsv_prep_weight_grouped(const long long* src, const long long* dst, const int* dims,

@@ -249,17 +249,48 @@ class FlatAdam:
             self.params[i].grad = self._grad_views[i]
         self._loose = []
 
-    def _all_reduce(self, view):
+    exchange_log = None          # set to a list to record every collective (exchange_summary)
+
+    def _all_reduce(self, view, label='', side=False):
         """hook-free mode: the collective is issued with a work handle (async_op=True), the issuing stream waits for it at once
         (`wait()` on an RCCL work is a stream-side dependency, the host does not block) and the handle is kept until
         drain_works(): graph_step waits for every handle to report completion before it starts a hipGraph capture, so the
         process group's watchdog thread has nothing of ours left in flight while streams are capturing."""
+        log = self.exchange_log
+        if log is not None:                    # bench.py at N > 1: bytes and issue -> complete time of every collective
+            import time
+            cuda = view.is_cuda
+            if cuda:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+            t0 = time.perf_counter()
         h = dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
         if h is not None:
             h.wait()
             if len(self._works) >= 16:         # a long replay loop never drains: keep only what is still in flight
                 self._works = [w for w in self._works if not w.is_completed()]
             self._works.append(h)
+        if log is not None:
+            if cuda:
+                e1.record()                    # behind the stream-side wait: reached when the collective has completed
+            log.append(dict(name=label, bytes=view.numel() * view.element_size(), side=bool(side),
+                            events=(e0, e1) if cuda else None, host_s=time.perf_counter() - t0))
+
+    @staticmethod
+    def exchange_summary(log):
+        """per collective name: launches, bytes and the average issue -> complete time (device events on the issuing stream; the
+        host-side wall time for a CPU group).  Call after a device synchronise."""
+        agg = {}
+        for r in log:
+            a = agg.setdefault(r['name'], dict(name=r['name'], n=0, bytes=r['bytes'], ms=0.0, side_stream=r['side']))
+            a['n'] += 1
+            a['ms'] += (r['events'][0].elapsed_time(r['events'][1]) if r['events'] is not None else r['host_s'] * 1e3)
+        out = []
+        for a in agg.values():
+            a['ms'] = round(a['ms'] / max(a['n'], 1), 3)
+            a['GB_per_s'] = round(a['bytes'] / max(a['ms'], 1e-6) / 1e6, 1)
+            out.append(a)
+        return out
 
     def drain_works(self, timeout_s=60.0):
         """Block the host until every collective issued through _all_reduce has completed (work.is_completed(): the end event of
@@ -274,13 +305,13 @@ class FlatAdam:
                 time.sleep(0.001)
         return len(works)
 
-    def exchange_all(self):
+    def exchange_all(self, label=''):
         """Non-overlapped mode: one all-reduce over the whole flat gradient buffer on the current stream."""
         self.finalize_grads()
         if self.exchange and not self.overlap:
-            self._all_reduce(self.flat_g)
+            self._all_reduce(self.flat_g, label or 'all')
 
-    def exchange_range(self, lo, hi, side=False):
+    def exchange_range(self, lo, hi, side=False, label=''):
         """All-reduce flat_g[lo:hi] (hook-free mode; the caller has finalised the gradients in that range).  side=True:
         on this optimiser's side stream, which first waits for the work queued on the current stream - the collective then
         runs next to whatever the caller enqueues on the current stream afterwards; join with wait_exchange()."""
@@ -292,10 +323,10 @@ class FlatAdam:
                 self.side_stream = torch.cuda.Stream(device=self.device)
             self.side_stream.wait_stream(torch.cuda.current_stream(self.device))
             with torch.cuda.stream(self.side_stream):
-                self._all_reduce(view)
+                self._all_reduce(view, label, side=True)
             self._side_pending = True
         else:
-            self._all_reduce(view)
+            self._all_reduce(view, label)
 
     def wait_exchange(self):
         if getattr(self, '_side_pending', False):

@@ -177,27 +177,27 @@ class GraphedIteration:
     # ---- the collectives between the segments (host side; never captured) -------------------------------------------------
     def _exchange_d(self):
         # the discriminator's 11 MB on the optimiser's side stream: it runs next to the segment that follows (_seg_gf)
-        self.opt_D.exchange_range(0, self.opt_D.total, side=True)
+        self.opt_D.exchange_range(0, self.opt_D.total, side=True, label='D')
 
     def _wait_d(self):
         self.opt_D.wait_exchange()
 
     def _exchange_d_serial(self):
-        self.opt_D.exchange_all()
+        self.opt_D.exchange_all('D')
 
     def _exchange_g_first(self):
-        self.opt_G.exchange_range(0, self.opt_G.split_at, side=True)
+        self.opt_G.exchange_range(0, self.opt_G.split_at, side=True, label='G decoder stage')
 
     def _exchange_g_middle(self):
         # (the side stream runs its collectives in order: this one queues behind the first range)
-        self.opt_G.exchange_range(self.opt_G.split_at, self.opt_G.split_at2, side=True)
+        self.opt_G.exchange_range(self.opt_G.split_at, self.opt_G.split_at2, side=True, label='G middle')
 
     def _exchange_g_rest(self):
-        self.opt_G.exchange_range(self.opt_G.split_at2 if self.pieces == 3 else self.opt_G.split_at, self.opt_G.total)
+        self.opt_G.exchange_range(self.opt_G.split_at2 if self.pieces == 3 else self.opt_G.split_at, self.opt_G.total, label='G rest')
         self.opt_G.wait_exchange()
 
     def _exchange_g_all(self):
-        self.opt_G.exchange_all()
+        self.opt_G.exchange_all('G')
 
     def _steps(self, e, save_images):
         """The iteration as (body, after) pairs: `body` is what one hipGraph segment captures, `after` runs on the host behind it

@@ -205,8 +205,11 @@ int fsv_prep_weight(const float* w, float* wt, const float* scale_ptr, int mode,
                     int Kpad, int ldw, long long w_bstride, long long wt_bstride, fsv_stream_t stream);
 
 /* every parameter weight of an optimiser re-arranged in one launch (un-scaled; used once per optimiser step).  dims[l] =
- * {Cout, Cin_pad, Cin_real, KH, KW, ntaps, Kpad, ldw, mode}; tmap = (layout, 32-co tile, ci tile) triples (ci tile = 32
- * channels for KH*KW <= 8, else 16); only the valid region of each (pre-zeroed) layout is written */
+ * {Cout, Cin_pad, Cin_real, KH, KW, ntaps, Kpad, ldw, mode}; the layouts of one weight are consecutive in the tables and share
+ * its source tile: tmap = (first layout of the weight, number of its layouts, 32-co tile, ci tile) quadruples (ci tile = 32
+ * channels for KH*KW <= 8, else 16); only the valid region of each (pre-zeroed) layout is written.  mode | 4: the two nibbles of
+ * a tap code are MASKS over kh / kw and the written weight is the sum of the selected source taps (the summed-tap layouts of
+ * conv3x3(nearest_x2(x)): sub-pixel forward classes, one-launch data gradient) */
 int fsv_prep_weight_grouped(const long long* src, const long long* dst, const int* dims, const unsigned long long* taps,
                             const int* tmap, int nblocks, fsv_stream_t stream);
 /* grouped fixed-order sums: dst[j] = src[4 j] + src[4 j + 1] + ... (nsrc[j] in 1..4 terms, left to right) over count[j] floats,

@@ -996,6 +996,23 @@ def check_temporal_step(device, opt, b=1, tol=1e-3, seed=31, grad_tol=2e-2):
     return compare_grads_l2(model.netG, sd32, sd64, grad_tol)
 
 
+def masked_tap_sums(w, mhs, mws):
+    """[Cout, Cin, KH, KW] -> [Cout, Cin, ntaps, 1]: tap j = the sum of the source taps its two masks select, in the kernel's order
+    (csrc/conv_igemm.hip fsv_prep_pick: kh ascending outside, kw ascending inside, one fp32 add at a time)"""
+    taps = []
+    for mh, mw in zip(mhs, mws):
+        acc = None
+        for kh in range(w.shape[2]):
+            if not (mh >> kh) & 1:
+                continue
+            for kw in range(w.shape[3]):
+                if not (mw >> kw) & 1:
+                    continue
+                acc = w[:, :, kh, kw].clone() if acc is None else acc + w[:, :, kh, kw]
+        taps.append(acc)
+    return torch.stack(taps, dim=2).unsqueeze(-1).contiguous()
+
+
 def _verify_layouts(optimizer):
     """every cached layout == a fresh per-call re-arrangement of the parameter's current values (bit-exact)"""
     from fsv2v_amd import conv as C
@@ -1009,7 +1026,9 @@ def _verify_layouts(optimizer):
             wp = torch.nn.functional.pad(w, (0, 0, 0, 0, 0, cinp - cin))
             khs = [((lo if j < 8 else hi) >> ((j & 7) * 8)) & 15 for j in range(nt)]
             kws = [((lo if j < 8 else hi) >> ((j & 7) * 8 + 4)) & 15 for j in range(nt)]
-            ref, _, _ = C.prep_weight(wp, mode, None, khs, kws)
+            if mode & 4:        # summed-tap layout (conv3x3(nearest_x2(x))): the nibbles are masks; kh ascending outside, kw inside
+                wp, khs, kws = masked_tap_sums(wp, khs, kws), list(range(nt)), [0] * nt
+            ref, _, _ = C.prep_weight(wp, mode & 1, None, khs, kws)
             assert torch.equal(ref, wt), (d, float((ref - wt).abs().max()))
             n += 1
     return n

@@ -80,7 +80,7 @@ def check_conv(device, n, cin, h, w, cout, k, s, p, act='lrelu', bias=True, seed
 
 
 def check_conv_up(device, n=2, cin=16, h=6, w=10, cout=24, k=3, act='lrelu', stats=0, tile=-1, split=0, seed=71, expect_fold=True,
-                  amp=False):
+                  amp=False, cache=None):
     """conv(nearest_x2(x)) (nn.Upsample in front of a convolution: generator.py:124,489-493,559-563) with the up-sampling folded
     into the gather (csrc/conv_igemm.hip ConvP::up, forward and weight gradient; round 5) against F.conv2d(F.interpolate(x)):
     output, dx (the 2 x 2 pooled data gradient), dw, db; bit-equal to the same convolution on the materialised tensor
@@ -104,10 +104,12 @@ def check_conv_up(device, n=2, cin=16, h=6, w=10, cout=24, k=3, act='lrelu', sta
         xd = _dev(x, device).detach().clone().requires_grad_(True)
         wd = _dev(wt, device).detach().clone().requires_grad_(True)
         bd = _dev(b, device).detach().clone().requires_grad_(True)
+        if cache is not None:          # an optimiser-owned weight: persistent layouts, the summed-tap ones included (round 6)
+            wd._fsv_cache = cache
         seen, real_call = [], lib.call
 
         def recording_call(name, *a):
-            seen.append((name, a))
+            seen.append((name if name != 'fsv_prep_weight' else 'fsv_prep_weight:mode%d' % a[3], a))
             return real_call(name, *a)
         os.environ['FSV_UP_FOLD'] = '1' if fold else '0'
         os.environ['FSV_UP_DGRAD'] = '1' if direct else '0'
@@ -165,6 +167,23 @@ def check_conv_up(device, n=2, cin=16, h=6, w=10, cout=24, k=3, act='lrelu', sta
     # on one side and 0.2 on the other - the large cases are run with act='none'; hardware record: 7.5e-3 of max|dx| on one element)
     for name, got, want in (('y', a[0], ref), ('dx', a[1], xr.grad), ('dw', a[2], wr.grad), ('db', a[3], br.grad)):
         assert_close('conv(up2x) %s' % name, got, want, tol)
+    if cache is not None and k == 3 and not amp and cin % 4 == 0 and folded:
+        # the summed-tap layouts live in the layout cache: no per-call re-arrangement in any of the folded runs, and the cached
+        # operands equal the per-call construction (0 / 1 coefficient product + re-arrangement) to the last rounding of a sum
+        for r in (a, pooled, sub):
+            assert 'fsv_prep_weight:mode0' not in r[4] and 'fsv_prep_weight:mode1' not in r[4], r[4]
+        ups = [e for e in cache.entries if e.up_fwd is not None and tuple(e.weight.shape) == (cout, cin, 3, 3)]
+        assert ups, 'no summed-tap layouts were registered'
+        e = ups[-1]
+        w4 = e.weight.detach()
+        v, khs, kws, _, _ = ops._up_dgrad_weight(w4)
+        refd, _, _ = conv.prep_weight(v, 1, conv.Geom(3, 3, 1, 1), khs, kws, None)
+        assert_close('cached summed-tap data-gradient layout', e.up_dgrad[0], refd, 1e-6)
+        cls = [(ry, rx) for ry in (0, 1) for rx in (0, 1)]
+        khs = [2 * ry + iy for ry, rx in cls for iy in (0, 1) for _ in (0, 1)]
+        kws = [2 * rx + ix for ry, rx in cls for _ in (0, 1) for ix in (0, 1)]
+        reff, _, _ = conv.prep_weight(ops._tap_sums(w4, ops._SUBPIXEL_ROWS), 0, conv.Geom(3, 3, 1, 1), khs, kws, None)
+        assert_close('cached summed-tap forward layout', e.up_fwd[0], reff, 1e-6)
     if want_sub:
         # the sub-pixel forward's own arithmetic (summed weights: one extra fp32 rounding) against F.conv2d(F.interpolate(x))
         # itself, not only against the product's other path (round-5 review, weak #2)
@@ -283,7 +302,10 @@ def check_layout_cache(device, seed=14):
             wp = F.pad(w4, (0, 0, 0, 0, 0, cinp - cin))
             khs = [((lo if j < 8 else hi) >> ((j & 7) * 8)) & 15 for j in range(nt)]
             kws = [((lo if j < 8 else hi) >> ((j & 7) * 8 + 4)) & 15 for j in range(nt)]
-            ref, _, _ = conv.prep_weight(wp, mode, None, khs, kws)
+            if mode & 4:
+                import model_checks as _mc
+                wp, khs, kws = _mc.masked_tap_sums(wp, khs, kws), list(range(nt)), [0] * nt
+            ref, _, _ = conv.prep_weight(wp, mode & 1, None, khs, kws)
             assert torch.equal(ref, wt), d
 
 

@@ -515,7 +515,7 @@ def test_amp_cast_list_against_torch_autocast(name):
     assert all(set(v) <= {'float32'} for k, v in cen.ops.items() if k != 'convolution'), {k: v for k, v in cen.ops.items() if set(v) - {'float32'}}
 
 
-@pytest.mark.parametrize('case', ['pose_fullsize', 'street_fullsize'])
+@pytest.mark.parametrize('case', ['pose_fullsize', 'street_fullsize', 'pose_face_d_fullsize'])
 def test_fullsize_fixture_is_consistent(case):
     """The full-size fixtures (BASELINE configs[2] / [4] at full width and resolution; oracle/make_golden.py `fullsize`) hold the
     unmodified reference's fp32 iteration AND its distance to the oracle's fp64 evaluation of the same iteration, computed when the

@@ -211,4 +211,7 @@ def test_conv_with_the_upsampling_folded_into_the_gather(emu_lib):
     oc.check_conv_up(DEV, n=1, cin=16, h=5, w=6, cout=3, expect_fold=False)          # thin head: materialised
     oc.check_conv_up(DEV, n=1, cin=16, h=6, w=6, cout=16, amp=True, expect_fold=False)   # half-precision path: materialised
     oc.check_conv_up(DEV, n=2, cin=8, h=64, w=64, cout=8, act='none')                # >= 8192 source pixels: the sub-pixel forward
+    from fsv2v_amd.layout_cache import LayoutCache
+    oc.check_conv_up(DEV, n=2, cin=8, h=64, w=64, cout=40, act='none', cache=LayoutCache())   # ... from the cached summed-tap layouts
+    oc.check_conv_up(DEV, n=1, cin=20, h=6, w=7, cout=24, cache=LayoutCache())       # cin % 8 != 0: data gradient cached, forward per call
     oc.check_conv_up_spectral(DEV, n=2, cin=8, h=64, w=64, cout=8, with_res=False)   # ... of a spectral-normalised layer

@@ -55,6 +55,30 @@ def test_bench_bare_launch_spawns_one_rank_per_gpu(emu_lib):
     assert rec['steps'] == 1 and rec['scaling'] == 'weak' and 'emulated' in rec['config']['launch']
 
 
+def test_bench_eight_ranks_emulated_prints_the_exchange(emu_lib):
+    """`python bench.py --gpus 8` - the world size the driver's scaling run ends at - on the emulated kernels + gloo at a tiny size:
+    rank / port / JSON plumbing of eight processes, the segmented step with its five collectives per iteration, and the
+    per-collective record (`exchange`: bytes and issue -> complete time of every all-reduce) in the one line rank 0 prints."""
+    env = dict(os.environ)
+    for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT'):
+        env.pop(k, None)
+    env.update(FSV2V_EMU='1', OMP_NUM_THREADS='1')
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '8', '--steps', '1', '--warmup', '1',
+                        '--size', '64', '--batch', '1', '--ngf', '4'], capture_output=True, text=True, env=env, timeout=1500)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1, r.stdout[-2000:]
+    rec = json.loads(lines[0])
+    assert rec['n_gpus'] == 8 and rec['config']['global_batch'] == 8 and rec['config']['parallelism'] == 'dp8'
+    assert 'segments' in rec['config']['launch'], rec['config']['launch']
+    ex = {e['name']: e for e in rec['exchange']}
+    # the discriminator's range, the generator's decoder-stage range (side stream, next to backward piece 2) and the rest
+    assert set(ex) == {'D', 'G decoder stage', 'G rest'}, ex
+    assert all(e['n'] == 1 and e['bytes'] > 0 and e['ms'] > 0 for e in ex.values()), ex
+    n_g = ex['G decoder stage']['bytes'] + ex['G rest']['bytes']
+    assert n_g % 4 == 0 and n_g > ex['D']['bytes']
+
+
 def _bench_one_rank(extra_env, *extra_args):
     env = dict(os.environ)
     for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT'):
@@ -125,5 +149,6 @@ def test_oracle_worker_round_trip(tmp_path, monkeypatch):
     mc._ORACLE_CACHE.clear()
     names = {n for n, f in inspect.getmembers(tf, inspect.isfunction) if n.startswith('test_')}
     assert set(tf.ORACLE_SPECS) <= names, set(tf.ORACLE_SPECS) - names
-    uses = {n for n in names if 'check_train_step' in inspect.getsource(getattr(tf, n)) or 'check_amp_train_step' in inspect.getsource(getattr(tf, n))}
+    # (check_train_step_golden compares with a committed reference fixture: no oracle pair)
+    uses = {n for n in names if 'check_train_step(' in inspect.getsource(getattr(tf, n)) or 'check_amp_train_step(' in inspect.getsource(getattr(tf, n))}
     assert uses == set(tf.ORACLE_SPECS), uses ^ set(tf.ORACLE_SPECS)

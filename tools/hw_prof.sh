@@ -28,6 +28,7 @@ find "$RAW" -type f | head -50 > "$OUT/raw_files.txt"; du -sh "$RAW"/* >> "$OUT/
 for f in $(find "$RAW/prof" -name "*stats*.csv"); do cp "$f" "$OUT/"; done
 head -3 "$(find "$RAW/prof" -name "*kernel_trace.csv" | head -1)" > "$OUT/kernel_trace_head.csv"
 python tools/trace_by_grid.py "$(find "$RAW/prof" -name "*kernel_trace.csv" | head -1)" --steps 13 --out "$OUT/trace_by_grid.jsonl" > "$OUT/trace_by_grid.log" 2>&1
+python tools/step_sequence.py "$(find "$RAW/prof" -name "*kernel_trace.csv" | head -1)" --out "$OUT/step_sequence.txt" > "$OUT/step_sequence.log" 2>&1
 python tools/pmc_traffic.py "$RAW/pmc_fetch" "$RAW/pmc_write" "$OUT/pmc_hbm_traffic.json" ${PMC_META:-} > "$OUT/pmc_summary.log" 2>&1
 du -sh "$OUT" >> "$OUT/summary.txt"
 cat "$OUT/summary.txt"
