@@ -804,6 +804,34 @@ __global__ __launch_bounds__(256) void fsv_split_finish_kernel(const float* part
   }
 }
 
+// the same, four consecutive channels per work-item (C % 4 == 0, 16-byte aligned tensors): round 6 - the scalar form walks eight
+// elements per work-item one dependent round trip after the other (16 - 21 us for 0.5 M outputs x 8 splits: 0.9 TB/s); here every
+// work-item has its nsplit 16-byte loads in flight at once and the launch is one pass (the same sums in the same order)
+__global__ __launch_bounds__(256) void fsv_split_finish4_kernel(const float4* part, long long part_stride4, int nsplit, float4* out,
+                                                                const float* bias, const float4* res, long long total4, int C,
+                                                                long long pix_per_sample, long long b_bstride, int act, float scale) {
+  long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  const long long stride = (long long)gridDim.x * 256;
+  for (; i < total4; i += stride) {
+    float4 v = part[i];
+#pragma unroll 4
+    for (int k = 1; k < nsplit; ++k) {
+      const float4 t = part[(long long)k * part_stride4 + i];
+      v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+    }
+    if (bias) {
+      const long long e = i * 4;
+      const int c = (int)(e % C);
+      const long long n = b_bstride ? (e / C) / pix_per_sample : 0;
+      const float* b = bias + n * b_bstride + c;
+      v.x += b[0]; v.y += b[1]; v.z += b[2]; v.w += b[3];
+    }
+    v.x = fsv_act(v.x * scale, act); v.y = fsv_act(v.y * scale, act); v.z = fsv_act(v.z * scale, act); v.w = fsv_act(v.w * scale, act);
+    if (res) { const float4 r = res[i]; v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w; }
+    out[i] = v;
+  }
+}
+
 // ---- weight gradient: dwt[z][t*Cin+ci][co] (+)= sum_pixels in[n, oy*sy+ty, ox*sx+tx, ci] * dout[n,oy,ox,co] ----
 // All workgroups of one pixel range (blockIdx.z) read the same x pixels (shifted by their taps) and the same dout rows:
 // they are mapped onto ONE XCD so that x and dout are fetched from HBM once per range instead of once per L2
@@ -1256,7 +1284,10 @@ __global__ __launch_bounds__(64 * WM * WN) void fsv_conv_wgrad_v1_kernel(WgradP 
 // order, but not the ascending-k chain of the MFMA path: these heads feed tanh / sigmoid / a scale, no LeakyReLU kink).
 // Host: Cin / 4 a power of two <= 64, K <= FSV_THIN_MAXK.
 #define FSV_THIN_MAXK 1152
-template <int CO>
+// T9 (round 6; the three heads of the step are 3x3): the lane's 9 x 4 x CO weights live in REGISTERS for the whole launch (they
+// depend on the lane's channel quad only - the loop used to re-read them from LDS for every pixel: 12 ds_reads per 12 fmas) and
+// the nine tap loads of a pixel are issued together; the fma chain of every output is the one of the generic loop (bit-equal).
+template <int CO, bool T9 = false>
 __global__ __launch_bounds__(256) void fsv_conv_thin_fwd_kernel(ConvP p, int iters) {
   __shared__ float wl[FSV_THIN_MAXK * CO];        // [k][co]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1272,6 +1303,18 @@ __global__ __launch_bounds__(256) void fsv_conv_thin_fwd_kernel(ConvP p, int ite
   const fsv_buf abuf = fsv_make_buf(p.in, (long long)p.N * p.H * p.W * p.Cin * 4);
   const float ws = p.wscale ? p.wscale[0] : 1.f;
   const int m_base = blockIdx.x * (4 * PPW * iters);
+  float wr[T9 ? 9 : 1][4][CO];
+  int tyr[T9 ? 9 : 1], txr[T9 ? 9 : 1];
+  if constexpr (T9) {
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      fsv_tap(p, t, tyr[t], txr[t]);
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int c = 0; c < CO; ++c) wr[t][e][c] = wl[(t * p.Cin + cq * 4 + e) * CO + c];
+    }
+  }
 #pragma unroll 1
   for (int it = 0; it < iters; ++it) {
     const int m = m_base + (it * 4 + wave) * PPW + pl;
@@ -1282,6 +1325,25 @@ __global__ __launch_bounds__(256) void fsv_conv_thin_fwd_kernel(ConvP p, int ite
     float acc[CO];
 #pragma unroll
     for (int c = 0; c < CO; ++c) acc[c] = 0.f;
+    if constexpr (T9) {
+      float4 v9[9];
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        const int iy = oy * p.sy + tyr[t], ix = ox * p.sx + txr[t];
+        const bool ok = live & ((unsigned)iy < (unsigned)p.H) & ((unsigned)ix < (unsigned)p.W);
+        v9[t] = fsv_buf_load4(abuf, ok ? (unsigned)((((n * p.H + iy) * p.W + ix) * p.Cin + cq * 4) * 4) : FSV_BUF_OOB);
+      }
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+#pragma unroll
+        for (int c = 0; c < CO; ++c) {
+          acc[c] = fmaf(v9[t].x, wr[t][0][c], acc[c]);
+          acc[c] = fmaf(v9[t].y, wr[t][1][c], acc[c]);
+          acc[c] = fmaf(v9[t].z, wr[t][2][c], acc[c]);
+          acc[c] = fmaf(v9[t].w, wr[t][3][c], acc[c]);
+        }
+      }
+    } else
 #pragma unroll 3
     for (int t = 0; t < p.ntaps; ++t) {
       int ty, tx;
@@ -1352,7 +1414,9 @@ __global__ __launch_bounds__(256) void fsv_conv_thin_wgrad_kernel(WgradP p, int 
 #pragma unroll
     for (int c = 0; c < CO; ++c) acc[e][c] = 0.f;
   if (lane_on) {
-#pragma unroll 2
+    // (round 6: four pixels of loads in flight per work-item instead of two - the loop is one 16-byte load + CO 4-byte loads per
+    // pixel and latency-bound; the per-(k, co) sums keep their order)
+#pragma unroll 4
     for (int m = m0 + g; m < m1; m += NG) {
       const int n = m / ohw, rem = m - n * ohw;
       const int oy = rem / p.OW, ox = rem - oy * p.OW;
@@ -1887,11 +1951,17 @@ static int fsv_conv_gather_impl(const float* in, const float* wt, const float* b
     int iters = 16;
     while (iters > 1 && fsv_cdiv(p.Mz, ppb * iters) < 1024) iters >>= 1;
     const dim3 g(fsv_cdiv(p.Mz, ppb * iters));
+    const char* t9e = getenv("FSV_THIN_T9");             // =0: the generic tap loop (A/B)
+    const bool t9 = p.ntaps == 9 && !(t9e && t9e[0] == '0');
     switch (Cout) {
-      case 1: FSV_LAUNCH((fsv_conv_thin_fwd_kernel<1>), g, dim3(256), stream, p, iters); break;
-      case 2: FSV_LAUNCH((fsv_conv_thin_fwd_kernel<2>), g, dim3(256), stream, p, iters); break;
-      case 3: FSV_LAUNCH((fsv_conv_thin_fwd_kernel<3>), g, dim3(256), stream, p, iters); break;
-      default: FSV_LAUNCH((fsv_conv_thin_fwd_kernel<4>), g, dim3(256), stream, p, iters); break;
+      case 1: if (t9) FSV_LAUNCH((fsv_conv_thin_fwd_kernel<1, true>), g, dim3(256), stream, p, iters);
+              else FSV_LAUNCH((fsv_conv_thin_fwd_kernel<1>), g, dim3(256), stream, p, iters); break;
+      case 2: if (t9) FSV_LAUNCH((fsv_conv_thin_fwd_kernel<2, true>), g, dim3(256), stream, p, iters);
+              else FSV_LAUNCH((fsv_conv_thin_fwd_kernel<2>), g, dim3(256), stream, p, iters); break;
+      case 3: if (t9) FSV_LAUNCH((fsv_conv_thin_fwd_kernel<3, true>), g, dim3(256), stream, p, iters);
+              else FSV_LAUNCH((fsv_conv_thin_fwd_kernel<3>), g, dim3(256), stream, p, iters); break;
+      default: if (t9) FSV_LAUNCH((fsv_conv_thin_fwd_kernel<4, true>), g, dim3(256), stream, p, iters);
+               else FSV_LAUNCH((fsv_conv_thin_fwd_kernel<4>), g, dim3(256), stream, p, iters); break;
     }
     return fsv_check_launch();
   }
@@ -1933,7 +2003,15 @@ static int fsv_conv_gather_impl(const float* in, const float* wt, const float* b
     int grid = (int)((total + 256 * 8 - 1) / (256 * 8));
     if (grid > 4096) grid = 4096;
     if (grid < 1) grid = 1;
-    if (p.part)
+    const char* f4e = getenv("FSV_SPLIT_FIN4");          // =0: the scalar finishing pass (A/B, bit-equality test)
+    const bool fin4 = !(f4e && f4e[0] == '0') && p.part && (Cout % 4 == 0) && (total % 4 == 0) &&
+                      (((unsigned long long)p.part | (unsigned long long)out | (unsigned long long)res) & 15ull) == 0;
+    if (fin4) {
+      int g4 = (int)((total / 4 + 255) / 256);
+      if (g4 > 8192) g4 = 8192;
+      FSV_LAUNCH(fsv_split_finish4_kernel, dim3(g4), dim3(256), stream, (const float4*)p.part, p.part_stride / 4, nsplit, (float4*)out,
+                 bias, (const float4*)res, total / 4, Cout, (long long)outH * outW, per_sample ? b_bstride : 0ll, act, scale);
+    } else if (p.part)
       FSV_LAUNCH(fsv_split_finish_kernel, dim3(grid), dim3(256), stream, (const float*)p.part, p.part_stride, nsplit, out, bias, res,
                  total, Cout, (long long)outH * outW, per_sample ? b_bstride : 0ll, act, scale);
     else

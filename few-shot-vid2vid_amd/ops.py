@@ -428,7 +428,11 @@ class _ConvFn(torch.autograd.Function):
                 y = _spade_conv_s_launch(site, wh, kpad_h, cout, wscale, want_hs=any(ctx.needs_input_grad))
             else:
                 y = _spade_conv_s_launch(site, wt, ldw, cout, wscale, want_hs=any(ctx.needs_input_grad))
-        if y is None and fold and _up_subpixel_wanted(x.shape[0], x.shape[2], x.shape[3], cin, cout, geom, per_sample, res):
+        # (a layer whose output feeds a BatchNorm - the flow decoder's three - loses the statistics epilogue on the placed class
+        # launches and reduces in a pass of its own: FSV_UP_SUBPIXEL_STATS=0 keeps such layers on the single gather + fused
+        # statistics instead; in-box A/B of round 6: profiles/r06_notes.md)
+        if (y is None and fold and _up_subpixel_wanted(x.shape[0], x.shape[2], x.shape[3], cin, cout, geom, per_sample, res) and
+                (not st_wanted or _os.environ.get('FSV_UP_SUBPIXEL_STATS', '1') == '1')):
             y = _up_subpixel_forward(x, w4, cout, b, act, scale, inv, cached=entry.up_fwd if entry is not None else None)
         if y is None:
             y = conv_forward(x, wt, ldw, cout, geom, bias=b, res=res.detach() if res is not None else None, act=act,

@@ -996,6 +996,20 @@ def check_ordered_split(device, seed=93):
     finally:
         os.environ.pop('FSV_ORDERED_SPLIT', None)
     assert_close('atomic split', atomic, ref, 1e-5)
+    # round 6: the finishing pass handles four channels per work-item where Cout % 4 == 0 - the same sums in the same order as the
+    # scalar pass (bit for bit); Cout % 4 != 0 stays on the scalar pass
+    os.environ['FSV_SPLIT_FIN4'] = '0'
+    try:
+        scalar = run(4)
+    finally:
+        os.environ.pop('FSV_SPLIT_FIN4', None)
+    assert bool((scalar == outs[0]).all()), 'vectorised finishing pass changed the bits'
+    cout2 = 94
+    wt2 = _dev(torch.randn(cout2, cin, 3, 3, generator=g) * 0.05, device)
+    b2 = _dev(torch.randn(cout2, generator=g), device)
+    wf2, _, ldw2 = conv.prep_weight(wt2, 0, geo)
+    y2 = conv.conv_forward(x, wf2, ldw2, cout2, geo, bias=b2, act=conv.ACT_LRELU, force_split=3)
+    assert_close('ordered split, Cout % 4 != 0, LeakyReLU', y2, O.actvn(F.conv2d(x.cpu(), wt2.cpu(), b2.cpu(), padding=1)), 1e-5)
 
 
 def check_adaptive_avgpool(device, seed=92):
@@ -1439,6 +1453,7 @@ def check_thin_conv(device, seed=88):
 
 
 def _check_thin_conv(device, ops, conv, g):
+    import os
     cases = [(2, 32, 17, 19, 3, 3, 1, 1, conv.ACT_TANH, 1.0), (1, 32, 9, 33, 2, 3, 1, 1, conv.ACT_NONE, 20.0),
              (2, 16, 12, 10, 1, 3, 1, 1, conv.ACT_SIGMOID, 1.0), (1, 8, 7, 9, 4, 1, 1, 0, conv.ACT_LRELU, 1.0),
              (1, 64, 10, 12, 3, 3, 2, 1, conv.ACT_NONE, 1.0), (2, 12, 6, 5, 2, 4, 2, 2, conv.ACT_NONE, 1.0)]
@@ -1465,4 +1480,13 @@ def _check_thin_conv(device, ops, conv, g):
         thin = conv.conv_forward(xn, wf, ldw, cout, ge, bias=_dev(b, device))
         mfma = conv.conv_forward(xn, wf, ldw, cout, ge, bias=_dev(b, device), force_tile=4, force_split=1)
         assert_close(name + ': vector-ALU kernel vs the gather-GEMM kernel (summation order)', thin, mfma, tol=2e-6)
+        if k == 3:
+            # round 6: the 3x3 form keeps the lane's weights in registers and issues its nine tap loads together - the same fma
+            # chain per output as the generic tap loop, bit for bit
+            os.environ['FSV_THIN_T9'] = '0'
+            try:
+                generic = conv.conv_forward(xn, wf, ldw, cout, ge, bias=_dev(b, device))
+            finally:
+                os.environ.pop('FSV_THIN_T9', None)
+            assert bool((thin == generic).all()), name + ': register-resident 3x3 form changed the bits'
 
