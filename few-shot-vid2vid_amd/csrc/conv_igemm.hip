@@ -1537,11 +1537,12 @@ __device__ __forceinline__ void fsv_prep_stage(const PrepGroup& g, const int lay
   const int co0 = cot * 32, ci0 = cit * CI_T;
   const int tid = threadIdx.x;
   const int total = 32 * run;
-  for (int e0 = tid; e0 < total; e0 += 1024) {
-    float val[4];
-    int dst[4];
+  constexpr int U = 8;          // loads in flight per work-item (4 until round 6: 2.3 TB/s on a pure stream)
+  for (int e0 = tid; e0 < total; e0 += 256 * U) {
+    float val[U];
+    int dst[U];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < U; ++u) {
       const int e = e0 + 256 * u;
       const int col = e / run, idx = e - col * run;
       const int co = co0 + col, ci = ci0 + idx / KK;
@@ -1550,7 +1551,7 @@ __device__ __forceinline__ void fsv_prep_stage(const PrepGroup& g, const int lay
       dst[u] = (e < total) ? col * lds + idx : -1;
     }
 #pragma unroll
-    for (int u = 0; u < 4; ++u)
+    for (int u = 0; u < U; ++u)
       if (dst[u] >= 0) t[dst[u]] = val[u];
   }
 }
@@ -1951,8 +1952,10 @@ static int fsv_conv_gather_impl(const float* in, const float* wt, const float* b
     int iters = 16;
     while (iters > 1 && fsv_cdiv(p.Mz, ppb * iters) < 1024) iters >>= 1;
     const dim3 g(fsv_cdiv(p.Mz, ppb * iters));
-    const char* t9e = getenv("FSV_THIN_T9");             // =0: the generic tap loop (A/B)
-    const bool t9 = p.ntaps == 9 && !(t9e && t9e[0] == '0');
+    // measured neutral on the step (profiles/r06_step_ab_kernel_tweaks.txt: 42.81 ms with, 42.74 without - the heads are bound by
+    // their L2 gathers, not by the LDS weight reads): opt-in, FSV_THIN_T9=1
+    const char* t9e = getenv("FSV_THIN_T9");
+    const bool t9 = p.ntaps == 9 && t9e && t9e[0] == '1';
     switch (Cout) {
       case 1: if (t9) FSV_LAUNCH((fsv_conv_thin_fwd_kernel<1, true>), g, dim3(256), stream, p, iters);
               else FSV_LAUNCH((fsv_conv_thin_fwd_kernel<1>), g, dim3(256), stream, p, iters); break;

@@ -1481,12 +1481,12 @@ def _check_thin_conv(device, ops, conv, g):
         mfma = conv.conv_forward(xn, wf, ldw, cout, ge, bias=_dev(b, device), force_tile=4, force_split=1)
         assert_close(name + ': vector-ALU kernel vs the gather-GEMM kernel (summation order)', thin, mfma, tol=2e-6)
         if k == 3:
-            # round 6: the 3x3 form keeps the lane's weights in registers and issues its nine tap loads together - the same fma
-            # chain per output as the generic tap loop, bit for bit
-            os.environ['FSV_THIN_T9'] = '0'
+            # round 6 (opt-in, measured neutral): the 3x3 form keeps the lane's weights in registers and issues its nine tap loads
+            # together - the same fma chain per output as the generic tap loop, bit for bit
+            os.environ['FSV_THIN_T9'] = '1'
             try:
-                generic = conv.conv_forward(xn, wf, ldw, cout, ge, bias=_dev(b, device))
+                t9 = conv.conv_forward(xn, wf, ldw, cout, ge, bias=_dev(b, device))
             finally:
                 os.environ.pop('FSV_THIN_T9', None)
-            assert bool((thin == generic).all()), name + ': register-resident 3x3 form changed the bits'
+            assert bool((thin == t9).all()), name + ': register-resident 3x3 form changed the bits'
 
