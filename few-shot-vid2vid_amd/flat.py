@@ -44,6 +44,7 @@ class FlatAdam:
         # two-piece backward (set by Vid2VidModel.build_optimizers(split_backward=True): stage-2 parameters are laid out first)
         self.split_at = 0
         self.split_at2 = 0           # three-piece backward: flat_g[split_at:split_at2] is complete after the second piece
+        self._side_events = {}       # label -> event behind that side-stream collective (wait_exchange_of)
         self._lay_out(params, lr, loss_scale)
 
     def rebuild(self, params, lr=None, loss_scale='keep'):
@@ -324,9 +325,39 @@ class FlatAdam:
             self.side_stream.wait_stream(torch.cuda.current_stream(self.device))
             with torch.cuda.stream(self.side_stream):
                 self._all_reduce(view, label, side=True)
+                # (the side stream runs its collectives in order: an event behind each lets a consumer wait for ONE range)
+                ev = torch.cuda.Event()
+                ev.record(self.side_stream)
+            self._side_events[label] = ev
             self._side_pending = True
         else:
             self._all_reduce(view, label)
+
+    def wait_exchange_of(self, label):
+        """the current stream waits for the side-stream collective issued under `label` (not for the ones queued behind it)"""
+        ev = self._side_events.pop(label, None)
+        if ev is not None:
+            torch.cuda.current_stream(self.device).wait_event(ev)
+
+    def split_adam_ready(self):
+        """the optimiser step of a segmented iteration in two launches (adam_part): needs the two-piece layout, plain fp32 (the
+        `--amp` overflow test spans all gradients) and the layout cache (refresh_split)"""
+        return (0 < self.split_at < self.total and self.scaler is None and self.layouts is not None and self._early is None and
+                os.environ.get('FSV_SEG_SPLIT_ADAM', '1') == '1')
+
+    def adam_part(self, part):
+        """Round 6 (N > 1): Adam + layout refresh of flat[:split_at] (part 0: the decoder stage, whose gradients were exchanged next
+        to the second backward piece) issued while the LAST range of the exchange is still in flight on the side stream, then part 1
+        for the rest.  One optimiser step: the state ticks once (with part 0), every parameter sees the arithmetic of adam() -
+        bit-identical weights (tests/test_ddp_gloo.py)."""
+        s = self.split_at
+        sl = slice(0, s) if part == 0 else slice(s, self.total)
+        ops.adam_step(self.flat_p[sl], self.flat_g[sl], self.m[sl], self.v[sl], self.state, self.betas[0], self.betas[1], self.eps,
+                      1.0 / self.world_size, tick=(part == 0))
+        base = self.flat_p.data_ptr()
+        self.layouts.refresh_split(part, base, base + 4 * s)
+        if part == 1:
+            self._steps_done += 1
 
     def wait_exchange(self):
         if getattr(self, '_side_pending', False):

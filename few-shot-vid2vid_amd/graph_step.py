@@ -174,6 +174,14 @@ class GraphedIteration:
     def _seg_a(self):
         self.opt_G.adam()
 
+    # round 6: the generator's optimiser step in two segments - the decoder-stage range (its exchange completed next to the second
+    # backward piece) steps while the last range of the exchange is still in flight (FlatAdam.adam_part)
+    def _seg_a1(self):
+        self.opt_G.adam_part(0)
+
+    def _seg_a2(self):
+        self.opt_G.adam_part(1)
+
     # ---- the collectives between the segments (host side; never captured) -------------------------------------------------
     def _exchange_d(self):
         # the discriminator's 11 MB on the optimiser's side stream: it runs next to the segment that follows (_seg_gf)
@@ -196,6 +204,14 @@ class GraphedIteration:
         self.opt_G.exchange_range(self.opt_G.split_at2 if self.pieces == 3 else self.opt_G.split_at, self.opt_G.total, label='G rest')
         self.opt_G.wait_exchange()
 
+    def _exchange_g_rest_side(self):
+        # the last range on the side stream (behind the decoder-stage range); the caller's stream only waits for the decoder range
+        self.opt_G.exchange_range(self.opt_G.split_at, self.opt_G.total, side=True, label='G rest')
+        self.opt_G.wait_exchange_of('G decoder stage')
+
+    def _wait_g(self):
+        self.opt_G.wait_exchange()
+
     def _exchange_g_all(self):
         self.opt_G.exchange_all('G')
 
@@ -206,8 +222,9 @@ class GraphedIteration:
             D fwd + bwd             | all-reduce(D) -> side stream
             G forward (train.py:61) |                   ... runs next to it | wait
             Adam(D), D pass, losses, backward piece 1 | all-reduce(G decoder range) -> side stream
-            backward piece 2        |                   ... runs next to it | all-reduce(G rest), wait      <- the one on the critical path
-            Adam(G)
+            backward piece 2        |                   ... runs next to it | all-reduce(G rest) -> side stream; wait for the decoder range
+            Adam + layouts, decoder range |                ... runs next to it | wait                    <- what is left of it is exposed
+            Adam + layouts, the rest                                            (round 6; FSV_SEG_SPLIT_ADAM=0: one Adam segment behind the wait)
         """
         seg = self.segmented
         steps = []
@@ -221,6 +238,14 @@ class GraphedIteration:
             if self.pieces == 3:
                 steps.append((self._seg_g2, self._exchange_g_middle))
                 steps.append((self._seg_g3, self._exchange_g_rest))
+            elif self._split_adam():
+                # backward piece 2 | all-reduce(G rest) -> side stream, wait for the decoder range only
+                # Adam + layouts of the decoder range ... next to it | wait
+                # Adam + layouts of the rest
+                steps.append((self._seg_g2, self._exchange_g_rest_side))
+                steps.append((self._seg_a1, self._wait_g))
+                steps.append((self._seg_a2, None))
+                return steps
             else:
                 steps.append((self._seg_g2, self._exchange_g_rest))
         else:
@@ -228,8 +253,12 @@ class GraphedIteration:
         steps.append((self._seg_a, None))
         return steps
 
+    def _split_adam(self):
+        return self.segmented and self.split and self.pieces == 2 and self.opt_G.split_adam_ready()
+
     def n_segments(self):
-        return (3 + (self.pieces - 1 if self.split else 0) + (1 if (self.segmented and self.seg_early) else 0))
+        return (3 + (self.pieces - 1 if self.split else 0) + (1 if (self.segmented and self.seg_early) else 0) +
+                (1 if self._split_adam() else 0))
 
     def _eager(self, e, save_images):
         for body, after in self._steps(e, save_images):

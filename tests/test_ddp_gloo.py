@@ -88,13 +88,14 @@ def test_two_rank_whole_buffer_exchange(emu_lib, tmp_path):
     assert float((r0['gD'] - local).abs().max()) <= 1e-5 * scale
 
 
-def _split_worker(rank, world, port, out_dir, split, serial=False):
+def _split_worker(rank, world, port, out_dir, split, serial=False, split_adam=False):
     """the N > 1 bench path: GraphedIteration over hook-free optimisers; split=True adds the two-piece generator backward
     with the decoder-stage range exchanged on its own (on a GPU: on a side stream next to the second piece)"""
     os.environ['FSV2V_EMU'] = '1'
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(port)
     os.environ['FSV_SEG_EARLY_G'] = '0' if serial else '1'        # serial: round 4's order (D exchange in front of the generator pass)
+    os.environ['FSV_SEG_SPLIT_ADAM'] = '1' if split_adam else '0'  # round 6: Adam of the decoder range next to the last exchange range
     sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
     torch.set_num_threads(1)
     import model_checks as mc
@@ -110,7 +111,8 @@ def _split_worker(rank, world, port, out_dir, split, serial=False):
     opt_G, opt_D = model.build_optimizers(world_size=world, overlap=False, split_backward=split)
     gi = gs.GraphedIteration(model, opt, warmup=1)
     assert gi.segmented and gi.split == bool(split) and gi.pieces == (3 if split == 3 else (2 if split else 1))
-    assert gi.seg_early == (not serial) and gi.n_segments() == 3 + (gi.pieces - 1 if split else 0) + (0 if serial else 1)
+    assert gi.seg_early == (not serial) and gi.n_segments() == (3 + (gi.pieces - 1 if split else 0) + (0 if serial else 1) +
+                                                               (1 if (split_adam and split is True) else 0))
     tl, ti, rl, ri = mc.synth_pose_inputs(1, 32, 32, 200 + rank, 6)
     data = [tl, ti, [None, None], [None, None], rl, ri, None, None, None]
     for it in range(2):
@@ -121,7 +123,7 @@ def _split_worker(rank, world, port, out_dir, split, serial=False):
                     gD={n: p.grad.clone() for n, p in model.netD.named_parameters() if p.grad is not None},
                     launch=gi.launch_mode(), split_at=opt_G.split_at,
                     total=opt_G.total, split_at2=opt_G.split_at2),
-               os.path.join(out_dir, 'split%d%s_rank%d.pt' % (int(split), '_serial' if serial else '', rank)))
+               os.path.join(out_dir, 'split%d%s%s_rank%d.pt' % (int(split), '_serial' if serial else '', '_adam2' if split_adam else '', rank)))
     dist.destroy_process_group()
 
 
@@ -136,6 +138,23 @@ def test_two_rank_generator_pass_next_to_the_discriminator_exchange_is_the_seria
     b0 = torch.load(os.path.join(tmp_path, 'split1_rank0.pt'))
     b1 = torch.load(os.path.join(tmp_path, 'split1_rank1.pt'))
     assert '5 eager segments' in b0['launch'] and '4 eager segments' in a0['launch'], (a0['launch'], b0['launch'])
+    for key in ('g', 'p', 'pD', 'gD'):
+        for n in a0[key]:
+            assert torch.equal(a0[key][n], b0[key][n]), (key, n)
+            assert torch.equal(b0[key][n], b1[key][n]), (key, n)                  # replicas in lock-step
+
+
+def test_two_rank_split_optimiser_step_next_to_the_last_exchange_is_the_one_piece_step(emu_lib, tmp_path):
+    """round 6: the generator's Adam + layout refresh as two segments - the decoder-stage range steps while the last range of the
+    gradient exchange is in flight, the rest behind it (graph_step.GraphedIteration._steps, FlatAdam.adam_part) - two ranks, two
+    iterations with real Adam steps: gradients and weights of G and D bit for bit those of the single Adam segment"""
+    world = 2
+    mp.spawn(_split_worker, args=(world, 29671, str(tmp_path), True, False, False), nprocs=world, join=True)
+    mp.spawn(_split_worker, args=(world, 29673, str(tmp_path), True, False, True), nprocs=world, join=True)
+    a0 = torch.load(os.path.join(tmp_path, 'split1_rank0.pt'))
+    b0 = torch.load(os.path.join(tmp_path, 'split1_adam2_rank0.pt'))
+    b1 = torch.load(os.path.join(tmp_path, 'split1_adam2_rank1.pt'))
+    assert '5 eager segments' in a0['launch'] and '6 eager segments' in b0['launch'], (a0['launch'], b0['launch'])
     for key in ('g', 'p', 'pD', 'gD'):
         for n in a0[key]:
             assert torch.equal(a0[key][n], b0[key][n]), (key, n)
