@@ -27,7 +27,7 @@ def test_one_rank_rccl_runs_the_segmented_bench_path(hip_lib):
     assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])
     line = [l for l in r.stdout.splitlines() if l.startswith('{')][-1]
     res = json.loads(line)
-    assert res['value'] > 0 and 'hipgraph x5' in res['config']['launch'] and 'next to the generator-mode forward pass' in res['config']['launch'], res['config']
+    assert res['value'] > 0 and 'hipgraph x6' in res['config']['launch'] and 'next to the generator-mode forward pass' in res['config']['launch'], res['config']
     # and the same step without the process group gives the same throughput class (sanity, not a benchmark)
     assert res['n_gpus'] == 1
 
@@ -74,7 +74,7 @@ def _one_rank(rank, port, out_dir, mode):
 
 def test_one_rank_rccl_schedule_reproduces_the_single_graph_weights(hip_lib, tmp_path):
     """round-4 review: the one-rank run asserted `value > 0`.  Now: four iterations with real Adam steps (fixed-order mode, so that
-    a run is bit-reproducible) through (a) one hipGraph without a process group, (b) the N > 1 schedule - five segments, the
+    a run is bit-reproducible) through (a) one hipGraph without a process group, (b) the N > 1 schedule - six segments, the
     discriminator range exchanged on a side stream next to the generator-mode forward pass, the decoder-stage range next to
     the second backward piece - in a one-rank RCCL group: all weights of G and D equal bit for bit.  (Round 4's serial order against
     this one, and the sum over ranks that a one-rank group cannot show: two gloo ranks, tests/test_ddp_gloo.py.)"""
@@ -83,7 +83,7 @@ def test_one_rank_rccl_schedule_reproduces_the_single_graph_weights(hip_lib, tmp
         mp.spawn(_one_rank, args=(29651 + 2 * k, str(tmp_path), mode), nprocs=1, join=True)
     a = torch.load(os.path.join(tmp_path, 'one_rank_plain.pt'))
     b = torch.load(os.path.join(tmp_path, 'one_rank_rccl.pt'))
-    assert a['launch'] == 'hipgraph' and 'hipgraph x5' in b['launch'], (a['launch'], b['launch'])
+    assert a['launch'] == 'hipgraph' and 'hipgraph x6' in b['launch'], (a['launch'], b['launch'])
     for net in ('G', 'D'):
         for n in a[net]:
             assert torch.equal(a[net][n], b[net][n]), 'one-rank RCCL schedule: %s.%s differs from the single-graph run' % (net, n)
