@@ -254,6 +254,11 @@ class SPADEResnetBlock(nn.Module):
         return self.conv_1(self.bn_1(dx, act=ACT_LRELU), res=x_s, stats=hint if feeds_norm else 0)
 
 
+def _decode_early():
+    import os
+    return streams.ENABLED and os.environ.get('FSV_DECODE_EARLY', '1') == '1'
+
+
 def spectral_layers(module):
     """every spectral-normalised Conv2d / Linear below `module`, each once, in registration order"""
     seen, out = set(), []
@@ -576,6 +581,8 @@ class FewShotGenerator(nn.Module):
 
     def reference_encoding(self, img_ref, label_ref, encode=True, label=None):
         n = self.n_downsample_G
+        # (the two encoders as parallel branches of the captured graph: +2 ... 3 ms in round 2, re-measured in round 6 on the final
+        # kernels: 42.32 / 42.65 -> 43.50 / 43.51 ms per step - profiles/r06_step_ab_schedule.txt; not kept)
         x = self.ref_img_first(img_ref)
         xl = self.ref_label_first(label_ref)
         atn = atn_vis = ref_idx = None
@@ -593,6 +600,10 @@ class FewShotGenerator(nn.Module):
         for i in reversed(range(n)):
             fi.append(getattr(self, 'ref_img_up_%d' % i)(fi[-1]))
             fl.append(getattr(self, 'ref_label_up_%d' % i)(fl[-1]))
+        return x, self._pooled(fi, fl)
+
+    @staticmethod
+    def _pooled(fi, fl):
         enc = []
         for a, l in zip(fi, fl):
             b, c, h, w = a.shape
@@ -603,7 +614,7 @@ class FewShotGenerator(nn.Module):
             wts = sm.reshape(b, c, h * w, 1, 1)
             prod = ops.batch_conv(a_rows, wts, allow_half=False)                                    # logical [b, c(j), c(i), 1]
             enc.append(prod.permute(0, 2, 1, 3))                                  # [b, c(i), c(j), 1]
-        return x, enc[::-1]
+        return enc[::-1]
 
     def weight_generation(self, img_ref, label_ref, label, t=0, label_maps_elsewhere=False):
         """returns (x, label maps, SPADE weights); with `label_maps_elsewhere` the middle entry is the generated embedding
@@ -680,9 +691,23 @@ class FewShotGenerator(nn.Module):
     def flow_branch(self, label, label_ref, img_ref, prev, with_label_maps=False):
         """everything of the forward pass that needs neither the reference encoders nor the generated weights: flow network,
         warp, the SPADE maps of the warped image and (with_label_maps) the weight-free part of the label embedding"""
+        maps = None
+        early = with_label_maps and _decode_early() and label.is_cuda
+        if early:
+            # round 6 (FSV_DECODE_EARLY=0: the old order): the label maps FIRST, with an event behind them - the other branch then
+            # decodes them right behind its weight generators instead of behind the join of both branches.  In the replayed graph the
+            # twelve small launches of decode_maps sat ~90 us apart behind that join in the generator-mode pass (a 0.7 ms hole in
+            # profiles/r06_step_sequence.txt; back to back in the no-grad pass and, here, on the branch's own queue); unprofiled the
+            # step gains 0.1 ms (profiles/r06_step_ab_schedule.txt) - most of that hole is the profiler's cross-queue cost
+            maps = self.label_embedding.encode_maps(label)
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(label.device))
+            self._maps_ready = (ev, maps)
         flow, mask, warp, ds = self.flow_generation(label, label_ref, img_ref, prev)
         emb = self.combine_embeddings(ds)
-        return flow, mask, warp, emb, (self.label_embedding.encode_maps(label) if with_label_maps else None)
+        if with_label_maps and not early:
+            maps = self.label_embedding.encode_maps(label)
+        return flow, mask, warp, emb, maps
 
     def stage2_parameters(self):
         """parameters below the BackwardCut boundary of forward(): decoder blocks, output conv"""
@@ -711,10 +736,24 @@ class FewShotGenerator(nn.Module):
             # The flow branch (flow network, warp, the SPADE maps of the warped image) depends on nothing the reference
             # encoders / weight generators produce: two parallel branches (streams.fork).  With attention (n_shot > 1) it
             # needs ref_idx first.
-            (x, embed_w, norm_w), (flow, mask, warp, emb, maps) = streams.fork(label, [
-                lambda: self.weight_generation(img_refs, label_refs, label, t=t, label_maps_elsewhere=True),
+            self._maps_ready = None
+
+            def generate_and_decode():
+                x, embed_w, norm_w = self.weight_generation(img_refs, label_refs, label, t=t, label_maps_elsewhere=True)
+                ready = self._maps_ready            # (set by the flow branch, which streams.fork issues first)
+                if ready is None:
+                    return x, embed_w, norm_w, None
+                ev, maps = ready
+                cur = torch.cuda.current_stream(label.device)
+                cur.wait_event(ev)
+                streams._record(maps, cur)
+                return x, embed_w, norm_w, self.label_embedding.decode_maps(maps, embed_w)
+            (x, embed_w, norm_w, enc_label), (flow, mask, warp, emb, maps) = streams.fork(label, [
+                generate_and_decode,
                 lambda: self.flow_branch(label, label_refs[:, 0], img_refs[:, 0], prev, with_label_maps=True)])
-            enc_label = self.label_embedding.decode_maps(maps, embed_w)
+            self._maps_ready = None
+            if enc_label is None:
+                enc_label = self.label_embedding.decode_maps(maps, embed_w)
             atn_vis, ref_idx = self._atn
         else:
             x, enc_label, norm_w = self.weight_generation(img_refs, label_refs, label, t=t)
