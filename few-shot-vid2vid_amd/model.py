@@ -47,8 +47,20 @@ def _memoised(tag, tensors, make):
         return make()
     key = (tag,) + tuple(_memo_key(t) for t in tensors)
     hit = _MEMO.get(key)
+    cross = streams.CROSS and tensors[0].is_cuda          # two passes of the iteration are being issued on different streams
     if hit is None:
-        hit = _MEMO[key] = (tensors, make())
+        val = make()
+        ev = stream = None
+        if cross:
+            stream = torch.cuda.current_stream(tensors[0].device)
+            ev = torch.cuda.Event()
+            ev.record(stream)
+        hit = _MEMO[key] = (tensors, val, ev, stream)
+    elif hit[2] is not None and cross:
+        cur = torch.cuda.current_stream(tensors[0].device)
+        if cur != hit[3]:                                   # made on the other pass's stream: order this stream behind it
+            cur.wait_event(hit[2])
+            streams._record(hit[1], cur)
     return hit[1]
 
 
@@ -764,6 +776,7 @@ class Vid2VidModel(nn.Module):
                 real_outs = rb() if rb is not None else None
         self._pre_g = None
         branch.finish(real_outs)
+        self._fold_bn_standins()             # (twin generator passes: the second pass's running-statistics update, in pass order)
         if self.optimizer_D is not None:
             self.optimizer_D._fsv_branch = None
         return (gen, real_outs) if ours else None
@@ -937,6 +950,8 @@ class Vid2VidModel(nn.Module):
     def forward_discriminator(self, tgt_label, tgt_image, ref_labels, ref_images, prevs, early=None):
         """vid2vid_model.py:106-128.  early: key of the data_list when the discriminator's part goes to a side stream and the
         generator-mode pass is issued here (see `early_generator`)."""
+        if early is not None and self._twin_ready(tgt_label, ref_labels, prevs):
+            return self._forward_discriminator_twin(tgt_label, tgt_image, ref_labels, ref_images, prevs, early)
         with torch.no_grad():
             (fake, raw, _, _, _), (fg, ref_fg), (ref_label, ref_image), _ = \
                 self.generate_images(tgt_label, tgt_image, ref_labels, ref_images, prevs, want_prevs=False)
@@ -966,6 +981,109 @@ class Vid2VidModel(nn.Module):
             losses[0]._fsv_branch = branch
             if self.optimizer_D is not None:
                 self.optimizer_D._fsv_branch = branch
+        return losses
+
+    # ---- the iteration's TWO generator passes next to each other (round 6) ------------------------------------------------------
+    # train.py:58 runs the generator without autograd (the discriminator step's fake image), train.py:61 runs it again with: same
+    # weights, same data - the passes differ in the spectral-norm iteration they see and in what they keep.  Nothing the second
+    # reads is produced by the first once (1) both power iterations are issued up front, in pass order (netG.begin_pass x 2), and
+    # (2) the second pass writes its BatchNorm running-statistics updates into zeroed stand-ins that are folded into the buffers
+    # behind the first pass's in-place updates (networks.BatchNorm._redirect: the same two products and one sum per element).
+    # With `early_generator` on, `mode='discriminator'` then issues the no-grad pass AND the whole discriminator step on a side
+    # stream and the generator-mode pass on the caller's stream right away (the pass with autograd has to be the one on the
+    # caller's stream: its backward runs where its forward ran, see `early_generator`).  Same kernels, same data, same
+    # per-network order of everything stateful: bit-identical to the sequential schedule (tests/test_graph_step_emu.py on the
+    # emulator's single queue; tests/graph_step_checks.py on hardware).  Only for passes that meet every BatchNorm / spectral layer
+    # once (no previous frames, no --add_raw_output_loss, one reference image, no face generator) and in exact fp32 (the half
+    # twins of the `--amp` path are made lazily on whichever stream asks first).  FSV_TWIN_G=0: the old order (A/B).
+    def _twin_ready(self, tgt_label, ref_labels, prevs):
+        # (FSV_TWIN_G=2: also on host tensors - the emulator's single queue runs the two passes in issue order, which exercises the
+        # spectral-norm queue and the stand-in fold of the schedule in the CPU test-suite)
+        sw = os.environ.get('FSV_TWIN_G', '1')
+        if sw not in ('1', '2') or not ((streams.ENABLED and tgt_label.is_cuda) or sw == '2'):
+            return False
+        G = self.netG
+        if (not self.isTrain or not G.training or any(p is not None for p in prevs) or G.add_raw_output_loss or
+                getattr(self.opt, 'n_shot', 1) != 1 or ref_labels.shape[1] != 1 or self.netGf is not None or self.refine_face or
+                conv.mfma_mode() != conv.MFMA_F32 or ops.bn_sync_world() > 1):
+            return False
+        return self._bn_standins(tgt_label.device) is not None
+
+    def _bn_standins(self, device):
+        mods = [m for m in self.netG.modules() if isinstance(m, networks.BatchNorm)]
+        st = getattr(self, '_bn_twin', None)
+        if st is None or st['n'] != len(mods) or st['flat'].device != device:
+            if device.type == 'cuda' and torch.cuda.is_current_stream_capturing():
+                return None                  # (built by the eager iterations in front of a capture)
+            total = sum(2 * m.running_mean.numel() for m in mods)
+            flat = torch.zeros(total, dtype=torch.float32, device=device)
+            table, off = {}, 0
+            for m in mods:
+                c = m.running_mean.numel()
+                table[id(m)] = [flat[off:off + c], flat[off + c:off + 2 * c], False]
+                off += 2 * c
+            st = self._bn_twin = dict(n=len(mods), flat=flat, table=table, mods=mods, pending=False)
+        return st
+
+    def _fold_bn_standins(self):
+        """running = (1 - m) running + stand-in for every BatchNorm site of the generator: the second pass's update, applied behind
+        the first's (on the caller's stream, after the side stream has been joined)"""
+        st = getattr(self, '_bn_twin', None)
+        if st is None or not st['pending']:
+            return
+        st['pending'] = False
+        import numpy as np
+        keep = float(np.float32(1.0) - np.float32(networks.BatchNorm.MOMENTUM))        # the kernel's (1.f - momentum)
+        real, stand = [], []
+        for m in st['mods']:
+            a, b, _ = st['table'][id(m)]
+            real += [m.running_mean, m.running_var]
+            stand += [a, b]
+        with torch.no_grad():
+            torch._foreach_mul_(real, keep)
+            torch._foreach_add_(real, stand)
+
+    def _forward_discriminator_twin(self, tgt_label, tgt_image, ref_labels, ref_images, prevs, early):
+        G = self.netG
+        st = self._bn_standins(tgt_label.device)
+        self._fold_bn_standins()             # (an iteration whose generator-mode call never came)
+        st['flat'].zero_()
+        for ent in st['table'].values():
+            ent[2] = False
+        G.begin_pass()                       # power iteration of the no-grad pass ...
+        G.begin_pass()                       # ... and of the generator-mode pass, both on the caller's stream, in pass order
+        branch = streams.Branch(tgt_label)
+        branch.uses([tgt_label, tgt_image, ref_labels, ref_images])
+        was = streams.CROSS
+        streams.CROSS = True
+        try:
+            with streams.hold():
+                with branch.guarded():
+                    with torch.no_grad():
+                        (fake, raw, _, _, _), (fg, ref_fg), (ref_label, ref_image), _ = \
+                            self.generate_images(tgt_label, tgt_image, ref_labels, ref_images, prevs, want_prevs=False)
+                    fg_union = union_fg(fg, ref_fg, self.has_fg)
+                    real = tgt_image[:, 0]
+                    losses = self.lossCollector.gan_losses(self.netD, tgt_label, [real, real * fg_union], [fake, raw], ref_label,
+                                                           ref_image, for_discriminator=True, netDf=self.netDf)
+                    losses = LossCollector.outward(losses)
+                networks.BatchNorm._redirect = st['table']
+                try:
+                    with torch.enable_grad():
+                        gen = self.generate_images(tgt_label, tgt_image, ref_labels, ref_images, prevs)
+                except BaseException:
+                    branch.finish()
+                    G._sn_presets = []
+                    raise
+                finally:
+                    networks.BatchNorm._redirect = None
+        finally:
+            streams.CROSS = was
+        st['pending'] = True
+        self._pre_g = (early, branch, gen)
+        losses[0]._fsv_branch = branch
+        if self.optimizer_D is not None:
+            self.optimizer_D._fsv_branch = branch
         return losses
 
     def forward_generator(self, tgt_label, tgt_image, ref_labels, ref_images, prevs, flow_gt=(None, None),

@@ -108,10 +108,30 @@ class BatchNorm(nn.Module):
         if self.training:
             self._pending += 1
 
+    # Two forward passes of ONE network issued next to each other on different streams (model.Vid2VidModel's twin generator passes)
+    # must not both read-modify-write the running statistics.  While `_redirect` is set, a module found in it hands its kernels a
+    # ZEROED stand-in pair instead: the kernel's update `r = (1 - m) r + m s` leaves exactly `m s` there, and the caller folds it
+    # into the real buffers in pass order afterwards (`running = (1 - m) running + stand-in`: the same two products and one sum as
+    # the in-place update, bit for bit).  A module may be met once per redirected pass (its second update would need (1 - m)^2).
+    _redirect = None
+    MOMENTUM = 0.1
+
+    def buffers(self):
+        red = BatchNorm._redirect
+        if red is not None and self.training:
+            hit = red.get(id(self))
+            if hit is not None:
+                if hit[2]:
+                    raise RuntimeError("a BatchNorm site was met twice in a redirected pass")
+                hit[2] = True
+                return hit[0], hit[1]
+        return self.running_mean, self.running_var
+
     def forward(self, x, act=ACT_NONE):
         self.note_forward()
+        rm, rv = self.buffers()
         return ops.norm_act(x, self.weight if self.affine else None, self.bias if self.affine else None,
-                            self.running_mean, self.running_var, instance=False, eps=1e-5, momentum=0.1, act=act,
+                            rm, rv, instance=False, eps=1e-5, momentum=BatchNorm.MOMENTUM, act=act,
                             training=self.training)
 
 
@@ -191,8 +211,8 @@ class SPADE(nn.Module):
                 use_w.append((wg, wb, zb, zb))
             use_maps.append(m)
         self.norm.note_forward()
-        return ops.spade_mod(x, use_maps, use_w, self.norm.running_mean, self.norm.running_var, act=act,
-                             training=self.training, up=up)
+        rm, rv = self.norm.buffers()
+        return ops.spade_mod(x, use_maps, use_w, rm, rv, act=act, training=self.training, up=up)
 
 
 class SPADEResnetBlock(nn.Module):
@@ -720,16 +740,36 @@ class FewShotGenerator(nn.Module):
         names = ('ref_img_', 'ref_label_', 'atn_')
         return [p for n, p in self.named_parameters() if n.startswith(names)]
 
+    def _sn_update(self):
+        if self._sn_group is None or self._sn_count != sum(1 for _ in self.modules()):
+            self._sn_group = ops.SpectralGroup(spectral_layers(self))
+            self._sn_count = sum(1 for _ in self.modules())
+        self._sn_group.update(self.training)
+
+    def begin_pass(self):
+        """One power iteration of every spectral layer NOW, for a forward pass that is issued later (possibly on another stream,
+        possibly behind further begin_pass() calls): the (layer, sigma / u / v snapshot) list is queued and the next forward pass
+        takes it instead of iterating itself - the iterations keep their order whatever the order the passes run in."""
+        self._sn_update()
+        snap = [(l, l._sig_cached) for l in self._sn_group.layers]
+        for l, _ in snap:
+            l._sig_cached = None
+        if getattr(self, '_sn_presets', None) is None:
+            self._sn_presets = []
+        self._sn_presets.append(snap)
+
     def forward(self, label, label_refs, img_refs, prev=(None, None), t=0, img_coarse=None):
         from .conv import stats_pass
         with stats_pass(label.device):          # a no-op inside Vid2VidModel.forward's pass; opens one for bare generator calls
             return self._forward(label, label_refs, img_refs, prev, t, img_coarse)
 
     def _forward(self, label, label_refs, img_refs, prev=(None, None), t=0, img_coarse=None):
-        if self._sn_group is None or self._sn_count != sum(1 for _ in self.modules()):
-            self._sn_group = ops.SpectralGroup(spectral_layers(self))
-            self._sn_count = sum(1 for _ in self.modules())
-        self._sn_group.update(self.training)
+        presets = getattr(self, '_sn_presets', None)
+        if presets:
+            for l, c in presets.pop(0):          # this pass's power iteration was issued ahead of it (begin_pass)
+                l._sig_cached = c
+        else:
+            self._sn_update()
         if img_coarse is not None:
             return self.forward_face(label, label_refs, img_refs, img_coarse)
         if self.n_shot == 1 and label_refs.shape[1] == 1:

@@ -1233,6 +1233,11 @@ def _spade_launch(a, b=None):
                  _ll(a['bstr'] + b['bstr'] + [0]), n, hw, c, ldw, 0, a['act'], b['act'], w, up, lib.stream_ptr())
 
 
+def _streams_mod():
+    from . import streams
+    return streams
+
+
 class _SpadeFn(torch.autograd.Function):
     """h = act(spade(x; maps, weights)).  Argument list: x, run_mean, run_var, then per map (map, wg, wb, bg, bb).
 
@@ -1320,6 +1325,12 @@ class _SpadeFn(torch.autograd.Function):
                     hit = getattr(wgs[k], '_fsv_spade_prep', None)
                     if hit is not None and hit[0] == key:
                         wcat_x, wcat_d, bcat = hit[1]
+                        if len(hit) > 2 and hit[2] is not None and x.is_cuda:
+                            cur_s = torch.cuda.current_stream(x.device)
+                            if cur_s != hit[3]:          # built by the other of two passes issued next to each other (streams.CROSS)
+                                cur_s.wait_event(hit[2])
+                                for t_ in hit[1]:
+                                    t_.record_stream(cur_s)
                         prepped += [wcat_x, wcat_d, bcat]
                         if ctx.f16:
                             wg_p.append(wcat_x.data_ptr()); wb_p.append(wcat_x.data_ptr() + 2 * c * kt)
@@ -1355,7 +1366,12 @@ class _SpadeFn(torch.autograd.Function):
                     wg_p.append(wcat_t.data_ptr()); wb_p.append(wcat_t.data_ptr() + 4 * c)
                     wstr.append(kt * 2 * c if per_sample else 0)
                 if owner is not None:
-                    wgs[k]._fsv_spade_prep = (key, tuple(prepped[-3:]))
+                    ev_ = st_ = None
+                    if _streams_mod().CROSS and x.is_cuda:
+                        st_ = torch.cuda.current_stream(x.device)
+                        ev_ = torch.cuda.Event()
+                        ev_.record(st_)
+                    wgs[k]._fsv_spade_prep = (key, tuple(prepped[-3:]), ev_, st_)
                 bg_p.append(bcat.data_ptr()); bb_p.append(bcat.data_ptr() + 4 * c)
                 bstr.append(2 * c if per_sample else 0)
             site = dict(x=x, mean=mean, rstd=rstd, h=hout, maps=maps, wg=wg_p, wb=wb_p, bg=bg_p, bb=bb_p, chs=chs, wstr=wstr,

@@ -61,6 +61,31 @@ def shared(make):
     return t
 
 
+CROSS = False       # set while two passes of one iteration are issued on different streams: values one pass caches for the
+                    # other (model._memoised, ops._SpadeFn's fixed-weight operands) then carry an event
+
+_held = None        # while a `hold()` block is open: side streams that forks inside it took (they stay reserved until it closes)
+
+
+class hold:
+    """`with hold():` - the side streams that forks inside the block take stay reserved until the block closes.  A forward pass that
+    is issued on one stream while ANOTHER pass of the same shape is issued next to it (model.Vid2VidModel's twin generator passes)
+    must not hand its branch streams to that pass: the second pass's branches would queue behind the first's on the device."""
+
+    def __enter__(self):
+        global _held
+        self.prev, _held = _held, []
+        return self
+
+    def __exit__(self, *exc):
+        global _held
+        for s in _held:
+            if any(s is b for b in _busy):
+                _busy.remove(s)
+        _held = self.prev
+        return False
+
+
 def fork(ref, fns):
     """[f() for f in fns]; on a GPU fns[1:] run on side streams next to fns[0] on the current one and are joined before the
     return.  `ref` is any tensor of the pass (it names the device; CPU / emulated tensors run the branches in order)."""
@@ -78,7 +103,10 @@ def fork(ref, fns):
         outs[0] = fns[0]()
     finally:
         for s in sides:
-            _busy.remove(s)
+            if _held is not None:
+                _held.append(s)          # stays in _busy until the enclosing hold() closes
+            else:
+                _busy.remove(s)
     for s, i in zip(sides, range(1, len(fns))):
         cur.wait_stream(s)
         _record(outs[i], cur)

@@ -34,6 +34,12 @@ def _run(device, graphed, iters, seed, opt_kw, b=1, split=False, early=False):
             g = M.loss_backward(opt, g, opt_G, 0)
         log.append(dict(d=[float(x.detach()) for x in d], g=[float(x.detach()) for x in g if not isinstance(x, int)],
                         img=gen[0].detach().clone().cpu()))
+    if graphed is False and early:
+        model.join_early()                  # (an open side-stream step; also folds the twin passes' running-statistics stand-ins)
+    # every buffer of both networks (BatchNorm running statistics and counters, spectral-norm u / v) rides along on the last log entry
+    log[-1]['buffers'] = {('G.' if net is model.netG else 'D.') + k: v.detach().clone().cpu()
+                          for net in (model.netG, model.netD) for k, v in net.state_dict().items()
+                          if k.endswith(('running_mean', 'running_var', 'num_batches_tracked', 'weight_u', 'weight_v'))}
     return log, opt_G.flat_p.detach().clone().cpu(), opt_D.flat_p.detach().clone().cpu(), step
 
 
@@ -65,6 +71,61 @@ def check_early_generator(device, iters=3, seed=560, tol=0.0):
                 assert abs(x - y) <= tol * max(abs(x), 1.0), (it, k, a[k], b[k])
         assert float((a['img'] - b['img']).abs().max()) <= tol * 2.0, it
     assert float((pG - qG).abs().max()) <= tol and float((pD - qD).abs().max()) <= tol
+
+
+def check_twin_generator_passes(device, iters=3, seed=570, graphed=False):
+    """Round 6: the iteration's two generator passes issued next to each other (model.Vid2VidModel._forward_discriminator_twin: the
+    no-grad pass and the discriminator step on a side stream, the generator-mode pass on the caller's stream; both spectral-norm
+    iterations up front, the second pass's BatchNorm running-statistics updates through zeroed stand-ins folded in afterwards)
+    against the same loop with FSV_TWIN_G=0: losses, images, all weights AND every buffer (running statistics, counters,
+    spectral-norm vectors) bit for bit under the emulator, which runs the two passes in issue order."""
+    import os
+    from importlib import import_module
+    M = mc._model()
+    kw = dict(warp_ref=True, spade_combine=True, remove_face_labels=True, fineSize=32, loadSize=32, n_downsample_G=3, n_adaptive_layers=2)
+    calls = []
+    real = M.Vid2VidModel._forward_discriminator_twin
+
+    def counted(self, *a, **k):
+        calls.append(1)
+        return real(self, *a, **k)
+    M.Vid2VidModel._forward_discriminator_twin = counted
+    old = os.environ.get('FSV_TWIN_G')
+    try:
+        os.environ['FSV_TWIN_G'] = '0'
+        ref, pG, pD, _ = _run(device, graphed, iters, seed, kw, split=True, early=True)
+        assert not calls
+        os.environ['FSV_TWIN_G'] = '2' if device.type == 'cpu' else '1'
+        got, qG, qD, _ = _run(device, graphed, iters, seed, kw, split=True, early=True)
+        assert len(calls) >= iters - (2 if graphed else 0), calls
+    finally:
+        M.Vid2VidModel._forward_discriminator_twin = real
+        if old is None:
+            os.environ.pop('FSV_TWIN_G', None)
+        else:
+            os.environ['FSV_TWIN_G'] = old
+    exact = device.type == 'cpu'
+    for it, (a, b) in enumerate(zip(ref, got)):
+        for k in ('d', 'g'):
+            for x, y in zip(a[k], b[k]):
+                assert (x == y) if exact else abs(x - y) <= 5e-2 * max(abs(x), 1.0), (it, k, a[k], b[k])
+        if exact:
+            assert torch.equal(a['img'], b['img']), it
+    if exact:
+        assert torch.equal(pG, qG) and torch.equal(pD, qD)
+        ba, bb = ref[-1]['buffers'], got[-1]['buffers']
+        assert set(ba) == set(bb)
+        for k in ba:
+            assert torch.equal(ba[k], bb[k]), 'buffer %s differs between the twin and the sequential schedule' % k
+    else:
+        # hardware: atomics reorder sums from run to run (see __main__ below) - first iteration to rounding, buffers loosely
+        assert float((ref[0]['img'] - got[0]['img']).abs().max()) <= 1e-4
+        ba, bb = ref[-1]['buffers'], got[-1]['buffers']
+        for k in ba:
+            if ba[k].dtype.is_floating_point:
+                assert float((ba[k] - bb[k]).abs().max()) <= 2e-2 * max(float(ba[k].abs().max()), 1e-3), k
+            else:
+                assert torch.equal(ba[k], bb[k]), k
 
 
 def check_capture_failure_falls_back(device, iters=4, seed=540):
@@ -160,4 +221,8 @@ if __name__ == '__main__':
         assert float((one[0]['img'] - other[0]['img']).abs().max()) <= 1e-4
         for x, y in zip(one[0]['d'] + one[0]['g'], other[0]['d'] + other[0]['g']):
             assert abs(x - y) <= 1e-4 * max(abs(x), 1.0), (one[0], other[0])
+    # round 6: the two generator passes of an iteration next to each other (twin schedule) against FSV_TWIN_G=0 - plain loop and
+    # captured graph
+    check_twin_generator_passes(dev, iters=4)
+    check_twin_generator_passes(dev, iters=5, graphed=True)
     print('GRAPH_STEP_GPU_OK', flush=True)

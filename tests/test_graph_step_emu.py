@@ -34,3 +34,9 @@ def test_three_piece_backward_keeps_every_gradient(emu_lib):
     """build_optimizers(split_backward=3): a second stage boundary behind the reference encoders - weights equal to the one-piece
     loop bit for bit, eager and graphed driver"""
     gc.check_split_backward_single_rank(DEV, iters=2, pieces=3)
+
+
+def test_twin_generator_passes_change_no_result_and_no_buffer(emu_lib):
+    """round 6: the no-grad and the generator-mode pass of an iteration issued next to each other - plain loop and graphed driver"""
+    gc.check_twin_generator_passes(DEV)
+    gc.check_twin_generator_passes(DEV, graphed=True)
