@@ -995,11 +995,15 @@ class Vid2VidModel(nn.Module):
     # per-network order of everything stateful: bit-identical to the sequential schedule (tests/test_graph_step_emu.py on the
     # emulator's single queue; tests/graph_step_checks.py on hardware).  Only for passes that meet every BatchNorm / spectral layer
     # once (no previous frames, no --add_raw_output_loss, one reference image, no face generator) and in exact fp32 (the half
-    # twins of the `--amp` path are made lazily on whichever stream asks first).  FSV_TWIN_G=0: the old order (A/B).
+    # twins of the `--amp` path are made lazily on whichever stream asks first).
+    # MEASURED AND NOT ADOPTED (profiles/r06_step_ab_schedule.txt, one box): sequential 42.91 / 42.96 ms per step; twin passes with the
+    # no-grad pass's own fork rooted at the caller's stream (four streams) 43.48 / 44.14; twin passes with that pass on ONE stream
+    # 43.01 / 43.01 - two heavy passes next to each other take their time from each other, and what the overlap of their launch-bound
+    # stretches buys is what the no-grad pass loses with its own fork.  Opt-in: FSV_TWIN_G=1 (2: also on host tensors, test-suite).
     def _twin_ready(self, tgt_label, ref_labels, prevs):
         # (FSV_TWIN_G=2: also on host tensors - the emulator's single queue runs the two passes in issue order, which exercises the
         # spectral-norm queue and the stand-in fold of the schedule in the CPU test-suite)
-        sw = os.environ.get('FSV_TWIN_G', '1')
+        sw = os.environ.get('FSV_TWIN_G', '0')
         if sw not in ('1', '2') or not ((streams.ENABLED and tgt_label.is_cuda) or sw == '2'):
             return False
         G = self.netG
@@ -1052,6 +1056,13 @@ class Vid2VidModel(nn.Module):
             ent[2] = False
         G.begin_pass()                       # power iteration of the no-grad pass ...
         G.begin_pass()                       # ... and of the generator-mode pass, both on the caller's stream, in pass order
+        # everything the no-grad pass launches in front of its own fork (the label helpers of generate_images) runs HERE, on the
+        # caller's stream, so that the fork's branches can start from this stream (streams.FORK_ROOT)
+        rooted = _MEMO is not None and os.environ.get('FSV_TWIN_INNER', '1') == '1'
+        if rooted:
+            valid_labels(self.opt, ref_labels)
+            valid_labels(self.opt, tgt_label[:, 0])
+        main = torch.cuda.current_stream(tgt_label.device) if tgt_label.is_cuda else None
         branch = streams.Branch(tgt_label)
         branch.uses([tgt_label, tgt_image, ref_labels, ref_images])
         was = streams.CROSS
@@ -1059,9 +1070,18 @@ class Vid2VidModel(nn.Module):
         try:
             with streams.hold():
                 with branch.guarded():
-                    with torch.no_grad():
-                        (fake, raw, _, _, _), (fg, ref_fg), (ref_label, ref_image), _ = \
-                            self.generate_images(tgt_label, tgt_image, ref_labels, ref_images, prevs, want_prevs=False)
+                    inner = streams.ENABLED
+                    if not rooted:
+                        streams.ENABLED = False          # the no-grad pass's own branches in issue order on its stream (FORK_ROOT)
+                    else:
+                        streams.FORK_ROOT = main
+                    try:
+                        with torch.no_grad():
+                            (fake, raw, _, _, _), (fg, ref_fg), (ref_label, ref_image), _ = \
+                                self.generate_images(tgt_label, tgt_image, ref_labels, ref_images, prevs, want_prevs=False)
+                    finally:
+                        streams.ENABLED = inner
+                        streams.FORK_ROOT = None
                     fg_union = union_fg(fg, ref_fg, self.has_fg)
                     real = tgt_image[:, 0]
                     losses = self.lossCollector.gan_losses(self.netD, tgt_label, [real, real * fg_union], [fake, raw], ref_label,

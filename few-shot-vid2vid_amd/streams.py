@@ -64,6 +64,12 @@ def shared(make):
 CROSS = False       # set while two passes of one iteration are issued on different streams: values one pass caches for the
                     # other (model._memoised, ops._SpadeFn's fixed-weight operands) then carry an event
 
+FORK_ROOT = None    # set by a caller that issues a pass on a SIDE stream (model.Vid2VidModel's twin generator passes): the branches
+                    # of a fork inside that pass then start from this stream - the capture's origin - instead of the side stream.
+                    # hipStreamEndCapture of ROCm 7.2 crashes on a branch of a branch (round 6: segmentation fault in capture_end,
+                    # gone with the inner fork off); a sibling of the side stream is fine.  Only valid while the side stream has
+                    # launched nothing since it was forked from FORK_ROOT that the branches read (the caller's responsibility).
+
 _held = None        # while a `hold()` block is open: side streams that forks inside it took (they stay reserved until it closes)
 
 
@@ -97,7 +103,7 @@ def fork(ref, fns):
     _busy.extend(sides)
     try:
         for s, i in zip(sides, range(1, len(fns))):
-            s.wait_stream(cur)
+            s.wait_stream(cur if FORK_ROOT is None else FORK_ROOT)
             with torch.cuda.stream(s):
                 outs[i] = fns[i]()
         outs[0] = fns[0]()
