@@ -1826,7 +1826,17 @@ static inline double fsv_conv_cost(int Mz, int Cout, int nchunks, int nsamp, int
   const double eff = w8 ? (L <= 1.0 ? 0.91 : 0.97) : (L <= 1.0 ? 0.78 : (L <= 2.0 ? 0.88 : 0.95));
   const double ovh = (5000.0 + bm * bn / 8.0) * (L <= 1.0 ? 1.0 : 0.45);
   double t = L * (cps * cyc / eff + ovh) / 1.95e9 + 4e-6;
-  if (nsplit > 1) t += 6e-6 + 0.5e-6 * nsplit + (double)Mz * Cout * nsamp * 4.0 * (2.0 + 0.25 * nsplit) / 3.0e12;
+  // (FSV_SPLIT_FIX_US / FSV_SPLIT_BW_TBS: in-box A/B of the split's fixed cost and of the rate of its copies + finishing pass)
+  static double split_fix = -1.0, split_bw = 0.0;
+  if (split_fix < 0.0) {
+    const char* a = getenv("FSV_SPLIT_FIX_US");
+    const char* b = getenv("FSV_SPLIT_BW_TBS");
+    // round 6: 3 us + 4.5 TB/s (6 us + 3.0 TB/s until the finishing pass became one vectorised pass: 15.6 -> 5.8 us per launch);
+    // in-box: 42.86 -> 42.77 ms per step, the M2048 N512 K2304 layers now split in two (79.6 -> 94.0 TFLOP/s in isolation)
+    split_bw = (b ? atof(b) : 4.5) * 1e12;
+    split_fix = (a ? atof(a) : 3.0) * 1e-6;
+  }
+  if (nsplit > 1) t += split_fix + 0.5e-6 * nsplit + (double)Mz * Cout * nsamp * 4.0 * (2.0 + 0.25 * nsplit) / split_bw;
   return t;
 }
 
