@@ -38,5 +38,5 @@ def test_three_piece_backward_keeps_every_gradient(emu_lib):
 
 def test_twin_generator_passes_change_no_result_and_no_buffer(emu_lib):
     """round 6: the no-grad and the generator-mode pass of an iteration issued next to each other - plain loop and graphed driver"""
-    gc.check_twin_generator_passes(DEV)
+    gc.check_twin_generator_passes(DEV, iters=2)
     gc.check_twin_generator_passes(DEV, graphed=True)
