@@ -58,6 +58,10 @@ lib.register_sigs({
     "fsv_spade_conv_s_supported": [c_i, c_i, c_i],
     "fsv_spade_conv_s_fwd": [c_p, c_p, c_p, c_p, c_p, c_i, c_pp, c_pp, c_pp, c_pp, c_pp, c_ip, c_llp, c_llp,
                              c_i, c_i, c_i, c_i, c_ll, c_i, c_i, c_p, c_i, c_i, c_p, c_p],
+    "fsv_spade_conv3_supported": [c_i, c_i, c_i],
+    # x mean rstd hs out | nmaps maps wg wb bg bb ch w_bstride b_bstride | N H W C ldw stat_bstride up act | wc ldwc Cout bias res wscale stream
+    "fsv_spade_conv3_fwd": [c_p, c_p, c_p, c_p, c_p, c_i, c_pp, c_pp, c_pp, c_pp, c_pp, c_ip, c_llp, c_llp,
+                            c_i, c_i, c_i, c_i, c_i, c_ll, c_i, c_i, c_p, c_i, c_i, c_p, c_p, c_p, c_p],
     "fsv_spade_conv_s_fwd_h": [c_p, c_p, c_p, c_p, c_p, c_i, c_pp, c_pp, c_pp, c_pp, c_pp, c_ip, c_llp, c_llp,
                                c_i, c_i, c_i, c_ll, c_i, c_i, c_p, c_i, c_i, c_p, c_p],
     "fsv_upsample2x_fwd": [c_p, c_p, c_i, c_i, c_i, c_i, c_p],
@@ -374,7 +378,14 @@ class _ConvFn(torch.autograd.Function):
         # fp32 tensor, the pointer comparison then failed and the modulation ran after its consumer)
         st_wanted = bool(stats_groups and not per_sample)
         site = _spade_pending_for(x)
-        if site is not None and not _spade_conv_s_fits(site, geom, per_sample, bias, res, act, scale, half, cpad, st_wanted, cout):
+        site3 = None
+        if site is not None and site.get('conv3'):
+            if _spade_conv3_fits(site, geom, per_sample, res, act, scale, half, cpad, cout, up):
+                site3, site = site, None
+            else:
+                _spade_launch(site)
+                site = None
+        elif site is not None and not _spade_conv_s_fits(site, geom, per_sample, bias, res, act, scale, half, cpad, st_wanted, cout):
             _spade_launch(site)
             site = None
         # up: x stands for its nearest x2 up-sampling (generator.py:124,497-504,541-572: nn.Upsample in front of a 3x3
@@ -428,6 +439,9 @@ class _ConvFn(torch.autograd.Function):
                 y = _spade_conv_s_launch(site, wh, kpad_h, cout, wscale, want_hs=any(ctx.needs_input_grad))
             else:
                 y = _spade_conv_s_launch(site, wt, ldw, cout, wscale, want_hs=any(ctx.needs_input_grad))
+        elif site3 is not None:
+            y = _spade_conv3_launch(site3, wt, ldw, cout, wscale, b, res.detach() if res is not None else None,
+                                    want_hs=any(ctx.needs_input_grad))
         # (a layer whose output feeds a BatchNorm - the flow decoder's three - loses the statistics epilogue on the placed class
         # launches and reduces in a pass of its own: FSV_UP_SUBPIXEL_STATS=0 keeps such layers on the single gather + fused
         # statistics instead; in-box A/B of round 6: profiles/r06_notes.md)
@@ -1102,12 +1116,23 @@ class spade_into_conv:
     modulated tensor is never written; a training forward gets it as a side output (conv_s' weight gradient reads it) - autograd
     is untouched (the same two nodes, the same two backward passes).  A consumer the fused kernel does not cover (other widths,
     `--amp`, a convolution with bias / residual) launches the held-back modulation first and proceeds as usual.
-    FSV_SPADE_CONV_S=0 switches the fusion off (in-box A/B)."""
+    FSV_SPADE_CONV_S=0 switches the fusion off (in-box A/B).
+
+    conv3=True (round 6): around `conv_0(actvn(bn_0(x)))` / `conv_1(actvn(bn_1(dx)))` (architecture.py:96-99) - the 3x3 consumer
+    issues modulation + activation + convolution as one kernel (csrc/spade_conv3.hip: the modulated haloed tile lives in LDS) where
+    that kernel covers the widths.  Built and measured against the two launches (profiles/r06_notes.md section 8); an opt-in:
+    FSV_SPADE_CONV3=1."""
+
+    def __init__(self, conv3=False):
+        self.conv3 = bool(conv3)
 
     def __enter__(self):
         self.pending = None
         self.outer = getattr(_spade_tls, 'defer', None)
-        _spade_tls.defer = self if _os.environ.get('FSV_SPADE_CONV_S', '1') == '1' else None
+        if self.conv3:
+            _spade_tls.defer = self if spade_conv3_enabled() else None
+        else:
+            _spade_tls.defer = self if _os.environ.get('FSV_SPADE_CONV_S', '1') == '1' else None
         return self
 
     def __exit__(self, et, ev, tb):
@@ -1120,6 +1145,10 @@ class spade_into_conv:
 
 def spade_pair_enabled():
     return _os.environ.get('FSV_SPADE_PAIR', '0') == '1'
+
+
+def spade_conv3_enabled():
+    return _os.environ.get('FSV_SPADE_CONV3', '0') == '1'
 
 
 def _spade_pending_for(x):
@@ -1186,6 +1215,51 @@ def _spade_conv_s_launch(site, wt, ldws, cout, wscale, want_hs):
                      arr(site['wb']), arr(site['bg']), arr(site['bb']), lib.int_array(chs + [0]), _ll(site['wstr'] + [0]),
                      _ll(site['bstr'] + [0]), n, hw, c, ldw, 0, w, up, lib.ptr(wt), ldws, cout, lib.ptr(wscale), lib.stream_ptr())
     return xs
+
+
+def _spade_conv3_fits(site, geom, per_sample, res, act, scale, half, cpad, cout, up):
+    """every condition of the fused bn -> actvn -> 3x3 convolution launch (csrc/spade_conv3.hip fsv_spade_conv3_fwd), from shapes alone
+    (as _spade_conv_s_fits: a site that passes here cannot come back FSV_ERR_UNSUPPORTED).  A bias, a residual and a statistics hint
+    are fine (the statistics of the output are then reduced by the normalisation that follows, in a pass of its own)."""
+    if not (site.get('conv3') and geom.kh == 3 and geom.kw == 3 and geom.stride == 1 and geom.pad == 1 and not per_sample and
+            act == ACT_NONE and scale == 1.0 and cpad == 0 and not half and not up):
+        return False
+    if site.get('f16') or site.get('half') or site['act'] not in (ACT_NONE, ACT_LRELU):
+        return False
+    n, hw, c, _, w, s_up = site['dims']
+    chs = site['chs']
+    if lib.call_status("fsv_spade_conv3_supported", c, cout, len(chs)) != 1:
+        return False
+    if any(ch < 1 or ch % 4 for ch in chs):
+        return False
+    lim = 2 ** 31
+    if hw * c * 4 > lim or hw * cout * 4 > lim or any(hw * ch * 4 > lim for ch in chs):
+        return False
+    if s_up and (w % 2 or (hw // w) % 2):
+        return False
+    if res is not None and tuple(res.shape) != (n, cout, hw // w, w):
+        return False
+    return True
+
+
+def _spade_conv3_launch(site, wt, ldwc, cout, wscale, bias, res, want_hs):
+    """out = conv3x3(actvn(bn(x))) (+ bias, + res) in one launch; returns out (NHWC storage, logical NCHW)"""
+    arr = lambda v: (ctypes.c_void_p * max(len(v), 1))(*v)
+    n, hw, c, ldw, w, up = site['dims']
+    chs = site['chs']
+    hgt = hw // w
+    out = empty_nhwc(n, cout, hgt, w, site['x'])
+    if res is not None:
+        res = to_nhwc(res)
+    lib.check_device(site['x'], wt, wscale, bias, res)
+    with profile.scope('fsv_spade_conv3_kernel' + (' P%d C%d N%d K%s' % (n * hw, c, cout, '+'.join(map(str, chs))) if profile.detail() else ''),
+                       site['flops'] + 2.0 * n * hw * 9 * c * cout):
+        lib.call("fsv_spade_conv3_fwd", lib.ptr(site['x']), lib.ptr(site['mean']), lib.ptr(site['rstd']),
+                 lib.ptr(site['h']) if want_hs else None, lib.ptr(out), len(chs), _pp(site['maps']), arr(site['wg']),
+                 arr(site['wb']), arr(site['bg']), arr(site['bb']), lib.int_array(chs + [0]), _ll(site['wstr'] + [0]),
+                 _ll(site['bstr'] + [0]), n, hgt, w, c, ldw, 0, up, site['act'], lib.ptr(wt), ldwc, cout, lib.ptr(bias),
+                 lib.ptr(res), lib.ptr(wscale), lib.stream_ptr())
+    return out
 
 
 def _spade_same_input(a, b):
@@ -1379,9 +1453,12 @@ class _SpadeFn(torch.autograd.Function):
                         flops=2.0 * n * h * w * c * 2 * sum(chs))
             pair = getattr(_spade_tls, 'pair', None)
             defer = getattr(_spade_tls, 'defer', None)
-            if (defer is not None and defer.pending is None and pair is None and nmaps > 0 and (ctx.f16 or not ctx.half_out) and
-                    act == ACT_NONE and c in (64, 128)):
-                defer.pending = site            # the 1x1 convolution that reads hout issues both (spade_into_conv)
+            conv3 = bool(defer is not None and defer.conv3)
+            if (defer is not None and defer.pending is None and pair is None and nmaps > 0 and
+                    ((not conv3 and (ctx.f16 or not ctx.half_out) and act == ACT_NONE and c in (64, 128)) or
+                     (conv3 and not ctx.half_out and act in (ACT_NONE, ACT_LRELU) and c == 64))):
+                site['conv3'] = conv3
+                defer.pending = site            # the convolution that reads hout issues both (spade_into_conv)
             elif pair is None or nmaps == 0:
                 _spade_launch(site)
             elif pair.pending is None:

@@ -1391,6 +1391,111 @@ def _check_spade_conv_s(device, ops, conv, n, c, cout, chs, h, w, up, grad, spec
             assert_close('fused bn_s -> conv_s grad %d vs the oracle' % i, b, a, tol=otol * 2)
 
 
+def check_spade_conv3(device, n=2, c=64, cout=32, chs=(16, 8), h=20, w=24, up=True, grad=True, spectral=True, res=False, act='lrelu',
+                      seed=59):
+    """dx = conv_0(actvn(bn_0(x, maps))) / conv_1(actvn(bn_1(dx, maps))) + x_s (architecture.py:96-99) through
+    ops.spade_into_conv(conv3=True) - ONE launch of csrc/spade_conv3.hip (the modulated haloed tile in LDS, round 6) - against the same
+    two operators launched one after the other AND against the oracle directly (normalization.py:37-52 + leaky_relu + the 3x3
+    spectral-norm convolution restated by oracle/fsv_oracle.py): output within the fp32 summation-order band, gradients equal (the
+    backward passes are the same two nodes; the training forward writes the modulated tensor as a side output).  Sizes that are not a
+    multiple of the 8 x 16 tile exercise the partial tiles; every tile has halo pixels outside the image (the convolution's padding)."""
+    import contextlib
+    from importlib import import_module
+    ops, conv = pkg()
+    lib = import_module('few-shot-vid2vid_amd.lib')
+    g = torch.Generator().manual_seed(seed)
+    xs_h, xs_w = (h // 2, w // 2) if up else (h, w)
+    x = torch.randn(n, c, xs_h, xs_w, generator=g) + 0.2
+    maps = [torch.randn(n, ch, h, w, generator=g) for ch in chs]
+    wts = []
+    for k, ch in enumerate(chs):
+        if k == 0:
+            wts.append((torch.randn(n, c, ch, 1, 1, generator=g) * 0.3, torch.randn(n, c, ch, 1, 1, generator=g) * 0.3,
+                        torch.randn(n, c, generator=g) * 0.3, torch.randn(n, c, generator=g) * 0.3))
+        else:
+            wts.append((torch.randn(c, ch, 1, 1, generator=g) * 0.3, torch.randn(c, ch, 1, 1, generator=g) * 0.3,
+                        torch.randn(c, generator=g) * 0.3, torch.randn(c, generator=g) * 0.3))
+    wconv = torch.randn(cout, c, 3, 3, generator=g) * (1.0 / (9 * c) ** 0.5)
+    bconv = torch.randn(cout, generator=g) * 0.1
+    u0 = F.normalize(torch.randn(cout, generator=g), dim=0)
+    v0 = F.normalize(torch.randn(c * 9, generator=g), dim=0)
+    rs = torch.randn(n, cout, h, w, generator=g) if res else None
+    dy = torch.randn(n, cout, h, w, generator=g)
+    act_code = conv.ACT_LRELU if act == 'lrelu' else conv.ACT_NONE
+
+    def run(fused):
+        cl = lambda t: _dev(t, device).detach().clone().contiguous(memory_format=torch.channels_last)
+        xd = cl(x).requires_grad_(grad)
+        md = [cl(m).requires_grad_(grad) for m in maps]
+        wd = [tuple(_dev(t, device).detach().clone().requires_grad_(grad) for t in ws) for ws in wts]
+        wc = _dev(wconv, device).detach().clone().requires_grad_(grad)
+        bc = _dev(bconv, device).detach().clone().requires_grad_(grad)
+        rd = cl(rs).requires_grad_(grad) if res else None
+        rm, rv = _dev(torch.zeros(c), device), _dev(torch.ones(c), device)
+        u, v = _dev(u0.clone(), device), _dev(v0.clone(), device)
+        seen, real_call = [], lib.call
+
+        def recording_call(name, *a):
+            seen.append((name, a))
+            return real_call(name, *a)
+        lib.call = recording_call
+        os.environ['FSV_SPADE_CONV3'] = '1' if fused else '0'
+        try:
+            with (contextlib.nullcontext() if grad else torch.no_grad()):
+                with ops.spade_into_conv(conv3=True):
+                    hm = ops.spade_mod(xd, md, wd, rm, rv, act=act_code, up=up)
+                    sn = ops.SpectralState.update(wc, u, v, True) if spectral else None
+                    y = ops.conv2d(hm, wc, bc, 1, 1, sn=(sn, u, v) if spectral else None, res=rd, stats_groups=1)
+            grads = None
+            if grad:
+                (y * _dev(dy, device)).sum().backward()
+                grads = ([xd.grad] + [m.grad for m in md] + [t.grad for ws in wd for t in ws] + [wc.grad, bc.grad] +
+                         ([rd.grad] if res else []))
+        finally:
+            lib.call = real_call
+            os.environ.pop('FSV_SPADE_CONV3', None)
+        return y.detach(), grads, seen, (rm, rv)
+    y1, g1, seen1, st1 = run(False)
+    y2, g2, seen2, st2 = run(True)
+    names1, names2 = [s_[0] for s_ in seen1], [s_[0] for s_ in seen2]
+    assert 'fsv_spade_conv3_fwd' not in names1 and 'fsv_spade_mod_fwd' in names1, names1
+    assert 'fsv_spade_conv3_fwd' in names2 and 'fsv_spade_mod_fwd' not in names2, names2
+    # the convolution itself is in the fused launch (the gather launches that remain are the data gradients of the backward pass)
+    fwd = lambda names: sum(nm in ('fsv_conv_gather_fwd', 'fsv_conv_gather_fwd_stats') for nm in names)
+    assert fwd(names2) == fwd(names1) - 1, (names1, names2)
+    fused_args = [a for (nm, a) in seen2 if nm == 'fsv_spade_conv3_fwd'][0]
+    assert (fused_args[3] is not None) == grad, 'the modulated tensor is a side output of the training forward only'
+    assert_close('fused bn -> actvn -> conv3x3 output', y2, y1, tol=2e-5)
+    for a, b in zip(st1, st2):
+        assert float((a.cpu() - b.cpu()).abs().max()) == 0.0
+    if grad:
+        for i, (a, b) in enumerate(zip(g1, g2)):
+            assert_close('fused bn -> actvn -> conv3x3 grad %d' % i, b, a, tol=2e-5)
+    leaf = lambda t: t.detach().clone().requires_grad_(grad)
+    xr, mr = leaf(x), [leaf(m) for m in maps]
+    wr = [tuple(leaf(t) for t in ws) for ws in wts]
+    wcr, bcr = leaf(wconv), leaf(bconv)
+    rr = leaf(rs) if res else None
+    fixed_r = [None if k == 0 else (wr[k][0], wr[k][2], wr[k][1], wr[k][3]) for k in range(len(chs))]
+    gen_r = ((wr[0][0], wr[0][2]), (wr[0][1], wr[0][3]))
+    sd = {'weight_orig': wcr, 'weight_u': u0.clone(), 'weight_v': v0.clone(), 'bias': bcr}
+    with (contextlib.nullcontext() if grad else torch.no_grad()):
+        x_in = F.interpolate(xr, scale_factor=2, mode='nearest') if up else xr
+        h_ref = O.spade(x_in, mr, fixed_r, gen_r)
+        if act == 'lrelu':
+            h_ref = F.leaky_relu(h_ref, 0.2)
+        y_ref = O._sn_conv(sd, '', h_ref, 1, 1) if spectral else O._conv2d(h_ref, wcr, bcr, 1, 1)
+        if res:
+            y_ref = y_ref + rr
+        if grad:
+            (y_ref * dy).sum().backward()
+    assert_close('fused bn -> actvn -> conv3x3 output vs the oracle', y2, y_ref, tol=2e-5)
+    if grad:
+        refs = [xr.grad] + [m.grad for m in mr] + [t.grad for ws in wr for t in ws] + [wcr.grad, bcr.grad] + ([rr.grad] if res else [])
+        for i, (a, b) in enumerate(zip(refs, g2)):
+            assert_close('fused bn -> actvn -> conv3x3 grad %d vs the oracle' % i, b, a, tol=4e-5)
+
+
 def check_conv_stats(device, seed=61):
     """BatchNorm / InstanceNorm statistics from the producing convolution's epilogue (ops.conv2d stats_groups -> `_fsv_stats` ->
     norm_act / spade_mod) against the separate reduction pass: same normalised output, running statistics and gradients; the

@@ -179,6 +179,14 @@ def test_spade_modulation_fused_with_the_shortcut_convolution(emu_lib):
     oc.check_spade_conv_s(DEV, c=128, cout=64, chs=(40,), h=9, w=7, up=False, grad=False, amp=True)
 
 
+def test_spade_modulation_fused_with_the_3x3_convolution(emu_lib):
+    """actvn(bn_0 / bn_1) -> conv_0 / conv_1 as one kernel (csrc/spade_conv3.hip, round 6) == the two launches == the oracle"""
+    oc.check_spade_conv3(DEV)                                                       # level-0 conv_0: 64 -> 32, folded up-sampling, two maps
+    oc.check_spade_conv3(DEV, cout=64, chs=(8, 8, 4), h=13, w=19, up=False, res=True)             # ragged tiles, three maps, residual
+    oc.check_spade_conv3(DEV, cout=32, chs=(36,), h=8, w=16, up=False, grad=False, spectral=False)   # no graph: hs never written; k % 8 != 0
+    oc.check_spade_conv3(DEV, cout=64, chs=(32, 32), h=18, w=34, up=True, act='none', grad=False, res=True)
+
+
 def test_spade_two_site_launch(emu_lib):
     oc.check_spade_pair(DEV)
     oc.check_spade_pair(DEV, c=32, chs=(8,), h=9, w=7, up=False)
