@@ -23,6 +23,19 @@
 
 #define FSV_S3_MAXMAPS 3
 
+// A base address that is the same in every lane (kernel arguments and blockIdx only) but that the compiler evaluated on the vector
+// unit (a 64-bit multiply by blockIdx.z): pinned into scalar registers, so that the buffer descriptor built from it is scalar and the
+// loads through it need no per-load waterfall loop (first build of this kernel: 139 of them, guide T20).
+#ifdef FSV_EMU
+template <typename T> static inline T* fsv_s3_uniform(T* q) { return q; }
+#else
+template <typename T> __device__ __forceinline__ T* fsv_s3_uniform(T* q) {
+  const unsigned long long a = (unsigned long long)q;
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a), hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+  return (T*)(((unsigned long long)hi << 32) | lo);
+}
+#endif
+
 struct SpadeConv3P {
   const float* x;         // [N][H W or H W / 4][C]
   const float* mean;      // [C] (+ z * stat_bstride)
@@ -45,7 +58,9 @@ struct SpadeConv3P {
   const float* res;       // [N][H W][Cout] or null: added behind the bias
   const float* wscale;    // optional device scalar on the accumulator (spectral-norm 1 / sigma)
   int Cout, ldwc;
-  int tiles_x;
+  int tiles_x, ntiles;
+  double* stats;          // optional: zeroed partials [stats_slots][Cout][2] = (sum v, sum v^2) of the stored output over all samples -
+  int stats_slots;        // the BatchNorm statistics of the normalisation that follows (layout of ConvP::stats, one group)
 };
 
 // TN2 output column blocks of 32 (Cout = 32 TN2); C = 64
@@ -62,7 +77,12 @@ __global__ __launch_bounds__(256, 2) void fsv_spade_conv3_kernel(SpadeConv3P p) 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lrow = lane & 31, lk = lane >> 5;
   const int z = blockIdx.z;
-  const int tyi = (int)blockIdx.x / p.tiles_x, txi = (int)blockIdx.x - tyi * p.tiles_x;
+  // workgroups go to the eight XCDs round-robin: XCD i takes the i-th CONTIGUOUS eighth of the tiles, so that the halo rows two
+  // neighbouring tiles share (and the label maps under them) are fetched into one L2
+  const int per_xcd = (p.ntiles + 7) >> 3;
+  const int tile = ((int)blockIdx.x & 7) * per_xcd + ((int)blockIdx.x >> 3);
+  if (tile >= p.ntiles) return;
+  const int tyi = tile / p.tiles_x, txi = tile - tyi * p.tiles_x;
   const int y0 = tyi * TH, x0 = txi * TW;
   const int H = p.H, W = p.W, HWp = H * W;
 
@@ -79,7 +99,7 @@ __global__ __launch_bounds__(256, 2) void fsv_spade_conv3_kernel(SpadeConv3P p) 
   }
 
   // the convolution's first weight chunk is requested now and lands in LDS behind phase 1
-  const fsv_buf cbuf = fsv_make_buf(p.wc, (long long)9 * C * p.ldwc * 4);
+  const fsv_buf cbuf = fsv_make_buf(fsv_s3_uniform(p.wc), (long long)9 * C * p.ldwc * 4);
   float4 wreg[TN2];
   auto load_wchunk = [&](int ci) {
 #pragma unroll
@@ -115,7 +135,7 @@ __global__ __launch_bounds__(256, 2) void fsv_spade_conv3_kernel(SpadeConv3P p) 
       inner[u] = ok & (hy >= 1) & (hy <= TH) & (hx >= 1) & (hx <= TW);
     }
     const long long xpix_n = p.up ? (HWp >> 2) : HWp;
-    const fsv_buf xbuf = fsv_make_buf(p.x + (long long)z * xpix_n * C, xpix_n * C * 4);
+    const fsv_buf xbuf = fsv_make_buf(fsv_s3_uniform(p.x + (long long)z * xpix_n * C), xpix_n * C * 4);
     float xv[NU][16];                                    // x, then the running modulated value: register r = channel c(r)
 #pragma unroll
     for (int u = 0; u < NU; ++u) {
@@ -140,10 +160,10 @@ __global__ __launch_bounds__(256, 2) void fsv_spade_conv3_kernel(SpadeConv3P p) 
     for (int k = 0; k < FSV_S3_MAXMAPS; ++k) {
       if (k < p.nmaps) {
         const int Ch = p.ch[k];
-        const fsv_buf abuf = fsv_make_buf(p.map[k] + (long long)z * HWp * Ch, (long long)HWp * Ch * 4);
+        const fsv_buf abuf = fsv_make_buf(fsv_s3_uniform(p.map[k] + (long long)z * HWp * Ch), (long long)HWp * Ch * 4);
         const long long wbytes = (long long)((Ch + 31) / 32) * 32 * p.ldw * 4;
-        const fsv_buf gbuf = fsv_make_buf(p.wg[k] + z * p.w_bstride[k], wbytes);
-        const fsv_buf bbuf = fsv_make_buf(p.wb[k] + z * p.w_bstride[k], wbytes);
+        const fsv_buf gbuf = fsv_make_buf(fsv_s3_uniform(p.wg[k] + z * p.w_bstride[k]), wbytes);
+        const fsv_buf bbuf = fsv_make_buf(fsv_s3_uniform(p.wb[k] + z * p.w_bstride[k]), wbytes);
         const int ngrp = (Ch + 7) / 8;
         float4 mp[2][NU];
         float wgv[2][4], wbv[2][4];
@@ -155,7 +175,9 @@ __global__ __launch_bounds__(256, 2) void fsv_spade_conv3_kernel(SpadeConv3P p) 
             mp[b][u] = fsv_buf_load4(abuf, (kin & (pix[u] >= 0)) ? (unsigned)((pix[u] * Ch + kk) * 4) : FSV_BUF_OOB);
 #pragma unroll
           for (int s = 0; s < 4; ++s) {
-            const unsigned off = kin ? (unsigned)(((kk + s) * p.ldw + 32 * cb + lrow) * 4) : FSV_BUF_OOB;
+            // no mask: rows [Ch, ceil32(Ch)) of the operand are zeros (fsv_spade_prep), rows past it are outside the descriptor
+            // (a select here came back as a branch around the loads with a vmcnt(0) inside - guide trap 4c)
+            const unsigned off = (unsigned)(((kk + s) * p.ldw + 32 * cb + lrow) * 4);
             wgv[b][s] = fsv_buf_load1(gbuf, off);
             wbv[b][s] = fsv_buf_load1(bbuf, off);
           }
@@ -174,10 +196,16 @@ __global__ __launch_bounds__(256, 2) void fsv_spade_conv3_kernel(SpadeConv3P p) 
         load_group(0, 0);
 #pragma unroll 1
         for (int j = 0; j < ngrp; j += 2) {              // the next group's operands are in flight under this group's MFMAs
+          // (fences: left alone the scheduler sinks the loads below the MFMAs they are meant to hide behind and waits for them
+          // with vmcnt(0) at the top of the next group)
           load_group(j + 1, 1);
+          FSV_SCHED_FENCE();
           mma_group(0);
+          FSV_SCHED_FENCE();
           load_group(j + 2, 0);
+          FSV_SCHED_FENCE();
           if (j + 1 < ngrp) mma_group(1);
+          FSV_SCHED_FENCE();
         }
         // modulation with map k (registers only)
 #pragma unroll
@@ -224,13 +252,18 @@ __global__ __launch_bounds__(256, 2) void fsv_spade_conv3_kernel(SpadeConv3P p) 
   __syncthreads();                                       // patch and the first weight chunk are complete
 
   // ---- phase 2: the 3x3 convolution from the patch -------------------------------------------------------------------------------------
-  f32x16 acc2[TN2];
+  // (one output column block: the k steps alternate between two accumulators - two independent chains of matrix instructions -
+  // and meet in the epilogue)
+  constexpr int NACC = TN2 == 1 ? 2 : TN2;
+  f32x16 acc2[NACC];
 #pragma unroll
-  for (int jn = 0; jn < TN2; ++jn)
+  for (int jn = 0; jn < NACC; ++jn)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc2[jn][r] = 0.f;
   const int oy_a = 2 * wave + (lrow >> 4), ox_a = lrow & 15;        // this lane's pixel as the A row of its wave's block
   int buf = 0;
+  float4 fa[2];
+  float fb[2][4][TN2];
 #pragma unroll 1
   for (int ci = 0; ci < NCHUNK; ++ci) {
     if (ci + 1 < NCHUNK) load_wchunk(ci + 1);
@@ -238,19 +271,39 @@ __global__ __launch_bounds__(256, 2) void fsv_spade_conv3_kernel(SpadeConv3P p) 
     const int ty = tap / 3, tx = tap - 3 * ty;
     const float* arow = patch + ((oy_a + ty) * HWD + ox_a + tx) * PS + 32 * chalf + 4 * lk;
     const float* brow = wch + (buf * 32 + 4 * lk) * BNC + lrow;
-#pragma unroll
-    for (int jg = 0; jg < 4; ++jg) {
-      const float4 a4 = *reinterpret_cast<const float4*>(arow + 8 * jg);
-      const float av[4] = {a4.x, a4.y, a4.z, a4.w};
+    auto read_group = [&](int jg, int b) {
+      fa[b] = *reinterpret_cast<const float4*>(arow + 8 * jg);
 #pragma unroll
       for (int s = 0; s < 4; ++s)
 #pragma unroll
-        for (int jn = 0; jn < TN2; ++jn)
-          acc2[jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s], brow[(8 * jg + s) * BNC + 32 * jn], acc2[jn], 0, 0, 0);
+        for (int jn = 0; jn < TN2; ++jn) fb[b][s][jn] = brow[(8 * jg + s) * BNC + 32 * jn];
+    };
+    auto mma_group = [&](int b) {
+      const float av[4] = {fa[b].x, fa[b].y, fa[b].z, fa[b].w};
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int jn = 0; jn < TN2; ++jn) {
+          const int a = TN2 == 1 ? (s & 1) : jn;
+          acc2[a] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s], fb[b][s][jn], acc2[a], 0, 0, 0);
+        }
+    };
+    // the next group's fragments are read from LDS under this group's matrix instructions
+    read_group(0, 0);
+#pragma unroll
+    for (int jg = 0; jg < 4; ++jg) {
+      if (jg + 1 < 4) read_group(jg + 1, (jg + 1) & 1);
+      FSV_SCHED_FENCE();
+      mma_group(jg & 1);
+      FSV_SCHED_FENCE();
     }
     if (ci + 1 < NCHUNK) store_wchunk(buf ^ 1);
     __syncthreads();
     buf ^= 1;
+  }
+  if constexpr (TN2 == 1) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc2[0][r] += acc2[1][r];
   }
 
   // ---- epilogue: D layout col = lane & 31 (channel), row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5) (pixel of the wave's block) ------------
@@ -261,6 +314,7 @@ __global__ __launch_bounds__(256, 2) void fsv_spade_conv3_kernel(SpadeConv3P p) 
   for (int jn = 0; jn < TN2; ++jn) {
     const int co = 32 * jn + lrow;
     const float bv = p.bias ? p.bias[co] : 0.f;
+    float s0 = 0.f, q0 = 0.f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int m = (r & 3) + 8 * (r >> 2) + 4 * lk;
@@ -270,6 +324,15 @@ __global__ __launch_bounds__(256, 2) void fsv_spade_conv3_kernel(SpadeConv3P p) 
         float v = acc2[jn][r] * sc + bv;
         if (res_z) v += res_z[o];
         out_z[o] = v;
+        s0 += v; q0 += v * v;
+      }
+    }
+    if (p.stats) {            // uniform
+      // the two half-waves hold the same 32 channels: fold them, then one fp64 atomic pair per channel and wave (conv_igemm.hip)
+      s0 += __shfl_xor(s0, 32); q0 += __shfl_xor(q0, 32);
+      if (lk == 0) {
+        double* d = p.stats + ((long long)(tile % p.stats_slots) * p.Cout + co) * 2;
+        atomicAdd(d, (double)s0); atomicAdd(d + 1, (double)q0);
       }
     }
   }
@@ -287,13 +350,16 @@ int fsv_spade_conv3_supported(int C, int Cout, int nmaps) {
 // per map k: maps[k] [N][H W][ch[k]] (ch % 4 == 0), wg[k] / wb[k] K-major [ceil32(ch)][ldw] gamma / beta operands, bg[k] / bb[k] [C],
 // w_bstride / b_bstride per-sample strides in floats (0: shared).  wc = the K-major forward operand of the 3x3 weight
 // ([9 C rows = (tap, ci)][ldwc], fsv_prep_weight mode 0), padding 1, stride 1.  hs (optional) receives the modulated + activated
-// tensor.  FSV_ERR_UNSUPPORTED for geometries without a kernel (fsv_spade_conv3_supported).
+// tensor.  stats (optional): fp64 partials [stats_slots][Cout][2] of the stored output's per-channel (sum, sum of squares) over all
+// samples - the BatchNorm statistics of the normalisation that follows, finished by fsv_norm_stats_finish like the gather-GEMM's
+// (fsv_conv_gather_fwd_stats, one group); zeroed here unless stats_prezeroed.
+// FSV_ERR_UNSUPPORTED for geometries without a kernel (fsv_spade_conv3_supported).
 int fsv_spade_conv3_fwd(const float* x, const float* mean, const float* rstd, float* hs, float* out,
                         int nmaps, const float* const* maps, const float* const* wg, const float* const* wb,
                         const float* const* bg, const float* const* bb, const int* ch, const long long* w_bstride,
                         const long long* b_bstride, int N, int H, int W, int C, int ldw, long long stat_bstride, int up, int act,
                         const float* wc, int ldwc, int Cout, const float* bias, const float* res, const float* wscale,
-                        hipStream_t stream) {
+                        double* stats, int stats_slots, int stats_prezeroed, hipStream_t stream) {
   if (!x || !mean || !rstd || !out || !wc || !maps || !wg || !wb || !bg || !bb || !ch || N < 1 || H < 1 || W < 1 || (ldw & 3) ||
       ldwc < Cout || (ldwc & 3))
     return FSV_ERR_BAD_ARG;
@@ -315,8 +381,15 @@ int fsv_spade_conv3_fwd(const float* x, const float* mean, const float* rstd, fl
   p.nmaps = nmaps; p.N = N; p.H = H; p.W = W; p.C = C; p.ldw = ldw; p.stat_bstride = stat_bstride;
   p.up = up ? 1 : 0; p.act = act;
   p.wc = wc; p.bias = bias; p.res = res; p.wscale = wscale; p.Cout = Cout; p.ldwc = ldwc;
+  p.stats = nullptr; p.stats_slots = 1;
+  if (stats) {
+    if (stats_slots < 1) return FSV_ERR_BAD_ARG;
+    p.stats = stats; p.stats_slots = stats_slots;
+    if (!stats_prezeroed) (void)hipMemsetAsync(stats, 0, (size_t)stats_slots * Cout * 2 * sizeof(double), stream);
+  }
   p.tiles_x = fsv_cdiv(W, 16);
-  dim3 g((unsigned)(p.tiles_x * fsv_cdiv(H, 8)), 1, N);
+  p.ntiles = p.tiles_x * fsv_cdiv(H, 8);
+  dim3 g((unsigned)(((p.ntiles + 7) / 8) * 8), 1, N);
   if (Cout == 32) FSV_LAUNCH((fsv_spade_conv3_kernel<1>), g, dim3(256), stream, p);
   else FSV_LAUNCH((fsv_spade_conv3_kernel<2>), g, dim3(256), stream, p);
   return fsv_check_launch();

@@ -59,9 +59,10 @@ lib.register_sigs({
     "fsv_spade_conv_s_fwd": [c_p, c_p, c_p, c_p, c_p, c_i, c_pp, c_pp, c_pp, c_pp, c_pp, c_ip, c_llp, c_llp,
                              c_i, c_i, c_i, c_i, c_ll, c_i, c_i, c_p, c_i, c_i, c_p, c_p],
     "fsv_spade_conv3_supported": [c_i, c_i, c_i],
-    # x mean rstd hs out | nmaps maps wg wb bg bb ch w_bstride b_bstride | N H W C ldw stat_bstride up act | wc ldwc Cout bias res wscale stream
+    # x mean rstd hs out | nmaps maps wg wb bg bb ch w_bstride b_bstride | N H W C ldw stat_bstride up act | wc ldwc Cout bias res wscale |
+    # stats stats_slots stats_prezeroed stream
     "fsv_spade_conv3_fwd": [c_p, c_p, c_p, c_p, c_p, c_i, c_pp, c_pp, c_pp, c_pp, c_pp, c_ip, c_llp, c_llp,
-                            c_i, c_i, c_i, c_i, c_i, c_ll, c_i, c_i, c_p, c_i, c_i, c_p, c_p, c_p, c_p],
+                            c_i, c_i, c_i, c_i, c_i, c_ll, c_i, c_i, c_p, c_i, c_i, c_p, c_p, c_p, c_p, c_i, c_i, c_p],
     "fsv_spade_conv_s_fwd_h": [c_p, c_p, c_p, c_p, c_p, c_i, c_pp, c_pp, c_pp, c_pp, c_pp, c_ip, c_llp, c_llp,
                                c_i, c_i, c_i, c_ll, c_i, c_i, c_p, c_i, c_i, c_p, c_p],
     "fsv_upsample2x_fwd": [c_p, c_p, c_i, c_i, c_i, c_i, c_p],
@@ -441,7 +442,7 @@ class _ConvFn(torch.autograd.Function):
                 y = _spade_conv_s_launch(site, wt, ldw, cout, wscale, want_hs=any(ctx.needs_input_grad))
         elif site3 is not None:
             y = _spade_conv3_launch(site3, wt, ldw, cout, wscale, b, res.detach() if res is not None else None,
-                                    want_hs=any(ctx.needs_input_grad))
+                                    want_hs=any(ctx.needs_input_grad), st=st)
         # (a layer whose output feeds a BatchNorm - the flow decoder's three - loses the statistics epilogue on the placed class
         # launches and reduces in a pass of its own: FSV_UP_SUBPIXEL_STATS=0 keeps such layers on the single gather + fused
         # statistics instead; in-box A/B of round 6: profiles/r06_notes.md)
@@ -1242,8 +1243,9 @@ def _spade_conv3_fits(site, geom, per_sample, res, act, scale, half, cpad, cout,
     return True
 
 
-def _spade_conv3_launch(site, wt, ldwc, cout, wscale, bias, res, want_hs):
-    """out = conv3x3(actvn(bn(x))) (+ bias, + res) in one launch; returns out (NHWC storage, logical NCHW)"""
+def _spade_conv3_launch(site, wt, ldwc, cout, wscale, bias, res, want_hs, st=None):
+    """out = conv3x3(actvn(bn(x))) (+ bias, + res) in one launch; returns out (NHWC storage, logical NCHW).  st: the statistics hint
+    of conv_forward ({'groups': 1}: a BatchNorm follows) - filled with the epilogue's partials like the gather-GEMM's"""
     arr = lambda v: (ctypes.c_void_p * max(len(v), 1))(*v)
     n, hw, c, ldw, w, up = site['dims']
     chs = site['chs']
@@ -1252,13 +1254,21 @@ def _spade_conv3_launch(site, wt, ldwc, cout, wscale, bias, res, want_hs):
     if res is not None:
         res = to_nhwc(res)
     lib.check_device(site['x'], wt, wscale, bias, res)
+    part, prezeroed = None, False
+    if st is not None and int(st['groups']) == 1 and _conv.stats_enabled():
+        part = _conv.stats_arena(out.device).take(_conv.STATS_SLOTS * cout * 2)
+        prezeroed = part is not None
+        if part is None:
+            part = torch.empty(_conv.STATS_SLOTS * cout * 2, dtype=torch.float64, device=out.device)
     with profile.scope('fsv_spade_conv3_kernel' + (' P%d C%d N%d K%s' % (n * hw, c, cout, '+'.join(map(str, chs))) if profile.detail() else ''),
                        site['flops'] + 2.0 * n * hw * 9 * c * cout):
         lib.call("fsv_spade_conv3_fwd", lib.ptr(site['x']), lib.ptr(site['mean']), lib.ptr(site['rstd']),
                  lib.ptr(site['h']) if want_hs else None, lib.ptr(out), len(chs), _pp(site['maps']), arr(site['wg']),
                  arr(site['wb']), arr(site['bg']), arr(site['bb']), lib.int_array(chs + [0]), _ll(site['wstr'] + [0]),
                  _ll(site['bstr'] + [0]), n, hgt, w, c, ldw, 0, up, site['act'], lib.ptr(wt), ldwc, cout, lib.ptr(bias),
-                 lib.ptr(res), lib.ptr(wscale), lib.stream_ptr())
+                 lib.ptr(res), lib.ptr(wscale), lib.ptr(part), _conv.STATS_SLOTS, 1 if prezeroed else 0, lib.stream_ptr())
+    if part is not None:
+        st['part'], st['slots'] = part, _conv.STATS_SLOTS
     return out
 
 

@@ -304,7 +304,8 @@ int fsv_spade_conv_s_fwd_h(const float* x, const float* mean, const float* rstd,
  * GEMMs with swapped operands, operands straight from global memory) and runs the convolution from that patch; the modulated
  * tensor is written only when hs != NULL.  Operands of the modulation as fsv_spade_mod_fwd with the image as (H, W); wc = K-major
  * forward operand of the 3x3 weight ([9 C rows (tap, ci)][ldwc], fsv_prep_weight mode 0); out = acc * wscale + bias (+ res),
- * [N][H W][Cout].  fsv_spade_conv3_supported: 1 when a kernel exists - C == 64, Cout in {32, 64}, 1..3 maps;
+ * [N][H W][Cout]; stats (optional): fp64 partials [stats_slots][Cout][2] of the output's per-channel sums for the BatchNorm that
+ * follows (as fsv_conv_gather_fwd_stats with one group).  fsv_spade_conv3_supported: 1 when a kernel exists - C == 64, Cout in {32, 64}, 1..3 maps;
  * FSV_ERR_UNSUPPORTED otherwise.  Round 6: built and measured against the two-launch form (profiles/r06_notes.md section 8). */
 int fsv_spade_conv3_supported(int C, int Cout, int nmaps);
 int fsv_spade_conv3_fwd(const float* x, const float* mean, const float* rstd, float* hs, float* out,
@@ -312,7 +313,7 @@ int fsv_spade_conv3_fwd(const float* x, const float* mean, const float* rstd, fl
                         const float* const* bg, const float* const* bb, const int* ch, const long long* w_bstride,
                         const long long* b_bstride, int N, int H, int W, int C, int ldw, long long stat_bstride, int up, int act,
                         const float* wc, int ldwc, int Cout, const float* bias, const float* res, const float* wscale,
-                        fsv_stream_t stream);
+                        double* stats, int stats_slots, int stats_prezeroed, fsv_stream_t stream);
 /* backward twin of fsv_spade_mod_fwd: the same operands plus the upstream gradient dh; gamma / beta are recomputed in
  * registers, outputs are dgb[k] = d(gamma | beta) of every map ([P][2C], gamma in columns [0, C)) and dxhat [P][C] (per
  * full-resolution pixel also when up != 0).  act: FSV_ACT_NONE or FSV_ACT_LRELU. */

@@ -1454,6 +1454,15 @@ def check_spade_conv3(device, n=2, c=64, cout=32, chs=(16, 8), h=20, w=24, up=Tr
         finally:
             lib.call = real_call
             os.environ.pop('FSV_SPADE_CONV3', None)
+        # the BatchNorm statistics of the output from the fused launch's own epilogue (as the gather-GEMM's: fp64 partials)
+        ys = getattr(y, '_fsv_stats', None)
+        if fused and conv.stats_enabled():
+            assert ys is not None, 'the fused launch leaves the statistics of its output'
+            part, groups, slots, px, ch_ = ys
+            got = part.view(slots, ch_, 2).sum(0).cpu()
+            yd = y.detach().double().cpu()
+            want = torch.stack([yd.sum(dim=(0, 2, 3)), (yd * yd).sum(dim=(0, 2, 3))], dim=1)
+            assert groups == 1 and px == n * h * w and float((got - want).abs().max()) <= 1e-5 * float(want.abs().max()), (got, want)
         return y.detach(), grads, seen, (rm, rv)
     y1, g1, seen1, st1 = run(False)
     y2, g2, seen2, st2 = run(True)

@@ -2,8 +2,8 @@
 (architecture.py:96-99), isolated and warm, at the widths the fused kernel covers in the two bench workloads:
     two launches    fsv_spade_mod_fwd (writes the modulated tensor) + fsv_conv_gather_fwd[_stats] (3x3, reads it back nine times
                     through L2; the statistics of the output for the next normalisation come from its epilogue)
-    one launch      fsv_spade_conv3_fwd (csrc/spade_conv3.hip), without / with the modulated tensor as a side output; the statistics
-                    of its output then cost a reduction pass of their own (fsv_norm_stats*), timed beside it
+    one launch      fsv_spade_conv3_fwd (csrc/spade_conv3.hip), without / with the modulated tensor as a side output (statistics of
+                    the output from its epilogue as well)
 python tools/spade_conv3_ab.py [--reps 20]     -> one JSON line per shape (microseconds per call, median of 5 rounds)"""
 import argparse
 import json
@@ -88,18 +88,6 @@ def main():
         out['two_launches_total_us'] = round(sum(t2.values()), 1)
         out['fused_us'] = round(t1.get('fsv_spade_conv3_fwd', float('nan')), 1)
         out['fused_with_side_output_us'] = round(t1g.get('fsv_spade_conv3_fwd', float('nan')), 1)
-        # the statistics pass the fused form leaves to the next normalisation (the two-launch form has them from its epilogue)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        samples = []
-        for _ in range(args.rounds):
-            torch.cuda.synchronize()
-            e0.record()
-            for _ in range(args.reps):
-                ops.norm_stats(y1, 1, n * h * w, cout, 1e-5, None, None, 0.1)
-            e1.record()
-            torch.cuda.synchronize()
-            samples.append(e0.elapsed_time(e1) * 1e3 / args.reps)
-        out['statistics_pass_us'] = round(sorted(samples)[len(samples) // 2], 1)
         out['max_rel_diff'] = float((y1 - y2).abs().max() / y2.abs().max())
         px = n * h * w
         flop = 2.0 * px * c * 2 * sum(chs) + 2.0 * px * 9 * c * cout
