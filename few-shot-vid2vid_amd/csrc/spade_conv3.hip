@@ -16,9 +16,10 @@
 //            fragment layout (a lane's 16-byte map vector = four k steps; weight rows are 128-byte coalesced loads) - no staging, no
 //            barrier: the four waves run independently.  Pixels outside the image are stored as zeros: the convolution's padding.
 //   phase 2  the convolution reads its A fragments from the LDS patch at the tap's offset (one ds_read_b128 = four k steps,
-//            conflict-free at a row length of C + 4) and streams its K-major weight in 32-row chunks through a double-buffered LDS
-//            tile (one barrier per chunk).  Each wave finishes a 2 x 16 pixel block for every output channel.
-// 64.5 KB (Cout 32) / 72.7 KB (Cout 64) of LDS: two workgroups per CU.
+//            conflict-free at a row length of C + 4) and streams its K-major weight in 64-row (Cout 32) / 32-row (Cout 64) chunks
+//            through a double-buffered LDS tile (one barrier per chunk).  Each wave finishes a 2 x 16 pixel block for every output
+//            channel.
+// 74.8 KB (Cout 32) / 72.7 KB (Cout 64) of LDS: two workgroups per CU.
 #include "conv_igemm.h"
 
 #define FSV_S3_MAXMAPS 3
@@ -70,9 +71,11 @@ __global__ __launch_bounds__(256, 2) void fsv_spade_conv3_kernel(SpadeConv3P p) 
   constexpr int NU = 3;                                  // (pixel block, channel block) units per wave: 6 x 2 over 4 waves
   constexpr int BNC = 32 * TN2 + 8;                      // row length of a weight chunk in LDS (+ 8: the k halves on different banks)
   constexpr int NKIND = 2 + 2 * FSV_S3_MAXMAPS;
-  constexpr int NCHUNK = 9 * C / 32;
+  constexpr int RW = TN2 == 1 ? 64 : 32;                 // weight rows per chunk of phase 2 (one barrier per chunk)
+  constexpr int NCHUNK = 9 * C / RW;
+  constexpr int WQ = RW * 8 * TN2 / 256;                 // 16-byte vectors of a chunk per work-item
   __shared__ __attribute__((aligned(16))) float patch[192 * PS];
-  __shared__ __attribute__((aligned(16))) float wch[2 * 32 * BNC];
+  __shared__ __attribute__((aligned(16))) float wch[2 * RW * BNC];
   __shared__ __attribute__((aligned(16))) float cst[NKIND * C];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lrow = lane & 31, lk = lane >> 5;
@@ -100,21 +103,21 @@ __global__ __launch_bounds__(256, 2) void fsv_spade_conv3_kernel(SpadeConv3P p) 
 
   // the convolution's first weight chunk is requested now and lands in LDS behind phase 1
   const fsv_buf cbuf = fsv_make_buf(fsv_s3_uniform(p.wc), (long long)9 * C * p.ldwc * 4);
-  float4 wreg[TN2];
+  float4 wreg[WQ];
   auto load_wchunk = [&](int ci) {
 #pragma unroll
-    for (int i = 0; i < TN2; ++i) {
-      const int e = tid + 256 * i;                       // 32 rows x (8 TN2) quads
+    for (int i = 0; i < WQ; ++i) {
+      const int e = tid + 256 * i;                       // RW rows x (8 TN2) quads
       const int row = e / (8 * TN2), q4 = e - row * (8 * TN2);
-      wreg[i] = fsv_buf_load4(cbuf, (unsigned)(((ci * 32 + row) * p.ldwc + 4 * q4) * 4));
+      wreg[i] = fsv_buf_load4(cbuf, (unsigned)(((ci * RW + row) * p.ldwc + 4 * q4) * 4));
     }
   };
   auto store_wchunk = [&](int buf) {
 #pragma unroll
-    for (int i = 0; i < TN2; ++i) {
+    for (int i = 0; i < WQ; ++i) {
       const int e = tid + 256 * i;
       const int row = e / (8 * TN2), q4 = e - row * (8 * TN2);
-      *reinterpret_cast<float4*>(&wch[(buf * 32 + row) * BNC + 4 * q4]) = wreg[i];
+      *reinterpret_cast<float4*>(&wch[(buf * RW + row) * BNC + 4 * q4]) = wreg[i];
     }
   };
   load_wchunk(0);
@@ -156,79 +159,90 @@ __global__ __launch_bounds__(256, 2) void fsv_spade_conv3_kernel(SpadeConv3P p) 
 #pragma unroll
       for (int r = 0; r < 16; ++r) { ag[u][r] = 0.f; ab[u][r] = 0.f; }
 
+    // the k groups (eight map channels each) of ALL maps form one flat sequence whose operands run one group ahead of the matrix
+    // instructions - also across a map boundary (a per-map loop exposed one full memory latency per map); the modulation with map k
+    // sits behind the last group of that map
+    int ngrp[FSV_S3_MAXMAPS], G = 0;
 #pragma unroll
-    for (int k = 0; k < FSV_S3_MAXMAPS; ++k) {
-      if (k < p.nmaps) {
-        const int Ch = p.ch[k];
-        const fsv_buf abuf = fsv_make_buf(fsv_s3_uniform(p.map[k] + (long long)z * HWp * Ch), (long long)HWp * Ch * 4);
-        const long long wbytes = (long long)((Ch + 31) / 32) * 32 * p.ldw * 4;
-        const fsv_buf gbuf = fsv_make_buf(fsv_s3_uniform(p.wg[k] + z * p.w_bstride[k]), wbytes);
-        const fsv_buf bbuf = fsv_make_buf(fsv_s3_uniform(p.wb[k] + z * p.w_bstride[k]), wbytes);
-        const int ngrp = (Ch + 7) / 8;
-        float4 mp[2][NU];
-        float wgv[2][4], wbv[2][4];
-        auto load_group = [&](int j, int b) {
-          const int kk = 8 * j + 4 * lk;                 // this lane's four k of the group: steps s = 0 .. 3
-          const bool kin = (kk < Ch) & (j < ngrp);
+    for (int k = 0; k < FSV_S3_MAXMAPS; ++k) { ngrp[k] = k < p.nmaps ? (p.ch[k] + 7) / 8 : 0; G += ngrp[k]; }
+    auto ngrp_of = [&](int k) { return k == 0 ? ngrp[0] : (k == 1 ? ngrp[1] : ngrp[2]); };
+    float4 mp[2][NU];
+    float wgv[2][4], wbv[2][4];
+    int ld_k = 0, ld_j = 0;                              // the loader's cursor: (map, group)
+    auto load_group = [&](int b) {
+      const bool live = ld_k < p.nmaps;
+      const int k = live ? ld_k : 0;
+      const int Ch = p.ch[k];
+      const fsv_buf abuf = fsv_make_buf(fsv_s3_uniform(p.map[k] + (long long)z * HWp * Ch), (long long)HWp * Ch * 4);
+      const long long wbytes = (long long)((Ch + 31) / 32) * 32 * p.ldw * 4;
+      const fsv_buf gbuf = fsv_make_buf(fsv_s3_uniform(p.wg[k] + z * p.w_bstride[k]), wbytes);
+      const fsv_buf bbuf = fsv_make_buf(fsv_s3_uniform(p.wb[k] + z * p.w_bstride[k]), wbytes);
+      const int kk = 8 * ld_j + 4 * lk;                  // this lane's four k of the group: steps s = 0 .. 3
+      const bool kin = live & (kk < Ch);
 #pragma unroll
-          for (int u = 0; u < NU; ++u)
-            mp[b][u] = fsv_buf_load4(abuf, (kin & (pix[u] >= 0)) ? (unsigned)((pix[u] * Ch + kk) * 4) : FSV_BUF_OOB);
+      for (int u = 0; u < NU; ++u)
+        mp[b][u] = fsv_buf_load4(abuf, (kin & (pix[u] >= 0)) ? (unsigned)((pix[u] * Ch + kk) * 4) : FSV_BUF_OOB);
 #pragma unroll
-          for (int s = 0; s < 4; ++s) {
-            // no mask: rows [Ch, ceil32(Ch)) of the operand are zeros (fsv_spade_prep), rows past it are outside the descriptor
-            // (a select here came back as a branch around the loads with a vmcnt(0) inside - guide trap 4c)
-            const unsigned off = (unsigned)(((kk + s) * p.ldw + 32 * cb + lrow) * 4);
-            wgv[b][s] = fsv_buf_load1(gbuf, off);
-            wbv[b][s] = fsv_buf_load1(bbuf, off);
-          }
-        };
-        auto mma_group = [&](int b) {
-#pragma unroll
-          for (int s = 0; s < 4; ++s)
-#pragma unroll
-            for (int u = 0; u < NU; ++u) {
-              const float m = s == 0 ? mp[b][u].x : (s == 1 ? mp[b][u].y : (s == 2 ? mp[b][u].z : mp[b][u].w));
-              // operands swapped: rows of D = channels (the weight fragment), columns = pixels (the map fragment)
-              ag[u] = __builtin_amdgcn_mfma_f32_32x32x2f32(wgv[b][s], m, ag[u], 0, 0, 0);
-              ab[u] = __builtin_amdgcn_mfma_f32_32x32x2f32(wbv[b][s], m, ab[u], 0, 0, 0);
-            }
-        };
-        load_group(0, 0);
-#pragma unroll 1
-        for (int j = 0; j < ngrp; j += 2) {              // the next group's operands are in flight under this group's MFMAs
-          // (fences: left alone the scheduler sinks the loads below the MFMAs they are meant to hide behind and waits for them
-          // with vmcnt(0) at the top of the next group)
-          load_group(j + 1, 1);
-          FSV_SCHED_FENCE();
-          mma_group(0);
-          FSV_SCHED_FENCE();
-          load_group(j + 2, 0);
-          FSV_SCHED_FENCE();
-          if (j + 1 < ngrp) mma_group(1);
-          FSV_SCHED_FENCE();
-        }
-        // modulation with map k (registers only)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const int c4 = 32 * cb + 8 * q + 4 * lk;
-          const float4 g4 = *reinterpret_cast<const float4*>(&cst[(2 + 2 * k) * C + c4]);
-          const float4 b4 = *reinterpret_cast<const float4*>(&cst[(3 + 2 * k) * C + c4]);
-          const float4 m4 = *reinterpret_cast<const float4*>(&cst[c4]);
-          const float4 r4 = *reinterpret_cast<const float4*>(&cst[C + c4]);
-          const float gq[4] = {g4.x, g4.y, g4.z, g4.w}, bq[4] = {b4.x, b4.y, b4.z, b4.w};
-          const float mu[4] = {m4.x, m4.y, m4.z, m4.w}, rs[4] = {r4.x, r4.y, r4.z, r4.w};
-#pragma unroll
-          for (int u = 0; u < NU; ++u)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              const int r = 4 * q + e;
-              const float o = k == 0 ? (xv[u][r] - mu[e]) * rs[e] : xv[u][r];
-              const float gk = ag[u][r] + gq[e];
-              xv[u][r] = o * (1.f + gk) + (ab[u][r] + bq[e]);
-              ag[u][r] = 0.f; ab[u][r] = 0.f;
-            }
-        }
+      for (int s = 0; s < 4; ++s) {
+        // no mask: rows [Ch, ceil32(Ch)) of the operand are zeros (fsv_spade_prep), rows past it are outside the descriptor
+        // (a select here came back as a branch around the loads with a vmcnt(0) inside - guide trap 4c)
+        const unsigned off = (unsigned)(((kk + s) * p.ldw + 32 * cb + lrow) * 4);
+        wgv[b][s] = fsv_buf_load1(gbuf, off);
+        wbv[b][s] = fsv_buf_load1(bbuf, off);
       }
+      if (++ld_j >= ngrp_of(k)) { ld_j = 0; ++ld_k; }
+    };
+    auto mma_group = [&](int b) {
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int u = 0; u < NU; ++u) {
+          const float m = s == 0 ? mp[b][u].x : (s == 1 ? mp[b][u].y : (s == 2 ? mp[b][u].z : mp[b][u].w));
+          // operands swapped: rows of D = channels (the weight fragment), columns = pixels (the map fragment)
+          ag[u] = __builtin_amdgcn_mfma_f32_32x32x2f32(wgv[b][s], m, ag[u], 0, 0, 0);
+          ab[u] = __builtin_amdgcn_mfma_f32_32x32x2f32(wbv[b][s], m, ab[u], 0, 0, 0);
+        }
+    };
+    auto modulate = [&](int k) {                         // registers only
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int c4 = 32 * cb + 8 * q + 4 * lk;
+        const float4 g4 = *reinterpret_cast<const float4*>(&cst[(2 + 2 * k) * C + c4]);
+        const float4 b4 = *reinterpret_cast<const float4*>(&cst[(3 + 2 * k) * C + c4]);
+        const float4 m4 = *reinterpret_cast<const float4*>(&cst[c4]);
+        const float4 r4 = *reinterpret_cast<const float4*>(&cst[C + c4]);
+        const float gq[4] = {g4.x, g4.y, g4.z, g4.w}, bq[4] = {b4.x, b4.y, b4.z, b4.w};
+        const float mu[4] = {m4.x, m4.y, m4.z, m4.w}, rs[4] = {r4.x, r4.y, r4.z, r4.w};
+#pragma unroll
+        for (int u = 0; u < NU; ++u)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int r = 4 * q + e;
+            const float o = k == 0 ? (xv[u][r] - mu[e]) * rs[e] : xv[u][r];
+            const float gk = ag[u][r] + gq[e];
+            xv[u][r] = o * (1.f + gk) + (ab[u][r] + bq[e]);
+            ag[u][r] = 0.f; ab[u][r] = 0.f;
+          }
+      }
+    };
+    int cs_k = 0, cs_j = 0;                              // the consumer's cursor
+    auto consume = [&](int b) {
+      mma_group(b);
+      if (++cs_j >= ngrp_of(cs_k)) { modulate(cs_k); cs_j = 0; ++cs_k; }
+    };
+    load_group(0);
+#pragma unroll 1
+    for (int g = 0; g < G; g += 2) {
+      // (fences: left alone the scheduler sinks the loads below the MFMAs they are meant to hide behind and waits for them with
+      // vmcnt(0) at the top of the next group)
+      load_group(1);
+      FSV_SCHED_FENCE();
+      consume(0);
+      FSV_SCHED_FENCE();
+      load_group(0);
+      FSV_SCHED_FENCE();
+      if (g + 1 < G) consume(1);
+      FSV_SCHED_FENCE();
     }
     // activation, zero outside the image, into the patch (+ the side output for the pixels this tile owns)
     float* hs_z = p.hs ? p.hs + (long long)z * HWp * C : nullptr;
@@ -267,10 +281,10 @@ __global__ __launch_bounds__(256, 2) void fsv_spade_conv3_kernel(SpadeConv3P p) 
 #pragma unroll 1
   for (int ci = 0; ci < NCHUNK; ++ci) {
     if (ci + 1 < NCHUNK) load_wchunk(ci + 1);
-    const int tap = ci / (C / 32), chalf = ci - tap * (C / 32);
+    const int tap = ci * RW / C, cbase = ci * RW - tap * C;
     const int ty = tap / 3, tx = tap - 3 * ty;
-    const float* arow = patch + ((oy_a + ty) * HWD + ox_a + tx) * PS + 32 * chalf + 4 * lk;
-    const float* brow = wch + (buf * 32 + 4 * lk) * BNC + lrow;
+    const float* arow = patch + ((oy_a + ty) * HWD + ox_a + tx) * PS + cbase + 4 * lk;
+    const float* brow = wch + (buf * RW + 4 * lk) * BNC + lrow;
     auto read_group = [&](int jg, int b) {
       fa[b] = *reinterpret_cast<const float4*>(arow + 8 * jg);
 #pragma unroll
@@ -291,8 +305,8 @@ __global__ __launch_bounds__(256, 2) void fsv_spade_conv3_kernel(SpadeConv3P p) 
     // the next group's fragments are read from LDS under this group's matrix instructions
     read_group(0, 0);
 #pragma unroll
-    for (int jg = 0; jg < 4; ++jg) {
-      if (jg + 1 < 4) read_group(jg + 1, (jg + 1) & 1);
+    for (int jg = 0; jg < RW / 8; ++jg) {
+      if (jg + 1 < RW / 8) read_group(jg + 1, (jg + 1) & 1);
       FSV_SCHED_FENCE();
       mma_group(jg & 1);
       FSV_SCHED_FENCE();
