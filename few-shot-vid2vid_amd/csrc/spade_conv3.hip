@@ -16,10 +16,11 @@
 //            fragment layout (a lane's 16-byte map vector = four k steps; weight rows are 128-byte coalesced loads) - no staging, no
 //            barrier: the four waves run independently.  Pixels outside the image are stored as zeros: the convolution's padding.
 //   phase 2  the convolution reads its A fragments from the LDS patch at the tap's offset (one ds_read_b128 = four k steps,
-//            conflict-free at a row length of C + 4) and streams its K-major weight in 64-row (Cout 32) / 32-row (Cout 64) chunks
-//            through a double-buffered LDS tile (one barrier per chunk).  Each wave finishes a 2 x 16 pixel block for every output
-//            channel.
-// 74.8 KB (Cout 32) / 72.7 KB (Cout 64) of LDS: two workgroups per CU.
+//            conflict-free at a row length of C + 4) and streams its K-major weight in 32-row chunks (FSV_S3_RW=64: 64-row chunks
+//            for Cout 32) through a double-buffered LDS tile (one barrier per chunk).  Each wave finishes a 2 x 16 pixel block for
+//            every output channel.
+// 64.5 KB (Cout 32) / 72.7 KB (Cout 64) of LDS: two workgroups per CU.
+#include <type_traits>
 #include "conv_igemm.h"
 
 #define FSV_S3_MAXMAPS 3
@@ -65,13 +66,13 @@ struct SpadeConv3P {
 };
 
 // TN2 output column blocks of 32 (Cout = 32 TN2); C = 64
-template <int TN2>
+template <int TN2, int RW>
 __global__ __launch_bounds__(256, 2) void fsv_spade_conv3_kernel(SpadeConv3P p) {
   constexpr int C = 64, TH = 8, TW = 16, HWD = TW + 2, HP = (TH + 2) * HWD, PS = C + 4;
   constexpr int NU = 3;                                  // (pixel block, channel block) units per wave: 6 x 2 over 4 waves
   constexpr int BNC = 32 * TN2 + 8;                      // row length of a weight chunk in LDS (+ 8: the k halves on different banks)
   constexpr int NKIND = 2 + 2 * FSV_S3_MAXMAPS;
-  constexpr int RW = TN2 == 1 ? 64 : 32;                 // weight rows per chunk of phase 2 (one barrier per chunk)
+  // RW: weight rows per chunk of phase 2 (one barrier per chunk): 32, or 64 for Cout 32
   constexpr int NCHUNK = 9 * C / RW;
   constexpr int WQ = RW * 8 * TN2 / 256;                 // 16-byte vectors of a chunk per work-item
   __shared__ __attribute__((aligned(16))) float patch[192 * PS];
@@ -159,38 +160,37 @@ __global__ __launch_bounds__(256, 2) void fsv_spade_conv3_kernel(SpadeConv3P p) 
 #pragma unroll
       for (int r = 0; r < 16; ++r) { ag[u][r] = 0.f; ab[u][r] = 0.f; }
 
-    // the k groups (eight map channels each) of ALL maps form one flat sequence whose operands run one group ahead of the matrix
-    // instructions - also across a map boundary (a per-map loop exposed one full memory latency per map); the modulation with map k
-    // sits behind the last group of that map
-    int ngrp[FSV_S3_MAXMAPS], G = 0;
+    // per map: its k groups (eight map channels each) with the operands one group ahead of the matrix instructions; the first group
+    // of the NEXT map is requested under the last group of this one (a loop that started every map cold exposed one memory latency
+    // per map).  (A flat sequence over all maps with run-time map indices was measured slower: descriptors rebuilt per group.)
+    fsv_buf abuf[FSV_S3_MAXMAPS], gbuf[FSV_S3_MAXMAPS], bbuf[FSV_S3_MAXMAPS];
 #pragma unroll
-    for (int k = 0; k < FSV_S3_MAXMAPS; ++k) { ngrp[k] = k < p.nmaps ? (p.ch[k] + 7) / 8 : 0; G += ngrp[k]; }
-    auto ngrp_of = [&](int k) { return k == 0 ? ngrp[0] : (k == 1 ? ngrp[1] : ngrp[2]); };
+    for (int k = 0; k < FSV_S3_MAXMAPS; ++k) {
+      const int kk = k < p.nmaps ? k : 0;
+      const int Ch = p.ch[kk];
+      const long long wbytes = (long long)((Ch + 31) / 32) * 32 * p.ldw * 4;
+      abuf[k] = fsv_make_buf(fsv_s3_uniform(p.map[kk] + (long long)z * HWp * Ch), (long long)HWp * Ch * 4);
+      gbuf[k] = fsv_make_buf(fsv_s3_uniform(p.wg[kk] + z * p.w_bstride[kk]), wbytes);
+      bbuf[k] = fsv_make_buf(fsv_s3_uniform(p.wb[kk] + z * p.w_bstride[kk]), wbytes);
+    }
     float4 mp[2][NU];
     float wgv[2][4], wbv[2][4];
-    int ld_k = 0, ld_j = 0;                              // the loader's cursor: (map, group)
-    auto load_group = [&](int b) {
-      const bool live = ld_k < p.nmaps;
-      const int k = live ? ld_k : 0;
+    auto load_group = [&](auto KC, int j, int b) {
+      constexpr int k = decltype(KC)::value;
       const int Ch = p.ch[k];
-      const fsv_buf abuf = fsv_make_buf(fsv_s3_uniform(p.map[k] + (long long)z * HWp * Ch), (long long)HWp * Ch * 4);
-      const long long wbytes = (long long)((Ch + 31) / 32) * 32 * p.ldw * 4;
-      const fsv_buf gbuf = fsv_make_buf(fsv_s3_uniform(p.wg[k] + z * p.w_bstride[k]), wbytes);
-      const fsv_buf bbuf = fsv_make_buf(fsv_s3_uniform(p.wb[k] + z * p.w_bstride[k]), wbytes);
-      const int kk = 8 * ld_j + 4 * lk;                  // this lane's four k of the group: steps s = 0 .. 3
-      const bool kin = live & (kk < Ch);
+      const int kk = 8 * j + 4 * lk;                     // this lane's four k of the group: steps s = 0 .. 3
+      const bool kin = (kk < Ch) & (k < p.nmaps);
 #pragma unroll
       for (int u = 0; u < NU; ++u)
-        mp[b][u] = fsv_buf_load4(abuf, (kin & (pix[u] >= 0)) ? (unsigned)((pix[u] * Ch + kk) * 4) : FSV_BUF_OOB);
+        mp[b][u] = fsv_buf_load4(abuf[k], (kin & (pix[u] >= 0)) ? (unsigned)((pix[u] * Ch + kk) * 4) : FSV_BUF_OOB);
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
         // no mask: rows [Ch, ceil32(Ch)) of the operand are zeros (fsv_spade_prep), rows past it are outside the descriptor
         // (a select here came back as a branch around the loads with a vmcnt(0) inside - guide trap 4c)
         const unsigned off = (unsigned)(((kk + s) * p.ldw + 32 * cb + lrow) * 4);
-        wgv[b][s] = fsv_buf_load1(gbuf, off);
-        wbv[b][s] = fsv_buf_load1(bbuf, off);
+        wgv[b][s] = fsv_buf_load1(gbuf[k], off);
+        wbv[b][s] = fsv_buf_load1(bbuf[k], off);
       }
-      if (++ld_j >= ngrp_of(k)) { ld_j = 0; ++ld_k; }
     };
     auto mma_group = [&](int b) {
 #pragma unroll
@@ -203,7 +203,25 @@ __global__ __launch_bounds__(256, 2) void fsv_spade_conv3_kernel(SpadeConv3P p) 
           ab[u] = __builtin_amdgcn_mfma_f32_32x32x2f32(wbv[b][s], m, ab[u], 0, 0, 0);
         }
     };
-    auto modulate = [&](int k) {                         // registers only
+    auto one_map = [&](auto KC) {
+      constexpr int k = decltype(KC)::value;
+      constexpr int kn = k + 1 < FSV_S3_MAXMAPS ? k + 1 : k;
+      const int ngrp = (p.ch[k] + 7) / 8;
+#pragma unroll 1
+      for (int j = 0; j < ngrp; j += 2) {
+        // (fences: left alone the scheduler sinks the loads below the MFMAs they are meant to hide behind and waits for them with
+        // vmcnt(0) at the top of the next group)
+        load_group(KC, j + 1, 1);                        // (past the map's end: every lane out of range, zeros, never used)
+        FSV_SCHED_FENCE();
+        mma_group(0);
+        FSV_SCHED_FENCE();
+        if (j + 2 < ngrp) load_group(KC, j + 2, 0);
+        else if (k + 1 < FSV_S3_MAXMAPS && k + 1 < p.nmaps) load_group(std::integral_constant<int, kn>{}, 0, 0);
+        FSV_SCHED_FENCE();
+        if (j + 1 < ngrp) mma_group(1);
+        FSV_SCHED_FENCE();
+      }
+      // modulation with map k (registers only)
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const int c4 = 32 * cb + 8 * q + 4 * lk;
@@ -225,25 +243,10 @@ __global__ __launch_bounds__(256, 2) void fsv_spade_conv3_kernel(SpadeConv3P p) 
           }
       }
     };
-    int cs_k = 0, cs_j = 0;                              // the consumer's cursor
-    auto consume = [&](int b) {
-      mma_group(b);
-      if (++cs_j >= ngrp_of(cs_k)) { modulate(cs_k); cs_j = 0; ++cs_k; }
-    };
-    load_group(0);
-#pragma unroll 1
-    for (int g = 0; g < G; g += 2) {
-      // (fences: left alone the scheduler sinks the loads below the MFMAs they are meant to hide behind and waits for them with
-      // vmcnt(0) at the top of the next group)
-      load_group(1);
-      FSV_SCHED_FENCE();
-      consume(0);
-      FSV_SCHED_FENCE();
-      load_group(0);
-      FSV_SCHED_FENCE();
-      if (g + 1 < G) consume(1);
-      FSV_SCHED_FENCE();
-    }
+    load_group(std::integral_constant<int, 0>{}, 0, 0);
+    one_map(std::integral_constant<int, 0>{});
+    if (p.nmaps > 1) one_map(std::integral_constant<int, 1>{});
+    if (p.nmaps > 2) one_map(std::integral_constant<int, 2>{});
     // activation, zero outside the image, into the patch (+ the side output for the pixels this tile owns)
     float* hs_z = p.hs ? p.hs + (long long)z * HWp * C : nullptr;
 #pragma unroll
@@ -404,8 +407,11 @@ int fsv_spade_conv3_fwd(const float* x, const float* mean, const float* rstd, fl
   p.tiles_x = fsv_cdiv(W, 16);
   p.ntiles = p.tiles_x * fsv_cdiv(H, 8);
   dim3 g((unsigned)(((p.ntiles + 7) / 8) * 8), 1, N);
-  if (Cout == 32) FSV_LAUNCH((fsv_spade_conv3_kernel<1>), g, dim3(256), stream, p);
-  else FSV_LAUNCH((fsv_spade_conv3_kernel<2>), g, dim3(256), stream, p);
+  const char* e = getenv("FSV_S3_RW");                   // in-box A/B: 64-row weight chunks for Cout 32 (half the barriers)
+  const bool rw64 = e && atoi(e) == 64;
+  if (Cout == 32 && rw64) FSV_LAUNCH((fsv_spade_conv3_kernel<1, 64>), g, dim3(256), stream, p);
+  else if (Cout == 32) FSV_LAUNCH((fsv_spade_conv3_kernel<1, 32>), g, dim3(256), stream, p);
+  else FSV_LAUNCH((fsv_spade_conv3_kernel<2, 32>), g, dim3(256), stream, p);
   return fsv_check_launch();
 }
 

@@ -16,5 +16,5 @@ cat "$OUT/ab.jsonl" | tee -a "$OUT/summary.txt"
 t0=$SECONDS
 FSV_SPADE_CONV3=1 timeout 900 python -m pytest tests/test_fullsize_gpu.py -q -m gpu -rf -k "c3_pose_512_b2_full_step or c5_street_1024x512_nc35_fp32" > "$OUT/pytest_full.log" 2>&1
 echo "full-size parity with FSV_SPADE_CONV3=1: exit $? in $((SECONDS-t0))s: $(tail -n 1 "$OUT/pytest_full.log")" | tee -a "$OUT/summary.txt"
-AB_NAME=conv3/step REPS=2 bash tools/hw_ab.sh two_launches fused:FSV_SPADE_CONV3=1
+AB_NAME=conv3/step REPS=2 bash tools/hw_ab.sh two_launches fused:FSV_SPADE_CONV3=1 fused_rw64:FSV_SPADE_CONV3=1,FSV_S3_RW=64
 cat "$OUT/step/summary.txt" >> "$OUT/summary.txt"

@@ -84,9 +84,13 @@ def main():
         t2, y2 = run(False, False, True)
         t1, y1 = run(True, False, True)
         t1g, _ = run(True, True, True)
+        os.environ['FSV_S3_RW'] = '64'                   # 64-row weight chunks in phase 2 (Cout 32 only)
+        t1w, _ = run(True, False, True)
+        os.environ.pop('FSV_S3_RW', None)
         out['two_launches_us'] = {k.replace('fsv_', ''): round(v, 1) for k, v in t2.items()}
         out['two_launches_total_us'] = round(sum(t2.values()), 1)
         out['fused_us'] = round(t1.get('fsv_spade_conv3_fwd', float('nan')), 1)
+        out['fused_rw64_us'] = round(t1w.get('fsv_spade_conv3_fwd', float('nan')), 1)
         out['fused_with_side_output_us'] = round(t1g.get('fsv_spade_conv3_fwd', float('nan')), 1)
         out['max_rel_diff'] = float((y1 - y2).abs().max() / y2.abs().max())
         px = n * h * w
