@@ -16,10 +16,10 @@
 //            fragment layout (a lane's 16-byte map vector = four k steps; weight rows are 128-byte coalesced loads) - no staging, no
 //            barrier: the four waves run independently.  Pixels outside the image are stored as zeros: the convolution's padding.
 //   phase 2  the convolution reads its A fragments from the LDS patch at the tap's offset (one ds_read_b128 = four k steps,
-//            conflict-free at a row length of C + 4) and streams its K-major weight in 32-row chunks (FSV_S3_RW=64: 64-row chunks
-//            for Cout 32) through a double-buffered LDS tile (one barrier per chunk).  Each wave finishes a 2 x 16 pixel block for
+//            conflict-free at a row length of C + 4) and streams its K-major weight in 64-row (Cout 32; FSV_S3_RW=32: 32-row) /
+//            32-row (Cout 64) chunks through a double-buffered LDS tile (one barrier per chunk).  Each wave finishes a 2 x 16 pixel block for
 //            every output channel.
-// 64.5 KB (Cout 32) / 72.7 KB (Cout 64) of LDS: two workgroups per CU.
+// 74.8 KB (Cout 32) / 72.7 KB (Cout 64) of LDS: two workgroups per CU.
 #include <type_traits>
 #include "conv_igemm.h"
 
@@ -407,8 +407,8 @@ int fsv_spade_conv3_fwd(const float* x, const float* mean, const float* rstd, fl
   p.tiles_x = fsv_cdiv(W, 16);
   p.ntiles = p.tiles_x * fsv_cdiv(H, 8);
   dim3 g((unsigned)(((p.ntiles + 7) / 8) * 8), 1, N);
-  const char* e = getenv("FSV_S3_RW");                   // in-box A/B: 64-row weight chunks for Cout 32 (half the barriers)
-  const bool rw64 = e && atoi(e) == 64;
+  const char* e = getenv("FSV_S3_RW");                   // in-box A/B: 32-row weight chunks for Cout 32 as well (64: half the
+  const bool rw64 = !(e && atoi(e) == 32);               // barriers, measured 1 - 2.5 % faster)
   if (Cout == 32 && rw64) FSV_LAUNCH((fsv_spade_conv3_kernel<1, 64>), g, dim3(256), stream, p);
   else if (Cout == 32) FSV_LAUNCH((fsv_spade_conv3_kernel<1, 32>), g, dim3(256), stream, p);
   else FSV_LAUNCH((fsv_spade_conv3_kernel<2, 32>), g, dim3(256), stream, p);

@@ -26,6 +26,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--reps', type=int, default=20)
     ap.add_argument('--rounds', type=int, default=5)
+    ap.add_argument('--only', type=int, default=-1, help='one shape of the list (counter passes)')
     args = ap.parse_args()
     from importlib import import_module
     import fsv2v_amd  # noqa: F401
@@ -35,7 +36,7 @@ def main():
     dev = torch.device('cuda:0')
     g = torch.Generator().manual_seed(1)
     watch = ('fsv_spade_mod_fwd', 'fsv_conv_gather_fwd', 'fsv_conv_gather_fwd_stats', 'fsv_spade_conv3_fwd')
-    for (tag, n, c, cout, chs, h, w, up, res) in SHAPES:
+    for (tag, n, c, cout, chs, h, w, up, res) in (SHAPES if args.only < 0 else SHAPES[args.only:args.only + 1]):
         xs = (h // 2, w // 2) if up else (h, w)
         cl = lambda t: t.to(dev).contiguous(memory_format=torch.channels_last)
         x = cl(torch.randn(n, c, *xs, generator=g))
@@ -84,13 +85,13 @@ def main():
         t2, y2 = run(False, False, True)
         t1, y1 = run(True, False, True)
         t1g, _ = run(True, True, True)
-        os.environ['FSV_S3_RW'] = '64'                   # 64-row weight chunks in phase 2 (Cout 32 only)
+        os.environ['FSV_S3_RW'] = '32'                   # 32-row weight chunks in phase 2 (Cout 32: 64 by default)
         t1w, _ = run(True, False, True)
         os.environ.pop('FSV_S3_RW', None)
         out['two_launches_us'] = {k.replace('fsv_', ''): round(v, 1) for k, v in t2.items()}
         out['two_launches_total_us'] = round(sum(t2.values()), 1)
         out['fused_us'] = round(t1.get('fsv_spade_conv3_fwd', float('nan')), 1)
-        out['fused_rw64_us'] = round(t1w.get('fsv_spade_conv3_fwd', float('nan')), 1)
+        out['fused_rw32_us'] = round(t1w.get('fsv_spade_conv3_fwd', float('nan')), 1)
         out['fused_with_side_output_us'] = round(t1g.get('fsv_spade_conv3_fwd', float('nan')), 1)
         out['max_rel_diff'] = float((y1 - y2).abs().max() / y2.abs().max())
         px = n * h * w
