@@ -30,13 +30,7 @@
 // loads through it need no per-load waterfall loop (first build of this kernel: 139 of them, guide T20).
 #ifdef FSV_EMU
 template <typename T> static inline T* fsv_s3_uniform(T* q) { return q; }
-#define FSV_S3_OPAQUE_S(v) ((void)0)
-#define FSV_S3_OPAQUE_V(v) ((void)0)
 #else
-// the value is re-materialised here as far as the optimiser can tell: nothing derived from it is hoisted out of the tile loop
-// (hoisted, the per-tile invariants - descriptors, lane offsets - cost 64 scalar and 40 vector registers of spills)
-#define FSV_S3_OPAQUE_S(v) asm volatile("" : "+s"(v))
-#define FSV_S3_OPAQUE_V(v) asm volatile("" : "+v"(v))
 template <typename T> __device__ __forceinline__ T* fsv_s3_uniform(T* q) {
   const unsigned long long a = (unsigned long long)q;
   const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a), hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
@@ -84,40 +78,31 @@ __global__ __launch_bounds__(256, 2) void fsv_spade_conv3_kernel(SpadeConv3P p) 
   __shared__ __attribute__((aligned(16))) float patch[192 * PS];
   __shared__ __attribute__((aligned(16))) float wch[2 * RW * BNC];
   __shared__ __attribute__((aligned(16))) float cst[NKIND * C];
-  const int tid0 = threadIdx.x;
-  const int z0 = blockIdx.z;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lrow = lane & 31, lk = lane >> 5;
+  const int z = blockIdx.z;
   // workgroups go to the eight XCDs round-robin: XCD i takes the i-th CONTIGUOUS eighth of the tiles, so that the halo rows two
-  // neighbouring tiles share (and the label maps under them) are fetched into one L2
-  // A workgroup walks its XCD's tiles with the stride of the workgroups resident there (the host launches no more than stay
-  // resident): the per-channel constants are fetched once, and a tile starts without a dispatch in front of it.
+  // neighbouring tiles share (and the label maps under them) are fetched into one L2.  (One workgroup per tile: a resident grid of
+  // tile walkers was measured 3 - 4 % slower and read 17 % more - the tiles in flight at one time are then a stride apart.)
   const int per_xcd = (p.ntiles + 7) >> 3;
-  const int tile_last = (((int)blockIdx.x & 7) + 1) * per_xcd;
-  const int tile_end = tile_last < p.ntiles ? tile_last : p.ntiles;
-  const int tile_step = (int)gridDim.x >> 3;
+  const int tile = ((int)blockIdx.x & 7) * per_xcd + ((int)blockIdx.x >> 3);
+  if (tile >= p.ntiles) return;
+  const int tyi = tile / p.tiles_x, txi = tile - tyi * p.tiles_x;
+  const int y0 = tyi * TH, x0 = txi * TW;
   const int H = p.H, W = p.W, HWp = H * W;
 
-  for (int i = tid0; i < NKIND * C; i += 256) {
+  for (int i = tid; i < NKIND * C; i += 256) {
     const int kind = i / C, c = i - kind * C;
     float v = 0.f;
-    if (kind == 0) v = (p.mean + z0 * p.stat_bstride)[c];
-    else if (kind == 1) v = (p.rstd + z0 * p.stat_bstride)[c];
+    if (kind == 0) v = (p.mean + z * p.stat_bstride)[c];
+    else if (kind == 1) v = (p.rstd + z * p.stat_bstride)[c];
     else {
       const int k = (kind - 2) >> 1;
-      if (k < p.nmaps) v = (((kind & 1) ? p.bb[k] : p.bg[k]) + z0 * p.b_bstride[k])[c];
+      if (k < p.nmaps) v = (((kind & 1) ? p.bb[k] : p.bg[k]) + z * p.b_bstride[k])[c];
     }
     cst[i] = v;
   }
 
-  __syncthreads();                                       // publishes cst
-#pragma unroll 1
-  for (int tile = ((int)blockIdx.x & 7) * per_xcd + ((int)blockIdx.x >> 3); tile < tile_end; tile += tile_step) {
-  int tid = tid0, z = z0;
-  FSV_S3_OPAQUE_V(tid);
-  FSV_S3_OPAQUE_S(z);
-  const int lane = tid & 63, wave = tid >> 6;
-  const int lrow = lane & 31, lk = lane >> 5;
-  const int tyi = tile / p.tiles_x, txi = tile - tyi * p.tiles_x;
-  const int y0 = tyi * TH, x0 = txi * TW;
   // the convolution's first weight chunk is requested now and lands in LDS behind phase 1
   const fsv_buf cbuf = fsv_make_buf(fsv_s3_uniform(p.wc), (long long)9 * C * p.ldwc * 4);
   float4 wreg[WQ];
@@ -138,6 +123,7 @@ __global__ __launch_bounds__(256, 2) void fsv_spade_conv3_kernel(SpadeConv3P p) 
     }
   };
   load_wchunk(0);
+  __syncthreads();                                       // publishes cst
 
   // ---- phase 1: h of the haloed tile into the LDS patch ------------------------------------------------------------------------------
   {
@@ -178,32 +164,33 @@ __global__ __launch_bounds__(256, 2) void fsv_spade_conv3_kernel(SpadeConv3P p) 
     // per map: its k groups (eight map channels each) with the operands one group ahead of the matrix instructions; the first group
     // of the NEXT map is requested under the last group of this one (a loop that started every map cold exposed one memory latency
     // per map).  (A flat sequence over all maps with run-time map indices was measured slower: descriptors rebuilt per group.)
-    // (descriptors of one map at a time: all nine at once spilled scalar registers into vector registers)
-    struct MapBufs { fsv_buf a, g, b; int Ch; };
-    auto bufs_of = [&](int k) {
-      MapBufs m;
-      m.Ch = p.ch[k];
-      const long long wbytes = (long long)((m.Ch + 31) / 32) * 32 * p.ldw * 4;
-      m.a = fsv_make_buf(fsv_s3_uniform(p.map[k] + (long long)z * HWp * m.Ch), (long long)HWp * m.Ch * 4);
-      m.g = fsv_make_buf(fsv_s3_uniform(p.wg[k] + z * p.w_bstride[k]), wbytes);
-      m.b = fsv_make_buf(fsv_s3_uniform(p.wb[k] + z * p.w_bstride[k]), wbytes);
-      return m;
-    };
+    fsv_buf abuf[FSV_S3_MAXMAPS], gbuf[FSV_S3_MAXMAPS], bbuf[FSV_S3_MAXMAPS];
+#pragma unroll
+    for (int k = 0; k < FSV_S3_MAXMAPS; ++k) {
+      const int kk = k < p.nmaps ? k : 0;
+      const int Ch = p.ch[kk];
+      const long long wbytes = (long long)((Ch + 31) / 32) * 32 * p.ldw * 4;
+      abuf[k] = fsv_make_buf(fsv_s3_uniform(p.map[kk] + (long long)z * HWp * Ch), (long long)HWp * Ch * 4);
+      gbuf[k] = fsv_make_buf(fsv_s3_uniform(p.wg[kk] + z * p.w_bstride[kk]), wbytes);
+      bbuf[k] = fsv_make_buf(fsv_s3_uniform(p.wb[kk] + z * p.w_bstride[kk]), wbytes);
+    }
     float4 mp[2][NU];
     float wgv[2][4], wbv[2][4];
-    auto load_group = [&](const MapBufs& m, int j, int b) {
+    auto load_group = [&](auto KC, int j, int b) {
+      constexpr int k = decltype(KC)::value;
+      const int Ch = p.ch[k];
       const int kk = 8 * j + 4 * lk;                     // this lane's four k of the group: steps s = 0 .. 3
-      const bool kin = kk < m.Ch;
+      const bool kin = (kk < Ch) & (k < p.nmaps);
 #pragma unroll
       for (int u = 0; u < NU; ++u)
-        mp[b][u] = fsv_buf_load4(m.a, (kin & (pix[u] >= 0)) ? (unsigned)((pix[u] * m.Ch + kk) * 4) : FSV_BUF_OOB);
+        mp[b][u] = fsv_buf_load4(abuf[k], (kin & (pix[u] >= 0)) ? (unsigned)((pix[u] * Ch + kk) * 4) : FSV_BUF_OOB);
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
         // no mask: rows [Ch, ceil32(Ch)) of the operand are zeros (fsv_spade_prep), rows past it are outside the descriptor
         // (a select here came back as a branch around the loads with a vmcnt(0) inside - guide trap 4c)
         const unsigned off = (unsigned)(((kk + s) * p.ldw + 32 * cb + lrow) * 4);
-        wgv[b][s] = fsv_buf_load1(m.g, off);
-        wbv[b][s] = fsv_buf_load1(m.b, off);
+        wgv[b][s] = fsv_buf_load1(gbuf[k], off);
+        wbv[b][s] = fsv_buf_load1(bbuf[k], off);
       }
     };
     auto mma_group = [&](int b) {
@@ -220,18 +207,17 @@ __global__ __launch_bounds__(256, 2) void fsv_spade_conv3_kernel(SpadeConv3P p) 
     auto one_map = [&](auto KC) {
       constexpr int k = decltype(KC)::value;
       constexpr int kn = k + 1 < FSV_S3_MAXMAPS ? k + 1 : k;
-      const MapBufs cur = bufs_of(k);
-      const int ngrp = (cur.Ch + 7) / 8;
+      const int ngrp = (p.ch[k] + 7) / 8;
 #pragma unroll 1
       for (int j = 0; j < ngrp; j += 2) {
         // (fences: left alone the scheduler sinks the loads below the MFMAs they are meant to hide behind and waits for them with
         // vmcnt(0) at the top of the next group)
-        load_group(cur, j + 1, 1);                       // (past the map's end: every lane out of range, zeros, never used)
+        load_group(KC, j + 1, 1);                        // (past the map's end: every lane out of range, zeros, never used)
         FSV_SCHED_FENCE();
         mma_group(0);
         FSV_SCHED_FENCE();
-        if (j + 2 < ngrp) load_group(cur, j + 2, 0);
-        else if (k + 1 < FSV_S3_MAXMAPS && k + 1 < p.nmaps) load_group(bufs_of(kn), 0, 0);
+        if (j + 2 < ngrp) load_group(KC, j + 2, 0);
+        else if (k + 1 < FSV_S3_MAXMAPS && k + 1 < p.nmaps) load_group(std::integral_constant<int, kn>{}, 0, 0);
         FSV_SCHED_FENCE();
         if (j + 1 < ngrp) mma_group(1);
         FSV_SCHED_FENCE();
@@ -258,7 +244,7 @@ __global__ __launch_bounds__(256, 2) void fsv_spade_conv3_kernel(SpadeConv3P p) 
           }
       }
     };
-    load_group(bufs_of(0), 0, 0);
+    load_group(std::integral_constant<int, 0>{}, 0, 0);
     one_map(std::integral_constant<int, 0>{});
     if (p.nmaps > 1) one_map(std::integral_constant<int, 1>{});
     if (p.nmaps > 2) one_map(std::integral_constant<int, 2>{});
@@ -368,7 +354,6 @@ __global__ __launch_bounds__(256, 2) void fsv_spade_conv3_kernel(SpadeConv3P p) 
       }
     }
   }
-  }   // (the last chunk's barrier stands between this tile's patch reads and the next tile's patch writes)
 }
 
 extern "C" {
@@ -422,14 +407,7 @@ int fsv_spade_conv3_fwd(const float* x, const float* mean, const float* rstd, fl
   }
   p.tiles_x = fsv_cdiv(W, 16);
   p.ntiles = p.tiles_x * fsv_cdiv(H, 8);
-  // as many tile walkers as stay resident (two workgroups per CU), a multiple of eight (the XCD mapping)
-  int gx = ((p.ntiles + 7) / 8) * 8;
-  int cap = (256 * 2 / N) / 8 * 8;
-  const char* ge = getenv("FSV_SPADE_MAX_GX");             // tests: a multi-tile walk on a small map
-  if (ge && atoi(ge) > 0) cap = (atoi(ge) + 7) / 8 * 8;
-  if (cap < 8) cap = 8;
-  if (gx > cap) gx = cap;
-  dim3 g((unsigned)gx, 1, N);
+  dim3 g((unsigned)(((p.ntiles + 7) / 8) * 8), 1, N);
   const char* e = getenv("FSV_S3_RW");                   // in-box A/B: 32-row weight chunks for Cout 32 as well (64: half the
   const bool rw64 = !(e && atoi(e) == 32);               // barriers, measured 1 - 2.5 % faster)
   if (Cout == 32 && rw64) FSV_LAUNCH((fsv_spade_conv3_kernel<1, 64>), g, dim3(256), stream, p);

@@ -1392,14 +1392,13 @@ def _check_spade_conv_s(device, ops, conv, n, c, cout, chs, h, w, up, grad, spec
 
 
 def check_spade_conv3(device, n=2, c=64, cout=32, chs=(16, 8), h=20, w=24, up=True, grad=True, spectral=True, res=False, act='lrelu',
-                      seed=59, max_gx=None):
+                      seed=59):
     """dx = conv_0(actvn(bn_0(x, maps))) / conv_1(actvn(bn_1(dx, maps))) + x_s (architecture.py:96-99) through
     ops.spade_into_conv(conv3=True) - ONE launch of csrc/spade_conv3.hip (the modulated haloed tile in LDS, round 6) - against the same
     two operators launched one after the other AND against the oracle directly (normalization.py:37-52 + leaky_relu + the 3x3
     spectral-norm convolution restated by oracle/fsv_oracle.py): output within the fp32 summation-order band, gradients equal (the
     backward passes are the same two nodes; the training forward writes the modulated tensor as a side output).  Sizes that are not a
-    multiple of the 8 x 16 tile exercise the partial tiles; every tile has halo pixels outside the image (the convolution's padding).
-    max_gx: FSV_SPADE_MAX_GX - a workgroup then walks several tiles of its XCD's share."""
+    multiple of the 8 x 16 tile exercise the partial tiles; every tile has halo pixels outside the image (the convolution's padding)."""
     import contextlib
     from importlib import import_module
     ops, conv = pkg()
@@ -1441,8 +1440,6 @@ def check_spade_conv3(device, n=2, c=64, cout=32, chs=(16, 8), h=20, w=24, up=Tr
             return real_call(name, *a)
         lib.call = recording_call
         os.environ['FSV_SPADE_CONV3'] = '1' if fused else '0'
-        if max_gx:
-            os.environ['FSV_SPADE_MAX_GX'] = str(max_gx)
         try:
             with (contextlib.nullcontext() if grad else torch.no_grad()):
                 with ops.spade_into_conv(conv3=True):
@@ -1457,7 +1454,6 @@ def check_spade_conv3(device, n=2, c=64, cout=32, chs=(16, 8), h=20, w=24, up=Tr
         finally:
             lib.call = real_call
             os.environ.pop('FSV_SPADE_CONV3', None)
-            os.environ.pop('FSV_SPADE_MAX_GX', None)
         # the BatchNorm statistics of the output from the fused launch's own epilogue (as the gather-GEMM's: fp64 partials)
         ys = getattr(y, '_fsv_stats', None)
         if fused and conv.stats_enabled():

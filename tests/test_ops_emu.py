@@ -185,7 +185,6 @@ def test_spade_modulation_fused_with_the_3x3_convolution(emu_lib):
     oc.check_spade_conv3(DEV, cout=64, chs=(8, 8, 4), h=13, w=19, up=False, res=True)             # ragged tiles, three maps, residual
     oc.check_spade_conv3(DEV, cout=32, chs=(36,), h=8, w=16, up=False, grad=False, spectral=False)   # no graph: hs never written; k % 8 != 0
     oc.check_spade_conv3(DEV, cout=64, chs=(32, 32), h=18, w=34, up=True, act='none', grad=False, res=True)
-    oc.check_spade_conv3(DEV, n=1, cout=32, chs=(8,), h=40, w=56, up=False, grad=False, max_gx=8)      # 20 tiles on 8 walkers: 2 - 3 tiles each
 
 
 def test_spade_two_site_launch(emu_lib):

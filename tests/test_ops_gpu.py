@@ -190,7 +190,6 @@ def test_spade_modulation_fused_with_the_3x3_convolution(hip_lib):
     oc.check_spade_conv3(dev(), cout=64, chs=(8, 8, 4), h=13, w=19, up=False, res=True)             # ragged tiles, three maps, residual
     oc.check_spade_conv3(dev(), cout=32, chs=(36,), h=8, w=16, up=False, grad=False, spectral=False)   # no graph; k % 8 != 0
     oc.check_spade_conv3(dev(), cout=64, chs=(32, 32), h=18, w=34, up=True, act='none', grad=False, res=True)
-    oc.check_spade_conv3(dev(), n=1, cout=32, chs=(8,), h=40, w=56, up=False, grad=False, max_gx=8)      # 20 tiles on 8 walkers: 2 - 3 tiles each
     oc.check_spade_conv3(dev(), n=2, c=64, cout=32, chs=(32, 32), h=64, w=96, up=True)               # many tiles, both workgroups of a CU
     oc.check_spade_conv3(dev(), n=1, c=64, cout=64, chs=(64, 64), h=48, w=80, up=False, res=True, grad=False)
 
