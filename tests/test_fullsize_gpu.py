@@ -152,6 +152,26 @@ def test_c3_pose_512_b2_in_the_schedule_bench_py_runs(hip_lib):
     mc.check_train_step_golden(DEV, opt, 'pose_fullsize', tol=1e-3, grad_tol=1e-2, bench_schedule=True)
 
 
+def test_c3_pose_512_b2_with_the_3x3_spade_fusion(hip_lib, monkeypatch):
+    """The bench workload with `FSV_SPADE_CONV3=1` (round 6, opt-in): the level-0 `conv_0` and level-1 `conv_1` of the generator's
+    SPADE blocks run as ONE kernel with their modulation + activation (csrc/spade_conv3.hip, the modulated haloed tile in LDS) in
+    both generator passes - the whole iteration against the reference's own (fixture) at the bars of the default path, and the
+    fused entry point must actually have been the one that ran (both widths, with and without the side output)."""
+    from importlib import import_module
+    lib = import_module('few-shot-vid2vid_amd.lib')
+    monkeypatch.setenv('FSV_SPADE_CONV3', '1')
+    seen, real_call = [], lib.call
+
+    def recording_call(name, *a):
+        if name == 'fsv_spade_conv3_fwd':
+            seen.append((a[24], a[3] is not None))         # (Cout, side output requested)
+        return real_call(name, *a)
+    monkeypatch.setattr(lib, 'call', recording_call)
+    worst = mc.check_train_step_golden(DEV, _c3(), 'pose_fullsize', tol=1e-3, grad_tol=1e-2)
+    print('C3 with the 3x3 SPADE fusion vs the reference fixture: worst generator-gradient sketch distance %.3e of its norm' % worst)
+    assert {(32, False), (32, True), (64, False), (64, True)} <= set(seen), sorted(set(seen))
+
+
 def test_c4_pose_512_face_d_vgg(hip_lib):
     """BASELINE.json configs[3] per rank (scripts/pose/train_g8.sh:8-10: the C3 flags + --add_face_D, which brings the VGG19 loss
     with it - loss_collector.py:70-85): full width, 512x512, the per-GPU batch of 2, full D step (netD + netDf) + G step against
