@@ -339,6 +339,22 @@ def _stats_from_producer(x, groups, pixels, channels, eps, run_mean, run_var, mo
     return mean, rstd
 
 
+# `ctx.needs_input_grad` of a custom Function says which inputs REQUIRE a gradient - it is (.., True, ..) for a module's weight also
+# inside `torch.no_grad()` (round 6: the no-graph generator pass of the discriminator step had been asking the fused SPADE kernels for
+# their side outputs, a 134 MB write per level-0 site that nobody read), and grad mode is always off inside forward().  The wrappers
+# below note the caller's grad mode right before .apply (same thread, synchronous).
+_outer_grad = _threading.local()
+
+
+def _note_grad_mode():
+    _outer_grad.on = torch.is_grad_enabled()
+
+
+def _keeps_graph(ctx):
+    """will this forward have a backward? (some input requires a gradient AND the caller records a graph)"""
+    return bool(any(ctx.needs_input_grad) and getattr(_outer_grad, 'on', True))
+
+
 class _ConvFn(torch.autograd.Function):
     """y = act((conv(x, W * inv_sigma) + bias) * scale) + res.  W: OIHW, or [B]OIHW for per-sample weights."""
 
@@ -437,12 +453,12 @@ class _ConvFn(torch.autograd.Function):
             # x is the output of the held-back bn_s modulation and the fused kernel covers the pair (checked above)
             if half:          # the N-major half twin of the layout the half-precision convolution would read
                 wh, kpad_h, _ = _conv.half_twin(wt)
-                y = _spade_conv_s_launch(site, wh, kpad_h, cout, wscale, want_hs=any(ctx.needs_input_grad))
+                y = _spade_conv_s_launch(site, wh, kpad_h, cout, wscale, want_hs=_keeps_graph(ctx))
             else:
-                y = _spade_conv_s_launch(site, wt, ldw, cout, wscale, want_hs=any(ctx.needs_input_grad))
+                y = _spade_conv_s_launch(site, wt, ldw, cout, wscale, want_hs=_keeps_graph(ctx))
         elif site3 is not None:
             y = _spade_conv3_launch(site3, wt, ldw, cout, wscale, b, res.detach() if res is not None else None,
-                                    want_hs=any(ctx.needs_input_grad), st=st)
+                                    want_hs=_keeps_graph(ctx), st=st)
         # (a layer whose output feeds a BatchNorm - the flow decoder's three - loses the statistics epilogue on the placed class
         # launches and reduces in a pass of its own: FSV_UP_SUBPIXEL_STATS=0 keeps such layers on the single gather + fused
         # statistics instead; in-box A/B of round 6: profiles/r06_notes.md)
@@ -458,7 +474,7 @@ class _ConvFn(torch.autograd.Function):
         ctx.has_bias, ctx.has_res, ctx.has_sn = bias is not None, res is not None, sig is not None
         ctx.bias_ref = bias                      # the leaf itself (its .grad slice is the sink target), not saved data
         ctx.x_shape = tuple(x.shape)
-        if not any(ctx.needs_input_grad):
+        if not _keeps_graph(ctx):
             return y                     # forward under no_grad (the D step's generator pass): nothing to keep
         if ctx.has_sn:
             # u / v of the persistent buffers are overwritten by the next power iteration: keep this call's values
@@ -748,6 +764,7 @@ def conv2d(x, weight, bias=None, stride=1, padding=0, act=ACT_NONE, scale=1.0, r
     sig, u, v, owned = _unpack_sn(sn)
     groups = (x.shape[0] if stats_groups < 0 else stats_groups) if stats_groups else 0
     # up: the convolution of nearest_x2(x) (ops._ConvFn.forward: folded into the gather where the launch allows)
+    _note_grad_mode()
     y = _ConvFn.apply(x, weight, bias, res, sig, u, v, geom, act, scale, owned, groups, True, bool(up))
     st = getattr(_conv_stats_tls, 'last', None)
     if groups and st is not None:
@@ -762,6 +779,7 @@ def linear(x2d, weight, bias=None, act=ACT_NONE, sn=None):
     x4 = x2d.contiguous().view(1, 1, r, cin).permute(0, 3, 1, 2)
     sig, u, v, owned = _unpack_sn(sn)
     # (nn.Linear = the weight generators: fp32 also under `--amp`, like the grouped bank below - see mlp_bank)
+    _note_grad_mode()
     y4 = _ConvFn.apply(x4, weight, bias, None, sig, u, v, Geom(1, 1, 1, 0), act, 1.0, owned, 0, False)
     return y4.permute(0, 2, 3, 1).reshape(r, weight.shape[0])
 
@@ -967,6 +985,7 @@ def batch_conv(x, weight, bias=None, act=ACT_NONE, stride=1, allow_half=True):
     geom = Geom(k, k, int(stride), k // 2)
     # weights / biases are usually strided views into the weight-generating FC's output: conv.prep_weight / gather_gemm
     # read them in place (sample stride), no copies here
+    _note_grad_mode()
     return _ConvFn.apply(x, weight, bias, None, None, None, None, geom, act, 1.0, False, 0, allow_half)
 
 
@@ -1429,7 +1448,7 @@ class _SpadeFn(torch.autograd.Function):
                 # columns only feed output channels >= C, which are never stored
                 flat_t = torch.empty(nb * kt * 2 * c + 64, dtype=torch.float32, device=x.device)
                 wcat_t = flat_t[:nb * kt * 2 * c].view(nb, kt, 2 * c)
-                need_d = ctx.needs_input_grad[7 + 5 * k] or owner is not None      # (cached: whichever pass comes next may need it)
+                need_d = (ctx.needs_input_grad[7 + 5 * k] and getattr(_outer_grad, 'on', True)) or owner is not None      # (cached: whichever pass comes next may need it)
                 wcat_d = torch.empty((nb, kd, ld), dtype=torch.float32, device=x.device) if need_d else None
                 bcat = torch.empty((nb, 2 * c), dtype=torch.float32, device=x.device)
                 lib.check_device(wg, wb, bg, bb)
@@ -1654,6 +1673,7 @@ def spade_mod(x, maps, weights, run_mean=None, run_var=None, act=ACT_LRELU, trai
     flat = []
     for m, (wg, wb, bg, bb) in zip(maps, weights):
         flat += [m, wg, wb, bg, bb]
+    _note_grad_mode()
     return _SpadeFn.apply((act, 1) if up else act, training, eps, momentum, x, run_mean, run_var, *flat)
 
 

@@ -1321,7 +1321,9 @@ def _check_spade_conv_s(device, ops, conv, n, c, cout, chs, h, w, up, grad, spec
         xd = cl(x).requires_grad_(grad)
         md = [cl(m).requires_grad_(grad) for m in maps]
         wd = [tuple(_dev(t, device).detach().clone().requires_grad_(grad) for t in ws) for ws in wts]
-        wc = _dev(wconv, device).detach().clone().requires_grad_(grad)
+        # (the convolution's weight is a module parameter: it requires a gradient also in the forward that keeps no graph - the
+        # kernel must not be asked for its side output there, round 6)
+        wc = _dev(wconv, device).detach().clone().requires_grad_(True)
         rm, rv = _dev(torch.zeros(c), device), _dev(torch.ones(c), device)
         u, v = _dev(u0.clone(), device), _dev(v0.clone(), device)
         seen, real_call = [], lib.call
@@ -1428,8 +1430,9 @@ def check_spade_conv3(device, n=2, c=64, cout=32, chs=(16, 8), h=20, w=24, up=Tr
         xd = cl(x).requires_grad_(grad)
         md = [cl(m).requires_grad_(grad) for m in maps]
         wd = [tuple(_dev(t, device).detach().clone().requires_grad_(grad) for t in ws) for ws in wts]
-        wc = _dev(wconv, device).detach().clone().requires_grad_(grad)
-        bc = _dev(bconv, device).detach().clone().requires_grad_(grad)
+        # (module parameters: they require a gradient also in the forward that keeps no graph - no side output there)
+        wc = _dev(wconv, device).detach().clone().requires_grad_(True)
+        bc = _dev(bconv, device).detach().clone().requires_grad_(True)
         rd = cl(rs).requires_grad_(grad) if res else None
         rm, rv = _dev(torch.zeros(c), device), _dev(torch.ones(c), device)
         u, v = _dev(u0.clone(), device), _dev(v0.clone(), device)
