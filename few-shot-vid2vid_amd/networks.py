@@ -635,6 +635,10 @@ class FewShotGenerator(nn.Module):
         for a, l in zip(fi, fl):
             b, c, h, w = a.shape
             sm = ops.softmax_channels(l)
+            if ops.pooled_product_ready(a, sm):
+                # round 6: the product over positions as a per-sample 1x1 weight-gradient GEMM - both operands read in place
+                enc.append(ops.pooled_product(a, sm))                               # [b, c(i), c(j), 1]
+                continue
             # prod[b, i, j] = sum_p a[b, i, p] * sm[b, j, p]  as a per-sample 1x1 "convolution" on the gather-GEMM
             # kernel: pixels = image channels i, input channels = positions p, generated weights = softmax rows j
             a_rows = a.reshape(b, c, 1, h * w).permute(0, 3, 1, 2)              # logical [b, hw, c, 1]

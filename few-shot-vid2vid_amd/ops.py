@@ -975,6 +975,57 @@ def mlp_bank(rows, chains):
     return list(_MlpBankFn.apply(meta, *flat))
 
 
+class _PooledFn(torch.autograd.Function):
+    """prod[b, i, j] = sum_p a[b, i, p] * sm[b, j, p]: the softmax pooling of the reference encoder (generator.py:378-389,
+    `torch.bmm(x, softmax(label).transpose)`), a and sm NCHW tensors in channels-last memory.
+
+    Both operands lie in memory as [position p][channel]: the product over positions is exactly the shape of a per-sample 1x1
+    WEIGHT-GRADIENT GEMM, `dwt[ci][co] = sum_pixels in[pixel][ci] * dout[pixel][co]`, whose kernel reads both of them in place
+    (round 6; before: a transposed copy of each operand + a K-major re-arrangement + a gather-GEMM whose "pixels" were the 32 ...
+    1024 channels - four launches per level and pass, 17 - 26 us for the GEMM alone on the 16x16 maps).  One launch, one split
+    (direct stores, fixed summation order).  Backward in the operands' own layouts as well: d a[p][i] = sum_j sm[p][j] dprod[i][j] and
+    d sm[p][j] = sum_i a[p][i] dprod[i][j] are per-sample 1x1 convolutions over the positions whose K-major weight operands are
+    dprod re-arranged (a c x c matrix) and dprod itself."""
+
+    @staticmethod
+    def forward(ctx, a, sm):
+        a_, sm_ = to_nhwc(a), to_nhwc(sm)
+        b, c, h, w = a_.shape
+        g1 = Geom(1, 1, 1, 0)
+        dwt = conv_wgrad(a_, sm_, g1, (c, c, 1, 1), per_sample=True, raw=True, force_split=1)       # [b, c, c] (c % 32 == 0)
+        ctx.save_for_backward(a_, sm_)
+        return dwt.view(b, c, c, 1)
+
+    @staticmethod
+    def backward(ctx, dprod):
+        a_, sm_ = ctx.saved_tensors
+        b, c, h, w = a_.shape
+        g1 = Geom(1, 1, 1, 0)
+        d = dprod.reshape(b, c, c).contiguous()
+        da = dsm = None
+        if ctx.needs_input_grad[0]:
+            wt, _, ldw = prep_weight(d.view(b, c, c, 1, 1), 0, g1)            # K-major [j][i] per sample
+            da = conv_forward(sm_, wt, ldw, c, g1, per_sample=True)
+        if ctx.needs_input_grad[1]:
+            dsm = conv_forward(a_, d, c, c, g1, per_sample=True)              # K-major [i][j] = dprod as it lies in memory
+        return da, dsm
+
+
+def pooled_product_ready(a, sm):
+    """can _PooledFn take this pair?  (channel counts a multiple of 32: no padding rows / columns in the c x c results; the float4
+    weight-gradient kernel's geometry; the exact-fp32 kernels.)  FSV_POOL_WGRAD=0: the gather-GEMM form (in-box A/B)."""
+    if a.shape != sm.shape or a.dim() != 4 or a.dtype != torch.float32 or sm.dtype != torch.float32:
+        return False
+    b, c, h, w = a.shape
+    return (c % 32 == 0 and 32 // w + 1 <= h and _conv.narrow_staging_mode() == 0 and
+            _os.environ.get('FSV_POOL_WGRAD', '1') == '1')
+
+
+def pooled_product(a, sm):
+    """[b, c(i), c(j), 1] = sum over positions of a[b, i, p] * sm[b, j, p] (see _PooledFn)"""
+    return _PooledFn.apply(a, sm)
+
+
 def batch_conv(x, weight, bias=None, act=ACT_NONE, stride=1, allow_half=True):
     """Per-sample 1x1 (or kxk) convolution with generated weights [B, Cout, Cin, k, k] (base_network.py:56-71);
     stride 1 or 2 (padding k // 2, as the reference).  allow_half=False: a call site that only borrows the kernel for a

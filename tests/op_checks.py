@@ -1508,6 +1508,54 @@ def check_spade_conv3(device, n=2, c=64, cout=32, chs=(16, 8), h=20, w=24, up=Tr
             assert_close('fused bn -> actvn -> conv3x3 grad %d vs the oracle' % i, b, a, tol=4e-5)
 
 
+def check_pooled_product(device, b=2, c=64, h=16, w=16, seed=97):
+    """ops.pooled_product: prod[b, i, j] = sum_p a[b, i, p] * softmax(l)[b, j, p] (generator.py:378-389: torch.bmm of the image
+    features with the transposed channel softmax of the label features) issued as a per-sample 1x1 weight-gradient GEMM (round 6:
+    both operands read in place) - values and both gradients against the bmm, and against the gather-GEMM form it replaces
+    (FSV_POOL_WGRAD=0) at summation-order distance; the launch list: one weight-gradient launch, no re-arrangement, no copy."""
+    from importlib import import_module
+    ops, conv = pkg()
+    lib = import_module('few-shot-vid2vid_amd.lib')
+    networks = import_module('few-shot-vid2vid_amd.networks')
+    g = torch.Generator().manual_seed(seed)
+    a0 = torch.randn(b, c, h, w, generator=g)
+    l0 = torch.randn(b, c, h, w, generator=g)
+    dy = torch.randn(b, c, c, 1, generator=g)
+
+    def run(new):
+        cl = lambda t: _dev(t, device).detach().clone().contiguous(memory_format=torch.channels_last).requires_grad_(True)
+        a, l = cl(a0), cl(l0)
+        seen, real_call = [], lib.call
+
+        def recording_call(name, *args):
+            seen.append(name)
+            return real_call(name, *args)
+        os.environ['FSV_POOL_WGRAD'] = '1' if new else '0'
+        lib.call = recording_call
+        try:
+            (enc,) = networks.FewShotGenerator._pooled([a], [l])
+            n_fwd = len(seen)
+            (enc * _dev(dy, device)).sum().backward()
+        finally:
+            lib.call = real_call
+            os.environ.pop('FSV_POOL_WGRAD', None)
+        return enc.detach(), a.grad, l.grad, seen[:n_fwd], seen[n_fwd:]
+    y1, ga1, gl1, f1, b1 = run(True)
+    y0, ga0, gl0, f0, b0 = run(False)
+    assert f1 == ['fsv_softmax_rows_fwd', 'fsv_conv_wgrad'], f1
+    assert 'fsv_conv_wgrad' not in f0 and len(f0) > len(f1), f0
+    # backward: two position-major 1x1 convolutions + one c x c re-arrangement; no weight-gradient launch, no un-arrangement
+    assert [n for n in b1 if n != 'fsv_conv_plan'] == ['fsv_prep_weight', 'fsv_conv_gather_fwd', 'fsv_conv_gather_fwd', 'fsv_softmax_rows_bwd'], b1
+    ar, lr = a0.clone().requires_grad_(True), l0.clone().requires_grad_(True)
+    sm = torch.softmax(lr, dim=1)
+    ref = torch.bmm(ar.reshape(b, c, h * w), sm.reshape(b, c, h * w).transpose(1, 2)).unsqueeze(-1)
+    (ref * dy).sum().backward()
+    for nm, got, want in (('product', y1, ref), ('d a', ga1, ar.grad), ('d label', gl1, lr.grad),
+                          ('product vs the gather-GEMM form', y1, y0), ('d a vs the gather-GEMM form', ga1, ga0),
+                          ('d label vs the gather-GEMM form', gl1, gl0)):
+        assert_close('softmax pooling ' + nm, got, want, tol=2e-5)
+
+
 def check_conv_stats(device, seed=61):
     """BatchNorm / InstanceNorm statistics from the producing convolution's epilogue (ops.conv2d stats_groups -> `_fsv_stats` ->
     norm_act / spade_mod) against the separate reduction pass: same normalised output, running statistics and gradients; the
