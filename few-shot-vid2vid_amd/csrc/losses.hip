@@ -239,6 +239,27 @@ static inline int fsv_loss_grid(long long n) {
   return (int)g;
 }
 
+// ---- weighted sum of one-element loss tensors (round 6) ---------------------------------------------------------------------------
+// `loss = sum(lambda_i * term_i)` (loss_collector.py:60-67,85,161-162,204 and :218-219, the sum of the means): the collector combines two
+// dozen scalars per iteration in five such sums; as torch ops each is cat + mul + sum (and a mul + slices on the way back) of
+// 5-us launches at the one serial point of the step, between the forward pass and the backward pass.  One launch each way: the
+// pointers and weights travel in the kernel argument.
+#define FSV_WSUM_MAX 32
+struct WsumP { const float* t[FSV_WSUM_MAX]; float w[FSV_WSUM_MAX]; int n; };
+
+__global__ void fsv_wsum_fwd_kernel(WsumP p, float* out) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    float s = 0.f;
+    for (int i = 0; i < p.n; ++i) s += p.w[i] * p.t[i][0];       // ascending order, fp32 (what cat -> mul -> sum computed)
+    out[0] = s;
+  }
+}
+
+__global__ void fsv_wsum_bwd_kernel(WsumP p, const float* g, float* dterms) {
+  const int i = threadIdx.x;
+  if (blockIdx.x == 0 && i < p.n) dterms[i] = p.w[i] * g[0];
+}
+
 extern "C" {
 
 // loss[0] = (1 / (N*C*P)) * sum |a*m - b*m|.  strides: 3 x long long (batch, channel, pixel).  part: double[512].
@@ -369,6 +390,27 @@ int fsv_pool15(const float* x, float* y, int N, int H, int W, long long sn, long
   if (!x || !y || N < 1 || H < 1 || W < 1 || mode < 0 || mode > 1) return FSV_ERR_BAD_ARG;
   FSV_LAUNCH(fsv_pool15_kernel, dim3(fsv_cdiv(W, FSV_P15_T), fsv_cdiv(H, FSV_P15_T), N), dim3(256), stream, x, y, N, H, W, sn,
              sy, sx, mode, thresh);
+  return fsv_check_launch();
+}
+
+// out[0] = sum_i weights[i] * terms[i][0], i ascending; n <= 32 one-element device tensors
+int fsv_wsum_fwd(const float* const* terms, const float* weights, int n, float* out, hipStream_t stream) {
+  if (!terms || !weights || !out || n < 1 || n > FSV_WSUM_MAX) return FSV_ERR_BAD_ARG;
+  WsumP p;
+  for (int i = 0; i < FSV_WSUM_MAX; ++i) { p.t[i] = i < n ? terms[i] : nullptr; p.w[i] = i < n ? weights[i] : 0.f; }
+  for (int i = 0; i < n; ++i) if (!terms[i]) return FSV_ERR_BAD_ARG;
+  p.n = n;
+  FSV_LAUNCH(fsv_wsum_fwd_kernel, dim3(1), dim3(64), stream, p, out);
+  return fsv_check_launch();
+}
+
+// dterms[i] = weights[i] * g[0]: the gradients of the n terms, one float each
+int fsv_wsum_bwd(const float* weights, int n, const float* g, float* dterms, hipStream_t stream) {
+  if (!weights || !g || !dterms || n < 1 || n > FSV_WSUM_MAX) return FSV_ERR_BAD_ARG;
+  WsumP p;
+  for (int i = 0; i < FSV_WSUM_MAX; ++i) { p.t[i] = nullptr; p.w[i] = i < n ? weights[i] : 0.f; }
+  p.n = n;
+  FSV_LAUNCH(fsv_wsum_bwd_kernel, dim3(1), dim3(64), stream, p, g, dterms);
   return fsv_check_launch();
 }
 

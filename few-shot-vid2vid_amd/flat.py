@@ -185,12 +185,37 @@ class FlatAdam:
         self._armed = False
 
     # ------------------------------------------------------------------------------------------------ optimiser API
+    _prezeroed = False           # zero_early() has cleared the gradient buffers of the pass that comes next
+    _dirty = False               # a backward pass may have written gradients that no step has consumed yet
+
+    def zero_early(self, ref):
+        """The fills of zero_grad() ahead of time, on a side stream: returns the open streams.Branch (the caller joins it with
+        .finish() before anything can write a gradient - model.Vid2VidModel.generate_images joins at the end of the generator's
+        forward pass) or None.  Only between a step and the next zero_grad() (no un-stepped gradients), one GPU, plain fp32 or
+        `--amp` alike; FSV_ZERO_EARLY=0 switches it off (in-box A/B)."""
+        if (self._dirty or self._prezeroed or self.exchange or self._early is not None or not torch.is_tensor(ref) or
+                not ref.is_cuda or os.environ.get('FSV_ZERO_EARLY', '1') != '1' or self._steps_done < 1):
+            return None
+        from . import streams
+        br = streams.Branch(ref)
+        if br.stream is None:
+            return None
+        with br.on():
+            self.flat_g.zero_()
+            if self.finalizer is not None:
+                self.finalizer.zero_arena()
+        self._prezeroed = True
+        return br
+
     def zero_grad(self, set_to_none=False):
         """Called by loss_backward right before backward: clears the flat gradient and arms the bucket hooks."""
         self.abandon_early()
-        self.flat_g.zero_()
+        pre, self._prezeroed = self._prezeroed, False
+        self._dirty = True
+        if not pre:
+            self.flat_g.zero_()
         if self.finalizer is not None:
-            self.finalizer.begin_pass()       # drops jobs of a pass that was never stepped, zeroes the wgrad arena
+            self.finalizer.begin_pass(prezeroed=pre)       # drops jobs of a pass that was never stepped, zeroes the wgrad arena
             # Small parameters that do not take their gradient through a kernel-side sink (norm weights / biases, fixed
             # SPADE weights) would each cost an AccumulateGrad add launch into their flat_g slice.  Detach .grad for the
             # pass instead - autograd then just keeps the incoming tensor - and fold all of them into flat_g with one
@@ -358,6 +383,7 @@ class FlatAdam:
         self.layouts.refresh_split(part, base, base + 4 * s)
         if part == 1:
             self._steps_done += 1
+            self._dirty = False
 
     def wait_exchange(self):
         if getattr(self, '_side_pending', False):
@@ -406,6 +432,7 @@ class FlatAdam:
         return True
 
     def adam(self):
+        self._dirty = False
         self.finalize_grads()
         if self._early is not None:
             branch, self._early = self._early, None

@@ -88,7 +88,13 @@ class GradFinalizer:
         lib.call("fsv_colsum_grouped", lib.ptr(table), len(jobs), lib.ptr(tmap1), nblk1, lib.ptr(tmap2), nblk2,
                  lib.ptr(part), lib.stream_ptr())
 
-    def begin_pass(self):
+    def zero_arena(self):
+        """the arena's fill ahead of time (FlatAdam.zero_early, on a side stream); begin_pass(prezeroed=True) then skips it unless
+        it has to allocate a larger arena"""
+        if self.arena is not None:
+            self.arena.zero_()
+
+    def begin_pass(self, prezeroed=False):
         """Called by FlatAdam.zero_grad right before a backward pass."""
         self.jobs = []
         self.bias_jobs = []
@@ -96,7 +102,8 @@ class GradFinalizer:
         if self._arena_need and not capturing and (self.arena is None or self.arena.numel() < self._arena_need):
             self.arena = None
             self.arena = torch.empty(self._arena_need, dtype=torch.float32, device=self._arena_dev)
-        if self.arena is not None:
+            prezeroed = False
+        if self.arena is not None and not prezeroed:
             self.arena.zero_()
         self._arena_off = 0
         self._arena_need = 0

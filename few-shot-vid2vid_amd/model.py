@@ -212,7 +212,19 @@ class LossCollector:
         does all_reduce + div_ on the tensor it is given, util/distributed.py:66-72) must not corrupt the constant that later
         iterations and captured graphs read"""
         shared = set(z.data_ptr() for z in _ZEROS.values())
-        return [(l.clone() if l.data_ptr() in shared else l).view(1, 1) for l in losses]
+        n_shared = sum(1 for l in losses if l.data_ptr() in shared)
+        if not n_shared:
+            return [l.view(1, 1) for l in losses]
+        # (one fill for all of them: six one-element copies cost 9 us each inside a replayed graph - round 6)
+        fresh = torch.zeros(n_shared, dtype=losses[0].dtype, device=losses[0].device)
+        out, k = [], 0
+        for l in losses:
+            if l.data_ptr() in shared:
+                out.append(fresh[k:k + 1].view(1, 1))
+                k += 1
+            else:
+                out.append(l.view(1, 1))
+        return out
 
     def discriminate(self, netD, label, fake, real, ref, for_discriminator, real_out=None):
         """loss_collector.py:47-68: D sees [ref | label | image] with fake and real stacked on the batch axis.  real_out:
@@ -927,8 +939,20 @@ class Vid2VidModel(nn.Module):
         tgt_label_valid = valid_labels(opt, tgt_label_t)
         tgt_image = tgt_images[:, 0]
         prev_t = [p.contiguous().view(b, -1, h, w) if p is not None else None for p in (prevs[0], prevs[2])]
-        fake, flow, mask, raw, warped, _, _, atn_score, ref_idx = self.netG(tgt_label_valid, ref_labels_valid, ref_images,
-                                                                            prev_t)
+        # round 6: the generator optimiser's two big fills (flat gradient buffer + weight-gradient arena: 392 + 312 MB at the bench
+        # widths, 93 us) used to sit in zero_grad() - at the one serial point of the step, between the losses and the backward pass.
+        # They are issued here on a side stream next to the generator's forward pass (nothing touches those buffers before the
+        # backward pass) and joined before this call returns; zero_grad() then skips them (flat.FlatAdam.zero_early).
+        zero_early = None
+        opt_g = getattr(self, 'optimizer_G', None)
+        if self.isTrain and torch.is_grad_enabled() and hasattr(opt_g, 'zero_early'):
+            zero_early = opt_g.zero_early(tgt_label_valid)
+        try:
+            fake, flow, mask, raw, warped, _, _, atn_score, ref_idx = self.netG(tgt_label_valid, ref_labels_valid, ref_images,
+                                                                                prev_t)
+        finally:
+            if zero_early is not None:
+                zero_early.finish()
         self.atn_score = atn_score
         pick = networks.pick_ref                     # vid2vid_model.py:144 (the attended reference when n_shot > 1)
         ref_label_valid, ref_label_t, ref_image_t = pick(ref_labels_valid, ref_idx), pick(ref_labels, ref_idx), \

@@ -636,7 +636,8 @@ class FewShotGenerator(nn.Module):
             b, c, h, w = a.shape
             sm = ops.softmax_channels(l)
             if ops.pooled_product_ready(a, sm):
-                # round 6: the product over positions as a per-sample 1x1 weight-gradient GEMM - both operands read in place
+                # round 6, opt-in (FSV_POOL_WGRAD=1, measured neutral): the product over positions as a per-sample 1x1 weight-gradient
+                # GEMM - both operands read in place
                 enc.append(ops.pooled_product(a, sm))                               # [b, c(i), c(j), 1]
                 continue
             # prod[b, i, j] = sum_p a[b, i, p] * sm[b, j, p]  as a per-sample 1x1 "convolution" on the gather-GEMM

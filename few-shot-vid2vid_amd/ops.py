@@ -1013,12 +1013,15 @@ class _PooledFn(torch.autograd.Function):
 
 def pooled_product_ready(a, sm):
     """can _PooledFn take this pair?  (channel counts a multiple of 32: no padding rows / columns in the c x c results; the float4
-    weight-gradient kernel's geometry; the exact-fp32 kernels.)  FSV_POOL_WGRAD=0: the gather-GEMM form (in-box A/B)."""
+    weight-gradient kernel's geometry; the exact-fp32 kernels.)  Opt-in, FSV_POOL_WGRAD=1: measured in-box against the gather-GEMM
+    form over three alternating pairs - 42.49 / 42.42 / 42.46 ms per step with the gather-GEMM, 42.48 / 42.59 / 42.55 with this one
+    (profiles/r06_notes.md section 9): the ~40 launches it removes sit on the reference-encoder chain, which runs next to the flow
+    branch and is not what the step waits for."""
     if a.shape != sm.shape or a.dim() != 4 or a.dtype != torch.float32 or sm.dtype != torch.float32:
         return False
     b, c, h, w = a.shape
     return (c % 32 == 0 and 32 // w + 1 <= h and _conv.narrow_staging_mode() == 0 and
-            _os.environ.get('FSV_POOL_WGRAD', '1') == '1')
+            _os.environ.get('FSV_POOL_WGRAD', '0') == '1')
 
 
 def pooled_product(a, sm):
@@ -1932,6 +1935,8 @@ def amp_adam_step(param, grad, m, v, state, scaler, beta1, beta2, eps, gscale=1.
 lib.register_sigs({
     "fsv_l1_fwd": [c_p, c_p, c_f, c_p, c_i, c_i, c_ll, c_llp, c_llp, c_p, c_p, c_p],
     "fsv_l1_bwd": [c_p, c_p, c_f, c_p, c_i, c_i, c_ll, c_llp, c_llp, c_p, c_p, c_p, c_p, c_p],
+    "fsv_wsum_fwd": [c_pp, ctypes.POINTER(ctypes.c_float), c_i, c_p, c_p],
+    "fsv_wsum_bwd": [ctypes.POINTER(ctypes.c_float), c_i, c_p, c_p, c_p],
     "fsv_hinge_fwd": [c_p, c_ll, c_f, c_p, c_p, c_p],
     "fsv_hinge_bwd": [c_p, c_ll, c_f, c_p, c_p, c_p],
     "fsv_pack_d_input": [c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_ll, c_llp, c_llp, c_llp, c_llp, c_p],
@@ -2014,15 +2019,40 @@ def l1_loss(a, b, mask=None):
 _wvec_cache = {}
 
 
+class _WsumFn(torch.autograd.Function):
+    """sum_i w_i * t_i of one-element fp32 tensors: ONE launch (csrc/losses.hip fsv_wsum_fwd), ONE launch for all gradients"""
+
+    @staticmethod
+    def forward(ctx, weights, *terms):
+        ctx.weights = weights
+        ts = [t.detach() if t.is_contiguous() else t.detach().contiguous() for t in terms]
+        out = torch.empty(1, dtype=torch.float32, device=ts[0].device)
+        lib.check_device(*ts)
+        wv = (ctypes.c_float * len(ts))(*weights)
+        lib.call("fsv_wsum_fwd", (ctypes.c_void_p * len(ts))(*[t.data_ptr() for t in ts]), wv, len(ts), lib.ptr(out), lib.stream_ptr())
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        n = len(ctx.weights)
+        g = g.contiguous()
+        d = torch.empty(n, dtype=torch.float32, device=g.device)
+        lib.call("fsv_wsum_bwd", (ctypes.c_float * n)(*ctx.weights), n, lib.ptr(g), lib.ptr(d), lib.stream_ptr())
+        return (None,) + tuple(d[i:i + 1] if ctx.needs_input_grad[1 + i] else None for i in range(n))
+
+
 def weighted_sum(terms, weights=None):
     """sum_i weights[i] * terms[i] over one-element loss tensors -> shape [1].  The loss collector combines two dozen such
-    scalars per iteration; one add / mul / div launch per term (and as many again in backward) becomes cat + mul + sum."""
+    scalars per iteration; one add / mul / div launch per term (and as many again in backward) became cat + mul + sum in round 2
+    and is one launch each way since round 6 (FSV_WSUM=0: the torch form, in-box A/B)."""
     terms = [t.reshape(1) for t in terms]
     if weights is None:
         weights = [1.0] * len(terms)
     weights = [float(w) for w in weights]
     if len(terms) == 1:
         return terms[0] if weights[0] == 1.0 else terms[0] * weights[0]
+    if (len(terms) <= 32 and all(t.dtype == torch.float32 for t in terms) and _os.environ.get('FSV_WSUM', '1') == '1'):
+        return _WsumFn.apply(tuple(weights), *terms)
     cat = torch.cat(terms)
     if any(w != 1.0 for w in weights):
         key = (tuple(weights), cat.device, cat.dtype)

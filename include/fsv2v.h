@@ -496,6 +496,11 @@ int fsv_l1_fwd(const float* a, const float* b, float bconst, const float* m, int
 int fsv_l1_bwd(const float* a, const float* b, float bconst, const float* m, int N, int C, long long P,
                const long long* a_strides, const long long* b_strides, const float* gloss, float* da, float* db, float* dm,
                fsv_stream_t stream);
+/* weighted sums of one-element loss tensors - `sum(lambda_i * term_i)` of loss_collector.py:60-67,85,161-162,204 and the sum of the
+ * means of :218-219 - as one launch each way: out[0] = sum_i weights[i] * terms[i][0] (i ascending, fp32; terms: n <= 32 HOST-side
+ * array of device pointers, weights: n host floats - both travel in the kernel argument); dterms[i] = weights[i] * g[0] */
+int fsv_wsum_fwd(const float* const* terms, const float* weights, int n, float* out, fsv_stream_t stream);
+int fsv_wsum_bwd(const float* weights, int n, const float* g, float* dterms, fsv_stream_t stream);
 int fsv_hinge_fwd(const float* x, long long n, float sign, double* part, float* loss, fsv_stream_t stream);
 int fsv_hinge_bwd(const float* x, long long n, float sign, const float* gloss, float* dx, fsv_stream_t stream);
 int fsv_pack_d_input(const float* ref, const float* lab, const float* fake, const float* real, float* out,

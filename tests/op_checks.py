@@ -1512,7 +1512,7 @@ def check_pooled_product(device, b=2, c=64, h=16, w=16, seed=97):
     """ops.pooled_product: prod[b, i, j] = sum_p a[b, i, p] * softmax(l)[b, j, p] (generator.py:378-389: torch.bmm of the image
     features with the transposed channel softmax of the label features) issued as a per-sample 1x1 weight-gradient GEMM (round 6:
     both operands read in place) - values and both gradients against the bmm, and against the gather-GEMM form it replaces
-    (FSV_POOL_WGRAD=0) at summation-order distance; the launch list: one weight-gradient launch, no re-arrangement, no copy."""
+    (the default, FSV_POOL_WGRAD=0) at summation-order distance; the launch list: one weight-gradient launch, no re-arrangement, no copy."""
     from importlib import import_module
     ops, conv = pkg()
     lib = import_module('few-shot-vid2vid_amd.lib')
@@ -1554,6 +1554,36 @@ def check_pooled_product(device, b=2, c=64, h=16, w=16, seed=97):
                           ('product vs the gather-GEMM form', y1, y0), ('d a vs the gather-GEMM form', ga1, ga0),
                           ('d label vs the gather-GEMM form', gl1, gl0)):
         assert_close('softmax pooling ' + nm, got, want, tol=2e-5)
+
+
+def check_weighted_sum(device, seed=96):
+    """ops.weighted_sum (the loss collector's `sum(lambda_i * term_i)`, loss_collector.py:60-67,161-162,204,218-219) as one launch
+    each way (round 6) against the torch expression: value to the last fp32 rounding of a sequential sum, every term's gradient
+    = lambda_i * g exactly; terms that need no gradient get none; the torch form (FSV_WSUM=0) agrees."""
+    ops, conv = pkg()
+    g = torch.Generator().manual_seed(seed)
+    for n, with_w in ((2, False), (5, True), (17, True), (32, True)):
+        vals = torch.randn(n, generator=g) * 3
+        ws = [float(w) for w in (torch.rand(n, generator=g) * 4 + 0.1)] if with_w else None
+        terms = [_dev(vals[i:i + 1].clone(), device).requires_grad_(i % 3 != 1) for i in range(n)]
+        y = ops.weighted_sum([t.view(1, 1) if i % 2 else t for i, t in enumerate(terms)], ws)
+        os.environ['FSV_WSUM'] = '0'
+        try:
+            terms0 = [_dev(vals[i:i + 1].clone(), device).requires_grad_(i % 3 != 1) for i in range(n)]
+            y0 = ops.weighted_sum(terms0, ws)
+        finally:
+            os.environ.pop('FSV_WSUM', None)
+        ref = sum((ws[i] if ws else 1.0) * float(vals[i]) for i in range(n))
+        assert tuple(y.shape) == (1,) and abs(float(y.detach()) - ref) <= 1e-5 * max(1.0, abs(ref)), (float(y.detach()), ref)
+        assert abs(float(y.detach()) - float(y0.detach())) <= 1e-5 * max(1.0, abs(ref))
+        (y * 1.5).backward()
+        (y0 * 1.5).backward()
+        for i, (t, t0) in enumerate(zip(terms, terms0)):
+            if i % 3 == 1:
+                assert t.grad is None and t0.grad is None
+            else:
+                want = torch.tensor([(ws[i] if ws else 1.0)], dtype=torch.float32) * 1.5
+                assert float(t.grad.cpu()) == float(want) == float(t0.grad.cpu()), (i, t.grad, want, t0.grad)
 
 
 def check_conv_stats(device, seed=61):

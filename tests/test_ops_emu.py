@@ -187,6 +187,10 @@ def test_spade_modulation_fused_with_the_3x3_convolution(emu_lib):
     oc.check_spade_conv3(DEV, cout=64, chs=(32, 32), h=18, w=34, up=True, act='none', grad=False, res=True)
 
 
+def test_weighted_sum_of_loss_terms(emu_lib):
+    oc.check_weighted_sum(DEV)
+
+
 def test_softmax_pooling_as_a_weight_gradient_gemm(emu_lib):
     oc.check_pooled_product(DEV)
     oc.check_pooled_product(DEV, b=1, c=32, h=8, w=16, seed=98)

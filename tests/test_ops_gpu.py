@@ -194,6 +194,10 @@ def test_spade_modulation_fused_with_the_3x3_convolution(hip_lib):
     oc.check_spade_conv3(dev(), n=1, c=64, cout=64, chs=(64, 64), h=48, w=80, up=False, res=True, grad=False)
 
 
+def test_weighted_sum_of_loss_terms(hip_lib):
+    oc.check_weighted_sum(dev())
+
+
 def test_softmax_pooling_as_a_weight_gradient_gemm(hip_lib):
     oc.check_pooled_product(dev())
     oc.check_pooled_product(dev(), b=1, c=32, h=8, w=16, seed=98)
