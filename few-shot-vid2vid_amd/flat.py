@@ -191,10 +191,12 @@ class FlatAdam:
     def zero_early(self, ref):
         """The fills of zero_grad() ahead of time, on a side stream: returns the open streams.Branch (the caller joins it with
         .finish() before anything can write a gradient - model.Vid2VidModel.generate_images joins at the end of the generator's
-        forward pass) or None.  Only between a step and the next zero_grad() (no un-stepped gradients), one GPU, plain fp32 or
-        `--amp` alike; FSV_ZERO_EARLY=0 switches it off (in-box A/B)."""
+        forward pass) or None.  Only between a step and the next zero_grad() (no un-stepped gradients), one GPU.
+        Opt-in (FSV_ZERO_EARLY=1): measured in-box 42.59 / 42.63 ms per step without, 42.80 / 42.88 with
+        (profiles/r06_step_ab_serial_point.txt) - the 93 us of fills leave the serial point, but one more fork in the captured
+        forward pass costs the graph executor more than that (the finding of rounds 2 and 6 about finer forks, once more)."""
         if (self._dirty or self._prezeroed or self.exchange or self._early is not None or not torch.is_tensor(ref) or
-                not ref.is_cuda or os.environ.get('FSV_ZERO_EARLY', '1') != '1' or self._steps_done < 1):
+                not ref.is_cuda or os.environ.get('FSV_ZERO_EARLY', '0') != '1' or self._steps_done < 1):
             return None
         from . import streams
         br = streams.Branch(ref)

@@ -942,7 +942,8 @@ class Vid2VidModel(nn.Module):
         # round 6: the generator optimiser's two big fills (flat gradient buffer + weight-gradient arena: 392 + 312 MB at the bench
         # widths, 93 us) used to sit in zero_grad() - at the one serial point of the step, between the losses and the backward pass.
         # They are issued here on a side stream next to the generator's forward pass (nothing touches those buffers before the
-        # backward pass) and joined before this call returns; zero_grad() then skips them (flat.FlatAdam.zero_early).
+        # backward pass) and joined before this call returns; zero_grad() then skips them (flat.FlatAdam.zero_early).  Measured
+        # slower (+0.2 ms: one more fork in the captured pass) - opt-in, FSV_ZERO_EARLY=1.
         zero_early = None
         opt_g = getattr(self, 'optimizer_G', None)
         if self.isTrain and torch.is_grad_enabled() and hasattr(opt_g, 'zero_early'):
