@@ -27,7 +27,28 @@ struct L1P {
   int N, C; long long P;
 };
 
-__global__ __launch_bounds__(256) void fsv_l1_fwd_kernel(L1P p, double* part) {
+// Second stage of a two-stage loss reduction inside the first launch (round 6): the workgroup that takes the last ticket sums the
+// gridDim.x partials - in index order, whoever it is: the same bits as fsv_loss_final_kernel - and leaves the ticket at zero for the
+// next launch.  `ticket`: one zeroed int per launch in flight (conv.ticket_range); null: the caller finishes with fsv_loss_final_kernel.
+__device__ __forceinline__ void fsv_loss_finish(double* part, int* ticket, float* out, double scale, double* red) {
+  __shared__ int is_last;
+  __threadfence();                       // this workgroup's partial is visible device-wide before the ticket is taken
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const int prev = atomicAdd(ticket, 1);
+    is_last = (prev == (int)gridDim.x - 1) ? 1 : 0;
+    if (is_last) ticket[0] = 0;
+  }
+  __syncthreads();
+  if (!is_last) return;
+  __threadfence();                       // acquire: the other workgroups' partials
+  double a = 0.0;
+  for (int i = threadIdx.x; i < (int)gridDim.x; i += 256) a += part[i];
+  const double t = fsv_block_sum(a, red);
+  if (threadIdx.x == 0) out[0] = (float)(t * scale);
+}
+
+__global__ __launch_bounds__(256) void fsv_l1_fwd_kernel(L1P p, double* part, int* ticket, float* out, double scale) {
   __shared__ double red[256];
   const long long total = (long long)p.N * p.P;
   double acc = 0.0;
@@ -44,6 +65,7 @@ __global__ __launch_bounds__(256) void fsv_l1_fwd_kernel(L1P p, double* part) {
   }
   double t = fsv_block_sum(acc, red);
   if (threadIdx.x == 0) part[blockIdx.x] = t;
+  if (ticket) fsv_loss_finish(part, ticket, out, scale, red);
 }
 
 // out[0] = scale * sum(part)
@@ -79,13 +101,15 @@ __global__ __launch_bounds__(256) void fsv_l1_bwd_kernel(L1P p, const float* gpt
 }
 
 // ---- hinge: sum min(sign * x - 1, 0) ------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void fsv_hinge_fwd_kernel(const float* x, long long n, float sign, double* part) {
+__global__ __launch_bounds__(256) void fsv_hinge_fwd_kernel(const float* x, long long n, float sign, double* part, int* ticket,
+                                                            float* out, double scale) {
   __shared__ double red[256];
   double acc = 0.0;
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256)
     acc += (double)fminf(sign * x[i] - 1.f, 0.f);
   double t = fsv_block_sum(acc, red);
   if (threadIdx.x == 0) part[blockIdx.x] = t;
+  if (ticket) fsv_loss_finish(part, ticket, out, scale, red);
 }
 
 // loss = -(1/n) sum min(s x - 1, 0)  ->  dx = g * (-1/n) * s * [s x - 1 < 0]   (ties: 1/2, as torch.min does)
@@ -264,15 +288,17 @@ extern "C" {
 
 // loss[0] = (1 / (N*C*P)) * sum |a*m - b*m|.  strides: 3 x long long (batch, channel, pixel).  part: double[512].
 int fsv_l1_fwd(const float* a, const float* b, float bconst, const float* m, int N, int C, long long P,
-               const long long* a_strides, const long long* b_strides, double* part, float* loss, hipStream_t stream) {
+               const long long* a_strides, const long long* b_strides, double* part, float* loss, int* ticket,
+               hipStream_t stream) {
   if (!a || !part || !loss || N < 1 || C < 1 || P < 1) return FSV_ERR_BAD_ARG;
   L1P p;
   p.a = a; p.b = b; p.m = m; p.bconst = bconst; p.N = N; p.C = C; p.P = P;
   p.asn = a_strides[0]; p.asc = a_strides[1]; p.asp = a_strides[2];
   if (b) { p.bsn = b_strides[0]; p.bsc = b_strides[1]; p.bsp = b_strides[2]; } else { p.bsn = p.bsc = p.bsp = 0; }
   const int grid = fsv_loss_grid((long long)N * P);
-  FSV_LAUNCH(fsv_l1_fwd_kernel, dim3(grid), dim3(256), stream, p, part);
-  FSV_LAUNCH(fsv_loss_final_kernel, dim3(1), dim3(256), stream, (const double*)part, grid, loss, 1.0 / ((double)N * C * P));
+  const double scale = 1.0 / ((double)N * C * P);
+  FSV_LAUNCH(fsv_l1_fwd_kernel, dim3(grid), dim3(256), stream, p, part, ticket, loss, scale);
+  if (!ticket) FSV_LAUNCH(fsv_loss_final_kernel, dim3(1), dim3(256), stream, (const double*)part, grid, loss, scale);
   return fsv_check_launch();
 }
 
@@ -290,11 +316,11 @@ int fsv_l1_bwd(const float* a, const float* b, float bconst, const float* m, int
 }
 
 // loss[0] = -(1/n) * sum min(sign * x - 1, 0)
-int fsv_hinge_fwd(const float* x, long long n, float sign, double* part, float* loss, hipStream_t stream) {
+int fsv_hinge_fwd(const float* x, long long n, float sign, double* part, float* loss, int* ticket, hipStream_t stream) {
   if (!x || !part || !loss || n < 1) return FSV_ERR_BAD_ARG;
   const int grid = fsv_loss_grid(n);
-  FSV_LAUNCH(fsv_hinge_fwd_kernel, dim3(grid), dim3(256), stream, x, n, sign, part);
-  FSV_LAUNCH(fsv_loss_final_kernel, dim3(1), dim3(256), stream, (const double*)part, grid, loss, -1.0 / (double)n);
+  FSV_LAUNCH(fsv_hinge_fwd_kernel, dim3(grid), dim3(256), stream, x, n, sign, part, ticket, loss, -1.0 / (double)n);
+  if (!ticket) FSV_LAUNCH(fsv_loss_final_kernel, dim3(1), dim3(256), stream, (const double*)part, grid, loss, -1.0 / (double)n);
   return fsv_check_launch();
 }
 

@@ -1933,11 +1933,11 @@ def amp_adam_step(param, grad, m, v, state, scaler, beta1, beta2, eps, gscale=1.
 
 # ------------------------------------------------------------------------------------------------ losses / packing / masks
 lib.register_sigs({
-    "fsv_l1_fwd": [c_p, c_p, c_f, c_p, c_i, c_i, c_ll, c_llp, c_llp, c_p, c_p, c_p],
+    "fsv_l1_fwd": [c_p, c_p, c_f, c_p, c_i, c_i, c_ll, c_llp, c_llp, c_p, c_p, c_p, c_p],
     "fsv_l1_bwd": [c_p, c_p, c_f, c_p, c_i, c_i, c_ll, c_llp, c_llp, c_p, c_p, c_p, c_p, c_p],
     "fsv_wsum_fwd": [c_pp, ctypes.POINTER(ctypes.c_float), c_i, c_p, c_p],
     "fsv_wsum_bwd": [ctypes.POINTER(ctypes.c_float), c_i, c_p, c_p, c_p],
-    "fsv_hinge_fwd": [c_p, c_ll, c_f, c_p, c_p, c_p],
+    "fsv_hinge_fwd": [c_p, c_ll, c_f, c_p, c_p, c_p, c_p],
     "fsv_hinge_bwd": [c_p, c_ll, c_f, c_p, c_p, c_p],
     "fsv_pack_d_input": [c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_ll, c_llp, c_llp, c_llp, c_llp, c_p],
     "fsv_unpack_d_grad": [c_p, c_p, c_i, c_i, c_i, c_i, c_ll, c_p],
@@ -1993,7 +1993,7 @@ class _L1Fn(torch.autograd.Function):
         loss = torch.empty(1, dtype=torch.float32, device=a.device)
         lib.check_device(a, bt, mt)
         lib.call("fsv_l1_fwd", lib.ptr(a), lib.ptr(bt), bconst, lib.ptr(mt), dims[0], dims[1], dims[2], _ll(sa_), _ll(sb_),
-                 lib.ptr(part), lib.ptr(loss), lib.stream_ptr())
+                 lib.ptr(part), lib.ptr(loss), _loss_ticket(a), lib.stream_ptr())
         ctx.meta = (dims, sa_, sb_, bconst, bt is not None, mt is not None)
         ctx.save_for_backward(a, bt if bt is not None else a, mt if mt is not None else a)
         return loss
@@ -2017,6 +2017,15 @@ def l1_loss(a, b, mask=None):
 
 
 _wvec_cache = {}
+
+
+def _loss_ticket(like):
+    """the ticket of a loss reduction that finishes in its own launch (csrc/losses.hip fsv_loss_finish; round 6: a dozen 5-us
+    finishing launches per step at the serial point between the forward and the backward pass).  None - the two-launch form - in
+    the fixed-order mode's A/B switch FSV_LOSS_TICKET=0."""
+    if _os.environ.get('FSV_LOSS_TICKET', '1') != '1':
+        return None
+    return _conv.ticket_range(like, 64)
 
 
 class _WsumFn(torch.autograd.Function):
@@ -2075,7 +2084,7 @@ class _HingeFn(torch.autograd.Function):
         part = torch.empty(512, dtype=torch.float64, device=x.device)
         loss = torch.empty(1, dtype=torch.float32, device=x.device)
         lib.check_device(x)
-        lib.call("fsv_hinge_fwd", lib.ptr(x), x.numel(), float(sign), lib.ptr(part), lib.ptr(loss), lib.stream_ptr())
+        lib.call("fsv_hinge_fwd", lib.ptr(x), x.numel(), float(sign), lib.ptr(part), lib.ptr(loss), _loss_ticket(x), lib.stream_ptr())
         ctx.sign = float(sign)
         ctx.save_for_backward(x)
         return loss

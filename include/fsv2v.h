@@ -491,8 +491,12 @@ int fsv_adam_step_range(float* param, const float* grad, float* m, float* v, flo
 
 /* ---- losses, D-input packing, mask pooling (csrc/losses.hip) - models/networks/loss.py:69-83,130-138;
  * models/loss_collector.py:47-58,105-110,180; models/input_process.py:59 -------------------------------------------- */
+/* ticket (nullable, fsv_l1_fwd / fsv_hinge_fwd): ONE zeroed int owned by this launch until it completes - the workgroup that takes
+ * the last ticket sums the per-workgroup partials in index order (the bits of the two-launch form) and leaves the int at zero;
+ * NULL: a second launch finishes the reduction */
 int fsv_l1_fwd(const float* a, const float* b, float bconst, const float* m, int N, int C, long long P,
-               const long long* a_strides, const long long* b_strides, double* part, float* loss, fsv_stream_t stream);
+               const long long* a_strides, const long long* b_strides, double* part, float* loss, int* ticket,
+               fsv_stream_t stream);
 int fsv_l1_bwd(const float* a, const float* b, float bconst, const float* m, int N, int C, long long P,
                const long long* a_strides, const long long* b_strides, const float* gloss, float* da, float* db, float* dm,
                fsv_stream_t stream);
@@ -501,7 +505,7 @@ int fsv_l1_bwd(const float* a, const float* b, float bconst, const float* m, int
  * array of device pointers, weights: n host floats - both travel in the kernel argument); dterms[i] = weights[i] * g[0] */
 int fsv_wsum_fwd(const float* const* terms, const float* weights, int n, float* out, fsv_stream_t stream);
 int fsv_wsum_bwd(const float* weights, int n, const float* g, float* dterms, fsv_stream_t stream);
-int fsv_hinge_fwd(const float* x, long long n, float sign, double* part, float* loss, fsv_stream_t stream);
+int fsv_hinge_fwd(const float* x, long long n, float sign, double* part, float* loss, int* ticket, fsv_stream_t stream);
 int fsv_hinge_bwd(const float* x, long long n, float sign, const float* gloss, float* dx, fsv_stream_t stream);
 int fsv_pack_d_input(const float* ref, const float* lab, const float* fake, const float* real, float* out,
                      int B, int Cr, int Cl, int Ci, long long P, const long long* ref_strides, const long long* lab_strides,

@@ -1586,6 +1586,37 @@ def check_weighted_sum(device, seed=96):
                 assert float(t.grad.cpu()) == float(want) == float(t0.grad.cpu()), (i, t.grad, want, t0.grad)
 
 
+def check_loss_ticket(device, seed=95):
+    """The loss reductions that finish in their own launch (csrc/losses.hip fsv_loss_finish, round 6: the last workgroup sums the
+    partials in index order) give the BITS of the two-launch form (FSV_LOSS_TICKET=0), for several grid sizes, repeatedly (the
+    ticket must come back to zero), and issue one launch instead of two."""
+    from importlib import import_module
+    ops, conv = pkg()
+    lib = import_module('few-shot-vid2vid_amd.lib')
+    g = torch.Generator().manual_seed(seed)
+    for shape in ((1, 3, 5, 7), (2, 8, 33, 40), (2, 3, 128, 160)):
+        a, b = _dev(torch.randn(*shape, generator=g), device), _dev(torch.randn(*shape, generator=g), device)
+        m = _dev((torch.rand(shape[0], 1, *shape[2:], generator=g) > 0.4).float(), device)
+        x = _dev(torch.randn(*shape, generator=g), device)
+        got = {}
+        for mode in ('1', '0'):
+            os.environ['FSV_LOSS_TICKET'] = mode
+            seen, real_call = [], lib.call
+            lib.call = lambda name, *args: (seen.append(name), real_call(name, *args))[1]
+            try:
+                vals = []
+                for _ in range(3):
+                    vals += [ops.l1_loss(a, b), ops.l1_loss(a, b, m), ops.l1_loss(a, 1.0, m), ops.hinge_loss(x, True),
+                             ops.hinge_loss(x, False)]
+                got[mode] = torch.cat([v.detach().reshape(1).cpu() for v in vals])
+            finally:
+                lib.call = real_call
+                os.environ.pop('FSV_LOSS_TICKET', None)
+        assert torch.equal(got['1'], got['0']), (got['1'], got['0'])
+        ref = torch.stack([(a - b).abs().mean().cpu(), ((a - b) * m).abs().mean().cpu()])
+        assert float((got['1'][:2] - ref).abs().max()) <= 1e-5 * float(ref.abs().max())
+
+
 def check_conv_stats(device, seed=61):
     """BatchNorm / InstanceNorm statistics from the producing convolution's epilogue (ops.conv2d stats_groups -> `_fsv_stats` ->
     norm_act / spade_mod) against the separate reduction pass: same normalised output, running statistics and gradients; the

@@ -189,6 +189,7 @@ def test_spade_modulation_fused_with_the_3x3_convolution(emu_lib):
 
 def test_weighted_sum_of_loss_terms(emu_lib):
     oc.check_weighted_sum(DEV)
+    oc.check_loss_ticket(DEV)
 
 
 def test_softmax_pooling_as_a_weight_gradient_gemm(emu_lib):

@@ -196,6 +196,7 @@ def test_spade_modulation_fused_with_the_3x3_convolution(hip_lib):
 
 def test_weighted_sum_of_loss_terms(hip_lib):
     oc.check_weighted_sum(dev())
+    oc.check_loss_ticket(dev())
 
 
 def test_softmax_pooling_as_a_weight_gradient_gemm(hip_lib):
