@@ -2021,9 +2021,12 @@ _wvec_cache = {}
 
 def _loss_ticket(like):
     """the ticket of a loss reduction that finishes in its own launch (csrc/losses.hip fsv_loss_finish; round 6: a dozen 5-us
-    finishing launches per step at the serial point between the forward and the backward pass).  None - the two-launch form - in
-    the fixed-order mode's A/B switch FSV_LOSS_TICKET=0."""
-    if _os.environ.get('FSV_LOSS_TICKET', '1') != '1':
+    finishing launches per step at the serial point between the forward and the backward pass).  None: the two-launch form - the
+    default.  Opt-in (FSV_LOSS_TICKET=1): bit-identical, and measured SLOWER in-box, 42.41 / 42.52 / 42.53 ms per step without,
+    42.92 / 42.87 / 42.85 with (profiles/r06_step_ab_serial_point.txt) - every workgroup of the fourteen launches pays a
+    device-scope release (an L2 write-back on this part) in front of its ticket, which costs more than the 5-us launches it saves
+    (the round-3 and round-5 findings about producer-side tickets, once more)."""
+    if _os.environ.get('FSV_LOSS_TICKET', '0') != '1':
         return None
     return _conv.ticket_range(like, 64)
 
