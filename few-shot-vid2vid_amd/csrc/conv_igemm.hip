@@ -832,6 +832,51 @@ __global__ __launch_bounds__(256) void fsv_split_finish4_kernel(const float4* pa
   }
 }
 
+// the finishing pass that ALSO leaves the per-channel (sum, sum of squares) of the finished output for the normalisation that
+// follows (second session of round 6).  A K-split launch had no statistics epilogue - the splits only hold partial outputs - so its
+// consumer ran a reduction pass of its own (fsv_red2_kernel<0>: 60 launches of 5 - 6 us per step, one in every conv -> norm chain of
+// the 16x16 ... 64x64 encoder levels).  This pass has the finished values in registers anyway: a workgroup takes a 32-pixel x
+// 32-channel tile (eight work-items of four channels per pixel row: 128-byte runs), reduces its 32 rows through LDS and adds
+// 32 x 2 doubles into the slotted partials of ConvP::stats (slot = pixel tile % slots; same layout, same consumer).  Same output
+// bits as fsv_split_finish4_kernel (the same sums in the same order).  Needs C % 32 == 0 and group sizes that are multiples of 32.
+__global__ __launch_bounds__(256) void fsv_split_finish4_stats_kernel(const float4* part, long long part_stride4, int nsplit,
+                                                                      float4* out, const float* bias, const float4* res,
+                                                                      long long npix, int C, int act, float scale, double* stats,
+                                                                      int stats_slots, long long stats_ohw) {
+  __shared__ float red[32 * 8 * 8];
+  const int tid = threadIdx.x, prow = tid >> 3, cq = tid & 7;
+  const long long pix = (long long)blockIdx.x * 32 + prow;
+  const int c0 = (int)blockIdx.y * 32 + 4 * cq;
+  float s[4] = {0.f, 0.f, 0.f, 0.f}, q[4] = {0.f, 0.f, 0.f, 0.f};
+  if (pix < npix) {
+    const long long i = (pix * C + c0) >> 2;
+    float4 v = part[i];
+#pragma unroll 4
+    for (int k = 1; k < nsplit; ++k) {
+      const float4 t = part[(long long)k * part_stride4 + i];
+      v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+    }
+    if (bias) { const float* b = bias + c0; v.x += b[0]; v.y += b[1]; v.z += b[2]; v.w += b[3]; }
+    v.x = fsv_act(v.x * scale, act); v.y = fsv_act(v.y * scale, act); v.z = fsv_act(v.z * scale, act); v.w = fsv_act(v.w * scale, act);
+    if (res) { const float4 r = res[i]; v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w; }
+    out[i] = v;
+    s[0] = v.x; s[1] = v.y; s[2] = v.z; s[3] = v.w;
+    q[0] = v.x * v.x; q[1] = v.y * v.y; q[2] = v.z * v.z; q[3] = v.w * v.w;
+  }
+  float* mine = red + (prow * 8 + cq) * 8;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) { mine[e] = s[e]; mine[4 + e] = q[e]; }
+  __syncthreads();
+  if (tid < 64) {                       // (channel tid & 31 of the tile, component tid >> 5): the 32 rows in ascending order
+    const int c = tid & 31, comp = tid >> 5;
+    float a = 0.f;
+    for (int r = 0; r < 32; ++r) a += red[(r * 8 + (c >> 2)) * 8 + 4 * comp + (c & 3)];
+    const long long g = ((long long)blockIdx.x * 32) / stats_ohw;
+    const int slot = (int)(blockIdx.x % (unsigned)stats_slots);
+    atomicAdd(stats + ((g * stats_slots + slot) * C + (int)blockIdx.y * 32 + c) * 2 + comp, (double)a);
+  }
+}
+
 // ---- weight gradient: dwt[z][t*Cin+ci][co] (+)= sum_pixels in[n, oy*sy+ty, ox*sx+tx, ci] * dout[n,oy,ox,co] ----
 // All workgroups of one pixel range (blockIdx.z) read the same x pixels (shifted by their taps) and the same dout rows:
 // they are mapped onto ONE XCD so that x and dout are fetched from HBM once per range instead of once per L2
@@ -2008,6 +2053,21 @@ static int fsv_conv_gather_impl(const float* in, const float* wt, const float* b
       (void)hipMemsetAsync(stats, 0, (size_t)stats_groups * stats_slots * Cout * 2 * sizeof(double), stream);
     if (produced) *produced = 1;
   }
+  // ... or from the finishing pass of an ordered K-split launch (fsv_split_finish4_stats_kernel)
+  double* fin_stats = nullptr;
+  {
+    const char* fse = getenv("FSV_SPLIT_FIN_STATS");       // =0: the consumer's own reduction pass (in-box A/B; read at every call)
+    const char* f4e = getenv("FSV_SPLIT_FIN4");
+    if (stats && !(fse && fse[0] == '0') && !(f4e && f4e[0] == '0') && nsplit > 1 && p.part && !accumulate && !per_sample && p.dense_out &&
+        stats_groups >= 1 && stats_slots >= 1 && (Cout % 32) == 0 && p.Mz % stats_groups == 0 && ((p.Mz / stats_groups) % 32) == 0 &&
+        act != FSV_ACT_DLRELU && !fsv_deterministic() &&
+        (((unsigned long long)p.part | (unsigned long long)out | (unsigned long long)res) & 15ull) == 0) {
+      fin_stats = stats;
+      if (!stats_prezeroed)
+        (void)hipMemsetAsync(stats, 0, (size_t)stats_groups * stats_slots * Cout * 2 * sizeof(double), stream);
+      if (produced) *produced = 1;
+    }
+  }
   // the plan's 8-wave tiles run as their prefetch-distance-2 variants (a forced tile id is taken literally)
   if (force_tile < 0 && vec4) tile = fsv_conv_variant(tile);
   int rc = fsv_launch_conv(p, vec4, nsamp * nsplit, stream, tile);
@@ -2019,7 +2079,12 @@ static int fsv_conv_gather_impl(const float* in, const float* wt, const float* b
     const char* f4e = getenv("FSV_SPLIT_FIN4");          // =0: the scalar finishing pass (A/B, bit-equality test)
     const bool fin4 = !(f4e && f4e[0] == '0') && p.part && (Cout % 4 == 0) && (total % 4 == 0) &&
                       (((unsigned long long)p.part | (unsigned long long)out | (unsigned long long)res) & 15ull) == 0;
-    if (fin4) {
+    if (fin_stats) {
+      const long long npix = (long long)N * outH * outW;
+      FSV_LAUNCH(fsv_split_finish4_stats_kernel, dim3((unsigned)((npix + 31) / 32), (unsigned)(Cout / 32)), dim3(256), stream,
+                 (const float4*)p.part, p.part_stride / 4, nsplit, (float4*)out, bias, (const float4*)res, npix, Cout, act, scale,
+                 fin_stats, stats_slots, (long long)(p.Mz / stats_groups));
+    } else if (fin4) {
       int g4 = (int)((total / 4 + 255) / 256);
       if (g4 > 8192) g4 = 8192;
       FSV_LAUNCH(fsv_split_finish4_kernel, dim3(g4), dim3(256), stream, (const float4*)p.part, p.part_stride / 4, nsplit, (float4*)out,

@@ -1629,7 +1629,12 @@ def check_conv_stats(device, seed=61):
         (3, 8, 9, 7, 40, 4, 2, 2, True, False),           # 20 pixels per sample: a tile would span three groups -> fallback
         (2, 32, 8, 8, 32, 3, 1, 1, False, True),
         (2, 6, 8, 8, 16, 3, 1, 1, False, False),          # padded input channels still take the float4 path
-        (1, 512, 4, 4, 64, 3, 1, 1, False, False),        # deep K on a tiny map: the plan splits K -> no statistics, fallback
+        (1, 512, 4, 4, 64, 3, 1, 1, False, False),        # deep K on a tiny map (16 pixels): the plan splits K, and the group is
+                                                          # smaller than the finishing pass's 32-pixel tile -> fallback
+        # round 6: a K-split launch leaves the statistics from its FINISHING pass (fsv_split_finish4_stats_kernel)
+        (2, 512, 8, 8, 64, 3, 1, 1, False, True),         # 128 pixels, 144 K chunks: split; BatchNorm, residual
+        (2, 256, 8, 8, 96, 3, 1, 1, True, False),         # InstanceNorm: two groups of 64 pixels
+        (2, 512, 8, 8, 40, 3, 1, 1, False, False),        # Cout % 32 != 0 -> fallback
     ]
     for (n, cin, h, w, cout, k, s, p, inst, with_res) in cases:
         x = torch.randn(n, cin, h, w, generator=g)
@@ -1652,8 +1657,23 @@ def check_conv_stats(device, seed=61):
             z.backward(_dev(dy, device))
             return z.detach(), [t.grad for t in (xd, wd, bd, gd, be)], rm, rv, had
         z0, g0, rm0, rv0, _ = run(False)
-        z1, g1, rm1, rv1, had = run(True)
-        assert had == (cin != 512 and not (inst and h == 9)), ('statistics attribute', cin, had)
+        conv.start_plan_log()
+        try:
+            z1, g1, rm1, rv1, had = run(True)
+        finally:
+            splits = [e[1] for e in conv.stop_plan_log() if e[0] != 'group']
+        if cin >= 256:
+            assert splits and splits[0] > 1, ('the forward launch of this case is meant to split K', splits)
+        expect = not (inst and h == 9) and not (cin >= 256 and (h == 4 or cout % 32))
+        assert had == expect, ('statistics attribute', (n, cin, h, w, cout), had)
+        if had and cin >= 256:
+            os.environ['FSV_SPLIT_FIN_STATS'] = '0'
+            try:
+                z2, _, _, _, had2 = run(True)
+            finally:
+                os.environ.pop('FSV_SPLIT_FIN_STATS', None)
+            assert not had2, 'FSV_SPLIT_FIN_STATS=0 must leave the reduction to the consumer'
+            assert_close('statistics from the split finishing pass vs the consumer\'s own pass', z1, z2, tol=2e-6)
         assert_close('norm(conv) with epilogue statistics %s' % ((n, cin, h, w, cout),), z1, z0, tol=2e-6)
         for i, (a, bb) in enumerate(zip(g0, g1)):
             if i == 2:
