@@ -247,6 +247,7 @@ class SPADEResnetBlock(nn.Module):
         if up and not fold:
             x = ops.upsample2x(x)
         if self.spade:
+            conv3 = ops.spade_conv3_enabled() and not ops.spade_pair_enabled()      # (two opt-ins that both want bn_0: the pair wins)
             if self.learned_shortcut:
                 # bn_s and bn_0 normalise the same x with the same maps: one two-site launch (ops.spade_pair)
                 if ops.spade_pair_enabled():
@@ -258,15 +259,15 @@ class SPADEResnetBlock(nn.Module):
                     # bn_s -> conv_s as ONE kernel where csrc/spade_conv.hip covers the widths (ops.spade_into_conv)
                     with ops.spade_into_conv():
                         x_s = self.conv_s(self.bn_s(x, label, nw[2], act=ACT_NONE, up=fold))
-                    h0 = None if ops.spade_conv3_enabled() else self.bn_0(x, label, nw[0], act=ACT_LRELU, up=fold)
+                    h0 = None if conv3 else self.bn_0(x, label, nw[0], act=ACT_LRELU, up=fold)
             else:
                 x_s = x
-                h0 = None if ops.spade_conv3_enabled() else self.bn_0(x, label, nw[0], act=ACT_LRELU, up=fold)
+                h0 = None if conv3 else self.bn_0(x, label, nw[0], act=ACT_LRELU, up=fold)
             # conv_0 feeds bn_1, conv_1 (+ shortcut) the next block's bn_0 / bn_s: BatchNorm statistics from their epilogues
             # (in training mode only: eval-mode BatchNorm takes its running buffers and would leave the partials unused; a next
             # block that materialises the up-sampling - up and not fold - reduces over the up-sampled tensor itself)
             hint = 1 if self.training else 0
-            if ops.spade_conv3_enabled():
+            if conv3:
                 # round 6, opt-in (FSV_SPADE_CONV3=1): actvn(bn_*) -> 3x3 convolution as ONE kernel where csrc/spade_conv3.hip covers
                 # the widths (the modulated tensor stays in LDS); anything else falls through to the two launches
                 with ops.spade_into_conv(conv3=True):
