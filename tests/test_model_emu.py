@@ -36,6 +36,25 @@ def test_train_step_with_the_subpixel_forward_on_every_up_layer(emu_lib, monkeyp
     assert len(calls) >= 8, calls          # embedding / flow decoders, both generator passes
 
 
+def test_generator_with_the_3x3_spade_fusion(emu_lib, monkeypatch):
+    """`FSV_SPADE_CONV3=1` (round 6, opt-in): at ngf = 16 the generator has SPADE blocks with 64 input channels - their
+    `actvn(bn_0) -> conv_0` (64 -> 32) and `actvn(bn_1) -> conv_1` (64 -> 64, + the shortcut) run as ONE kernel each
+    (csrc/spade_conv3.hip on the emulator): the generator's forward and backward pass against the oracle at the usual bars, and the
+    fused entry point is what ran."""
+    from importlib import import_module
+    lib = import_module('few-shot-vid2vid_amd.lib')
+    monkeypatch.setenv('FSV_SPADE_CONV3', '1')
+    seen, real_call = [], lib.call
+
+    def recording_call(name, *a):
+        if name == 'fsv_spade_conv3_fwd':
+            seen.append((a[17], a[24]))            # (C, Cout)
+        return real_call(name, *a)
+    monkeypatch.setattr(lib, 'call', recording_call)
+    mc.check_generator(DEV, mc.tiny_opt(ngf=16, nff=4, warp_ref=True, spade_combine=True), b=1)
+    assert {(64, 32), (64, 64)} <= set(seen), sorted(set(seen))
+
+
 def test_train_step_in_the_schedule_bench_py_runs(emu_lib):
     """the discriminator step "on a side stream" (issue order on the emulator), the early generator pass picked up by the
     generator-mode call, the two-piece backward - against the oracle like the plain step"""
