@@ -128,6 +128,50 @@ def check_twin_generator_passes(device, iters=3, seed=570, graphed=False):
                 assert torch.equal(ba[k], bb[k]), k
 
 
+def check_serial_point_opt_ins(device, iters=4, seed=580):
+    """Round 6, second session - the two opt-in forms of the step's serial point that were measured slower and kept as switches:
+    `FSV_ZERO_EARLY=1` (the generator optimiser's gradient-buffer and weight-gradient-arena fills on a side stream next to the
+    generator's forward pass, flat.FlatAdam.zero_early) and `FSV_LOSS_TICKET=1` (loss reductions that finish in their own launch).
+    Neither changes a value: in the fixed-order mode the loop gives the same losses, images and weights bit for bit with and
+    without them - eager and captured -, and the early fills must actually have been issued (on a device)."""
+    import os
+    from importlib import import_module
+    flat = import_module('few-shot-vid2vid_amd.flat')
+    kw = dict(warp_ref=True, spade_combine=True, remove_face_labels=True, fineSize=32, loadSize=32, n_downsample_G=3, n_adaptive_layers=2)
+    issued = []
+    real = flat.FlatAdam.zero_early
+
+    def counted(self, ref):
+        br = real(self, ref)
+        issued.append(br is not None)
+        return br
+    keys = ('FSV_DETERMINISTIC', 'FSV_ZERO_EARLY', 'FSV_LOSS_TICKET')
+    old = {k: os.environ.get(k) for k in keys}
+    flat.FlatAdam.zero_early = counted
+    try:
+        os.environ['FSV_DETERMINISTIC'] = '1'
+        for graphed in (False, True):
+            os.environ['FSV_ZERO_EARLY'], os.environ['FSV_LOSS_TICKET'] = '0', '0'
+            ref, pG, pD, _ = _run(device, graphed, iters, seed, kw, split=True, early=True)
+            assert not any(issued), issued
+            os.environ['FSV_ZERO_EARLY'], os.environ['FSV_LOSS_TICKET'] = '1', '1'
+            got, qG, qD, _ = _run(device, graphed, iters, seed, kw, split=True, early=True)
+            if device.type != 'cpu':
+                assert sum(issued) >= iters - 2, issued          # (not before the first optimiser step; one GPU)
+            del issued[:]
+            for it, (a, b) in enumerate(zip(ref, got)):
+                assert a['d'] == b['d'] and a['g'] == b['g'], (graphed, it, a['d'], b['d'], a['g'], b['g'])
+                assert torch.equal(a['img'], b['img']), (graphed, it)
+            assert torch.equal(pG, qG) and torch.equal(pD, qD), graphed
+    finally:
+        flat.FlatAdam.zero_early = real
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
 def check_capture_failure_falls_back(device, iters=4, seed=540):
     """A capture that raises half-way through the iteration body (what a foreign hipEventQuery inside a capture does) must not
     cost the caller its iteration: GraphedIteration drops to the eager step for that signature, says so (launch_mode,
@@ -225,4 +269,6 @@ if __name__ == '__main__':
     # captured graph
     check_twin_generator_passes(dev, iters=4)
     check_twin_generator_passes(dev, iters=5, graphed=True)
+    # second session: the opt-in forms of the serial point (early fills on a side stream, ticketed loss reductions) change no bit
+    check_serial_point_opt_ins(dev)
     print('GRAPH_STEP_GPU_OK', flush=True)

@@ -40,3 +40,8 @@ def test_twin_generator_passes_change_no_result_and_no_buffer(emu_lib):
     """round 6: the no-grad and the generator-mode pass of an iteration issued next to each other - plain loop and graphed driver"""
     gc.check_twin_generator_passes(DEV, iters=2)
     gc.check_twin_generator_passes(DEV, graphed=True)
+
+
+def test_serial_point_opt_ins_change_no_bit(emu_lib):
+    """FSV_LOSS_TICKET=1 on the emulated kernels (FSV_ZERO_EARLY=1 needs a device: the hardware run of graph_step_checks.py)"""
+    gc.check_serial_point_opt_ins(DEV, iters=3)
